@@ -1,0 +1,114 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
+// C API of the CPU restatement of the rvtests kernel/burden hot path (see each .cpp for the
+// reference file:line it follows).  Loaded with ctypes by tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py — never by rvtests_amd/ itself.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double (*orc_integrand)(double x, void* params);
+
+/* ---- scalar special functions (orc_special.cpp) ---- */
+double orc_gamma_inc_P(double a, double x);
+double orc_gamma_inc_Q(double a, double x);
+double orc_gamma_cdf_P(double x, double a, double b);
+double orc_gamma_cdf_Q(double x, double a, double b);
+double orc_gamma_cdf_Qinv(double Q, double a, double b);
+double orc_gamma_pdf(double x, double a, double b);
+double orc_chisq_P(double x, double nu);
+double orc_chisq_Q(double x, double nu);
+double orc_chisq_Qinv(double Q, double nu);
+double orc_chisq_pdf(double x, double nu);
+double orc_beta_pdf(double x, double a, double b);
+
+/* ---- Davies / Liu (orc_davies.cpp, orc_liu.cpp) ---- */
+double orc_qf(const double* lb, const double* nc, const int* n, int r, double sigma, double c, int lim,
+              double acc, double* trace, int* ifault);
+double orc_davies_pvalue(const double* lambda, int n, double Q, int* fault_out);
+double orc_liu_pvalue(const double* lambda, int n, double Q);
+void orc_cumchn(double x, double df, double pnonc, double* cum, double* ccum);
+
+/* ---- QAGS (orc_qags.cpp) ---- */
+int orc_qags(orc_integrand f, void* params, double a, double b, double epsabs, double epsrel, int limit,
+             double* result, double* abserr, int* neval_out);
+/* test hook: integrate one of a few built-in integrands (id) with parameter alpha */
+int orc_qags_builtin(int id, double alpha, double a, double b, double epsabs, double epsrel, int limit,
+                     double* result, double* abserr, int* neval_out);
+
+/* ---- dense helpers (orc_linalg.cpp) ---- */
+/* eigenvalues (ascending) of the symmetric n x n column-major matrix A (cyclic Jacobi) */
+void orc_sym_eigvals(const double* A, int n, double* w);
+
+/* ---- null models (orc_models.cpp) ---- */
+/* LinearRegression::FitLinearModel: X is N x d column-major incl. intercept. Outputs beta[d],
+   predicted[N], resid[N], sigma2 (= RSS/N).  Returns 0 on success. */
+int orc_fit_linear(const double* X, const double* y, int64_t N, int d, double* beta, double* pred,
+                   double* resid, double* sigma2);
+/* LogisticRegression::FitLogisticModel(X, y, nrrounds): outputs beta[d], p[N], v[N]. 0 = ok, -1 = failed */
+int orc_fit_logistic(const double* X, const double* y, int64_t N, int d, int nrrounds, double* beta,
+                     double* p, double* v);
+
+/* ---- DataConsolidator semantics ---- */
+/* imputeGenotypeToMean in place (G: N x M col-major, missing < 0). */
+void orc_impute_mean(double* G, int64_t N, int M);
+/* GenotypeCounter AF per column of the raw (un-imputed) matrix. */
+void orc_counter_af(const double* Graw, int64_t N, int M, double* af);
+/* getFlippedToMinorPolymorphicGenotype: writes N x Mout matrix, returns Mout; flipped[M], kept[M] flags */
+int orc_flip_poly(const double* G, int64_t N, int M, double* out, int* flipped, int* kept);
+
+/* ---- per-gene tests.  G is the imputed, UNFLIPPED N x M block (as dc->getGenotype()),
+        af[M] the counter AF (quirk #3: indexed by filtered column), X incl. intercept. ---- */
+typedef struct {
+  int fit_ok;      /* 1 if the reference would print numbers, 0 for NA */
+  int n_poly;      /* columns after flip + monomorphic removal */
+  double Q;
+  double pvalue;
+  double rho;      /* SKAT-O only */
+  int n_lambda;    /* SKAT: kept eigenvalues */
+  double lambda[512];
+  /* SKAT-O diagnostics */
+  double Qs[11], pvals[11], taus[11], qminp[11];
+  double muQ, varQ, varZeta, df, minP;
+  int qags_status, qags_neval;
+} orc_kernel_result;
+
+typedef struct {
+  int fit_ok;
+  int n_poly;
+  int nonref_site; /* CMC only */
+  double U, V, stat, pvalue;
+} orc_burden_result;
+
+/* SkatTest::fit + Skat::Fit with the P0 projection folded (fp64).  binary: 0 QT, 1 binary. */
+int orc_skat(const double* G, const double* af, int64_t N, int M, const double* X, int d, const double* res,
+             const double* v, int binary, double beta1, double beta2, orc_kernel_result* out);
+/* literal Skat::Fit with the N x N P0 (fp64 arithmetic; use_float=1 mirrors the reference's float casts) */
+int orc_skat_literal(const double* G, const double* af, int64_t N, int M, const double* X, int d,
+                     const double* res, const double* v, int binary, double beta1, double beta2, int use_float,
+                     orc_kernel_result* out);
+/* SkatOTest::fit + SkatO::Fit, literal operation order (Z1, Z1*L, Z2'Z2 per rho). */
+int orc_skato(const double* G, const double* af, int64_t N, int M, const double* X, int d, const double* res,
+              const double* v, int binary, double beta1, double beta2, orc_kernel_result* out);
+/* CMCTest / ZegginiTest: which = 0 CMC, 1 Zeggini.  y and X are used to refit the null as the reference does. */
+int orc_burden(const double* G, int64_t N, int M, const double* X, int d, const double* y, int binary, int which,
+               orc_burden_result* out);
+/* collapsed vectors only (bit-exact checks) */
+void orc_collapse(const double* G, int64_t N, int M, int which, double* out);
+
+/* Permutation p-value machinery (src/Permutation.h:69-98, src/LinearAlgebra.h:8-21) with an explicit
+   glibc-TYPE_3 rand() emulator state so that runs are reproducible. */
+typedef struct {
+  int num_perm, actual_perm, num_x, num_equal;
+  double threshold, pvalue;
+} orc_perm_result;
+void orc_rand_seed(unsigned seed);
+int orc_rand(void);
+int orc_skat_permute(const double* G, const double* af, int64_t N, int M, const double* res, double beta1,
+                     double beta2, double obs, int nPerm, double alpha, int use_float, orc_perm_result* out);
+
+#ifdef __cplusplus
+}
+#endif

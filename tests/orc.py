@@ -1,0 +1,277 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so) and the compiled reference fragment
+(oracle/_ref/libref_mixchisq.so).  TEST INFRASTRUCTURE ONLY — nothing under rvtests_amd/ imports this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+class KernelResult(C.Structure):
+    _fields_ = [
+        ("fit_ok", C.c_int), ("n_poly", C.c_int), ("Q", C.c_double), ("pvalue", C.c_double),
+        ("rho", C.c_double), ("n_lambda", C.c_int), ("lambda_", C.c_double * 512),
+        ("Qs", C.c_double * 11), ("pvals", C.c_double * 11), ("taus", C.c_double * 11),
+        ("qminp", C.c_double * 11), ("muQ", C.c_double), ("varQ", C.c_double), ("varZeta", C.c_double),
+        ("df", C.c_double), ("minP", C.c_double), ("qags_status", C.c_int), ("qags_neval", C.c_int),
+    ]
+
+
+class BurdenResult(C.Structure):
+    _fields_ = [("fit_ok", C.c_int), ("n_poly", C.c_int), ("nonref_site", C.c_int), ("U", C.c_double),
+                ("V", C.c_double), ("stat", C.c_double), ("pvalue", C.c_double)]
+
+
+class PermResult(C.Structure):
+    _fields_ = [("num_perm", C.c_int), ("actual_perm", C.c_int), ("num_x", C.c_int), ("num_equal", C.c_int),
+                ("threshold", C.c_double), ("pvalue", C.c_double)]
+
+
+def build(native=False):
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+    if os.path.isdir("/root/reference/regression"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+_lib = None
+_ref = None
+
+
+def lib(native=False):
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        d = C.c_double
+        for name, args in [
+            ("orc_gamma_inc_P", [d, d]), ("orc_gamma_inc_Q", [d, d]), ("orc_chisq_P", [d, d]),
+            ("orc_chisq_Q", [d, d]), ("orc_chisq_Qinv", [d, d]), ("orc_chisq_pdf", [d, d]),
+            ("orc_beta_pdf", [d, d, d]), ("orc_gamma_pdf", [d, d, d]),
+            ("orc_gamma_cdf_P", [d, d, d]), ("orc_gamma_cdf_Q", [d, d, d]), ("orc_gamma_cdf_Qinv", [d, d, d]),
+        ]:
+            f = getattr(L, name)
+            f.restype = d
+            f.argtypes = args
+        L.orc_qf.restype = d
+        L.orc_qf.argtypes = [c_double_p, c_double_p, c_int_p, C.c_int, d, d, C.c_int, d, c_double_p, c_int_p]
+        L.orc_davies_pvalue.restype = d
+        L.orc_davies_pvalue.argtypes = [c_double_p, C.c_int, d, c_int_p]
+        L.orc_liu_pvalue.restype = d
+        L.orc_liu_pvalue.argtypes = [c_double_p, C.c_int, d]
+        L.orc_cumchn.restype = None
+        L.orc_cumchn.argtypes = [d, d, d, c_double_p, c_double_p]
+        L.orc_qags_builtin.restype = C.c_int
+        L.orc_qags_builtin.argtypes = [C.c_int, d, d, d, d, d, C.c_int, c_double_p, c_double_p, c_int_p]
+        L.orc_sym_eigvals.restype = None
+        L.orc_sym_eigvals.argtypes = [c_double_p, C.c_int, c_double_p]
+        L.orc_fit_linear.restype = C.c_int
+        L.orc_fit_linear.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, c_double_p,
+                                     c_double_p, c_double_p]
+        L.orc_fit_logistic.restype = C.c_int
+        L.orc_fit_logistic.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, C.c_int, c_double_p,
+                                       c_double_p, c_double_p]
+        L.orc_impute_mean.restype = None
+        L.orc_impute_mean.argtypes = [c_double_p, C.c_int64, C.c_int]
+        L.orc_counter_af.restype = None
+        L.orc_counter_af.argtypes = [c_double_p, C.c_int64, C.c_int, c_double_p]
+        L.orc_flip_poly.restype = C.c_int
+        L.orc_flip_poly.argtypes = [c_double_p, C.c_int64, C.c_int, c_double_p, c_int_p, c_int_p]
+        L.orc_collapse.restype = None
+        L.orc_collapse.argtypes = [c_double_p, C.c_int64, C.c_int, C.c_int, c_double_p]
+        kargs = [c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p,
+                 C.c_int, d, d, C.POINTER(KernelResult)]
+        L.orc_skat.restype = C.c_int
+        L.orc_skat.argtypes = kargs
+        L.orc_skato.restype = C.c_int
+        L.orc_skato.argtypes = kargs
+        L.orc_skat_literal.restype = C.c_int
+        L.orc_skat_literal.argtypes = kargs[:-1] + [C.c_int, C.POINTER(KernelResult)]
+        L.orc_burden.restype = C.c_int
+        L.orc_burden.argtypes = [c_double_p, C.c_int64, C.c_int, c_double_p, C.c_int, c_double_p, C.c_int,
+                                 C.c_int, C.POINTER(BurdenResult)]
+        L.orc_rand_seed.restype = None
+        L.orc_rand_seed.argtypes = [C.c_uint]
+        L.orc_rand.restype = C.c_int
+        L.orc_skat_permute.restype = C.c_int
+        L.orc_skat_permute.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, d, d, d, C.c_int,
+                                       d, C.c_int, C.POINTER(PermResult)]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The compiled reference fragment, or None when it has not been built / is absent."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_mixchisq.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference/regression"):
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+            else:
+                return None
+        R = C.CDLL(path)
+        d = C.c_double
+        R.ref_davies_pvalue.restype = d
+        R.ref_davies_pvalue.argtypes = [c_double_p, C.c_int, d]
+        R.ref_liu_pvalue.restype = d
+        R.ref_liu_pvalue.argtypes = [c_double_p, C.c_int, d]
+        R.ref_qf.restype = d
+        R.ref_qf.argtypes = [c_double_p, c_double_p, c_int_p, C.c_int, d, d, C.c_int, d, c_double_p, c_int_p]
+        R.ref_cumchn.restype = None
+        R.ref_cumchn.argtypes = [d, d, d, c_double_p, c_double_p]
+        R.ref_cumchi.restype = None
+        R.ref_cumchi.argtypes = [d, d, c_double_p, c_double_p]
+        R.ref_gamma_inc.restype = None
+        R.ref_gamma_inc.argtypes = [d, d, c_double_p, c_double_p]
+        _ref = R
+    return _ref
+
+
+# ------------------------------------------------------------------ convenience wrappers
+def F(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def davies(lam, Q, which="orc"):
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    if which == "ref":
+        return ref().ref_davies_pvalue(_dp(lam), len(lam), float(Q))
+    fault = C.c_int(0)
+    return lib().orc_davies_pvalue(_dp(lam), len(lam), float(Q), C.byref(fault))
+
+
+def liu(lam, Q, which="orc"):
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    if which == "ref":
+        return ref().ref_liu_pvalue(_dp(lam), len(lam), float(Q))
+    return lib().orc_liu_pvalue(_dp(lam), len(lam), float(Q))
+
+
+def qf(lam, c, which="orc", lim=10000, acc=1e-6, sigma=0.0):
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    r = len(lam)
+    nc = np.zeros(r)
+    n = np.ones(r, dtype=np.int32)
+    trace = np.zeros(7)
+    fault = C.c_int(0)
+    fn = ref().ref_qf if which == "ref" else lib().orc_qf
+    val = fn(_dp(lam), _dp(nc), _ip(n), r, sigma, float(c), lim, acc, _dp(trace), C.byref(fault))
+    return val, fault.value, trace
+
+
+def sym_eigvals(A):
+    A = F(A)
+    n = A.shape[0]
+    w = np.zeros(n)
+    lib().orc_sym_eigvals(_dp(A), n, _dp(w))
+    return w
+
+
+def fit_linear(X, y):
+    X = F(X)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    N, d = X.shape
+    beta = np.zeros(d)
+    pred = np.zeros(N)
+    resid = np.zeros(N)
+    s2 = C.c_double(0)
+    rc = lib().orc_fit_linear(_dp(X), _dp(y), N, d, _dp(beta), _dp(pred), _dp(resid), C.byref(s2))
+    return rc, beta, pred, resid, s2.value
+
+
+def fit_logistic(X, y, rounds=100):
+    X = F(X)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    N, d = X.shape
+    beta = np.zeros(d)
+    p = np.zeros(N)
+    v = np.zeros(N)
+    rc = lib().orc_fit_logistic(_dp(X), _dp(y), N, d, rounds, _dp(beta), _dp(p), _dp(v))
+    return rc, beta, p, v
+
+
+def impute_mean(Graw):
+    G = F(Graw).copy(order="F")
+    N, M = G.shape
+    lib().orc_impute_mean(_dp(G), N, M)
+    return G
+
+
+def counter_af(Graw):
+    G = F(Graw)
+    N, M = G.shape
+    af = np.zeros(M)
+    lib().orc_counter_af(_dp(G), N, M, _dp(af))
+    return af
+
+
+def flip_poly(G):
+    G = F(G)
+    N, M = G.shape
+    out = np.zeros((N, M), order="F")
+    fl = np.zeros(M, dtype=np.int32)
+    kp = np.zeros(M, dtype=np.int32)
+    m = lib().orc_flip_poly(_dp(G), N, M, _dp(out), _ip(fl), _ip(kp))
+    return np.asfortranarray(out.reshape(-1, order="F")[: N * m].reshape((N, m), order="F")), fl, kp
+
+
+def collapse(Gf, which):
+    Gf = F(Gf)
+    N, M = Gf.shape
+    out = np.zeros(N)
+    lib().orc_collapse(_dp(Gf), N, M, which, _dp(out))
+    return out
+
+
+def _kernel(fn, G, af, X, res, v, binary, b1, b2, extra=None):
+    G = F(G)
+    X = F(X)
+    N, M = G.shape
+    d = X.shape[1]
+    af = np.ascontiguousarray(af, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = KernelResult()
+    args = [_dp(G), _dp(af), N, M, _dp(X), d, _dp(res), _dp(v), int(binary), b1, b2]
+    if extra is not None:
+        args.append(extra)
+    rc = fn(*args, C.byref(out))
+    return rc, out
+
+
+def skat(G, af, X, res, v, binary=0, b1=1.0, b2=25.0):
+    return _kernel(lib().orc_skat, G, af, X, res, v, binary, b1, b2)
+
+
+def skat_literal(G, af, X, res, v, binary=0, b1=1.0, b2=25.0, use_float=0):
+    return _kernel(lib().orc_skat_literal, G, af, X, res, v, binary, b1, b2, extra=use_float)
+
+
+def skato(G, af, X, res, v, binary=0, b1=1.0, b2=25.0):
+    return _kernel(lib().orc_skato, G, af, X, res, v, binary, b1, b2)
+
+
+def burden(G, X, y, binary, which):
+    G = F(G)
+    X = F(X)
+    N, M = G.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = BurdenResult()
+    rc = lib().orc_burden(_dp(G), N, M, _dp(X), X.shape[1], _dp(y), int(binary), int(which), C.byref(out))
+    return rc, out
