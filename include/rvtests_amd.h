@@ -1,0 +1,170 @@
+/* rvtests_amd — C ABI of the MI355X kernel/burden association engine.
+ *
+ * This is the drop-in boundary for the rvtests hot path: the entry points below are what GPU-backed
+ * `ModelFitter` subclasses (SkatTest, SkatOTest, CMCTest, ZegginiTest — see
+ * rvtests_amd/csrc/host/ModelFitterGpu.h and INTEGRATION.md) call instead of
+ *   Skat::Fit                         /root/reference/regression/Skat.h:26-31   (Skat.cpp:29-105)
+ *   SkatO::Fit                        regression/SkatO.h:28-35                  (SkatO.cpp:101-281,500-519)
+ *   cmcCollapse / zegginiCollapse     src/Model.cpp:73-89,115-130
+ *   LinearRegressionScoreTest::TestCovariate(Matrix,Vector,Matrix)      regression/LinearRegressionScoreTest.cpp:173-263
+ *   LogisticRegressionScoreTest::TestCovariate(Matrix,Vector,Matrix)    regression/LogisticRegressionScoreTest.cpp:220-302
+ *   DataConsolidator::getFlippedToMinorPolymorphicGenotype               src/DataConsolidator.h:128-132
+ * Plain C, plain pointers and sizes; no C++ or torch types cross it.  All functions return 0 on
+ * success and a negative RVT_E_* code on failure; rvt_last_error() gives the text.  One calling
+ * thread per context; one context per GPU (one process per GPU).
+ *
+ * Data layout.  Matrices are column-major doubles exactly as the reference's `Matrix`
+ * (base/MathMatrix.h:33-41,107-110: data[i + j*rows]).  On the device every sample-indexed array is
+ * padded to a leading dimension ld = rvt_padded_ld(N) (next multiple of 16, i.e. whole 128-byte
+ * lines) and the pad rows are zero.
+ */
+#ifndef RVTESTS_AMD_H_
+#define RVTESTS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVT_MAX_COV 16 /* max columns of X (intercept included) */
+
+/* error codes */
+#define RVT_OK 0
+#define RVT_E_INVALID (-1)   /* bad argument */
+#define RVT_E_NO_DEVICE (-2) /* no usable HIP device: the engine has NO CPU fallback */
+#define RVT_E_HIP (-3)       /* a HIP call failed */
+#define RVT_E_STATE (-4)     /* call sequence error (e.g. no null model set) */
+#define RVT_E_TOO_LARGE (-5) /* gene wider than RVT_MAX_VARIANTS */
+
+#define RVT_MAX_VARIANTS 1024
+
+/* test selection bitmask (which ModelFitter::fit bodies to run) */
+#define RVT_TEST_SKAT 1u    /* --kernel skat   : SkatTest    src/Model.h:2612-2772 */
+#define RVT_TEST_SKATO 2u   /* --kernel skato  : SkatOTest   src/Model.h:2774-2889 */
+#define RVT_TEST_CMC 4u     /* --burden cmc    : CMCTest     src/Model.h:807-907   */
+#define RVT_TEST_ZEGGINI 8u /* --burden zeggini: ZegginiTest src/Model.h:1170-1242 */
+#define RVT_TEST_ALL 15u
+
+/* trait type of the null model */
+#define RVT_TRAIT_QUANTITATIVE 0
+#define RVT_TRAIT_BINARY 1
+
+/* per-gene status bits */
+#define RVT_ST_NO_POLY 1u      /* no polymorphic variant left: every test prints NA (fit returns -1) */
+#define RVT_ST_SKATO_EIGEN 2u  /* SkatO::Fit returned -1 (no positive eigenvalue)  SkatO.cpp:170-175 */
+#define RVT_ST_CMC_FAIL 4u
+#define RVT_ST_ZEG_FAIL 8u
+
+typedef struct rvt_ctx rvt_ctx;
+
+/* model parameters, the tags ModelParser hands to the models (src/ModelManager.cpp:168-198) */
+typedef struct rvt_params {
+  double skat_beta1, skat_beta2;   /* skat[beta1=1:beta2=25]  */
+  double skato_beta1, skato_beta2; /* skato[beta1=1:beta2=25] */
+  int skat_nperm;                  /* skat[nPerm=...]; 0 = analytic p-value only */
+  double skat_alpha;               /* skat[alpha=0.05] */
+} rvt_params;
+
+/* one record per gene, in submission order — the numbers the models' writeOutput() print */
+typedef struct rvt_gene_result {
+  int64_t gene_id;
+  uint32_t status;  /* RVT_ST_* */
+  int n_variants;   /* columns submitted */
+  int n_poly;       /* columns after flip-to-minor + monomorphic removal ("NumPolyVar") */
+  /* SKAT: "Q\tPvalue"  (src/Model.h:2722-2749) */
+  int skat_ok;
+  double skat_Q, skat_p;
+  int skat_nlambda;
+  /* SKAT-O: "Q\trho\tPvalue"  (src/Model.h:2862-2875) */
+  int skato_ok;
+  double skato_Q, skato_rho, skato_p;
+  int skato_qags_status; /* GSL error number of the Davies-integrand integration (0 = converged) */
+  int skato_qags_neval;  /* integrand evaluations */
+  /* CMC: "NonRefSite\tPvalue"  (src/Model.h:860-888) */
+  int cmc_ok, cmc_nonref;
+  double cmc_U, cmc_V, cmc_stat, cmc_p;
+  /* Zeggini: "Pvalue"  (src/Model.h:1217-1231) */
+  int zeg_ok;
+  double zeg_U, zeg_V, zeg_stat, zeg_p;
+  /* diagnostics */
+  double davies_terms; /* integrand terms evaluated by all Davies calls of this gene */
+} rvt_gene_result;
+
+/* accumulated device time per kernel family, measured with HIP events on the engine's stream */
+typedef struct rvt_timing {
+  double ms_suffstat;   /* gene_suffstat_mfma (fp64 MFMA contraction + masks)  */
+  double ms_burden;     /* burden_collapse                                     */
+  double ms_stats;      /* gene_stats (flip algebra, eigen, moments)           */
+  double ms_pvalue;     /* gene_pvalue (Davies / Liu / QAGS)                   */
+  int64_t n_suffstat_launches, n_burden_launches, n_stats_launches, n_pvalue_launches;
+  int64_t genes;        /* genes processed while profiling was on              */
+  double alg_bytes;     /* algorithmic bytes of those genes: 8*N*M + 8*N*(d+2) each */
+  double alg_flops;     /* algorithmic flops: 2*N*M*(M+d+1) each                                 */
+} rvt_timing;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* Create a context on HIP device `device_id`.  Fails with RVT_E_NO_DEVICE when there is no GPU. */
+int rvt_init(rvt_ctx** ctx, int device_id);
+void rvt_destroy(rvt_ctx* ctx);
+const char* rvt_last_error(const rvt_ctx* ctx);
+const char* rvt_version(void);
+/* padded leading dimension for N samples (multiple of 16) */
+int64_t rvt_padded_ld(int64_t N);
+
+/* ---- null model ------------------------------------------------------------------------------
+ * What SkatTest::fit caches after LinearRegression::FitLinearModel / LogisticRegression::
+ * FitLogisticModel (src/Model.h:2672-2699): X is N x d column-major INCLUDING the intercept column
+ * (copyCovariateAndIntercept, src/ModelUtil.h:102-130), res = y - yhat, v = per-sample variance
+ * (sigma2 for a quantitative trait, p(1-p) for a binary one).  Host pointers; copied. */
+int rvt_set_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, const double* res,
+                 const double* v, double sigma2);
+
+/* ---- device-resident genotype blocks ------------------------------------------------------------
+ * A block is the imputed, UNFLIPPED genotype matrix of one gene (what dc->getGenotype() holds when
+ * fit() is called), N x M doubles, column-major with leading dimension rvt_padded_ld(N), pad = 0. */
+int rvt_block_alloc(rvt_ctx* ctx, int M, double** dG_out);
+int rvt_block_free(rvt_ctx* ctx, double* dG);
+/* copy a host N x M column-major matrix (leading dimension N) into a block */
+int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
+
+/* Run the selected tests on n_genes blocks that are already in HBM.  dG[g] are DEVICE pointers
+ * (rvt_block_alloc, or any 128-byte aligned device allocation with the layout above, e.g. a torch
+ * tensor); M[g] the column counts; af is the HOST concatenation of the per-column allele
+ * frequencies GenotypeCounter::getAF() reports (src/GenotypeCounter.h:46-51), sum(M) entries.
+ * Blocks until the results are in out[0..n_genes).  */
+int rvt_run_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const double* af,
+                   const int64_t* gene_ids, uint32_t tests, const rvt_params* params, rvt_gene_result* out);
+/* Same, but only enqueue on the engine's stream; results are valid after rvt_sync(). `out` must stay
+ * alive until then. */
+int rvt_run_blocks_async(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const double* af,
+                         const int64_t* gene_ids, uint32_t tests, const rvt_params* params,
+                         rvt_gene_result* out);
+int rvt_sync(rvt_ctx* ctx);
+
+/* ---- streaming interface used by the ModelFitter adapters ------------------------------------------
+ * rvt_submit_gene copies G (host, N x M column-major, imputed, unflipped) before returning — the
+ * caller's buffer is overwritten by the next gene (src/Main.cpp:1086,1225).  Results come back in
+ * submission order from rvt_collect (which flushes pending genes). */
+int rvt_submit_gene(rvt_ctx* ctx, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                    const rvt_params* params);
+int rvt_collect(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
+
+/* ---- test / inspection hooks ---------------------------------------------------------------------- */
+/* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */
+int rvt_debug_collapse(rvt_ctx* ctx, const double* dG, int M, double* cmc_out, double* zeg_out,
+                       int* flipped_out, int* kept_out);
+/* sufficient statistics of ONE block as the MFMA kernel produced them: S (M x M), T (M x d), u (M),
+ * colsum/min/max (M each); host outputs, row-major */
+int rvt_debug_suffstat(rvt_ctx* ctx, const double* dG, int M, double* S, double* T, double* u, double* colsum,
+                       double* cmin, double* cmax);
+int rvt_set_profiling(rvt_ctx* ctx, int on);
+int rvt_get_timing(rvt_ctx* ctx, rvt_timing* t, int reset);
+/* the HIP stream (hipStream_t) the engine launches on, for callers that record their own events */
+void* rvt_stream(rvt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVTESTS_AMD_H_ */

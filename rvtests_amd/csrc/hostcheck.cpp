@@ -1,0 +1,116 @@
+// rvtests_amd — HOST TEST HARNESS (test-only; never linked into librvtests_amd.so).
+//
+// Compiles the RVT_HD device algorithms (special functions, Davies / Liu, QAGS state machine, per-gene
+// statistics with flip algebra and the tridiagonal eigen solver, p-value stage) with g++ so that the
+// CPU test-suite (`pytest -m "not gpu"`) can exercise them against the oracle without a GPU.
+// It consumes sufficient statistics the TEST computes (numpy) — it is not a CPU implementation of the
+// engine and the shipped library has no path into it.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "rvt_pvalue.h"
+
+using namespace rvt;
+
+extern "C" {
+
+double hc_chisq_Q(double x, double nu) { return chisq_Q(x, nu); }
+double hc_chisq_P(double x, double nu) { return chisq_P(x, nu); }
+double hc_chisq_Qinv(double q, double nu) { return chisq_quantile_Q(q, nu); }
+double hc_chisq_pdf(double x, double nu) { return chisq_density(x, nu); }
+double hc_beta_pdf(double x, double a, double b) { return beta_density(x, a, b); }
+
+double hc_davies_pvalue(const double* lam, int n, double Q, int* fault, double* nterms) {
+  std::vector<int> th(n > 0 ? n : 1);
+  davies_order(lam, n, th.data());
+  return davies_pvalue(lam, th.data(), n, Q, fault, nterms);
+}
+double hc_liu_pvalue(const double* lam, int n, double Q) { return liu_pvalue(lam, n, Q); }
+
+void hc_sym_eigvals(const double* Ain, int n, double* out) {
+  std::vector<double> A(Ain, Ain + (size_t)n * n), d(n), e(n), v(n), w(n), red(64);
+  Coop co{0, 1, red.data()};
+  coop_sym_eigvals(co, A.data(), n, d.data(), e.data(), v.data(), w.data(), out);
+}
+
+// QAGS state machine driven serially on one of the fixture integrands (ids as in the oracle)
+static double builtin_f(int id, double alpha, double x) {
+  switch (id) {
+    case 0: return pow(x, alpha) * log(1 / x);
+    case 1: return exp(-x) * sin(alpha * x);
+    case 2: return chisq_density(x, 1.0) * exp(-alpha * x);
+    case 3: return 1.0 / (1.0 + alpha * x * x);
+    case 4: return (x > 0 ? pow(x, -0.5) : 0.0) * cos(alpha * x);
+    default: return 0.0;
+  }
+}
+int hc_qags_builtin(int id, double alpha, double a, double b, double epsabs, double epsrel, int limit,
+                    double* result, double* abserr, int* neval) {
+  std::vector<char> mem(qags_workspace_bytes(limit));
+  QagsWorkspace ws = qags_workspace_carve(mem.data(), limit);
+  QagsMachine qm;
+  double fv[42];
+  int ne = 0;
+  qm.begin(a, b, epsabs, epsrel, limit, ws);
+  if (qm.running()) {
+    for (int t = 0; t < 21; ++t) fv[t] = builtin_f(id, alpha, gk21_abscissa(a, b, t));
+    ne += 21;
+    qm.first_panel(fv);
+  }
+  while (qm.running()) {
+    double a1, b1, b2;
+    qm.bisect(&a1, &b1, &b2);
+    for (int t = 0; t < 42; ++t)
+      fv[t] = builtin_f(id, alpha, t < 21 ? gk21_abscissa(a1, b1, t) : gk21_abscissa(b1, b2, t - 21));
+    ne += 42;
+    qm.advance(fv, fv + 21);
+  }
+  *result = qm.result;
+  *abserr = qm.abserr;
+  *neval = ne;
+  return qm.status;
+}
+
+// Full per-gene stage from test-provided sufficient statistics.
+//   R: M x (M+d+1) row-major = G' D [G | X | rr];  colstat: 3 x M (sum, min, max);
+//   bstats: 2 x (3+d) burden sums (may be null)
+int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum, const double* C,
+            const double* Cinv, int M, const double* Rin, const double* colstat_in, const double* bstats,
+            const double* af, const rvt_params* prm, unsigned tests, rvt_gene_result* out, int* flip_out,
+            int* kept_out, double* lambda_out /* 2*M or null */) {
+  NullConsts nc;
+  std::memset(&nc, 0, sizeof(nc));
+  nc.N = N;
+  nc.ld = (N + 15) / 16 * 16;
+  nc.d = d;
+  nc.binary = trait;
+  nc.sigma2 = sigma2;
+  nc.rss = rss;
+  nc.rsum = rsum;
+  for (int i = 0; i < d * d; ++i) {
+    nc.C[i] = C[i];
+    nc.Cinv[i] = Cinv[i];
+  }
+  const int Cc = M + d + 1;
+  const int Mp = (M + 15) / 16 * 16, Cp = (Cc + 15) / 16 * 16;
+  std::vector<double> parts((size_t)Mp * Cp, 0.0), cs((size_t)3 * Mp, 0.0);
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < Cc; ++j)
+      if ((j >> 4) >= (i >> 4)) parts[(size_t)i * Cp + j] = Rin[(size_t)i * Cc + j];
+  for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < M; ++j) cs[(size_t)k * Mp + j] = colstat_in[(size_t)k * M + j];
+  std::vector<double> mem(gene_scratch_doubles(Mp, Cp) + 16), red(64), lam((size_t)2 * M + 2);
+  GeneScratch ws = gene_scratch_carve(mem.data(), Mp, Cp);
+  Coop co{0, 1, red.data()};
+  GeneStats gs;
+  std::memset(&gs, 0, sizeof(gs));
+  gene_stats(co, nc, M, Mp, Cp, parts.data(), 1, cs.data(), bstats, 1, af, *prm, tests, ws, &gs, lam.data(),
+             flip_out, kept_out);
+  std::vector<int> th1(M + 1), th2(M + 1);
+  std::vector<char> qmem(qags_workspace_bytes(kSkatoLimit));
+  gene_pvalue_serial(gs, lam.data(), tests, 0, th1.data(), th2.data(), qmem.data(), out);
+  if (lambda_out) std::memcpy(lambda_out, lam.data(), sizeof(double) * 2 * M);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,539 @@
+// rvtests_amd — HIP kernels for gfx950 (MI355X).  Included once by rvt_engine.hip.
+//
+//  gene_suffstat_mfma<MT,CT,W>  fp64-MFMA sufficient statistics  R = G'·D·[G | X | rr]  + exact column
+//                               sum/min/max + per-sample ">=1" / "<=1" bit masks, ONE pass over G
+//  gene_flags_kernel            flip / polymorphic flags per 16-variant block
+//  burden_collapse_kernel       cmcCollapse / zegginiCollapse from the bit masks + score partial sums
+//  gene_stats_kernel            flip algebra, weights, eigenvalues, SKAT-O moments (one workgroup / gene)
+//  gene_pvalue_kernel           Davies / Liu / QAGS (one wave / gene, one lane / quadrature abscissa)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rvt_pvalue.h"
+
+namespace rvt {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// One gene as the kernels see it.
+struct GeneDesc {
+  const double* G;       // N x M block, leading dimension ld
+  int M, MT, CT;         // columns, row tiles (ceil(M/16)), column tiles (ceil((M+d+1)/16))
+  int Mp, Cp;            // 16*MT, 16*CT
+  int n_wparts;          // wave-parts the sample axis is cut into
+  int steps_per_wpart;   // 16-sample steps per wave-part
+  double* parts;         // n_wparts x Mp x Cp partial statistics (row-major)
+  double* colstat;       // n_wparts x 3 x Mp
+  unsigned long long* masks;  // [2][nsteps][MT][4] ballots: kind 0 "g >= 1", kind 1 "g <= 1"
+  unsigned short* flags;      // [2][MT]: flip bits, polymorphic bits per 16-variant block
+  double* bparts;        // n_bparts x 2 x (3+d)
+  double* scratch;       // gene_scratch_doubles(Mp, Cp)
+  double* lambda;        // 2*M
+  void* qags_mem;        // qags_workspace_bytes(1000)
+  const double* af;      // M allele frequencies (device copy)
+  GeneStats* stats;
+  rvt_gene_result* result;
+  int* dbg_flip;         // optional M ints
+  int* dbg_kept;         // optional M ints
+  double* dbg_cmc;       // optional N doubles
+  double* dbg_zeg;       // optional N doubles
+  long long gene_id;
+};
+
+struct NullDev {
+  const double* X;     // ld x d  (column k at X + k*ld)
+  const double* res;   // ld
+  const double* rr;    // ld: res (quantitative) or res / v (binary)
+  const double* v;     // ld
+  const double* zeros; // ld zeros
+};
+
+// =====================================================================================================
+// K2: sufficient statistics on the fp64 matrix cores.
+//
+// v_mfma_f64_16x16x4_f64 computes D(16x16) += A(16x4)·B(4x16) with lane l holding A[l&15][l>>4] and
+// B[l>>4][l&15].  Here the contraction index is the SAMPLE, A's row index is a variant and B's column
+// index is a column of [G | X | rr]; since A and B use the same (index, k) lane map, the register that
+// holds 16 variants x 4 samples of G serves as the A operand of one tile row AND as the B operand of
+// one tile column — every element of G is loaded from HBM exactly once, by exactly one lane, and never
+// passes through LDS.  The sample order inside a wave is permuted so that each lane reads 4 CONSECUTIVE
+// samples (32 B) of its column per step: a 16-lane group covers one full 128-byte line per variant.
+// Waves are fully independent (each owns a contiguous sample range and all output tiles), so the kernel
+// has no barriers; partial tiles go to a workspace and are summed in a fixed order by gene_stats_kernel.
+// Only tiles with col-tile >= row-tile are computed (G'DG is symmetric).
+// =====================================================================================================
+template <int MT, int CT, bool WEIGHTED, bool GUARD>
+__device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], const double* vptr, long long off,
+                                              long long nvalid, d4_t (&acc)[MT][CT], double (&cs)[MT],
+                                              double (&cmn)[MT], double (&cmx)[MT], double (&f)[CT][4],
+                                              unsigned long long* mask_ge, unsigned long long* mask_le, int lane) {
+  // (loads for this step were issued by the caller into f)
+  double a[MT][4];
+  if (WEIGHTED) {
+    const d2_t v0 = *reinterpret_cast<const d2_t*>(vptr + off);
+    const d2_t v1 = *reinterpret_cast<const d2_t*>(vptr + off + 2);
+    const double vv[4] = {v0[0], v0[1], v1[0], v1[1]};
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a[c][l] = f[c][l] * vv[l];
+  } else {
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a[c][l] = f[c][l];
+  }
+  unsigned long long wge = 0, wle = 0;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const double g = f[c][l];
+      cs[c] += g;
+      if (GUARD) {
+        if ((long long)l < nvalid) {
+          cmn[c] = fmin(cmn[c], g);
+          cmx[c] = fmax(cmx[c], g);
+        }
+      } else {
+        cmn[c] = fmin(cmn[c], g);
+        cmx[c] = fmax(cmx[c], g);
+      }
+      const unsigned long long bge = __ballot(g >= 1.0);
+      const unsigned long long ble = __ballot(g <= 1.0);
+      if (lane == c * 4 + l) {
+        wge = bge;
+        wle = ble;
+      }
+    }
+  }
+  if (lane < MT * 4) {
+    mask_ge[lane] = wge;
+    mask_le[lane] = wle;
+  }
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+#pragma unroll
+      for (int c = r; c < CT; ++c) {
+        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][l], f[c][l], acc[r][c], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int CT>
+__device__ __forceinline__ void suffstat_load(const double* const (&colp)[CT], long long off, double (&f)[CT][4]) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const d2_t x0 = *reinterpret_cast<const d2_t*>(colp[c] + off);
+    const d2_t x1 = *reinterpret_cast<const d2_t*>(colp[c] + off + 2);
+    f[c][0] = x0[0];
+    f[c][1] = x0[1];
+    f[c][2] = x1[0];
+    f[c][3] = x1[1];
+  }
+}
+
+template <int MT, int CT, bool WEIGHTED>
+__global__ __launch_bounds__(256) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes, NullDev nd, long long N,
+                                                          long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wpart >= gd.n_wparts) return;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  const int M = gd.M;
+  // per-lane column pointers
+  const double* colp[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int j = c * 16 + (lane & 15);
+    const double* p;
+    if (j < M)
+      p = gd.G + (long long)j * ld;
+    else if (j < M + d)
+      p = nd.X + (long long)(j - M) * ld;
+    else if (j == M + d)
+      p = nd.rr;
+    else
+      p = nd.zeros;
+    colp[c] = p;
+  }
+  d4_t acc[MT][CT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[r][c] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double cs[MT], cmn[MT], cmx[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    cs[c] = 0.0;
+    cmn[c] = INFINITY;
+    cmx[c] = -INFINITY;
+  }
+  const long long koff = (long long)(lane >> 4) * 4;
+  unsigned long long* mge = gd.masks;
+  unsigned long long* mle = gd.masks + nsteps * MT * 4;
+  // steps whose 16 samples are all < N need no guard
+  const long long full_steps = N >> 4;
+  double f[CT][4], fn[CT][4];
+  if (s_begin < s_end) suffstat_load<CT>(colp, s_begin * 16 + koff, f);
+  for (long long s = s_begin; s < s_end; ++s) {
+    const long long off = s * 16 + koff;
+    if (s + 1 < s_end) suffstat_load<CT>(colp, off + 16, fn);
+    if (s < full_steps) {
+      suffstat_step<MT, CT, WEIGHTED, false>(colp, nd.v, off, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
+                                             mle + s * MT * 4, lane);
+    } else {
+      suffstat_step<MT, CT, WEIGHTED, true>(colp, nd.v, off, N - off, acc, cs, cmn, cmx, f, mge + s * MT * 4,
+                                            mle + s * MT * 4, lane);
+    }
+    if (s + 1 < s_end) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) f[c][l] = fn[c][l];
+    }
+  }
+  // ---- write this wave's partial tiles: element (row, col) -> parts[row*Cp + col] --------------------
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+#pragma unroll
+    for (int c = r; c < CT; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r * 16 + (lane >> 4) + 4 * i;
+        const int col = c * 16 + (lane & 15);
+        out[(long long)row * gd.Cp + col] = acc[r][c][i];
+      }
+    }
+  }
+  // ---- column sum / min / max: combine the 4 sample groups (lane>>4) --------------------------------
+  double* cst = gd.colstat + (long long)wpart * 3 * gd.Mp;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    double s = cs[c], mn = cmn[c], mx = cmx[c];
+    s += __shfl_xor(s, 16, 64);
+    mn = fmin(mn, __shfl_xor(mn, 16, 64));
+    mx = fmax(mx, __shfl_xor(mx, 16, 64));
+    s += __shfl_xor(s, 32, 64);
+    mn = fmin(mn, __shfl_xor(mn, 32, 64));
+    mx = fmax(mx, __shfl_xor(mx, 32, 64));
+    if (lane < 16) {
+      cst[c * 16 + lane] = s;
+      cst[gd.Mp + c * 16 + lane] = mn;
+      cst[2 * gd.Mp + c * 16 + lane] = mx;
+    }
+  }
+}
+
+// =====================================================================================================
+// flip / polymorphic flags per 16-variant block (needed by the burden kernel before gene_stats runs)
+//   flip:  column sum > N       convertToMinorAlleleCount   src/DataConsolidator.cpp:46-69
+//   poly:  min != max           isMonomorphicMarker          src/DataConsolidator.cpp:94-116
+// =====================================================================================================
+__global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restrict__ genes, long long N) {
+  const GeneDesc gd = genes[blockIdx.x];
+  const int tid = threadIdx.x;  // blockDim.x == 64: one wave
+  for (int base = 0; base < gd.Mp; base += 64) {
+    const int j = base + tid;
+    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    if (j < gd.M) {
+      for (int p = 0; p < gd.n_wparts; ++p) {
+        const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+        s += c[j];
+        mn = fmin(mn, c[gd.Mp + j]);
+        mx = fmax(mx, c[2 * gd.Mp + j]);
+      }
+    }
+    const bool flip = (j < gd.M) && !(s <= (double)N);
+    const bool poly = (j < gd.M) && !(mn == mx);
+    const unsigned long long bf = __ballot(flip), bp = __ballot(poly);
+    if (tid < 4) {
+      const int b = (base >> 4) + tid;  // 16-variant block
+      if (b < gd.MT) {
+        gd.flags[b] = (unsigned short)((bf >> (16 * tid)) & 0xffffu);
+        gd.flags[gd.MT + b] = (unsigned short)((bp >> (16 * tid)) & 0xffffu);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// K1b: collapsed burden genotypes and their score-test partial sums.
+//   cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130): a variant "counts" for a sample when
+//   (int)g' > 0 on the flipped genotype g': g >= 1 for an unflipped column, g <= 1 for a flipped one.
+//   Per sample:  n = popcount(((ge & ~flip) | (le & flip)) & poly);  c_cmc = (n > 0), c_zeg = n.
+//   Partial sums per block and test: U = Σ c·res, Σ w c², #(c != 0), Σ w c x_k   (w = v if binary else 1)
+// One thread = one sample, looped over the genes of the launch so X/res/v are read once per sample.
+// =====================================================================================================
+constexpr int kBurdenSPB = 1024;  // samples per block (256 threads x 4)
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __restrict__ genes, int n_genes,
+                                                              NullDev nd, long long N, long long ld, int d, int binary,
+                                                              unsigned tests) {
+  __shared__ double red[4][2 * (3 + DMAX)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long base = (long long)blockIdx.x * kBurdenSPB;
+  const long long nsteps = ld >> 4;
+  const int rl = 3 + d;
+  double xr[4][DMAX], rres[4], wv[4];
+  bool valid[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long smp = base + tid + 256 * q;
+    valid[q] = smp < N;
+    const long long sidx = valid[q] ? smp : 0;
+    rres[q] = valid[q] ? nd.res[sidx] : 0.0;
+    wv[q] = valid[q] ? (binary ? nd.v[sidx] : 1.0) : 0.0;
+    #pragma unroll
+    for (int k = 0; k < DMAX; ++k) xr[q][k] = (valid[q] && k < d) ? nd.X[(long long)k * ld + sidx] : 0.0;
+  }
+  for (int g = 0; g < n_genes; ++g) {
+    const GeneDesc gd = genes[g];
+    const int MT = gd.MT;
+    const unsigned long long* mge = gd.masks;
+    const unsigned long long* mle = gd.masks + nsteps * MT * 4;
+    double acc[2][3 + DMAX];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 3 + DMAX; ++k) acc[t][k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long smp = base + tid + 256 * q;
+      int n = 0;
+      if (valid[q]) {
+        const long long step = smp >> 4;
+        const int t16 = (int)(smp & 15), kk = t16 >> 2, l = t16 & 3;
+        for (int c = 0; c < MT; ++c) {
+          const unsigned ge = (unsigned)((mge[(step * MT + c) * 4 + l] >> (16 * kk)) & 0xffffu);
+          const unsigned le = (unsigned)((mle[(step * MT + c) * 4 + l] >> (16 * kk)) & 0xffffu);
+          const unsigned fl = gd.flags[c], po = gd.flags[MT + c];
+          n += __popc(((ge & ~fl) | (le & fl)) & po);
+        }
+      }
+      const double cv[2] = {n > 0 ? 1.0 : 0.0, (double)n};
+      if (valid[q]) {
+        if (gd.dbg_cmc) gd.dbg_cmc[smp] = cv[0];
+        if (gd.dbg_zeg) gd.dbg_zeg[smp] = cv[1];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const double c = cv[t];
+        acc[t][0] += c * rres[q];
+        acc[t][1] += (c * wv[q]) * c;
+        acc[t][2] += (c != 0.0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) acc[t][3 + k] += (c * wv[q]) * xr[q][k];
+      }
+    }
+    // block reduction in a fixed order
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 3 + DMAX; ++k) {
+        double v = acc[t][k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && k < rl) red[wave][t * rl + k] = v;
+      }
+    __syncthreads();
+    if (tid < 2 * rl) {
+      const double s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      gd.bparts[(long long)blockIdx.x * 2 * rl + tid] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================
+// K3: per-gene statistics, one 256-thread workgroup per gene.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void gene_stats_kernel(const GeneDesc* __restrict__ genes,
+                                                         const NullConsts* __restrict__ ncp, rvt_params prm,
+                                                         unsigned tests, int n_bparts) {
+  __shared__ double red[64];
+  __shared__ NullConsts nc;
+  const GeneDesc gd = genes[blockIdx.x];
+  if (threadIdx.x == 0) nc = *ncp;
+  __syncthreads();
+  Coop co{(int)threadIdx.x, (int)blockDim.x, red};
+  GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  gene_stats(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
+             (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, n_bparts, gd.af, prm, tests, ws,
+             gd.stats, gd.lambda, gd.dbg_flip, gd.dbg_kept);
+}
+
+// =====================================================================================================
+// K4: p-values, one wave per gene.  Lane t evaluates quadrature abscissa t (21 for the first panel, 42
+// for the two halves of a bisected interval); lane 63 does the SKAT Davies call alongside the first
+// panel; lanes 0..10 do the per-rho tails and quantiles.  Lane 0 runs the QAGS bookkeeping.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes, unsigned tests) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GeneDesc gd = genes[blockIdx.x];
+  const GeneStats gs = *gd.stats;
+  const int lane = threadIdx.x;
+  const int M = gd.M;
+  double* lam_skat = reinterpret_cast<double*>(smem);
+  double* lam_zimz = lam_skat + M;
+  int* th_skat = reinterpret_cast<int*>(lam_zimz + M);
+  int* th_zimz = th_skat + M;
+  rvt_gene_result res;
+  pvalue_init_result(gs, gd.gene_id, &res);
+  if (gs.n_poly == 0) {
+    if (lane == 0) *gd.result = res;
+    return;
+  }
+  for (int i = lane; i < gs.skat_nlambda; i += 64) lam_skat[i] = gd.lambda[gs.skat_lambda_off + i];
+  for (int i = lane; i < gs.zimz_nlambda; i += 64) lam_zimz[i] = gd.lambda[gs.zimz_lambda_off + i];
+  __syncthreads();
+  if (lane == 0) davies_order(lam_skat, gs.skat_nlambda, th_skat);
+  if (lane == 1) davies_order(lam_zimz, gs.zimz_nlambda, th_zimz);
+  __syncthreads();
+  double terms = 0.0;
+  // ---- SKAT on lane 63 (runs concurrently with the per-rho work below) --------------------------------
+  double skat_p = 0.0;
+  const bool do_skat = (tests & RVT_TEST_SKAT) != 0;
+  const bool do_skato = (tests & RVT_TEST_SKATO) && gs.skato_ok;
+  double pv_rho = 1.0;
+  SkatoMoment mo;
+  mo.muQ = mo.varQ = mo.df = 1.0;
+  if (lane == 63 && do_skat) {
+    int fault;
+    double nt;
+    double p = davies_pvalue(lam_skat, th_skat, gs.skat_nlambda, gs.skat_Q, &fault, &nt);
+    terms += nt;
+    if (p <= 0.0 || p == 1.0) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);
+    skat_p = p;
+  } else if (lane < kNRho && do_skato && !gs.skato_single) {
+    mo.muQ = gs.mom_mu[lane];
+    mo.varQ = gs.mom_var[lane];
+    mo.df = gs.mom_df[lane];
+    pv_rho = skato_p_by_moment(gs.Qs[lane], mo);
+  } else if (lane == 62 && do_skato && gs.skato_single) {
+    int fault;
+    double nt;
+    pv_rho = davies_pvalue(lam_zimz, th_zimz, gs.zimz_nlambda, gs.Qs[0], &fault, &nt);
+  } else if (lane == 61 && (tests & RVT_TEST_CMC) && gs.cmc_ok) {
+    pv_rho = chisq_Q(gs.cmc_stat, 1.0);
+  } else if (lane == 60 && (tests & RVT_TEST_ZEGGINI) && gs.zeg_ok) {
+    pv_rho = chisq_Q(gs.zeg_stat, 1.0);
+  }
+  skat_p = __shfl(skat_p, 63, 64);
+  if (do_skat) {
+    res.skat_ok = 1;
+    res.skat_Q = gs.skat_Q;
+    res.skat_p = skat_p;
+  }
+  res.cmc_p = __shfl(pv_rho, 61, 64);
+  res.zeg_p = __shfl(pv_rho, 60, 64);
+  if (!((tests & RVT_TEST_CMC) && gs.cmc_ok)) res.cmc_p = 0.0;
+  if (!((tests & RVT_TEST_ZEGGINI) && gs.zeg_ok)) res.zeg_p = 0.0;
+  if (do_skato && gs.skato_single) {
+    res.skato_ok = 1;
+    res.skato_Q = gs.Qs[0];
+    res.skato_rho = 0.0;
+    res.skato_p = __shfl(pv_rho, 62, 64);
+  } else if (do_skato) {
+    double pvals[kNRho], qminp[kNRho];
+#pragma unroll
+    for (int i = 0; i < kNRho; ++i) pvals[i] = __shfl(pv_rho, i, 64);
+    double minP;
+    int minIndex;
+    skato_select(gs, pvals, &minP, &minIndex);
+    double qm_l = 0.0;
+    if (lane < kNRho) qm_l = skato_q_by_moment(minP, mo);
+#pragma unroll
+    for (int i = 0; i < kNRho; ++i) qminp[i] = __shfl(qm_l, i, 64);
+    SkatoIntegrand si;
+    skato_fill_integrand(gs, qminp, lam_zimz, th_zimz, &si);
+    QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
+    double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
+    int neval = 0;
+    double integral = 0.0;
+    int status = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      // QagsMachine lives in registers/scratch of lane 0; the wave-uniform control words go through LDS
+      QagsMachine qm;
+      __shared__ double ctl[4];   // a1, b1, b2, running
+      if (lane == 0) {
+        qm.begin(0., 40., kSkatoEpsAbs, kSkatoEpsRel, kSkatoLimit, ws);
+        ctl[3] = qm.running() ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      bool running = ctl[3] != 0.0;
+      if (running) {
+        if (lane < 21) {
+          const double x = gk21_abscissa(0., 40., lane);
+          double nt = 0.0;
+          fv[lane] = pass == 0 ? skato_integrand_davies(si, x, &nt) : skato_integrand_liu(si, x);
+          terms += nt;
+        }
+        neval += 21;
+        __syncthreads();
+        if (lane == 0) {
+          qm.first_panel(fv);
+          ctl[3] = qm.running() ? 1.0 : 0.0;
+          if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
+        }
+        __syncthreads();
+        running = ctl[3] != 0.0;
+      }
+      while (running) {
+        const double a1 = ctl[0], b1 = ctl[1], b2 = ctl[2];
+        if (lane < 42) {
+          const double x = (lane < 21) ? gk21_abscissa(a1, b1, lane) : gk21_abscissa(b1, b2, lane - 21);
+          double nt = 0.0;
+          fv[lane] = pass == 0 ? skato_integrand_davies(si, x, &nt) : skato_integrand_liu(si, x);
+          terms += nt;
+        }
+        neval += 42;
+        __syncthreads();
+        if (lane == 0) {
+          qm.advance(fv, fv + 21);
+          ctl[3] = qm.running() ? 1.0 : 0.0;
+          if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
+        }
+        __syncthreads();
+        running = ctl[3] != 0.0;
+      }
+      if (lane == 0) {
+        ctl[0] = qm.result;
+        ctl[1] = (double)qm.status;
+      }
+      __syncthreads();
+      integral = ctl[0];
+      status = (int)ctl[1];
+      __syncthreads();
+      if (pass == 0) {
+        res.skato_qags_status = status;
+        if (status == 0) break;
+      } else {
+        res.skato_qags_status = res.skato_qags_status * 100 + status;
+      }
+    }
+    res.skato_qags_neval = neval;
+    double rho = (minIndex == 10) ? 0.999 : 1.0 * minIndex / 10;
+    if (rho >= 0.999) rho = 1.;
+    res.skato_rho = rho;
+    res.skato_Q = gs.Qs[minIndex];
+    res.skato_p = skato_finish(integral, minP, pvals);
+    res.skato_ok = 1;
+  }
+  // total Davies terms over the wave
+  for (int off = 32; off > 0; off >>= 1) terms += __shfl_down(terms, off, 64);
+  if (lane == 0) {
+    res.davies_terms = terms;
+    *gd.result = res;
+  }
+}
+
+}  // namespace rvt

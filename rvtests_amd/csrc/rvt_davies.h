@@ -1,0 +1,472 @@
+// rvtests_amd — mixture-of-chi-square tail probabilities, one evaluation per GPU lane.
+//
+// Device implementation (RVT_HD: also compiled on the host ONLY for the test harness) of what the
+// reference computes in
+//   MixtureChiSquare::getPvalue / getLiuPvalue   regression/MixtureChiSquare.cpp:7-29, 44-83
+//   qf (Davies 1980, AS 155)                     regression/qfc.c:297-436 and helpers :82-304
+//   cdfchn(which=1) -> cumchn                    regression/cdflib.cpp:2634-2800, 5172-5350
+// as called on the hot path: sigma = 0, every term 1 df and non-centrality 0, lim = 10000,
+// acc = 1e-6 (regression/MixtureChiSquare.h:7,31-33).
+//
+// GPU shape: the reference keeps qf's state in file-scope statics and leaves through longjmp; here
+// the state is a small struct in registers, the coefficient array lives in LDS (read as a
+// broadcast by every lane of the wave), and "count > lim" is a sticky flag tested by each search
+// loop.  Each lane of a wave evaluates a DIFFERENT point c against the SAME coefficients, which
+// is exactly the access pattern of SKAT-O's quadrature (21 or 42 abscissae per QAGS step).
+// The order of floating-point operations inside every sum is the reference's, so results differ
+// from it only through libm (ocml vs glibc) rounding.
+#pragma once
+#include "rvt_special.h"
+
+namespace rvt {
+
+struct DaviesState {
+  const double* lb;  // coefficients (all > 0 on the hot path), length r
+  const int* th;     // indices of lb ordered by decreasing |lb|
+  int r;
+  int lim;
+  int count;
+  bool over;   // count exceeded lim  (reference: longjmp -> fault 4)
+  bool fail;   // cfe() could not bound the error
+  double sigsq, lmax, lmin, mean, c;
+  double intl, ersm;
+};
+
+constexpr double kDaviesPi = 3.14159265358979;  // value used by the reference (qfc.c:22)
+constexpr double kDaviesLog28 = .0866;          // qfc.c:23
+
+RVT_HD double dv_exp1(double x) { return x < -50.0 ? 0.0 : exp(x); }
+
+// log(1+x) if first, else log(1+x) - x      (qfc.c:95-113)
+RVT_HD double dv_log1(double x, bool first) {
+  if (fabs(x) > 0.1) return first ? log(1.0 + x) : (log(1.0 + x) - x);
+  double y = x / (2.0 + x);
+  double term = 2.0 * (y * y * y);
+  double k = 3.0;
+  double s = (first ? 2.0 : -x) * y;
+  y = y * y;
+  double s1 = s + term / k;
+  for (int guard = 0; s1 != s && guard < 64; ++guard) {  // converges in < 10 steps for |x| <= 0.1
+    k = k + 2.0;
+    term = term * y;
+    s = s1;
+    s1 = s + term / k;
+  }
+  return s;
+}
+
+RVT_HD void dv_tick(DaviesState& st) {
+  st.count = st.count + 1;
+  if (st.count > st.lim) st.over = true;
+}
+
+// bound on the tail probability from the mgf; cutoff returned in *cx      (qfc.c:137-155)
+RVT_HD double dv_errbd(DaviesState& st, double u, double* cx) {
+  dv_tick(st);
+  if (st.over) {
+    *cx = 0.0;
+    return 0.0;
+  }
+  double xconst = u * st.sigsq, sum1 = u * xconst;
+  u = 2.0 * u;
+  for (int j = st.r - 1; j >= 0; j--) {
+    const double lj = st.lb[j];
+    const double x = u * lj, y = 1.0 - x;
+    xconst = xconst + lj / y;
+    sum1 = sum1 + ((x * x) / y + dv_log1(-x, false));
+  }
+  *cx = xconst;
+  return dv_exp1(-0.5 * sum1);
+}
+
+// find ctff so that p(qf > ctff) < accx (upn > 0) or p(qf < ctff) < accx      (qfc.c:157-178)
+RVT_HD double dv_ctff(DaviesState& st, double accx, double* upn) {
+  double u1, u2, u, rb, xconst = 0.0, c1, c2 = 0.0;
+  u2 = *upn;
+  u1 = 0.0;
+  c1 = st.mean;
+  rb = 2.0 * ((u2 > 0.0) ? st.lmax : st.lmin);
+  for (u = u2 / (1.0 + u2 * rb); dv_errbd(st, u, &c2) > accx && !st.over; u = u2 / (1.0 + u2 * rb)) {
+    u1 = u2;
+    c1 = c2;
+    u2 = 2.0 * u2;
+  }
+  for (u = (c1 - st.mean) / (c2 - st.mean); u < 0.9 && !st.over; u = (c1 - st.mean) / (c2 - st.mean)) {
+    u = (u1 + u2) / 2.0;
+    if (dv_errbd(st, u / (1.0 + u * rb), &xconst) > accx) {
+      u1 = u;
+      c1 = xconst;
+    } else {
+      u2 = u;
+      c2 = xconst;
+    }
+  }
+  *upn = u2;
+  return c2;
+}
+
+// bound on the integration error due to truncation at u      (qfc.c:180-215)
+RVT_HD double dv_truncation(DaviesState& st, double u, double tausq) {
+  dv_tick(st);
+  if (st.over) return 0.0;
+  double sum1 = 0.0, prod2 = 0.0, prod3 = 0.0;
+  int s = 0;
+  const double sum2 = (st.sigsq + tausq) * (u * u);
+  double prod1 = 2.0 * sum2;
+  u = 2.0 * u;
+  for (int j = 0; j < st.r; j++) {
+    const double t = u * st.lb[j];
+    const double x = t * t;
+    if (x > 1.0) {
+      prod2 = prod2 + log(x);
+      prod3 = prod3 + dv_log1(x, true);
+      s = s + 1;
+    } else
+      prod1 = prod1 + dv_log1(x, true);
+  }
+  sum1 = 0.5 * sum1;
+  prod2 = prod1 + prod2;
+  prod3 = prod1 + prod3;
+  double x = dv_exp1(-sum1 - 0.25 * prod2) / kDaviesPi;
+  const double y = dv_exp1(-sum1 - 0.25 * prod3) / kDaviesPi;
+  double err1 = (s == 0) ? 1.0 : x * 2.0 / s;
+  double err2 = (prod3 > 1.0) ? 2.5 * y : 1.0;
+  if (err2 < err1) err1 = err2;
+  x = 0.5 * sum2;
+  err2 = (x <= y) ? 1.0 : y / x;
+  return (err1 < err2) ? err1 : err2;
+}
+
+// find u with truncation(u) < accx and truncation(u/1.2) > accx      (qfc.c:217-238)
+RVT_HD void dv_findu(DaviesState& st, double* utx, double accx) {
+  double ut = *utx, u = ut / 4.0;
+  if (dv_truncation(st, u, 0.0) > accx) {
+    for (u = ut; dv_truncation(st, u, 0.0) > accx && !st.over; u = ut) ut = ut * 4.0;
+  } else {
+    ut = u;
+    for (u = u / 4.0; dv_truncation(st, u, 0.0) <= accx && !st.over; u = u / 4.0) ut = u;
+  }
+  const double divis[4] = {2.0, 1.4, 1.2, 1.1};
+  for (int i = 0; i < 4; i++) {
+    u = ut / divis[i];
+    if (dv_truncation(st, u, 0.0) <= accx) ut = u;
+  }
+  *utx = ut;
+}
+
+// nterm+1 terms of the inversion integral at step interv      (qfc.c:241-270)
+RVT_HD void dv_integrate(DaviesState& st, int nterm, double interv, double tausq, bool mainx) {
+  const double inpi = interv / kDaviesPi;
+  for (int k = nterm; k >= 0; k--) {
+    const double u = (k + 0.5) * interv;
+    double sum1 = -2.0 * u * st.c, sum2 = fabs(sum1);
+    double sum3 = -0.5 * st.sigsq * (u * u);
+    for (int j = st.r - 1; j >= 0; j--) {
+      const double x = 2.0 * st.lb[j] * u;
+      const double y = x * x;
+      sum3 = sum3 - 0.25 * dv_log1(y, true);
+      const double z = atan(x);
+      sum1 = sum1 + z;
+      sum2 = sum2 + fabs(z);
+    }
+    double x = inpi * dv_exp1(sum3) / u;
+    if (!mainx) x = x * (1.0 - dv_exp1(-0.5 * tausq * (u * u)));
+    sum1 = sin(0.5 * sum1) * x;
+    sum2 = 0.5 * sum2 * x;
+    st.intl = st.intl + sum1;
+    st.ersm = st.ersm + sum2;
+  }
+}
+
+// coefficient of tausq in the error when the convergence factor is used      (qfc.c:272-304)
+RVT_HD double dv_cfe(DaviesState& st, double x) {
+  dv_tick(st);
+  if (st.over) return 1.0;
+  double axl = fabs(x);
+  const double sxl = (x > 0.0) ? 1.0 : -1.0;
+  double sum1 = 0.0;
+  for (int j = st.r - 1; j >= 0; j--) {
+    const int t = st.th[j];
+    if (st.lb[t] * sxl > 0.0) {
+      const double lj = fabs(st.lb[t]);
+      const double axl1 = axl - lj, axl2 = lj / kDaviesLog28;
+      if (axl1 > axl2)
+        axl = axl1;
+      else {
+        if (axl > axl2) axl = axl2;
+        sum1 = (axl - axl1) / lj;
+        for (int k = j - 1; k >= 0; k--) sum1 = sum1 + 1.0;
+        break;
+      }
+    }
+  }
+  if (sum1 > 100.0) {
+    st.fail = true;
+    return 1.0;
+  }
+  return pow(2.0, (sum1 / 4.0)) / (kDaviesPi * (axl * axl));
+}
+
+// P[ sum_j lb_j chi²_1 < c ]; *ifault as in the reference (0 ok, 1 accuracy, 2 round-off, 3 invalid,
+// 4 search overran lim).  nterms_out (optional) = number of integrand terms evaluated.
+RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
+                        double* nterms_out) {
+  DaviesState st;
+  st.lb = lb;
+  st.th = th;
+  st.r = r;
+  st.lim = lim;
+  st.c = c;
+  st.count = 0;
+  st.over = false;
+  st.fail = false;
+  st.intl = 0.0;
+  st.ersm = 0.0;
+  *ifault = 0;
+  double nterms = 0.0;
+  double qfval = -1.0;
+  double acc1 = acc;
+  double xlim = (double)lim;
+  st.sigsq = 0.0;
+  double sd = 0.0;
+  st.lmax = 0.0;
+  st.lmin = 0.0;
+  st.mean = 0.0;
+  for (int j = 0; j < r; j++) {
+    const double lj = lb[j];
+    sd = sd + (lj * lj) * 2.0;
+    st.mean = st.mean + lj;
+    if (st.lmax < lj)
+      st.lmax = lj;
+    else if (st.lmin > lj)
+      st.lmin = lj;
+  }
+  bool done = false;
+  double utx = 0, up = 0, un = 0, intv = 0, xnt = 0;
+  if (sd == 0.0) {
+    qfval = (c > 0.0) ? 1.0 : 0.0;
+    done = true;
+  } else if (st.lmin == 0.0 && st.lmax == 0.0) {
+    *ifault = 3;
+    done = true;
+  }
+  if (!done) {
+    sd = sqrt(sd);
+    const double almx = (st.lmax < -st.lmin) ? -st.lmin : st.lmax;
+    utx = 16.0 / sd;
+    up = 4.5 / sd;
+    un = -up;
+    dv_findu(st, &utx, .5 * acc1);
+    if (c != 0.0 && (almx > 0.07 * sd)) {
+      const double tausq = .25 * acc1 / dv_cfe(st, c);
+      if (st.fail)
+        st.fail = false;
+      else if (dv_truncation(st, utx, tausq) < .2 * acc1) {
+        st.sigsq = st.sigsq + tausq;
+        dv_findu(st, &utx, .25 * acc1);
+      }
+    }
+    acc1 = 0.5 * acc1;
+    bool to_main = false;
+    while (!done && !to_main && !st.over) {
+      const double d1 = dv_ctff(st, acc1, &up) - c;
+      if (st.over) break;
+      if (d1 < 0.0) {
+        qfval = 1.0;
+        done = true;
+        break;
+      }
+      const double d2 = c - dv_ctff(st, acc1, &un);
+      if (st.over) break;
+      if (d2 < 0.0) {
+        qfval = 0.0;
+        done = true;
+        break;
+      }
+      intv = 2.0 * kDaviesPi / ((d1 > d2) ? d1 : d2);
+      xnt = utx / intv;
+      const double xntm = 3.0 / sqrt(acc1);
+      if (xnt > xntm * 1.5) {
+        if (xntm > xlim) {
+          *ifault = 1;
+          done = true;
+          break;
+        }
+        const int ntm = (int)floor(xntm + 0.5);
+        const double intv1 = utx / ntm;
+        const double x = 2.0 * kDaviesPi / intv1;
+        if (x <= fabs(c)) {
+          to_main = true;
+          break;
+        }
+        const double cf = dv_cfe(st, c - x) + dv_cfe(st, c + x);
+        if (st.over) break;
+        const double tausq = .33 * acc1 / (1.1 * cf);
+        if (st.fail) {
+          to_main = true;
+          break;
+        }
+        acc1 = .67 * acc1;
+        dv_integrate(st, ntm, intv1, tausq, false);
+        nterms += ntm + 1;
+        xlim = xlim - xntm;
+        st.sigsq = st.sigsq + tausq;
+        dv_findu(st, &utx, .25 * acc1);
+        acc1 = 0.75 * acc1;
+        continue;
+      }
+      to_main = true;
+    }
+    if (!done && !st.over) {
+      if (xnt > xlim) {
+        *ifault = 1;
+      } else {
+        const int nt = (int)floor(xnt + 0.5);
+        dv_integrate(st, nt, intv, 0.0, true);
+        nterms += nt + 1;
+        qfval = 0.5 - st.intl;
+        const double up2 = st.ersm;
+        const double x = up2 + acc / 10.0;
+        if (1.0 * x == 1.0 * up2 || 2.0 * x == 2.0 * up2 || 4.0 * x == 4.0 * up2 || 8.0 * x == 8.0 * up2)
+          *ifault = 2;
+      }
+    }
+  }
+  if (st.over) *ifault = 4;
+  if (nterms_out) *nterms_out = nterms;
+  return qfval;
+}
+
+// ---- Liu et al. moment matching through the non-central chi-square  -----------------------------
+// cumulative central chi-square, both tails       (cdflib cumchi -> cumgam -> gamma_inc)
+RVT_HD void chisq_both_tails(double x, double df, double* cum, double* ccum) {
+  const double a = df * 0.5, xx = x * 0.5;
+  if (xx <= 0.0) {
+    *cum = 0.0;
+    *ccum = 1.0;
+    return;
+  }
+  *cum = igam_P(a, xx);
+  *ccum = igam_Q(a, xx);
+}
+
+// non-central chi-square CDF: Poisson-weighted sum started at the central term, truncated with the
+// reference's eps = 1e-5 / 1000-term rules (they set the digits, so they are kept), including its
+// `sumadj = sum + adj` update in the forward sweep        (regression/cdflib.cpp:5172-5350)
+RVT_HD void noncentral_chisq_tails(double x, double df, double pnonc, double* cum, double* ccum) {
+  const double eps = 1.0e-5;
+  const int ntired = 1000;
+  if (x <= 0.0) {
+    *cum = 0.0;
+    *ccum = 1.0;
+    return;
+  }
+  if (pnonc <= 1.0e-10) {
+    chisq_both_tails(x, df, cum, ccum);
+    return;
+  }
+  const double xnonc = pnonc / 2.0;
+  int icent = (int)xnonc;
+  if (icent == 0) icent = 1;
+  const double chid2 = x / 2.0;
+  const double centwt = exp(-xnonc + (double)icent * log(xnonc) - lgamma((double)(icent + 1)));
+  double pcent, tmp;
+  chisq_both_tails(x, df + 2.0 * (double)icent, &pcent, &tmp);
+  double dfd2 = (df + 2.0 * (double)icent) / 2.0;
+  const double centaj = exp(dfd2 * log(chid2) - chid2 - lgamma(1.0 + dfd2));
+  double sum = centwt * pcent;
+  // towards zero
+  double sumadj = 0.0, adj = centaj, wt = centwt, term;
+  int i = icent, iter = 0;
+  do {
+    dfd2 = (df + 2.0 * (double)i) / 2.0;
+    adj = adj * dfd2 / chid2;
+    sumadj = sumadj + adj;
+    wt *= ((double)i / xnonc);
+    term = wt * (pcent + sumadj);
+    sum = sum + term;
+    i -= 1;
+    iter += 1;
+  } while (!(iter > ntired || (sum < 1.0e-20 || term < eps * sum) || i == 0));
+  // towards infinity
+  sumadj = adj = centaj;
+  wt = centwt;
+  i = icent;
+  iter = 0;
+  do {
+    wt *= (xnonc / (double)(i + 1));
+    term = wt * (pcent - sumadj);
+    sum = sum + term;
+    i += 1;
+    dfd2 = (df + 2.0 * (double)i) / 2.0;
+    adj = adj * chid2 / dfd2;
+    sumadj = sum + adj;
+    iter += 1;
+  } while (!(iter > ntired || (sum < 1.0e-20 || term < eps * sum)));
+  *cum = sum;
+  *ccum = 0.5 + (0.5 - sum);
+}
+
+RVT_HD double dv_powsum(const double* d, int n, int power) {
+  double r = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double t = d[i];
+    for (int j = 1; j < power; ++j) t *= d[i];
+    r += t;
+  }
+  return r;
+}
+
+// MixtureChiSquare::getLiuPvalue      (regression/MixtureChiSquare.cpp:44-83)
+RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
+  const double c1 = dv_powsum(lambda, n, 1), c2 = dv_powsum(lambda, n, 2), c3 = dv_powsum(lambda, n, 3),
+               c4 = dv_powsum(lambda, n, 4);
+  const double s1 = c3 / c2 / sqrt(c2), s2 = c4 / c2 / c2;
+  const double tstar = (Q - c1) / sqrt(2.0 * c2);
+  double a, delta, l;
+  if (s1 * s1 > s2) {
+    a = 1 / (s1 - sqrt(s1 * s1 - s2));
+    delta = (s1 * a - 1) * a * a;
+    l = a * a - 2.0 * delta;
+  } else {
+    a = 1.0 / s1;
+    delta = 0.0;
+    l = c2 * c2 * c2 / c3 / c3;
+  }
+  const double x = tstar * (sqrt(2.0) * a) + (l + delta);
+  if (x < 0.0 || l <= 0.0 || delta < 0.0) return 1.0;  // cdfchn status != 0
+  double p, q;
+  noncentral_chisq_tails(x, l, delta, &p, &q);
+  return q;
+}
+
+// MixtureChiSquare::getPvalue        (regression/MixtureChiSquare.cpp:7-29)
+RVT_HD double davies_pvalue(const double* lambda, const int* th, int n, double Q, int* fault_out,
+                            double* nterms_out) {
+  if (nterms_out) *nterms_out = 0.0;
+  if (fault_out) *fault_out = 0;
+  if (n == 1) return liu_pvalue(lambda, n, Q);
+  int fault;
+  double p = 1.0 - davies_qf(lambda, th, n, Q, 10000, 0.000001, &fault, nterms_out);
+  if (p > 1.0) p = 1.0;
+  if (fault) p = -1.0;
+  if (fault_out) *fault_out = fault;
+  return p;
+}
+
+// indices of lb by decreasing |lb| (stable), as qfc.c:115-134 builds them
+RVT_HD void davies_order(const double* lb, int r, int* th) {
+  for (int j = 0; j < r; j++) {
+    const double lj = fabs(lb[j]);
+    int k = j - 1;
+    for (; k >= 0; k--) {
+      if (lj > fabs(lb[th[k]]))
+        th[k + 1] = th[k];
+      else
+        break;
+    }
+    th[k + 1] = j;
+  }
+}
+
+}  // namespace rvt

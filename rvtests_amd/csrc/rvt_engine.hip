@@ -1,0 +1,734 @@
+// rvtests_amd — the engine behind include/rvtests_amd.h: device memory, the per-batch kernel pipeline
+// and the C ABI.  Built by hipcc for gfx950 into librvtests_amd.so.  There is no CPU fallback: without a
+// HIP device rvt_init() fails with RVT_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "kernels.hip.h"
+
+using namespace rvt;
+
+namespace {
+
+constexpr int kMaxMT = 6;  // widest single-pass tile configuration instantiated below
+
+struct Arena {  // grow-only bump allocator over one device allocation
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  void reset() { off = 0; }
+  void* take(size_t bytes, size_t align = 256) {
+    off = (off + align - 1) / align * align;
+    void* p = base + off;
+    off += bytes;
+    return p;
+  }
+};
+
+struct ProfEvent {
+  int family;  // 0 suffstat, 1 burden, 2 stats, 3 pvalue
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rvt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // null model
+  bool have_null = false;
+  NullConsts nc;
+  NullConsts* d_nc = nullptr;
+  double *d_X = nullptr, *d_res = nullptr, *d_rr = nullptr, *d_v = nullptr, *d_zeros = nullptr;
+  int64_t null_ld = 0;
+  // workspace
+  Arena arena;
+  // pinned host staging
+  char* h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  // in-flight batch
+  rvt_gene_result* pending_out = nullptr;
+  rvt_gene_result* d_results = nullptr;
+  int pending_n = 0;
+  // streaming interface
+  struct Pending {
+    int64_t id;
+    int M;
+    double* dG;
+    std::vector<double> af;
+    uint32_t tests;
+    rvt_params prm;
+  };
+  std::vector<Pending> queue;
+  std::vector<double*> block_pool;  // not pooled by size in round 1
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEvent> events;
+  std::vector<hipEvent_t> event_pool;
+  rvt_timing timing;
+};
+
+namespace {
+
+int fail(rvt_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return fail(ctx, RVT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure_arena(rvt_ctx* c, size_t bytes) {
+  if (c->arena.cap >= bytes) return RVT_OK;
+  if (c->arena.base) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(c->arena.base));
+    c->arena.base = nullptr;
+    c->arena.cap = 0;
+  }
+  const size_t want = bytes + bytes / 4;
+  HIP_TRY(c, hipMalloc((void**)&c->arena.base, want));
+  c->arena.cap = want;
+  return RVT_OK;
+}
+
+int ensure_stage(rvt_ctx* c, size_t bytes) {
+  if (c->h_stage_cap >= bytes) return RVT_OK;
+  if (c->h_stage) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+  }
+  const size_t want = bytes * 2;
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault));
+  c->h_stage_cap = want;
+  return RVT_OK;
+}
+
+hipEvent_t get_event(rvt_ctx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct Scope {  // times one kernel launch with HIP events on the engine's stream when profiling is on
+  rvt_ctx* c;
+  int fam;
+  hipEvent_t a = nullptr;
+  Scope(rvt_ctx* c_, int fam_) : c(c_), fam(fam_) {
+    if (c->profiling) {
+      a = get_event(c);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~Scope() {
+    if (c->profiling) {
+      hipEvent_t b = get_event(c);
+      hipEventRecord(b, c->stream);
+      c->events.push_back({fam, a, b});
+    }
+  }
+};
+
+void drain_events(rvt_ctx* c) {
+  for (auto& e : c->events) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e.a, e.b);
+    switch (e.family) {
+      case 0: c->timing.ms_suffstat += ms; c->timing.n_suffstat_launches++; break;
+      case 1: c->timing.ms_burden += ms; c->timing.n_burden_launches++; break;
+      case 2: c->timing.ms_stats += ms; c->timing.n_stats_launches++; break;
+      default: c->timing.ms_pvalue += ms; c->timing.n_pvalue_launches++; break;
+    }
+    c->event_pool.push_back(e.a);
+    c->event_pool.push_back(e.b);
+  }
+  c->events.clear();
+}
+
+template <int MT, int CT>
+void launch_suffstat(rvt_ctx* c, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
+  dim3 grid((max_wparts + 3) / 4, n), block(256);
+  if (c->nc.binary)
+    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, true>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
+                       (long long)c->nc.ld, c->nc.d);
+  else
+    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, false>), grid, block, 0, c->stream, d_desc, nd,
+                       (long long)c->nc.N, (long long)c->nc.ld, c->nc.d);
+}
+
+void launch_suffstat_class(rvt_ctx* c, int MT, int CT, const GeneDesc* d_desc, int n, int max_wparts,
+                           const NullDev& nd) {
+  Scope sc(c, 0);
+#define RVT_CASE(mt, ct) \
+  if (MT == mt && CT == ct) return launch_suffstat<mt, ct>(c, d_desc, n, max_wparts, nd)
+  RVT_CASE(1, 1);
+  RVT_CASE(1, 2);
+  RVT_CASE(2, 2);
+  RVT_CASE(2, 3);
+  RVT_CASE(3, 3);
+  RVT_CASE(3, 4);
+  RVT_CASE(4, 4);
+  RVT_CASE(4, 5);
+  RVT_CASE(5, 5);
+  RVT_CASE(5, 6);
+  RVT_CASE(6, 6);
+  RVT_CASE(6, 7);
+#undef RVT_CASE
+}
+
+// 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
+// that a gene still spreads over >= 32..128 waves
+void choose_split(int64_t ld, int* n_wparts, int* steps_per) {
+  const int64_t nsteps = ld >> 4;
+  int64_t spw = (nsteps + 127) / 128;
+  if (spw < 64) spw = 64;
+  int64_t nw = (nsteps + spw - 1) / spw;
+  if (nw < 1) nw = 1;
+  *n_wparts = (int)nw;
+  *steps_per = (int)spw;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rvt_version(void) { return "rvtests_amd 0.1 (gfx950)"; }
+int64_t rvt_padded_ld(int64_t N) { return (N + 15) / 16 * 16; }
+const char* rvt_last_error(const rvt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void* rvt_stream(rvt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rvt_init(rvt_ctx** out, int device_id) {
+  if (!out) return RVT_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RVT_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return RVT_E_INVALID;
+  if (hipSetDevice(device_id) != hipSuccess) return RVT_E_NO_DEVICE;
+  rvt_ctx* c = new rvt_ctx();
+  c->device = device_id;
+  std::memset(&c->timing, 0, sizeof(c->timing));
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RVT_E_HIP;
+  }
+  if (hipMalloc((void**)&c->d_nc, sizeof(NullConsts)) != hipSuccess) {
+    hipStreamDestroy(c->stream);
+    delete c;
+    return RVT_E_HIP;
+  }
+  *out = c;
+  return RVT_OK;
+}
+
+static void free_null(rvt_ctx* c) {
+  for (double** p : {&c->d_X, &c->d_res, &c->d_rr, &c->d_v, &c->d_zeros}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  c->have_null = false;
+}
+
+void rvt_destroy(rvt_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  drain_events(c);
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  free_null(c);
+  for (auto& p : c->queue)
+    if (p.dG) hipFree(p.dG);
+  if (c->arena.base) hipFree(c->arena.base);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_nc) hipFree(c->d_nc);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const double* res, const double* v,
+                 double sigma2) {
+  if (!c || !X || !res || !v || N < 1 || d < 1 || d > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad null model");
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_null(c);
+  const int64_t ld = rvt_padded_ld(N);
+  NullConsts& nc = c->nc;
+  std::memset(&nc, 0, sizeof(nc));
+  nc.N = N;
+  nc.ld = ld;
+  nc.d = d;
+  nc.binary = (trait == RVT_TRAIT_BINARY) ? 1 : 0;
+  nc.sigma2 = nc.binary ? 1.0 : sigma2;
+  // d x d cross-products of the null model (once per analysis; X'VX for a binary trait, X'X otherwise)
+  double rss = 0, rsum = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    rss += res[i] * res[i];
+    rsum += res[i];
+  }
+  nc.rss = rss;
+  nc.rsum = rsum;
+  for (int a = 0; a < d; ++a)
+    for (int b = a; b < d; ++b) {
+      double s = 0;
+      const double *xa = X + (size_t)a * N, *xb = X + (size_t)b * N;
+      if (nc.binary)
+        for (int64_t i = 0; i < N; ++i) s += xa[i] * v[i] * xb[i];
+      else
+        for (int64_t i = 0; i < N; ++i) s += xa[i] * xb[i];
+      nc.C[a * d + b] = nc.C[b * d + a] = s;
+    }
+  {  // inverse by Gauss-Jordan with partial pivoting (d <= 16)
+    double A[RVT_MAX_COV][2 * RVT_MAX_COV];
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) {
+        A[i][j] = nc.C[i * d + j];
+        A[i][d + j] = (i == j) ? 1.0 : 0.0;
+      }
+    for (int k = 0; k < d; ++k) {
+      int piv = k;
+      for (int i = k + 1; i < d; ++i)
+        if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+      if (A[piv][k] == 0.0) return fail(c, RVT_E_INVALID, "X'VX is singular");
+      if (piv != k)
+        for (int j = 0; j < 2 * d; ++j) std::swap(A[k][j], A[piv][j]);
+      const double pv = A[k][k];
+      for (int j = 0; j < 2 * d; ++j) A[k][j] /= pv;
+      for (int i = 0; i < d; ++i)
+        if (i != k) {
+          const double f = A[i][k];
+          if (f != 0.0)
+            for (int j = 0; j < 2 * d; ++j) A[i][j] -= f * A[k][j];
+        }
+    }
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) nc.Cinv[i * d + j] = A[i][d + j];
+  }
+  // device copies, padded with zeros
+  const size_t vb = sizeof(double) * (size_t)ld;
+  HIP_TRY(c, hipMalloc((void**)&c->d_X, vb * d));
+  HIP_TRY(c, hipMalloc((void**)&c->d_res, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_rr, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_v, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_zeros, vb));
+  HIP_TRY(c, hipMemset(c->d_X, 0, vb * d));
+  HIP_TRY(c, hipMemset(c->d_res, 0, vb));
+  HIP_TRY(c, hipMemset(c->d_rr, 0, vb));
+  HIP_TRY(c, hipMemset(c->d_v, 0, vb));
+  HIP_TRY(c, hipMemset(c->d_zeros, 0, vb));
+  HIP_TRY(c, hipMemcpy2D(c->d_X, vb, X, sizeof(double) * (size_t)N, sizeof(double) * (size_t)N, d,
+                         hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_res, res, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_v, v, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  {
+    std::vector<double> rr((size_t)N);
+    if (nc.binary)
+      for (int64_t i = 0; i < N; ++i) rr[i] = res[i] / v[i];
+    else
+      for (int64_t i = 0; i < N; ++i) rr[i] = res[i];
+    HIP_TRY(c, hipMemcpy(c->d_rr, rr.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(c, hipMemcpy(c->d_nc, &nc, sizeof(nc), hipMemcpyHostToDevice));
+  c->null_ld = ld;
+  c->have_null = true;
+  return RVT_OK;
+}
+
+int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
+  if (!c || !out || M < 1) return fail(c, RVT_E_INVALID, "bad block");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first (defines N)");
+  hipSetDevice(c->device);
+  const size_t bytes = sizeof(double) * (size_t)c->null_ld * M;
+  HIP_TRY(c, hipMalloc((void**)out, bytes));
+  HIP_TRY(c, hipMemset(*out, 0, bytes));
+  return RVT_OK;
+}
+
+int rvt_block_free(rvt_ctx* c, double* dG) {
+  if (!c) return RVT_E_INVALID;
+  hipSetDevice(c->device);
+  if (dG) HIP_TRY(c, hipFree(dG));
+  return RVT_OK;
+}
+
+int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
+  if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first");
+  hipSetDevice(c->device);
+  const size_t N = (size_t)c->nc.N;
+  HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * (size_t)c->null_ld, G, sizeof(double) * N, sizeof(double) * N, M,
+                         hipMemcpyHostToDevice));
+  return RVT_OK;
+}
+
+int rvt_set_profiling(rvt_ctx* c, int on) {
+  if (!c) return RVT_E_INVALID;
+  c->profiling = on != 0;
+  return RVT_OK;
+}
+
+int rvt_get_timing(rvt_ctx* c, rvt_timing* t, int reset) {
+  if (!c || !t) return RVT_E_INVALID;
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  *t = c->timing;
+  if (reset) std::memset(&c->timing, 0, sizeof(c->timing));
+  return RVT_OK;
+}
+
+struct DebugOut {
+  int* flip = nullptr;
+  int* kept = nullptr;
+  double* cmc = nullptr;
+  double* zeg = nullptr;
+  double** parts_out = nullptr;  // device pointers of gene 0's partials etc.
+  GeneDesc* desc0 = nullptr;
+};
+
+static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
+                     const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
+                     DebugOut* dbg) {
+  if (!c || n < 0 || (n > 0 && (!dG || !Ms || !af || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (n == 0) return RVT_OK;
+  hipSetDevice(c->device);
+  if (c->pending_out) {  // one batch in flight at a time
+    int rc = rvt_sync(c);
+    if (rc) return rc;
+  }
+  rvt_params params;
+  if (prm)
+    params = *prm;
+  else
+    params = rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+  const NullConsts& nc = c->nc;
+  const int d = nc.d;
+  const int64_t ld = nc.ld, N = nc.N, nsteps = ld >> 4;
+  const int n_bparts = (int)((N + kBurdenSPB - 1) / kBurdenSPB);
+  int n_wparts, steps_per;
+  choose_split(ld, &n_wparts, &steps_per);
+  // ---- sizes ---------------------------------------------------------------------------------------
+  std::vector<GeneDesc> desc(n);
+  size_t total = 0, af_total = 0;
+  auto add = [&](size_t bytes) {
+    total = (total + 255) / 256 * 256;
+    const size_t o = total;
+    total += bytes;
+    return o;
+  };
+  struct Off {
+    size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, af, stats, dbg_flip, dbg_kept;
+  };
+  std::vector<Off> offs(n);
+  int maxM = 0;
+  for (int g = 0; g < n; ++g) {
+    const int M = Ms[g];
+    if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
+    const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16;
+    if (MT > kMaxMT) return fail(c, RVT_E_TOO_LARGE, "gene %d: M=%d exceeds the single-pass limit %d", g, M, kMaxMT * 16);
+    maxM = std::max(maxM, M);
+    GeneDesc& gd = desc[g];
+    std::memset(&gd, 0, sizeof(gd));
+    gd.G = dG[g];
+    gd.M = M;
+    gd.MT = MT;
+    gd.CT = CT;
+    gd.Mp = 16 * MT;
+    gd.Cp = 16 * CT;
+    gd.n_wparts = n_wparts;
+    gd.steps_per_wpart = steps_per;
+    gd.gene_id = ids ? ids[g] : g;
+    Off& o = offs[g];
+    o.parts = add(sizeof(double) * (size_t)n_wparts * gd.Mp * gd.Cp);
+    o.colstat = add(sizeof(double) * (size_t)n_wparts * 3 * gd.Mp);
+    o.masks = add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
+    o.flags = add(sizeof(unsigned short) * 2 * MT);
+    o.bparts = add(sizeof(double) * (size_t)n_bparts * 2 * (3 + d));
+    o.scratch = add(sizeof(double) * (gene_scratch_doubles(gd.Mp, gd.Cp) + 8));
+    o.lambda = add(sizeof(double) * 2 * M);
+    o.qags = add(qags_workspace_bytes(kSkatoLimit));
+    o.af = add(sizeof(double) * M);
+    o.stats = add(sizeof(GeneStats));
+    if (dbg) {
+      o.dbg_flip = add(sizeof(int) * M);
+      o.dbg_kept = add(sizeof(int) * M);
+    }
+    af_total += M;
+  }
+  const size_t off_desc = add(sizeof(GeneDesc) * n);
+  const size_t off_res = add(sizeof(rvt_gene_result) * n);
+  size_t off_dbg_cmc = 0, off_dbg_zeg = 0;
+  if (dbg && dbg->cmc) {
+    off_dbg_cmc = add(sizeof(double) * N);
+    off_dbg_zeg = add(sizeof(double) * N);
+  }
+  int rc = ensure_arena(c, total + 4096);
+  if (rc) return rc;
+  char* base = c->arena.base;
+  // ---- host staging: descriptors + af ------------------------------------------------------------------
+  const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
+  rc = ensure_stage(c, stage_bytes);
+  if (rc) return rc;
+  GeneDesc* h_desc = reinterpret_cast<GeneDesc*>(c->h_stage);
+  double* h_af = reinterpret_cast<double*>(c->h_stage + sizeof(GeneDesc) * n);
+  size_t afpos = 0;
+  for (int g = 0; g < n; ++g) {
+    GeneDesc& gd = desc[g];
+    const Off& o = offs[g];
+    gd.parts = reinterpret_cast<double*>(base + o.parts);
+    gd.colstat = reinterpret_cast<double*>(base + o.colstat);
+    gd.masks = reinterpret_cast<unsigned long long*>(base + o.masks);
+    gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
+    gd.bparts = reinterpret_cast<double*>(base + o.bparts);
+    gd.scratch = reinterpret_cast<double*>(base + o.scratch);
+    gd.lambda = reinterpret_cast<double*>(base + o.lambda);
+    gd.qags_mem = base + o.qags;
+    gd.af = reinterpret_cast<const double*>(base + o.af);
+    gd.stats = reinterpret_cast<GeneStats*>(base + o.stats);
+    gd.result = reinterpret_cast<rvt_gene_result*>(base + off_res) + g;
+    if (dbg) {
+      gd.dbg_flip = reinterpret_cast<int*>(base + o.dbg_flip);
+      gd.dbg_kept = reinterpret_cast<int*>(base + o.dbg_kept);
+      if (dbg->cmc && g == 0) {
+        gd.dbg_cmc = reinterpret_cast<double*>(base + off_dbg_cmc);
+        gd.dbg_zeg = reinterpret_cast<double*>(base + off_dbg_zeg);
+      }
+    }
+    std::memcpy(h_af + afpos, af + afpos, sizeof(double) * gd.M);
+    HIP_TRY(c, hipMemcpyAsync(base + o.af, h_af + afpos, sizeof(double) * gd.M, hipMemcpyHostToDevice, c->stream));
+    afpos += gd.M;
+  }
+  // order genes by tile class so each class is one launch; descriptors are stored class-sorted, the
+  // result slot keeps the submission index
+  std::vector<int> order(n);
+  for (int g = 0; g < n; ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (desc[a].MT != desc[b].MT) return desc[a].MT < desc[b].MT;
+    return desc[a].CT < desc[b].CT;
+  });
+  for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
+  GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
+  HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, c->stream));
+  NullDev nd{c->d_X, c->d_res, c->d_rr, c->d_v, c->d_zeros};
+  // ---- K2 per tile class --------------------------------------------------------------------------------
+  for (int k = 0; k < n;) {
+    int e = k;
+    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].CT == h_desc[k].CT) ++e;
+    launch_suffstat_class(c, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
+    k = e;
+  }
+  const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
+  if (burden || dbg) {
+    {
+      Scope sc(c, 1);
+      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, c->stream, d_desc, (long long)N);
+    }
+    // gene groups of <= 64 per launch keep one block's loop short while X/res/v stay in registers
+    for (int k = 0; k < n; k += 64) {
+      const int cnt = std::min(64, n - k);
+      Scope sc(c, 1);
+      if (d <= 4)
+        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, c->stream, d_desc + k, cnt, nd,
+                           (long long)N, (long long)ld, d, nc.binary, tests);
+      else
+        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, c->stream,
+                           d_desc + k, cnt, nd, (long long)N, (long long)ld, d, nc.binary, tests);
+    }
+  }
+  {
+    Scope sc(c, 2);
+    hipLaunchKernelGGL(gene_stats_kernel, dim3(n), dim3(256), 0, c->stream, d_desc, c->d_nc, params,
+                       burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI)), n_bparts);
+  }
+  {
+    Scope sc(c, 3);
+    const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 + 16;
+    hipLaunchKernelGGL(gene_pvalue_kernel, dim3(n), dim3(64), smem, c->stream, d_desc, tests);
+  }
+  HIP_TRY(c, hipGetLastError());
+  rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(c->h_stage + sizeof(GeneDesc) * n +
+                                                               (sizeof(double) * af_total + 63) / 64 * 64);
+  HIP_TRY(c, hipMemcpyAsync(h_res, base + off_res, sizeof(rvt_gene_result) * n, hipMemcpyDeviceToHost, c->stream));
+  c->pending_out = out;
+  c->d_results = h_res;
+  c->pending_n = n;
+  if (c->profiling) {
+    c->timing.genes += n;
+    for (int g = 0; g < n; ++g) {
+      c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
+      c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
+    }
+  }
+  if (dbg) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const GeneDesc& g0 = desc[0];
+    if (dbg->flip) HIP_TRY(c, hipMemcpy(dbg->flip, g0.dbg_flip, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
+    if (dbg->kept) HIP_TRY(c, hipMemcpy(dbg->kept, g0.dbg_kept, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
+    if (dbg->cmc) HIP_TRY(c, hipMemcpy(dbg->cmc, g0.dbg_cmc, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (dbg->zeg) HIP_TRY(c, hipMemcpy(dbg->zeg, g0.dbg_zeg, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (dbg->desc0) *dbg->desc0 = g0;
+  }
+  return RVT_OK;
+}
+
+int rvt_sync(rvt_ctx* c) {
+  if (!c) return RVT_E_INVALID;
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pending_out) {
+    std::memcpy(c->pending_out, c->d_results, sizeof(rvt_gene_result) * c->pending_n);
+    c->pending_out = nullptr;
+    c->pending_n = 0;
+  }
+  return RVT_OK;
+}
+
+int rvt_run_blocks_async(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
+                         const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  return run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
+}
+
+int rvt_run_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af, const int64_t* ids,
+                   uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  int rc = run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
+  if (rc) return rc;
+  return rvt_sync(c);
+}
+
+int rvt_debug_collapse(rvt_ctx* c, const double* dG, int M, double* cmc_out, double* zeg_out, int* flipped_out,
+                       int* kept_out) {
+  if (!c || !dG || !cmc_out || !zeg_out) return fail(c, RVT_E_INVALID, "bad arguments");
+  std::vector<double> af(M, 0.01);
+  rvt_gene_result r;
+  DebugOut dbg;
+  dbg.flip = flipped_out;
+  dbg.kept = kept_out;
+  dbg.cmc = cmc_out;
+  dbg.zeg = zeg_out;
+  const double* p = dG;
+  int rc = run_batch(c, 1, &p, &M, af.data(), nullptr, RVT_TEST_ALL, nullptr, &r, &dbg);
+  if (rc) return rc;
+  return rvt_sync(c);
+}
+
+int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T, double* u, double* colsum,
+                       double* cmin, double* cmax) {
+  if (!c || !dG) return fail(c, RVT_E_INVALID, "bad arguments");
+  std::vector<double> af(M, 0.01);
+  rvt_gene_result r;
+  DebugOut dbg;
+  GeneDesc g0;
+  dbg.desc0 = &g0;
+  const double* p = dG;
+  int rc = run_batch(c, 1, &p, &M, af.data(), nullptr, RVT_TEST_SKAT, nullptr, &r, &dbg);
+  if (rc) return rc;
+  rc = rvt_sync(c);
+  if (rc) return rc;
+  const int d = c->nc.d;
+  const size_t psz = (size_t)g0.Mp * g0.Cp;
+  std::vector<double> parts((size_t)g0.n_wparts * psz), cs((size_t)g0.n_wparts * 3 * g0.Mp);
+  HIP_TRY(c, hipMemcpy(parts.data(), g0.parts, sizeof(double) * parts.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(cs.data(), g0.colstat, sizeof(double) * cs.size(), hipMemcpyDeviceToHost));
+  auto R = [&](int i, int j) {
+    if ((j >> 4) < (i >> 4)) std::swap(i, j);
+    double s = 0;
+    for (int p2 = 0; p2 < g0.n_wparts; ++p2) s += parts[(size_t)p2 * psz + (size_t)i * g0.Cp + j];
+    return s;
+  };
+  for (int i = 0; i < M; ++i) {
+    if (S)
+      for (int j = 0; j < M; ++j) S[(size_t)i * M + j] = R(i, j);
+    if (T)
+      for (int k = 0; k < d; ++k) T[(size_t)i * d + k] = R(i, M + k);
+    if (u) u[i] = R(i, M + d);
+    double s = 0, mn = INFINITY, mx = -INFINITY;
+    for (int p2 = 0; p2 < g0.n_wparts; ++p2) {
+      const double* cc = cs.data() + (size_t)p2 * 3 * g0.Mp;
+      s += cc[i];
+      mn = std::min(mn, cc[g0.Mp + i]);
+      mx = std::max(mx, cc[2 * g0.Mp + i]);
+    }
+    if (colsum) colsum[i] = s;
+    if (cmin) cmin[i] = mn;
+    if (cmax) cmax[i] = mx;
+  }
+  return RVT_OK;
+}
+
+// ---- streaming interface --------------------------------------------------------------------------------
+int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                    const rvt_params* prm) {
+  if (!c || !G || !af || M < 1) return fail(c, RVT_E_INVALID, "bad gene");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  rvt_ctx::Pending p;
+  p.id = gene_id;
+  p.M = M;
+  p.dG = nullptr;
+  int rc = rvt_block_alloc(c, M, &p.dG);
+  if (rc) return rc;
+  rc = rvt_block_upload(c, p.dG, M, G);  // synchronous copy: the caller may overwrite G on return
+  if (rc) {
+    hipFree(p.dG);
+    return rc;
+  }
+  p.af.assign(af, af + M);
+  p.tests = tests;
+  p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+  c->queue.push_back(std::move(p));
+  return RVT_OK;
+}
+
+int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
+  if (!c || !out || !n_out) return RVT_E_INVALID;
+  *n_out = 0;
+  const int n = (int)std::min<size_t>(c->queue.size(), (size_t)cap);
+  if (n == 0) return RVT_OK;
+  // genes are grouped by (tests, params) runs in submission order
+  int done = 0;
+  while (done < n) {
+    int e = done + 1;
+    while (e < n && c->queue[e].tests == c->queue[done].tests &&
+           std::memcmp(&c->queue[e].prm, &c->queue[done].prm, sizeof(rvt_params)) == 0)
+      ++e;
+    std::vector<const double*> ptrs;
+    std::vector<int> Ms;
+    std::vector<double> af;
+    std::vector<int64_t> ids;
+    for (int g = done; g < e; ++g) {
+      ptrs.push_back(c->queue[g].dG);
+      Ms.push_back(c->queue[g].M);
+      ids.push_back(c->queue[g].id);
+      af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
+    }
+    int rc = rvt_run_blocks(c, e - done, ptrs.data(), Ms.data(), af.data(), ids.data(), c->queue[done].tests,
+                            &c->queue[done].prm, out + done);
+    if (rc) return rc;
+    done = e;
+  }
+  for (int g = 0; g < n; ++g) hipFree(c->queue[g].dG);
+  c->queue.erase(c->queue.begin(), c->queue.begin() + n);
+  *n_out = n;
+  return RVT_OK;
+}
+
+}  // extern "C"

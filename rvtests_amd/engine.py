@@ -1,0 +1,270 @@
+"""ctypes binding of include/rvtests_amd.h (the C ABI of librvtests_amd.so).
+
+Every call goes through the C ABI; numpy/torch are used only to hold host arrays and device pointers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBNAME = "librvtests_amd.so"
+
+TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL = 1, 2, 4, 8, 15
+TRAIT_QUANTITATIVE, TRAIT_BINARY = 0, 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class RvtError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("skat_beta1", C.c_double), ("skat_beta2", C.c_double), ("skato_beta1", C.c_double),
+                ("skato_beta2", C.c_double), ("skat_nperm", C.c_int), ("skat_alpha", C.c_double)]
+
+    @staticmethod
+    def default():
+        return Params(1.0, 25.0, 1.0, 25.0, 0, 0.05)
+
+
+class GeneResult(C.Structure):
+    _fields_ = [
+        ("gene_id", C.c_int64), ("status", C.c_uint32), ("n_variants", C.c_int), ("n_poly", C.c_int),
+        ("skat_ok", C.c_int), ("skat_Q", C.c_double), ("skat_p", C.c_double), ("skat_nlambda", C.c_int),
+        ("skato_ok", C.c_int), ("skato_Q", C.c_double), ("skato_rho", C.c_double), ("skato_p", C.c_double),
+        ("skato_qags_status", C.c_int), ("skato_qags_neval", C.c_int),
+        ("cmc_ok", C.c_int), ("cmc_nonref", C.c_int), ("cmc_U", C.c_double), ("cmc_V", C.c_double),
+        ("cmc_stat", C.c_double), ("cmc_p", C.c_double),
+        ("zeg_ok", C.c_int), ("zeg_U", C.c_double), ("zeg_V", C.c_double), ("zeg_stat", C.c_double),
+        ("zeg_p", C.c_double), ("davies_terms", C.c_double),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_suffstat", C.c_double), ("ms_burden", C.c_double), ("ms_stats", C.c_double),
+                ("ms_pvalue", C.c_double), ("n_suffstat_launches", C.c_int64), ("n_burden_launches", C.c_int64),
+                ("n_stats_launches", C.c_int64), ("n_pvalue_launches", C.c_int64), ("genes", C.c_int64),
+                ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
+
+
+def library_path():
+    return os.path.join(CSRC, LIBNAME)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/rvt_engine.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = library_path()
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
+    if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
+        return out
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", out, os.path.join(CSRC, "rvt_engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+_lib = None
+
+
+def load_library():
+    """Load librvtests_amd.so; raises RvtError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RvtError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the engine has no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.rvt_version.restype = C.c_char_p
+    L.rvt_last_error.restype = C.c_char_p
+    L.rvt_last_error.argtypes = [vp]
+    L.rvt_padded_ld.restype = C.c_int64
+    L.rvt_padded_ld.argtypes = [C.c_int64]
+    L.rvt_init.restype = C.c_int
+    L.rvt_init.argtypes = [C.POINTER(vp), C.c_int]
+    L.rvt_destroy.restype = None
+    L.rvt_destroy.argtypes = [vp]
+    L.rvt_set_null.restype = C.c_int
+    L.rvt_set_null.argtypes = [vp, C.c_int, C.c_int64, C.c_int, c_double_p, c_double_p, c_double_p, C.c_double]
+    L.rvt_block_alloc.restype = C.c_int
+    L.rvt_block_alloc.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rvt_block_free.restype = C.c_int
+    L.rvt_block_free.argtypes = [vp, vp]
+    L.rvt_block_upload.restype = C.c_int
+    L.rvt_block_upload.argtypes = [vp, vp, C.c_int, c_double_p]
+    run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
+                C.POINTER(Params), C.POINTER(GeneResult)]
+    L.rvt_run_blocks.restype = C.c_int
+    L.rvt_run_blocks.argtypes = run_args
+    L.rvt_run_blocks_async.restype = C.c_int
+    L.rvt_run_blocks_async.argtypes = run_args
+    L.rvt_sync.restype = C.c_int
+    L.rvt_sync.argtypes = [vp]
+    L.rvt_submit_gene.restype = C.c_int
+    L.rvt_submit_gene.argtypes = [vp, C.c_int64, C.c_int, c_double_p, c_double_p, C.c_uint32, C.POINTER(Params)]
+    L.rvt_collect.restype = C.c_int
+    L.rvt_collect.argtypes = [vp, C.POINTER(GeneResult), C.c_int, c_int_p]
+    L.rvt_debug_collapse.restype = C.c_int
+    L.rvt_debug_collapse.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p]
+    L.rvt_debug_suffstat.restype = C.c_int
+    L.rvt_debug_suffstat.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                     c_double_p]
+    L.rvt_set_profiling.restype = C.c_int
+    L.rvt_set_profiling.argtypes = [vp, C.c_int]
+    L.rvt_get_timing.restype = C.c_int
+    L.rvt_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.rvt_stream.restype = vp
+    L.rvt_stream.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class Engine:
+    """One engine context = one GPU (one process per GPU)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.L.rvt_init(C.byref(self.ctx), int(device))
+        if rc != 0:
+            raise RvtError("rvt_init failed (%d): no usable HIP device — the engine has no CPU fallback" % rc)
+        self.N = None
+        self.d = None
+        self._blocks = []
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RvtError("rvtests_amd error %d: %s" % (rc, self.L.rvt_last_error(self.ctx).decode()))
+
+    def close(self):
+        if self.ctx:
+            for b in self._blocks:
+                self.L.rvt_block_free(self.ctx, b)
+            self._blocks = []
+            self.L.rvt_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- null model -----------------------------------------------------------------------------------
+    def set_null(self, trait, X, res, v, sigma2=1.0):
+        X = np.asfortranarray(X, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        N, d = X.shape
+        self._check(self.L.rvt_set_null(self.ctx, int(trait), N, d, _dp(X), _dp(res), _dp(v), float(sigma2)))
+        self.N, self.d = N, d
+
+    def padded_ld(self, N=None):
+        return int(self.L.rvt_padded_ld(int(self.N if N is None else N)))
+
+    # ---- blocks -----------------------------------------------------------------------------------------
+    def upload_block(self, G):
+        """Copy a host N x M matrix into a device block; returns the device pointer (int)."""
+        G = np.asfortranarray(G, dtype=np.float64)
+        N, M = G.shape
+        assert N == self.N
+        p = C.c_void_p()
+        self._check(self.L.rvt_block_alloc(self.ctx, M, C.byref(p)))
+        self._check(self.L.rvt_block_upload(self.ctx, p, M, _dp(G)))
+        self._blocks.append(p)
+        return p.value
+
+    def free_block(self, ptr):
+        self._check(self.L.rvt_block_free(self.ctx, C.c_void_p(ptr)))
+        self._blocks = [b for b in self._blocks if b.value != ptr]
+
+    # ---- batched run over device-resident blocks ---------------------------------------------------------
+    def _pack(self, ptrs, Ms, afs, ids):
+        n = len(ptrs)
+        arr_p = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+        arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
+        af = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64) for a in afs]))
+        assert af.size == int(arr_m.sum())
+        arr_id = np.ascontiguousarray(ids if ids is not None else np.arange(n), dtype=np.int64)
+        return n, arr_p, arr_m, af, arr_id
+
+    def run_blocks(self, ptrs, Ms, afs, tests=TEST_ALL, params=None, ids=None):
+        n, arr_p, arr_m, af, arr_id = self._pack(ptrs, Ms, afs, ids)
+        out = (GeneResult * n)()
+        prm = params or Params.default()
+        self._check(self.L.rvt_run_blocks(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p), _dp(af),
+                                          arr_id.ctypes.data_as(C.POINTER(C.c_int64)), int(tests), C.byref(prm), out))
+        return list(out)
+
+    def prepare(self, ptrs, Ms, afs, tests=TEST_ALL, params=None, ids=None):
+        """Pre-pack a batch so that repeated launches (bench) pay no Python packing cost."""
+        n, arr_p, arr_m, af, arr_id = self._pack(ptrs, Ms, afs, ids)
+        out = (GeneResult * n)()
+        prm = params or Params.default()
+        return dict(n=n, p=arr_p, m=arr_m, af=af, id=arr_id, out=out, prm=prm, tests=int(tests))
+
+    def launch(self, batch):
+        self._check(self.L.rvt_run_blocks_async(self.ctx, batch["n"], batch["p"], batch["m"].ctypes.data_as(c_int_p),
+                                                _dp(batch["af"]), batch["id"].ctypes.data_as(C.POINTER(C.c_int64)),
+                                                batch["tests"], C.byref(batch["prm"]), batch["out"]))
+
+    def sync(self):
+        self._check(self.L.rvt_sync(self.ctx))
+
+    # ---- streaming (ModelFitter-style) interface ----------------------------------------------------------
+    def submit_gene(self, gene_id, G, af, tests=TEST_ALL, params=None):
+        G = np.asfortranarray(G, dtype=np.float64)
+        af = np.ascontiguousarray(af, dtype=np.float64)
+        prm = params or Params.default()
+        self._check(self.L.rvt_submit_gene(self.ctx, int(gene_id), G.shape[1], _dp(G), _dp(af), int(tests),
+                                           C.byref(prm)))
+
+    def collect(self, cap=4096):
+        out = (GeneResult * cap)()
+        n = C.c_int(0)
+        self._check(self.L.rvt_collect(self.ctx, out, cap, C.byref(n)))
+        return list(out[: n.value])
+
+    # ---- inspection ------------------------------------------------------------------------------------------
+    def debug_collapse(self, ptr, M):
+        cmc = np.zeros(self.N)
+        zeg = np.zeros(self.N)
+        fl = np.zeros(M, dtype=np.int32)
+        kp = np.zeros(M, dtype=np.int32)
+        self._check(self.L.rvt_debug_collapse(self.ctx, C.c_void_p(int(ptr)), M, _dp(cmc), _dp(zeg),
+                                              fl.ctypes.data_as(c_int_p), kp.ctypes.data_as(c_int_p)))
+        return cmc, zeg, fl, kp
+
+    def debug_suffstat(self, ptr, M):
+        d = self.d
+        S = np.zeros((M, M))
+        T = np.zeros((M, d))
+        u = np.zeros(M)
+        cs = np.zeros(M)
+        mn = np.zeros(M)
+        mx = np.zeros(M)
+        self._check(self.L.rvt_debug_suffstat(self.ctx, C.c_void_p(int(ptr)), M, _dp(S), _dp(T), _dp(u), _dp(cs),
+                                              _dp(mn), _dp(mx)))
+        return S, T, u, cs, mn, mx
+
+    def set_profiling(self, on):
+        self._check(self.L.rvt_set_profiling(self.ctx, 1 if on else 0))
+
+    def timing(self, reset=False):
+        t = Timing()
+        self._check(self.L.rvt_get_timing(self.ctx, C.byref(t), 1 if reset else 0))
+        return t
