@@ -650,7 +650,7 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
   HIP_TRY(c, hipMemcpy(parts.data(), g0.parts, sizeof(double) * parts.size(), hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(cs.data(), g0.colstat, sizeof(double) * cs.size(), hipMemcpyDeviceToHost));
   auto R = [&](int i, int j) {
-    if ((j >> 4) < (i >> 4)) std::swap(i, j);
+    if (j < M && j < i) std::swap(i, j);  // the engine uses the upper triangle of G'DG
     double s = 0;
     for (int p2 = 0; p2 < g0.n_wparts; ++p2) s += parts[(size_t)p2 * psz + (size_t)i * g0.Cp + j];
     return s;

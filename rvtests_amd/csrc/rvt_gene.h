@@ -129,7 +129,7 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
   // symmetric completion of the G'DG block
   for (int idx = co.tid; idx < M * M; idx += co.nt) {
     const int i = idx / M, j = idx % M;
-    if ((j >> 4) < (i >> 4)) R[(size_t)i * ldr + j] = R[(size_t)j * ldr + i];
+    if (j < i) R[(size_t)i * ldr + j] = R[(size_t)j * ldr + i];  // lower triangle := upper (exact symmetry)
   }
   co.sync();
   // ---- 2. polymorphic columns ----------------------------------------------------------------------

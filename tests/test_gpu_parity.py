@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 
 REL = 1e-6
 ABS_P = 1e-14
+# SKAT-O reports 1 - (adaptive integral of ~800 Davies values): the reference's own result carries rounding
+# noise of a few hundred ulp of 1.0, so p-values below ~1e-7 only agree to that absolute level.
+ABS_SKATO = 5e-13
 
 
 def close(a, b, rel=REL, abs_=0.0):
@@ -75,7 +78,7 @@ def _check_gene(r, G, af, X, y, res, v, binary, d):
         assert r.skato_ok == 1
         assert close(r.skato_Q, o.Q, 1e-10)
         assert r.skato_rho == o.rho
-        assert close(r.skato_p, o.pvalue, REL, ABS_P), (r.skato_p, o.pvalue)
+        assert close(r.skato_p, o.pvalue, REL, ABS_SKATO), (r.skato_p, o.pvalue)
     else:
         assert r.skato_ok == 0
     if not (binary and d > 1):  # reference behaviour undefined there
