@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — gene-sets/sec of the kernel/burden hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (SKAT + SKAT-O + CMC + Zeggini, analytic p-values) over one batch of
+`--genes` synthetic genes that are ALREADY RESIDENT in HBM in the engine's boundary layout (fp64, column-major,
+leading dimension padded to 16 samples).  Workload = BASELINE.json configs[2] ("N=500k, M̄=50,
+--kernel skat,skato --burden cmc,zeggini"), the configuration the metric is quoted on: per GPU a shard of
+genes with M_g ~ Uniform{20..80}; genes shard across ranks with no data-path collective (weak scaling) — the
+only collectives are one broadcast of the null model and one gather of the per-gene result records per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the engine's stream around the
+fp64-MFMA sufficient-statistics kernel; `cpu_baseline` times the CPU oracle (literal SKAT-O + folded SKAT +
+CMC + Zeggini, reference release flags -O2 -msse2, 1 thread) on ONE gene of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import rvtests_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (≈6.3 TB/s achievable)
+
+
+def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi):
+    """Synthetic genotype blocks on the device (config 3 of SURVEY.md §8d): per-variant MAF ~ LogUniform(5e-4,
+    5e-2), g ~ Binomial(2, maf); 0.1 % of genotypes missing in 5 % of the genes and imputed to the column mean
+    exactly as DataConsolidator::imputeGenotypeToMean leaves them.  Returns blocks (M x ld tensors, i.e.
+    column-major N x M with leading dimension ld), Ms and counter allele frequencies."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    blocks, Ms, afs = [], [], []
+    for k in range(n_genes):
+        M = int(rng.integers(m_lo, m_hi + 1))
+        maf = torch.tensor(10 ** rng.uniform(np.log10(5e-4), np.log10(5e-2), M), device=dev, dtype=torch.float32)
+        G = torch.zeros((M, ld), dtype=torch.float64, device=dev)
+        for h in range(2):
+            u = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32)
+            G[:, :N] += (u < maf[:, None]).to(torch.float64)
+            del u
+        nsample = float(N)
+        if rng.random() < 0.05:
+            miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3
+            Gv = G[:, :N]
+            ac = torch.where(miss, torch.zeros_like(Gv), Gv).sum(1)                  # integer-valued
+            an = 2.0 * (~miss).sum(1).to(torch.float64)
+            mean = 2.0 * torch.floor(ac) / an
+            Gv[miss] = mean[:, None].expand(-1, N)[miss]
+            af = 0.5 * ac / nsample                                                   # GenotypeCounter::getAF
+            del miss
+        else:
+            af = 0.5 * G[:, :N].sum(1) / nsample
+        blocks.append(G)
+        Ms.append(M)
+        afs.append(af.cpu().numpy())
+    return blocks, Ms, afs
+
+
+def fit_null_qt(dev, N, seed):
+    """Quantitative null model y ~ 1 + c1 + c2 (plumbing: solved with torch in fp64 on the device)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    c = torch.randn((N, 2), generator=g, device=dev, dtype=torch.float64)
+    X = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float64), c], 1)
+    y = 0.3 * c[:, 0] - 0.2 * c[:, 1] + torch.randn(N, generator=g, device=dev, dtype=torch.float64)
+    beta = torch.linalg.solve(X.T @ X, X.T @ y)
+    res = y - X @ beta
+    sigma2 = float((res @ res) / N)
+    return X, y, res, sigma2
+
+
+def cpu_baseline(G_host, af, X, y, res, v, n_threads=1):
+    """Time the CPU oracle on one gene: SKAT (P0 folded; the literal N x N form cannot run at this N), literal
+    SKAT-O, CMC and Zeggini — the four ModelFitter::fit bodies of the workload."""
+    import orc
+    t0 = time.perf_counter()
+    orc.skat(G_host, af, X, res, v, 0)
+    orc.skato(G_host, af, X, res, v, 0)
+    orc.burden(G_host, X, y, 0, 0)
+    orc.burden(G_host, X, y, 0, 1)
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=500000)
+    ap.add_argument("--genes", type=int, default=64, help="genes per step per GPU")
+    ap.add_argument("--m-lo", type=int, default=20)
+    ap.add_argument("--m-hi", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tests", type=int, default=rvtests_amd.TEST_ALL)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    N = args.samples
+    eng = rvtests_amd.Engine(local_rank)
+    ld = eng.padded_ld(N)
+
+    # ---- null model: fitted on rank 0, broadcast (collective C1), installed on every rank ----------------
+    d = 3
+    pack = torch.empty((N, d + 2), dtype=torch.float64, device=dev)
+    sig = torch.zeros(1, dtype=torch.float64, device=dev)
+    if rank == 0:
+        X, y, res, sigma2 = fit_null_qt(dev, N, 20260002)
+        pack[:, :d] = X
+        pack[:, d] = res
+        pack[:, d + 1] = y
+        sig[0] = sigma2
+    if world > 1:
+        dist.broadcast(pack, 0)
+        dist.broadcast(sig, 0)
+    sigma2 = float(sig[0])
+    Xh = np.asfortranarray(pack[:, :d].cpu().numpy())
+    resh = pack[:, d].cpu().numpy().copy()
+    yh = pack[:, d + 1].cpu().numpy().copy()
+    vh = np.full(N, sigma2)
+    eng.set_null(rvtests_amd.TRAIT_QUANTITATIVE, Xh, resh, vh, sigma2)
+
+    # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
+    blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi)
+    torch.cuda.synchronize()
+    batch = eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = [torch.empty((args.genes, 4), dtype=torch.float64, device=dev) for _ in range(world)] if (
+        world > 1 and rank == 0) else None
+
+    def step():
+        eng.launch(batch)
+        eng.sync()
+        if world > 1:  # collective C2: per-gene statistics only
+            rec = torch.tensor([[r.skat_p, r.skato_p, r.cmc_p, r.zeg_p] for r in batch["out"]], dtype=torch.float64,
+                               device=dev)
+            dist.gather(rec, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.set_profiling(True)
+    eng.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing(reset=True)
+    eng.set_profiling(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+
+    if rank == 0:
+        total_genes = world * args.genes * args.steps
+        value = total_genes / elapsed
+        out0 = batch["out"]
+        ok = sum(1 for r in out0 if r.skat_ok and r.skato_ok)
+        # roofline of the sufficient-statistics kernel (the contraction over N): algorithmic bytes / measured time
+        ms_k2 = tm.ms_suffstat / max(tm.n_suffstat_launches, 1)
+        bytes_per_launch = tm.alg_bytes / max(tm.n_suffstat_launches, 1)
+        achieved = bytes_per_launch / (ms_k2 * 1e-3) / 1e9 if ms_k2 > 0 else 0.0
+        tot_ms = tm.ms_suffstat + tm.ms_burden + tm.ms_stats + tm.ms_pvalue
+        line = {
+            "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",
+            "value": value, "unit": "gene-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: N=%d, genes/step/GPU=%d, M~U{%d..%d}, quantitative trait, "
+                                   "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
+                                   "fp64 column-major blocks" % (N, args.genes, args.m_lo, args.m_hi),
+                       "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
+                       "parallelism": "gene-sharded x%d" % world, "genes_ok": ok},
+            "roofline": {"kernel": "gene_suffstat_mfma", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "tflops_fp64_mfma": (tm.alg_flops / max(tm.ms_suffstat, 1e-9)) / 1e9,
+                         "avg_launch_ms": ms_k2, "launches": int(tm.n_suffstat_launches)},
+            "kernel_time_share": {"suffstat_mfma": tm.ms_suffstat / tot_ms, "burden": tm.ms_burden / tot_ms,
+                                  "gene_stats": tm.ms_stats / tot_ms, "gene_pvalue": tm.ms_pvalue / tot_ms,
+                                  "device_ms_per_step": tot_ms / args.steps},
+            "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            k = int(np.argmin(np.abs(np.array(Ms) - 50)))
+            Gh = np.asfortranarray(blocks[k][:, :N].T.cpu().numpy())
+            t = cpu_baseline(Gh, afs[k], Xh, yh, resh, vh)
+            line["cpu_baseline"] = {"value": 1.0 / t, "unit": "gene-sets/s", "cores": 1, "kind": "port",
+                                    "sample": "1 gene of the batch (M=%d, N=%d): oracle folded SKAT + literal SKAT-O + "
+                                              "CMC + Zeggini, g++ -O2 -msse2, %.1f s" % (Ms[k], N, t)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
