@@ -25,6 +25,14 @@ double hc_davies_pvalue(const double* lam, int n, double Q, int* fault, double* 
   davies_order(lam, n, th.data());
   return davies_pvalue(lam, th.data(), n, Q, fault, nterms);
 }
+// same, replaying the c-independent searches from davies_prelude() (what the SKAT-O integrand does)
+double hc_davies_pvalue_cached(const double* lam, int n, double Q, int* fault, double* nterms) {
+  std::vector<int> th(n > 0 ? n : 1);
+  davies_order(lam, n, th.data());
+  DaviesPrelude pre;
+  davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre);
+  return davies_pvalue(lam, th.data(), n, Q, fault, nterms, &pre);
+}
 double hc_liu_pvalue(const double* lam, int n, double Q) { return liu_pvalue(lam, n, Q); }
 
 void hc_sym_eigvals(const double* Ain, int n, double* out) {
@@ -77,7 +85,7 @@ int hc_qags_builtin(int id, double alpha, double a, double b, double epsabs, dou
 int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum, const double* C,
             const double* Cinv, int M, const double* Rin, const double* colstat_in, const double* bstats,
             const double* af, const rvt_params* prm, unsigned tests, rvt_gene_result* out, int* flip_out,
-            int* kept_out, double* lambda_out /* 2*M or null */) {
+            int* kept_out, double* lambda_out /* 2*M or null */, double* dbg /* 64 or null */) {
   NullConsts nc;
   std::memset(&nc, 0, sizeof(nc));
   nc.N = N;
@@ -104,12 +112,30 @@ int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum,
   Coop co{0, 1, red.data()};
   GeneStats gs;
   std::memset(&gs, 0, sizeof(gs));
-  gene_stats(co, nc, M, Mp, Cp, parts.data(), 1, cs.data(), bstats, 1, af, *prm, tests, ws, &gs, lam.data(),
-             flip_out, kept_out);
+  gene_assemble(co, nc, M, Mp, Cp, parts.data(), 1, cs.data(), bstats, 1, af, *prm, tests, ws, &gs, flip_out,
+                kept_out);
+  std::vector<double> vec((size_t)8 * Mp + 8);
+  for (int k = 0; k < kNEigen; ++k)
+    gene_eigen(co, nc, k, M, Mp, tests, ws, ws.eig + (size_t)k * Mp * Mp, vec.data(), &gs, lam.data());
   std::vector<int> th1(M + 1), th2(M + 1);
   std::vector<char> qmem(qags_workspace_bytes(kSkatoLimit));
   gene_pvalue_serial(gs, lam.data(), tests, 0, th1.data(), th2.data(), qmem.data(), out);
   if (lambda_out) std::memcpy(lambda_out, lam.data(), sizeof(double) * 2 * M);
+  if (dbg) {
+    for (int i = 0; i < 11; ++i) {
+      dbg[i] = gs.Qs[i];
+      dbg[11 + i] = gs.mom_mu[i];
+      dbg[22 + i] = gs.mom_var[i];
+      dbg[33 + i] = gs.mom_df[i];
+      dbg[44 + i] = gs.tau[i];
+    }
+    dbg[55] = gs.muQ;
+    dbg[56] = gs.varQ;
+    dbg[57] = gs.varZeta;
+    dbg[58] = gs.df;
+    dbg[59] = gs.zimz_nlambda;
+    dbg[60] = gs.skat_nlambda;
+  }
   return 0;
 }
 

@@ -137,9 +137,7 @@ __device__ __forceinline__ void suffstat_load(const double* const (&colp)[CT], l
 }
 
 template <int MT, int CT, bool WEIGHTED>
-__global__ __launch_bounds__(256) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes, NullDev nd, long long N,
-                                                          long long ld, int d) {
-  const GeneDesc gd = genes[blockIdx.y];
+__device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev& nd, long long N, long long ld, int d) {
   const int lane = threadIdx.x & 63;
   const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wpart >= gd.n_wparts) return;
@@ -230,6 +228,36 @@ __global__ __launch_bounds__(256) void gene_suffstat_mfma(const GeneDesc* __rest
       cst[gd.Mp + c * 16 + lane] = mn;
       cst[2 * gd.Mp + c * 16 + lane] = mx;
     }
+  }
+}
+
+
+// One launch covers every gene of the batch: the tile configuration (MT row tiles x CT column tiles) is a
+// property of the gene, dispatched per workgroup.  Grid = (wave-parts / 4, genes).
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes, NullDev nd, long long N,
+                                                          long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  switch (gd.MT * 8 + gd.CT) {
+#define RVT_TILE_CASE(mt, ct) \
+  case mt * 8 + ct:           \
+    suffstat_body<mt, ct, WEIGHTED>(gd, nd, N, ld, d); \
+    break
+    RVT_TILE_CASE(1, 1);
+    RVT_TILE_CASE(1, 2);
+    RVT_TILE_CASE(2, 2);
+    RVT_TILE_CASE(2, 3);
+    RVT_TILE_CASE(3, 3);
+    RVT_TILE_CASE(3, 4);
+    RVT_TILE_CASE(4, 4);
+    RVT_TILE_CASE(4, 5);
+    RVT_TILE_CASE(5, 5);
+    RVT_TILE_CASE(5, 6);
+    RVT_TILE_CASE(6, 6);
+    RVT_TILE_CASE(6, 7);
+#undef RVT_TILE_CASE
+    default:
+      break;
   }
 }
 
@@ -354,11 +382,14 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 }
 
 // =====================================================================================================
-// K3: per-gene statistics, one 256-thread workgroup per gene.
+// K3a: per-gene assembly (reduce partials, flags, flip algebra, projection, weights, Q, tau, burden
+//      statistics), one 256-thread workgroup per gene.
+// K3b: one workgroup per (eigenproblem, gene): build the matrix in LDS, Householder tridiagonalisation,
+//      Sturm bisection, eigenvalue filter and moments.  13 eigenproblems per gene run concurrently.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void gene_stats_kernel(const GeneDesc* __restrict__ genes,
-                                                         const NullConsts* __restrict__ ncp, rvt_params prm,
-                                                         unsigned tests, int n_bparts) {
+__global__ __launch_bounds__(256) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
+                                                            const NullConsts* __restrict__ ncp, rvt_params prm,
+                                                            unsigned tests, int n_bparts) {
   __shared__ double red[64];
   __shared__ NullConsts nc;
   const GeneDesc gd = genes[blockIdx.x];
@@ -366,9 +397,24 @@ __global__ __launch_bounds__(256) void gene_stats_kernel(const GeneDesc* __restr
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  gene_stats(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
-             (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, n_bparts, gd.af, prm, tests, ws,
-             gd.stats, gd.lambda, gd.dbg_flip, gd.dbg_kept);
+  gene_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
+                (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, n_bparts, gd.af, prm, tests, ws,
+                gd.stats, gd.dbg_flip, gd.dbg_kept);
+}
+
+__global__ __launch_bounds__(256) void gene_eigen_kernel(const GeneDesc* __restrict__ genes,
+                                                         const NullConsts* __restrict__ ncp, unsigned tests,
+                                                         int lds_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double esm[];
+  __shared__ double red[64];
+  const GeneDesc gd = genes[blockIdx.y];
+  const int k = blockIdx.x;
+  Coop co{(int)threadIdx.x, (int)blockDim.x, red};
+  GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  const int m = gd.stats->n_poly;
+  double* vec = esm;  // 8 * Mp doubles
+  double* Bm = (8 * gd.Mp + m * m <= lds_doubles) ? esm + 8 * gd.Mp : ws.eig + (size_t)k * gd.Mp * gd.Mp;
+  gene_eigen(co, *ncp, k, gd.M, gd.Mp, tests, ws, Bm, vec, gd.stats, gd.lambda);
 }
 
 // =====================================================================================================
@@ -402,7 +448,7 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
   // ---- SKAT on lane 63 (runs concurrently with the per-rho work below) --------------------------------
   double skat_p = 0.0;
   const bool do_skat = (tests & RVT_TEST_SKAT) != 0;
-  const bool do_skato = (tests & RVT_TEST_SKATO) && gs.skato_ok;
+  const bool do_skato = (tests & RVT_TEST_SKATO) && skato_fit_ok(gs);
   double pv_rho = 1.0;
   SkatoMoment mo;
   mo.muQ = mo.varQ = mo.df = 1.0;
@@ -455,6 +501,9 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
     for (int i = 0; i < kNRho; ++i) qminp[i] = __shfl(qm_l, i, 64);
     SkatoIntegrand si;
     skato_fill_integrand(gs, qminp, lam_zimz, th_zimz, &si);
+    DaviesPrelude pre;  // every lane computes the same values; kept in registers
+    davies_prelude(lam_zimz, th_zimz, gs.zimz_nlambda, 10000, 0.000001, &pre);
+    si.pre = &pre;
     QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
     double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
     int neval = 0;

@@ -207,10 +207,75 @@ RVT_HD double dv_cfe(DaviesState& st, double x) {
   return pow(2.0, (sum1 / 4.0)) / (kDaviesPi * (axl * axl));
 }
 
+// ---- the part of qf() that does not depend on the evaluation point c ------------------------------------
+// SKAT-O evaluates qf() at ~10^3 points c against ONE coefficient set (every abscissa of every QAGS panel,
+// regression/SkatO.cpp:303-325).  In qfc.c:343-377 the moments, the first truncation search
+// findu(&utx, .5*acc) and — as long as no convergence factor has been added to sigsq — the two cutoff
+// searches ctff(acc1, &up) / ctff(acc1, &un) are functions of the coefficients only.  They are computed
+// once per coefficient set here and replayed by davies_qf(); the replay is value-for-value what qf()
+// would recompute, so results are unchanged.
+struct DaviesPrelude {
+  bool valid;        // false: not usable (degenerate coefficients or the search overran lim) -> full path
+  double sd, mean, lmax, lmin;
+  double utx;        // after findu(&utx, .5*acc)
+  int cnt_findu;     // errbd/truncation/cfe calls spent so far (qf's `count`)
+  double up, c_up;   // ctff(.5*acc, &up) with sigsq = 0
+  int cnt_up;
+  double un, c_un;   // ctff(.5*acc, &un) with sigsq = 0
+  int cnt_un;
+};
+
+RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P) {
+  DaviesState st;
+  st.lb = lb;
+  st.th = th;
+  st.r = r;
+  st.lim = lim;
+  st.c = 0.0;
+  st.count = 0;
+  st.over = false;
+  st.fail = false;
+  st.intl = st.ersm = 0.0;
+  st.sigsq = 0.0;
+  double sd = 0.0;
+  st.lmax = st.lmin = st.mean = 0.0;
+  for (int j = 0; j < r; j++) {
+    const double lj = lb[j];
+    sd = sd + (lj * lj) * 2.0;
+    st.mean = st.mean + lj;
+    if (st.lmax < lj)
+      st.lmax = lj;
+    else if (st.lmin > lj)
+      st.lmin = lj;
+  }
+  P->valid = false;
+  if (sd == 0.0 || (st.lmin == 0.0 && st.lmax == 0.0)) return;
+  sd = sqrt(sd);
+  P->sd = sd;
+  P->mean = st.mean;
+  P->lmax = st.lmax;
+  P->lmin = st.lmin;
+  double utx = 16.0 / sd, up = 4.5 / sd, un = -up;
+  dv_findu(st, &utx, .5 * acc);
+  P->utx = utx;
+  P->cnt_findu = st.count;
+  const double acc1 = 0.5 * acc;
+  P->c_up = dv_ctff(st, acc1, &up);
+  P->up = up;
+  P->cnt_up = st.count - P->cnt_findu;
+  const int before = st.count;
+  P->c_un = dv_ctff(st, acc1, &un);
+  P->un = un;
+  P->cnt_un = st.count - before;
+  P->valid = !st.over;
+}
+
 // P[ sum_j lb_j chi²_1 < c ]; *ifault as in the reference (0 ok, 1 accuracy, 2 round-off, 3 invalid,
 // 4 search overran lim).  nterms_out (optional) = number of integrand terms evaluated.
+// `pre` (optional) = davies_prelude() of the same coefficients: the c-independent searches are replayed.
 RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
-                        double* nterms_out) {
+                        double* nterms_out, const DaviesPrelude* pre = nullptr) {
+  if (pre && !pre->valid) pre = nullptr;
   DaviesState st;
   st.lb = lb;
   st.th = th;
@@ -256,27 +321,52 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
     utx = 16.0 / sd;
     up = 4.5 / sd;
     un = -up;
-    dv_findu(st, &utx, .5 * acc1);
+    if (pre) {
+      utx = pre->utx;
+      st.count = pre->cnt_findu;
+    } else {
+      dv_findu(st, &utx, .5 * acc1);
+    }
+    bool sig_changed = false;  // has a convergence factor been added to sigsq?
     if (c != 0.0 && (almx > 0.07 * sd)) {
       const double tausq = .25 * acc1 / dv_cfe(st, c);
       if (st.fail)
         st.fail = false;
       else if (dv_truncation(st, utx, tausq) < .2 * acc1) {
         st.sigsq = st.sigsq + tausq;
+        sig_changed = true;
         dv_findu(st, &utx, .25 * acc1);
       }
     }
     acc1 = 0.5 * acc1;
     bool to_main = false;
     while (!done && !to_main && !st.over) {
-      const double d1 = dv_ctff(st, acc1, &up) - c;
+      double cut_up, cut_un;
+      const bool replay = pre && !sig_changed;  // first pass, sigsq still 0, acc1 still .5*acc
+      if (replay) {
+        cut_up = pre->c_up;
+        up = pre->up;
+        st.count += pre->cnt_up;
+        if (st.count > st.lim) st.over = true;
+      } else {
+        cut_up = dv_ctff(st, acc1, &up);
+      }
+      const double d1 = cut_up - c;
       if (st.over) break;
       if (d1 < 0.0) {
         qfval = 1.0;
         done = true;
         break;
       }
-      const double d2 = c - dv_ctff(st, acc1, &un);
+      if (replay) {
+        cut_un = pre->c_un;
+        un = pre->un;
+        st.count += pre->cnt_un;
+        if (st.count > st.lim) st.over = true;
+      } else {
+        cut_un = dv_ctff(st, acc1, &un);
+      }
+      const double d2 = c - cut_un;
       if (st.over) break;
       if (d2 < 0.0) {
         qfval = 0.0;
@@ -311,6 +401,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
         nterms += ntm + 1;
         xlim = xlim - xntm;
         st.sigsq = st.sigsq + tausq;
+        sig_changed = true;
         dv_findu(st, &utx, .25 * acc1);
         acc1 = 0.75 * acc1;
         continue;
@@ -441,13 +532,19 @@ RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
 }
 
 // MixtureChiSquare::getPvalue        (regression/MixtureChiSquare.cpp:7-29)
+// All coefficients on the hot path are > 0 (Skat.cpp:92 keeps lambda > 1e-30, SkatO.cpp:365-374 keeps
+// lambda >= mean/1e5), so for Q < 0 the reference's qf() stops at "d2 < 0 -> qfval = 0" (or faults) and
+// getPvalue returns exactly 1 (or -1); every caller on the hot path then replaces that value by Liu's
+// (Skat.cpp:100-103, SkatO.cpp:318-321).  The search is therefore skipped for Q < 0 and 1.0 returned —
+// pinned against the compiled reference by tests/test_oracle_ref.py::test_negative_q_is_one_or_fault.
 RVT_HD double davies_pvalue(const double* lambda, const int* th, int n, double Q, int* fault_out,
-                            double* nterms_out) {
+                            double* nterms_out, const DaviesPrelude* pre = nullptr) {
   if (nterms_out) *nterms_out = 0.0;
   if (fault_out) *fault_out = 0;
   if (n == 1) return liu_pvalue(lambda, n, Q);
+  if (Q < 0.0) return 1.0;
   int fault;
-  double p = 1.0 - davies_qf(lambda, th, n, Q, 10000, 0.000001, &fault, nterms_out);
+  double p = 1.0 - davies_qf(lambda, th, n, Q, 10000, 0.000001, &fault, nterms_out, pre);
   if (p > 1.0) p = 1.0;
   if (fault) p = -1.0;
   if (fault_out) *fault_out = fault;

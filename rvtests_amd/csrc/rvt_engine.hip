@@ -71,6 +71,7 @@ struct rvt_ctx {
   std::vector<ProfEvent> events;
   std::vector<hipEvent_t> event_pool;
   rvt_timing timing;
+  size_t eigen_lds_max = 48 * 1024;
 };
 
 namespace {
@@ -166,35 +167,15 @@ void drain_events(rvt_ctx* c) {
   c->events.clear();
 }
 
-template <int MT, int CT>
 void launch_suffstat(rvt_ctx* c, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
+  Scope sc(c, 0);
   dim3 grid((max_wparts + 3) / 4, n), block(256);
   if (c->nc.binary)
-    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, true>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
+    hipLaunchKernelGGL((gene_suffstat_mfma<true>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
                        (long long)c->nc.ld, c->nc.d);
   else
-    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, false>), grid, block, 0, c->stream, d_desc, nd,
-                       (long long)c->nc.N, (long long)c->nc.ld, c->nc.d);
-}
-
-void launch_suffstat_class(rvt_ctx* c, int MT, int CT, const GeneDesc* d_desc, int n, int max_wparts,
-                           const NullDev& nd) {
-  Scope sc(c, 0);
-#define RVT_CASE(mt, ct) \
-  if (MT == mt && CT == ct) return launch_suffstat<mt, ct>(c, d_desc, n, max_wparts, nd)
-  RVT_CASE(1, 1);
-  RVT_CASE(1, 2);
-  RVT_CASE(2, 2);
-  RVT_CASE(2, 3);
-  RVT_CASE(3, 3);
-  RVT_CASE(3, 4);
-  RVT_CASE(4, 4);
-  RVT_CASE(4, 5);
-  RVT_CASE(5, 5);
-  RVT_CASE(5, 6);
-  RVT_CASE(6, 6);
-  RVT_CASE(6, 7);
-#undef RVT_CASE
+    hipLaunchKernelGGL((gene_suffstat_mfma<false>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
+                       (long long)c->nc.ld, c->nc.d);
 }
 
 // 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
@@ -236,6 +217,13 @@ int rvt_init(rvt_ctx** out, int device_id) {
     hipStreamDestroy(c->stream);
     delete c;
     return RVT_E_HIP;
+  }
+  {  // let the eigen kernel keep matrices up to ~120 x 120 doubles in LDS
+    const int want = 128 * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gene_eigen_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
+      c->eigen_lds_max = want;
+    (void)hipGetLastError();
   }
   *out = c;
   return RVT_OK;
@@ -518,25 +506,16 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     HIP_TRY(c, hipMemcpyAsync(base + o.af, h_af + afpos, sizeof(double) * gd.M, hipMemcpyHostToDevice, c->stream));
     afpos += gd.M;
   }
-  // order genes by tile class so each class is one launch; descriptors are stored class-sorted, the
-  // result slot keeps the submission index
+  // widest genes first: their workgroups run longest, so they should not be the tail of the launch
   std::vector<int> order(n);
   for (int g = 0; g < n; ++g) order[g] = g;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (desc[a].MT != desc[b].MT) return desc[a].MT < desc[b].MT;
-    return desc[a].CT < desc[b].CT;
-  });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return desc[a].M > desc[b].M; });
   for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
   GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
   HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, c->stream));
   NullDev nd{c->d_X, c->d_res, c->d_rr, c->d_v, c->d_zeros};
-  // ---- K2 per tile class --------------------------------------------------------------------------------
-  for (int k = 0; k < n;) {
-    int e = k;
-    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].CT == h_desc[k].CT) ++e;
-    launch_suffstat_class(c, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
-    k = e;
-  }
+  // ---- K2: one launch for the whole batch ------------------------------------------------------------------
+  launch_suffstat(c, d_desc, n, n_wparts, nd);
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
   if (burden || dbg) {
     {
@@ -555,10 +534,19 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                            d_desc + k, cnt, nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
   }
+  const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
     Scope sc(c, 2);
-    hipLaunchKernelGGL(gene_stats_kernel, dim3(n), dim3(256), 0, c->stream, d_desc, c->d_nc, params,
-                       burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI)), n_bparts);
+    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(256), 0, c->stream, d_desc, c->d_nc, params, tests_eff,
+                       n_bparts);
+  }
+  if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO)) {
+    Scope sc(c, 2);
+    const int maxMp = (maxM + 15) / 16 * 16;
+    size_t want = sizeof(double) * ((size_t)8 * maxMp + (size_t)maxM * maxM);
+    if (want > c->eigen_lds_max) want = sizeof(double) * (size_t)8 * maxMp;  // matrices stay in global scratch
+    hipLaunchKernelGGL(gene_eigen_kernel, dim3(kNEigen, n), dim3(256), want, c->stream, d_desc, c->d_nc, tests_eff,
+                       (int)(want / sizeof(double)));
   }
   {
     Scope sc(c, 3);

@@ -26,25 +26,30 @@ namespace rvt {
 // layout of one burden partial record (per test): U, cVc, count, cVX[0..d-1]
 RVT_HD int burden_rec_len(int d) { return 3 + d; }
 
+constexpr int kNEigen = 13;  // eigenproblems per gene: 11 rho, Z(I-M)Z', SKAT
+
+// per-gene workspace in global memory
 struct GeneScratch {
   double* R;     // Mp x Cp   reduced statistics, row-major (ld = Cp)
-  double* A;     // Mmax x Mmax
-  double* B;     // Mmax x Mmax   (work copy for the eigen solver)
-  double* suf;   // Mmax x Mmax   row suffix sums of A
-  double* vecs;  // 16 * Mmax doubles of vector scratch
-  int* ivec;     // 2 * Mmax ints
+  double* Wm;    // Mp x Mp   projected matrix S' - T' Cinv T'^T on the kept columns (m x m, column-major)
+  double* eig;   // kNEigen x Mp x Mp   per-eigenproblem work matrices (used when they do not fit in LDS)
+  double* vecs;  // 16 * Mp doubles of vector scratch (assemble stage)
+  double* bw;    // 2 * Mp: sqrt(SKAT weight), SKAT-O weight (filtered index)
+  double* rowsum;  // Mp: row sums of A = B Wm B / 2
+  int* ivec;     // 2 * Mp ints
 };
 RVT_HD size_t gene_scratch_doubles(int Mp, int Cp) {
-  return (size_t)Mp * Cp + 3 * (size_t)Mp * Mp + 16 * (size_t)Mp + (size_t)Mp;  // ivec packed in the tail
+  return (size_t)Mp * Cp + (size_t)(1 + kNEigen) * Mp * Mp + 16 * (size_t)Mp + 3 * (size_t)Mp + (size_t)Mp;
 }
 RVT_HD GeneScratch gene_scratch_carve(double* mem, int Mp, int Cp) {
   GeneScratch s;
   s.R = mem;
-  s.A = s.R + (size_t)Mp * Cp;
-  s.B = s.A + (size_t)Mp * Mp;
-  s.suf = s.B + (size_t)Mp * Mp;
-  s.vecs = s.suf + (size_t)Mp * Mp;
-  s.ivec = (int*)(s.vecs + 16 * (size_t)Mp);
+  s.Wm = s.R + (size_t)Mp * Cp;
+  s.eig = s.Wm + (size_t)Mp * Mp;
+  s.vecs = s.eig + (size_t)kNEigen * Mp * Mp;
+  s.bw = s.vecs + 16 * (size_t)Mp;
+  s.rowsum = s.bw + 2 * (size_t)Mp;
+  s.ivec = (int*)(s.rowsum + (size_t)Mp);
   return s;
 }
 
@@ -71,15 +76,23 @@ RVT_HD int skato_filter_eigen(const double* ev, int n, double* out) {
   return numKeep;
 }
 
-// The whole per-gene statistics stage.
+RVT_HD double skato_rho_value(int i) {
+  const double r0 = 1.0 * i / 10;
+  return (r0 > 0.999) ? 0.999 : r0;  // capRhos, SkatO.cpp:436-446
+}
+
+// ======================================================================================================
+// Stage A (one workgroup per gene): reduce the partial statistics, flags, flip algebra, projection,
+// weights, Q statistics, tau, burden score statistics.  Leaves Wm, the weights and the row sums of
+// A = B Wm B / 2 in the gene's scratch for stage B.
 //   parts:   P partial matrices of Mp x Cp doubles (row-major); only tiles with tile_col >= tile_row hold data
 //   colstat: P x 3 x Mp  (sum, min, max) partials
 //   bparts:  PB x 2 x burden_rec_len(d) partial burden sums (CMC, Zeggini) — may be null when no burden test
-//   lambda_out: 2*M doubles: [0,M) SKAT eigenvalues, [M,2M) Z(I-M)Z' eigenvalues
-RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
-                       const double* colstat, const double* bparts, int PB, const double* af, const rvt_params& prm,
-                       unsigned tests, GeneScratch ws, GeneStats* out, double* lambda_out, int* flip_out,
-                       int* kept_out) {
+// ======================================================================================================
+RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
+                          const double* colstat, const double* bparts, int PB, const double* af,
+                          const rvt_params& prm, unsigned tests, GeneScratch ws, GeneStats* out, int* flip_out,
+                          int* kept_out) {
   const int d = nc.d;
   const int ldr = Cp;
   double* R = ws.R;
@@ -92,23 +105,16 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
     }
     R[idx] = s;
   }
-  double* colsum = ws.vecs;            // [Mp]
-  double* cmin = ws.vecs + Mp;         // [Mp]
-  double* cmax = ws.vecs + 2 * Mp;     // [Mp]
-  double* sgn = ws.vecs + 3 * Mp;      // [Mp]  +1 / -1
-  double* shf = ws.vecs + 4 * Mp;      // [Mp]   0 / 2
-  double* bw = ws.vecs + 5 * Mp;       // beta weights (filtered index)
-  double* ut = ws.vecs + 6 * Mp;       // weighted scores
-  double* rowsum = ws.vecs + 7 * Mp;   // A·1
-  double* ev = ws.vecs + 8 * Mp;       // eigenvalues ascending
-  double* td = ws.vecs + 9 * Mp;       // tridiagonal d
-  double* te = ws.vecs + 10 * Mp;      // tridiagonal e
-  double* hv = ws.vecs + 11 * Mp;      // householder v
-  double* hw = ws.vecs + 12 * Mp;      // householder w
-  double* cd = ws.vecs + 13 * Mp;      // cholesky diag of R_rho
-  double* cc = ws.vecs + 14 * Mp;      // cholesky below-diagonal constant per column
-  double* tmpv = ws.vecs + 15 * Mp;
-  int* kidx = ws.ivec;                 // kept column list
+  double* colsum = ws.vecs;         // [Mp]
+  double* cmin = ws.vecs + Mp;      // [Mp]
+  double* cmax = ws.vecs + 2 * Mp;  // [Mp]
+  double* sgn = ws.vecs + 3 * Mp;   // [Mp]  +1 / -1
+  double* shf = ws.vecs + 4 * Mp;   // [Mp]   0 / 2
+  double* ut = ws.vecs + 5 * Mp;    // weighted scores
+  double* bw_skat = ws.bw;          // sqrt(beta_pdf^2)
+  double* bw_skato = ws.bw + Mp;    // beta_pdf
+  double* rowsum = ws.rowsum;
+  int* kidx = ws.ivec;              // kept column list
   for (int j = co.tid; j < M; j += co.nt) {
     double s = 0.0, mn = INFINITY, mx = -INFINITY;
     for (int p = 0; p < P; ++p) {
@@ -154,10 +160,11 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
     out->zimz_lambda_off = M;
     out->cmc_ok = out->zeg_ok = 0;
     out->cmc_nonref = 0;
+    for (int k = 0; k < kNEigen; ++k) out->eig_ok[k] = 0;
   }
   co.sync();
   const int m = kidx[Mp];
-  // ---- 8. burden score statistics (independent of the rest) ----------------------------------------
+  // ---- burden score statistics (independent of the rest) ---------------------------------------------
   if (co.tid == 0 && bparts && m > 0) {
     const int rl = burden_rec_len(d);
     for (int t = 0; t < 2; ++t) {
@@ -230,8 +237,8 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
     }
   }
   co.sync();
-  // ---- 4. projected matrix  Wm = S' − T' Cinv T'ᵀ  on the kept columns (into A, column-major m x m) --
-  double* A = ws.A;
+  // ---- 4. projected matrix  Wm = S' − T' Cinv T'ᵀ  on the kept columns (column-major m x m) ----------
+  double* Wm = ws.Wm;
   for (int idx = co.tid; idx < m * m; idx += co.nt) {
     const int a = idx % m, b = idx / m;
     const int ia = kidx[a], ib = kidx[b];
@@ -241,117 +248,154 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
       for (int l = 0; l < d; ++l) s += nc.Cinv[k * d + l] * R[(size_t)ib * ldr + M + l];
       q += R[(size_t)ia * ldr + M + k] * s;
     }
-    A[(size_t)b * m + a] = R[(size_t)ia * ldr + ib] - q;
+    Wm[(size_t)b * m + a] = R[(size_t)ia * ldr + ib] - q;
   }
-  co.sync();
-  const double vscale = nc.binary ? 1.0 : nc.sigma2;  // quantitative: statistics were unweighted, v = sigma2
-  double* lam_skat = lambda_out;
-  double* lam_zimz = lambda_out + M;
-  // ---- 5/6. SKAT --------------------------------------------------------------------------------------
-  if (tests & RVT_TEST_SKAT) {
-    for (int a = co.tid; a < m; a += co.nt) {
-      double freq = af[a];  // quirk: filtered position a reads the counter of unfiltered column a
-      if (freq > 0.5) freq = 1.0 - freq;
-      double wgt = 0.0;
-      if (freq > 1e-30) {
-        wgt = beta_density(freq, prm.skat_beta1, prm.skat_beta2);
-        wgt *= wgt;
-      }
-      bw[a] = sqrt(wgt);
-      const double s = bw[a] * R[(size_t)kidx[a] * ldr + M + d];
-      ut[a] = s * s;
-    }
-    co.sync();
-    double* Bm = ws.B;
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int a = idx % m, b = idx / m;
-      Bm[idx] = bw[a] * (vscale * A[idx]) * bw[b];
-    }
-    co.sync();
-    coop_sym_eigvals(co, Bm, m, td, te, hv, hw, ev);
-    if (co.tid == 0) {
-      double Q = 0.0;
-      for (int a = 0; a < m; ++a) Q += ut[a];
-      out->skat_Q = Q;
-      const int r_ub = (nc.N < (int64_t)m) ? (int)nc.N : m;
-      int r = 0;
-      for (int i = m - 1; i >= 0; --i) {
-        if (ev[i] > 1e-30 && r < r_ub) {
-          lam_skat[r++] = ev[i];
-        } else
-          break;
-      }
-      out->skat_nlambda = r;
-    }
-    co.sync();
-  }
-  if (!(tests & RVT_TEST_SKATO)) return;
-  // ---- 7. SKAT-O ----------------------------------------------------------------------------------------
+  // ---- 5. weights (quirk: filtered position a reads the counter of unfiltered column a) ----------------
   for (int a = co.tid; a < m; a += co.nt) {
     double freq = af[a];
     if (freq > 0.5) freq = 1.0 - freq;
-    bw[a] = (freq > 1e-30) ? beta_density(freq, prm.skato_beta1, prm.skato_beta2) : 0.0;
-    ut[a] = bw[a] * R[(size_t)kidx[a] * ldr + M + d];
-  }
-  co.sync();
-  // A <- B Wm B / 2   (= Z1'Z1)
-  for (int idx = co.tid; idx < m * m; idx += co.nt) {
-    const int a = idx % m, b = idx / m;
-    A[idx] = bw[a] * A[idx] * bw[b] / 2.0;
-  }
-  co.sync();
-  double s2;
-  if (nc.binary)
-    s2 = 1.0;
-  else {
-    s2 = sqrt(nc.rss);
-    s2 = (s2 * s2) / (double)(nc.N - 1);
-  }
-  double su = 0.0, su2 = 0.0;
-  for (int a = 0; a < m; ++a) {  // every thread: m is small
-    su += ut[a];
-    su2 += ut[a] * ut[a];
-  }
-  if (m == 1) {
-    // FitSKAT: Q = u²/s2/2, W = A, Davies on its single eigenvalue (=> Liu)
-    if (co.tid == 0) {
-      out->skato_single = 1;
-      double Q = ut[0] * ut[0];
-      if (!nc.binary) Q /= nc.rss / (double)(nc.N - 1);  // FitSKAT: squaredNorm()/(nPeople-1)
-      Q /= 2.;
-      out->Qs[0] = Q;
-      const double lam = A[0];
-      if (lam > 0) {
-        lam_zimz[0] = lam;
-        out->zimz_nlambda = 1;
-        out->skato_ok = 1;
-      } else {
-        out->skato_ok = 0;
-        out->status |= RVT_ST_SKATO_EIGEN;
-      }
+    double w1 = 0.0, w2 = 0.0;
+    if (freq > 1e-30) {
+      w1 = beta_density(freq, prm.skat_beta1, prm.skat_beta2);
+      w1 *= w1;
+      w2 = beta_density(freq, prm.skato_beta1, prm.skato_beta2);
     }
+    bw_skat[a] = sqrt(w1);
+    bw_skato[a] = w2;
+  }
+  co.sync();
+  // ---- 6. SKAT Q = || W½ G'ᵀ r ||²      (Skat.cpp:52) ----------------------------------------------------
+  if ((tests & RVT_TEST_SKAT) && co.tid == 0) {
+    double Q = 0.0;
+    for (int a = 0; a < m; ++a) {
+      const double s = bw_skat[a] * R[(size_t)kidx[a] * ldr + M + d];
+      Q += s * s;
+    }
+    out->skat_Q = Q;
+  }
+  if (!(tests & RVT_TEST_SKATO)) {
     co.sync();
     return;
   }
-  double rho[kNRho];
-  for (int i = 0; i < kNRho; ++i) {
-    const double r0 = 1.0 * i / 10;
-    rho[i] = (r0 > 0.999) ? 0.999 : r0;
-  }
-  // row suffix sums of A: suf[i][q] = sum_{j >= q} A[i][j]      (rho independent)
-  double* suf = ws.suf;
-  for (int i = co.tid; i < m; i += co.nt) {
+  // ---- 7. SKAT-O scalars: Q_rho, row sums of A = B Wm B / 2, tau_rho -------------------------------------
+  for (int a = co.tid; a < m; a += co.nt) {
+    ut[a] = bw_skato[a] * R[(size_t)kidx[a] * ldr + M + d];
     double s = 0.0;
-    for (int q = m - 1; q >= 0; --q) {
-      s += A[(size_t)q * m + i];
-      suf[(size_t)q * m + i] = s;
-    }
-    rowsum[i] = s;
+    for (int q = m - 1; q >= 0; --q) s += bw_skato[a] * Wm[(size_t)q * m + a] * bw_skato[q] / 2.0;
+    rowsum[a] = s;
   }
   co.sync();
-  int ok = 1;
-  for (int ir = 0; ir < kNRho && ok; ++ir) {
-    const double rh = rho[ir];
+  if (co.tid == 0) {
+    double s2;
+    if (nc.binary)
+      s2 = 1.0;
+    else {
+      s2 = sqrt(nc.rss);
+      s2 = (s2 * s2) / (double)(nc.N - 1);
+    }
+    double su = 0.0, su2 = 0.0;
+    for (int a = 0; a < m; ++a) {
+      su += ut[a];
+      su2 += ut[a] * ut[a];
+    }
+    if (m == 1) {
+      // FitSKAT (SkatO.cpp:60-99): Q = u²/s2/2, W = A (1 x 1), Davies on its single eigenvalue (=> Liu)
+      out->skato_single = 1;
+      double Q = ut[0] * ut[0];
+      if (!nc.binary) Q /= nc.rss / (double)(nc.N - 1);  // squaredNorm()/(nPeople-1)
+      Q /= 2.;
+      out->Qs[0] = Q;
+      out->skato_ok = 1;  // stage B (problem 11) clears it when the eigenvalue is not positive
+    } else {
+      double tot = 0.0, r2 = 0.0;
+      for (int a = 0; a < m; ++a) {
+        tot += rowsum[a];
+        r2 += rowsum[a] * rowsum[a];
+      }
+      // tau_rho = m² rho z_norm + (1-rho) ||z̄'Z1||² / z_norm, z_norm = 1'A1/m², z̄'Z1 = (A1)'/m   (SkatO.cpp:198-203)
+      const double z_norm = tot / ((double)m * (double)m);
+      const double zz = r2 / ((double)m * (double)m);
+      for (int i = 0; i < kNRho; ++i) {
+        const double rh = skato_rho_value(i);
+        double q = (1.0 - rh) * su2 + rh * (su * su);
+        q /= s2;
+        q /= 2.0;
+        out->Qs[i] = q;
+        out->tau[i] = (double)(m * m) * rh * z_norm + (1.0 - rh) * zz / z_norm;
+      }
+      out->skato_ok = 1;  // stage B clears eig_ok[k] when a getEigen finds no positive eigenvalue
+    }
+  }
+  co.sync();
+}
+
+// ======================================================================================================
+// Stage B (one workgroup per gene AND eigenproblem k): build the k-th symmetric matrix from Wm, reduce it to
+// tridiagonal form, bisect for all eigenvalues, apply the reference's eigenvalue filter and moments.
+//   k = 0..10   L'(Z1'Z1)L for rho_k      (SkatO.cpp:163-175)  -> mom_mu/var/df[k]
+//   k = 11      Z(I-M)Z'                   (SkatO.cpp:178-195)  -> lambda (zimz), VarZeta, MuQ, VarQ, Df
+//   k = 12      K_sqrt P0 K_sqrt'          (Skat.cpp:47-98)     -> lambda (skat)
+// `Bm` is the m x m work matrix (LDS when it fits, the gene's scratch otherwise); `vec` >= 8*m doubles.
+// ======================================================================================================
+RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int Mp, unsigned tests, GeneScratch ws,
+                       double* Bm, double* vec, GeneStats* out, double* lambda_out) {
+  const int m = out->n_poly;
+  if (m == 0) return;
+  const bool is_skat = (k == 12);
+  if (is_skat && !(tests & RVT_TEST_SKAT)) return;
+  if (!is_skat && !(tests & RVT_TEST_SKATO)) return;
+  if (!is_skat && m == 1 && k != 11) return;  // single-variant shortcut only needs the one "eigenvalue"
+  const double* Wm = ws.Wm;
+  const double* bw_skat = ws.bw;
+  const double* bw_skato = ws.bw + Mp;
+  const double* rowsum = ws.rowsum;
+  double* ev = vec;          // eigenvalues ascending
+  double* td = vec + m;      // tridiagonal d
+  double* te = vec + 2 * m;  // tridiagonal e
+  double* hv = vec + 3 * m;  // householder v
+  double* hw = vec + 4 * m;  // householder w
+  double* cd = vec + 5 * m;  // cholesky diag of R_rho
+  double* cc = vec + 6 * m;  // cholesky below-diagonal constant per column
+  double* tmpv = vec + 7 * m;
+  double vz = 0.0;
+  if (is_skat) {
+    const double vscale = nc.binary ? 1.0 : nc.sigma2;  // quantitative: statistics were unweighted, v = sigma2
+    for (int idx = co.tid; idx < m * m; idx += co.nt) {
+      const int a = idx % m, b = idx / m;
+      Bm[idx] = bw_skat[a] * (vscale * Wm[idx]) * bw_skat[b];
+    }
+    co.sync();
+  } else if (k == 11) {
+    if (m == 1) {
+      if (co.tid == 0) {
+        const double lam = bw_skato[0] * Wm[0] * bw_skato[0] / 2.0;
+        if (lam > 0) {
+          lambda_out[M] = lam;
+          out->zimz_nlambda = 1;
+          out->zimz_lambda_sum = lam;
+          out->eig_ok[11] = 1;
+        } else {
+          out->eig_ok[11] = 0;
+        }
+      }
+      co.sync();
+      return;
+    }
+    double tot = 0.0;
+    for (int a = 0; a < m; ++a) tot += rowsum[a];
+    double vzpart = 0.0;
+    for (int idx = co.tid; idx < m * m; idx += co.nt) {
+      const int i = idx % m, j = idx / m;
+      const double aij = bw_skato[i] * Wm[idx] * bw_skato[j] / 2.0;
+      const double zmz = rowsum[i] * rowsum[j] / tot;
+      const double zimz = aij - zmz;
+      Bm[idx] = zimz;
+      vzpart += zmz * zimz;
+    }
+    vz = co.sum(vzpart);
+    co.sync();
+  } else {
+    const double rh = skato_rho_value(k);
     // Cholesky factor of R_rho = (1-rho) I + rho 11': L[j][j] = cd[j], L[i][j] = cc[j] (i > j)
     if (co.tid == 0) {
       double acc = 0.0;  // sum_{k<j} cc[k]^2
@@ -363,17 +407,19 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
       }
     }
     co.sync();
-    // AL[i][q] = A[i][q] cd[q] + cc[q] * suf[i][q+1]   -> into B (column-major)
-    double* Bm = ws.B;
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int i = idx % m, q = idx / m;
-      const double tail = (q + 1 < m) ? suf[(size_t)(q + 1) * m + i] : 0.0;
-      Bm[idx] = A[idx] * cd[q] + cc[q] * tail;
+    // (A L)[i][q] = A[i][q] cd[q] + cc[q] * sum_{j>q} A[i][j] : thread i walks its row from the right
+    for (int i = co.tid; i < m; i += co.nt) {
+      double tail = 0.0;
+      for (int q = m - 1; q >= 0; --q) {
+        const double aiq = bw_skato[i] * Wm[(size_t)q * m + i] * bw_skato[q] / 2.0;
+        Bm[(size_t)q * m + i] = aiq * cd[q] + cc[q] * tail;
+        tail += aiq;
+      }
     }
     co.sync();
-    // K[p][q] = cd[p] AL[p][q] + cc[p] * sum_{i > p} AL[i][q]   (column suffix sums), in place per column
+    // K[p][q] = cd[p] AL[p][q] + cc[p] * sum_{i>p} AL[i][q] : thread q walks its column from the bottom
     for (int q = co.tid; q < m; q += co.nt) {
-      double tail = 0.0;  // sum_{i > p} AL[i][q]
+      double tail = 0.0;
       for (int p = m - 1; p >= 0; --p) {
         const double alpq = Bm[(size_t)q * m + p];
         Bm[(size_t)q * m + p] = cd[p] * alpq + cc[p] * tail;
@@ -381,13 +427,10 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
       }
     }
     co.sync();
-    // symmetrise (rounding) so the eigen solver sees an exactly symmetric matrix
+    // exact symmetry for the eigen solver
     for (int idx = co.tid; idx < m * m; idx += co.nt) {
       const int i = idx % m, j = idx / m;
-      if (i > j) {
-        const double s = 0.5 * (Bm[(size_t)j * m + i] + Bm[(size_t)i * m + j]);
-        Bm[(size_t)j * m + i] = s;
-      }
+      if (i > j) Bm[(size_t)j * m + i] = 0.5 * (Bm[(size_t)j * m + i] + Bm[(size_t)i * m + j]);
     }
     co.sync();
     for (int idx = co.tid; idx < m * m; idx += co.nt) {
@@ -395,82 +438,66 @@ RVT_HD void gene_stats(const Coop& co, const NullConsts& nc, int M, int Mp, int 
       if (i < j) Bm[(size_t)j * m + i] = Bm[(size_t)i * m + j];
     }
     co.sync();
-    coop_sym_eigvals(co, Bm, m, td, te, hv, hw, ev);
-    if (co.tid == 0) {
-      const int nk = skato_filter_eigen(ev, m, tmpv);
-      if (nk < 0) {
-        kidx[Mp + 1] = 0;
-      } else {
-        kidx[Mp + 1] = 1;
-        const SkatoMoment mo = skato_moment(tmpv, nk);
-        out->mom_mu[ir] = mo.muQ;
-        out->mom_var[ir] = mo.varQ;
-        out->mom_df[ir] = mo.df;
-        double q = (1.0 - rh) * su2 + rh * (su * su);
-        q /= s2;
-        q /= 2.0;
-        out->Qs[ir] = q;
-      }
-    }
-    co.sync();
-    ok = kidx[Mp + 1];
-    co.sync();
   }
-  if (!ok) {
-    if (co.tid == 0) {
-      out->skato_ok = 0;
-      out->status |= RVT_ST_SKATO_EIGEN;
-    }
-    co.sync();
-    return;
-  }
-  // Z(I-M)Z' = A − (A1)(A1)'/(1'A1)
-  double tot = 0.0, r2 = 0.0;
-  for (int a = 0; a < m; ++a) {
-    tot += rowsum[a];
-    r2 += rowsum[a] * rowsum[a];
-  }
-  double* Bm = ws.B;
-  double vzpart = 0.0;
-  for (int idx = co.tid; idx < m * m; idx += co.nt) {
-    const int i = idx % m, j = idx / m;
-    const double zmz = rowsum[i] * rowsum[j] / tot;
-    const double zimz = A[idx] - zmz;
-    Bm[idx] = zimz;
-    vzpart += zmz * zimz;
-  }
-  const double vz = co.sum(vzpart);
-  co.sync();
   coop_sym_eigvals(co, Bm, m, td, te, hv, hw, ev);
   if (co.tid == 0) {
-    const int nk = skato_filter_eigen(ev, m, lam_zimz);
-    if (nk < 0) {
-      out->skato_ok = 0;
-      out->status |= RVT_ST_SKATO_EIGEN;
-    } else {
-      out->zimz_nlambda = nk;
-      double ls = 0, l2 = 0, l4 = 0;
-      for (int i = 0; i < nk; ++i) {
-        const double l = lam_zimz[i];
-        ls += l;
-        l2 += l * l;
-        l4 += l * l * l * l;
+    if (is_skat) {
+      double* lam_skat = lambda_out;
+      const int r_ub = (nc.N < (int64_t)m) ? (int)nc.N : m;
+      int r = 0;
+      for (int i = m - 1; i >= 0; --i) {
+        if (ev[i] > 1e-30 && r < r_ub) {
+          lam_skat[r++] = ev[i];
+        } else
+          break;
       }
-      out->zimz_lambda_sum = ls;
-      out->varZeta = 4.0 * vz;
-      out->muQ = ls;
-      out->varQ = 2.0 * l2 + out->varZeta;
-      const double KerQ = l4 / l2 / l2 * 12;
-      out->df = 12 / KerQ;
-      // tau_rho = m² rho z_norm + (1-rho) ||z̄'Z1||² / z_norm, z_norm = 1'A1/m², z̄'Z1 = (A1)'/m
-      const double z_norm = tot / ((double)m * (double)m);
-      const double zz = r2 / ((double)m * (double)m);
-      for (int i = 0; i < kNRho; ++i)
-        out->tau[i] = (double)(m * m) * rho[i] * z_norm + (1.0 - rho[i]) * zz / z_norm;
-      out->skato_ok = 1;
+      out->skat_nlambda = r;
+      out->eig_ok[12] = 1;
+    } else if (k == 11) {
+      double* lam_zimz = lambda_out + M;
+      const int nk = skato_filter_eigen(ev, m, lam_zimz);
+      if (nk < 0) {
+        out->eig_ok[11] = 0;
+      } else {
+        out->zimz_nlambda = nk;
+        double ls = 0, l2 = 0, l4 = 0;
+        for (int i = 0; i < nk; ++i) {
+          const double l = lam_zimz[i];
+          ls += l;
+          l2 += l * l;
+          l4 += l * l * l * l;
+        }
+        out->zimz_lambda_sum = ls;
+        out->varZeta = 4.0 * vz;
+        out->muQ = ls;
+        out->varQ = 2.0 * l2 + out->varZeta;
+        const double KerQ = l4 / l2 / l2 * 12;
+        out->df = 12 / KerQ;
+        out->eig_ok[11] = 1;
+      }
+    } else {
+      const int nk = skato_filter_eigen(ev, m, tmpv);
+      if (nk < 0) {
+        out->eig_ok[k] = 0;
+      } else {
+        const SkatoMoment mo = skato_moment(tmpv, nk);
+        out->mom_mu[k] = mo.muQ;
+        out->mom_var[k] = mo.varQ;
+        out->mom_df[k] = mo.df;
+        out->eig_ok[k] = 1;
+      }
     }
   }
   co.sync();
+}
+
+// did SkatO::Fit succeed?  (every getEigen found a positive eigenvalue)
+RVT_HD bool skato_fit_ok(const GeneStats& gs) {
+  if (!gs.skato_ok || gs.n_poly == 0) return false;
+  if (gs.skato_single) return gs.eig_ok[11] != 0;
+  for (int k = 0; k < 12; ++k)
+    if (!gs.eig_ok[k]) return false;
+  return true;
 }
 
 }  // namespace rvt

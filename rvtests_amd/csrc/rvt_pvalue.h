@@ -22,6 +22,7 @@ constexpr int kSkatoLimit = 1000;
 RVT_HD void pvalue_init_result(const GeneStats& gs, int64_t gene_id, rvt_gene_result* r) {
   r->gene_id = gene_id;
   r->status = (uint32_t)gs.status;
+  if (gs.n_poly > 0 && gs.skato_ok && !skato_fit_ok(gs)) r->status |= RVT_ST_SKATO_EIGEN;
   r->n_variants = gs.n_variants;
   r->n_poly = gs.n_poly;
   r->skat_ok = 0;
@@ -74,6 +75,7 @@ RVT_HD void skato_fill_integrand(const GeneStats& gs, const double* qminp, const
   s->th = th;
   s->r = gs.zimz_nlambda;
   s->lambda_sum = gs.zimz_lambda_sum;
+  s->pre = nullptr;
 }
 
 // th_skat / th_zimz: scratch of >= n ints each; qags_mem: qags_workspace_bytes(kSkatoLimit) bytes
@@ -94,7 +96,7 @@ RVT_HD void gene_pvalue_serial(const GeneStats& gs, const double* lambda_buf, un
     r->skat_Q = gs.skat_Q;
     r->skat_p = p;
   }
-  if ((tests & RVT_TEST_SKATO) && gs.skato_ok) {
+  if ((tests & RVT_TEST_SKATO) && skato_fit_ok(gs)) {
     const double* lam = lambda_buf + gs.zimz_lambda_off;
     const int n = gs.zimz_nlambda;
     davies_order(lam, n, th_zimz);
@@ -118,6 +120,9 @@ RVT_HD void gene_pvalue_serial(const GeneStats& gs, const double* lambda_buf, un
       for (int i = 0; i < kNRho; ++i) qminp[i] = skato_q_by_moment(minP, mo[i]);
       SkatoIntegrand si;
       skato_fill_integrand(gs, qminp, lam, th_zimz, &si);
+      DaviesPrelude pre;
+      davies_prelude(lam, th_zimz, n, 10000, 0.000001, &pre);
+      si.pre = &pre;
       QagsWorkspace ws = qags_workspace_carve(qags_mem, kSkatoLimit);
       double fv[42];
       int neval = 0, status;

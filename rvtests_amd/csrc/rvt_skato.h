@@ -63,6 +63,7 @@ struct SkatoIntegrand {
   const int* th;         // davies_order(lambda)
   int r;
   double lambda_sum;
+  const DaviesPrelude* pre;  // c-independent part of qf() for `lambda` (may be null)
 };
 
 RVT_HD double skato_kappa(const SkatoIntegrand& s, double x) {
@@ -85,7 +86,7 @@ RVT_HD double skato_integrand_davies(const SkatoIntegrand& s, double x, double* 
   } else {
     const double Q = (kappa - s.muQ) * sqrt(s.varQ - s.varZeta) / sqrt(s.varQ) + s.muQ;
     int fault;
-    temp = davies_pvalue(s.lambda, s.th, s.r, Q, &fault, nterms);
+    temp = davies_pvalue(s.lambda, s.th, s.r, Q, &fault, nterms, s.pre);
     if (temp <= 0.0 || temp == 1.0) temp = liu_pvalue(s.lambda, s.r, Q);
   }
   return (1.0 - temp) * chisq_density(x, 1.0);

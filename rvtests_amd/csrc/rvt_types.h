@@ -33,7 +33,8 @@ struct GeneStats {
   int skat_lambda_off;
   // SKAT-O
   int skato_single;  // 1: single-variant shortcut (FitSKAT)       SkatO.cpp:60-99,118-120
-  int skato_ok;      // 0 if some getEigen found no positive eigenvalue
+  int skato_ok;      // stage A reached the SKAT-O part (see skato_fit_ok for the eigen checks)
+  int eig_ok[13];    // per eigenproblem: 1 if getEigen found a positive eigenvalue
   double Qs[11];
   double mom_mu[11], mom_var[11], mom_df[11];
   double tau[11];

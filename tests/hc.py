@@ -65,6 +65,8 @@ def lib():
         L.hc_beta_pdf.argtypes = [d, d, d]
         L.hc_davies_pvalue.restype = d
         L.hc_davies_pvalue.argtypes = [c_double_p, C.c_int, d, c_int_p, c_double_p]
+        L.hc_davies_pvalue_cached.restype = d
+        L.hc_davies_pvalue_cached.argtypes = [c_double_p, C.c_int, d, c_int_p, c_double_p]
         L.hc_liu_pvalue.restype = d
         L.hc_liu_pvalue.argtypes = [c_double_p, C.c_int, d]
         L.hc_sym_eigvals.restype = None
@@ -74,16 +76,17 @@ def lib():
         L.hc_gene.restype = C.c_int
         L.hc_gene.argtypes = [C.c_int, C.c_int64, C.c_int, d, d, d, c_double_p, c_double_p, C.c_int, c_double_p,
                               c_double_p, c_double_p, c_double_p, C.POINTER(Params), C.c_uint,
-                              C.POINTER(GeneResult), c_int_p, c_int_p, c_double_p]
+                              C.POINTER(GeneResult), c_int_p, c_int_p, c_double_p, c_double_p]
         _lib = L
     return _lib
 
 
-def davies(lam, Q):
+def davies(lam, Q, cached=False):
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     fault = C.c_int(0)
     nt = C.c_double(0)
-    p = lib().hc_davies_pvalue(_dp(lam), len(lam), float(Q), C.byref(fault), C.byref(nt))
+    fn = lib().hc_davies_pvalue_cached if cached else lib().hc_davies_pvalue
+    p = fn(_dp(lam), len(lam), float(Q), C.byref(fault), C.byref(nt))
     return p, fault.value, nt.value
 
 
@@ -142,9 +145,11 @@ def gene(G, af, X, res, v, binary, sigma2, tests=15, params=None, bstats=None):
     flip = np.zeros(M, dtype=np.int32)
     kept = np.zeros(M, dtype=np.int32)
     lam = np.zeros(2 * M)
+    dbg = np.zeros(64)
     af = np.ascontiguousarray(af, dtype=np.float64)
     bs = _dp(bstats) if bstats is not None else None
     lib().hc_gene(int(binary), N, d, float(sigma2), rss, rsum, _dp(Cm), _dp(Cinv), M, _dp(R), _dp(colstat), bs,
                   _dp(af), C.byref(prm), tests, C.byref(out), flip.ctypes.data_as(c_int_p),
-                  kept.ctypes.data_as(c_int_p), _dp(lam))
+                  kept.ctypes.data_as(c_int_p), _dp(lam), _dp(dbg))
+    out.dbg = dbg
     return out, flip, kept, lam
