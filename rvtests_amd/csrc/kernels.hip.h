@@ -418,12 +418,133 @@ __global__ __launch_bounds__(256) void gene_eigen_kernel(const GeneDesc* __restr
 }
 
 // =====================================================================================================
-// K4: p-values, one wave per gene.  Lane t evaluates quadrature abscissa t (21 for the first panel, 42
-// for the two halves of a bisected interval); lane 63 does the SKAT Davies call alongside the first
-// panel; lanes 0..10 do the per-rho tails and quantiles.  Lane 0 runs the QAGS bookkeeping.
+// K4: p-values, one wave per gene.
+//
+// Lane t owns quadrature abscissa t (21 for the first panel, 42 for the two halves of a bisected interval);
+// lanes 0..10 also do the per-rho tails and quantiles; lane 0 runs the QAGS bookkeeping.  The expensive
+// part of a Davies evaluation is its main integration — (nt+1) terms, each a loop over all coefficients —
+// and in one QAGS step only the abscissae with Q >= 0 need it, so the lanes would mostly idle if each
+// integrated its own point.  Instead every lane runs qf() up to the integration (davies_qf_front), the
+// (point, term) pairs of ALL lanes are laid out in one flat list, the 64 lanes evaluate 64 terms at a time
+// (davies_term), and each point's lane then adds its terms in the reference's order (k = nt .. 0), so the
+// sums are bit-identical to the sequential loop of qfc.c:241-270.
 // =====================================================================================================
+constexpr int kTermCap = 512;  // (point, term) pairs staged in LDS per pass
+
+struct WaveDaviesLds {
+  double* c;      // [64]
+  double* sig;    // [64]
+  double* intv;   // [64]
+  int* nt1;       // [64]  nt+1, 0 = no main integration
+  int* which;     // [64]  coefficient set of the lane's task
+  int* off;       // [65]  exclusive prefix of nt1
+  double* v1;     // [kTermCap]
+  double* v2;     // [kTermCap]
+};
+__device__ __forceinline__ size_t wave_davies_lds_bytes() {
+  return sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66);
+}
+__device__ __forceinline__ WaveDaviesLds wave_davies_lds_carve(char* mem) {
+  WaveDaviesLds w;
+  double* d = reinterpret_cast<double*>(mem);
+  w.c = d;
+  w.sig = d + 64;
+  w.intv = d + 128;
+  w.v1 = d + 192;
+  w.v2 = w.v1 + kTermCap;
+  int* ip = reinterpret_cast<int*>(w.v2 + kTermCap);
+  w.nt1 = ip;
+  w.which = ip + 64;
+  w.off = ip + 128;
+  return w;
+}
+
+// MixtureChiSquare::getPvalue for one point per lane (regression/MixtureChiSquare.cpp:7-29), cooperative
+// main integration.  Every lane of the wave must call it; `active` says whether the lane has a point.
+// lbs/ths/rs: the (at most two) coefficient sets in LDS; `which` selects the lane's set.
+__device__ double wave_davies_pvalue(bool active, int which, const double* const* lbs, const int* const* ths,
+                                     const int* rs, double c, const DaviesPrelude* pre, int lane,
+                                     const WaveDaviesLds& L, double* nterms) {
+  DaviesTask task;
+  task.need_main = false;
+  task.fault = 0;
+  task.qfval = 0.0;
+  task.nterms = 0.0;
+  task.intl = task.ersm = 0.0;
+  task.acc = 0.000001;
+  task.c = task.sigsq = task.intv = 0.0;
+  task.nt = 0;
+  bool direct = true;   // result already known (Liu for a single coefficient, 1.0 for c < 0, or inactive)
+  double pdirect = 0.0;
+  if (active) {
+    const double* lb = lbs[which];
+    const int r = rs[which];
+    if (r == 1) {
+      pdirect = liu_pvalue(lb, r, c);
+    } else if (c < 0.0) {
+      pdirect = 1.0;  // see davies_pvalue(): qf() = 0 or a fault, both replaced by Liu at every call site
+    } else {
+      direct = false;
+      davies_qf_front(lb, ths[which], r, c, 10000, 0.000001, pre, &task);
+    }
+  }
+  const bool need = active && !direct && task.need_main;
+  L.nt1[lane] = need ? task.nt + 1 : 0;
+  L.which[lane] = which;
+  L.c[lane] = task.c;
+  L.sig[lane] = task.sigsq;
+  L.intv[lane] = task.intv;
+  __syncthreads();
+  if (lane == 0) {
+    int acc = 0;
+    for (int q = 0; q < 64; ++q) {
+      L.off[q] = acc;
+      acc += L.nt1[q];
+    }
+    L.off[64] = acc;
+  }
+  __syncthreads();
+  const int total = L.off[64];
+  const int my_begin = L.off[lane], my_end = L.off[lane + 1];
+  double intl = task.intl, ersm = task.ersm;
+  for (int cs = 0; cs < total; cs += kTermCap) {
+    const int ce = (cs + kTermCap < total) ? cs + kTermCap : total;
+    for (int idx = cs + lane; idx < ce; idx += 64) {
+      int p = 0;
+      for (int q = 1; q < 64; ++q) p += (idx >= L.off[q]) ? 1 : 0;  // owner of this flat index
+      // (owners with nt1 == 0 share their offset with the next one; the count above lands on the last of
+      //  them, which is the one that really owns idx because off is non-decreasing)
+      const int k = (L.nt1[p] - 1) - (idx - L.off[p]);
+      const int w = L.which[p];
+      double t1, t2;
+      davies_term(lbs[w], rs[w], L.c[p], L.sig[p], L.intv[p], k, &t1, &t2);
+      L.v1[idx - cs] = t1;
+      L.v2[idx - cs] = t2;
+    }
+    __syncthreads();
+    if (need) {
+      const int b = (my_begin > cs) ? my_begin : cs, e = (my_end < ce) ? my_end : ce;
+      for (int idx = b; idx < e; ++idx) {  // k descending = flat index ascending: the reference's order
+        intl = intl + L.v1[idx - cs];
+        ersm = ersm + L.v2[idx - cs];
+      }
+    }
+    __syncthreads();
+  }
+  if (!active) return 0.0;
+  if (direct) return pdirect;
+  if (need) task.nterms += task.nt + 1;
+  *nterms += task.nterms;
+  int fault;
+  double p = 1.0 - davies_qf_back(task, intl, ersm, &fault);
+  if (p > 1.0) p = 1.0;
+  if (fault) p = -1.0;
+  return p;
+}
+
 __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes, unsigned tests) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double ctl[4];  // a1, b1, b2, running / result, status
   const GeneDesc gd = genes[blockIdx.x];
   const GeneStats gs = *gd.stats;
   const int lane = threadIdx.x;
@@ -432,6 +553,8 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
   double* lam_zimz = lam_skat + M;
   int* th_skat = reinterpret_cast<int*>(lam_zimz + M);
   int* th_zimz = th_skat + M;
+  double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
+  const WaveDaviesLds L = wave_davies_lds_carve(reinterpret_cast<char*>(fv + 42));
   rvt_gene_result res;
   pvalue_init_result(gs, gd.gene_id, &res);
   if (gs.n_poly == 0) {
@@ -444,131 +567,172 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
   if (lane == 0) davies_order(lam_skat, gs.skat_nlambda, th_skat);
   if (lane == 1) davies_order(lam_zimz, gs.zimz_nlambda, th_zimz);
   __syncthreads();
+  const double* lbs[2] = {lam_zimz, lam_skat};
+  const int* ths[2] = {th_zimz, th_skat};
+  const int rs[2] = {gs.zimz_nlambda, gs.skat_nlambda};
   double terms = 0.0;
-  // ---- SKAT on lane 63 (runs concurrently with the per-rho work below) --------------------------------
-  double skat_p = 0.0;
   const bool do_skat = (tests & RVT_TEST_SKAT) != 0;
   const bool do_skato = (tests & RVT_TEST_SKATO) && skato_fit_ok(gs);
+  // ---- per-rho tails (lanes 0..10), burden tails (lanes 60, 61) ------------------------------------------
   double pv_rho = 1.0;
   SkatoMoment mo;
   mo.muQ = mo.varQ = mo.df = 1.0;
-  if (lane == 63 && do_skat) {
-    int fault;
-    double nt;
-    double p = davies_pvalue(lam_skat, th_skat, gs.skat_nlambda, gs.skat_Q, &fault, &nt);
-    terms += nt;
-    if (p <= 0.0 || p == 1.0) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);
-    skat_p = p;
-  } else if (lane < kNRho && do_skato && !gs.skato_single) {
+  if (lane < kNRho && do_skato && !gs.skato_single) {
     mo.muQ = gs.mom_mu[lane];
     mo.varQ = gs.mom_var[lane];
     mo.df = gs.mom_df[lane];
     pv_rho = skato_p_by_moment(gs.Qs[lane], mo);
-  } else if (lane == 62 && do_skato && gs.skato_single) {
-    int fault;
-    double nt;
-    pv_rho = davies_pvalue(lam_zimz, th_zimz, gs.zimz_nlambda, gs.Qs[0], &fault, &nt);
   } else if (lane == 61 && (tests & RVT_TEST_CMC) && gs.cmc_ok) {
     pv_rho = chisq_Q(gs.cmc_stat, 1.0);
   } else if (lane == 60 && (tests & RVT_TEST_ZEGGINI) && gs.zeg_ok) {
     pv_rho = chisq_Q(gs.zeg_stat, 1.0);
   }
-  skat_p = __shfl(skat_p, 63, 64);
-  if (do_skat) {
-    res.skat_ok = 1;
-    res.skat_Q = gs.skat_Q;
-    res.skat_p = skat_p;
-  }
   res.cmc_p = __shfl(pv_rho, 61, 64);
   res.zeg_p = __shfl(pv_rho, 60, 64);
   if (!((tests & RVT_TEST_CMC) && gs.cmc_ok)) res.cmc_p = 0.0;
   if (!((tests & RVT_TEST_ZEGGINI) && gs.zeg_ok)) res.zeg_p = 0.0;
-  if (do_skato && gs.skato_single) {
-    res.skato_ok = 1;
-    res.skato_Q = gs.Qs[0];
-    res.skato_rho = 0.0;
-    res.skato_p = __shfl(pv_rho, 62, 64);
-  } else if (do_skato) {
-    double pvals[kNRho], qminp[kNRho];
+  // ---- SKAT-O preparation -------------------------------------------------------------------------------
+  double pvals[kNRho], qminp[kNRho], minP = 1.0;
+  int minIndex = 0;
+  SkatoIntegrand si;
+  DaviesPrelude pre;
+  pre.valid = false;
+  const bool skato_quad = do_skato && !gs.skato_single;
+  if (skato_quad) {
 #pragma unroll
     for (int i = 0; i < kNRho; ++i) pvals[i] = __shfl(pv_rho, i, 64);
-    double minP;
-    int minIndex;
     skato_select(gs, pvals, &minP, &minIndex);
     double qm_l = 0.0;
     if (lane < kNRho) qm_l = skato_q_by_moment(minP, mo);
 #pragma unroll
     for (int i = 0; i < kNRho; ++i) qminp[i] = __shfl(qm_l, i, 64);
-    SkatoIntegrand si;
     skato_fill_integrand(gs, qminp, lam_zimz, th_zimz, &si);
-    DaviesPrelude pre;  // every lane computes the same values; kept in registers
-    davies_prelude(lam_zimz, th_zimz, gs.zimz_nlambda, 10000, 0.000001, &pre);
+    davies_prelude(lam_zimz, th_zimz, gs.zimz_nlambda, 10000, 0.000001, &pre);  // same values in every lane
     si.pre = &pre;
-    QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
-    double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
-    int neval = 0;
-    double integral = 0.0;
-    int status = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-      // QagsMachine lives in registers/scratch of lane 0; the wave-uniform control words go through LDS
-      QagsMachine qm;
-      __shared__ double ctl[4];   // a1, b1, b2, running
-      if (lane == 0) {
+  }
+  // One cooperative Davies round evaluates: the quadrature abscissae of this step (lanes < npts), and — in
+  // the first round only — SKAT's own Q (lane 62) and the single-variant SKAT-O Q (lane 63).
+  auto davies_round = [&](int npts, double a1, double b1, double b2, bool first, int pass, double* extra62,
+                          double* extra63) {
+    bool active = false;
+    int which = 0;
+    double c = 0.0, x = 0.0;
+    bool skip_zero = false;  // kappa beyond the cut: integrand uses temp = 0
+    const DaviesPrelude* pp = nullptr;
+    if (lane < npts && skato_quad) {
+      x = first ? gk21_abscissa(a1, b2, lane)
+                : ((lane < 21) ? gk21_abscissa(a1, b1, lane) : gk21_abscissa(b1, b2, lane - 21));
+      if (pass == 0) {
+        const double kappa = skato_kappa(si, x);
+        if (kappa > si.lambda_sum * 10000) {
+          skip_zero = true;
+        } else {
+          c = (kappa - si.muQ) * sqrt(si.varQ - si.varZeta) / sqrt(si.varQ) + si.muQ;
+          active = true;
+          pp = &pre;
+        }
+      }
+    } else if (first && lane == 62 && do_skat) {
+      active = true;
+      which = 1;
+      c = gs.skat_Q;
+    } else if (first && lane == 63 && do_skato && gs.skato_single) {
+      active = true;
+      which = 0;
+      c = gs.Qs[0];
+    }
+    double nt = 0.0;
+    double p = 0.0;
+    if (pass == 0 || first) p = wave_davies_pvalue(active, which, lbs, ths, rs, c, pp, lane, L, &nt);
+    terms += nt;
+    if (lane < npts && skato_quad) {
+      double val;
+      if (pass == 0) {
+        double temp = skip_zero ? 0.0 : p;
+        if (!skip_zero && (temp <= 0.0 || temp == 1.0)) temp = liu_pvalue(si.lambda, si.r, c);
+        val = (1.0 - temp) * chisq_density(x, 1.0);
+      } else {
+        val = skato_integrand_liu(si, x);
+      }
+      fv[lane] = val;
+    }
+    if (first && lane == 62 && do_skat) {
+      if (p <= 0.0 || p == 1.0) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);  // Skat.cpp:100-103
+      *extra62 = p;
+    }
+    if (first && lane == 63 && do_skato && gs.skato_single) *extra63 = p;
+    __syncthreads();
+  };
+  double skat_p = 0.0, single_p = 0.0;
+  int neval = 0, status = 0;
+  double integral = 0.0;
+  QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
+  for (int pass = 0; pass < 2; ++pass) {
+    QagsMachine qm;  // lives in lane 0; the wave-uniform control words go through LDS
+    if (lane == 0) {
+      if (skato_quad) {
         qm.begin(0., 40., kSkatoEpsAbs, kSkatoEpsRel, kSkatoLimit, ws);
         ctl[3] = qm.running() ? 1.0 : 0.0;
-      }
-      __syncthreads();
-      bool running = ctl[3] != 0.0;
-      if (running) {
-        if (lane < 21) {
-          const double x = gk21_abscissa(0., 40., lane);
-          double nt = 0.0;
-          fv[lane] = pass == 0 ? skato_integrand_davies(si, x, &nt) : skato_integrand_liu(si, x);
-          terms += nt;
-        }
-        neval += 21;
-        __syncthreads();
-        if (lane == 0) {
-          qm.first_panel(fv);
-          ctl[3] = qm.running() ? 1.0 : 0.0;
-          if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
-        }
-        __syncthreads();
-        running = ctl[3] != 0.0;
-      }
-      while (running) {
-        const double a1 = ctl[0], b1 = ctl[1], b2 = ctl[2];
-        if (lane < 42) {
-          const double x = (lane < 21) ? gk21_abscissa(a1, b1, lane) : gk21_abscissa(b1, b2, lane - 21);
-          double nt = 0.0;
-          fv[lane] = pass == 0 ? skato_integrand_davies(si, x, &nt) : skato_integrand_liu(si, x);
-          terms += nt;
-        }
-        neval += 42;
-        __syncthreads();
-        if (lane == 0) {
-          qm.advance(fv, fv + 21);
-          ctl[3] = qm.running() ? 1.0 : 0.0;
-          if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
-        }
-        __syncthreads();
-        running = ctl[3] != 0.0;
-      }
-      if (lane == 0) {
-        ctl[0] = qm.result;
-        ctl[1] = (double)qm.status;
-      }
-      __syncthreads();
-      integral = ctl[0];
-      status = (int)ctl[1];
-      __syncthreads();
-      if (pass == 0) {
-        res.skato_qags_status = status;
-        if (status == 0) break;
       } else {
-        res.skato_qags_status = res.skato_qags_status * 100 + status;
+        ctl[3] = 0.0;
       }
     }
+    __syncthreads();
+    bool running = ctl[3] != 0.0;
+    if (running || pass == 0) {
+      davies_round(running ? 21 : 0, 0., 20., 40., true, pass, &skat_p, &single_p);
+      if (running) neval += 21;
+      if (lane == 0 && running) {
+        qm.first_panel(fv);
+        ctl[3] = qm.running() ? 1.0 : 0.0;
+        if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
+      }
+      __syncthreads();
+      running = running && ctl[3] != 0.0;
+    }
+    while (running) {
+      const double a1 = ctl[0], b1 = ctl[1], b2 = ctl[2];
+      __syncthreads();
+      davies_round(42, a1, b1, b2, false, pass, &skat_p, &single_p);
+      neval += 42;
+      if (lane == 0) {
+        qm.advance(fv, fv + 21);
+        ctl[3] = qm.running() ? 1.0 : 0.0;
+        if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
+      }
+      __syncthreads();
+      running = ctl[3] != 0.0;
+    }
+    if (!skato_quad) break;
+    __syncthreads();
+    if (lane == 0) {
+      ctl[0] = qm.result;
+      ctl[1] = (double)qm.status;
+    }
+    __syncthreads();
+    integral = ctl[0];
+    status = (int)ctl[1];
+    __syncthreads();
+    if (pass == 0) {
+      res.skato_qags_status = status;
+      if (status == 0) break;
+    } else {
+      res.skato_qags_status = res.skato_qags_status * 100 + status;
+    }
+  }
+  skat_p = __shfl(skat_p, 62, 64);
+  single_p = __shfl(single_p, 63, 64);
+  if (do_skat) {
+    res.skat_ok = 1;
+    res.skat_Q = gs.skat_Q;
+    res.skat_p = skat_p;
+  }
+  if (do_skato && gs.skato_single) {
+    res.skato_ok = 1;
+    res.skato_Q = gs.Qs[0];
+    res.skato_rho = 0.0;
+    res.skato_p = single_p;
+  } else if (do_skato) {
     res.skato_qags_neval = neval;
     double rho = (minIndex == 10) ? 0.999 : 1.0 * minIndex / 10;
     if (rho >= 0.999) rho = 1.;

@@ -270,11 +270,43 @@ RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, doub
   P->valid = !st.over;
 }
 
-// P[ sum_j lb_j chi²_1 < c ]; *ifault as in the reference (0 ok, 1 accuracy, 2 round-off, 3 invalid,
-// 4 search overran lim).  nterms_out (optional) = number of integrand terms evaluated.
+// One term of the inversion integral (the body of qfc.c:250-268 for term k, main integration).
+RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
+                        double* t2) {
+  const double inpi = interv / kDaviesPi;
+  const double u = (k + 0.5) * interv;
+  double sum1 = -2.0 * u * c, sum2 = fabs(sum1);
+  double sum3 = -0.5 * sigsq * (u * u);
+  for (int j = r - 1; j >= 0; j--) {
+    const double x = 2.0 * lb[j] * u;
+    const double y = x * x;
+    sum3 = sum3 - 0.25 * dv_log1(y, true);
+    const double z = atan(x);
+    sum1 = sum1 + z;
+    sum2 = sum2 + fabs(z);
+  }
+  const double x = inpi * dv_exp1(sum3) / u;
+  *t1 = sin(0.5 * sum1) * x;
+  *t2 = 0.5 * sum2 * x;
+}
+
+// qf() split at its main integration so that the GPU can spread the nt+1 independent terms of MANY
+// evaluation points over the lanes of a wave (gene_pvalue_kernel) while keeping the reference's
+// summation order:  front -> { for k = nt..0: intl += term1(k); ersm += term2(k) } -> back.
+struct DaviesTask {
+  bool need_main;   // the main integration has to run: nt, intv, sigsq, c are set
+  int nt;
+  double intv, sigsq, c, acc;
+  double intl, ersm;  // running sums (non-zero when an auxiliary integration ran)
+  double qfval;       // result when !need_main
+  int fault;
+  bool over;
+  double nterms;      // terms already evaluated (auxiliary integrations)
+};
+
 // `pre` (optional) = davies_prelude() of the same coefficients: the c-independent searches are replayed.
-RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
-                        double* nterms_out, const DaviesPrelude* pre = nullptr) {
+RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
+                            const DaviesPrelude* pre, DaviesTask* task) {
   if (pre && !pre->valid) pre = nullptr;
   DaviesState st;
   st.lb = lb;
@@ -287,9 +319,12 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
   st.fail = false;
   st.intl = 0.0;
   st.ersm = 0.0;
-  *ifault = 0;
-  double nterms = 0.0;
-  double qfval = -1.0;
+  task->need_main = false;
+  task->fault = 0;
+  task->qfval = -1.0;
+  task->nterms = 0.0;
+  task->c = c;
+  task->acc = acc;
   double acc1 = acc;
   double xlim = (double)lim;
   st.sigsq = 0.0;
@@ -309,10 +344,10 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
   bool done = false;
   double utx = 0, up = 0, un = 0, intv = 0, xnt = 0;
   if (sd == 0.0) {
-    qfval = (c > 0.0) ? 1.0 : 0.0;
+    task->qfval = (c > 0.0) ? 1.0 : 0.0;
     done = true;
   } else if (st.lmin == 0.0 && st.lmax == 0.0) {
-    *ifault = 3;
+    task->fault = 3;
     done = true;
   }
   if (!done) {
@@ -354,7 +389,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
       const double d1 = cut_up - c;
       if (st.over) break;
       if (d1 < 0.0) {
-        qfval = 1.0;
+        task->qfval = 1.0;
         done = true;
         break;
       }
@@ -369,7 +404,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
       const double d2 = c - cut_un;
       if (st.over) break;
       if (d2 < 0.0) {
-        qfval = 0.0;
+        task->qfval = 0.0;
         done = true;
         break;
       }
@@ -378,7 +413,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
       const double xntm = 3.0 / sqrt(acc1);
       if (xnt > xntm * 1.5) {
         if (xntm > xlim) {
-          *ifault = 1;
+          task->fault = 1;
           done = true;
           break;
         }
@@ -398,7 +433,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
         }
         acc1 = .67 * acc1;
         dv_integrate(st, ntm, intv1, tausq, false);
-        nterms += ntm + 1;
+        task->nterms += ntm + 1;
         xlim = xlim - xntm;
         st.sigsq = st.sigsq + tausq;
         sig_changed = true;
@@ -410,22 +445,53 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
     }
     if (!done && !st.over) {
       if (xnt > xlim) {
-        *ifault = 1;
+        task->fault = 1;
       } else {
-        const int nt = (int)floor(xnt + 0.5);
-        dv_integrate(st, nt, intv, 0.0, true);
-        nterms += nt + 1;
-        qfval = 0.5 - st.intl;
-        const double up2 = st.ersm;
-        const double x = up2 + acc / 10.0;
-        if (1.0 * x == 1.0 * up2 || 2.0 * x == 2.0 * up2 || 4.0 * x == 4.0 * up2 || 8.0 * x == 8.0 * up2)
-          *ifault = 2;
+        task->need_main = true;
+        task->nt = (int)floor(xnt + 0.5);
+        task->intv = intv;
+        task->sigsq = st.sigsq;
       }
     }
   }
-  if (st.over) *ifault = 4;
-  if (nterms_out) *nterms_out = nterms;
+  task->intl = st.intl;
+  task->ersm = st.ersm;
+  task->over = st.over;
+  if (st.over) {
+    task->fault = 4;
+    task->need_main = false;
+  }
+}
+
+// after the main integration: qfval and the round-off test (qfc.c:424-431)
+RVT_HD double davies_qf_back(const DaviesTask& task, double intl, double ersm, int* ifault) {
+  *ifault = task.fault;
+  if (!task.need_main) return task.qfval;
+  const double qfval = 0.5 - intl;
+  const double up2 = ersm;
+  const double x = up2 + task.acc / 10.0;
+  if (1.0 * x == 1.0 * up2 || 2.0 * x == 2.0 * up2 || 4.0 * x == 4.0 * up2 || 8.0 * x == 8.0 * up2) *ifault = 2;
   return qfval;
+}
+
+// P[ sum_j lb_j chi²_1 < c ]; *ifault as in the reference (0 ok, 1 accuracy, 2 round-off, 3 invalid,
+// 4 search overran lim).  nterms_out (optional) = number of integrand terms evaluated.
+RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
+                        double* nterms_out, const DaviesPrelude* pre = nullptr) {
+  DaviesTask task;
+  davies_qf_front(lb, th, r, c, lim, acc, pre, &task);
+  double intl = task.intl, ersm = task.ersm;
+  if (task.need_main) {
+    for (int k = task.nt; k >= 0; k--) {
+      double t1, t2;
+      davies_term(lb, r, task.c, task.sigsq, task.intv, k, &t1, &t2);
+      intl = intl + t1;
+      ersm = ersm + t2;
+    }
+    task.nterms += task.nt + 1;
+  }
+  if (nterms_out) *nterms_out = task.nterms;
+  return davies_qf_back(task, intl, ersm, ifault);
 }
 
 // ---- Liu et al. moment matching through the non-central chi-square  -----------------------------

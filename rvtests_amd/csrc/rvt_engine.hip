@@ -550,7 +550,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   {
     Scope sc(c, 3);
-    const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 + 16;
+    const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
+                        sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
     hipLaunchKernelGGL(gene_pvalue_kernel, dim3(n), dim3(64), smem, c->stream, d_desc, tests);
   }
   HIP_TRY(c, hipGetLastError());

@@ -53,7 +53,7 @@ class Timing(C.Structure):
 
 
 def library_path():
-    return os.path.join(CSRC, LIBNAME)
+    return os.environ.get("RVT_LIBRARY", os.path.join(CSRC, LIBNAME))
 
 
 def build_library(force=False, verbose=False):
