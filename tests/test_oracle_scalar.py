@@ -1,0 +1,90 @@
+"""CPU: the oracle's scalar functions AND the device algorithms (host harness build of the RVT_HD code) against
+the GSL 1.16 golden vectors (tests/golden/gsl_scalar.json, generated from the tarball the reference vendors)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hc
+import orc
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gsl_scalar.json")))["cases"]
+
+
+def _rel(a, b):
+    return abs(a - b) / abs(b) if b != 0 else abs(a)
+
+
+@pytest.mark.parametrize("op", ["beta", "chisqQ", "chisqP", "chisqQinv", "chisqpdf"])
+def test_special_functions_match_gsl(op):
+    L, H = orc.lib(), hc.lib()
+    fo = {"beta": L.orc_beta_pdf, "chisqQ": L.orc_chisq_Q, "chisqP": L.orc_chisq_P, "chisqQinv": L.orc_chisq_Qinv,
+          "chisqpdf": L.orc_chisq_pdf}[op]
+    fh = {"beta": H.hc_beta_pdf, "chisqQ": H.hc_chisq_Q, "chisqP": H.hc_chisq_P, "chisqQinv": H.hc_chisq_Qinv,
+          "chisqpdf": H.hc_chisq_pdf}[op]
+    n = 0
+    for c in GOLD:
+        if c["op"] != op:
+            continue
+        ref = c["value"]
+        assert _rel(fo(*c["args"]), ref) < 2e-12, (op, c["args"])
+        assert _rel(fh(*c["args"]), ref) < 2e-12, (op, c["args"])
+        n += 1
+    assert n > 50
+
+
+def test_qags_matches_gsl():
+    """Same abscissae => same number of intervals; results equal to rounding (bit-equal for libm-only integrands)."""
+    L, H = orc.lib(), hc.lib()
+    n = 0
+    for c in GOLD:
+        if c["op"] != "qags":
+            continue
+        a = c["args"]
+        for fn in (L.orc_qags_builtin, H.hc_qags_builtin):
+            r, e, ne = C.c_double(), C.c_double(), C.c_int()
+            st = fn(int(a[0]), a[1], a[2], a[3], a[4], a[5], int(a[6]), C.byref(r), C.byref(e), C.byref(ne))
+            assert st == c["status"]
+            assert ne.value == 21 * (2 * c["intervals"] - 1)
+            assert abs(r.value - c["result"]) <= 1e-12 * abs(c["result"])
+            # the error ESTIMATE amplifies 1e-15 differences of the integrand (lgamma) when it is itself ~1e-13
+            assert abs(e.value - c["abserr"]) <= 1e-6 * abs(c["abserr"]) + 1e-13
+        n += 1
+    assert n >= 10
+
+
+def test_oracle_vs_scipy():
+    from scipy import stats
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    for _ in range(500):
+        df = float(rng.uniform(0.5, 60))
+        x = float(df * 10 ** rng.uniform(-2, 1))
+        assert _rel(L.orc_chisq_Q(x, df), stats.chi2.sf(x, df)) < 1e-11
+        q = float(rng.uniform(1e-10, 0.99))
+        assert _rel(L.orc_chisq_Qinv(q, df), stats.chi2.isf(q, df)) < 1e-9
+
+
+def test_glibc_rand_emulator_matches_libc():
+    libc = C.CDLL("libc.so.6")
+    L = orc.lib()
+    for seed in (1, 12345):
+        libc.srand(seed)
+        L.orc_rand_seed(seed)
+        assert all(libc.rand() == L.orc_rand() for _ in range(20000))
+
+
+def test_eigen_solvers_agree_with_lapack():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 17, 50, 96):
+        B = rng.normal(size=(n + 3, n))
+        A = B.T @ B
+        if n > 4:
+            A[:, 1] = A[:, 0]
+            A[1, :] = A[0, :]  # rank deficient
+        w0 = np.linalg.eigvalsh(A)
+        scale = max(abs(w0).max(), 1e-300)
+        assert np.max(np.abs(orc.sym_eigvals(A) - w0)) < 1e-12 * scale
+        assert np.max(np.abs(hc.sym_eigvals(A) - w0)) < 1e-12 * scale
