@@ -1,0 +1,200 @@
+// rvtests_amd — host side (C++), mirror of the reference's plugin surface for the hot path.
+//
+// Same class names, constructor arguments, method names and output formats as the reference, so that these
+// classes can be dropped into src/ModelManager.cpp in place of the CPU ones:
+//   ModelFitter   src/ModelFitter.h:17-75     fit / writeHeader / writeOutput / writeFootnote / reset / setParameter
+//   ModelParser   src/ModelParser.{h,cpp}     "name[k=v:k2=v2]", case-folded, ':' or ',' separated
+//   ModelManager  src/ModelManager.cpp:26-44,99-103,168-198,273-297   create(type, "a[..],b")
+//   SkatTest      src/Model.h:2612-2772       "Q\tPvalue"            %g
+//   SkatOTest     src/Model.h:2774-2889       "Q\trho\tPvalue"       %g
+//   CMCTest       src/Model.h:807-907         "NonRefSite\tPvalue"   Result / floatToString (6 significant digits)
+//   ZegginiTest   src/Model.h:1170-1242       "Pvalue"
+// Every fit() goes through the C ABI of include/rvtests_amd.h; nothing here computes statistics on the CPU.
+//
+// Inside the real rvtests tree the adapters read the reference's own `DataConsolidator`, `Matrix`, `FileWriter`
+// and `Result`.  To keep this repository self-contained (and testable without Eigen) the few members the hot
+// path touches are abstracted behind `GeneData` / `TextSink` below; INTEGRATION.md lists the one-line mapping
+// of each onto the reference types.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/rvtests_amd.h"
+
+namespace rvt_host {
+
+// ---- what fit() may read: DataConsolidator getters (src/DataConsolidator.h:126-137,223-224) -------------
+struct GeneData {
+  int64_t N = 0;
+  int M = 0;
+  const double* genotype = nullptr;   // dc->getGenotype(): imputed, unflipped, N x M column-major
+  const double* phenotype = nullptr;  // dc->getPhenotype(): N
+  const double* covariate = nullptr;  // dc->getCovariate(): N x ncov column-major, NO intercept
+  int ncov = 0;
+  std::vector<double> markerFrequency;  // dc->getMarkerFrequency(col) for col < M
+  bool phenotypeUpdated = false, covariateUpdated = false;  // dc->isPhenotypeUpdated() / isCovariateUpdated()
+  int64_t serial = 0;                 // increases with every dc.consolidate() (new gene)
+};
+
+// ---- FileWriter stand-in (base/IO.h FileWriter::write / printf) -------------------------------------------
+struct TextSink {
+  std::string text;
+  void write(const std::string& s) { text += s; }
+  void write(const char* s) { text += s; }
+};
+
+// site columns the caller passes to writeHeader/writeOutput (Result::writeHeaderTab / writeValueTab)
+struct SiteInfo {
+  std::vector<std::pair<std::string, std::string>> kv;
+  std::string headerTab() const {
+    std::string s;
+    for (auto& p : kv) s += p.first + "\t";
+    return s;
+  }
+  std::string valueTab() const {
+    std::string s;
+    for (auto& p : kv) s += p.second + "\t";
+    return s;
+  }
+};
+
+std::string floatToString(double v);  // base/TypeConversion.h:100-105 (6 significant digits)
+std::string formatG(double v);        // printf("%g")
+
+// ---- ModelParser --------------------------------------------------------------------------------------------
+class ModelParser {
+ public:
+  int parse(const std::string& s);
+  const std::string& getName() const { return name; }
+  bool hasTag(const std::string& tag) const;
+  const char* value(const std::string& tag) const;
+  size_t size() const { return param.size(); }
+  const ModelParser& assign(const std::string& tag, double* v, double def) const;
+  const ModelParser& assign(const std::string& tag, int* v, int def) const;
+  const ModelParser& assign(const std::string& tag, bool* v, bool def) const;
+
+ private:
+  std::string name;
+  std::map<std::string, std::string> param;
+};
+
+// ---- the engine shared by all GPU-backed models of one run ---------------------------------------------------
+// One rvt_ctx per process/GPU.  The null model is installed once (and again when the caller flags an updated
+// phenotype/covariate); each new gene is submitted ONCE with the union of the registered tests, whichever model's
+// fit() sees it first.
+class GpuBroker {
+ public:
+  static GpuBroker& instance();
+  int ensureContext(int device);
+  void registerTests(uint32_t mask, const rvt_params& p);
+  // Returns the result of the gene currently held by `gd` (submits + collects on first use). nullptr on error.
+  const rvt_gene_result* resultFor(const GeneData& gd, bool binary, std::string* err);
+  void shutdown();
+  // null model: fitted on the host by the caller-supplied routine (the reference's LinearRegression /
+  // LogisticRegression in the real tree); see INTEGRATION.md
+  typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
+                            double* sigma2);
+  void setNullFitter(NullFitter f) { fitter = f; }
+
+ private:
+  rvt_ctx* ctx = nullptr;
+  uint32_t tests = 0;
+  rvt_params params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+  bool haveNull = false;
+  int64_t curSerial = -1;
+  rvt_gene_result cur{};
+  bool curOk = false;
+  NullFitter fitter = nullptr;
+  int installNull(const GeneData& gd, bool binary, std::string* err);
+};
+
+// ---- ModelFitter ---------------------------------------------------------------------------------------------------
+class ModelFitter {
+ public:
+  virtual int fit(GeneData* dc) = 0;
+  virtual void writeHeader(TextSink* fp, const SiteInfo& siteInfo) = 0;
+  virtual void writeOutput(TextSink* fp, const SiteInfo& siteInfo) = 0;
+  virtual void writeFootnote(TextSink*) {}
+  virtual int setParameter(const ModelParser&) { return 0; }
+  virtual void reset() {}
+  virtual ~ModelFitter() {}
+  const std::string& getModelName() const { return modelName; }
+  bool isBinaryOutcome() const { return binaryOutcome; }
+  void setBinaryOutcome() { binaryOutcome = true; }
+  void setQuantitativeOutcome() { binaryOutcome = false; }
+
+ protected:
+  std::string modelName = "UninitializedModel";
+  bool binaryOutcome = false;
+  const rvt_gene_result* res = nullptr;
+  std::string lastError;
+};
+
+class SkatTest : public ModelFitter {
+ public:
+  SkatTest(int nPerm, double alpha, double beta1, double beta2);
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool fitOK = false;
+  bool usePermutation;
+};
+
+class SkatOTest : public ModelFitter {
+ public:
+  SkatOTest(double beta1, double beta2);
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool fitOK = false;
+};
+
+class CMCTest : public ModelFitter {
+ public:
+  CMCTest();
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool fitOK = false;
+};
+
+class ZegginiTest : public ModelFitter {
+ public:
+  ZegginiTest();
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool fitOK = false;
+};
+
+// ---- ModelManager::create -----------------------------------------------------------------------------------------
+class ModelManager {
+ public:
+  ~ModelManager();
+  // type: "burden" | "kernel"; modelList: "cmc,zeggini" or "skat[nPerm=0:beta1=1],skato"
+  int create(const std::string& type, const std::string& modelList);
+  const std::vector<ModelFitter*>& getModel() const { return model; }
+  void setBinaryOutcome();
+  void setQuantitativeOutcome();
+  // "<prefix>.<ModelName>.assoc" names (src/ModelManager.cpp:285-297)
+  std::vector<std::string> outputNames(const std::string& prefix) const;
+  std::string lastError;
+
+ private:
+  std::vector<ModelFitter*> model;
+};
+
+}  // namespace rvt_host

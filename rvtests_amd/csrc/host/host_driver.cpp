@@ -1,0 +1,182 @@
+// rvtests_amd — minimal host driver reproducing the reference's group-mode gene loop for the GPU models
+// (src/Main.cpp:1207-1256: for each gene { consolidate; for each model { reset(); fit(&dc); writeOutput(); } })
+// on pre-consolidated inputs read from a binary file.  Used by tests/test_host_driver.py; the full VCF front
+// end is out of scope (SURVEY §8f "next" #1).
+//
+//   host_driver <input.bin> <kernel list, e.g. "skat[nPerm=0],skato" or "-"> <burden list, e.g. "cmc,zeggini" or "-">
+//
+// input.bin: int64 N; int32 ncov, binary, ngenes; double y[N]; double cov[N*ncov] (column-major);
+//            per gene: int32 M; double af[M]; double G[N*M] (column-major, imputed, unflipped)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ModelFitterGpu.h"
+
+using namespace rvt_host;
+
+// Null models of the caller.  In the real rvtests tree these are LinearRegression::FitLinearModel
+// (regression/LinearRegression.cpp:20-69) and LogisticRegression::FitLogisticModel (:279-336); this driver
+// carries a small equivalent so that it is self-contained.
+static bool chol_solve(std::vector<double> A, int d, std::vector<double>& b) {
+  for (int j = 0; j < d; ++j) {
+    double s = A[j * d + j];
+    for (int k = 0; k < j; ++k) s -= A[j * d + k] * A[j * d + k];
+    if (!(s > 0)) return false;
+    const double dj = std::sqrt(s);
+    A[j * d + j] = dj;
+    for (int i = j + 1; i < d; ++i) {
+      double t = A[i * d + j];
+      for (int k = 0; k < j; ++k) t -= A[i * d + k] * A[j * d + k];
+      A[i * d + j] = t / dj;
+    }
+  }
+  for (int i = 0; i < d; ++i) {
+    double t = b[i];
+    for (int k = 0; k < i; ++k) t -= A[i * d + k] * b[k];
+    b[i] = t / A[i * d + i];
+  }
+  for (int i = d - 1; i >= 0; --i) {
+    double t = b[i];
+    for (int k = i + 1; k < d; ++k) t -= A[k * d + i] * b[k];
+    b[i] = t / A[i * d + i];
+  }
+  return true;
+}
+
+static int null_fitter(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
+                       double* sigma2) {
+  std::vector<double> beta(d, 0.0), p(N);
+  auto xtwx = [&](const double* w, std::vector<double>& A) {
+    A.assign((size_t)d * d, 0.0);
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        double s = 0;
+        for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * (w ? w[i] : 1.0) * X[(size_t)b * N + i];
+        A[a * d + b] = s;
+      }
+  };
+  if (!binary) {
+    std::vector<double> A, b(d);
+    xtwx(nullptr, A);
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * y[i];
+      b[a] = s;
+    }
+    if (!chol_solve(A, d, b)) return -1;
+    double rss = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      double pr = 0;
+      for (int a = 0; a < d; ++a) pr += X[(size_t)a * N + i] * b[a];
+      res[i] = y[i] - pr;
+      rss += res[i] * res[i];
+    }
+    *sigma2 = rss / (double)N;
+    for (int64_t i = 0; i < N; ++i) v[i] = *sigma2;
+    return 0;
+  }
+  int rounds = 0;
+  double last = -99999, cur = -9999;
+  while (rounds < 100) {
+    for (int64_t i = 0; i < N; ++i) {
+      double e = 0;
+      for (int a = 0; a < d; ++a) e += X[(size_t)a * N + i] * beta[a];
+      p[i] = 1.0 / (1.0 + std::exp(-e));
+      v[i] = p[i] * (1.0 - p[i]);
+    }
+    std::vector<double> A, r(d);
+    xtwx(v, A);
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * (y[i] - p[i]);
+      r[a] = s;
+    }
+    if (!chol_solve(A, d, r)) return -1;
+    for (int a = 0; a < d; ++a) beta[a] += r[a];
+    double ll = 0;
+    for (int64_t i = 0; i < N; ++i) ll += y[i] * std::log(p[i]) + (1. - y[i]) * std::log(1.0 - p[i]);
+    cur = -2.0 * ll;
+    if (rounds > 1 && std::fabs(cur - last) < 1e-3) {
+      rounds = 0;
+      break;
+    }
+    if (std::fpclassify(cur) != FP_NORMAL) return -1;
+    last = cur;
+    rounds++;
+  }
+  if (rounds == 100) return -1;
+  for (int64_t i = 0; i < N; ++i) res[i] = y[i] - p[i];
+  *sigma2 = 1.0;
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    fprintf(stderr, "usage: host_driver input.bin <kernel list|-> <burden list|->\n");
+    return 2;
+  }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  int64_t N;
+  int32_t ncov, binary, ngenes;
+  if (fread(&N, 8, 1, f) != 1 || fread(&ncov, 4, 1, f) != 1 || fread(&binary, 4, 1, f) != 1 ||
+      fread(&ngenes, 4, 1, f) != 1)
+    return 2;
+  std::vector<double> y(N), cov((size_t)N * ncov);
+  if (fread(y.data(), 8, N, f) != (size_t)N) return 2;
+  if (ncov && fread(cov.data(), 8, (size_t)N * ncov, f) != (size_t)N * ncov) return 2;
+
+  ModelManager mm;
+  if (std::string(argv[2]) != "-" && mm.create("kernel", argv[2])) {
+    fprintf(stderr, "%s\n", mm.lastError.c_str());
+    return 1;
+  }
+  if (std::string(argv[3]) != "-" && mm.create("burden", argv[3])) {
+    fprintf(stderr, "%s\n", mm.lastError.c_str());
+    return 1;
+  }
+  if (binary)
+    mm.setBinaryOutcome();
+  else
+    mm.setQuantitativeOutcome();
+  GpuBroker::instance().setNullFitter(null_fitter);
+  const auto& models = mm.getModel();
+  std::vector<TextSink> outs(models.size());
+  SiteInfo site;
+  site.kv = {{"Range", ""}, {"N_INFORMATIVE", std::to_string(N)}, {"NumVar", ""}, {"NumPolyVar", ""}};
+  for (size_t m = 0; m < models.size(); ++m) models[m]->writeHeader(&outs[m], site);
+
+  GeneData dc;
+  dc.N = N;
+  dc.phenotype = y.data();
+  dc.covariate = cov.data();
+  dc.ncov = ncov;
+  std::vector<double> G;
+  for (int g = 0; g < ngenes; ++g) {
+    int32_t M;
+    if (fread(&M, 4, 1, f) != 1) return 2;
+    dc.markerFrequency.resize(M);
+    G.resize((size_t)N * M);
+    if (fread(dc.markerFrequency.data(), 8, M, f) != (size_t)M) return 2;
+    if (fread(G.data(), 8, (size_t)N * M, f) != (size_t)N * M) return 2;
+    dc.M = M;
+    dc.genotype = G.data();
+    dc.serial = g + 1;  // dc.consolidate(...) happened
+    site.kv[0].second = "gene" + std::to_string(g);
+    site.kv[2].second = std::to_string(M);
+    for (size_t m = 0; m < models.size(); ++m) {
+      models[m]->reset();
+      models[m]->fit(&dc);
+      models[m]->writeOutput(&outs[m], site);
+    }
+  }
+  fclose(f);
+  const auto names = mm.outputNames("out");
+  for (size_t m = 0; m < models.size(); ++m) printf("== %s\n%s", names[m].c_str(), outs[m].text.c_str());
+  GpuBroker::instance().shutdown();
+  return 0;
+}
