@@ -93,10 +93,10 @@ def cpu_baseline(G_host, af, X, y, res, v, n_threads=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--samples", type=int, default=500000)
-    ap.add_argument("--genes", type=int, default=64, help="genes per step per GPU")
+    ap.add_argument("--genes", type=int, default=256, help="genes per step per GPU")
     ap.add_argument("--m-lo", type=int, default=20)
     ap.add_argument("--m-hi", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +142,11 @@ def main():
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
     blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi)
     torch.cuda.synchronize()
-    batch = eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests)
+    # pre-packed batches over the same resident blocks: the engine keeps up to four batches in flight (one HIP
+    # stream each), so the latency-bound tail of step i overlaps the bandwidth-bound head of step i+1
+    NSLOT = 4  # RVT_MAX_INFLIGHT
+    batches = [eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests) for _ in range(NSLOT)]
+    batch = batches[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -150,25 +154,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = [torch.empty((args.genes, 4), dtype=torch.float64, device=dev) for _ in range(world)] if (
-        world > 1 and rank == 0) else None
+    from rvtests_amd import shard
+    counts = [args.genes] * world
+    inflight = []
 
-    def step():
-        eng.launch(batch)
+    def retire(b):
+        """step finished on this rank: C2 = gather its per-gene records on rank 0 (gene order)"""
+        if world > 1:
+            shard.gather_records(dist, shard.records_from_results(b["out"]), counts, device=dev, dst=0)
+
+    def run_steps(k):
+        for i in range(k):
+            b = batches[i % NSLOT]
+            if len(inflight) == NSLOT:      # launching into a busy slot first finishes the oldest batch
+                eng.wait_oldest()
+                retire(inflight.pop(0))
+            eng.launch(b)
+            inflight.append(b)
         eng.sync()
-        if world > 1:  # collective C2: per-gene statistics only
-            rec = torch.tensor([[r.skat_p, r.skato_p, r.cmc_p, r.zeg_p] for r in batch["out"]], dtype=torch.float64,
-                               device=dev)
-            dist.gather(rec, gathered, dst=0)
+        while inflight:
+            retire(inflight.pop(0))
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     eng.set_profiling(True)
     eng.timing(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     tm = eng.timing(reset=True)
@@ -181,7 +193,7 @@ def main():
     if rank == 0:
         total_genes = world * args.genes * args.steps
         value = total_genes / elapsed
-        out0 = batch["out"]
+        out0 = batches[(args.steps - 1) % NSLOT]["out"] if args.steps else batch["out"]
         ok = sum(1 for r in out0 if r.skat_ok and r.skato_ok)
         # roofline of the sufficient-statistics kernel (the contraction over N): algorithmic bytes / measured time
         ms_k2 = tm.ms_suffstat / max(tm.n_suffstat_launches, 1)

@@ -39,6 +39,7 @@ extern "C" {
 #define RVT_E_TOO_LARGE (-5) /* gene wider than RVT_MAX_VARIANTS */
 
 #define RVT_MAX_VARIANTS 1024
+#define RVT_MAX_INFLIGHT 4 /* batches that rvt_run_blocks_async keeps in flight */
 
 /* test selection bitmask (which ModelFitter::fit bodies to run) */
 #define RVT_TEST_SKAT 1u    /* --kernel skat   : SkatTest    src/Model.h:2612-2772 */
@@ -136,12 +137,15 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * Blocks until the results are in out[0..n_genes).  */
 int rvt_run_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const double* af,
                    const int64_t* gene_ids, uint32_t tests, const rvt_params* params, rvt_gene_result* out);
-/* Same, but only enqueue on the engine's stream; results are valid after rvt_sync(). `out` must stay
- * alive until then. */
+/* Same, but only enqueue; up to RVT_MAX_INFLIGHT batches may be in flight (each on its own HIP stream, so that
+ * the latency-bound tail of one overlaps the bandwidth-bound head of the next).  A batch's records are valid after
+ * rvt_sync() (everything) or rvt_wait_oldest() (the batch launched first); launching one more first
+ * finishes the oldest one.  `out` must stay alive until then. */
 int rvt_run_blocks_async(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const double* af,
                          const int64_t* gene_ids, uint32_t tests, const rvt_params* params,
                          rvt_gene_result* out);
 int rvt_sync(rvt_ctx* ctx);
+int rvt_wait_oldest(rvt_ctx* ctx);
 
 /* ---- streaming interface used by the ModelFitter adapters ------------------------------------------
  * rvt_submit_gene copies G (host, N x M column-major, imputed, unflipped) before returning — the

@@ -62,6 +62,18 @@ struct NullDev {
 // has no barriers; partial tiles go to a workspace and are summed in a fixed order by gene_stats_kernel.
 // Only tiles with col-tile >= row-tile are computed (G'DG is symmetric).
 // =====================================================================================================
+// v_min_f64 / v_max_f64 without the canonicalisation pre-op fmin()/fmax() would add (inputs are finite genotypes)
+__device__ __forceinline__ double raw_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double raw_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int MT, int CT, bool WEIGHTED, bool GUARD>
 __device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], const double* vptr, long long off,
                                               long long nvalid, d4_t (&acc)[MT][CT], double (&cs)[MT],
@@ -92,12 +104,12 @@ __device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], c
       cs[c] += g;
       if (GUARD) {
         if ((long long)l < nvalid) {
-          cmn[c] = fmin(cmn[c], g);
-          cmx[c] = fmax(cmx[c], g);
+          cmn[c] = raw_min(cmn[c], g);
+          cmx[c] = raw_max(cmx[c], g);
         }
       } else {
-        cmn[c] = fmin(cmn[c], g);
-        cmx[c] = fmax(cmx[c], g);
+        cmn[c] = raw_min(cmn[c], g);
+        cmx[c] = raw_max(cmx[c], g);
       }
       const unsigned long long bge = __ballot(g >= 1.0);
       const unsigned long long ble = __ballot(g <= 1.0);
@@ -121,6 +133,18 @@ __device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], c
       }
     }
   }
+  if (!GUARD) {
+    // One wave per SIMD: the VALU work of this step (column statistics, ballots) only overlaps the matrix pipe
+    // if it is issued BETWEEN the MFMAs (each occupies the pipe 64 cycles).  Ask the scheduler for
+    // "1 MFMA, then a handful of VALU" groups instead of an MFMA cluster followed by a VALU cluster.
+    constexpr int kMfma = 4 * (MT * CT - MT * (MT - 1) / 2);
+    constexpr int kValuPer = (MT * 4 * 9 + kMfma - 1) / kMfma + 1;
+#pragma unroll
+    for (int i = 0; i < kMfma; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);  // a few VALU
+    }
+  }
 }
 
 template <int CT>
@@ -136,7 +160,7 @@ __device__ __forceinline__ void suffstat_load(const double* const (&colp)[CT], l
   }
 }
 
-template <int MT, int CT, bool WEIGHTED>
+template <int MT, int CT, bool WEIGHTED, int DEPTH>
 __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev& nd, long long N, long long ld, int d) {
   const int lane = threadIdx.x & 63;
   const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -179,24 +203,54 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
   unsigned long long* mle = gd.masks + nsteps * MT * 4;
   // steps whose 16 samples are all < N need no guard
   const long long full_steps = N >> 4;
-  double f[CT][4], fn[CT][4];
-  if (s_begin < s_end) suffstat_load<CT>(colp, s_begin * 16 + koff, f);
-  for (long long s = s_begin; s < s_end; ++s) {
-    const long long off = s * 16 + koff;
-    if (s + 1 < s_end) suffstat_load<CT>(colp, off + 16, fn);
-    if (s < full_steps) {
-      suffstat_step<MT, CT, WEIGHTED, false>(colp, nd.v, off, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
-                                             mle + s * MT * 4, lane);
+  // Register ring of DEPTH step buffers: while step s is multiplied, the loads of the next DEPTH-1 steps are in
+  // flight (one wave per SIMD at these register counts, so memory-level parallelism has to come from the wave
+  // itself: (DEPTH-1) x CT x 2 KiB outstanding per wave).  DEPTH = 3 for genes up to 64 variants, 2 above.
+  // Steps whose 16 samples are all < N run unguarded in a branch-free loop (prefetch indices are clamped instead
+  // of tested); the single possibly-partial last step of the gene is handled after the loop.
+  const long long s_lim = (s_end < full_steps) ? s_end : full_steps;
+  auto step = [&](double (&f)[CT][4], long long s) {
+    suffstat_step<MT, CT, WEIGHTED, false>(colp, nd.v, s * 16 + koff, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
+                                           mle + s * MT * 4, lane);
+  };
+  auto load = [&](double (&f)[CT][4], long long s) {
+    const long long sc = (s < s_lim) ? s : s_lim - 1;  // clamp: a redundant reload near the end, never out of range
+    suffstat_load<CT>(colp, sc * 16 + koff, f);
+  };
+  long long s = s_begin;
+  if (s < s_lim) {
+    if constexpr (DEPTH == 3) {
+      double f0[CT][4], f1[CT][4], f2[CT][4];
+      load(f0, s);
+      load(f1, s + 1);
+      for (; s + 2 < s_lim; s += 3) {
+        load(f2, s + 2);
+        step(f0, s);
+        load(f0, s + 3);
+        step(f1, s + 1);
+        load(f1, s + 4);
+        step(f2, s + 2);
+      }
+      if (s < s_lim) step(f0, s);  // 0, 1 or 2 steps left; their data is already in f0 / f1
+      if (s + 1 < s_lim) step(f1, s + 1);
     } else {
-      suffstat_step<MT, CT, WEIGHTED, true>(colp, nd.v, off, N - off, acc, cs, cmn, cmx, f, mge + s * MT * 4,
-                                            mle + s * MT * 4, lane);
+      double f0[CT][4], f1[CT][4];
+      load(f0, s);
+      for (; s + 1 < s_lim; s += 2) {
+        load(f1, s + 1);
+        step(f0, s);
+        load(f0, s + 2);
+        step(f1, s + 1);
+      }
+      if (s < s_lim) step(f0, s);
     }
-    if (s + 1 < s_end) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int l = 0; l < 4; ++l) f[c][l] = fn[c][l];
-    }
+  }
+  if (s_end > full_steps && full_steps >= s_begin) {  // the gene's last, partially filled step
+    double fg[CT][4];
+    const long long sg = full_steps, off = sg * 16 + koff;
+    suffstat_load<CT>(colp, off, fg);
+    suffstat_step<MT, CT, WEIGHTED, true>(colp, nd.v, off, N - off, acc, cs, cmn, cmx, fg, mge + sg * MT * 4,
+                                          mle + sg * MT * 4, lane);
   }
   // ---- write this wave's partial tiles: element (row, col) -> parts[row*Cp + col] --------------------
   double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
@@ -232,33 +286,16 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
 }
 
 
-// One launch covers every gene of the batch: the tile configuration (MT row tiles x CT column tiles) is a
-// property of the gene, dispatched per workgroup.  Grid = (wave-parts / 4, genes).
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes, NullDev nd, long long N,
-                                                          long long ld, int d) {
+// One kernel per tile configuration (MT row tiles x CT column tiles), so each gets its own register allocation:
+// up to 59 variants (MT*CT <= 16) accumulators + load ring (3 deep up to CT = 3, else 2 deep) fit the 256 registers
+// that allow two waves per SIMD, wider genes run one wave per SIMD; the engine launches the classes of a batch back to back.
+// Grid = (wave-parts / 4, genes of this class).
+template <int MT, int CT, bool WEIGHTED>
+__global__ __launch_bounds__(256, (MT * CT <= 16) ? 2 : 1) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes,
+                                                                                  NullDev nd, long long N,
+                                                                                  long long ld, int d) {
   const GeneDesc gd = genes[blockIdx.y];
-  switch (gd.MT * 8 + gd.CT) {
-#define RVT_TILE_CASE(mt, ct) \
-  case mt * 8 + ct:           \
-    suffstat_body<mt, ct, WEIGHTED>(gd, nd, N, ld, d); \
-    break
-    RVT_TILE_CASE(1, 1);
-    RVT_TILE_CASE(1, 2);
-    RVT_TILE_CASE(2, 2);
-    RVT_TILE_CASE(2, 3);
-    RVT_TILE_CASE(3, 3);
-    RVT_TILE_CASE(3, 4);
-    RVT_TILE_CASE(4, 4);
-    RVT_TILE_CASE(4, 5);
-    RVT_TILE_CASE(5, 5);
-    RVT_TILE_CASE(5, 6);
-    RVT_TILE_CASE(6, 6);
-    RVT_TILE_CASE(6, 7);
-#undef RVT_TILE_CASE
-    default:
-      break;
-  }
+  suffstat_body<MT, CT, WEIGHTED, (CT <= 3) ? 3 : 2>(gd, nd, N, ld, d);
 }
 
 // =====================================================================================================

@@ -36,9 +36,28 @@ struct ProfEvent {
 
 }  // namespace
 
+// One in-flight batch: its stream, workspace, pinned staging and where the results go.  Several slots let the
+// latency-bound tail of batch i (eigen / p-value kernels, few waves) overlap the bandwidth-bound head of
+// batch i+1 (sufficient statistics) on a second HIP stream.
+struct Slot {
+  hipStream_t stream = nullptr;
+  Arena arena;
+  char* h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  rvt_gene_result* pending_out = nullptr;
+  rvt_gene_result* h_results = nullptr;
+  int pending_n = 0;
+  unsigned long long seq = 0;  // launch order
+};
+constexpr int kSlots = 4;
+
 struct rvt_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  Slot slots[kSlots];
+  unsigned long long launch_seq = 0;
+  hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
+  hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
+  hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
   bool have_null = false;
@@ -46,15 +65,6 @@ struct rvt_ctx {
   NullConsts* d_nc = nullptr;
   double *d_X = nullptr, *d_res = nullptr, *d_rr = nullptr, *d_v = nullptr, *d_zeros = nullptr;
   int64_t null_ld = 0;
-  // workspace
-  Arena arena;
-  // pinned host staging
-  char* h_stage = nullptr;
-  size_t h_stage_cap = 0;
-  // in-flight batch
-  rvt_gene_result* pending_out = nullptr;
-  rvt_gene_result* d_results = nullptr;
-  int pending_n = 0;
   // streaming interface
   struct Pending {
     int64_t id;
@@ -94,30 +104,41 @@ int fail(rvt_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, RVT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
-int ensure_arena(rvt_ctx* c, size_t bytes) {
-  if (c->arena.cap >= bytes) return RVT_OK;
-  if (c->arena.base) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipFree(c->arena.base));
-    c->arena.base = nullptr;
-    c->arena.cap = 0;
+int ensure_arena(rvt_ctx* c, Slot& sl, size_t bytes) {
+  if (sl.arena.cap >= bytes) return RVT_OK;
+  if (sl.arena.base) {
+    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    HIP_TRY(c, hipFree(sl.arena.base));
+    sl.arena.base = nullptr;
+    sl.arena.cap = 0;
   }
   const size_t want = bytes + bytes / 4;
-  HIP_TRY(c, hipMalloc((void**)&c->arena.base, want));
-  c->arena.cap = want;
+  HIP_TRY(c, hipMalloc((void**)&sl.arena.base, want));
+  sl.arena.cap = want;
   return RVT_OK;
 }
 
-int ensure_stage(rvt_ctx* c, size_t bytes) {
-  if (c->h_stage_cap >= bytes) return RVT_OK;
-  if (c->h_stage) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipHostFree(c->h_stage));
-    c->h_stage = nullptr;
+int ensure_stage(rvt_ctx* c, Slot& sl, size_t bytes) {
+  if (sl.h_stage_cap >= bytes) return RVT_OK;
+  if (sl.h_stage) {
+    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    HIP_TRY(c, hipHostFree(sl.h_stage));
+    sl.h_stage = nullptr;
   }
   const size_t want = bytes * 2;
-  HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault));
-  c->h_stage_cap = want;
+  HIP_TRY(c, hipHostMalloc((void**)&sl.h_stage, want, hipHostMallocDefault));
+  sl.h_stage_cap = want;
+  return RVT_OK;
+}
+
+// wait for one slot's batch and hand its records to the caller
+int finish_slot(rvt_ctx* c, Slot& sl) {
+  HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  if (sl.pending_out) {
+    std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
+    sl.pending_out = nullptr;
+    sl.pending_n = 0;
+  }
   return RVT_OK;
 }
 
@@ -132,20 +153,21 @@ hipEvent_t get_event(rvt_ctx* c) {
   return e;
 }
 
-struct Scope {  // times one kernel launch with HIP events on the engine's stream when profiling is on
+struct Scope {  // times one kernel launch with HIP events on the launching stream when profiling is on
   rvt_ctx* c;
   int fam;
+  hipStream_t st;
   hipEvent_t a = nullptr;
-  Scope(rvt_ctx* c_, int fam_) : c(c_), fam(fam_) {
+  Scope(rvt_ctx* c_, int fam_, hipStream_t st_) : c(c_), fam(fam_), st(st_) {
     if (c->profiling) {
       a = get_event(c);
-      hipEventRecord(a, c->stream);
+      hipEventRecord(a, st);
     }
   }
   ~Scope() {
     if (c->profiling) {
       hipEvent_t b = get_event(c);
-      hipEventRecord(b, c->stream);
+      hipEventRecord(b, st);
       c->events.push_back({fam, a, b});
     }
   }
@@ -167,15 +189,35 @@ void drain_events(rvt_ctx* c) {
   c->events.clear();
 }
 
-void launch_suffstat(rvt_ctx* c, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
-  Scope sc(c, 0);
+template <int MT, int CT>
+void launch_suffstat_t(rvt_ctx* c, hipStream_t st, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
   dim3 grid((max_wparts + 3) / 4, n), block(256);
+  const long long N = c->nc.N, ld = c->nc.ld;
   if (c->nc.binary)
-    hipLaunchKernelGGL((gene_suffstat_mfma<true>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
-                       (long long)c->nc.ld, c->nc.d);
+    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, true>), grid, block, 0, st, d_desc, nd, N, ld, c->nc.d);
   else
-    hipLaunchKernelGGL((gene_suffstat_mfma<false>), grid, block, 0, c->stream, d_desc, nd, (long long)c->nc.N,
-                       (long long)c->nc.ld, c->nc.d);
+    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, false>), grid, block, 0, st, d_desc, nd, N, ld, c->nc.d);
+}
+
+// genes [0, n) of one tile class
+void launch_suffstat(rvt_ctx* c, hipStream_t st, int MT, int CT, const GeneDesc* d_desc, int n, int max_wparts,
+                     const NullDev& nd) {
+  Scope sc(c, 0, st);
+#define RVT_CASE(mt, ct) \
+  if (MT == mt && CT == ct) return launch_suffstat_t<mt, ct>(c, st, d_desc, n, max_wparts, nd)
+  RVT_CASE(1, 1);
+  RVT_CASE(1, 2);
+  RVT_CASE(2, 2);
+  RVT_CASE(2, 3);
+  RVT_CASE(3, 3);
+  RVT_CASE(3, 4);
+  RVT_CASE(4, 4);
+  RVT_CASE(4, 5);
+  RVT_CASE(5, 5);
+  RVT_CASE(5, 6);
+  RVT_CASE(6, 6);
+  RVT_CASE(6, 7);
+#undef RVT_CASE
 }
 
 // 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
@@ -209,12 +251,21 @@ int rvt_init(rvt_ctx** out, int device_id) {
   rvt_ctx* c = new rvt_ctx();
   c->device = device_id;
   std::memset(&c->timing, 0, sizeof(c->timing));
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  for (int i = 0; i < kSlots; ++i)
+    if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return RVT_E_HIP;
+    }
+  c->stream = c->slots[0].stream;
+  if (hipStreamCreateWithFlags(&c->k2_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return RVT_E_HIP;
   }
+  for (int i = 0; i < kSlots; ++i) {
+    hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming);
+  }
   if (hipMalloc((void**)&c->d_nc, sizeof(NullConsts)) != hipSuccess) {
-    hipStreamDestroy(c->stream);
     delete c;
     return RVT_E_HIP;
   }
@@ -240,16 +291,26 @@ static void free_null(rvt_ctx* c) {
 void rvt_destroy(rvt_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  for (auto& sl : c->slots) hipStreamSynchronize(sl.stream);
+  if (c->k2_stream) {
+    hipStreamSynchronize(c->k2_stream);
+    hipStreamDestroy(c->k2_stream);
+  }
+  for (int i = 0; i < kSlots; ++i) {
+    if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
+    if (c->ev_k2[i]) hipEventDestroy(c->ev_k2[i]);
+  }
   drain_events(c);
   for (auto e : c->event_pool) hipEventDestroy(e);
   free_null(c);
   for (auto& p : c->queue)
     if (p.dG) hipFree(p.dG);
-  if (c->arena.base) hipFree(c->arena.base);
-  if (c->h_stage) hipHostFree(c->h_stage);
+  for (auto& sl : c->slots) {
+    if (sl.arena.base) hipFree(sl.arena.base);
+    if (sl.h_stage) hipHostFree(sl.h_stage);
+    hipStreamDestroy(sl.stream);
+  }
   if (c->d_nc) hipFree(c->d_nc);
-  hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -257,7 +318,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
                  double sigma2) {
   if (!c || !X || !res || !v || N < 1 || d < 1 || d > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad null model");
   hipSetDevice(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& sl : c->slots) HIP_TRY(c, finish_slot(c, sl) ? hipErrorUnknown : hipSuccess);
   free_null(c);
   const int64_t ld = rvt_padded_ld(N);
   NullConsts& nc = c->nc;
@@ -377,7 +438,8 @@ int rvt_set_profiling(rvt_ctx* c, int on) {
 int rvt_get_timing(rvt_ctx* c, rvt_timing* t, int reset) {
   if (!c || !t) return RVT_E_INVALID;
   hipSetDevice(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& sl : c->slots) HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  HIP_TRY(c, hipStreamSynchronize(c->k2_stream));
   drain_events(c);
   *t = c->timing;
   if (reset) std::memset(&c->timing, 0, sizeof(c->timing));
@@ -400,10 +462,22 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
   hipSetDevice(c->device);
-  if (c->pending_out) {  // one batch in flight at a time
+  // pick the slot that was launched longest ago; if its batch is still in flight, finish it first
+  Slot* slp = &c->slots[0];
+  for (auto& cand : c->slots)
+    if (cand.seq < slp->seq) slp = &cand;
+  if (dbg) {  // inspection calls run alone
     int rc = rvt_sync(c);
     if (rc) return rc;
+    slp = &c->slots[0];
   }
+  Slot& sl = *slp;
+  {
+    int rc = finish_slot(c, sl);
+    if (rc) return rc;
+  }
+  sl.seq = ++c->launch_seq;
+  hipStream_t st = sl.stream;
   rvt_params params;
   if (prm)
     params = *prm;
@@ -470,15 +544,15 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     off_dbg_cmc = add(sizeof(double) * N);
     off_dbg_zeg = add(sizeof(double) * N);
   }
-  int rc = ensure_arena(c, total + 4096);
+  int rc = ensure_arena(c, sl, total + 4096);
   if (rc) return rc;
-  char* base = c->arena.base;
+  char* base = sl.arena.base;
   // ---- host staging: descriptors + af ------------------------------------------------------------------
   const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
-  rc = ensure_stage(c, stage_bytes);
+  rc = ensure_stage(c, sl, stage_bytes);
   if (rc) return rc;
-  GeneDesc* h_desc = reinterpret_cast<GeneDesc*>(c->h_stage);
-  double* h_af = reinterpret_cast<double*>(c->h_stage + sizeof(GeneDesc) * n);
+  GeneDesc* h_desc = reinterpret_cast<GeneDesc*>(sl.h_stage);
+  double* h_af = reinterpret_cast<double*>(sl.h_stage + sizeof(GeneDesc) * n);
   size_t afpos = 0;
   for (int g = 0; g < n; ++g) {
     GeneDesc& gd = desc[g];
@@ -503,7 +577,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       }
     }
     std::memcpy(h_af + afpos, af + afpos, sizeof(double) * gd.M);
-    HIP_TRY(c, hipMemcpyAsync(base + o.af, h_af + afpos, sizeof(double) * gd.M, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + o.af, h_af + afpos, sizeof(double) * gd.M, hipMemcpyHostToDevice, st));
     afpos += gd.M;
   }
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
@@ -512,55 +586,68 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return desc[a].M > desc[b].M; });
   for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
   GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
-  HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, st));
   NullDev nd{c->d_X, c->d_res, c->d_rr, c->d_v, c->d_zeros};
   // ---- K2: one launch for the whole batch ------------------------------------------------------------------
-  launch_suffstat(c, d_desc, n, n_wparts, nd);
+  // Stage 1 (bandwidth / MFMA bound) runs on the shared K2 stream so that two batches never split the chip
+  // between two sufficient-statistics launches; stage 2 (latency bound, few waves) continues on the slot's
+  // stream and overlaps the NEXT batch's stage 1.
+  const int slot_idx = (int)(slp - &c->slots[0]);
+  HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
+  HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
+  for (int k = 0; k < n;) {  // descriptors are sorted by width, so every tile class is one contiguous run
+    int e = k;
+    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].CT == h_desc[k].CT) ++e;
+    launch_suffstat(c, c->k2_stream, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
+    k = e;
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
+  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
   if (burden || dbg) {
     {
-      Scope sc(c, 1);
-      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, c->stream, d_desc, (long long)N);
+      Scope sc(c, 1, st);
+      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, st, d_desc, (long long)N);
     }
     // gene groups of <= 64 per launch keep one block's loop short while X/res/v stay in registers
     for (int k = 0; k < n; k += 64) {
       const int cnt = std::min(64, n - k);
-      Scope sc(c, 1);
+      Scope sc(c, 1, st);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, c->stream, d_desc + k, cnt, nd,
+        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, st, d_desc + k, cnt, nd,
                            (long long)N, (long long)ld, d, nc.binary, tests);
       else
-        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, st,
                            d_desc + k, cnt, nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
-    Scope sc(c, 2);
-    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(256), 0, c->stream, d_desc, c->d_nc, params, tests_eff,
+    Scope sc(c, 2, st);
+    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(256), 0, st, d_desc, c->d_nc, params, tests_eff,
                        n_bparts);
   }
   if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO)) {
-    Scope sc(c, 2);
+    Scope sc(c, 2, st);
     const int maxMp = (maxM + 15) / 16 * 16;
     size_t want = sizeof(double) * ((size_t)8 * maxMp + (size_t)maxM * maxM);
     if (want > c->eigen_lds_max) want = sizeof(double) * (size_t)8 * maxMp;  // matrices stay in global scratch
-    hipLaunchKernelGGL(gene_eigen_kernel, dim3(kNEigen, n), dim3(256), want, c->stream, d_desc, c->d_nc, tests_eff,
+    hipLaunchKernelGGL(gene_eigen_kernel, dim3(kNEigen, n), dim3(256), want, st, d_desc, c->d_nc, tests_eff,
                        (int)(want / sizeof(double)));
   }
   {
-    Scope sc(c, 3);
+    Scope sc(c, 3, st);
     const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
                         sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
-    hipLaunchKernelGGL(gene_pvalue_kernel, dim3(n), dim3(64), smem, c->stream, d_desc, tests);
+    hipLaunchKernelGGL(gene_pvalue_kernel, dim3(n), dim3(64), smem, st, d_desc, tests);
   }
   HIP_TRY(c, hipGetLastError());
-  rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(c->h_stage + sizeof(GeneDesc) * n +
+  rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(sl.h_stage + sizeof(GeneDesc) * n +
                                                                (sizeof(double) * af_total + 63) / 64 * 64);
-  HIP_TRY(c, hipMemcpyAsync(h_res, base + off_res, sizeof(rvt_gene_result) * n, hipMemcpyDeviceToHost, c->stream));
-  c->pending_out = out;
-  c->d_results = h_res;
-  c->pending_n = n;
+  HIP_TRY(c, hipMemcpyAsync(h_res, base + off_res, sizeof(rvt_gene_result) * n, hipMemcpyDeviceToHost, st));
+  sl.pending_out = out;
+  sl.h_results = h_res;
+  sl.pending_n = n;
   if (c->profiling) {
     c->timing.genes += n;
     for (int g = 0; g < n; ++g) {
@@ -569,7 +656,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
   }
   if (dbg) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(st));
     const GeneDesc& g0 = desc[0];
     if (dbg->flip) HIP_TRY(c, hipMemcpy(dbg->flip, g0.dbg_flip, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
     if (dbg->kept) HIP_TRY(c, hipMemcpy(dbg->kept, g0.dbg_kept, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
@@ -583,13 +670,24 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
 int rvt_sync(rvt_ctx* c) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pending_out) {
-    std::memcpy(c->pending_out, c->d_results, sizeof(rvt_gene_result) * c->pending_n);
-    c->pending_out = nullptr;
-    c->pending_n = 0;
+  // oldest batch first, so records reach the caller in launch order
+  Slot* order[kSlots];
+  for (int i = 0; i < kSlots; ++i) order[i] = &c->slots[i];
+  std::sort(order, order + kSlots, [](const Slot* a, const Slot* b) { return a->seq < b->seq; });
+  for (Slot* sl : order) {
+    int rc = finish_slot(c, *sl);
+    if (rc) return rc;
   }
   return RVT_OK;
+}
+
+int rvt_wait_oldest(rvt_ctx* c) {
+  if (!c) return RVT_E_INVALID;
+  hipSetDevice(c->device);
+  Slot* oldest = nullptr;
+  for (auto& sl : c->slots)
+    if (sl.pending_out && (!oldest || sl.seq < oldest->seq)) oldest = &sl;
+  return oldest ? finish_slot(c, *oldest) : RVT_OK;
 }
 
 int rvt_run_blocks_async(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,

@@ -110,6 +110,8 @@ def load_library():
     L.rvt_run_blocks_async.argtypes = run_args
     L.rvt_sync.restype = C.c_int
     L.rvt_sync.argtypes = [vp]
+    L.rvt_wait_oldest.restype = C.c_int
+    L.rvt_wait_oldest.argtypes = [vp]
     L.rvt_submit_gene.restype = C.c_int
     L.rvt_submit_gene.argtypes = [vp, C.c_int64, C.c_int, c_double_p, c_double_p, C.c_uint32, C.POINTER(Params)]
     L.rvt_collect.restype = C.c_int
@@ -224,6 +226,9 @@ class Engine:
 
     def sync(self):
         self._check(self.L.rvt_sync(self.ctx))
+
+    def wait_oldest(self):
+        self._check(self.L.rvt_wait_oldest(self.ctx))
 
     # ---- streaming (ModelFitter-style) interface ----------------------------------------------------------
     def submit_gene(self, gene_id, G, af, tests=TEST_ALL, params=None):
