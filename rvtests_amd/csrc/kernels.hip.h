@@ -14,6 +14,11 @@ namespace rvt {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
+// pointers read from descriptors in memory are generic; loads through them would be flat_load (which also ties
+// up lgkmcnt and forces a full drain).  These are known to be global memory.
+typedef const double __attribute__((address_space(1))) * gcdp_t;
+typedef const d2_t __attribute__((address_space(1))) * gcd2p_t;
+__device__ __forceinline__ gcdp_t as_global(const double* p) { return (gcdp_t)(unsigned long long)p; }
 
 // One gene as the kernels see it.
 struct GeneDesc {
@@ -75,15 +80,15 @@ __device__ __forceinline__ double raw_max(double a, double b) {
 }
 
 template <int MT, int CT, bool WEIGHTED, bool GUARD>
-__device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], const double* vptr, long long off,
+__device__ __forceinline__ void suffstat_step(const gcdp_t (&colp)[CT], gcdp_t vptr, long long off,
                                               long long nvalid, d4_t (&acc)[MT][CT], double (&cs)[MT],
                                               double (&cmn)[MT], double (&cmx)[MT], double (&f)[CT][4],
                                               unsigned long long* mask_ge, unsigned long long* mask_le, int lane) {
   // (loads for this step were issued by the caller into f)
   double a[MT][4];
   if (WEIGHTED) {
-    const d2_t v0 = *reinterpret_cast<const d2_t*>(vptr + off);
-    const d2_t v1 = *reinterpret_cast<const d2_t*>(vptr + off + 2);
+    const d2_t v0 = *(gcd2p_t)(vptr + off);
+    const d2_t v1 = *(gcd2p_t)(vptr + off + 2);
     const double vv[4] = {v0[0], v0[1], v1[0], v1[1]};
 #pragma unroll
     for (int c = 0; c < MT; ++c)
@@ -119,9 +124,28 @@ __device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], c
       }
     }
   }
-  if (lane < MT * 4) {
-    mask_ge[lane] = wge;
-    mask_le[lane] = wle;
+  // Lanes 0 .. 4*MT-1 hold this step's ballots.  Store them through a buffer descriptor whose num_records covers
+  // exactly those lanes: the hardware drops the out-of-range lanes, so there is no exec-masked branch in the loop
+  // (a branch here makes the compiler wait vmcnt(0) every step and serialises the load ring).
+  {
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    // the descriptor must live in SGPRs: make the (wave-uniform) base addresses provably uniform, otherwise the
+    // compiler wraps each store in a waterfall loop
+    auto uniform_ptr = [](unsigned long long* p) {
+      const unsigned long long a = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t rge = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_ge), 0, MT * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rle = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_le), 0, MT * 32, 0x00020000);
+    u2_t dge, dle;
+    dge[0] = (unsigned)wge;
+    dge[1] = (unsigned)(wge >> 32);
+    dle[0] = (unsigned)wle;
+    dle[1] = (unsigned)(wle >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(dge, rge, lane * 8, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(dle, rle, lane * 8, 0, 0);
   }
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
@@ -148,11 +172,11 @@ __device__ __forceinline__ void suffstat_step(const double* const (&colp)[CT], c
 }
 
 template <int CT>
-__device__ __forceinline__ void suffstat_load(const double* const (&colp)[CT], long long off, double (&f)[CT][4]) {
+__device__ __forceinline__ void suffstat_load(const gcdp_t (&colp)[CT], long long off, double (&f)[CT][4]) {
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const d2_t x0 = *reinterpret_cast<const d2_t*>(colp[c] + off);
-    const d2_t x1 = *reinterpret_cast<const d2_t*>(colp[c] + off + 2);
+    const d2_t x0 = *(gcd2p_t)(colp[c] + off);
+    const d2_t x1 = *(gcd2p_t)(colp[c] + off + 2);
     f[c][0] = x0[0];
     f[c][1] = x0[1];
     f[c][2] = x1[0];
@@ -171,7 +195,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
   if (s_end > nsteps) s_end = nsteps;
   const int M = gd.M;
   // per-lane column pointers
-  const double* colp[CT];
+  gcdp_t colp[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     const int j = c * 16 + (lane & 15);
@@ -184,8 +208,9 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
       p = nd.rr;
     else
       p = nd.zeros;
-    colp[c] = p;
+    colp[c] = as_global(p);
   }
+  const gcdp_t vglob = as_global(nd.v);
   d4_t acc[MT][CT];
 #pragma unroll
   for (int r = 0; r < MT; ++r)
@@ -210,7 +235,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
   // of tested); the single possibly-partial last step of the gene is handled after the loop.
   const long long s_lim = (s_end < full_steps) ? s_end : full_steps;
   auto step = [&](double (&f)[CT][4], long long s) {
-    suffstat_step<MT, CT, WEIGHTED, false>(colp, nd.v, s * 16 + koff, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
+    suffstat_step<MT, CT, WEIGHTED, false>(colp, vglob, s * 16 + koff, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
                                            mle + s * MT * 4, lane);
   };
   auto load = [&](double (&f)[CT][4], long long s) {
@@ -249,7 +274,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
     double fg[CT][4];
     const long long sg = full_steps, off = sg * 16 + koff;
     suffstat_load<CT>(colp, off, fg);
-    suffstat_step<MT, CT, WEIGHTED, true>(colp, nd.v, off, N - off, acc, cs, cmn, cmx, fg, mge + sg * MT * 4,
+    suffstat_step<MT, CT, WEIGHTED, true>(colp, vglob, off, N - off, acc, cs, cmn, cmx, fg, mge + sg * MT * 4,
                                           mle + sg * MT * 4, lane);
   }
   // ---- write this wave's partial tiles: element (row, col) -> parts[row*Cp + col] --------------------
