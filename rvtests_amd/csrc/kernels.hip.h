@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 // K3b: one workgroup per (eigenproblem, gene): build the matrix in LDS, Householder tridiagonalisation,
 //      Sturm bisection, eigenvalue filter and moments.  13 eigenproblems per gene run concurrently.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
+__global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
                                                             unsigned tests, int n_bparts) {
   __shared__ double red[64];
@@ -550,6 +550,7 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
       davies_qf_front(lb, ths[which], r, c, 10000, 0.000001, pre, &task);
     }
   }
+
   const bool need = active && !direct && task.need_main;
   L.nt1[lane] = need ? task.nt + 1 : 0;
   L.which[lane] = which;
@@ -659,6 +660,7 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
   SkatoIntegrand si;
   DaviesPrelude pre;
   pre.valid = false;
+  LiuPre liu_zimz;
   const bool skato_quad = do_skato && !gs.skato_single;
   if (skato_quad) {
 #pragma unroll
@@ -671,9 +673,14 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
     skato_fill_integrand(gs, qminp, lam_zimz, th_zimz, &si);
     davies_prelude(lam_zimz, th_zimz, gs.zimz_nlambda, 10000, 0.000001, &pre);  // same values in every lane
     si.pre = &pre;
+    liu_zimz = liu_prepare(lam_zimz, gs.zimz_nlambda);
+    si.liu = &liu_zimz;
   }
   // One cooperative Davies round evaluates: the quadrature abscissae of this step (lanes < npts), and — in
   // the first round only — SKAT's own Q (lane 62) and the single-variant SKAT-O Q (lane 63).
+#ifdef RVT_PROF_K4
+  double prof[4] = {0, 0, 0, 0};
+#endif
   auto davies_round = [&](int npts, double a1, double b1, double b2, bool first, int pass, double* extra62,
                           double* extra63) {
     bool active = false;
@@ -705,14 +712,21 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
     }
     double nt = 0.0;
     double p = 0.0;
+#ifdef RVT_PROF_K4
+    const long long tk0 = clock64();
+#endif
     if (pass == 0 || first) p = wave_davies_pvalue(active, which, lbs, ths, rs, c, pp, lane, L, &nt);
     terms += nt;
+#ifdef RVT_PROF_K4
+    const long long tk1 = clock64();
+    prof[0] += (double)(tk1 - tk0);
+#endif
     if (lane < npts && skato_quad) {
       double val;
       if (pass == 0) {
         double temp = skip_zero ? 0.0 : p;
-        if (!skip_zero && (temp <= 0.0 || temp == 1.0)) temp = liu_pvalue(si.lambda, si.r, c);
-        val = (1.0 - temp) * chisq_density(x, 1.0);
+        if (!skip_zero && (temp <= 0.0 || temp == 1.0)) temp = liu_pvalue_pre(liu_zimz, c);
+        val = (1.0 - temp) * chisq_density_lg(x, 1.0, si.lg_half);
       } else {
         val = skato_integrand_liu(si, x);
       }
@@ -723,10 +737,16 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
       *extra62 = p;
     }
     if (first && lane == 63 && do_skato && gs.skato_single) *extra63 = p;
+#ifdef RVT_PROF_K4
+    prof[1] += (double)(clock64() - tk1);
+#endif
     __syncthreads();
   };
   double skat_p = 0.0, single_p = 0.0;
   int neval = 0, status = 0;
+#ifdef RVT_PROF_K4
+  const long long tk_start = clock64();
+#endif
   double integral = 0.0;
   QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
   for (int pass = 0; pass < 2; ++pass) {
@@ -807,6 +827,12 @@ __global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restr
   for (int off = 32; off > 0; off >>= 1) terms += __shfl_down(terms, off, 64);
   if (lane == 0) {
     res.davies_terms = terms;
+#ifdef RVT_PROF_K4
+    res.cmc_U = prof[0];                              // cycles inside wave_davies_pvalue
+    res.cmc_V = prof[1];                              // cycles in Liu fallback + density + fv store
+    res.zeg_U = (double)(clock64() - tk_start);       // cycles from QAGS start to end
+    res.zeg_V = (double)neval;
+#endif
     *gd.result = res;
   }
 }

@@ -55,6 +55,24 @@ RVT_HD double dv_log1(double x, bool first) {
   return s;
 }
 
+// Four independent evaluations of dv_log1 at once.  Values are exactly dv_log1's; the point is instruction-level
+// parallelism: one wave evaluates these sums essentially alone on its SIMD, so a chain of dependent fp64 ops runs
+// at their latency.  The common case (|x| > 0.1: a plain log) is issued for all four elements back to back; the
+// series branch of qfc.c:103-112 is taken only for the elements that need it.
+RVT_HD void dv_log1_x4(const double (&x)[4], int cnt, bool first, double (&out)[4]) {
+  bool any_small = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    out[k] = first ? log(1.0 + x[k]) : (log(1.0 + x[k]) - x[k]);
+    if (k < cnt && !(fabs(x[k]) > 0.1)) any_small = true;
+  }
+  if (any_small) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < cnt && !(fabs(x[k]) > 0.1)) out[k] = dv_log1(x[k], first);
+  }
+}
+
 RVT_HD void dv_tick(DaviesState& st) {
   st.count = st.count + 1;
   if (st.count > st.lim) st.over = true;
@@ -69,11 +87,24 @@ RVT_HD double dv_errbd(DaviesState& st, double u, double* cx) {
   }
   double xconst = u * st.sigsq, sum1 = u * xconst;
   u = 2.0 * u;
-  for (int j = st.r - 1; j >= 0; j--) {
-    const double lj = st.lb[j];
-    const double x = u * lj, y = 1.0 - x;
-    xconst = xconst + lj / y;
-    sum1 = sum1 + ((x * x) / y + dv_log1(-x, false));
+  for (int j0 = st.r - 1; j0 >= 0; j0 -= 4) {  // elements evaluated 4 at a time, accumulated in the reference's order
+    const int cnt = (j0 >= 3) ? 4 : j0 + 1;
+    double lj[4], x[4], y[4], mx[4], lg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lj[k] = (k < cnt) ? st.lb[j0 - k] : 1.0;
+      x[k] = u * lj[k];
+      y[k] = 1.0 - x[k];
+      mx[k] = (k < cnt) ? -x[k] : 1.0;
+    }
+    dv_log1_x4(mx, cnt, false, lg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < cnt) {
+        xconst = xconst + lj[k] / y[k];
+        sum1 = sum1 + ((x[k] * x[k]) / y[k] + lg[k]);
+      }
+    }
   }
   *cx = xconst;
   return dv_exp1(-0.5 * sum1);
@@ -114,15 +145,28 @@ RVT_HD double dv_truncation(DaviesState& st, double u, double tausq) {
   const double sum2 = (st.sigsq + tausq) * (u * u);
   double prod1 = 2.0 * sum2;
   u = 2.0 * u;
-  for (int j = 0; j < st.r; j++) {
-    const double t = u * st.lb[j];
-    const double x = t * t;
-    if (x > 1.0) {
-      prod2 = prod2 + log(x);
-      prod3 = prod3 + dv_log1(x, true);
-      s = s + 1;
-    } else
-      prod1 = prod1 + dv_log1(x, true);
+  for (int j0 = 0; j0 < st.r; j0 += 4) {
+    const int cnt = (st.r - j0 >= 4) ? 4 : st.r - j0;
+    double x[4], l1[4], lx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double t = u * ((k < cnt) ? st.lb[j0 + k] : 1.0);
+      x[k] = t * t;
+    }
+    dv_log1_x4(x, cnt, true, l1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lx[k] = log(x[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < cnt) {
+        if (x[k] > 1.0) {
+          prod2 = prod2 + lx[k];
+          prod3 = prod3 + l1[k];
+          s = s + 1;
+        } else
+          prod1 = prod1 + l1[k];
+      }
+    }
   }
   sum1 = 0.5 * sum1;
   prod2 = prod1 + prod2;
@@ -277,13 +321,25 @@ RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double 
   const double u = (k + 0.5) * interv;
   double sum1 = -2.0 * u * c, sum2 = fabs(sum1);
   double sum3 = -0.5 * sigsq * (u * u);
-  for (int j = r - 1; j >= 0; j--) {
-    const double x = 2.0 * lb[j] * u;
-    const double y = x * x;
-    sum3 = sum3 - 0.25 * dv_log1(y, true);
-    const double z = atan(x);
-    sum1 = sum1 + z;
-    sum2 = sum2 + fabs(z);
+  for (int j0 = r - 1; j0 >= 0; j0 -= 4) {
+    const int cnt = (j0 >= 3) ? 4 : j0 + 1;
+    double x[4], y[4], l1[4], z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[k] = 2.0 * ((k < cnt) ? lb[j0 - k] : 1.0) * u;
+      y[k] = x[k] * x[k];
+    }
+    dv_log1_x4(y, cnt, true, l1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = atan(x[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < cnt) {
+        sum3 = sum3 - 0.25 * l1[k];
+        sum1 = sum1 + z[k];
+        sum2 = sum2 + fabs(z[k]);
+      }
+    }
   }
   const double x = inpi * dv_exp1(sum3) / u;
   *t1 = sin(0.5 * sum1) * x;
@@ -510,7 +566,40 @@ RVT_HD void chisq_both_tails(double x, double df, double* cum, double* ccum) {
 // non-central chi-square CDF: Poisson-weighted sum started at the central term, truncated with the
 // reference's eps = 1e-5 / 1000-term rules (they set the digits, so they are kept), including its
 // `sumadj = sum + adj` update in the forward sweep        (regression/cdflib.cpp:5172-5350)
-RVT_HD void noncentral_chisq_tails(double x, double df, double pnonc, double* cum, double* ccum) {
+// The pieces that do not depend on x (central index, its Poisson weight, the lgamma of the adjustment term)
+// are split off so that many evaluations against one (df, pnonc) — every abscissa of a SKAT-O quadrature —
+// pay for them once; values are exactly those the one-shot form computes.
+struct NoncentralPre {
+  double df, pnonc;
+  bool central;      // pnonc <= 1e-10: plain chi-square
+  double xnonc;
+  int icent;
+  double centwt;     // exp(-xnonc + icent log(xnonc) - lgamma(icent + 1))
+  double dfd2c;      // (df + 2 icent) / 2
+  double lgam_adj;   // lgamma(1 + dfd2c)
+};
+
+RVT_HD NoncentralPre noncentral_prepare(double df, double pnonc) {
+  NoncentralPre q;
+  q.df = df;
+  q.pnonc = pnonc;
+  q.central = (pnonc <= 1.0e-10);
+  q.xnonc = pnonc / 2.0;
+  q.icent = 1;
+  q.centwt = 0.0;
+  q.dfd2c = 0.0;
+  q.lgam_adj = 0.0;
+  if (q.central) return q;
+  int icent = (int)q.xnonc;
+  if (icent == 0) icent = 1;
+  q.icent = icent;
+  q.centwt = exp(-q.xnonc + (double)icent * log(q.xnonc) - lgamma((double)(icent + 1)));
+  q.dfd2c = (df + 2.0 * (double)icent) / 2.0;
+  q.lgam_adj = lgamma(1.0 + q.dfd2c);
+  return q;
+}
+
+RVT_HD void noncentral_chisq_tails_pre(const NoncentralPre& q, double x, double* cum, double* ccum) {
   const double eps = 1.0e-5;
   const int ntired = 1000;
   if (x <= 0.0) {
@@ -518,19 +607,18 @@ RVT_HD void noncentral_chisq_tails(double x, double df, double pnonc, double* cu
     *ccum = 1.0;
     return;
   }
-  if (pnonc <= 1.0e-10) {
-    chisq_both_tails(x, df, cum, ccum);
+  if (q.central) {
+    chisq_both_tails(x, q.df, cum, ccum);
     return;
   }
-  const double xnonc = pnonc / 2.0;
-  int icent = (int)xnonc;
-  if (icent == 0) icent = 1;
+  const double df = q.df, xnonc = q.xnonc;
+  const int icent = q.icent;
   const double chid2 = x / 2.0;
-  const double centwt = exp(-xnonc + (double)icent * log(xnonc) - lgamma((double)(icent + 1)));
+  const double centwt = q.centwt;
   double pcent, tmp;
   chisq_both_tails(x, df + 2.0 * (double)icent, &pcent, &tmp);
-  double dfd2 = (df + 2.0 * (double)icent) / 2.0;
-  const double centaj = exp(dfd2 * log(chid2) - chid2 - lgamma(1.0 + dfd2));
+  double dfd2 = q.dfd2c;
+  const double centaj = exp(dfd2 * log(chid2) - chid2 - q.lgam_adj);
   double sum = centwt * pcent;
   // towards zero
   double sumadj = 0.0, adj = centaj, wt = centwt, term;
@@ -564,6 +652,16 @@ RVT_HD void noncentral_chisq_tails(double x, double df, double pnonc, double* cu
   *ccum = 0.5 + (0.5 - sum);
 }
 
+RVT_HD void noncentral_chisq_tails(double x, double df, double pnonc, double* cum, double* ccum) {
+  if (x <= 0.0) {
+    *cum = 0.0;
+    *ccum = 1.0;
+    return;
+  }
+  const NoncentralPre q = noncentral_prepare(df, pnonc);
+  noncentral_chisq_tails_pre(q, x, cum, ccum);
+}
+
 RVT_HD double dv_powsum(const double* d, int n, int power) {
   double r = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -574,12 +672,21 @@ RVT_HD double dv_powsum(const double* d, int n, int power) {
   return r;
 }
 
-// MixtureChiSquare::getLiuPvalue      (regression/MixtureChiSquare.cpp:44-83)
-RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
+// MixtureChiSquare::getLiuPvalue      (regression/MixtureChiSquare.cpp:44-83), split into the part that only
+// depends on the coefficients (moments -> a, delta, l) and the part that depends on Q.
+struct LiuPre {
+  double muQ, sigmaQ, muX, sigmaX, l, delta;
+  bool bad_args;  // cdfchn would return status != 0 regardless of x (df <= 0 or ncp < 0)
+  NoncentralPre nc;
+};
+
+RVT_HD LiuPre liu_prepare(const double* lambda, int n) {
+  LiuPre p;
   const double c1 = dv_powsum(lambda, n, 1), c2 = dv_powsum(lambda, n, 2), c3 = dv_powsum(lambda, n, 3),
                c4 = dv_powsum(lambda, n, 4);
   const double s1 = c3 / c2 / sqrt(c2), s2 = c4 / c2 / c2;
-  const double tstar = (Q - c1) / sqrt(2.0 * c2);
+  p.muQ = c1;
+  p.sigmaQ = sqrt(2.0 * c2);
   double a, delta, l;
   if (s1 * s1 > s2) {
     a = 1 / (s1 - sqrt(s1 * s1 - s2));
@@ -590,11 +697,27 @@ RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
     delta = 0.0;
     l = c2 * c2 * c2 / c3 / c3;
   }
-  const double x = tstar * (sqrt(2.0) * a) + (l + delta);
-  if (x < 0.0 || l <= 0.0 || delta < 0.0) return 1.0;  // cdfchn status != 0
-  double p, q;
-  noncentral_chisq_tails(x, l, delta, &p, &q);
+  p.l = l;
+  p.delta = delta;
+  p.muX = l + delta;
+  p.sigmaX = sqrt(2.0) * a;
+  p.bad_args = (l <= 0.0 || delta < 0.0);
+  p.nc = noncentral_prepare(l, delta);
+  return p;
+}
+
+RVT_HD double liu_pvalue_pre(const LiuPre& p, double Q) {
+  const double tstar = (Q - p.muQ) / p.sigmaQ;
+  const double x = tstar * p.sigmaX + p.muX;
+  if (x < 0.0 || p.bad_args) return 1.0;  // cdfchn status != 0
+  double cum, q;
+  noncentral_chisq_tails_pre(p.nc, x, &cum, &q);
   return q;
+}
+
+RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
+  const LiuPre p = liu_prepare(lambda, n);
+  return liu_pvalue_pre(p, Q);
 }
 
 // MixtureChiSquare::getPvalue        (regression/MixtureChiSquare.cpp:7-29)

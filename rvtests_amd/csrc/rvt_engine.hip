@@ -624,7 +624,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
     Scope sc(c, 2, st);
-    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(256), 0, st, d_desc, c->d_nc, params, tests_eff,
+    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
                        n_bparts);
   }
   if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO)) {

@@ -101,7 +101,25 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     const int i = idx / Cp, j = idx % Cp;
     double s = 0.0;
     if ((j >> 4) >= (i >> 4)) {
-      for (int p = 0; p < P; ++p) s += parts[(size_t)p * Mp * Cp + idx];
+      // fixed order p = 0..P-1 (bit-reproducible); loads are independent, so keep many in flight
+      const double* src = parts + idx;
+      const size_t stride = (size_t)Mp * Cp;
+      int p = 0;
+      for (; p + 8 <= P; p += 8) {
+        const double a0 = src[(size_t)(p + 0) * stride], a1 = src[(size_t)(p + 1) * stride],
+                     a2 = src[(size_t)(p + 2) * stride], a3 = src[(size_t)(p + 3) * stride],
+                     a4 = src[(size_t)(p + 4) * stride], a5 = src[(size_t)(p + 5) * stride],
+                     a6 = src[(size_t)(p + 6) * stride], a7 = src[(size_t)(p + 7) * stride];
+        s += a0;
+        s += a1;
+        s += a2;
+        s += a3;
+        s += a4;
+        s += a5;
+        s += a6;
+        s += a7;
+      }
+      for (; p < P; ++p) s += src[(size_t)p * stride];
     }
     R[idx] = s;
   }

@@ -76,6 +76,8 @@ RVT_HD void skato_fill_integrand(const GeneStats& gs, const double* qminp, const
   s->r = gs.zimz_nlambda;
   s->lambda_sum = gs.zimz_lambda_sum;
   s->pre = nullptr;
+  s->liu = nullptr;
+  s->lg_half = lgamma(0.5);
 }
 
 // th_skat / th_zimz: scratch of >= n ints each; qags_mem: qags_workspace_bytes(kSkatoLimit) bytes
@@ -123,6 +125,8 @@ RVT_HD void gene_pvalue_serial(const GeneStats& gs, const double* lambda_buf, un
       DaviesPrelude pre;
       davies_prelude(lam, th_zimz, n, 10000, 0.000001, &pre);
       si.pre = &pre;
+      const LiuPre liu = liu_prepare(lam, n);
+      si.liu = &liu;
       QagsWorkspace ws = qags_workspace_carve(qags_mem, kSkatoLimit);
       double fv[42];
       int neval = 0, status;

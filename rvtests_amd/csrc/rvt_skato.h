@@ -64,6 +64,8 @@ struct SkatoIntegrand {
   int r;
   double lambda_sum;
   const DaviesPrelude* pre;  // c-independent part of qf() for `lambda` (may be null)
+  const LiuPre* liu;         // coefficient-only part of Liu's approximation (may be null)
+  double lg_half;            // lgamma(0.5) for the chi-square(1) density
 };
 
 RVT_HD double skato_kappa(const SkatoIntegrand& s, double x) {
@@ -87,9 +89,9 @@ RVT_HD double skato_integrand_davies(const SkatoIntegrand& s, double x, double* 
     const double Q = (kappa - s.muQ) * sqrt(s.varQ - s.varZeta) / sqrt(s.varQ) + s.muQ;
     int fault;
     temp = davies_pvalue(s.lambda, s.th, s.r, Q, &fault, nterms, s.pre);
-    if (temp <= 0.0 || temp == 1.0) temp = liu_pvalue(s.lambda, s.r, Q);
+    if (temp <= 0.0 || temp == 1.0) temp = s.liu ? liu_pvalue_pre(*s.liu, Q) : liu_pvalue(s.lambda, s.r, Q);
   }
-  return (1.0 - temp) * chisq_density(x, 1.0);
+  return (1.0 - temp) * chisq_density_lg(x, 1.0, s.lg_half);
 }
 
 // integrandLiu      (regression/SkatO.cpp:327-337)
@@ -100,7 +102,7 @@ RVT_HD double skato_integrand_liu(const SkatoIntegrand& s, double x) {
     if (v < kappa) kappa = v;
   }
   const double Q = (kappa - s.muQ) / sqrt(s.varQ) * sqrt(2.0 * s.df) + s.df;
-  return chisq_P(Q, s.df) * chisq_density(x, 1.0);
+  return chisq_P(Q, s.df) * chisq_density_lg(x, 1.0, s.lg_half);
 }
 
 // corrections after the integral      (regression/SkatO.cpp:258-277), nRho = 11 -> multi = 3

@@ -145,11 +145,13 @@ RVT_HD double gamma_density(double x, double a, double b) {
   return exp((a - 1) * log(x / b) - x / b - lgamma(a)) / b;
 }
 
-RVT_HD double chisq_density(double x, double nu) {
+// lg = lgamma(nu / 2), passed in so that a caller evaluating many x for one nu computes it once
+RVT_HD double chisq_density_lg(double x, double nu, double lg) {
   if (x < 0) return 0.0;
   if (nu == 2.0) return exp(-x / 2.0) / 2.0;
-  return exp((nu / 2 - 1) * log(x / 2) - x / 2 - lgamma(nu / 2)) / 2;
+  return exp((nu / 2 - 1) * log(x / 2) - x / 2 - lg) / 2;
 }
+RVT_HD double chisq_density(double x, double nu) { return chisq_density_lg(x, nu, lgamma(nu / 2)); }
 
 RVT_HD double beta_density(double x, double a, double b) {
   if (x < 0 || x > 1) return 0.0;
