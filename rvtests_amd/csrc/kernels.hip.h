@@ -323,6 +323,157 @@ __global__ __launch_bounds__(256, (MT * CT <= 16) ? 2 : 1) void gene_suffstat_mf
   suffstat_body<MT, CT, WEIGHTED, (CT <= 3) ? 3 : 2>(gd, nd, N, ld, d);
 }
 
+// ---- genes wider than 6 row tiles (M > 96): the tile grid is cut into panels of up to 4 x 4 tiles -----------
+// blockIdx.z enumerates the panels (pr, pc), pc >= pr.  A diagonal panel (pr == pc) holds the same 64 columns on
+// both sides (one set of loads) and also produces the column statistics and bit masks of those columns; an
+// off-diagonal panel loads its 64 "row" columns and its 64 "column" columns separately.  G is therefore read
+// about (number of panel rows) times — wide genes are compute-bound anyway (intensity grows with M).
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void gene_suffstat_panel(const GeneDesc* __restrict__ genes, NullDev nd, long long N,
+                                                           long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wpart >= gd.n_wparts) return;
+  const int nPR = (gd.MT + 3) / 4, nPC = (gd.CT + 3) / 4;
+  int pr = 0, pc = 0, z = blockIdx.z;
+  for (pr = 0; pr < nPR; ++pr) {
+    const int cnt = nPC - pr;
+    if (z < cnt) {
+      pc = pr + z;
+      break;
+    }
+    z -= cnt;
+  }
+  if (pr >= nPR) return;
+  const bool diag = (pr == pc);
+  const int r0 = pr * 4, c0 = pc * 4, M = gd.M, MT = gd.MT;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  auto column = [&](int j) -> const double* {
+    if (j < M) return gd.G + (long long)j * ld;
+    if (j < M + d) return nd.X + (long long)(j - M) * ld;
+    if (j == M + d) return nd.rr;
+    return nd.zeros;
+  };
+  gcdp_t pa[4], pb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ja = (r0 + t) * 16 + (lane & 15);
+    pa[t] = as_global((r0 + t < MT && ja < M) ? gd.G + (long long)ja * ld : nd.zeros);
+    pb[t] = as_global((c0 + t < gd.CT) ? column((c0 + t) * 16 + (lane & 15)) : nd.zeros);
+  }
+  const gcdp_t vglob = as_global(nd.v);
+  d4_t acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double cs[4], cmn[4], cmx[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    cs[t] = 0.0;
+    cmn[t] = INFINITY;
+    cmx[t] = -INFINITY;
+  }
+  const long long koff = (long long)(lane >> 4) * 4;
+  unsigned long long* mge = gd.masks;
+  unsigned long long* mle = gd.masks + nsteps * MT * 4;
+  const int nrow = (MT - r0 < 4) ? MT - r0 : 4;  // row tiles of this panel that exist
+  for (long long s = s_begin; s < s_end; ++s) {
+    const long long off = s * 16 + koff;
+    double fa[4][4], fb[4][4], a[4][4];
+    suffstat_load<4>(pa, off, fa);
+    // B side: its own loads, except in a diagonal panel where a tile made only of genotype columns is the very
+    // register set already loaded for the A side (a tile that also holds X / rr columns differs: A rows are G only)
+    if (!diag || (c0 + 4) * 16 > M) suffstat_load<4>(pb, off, fb);
+    double vv[4] = {1.0, 1.0, 1.0, 1.0};
+    if (WEIGHTED) {
+      const d2_t v0 = *(gcd2p_t)(vglob + off);
+      const d2_t v1 = *(gcd2p_t)(vglob + off + 2);
+      vv[0] = v0[0];
+      vv[1] = v0[1];
+      vv[2] = v1[0];
+      vv[3] = v1[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        a[t][l] = WEIGHTED ? fa[t][l] * vv[l] : fa[t][l];
+        if (diag && (c0 + 4) * 16 <= M) fb[t][l] = fa[t][l];
+      }
+    if (diag) {
+      unsigned long long wge = 0, wle = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const double g = fa[t][l];
+          cs[t] += g;
+          if (off + l < N) {
+            cmn[t] = raw_min(cmn[t], g);
+            cmx[t] = raw_max(cmx[t], g);
+          }
+          const unsigned long long bge = __ballot(g >= 1.0);
+          const unsigned long long ble = __ballot(g <= 1.0);
+          if (lane == t * 4 + l) {
+            wge = bge;
+            wle = ble;
+          }
+        }
+      if (lane < nrow * 4) {
+        mge[s * MT * 4 + r0 * 4 + lane] = wge;
+        mle[s * MT * 4 + r0 * 4 + lane] = wle;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (diag && c < r) continue;
+          acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][l], fb[c][l], acc[r][c], 0, 0, 0);
+        }
+  }
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (diag && c < r) continue;
+      if (r0 + r < MT && c0 + c < gd.CT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (r0 + r) * 16 + (lane >> 4) + 4 * i;
+          const int col = (c0 + c) * 16 + (lane & 15);
+          out[(long long)row * gd.Cp + col] = acc[r][c][i];
+        }
+      }
+    }
+  if (diag) {
+    double* cst = gd.colstat + (long long)wpart * 3 * gd.Mp;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double sm = cs[t], mn = cmn[t], mx = cmx[t];
+      sm += __shfl_xor(sm, 16, 64);
+      mn = fmin(mn, __shfl_xor(mn, 16, 64));
+      mx = fmax(mx, __shfl_xor(mx, 16, 64));
+      sm += __shfl_xor(sm, 32, 64);
+      mn = fmin(mn, __shfl_xor(mn, 32, 64));
+      mx = fmax(mx, __shfl_xor(mx, 32, 64));
+      if (lane < 16 && r0 + t < MT) {
+        cst[(r0 + t) * 16 + lane] = sm;
+        cst[gd.Mp + (r0 + t) * 16 + lane] = mn;
+        cst[2 * gd.Mp + (r0 + t) * 16 + lane] = mx;
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // flip / polymorphic flags per 16-variant block (needed by the burden kernel before gene_stats runs)
 //   flip:  column sum > N       convertToMinorAlleleCount   src/DataConsolidator.cpp:46-69

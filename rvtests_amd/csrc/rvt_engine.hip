@@ -507,7 +507,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
     const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16;
-    if (MT > kMaxMT) return fail(c, RVT_E_TOO_LARGE, "gene %d: M=%d exceeds the single-pass limit %d", g, M, kMaxMT * 16);
+    if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene %d: M=%d exceeds RVT_MAX_VARIANTS", g, M);
     maxM = std::max(maxM, M);
     GeneDesc& gd = desc[g];
     std::memset(&gd, 0, sizeof(gd));
@@ -595,7 +595,22 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int slot_idx = (int)(slp - &c->slots[0]);
   HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
-  for (int k = 0; k < n;) {  // descriptors are sorted by width, so every tile class is one contiguous run
+  int k0 = 0;
+  while (k0 < n && h_desc[k0].MT > kMaxMT) ++k0;  // widest first: these need the panelled kernel
+  if (k0 > 0) {
+    Scope sc(c, 0, c->k2_stream);
+    const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;
+    int npanels = 0;
+    for (int pr = 0; pr < nPR; ++pr) npanels += nPC - pr;
+    dim3 grid((n_wparts + 3) / 4, k0, npanels), block(256);
+    if (nc.binary)
+      hipLaunchKernelGGL((gene_suffstat_panel<true>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
+                         (long long)ld, d);
+    else
+      hipLaunchKernelGGL((gene_suffstat_panel<false>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
+                         (long long)ld, d);
+  }
+  for (int k = k0; k < n;) {  // descriptors are sorted by width, so every tile class is one contiguous run
     int e = k;
     while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].CT == h_desc[k].CT) ++e;
     launch_suffstat(c, c->k2_stream, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);

@@ -115,6 +115,33 @@ def test_full_pipeline_vs_oracle(engine, binary, d):
     assert [r.gene_id for r in out] == list(range(len(genes)))
 
 
+@pytest.mark.parametrize("M,binary", [(97, 0), (130, 0), (200, 1)])
+def test_wide_genes_use_the_panelled_kernel(engine, M, binary):
+    """M > 96 goes through gene_suffstat_panel (4 x 4 tile panels) and the global-memory eigen path."""
+    N, d = 2500, 2
+    Graw, G, af = synth.make_gene(N, M, seed=M, missing=0.01, common=True, mono=True, maf_hi=-1.0)
+    narrow = synth.make_gene(N, 20, seed=3)[1:]
+    X, y, res, v, s2 = synth.make_null(N, d, binary, seed=M, G_effect=0.4 * G[:, :3].sum(1))
+    engine.set_null(binary, X, res, v, s2)
+    ptr = engine.upload_block(G)
+    S, T, u, cs, mn, mx = engine.debug_suffstat(ptr, M)
+    w = v if binary else np.ones(N)
+    S0 = (G * w[:, None]).T @ G
+    assert np.max(np.abs(S - S0)) <= 1e-11 * np.max(np.abs(S0))
+    assert np.max(np.abs(T - (G * w[:, None]).T @ X)) <= 1e-11 * max(np.max(np.abs(S0)), 1.0)
+    assert np.array_equal(mn, G.min(0)) and np.array_equal(mx, G.max(0))
+    cmc, zeg, fl, kp = engine.debug_collapse(ptr, M)
+    Gf, fl0, kp0 = orc.flip_poly(G)
+    assert np.array_equal(fl, fl0) and np.array_equal(kp, kp0)
+    assert np.array_equal(cmc, orc.collapse(Gf, 0)) and np.array_equal(zeg, orc.collapse(Gf, 1))
+    p2 = engine.upload_block(narrow[0])
+    out = engine.run_blocks([p2, ptr], [20, M], [narrow[1], af])      # mixed batch: narrow + wide
+    engine.free_block(ptr)
+    engine.free_block(p2)
+    _check_gene(out[1], G, af, X, y, res, v, binary, d)
+    _check_gene(out[0], narrow[0], narrow[1], X, y, res, v, binary, d)
+
+
 def test_streaming_interface_matches_batch(engine):
     N, d = 2000, 2
     genes = [synth.make_gene(N, M, seed=50 + M)[1:] for M in (5, 17, 33)]
