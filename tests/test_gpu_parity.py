@@ -170,3 +170,50 @@ def test_determinism(engine):
     engine.free_block(ptr)
     for f in ("skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_stat", "zeg_stat"):
         assert getattr(a, f) == getattr(b, f)
+
+
+def test_full_size_properties(engine):
+    """BASELINE configs[2] size (N = 500 000, M = 50): the oracle's literal SKAT-O needs ~20 s per gene here, so the
+    full-size check uses size-independent properties instead:
+      * sufficient statistics equal numpy's G'[G X r] (exact for the integer-valued genotype part),
+      * the p-values equal those of the SAME algorithms run on the host from numpy's statistics (hc.gene),
+      * invariance under a permutation of the samples and under reordering the genes of a batch,
+      * burden counts equal a numpy restatement of the collapsers (bit-exact)."""
+    import hc
+    N, M, d = 500000, 50, 3
+    rng = np.random.default_rng(20260002)
+    maf = 10 ** rng.uniform(np.log10(5e-4), np.log10(5e-2), M)
+    G = np.asfortranarray((rng.random((N, M)) < maf).astype(np.float64) + (rng.random((N, M)) < maf))
+    af = G.sum(0) / (2.0 * N)
+    X = np.column_stack([np.ones(N), rng.normal(size=N), rng.normal(size=N)])
+    y = 0.3 * X[:, 1] - 0.2 * X[:, 2] + rng.normal(size=N) + 0.05 * G[:, :5].sum(1)
+    beta = np.linalg.solve(X.T @ X, X.T @ y)
+    res = y - X @ beta
+    s2 = float(res @ res / N)
+    v = np.full(N, s2)
+    engine.set_null(0, X, res, v, s2)
+    ptr = engine.upload_block(G)
+    S, T, u, cs, mn, mx = engine.debug_suffstat(ptr, M)
+    assert np.array_equal(S, G.T @ G)                      # integers: exact in any summation order
+    assert np.array_equal(cs, G.sum(0))
+    assert np.max(np.abs(T - G.T @ X)) <= 1e-10 * N and np.max(np.abs(u - G.T @ res)) <= 1e-10 * N
+    r1 = engine.run_blocks([ptr], [M], [af])[0]
+    # same algorithms on the host, fed with numpy's statistics
+    c = (G.astype(np.int64) > 0).sum(1).astype(np.float64)
+    bs = hc.burden_sums((c > 0).astype(np.float64), c, X, res, v, 0)
+    h, _, _, _ = hc.gene(G, af, X, res, v, 0, s2, bstats=bs)
+    assert abs(r1.skat_Q - h.skat_Q) <= 1e-11 * h.skat_Q and abs(r1.skat_p - h.skat_p) <= 1e-6 * h.skat_p + ABS_P
+    assert r1.skato_rho == h.skato_rho and abs(r1.skato_p - h.skato_p) <= 1e-6 * h.skato_p + ABS_SKATO
+    assert r1.cmc_nonref == int((c > 0).sum())
+    assert abs(r1.cmc_p - h.cmc_p) <= 1e-8 * h.cmc_p and abs(r1.zeg_p - h.zeg_p) <= 1e-8 * h.zeg_p
+    # permutation of the samples
+    perm = rng.permutation(N)
+    engine.set_null(0, X[perm], res[perm], v, s2)
+    ptr2 = engine.upload_block(np.asfortranarray(G[perm]))
+    r2 = engine.run_blocks([ptr2, ptr2], [M, M], [af, af])
+    assert r2[0].skat_p == r2[1].skat_p and r2[0].skato_p == r2[1].skato_p            # order within a batch
+    assert abs(r2[0].skat_p - r1.skat_p) <= 1e-6 * r1.skat_p + ABS_P
+    assert abs(r2[0].skato_p - r1.skato_p) <= 1e-6 * r1.skato_p + ABS_SKATO
+    assert r2[0].cmc_nonref == r1.cmc_nonref and abs(r2[0].cmc_stat - r1.cmc_stat) <= 1e-9 * r1.cmc_stat
+    engine.free_block(ptr)
+    engine.free_block(ptr2)
