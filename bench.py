@@ -108,15 +108,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; RVT_BENCH_BACKEND=gloo lets two ranks share GPU 0 to exercise the N > 1 path on a 1-GPU box
+    backend = os.environ.get("RVT_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     N = args.samples
-    eng = rvtests_amd.Engine(local_rank)
+    eng = rvtests_amd.Engine(gpu_index)
     ld = eng.padded_ld(N)
 
     # ---- null model: fitted on rank 0, broadcast (collective C1), installed on every rank ----------------
@@ -161,7 +167,8 @@ def main():
     def retire(b):
         """step finished on this rank: C2 = gather its per-gene records on rank 0 (gene order)"""
         if world > 1:
-            shard.gather_records(dist, shard.records_from_results(b["out"]), counts, device=dev, dst=0)
+            shard.gather_records(dist, shard.records_from_results(b["out"]), counts,
+                                 device=dev if backend == "nccl" else None, dst=0)
 
     def run_steps(k):
         for i in range(k):
@@ -185,7 +192,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = eng.timing(reset=True)
     eng.set_profiling(False)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0])
