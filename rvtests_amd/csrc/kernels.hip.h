@@ -512,7 +512,11 @@ __global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restri
 //   (int)g' > 0 on the flipped genotype g': g >= 1 for an unflipped column, g <= 1 for a flipped one.
 //   Per sample:  n = popcount(((ge & ~flip) | (le & flip)) & poly);  c_cmc = (n > 0), c_zeg = n.
 //   Partial sums per block and test: U = Σ c·res, Σ w c², #(c != 0), Σ w c x_k   (w = v if binary else 1)
-// One thread = one sample, looped over the genes of the launch so X/res/v are read once per sample.
+// One thread = one (16-sample step, l) pair, i.e. the 4 samples whose bits share a ballot word, looped over the
+// genes of the launch so X/res/v are read once per sample; each mask word is read by exactly one thread and a
+// wave consumes a contiguous 16-step run of the mask array.  The 2 x (3+d) partial sums of a wave are reduced by
+// a halving butterfly (the value set is split between the two halves of the exchange at every stage), which
+// needs ~(3+d)*2 + 6 cross-lane moves instead of 6 per value.
 // =====================================================================================================
 constexpr int kBurdenSPB = 1024;  // samples per block (256 threads x 4)
 
@@ -520,71 +524,108 @@ template <int DMAX>
 __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __restrict__ genes, int n_genes,
                                                               NullDev nd, long long N, long long ld, int d, int binary,
                                                               unsigned tests) {
-  __shared__ double red[4][2 * (3 + DMAX)];
+  constexpr int NV = 2 * (3 + DMAX);                       // values reduced per gene
+  constexpr int NP = NV <= 16 ? 16 : (NV <= 32 ? 32 : 64); // padded to a power of two for the butterfly
+  __shared__ double red[4][NV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long base = (long long)blockIdx.x * kBurdenSPB;
   const long long nsteps = ld >> 4;
   const int rl = 3 + d;
+  const long long step = (base >> 4) + (tid >> 2);
+  const int l = tid & 3;
+  const bool step_ok = step < nsteps;
   double xr[4][DMAX], rres[4], wv[4];
   bool valid[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const long long smp = base + tid + 256 * q;
+  for (int q = 0; q < 4; ++q) {  // q = the 4-sample group (kk) inside the step
+    const long long smp = step * 16 + q * 4 + l;
     valid[q] = smp < N;
     const long long sidx = valid[q] ? smp : 0;
     rres[q] = valid[q] ? nd.res[sidx] : 0.0;
     wv[q] = valid[q] ? (binary ? nd.v[sidx] : 1.0) : 0.0;
-    #pragma unroll
+#pragma unroll
     for (int k = 0; k < DMAX; ++k) xr[q][k] = (valid[q] && k < d) ? nd.X[(long long)k * ld + sidx] : 0.0;
   }
   for (int g = 0; g < n_genes; ++g) {
     const GeneDesc gd = genes[g];
     const int MT = gd.MT;
-    const unsigned long long* mge = gd.masks;
-    const unsigned long long* mle = gd.masks + nsteps * MT * 4;
-    double acc[2][3 + DMAX];
+    const unsigned long long* mge = gd.masks + (step * MT) * 4 + l;
+    const unsigned long long* mle = mge + nsteps * MT * 4;
+    int n[4] = {0, 0, 0, 0};
+    if (step_ok) {
+      for (int c = 0; c < MT; ++c) {
+        const unsigned long long ge = mge[c * 4], le = mle[c * 4];
+        unsigned long long fl = gd.flags[c], po = gd.flags[MT + c];
+        fl |= fl << 16;
+        fl |= fl << 32;
+        po |= po << 16;
+        po |= po << 32;
+        const unsigned long long hit = ((ge & ~fl) | (le & fl)) & po;
+        n[0] += __popc((unsigned)hit & 0xffffu);
+        n[1] += __popc((unsigned)hit >> 16);
+        n[2] += __popc((unsigned)(hit >> 32) & 0xffffu);
+        n[3] += __popc((unsigned)(hit >> 48));
+      }
+    }
+    double val[NP];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int k = 0; k < 3 + DMAX; ++k) acc[t][k] = 0.0;
+    for (int k = 0; k < NP; ++k) val[k] = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const long long smp = base + tid + 256 * q;
-      int n = 0;
+      const int nq = valid[q] ? n[q] : 0;
+      const double cv[2] = {nq > 0 ? 1.0 : 0.0, (double)nq};
       if (valid[q]) {
-        const long long step = smp >> 4;
-        const int t16 = (int)(smp & 15), kk = t16 >> 2, l = t16 & 3;
-        for (int c = 0; c < MT; ++c) {
-          const unsigned ge = (unsigned)((mge[(step * MT + c) * 4 + l] >> (16 * kk)) & 0xffffu);
-          const unsigned le = (unsigned)((mle[(step * MT + c) * 4 + l] >> (16 * kk)) & 0xffffu);
-          const unsigned fl = gd.flags[c], po = gd.flags[MT + c];
-          n += __popc(((ge & ~fl) | (le & fl)) & po);
-        }
-      }
-      const double cv[2] = {n > 0 ? 1.0 : 0.0, (double)n};
-      if (valid[q]) {
+        const long long smp = step * 16 + q * 4 + l;
         if (gd.dbg_cmc) gd.dbg_cmc[smp] = cv[0];
         if (gd.dbg_zeg) gd.dbg_zeg[smp] = cv[1];
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const double c = cv[t];
-        acc[t][0] += c * rres[q];
-        acc[t][1] += (c * wv[q]) * c;
-        acc[t][2] += (c != 0.0) ? 1.0 : 0.0;
+        val[t * (3 + DMAX) + 0] += c * rres[q];
+        val[t * (3 + DMAX) + 1] += (c * wv[q]) * c;
+        val[t * (3 + DMAX) + 2] += (c != 0.0) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) acc[t][3 + k] += (c * wv[q]) * xr[q][k];
+        for (int k = 0; k < DMAX; ++k) val[t * (3 + DMAX) + 3 + k] += (c * wv[q]) * xr[q][k];
       }
     }
-    // block reduction in a fixed order
+    // halving butterfly in a fixed order: after the stage with lane distance D, a lane holds the sums over its
+    // D-pair of the half of the value set selected by its bit; when one value is left the remaining stages are
+    // plain exchanges.  Lane L ends with the wave total of value index bitreverse-free id computed below.
+    int width = NP;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int D = 32; D >= 1; D >>= 1) {
+      const bool upper = (lane & D) != 0;
+      if (width > 1) {
+        const int h = width >> 1;
 #pragma unroll
-      for (int k = 0; k < 3 + DMAX; ++k) {
-        double v = acc[t][k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && k < rl) red[wave][t * rl + k] = v;
+        for (int k = 0; k < NP / 2; ++k) {
+          if (k < h) {
+            const double keep = upper ? val[k + h] : val[k];
+            const double send = upper ? val[k] : val[k + h];
+            val[k] = keep + __shfl_xor(send, D, 64);
+          }
+        }
+        width = h;
+      } else {
+        val[0] += __shfl_xor(val[0], D, 64);
       }
+    }
+    // value index held by this lane: stage i (D = 32 >> i) chose the upper half of a width NP >> i set
+    {
+      int idx = 0, w = NP, D = 32;
+      while (w > 1) {
+        w >>= 1;
+        if (lane & D) idx += w;
+        D >>= 1;
+      }
+      // lanes that differ only in bits below the last halving stage hold the same value; one of them writes
+      const int low_mask = (NP >= 64) ? 0 : ((64 / NP) - 1);
+      if ((lane & low_mask) == 0) {
+        const int t = idx / (3 + DMAX), k = idx % (3 + DMAX);
+        if (idx < NV && k < rl) red[wave][t * rl + k] = val[0];
+      }
+    }
     __syncthreads();
     if (tid < 2 * rl) {
       const double s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];

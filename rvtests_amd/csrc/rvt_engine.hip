@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -57,6 +58,7 @@ struct rvt_ctx {
   unsigned long long launch_seq = 0;
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
+  bool cu_partitioned = false;
   hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
@@ -251,16 +253,58 @@ int rvt_init(rvt_ctx** out, int device_id) {
   rvt_ctx* c = new rvt_ctx();
   c->device = device_id;
   std::memset(&c->timing, 0, sizeof(c->timing));
-  for (int i = 0; i < kSlots; ++i)
-    if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
+  // Streams.  Every stream is created through hipExtStreamCreateWithCUMask, which gives it a hardware queue of its
+  // own: the runtime multiplexes ordinary streams onto at most GPU_MAX_HW_QUEUES (default 4) queues, and with
+  // five streams in use two of them would share a queue and serialise (measured: -8% throughput).
+  // By default the masks enable every CU.  RVT_STAGE2_CUS=k (a multiple of 32, 0 = off) instead partitions the
+  // chip: k CUs for the latency-bound stage (assemble / eigen / p-value), the rest for the streaming stage
+  // (sufficient statistics, burden collapse).  Mask bit b addresses XCD (b % 8), and inside it shader engine
+  // ((b / 8) % 4), CU slot (b / 32) — measured with tools/cu_probe.hip; an XCD whose bits are all zero is NOT
+  // restricted.  With the current kernels the partition does not pay (r1 measurements in DESIGN.md), so it is off.
+  int stage2_cus = 0;
+  if (const char* e = getenv("RVT_STAGE2_CUS")) stage2_cus = atoi(e);
+  hipDeviceProp_t prop;
+  const bool have_prop = hipGetDeviceProperties(&prop, device_id) == hipSuccess;
+  const int ncu = have_prop ? prop.multiProcessorCount : 0;
+  bool masked = false;
+  if (ncu >= 64 && stage2_cus < ncu && !getenv("RVT_PLAIN_STREAMS")) {
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> m1(words, 0u), m2(words, 0u);
+    stage2_cus = stage2_cus > 0 ? std::max(32, stage2_cus / 32 * 32) : 0;
+    for (int b = 0; b < ncu; ++b) {
+      if (stage2_cus == 0) {
+        m1[b / 32] |= 1u << (b % 32);
+        m2[b / 32] |= 1u << (b % 32);
+      } else {
+        (b < stage2_cus ? m2 : m1)[b / 32] |= 1u << (b % 32);
+      }
+    }
+    masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
+    for (int i = 0; masked && i < kSlots; ++i)
+      masked = hipExtStreamCreateWithCUMask(&c->slots[i].stream, words, m2.data()) == hipSuccess;
+    if (!masked) {
+      (void)hipGetLastError();
+      if (c->k2_stream) hipStreamDestroy(c->k2_stream);
+      c->k2_stream = nullptr;
+      for (int i = 0; i < kSlots; ++i) {
+        if (c->slots[i].stream) hipStreamDestroy(c->slots[i].stream);
+        c->slots[i].stream = nullptr;
+      }
+    }
+  }
+  c->cu_partitioned = masked && stage2_cus > 0;
+  if (!masked) {
+    for (int i = 0; i < kSlots; ++i)
+      if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RVT_E_HIP;
+      }
+    if (hipStreamCreateWithFlags(&c->k2_stream, hipStreamNonBlocking) != hipSuccess) {
       delete c;
       return RVT_E_HIP;
     }
-  c->stream = c->slots[0].stream;
-  if (hipStreamCreateWithFlags(&c->k2_stream, hipStreamNonBlocking) != hipSuccess) {
-    delete c;
-    return RVT_E_HIP;
   }
+  c->stream = c->slots[0].stream;
   for (int i = 0; i < kSlots; ++i) {
     hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming);
@@ -616,26 +660,27 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     launch_suffstat(c, c->k2_stream, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
-  HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
-  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
   if (burden || dbg) {
+    hipStream_t bs = c->k2_stream;  // bandwidth-class work stays on the streaming partition
     {
-      Scope sc(c, 1, st);
-      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, st, d_desc, (long long)N);
+      Scope sc(c, 1, bs);
+      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, bs, d_desc, (long long)N);
     }
     // gene groups of <= 64 per launch keep one block's loop short while X/res/v stay in registers
     for (int k = 0; k < n; k += 64) {
       const int cnt = std::min(64, n - k);
-      Scope sc(c, 1, st);
+      Scope sc(c, 1, bs);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, st, d_desc + k, cnt, nd,
+        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, bs, d_desc + k, cnt, nd,
                            (long long)N, (long long)ld, d, nc.binary, tests);
       else
-        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, st,
-                           d_desc + k, cnt, nd, (long long)N, (long long)ld, d, nc.binary, tests);
+        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, bs, d_desc + k, cnt,
+                           nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
   }
+  HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
+  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
     Scope sc(c, 2, st);
