@@ -115,8 +115,9 @@ int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum,
   gene_assemble(co, nc, M, Mp, Cp, parts.data(), 1, cs.data(), bstats, 1, af, *prm, tests, ws, &gs, flip_out,
                 kept_out);
   std::vector<double> vec((size_t)8 * Mp + 8);
-  for (int k = 0; k < kNEigen; ++k)
-    gene_eigen(co, nc, k, M, Mp, tests, ws, ws.eig + (size_t)k * Mp * Mp, vec.data(), &gs, lam.data());
+  for (int w = 0; w < kNTridiag; ++w)
+    gene_tridiag(co, nc, w, M, Mp, tests, ws, ws.eig + (size_t)w * Mp * Mp, vec.data(), &gs);
+  for (int k = 0; k < kNEigen; ++k) gene_spectrum(co, nc, k, M, Mp, tests, ws, vec.data(), &gs, lam.data());
   std::vector<int> th1(M + 1), th2(M + 1);
   std::vector<char> qmem(qags_workspace_bytes(kSkatoLimit));
   gene_pvalue_serial(gs, lam.data(), tests, 0, th1.data(), th2.data(), qmem.data(), out);

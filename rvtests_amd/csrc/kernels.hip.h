@@ -187,7 +187,7 @@ __device__ __forceinline__ void suffstat_load(const gcdp_t (&colp)[CT], long lon
 template <int MT, int CT, bool WEIGHTED, int DEPTH>
 __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev& nd, long long N, long long ld, int d) {
   const int lane = threadIdx.x & 63;
-  const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wpart = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wpart >= gd.n_wparts) return;
   const long long nsteps = ld >> 4;
   const long long s_begin = (long long)wpart * gd.steps_per_wpart;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void gene_suffstat_panel(const GeneDesc* __res
                                                            long long ld, int d) {
   const GeneDesc gd = genes[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int wpart = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wpart = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wpart >= gd.n_wparts) return;
   const int nPR = (gd.MT + 3) / 4, nPC = (gd.CT + 3) / 4;
   int pr = 0, pc = 0, z = blockIdx.z;
@@ -638,8 +638,9 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 // =====================================================================================================
 // K3a: per-gene assembly (reduce partials, flags, flip algebra, projection, weights, Q, tau, burden
 //      statistics), one 256-thread workgroup per gene.
-// K3b: one workgroup per (eigenproblem, gene): build the matrix in LDS, Householder tridiagonalisation,
-//      Sturm bisection, eigenvalue filter and moments.  13 eigenproblems per gene run concurrently.
+// K3b: one workgroup per (dense reduction, gene): build the matrix in LDS, Householder tridiagonalisation
+//      (one shared reduction serves the 12 SKAT-O eigenproblems, see rvt_gene.h stage B).
+// K3c: one workgroup per (eigenproblem, gene): Sturm bisection of its tridiagonal, eigenvalue filter, moments.
 // =====================================================================================================
 __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
@@ -656,19 +657,29 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
                 gd.stats, gd.dbg_flip, gd.dbg_kept);
 }
 
-__global__ __launch_bounds__(256) void gene_eigen_kernel(const GeneDesc* __restrict__ genes,
-                                                         const NullConsts* __restrict__ ncp, unsigned tests,
-                                                         int lds_doubles) {
+__global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
+                                                           const NullConsts* __restrict__ ncp, unsigned tests,
+                                                           int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double esm[];
   __shared__ double red[64];
   const GeneDesc gd = genes[blockIdx.y];
-  const int k = blockIdx.x;
+  const int which = blockIdx.x;
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   const int m = gd.stats->n_poly;
-  double* vec = esm;  // 8 * Mp doubles
-  double* Bm = (8 * gd.Mp + m * m <= lds_doubles) ? esm + 8 * gd.Mp : ws.eig + (size_t)k * gd.Mp * gd.Mp;
-  gene_eigen(co, *ncp, k, gd.M, gd.Mp, tests, ws, Bm, vec, gd.stats, gd.lambda);
+  double* vec = esm;  // 4 * Mp doubles
+  double* Bm = (4 * gd.Mp + m * m <= lds_doubles) ? esm + 4 * gd.Mp : ws.eig + (size_t)which * gd.Mp * gd.Mp;
+  gene_tridiag(co, *ncp, which, gd.M, gd.Mp, tests, ws, Bm, vec, gd.stats);
+}
+
+__global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDesc* __restrict__ genes,
+                                                            const NullConsts* __restrict__ ncp, unsigned tests) {
+  extern __shared__ __attribute__((aligned(16))) double esm[];  // 4 * Mp doubles
+  __shared__ double red[64];
+  const GeneDesc gd = genes[blockIdx.y];
+  Coop co{(int)threadIdx.x, (int)blockDim.x, red};
+  GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  gene_spectrum(co, *ncp, blockIdx.x, gd.M, gd.Mp, tests, ws, esm, gd.stats, gd.lambda);
 }
 
 // =====================================================================================================

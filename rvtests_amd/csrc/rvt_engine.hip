@@ -59,6 +59,7 @@ struct rvt_ctx {
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
   bool cu_partitioned = false;
+  int k2_waves_per_block = 1;
   hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
@@ -193,7 +194,11 @@ void drain_events(rvt_ctx* c) {
 
 template <int MT, int CT>
 void launch_suffstat_t(rvt_ctx* c, hipStream_t st, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
-  dim3 grid((max_wparts + 3) / 4, n), block(256);
+  // Waves are independent (no LDS, no barriers), so a workgroup is ONE wave: the dispatcher can then place the
+  // wide classes (one wave fills a SIMD's register file) on any free SIMD, instead of needing four free SIMDs on
+  // one CU at once — which a single long-lived p-value wave per CU would block for its whole lifetime.
+  const int wpb = c->k2_waves_per_block;
+  dim3 grid((max_wparts + wpb - 1) / wpb, n), block(64 * wpb);
   const long long N = c->nc.N, ld = c->nc.ld;
   if (c->nc.binary)
     hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, true>), grid, block, 0, st, d_desc, nd, N, ld, c->nc.d);
@@ -293,6 +298,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
     }
   }
   c->cu_partitioned = masked && stage2_cus > 0;
+  if (const char* e = getenv("RVT_K2_WAVES_PER_BLOCK")) c->k2_waves_per_block = std::min(4, std::max(1, atoi(e)));
   if (!masked) {
     for (int i = 0; i < kSlots; ++i)
       if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
@@ -315,7 +321,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
   }
   {  // let the eigen kernel keep matrices up to ~120 x 120 doubles in LDS
     const int want = 128 * 1024;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gene_eigen_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gene_tridiag_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
       c->eigen_lds_max = want;
     (void)hipGetLastError();
@@ -646,7 +652,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;
     int npanels = 0;
     for (int pr = 0; pr < nPR; ++pr) npanels += nPC - pr;
-    dim3 grid((n_wparts + 3) / 4, k0, npanels), block(256);
+    const int wpb = c->k2_waves_per_block;
+    dim3 grid((n_wparts + wpb - 1) / wpb, k0, npanels), block(64 * wpb);
     if (nc.binary)
       hipLaunchKernelGGL((gene_suffstat_panel<true>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
                          (long long)ld, d);
@@ -688,12 +695,19 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                        n_bparts);
   }
   if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO)) {
-    Scope sc(c, 2, st);
     const int maxMp = (maxM + 15) / 16 * 16;
-    size_t want = sizeof(double) * ((size_t)8 * maxMp + (size_t)maxM * maxM);
-    if (want > c->eigen_lds_max) want = sizeof(double) * (size_t)8 * maxMp;  // matrices stay in global scratch
-    hipLaunchKernelGGL(gene_eigen_kernel, dim3(kNEigen, n), dim3(256), want, st, d_desc, c->d_nc, tests_eff,
-                       (int)(want / sizeof(double)));
+    {
+      Scope sc(c, 2, st);
+      size_t want = sizeof(double) * ((size_t)4 * maxMp + (size_t)maxM * maxM);
+      if (want > c->eigen_lds_max) want = sizeof(double) * (size_t)4 * maxMp;  // matrices stay in global scratch
+      hipLaunchKernelGGL(gene_tridiag_kernel, dim3(kNTridiag, n), dim3(256), want, st, d_desc, c->d_nc, tests_eff,
+                         (int)(want / sizeof(double)));
+    }
+    {
+      Scope sc(c, 2, st);
+      hipLaunchKernelGGL(gene_spectrum_kernel, dim3(kNEigen, n), dim3(128), sizeof(double) * (size_t)4 * maxMp, st,
+                         d_desc, c->d_nc, tests_eff);
+    }
   }
   {
     Scope sc(c, 3, st);

@@ -26,30 +26,34 @@ namespace rvt {
 // layout of one burden partial record (per test): U, cVc, count, cVX[0..d-1]
 RVT_HD int burden_rec_len(int d) { return 3 + d; }
 
-constexpr int kNEigen = 13;  // eigenproblems per gene: 11 rho, Z(I-M)Z', SKAT
+constexpr int kNEigen = 13;   // eigenproblems per gene: 11 rho, Z(I-M)Z', SKAT
+constexpr int kNTridiag = 2;  // dense reductions per gene: the SKAT-O family's shared one, SKAT's own
 
 // per-gene workspace in global memory
 struct GeneScratch {
   double* R;     // Mp x Cp   reduced statistics, row-major (ld = Cp)
   double* Wm;    // Mp x Mp   projected matrix S' - T' Cinv T'^T on the kept columns (m x m, column-major)
-  double* eig;   // kNEigen x Mp x Mp   per-eigenproblem work matrices (used when they do not fit in LDS)
+  double* eig;   // kNTridiag x Mp x Mp   work matrices of the dense reductions (used when they do not fit in LDS)
+  double* tri;   // kNTridiag x 2 x Mp    tridiagonal forms (d, e) of the SKAT-O family and of SKAT
   double* vecs;  // 16 * Mp doubles of vector scratch (assemble stage)
   double* bw;    // 2 * Mp: sqrt(SKAT weight), SKAT-O weight (filtered index)
   double* rowsum;  // Mp: row sums of A = B Wm B / 2
   int* ivec;     // 2 * Mp ints
 };
 RVT_HD size_t gene_scratch_doubles(int Mp, int Cp) {
-  return (size_t)Mp * Cp + (size_t)(1 + kNEigen) * Mp * Mp + 16 * (size_t)Mp + 3 * (size_t)Mp + (size_t)Mp;
+  return (size_t)Mp * Cp + (size_t)(1 + kNTridiag) * Mp * Mp + 16 * (size_t)Mp + 3 * (size_t)Mp + (size_t)Mp +
+         (size_t)kNTridiag * 2 * Mp;
 }
 RVT_HD GeneScratch gene_scratch_carve(double* mem, int Mp, int Cp) {
   GeneScratch s;
   s.R = mem;
   s.Wm = s.R + (size_t)Mp * Cp;
   s.eig = s.Wm + (size_t)Mp * Mp;
-  s.vecs = s.eig + (size_t)kNEigen * Mp * Mp;
+  s.vecs = s.eig + (size_t)kNTridiag * Mp * Mp;
   s.bw = s.vecs + 16 * (size_t)Mp;
   s.rowsum = s.bw + 2 * (size_t)Mp;
   s.ivec = (int*)(s.rowsum + (size_t)Mp);
+  s.tri = (double*)(s.ivec) + (size_t)Mp;  // ivec holds 2*Mp ints = Mp doubles
   return s;
 }
 
@@ -348,15 +352,112 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
 }
 
 // ======================================================================================================
-// Stage B (one workgroup per gene AND eigenproblem k): build the k-th symmetric matrix from Wm, reduce it to
-// tridiagonal form, bisect for all eigenvalues, apply the reference's eigenvalue filter and moments.
-//   k = 0..10   L'(Z1'Z1)L for rho_k      (SkatO.cpp:163-175)  -> mom_mu/var/df[k]
-//   k = 11      Z(I-M)Z'                   (SkatO.cpp:178-195)  -> lambda (zimz), VarZeta, MuQ, VarQ, Df
-//   k = 12      K_sqrt P0 K_sqrt'          (Skat.cpp:47-98)     -> lambda (skat)
-// `Bm` is the m x m work matrix (LDS when it fits, the gene's scratch otherwise); `vec` >= 8*m doubles.
+// Stage B: eigenvalues.  The reference solves 13 dense symmetric eigenproblems per gene
+//   k = 0..10   L'(Z1'Z1/2)L for rho_k, L L' = R_rho = (1-rho) I + rho 11'   (SkatO.cpp:163-175)
+//   k = 11      Z(I-M)Z' = A - (A1)(A1)'/(1'A1)                               (SkatO.cpp:178-195)
+//   k = 12      K_sqrt P0 K_sqrt'                                             (Skat.cpp:47-98)
+// with A = Z1'Z1/2 = B Wm B / 2.  Twelve of them are rank-one modifications of the SAME matrix, and they
+// share one tridiagonal form:
+//   * L'AL is similar to R^1/2 A R^1/2 and R^1/2 = sqrt(1-rho) (I + (kappa-1) e e'), e = 1/sqrt(m),
+//     kappa^2 = (1-rho+m rho)/(1-rho).  With the Householder reflector H that maps e onto the first unit
+//     vector, H R^1/2 H = sqrt(1-rho) D, D = diag(kappa, 1, .., 1), so L'AL ~ (1-rho) D (HAH) D.
+//   * Householder tridiagonalisation T = Q'(HAH)Q never touches the first coordinate (Q = diag(1, Q')),
+//     so Q commutes with D and (1-rho) D T D — T with t11 scaled by (1-rho+m rho), t12 by
+//     sqrt((1-rho)(1-rho+m rho)) and the rest by (1-rho) — is the tridiagonal form for EVERY rho.
+//   * H (A1) = -sqrt(m) (HAH) e1, so in the same basis Z(I-M)Z' becomes T - (T e1)(T e1)'/t11: row and
+//     column 1 vanish (the exact zero eigenvalue, which the reference's filter drops) and the rest is the
+//     trailing tridiagonal of T with its first diagonal entry replaced by t22 - t12^2/t11.
+// The SKAT matrix equals 2 v A when SKAT and SKAT-O use the same weights (the defaults) and then reuses T as
+// well; otherwise it gets its own reduction.  So: stage B1 = one (or two) dense Householder reductions per
+// gene, stage B2 = 13 tridiagonal bisections (one workgroup each), instead of 13 dense reductions.
+// All of this is orthogonal similarity: the eigenvalues are those of the reference's matrices to rounding.
 // ======================================================================================================
-RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int Mp, unsigned tests, GeneScratch ws,
-                       double* Bm, double* vec, GeneStats* out, double* lambda_out) {
+
+// B <- H B H for the reflector H with H 1 = -sqrt(n) e1 (B symmetric n x n, column-major, full storage)
+RVT_HD void coop_reflect_ones(const Coop& co, double* B, int n, double* v, double* w) {
+  const double nrm = sqrt((double)n);
+  const double tau = (nrm + 1.0) / nrm;  // alpha = 1, beta = -sqrt(n): tau = (beta - alpha) / beta
+  const double scal = 1.0 / (1.0 + nrm);
+  for (int i = co.tid; i < n; i += co.nt) v[i] = (i == 0) ? 1.0 : scal;
+  co.sync();
+  double dotpart = 0.0;
+  for (int i = co.tid; i < n; i += co.nt) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += B[(size_t)j * n + i] * v[j];
+    s *= tau;
+    w[i] = s;
+    dotpart += s * v[i];
+  }
+  const double pv = co.sum(dotpart);
+  const double a2 = -0.5 * tau * pv;
+  for (int i = co.tid; i < n; i += co.nt) w[i] = w[i] + a2 * v[i];
+  co.sync();
+  for (int idx = co.tid; idx < n * n; idx += co.nt) {
+    const int i = idx % n, j = idx / n;
+    B[idx] -= v[i] * w[j] + w[i] * v[j];
+  }
+  co.sync();
+}
+
+// do SKAT and SKAT-O weigh the variants identically?  (every thread gets the same answer)
+RVT_HD bool skat_shares_weights(const GeneScratch& ws, int Mp, int m) {
+  for (int i = 0; i < m; ++i)
+    if (ws.bw[i] != ws.bw[Mp + i]) return false;
+  return true;
+}
+
+// Stage B1.  which = 0: SKAT-O family (also VarZeta); which = 1: SKAT (skipped when it can share).
+// `Bm` is the m x m work matrix (LDS when it fits, the gene's scratch otherwise); `vec` >= 4*m doubles.
+RVT_HD void gene_tridiag(const Coop& co, const NullConsts& nc, int which, int M, int Mp, unsigned tests,
+                         GeneScratch ws, double* Bm, double* vec, GeneStats* out) {
+  const int m = out->n_poly;
+  if (m < 2) return;  // single-variant genes need no reduction
+  const double* Wm = ws.Wm;
+  const double* bw_skat = ws.bw;
+  const double* bw_skato = ws.bw + Mp;
+  double* td = vec;          // tridiagonal d
+  double* te = vec + m;      // tridiagonal e
+  double* hv = vec + 2 * m;  // householder v
+  double* hw = vec + 3 * m;  // householder w
+  double* tri = ws.tri + (size_t)which * 2 * Mp;
+  if (which == 0) {
+    if (!(tests & RVT_TEST_SKATO) && !((tests & RVT_TEST_SKAT) && skat_shares_weights(ws, Mp, m))) return;
+    const double* rowsum = ws.rowsum;
+    double tot = 0.0;
+    for (int a = 0; a < m; ++a) tot += rowsum[a];
+    double vzpart = 0.0;
+    for (int idx = co.tid; idx < m * m; idx += co.nt) {
+      const int i = idx % m, j = idx / m;
+      const double aij = bw_skato[i] * Wm[idx] * bw_skato[j] / 2.0;
+      const double zmz = rowsum[i] * rowsum[j] / tot;
+      Bm[idx] = aij;
+      vzpart += zmz * (aij - zmz);
+    }
+    const double vz = co.sum(vzpart);
+    if (co.tid == 0) out->varZeta = 4.0 * vz;
+    co.sync();
+    coop_reflect_ones(co, Bm, m, hv, hw);
+  } else {
+    if (!(tests & RVT_TEST_SKAT) || skat_shares_weights(ws, Mp, m)) return;
+    const double vscale = nc.binary ? 1.0 : nc.sigma2;  // quantitative: statistics were unweighted, v = sigma2
+    for (int idx = co.tid; idx < m * m; idx += co.nt) {
+      const int a = idx % m, b = idx / m;
+      Bm[idx] = bw_skat[a] * (vscale * Wm[idx]) * bw_skat[b];
+    }
+    co.sync();
+  }
+  coop_tridiagonalize(co, Bm, m, td, te, hv, hw);
+  for (int i = co.tid; i < m; i += co.nt) {
+    tri[i] = td[i];
+    tri[Mp + i] = (i < m - 1) ? te[i] : 0.0;
+  }
+  co.sync();
+}
+
+// Stage B2 (one workgroup per gene AND eigenproblem k): the k-th tridiagonal from stage B1's, bisection for all
+// eigenvalues, the reference's eigenvalue filter and moments.  `vec` >= 4*m doubles.
+RVT_HD void gene_spectrum(const Coop& co, const NullConsts& nc, int k, int M, int Mp, unsigned tests, GeneScratch ws,
+                          double* vec, GeneStats* out, double* lambda_out) {
   const int m = out->n_poly;
   if (m == 0) return;
   const bool is_skat = (k == 12);
@@ -366,26 +467,17 @@ RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int M
   const double* Wm = ws.Wm;
   const double* bw_skat = ws.bw;
   const double* bw_skato = ws.bw + Mp;
-  const double* rowsum = ws.rowsum;
   double* ev = vec;          // eigenvalues ascending
-  double* td = vec + m;      // tridiagonal d
-  double* te = vec + 2 * m;  // tridiagonal e
-  double* hv = vec + 3 * m;  // householder v
-  double* hw = vec + 4 * m;  // householder w
-  double* cd = vec + 5 * m;  // cholesky diag of R_rho
-  double* cc = vec + 6 * m;  // cholesky below-diagonal constant per column
-  double* tmpv = vec + 7 * m;
-  double vz = 0.0;
-  if (is_skat) {
-    const double vscale = nc.binary ? 1.0 : nc.sigma2;  // quantitative: statistics were unweighted, v = sigma2
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int a = idx % m, b = idx / m;
-      Bm[idx] = bw_skat[a] * (vscale * Wm[idx]) * bw_skat[b];
-    }
-    co.sync();
-  } else if (k == 11) {
-    if (m == 1) {
-      if (co.tid == 0) {
+  double* td = vec + m;      // this problem's tridiagonal d
+  double* te = vec + 2 * m;  // ... and e
+  double* tmpv = vec + 3 * m;
+  int n = m;
+  if (m == 1) {
+    if (co.tid == 0) {
+      if (is_skat) {
+        const double vscale = nc.binary ? 1.0 : nc.sigma2;
+        ev[0] = bw_skat[0] * (vscale * Wm[0]) * bw_skat[0];
+      } else {
         const double lam = bw_skato[0] * Wm[0] * bw_skato[0] / 2.0;
         if (lam > 0) {
           lambda_out[M] = lam;
@@ -396,74 +488,54 @@ RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int M
           out->eig_ok[11] = 0;
         }
       }
-      co.sync();
-      return;
     }
-    double tot = 0.0;
-    for (int a = 0; a < m; ++a) tot += rowsum[a];
-    double vzpart = 0.0;
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int i = idx % m, j = idx / m;
-      const double aij = bw_skato[i] * Wm[idx] * bw_skato[j] / 2.0;
-      const double zmz = rowsum[i] * rowsum[j] / tot;
-      const double zimz = aij - zmz;
-      Bm[idx] = zimz;
-      vzpart += zmz * zimz;
-    }
-    vz = co.sum(vzpart);
     co.sync();
+    if (!is_skat) return;
   } else {
-    const double rh = skato_rho_value(k);
-    // Cholesky factor of R_rho = (1-rho) I + rho 11': L[j][j] = cd[j], L[i][j] = cc[j] (i > j)
-    if (co.tid == 0) {
-      double acc = 0.0;  // sum_{k<j} cc[k]^2
-      for (int j = 0; j < m; ++j) {
-        const double dj = sqrt(1.0 - acc);
-        cd[j] = dj;
-        cc[j] = (rh - acc) / dj;
-        acc += cc[j] * cc[j];
+    const double* d0 = ws.tri;
+    const double* e0 = ws.tri + Mp;
+    if (is_skat) {
+      if (skat_shares_weights(ws, Mp, m)) {
+        const double sc = 2.0 * (nc.binary ? 1.0 : nc.sigma2);
+        for (int i = co.tid; i < m; i += co.nt) {
+          td[i] = sc * d0[i];
+          te[i] = sc * e0[i];
+        }
+      } else {
+        for (int i = co.tid; i < m; i += co.nt) {
+          td[i] = ws.tri[2 * Mp + i];
+          te[i] = ws.tri[3 * Mp + i];
+        }
+      }
+    } else if (k == 11) {
+      n = m - 1;
+      if (!(d0[0] > 0.0)) {  // 1'A1 <= 0: the reference's M is 0/0 and every eigenvalue NaN
+        if (co.tid == 0) out->eig_ok[11] = 0;
+        co.sync();
+        return;
+      }
+      for (int i = co.tid; i < n; i += co.nt) {
+        td[i] = (i == 0) ? d0[1] - e0[0] * e0[0] / d0[0] : d0[i + 1];
+        te[i] = e0[i + 1];
+      }
+    } else {
+      const double rh = skato_rho_value(k);
+      const double s1 = 1.0 - rh, sm = 1.0 - rh + (double)m * rh;
+      const double s1m = sqrt(s1 * sm);
+      for (int i = co.tid; i < m; i += co.nt) {
+        td[i] = (i == 0) ? sm * d0[0] : s1 * d0[i];
+        te[i] = (i == 0) ? s1m * e0[0] : s1 * e0[i];
       }
     }
     co.sync();
-    // (A L)[i][q] = A[i][q] cd[q] + cc[q] * sum_{j>q} A[i][j] : thread i walks its row from the right
-    for (int i = co.tid; i < m; i += co.nt) {
-      double tail = 0.0;
-      for (int q = m - 1; q >= 0; --q) {
-        const double aiq = bw_skato[i] * Wm[(size_t)q * m + i] * bw_skato[q] / 2.0;
-        Bm[(size_t)q * m + i] = aiq * cd[q] + cc[q] * tail;
-        tail += aiq;
-      }
-    }
-    co.sync();
-    // K[p][q] = cd[p] AL[p][q] + cc[p] * sum_{i>p} AL[i][q] : thread q walks its column from the bottom
-    for (int q = co.tid; q < m; q += co.nt) {
-      double tail = 0.0;
-      for (int p = m - 1; p >= 0; --p) {
-        const double alpq = Bm[(size_t)q * m + p];
-        Bm[(size_t)q * m + p] = cd[p] * alpq + cc[p] * tail;
-        tail += alpq;
-      }
-    }
-    co.sync();
-    // exact symmetry for the eigen solver
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int i = idx % m, j = idx / m;
-      if (i > j) Bm[(size_t)j * m + i] = 0.5 * (Bm[(size_t)j * m + i] + Bm[(size_t)i * m + j]);
-    }
-    co.sync();
-    for (int idx = co.tid; idx < m * m; idx += co.nt) {
-      const int i = idx % m, j = idx / m;
-      if (i < j) Bm[(size_t)j * m + i] = Bm[(size_t)i * m + j];
-    }
-    co.sync();
+    coop_tridiag_eigvals(co, td, te, n, ev);
   }
-  coop_sym_eigvals(co, Bm, m, td, te, hv, hw, ev);
   if (co.tid == 0) {
     if (is_skat) {
       double* lam_skat = lambda_out;
       const int r_ub = (nc.N < (int64_t)m) ? (int)nc.N : m;
       int r = 0;
-      for (int i = m - 1; i >= 0; --i) {
+      for (int i = n - 1; i >= 0; --i) {
         if (ev[i] > 1e-30 && r < r_ub) {
           lam_skat[r++] = ev[i];
         } else
@@ -473,7 +545,7 @@ RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int M
       out->eig_ok[12] = 1;
     } else if (k == 11) {
       double* lam_zimz = lambda_out + M;
-      const int nk = skato_filter_eigen(ev, m, lam_zimz);
+      const int nk = skato_filter_eigen(ev, n, lam_zimz);
       if (nk < 0) {
         out->eig_ok[11] = 0;
       } else {
@@ -486,7 +558,6 @@ RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int M
           l4 += l * l * l * l;
         }
         out->zimz_lambda_sum = ls;
-        out->varZeta = 4.0 * vz;
         out->muQ = ls;
         out->varQ = 2.0 * l2 + out->varZeta;
         const double KerQ = l4 / l2 / l2 * 12;
@@ -494,7 +565,7 @@ RVT_HD void gene_eigen(const Coop& co, const NullConsts& nc, int k, int M, int M
         out->eig_ok[11] = 1;
       }
     } else {
-      const int nk = skato_filter_eigen(ev, m, tmpv);
+      const int nk = skato_filter_eigen(ev, n, tmpv);
       if (nk < 0) {
         out->eig_ok[k] = 0;
       } else {

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 def short(name):
     for key, tag in (("gene_suffstat_panel", "K2p"), ("gene_suffstat_mfma", "K2"), ("gene_flags", "FL"),
-                     ("burden_collapse", "BU"), ("gene_assemble", "AS"), ("gene_eigen", "EI"),
+                     ("burden_collapse", "BU"), ("gene_assemble", "AS"), ("gene_tridiag", "TD"), ("gene_spectrum", "SP"),
                      ("gene_pvalue", "PV")):
         if key in name:
             if tag == "K2":
@@ -52,7 +52,7 @@ def main():
     print("%-22s %6s %10s %12s" % ("kernel", "calls", "total ms", "ms / batch"))
     for tag, (n, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print("%-22s %6d %10.2f %12.3f" % (tag, n, ms, ms / max(npv, 1)))
-    for grp, pred in (("K2*", lambda t: t.startswith("K2")), ("stage2 (AS+EI+PV)", lambda t: t in ("AS", "EI", "PV"))):
+    for grp, pred in (("K2*", lambda t: t.startswith("K2")), ("stage2 (AS+TD+SP+PV)", lambda t: t in ("AS", "TD", "SP", "PV"))):
         # union of busy intervals
         iv = sorted((s, e) for s, e, t, q in win if pred(t))
         busy, cur_s, cur_e = 0, None, None
