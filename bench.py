@@ -150,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     # pre-packed batches over the same resident blocks: the engine keeps up to four batches in flight (one HIP
     # stream each), so the latency-bound tail of step i overlaps the bandwidth-bound head of step i+1
-    NSLOT = 4  # RVT_MAX_INFLIGHT
+    NSLOT = rvtests_amd.MAX_INFLIGHT  # RVT_MAX_INFLIGHT
     batches = [eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests) for _ in range(NSLOT)]
     batch = batches[0]
 

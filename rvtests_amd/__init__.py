@@ -6,7 +6,9 @@ reference's model registry (``rvtests_amd.models``).  There is no CPU fallback: 
 missing or there is no GPU, construction fails loudly.
 """
 from .engine import (Engine, GeneResult, Params, Timing, RvtError, build_library, library_path, load_library,
-                     TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL, TRAIT_QUANTITATIVE, TRAIT_BINARY)
+                     TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL, TRAIT_QUANTITATIVE, TRAIT_BINARY,
+                     MAX_INFLIGHT)
 
 __all__ = ["Engine", "GeneResult", "Params", "Timing", "RvtError", "build_library", "library_path", "load_library",
-           "TEST_SKAT", "TEST_SKATO", "TEST_CMC", "TEST_ZEGGINI", "TEST_ALL", "TRAIT_QUANTITATIVE", "TRAIT_BINARY"]
+           "TEST_SKAT", "TEST_SKATO", "TEST_CMC", "TEST_ZEGGINI", "TEST_ALL", "TRAIT_QUANTITATIVE", "TRAIT_BINARY",
+           "MAX_INFLIGHT"]

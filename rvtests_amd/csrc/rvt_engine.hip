@@ -50,7 +50,7 @@ struct Slot {
   int pending_n = 0;
   unsigned long long seq = 0;  // launch order
 };
-constexpr int kSlots = 4;
+constexpr int kSlots = RVT_MAX_INFLIGHT;
 
 struct rvt_ctx {
   int device = 0;
@@ -667,9 +667,13 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     launch_suffstat(c, c->k2_stream, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
+  HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
+  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
   if (burden || dbg) {
-    hipStream_t bs = c->k2_stream;  // bandwidth-class work stays on the streaming partition
+    // on the batch's own stream: the collapse overlaps the next batch's sufficient-statistics launches, which
+    // leave about half of the HBM bandwidth unused
+    hipStream_t bs = st;
     {
       Scope sc(c, 1, bs);
       hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, bs, d_desc, (long long)N);
@@ -686,8 +690,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                            nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
   }
-  HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
-  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
     Scope sc(c, 2, st);

@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBNAME = "librvtests_amd.so"
 
 TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL = 1, 2, 4, 8, 15
+MAX_INFLIGHT = 8  # RVT_MAX_INFLIGHT (include/rvtests_amd.h)
 TRAIT_QUANTITATIVE, TRAIT_BINARY = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
