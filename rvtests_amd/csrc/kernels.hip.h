@@ -311,16 +311,57 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
 }
 
 
-// One kernel per tile configuration (MT row tiles x CT column tiles), so each gets its own register allocation:
-// up to 59 variants (MT*CT <= 16) accumulators + load ring (3 deep up to CT = 3, else 2 deep) fit the 256 registers
-// that allow two waves per SIMD, wider genes run one wave per SIMD; the engine launches the classes of a batch back to back.
-// Grid = (wave-parts / 4, genes of this class).
+// One body per tile configuration (MT row tiles x CT column tiles); the configurations are grouped by register
+// budget into three kernels so that a batch needs three launches, not one per configuration — every launch ends
+// with a tail in which the chip drains, and with the genes of a launch sorted widest-first the tail of a big
+// launch is short:
+//   group 0  <= 128 registers, 4 waves / SIMD   (1,1) (1,2) (2,2)            M <= 28 (unweighted)
+//   group 1  <= 256 registers, 2 waves / SIMD   (2,3) (3,3) (3,4) (4,4)      M <= 60   [+ weighted (2,2)]
+//   group 2  <= 512 registers, 1 wave  / SIMD   (4,5) (5,5) (5,6) (6,6) (6,7) M <= 96
+// Inside a kernel the gene's configuration selects the body (a wave-uniform switch); the register allocation of
+// the kernel is the largest of its group.  Grid = (wave-parts, genes of the group), one wave per workgroup.
 template <int MT, int CT, bool WEIGHTED>
-__global__ __launch_bounds__(256, (MT * CT <= 16) ? 2 : 1) void gene_suffstat_mfma(const GeneDesc* __restrict__ genes,
-                                                                                  NullDev nd, long long N,
-                                                                                  long long ld, int d) {
+__device__ __forceinline__ void suffstat_class(const GeneDesc& gd, const NullDev& nd, long long N, long long ld,
+                                               int d) {
+  // ring depth: 3 wherever the registers allow it without dropping an occupancy step (see tools/kernel_regs.sh)
+  constexpr int kDepth = (CT <= 3)         ? 3
+                         : (MT * CT <= 16) ? (WEIGHTED ? 2 : 3)
+                         : (CT <= 5)       ? 3
+                                           : 2;
+  suffstat_body<MT, CT, WEIGHTED, kDepth>(gd, nd, N, ld, d);
+}
+
+__host__ __device__ constexpr int suffstat_group(int MT, int CT, bool weighted) {
+  return (MT * CT > 16) ? 2 : ((MT * CT <= 4 && !(weighted && MT == 2)) ? 0 : 1);
+}
+
+template <int GROUP, bool WEIGHTED>
+__global__ __launch_bounds__(64, GROUP == 0 ? 4 : (GROUP == 1 ? 2 : 1)) void gene_suffstat_mfma(
+    const GeneDesc* __restrict__ genes, NullDev nd, long long N, long long ld, int d) {
   const GeneDesc gd = genes[blockIdx.y];
-  suffstat_body<MT, CT, WEIGHTED, (CT <= 3) ? 3 : 2>(gd, nd, N, ld, d);
+  const int cls = gd.MT * 8 + gd.CT;
+#define RVT_CLASS(mt, ct)                                                \
+  case mt * 8 + ct:                                                      \
+    if constexpr (suffstat_group(mt, ct, WEIGHTED) == GROUP)             \
+      suffstat_class<mt, ct, WEIGHTED>(gd, nd, N, ld, d);                \
+    break
+  switch (cls) {
+    RVT_CLASS(1, 1);
+    RVT_CLASS(1, 2);
+    RVT_CLASS(2, 2);
+    RVT_CLASS(2, 3);
+    RVT_CLASS(3, 3);
+    RVT_CLASS(3, 4);
+    RVT_CLASS(4, 4);
+    RVT_CLASS(4, 5);
+    RVT_CLASS(5, 5);
+    RVT_CLASS(5, 6);
+    RVT_CLASS(6, 6);
+    RVT_CLASS(6, 7);
+    default:
+      break;
+  }
+#undef RVT_CLASS
 }
 
 // ---- genes wider than 6 row tiles (M > 96): the tile grid is cut into panels of up to 4 x 4 tiles -----------

@@ -59,7 +59,6 @@ struct rvt_ctx {
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
   bool cu_partitioned = false;
-  int k2_waves_per_block = 1;
   hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
@@ -192,39 +191,28 @@ void drain_events(rvt_ctx* c) {
   c->events.clear();
 }
 
-template <int MT, int CT>
-void launch_suffstat_t(rvt_ctx* c, hipStream_t st, const GeneDesc* d_desc, int n, int max_wparts, const NullDev& nd) {
+// genes [0, n) of one register-budget group (kernels.hip.h: suffstat_group)
+void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_desc, int n, int max_wparts,
+                     const NullDev& nd) {
+  Scope sc(c, 0, st);
   // Waves are independent (no LDS, no barriers), so a workgroup is ONE wave: the dispatcher can then place the
   // wide classes (one wave fills a SIMD's register file) on any free SIMD, instead of needing four free SIMDs on
   // one CU at once — which a single long-lived p-value wave per CU would block for its whole lifetime.
-  const int wpb = c->k2_waves_per_block;
-  dim3 grid((max_wparts + wpb - 1) / wpb, n), block(64 * wpb);
+  dim3 grid(max_wparts, n), block(64);
   const long long N = c->nc.N, ld = c->nc.ld;
-  if (c->nc.binary)
-    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, true>), grid, block, 0, st, d_desc, nd, N, ld, c->nc.d);
-  else
-    hipLaunchKernelGGL((gene_suffstat_mfma<MT, CT, false>), grid, block, 0, st, d_desc, nd, N, ld, c->nc.d);
-}
-
-// genes [0, n) of one tile class
-void launch_suffstat(rvt_ctx* c, hipStream_t st, int MT, int CT, const GeneDesc* d_desc, int n, int max_wparts,
-                     const NullDev& nd) {
-  Scope sc(c, 0, st);
-#define RVT_CASE(mt, ct) \
-  if (MT == mt && CT == ct) return launch_suffstat_t<mt, ct>(c, st, d_desc, n, max_wparts, nd)
-  RVT_CASE(1, 1);
-  RVT_CASE(1, 2);
-  RVT_CASE(2, 2);
-  RVT_CASE(2, 3);
-  RVT_CASE(3, 3);
-  RVT_CASE(3, 4);
-  RVT_CASE(4, 4);
-  RVT_CASE(4, 5);
-  RVT_CASE(5, 5);
-  RVT_CASE(5, 6);
-  RVT_CASE(6, 6);
-  RVT_CASE(6, 7);
-#undef RVT_CASE
+  const int d = c->nc.d;
+#define RVT_GROUP(g)                                                                                            \
+  if (group == g) {                                                                                             \
+    if (c->nc.binary)                                                                                           \
+      hipLaunchKernelGGL((gene_suffstat_mfma<g, true>), grid, block, 0, st, d_desc, nd, N, ld, d);              \
+    else                                                                                                        \
+      hipLaunchKernelGGL((gene_suffstat_mfma<g, false>), grid, block, 0, st, d_desc, nd, N, ld, d);             \
+    return;                                                                                                     \
+  }
+  RVT_GROUP(0)
+  RVT_GROUP(1)
+  RVT_GROUP(2)
+#undef RVT_GROUP
 }
 
 // 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
@@ -298,7 +286,6 @@ int rvt_init(rvt_ctx** out, int device_id) {
     }
   }
   c->cu_partitioned = masked && stage2_cus > 0;
-  if (const char* e = getenv("RVT_K2_WAVES_PER_BLOCK")) c->k2_waves_per_block = std::min(4, std::max(1, atoi(e)));
   if (!masked) {
     for (int i = 0; i < kSlots; ++i)
       if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
@@ -549,7 +536,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     return o;
   };
   struct Off {
-    size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, af, stats, dbg_flip, dbg_kept;
+    size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, dbg_flip, dbg_kept;
   };
   std::vector<Off> offs(n);
   int maxM = 0;
@@ -579,7 +566,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     o.scratch = add(sizeof(double) * (gene_scratch_doubles(gd.Mp, gd.Cp) + 8));
     o.lambda = add(sizeof(double) * 2 * M);
     o.qags = add(qags_workspace_bytes(kSkatoLimit));
-    o.af = add(sizeof(double) * M);
     o.stats = add(sizeof(GeneStats));
     if (dbg) {
       o.dbg_flip = add(sizeof(int) * M);
@@ -587,6 +573,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
     af_total += M;
   }
+  const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
   size_t off_dbg_cmc = 0, off_dbg_zeg = 0;
@@ -615,7 +602,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.scratch = reinterpret_cast<double*>(base + o.scratch);
     gd.lambda = reinterpret_cast<double*>(base + o.lambda);
     gd.qags_mem = base + o.qags;
-    gd.af = reinterpret_cast<const double*>(base + o.af);
+    gd.af = reinterpret_cast<const double*>(base + off_af) + afpos;
     gd.stats = reinterpret_cast<GeneStats*>(base + o.stats);
     gd.result = reinterpret_cast<rvt_gene_result*>(base + off_res) + g;
     if (dbg) {
@@ -626,10 +613,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
         gd.dbg_zeg = reinterpret_cast<double*>(base + off_dbg_zeg);
       }
     }
-    std::memcpy(h_af + afpos, af + afpos, sizeof(double) * gd.M);
-    HIP_TRY(c, hipMemcpyAsync(base + o.af, h_af + afpos, sizeof(double) * gd.M, hipMemcpyHostToDevice, st));
     afpos += gd.M;
   }
+  std::memcpy(h_af, af, sizeof(double) * af_total);
+  HIP_TRY(c, hipMemcpyAsync(base + off_af, h_af, sizeof(double) * af_total, hipMemcpyHostToDevice, st));
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
   std::vector<int> order(n);
   for (int g = 0; g < n; ++g) order[g] = g;
@@ -652,8 +639,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;
     int npanels = 0;
     for (int pr = 0; pr < nPR; ++pr) npanels += nPC - pr;
-    const int wpb = c->k2_waves_per_block;
-    dim3 grid((n_wparts + wpb - 1) / wpb, k0, npanels), block(64 * wpb);
+    dim3 grid(n_wparts, k0, npanels), block(64);
     if (nc.binary)
       hipLaunchKernelGGL((gene_suffstat_panel<true>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
                          (long long)ld, d);
@@ -661,10 +647,11 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       hipLaunchKernelGGL((gene_suffstat_panel<false>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
                          (long long)ld, d);
   }
-  for (int k = k0; k < n;) {  // descriptors are sorted by width, so every tile class is one contiguous run
+  for (int k = k0; k < n;) {  // descriptors are sorted by width, so every register-budget group is one contiguous run
+    const int grp = suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0);
     int e = k;
-    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].CT == h_desc[k].CT) ++e;
-    launch_suffstat(c, c->k2_stream, h_desc[k].MT, h_desc[k].CT, d_desc + k, e - k, n_wparts, nd);
+    while (e < n && suffstat_group(h_desc[e].MT, h_desc[e].CT, nc.binary != 0) == grp) ++e;
+    launch_suffstat(c, c->k2_stream, grp, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
