@@ -93,8 +93,8 @@ def cpu_baseline(G_host, af, X, y, res, v, n_threads=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--samples", type=int, default=500000)
     ap.add_argument("--genes", type=int, default=256, help="genes per step per GPU")
     ap.add_argument("--m-lo", type=int, default=20)
@@ -207,6 +207,16 @@ def main():
         bytes_per_launch = tm.alg_bytes / max(tm.n_suffstat_launches, 1)
         achieved = bytes_per_launch / (ms_k2 * 1e-3) / 1e9 if ms_k2 > 0 else 0.0
         tot_ms = tm.ms_suffstat + tm.ms_burden + tm.ms_stats + tm.ms_pvalue
+        # HBM traffic per launch from the committed PMC passes of this same workload (tools/collect_profiles.sh,
+        # tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); null when the workload differs
+        traffic = None
+        key = "N=%d,genes=%d,m=%d..%d,seed=20260002,tests=%d" % (N, args.genes, args.m_lo, args.m_hi, args.tests)
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == key:
+                k2 = pmc["kernels"]["suffstat"]
+                traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
         line = {
             "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",
             "value": value, "unit": "gene-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,7 +228,8 @@ def main():
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
                        "parallelism": "gene-sharded x%d" % world, "genes_ok": ok},
             "roofline": {"kernel": "gene_suffstat_mfma", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "tflops_fp64_mfma": (tm.alg_flops / max(tm.ms_suffstat, 1e-9)) / 1e9,
                          "avg_launch_ms": ms_k2, "launches": int(tm.n_suffstat_launches)},
             "kernel_time_share": {"suffstat_mfma": tm.ms_suffstat / tot_ms, "burden": tm.ms_burden / tot_ms,
