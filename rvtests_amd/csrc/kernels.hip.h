@@ -849,7 +849,7 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
   return p;
 }
 
-__global__ __launch_bounds__(64) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes, unsigned tests) {
+__global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes, unsigned tests) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double ctl[4];  // a1, b1, b2, running / result, status
   const GeneDesc gd = genes[blockIdx.x];
