@@ -155,6 +155,26 @@ int rvt_submit_gene(rvt_ctx* ctx, int64_t gene_id, int M, const double* G, const
                     const rvt_params* params);
 int rvt_collect(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
 
+/* ---- MetaCov: score-covariance band (`--meta cov`) ------------------------------------------------------
+ * Replaces the arithmetic of MetaCovTest::fitWithGivenGenotype / printCovariance / computeScaledXX
+ * (src/Model.cpp:844-1004, src/Model.h:3993-4005) with MetaCovUnrelatedQtl / MetaCovUnrelatedBinary
+ * (src/Model.cpp:506-593, 694-778) as the model — i.e. unrelated samples; the family (FastLMM) variants are not
+ * provided.  `dG` is a device block (rvt_block_alloc) whose V <= RVT_MAX_VARIANTS columns are the imputed genotype
+ * vectors of V consecutive single-variant fit() calls (what assignGenotype copies into its ring, Model.cpp:936-942).
+ * Outputs (host):
+ *   cov[h + j*V], j >= h : covXX(h,j) - covXZ_h' covZZInv covXZ_j, the value printCovariance prints for head h and
+ *                          marker j BEFORE its 1/N scaling (lower triangle untouched)
+ *   xz[h*d + k]          : covXZ of variant h (printed after ':' for binary traits / gwama)
+ *   zz[a*d + b]          : covZZ (may be NULL)
+ *   polymorphic[h]       : 0 when isMonomorphicMarker (src/DataConsolidator.cpp:94-116) would have skipped h
+ * The caller applies the window rule (src/Model.h:3956-3990) and the text formatting; the null model is the one
+ * installed by rvt_set_null (trait, X with intercept, sigma2 / v).  Synchronous. */
+int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
+/* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous). */
+int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, const double* G);
+/* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */
+int rvt_block_move_columns(rvt_ctx* ctx, double* dG, int dst_col, int src_col, int ncols);
+
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */
 int rvt_debug_collapse(rvt_ctx* ctx, const double* dG, int M, double* cmc_out, double* zeg_out,

@@ -109,6 +109,22 @@ int orc_rand(void);
 int orc_skat_permute(const double* G, const double* af, int64_t N, int M, const double* res, double beta1,
                      double beta2, double obs, int nPerm, double alpha, int use_float, orc_perm_result* out);
 
+/* ---- MetaCovTest for unrelated samples (src/Model.cpp:844-1004; MetaCovUnrelatedQtl :506-593,
+        MetaCovUnrelatedBinary :694-778; window rule src/Model.h:3956-3990).
+        G: N x V imputed genotypes (one variant per column, file order); chrom[V] (any integer id), pos[V];
+        X: N x d incl. intercept; y: N.  use_float = 1 restates the reference's fp32 storage/arithmetic.
+        Outputs (all caller-allocated):
+          kept[V]      1 if the variant entered the queue (not monomorphic)
+          cov[V*V]     cov[h + j*V] for j >= h in the same window = the value printed for (head h, marker j)
+                       BEFORE the 1/N scaling; NaN elsewhere
+          row_end[V]   for a kept head h: index of the last marker of its output row; -1 if not kept
+          xz[V*d]      cov(G,Z) of each kept variant (row-major by variant), unscaled
+          zz[d*d]      covZZ, unscaled
+        Returns 0, or -1 if the null model cannot be fitted. ---- */
+int orc_metacov(const double* G, int64_t N, int V, const int* chrom, const int* pos, const double* X, const double* y,
+                int d, int binary, int window, int use_float, int* kept, double* cov, int* row_end, double* xz,
+                double* zz);
+
 #ifdef __cplusplus
 }
 #endif

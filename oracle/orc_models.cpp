@@ -854,6 +854,146 @@ int orc_skat_permute(const double* Gp, const double* af, int64_t N, int M, const
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MetaCovTest, unrelated samples  (src/Model.cpp:844-1004)
+//   QT     (MetaCovUnrelatedQtl, :506-593): g <- g - mean(g) in float; covXX = g1.g2 / sigma2;
+//          covXZ = g'Z / sigma2 (Z = covariates with intercept, NOT centred); covZZ = Zc'Zc / sigma2 (Zc centred,
+//          double); covZZInv = LDLT solve of the identity (the zero pivot of the centred intercept yields a zero
+//          row/column, Eigen LDLT::solve)
+//   binary (MetaCovUnrelatedBinary, :694-778): no centring; covXX = sum g1 w g2, covXZ = g'WZ, covZZ = Z'WZ with
+//          w = p(1-p) stored as float
+//   value printed for (head h, marker j): covXX(h,j) - covXZ_h' covZZInv covXZ_j  (computeScaledXX, Model.h:3997-4005),
+//   float throughout, scaled by 1/N only when written.
+//   Window (Model.h:3956-3990): a new variant evicts queue heads while |pos_new - pos_head| > window or the
+//   chromosome differs; monomorphic variants never enter the queue (but still evict).  The row of head h therefore
+//   holds h and every later kept variant pushed before h's eviction.
+// ---------------------------------------------------------------------------------------------
+int orc_metacov(const double* Gp, int64_t N, int V, const int* chrom, const int* pos, const double* Xp,
+                const double* y, int d, int binary, int window, int use_float, int* kept, double* cov, int* row_end,
+                double* xz, double* zz) {
+  Mat G = wrap(Gp, N, V);
+  Mat X = wrap(Xp, N, d);
+  auto F = [&](double x) { return use_float ? (double)(float)x : x; };
+  // ---- null model -----------------------------------------------------------------------------
+  double sigma2 = 0;
+  std::vector<double> w(N, 1.0);
+  if (!binary) {
+    std::vector<double> beta(d), pred(N), res(N);
+    if (orc_fit_linear(Xp, y, N, d, beta.data(), pred.data(), res.data(), &sigma2)) return -1;
+    sigma2 = F(sigma2);  // `float sigma2` member (Model.cpp:592)
+  } else {
+    std::vector<double> beta(d), p(N), v(N);
+    if (orc_fit_logistic(Xp, y, N, d, 100, beta.data(), p.data(), v.data())) return -1;
+    for (int64_t i = 0; i < N; ++i) w[i] = F(v[i]);  // Eigen::VectorXf weight
+  }
+  // ---- covZZ, covZZInv (double) ---------------------------------------------------------------
+  Mat ZZ(d, d);
+  if (!binary) {
+    std::vector<double> mean(d, 0.0);
+    for (int k = 0; k < d; ++k) {
+      double sx = 0;
+      for (int64_t i = 0; i < N; ++i) sx += X(i, k);
+      mean[k] = sx / (double)N;
+    }
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        double sx = 0;
+        for (int64_t i = 0; i < N; ++i) sx += (X(i, a) - mean[a]) * (X(i, b) - mean[b]);
+        ZZ(a, b) = sx * (1.0 / sigma2);
+      }
+  } else {
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b <= a; ++b) {
+        double sx = 0;
+        for (int64_t i = 0; i < N; ++i) sx += X(i, a) * w[i] * X(i, b);
+        ZZ(a, b) = ZZ(b, a) = sx;
+      }
+  }
+  // LDLT solve with zero pivots mapped to zero: for the centred QT matrix the intercept row/column is exactly 0
+  Mat ZZinv(d, d);
+  {
+    std::vector<int> live;
+    for (int a = 0; a < d; ++a) {
+      bool zero = true;
+      for (int b = 0; b < d; ++b)
+        if (ZZ(a, b) != 0.0) zero = false;
+      if (!zero) live.push_back(a);
+    }
+    const int q = (int)live.size();
+    if (q > 0) {
+      Mat A(q, q), I(q, q), Ai;
+      for (int a = 0; a < q; ++a) {
+        I(a, a) = 1.0;
+        for (int b = 0; b < q; ++b) A(a, b) = ZZ(live[a], live[b]);
+      }
+      if (!orc::sym_solve(A, I, &Ai)) return -1;
+      for (int a = 0; a < q; ++a)
+        for (int b = 0; b < q; ++b) ZZinv(live[a], live[b]) = Ai(a, b);
+    }
+  }
+  for (int a = 0; a < d; ++a)
+    for (int b = 0; b < d; ++b) zz[a * d + b] = ZZ(a, b);
+  // ---- per-variant transform and covXZ ------------------------------------------------------------
+  std::vector<std::vector<double>> gt(V);
+  for (int j = 0; j < V; ++j) {
+    // isMonomorphicMarker on the imputed column (DataConsolidator.cpp:94-116)
+    bool mono = true;
+    int64_t first = N;
+    for (int64_t i = 0; i < N; ++i)
+      if (G(i, j) >= 0) {
+        first = i;
+        break;
+      }
+    for (int64_t i = first + 1; i < N; ++i) {
+      if (G(i, j) < 0) continue;
+      if (G(i, j) != G(first, j)) {
+        mono = false;
+        break;
+      }
+    }
+    kept[j] = mono ? 0 : 1;
+    row_end[j] = -1;
+    for (int k = 0; k < d; ++k) xz[(size_t)j * d + k] = NAN;
+    if (mono) continue;
+    std::vector<double>& g = gt[j];
+    g.resize(N);
+    for (int64_t i = 0; i < N; ++i) g[i] = F(G(i, j));  // assignGenotype: float copy
+    if (!binary) {
+      double sx = 0;
+      for (int64_t i = 0; i < N; ++i) sx = F(sx + g[i]);
+      const double avg = F(sx / (double)N);
+      for (int64_t i = 0; i < N; ++i) g[i] = F(g[i] - avg);
+    }
+    for (int k = 0; k < d; ++k) {
+      double sx = 0;
+      for (int64_t i = 0; i < N; ++i)
+        sx = binary ? F(sx + F(F(g[i] * w[i]) * F(X(i, k)))) : F(sx + F(g[i] * F(X(i, k))));
+      xz[(size_t)j * d + k] = binary ? sx : F(sx / sigma2);
+    }
+  }
+  // ---- rows -------------------------------------------------------------------------------------------
+  for (size_t i = 0; i < (size_t)V * V; ++i) cov[i] = NAN;
+  for (int h = 0; h < V; ++h) {
+    if (!kept[h]) continue;
+    for (int j = h; j < V; ++j) {
+      // the variant at j evicts h (and ends its row) when it is out of the window, kept or not
+      if (chrom[j] != chrom[h] || std::abs(pos[j] - pos[h]) > window) break;
+      if (!kept[j]) continue;
+      double xx = 0;
+      for (int64_t i = 0; i < N; ++i)
+        xx = binary ? F(xx + F(F(gt[h][i] * w[i]) * gt[j][i])) : F(xx + F(gt[h][i] * gt[j][i]));
+      if (!binary) xx = F(xx / sigma2);
+      double quad = 0;
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b)
+          quad = F(quad + F(F(xz[(size_t)h * d + a] * F(ZZinv(a, b))) * xz[(size_t)j * d + b]));
+      cov[h + (size_t)j * V] = F(xx - quad);
+      row_end[h] = j;
+    }
+  }
+  return 0;
+}
+
 // built-in integrands for the QAGS fixture checks
 static double builtin_f(double x, void* p) {
   const double* q = (const double*)p;

@@ -724,6 +724,73 @@ __global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDesc* __re
 }
 
 // =====================================================================================================
+// MetaCov (src/Model.cpp:844-1004): the score covariances of a block of V consecutive variants are a by-product
+// of the SAME sufficient statistics R = G'D[G | X | rr] the gene tests use — the block is run through the
+// suffstat kernels as one "gene" and the two kernels below finish the algebra per (head, marker) pair:
+//   quantitative (MetaCovUnrelatedQtl, :506-593): genotypes are centred, so
+//       covXX(h,j) = (S_hj - s_h s_j / N) / sigma2,   covXZ_h = (T_h - (s_h/N) 1'Z) / sigma2
+//   binary (MetaCovUnrelatedBinary, :694-778):  covXX = G'WG = S,  covXZ = G'WZ = T   (D = diag(v) already)
+//   value(h,j) = covXX(h,j) - covXZ_h' covZZInv covXZ_j          (computeScaledXX, src/Model.h:3997-4005)
+// s = exact column sums, T = G'DX from the X columns of R; covZZInv comes from the null model (engine side).
+// =====================================================================================================
+struct CovConsts {
+  double zzinv[RVT_MAX_COV * RVT_MAX_COV];  // covZZInv, row-major d x d
+  double zsum[RVT_MAX_COV];                 // 1'Z (quantitative centring)
+  double inv_sigma2;                        // 1/sigma2 (quantitative), 1 (binary)
+  double inv_n;                             // 1/N
+  int d, binary;
+};
+
+// one workgroup: column sums, polymorphic flags, T = G'DX, covXZ   (xz: V x d row-major; colsum: V)
+__global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
+                                                          double* __restrict__ xz, double* __restrict__ colsum,
+                                                          int* __restrict__ poly) {
+  const GeneDesc gd = genes[0];
+  const int V = gd.M, d = cc.d;
+  for (int h = threadIdx.x; h < V; h += blockDim.x) {
+    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int p = 0; p < gd.n_wparts; ++p) {
+      const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+      s += c[h];
+      mn = fmin(mn, c[gd.Mp + h]);
+      mx = fmax(mx, c[2 * gd.Mp + h]);
+    }
+    colsum[h] = s;
+    poly[h] = (mn == mx) ? 0 : 1;
+    for (int k = 0; k < d; ++k) {
+      double t = 0.0;
+      for (int p = 0; p < gd.n_wparts; ++p)
+        t += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + V + k];
+      xz[(long long)h * d + k] = cc.binary ? t : (t - s * cc.inv_n * cc.zsum[k]) * cc.inv_sigma2;
+    }
+  }
+}
+
+// grid = V workgroups (one per head h): value(h, j) for j >= h into cov[h + j*V]
+__global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
+                                                       const double* __restrict__ xz,
+                                                       const double* __restrict__ colsum, double* __restrict__ cov) {
+  const GeneDesc gd = genes[0];
+  const int V = gd.M, d = cc.d, h = blockIdx.x;
+  __shared__ double a[RVT_MAX_COV];  // covXZ_h' covZZInv
+  if (threadIdx.x < d) {
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
+    a[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double sh = colsum[h];
+  for (int j = h + threadIdx.x; j < V; j += blockDim.x) {
+    double sxx = 0.0;
+    for (int p = 0; p < gd.n_wparts; ++p) sxx += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + j];
+    const double xx = cc.binary ? sxx : (sxx - sh * colsum[j] * cc.inv_n) * cc.inv_sigma2;
+    double quad = 0.0;
+    for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
+    cov[h + (long long)j * V] = xx - quad;
+  }
+}
+
+// =====================================================================================================
 // K4: p-values, one wave per gene.
 //
 // Lane t owns quadrature abscissa t (21 for the first panel, 42 for the two halves of a bisected interval);

@@ -215,6 +215,35 @@ void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_de
 #undef RVT_GROUP
 }
 
+// inverse of a small (n <= RVT_MAX_COV) nonsingular matrix, row-major, Gauss-Jordan with partial pivoting
+bool invert_spd(const double* M, int n, double* Minv) {
+  double A[RVT_MAX_COV][2 * RVT_MAX_COV];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      A[i][j] = M[i * n + j];
+      A[i][n + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+    if (A[piv][k] == 0.0) return false;
+    if (piv != k)
+      for (int j = 0; j < 2 * n; ++j) std::swap(A[k][j], A[piv][j]);
+    const double pv = A[k][k];
+    for (int j = 0; j < 2 * n; ++j) A[k][j] /= pv;
+    for (int i = 0; i < n; ++i)
+      if (i != k) {
+        const double f = A[i][k];
+        if (f != 0.0)
+          for (int j = 0; j < 2 * n; ++j) A[i][j] -= f * A[k][j];
+      }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) Minv[i * n + j] = A[i][n + j];
+  return true;
+}
+
 // 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
 // that a gene still spreads over >= 32..128 waves
 void choose_split(int64_t ld, int* n_wparts, int* steps_per) {
@@ -383,32 +412,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
         for (int64_t i = 0; i < N; ++i) s += xa[i] * xb[i];
       nc.C[a * d + b] = nc.C[b * d + a] = s;
     }
-  {  // inverse by Gauss-Jordan with partial pivoting (d <= 16)
-    double A[RVT_MAX_COV][2 * RVT_MAX_COV];
-    for (int i = 0; i < d; ++i)
-      for (int j = 0; j < d; ++j) {
-        A[i][j] = nc.C[i * d + j];
-        A[i][d + j] = (i == j) ? 1.0 : 0.0;
-      }
-    for (int k = 0; k < d; ++k) {
-      int piv = k;
-      for (int i = k + 1; i < d; ++i)
-        if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
-      if (A[piv][k] == 0.0) return fail(c, RVT_E_INVALID, "X'VX is singular");
-      if (piv != k)
-        for (int j = 0; j < 2 * d; ++j) std::swap(A[k][j], A[piv][j]);
-      const double pv = A[k][k];
-      for (int j = 0; j < 2 * d; ++j) A[k][j] /= pv;
-      for (int i = 0; i < d; ++i)
-        if (i != k) {
-          const double f = A[i][k];
-          if (f != 0.0)
-            for (int j = 0; j < 2 * d; ++j) A[i][j] -= f * A[k][j];
-        }
-    }
-    for (int i = 0; i < d; ++i)
-      for (int j = 0; j < d; ++j) nc.Cinv[i * d + j] = A[i][d + j];
-  }
+  if (!invert_spd(nc.C, d, nc.Cinv)) return fail(c, RVT_E_INVALID, "X'VX is singular");
   // device copies, padded with zeros
   const size_t vb = sizeof(double) * (size_t)ld;
   HIP_TRY(c, hipMalloc((void**)&c->d_X, vb * d));
@@ -492,9 +496,16 @@ struct DebugOut {
   GeneDesc* desc0 = nullptr;
 };
 
+struct CovOut {  // rvt_cov_block: host destinations
+  double* cov = nullptr;   // V x V
+  double* xz = nullptr;    // V x d
+  double* zz = nullptr;    // d x d
+  int* poly = nullptr;     // V
+};
+
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
                      const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
-                     DebugOut* dbg) {
+                     DebugOut* dbg, CovOut* cov = nullptr) {
   if (!c || n < 0 || (n > 0 && (!dG || !Ms || !af || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
@@ -576,6 +587,14 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
+  size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0;
+  if (cov) {
+    const size_t V = (size_t)Ms[0];
+    off_cov = add(sizeof(double) * V * V);
+    off_cov_xz = add(sizeof(double) * V * (size_t)d);
+    off_cov_cs = add(sizeof(double) * V);
+    off_cov_poly = add(sizeof(int) * V);
+  }
   size_t off_dbg_cmc = 0, off_dbg_zeg = 0;
   if (dbg && dbg->cmc) {
     off_dbg_cmc = add(sizeof(double) * N);
@@ -656,6 +675,53 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
   HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
+  if (cov) {  // MetaCov: finish the covariance algebra of this one block and return its band synchronously
+    const int V = Ms[0];
+    CovConsts cc;
+    std::memset(&cc, 0, sizeof(cc));
+    cc.d = d;
+    cc.binary = nc.binary;
+    cc.inv_n = 1.0 / (double)N;
+    std::vector<double> zz((size_t)d * d, 0.0);
+    if (nc.binary) {  // covZZ = Z'WZ, covZZInv its inverse (MetaCovUnrelatedBinary::calculateZZ, Model.cpp:748-765)
+      cc.inv_sigma2 = 1.0;
+      for (int a = 0; a < d * d; ++a) {
+        zz[a] = nc.C[a];
+        cc.zzinv[a] = nc.Cinv[a];
+      }
+    } else {
+      // covZZ = Zc'Zc / sigma2 with centred columns (MetaCovUnrelatedQtl::calculateZZ, Model.cpp:582-591); the
+      // intercept's row/column is exactly zero and CholeskyInverseMatrix (LDLT solve) leaves it zero, so covZZInv is
+      // the inverse of the covariate block — a d x d job on null-model constants, done once per call on the host.
+      cc.inv_sigma2 = 1.0 / nc.sigma2;
+      for (int k = 0; k < d; ++k) cc.zsum[k] = nc.C[k];  // first row of X'X = 1'Z (column 0 is the intercept)
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) zz[a * d + b] = (nc.C[a * d + b] - cc.zsum[a] * cc.zsum[b] / (double)N) / nc.sigma2;
+      for (int a = 0; a < d; ++a) zz[a * d + 0] = zz[0 * d + a] = 0.0;
+      const int q = d - 1;
+      if (q > 0) {
+        std::vector<double> A((size_t)q * q), Ai((size_t)q * q);
+        for (int a = 0; a < q; ++a)
+          for (int b = 0; b < q; ++b) A[a * q + b] = zz[(a + 1) * d + (b + 1)];
+        if (!invert_spd(A.data(), q, Ai.data())) return fail(c, RVT_E_INVALID, "covariate covariance is singular");
+        for (int a = 0; a < q; ++a)
+          for (int b = 0; b < q; ++b) cc.zzinv[(a + 1) * d + (b + 1)] = Ai[a * q + b];
+      }
+    }
+    double* d_xz = reinterpret_cast<double*>(base + off_cov_xz);
+    double* d_cs = reinterpret_cast<double*>(base + off_cov_cs);
+    int* d_poly = reinterpret_cast<int*>(base + off_cov_poly);
+    double* d_cov = reinterpret_cast<double*>(base + off_cov);
+    hipLaunchKernelGGL(cov_prepare_kernel, dim3(1), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_poly);
+    hipLaunchKernelGGL(cov_rows_kernel, dim3(V), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_cov);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(cov->cov, d_cov, sizeof(double) * (size_t)V * V, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->xz, d_xz, sizeof(double) * (size_t)V * d, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->poly, d_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (cov->zz) std::memcpy(cov->zz, zz.data(), sizeof(double) * (size_t)d * d);
+    return RVT_OK;
+  }
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
   if (burden || dbg) {
     // on the batch's own stream: the collapse overlaps the next batch's sufficient-statistics launches, which
@@ -822,6 +888,55 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
     if (cmin) cmin[i] = mn;
     if (cmax) cmax[i] = mx;
   }
+  return RVT_OK;
+}
+
+// ---- MetaCov: covariance band of one block of consecutive variants ---------------------------------------
+int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
+  int rc = rvt_sync(c);  // the block is processed alone and synchronously
+  if (rc) return rc;
+  std::vector<double> af(V, 0.01);
+  rvt_gene_result r;
+  CovOut co;
+  co.cov = cov;
+  co.xz = xz;
+  co.zz = zz;
+  co.poly = polymorphic;
+  const double* p = dG;
+  rc = run_batch(c, 1, &p, &V, af.data(), nullptr, 0u, nullptr, &r, nullptr, &co);
+  if (rc) return rc;
+  // run_batch marked the slot busy without enqueuing a record copy: clear it
+  for (auto& sl : c->slots) {
+    if (sl.pending_out == &r) {
+      sl.pending_out = nullptr;
+      sl.pending_n = 0;
+    }
+  }
+  return RVT_OK;
+}
+
+int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const double* G) {
+  if (!c || !dG || !G || col0 < 0 || ncols < 1) return fail(c, RVT_E_INVALID, "bad upload");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first");
+  hipSetDevice(c->device);
+  const size_t N = (size_t)c->nc.N, ld = (size_t)c->null_ld;
+  HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
+                         hipMemcpyHostToDevice));
+  return RVT_OK;
+}
+
+int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int ncols) {
+  if (!c || !dG || dst_col < 0 || src_col < dst_col || ncols < 0) return fail(c, RVT_E_INVALID, "bad move");
+  if (ncols == 0 || dst_col == src_col) return RVT_OK;
+  hipSetDevice(c->device);
+  const size_t ld = (size_t)c->null_ld;
+  // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
+  for (int k = 0; k < ncols; ++k)
+    HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
+                              hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RVT_OK;
 }
 

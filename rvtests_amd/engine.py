@@ -122,6 +122,12 @@ def load_library():
     L.rvt_debug_suffstat.restype = C.c_int
     L.rvt_debug_suffstat.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]
+    L.rvt_cov_block.restype = C.c_int
+    L.rvt_cov_block.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
+    L.rvt_block_upload_columns.restype = C.c_int
+    L.rvt_block_upload_columns.argtypes = [vp, vp, C.c_int, C.c_int, c_double_p]
+    L.rvt_block_move_columns.restype = C.c_int
+    L.rvt_block_move_columns.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.rvt_set_profiling.restype = C.c_int
     L.rvt_set_profiling.argtypes = [vp, C.c_int]
     L.rvt_get_timing.restype = C.c_int
@@ -266,6 +272,28 @@ class Engine:
         self._check(self.L.rvt_debug_suffstat(self.ctx, C.c_void_p(int(ptr)), M, _dp(S), _dp(T), _dp(u), _dp(cs),
                                               _dp(mn), _dp(mx)))
         return S, T, u, cs, mn, mx
+
+    # ---- MetaCov --------------------------------------------------------------------------------------------
+    def cov_block(self, ptr, V):
+        """Covariance band of one device block of V variants: (cov V x V with cov[h, j] valid for j >= h, xz V x d,
+        zz d x d, polymorphic flags)."""
+        d = self.d
+        cov = np.full((V, V), np.nan, order="F")     # cov[h + j*V]
+        xz = np.zeros((V, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(V, dtype=np.int32)
+        self._check(self.L.rvt_cov_block(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
+                                         poly.ctypes.data_as(c_int_p)))
+        return cov, xz, zz, poly
+
+    def upload_columns(self, ptr, col0, G):
+        G = np.asfortranarray(G, dtype=np.float64)
+        if G.ndim == 1:
+            G = G.reshape(-1, 1, order="F")
+        self._check(self.L.rvt_block_upload_columns(self.ctx, C.c_void_p(int(ptr)), int(col0), G.shape[1], _dp(G)))
+
+    def move_columns(self, ptr, dst, src, n):
+        self._check(self.L.rvt_block_move_columns(self.ctx, C.c_void_p(int(ptr)), int(dst), int(src), int(n)))
 
     def set_profiling(self, on):
         self._check(self.L.rvt_set_profiling(self.ctx, 1 if on else 0))

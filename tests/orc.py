@@ -275,3 +275,25 @@ def burden(G, X, y, binary, which):
     out = BurdenResult()
     rc = lib().orc_burden(_dp(G), N, M, _dp(X), X.shape[1], _dp(y), int(binary), int(which), C.byref(out))
     return rc, out
+
+
+def metacov(G, chrom, pos, X, y, binary, window, use_float=False):
+    """MetaCovTest (unrelated samples) restatement: returns rc, kept[V], cov[V, V] (cov[h, j] for j >= h in h's
+    row, NaN elsewhere; unscaled), row_end[V], xz[V, d], zz[d, d]."""
+    G = F(G)
+    X = F(X)
+    N, V = G.shape
+    d = X.shape[1]
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    chrom = np.ascontiguousarray(chrom, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    kept = np.zeros(V, dtype=np.int32)
+    row_end = np.zeros(V, dtype=np.int32)
+    cov = np.zeros((V, V), order="F")
+    xz = np.zeros((V, d))
+    zz = np.zeros((d, d))
+    L = lib()
+    L.orc_metacov.restype = C.c_int
+    rc = L.orc_metacov(_dp(G), C.c_int64(N), V, _ip(chrom), _ip(pos), _dp(X), _dp(y), d, int(binary), int(window),
+                       int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz), _dp(zz))
+    return rc, kept, cov, row_end, xz, zz

@@ -1,0 +1,78 @@
+"""GPU parity of the MetaCov covariance band (rvt_cov_block, through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+from test_metacov_cpu import make_case
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9   # of the largest covariance of the block (values are differences of O(N) sums)
+
+
+def run_case(engine_factory, N, V, d, binary, seed, window):
+    G, chrom, pos, X, y = make_case(N, V, d, binary, seed)
+    if binary:
+        rc, beta, p, v = orc.fit_logistic(X, y)
+        assert rc == 0
+        res, s2 = y - p, 1.0
+    else:
+        rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+        assert rc == 0
+        v = np.full(N, s2)
+    eng = engine_factory()
+    eng.set_null(binary, X, res, v, s2)
+    ptr = eng.upload_block(G)
+    cov, xz, zz, poly = eng.cov_block(ptr, V)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, binary, window)
+    assert rc == 0
+    assert (poly == kept).all()
+    m = ~np.isnan(ocov)                        # the pairs the reference prints
+    assert m.sum() > V
+    scale = np.abs(ocov[m]).max()
+    assert np.abs(cov[m] - ocov[m]).max() < REL * scale
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    assert np.allclose(zz, ozz, rtol=1e-9, atol=1e-9 * max(np.abs(ozz).max(), 1.0))
+    eng.free_block(ptr)
+    return eng
+
+
+@pytest.fixture
+def engine_factory():
+    import rvtests_amd
+    made = []
+
+    def make():
+        e = rvtests_amd.Engine(0)
+        made.append(e)
+        return e
+    yield make
+    for e in made:
+        e.close()
+
+
+@pytest.mark.parametrize("binary", [0, 1])
+@pytest.mark.parametrize("V,d", [(23, 3), (64, 1), (97, 2), (200, 3)])
+def test_cov_block_matches_oracle(engine_factory, binary, V, d):
+    run_case(engine_factory, 1500, V, d, binary, 100 + V + d + 13 * binary, window=3000)
+
+
+def test_cov_block_ring_moves(engine_factory):
+    """upload_columns / move_columns (the adapter's device ring): a block assembled column by column and compacted
+    gives the same band as the block uploaded at once."""
+    N, V, d = 1200, 40, 2
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 77)
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    whole = eng.upload_block(G)
+    ref = eng.cov_block(whole, V)[0]
+    ring = eng.upload_block(np.zeros((N, V + 8)))
+    for j in range(V):
+        eng.upload_columns(ring, j + 8, G[:, j])
+    eng.move_columns(ring, 0, 8, V)
+    got = eng.cov_block(ring, V)[0]
+    iu = np.triu_indices(V)
+    assert np.array_equal(got[iu], ref[iu])
