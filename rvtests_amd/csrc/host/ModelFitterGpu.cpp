@@ -131,6 +131,16 @@ int GpuBroker::installNull(const GeneData& gd, bool binary, std::string* err) {
   return 0;
 }
 
+rvt_ctx* GpuBroker::contextWithNull(const GeneData& gd, bool binary, std::string* err) {
+  if (ensureContext(0)) {
+    *err = "no MI355X device: the GPU models have no CPU fallback";
+    return nullptr;
+  }
+  if (!haveNull || gd.phenotypeUpdated || gd.covariateUpdated)
+    if (installNull(gd, binary, err)) return nullptr;
+  return ctx;
+}
+
 const rvt_gene_result* GpuBroker::resultFor(const GeneData& gd, bool binary, std::string* err) {
   if (gd.serial == curSerial) return curOk ? &cur : nullptr;
   curSerial = gd.serial;
@@ -254,6 +264,127 @@ void ZegginiTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(fitOK ? floatToString(res->zeg_p) + "\n" : std::string("NA\n"));
 }
 
+// ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
+MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
+  modelName = "MetaCov";
+  // block size of the device ring; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush with it)
+  if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(RVT_MAX_VARIANTS, atoi(e)));
+}
+MetaCovTest::~MetaCovTest() {
+  if (fout) flush(true);
+  if (ctx && block) rvt_block_free(ctx, block);
+}
+int MetaCovTest::setParameter(const ModelParser& parser) {
+  outputGwama = parser.hasTag("gwama");
+  return 0;
+}
+int MetaCovTest::fit(GeneData* dc) {
+  fitOK = false;
+  if (dc->M != 1 || dc->N == 0) return -1;  // src/Model.cpp:851-858
+  if (!dc->site) {
+    lastError = "MetaCov needs the site's CHROM/POS";
+    return -1;
+  }
+  if (nSample >= 0 && nSample != dc->N) {
+    lastError = "Sample size changed at [ " + dc->site->get("CHROM") + ":" + dc->site->get("POS") + " ]";
+    return -1;
+  }
+  ctx = GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
+  if (!ctx) return -1;
+  if (nSample < 0) {
+    nSample = dc->N;
+    nCovariate = dc->ncov + 1;
+    if (rvt_block_alloc(ctx, capacity, &block)) {
+      lastError = rvt_last_error(ctx);
+      return -1;
+    }
+  }
+  if ((int)sites.size() == capacity && (flush(false) || (int)sites.size() == capacity)) return -1;
+  // the caller overwrites the genotype buffer for the next site: copy the column into the device ring now
+  if (rvt_block_upload_columns(ctx, block, (int)sites.size(), 1, dc->genotype)) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  sites.push_back(Site{dc->site->get("CHROM"), atoi(dc->site->get("POS").c_str())});
+  fitOK = true;  // whether the site is monomorphic (and therefore skipped) is decided on the device at flush time
+  return 0;
+}
+void MetaCovTest::writeHeader(TextSink* fp, const SiteInfo&) {
+  fp->write("CHROM\tSTART_POS\tEND_POS\tNUM_MARKER\tMARKER_POS\tCOV\n");
+}
+void MetaCovTest::writeOutput(TextSink* fp, const SiteInfo&) { fout = fp; }
+void MetaCovTest::writeFootnote(TextSink* fp) {
+  fout = fp;
+  flush(true);
+}
+
+// Emit the rows of every head whose window is complete (all of them when `final`), then compact the ring.
+int MetaCovTest::flush(bool final) {
+  const int V = (int)sites.size();
+  if (V == 0 || !fout) return 0;
+  const int d = nCovariate;
+  std::vector<double> cov((size_t)V * V), xz((size_t)V * d), zz((size_t)d * d);
+  std::vector<int> poly(V);
+  if (rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  auto outOfWindow = [&](int h, int j) {  // getWindowSize(queue, loci) > windowSize, src/Model.h:3974-3990
+    return sites[j].chrom != sites[h].chrom || std::abs(sites[j].pos - sites[h].pos) > windowSize;
+  };
+  const float scale = (float)(1.0 / (double)nSample);
+  int H = 0;  // heads [0, H) are complete
+  for (; H < V; ++H) {
+    bool complete = final;
+    for (int j = H + 1; j < V && !complete; ++j) complete = outOfWindow(H, j);
+    if (!complete) break;
+  }
+  if (H == 0) {
+    lastError = "MetaCov: more variants inside one window than the device block holds (RVT_MAX_VARIANTS)";
+    return -1;
+  }
+  std::string line;
+  for (int h = 0; h < H; ++h) {
+    if (!poly[h]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
+    std::string positions, values;
+    int last = h, num = 0;
+    for (int j = h; j < V; ++j) {
+      if (outOfWindow(h, j)) break;
+      if (!poly[j]) continue;
+      if (num) {
+        positions += ',';
+        values += ',';
+      }
+      positions += std::to_string(sites[j].pos);
+      values += formatG((double)((float)cov[(size_t)h + (size_t)j * V] * scale));
+      last = j;
+      ++num;
+    }
+    if (outputGwama || isBinaryOutcome()) {  // src/Model.cpp:992-1000
+      values += ':';
+      for (int k = 0; k < d; ++k) {
+        if (k) values += ',';
+        values += formatG((double)((float)xz[(size_t)h * d + k] * scale));
+      }
+      values += ':';
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b <= a; ++b) {
+          if (a || b) values += ',';
+          values += floatToString(zz[(size_t)a * d + b] * (double)scale);
+        }
+    }
+    line = sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[last].pos) + "\t" +
+           std::to_string(num) + "\t" + positions + "\t" + values + "\n";
+    fout->write(line);
+  }
+  if (H < V && rvt_block_move_columns(ctx, block, 0, H, V - H)) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  sites.erase(sites.begin(), sites.begin() + H);
+  return 0;
+}
+
 // ---- ModelManager (src/ModelManager.cpp:26-44 tokeniser, :46-271 switch) --------------------------------------------------------
 ModelManager::~ModelManager() {
   for (auto* m : model) delete m;
@@ -308,10 +439,20 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         lastError = "Unknown model name: " + modelName + " .";
         return -1;
       }
+    } else if (modelType == "meta") {
+      if (modelName == "cov") {
+        int windowSize;
+        parser.assign("windowSize", &windowSize, 1000000);  // src/ModelManager.cpp:227-233
+        model.push_back(new MetaCovTest(windowSize));
+      } else {
+        lastError = "Unknown model name: " + modelName + " .";
+        return -1;
+      }
     } else {
       lastError = "Unrecognized model type: " + type;
       return -1;
     }
+    model.back()->setParameter(parser);  // src/ModelManager.cpp:273-275
   }
   return 0;
 }

@@ -28,6 +28,8 @@
 
 namespace rvt_host {
 
+struct SiteInfo;
+
 // ---- what fit() may read: DataConsolidator getters (src/DataConsolidator.h:126-137,223-224) -------------
 struct GeneData {
   int64_t N = 0;
@@ -39,6 +41,7 @@ struct GeneData {
   std::vector<double> markerFrequency;  // dc->getMarkerFrequency(col) for col < M
   bool phenotypeUpdated = false, covariateUpdated = false;  // dc->isPhenotypeUpdated() / isCovariateUpdated()
   int64_t serial = 0;                 // increases with every dc.consolidate() (new gene)
+  const SiteInfo* site = nullptr;     // dc->getResult(): CHROM / POS of the current site (single-variant models)
 };
 
 // ---- FileWriter stand-in (base/IO.h FileWriter::write / printf) -------------------------------------------
@@ -60,6 +63,11 @@ struct SiteInfo {
     std::string s;
     for (auto& p : kv) s += p.second + "\t";
     return s;
+  }
+  std::string get(const std::string& key) const {  // Result::operator[]
+    for (auto& p : kv)
+      if (p.first == key) return p.second;
+    return "";
   }
 };
 
@@ -95,6 +103,8 @@ class GpuBroker {
   // Returns the result of the gene currently held by `gd` (submits + collects on first use). nullptr on error.
   const rvt_gene_result* resultFor(const GeneData& gd, bool binary, std::string* err);
   void shutdown();
+  // context + null model for models that drive the C ABI themselves (MetaCovTest)
+  rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
   // null model: fitted on the host by the caller-supplied routine (the reference's LinearRegression /
   // LogisticRegression in the real tree); see INTEGRATION.md
   typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
@@ -180,11 +190,45 @@ class ZegginiTest : public ModelFitter {
   bool fitOK = false;
 };
 
+// `--meta cov[windowSize=..:gwama]` for unrelated samples.  fit() is called once per variant (genotype.cols == 1,
+// src/Model.cpp:844-858) and only copies the column into a device-resident ring; covariance rows are produced block
+// by block on the GPU (rvt_cov_block) and written in the reference's order and format when their window is complete
+// — the reference itself defers each row until its head is evicted (src/Model.h:3956-3968), so deferring changes
+// when a row reaches the file, not what the file holds.  Rows still pending are flushed by writeFootnote() / the
+// destructor, as the reference's destructor does (src/Model.cpp:828-834).
+class MetaCovTest : public ModelFitter {
+ public:
+  explicit MetaCovTest(int windowSize);
+  ~MetaCovTest() override;
+  int setParameter(const ModelParser& parser) override;
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeFootnote(TextSink* fp) override;
+
+ private:
+  struct Site {
+    std::string chrom;
+    int pos;
+  };
+  int flush(bool final);
+  int windowSize;
+  int capacity = RVT_MAX_VARIANTS;  // columns of the device ring
+  bool outputGwama = false;
+  bool fitOK = false;
+  int64_t nSample = -1;
+  int nCovariate = 0;
+  rvt_ctx* ctx = nullptr;
+  double* block = nullptr;   // device block of RVT_MAX_VARIANTS columns
+  std::vector<Site> sites;   // variants currently in the block, file order
+  TextSink* fout = nullptr;
+};
+
 // ---- ModelManager::create -----------------------------------------------------------------------------------------
 class ModelManager {
  public:
   ~ModelManager();
-  // type: "burden" | "kernel"; modelList: "cmc,zeggini" or "skat[nPerm=0:beta1=1],skato"
+  // type: "burden" | "kernel" | "meta"; modelList: "cmc,zeggini", "skat[nPerm=0:beta1=1],skato" or "cov[windowSize=500000]"
   int create(const std::string& type, const std::string& modelList);
   const std::vector<ModelFitter*>& getModel() const { return model; }
   void setBinaryOutcome();

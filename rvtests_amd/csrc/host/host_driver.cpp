@@ -4,6 +4,9 @@
 // end is out of scope (SURVEY §8f "next" #1).
 //
 //   host_driver <input.bin> <kernel list, e.g. "skat[nPerm=0],skato" or "-"> <burden list, e.g. "cmc,zeggini" or "-">
+//               [<meta list, e.g. "cov[windowSize=3000]"> <sites.txt: one "chrom pos" line per variant, file order>]
+// With a meta list the driver runs the reference's single-variant loop instead (src/Main.cpp:1010-1078): every
+// column of every block is one fit() call with CHROM / POS in the site record.
 //
 // input.bin: int64 N; int32 ncov, binary, ngenes; double y[N]; double cov[N*ncov] (column-major);
 //            per gene: int32 M; double af[M]; double G[N*M] (column-major, imputed, unflipped)
@@ -139,6 +142,22 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%s\n", mm.lastError.c_str());
     return 1;
   }
+  const bool metaMode = argc >= 6 && std::string(argv[4]) != "-";
+  std::vector<std::pair<std::string, std::string>> sitePos;
+  if (metaMode) {
+    if (mm.create("meta", argv[4])) {
+      fprintf(stderr, "%s\n", mm.lastError.c_str());
+      return 1;
+    }
+    FILE* sf = fopen(argv[5], "r");
+    if (!sf) {
+      fprintf(stderr, "cannot open %s\n", argv[5]);
+      return 1;
+    }
+    char cbuf[64], pbuf[64];
+    while (fscanf(sf, "%63s %63s", cbuf, pbuf) == 2) sitePos.emplace_back(cbuf, pbuf);
+    fclose(sf);
+  }
   if (binary)
     mm.setBinaryOutcome();
   else
@@ -156,6 +175,7 @@ int main(int argc, char** argv) {
   dc.covariate = cov.data();
   dc.ncov = ncov;
   std::vector<double> G;
+  size_t variantIndex = 0;
   for (int g = 0; g < ngenes; ++g) {
     int32_t M;
     if (fread(&M, 4, 1, f) != 1) return 2;
@@ -163,6 +183,24 @@ int main(int argc, char** argv) {
     G.resize((size_t)N * M);
     if (fread(dc.markerFrequency.data(), 8, M, f) != (size_t)M) return 2;
     if (fread(G.data(), 8, (size_t)N * M, f) != (size_t)N * M) return 2;
+    if (metaMode) {  // single-variant loop: one fit() per column
+      for (int j = 0; j < M; ++j) {
+        if (variantIndex >= sitePos.size()) return 2;
+        SiteInfo vs;
+        vs.kv = {{"CHROM", sitePos[variantIndex].first}, {"POS", sitePos[variantIndex].second}};
+        dc.M = 1;
+        dc.genotype = G.data() + (size_t)j * N;
+        dc.serial = (int64_t)(++variantIndex);
+        dc.site = &vs;
+        for (size_t m = 0; m < models.size(); ++m) {
+          models[m]->reset();
+          models[m]->fit(&dc);
+          models[m]->writeOutput(&outs[m], vs);
+        }
+        dc.site = nullptr;
+      }
+      continue;
+    }
     dc.M = M;
     dc.genotype = G.data();
     dc.serial = g + 1;  // dc.consolidate(...) happened
@@ -175,6 +213,7 @@ int main(int argc, char** argv) {
     }
   }
   fclose(f);
+  for (size_t m = 0; m < models.size(); ++m) models[m]->writeFootnote(&outs[m]);  // ModelManager::close, :304-314
   const auto names = mm.outputNames("out");
   for (size_t m = 0; m < models.size(); ++m) printf("== %s\n%s", names[m].c_str(), outs[m].text.c_str());
   GpuBroker::instance().shutdown();

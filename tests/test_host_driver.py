@@ -116,3 +116,89 @@ def test_driver_output_matches_oracle(tmp_path, binary, d):
         row = sec["out.Zeggini.assoc"][1 + i]
         if rc4 == 0:
             assert abs(float(row[-1]) - z.pvalue) <= 2e-6 * z.pvalue
+
+
+def run_driver_meta(path, meta, sites_path, block=None):
+    env = dict(os.environ)
+    if block:
+        env["RVT_METACOV_BLOCK"] = str(block)
+    p = subprocess.run([DRIVER, path, "-", "-", meta, sites_path], capture_output=True, text=True, timeout=300,
+                       env=env)
+    lines = [ln for ln in p.stdout.splitlines()]
+    return p.returncode, lines, p.stderr
+
+
+def test_meta_registry_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    _ensure_driver()
+    path, genes, X, y, res, v = _case(tmp_path)
+    sites = str(tmp_path / "sites.txt")
+    with open(sites, "w") as f:
+        k = 0
+        for G, af in genes:
+            for j in range(G.shape[1]):
+                f.write("1 %d\n" % (100 + 10 * k))
+                k += 1
+    rc, lines, err = run_driver_meta(path, "cov[windowSize=200]", sites)
+    assert rc == 0, err
+    assert lines[0] == "== out.MetaCov.assoc"
+    assert lines[1].split("\t") == ["CHROM", "START_POS", "END_POS", "NUM_MARKER", "MARKER_POS", "COV"]
+    assert len(lines) == 2                      # no device => no rows, never a CPU result
+    rc, lines, err = run_driver_meta(path, "nosuch", sites)
+    assert rc == 1 and "Unknown model name: nosuch" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary,gwama,block", [(0, False, None), (0, True, None), (1, False, None), (0, False, 16),
+                                                (1, True, 19)])
+def test_driver_metacov_rows_match_oracle(tmp_path, binary, gwama, block):
+    """--meta cov through the C++ adapter: row structure (window rule, monomorphic sites skipped, chromosome change)
+    identical to the oracle's, numbers equal to its fp64 values after the reference's float / 1/N / %g formatting."""
+    _ensure_driver()
+    N, d = 1500, 3
+    genes = [synth.make_gene(N, M, seed=70 + M, missing=0.01, common=True, mono=True)[1:] for M in (30, 25)]
+    X, y, res, v, s2 = synth.make_null(N, d, binary, seed=9)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], binary, genes)
+    G = np.concatenate([g for g, af in genes], axis=1)
+    V = G.shape[1]
+    rng = np.random.default_rng(3)
+    pos = np.cumsum(rng.integers(1, 300, V)).astype(np.int32)
+    chrom = np.where(np.arange(V) < 40, 1, 2).astype(np.int32)
+    sites = str(tmp_path / "sites.txt")
+    with open(sites, "w") as f:
+        for c, p_ in zip(chrom, pos):
+            f.write("%d %d\n" % (c, p_))
+    window = 1200
+    # block: a device ring far smaller than the stream, so rows are emitted by several mid-stream flushes with
+    # compaction in between (the window then has to fit the ring: at most ~10 sites per window here)
+    if block:
+        window = 450
+    rc, lines, err = run_driver_meta(path, "cov[windowSize=%d%s]" % (window, ":gwama" if gwama else ""), sites, block)
+    assert rc == 0, err
+    assert lines[0] == "== out.MetaCov.assoc"
+    rows = [ln.split("\t") for ln in lines[2:]]
+    rc, kept, cov, row_end, xz, zz = orc.metacov(G, chrom, pos, X, y, binary, window)
+    assert rc == 0
+    heads = [h for h in range(V) if kept[h]]
+    assert len(rows) == len(heads)
+    scale = np.float32(1.0 / N)
+    for row, h in zip(rows, heads):
+        js = [j for j in range(h, row_end[h] + 1) if kept[j] and not np.isnan(cov[h, j])]
+        assert row[0] == str(chrom[h]) and row[1] == str(pos[h]) and row[2] == str(pos[row_end[h]])
+        assert int(row[3]) == len(js)
+        assert row[4] == ",".join(str(pos[j]) for j in js)
+        parts = row[5].split(":")
+        assert len(parts) == (3 if (binary or gwama) else 1)
+        got = np.array([float(t) for t in parts[0].split(",")])
+        want = np.array([float(np.float32(cov[h, j]) * scale) for j in js])
+        assert (np.abs(got - want) <= 6e-6 * np.abs(want) + 1e-30).all()      # %g prints 6 significant digits
+        if len(parts) == 3:
+            gx = np.array([float(t) for t in parts[1].split(",")])
+            wx = np.array([float(np.float32(x) * scale) for x in xz[h]])
+            assert np.allclose(gx, wx, rtol=2e-5, atol=1e-5 * max(np.abs(wx).max(), 1e-30))
+            gz = np.array([float(t) for t in parts[2].split(",")])
+            wz = np.array([zz[a, b] * float(scale) for a in range(d) for b in range(a + 1)])
+            assert np.allclose(gz, wz, rtol=2e-5, atol=1e-12)
