@@ -109,6 +109,26 @@ int orc_rand(void);
 int orc_skat_permute(const double* G, const double* af, int64_t N, int M, const double* res, double beta1,
                      double beta2, double obs, int nPerm, double alpha, int use_float, orc_perm_result* out);
 
+/* ---- related samples (orc_fam.cpp): FastLMM null model (MLE, score) and FamSKAT ----
+        U: N x N column-major eigenvectors of the kinship, S: N eigenvalues (EigenMatrix holds them as float; here
+        doubles carrying those values).  use_float = 1 restates the reference's fp32 arithmetic. */
+typedef struct {
+  int ok;
+  int max_index;    /* best point of the 101-point delta grid */
+  int brent_evals;  /* goal-function evaluations inside Minimizer::minimize (0 on the boundary) */
+  double delta;     /* sigma2_e / sigma2_g as FastLMM::GetDelta() returns it */
+  double sigma2;    /* FastLMM::GetSigmaG2() */
+  double beta[16];  /* FastLMM::GetBeta() */
+} orc_fam_null;
+/* FastLMM::FitNullModel (regression/FastLMM.cpp:28-142) incl. the GSL Brent refinement (GSLMinimizer.cpp:18-66) */
+int orc_fastlmm_null(const double* X, const double* y, int64_t N, int d, const double* U, const double* S,
+                     int use_float, orc_fam_null* out);
+/* FamSkat::FitNullModel + TestCovariate (regression/FamSkat.cpp:34-138) with the literal N x N Sigma / P0;
+   G is the imputed UNFLIPPED block (the function applies getFlippedToMinorPolymorphicGenotype itself).
+   Fills fit_ok, n_poly, Q, pvalue, n_lambda, lambda.  Returns -1 when no polymorphic column is left. */
+int orc_famskat(const double* G, int64_t N, int M, const double* X, const double* y, int d, const double* U,
+                const double* S, const orc_fam_null* nul, int use_float, orc_kernel_result* out);
+
 /* ---- MetaCovTest for unrelated samples (src/Model.cpp:844-1004; MetaCovUnrelatedQtl :506-593,
         MetaCovUnrelatedBinary :694-778; window rule src/Model.h:3956-3990).
         G: N x V imputed genotypes (one variant per column, file order); chrom[V] (any integer id), pos[V];

@@ -297,3 +297,32 @@ def metacov(G, chrom, pos, X, y, binary, window, use_float=False):
     rc = L.orc_metacov(_dp(G), C.c_int64(N), V, _ip(chrom), _ip(pos), _dp(X), _dp(y), d, int(binary), int(window),
                        int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz), _dp(zz))
     return rc, kept, cov, row_end, xz, zz
+
+
+class FamNull(C.Structure):
+    _fields_ = [("ok", C.c_int), ("max_index", C.c_int), ("brent_evals", C.c_int), ("delta", C.c_double),
+                ("sigma2", C.c_double), ("beta", C.c_double * 16)]
+
+
+def fastlmm_null(X, y, U, S, use_float=False):
+    X = F(X)
+    U = F(U)
+    N, d = X.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    out = FamNull()
+    rc = lib().orc_fastlmm_null(_dp(X), _dp(y), C.c_int64(N), d, _dp(U), _dp(S), int(use_float), C.byref(out))
+    return rc, out
+
+
+def famskat(G, X, y, U, S, nul, use_float=False):
+    G = F(G)
+    X = F(X)
+    U = F(U)
+    N, M = G.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    out = KernelResult()
+    rc = lib().orc_famskat(_dp(G), C.c_int64(N), M, _dp(X), _dp(y), X.shape[1], _dp(U), _dp(S), C.byref(nul),
+                           int(use_float), C.byref(out))
+    return rc, out

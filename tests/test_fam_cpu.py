@@ -1,0 +1,89 @@
+"""FastLMM null + FamSKAT oracle (oracle/orc_fam.cpp) against an independent numpy statement of the reference's
+formulas (regression/FastLMM.cpp:28-142,283-346,402-443; regression/FamSkat.cpp:34-138)."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+
+def make_family_case(n_fam, d, seed, h2=0.4):
+    """Nuclear families of 4 (SURVEY config 5): kinship blocks, U/S by eigendecomposition, phenotype with a
+    family random effect."""
+    rng = np.random.default_rng(seed)
+    N = 4 * n_fam
+    blk = np.array([[1, 0, .5, .5], [0, 1, .5, .5], [.5, .5, 1, .5], [.5, .5, .5, 1]])
+    K = np.kron(np.eye(n_fam), blk)
+    S, U = np.linalg.eigh(K)
+    U = U.astype(np.float32).astype(np.float64)      # EigenMatrix holds floats
+    S = S.astype(np.float32).astype(np.float64)
+    X = np.column_stack([np.ones(N)] + [rng.standard_normal(N) for _ in range(d - 1)])
+    L = np.linalg.cholesky(K + 1e-9 * np.eye(N))
+    y = X @ rng.standard_normal(d) * 0.3 + np.sqrt(h2) * (L @ rng.standard_normal(N)) + \
+        np.sqrt(1 - h2) * rng.standard_normal(N)
+    return N, K, U, S, X, y
+
+
+def loglik(delta, ux, uy, lam):
+    D = 1.0 / np.abs(lam + delta)
+    A = ux.T @ (ux * D[:, None])
+    b = ux.T @ (uy * D)
+    beta = np.linalg.solve(A, b)
+    r = uy - ux @ beta
+    s2 = np.sum(r * r / (lam + delta)) / len(uy)
+    n = len(uy)
+    return -0.5 * (n * np.log(2 * np.pi) + np.sum(np.log(np.abs(lam + delta))) + n + n * np.log(s2)), beta, s2
+
+
+@pytest.mark.parametrize("d", [1, 3])
+def test_fastlmm_null_is_the_grid_plus_brent_optimum(d):
+    N, K, U, S, X, y = make_family_case(40, d, 3 + d)
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0 and nul.ok
+    ux, uy, lam = U.T @ X, U.T @ y, np.abs(S)
+    grid = np.exp(-10 + 0.2 * np.arange(101))
+    lls = np.array([loglik(t, ux, uy, lam)[0] for t in grid])
+    assert nul.max_index == int(np.argmax(lls))
+    assert 0 < nul.max_index < 100 and nul.brent_evals >= 4
+    lo, hi = grid[nul.max_index - 1], grid[nul.max_index + 1]
+    assert lo < nul.delta < hi
+    fine = np.linspace(lo, hi, 4001)
+    best = fine[int(np.argmax([loglik(t, ux, uy, lam)[0] for t in fine]))]
+    assert abs(nul.delta - best) < 2e-3 + 1e-3 * best          # Brent stops on an ABSOLUTE 1e-3 bracket
+    # beta / sigma2 belong to the LAST point Brent evaluated, which lies inside the final bracket around delta
+    ll, beta, s2 = loglik(nul.delta, ux, uy, lam)
+    assert np.allclose(nul.beta[:d], beta, rtol=5e-3, atol=5e-4)
+    assert abs(nul.sigma2 - s2) < 5e-3 * s2
+
+
+def test_famskat_matches_numpy_literal():
+    N, K, U, S, X, y = make_family_case(30, 2, 11)
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    _, G, af = synth.make_gene(N, 12, seed=5, missing=0.02, common=True, mono=True)
+    rc, out = orc.famskat(G, X, y, U, S, nul)
+    assert rc == 0 and out.fit_ok
+    # independent statement
+    Gf, fl, kp = orc.flip_poly(G)
+    m = Gf.shape[1]
+    assert out.n_poly == m
+    beta = np.array(nul.beta[:2])
+    Sigma = (U * (S + nul.delta)) @ U.T * nul.sigma2
+    Sinv = (U / (S + nul.delta)) @ U.T / nul.sigma2
+    P0 = Sigma - X @ np.linalg.inv(X.T @ Sinv @ X) @ X.T
+    u1 = U.sum(0)
+    denom = np.sum(u1 * u1 / np.abs(S))
+    alpha = (u1 / np.abs(S)) @ U.T
+    afs = 0.5 * (alpha @ Gf) / denom
+    from scipy.stats import beta as beta_dist
+    w = beta_dist.pdf(afs, 1, 25)
+    wg = w[:, None] * Gf.T
+    Q = np.sum((wg @ (Sinv @ (y - X @ beta))) ** 2)
+    ev = np.linalg.eigvalsh(wg @ P0 @ wg.T)[::-1]
+    ev = ev[ev > 1e-30]
+    assert abs(out.Q - Q) < 1e-9 * Q
+    assert out.n_lambda == len(ev)
+    got = np.array(out.lambda_[: out.n_lambda])
+    assert np.allclose(got, ev, rtol=1e-8, atol=1e-10 * ev[0])
+    p = orc.davies(ev, Q)
+    assert abs(out.pvalue - p) <= 1e-6 * p + 1e-12
