@@ -47,6 +47,7 @@ extern "C" {
 #define RVT_TEST_CMC 4u     /* --burden cmc    : CMCTest     src/Model.h:807-907   */
 #define RVT_TEST_ZEGGINI 8u /* --burden zeggini: ZegginiTest src/Model.h:1170-1242 */
 #define RVT_TEST_ALL 15u
+#define RVT_TEST_FAMSKAT 16u /* --kernel famSkat: FamSkatTest src/Model.h:3048-3145 (rvt_run_fam_blocks only) */
 
 /* trait type of the null model */
 #define RVT_TRAIT_QUANTITATIVE 0
@@ -91,7 +92,19 @@ typedef struct rvt_gene_result {
   double zeg_U, zeg_V, zeg_stat, zeg_p;
   /* diagnostics */
   double davies_terms; /* integrand terms evaluated by all Davies calls of this gene */
+  /* FamSKAT: "Q\tPvalue"  (src/Model.h:3121-3132); famskat_p may be -1 (Davies fault, no Liu fallback there) */
+  int famskat_ok;
+  double famskat_Q, famskat_p;
 } rvt_gene_result;
+
+/* FastLMM null model of the related-sample tests, as FamSkat::FitNullModel consumes it */
+typedef struct rvt_fam_null {
+  double delta;             /* sigma2_e / sigma2_g, FastLMM::GetDelta()              */
+  double sigma2_g;          /* FastLMM::GetSigmaG2()                                 */
+  double beta[RVT_MAX_COV]; /* FastLMM::GetBeta()                                    */
+  int max_index;            /* best point of the 101-point delta grid                */
+  int brent_evals;          /* goal-function evaluations of the Brent refinement     */
+} rvt_fam_null;
 
 /* accumulated device time per kernel family, measured with HIP events on the engine's stream */
 typedef struct rvt_timing {
@@ -174,6 +187,26 @@ int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz
 int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, const double* G);
 /* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */
 int rvt_block_move_columns(rvt_ctx* ctx, double* dG, int dst_col, int src_col, int ncols);
+
+/* ---- related samples: FastLMM null + FamSKAT (`--kernel famSkat`) --------------------------------------------
+ * rvt_set_kinship   installs the eigendecomposition of the kinship the caller already holds
+ *                   (dc->getKinshipUForAuto() / getKinshipSForAuto(): EigenMatrix = Eigen::MatrixXf, column-major
+ *                   N x N and N x 1, regression/EigenMatrix.h:9-12); kept on the device in fp64.
+ * rvt_fit_fam_null  FastLMM::FitNullModel (regression/FastLMM.cpp:28-142; model MLE, test SCORE as
+ *                   FamSkat.cpp:27 constructs it): rotation by U', the 101-point delta grid, the GSL-Brent
+ *                   refinement of GSLMinimizer.cpp:18-66 (same evaluation sequence, so the same quirks: delta is the
+ *                   bracket's minimum while beta / sigma2 belong to the last evaluated point), followed by the
+ *                   products FamSkat::FitNullModel (regression/FamSkat.cpp:34-64) prepares — without forming the
+ *                   N x N Sigma / Sigma^-1 / P0.  X: N x d column-major incl. intercept, y: N.
+ * rvt_run_fam_blocks  FamSkat::TestCovariate (regression/FamSkat.cpp:65-138) for n device-resident blocks (imputed,
+ *                   UNFLIPPED, like rvt_run_blocks): flip-to-minor + monomorphic removal, weights
+ *                   beta_pdf(FastGetAF; 1, 25) (FastLMM.cpp:402-443), Q, eigenvalues of wg P0 wg', Davies only.
+ *                   Fills n_variants, n_poly, famskat_ok / famskat_Q / famskat_p of each record.  Synchronous. */
+int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
+int rvt_fit_fam_null(rvt_ctx* ctx, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
+int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
+                       rvt_gene_result* out);
+/* device block for genotype data when no rvt_set_null was called (family-only analyses): N from rvt_set_kinship */
 
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */

@@ -1,0 +1,216 @@
+// rvtests_amd — related-sample path (FastLMM null model + FamSKAT): the small kernels around the shared
+// sufficient-statistics machinery.
+//
+// FamSkat (regression/FamSkat.cpp:34-138) works with N x N matrices Sigma = sigma2 U (S + delta) U', Sigma^-1 and
+// P0 = Sigma - X (X' Sigma^-1 X)^-1 X'.  With G~ = U'G (one GEMM per batch of genes) everything it needs is a
+// diagonal-weighted contraction over the rotated samples,
+//     wg P0 wg' = W (G~' V G~  -  (G'X) C^-1 (G'X)') W,   V = sigma2 (S + delta),  G'X = G~'(U'X),  C = X' Sigma^-1 X
+//     wg Sigma^-1 r = W G~' V^-1 U'(y - X beta)
+//     FastGetAF_j  = 0.5 * sum_i G~_ij u1_i / |S_i| / (u1'|S|^-1 u1),   u1 = U'1        (FastLMM.cpp:402-443)
+// i.e. exactly R = G~' D [G~ | X_in | rr_in] of gene_suffstat_mfma in its weighted mode with
+//     D = V,  X_in = [ V^-1 U'X | V^-1 u1/|S| ],  rr_in = V^-2 U'(y - X beta).
+// N x N objects never exist; U is read once per batch by the rotation GEMM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rvt_gene.h"
+
+namespace rvt {
+
+__global__ void cvt_f32_f64_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+
+// out[k] = sum_i A[i + k*lda], one workgroup per column, fixed reduction order
+__global__ __launch_bounds__(256) void column_sums_kernel(const double* __restrict__ A, long long n, long long lda,
+                                                          double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* col = A + (long long)blockIdx.x * lda;
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) s += col[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// FastLMM getBetaSigma2 / getLogLikelihood (regression/FastLMM.cpp:297-346) need, for one delta,
+//   A = ux' D ux, b = ux' D uy, yy = uy' D uy (D = 1/|lambda + delta|) and sum log|lambda + delta|.
+// uxy: N x (d+1) column-major, columns 0..d-1 = U'X, column d = U'y.  Each workgroup writes one partial record
+// of kLmmRec doubles: A (d x d row-major), b (d), yy, slog.
+constexpr int kLmmBlocks = 256;
+__host__ __device__ constexpr int lmm_rec_len(int d) { return d * d + d + 2; }
+
+__global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict__ uxy, const double* __restrict__ lam,
+                                                       long long N, int d, double delta, int take_abs,
+                                                       double* __restrict__ partial) {
+  extern __shared__ double sm[];  // 256 doubles
+  const int rec = lmm_rec_len(d);
+  double* out = partial + (long long)blockIdx.x * rec;
+  // one quantity at a time keeps the register footprint independent of d (this kernel runs ~120 times per fit)
+  for (int q = 0; q < rec; ++q) {
+    int a = 0, b = 0, kind;
+    if (q < d * d) {
+      kind = 0;
+      a = q / d;
+      b = q % d;
+    } else if (q < d * d + d) {
+      kind = 1;
+      a = q - d * d;
+    } else
+      kind = (q == d * d + d) ? 2 : 3;
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += 256LL * gridDim.x) {
+      const double t = lam[i] + delta;
+      const double w = 1.0 / (take_abs ? fabs(t) : t);
+      double v;
+      if (kind == 0)
+        v = uxy[i + a * N] * w * uxy[i + b * N];
+      else if (kind == 1)
+        v = uxy[i + a * N] * w * uxy[i + (long long)d * N];
+      else if (kind == 2)
+        v = uxy[i + (long long)d * N] * w * uxy[i + (long long)d * N];
+      else
+        v = log(fabs(t));
+      s += v;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = sm[0];
+    __syncthreads();
+  }
+}
+
+// The "null set" the sufficient-statistics kernels read in FamSKAT mode (see the header comment).
+__global__ void fam_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
+                                      const double* __restrict__ u1, long long N, long long ld, int d, double sigma2,
+                                      double delta, const double* __restrict__ beta, double* __restrict__ Xin,
+                                      double* __restrict__ rr, double* __restrict__ v) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double V = sigma2 * (S[i] + delta);  // raw S, as FamSkat.cpp:48-54 uses kinshipS
+  double p = 0.0;
+  for (int k = 0; k < d; ++k) p += uxy[i + k * N] * beta[k];
+  const double r = uxy[i + (long long)d * N] - p;
+  for (int k = 0; k < d; ++k) Xin[i + k * ld] = uxy[i + k * N] / V;
+  Xin[i + (long long)d * ld] = (u1[i] / fabs(S[i])) / V;
+  rr[i] = r / (V * V);
+  v[i] = V;
+}
+
+// flip / polymorphic decision per genotype column (DataConsolidator.cpp:46-69,94-116): bit 0 = flip, bit 1 = keep
+__global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* __restrict__ cols, long long N,
+                                                          int* __restrict__ flags) {
+  __shared__ double rs[256], rmn[256], rmx[256];
+  const double* col = cols[blockIdx.x];
+  double s = 0.0, mn = INFINITY, mx = -INFINITY;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const double g = col[i];
+    s += g;
+    mn = fmin(mn, g);
+    mx = fmax(mx, g);
+  }
+  rs[threadIdx.x] = s;
+  rmn[threadIdx.x] = mn;
+  rmx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      rs[threadIdx.x] += rs[threadIdx.x + off];
+      rmn[threadIdx.x] = fmin(rmn[threadIdx.x], rmn[threadIdx.x + off]);
+      rmx[threadIdx.x] = fmax(rmx[threadIdx.x], rmx[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) flags[blockIdx.x] = (!(rs[0] <= (double)N) ? 1 : 0) | ((rmn[0] != rmx[0]) ? 2 : 0);
+}
+
+// dst column c (of the compact N x T matrix, leading dimension ld) = kept source column, flipped to 2 - g if flagged
+__global__ void fam_flip_compact_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
+                                        long long N, long long ld, double* __restrict__ dst) {
+  const double* s = src_cols[blockIdx.y];
+  const bool fl = src_flip[blockIdx.y] != 0;
+  double* d = dst + (long long)blockIdx.y * ld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+    d[i] = fl ? 2.0 - s[i] : s[i];
+}
+
+// Stage A of FamSkat::TestCovariate on the rotated statistics (one workgroup per gene).
+//   R = G~' V [G~ | V^-1 U'X | V^-1 u1/|S| | V^-2 r~]  ->  weights, Q, Wm = S - T Cinv T'  (m = M: the block was
+//   flipped and filtered before the rotation)
+RVT_HD void fam_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
+                         GeneScratch ws, GeneStats* out) {
+  const int dx = nc.d, d = dx - 1;
+  double* R = ws.R;
+  for (int idx = co.tid; idx < Mp * Cp; idx += co.nt) {
+    const int i = idx / Cp, j = idx % Cp;
+    double s = 0.0;
+    if ((j >> 4) >= (i >> 4))
+      for (int p = 0; p < P; ++p) s += parts[(size_t)p * Mp * Cp + idx];
+    R[idx] = s;
+  }
+  co.sync();
+  double qpart = 0.0;
+  for (int i = co.tid; i < M; i += co.nt) {
+    // FastGetAF (FastLMM.cpp:402-443): 0.5 * alpha.g / denom; denom == 0 -> 0
+    const double af = (nc.rss == 0.0) ? 0.0 : 0.5 * (R[(size_t)i * Cp + M + d] / nc.rss);
+    const double w = beta_density(af, 1.0, 25.0);  // FamSkat.cpp:129-137: beta1 = 1, beta2 = 25 always
+    const double u = R[(size_t)i * Cp + M + d + 1];
+    ws.bw[i] = w;
+    ws.bw[Mp + i] = NAN;  // never equal to the SKAT weights: the eigen stage builds SKAT's own matrix
+    qpart += (w * u) * (w * u);
+  }
+  const double Q = co.sum(qpart);
+  double* TC = ws.vecs;  // M x d: T Cinv
+  for (int idx = co.tid; idx < M * d; idx += co.nt) {
+    const int i = idx / d, b = idx % d;
+    double s = 0.0;
+    for (int a = 0; a < d; ++a) s += R[(size_t)i * Cp + M + a] * nc.Cinv[a * dx + b];
+    TC[idx] = s;
+  }
+  co.sync();
+  for (int idx = co.tid; idx < M * M; idx += co.nt) {
+    const int i = idx % M, j = idx / M;
+    const double S = (j >= i) ? R[(size_t)i * Cp + j] : R[(size_t)j * Cp + i];
+    double q = 0.0;
+    for (int b = 0; b < d; ++b) q += TC[(size_t)i * d + b] * R[(size_t)j * Cp + M + b];
+    ws.Wm[idx] = S - q;
+  }
+  if (co.tid == 0) {
+    out->status = 0;
+    out->n_variants = M;
+    out->n_poly = M;
+    out->flip_count = 0;
+    out->skat_Q = Q;
+    out->skat_nlambda = 0;
+    out->skat_lambda_off = 0;
+    out->zimz_lambda_off = M;
+    out->zimz_nlambda = 0;
+    out->skato_ok = 0;
+    out->skato_single = 0;
+    out->cmc_ok = 0;
+    out->zeg_ok = 0;
+  }
+  co.sync();
+}
+
+__global__ __launch_bounds__(1024) void fam_assemble_kernel(const GeneDesc* __restrict__ genes,
+                                                           const NullConsts* __restrict__ ncp) {
+  __shared__ double red[64];
+  __shared__ NullConsts nc;
+  const GeneDesc gd = genes[blockIdx.x];
+  if (threadIdx.x == 0) nc = *ncp;
+  __syncthreads();
+  Coop co{(int)threadIdx.x, (int)blockDim.x, red};
+  GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  fam_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, ws, gd.stats);
+}
+
+}  // namespace rvt

@@ -945,7 +945,8 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
   const int* ths[2] = {th_zimz, th_skat};
   const int rs[2] = {gs.zimz_nlambda, gs.skat_nlambda};
   double terms = 0.0;
-  const bool do_skat = (tests & RVT_TEST_SKAT) != 0;
+  const bool fam = (tests & RVT_TEST_FAMSKAT) != 0;  // FamSkat.cpp:118: Davies only, result in the famskat fields
+  const bool do_skat = (tests & (RVT_TEST_SKAT | RVT_TEST_FAMSKAT)) != 0;
   const bool do_skato = (tests & RVT_TEST_SKATO) && skato_fit_ok(gs);
   // ---- per-rho tails (lanes 0..10), burden tails (lanes 60, 61) ------------------------------------------
   double pv_rho = 1.0;
@@ -1044,7 +1045,7 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
       fv[lane] = val;
     }
     if (first && lane == 62 && do_skat) {
-      if (p <= 0.0 || p == 1.0) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);  // Skat.cpp:100-103
+      if (!fam && (p <= 0.0 || p == 1.0)) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);  // Skat.cpp:100-103
       *extra62 = p;
     }
     if (first && lane == 63 && do_skato && gs.skato_single) *extra63 = p;
@@ -1115,7 +1116,12 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
   }
   skat_p = __shfl(skat_p, 62, 64);
   single_p = __shfl(single_p, 63, 64);
-  if (do_skat) {
+  if (do_skat && fam) {
+    res.famskat_ok = 1;
+    res.famskat_Q = gs.skat_Q;
+    res.famskat_p = skat_p;
+    res.skat_nlambda = gs.skat_nlambda;
+  } else if (do_skat) {
     res.skat_ok = 1;
     res.skat_Q = gs.skat_Q;
     res.skat_p = skat_p;

@@ -10,7 +10,11 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <rocblas/rocblas.h>
+#include <cmath>
+#include <functional>
 #include "kernels.hip.h"
+#include "fam_kernels.hip.h"
 
 using namespace rvt;
 
@@ -59,6 +63,22 @@ struct rvt_ctx {
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
   bool cu_partitioned = false;
+  // ---- related samples (FastLMM null + FamSKAT) ----
+  bool have_kin = false, have_fam = false;
+  int64_t kin_N = 0;
+  double* d_U = nullptr;   // N x N fp64, column-major (eigenvectors of the kinship)
+  double* d_S = nullptr;   // N raw eigenvalues
+  double* d_u1 = nullptr;  // U'1
+  std::vector<double> h_S, h_u1;
+  double* d_uxy = nullptr;  // N x (d+1): U'X | U'y
+  double* d_lmm_part = nullptr;
+  NullConsts fam_nc;
+  NullConsts* d_fam_nc = nullptr;
+  double *d_fX = nullptr, *d_frr = nullptr, *d_fv = nullptr, *d_fzeros = nullptr, *d_fbeta = nullptr;
+  double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
+  double* d_Gt = nullptr;  // ... rotated by U'
+  size_t fam_cols_cap = 0;
+  rocblas_handle blas = nullptr;
   hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
@@ -377,6 +397,11 @@ void rvt_destroy(rvt_ctx* c) {
     hipStreamDestroy(sl.stream);
   }
   if (c->d_nc) hipFree(c->d_nc);
+  for (double* p : {c->d_U, c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
+                    c->d_fbeta, c->d_Gp, c->d_Gt})
+    if (p) hipFree(p);
+  if (c->d_fam_nc) hipFree(c->d_fam_nc);
+  if (c->blas) rocblas_destroy_handle(c->blas);
   delete c;
 }
 
@@ -445,9 +470,9 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
 
 int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
   if (!c || !out || M < 1) return fail(c, RVT_E_INVALID, "bad block");
-  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first (defines N)");
+  if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first (defines N)");
   hipSetDevice(c->device);
-  const size_t bytes = sizeof(double) * (size_t)c->null_ld * M;
+  const size_t bytes = sizeof(double) * (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld) * M;
   HIP_TRY(c, hipMalloc((void**)out, bytes));
   HIP_TRY(c, hipMemset(*out, 0, bytes));
   return RVT_OK;
@@ -462,10 +487,11 @@ int rvt_block_free(rvt_ctx* c, double* dG) {
 
 int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
   if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
-  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first");
+  if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
-  const size_t N = (size_t)c->nc.N;
-  HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * (size_t)c->null_ld, G, sizeof(double) * N, sizeof(double) * N, M,
+  const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
+  const size_t bld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * bld, G, sizeof(double) * N, sizeof(double) * N, M,
                          hipMemcpyHostToDevice));
   return RVT_OK;
 }
@@ -746,22 +772,26 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
   {
     Scope sc(c, 2, st);
-    hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
-                       n_bparts);
+    if (tests & RVT_TEST_FAMSKAT)
+      hipLaunchKernelGGL(fam_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc);
+    else
+      hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
+                         n_bparts);
   }
-  if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO)) {
+  const unsigned tests_eig = (tests & RVT_TEST_FAMSKAT) ? (unsigned)RVT_TEST_SKAT : tests_eff;
+  if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO | RVT_TEST_FAMSKAT)) {
     const int maxMp = (maxM + 15) / 16 * 16;
     {
       Scope sc(c, 2, st);
       size_t want = sizeof(double) * ((size_t)4 * maxMp + (size_t)maxM * maxM);
       if (want > c->eigen_lds_max) want = sizeof(double) * (size_t)4 * maxMp;  // matrices stay in global scratch
-      hipLaunchKernelGGL(gene_tridiag_kernel, dim3(kNTridiag, n), dim3(256), want, st, d_desc, c->d_nc, tests_eff,
+      hipLaunchKernelGGL(gene_tridiag_kernel, dim3(kNTridiag, n), dim3(256), want, st, d_desc, c->d_nc, tests_eig,
                          (int)(want / sizeof(double)));
     }
     {
       Scope sc(c, 2, st);
       hipLaunchKernelGGL(gene_spectrum_kernel, dim3(kNEigen, n), dim3(128), sizeof(double) * (size_t)4 * maxMp, st,
-                         d_desc, c->d_nc, tests_eff);
+                         d_desc, c->d_nc, tests_eig);
     }
   }
   {
@@ -887,6 +917,452 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
     if (colsum) colsum[i] = s;
     if (cmin) cmin[i] = mn;
     if (cmax) cmax[i] = mx;
+  }
+  return RVT_OK;
+}
+
+// ---- related samples: kinship, FastLMM null model, FamSKAT ----------------------------------------------------
+#define BLAS_TRY(ctx, call)                                                                  \
+  do {                                                                                       \
+    rocblas_status st_ = (call);                                                             \
+    if (st_ != rocblas_status_success) return fail(ctx, RVT_E_HIP, "%s: rocblas status %d", #call, (int)st_); \
+  } while (0)
+
+int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
+  if (!c || !U || !S || N < 2) return fail(c, RVT_E_INVALID, "bad kinship");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  for (double** p : {&c->d_U, &c->d_S, &c->d_u1}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  c->have_kin = c->have_fam = false;
+  const size_t nn = (size_t)N * N;
+  HIP_TRY(c, hipMalloc((void**)&c->d_U, sizeof(double) * nn));
+  HIP_TRY(c, hipMalloc((void**)&c->d_S, sizeof(double) * N));
+  HIP_TRY(c, hipMalloc((void**)&c->d_u1, sizeof(double) * N));
+  {  // fp32 -> fp64 through a bounded staging buffer (the caller's U can be tens of GB)
+    const size_t chunk = std::min<size_t>(nn, (size_t)256 << 20);
+    float* d_tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(float) * chunk));
+    for (size_t off = 0; off < nn; off += chunk) {
+      const size_t n = std::min(chunk, nn - off);
+      HIP_TRY(c, hipMemcpyAsync(d_tmp, U + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, c->d_U + off, n);
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    hipFree(d_tmp);
+  }
+  c->h_S.resize(N);
+  for (int64_t i = 0; i < N; ++i) c->h_S[i] = (double)S[i];
+  HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(column_sums_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, c->d_U, (long long)N,
+                     (long long)N, c->d_u1);
+  c->h_u1.resize(N);
+  HIP_TRY(c, hipMemcpyAsync(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->kin_N = N;
+  c->have_kin = true;
+  if (!c->blas) {
+    BLAS_TRY(c, rocblas_create_handle(&c->blas));
+    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+  }
+  return RVT_OK;
+}
+
+namespace {
+// GSL 1.16 Brent minimiser exactly as Minimizer::minimize drives it (regression/GSLMinimizer.cpp:18-66: set, then
+// iterate until the bracket is narrower than epsabs = 1e-3 or 100 iterations).  The evaluation SEQUENCE matters:
+// the reference's beta / sigma2 are side effects of the last evaluation (regression/FastLMM.cpp:812-817).
+int brent_like_gsl(const std::function<double(double)>& f, double start, double lb, double ub, double* xmin) {
+  const double golden = 0.3819660, sqrt_eps = 1.4901161193847656e-08;
+  double xl = lb, xu = ub, xm = start;
+  const double fl = f(xl);
+  if (!std::isfinite(fl)) return -1;
+  const double fu = f(xu);
+  if (!std::isfinite(fu)) return -1;
+  double fm = f(xm);
+  if (!std::isfinite(fm)) return -1;
+  if (xl > xu || xm >= xu || xm <= xl || fm >= fl || fm >= fu) return -1;
+  double v = xl + golden * (xu - xl), w = v, st_d = 0, st_e = 0;
+  double fv = f(v);
+  if (!std::isfinite(fv)) return -1;
+  double fw = fv;
+  for (int iter = 1;; ++iter) {
+    const double z = xm, fz = fm;
+    double d = st_e, e = st_d;  // the roles of the two saved steps are exchanged on entry, as in GSL
+    const double w_lower = z - xl, w_upper = xu - z, tol = sqrt_eps * std::fabs(z), mid = 0.5 * (xl + xu);
+    double p = 0, q = 0, r = 0;
+    if (std::fabs(e) > tol) {  // parabola through (v, w, z)
+      r = (z - w) * (fz - fv);
+      q = (z - v) * (fz - fw);
+      p = (z - v) * q - (z - w) * r;
+      q = 2 * (q - r);
+      if (q > 0)
+        p = -p;
+      else
+        q = -q;
+      r = e;
+      e = d;
+    }
+    double u;
+    if (std::fabs(p) < std::fabs(0.5 * q * r) && p < q * w_lower && p < q * w_upper) {
+      d = p / q;
+      u = z + d;
+      if ((u - xl) < 2 * tol || (xu - u) < 2 * tol) d = (z < mid) ? tol : -tol;
+    } else {  // golden section into the larger part
+      e = (z < mid) ? xu - z : -(z - xl);
+      d = golden * e;
+    }
+    u = (std::fabs(d) >= tol) ? z + d : z + ((d > 0) ? tol : -tol);
+    st_e = e;
+    st_d = d;
+    const double fuu = f(u);
+    if (!std::isfinite(fuu)) return -1;
+    if (fuu <= fz) {
+      if (u < z)
+        xu = z;
+      else
+        xl = z;
+      v = w;
+      fv = fw;
+      w = z;
+      fw = fz;
+      xm = u;
+      fm = fuu;
+    } else {
+      if (u < z)
+        xl = u;
+      else
+        xu = u;
+      if (fuu <= fw || w == z) {
+        v = w;
+        fv = fw;
+        w = u;
+        fw = fuu;
+      } else if (fuu <= fv || v == z || v == w) {
+        v = u;
+        fv = fuu;
+      }
+    }
+    *xmin = xm;
+    if (std::fabs(xu - xl) < 0.001 || iter >= 100) return 0;
+  }
+}
+}  // namespace
+
+int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out) {
+  if (!c || !X || !y || !out || d < 1 || d + 1 > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_kin || c->kin_N != N) return fail(c, RVT_E_STATE, "rvt_set_kinship with the same N first");
+  if (c->have_null && c->nc.N != N) return fail(c, RVT_E_STATE, "sample count differs from the installed null model");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t ld = rvt_padded_ld(N);
+  for (double** p : {&c->d_uxy, &c->d_lmm_part, &c->d_fX, &c->d_frr, &c->d_fv, &c->d_fzeros, &c->d_fbeta}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  c->have_fam = false;
+  const int dx = d + 1;
+  double* d_xy = nullptr;  // N x (d+1): X | y
+  HIP_TRY(c, hipMalloc((void**)&d_xy, sizeof(double) * (size_t)N * dx));
+  HIP_TRY(c, hipMalloc((void**)&c->d_uxy, sizeof(double) * (size_t)N * dx));
+  HIP_TRY(c, hipMemcpy(d_xy, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d_xy + (size_t)N * d, y, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  {  // ux = U'X, uy = U'y  (FastLMM.cpp:55-57)
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, dx,
+                              (rocblas_int)N, &one, c->d_U, (rocblas_int)N, d_xy, (rocblas_int)N, &zero, c->d_uxy,
+                              (rocblas_int)N));
+    HIP_TRY(c, hipStreamSynchronize(st));
+  }
+  hipFree(d_xy);
+  // |lambda| for the likelihood (FastLMM.cpp:50); the raw S stays in d_S for FamSkat's Sigma
+  std::vector<double> absS(N);
+  for (int64_t i = 0; i < N; ++i) absS[i] = std::fabs(c->h_S[i]);
+  double* d_abs = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_abs, sizeof(double) * N));
+  HIP_TRY(c, hipMemcpy(d_abs, absS.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  const int rec = lmm_rec_len(d);
+  HIP_TRY(c, hipMalloc((void**)&c->d_lmm_part, sizeof(double) * (size_t)kLmmBlocks * rec));
+  std::vector<double> part((size_t)kLmmBlocks * rec), sums(rec);
+  std::vector<double> beta(d, 0.0);
+  double sigma2 = 0.0;
+  bool hip_failed = false;
+  // device sums for one delta: A, b, yy, sum log|lambda + delta|
+  auto device_sums = [&](const double* lam, double delta, int take_abs) {
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, c->d_uxy, lam,
+                       (long long)N, d, delta, take_abs, c->d_lmm_part);
+    if (hipMemcpyAsync(part.data(), c->d_lmm_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      hip_failed = true;
+    for (int q = 0; q < rec; ++q) {
+      double s = 0.0;
+      for (int b = 0; b < kLmmBlocks; ++b) s += part[(size_t)b * rec + q];  // fixed order
+      sums[q] = s;
+    }
+  };
+  // getBetaSigma2 + getLogLikelihood for one delta (FastLMM.cpp:297-346, model MLE); returns the log-likelihood
+  auto evaluate = [&](double delta) {
+    device_sums(d_abs, delta, 1);
+    const double* A = sums.data();
+    const double* b = A + d * d;
+    const double yy = sums[d * d + d], slog = sums[d * d + d + 1];
+    double Ai[RVT_MAX_COV * RVT_MAX_COV];
+    if (!invert_spd(A, d, Ai)) return (double)NAN;
+    for (int a = 0; a < d; ++a) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s += Ai[a * d + k] * b[k];
+      beta[a] = s;
+    }
+    // sum (uy - ux beta)^2 / (lambda + delta) = yy - 2 beta'b + beta'A beta
+    double bb = 0.0, bAb = 0.0;
+    for (int a = 0; a < d; ++a) {
+      bb += beta[a] * b[a];
+      for (int k = 0; k < d; ++k) bAb += beta[a] * A[a * d + k] * beta[k];
+    }
+    sigma2 = (yy - 2.0 * bb + bAb) / (double)N;
+    const double n = (double)N;
+    return -0.5 * (n * std::log(2.0 * 3.14159265358979323846) + slog + n + n * std::log(sigma2));
+  };
+  int maxIndex = -1;
+  double maxLL = 0.0, delta = 0.0;
+  for (int i = 0; i <= 100; ++i) {
+    delta = std::exp(-10. + i * 0.2);
+    const double ll = evaluate(delta);
+    if (std::isnan(ll)) continue;
+    if (maxIndex < 0 || ll > maxLL) {
+      maxIndex = i;
+      maxLL = ll;
+    }
+  }
+  int evals = 0;
+  if (maxIndex > 0 && maxIndex < 100) {
+    const double lb = std::exp(-10. + (maxIndex - 1) * 0.2), ub = std::exp(-10. + (maxIndex + 1) * 0.2);
+    const double start = std::exp(-10. + maxIndex * 0.2);
+    double xmin = start;
+    auto goal = [&](double x) {
+      ++evals;
+      return -evaluate(x);
+    };
+    delta = brent_like_gsl(goal, start, lb, ub, &xmin) ? start : xmin;
+  }  // else: on the boundary delta (and beta, sigma2) stay at the LAST grid point, as in the reference
+  if (hip_failed) {
+    hipFree(d_abs);
+    return fail(c, RVT_E_HIP, "device evaluation of the FastLMM likelihood failed");
+  }
+  out->delta = delta;
+  out->sigma2_g = sigma2;
+  std::memset(out->beta, 0, sizeof(out->beta));
+  for (int a = 0; a < d; ++a) out->beta[a] = beta[a];
+  out->max_index = maxIndex;
+  out->brent_evals = evals;
+  // ---- what FamSkat::FitNullModel prepares (FamSkat.cpp:34-64), in rotated / folded form --------------------
+  NullConsts& fn = c->fam_nc;
+  std::memset(&fn, 0, sizeof(fn));
+  fn.N = N;
+  fn.ld = ld;
+  fn.d = dx;
+  fn.binary = 1;  // the sufficient statistics are weighted by V = sigma2 (S + delta)
+  fn.sigma2 = 1.0;
+  {  // C = X' Sigma^-1 X = sum ux ux' / (sigma2 (S + delta)) with the RAW S (FamSkat.cpp:48-56)
+    device_sums(c->d_S, delta, 0);
+    double C[RVT_MAX_COV * RVT_MAX_COV], Ci[RVT_MAX_COV * RVT_MAX_COV];
+    for (int a = 0; a < d * d; ++a) C[a] = sums[a] / sigma2;
+    if (hip_failed || !invert_spd(C, d, Ci)) {
+      hipFree(d_abs);
+      return fail(c, RVT_E_INVALID, "X' Sigma^-1 X is singular");
+    }
+    for (int a = 0; a < dx; ++a)
+      for (int b = 0; b < dx; ++b) {
+        const bool in = a < d && b < d;
+        fn.C[a * dx + b] = in ? C[a * d + b] : (a == b ? 1.0 : 0.0);
+        fn.Cinv[a * dx + b] = in ? Ci[a * d + b] : (a == b ? 1.0 : 0.0);
+      }
+  }
+  hipFree(d_abs);
+  {  // denom of FastGetAF: u1' |S|^-1 u1 (FastLMM.cpp:414-420), kept in the otherwise unused rss slot
+    double den = 0.0;
+    for (int64_t i = 0; i < N; ++i) den += c->h_u1[i] / std::fabs(c->h_S[i]) * c->h_u1[i];
+    fn.rss = den;
+  }
+  const size_t vb = sizeof(double) * (size_t)ld;
+  HIP_TRY(c, hipMalloc((void**)&c->d_fX, vb * dx));
+  HIP_TRY(c, hipMalloc((void**)&c->d_frr, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_fv, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_fzeros, vb));
+  HIP_TRY(c, hipMalloc((void**)&c->d_fbeta, sizeof(double) * RVT_MAX_COV));
+  HIP_TRY(c, hipMemsetAsync(c->d_fX, 0, vb * dx, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_frr, 0, vb, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_fv, 0, vb, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_fzeros, 0, vb, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_fbeta, out->beta, sizeof(double) * RVT_MAX_COV, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_build_null_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_uxy, c->d_S,
+                     c->d_u1, (long long)N, (long long)ld, d, sigma2, delta, c->d_fbeta, c->d_fX, c->d_frr, c->d_fv);
+  if (!c->d_fam_nc) HIP_TRY(c, hipMalloc((void**)&c->d_fam_nc, sizeof(NullConsts)));
+  HIP_TRY(c, hipMemcpyAsync(c->d_fam_nc, &fn, sizeof(NullConsts), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  c->have_fam = true;
+  return RVT_OK;
+}
+
+int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const int64_t* ids,
+                       rvt_gene_result* out) {
+  if (!c || n < 0 || (n > 0 && (!dG || !Ms || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  if (n == 0) return RVT_OK;
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t N = c->fam_nc.N, ld = c->fam_nc.ld;
+  // ---- 1. flip / monomorphic flags of every column (DataConsolidator.cpp:46-69,94-142) ------------------------
+  size_t tot = 0;
+  for (int g = 0; g < n; ++g) {
+    if (Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene %d: M=%d", g, Ms[g]);
+    tot += (size_t)Ms[g];
+  }
+  std::vector<const double*> cols(tot);
+  {
+    size_t k = 0;
+    for (int g = 0; g < n; ++g)
+      for (int j = 0; j < Ms[g]; ++j) cols[k++] = dG[g] + (size_t)j * ld;
+  }
+  const double** d_cols = nullptr;
+  int* d_flags = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * tot * 2));
+  HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * tot * 2));
+  struct Guard {
+    void *a, *b;
+    ~Guard() {
+      hipFree(a);
+      hipFree(b);
+    }
+  } guard{(void*)d_cols, (void*)d_flags};
+  HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * tot, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)tot), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+  std::vector<int> flags(tot);
+  HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * tot, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  // ---- 2. compact the kept columns (flipped where needed) and rotate them by U' --------------------------------
+  std::vector<const double*> kept_cols;
+  std::vector<int> kept_flip, Mk(n), off(n);
+  {
+    size_t k = 0;
+    for (int g = 0; g < n; ++g) {
+      off[g] = (int)kept_cols.size();
+      for (int j = 0; j < Ms[g]; ++j, ++k)
+        if (flags[k] & 2) {
+          kept_cols.push_back(cols[k]);
+          kept_flip.push_back(flags[k] & 1);
+        }
+      Mk[g] = (int)kept_cols.size() - off[g];
+    }
+  }
+  const size_t T = kept_cols.size();
+  for (int g = 0; g < n; ++g) {
+    rvt_gene_result& r = out[g];
+    std::memset(&r, 0, sizeof(r));
+    r.gene_id = ids ? ids[g] : g;
+    r.n_variants = Ms[g];
+    r.n_poly = Mk[g];
+  }
+  if (T == 0) return RVT_OK;  // genotype.cols == 0 everywhere: all NA (src/Model.h:3066-3069)
+  if (T > c->fam_cols_cap) {
+    if (c->d_Gp) hipFree(c->d_Gp);
+    if (c->d_Gt) hipFree(c->d_Gt);
+    c->d_Gp = c->d_Gt = nullptr;
+    c->fam_cols_cap = 0;
+    const size_t want = T + T / 4;
+    HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
+    HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
+    c->fam_cols_cap = want;
+  }
+  HIP_TRY(c, hipMemcpyAsync(d_cols + tot, kept_cols.data(), sizeof(double*) * T, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(d_flags + tot, kept_flip.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * T, st));  // pad rows must be zero
+  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
+                     (long long)N, (long long)ld, c->d_Gp);
+  {
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N,
+                              (rocblas_int)T, (rocblas_int)N, &one, c->d_U, (rocblas_int)N, c->d_Gp,
+                              (rocblas_int)ld, &zero, c->d_Gt, (rocblas_int)ld));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  // ---- 3. the rotated blocks go through the ordinary batch machinery with the FamSKAT null set ---------------
+  std::vector<const double*> ptr;
+  std::vector<int> mm, which;
+  std::vector<int64_t> gid;
+  size_t af_total = 0;
+  for (int g = 0; g < n; ++g)
+    if (Mk[g] > 0) {
+      ptr.push_back(c->d_Gt + (size_t)off[g] * ld);
+      mm.push_back(Mk[g]);
+      which.push_back(g);
+      gid.push_back(out[g].gene_id);
+      af_total += (size_t)Mk[g];
+    }
+  std::vector<double> af(af_total, 0.0);  // unused: FamSKAT derives its allele frequencies on the device
+  std::vector<rvt_gene_result> rec(ptr.size());
+  struct Swap {  // the batch code reads the null set from the context
+    rvt_ctx* c;
+    NullConsts nc;
+    NullConsts* d_nc;
+    double *X, *res, *rr, *v, *zeros;
+    bool have;
+    int64_t nld;
+    explicit Swap(rvt_ctx* c_) : c(c_), nc(c_->nc), d_nc(c_->d_nc), X(c_->d_X), res(c_->d_res), rr(c_->d_rr),
+                                 v(c_->d_v), zeros(c_->d_zeros), have(c_->have_null), nld(c_->null_ld) {
+      c->nc = c->fam_nc;
+      c->d_nc = c->d_fam_nc;
+      c->d_X = c->d_fX;
+      c->d_res = c->d_fzeros;
+      c->d_rr = c->d_frr;
+      c->d_v = c->d_fv;
+      c->d_zeros = c->d_fzeros;
+      c->have_null = true;
+      c->null_ld = c->fam_nc.ld;
+    }
+    ~Swap() {
+      c->nc = nc;
+      c->d_nc = d_nc;
+      c->d_X = X;
+      c->d_res = res;
+      c->d_rr = rr;
+      c->d_v = v;
+      c->d_zeros = zeros;
+      c->have_null = have;
+      c->null_ld = nld;
+    }
+  };
+  {
+    Swap sw(c);
+    // batches of <= 256 genes keep the per-batch arena bounded
+    for (size_t b0 = 0; b0 < ptr.size(); b0 += 256) {
+      const int nb = (int)std::min<size_t>(256, ptr.size() - b0);
+      size_t afo = 0;
+      for (size_t k = 0; k < b0; ++k) afo += (size_t)mm[k];
+      rc = run_batch(c, nb, ptr.data() + b0, mm.data() + b0, af.data() + afo, gid.data() + b0, RVT_TEST_FAMSKAT,
+                     nullptr, rec.data() + b0, nullptr);
+      if (!rc) rc = rvt_sync(c);
+      if (rc) return rc;
+    }
+  }
+  for (size_t k = 0; k < which.size(); ++k) {
+    rvt_gene_result& r = out[which[k]];
+    r.status = rec[k].status;
+    r.famskat_ok = rec[k].famskat_ok;
+    r.famskat_Q = rec[k].famskat_Q;
+    r.famskat_p = rec[k].famskat_p;
+    r.skat_nlambda = rec[k].skat_nlambda;
+    r.davies_terms = rec[k].davies_terms;
   }
   return RVT_OK;
 }

@@ -28,6 +28,8 @@ RVT_HD void pvalue_init_result(const GeneStats& gs, int64_t gene_id, rvt_gene_re
   r->skat_ok = 0;
   r->skat_Q = r->skat_p = 0.0;
   r->skat_nlambda = gs.skat_nlambda;
+  r->famskat_ok = 0;
+  r->famskat_Q = r->famskat_p = 0.0;
   r->skato_ok = 0;
   r->skato_Q = r->skato_rho = r->skato_p = 0.0;
   r->skato_qags_status = 0;

@@ -43,7 +43,13 @@ class GeneResult(C.Structure):
         ("cmc_stat", C.c_double), ("cmc_p", C.c_double),
         ("zeg_ok", C.c_int), ("zeg_U", C.c_double), ("zeg_V", C.c_double), ("zeg_stat", C.c_double),
         ("zeg_p", C.c_double), ("davies_terms", C.c_double),
+        ("famskat_ok", C.c_int), ("famskat_Q", C.c_double), ("famskat_p", C.c_double),
     ]
+
+
+class FamNull(C.Structure):
+    _fields_ = [("delta", C.c_double), ("sigma2_g", C.c_double), ("beta", C.c_double * 16), ("max_index", C.c_int),
+                ("brent_evals", C.c_int)]
 
 
 class Timing(C.Structure):
@@ -65,7 +71,7 @@ def build_library(force=False, verbose=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", out, os.path.join(CSRC, "rvt_engine.hip")]
+           "-o", out, os.path.join(CSRC, "rvt_engine.hip"), "-lrocblas"]  # rocBLAS: the FamSKAT rotation U'G only
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -122,6 +128,13 @@ def load_library():
     L.rvt_debug_suffstat.restype = C.c_int
     L.rvt_debug_suffstat.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]
+    L.rvt_set_kinship.restype = C.c_int
+    L.rvt_set_kinship.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rvt_fit_fam_null.restype = C.c_int
+    L.rvt_fit_fam_null.argtypes = [vp, C.c_int64, C.c_int, c_double_p, c_double_p, C.POINTER(FamNull)]
+    L.rvt_run_fam_blocks.restype = C.c_int
+    L.rvt_run_fam_blocks.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(C.c_int64),
+                                     C.POINTER(GeneResult)]
     L.rvt_cov_block.restype = C.c_int
     L.rvt_cov_block.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_upload_columns.restype = C.c_int
@@ -272,6 +285,35 @@ class Engine:
         self._check(self.L.rvt_debug_suffstat(self.ctx, C.c_void_p(int(ptr)), M, _dp(S), _dp(T), _dp(u), _dp(cs),
                                               _dp(mn), _dp(mx)))
         return S, T, u, cs, mn, mx
+
+    # ---- related samples: FastLMM null + FamSKAT -----------------------------------------------------------
+    def set_kinship(self, U, S):
+        U = np.asfortranarray(U, dtype=np.float32)
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        N = U.shape[0]
+        assert U.shape == (N, N) and S.shape == (N,)
+        fp = C.POINTER(C.c_float)
+        self._check(self.L.rvt_set_kinship(self.ctx, N, U.ctypes.data_as(fp), S.ctypes.data_as(fp)))
+        self.N = N
+
+    def fit_fam_null(self, X, y):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        N, d = X.shape
+        out = FamNull()
+        self._check(self.L.rvt_fit_fam_null(self.ctx, N, d, _dp(X), _dp(y), C.byref(out)))
+        self.d = getattr(self, "d", d)
+        return out
+
+    def run_fam_blocks(self, ptrs, Ms, ids=None):
+        n = len(ptrs)
+        arr_p = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+        arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
+        arr_id = np.ascontiguousarray(ids if ids is not None else np.arange(n), dtype=np.int64)
+        out = (GeneResult * n)()
+        self._check(self.L.rvt_run_fam_blocks(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p),
+                                              arr_id.ctypes.data_as(C.POINTER(C.c_int64)), out))
+        return list(out)
 
     # ---- MetaCov --------------------------------------------------------------------------------------------
     def cov_block(self, ptr, V):

@@ -1,0 +1,67 @@
+"""GPU parity of the related-sample path through the C ABI: FastLMM null model (rvt_fit_fam_null) and FamSKAT
+(rvt_run_fam_blocks) against the CPU oracle's literal N x N restatement."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+from test_fam_cpu import make_family_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def eng():
+    import rvtests_amd
+    e = rvtests_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("n_fam,d", [(40, 1), (60, 3)])
+def test_fam_null_matches_oracle(eng, n_fam, d):
+    N, K, U, S, X, y = make_family_case(n_fam, d, 3 + d)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    rc, onul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    assert nul.max_index == onul.max_index and nul.brent_evals >= 4
+    # The likelihood is flat at its optimum (differences of 1e-12 between Brent's trial points), so rounding-level
+    # differences in the function values can change a comparison inside Brent and with it the trajectory; what the
+    # reference's stopping rule (bracket < 1e-3 ABSOLUTE, GSLMinimizer.cpp:8) pins down is delta to ~1e-3 and
+    # beta / sigma2 to the corresponding accuracy.  When the trajectories coincide the numbers agree to 1e-8.
+    assert abs(nul.delta - onul.delta) <= 2e-3 + 1e-3 * onul.delta
+    if nul.brent_evals == onul.brent_evals:
+        assert abs(nul.delta - onul.delta) <= 1e-7 * onul.delta
+        assert abs(nul.sigma2_g - onul.sigma2) <= 1e-8 * onul.sigma2
+        assert np.allclose(nul.beta[:d], onul.beta[:d], rtol=1e-8, atol=1e-10)
+    assert abs(nul.sigma2_g - onul.sigma2) <= 5e-3 * onul.sigma2
+    assert np.allclose(nul.beta[:d], onul.beta[:d], rtol=5e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("n_fam,d,Ms", [(40, 2, (12, 1, 30)), (75, 3, (20, 45, 7))])
+def test_famskat_matches_oracle(eng, n_fam, d, Ms):
+    N, K, U, S, X, y = make_family_case(n_fam, d, 20 + d)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    # FamSkat::FitNullModel takes (delta, sigma2, beta) from FastLMM: give the oracle the device's values so that this
+    # test pins the FamSKAT stage itself (the null fit has its own test above)
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(d):
+        onul.beta[k] = nul.beta[k]
+    genes = [synth.make_gene(N, M, seed=300 + M, missing=0.02, common=True, mono=(M > 5))[1] for M in Ms]
+    genes.append(np.ones((N, 3)))                       # all monomorphic: NA row
+    ptrs = [eng.upload_block(G) for G in genes]
+    out = eng.run_fam_blocks(ptrs, [G.shape[1] for G in genes])
+    for r, G in zip(out, genes):
+        rc, o = orc.famskat(G, X, y, U, S, onul)
+        assert r.n_variants == G.shape[1] and r.n_poly == o.n_poly
+        if rc != 0:
+            assert r.famskat_ok == 0
+            continue
+        assert r.famskat_ok == 1
+        assert abs(r.famskat_Q - o.Q) <= 1e-7 * o.Q
+        assert r.skat_nlambda == o.n_lambda
+        assert abs(r.famskat_p - o.pvalue) <= 2e-6 * abs(o.pvalue) + 1e-12
