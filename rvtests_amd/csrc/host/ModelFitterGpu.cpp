@@ -102,6 +102,8 @@ void GpuBroker::shutdown() {
   if (ctx) rvt_destroy(ctx);
   ctx = nullptr;
   haveNull = false;
+  haveFamNull = false;
+  kinU = nullptr;
   curSerial = -1;
   tests = 0;
 }
@@ -138,6 +140,34 @@ rvt_ctx* GpuBroker::contextWithNull(const GeneData& gd, bool binary, std::string
   }
   if (!haveNull || gd.phenotypeUpdated || gd.covariateUpdated)
     if (installNull(gd, binary, err)) return nullptr;
+  return ctx;
+}
+
+rvt_ctx* GpuBroker::contextWithFamNull(const GeneData& gd, std::string* err) {
+  if (ensureContext(0)) {
+    *err = "no MI355X device: the GPU models have no CPU fallback";
+    return nullptr;
+  }
+  if (kinU != gd.kinshipU) {  // a new decomposition (autosomes vs X region in the reference): install it once
+    if (rvt_set_kinship(ctx, gd.N, gd.kinshipU, gd.kinshipS)) {
+      *err = rvt_last_error(ctx);
+      return nullptr;
+    }
+    kinU = gd.kinshipU;
+    haveFamNull = false;
+  }
+  if (!haveFamNull || gd.phenotypeUpdated || gd.covariateUpdated) {
+    const int d = 1 + gd.ncov;  // copyCovariateAndIntercept (src/ModelUtil.h:102-130)
+    std::vector<double> X((size_t)gd.N * d);
+    for (int64_t i = 0; i < gd.N; ++i) X[i] = 1.0;
+    if (gd.ncov) std::memcpy(X.data() + gd.N, gd.covariate, sizeof(double) * (size_t)gd.N * gd.ncov);
+    rvt_fam_null fn;
+    if (rvt_fit_fam_null(ctx, gd.N, d, X.data(), gd.phenotype, &fn)) {
+      *err = "SKAT test (for related individuals) failed in fitting null model (SKAT)";
+      return nullptr;
+    }
+    haveFamNull = true;
+  }
   return ctx;
 }
 
@@ -262,6 +292,49 @@ void ZegginiTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
 void ZegginiTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.valueTab());
   fp->write(fitOK ? floatToString(res->zeg_p) + "\n" : std::string("NA\n"));
+}
+
+// ---- FamSkatTest ----------------------------------------------------------------------------------------------------------
+FamSkatTest::FamSkatTest(double, double) { modelName = "FamSkat"; }
+int FamSkatTest::fit(GeneData* dc) {
+  fitOK = false;
+  if (isBinaryOutcome()) {  // src/Model.h:3071-3078
+    lastError = "SKAT test (for related individuals) does not support binary outcomes. Results will be all NAs.";
+    return -1;
+  }
+  if (!dc->kinshipU || !dc->kinshipS) {  // src/Model.h:3079-3087
+    lastError = "SKAT test (for related individuals) cannot find kinship. Results will be all NAs.";
+    return -1;
+  }
+  rvt_ctx* ctx = GpuBroker::instance().contextWithFamNull(*dc, &lastError);
+  if (!ctx) return -1;
+  double* block = nullptr;
+  if (rvt_block_alloc(ctx, dc->M, &block) || rvt_block_upload(ctx, block, dc->M, dc->genotype)) {
+    lastError = rvt_last_error(ctx);
+    if (block) rvt_block_free(ctx, block);
+    return -1;
+  }
+  const double* p = block;
+  const int rc = rvt_run_fam_blocks(ctx, 1, &p, &dc->M, &dc->serial, &rec);
+  rvt_block_free(ctx, block);
+  if (rc) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  if (!rec.famskat_ok) return -1;  // genotype.cols == 0 after filtering -> NA row (src/Model.h:3066-3069)
+  fitOK = true;
+  return 0;
+}
+void FamSkatTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.headerTab());
+  fp->write("Q\tPvalue\n");
+}
+void FamSkatTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.valueTab());
+  if (!fitOK)
+    fp->write("NA\tNA\n");
+  else
+    fp->write(formatG(rec.famskat_Q) + "\t" + formatG(rec.famskat_p) + "\n");
 }
 
 // ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
@@ -435,6 +508,10 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         double beta1, beta2;
         parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);
         model.push_back(new SkatOTest(beta1, beta2));
+      } else if (modelName == "famskat") {
+        double beta1, beta2;
+        parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);  // src/ModelManager.cpp:188-193
+        model.push_back(new FamSkatTest(beta1, beta2));
       } else {
         lastError = "Unknown model name: " + modelName + " .";
         return -1;

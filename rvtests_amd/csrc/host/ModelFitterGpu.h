@@ -42,6 +42,10 @@ struct GeneData {
   bool phenotypeUpdated = false, covariateUpdated = false;  // dc->isPhenotypeUpdated() / isCovariateUpdated()
   int64_t serial = 0;                 // increases with every dc.consolidate() (new gene)
   const SiteInfo* site = nullptr;     // dc->getResult(): CHROM / POS of the current site (single-variant models)
+  // dc->hasKinship(), getKinshipUForAuto() / getKinshipSForAuto() (src/DataConsolidator.h:236-258): EigenMatrix holds
+  // Eigen::MatrixXf, i.e. float, column-major N x N and N x 1
+  const float* kinshipU = nullptr;
+  const float* kinshipS = nullptr;
 };
 
 // ---- FileWriter stand-in (base/IO.h FileWriter::write / printf) -------------------------------------------
@@ -105,6 +109,8 @@ class GpuBroker {
   void shutdown();
   // context + null model for models that drive the C ABI themselves (MetaCovTest)
   rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
+  // context + kinship + FastLMM null for FamSkatTest (refitted when the caller flags new phenotype / covariates)
+  rvt_ctx* contextWithFamNull(const GeneData& gd, std::string* err);
   // null model: fitted on the host by the caller-supplied routine (the reference's LinearRegression /
   // LogisticRegression in the real tree); see INTEGRATION.md
   typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
@@ -120,6 +126,8 @@ class GpuBroker {
   rvt_gene_result cur{};
   bool curOk = false;
   NullFitter fitter = nullptr;
+  const float* kinU = nullptr;
+  bool haveFamNull = false;
   int installNull(const GeneData& gd, bool binary, std::string* err);
 };
 
@@ -188,6 +196,20 @@ class ZegginiTest : public ModelFitter {
 
  private:
   bool fitOK = false;
+};
+
+// `--kernel famSkat[beta1:beta2]` (src/Model.h:3048-3145).  The reference ignores beta1 / beta2 for this model
+// (FamSkat.cpp:129-137 always uses Beta(1, 25)); so does this adapter.
+class FamSkatTest : public ModelFitter {
+ public:
+  FamSkatTest(double beta1, double beta2);
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool fitOK = false;
+  rvt_gene_result rec{};
 };
 
 // `--meta cov[windowSize=..:gwama]` for unrelated samples.  fit() is called once per variant (genotype.cols == 1,

@@ -5,6 +5,7 @@
 //
 //   host_driver <input.bin> <kernel list, e.g. "skat[nPerm=0],skato" or "-"> <burden list, e.g. "cmc,zeggini" or "-">
 //               [<meta list, e.g. "cov[windowSize=3000]"> <sites.txt: one "chrom pos" line per variant, file order>]
+//               [... <kinship.bin: int64 N; float U[N*N] (column-major); float S[N]>]   (7th argument, for famSkat)
 // With a meta list the driver runs the reference's single-variant loop instead (src/Main.cpp:1010-1078): every
 // column of every block is one fit() call with CHROM / POS in the site record.
 //
@@ -169,8 +170,25 @@ int main(int argc, char** argv) {
   site.kv = {{"Range", ""}, {"N_INFORMATIVE", std::to_string(N)}, {"NumVar", ""}, {"NumPolyVar", ""}};
   for (size_t m = 0; m < models.size(); ++m) models[m]->writeHeader(&outs[m], site);
 
+  std::vector<float> kinU, kinS;
+  if (argc >= 7) {
+    FILE* kf = fopen(argv[6], "rb");
+    int64_t kn = 0;
+    if (!kf || fread(&kn, 8, 1, kf) != 1 || kn != N) {
+      fprintf(stderr, "bad kinship file %s\n", argv[6]);
+      return 1;
+    }
+    kinU.resize((size_t)N * N);
+    kinS.resize(N);
+    if (fread(kinU.data(), 4, kinU.size(), kf) != kinU.size() || fread(kinS.data(), 4, N, kf) != (size_t)N) return 2;
+    fclose(kf);
+  }
   GeneData dc;
   dc.N = N;
+  if (!kinU.empty()) {
+    dc.kinshipU = kinU.data();
+    dc.kinshipS = kinS.data();
+  }
   dc.phenotype = y.data();
   dc.covariate = cov.data();
   dc.ncov = ncov;

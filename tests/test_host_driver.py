@@ -202,3 +202,38 @@ def test_driver_metacov_rows_match_oracle(tmp_path, binary, gwama, block):
             gz = np.array([float(t) for t in parts[2].split(",")])
             wz = np.array([zz[a, b] * float(scale) for a in range(d) for b in range(a + 1)])
             assert np.allclose(gz, wz, rtol=2e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_driver_famskat_matches_oracle(tmp_path):
+    """--kernel famSkat through the C++ adapter: kinship + FastLMM null installed once, one row per gene."""
+    _ensure_driver()
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(50, 2, 31)
+    genes = [synth.make_gene(N, M, seed=90 + M, missing=0.01, common=True, mono=(M > 5))[1:] for M in (9, 24, 3)]
+    genes.append((np.ones((N, 2)), np.zeros(2)))          # monomorphic only -> NA row
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, genes)
+    kin = str(tmp_path / "kin.bin")
+    with open(kin, "wb") as f:
+        f.write(struct.pack("<q", N))
+        f.write(np.asfortranarray(U, dtype="<f4").tobytes(order="F"))
+        f.write(np.ascontiguousarray(S, dtype="<f4").tobytes())
+    p = subprocess.run([DRIVER, path, "famSkat[beta1=1:beta2=25]", "-", "-", "-", kin], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.FamSkat.assoc"
+    assert lines[1].split("\t")[-2:] == ["Q", "Pvalue"]
+    rows = [ln.split("\t") for ln in lines[2:]]
+    assert len(rows) == len(genes)
+    rc, onul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    for row, (G, af) in zip(rows, genes):
+        rc, o = orc.famskat(G, X, y, U, S, onul)
+        if rc != 0:
+            assert row[-2:] == ["NA", "NA"]
+            continue
+        # the null fit is pinned only to the accuracy of the reference's Brent stopping rule (test_gpu_fam.py)
+        assert abs(float(row[-2]) - o.Q) <= 2e-2 * o.Q
+        assert abs(np.log(float(row[-1])) - np.log(o.pvalue)) <= 5e-2 * max(1.0, abs(np.log(o.pvalue)))
