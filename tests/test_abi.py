@@ -59,3 +59,26 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "import orc" not in txt and "oracle/" not in txt.replace(
                     "tests/test_oracle_ref.py", ""), f
+
+
+def test_result_struct_sizes_agree():
+    """The ctypes mirrors of rvt_gene_result (engine binding and host-harness binding) must have the size the C
+    header gives the struct — a stale mirror lets the library write past a Python-owned buffer."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    import hc
+    import rvtests_amd
+    src = '#include <stdio.h>\n#include "rvtests_amd.h"\nint main(){printf("%zu %zu\\n", sizeof(rvt_gene_result), ' \
+          'sizeof(rvt_fam_null));return 0;}\n'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        cpath = os.path.join(td, "sz.c")
+        open(cpath, "w").write(src)
+        exe = os.path.join(td, "sz")
+        subprocess.check_call(["gcc", "-I" + os.path.join(root, "include"), "-o", exe, cpath])
+        a, b = (int(t) for t in subprocess.check_output([exe]).split())
+    assert C.sizeof(rvtests_amd.GeneResult) == a
+    assert C.sizeof(hc.GeneResult) == a
+    from rvtests_amd.engine import FamNull
+    assert C.sizeof(FamNull) == b
