@@ -92,6 +92,11 @@ typedef struct rvt_gene_result {
   double zeg_U, zeg_V, zeg_stat, zeg_p;
   /* diagnostics */
   double davies_terms; /* integrand terms evaluated by all Davies calls of this gene */
+  /* SKAT permutation columns "NumPerm ActualPerm Stat NumGreater NumEqual PermPvalue" (src/Permutation.h:40-141);
+   * Stat = skat_Q.  Filled when rvt_params.skat_nperm > 0 (synchronous entry points only). */
+  int perm_ok;
+  int perm_num_perm, perm_actual_perm, perm_num_greater, perm_num_equal;
+  double perm_pvalue;
   /* FamSKAT: "Q\tPvalue"  (src/Model.h:3121-3132); famskat_p may be -1 (Davies fault, no Liu fallback there) */
   int famskat_ok;
   double famskat_Q, famskat_p;
@@ -187,6 +192,16 @@ int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz
 int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, const double* G);
 /* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */
 int rvt_block_move_columns(rvt_ctx* ctx, double* dG, int dst_col, int src_col, int ncols);
+
+/* ---- SKAT permutations -----------------------------------------------------------------------------------------
+ * With rvt_params.skat_nperm > 0, rvt_run_blocks / rvt_collect also run the adaptive permutation test of
+ * SkatTest::fit (src/Model.h:2706-2718; Permutation src/Permutation.h:69-98; permute src/LinearAlgebra.h:8-21;
+ * Skat::GetQFromNewResidual regression/Skat.cpp:107-116) gene after gene, drawing from ONE emulated glibc rand()
+ * stream exactly as the reference's process-wide rand() is consumed, so the permutations themselves are the
+ * reference's (Q is evaluated in fp64 instead of fp32).  rvt_rand_seed restarts that stream (srand semantics; the
+ * reference never calls srand, i.e. seed 1, which is also the state of a fresh context).
+ * rvt_run_blocks_async rejects skat_nperm > 0. */
+int rvt_rand_seed(rvt_ctx* ctx, unsigned seed);
 
 /* ---- related samples: FastLMM null + FamSKAT (`--kernel famSkat`) --------------------------------------------
  * rvt_set_kinship   installs the eigendecomposition of the kinship the caller already holds

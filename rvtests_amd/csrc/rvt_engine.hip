@@ -15,6 +15,7 @@
 #include <functional>
 #include "kernels.hip.h"
 #include "fam_kernels.hip.h"
+#include "perm_kernels.hip.h"
 
 using namespace rvt;
 
@@ -79,6 +80,15 @@ struct rvt_ctx {
   double* d_Gt = nullptr;  // ... rotated by U'
   size_t fam_cols_cap = 0;
   rocblas_handle blas = nullptr;
+  // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
+  uint32_t rand_state[31];
+  int64_t jump_N = -1;                 // J = A^(jump_N - 1) is cached for this sample count
+  std::vector<uint32_t> jump;          // 31 x 31, row-major
+  uint32_t* d_perm_idx = nullptr;      // N x B
+  uint32_t* d_perm_states = nullptr;   // B x 31
+  double *d_perm_R = nullptr, *d_perm_C = nullptr, *d_perm_Q = nullptr, *d_perm_cur = nullptr;
+  size_t perm_cap_NB = 0, perm_cap_BM = 0;
+  int perm_cap_B = 0;
   hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
   std::string err;
   // null model
@@ -235,6 +245,24 @@ void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_de
 #undef RVT_GROUP
 }
 
+// glibc srandom_r / random_r for the default TYPE_3 generator: r[i] = 16807 r[i-1] mod (2^31 - 1) for the first 31
+// words, then 310 outputs are discarded.  The state is kept normalised (oldest word first): a draw is
+// x' = (x[1..30], x[0] + x[28]).
+void seed_rand_state(uint32_t* x, unsigned seed) {
+  int32_t r[34];
+  r[0] = (int32_t)(seed == 0 ? 1 : seed);
+  for (int i = 1; i < 31; ++i) {
+    int64_t v = (16807LL * r[i - 1]) % 2147483647;
+    if (v < 0) v += 2147483647;
+    r[i] = (int32_t)v;
+  }
+  std::vector<uint32_t> o(344);
+  for (int i = 0; i < 31; ++i) o[i] = (uint32_t)r[i];
+  for (int i = 31; i < 34; ++i) o[i] = o[i - 31];
+  for (int i = 34; i < 344; ++i) o[i] = o[i - 31] + o[i - 3];
+  for (int i = 0; i < 31; ++i) x[i] = o[344 - 31 + i];
+}
+
 // inverse of a small (n <= RVT_MAX_COV) nonsingular matrix, row-major, Gauss-Jordan with partial pivoting
 bool invert_spd(const double* M, int n, double* Minv) {
   double A[RVT_MAX_COV][2 * RVT_MAX_COV];
@@ -362,6 +390,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
       c->eigen_lds_max = want;
     (void)hipGetLastError();
   }
+  seed_rand_state(c->rand_state, 1u);
   *out = c;
   return RVT_OK;
 }
@@ -399,6 +428,9 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_nc) hipFree(c->d_nc);
   for (double* p : {c->d_U, c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
                     c->d_fbeta, c->d_Gp, c->d_Gt})
+    if (p) hipFree(p);
+  for (void* p : {(void*)c->d_perm_idx, (void*)c->d_perm_states, (void*)c->d_perm_R, (void*)c->d_perm_C,
+                  (void*)c->d_perm_Q, (void*)c->d_perm_cur})
     if (p) hipFree(p);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   if (c->blas) rocblas_destroy_handle(c->blas);
@@ -849,13 +881,25 @@ int rvt_wait_oldest(rvt_ctx* c) {
   return oldest ? finish_slot(c, *oldest) : RVT_OK;
 }
 
+namespace {
+int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
+                         const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out);
+}
+
 int rvt_run_blocks_async(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
                          const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  if (c && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT))
+    return fail(c, RVT_E_STATE, "permutation p-values need the synchronous rvt_run_blocks / rvt_collect");
   return run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
 }
 
 int rvt_run_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af, const int64_t* ids,
                    uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  if (c && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) {
+    int rc0 = rvt_sync(c);
+    if (rc0) return rc0;
+    return run_blocks_with_perm(c, n, dG, M, af, ids, tests, prm, out);
+  }
   int rc = run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
   if (rc) return rc;
   return rvt_sync(c);
@@ -1364,6 +1408,220 @@ int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms
     r.skat_nlambda = rec[k].skat_nlambda;
     r.davies_terms = rec[k].davies_terms;
   }
+  return RVT_OK;
+}
+
+// ---- SKAT permutations (exact replay of the reference's rand() stream) ------------------------------------------
+namespace {
+void mat31_mul(const uint32_t* A, const uint32_t* B, uint32_t* C) {  // C = A B over Z/2^32
+  uint32_t T[31 * 31];
+  for (int i = 0; i < 31; ++i)
+    for (int j = 0; j < 31; ++j) {
+      uint32_t s = 0;
+      for (int k = 0; k < 31; ++k) s += A[i * 31 + k] * B[k * 31 + j];
+      T[i * 31 + j] = s;
+    }
+  std::memcpy(C, T, sizeof(T));
+}
+// J = A^e, A the one-draw transition x' = (x[1..30], x[0] + x[28])
+void jump_matrix(uint64_t e, uint32_t* J) {
+  uint32_t P[31 * 31] = {0}, R[31 * 31] = {0};
+  for (int t = 0; t < 30; ++t) P[t * 31 + t + 1] = 1;
+  P[30 * 31 + 0] = 1;
+  P[30 * 31 + 28] = 1;
+  for (int t = 0; t < 31; ++t) R[t * 31 + t] = 1;
+  while (e) {
+    if (e & 1) mat31_mul(R, P, R);
+    mat31_mul(P, P, P);
+    e >>= 1;
+  }
+  std::memcpy(J, R, sizeof(R));
+}
+void mat31_apply(const uint32_t* J, const uint32_t* x, uint32_t* y) {
+  uint32_t t[31];
+  for (int i = 0; i < 31; ++i) {
+    uint32_t s = 0;
+    for (int k = 0; k < 31; ++k) s += J[i * 31 + k] * x[k];
+    t[i] = s;
+  }
+  std::memcpy(y, t, sizeof(t));
+}
+
+int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld) {
+  if (T <= c->fam_cols_cap) return RVT_OK;
+  if (c->d_Gp) hipFree(c->d_Gp);
+  if (c->d_Gt) hipFree(c->d_Gt);
+  c->d_Gp = c->d_Gt = nullptr;
+  c->fam_cols_cap = 0;
+  const size_t want = T + T / 4;
+  HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
+  HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
+  c->fam_cols_cap = want;
+  return RVT_OK;
+}
+
+// The permutation test of one gene whose analytic SKAT result (obs = skat_Q) and weights are already on the device.
+//   dG: the gene's block (unflipped), g0: its descriptor of the batch that just finished (weights in its scratch)
+int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rvt_params& prm, rvt_gene_result* r) {
+  const int64_t N = c->nc.N, ld = c->nc.ld;
+  const int nPerm = prm.skat_nperm;
+  hipStream_t st = c->stream;
+  // flipped, polymorphic genotype block (K_sqrt = diag(w^1/2) G', Skat.cpp:42-47)
+  std::vector<const double*> cols(M);
+  for (int j = 0; j < M; ++j) cols[j] = dG + (size_t)j * ld;
+  const double** d_cols = nullptr;
+  int* d_flags = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * (size_t)M * 2));
+  HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * (size_t)M * 2));
+  struct Guard {
+    void *a, *b;
+    ~Guard() {
+      hipFree(a);
+      hipFree(b);
+    }
+  } guard{(void*)d_cols, (void*)d_flags};
+  HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * M, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+  std::vector<int> flags(M);
+  HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  std::vector<const double*> kc;
+  std::vector<int> kf;
+  for (int j = 0; j < M; ++j)
+    if (flags[j] & 2) {
+      kc.push_back(cols[j]);
+      kf.push_back(flags[j] & 1);
+    }
+  const int m = (int)kc.size();
+  if (m != r->n_poly) return fail(c, RVT_E_STATE, "permutation stage: %d polymorphic columns, batch reported %d", m, r->n_poly);
+  int rc = ensure_fam_cols(c, (size_t)m, ld);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(d_cols + M, kc.data(), sizeof(double*) * m, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(d_flags + M, kf.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)m), dim3(256), 0, st, d_cols + M, d_flags + M,
+                     (long long)N, (long long)ld, c->d_Gp);
+  const double* d_bw = gene_scratch_carve(g0.scratch, g0.Mp, g0.Cp).bw;  // sqrt of the SKAT weights, filtered order
+  // chunk buffers
+  const int B = std::max(1, std::min(nPerm, (int)std::min<int64_t>(2048, ((int64_t)6 << 30) / (8 * N))));
+  if ((size_t)N * B > c->perm_cap_NB || B > c->perm_cap_B || (size_t)B * m > c->perm_cap_BM) {
+    for (void** p : {(void**)&c->d_perm_idx, (void**)&c->d_perm_states, (void**)&c->d_perm_R, (void**)&c->d_perm_C,
+                     (void**)&c->d_perm_Q, (void**)&c->d_perm_cur}) {
+      if (*p) hipFree(*p);
+      *p = nullptr;
+    }
+    c->perm_cap_NB = c->perm_cap_BM = 0;
+    c->perm_cap_B = 0;
+    const size_t bm = (size_t)B * std::max(m, RVT_MAX_VARIANTS / 4);
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_idx, sizeof(uint32_t) * (size_t)N * B));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_states, sizeof(uint32_t) * 31 * (size_t)B));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_R, sizeof(double) * (size_t)N * B));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_C, sizeof(double) * bm));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_Q, sizeof(double) * (size_t)B));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_cur, sizeof(double) * (size_t)N * 2));
+    c->perm_cap_NB = (size_t)N * B;
+    c->perm_cap_B = B;
+    c->perm_cap_BM = bm;
+  }
+  if (c->jump_N != N) {
+    c->jump.resize(31 * 31);
+    jump_matrix((uint64_t)(N - 1), c->jump.data());  // one shuffle draws N-1 numbers (LinearAlgebra.h:12-14)
+    c->jump_N = N;
+  }
+  // permutedRes = res (src/Model.h:2708)
+  double* cur = c->d_perm_cur;
+  double* nxt = c->d_perm_cur + N;
+  HIP_TRY(c, hipMemcpyAsync(cur, c->d_res, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  BLAS_TRY(c, rocblas_set_stream(c->blas, st));
+  const double obs = r->skat_Q;
+  const double threshold = 1.0 * nPerm * prm.skat_alpha * 2;  // Permutation::init
+  int actual = 0, numX = 0, numEq = 0;
+  uint32_t s0[31];
+  std::memcpy(s0, c->rand_state, sizeof(s0));
+  std::vector<uint32_t> states((size_t)31 * (B + 1));
+  std::vector<double> Q(B);
+  bool more = true;
+  while (more) {
+    // Permutation::next() before every shuffle
+    if (actual >= nPerm || numX + numEq >= threshold) break;
+    const int nb = std::min(B, nPerm - actual);
+    std::memcpy(states.data(), s0, sizeof(s0));
+    for (int p = 0; p < nb; ++p) mat31_apply(c->jump.data(), &states[(size_t)31 * p], &states[(size_t)31 * (p + 1)]);
+    HIP_TRY(c, hipMemcpyAsync(c->d_perm_states, states.data(), sizeof(uint32_t) * 31 * (size_t)nb,
+                              hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(perm_init_kernel, dim3(2048), dim3(256), 0, st, c->d_perm_idx, (long long)N, B);
+    hipLaunchKernelGGL(perm_fisher_yates_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st,
+                       c->d_perm_states, c->d_perm_idx, (long long)N, B);
+    for (int p = 0; p < nb; ++p) {  // the shuffles are cumulative: apply them in order
+      hipLaunchKernelGGL(perm_apply_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_perm_idx, cur,
+                         nxt, c->d_perm_R, (long long)N, B, p);
+      std::swap(cur, nxt);
+    }
+    {  // C (nb x m) = Rp (nb x N) G' (N x m)
+      const double one = 1.0, zero = 0.0;
+      BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nb, m,
+                                (rocblas_int)N, &one, c->d_perm_R, B, c->d_Gp, (rocblas_int)ld, &zero, c->d_perm_C,
+                                B));
+    }
+    hipLaunchKernelGGL(perm_q_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, c->d_perm_C, d_bw, B, m,
+                       c->d_perm_Q);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(Q.data(), c->d_perm_Q, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    int used = 0;
+    for (; used < nb; ++used) {
+      if (actual >= nPerm || numX + numEq >= threshold) {
+        more = false;
+        break;
+      }
+      ++actual;  // Permutation::add
+      if (Q[used] > obs) ++numX;
+      if (Q[used] == obs) ++numEq;
+    }
+    std::memcpy(s0, &states[(size_t)31 * used], sizeof(s0));  // the stream continues after the shuffles performed
+    if (used < nb) {
+      // the residual vector of the next gene restarts from res anyway; nothing else carries over
+      more = false;
+    }
+  }
+  std::memcpy(c->rand_state, s0, sizeof(s0));
+  r->perm_ok = 1;
+  r->perm_num_perm = nPerm;
+  r->perm_actual_perm = actual;
+  r->perm_num_greater = numX;
+  r->perm_num_equal = numEq;
+  r->perm_pvalue = actual == 0 ? 1.0 : 1.0 * (numX + 0.5 * numEq) / actual;
+  return RVT_OK;
+}
+
+// analytic tests + permutation test, one gene at a time (the random stream is consumed in gene order)
+int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
+                         const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  if (!c->blas) {
+    BLAS_TRY(c, rocblas_create_handle(&c->blas));
+    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+  }
+  size_t afo = 0;
+  for (int g = 0; g < n; ++g) {
+    DebugOut dbg;
+    GeneDesc g0;
+    dbg.desc0 = &g0;
+    int64_t id = ids ? ids[g] : g;
+    int rc = run_batch(c, 1, dG + g, M + g, af + afo, &id, tests, prm, out + g, &dbg);
+    if (!rc) rc = rvt_sync(c);
+    if (rc) return rc;
+    afo += (size_t)M[g];
+    if (out[g].skat_ok) {  // genotype.cols == 0 returns before the permutations (src/Model.h:2665-2668)
+      rc = perm_stage(c, dG[g], M[g], g0, *prm, out + g);
+      if (rc) return rc;
+    }
+  }
+  return RVT_OK;
+}
+}  // namespace
+
+int rvt_rand_seed(rvt_ctx* c, unsigned seed) {
+  if (!c) return RVT_E_INVALID;
+  seed_rand_state(c->rand_state, seed);
   return RVT_OK;
 }
 

@@ -28,6 +28,9 @@ RVT_HD void pvalue_init_result(const GeneStats& gs, int64_t gene_id, rvt_gene_re
   r->skat_ok = 0;
   r->skat_Q = r->skat_p = 0.0;
   r->skat_nlambda = gs.skat_nlambda;
+  r->perm_ok = 0;
+  r->perm_num_perm = r->perm_actual_perm = r->perm_num_greater = r->perm_num_equal = 0;
+  r->perm_pvalue = 0.0;
   r->famskat_ok = 0;
   r->famskat_Q = r->famskat_p = 0.0;
   r->skato_ok = 0;

@@ -43,6 +43,8 @@ class GeneResult(C.Structure):
         ("cmc_stat", C.c_double), ("cmc_p", C.c_double),
         ("zeg_ok", C.c_int), ("zeg_U", C.c_double), ("zeg_V", C.c_double), ("zeg_stat", C.c_double),
         ("zeg_p", C.c_double), ("davies_terms", C.c_double),
+        ("perm_ok", C.c_int), ("perm_num_perm", C.c_int), ("perm_actual_perm", C.c_int),
+        ("perm_num_greater", C.c_int), ("perm_num_equal", C.c_int), ("perm_pvalue", C.c_double),
         ("famskat_ok", C.c_int), ("famskat_Q", C.c_double), ("famskat_p", C.c_double),
     ]
 
@@ -128,6 +130,8 @@ def load_library():
     L.rvt_debug_suffstat.restype = C.c_int
     L.rvt_debug_suffstat.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]
+    L.rvt_rand_seed.restype = C.c_int
+    L.rvt_rand_seed.argtypes = [vp, C.c_uint]
     L.rvt_set_kinship.restype = C.c_int
     L.rvt_set_kinship.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rvt_fit_fam_null.restype = C.c_int
@@ -285,6 +289,10 @@ class Engine:
         self._check(self.L.rvt_debug_suffstat(self.ctx, C.c_void_p(int(ptr)), M, _dp(S), _dp(T), _dp(u), _dp(cs),
                                               _dp(mn), _dp(mx)))
         return S, T, u, cs, mn, mx
+
+    def rand_seed(self, seed=1):
+        """Restart the emulated glibc rand() stream the SKAT permutations draw from (srand semantics)."""
+        self._check(self.L.rvt_rand_seed(self.ctx, int(seed)))
 
     # ---- related samples: FastLMM null + FamSKAT -----------------------------------------------------------
     def set_kinship(self, U, S):

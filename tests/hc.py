@@ -28,6 +28,8 @@ class GeneResult(C.Structure):
         ("cmc_stat", C.c_double), ("cmc_p", C.c_double),
         ("zeg_ok", C.c_int), ("zeg_U", C.c_double), ("zeg_V", C.c_double), ("zeg_stat", C.c_double),
         ("zeg_p", C.c_double), ("davies_terms", C.c_double),
+        ("perm_ok", C.c_int), ("perm_num_perm", C.c_int), ("perm_actual_perm", C.c_int),
+        ("perm_num_greater", C.c_int), ("perm_num_equal", C.c_int), ("perm_pvalue", C.c_double),
         ("famskat_ok", C.c_int), ("famskat_Q", C.c_double), ("famskat_p", C.c_double),
     ]
 

@@ -326,3 +326,19 @@ def famskat(G, X, y, U, S, nul, use_float=False):
     rc = lib().orc_famskat(_dp(G), C.c_int64(N), M, _dp(X), _dp(y), X.shape[1], _dp(U), _dp(S), C.byref(nul),
                            int(use_float), C.byref(out))
     return rc, out
+
+
+def rand_seed(seed=1):
+    lib().orc_rand_seed(int(seed))
+
+
+def skat_permute(G, af, res, obs, n_perm, alpha, b1=1.0, b2=25.0, use_float=False):
+    """SkatTest's permutation loop on the oracle's glibc rand() emulation (continues the oracle's global stream)."""
+    G = F(G)
+    N, M = G.shape
+    af = np.ascontiguousarray(af, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.float64)
+    out = PermResult()
+    rc = lib().orc_skat_permute(_dp(G), _dp(af), C.c_int64(N), M, _dp(res), float(b1), float(b2), float(obs),
+                                int(n_perm), float(alpha), int(use_float), C.byref(out))
+    return rc, out
