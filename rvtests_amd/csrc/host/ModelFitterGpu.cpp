@@ -204,25 +204,31 @@ SkatTest::SkatTest(int nPerm, double alpha, double beta1, double beta2) : usePer
 }
 int SkatTest::fit(GeneData* dc) {
   fitOK = false;
-  if (usePermutation) {  // permutation p-values are not part of the device path yet
-    lastError = "skat: use skat[nPerm=0] with the GPU backend";
-    return -1;
-  }
   res = GpuBroker::instance().resultFor(*dc, isBinaryOutcome(), &lastError);
   if (!res || !res->skat_ok) return -1;  // genotype.cols == 0 after filtering -> NA row
+  if (usePermutation && !res->perm_ok) return -1;
   fitOK = true;
   return 0;
 }
 void SkatTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
-  fp->write("Q\tPvalue\n");
+  if (!usePermutation)
+    fp->write("Q\tPvalue\n");
+  else  // Permutation::writeHeader (src/Permutation.h:51-56,99-104)
+    fp->write("Q\tPvalue\tNumPerm\tActualPerm\tStat\tNumGreater\tNumEqual\tPermPvalue\n");
 }
 void SkatTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.valueTab());
-  if (!fitOK)
-    fp->write("NA\tNA\n");
-  else
-    fp->write(formatG(res->skat_Q) + "\t" + formatG(res->skat_p) + "\n");
+  if (!fitOK) {
+    fp->write(usePermutation ? "NA\tNA\tNA\tNA\tNA\tNA\tNA\tNA\n" : "NA\tNA\n");
+    return;
+  }
+  std::string line = formatG(res->skat_Q) + "\t" + formatG(res->skat_p);
+  if (usePermutation)  // Permutation::updateValue: ints via toString, doubles via floatToString (src/Result.h:52-63)
+    line += "\t" + std::to_string(res->perm_num_perm) + "\t" + std::to_string(res->perm_actual_perm) + "\t" +
+            floatToString(res->skat_Q) + "\t" + std::to_string(res->perm_num_greater) + "\t" +
+            std::to_string(res->perm_num_equal) + "\t" + floatToString(res->perm_pvalue);
+  fp->write(line + "\n");
 }
 
 // ---- SkatOTest -----------------------------------------------------------------------------------------------------------

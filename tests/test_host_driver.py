@@ -237,3 +237,26 @@ def test_driver_famskat_matches_oracle(tmp_path):
         # the null fit is pinned only to the accuracy of the reference's Brent stopping rule (test_gpu_fam.py)
         assert abs(float(row[-2]) - o.Q) <= 2e-2 * o.Q
         assert abs(np.log(float(row[-1])) - np.log(o.pvalue)) <= 5e-2 * max(1.0, abs(np.log(o.pvalue)))
+
+
+@pytest.mark.gpu
+def test_driver_skat_with_permutations(tmp_path):
+    """default-style `skat` (nPerm > 0): the eight columns of SkatTest::writeOutput with Permutation's fields, counts
+    equal to the oracle's replay of the same rand() stream across consecutive genes."""
+    _ensure_driver()
+    path, genes, X, y, res, v = _case(tmp_path, binary=0, d=2, N=700)
+    rc, sec, err = run_driver(path, "skat[nPerm=150:alpha=0.1]", "-")
+    assert rc == 0, err
+    rows = sec["out.Skat.assoc"]
+    assert rows[0][-8:] == ["Q", "Pvalue", "NumPerm", "ActualPerm", "Stat", "NumGreater", "NumEqual", "PermPvalue"]
+    orc.rand_seed(1)
+    for row, (G, af) in zip(rows[1:], genes):
+        rc1, a = orc.skat(G, af, X, res, v, 0)
+        if a.n_poly == 0:
+            assert row[-8:] == ["NA"] * 8
+            continue
+        rc2, p = orc.skat_permute(G, af, res, a.Q, 150, 0.1)
+        assert row[-6] == "150" and int(row[-5]) == p.actual_perm
+        assert int(row[-3]) == p.num_x and int(row[-2]) == p.num_equal
+        assert abs(float(row[-1]) - p.pvalue) <= 1e-5 * max(p.pvalue, 1e-30)
+        assert row[-4] == "%g" % a.Q or abs(float(row[-4]) - a.Q) <= 2e-6 * a.Q
