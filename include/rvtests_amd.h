@@ -193,6 +193,20 @@ int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, cons
 /* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */
 int rvt_block_move_columns(rvt_ctx* ctx, double* dG, int dst_col, int src_col, int ncols);
 
+/* ---- null models of unrelated samples on the device ---------------------------------------------------------------
+ * rvt_fit_null fits what SkatTest::fit / SkatOTest::fit / MetaCovUnrelated* fit once per analysis
+ * (src/Model.h:2672-2699) and installs it as rvt_set_null would:
+ *   quantitative: LinearRegression::FitLinearModel (regression/LinearRegression.cpp:20-69): beta = (X'X)^-1 X'y,
+ *                 res = y - X beta, sigma2 = ||res||^2 / N, v_i = sigma2
+ *   binary:       LogisticRegression::FitLogisticModel(X, y, 100) (regression/LogisticRegression.cpp:279-336): Newton /
+ *                 IRLS from beta = 0, stop when rounds > 1 and |deviance change| < 1e-3, failure on a non-normal
+ *                 deviance or 100 rounds; res = y - p, v = p (1 - p) with p, v of the LAST EXECUTED round (i.e. before
+ *                 the final beta update, as the reference leaves them)
+ * X: N x d column-major incl. intercept; y: N (0/1 for binary).  beta_out (d) and sigma2_out may be NULL.
+ * Returns RVT_E_INVALID when the fit fails (singular X'VX, no convergence) — the callers then print NA rows. */
+int rvt_fit_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, const double* y, double* beta_out,
+                 double* sigma2_out);
+
 /* ---- SKAT permutations -----------------------------------------------------------------------------------------
  * With rvt_params.skat_nperm > 0, rvt_run_blocks / rvt_collect also run the adaptive permutation test of
  * SkatTest::fit (src/Model.h:2706-2718; Permutation src/Permutation.h:69-98; permute src/LinearAlgebra.h:8-21;

@@ -88,6 +88,81 @@ __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict_
   }
 }
 
+// ---- unrelated null models on the device (LinearRegression.cpp:20-69, LogisticRegression.cpp:279-336) ----------------
+// One IRLS round: p = 1/(1+exp(-X beta)), V = p(1-p) stored; per-workgroup partial record
+//   D = X'VX (d x d), r = X'(y - p) (d), dev = sum y log p + (1-y) log(1-p)      -> lmm_rec_len(d) doubles (last slot unused... dev in slot d*d+d)
+__global__ __launch_bounds__(256) void logistic_round_kernel(const double* __restrict__ X, const double* __restrict__ y,
+                                                             const double* __restrict__ beta, long long N,
+                                                             long long ldx, int d, double* __restrict__ p_out,
+                                                             double* __restrict__ v_out, double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  const int rec = lmm_rec_len(d);
+  double* out = partial + (long long)blockIdx.x * rec;
+  // pass 1: p and V of this workgroup's samples
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += 256LL * gridDim.x) {
+    double e = 0.0;
+    for (int k = 0; k < d; ++k) e += X[i + k * ldx] * beta[k];
+    const double p = 1.0 / (1.0 + exp(-e));
+    p_out[i] = p;
+    v_out[i] = p * (1.0 - p);
+  }
+  __syncthreads();
+  for (int q = 0; q < rec; ++q) {
+    int a = 0, b = 0, kind;
+    if (q < d * d) {
+      kind = 0;
+      a = q / d;
+      b = q % d;
+    } else if (q < d * d + d) {
+      kind = 1;
+      a = q - d * d;
+    } else
+      kind = (q == d * d + d) ? 2 : 3;
+    double s = 0.0;
+    if (kind != 3)
+      for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += 256LL * gridDim.x) {
+        const double p = p_out[i];
+        if (kind == 0)
+          s += X[i + a * ldx] * v_out[i] * X[i + b * ldx];
+        else if (kind == 1)
+          s += X[i + a * ldx] * (y[i] - p);
+        else
+          s += y[i] * log(p) + (1.0 - y[i]) * log(1.0 - p);
+      }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = sm[0];
+    __syncthreads();
+  }
+}
+
+// res = y - X beta (linear) and per-workgroup partial sum of res^2
+__global__ __launch_bounds__(256) void linear_residual_kernel(const double* __restrict__ X, const double* __restrict__ y,
+                                                              const double* __restrict__ beta, long long N,
+                                                              long long ldx, int d, double* __restrict__ res,
+                                                              double* __restrict__ partial) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += 256LL * gridDim.x) {
+    double e = 0.0;
+    for (int k = 0; k < d; ++k) e += X[i + k * ldx] * beta[k];
+    const double r = y[i] - e;
+    res[i] = r;
+    s += r * r;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
 // The "null set" the sufficient-statistics kernels read in FamSKAT mode (see the header comment).
 __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                       const double* __restrict__ u1, long long N, long long ld, int d, double sigma2,

@@ -110,23 +110,28 @@ void GpuBroker::shutdown() {
 
 // copyCovariateAndIntercept (src/ModelUtil.h:102-130) + the null fit SkatTest::fit caches (src/Model.h:2672-2699)
 int GpuBroker::installNull(const GeneData& gd, bool binary, std::string* err) {
-  if (!fitter) {
-    *err = "no null-model fitter installed";
-    return -1;
-  }
   const int d = 1 + gd.ncov;
-  std::vector<double> X((size_t)gd.N * d), res(gd.N), v(gd.N);
+  std::vector<double> X((size_t)gd.N * d);
   for (int64_t i = 0; i < gd.N; ++i) X[i] = 1.0;
   if (gd.ncov) std::memcpy(X.data() + gd.N, gd.covariate, sizeof(double) * (size_t)gd.N * gd.ncov);
-  double sigma2 = 1.0;
-  if (fitter(binary, gd.N, d, X.data(), gd.phenotype, res.data(), v.data(), &sigma2)) {
-    *err = binary ? "failed in fitting null model (logistic model)." : "failed in fitting null model (linear model).";
-    return -1;
+  const int trait = binary ? RVT_TRAIT_BINARY : RVT_TRAIT_QUANTITATIVE;
+  int rc;
+  if (!fitter) {
+    // default: LinearRegression::FitLinearModel / LogisticRegression::FitLogisticModel(cov, y, 100) on the device
+    rc = rvt_fit_null(ctx, trait, gd.N, d, X.data(), gd.phenotype, nullptr, nullptr);
+  } else {
+    // a caller-supplied fitter (e.g. the reference's own regression classes inside the rvtests tree)
+    std::vector<double> res(gd.N), v(gd.N);
+    double sigma2 = 1.0;
+    if (fitter(binary, gd.N, d, X.data(), gd.phenotype, res.data(), v.data(), &sigma2)) {
+      *err = binary ? "failed in fitting null model (logistic model)." : "failed in fitting null model (linear model).";
+      return -1;
+    }
+    rc = rvt_set_null(ctx, trait, gd.N, d, X.data(), res.data(), v.data(), sigma2);
   }
-  int rc = rvt_set_null(ctx, binary ? RVT_TRAIT_BINARY : RVT_TRAIT_QUANTITATIVE, gd.N, d, X.data(), res.data(),
-                        v.data(), sigma2);
   if (rc) {
-    *err = rvt_last_error(ctx);
+    *err = binary ? "failed in fitting null model (logistic model)." : "failed in fitting null model (linear model).";
+    *err += std::string(" [") + rvt_last_error(ctx) + "]";
     return -1;
   }
   haveNull = true;

@@ -111,8 +111,8 @@ class GpuBroker {
   rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
   // context + kinship + FastLMM null for FamSkatTest (refitted when the caller flags new phenotype / covariates)
   rvt_ctx* contextWithFamNull(const GeneData& gd, std::string* err);
-  // null model: fitted on the host by the caller-supplied routine (the reference's LinearRegression /
-  // LogisticRegression in the real tree); see INTEGRATION.md
+  // null model: fitted on the device (rvt_fit_null) unless the caller installs its own routine (e.g. the
+  // reference's LinearRegression / LogisticRegression inside the rvtests tree); see INTEGRATION.md
   typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
                             double* sigma2);
   void setNullFitter(NullFitter f) { fitter = f; }

@@ -22,102 +22,6 @@
 
 using namespace rvt_host;
 
-// Null models of the caller.  In the real rvtests tree these are LinearRegression::FitLinearModel
-// (regression/LinearRegression.cpp:20-69) and LogisticRegression::FitLogisticModel (:279-336); this driver
-// carries a small equivalent so that it is self-contained.
-static bool chol_solve(std::vector<double> A, int d, std::vector<double>& b) {
-  for (int j = 0; j < d; ++j) {
-    double s = A[j * d + j];
-    for (int k = 0; k < j; ++k) s -= A[j * d + k] * A[j * d + k];
-    if (!(s > 0)) return false;
-    const double dj = std::sqrt(s);
-    A[j * d + j] = dj;
-    for (int i = j + 1; i < d; ++i) {
-      double t = A[i * d + j];
-      for (int k = 0; k < j; ++k) t -= A[i * d + k] * A[j * d + k];
-      A[i * d + j] = t / dj;
-    }
-  }
-  for (int i = 0; i < d; ++i) {
-    double t = b[i];
-    for (int k = 0; k < i; ++k) t -= A[i * d + k] * b[k];
-    b[i] = t / A[i * d + i];
-  }
-  for (int i = d - 1; i >= 0; --i) {
-    double t = b[i];
-    for (int k = i + 1; k < d; ++k) t -= A[k * d + i] * b[k];
-    b[i] = t / A[i * d + i];
-  }
-  return true;
-}
-
-static int null_fitter(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
-                       double* sigma2) {
-  std::vector<double> beta(d, 0.0), p(N);
-  auto xtwx = [&](const double* w, std::vector<double>& A) {
-    A.assign((size_t)d * d, 0.0);
-    for (int a = 0; a < d; ++a)
-      for (int b = 0; b < d; ++b) {
-        double s = 0;
-        for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * (w ? w[i] : 1.0) * X[(size_t)b * N + i];
-        A[a * d + b] = s;
-      }
-  };
-  if (!binary) {
-    std::vector<double> A, b(d);
-    xtwx(nullptr, A);
-    for (int a = 0; a < d; ++a) {
-      double s = 0;
-      for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * y[i];
-      b[a] = s;
-    }
-    if (!chol_solve(A, d, b)) return -1;
-    double rss = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      double pr = 0;
-      for (int a = 0; a < d; ++a) pr += X[(size_t)a * N + i] * b[a];
-      res[i] = y[i] - pr;
-      rss += res[i] * res[i];
-    }
-    *sigma2 = rss / (double)N;
-    for (int64_t i = 0; i < N; ++i) v[i] = *sigma2;
-    return 0;
-  }
-  int rounds = 0;
-  double last = -99999, cur = -9999;
-  while (rounds < 100) {
-    for (int64_t i = 0; i < N; ++i) {
-      double e = 0;
-      for (int a = 0; a < d; ++a) e += X[(size_t)a * N + i] * beta[a];
-      p[i] = 1.0 / (1.0 + std::exp(-e));
-      v[i] = p[i] * (1.0 - p[i]);
-    }
-    std::vector<double> A, r(d);
-    xtwx(v, A);
-    for (int a = 0; a < d; ++a) {
-      double s = 0;
-      for (int64_t i = 0; i < N; ++i) s += X[(size_t)a * N + i] * (y[i] - p[i]);
-      r[a] = s;
-    }
-    if (!chol_solve(A, d, r)) return -1;
-    for (int a = 0; a < d; ++a) beta[a] += r[a];
-    double ll = 0;
-    for (int64_t i = 0; i < N; ++i) ll += y[i] * std::log(p[i]) + (1. - y[i]) * std::log(1.0 - p[i]);
-    cur = -2.0 * ll;
-    if (rounds > 1 && std::fabs(cur - last) < 1e-3) {
-      rounds = 0;
-      break;
-    }
-    if (std::fpclassify(cur) != FP_NORMAL) return -1;
-    last = cur;
-    rounds++;
-  }
-  if (rounds == 100) return -1;
-  for (int64_t i = 0; i < N; ++i) res[i] = y[i] - p[i];
-  *sigma2 = 1.0;
-  return 0;
-}
-
 int main(int argc, char** argv) {
   if (argc < 4) {
     fprintf(stderr, "usage: host_driver input.bin <kernel list|-> <burden list|->\n");
@@ -163,7 +67,6 @@ int main(int argc, char** argv) {
     mm.setBinaryOutcome();
   else
     mm.setQuantitativeOutcome();
-  GpuBroker::instance().setNullFitter(null_fitter);
   const auto& models = mm.getModel();
   std::vector<TextSink> outs(models.size());
   SiteInfo site;

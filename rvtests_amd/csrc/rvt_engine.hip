@@ -1411,6 +1411,106 @@ int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms
   return RVT_OK;
 }
 
+// ---- unrelated null models on the device -----------------------------------------------------------------------
+int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const double* y, double* beta_out,
+                 double* sigma2_out) {
+  if (!c || !X || !y || N < 1 || d < 1 || d > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad null model");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const bool binary = trait == RVT_TRAIT_BINARY;
+  double *d_xy = nullptr, *d_part = nullptr, *d_beta = nullptr, *d_a = nullptr, *d_b = nullptr, *d_zero = nullptr;
+  struct Guard {
+    double **a, **b, **c2, **d2, **e, **f;
+    ~Guard() {
+      for (double** p : {a, b, c2, d2, e, f})
+        if (*p) hipFree(*p);
+    }
+  } guard{&d_xy, &d_part, &d_beta, &d_a, &d_b, &d_zero};
+  const int rec = lmm_rec_len(d);
+  HIP_TRY(c, hipMalloc((void**)&d_xy, sizeof(double) * (size_t)N * (d + 1)));  // X | y
+  HIP_TRY(c, hipMalloc((void**)&d_part, sizeof(double) * (size_t)kLmmBlocks * rec));
+  HIP_TRY(c, hipMalloc((void**)&d_beta, sizeof(double) * RVT_MAX_COV));
+  HIP_TRY(c, hipMalloc((void**)&d_a, sizeof(double) * (size_t)N));
+  HIP_TRY(c, hipMalloc((void**)&d_b, sizeof(double) * (size_t)N));
+  HIP_TRY(c, hipMalloc((void**)&d_zero, sizeof(double) * (size_t)N));
+  HIP_TRY(c, hipMemcpyAsync(d_xy, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(d_xy + (size_t)N * d, y, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(d_zero, 0, sizeof(double) * (size_t)N, st));
+  std::vector<double> part((size_t)kLmmBlocks * rec), sums(rec), beta(RVT_MAX_COV, 0.0);
+  auto reduce = [&](int n_rec) {
+    for (int q = 0; q < n_rec; ++q) {
+      double s = 0.0;
+      for (int b = 0; b < kLmmBlocks; ++b) s += part[(size_t)b * n_rec + q];
+      sums[q] = s;
+    }
+  };
+  std::vector<double> res(N), v(N);
+  double sigma2 = 1.0;
+  if (!binary) {
+    // X'X, X'y with the weighted-sums kernel at unit weights (lambda = 0, delta = 1)
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xy, d_zero,
+                       (long long)N, d, 1.0, 0, d_part);
+    HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    reduce(rec);
+    double Ai[RVT_MAX_COV * RVT_MAX_COV];
+    if (!invert_spd(sums.data(), d, Ai)) return fail(c, RVT_E_INVALID, "X'X is singular");
+    for (int a = 0; a < d; ++a) {
+      double t = 0.0;
+      for (int k = 0; k < d; ++k) t += Ai[a * d + k] * sums[d * d + k];
+      beta[a] = t;
+    }
+    HIP_TRY(c, hipMemcpyAsync(d_beta, beta.data(), sizeof(double) * RVT_MAX_COV, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(linear_residual_kernel, dim3(kLmmBlocks), dim3(256), 0, st, d_xy, d_xy + (size_t)N * d, d_beta,
+                       (long long)N, (long long)N, d, d_a, d_part);
+    HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * kLmmBlocks, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(res.data(), d_a, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    double rss = 0.0;
+    for (int b = 0; b < kLmmBlocks; ++b) rss += part[b];
+    sigma2 = rss / (double)N;
+    std::fill(v.begin(), v.end(), sigma2);
+  } else {
+    int rounds = 0;
+    double lastDev = -99999, curDev = -9999;
+    const int nrrounds = 100;
+    while (rounds < nrrounds) {
+      HIP_TRY(c, hipMemcpyAsync(d_beta, beta.data(), sizeof(double) * RVT_MAX_COV, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(logistic_round_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xy,
+                         d_xy + (size_t)N * d, d_beta, (long long)N, (long long)N, d, d_a, d_b, d_part);
+      HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipStreamSynchronize(st));
+      reduce(rec);
+      double Di[RVT_MAX_COV * RVT_MAX_COV];
+      if (!invert_spd(sums.data(), d, Di)) return fail(c, RVT_E_INVALID, "X'VX is singular");
+      for (int a = 0; a < d; ++a) {
+        double t = 0.0;
+        for (int k = 0; k < d; ++k) t += Di[a * d + k] * sums[d * d + k];
+        beta[a] += t;
+      }
+      curDev = -2.0 * sums[d * d + d];  // GetDeviance() on the stored p (LogisticRegression.cpp:75-94)
+      if (rounds > 1 && std::fabs(curDev - lastDev) < 1e-3) {
+        rounds = 0;
+        break;
+      }
+      if (std::fpclassify(curDev) != FP_NORMAL) return fail(c, RVT_E_INVALID, "logistic deviance is not normal");
+      lastDev = curDev;
+      ++rounds;
+    }
+    if (rounds == nrrounds) return fail(c, RVT_E_INVALID, "logistic model did not converge in 100 rounds");
+    std::vector<double> p(N);
+    HIP_TRY(c, hipMemcpy(p.data(), d_a, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(v.data(), d_b, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i) res[i] = y[i] - p[i];
+  }
+  if (beta_out)
+    for (int a = 0; a < d; ++a) beta_out[a] = beta[a];
+  if (sigma2_out) *sigma2_out = sigma2;
+  return rvt_set_null(c, trait, N, d, X, res.data(), v.data(), sigma2);
+}
+
 // ---- SKAT permutations (exact replay of the reference's rand() stream) ------------------------------------------
 namespace {
 void mat31_mul(const uint32_t* A, const uint32_t* B, uint32_t* C) {  // C = A B over Z/2^32

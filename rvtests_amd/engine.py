@@ -130,6 +130,8 @@ def load_library():
     L.rvt_debug_suffstat.restype = C.c_int
     L.rvt_debug_suffstat.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]
+    L.rvt_fit_null.restype = C.c_int
+    L.rvt_fit_null.argtypes = [vp, C.c_int, C.c_int64, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     L.rvt_rand_seed.restype = C.c_int
     L.rvt_rand_seed.argtypes = [vp, C.c_uint]
     L.rvt_set_kinship.restype = C.c_int
@@ -198,6 +200,18 @@ class Engine:
         N, d = X.shape
         self._check(self.L.rvt_set_null(self.ctx, int(trait), N, d, _dp(X), _dp(res), _dp(v), float(sigma2)))
         self.N, self.d = N, d
+
+    def fit_null(self, trait, X, y):
+        """Fit the unrelated null model on the device and install it; returns (beta, sigma2)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        N, d = X.shape
+        beta = np.zeros(d)
+        s2 = C.c_double(0.0)
+        self._check(self.L.rvt_fit_null(self.ctx, int(trait), N, d, _dp(X), _dp(y), _dp(beta),
+                                        C.cast(C.byref(s2), c_double_p)))
+        self.N, self.d = N, d
+        return beta, s2.value
 
     def padded_ld(self, N=None):
         return int(self.L.rvt_padded_ld(int(self.N if N is None else N)))
