@@ -235,7 +235,10 @@ int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
 int rvt_fit_fam_null(rvt_ctx* ctx, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
 int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
                        rvt_gene_result* out);
-/* device block for genotype data when no rvt_set_null was called (family-only analyses): N from rvt_set_kinship */
+/* MetaCov with kinship, quantitative trait (MetaCovFamQtl, src/Model.cpp:437-504 over FastLMM::TransformCentered /
+ * GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same contract as rvt_cov_block, with the null model
+ * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  The binary family variant is not provided. */
+int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
 
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */

@@ -129,6 +129,12 @@ int orc_fastlmm_null(const double* X, const double* y, int64_t N, int d, const d
 int orc_famskat(const double* G, int64_t N, int M, const double* X, const double* y, int d, const double* U,
                 const double* S, const orc_fam_null* nul, int use_float, orc_kernel_result* out);
 
+/* MetaCovTest with kinship, quantitative trait (MetaCovFamQtl, src/Model.cpp:437-504 over FastLMM::TransformCentered /
+   GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same outputs as orc_metacov. */
+int orc_metacov_fam(const double* G, int64_t N, int V, const int* chrom, const int* pos, const double* X, int d,
+                    const double* U, const double* S, const orc_fam_null* nul, int window, int use_float, int* kept,
+                    double* cov, int* row_end, double* xz, double* zz);
+
 /* ---- MetaCovTest for unrelated samples (src/Model.cpp:844-1004; MetaCovUnrelatedQtl :506-593,
         MetaCovUnrelatedBinary :694-778; window rule src/Model.h:3956-3990).
         G: N x V imputed genotypes (one variant per column, file order); chrom[V] (any integer id), pos[V];

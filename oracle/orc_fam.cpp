@@ -390,4 +390,88 @@ int orc_famskat(const double* Gp, int64_t N, int M, const double* Xp, const doub
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MetaCovFamQtl (src/Model.cpp:437-504): g <- U'(g - mean(g)) (FastLMM::TransformCentered, FastLMM.cpp:611-625);
+// covXX = sum g1 g2 / (lambda + delta) / sigma2 (:535-549); covXZ = g' diag(1/(lambda+delta)) ux / sigma2 (:568-590);
+// covZZ = ux' diag(1/(lambda+delta)) ux / sigma2 (:510-516), lambda = |S|; rows and value as in orc_metacov.
+// ---------------------------------------------------------------------------------------------
+int orc_metacov_fam(const double* Gp, int64_t N, int V, const int* chrom, const int* pos, const double* Xp, int d,
+                    const double* Up, const double* S, const orc_fam_null* nul, int window, int use_float, int* kept,
+                    double* cov, int* row_end, double* xz, double* zz) {
+  F32 F{use_float != 0};
+  Mat G = wrapd(Gp, N, V), U = wrapd(Up, N, N), X = wrapd(Xp, N, d);
+  const double sigma2 = nul->sigma2, delta = nul->delta;
+  std::vector<double> w(N);  // 1 / (lambda + delta)
+  for (int64_t i = 0; i < N; ++i) w[i] = F(1.0 / F(std::fabs(F(S[i])) + delta));
+  Mat ux(N, d);
+  for (int64_t k = 0; k < N; ++k)
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(U(i, k)) * F(X(i, a))));
+      ux(k, a) = s;
+    }
+  Mat ZZ(d, d), I(d, d), ZZinv;
+  for (int a = 0; a < d; ++a) {
+    I(a, a) = 1.0;
+    for (int b = 0; b < d; ++b) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(ux(i, a) * w[i]) * ux(i, b)));
+      ZZ(a, b) = F(s / sigma2);
+    }
+  }
+  if (!orc::sym_solve(ZZ, I, &ZZinv)) return -1;
+  for (int a = 0; a < d; ++a)
+    for (int b = 0; b < d; ++b) zz[a * d + b] = ZZ(a, b);
+  std::vector<std::vector<double>> gt(V);
+  for (int j = 0; j < V; ++j) {
+    bool mono = true;
+    for (int64_t i = 1; i < N; ++i)
+      if (G(i, j) != G(0, j)) {
+        mono = false;
+        break;
+      }
+    kept[j] = mono ? 0 : 1;
+    row_end[j] = -1;
+    for (int k = 0; k < d; ++k) xz[(size_t)j * d + k] = NAN;
+    if (mono) continue;
+    std::vector<double> g(N);
+    double sx = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      g[i] = F(G(i, j));
+      sx = F(sx + g[i]);
+    }
+    const double avg = F(sx / (double)N);
+    for (int64_t i = 0; i < N; ++i) g[i] = F(g[i] - avg);
+    gt[j].assign(N, 0.0);
+    for (int64_t k = 0; k < N; ++k) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(U(i, k)) * g[i]));
+      gt[j][k] = s;
+    }
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(gt[j][i] * w[i]) * ux(i, a)));
+      xz[(size_t)j * d + a] = F(s / sigma2);
+    }
+  }
+  for (size_t i = 0; i < (size_t)V * V; ++i) cov[i] = NAN;
+  for (int h = 0; h < V; ++h) {
+    if (!kept[h]) continue;
+    for (int j = h; j < V; ++j) {
+      if (chrom[j] != chrom[h] || std::abs(pos[j] - pos[h]) > window) break;
+      if (!kept[j]) continue;
+      double xx = 0;
+      for (int64_t i = 0; i < N; ++i) xx = F(xx + F(F(gt[h][i] * w[i]) * gt[j][i]));
+      xx = F(xx / sigma2);
+      double quad = 0;
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b)
+          quad = F(quad + F(F(xz[(size_t)h * d + a] * F(ZZinv(a, b))) * xz[(size_t)j * d + b]));
+      cov[h + (size_t)j * V] = F(xx - quad);
+      row_end[h] = j;
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -180,6 +180,48 @@ __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const doub
   v[i] = V;
 }
 
+// null set of the family MetaCov (MetaCovFamQtl): weights D = 1/((|S| + delta) sigma2), columns [U'X | u1]
+__global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
+                                         const double* __restrict__ u1, long long N, long long ld, int d,
+                                         double sigma2, double delta, double* __restrict__ Xin,
+                                         double* __restrict__ v) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < d; ++k) Xin[i + k * ld] = uxy[i + k * N];
+  Xin[i + (long long)d * ld] = u1[i];
+  v[i] = 1.0 / ((fabs(S[i]) + delta) * sigma2);
+}
+
+// raw column sum + monomorphic flag of the columns of one block (MetaCov family mode)
+__global__ __launch_bounds__(256) void raw_colstat_kernel(const double* __restrict__ G, long long N, long long ld,
+                                                          double* __restrict__ colsum, int* __restrict__ poly) {
+  __shared__ double rs[256], rmn[256], rmx[256];
+  const double* col = G + (long long)blockIdx.x * ld;
+  double s = 0.0, mn = INFINITY, mx = -INFINITY;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const double g = col[i];
+    s += g;
+    mn = fmin(mn, g);
+    mx = fmax(mx, g);
+  }
+  rs[threadIdx.x] = s;
+  rmn[threadIdx.x] = mn;
+  rmx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      rs[threadIdx.x] += rs[threadIdx.x + off];
+      rmn[threadIdx.x] = fmin(rmn[threadIdx.x], rmn[threadIdx.x + off]);
+      rmx[threadIdx.x] = fmax(rmx[threadIdx.x], rmx[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    colsum[blockIdx.x] = rs[0];
+    poly[blockIdx.x] = (rmn[0] != rmx[0]) ? 1 : 0;
+  }
+}
+
 // flip / polymorphic decision per genotype column (DataConsolidator.cpp:46-69,94-116): bit 0 = flip, bit 1 = keep
 __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* __restrict__ cols, long long N,
                                                           int* __restrict__ flags) {

@@ -373,7 +373,13 @@ int MetaCovTest::fit(GeneData* dc) {
     lastError = "Sample size changed at [ " + dc->site->get("CHROM") + ":" + dc->site->get("POS") + " ]";
     return -1;
   }
-  ctx = GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
+  useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaCovFamQtl instead of MetaCovUnrelatedQtl
+  if (useFamilyModel && isBinaryOutcome()) {
+    lastError = "MetaCov with kinship for binary traits (MetaCovFamBinary) is not provided by the GPU backend";
+    return -1;
+  }
+  ctx = useFamilyModel ? GpuBroker::instance().contextWithFamNull(*dc, &lastError)
+                       : GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
   if (!ctx) return -1;
   if (nSample < 0) {
     nSample = dc->N;
@@ -409,7 +415,8 @@ int MetaCovTest::flush(bool final) {
   const int d = nCovariate;
   std::vector<double> cov((size_t)V * V), xz((size_t)V * d), zz((size_t)d * d);
   std::vector<int> poly(V);
-  if (rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
+  if (useFamilyModel ? rvt_cov_block_fam(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())
+                     : rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
     lastError = rvt_last_error(ctx);
     return -1;
   }

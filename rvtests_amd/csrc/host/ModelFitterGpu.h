@@ -238,6 +238,7 @@ class MetaCovTest : public ModelFitter {
   int capacity = RVT_MAX_VARIANTS;  // columns of the device ring
   bool outputGwama = false;
   bool fitOK = false;
+  bool useFamilyModel = false;
   int64_t nSample = -1;
   int nCovariate = 0;
   rvt_ctx* ctx = nullptr;

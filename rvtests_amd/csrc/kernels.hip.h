@@ -738,7 +738,12 @@ struct CovConsts {
   double zsum[RVT_MAX_COV];                 // 1'Z (quantitative centring)
   double inv_sigma2;                        // 1/sigma2 (quantitative), 1 (binary)
   double inv_n;                             // 1/N
+  double c11;                               // family mode: u1' D u1
   int d, binary;
+  int fam;  // family mode (MetaCovFamQtl): R comes from the ROTATED block with D = 1/((|S|+delta) sigma2) and null
+            // columns [U'X | u1]; genotypes are centred BEFORE the rotation, i.e. g~ - mean(g) u1:
+            //   covXX = S_hj - m_h t1_j - m_j t1_h + m_h m_j c11,  covXZ_h = T_h - m_h (u1'D U'X),  t1 = G~'D u1
+            // (zsum then holds u1'D U'X and `colsum` the RAW column sums, d counts U'X only)
 };
 
 // one workgroup: column sums, polymorphic flags, T = G'DX, covXZ   (xz: V x d row-major; colsum: V)
@@ -755,13 +760,20 @@ __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __rest
       mn = fmin(mn, c[gd.Mp + h]);
       mx = fmax(mx, c[2 * gd.Mp + h]);
     }
-    colsum[h] = s;
-    poly[h] = (mn == mx) ? 0 : 1;
+    if (!cc.fam) {  // family mode: raw column sums and flags were computed before the rotation
+      colsum[h] = s;
+      poly[h] = (mn == mx) ? 0 : 1;
+    } else {
+      s = colsum[h];
+    }
     for (int k = 0; k < d; ++k) {
       double t = 0.0;
       for (int p = 0; p < gd.n_wparts; ++p)
         t += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + V + k];
-      xz[(long long)h * d + k] = cc.binary ? t : (t - s * cc.inv_n * cc.zsum[k]) * cc.inv_sigma2;
+      if (cc.fam)
+        xz[(long long)h * d + k] = t - s * cc.inv_n * cc.zsum[k];
+      else
+        xz[(long long)h * d + k] = cc.binary ? t : (t - s * cc.inv_n * cc.zsum[k]) * cc.inv_sigma2;
     }
   }
 }
@@ -780,10 +792,26 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restric
   }
   __syncthreads();
   const double sh = colsum[h];
+  __shared__ double t1h;
+  if (cc.fam && threadIdx.x == 0) {
+    double t = 0.0;
+    for (int p = 0; p < gd.n_wparts; ++p) t += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + V + d];
+    t1h = t;
+  }
+  __syncthreads();
   for (int j = h + threadIdx.x; j < V; j += blockDim.x) {
     double sxx = 0.0;
     for (int p = 0; p < gd.n_wparts; ++p) sxx += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + j];
-    const double xx = cc.binary ? sxx : (sxx - sh * colsum[j] * cc.inv_n) * cc.inv_sigma2;
+    double xx;
+    if (cc.fam) {
+      double t1j = 0.0;
+      for (int p = 0; p < gd.n_wparts; ++p)
+        t1j += gd.parts[(long long)p * gd.Mp * gd.Cp + (long long)j * gd.Cp + V + d];
+      const double mh = sh * cc.inv_n, mj = colsum[j] * cc.inv_n;
+      xx = sxx - mh * t1j - mj * t1h + mh * mj * cc.c11;
+    } else {
+      xx = cc.binary ? sxx : (sxx - sh * colsum[j] * cc.inv_n) * cc.inv_sigma2;
+    }
     double quad = 0.0;
     for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
     cov[h + (long long)j * V] = xx - quad;

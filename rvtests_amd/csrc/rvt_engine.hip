@@ -76,6 +76,12 @@ struct rvt_ctx {
   NullConsts fam_nc;
   NullConsts* d_fam_nc = nullptr;
   double *d_fX = nullptr, *d_frr = nullptr, *d_fv = nullptr, *d_fzeros = nullptr, *d_fbeta = nullptr;
+  // family MetaCov null set + constants
+  NullConsts famcov_nc;
+  NullConsts* d_famcov_nc = nullptr;
+  double *d_cX = nullptr, *d_cv = nullptr;
+  double famcov_c11 = 0.0, famcov_c1x[RVT_MAX_COV], famcov_zz[RVT_MAX_COV * RVT_MAX_COV],
+         famcov_zzinv[RVT_MAX_COV * RVT_MAX_COV];
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
   double* d_Gt = nullptr;  // ... rotated by U'
   size_t fam_cols_cap = 0;
@@ -427,8 +433,9 @@ void rvt_destroy(rvt_ctx* c) {
   }
   if (c->d_nc) hipFree(c->d_nc);
   for (double* p : {c->d_U, c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
-                    c->d_fbeta, c->d_Gp, c->d_Gt})
+                    c->d_fbeta, c->d_Gp, c->d_Gt, c->d_cX, c->d_cv})
     if (p) hipFree(p);
+  if (c->d_famcov_nc) hipFree(c->d_famcov_nc);
   for (void* p : {(void*)c->d_perm_idx, (void*)c->d_perm_states, (void*)c->d_perm_R, (void*)c->d_perm_C,
                   (void*)c->d_perm_Q, (void*)c->d_perm_cur})
     if (p) hipFree(p);
@@ -559,6 +566,9 @@ struct CovOut {  // rvt_cov_block: host destinations
   double* xz = nullptr;    // V x d
   double* zz = nullptr;    // d x d
   int* poly = nullptr;     // V
+  bool fam = false;        // family mode: the block is already rotated; raw column sums / flags are supplied
+  const double* d_raw_colsum = nullptr;
+  const int* d_raw_poly = nullptr;
 };
 
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
@@ -741,7 +751,21 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     cc.binary = nc.binary;
     cc.inv_n = 1.0 / (double)N;
     std::vector<double> zz((size_t)d * d, 0.0);
-    if (nc.binary) {  // covZZ = Z'WZ, covZZInv its inverse (MetaCovUnrelatedBinary::calculateZZ, Model.cpp:748-765)
+    if (cov->fam) {  // MetaCovFamQtl: constants prepared by rvt_fit_fam_null
+      const int du = d - 1;  // U'X columns (the null set carries u1 as an extra column)
+      cc.fam = 1;
+      cc.d = du;
+      cc.inv_sigma2 = 1.0;
+      cc.c11 = c->famcov_c11;
+      zz.assign((size_t)du * du, 0.0);
+      for (int a = 0; a < du; ++a) {
+        cc.zsum[a] = c->famcov_c1x[a];
+        for (int b = 0; b < du; ++b) {
+          zz[a * du + b] = c->famcov_zz[a * du + b];
+          cc.zzinv[a * du + b] = c->famcov_zzinv[a * du + b];
+        }
+      }
+    } else if (nc.binary) {  // covZZ = Z'WZ, covZZInv its inverse (MetaCovUnrelatedBinary::calculateZZ, Model.cpp:748-765)
       cc.inv_sigma2 = 1.0;
       for (int a = 0; a < d * d; ++a) {
         zz[a] = nc.C[a];
@@ -770,14 +794,19 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     double* d_cs = reinterpret_cast<double*>(base + off_cov_cs);
     int* d_poly = reinterpret_cast<int*>(base + off_cov_poly);
     double* d_cov = reinterpret_cast<double*>(base + off_cov);
+    if (cov->fam) {
+      HIP_TRY(c, hipMemcpyAsync(d_cs, cov->d_raw_colsum, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(d_poly, cov->d_raw_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToDevice, st));
+    }
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(1), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_poly);
     hipLaunchKernelGGL(cov_rows_kernel, dim3(V), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_cov);
     HIP_TRY(c, hipGetLastError());
+    const int dz = cc.d;
     HIP_TRY(c, hipMemcpyAsync(cov->cov, d_cov, sizeof(double) * (size_t)V * V, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(cov->xz, d_xz, sizeof(double) * (size_t)V * d, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->xz, d_xz, sizeof(double) * (size_t)V * dz, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(cov->poly, d_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (cov->zz) std::memcpy(cov->zz, zz.data(), sizeof(double) * (size_t)d * d);
+    if (cov->zz) std::memcpy(cov->zz, zz.data(), sizeof(double) * (size_t)dz * dz);
     return RVT_OK;
   }
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
@@ -964,6 +993,22 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
   }
   return RVT_OK;
 }
+
+namespace {
+int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld) {
+  if (T <= c->fam_cols_cap) return RVT_OK;
+  if (c->d_Gp) hipFree(c->d_Gp);
+  if (c->d_Gt) hipFree(c->d_Gt);
+  c->d_Gp = c->d_Gt = nullptr;
+  c->fam_cols_cap = 0;
+  const size_t want = T + T / 4;
+  HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
+  HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
+  c->fam_cols_cap = want;
+  return RVT_OK;
+}
+
+}  // namespace
 
 // ---- related samples: kinship, FastLMM null model, FamSKAT ----------------------------------------------------
 #define BLAS_TRY(ctx, call)                                                                  \
@@ -1250,9 +1295,135 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
                      c->d_u1, (long long)N, (long long)ld, d, sigma2, delta, c->d_fbeta, c->d_fX, c->d_frr, c->d_fv);
   if (!c->d_fam_nc) HIP_TRY(c, hipMalloc((void**)&c->d_fam_nc, sizeof(NullConsts)));
   HIP_TRY(c, hipMemcpyAsync(c->d_fam_nc, &fn, sizeof(NullConsts), hipMemcpyHostToDevice, st));
+  // ---- the family MetaCov's constants and null set (MetaCovFamQtl over FastLMM::GetCov*, FastLMM.cpp:510-625) ----
+  {
+    // [U'X | u1] with weights 1/|lambda + delta|: A = ux'W ux, b = ux'W u1, yy = u1'W u1
+    double* d_xu = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_xu, sizeof(double) * (size_t)N * dx));
+    HIP_TRY(c, hipMemcpyAsync(d_xu, c->d_uxy, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_xu + (size_t)N * d, c->d_u1, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+    double* d_abs2 = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_abs2, sizeof(double) * N));
+    HIP_TRY(c, hipMemcpyAsync(d_abs2, absS.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xu, d_abs2,
+                       (long long)N, d, delta, 1, c->d_lmm_part);
+    HIP_TRY(c, hipMemcpyAsync(part.data(), c->d_lmm_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    hipFree(d_xu);
+    hipFree(d_abs2);
+    for (int q = 0; q < rec; ++q) {
+      double s2 = 0.0;
+      for (int b = 0; b < kLmmBlocks; ++b) s2 += part[(size_t)b * rec + q];
+      sums[q] = s2;
+    }
+    for (int a = 0; a < d * d; ++a) c->famcov_zz[a] = sums[a] / sigma2;
+    for (int a = 0; a < d; ++a) c->famcov_c1x[a] = sums[d * d + a] / sigma2;
+    c->famcov_c11 = sums[d * d + d] / sigma2;
+    if (!invert_spd(c->famcov_zz, d, c->famcov_zzinv)) return fail(c, RVT_E_INVALID, "covZZ is singular");
+    if (c->d_cX) hipFree(c->d_cX);
+    if (c->d_cv) hipFree(c->d_cv);
+    c->d_cX = c->d_cv = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&c->d_cX, vb * dx));
+    HIP_TRY(c, hipMalloc((void**)&c->d_cv, vb));
+    HIP_TRY(c, hipMemsetAsync(c->d_cX, 0, vb * dx, st));
+    HIP_TRY(c, hipMemsetAsync(c->d_cv, 0, vb, st));
+    hipLaunchKernelGGL(famcov_build_null_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_uxy,
+                       c->d_S, c->d_u1, (long long)N, (long long)ld, d, sigma2, delta, c->d_cX, c->d_cv);
+    NullConsts& cn = c->famcov_nc;
+    std::memset(&cn, 0, sizeof(cn));
+    cn.N = N;
+    cn.ld = ld;
+    cn.d = dx;
+    cn.binary = 1;
+    cn.sigma2 = 1.0;
+    for (int a = 0; a < dx; ++a) cn.C[a * dx + a] = cn.Cinv[a * dx + a] = 1.0;  // unused by the covariance kernels
+    if (!c->d_famcov_nc) HIP_TRY(c, hipMalloc((void**)&c->d_famcov_nc, sizeof(NullConsts)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_famcov_nc, &cn, sizeof(NullConsts), hipMemcpyHostToDevice, st));
+  }
   HIP_TRY(c, hipStreamSynchronize(st));
   c->have_fam = true;
   return RVT_OK;
+}
+
+// MetaCov with kinship (quantitative): rotate the block, run it through the sufficient statistics with the family
+// null set, finish with the covariance kernels in family mode.
+int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t N = c->fam_nc.N, ld = c->fam_nc.ld;
+  rc = ensure_fam_cols(c, (size_t)V, ld);
+  if (rc) return rc;
+  double* d_cs = nullptr;
+  int* d_poly = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)V));
+  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)V));
+  struct Guard {
+    void *a, *b;
+    ~Guard() {
+      hipFree(a);
+      hipFree(b);
+    }
+  } guard{(void*)d_cs, (void*)d_poly};
+  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)V), dim3(256), 0, st, dG, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * V, st));
+  {
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, V,
+                              (rocblas_int)N, &one, c->d_U, (rocblas_int)N, dG, (rocblas_int)ld, &zero, c->d_Gt,
+                              (rocblas_int)ld));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  std::vector<double> af(V, 0.01);
+  rvt_gene_result r;
+  CovOut co;
+  co.cov = cov;
+  co.xz = xz;
+  co.zz = zz;
+  co.poly = polymorphic;
+  co.fam = true;
+  co.d_raw_colsum = d_cs;
+  co.d_raw_poly = d_poly;
+  const double* p = c->d_Gt;
+  {
+    // the batch code reads the null set from the context: install the family-covariance set for this call
+    NullConsts keep_nc = c->nc;
+    NullConsts* keep_dnc = c->d_nc;
+    double *kX = c->d_X, *kres = c->d_res, *krr = c->d_rr, *kv = c->d_v, *kz = c->d_zeros;
+    const bool khave = c->have_null;
+    const int64_t kld = c->null_ld;
+    c->nc = c->famcov_nc;
+    c->d_nc = c->d_famcov_nc;
+    c->d_X = c->d_cX;
+    c->d_res = c->d_fzeros;
+    c->d_rr = c->d_fzeros;
+    c->d_v = c->d_cv;
+    c->d_zeros = c->d_fzeros;
+    c->have_null = true;
+    c->null_ld = ld;
+    rc = run_batch(c, 1, &p, &V, af.data(), nullptr, 0u, nullptr, &r, nullptr, &co);
+    c->nc = keep_nc;
+    c->d_nc = keep_dnc;
+    c->d_X = kX;
+    c->d_res = kres;
+    c->d_rr = krr;
+    c->d_v = kv;
+    c->d_zeros = kz;
+    c->have_null = khave;
+    c->null_ld = kld;
+  }
+  for (auto& sl : c->slots)
+    if (sl.pending_out == &r) {
+      sl.pending_out = nullptr;
+      sl.pending_n = 0;
+    }
+  return rc;
 }
 
 int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const int64_t* ids,
@@ -1547,19 +1718,6 @@ void mat31_apply(const uint32_t* J, const uint32_t* x, uint32_t* y) {
   std::memcpy(y, t, sizeof(t));
 }
 
-int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld) {
-  if (T <= c->fam_cols_cap) return RVT_OK;
-  if (c->d_Gp) hipFree(c->d_Gp);
-  if (c->d_Gt) hipFree(c->d_Gt);
-  c->d_Gp = c->d_Gt = nullptr;
-  c->fam_cols_cap = 0;
-  const size_t want = T + T / 4;
-  HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
-  HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
-  c->fam_cols_cap = want;
-  return RVT_OK;
-}
-
 // The permutation test of one gene whose analytic SKAT result (obs = skat_Q) and weights are already on the device.
 //   dG: the gene's block (unflipped), g0: its descriptor of the batch that just finished (weights in its scratch)
 int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rvt_params& prm, rvt_gene_result* r) {
@@ -1753,9 +1911,10 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
 
 int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const double* G) {
   if (!c || !dG || !G || col0 < 0 || ncols < 1) return fail(c, RVT_E_INVALID, "bad upload");
-  if (!c->have_null) return fail(c, RVT_E_STATE, "set the null model first");
+  if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
-  const size_t N = (size_t)c->nc.N, ld = (size_t)c->null_ld;
+  const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
                          hipMemcpyHostToDevice));
   return RVT_OK;
@@ -1765,7 +1924,7 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   if (!c || !dG || dst_col < 0 || src_col < dst_col || ncols < 0) return fail(c, RVT_E_INVALID, "bad move");
   if (ncols == 0 || dst_col == src_col) return RVT_OK;
   hipSetDevice(c->device);
-  const size_t ld = (size_t)c->null_ld;
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
   for (int k = 0; k < ncols; ++k)
     HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,

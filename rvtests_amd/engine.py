@@ -141,6 +141,8 @@ def load_library():
     L.rvt_run_fam_blocks.restype = C.c_int
     L.rvt_run_fam_blocks.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(C.c_int64),
                                      C.POINTER(GeneResult)]
+    L.rvt_cov_block_fam.restype = C.c_int
+    L.rvt_cov_block_fam.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_cov_block.restype = C.c_int
     L.rvt_cov_block.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_upload_columns.restype = C.c_int
@@ -348,6 +350,16 @@ class Engine:
         poly = np.zeros(V, dtype=np.int32)
         self._check(self.L.rvt_cov_block(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
                                          poly.ctypes.data_as(c_int_p)))
+        return cov, xz, zz, poly
+
+    def cov_block_fam(self, ptr, V, d):
+        """Family-mode covariance band (after set_kinship + fit_fam_null); d = columns of X."""
+        cov = np.full((V, V), np.nan, order="F")
+        xz = np.zeros((V, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(V, dtype=np.int32)
+        self._check(self.L.rvt_cov_block_fam(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
+                                             poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
 
     def upload_columns(self, ptr, col0, G):

@@ -342,3 +342,24 @@ def skat_permute(G, af, res, obs, n_perm, alpha, b1=1.0, b2=25.0, use_float=Fals
     rc = lib().orc_skat_permute(_dp(G), _dp(af), C.c_int64(N), M, _dp(res), float(b1), float(b2), float(obs),
                                 int(n_perm), float(alpha), int(use_float), C.byref(out))
     return rc, out
+
+
+def metacov_fam(G, chrom, pos, X, U, S, nul, window, use_float=False):
+    G = F(G)
+    X = F(X)
+    U = F(U)
+    N, V = G.shape
+    d = X.shape[1]
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    chrom = np.ascontiguousarray(chrom, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    kept = np.zeros(V, dtype=np.int32)
+    row_end = np.zeros(V, dtype=np.int32)
+    cov = np.zeros((V, V), order="F")
+    xz = np.zeros((V, d))
+    zz = np.zeros((d, d))
+    L = lib()
+    L.orc_metacov_fam.restype = C.c_int
+    rc = L.orc_metacov_fam(_dp(G), C.c_int64(N), V, _ip(chrom), _ip(pos), _dp(X), d, _dp(U), _dp(S), C.byref(nul),
+                           int(window), int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz), _dp(zz))
+    return rc, kept, cov, row_end, xz, zz

@@ -87,3 +87,29 @@ def test_famskat_matches_numpy_literal():
     assert np.allclose(got, ev, rtol=1e-8, atol=1e-10 * ev[0])
     p = orc.davies(ev, Q)
     assert abs(out.pvalue - p) <= 1e-6 * p + 1e-12
+
+
+def test_metacov_fam_matches_numpy():
+    N, K, U, S, X, y = make_family_case(30, 2, 17)
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    _, G, af = synth.make_gene(N, 15, seed=8, missing=0.02, common=True, mono=True)
+    rng = np.random.default_rng(2)
+    pos = np.cumsum(rng.integers(1, 300, 15)).astype(np.int32)
+    chrom = np.ones(15, dtype=np.int32)
+    rc, kept, cov, row_end, xz, zz = orc.metacov_fam(G, chrom, pos, X, U, S, nul, 900)
+    assert rc == 0
+    w = 1.0 / (np.abs(S) + nul.delta)
+    Gt = U.T @ (G - G.mean(0))
+    ux = U.T @ X
+    XX = Gt.T @ (Gt * w[:, None]) / nul.sigma2
+    XZ = Gt.T @ (ux * w[:, None]) / nul.sigma2
+    ZZ = ux.T @ (ux * w[:, None]) / nul.sigma2
+    val = XX - XZ @ np.linalg.inv(ZZ) @ XZ.T
+    k2 = np.array([len(np.unique(G[:, j])) > 1 for j in range(15)])
+    assert (kept.astype(bool) == k2).all()
+    m = ~np.isnan(cov)
+    assert m.sum() > 15
+    assert np.abs(cov[m] - val[m]).max() < 1e-9 * np.abs(val[m]).max()
+    assert np.allclose(zz, ZZ, rtol=1e-9)
+    assert np.allclose(xz[k2], XZ[k2], rtol=1e-8, atol=1e-9 * np.abs(XZ).max())

@@ -65,3 +65,31 @@ def test_famskat_matches_oracle(eng, n_fam, d, Ms):
         assert abs(r.famskat_Q - o.Q) <= 1e-7 * o.Q
         assert r.skat_nlambda == o.n_lambda
         assert abs(r.famskat_p - o.pvalue) <= 2e-6 * abs(o.pvalue) + 1e-12
+
+
+@pytest.mark.parametrize("n_fam,d,V", [(40, 2, 25), (60, 3, 110)])
+def test_metacov_fam_matches_oracle(eng, n_fam, d, V):
+    """MetaCov with kinship (quantitative): rvt_cov_block_fam against the oracle's MetaCovFamQtl restatement."""
+    N, K, U, S, X, y = make_family_case(n_fam, d, 50 + d)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(d):
+        onul.beta[k] = nul.beta[k]
+    _, G, af = synth.make_gene(N, V, seed=600 + V, missing=0.02, common=True, mono=True)
+    rng = np.random.default_rng(5)
+    pos = np.cumsum(rng.integers(1, 300, V)).astype(np.int32)
+    chrom = np.ones(V, dtype=np.int32)
+    ptr = eng.upload_block(G)
+    cov, xz, zz, poly = eng.cov_block_fam(ptr, V, d)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov_fam(G, chrom, pos, X, U, S, onul, 2500)
+    assert rc == 0
+    assert (poly == kept).all()
+    m = ~np.isnan(ocov)
+    assert m.sum() > V
+    assert np.abs(cov[m] - ocov[m]).max() < 1e-8 * np.abs(ocov[m]).max()
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-8, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    assert np.allclose(zz, ozz, rtol=1e-9)

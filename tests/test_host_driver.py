@@ -260,3 +260,44 @@ def test_driver_skat_with_permutations(tmp_path):
         assert int(row[-3]) == p.num_x and int(row[-2]) == p.num_equal
         assert abs(float(row[-1]) - p.pvalue) <= 1e-5 * max(p.pvalue, 1e-30)
         assert row[-4] == "%g" % a.Q or abs(float(row[-4]) - a.Q) <= 2e-6 * a.Q
+
+
+@pytest.mark.gpu
+def test_driver_metacov_with_kinship(tmp_path):
+    """--meta cov with a kinship decomposition: MetaCovFamQtl through the adapter (rows and numbers vs the oracle)."""
+    _ensure_driver()
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(45, 2, 61)
+    _, G, af = synth.make_gene(N, 28, seed=12, missing=0.01, common=True, mono=True)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, [(G, af)])
+    kin = str(tmp_path / "kin.bin")
+    with open(kin, "wb") as f:
+        f.write(struct.pack("<q", N))
+        f.write(np.asfortranarray(U, dtype="<f4").tobytes(order="F"))
+        f.write(np.ascontiguousarray(S, dtype="<f4").tobytes())
+    V = G.shape[1]
+    pos = np.cumsum(np.random.default_rng(4).integers(1, 300, V)).astype(np.int32)
+    chrom = np.ones(V, dtype=np.int32)
+    sites = str(tmp_path / "sites.txt")
+    with open(sites, "w") as f:
+        for p_ in pos:
+            f.write("1 %d\n" % p_)
+    p = subprocess.run([DRIVER, path, "-", "-", "cov[windowSize=1000]", sites, kin], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.MetaCov.assoc"
+    rows = [ln.split("\t") for ln in lines[2:]]
+    rc, onul = orc.fastlmm_null(X, y, U, S)
+    rc, kept, cov, row_end, xz, zz = orc.metacov_fam(G, chrom, pos, X, U, S, onul, 1000)
+    heads = [h for h in range(V) if kept[h]]
+    assert len(rows) == len(heads)
+    scale = np.float32(1.0 / N)
+    for row, h in zip(rows, heads):
+        js = [j for j in range(h, row_end[h] + 1) if kept[j] and not np.isnan(cov[h, j])]
+        assert row[1] == str(pos[h]) and int(row[3]) == len(js)
+        got = np.array([float(t) for t in row[5].split(",")])
+        want = np.array([float(np.float32(cov[h, j]) * scale) for j in js])
+        # the null fit (delta) is pinned to the reference's Brent stopping accuracy only, see test_gpu_fam.py
+        assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
