@@ -76,6 +76,11 @@ const ModelParser& ModelParser::assign(const std::string& tag, bool* v, bool def
 // ---- GpuBroker ----------------------------------------------------------------------------------------------------
 GpuBroker& GpuBroker::instance() {
   static GpuBroker b;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    if (const char* e = getenv("RVT_ADAPTER_BATCH")) b.setBatchWindow(atoi(e));
+  }
   return b;
 }
 
@@ -101,6 +106,9 @@ void GpuBroker::registerTests(uint32_t mask, const rvt_params& p) {
 void GpuBroker::shutdown() {
   if (ctx) rvt_destroy(ctx);
   ctx = nullptr;
+  rows.clear();
+  pendingSerial.clear();
+  failedSerial.clear();
   haveNull = false;
   haveFamNull = false;
   kinU = nullptr;
@@ -176,29 +184,66 @@ rvt_ctx* GpuBroker::contextWithFamNull(const GeneData& gd, std::string* err) {
   return ctx;
 }
 
-const rvt_gene_result* GpuBroker::resultFor(const GeneData& gd, bool binary, std::string* err) {
-  if (gd.serial == curSerial) return curOk ? &cur : nullptr;
+int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
+  if (gd.serial == curSerial) return curOk ? 0 : -1;  // another model of the same gene already submitted it
+  if ((int)pendingSerial.size() >= window) flush();
   curSerial = gd.serial;
   curOk = false;
+  auto failed = [&]() {
+    failedSerial.push_back(gd.serial);
+    return -1;
+  };
   if (ensureContext(0)) {
     *err = "no MI355X device: the GPU models have no CPU fallback";
-    return nullptr;
+    return failed();
   }
-  if (!haveNull || gd.phenotypeUpdated || gd.covariateUpdated)
-    if (installNull(gd, binary, err)) return nullptr;
+  if (!haveNull || gd.phenotypeUpdated || gd.covariateUpdated) {
+    flush();  // pending genes belong to the previous null model
+    if (installNull(gd, binary, err)) return failed();
+  }
   if ((int)gd.markerFrequency.size() < gd.M) {
     *err = "marker frequencies missing";
-    return nullptr;
+    return failed();
   }
-  int rc = rvt_submit_gene(ctx, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params);
-  int n = 0;
-  if (!rc) rc = rvt_collect(ctx, &cur, 1, &n);
-  if (rc || n != 1) {
+  if (rvt_submit_gene(ctx, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params)) {
     *err = rvt_last_error(ctx);
-    return nullptr;
+    return failed();
   }
+  pendingSerial.push_back(gd.serial);
   curOk = true;
-  return &cur;
+  return 0;
+}
+
+void GpuBroker::enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab, int64_t serial) {
+  rows.push_back(Row{m, fp, siteTab, serial});
+}
+
+int GpuBroker::flush() {
+  std::map<int64_t, rvt_gene_result> got;
+  int rc = 0;
+  if (ctx && !pendingSerial.empty()) {
+    std::vector<rvt_gene_result> recs(pendingSerial.size());
+    int n = 0;
+    rc = rvt_collect(ctx, recs.data(), (int)recs.size(), &n);
+    if (!rc)
+      for (int i = 0; i < n; ++i) got[recs[i].gene_id] = recs[i];
+  }
+  for (const Row& r : rows) {
+    auto it = got.find(r.serial);
+    r.fp->write(r.siteTab + r.model->formatRow(it == got.end() ? nullptr : &it->second));
+  }
+  rows.clear();
+  pendingSerial.clear();
+  failedSerial.clear();
+  return rc;
+}
+
+int ModelFitter::deferredFit(GeneData* dc) {
+  curSerial = dc->serial;
+  return GpuBroker::instance().submit(*dc, isBinaryOutcome(), &lastError);
+}
+void ModelFitter::deferredOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  GpuBroker::instance().enqueue(this, fp, siteInfo.valueTab(), curSerial);
 }
 
 // ---- SkatTest ----------------------------------------------------------------------------------------------------------
@@ -207,14 +252,7 @@ SkatTest::SkatTest(int nPerm, double alpha, double beta1, double beta2) : usePer
   rvt_params p{beta1, beta2, 1.0, 25.0, nPerm, alpha};
   GpuBroker::instance().registerTests(RVT_TEST_SKAT, p);
 }
-int SkatTest::fit(GeneData* dc) {
-  fitOK = false;
-  res = GpuBroker::instance().resultFor(*dc, isBinaryOutcome(), &lastError);
-  if (!res || !res->skat_ok) return -1;  // genotype.cols == 0 after filtering -> NA row
-  if (usePermutation && !res->perm_ok) return -1;
-  fitOK = true;
-  return 0;
-}
+int SkatTest::fit(GeneData* dc) { return deferredFit(dc); }
 void SkatTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
   if (!usePermutation)
@@ -222,18 +260,18 @@ void SkatTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   else  // Permutation::writeHeader (src/Permutation.h:51-56,99-104)
     fp->write("Q\tPvalue\tNumPerm\tActualPerm\tStat\tNumGreater\tNumEqual\tPermPvalue\n");
 }
-void SkatTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
-  fp->write(siteInfo.valueTab());
-  if (!fitOK) {
-    fp->write(usePermutation ? "NA\tNA\tNA\tNA\tNA\tNA\tNA\tNA\n" : "NA\tNA\n");
-    return;
-  }
+void SkatTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
+void SkatTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+std::string SkatTest::formatRow(const rvt_gene_result* res) const {
+  // fitOK: genotype.cols == 0 after filtering -> NA row (src/Model.h:2665-2668)
+  if (!res || !res->skat_ok || (usePermutation && !res->perm_ok))
+    return usePermutation ? "NA\tNA\tNA\tNA\tNA\tNA\tNA\tNA\n" : "NA\tNA\n";
   std::string line = formatG(res->skat_Q) + "\t" + formatG(res->skat_p);
   if (usePermutation)  // Permutation::updateValue: ints via toString, doubles via floatToString (src/Result.h:52-63)
     line += "\t" + std::to_string(res->perm_num_perm) + "\t" + std::to_string(res->perm_actual_perm) + "\t" +
             floatToString(res->skat_Q) + "\t" + std::to_string(res->perm_num_greater) + "\t" +
             std::to_string(res->perm_num_equal) + "\t" + floatToString(res->perm_pvalue);
-  fp->write(line + "\n");
+  return line + "\n";
 }
 
 // ---- SkatOTest -----------------------------------------------------------------------------------------------------------
@@ -242,23 +280,17 @@ SkatOTest::SkatOTest(double beta1, double beta2) {
   rvt_params p{1.0, 25.0, beta1, beta2, 0, 0.05};
   GpuBroker::instance().registerTests(RVT_TEST_SKATO, p);
 }
-int SkatOTest::fit(GeneData* dc) {
-  fitOK = false;
-  res = GpuBroker::instance().resultFor(*dc, isBinaryOutcome(), &lastError);
-  if (!res || res->n_poly == 0) return -1;
-  fitOK = res->skato_ok != 0;  // fitOK = (skato.Fit(...) == 0); fit() itself returns 0 (src/Model.h:2853-2859)
-  return 0;
-}
+int SkatOTest::fit(GeneData* dc) { return deferredFit(dc); }
 void SkatOTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
   fp->write("Q\trho\tPvalue\n");
 }
-void SkatOTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
-  fp->write(siteInfo.valueTab());
-  if (!fitOK)
-    fp->write("NA\tNA\tNA\n");
-  else
-    fp->write(formatG(res->skato_Q) + "\t" + formatG(res->skato_rho) + "\t" + formatG(res->skato_p) + "\n");
+void SkatOTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
+void SkatOTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+std::string SkatOTest::formatRow(const rvt_gene_result* res) const {
+  // fitOK = (skato.Fit(...) == 0) (src/Model.h:2853-2859)
+  if (!res || res->n_poly == 0 || !res->skato_ok) return "NA\tNA\tNA\n";
+  return formatG(res->skato_Q) + "\t" + formatG(res->skato_rho) + "\t" + formatG(res->skato_p) + "\n";
 }
 
 // ---- CMCTest / ZegginiTest -------------------------------------------------------------------------------------------------
@@ -266,43 +298,31 @@ CMCTest::CMCTest() {
   modelName = "CMC";
   GpuBroker::instance().registerTests(RVT_TEST_CMC, rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05});
 }
-int CMCTest::fit(GeneData* dc) {
-  fitOK = false;
-  res = GpuBroker::instance().resultFor(*dc, isBinaryOutcome(), &lastError);
-  if (!res || !res->cmc_ok) return -1;
-  fitOK = true;
-  return 0;
-}
+int CMCTest::fit(GeneData* dc) { return deferredFit(dc); }
 void CMCTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
   fp->write("NonRefSite\tPvalue\n");
 }
-void CMCTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
-  fp->write(siteInfo.valueTab());
-  if (fitOK)
-    fp->write(std::to_string(res->cmc_nonref) + "\t" + floatToString(res->cmc_p) + "\n");
-  else
-    fp->write("NA\tNA\n");
+void CMCTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
+void CMCTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+std::string CMCTest::formatRow(const rvt_gene_result* res) const {
+  if (!res || !res->cmc_ok) return "NA\tNA\n";
+  return std::to_string(res->cmc_nonref) + "\t" + floatToString(res->cmc_p) + "\n";
 }
 
 ZegginiTest::ZegginiTest() {
   modelName = "Zeggini";
   GpuBroker::instance().registerTests(RVT_TEST_ZEGGINI, rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05});
 }
-int ZegginiTest::fit(GeneData* dc) {
-  fitOK = false;
-  res = GpuBroker::instance().resultFor(*dc, isBinaryOutcome(), &lastError);
-  if (!res || !res->zeg_ok) return -1;
-  fitOK = true;
-  return 0;
-}
+int ZegginiTest::fit(GeneData* dc) { return deferredFit(dc); }
 void ZegginiTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
   fp->write("Pvalue\n");
 }
-void ZegginiTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
-  fp->write(siteInfo.valueTab());
-  fp->write(fitOK ? floatToString(res->zeg_p) + "\n" : std::string("NA\n"));
+void ZegginiTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
+void ZegginiTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+std::string ZegginiTest::formatRow(const rvt_gene_result* res) const {
+  return (res && res->zeg_ok) ? floatToString(res->zeg_p) + "\n" : std::string("NA\n");
 }
 
 // ---- FamSkatTest ----------------------------------------------------------------------------------------------------------
@@ -478,6 +498,7 @@ int MetaCovTest::flush(bool final) {
 
 // ---- ModelManager (src/ModelManager.cpp:26-44 tokeniser, :46-271 switch) --------------------------------------------------------
 ModelManager::~ModelManager() {
+  GpuBroker::instance().flush();  // rows still pending refer to the models
   for (auto* m : model) delete m;
 }
 

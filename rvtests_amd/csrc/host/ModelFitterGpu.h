@@ -95,6 +95,8 @@ class ModelParser {
   std::map<std::string, std::string> param;
 };
 
+class ModelFitter;
+
 // ---- the engine shared by all GPU-backed models of one run ---------------------------------------------------
 // One rvt_ctx per process/GPU.  The null model is installed once (and again when the caller flags an updated
 // phenotype/covariate); each new gene is submitted ONCE with the union of the registered tests, whichever model's
@@ -104,8 +106,16 @@ class GpuBroker {
   static GpuBroker& instance();
   int ensureContext(int device);
   void registerTests(uint32_t mask, const rvt_params& p);
-  // Returns the result of the gene currently held by `gd` (submits + collects on first use). nullptr on error.
-  const rvt_gene_result* resultFor(const GeneData& gd, bool binary, std::string* err);
+  // Deferred, batched execution.  fit() only SUBMITS the gene (rvt_submit_gene copies the caller's buffer, which
+  // the next consolidate() overwrites); writeOutput() only records (sink, site columns); rows are written in call
+  // order by flush(), which runs one rvt_collect over everything pending.  flush() is triggered when `window` genes
+  // are pending and a new one arrives, by writeFootnote() and by ~ModelManager — the reference's own MetaCovTest
+  // defers its rows the same way (src/Model.cpp:828-834), and `main` ignores fit()'s return value
+  // (src/Main.cpp:1251).  window = 1 (default; RVT_ADAPTER_BATCH overrides) keeps at most one gene in flight.
+  void setBatchWindow(int k) { window = k < 1 ? 1 : k; }
+  int submit(const GeneData& gd, bool binary, std::string* err);
+  void enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab, int64_t serial);
+  int flush();
   void shutdown();
   // context + null model for models that drive the C ABI themselves (MetaCovTest)
   rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
@@ -123,8 +133,17 @@ class GpuBroker {
   rvt_params params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   bool haveNull = false;
   int64_t curSerial = -1;
-  rvt_gene_result cur{};
   bool curOk = false;
+  int window = 1;
+  struct Row {
+    ModelFitter* model;
+    TextSink* fp;
+    std::string siteTab;
+    int64_t serial;
+  };
+  std::vector<Row> rows;               // in writeOutput() order
+  std::vector<int64_t> pendingSerial;  // genes submitted and not yet collected, submission order
+  std::vector<int64_t> failedSerial;   // genes whose submission failed: NA rows
   NullFitter fitter = nullptr;
   const float* kinU = nullptr;
   bool haveFamNull = false;
@@ -140,6 +159,11 @@ class ModelFitter {
   virtual void writeFootnote(TextSink*) {}
   virtual int setParameter(const ModelParser&) { return 0; }
   virtual void reset() {}
+  // one output row (without the site columns, with the newline) from a collected record; r == nullptr -> NA row
+  virtual std::string formatRow(const rvt_gene_result* r) const {
+    (void)r;
+    return "\n";
+  }
   virtual ~ModelFitter() {}
   const std::string& getModelName() const { return modelName; }
   bool isBinaryOutcome() const { return binaryOutcome; }
@@ -149,53 +173,60 @@ class ModelFitter {
  protected:
   std::string modelName = "UninitializedModel";
   bool binaryOutcome = false;
-  const rvt_gene_result* res = nullptr;
+  int64_t curSerial = -1;  // gene handed to the last fit()
   std::string lastError;
+  // shared by the gene-level GPU models: fit() = submit, writeOutput() = enqueue, writeFootnote() = flush
+  int deferredFit(GeneData* dc);
+  void deferredOutput(TextSink* fp, const SiteInfo& siteInfo);
 };
 
 class SkatTest : public ModelFitter {
  public:
+  std::string formatRow(const rvt_gene_result* r) const override;
+  void writeFootnote(TextSink* fp) override;
   SkatTest(int nPerm, double alpha, double beta1, double beta2);
   int fit(GeneData* dc) override;
   void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
 
  private:
-  bool fitOK = false;
   bool usePermutation;
 };
 
 class SkatOTest : public ModelFitter {
  public:
+  std::string formatRow(const rvt_gene_result* r) const override;
+  void writeFootnote(TextSink* fp) override;
   SkatOTest(double beta1, double beta2);
   int fit(GeneData* dc) override;
   void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
 
  private:
-  bool fitOK = false;
 };
 
 class CMCTest : public ModelFitter {
  public:
+  std::string formatRow(const rvt_gene_result* r) const override;
+  void writeFootnote(TextSink* fp) override;
   CMCTest();
   int fit(GeneData* dc) override;
   void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
 
  private:
-  bool fitOK = false;
 };
 
 class ZegginiTest : public ModelFitter {
  public:
+  std::string formatRow(const rvt_gene_result* r) const override;
+  void writeFootnote(TextSink* fp) override;
   ZegginiTest();
   int fit(GeneData* dc) override;
   void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
 
  private:
-  bool fitOK = false;
 };
 
 // `--kernel famSkat[beta1:beta2]` (src/Model.h:3048-3145).  The reference ignores beta1 / beta2 for this model

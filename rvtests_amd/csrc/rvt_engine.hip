@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -108,12 +109,22 @@ struct rvt_ctx {
     int64_t id;
     int M;
     double* dG;
+    size_t bytes;  // capacity of dG
     std::vector<double> af;
     uint32_t tests;
     rvt_params prm;
+    rvt_gene_result res;  // filled by the batch this gene was launched in (the queue is a deque: stable addresses)
+    bool launched;
   };
-  std::vector<Pending> queue;
-  std::vector<double*> block_pool;  // not pooled by size in round 1
+  std::deque<Pending> queue;
+  std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
+  // results of launched sub-batches land in contiguous arrays, then move into Pending::res at collect time
+  struct Launched {
+    size_t first;  // index into the queue at launch time (adjusted when the queue is popped)
+    int n;
+    std::vector<rvt_gene_result> res;
+  };
+  std::deque<Launched> launched;
   // profiling
   bool profiling = false;
   std::vector<ProfEvent> events;
@@ -426,6 +437,7 @@ void rvt_destroy(rvt_ctx* c) {
   free_null(c);
   for (auto& p : c->queue)
     if (p.dG) hipFree(p.dG);
+  for (auto& bp : c->block_pool) hipFree(bp.second);
   for (auto& sl : c->slots) {
     if (sl.arena.base) hipFree(sl.arena.base);
     if (sl.h_stage) hipHostFree(sl.h_stage);
@@ -449,6 +461,9 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (!c || !X || !res || !v || N < 1 || d < 1 || d > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad null model");
   hipSetDevice(c->device);
   for (auto& sl : c->slots) HIP_TRY(c, finish_slot(c, sl) ? hipErrorUnknown : hipSuccess);
+  if (!c->queue.empty()) return fail(c, RVT_E_STATE, "collect the submitted genes before changing the null model");
+  for (auto& bp : c->block_pool) hipFree(bp.second);  // pooled blocks were laid out for the previous N
+  c->block_pool.clear();
   free_null(c);
   const int64_t ld = rvt_padded_ld(N);
   NullConsts& nc = c->nc;
@@ -1934,57 +1949,154 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
 }
 
 // ---- streaming interface --------------------------------------------------------------------------------
+namespace {
+constexpr int kSubmitGroup = 16;  // genes per asynchronous sub-batch of the streaming interface
+
+bool same_config(const rvt_ctx::Pending& a, const rvt_ctx::Pending& b) {
+  return a.tests == b.tests && std::memcmp(&a.prm, &b.prm, sizeof(rvt_params)) == 0;
+}
+
+// launch queue[first, first+n) as one asynchronous batch (analytic tests only)
+int launch_group(rvt_ctx* c, size_t first, int n) {
+  std::vector<const double*> ptrs;
+  std::vector<int> Ms;
+  std::vector<double> af;
+  std::vector<int64_t> ids;
+  for (int g = 0; g < n; ++g) {
+    const rvt_ctx::Pending& p = c->queue[first + g];
+    ptrs.push_back(p.dG);
+    Ms.push_back(p.M);
+    ids.push_back(p.id);
+    af.insert(af.end(), p.af.begin(), p.af.end());
+  }
+  c->launched.emplace_back();
+  rvt_ctx::Launched& L = c->launched.back();
+  L.first = first;
+  L.n = n;
+  L.res.resize(n);
+  const rvt_ctx::Pending& p0 = c->queue[first];
+  int rc = run_batch(c, n, ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm, L.res.data(), nullptr);
+  if (rc) {
+    c->launched.pop_back();
+    return rc;
+  }
+  for (int g = 0; g < n; ++g) c->queue[first + g].launched = true;
+  return RVT_OK;
+}
+
+// launch every still-unlaunched run of equally configured genes among the first `upto` queue entries;
+// only_full: launch only complete groups of kSubmitGroup (the submit path), else everything (the collect path)
+int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
+  size_t i = 0;
+  while (i < upto) {
+    if (c->queue[i].launched) {
+      ++i;
+      continue;
+    }
+    size_t e = i + 1;
+    while (e < upto && !c->queue[e].launched && same_config(c->queue[e], c->queue[i]) &&
+           (int)(e - i) < (only_full ? kSubmitGroup : 256))
+      ++e;
+    const rvt_ctx::Pending& p0 = c->queue[i];
+    const bool perm = p0.prm.skat_nperm > 0 && (p0.tests & RVT_TEST_SKAT);
+    if (only_full && ((int)(e - i) < kSubmitGroup || perm)) return RVT_OK;  // wait for more genes / for collect
+    if (perm) {
+      // permutation p-values consume one random stream in gene order: synchronous, gene by gene
+      int rc = rvt_sync(c);
+      if (rc) return rc;
+      std::vector<const double*> ptrs;
+      std::vector<int> Ms;
+      std::vector<double> af;
+      std::vector<int64_t> ids;
+      for (size_t g = i; g < e; ++g) {
+        ptrs.push_back(c->queue[g].dG);
+        Ms.push_back(c->queue[g].M);
+        ids.push_back(c->queue[g].id);
+        af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
+      }
+      std::vector<rvt_gene_result> res(e - i);
+      rc = run_blocks_with_perm(c, (int)(e - i), ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm,
+                                res.data());
+      if (rc) return rc;
+      for (size_t g = i; g < e; ++g) {
+        c->queue[g].res = res[g - i];
+        c->queue[g].launched = true;
+      }
+    } else {
+      int rc = launch_group(c, i, (int)(e - i));
+      if (rc) return rc;
+    }
+    i = e;
+  }
+  return RVT_OK;
+}
+}  // namespace
+
 int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                     const rvt_params* prm) {
   if (!c || !G || !af || M < 1) return fail(c, RVT_E_INVALID, "bad gene");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  hipSetDevice(c->device);
   rvt_ctx::Pending p;
   p.id = gene_id;
   p.M = M;
   p.dG = nullptr;
-  int rc = rvt_block_alloc(c, M, &p.dG);
-  if (rc) return rc;
-  rc = rvt_block_upload(c, p.dG, M, G);  // synchronous copy: the caller may overwrite G on return
+  p.launched = false;
+  std::memset(&p.res, 0, sizeof(p.res));
+  // device block from the pool (smallest that fits) or a fresh zeroed allocation; pad rows stay zero because only
+  // the N data rows of a column are ever written
+  const size_t need = sizeof(double) * (size_t)c->null_ld * M;
+  int best = -1;
+  for (int i = 0; i < (int)c->block_pool.size(); ++i)
+    if (c->block_pool[i].first >= need && (best < 0 || c->block_pool[i].first < c->block_pool[best].first)) best = i;
+  if (best >= 0) {
+    p.dG = c->block_pool[best].second;
+    p.bytes = c->block_pool[best].first;
+    c->block_pool.erase(c->block_pool.begin() + best);
+  } else {
+    int rc = rvt_block_alloc(c, M, &p.dG);
+    if (rc) return rc;
+    p.bytes = need;
+  }
+  int rc = rvt_block_upload(c, p.dG, M, G);  // synchronous copy: the caller may overwrite G on return
   if (rc) {
-    hipFree(p.dG);
+    c->block_pool.emplace_back(p.bytes, p.dG);
     return rc;
   }
   p.af.assign(af, af + M);
   p.tests = tests;
   p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   c->queue.push_back(std::move(p));
-  return RVT_OK;
+  // complete groups start computing now and overlap the host-side copies of the following genes
+  return launch_pending(c, c->queue.size(), true);
 }
 
 int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
   if (!c || !out || !n_out) return RVT_E_INVALID;
   *n_out = 0;
+  hipSetDevice(c->device);
   const int n = (int)std::min<size_t>(c->queue.size(), (size_t)cap);
   if (n == 0) return RVT_OK;
-  // genes are grouped by (tests, params) runs in submission order
-  int done = 0;
-  while (done < n) {
-    int e = done + 1;
-    while (e < n && c->queue[e].tests == c->queue[done].tests &&
-           std::memcmp(&c->queue[e].prm, &c->queue[done].prm, sizeof(rvt_params)) == 0)
-      ++e;
-    std::vector<const double*> ptrs;
-    std::vector<int> Ms;
-    std::vector<double> af;
-    std::vector<int64_t> ids;
-    for (int g = done; g < e; ++g) {
-      ptrs.push_back(c->queue[g].dG);
-      Ms.push_back(c->queue[g].M);
-      ids.push_back(c->queue[g].id);
-      af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
-    }
-    int rc = rvt_run_blocks(c, e - done, ptrs.data(), Ms.data(), af.data(), ids.data(), c->queue[done].tests,
-                            &c->queue[done].prm, out + done);
-    if (rc) return rc;
-    done = e;
+  int rc = launch_pending(c, (size_t)n, false);
+  if (!rc) rc = rvt_sync(c);
+  if (rc) return rc;
+  // records of the asynchronous groups
+  while (!c->launched.empty() && c->launched.front().first < (size_t)n) {
+    rvt_ctx::Launched& L = c->launched.front();
+    for (int g = 0; g < L.n; ++g) c->queue[L.first + g].res = L.res[g];
+    c->launched.pop_front();
   }
-  for (int g = 0; g < n; ++g) hipFree(c->queue[g].dG);
+  for (int g = 0; g < n; ++g) {
+    out[g] = c->queue[g].res;
+    c->block_pool.emplace_back(c->queue[g].bytes, c->queue[g].dG);
+  }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);
+  for (auto& L : c->launched) L.first -= (size_t)n;
+  // keep the pool bounded: free the largest blocks beyond 128 entries
+  while (c->block_pool.size() > 128) {
+    hipFree(c->block_pool.back().second);
+    c->block_pool.pop_back();
+  }
   *n_out = n;
   return RVT_OK;
 }

@@ -35,8 +35,11 @@ def write_input(path, y, cov, binary, genes):
             f.write(np.asfortranarray(G, dtype="<f8").tobytes(order="F"))
 
 
-def run_driver(path, kernel, burden):
-    p = subprocess.run([DRIVER, path, kernel, burden], capture_output=True, text=True, timeout=300)
+def run_driver(path, kernel, burden, batch=None):
+    env = dict(os.environ)
+    if batch:
+        env["RVT_ADAPTER_BATCH"] = str(batch)      # genes the adapters keep in flight before collecting
+    p = subprocess.run([DRIVER, path, kernel, burden], capture_output=True, text=True, timeout=300, env=env)
     sections = {}
     cur = None
     for line in p.stdout.splitlines():
@@ -80,12 +83,15 @@ def test_registry_parser_and_na_rows_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("binary,d", [(0, 3), (1, 1)])
-def test_driver_output_matches_oracle(tmp_path, binary, d):
+@pytest.mark.parametrize("binary,d,batch", [(0, 3, None), (1, 1, None), (0, 3, 3), (1, 2, 64)])
+def test_driver_output_matches_oracle(tmp_path, binary, d, batch):
     _ensure_driver()
     path, genes, X, y, res, v = _case(tmp_path, binary=binary, d=d)
-    rc, sec, err = run_driver(path, "skat[nPerm=0],skato", "cmc,zeggini")
+    rc, sec, err = run_driver(path, "skat[nPerm=0],skato", "cmc,zeggini", batch)
     assert rc == 0, err
+    if batch:       # deferred, batched collection must not change a single character of the output
+        rc1, sec1, err1 = run_driver(path, "skat[nPerm=0],skato", "cmc,zeggini")
+        assert sec1 == sec
 
     def g(x):
         return "%g" % x
@@ -101,21 +107,21 @@ def test_driver_output_matches_oracle(tmp_path, binary, d):
         if a.n_poly == 0:
             assert row[-2:] == ["NA", "NA"]
             continue
-        assert abs(float(row[-2]) - a.Q) <= 2e-6 * a.Q and abs(float(row[-1]) - a.pvalue) <= 2e-6 * a.pvalue + 1e-14
+        assert abs(float(row[-2]) - a.Q) <= 6e-6 * a.Q and abs(float(row[-1]) - a.pvalue) <= 6e-6 * a.pvalue + 1e-14
         row = sec["out.SkatO.assoc"][1 + i]
         if rc2 == 0:
-            assert abs(float(row[-3]) - o.Q) <= 2e-6 * o.Q and float(row[-2]) == o.rho
-            assert abs(float(row[-1]) - o.pvalue) <= 2e-6 * o.pvalue + 1e-12
+            assert abs(float(row[-3]) - o.Q) <= 6e-6 * o.Q and float(row[-2]) == o.rho      # %g: 6 digits
+            assert abs(float(row[-1]) - o.pvalue) <= 6e-6 * o.pvalue + 1e-12
         else:
             assert row[-3:] == ["NA"] * 3
         rc3, c = orc.burden(G, X, y, binary, 0)
         row = sec["out.CMC.assoc"][1 + i]
         if rc3 == 0:
-            assert int(row[-2]) == c.nonref_site and abs(float(row[-1]) - c.pvalue) <= 2e-6 * c.pvalue
+            assert int(row[-2]) == c.nonref_site and abs(float(row[-1]) - c.pvalue) <= 6e-6 * c.pvalue
         rc4, z = orc.burden(G, X, y, binary, 1)
         row = sec["out.Zeggini.assoc"][1 + i]
         if rc4 == 0:
-            assert abs(float(row[-1]) - z.pvalue) <= 2e-6 * z.pvalue
+            assert abs(float(row[-1]) - z.pvalue) <= 6e-6 * z.pvalue
 
 
 def run_driver_meta(path, meta, sites_path, block=None):
