@@ -120,6 +120,11 @@ typedef struct {
   double sigma2;    /* FastLMM::GetSigmaG2() */
   double beta[16];  /* FastLMM::GetBeta() */
 } orc_fam_null;
+/* The Brent minimiser restatement (GSL 1.16 min/brent.c as driven by Minimizer::minimize, GSLMinimizer.cpp:18-66) on
+   built-in test functions, for the fixture check against GSL itself:
+     id 0: (x-a)^2   1: cosh(x-a)   2: x^4 - a x   3: -log-likelihood-like  a/x + log(x)   4: |x-a|^1.5
+   Returns the minimize() status (0 / -1); outputs x_minimum, number of function evaluations, last evaluated x. */
+int orc_brent_builtin(int id, double a, double start, double lb, double ub, double* xmin, int* evals, double* last_x);
 /* FastLMM::FitNullModel (regression/FastLMM.cpp:28-142) incl. the GSL Brent refinement (GSLMinimizer.cpp:18-66) */
 int orc_fastlmm_null(const double* X, const double* y, int64_t N, int d, const double* U, const double* S,
                      int use_float, orc_fam_null* out);

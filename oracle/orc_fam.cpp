@@ -190,6 +190,28 @@ Mat wrapd(const double* p, int64_t r, int64_t c) {
 
 extern "C" {
 
+int orc_brent_builtin(int id, double a, double start, double lb, double ub, double* xmin, int* evals,
+                      double* last_x) {
+  int n = 0;
+  double last = NAN;
+  auto f = [&](double x) {
+    ++n;
+    last = x;
+    switch (id) {
+      case 0: return (x - a) * (x - a);
+      case 1: return std::cosh(x - a);
+      case 2: return x * x * x * x - a * x;
+      case 3: return a / x + std::log(x);
+      default: return std::pow(std::fabs(x - a), 1.5);
+    }
+  };
+  *xmin = start;
+  const int rc = brent_minimize(f, start, lb, ub, xmin);
+  *evals = n;
+  *last_x = last;
+  return rc;
+}
+
 int orc_fastlmm_null(const double* Xp, const double* y, int64_t N, int d, const double* Up, const double* S,
                      int use_float, orc_fam_null* out) {
   std::memset(out, 0, sizeof(*out));

@@ -113,3 +113,29 @@ def test_metacov_fam_matches_numpy():
     assert np.abs(cov[m] - val[m]).max() < 1e-9 * np.abs(val[m]).max()
     assert np.allclose(zz, ZZ, rtol=1e-9)
     assert np.allclose(xz[k2], XZ[k2], rtol=1e-8, atol=1e-9 * np.abs(XZ).max())
+
+
+def test_brent_restatement_matches_gsl_fixture():
+    """The oracle's Brent minimiser against GSL 1.16 itself (tests/golden/gsl_brent.json, generated from the library
+    the reference vendors): same status, same minimum, same number of evaluations, same last abscissa."""
+    import ctypes as C
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gsl_brent.json")))
+    L = orc.lib()
+    L.orc_brent_builtin.restype = C.c_int
+    L.orc_brent_builtin.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert len(fx["cases"]) >= 20
+    seen_fail = False
+    for c in fx["cases"]:
+        xmin, n, last = C.c_double(0), C.c_int(0), C.c_double(0)
+        rc = L.orc_brent_builtin(c["id"], c["a"], c["start"], c["lb"], c["ub"], C.byref(xmin), C.byref(n),
+                                 C.byref(last))
+        assert rc == c["rc"], c
+        assert n.value == c["evals"], c
+        if rc == 0:
+            assert xmin.value == c["xmin"] and last.value == c["last_x"], c      # bit-identical trajectories
+        else:
+            seen_fail = True
+    assert seen_fail
