@@ -316,8 +316,8 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
 // with a tail in which the chip drains, and with the genes of a launch sorted widest-first the tail of a big
 // launch is short:
 //   group 0  <= 128 registers, 4 waves / SIMD   (1,1) (1,2) (2,2)            M <= 28 (unweighted)
-//   group 1  <= 256 registers, 2 waves / SIMD   (2,3) (3,3) (3,4) (4,4)      M <= 60   [+ weighted (2,2)]
-//   group 2  <= 512 registers, 1 wave  / SIMD   (4,5) (5,5) (5,6) (6,6) (6,7) M <= 96
+//   group 1  <= 256 registers, 2 waves / SIMD   (2,3) (3,3) (3,4) (4,4) (4,5) M <= 64   [+ weighted (2,2)]
+//   group 2  <= 512 registers, 1 wave  / SIMD   (5,5) (5,6) (6,6) (6,7)       M <= 96
 // Inside a kernel the gene's configuration selects the body (a wave-uniform switch); the register allocation of
 // the kernel is the largest of its group.  Grid = (wave-parts, genes of the group), one wave per workgroup.
 template <int MT, int CT, bool WEIGHTED>
@@ -326,13 +326,14 @@ __device__ __forceinline__ void suffstat_class(const GeneDesc& gd, const NullDev
   // ring depth: 3 wherever the registers allow it without dropping an occupancy step (see tools/kernel_regs.sh)
   constexpr int kDepth = (CT <= 3)         ? 3
                          : (MT * CT <= 16) ? (WEIGHTED ? 2 : 3)
+                         : (MT * CT <= 20) ? 2   // (4,5): fits 256 registers, two waves per SIMD
                          : (CT <= 5)       ? 3
                                            : 2;
   suffstat_body<MT, CT, WEIGHTED, kDepth>(gd, nd, N, ld, d);
 }
 
 __host__ __device__ constexpr int suffstat_group(int MT, int CT, bool weighted) {
-  return (MT * CT > 16) ? 2 : ((MT * CT <= 4 && !(weighted && MT == 2)) ? 0 : 1);
+  return (MT * CT > 20) ? 2 : ((MT * CT <= 4 && !(weighted && MT == 2)) ? 0 : 1);
 }
 
 template <int GROUP, bool WEIGHTED>
@@ -563,8 +564,8 @@ constexpr int kBurdenSPB = 1024;  // samples per block (256 threads x 4)
 
 template <int DMAX>
 __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __restrict__ genes, int n_genes,
-                                                              NullDev nd, long long N, long long ld, int d, int binary,
-                                                              unsigned tests) {
+                                                              int genes_per_group, NullDev nd, long long N,
+                                                              long long ld, int d, int binary, unsigned tests) {
   constexpr int NV = 2 * (3 + DMAX);                       // values reduced per gene
   constexpr int NP = NV <= 16 ? 16 : (NV <= 32 ? 32 : 64); // padded to a power of two for the butterfly
   __shared__ double red[4][NV];
@@ -587,7 +588,11 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) xr[q][k] = (valid[q] && k < d) ? nd.X[(long long)k * ld + sidx] : 0.0;
   }
-  for (int g = 0; g < n_genes; ++g) {
+  // blockIdx.y = gene group: groups of `genes_per_group` genes run as concurrent workgroups of ONE launch (more waves
+  // in flight than one launch per group; the kernel is latency-bound)
+  const int g_begin = blockIdx.y * genes_per_group;
+  const int g_end = (g_begin + genes_per_group < n_genes) ? g_begin + genes_per_group : n_genes;
+  for (int g = g_begin; g < g_end; ++g) {
     const GeneDesc gd = genes[g];
     const int MT = gd.MT;
     const unsigned long long* mge = gd.masks + (step * MT) * 4 + l;

@@ -833,16 +833,16 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       Scope sc(c, 1, bs);
       hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, bs, d_desc, (long long)N);
     }
-    // gene groups of <= 64 per launch keep one block's loop short while X/res/v stay in registers
-    for (int k = 0; k < n; k += 64) {
-      const int cnt = std::min(64, n - k);
+    // gene groups of <= 64 keep one workgroup's loop short while X/res/v stay in registers; all groups in one launch
+    {
+      const int gpg = 64, ngroups = (n + gpg - 1) / gpg;
       Scope sc(c, 1, bs);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts), dim3(256), 0, bs, d_desc + k, cnt, nd,
+        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts, ngroups), dim3(256), 0, bs, d_desc, n, gpg, nd,
                            (long long)N, (long long)ld, d, nc.binary, tests);
       else
-        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts), dim3(256), 0, bs, d_desc + k, cnt,
-                           nd, (long long)N, (long long)ld, d, nc.binary, tests);
+        hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts, ngroups), dim3(256), 0, bs, d_desc,
+                           n, gpg, nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
