@@ -15,6 +15,17 @@
 #include <cmath>
 #include <functional>
 #include "kernels.hip.h"
+
+namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
+void k2_launch_group_w0(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N,
+                        long long ld, int d);
+void k2_launch_group_w1(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N,
+                        long long ld, int d);
+void k2_launch_panel_w0(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N, long long ld,
+                        int d);
+void k2_launch_panel_w1(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N, long long ld,
+                        int d);
+}  // namespace rvt
 #include "fam_kernels.hip.h"
 #include "perm_kernels.hip.h"
 
@@ -245,21 +256,13 @@ void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_de
   // Waves are independent (no LDS, no barriers), so a workgroup is ONE wave: the dispatcher can then place the
   // wide classes (one wave fills a SIMD's register file) on any free SIMD, instead of needing four free SIMDs on
   // one CU at once — which a single long-lived p-value wave per CU would block for its whole lifetime.
-  dim3 grid(max_wparts, n), block(64);
+  dim3 grid(max_wparts, n);
   const long long N = c->nc.N, ld = c->nc.ld;
   const int d = c->nc.d;
-#define RVT_GROUP(g)                                                                                            \
-  if (group == g) {                                                                                             \
-    if (c->nc.binary)                                                                                           \
-      hipLaunchKernelGGL((gene_suffstat_mfma<g, true>), grid, block, 0, st, d_desc, nd, N, ld, d);              \
-    else                                                                                                        \
-      hipLaunchKernelGGL((gene_suffstat_mfma<g, false>), grid, block, 0, st, d_desc, nd, N, ld, d);             \
-    return;                                                                                                     \
-  }
-  RVT_GROUP(0)
-  RVT_GROUP(1)
-  RVT_GROUP(2)
-#undef RVT_GROUP
+  if (c->nc.binary)
+    k2_launch_group_w1(group, grid, st, d_desc, nd, N, ld, d);
+  else
+    k2_launch_group_w0(group, grid, st, d_desc, nd, N, ld, d);
 }
 
 // glibc srandom_r / random_r for the default TYPE_3 generator: r[i] = 16807 r[i-1] mod (2^31 - 1) for the first 31
@@ -743,11 +746,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     for (int pr = 0; pr < nPR; ++pr) npanels += nPC - pr;
     dim3 grid(n_wparts, k0, npanels), block(64);
     if (nc.binary)
-      hipLaunchKernelGGL((gene_suffstat_panel<true>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
-                         (long long)ld, d);
+      k2_launch_panel_w1(grid, c->k2_stream, d_desc, nd, (long long)N, (long long)ld, d);
     else
-      hipLaunchKernelGGL((gene_suffstat_panel<false>), grid, block, 0, c->k2_stream, d_desc, nd, (long long)N,
-                         (long long)ld, d);
+      k2_launch_panel_w0(grid, c->k2_stream, d_desc, nd, (long long)N, (long long)ld, d);
   }
   for (int k = k0; k < n;) {  // descriptors are sorted by width, so every register-budget group is one contiguous run
     const int grp = suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0);
