@@ -65,28 +65,46 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi):
     return blocks, Ms, afs
 
 
-def fit_null_qt(dev, N, seed):
-    """Quantitative null model y ~ 1 + c1 + c2 (plumbing: solved with torch in fp64 on the device)."""
+def make_phenotype(dev, N, seed, binary=False):
+    """Covariates and phenotype of SURVEY §8d: quantitative y = 0.3 c1 - 0.2 c2 + N(0,1) (configs 2/3) or binary
+    y ~ Bernoulli(logit^-1(-2 + 0.3 c1)) (config 4).  Returns X (with intercept) and y as device tensors."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     c = torch.randn((N, 2), generator=g, device=dev, dtype=torch.float64)
     X = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float64), c], 1)
-    y = 0.3 * c[:, 0] - 0.2 * c[:, 1] + torch.randn(N, generator=g, device=dev, dtype=torch.float64)
+    if binary:
+        pr = torch.sigmoid(-2.0 + 0.3 * c[:, 0])
+        y = (torch.rand(N, generator=g, device=dev, dtype=torch.float64) < pr).to(torch.float64)
+    else:
+        y = 0.3 * c[:, 0] - 0.2 * c[:, 1] + torch.randn(N, generator=g, device=dev, dtype=torch.float64)
+    return X, y
+
+
+def fit_null_qt(dev, N, seed):
+    """Quantitative null model y ~ 1 + c1 + c2 solved with torch (used by the tools/ microbenchmarks)."""
+    X, y = make_phenotype(dev, N, seed)
     beta = torch.linalg.solve(X.T @ X, X.T @ y)
     res = y - X @ beta
     sigma2 = float((res @ res) / N)
     return X, y, res, sigma2
 
 
-def cpu_baseline(G_host, af, X, y, res, v, n_threads=1):
+def cpu_baseline(G_host, af, X, y, binary):
     """Time the CPU oracle on one gene: SKAT (P0 folded; the literal N x N form cannot run at this N), literal
-    SKAT-O, CMC and Zeggini — the four ModelFitter::fit bodies of the workload."""
+    SKAT-O, CMC and Zeggini — the four ModelFitter::fit bodies of the workload.  The null model (fitted once per
+    analysis, not per gene) is outside the timed region."""
     import orc
+    if binary:
+        rc, beta, p, v = orc.fit_logistic(X, y)
+        res = y - p
+    else:
+        rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+        v = np.full(len(y), s2)
     t0 = time.perf_counter()
-    orc.skat(G_host, af, X, res, v, 0)
-    orc.skato(G_host, af, X, res, v, 0)
-    orc.burden(G_host, X, y, 0, 0)
-    orc.burden(G_host, X, y, 0, 1)
+    orc.skat(G_host, af, X, res, v, binary)
+    orc.skato(G_host, af, X, res, v, binary)
+    orc.burden(G_host, X, y, binary, 0)
+    orc.burden(G_host, X, y, binary, 1)
     return time.perf_counter() - t0
 
 
@@ -101,6 +119,8 @@ def main():
     ap.add_argument("--m-hi", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tests", type=int, default=rvtests_amd.TEST_ALL)
+    ap.add_argument("--trait", choices=["qt", "binary"], default="qt",
+                    help="qt = BASELINE configs[2] (default); binary = configs[3]-style logistic null")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,25 +145,20 @@ def main():
     eng = rvtests_amd.Engine(gpu_index)
     ld = eng.padded_ld(N)
 
-    # ---- null model: fitted on rank 0, broadcast (collective C1), installed on every rank ----------------
+    # ---- null model: phenotype and covariates from rank 0 (collective C1: one broadcast), fitted and installed on
+    #      every rank by the engine itself (rvt_fit_null: OLS / IRLS on the device) -----------------------------
     d = 3
-    pack = torch.empty((N, d + 2), dtype=torch.float64, device=dev)
-    sig = torch.zeros(1, dtype=torch.float64, device=dev)
+    binary = args.trait == "binary"
+    pack = torch.empty((N, d + 1), dtype=torch.float64, device=dev)
     if rank == 0:
-        X, y, res, sigma2 = fit_null_qt(dev, N, 20260002)
+        X, y = make_phenotype(dev, N, 20260002, binary)
         pack[:, :d] = X
-        pack[:, d] = res
-        pack[:, d + 1] = y
-        sig[0] = sigma2
+        pack[:, d] = y
     if world > 1:
         dist.broadcast(pack, 0)
-        dist.broadcast(sig, 0)
-    sigma2 = float(sig[0])
     Xh = np.asfortranarray(pack[:, :d].cpu().numpy())
-    resh = pack[:, d].cpu().numpy().copy()
-    yh = pack[:, d + 1].cpu().numpy().copy()
-    vh = np.full(N, sigma2)
-    eng.set_null(rvtests_amd.TRAIT_QUANTITATIVE, Xh, resh, vh, sigma2)
+    yh = pack[:, d].cpu().numpy().copy()
+    eng.fit_null(rvtests_amd.TRAIT_BINARY if binary else rvtests_amd.TRAIT_QUANTITATIVE, Xh, yh)
 
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
     blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi)
@@ -211,6 +226,8 @@ def main():
         # tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); null when the workload differs
         traffic = None
         key = "N=%d,genes=%d,m=%d..%d,seed=20260002,tests=%d" % (N, args.genes, args.m_lo, args.m_hi, args.tests)
+        if binary:
+            key += ",binary"
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
@@ -222,9 +239,10 @@ def main():
             "value": value, "unit": "gene-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: N=%d, genes/step/GPU=%d, M~U{%d..%d}, quantitative trait, "
+            "config": {"workload": "BASELINE configs[%d]: N=%d, genes/step/GPU=%d, M~U{%d..%d}, %s trait, "
                                    "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
-                                   "fp64 column-major blocks" % (N, args.genes, args.m_lo, args.m_hi),
+                                   "fp64 column-major blocks" % (3 if binary else 2, N, args.genes, args.m_lo,
+                                                                 args.m_hi, "binary" if binary else "quantitative"),
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
                        "parallelism": "gene-sharded x%d" % world, "genes_ok": ok},
             "roofline": {"kernel": "gene_suffstat_mfma", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -240,7 +258,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             k = int(np.argmin(np.abs(np.array(Ms) - 50)))
             Gh = np.asfortranarray(blocks[k][:, :N].T.cpu().numpy())
-            t = cpu_baseline(Gh, afs[k], Xh, yh, resh, vh)
+            t = cpu_baseline(Gh, afs[k], Xh, yh, 1 if binary else 0)
             line["cpu_baseline"] = {"value": 1.0 / t, "unit": "gene-sets/s", "cores": 1, "kind": "port",
                                     "sample": "1 gene of the batch (M=%d, N=%d): oracle folded SKAT + literal SKAT-O + "
                                               "CMC + Zeggini, g++ -O2 -msse2, %.1f s" % (Ms[k], N, t)}
