@@ -188,6 +188,13 @@ int rvt_collect(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
  * The caller applies the window rule (src/Model.h:3956-3990) and the text formatting; the null model is the one
  * installed by rvt_set_null (trait, X with intercept, sigma2 / v).  Synchronous. */
 int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
+/* The same numbers for windows wider than one block (unrelated samples): heads = columns [col0, col0+H) of `dG`,
+ * markers = columns [col0, col0+W), W >= H, no limit on W other than memory.  Two plain GEMMs (rocBLAS) replace the
+ * symmetric block kernel.  cov[(h-col0) + (j-col0)*H] for j >= h; xz: W x d; polymorphic: W. */
+int rvt_cov_rect(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                 int* polymorphic);
+/* Copy columns between two device blocks (growing the adapter's ring). */
+int rvt_block_copy_columns(rvt_ctx* ctx, double* dst, int dst_col, const double* src, int src_col, int ncols);
 /* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous). */
 int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, const double* G);
 /* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */

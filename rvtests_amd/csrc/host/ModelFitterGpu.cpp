@@ -6,6 +6,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 namespace rvt_host {
 
@@ -373,6 +374,9 @@ MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
   modelName = "MetaCov";
   // block size of the device ring; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush with it)
   if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(RVT_MAX_VARIANTS, atoi(e)));
+  // blocks up to this many columns use the symmetric block kernel, wider ones the heads-by-window rectangle
+  if (const char* e = getenv("RVT_METACOV_RECT_ABOVE")) rectAbove = std::max(1, std::min(RVT_MAX_VARIANTS, atoi(e)));
+  if (const char* e = getenv("RVT_METACOV_MAX_COLUMNS")) maxColumns = std::max(capacity, atoi(e));
 }
 MetaCovTest::~MetaCovTest() {
   if (fout) flush(true);
@@ -409,7 +413,10 @@ int MetaCovTest::fit(GeneData* dc) {
       return -1;
     }
   }
-  if ((int)sites.size() == capacity && (flush(false) || (int)sites.size() == capacity)) return -1;
+  if ((int)sites.size() == capacity) {
+    if (flush(false)) return -1;
+    if ((int)sites.size() == capacity && grow()) return -1;  // one window holds more sites than the ring: enlarge it
+  }
   // the caller overwrites the genotype buffer for the next site: copy the column into the device ring now
   if (rvt_block_upload_columns(ctx, block, (int)sites.size(), 1, dc->genotype)) {
     lastError = rvt_last_error(ctx);
@@ -428,46 +435,61 @@ void MetaCovTest::writeFootnote(TextSink* fp) {
   flush(true);
 }
 
+// Double the device ring (a window can hold more sites than the current block).
+int MetaCovTest::grow() {
+  if (useFamilyModel) {
+    lastError = "MetaCov with kinship: one window holds more sites than the device block (RVT_MAX_VARIANTS)";
+    return -1;
+  }
+  const int want = std::min(maxColumns, capacity * 2);
+  if (want <= capacity) {
+    lastError = "MetaCov: one window holds more sites than RVT_METACOV_MAX_COLUMNS allows";
+    return -1;
+  }
+  double* bigger = nullptr;
+  if (rvt_block_alloc(ctx, want, &bigger) ||
+      rvt_block_copy_columns(ctx, bigger, 0, block, 0, (int)sites.size())) {
+    lastError = rvt_last_error(ctx);
+    if (bigger) rvt_block_free(ctx, bigger);
+    return -1;
+  }
+  rvt_block_free(ctx, block);
+  block = bigger;
+  capacity = want;
+  return 0;
+}
+
 // Emit the rows of every head whose window is complete (all of them when `final`), then compact the ring.
 int MetaCovTest::flush(bool final) {
   const int V = (int)sites.size();
   if (V == 0 || !fout) return 0;
   const int d = nCovariate;
-  std::vector<double> cov((size_t)V * V), xz((size_t)V * d), zz((size_t)d * d);
-  std::vector<int> poly(V);
-  if (useFamilyModel ? rvt_cov_block_fam(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())
-                     : rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
-    lastError = rvt_last_error(ctx);
-    return -1;
-  }
   auto outOfWindow = [&](int h, int j) {  // getWindowSize(queue, loci) > windowSize, src/Model.h:3974-3990
     return sites[j].chrom != sites[h].chrom || std::abs(sites[j].pos - sites[h].pos) > windowSize;
   };
-  const float scale = (float)(1.0 / (double)nSample);
   int H = 0;  // heads [0, H) are complete
   for (; H < V; ++H) {
     bool complete = final;
     for (int j = H + 1; j < V && !complete; ++j) complete = outOfWindow(H, j);
     if (!complete) break;
   }
-  if (H == 0) {
-    lastError = "MetaCov: more variants inside one window than the device block holds (RVT_MAX_VARIANTS)";
-    return -1;
-  }
-  std::string line;
-  for (int h = 0; h < H; ++h) {
-    if (!poly[h]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
+  if (H == 0) return 0;  // nothing can be written yet: the caller enlarges the ring
+  const float scale = (float)(1.0 / (double)nSample);
+  std::vector<double> zz((size_t)d * d);
+  // one output row; covAt(j) / xzHead / polyAt(j) read whichever layout the device call produced
+  auto emitRow = [&](int h, const std::function<double(int)>& covAt, const double* xzHead,
+                     const std::function<bool(int)>& polyAt) {
     std::string positions, values;
     int last = h, num = 0;
     for (int j = h; j < V; ++j) {
       if (outOfWindow(h, j)) break;
-      if (!poly[j]) continue;
+      if (!polyAt(j)) continue;
       if (num) {
         positions += ',';
         values += ',';
       }
       positions += std::to_string(sites[j].pos);
-      values += formatG((double)((float)cov[(size_t)h + (size_t)j * V] * scale));
+      values += formatG((double)((float)covAt(j) * scale));
       last = j;
       ++num;
     }
@@ -475,7 +497,7 @@ int MetaCovTest::flush(bool final) {
       values += ':';
       for (int k = 0; k < d; ++k) {
         if (k) values += ',';
-        values += formatG((double)((float)xz[(size_t)h * d + k] * scale));
+        values += formatG((double)((float)xzHead[k] * scale));
       }
       values += ':';
       for (int a = 0; a < d; ++a)
@@ -484,9 +506,48 @@ int MetaCovTest::flush(bool final) {
           values += floatToString(zz[(size_t)a * d + b] * (double)scale);
         }
     }
-    line = sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[last].pos) + "\t" +
-           std::to_string(num) + "\t" + positions + "\t" + values + "\n";
-    fout->write(line);
+    fout->write(sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[last].pos) + "\t" +
+                std::to_string(num) + "\t" + positions + "\t" + values + "\n");
+  };
+  if (V <= rectAbove || useFamilyModel) {
+    // the whole ring is one block of the symmetric kernel
+    std::vector<double> cov((size_t)V * V), xz((size_t)V * d);
+    std::vector<int> poly(V);
+    if (useFamilyModel ? rvt_cov_block_fam(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())
+                       : rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
+      lastError = rvt_last_error(ctx);
+      return -1;
+    }
+    for (int h = 0; h < H; ++h) {
+      if (!poly[h]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
+      emitRow(
+          h, [&](int j) { return cov[(size_t)h + (size_t)j * V]; }, xz.data() + (size_t)h * d,
+          [&](int j) { return poly[j] != 0; });
+    }
+  } else {
+    // wide windows: chunks of heads against everything up to the end of the last head's window
+    const int Hc = std::min(256, rectAbove);
+    for (int h0 = 0; h0 < H; h0 += Hc) {
+      const int h1 = std::min(H, h0 + Hc);
+      int jmax = h1 - 1;
+      for (int j = h1; j < V && !outOfWindow(h1 - 1, j); ++j) jmax = j;
+      // (positions are sorted within a chromosome, so the last head's window contains the others' windows)
+      for (int h = h0; h < h1; ++h)
+        for (int j = jmax + 1; j < V && !outOfWindow(h, j); ++j) jmax = j;
+      const int nh = h1 - h0, W = jmax - h0 + 1;
+      std::vector<double> cov((size_t)nh * W), xz((size_t)W * d);
+      std::vector<int> poly(W);
+      if (rvt_cov_rect(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())) {
+        lastError = rvt_last_error(ctx);
+        return -1;
+      }
+      for (int h = h0; h < h1; ++h) {
+        if (!poly[h - h0]) continue;
+        emitRow(
+            h, [&](int j) { return cov[(size_t)(h - h0) + (size_t)(j - h0) * nh]; },
+            xz.data() + (size_t)(h - h0) * d, [&](int j) { return j - h0 < W && poly[j - h0] != 0; });
+      }
+    }
   }
   if (H < V && rvt_block_move_columns(ctx, block, 0, H, V - H)) {
     lastError = rvt_last_error(ctx);

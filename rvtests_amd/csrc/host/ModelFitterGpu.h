@@ -247,7 +247,9 @@ class FamSkatTest : public ModelFitter {
 // src/Model.cpp:844-858) and only copies the column into a device-resident ring; covariance rows are produced block
 // by block on the GPU (rvt_cov_block) and written in the reference's order and format when their window is complete
 // — the reference itself defers each row until its head is evicted (src/Model.h:3956-3968), so deferring changes
-// when a row reaches the file, not what the file holds.  Rows still pending are flushed by writeFootnote() / the
+// when a row reaches the file, not what the file holds.  A window that holds more sites than the ring makes the ring
+// grow (up to RVT_METACOV_MAX_COLUMNS); rings wider than one block of the symmetric kernel are processed as
+// heads-by-window rectangles (rvt_cov_rect).  Rows still pending are flushed by writeFootnote() / the
 // destructor, as the reference's destructor does (src/Model.cpp:828-834).
 class MetaCovTest : public ModelFitter {
  public:
@@ -265,8 +267,11 @@ class MetaCovTest : public ModelFitter {
     int pos;
   };
   int flush(bool final);
+  int grow();
   int windowSize;
-  int capacity = RVT_MAX_VARIANTS;  // columns of the device ring
+  int capacity = RVT_MAX_VARIANTS;     // columns of the device ring (grows when one window needs more)
+  int rectAbove = RVT_MAX_VARIANTS;    // widest ring handled by the symmetric block kernel
+  int maxColumns = 65536;              // RVT_METACOV_MAX_COLUMNS
   bool outputGwama = false;
   bool fitOK = false;
   bool useFamilyModel = false;

@@ -321,6 +321,51 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restric
   }
 }
 
+// ---- MetaCov for windows wider than one block: heads x window rectangle from two plain GEMMs ------------------
+// S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from rocBLAS; cs = raw column sums
+// of the W window columns (the H heads are its first H columns).  Unrelated samples only.
+__global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
+                                   double* __restrict__ xz) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W) return;
+  for (int k = 0; k < cc.d; ++k) {
+    const double t = T[j + (long long)k * W];
+    xz[(long long)j * cc.d + k] = cc.binary ? t : (t - cs[j] * cc.inv_n * cc.zsum[k]) * cc.inv_sigma2;
+  }
+}
+
+// grid = H workgroups: cov[h + j*H] for j >= h
+__global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const double* __restrict__ S,
+                                                            const double* __restrict__ cs,
+                                                            const double* __restrict__ xz, int H, int W,
+                                                            double* __restrict__ cov) {
+  const int h = blockIdx.x, d = cc.d;
+  __shared__ double a[RVT_MAX_COV];
+  if (threadIdx.x < d) {
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
+    a[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double sh = cs[h];
+  for (int j = h + threadIdx.x; j < W; j += blockDim.x) {
+    const double sxx = S[h + (long long)j * H];
+    const double xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
+    double quad = 0.0;
+    for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
+    cov[h + (long long)j * H] = xx - quad;
+  }
+}
+
+// dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)
+__global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
+                                  long long ld, double* __restrict__ dst) {
+  const double* s = src + (long long)blockIdx.y * ld;
+  double* d = dst + (long long)blockIdx.y * ld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+    d[i] = s[i] * v[i];
+}
+
 // =====================================================================================================
 // K4: p-values, one wave per gene.
 //

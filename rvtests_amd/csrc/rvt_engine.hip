@@ -589,6 +589,61 @@ struct CovOut {  // rvt_cov_block: host destinations
   const int* d_raw_poly = nullptr;
 };
 
+// covZZ / covZZInv and the other constants of the MetaCov algebra for the installed null model (or, fam = true,
+// for the family set prepared by rvt_fit_fam_null).  zz receives covZZ (cc.d x cc.d).
+int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp) {
+  const NullConsts& nc = c->nc;
+  const int d = nc.d;
+  const int64_t N = nc.N;
+  CovConsts& cc = *ccp;
+  std::vector<double>& zz = *zzp;
+  std::memset(&cc, 0, sizeof(cc));
+    cc.d = d;
+    cc.binary = nc.binary;
+    cc.inv_n = 1.0 / (double)N;
+  zz.assign((size_t)d * d, 0.0);
+    if (fam) {  // MetaCovFamQtl: constants prepared by rvt_fit_fam_null
+      const int du = d - 1;  // U'X columns (the null set carries u1 as an extra column)
+      cc.fam = 1;
+      cc.d = du;
+      cc.inv_sigma2 = 1.0;
+      cc.c11 = c->famcov_c11;
+      zz.assign((size_t)du * du, 0.0);
+      for (int a = 0; a < du; ++a) {
+        cc.zsum[a] = c->famcov_c1x[a];
+        for (int b = 0; b < du; ++b) {
+          zz[a * du + b] = c->famcov_zz[a * du + b];
+          cc.zzinv[a * du + b] = c->famcov_zzinv[a * du + b];
+        }
+      }
+    } else if (nc.binary) {  // covZZ = Z'WZ, covZZInv its inverse (MetaCovUnrelatedBinary::calculateZZ, Model.cpp:748-765)
+      cc.inv_sigma2 = 1.0;
+      for (int a = 0; a < d * d; ++a) {
+        zz[a] = nc.C[a];
+        cc.zzinv[a] = nc.Cinv[a];
+      }
+    } else {
+      // covZZ = Zc'Zc / sigma2 with centred columns (MetaCovUnrelatedQtl::calculateZZ, Model.cpp:582-591); the
+      // intercept's row/column is exactly zero and CholeskyInverseMatrix (LDLT solve) leaves it zero, so covZZInv is
+      // the inverse of the covariate block — a d x d job on null-model constants, done once per call on the host.
+      cc.inv_sigma2 = 1.0 / nc.sigma2;
+      for (int k = 0; k < d; ++k) cc.zsum[k] = nc.C[k];  // first row of X'X = 1'Z (column 0 is the intercept)
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) zz[a * d + b] = (nc.C[a * d + b] - cc.zsum[a] * cc.zsum[b] / (double)N) / nc.sigma2;
+      for (int a = 0; a < d; ++a) zz[a * d + 0] = zz[0 * d + a] = 0.0;
+      const int q = d - 1;
+      if (q > 0) {
+        std::vector<double> A((size_t)q * q), Ai((size_t)q * q);
+        for (int a = 0; a < q; ++a)
+          for (int b = 0; b < q; ++b) A[a * q + b] = zz[(a + 1) * d + (b + 1)];
+        if (!invert_spd(A.data(), q, Ai.data())) return fail(c, RVT_E_INVALID, "covariate covariance is singular");
+        for (int a = 0; a < q; ++a)
+          for (int b = 0; b < q; ++b) cc.zzinv[(a + 1) * d + (b + 1)] = Ai[a * q + b];
+      }
+    }
+  return RVT_OK;
+}
+
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
                      const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
                      DebugOut* dbg, CovOut* cov = nullptr) {
@@ -762,49 +817,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   if (cov) {  // MetaCov: finish the covariance algebra of this one block and return its band synchronously
     const int V = Ms[0];
     CovConsts cc;
-    std::memset(&cc, 0, sizeof(cc));
-    cc.d = d;
-    cc.binary = nc.binary;
-    cc.inv_n = 1.0 / (double)N;
-    std::vector<double> zz((size_t)d * d, 0.0);
-    if (cov->fam) {  // MetaCovFamQtl: constants prepared by rvt_fit_fam_null
-      const int du = d - 1;  // U'X columns (the null set carries u1 as an extra column)
-      cc.fam = 1;
-      cc.d = du;
-      cc.inv_sigma2 = 1.0;
-      cc.c11 = c->famcov_c11;
-      zz.assign((size_t)du * du, 0.0);
-      for (int a = 0; a < du; ++a) {
-        cc.zsum[a] = c->famcov_c1x[a];
-        for (int b = 0; b < du; ++b) {
-          zz[a * du + b] = c->famcov_zz[a * du + b];
-          cc.zzinv[a * du + b] = c->famcov_zzinv[a * du + b];
-        }
-      }
-    } else if (nc.binary) {  // covZZ = Z'WZ, covZZInv its inverse (MetaCovUnrelatedBinary::calculateZZ, Model.cpp:748-765)
-      cc.inv_sigma2 = 1.0;
-      for (int a = 0; a < d * d; ++a) {
-        zz[a] = nc.C[a];
-        cc.zzinv[a] = nc.Cinv[a];
-      }
-    } else {
-      // covZZ = Zc'Zc / sigma2 with centred columns (MetaCovUnrelatedQtl::calculateZZ, Model.cpp:582-591); the
-      // intercept's row/column is exactly zero and CholeskyInverseMatrix (LDLT solve) leaves it zero, so covZZInv is
-      // the inverse of the covariate block — a d x d job on null-model constants, done once per call on the host.
-      cc.inv_sigma2 = 1.0 / nc.sigma2;
-      for (int k = 0; k < d; ++k) cc.zsum[k] = nc.C[k];  // first row of X'X = 1'Z (column 0 is the intercept)
-      for (int a = 0; a < d; ++a)
-        for (int b = 0; b < d; ++b) zz[a * d + b] = (nc.C[a * d + b] - cc.zsum[a] * cc.zsum[b] / (double)N) / nc.sigma2;
-      for (int a = 0; a < d; ++a) zz[a * d + 0] = zz[0 * d + a] = 0.0;
-      const int q = d - 1;
-      if (q > 0) {
-        std::vector<double> A((size_t)q * q), Ai((size_t)q * q);
-        for (int a = 0; a < q; ++a)
-          for (int b = 0; b < q; ++b) A[a * q + b] = zz[(a + 1) * d + (b + 1)];
-        if (!invert_spd(A.data(), q, Ai.data())) return fail(c, RVT_E_INVALID, "covariate covariance is singular");
-        for (int a = 0; a < q; ++a)
-          for (int b = 0; b < q; ++b) cc.zzinv[(a + 1) * d + (b + 1)] = Ai[a * q + b];
-      }
+    std::vector<double> zz;
+    {
+      int rcc = cov_constants(c, cov->fam, &cc, &zz);
+      if (rcc) return rcc;
     }
     double* d_xz = reinterpret_cast<double*>(base + off_cov_xz);
     double* d_cs = reinterpret_cast<double*>(base + off_cov_cs);
@@ -1922,6 +1938,87 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
       sl.pending_n = 0;
     }
   }
+  return RVT_OK;
+}
+
+int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                 int* polymorphic) {
+  if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  if (!c->blas) {
+    BLAS_TRY(c, rocblas_create_handle(&c->blas));
+    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+  }
+  hipStream_t st = c->stream;
+  const NullConsts& nc = c->nc;
+  const int64_t N = nc.N, ld = nc.ld;
+  const int d = nc.d;
+  CovConsts cc;
+  std::vector<double> zzv;
+  rc = cov_constants(c, false, &cc, &zzv);
+  if (rc) return rc;
+  const double* GW = dG + (size_t)col0 * ld;
+  double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_tmp = nullptr;
+  int* d_poly = nullptr;
+  struct Guard {
+    std::vector<void**> p;
+    ~Guard() {
+      for (void** q : p)
+        if (*q) hipFree(*q);
+    }
+  } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_tmp,
+           (void**)&d_poly}};
+  HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * d));
+  HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * d));
+  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
+  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  const double* Xop = c->d_X;   // N x d operand of T = G_W' D X
+  const double* GHop = GW;      // N x H operand of S = G_H' D G_W
+  if (nc.binary) {              // carry the weights on the small operands
+    const int cols = std::max(d, H);
+    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)ld * (d + H)));
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)d), dim3(256), 0, st, c->d_X, c->d_v, (long long)N,
+                       (long long)ld, d_tmp);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)H), dim3(256), 0, st, GW, c->d_v, (long long)N,
+                       (long long)ld, d_tmp + (size_t)ld * d);
+    (void)cols;
+    Xop = d_tmp;
+    GHop = d_tmp + (size_t)ld * d;
+  }
+  {
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, W, d, (rocblas_int)N,
+                              &one, GW, (rocblas_int)ld, Xop, (rocblas_int)ld, &zero, d_T, W));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, H, W, (rocblas_int)N,
+                              &one, GHop, (rocblas_int)ld, GW, (rocblas_int)ld, &zero, d_S, H));
+  }
+  hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
+  hipLaunchKernelGGL(cov_rect_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, H, W, d_cov);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
+  return RVT_OK;
+}
+
+int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* src, int src_col, int ncols) {
+  if (!c || !dst || !src || dst_col < 0 || src_col < 0 || ncols < 0) return fail(c, RVT_E_INVALID, "bad copy");
+  if (ncols == 0) return RVT_OK;
+  hipSetDevice(c->device);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
+                       hipMemcpyDeviceToDevice));
   return RVT_OK;
 }
 

@@ -155,6 +155,10 @@ def load_library():
     L.rvt_run_fam_blocks.restype = C.c_int
     L.rvt_run_fam_blocks.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(C.c_int64),
                                      C.POINTER(GeneResult)]
+    L.rvt_cov_rect.restype = C.c_int
+    L.rvt_cov_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
+    L.rvt_block_copy_columns.restype = C.c_int
+    L.rvt_block_copy_columns.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
     L.rvt_cov_block_fam.restype = C.c_int
     L.rvt_cov_block_fam.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_cov_block.restype = C.c_int
@@ -364,6 +368,18 @@ class Engine:
         poly = np.zeros(V, dtype=np.int32)
         self._check(self.L.rvt_cov_block(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
                                          poly.ctypes.data_as(c_int_p)))
+        return cov, xz, zz, poly
+
+    def cov_rect(self, ptr, col0, H, W):
+        """Heads [col0, col0+H) against markers [col0, col0+W): (cov H x W with cov[h, j] valid for j >= h, xz W x d,
+        zz, polymorphic flags of the W markers)."""
+        d = self.d
+        cov = np.full((H, W), np.nan, order="F")
+        xz = np.zeros((W, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(W, dtype=np.int32)
+        self._check(self.L.rvt_cov_rect(self.ctx, C.c_void_p(int(ptr)), int(col0), int(H), int(W), _dp(cov), _dp(xz),
+                                        _dp(zz), poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
 
     def cov_block_fam(self, ptr, V, d):

@@ -76,3 +76,30 @@ def test_cov_block_ring_moves(engine_factory):
     got = eng.cov_block(ring, V)[0]
     iu = np.triu_indices(V)
     assert np.array_equal(got[iu], ref[iu])
+
+
+@pytest.mark.parametrize("binary", [0, 1])
+def test_cov_rect_matches_block(engine_factory, binary):
+    """The heads-by-window rectangle (two GEMMs; for windows wider than one block) gives the same band as the
+    symmetric block kernel, and the same numbers as the oracle."""
+    N, V, d = 1500, 90, 3
+    G, chrom, pos, X, y = make_case(N, V, d, binary, 321 + binary)
+    if binary:
+        rc, beta, p, v = orc.fit_logistic(X, y)
+        res, s2 = y - p, 1.0
+    else:
+        rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+        v = np.full(N, s2)
+    eng = engine_factory()
+    eng.set_null(binary, X, res, v, s2)
+    ptr = eng.upload_block(G)
+    cov, xz, zz, poly = eng.cov_block(ptr, V)
+    col0, H, W = 7, 20, 70
+    rcov, rxz, rzz, rpoly = eng.cov_rect(ptr, col0, H, W)
+    assert (rpoly == poly[col0:col0 + W]).all()
+    scale = np.nanmax(np.abs(cov[np.triu_indices(V)]))
+    for h in range(H):
+        for j in range(h, W):
+            assert abs(rcov[h, j] - cov[col0 + h, col0 + j]) <= 1e-9 * scale
+    assert np.allclose(rxz, xz[col0:col0 + W], rtol=1e-9, atol=1e-9 * max(np.abs(xz).max(), 1.0))
+    assert np.allclose(rzz, zz, rtol=1e-12, atol=0)

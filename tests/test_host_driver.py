@@ -124,10 +124,12 @@ def test_driver_output_matches_oracle(tmp_path, binary, d, batch):
             assert abs(float(row[-1]) - z.pvalue) <= 6e-6 * z.pvalue
 
 
-def run_driver_meta(path, meta, sites_path, block=None):
+def run_driver_meta(path, meta, sites_path, block=None, rect_above=None):
     env = dict(os.environ)
     if block:
         env["RVT_METACOV_BLOCK"] = str(block)
+    if rect_above:
+        env["RVT_METACOV_RECT_ABOVE"] = str(rect_above)
     p = subprocess.run([DRIVER, path, "-", "-", meta, sites_path], capture_output=True, text=True, timeout=300,
                        env=env)
     lines = [ln for ln in p.stdout.splitlines()]
@@ -157,9 +159,10 @@ def test_meta_registry_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("binary,gwama,block", [(0, False, None), (0, True, None), (1, False, None), (0, False, 16),
-                                                (1, True, 19)])
-def test_driver_metacov_rows_match_oracle(tmp_path, binary, gwama, block):
+@pytest.mark.parametrize("binary,gwama,block,rect", [(0, False, None, None), (0, True, None, None),
+                                                     (1, False, None, None), (0, False, 16, None),
+                                                     (1, True, 19, None), (0, False, 8, 8), (1, True, 8, 12)])
+def test_driver_metacov_rows_match_oracle(tmp_path, binary, gwama, block, rect):
     """--meta cov through the C++ adapter: row structure (window rule, monomorphic sites skipped, chromosome change)
     identical to the oracle's, numbers equal to its fp64 values after the reference's float / 1/N / %g formatting."""
     _ensure_driver()
@@ -180,9 +183,12 @@ def test_driver_metacov_rows_match_oracle(tmp_path, binary, gwama, block):
     window = 1200
     # block: a device ring far smaller than the stream, so rows are emitted by several mid-stream flushes with
     # compaction in between (the window then has to fit the ring: at most ~10 sites per window here)
-    if block:
+    if block and not rect:
         window = 450
-    rc, lines, err = run_driver_meta(path, "cov[windowSize=%d%s]" % (window, ":gwama" if gwama else ""), sites, block)
+    # rect: the ring starts smaller than one window (it has to grow) and everything wider than `rect` columns goes
+    # through the heads-by-window rectangle instead of the symmetric block kernel
+    rc, lines, err = run_driver_meta(path, "cov[windowSize=%d%s]" % (window, ":gwama" if gwama else ""), sites, block,
+                                     rect)
     assert rc == 0, err
     assert lines[0] == "== out.MetaCov.assoc"
     rows = [ln.split("\t") for ln in lines[2:]]
