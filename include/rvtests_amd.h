@@ -1,7 +1,7 @@
 /* rvtests_amd — C ABI of the MI355X kernel/burden association engine.
  *
  * This is the drop-in boundary for the rvtests hot path: the entry points below are what GPU-backed
- * `ModelFitter` subclasses (SkatTest, SkatOTest, CMCTest, ZegginiTest — see
+ * `ModelFitter` subclasses (SkatTest, SkatOTest, CMCTest, ZegginiTest, FamSkatTest, MetaCovTest — see
  * rvtests_amd/csrc/host/ModelFitterGpu.h and INTEGRATION.md) call instead of
  *   Skat::Fit                         /root/reference/regression/Skat.h:26-31   (Skat.cpp:29-105)
  *   SkatO::Fit                        regression/SkatO.h:28-35                  (SkatO.cpp:101-281,500-519)
@@ -9,6 +9,12 @@
  *   LinearRegressionScoreTest::TestCovariate(Matrix,Vector,Matrix)      regression/LinearRegressionScoreTest.cpp:173-263
  *   LogisticRegressionScoreTest::TestCovariate(Matrix,Vector,Matrix)    regression/LogisticRegressionScoreTest.cpp:220-302
  *   DataConsolidator::getFlippedToMinorPolymorphicGenotype               src/DataConsolidator.h:128-132
+ *   Skat::GetQFromNewResidual + Permutation (skat[nPerm>0])               regression/Skat.cpp:107-116, src/Permutation.h:69-98
+ *   LinearRegression::FitLinearModel / LogisticRegression::FitLogisticModel   regression/LinearRegression.cpp:20-69,
+ *                                                                             regression/LogisticRegression.cpp:279-336
+ *   FamSkat::FitNullModel / TestCovariate, FastLMM::FitNullModel / FastGetAF  regression/FamSkat.cpp:34-138,
+ *                                                                             regression/FastLMM.cpp:28-142,402-443
+ *   MetaCovTest (MetaCovUnrelatedQtl / UnrelatedBinary / FamQtl)          src/Model.cpp:437-1004
  * Plain C, plain pointers and sizes; no C++ or torch types cross it.  All functions return 0 on
  * success and a negative RVT_E_* code on failure; rvt_last_error() gives the text.  One calling
  * thread per context; one context per GPU (one process per GPU).
