@@ -951,11 +951,13 @@ int rvt_run_blocks_async(rvt_ctx* c, int n, const double* const* dG, const int* 
                          const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
   if (c && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT))
     return fail(c, RVT_E_STATE, "permutation p-values need the synchronous rvt_run_blocks / rvt_collect");
+  if (c && (tests & RVT_TEST_FAMSKAT)) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
   return run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
 }
 
 int rvt_run_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af, const int64_t* ids,
                    uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
+  if (c && (tests & RVT_TEST_FAMSKAT)) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
   if (c && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) {
     int rc0 = rvt_sync(c);
     if (rc0) return rc0;
@@ -2134,6 +2136,8 @@ int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const d
                     const rvt_params* prm) {
   if (!c || !G || !af || M < 1) return fail(c, RVT_E_INVALID, "bad gene");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (tests & RVT_TEST_FAMSKAT) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
+  if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene of %d variants exceeds RVT_MAX_VARIANTS", M);
   hipSetDevice(c->device);
   rvt_ctx::Pending p;
   p.id = gene_id;
