@@ -252,6 +252,11 @@ int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const
  * GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same contract as rvt_cov_block, with the null model
  * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  The binary family variant is not provided. */
 int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
+/* MetaCovFamBinary (src/Model.cpp:595-692): after rvt_fit_fam_null on the 0/1 phenotype, scale everything
+ * rvt_cov_block_fam returns by b^2, b = obtainB(alpha) = integral of logistic'(alpha + x) phi(x) dx
+ * (src/Model.cpp:339-369; the reference uses gsl_integration_qagi with epsrel 1e-7), alpha = log(n_case / n_ctrl) kept
+ * as float, 500 without controls.  The factor stays until the next rvt_fit_fam_null.  Outputs may be NULL. */
+int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* alpha_out, double* b_out);
 
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */

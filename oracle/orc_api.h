@@ -134,11 +134,22 @@ int orc_fastlmm_null(const double* X, const double* y, int64_t N, int d, const d
 int orc_famskat(const double* G, int64_t N, int M, const double* X, const double* y, int d, const double* U,
                 const double* S, const orc_fam_null* nul, int use_float, orc_kernel_result* out);
 
+/* obtainB (src/Model.cpp:339-369): b = integral over R of logistic'(alpha + x) phi(x) dx, evaluated by the reference
+   with gsl_integration_qagi (epsrel 1e-7).  Restated with the QAGS restatement on QAGI's own change of variable
+   x = (1 - t) / t over (0, 1] (both half lines folded); the integrand is smooth, so the two adaptive rules agree far
+   below the 6 digits that are printed. */
+double orc_obtain_b(double alpha);
 /* MetaCovTest with kinship, quantitative trait (MetaCovFamQtl, src/Model.cpp:437-504 over FastLMM::TransformCentered /
    GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same outputs as orc_metacov. */
 int orc_metacov_fam(const double* G, int64_t N, int V, const int* chrom, const int* pos, const double* X, int d,
                     const double* U, const double* S, const orc_fam_null* nul, int window, int use_float, int* kept,
                     double* cov, int* row_end, double* xz, double* zz);
+/* MetaCovFamBinary (src/Model.cpp:595-692): the same with covXX, covXZ, covZZ scaled by b^2, b = obtainB(alpha),
+   alpha = log(nCase / nCtrl) stored as float (500 when there is no control); y is the 0/1 phenotype the FastLMM null
+   (`nul`) was fitted to. */
+int orc_metacov_fam_binary(const double* G, int64_t N, int V, const int* chrom, const int* pos, const double* X, int d,
+                           const double* y, const double* U, const double* S, const orc_fam_null* nul, int window,
+                           int use_float, int* kept, double* cov, int* row_end, double* xz, double* zz);
 
 /* ---- MetaCovTest for unrelated samples (src/Model.cpp:844-1004; MetaCovUnrelatedQtl :506-593,
         MetaCovUnrelatedBinary :694-778; window rule src/Model.h:3956-3990).

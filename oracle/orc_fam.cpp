@@ -496,4 +496,45 @@ int orc_metacov_fam(const double* Gp, int64_t N, int V, const int* chrom, const 
   return 0;
 }
 
+static double obtain_b_integrand(double t, void* p) {
+  const double alpha = *(const double*)p;
+  if (t <= 0.0) return 0.0;
+  const double x = (1.0 - t) / t;
+  auto f = [&](double xx) {  // fIntegrand, src/Model.cpp:339-348
+    if (xx > 500 || xx < -500) return 0.0;
+    const double tmp = std::exp(alpha + xx);
+    if (!std::isfinite(tmp)) return 0.0;  // (alpha = 500, the no-control case, overflows in the reference: NaN there)
+    const double k = 1.0 / std::sqrt(2.0 * 3.1415926535897);
+    return tmp / (1. + tmp) / (1. + tmp) * k * std::exp(-xx * xx * 0.5);
+  };
+  return (f(x) + f(-x)) / (t * t);
+}
+
+double orc_obtain_b(double alpha) {
+  double res = 0, err = 0;
+  int neval = 0;
+  orc_qags(obtain_b_integrand, &alpha, 0.0, 1.0, 0.0, 1e-10, 1000, &res, &err, &neval);
+  return res;
+}
+
+int orc_metacov_fam_binary(const double* Gp, int64_t N, int V, const int* chrom, const int* pos, const double* Xp,
+                           int d, const double* y, const double* Up, const double* S, const orc_fam_null* nul,
+                           int window, int use_float, int* kept, double* cov, int* row_end, double* xz, double* zz) {
+  int nCase = 0, nCtrl = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    if (y[i] == 1) ++nCase;
+    else if (y[i] == 0) ++nCtrl;
+  }
+  const float alpha = (nCtrl > 0) ? (float)std::log(1.0 * nCase / nCtrl) : 500.f;  // `float alpha` member
+  const float b = (float)orc_obtain_b((double)alpha);                              // `float b` member
+  const int rc = orc_metacov_fam(Gp, N, V, chrom, pos, Xp, d, Up, S, nul, window, use_float, kept, cov, row_end, xz, zz);
+  if (rc) return rc;
+  // covXX, covXZ, covZZ are each multiplied by b*b (Model.cpp:651-668); value = xx - xz' zz^-1 xz scales by b^2 too
+  const double b2 = (double)b * (double)b;
+  for (size_t i = 0; i < (size_t)V * V; ++i) cov[i] *= b2;
+  for (size_t i = 0; i < (size_t)V * d; ++i) xz[i] *= b2;
+  for (int i = 0; i < d * d; ++i) zz[i] *= b2;
+  return 0;
+}
+
 }  // extern "C"

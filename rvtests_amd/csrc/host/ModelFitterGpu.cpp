@@ -398,13 +398,21 @@ int MetaCovTest::fit(GeneData* dc) {
     return -1;
   }
   useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaCovFamQtl instead of MetaCovUnrelatedQtl
-  if (useFamilyModel && isBinaryOutcome()) {
-    lastError = "MetaCov with kinship for binary traits (MetaCovFamBinary) is not provided by the GPU backend";
-    return -1;
-  }
   ctx = useFamilyModel ? GpuBroker::instance().contextWithFamNull(*dc, &lastError)
                        : GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
   if (!ctx) return -1;
+  if (useFamilyModel && isBinaryOutcome() && (nSample < 0 || dc->phenotypeUpdated)) {
+    // MetaCovFamBinary::FitNullModel (src/Model.cpp:598-640): alpha = log(nCase / nCtrl), b = obtainB(alpha)
+    int64_t nCase = 0, nCtrl = 0;
+    for (int64_t i = 0; i < dc->N; ++i) {
+      if (dc->phenotype[i] == 1) ++nCase;
+      else if (dc->phenotype[i] == 0) ++nCtrl;
+    }
+    if (rvt_fam_binary_scale(ctx, nCase, nCtrl, nullptr, nullptr)) {
+      lastError = rvt_last_error(ctx);
+      return -1;
+    }
+  }
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;

@@ -92,6 +92,7 @@ struct rvt_ctx {
   NullConsts famcov_nc;
   NullConsts* d_famcov_nc = nullptr;
   double *d_cX = nullptr, *d_cv = nullptr;
+  double famcov_b2 = 1.0;  // MetaCovFamBinary: b^2
   double famcov_c11 = 0.0, famcov_c1x[RVT_MAX_COV], famcov_zz[RVT_MAX_COV * RVT_MAX_COV],
          famcov_zzinv[RVT_MAX_COV * RVT_MAX_COV];
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
@@ -1189,6 +1190,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
     *p = nullptr;
   }
   c->have_fam = false;
+  c->famcov_b2 = 1.0;
   const int dx = d + 1;
   double* d_xy = nullptr;  // N x (d+1): X | y
   HIP_TRY(c, hipMalloc((void**)&d_xy, sizeof(double) * (size_t)N * dx));
@@ -1457,7 +1459,39 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
       sl.pending_out = nullptr;
       sl.pending_n = 0;
     }
+  if (!rc && c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
+    const double b2 = c->famcov_b2;
+    const int du = c->famcov_nc.d - 1;
+    for (int h = 0; h < V; ++h)
+      for (int j = h; j < V; ++j) cov[(size_t)h + (size_t)j * V] *= b2;
+    for (size_t i = 0; i < (size_t)V * du; ++i) xz[i] *= b2;
+    if (zz)
+      for (int i = 0; i < du * du; ++i) zz[i] *= b2;
+  }
   return rc;
+}
+
+int rvt_fam_binary_scale(rvt_ctx* c, int64_t n_case, int64_t n_ctrl, double* alpha_out, double* b_out) {
+  if (!c || n_case < 0 || n_ctrl < 0) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_fit_fam_null first");
+  const float alpha = (n_ctrl > 0) ? (float)std::log(1.0 * (double)n_case / (double)n_ctrl) : 500.f;
+  // b = int logistic'(alpha + x) phi(x) dx.  The integrand is analytic and decays like exp(-x^2/2), for which the
+  // trapezoidal rule converges geometrically: h = 1/64 over [-40, 40] is exact to rounding (the reference's QAGI
+  // stops at 1e-7 relative).  A scalar constant of the null model, evaluated once.
+  const double a = (double)alpha, h = 1.0 / 64.0;
+  double sum = 0.0;
+  for (int i = -40 * 64; i <= 40 * 64; ++i) {
+    const double x = i * h;
+    const double t = std::exp(a + x);
+    const double k = 1.0 / std::sqrt(2.0 * 3.1415926535897);  // the reference's constant (src/Model.cpp:343)
+    const double f = std::isfinite(t) ? t / (1. + t) / (1. + t) * k * std::exp(-x * x * 0.5) : 0.0;
+    sum += f;
+  }
+  const float b = (float)(sum * h);  // `float b` member (src/Model.cpp:680)
+  c->famcov_b2 = (double)b * (double)b;
+  if (alpha_out) *alpha_out = alpha;
+  if (b_out) *b_out = b;
+  return RVT_OK;
 }
 
 int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const int64_t* ids,

@@ -155,6 +155,8 @@ def load_library():
     L.rvt_run_fam_blocks.restype = C.c_int
     L.rvt_run_fam_blocks.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(C.c_int64),
                                      C.POINTER(GeneResult)]
+    L.rvt_fam_binary_scale.restype = C.c_int
+    L.rvt_fam_binary_scale.argtypes = [vp, C.c_int64, C.c_int64, c_double_p, c_double_p]
     L.rvt_cov_rect.restype = C.c_int
     L.rvt_cov_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_copy_columns.restype = C.c_int
@@ -369,6 +371,12 @@ class Engine:
         self._check(self.L.rvt_cov_block(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
                                          poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
+
+    def fam_binary_scale(self, n_case, n_ctrl):
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self.L.rvt_fam_binary_scale(self.ctx, int(n_case), int(n_ctrl), C.cast(C.byref(a), c_double_p),
+                                                C.cast(C.byref(b), c_double_p)))
+        return a.value, b.value
 
     def cov_rect(self, ptr, col0, H, W):
         """Heads [col0, col0+H) against markers [col0, col0+W): (cov H x W with cov[h, j] valid for j >= h, xz W x d,

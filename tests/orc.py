@@ -363,3 +363,33 @@ def metacov_fam(G, chrom, pos, X, U, S, nul, window, use_float=False):
     rc = L.orc_metacov_fam(_dp(G), C.c_int64(N), V, _ip(chrom), _ip(pos), _dp(X), d, _dp(U), _dp(S), C.byref(nul),
                            int(window), int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz), _dp(zz))
     return rc, kept, cov, row_end, xz, zz
+
+
+def obtain_b(alpha):
+    L = lib()
+    L.orc_obtain_b.restype = C.c_double
+    L.orc_obtain_b.argtypes = [C.c_double]
+    return L.orc_obtain_b(float(alpha))
+
+
+def metacov_fam_binary(G, chrom, pos, X, y, U, S, nul, window, use_float=False):
+    G = F(G)
+    X = F(X)
+    U = F(U)
+    N, V = G.shape
+    d = X.shape[1]
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    chrom = np.ascontiguousarray(chrom, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    kept = np.zeros(V, dtype=np.int32)
+    row_end = np.zeros(V, dtype=np.int32)
+    cov = np.zeros((V, V), order="F")
+    xz = np.zeros((V, d))
+    zz = np.zeros((d, d))
+    L = lib()
+    L.orc_metacov_fam_binary.restype = C.c_int
+    rc = L.orc_metacov_fam_binary(_dp(G), C.c_int64(N), V, _ip(chrom), _ip(pos), _dp(X), d, _dp(y), _dp(U), _dp(S),
+                                  C.byref(nul), int(window), int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz),
+                                  _dp(zz))
+    return rc, kept, cov, row_end, xz, zz

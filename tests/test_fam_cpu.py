@@ -139,3 +139,12 @@ def test_brent_restatement_matches_gsl_fixture():
         else:
             seen_fail = True
     assert seen_fail
+
+
+def test_obtain_b_matches_scipy_quad():
+    from scipy.integrate import quad
+    for alpha in (-3.0, -0.4054651, 0.0, 1.2, 4.0):
+        f = lambda x: (lambda t: t / (1 + t) ** 2)(np.exp(alpha + x)) * np.exp(-x * x / 2) / np.sqrt(2 * 3.1415926535897) \
+            if alpha + x < 700 else 0.0
+        want = quad(f, -40, 40, epsabs=0, epsrel=1e-12, limit=400)[0]
+        assert abs(orc.obtain_b(alpha) - want) <= 1e-9 * max(want, 1e-300) + 1e-300

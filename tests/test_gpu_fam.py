@@ -93,3 +93,30 @@ def test_metacov_fam_matches_oracle(eng, n_fam, d, V):
     kk = kept.astype(bool)
     assert np.allclose(xz[kk], oxz[kk], rtol=1e-8, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
     assert np.allclose(zz, ozz, rtol=1e-9)
+
+
+def test_metacov_fam_binary_scale(eng):
+    """MetaCovFamBinary: the family covariance of a 0/1 phenotype scaled by b^2 (b = obtainB(alpha))."""
+    N, K, U, S, X, y = make_family_case(50, 2, 77)
+    yb = (y > np.median(y)).astype(np.float64)
+    yb[:7] = 1.0
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, yb)
+    alpha, b = eng.fam_binary_scale(int(yb.sum()), int(N - yb.sum()))
+    assert abs(b - orc.obtain_b(alpha)) <= 2e-7 * b              # float storage of b
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(2):
+        onul.beta[k] = nul.beta[k]
+    V = 20
+    _, G, af = synth.make_gene(N, V, seed=41, missing=0.02, common=True, mono=True)
+    pos = np.cumsum(np.random.default_rng(6).integers(1, 300, V)).astype(np.int32)
+    chrom = np.ones(V, dtype=np.int32)
+    ptr = eng.upload_block(G)
+    cov, xz, zz, poly = eng.cov_block_fam(ptr, V, 2)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov_fam_binary(G, chrom, pos, X, yb, U, S, onul, 2500)
+    assert rc == 0 and (poly == kept).all()
+    m = ~np.isnan(ocov)
+    assert np.abs(cov[m] - ocov[m]).max() < 1e-6 * np.abs(ocov[m]).max()      # b is a float on both sides
+    assert np.allclose(zz, ozz, rtol=1e-6)
