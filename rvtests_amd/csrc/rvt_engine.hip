@@ -370,7 +370,17 @@ int rvt_init(rvt_ctx** out, int device_id) {
         (b < stage2_cus ? m2 : m1)[b / 32] |= 1u << (b % 32);
       }
     }
-    masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
+    // The streaming stage is the critical path of the pipeline: its stream is an ordinary stream at the HIGHEST queue
+    // priority, so the dispatcher hands free SIMDs to its workgroups first (+3 %); the batch streams keep dedicated
+    // default-priority queues through the CU-mask constructor.  RVT_K2_HIGH=0 restores a CU-mask stream for it too.
+    const char* k2h = getenv("RVT_K2_HIGH");
+    if ((!k2h || atoi(k2h) != 0) && stage2_cus == 0) {
+      int lo = 0, hi = 0;
+      hipDeviceGetStreamPriorityRange(&lo, &hi);
+      masked = hipStreamCreateWithPriority(&c->k2_stream, hipStreamNonBlocking, hi) == hipSuccess;
+    } else {
+      masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
+    }
     for (int i = 0; masked && i < kSlots; ++i)
       masked = hipExtStreamCreateWithCUMask(&c->slots[i].stream, words, m2.data()) == hipSuccess;
     if (!masked) {
