@@ -791,7 +791,14 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
   std::vector<int> order(n);
   for (int g = 0; g < n; ++g) order[g] = g;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return desc[a].M > desc[b].M; });
+  // genes whose tile configuration has no unrolled body (more than 6 row tiles, or — with many covariates — more than
+  // one extra column tile) go to the panelled kernel; they come first
+  auto needs_panel = [&](const GeneDesc& g) { return g.MT > kMaxMT || g.CT > g.MT + 1; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const bool pa = needs_panel(desc[a]), pb = needs_panel(desc[b]);
+    if (pa != pb) return pa;
+    return desc[a].M > desc[b].M;
+  });
   for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
   GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
   HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, st));
@@ -804,7 +811,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
   int k0 = 0;
-  while (k0 < n && h_desc[k0].MT > kMaxMT) ++k0;  // widest first: these need the panelled kernel
+  while (k0 < n && needs_panel(h_desc[k0])) ++k0;  // these need the panelled kernel
   if (k0 > 0) {
     Scope sc(c, 0, c->k2_stream);
     const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;

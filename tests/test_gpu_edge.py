@@ -1,0 +1,75 @@
+"""Edge cases of the hot path through the C ABI: many covariates (tile shapes without an unrolled body go to the
+panelled kernel), tiny sample counts, empty batches, single-variant and all-monomorphic genes, oversize genes."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+from test_gpu_parity import _check_gene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("binary,d", [(0, 16), (0, 9), (1, 1), (0, 13)])
+def test_many_covariates_and_all_tile_shapes(engine, binary, d):
+    """d up to RVT_MAX_COV: M + d + 1 can need two column tiles more than row tiles — (1,3), (2,4), ... have no
+    unrolled body and must take the panelled kernel, in one batch with the ordinary classes."""
+    N = 2500
+    Ms = (1, 3, 15, 16, 17, 31, 32, 40, 63, 64, 80, 95, 96, 100)
+    genes = [synth.make_gene(N, M, seed=7 * M + d, missing=0.01 if M % 2 else 0.0, common=(M % 3 == 0),
+                             mono=(M > 4), maf_hi=-1.0)[1:] for M in Ms]
+    X, y, res, v, s2 = synth.make_null(N, d, binary, seed=3 + d, G_effect=0.4 * genes[5][0][:, :3].sum(1))
+    engine.set_null(binary, X, res, v, s2)
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+    for p in ptrs:
+        engine.free_block(p)
+    for r, (G, af) in zip(out, genes):
+        _check_gene(r, G, af, X, y, res, v, binary, d)
+
+
+@pytest.mark.parametrize("N", [15, 17, 33])
+def test_tiny_sample_counts(engine, N):
+    """fewer samples than one 16-sample step / not a multiple of 16 (guarded last step, rank <= N eigenvalue rule)"""
+    rng = np.random.default_rng(N)
+    genes = []
+    for M in (2, 5, 20):
+        G = rng.integers(0, 3, size=(N, M)).astype(np.float64)
+        G[:, 0] = rng.permutation(np.r_[np.ones(3), np.zeros(N - 3)])
+        af = 0.5 * G.sum(0) / N
+        genes.append((G, af))
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=N)
+    engine.set_null(0, X, res, v, s2)
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+    for r, (G, af) in zip(out, genes):
+        _check_gene(r, G, af, X, y, res, v, 0, 2)
+
+
+def test_empty_batch_and_degenerate_genes(engine):
+    import rvtests_amd
+    N = 400
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=1)
+    engine.set_null(0, X, res, v, s2)
+    # n = 0 is a no-op
+    assert engine.L.rvt_run_blocks(engine.ctx, 0, None, None, None, None, 15, None, None) == 0
+    genes = [(np.zeros((N, 4)), np.zeros(4)),                       # all monomorphic (zero)
+             (np.full((N, 2), 2.0), np.ones(2)),                    # all monomorphic (non-zero)
+             (np.r_[np.ones(5), np.zeros(N - 5)].reshape(N, 1), np.array([2.5 / N]))]   # single variant
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+    for r, (G, af) in zip(out, genes):
+        _check_gene(r, G, af, X, y, res, v, 0, 2)
+    assert out[0].n_poly == 0 and out[1].n_poly == 0 and out[2].n_poly == 1
+
+
+def test_oversize_gene_is_refused(engine):
+    import rvtests_amd
+    N = 64
+    X, y, res, v, s2 = synth.make_null(N, 1, 0, seed=2)
+    engine.set_null(0, X, res, v, s2)
+    M = 1025                                                         # RVT_MAX_VARIANTS + 1
+    G = np.random.default_rng(0).integers(0, 3, size=(N, M)).astype(np.float64)
+    ptr = engine.upload_block(G)
+    with pytest.raises(rvtests_amd.RvtError):
+        engine.run_blocks([ptr], [M], [0.5 * G.sum(0) / N])
