@@ -981,9 +981,19 @@ int rvt_run_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, con
     if (rc0) return rc0;
     return run_blocks_with_perm(c, n, dG, M, af, ids, tests, prm, out);
   }
-  int rc = run_batch(c, n, dG, M, af, ids, tests, prm, out, nullptr);
+  // batches of at most 256 genes (bounded work space per batch); consecutive batches pipeline over the slots
+  size_t afo = 0;
+  for (int g0 = 0; g0 < n; g0 += 256) {
+    const int nb = std::min(256, n - g0);
+    int rc = run_batch(c, nb, dG + g0, M + g0, af + afo, ids ? ids + g0 : nullptr, tests, prm, out + g0, nullptr);
+    if (rc) return rc;
+    for (int g = g0; g < g0 + nb; ++g) afo += (size_t)M[g];
+  }
+  int rc = rvt_sync(c);
   if (rc) return rc;
-  return rvt_sync(c);
+  if (!ids)
+    for (int g = 0; g < n; ++g) out[g].gene_id = g;
+  return RVT_OK;
 }
 
 int rvt_debug_collapse(rvt_ctx* c, const double* dG, int M, double* cmc_out, double* zeg_out, int* flipped_out,

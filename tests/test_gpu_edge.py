@@ -73,3 +73,20 @@ def test_oversize_gene_is_refused(engine):
     ptr = engine.upload_block(G)
     with pytest.raises(rvtests_amd.RvtError):
         engine.run_blocks([ptr], [M], [0.5 * G.sum(0) / N])
+
+
+def test_large_gene_list_is_chunked(engine):
+    """rvt_run_blocks splits long lists into batches of 256 genes; records come back in the caller's order."""
+    N, n = 300, 600
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=5)
+    engine.set_null(0, X, res, v, s2)
+    genes = [synth.make_gene(N, 1 + (g % 7), seed=g, missing=0.0, common=True, mono=False)[1:] for g in range(n)]
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+    assert [r.gene_id for r in out] == list(range(n))
+    for g in (0, 255, 256, 257, 511, 512, 599):
+        r, (G, af) = out[g], genes[g]
+        rc, a = orc.skat(G, af, X, res, v, 0)
+        assert r.n_variants == G.shape[1] and r.n_poly == a.n_poly
+        if a.n_poly:
+            assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
