@@ -258,6 +258,20 @@ int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double
  * as float, 500 without controls.  The factor stays until the next rvt_fit_fam_null.  Outputs may be NULL. */
 int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* alpha_out, double* b_out);
 
+/* ---- raw / packed genotypes at the boundary (SURVEY §8f "next" #1) --------------------------------------------------
+ * Like rvt_submit_gene, but the block is what the genotype extractor produced, BEFORE DataConsolidator::consolidate:
+ * missing genotypes are negative (-9, libVcf/VCFConstant.h:4).  The device then does what consolidate() does to the
+ * genotype matrix: GenotypeCounter allele frequencies (src/GenotypeCounter.h:14-51; missing counted in the
+ * denominator) and imputeGenotypeToMean with its integer-truncated allele count (src/DataConsolidator.cpp:217-245).
+ *   rvt_submit_gene_raw : N x M doubles, column-major (hard calls or dosages)
+ *   rvt_submit_gene_i8  : N x M int8, column-major (hard calls 0/1/2, negative = missing): 1 byte per genotype over
+ *                         PCIe instead of 8
+ * af_out (M, may be NULL) receives the allele frequencies the tests use (dc->getMarkerFrequency). */
+int rvt_submit_gene_raw(rvt_ctx* ctx, int64_t gene_id, int M, const double* Graw, uint32_t tests,
+                        const rvt_params* params, double* af_out);
+int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
+                       const rvt_params* params, double* af_out);
+
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */
 int rvt_debug_collapse(rvt_ctx* ctx, const double* dG, int M, double* cmc_out, double* zeg_out,

@@ -88,6 +88,84 @@ __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict_
   }
 }
 
+// ---- genotype consolidation on the device (the "next" row of the boundary: raw / packed genotypes) -------------------
+// One workgroup per variant column.  Reproduces, for a column of raw genotypes (missing = negative):
+//   GenotypeCounter::add / getAF   (src/GenotypeCounter.h:14-51): AF = 0.5 * sum{0 <= g <= 2} g / nSample, g < 0 or g > 2
+//                                  count as missing, nSample counts every sample
+//   DataConsolidator::imputeGenotypeToMean (src/DataConsolidator.cpp:217-245): only when the counter saw a missing
+//                                  value; `int ac` accumulates every g >= 0 with truncation after each addition
+//                                  (quirk #5), an = 2 * #{g >= 0}; g < 0 <- 2 * ac / an
+// For integer-valued columns (hard calls) the truncating accumulation is an exact integer sum and is reduced in
+// parallel; a column that mixes fractional dosages with missing values replays the reference's sequential
+// accumulation on one lane.  SRC is double (in place) or int8 (packed hard calls, expanded to fp64).
+template <typename SRC>
+__global__ __launch_bounds__(256) void consolidate_kernel(const SRC* __restrict__ src, long long src_ld, long long N,
+                                                          long long ld, double* __restrict__ dst,
+                                                          double* __restrict__ af_out) {
+  __shared__ double s_sum[256], s_ac[256];
+  __shared__ long long s_cnt[256];
+  __shared__ int s_flag[256];
+  __shared__ double s_fill;
+  const SRC* col = src + (long long)blockIdx.x * src_ld;
+  double* out = dst + (long long)blockIdx.x * ld;
+  double sumAC = 0.0, ac = 0.0;
+  long long nonneg = 0;
+  int flags = 0;  // bit 0: counter saw a missing value; bit 1: a value < 0 exists; bit 2: a fractional value >= 0
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const double g = (double)col[i];
+    if (g < 0.0) {
+      flags |= 3;
+    } else {
+      if (g <= 2.0)
+        sumAC += g;
+      else
+        flags |= 1;
+      ac += g;
+      ++nonneg;
+      if (g != floor(g)) flags |= 4;
+    }
+  }
+  s_sum[threadIdx.x] = sumAC;
+  s_ac[threadIdx.x] = ac;
+  s_cnt[threadIdx.x] = nonneg;
+  s_flag[threadIdx.x] = flags;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+      s_ac[threadIdx.x] += s_ac[threadIdx.x + off];
+      s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
+      s_flag[threadIdx.x] |= s_flag[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    af_out[blockIdx.x] = N ? 0.5 * s_sum[0] / (double)N : -1.0;
+    double fill = 0.0;
+    if ((s_flag[0] & 1) && (s_flag[0] & 2)) {
+      const long long an = 2 * s_cnt[0];
+      int aci;
+      if (s_flag[0] & 4) {  // fractional dosages: the reference's truncating running sum, in sample order
+        aci = 0;
+        for (long long i = 0; i < N; ++i) {
+          const double g = (double)col[i];
+          if (g >= 0.0) aci = (int)((double)aci + g);
+        }
+      } else {
+        aci = (int)s_ac[0];
+      }
+      fill = (an == 0) ? 0.0 : 2.0 * (1.0 * aci / (double)an);
+    }
+    s_fill = fill;
+  }
+  __syncthreads();
+  const double fill = s_fill;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const double g = (double)col[i];
+    out[i] = (g < 0.0) ? fill : g;
+  }
+}
+
 // ---- unrelated null models on the device (LinearRegression.cpp:20-69, LogisticRegression.cpp:279-336) ----------------
 // One IRLS round: p = 1/(1+exp(-X beta)), V = p(1-p) stored; per-workgroup partial record
 //   D = X'VX (d x d), r = X'(y - p) (d), dev = sum y log p + (1-y) log(1-p)      -> lmm_rec_len(d) doubles (last slot unused... dev in slot d*d+d)

@@ -99,6 +99,11 @@ struct rvt_ctx {
   double* d_Gt = nullptr;  // ... rotated by U'
   size_t fam_cols_cap = 0;
   rocblas_handle blas = nullptr;
+  // raw / packed genotype submission
+  double* d_consol_af = nullptr;
+  size_t consol_af_cap = 0;
+  void* d_consol_i8 = nullptr;
+  size_t consol_i8_cap = 0;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
   uint32_t rand_state[31];
   int64_t jump_N = -1;                 // J = A^(jump_N - 1) is cached for this sample count
@@ -465,6 +470,8 @@ void rvt_destroy(rvt_ctx* c) {
   for (void* p : {(void*)c->d_perm_idx, (void*)c->d_perm_states, (void*)c->d_perm_R, (void*)c->d_perm_C,
                   (void*)c->d_perm_Q, (void*)c->d_perm_cur})
     if (p) hipFree(p);
+  if (c->d_consol_af) hipFree(c->d_consol_af);
+  if (c->d_consol_i8) hipFree(c->d_consol_i8);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   if (c->blas) rocblas_destroy_handle(c->blas);
   delete c;
@@ -2193,9 +2200,11 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
 }
 }  // namespace
 
-int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
-                    const rvt_params* prm) {
-  if (!c || !G || !af || M < 1) return fail(c, RVT_E_INVALID, "bad gene");
+namespace {
+// mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto)
+int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
+                  uint32_t tests, const rvt_params* prm) {
+  if (!c || !G || M < 1 || (mode == 0 && !af)) return fail(c, RVT_E_INVALID, "bad gene");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (tests & RVT_TEST_FAMSKAT) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
   if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene of %d variants exceeds RVT_MAX_VARIANTS", M);
@@ -2221,17 +2230,81 @@ int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const d
     if (rc) return rc;
     p.bytes = need;
   }
-  int rc = rvt_block_upload(c, p.dG, M, G);  // synchronous copy: the caller may overwrite G on return
-  if (rc) {
-    c->block_pool.emplace_back(p.bytes, p.dG);
-    return rc;
+  auto give_back = [&]() { c->block_pool.emplace_back(p.bytes, p.dG); };
+  const int64_t N = c->nc.N, ld = c->null_ld;
+  if (mode == 0) {
+    int rc = rvt_block_upload(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
+    if (rc) {
+      give_back();
+      return rc;
+    }
+    p.af.assign(af, af + M);
+  } else {
+    // DataConsolidator::consolidate's genotype part on the device: counter AF + mean imputation
+    hipStream_t st = c->stream;
+    const size_t afb = sizeof(double) * (size_t)M;
+    if (c->consol_af_cap < (size_t)M) {
+      if (c->d_consol_af) hipFree(c->d_consol_af);
+      c->d_consol_af = nullptr;
+      c->consol_af_cap = 0;
+      if (hipMalloc((void**)&c->d_consol_af, sizeof(double) * RVT_MAX_VARIANTS) != hipSuccess) {
+        give_back();
+        return fail(c, RVT_E_HIP, "hipMalloc failed");
+      }
+      c->consol_af_cap = RVT_MAX_VARIANTS;
+    }
+    hipError_t e = hipSuccess;
+    if (mode == 1) {
+      int rc = rvt_block_upload(c, p.dG, M, (const double*)G);
+      if (rc) {
+        give_back();
+        return rc;
+      }
+      hipLaunchKernelGGL((consolidate_kernel<double>), dim3((unsigned)M), dim3(256), 0, st, p.dG, (long long)ld,
+                         (long long)N, (long long)ld, p.dG, c->d_consol_af);
+    } else {
+      const size_t bytes8 = (size_t)N * M;
+      if (c->consol_i8_cap < bytes8) {
+        if (c->d_consol_i8) hipFree(c->d_consol_i8);
+        c->d_consol_i8 = nullptr;
+        c->consol_i8_cap = 0;
+        e = hipMalloc((void**)&c->d_consol_i8, bytes8 + bytes8 / 4);
+        if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess)
+        hipLaunchKernelGGL((consolidate_kernel<signed char>), dim3((unsigned)M), dim3(256), 0, st,
+                           (const signed char*)c->d_consol_i8, (long long)N, (long long)N, (long long)ld, p.dG,
+                           c->d_consol_af);
+    }
+    p.af.resize(M);
+    if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // also: the caller may overwrite its buffer on return
+    if (e != hipSuccess) {
+      give_back();
+      return fail(c, RVT_E_HIP, "genotype consolidation failed: %s", hipGetErrorString(e));
+    }
+    if (af_out) std::memcpy(af_out, p.af.data(), afb);
   }
-  p.af.assign(af, af + M);
   p.tests = tests;
   p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   c->queue.push_back(std::move(p));
   // complete groups start computing now and overlap the host-side copies of the following genes
   return launch_pending(c, c->queue.size(), true);
+}
+}  // namespace
+
+int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                    const rvt_params* prm) {
+  return submit_common(c, gene_id, M, G, 0, af, nullptr, tests, prm);
+}
+int rvt_submit_gene_raw(rvt_ctx* c, int64_t gene_id, int M, const double* Graw, uint32_t tests,
+                        const rvt_params* prm, double* af_out) {
+  return submit_common(c, gene_id, M, Graw, 1, nullptr, af_out, tests, prm);
+}
+int rvt_submit_gene_i8(rvt_ctx* c, int64_t gene_id, int M, const int8_t* G8, uint32_t tests, const rvt_params* prm,
+                       double* af_out) {
+  return submit_common(c, gene_id, M, G8, 2, nullptr, af_out, tests, prm);
 }
 
 int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {

@@ -137,6 +137,11 @@ def load_library():
     L.rvt_wait_oldest.argtypes = [vp]
     L.rvt_submit_gene.restype = C.c_int
     L.rvt_submit_gene.argtypes = [vp, C.c_int64, C.c_int, c_double_p, c_double_p, C.c_uint32, C.POINTER(Params)]
+    L.rvt_submit_gene_raw.restype = C.c_int
+    L.rvt_submit_gene_raw.argtypes = [vp, C.c_int64, C.c_int, c_double_p, C.c_uint32, C.POINTER(Params), c_double_p]
+    L.rvt_submit_gene_i8.restype = C.c_int
+    L.rvt_submit_gene_i8.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(Params),
+                                     c_double_p]
     L.rvt_collect.restype = C.c_int
     L.rvt_collect.argtypes = [vp, C.POINTER(GeneResult), C.c_int, c_int_p]
     L.rvt_debug_collapse.restype = C.c_int
@@ -297,6 +302,23 @@ class Engine:
         prm = params or Params.default()
         self._check(self.L.rvt_submit_gene(self.ctx, int(gene_id), G.shape[1], _dp(G), _dp(af), int(tests),
                                            C.byref(prm)))
+
+    def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None):
+        """Raw extractor output (missing < 0): float64 -> rvt_submit_gene_raw, int8 -> rvt_submit_gene_i8.  The device
+        imputes and counts allele frequencies; returns the frequencies the tests will use."""
+        prm = params or Params.default()
+        if Graw.dtype == np.int8:
+            G = np.asfortranarray(Graw)
+            af = np.zeros(G.shape[1])
+            self._check(self.L.rvt_submit_gene_i8(self.ctx, int(gene_id), G.shape[1],
+                                                  G.ctypes.data_as(C.POINTER(C.c_int8)), int(tests), C.byref(prm),
+                                                  _dp(af)))
+        else:
+            G = np.asfortranarray(Graw, dtype=np.float64)
+            af = np.zeros(G.shape[1])
+            self._check(self.L.rvt_submit_gene_raw(self.ctx, int(gene_id), G.shape[1], _dp(G), int(tests),
+                                                   C.byref(prm), _dp(af)))
+        return af
 
     def collect(self, cap=4096):
         out = (GeneResult * cap)()

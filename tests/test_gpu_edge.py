@@ -90,3 +90,35 @@ def test_large_gene_list_is_chunked(engine):
         assert r.n_variants == G.shape[1] and r.n_poly == a.n_poly
         if a.n_poly:
             assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_raw_and_packed_submission_consolidate_on_device(engine, packed):
+    """rvt_submit_gene_raw / _i8: counter allele frequencies and mean imputation done on the device give the same
+    records as handing over the block DataConsolidator would have produced (oracle imputation + counter AF)."""
+    N = 1200
+    X, y, res, v, s2 = synth.make_null(N, 3, 0, seed=9)
+    engine.set_null(0, X, res, v, s2)
+    cases = [synth.make_gene(N, M, seed=70 + M, missing=miss, common=True, mono=True)
+             for M, miss in ((5, 0.0), (18, 0.03), (40, 0.2), (3, 0.9))]
+    rng = np.random.default_rng(4)
+    if not packed:      # fractional dosages with missing values: the reference's truncating running allele count
+        Graw = np.round(rng.uniform(0, 2, size=(N, 6)), 3)
+        Graw[rng.random((N, 6)) < 0.05] = -9.0
+        Graw[:, 2] = np.where(Graw[:, 2] > 1.9, 2.5, Graw[:, 2])       # > 2: counted missing, not imputed
+        cases.append((Graw, orc.impute_mean(Graw), orc.counter_af(Graw)))
+    for k, (Graw, G, af) in enumerate(cases):
+        raw = Graw.astype(np.int8) if packed else Graw
+        got_af = engine.submit_gene_raw(k, raw)
+        assert np.allclose(got_af, af, rtol=1e-14, atol=0)
+    got = engine.collect()
+    ptrs = [engine.upload_block(G) for Graw, G, af in cases]
+    want = engine.run_blocks(ptrs, [G.shape[1] for Graw, G, af in cases], [af for Graw, G, af in cases])
+    for a, b in zip(got, want):
+        for f in ("n_variants", "n_poly", "skat_ok", "skato_ok", "cmc_ok", "cmc_nonref", "zeg_ok", "skato_rho"):
+            assert getattr(a, f) == getattr(b, f), f
+        for f in ("skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p"):
+            x, w = getattr(a, f), getattr(b, f)
+            # identical blocks; the allele frequency of a fractional-dosage column may differ in its last bit (parallel
+            # instead of sequential sum), hence not exact equality
+            assert abs(x - w) <= 1e-11 * abs(w) + 1e-300, f
