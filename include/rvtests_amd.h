@@ -53,7 +53,9 @@ extern "C" {
 #define RVT_TEST_CMC 4u     /* --burden cmc    : CMCTest     src/Model.h:807-907   */
 #define RVT_TEST_ZEGGINI 8u /* --burden zeggini: ZegginiTest src/Model.h:1170-1242 */
 #define RVT_TEST_ALL 15u
-#define RVT_TEST_FAMSKAT 16u /* --kernel famSkat: FamSkatTest src/Model.h:3048-3145 (rvt_run_fam_blocks only) */
+#define RVT_TEST_FAMSKAT 16u /* --kernel famSkat: FamSkatTest src/Model.h:3048-3145 (rvt_run_fam_tests only) */
+#define RVT_TEST_FAMCMC 32u     /* --burden famcmc    : FamCMC     src/Model.h:2261-2376 (rvt_run_fam_tests only) */
+#define RVT_TEST_FAMZEGGINI 64u /* --burden famzeggini: FamZeggini src/Model.h:2378-2492 (rvt_run_fam_tests only) */
 
 /* trait type of the null model */
 #define RVT_TRAIT_QUANTITATIVE 0
@@ -106,6 +108,12 @@ typedef struct rvt_gene_result {
   /* FamSKAT: "Q\tPvalue"  (src/Model.h:3121-3132); famskat_p may be -1 (Davies fault, no Liu fallback there) */
   int famskat_ok;
   double famskat_Q, famskat_p;
+  /* FamCMC "NumSite AF U V Effect Pvalue" / FamZeggini "NumSite MeanBurden U V Effect Pvalue" (NumSite = n_poly,
+   * Effect = U / V); src/Model.h:2344-2357, 2461-2473 */
+  int famcmc_ok;
+  double famcmc_af, famcmc_U, famcmc_V, famcmc_p;
+  int famzeg_ok;
+  double famzeg_af, famzeg_U, famzeg_V, famzeg_p;
 } rvt_gene_result;
 
 /* FastLMM null model of the related-sample tests, as FamSkat::FitNullModel consumes it */
@@ -248,6 +256,13 @@ int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
 int rvt_fit_fam_null(rvt_ctx* ctx, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
 int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
                        rvt_gene_result* out);
+/* The same with a test mask out of RVT_TEST_FAMSKAT | RVT_TEST_FAMCMC | RVT_TEST_FAMZEGGINI.  The family burden tests
+ * (src/Model.h:2261-2492) collapse the flipped, polymorphic block (cmcCollapse / zegginiCollapse), and run
+ * FastLMM::TestCovariate's SCORE branch (regression/FastLMM.cpp:215-247: U, V = g~' scaledK g~ / sigma2 on the centred,
+ * rotated collapsed genotype, p = chisq(1)) and FastLMM::GetAF (:356-398); the collapsed columns ride through the same
+ * rotation GEMM as the genotypes. */
+int rvt_run_fam_tests(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
+                      uint32_t tests, rvt_gene_result* out);
 /* MetaCov with kinship, quantitative trait (MetaCovFamQtl, src/Model.cpp:437-504 over FastLMM::TransformCentered /
  * GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same contract as rvt_cov_block, with the null model
  * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  The binary family variant is not provided. */

@@ -496,6 +496,106 @@ int orc_metacov_fam(const double* Gp, int64_t N, int V, const int* chrom, const 
   return 0;
 }
 
+int orc_fam_burden(const double* Gp, int64_t N, int M, const double* Xp, const double* y, int d, const double* Up,
+                   const double* S, const orc_fam_null* nul, int which, int use_float, orc_fam_burden_result* out) {
+  std::memset(out, 0, sizeof(*out));
+  F32 F{use_float != 0};
+  std::vector<double> Gf((size_t)N * M);
+  std::vector<int> fl(M), kp(M);
+  const int m = orc_flip_poly(Gp, N, M, Gf.data(), fl.data(), kp.data());
+  out->num_site = m;
+  if (m == 0) return -1;
+  // cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130)
+  std::vector<double> c(N, 0.0);
+  for (int64_t i = 0; i < N; ++i) {
+    int n = 0;
+    for (int j = 0; j < m; ++j)
+      if ((int)Gf[(size_t)j * N + i] > 0) ++n;
+    c[i] = which == 0 ? (n > 0 ? 1.0 : 0.0) : (double)n;
+  }
+  Mat U = wrapd(Up, N, N), X = wrapd(Xp, N, d);
+  const double sigma2 = nul->sigma2, delta = nul->delta;
+  std::vector<double> lam(N), sinv(N);
+  for (int64_t i = 0; i < N; ++i) {
+    lam[i] = std::fabs(F(S[i]));
+    sinv[i] = F(1.0 / F(lam[i] + delta));
+  }
+  // ux = U'X, uResid = U'y - ux beta, u_g_center = U'(g - mean(g))
+  Mat ux(N, d);
+  std::vector<double> ur(N), ug(N), ugc(N);
+  double cs = 0;
+  for (int64_t i = 0; i < N; ++i) cs = F(cs + F(c[i]));
+  const double cmean = F(cs / (double)N);
+  for (int64_t k = 0; k < N; ++k) {
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(U(i, k)) * F(X(i, a))));
+      ux(k, a) = s;
+    }
+    double sy = 0, sg = 0, sc = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      sy = F(sy + F(F(U(i, k)) * F(y[i])));
+      sg = F(sg + F(F(U(i, k)) * F(c[i])));
+      sc = F(sc + F(F(U(i, k)) * F(F(c[i]) - cmean)));
+    }
+    double p = 0;
+    for (int a = 0; a < d; ++a) p = F(p + F(ux(k, a) * F(nul->beta[a])));
+    ur[k] = F(sy - p);
+    ug[k] = sg;
+    ugc[k] = sc;
+  }
+  // scaledK = Sinv - Sinv ux (ux' Sinv ux)^-1 ux' Sinv   (N x N, FastLMM.cpp:124-138)
+  Mat A(d, d), I(d, d), Ai;
+  for (int a = 0; a < d; ++a) {
+    I(a, a) = 1.0;
+    for (int b = 0; b < d; ++b) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(ux(i, a) * sinv[i]) * ux(i, b)));
+      A(a, b) = s;
+    }
+  }
+  if (!orc::sym_solve(A, I, &Ai)) return -1;
+  Mat K(N, N);
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) {
+      double q = 0;
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) q = F(q + F(F(F(sinv[i] * ux(i, a)) * F(Ai(a, b))) * F(ux(j, b) * sinv[j])));
+      K(i, j) = F((i == j ? sinv[i] : 0.0) - q);
+    }
+  double Us = 0;
+  for (int64_t i = 0; i < N; ++i) Us = F(Us + F(F(ugc[i] * ur[i]) / F(lam[i] + delta)));
+  Us = Us / sigma2;
+  double Vs = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    double t = 0;
+    for (int64_t j = 0; j < N; ++j) t = F(t + F(K(i, j) * ugc[j]));
+    Vs = F(Vs + F(ugc[i] * t));
+  }
+  Vs = Vs / sigma2;
+  out->U = Us;
+  out->V = Vs;
+  if (Vs > 0.0) {
+    out->stat = Us * Us / Vs;
+    out->pvalue = orc_chisq_Q(out->stat, 1.0);
+  } else {
+    out->stat = 0;
+    out->pvalue = 1.0;
+  }
+  // GetAF: 0.5 * (u1s . ug) / (u1s . u1), u1 = U'1, u1s = u1 / |lambda|
+  double denom = 0, numer = 0;
+  for (int64_t k = 0; k < N; ++k) {
+    double u1 = 0;
+    for (int64_t i = 0; i < N; ++i) u1 = F(u1 + F(U(i, k)));
+    const double u1s = F(u1 / lam[k]);
+    denom = F(denom + F(u1s * u1));
+    numer = F(numer + F(u1s * ug[k]));
+  }
+  out->af = (denom == 0.0) ? 0.0 : 0.5 * (numer / denom);
+  out->fit_ok = 1;
+  return 0;
+}
+
 static double obtain_b_integrand(double t, void* p) {
   const double alpha = *(const double*)p;
   if (t <= 0.0) return 0.0;

@@ -261,13 +261,46 @@ __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const doub
 // null set of the family MetaCov (MetaCovFamQtl): weights D = 1/((|S| + delta) sigma2), columns [U'X | u1]
 __global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                          const double* __restrict__ u1, long long N, long long ld, int d,
-                                         double sigma2, double delta, double* __restrict__ Xin,
-                                         double* __restrict__ v) {
+                                         double sigma2, double delta, const double* __restrict__ beta,
+                                         double* __restrict__ Xin, double* __restrict__ rr, double* __restrict__ v) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= N) return;
-  for (int k = 0; k < d; ++k) Xin[i + k * ld] = uxy[i + k * N];
+  double p = 0.0;
+  for (int k = 0; k < d; ++k) {
+    Xin[i + k * ld] = uxy[i + k * N];
+    p += uxy[i + k * N] * beta[k];
+  }
+  const double al = fabs(S[i]);
+  const double D = 1.0 / ((al + delta) * sigma2);
   Xin[i + (long long)d * ld] = u1[i];
-  v[i] = 1.0 / ((fabs(S[i]) + delta) * sigma2);
+  Xin[i + (long long)(d + 1) * ld] = (u1[i] / al) / D;  // FastLMM::GetAF numerator: sum u1 ug / |lambda|
+  rr[i] = uxy[i + (long long)d * N] - p;                 // uResid = U'y - U'X beta (score statistic)
+  v[i] = D;
+}
+
+// cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130) of flipped, filtered blocks: gene k owns columns
+// [off[k], off[k] + m[k]) of Gp and writes its two collapsed columns to out + (2k) * ld and out + (2k+1) * ld
+__global__ void fam_collapse_kernel(const double* __restrict__ Gp, const int* __restrict__ off,
+                                    const int* __restrict__ m, long long N, long long ld, double* __restrict__ out) {
+  const int k = blockIdx.y;
+  const double* g0 = Gp + (long long)off[k] * ld;
+  const int mk = m[k];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+    int n = 0;
+    for (int j = 0; j < mk; ++j) n += ((int)g0[i + (long long)j * ld] > 0) ? 1 : 0;
+    out[i + (long long)(2 * k) * ld] = n > 0 ? 1.0 : 0.0;
+    out[i + (long long)(2 * k + 1) * ld] = (double)n;
+  }
+}
+
+// FastLMM::TestCovariate, SCORE branch (FastLMM.cpp:236-247): stat = U^2 / V, p = chisq_Q(stat, 1) when V > 0
+__global__ void fam_burden_finish_kernel(const double* __restrict__ cov, int V, const double* __restrict__ ustat,
+                                         double* __restrict__ vstat, double* __restrict__ pval) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= V) return;
+  const double v = cov[h + (long long)h * V], u = ustat[h];
+  vstat[h] = v;
+  pval[h] = (v > 0.0) ? chisq_Q(u * u / v, 1.0) : 1.0;
 }
 
 // raw column sum + monomorphic flag of the columns of one block (MetaCov family mode)

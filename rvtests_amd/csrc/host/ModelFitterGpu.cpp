@@ -112,6 +112,8 @@ void GpuBroker::shutdown() {
   failedSerial.clear();
   haveNull = false;
   haveFamNull = false;
+  famSerial = -1;
+  famTests = 0;
   kinU = nullptr;
   curSerial = -1;
   tests = 0;
@@ -183,6 +185,29 @@ rvt_ctx* GpuBroker::contextWithFamNull(const GeneData& gd, std::string* err) {
     haveFamNull = true;
   }
   return ctx;
+}
+
+const rvt_gene_result* GpuBroker::famResultFor(const GeneData& gd, std::string* err) {
+  if (gd.serial == famSerial) return famOk ? &famRec : nullptr;
+  famSerial = gd.serial;
+  famOk = false;
+  rvt_ctx* cx = contextWithFamNull(gd, err);
+  if (!cx) return nullptr;
+  double* block = nullptr;
+  if (rvt_block_alloc(cx, gd.M, &block) || rvt_block_upload(cx, block, gd.M, gd.genotype)) {
+    *err = rvt_last_error(cx);
+    if (block) rvt_block_free(cx, block);
+    return nullptr;
+  }
+  const double* p = block;
+  const int rc = rvt_run_fam_tests(cx, 1, &p, &gd.M, &gd.serial, famTests, &famRec);
+  rvt_block_free(cx, block);
+  if (rc) {
+    *err = rvt_last_error(cx);
+    return nullptr;
+  }
+  famOk = true;
+  return &famRec;
 }
 
 int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
@@ -327,7 +352,10 @@ std::string ZegginiTest::formatRow(const rvt_gene_result* res) const {
 }
 
 // ---- FamSkatTest ----------------------------------------------------------------------------------------------------------
-FamSkatTest::FamSkatTest(double, double) { modelName = "FamSkat"; }
+FamSkatTest::FamSkatTest(double, double) {
+  modelName = "FamSkat";
+  GpuBroker::instance().registerFamTests(RVT_TEST_FAMSKAT);
+}
 int FamSkatTest::fit(GeneData* dc) {
   fitOK = false;
   if (isBinaryOutcome()) {  // src/Model.h:3071-3078
@@ -338,21 +366,9 @@ int FamSkatTest::fit(GeneData* dc) {
     lastError = "SKAT test (for related individuals) cannot find kinship. Results will be all NAs.";
     return -1;
   }
-  rvt_ctx* ctx = GpuBroker::instance().contextWithFamNull(*dc, &lastError);
-  if (!ctx) return -1;
-  double* block = nullptr;
-  if (rvt_block_alloc(ctx, dc->M, &block) || rvt_block_upload(ctx, block, dc->M, dc->genotype)) {
-    lastError = rvt_last_error(ctx);
-    if (block) rvt_block_free(ctx, block);
-    return -1;
-  }
-  const double* p = block;
-  const int rc = rvt_run_fam_blocks(ctx, 1, &p, &dc->M, &dc->serial, &rec);
-  rvt_block_free(ctx, block);
-  if (rc) {
-    lastError = rvt_last_error(ctx);
-    return -1;
-  }
+  const rvt_gene_result* r = GpuBroker::instance().famResultFor(*dc, &lastError);
+  if (!r) return -1;
+  rec = *r;
   if (!rec.famskat_ok) return -1;  // genotype.cols == 0 after filtering -> NA row (src/Model.h:3066-3069)
   fitOK = true;
   return 0;
@@ -367,6 +383,46 @@ void FamSkatTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
     fp->write("NA\tNA\n");
   else
     fp->write(formatG(rec.famskat_Q) + "\t" + formatG(rec.famskat_p) + "\n");
+}
+
+// ---- FamCMC / FamZeggini ---------------------------------------------------------------------------------------------------
+FamBurdenTest::FamBurdenTest(bool zeg) : zeggini(zeg) {
+  modelName = zeg ? "FamZeggini" : "FamCMC";
+  GpuBroker::instance().registerFamTests(zeg ? RVT_TEST_FAMZEGGINI : RVT_TEST_FAMCMC);
+}
+int FamBurdenTest::fit(GeneData* dc) {
+  fitOK = false;
+  if (isBinaryOutcome()) {  // src/Model.h:2284-2291
+    lastError = "burden test (for related individuals) does not support binary outcomes. Results will be all NAs.";
+    return -1;
+  }
+  if (!dc->kinshipU || !dc->kinshipS) {
+    lastError = "burden test (for related individuals) cannot find kinship.";
+    return -1;
+  }
+  const rvt_gene_result* r = GpuBroker::instance().famResultFor(*dc, &lastError);
+  if (!r) return -1;
+  rec = *r;
+  if (!(zeggini ? rec.famzeg_ok : rec.famcmc_ok)) return -1;  // genotype.cols == 0 (src/Model.h:2297-2301)
+  const double u = zeggini ? rec.famzeg_U : rec.famcmc_U, v = zeggini ? rec.famzeg_V : rec.famcmc_V;
+  if (v != 0) effect = u / v;
+  fitOK = true;
+  return 0;
+}
+void FamBurdenTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.headerTab());
+  fp->write(zeggini ? "NumSite\tMeanBurden\tU\tV\tEffect\tPvalue\n" : "NumSite\tAF\tU\tV\tEffect\tPvalue\n");
+}
+void FamBurdenTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.valueTab());
+  if (!fitOK) {  // Result keeps "NA" for values that were not updated (src/Model.h:2344-2357)
+    fp->write("NA\tNA\tNA\tNA\tNA\tNA\n");
+    return;
+  }
+  const double af = zeggini ? rec.famzeg_af : rec.famcmc_af, u = zeggini ? rec.famzeg_U : rec.famcmc_U,
+               v = zeggini ? rec.famzeg_V : rec.famcmc_V, p = zeggini ? rec.famzeg_p : rec.famcmc_p;
+  fp->write(std::to_string(rec.n_poly) + "\t" + floatToString(af) + "\t" + floatToString(u) + "\t" +
+            floatToString(v) + "\t" + floatToString(effect) + "\t" + floatToString(p) + "\n");
 }
 
 // ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
@@ -602,6 +658,10 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         model.push_back(new CMCTest);
       else if (modelName == "zeggini")
         model.push_back(new ZegginiTest);
+      else if (modelName == "famcmc")  // src/ModelManager.cpp:133-136
+        model.push_back(new FamBurdenTest(false));
+      else if (modelName == "famzeggini")
+        model.push_back(new FamBurdenTest(true));
       else {
         lastError = "Unknown model name: " + modelName + " .";
         return -1;

@@ -121,6 +121,10 @@ class GpuBroker {
   rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
   // context + kinship + FastLMM null for FamSkatTest (refitted when the caller flags new phenotype / covariates)
   rvt_ctx* contextWithFamNull(const GeneData& gd, std::string* err);
+  // the related-sample gene tests (FamSkat, FamCMC, FamZeggini) share one rotation per gene: the first model whose
+  // fit() sees a gene runs the union of the registered tests, the others read the cached record
+  void registerFamTests(uint32_t mask) { famTests |= mask; }
+  const rvt_gene_result* famResultFor(const GeneData& gd, std::string* err);
   // null model: fitted on the device (rvt_fit_null) unless the caller installs its own routine (e.g. the
   // reference's LinearRegression / LogisticRegression inside the rvtests tree); see INTEGRATION.md
   typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
@@ -147,6 +151,10 @@ class GpuBroker {
   NullFitter fitter = nullptr;
   const float* kinU = nullptr;
   bool haveFamNull = false;
+  uint32_t famTests = 0;
+  int64_t famSerial = -1;
+  bool famOk = false;
+  rvt_gene_result famRec{};
   int installNull(const GeneData& gd, bool binary, std::string* err);
 };
 
@@ -240,6 +248,21 @@ class FamSkatTest : public ModelFitter {
 
  private:
   bool fitOK = false;
+  rvt_gene_result rec{};
+};
+
+// `--burden famcmc` / `--burden famzeggini` (src/Model.h:2261-2492): collapse + FastLMM score test.
+class FamBurdenTest : public ModelFitter {
+ public:
+  explicit FamBurdenTest(bool zeggini);
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool zeggini;
+  bool fitOK = false;
+  double effect = -1.0;  // the reference leaves the previous value when V == 0 (src/Model.h:2338-2340)
   rvt_gene_result rec{};
 };
 

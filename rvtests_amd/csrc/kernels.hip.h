@@ -242,6 +242,8 @@ struct CovConsts {
   double inv_sigma2;                        // 1/sigma2 (quantitative), 1 (binary)
   double inv_n;                             // 1/N
   double c11;                               // family mode: u1' D u1
+  double k1r;                               // family mode: u1' D uResid
+  double af_denom;                          // family mode: u1' |lambda|^-1 u1 (FastLMM::GetAF)
   int d, binary;
   int fam;  // family mode (MetaCovFamQtl): R comes from the ROTATED block with D = 1/((|S|+delta) sigma2) and null
             // columns [U'X | u1]; genotypes are centred BEFORE the rotation, i.e. g~ - mean(g) u1:
@@ -252,7 +254,8 @@ struct CovConsts {
 // one workgroup: column sums, polymorphic flags, T = G'DX, covXZ   (xz: V x d row-major; colsum: V)
 __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
                                                           double* __restrict__ xz, double* __restrict__ colsum,
-                                                          int* __restrict__ poly) {
+                                                          int* __restrict__ poly, double* __restrict__ ustat,
+                                                          double* __restrict__ afout) {
   const GeneDesc gd = genes[0];
   const int V = gd.M, d = cc.d;
   for (int h = threadIdx.x; h < V; h += blockDim.x) {
@@ -268,6 +271,16 @@ __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __rest
       poly[h] = (mn == mx) ? 0 : 1;
     } else {
       s = colsum[h];
+      if (ustat) {  // family burden tests: score U of the centred column and the GLS allele frequency
+        double tu = 0.0, ta = 0.0;
+        for (int p = 0; p < gd.n_wparts; ++p) {
+          const double* row = gd.parts + (long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp + V;
+          ta += row[d + 1];
+          tu += row[d + 2];
+        }
+        ustat[h] = tu - s * cc.inv_n * cc.k1r;
+        afout[h] = (cc.af_denom == 0.0) ? 0.0 : 0.5 * (ta / cc.af_denom);
+      }
     }
     for (int k = 0; k < d; ++k) {
       double t = 0.0;

@@ -93,6 +93,8 @@ struct rvt_ctx {
   NullConsts* d_famcov_nc = nullptr;
   double *d_cX = nullptr, *d_cv = nullptr;
   double famcov_b2 = 1.0;  // MetaCovFamBinary: b^2
+  double famcov_k1r = 0.0; // u1' D uResid
+  double* d_cr = nullptr;  // uResid (the rr column of the family-covariance null set)
   double famcov_c11 = 0.0, famcov_c1x[RVT_MAX_COV], famcov_zz[RVT_MAX_COV * RVT_MAX_COV],
          famcov_zzinv[RVT_MAX_COV * RVT_MAX_COV];
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
@@ -464,7 +466,7 @@ void rvt_destroy(rvt_ctx* c) {
   }
   if (c->d_nc) hipFree(c->d_nc);
   for (double* p : {c->d_U, c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
-                    c->d_fbeta, c->d_Gp, c->d_Gt, c->d_cX, c->d_cv})
+                    c->d_fbeta, c->d_Gp, c->d_Gt, c->d_cX, c->d_cv, c->d_cr})
     if (p) hipFree(p);
   if (c->d_famcov_nc) hipFree(c->d_famcov_nc);
   for (void* p : {(void*)c->d_perm_idx, (void*)c->d_perm_states, (void*)c->d_perm_R, (void*)c->d_perm_C,
@@ -605,6 +607,8 @@ struct CovOut {  // rvt_cov_block: host destinations
   bool fam = false;        // family mode: the block is already rotated; raw column sums / flags are supplied
   const double* d_raw_colsum = nullptr;
   const int* d_raw_poly = nullptr;
+  // family burden tests: per-column U, V, GLS allele frequency, p-value (host, V entries each); cov/xz may be null
+  double *ustat = nullptr, *vstat = nullptr, *af = nullptr, *pval = nullptr;
 };
 
 // covZZ / covZZInv and the other constants of the MetaCov algebra for the installed null model (or, fam = true,
@@ -621,11 +625,13 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
     cc.inv_n = 1.0 / (double)N;
   zz.assign((size_t)d * d, 0.0);
     if (fam) {  // MetaCovFamQtl: constants prepared by rvt_fit_fam_null
-      const int du = d - 1;  // U'X columns (the null set carries u1 as an extra column)
+      const int du = d - 2;  // U'X columns (the null set carries u1 and the allele-frequency column as well)
       cc.fam = 1;
       cc.d = du;
       cc.inv_sigma2 = 1.0;
       cc.c11 = c->famcov_c11;
+      cc.k1r = c->famcov_k1r;
+      cc.af_denom = c->fam_nc.rss;
       zz.assign((size_t)du * du, 0.0);
       for (int a = 0; a < du; ++a) {
         cc.zsum[a] = c->famcov_c1x[a];
@@ -746,13 +752,14 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
-  size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0;
+  size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0, off_cov_bur = 0;
   if (cov) {
     const size_t V = (size_t)Ms[0];
     off_cov = add(sizeof(double) * V * V);
     off_cov_xz = add(sizeof(double) * V * (size_t)d);
     off_cov_cs = add(sizeof(double) * V);
     off_cov_poly = add(sizeof(int) * V);
+    off_cov_bur = add(sizeof(double) * V * 4);
   }
   size_t off_dbg_cmc = 0, off_dbg_zeg = 0;
   if (dbg && dbg->cmc) {
@@ -855,13 +862,29 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       HIP_TRY(c, hipMemcpyAsync(d_cs, cov->d_raw_colsum, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, st));
       HIP_TRY(c, hipMemcpyAsync(d_poly, cov->d_raw_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToDevice, st));
     }
-    hipLaunchKernelGGL(cov_prepare_kernel, dim3(1), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_poly);
+    double* d_bur = reinterpret_cast<double*>(base + off_cov_bur);  // ustat | vstat | af | pval
+    const bool bur = cov->fam && cov->ustat;
+    hipLaunchKernelGGL(cov_prepare_kernel, dim3(1), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_poly,
+                       bur ? d_bur : (double*)nullptr, bur ? d_bur + 2 * (size_t)V : (double*)nullptr);
     hipLaunchKernelGGL(cov_rows_kernel, dim3(V), dim3(256), 0, st, d_desc, cc, d_xz, d_cs, d_cov);
+    if (bur)
+      hipLaunchKernelGGL(fam_burden_finish_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d_cov, V, d_bur,
+                         d_bur + (size_t)V, d_bur + 3 * (size_t)V);
     HIP_TRY(c, hipGetLastError());
     const int dz = cc.d;
-    HIP_TRY(c, hipMemcpyAsync(cov->cov, d_cov, sizeof(double) * (size_t)V * V, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(cov->xz, d_xz, sizeof(double) * (size_t)V * dz, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(cov->poly, d_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, st));
+    if (cov->cov)
+      HIP_TRY(c, hipMemcpyAsync(cov->cov, d_cov, sizeof(double) * (size_t)V * V, hipMemcpyDeviceToHost, st));
+    if (cov->xz)
+      HIP_TRY(c, hipMemcpyAsync(cov->xz, d_xz, sizeof(double) * (size_t)V * dz, hipMemcpyDeviceToHost, st));
+    if (cov->poly)
+      HIP_TRY(c, hipMemcpyAsync(cov->poly, d_poly, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, st));
+    if (bur) {
+      const size_t vb8 = sizeof(double) * (size_t)V;
+      HIP_TRY(c, hipMemcpyAsync(cov->ustat, d_bur, vb8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(cov->vstat, d_bur + (size_t)V, vb8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(cov->af, d_bur + 2 * (size_t)V, vb8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(cov->pval, d_bur + 3 * (size_t)V, vb8, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(c, hipStreamSynchronize(st));
     if (cov->zz) std::memcpy(cov->zz, zz.data(), sizeof(double) * (size_t)dz * dz);
     return RVT_OK;
@@ -1211,7 +1234,7 @@ int brent_like_gsl(const std::function<double(double)>& f, double start, double 
 }  // namespace
 
 int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out) {
-  if (!c || !X || !y || !out || d < 1 || d + 1 > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c || !X || !y || !out || d < 1 || d + 2 > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad arguments");
   if (!c->have_kin || c->kin_N != N) return fail(c, RVT_E_STATE, "rvt_set_kinship with the same N first");
   if (c->have_null && c->nc.N != N) return fail(c, RVT_E_STATE, "sample count differs from the installed null model");
   hipSetDevice(c->device);
@@ -1390,23 +1413,51 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
     for (int a = 0; a < d; ++a) c->famcov_c1x[a] = sums[d * d + a] / sigma2;
     c->famcov_c11 = sums[d * d + d] / sigma2;
     if (!invert_spd(c->famcov_zz, d, c->famcov_zzinv)) return fail(c, RVT_E_INVALID, "covZZ is singular");
-    if (c->d_cX) hipFree(c->d_cX);
-    if (c->d_cv) hipFree(c->d_cv);
-    c->d_cX = c->d_cv = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&c->d_cX, vb * dx));
+    {  // k1r = u1' D uResid = (u1'W uy - (ux'W u1)' beta) / sigma2 : one more reduction over [u1 | uy]
+      double* d_uy2 = nullptr;
+      HIP_TRY(c, hipMalloc((void**)&d_uy2, sizeof(double) * (size_t)N * 2));
+      HIP_TRY(c, hipMemcpyAsync(d_uy2, c->d_u1, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(d_uy2 + (size_t)N, c->d_uxy + (size_t)N * d, sizeof(double) * (size_t)N,
+                                hipMemcpyDeviceToDevice, st));
+      double* d_abs3 = nullptr;
+      HIP_TRY(c, hipMalloc((void**)&d_abs3, sizeof(double) * N));
+      HIP_TRY(c, hipMemcpyAsync(d_abs3, absS.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_uy2, d_abs3,
+                         (long long)N, 1, delta, 1, c->d_lmm_part);
+      const int rec1 = lmm_rec_len(1);
+      std::vector<double> p1((size_t)kLmmBlocks * rec1);
+      HIP_TRY(c, hipMemcpyAsync(p1.data(), c->d_lmm_part, sizeof(double) * p1.size(), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipStreamSynchronize(st));
+      hipFree(d_uy2);
+      hipFree(d_abs3);
+      double u1Wy = 0.0;
+      for (int b = 0; b < kLmmBlocks; ++b) u1Wy += p1[(size_t)b * rec1 + 1];  // b[0] = u1' W uy
+      double k = u1Wy;
+      for (int a = 0; a < d; ++a) k -= sums[d * d + a] * beta[a];
+      c->famcov_k1r = k / sigma2;
+    }
+    for (double** pp : {&c->d_cX, &c->d_cv, &c->d_cr}) {
+      if (*pp) hipFree(*pp);
+      *pp = nullptr;
+    }
+    const int dc = d + 2;  // U'X | u1 | allele-frequency column
+    HIP_TRY(c, hipMalloc((void**)&c->d_cX, vb * dc));
     HIP_TRY(c, hipMalloc((void**)&c->d_cv, vb));
-    HIP_TRY(c, hipMemsetAsync(c->d_cX, 0, vb * dx, st));
+    HIP_TRY(c, hipMalloc((void**)&c->d_cr, vb));
+    HIP_TRY(c, hipMemsetAsync(c->d_cX, 0, vb * dc, st));
     HIP_TRY(c, hipMemsetAsync(c->d_cv, 0, vb, st));
+    HIP_TRY(c, hipMemsetAsync(c->d_cr, 0, vb, st));
     hipLaunchKernelGGL(famcov_build_null_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_uxy,
-                       c->d_S, c->d_u1, (long long)N, (long long)ld, d, sigma2, delta, c->d_cX, c->d_cv);
+                       c->d_S, c->d_u1, (long long)N, (long long)ld, d, sigma2, delta, c->d_fbeta, c->d_cX, c->d_cr,
+                       c->d_cv);
     NullConsts& cn = c->famcov_nc;
     std::memset(&cn, 0, sizeof(cn));
     cn.N = N;
     cn.ld = ld;
-    cn.d = dx;
+    cn.d = dc;
     cn.binary = 1;
     cn.sigma2 = 1.0;
-    for (int a = 0; a < dx; ++a) cn.C[a * dx + a] = cn.Cinv[a * dx + a] = 1.0;  // unused by the covariance kernels
+    for (int a = 0; a < dc; ++a) cn.C[a * dc + a] = cn.Cinv[a * dc + a] = 1.0;  // unused by the covariance kernels
     if (!c->d_famcov_nc) HIP_TRY(c, hipMalloc((void**)&c->d_famcov_nc, sizeof(NullConsts)));
     HIP_TRY(c, hipMemcpyAsync(c->d_famcov_nc, &cn, sizeof(NullConsts), hipMemcpyHostToDevice, st));
   }
@@ -1415,8 +1466,53 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
   return RVT_OK;
 }
 
-// MetaCov with kinship (quantitative): rotate the block, run it through the sufficient statistics with the family
-// null set, finish with the covariance kernels in family mode.
+// Run V already ROTATED columns (d_rot, leading dimension ld) through the sufficient statistics with the family
+// covariance null set and finish with the covariance kernels in family mode.  d_cs / d_poly: raw (unrotated) column
+// sums and polymorphic flags on the device.
+namespace {
+int famcov_run(rvt_ctx* c, const double* d_rot, int V, const double* d_cs, const int* d_poly, CovOut* co) {
+  const int64_t ld = c->fam_nc.ld;
+  std::vector<double> af(V, 0.01);
+  rvt_gene_result r;
+  co->fam = true;
+  co->d_raw_colsum = d_cs;
+  co->d_raw_poly = d_poly;
+  const double* p = d_rot;
+  // the batch code reads the null set from the context: install the family-covariance set for this call
+  NullConsts keep_nc = c->nc;
+  NullConsts* keep_dnc = c->d_nc;
+  double *kX = c->d_X, *kres = c->d_res, *krr = c->d_rr, *kv = c->d_v, *kz = c->d_zeros;
+  const bool khave = c->have_null;
+  const int64_t kld = c->null_ld;
+  c->nc = c->famcov_nc;
+  c->d_nc = c->d_famcov_nc;
+  c->d_X = c->d_cX;
+  c->d_res = c->d_fzeros;
+  c->d_rr = c->d_cr;
+  c->d_v = c->d_cv;
+  c->d_zeros = c->d_fzeros;
+  c->have_null = true;
+  c->null_ld = ld;
+  int rc = run_batch(c, 1, &p, &V, af.data(), nullptr, 0u, nullptr, &r, nullptr, co);
+  c->nc = keep_nc;
+  c->d_nc = keep_dnc;
+  c->d_X = kX;
+  c->d_res = kres;
+  c->d_rr = krr;
+  c->d_v = kv;
+  c->d_zeros = kz;
+  c->have_null = khave;
+  c->null_ld = kld;
+  for (auto& sl : c->slots)
+    if (sl.pending_out == &r) {
+      sl.pending_out = nullptr;
+      sl.pending_n = 0;
+    }
+  return rc;
+}
+}  // namespace
+
+// MetaCov with kinship (quantitative): rotate the block, then famcov_run.
 int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
   if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
   if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
@@ -1450,52 +1546,15 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
                               (rocblas_int)ld));
   }
   HIP_TRY(c, hipStreamSynchronize(st));
-  std::vector<double> af(V, 0.01);
-  rvt_gene_result r;
   CovOut co;
   co.cov = cov;
   co.xz = xz;
   co.zz = zz;
   co.poly = polymorphic;
-  co.fam = true;
-  co.d_raw_colsum = d_cs;
-  co.d_raw_poly = d_poly;
-  const double* p = c->d_Gt;
-  {
-    // the batch code reads the null set from the context: install the family-covariance set for this call
-    NullConsts keep_nc = c->nc;
-    NullConsts* keep_dnc = c->d_nc;
-    double *kX = c->d_X, *kres = c->d_res, *krr = c->d_rr, *kv = c->d_v, *kz = c->d_zeros;
-    const bool khave = c->have_null;
-    const int64_t kld = c->null_ld;
-    c->nc = c->famcov_nc;
-    c->d_nc = c->d_famcov_nc;
-    c->d_X = c->d_cX;
-    c->d_res = c->d_fzeros;
-    c->d_rr = c->d_fzeros;
-    c->d_v = c->d_cv;
-    c->d_zeros = c->d_fzeros;
-    c->have_null = true;
-    c->null_ld = ld;
-    rc = run_batch(c, 1, &p, &V, af.data(), nullptr, 0u, nullptr, &r, nullptr, &co);
-    c->nc = keep_nc;
-    c->d_nc = keep_dnc;
-    c->d_X = kX;
-    c->d_res = kres;
-    c->d_rr = krr;
-    c->d_v = kv;
-    c->d_zeros = kz;
-    c->have_null = khave;
-    c->null_ld = kld;
-  }
-  for (auto& sl : c->slots)
-    if (sl.pending_out == &r) {
-      sl.pending_out = nullptr;
-      sl.pending_n = 0;
-    }
+  rc = famcov_run(c, c->d_Gt, V, d_cs, d_poly, &co);
   if (!rc && c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
     const double b2 = c->famcov_b2;
-    const int du = c->famcov_nc.d - 1;
+    const int du = c->famcov_nc.d - 2;
     for (int h = 0; h < V; ++h)
       for (int j = h; j < V; ++j) cov[(size_t)h + (size_t)j * V] *= b2;
     for (size_t i = 0; i < (size_t)V * du; ++i) xz[i] *= b2;
@@ -1530,7 +1589,15 @@ int rvt_fam_binary_scale(rvt_ctx* c, int64_t n_case, int64_t n_ctrl, double* alp
 
 int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const int64_t* ids,
                        rvt_gene_result* out) {
+  return rvt_run_fam_tests(c, n, dG, Ms, ids, RVT_TEST_FAMSKAT, out);
+}
+
+int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const int64_t* ids, uint32_t tests,
+                      rvt_gene_result* out) {
   if (!c || n < 0 || (n > 0 && (!dG || !Ms || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
+  if (!(tests & (RVT_TEST_FAMSKAT | RVT_TEST_FAMCMC | RVT_TEST_FAMZEGGINI)) ||
+      (tests & ~(RVT_TEST_FAMSKAT | RVT_TEST_FAMCMC | RVT_TEST_FAMZEGGINI)))
+    return fail(c, RVT_E_INVALID, "rvt_run_fam_tests takes the FAMSKAT / FAMCMC / FAMZEGGINI bits");
   if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
   if (n == 0) return RVT_OK;
   hipSetDevice(c->device);
@@ -1590,29 +1657,88 @@ int rvt_run_fam_blocks(rvt_ctx* c, int n, const double* const* dG, const int* Ms
     r.n_poly = Mk[g];
   }
   if (T == 0) return RVT_OK;  // genotype.cols == 0 everywhere: all NA (src/Model.h:3066-3069)
-  if (T > c->fam_cols_cap) {
-    if (c->d_Gp) hipFree(c->d_Gp);
-    if (c->d_Gt) hipFree(c->d_Gt);
-    c->d_Gp = c->d_Gt = nullptr;
-    c->fam_cols_cap = 0;
-    const size_t want = T + T / 4;
-    HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
-    HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
-    c->fam_cols_cap = want;
-  }
+  // genes with a polymorphic column, and — for the burden tests — two collapsed columns each after the T genotype ones
+  const bool burden = (tests & (RVT_TEST_FAMCMC | RVT_TEST_FAMZEGGINI)) != 0;
+  std::vector<int> kgene, koff, km;
+  for (int g = 0; g < n; ++g)
+    if (Mk[g] > 0) {
+      kgene.push_back(g);
+      koff.push_back(off[g]);
+      km.push_back(Mk[g]);
+    }
+  const size_t nk = kgene.size(), TB = burden ? 2 * nk : 0;
+  rc = ensure_fam_cols(c, T + TB, ld);
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(d_cols + tot, kept_cols.data(), sizeof(double*) * T, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(d_flags + tot, kept_flip.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * T, st));  // pad rows must be zero
+  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * (T + TB), st));  // pad rows must be zero
   hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
                      (long long)N, (long long)ld, c->d_Gp);
+  int* d_koff = nullptr;
+  double* d_bcs = nullptr;
+  int* d_bpoly = nullptr;
+  struct Guard2 {
+    void **a, **b, **c2;
+    ~Guard2() {
+      for (void** p : {a, b, c2})
+        if (*p) hipFree(*p);
+    }
+  } guard2{(void**)&d_koff, (void**)&d_bcs, (void**)&d_bpoly};
+  if (burden) {
+    // cmcCollapse / zegginiCollapse of the flipped, filtered blocks into columns T .. T + 2 nk - 1, then their raw
+    // sums (the score test centres the collapsed genotype, FastLMM.cpp:218-220)
+    HIP_TRY(c, hipMalloc((void**)&d_koff, sizeof(int) * 2 * nk));
+    HIP_TRY(c, hipMalloc((void**)&d_bcs, sizeof(double) * TB));
+    HIP_TRY(c, hipMalloc((void**)&d_bpoly, sizeof(int) * TB));
+    HIP_TRY(c, hipMemcpyAsync(d_koff, koff.data(), sizeof(int) * nk, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_koff + nk, km.data(), sizeof(int) * nk, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->d_Gp + (size_t)T * ld, 0, sizeof(double) * (size_t)ld * TB, st));
+    hipLaunchKernelGGL(fam_collapse_kernel, dim3(64, (unsigned)nk), dim3(256), 0, st, c->d_Gp, d_koff, d_koff + nk,
+                       (long long)N, (long long)ld, c->d_Gp + (size_t)T * ld);
+    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)TB), dim3(256), 0, st, c->d_Gp + (size_t)T * ld,
+                       (long long)N, (long long)ld, d_bcs, d_bpoly);
+  }
   {
     const double one = 1.0, zero = 0.0;
     BLAS_TRY(c, rocblas_set_stream(c->blas, st));
     BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N,
-                              (rocblas_int)T, (rocblas_int)N, &one, c->d_U, (rocblas_int)N, c->d_Gp,
+                              (rocblas_int)(T + TB), (rocblas_int)N, &one, c->d_U, (rocblas_int)N, c->d_Gp,
                               (rocblas_int)ld, &zero, c->d_Gt, (rocblas_int)ld));
   }
   HIP_TRY(c, hipStreamSynchronize(st));
+  if (burden) {
+    // FamCMC / FamZeggini: the 2 nk rotated collapsed columns as blocks of the family covariance machinery
+    // (V = cov(h,h), U from the uResid column, AF from the allele-frequency column)
+    std::vector<double> us(TB), vs(TB), afs(TB), ps(TB);
+    for (size_t b0 = 0; b0 < TB; b0 += RVT_MAX_VARIANTS) {
+      const int V = (int)std::min<size_t>(RVT_MAX_VARIANTS, TB - b0);
+      CovOut co;
+      co.ustat = us.data() + b0;
+      co.vstat = vs.data() + b0;
+      co.af = afs.data() + b0;
+      co.pval = ps.data() + b0;
+      rc = famcov_run(c, c->d_Gt + (T + b0) * (size_t)ld, V, d_bcs + b0, d_bpoly + b0, &co);
+      if (rc) return rc;
+    }
+    for (size_t k = 0; k < nk; ++k) {
+      rvt_gene_result& r = out[kgene[k]];
+      if (tests & RVT_TEST_FAMCMC) {
+        r.famcmc_ok = 1;
+        r.famcmc_af = afs[2 * k];
+        r.famcmc_U = us[2 * k];
+        r.famcmc_V = vs[2 * k];
+        r.famcmc_p = ps[2 * k];
+      }
+      if (tests & RVT_TEST_FAMZEGGINI) {
+        r.famzeg_ok = 1;
+        r.famzeg_af = afs[2 * k + 1];
+        r.famzeg_U = us[2 * k + 1];
+        r.famzeg_V = vs[2 * k + 1];
+        r.famzeg_p = ps[2 * k + 1];
+      }
+    }
+  }
+  if (!(tests & RVT_TEST_FAMSKAT)) return RVT_OK;
   // ---- 3. the rotated blocks go through the ordinary batch machinery with the FamSKAT null set ---------------
   std::vector<const double*> ptr;
   std::vector<int> mm, which;

@@ -32,6 +32,9 @@ RVT_HD void pvalue_init_result(const GeneStats& gs, int64_t gene_id, rvt_gene_re
   r->perm_num_perm = r->perm_actual_perm = r->perm_num_greater = r->perm_num_equal = 0;
   r->perm_pvalue = 0.0;
   r->famskat_ok = 0;
+  r->famcmc_ok = r->famzeg_ok = 0;
+  r->famcmc_af = r->famcmc_U = r->famcmc_V = r->famcmc_p = 0.0;
+  r->famzeg_af = r->famzeg_U = r->famzeg_V = r->famzeg_p = 0.0;
   r->famskat_Q = r->famskat_p = 0.0;
   r->skato_ok = 0;
   r->skato_Q = r->skato_rho = r->skato_p = 0.0;

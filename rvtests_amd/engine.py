@@ -46,6 +46,10 @@ class GeneResult(C.Structure):
         ("perm_ok", C.c_int), ("perm_num_perm", C.c_int), ("perm_actual_perm", C.c_int),
         ("perm_num_greater", C.c_int), ("perm_num_equal", C.c_int), ("perm_pvalue", C.c_double),
         ("famskat_ok", C.c_int), ("famskat_Q", C.c_double), ("famskat_p", C.c_double),
+        ("famcmc_ok", C.c_int), ("famcmc_af", C.c_double), ("famcmc_U", C.c_double), ("famcmc_V", C.c_double),
+        ("famcmc_p", C.c_double),
+        ("famzeg_ok", C.c_int), ("famzeg_af", C.c_double), ("famzeg_U", C.c_double), ("famzeg_V", C.c_double),
+        ("famzeg_p", C.c_double),
     ]
 
 
@@ -162,6 +166,9 @@ def load_library():
                                      C.POINTER(GeneResult)]
     L.rvt_fam_binary_scale.restype = C.c_int
     L.rvt_fam_binary_scale.argtypes = [vp, C.c_int64, C.c_int64, c_double_p, c_double_p]
+    L.rvt_run_fam_tests.restype = C.c_int
+    L.rvt_run_fam_tests.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(C.c_int64), C.c_uint32,
+                                    C.POINTER(GeneResult)]
     L.rvt_cov_rect.restype = C.c_int
     L.rvt_cov_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_copy_columns.restype = C.c_int
@@ -371,14 +378,15 @@ class Engine:
         self.d = getattr(self, "d", d)
         return out
 
-    def run_fam_blocks(self, ptrs, Ms, ids=None):
+    def run_fam_blocks(self, ptrs, Ms, ids=None, tests=16):
+        """tests: TEST_FAMSKAT (16) | TEST_FAMCMC (32) | TEST_FAMZEGGINI (64)"""
         n = len(ptrs)
         arr_p = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
         arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
         arr_id = np.ascontiguousarray(ids if ids is not None else np.arange(n), dtype=np.int64)
         out = (GeneResult * n)()
-        self._check(self.L.rvt_run_fam_blocks(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p),
-                                              arr_id.ctypes.data_as(C.POINTER(C.c_int64)), out))
+        self._check(self.L.rvt_run_fam_tests(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p),
+                                             arr_id.ctypes.data_as(C.POINTER(C.c_int64)), int(tests), out))
         return list(out)
 
     # ---- MetaCov --------------------------------------------------------------------------------------------

@@ -31,6 +31,10 @@ class GeneResult(C.Structure):
         ("perm_ok", C.c_int), ("perm_num_perm", C.c_int), ("perm_actual_perm", C.c_int),
         ("perm_num_greater", C.c_int), ("perm_num_equal", C.c_int), ("perm_pvalue", C.c_double),
         ("famskat_ok", C.c_int), ("famskat_Q", C.c_double), ("famskat_p", C.c_double),
+        ("famcmc_ok", C.c_int), ("famcmc_af", C.c_double), ("famcmc_U", C.c_double), ("famcmc_V", C.c_double),
+        ("famcmc_p", C.c_double),
+        ("famzeg_ok", C.c_int), ("famzeg_af", C.c_double), ("famzeg_U", C.c_double), ("famzeg_V", C.c_double),
+        ("famzeg_p", C.c_double),
     ]
 
 

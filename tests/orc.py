@@ -393,3 +393,23 @@ def metacov_fam_binary(G, chrom, pos, X, y, U, S, nul, window, use_float=False):
                                   C.byref(nul), int(window), int(use_float), _ip(kept), _dp(cov), _ip(row_end), _dp(xz),
                                   _dp(zz))
     return rc, kept, cov, row_end, xz, zz
+
+
+class FamBurdenResult(C.Structure):
+    _fields_ = [("fit_ok", C.c_int), ("num_site", C.c_int), ("af", C.c_double), ("U", C.c_double), ("V", C.c_double),
+                ("stat", C.c_double), ("pvalue", C.c_double)]
+
+
+def fam_burden(G, X, y, U, S, nul, which, use_float=False):
+    G = F(G)
+    X = F(X)
+    U = F(U)
+    N, M = G.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    out = FamBurdenResult()
+    L = lib()
+    L.orc_fam_burden.restype = C.c_int
+    rc = L.orc_fam_burden(_dp(G), C.c_int64(N), M, _dp(X), _dp(y), X.shape[1], _dp(U), _dp(S), C.byref(nul),
+                          int(which), int(use_float), C.byref(out))
+    return rc, out

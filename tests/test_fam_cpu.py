@@ -148,3 +148,31 @@ def test_obtain_b_matches_scipy_quad():
             if alpha + x < 700 else 0.0
         want = quad(f, -40, 40, epsabs=0, epsrel=1e-12, limit=400)[0]
         assert abs(orc.obtain_b(alpha) - want) <= 1e-9 * max(want, 1e-300) + 1e-300
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_fam_burden_matches_numpy(which):
+    N, K, U, S, X, y = make_family_case(30, 2, 23)
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    _, G, af = synth.make_gene(N, 10, seed=15, missing=0.02, common=True, mono=True, maf_hi=-0.7)
+    rc, o = orc.fam_burden(G, X, y, U, S, nul, which)
+    assert rc == 0 and o.fit_ok
+    Gf, fl, kp = orc.flip_poly(G)
+    n = (Gf.astype(int) > 0).sum(1)
+    c = (n > 0).astype(float) if which == 0 else n.astype(float)
+    beta = np.array(nul.beta[:2])
+    lam = np.abs(S)
+    Sinv = np.diag(1.0 / (lam + nul.delta))
+    ux = U.T @ X
+    ur = U.T @ y - ux @ beta
+    ugc = U.T @ (c - c.mean())
+    scaledK = Sinv - Sinv @ ux @ np.linalg.inv(ux.T @ Sinv @ ux) @ ux.T @ Sinv
+    Us = np.sum(ugc * ur / (lam + nul.delta)) / nul.sigma2
+    Vs = ugc @ scaledK @ ugc / nul.sigma2
+    u1 = U.sum(0)
+    afw = 0.5 * np.sum(u1 / lam * (U.T @ c)) / np.sum(u1 * u1 / lam)
+    from scipy.stats import chi2
+    assert o.num_site == Gf.shape[1]
+    assert abs(o.U - Us) <= 1e-9 * abs(Us) and abs(o.V - Vs) <= 1e-9 * Vs
+    assert abs(o.af - afw) <= 1e-10 * abs(afw)
+    assert abs(o.pvalue - chi2.sf(Us * Us / Vs, 1)) <= 1e-9 * o.pvalue

@@ -120,3 +120,37 @@ def test_metacov_fam_binary_scale(eng):
     m = ~np.isnan(ocov)
     assert np.abs(cov[m] - ocov[m]).max() < 1e-6 * np.abs(ocov[m]).max()      # b is a float on both sides
     assert np.allclose(zz, ozz, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_fam,d", [(40, 2), (70, 3)])
+def test_fam_burden_matches_oracle(eng, n_fam, d):
+    """FamCMC / FamZeggini (collapse + FastLMM score test + GLS allele frequency) together with FamSKAT in one call."""
+    N, K, U, S, X, y = make_family_case(n_fam, d, 90 + d)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(d):
+        onul.beta[k] = nul.beta[k]
+    genes = [synth.make_gene(N, M, seed=800 + M, missing=0.02, common=True, mono=(M > 5), maf_hi=-0.8)[1]
+             for M in (14, 2, 33, 9)]
+    genes.append(np.zeros((N, 3)))                      # no polymorphic column
+    ptrs = [eng.upload_block(G) for G in genes]
+    out = eng.run_fam_blocks(ptrs, [G.shape[1] for G in genes], tests=16 | 32 | 64)
+    for r, G in zip(out, genes):
+        for which, ok, af, u, v, p in ((0, r.famcmc_ok, r.famcmc_af, r.famcmc_U, r.famcmc_V, r.famcmc_p),
+                                       (1, r.famzeg_ok, r.famzeg_af, r.famzeg_U, r.famzeg_V, r.famzeg_p)):
+            rc, o = orc.fam_burden(G, X, y, U, S, onul, which)
+            if rc != 0:
+                assert ok == 0
+                continue
+            assert ok == 1 and r.n_poly == o.num_site
+            assert abs(u - o.U) <= 1e-8 * abs(o.U) + 1e-12
+            assert abs(v - o.V) <= 1e-8 * o.V
+            assert abs(af - o.af) <= 1e-9 * abs(o.af) + 1e-15
+            assert abs(p - o.pvalue) <= 1e-6 * o.pvalue
+        rc, s = orc.famskat(G, X, y, U, S, onul)
+        assert r.famskat_ok == (1 if rc == 0 else 0)
+        if rc == 0:
+            assert abs(r.famskat_Q - s.Q) <= 1e-7 * s.Q

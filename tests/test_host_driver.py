@@ -231,14 +231,37 @@ def test_driver_famskat_matches_oracle(tmp_path):
         f.write(struct.pack("<q", N))
         f.write(np.asfortranarray(U, dtype="<f4").tobytes(order="F"))
         f.write(np.ascontiguousarray(S, dtype="<f4").tobytes())
-    p = subprocess.run([DRIVER, path, "famSkat[beta1=1:beta2=25]", "-", "-", "-", kin], capture_output=True, text=True,
-                       timeout=300)
+    p = subprocess.run([DRIVER, path, "famSkat[beta1=1:beta2=25]", "famcmc,famzeggini", "-", "-", kin],
+                       capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
-    lines = p.stdout.splitlines()
-    assert lines[0] == "== out.FamSkat.assoc"
+    sections, cur = {}, None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("== "):
+            cur = ln[3:]
+            sections[cur] = []
+        else:
+            sections[cur].append(ln.split("\t"))
+    assert list(sections) == ["out.FamSkat.assoc", "out.FamCMC.assoc", "out.FamZeggini.assoc"]
+    assert sections["out.FamCMC.assoc"][0][-6:] == ["NumSite", "AF", "U", "V", "Effect", "Pvalue"]
+    assert sections["out.FamZeggini.assoc"][0][-6:] == ["NumSite", "MeanBurden", "U", "V", "Effect", "Pvalue"]
+    lines = ["== out.FamSkat.assoc"] + ["\t".join(r) for r in sections["out.FamSkat.assoc"]]
     assert lines[1].split("\t")[-2:] == ["Q", "Pvalue"]
     rows = [ln.split("\t") for ln in lines[2:]]
     assert len(rows) == len(genes)
+    rc0, onul0 = orc.fastlmm_null(X, y, U, S)
+    for name, which in (("out.FamCMC.assoc", 0), ("out.FamZeggini.assoc", 1)):
+        for row, (G, af) in zip(sections[name][1:], genes):
+            rcb, ob = orc.fam_burden(G, X, y, U, S, onul0, which)
+            if rcb != 0:
+                assert row[-6:] == ["NA"] * 6
+                continue
+            assert int(row[-6]) == ob.num_site
+            assert abs(float(row[-5]) - ob.af) <= 1e-5 * abs(ob.af) + 1e-12
+            # (the null fit is pinned to the reference's Brent stopping accuracy only)
+            assert abs(float(row[-4]) - ob.U) <= 2e-2 * abs(ob.U) + 1e-6
+            assert abs(float(row[-3]) - ob.V) <= 2e-2 * ob.V
+            assert abs(float(row[-2]) - ob.U / ob.V) <= 3e-2 * abs(ob.U / ob.V) + 1e-6
+            assert abs(np.log(float(row[-1])) - np.log(ob.pvalue)) <= 5e-2 * max(1.0, abs(np.log(ob.pvalue)))
     rc, onul = orc.fastlmm_null(X, y, U, S)
     assert rc == 0
     for row, (G, af) in zip(rows, genes):
