@@ -166,7 +166,8 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * (rvt_block_alloc, or any 128-byte aligned device allocation with the layout above, e.g. a torch
  * tensor); M[g] the column counts; af is the HOST concatenation of the per-column allele
  * frequencies GenotypeCounter::getAF() reports (src/GenotypeCounter.h:46-51), sum(M) entries.
- * Blocks until the results are in out[0..n_genes).  */
+ * Blocks until the results are in out[0..n_genes); lists longer than 256 genes are processed as pipelined batches of
+ * 256.  */
 int rvt_run_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const double* af,
                    const int64_t* gene_ids, uint32_t tests, const rvt_params* params, rvt_gene_result* out);
 /* Same, but only enqueue; up to RVT_MAX_INFLIGHT batches may be in flight (each on its own HIP stream, so that
@@ -190,8 +191,8 @@ int rvt_collect(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
 /* ---- MetaCov: score-covariance band (`--meta cov`) ------------------------------------------------------
  * Replaces the arithmetic of MetaCovTest::fitWithGivenGenotype / printCovariance / computeScaledXX
  * (src/Model.cpp:844-1004, src/Model.h:3993-4005) with MetaCovUnrelatedQtl / MetaCovUnrelatedBinary
- * (src/Model.cpp:506-593, 694-778) as the model — i.e. unrelated samples; the family (FastLMM) variants are not
- * provided.  `dG` is a device block (rvt_block_alloc) whose V <= RVT_MAX_VARIANTS columns are the imputed genotype
+ * (src/Model.cpp:506-593, 694-778) as the model — i.e. unrelated samples; rvt_cov_block_fam below is the family
+ * (FastLMM) counterpart.  `dG` is a device block (rvt_block_alloc) whose V <= RVT_MAX_VARIANTS columns are the imputed genotype
  * vectors of V consecutive single-variant fit() calls (what assignGenotype copies into its ring, Model.cpp:936-942).
  * Outputs (host):
  *   cov[h + j*V], j >= h : covXX(h,j) - covXZ_h' covZZInv covXZ_j, the value printCovariance prints for head h and
@@ -247,7 +248,7 @@ int rvt_rand_seed(rvt_ctx* ctx, unsigned seed);
  *                   refinement of GSLMinimizer.cpp:18-66 (same evaluation sequence, so the same quirks: delta is the
  *                   bracket's minimum while beta / sigma2 belong to the last evaluated point), followed by the
  *                   products FamSkat::FitNullModel (regression/FamSkat.cpp:34-64) prepares — without forming the
- *                   N x N Sigma / Sigma^-1 / P0.  X: N x d column-major incl. intercept, y: N.
+ *                   N x N Sigma / Sigma^-1 / P0.  X: N x d column-major incl. intercept (d <= RVT_MAX_COV - 2), y: N.
  * rvt_run_fam_blocks  FamSkat::TestCovariate (regression/FamSkat.cpp:65-138) for n device-resident blocks (imputed,
  *                   UNFLIPPED, like rvt_run_blocks): flip-to-minor + monomorphic removal, weights
  *                   beta_pdf(FastGetAF; 1, 25) (FastLMM.cpp:402-443), Q, eigenvalues of wg P0 wg', Davies only.
