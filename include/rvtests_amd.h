@@ -208,6 +208,25 @@ int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz
  * symmetric block kernel.  cov[(h-col0) + (j-col0)*H] for j >= h; xz: W x d; polymorphic: W. */
 int rvt_cov_rect(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
                  int* polymorphic);
+/* ---- MetaScore: single-variant score statistics (unrelated samples) ----------------------------------------------
+ * Replaces the per-variant body of MetaScoreTest::fit for MetaUnrelatedQtl / MetaUnrelatedBinary
+ * (src/Model.h:3246-3258 -> 3516-3549 / 3706-3769), i.e. LinearRegressionScoreTest::TestCovariate
+ * (regression/LinearRegressionScoreTest.cpp:173-263) or LogisticRegressionScoreTest::TestCovariate
+ * (regression/LogisticRegressionScoreTest.cpp:220-302) of ONE genotype column against the installed null model, for all
+ * V columns of a device block in one pass (the block is cut into 16-column slices, each streamed once by the
+ * sufficient-statistics kernel).  Outputs, V entries each, in the units MetaScoreTest::writeOutput prints:
+ *   ustat = U_STAT, vstat = V (SQRT_V_STAT is its square root), effect = ALT_EFFSIZE, effect_se = ALT_EFFSIZE_SE,
+ *   pvalue = PVALUE;  ok[h] = 0 for a monomorphic site (isMonomorphicMarker) or a non-positive variance, in which
+ *   case the reference prints the site columns and leaves these five empty (NA).
+ * Genotypes are taken as stored (imputed, NOT flipped), as MetaScoreTest does. */
+int rvt_score_block(rvt_ctx* ctx, const double* dG, int V, int* ok, double* ustat, double* vstat, double* effect,
+                    double* effect_se, double* pvalue);
+/* What MetaScoreTest::PrintNullModel prints (src/Model.h:3526-3542, 3737-3752): the estimates beta (d; NaN when the
+ * model was installed by rvt_set_null, whose caller fitted it), the diagonal of their covariance (LinearRegression
+ * covB = (X'X)^-1 sigma2, regression/LinearRegression.cpp:62-66; LogisticRegression covB = (X'WX)^-1,
+ * regression/LogisticRegression.cpp:330-334) and sigma2 (quantitative; 1 for a binary trait).  beta / sigma2 may be
+ * NULL. */
+int rvt_null_summary(rvt_ctx* ctx, double* beta, double* covb_diag, double* sigma2);
 /* Copy columns between two device blocks (growing the adapter's ring). */
 int rvt_block_copy_columns(rvt_ctx* ctx, double* dst, int dst_col, const double* src, int src_col, int ncols);
 /* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous). */

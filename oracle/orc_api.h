@@ -92,6 +92,10 @@ int orc_skat_literal(const double* G, const double* af, int64_t N, int M, const 
 /* SkatOTest::fit + SkatO::Fit, literal operation order (Z1, Z1*L, Z2'Z2 per rho). */
 int orc_skato(const double* G, const double* af, int64_t N, int M, const double* X, int d, const double* res,
               const double* v, int binary, double beta1, double beta2, orc_kernel_result* out);
+/* MetaScoreTest (unrelated samples): per-column score statistics in the printed units + the null-model summary. */
+int orc_metascore(const double* G, int64_t N, int V, const double* X, int d, const double* y, int binary, int* ok,
+                  double* ustat, double* vstat, double* effect, double* se, double* pval, double* beta_out,
+                  double* covb_diag, double* sigma2_out);
 /* CMCTest / ZegginiTest: which = 0 CMC, 1 Zeggini.  y and X are used to refit the null as the reference does. */
 int orc_burden(const double* G, int64_t N, int M, const double* X, int d, const double* y, int binary, int which,
                orc_burden_result* out);

@@ -808,6 +808,82 @@ int orc_burden(const double* Gp, int64_t N, int M, const double* Xp, int d, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// MetaScoreTest::fit, unrelated samples (src/Model.h:3232-3258): the null model is fitted once
+// (MetaUnrelatedQtl::FitNullModel :3503-3515 / MetaUnrelatedBinary::FitNullModel :3672-3705), then every
+// genotype column — imputed, NOT flipped — is tested alone; monomorphic sites are skipped (:3246-3250).
+//   quantitative: LinearRegressionScoreTest::TestCovariate (LinearRegressionScoreTest.cpp:173-263) and the
+//     accessors of MetaUnrelatedQtl (:3543-3549), GetSEBeta (LinearRegressionScoreTest.cpp:365-376)
+//   binary: LogisticRegressionScoreTest::TestCovariate (LogisticRegressionScoreTest.cpp:220-302) and the
+//     accessors of MetaUnrelatedBinary (:3754-3769); the d > 1 dimension mismatch is SURVEY quirk #15, as in
+//     orc_burden.
+// covb_diag: what PrintNullModel prints next to beta (LinearRegression.cpp:62-66, LogisticRegression.cpp:330-334).
+// ---------------------------------------------------------------------------------------------
+int orc_metascore(const double* Gp, int64_t N, int V, const double* Xp, int d, const double* y, int binary, int* ok,
+                  double* ustat, double* vstat, double* effect, double* se, double* pval, double* beta_out,
+                  double* covb_diag, double* sigma2_out) {
+  Mat X = wrap(Xp, N, d);
+  std::vector<double> beta(d), pred(N), resid(N), vv(N, 1.0);
+  double sigma2 = 1.0;
+  if (!binary) {
+    if (orc_fit_linear(Xp, y, N, d, beta.data(), pred.data(), resid.data(), &sigma2)) return -1;
+  } else {
+    if (orc_fit_logistic(Xp, y, N, d, 100, beta.data(), pred.data(), vv.data())) return -1;
+    for (int64_t i = 0; i < N; ++i) resid[i] = y[i] - pred[i];
+  }
+  Mat ZZ = binary ? orc::AtB(X, X, vv.data()) : orc::AtB(X, X), I(d, d), ZZi;
+  for (int i = 0; i < d; ++i) I(i, i) = 1;
+  if (!orc::chol_solve(ZZ, I, &ZZi)) return -1;
+  for (int k = 0; k < d; ++k) {
+    if (beta_out) beta_out[k] = beta[k];
+    if (covb_diag) covb_diag[k] = ZZi(k, k) * (binary ? 1.0 : sigma2);
+  }
+  if (sigma2_out) *sigma2_out = sigma2;
+  for (int h = 0; h < V; ++h) {
+    const double* g = Gp + (size_t)h * N;
+    ok[h] = 0;
+    ustat[h] = vstat[h] = effect[h] = se[h] = 0.0;
+    pval[h] = 1.0;
+    bool mono = true;
+    for (int64_t i = 1; i < N; ++i)
+      if (g[i] != g[0]) {
+        mono = false;
+        break;
+      }
+    if (mono) continue;
+    Mat Cm(N, 1);
+    std::memcpy(Cm.a.data(), g, sizeof(double) * (size_t)N);
+    double U = 0;
+    for (int64_t i = 0; i < N; ++i) U += g[i] * resid[i];
+    Mat ss = binary ? orc::AtB(Cm, Cm, vv.data()) : orc::AtB(Cm, Cm);
+    Mat SZ = binary ? orc::AtB(Cm, X, vv.data()) : orc::AtB(Cm, X);
+    Mat t = orc::mul(orc::mul(SZ, ZZi), orc::transpose(SZ));
+    const double SS = ss(0, 0) - t(0, 0);
+    if (!(SS > 0)) continue;
+    double stat;
+    if (!binary) {
+      const double Vlin = SS * sigma2;
+      ustat[h] = U / sigma2;
+      vstat[h] = Vlin / sigma2 / sigma2;
+      effect[h] = (Vlin != 0.0) ? U / SS : 0.0;
+      se[h] = sigma2 / std::sqrt(Vlin);
+      double SSi = 1.0 / SS;
+      SSi /= sigma2;
+      stat = U * SSi * U;
+    } else {
+      ustat[h] = U;
+      vstat[h] = SS;
+      effect[h] = (U != 0.0) ? U / SS : 0.0;
+      se[h] = 1.0 / std::sqrt(SS);
+      stat = U * (1.0 / SS) * U;
+    }
+    if (stat < 0) continue;
+    pval[h] = orc_chisq_Q(stat, 1.0);
+    ok[h] = 1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SKAT adaptive permutation (src/Model.h:2707-2717, src/Permutation.h:69-98, src/LinearAlgebra.h:8-21,
 // regression/Skat.cpp:107-116).  The residual vector is permuted cumulatively.
 // ---------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -425,6 +426,162 @@ void FamBurdenTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
             floatToString(v) + "\t" + floatToString(effect) + "\t" + floatToString(p) + "\n");
 }
 
+// ---- MetaScoreTest (src/Model.h:3155-3398), unrelated samples ------------------------------------------------------------
+MetaScoreTest::MetaScoreTest() {
+  modelName = "MetaScore";
+  if (const char* e = getenv("RVT_METASCORE_BLOCK")) capacity = std::max(1, std::min(65536, atoi(e)));
+}
+MetaScoreTest::~MetaScoreTest() {
+  if (fout) flush();
+  if (ctx && block) rvt_block_free(ctx, block);
+}
+int MetaScoreTest::setParameter(const ModelParser& parser) {
+  outputSE = parser.hasTag("se");  // src/Model.h:3177-3182 ("gwama" / "bolt" are not provided)
+  return 0;
+}
+int MetaScoreTest::fit(GeneData* dc) {
+  if (dc->kinshipU) {
+    lastError = "MetaScore with kinship (MetaFamQtl / MetaFamBinary) is not provided by the GPU library";
+    return -1;
+  }
+  if ((int)rows.size() >= capacity && used > 0 && flush()) return -1;
+  rows.emplace_back();
+  Row& row = rows.back();
+  row.all = dc->counter;  // site statistics are printed whether or not the test runs (src/Model.h:3211-3230)
+  if (isBinaryOutcome()) {
+    row.cases = dc->caseCounter;
+    row.ctrls = dc->ctrlCounter;
+  }
+  if (dc->N == 0) return -1;
+  if (nSample >= 0 && nSample != dc->N) {
+    lastError = "Sample size changed";
+    return -1;
+  }
+  if ((nSample >= 0) && (dc->phenotypeUpdated || dc->covariateUpdated) && used > 0) {
+    // rows tested so far belong to the previous null model: finish them before it is replaced
+    Row keep = row;
+    rows.pop_back();
+    if (flush()) return -1;
+    rows.push_back(keep);
+  }
+  ctx = GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
+  if (!ctx) return -1;
+  if (nSample < 0) {
+    nSample = dc->N;
+    nCovariate = dc->ncov + 1;
+    if (rvt_block_alloc(ctx, capacity, &block)) {
+      lastError = rvt_last_error(ctx);
+      return -1;
+    }
+  }
+  if (dc->M != 1) return -1;  // "sanity check, this should not happen" (src/Model.h:3241-3244)
+  // the caller overwrites the genotype buffer for the next site: copy the column into the device block now; whether
+  // the site is monomorphic (src/Model.h:3246-3250) is decided on the device when the block is processed
+  if (rvt_block_upload_columns(ctx, block, used, 1, dc->genotype)) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  rows.back().column = used++;
+  rows.back().tested = true;
+  return 0;
+}
+void MetaScoreTest::writeHeader(TextSink*, const SiteInfo&) {
+  // the header is deferred until the null model is known and is printed with the site columns writeOutput is given
+  // (src/Model.h:3262-3264, 3283-3303)
+}
+void MetaScoreTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  fout = fp;
+  if (siteHeaderTab.empty()) siteHeaderTab = siteInfo.headerTab();
+  if (rows.empty() || rows.back().written) rows.emplace_back();  // writeOutput without a fit(): counters unknown
+  rows.back().siteTab = siteInfo.valueTab();
+  rows.back().written = true;
+}
+void MetaScoreTest::writeFootnote(TextSink* fp) {
+  fout = fp;
+  flush();
+}
+
+namespace {
+std::string triple(const char* fmt, double a, double b, double c) {
+  char buf[128];
+  snprintf(buf, sizeof(buf), fmt, a, b, c);
+  return buf;
+}
+std::string tripleInt(int a, int b, int c) {
+  char buf[128];
+  snprintf(buf, sizeof(buf), "%d:%d:%d", a, b, c);
+  return buf;
+}
+}  // namespace
+
+int MetaScoreTest::flush() {
+  if (!fout) return 0;
+  std::vector<int> ok(std::max(used, 1));
+  std::vector<double> u(ok.size()), v(ok.size()), eff(ok.size()), se(ok.size()), pv(ok.size());
+  bool scored = false;
+  if (used > 0) {
+    if (rvt_score_block(ctx, block, used, ok.data(), u.data(), v.data(), eff.data(), se.data(), pv.data())) {
+      lastError = rvt_last_error(ctx);
+    } else {
+      scored = true;
+    }
+  }
+  if (!headerOutputted && (scored || used == 0)) {
+    // writeSummaryAndHeader (src/Model.h:3283-3297): g_SummaryHeader->outputHeader is the caller's; PrintNullModel:
+    if (scored) {
+      std::vector<double> beta(nCovariate), covb(nCovariate);
+      double sigma2 = 0.0;
+      if (rvt_null_summary(ctx, beta.data(), covb.data(), &sigma2) == RVT_OK) {
+        fout->write("##NullModelEstimates\n");
+        fout->write("## - Name\tBeta\tSD\n");
+        fout->write("## - Intercept\t" + formatG(beta[0]) + "\t" + formatG(covb[0]) + "\n");
+        for (size_t i = 0; i < covLabel.size(); ++i) {
+          if ((int)i + 1 >= nCovariate) break;
+          fout->write("## - " + covLabel[i] + "\t" + formatG(beta[i + 1]) + "\t" + formatG(covb[i + 1]) + "\n");
+        }
+        if (isBinaryOutcome())
+          fout->write("## - Sigma2\tNA\tNA\n");
+        else
+          fout->write("## - Sigma2\t" + formatG(sigma2) + "\tNA\n");
+      }
+    }
+    fout->write(siteHeaderTab);
+    fout->write(std::string("AF\tINFORMATIVE_ALT_AC\tCALL_RATE\tHWE_PVALUE\tN_REF\tN_HET\tN_ALT\tU_STAT\tSQRT_V_STAT\t"
+                            "ALT_EFFSIZE\t") +
+                (outputSE ? "ALT_EFFSIZE_SE\t" : "") + "PVALUE\n");
+    headerOutputted = true;
+  }
+  for (const Row& r : rows) {
+    if (!r.written) continue;  // main calls writeOutput after every fit(); a row never written is never printed
+    std::string line = r.siteTab;
+    const SiteCounts &a = r.all, &ca = r.cases, &ct = r.ctrls;
+    if (!isBinaryOutcome()) {  // src/Model.h:3307-3325
+      line += (a.af >= 0.0 ? floatToString(a.af) : std::string("NA")) + "\t";
+      line += floatToString(a.ac) + "\t" + floatToString(a.callRate) + "\t" + floatToString(a.hwe) + "\t";
+      line += std::to_string(a.nHomRef) + "\t" + std::to_string(a.nHet) + "\t" + std::to_string(a.nHomAlt) + "\t";
+    } else {  // src/Model.h:3310-3351
+      line += (a.af >= 0.0 ? triple("%g:%g:%g", a.af, ca.af, ct.af) : std::string("NA")) + "\t";
+      line += triple("%g:%g:%g", a.ac, ca.ac, ct.ac) + "\t";
+      line += triple("%g:%g:%g", a.callRate, ca.callRate, ct.callRate) + "\t";
+      line += triple("%g:%g:%g", a.hwe, ca.hwe, ct.hwe) + "\t";
+      line += tripleInt(a.nHomRef, ca.nHomRef, ct.nHomRef) + "\t" + tripleInt(a.nHet, ca.nHet, ct.nHet) + "\t" +
+              tripleInt(a.nHomAlt, ca.nHomAlt, ct.nHomAlt) + "\t";
+    }
+    const int k = r.column;
+    if (r.tested && scored && k >= 0 && ok[k]) {  // src/Model.h:3353-3364
+      line += floatToString(u[k]) + "\t" + floatToString(std::sqrt(v[k])) + "\t" + floatToString(eff[k]) + "\t";
+      if (outputSE) line += (v[k] > 0.0 ? floatToString(se[k]) : std::string("NA")) + "\t";
+      line += floatToString(pv[k]) + "\n";
+    } else {
+      line += std::string("NA\tNA\tNA\t") + (outputSE ? "NA\t" : "") + "NA\n";
+    }
+    fout->write(line);
+  }
+  rows.clear();
+  used = 0;
+  return scored || lastError.empty() ? 0 : -1;
+}
+
 // ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
 MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
   modelName = "MetaCov";
@@ -685,7 +842,9 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         return -1;
       }
     } else if (modelType == "meta") {
-      if (modelName == "cov") {
+      if (modelName == "score") {  // src/ModelManager.cpp:209-210
+        model.push_back(new MetaScoreTest());
+      } else if (modelName == "cov") {
         int windowSize;
         parser.assign("windowSize", &windowSize, 1000000);  // src/ModelManager.cpp:227-233
         model.push_back(new MetaCovTest(windowSize));

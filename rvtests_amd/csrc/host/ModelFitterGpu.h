@@ -31,6 +31,17 @@ namespace rvt_host {
 struct SiteInfo;
 
 // ---- what fit() may read: DataConsolidator getters (src/DataConsolidator.h:126-137,223-224) -------------
+// What MetaScoreTest reads from the caller's GenotypeCounter after dc->countRawGenotype(0, &counter)
+// (src/Model.h:3211-3230; libsrc/GenotypeCounter.h): the counting and the exact HWE test stay with the caller
+// (DataConsolidator / GenotypeCounter are not on the accelerated path), the adapter only prints them.
+struct SiteCounts {
+  double af = -1.0;       // getAF(); < 0 prints NA
+  double ac = 0.0;        // getAC()
+  double callRate = 0.0;  // getCallRate()
+  double hwe = 0.0;       // getHWE()
+  int nHomRef = 0, nHet = 0, nHomAlt = 0;
+};
+
 struct GeneData {
   int64_t N = 0;
   int M = 0;
@@ -46,6 +57,8 @@ struct GeneData {
   // Eigen::MatrixXf, i.e. float, column-major N x N and N x 1
   const float* kinshipU = nullptr;
   const float* kinshipS = nullptr;
+  // MetaScoreTest: raw-genotype counters of the current site — all samples, cases, controls (binary traits only)
+  SiteCounts counter, caseCounter, ctrlCounter;
 };
 
 // ---- FileWriter stand-in (base/IO.h FileWriter::write / printf) -------------------------------------------
@@ -303,6 +316,42 @@ class MetaCovTest : public ModelFitter {
   rvt_ctx* ctx = nullptr;
   double* block = nullptr;   // device block of RVT_MAX_VARIANTS columns
   std::vector<Site> sites;   // variants currently in the block, file order
+  TextSink* fout = nullptr;
+};
+
+// `--meta score` (src/Model.h:3155-3398), unrelated samples: MetaUnrelatedQtl / MetaUnrelatedBinary.  Sites are copied
+// into a device block as fit() sees them; a full block (or writeFootnote / the destructor) runs ONE rvt_score_block
+// over all of them and writes their rows in file order, after the summary header with the null-model estimates.
+class MetaScoreTest : public ModelFitter {
+ public:
+  MetaScoreTest();
+  ~MetaScoreTest() override;
+  int setParameter(const ModelParser& parser) override;
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeFootnote(TextSink* fp) override;
+  std::vector<std::string> covLabel;  // g_SummaryHeader->getCovLabel() (src/Model.h:3287-3289): set by the caller
+
+ private:
+  struct Row {
+    std::string siteTab;            // filled by writeOutput
+    SiteCounts all, cases, ctrls;
+    bool tested = false;            // fit() reached the score test (false: the row prints the counters only)
+    bool written = false;           // writeOutput was called for this site
+    int column = -1;                // column in the device block
+  };
+  int flush();
+  int capacity = 1024;              // RVT_METASCORE_BLOCK
+  bool outputSE = false;
+  bool headerOutputted = false;
+  std::string siteHeaderTab;
+  int64_t nSample = -1;
+  int nCovariate = 0;
+  int used = 0;                     // columns of the block in use
+  rvt_ctx* ctx = nullptr;
+  double* block = nullptr;
+  std::vector<Row> rows;
   TextSink* fout = nullptr;
 };
 

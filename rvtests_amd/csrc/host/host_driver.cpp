@@ -68,6 +68,9 @@ int main(int argc, char** argv) {
   else
     mm.setQuantitativeOutcome();
   const auto& models = mm.getModel();
+  for (auto* m : models)
+    if (auto* ms = dynamic_cast<MetaScoreTest*>(m))
+      for (int k = 0; k < ncov; ++k) ms->covLabel.push_back("cov" + std::to_string(k + 1));
   std::vector<TextSink> outs(models.size());
   SiteInfo site;
   site.kv = {{"Range", ""}, {"N_INFORMATIVE", std::to_string(N)}, {"NumVar", ""}, {"NumPolyVar", ""}};
@@ -113,6 +116,29 @@ int main(int argc, char** argv) {
         dc.genotype = G.data() + (size_t)j * N;
         dc.serial = (int64_t)(++variantIndex);
         dc.site = &vs;
+        // stand-in for dc->countRawGenotype(0, &counter) (+ case / control counters): this harness's genotypes are
+        // already imputed, the HWE exact test is the caller's and is not run here
+        for (int grp = 0; grp < (binary ? 3 : 1); ++grp) {
+          SiteCounts sc;
+          double sum = 0.0;
+          int64_t n = 0;
+          for (int64_t i = 0; i < N; ++i) {
+            if (grp == 1 && y[i] != 1.0) continue;
+            if (grp == 2 && y[i] != 0.0) continue;
+            const double gv = dc.genotype[i];
+            sum += gv;
+            ++n;
+            const long r = std::lround(gv);
+            if (r <= 0) ++sc.nHomRef;
+            else if (r == 1) ++sc.nHet;
+            else ++sc.nHomAlt;
+          }
+          sc.ac = sum;
+          sc.af = n ? sum / (2.0 * n) : -1.0;
+          sc.callRate = 1.0;
+          sc.hwe = 1.0;
+          (grp == 0 ? dc.counter : grp == 1 ? dc.caseCounter : dc.ctrlCounter) = sc;
+        }
         for (size_t m = 0; m < models.size(); ++m) {
           models[m]->reset();
           models[m]->fit(&dc);

@@ -334,6 +334,75 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restric
   }
 }
 
+// ---- MetaScoreTest, unrelated samples: single-variant score statistics of one block from the same partials ----
+//   quantitative (MetaUnrelatedQtl, src/Model.h:3516-3549 over LinearRegressionScoreTest.cpp:173-263):
+//     U = g'res, SS = g'g - g'X (X'X)^-1 X'g;  U_STAT = U / sigma2, V_STAT = SS / sigma2, effect = U / SS,
+//     SE = sigma2 / sqrt(SS sigma2), stat = U^2 / (SS sigma2)
+//   binary (MetaUnrelatedBinary, src/Model.h:3706-3769 over LogisticRegressionScoreTest.cpp:220-302):
+//     U = g'(y - p), V = g'Wg - g'WX (X'WX)^-1 X'Wg, effect = U / V (0 when U == 0), SE = 1 / sqrt(V), stat = U^2 / V
+//     (for d > 1 the reference's llt().solve(Identity(d, d)) on the 1 x 1 SS is a dimension mismatch, SURVEY quirk
+//     #15; the intended 1-df statistic is returned, as for CMC / Zeggini)
+// The block is submitted as one "gene" per slice of <= 16 columns (only the diagonal tile and the [X | rr] tile are
+// needed, so each slice streams once at the narrow-class rate); gene_id carries the slice's first column.
+// out: ustat | vstat | effect | se | pval (vt entries each); ok[h] = 1 when the site is polymorphic and SS > 0.
+__global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __restrict__ genes,
+                                                          const NullConsts* __restrict__ ncp, int vt,
+                                                          double* __restrict__ out, int* __restrict__ ok) {
+  const GeneDesc gd = genes[blockIdx.x];
+  const int V = gd.M, h = threadIdx.x;
+  if (h >= V) return;
+  const long long col = gd.gene_id + h;
+  double mn = INFINITY, mx = -INFINITY;
+  for (int p = 0; p < gd.n_wparts; ++p) {
+    const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+    mn = fmin(mn, c[gd.Mp + h]);
+    mx = fmax(mx, c[2 * gd.Mp + h]);
+  }
+  const int polymorphic = (mn == mx) ? 0 : 1;
+  const int d = ncp->d, binary = ncp->binary;
+  const double sigma2 = ncp->sigma2;
+  double shh = 0.0, u = 0.0, t[RVT_MAX_COV];
+  for (int k = 0; k < d; ++k) t[k] = 0.0;
+  for (int p = 0; p < gd.n_wparts; ++p) {
+    const double* row = gd.parts + (long long)p * gd.Mp * gd.Cp + (long long)h * gd.Cp;
+    shh += row[h];
+    for (int k = 0; k < d; ++k) t[k] += row[V + k];
+    u += row[V + d];
+  }
+  double q = 0.0;
+  for (int k = 0; k < d; ++k) {
+    double s = 0.0;
+    for (int l = 0; l < d; ++l) s += ncp->Cinv[k * d + l] * t[l];
+    q += t[k] * s;
+  }
+  const double SS = shh - q;
+  const int fit = polymorphic && SS > 0.0;
+  double us = 0.0, vs = 0.0, eff = 0.0, se = 0.0, pv = 1.0;
+  if (fit) {
+    if (!binary) {
+      us = u / sigma2;
+      vs = SS / sigma2;
+      eff = u / SS;
+      se = sigma2 / sqrt(SS * sigma2);
+      double SSi = 1.0 / SS;
+      SSi /= sigma2;
+      pv = chisq_Q(u * SSi * u, 1.0);
+    } else {
+      us = u;
+      vs = SS;
+      eff = (u != 0.0) ? u / SS : 0.0;
+      se = 1.0 / sqrt(SS);
+      pv = chisq_Q(u * (1.0 / SS) * u, 1.0);
+    }
+  }
+  out[col] = us;
+  out[(long long)vt + col] = vs;
+  out[2LL * vt + col] = eff;
+  out[3LL * vt + col] = se;
+  out[4LL * vt + col] = pv;
+  ok[col] = fit;
+}
+
 // ---- MetaCov for windows wider than one block: heads x window rectangle from two plain GEMMs ------------------
 // S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from rocBLAS; cs = raw column sums
 // of the W window columns (the H heads are its first H columns).  Unrelated samples only.

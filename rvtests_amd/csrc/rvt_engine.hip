@@ -123,6 +123,8 @@ struct rvt_ctx {
   NullConsts* d_nc = nullptr;
   double *d_X = nullptr, *d_res = nullptr, *d_rr = nullptr, *d_v = nullptr, *d_zeros = nullptr;
   int64_t null_ld = 0;
+  double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
+  bool have_null_beta = false;
   // streaming interface
   struct Pending {
     int64_t id;
@@ -488,6 +490,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   for (auto& bp : c->block_pool) hipFree(bp.second);  // pooled blocks were laid out for the previous N
   c->block_pool.clear();
   free_null(c);
+  c->have_null_beta = false;
   const int64_t ld = rvt_padded_ld(N);
   NullConsts& nc = c->nc;
   std::memset(&nc, 0, sizeof(nc));
@@ -609,6 +612,10 @@ struct CovOut {  // rvt_cov_block: host destinations
   const int* d_raw_poly = nullptr;
   // family burden tests: per-column U, V, GLS allele frequency, p-value (host, V entries each); cov/xz may be null
   double *ustat = nullptr, *vstat = nullptr, *af = nullptr, *pval = nullptr;
+  // MetaScoreTest (unrelated samples): ustat / vstat / effect / se / pval / ok, V entries each; no covariance rows
+  bool score = false;
+  double *effect = nullptr, *se = nullptr;
+  int* ok = nullptr;
 };
 
 // covZZ / covZZInv and the other constants of the MetaCov algebra for the installed null model (or, fam = true,
@@ -752,8 +759,13 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
-  size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0, off_cov_bur = 0;
-  if (cov) {
+  size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0, off_cov_bur = 0, off_cov_ok = 0;
+  if (cov && cov->score) {  // one gene per 16-column slice of the block: per-variant records only
+    size_t vt = 0;
+    for (int g = 0; g < n; ++g) vt += (size_t)Ms[g];
+    off_cov_bur = add(sizeof(double) * vt * 5);
+    off_cov_ok = add(sizeof(int) * vt);
+  } else if (cov) {
     const size_t V = (size_t)Ms[0];
     off_cov = add(sizeof(double) * V * V);
     off_cov_xz = add(sizeof(double) * V * (size_t)d);
@@ -846,6 +858,23 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
   HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
+  if (cov && cov->score) {  // MetaScore: per-variant statistics of every slice, returned synchronously
+    size_t vt = 0;
+    for (int g = 0; g < n; ++g) vt += (size_t)Ms[g];
+    double* d_bur = reinterpret_cast<double*>(base + off_cov_bur);
+    int* d_ok = reinterpret_cast<int*>(base + off_cov_ok);
+    hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)n), dim3(64), 0, st, d_desc, c->d_nc, (int)vt, d_bur, d_ok);
+    HIP_TRY(c, hipGetLastError());
+    const size_t vb8 = sizeof(double) * vt;
+    HIP_TRY(c, hipMemcpyAsync(cov->ustat, d_bur, vb8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->vstat, d_bur + vt, vb8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->effect, d_bur + 2 * vt, vb8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->se, d_bur + 3 * vt, vb8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->pval, d_bur + 4 * vt, vb8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(cov->ok, d_ok, sizeof(int) * vt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return RVT_OK;
+  }
   if (cov) {  // MetaCov: finish the covariance algebra of this one block and return its band synchronously
     const int V = Ms[0];
     CovConsts cc;
@@ -1907,7 +1936,12 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (beta_out)
     for (int a = 0; a < d; ++a) beta_out[a] = beta[a];
   if (sigma2_out) *sigma2_out = sigma2;
-  return rvt_set_null(c, trait, N, d, X, res.data(), v.data(), sigma2);
+  const int rcs = rvt_set_null(c, trait, N, d, X, res.data(), v.data(), sigma2);
+  if (rcs == RVT_OK) {  // kept for rvt_null_summary (rvt_set_null alone leaves the estimates unknown)
+    for (int a = 0; a < d; ++a) c->null_beta[a] = beta[a];
+    c->have_null_beta = true;
+  }
+  return rcs;
 }
 
 // ---- SKAT permutations (exact replay of the reference's rand() stream) ------------------------------------------
@@ -2108,6 +2142,59 @@ int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* 
 int rvt_rand_seed(rvt_ctx* c, unsigned seed) {
   if (!c) return RVT_E_INVALID;
   seed_rand_state(c->rand_state, seed);
+  return RVT_OK;
+}
+
+// ---- MetaScore: single-variant score statistics of a block of variants (unrelated samples) -----------------
+int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat, double* vstat, double* effect,
+                    double* effect_se, double* pvalue) {
+  if (!c || !dG || V < 1 || !ok || !ustat || !vstat || !effect || !effect_se || !pvalue)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  int rc = rvt_sync(c);  // processed synchronously
+  if (rc) return rc;
+  constexpr int kSlice = 16, kChunk = 256;  // columns per slice, slices per launch
+  const int64_t ld = c->null_ld;
+  std::vector<double> af((size_t)kSlice * kChunk, 0.01);
+  std::vector<rvt_gene_result> rs(kChunk);
+  for (int c0 = 0; c0 < V; c0 += kSlice * kChunk) {
+    const int cols = std::min(V - c0, kSlice * kChunk), n = (cols + kSlice - 1) / kSlice;
+    std::vector<const double*> ptr(n);
+    std::vector<int> Ms(n);
+    std::vector<int64_t> ids(n);
+    for (int g = 0; g < n; ++g) {
+      ptr[g] = dG + (size_t)(c0 + g * kSlice) * ld;
+      Ms[g] = std::min(kSlice, cols - g * kSlice);
+      ids[g] = (int64_t)g * kSlice;
+    }
+    CovOut co;
+    co.score = true;
+    co.ok = ok + c0;
+    co.ustat = ustat + c0;
+    co.vstat = vstat + c0;
+    co.effect = effect + c0;
+    co.se = effect_se + c0;
+    co.pval = pvalue + c0;
+    rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
+    for (auto& sl : c->slots) {
+      if (sl.pending_out == rs.data()) {
+        sl.pending_out = nullptr;
+        sl.pending_n = 0;
+      }
+    }
+    if (rc) return rc;
+  }
+  return RVT_OK;
+}
+
+int rvt_null_summary(rvt_ctx* c, double* beta, double* covb_diag, double* sigma2) {
+  if (!c || !covb_diag) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  const NullConsts& nc = c->nc;
+  if (beta)
+    for (int k = 0; k < nc.d; ++k) beta[k] = c->have_null_beta ? c->null_beta[k] : NAN;
+  for (int k = 0; k < nc.d; ++k) covb_diag[k] = nc.Cinv[k * nc.d + k] * (nc.binary ? 1.0 : nc.sigma2);
+  if (sigma2) *sigma2 = nc.sigma2;
   return RVT_OK;
 }
 

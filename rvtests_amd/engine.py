@@ -175,6 +175,10 @@ def load_library():
     L.rvt_block_copy_columns.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
     L.rvt_cov_block_fam.restype = C.c_int
     L.rvt_cov_block_fam.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
+    L.rvt_score_block.restype = C.c_int
+    L.rvt_score_block.argtypes = [vp, vp, C.c_int, c_int_p] + [c_double_p] * 5
+    L.rvt_null_summary.restype = C.c_int
+    L.rvt_null_summary.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     L.rvt_cov_block.restype = C.c_int
     L.rvt_cov_block.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_upload_columns.restype = C.c_int
@@ -401,6 +405,21 @@ class Engine:
         self._check(self.L.rvt_cov_block(self.ctx, C.c_void_p(int(ptr)), V, _dp(cov), _dp(xz), _dp(zz),
                                          poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
+
+    def score_block(self, ptr, V):
+        """MetaScore statistics of the V columns of a device block: dict of ok, U, V, effect, se, p arrays."""
+        ok = np.zeros(V, dtype=np.int32)
+        arr = [np.zeros(V) for _ in range(5)]
+        self._check(self.L.rvt_score_block(self.ctx, C.c_void_p(int(ptr)), int(V), ok.ctypes.data_as(c_int_p),
+                                           *[_dp(a) for a in arr]))
+        return dict(ok=ok, U=arr[0], V=arr[1], effect=arr[2], se=arr[3], p=arr[4])
+
+    def null_summary(self):
+        """(beta, diag covB, sigma2) of the installed null model, as MetaScoreTest::PrintNullModel prints them."""
+        beta, covb = np.zeros(self.d), np.zeros(self.d)
+        s2 = C.c_double(0)
+        self._check(self.L.rvt_null_summary(self.ctx, _dp(beta), _dp(covb), C.cast(C.byref(s2), c_double_p)))
+        return beta, covb, s2.value
 
     def fam_binary_scale(self, n_case, n_ctrl):
         a, b = C.c_double(0), C.c_double(0)

@@ -277,6 +277,26 @@ def burden(G, X, y, binary, which):
     return rc, out
 
 
+def metascore(G, X, y, binary):
+    """MetaScoreTest (unrelated samples) restatement: dict of ok, U, V, effect, se, p (V entries) + beta, covb, sigma2."""
+    G = F(G)
+    X = F(X)
+    N, V = G.shape
+    d = X.shape[1]
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    ok = np.zeros(V, dtype=np.int32)
+    arr = [np.zeros(V) for _ in range(5)]
+    beta, covb = np.zeros(d), np.zeros(d)
+    s2 = C.c_double(0)
+    L = lib()
+    L.orc_metascore.restype = C.c_int
+    rc = L.orc_metascore(_dp(G), C.c_int64(N), V, _dp(X), d, _dp(y), int(binary),
+                         ok.ctypes.data_as(C.POINTER(C.c_int)), *[_dp(a) for a in arr], _dp(beta), _dp(covb),
+                         C.byref(s2))
+    return rc, dict(ok=ok, U=arr[0], V=arr[1], effect=arr[2], se=arr[3], p=arr[4], beta=beta, covb=covb,
+                    sigma2=s2.value)
+
+
 def metacov(G, chrom, pos, X, y, binary, window, use_float=False):
     """MetaCovTest (unrelated samples) restatement: returns rc, kept[V], cov[V, V] (cov[h, j] for j >= h in h's
     row, NaN elsewhere; unscaled), row_end[V], xz[V, d], zz[d, d]."""

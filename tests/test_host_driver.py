@@ -336,3 +336,95 @@ def test_driver_metacov_with_kinship(tmp_path):
         want = np.array([float(np.float32(cov[h, j]) * scale) for j in js])
         # the null fit (delta) is pinned to the reference's Brent stopping accuracy only, see test_gpu_fam.py
         assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
+
+
+def _score_case(tmp_path, binary, N=1500, d=3):
+    genes = [synth.make_gene(N, M, seed=170 + M, missing=0.01, common=True, mono=True)[1:] for M in (30, 25)]
+    X, y, res, v, s2 = synth.make_null(N, d, binary, seed=19)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], binary, genes)
+    G = np.concatenate([g for g, af in genes], axis=1)
+    sites = str(tmp_path / "sites.txt")
+    with open(sites, "w") as f:
+        for k in range(G.shape[1]):
+            f.write("1 %d\n" % (100 + 10 * k))
+    return path, sites, G, X, y
+
+
+def test_metascore_registry_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    _ensure_driver()
+    path, sites, G, X, y = _score_case(tmp_path, 0)
+    rc, lines, err = run_driver_meta(path, "score[se]", sites)
+    assert rc == 0, err
+    assert lines[0] == "== out.MetaScore.assoc"
+    # no device => no null model: as when the reference's null fit fails, every row carries the caller's site counters
+    # and NA statistics — never a CPU result
+    assert lines[1].split("\t")[-5:] == ["U_STAT", "SQRT_V_STAT", "ALT_EFFSIZE", "ALT_EFFSIZE_SE", "PVALUE"]
+    assert len(lines) == 2 + G.shape[1]
+    assert all(ln.split("\t")[-5:] == ["NA"] * 5 for ln in lines[2:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary,se,block", [(0, False, None), (0, True, 7), (1, False, None), (1, True, 16)])
+def test_driver_metascore_rows_match_oracle(tmp_path, binary, se, block):
+    """--meta score through the C++ adapter: the deferred summary header with the null-model estimates, one row per
+    site in file order (NA statistics for monomorphic sites), numbers equal to the oracle's after %g formatting;
+    `block` forces several mid-stream flushes."""
+    _ensure_driver()
+    path, sites, G, X, y = _score_case(tmp_path, binary)
+    N, V = G.shape
+    d = X.shape[1]
+    env = dict(os.environ)
+    if block:
+        env["RVT_METASCORE_BLOCK"] = str(block)
+    p = subprocess.run([DRIVER, path, "-", "-", "score[se]" if se else "score", sites], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.MetaScore.assoc"
+    rc, o = orc.metascore(G, X, y, binary)
+    assert rc == 0
+    # summary header (MetaScoreTest::PrintNullModel)
+    assert lines[1] == "##NullModelEstimates" and lines[2] == "## - Name\tBeta\tSD"
+    est = [ln.split("\t") for ln in lines[3:3 + d + 1]]
+    assert [e[0] for e in est] == ["## - Intercept"] + ["## - cov%d" % k for k in range(1, d)] + ["## - Sigma2"]
+    for k in range(d):
+        assert float(est[k][1]) == pytest.approx(o["beta"][k], rel=6e-6, abs=1e-9)
+        assert float(est[k][2]) == pytest.approx(o["covb"][k], rel=6e-6)
+    if binary:
+        assert est[d][1:] == ["NA", "NA"]
+    else:
+        assert float(est[d][1]) == pytest.approx(o["sigma2"], rel=6e-6) and est[d][2] == "NA"
+    hdr = lines[4 + d].split("\t")
+    cols = ["CHROM", "POS", "AF", "INFORMATIVE_ALT_AC", "CALL_RATE", "HWE_PVALUE", "N_REF", "N_HET", "N_ALT", "U_STAT",
+            "SQRT_V_STAT", "ALT_EFFSIZE"] + (["ALT_EFFSIZE_SE"] if se else []) + ["PVALUE"]
+    assert hdr == cols
+    rows = [ln.split("\t") for ln in lines[5 + d:]]
+    assert len(rows) == V
+    n_na = 0
+    for h, row in enumerate(rows):
+        assert len(row) == len(cols)
+        assert row[0] == "1" and row[1] == str(100 + 10 * h)
+        g = G[:, h]
+        if binary:
+            af = [float(t) for t in row[2].split(":")]
+            assert len(af) == 3 and af[0] == pytest.approx(g.sum() / (2 * N), rel=6e-6, abs=1e-12)
+            assert af[1] == pytest.approx(g[y == 1].sum() / (2 * (y == 1).sum()), rel=6e-6, abs=1e-12)
+            nref = [int(t) for t in row[6].split(":")]
+            assert nref[0] == nref[1] + nref[2] == int((np.rint(g) <= 0).sum())
+        else:
+            assert float(row[2]) == pytest.approx(g.sum() / (2 * N), rel=6e-6, abs=1e-12)
+            assert [int(row[6]), int(row[7]), int(row[8])] == [int((np.rint(g) <= 0).sum()), int((np.rint(g) == 1).sum()),
+                                                              int((np.rint(g) >= 2).sum())]
+        stats = row[9:]
+        if not o["ok"][h]:
+            assert stats == ["NA"] * len(stats)
+            n_na += 1
+            continue
+        want = [o["U"][h], np.sqrt(o["V"][h]), o["effect"][h]] + ([o["se"][h]] if se else []) + [o["p"][h]]
+        for got, w in zip(stats, want):
+            assert float(got) == pytest.approx(w, rel=6e-6, abs=1e-12)
+    assert 0 < n_na < V // 2

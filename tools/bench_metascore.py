@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Throughput of the MetaScore single-variant statistics (rvt_score_block) at full size: one device block of V
+variants, N samples, read once (8 N V algorithmic bytes).  Reports ms per block, variants per second and the
+algorithmic bandwidth.  usage (GPU box): python tools/bench_metascore.py [--samples 500000] [--variants 4096]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rvtests_amd  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=500000)
+    ap.add_argument("--variants", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    N, V = a.samples, a.variants
+    eng = rvtests_amd.Engine(0)
+    ld = eng.padded_ld(N)
+    X, y, res, sigma2 = bench.fit_null_qt(dev, N, 7)
+    eng.set_null(rvtests_amd.TRAIT_QUANTITATIVE, np.asfortranarray(X.cpu().numpy()), res.cpu().numpy().copy(),
+                 np.full(N, float(sigma2)), float(sigma2))
+    blocks, Ms, afs = bench.make_genes(dev, N, ld, 1, 5, V, V)
+    torch.cuda.synchronize()
+    eng.score_block(blocks[0].data_ptr(), V)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        r = eng.score_block(blocks[0].data_ptr(), V)
+    dt = (time.perf_counter() - t0) / a.reps
+    print({"N": N, "V": V, "ms_per_block": 1e3 * dt, "variants_per_s": V / dt, "alg_GBps": 8.0 * N * V / dt / 1e9,
+           "tested": int(r["ok"].sum())})
+
+
+if __name__ == "__main__":
+    main()
