@@ -227,6 +227,16 @@ int rvt_score_block(rvt_ctx* ctx, const double* dG, int V, int* ok, double* usta
  * regression/LogisticRegression.cpp:330-334) and sigma2 (quantitative; 1 for a binary trait).  beta / sigma2 may be
  * NULL. */
 int rvt_null_summary(rvt_ctx* ctx, double* beta, double* covb_diag, double* sigma2);
+/* MetaScore with kinship, quantitative trait (MetaFamQtl, src/Model.h:3398-3499): FastLMM::TestCovariate in its SCORE
+ * branch (regression/FastLMM.cpp:215-247; genotype centred) and FastLMM::FastGetAF (:400-424) of every raw column of a
+ * device block, after rvt_set_kinship + rvt_fit_fam_null.  ustat / vstat = GetUStat / GetVStat, af = the GLS allele
+ * frequency, pvalue = 1 when V <= 0; ALT_EFFSIZE = U / V and its SE = 1 / sqrt(V) are the caller's divisions.
+ * ok[h] = 0 for a monomorphic site.  MetaFamBinary (uncentred genotypes, b scaling) is not provided. */
+int rvt_score_block_fam(rvt_ctx* ctx, const double* dG, int V, int* ok, double* ustat, double* vstat, double* af,
+                        double* pvalue);
+/* Diagonal of FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483) for MetaFamQtl::PrintNullModel; beta, SigmaG2 =
+ * sigma2_g and SigmaE2 = sigma2_g * delta come from rvt_fit_fam_null's rvt_fam_null. */
+int rvt_fam_null_summary(rvt_ctx* ctx, double* covb_diag);
 /* Copy columns between two device blocks (growing the adapter's ring). */
 int rvt_block_copy_columns(rvt_ctx* ctx, double* dst, int dst_col, const double* src, int src_col, int ncols);
 /* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous). */

@@ -140,13 +140,17 @@ int orc_famskat(const double* G, int64_t N, int M, const double* X, const double
 
 /* FamCMC / FamZeggini (src/Model.h:2261-2492): cmcCollapse / zegginiCollapse of the flipped, polymorphic block, then
    FastLMM::TestCovariate in its SCORE branch (regression/FastLMM.cpp:215-247, scaledK LITERALLY as an N x N matrix) and
-   FastLMM::GetAF (:356-398).  which: 0 = CMC, 1 = Zeggini.  Returns -1 when no polymorphic column is left. */
+   FastLMM::GetAF (:356-398).  which: 0 = CMC, 1 = Zeggini, 2 = MetaScoreTest's MetaFamQtl (src/Model.h:3421-3434: the
+   single raw column itself, M == 1, no flip).  Returns -1 when no polymorphic column is left. */
 typedef struct {
   int fit_ok, num_site;
   double af, U, V, stat, pvalue;
 } orc_fam_burden_result;
 int orc_fam_burden(const double* G, int64_t N, int M, const double* X, const double* y, int d, const double* U,
                    const double* S, const orc_fam_null* nul, int which, int use_float, orc_fam_burden_result* out);
+/* FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483), d x d. */
+int orc_fastlmm_covb(const double* X, int64_t N, int d, const double* U, const double* S, double delta, int use_float,
+                     double* covb);
 /* obtainB (src/Model.cpp:339-369): b = integral over R of logistic'(alpha + x) phi(x) dx, evaluated by the reference
    with gsl_integration_qagi (epsrel 1e-7).  Restated with the QAGS restatement on QAGI's own change of variable
    x = (1 - t) / t over (0, 1] (both half lines folded); the integrand is smooth, so the two adaptive rules agree far

@@ -502,16 +502,28 @@ int orc_fam_burden(const double* Gp, int64_t N, int M, const double* Xp, const d
   F32 F{use_float != 0};
   std::vector<double> Gf((size_t)N * M);
   std::vector<int> fl(M), kp(M);
-  const int m = orc_flip_poly(Gp, N, M, Gf.data(), fl.data(), kp.data());
-  out->num_site = m;
-  if (m == 0) return -1;
-  // cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130)
   std::vector<double> c(N, 0.0);
-  for (int64_t i = 0; i < N; ++i) {
-    int n = 0;
-    for (int j = 0; j < m; ++j)
-      if ((int)Gf[(size_t)j * N + i] > 0) ++n;
-    c[i] = which == 0 ? (n > 0 ? 1.0 : 0.0) : (double)n;
+  if (which == 2) {
+    // MetaScoreTest with kinship (MetaFamQtl::TestCovariate, src/Model.h:3421-3434): the single genotype column as it
+    // is (imputed, not flipped); monomorphic sites are skipped before the test (:3246-3250)
+    if (M != 1) return -1;
+    bool mono = true;
+    for (int64_t i = 1; i < N; ++i)
+      if (Gp[i] != Gp[0]) mono = false;
+    out->num_site = mono ? 0 : 1;
+    if (mono) return -1;
+    for (int64_t i = 0; i < N; ++i) c[i] = Gp[i];
+  } else {
+    const int m = orc_flip_poly(Gp, N, M, Gf.data(), fl.data(), kp.data());
+    out->num_site = m;
+    if (m == 0) return -1;
+    // cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130)
+    for (int64_t i = 0; i < N; ++i) {
+      int n = 0;
+      for (int j = 0; j < m; ++j)
+        if ((int)Gf[(size_t)j * N + i] > 0) ++n;
+      c[i] = which == 0 ? (n > 0 ? 1.0 : 0.0) : (double)n;
+    }
   }
   Mat U = wrapd(Up, N, N), X = wrapd(Xp, N, d);
   const double sigma2 = nul->sigma2, delta = nul->delta;
@@ -593,6 +605,32 @@ int orc_fam_burden(const double* Gp, int64_t N, int M, const double* Xp, const d
   }
   out->af = (denom == 0.0) ? 0.0 : 0.5 * (numer / denom);
   out->fit_ok = 1;
+  return 0;
+}
+
+// FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483): (ux' diag(lambda + delta) ux)^-1, ux = U'X, lambda = |S|
+// (the reference multiplies by lambda + delta although its comment derives the inverse weights; restated literally).
+int orc_fastlmm_covb(const double* Xp, int64_t N, int d, const double* Up, const double* S, double delta, int use_float,
+                     double* covb) {
+  F32 F{use_float != 0};
+  Mat U = wrapd(Up, N, N), X = wrapd(Xp, N, d), ux(N, d);
+  for (int64_t k = 0; k < N; ++k)
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(U(i, k)) * F(X(i, a))));
+      ux(k, a) = s;
+    }
+  Mat A(d, d), I(d, d), Ai;
+  for (int a = 0; a < d; ++a) {
+    I(a, a) = 1.0;
+    for (int b = 0; b < d; ++b) {
+      double s = 0;
+      for (int64_t i = 0; i < N; ++i) s = F(s + F(F(ux(i, a) * F(std::fabs(F(S[i])) + delta)) * ux(i, b)));
+      A(a, b) = s;
+    }
+  }
+  if (!orc::sym_solve(A, I, &Ai)) return -1;
+  for (int a = 0; a < d * d; ++a) covb[a] = Ai.a[a];
   return 0;
 }
 

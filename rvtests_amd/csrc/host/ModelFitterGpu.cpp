@@ -178,8 +178,7 @@ rvt_ctx* GpuBroker::contextWithFamNull(const GeneData& gd, std::string* err) {
     std::vector<double> X((size_t)gd.N * d);
     for (int64_t i = 0; i < gd.N; ++i) X[i] = 1.0;
     if (gd.ncov) std::memcpy(X.data() + gd.N, gd.covariate, sizeof(double) * (size_t)gd.N * gd.ncov);
-    rvt_fam_null fn;
-    if (rvt_fit_fam_null(ctx, gd.N, d, X.data(), gd.phenotype, &fn)) {
+    if (rvt_fit_fam_null(ctx, gd.N, d, X.data(), gd.phenotype, &famNull)) {
       *err = "SKAT test (for related individuals) failed in fitting null model (SKAT)";
       return nullptr;
     }
@@ -440,8 +439,9 @@ int MetaScoreTest::setParameter(const ModelParser& parser) {
   return 0;
 }
 int MetaScoreTest::fit(GeneData* dc) {
-  if (dc->kinshipU) {
-    lastError = "MetaScore with kinship (MetaFamQtl / MetaFamBinary) is not provided by the GPU library";
+  useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaFamQtl (src/Model.h:3398-3499)
+  if (useFamilyModel && isBinaryOutcome()) {
+    lastError = "MetaScore with kinship for a binary trait (MetaFamBinary) is not provided by the GPU library";
     return -1;
   }
   if ((int)rows.size() >= capacity && used > 0 && flush()) return -1;
@@ -464,7 +464,8 @@ int MetaScoreTest::fit(GeneData* dc) {
     if (flush()) return -1;
     rows.push_back(keep);
   }
-  ctx = GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
+  ctx = useFamilyModel ? GpuBroker::instance().contextWithFamNull(*dc, &lastError)
+                       : GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
   if (!ctx) return -1;
   if (nSample < 0) {
     nSample = dc->N;
@@ -519,11 +520,21 @@ int MetaScoreTest::flush() {
   std::vector<int> ok(std::max(used, 1));
   std::vector<double> u(ok.size()), v(ok.size()), eff(ok.size()), se(ok.size()), pv(ok.size());
   bool scored = false;
+  std::vector<double> famAf(ok.size());
   if (used > 0) {
-    if (rvt_score_block(ctx, block, used, ok.data(), u.data(), v.data(), eff.data(), se.data(), pv.data())) {
+    const int rc = useFamilyModel
+                       ? rvt_score_block_fam(ctx, block, used, ok.data(), u.data(), v.data(), famAf.data(), pv.data())
+                       : rvt_score_block(ctx, block, used, ok.data(), u.data(), v.data(), eff.data(), se.data(),
+                                         pv.data());
+    if (rc) {
       lastError = rvt_last_error(ctx);
     } else {
       scored = true;
+      if (useFamilyModel)  // MetaFamQtl::GetEffect / FastLMM::GetSE (src/Model.h:3491-3496, FastLMM.cpp:452-455)
+        for (int k = 0; k < used; ++k) {
+          eff[k] = v[k] != 0.0 ? u[k] / v[k] : 0.0;
+          se[k] = v[k] != 0.0 ? 1.0 / std::sqrt(v[k]) : 0.0;
+        }
     }
   }
   if (!headerOutputted && (scored || used == 0)) {
@@ -531,7 +542,15 @@ int MetaScoreTest::flush() {
     if (scored) {
       std::vector<double> beta(nCovariate), covb(nCovariate);
       double sigma2 = 0.0;
-      if (rvt_null_summary(ctx, beta.data(), covb.data(), &sigma2) == RVT_OK) {
+      int rcs;
+      const rvt_fam_null& fnull = GpuBroker::instance().familyNull();
+      if (useFamilyModel) {
+        rcs = rvt_fam_null_summary(ctx, covb.data());
+        for (int k = 0; k < nCovariate; ++k) beta[k] = fnull.beta[k];
+      } else {
+        rcs = rvt_null_summary(ctx, beta.data(), covb.data(), &sigma2);
+      }
+      if (rcs == RVT_OK) {
         fout->write("##NullModelEstimates\n");
         fout->write("## - Name\tBeta\tSD\n");
         fout->write("## - Intercept\t" + formatG(beta[0]) + "\t" + formatG(covb[0]) + "\n");
@@ -539,10 +558,14 @@ int MetaScoreTest::flush() {
           if ((int)i + 1 >= nCovariate) break;
           fout->write("## - " + covLabel[i] + "\t" + formatG(beta[i + 1]) + "\t" + formatG(covb[i + 1]) + "\n");
         }
-        if (isBinaryOutcome())
+        if (useFamilyModel) {  // GetSigmaG2 = sigma2, GetSigmaE2 = sigma2 * delta (FastLMM.cpp:456-457)
+          fout->write("## - SigmaG2\t" + formatG(fnull.sigma2_g) + "\tNA\n");
+          fout->write("## - SigmaE2\t" + formatG(fnull.sigma2_g * fnull.delta) + "\tNA\n");
+        } else if (isBinaryOutcome()) {
           fout->write("## - Sigma2\tNA\tNA\n");
-        else
+        } else {
           fout->write("## - Sigma2\t" + formatG(sigma2) + "\tNA\n");
+        }
       }
     }
     fout->write(siteHeaderTab);
@@ -556,7 +579,9 @@ int MetaScoreTest::flush() {
     std::string line = r.siteTab;
     const SiteCounts &a = r.all, &ca = r.cases, &ct = r.ctrls;
     if (!isBinaryOutcome()) {  // src/Model.h:3307-3325
-      line += (a.af >= 0.0 ? floatToString(a.af) : std::string("NA")) + "\t";
+      // with kinship a tested site prints FastGetAF instead of the counter's frequency (src/Model.h:3255-3257)
+      const double afv = (useFamilyModel && r.tested && scored && r.column >= 0 && ok[r.column]) ? famAf[r.column] : a.af;
+      line += (afv >= 0.0 ? floatToString(afv) : std::string("NA")) + "\t";
       line += floatToString(a.ac) + "\t" + floatToString(a.callRate) + "\t" + floatToString(a.hwe) + "\t";
       line += std::to_string(a.nHomRef) + "\t" + std::to_string(a.nHet) + "\t" + std::to_string(a.nHomAlt) + "\t";
     } else {  // src/Model.h:3310-3351

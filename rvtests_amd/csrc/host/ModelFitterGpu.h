@@ -143,12 +143,14 @@ class GpuBroker {
   typedef int (*NullFitter)(bool binary, int64_t N, int d, const double* X, const double* y, double* res, double* v,
                             double* sigma2);
   void setNullFitter(NullFitter f) { fitter = f; }
+  const rvt_fam_null& familyNull() const { return famNull; }  // estimates of the FastLMM null last fitted
 
  private:
   rvt_ctx* ctx = nullptr;
   uint32_t tests = 0;
   rvt_params params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   bool haveNull = false;
+  rvt_fam_null famNull{};
   int64_t curSerial = -1;
   bool curOk = false;
   int window = 1;
@@ -319,7 +321,8 @@ class MetaCovTest : public ModelFitter {
   TextSink* fout = nullptr;
 };
 
-// `--meta score` (src/Model.h:3155-3398), unrelated samples: MetaUnrelatedQtl / MetaUnrelatedBinary.  Sites are copied
+// `--meta score` (src/Model.h:3155-3398): MetaUnrelatedQtl / MetaUnrelatedBinary, and MetaFamQtl when the caller hands
+// over a kinship decomposition (MetaFamBinary and the BOLT variants are not provided).  Sites are copied
 // into a device block as fit() sees them; a full block (or writeFootnote / the destructor) runs ONE rvt_score_block
 // over all of them and writes their rows in file order, after the summary header with the null-model estimates.
 class MetaScoreTest : public ModelFitter {
@@ -344,6 +347,7 @@ class MetaScoreTest : public ModelFitter {
   int flush();
   int capacity = 1024;              // RVT_METASCORE_BLOCK
   bool outputSE = false;
+  bool useFamilyModel = false;
   bool headerOutputted = false;
   std::string siteHeaderTab;
   int64_t nSample = -1;

@@ -92,6 +92,7 @@ struct rvt_ctx {
   NullConsts famcov_nc;
   NullConsts* d_famcov_nc = nullptr;
   double *d_cX = nullptr, *d_cv = nullptr;
+  double fam_delta = 0.0;   // delta of the fitted FastLMM null (rvt_fam_null_summary)
   double famcov_b2 = 1.0;  // MetaCovFamBinary: b^2
   double famcov_k1r = 0.0; // u1' D uResid
   double* d_cr = nullptr;  // uResid (the rr column of the family-covariance null set)
@@ -1369,6 +1370,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
   }
   out->delta = delta;
   out->sigma2_g = sigma2;
+  c->fam_delta = delta;
   std::memset(out->beta, 0, sizeof(out->beta));
   for (int a = 0; a < d; ++a) out->beta[a] = beta[a];
   out->max_index = maxIndex;
@@ -1541,9 +1543,8 @@ int famcov_run(rvt_ctx* c, const double* d_rot, int V, const double* d_cs, const
 }
 }  // namespace
 
-// MetaCov with kinship (quantitative): rotate the block, then famcov_run.
-int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
-  if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
+// Raw column statistics + rotation by U' of one block of <= RVT_MAX_VARIANTS raw columns, then famcov_run.
+static int fam_block_run(rvt_ctx* c, const double* dG, int V, CovOut* cop) {
   if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
   if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
   hipSetDevice(c->device);
@@ -1575,12 +1576,18 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
                               (rocblas_int)ld));
   }
   HIP_TRY(c, hipStreamSynchronize(st));
+  return famcov_run(c, c->d_Gt, V, d_cs, d_poly, cop);
+}
+
+// MetaCov with kinship (quantitative): rotate the block, then famcov_run.
+int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
   CovOut co;
   co.cov = cov;
   co.xz = xz;
   co.zz = zz;
   co.poly = polymorphic;
-  rc = famcov_run(c, c->d_Gt, V, d_cs, d_poly, &co);
+  int rc = fam_block_run(c, dG, V, &co);
   if (!rc && c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
     const double b2 = c->famcov_b2;
     const int du = c->famcov_nc.d - 2;
@@ -1591,6 +1598,52 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
       for (int i = 0; i < du * du; ++i) zz[i] *= b2;
   }
   return rc;
+}
+
+// MetaScore with kinship (MetaFamQtl): FastLMM score test of every raw column, the block in pieces of RVT_MAX_VARIANTS.
+int rvt_score_block_fam(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat, double* vstat, double* af,
+                        double* pvalue) {
+  if (!c || !dG || V < 1 || !ok || !ustat || !vstat || !af || !pvalue) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  const int64_t ld = c->fam_nc.ld;
+  for (int c0 = 0; c0 < V; c0 += RVT_MAX_VARIANTS) {
+    const int n = std::min(RVT_MAX_VARIANTS, V - c0);
+    CovOut co;
+    co.poly = ok + c0;
+    co.ustat = ustat + c0;
+    co.vstat = vstat + c0;
+    co.af = af + c0;
+    co.pval = pvalue + c0;
+    int rc = fam_block_run(c, dG + (size_t)c0 * ld, n, &co);
+    if (rc) return rc;
+  }
+  return RVT_OK;
+}
+
+// FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483) as MetaFamQtl::PrintNullModel prints it: the diagonal of
+// (ux' diag(lambda + delta) ux)^-1 — literally the reference's expression (it multiplies by lambda + delta where its
+// own comment derives the inverse weights).
+int rvt_fam_null_summary(rvt_ctx* c, double* covb_diag) {
+  if (!c || !covb_diag) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  const int64_t N = c->fam_nc.N;
+  const int d = c->fam_nc.d - 1;
+  std::vector<double> ux((size_t)N * d);
+  HIP_TRY(c, hipMemcpy(ux.data(), c->d_uxy, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
+  double A[RVT_MAX_COV * RVT_MAX_COV] = {}, Ai[RVT_MAX_COV * RVT_MAX_COV];
+  for (int a = 0; a < d; ++a)
+    for (int b = a; b < d; ++b) {
+      double t = 0.0;
+      for (int64_t i = 0; i < N; ++i)
+        t += ux[(size_t)a * N + i] * (std::fabs(c->h_S[i]) + c->fam_delta) * ux[(size_t)b * N + i];
+      A[a * d + b] = A[b * d + a] = t;
+    }
+  if (!invert_spd(A, d, Ai)) return fail(c, RVT_E_INVALID, "ux' (lambda + delta) ux is singular");
+  for (int a = 0; a < d; ++a) covb_diag[a] = Ai[a * d + a];
+  return RVT_OK;
 }
 
 int rvt_fam_binary_scale(rvt_ctx* c, int64_t n_case, int64_t n_ctrl, double* alpha_out, double* b_out) {

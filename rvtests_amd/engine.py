@@ -179,6 +179,10 @@ def load_library():
     L.rvt_score_block.argtypes = [vp, vp, C.c_int, c_int_p] + [c_double_p] * 5
     L.rvt_null_summary.restype = C.c_int
     L.rvt_null_summary.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    L.rvt_score_block_fam.restype = C.c_int
+    L.rvt_score_block_fam.argtypes = [vp, vp, C.c_int, c_int_p] + [c_double_p] * 4
+    L.rvt_fam_null_summary.restype = C.c_int
+    L.rvt_fam_null_summary.argtypes = [vp, c_double_p]
     L.rvt_cov_block.restype = C.c_int
     L.rvt_cov_block.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_upload_columns.restype = C.c_int
@@ -413,6 +417,19 @@ class Engine:
         self._check(self.L.rvt_score_block(self.ctx, C.c_void_p(int(ptr)), int(V), ok.ctypes.data_as(c_int_p),
                                            *[_dp(a) for a in arr]))
         return dict(ok=ok, U=arr[0], V=arr[1], effect=arr[2], se=arr[3], p=arr[4])
+
+    def score_block_fam(self, ptr, V):
+        """MetaFamQtl statistics of the V raw columns of a device block (after set_kinship + fit_fam_null)."""
+        ok = np.zeros(V, dtype=np.int32)
+        arr = [np.zeros(V) for _ in range(4)]
+        self._check(self.L.rvt_score_block_fam(self.ctx, C.c_void_p(int(ptr)), int(V), ok.ctypes.data_as(c_int_p),
+                                               *[_dp(a) for a in arr]))
+        return dict(ok=ok, U=arr[0], V=arr[1], af=arr[2], p=arr[3])
+
+    def fam_null_summary(self, d):
+        covb = np.zeros(d)
+        self._check(self.L.rvt_fam_null_summary(self.ctx, _dp(covb)))
+        return covb
 
     def null_summary(self):
         """(beta, diag covB, sigma2) of the installed null model, as MetaScoreTest::PrintNullModel prints them."""

@@ -433,3 +433,16 @@ def fam_burden(G, X, y, U, S, nul, which, use_float=False):
     rc = L.orc_fam_burden(_dp(G), C.c_int64(N), M, _dp(X), _dp(y), X.shape[1], _dp(U), _dp(S), C.byref(nul),
                           int(which), int(use_float), C.byref(out))
     return rc, out
+
+
+def fastlmm_covb(X, U, S, delta, use_float=False):
+    """FastLMM::GetNullCovB restated: (ux' diag(|S| + delta) ux)^-1, d x d."""
+    X = F(X)
+    U = F(U)
+    N, d = X.shape
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    out = np.zeros((d, d))
+    L = lib()
+    L.orc_fastlmm_covb.restype = C.c_int
+    rc = L.orc_fastlmm_covb(_dp(X), C.c_int64(N), d, _dp(U), _dp(S), C.c_double(delta), int(use_float), _dp(out))
+    return rc, out

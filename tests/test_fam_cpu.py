@@ -176,3 +176,27 @@ def test_fam_burden_matches_numpy(which):
     assert abs(o.U - Us) <= 1e-9 * abs(Us) and abs(o.V - Vs) <= 1e-9 * Vs
     assert abs(o.af - afw) <= 1e-10 * abs(afw)
     assert abs(o.pvalue - chi2.sf(Us * Us / Vs, 1)) <= 1e-9 * o.pvalue
+
+
+def test_fam_score_of_a_raw_column_is_the_zeggini_score_of_a_01_column():
+    """orc_fam_burden(which=2) (MetaScoreTest's MetaFamQtl: the raw column, unflipped) against which=1 on a column for
+    which zegginiCollapse is the identity (values 0/1, allele frequency below one half), and GetNullCovB against
+    numpy."""
+    N, K, U, S, X, y = make_family_case(30, 2, 77)
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    rng = np.random.default_rng(5)
+    g = (rng.random(N) < 0.2).astype(float).reshape(-1, 1)
+    rc1, a = orc.fam_burden(g, X, y, U, S, nul, 1)
+    rc2, b = orc.fam_burden(g, X, y, U, S, nul, 2)
+    assert rc1 == 0 and rc2 == 0
+    assert b.U == pytest.approx(a.U, rel=1e-12) and b.V == pytest.approx(a.V, rel=1e-12)
+    assert b.pvalue == pytest.approx(a.pvalue, rel=1e-12) and b.af == pytest.approx(a.af, rel=1e-12)
+    # not flipped: g -> 2 - g changes the sign of U only
+    rc3, c = orc.fam_burden(2.0 - g, X, y, U, S, nul, 2)
+    assert rc3 == 0 and c.U == pytest.approx(-a.U, rel=1e-8) and c.V == pytest.approx(a.V, rel=1e-8)
+    assert orc.fam_burden(np.ones((N, 1)), X, y, U, S, nul, 2)[0] == -1
+    rc, covb = orc.fastlmm_covb(X, U, S, nul.delta)
+    ux = U.T @ X
+    want = np.linalg.inv(ux.T @ (ux * (np.abs(S) + nul.delta)[:, None]))
+    assert rc == 0 and np.allclose(covb, want, rtol=1e-9)

@@ -428,3 +428,51 @@ def test_driver_metascore_rows_match_oracle(tmp_path, binary, se, block):
         for got, w in zip(stats, want):
             assert float(got) == pytest.approx(w, rel=6e-6, abs=1e-12)
     assert 0 < n_na < V // 2
+
+
+@pytest.mark.gpu
+def test_driver_metascore_with_kinship(tmp_path):
+    """--meta score with a kinship decomposition: MetaFamQtl through the adapter — SigmaG2 / SigmaE2 header, the GLS
+    allele frequency in the AF column of tested sites, U / sqrt(V) / effect / p of the FastLMM score test."""
+    _ensure_driver()
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(45, 2, 61)
+    _, G, af = synth.make_gene(N, 28, seed=12, missing=0.01, common=True, mono=True)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, [(G, af)])
+    kin = str(tmp_path / "kin.bin")
+    with open(kin, "wb") as f:
+        f.write(struct.pack("<q", N))
+        f.write(np.asfortranarray(U, dtype="<f4").tobytes(order="F"))
+        f.write(np.ascontiguousarray(S, dtype="<f4").tobytes())
+    V = G.shape[1]
+    sites = str(tmp_path / "sites.txt")
+    with open(sites, "w") as f:
+        for k in range(V):
+            f.write("1 %d\n" % (100 + k))
+    p = subprocess.run([DRIVER, path, "-", "-", "score[se]", sites, kin], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.MetaScore.assoc" and lines[1] == "##NullModelEstimates"
+    Uf, Sf = U.astype(np.float32).astype(np.float64), S.astype(np.float32).astype(np.float64)
+    rc, onul = orc.fastlmm_null(X, y, Uf, Sf)
+    assert rc == 0
+    est = [ln.split("\t") for ln in lines[3:7]]
+    assert [e[0] for e in est] == ["## - Intercept", "## - cov1", "## - SigmaG2", "## - SigmaE2"]
+    # the null fit (delta) is pinned to the reference's Brent stopping accuracy only, see test_gpu_fam.py
+    assert float(est[2][1]) == pytest.approx(onul.sigma2, rel=2e-2)
+    assert float(est[3][1]) == pytest.approx(onul.sigma2 * onul.delta, rel=5e-2)
+    assert lines[7].split("\t")[-5:] == ["U_STAT", "SQRT_V_STAT", "ALT_EFFSIZE", "ALT_EFFSIZE_SE", "PVALUE"]
+    rows = [ln.split("\t") for ln in lines[8:]]
+    assert len(rows) == V
+    tested = 0
+    for h, row in enumerate(rows):
+        rc, o = orc.fam_burden(G[:, [h]], X, y, Uf, Sf, onul, 2)
+        if rc:
+            assert row[-5:] == ["NA"] * 5
+            continue
+        tested += 1
+        want = [o.af, o.U, np.sqrt(o.V), o.U / o.V, 1 / np.sqrt(o.V), o.pvalue]
+        got = [float(row[2])] + [float(t) for t in row[-5:]]
+        assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
+    assert tested > 10
