@@ -1,7 +1,7 @@
 /* rvtests_amd — C ABI of the MI355X kernel/burden association engine.
  *
  * This is the drop-in boundary for the rvtests hot path: the entry points below are what GPU-backed
- * `ModelFitter` subclasses (SkatTest, SkatOTest, CMCTest, ZegginiTest, FamSkatTest, MetaCovTest — see
+ * `ModelFitter` subclasses (SkatTest, SkatOTest, CMCTest, ZegginiTest, FamSkatTest, MetaCovTest, MetaScoreTest — see
  * rvtests_amd/csrc/host/ModelFitterGpu.h and INTEGRATION.md) call instead of
  *   Skat::Fit                         /root/reference/regression/Skat.h:26-31   (Skat.cpp:29-105)
  *   SkatO::Fit                        regression/SkatO.h:28-35                  (SkatO.cpp:101-281,500-519)
@@ -15,6 +15,7 @@
  *   FamSkat::FitNullModel / TestCovariate, FastLMM::FitNullModel / FastGetAF  regression/FamSkat.cpp:34-138,
  *                                                                             regression/FastLMM.cpp:28-142,402-443
  *   MetaCovTest (MetaCovUnrelatedQtl / UnrelatedBinary / FamQtl)          src/Model.cpp:437-1004
+ *   MetaScoreTest (MetaUnrelatedQtl / MetaUnrelatedBinary / MetaFamQtl)   src/Model.h:3155-3784
  * Plain C, plain pointers and sizes; no C++ or torch types cross it.  All functions return 0 on
  * success and a negative RVT_E_* code on failure; rvt_last_error() gives the text.  One calling
  * thread per context; one context per GPU (one process per GPU).
