@@ -228,13 +228,17 @@ int rvt_score_block(rvt_ctx* ctx, const double* dG, int V, int* ok, double* usta
  * regression/LogisticRegression.cpp:330-334) and sigma2 (quantitative; 1 for a binary trait).  beta / sigma2 may be
  * NULL. */
 int rvt_null_summary(rvt_ctx* ctx, double* beta, double* covb_diag, double* sigma2);
-/* MetaScore with kinship, quantitative trait (MetaFamQtl, src/Model.h:3398-3499): FastLMM::TestCovariate in its SCORE
- * branch (regression/FastLMM.cpp:215-247; genotype centred) and FastLMM::FastGetAF (:400-424) of every raw column of a
- * device block, after rvt_set_kinship + rvt_fit_fam_null.  ustat / vstat = GetUStat / GetVStat, af = the GLS allele
- * frequency, pvalue = 1 when V <= 0; ALT_EFFSIZE = U / V and its SE = 1 / sqrt(V) are the caller's divisions.
- * ok[h] = 0 for a monomorphic site.  MetaFamBinary (uncentred genotypes, b scaling) is not provided. */
-int rvt_score_block_fam(rvt_ctx* ctx, const double* dG, int V, int* ok, double* ustat, double* vstat, double* af,
-                        double* pvalue);
+/* MetaScore with kinship (MetaFamQtl, src/Model.h:3398-3499; MetaFamBinary, :3556-3668): FastLMM::TestCovariate in its
+ * SCORE branch (regression/FastLMM.cpp:215-247) and FastLMM::FastGetAF (:400-424) of every raw column of a device
+ * block, after rvt_set_kinship + rvt_fit_fam_null.
+ *   binary = 0: genotype centred; ustat / vstat = GetUStat / GetVStat
+ *   binary = 1: genotype NOT centred (disableCenterGenotype, :3558-3560); ustat = GetUStat b, vstat = GetVStat b^2 with
+ *               the b of the last rvt_fam_binary_scale (:3647-3648)
+ * af = the GLS allele frequency, pvalue = chisq_Q(U^2 / V, 1), 1 when V <= 0.  ALT_EFFSIZE (U / V, :3491-3494; binary
+ * ustat / vstat, the same as U / V / b of :3649-3654) and its SE (1 / sqrt(V); binary 1 / sqrt(vstat) / b) are the
+ * caller's divisions.  ok[h] = 0 for a monomorphic site. */
+int rvt_score_block_fam(rvt_ctx* ctx, const double* dG, int V, int binary, int* ok, double* ustat, double* vstat,
+                        double* af, double* pvalue);
 /* Diagonal of FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483) for MetaFamQtl::PrintNullModel; beta, SigmaG2 =
  * sigma2_g and SigmaE2 = sigma2_g * delta come from rvt_fit_fam_null's rvt_fam_null. */
 int rvt_fam_null_summary(rvt_ctx* ctx, double* covb_diag);

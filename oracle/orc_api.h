@@ -141,7 +141,8 @@ int orc_famskat(const double* G, int64_t N, int M, const double* X, const double
 /* FamCMC / FamZeggini (src/Model.h:2261-2492): cmcCollapse / zegginiCollapse of the flipped, polymorphic block, then
    FastLMM::TestCovariate in its SCORE branch (regression/FastLMM.cpp:215-247, scaledK LITERALLY as an N x N matrix) and
    FastLMM::GetAF (:356-398).  which: 0 = CMC, 1 = Zeggini, 2 = MetaScoreTest's MetaFamQtl (src/Model.h:3421-3434: the
-   single raw column itself, M == 1, no flip).  Returns -1 when no polymorphic column is left. */
+   single raw column itself, M == 1, no flip), 3 = MetaFamBinary (as 2 with the genotype NOT centred, :3558-3560; the
+   caller applies the b scaling of :3647-3662).  Returns -1 when no polymorphic column is left. */
 typedef struct {
   int fit_ok, num_site;
   double af, U, V, stat, pvalue;

@@ -503,7 +503,7 @@ int orc_fam_burden(const double* Gp, int64_t N, int M, const double* Xp, const d
   std::vector<double> Gf((size_t)N * M);
   std::vector<int> fl(M), kp(M);
   std::vector<double> c(N, 0.0);
-  if (which == 2) {
+  if (which >= 2) {
     // MetaScoreTest with kinship (MetaFamQtl::TestCovariate, src/Model.h:3421-3434): the single genotype column as it
     // is (imputed, not flipped); monomorphic sites are skipped before the test (:3246-3250)
     if (M != 1) return -1;
@@ -537,7 +537,8 @@ int orc_fam_burden(const double* Gp, int64_t N, int M, const double* Xp, const d
   std::vector<double> ur(N), ug(N), ugc(N);
   double cs = 0;
   for (int64_t i = 0; i < N; ++i) cs = F(cs + F(c[i]));
-  const double cmean = F(cs / (double)N);
+  // which == 3: MetaFamBinary calls lmm.disableCenterGenotype() (src/Model.h:3558-3560; FastLMM.cpp:218-223)
+  const double cmean = (which == 3) ? 0.0 : F(cs / (double)N);
   for (int64_t k = 0; k < N; ++k) {
     for (int a = 0; a < d; ++a) {
       double s = 0;

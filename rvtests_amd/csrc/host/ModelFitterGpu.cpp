@@ -439,11 +439,7 @@ int MetaScoreTest::setParameter(const ModelParser& parser) {
   return 0;
 }
 int MetaScoreTest::fit(GeneData* dc) {
-  useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaFamQtl (src/Model.h:3398-3499)
-  if (useFamilyModel && isBinaryOutcome()) {
-    lastError = "MetaScore with kinship for a binary trait (MetaFamBinary) is not provided by the GPU library";
-    return -1;
-  }
+  useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaFamQtl / MetaFamBinary (src/Model.h:3398-3668)
   if ((int)rows.size() >= capacity && used > 0 && flush()) return -1;
   rows.emplace_back();
   Row& row = rows.back();
@@ -467,6 +463,18 @@ int MetaScoreTest::fit(GeneData* dc) {
   ctx = useFamilyModel ? GpuBroker::instance().contextWithFamNull(*dc, &lastError)
                        : GpuBroker::instance().contextWithNull(*dc, isBinaryOutcome(), &lastError);
   if (!ctx) return -1;
+  if (useFamilyModel && isBinaryOutcome() && (nSample < 0 || dc->phenotypeUpdated)) {
+    // MetaFamBinary::FitNullModel (src/Model.h:3566-3581): alpha = log(nCase / nCtrl), b = calculateB()
+    int64_t nCase = 0, nCtrl = 0;
+    for (int64_t i = 0; i < dc->N; ++i) {
+      if (dc->phenotype[i] == 1) ++nCase;
+      else if (dc->phenotype[i] == 0) ++nCtrl;
+    }
+    if (rvt_fam_binary_scale(ctx, nCase, nCtrl, nullptr, &famB)) {
+      lastError = rvt_last_error(ctx);
+      return -1;
+    }
+  }
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;
@@ -523,18 +531,24 @@ int MetaScoreTest::flush() {
   std::vector<double> famAf(ok.size());
   if (used > 0) {
     const int rc = useFamilyModel
-                       ? rvt_score_block_fam(ctx, block, used, ok.data(), u.data(), v.data(), famAf.data(), pv.data())
+                       ? rvt_score_block_fam(ctx, block, used, isBinaryOutcome() ? 1 : 0, ok.data(), u.data(), v.data(),
+                                             famAf.data(), pv.data())
                        : rvt_score_block(ctx, block, used, ok.data(), u.data(), v.data(), eff.data(), se.data(),
                                          pv.data());
     if (rc) {
       lastError = rvt_last_error(ctx);
     } else {
       scored = true;
-      if (useFamilyModel)  // MetaFamQtl::GetEffect / FastLMM::GetSE (src/Model.h:3491-3496, FastLMM.cpp:452-455)
+      if (useFamilyModel) {
+        // MetaFamQtl::GetEffect / FastLMM::GetSE (src/Model.h:3491-3496, FastLMM.cpp:452-455); MetaFamBinary: U b and
+        // V b^2 are returned, effect = U / V / b = (U b) / (V b^2), SE = 1 / sqrt(V b^2) / b (:3647-3662)
+        const double bdiv = isBinaryOutcome() ? famB : 1.0;
         for (int k = 0; k < used; ++k) {
-          eff[k] = v[k] != 0.0 ? u[k] / v[k] : 0.0;
-          se[k] = v[k] != 0.0 ? 1.0 / std::sqrt(v[k]) : 0.0;
+          const bool nz = v[k] != 0.0 && bdiv != 0.0;
+          eff[k] = nz ? u[k] / v[k] : 0.0;
+          se[k] = nz ? 1.0 / std::sqrt(v[k]) / bdiv : 0.0;
         }
+      }
     }
   }
   if (!headerOutputted && (scored || used == 0)) {
@@ -561,7 +575,7 @@ int MetaScoreTest::flush() {
         if (useFamilyModel) {  // GetSigmaG2 = sigma2, GetSigmaE2 = sigma2 * delta (FastLMM.cpp:456-457)
           fout->write("## - SigmaG2\t" + formatG(fnull.sigma2_g) + "\tNA\n");
           fout->write("## - SigmaE2\t" + formatG(fnull.sigma2_g * fnull.delta) + "\tNA\n");
-        } else if (isBinaryOutcome()) {
+        } else if (isBinaryOutcome()) {  // MetaUnrelatedBinary::PrintNullModel (src/Model.h:3751)
           fout->write("## - Sigma2\tNA\tNA\n");
         } else {
           fout->write("## - Sigma2\t" + formatG(sigma2) + "\tNA\n");
@@ -585,7 +599,8 @@ int MetaScoreTest::flush() {
       line += floatToString(a.ac) + "\t" + floatToString(a.callRate) + "\t" + floatToString(a.hwe) + "\t";
       line += std::to_string(a.nHomRef) + "\t" + std::to_string(a.nHet) + "\t" + std::to_string(a.nHomAlt) + "\t";
     } else {  // src/Model.h:3310-3351
-      line += (a.af >= 0.0 ? triple("%g:%g:%g", a.af, ca.af, ct.af) : std::string("NA")) + "\t";
+      const double afb = (useFamilyModel && r.tested && scored && r.column >= 0 && ok[r.column]) ? famAf[r.column] : a.af;
+      line += (afb >= 0.0 ? triple("%g:%g:%g", afb, ca.af, ct.af) : std::string("NA")) + "\t";
       line += triple("%g:%g:%g", a.ac, ca.ac, ct.ac) + "\t";
       line += triple("%g:%g:%g", a.callRate, ca.callRate, ct.callRate) + "\t";
       line += triple("%g:%g:%g", a.hwe, ca.hwe, ct.hwe) + "\t";

@@ -321,8 +321,8 @@ class MetaCovTest : public ModelFitter {
   TextSink* fout = nullptr;
 };
 
-// `--meta score` (src/Model.h:3155-3398): MetaUnrelatedQtl / MetaUnrelatedBinary, and MetaFamQtl when the caller hands
-// over a kinship decomposition (MetaFamBinary and the BOLT variants are not provided).  Sites are copied
+// `--meta score` (src/Model.h:3155-3398): MetaUnrelatedQtl / MetaUnrelatedBinary, and MetaFamQtl / MetaFamBinary when the
+// caller hands over a kinship decomposition (the BOLT variants are not provided).  Sites are copied
 // into a device block as fit() sees them; a full block (or writeFootnote / the destructor) runs ONE rvt_score_block
 // over all of them and writes their rows in file order, after the summary header with the null-model estimates.
 class MetaScoreTest : public ModelFitter {
@@ -348,6 +348,7 @@ class MetaScoreTest : public ModelFitter {
   int capacity = 1024;              // RVT_METASCORE_BLOCK
   bool outputSE = false;
   bool useFamilyModel = false;
+  double famB = 1.0;                // MetaFamBinary: b
   bool headerOutputted = false;
   std::string siteHeaderTab;
   int64_t nSample = -1;

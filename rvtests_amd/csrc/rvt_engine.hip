@@ -615,6 +615,7 @@ struct CovOut {  // rvt_cov_block: host destinations
   double *ustat = nullptr, *vstat = nullptr, *af = nullptr, *pval = nullptr;
   // MetaScoreTest (unrelated samples): ustat / vstat / effect / se / pval / ok, V entries each; no covariance rows
   bool score = false;
+  bool uncentred = false;  // family mode: FastLMM::disableCenterGenotype (MetaFamBinary)
   double *effect = nullptr, *se = nullptr;
   int* ok = nullptr;
 };
@@ -883,6 +884,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     {
       int rcc = cov_constants(c, cov->fam, &cc, &zz);
       if (rcc) return rcc;
+      if (cov->fam && cov->uncentred) cc.inv_n = 0.0;  // every centring term carries the column mean s / N
     }
     double* d_xz = reinterpret_cast<double*>(base + off_cov_xz);
     double* d_cs = reinterpret_cast<double*>(base + off_cov_cs);
@@ -1600,9 +1602,10 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
   return rc;
 }
 
-// MetaScore with kinship (MetaFamQtl): FastLMM score test of every raw column, the block in pieces of RVT_MAX_VARIANTS.
-int rvt_score_block_fam(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat, double* vstat, double* af,
-                        double* pvalue) {
+// MetaScore with kinship: FastLMM score test of every raw column, the block in pieces of RVT_MAX_VARIANTS.
+// binary = 0: MetaFamQtl; binary = 1: MetaFamBinary (genotype not centred; U b, V b^2 with the b of rvt_fam_binary_scale).
+int rvt_score_block_fam(rvt_ctx* c, const double* dG, int V, int binary, int* ok, double* ustat, double* vstat,
+                        double* af, double* pvalue) {
   if (!c || !dG || V < 1 || !ok || !ustat || !vstat || !af || !pvalue) return fail(c, RVT_E_INVALID, "bad arguments");
   if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
   const int64_t ld = c->fam_nc.ld;
@@ -1614,8 +1617,16 @@ int rvt_score_block_fam(rvt_ctx* c, const double* dG, int V, int* ok, double* us
     co.vstat = vstat + c0;
     co.af = af + c0;
     co.pval = pvalue + c0;
+    co.uncentred = binary != 0;
     int rc = fam_block_run(c, dG + (size_t)c0 * ld, n, &co);
     if (rc) return rc;
+  }
+  if (binary) {  // MetaFamBinary::GetU / GetV (src/Model.h:3647-3648); the p-value is the unscaled statistic's
+    const double b2 = c->famcov_b2, b = std::sqrt(b2);
+    for (int h = 0; h < V; ++h) {
+      ustat[h] *= b;
+      vstat[h] *= b2;
+    }
   }
   return RVT_OK;
 }
@@ -2206,7 +2217,12 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   int rc = rvt_sync(c);  // processed synchronously
   if (rc) return rc;
-  constexpr int kSlice = 16, kChunk = 256;  // columns per slice, slices per launch
+  // columns per slice: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column tiles, i.e. tile
+  // class (2,2) (or (1,2) for 16 covariates) — 12 % fewer MFMA per genotype than 16-column slices and two row tiles
+  // of loads in flight per wave
+  int kSlice = 32 - (c->nc.d + 1);
+  if (const char* e = getenv("RVT_SCORE_SLICE")) kSlice = std::max(1, std::min(64, atoi(e)));
+  constexpr int kChunk = 256;  // slices per launch
   const int64_t ld = c->null_ld;
   std::vector<double> af((size_t)kSlice * kChunk, 0.01);
   std::vector<rvt_gene_result> rs(kChunk);

@@ -180,7 +180,7 @@ def load_library():
     L.rvt_null_summary.restype = C.c_int
     L.rvt_null_summary.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     L.rvt_score_block_fam.restype = C.c_int
-    L.rvt_score_block_fam.argtypes = [vp, vp, C.c_int, c_int_p] + [c_double_p] * 4
+    L.rvt_score_block_fam.argtypes = [vp, vp, C.c_int, C.c_int, c_int_p] + [c_double_p] * 4
     L.rvt_fam_null_summary.restype = C.c_int
     L.rvt_fam_null_summary.argtypes = [vp, c_double_p]
     L.rvt_cov_block.restype = C.c_int
@@ -418,11 +418,13 @@ class Engine:
                                            *[_dp(a) for a in arr]))
         return dict(ok=ok, U=arr[0], V=arr[1], effect=arr[2], se=arr[3], p=arr[4])
 
-    def score_block_fam(self, ptr, V):
-        """MetaFamQtl statistics of the V raw columns of a device block (after set_kinship + fit_fam_null)."""
+    def score_block_fam(self, ptr, V, binary=0):
+        """MetaFamQtl (binary=1: MetaFamBinary) statistics of the V raw columns of a device block (after set_kinship +
+        fit_fam_null [+ fam_binary_scale])."""
         ok = np.zeros(V, dtype=np.int32)
         arr = [np.zeros(V) for _ in range(4)]
-        self._check(self.L.rvt_score_block_fam(self.ctx, C.c_void_p(int(ptr)), int(V), ok.ctypes.data_as(c_int_p),
+        self._check(self.L.rvt_score_block_fam(self.ctx, C.c_void_p(int(ptr)), int(V), int(binary),
+                                               ok.ctypes.data_as(c_int_p),
                                                *[_dp(a) for a in arr]))
         return dict(ok=ok, U=arr[0], V=arr[1], af=arr[2], p=arr[3])
 

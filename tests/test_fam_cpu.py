@@ -196,6 +196,15 @@ def test_fam_score_of_a_raw_column_is_the_zeggini_score_of_a_01_column():
     rc3, c = orc.fam_burden(2.0 - g, X, y, U, S, nul, 2)
     assert rc3 == 0 and c.U == pytest.approx(-a.U, rel=1e-8) and c.V == pytest.approx(a.V, rel=1e-8)
     assert orc.fam_burden(np.ones((N, 1)), X, y, U, S, nul, 2)[0] == -1
+    # which = 3 (MetaFamBinary: genotype not centred) against numpy: U = sum ug ur / (|S| + delta) / sigma2
+    rc4, e = orc.fam_burden(g, X, y, U, S, nul, 3)
+    beta = np.array([nul.beta[k] for k in range(X.shape[1])])
+    ug, ur, sinv = U.T @ g[:, 0], U.T @ y - (U.T @ X) @ beta, 1.0 / (np.abs(S) + nul.delta)
+    uxm = U.T @ X
+    Kmat = np.diag(sinv) - (sinv[:, None] * uxm) @ np.linalg.inv(uxm.T @ (uxm * sinv[:, None])) @ (uxm * sinv[:, None]).T
+    assert rc4 == 0
+    assert e.U == pytest.approx((ug * ur * sinv).sum() / nul.sigma2, rel=1e-9)
+    assert e.V == pytest.approx(ug @ Kmat @ ug / nul.sigma2, rel=1e-8)
     rc, covb = orc.fastlmm_covb(X, U, S, nul.delta)
     ux = U.T @ X
     want = np.linalg.inv(ux.T @ (ux * (np.abs(S) + nul.delta)[:, None]))

@@ -77,15 +77,23 @@ def test_score_block_needs_null(engine_factory):
         eng.score_block(1, 4)
 
 
+@pytest.mark.parametrize("binary", [0, 1])
 @pytest.mark.parametrize("n_fam,d", [(40, 1), (60, 3)])
-def test_score_block_fam_matches_oracle(engine_factory, n_fam, d):
-    """MetaFamQtl: FastLMM score test + GLS allele frequency of every raw column, and GetNullCovB."""
+def test_score_block_fam_matches_oracle(engine_factory, n_fam, d, binary):
+    """MetaFamQtl / MetaFamBinary: FastLMM score test (+ b scaling, uncentred genotypes for the binary trait) and GLS
+    allele frequency of every raw column, and GetNullCovB."""
     import synth
     from test_fam_cpu import make_family_case
     N, K, U, S, X, y = make_family_case(n_fam, d, 190 + d)
+    b = 1.0
+    if binary:
+        y = (y > np.median(y)).astype(float)       # MetaFamBinary fits the LMM to the 0/1 phenotype as it is
     eng = engine_factory()
     eng.set_kinship(U, S)
     nul = eng.fit_fam_null(X, y)
+    if binary:
+        alpha, b = eng.fam_binary_scale(int((y == 1).sum()), int((y == 0).sum()))
+        assert b == pytest.approx(orc.obtain_b(alpha), rel=1e-6)
     onul = orc.FamNull()
     onul.ok = 1
     onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
@@ -93,16 +101,16 @@ def test_score_block_fam_matches_oracle(engine_factory, n_fam, d):
         onul.beta[k] = nul.beta[k]
     G = synth.make_gene(N, 37, seed=1234, missing=0.02, common=True, mono=True, maf_hi=-0.8)[1]
     ptr = eng.upload_block(G)
-    r = eng.score_block_fam(ptr, G.shape[1])
+    r = eng.score_block_fam(ptr, G.shape[1], binary)
     tested = 0
     for h in range(G.shape[1]):
-        rc, o = orc.fam_burden(G[:, [h]], X, y, U, S, onul, 2)
+        rc, o = orc.fam_burden(G[:, [h]], X, y, U, S, onul, 3 if binary else 2)
         assert r["ok"][h] == (1 if rc == 0 else 0)
         if rc:
             continue
         tested += 1
-        assert abs(r["U"][h] - o.U) <= 1e-8 * abs(o.U) + 1e-12
-        assert abs(r["V"][h] - o.V) <= 1e-8 * o.V
+        assert abs(r["U"][h] - o.U * b) <= 1e-8 * abs(o.U * b) + 1e-12
+        assert abs(r["V"][h] - o.V * b * b) <= 1e-8 * o.V * b * b
         assert abs(r["af"][h] - o.af) <= 1e-9 * abs(o.af) + 1e-15
         assert abs(r["p"][h] - o.pvalue) <= 1e-6 * o.pvalue
     assert 5 < tested < G.shape[1]

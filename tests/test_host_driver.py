@@ -431,15 +431,19 @@ def test_driver_metascore_rows_match_oracle(tmp_path, binary, se, block):
 
 
 @pytest.mark.gpu
-def test_driver_metascore_with_kinship(tmp_path):
-    """--meta score with a kinship decomposition: MetaFamQtl through the adapter — SigmaG2 / SigmaE2 header, the GLS
-    allele frequency in the AF column of tested sites, U / sqrt(V) / effect / p of the FastLMM score test."""
+@pytest.mark.parametrize("binary", [0, 1])
+def test_driver_metascore_with_kinship(tmp_path, binary):
+    """--meta score with a kinship decomposition: MetaFamQtl / MetaFamBinary through the adapter — SigmaG2 / SigmaE2
+    header, the GLS allele frequency in the AF column of tested sites, U / sqrt(V) / effect / SE / p of the FastLMM score
+    test (binary: uncentred genotypes and the b scaling)."""
     _ensure_driver()
     from test_fam_cpu import make_family_case
     N, K, U, S, X, y = make_family_case(45, 2, 61)
+    if binary:
+        y = (y > np.median(y)).astype(float)
     _, G, af = synth.make_gene(N, 28, seed=12, missing=0.01, common=True, mono=True)
     path = str(tmp_path / "in.bin")
-    write_input(path, y, X[:, 1:], 0, [(G, af)])
+    write_input(path, y, X[:, 1:], binary, [(G, af)])
     kin = str(tmp_path / "kin.bin")
     with open(kin, "wb") as f:
         f.write(struct.pack("<q", N))
@@ -457,6 +461,9 @@ def test_driver_metascore_with_kinship(tmp_path):
     Uf, Sf = U.astype(np.float32).astype(np.float64), S.astype(np.float32).astype(np.float64)
     rc, onul = orc.fastlmm_null(X, y, Uf, Sf)
     assert rc == 0
+    b = 1.0
+    if binary:
+        b = orc.obtain_b(float(np.float32(np.log((y == 1).sum() / (y == 0).sum()))))
     est = [ln.split("\t") for ln in lines[3:7]]
     assert [e[0] for e in est] == ["## - Intercept", "## - cov1", "## - SigmaG2", "## - SigmaE2"]
     # the null fit (delta) is pinned to the reference's Brent stopping accuracy only, see test_gpu_fam.py
@@ -467,12 +474,12 @@ def test_driver_metascore_with_kinship(tmp_path):
     assert len(rows) == V
     tested = 0
     for h, row in enumerate(rows):
-        rc, o = orc.fam_burden(G[:, [h]], X, y, Uf, Sf, onul, 2)
+        rc, o = orc.fam_burden(G[:, [h]], X, y, Uf, Sf, onul, 3 if binary else 2)
         if rc:
             assert row[-5:] == ["NA"] * 5
             continue
         tested += 1
-        want = [o.af, o.U, np.sqrt(o.V), o.U / o.V, 1 / np.sqrt(o.V), o.pvalue]
-        got = [float(row[2])] + [float(t) for t in row[-5:]]
+        want = [o.af, o.U * b, np.sqrt(o.V) * b, o.U / o.V / b, 1 / np.sqrt(o.V * b * b) / b, o.pvalue]
+        got = [float(row[2].split(":")[0])] + [float(t) for t in row[-5:]]
         assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
     assert tested > 10
