@@ -89,29 +89,37 @@ __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict_
 }
 
 // ---- genotype consolidation on the device (the "next" row of the boundary: raw / packed genotypes) -------------------
-// One workgroup per variant column.  Reproduces, for a column of raw genotypes (missing = negative):
+// Reproduces, for every column of raw genotypes (missing = negative):
 //   GenotypeCounter::add / getAF   (src/GenotypeCounter.h:14-51): AF = 0.5 * sum{0 <= g <= 2} g / nSample, g < 0 or g > 2
 //                                  count as missing, nSample counts every sample
 //   DataConsolidator::imputeGenotypeToMean (src/DataConsolidator.cpp:217-245): only when the counter saw a missing
 //                                  value; `int ac` accumulates every g >= 0 with truncation after each addition
 //                                  (quirk #5), an = 2 * #{g >= 0}; g < 0 <- 2 * ac / an
-// For integer-valued columns (hard calls) the truncating accumulation is an exact integer sum and is reduced in
-// parallel; a column that mixes fractional dosages with missing values replays the reference's sequential
+// Three launches, all columns at once and the sample axis cut into kConsolChunk-sample pieces (a 500 000 x 50 gene is
+// 3 100 workgroups instead of 50): partial counts per (column, piece) -> per-column AF and fill value (partials summed
+// in piece order) -> imputed fp64 columns.  For integer-valued columns (hard calls) the truncating accumulation is an
+// exact integer sum; a column that mixes fractional dosages with missing values replays the reference's sequential
 // accumulation on one lane.  SRC is double (in place) or int8 (packed hard calls, expanded to fp64).
+constexpr int kConsolChunk = 8192;  // samples per workgroup
+struct ConsolPart {
+  double sumAC, ac;
+  long long nonneg;
+  int flags, pad;  // bit 0: counter saw a missing value; bit 1: a value < 0 exists; bit 2: a fractional value >= 0
+};
+
 template <typename SRC>
-__global__ __launch_bounds__(256) void consolidate_kernel(const SRC* __restrict__ src, long long src_ld, long long N,
-                                                          long long ld, double* __restrict__ dst,
-                                                          double* __restrict__ af_out) {
+__global__ __launch_bounds__(256) void consolidate_count_kernel(const SRC* __restrict__ src, long long src_ld,
+                                                                long long N, ConsolPart* __restrict__ parts) {
   __shared__ double s_sum[256], s_ac[256];
   __shared__ long long s_cnt[256];
   __shared__ int s_flag[256];
-  __shared__ double s_fill;
-  const SRC* col = src + (long long)blockIdx.x * src_ld;
-  double* out = dst + (long long)blockIdx.x * ld;
+  const SRC* col = src + (long long)blockIdx.y * src_ld;
+  const long long i0 = (long long)blockIdx.x * kConsolChunk;
+  const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
   double sumAC = 0.0, ac = 0.0;
   long long nonneg = 0;
-  int flags = 0;  // bit 0: counter saw a missing value; bit 1: a value < 0 exists; bit 2: a fractional value >= 0
-  for (long long i = threadIdx.x; i < N; i += 256) {
+  int flags = 0;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
     const double g = (double)col[i];
     if (g < 0.0) {
       flags |= 3;
@@ -139,28 +147,58 @@ __global__ __launch_bounds__(256) void consolidate_kernel(const SRC* __restrict_
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    af_out[blockIdx.x] = N ? 0.5 * s_sum[0] / (double)N : -1.0;
-    double fill = 0.0;
-    if ((s_flag[0] & 1) && (s_flag[0] & 2)) {
-      const long long an = 2 * s_cnt[0];
-      int aci;
-      if (s_flag[0] & 4) {  // fractional dosages: the reference's truncating running sum, in sample order
-        aci = 0;
-        for (long long i = 0; i < N; ++i) {
-          const double g = (double)col[i];
-          if (g >= 0.0) aci = (int)((double)aci + g);
-        }
-      } else {
-        aci = (int)s_ac[0];
-      }
-      fill = (an == 0) ? 0.0 : 2.0 * (1.0 * aci / (double)an);
-    }
-    s_fill = fill;
+  if (threadIdx.x == 0)
+    parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] = ConsolPart{s_sum[0], s_ac[0], s_cnt[0], s_flag[0], 0};
+}
+
+// one wave per column: AF and the imputation value
+template <typename SRC>
+__global__ __launch_bounds__(64) void consolidate_fill_kernel(const SRC* __restrict__ src, long long src_ld,
+                                                              long long N, int nparts,
+                                                              const ConsolPart* __restrict__ parts,
+                                                              double* __restrict__ af_out, double* __restrict__ fill_out) {
+  if (threadIdx.x != 0) return;
+  const ConsolPart* p = parts + (long long)blockIdx.x * nparts;
+  double sumAC = 0.0, ac = 0.0;
+  long long nonneg = 0;
+  int flags = 0;
+  for (int k = 0; k < nparts; ++k) {
+    sumAC += p[k].sumAC;
+    ac += p[k].ac;
+    nonneg += p[k].nonneg;
+    flags |= p[k].flags;
   }
-  __syncthreads();
-  const double fill = s_fill;
-  for (long long i = threadIdx.x; i < N; i += 256) {
+  af_out[blockIdx.x] = N ? 0.5 * sumAC / (double)N : -1.0;
+  double fill = 0.0;
+  if ((flags & 1) && (flags & 2)) {
+    const long long an = 2 * nonneg;
+    int aci;
+    if (flags & 4) {  // fractional dosages: the reference's truncating running sum, in sample order
+      const SRC* col = src + (long long)blockIdx.x * src_ld;
+      aci = 0;
+      for (long long i = 0; i < N; ++i) {
+        const double g = (double)col[i];
+        if (g >= 0.0) aci = (int)((double)aci + g);
+      }
+    } else {
+      aci = (int)ac;
+    }
+    fill = (an == 0) ? 0.0 : 2.0 * (1.0 * aci / (double)an);
+  }
+  fill_out[blockIdx.x] = fill;
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void consolidate_write_kernel(const SRC* __restrict__ src, long long src_ld,
+                                                                long long N, long long ld,
+                                                                const double* __restrict__ fill_in,
+                                                                double* __restrict__ dst) {
+  const SRC* col = src + (long long)blockIdx.y * src_ld;
+  double* out = dst + (long long)blockIdx.y * ld;
+  const double fill = fill_in[blockIdx.y];
+  const long long i0 = (long long)blockIdx.x * kConsolChunk;
+  const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
     const double g = (double)col[i];
     out[i] = (g < 0.0) ? fill : g;
   }

@@ -103,8 +103,10 @@ struct rvt_ctx {
   size_t fam_cols_cap = 0;
   rocblas_handle blas = nullptr;
   // raw / packed genotype submission
-  double* d_consol_af = nullptr;
+  double* d_consol_af = nullptr;  // af (RVT_MAX_VARIANTS) | fill values (RVT_MAX_VARIANTS)
   size_t consol_af_cap = 0;
+  ConsolPart* d_consol_parts = nullptr;
+  size_t consol_parts_cap = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
@@ -476,6 +478,7 @@ void rvt_destroy(rvt_ctx* c) {
                   (void*)c->d_perm_Q, (void*)c->d_perm_cur})
     if (p) hipFree(p);
   if (c->d_consol_af) hipFree(c->d_consol_af);
+  if (c->d_consol_parts) hipFree(c->d_consol_parts);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   if (c->blas) rocblas_destroy_handle(c->blas);
@@ -2529,21 +2532,38 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       if (c->d_consol_af) hipFree(c->d_consol_af);
       c->d_consol_af = nullptr;
       c->consol_af_cap = 0;
-      if (hipMalloc((void**)&c->d_consol_af, sizeof(double) * RVT_MAX_VARIANTS) != hipSuccess) {
+      if (hipMalloc((void**)&c->d_consol_af, sizeof(double) * 2 * RVT_MAX_VARIANTS) != hipSuccess) {
         give_back();
         return fail(c, RVT_E_HIP, "hipMalloc failed");
       }
       c->consol_af_cap = RVT_MAX_VARIANTS;
     }
     hipError_t e = hipSuccess;
-    if (mode == 1) {
+    const int nparts = (int)((N + kConsolChunk - 1) / kConsolChunk);
+    if (c->consol_parts_cap < (size_t)M * nparts) {
+      if (c->d_consol_parts) hipFree(c->d_consol_parts);
+      c->d_consol_parts = nullptr;
+      c->consol_parts_cap = 0;
+      const size_t want = (size_t)std::max(M, 128) * nparts;
+      e = hipMalloc((void**)&c->d_consol_parts, sizeof(ConsolPart) * want);
+      if (e == hipSuccess) c->consol_parts_cap = want;
+    }
+    double* d_fill = c->d_consol_af + RVT_MAX_VARIANTS;
+    const dim3 cgrid((unsigned)nparts, (unsigned)M);
+    if (e != hipSuccess) {
+      // fall through to the error return below
+    } else if (mode == 1) {
       int rc = rvt_block_upload(c, p.dG, M, (const double*)G);
       if (rc) {
         give_back();
         return rc;
       }
-      hipLaunchKernelGGL((consolidate_kernel<double>), dim3((unsigned)M), dim3(256), 0, st, p.dG, (long long)ld,
-                         (long long)N, (long long)ld, p.dG, c->d_consol_af);
+      hipLaunchKernelGGL((consolidate_count_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
+                         c->d_consol_parts);
+      hipLaunchKernelGGL((consolidate_fill_kernel<double>), dim3((unsigned)M), dim3(64), 0, st, p.dG, (long long)ld,
+                         (long long)N, nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+      hipLaunchKernelGGL((consolidate_write_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
+                         (long long)ld, d_fill, p.dG);
     } else {
       const size_t bytes8 = (size_t)N * M;
       if (c->consol_i8_cap < bytes8) {
@@ -2554,10 +2574,15 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
       }
       if (e == hipSuccess) e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess)
-        hipLaunchKernelGGL((consolidate_kernel<signed char>), dim3((unsigned)M), dim3(256), 0, st,
-                           (const signed char*)c->d_consol_i8, (long long)N, (long long)N, (long long)ld, p.dG,
-                           c->d_consol_af);
+      if (e == hipSuccess) {
+        const signed char* s8 = (const signed char*)c->d_consol_i8;
+        hipLaunchKernelGGL((consolidate_count_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
+                           (long long)N, c->d_consol_parts);
+        hipLaunchKernelGGL((consolidate_fill_kernel<signed char>), dim3((unsigned)M), dim3(64), 0, st, s8, (long long)N,
+                           (long long)N, nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+        hipLaunchKernelGGL((consolidate_write_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
+                           (long long)N, (long long)ld, d_fill, p.dG);
+      }
     }
     p.af.resize(M);
     if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
