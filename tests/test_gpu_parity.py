@@ -172,6 +172,40 @@ def test_determinism(engine):
         assert getattr(a, f) == getattr(b, f)
 
 
+def test_full_size_properties_binary(engine):
+    """BASELINE configs[3] size (binary trait, logistic null, N = 200 000, M = 50): as test_full_size_properties with
+    the weighted statistics G'W[G X rr], W = diag(p(1-p)) of the device-fitted logistic null."""
+    import hc
+    N, M, d = 200000, 50, 2
+    rng = np.random.default_rng(20260003)
+    maf = 10 ** rng.uniform(np.log10(5e-4), np.log10(5e-2), M)
+    G = np.asfortranarray((rng.random((N, M)) < maf).astype(np.float64) + (rng.random((N, M)) < maf))
+    af = G.sum(0) / (2.0 * N)
+    X = np.column_stack([np.ones(N), rng.normal(size=N)])
+    eta = -2.0 + 0.3 * X[:, 1] + 0.1 * G[:, :5].sum(1)
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float64)
+    rc, beta, p, v = orc.fit_logistic(X, y)
+    assert rc == 0
+    res = y - p
+    gb, _ = engine.fit_null(1, X, y)                         # LogisticRegression::FitLogisticModel on the device
+    assert np.allclose(gb, beta, rtol=1e-9, atol=1e-12)
+    ptr = engine.upload_block(G)
+    S, T, u, cs, mn, mx = engine.debug_suffstat(ptr, M)
+    Gw = G * v[:, None]
+    assert np.max(np.abs(S - G.T @ Gw)) <= 1e-10 * np.abs(S).max()
+    assert np.array_equal(cs, G.sum(0))
+    assert np.max(np.abs(T - Gw.T @ X)) <= 1e-10 * N and np.max(np.abs(u - G.T @ res)) <= 1e-10 * N
+    r1 = engine.run_blocks([ptr], [M], [af])[0]
+    c = (G.astype(np.int64) > 0).sum(1).astype(np.float64)
+    bs = hc.burden_sums((c > 0).astype(np.float64), c, X, res, v, 1)
+    h, _, _, _ = hc.gene(G, af, X, res, v, 1, 1.0, bstats=bs)
+    assert abs(r1.skat_Q - h.skat_Q) <= 1e-10 * h.skat_Q and abs(r1.skat_p - h.skat_p) <= 1e-6 * h.skat_p + ABS_P
+    assert r1.skato_rho == h.skato_rho and abs(r1.skato_p - h.skato_p) <= 1e-6 * h.skato_p + ABS_SKATO
+    assert r1.cmc_nonref == int((c > 0).sum())
+    assert abs(r1.cmc_p - h.cmc_p) <= 1e-7 * h.cmc_p and abs(r1.zeg_p - h.zeg_p) <= 1e-7 * h.zeg_p
+    engine.free_block(ptr)
+
+
 def test_full_size_properties(engine):
     """BASELINE configs[2] size (N = 500 000, M = 50): the oracle's literal SKAT-O needs ~20 s per gene here, so the
     full-size check uses size-independent properties instead:
