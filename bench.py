@@ -197,20 +197,37 @@ def main():
         while inflight:
             retire(inflight.pop(0))
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else None)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    barrier()
+    tw = time.perf_counter()
     run_steps(args.warmup)
     barrier()
-    eng.set_profiling(True)
-    eng.timing(reset=True)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tm = eng.timing(reset=True)
-    eng.set_profiling(False)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax[0])
+    warm_ms = max_over_ranks(time.perf_counter() - tw) * 1e3 / max(args.warmup, 1)
+    # The timed region is EXACTLY args.steps steps between barriers.  Once in some tens of runs a fresh box shows a host-side
+    # stall (seconds per step while the kernels themselves run at their usual duration — lost wake-ups of the blocking
+    # stream waits); a timed region more than 5x slower per step than the untimed warm-up steps (which include the
+    # first-launch overheads) is therefore measured again, at most twice, and every discarded attempt is reported.
+    discarded = []
+    while True:
+        eng.set_profiling(True)
+        eng.timing(reset=True)
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tm = eng.timing(reset=True)
+        eng.set_profiling(False)
+        elapsed = max_over_ranks(elapsed)
+        step_ms = elapsed * 1e3 / max(args.steps, 1)
+        if args.warmup > 0 and step_ms > 5.0 * warm_ms and len(discarded) < 2:
+            discarded.append(round(step_ms, 3))
+            continue
+        break
 
     if rank == 0:
         total_genes = world * args.genes * args.steps
@@ -254,6 +271,8 @@ def main():
                                   "gene_stats": tm.ms_stats / tot_ms, "gene_pvalue": tm.ms_pvalue / tot_ms,
                                   "device_ms_per_step": tot_ms / args.steps},
             "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
+            # untimed warm-up rate and any timed region that was measured again (see the guard above): ms per step
+            "warmup_ms_per_step": warm_ms, "discarded_timed_regions_ms_per_step": discarded,
         }
         if world == 1 and not args.no_cpu_baseline:
             k = int(np.argmin(np.abs(np.array(Ms) - 50)))
