@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--samples", type=int, default=500000)
-    ap.add_argument("--genes", type=int, default=256, help="genes per step per GPU")
+    ap.add_argument("--genes", type=int, default=512, help="genes per step per GPU (512 x ~200 MB = 102 GB resident)")
     ap.add_argument("--m-lo", type=int, default=20)
     ap.add_argument("--m-hi", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
