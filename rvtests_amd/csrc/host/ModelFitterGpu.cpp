@@ -441,6 +441,10 @@ int MetaScoreTest::setParameter(const ModelParser& parser) {
 int MetaScoreTest::fit(GeneData* dc) {
   useFamilyModel = dc->kinshipU != nullptr;  // dc->hasKinship(): MetaFamQtl / MetaFamBinary (src/Model.h:3398-3668)
   if ((int)rows.size() >= capacity && used > 0 && flush()) return -1;
+  if (used >= capacity) {  // flush() could not run: no writeOutput() has named the output sink yet
+    lastError = "MetaScore: the device block is full and no output was requested for its sites";
+    return -1;
+  }
   rows.emplace_back();
   Row& row = rows.back();
   row.all = dc->counter;  // site statistics are printed whether or not the test runs (src/Model.h:3211-3230)
