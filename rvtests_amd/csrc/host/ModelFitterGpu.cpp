@@ -82,6 +82,7 @@ GpuBroker& GpuBroker::instance() {
   if (!init) {
     init = true;
     if (const char* e = getenv("RVT_ADAPTER_BATCH")) b.setBatchWindow(atoi(e));
+    if (const char* e = getenv("RVT_ADAPTER_BATCH_GB")) b.setBatchBytes((size_t)std::max(1, atoi(e)) << 30);
   }
   return b;
 }
@@ -110,6 +111,7 @@ void GpuBroker::shutdown() {
   ctx = nullptr;
   rows.clear();
   pendingSerial.clear();
+  pendingBytes = 0;
   failedSerial.clear();
   haveNull = false;
   haveFamNull = false;
@@ -212,7 +214,10 @@ const rvt_gene_result* GpuBroker::famResultFor(const GeneData& gd, std::string* 
 
 int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
   if (gd.serial == curSerial) return curOk ? 0 : -1;  // another model of the same gene already submitted it
-  if ((int)pendingSerial.size() >= window) flush();
+  // genes in flight are bounded by count and by the bytes of their device blocks (a 1024-variant gene is 4 GB at
+  // N = 500 000)
+  const size_t geneBytes = sizeof(double) * (size_t)gd.N * (size_t)gd.M;
+  if ((int)pendingSerial.size() >= window || (!pendingSerial.empty() && pendingBytes + geneBytes > windowBytes)) flush();
   curSerial = gd.serial;
   curOk = false;
   auto failed = [&]() {
@@ -236,6 +241,7 @@ int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
     return failed();
   }
   pendingSerial.push_back(gd.serial);
+  pendingBytes += geneBytes;
   curOk = true;
   return 0;
 }

@@ -124,8 +124,10 @@ class GpuBroker {
   // order by flush(), which runs one rvt_collect over everything pending.  flush() is triggered when `window` genes
   // are pending and a new one arrives, by writeFootnote() and by ~ModelManager — the reference's own MetaCovTest
   // defers its rows the same way (src/Model.cpp:828-834), and `main` ignores fit()'s return value
-  // (src/Main.cpp:1251).  window = 1 (default; RVT_ADAPTER_BATCH overrides) keeps at most one gene in flight.
+  // (src/Main.cpp:1251).  Default window: 64 genes or 64 GB of genotype blocks, whichever fills first (RVT_ADAPTER_BATCH /
+  // RVT_ADAPTER_BATCH_GB override; window = 1 keeps at most one gene in flight).
   void setBatchWindow(int k) { window = k < 1 ? 1 : k; }
+  void setBatchBytes(size_t b) { windowBytes = b; }
   int submit(const GeneData& gd, bool binary, std::string* err);
   void enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab, int64_t serial);
   int flush();
@@ -153,7 +155,9 @@ class GpuBroker {
   rvt_fam_null famNull{};
   int64_t curSerial = -1;
   bool curOk = false;
-  int window = 1;
+  int window = 64;                              // genes in flight (RVT_ADAPTER_BATCH)
+  size_t windowBytes = (size_t)64 << 30;        // ... and the bytes of their device blocks (RVT_ADAPTER_BATCH_GB)
+  size_t pendingBytes = 0;
   struct Row {
     ModelFitter* model;
     TextSink* fp;
