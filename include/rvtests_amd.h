@@ -316,11 +316,17 @@ int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* a
  *   rvt_submit_gene_raw : N x M doubles, column-major (hard calls or dosages)
  *   rvt_submit_gene_i8  : N x M int8, column-major (hard calls 0/1/2, negative = missing): 1 byte per genotype over
  *                         PCIe instead of 8
+ *   rvt_submit_gene_bed : PLINK .bed storage as PlinkInputFile reads it in SNP-major mode
+ *                         (libVcf/PlinkInputFile.cpp:24-47, codes libVcf/PlinkInputFile.h:206-209): M rows of
+ *                         ceil(N/4) bytes, sample p in bits 2(p&3).. of byte p>>2; 00 -> 0, 10 -> 1, 11 -> 2,
+ *                         01 -> missing: a quarter of a byte per genotype
  * af_out (M, may be NULL) receives the allele frequencies the tests use (dc->getMarkerFrequency). */
 int rvt_submit_gene_raw(rvt_ctx* ctx, int64_t gene_id, int M, const double* Graw, uint32_t tests,
                         const rvt_params* params, double* af_out);
 int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
                        const rvt_params* params, double* af_out);
+int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
+                        const rvt_params* params, double* af_out);
 
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */

@@ -99,8 +99,24 @@ __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict_
 // 3 100 workgroups instead of 50): partial counts per (column, piece) -> per-column AF and fill value (partials summed
 // in piece order) -> imputed fp64 columns.  For integer-valued columns (hard calls) the truncating accumulation is an
 // exact integer sum; a column that mixes fractional dosages with missing values replays the reference's sequential
-// accumulation on one lane.  SRC is double (in place) or int8 (packed hard calls, expanded to fp64).
+// accumulation on one lane.  SRC is double (in place), int8 (packed hard calls) or bed2_t (PLINK 2-bit codes); the
+// packed forms are expanded to fp64.
 constexpr int kConsolChunk = 8192;  // samples per workgroup
+// PLINK .bed storage, SNP-major (libVcf/PlinkInputFile.cpp:24-47, codes libVcf/PlinkInputFile.h:206-209): 4 samples per
+// byte, sample p in bits 2(p & 3) .. 2(p & 3)+1 of byte p >> 2; 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing (-9).  Every
+// variant starts on a byte boundary (its row is ceil(N/4) bytes).
+struct bed2_t {
+  unsigned char b;
+};
+template <typename SRC>
+__device__ __forceinline__ double load_genotype(const SRC* col, long long i) {
+  return (double)col[i];
+}
+template <>
+__device__ __forceinline__ double load_genotype<bed2_t>(const bed2_t* col, long long i) {
+  const unsigned code = (col[i >> 2].b >> ((i & 3) << 1)) & 3u;
+  return code == 0u ? 0.0 : (code == 2u ? 1.0 : (code == 3u ? 2.0 : -9.0));
+}
 struct ConsolPart {
   double sumAC, ac;
   long long nonneg;
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel(const SRC* __res
   long long nonneg = 0;
   int flags = 0;
   for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const double g = (double)col[i];
+    const double g = load_genotype(col, i);
     if (g < 0.0) {
       flags |= 3;
     } else {
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(64) void consolidate_fill_kernel(const SRC* __restr
       const SRC* col = src + (long long)blockIdx.x * src_ld;
       aci = 0;
       for (long long i = 0; i < N; ++i) {
-        const double g = (double)col[i];
+        const double g = load_genotype(col, i);
         if (g >= 0.0) aci = (int)((double)aci + g);
       }
     } else {
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(256) void consolidate_write_kernel(const SRC* __res
   const long long i0 = (long long)blockIdx.x * kConsolChunk;
   const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
   for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const double g = (double)col[i];
+    const double g = load_genotype(col, i);
     out[i] = (g < 0.0) ? fill : g;
   }
 }

@@ -2486,7 +2486,8 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
 }  // namespace
 
 namespace {
-// mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto)
+// mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto);
+// 3: PLINK 2-bit codes (ditto)
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
   if (!c || !G || M < 1 || (mode == 0 && !af)) return fail(c, RVT_E_INVALID, "bad gene");
@@ -2565,7 +2566,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       hipLaunchKernelGGL((consolidate_write_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
                          (long long)ld, d_fill, p.dG);
     } else {
-      const size_t bytes8 = (size_t)N * M;
+      // packed hard calls: one byte per genotype (mode 2) or PLINK's 2-bit codes, ceil(N/4) bytes per variant (mode 3)
+      const size_t col_bytes = (mode == 3) ? (size_t)((N + 3) / 4) : (size_t)N;
+      const size_t bytes8 = col_bytes * M;
       if (c->consol_i8_cap < bytes8) {
         if (c->d_consol_i8) hipFree(c->d_consol_i8);
         c->d_consol_i8 = nullptr;
@@ -2574,7 +2577,16 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
       }
       if (e == hipSuccess) e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess) {
+      if (e == hipSuccess && mode == 3) {
+        const bed2_t* sb = (const bed2_t*)c->d_consol_i8;
+        const long long cb = (long long)col_bytes;
+        hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
+                           c->d_consol_parts);
+        hipLaunchKernelGGL((consolidate_fill_kernel<bed2_t>), dim3((unsigned)M), dim3(64), 0, st, sb, cb, (long long)N,
+                           nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+        hipLaunchKernelGGL((consolidate_write_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
+                           (long long)ld, d_fill, p.dG);
+      } else if (e == hipSuccess) {
         const signed char* s8 = (const signed char*)c->d_consol_i8;
         hipLaunchKernelGGL((consolidate_count_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
                            (long long)N, c->d_consol_parts);
@@ -2604,6 +2616,10 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
 int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                     const rvt_params* prm) {
   return submit_common(c, gene_id, M, G, 0, af, nullptr, tests, prm);
+}
+int rvt_submit_gene_bed(rvt_ctx* c, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
+                        const rvt_params* prm, double* af_out) {
+  return submit_common(c, gene_id, M, bed, 3, nullptr, af_out, tests, prm);
 }
 int rvt_submit_gene_raw(rvt_ctx* c, int64_t gene_id, int M, const double* Graw, uint32_t tests,
                         const rvt_params* prm, double* af_out) {

@@ -146,6 +146,9 @@ def load_library():
     L.rvt_submit_gene_i8.restype = C.c_int
     L.rvt_submit_gene_i8.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(Params),
                                      c_double_p]
+    L.rvt_submit_gene_bed.restype = C.c_int
+    L.rvt_submit_gene_bed.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(Params),
+                                      c_double_p]
     L.rvt_collect.restype = C.c_int
     L.rvt_collect.argtypes = [vp, C.POINTER(GeneResult), C.c_int, c_int_p]
     L.rvt_debug_collapse.restype = C.c_int
@@ -317,6 +320,28 @@ class Engine:
         prm = params or Params.default()
         self._check(self.L.rvt_submit_gene(self.ctx, int(gene_id), G.shape[1], _dp(G), _dp(af), int(tests),
                                            C.byref(prm)))
+
+    @staticmethod
+    def pack_bed(Graw):
+        """PLINK .bed SNP-major packing of an N x M matrix of hard calls (negative = missing): M rows of ceil(N/4)
+        bytes, 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing (what PlinkInputFile reads)."""
+        G = np.asarray(Graw)
+        N, M = G.shape
+        code = np.where(G < 0, 1, np.where(G == 0, 0, np.where(G == 1, 2, 3))).astype(np.uint8)
+        pad = (-N) % 4
+        if pad:
+            code = np.vstack([code, np.zeros((pad, M), dtype=np.uint8)])
+        c4 = code.T.reshape(M, -1, 4)
+        return np.ascontiguousarray(c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6))
+
+    def submit_gene_bed(self, gene_id, bed, M, tests=TEST_ALL, params=None):
+        """PLINK 2-bit codes (pack_bed layout) -> rvt_submit_gene_bed; returns the allele frequencies used."""
+        prm = params or Params.default()
+        bed = np.ascontiguousarray(bed, dtype=np.uint8)
+        af = np.zeros(M)
+        self._check(self.L.rvt_submit_gene_bed(self.ctx, int(gene_id), int(M), bed.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               int(tests), C.byref(prm), _dp(af)))
+        return af
 
     def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None):
         """Raw extractor output (missing < 0): float64 -> rvt_submit_gene_raw, int8 -> rvt_submit_gene_i8.  The device

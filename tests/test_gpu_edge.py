@@ -92,11 +92,12 @@ def test_large_gene_list_is_chunked(engine):
             assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
 
 
-@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("packed", [False, True, "bed"])
 def test_raw_and_packed_submission_consolidate_on_device(engine, packed):
-    """rvt_submit_gene_raw / _i8: counter allele frequencies and mean imputation done on the device give the same
-    records as handing over the block DataConsolidator would have produced (oracle imputation + counter AF)."""
-    N = 1200
+    """rvt_submit_gene_raw / _i8 / _bed: counter allele frequencies and mean imputation done on the device give the same
+    records as handing over the block DataConsolidator would have produced (oracle imputation + counter AF).  N is not
+    a multiple of 4 so the last byte of every PLINK row is partly used."""
+    N = 1202
     X, y, res, v, s2 = synth.make_null(N, 3, 0, seed=9)
     engine.set_null(0, X, res, v, s2)
     cases = [synth.make_gene(N, M, seed=70 + M, missing=miss, common=True, mono=True)
@@ -108,8 +109,11 @@ def test_raw_and_packed_submission_consolidate_on_device(engine, packed):
         Graw[:, 2] = np.where(Graw[:, 2] > 1.9, 2.5, Graw[:, 2])       # > 2: counted missing, not imputed
         cases.append((Graw, orc.impute_mean(Graw), orc.counter_af(Graw)))
     for k, (Graw, G, af) in enumerate(cases):
-        raw = Graw.astype(np.int8) if packed else Graw
-        got_af = engine.submit_gene_raw(k, raw)
+        if packed == "bed":
+            got_af = engine.submit_gene_bed(k, engine.pack_bed(Graw), Graw.shape[1])
+        else:
+            raw = Graw.astype(np.int8) if packed else Graw
+            got_af = engine.submit_gene_raw(k, raw)
         assert np.allclose(got_af, af, rtol=1e-14, atol=0)
     got = engine.collect()
     ptrs = [engine.upload_block(G) for Graw, G, af in cases]

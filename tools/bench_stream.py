@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--genes", type=int, default=128)
     ap.add_argument("--window", type=int, default=64)
     ap.add_argument("--packed", action="store_true", help="int8 hard calls through rvt_submit_gene_i8")
+    ap.add_argument("--bed", action="store_true", help="PLINK 2-bit codes through rvt_submit_gene_bed")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N = a.samples
@@ -32,14 +33,18 @@ def main():
                  np.full(N, float(sigma2)), float(sigma2))
     blocks, Ms, afs = bench.make_genes(dev, N, ld, 4, 21, a.variants, a.variants)
     host = [np.asfortranarray(b[:, :N].T.cpu().numpy()) for b in blocks]        # pageable caller buffers
-    if a.packed:
+    if a.bed:
+        host = [eng.pack_bed(np.rint(h)) for h in host]      # hard calls (imputed means of the synthetic genes rounded)
+    elif a.packed:
         host = [np.asfortranarray(h.astype(np.int8)) for h in host]
     del blocks
     for w in (1, a.window):
         t0 = time.perf_counter()
         done = 0
         for g in range(a.genes):
-            if a.packed:
+            if a.bed:
+                eng.submit_gene_bed(g, host[g % 4], a.variants)
+            elif a.packed:
                 eng.submit_gene_raw(g, host[g % 4])
             else:
                 eng.submit_gene(g, host[g % 4], afs[g % 4])
@@ -48,7 +53,8 @@ def main():
         done += len(eng.collect())
         dt = time.perf_counter() - t0
         print({"N": N, "M": a.variants, "window": w, "genes": done, "gene_sets_per_s": done / dt,
-               "host_GBps": done * (1.0 if a.packed else 8.0) * N * a.variants / dt / 1e9, "packed": a.packed})
+               "host_GBps": done * (0.25 if a.bed else 1.0 if a.packed else 8.0) * N * a.variants / dt / 1e9,
+               "packed": "bed" if a.bed else a.packed})
 
 
 if __name__ == "__main__":
