@@ -74,6 +74,7 @@ struct rvt_ctx {
   Slot slots[kSlots];
   unsigned long long launch_seq = 0;
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
+  hipStream_t io_stream = nullptr;  // host copies + consolidation of the streaming interface: never behind a batch
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
   bool cu_partitioned = false;
   // ---- related samples (FastLMM null + FamSKAT) ----
@@ -418,6 +419,10 @@ int rvt_init(rvt_ctx** out, int device_id) {
     }
   }
   c->stream = c->slots[0].stream;
+  if (hipStreamCreateWithFlags(&c->io_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RVT_E_HIP;
+  }
   for (int i = 0; i < kSlots; ++i) {
     hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming);
@@ -453,6 +458,10 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->k2_stream) {
     hipStreamSynchronize(c->k2_stream);
     hipStreamDestroy(c->k2_stream);
+  }
+  if (c->io_stream) {
+    hipStreamSynchronize(c->io_stream);
+    hipStreamDestroy(c->io_stream);
   }
   for (int i = 0; i < kSlots; ++i) {
     if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
@@ -2526,8 +2535,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     }
     p.af.assign(af, af + M);
   } else {
-    // DataConsolidator::consolidate's genotype part on the device: counter AF + mean imputation
-    hipStream_t st = c->stream;
+    // DataConsolidator::consolidate's genotype part on the device: counter AF + mean imputation.  On a stream of its
+    // own: the set-up stream is also slot 0's batch stream, and waiting on it would wait for a whole batch.
+    hipStream_t st = c->io_stream;
     const size_t afb = sizeof(double) * (size_t)M;
     if (c->consol_af_cap < (size_t)M) {
       if (c->d_consol_af) hipFree(c->d_consol_af);
