@@ -108,6 +108,13 @@ struct rvt_ctx {
   size_t consol_af_cap = 0;
   ConsolPart* d_consol_parts = nullptr;
   size_t consol_parts_cap = 0;
+  // allele frequencies of raw / packed submissions whose caller did not ask for them: written into a ring slot and
+  // copied back asynchronously; resolved (one stream wait) when the gene's group is launched
+  static constexpr int kAfSlots = 128;
+  double* d_af_ring = nullptr;  // kAfSlots x RVT_MAX_VARIANTS
+  double* h_af_ring = nullptr;  // pinned mirror
+  unsigned long long af_seq = 0;
+  int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
@@ -140,6 +147,7 @@ struct rvt_ctx {
     rvt_params prm;
     rvt_gene_result res;  // filled by the batch this gene was launched in (the queue is a deque: stable addresses)
     bool launched;
+    int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
   };
   std::deque<Pending> queue;
   std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
@@ -488,6 +496,8 @@ void rvt_destroy(rvt_ctx* c) {
     if (p) hipFree(p);
   if (c->d_consol_af) hipFree(c->d_consol_af);
   if (c->d_consol_parts) hipFree(c->d_consol_parts);
+  if (c->d_af_ring) hipFree(c->d_af_ring);
+  if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   if (c->blas) rocblas_destroy_handle(c->blas);
@@ -2418,8 +2428,27 @@ bool same_config(const rvt_ctx::Pending& a, const rvt_ctx::Pending& b) {
   return a.tests == b.tests && std::memcmp(&a.prm, &b.prm, sizeof(rvt_params)) == 0;
 }
 
+// wait for the consolidation of every submitted gene (blocks written, allele frequencies in the pinned ring) and move
+// the frequencies into their queue entries
+int resolve_af(rvt_ctx* c) {
+  if (c->af_unresolved == 0) return RVT_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->io_stream));
+  for (auto& p : c->queue)
+    if (p.af_slot >= 0) {
+      const double* h = c->h_af_ring + (size_t)p.af_slot * RVT_MAX_VARIANTS;
+      p.af.assign(h, h + p.M);
+      p.af_slot = -1;
+    }
+  c->af_unresolved = 0;
+  return RVT_OK;
+}
+
 // launch queue[first, first+n) as one asynchronous batch (analytic tests only)
 int launch_group(rvt_ctx* c, size_t first, int n) {
+  {
+    int rc = resolve_af(c);
+    if (rc) return rc;
+  }
   std::vector<const double*> ptrs;
   std::vector<int> Ms;
   std::vector<double> af;
@@ -2465,6 +2494,8 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
     if (perm) {
       // permutation p-values consume one random stream in gene order: synchronous, gene by gene
       int rc = rvt_sync(c);
+      if (rc) return rc;
+      rc = resolve_af(c);
       if (rc) return rc;
       std::vector<const double*> ptrs;
       std::vector<int> Ms;
@@ -2607,8 +2638,31 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       }
     }
     p.af.resize(M);
-    if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // also: the caller may overwrite its buffer on return
+    if (af_out) {
+      if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    } else if (e == hipSuccess) {
+      // nobody waits for the frequencies: the host copy of the block is already consumed (a copy from pageable memory
+      // returns once the source has been read), so return now and pick the frequencies up at launch time
+      if (!c->d_af_ring) {
+        e = hipMalloc((void**)&c->d_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS);
+        if (e == hipSuccess)
+          e = hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS,
+                            hipHostMallocDefault);
+      }
+      if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
+      if (e == hipSuccess) {
+        const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+        double* d_slot = c->d_af_ring + (size_t)slot * RVT_MAX_VARIANTS;
+        e = hipMemcpyAsync(d_slot, c->d_consol_af, afb, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(c->h_af_ring + (size_t)slot * RVT_MAX_VARIANTS, d_slot, afb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) {
+          p.af_slot = slot;
+          ++c->af_unresolved;
+        }
+      }
+    }
     if (e != hipSuccess) {
       give_back();
       return fail(c, RVT_E_HIP, "genotype consolidation failed: %s", hipGetErrorString(e));
@@ -2662,9 +2716,16 @@ int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);
   for (auto& L : c->launched) L.first -= (size_t)n;
   // keep the pool bounded: free the largest blocks beyond 128 entries
-  while (c->block_pool.size() > 128) {
-    hipFree(c->block_pool.back().second);
-    c->block_pool.pop_back();
+  {  // keep the free blocks for the next window, bounded by their BYTES (a count bound would free and re-allocate
+     // half of a 256-gene window every time: hipMalloc + memset of a 200 MB block is ~3 ms)
+    constexpr size_t kPoolBytes = (size_t)96 << 30;
+    size_t total = 0;
+    for (auto& bp : c->block_pool) total += bp.first;
+    while (!c->block_pool.empty() && (total > kPoolBytes || c->block_pool.size() > 4096)) {
+      total -= c->block_pool.back().first;
+      hipFree(c->block_pool.back().second);
+      c->block_pool.pop_back();
+    }
   }
   *n_out = n;
   return RVT_OK;

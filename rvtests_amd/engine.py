@@ -334,30 +334,31 @@ class Engine:
         c4 = code.T.reshape(M, -1, 4)
         return np.ascontiguousarray(c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6))
 
-    def submit_gene_bed(self, gene_id, bed, M, tests=TEST_ALL, params=None):
-        """PLINK 2-bit codes (pack_bed layout) -> rvt_submit_gene_bed; returns the allele frequencies used."""
+    def submit_gene_bed(self, gene_id, bed, M, tests=TEST_ALL, params=None, want_af=True):
+        """PLINK 2-bit codes (pack_bed layout) -> rvt_submit_gene_bed; returns the allele frequencies used (None with
+        want_af=False: the call then does not wait for the device)."""
         prm = params or Params.default()
         bed = np.ascontiguousarray(bed, dtype=np.uint8)
-        af = np.zeros(M)
+        af = np.zeros(M) if want_af else None
         self._check(self.L.rvt_submit_gene_bed(self.ctx, int(gene_id), int(M), bed.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                               int(tests), C.byref(prm), _dp(af)))
+                                               int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
 
-    def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None):
+    def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None, want_af=True):
         """Raw extractor output (missing < 0): float64 -> rvt_submit_gene_raw, int8 -> rvt_submit_gene_i8.  The device
-        imputes and counts allele frequencies; returns the frequencies the tests will use."""
+        imputes and counts allele frequencies; returns the frequencies the tests will use (None with want_af=False)."""
         prm = params or Params.default()
         if Graw.dtype == np.int8:
             G = np.asfortranarray(Graw)
-            af = np.zeros(G.shape[1])
+            af = np.zeros(G.shape[1]) if want_af else None
             self._check(self.L.rvt_submit_gene_i8(self.ctx, int(gene_id), G.shape[1],
                                                   G.ctypes.data_as(C.POINTER(C.c_int8)), int(tests), C.byref(prm),
-                                                  _dp(af)))
+                                                  _dp(af) if want_af else None))
         else:
             G = np.asfortranarray(Graw, dtype=np.float64)
-            af = np.zeros(G.shape[1])
+            af = np.zeros(G.shape[1]) if want_af else None
             self._check(self.L.rvt_submit_gene_raw(self.ctx, int(gene_id), G.shape[1], _dp(G), int(tests),
-                                                   C.byref(prm), _dp(af)))
+                                                   C.byref(prm), _dp(af) if want_af else None))
         return af
 
     def collect(self, cap=4096):

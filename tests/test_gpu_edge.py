@@ -92,8 +92,9 @@ def test_large_gene_list_is_chunked(engine):
             assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
 
 
+@pytest.mark.parametrize("want_af", [True, False])
 @pytest.mark.parametrize("packed", [False, True, "bed"])
-def test_raw_and_packed_submission_consolidate_on_device(engine, packed):
+def test_raw_and_packed_submission_consolidate_on_device(engine, packed, want_af):
     """rvt_submit_gene_raw / _i8 / _bed: counter allele frequencies and mean imputation done on the device give the same
     records as handing over the block DataConsolidator would have produced (oracle imputation + counter AF).  N is not
     a multiple of 4 so the last byte of every PLINK row is partly used."""
@@ -109,12 +110,15 @@ def test_raw_and_packed_submission_consolidate_on_device(engine, packed):
         Graw[:, 2] = np.where(Graw[:, 2] > 1.9, 2.5, Graw[:, 2])       # > 2: counted missing, not imputed
         cases.append((Graw, orc.impute_mean(Graw), orc.counter_af(Graw)))
     for k, (Graw, G, af) in enumerate(cases):
+        # want_af = False: the call returns without waiting for the device; the frequencies are picked up when the
+        # gene's group is launched
         if packed == "bed":
-            got_af = engine.submit_gene_bed(k, engine.pack_bed(Graw), Graw.shape[1])
+            got_af = engine.submit_gene_bed(k, engine.pack_bed(Graw), Graw.shape[1], want_af=want_af)
         else:
             raw = Graw.astype(np.int8) if packed else Graw
-            got_af = engine.submit_gene_raw(k, raw)
-        assert np.allclose(got_af, af, rtol=1e-14, atol=0)
+            got_af = engine.submit_gene_raw(k, raw, want_af=want_af)
+        if want_af:
+            assert np.allclose(got_af, af, rtol=1e-14, atol=0)
     got = engine.collect()
     ptrs = [engine.upload_block(G) for Graw, G, af in cases]
     want = engine.run_blocks(ptrs, [G.shape[1] for Graw, G, af in cases], [af for Graw, G, af in cases])

@@ -43,9 +43,9 @@ def main():
         done = 0
         for g in range(a.genes):
             if a.bed:
-                eng.submit_gene_bed(g, host[g % 4], a.variants)
+                eng.submit_gene_bed(g, host[g % 4], a.variants, want_af=False)
             elif a.packed:
-                eng.submit_gene_raw(g, host[g % 4])
+                eng.submit_gene_raw(g, host[g % 4], want_af=False)
             else:
                 eng.submit_gene(g, host[g % 4], afs[g % 4])
             if (g + 1) % w == 0:
