@@ -206,7 +206,8 @@ def main():
     torch.cuda.synchronize()
     # pre-packed batches over the same resident blocks: the engine keeps up to four batches in flight (one HIP
     # stream each), so the latency-bound tail of step i overlaps the bandwidth-bound head of step i+1
-    NSLOT = rvtests_amd.MAX_INFLIGHT  # RVT_MAX_INFLIGHT
+    # batches in flight: RVT_MAX_INFLIGHT by default (RVT_BENCH_INFLIGHT lowers it for experiments)
+    NSLOT = max(1, min(rvtests_amd.MAX_INFLIGHT, int(os.environ.get("RVT_BENCH_INFLIGHT", rvtests_amd.MAX_INFLIGHT))))
     batches = [eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests) for _ in range(NSLOT)]
     batch = batches[0]
 
