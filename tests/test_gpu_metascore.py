@@ -118,3 +118,26 @@ def test_score_block_fam_matches_oracle(engine_factory, n_fam, d, binary):
     assert rc == 0
     assert np.allclose(eng.fam_null_summary(d), np.diag(covb), rtol=1e-8)
     eng.free_block(ptr)
+
+
+def test_score_block_fam_chunks_beyond_one_block(engine_factory):
+    """More raw columns than RVT_MAX_VARIANTS: rvt_score_block_fam walks the block in pieces; every column equals what a
+    call on a small block that holds only its neighbourhood returns."""
+    import synth
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(40, 2, 77)
+    eng = engine_factory()
+    eng.set_kinship(U, S)
+    eng.fit_fam_null(X, y)
+    V = 1100
+    G = synth.make_gene(N, V, seed=99, missing=0.02, common=True, mono=True, maf_hi=-0.7)[1]
+    ptr = eng.upload_block(G)
+    whole = eng.score_block_fam(ptr, V)
+    eng.free_block(ptr)
+    for lo, hi in ((0, 40), (1000, 1060), (1060, 1100)):
+        p2 = eng.upload_block(np.asfortranarray(G[:, lo:hi]))
+        part = eng.score_block_fam(p2, hi - lo)
+        eng.free_block(p2)
+        assert (part["ok"] == whole["ok"][lo:hi]).all() and part["ok"].sum() > 5
+        for f in ("U", "V", "af", "p"):
+            assert np.allclose(part[f], whole[f][lo:hi], rtol=1e-9, atol=1e-12), f
