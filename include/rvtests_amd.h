@@ -300,7 +300,8 @@ int rvt_run_fam_tests(rvt_ctx* ctx, int n_genes, const double* const* dG, const 
                       uint32_t tests, rvt_gene_result* out);
 /* MetaCov with kinship, quantitative trait (MetaCovFamQtl, src/Model.cpp:437-504 over FastLMM::TransformCentered /
  * GetCovXX / GetCovXZ / GetCovZZ, regression/FastLMM.cpp:510-625): same contract as rvt_cov_block, with the null model
- * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  The binary family variant is not provided. */
+ * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  For the binary family variant (MetaCovFamBinary) call
+ * rvt_fam_binary_scale first. */
 int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
 /* MetaCovFamBinary (src/Model.cpp:595-692): after rvt_fit_fam_null on the 0/1 phenotype, scale everything
  * rvt_cov_block_fam returns by b^2, b = obtainB(alpha) = integral of logistic'(alpha + x) phi(x) dx
