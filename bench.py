@@ -9,8 +9,13 @@ genes with M_g ~ Uniform{20..80}; genes shard across ranks with no data-path col
 only collectives are one broadcast of the null model and one gather of the per-gene result records per step.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the engine's stream around the
-fp64-MFMA sufficient-statistics kernel; `cpu_baseline` times the CPU oracle (literal SKAT-O + folded SKAT +
-CMC + Zeggini, reference release flags -O2 -msse2, 1 thread) on ONE gene of the same workload.
+sufficient-statistics kernel; `cpu_baseline` times the CPU oracle (literal SKAT-O + folded SKAT + CMC + Zeggini,
+reference release flags -O2 -msse2) on a sample of genes of the same workload — 1 thread alone, then one process
+per core — and `parity` compares the oracle's numbers for those genes with the GPU records of the timed run
+(the second half of the BASELINE metric: p-value max-abs-diff).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run as a child
+process, before this process touches the GPU).
 """
 import argparse
 import json
@@ -92,63 +97,119 @@ def fit_null_qt(dev, N, seed):
     return X, y, res, sigma2
 
 
-def cpu_baseline(G_host, af, X, y, binary):
-    """Time the CPU oracle on one gene: SKAT (P0 folded; the literal N x N form cannot run at this N), literal
-    SKAT-O, CMC and Zeggini — the four ModelFitter::fit bodies of the workload.  The null model (fitted once per
-    analysis, not per gene) is outside the timed region."""
+def oracle_gene(orc, G_host, af, X, y, res, v, binary):
+    """The four ModelFitter::fit bodies of the workload on one gene through the CPU oracle: SKAT (P0 folded; the
+    literal N x N form cannot run at this N), literal SKAT-O, CMC and Zeggini.  Returns (seconds, numbers)."""
+    t0 = time.perf_counter()
+    rc1, a = orc.skat(G_host, af, X, res, v, binary)
+    rc2, o = orc.skato(G_host, af, X, res, v, binary)
+    rc3, c = orc.burden(G_host, X, y, binary, 0)
+    rc4, z = orc.burden(G_host, X, y, binary, 1)
+    t = time.perf_counter() - t0
+    return t, dict(skat_Q=a.Q, skat_p=a.pvalue, skato_Q=o.Q, skato_p=o.pvalue, skato_rho=o.rho, cmc_p=c.pvalue,
+                   zeg_p=z.pvalue, cmc_nonref=c.nonref_site, n_poly=a.n_poly,
+                   ok=[int(a.fit_ok), int(o.fit_ok), int(c.fit_ok), int(z.fit_ok)])
+
+
+def cpu_worker(path):
+    """Child process of cpu_oracle_pool: CPU only (torch is never imported).  Fits the null model once, then runs its
+    genes; prints one JSON object."""
     import orc
+    z = np.load(path)
+    X = np.asfortranarray(z["X"])
+    y = z["y"]
+    binary = int(z["binary"])
     if binary:
         rc, beta, p, v = orc.fit_logistic(X, y)
         res = y - p
     else:
         rc, beta, pred, res, s2 = orc.fit_linear(X, y)
         v = np.full(len(y), s2)
-    t0 = time.perf_counter()
-    orc.skat(G_host, af, X, res, v, binary)
-    orc.skato(G_host, af, X, res, v, binary)
-    orc.burden(G_host, X, y, binary, 0)
-    orc.burden(G_host, X, y, binary, 1)
-    return time.perf_counter() - t0
+    out = []
+    t_all = time.perf_counter()
+    for k in z["genes"]:
+        t, r = oracle_gene(orc, np.asfortranarray(z["G%d" % k]), z["af%d" % k], X, y, res, v, binary)
+        r["gene"] = int(k)
+        r["seconds"] = t
+        out.append(r)
+    print(json.dumps({"results": out, "seconds": time.perf_counter() - t_all}))
 
 
-def cpu_baseline_all_cores(G_host, af, X, y, binary, max_workers=32):
-    """The same single-gene oracle run as `cpu_baseline`, one independent process per core on `workers` cores at once
-    (genes are independent, so this is how the CPU port would use a whole host): returns (genes/s, workers, wall s).
-    Child processes are plain `python bench.py --cpu-worker <file>` interpreters that never touch the GPU; their number
-    is bounded by the cores this process may use and by the free host memory (about 4 GB per worker)."""
+def cpu_oracle_pool(genes, X, y, binary, workers):
+    """Run the oracle on `genes` ({index: (G_host, af)}) in `workers` independent single-thread processes at once, the
+    genes dealt round-robin (genes are independent: this is how the CPU port would use a whole host).  The timed
+    wall clock starts when the processes are started and includes their start-up and null fit.  Returns
+    (records by gene index, wall seconds)."""
     import subprocess
     import tempfile
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    try:
-        import psutil
-        by_mem = int(psutil.virtual_memory().available / (4 << 30))
-    except Exception:
-        by_mem = 4
-    workers = max(1, min(max_workers, ncpu, by_mem))
+    idx = sorted(genes)
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=base) as td:
-        path = os.path.join(td, "gene.npz")
-        np.savez(path, G=G_host, af=af, X=X, y=y, binary=np.int64(binary))
+        paths = []
+        for w in range(workers):
+            mine = idx[w::workers]
+            if not mine:
+                continue
+            path = os.path.join(td, "w%d.npz" % w)
+            arrs = dict(X=X, y=y, binary=np.int64(binary), genes=np.array(mine, dtype=np.int64))
+            for k in mine:
+                arrs["G%d" % k] = genes[k][0]
+                arrs["af%d" % k] = genes[k][1]
+            np.savez(path, **arrs)
+            paths.append(path)
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
-                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(workers)]
-        ok = 0
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for path in paths]
+        recs = {}
+        ok = True
         for pr in procs:
             out, _ = pr.communicate()
-            ok += 1 if pr.returncode == 0 and out.strip() else 0
+            if pr.returncode != 0 or not out.strip():
+                ok = False
+                continue
+            for r in json.loads(out.decode().strip().splitlines()[-1])["results"]:
+                recs[r["gene"]] = r
         wall = time.perf_counter() - t0
-    if ok != workers:
-        return None
-    return workers / wall, workers, wall
+    return (recs if ok else None), wall
+
+
+def parity_summary(recs, gpu):
+    """GPU records vs oracle records of the same genes: the BASELINE metric's parity half."""
+    worst = dict(pvalue_max_abs_diff=0.0, pvalue_max_rel_diff=0.0, q_max_rel_diff=0.0)
+    nonref_equal = True
+    for k, r in recs.items():
+        g = gpu[k]
+        for name in ("skat_p", "skato_p", "cmc_p", "zeg_p"):
+            a, b = getattr(g, name), r[name]
+            worst["pvalue_max_abs_diff"] = max(worst["pvalue_max_abs_diff"], abs(a - b))
+            worst["pvalue_max_rel_diff"] = max(worst["pvalue_max_rel_diff"], abs(a - b) / max(abs(b), 1e-300))
+        for name in ("skat_Q", "skato_Q"):
+            a, b = getattr(g, name), r[name]
+            worst["q_max_rel_diff"] = max(worst["q_max_rel_diff"], abs(a - b) / max(abs(b), 1e-300))
+        nonref_equal = nonref_equal and g.cmc_nonref == r["cmc_nonref"] and g.n_poly == r["n_poly"] and \
+            abs(g.skato_rho - r["skato_rho"]) < 1e-12
+    worst["genes_compared"] = len(recs)
+    worst["counts_bit_exact"] = bool(nonref_equal)
+    worst["min_p_compared"] = min(min(r["skat_p"], r["skato_p"]) for r in recs.values()) if recs else None
+    return worst
+
+
+def spawn_ranks(n):
+    """`--gpus n` without a launcher: start n ranks as a child torch.distributed.run BEFORE this process touches the
+    GPU, pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     if _CPU_WORKER:
-        z = np.load(sys.argv[2])
-        print(cpu_baseline(np.asfortranarray(z["G"]), z["af"], np.asfortranarray(z["X"]), z["y"], int(z["binary"])))
+        cpu_worker(sys.argv[2])
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,11 +220,15 @@ def main():
     ap.add_argument("--m-lo", type=int, default=20)
     ap.add_argument("--m-hi", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-genes", type=int, default=24,
+                    help="genes of the batch run through the CPU oracle after the timed region (baseline + parity)")
     ap.add_argument("--tests", type=int, default=rvtests_amd.TEST_ALL)
     ap.add_argument("--trait", choices=["qt", "binary"], default="qt",
                     help="qt = BASELINE configs[2] (default); binary = configs[3]-style logistic null")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,6 +275,7 @@ def main():
     NSLOT = max(1, min(rvtests_amd.MAX_INFLIGHT, int(os.environ.get("RVT_BENCH_INFLIGHT", rvtests_amd.MAX_INFLIGHT))))
     batches = [eng.prepare([b.data_ptr() for b in blocks], Ms, afs, tests=args.tests) for _ in range(NSLOT)]
     batch = batches[0]
+    eng.reserve(Ms)     # every pipeline slot's workspace up front: no allocation inside a step, warm-up or timed
 
     def barrier():
         torch.cuda.synchronize()
@@ -250,26 +316,16 @@ def main():
     run_steps(args.warmup)
     barrier()
     warm_ms = max_over_ranks(time.perf_counter() - tw) * 1e3 / max(args.warmup, 1)
-    # The timed region is EXACTLY args.steps steps between barriers.  Once in some tens of runs a fresh box shows a host-side
-    # stall (seconds per step while the kernels themselves run at their usual duration — lost wake-ups of the blocking
-    # stream waits); a timed region more than 5x slower per step than the untimed warm-up steps (which include the
-    # first-launch overheads) is therefore measured again, at most twice, and every discarded attempt is reported.
-    discarded = []
-    while True:
-        eng.set_profiling(True)
-        eng.timing(reset=True)
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        tm = eng.timing(reset=True)
-        eng.set_profiling(False)
-        elapsed = max_over_ranks(elapsed)
-        step_ms = elapsed * 1e3 / max(args.steps, 1)
-        if args.warmup > 0 and step_ms > 5.0 * warm_ms and len(discarded) < 2:
-            discarded.append(round(step_ms, 3))
-            continue
-        break
+    # The timed region is EXACTLY args.steps steps between barriers, measured once.
+    eng.set_profiling(True)
+    eng.timing(reset=True)
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing(reset=True)
+    eng.set_profiling(False)
+    elapsed = max_over_ranks(elapsed)
 
     if rank == 0:
         total_genes = world * args.genes * args.steps
@@ -313,22 +369,46 @@ def main():
                                   "gene_stats": tm.ms_stats / tot_ms, "gene_pvalue": tm.ms_pvalue / tot_ms,
                                   "device_ms_per_step": tot_ms / args.steps},
             "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
-            # untimed warm-up rate and any timed region that was measured again (see the guard above): ms per step
-            "warmup_ms_per_step": warm_ms, "discarded_timed_regions_ms_per_step": discarded,
+            "warmup_ms_per_step": warm_ms,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            k = int(np.argmin(np.abs(np.array(Ms) - 50)))
-            Gh = np.asfortranarray(blocks[k][:, :N].T.cpu().numpy())
-            t = cpu_baseline(Gh, afs[k], Xh, yh, 1 if binary else 0)
-            line["cpu_baseline"] = {"value": 1.0 / t, "unit": "gene-sets/s", "cores": 1, "kind": "port",
-                                    "sample": "1 gene of the batch (M=%d, N=%d): oracle folded SKAT + literal SKAT-O + "
-                                              "CMC + Zeggini, g++ -O2 -msse2, %.1f s" % (Ms[k], N, t)}
-            allc = cpu_baseline_all_cores(Gh, afs[k], Xh, yh, 1 if binary else 0)
-            if allc:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_genes > 0:
+            # ---- CPU baseline + parity on a sample of the batch's genes (after the timed region) ------------------
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            try:
+                import psutil
+                by_mem = int(psutil.virtual_memory().available / (3 << 30))
+            except Exception:
+                by_mem = 4
+            workers = max(1, min(ncpu, by_mem, args.cpu_genes))
+            n_sample = min(args.cpu_genes, args.genes)
+            # spread over the batch's widths: every (genes / n_sample)-th gene in order of M
+            by_m = np.argsort(np.array(Ms), kind="stable")
+            pick = [int(by_m[int(round(i * (len(by_m) - 1) / max(n_sample - 1, 1)))]) for i in range(n_sample)]
+            pick = sorted(set(pick))
+            k1 = int(np.argmin(np.abs(np.array(Ms) - 50)))           # the 1-thread gene: mean width
+            host = {k: (np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()), afs[k]) for k in set(pick) | {k1}}
+            one, wall1 = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, 1)
+            if one:
+                t1 = one[k1]["seconds"]
+                line["cpu_baseline"] = {"value": 1.0 / t1, "unit": "gene-sets/s", "cores": 1, "kind": "port",
+                                        "sample": "1 gene of the batch (M=%d, N=%d) alone on the host: oracle folded SKAT "
+                                                  "+ literal SKAT-O + CMC + Zeggini, g++ -O2 -msse2, %.1f s (null fit "
+                                                  "excluded)" % (Ms[k1], N, t1)}
+            recs, wall = cpu_oracle_pool({k: host[k] for k in pick}, Xh, yh, 1 if binary else 0, workers)
+            if recs:
                 line["cpu_baseline_all_cores"] = {
-                    "value": allc[0], "unit": "gene-sets/s", "cores": allc[1], "kind": "port",
-                    "sample": "the same gene in %d independent single-thread processes at once (process start-up "
-                              "and the null fit included), %.1f s wall" % (allc[1], allc[2])}
+                    "value": len(pick) / wall, "unit": "gene-sets/s", "cores": workers, "kind": "port",
+                    "sample": "%d genes of the batch (M %d..%d) dealt to %d single-thread processes at once, %.1f s wall "
+                              "(process start-up and one null fit per process included); host has %d cores"
+                              % (len(pick), min(Ms[k] for k in pick), max(Ms[k] for k in pick), workers, wall, ncpu)}
+                if one:
+                    recs.setdefault(k1, one[k1])
+                line["parity"] = parity_summary(recs, out0)
+                line["pvalue_max_abs_diff"] = line["parity"]["pvalue_max_abs_diff"]
+                line["q_max_rel_diff"] = line["parity"]["q_max_rel_diff"]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

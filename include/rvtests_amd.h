@@ -180,6 +180,10 @@ int rvt_run_blocks_async(rvt_ctx* ctx, int n_genes, const double* const* dG, con
                          rvt_gene_result* out);
 int rvt_sync(rvt_ctx* ctx);
 int rvt_wait_oldest(rvt_ctx* ctx);
+/* Allocate, for all RVT_MAX_INFLIGHT pipeline slots at once, the device workspace and pinned staging a batch of
+ * n_genes genes with column counts M[] needs (otherwise each slot grows on its first use: a hipMalloc /
+ * hipHostMalloc of some hundred milliseconds inside the first batches).  Needs the null model (defines N, d). */
+int rvt_reserve(rvt_ctx* ctx, int n_genes, const int* M);
 
 /* ---- streaming interface used by the ModelFitter adapters ------------------------------------------
  * rvt_submit_gene copies G (host, N x M column-major, imputed, unflipped) before returning — the

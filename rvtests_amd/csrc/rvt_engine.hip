@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <map>
 #include <string>
@@ -186,10 +187,25 @@ int fail(rvt_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, RVT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+// Wait for a stream by polling.  A blocking hipStreamSynchronize() relies on a completion interrupt; on a fresh box
+// one such wake-up was seen to go missing (the kernels had long finished while the host slept for seconds), so the
+// engine never blocks in the runtime: it spins briefly, then sleeps in 20 us slices between hipStreamQuery calls.
+hipError_t sync_stream(hipStream_t st) {
+  hipError_t e;
+  int spins = 0;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) {
+    if (++spins > 64) {
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  return e;
+}
+
 int ensure_arena(rvt_ctx* c, Slot& sl, size_t bytes) {
   if (sl.arena.cap >= bytes) return RVT_OK;
   if (sl.arena.base) {
-    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    HIP_TRY(c, sync_stream(sl.stream));
     HIP_TRY(c, hipFree(sl.arena.base));
     sl.arena.base = nullptr;
     sl.arena.cap = 0;
@@ -203,7 +219,7 @@ int ensure_arena(rvt_ctx* c, Slot& sl, size_t bytes) {
 int ensure_stage(rvt_ctx* c, Slot& sl, size_t bytes) {
   if (sl.h_stage_cap >= bytes) return RVT_OK;
   if (sl.h_stage) {
-    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    HIP_TRY(c, sync_stream(sl.stream));
     HIP_TRY(c, hipHostFree(sl.h_stage));
     sl.h_stage = nullptr;
   }
@@ -215,7 +231,7 @@ int ensure_stage(rvt_ctx* c, Slot& sl, size_t bytes) {
 
 // wait for one slot's batch and hand its records to the caller
 int finish_slot(rvt_ctx* c, Slot& sl) {
-  HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  HIP_TRY(c, sync_stream(sl.stream));
   if (sl.pending_out) {
     std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
     sl.pending_out = nullptr;
@@ -462,13 +478,13 @@ static void free_null(rvt_ctx* c) {
 void rvt_destroy(rvt_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  for (auto& sl : c->slots) hipStreamSynchronize(sl.stream);
+  for (auto& sl : c->slots) sync_stream(sl.stream);
   if (c->k2_stream) {
-    hipStreamSynchronize(c->k2_stream);
+    sync_stream(c->k2_stream);
     hipStreamDestroy(c->k2_stream);
   }
   if (c->io_stream) {
-    hipStreamSynchronize(c->io_stream);
+    sync_stream(c->io_stream);
     hipStreamDestroy(c->io_stream);
   }
   for (int i = 0; i < kSlots; ++i) {
@@ -608,8 +624,8 @@ int rvt_set_profiling(rvt_ctx* c, int on) {
 int rvt_get_timing(rvt_ctx* c, rvt_timing* t, int reset) {
   if (!c || !t) return RVT_E_INVALID;
   hipSetDevice(c->device);
-  for (auto& sl : c->slots) HIP_TRY(c, hipStreamSynchronize(sl.stream));
-  HIP_TRY(c, hipStreamSynchronize(c->k2_stream));
+  for (auto& sl : c->slots) HIP_TRY(c, sync_stream(sl.stream));
+  HIP_TRY(c, sync_stream(c->k2_stream));
   drain_events(c);
   *t = c->timing;
   if (reset) std::memset(&c->timing, 0, sizeof(c->timing));
@@ -699,6 +715,35 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
   return RVT_OK;
 }
 
+// Arena layout of one gene of a batch (shared by run_batch and rvt_reserve).
+struct GeneOff {
+  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, dbg_flip, dbg_kept;
+};
+static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, size_t* total,
+                        GeneOff* o) {
+  auto add = [&](size_t bytes) {
+    *total = (*total + 255) / 256 * 256;
+    const size_t at = *total;
+    *total += bytes;
+    return at;
+  };
+  const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CT;
+  o->parts = add(sizeof(double) * (size_t)n_wparts * Mp * Cp);
+  o->colstat = add(sizeof(double) * (size_t)n_wparts * 3 * Mp);
+  o->masks = add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
+  o->flags = add(sizeof(unsigned short) * 2 * MT);
+  o->bparts = add(sizeof(double) * (size_t)n_bparts * 2 * (3 + d));
+  o->scratch = add(sizeof(double) * (gene_scratch_doubles(Mp, Cp) + 8));
+  o->lambda = add(sizeof(double) * 2 * M);
+  o->qags = add(qags_workspace_bytes(kSkatoLimit));
+  o->stats = add(sizeof(GeneStats));
+  o->dbg_flip = o->dbg_kept = 0;
+  if (dbg) {
+    o->dbg_flip = add(sizeof(int) * M);
+    o->dbg_kept = add(sizeof(int) * M);
+  }
+}
+
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
                      const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
                      DebugOut* dbg, CovOut* cov = nullptr) {
@@ -742,42 +787,25 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     total += bytes;
     return o;
   };
-  struct Off {
-    size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, dbg_flip, dbg_kept;
-  };
-  std::vector<Off> offs(n);
+  std::vector<GeneOff> offs(n);
   int maxM = 0;
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
-    const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16;
     if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene %d: M=%d exceeds RVT_MAX_VARIANTS", g, M);
     maxM = std::max(maxM, M);
     GeneDesc& gd = desc[g];
     std::memset(&gd, 0, sizeof(gd));
     gd.G = dG[g];
     gd.M = M;
-    gd.MT = MT;
-    gd.CT = CT;
-    gd.Mp = 16 * MT;
-    gd.Cp = 16 * CT;
+    gd.MT = (M + 15) / 16;
+    gd.CT = (M + d + 1 + 15) / 16;
+    gd.Mp = 16 * gd.MT;
+    gd.Cp = 16 * gd.CT;
     gd.n_wparts = n_wparts;
     gd.steps_per_wpart = steps_per;
     gd.gene_id = ids ? ids[g] : g;
-    Off& o = offs[g];
-    o.parts = add(sizeof(double) * (size_t)n_wparts * gd.Mp * gd.Cp);
-    o.colstat = add(sizeof(double) * (size_t)n_wparts * 3 * gd.Mp);
-    o.masks = add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
-    o.flags = add(sizeof(unsigned short) * 2 * MT);
-    o.bparts = add(sizeof(double) * (size_t)n_bparts * 2 * (3 + d));
-    o.scratch = add(sizeof(double) * (gene_scratch_doubles(gd.Mp, gd.Cp) + 8));
-    o.lambda = add(sizeof(double) * 2 * M);
-    o.qags = add(qags_workspace_bytes(kSkatoLimit));
-    o.stats = add(sizeof(GeneStats));
-    if (dbg) {
-      o.dbg_flip = add(sizeof(int) * M);
-      o.dbg_kept = add(sizeof(int) * M);
-    }
+    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, &total, &offs[g]);
     af_total += M;
   }
   const size_t off_af = add(sizeof(double) * af_total);
@@ -814,7 +842,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   size_t afpos = 0;
   for (int g = 0; g < n; ++g) {
     GeneDesc& gd = desc[g];
-    const Off& o = offs[g];
+    const GeneOff& o = offs[g];
     gd.parts = reinterpret_cast<double*>(base + o.parts);
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
     gd.masks = reinterpret_cast<unsigned long long*>(base + o.masks);
@@ -896,7 +924,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     HIP_TRY(c, hipMemcpyAsync(cov->se, d_bur + 3 * vt, vb8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(cov->pval, d_bur + 4 * vt, vb8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(cov->ok, d_ok, sizeof(int) * vt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     return RVT_OK;
   }
   if (cov) {  // MetaCov: finish the covariance algebra of this one block and return its band synchronously
@@ -939,7 +967,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       HIP_TRY(c, hipMemcpyAsync(cov->af, d_bur + 2 * (size_t)V, vb8, hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipMemcpyAsync(cov->pval, d_bur + 3 * (size_t)V, vb8, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     if (cov->zz) std::memcpy(cov->zz, zz.data(), sizeof(double) * (size_t)dz * dz);
     return RVT_OK;
   }
@@ -1010,7 +1038,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
   }
   if (dbg) {
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     const GeneDesc& g0 = desc[0];
     if (dbg->flip) HIP_TRY(c, hipMemcpy(dbg->flip, g0.dbg_flip, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
     if (dbg->kept) HIP_TRY(c, hipMemcpy(dbg->kept, g0.dbg_kept, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
@@ -1042,6 +1070,34 @@ int rvt_wait_oldest(rvt_ctx* c) {
   for (auto& sl : c->slots)
     if (sl.pending_out && (!oldest || sl.seq < oldest->seq)) oldest = &sl;
   return oldest ? finish_slot(c, *oldest) : RVT_OK;
+}
+
+int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
+  if (!c || n < 1 || !Ms) return fail(c, RVT_E_INVALID, "bad reserve arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  hipSetDevice(c->device);
+  const NullConsts& nc = c->nc;
+  const int d = nc.d;
+  const int64_t nsteps = nc.ld >> 4;
+  const int n_bparts = (int)((nc.N + kBurdenSPB - 1) / kBurdenSPB);
+  int n_wparts, steps_per;
+  choose_split(nc.ld, &n_wparts, &steps_per);
+  size_t total = 0, af_total = 0;
+  GeneOff o;
+  for (int g = 0; g < n; ++g) {
+    if (Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, Ms[g]);
+    layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, &total, &o);
+    af_total += (size_t)Ms[g];
+  }
+  total += sizeof(double) * af_total + sizeof(GeneDesc) * n + sizeof(rvt_gene_result) * n + 4 * 256;
+  const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
+  for (auto& sl : c->slots) {
+    int rc = ensure_arena(c, sl, total + 4096);
+    if (rc) return rc;
+    rc = ensure_stage(c, sl, stage_bytes);
+    if (rc) return rc;
+  }
+  return RVT_OK;
 }
 
 namespace {
@@ -1185,7 +1241,7 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
       const size_t n = std::min(chunk, nn - off);
       HIP_TRY(c, hipMemcpyAsync(d_tmp, U + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, c->d_U + off, n);
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, sync_stream(c->stream));
     }
     hipFree(d_tmp);
   }
@@ -1196,7 +1252,7 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
                      (long long)N, c->d_u1);
   c->h_u1.resize(N);
   HIP_TRY(c, hipMemcpyAsync(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_stream(c->stream));
   c->kin_N = N;
   c->have_kin = true;
   if (!c->blas) {
@@ -1314,7 +1370,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
     BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, dx,
                               (rocblas_int)N, &one, c->d_U, (rocblas_int)N, d_xy, (rocblas_int)N, &zero, c->d_uxy,
                               (rocblas_int)N));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
   }
   hipFree(d_xy);
   // |lambda| for the likelihood (FastLMM.cpp:50); the raw S stays in d_S for FamSkat's Sigma
@@ -1335,7 +1391,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
                        (long long)N, d, delta, take_abs, c->d_lmm_part);
     if (hipMemcpyAsync(part.data(), c->d_lmm_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st) !=
             hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
+        sync_stream(st) != hipSuccess)
       hip_failed = true;
     for (int q = 0; q < rec; ++q) {
       double s = 0.0;
@@ -1456,7 +1512,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
     hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xu, d_abs2,
                        (long long)N, d, delta, 1, c->d_lmm_part);
     HIP_TRY(c, hipMemcpyAsync(part.data(), c->d_lmm_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     hipFree(d_xu);
     hipFree(d_abs2);
     for (int q = 0; q < rec; ++q) {
@@ -1482,7 +1538,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
       const int rec1 = lmm_rec_len(1);
       std::vector<double> p1((size_t)kLmmBlocks * rec1);
       HIP_TRY(c, hipMemcpyAsync(p1.data(), c->d_lmm_part, sizeof(double) * p1.size(), hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, sync_stream(st));
       hipFree(d_uy2);
       hipFree(d_abs3);
       double u1Wy = 0.0;
@@ -1516,7 +1572,7 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
     if (!c->d_famcov_nc) HIP_TRY(c, hipMalloc((void**)&c->d_famcov_nc, sizeof(NullConsts)));
     HIP_TRY(c, hipMemcpyAsync(c->d_famcov_nc, &cn, sizeof(NullConsts), hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   c->have_fam = true;
   return RVT_OK;
 }
@@ -1599,7 +1655,7 @@ static int fam_block_run(rvt_ctx* c, const double* dG, int V, CovOut* cop) {
                               (rocblas_int)N, &one, c->d_U, (rocblas_int)N, dG, (rocblas_int)ld, &zero, c->d_Gt,
                               (rocblas_int)ld));
   }
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   return famcov_run(c, c->d_Gt, V, d_cs, d_poly, cop);
 }
 
@@ -1747,7 +1803,7 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
   hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)tot), dim3(256), 0, st, d_cols, (long long)N, d_flags);
   std::vector<int> flags(tot);
   HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * tot, hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   // ---- 2. compact the kept columns (flipped where needed) and rotate them by U' --------------------------------
   std::vector<const double*> kept_cols;
   std::vector<int> kept_flip, Mk(n), off(n);
@@ -1820,7 +1876,7 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
                               (rocblas_int)(T + TB), (rocblas_int)N, &one, c->d_U, (rocblas_int)N, c->d_Gp,
                               (rocblas_int)ld, &zero, c->d_Gt, (rocblas_int)ld));
   }
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   if (burden) {
     // FamCMC / FamZeggini: the 2 nk rotated collapsed columns as blocks of the family covariance machinery
     // (V = cov(h,h), U from the uResid column, AF from the allele-frequency column)
@@ -1967,7 +2023,7 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
     hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xy, d_zero,
                        (long long)N, d, 1.0, 0, d_part);
     HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     reduce(rec);
     double Ai[RVT_MAX_COV * RVT_MAX_COV];
     if (!invert_spd(sums.data(), d, Ai)) return fail(c, RVT_E_INVALID, "X'X is singular");
@@ -1981,7 +2037,7 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
                        (long long)N, (long long)N, d, d_a, d_part);
     HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * kLmmBlocks, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(res.data(), d_a, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     double rss = 0.0;
     for (int b = 0; b < kLmmBlocks; ++b) rss += part[b];
     sigma2 = rss / (double)N;
@@ -1995,7 +2051,7 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       hipLaunchKernelGGL(logistic_round_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xy,
                          d_xy + (size_t)N * d, d_beta, (long long)N, (long long)N, d, d_a, d_b, d_part);
       HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, sync_stream(st));
       reduce(rec);
       double Di[RVT_MAX_COV * RVT_MAX_COV];
       if (!invert_spd(sums.data(), d, Di)) return fail(c, RVT_E_INVALID, "X'VX is singular");
@@ -2090,7 +2146,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
   std::vector<int> flags(M);
   HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   std::vector<const double*> kc;
   std::vector<int> kf;
   for (int j = 0; j < M; ++j)
@@ -2172,7 +2228,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
                        c->d_perm_Q);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(Q.data(), c->d_perm_Q, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, sync_stream(st));
     int used = 0;
     for (; used < nb; ++used) {
       if (actual >= nPerm || numX + numEq >= threshold) {
@@ -2381,7 +2437,7 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, sync_stream(st));
   if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
   return RVT_OK;
 }
@@ -2416,7 +2472,7 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   for (int k = 0; k < ncols; ++k)
     HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
                               hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_stream(c->stream));
   return RVT_OK;
 }
 
@@ -2432,7 +2488,7 @@ bool same_config(const rvt_ctx::Pending& a, const rvt_ctx::Pending& b) {
 // the frequencies into their queue entries
 int resolve_af(rvt_ctx* c) {
   if (c->af_unresolved == 0) return RVT_OK;
-  HIP_TRY(c, hipStreamSynchronize(c->io_stream));
+  HIP_TRY(c, sync_stream(c->io_stream));
   for (auto& p : c->queue)
     if (p.af_slot >= 0) {
       const double* h = c->h_af_ring + (size_t)p.af_slot * RVT_MAX_VARIANTS;
@@ -2640,7 +2696,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     p.af.resize(M);
     if (af_out) {
       if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess) e = sync_stream(st);
     } else if (e == hipSuccess) {
       // nobody waits for the frequencies: the host copy of the block is already consumed (a copy from pageable memory
       // returns once the source has been read), so return now and pick the frequencies up at launch time

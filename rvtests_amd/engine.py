@@ -139,6 +139,8 @@ def load_library():
     L.rvt_sync.argtypes = [vp]
     L.rvt_wait_oldest.restype = C.c_int
     L.rvt_wait_oldest.argtypes = [vp]
+    L.rvt_reserve.restype = C.c_int
+    L.rvt_reserve.argtypes = [vp, C.c_int, c_int_p]
     L.rvt_submit_gene.restype = C.c_int
     L.rvt_submit_gene.argtypes = [vp, C.c_int64, C.c_int, c_double_p, c_double_p, C.c_uint32, C.POINTER(Params)]
     L.rvt_submit_gene_raw.restype = C.c_int
@@ -301,6 +303,11 @@ class Engine:
         out = (GeneResult * n)()
         prm = params or Params.default()
         return dict(n=n, p=arr_p, m=arr_m, af=af, id=arr_id, out=out, prm=prm, tests=int(tests))
+
+    def reserve(self, Ms):
+        """Allocate the workspace of every pipeline slot for batches shaped like Ms up front (rvt_reserve)."""
+        arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
+        self._check(self.L.rvt_reserve(self.ctx, len(arr_m), arr_m.ctypes.data_as(c_int_p)))
 
     def launch(self, batch):
         self._check(self.L.rvt_run_blocks_async(self.ctx, batch["n"], batch["p"], batch["m"].ctypes.data_as(c_int_p),

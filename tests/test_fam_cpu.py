@@ -209,3 +209,24 @@ def test_fam_score_of_a_raw_column_is_the_zeggini_score_of_a_01_column():
     ux = U.T @ X
     want = np.linalg.inv(ux.T @ (ux * (np.abs(S) + nul.delta)[:, None]))
     assert rc == 0 and np.allclose(covb, want, rtol=1e-9)
+
+
+def test_blockwise_numpy_statement_matches_literal_oracle():
+    """The block-wise numpy statement of FamSKAT that the full-size GPU tests (tests/test_gpu_configs.py, N up to
+    100 000) compare against equals the oracle's literal N x N restatement where that can still run."""
+    import test_gpu_configs as t
+    n_fam, d = 60, 3
+    N, u4, s4, X, y, rng = t._family_blocks(n_fam, d, 5)
+    U = t._dense_U(n_fam, u4).astype(np.float64)
+    S = np.tile(s4, n_fam).astype(np.float64)
+    assert np.abs((U * S) @ U.T - np.kron(np.eye(n_fam), t.BLK)).max() < 1e-6
+    rc, nul = orc.fastlmm_null(X, y, U, S)
+    assert rc == 0
+    for M in (25, 3):
+        G = t._gene_dropping(rng, n_fam, M)
+        assert set(np.unique(G)) <= {0.0, 1.0, 2.0}
+        rc, o = orc.famskat(G, X, y, U, S, nul)
+        m, Q, ev = t._famskat_blockwise(G, X, y, u4, s4, nul.delta, nul.sigma2, np.array(nul.beta[:d]))
+        assert rc == 0 and o.n_poly == m and o.n_lambda == len(ev)
+        assert abs(o.Q - Q) <= 1e-10 * Q
+        assert np.allclose(np.array(o.lambda_[:o.n_lambda]), ev, rtol=1e-9, atol=1e-11 * ev[0])
