@@ -269,6 +269,9 @@ def main():
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
     blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi)
     torch.cuda.synchronize()
+    # the blocks are torch allocations: let the engine record once what each one holds (hard calls only, or also
+    # imputed means) — what rvt_block_upload / rvt_submit_gene* do when they write a block themselves
+    n_hard = sum(1 for b, M in zip(blocks, Ms) if eng.classify_block(b.data_ptr(), M))
     # pre-packed batches over the same resident blocks: the engine keeps up to four batches in flight (one HIP
     # stream each), so the latency-bound tail of step i overlaps the bandwidth-bound head of step i+1
     # batches in flight: RVT_MAX_INFLIGHT by default (RVT_BENCH_INFLIGHT lowers it for experiments)
@@ -359,7 +362,8 @@ def main():
                                    "fp64 column-major blocks" % (3 if binary else 2, N, args.genes, args.m_lo,
                                                                  args.m_hi, "binary" if binary else "quantitative"),
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
-                       "parallelism": "gene-sharded x%d" % world, "genes_ok": ok},
+                       "parallelism": "gene-sharded x%d" % world, "genes_ok": ok,
+                       "hard_call_blocks": n_hard},
             "roofline": {"kernel": "gene_suffstat_mfma", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -136,6 +136,7 @@ typedef struct rvt_timing {
   int64_t genes;        /* genes processed while profiling was on              */
   double alg_bytes;     /* algorithmic bytes of those genes: 8*N*M + 8*N*(d+2) each */
   double alg_flops;     /* algorithmic flops: 2*N*M*(M+d+1) each                                 */
+  int64_t genes_hard_call; /* of `genes`: those that took the hard-call (int8 matrix core) kernel        */
 } rvt_timing;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -160,8 +161,21 @@ int rvt_set_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, con
  * fit() is called), N x M doubles, column-major with leading dimension rvt_padded_ld(N), pad = 0. */
 int rvt_block_alloc(rvt_ctx* ctx, int M, double** dG_out);
 int rvt_block_free(rvt_ctx* ctx, double* dG);
-/* copy a host N x M column-major matrix (leading dimension N) into a block */
+/* copy a host N x M column-major matrix (leading dimension N) into a block; the copy is followed by one streaming pass
+ * that records whether the block holds hard calls only (see rvt_block_classify) */
 int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
+/* Hard-call blocks.  When every entry of a block is exactly 0.0, 1.0 or 2.0 (no dosages, no imputed means) and the null
+ * model is unweighted (quantitative trait), G'G is an integer matrix and the engine computes it on the int8 matrix
+ * cores instead of the fp64 ones, with the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h) —
+ * the results are the same numbers (the integer part exactly, G'X and G'r by the same fp64 products), the kernel is
+ * then bound by HBM alone.  What a block holds is recorded when it is written through this ABI (rvt_block_upload,
+ * rvt_submit_gene*: one extra streaming pass, ~0.03 ms per gene at N = 500 000) and forgotten when it is modified or
+ * freed.  For a device allocation the engine did not fill (e.g. a torch tensor handed to rvt_run_blocks)
+ * rvt_block_classify scans it once and records the answer (is_hard_call may be NULL); the CALLER must call it again,
+ * or rvt_block_forget, after changing the block's content or releasing the memory.  Blocks the engine knows nothing
+ * about take the general fp64 kernel. */
+int rvt_block_classify(rvt_ctx* ctx, const double* dG, int M, int* is_hard_call);
+int rvt_block_forget(rvt_ctx* ctx, const double* dG);
 
 /* Run the selected tests on n_genes blocks that are already in HBM.  dG[g] are DEVICE pointers
  * (rvt_block_alloc, or any 128-byte aligned device allocation with the layout above, e.g. a torch

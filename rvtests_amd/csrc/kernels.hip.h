@@ -11,6 +11,7 @@
 #include "rvt_pvalue.h"
 
 #include "suffstat_kernels.hip.h"
+#include "suffstat_hc.hip.h"
 
 namespace rvt {
 
@@ -180,6 +181,102 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 }
 
 // =====================================================================================================
+// Hard-call path (suffstat_hc.hip.h): flags + verification of what the in-pass burden collapse assumed.
+//   flags[0 .. MT)      flip bits per 16-variant block (column sum > N)
+//   flags[MT .. 2 MT)   polymorphic bits
+//   flags[2 MT]         1 = the burden sums of gene_suffstat_hc are NOT valid: a column's flip was predicted wrongly
+//                       (allele frequency vs exact column sum) or a monomorphic column was counted by the collapse
+//                       (all-1 column; all-0 and all-2 columns never count) -> burden_fallback_kernel redoes them
+// =====================================================================================================
+__global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N) {
+  const GeneDesc gd = genes[blockIdx.x];
+  const int tid = threadIdx.x;
+  bool bad = false;
+  for (int base = 0; base < gd.Mp; base += 64) {
+    const int j = base + tid;
+    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    if (j < gd.M) {
+      for (int p = 0; p < gd.n_wparts; ++p) {
+        const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+        s += c[j];
+        mn = fmin(mn, c[gd.Mp + j]);
+        mx = fmax(mx, c[2 * gd.Mp + j]);
+      }
+    }
+    const bool in = j < gd.M;
+    const bool flip = in && !(s <= (double)N);
+    const bool poly = in && !(mn == mx);
+    const bool pred = in && (j >> 4) < 8 && ((gd.pflip[(j >> 4) & 7] >> (j & 15)) & 1);
+    const bool counted_mono = in && !poly && (pred ? mn != 2.0 : mn != 0.0);
+    bad |= (flip != pred) || counted_mono;
+    const unsigned long long bf = __ballot(flip), bp = __ballot(poly);
+    if (tid < 4) {
+      const int b = (base >> 4) + tid;
+      if (b < gd.MT) {
+        gd.flags[b] = (unsigned short)((bf >> (16 * tid)) & 0xffffu);
+        gd.flags[gd.MT + b] = (unsigned short)((bp >> (16 * tid)) & 0xffffu);
+      }
+    }
+  }
+  const bool any = __any(bad);
+  if (tid == 0) gd.flags[2 * gd.MT] = any ? 1 : 0;
+}
+
+// Burden partial sums of a hard-call gene straight from its genotype block with the ACTUAL flags (rare: see above).
+// grid (wave-parts, genes), 256 threads; writes the same records gene_suffstat_hc writes: bparts[part][test][..].
+template <int DMAX>
+__global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __restrict__ genes, NullDev nd,
+                                                              long long N, long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  if (!gd.bparts || gd.flags[2 * gd.MT] == 0) return;
+  const int part = blockIdx.x;
+  if (part >= gd.n_wparts) return;
+  constexpr int NV = 2 * (3 + DMAX);
+  __shared__ double red[4][NV];
+  const int tid = threadIdx.x;
+  const long long s0 = (long long)part * gd.steps_per_wpart * 16;
+  long long s1 = s0 + (long long)gd.steps_per_wpart * 16;
+  if (s1 > N) s1 = N;
+  double val[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) val[k] = 0.0;
+  for (long long i = s0 + tid; i < s1; i += 256) {
+    int n = 0;
+    for (int j = 0; j < gd.M; ++j) {
+      const int b = j >> 4, bit = j & 15;
+      if (!((gd.flags[gd.MT + b] >> bit) & 1)) continue;
+      const double g = gd.G[(long long)j * ld + i];
+      const double gf = ((gd.flags[b] >> bit) & 1) ? 2.0 - g : g;
+      n += ((int)gf > 0) ? 1 : 0;
+    }
+    const double cv[2] = {n > 0 ? 1.0 : 0.0, (double)n};
+    const double r = nd.res[i];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double c = cv[t];
+      val[t * (3 + DMAX) + 0] += c * r;
+      val[t * (3 + DMAX) + 1] += c * c;
+      val[t * (3 + DMAX) + 2] += (c != 0.0) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < DMAX; ++k)
+        if (k < d) val[t * (3 + DMAX) + 3 + k] += c * nd.X[(long long)k * ld + i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {  // fixed-order butterfly inside the wave, then the four waves in order
+    double v = val[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  const int rl = 3 + d;
+  if (tid < 2 * rl) {
+    const int t = tid / rl, k = tid % rl, idx = t * (3 + DMAX) + k;
+    gd.bparts[(long long)part * 2 * rl + tid] = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+  }
+}
+
+// =====================================================================================================
 // K3a: per-gene assembly (reduce partials, flags, flip algebra, projection, weights, Q, tau, burden
 //      statistics), one 256-thread workgroup per gene.
 // K3b: one workgroup per (dense reduction, gene): build the matrix in LDS, Householder tridiagonalisation
@@ -197,7 +294,8 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   gene_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
-                (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, n_bparts, gd.af, prm, tests, ws,
+                (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, gd.n_bparts > 0 ? gd.n_bparts : n_bparts,
+                gd.af, prm, tests, ws,
                 gd.stats, gd.dbg_flip, gd.dbg_kept);
 }
 

@@ -11,6 +11,7 @@
 #include <deque>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <rocblas/rocblas.h>
 #include <cmath>
@@ -26,6 +27,9 @@ void k2_launch_panel_w0(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullD
                         int d);
 void k2_launch_panel_w1(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N, long long ld,
                         int d);
+void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
+                  int d);
+void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
 #include "perm_kernels.hip.h"
@@ -134,7 +138,17 @@ struct rvt_ctx {
   NullConsts nc;
   NullConsts* d_nc = nullptr;
   double *d_X = nullptr, *d_res = nullptr, *d_rr = nullptr, *d_v = nullptr, *d_zeros = nullptr;
+  double* d_nulltile = nullptr;  // ONE allocation [X_0 .. X_{d-1} | rr | zeros]: d_X, d_rr and d_zeros point into it
   int64_t null_ld = 0;
+  // what is known about the CONTENT of device blocks: 1 = every entry is exactly 0.0, 1.0 or 2.0 ("hard calls": the
+  // integer sufficient-statistics kernel applies), 0 = anything else.  Recorded when a block is uploaded through the
+  // ABI (one streaming pass, ~0.03 ms per gene against ~5 ms of PCIe) or registered with rvt_block_classify; erased
+  // when the block is written to or freed.  Unknown pointers take the general fp64 kernel.
+  std::unordered_map<const void*, int> block_kind;
+  int* d_kind = nullptr;      // device flag of the synchronous classification
+  int* d_kind_ring = nullptr; // flags of streaming submissions (kAfSlots), copied back with the allele frequencies
+  int* h_kind_ring = nullptr; // pinned mirror
+  bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
   double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
   bool have_null_beta = false;
   // streaming interface
@@ -149,6 +163,8 @@ struct rvt_ctx {
     rvt_gene_result res;  // filled by the batch this gene was launched in (the queue is a deque: stable addresses)
     bool launched;
     int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
+    int kind = 0;         // 1: hard-call block (see block_kind)
+    int kind_slot = -1;   // >= 0: the classification flag is still on its way back (kind_ring slot)
   };
   std::deque<Pending> queue;
   std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
@@ -356,6 +372,7 @@ void choose_split(int64_t ld, int* n_wparts, int* steps_per) {
   const int64_t nsteps = ld >> 4;
   int64_t spw = (nsteps + 127) / 128;
   if (spw < 64) spw = 64;
+  spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;  // whole ring iterations of the hard-call kernel
   int64_t nw = (nsteps + spw - 1) / spw;
   if (nw < 1) nw = 1;
   *n_wparts = (int)nw;
@@ -463,15 +480,17 @@ int rvt_init(rvt_ctx** out, int device_id) {
     (void)hipGetLastError();
   }
   seed_rand_state(c->rand_state, 1u);
+  if (const char* e = getenv("RVT_HARDCALL")) c->hc_enabled = atoi(e) != 0;
   *out = c;
   return RVT_OK;
 }
 
 static void free_null(rvt_ctx* c) {
-  for (double** p : {&c->d_X, &c->d_res, &c->d_rr, &c->d_v, &c->d_zeros}) {
+  for (double** p : {&c->d_nulltile, &c->d_res, &c->d_v}) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }
+  c->d_X = c->d_rr = c->d_zeros = nullptr;  // inside d_nulltile
   c->have_null = false;
 }
 
@@ -515,6 +534,9 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_af_ring) hipFree(c->d_af_ring);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
+  if (c->d_kind) hipFree(c->d_kind);
+  if (c->d_kind_ring) hipFree(c->d_kind_ring);
+  if (c->h_kind_ring) hipHostFree(c->h_kind_ring);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   if (c->blas) rocblas_destroy_handle(c->blas);
   delete c;
@@ -528,6 +550,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (!c->queue.empty()) return fail(c, RVT_E_STATE, "collect the submitted genes before changing the null model");
   for (auto& bp : c->block_pool) hipFree(bp.second);  // pooled blocks were laid out for the previous N
   c->block_pool.clear();
+  c->block_kind.clear();  // recorded for blocks of the previous N
   free_null(c);
   c->have_null_beta = false;
   const int64_t ld = rvt_padded_ld(N);
@@ -559,16 +582,16 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (!invert_spd(nc.C, d, nc.Cinv)) return fail(c, RVT_E_INVALID, "X'VX is singular");
   // device copies, padded with zeros
   const size_t vb = sizeof(double) * (size_t)ld;
-  HIP_TRY(c, hipMalloc((void**)&c->d_X, vb * d));
+  // [X | rr | zeros] in one allocation: the hard-call kernel reads its null-model tile through one buffer descriptor
+  HIP_TRY(c, hipMalloc((void**)&c->d_nulltile, vb * (d + 2)));
+  c->d_X = c->d_nulltile;
+  c->d_rr = c->d_nulltile + (size_t)ld * d;
+  c->d_zeros = c->d_nulltile + (size_t)ld * (d + 1);
   HIP_TRY(c, hipMalloc((void**)&c->d_res, vb));
-  HIP_TRY(c, hipMalloc((void**)&c->d_rr, vb));
   HIP_TRY(c, hipMalloc((void**)&c->d_v, vb));
-  HIP_TRY(c, hipMalloc((void**)&c->d_zeros, vb));
-  HIP_TRY(c, hipMemset(c->d_X, 0, vb * d));
+  HIP_TRY(c, hipMemset(c->d_nulltile, 0, vb * (d + 2)));
   HIP_TRY(c, hipMemset(c->d_res, 0, vb));
-  HIP_TRY(c, hipMemset(c->d_rr, 0, vb));
   HIP_TRY(c, hipMemset(c->d_v, 0, vb));
-  HIP_TRY(c, hipMemset(c->d_zeros, 0, vb));
   HIP_TRY(c, hipMemcpy2D(c->d_X, vb, X, sizeof(double) * (size_t)N, sizeof(double) * (size_t)N, d,
                          hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_res, res, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
@@ -597,22 +620,66 @@ int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
   return RVT_OK;
 }
 
+// one streaming pass over a block: 1 when every entry is exactly 0.0, 1.0 or 2.0.  Enqueued on `st`; the flag lands
+// in d_flag[0] (set to 1 first).
+static int enqueue_classify(rvt_ctx* c, const double* dG, int M, int64_t N, int64_t ld, hipStream_t st, int* d_flag) {
+  static const int one = 1;
+  HIP_TRY(c, hipMemcpyAsync(d_flag, &one, sizeof(int), hipMemcpyHostToDevice, st));
+  const long long pairs = ((long long)N + 1) / 2 * M;
+  long long blocks = (pairs + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  k2_launch_classify(dim3((unsigned)blocks), st, dG, (long long)N, (long long)ld, M, d_flag);
+  HIP_TRY(c, hipGetLastError());
+  return RVT_OK;
+}
+
+int rvt_block_classify(rvt_ctx* c, const double* dG, int M, int* is_hard_call) {
+  if (!c || !dG || M < 1) return fail(c, RVT_E_INVALID, "bad block");
+  if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first (defines N)");
+  hipSetDevice(c->device);
+  const int64_t N = c->have_null ? c->nc.N : c->fam_nc.N, ld = c->have_null ? c->null_ld : c->fam_nc.ld;
+  if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
+  int rc = enqueue_classify(c, dG, M, N, ld, c->io_stream, c->d_kind);
+  if (rc) return rc;
+  int flag = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_kind, sizeof(int), hipMemcpyDeviceToHost, c->io_stream));
+  HIP_TRY(c, sync_stream(c->io_stream));
+  c->block_kind[dG] = flag ? 1 : 0;
+  if (is_hard_call) *is_hard_call = flag ? 1 : 0;
+  return RVT_OK;
+}
+
+int rvt_block_forget(rvt_ctx* c, const double* dG) {
+  if (!c) return RVT_E_INVALID;
+  c->block_kind.erase(dG);
+  return RVT_OK;
+}
+
 int rvt_block_free(rvt_ctx* c, double* dG) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
+  c->block_kind.erase(dG);
   if (dG) HIP_TRY(c, hipFree(dG));
   return RVT_OK;
 }
 
-int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
+static int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
   if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t bld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  c->block_kind.erase(dG);
   HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * bld, G, sizeof(double) * N, sizeof(double) * N, M,
                          hipMemcpyHostToDevice));
   return RVT_OK;
+}
+
+int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
+  int rc = upload_block_data(c, dG, M, G);
+  if (rc) return rc;
+  return rvt_block_classify(c, dG, M, nullptr);  // content known from now on (see rvt_ctx::block_kind)
 }
 
 int rvt_set_profiling(rvt_ctx* c, int on) {
@@ -719,7 +786,8 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
 struct GeneOff {
   size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, dbg_flip, dbg_kept;
 };
-static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, size_t* total,
+// hc: 1 = hard-call path (no mask planes, burden records per wave-part), 0 = general path, -1 = either (rvt_reserve)
+static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, int hc, size_t* total,
                         GeneOff* o) {
   auto add = [&](size_t bytes) {
     *total = (*total + 255) / 256 * 256;
@@ -730,9 +798,10 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CT;
   o->parts = add(sizeof(double) * (size_t)n_wparts * Mp * Cp);
   o->colstat = add(sizeof(double) * (size_t)n_wparts * 3 * Mp);
-  o->masks = add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
-  o->flags = add(sizeof(unsigned short) * 2 * MT);
-  o->bparts = add(sizeof(double) * (size_t)n_bparts * 2 * (3 + d));
+  o->masks = (hc == 1) ? 0 : add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
+  o->flags = add(sizeof(unsigned short) * (2 * MT + 2));
+  const int nb = (hc == 1) ? n_wparts : (hc == 0 ? n_bparts : std::max(n_bparts, n_wparts));
+  o->bparts = add(sizeof(double) * (size_t)nb * 2 * (3 + d));
   o->scratch = add(sizeof(double) * (gene_scratch_doubles(Mp, Cp) + 8));
   o->lambda = add(sizeof(double) * 2 * M);
   o->qags = add(qags_workspace_bytes(kSkatoLimit));
@@ -788,7 +857,11 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     return o;
   };
   std::vector<GeneOff> offs(n);
-  int maxM = 0;
+  int maxM = 0, n_hc = 0;
+  const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
+                             c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
+  const bool hc_possible = c->hc_enabled && !nc.binary && !cov && !(dbg && dbg->cmc) && d <= kHcMaxD &&
+                           !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
@@ -805,7 +878,19 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.n_wparts = n_wparts;
     gd.steps_per_wpart = steps_per;
     gd.gene_id = ids ? ids[g] : g;
-    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, &total, &offs[g]);
+    // hard-call path: unweighted null model, block known to hold only 0.0 / 1.0 / 2.0, a single-pass tile class
+    gd.hc = 0;
+    if (hc_possible && gd.MT <= kHcMaxMT && (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31)) {
+      auto it = c->block_kind.find(dG[g]);
+      if (it != c->block_kind.end() && it->second == 1) gd.hc = 1;
+    }
+    gd.n_bparts = gd.hc ? n_wparts : n_bparts;
+    if (gd.hc) {
+      n_hc++;
+      for (int j = 0; j < M; ++j)  // predicted flips: column sum > N  <=>  allele frequency > 1/2 (verified on the device)
+        if (af[af_total + j] > 0.5) gd.pflip[j >> 4] |= (unsigned short)(1u << (j & 15));
+    }
+    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc, &total, &offs[g]);
     af_total += M;
   }
   const size_t off_af = add(sizeof(double) * af_total);
@@ -845,7 +930,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     const GeneOff& o = offs[g];
     gd.parts = reinterpret_cast<double*>(base + o.parts);
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
-    gd.masks = reinterpret_cast<unsigned long long*>(base + o.masks);
+    gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
     gd.scratch = reinterpret_cast<double*>(base + o.scratch);
@@ -871,12 +956,15 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   for (int g = 0; g < n; ++g) order[g] = g;
   // genes whose tile configuration has no unrolled body (more than 6 row tiles, or — with many covariates — more than
   // one extra column tile) go to the panelled kernel; they come first
-  auto needs_panel = [&](const GeneDesc& g) { return g.MT > kMaxMT || g.CT > g.MT + 1; };
+  // order: general-path genes first (panelled ones in front), then the hard-call genes; widest first inside each
+  auto needs_panel = [&](const GeneDesc& g) { return !g.hc && (g.MT > kMaxMT || g.CT > g.MT + 1); };
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (desc[a].hc != desc[b].hc) return desc[a].hc < desc[b].hc;
     const bool pa = needs_panel(desc[a]), pb = needs_panel(desc[b]);
     if (pa != pb) return pa;
     return desc[a].M > desc[b].M;
   });
+  const int n_gen = n - n_hc;  // descriptors [0, n_gen) take the general kernels, [n_gen, n) the hard-call kernels
   for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
   GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
   HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, st));
@@ -889,7 +977,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
   int k0 = 0;
-  while (k0 < n && needs_panel(h_desc[k0])) ++k0;  // these need the panelled kernel
+  while (k0 < n_gen && needs_panel(h_desc[k0])) ++k0;  // these need the panelled kernel
   if (k0 > 0) {
     Scope sc(c, 0, c->k2_stream);
     const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;
@@ -901,11 +989,19 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     else
       k2_launch_panel_w0(grid, c->k2_stream, d_desc, nd, (long long)N, (long long)ld, d);
   }
-  for (int k = k0; k < n;) {  // descriptors are sorted by width, so every register-budget group is one contiguous run
+  for (int k = k0; k < n_gen;) {  // descriptors are sorted by width, so every register-budget group is one contiguous run
     const int grp = suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0);
     int e = k;
-    while (e < n && suffstat_group(h_desc[e].MT, h_desc[e].CT, nc.binary != 0) == grp) ++e;
+    while (e < n_gen && suffstat_group(h_desc[e].MT, h_desc[e].CT, nc.binary != 0) == grp) ++e;
     launch_suffstat(c, c->k2_stream, grp, d_desc + k, e - k, n_wparts, nd);
+    k = e;
+  }
+  for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
+    int e = k;
+    while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
+    Scope sc(c, 0, c->k2_stream);
+    k2_launch_hc(h_desc[k].MT, dim3(n_wparts, e - k), c->k2_stream, d_desc + k, NullTile{c->d_nulltile, d + 2},
+                 (long long)N, (long long)ld, d);
     k = e;
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
@@ -976,20 +1072,32 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     // on the batch's own stream: the collapse overlaps the next batch's sufficient-statistics launches, which
     // leave about half of the HBM bandwidth unused
     hipStream_t bs = st;
-    {
-      Scope sc(c, 1, bs);
-      hipLaunchKernelGGL(gene_flags_kernel, dim3(n), dim3(64), 0, bs, d_desc, (long long)N);
-    }
-    // gene groups of <= 64 keep one workgroup's loop short while X/res/v stay in registers; all groups in one launch
-    {
-      const int gpg = 64, ngroups = (n + gpg - 1) / gpg;
+    if (n_gen > 0) {
+      {
+        Scope sc(c, 1, bs);
+        hipLaunchKernelGGL(gene_flags_kernel, dim3(n_gen), dim3(64), 0, bs, d_desc, (long long)N);
+      }
+      // gene groups of <= 64 keep one workgroup's loop short while X/res/v stay in registers; all groups in one launch
+      const int gpg = 64, ngroups = (n_gen + gpg - 1) / gpg;
       Scope sc(c, 1, bs);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts, ngroups), dim3(256), 0, bs, d_desc, n, gpg, nd,
-                           (long long)N, (long long)ld, d, nc.binary, tests);
+        hipLaunchKernelGGL((burden_collapse_kernel<4>), dim3(n_bparts, ngroups), dim3(256), 0, bs, d_desc, n_gen, gpg,
+                           nd, (long long)N, (long long)ld, d, nc.binary, tests);
       else
         hipLaunchKernelGGL((burden_collapse_kernel<RVT_MAX_COV>), dim3(n_bparts, ngroups), dim3(256), 0, bs, d_desc,
-                           n, gpg, nd, (long long)N, (long long)ld, d, nc.binary, tests);
+                           n_gen, gpg, nd, (long long)N, (long long)ld, d, nc.binary, tests);
+    }
+    if (n_hc > 0) {
+      // hard-call genes carry their burden sums already; verify what the in-pass collapse assumed (flip prediction,
+      // no counted monomorphic column) and redo the sums of the rare gene where it does not hold
+      Scope sc(c, 1, bs);
+      hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, bs, d_desc + n_gen, (long long)N);
+      if (d <= 4)
+        hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(n_wparts, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
+                           (long long)N, (long long)ld, d);
+      else
+        hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(n_wparts, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
+                           (long long)N, (long long)ld, d);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
@@ -1032,6 +1140,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   sl.pending_n = n;
   if (c->profiling) {
     c->timing.genes += n;
+    c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
       c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
@@ -1086,7 +1195,7 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   GeneOff o;
   for (int g = 0; g < n; ++g) {
     if (Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, Ms[g]);
-    layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, &total, &o);
+    layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, -1, &total, &o);
     af_total += (size_t)Ms[g];
   }
   total += sizeof(double) * af_total + sizeof(GeneDesc) * n + sizeof(rvt_gene_result) * n + 4 * 256;
@@ -2447,6 +2556,7 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   if (ncols == 0) return RVT_OK;
   hipSetDevice(c->device);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  c->block_kind.erase(dst);
   HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
                        hipMemcpyDeviceToDevice));
   return RVT_OK;
@@ -2458,6 +2568,7 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   hipSetDevice(c->device);
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  c->block_kind.erase(dG);
   HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
                          hipMemcpyHostToDevice));
   return RVT_OK;
@@ -2468,6 +2579,7 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   if (ncols == 0 || dst_col == src_col) return RVT_OK;
   hipSetDevice(c->device);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  c->block_kind.erase(dG);
   // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
   for (int k = 0; k < ncols; ++k)
     HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
@@ -2489,12 +2601,17 @@ bool same_config(const rvt_ctx::Pending& a, const rvt_ctx::Pending& b) {
 int resolve_af(rvt_ctx* c) {
   if (c->af_unresolved == 0) return RVT_OK;
   HIP_TRY(c, sync_stream(c->io_stream));
-  for (auto& p : c->queue)
+  for (auto& p : c->queue) {
     if (p.af_slot >= 0) {
       const double* h = c->h_af_ring + (size_t)p.af_slot * RVT_MAX_VARIANTS;
       p.af.assign(h, h + p.M);
       p.af_slot = -1;
     }
+    if (p.kind_slot >= 0) {
+      p.kind = c->h_kind_ring[p.kind_slot] ? 1 : 0;
+      p.kind_slot = -1;
+    }
+  }
   c->af_unresolved = 0;
   return RVT_OK;
 }
@@ -2515,6 +2632,7 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
     Ms.push_back(p.M);
     ids.push_back(p.id);
     af.insert(af.end(), p.af.begin(), p.af.end());
+    c->block_kind[p.dG] = p.kind;  // (erased again when the block goes back to the pool)
   }
   c->launched.emplace_back();
   rvt_ctx::Launched& L = c->launched.back();
@@ -2562,6 +2680,7 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
         Ms.push_back(c->queue[g].M);
         ids.push_back(c->queue[g].id);
         af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
+        c->block_kind[c->queue[g].dG] = c->queue[g].kind;
       }
       std::vector<rvt_gene_result> res(e - i);
       rc = run_blocks_with_perm(c, (int)(e - i), ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm,
@@ -2614,8 +2733,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   }
   auto give_back = [&]() { c->block_pool.emplace_back(p.bytes, p.dG); };
   const int64_t N = c->nc.N, ld = c->null_ld;
+  c->block_kind.erase(p.dG);
   if (mode == 0) {
-    int rc = rvt_block_upload(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
+    int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
     if (rc) {
       give_back();
       return rc;
@@ -2651,7 +2771,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     if (e != hipSuccess) {
       // fall through to the error return below
     } else if (mode == 1) {
-      int rc = rvt_block_upload(c, p.dG, M, (const double*)G);
+      int rc = upload_block_data(c, p.dG, M, (const double*)G);
       if (rc) {
         give_back();
         return rc;
@@ -2725,6 +2845,30 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     }
     if (af_out) std::memcpy(af_out, p.af.data(), afb);
   }
+  if (c->hc_enabled && !c->nc.binary) {
+    // content of the finished block (hard calls or not), classified on the io stream behind the copy / consolidation;
+    // the flag comes back through a pinned ring and is read when the gene's group is launched
+    hipError_t e = hipSuccess;
+    if (!c->d_kind_ring) {
+      e = hipMalloc((void**)&c->d_kind_ring, sizeof(int) * rvt_ctx::kAfSlots);
+      if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_kind_ring, sizeof(int) * rvt_ctx::kAfSlots, hipHostMallocDefault);
+    }
+    if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
+    if (e == hipSuccess) {
+      const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+      if (enqueue_classify(c, p.dG, M, N, ld, c->io_stream, c->d_kind_ring + slot) != RVT_OK) e = hipErrorUnknown;
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(c->h_kind_ring + slot, c->d_kind_ring + slot, sizeof(int), hipMemcpyDeviceToHost, c->io_stream);
+      if (e == hipSuccess) {
+        p.kind_slot = slot;
+        ++c->af_unresolved;
+      }
+    }
+    if (e != hipSuccess) {
+      give_back();
+      return fail(c, RVT_E_HIP, "block classification failed: %s", hipGetErrorString(e));
+    }
+  }
   p.tests = tests;
   p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   c->queue.push_back(std::move(p));
@@ -2767,6 +2911,7 @@ int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
   }
   for (int g = 0; g < n; ++g) {
     out[g] = c->queue[g].res;
+    c->block_kind.erase(c->queue[g].dG);
     c->block_pool.emplace_back(c->queue[g].bytes, c->queue[g].dG);
   }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);

@@ -44,6 +44,10 @@ struct GeneDesc {
   double* dbg_cmc;       // optional N doubles
   double* dbg_zeg;       // optional N doubles
   long long gene_id;
+  // hard-call path (suffstat_hc.hip.h)
+  unsigned short pflip[8];  // predicted flip bits (af > 0.5) per 16-variant block, first 6 blocks
+  int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
+  int hc;                   // 1: the block holds only 0.0 / 1.0 / 2.0 and went through gene_suffstat_hc
 };
 
 struct NullDev {

@@ -62,7 +62,7 @@ class Timing(C.Structure):
     _fields_ = [("ms_suffstat", C.c_double), ("ms_burden", C.c_double), ("ms_stats", C.c_double),
                 ("ms_pvalue", C.c_double), ("n_suffstat_launches", C.c_int64), ("n_burden_launches", C.c_int64),
                 ("n_stats_launches", C.c_int64), ("n_pvalue_launches", C.c_int64), ("genes", C.c_int64),
-                ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
+                ("alg_bytes", C.c_double), ("alg_flops", C.c_double), ("genes_hard_call", C.c_int64)]
 
 
 def library_path():
@@ -76,9 +76,9 @@ def build_library(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
-    # three objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
+    # four objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-    units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip"]
+    units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip"]
     objs, procs = [], []
     for u in units:
         obj = os.path.join(CSRC, u.replace(".hip", ".o"))
@@ -129,6 +129,10 @@ def load_library():
     L.rvt_block_free.argtypes = [vp, vp]
     L.rvt_block_upload.restype = C.c_int
     L.rvt_block_upload.argtypes = [vp, vp, C.c_int, c_double_p]
+    L.rvt_block_classify.restype = C.c_int
+    L.rvt_block_classify.argtypes = [vp, vp, C.c_int, c_int_p]
+    L.rvt_block_forget.restype = C.c_int
+    L.rvt_block_forget.argtypes = [vp, vp]
     run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
                 C.POINTER(Params), C.POINTER(GeneResult)]
     L.rvt_run_blocks.restype = C.c_int
@@ -274,6 +278,16 @@ class Engine:
         self._check(self.L.rvt_block_upload(self.ctx, p, M, _dp(G)))
         self._blocks.append(p)
         return p.value
+
+    def classify_block(self, ptr, M):
+        """Scan a device block the engine did not fill (e.g. a torch tensor) and record whether it holds hard calls only
+        (rvt_block_classify); returns True / False."""
+        flag = C.c_int(0)
+        self._check(self.L.rvt_block_classify(self.ctx, C.c_void_p(int(ptr)), int(M), C.byref(flag)))
+        return bool(flag.value)
+
+    def forget_block(self, ptr):
+        self._check(self.L.rvt_block_forget(self.ctx, C.c_void_p(int(ptr))))
 
     def free_block(self, ptr):
         self._check(self.L.rvt_block_free(self.ctx, C.c_void_p(ptr)))
