@@ -58,6 +58,11 @@ extern "C" {
 #define RVT_TEST_FAMCMC 32u     /* --burden famcmc    : FamCMC     src/Model.h:2261-2376 (rvt_run_fam_tests only) */
 #define RVT_TEST_FAMZEGGINI 64u /* --burden famzeggini: FamZeggini src/Model.h:2378-2492 (rvt_run_fam_tests only) */
 
+/* Evaluate the coefficient sums of Davies' qf() term by term, in the reference's order (one atan and one log per
+ * coefficient and term, regression/qfc.c:143-152,192-205,250-262), instead of the product form the engine uses by
+ * default (rvtests_amd/csrc/rvt_davies.h: same sums to ~1e-15 absolute, ~8x fewer instructions).  For verification. */
+#define RVT_TEST_EXACT_DAVIES 0x80000000u
+
 /* trait type of the null model */
 #define RVT_TRAIT_QUANTITATIVE 0
 #define RVT_TRAIT_BINARY 1
@@ -128,7 +133,7 @@ typedef struct rvt_fam_null {
 
 /* accumulated device time per kernel family, measured with HIP events on the engine's stream */
 typedef struct rvt_timing {
-  double ms_suffstat;   /* gene_suffstat_mfma (fp64 MFMA contraction + masks)  */
+  double ms_suffstat;   /* gene_suffstat_hc + gene_suffstat_mfma launches      */
   double ms_burden;     /* burden_collapse                                     */
   double ms_stats;      /* gene_stats (flip algebra, eigen, moments)           */
   double ms_pvalue;     /* gene_pvalue (Davies / Liu / QAGS)                   */
@@ -137,6 +142,9 @@ typedef struct rvt_timing {
   double alg_bytes;     /* algorithmic bytes of those genes: 8*N*M + 8*N*(d+2) each */
   double alg_flops;     /* algorithmic flops: 2*N*M*(M+d+1) each                                 */
   int64_t genes_hard_call; /* of `genes`: those that took the hard-call (int8 matrix core) kernel        */
+  double ms_suffstat_hc;   /* of ms_suffstat: the gene_suffstat_hc launches                              */
+  int64_t n_suffstat_hc_launches;
+  double alg_bytes_hc;     /* of alg_bytes: the hard-call genes                                           */
 } rvt_timing;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -20,18 +20,28 @@ double hc_chisq_Qinv(double q, double nu) { return chisq_quantile_Q(q, nu); }
 double hc_chisq_pdf(double x, double nu) { return chisq_density(x, nu); }
 double hc_beta_pdf(double x, double a, double b) { return beta_density(x, a, b); }
 
+// term-by-term evaluation in the reference's order (bit-identical to qfc.c)
 double hc_davies_pvalue(const double* lam, int n, double Q, int* fault, double* nterms) {
   std::vector<int> th(n > 0 ? n : 1);
   davies_order(lam, n, th.data());
-  return davies_pvalue(lam, th.data(), n, Q, fault, nterms);
+  return davies_pvalue(lam, th.data(), n, Q, fault, nterms, nullptr, false);
 }
 // same, replaying the c-independent searches from davies_prelude() (what the SKAT-O integrand does)
 double hc_davies_pvalue_cached(const double* lam, int n, double Q, int* fault, double* nterms) {
   std::vector<int> th(n > 0 ? n : 1);
   davies_order(lam, n, th.data());
   DaviesPrelude pre;
-  davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre);
-  return davies_pvalue(lam, th.data(), n, Q, fault, nterms, &pre);
+  davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre, false);
+  return davies_pvalue(lam, th.data(), n, Q, fault, nterms, &pre, false);
+}
+// product form of the coefficient sums (the engine's default), with or without the cached searches
+double hc_davies_pvalue_fast(const double* lam, int n, double Q, int cached, int* fault, double* nterms) {
+  std::vector<int> th(n > 0 ? n : 1);
+  davies_order(lam, n, th.data());
+  if (!cached) return davies_pvalue(lam, th.data(), n, Q, fault, nterms, nullptr, true);
+  DaviesPrelude pre;
+  davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre, true);
+  return davies_pvalue(lam, th.data(), n, Q, fault, nterms, &pre, true);
 }
 double hc_liu_pvalue(const double* lam, int n, double Q) { return liu_pvalue(lam, n, Q); }
 

@@ -223,17 +223,19 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
 }
 
 // Burden partial sums of a hard-call gene straight from its genotype block with the ACTUAL flags (rare: see above).
-// grid (wave-parts, genes), 256 threads; writes the same records gene_suffstat_hc writes: bparts[part][test][..].
+// grid (kFallbackSplit, genes), 256 threads: almost every workgroup leaves at once (flag clear), so the grid is kept
+// small; a flagged gene's wave-parts are dealt to its kFallbackSplit workgroups.  Writes the same records
+// gene_suffstat_hc writes: bparts[part][test][..].
+constexpr int kFallbackSplit = 8;
 template <int DMAX>
 __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __restrict__ genes, NullDev nd,
                                                               long long N, long long ld, int d) {
   const GeneDesc gd = genes[blockIdx.y];
   if (!gd.bparts || gd.flags[2 * gd.MT] == 0) return;
-  const int part = blockIdx.x;
-  if (part >= gd.n_wparts) return;
   constexpr int NV = 2 * (3 + DMAX);
   __shared__ double red[4][NV];
   const int tid = threadIdx.x;
+  for (int part = blockIdx.x; part < gd.n_wparts; part += gridDim.x) {
   const long long s0 = (long long)part * gd.steps_per_wpart * 16;
   long long s1 = s0 + (long long)gd.steps_per_wpart * 16;
   if (s1 > N) s1 = N;
@@ -273,6 +275,8 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
   if (tid < 2 * rl) {
     const int t = tid / rl, k = tid % rl, idx = t * (3 + DMAX) + k;
     gd.bparts[(long long)part * 2 * rl + tid] = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+  }
+  __syncthreads();
   }
 }
 
@@ -591,9 +595,19 @@ __device__ __forceinline__ WaveDaviesLds wave_davies_lds_carve(char* mem) {
 // MixtureChiSquare::getPvalue for one point per lane (regression/MixtureChiSquare.cpp:7-29), cooperative
 // main integration.  Every lane of the wave must call it; `active` says whether the lane has a point.
 // lbs/ths/rs: the (at most two) coefficient sets in LDS; `which` selects the lane's set.
-__device__ double wave_davies_pvalue(bool active, int which, const double* const* lbs, const int* const* ths,
-                                     const int* rs, double c, const DaviesPrelude* pre, int lane,
-                                     const WaveDaviesLds& L, double* nterms) {
+#ifdef RVT_PROF_K4
+#define RVT_K4_TICK(slot, t0) do { if (prof4) prof4[slot] += (double)(clock64() - (t0)); } while (0)
+#else
+#define RVT_K4_TICK(slot, t0) do { } while (0)
+#endif
+template <bool FAST>
+__device__ __forceinline__ double wave_davies_pvalue(bool active, int which, const double* const* lbs,
+                                                     const int* const* ths, const int* rs, double c,
+                                                     const DaviesPrelude* pre, int lane, const WaveDaviesLds& L,
+                                                     double* nterms, double* prof4 = nullptr) {
+#ifdef RVT_PROF_K4
+  const long long tq0 = clock64();
+#endif
   DaviesTask task;
   task.need_main = false;
   task.fault = 0;
@@ -614,10 +628,14 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
       pdirect = 1.0;  // see davies_pvalue(): qf() = 0 or a fault, both replaced by Liu at every call site
     } else {
       direct = false;
-      davies_qf_front(lb, ths[which], r, c, 10000, 0.000001, pre, &task);
+      davies_qf_front_t<FAST>(lb, ths[which], r, c, 10000, 0.000001, pre, &task);
     }
   }
 
+  RVT_K4_TICK(0, tq0);  // front (per-lane searches)
+#ifdef RVT_PROF_K4
+  const long long tq1 = clock64();
+#endif
   const bool need = active && !direct && task.need_main;
   L.nt1[lane] = need ? task.nt + 1 : 0;
   L.which[lane] = which;
@@ -647,7 +665,7 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
       const int k = (L.nt1[p] - 1) - (idx - L.off[p]);
       const int w = L.which[p];
       double t1, t2;
-      davies_term(lbs[w], rs[w], L.c[p], L.sig[p], L.intv[p], k, &t1, &t2);
+      davies_term_t<FAST>(lbs[w], rs[w], L.c[p], L.sig[p], L.intv[p], k, &t1, &t2);
       L.v1[idx - cs] = t1;
       L.v2[idx - cs] = t2;
     }
@@ -661,6 +679,7 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
     }
     __syncthreads();
   }
+  RVT_K4_TICK(1, tq1);  // flattened main integration
   if (!active) return 0.0;
   if (direct) return pdirect;
   if (need) task.nterms += task.nt + 1;
@@ -672,12 +691,58 @@ __device__ double wave_davies_pvalue(bool active, int which, const double* const
   return p;
 }
 
-__global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes, unsigned tests) {
+// Per-gene state of the p-value kernel that every lane reads (or lane 0 updates): in LDS, so that nothing of it is
+// replicated per lane in registers / scratch memory (the kernel used to carry 2.5 KB of scratch per lane, i.e. global
+// memory round trips inside the sequential QAGS bookkeeping and the per-abscissa integrand set-up).
+constexpr int kQagsLds = 96;  // QAGS intervals kept in LDS; a store that outgrows it moves to the global workspace
+struct PvShared {
+  GeneStats gs;
+  SkatoIntegrand si;
+  DaviesPrelude pre;
+  LiuPre liu;
+  QagsMachine qm;
+  double pvals[kNRho];
+  double ctl[4];  // a1, b1, b2, running
+  double alist[kQagsLds], blist[kQagsLds], rlist[kQagsLds], elist[kQagsLds];
+  int order[kQagsLds], level[kQagsLds];
+};
+
+// indices of lb by decreasing |lb| (stable) — davies_order() as a rank computation, one element per lane
+__device__ __forceinline__ void wave_davies_order(const double* lb, int r, int* th, int lane) {
+  for (int j = lane; j < r; j += 64) {
+    const double lj = fabs(lb[j]);
+    int rank = 0;
+    for (int k = 0; k < r; ++k) {
+      const double lk = fabs(lb[k]);
+      rank += (lk > lj || (lk == lj && k < j)) ? 1 : 0;
+    }
+    th[rank] = j;
+  }
+}
+
+// FAST = true: product form of Davies' coefficient sums (rvt_davies.h) — every gene whose retained eigenvalues are all
+// positive, i.e. every gene of the hot path; FAST = false: the term-by-term form (RVT_TEST_EXACT_DAVIES, or a
+// coefficient that is not positive).  Both kernels are launched over the batch; each gene is processed by exactly one.
+#ifndef RVT_PV_WAVES
+#define RVT_PV_WAVES 2  // waves per SIMD the product-form kernel is compiled for
+#endif
+template <bool FAST>
+__global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kernel(const GeneDesc* __restrict__ genes,
+                                                                       unsigned tests) {
+#ifdef RVT_PROF_K4
+  const long long tk_entry = clock64();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double ctl[4];  // a1, b1, b2, running / result, status
-  const GeneDesc gd = genes[blockIdx.x];
-  const GeneStats gs = *gd.stats;
+  __shared__ PvShared sh;
+  const GeneDesc& gd = genes[blockIdx.x];
   const int lane = threadIdx.x;
+  {  // GeneStats -> LDS
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(gd.stats);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sh.gs);
+    for (int i = lane; i < (int)(sizeof(GeneStats) / 8); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const GeneStats& gs = sh.gs;
   const int M = gd.M;
   double* lam_skat = reinterpret_cast<double*>(smem);
   double* lam_zimz = lam_skat + M;
@@ -685,69 +750,85 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
   int* th_zimz = th_skat + M;
   double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
   const WaveDaviesLds L = wave_davies_lds_carve(reinterpret_cast<char*>(fv + 42));
-  rvt_gene_result res;
-  pvalue_init_result(gs, gd.gene_id, &res);
-  if (gs.n_poly == 0) {
-    if (lane == 0) *gd.result = res;
-    return;
-  }
-  for (int i = lane; i < gs.skat_nlambda; i += 64) lam_skat[i] = gd.lambda[gs.skat_lambda_off + i];
-  for (int i = lane; i < gs.zimz_nlambda; i += 64) lam_zimz[i] = gd.lambda[gs.zimz_lambda_off + i];
+  rvt_gene_result* const out = gd.result;
+  const int n_skat = gs.skat_nlambda, n_zimz = gs.zimz_nlambda;
+  for (int i = lane; i < n_skat; i += 64) lam_skat[i] = gd.lambda[gs.skat_lambda_off + i];
+  for (int i = lane; i < n_zimz; i += 64) lam_zimz[i] = gd.lambda[gs.zimz_lambda_off + i];
   __syncthreads();
-  if (lane == 0) davies_order(lam_skat, gs.skat_nlambda, th_skat);
-  if (lane == 1) davies_order(lam_zimz, gs.zimz_nlambda, th_zimz);
+  {  // which of the two kernels owns this gene
+    const bool positive = davies_all_positive(lam_zimz, n_zimz) && davies_all_positive(lam_skat, n_skat);
+    const bool want_fast = positive && !(tests & RVT_TEST_EXACT_DAVIES);
+    if (want_fast != FAST) return;
+  }
+  if (lane == 0) pvalue_init_result(gs, gd.gene_id, out);
+  if (gs.n_poly == 0) return;
+  wave_davies_order(lam_skat, n_skat, th_skat, lane);
+  wave_davies_order(lam_zimz, n_zimz, th_zimz, lane);
   __syncthreads();
   const double* lbs[2] = {lam_zimz, lam_skat};
   const int* ths[2] = {th_zimz, th_skat};
-  const int rs[2] = {gs.zimz_nlambda, gs.skat_nlambda};
+  const int rs[2] = {n_zimz, n_skat};
   double terms = 0.0;
   const bool fam = (tests & RVT_TEST_FAMSKAT) != 0;  // FamSkat.cpp:118: Davies only, result in the famskat fields
   const bool do_skat = (tests & (RVT_TEST_SKAT | RVT_TEST_FAMSKAT)) != 0;
   const bool do_skato = (tests & RVT_TEST_SKATO) && skato_fit_ok(gs);
+  const bool skato_quad = do_skato && !gs.skato_single;
   // ---- per-rho tails (lanes 0..10), burden tails (lanes 60, 61) ------------------------------------------
   double pv_rho = 1.0;
   SkatoMoment mo;
   mo.muQ = mo.varQ = mo.df = 1.0;
-  if (lane < kNRho && do_skato && !gs.skato_single) {
+  if (lane < kNRho && skato_quad) {
     mo.muQ = gs.mom_mu[lane];
     mo.varQ = gs.mom_var[lane];
     mo.df = gs.mom_df[lane];
     pv_rho = skato_p_by_moment(gs.Qs[lane], mo);
+    sh.pvals[lane] = pv_rho;
   } else if (lane == 61 && (tests & RVT_TEST_CMC) && gs.cmc_ok) {
     pv_rho = chisq_Q(gs.cmc_stat, 1.0);
   } else if (lane == 60 && (tests & RVT_TEST_ZEGGINI) && gs.zeg_ok) {
     pv_rho = chisq_Q(gs.zeg_stat, 1.0);
   }
-  res.cmc_p = __shfl(pv_rho, 61, 64);
-  res.zeg_p = __shfl(pv_rho, 60, 64);
-  if (!((tests & RVT_TEST_CMC) && gs.cmc_ok)) res.cmc_p = 0.0;
-  if (!((tests & RVT_TEST_ZEGGINI) && gs.zeg_ok)) res.zeg_p = 0.0;
+  const double cmc_p = __shfl(pv_rho, 61, 64), zeg_p = __shfl(pv_rho, 60, 64);
+  __syncthreads();
   // ---- SKAT-O preparation -------------------------------------------------------------------------------
-  double pvals[kNRho], qminp[kNRho], minP = 1.0;
+  double minP = 1.0;
   int minIndex = 0;
-  SkatoIntegrand si;
-  DaviesPrelude pre;
-  pre.valid = false;
-  LiuPre liu_zimz;
-  const bool skato_quad = do_skato && !gs.skato_single;
   if (skato_quad) {
-#pragma unroll
-    for (int i = 0; i < kNRho; ++i) pvals[i] = __shfl(pv_rho, i, 64);
-    skato_select(gs, pvals, &minP, &minIndex);
-    double qm_l = 0.0;
-    if (lane < kNRho) qm_l = skato_q_by_moment(minP, mo);
-#pragma unroll
-    for (int i = 0; i < kNRho; ++i) qminp[i] = __shfl(qm_l, i, 64);
-    skato_fill_integrand(gs, qminp, lam_zimz, th_zimz, &si);
-    davies_prelude(lam_zimz, th_zimz, gs.zimz_nlambda, 10000, 0.000001, &pre);  // same values in every lane
-    si.pre = &pre;
-    liu_zimz = liu_prepare(lam_zimz, gs.zimz_nlambda);
-    si.liu = &liu_zimz;
+    skato_select(gs, sh.pvals, &minP, &minIndex);  // (every lane: 11 LDS reads)
+    if (lane < kNRho) {
+      const double r0 = 1.0 * lane / 10;
+      sh.si.rho[lane] = (r0 > 0.999) ? 0.999 : r0;
+      sh.si.qminp[lane] = skato_q_by_moment(minP, mo);
+      sh.si.tau[lane] = gs.tau[lane];
+    }
+    if (lane == 11) {
+      sh.si.muQ = gs.muQ;
+      sh.si.varQ = gs.varQ;
+      sh.si.varZeta = gs.varZeta;
+      sh.si.df = gs.df;
+      sh.si.lambda = lam_zimz;
+      sh.si.th = th_zimz;
+      sh.si.r = n_zimz;
+      sh.si.lambda_sum = gs.zimz_lambda_sum;
+      sh.si.pre = &sh.pre;
+      sh.si.liu = &sh.liu;
+      sh.si.lg_half = lgamma(0.5);
+    }
+    if (lane == 12) davies_prelude_t<FAST>(lam_zimz, th_zimz, n_zimz, 10000, 0.000001, &sh.pre);
+    if (lane == 13) sh.liu = liu_prepare(lam_zimz, n_zimz);
+  } else if (lane == 12) {
+    sh.pre.valid = false;
+    sh.pre.fast = FAST;
   }
+  __syncthreads();
+  const SkatoIntegrand& si = sh.si;
   // One cooperative Davies round evaluates: the quadrature abscissae of this step (lanes < npts), and — in
   // the first round only — SKAT's own Q (lane 62) and the single-variant SKAT-O Q (lane 63).
 #ifdef RVT_PROF_K4
   double prof[4] = {0, 0, 0, 0};
+  double prof4[4] = {0, 0, 0, 0};   // front, main, QAGS bookkeeping (lane 0)
+#else
+  double* prof4 = nullptr;
 #endif
   auto davies_round = [&](int npts, double a1, double b1, double b2, bool first, int pass, double* extra62,
                           double* extra63) {
@@ -766,7 +847,7 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
         } else {
           c = (kappa - si.muQ) * sqrt(si.varQ - si.varZeta) / sqrt(si.varQ) + si.muQ;
           active = true;
-          pp = &pre;
+          pp = &sh.pre;
         }
       }
     } else if (first && lane == 62 && do_skat) {
@@ -783,7 +864,7 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
 #ifdef RVT_PROF_K4
     const long long tk0 = clock64();
 #endif
-    if (pass == 0 || first) p = wave_davies_pvalue(active, which, lbs, ths, rs, c, pp, lane, L, &nt);
+    if (pass == 0 || first) p = wave_davies_pvalue<FAST>(active, which, lbs, ths, rs, c, pp, lane, L, &nt, prof4);
     terms += nt;
 #ifdef RVT_PROF_K4
     const long long tk1 = clock64();
@@ -793,7 +874,7 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
       double val;
       if (pass == 0) {
         double temp = skip_zero ? 0.0 : p;
-        if (!skip_zero && (temp <= 0.0 || temp == 1.0)) temp = liu_pvalue_pre(liu_zimz, c);
+        if (!skip_zero && (temp <= 0.0 || temp == 1.0)) temp = liu_pvalue_pre(sh.liu, c);
         val = (1.0 - temp) * chisq_density_lg(x, 1.0, si.lg_half);
       } else {
         val = skato_integrand_liu(si, x);
@@ -801,7 +882,7 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
       fv[lane] = val;
     }
     if (first && lane == 62 && do_skat) {
-      if (!fam && (p <= 0.0 || p == 1.0)) p = liu_pvalue(lam_skat, gs.skat_nlambda, gs.skat_Q);  // Skat.cpp:100-103
+      if (!fam && (p <= 0.0 || p == 1.0)) p = liu_pvalue(lam_skat, n_skat, gs.skat_Q);  // Skat.cpp:100-103
       *extra62 = p;
     }
     if (first && lane == 63 && do_skato && gs.skato_single) *extra63 = p;
@@ -811,16 +892,24 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
     __syncthreads();
   };
   double skat_p = 0.0, single_p = 0.0;
-  int neval = 0, status = 0;
+  int neval = 0, status = 0, status0 = 0;
 #ifdef RVT_PROF_K4
   const long long tk_start = clock64();
 #endif
   double integral = 0.0;
-  QagsWorkspace ws = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
+  QagsMachine& qm = sh.qm;  // driven by lane 0; the wave-uniform control words sit in sh.ctl
+  double* const ctl = sh.ctl;
   for (int pass = 0; pass < 2; ++pass) {
-    QagsMachine qm;  // lives in lane 0; the wave-uniform control words go through LDS
+    bool in_lds = true;  // (lane 0) the interval store still fits the LDS arrays
     if (lane == 0) {
       if (skato_quad) {
+        QagsWorkspace ws;
+        ws.alist = sh.alist;
+        ws.blist = sh.blist;
+        ws.rlist = sh.rlist;
+        ws.elist = sh.elist;
+        ws.order = sh.order;
+        ws.level = sh.level;
         qm.begin(0., 40., kSkatoEpsAbs, kSkatoEpsRel, kSkatoLimit, ws);
         ctl[3] = qm.running() ? 1.0 : 0.0;
       } else {
@@ -846,9 +935,27 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
       davies_round(42, a1, b1, b2, false, pass, &skat_p, &single_p);
       neval += 42;
       if (lane == 0) {
+#ifdef RVT_PROF_K4
+        const long long tb0 = clock64();
+#endif
+        if (in_lds && qm.size + 2 >= kQagsLds) {  // the store outgrows LDS: continue in the global workspace
+          QagsWorkspace gw = qags_workspace_carve(gd.qags_mem, kSkatoLimit);
+          for (int i = 0; i < qm.size; ++i) {
+            gw.alist[i] = sh.alist[i];
+            gw.blist[i] = sh.blist[i];
+            gw.rlist[i] = sh.rlist[i];
+            gw.elist[i] = sh.elist[i];
+            gw.order[i] = sh.order[i];
+            gw.level[i] = sh.level[i];
+          }
+          gw.order[qm.size] = sh.order[qm.size];  // (sort_after_insert may read one slot past the end)
+          qm.w = gw;
+          in_lds = false;
+        }
         qm.advance(fv, fv + 21);
         ctl[3] = qm.running() ? 1.0 : 0.0;
         if (qm.running()) qm.bisect(&ctl[0], &ctl[1], &ctl[2]);
+        RVT_K4_TICK(2, tb0);
       }
       __syncthreads();
       running = ctl[3] != 0.0;
@@ -864,50 +971,55 @@ __global__ __launch_bounds__(64, 2) void gene_pvalue_kernel(const GeneDesc* __re
     status = (int)ctl[1];
     __syncthreads();
     if (pass == 0) {
-      res.skato_qags_status = status;
+      status0 = status;
       if (status == 0) break;
     } else {
-      res.skato_qags_status = res.skato_qags_status * 100 + status;
+      status0 = status0 * 100 + status;
     }
   }
   skat_p = __shfl(skat_p, 62, 64);
   single_p = __shfl(single_p, 63, 64);
-  if (do_skat && fam) {
-    res.famskat_ok = 1;
-    res.famskat_Q = gs.skat_Q;
-    res.famskat_p = skat_p;
-    res.skat_nlambda = gs.skat_nlambda;
-  } else if (do_skat) {
-    res.skat_ok = 1;
-    res.skat_Q = gs.skat_Q;
-    res.skat_p = skat_p;
-  }
-  if (do_skato && gs.skato_single) {
-    res.skato_ok = 1;
-    res.skato_Q = gs.Qs[0];
-    res.skato_rho = 0.0;
-    res.skato_p = single_p;
-  } else if (do_skato) {
-    res.skato_qags_neval = neval;
-    double rho = (minIndex == 10) ? 0.999 : 1.0 * minIndex / 10;
-    if (rho >= 0.999) rho = 1.;
-    res.skato_rho = rho;
-    res.skato_Q = gs.Qs[minIndex];
-    res.skato_p = skato_finish(integral, minP, pvals);
-    res.skato_ok = 1;
-  }
   // total Davies terms over the wave
   for (int off = 32; off > 0; off >>= 1) terms += __shfl_down(terms, off, 64);
-  if (lane == 0) {
-    res.davies_terms = terms;
-#ifdef RVT_PROF_K4
-    res.cmc_U = prof[0];                              // cycles inside wave_davies_pvalue
-    res.cmc_V = prof[1];                              // cycles in Liu fallback + density + fv store
-    res.zeg_U = (double)(clock64() - tk_start);       // cycles from QAGS start to end
-    res.zeg_V = (double)neval;
-#endif
-    *gd.result = res;
+  if (lane != 0) return;
+  if ((tests & RVT_TEST_CMC) && gs.cmc_ok) out->cmc_p = cmc_p;
+  if ((tests & RVT_TEST_ZEGGINI) && gs.zeg_ok) out->zeg_p = zeg_p;
+  if (do_skat && fam) {
+    out->famskat_ok = 1;
+    out->famskat_Q = gs.skat_Q;
+    out->famskat_p = skat_p;
+    out->skat_nlambda = gs.skat_nlambda;
+  } else if (do_skat) {
+    out->skat_ok = 1;
+    out->skat_Q = gs.skat_Q;
+    out->skat_p = skat_p;
   }
+  if (do_skato && gs.skato_single) {
+    out->skato_ok = 1;
+    out->skato_Q = gs.Qs[0];
+    out->skato_rho = 0.0;
+    out->skato_p = single_p;
+  } else if (do_skato) {
+    out->skato_qags_status = status0;
+    out->skato_qags_neval = neval;
+    double rho = (minIndex == 10) ? 0.999 : 1.0 * minIndex / 10;
+    if (rho >= 0.999) rho = 1.;
+    out->skato_rho = rho;
+    out->skato_Q = gs.Qs[minIndex];
+    out->skato_p = skato_finish(integral, minP, sh.pvals);
+    out->skato_ok = 1;
+  }
+  out->davies_terms = terms;
+#ifdef RVT_PROF_K4
+  out->cmc_U = prof[0];                              // cycles inside wave_davies_pvalue
+  out->cmc_V = prof[1];                              // cycles in Liu fallback + density + fv store
+  out->zeg_U = (double)(clock64() - tk_start);       // cycles from QAGS start to end
+  out->zeg_V = (double)neval;
+  out->famcmc_U = prof4[0];                          // front
+  out->famcmc_V = prof4[1];                          // flattened main integration
+  out->famzeg_U = prof4[2];                          // lane-0 QAGS bookkeeping
+  out->famzeg_V = (double)(tk_start - tk_entry);     // before the QAGS loop (loads, order, prelude, moments)
+#endif
 }
 
 }  // namespace rvt

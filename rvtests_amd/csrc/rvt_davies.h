@@ -18,6 +18,15 @@
 #pragma once
 #include "rvt_special.h"
 
+// The search routines below are force-inlined into their callers and specialised on the form of the coefficient sums
+// (template parameter FAST), so that DaviesState lives in registers and the p-value kernel that uses the product
+// form carries none of the term-by-term code.
+#if defined(__HIPCC__)
+#define RVT_HDI __host__ __device__ __forceinline__
+#else
+#define RVT_HDI inline __attribute__((always_inline))
+#endif
+
 namespace rvt {
 
 struct DaviesState {
@@ -36,6 +45,62 @@ constexpr double kDaviesPi = 3.14159265358979;  // value used by the reference (
 constexpr double kDaviesLog28 = .0866;          // qfc.c:23
 
 RVT_HD double dv_exp1(double x) { return x < -50.0 ? 0.0 : exp(x); }
+
+// ---- product form of the coefficient sums -------------------------------------------------------------------------
+// Every O(r) loop of qf() is a sum of logarithms and arc tangents over the coefficients:
+//   integrate():  sum_j atan(x_j),  sum_j log(1 + x_j^2)            x_j = 2 lb_j u           (qfc.c:250-262)
+//   errbd():      sum_j [log(1 - x_j) + x_j],  sum_j lb_j / (1 - x_j), sum_j x_j^2 / (1 - x_j)   (qfc.c:143-152)
+//   truncation(): sum_j log(1 + x_j), sum_j log(x_j)                 x_j = (u lb_j)^2         (qfc.c:192-205)
+// i.e. the argument and the log-modulus of prod_j (1 + i x_j), and the logs of three real products.  With all
+// coefficients positive (the hot path: Skat.cpp:92 keeps lambda > 1e-30, SkatO.cpp:365-374 lambda >= mean / 1e5) the
+// products are formed by two FMAs (complex) or one multiplication (real) per coefficient, with the binary exponent
+// carried separately, and ONE atan2 / log is taken per sum instead of one atan + one log (83 + 98 fp64 instructions in
+// the device library) per coefficient: the p-value stage costs ~8x fewer instructions.  The products carry a relative
+// error of ~r ulp, the same size as the accumulated rounding of the term-by-term sums, so results move by ~1e-15
+// absolute — the level at which ocml's and glibc's atan / log already differ.  The term-by-term form stays
+// available (DaviesState::fast = false; RVT_TEST_EXACT_DAVIES at the ABI) and is used whenever a coefficient is not
+// positive.
+constexpr double kLn2 = 0.693147180559945309417232121458;
+constexpr double kTwoPiHi = 6.283185307179586232;        // 2 pi rounded to double
+constexpr double kTwoPiLo = 2.4492935982947064e-16;      // 2 pi - kTwoPiHi
+
+struct ScaledProd {  // value = m * 2^e
+  double m;
+  int e;
+};
+RVT_HD void sp_renorm(ScaledProd& p) {
+  int k;
+  p.m = frexp(p.m, &k);
+  p.e += k;
+}
+RVT_HD double sp_log(ScaledProd p) {  // log(m 2^e), m > 0
+  sp_renorm(p);
+  return log(p.m) + (double)p.e * kLn2;
+}
+
+// sum_j atan(x_j) and sum_j log(1 + x_j^2) for x_j = lb_j * u2, lb_j > 0, u2 > 0
+RVT_HDI void dv_arg_logmod(const double* lb, int r, double u2, double* sum_atan, double* sum_log1p_sq) {
+  double a = 1.0, b = 0.0;  // prod (1 + i x_j) / 2^E
+  int E = 0, wraps = 0;     // the argument grows monotonically (every factor turns by less than pi / 2): count the
+                            // crossings of the negative real axis
+  for (int j = r - 1; j >= 0; --j) {
+    const double x = lb[j] * u2;
+    const double na = fma(-b, x, a), nb = fma(a, x, b);
+    wraps += (b >= 0.0 && nb < 0.0) ? 1 : 0;
+    a = na;
+    b = nb;
+    if ((j & 3) == 0) {
+      int k;
+      (void)frexp(fmax(fabs(a), fabs(b)), &k);
+      a = ldexp(a, -k);
+      b = ldexp(b, -k);
+      E += k;
+    }
+  }
+  const double w = (double)wraps;
+  *sum_atan = (atan2(b, a) + w * kTwoPiHi) + w * kTwoPiLo;
+  *sum_log1p_sq = log(fma(a, a, b * b)) + (double)(2 * E) * kLn2;
+}
 
 // log(1+x) if first, else log(1+x) - x      (qfc.c:95-113)
 RVT_HD double dv_log1(double x, bool first) {
@@ -73,13 +138,14 @@ RVT_HD void dv_log1_x4(const double (&x)[4], int cnt, bool first, double (&out)[
   }
 }
 
-RVT_HD void dv_tick(DaviesState& st) {
+RVT_HDI void dv_tick(DaviesState& st) {
   st.count = st.count + 1;
   if (st.count > st.lim) st.over = true;
 }
 
 // bound on the tail probability from the mgf; cutoff returned in *cx      (qfc.c:137-155)
-RVT_HD double dv_errbd(DaviesState& st, double u, double* cx) {
+template <bool FAST>
+RVT_HDI double dv_errbd(DaviesState& st, double u, double* cx) {
   dv_tick(st);
   if (st.over) {
     *cx = 0.0;
@@ -87,6 +153,22 @@ RVT_HD double dv_errbd(DaviesState& st, double u, double* cx) {
   }
   double xconst = u * st.sigsq, sum1 = u * xconst;
   u = 2.0 * u;
+  if (FAST) {
+    // sum_j [x^2 / y + log(y) + x] with y = 1 - x in (0, 1]: one reciprocal per coefficient, log of the product
+    ScaledProd py{1.0, 0};
+    double sx = 0.0, sq = 0.0;
+    for (int j = st.r - 1; j >= 0; --j) {
+      const double lj = st.lb[j], x = u * lj, y = 1.0 - x, ry = 1.0 / y;
+      xconst = fma(lj, ry, xconst);
+      sq = fma(x * x, ry, sq);
+      sx += x;
+      py.m *= y;
+      if ((j & 7) == 0) sp_renorm(py);
+    }
+    sum1 = sum1 + (sq + (sp_log(py) + sx));
+    *cx = xconst;
+    return dv_exp1(-0.5 * sum1);
+  }
   for (int j0 = st.r - 1; j0 >= 0; j0 -= 4) {  // elements evaluated 4 at a time, accumulated in the reference's order
     const int cnt = (j0 >= 3) ? 4 : j0 + 1;
     double lj[4], x[4], y[4], mx[4], lg[4];
@@ -111,20 +193,21 @@ RVT_HD double dv_errbd(DaviesState& st, double u, double* cx) {
 }
 
 // find ctff so that p(qf > ctff) < accx (upn > 0) or p(qf < ctff) < accx      (qfc.c:157-178)
-RVT_HD double dv_ctff(DaviesState& st, double accx, double* upn) {
+template <bool FAST>
+RVT_HDI double dv_ctff(DaviesState& st, double accx, double* upn) {
   double u1, u2, u, rb, xconst = 0.0, c1, c2 = 0.0;
   u2 = *upn;
   u1 = 0.0;
   c1 = st.mean;
   rb = 2.0 * ((u2 > 0.0) ? st.lmax : st.lmin);
-  for (u = u2 / (1.0 + u2 * rb); dv_errbd(st, u, &c2) > accx && !st.over; u = u2 / (1.0 + u2 * rb)) {
+  for (u = u2 / (1.0 + u2 * rb); dv_errbd<FAST>(st, u, &c2) > accx && !st.over; u = u2 / (1.0 + u2 * rb)) {
     u1 = u2;
     c1 = c2;
     u2 = 2.0 * u2;
   }
   for (u = (c1 - st.mean) / (c2 - st.mean); u < 0.9 && !st.over; u = (c1 - st.mean) / (c2 - st.mean)) {
     u = (u1 + u2) / 2.0;
-    if (dv_errbd(st, u / (1.0 + u * rb), &xconst) > accx) {
+    if (dv_errbd<FAST>(st, u / (1.0 + u * rb), &xconst) > accx) {
       u1 = u;
       c1 = xconst;
     } else {
@@ -137,7 +220,8 @@ RVT_HD double dv_ctff(DaviesState& st, double accx, double* upn) {
 }
 
 // bound on the integration error due to truncation at u      (qfc.c:180-215)
-RVT_HD double dv_truncation(DaviesState& st, double u, double tausq) {
+template <bool FAST>
+RVT_HDI double dv_truncation(DaviesState& st, double u, double tausq) {
   dv_tick(st);
   if (st.over) return 0.0;
   double sum1 = 0.0, prod2 = 0.0, prod3 = 0.0;
@@ -145,6 +229,26 @@ RVT_HD double dv_truncation(DaviesState& st, double u, double tausq) {
   const double sum2 = (st.sigsq + tausq) * (u * u);
   double prod1 = 2.0 * sum2;
   u = 2.0 * u;
+  if (FAST) {
+    // prod1 += sum_{x <= 1} log(1 + x), prod2 = sum_{x > 1} log(x), prod3 = sum_{x > 1} log(1 + x): three products
+    ScaledProd pa{1.0, 0}, pb{1.0, 0}, pc{1.0, 0};
+    for (int j = 0; j < st.r; ++j) {
+      const double t = u * st.lb[j], x = t * t;
+      const bool big = x > 1.0;
+      pa.m *= big ? 1.0 : 1.0 + x;
+      pb.m *= big ? x : 1.0;
+      pc.m *= big ? 1.0 + x : 1.0;
+      s += big ? 1 : 0;
+      if ((j & 3) == 3) {
+        sp_renorm(pa);
+        sp_renorm(pb);
+        sp_renorm(pc);
+      }
+    }
+    prod1 = prod1 + sp_log(pa);
+    prod2 = sp_log(pb);
+    prod3 = sp_log(pc);
+  } else
   for (int j0 = 0; j0 < st.r; j0 += 4) {
     const int cnt = (st.r - j0 >= 4) ? 4 : st.r - j0;
     double x[4], l1[4], lx[4];
@@ -182,29 +286,38 @@ RVT_HD double dv_truncation(DaviesState& st, double u, double tausq) {
 }
 
 // find u with truncation(u) < accx and truncation(u/1.2) > accx      (qfc.c:217-238)
-RVT_HD void dv_findu(DaviesState& st, double* utx, double accx) {
+template <bool FAST>
+RVT_HDI void dv_findu(DaviesState& st, double* utx, double accx) {
   double ut = *utx, u = ut / 4.0;
-  if (dv_truncation(st, u, 0.0) > accx) {
-    for (u = ut; dv_truncation(st, u, 0.0) > accx && !st.over; u = ut) ut = ut * 4.0;
+  if (dv_truncation<FAST>(st, u, 0.0) > accx) {
+    for (u = ut; dv_truncation<FAST>(st, u, 0.0) > accx && !st.over; u = ut) ut = ut * 4.0;
   } else {
     ut = u;
-    for (u = u / 4.0; dv_truncation(st, u, 0.0) <= accx && !st.over; u = u / 4.0) ut = u;
+    for (u = u / 4.0; dv_truncation<FAST>(st, u, 0.0) <= accx && !st.over; u = u / 4.0) ut = u;
   }
-  const double divis[4] = {2.0, 1.4, 1.2, 1.1};
   for (int i = 0; i < 4; i++) {
-    u = ut / divis[i];
-    if (dv_truncation(st, u, 0.0) <= accx) ut = u;
+    const double dv = (i == 0) ? 2.0 : (i == 1 ? 1.4 : (i == 2 ? 1.2 : 1.1));
+    u = ut / dv;
+    if (dv_truncation<FAST>(st, u, 0.0) <= accx) ut = u;
   }
   *utx = ut;
 }
 
 // nterm+1 terms of the inversion integral at step interv      (qfc.c:241-270)
-RVT_HD void dv_integrate(DaviesState& st, int nterm, double interv, double tausq, bool mainx) {
+template <bool FAST>
+RVT_HDI void dv_integrate(DaviesState& st, int nterm, double interv, double tausq, bool mainx) {
   const double inpi = interv / kDaviesPi;
   for (int k = nterm; k >= 0; k--) {
     const double u = (k + 0.5) * interv;
     double sum1 = -2.0 * u * st.c, sum2 = fabs(sum1);
     double sum3 = -0.5 * st.sigsq * (u * u);
+    if (FAST) {
+      double sa, sl;
+      dv_arg_logmod(st.lb, st.r, 2.0 * u, &sa, &sl);
+      sum1 = sum1 + sa;
+      sum2 = sum2 + sa;  // every atan is positive
+      sum3 = sum3 - 0.25 * sl;
+    } else
     for (int j = st.r - 1; j >= 0; j--) {
       const double x = 2.0 * st.lb[j] * u;
       const double y = x * x;
@@ -223,7 +336,7 @@ RVT_HD void dv_integrate(DaviesState& st, int nterm, double interv, double tausq
 }
 
 // coefficient of tausq in the error when the convergence factor is used      (qfc.c:272-304)
-RVT_HD double dv_cfe(DaviesState& st, double x) {
+RVT_HDI double dv_cfe(DaviesState& st, double x) {
   dv_tick(st);
   if (st.over) return 1.0;
   double axl = fabs(x);
@@ -260,6 +373,7 @@ RVT_HD double dv_cfe(DaviesState& st, double x) {
 // would recompute, so results are unchanged.
 struct DaviesPrelude {
   bool valid;        // false: not usable (degenerate coefficients or the search overran lim) -> full path
+  bool fast;         // the searches used (and davies_qf_front will use) the product form
   double sd, mean, lmax, lmin;
   double utx;        // after findu(&utx, .5*acc)
   int cnt_findu;     // errbd/truncation/cfe calls spent so far (qf's `count`)
@@ -269,8 +383,17 @@ struct DaviesPrelude {
   int cnt_un;
 };
 
-RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P) {
+// all coefficients strictly positive: the product form applies
+RVT_HD bool davies_all_positive(const double* lb, int r) {
+  bool ok = true;
+  for (int j = 0; j < r; ++j) ok = ok && (lb[j] > 0.0);
+  return ok;
+}
+
+template <bool FAST>
+RVT_HDI void davies_prelude_t(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P) {
   DaviesState st;
+  P->fast = FAST;
   st.lb = lb;
   st.th = th;
   st.r = r;
@@ -300,27 +423,43 @@ RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, doub
   P->lmax = st.lmax;
   P->lmin = st.lmin;
   double utx = 16.0 / sd, up = 4.5 / sd, un = -up;
-  dv_findu(st, &utx, .5 * acc);
+  dv_findu<FAST>(st, &utx, .5 * acc);
   P->utx = utx;
   P->cnt_findu = st.count;
   const double acc1 = 0.5 * acc;
-  P->c_up = dv_ctff(st, acc1, &up);
+  P->c_up = dv_ctff<FAST>(st, acc1, &up);
   P->up = up;
   P->cnt_up = st.count - P->cnt_findu;
   const int before = st.count;
-  P->c_un = dv_ctff(st, acc1, &un);
+  P->c_un = dv_ctff<FAST>(st, acc1, &un);
   P->un = un;
   P->cnt_un = st.count - before;
   P->valid = !st.over;
 }
+// fast: use the product form when every coefficient is positive (else the term-by-term form)
+RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P,
+                           bool fast = true) {
+  if (fast && davies_all_positive(lb, r))
+    davies_prelude_t<true>(lb, th, r, lim, acc, P);
+  else
+    davies_prelude_t<false>(lb, th, r, lim, acc, P);
+}
 
 // One term of the inversion integral (the body of qfc.c:250-268 for term k, main integration).
-RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
-                        double* t2) {
+template <bool FAST>
+RVT_HDI void davies_term_t(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
+                           double* t2) {
   const double inpi = interv / kDaviesPi;
   const double u = (k + 0.5) * interv;
   double sum1 = -2.0 * u * c, sum2 = fabs(sum1);
   double sum3 = -0.5 * sigsq * (u * u);
+  if (FAST) {
+    double sa, sl;
+    dv_arg_logmod(lb, r, 2.0 * u, &sa, &sl);
+    sum1 = sum1 + sa;
+    sum2 = sum2 + sa;
+    sum3 = sum3 - 0.25 * sl;
+  } else
   for (int j0 = r - 1; j0 >= 0; j0 -= 4) {
     const int cnt = (j0 >= 3) ? 4 : j0 + 1;
     double x[4], y[4], l1[4], z[4];
@@ -345,6 +484,13 @@ RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double 
   *t1 = sin(0.5 * sum1) * x;
   *t2 = 0.5 * sum2 * x;
 }
+RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
+                        double* t2, bool fast = false) {
+  if (fast)
+    davies_term_t<true>(lb, r, c, sigsq, interv, k, t1, t2);
+  else
+    davies_term_t<false>(lb, r, c, sigsq, interv, k, t1, t2);
+}
 
 // qf() split at its main integration so that the GPU can spread the nt+1 independent terms of MANY
 // evaluation points over the lanes of a wave (gene_pvalue_kernel) while keeping the reference's
@@ -357,14 +503,18 @@ struct DaviesTask {
   double qfval;       // result when !need_main
   int fault;
   bool over;
+  bool fast;          // evaluate the main integration's terms in the product form
   double nterms;      // terms already evaluated (auxiliary integrations)
 };
 
 // `pre` (optional) = davies_prelude() of the same coefficients: the c-independent searches are replayed.
-RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
-                            const DaviesPrelude* pre, DaviesTask* task) {
-  if (pre && !pre->valid) pre = nullptr;
+// FAST: the caller guarantees all lb > 0, and that `pre` (if any) was computed in the same form
+template <bool FAST>
+RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c, int lim, double acc,
+                               const DaviesPrelude* pre, DaviesTask* task) {
   DaviesState st;
+  task->fast = FAST;
+  if (pre && !pre->valid) pre = nullptr;
   st.lb = lb;
   st.th = th;
   st.r = r;
@@ -416,17 +566,17 @@ RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, in
       utx = pre->utx;
       st.count = pre->cnt_findu;
     } else {
-      dv_findu(st, &utx, .5 * acc1);
+      dv_findu<FAST>(st, &utx, .5 * acc1);
     }
     bool sig_changed = false;  // has a convergence factor been added to sigsq?
     if (c != 0.0 && (almx > 0.07 * sd)) {
       const double tausq = .25 * acc1 / dv_cfe(st, c);
       if (st.fail)
         st.fail = false;
-      else if (dv_truncation(st, utx, tausq) < .2 * acc1) {
+      else if (dv_truncation<FAST>(st, utx, tausq) < .2 * acc1) {
         st.sigsq = st.sigsq + tausq;
         sig_changed = true;
-        dv_findu(st, &utx, .25 * acc1);
+        dv_findu<FAST>(st, &utx, .25 * acc1);
       }
     }
     acc1 = 0.5 * acc1;
@@ -440,7 +590,7 @@ RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, in
         st.count += pre->cnt_up;
         if (st.count > st.lim) st.over = true;
       } else {
-        cut_up = dv_ctff(st, acc1, &up);
+        cut_up = dv_ctff<FAST>(st, acc1, &up);
       }
       const double d1 = cut_up - c;
       if (st.over) break;
@@ -455,7 +605,7 @@ RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, in
         st.count += pre->cnt_un;
         if (st.count > st.lim) st.over = true;
       } else {
-        cut_un = dv_ctff(st, acc1, &un);
+        cut_un = dv_ctff<FAST>(st, acc1, &un);
       }
       const double d2 = c - cut_un;
       if (st.over) break;
@@ -488,12 +638,12 @@ RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, in
           break;
         }
         acc1 = .67 * acc1;
-        dv_integrate(st, ntm, intv1, tausq, false);
+        dv_integrate<FAST>(st, ntm, intv1, tausq, false);
         task->nterms += ntm + 1;
         xlim = xlim - xntm;
         st.sigsq = st.sigsq + tausq;
         sig_changed = true;
-        dv_findu(st, &utx, .25 * acc1);
+        dv_findu<FAST>(st, &utx, .25 * acc1);
         acc1 = 0.75 * acc1;
         continue;
       }
@@ -518,6 +668,13 @@ RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, in
     task->need_main = false;
   }
 }
+RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
+                            const DaviesPrelude* pre, DaviesTask* task, bool fast = true) {
+  if (fast)
+    davies_qf_front_t<true>(lb, th, r, c, lim, acc, pre, task);
+  else
+    davies_qf_front_t<false>(lb, th, r, c, lim, acc, pre, task);
+}
 
 // after the main integration: qfval and the round-off test (qfc.c:424-431)
 RVT_HD double davies_qf_back(const DaviesTask& task, double intl, double ersm, int* ifault) {
@@ -533,14 +690,15 @@ RVT_HD double davies_qf_back(const DaviesTask& task, double intl, double ersm, i
 // P[ sum_j lb_j chi²_1 < c ]; *ifault as in the reference (0 ok, 1 accuracy, 2 round-off, 3 invalid,
 // 4 search overran lim).  nterms_out (optional) = number of integrand terms evaluated.
 RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
-                        double* nterms_out, const DaviesPrelude* pre = nullptr) {
+                        double* nterms_out, const DaviesPrelude* pre = nullptr, bool fast = true) {
   DaviesTask task;
-  davies_qf_front(lb, th, r, c, lim, acc, pre, &task);
+  fast = pre ? pre->fast : (fast && davies_all_positive(lb, r));
+  davies_qf_front(lb, th, r, c, lim, acc, pre, &task, fast);
   double intl = task.intl, ersm = task.ersm;
   if (task.need_main) {
     for (int k = task.nt; k >= 0; k--) {
       double t1, t2;
-      davies_term(lb, r, task.c, task.sigsq, task.intv, k, &t1, &t2);
+      davies_term(lb, r, task.c, task.sigsq, task.intv, k, &t1, &t2, task.fast);
       intl = intl + t1;
       ersm = ersm + t2;
     }
@@ -727,13 +885,13 @@ RVT_HD double liu_pvalue(const double* lambda, int n, double Q) {
 // (Skat.cpp:100-103, SkatO.cpp:318-321).  The search is therefore skipped for Q < 0 and 1.0 returned —
 // pinned against the compiled reference by tests/test_oracle_ref.py::test_negative_q_is_one_or_fault.
 RVT_HD double davies_pvalue(const double* lambda, const int* th, int n, double Q, int* fault_out,
-                            double* nterms_out, const DaviesPrelude* pre = nullptr) {
+                            double* nterms_out, const DaviesPrelude* pre = nullptr, bool fast = true) {
   if (nterms_out) *nterms_out = 0.0;
   if (fault_out) *fault_out = 0;
   if (n == 1) return liu_pvalue(lambda, n, Q);
   if (Q < 0.0) return 1.0;
   int fault;
-  double p = 1.0 - davies_qf(lambda, th, n, Q, 10000, 0.000001, &fault, nterms_out, pre);
+  double p = 1.0 - davies_qf(lambda, th, n, Q, 10000, 0.000001, &fault, nterms_out, pre, fast);
   if (p > 1.0) p = 1.0;
   if (fault) p = -1.0;
   if (fault_out) *fault_out = fault;

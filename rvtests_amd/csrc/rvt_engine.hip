@@ -53,7 +53,7 @@ struct Arena {  // grow-only bump allocator over one device allocation
 };
 
 struct ProfEvent {
-  int family;  // 0 suffstat, 1 burden, 2 stats, 3 pvalue
+  int family;  // 0 suffstat (general fp64 kernel), 1 burden, 2 stats, 3 pvalue, 4 suffstat (hard-call kernel)
   hipEvent_t a, b;
 };
 
@@ -81,6 +81,8 @@ struct rvt_ctx {
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t io_stream = nullptr;  // host copies + consolidation of the streaming interface: never behind a batch
   hipStream_t k2_stream = nullptr;  // the sufficient-statistics launches of all slots serialise here
+  hipStream_t k2b_stream = nullptr; // ... except the general-path launches of a batch that also has hard-call genes: a
+                                    // handful of genes per launch cannot fill the chip, so they run beside the others
   bool cu_partitioned = false;
   // ---- related samples (FastLMM null + FamSKAT) ----
   bool have_kin = false, have_fam = false;
@@ -131,7 +133,7 @@ struct rvt_ctx {
   double *d_perm_R = nullptr, *d_perm_C = nullptr, *d_perm_Q = nullptr, *d_perm_cur = nullptr;
   size_t perm_cap_NB = 0, perm_cap_BM = 0;
   int perm_cap_B = 0;
-  hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {};
+  hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {}, ev_k2b[kSlots] = {};
   std::string err;
   // null model
   bool have_null = false;
@@ -149,6 +151,7 @@ struct rvt_ctx {
   int* d_kind_ring = nullptr; // flags of streaming submissions (kAfSlots), copied back with the allele frequencies
   int* h_kind_ring = nullptr; // pinned mirror
   bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
+  bool k2_alternate = false;  // RVT_K2_ALT=1: consecutive hard-call launches alternate between the two K2 streams
   double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
   bool have_null_beta = false;
   // streaming interface
@@ -293,6 +296,12 @@ void drain_events(rvt_ctx* c) {
     hipEventElapsedTime(&ms, e.a, e.b);
     switch (e.family) {
       case 0: c->timing.ms_suffstat += ms; c->timing.n_suffstat_launches++; break;
+      case 4:
+        c->timing.ms_suffstat += ms;
+        c->timing.n_suffstat_launches++;
+        c->timing.ms_suffstat_hc += ms;
+        c->timing.n_suffstat_hc_launches++;
+        break;
       case 1: c->timing.ms_burden += ms; c->timing.n_burden_launches++; break;
       case 2: c->timing.ms_stats += ms; c->timing.n_stats_launches++; break;
       default: c->timing.ms_pvalue += ms; c->timing.n_pvalue_launches++; break;
@@ -431,7 +440,8 @@ int rvt_init(rvt_ctx** out, int device_id) {
     if ((!k2h || atoi(k2h) != 0) && stage2_cus == 0) {
       int lo = 0, hi = 0;
       hipDeviceGetStreamPriorityRange(&lo, &hi);
-      masked = hipStreamCreateWithPriority(&c->k2_stream, hipStreamNonBlocking, hi) == hipSuccess;
+      masked = hipStreamCreateWithPriority(&c->k2_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+               hipStreamCreateWithPriority(&c->k2b_stream, hipStreamNonBlocking, hi) == hipSuccess;
     } else {
       masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
     }
@@ -441,6 +451,8 @@ int rvt_init(rvt_ctx** out, int device_id) {
       (void)hipGetLastError();
       if (c->k2_stream) hipStreamDestroy(c->k2_stream);
       c->k2_stream = nullptr;
+      if (c->k2b_stream) hipStreamDestroy(c->k2b_stream);
+      c->k2b_stream = nullptr;
       for (int i = 0; i < kSlots; ++i) {
         if (c->slots[i].stream) hipStreamDestroy(c->slots[i].stream);
         c->slots[i].stream = nullptr;
@@ -459,6 +471,10 @@ int rvt_init(rvt_ctx** out, int device_id) {
       return RVT_E_HIP;
     }
   }
+  if (!c->k2b_stream && hipStreamCreateWithFlags(&c->k2b_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RVT_E_HIP;
+  }
   c->stream = c->slots[0].stream;
   if (hipStreamCreateWithFlags(&c->io_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -467,6 +483,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
   for (int i = 0; i < kSlots; ++i) {
     hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_k2b[i], hipEventDisableTiming);
   }
   if (hipMalloc((void**)&c->d_nc, sizeof(NullConsts)) != hipSuccess) {
     delete c;
@@ -481,6 +498,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
   }
   seed_rand_state(c->rand_state, 1u);
   if (const char* e = getenv("RVT_HARDCALL")) c->hc_enabled = atoi(e) != 0;
+  if (const char* e = getenv("RVT_K2_ALT")) c->k2_alternate = atoi(e) != 0;
   *out = c;
   return RVT_OK;
 }
@@ -498,6 +516,10 @@ void rvt_destroy(rvt_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   for (auto& sl : c->slots) sync_stream(sl.stream);
+  if (c->k2b_stream) {
+    sync_stream(c->k2b_stream);
+    hipStreamDestroy(c->k2b_stream);
+  }
   if (c->k2_stream) {
     sync_stream(c->k2_stream);
     hipStreamDestroy(c->k2_stream);
@@ -509,6 +531,7 @@ void rvt_destroy(rvt_ctx* c) {
   for (int i = 0; i < kSlots; ++i) {
     if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
     if (c->ev_k2[i]) hipEventDestroy(c->ev_k2[i]);
+    if (c->ev_k2b[i]) hipEventDestroy(c->ev_k2b[i]);
   }
   drain_events(c);
   for (auto e : c->event_pool) hipEventDestroy(e);
@@ -693,6 +716,7 @@ int rvt_get_timing(rvt_ctx* c, rvt_timing* t, int reset) {
   hipSetDevice(c->device);
   for (auto& sl : c->slots) HIP_TRY(c, sync_stream(sl.stream));
   HIP_TRY(c, sync_stream(c->k2_stream));
+  HIP_TRY(c, sync_stream(c->k2b_stream));
   drain_events(c);
   *t = c->timing;
   if (reset) std::memset(&c->timing, 0, sizeof(c->timing));
@@ -976,33 +1000,44 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int slot_idx = (int)(slp - &c->slots[0]);
   HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
+  // general-path genes of a mixed batch (a few genes with imputed values among hard-call ones) go to the second
+  // sufficient-statistics stream and run beside the hard-call launches
+  const bool split = (n_gen > 0 && n_hc > 0) || (c->k2_alternate && n_hc > 0);
+  hipStream_t gst = split ? c->k2b_stream : c->k2_stream;
+  if (split) HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_in[slot_idx], 0));
   int k0 = 0;
   while (k0 < n_gen && needs_panel(h_desc[k0])) ++k0;  // these need the panelled kernel
   if (k0 > 0) {
-    Scope sc(c, 0, c->k2_stream);
+    Scope sc(c, 0, gst);
     const int nPR = (h_desc[0].MT + 3) / 4, nPC = (h_desc[0].CT + 3) / 4;
     int npanels = 0;
     for (int pr = 0; pr < nPR; ++pr) npanels += nPC - pr;
     dim3 grid(n_wparts, k0, npanels), block(64);
     if (nc.binary)
-      k2_launch_panel_w1(grid, c->k2_stream, d_desc, nd, (long long)N, (long long)ld, d);
+      k2_launch_panel_w1(grid, gst, d_desc, nd, (long long)N, (long long)ld, d);
     else
-      k2_launch_panel_w0(grid, c->k2_stream, d_desc, nd, (long long)N, (long long)ld, d);
+      k2_launch_panel_w0(grid, gst, d_desc, nd, (long long)N, (long long)ld, d);
   }
   for (int k = k0; k < n_gen;) {  // descriptors are sorted by width, so every register-budget group is one contiguous run
     const int grp = suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0);
     int e = k;
     while (e < n_gen && suffstat_group(h_desc[e].MT, h_desc[e].CT, nc.binary != 0) == grp) ++e;
-    launch_suffstat(c, c->k2_stream, grp, d_desc + k, e - k, n_wparts, nd);
+    launch_suffstat(c, gst, grp, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
+  int hc_launches = 0;
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
     while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
-    Scope sc(c, 0, c->k2_stream);
-    k2_launch_hc(h_desc[k].MT, dim3(n_wparts, e - k), c->k2_stream, d_desc + k, NullTile{c->d_nulltile, d + 2},
-                 (long long)N, (long long)ld, d);
+    hipStream_t hst = (c->k2_alternate && (hc_launches++ & 1)) ? c->k2b_stream : c->k2_stream;
+    Scope sc(c, 4, hst);
+    k2_launch_hc(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
+                 (long long)ld, d);
     k = e;
+  }
+  if (split) {
+    HIP_TRY(c, hipEventRecord(c->ev_k2b[slot_idx], gst));
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2b[slot_idx], 0));
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
   HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
@@ -1093,11 +1128,11 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       Scope sc(c, 1, bs);
       hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, bs, d_desc + n_gen, (long long)N);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(n_wparts, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
+        hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
                            (long long)N, (long long)ld, d);
       else
-        hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(n_wparts, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
-                           (long long)N, (long long)ld, d);
+        hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs,
+                           d_desc + n_gen, nd, (long long)N, (long long)ld, d);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
@@ -1129,7 +1164,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     Scope sc(c, 3, st);
     const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
                         sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
-    hipLaunchKernelGGL(gene_pvalue_kernel, dim3(n), dim3(64), smem, st, d_desc, tests);
+    // two launches over the batch, each gene is taken by exactly one: product-form Davies sums (every gene of the hot
+    // path) / term-by-term sums (RVT_TEST_EXACT_DAVIES, or a coefficient that is not positive)
+    hipLaunchKernelGGL((gene_pvalue_kernel<true>), dim3(n), dim3(64), smem, st, d_desc, tests);
+    hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, st, d_desc, tests);
   }
   HIP_TRY(c, hipGetLastError());
   rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(sl.h_stage + sizeof(GeneDesc) * n +
@@ -1142,6 +1180,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     c->timing.genes += n;
     c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
+      if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
     }

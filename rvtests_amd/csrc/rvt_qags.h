@@ -25,7 +25,7 @@ namespace rvt {
 // abscissa t (0..20) of the 21-point Kronrod rule on [a,b]: t = 0 centre, 1..10 centre - h*x[t-1],
 // 11..20 centre + h*x[t-11]
 RVT_HD double gk21_node(int t) {  // |node| on [-1,1]
-  const double x[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+  static const double x[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
                         0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
                         0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
                         0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
@@ -46,10 +46,10 @@ struct GkPanel {
 
 // Combine the 21 values fv[t] (layout of gk21_abscissa) exactly as the QUADPACK panel routine does.
 RVT_HD GkPanel gk21_combine(const double* fv, double a, double b) {
-  const double wg[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+  static const double wg[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
                         0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
                         0.295524224714752870173892994651338};
-  const double wgk[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+  static const double wgk[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
                           0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
                           0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
                           0.123491976262065851077958109831074, 0.134709217311473325928054001771707,

@@ -62,7 +62,8 @@ class Timing(C.Structure):
     _fields_ = [("ms_suffstat", C.c_double), ("ms_burden", C.c_double), ("ms_stats", C.c_double),
                 ("ms_pvalue", C.c_double), ("n_suffstat_launches", C.c_int64), ("n_burden_launches", C.c_int64),
                 ("n_stats_launches", C.c_int64), ("n_pvalue_launches", C.c_int64), ("genes", C.c_int64),
-                ("alg_bytes", C.c_double), ("alg_flops", C.c_double), ("genes_hard_call", C.c_int64)]
+                ("alg_bytes", C.c_double), ("alg_flops", C.c_double), ("genes_hard_call", C.c_int64),
+                ("ms_suffstat_hc", C.c_double), ("n_suffstat_hc_launches", C.c_int64), ("alg_bytes_hc", C.c_double)]
 
 
 def library_path():

@@ -74,6 +74,8 @@ def lib():
         L.hc_davies_pvalue.argtypes = [c_double_p, C.c_int, d, c_int_p, c_double_p]
         L.hc_davies_pvalue_cached.restype = d
         L.hc_davies_pvalue_cached.argtypes = [c_double_p, C.c_int, d, c_int_p, c_double_p]
+        L.hc_davies_pvalue_fast.restype = d
+        L.hc_davies_pvalue_fast.argtypes = [c_double_p, C.c_int, d, C.c_int, c_int_p, c_double_p]
         L.hc_liu_pvalue.restype = d
         L.hc_liu_pvalue.argtypes = [c_double_p, C.c_int, d]
         L.hc_sym_eigvals.restype = None
@@ -88,10 +90,15 @@ def lib():
     return _lib
 
 
-def davies(lam, Q, cached=False):
+def davies(lam, Q, cached=False, fast=False):
+    """Davies p-value through the device algorithm compiled for the host.  fast=False: coefficient sums term by term in
+    the reference's order (bit-identical to qfc.c); fast=True: their product form (the engine's default)."""
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     fault = C.c_int(0)
     nt = C.c_double(0)
+    if fast:
+        p = lib().hc_davies_pvalue_fast(_dp(lam), len(lam), float(Q), 1 if cached else 0, C.byref(fault), C.byref(nt))
+        return p, fault.value, nt.value
     fn = lib().hc_davies_pvalue_cached if cached else lib().hc_davies_pvalue
     p = fn(_dp(lam), len(lam), float(Q), C.byref(fault), C.byref(nt))
     return p, fault.value, nt.value

@@ -9,7 +9,11 @@ from collections import defaultdict
 
 
 def short(name):
+    if "gene_suffstat_hc" in name:
+        i = name.find("<")
+        return "K2hc" + name[i:name.find(",", i)].replace(" ", "") + ">"
     for key, tag in (("gene_suffstat_panel", "K2p"), ("gene_suffstat_mfma", "K2"), ("gene_flags", "FL"),
+                     ("burden_fallback", "BF"),
                      ("burden_collapse", "BU"), ("gene_assemble", "AS"), ("gene_tridiag", "TD"), ("gene_spectrum", "SP"),
                      ("gene_pvalue", "PV")):
         if key in name:
