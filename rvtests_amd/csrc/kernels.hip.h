@@ -720,9 +720,8 @@ __device__ __forceinline__ void wave_davies_order(const double* lb, int r, int* 
   }
 }
 
-// FAST = true: product form of Davies' coefficient sums (rvt_davies.h) — every gene whose retained eigenvalues are all
-// positive, i.e. every gene of the hot path; FAST = false: the term-by-term form (RVT_TEST_EXACT_DAVIES, or a
-// coefficient that is not positive).  Both kernels are launched over the batch; each gene is processed by exactly one.
+// FAST = true: product form of Davies' coefficient sums (rvt_davies.h), the default; FAST = false: the term-by-term
+// form (RVT_TEST_EXACT_DAVIES).
 #ifndef RVT_PV_WAVES
 #define RVT_PV_WAVES 2  // waves per SIMD the product-form kernel is compiled for
 #endif
@@ -755,11 +754,6 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   for (int i = lane; i < n_skat; i += 64) lam_skat[i] = gd.lambda[gs.skat_lambda_off + i];
   for (int i = lane; i < n_zimz; i += 64) lam_zimz[i] = gd.lambda[gs.zimz_lambda_off + i];
   __syncthreads();
-  {  // which of the two kernels owns this gene
-    const bool positive = davies_all_positive(lam_zimz, n_zimz) && davies_all_positive(lam_skat, n_skat);
-    const bool want_fast = positive && !(tests & RVT_TEST_EXACT_DAVIES);
-    if (want_fast != FAST) return;
-  }
   if (lane == 0) pvalue_init_result(gs, gd.gene_id, out);
   if (gs.n_poly == 0) return;
   wave_davies_order(lam_skat, n_skat, th_skat, lane);

@@ -51,15 +51,13 @@ RVT_HD double dv_exp1(double x) { return x < -50.0 ? 0.0 : exp(x); }
 //   integrate():  sum_j atan(x_j),  sum_j log(1 + x_j^2)            x_j = 2 lb_j u           (qfc.c:250-262)
 //   errbd():      sum_j [log(1 - x_j) + x_j],  sum_j lb_j / (1 - x_j), sum_j x_j^2 / (1 - x_j)   (qfc.c:143-152)
 //   truncation(): sum_j log(1 + x_j), sum_j log(x_j)                 x_j = (u lb_j)^2         (qfc.c:192-205)
-// i.e. the argument and the log-modulus of prod_j (1 + i x_j), and the logs of three real products.  With all
-// coefficients positive (the hot path: Skat.cpp:92 keeps lambda > 1e-30, SkatO.cpp:365-374 lambda >= mean / 1e5) the
+// i.e. the argument and the log-modulus of prod_j (1 + i x_j), and the logs of three real products.  The
 // products are formed by two FMAs (complex) or one multiplication (real) per coefficient, with the binary exponent
 // carried separately, and ONE atan2 / log is taken per sum instead of one atan + one log (83 + 98 fp64 instructions in
 // the device library) per coefficient: the p-value stage costs ~8x fewer instructions.  The products carry a relative
 // error of ~r ulp, the same size as the accumulated rounding of the term-by-term sums, so results move by ~1e-15
 // absolute — the level at which ocml's and glibc's atan / log already differ.  The term-by-term form stays
-// available (DaviesState::fast = false; RVT_TEST_EXACT_DAVIES at the ABI) and is used whenever a coefficient is not
-// positive.
+// available (template parameter FAST = false; RVT_TEST_EXACT_DAVIES at the ABI).
 constexpr double kLn2 = 0.693147180559945309417232121458;
 constexpr double kTwoPiHi = 6.283185307179586232;        // 2 pi rounded to double
 constexpr double kTwoPiLo = 2.4492935982947064e-16;      // 2 pi - kTwoPiHi
@@ -78,28 +76,46 @@ RVT_HD double sp_log(ScaledProd p) {  // log(m 2^e), m > 0
   return log(p.m) + (double)p.e * kLn2;
 }
 
-// sum_j atan(x_j) and sum_j log(1 + x_j^2) for x_j = lb_j * u2, lb_j > 0, u2 > 0
-RVT_HDI void dv_arg_logmod(const double* lb, int r, double u2, double* sum_atan, double* sum_log1p_sq) {
-  double a = 1.0, b = 0.0;  // prod (1 + i x_j) / 2^E
-  int E = 0, wraps = 0;     // the argument grows monotonically (every factor turns by less than pi / 2): count the
-                            // crossings of the negative real axis
+// sum_j atan(x_j), sum_j |atan(x_j)| and sum_j log(1 + x_j^2) for x_j = lb_j * u2 (u2 > 0; lb_j of either sign).
+// The factors with x >= 0 and those with x < 0 go into two products: the argument of the first only grows, that of
+// the second only falls (every factor turns by less than pi / 2), so the crossings of the negative real axis can be
+// counted and the principal value of atan2 unwrapped.  (The sign of a coefficient is the same for every lane of a
+// wave, so the branch does not diverge.)
+RVT_HDI void dv_arg_logmod(const double* lb, int r, double u2, double* sum_atan, double* sum_abs_atan,
+                           double* sum_log1p_sq) {
+  double ap = 1.0, bp = 0.0, an = 1.0, bn = 0.0;  // prod (1 + i x_j) / 2^E over x >= 0 / over x < 0
+  int Ep = 0, En = 0, wp = 0, wn = 0;
   for (int j = r - 1; j >= 0; --j) {
     const double x = lb[j] * u2;
-    const double na = fma(-b, x, a), nb = fma(a, x, b);
-    wraps += (b >= 0.0 && nb < 0.0) ? 1 : 0;
-    a = na;
-    b = nb;
+    if (x >= 0.0) {
+      const double na = fma(-bp, x, ap), nb = fma(ap, x, bp);
+      wp += (bp >= 0.0 && nb < 0.0) ? 1 : 0;
+      ap = na;
+      bp = nb;
+    } else {
+      const double na = fma(-bn, x, an), nb = fma(an, x, bn);
+      wn += (bn <= 0.0 && nb > 0.0) ? 1 : 0;
+      an = na;
+      bn = nb;
+    }
     if ((j & 3) == 0) {
       int k;
-      (void)frexp(fmax(fabs(a), fabs(b)), &k);
-      a = ldexp(a, -k);
-      b = ldexp(b, -k);
-      E += k;
+      (void)frexp(fmax(fabs(ap), fabs(bp)), &k);
+      ap = ldexp(ap, -k);
+      bp = ldexp(bp, -k);
+      Ep += k;
+      (void)frexp(fmax(fabs(an), fabs(bn)), &k);
+      an = ldexp(an, -k);
+      bn = ldexp(bn, -k);
+      En += k;
     }
   }
-  const double w = (double)wraps;
-  *sum_atan = (atan2(b, a) + w * kTwoPiHi) + w * kTwoPiLo;
-  *sum_log1p_sq = log(fma(a, a, b * b)) + (double)(2 * E) * kLn2;
+  const double fp = (double)wp, fn = (double)wn;
+  const double tp = (atan2(bp, ap) + fp * kTwoPiHi) + fp * kTwoPiLo;   // >= 0
+  const double tn = (atan2(bn, an) - fn * kTwoPiHi) - fn * kTwoPiLo;   // <= 0
+  *sum_atan = tp + tn;
+  *sum_abs_atan = tp - tn;
+  *sum_log1p_sq = (log(fma(ap, ap, bp * bp)) + log(fma(an, an, bn * bn))) + (double)(2 * (Ep + En)) * kLn2;
 }
 
 // log(1+x) if first, else log(1+x) - x      (qfc.c:95-113)
@@ -312,10 +328,10 @@ RVT_HDI void dv_integrate(DaviesState& st, int nterm, double interv, double taus
     double sum1 = -2.0 * u * st.c, sum2 = fabs(sum1);
     double sum3 = -0.5 * st.sigsq * (u * u);
     if (FAST) {
-      double sa, sl;
-      dv_arg_logmod(st.lb, st.r, 2.0 * u, &sa, &sl);
+      double sa, sb, sl;
+      dv_arg_logmod(st.lb, st.r, 2.0 * u, &sa, &sb, &sl);
       sum1 = sum1 + sa;
-      sum2 = sum2 + sa;  // every atan is positive
+      sum2 = sum2 + sb;
       sum3 = sum3 - 0.25 * sl;
     } else
     for (int j = st.r - 1; j >= 0; j--) {
@@ -436,10 +452,10 @@ RVT_HDI void davies_prelude_t(const double* lb, const int* th, int r, int lim, d
   P->cnt_un = st.count - before;
   P->valid = !st.over;
 }
-// fast: use the product form when every coefficient is positive (else the term-by-term form)
+// fast: product form of the coefficient sums (else term by term)
 RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P,
                            bool fast = true) {
-  if (fast && davies_all_positive(lb, r))
+  if (fast)
     davies_prelude_t<true>(lb, th, r, lim, acc, P);
   else
     davies_prelude_t<false>(lb, th, r, lim, acc, P);
@@ -454,10 +470,10 @@ RVT_HDI void davies_term_t(const double* lb, int r, double c, double sigsq, doub
   double sum1 = -2.0 * u * c, sum2 = fabs(sum1);
   double sum3 = -0.5 * sigsq * (u * u);
   if (FAST) {
-    double sa, sl;
-    dv_arg_logmod(lb, r, 2.0 * u, &sa, &sl);
+    double sa, sb, sl;
+    dv_arg_logmod(lb, r, 2.0 * u, &sa, &sb, &sl);
     sum1 = sum1 + sa;
-    sum2 = sum2 + sa;
+    sum2 = sum2 + sb;
     sum3 = sum3 - 0.25 * sl;
   } else
   for (int j0 = r - 1; j0 >= 0; j0 -= 4) {
@@ -508,7 +524,7 @@ struct DaviesTask {
 };
 
 // `pre` (optional) = davies_prelude() of the same coefficients: the c-independent searches are replayed.
-// FAST: the caller guarantees all lb > 0, and that `pre` (if any) was computed in the same form
+// the caller guarantees that `pre` (if any) was computed in the same form
 template <bool FAST>
 RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c, int lim, double acc,
                                const DaviesPrelude* pre, DaviesTask* task) {
@@ -692,7 +708,7 @@ RVT_HD double davies_qf_back(const DaviesTask& task, double intl, double ersm, i
 RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int lim, double acc, int* ifault,
                         double* nterms_out, const DaviesPrelude* pre = nullptr, bool fast = true) {
   DaviesTask task;
-  fast = pre ? pre->fast : (fast && davies_all_positive(lb, r));
+  if (pre) fast = pre->fast;
   davies_qf_front(lb, th, r, c, lim, acc, pre, &task, fast);
   double intl = task.intl, ersm = task.ersm;
   if (task.need_main) {

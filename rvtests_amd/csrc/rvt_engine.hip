@@ -32,6 +32,7 @@ void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nul
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
+#include "rot_gemm.hip.h"
 #include "perm_kernels.hip.h"
 
 using namespace rvt;
@@ -87,7 +88,16 @@ struct rvt_ctx {
   // ---- related samples (FastLMM null + FamSKAT) ----
   bool have_kin = false, have_fam = false;
   int64_t kin_N = 0;
-  double* d_U = nullptr;   // N x N fp64, column-major (eigenvectors of the kinship)
+  // eigenvectors of the kinship as kRotPlanesU signed base-128 digit planes (rot_gemm.hip.h): plane p at
+  // d_Uq + p * uq_plane, row k (= column k of U) at k * uq_ldk; scaled by 2^uq_sexp
+  signed char* d_Uq = nullptr;
+  size_t uq_plane = 0;
+  int64_t uq_ldk = 0, uq_rows_pad = 0;
+  int uq_sexp = 0;
+  signed char* d_rotB = nullptr;  // digit planes of the columns being rotated
+  size_t rotB_cap = 0;
+  double* d_rot_scale = nullptr;  // per-column scale (RVT_ROT_MAXCOLS doubles) | column maxima
+  int* d_rot_sexp = nullptr;
   double* d_S = nullptr;   // N raw eigenvalues
   double* d_u1 = nullptr;  // U'1
   std::vector<double> h_S, h_u1;
@@ -377,9 +387,16 @@ bool invert_spd(const double* M, int n, double* Minv) {
 
 // 16-sample steps handled by one wave: large enough to amortise the partial-tile write, small enough
 // that a gene still spreads over >= 32..128 waves
-void choose_split(int64_t ld, int* n_wparts, int* steps_per) {
+// n_genes: genes of the batch — a big batch fills the chip with fewer, longer waves per gene (half the partial tiles
+// to write and to reduce: measured +2.7 % at 512 genes)
+void choose_split(int64_t ld, int n_genes, int* n_wparts, int* steps_per) {
   const int64_t nsteps = ld >> 4;
-  int64_t spw = (nsteps + 127) / 128;
+  static const int forced = [] {
+    const char* e = getenv("RVT_WPARTS");
+    return e ? atoi(e) : 0;
+  }();
+  const int target = forced > 0 ? forced : (n_genes >= 128 ? 64 : 128);
+  int64_t spw = (nsteps + target - 1) / target;
   if (spw < 64) spw = 64;
   spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;  // whole ring iterations of the hard-call kernel
   int64_t nw = (nsteps + spw - 1) / spw;
@@ -545,7 +562,7 @@ void rvt_destroy(rvt_ctx* c) {
     hipStreamDestroy(sl.stream);
   }
   if (c->d_nc) hipFree(c->d_nc);
-  for (double* p : {c->d_U, c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
+  for (double* p : {c->d_S, c->d_u1, c->d_uxy, c->d_lmm_part, c->d_fX, c->d_frr, c->d_fv, c->d_fzeros,
                     c->d_fbeta, c->d_Gp, c->d_Gt, c->d_cX, c->d_cv, c->d_cr})
     if (p) hipFree(p);
   if (c->d_famcov_nc) hipFree(c->d_famcov_nc);
@@ -557,6 +574,10 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_af_ring) hipFree(c->d_af_ring);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
+  if (c->d_Uq) hipFree(c->d_Uq);
+  if (c->d_rotB) hipFree(c->d_rotB);
+  if (c->d_rot_scale) hipFree(c->d_rot_scale);
+  if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);
   if (c->d_kind_ring) hipFree(c->d_kind_ring);
   if (c->h_kind_ring) hipHostFree(c->h_kind_ring);
@@ -870,7 +891,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int64_t ld = nc.ld, N = nc.N, nsteps = ld >> 4;
   const int n_bparts = (int)((N + kBurdenSPB - 1) / kBurdenSPB);
   int n_wparts, steps_per;
-  choose_split(ld, &n_wparts, &steps_per);
+  choose_split(ld, n, &n_wparts, &steps_per);
   // ---- sizes ---------------------------------------------------------------------------------------
   std::vector<GeneDesc> desc(n);
   size_t total = 0, af_total = 0;
@@ -1164,10 +1185,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     Scope sc(c, 3, st);
     const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
                         sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
-    // two launches over the batch, each gene is taken by exactly one: product-form Davies sums (every gene of the hot
-    // path) / term-by-term sums (RVT_TEST_EXACT_DAVIES, or a coefficient that is not positive)
-    hipLaunchKernelGGL((gene_pvalue_kernel<true>), dim3(n), dim3(64), smem, st, d_desc, tests);
-    hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, st, d_desc, tests);
+    if (tests & RVT_TEST_EXACT_DAVIES)  // Davies' coefficient sums term by term (verification) / in product form
+      hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, st, d_desc, tests);
+    else
+      hipLaunchKernelGGL((gene_pvalue_kernel<true>), dim3(n), dim3(64), smem, st, d_desc, tests);
   }
   HIP_TRY(c, hipGetLastError());
   rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(sl.h_stage + sizeof(GeneDesc) * n +
@@ -1229,7 +1250,7 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   const int64_t nsteps = nc.ld >> 4;
   const int n_bparts = (int)((nc.N + kBurdenSPB - 1) / kBurdenSPB);
   int n_wparts, steps_per;
-  choose_split(nc.ld, &n_wparts, &steps_per);
+  choose_split(nc.ld, n, &n_wparts, &steps_per);
   size_t total = 0, af_total = 0;
   GeneOff o;
   for (int g = 0; g < n; ++g) {
@@ -1372,41 +1393,126 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   hipSetDevice(c->device);
   int rc = rvt_sync(c);
   if (rc) return rc;
-  for (double** p : {&c->d_U, &c->d_S, &c->d_u1}) {
+  for (double** p : {&c->d_S, &c->d_u1}) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }
+  if (c->d_Uq) hipFree(c->d_Uq);
+  c->d_Uq = nullptr;
   c->have_kin = c->have_fam = false;
-  const size_t nn = (size_t)N * N;
-  HIP_TRY(c, hipMalloc((void**)&c->d_U, sizeof(double) * nn));
   HIP_TRY(c, hipMalloc((void**)&c->d_S, sizeof(double) * N));
   HIP_TRY(c, hipMalloc((void**)&c->d_u1, sizeof(double) * N));
-  {  // fp32 -> fp64 through a bounded staging buffer (the caller's U can be tens of GB)
-    const size_t chunk = std::min<size_t>(nn, (size_t)256 << 20);
+  // U -> fixed-point digit planes (rot_gemm.hip.h).  Eigenvectors have |u| <= 1; entries up to 2 are representable.
+  c->uq_ldk = (N + 127) / 128 * 128;
+  c->uq_rows_pad = (N + kRotBM - 1) / kRotBM * kRotBM;
+  c->uq_plane = (size_t)c->uq_rows_pad * (size_t)c->uq_ldk;
+  c->uq_sexp = 7 * kRotPlanesU - 3;
+  HIP_TRY(c, hipMalloc((void**)&c->d_Uq, c->uq_plane * kRotPlanesU));
+  HIP_TRY(c, hipMemsetAsync(c->d_Uq, 0, c->uq_plane * kRotPlanesU, c->stream));
+  {  // whole columns at a time through a bounded staging buffer (the caller's U can be tens of GB): digits + column sums
+    const int64_t cols_per = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)256 << 20) / N));
     float* d_tmp = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(float) * chunk));
-    for (size_t off = 0; off < nn; off += chunk) {
-      const size_t n = std::min(chunk, nn - off);
-      HIP_TRY(c, hipMemcpyAsync(d_tmp, U + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, c->d_U + off, n);
+    double* d_tmp64 = nullptr;
+    int* d_flag = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(float) * (size_t)cols_per * N));
+    HIP_TRY(c, hipMalloc((void**)&d_tmp64, sizeof(double) * (size_t)cols_per * N));
+    HIP_TRY(c, hipMalloc((void**)&d_flag, sizeof(int)));
+    HIP_TRY(c, hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+    for (int64_t k0 = 0; k0 < N; k0 += cols_per) {
+      const int64_t nc = std::min(cols_per, N - k0);
+      const size_t n = (size_t)nc * N;
+      HIP_TRY(c, hipMemcpyAsync(d_tmp, U + (size_t)k0 * N, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(rot_quantize_f32_kernel, dim3(2048), dim3(256), 0, c->stream, d_tmp, (long long)N, (long long)nc,
+                         (long long)N, c->uq_sexp, kRotPlanesU, c->d_Uq, (long long)c->uq_ldk, (long long)c->uq_plane,
+                         (long long)k0, d_flag);
+      hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, d_tmp64, n);
+      hipLaunchKernelGGL(column_sums_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp64, (long long)N,
+                         (long long)N, c->d_u1 + k0);
       HIP_TRY(c, sync_stream(c->stream));
     }
+    int bad = 0;
+    HIP_TRY(c, hipMemcpy(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(d_tmp);
+    hipFree(d_tmp64);
+    hipFree(d_flag);
+    if (bad) return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
   }
   c->h_S.resize(N);
   for (int64_t i = 0; i < N; ++i) c->h_S[i] = (double)S[i];
   HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(column_sums_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, c->d_U, (long long)N,
-                     (long long)N, c->d_u1);
   c->h_u1.resize(N);
-  HIP_TRY(c, hipMemcpyAsync(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, sync_stream(c->stream));
+  HIP_TRY(c, hipMemcpy(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost));
   c->kin_N = N;
   c->have_kin = true;
-  if (!c->blas) {
-    BLAS_TRY(c, rocblas_create_handle(&c->blas));
-    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+  return RVT_OK;
+}
+
+// dst (N x ncols doubles, leading dimension ld_dst) = U' src (src: N x ncols doubles, leading dimension ld_src), exactly
+// as the integer products of the digit planes (rot_gemm.hip.h).  Columns of small integers (hard calls after the flip,
+// collapsed burden columns) are one digit plane; any other batch is quantised to kRotPlanesG digits per column.
+static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int ncols, double* d_dst, int64_t ld_dst,
+                          hipStream_t st) {
+  if (ncols < 1) return RVT_OK;
+  const int64_t N = c->kin_N;
+  constexpr int kMaxCols = 1 << 15;
+  if (ncols > kMaxCols) {  // long lists in pieces
+    for (int c0 = 0; c0 < ncols; c0 += kMaxCols) {
+      int rc = rotate_columns(c, d_src + (size_t)c0 * ld_src, ld_src, std::min(kMaxCols, ncols - c0),
+                              d_dst + (size_t)c0 * ld_dst, ld_dst, st);
+      if (rc) return rc;
+    }
+    return RVT_OK;
   }
+  if (!c->d_rot_scale) {
+    HIP_TRY(c, hipMalloc((void**)&c->d_rot_scale, sizeof(double) * 2 * kMaxCols));
+    HIP_TRY(c, hipMalloc((void**)&c->d_rot_sexp, sizeof(int) * kMaxCols));
+  }
+  double* d_max = c->d_rot_scale + kMaxCols;
+  hipLaunchKernelGGL(rot_colmax_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_src, (long long)N, (long long)ld_src,
+                     d_max);
+  std::vector<double> cmax(ncols), scale(ncols);
+  std::vector<int> sexp(ncols, 0);
+  HIP_TRY(c, hipMemcpyAsync(cmax.data(), d_max, sizeof(double) * ncols, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  bool small = true;
+  for (int j = 0; j < ncols; ++j) small = small && cmax[j] >= 0.0 && cmax[j] <= 127.0;
+  const int PG = small ? 1 : kRotPlanesG;
+  for (int j = 0; j < ncols; ++j) {
+    const double mx = cmax[j] < 0.0 ? -cmax[j] - 1.0 : cmax[j];
+    if (!std::isfinite(mx)) return fail(c, RVT_E_INVALID, "non-finite value in a column to rotate");
+    sexp[j] = (PG == 1 || mx == 0.0) ? 0 : 7 * PG - 3 - std::ilogb(mx);
+    scale[j] = std::ldexp(1.0, -(c->uq_sexp + sexp[j]));
+  }
+  const int64_t cols_pad = ((int64_t)ncols + kRotBN - 1) / kRotBN * kRotBN;
+  const size_t bplane = (size_t)cols_pad * (size_t)c->uq_ldk, need = bplane * PG;
+  if (c->rotB_cap < need) {
+    if (c->d_rotB) hipFree(c->d_rotB);
+    c->d_rotB = nullptr;
+    c->rotB_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
+    c->rotB_cap = need + need / 4;
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rot_sexp, sexp.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rot_scale, scale.data(), sizeof(double) * ncols, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rot_quantize_f64_kernel, dim3(2048), dim3(256), 0, st, d_src, (long long)N, (long long)ncols,
+                     (long long)ld_src, c->d_rot_sexp, PG, c->d_rotB, (long long)c->uq_ldk, (long long)bplane);
+  const int nrp = (int)((N + kRotBM - 1) / kRotBM), nct = (int)(cols_pad / kRotBN);
+  const long long sets = (long long)((nrp + 31) / 32) * ((nct + 7) / 8);
+  const long long kbytes = (N + kRotKC - 1) / kRotKC * kRotKC;
+  int first = 1;
+  for (int sdeg = 0; sdeg <= (kRotPlanesU - 1) + (PG - 1); ++sdeg)  // least significant digit pairs first
+    for (int p = 0; p < kRotPlanesU; ++p) {
+      const int q = sdeg - p;
+      if (q < 0 || q >= PG) continue;
+      hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(512), 0, st,
+                         (const int8_t*)(c->d_Uq + (size_t)p * c->uq_plane), (const int8_t*)(c->d_rotB + (size_t)q * bplane),
+                         (long long)c->uq_ldk, kbytes, d_dst, (long long)ld_dst, (int)N, ncols, nrp, nct, c->d_rot_scale,
+                         std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1);
+      first = 0;
+    }
+  HIP_TRY(c, hipGetLastError());
+  // the sources reach the stack-allocated host vectors only through the copies above, which are complete (sync_stream)
   return RVT_OK;
 }
 
@@ -1513,11 +1619,11 @@ int rvt_fit_fam_null(rvt_ctx* c, int64_t N, int d, const double* X, const double
   HIP_TRY(c, hipMemcpy(d_xy, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(d_xy + (size_t)N * d, y, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
   {  // ux = U'X, uy = U'y  (FastLMM.cpp:55-57)
-    const double one = 1.0, zero = 0.0;
-    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
-    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, dx,
-                              (rocblas_int)N, &one, c->d_U, (rocblas_int)N, d_xy, (rocblas_int)N, &zero, c->d_uxy,
-                              (rocblas_int)N));
+    int rcr = rotate_columns(c, d_xy, N, dx, c->d_uxy, N, st);
+    if (rcr) {
+      hipFree(d_xy);
+      return rcr;
+    }
     HIP_TRY(c, sync_stream(st));
   }
   hipFree(d_xy);
@@ -1797,11 +1903,8 @@ static int fam_block_run(rvt_ctx* c, const double* dG, int V, CovOut* cop) {
                      d_poly);
   HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * V, st));
   {
-    const double one = 1.0, zero = 0.0;
-    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
-    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, V,
-                              (rocblas_int)N, &one, c->d_U, (rocblas_int)N, dG, (rocblas_int)ld, &zero, c->d_Gt,
-                              (rocblas_int)ld));
+    int rcr = rotate_columns(c, dG, ld, V, c->d_Gt, ld, st);
+    if (rcr) return rcr;
   }
   HIP_TRY(c, sync_stream(st));
   return famcov_run(c, c->d_Gt, V, d_cs, d_poly, cop);
@@ -2017,12 +2120,9 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
     hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)TB), dim3(256), 0, st, c->d_Gp + (size_t)T * ld,
                        (long long)N, (long long)ld, d_bcs, d_bpoly);
   }
-  {
-    const double one = 1.0, zero = 0.0;
-    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
-    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N,
-                              (rocblas_int)(T + TB), (rocblas_int)N, &one, c->d_U, (rocblas_int)N, c->d_Gp,
-                              (rocblas_int)ld, &zero, c->d_Gt, (rocblas_int)ld));
+  {  // the rotation of the whole batch: genotype columns + collapsed burden columns (exact int8 products, rot_gemm.hip.h)
+    int rcr = rotate_columns(c, c->d_Gp, ld, (int)(T + TB), c->d_Gt, ld, st);
+    if (rcr) return rcr;
   }
   HIP_TRY(c, sync_stream(st));
   if (burden) {

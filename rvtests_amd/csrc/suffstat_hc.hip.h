@@ -80,7 +80,45 @@ struct HcBurden {       // per-lane running sums of the collapsed-genotype score
   unsigned zz, cnt;     // sum c_zeg^2 and #(c != 0) over the samples of this lane's row
 };
 
-// One step: fp64 MFMAs for G'[X | rr], packing, column sums, burden hits.  T = position of the step in its group of 4.
+// one tile row of one step: fp64 MFMAs for G'[X | rr], packing, column sum, burden hits
+template <bool MASKED>
+__device__ __forceinline__ void hc_row(const u4_t& glo, const u4_t& ghi, const double (&xv)[4], d4_t& accT,
+                                       unsigned& pk, unsigned& cs, unsigned fx, unsigned& h, bool valid) {
+  const double g0 = hc_dbl(glo[0], glo[1]), g1 = hc_dbl(glo[2], glo[3]), g2 = hc_dbl(ghi[0], ghi[1]),
+               g3 = hc_dbl(ghi[2], ghi[3]);
+  accT = __builtin_amdgcn_mfma_f64_16x16x4f64(g0, xv[0], accT, 0, 0, 0);
+  accT = __builtin_amdgcn_mfma_f64_16x16x4f64(g1, xv[1], accT, 0, 0, 0);
+  accT = __builtin_amdgcn_mfma_f64_16x16x4f64(g2, xv[2], accT, 0, 0, 0);
+  accT = __builtin_amdgcn_mfma_f64_16x16x4f64(g3, xv[3], accT, 0, 0, 0);
+  // top bytes of the four doubles -> one dword (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = bytes of
+  // the 1st, 0x0c = 0x00), then 0x00 / 0x3F / 0x40 -> 0 / 1 / 2 in every byte
+  const unsigned w01 = __builtin_amdgcn_perm(glo[3], glo[1], 0x0c0c0703u);
+  const unsigned w23 = __builtin_amdgcn_perm(ghi[3], ghi[1], 0x07030c0cu);
+  unsigned p = ((w01 | w23) >> 5) & 0x03030303u;
+  if (MASKED) p = valid ? p : 0u;
+  pk = p;
+  cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
+  const unsigned t = p ^ fx;  // flipped column: (int)(2 - g) > 0  <=>  g != 2
+  h += (t | (t >> 1)) & 0x01010101u;
+}
+
+// end of a step: the per-sample variant counts of this lane's row and the burden sums
+template <bool MASKED>
+__device__ __forceinline__ void hc_finish(unsigned h, const double (&xv)[4], HcBurden& bu, unsigned vmask) {
+  h = row16_sum(h);  // byte l: variants with (int)g' > 0 for sample l of this lane's row
+  if (MASKED) h &= vmask;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const unsigned cz = (h >> (8 * l)) & 0xffu;
+    const unsigned cc = cz ? 1u : 0u;
+    bu.zz = cz * cz + bu.zz;
+    bu.cnt += cc;
+    bu.a_zeg = fma((double)cz, xv[l], bu.a_zeg);
+    bu.a_cmc = fma((double)cc, xv[l], bu.a_cmc);
+  }
+}
+
+// One step from a step buffer.  T = position of the step in its group of 4.
 template <int MT, bool MASKED>
 __device__ __forceinline__ void hc_step(const HcStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
                                         unsigned (&cs)[MT], const unsigned (&fx)[MT], HcBurden& bu, bool valid,
@@ -93,35 +131,8 @@ __device__ __forceinline__ void hc_step(const HcStep<MT>& f, const int T, d4_t (
   }
   unsigned h = 0;
 #pragma unroll
-  for (int c = 0; c < MT; ++c) {
-    const double g0 = hc_dbl(f.glo[c][0], f.glo[c][1]), g1 = hc_dbl(f.glo[c][2], f.glo[c][3]),
-                 g2 = hc_dbl(f.ghi[c][0], f.ghi[c][1]), g3 = hc_dbl(f.ghi[c][2], f.ghi[c][3]);
-    accT[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(g0, xv[0], accT[c], 0, 0, 0);
-    accT[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(g1, xv[1], accT[c], 0, 0, 0);
-    accT[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(g2, xv[2], accT[c], 0, 0, 0);
-    accT[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(g3, xv[3], accT[c], 0, 0, 0);
-    // top bytes of the four doubles -> one dword (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = bytes of
-    // the 1st, 0x0c = 0x00), then 0x00 / 0x3F / 0x40 -> 0 / 1 / 2 in every byte
-    const unsigned w01 = __builtin_amdgcn_perm(f.glo[c][3], f.glo[c][1], 0x0c0c0703u);
-    const unsigned w23 = __builtin_amdgcn_perm(f.ghi[c][3], f.ghi[c][1], 0x07030c0cu);
-    unsigned p = ((w01 | w23) >> 5) & 0x03030303u;
-    if (MASKED) p = valid ? p : 0u;
-    pk[c][T] = p;
-    cs[c] = __builtin_amdgcn_sad_u8(p, 0u, cs[c]);
-    const unsigned t = p ^ fx[c];  // flipped column: (int)(2 - g) > 0  <=>  g != 2
-    h += (t | (t >> 1)) & 0x01010101u;
-  }
-  h = row16_sum(h);  // byte l: variants with (int)g' > 0 for sample l of this lane's row
-  if (MASKED) h &= vmask;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const unsigned cz = (h >> (8 * l)) & 0xffu;
-    const unsigned cc = cz ? 1u : 0u;
-    bu.zz = cz * cz + bu.zz;
-    bu.cnt += cc;
-    bu.a_zeg = fma((double)cz, xv[l], bu.a_zeg);
-    bu.a_cmc = fma((double)cc, xv[l], bu.a_cmc);
-  }
+  for (int c = 0; c < MT; ++c) hc_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], fx[c], h, valid);
+  hc_finish<MASKED>(h, xv, bu, vmask);
 }
 
 template <int MT>
@@ -195,7 +206,51 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
   const long long s_fast_end = (s_end < full) ? s_end : full;
   constexpr int U = (DEPTH == 3) ? 12 : 4;
   const long long n_fast = (s_fast_end > s_begin) ? (s_fast_end - s_begin) / U : 0;
-  if (n_fast > 0) {
+  if constexpr (DEPTH == 1) {
+   if (n_fast > 0) {
+    // Rolling refill (wide classes): ONE step buffer; as soon as a tile row of step s has been consumed its registers
+    // are the destination of the same row of step s + 1, so every row's load has the other MT - 1 rows' work to land
+    // in.  Half the ring registers of the two-buffer scheme (what lets MT = 5, 6 run two waves per SIMD).  The
+    // null-model tile is double-buffered.
+    unsigned voff[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(s_begin * 128);
+    unsigned xoff = xbase + (unsigned)(s_begin * 128);
+    u4_t glo[MT], ghi[MT], xlo[2], xhi[2];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+      glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c], 0, NT ? 2 : 0));
+      ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + 16, 0, NT ? 2 : 0));
+    }
+    xlo[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, 0, 0));
+    xhi[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + 16, 0, 0));
+    for (long long it = 0; it < n_fast; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xlo[(u + 1) & 1] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (u + 1) * 128, 0, 0));
+        xhi[(u + 1) & 1] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (u + 1) * 128 + 16, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const double xv[4] = {hc_dbl(xlo[u & 1][0], xlo[u & 1][1]), hc_dbl(xlo[u & 1][2], xlo[u & 1][3]),
+                              hc_dbl(xhi[u & 1][0], xhi[u & 1][1]), hc_dbl(xhi[u & 1][2], xhi[u & 1][3])};
+        unsigned h = 0;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+          hc_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], fx[c], h, true);
+          glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128, 0, NT ? 2 : 0));
+          ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128 + 16, 0, NT ? 2 : 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        hc_finish<false>(h, xv, bu, 0xffffffffu);
+        if (u == 3) hc_gram<MT>(pk, accS);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int c = 0; c < MT; ++c) voff[c] += 4 * 128;
+      xoff += 4 * 128;
+    }
+    s += n_fast * U;
+   }
+  } else if (n_fast > 0) {
     unsigned voff[MT];
 #pragma unroll
     for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(s_begin * 128);

@@ -91,6 +91,12 @@ def test_product_form_davies_matches_term_by_term():
             continue
         Q = lam.sum() * rng.choice([0.01, 0.1, 0.5, 1, 2, 5, 10, 30, 80]) * rng.uniform(0.5, 1.5)
         cases.append((lam, Q))
+    for _ in range(300):      # coefficients of either sign (not met on the hot path; the product form still applies)
+        r = int(rng.integers(2, 60))
+        lam = rng.gamma(0.7, 1.0, size=r) * rng.choice([-1.0, 1.0], size=r, p=[0.3, 0.7]) * 10 ** rng.uniform(-3, 3)
+        Q = np.abs(lam).sum() * rng.choice([-1, -0.2, 0.05, 0.5, 1, 3, 10]) * rng.uniform(0.5, 1.5)
+        if Q >= 0:
+            cases.append((lam, Q))
     worst_abs = worst_rel = 0.0
     n_terms_differ = 0
     for lam, Q in cases:

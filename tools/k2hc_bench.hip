@@ -73,7 +73,7 @@ struct HcCfg {
 #define CFG(mt, dp, w) {mt, dp, w, {gene_suffstat_hc<mt, dp, w, false>, gene_suffstat_hc<mt, dp, w, true>}}
 static const HcCfg kCfgs[] = {
     CFG(1, 2, 4), CFG(1, 3, 4), CFG(1, 2, 5), CFG(2, 2, 3), CFG(2, 3, 3), CFG(2, 3, 2), CFG(3, 2, 2), CFG(3, 3, 2),
-    CFG(4, 2, 2), CFG(4, 3, 1), CFG(4, 4, 1), CFG(5, 2, 1), CFG(5, 3, 1), CFG(6, 2, 1), CFG(6, 3, 1),
+    CFG(4, 2, 2), CFG(4, 1, 2), CFG(5, 2, 1), CFG(5, 1, 1), CFG(5, 1, 2), CFG(6, 2, 1), CFG(6, 1, 1), CFG(6, 1, 2),
 };
 static void launch_cfg(const HcCfg& c, int nt_on, dim3 grid, const GeneDesc* dgd, NullTile nt, long long N, long long ld, int d) {
   hipLaunchKernelGGL(c.k[nt_on], grid, dim3(64), 0, 0, dgd, nt, N, ld, d);
