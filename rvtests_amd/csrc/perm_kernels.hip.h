@@ -9,7 +9,8 @@
 // J s with J = A^(N-1) a 31 x 31 matrix over Z/2^32.  The host jumps from permutation to permutation with J; on the
 // device every permutation of a chunk is generated INDEPENDENTLY by one thread (its own generator state, its own
 // index array), then the shuffles are composed in order (they are cumulative), the permuted residuals of the chunk
-// form a B x N matrix and all Q of the chunk come from ONE GEMM against the flipped / filtered genotype block.
+// form an N x B matrix and all Q of the chunk come from ONE integer-plane product (rot_gemm.hip.h) with the flipped /
+// filtered genotype block.
 // The permutations are therefore exactly the reference's; Q is evaluated in fp64 where the reference uses fp32.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,14 +57,30 @@ __global__ __launch_bounds__(64) void perm_fisher_yates_kernel(const uint32_t* _
 }
 
 // cumulative application of shuffle p to the current residual vector: next[k] = cur[idx[k][p]];
-// also column p of the chunk matrix Rp (B x N column-major: Rp[p + k*B])
+// also column p of the chunk matrix Rp (N x B column-major: Rp[k + p*N])
 __global__ void perm_apply_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ cur,
                                   double* __restrict__ next, double* __restrict__ Rp, long long N, int B, int p) {
   const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (k >= N) return;
   const double v = cur[idx[k * B + p]];
   next[k] = v;
-  Rp[p + k * (long long)B] = v;
+  Rp[k + (long long)p * N] = v;
+}
+
+// Small sample counts: C[p + j*B] = sum_i G[i + j*ld] Rp[i + p*N] summed in sample order i = 0 .. N-1, exactly as the
+// reference's (and the oracle's) dot product runs.  With a handful of samples — the reference's own example has 9 —
+// many shuffles reproduce the observed Q mathematically, and whether such a tie counts as "greater" is decided by the
+// last bit; only the same summation order resolves it the same way.
+__global__ void perm_dot_sequential_kernel(const double* __restrict__ Rp, const double* __restrict__ G, long long N,
+                                           long long ld, int nb, int m, int B, double* __restrict__ C) {
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= (long long)nb * m) return;
+  const int p = (int)(t % nb), j = (int)(t / nb);
+  const double* r = Rp + (long long)p * N;
+  const double* g = G + (long long)j * ld;
+  double s = 0.0;
+  for (long long i = 0; i < N; ++i) s += g[i] * r[i];
+  C[p + (long long)j * B] = s;
 }
 
 // Q_p = sum_j w_j (g_j . r_p)^2 from C = Rp * G' (B x m, column-major, ldc = B); bw[j] = sqrt(w_j)

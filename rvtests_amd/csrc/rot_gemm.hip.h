@@ -36,12 +36,13 @@ typedef int i4v_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int rot_lds_off(int row, int seg) { return row * 64 + ((seg ^ ((row >> 2) & 3)) << 4); }
 
 // One plane pair.  A: [Mpad rows][ldk] int8 (row m = column m of U), B: [Npad cols][ldk] int8, K = ldk rounded to 64.
-// C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j],  m < M, j < N.
+// C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j] [* row_scale[m]],  m < M, j < N.
 __global__ __launch_bounds__(512, 2) void rot_gemm_i8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
                                                              long long ldk, long long kbytes, double* __restrict__ C,
                                                              long long ldc, int M, int N, int n_row_panels,
                                                              int n_col_tiles, const double* __restrict__ col_scale,
-                                                             double weight, int accumulate) {
+                                                             const double* __restrict__ row_scale, double weight,
+                                                             int accumulate) {
   __shared__ __attribute__((aligned(16))) char lds[2][(kRotBM + kRotBN) * kRotKC];
   // ---- tile of this workgroup: 32 consecutive workgroups of one XCD = 4 row panels x 8 column tiles ----------------
   const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void rot_gemm_i8_kernel(const int8_t* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (m + e < M) {
-            const double v = (double)acc[a][b][4 * g + e] * sc;
+            const double v = (double)acc[a][b][4 * g + e] * (row_scale ? sc * row_scale[m + e] : sc);
             cj[m + e] = accumulate ? cj[m + e] + v : v;
           }
         }

@@ -13,7 +13,6 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-#include <rocblas/rocblas.h>
 #include <cmath>
 #include <functional>
 #include "kernels.hip.h"
@@ -94,8 +93,10 @@ struct rvt_ctx {
   size_t uq_plane = 0;
   int64_t uq_ldk = 0, uq_rows_pad = 0;
   int uq_sexp = 0;
-  signed char* d_rotB = nullptr;  // digit planes of the columns being rotated
+  signed char* d_rotB = nullptr;  // digit planes of the columns being rotated (B side of an integer-plane product)
   size_t rotB_cap = 0;
+  signed char* d_rotA = nullptr;  // A side of gemm_tn_planes
+  size_t rotA_cap = 0;
   double* d_rot_scale = nullptr;  // per-column scale (RVT_ROT_MAXCOLS doubles) | column maxima
   int* d_rot_sexp = nullptr;
   double* d_S = nullptr;   // N raw eigenvalues
@@ -119,7 +120,6 @@ struct rvt_ctx {
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
   double* d_Gt = nullptr;  // ... rotated by U'
   size_t fam_cols_cap = 0;
-  rocblas_handle blas = nullptr;
   // raw / packed genotype submission
   double* d_consol_af = nullptr;  // af (RVT_MAX_VARIANTS) | fill values (RVT_MAX_VARIANTS)
   size_t consol_af_cap = 0;
@@ -576,13 +576,13 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_rotB) hipFree(c->d_rotB);
+  if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_scale) hipFree(c->d_rot_scale);
   if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);
   if (c->d_kind_ring) hipFree(c->d_kind_ring);
   if (c->h_kind_ring) hipHostFree(c->h_kind_ring);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
-  if (c->blas) rocblas_destroy_handle(c->blas);
   delete c;
 }
 
@@ -1382,12 +1382,6 @@ int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld) {
 }  // namespace
 
 // ---- related samples: kinship, FastLMM null model, FamSKAT ----------------------------------------------------
-#define BLAS_TRY(ctx, call)                                                                  \
-  do {                                                                                       \
-    rocblas_status st_ = (call);                                                             \
-    if (st_ != rocblas_status_success) return fail(ctx, RVT_E_HIP, "%s: rocblas status %d", #call, (int)st_); \
-  } while (0)
-
 int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   if (!c || !U || !S || N < 2) return fail(c, RVT_E_INVALID, "bad kinship");
   hipSetDevice(c->device);
@@ -1447,73 +1441,135 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   return RVT_OK;
 }
 
-// dst (N x ncols doubles, leading dimension ld_dst) = U' src (src: N x ncols doubles, leading dimension ld_src), exactly
-// as the integer products of the digit planes (rot_gemm.hip.h).  Columns of small integers (hard calls after the flip,
-// collapsed burden columns) are one digit plane; any other batch is quantised to kRotPlanesG digits per column.
-static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int ncols, double* d_dst, int64_t ld_dst,
-                          hipStream_t st) {
-  if (ncols < 1) return RVT_OK;
-  const int64_t N = c->kin_N;
-  constexpr int kMaxCols = 1 << 15;
-  if (ncols > kMaxCols) {  // long lists in pieces
-    for (int c0 = 0; c0 < ncols; c0 += kMaxCols) {
-      int rc = rotate_columns(c, d_src + (size_t)c0 * ld_src, ld_src, std::min(kMaxCols, ncols - c0),
-                              d_dst + (size_t)c0 * ld_dst, ld_dst, st);
-      if (rc) return rc;
-    }
-    return RVT_OK;
-  }
+// ---- integer-plane GEMMs (rot_gemm.hip.h) ---------------------------------------------------------------------------
+namespace {
+constexpr int kRotMaxCols = 1 << 15;
+
+struct QuantCols {       // digit planes of a set of columns, in a context-owned buffer
+  signed char* d = nullptr;
+  size_t plane_stride = 0;
+  int planes = 0;
+  std::vector<int> sexp;  // per column: entries were scaled by 2^sexp
+};
+
+int ensure_rot_scratch(rvt_ctx* c) {
   if (!c->d_rot_scale) {
-    HIP_TRY(c, hipMalloc((void**)&c->d_rot_scale, sizeof(double) * 2 * kMaxCols));
-    HIP_TRY(c, hipMalloc((void**)&c->d_rot_sexp, sizeof(int) * kMaxCols));
+    HIP_TRY(c, hipMalloc((void**)&c->d_rot_scale, sizeof(double) * 4 * kRotMaxCols));  // col | max | row | spare
+    HIP_TRY(c, hipMalloc((void**)&c->d_rot_sexp, sizeof(int) * kRotMaxCols));
   }
-  double* d_max = c->d_rot_scale + kMaxCols;
-  hipLaunchKernelGGL(rot_colmax_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_src, (long long)N, (long long)ld_src,
-                     d_max);
-  std::vector<double> cmax(ncols), scale(ncols);
-  std::vector<int> sexp(ncols, 0);
+  return RVT_OK;
+}
+
+// Quantise ncols <= kRotMaxCols columns of n_rows doubles (column-major, leading dimension ld_src) into planes laid out
+// [plane][column (padded to `pad`)][ldk].  One plane when every column holds integers in [-127, 127], else kRotPlanesG.
+int quantize_columns(rvt_ctx* c, const double* d_src, int64_t n_rows, int64_t ld_src, int ncols, int pad, int64_t ldk,
+                     signed char** buf, size_t* cap, hipStream_t st, QuantCols* out) {
+  int rc = ensure_rot_scratch(c);
+  if (rc) return rc;
+  double* d_max = c->d_rot_scale + kRotMaxCols;
+  hipLaunchKernelGGL(rot_colmax_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_src, (long long)n_rows,
+                     (long long)ld_src, d_max);
+  std::vector<double> cmax(ncols);
   HIP_TRY(c, hipMemcpyAsync(cmax.data(), d_max, sizeof(double) * ncols, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
   bool small = true;
   for (int j = 0; j < ncols; ++j) small = small && cmax[j] >= 0.0 && cmax[j] <= 127.0;
   const int PG = small ? 1 : kRotPlanesG;
+  out->planes = PG;
+  out->sexp.assign(ncols, 0);
   for (int j = 0; j < ncols; ++j) {
     const double mx = cmax[j] < 0.0 ? -cmax[j] - 1.0 : cmax[j];
-    if (!std::isfinite(mx)) return fail(c, RVT_E_INVALID, "non-finite value in a column to rotate");
-    sexp[j] = (PG == 1 || mx == 0.0) ? 0 : 7 * PG - 3 - std::ilogb(mx);
-    scale[j] = std::ldexp(1.0, -(c->uq_sexp + sexp[j]));
+    if (!std::isfinite(mx)) return fail(c, RVT_E_INVALID, "non-finite value in a column of an integer-plane product");
+    out->sexp[j] = (PG == 1 || mx == 0.0) ? 0 : 7 * PG - 3 - std::ilogb(mx);
   }
-  const int64_t cols_pad = ((int64_t)ncols + kRotBN - 1) / kRotBN * kRotBN;
-  const size_t bplane = (size_t)cols_pad * (size_t)c->uq_ldk, need = bplane * PG;
-  if (c->rotB_cap < need) {
-    if (c->d_rotB) hipFree(c->d_rotB);
-    c->d_rotB = nullptr;
-    c->rotB_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
-    c->rotB_cap = need + need / 4;
+  const int64_t cols_pad = ((int64_t)ncols + pad - 1) / pad * pad;
+  out->plane_stride = (size_t)cols_pad * (size_t)ldk;
+  const size_t need = out->plane_stride * PG;
+  if (*cap < need) {
+    if (*buf) hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(c, hipMalloc((void**)buf, need + need / 4));
+    *cap = need + need / 4;
   }
-  HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
-  HIP_TRY(c, hipMemcpyAsync(c->d_rot_sexp, sexp.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(c->d_rot_scale, scale.data(), sizeof(double) * ncols, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(rot_quantize_f64_kernel, dim3(2048), dim3(256), 0, st, d_src, (long long)N, (long long)ncols,
-                     (long long)ld_src, c->d_rot_sexp, PG, c->d_rotB, (long long)c->uq_ldk, (long long)bplane);
-  const int nrp = (int)((N + kRotBM - 1) / kRotBM), nct = (int)(cols_pad / kRotBN);
+  out->d = *buf;
+  HIP_TRY(c, hipMemsetAsync(out->d, 0, need, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rot_sexp, out->sexp.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rot_quantize_f64_kernel, dim3(2048), dim3(256), 0, st, d_src, (long long)n_rows, (long long)ncols,
+                     (long long)ld_src, c->d_rot_sexp, PG, out->d, (long long)ldk, (long long)out->plane_stride);
+  HIP_TRY(c, sync_stream(st));  // d_rot_sexp / the host vectors are reused by the next call
+  return RVT_OK;
+}
+
+// C[a + b * ldc] = sum_i A[i, a] B[i, b] from digit planes: nA rows (A columns), nB columns, K = n_rows samples.
+// row_exp (host, may be null: uniform a_exp) / col_exp: binary scale exponents of the two sides.
+int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int nA, const int* row_exp, int a_exp,
+                const signed char* B, size_t b_stride, int PB, int nB, const int* col_exp, int64_t n_rows, int64_t ldk,
+                double* C, int64_t ldc, hipStream_t st) {
+  int rc = ensure_rot_scratch(c);
+  if (rc) return rc;
+  std::vector<double> cs(nB), rs;
+  for (int j = 0; j < nB; ++j) cs[j] = std::ldexp(1.0, -((row_exp ? 0 : a_exp) + (col_exp ? col_exp[j] : 0)));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rot_scale, cs.data(), sizeof(double) * nB, hipMemcpyHostToDevice, st));
+  const double* d_rs = nullptr;
+  if (row_exp) {
+    rs.resize(nA);
+    for (int a = 0; a < nA; ++a) rs[a] = std::ldexp(1.0, -row_exp[a]);
+    HIP_TRY(c, hipMemcpyAsync(c->d_rot_scale + 2 * kRotMaxCols, rs.data(), sizeof(double) * nA, hipMemcpyHostToDevice, st));
+    d_rs = c->d_rot_scale + 2 * kRotMaxCols;
+  }
+  const int nrp = (nA + kRotBM - 1) / kRotBM, nct = (nB + kRotBN - 1) / kRotBN;
   const long long sets = (long long)((nrp + 31) / 32) * ((nct + 7) / 8);
-  const long long kbytes = (N + kRotKC - 1) / kRotKC * kRotKC;
+  const long long kbytes = (n_rows + kRotKC - 1) / kRotKC * kRotKC;
   int first = 1;
-  for (int sdeg = 0; sdeg <= (kRotPlanesU - 1) + (PG - 1); ++sdeg)  // least significant digit pairs first
-    for (int p = 0; p < kRotPlanesU; ++p) {
+  for (int sdeg = 0; sdeg <= (PA - 1) + (PB - 1); ++sdeg)  // least significant digit pairs first
+    for (int p = 0; p < PA; ++p) {
       const int q = sdeg - p;
-      if (q < 0 || q >= PG) continue;
+      if (q < 0 || q >= PB) continue;
       hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(512), 0, st,
-                         (const int8_t*)(c->d_Uq + (size_t)p * c->uq_plane), (const int8_t*)(c->d_rotB + (size_t)q * bplane),
-                         (long long)c->uq_ldk, kbytes, d_dst, (long long)ld_dst, (int)N, ncols, nrp, nct, c->d_rot_scale,
-                         std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1);
+                         (const int8_t*)(A + (size_t)p * a_stride), (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk,
+                         kbytes, C, (long long)ldc, nA, nB, nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)),
+                         first ? 0 : 1);
       first = 0;
     }
   HIP_TRY(c, hipGetLastError());
-  // the sources reach the stack-allocated host vectors only through the copies above, which are complete (sync_stream)
+  HIP_TRY(c, sync_stream(st));  // (the scale arrays are reused by the next call)
   return RVT_OK;
+}
+}  // namespace
+
+// dst (N x ncols doubles, leading dimension ld_dst) = U' src (src: N x ncols doubles, leading dimension ld_src), exactly
+// as the integer products of the digit planes.  Columns of small integers (hard calls after the flip, collapsed burden
+// columns) are one digit plane; any other batch is quantised to kRotPlanesG digits per column.
+static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int ncols, double* d_dst, int64_t ld_dst,
+                          hipStream_t st) {
+  const int64_t N = c->kin_N;
+  for (int c0 = 0; c0 < ncols; c0 += kRotMaxCols) {  // long lists in pieces
+    const int nc = std::min(kRotMaxCols, ncols - c0);
+    QuantCols qb;
+    int rc = quantize_columns(c, d_src + (size_t)c0 * ld_src, N, ld_src, nc, kRotBN, c->uq_ldk, &c->d_rotB, &c->rotB_cap, st,
+                              &qb);
+    if (rc) return rc;
+    rc = planes_gemm(c, c->d_Uq, c->uq_plane, kRotPlanesU, (int)N, nullptr, c->uq_sexp, qb.d, qb.plane_stride, qb.planes,
+                     nc, qb.sexp.data(), N, c->uq_ldk, d_dst + (size_t)c0 * ld_dst, ld_dst, st);
+    if (rc) return rc;
+  }
+  return RVT_OK;
+}
+
+// C (nA x nB, column-major, leading dimension ldc) = A' B for two double matrices with n_rows rows (column-major) through
+// the integer planes: exact when both hold small integers, else to ~2^-40 relative of each column's largest entry.
+static int gemm_tn_planes(rvt_ctx* c, const double* dA, int64_t ldA, int nA, const double* dB, int64_t ldB, int nB,
+                          int64_t n_rows, double* C, int64_t ldc, hipStream_t st) {
+  if (nA > kRotMaxCols || nB > kRotMaxCols) return fail(c, RVT_E_TOO_LARGE, "integer-plane product: too many columns");
+  const int64_t ldk = (n_rows + 127) / 128 * 128;
+  QuantCols qa, qb;
+  int rc = quantize_columns(c, dA, n_rows, ldA, nA, kRotBM, ldk, &c->d_rotA, &c->rotA_cap, st, &qa);
+  if (rc) return rc;
+  rc = quantize_columns(c, dB, n_rows, ldB, nB, kRotBN, ldk, &c->d_rotB, &c->rotB_cap, st, &qb);
+  if (rc) return rc;
+  return planes_gemm(c, qa.d, qa.plane_stride, qa.planes, nA, qa.sexp.data(), 0, qb.d, qb.plane_stride, qb.planes, nB,
+                     qb.sexp.data(), n_rows, ldk, C, ldc, st);
 }
 
 namespace {
@@ -2441,7 +2497,6 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   double* cur = c->d_perm_cur;
   double* nxt = c->d_perm_cur + N;
   HIP_TRY(c, hipMemcpyAsync(cur, c->d_res, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
-  BLAS_TRY(c, rocblas_set_stream(c->blas, st));
   const double obs = r->skat_Q;
   const double threshold = 1.0 * nPerm * prm.skat_alpha * 2;  // Permutation::init
   int actual = 0, numX = 0, numEq = 0;
@@ -2466,11 +2521,12 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
                          nxt, c->d_perm_R, (long long)N, B, p);
       std::swap(cur, nxt);
     }
-    {  // C (nb x m) = Rp (nb x N) G' (N x m)
-      const double one = 1.0, zero = 0.0;
-      BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nb, m,
-                                (rocblas_int)N, &one, c->d_perm_R, B, c->d_Gp, (rocblas_int)ld, &zero, c->d_perm_C,
-                                B));
+    if (N <= 2048) {  // few samples: sums in sample order, so that exact ties with the observed Q resolve as in the reference
+      hipLaunchKernelGGL(perm_dot_sequential_kernel, dim3((unsigned)(((long long)nb * m + 255) / 256)), dim3(256), 0, st,
+                         c->d_perm_R, c->d_Gp, (long long)N, (long long)ld, nb, m, B, c->d_perm_C);
+    } else {  // C (nb x m) = Rp' G with Rp = the chunk's permuted residuals as columns (N x nb): integer-plane product
+      int rcg = gemm_tn_planes(c, c->d_perm_R, N, nb, c->d_Gp, ld, m, N, c->d_perm_C, B, st);
+      if (rcg) return rcg;
     }
     hipLaunchKernelGGL(perm_q_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, c->d_perm_C, d_bw, B, m,
                        c->d_perm_Q);
@@ -2506,10 +2562,6 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
 // analytic tests + permutation test, one gene at a time (the random stream is consumed in gene order)
 int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
                          const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
-  if (!c->blas) {
-    BLAS_TRY(c, rocblas_create_handle(&c->blas));
-    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
-  }
   size_t afo = 0;
   for (int g = 0; g < n; ++g) {
     DebugOut dbg;
@@ -2627,10 +2679,6 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   hipSetDevice(c->device);
   int rc = rvt_sync(c);
   if (rc) return rc;
-  if (!c->blas) {
-    BLAS_TRY(c, rocblas_create_handle(&c->blas));
-    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
-  }
   hipStream_t st = c->stream;
   const NullConsts& nc = c->nc;
   const int64_t N = nc.N, ld = nc.ld;
@@ -2671,14 +2719,12 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
     Xop = d_tmp;
     GHop = d_tmp + (size_t)ld * d;
   }
-  {
-    const double one = 1.0, zero = 0.0;
-    BLAS_TRY(c, rocblas_set_stream(c->blas, st));
-    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, W, d, (rocblas_int)N,
-                              &one, GW, (rocblas_int)ld, Xop, (rocblas_int)ld, &zero, d_T, W));
-    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, H, W, (rocblas_int)N,
-                              &one, GHop, (rocblas_int)ld, GW, (rocblas_int)ld, &zero, d_S, H));
-  }
+  // T = G_W' D X (W x d) and S = G_H' D G_W (H x W) as integer-plane products (rot_gemm.hip.h): exact for hard calls
+  // and an unweighted model, ~2^-40 relative otherwise
+  rc = gemm_tn_planes(c, GW, ld, W, Xop, ld, d, N, d_T, W, st);
+  if (rc) return rc;
+  rc = gemm_tn_planes(c, GHop, ld, H, GW, ld, W, N, d_S, H, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
   hipLaunchKernelGGL(cov_rect_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, H, W, d_cov);
   HIP_TRY(c, hipGetLastError());

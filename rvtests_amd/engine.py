@@ -91,8 +91,7 @@ def build_library(force=False, verbose=False):
     rcs = [p.wait() for p in procs]
     if any(rcs):
         raise subprocess.CalledProcessError(max(rcs), "hipcc -c")
-    # rocBLAS: the FamSKAT / permutation GEMMs only
-    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs + ["-lrocblas"]
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
