@@ -290,11 +290,17 @@ def main():
     counts = [args.genes] * world
     inflight = []
 
+    last_gather = {"n": None, "ordered": None}
+
     def retire(b):
         """step finished on this rank: C2 = gather its per-gene records on rank 0 (gene order)"""
         if world > 1:
-            shard.gather_records(dist, shard.records_from_results(b["out"]), counts,
-                                 device=dev if backend == "nccl" else None, dst=0)
+            rec = shard.records_from_results(b["out"])
+            rec[:, 0] += rank * args.genes          # gene ids are rank-local: make them global for the ordered merge
+            allr = shard.gather_records(dist, rec, counts, device=dev if backend == "nccl" else None, dst=0)
+            if rank == 0:
+                last_gather["n"] = int(allr.shape[0])
+                last_gather["ordered"] = bool(np.array_equal(allr[:, 0], np.arange(world * args.genes)))
 
     def run_steps(k):
         for i in range(k):
@@ -391,6 +397,9 @@ def main():
             "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
             "warmup_ms_per_step": warm_ms,
         }
+        if world > 1:
+            line["gathered_records_last_step"] = last_gather["n"]
+            line["gathered_ids_in_order"] = last_gather["ordered"]
         if world == 1 and not args.no_cpu_baseline and args.cpu_genes > 0:
             # ---- CPU baseline + parity on a sample of the batch's genes (after the timed region) ------------------
             try:

@@ -355,6 +355,41 @@ int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, u
 int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                         const rvt_params* params, double* af_out);
 
+/* ---- device groups: several GPUs of one node behind one calling thread ---------------------------------------------------
+ * Genes are independent units that share only the null model, so a group is one engine context per device
+ * (rvtests_amd/csrc/rvt_group.cpp): the null model / kinship decomposition is installed on every member, the gene stream is
+ * dealt to the members in runs of 16 genes, and rvt_group_collect returns the records in SUBMISSION order whichever member
+ * produced them (the reference's output files are gene-ordered, src/Main.cpp:1221-1254).  There is no device-to-device
+ * traffic; the ordered merge of the fixed-size records on the host is the only "gather".  A gene that asks for
+ * permutation p-values goes to member 0 (one process-wide random stream, src/Permutation.h:69-98).  The same device may
+ * be listed more than once (testing).  dev_ids == NULL: devices 0 .. n_dev-1. */
+typedef struct rvt_group rvt_group;
+int rvt_group_init(rvt_group** group, int n_dev, const int* dev_ids);
+void rvt_group_destroy(rvt_group* group);
+int rvt_group_size(const rvt_group* group);
+rvt_ctx* rvt_group_member(rvt_group* group, int k);
+const char* rvt_group_last_error(const rvt_group* group);
+int rvt_group_set_null(rvt_group* group, int trait, int64_t N, int d, const double* X, const double* res, const double* v,
+                       double sigma2);
+int rvt_group_fit_null(rvt_group* group, int trait, int64_t N, int d, const double* X, const double* y, double* beta_out,
+                       double* sigma2_out);
+int rvt_group_submit_gene(rvt_group* group, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                          const rvt_params* params);
+int rvt_group_submit_gene_raw(rvt_group* group, int64_t gene_id, int M, const double* Graw, uint32_t tests,
+                              const rvt_params* params, double* af_out);
+int rvt_group_submit_gene_i8(rvt_group* group, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
+                             const rvt_params* params, double* af_out);
+int rvt_group_submit_gene_bed(rvt_group* group, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
+                              const rvt_params* params, double* af_out);
+int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
+/* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host
+ * deals HOST genotype blocks (N x M[g] doubles, imputed, unflipped) to the members in contiguous shares balanced by column
+ * count, every member uploads and runs its share concurrently (one host thread per member inside the call). */
+int rvt_group_set_kinship(rvt_group* group, int64_t N, const float* U, const float* S);
+int rvt_group_fit_fam_null(rvt_group* group, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
+int rvt_group_run_fam_tests_host(rvt_group* group, int n_genes, const double* const* G_host, const int* M,
+                                 const int64_t* gene_ids, uint32_t tests, rvt_gene_result* out);
+
 /* ---- test / inspection hooks ---------------------------------------------------------------------- */
 /* collapsed burden vectors of ONE block (bit-exact parity checks): cmc_out/zeg_out are host N-vectors */
 int rvt_debug_collapse(rvt_ctx* ctx, const double* dG, int M, double* cmc_out, double* zeg_out,

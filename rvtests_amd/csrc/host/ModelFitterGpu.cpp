@@ -89,7 +89,21 @@ GpuBroker& GpuBroker::instance() {
 
 int GpuBroker::ensureContext(int device) {
   if (ctx) return 0;
-  return rvt_init(&ctx, device);
+  std::vector<int> ids;
+  if (const char* e = getenv("RVT_DEVICES")) {  // e.g. RVT_DEVICES=0,1,2,3
+    for (const char* p = e; *p;) {
+      char* end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p) break;
+      ids.push_back((int)v);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
+  if (ids.empty()) ids.push_back(device);
+  const int rc = rvt_group_init(&grp, (int)ids.size(), ids.data());
+  if (rc) return rc;
+  ctx = rvt_group_member(grp, 0);
+  return 0;
 }
 
 void GpuBroker::registerTests(uint32_t mask, const rvt_params& p) {
@@ -107,7 +121,8 @@ void GpuBroker::registerTests(uint32_t mask, const rvt_params& p) {
 }
 
 void GpuBroker::shutdown() {
-  if (ctx) rvt_destroy(ctx);
+  if (grp) rvt_group_destroy(grp);
+  grp = nullptr;
   ctx = nullptr;
   rows.clear();
   pendingSerial.clear();
@@ -132,7 +147,7 @@ int GpuBroker::installNull(const GeneData& gd, bool binary, std::string* err) {
   int rc;
   if (!fitter) {
     // default: LinearRegression::FitLinearModel / LogisticRegression::FitLogisticModel(cov, y, 100) on the device
-    rc = rvt_fit_null(ctx, trait, gd.N, d, X.data(), gd.phenotype, nullptr, nullptr);
+    rc = rvt_group_fit_null(grp, trait, gd.N, d, X.data(), gd.phenotype, nullptr, nullptr);
   } else {
     // a caller-supplied fitter (e.g. the reference's own regression classes inside the rvtests tree)
     std::vector<double> res(gd.N), v(gd.N);
@@ -141,11 +156,11 @@ int GpuBroker::installNull(const GeneData& gd, bool binary, std::string* err) {
       *err = binary ? "failed in fitting null model (logistic model)." : "failed in fitting null model (linear model).";
       return -1;
     }
-    rc = rvt_set_null(ctx, trait, gd.N, d, X.data(), res.data(), v.data(), sigma2);
+    rc = rvt_group_set_null(grp, trait, gd.N, d, X.data(), res.data(), v.data(), sigma2);
   }
   if (rc) {
     *err = binary ? "failed in fitting null model (logistic model)." : "failed in fitting null model (linear model).";
-    *err += std::string(" [") + rvt_last_error(ctx) + "]";
+    *err += std::string(" [") + rvt_group_last_error(grp) + "]";
     return -1;
   }
   haveNull = true;
@@ -236,8 +251,8 @@ int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
     *err = "marker frequencies missing";
     return failed();
   }
-  if (rvt_submit_gene(ctx, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params)) {
-    *err = rvt_last_error(ctx);
+  if (rvt_group_submit_gene(grp, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params)) {
+    *err = rvt_group_last_error(grp);
     return failed();
   }
   pendingSerial.push_back(gd.serial);
@@ -256,7 +271,7 @@ int GpuBroker::flush() {
   if (ctx && !pendingSerial.empty()) {
     std::vector<rvt_gene_result> recs(pendingSerial.size());
     int n = 0;
-    rc = rvt_collect(ctx, recs.data(), (int)recs.size(), &n);
+    rc = rvt_group_collect(grp, recs.data(), (int)recs.size(), &n);
     if (!rc)
       for (int i = 0; i < n; ++i) got[recs[i].gene_id] = recs[i];
   }

@@ -111,9 +111,11 @@ class ModelParser {
 class ModelFitter;
 
 // ---- the engine shared by all GPU-backed models of one run ---------------------------------------------------
-// One rvt_ctx per process/GPU.  The null model is installed once (and again when the caller flags an updated
-// phenotype/covariate); each new gene is submitted ONCE with the union of the registered tests, whichever model's
-// fit() sees it first.
+// One device group per process (rvt_group_*: RVT_DEVICES=0,1,... lists the GPUs, default device 0): the gene tests'
+// stream is dealt to the members and collected in submission order; the models that drive a context themselves
+// (MetaCov, MetaScore, the related-sample tests) use member 0.  The null model is installed once on every member (and
+// again when the caller flags an updated phenotype/covariate); each new gene is submitted ONCE with the union of the
+// registered tests, whichever model's fit() sees it first.
 class GpuBroker {
  public:
   static GpuBroker& instance();
@@ -148,7 +150,8 @@ class GpuBroker {
   const rvt_fam_null& familyNull() const { return famNull; }  // estimates of the FastLMM null last fitted
 
  private:
-  rvt_ctx* ctx = nullptr;
+  rvt_group* grp = nullptr;
+  rvt_ctx* ctx = nullptr;  // member 0
   uint32_t tests = 0;
   rvt_params params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   bool haveNull = false;

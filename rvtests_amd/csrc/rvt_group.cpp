@@ -1,0 +1,213 @@
+// rvtests_amd — several GPUs behind ONE caller thread (include/rvtests_amd.h, "device groups").
+//
+// Genes are independent units that share only the null model, so a group is simply one engine context
+// per device: the null model (and, for related samples, the kinship decomposition) is installed on every member, the
+// gene stream is dealt to the members in runs of kRun genes (the engine starts computing a run as soon as it is
+// complete, so one member computes while the caller's thread feeds the next), and rvt_group_collect hands the records
+// back in SUBMISSION order whatever member produced them — the reference writes its output files in gene order
+// (src/Main.cpp:1221-1254).  No device-to-device traffic at all: the only "collective" is this ordered merge of
+// fixed-size records on the host.  Permutation p-values consume one process-wide random stream in gene order
+// (src/Permutation.h:69-98), so a gene that asks for them always goes to member 0.
+//
+// Plain host C++ over the single-device C ABI; nothing here touches HIP directly.
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/rvtests_amd.h"
+
+struct rvt_group {
+  std::vector<rvt_ctx*> member;
+  std::deque<int> owner;       // member of every submitted, not yet collected gene, in submission order
+  long long submitted = 0;     // genes dealt so far (decides the member of the next one)
+  std::string err;
+};
+
+namespace {
+constexpr int kRun = 16;  // genes dealt to one member before moving on (= the engine's asynchronous sub-batch)
+
+int gfail(rvt_group* g, int code, const char* what, rvt_ctx* c) {
+  if (g) g->err = std::string(what) + (c ? std::string(": ") + rvt_last_error(c) : std::string());
+  return code;
+}
+
+int next_member(rvt_group* g, const rvt_params* prm, uint32_t tests) {
+  if (prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) return 0;
+  return (int)((g->submitted / kRun) % (long long)g->member.size());
+}
+}  // namespace
+
+extern "C" {
+
+int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
+  if (!out || n_dev < 1) return RVT_E_INVALID;
+  *out = nullptr;
+  rvt_group* g = new rvt_group();
+  for (int k = 0; k < n_dev; ++k) {
+    rvt_ctx* c = nullptr;
+    const int rc = rvt_init(&c, dev_ids ? dev_ids[k] : k);
+    if (rc) {
+      for (rvt_ctx* m : g->member) rvt_destroy(m);
+      delete g;
+      return rc;
+    }
+    g->member.push_back(c);
+  }
+  *out = g;
+  return RVT_OK;
+}
+
+void rvt_group_destroy(rvt_group* g) {
+  if (!g) return;
+  for (rvt_ctx* m : g->member) rvt_destroy(m);
+  delete g;
+}
+
+int rvt_group_size(const rvt_group* g) { return g ? (int)g->member.size() : 0; }
+rvt_ctx* rvt_group_member(rvt_group* g, int k) {
+  return (g && k >= 0 && k < (int)g->member.size()) ? g->member[k] : nullptr;
+}
+const char* rvt_group_last_error(const rvt_group* g) { return g ? g->err.c_str() : "null group"; }
+
+int rvt_group_set_null(rvt_group* g, int trait, int64_t N, int d, const double* X, const double* res, const double* v,
+                       double sigma2) {
+  if (!g) return RVT_E_INVALID;
+  if (!g->owner.empty()) return gfail(g, RVT_E_STATE, "collect the submitted genes before changing the null model", nullptr);
+  for (rvt_ctx* m : g->member) {
+    const int rc = rvt_set_null(m, trait, N, d, X, res, v, sigma2);
+    if (rc) return gfail(g, rc, "rvt_set_null", m);
+  }
+  return RVT_OK;
+}
+
+int rvt_group_fit_null(rvt_group* g, int trait, int64_t N, int d, const double* X, const double* y, double* beta_out,
+                       double* sigma2_out) {
+  if (!g) return RVT_E_INVALID;
+  if (!g->owner.empty()) return gfail(g, RVT_E_STATE, "collect the submitted genes before changing the null model", nullptr);
+  for (size_t k = 0; k < g->member.size(); ++k) {  // every member fits the same model from the same inputs
+    const int rc = rvt_fit_null(g->member[k], trait, N, d, X, y, k == 0 ? beta_out : nullptr, k == 0 ? sigma2_out : nullptr);
+    if (rc) return gfail(g, rc, "rvt_fit_null", g->member[k]);
+  }
+  return RVT_OK;
+}
+
+#define RVT_GROUP_SUBMIT(call)                                  \
+  if (!g) return RVT_E_INVALID;                                 \
+  const int k = next_member(g, params, tests);                  \
+  rvt_ctx* m = g->member[k];                                    \
+  const int rc = (call);                                        \
+  if (rc) return gfail(g, rc, "submit", m);                     \
+  g->owner.push_back(k);                                        \
+  ++g->submitted;                                               \
+  return RVT_OK;
+
+int rvt_group_submit_gene(rvt_group* g, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                          const rvt_params* params) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene(m, gene_id, M, G, af, tests, params))
+}
+int rvt_group_submit_gene_raw(rvt_group* g, int64_t gene_id, int M, const double* Graw, uint32_t tests,
+                              const rvt_params* params, double* af_out) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene_raw(m, gene_id, M, Graw, tests, params, af_out))
+}
+int rvt_group_submit_gene_i8(rvt_group* g, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
+                             const rvt_params* params, double* af_out) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene_i8(m, gene_id, M, G8, tests, params, af_out))
+}
+int rvt_group_submit_gene_bed(rvt_group* g, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
+                              const rvt_params* params, double* af_out) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene_bed(m, gene_id, M, bed, tests, params, af_out))
+}
+
+int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
+  if (!g || !out || !n_out) return RVT_E_INVALID;
+  *n_out = 0;
+  const int n = (int)std::min<size_t>(g->owner.size(), (size_t)std::max(cap, 0));
+  if (n == 0) return RVT_OK;
+  const int nm = (int)g->member.size();
+  std::vector<int> want(nm, 0);
+  for (int i = 0; i < n; ++i) ++want[g->owner[i]];
+  std::vector<std::vector<rvt_gene_result>> got(nm);
+  for (int k = 0; k < nm; ++k) {
+    if (!want[k]) continue;
+    got[k].resize(want[k]);
+    int nk = 0;
+    const int rc = rvt_collect(g->member[k], got[k].data(), want[k], &nk);
+    if (rc) return gfail(g, rc, "rvt_collect", g->member[k]);
+    if (nk != want[k]) return gfail(g, RVT_E_STATE, "a member returned fewer records than were submitted to it", nullptr);
+  }
+  std::vector<int> pos(nm, 0);
+  for (int i = 0; i < n; ++i) {  // the ordered merge: each member's records are already in ITS submission order
+    const int k = g->owner[i];
+    out[i] = got[k][pos[k]++];
+  }
+  g->owner.erase(g->owner.begin(), g->owner.begin() + n);
+  *n_out = n;
+  return RVT_OK;
+}
+
+// ---- related samples: the kinship decomposition is replicated on every member ------------------------------------------
+int rvt_group_set_kinship(rvt_group* g, int64_t N, const float* U, const float* S) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member) {
+    const int rc = rvt_set_kinship(m, N, U, S);
+    if (rc) return gfail(g, rc, "rvt_set_kinship", m);
+  }
+  return RVT_OK;
+}
+
+int rvt_group_fit_fam_null(rvt_group* g, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out) {
+  if (!g) return RVT_E_INVALID;
+  for (size_t k = 0; k < g->member.size(); ++k) {
+    rvt_fam_null tmp;
+    const int rc = rvt_fit_fam_null(g->member[k], N, d, X, y, k == 0 && out ? out : &tmp);
+    if (rc) return gfail(g, rc, "rvt_fit_fam_null", g->member[k]);
+  }
+  return RVT_OK;
+}
+
+// Host genotype blocks (N x M[g] doubles each, imputed, unflipped) dealt to the members in contiguous shares; every
+// member uploads and runs its share (rvt_run_fam_tests) at the same time; records come back in the caller's order.
+int rvt_group_run_fam_tests_host(rvt_group* g, int n_genes, const double* const* G_host, const int* M,
+                                 const int64_t* gene_ids, uint32_t tests, rvt_gene_result* out) {
+  if (!g || n_genes < 0 || (n_genes > 0 && (!G_host || !M || !out))) return RVT_E_INVALID;
+  const int nm = (int)g->member.size();
+  // contiguous shares balanced by column count (the rotation's cost is proportional to the columns)
+  long long total = 0;
+  for (int i = 0; i < n_genes; ++i) total += M[i];
+  // one host thread per member for the duration of this call (each context is still used by exactly one thread)
+  std::vector<int> rcs(nm, RVT_OK);
+  std::vector<std::thread> workers;
+  int begin = 0;
+  long long acc = 0;
+  for (int k = 0; k < nm; ++k) {
+    int end = begin;
+    const long long target = total * (k + 1) / nm;
+    while (end < n_genes && (k == nm - 1 || acc + M[end] <= target || end == begin)) acc += M[end++];
+    if (end > begin) {
+      rvt_ctx* m = g->member[k];
+      const int b0 = begin, e0 = end;
+      workers.emplace_back([=, &rcs]() {
+        std::vector<double*> blocks(e0 - b0, nullptr);
+        int rc = RVT_OK;
+        for (int i = b0; i < e0 && !rc; ++i) {
+          rc = rvt_block_alloc(m, M[i], &blocks[i - b0]);
+          if (!rc) rc = rvt_block_upload(m, blocks[i - b0], M[i], G_host[i]);
+        }
+        if (!rc)
+          rc = rvt_run_fam_tests(m, e0 - b0, blocks.data(), M + b0, gene_ids ? gene_ids + b0 : nullptr, tests, out + b0);
+        for (double* bl : blocks)
+          if (bl) rvt_block_free(m, bl);
+        rcs[k] = rc;
+      });
+    }
+    begin = end;
+  }
+  for (std::thread& t : workers) t.join();
+  for (int k = 0; k < nm; ++k)
+    if (rcs[k]) return gfail(g, rcs[k], "rvt_run_fam_tests", g->member[k]);
+  return RVT_OK;
+}
+
+}  // extern "C"

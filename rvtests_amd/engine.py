@@ -73,7 +73,7 @@ def library_path():
 def build_library(force=False, verbose=False):
     """Compile csrc/rvt_engine.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     out = library_path()
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", "rvt_group.cpp"))]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
@@ -88,10 +88,13 @@ def build_library(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))
+    gobj = os.path.join(CSRC, "rvt_group.o")     # device groups: plain host C++ over the C ABI
+    procs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", "-fPIC", "-c", os.path.join(CSRC, "rvt_group.cpp"), "-o", gobj]))
+    objs.append(gobj)
     rcs = [p.wait() for p in procs]
     if any(rcs):
         raise subprocess.CalledProcessError(max(rcs), "hipcc -c")
-    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
@@ -198,6 +201,40 @@ def load_library():
     L.rvt_block_upload_columns.argtypes = [vp, vp, C.c_int, C.c_int, c_double_p]
     L.rvt_block_move_columns.restype = C.c_int
     L.rvt_block_move_columns.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    gp = C.c_void_p
+    L.rvt_group_init.restype = C.c_int
+    L.rvt_group_init.argtypes = [C.POINTER(gp), C.c_int, c_int_p]
+    L.rvt_group_destroy.restype = None
+    L.rvt_group_destroy.argtypes = [gp]
+    L.rvt_group_size.restype = C.c_int
+    L.rvt_group_size.argtypes = [gp]
+    L.rvt_group_member.restype = vp
+    L.rvt_group_member.argtypes = [gp, C.c_int]
+    L.rvt_group_last_error.restype = C.c_char_p
+    L.rvt_group_last_error.argtypes = [gp]
+    L.rvt_group_set_null.restype = C.c_int
+    L.rvt_group_set_null.argtypes = [gp, C.c_int, C.c_int64, C.c_int, c_double_p, c_double_p, c_double_p, C.c_double]
+    L.rvt_group_fit_null.restype = C.c_int
+    L.rvt_group_fit_null.argtypes = [gp, C.c_int, C.c_int64, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.rvt_group_submit_gene.restype = C.c_int
+    L.rvt_group_submit_gene.argtypes = [gp, C.c_int64, C.c_int, c_double_p, c_double_p, C.c_uint32, C.POINTER(Params)]
+    L.rvt_group_submit_gene_raw.restype = C.c_int
+    L.rvt_group_submit_gene_raw.argtypes = [gp, C.c_int64, C.c_int, c_double_p, C.c_uint32, C.POINTER(Params), c_double_p]
+    L.rvt_group_submit_gene_i8.restype = C.c_int
+    L.rvt_group_submit_gene_i8.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(Params),
+                                           c_double_p]
+    L.rvt_group_submit_gene_bed.restype = C.c_int
+    L.rvt_group_submit_gene_bed.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(Params),
+                                            c_double_p]
+    L.rvt_group_collect.restype = C.c_int
+    L.rvt_group_collect.argtypes = [gp, C.POINTER(GeneResult), C.c_int, c_int_p]
+    L.rvt_group_set_kinship.restype = C.c_int
+    L.rvt_group_set_kinship.argtypes = [gp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rvt_group_fit_fam_null.restype = C.c_int
+    L.rvt_group_fit_fam_null.argtypes = [gp, C.c_int64, C.c_int, c_double_p, c_double_p, C.POINTER(FamNull)]
+    L.rvt_group_run_fam_tests_host.restype = C.c_int
+    L.rvt_group_run_fam_tests_host.argtypes = [gp, C.c_int, C.POINTER(c_double_p), c_int_p, C.POINTER(C.c_int64),
+                                               C.c_uint32, C.POINTER(GeneResult)]
     L.rvt_set_profiling.restype = C.c_int
     L.rvt_set_profiling.argtypes = [vp, C.c_int]
     L.rvt_get_timing.restype = C.c_int
@@ -531,3 +568,80 @@ class Engine:
         t = Timing()
         self._check(self.L.rvt_get_timing(self.ctx, C.byref(t), 1 if reset else 0))
         return t
+
+
+class Group:
+    """Several GPUs behind one caller (rvt_group_*): the null model on every member, the gene stream dealt in runs of 16,
+    records back in submission order.  `devices`: list of HIP device indices (a device may repeat)."""
+
+    def __init__(self, devices):
+        self.L = load_library()
+        self.g = C.c_void_p()
+        ids = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self.L.rvt_group_init(C.byref(self.g), len(ids), ids.ctypes.data_as(c_int_p))
+        if rc != 0:
+            raise RvtError("rvt_group_init failed (%d): no usable HIP device — the engine has no CPU fallback" % rc)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RvtError("rvtests_amd error %d: %s" % (rc, self.L.rvt_group_last_error(self.g).decode()))
+
+    def close(self):
+        if self.g:
+            self.L.rvt_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def fit_null(self, trait, X, y):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        N, d = X.shape
+        beta = np.zeros(d)
+        s2 = C.c_double(0.0)
+        self._check(self.L.rvt_group_fit_null(self.g, int(trait), N, d, _dp(X), _dp(y), _dp(beta),
+                                              C.cast(C.byref(s2), c_double_p)))
+        return beta, s2.value
+
+    def submit_gene(self, gene_id, G, af, tests=TEST_ALL, params=None):
+        G = np.asfortranarray(G, dtype=np.float64)
+        af = np.ascontiguousarray(af, dtype=np.float64)
+        prm = params or Params.default()
+        self._check(self.L.rvt_group_submit_gene(self.g, int(gene_id), G.shape[1], _dp(G), _dp(af), int(tests),
+                                                 C.byref(prm)))
+
+    def submit_gene_i8(self, gene_id, G8, tests=TEST_ALL, params=None):
+        G8 = np.asfortranarray(G8, dtype=np.int8)
+        prm = params or Params.default()
+        self._check(self.L.rvt_group_submit_gene_i8(self.g, int(gene_id), G8.shape[1],
+                                                    G8.ctypes.data_as(C.POINTER(C.c_int8)), int(tests), C.byref(prm),
+                                                    None))
+
+    def collect(self, cap=4096):
+        out = (GeneResult * cap)()
+        n = C.c_int(0)
+        self._check(self.L.rvt_group_collect(self.g, out, cap, C.byref(n)))
+        return list(out[: n.value])
+
+    def set_kinship(self, U, S):
+        U = np.asfortranarray(U, dtype=np.float32)
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self.L.rvt_group_set_kinship(self.g, U.shape[0], U.ctypes.data_as(fp), S.ctypes.data_as(fp)))
+
+    def fit_fam_null(self, X, y):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        out = FamNull()
+        self._check(self.L.rvt_group_fit_fam_null(self.g, X.shape[0], X.shape[1], _dp(X), _dp(y), C.byref(out)))
+        return out
+
+    def run_fam_tests_host(self, genes, tests=16, ids=None):
+        """genes: list of host N x M arrays."""
+        Gs = [np.asfortranarray(G, dtype=np.float64) for G in genes]
+        n = len(Gs)
+        ptrs = (c_double_p * n)(*[_dp(G) for G in Gs])
+        Ms = np.ascontiguousarray([G.shape[1] for G in Gs], dtype=np.int32)
+        arr_id = np.ascontiguousarray(ids if ids is not None else np.arange(n), dtype=np.int64)
+        out = (GeneResult * n)()
+        self._check(self.L.rvt_group_run_fam_tests_host(self.g, n, ptrs, Ms.ctypes.data_as(c_int_p),
+                                                        arr_id.ctypes.data_as(C.POINTER(C.c_int64)), int(tests), out))
+        return list(out)

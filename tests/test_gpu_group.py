@@ -1,0 +1,93 @@
+"""GPU: device groups (rvt_group_*, several GPUs behind one caller) and the one-process-per-GPU bench path, exercised
+on ONE device: a group that lists device 0 twice deals the gene stream to two engine contexts and must hand back the
+records in submission order with the single-context values; two bench ranks share GPU 0 over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_group_orders_records_and_matches_single_context(engine):
+    import rvtests_amd
+    N, d = 3001, 3
+    rng = np.random.default_rng(3)
+    genes = []
+    for g in range(75):                       # several runs of 16 per member + a ragged tail
+        M = int(rng.integers(1, 70))
+        Graw, G, af = synth.make_gene(N, M, seed=7000 + g, missing=0.01 if g % 4 == 0 else 0.0, common=(g % 5 == 1))
+        genes.append((G, af))
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=9, G_effect=0.4 * genes[3][0][:, :2].sum(1))
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        beta, sig = grp.fit_null(0, X, y)
+        ids = [1000 + 3 * g for g in range(len(genes))]
+        got = []
+        for g, (G, af) in enumerate(genes):
+            grp.submit_gene(ids[g], G, af)
+            if g == 40:                       # a partial collect in the middle of the stream
+                got += grp.collect(cap=25)
+        got += grp.collect()
+        assert [r.gene_id for r in got] == ids
+    finally:
+        grp.close()
+    engine.fit_null(0, X, y)
+    for g, (G, af) in enumerate(genes):
+        engine.submit_gene(ids[g], G, af)
+    ref = engine.collect()
+    assert [r.gene_id for r in ref] == ids
+    for a, b in zip(got, ref):
+        for f in ("skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f
+    rc, a0 = orc.skat(genes[3][0], genes[3][1], X, res, v, 0)
+    assert abs(got[3].skat_p - a0.pvalue) <= 1e-6 * a0.pvalue + 1e-14
+
+
+def test_group_famskat_shares(engine):
+    """Related samples: the kinship is replicated on both members, host blocks are dealt in two shares that run at the
+    same time, records come back in the caller's order and equal the single-context run."""
+    import rvtests_amd
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(50, 2, 31)
+    genes = [synth.make_gene(N, M, seed=400 + M, missing=0.0, common=(M % 2 == 0))[1] for M in (12, 5, 30, 7, 22, 9, 3)]
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        grp.set_kinship(U, S)
+        nul = grp.fit_fam_null(X, y)
+        got = grp.run_fam_tests_host(genes, tests=16, ids=list(range(50, 57)))
+    finally:
+        grp.close()
+    eng = rvtests_amd.Engine(0)
+    try:
+        eng.set_kinship(U, S)
+        nul1 = eng.fit_fam_null(X, y)
+        assert nul1.delta == nul.delta
+        ptrs = [eng.upload_block(G) for G in genes]
+        ref = eng.run_fam_blocks(ptrs, [G.shape[1] for G in genes], ids=list(range(50, 57)))
+    finally:
+        eng.close()
+    assert [r.gene_id for r in got] == list(range(50, 57))
+    for a, b in zip(got, ref):
+        assert a.famskat_ok == b.famskat_ok and a.famskat_Q == b.famskat_Q and a.famskat_p == b.famskat_p
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 path (one process per GPU, broadcast of the null inputs, per-step gather of REAL engine records
+    on rank 0) with two ranks on GPU 0 over gloo."""
+    env = dict(os.environ, RVT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--samples",
+           "20000", "--genes", "48", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["genes_ok"] == 48 and line["value"] > 0
+    assert line["gathered_records_last_step"] == 96 and line["gathered_ids_in_order"] is True
