@@ -57,6 +57,7 @@ int ModelParser::parse(const std::string& s) {
   }
   return 0;
 }
+void ModelParser::set(const std::string& tag, const std::string& value) { param[lower(tag)] = value; }
 bool ModelParser::hasTag(const std::string& tag) const { return param.find(lower(tag)) != param.end(); }
 const char* ModelParser::value(const std::string& tag) const {
   auto it = param.find(lower(tag));

@@ -64,19 +64,25 @@ struct GeneData {
 // ---- FileWriter stand-in (base/IO.h FileWriter::write / printf) -------------------------------------------
 struct TextSink {
   std::string text;
-  void write(const std::string& s) { text += s; }
-  void write(const char* s) { text += s; }
+  virtual ~TextSink() {}
+  virtual void write(const std::string& s) { text += s; }  // in_tree/GpuModelFitter.h forwards to FileWriter::write
+  void write(const char* s) { write(std::string(s)); }
 };
 
 // site columns the caller passes to writeHeader/writeOutput (Result::writeHeaderTab / writeValueTab)
 struct SiteInfo {
   std::vector<std::pair<std::string, std::string>> kv;
+  // set by the in-tree binding, which takes both lines from the reference's Result (joinValue): used verbatim
+  bool verbatim = false;
+  std::string headerLine, valueLine;
   std::string headerTab() const {
+    if (verbatim) return headerLine;
     std::string s;
     for (auto& p : kv) s += p.first + "\t";
     return s;
   }
   std::string valueTab() const {
+    if (verbatim) return valueLine;
     std::string s;
     for (auto& p : kv) s += p.second + "\t";
     return s;
@@ -102,6 +108,7 @@ class ModelParser {
   const ModelParser& assign(const std::string& tag, double* v, double def) const;
   const ModelParser& assign(const std::string& tag, int* v, int def) const;
   const ModelParser& assign(const std::string& tag, bool* v, bool def) const;
+  void set(const std::string& tag, const std::string& value);  // (in-tree binding: copy a tag of the reference's parser)
 
  private:
   std::string name;

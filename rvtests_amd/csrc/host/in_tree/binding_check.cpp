@@ -1,0 +1,47 @@
+// rvtests_amd — compile-only check of the in-tree binding against the reference's own headers (run by
+// tests/test_in_tree_binding.py with -fsyntax-only when /root/reference is present).  It repeats, with the GPU models,
+// what src/ModelManager.cpp does with the CPU ones: parse the model string, read the tags, construct, and call the
+// plugin interface through ModelFitter*.
+#include <vector>
+
+#include "GpuModelFitter.h"
+
+#include "DataConsolidator.h"
+
+int rvt_binding_check(DataConsolidator* dc, FileWriter* fp, const Result& siteInfo) {
+  std::vector< ::ModelFitter*> model;
+  ModelParser parser;
+  int nPerm = 10000;
+  double alpha = 0.05, beta1 = 1.0, beta2 = 25.0;
+  int windowSize = 1000000;
+  // src/ModelManager.cpp:168-198 (kernel), :99-103 (burden), :238-247 (meta)
+  parser.parse("skat[nPerm=0:beta1=1:beta2=25]");
+  parser.assign("nPerm", &nPerm, 10000).assign("alpha", &alpha, 0.05).assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);
+  model.push_back(new rvt_intree::SkatTest(nPerm, alpha, beta1, beta2));
+  parser.parse("skato");
+  parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);
+  model.push_back(new rvt_intree::SkatOTest(beta1, beta2));
+  model.push_back(&(new rvt_intree::FamSkatTest(beta1, beta2))->related());
+  model.push_back(new rvt_intree::CMCTest());
+  model.push_back(new rvt_intree::ZegginiTest());
+  model.push_back(&(new rvt_intree::FamBurdenTest(false))->related());
+  parser.parse("cov[windowSize=500000]");
+  parser.assign("windowSize", &windowSize, 1000000);
+  model.push_back(new rvt_intree::MetaCovTest(windowSize));
+  model.push_back(new rvt_intree::MetaScoreTest());
+  int rc = 0;
+  for (size_t m = 0; m < model.size(); ++m) {  // src/ModelManager.cpp:273-282, src/Main.cpp:1207-1256
+    model[m]->setParameter(parser);
+    model[m]->setPrefix("out");
+    model[m]->setQuantitativeOutcome();
+    model[m]->writeHeader(fp, siteInfo);
+    model[m]->reset();
+    rc |= model[m]->fit(dc);
+    model[m]->writeOutput(fp, siteInfo);
+    model[m]->writeFootnote(fp);
+    if (model[m]->isFamilyModel() != (m == 2 || m == 5)) rc |= 2;
+    if (model[m]->getModelName().empty() || model[m]->needToIndexResult()) rc |= 4;
+  }
+  for (size_t m = 0; m < model.size(); ++m) delete model[m];
+  return rc;
+}
