@@ -194,6 +194,41 @@ def parity_summary(recs, gpu):
     return worst
 
 
+def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
+    """Secondary figures: the same hot path fed from HOST memory through the ModelFitter-style streaming calls (what a
+    drop-in rvtests run does): pageable fp64 blocks (rvt_submit_gene, 8 B per genotype over PCIe), int8 hard calls
+    (rvt_submit_gene_i8, 1 B) and PLINK 2-bit rows (rvt_submit_gene_bed, 1/4 B); records are taken with
+    rvt_collect_ready while the stream runs (no drain) and rvt_collect at the end."""
+    ks = [k for k in range(len(Ms)) if 40 <= Ms[k] <= 60][:4] or list(range(min(4, len(Ms))))
+    host = [np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()) for k in ks]
+    hard = [np.rint(h) for h in host]
+    out = {}
+    for mode in ("fp64", "int8", "bed2bit"):
+        if mode == "int8":
+            data = [np.asfortranarray(h.astype(np.int8)) for h in hard]
+        elif mode == "bed2bit":
+            data = [eng.pack_bed(h) for h in hard]
+        else:
+            data = host
+        t0 = time.perf_counter()
+        done = 0
+        for g in range(genes):
+            i = g % len(ks)
+            if mode == "fp64":
+                eng.submit_gene(g, data[i], afs[ks[i]])
+            elif mode == "int8":
+                eng.submit_gene_raw(g, data[i], want_af=False)
+            else:
+                eng.submit_gene_bed(g, data[i], Ms[ks[i]], want_af=False)
+            if (g + 1) % window == 0:
+                done += len(eng.collect_ready())
+        done += len(eng.collect())
+        dt = time.perf_counter() - t0
+        out[mode] = {"gene_sets_per_s": done / dt, "genes": done,
+                     "host_GBps": sum(d.nbytes for d in data) / len(data) * done / dt / 1e9}
+    return out
+
+
 def spawn_ranks(n):
     """`--gpus n` without a launcher: start n ranks as a child torch.distributed.run BEFORE this process touches the
     GPU, pass its output through and return its exit code."""
@@ -220,6 +255,7 @@ def main():
     ap.add_argument("--m-lo", type=int, default=20)
     ap.add_argument("--m-hi", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
                     help="genes of the batch run through the CPU oracle after the timed region (baseline + parity)")
     ap.add_argument("--tests", type=int, default=rvtests_amd.TEST_ALL)
@@ -397,6 +433,8 @@ def main():
             "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
             "warmup_ms_per_step": warm_ms,
         }
+        if world == 1 and not args.no_from_host and not binary:
+            line["from_host"] = from_host_rates(eng, blocks, Ms, afs, N)
         if world > 1:
             line["gathered_records_last_step"] = last_gather["n"]
             line["gathered_ids_in_order"] = last_gather["ordered"]

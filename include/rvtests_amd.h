@@ -214,6 +214,11 @@ int rvt_reserve(rvt_ctx* ctx, int n_genes, const int* M);
 int rvt_submit_gene(rvt_ctx* ctx, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                     const rvt_params* params);
 int rvt_collect(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
+/* Non-blocking companion: the records of the longest FINISHED prefix of the submitted genes (at most cap), without
+ * launching incomplete groups and without waiting for anything — the pipeline keeps running.  *n_out may be 0.  A
+ * caller that streams genes (the ModelFitter adapters) polls this while it submits and calls rvt_collect only at the
+ * end, so the device never drains between windows. */
+int rvt_collect_ready(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
 
 /* ---- MetaCov: score-covariance band (`--meta cov`) ------------------------------------------------------
  * Replaces the arithmetic of MetaCovTest::fitWithGivenGenotype / printCovariance / computeScaledXX
@@ -382,6 +387,7 @@ int rvt_group_submit_gene_i8(rvt_group* group, int64_t gene_id, int M, const int
 int rvt_group_submit_gene_bed(rvt_group* group, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                               const rvt_params* params, double* af_out);
 int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
+int rvt_group_collect_ready(rvt_group* group, rvt_gene_result* out, int cap, int* n_out); /* cf. rvt_collect_ready */
 /* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host
  * deals HOST genotype blocks (N x M[g] doubles, imputed, unflipped) to the members in contiguous shares balanced by column
  * count, every member uploads and runs its share concurrently (one host thread per member inside the call). */

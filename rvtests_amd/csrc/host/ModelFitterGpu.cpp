@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <iterator>
 
 namespace rvt_host {
 
@@ -128,6 +129,8 @@ void GpuBroker::shutdown() {
   rows.clear();
   pendingSerial.clear();
   pendingBytes = 0;
+  recBytes.clear();
+  ready.clear();
   failedSerial.clear();
   haveNull = false;
   haveFamNull = false;
@@ -233,7 +236,13 @@ int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
   // genes in flight are bounded by count and by the bytes of their device blocks (a 1024-variant gene is 4 GB at
   // N = 500 000)
   const size_t geneBytes = sizeof(double) * (size_t)gd.N * (size_t)gd.M;
-  if ((int)pendingSerial.size() >= window || (!pendingSerial.empty() && pendingBytes + geneBytes > windowBytes)) flush();
+  // a full window first takes what has finished (no waiting: the device keeps its batches in flight); only when
+  // nothing comes back and twice the window is pending does the caller wait
+  if ((int)pendingSerial.size() >= window || (!pendingSerial.empty() && pendingBytes + geneBytes > windowBytes)) {
+    drainReady();
+    if ((int)pendingSerial.size() >= 2 * window || (!pendingSerial.empty() && pendingBytes + geneBytes > 2 * windowBytes))
+      flush();
+  }
   curSerial = gd.serial;
   curOk = false;
   auto failed = [&]() {
@@ -258,6 +267,7 @@ int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
   }
   pendingSerial.push_back(gd.serial);
   pendingBytes += geneBytes;
+  recBytes[gd.serial] = geneBytes;
   curOk = true;
   return 0;
 }
@@ -266,22 +276,56 @@ void GpuBroker::enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab
   rows.push_back(Row{m, fp, siteTab, serial});
 }
 
+// Write every row whose gene has its record (or failed at submission), in enqueue order, and stop at the first row that
+// has to wait — rows reach each file in the order the reference writes them.
+void GpuBroker::writeReadyRows(bool all) {
+  size_t k = 0;
+  for (; k < rows.size(); ++k) {
+    const Row& r = rows[k];
+    auto it = ready.find(r.serial);
+    const bool failed = std::find(failedSerial.begin(), failedSerial.end(), r.serial) != failedSerial.end();
+    if (it == ready.end() && !failed && !all) break;
+    r.fp->write(r.siteTab + r.model->formatRow(it == ready.end() ? nullptr : &it->second));
+  }
+  rows.erase(rows.begin(), rows.begin() + k);
+  // records nobody waits for any more: every remaining row belongs to a later gene (serials only grow)
+  const int64_t keep = rows.empty() ? (pendingSerial.empty() ? INT64_MAX : pendingSerial.front()) : rows.front().serial;
+  for (auto it = ready.begin(); it != ready.end();) it = (it->first < keep) ? ready.erase(it) : std::next(it);
+  failedSerial.erase(std::remove_if(failedSerial.begin(), failedSerial.end(), [&](int64_t s) { return s < keep; }),
+                     failedSerial.end());
+}
+
+// take what the device has finished, without waiting (rvt_collect_ready): the pipeline keeps running
+int GpuBroker::drainReady() {
+  if (!grp || pendingSerial.empty()) return 0;
+  std::vector<rvt_gene_result> recs(pendingSerial.size());
+  int n = 0;
+  const int rc = rvt_group_collect_ready(grp, recs.data(), (int)recs.size(), &n);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    ready[recs[i].gene_id] = recs[i];
+    pendingBytes -= std::min(pendingBytes, recBytes[recs[i].gene_id]);
+    recBytes.erase(recs[i].gene_id);
+  }
+  pendingSerial.erase(pendingSerial.begin(), pendingSerial.begin() + n);
+  writeReadyRows(false);
+  return 0;
+}
+
 int GpuBroker::flush() {
-  std::map<int64_t, rvt_gene_result> got;
   int rc = 0;
   if (ctx && !pendingSerial.empty()) {
     std::vector<rvt_gene_result> recs(pendingSerial.size());
     int n = 0;
     rc = rvt_group_collect(grp, recs.data(), (int)recs.size(), &n);
     if (!rc)
-      for (int i = 0; i < n; ++i) got[recs[i].gene_id] = recs[i];
+      for (int i = 0; i < n; ++i) ready[recs[i].gene_id] = recs[i];
   }
-  for (const Row& r : rows) {
-    auto it = got.find(r.serial);
-    r.fp->write(r.siteTab + r.model->formatRow(it == got.end() ? nullptr : &it->second));
-  }
-  rows.clear();
   pendingSerial.clear();
+  recBytes.clear();
+  pendingBytes = 0;
+  writeReadyRows(true);
+  ready.clear();
   failedSerial.clear();
   return rc;
 }

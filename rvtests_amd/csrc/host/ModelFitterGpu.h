@@ -139,7 +139,8 @@ class GpuBroker {
   void setBatchBytes(size_t b) { windowBytes = b; }
   int submit(const GeneData& gd, bool binary, std::string* err);
   void enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab, int64_t serial);
-  int flush();
+  int flush();       // wait for everything pending and write all rows
+  int drainReady();  // take the finished prefix without waiting (rvt_collect_ready) and write the rows it completes
   void shutdown();
   // context + null model for models that drive the C ABI themselves (MetaCovTest)
   rvt_ctx* contextWithNull(const GeneData& gd, bool binary, std::string* err);
@@ -176,6 +177,9 @@ class GpuBroker {
   };
   std::vector<Row> rows;               // in writeOutput() order
   std::vector<int64_t> pendingSerial;  // genes submitted and not yet collected, submission order
+  std::map<int64_t, rvt_gene_result> ready;  // records collected, waiting for their rows to be written
+  std::map<int64_t, size_t> recBytes;        // device bytes of each pending gene
+  void writeReadyRows(bool all);
   std::vector<int64_t> failedSerial;   // genes whose submission failed: NA rows
   NullFitter fitter = nullptr;
   const float* kinU = nullptr;

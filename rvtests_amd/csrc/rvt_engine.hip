@@ -68,6 +68,7 @@ struct Slot {
   char* h_stage = nullptr;
   size_t h_stage_cap = 0;
   rvt_gene_result* pending_out = nullptr;
+  bool* pending_done = nullptr;  // set when the batch's records have been handed over (streaming interface)
   rvt_gene_result* h_results = nullptr;
   int pending_n = 0;
   unsigned long long seq = 0;  // launch order
@@ -186,7 +187,9 @@ struct rvt_ctx {
     size_t first;  // index into the queue at launch time (adjusted when the queue is popped)
     int n;
     std::vector<rvt_gene_result> res;
+    bool done = false;  // the batch has finished and `res` is filled (set by finish_slot)
   };
+  bool* next_done_flag = nullptr;  // handed to the slot of the next run_batch call (launch_group)
   std::deque<Launched> launched;
   // profiling
   bool profiling = false;
@@ -263,6 +266,8 @@ int finish_slot(rvt_ctx* c, Slot& sl) {
   HIP_TRY(c, sync_stream(sl.stream));
   if (sl.pending_out) {
     std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
+    if (sl.pending_done) *sl.pending_done = true;
+    sl.pending_done = nullptr;
     sl.pending_out = nullptr;
     sl.pending_n = 0;
   }
@@ -1195,6 +1200,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                                                                (sizeof(double) * af_total + 63) / 64 * 64);
   HIP_TRY(c, hipMemcpyAsync(h_res, base + off_res, sizeof(rvt_gene_result) * n, hipMemcpyDeviceToHost, st));
   sl.pending_out = out;
+  sl.pending_done = c->next_done_flag;
+  c->next_done_flag = nullptr;
   sl.h_results = h_res;
   sl.pending_n = n;
   if (c->profiling) {
@@ -2825,7 +2832,9 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
   L.n = n;
   L.res.resize(n);
   const rvt_ctx::Pending& p0 = c->queue[first];
+  c->next_done_flag = &L.done;
   int rc = run_batch(c, n, ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm, L.res.data(), nullptr);
+  c->next_done_flag = nullptr;
   if (rc) {
     c->launched.pop_back();
     return rc;
@@ -3079,16 +3088,8 @@ int rvt_submit_gene_i8(rvt_ctx* c, int64_t gene_id, int M, const int8_t* G8, uin
   return submit_common(c, gene_id, M, G8, 2, nullptr, af_out, tests, prm);
 }
 
-int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
-  if (!c || !out || !n_out) return RVT_E_INVALID;
-  *n_out = 0;
-  hipSetDevice(c->device);
-  const int n = (int)std::min<size_t>(c->queue.size(), (size_t)cap);
-  if (n == 0) return RVT_OK;
-  int rc = launch_pending(c, (size_t)n, false);
-  if (!rc) rc = rvt_sync(c);
-  if (rc) return rc;
-  // records of the asynchronous groups
+// hand the first n queue entries (all launched and finished) to the caller, recycle their blocks
+static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
   while (!c->launched.empty() && c->launched.front().first < (size_t)n) {
     rvt_ctx::Launched& L = c->launched.front();
     for (int g = 0; g < L.n; ++g) c->queue[L.first + g].res = L.res[g];
@@ -3101,7 +3102,6 @@ int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
   }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);
   for (auto& L : c->launched) L.first -= (size_t)n;
-  // keep the pool bounded: free the largest blocks beyond 128 entries
   {  // keep the free blocks for the next window, bounded by their BYTES (a count bound would free and re-allocate
      // half of a 256-gene window every time: hipMalloc + memset of a 200 MB block is ~3 ms)
     constexpr size_t kPoolBytes = (size_t)96 << 30;
@@ -3113,6 +3113,40 @@ int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
       c->block_pool.pop_back();
     }
   }
+}
+
+int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
+  if (!c || !out || !n_out) return RVT_E_INVALID;
+  *n_out = 0;
+  hipSetDevice(c->device);
+  const int n = (int)std::min<size_t>(c->queue.size(), (size_t)cap);
+  if (n == 0) return RVT_OK;
+  int rc = launch_pending(c, (size_t)n, false);
+  if (!rc) rc = rvt_sync(c);
+  if (rc) return rc;
+  pop_collected(c, n, out);
+  *n_out = n;
+  return RVT_OK;
+}
+
+int rvt_collect_ready(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
+  if (!c || !out || !n_out) return RVT_E_INVALID;
+  *n_out = 0;
+  hipSetDevice(c->device);
+  // batches whose stream has run dry are finished: take their records without waiting for anything else
+  for (auto& sl : c->slots)
+    if (sl.pending_out && hipStreamQuery(sl.stream) == hipSuccess) {
+      int rc = finish_slot(c, sl);
+      if (rc) return rc;
+    }
+  (void)hipGetLastError();  // hipErrorNotReady of the queries is not an error
+  int n = 0;
+  for (const auto& L : c->launched) {  // the finished prefix of the submission order
+    if (!L.done || L.first != (size_t)n || n + L.n > cap) break;
+    n += L.n;
+  }
+  if (n == 0) return RVT_OK;
+  pop_collected(c, n, out);
   *n_out = n;
   return RVT_OK;
 }

@@ -21,6 +21,7 @@
 struct rvt_group {
   std::vector<rvt_ctx*> member;
   std::deque<int> owner;       // member of every submitted, not yet collected gene, in submission order
+  std::vector<std::deque<rvt_gene_result>> inbox;  // records already taken from a member, waiting for their turn
   long long submitted = 0;     // genes dealt so far (decides the member of the next one)
   std::string err;
 };
@@ -55,6 +56,7 @@ int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
     }
     g->member.push_back(c);
   }
+  g->inbox.resize(g->member.size());
   *out = g;
   return RVT_OK;
 }
@@ -120,6 +122,19 @@ int rvt_group_submit_gene_bed(rvt_group* g, int64_t gene_id, int M, const unsign
   RVT_GROUP_SUBMIT(rvt_submit_gene_bed(m, gene_id, M, bed, tests, params, af_out))
 }
 
+// the ordered merge: each member's records arrive in ITS submission order; hand out the global prefix
+static int pop_in_order(rvt_group* g, rvt_gene_result* out, int cap) {
+  int n = 0;
+  while (n < cap && !g->owner.empty()) {
+    std::deque<rvt_gene_result>& box = g->inbox[g->owner.front()];
+    if (box.empty()) break;
+    out[n++] = box.front();
+    box.pop_front();
+    g->owner.pop_front();
+  }
+  return n;
+}
+
 int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
   if (!g || !out || !n_out) return RVT_E_INVALID;
   *n_out = 0;
@@ -128,22 +143,35 @@ int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
   const int nm = (int)g->member.size();
   std::vector<int> want(nm, 0);
   for (int i = 0; i < n; ++i) ++want[g->owner[i]];
-  std::vector<std::vector<rvt_gene_result>> got(nm);
   for (int k = 0; k < nm; ++k) {
-    if (!want[k]) continue;
-    got[k].resize(want[k]);
+    const int more = want[k] - (int)g->inbox[k].size();
+    if (more <= 0) continue;
+    std::vector<rvt_gene_result> got(more);
     int nk = 0;
-    const int rc = rvt_collect(g->member[k], got[k].data(), want[k], &nk);
+    const int rc = rvt_collect(g->member[k], got.data(), more, &nk);
     if (rc) return gfail(g, rc, "rvt_collect", g->member[k]);
-    if (nk != want[k]) return gfail(g, RVT_E_STATE, "a member returned fewer records than were submitted to it", nullptr);
+    if (nk != more) return gfail(g, RVT_E_STATE, "a member returned fewer records than were submitted to it", nullptr);
+    g->inbox[k].insert(g->inbox[k].end(), got.begin(), got.end());
   }
-  std::vector<int> pos(nm, 0);
-  for (int i = 0; i < n; ++i) {  // the ordered merge: each member's records are already in ITS submission order
-    const int k = g->owner[i];
-    out[i] = got[k][pos[k]++];
+  *n_out = pop_in_order(g, out, n);
+  return RVT_OK;
+}
+
+int rvt_group_collect_ready(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
+  if (!g || !out || !n_out) return RVT_E_INVALID;
+  *n_out = 0;
+  if (g->owner.empty() || cap <= 0) return RVT_OK;
+  std::vector<rvt_gene_result> got(256);
+  for (size_t k = 0; k < g->member.size(); ++k) {
+    for (;;) {  // whatever the member has finished, without waiting
+      int nk = 0;
+      const int rc = rvt_collect_ready(g->member[k], got.data(), (int)got.size(), &nk);
+      if (rc) return gfail(g, rc, "rvt_collect_ready", g->member[k]);
+      if (nk == 0) break;
+      g->inbox[k].insert(g->inbox[k].end(), got.begin(), got.begin() + nk);
+    }
   }
-  g->owner.erase(g->owner.begin(), g->owner.begin() + n);
-  *n_out = n;
+  *n_out = pop_in_order(g, out, cap);
   return RVT_OK;
 }
 

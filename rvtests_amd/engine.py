@@ -160,6 +160,8 @@ def load_library():
                                       c_double_p]
     L.rvt_collect.restype = C.c_int
     L.rvt_collect.argtypes = [vp, C.POINTER(GeneResult), C.c_int, c_int_p]
+    L.rvt_collect_ready.restype = C.c_int
+    L.rvt_collect_ready.argtypes = [vp, C.POINTER(GeneResult), C.c_int, c_int_p]
     L.rvt_debug_collapse.restype = C.c_int
     L.rvt_debug_collapse.argtypes = [vp, vp, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p]
     L.rvt_debug_suffstat.restype = C.c_int
@@ -228,6 +230,8 @@ def load_library():
                                             c_double_p]
     L.rvt_group_collect.restype = C.c_int
     L.rvt_group_collect.argtypes = [gp, C.POINTER(GeneResult), C.c_int, c_int_p]
+    L.rvt_group_collect_ready.restype = C.c_int
+    L.rvt_group_collect_ready.argtypes = [gp, C.POINTER(GeneResult), C.c_int, c_int_p]
     L.rvt_group_set_kinship.restype = C.c_int
     L.rvt_group_set_kinship.argtypes = [gp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rvt_group_fit_fam_null.restype = C.c_int
@@ -425,6 +429,13 @@ class Engine:
         self._check(self.L.rvt_collect(self.ctx, out, cap, C.byref(n)))
         return list(out[: n.value])
 
+    def collect_ready(self, cap=4096):
+        """The finished prefix of the submitted genes, without waiting (rvt_collect_ready); may be empty."""
+        out = (GeneResult * cap)()
+        n = C.c_int(0)
+        self._check(self.L.rvt_collect_ready(self.ctx, out, cap, C.byref(n)))
+        return list(out[: n.value])
+
     # ---- inspection ------------------------------------------------------------------------------------------
     def debug_collapse(self, ptr, M):
         cmc = np.zeros(self.N)
@@ -619,6 +630,12 @@ class Group:
         out = (GeneResult * cap)()
         n = C.c_int(0)
         self._check(self.L.rvt_group_collect(self.g, out, cap, C.byref(n)))
+        return list(out[: n.value])
+
+    def collect_ready(self, cap=4096):
+        out = (GeneResult * cap)()
+        n = C.c_int(0)
+        self._check(self.L.rvt_group_collect_ready(self.g, out, cap, C.byref(n)))
         return list(out[: n.value])
 
     def set_kinship(self, U, S):

@@ -161,3 +161,22 @@ def test_streaming_submissions_take_the_hardcall_path(engine):
         rc3, c = orc.burden(G, X, y, 0, 0)
         assert abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14 and abs(r.skato_p - o.pvalue) <= 1e-6 * o.pvalue + 5e-13
         assert r.cmc_nonref == c.nonref_site and abs(r.cmc_p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
+
+
+def test_collect_ready_returns_finished_prefix_without_draining(engine):
+    """rvt_collect_ready: only finished genes, in submission order, nothing lost; rvt_collect gets the rest."""
+    N, d = 3000, 2
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=77)
+    engine.set_null(0, X, res, v, s2)
+    genes = [_hard_gene(N, 5 + (g % 40), seed=900 + g) for g in range(70)]
+    got = []
+    for g, (G, af) in enumerate(genes):
+        engine.submit_gene(500 + g, G, af)
+        if g % 10 == 9:
+            got += engine.collect_ready()
+    assert len(got) <= 64                     # the last, incomplete group of 16 cannot have been launched
+    got += engine.collect()
+    assert [r.gene_id for r in got] == [500 + g for g in range(70)]
+    for r, (G, af) in zip(got[::9], genes[::9]):
+        rc, a = orc.skat(G, af, X, res, v, 0)
+        assert abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14
