@@ -399,11 +399,11 @@ def main():
         key = "N=%d,genes=%d,m=%d..%d,seed=20260002,tests=%d" % (N, args.genes, args.m_lo, args.m_hi, args.tests)
         if binary:
             key += ",binary"
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == key:
-                k2 = pmc["kernels"]["suffstat"]
+            k2 = pmc["kernels"].get("suffstat_hc" if k2_name == "gene_suffstat_hc" else "suffstat")
+            if pmc.get("workload") == key and k2:
                 traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
         line = {
             "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",

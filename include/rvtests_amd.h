@@ -236,8 +236,8 @@ int rvt_collect_ready(rvt_ctx* ctx, rvt_gene_result* out, int cap, int* n_out);
  * installed by rvt_set_null (trait, X with intercept, sigma2 / v).  Synchronous. */
 int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
 /* The same numbers for windows wider than one block (unrelated samples): heads = columns [col0, col0+H) of `dG`,
- * markers = columns [col0, col0+W), W >= H, no limit on W other than memory.  Two plain GEMMs (rocBLAS) replace the
- * symmetric block kernel.  cov[(h-col0) + (j-col0)*H] for j >= h; xz: W x d; polymorphic: W. */
+ * markers = columns [col0, col0+W), W >= H, no limit on W other than memory.  Two integer-plane products
+ * (rvtests_amd/csrc/rot_gemm.hip.h) replace the symmetric block kernel.  cov[(h-col0) + (j-col0)*H] for j >= h; xz: W x d; polymorphic: W. */
 int rvt_cov_rect(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
                  int* polymorphic);
 /* ---- MetaScore: single-variant score statistics (unrelated samples) ----------------------------------------------
@@ -334,6 +334,11 @@ int rvt_run_fam_tests(rvt_ctx* ctx, int n_genes, const double* const* dG, const 
  * of rvt_fit_fam_null; xz is V x d, zz d x d (d = columns of X).  For the binary family variant (MetaCovFamBinary) call
  * rvt_fam_binary_scale first. */
 int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic);
+/* The family counterpart of rvt_cov_rect (windows wider than one block): heads [col0, col0 + H) against markers
+ * [col0, col0 + W) of the RAW block; the columns are rotated by U' on the device.  Same outputs as rvt_cov_rect (xz: W x d,
+ * d = columns of X). */
+int rvt_cov_rect_fam(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                     int* polymorphic);
 /* MetaCovFamBinary (src/Model.cpp:595-692): after rvt_fit_fam_null on the 0/1 phenotype, scale everything
  * rvt_cov_block_fam returns by b^2, b = obtainB(alpha) = integral of logistic'(alpha + x) phi(x) dx
  * (src/Model.cpp:339-369; the reference uses gsl_integration_qagi with epsrel 1e-7), alpha = log(n_case / n_ctrl) kept

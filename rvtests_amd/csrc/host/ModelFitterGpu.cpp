@@ -768,10 +768,6 @@ void MetaCovTest::writeFootnote(TextSink* fp) {
 
 // Double the device ring (a window can hold more sites than the current block).
 int MetaCovTest::grow() {
-  if (useFamilyModel) {
-    lastError = "MetaCov with kinship: one window holds more sites than the device block (RVT_MAX_VARIANTS)";
-    return -1;
-  }
   const int want = std::min(maxColumns, capacity * 2);
   if (want <= capacity) {
     lastError = "MetaCov: one window holds more sites than RVT_METACOV_MAX_COLUMNS allows";
@@ -840,7 +836,7 @@ int MetaCovTest::flush(bool final) {
     fout->write(sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[last].pos) + "\t" +
                 std::to_string(num) + "\t" + positions + "\t" + values + "\n");
   };
-  if (V <= rectAbove || useFamilyModel) {
+  if (V <= rectAbove) {
     // the whole ring is one block of the symmetric kernel
     std::vector<double> cov((size_t)V * V), xz((size_t)V * d);
     std::vector<int> poly(V);
@@ -868,7 +864,8 @@ int MetaCovTest::flush(bool final) {
       const int nh = h1 - h0, W = jmax - h0 + 1;
       std::vector<double> cov((size_t)nh * W), xz((size_t)W * d);
       std::vector<int> poly(W);
-      if (rvt_cov_rect(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())) {
+      if (useFamilyModel ? rvt_cov_rect_fam(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())
+                         : rvt_cov_rect(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())) {
         lastError = rvt_last_error(ctx);
         return -1;
       }

@@ -541,6 +541,39 @@ __global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const 
   }
 }
 
+// family mode of the two rectangle kernels (MetaCovFamQtl on rotated data, regression/FastLMM.cpp:510-595): T holds
+// G~_W' D [U'X | u1] (W x (d + 1), column-major), cs the RAW column sums; see CovConsts for the centring algebra
+__global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
+                                       double* __restrict__ xz, double* __restrict__ t1) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W) return;
+  const double m = cs[j] * cc.inv_n;
+  for (int k = 0; k < cc.d; ++k) xz[(long long)j * cc.d + k] = T[j + (long long)k * W] - m * cc.zsum[k];
+  t1[j] = T[j + (long long)cc.d * W];
+}
+__global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts cc, const double* __restrict__ S,
+                                                                const double* __restrict__ cs,
+                                                                const double* __restrict__ xz,
+                                                                const double* __restrict__ t1, int H, int W,
+                                                                double* __restrict__ cov) {
+  const int h = blockIdx.x, d = cc.d;
+  __shared__ double a[RVT_MAX_COV];
+  if (threadIdx.x < d) {
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
+    a[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double mh = cs[h] * cc.inv_n, t1h = t1[h];
+  for (int j = h + threadIdx.x; j < W; j += blockDim.x) {
+    const double mj = cs[j] * cc.inv_n;
+    const double xx = S[h + (long long)j * H] - mh * t1[j] - mj * t1h + mh * mj * cc.c11;
+    double quad = 0.0;
+    for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
+    cov[h + (long long)j * H] = xx - quad;
+  }
+}
+
 // dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)
 __global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
                                   long long ld, double* __restrict__ dst) {

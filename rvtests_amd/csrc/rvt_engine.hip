@@ -2743,6 +2743,87 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   return RVT_OK;
 }
 
+// MetaCov with kinship for windows wider than one block (MetaCovFamQtl / MetaCovFamBinary, src/Model.cpp:437-504,595-692):
+// heads [col0, col0 + H) against markers [col0, col0 + W) of the RAW block dG.  The W columns are rotated by U'
+// (integer planes), then S = (D G~_H)' G~_W and T = G~_W' D [U'X | u1] are two more integer-plane products and the
+// centring algebra of the block kernel finishes the rows.  Same outputs as rvt_cov_rect.
+int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                     int* polymorphic) {
+  if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t N = c->fam_nc.N, ld = c->fam_nc.ld;
+  const int du = c->famcov_nc.d - 2;  // columns of U'X
+  CovConsts cc;
+  std::vector<double> zzv;
+  {
+    const NullConsts keep = c->nc;
+    c->nc = c->famcov_nc;
+    rc = cov_constants(c, true, &cc, &zzv);
+    c->nc = keep;
+    if (rc) return rc;
+  }
+  rc = ensure_fam_cols(c, (size_t)W, ld);
+  if (rc) return rc;
+  const double* GW = dG + (size_t)col0 * ld;
+  double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_w = nullptr, *d_t1 = nullptr;
+  int* d_poly = nullptr;
+  struct Guard {
+    std::vector<void**> p;
+    ~Guard() {
+      for (void** q : p)
+        if (*q) hipFree(*q);
+    }
+  } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_w, (void**)&d_t1,
+           (void**)&d_poly}};
+  HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * (du + 1)));
+  HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * du));
+  HIP_TRY(c, hipMalloc((void**)&d_t1, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_w, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H)));
+  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * W, st));
+  rc = rotate_columns(c, GW, ld, W, c->d_Gt, ld, st);
+  if (rc) return rc;
+  // the weights D = 1 / ((|lambda| + delta) sigma2) ride on the small operands: D [U'X | u1] and D G~_H
+  HIP_TRY(c, hipMemsetAsync(d_w, 0, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H), st));
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)(du + 1)), dim3(256), 0, st, c->d_cX, c->d_cv, (long long)N,
+                     (long long)ld, d_w);
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)H), dim3(256), 0, st, c->d_Gt, c->d_cv, (long long)N,
+                     (long long)ld, d_w + (size_t)ld * (du + 1));
+  rc = gemm_tn_planes(c, c->d_Gt, ld, W, d_w, ld, du + 1, N, d_T, W, st);
+  if (rc) return rc;
+  rc = gemm_tn_planes(c, d_w + (size_t)ld * (du + 1), ld, H, c->d_Gt, ld, W, N, d_S, H, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cov_rect_fam_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz,
+                     d_t1);
+  hipLaunchKernelGGL(cov_rect_fam_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, d_t1, H, W,
+                     d_cov);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * du, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)du * du);
+  if (c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
+    const double b2 = c->famcov_b2;
+    for (int h = 0; h < H; ++h)
+      for (int j = h; j < W; ++j) cov[(size_t)h + (size_t)j * H] *= b2;
+    for (size_t i = 0; i < (size_t)W * du; ++i) xz[i] *= b2;
+    if (zz)
+      for (int i = 0; i < du * du; ++i) zz[i] *= b2;
+  }
+  return RVT_OK;
+}
+
 int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* src, int src_col, int ncols) {
   if (!c || !dst || !src || dst_col < 0 || src_col < 0 || ncols < 0) return fail(c, RVT_E_INVALID, "bad copy");
   if (ncols == 0) return RVT_OK;

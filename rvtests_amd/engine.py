@@ -185,6 +185,8 @@ def load_library():
                                     C.POINTER(GeneResult)]
     L.rvt_cov_rect.restype = C.c_int
     L.rvt_cov_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
+    L.rvt_cov_rect_fam.restype = C.c_int
+    L.rvt_cov_rect_fam.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_block_copy_columns.restype = C.c_int
     L.rvt_block_copy_columns.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
     L.rvt_cov_block_fam.restype = C.c_int
@@ -551,6 +553,16 @@ class Engine:
         poly = np.zeros(W, dtype=np.int32)
         self._check(self.L.rvt_cov_rect(self.ctx, C.c_void_p(int(ptr)), int(col0), int(H), int(W), _dp(cov), _dp(xz),
                                         _dp(zz), poly.ctypes.data_as(c_int_p)))
+        return cov, xz, zz, poly
+
+    def cov_rect_fam(self, ptr, col0, H, W, d):
+        """Family-mode heads x window rectangle (after set_kinship + fit_fam_null); d = columns of X."""
+        cov = np.full((H, W), np.nan, order="F")
+        xz = np.zeros((W, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(W, dtype=np.int32)
+        self._check(self.L.rvt_cov_rect_fam(self.ctx, C.c_void_p(int(ptr)), int(col0), int(H), int(W), _dp(cov), _dp(xz),
+                                            _dp(zz), poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
 
     def cov_block_fam(self, ptr, V, d):

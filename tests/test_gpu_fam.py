@@ -122,6 +122,50 @@ def test_metacov_fam_binary_scale(eng):
     assert np.allclose(zz, ozz, rtol=1e-6)
 
 
+@pytest.mark.parametrize("n_fam,d,V,col0,H,binary", [(40, 2, 60, 0, 60, 0), (60, 3, 110, 17, 40, 0),
+                                                      (50, 2, 48, 5, 9, 1)])
+def test_metacov_fam_rectangle_matches_block_and_oracle(eng, n_fam, d, V, col0, H, binary):
+    """rvt_cov_rect_fam (windows wider than one block: integer-plane products of the rotated columns) against the block
+    kernel on the same columns and against the oracle's MetaCovFamQtl / MetaCovFamBinary restatement."""
+    N, K, U, S, X, y = make_family_case(n_fam, d, 150 + d)
+    if binary:
+        y = (y > np.median(y)).astype(np.float64)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    if binary:
+        eng.fam_binary_scale(int(y.sum()), int(N - y.sum()))
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(d):
+        onul.beta[k] = nul.beta[k]
+    _, G, af = synth.make_gene(N, V, seed=900 + V, missing=0.02, common=True, mono=True)
+    pos = np.cumsum(np.random.default_rng(8).integers(1, 300, V)).astype(np.int32)
+    chrom = np.ones(V, dtype=np.int32)
+    ptr = eng.upload_block(G)
+    W = V - col0
+    bcov, bxz, bzz, bpoly = eng.cov_block_fam(ptr, V, d)
+    rcov, rxz, rzz, rpoly = eng.cov_rect_fam(ptr, col0, H, W, d)
+    assert (rpoly == bpoly[col0:]).all()
+    scale = np.abs(bcov[~np.isnan(bcov)]).max()
+    for h in range(H):
+        a, b = rcov[h, h:], bcov[col0 + h, col0 + h:]
+        assert np.abs(a - b).max() <= 1e-9 * scale, h
+    assert np.allclose(rxz, bxz[col0:], rtol=1e-8, atol=1e-9 * max(np.abs(bxz).max(), 1.0))
+    assert np.allclose(rzz, bzz, rtol=1e-12)
+    if binary:
+        rc, kept, ocov, row_end, oxz, ozz = orc.metacov_fam_binary(G, chrom, pos, X, y, U, S, onul, 10 ** 7)
+        tol = 1e-6
+    else:
+        rc, kept, ocov, row_end, oxz, ozz = orc.metacov_fam(G, chrom, pos, X, U, S, onul, 10 ** 7)
+        tol = 1e-8
+    assert rc == 0
+    sub = ocov[col0:col0 + H, col0:]
+    m = ~np.isnan(sub)
+    assert m.sum() > H
+    assert np.abs(rcov[m] - sub[m]).max() < tol * np.abs(sub[m]).max()
+
+
 @pytest.mark.parametrize("n_fam,d", [(40, 2), (70, 3)])
 def test_fam_burden_matches_oracle(eng, n_fam, d):
     """FamCMC / FamZeggini (collapse + FastLMM score test + GLS allele frequency) together with FamSKAT in one call."""

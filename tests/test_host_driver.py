@@ -298,8 +298,10 @@ def test_driver_skat_with_permutations(tmp_path):
 
 
 @pytest.mark.gpu
-def test_driver_metacov_with_kinship(tmp_path):
-    """--meta cov with a kinship decomposition: MetaCovFamQtl through the adapter (rows and numbers vs the oracle)."""
+@pytest.mark.parametrize("rect", [None, 8])
+def test_driver_metacov_with_kinship(tmp_path, rect):
+    """--meta cov with a kinship decomposition: MetaCovFamQtl through the adapter (rows and numbers vs the oracle);
+    rect = 8 forces the heads x window rectangles (rvt_cov_rect_fam) that windows wider than one block take."""
     _ensure_driver()
     from test_fam_cpu import make_family_case
     N, K, U, S, X, y = make_family_case(45, 2, 61)
@@ -318,8 +320,12 @@ def test_driver_metacov_with_kinship(tmp_path):
     with open(sites, "w") as f:
         for p_ in pos:
             f.write("1 %d\n" % p_)
+    env = dict(os.environ)
+    if rect:
+        env["RVT_METACOV_RECT_ABOVE"] = str(rect)
+        env["RVT_METACOV_BLOCK"] = str(rect)
     p = subprocess.run([DRIVER, path, "-", "-", "cov[windowSize=1000]", sites, kin], capture_output=True, text=True,
-                       timeout=300)
+                       timeout=300, env=env)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.splitlines()
     assert lines[0] == "== out.MetaCov.assoc"

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): everything committed under profiles/ for one round.
+# usage: tools/collect_profiles_all.sh <tag>    -> gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r2}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+tools/collect_profiles.sh "$TAG" > "$OUT/collect.log" 2>&1
+stats() {  # stats <name> <program args...>: rocprofv3 kernel statistics of one tool run
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$name" -o k -- "$@" > "$OUT/$name.log" 2>&1
+  find "$OUT/kt_$name" -name '*kernel_stats.csv' -exec cp {} "$OUT/${name}_kernel_stats.csv" \;
+  rm -rf "$OUT/kt_$name"
+}
+stats famskat python3 tools/bench_famskat.py --samples 100000 --genes 128
+stats metascore python3 tools/bench_metascore.py
+stats perm python3 tools/bench_perm.py
+stats stream_bed python3 tools/bench_stream.py --bed --genes 512
+./tools/k2hc_bench bench > "$OUT/k2hc_isolated.txt" 2>&1
+./tools/rotgemm_bench bench > "$OUT/rotgemm.txt" 2>&1
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1 > "$OUT/bench_config1.json" 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --trait binary --samples 200000 > "$OUT/bench_config3_binary.json" 2>/dev/null
+ls -la "$OUT"

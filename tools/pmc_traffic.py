@@ -25,7 +25,12 @@ def main():
     f, w = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     fam = {}
     for k in f:
-        tag = "suffstat" if "gene_suffstat" in k else k.split("rvt::")[1].split("(")[0].split("<")[0]
+        if "gene_suffstat_hc" in k:
+            tag = "suffstat_hc"
+        elif "gene_suffstat" in k:
+            tag = "suffstat"
+        else:
+            tag = k.split("rvt::")[1].split("(")[0].split("<")[0]
         e = fam.setdefault(tag, {"dispatches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
         e["dispatches"] += f[k][0]
         e["fetch_bytes"] += 2.0 * 1024.0 * f[k][1]
@@ -35,7 +40,7 @@ def main():
         e["launches_per_step"] = e["dispatches"] / batches
     json.dump({"workload": key, "batches": batches, "correction": "FETCH_SIZE x2 (gfx950), x1024 B; WRITE_SIZE x1024 B",
                "kernels": fam}, open(outp, "w"), indent=1)
-    print(json.dumps(fam["suffstat"]))
+    print(json.dumps({k: fam[k] for k in ("suffstat_hc", "suffstat") if k in fam}))
 
 
 if __name__ == "__main__":
