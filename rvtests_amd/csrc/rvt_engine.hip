@@ -1528,16 +1528,24 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
   const int nrp = (nA + kRotBM - 1) / kRotBM, nct = (nB + kRotBN - 1) / kRotBN;
   const long long sets = (long long)((nrp + 31) / 32) * ((nct + 7) / 8);
   const long long kbytes = (n_rows + kRotKC - 1) / kRotKC * kRotKC;
+  // the kernel accumulates a whole K range in int32: |digit| <= 64 (several planes) or <= 127 (one plane of small
+  // integers), so ranges longer than 2^31 / (bound_A bound_B) samples are cut and added in fp64
+  const long long bound = (long long)(PA == 1 ? 127 : 64) * (PB == 1 ? 127 : 64);
+  long long kmax = std::max<long long>(kRotKC, ((1LL << 31) - 1) / bound / kRotKC * kRotKC);
+  if (const char* e = getenv("RVT_ROT_KMAX"))  // tests: force the cut on small problems
+    kmax = std::max<long long>(kRotKC, std::min<long long>(kmax, atoll(e) / kRotKC * kRotKC));
   int first = 1;
   for (int sdeg = 0; sdeg <= (PA - 1) + (PB - 1); ++sdeg)  // least significant digit pairs first
     for (int p = 0; p < PA; ++p) {
       const int q = sdeg - p;
       if (q < 0 || q >= PB) continue;
-      hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(512), 0, st,
-                         (const int8_t*)(A + (size_t)p * a_stride), (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk,
-                         kbytes, C, (long long)ldc, nA, nB, nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)),
-                         first ? 0 : 1);
-      first = 0;
+      for (long long k0 = 0; k0 < kbytes; k0 += kmax) {
+        hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(512), 0, st,
+                           (const int8_t*)(A + (size_t)p * a_stride + k0), (const int8_t*)(B + (size_t)q * b_stride + k0),
+                           (long long)ldk, std::min(kmax, kbytes - k0), C, (long long)ldc, nA, nB, nrp, nct,
+                           c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1);
+        first = 0;
+      }
     }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_stream(st));  // (the scale arrays are reused by the next call)

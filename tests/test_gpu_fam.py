@@ -198,3 +198,25 @@ def test_fam_burden_matches_oracle(eng, n_fam, d):
         assert r.famskat_ok == (1 if rc == 0 else 0)
         if rc == 0:
             assert abs(r.famskat_Q - s.Q) <= 1e-7 * s.Q
+
+
+def test_rotation_k_range_cut_is_exact(monkeypatch):
+    """The integer GEMM accumulates a K range in int32 and cuts ranges that could overflow (planes_gemm); with the cut
+    forced to 128 samples the rotated statistics must not change by more than the fp64 re-association of the pieces."""
+    import rvtests_amd
+    N, K, U, S, X, y = make_family_case(60, 2, 11)
+    genes = [synth.make_gene(N, M, seed=700 + M, missing=0.02, common=True)[1] for M in (9, 31)]
+    outs = []
+    for kmax in (None, "128"):
+        if kmax:
+            monkeypatch.setenv("RVT_ROT_KMAX", kmax)
+        e = rvtests_amd.Engine(0)
+        try:
+            e.set_kinship(U, S)
+            e.fit_fam_null(X, y)
+            ptrs = [e.upload_block(G) for G in genes]
+            outs.append([(r.famskat_Q, r.famskat_p) for r in e.run_fam_blocks(ptrs, [G.shape[1] for G in genes])])
+        finally:
+            e.close()
+    for (q0, p0), (q1, p1) in zip(*outs):
+        assert abs(q0 - q1) <= 1e-12 * abs(q0) and abs(p0 - p1) <= 1e-9 * p0 + 1e-14
