@@ -365,6 +365,33 @@ int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, u
 int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                         const rvt_params* params, double* af_out);
 
+/* ---- VCF text at the boundary (SURVEY §8f "next" #1: the genotype front end) -------------------------------------------
+ * Replaces the per-sample loop of VCFGenotypeExtractor::extractMultipleGenotype (src/VCFGenotypeExtractor.cpp:29-140) for
+ * hard calls: the caller hands over the TEXT of the sample columns of each record of a gene; splitting at tabs and ':',
+ * VCFValue::getGenotype (libVcf/VCFValue.h:74-117; '.', multi-allelic or malformed calls -> missing, haploid calls -> 0 / 1),
+ * the GD / GQ filters (src/VCFGenotypeExtractor.cpp:304-317) and then everything rvt_submit_gene_i8 does (allele
+ * frequencies, mean imputation) run on the device.  Not provided: dosage tags, multi-allelic mode, the hemizygous
+ * (non-PAR X) recoding by sex.
+ *   rvt_vcf_locate      host-only helper: offset of the first sample column of a record line and the FORMAT indices
+ *                       of GT / GD / GQ by VCFRecord::getFormatIndex's prefix rule (libVcf/VCFRecord.h:280-305); -1 = absent
+ *   rvt_vcf_set_samples once per file: row_of_sample[s] = row of the analysis (0 .. N-1) that sample column s of the
+ *                       file feeds, -1 = sample not analysed (VCFPeople include / exclude); every row exactly once
+ *   rvt_vcf_set_filters GDmin / GDmax / GQmin / GQmax, <= 0 = off
+ *   rvt_submit_gene_vcf per record j: sample_text[j] = first byte of the first sample column, text_len[j] = bytes up to
+ *                       (not including) the end of line, gt_index[j] (and gd_index / gq_index, may be NULL) from
+ *                       rvt_vcf_locate.  The text is consumed before the call returns.  A record whose column count
+ *                       differs from the file's sample count is reported by a later submit / collect (RVT_E_INVALID). */
+int rvt_vcf_locate(const char* line, int64_t len, int64_t* sample_off, int* gt_index, int* gd_index, int* gq_index);
+int rvt_vcf_set_samples(rvt_ctx* ctx, int n_file_samples, const int32_t* row_of_sample);
+int rvt_vcf_set_filters(rvt_ctx* ctx, int gd_min, int gd_max, int gq_min, int gq_max);
+int rvt_submit_gene_vcf(rvt_ctx* ctx, int64_t gene_id, int M, const char* const* sample_text, const int64_t* text_len,
+                        const int* gt_index, const int* gd_index, const int* gq_index, uint32_t tests,
+                        const rvt_params* params, double* af_out);
+/* decode only (synchronous): out = N x M signed bytes, column-major, N = rows of the sample map; 0 / 1 / 2, missing = -9
+ * — VCFGenotypeExtractor's matrix before consolidate(), one byte per genotype */
+int rvt_vcf_decode(rvt_ctx* ctx, int M, const char* const* sample_text, const int64_t* text_len, const int* gt_index,
+                   const int* gd_index, const int* gq_index, int8_t* out);
+
 /* ---- device groups: several GPUs of one node behind one calling thread ---------------------------------------------------
  * Genes are independent units that share only the null model, so a group is one engine context per device
  * (rvtests_amd/csrc/rvt_group.cpp): the null model / kinship decomposition is installed on every member, the gene stream is
@@ -391,6 +418,11 @@ int rvt_group_submit_gene_i8(rvt_group* group, int64_t gene_id, int M, const int
                              const rvt_params* params, double* af_out);
 int rvt_group_submit_gene_bed(rvt_group* group, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                               const rvt_params* params, double* af_out);
+int rvt_group_vcf_set_samples(rvt_group* group, int n_file_samples, const int32_t* row_of_sample);
+int rvt_group_vcf_set_filters(rvt_group* group, int gd_min, int gd_max, int gq_min, int gq_max);
+int rvt_group_submit_gene_vcf(rvt_group* group, int64_t gene_id, int M, const char* const* sample_text,
+                              const int64_t* text_len, const int* gt_index, const int* gd_index, const int* gq_index,
+                              uint32_t tests, const rvt_params* params, double* af_out);
 int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
 int rvt_group_collect_ready(rvt_group* group, rvt_gene_result* out, int cap, int* n_out); /* cf. rvt_collect_ready */
 /* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host

@@ -137,6 +137,113 @@ __global__ __launch_bounds__(512, 2) void rot_gemm_i8_kernel(const int8_t* __res
   }
 }
 
+// ---- version 2: LDS-DMA staging, configurable register blocking --------------------------------------------------------
+// Same contract and workgroup-to-tile mapping as rot_gemm_i8_kernel.  Differences:
+//   * the K chunks go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers and no
+//     ds_write_b128 pass — a wide LDS store costs ~13 LDS-path cycles per wave-instruction against 4 for a wide read, and
+//     in version 1 the stores took more LDS time than the fragment reads).  The DMA writes lane-linear (base + 16 lane),
+//     so the XOR swizzle is applied to the SOURCE address: the lane that fills slot p of row r fetches segment
+//     p ^ ((r >> 2) & 3), and the fragment reads use the same involution (rot_lds_off);
+//   * WM x WN waves of TM x TN 32x32 tiles each: BM = 32 WM TM rows, BN = 32 WN TN columns.  A k-step of one wave is
+//     TM + TN fragment reads for TM TN matrix instructions (version 1: 4 for 4).
+template <int WM, int WN, int TM, int TN>
+struct RotCfg {
+  static constexpr int kWaves = WM * WN, kThreads = 64 * kWaves;
+  static constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static constexpr int kPieces = (BM + BN) / 16;             // 1 KiB pieces (16 rows x 64 B) per K chunk
+  static constexpr int kPiecesPerWave = kPieces / kWaves;
+  static constexpr int kStageBytes = (BM + BN) * kRotKC;
+  static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
+};
+
+template <int WM, int WN, int TM, int TN, int MINB>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_v2_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, long long ldk, long long kbytes, double* __restrict__ C,
+    long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
+    const double* __restrict__ row_scale, double weight, int accumulate) {
+  using Cfg = RotCfg<WM, WN, TM, TN>;
+  __shared__ __attribute__((aligned(1024))) char lds[2][Cfg::kStageBytes];
+  const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
+  const int n_ctg = (n_col_tiles + 7) / 8;
+  const int set = w >> 5, within = w & 31;
+  const int ctg = set % n_ctg, rpg = set / n_ctg;
+  const int rp = (rpg * 8 + xcd) * 4 + (within & 3), ct = ctg * 8 + (within >> 2);
+  if (rp >= n_row_panels || ct >= n_col_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long m0 = (long long)rp * Cfg::BM, n0 = (long long)ct * Cfg::BN;
+  // ---- LDS-DMA sources: piece P = wave + kWaves q covers rows 16 P .. 16 P + 15 of [A rows | B rows] -------------------
+  const int8_t* gsrc[Cfg::kPiecesPerWave];
+#pragma unroll
+  for (int q = 0; q < Cfg::kPiecesPerWave; ++q) {
+    const int P = wave + Cfg::kWaves * q;
+    const int r = 16 * P + (lane >> 2), slot = lane & 3, seg = slot ^ ((r >> 2) & 3);
+    gsrc[q] = (r < Cfg::BM ? A + (m0 + r) * ldk : B + (n0 + (r - Cfg::BM)) * ldk) + seg * 16;
+  }
+  auto stage = [&](int buf, long long kc) {
+#pragma unroll
+    for (int q = 0; q < Cfg::kPiecesPerWave; ++q) {
+      const int P = wave + Cfg::kWaves * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * kRotKC),
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
+    }
+  };
+  i16v_t acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+  const long long nchunks = kbytes / kRotKC;
+  stage(0, 0);
+  __syncthreads();  // (its fence waits for the DMA: vmcnt(0))
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (long long kc = 0; kc < nchunks; ++kc) {
+    const int cur = (int)(kc & 1);
+    if (kc + 1 < nchunks) stage(cur ^ 1, kc + 1);
+    const char* la = &lds[cur][0];
+    const char* lb = &lds[cur][Cfg::BM * 64];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      i4v_t fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        fa[a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        fb[b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();  // chunk kc + 1 has landed (vmcnt(0) in the fence) and every wave is done with buffer `cur`
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const long long j = n0 + wn * 32 * TN + b * 32 + (lane & 31);
+    if (j >= N) continue;
+    const double sc = weight * col_scale[j];
+    double* cj = C + j * ldc;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long long m = m0 + wm * 32 * TM + a * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (m + e < M) {
+            const double v = (double)acc[a][b][4 * g + e] * (row_scale ? sc * row_scale[m + e] : sc);
+            cj[m + e] = accumulate ? cj[m + e] + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- digits ------------------------------------------------------------------------------------------------------------
 // q = sum_p d_p 128^p, d_p in [-64, 63]
 __device__ __forceinline__ void rot_digits(long long q, int planes, signed char* d) {

@@ -33,6 +33,7 @@ void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N,
 #include "fam_kernels.hip.h"
 #include "rot_gemm.hip.h"
 #include "perm_kernels.hip.h"
+#include "vcf_kernels.hip.h"
 
 using namespace rvt;
 
@@ -135,6 +136,17 @@ struct rvt_ctx {
   int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
+  // VCF text front end (vcf_kernels.hip.h)
+  char* d_vcf_text = nullptr;
+  size_t vcf_text_cap = 0;
+  VcfRecord* d_vcf_rec = nullptr;
+  int* d_vcf_seg = nullptr;
+  size_t vcf_seg_cap = 0;
+  int* d_vcf_rows = nullptr;   // output row of every sample column of the file (-1: not analysed)
+  int vcf_n_file = 0;
+  int64_t vcf_n_rows = 0;      // rows the map addresses (must equal the null model's N)
+  VcfFilters vcf_flt{0, 0, 0, 0};
+  int* h_vcf_err = nullptr;    // pinned, device-visible: record index + 1 of a record with a wrong column count
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
   uint32_t rand_state[31];
   int64_t jump_N = -1;                 // J = A^(jump_N - 1) is cached for this sample count
@@ -579,6 +591,11 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_af_ring) hipFree(c->d_af_ring);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
+  if (c->d_vcf_text) hipFree(c->d_vcf_text);
+  if (c->d_vcf_rec) hipFree(c->d_vcf_rec);
+  if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
+  if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
+  if (c->h_vcf_err) hipHostFree(c->h_vcf_err);
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
@@ -2986,6 +3003,68 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
 namespace {
 // mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto);
 // 3: PLINK 2-bit codes (ditto)
+// VCF text of one gene -> N x M signed bytes in c->d_consol_i8 (vcf_kernels.hip.h), on stream st
+struct VcfGene {
+  const char* const* text;  // per record: first byte of the first sample column
+  const int64_t* len;       // per record: bytes up to (not including) the end of line
+  const int* gt_idx;        // per record: FORMAT index of GT (-1: absent -> every genotype missing)
+  const int* gd_idx;        // may be NULL (-1)
+  const int* gq_idx;        // may be NULL (-1)
+};
+int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t st) {
+  std::vector<VcfRecord> rec(M);
+  size_t total = 0;
+  int64_t max_len = 0;
+  for (int j = 0; j < M; ++j) {
+    rec[j].text_off = (long long)total;
+    rec[j].len = vg->len[j];
+    rec[j].gt_idx = vg->gt_idx[j];
+    rec[j].gd_idx = vg->gd_idx ? vg->gd_idx[j] : -1;
+    rec[j].gq_idx = vg->gq_idx ? vg->gq_idx[j] : -1;
+    rec[j].pad = 0;
+    total += ((size_t)vg->len[j] + 31) / 16 * 16;  // 16-byte aligned starts, >= 16 readable bytes behind the end
+    max_len = std::max<int64_t>(max_len, vg->len[j]);
+  }
+  if (c->vcf_text_cap < total) {
+    if (c->d_vcf_text) hipFree(c->d_vcf_text);
+    c->d_vcf_text = nullptr;
+    c->vcf_text_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_vcf_text, total + total / 4));
+    c->vcf_text_cap = total + total / 4;
+  }
+  if (!c->d_vcf_rec) HIP_TRY(c, hipMalloc((void**)&c->d_vcf_rec, sizeof(VcfRecord) * RVT_MAX_VARIANTS));
+  const int max_seg = (int)std::max<int64_t>(1, (max_len + kVcfSegBytes - 1) / kVcfSegBytes);
+  if (c->vcf_seg_cap < (size_t)max_seg * M) {
+    if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
+    c->d_vcf_seg = nullptr;
+    c->vcf_seg_cap = 0;
+    const size_t want = (size_t)max_seg * std::max(M, 64);
+    HIP_TRY(c, hipMalloc((void**)&c->d_vcf_seg, sizeof(int) * want));
+    c->vcf_seg_cap = want;
+  }
+  if (!c->h_vcf_err) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_vcf_err, sizeof(int), hipHostMallocMapped));
+    *c->h_vcf_err = 0;
+  }
+  for (int j = 0; j < M; ++j)  // (a copy from pageable memory returns once the source has been read)
+    if (vg->len[j] > 0)
+      HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j], hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, sync_stream(st));  // `rec` is a local
+  signed char* out = (signed char*)c->d_consol_i8;
+  HIP_TRY(c, hipMemsetAsync(out, 0xF7, (size_t)N * M, st));  // -9: rows the sample map never addresses stay missing
+  int* d_err = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_vcf_err, 0));
+  const dim3 grid((unsigned)max_seg, (unsigned)M);
+  hipLaunchKernelGGL(vcf_tab_count_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg);
+  hipLaunchKernelGGL(vcf_tab_scan_kernel, dim3((unsigned)M), dim3(256), 0, st, c->d_vcf_rec, max_seg, c->vcf_n_file,
+                     c->d_vcf_seg, d_err);
+  hipLaunchKernelGGL(vcf_decode_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg,
+                     c->d_vcf_rows, c->vcf_n_file, (long long)N, c->vcf_flt, out);
+  HIP_TRY(c, hipGetLastError());
+  return RVT_OK;
+}
+
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
   if (!c || !G || M < 1 || (mode == 0 && !af)) return fail(c, RVT_E_INVALID, "bad gene");
@@ -3066,7 +3145,8 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       hipLaunchKernelGGL((consolidate_write_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
                          (long long)ld, d_fill, p.dG);
     } else {
-      // packed hard calls: one byte per genotype (mode 2) or PLINK's 2-bit codes, ceil(N/4) bytes per variant (mode 3)
+      // packed hard calls: one byte per genotype (mode 2; mode 4 decodes VCF text into that form first) or PLINK's
+      // 2-bit codes, ceil(N/4) bytes per variant (mode 3)
       const size_t col_bytes = (mode == 3) ? (size_t)((N + 3) / 4) : (size_t)N;
       const size_t bytes8 = col_bytes * M;
       if (c->consol_i8_cap < bytes8) {
@@ -3076,7 +3156,11 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         e = hipMalloc((void**)&c->d_consol_i8, bytes8 + bytes8 / 4);
         if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
       }
-      if (e == hipSuccess) e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && mode == 4) {
+        if (vcf_decode_gene(c, (const VcfGene*)G, M, N, st) != RVT_OK) e = hipErrorUnknown;
+      } else if (e == hipSuccess) {
+        e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
+      }
       if (e == hipSuccess && mode == 3) {
         const bed2_t* sb = (const bed2_t*)c->d_consol_i8;
         const long long cb = (long long)col_bytes;
@@ -3175,6 +3259,126 @@ int rvt_submit_gene_raw(rvt_ctx* c, int64_t gene_id, int M, const double* Graw, 
 int rvt_submit_gene_i8(rvt_ctx* c, int64_t gene_id, int M, const int8_t* G8, uint32_t tests, const rvt_params* prm,
                        double* af_out) {
   return submit_common(c, gene_id, M, G8, 2, nullptr, af_out, tests, prm);
+}
+
+// ---- VCF text front end ----------------------------------------------------------------------------------------------
+int rvt_vcf_set_samples(rvt_ctx* c, int n_file_samples, const int32_t* row_of_sample) {
+  if (!c || n_file_samples < 1 || !row_of_sample) return fail(c, RVT_E_INVALID, "bad sample map");
+  hipSetDevice(c->device);
+  int64_t rows = 0;
+  for (int i = 0; i < n_file_samples; ++i) rows = std::max<int64_t>(rows, (int64_t)row_of_sample[i] + 1);
+  std::vector<char> seen((size_t)rows, 0);
+  for (int i = 0; i < n_file_samples; ++i) {
+    const int r = row_of_sample[i];
+    if (r < 0) continue;
+    if (seen[r]) return fail(c, RVT_E_INVALID, "sample map: row %d addressed twice", r);
+    seen[r] = 1;
+  }
+  for (int64_t r = 0; r < rows; ++r)
+    if (!seen[r]) return fail(c, RVT_E_INVALID, "sample map: row %lld is never addressed", (long long)r);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
+  c->d_vcf_rows = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&c->d_vcf_rows, sizeof(int) * (size_t)n_file_samples));
+  HIP_TRY(c, hipMemcpy(c->d_vcf_rows, row_of_sample, sizeof(int) * (size_t)n_file_samples, hipMemcpyHostToDevice));
+  c->vcf_n_file = n_file_samples;
+  c->vcf_n_rows = rows;
+  return RVT_OK;
+}
+
+int rvt_vcf_set_filters(rvt_ctx* c, int gd_min, int gd_max, int gq_min, int gq_max) {
+  if (!c) return RVT_E_INVALID;
+  c->vcf_flt = VcfFilters{gd_min, gd_max, gq_min, gq_max};
+  return RVT_OK;
+}
+
+int rvt_submit_gene_vcf(rvt_ctx* c, int64_t gene_id, int M, const char* const* sample_text, const int64_t* text_len,
+                        const int* gt_index, const int* gd_index, const int* gq_index, uint32_t tests,
+                        const rvt_params* prm, double* af_out) {
+  if (!c || !sample_text || !text_len || !gt_index || M < 1) return fail(c, RVT_E_INVALID, "bad gene");
+  if (!c->d_vcf_rows) return fail(c, RVT_E_STATE, "rvt_vcf_set_samples first");
+  if (c->have_null && c->vcf_n_rows != c->nc.N)
+    return fail(c, RVT_E_STATE, "the sample map addresses %lld rows, the null model has %lld samples",
+                (long long)c->vcf_n_rows, (long long)c->nc.N);
+  for (int j = 0; j < M; ++j)
+    if (!sample_text[j] || text_len[j] < 0) return fail(c, RVT_E_INVALID, "record %d: no text", j);
+  if (c->h_vcf_err && *c->h_vcf_err) {
+    const int k = *c->h_vcf_err;
+    *c->h_vcf_err = 0;
+    return fail(c, RVT_E_INVALID, "VCF record %d of an earlier gene does not hold %d sample columns", k - 1, c->vcf_n_file);
+  }
+  VcfGene vg{sample_text, text_len, gt_index, gd_index, gq_index};
+  return submit_common(c, gene_id, M, &vg, 4, nullptr, af_out, tests, prm);
+}
+
+// Decode only: the N x M signed bytes (column-major) the device reads out of the text, copied back to the caller.
+int rvt_vcf_decode(rvt_ctx* c, int M, const char* const* sample_text, const int64_t* text_len, const int* gt_index,
+                   const int* gd_index, const int* gq_index, int8_t* out) {
+  if (!c || !sample_text || !text_len || !gt_index || !out || M < 1 || M > RVT_MAX_VARIANTS)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->d_vcf_rows) return fail(c, RVT_E_STATE, "rvt_vcf_set_samples first");
+  hipSetDevice(c->device);
+  const int64_t N = c->vcf_n_rows;
+  const size_t bytes8 = (size_t)N * M;
+  hipStream_t st = c->io_stream;
+  HIP_TRY(c, sync_stream(st));
+  if (c->consol_i8_cap < bytes8) {
+    if (c->d_consol_i8) hipFree(c->d_consol_i8);
+    c->d_consol_i8 = nullptr;
+    c->consol_i8_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_consol_i8, bytes8 + bytes8 / 4));
+    c->consol_i8_cap = bytes8 + bytes8 / 4;
+  }
+  VcfGene vg{sample_text, text_len, gt_index, gd_index, gq_index};
+  int rc = vcf_decode_gene(c, &vg, M, N, st);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_consol_i8, bytes8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  if (*c->h_vcf_err) {
+    const int k = *c->h_vcf_err;
+    *c->h_vcf_err = 0;
+    return fail(c, RVT_E_INVALID, "VCF record %d does not hold %d sample columns", k - 1, c->vcf_n_file);
+  }
+  return RVT_OK;
+}
+
+// Host-only helper: the first nine columns of one record.  *sample_off = offset of the first sample column; FORMAT
+// indices by VCFRecord::getFormatIndex's rule (libVcf/VCFRecord.h:280-305: the key matches when the FORMAT entry
+// STARTS with it).  Returns RVT_E_INVALID when the line has fewer than ten columns.
+int rvt_vcf_locate(const char* line, int64_t len, int64_t* sample_off, int* gt_index, int* gd_index, int* gq_index) {
+  if (!line || len < 0 || !sample_off) return RVT_E_INVALID;
+  int64_t p = 0, fmt_b = -1, fmt_e = -1;
+  int tabs = 0;
+  for (; p < len && tabs < 9; ++p)
+    if (line[p] == '\t') {
+      ++tabs;
+      if (tabs == 8) fmt_b = p + 1;
+      if (tabs == 9) fmt_e = p;
+    }
+  if (tabs < 9) return RVT_E_INVALID;
+  *sample_off = p;
+  auto index_of = [&](const char* key) {
+    int64_t b = fmt_b;
+    int idx = 0;
+    while (b < fmt_e) {
+      bool match = true;
+      for (int i = 0; key[i]; ++i)
+        if (b + i >= len || line[b + i] != key[i]) {
+          match = false;
+          break;
+        }
+      if (match) return idx;
+      ++idx;
+      while (line[b++] != ':')
+        if (b >= fmt_e) return -1;
+    }
+    return -1;
+  };
+  if (gt_index) *gt_index = index_of("GT");
+  if (gd_index) *gd_index = index_of("GD");
+  if (gq_index) *gq_index = index_of("GQ");
+  return RVT_OK;
 }
 
 // hand the first n queue entries (all launched and finished) to the caller, recycle their blocks

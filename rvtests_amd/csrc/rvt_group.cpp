@@ -122,6 +122,25 @@ int rvt_group_submit_gene_bed(rvt_group* g, int64_t gene_id, int M, const unsign
   RVT_GROUP_SUBMIT(rvt_submit_gene_bed(m, gene_id, M, bed, tests, params, af_out))
 }
 
+int rvt_group_vcf_set_samples(rvt_group* g, int n_file_samples, const int32_t* row_of_sample) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member) {
+    const int rc = rvt_vcf_set_samples(m, n_file_samples, row_of_sample);
+    if (rc) return gfail(g, rc, "rvt_vcf_set_samples", m);
+  }
+  return RVT_OK;
+}
+int rvt_group_vcf_set_filters(rvt_group* g, int gd_min, int gd_max, int gq_min, int gq_max) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member) rvt_vcf_set_filters(m, gd_min, gd_max, gq_min, gq_max);
+  return RVT_OK;
+}
+int rvt_group_submit_gene_vcf(rvt_group* g, int64_t gene_id, int M, const char* const* sample_text,
+                              const int64_t* text_len, const int* gt_index, const int* gd_index, const int* gq_index,
+                              uint32_t tests, const rvt_params* params, double* af_out) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene_vcf(m, gene_id, M, sample_text, text_len, gt_index, gd_index, gq_index, tests, params, af_out))
+}
+
 // the ordered merge: each member's records arrive in ITS submission order; hand out the global prefix
 static int pop_in_order(rvt_group* g, rvt_gene_result* out, int cap) {
   int n = 0;

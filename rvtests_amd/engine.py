@@ -227,6 +227,26 @@ def load_library():
     L.rvt_group_submit_gene_i8.restype = C.c_int
     L.rvt_group_submit_gene_i8.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(Params),
                                            c_double_p]
+    c_i64_p = C.POINTER(C.c_int64)
+    L.rvt_vcf_locate.restype = C.c_int
+    L.rvt_vcf_locate.argtypes = [C.c_char_p, C.c_int64, c_i64_p, c_int_p, c_int_p, c_int_p]
+    L.rvt_vcf_set_samples.restype = C.c_int
+    L.rvt_vcf_set_samples.argtypes = [vp, C.c_int, c_int_p]
+    L.rvt_vcf_set_filters.restype = C.c_int
+    L.rvt_vcf_set_filters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rvt_submit_gene_vcf.restype = C.c_int
+    L.rvt_submit_gene_vcf.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p, c_int_p,
+                                      C.c_uint32, C.POINTER(Params), c_double_p]
+    L.rvt_vcf_decode.restype = C.c_int
+    L.rvt_vcf_decode.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p, c_int_p,
+                                 C.POINTER(C.c_int8)]
+    L.rvt_group_vcf_set_samples.restype = C.c_int
+    L.rvt_group_vcf_set_samples.argtypes = [gp, C.c_int, c_int_p]
+    L.rvt_group_vcf_set_filters.restype = C.c_int
+    L.rvt_group_vcf_set_filters.argtypes = [gp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rvt_group_submit_gene_vcf.restype = C.c_int
+    L.rvt_group_submit_gene_vcf.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p,
+                                            c_int_p, C.c_uint32, C.POINTER(Params), c_double_p]
     L.rvt_group_submit_gene_bed.restype = C.c_int
     L.rvt_group_submit_gene_bed.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(Params),
                                             c_double_p]
@@ -253,6 +273,16 @@ def load_library():
 
 def _dp(a):
     return a.ctypes.data_as(c_double_p)
+
+
+def vcf_locate(L, line):
+    """(offset of the first sample column, GT index, GD index, GQ index) of one VCF record line (rvt_vcf_locate)."""
+    off = C.c_int64(0)
+    gt, gd, gq = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    rc = L.rvt_vcf_locate(line, len(line), C.byref(off), C.byref(gt), C.byref(gd), C.byref(gq))
+    if rc:
+        raise ValueError("not a VCF record with sample columns")
+    return off.value, gt.value, gd.value, gq.value
 
 
 class Engine:
@@ -406,6 +436,47 @@ class Engine:
         af = np.zeros(M) if want_af else None
         self._check(self.L.rvt_submit_gene_bed(self.ctx, int(gene_id), int(M), bed.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
+        return af
+
+    def vcf_set_samples(self, row_of_sample):
+        rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)
+        self._check(self.L.rvt_vcf_set_samples(self.ctx, len(rows), rows.ctypes.data_as(c_int_p)))
+
+    def vcf_set_filters(self, gd_min=0, gd_max=0, gq_min=0, gq_max=0):
+        self._check(self.L.rvt_vcf_set_filters(self.ctx, int(gd_min), int(gd_max), int(gq_min), int(gq_max)))
+
+    def _vcf_args(self, lines):
+        M = len(lines)
+        keep = []                                     # the buffers must stay alive for the call
+        text = (C.c_char_p * M)()
+        tlen = (C.c_int64 * M)()
+        gt = (C.c_int * M)()
+        gd = (C.c_int * M)()
+        gq = (C.c_int * M)()
+        for j, ln in enumerate(lines):
+            off, a, b, c_ = vcf_locate(self.L, ln)
+            body = ln[off:]
+            keep.append(body)
+            text[j] = body
+            tlen[j] = len(body)
+            gt[j], gd[j], gq[j] = a, b, c_
+        return M, keep, text, tlen, gt, gd, gq
+
+    def vcf_decode(self, lines, n_rows):
+        """Genotype bytes (n_rows x M int8, missing = -9) the device reads out of the records' text."""
+        M, keep, text, tlen, gt, gd, gq = self._vcf_args(lines)
+        out = np.zeros((n_rows, M), dtype=np.int8, order="F")
+        self._check(self.L.rvt_vcf_decode(self.ctx, M, text, tlen, gt, gd, gq, out.ctypes.data_as(C.POINTER(C.c_int8))))
+        return out
+
+    def submit_gene_vcf(self, gene_id, lines, tests=TEST_ALL, params=None, want_af=True):
+        """lines: the full text of the gene's VCF records (bytes, no newline).  rvt_vcf_locate finds the sample columns
+        and the FORMAT indices on the host; the device decodes the genotypes (rvt_submit_gene_vcf)."""
+        prm = params or Params.default()
+        M, keep, text, tlen, gt, gd, gq = self._vcf_args(lines)
+        af = np.zeros(M) if want_af else None
+        self._check(self.L.rvt_submit_gene_vcf(self.ctx, int(gene_id), M, text, tlen, gt, gd, gq, int(tests),
+                                               C.byref(prm), _dp(af) if want_af else None))
         return af
 
     def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None, want_af=True):

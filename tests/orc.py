@@ -446,3 +446,54 @@ def fastlmm_covb(X, U, S, delta, use_float=False):
     L.orc_fastlmm_covb.restype = C.c_int
     rc = L.orc_fastlmm_covb(_dp(X), C.c_int64(N), d, _dp(U), _dp(S), C.c_double(delta), int(use_float), _dp(out))
     return rc, out
+
+
+# ---- VCF genotype text rules (oracle/orc_vcf.cpp; reference fragment oracle/_ref/libref_vcf.so) -----------------------
+_ref_vcf = None
+
+
+def ref_vcf():
+    """The reference's own libVcf value / individual parsers, or None where they are not built."""
+    global _ref_vcf
+    if _ref_vcf is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_vcf.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference/libVcf"):
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+            else:
+                return None
+        R = C.CDLL(path)
+        R.ref_vcf_column_genotype.restype = C.c_int
+        R.ref_vcf_column_genotype.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        R.ref_vcf_column_int.restype = C.c_int
+        R.ref_vcf_column_int.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        _ref_vcf = R
+    return _ref_vcf
+
+
+def vcf_column_genotype(col, gt_idx):
+    L = lib()
+    L.orc_vcf_column_genotype.restype = C.c_int
+    L.orc_vcf_column_genotype.argtypes = [C.c_char_p, C.c_int64, C.c_int]
+    return L.orc_vcf_column_genotype(col, len(col), gt_idx)
+
+
+def vcf_format_index(fmt, key):
+    L = lib()
+    L.orc_vcf_format_index.restype = C.c_int
+    L.orc_vcf_format_index.argtypes = [C.c_char_p, C.c_int64, C.c_char_p]
+    return L.orc_vcf_format_index(fmt, len(fmt), key)
+
+
+def vcf_decode_record(text, row_of_sample, n_rows, gt_idx, gd_idx=-1, gq_idx=-1, filters=(0, 0, 0, 0)):
+    """(codes[n_rows] int8 with -9 where no column addressed the row, number of columns found)."""
+    L = lib()
+    L.orc_vcf_decode_record.restype = C.c_int
+    L.orc_vcf_decode_record.argtypes = [C.c_char_p, C.c_int64, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, c_int_p,
+                                        C.POINTER(C.c_int8)]
+    rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)
+    flt = np.ascontiguousarray(filters, dtype=np.int32)
+    out = np.full(n_rows, -9, dtype=np.int8)
+    n = L.orc_vcf_decode_record(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), gt_idx, gd_idx, gq_idx,
+                                flt.ctypes.data_as(c_int_p), out.ctypes.data_as(C.POINTER(C.c_int8)))
+    return out, n

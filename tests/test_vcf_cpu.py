@@ -1,0 +1,92 @@
+"""CPU: the VCF genotype text rules.  oracle/orc_vcf.cpp against the REFERENCE's own libVcf parsers compiled where they
+lie (oracle/_ref/libref_vcf.so) on an exhaustive set of short columns, against the committed golden vector of the same
+set (tests/golden/vcf_genotype.json, for machines without the reference tree), and the host-side record locator of the
+C ABI against the oracle's restatement of VCFRecord::getFormatIndex."""
+import ctypes as C
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import vcfgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "vcf_genotype.json")
+ALPHABET = b"012./|-A:"
+
+
+def enumerate_columns(max_len=4):
+    """Every string over ALPHABET up to max_len bytes that is not malformed in the ways the reference itself cannot
+    handle (empty column, trailing ':')."""
+    for n in range(1, max_len + 1):
+        for t in itertools.product(ALPHABET, repeat=n):
+            if t[-1] == ord(":"):
+                continue
+            yield bytes(t)
+
+
+def test_oracle_matches_golden_vector():
+    g = json.load(open(GOLDEN))
+    assert g["alphabet"] == ALPHABET.decode() and g["max_len"] == 4
+    cols = list(enumerate_columns(4))
+    for idx in (0, 1, 2):
+        want = g["codes"][str(idx)]
+        assert len(want) == len(cols)
+        got = "".join("m" if (c := orc.vcf_column_genotype(col, idx)) < 0 else str(c) for col in cols)
+        assert got == want
+
+
+def test_oracle_matches_compiled_reference_exhaustively():
+    R = orc.ref_vcf()
+    if R is None:
+        pytest.skip("reference tree not present: the golden vector covers this machine")
+    n = 0
+    for col in enumerate_columns(5):
+        for idx in (0, 1, 2):
+            assert orc.vcf_column_genotype(col, idx) == R.ref_vcf_column_genotype(col, len(col), idx), (col, idx)
+            n += 1
+    assert n > 150000
+    for col in vcfgen.GT_POOL:                       # bytes >= 0x80 compare as negative chars on the host
+        assert orc.vcf_column_genotype(col, 0) == R.ref_vcf_column_genotype(col, len(col), 0), col
+    # the integer subfields the GD / GQ filters read (atoi of the NUL-terminated subfield; "." when absent)
+    for col, idx, want in [(b"0/1:17:40", 1, 17), (b"0/1:17:40", 2, 40), (b"0/1:17", 2, 0), (b"0/1:.:3", 1, 0),
+                           (b"0/1: 7x", 1, 7), (b"0/1:-4", 1, -4)]:
+        assert R.ref_vcf_column_int(col, len(col), idx) == want
+
+
+def test_filters_and_record_walk():
+    text = b"0/1:5:30\t1/1:20:10\t0/0\t./.:9:9\t0/1:12"
+    rows = np.array([2, 0, -1, 1, 3], dtype=np.int32)
+    out, n = orc.vcf_decode_record(text, rows, 4, 0)
+    assert n == 5 and out.tolist() == [2, -9, 1, 1]
+    out, n = orc.vcf_decode_record(text, rows, 4, 0, gd_idx=1, gq_idx=2, filters=(10, 0, 0, 0))
+    assert out.tolist() == [2, -9, -9, 1]            # depth 5 < 10 -> missing; absent GD in column 3 is excluded anyway
+    out, n = orc.vcf_decode_record(text, rows, 4, 0, gd_idx=1, gq_idx=2, filters=(0, 15, 0, 0))
+    assert out.tolist() == [-9, -9, 1, 1]            # depth 20 > GDmax
+    out, n = orc.vcf_decode_record(text, rows, 4, 0, gd_idx=1, gq_idx=2, filters=(0, 0, 20, 0))
+    assert out.tolist() == [-9, -9, 1, -9]           # GQ 10 < 20; column without GQ: atoi(".") = 0 < 20
+    out, n = orc.vcf_decode_record(text, rows, 4, -1)
+    assert (out == -9).all()                         # no GT key in FORMAT
+
+
+def _lib():
+    import rvtests_amd.engine as e
+    return e.load_library()
+
+
+def test_locate_matches_format_index_rule():
+    L = _lib()
+    import rvtests_amd.engine as e
+    for fmt in (b"GT", b"GT:DP:GQ", b"DP:GT", b"GD:GT:GQ", b"GTX:GT", b"DP:GDX:GQ", b"DP", b"A:B:GQ:GT:GD"):
+        line = b"1\t100\trs1\tA\tG\t.\tPASS\tAC=1\t" + fmt + b"\t0/1\t1/1"
+        off, gt, gd, gq = e.vcf_locate(L, line)
+        assert line[off:] == b"0/1\t1/1"
+        assert gt == orc.vcf_format_index(fmt, b"GT")
+        assert gd == orc.vcf_format_index(fmt, b"GD")
+        assert gq == orc.vcf_format_index(fmt, b"GQ")
+    assert orc.vcf_format_index(b"GTX:GT", b"GT") == 0           # the reference's prefix match
+    with pytest.raises(ValueError):
+        e.vcf_locate(L, b"1\t100\trs1\tA\tG\t.\tPASS\tAC=1")     # no FORMAT / sample columns
