@@ -197,14 +197,22 @@ def parity_summary(recs, gpu):
 def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
     """Secondary figures: the same hot path fed from HOST memory through the ModelFitter-style streaming calls (what a
     drop-in rvtests run does): pageable fp64 blocks (rvt_submit_gene, 8 B per genotype over PCIe), int8 hard calls
-    (rvt_submit_gene_i8, 1 B) and PLINK 2-bit rows (rvt_submit_gene_bed, 1/4 B); records are taken with
+    (rvt_submit_gene_i8, 1 B), PLINK 2-bit rows (rvt_submit_gene_bed, 1/4 B) and the TEXT of the VCF records
+    (rvt_submit_gene_vcf: "0/1<tab>" = 4 B per genotype, split and decoded on the device); records are taken with
     rvt_collect_ready while the stream runs (no drain) and rvt_collect at the end."""
     ks = [k for k in range(len(Ms)) if 40 <= Ms[k] <= 60][:4] or list(range(min(4, len(Ms))))
     host = [np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()) for k in ks]
     hard = [np.rint(h) for h in host]
     out = {}
-    for mode in ("fp64", "int8", "bed2bit"):
-        if mode == "int8":
+    for mode in ("fp64", "int8", "bed2bit", "vcf_text"):
+        if mode == "vcf_text":
+            lut = np.array([b"0/0", b"0/1", b"1/1"])
+            head = b"1\t1000\t.\tA\tG\t50\tPASS\t.\tGT\t"
+            eng.vcf_set_samples(np.arange(N, dtype=np.int32))
+            data = [eng.prepare_vcf([head + b"\t".join(lut[h[:, j].astype(np.int64)].tolist())
+                                     for j in range(h.shape[1])]) for h in hard]
+            nbytes = [sum(len(ln) for ln in d[1]) for d in data]
+        elif mode == "int8":
             data = [np.asfortranarray(h.astype(np.int8)) for h in hard]
         elif mode == "bed2bit":
             data = [eng.pack_bed(h) for h in hard]
@@ -218,14 +226,16 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
                 eng.submit_gene(g, data[i], afs[ks[i]])
             elif mode == "int8":
                 eng.submit_gene_raw(g, data[i], want_af=False)
+            elif mode == "vcf_text":
+                eng.submit_gene_vcf(g, data[i], want_af=False)
             else:
                 eng.submit_gene_bed(g, data[i], Ms[ks[i]], want_af=False)
             if (g + 1) % window == 0:
                 done += len(eng.collect_ready())
         done += len(eng.collect())
         dt = time.perf_counter() - t0
-        out[mode] = {"gene_sets_per_s": done / dt, "genes": done,
-                     "host_GBps": sum(d.nbytes for d in data) / len(data) * done / dt / 1e9}
+        per_gene = (sum(nbytes) if mode == "vcf_text" else sum(d.nbytes for d in data)) / len(data)
+        out[mode] = {"gene_sets_per_s": done / dt, "genes": done, "host_GBps": per_gene * done / dt / 1e9}
     return out
 
 

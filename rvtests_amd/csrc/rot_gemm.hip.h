@@ -15,154 +15,53 @@
 // N = 100 000) instead of 8 N^2 as doubles.
 //
 // Kernel: TN GEMM, both operands contiguous along the contraction (sample) index.  Workgroup tile 256 (rows of U') x
-// 128 (columns), K chunks of 64 bytes staged through LDS (XOR-swizzled 16-byte segments: conflict-free ds_read_b128 in
-// the MFMA operand layout), register prefetch of the next chunk, double-buffered LDS, 8 waves of 64 x 64.  Workgroups
-// are mapped so that the 32 workgroups resident on one XCD work on 4 row panels x 8 column tiles at a time: every
-// operand chunk is fetched from HBM once per XCD and shared through its L2.
+// 256 (columns), 8 waves as 2 x 4, each wave 4 x 2 tiles of v_mfma_i32_32x32x32_i8 (6 fragment reads per 8 matrix
+// instructions).  K is consumed in chunks of 128 bytes — whole cache lines — that go from global memory straight into
+// LDS (global_load_lds_dwordx4: no staging registers, no ds_write pass); the DMA writes lane-linear, so the XOR swizzle
+// of the 16-byte segments of a row (slot = seg ^ ((row >> 1) & 7): the 16 lanes of a ds_read_b128 group hit 16
+// different (row parity, slot) pairs = all 64 banks) is applied to the SOURCE address and again by the fragment reads.
+// Two LDS stages (128 KB): iteration kc waits (counted vmcnt) for its own chunk, passes ONE raw barrier — after which
+// every wave is done with chunk kc - 1, whose buffer is refilled at once — and computes; the fragments of k-step s + 1
+// are requested before the matrix instructions of k-step s.  Workgroups are mapped so that the 32 workgroups resident
+// on one XCD work on 4 row panels x 8 column tiles at a time: every operand chunk is fetched from HBM once per XCD and
+// shared through its L2.
+// Measured ladder at N = 100 000, T = 3840 (tools/rotgemm_bench, POP/s per plane pair): 256 x 128 tile, 2 x 2 tiles per
+// wave, register staging + ds_write, 64-byte chunks 1.23; the same with LDS-DMA 1.24 (the stores were not the limit);
+// 256 x 256 tile, 4 x 2 per wave 1.79; + 3 stages with counted vmcnt 2.01; + 128-byte chunks and fragment prefetch 2.11.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace rvt {
 
-constexpr int kRotBM = 256, kRotBN = 128, kRotKC = 64;  // workgroup tile and K chunk (bytes)
-constexpr int kRotPlanesU = 6;                           // digits of U
-constexpr int kRotPlanesG = 6;                           // digits of a non-integer column
+constexpr int kRotBM = 256, kRotBN = 256, kRotKC = 128;  // workgroup tile and K chunk (bytes)
+constexpr int kRotPlanesU = 6;                            // digits of U
+constexpr int kRotPlanesG = 6;                            // digits of a non-integer column
 
 typedef int i16v_t __attribute__((ext_vector_type(16)));
 typedef int i4v_t __attribute__((ext_vector_type(4)));
 
-// position of the 16-byte segment `seg` (0..3) of row `row` inside a [rows][64 B] LDS tile
-__device__ __forceinline__ int rot_lds_off(int row, int seg) { return row * 64 + ((seg ^ ((row >> 2) & 3)) << 4); }
+// position of the 16-byte segment `seg` (0..7) of row `row` inside a [rows][128 B] LDS tile
+__device__ __forceinline__ int rot_lds_off(int row, int seg) { return row * 128 + ((seg ^ ((row >> 1) & 7)) << 4); }
 
-// One plane pair.  A: [Mpad rows][ldk] int8 (row m = column m of U), B: [Npad cols][ldk] int8, K = ldk rounded to 64.
-// C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j] [* row_scale[m]],  m < M, j < N.
-__global__ __launch_bounds__(512, 2) void rot_gemm_i8_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
-                                                             long long ldk, long long kbytes, double* __restrict__ C,
-                                                             long long ldc, int M, int N, int n_row_panels,
-                                                             int n_col_tiles, const double* __restrict__ col_scale,
-                                                             const double* __restrict__ row_scale, double weight,
-                                                             int accumulate) {
-  __shared__ __attribute__((aligned(16))) char lds[2][(kRotBM + kRotBN) * kRotKC];
-  // ---- tile of this workgroup: 32 consecutive workgroups of one XCD = 4 row panels x 8 column tiles ----------------
-  const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
-  const int n_ctg = (n_col_tiles + 7) / 8;           // column-tile groups
-  const int set = w >> 5, within = w & 31;
-  const int ctg = set % n_ctg, rpg = set / n_ctg;
-  const int rp = (rpg * 8 + xcd) * 4 + (within & 3), ct = ctg * 8 + (within >> 2);
-  if (rp >= n_row_panels || ct >= n_col_tiles) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;           // 4 x 2 waves of 64 x 64
-  const long long m0 = (long long)rp * kRotBM, n0 = (long long)ct * kRotBN;
-  // ---- global -> register prefetch: (256 + 128) rows x 4 segments = 1536 x 16 B, 3 per thread ------------------------
-  const int8_t* gsrc[3];
-  int ldst[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int idx = tid + 512 * r;  // 0 .. 1535
-    const int row = idx >> 2, seg = idx & 3;
-    if (row < kRotBM) {
-      gsrc[r] = A + (m0 + row) * ldk + seg * 16;
-      ldst[r] = rot_lds_off(row, seg);
-    } else {
-      gsrc[r] = B + (n0 + (row - kRotBM)) * ldk + seg * 16;
-      ldst[r] = kRotBM * 64 + rot_lds_off(row - kRotBM, seg);
-    }
-  }
-  i16v_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
-  const long long nchunks = kbytes / kRotKC;
-  i4v_t pre[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) pre[r] = *reinterpret_cast<const i4v_t*>(gsrc[r]);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) *reinterpret_cast<i4v_t*>(&lds[0][ldst[r]]) = pre[r];
-  __syncthreads();
-  const int lrow = lane & 31, lk = lane >> 5;
-  for (long long kc = 0; kc < nchunks; ++kc) {
-    const int cur = (int)(kc & 1);
-    if (kc + 1 < nchunks) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) pre[r] = *reinterpret_cast<const i4v_t*>(gsrc[r] + (kc + 1) * kRotKC);
-    }
-    const char* la = &lds[cur][0];
-    const char* lb = &lds[cur][kRotBM * 64];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      i4v_t fa[2], fb[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-        fa[a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 64 + a * 32 + lrow, ks * 2 + lk));
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        fb[b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 64 + b * 32 + lrow, ks * 2 + lk));
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    }
-    if (kc + 1 < nchunks) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) *reinterpret_cast<i4v_t*>(&lds[cur ^ 1][ldst[r]]) = pre[r];
-    }
-    __syncthreads();
-  }
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -----------------
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const long long j = n0 + wn * 64 + b * 32 + (lane & 31);
-    if (j >= N) continue;
-    const double sc = weight * col_scale[j];
-    double* cj = C + j * ldc;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long long m = m0 + wm * 64 + a * 32 + 8 * g + 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (m + e < M) {
-            const double v = (double)acc[a][b][4 * g + e] * (row_scale ? sc * row_scale[m + e] : sc);
-            cj[m + e] = accumulate ? cj[m + e] + v : v;
-          }
-        }
-      }
-    }
-  }
+template <int N>
+__device__ __forceinline__ void rot_wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// ---- version 2: LDS-DMA staging, configurable register blocking --------------------------------------------------------
-// Same contract and workgroup-to-tile mapping as rot_gemm_i8_kernel.  Differences:
-//   * the K chunks go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers and no
-//     ds_write_b128 pass — a wide LDS store costs ~13 LDS-path cycles per wave-instruction against 4 for a wide read, and
-//     in version 1 the stores took more LDS time than the fragment reads).  The DMA writes lane-linear (base + 16 lane),
-//     so the XOR swizzle is applied to the SOURCE address: the lane that fills slot p of row r fetches segment
-//     p ^ ((r >> 2) & 3), and the fragment reads use the same involution (rot_lds_off);
-//   * WM x WN waves of TM x TN 32x32 tiles each: BM = 32 WM TM rows, BN = 32 WN TN columns.  A k-step of one wave is
-//     TM + TN fragment reads for TM TN matrix instructions (version 1: 4 for 4).
-template <int WM, int WN, int TM, int TN>
-struct RotCfg {
-  static constexpr int kWaves = WM * WN, kThreads = 64 * kWaves;
-  static constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  static constexpr int kPieces = (BM + BN) / 16;             // 1 KiB pieces (16 rows x 64 B) per K chunk
-  static constexpr int kPiecesPerWave = kPieces / kWaves;
-  static constexpr int kStageBytes = (BM + BN) * kRotKC;
-  static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
-};
-
-template <int WM, int WN, int TM, int TN, int MINB>
-__global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_v2_kernel(
+// One plane pair.  A: [Mpad rows][ldk] int8 (row m = column m of U), B: [Npad cols][ldk] int8, kbytes = K rounded up to 128.
+// C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j] [* row_scale[m]],  m < M, j < N.
+// grid = sets * 256 workgroups, sets = ceil(n_row_panels / 32) * ceil(n_col_tiles / 8).
+template <int WM, int WN, int TM, int TN, int NST, int MINB>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, long long ldk, long long kbytes, double* __restrict__ C,
     long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
     const double* __restrict__ row_scale, double weight, int accumulate) {
-  using Cfg = RotCfg<WM, WN, TM, TN>;
-  __shared__ __attribute__((aligned(1024))) char lds[2][Cfg::kStageBytes];
+  constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
+  constexpr int kStage = (BM + BN) * kRotKC;
+  static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
+  __shared__ __attribute__((aligned(1024))) char lds[NST][kStage];
   const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
   const int n_ctg = (n_col_tiles + 7) / 8;
   const int set = w >> 5, within = w & 31;
@@ -171,19 +70,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_v2_kernel(
   if (rp >= n_row_panels || ct >= n_col_tiles) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const long long m0 = (long long)rp * Cfg::BM, n0 = (long long)ct * Cfg::BN;
-  // ---- LDS-DMA sources: piece P = wave + kWaves q covers rows 16 P .. 16 P + 15 of [A rows | B rows] -------------------
-  const int8_t* gsrc[Cfg::kPiecesPerWave];
+  const long long m0 = (long long)rp * BM, n0 = (long long)ct * BN;
+  const int8_t* gsrc[PPW];
 #pragma unroll
-  for (int q = 0; q < Cfg::kPiecesPerWave; ++q) {
-    const int P = wave + Cfg::kWaves * q;
-    const int r = 16 * P + (lane >> 2), slot = lane & 3, seg = slot ^ ((r >> 2) & 3);
-    gsrc[q] = (r < Cfg::BM ? A + (m0 + r) * ldk : B + (n0 + (r - Cfg::BM)) * ldk) + seg * 16;
+  for (int q = 0; q < PPW; ++q) {
+    const int P = wave + kWaves * q;
+    const int r = 8 * P + (lane >> 3), slot = lane & 7, seg = slot ^ ((r >> 1) & 7);
+    gsrc[q] = (r < BM ? A + (m0 + r) * ldk : B + (n0 + (r - BM)) * ldk) + seg * 16;
   }
   auto stage = [&](int buf, long long kc) {
 #pragma unroll
-    for (int q = 0; q < Cfg::kPiecesPerWave; ++q) {
-      const int P = wave + Cfg::kWaves * q;
+    for (int q = 0; q < PPW; ++q) {
+      const int P = wave + kWaves * q;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * kRotKC),
                                        (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
     }
@@ -196,31 +94,45 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_v2_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
   const long long nchunks = kbytes / kRotKC;
-  stage(0, 0);
-  __syncthreads();  // (its fence waits for the DMA: vmcnt(0))
-  const int lrow = lane & 31, lk = lane >> 5;
-  for (long long kc = 0; kc < nchunks; ++kc) {
-    const int cur = (int)(kc & 1);
-    if (kc + 1 < nchunks) stage(cur ^ 1, kc + 1);
-    const char* la = &lds[cur][0];
-    const char* lb = &lds[cur][Cfg::BM * 64];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      i4v_t fa[TM], fb[TN];
+  for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
+  const int lrow = lane & 31, lk = lane >> 5;
+  int cur = 0;
+  for (long long kc = 0; kc < nchunks; ++kc) {
+    rot_wait_vm_barrier<PPW*(NST - 2)>();
+    {
+      const long long nx = kc + NST - 1;
+      int buf = cur + NST - 1;
+      if (buf >= NST) buf -= NST;
+      stage(buf, nx < nchunks ? nx : nchunks - 1);
+    }
+    const char* la = &lds[cur][0];
+    const char* lb = &lds[cur][BM * 128];
+    i4v_t fa[2][TM], fb[2][TN];
+    auto frags = [&](int ks, int slot) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        fa[a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
+        fa[slot][a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        fb[b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+        fb[slot][b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads in front of this k-step's matrix instructions
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // chunk kc + 1 has landed (vmcnt(0) in the fence) and every wave is done with buffer `cur`
+    asm volatile("" ::: "memory");
+    if (++cur == NST) cur = 0;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const long long j = n0 + wn * 32 * TN + b * 32 + (lane & 31);
@@ -243,6 +155,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_v2_kernel(
     }
   }
 }
+
+// the shipped configuration
+#define rot_gemm_i8_kernel (rot_gemm_i8_kernel_t<2, 4, 4, 2, 2, 1>)
+constexpr int kRotThreads = 512;
 
 // ---- digits ------------------------------------------------------------------------------------------------------------
 // q = sum_p d_p 128^p, d_p in [-64, 63]

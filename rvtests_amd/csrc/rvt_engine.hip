@@ -1557,7 +1557,7 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
       const int q = sdeg - p;
       if (q < 0 || q >= PB) continue;
       for (long long k0 = 0; k0 < kbytes; k0 += kmax) {
-        hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(512), 0, st,
+        hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(kRotThreads), 0, st,
                            (const int8_t*)(A + (size_t)p * a_stride + k0), (const int8_t*)(B + (size_t)q * b_stride + k0),
                            (long long)ldk, std::min(kmax, kbytes - k0), C, (long long)ldc, nA, nB, nrp, nct,
                            c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1);

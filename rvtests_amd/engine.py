@@ -446,21 +446,25 @@ class Engine:
         self._check(self.L.rvt_vcf_set_filters(self.ctx, int(gd_min), int(gd_max), int(gq_min), int(gq_max)))
 
     def _vcf_args(self, lines):
+        """(M, keep-alive, text[], len[], gt[], gd[], gq[]) for the records `lines` (bytes, no newline); the text pointers
+        point INTO the caller's bytes objects (no copy).  A tuple returned earlier is accepted as is."""
+        if isinstance(lines, tuple):
+            return lines
         M = len(lines)
-        keep = []                                     # the buffers must stay alive for the call
         text = (C.c_char_p * M)()
+        addr = C.cast(text, C.POINTER(C.c_void_p))
         tlen = (C.c_int64 * M)()
         gt = (C.c_int * M)()
         gd = (C.c_int * M)()
         gq = (C.c_int * M)()
         for j, ln in enumerate(lines):
             off, a, b, c_ = vcf_locate(self.L, ln)
-            body = ln[off:]
-            keep.append(body)
-            text[j] = body
-            tlen[j] = len(body)
+            addr[j] = C.cast(C.c_char_p(ln), C.c_void_p).value + off
+            tlen[j] = len(ln) - off
             gt[j], gd[j], gq[j] = a, b, c_
-        return M, keep, text, tlen, gt, gd, gq
+        return M, list(lines), text, tlen, gt, gd, gq
+
+    prepare_vcf = _vcf_args
 
     def vcf_decode(self, lines, n_rows):
         """Genotype bytes (n_rows x M int8, missing = -9) the device reads out of the records' text."""

@@ -23,43 +23,27 @@ __global__ void fill_i8(signed char* p, long long n, unsigned long long seed, in
   }
 }
 
-static int g_variant = 0;  // 0: version 1; 1: v2 <4,2,2,2> (same tile, LDS-DMA); 2: v2 <2,2,4,2> (256 threads); 3: v2 <2,4,4,2> (256 x 256)
-static int variant_bn() { return g_variant == 3 ? 256 : kRotBN; }
 static void launch_gemm(const signed char* A, const signed char* B, long long ldk, long long kbytes, double* C, long long ldc,
                         int M, int N, const double* cs, double weight, int accumulate) {
-  const int BN = variant_bn();
-  const int nrp = (M + kRotBM - 1) / kRotBM, nct = (N + BN - 1) / BN;
+  const int nrp = (M + kRotBM - 1) / kRotBM, nct = (N + kRotBN - 1) / kRotBN;
   const int nrpg = (nrp + 31) / 32, nctg = (nct + 7) / 8;
   const long long sets = (long long)nrpg * nctg;
-  const dim3 grid((unsigned)(sets * 32 * 8));
-  const double* rs = nullptr;
-  if (g_variant == 0)
-    hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(512), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk, kbytes, C, ldc, M, N, nrp, nct,
-                       cs, rs, weight, accumulate);
-  else if (g_variant == 1)
-    hipLaunchKernelGGL((rot_gemm_i8_v2_kernel<4, 2, 2, 2, 2>), grid, dim3(512), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk, kbytes, C, ldc,
-                       M, N, nrp, nct, cs, rs, weight, accumulate);
-  else if (g_variant == 2)
-    hipLaunchKernelGGL((rot_gemm_i8_v2_kernel<2, 2, 4, 2, 2>), grid, dim3(256), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk, kbytes, C, ldc,
-                       M, N, nrp, nct, cs, rs, weight, accumulate);
-  else
-    hipLaunchKernelGGL((rot_gemm_i8_v2_kernel<2, 4, 4, 2, 1>), grid, dim3(512), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk, kbytes, C, ldc,
-                       M, N, nrp, nct, cs, rs, weight, accumulate);
+  hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 32 * 8)), dim3(kRotThreads), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk,
+                     kbytes, C, ldc, M, N, nrp, nct, cs, (const double*)nullptr, weight, accumulate);
 }
 
 int main(int argc, char** argv) {
   const bool bench_only = argc > 1 && !strcmp(argv[1], "bench");
   CK(hipSetDevice(0));
   int fails = 0;
-  for (g_variant = 0; g_variant < 4; ++g_variant) {
-  printf("== variant %d\n", g_variant);
+
   if (!bench_only) {
     struct Case { int n, M, T, general; };
     const Case cases[] = {{1000, 1000, 200, 0}, {777, 777, 130, 0}, {2048, 2048, 384, 0}, {1500, 1500, 70, 1}, {300, 300, 5, 0}};
     for (const Case& cs : cases) {
       const int n = cs.n, M = cs.M, T = cs.T, PU = kRotPlanesU, PG = cs.general ? kRotPlanesG : 1;
-      const long long ldk = (n + 127) / 128 * 128, kbytes = (n + 63) / 64 * 64;
-      const long long Mpad = (long long)(M + kRotBM - 1) / kRotBM * kRotBM, Tpad = (long long)(T + variant_bn() - 1) / variant_bn() * variant_bn();
+      const long long ldk = (n + 127) / 128 * 128, kbytes = (n + kRotKC - 1) / kRotKC * kRotKC;
+      const long long Mpad = (long long)(M + kRotBM - 1) / kRotBM * kRotBM, Tpad = (long long)(T + kRotBN - 1) / kRotBN * kRotBN;
       std::vector<float> U((size_t)n * M);
       std::vector<double> G((size_t)n * T);
       for (size_t i = 0; i < U.size(); ++i) {
@@ -148,8 +132,8 @@ int main(int argc, char** argv) {
     const long long sizes[] = {20000, 40000, 100000};
     for (long long n : sizes) {
       const int T = 3840;
-      const long long ldk = (n + 127) / 128 * 128, kbytes = (n + 63) / 64 * 64;
-      const long long Mpad = (n + kRotBM - 1) / kRotBM * kRotBM, Tpad = (long long)(T + variant_bn() - 1) / variant_bn() * variant_bn();
+      const long long ldk = (n + 127) / 128 * 128, kbytes = (n + kRotKC - 1) / kRotKC * kRotKC;
+      const long long Mpad = (n + kRotBM - 1) / kRotBM * kRotBM, Tpad = (long long)(T + kRotBN - 1) / kRotBN * kRotBN;
       signed char *dA, *dB; double *dC, *dcs;
       if (hipMalloc(&dA, (size_t)Mpad * ldk) != hipSuccess) { printf("skip n=%lld (no memory)\n", n); continue; }
       CK(hipMalloc(&dB, (size_t)Tpad * ldk));
@@ -175,7 +159,6 @@ int main(int argc, char** argv) {
              ms / reps, ops / (ms / reps * 1e-3) / 1e15, 6 * ms / reps, 128.0 / (6 * ms / reps * 1e-3));
       hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dcs);
     }
-  }
   }
   return fails ? 1 : 0;
 }
