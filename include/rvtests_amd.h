@@ -345,6 +345,25 @@ int rvt_cov_rect_fam(rvt_ctx* ctx, const double* dG, int col0, int H, int W, dou
  * as float, 500 without controls.  The factor stays until the next rvt_fit_fam_null.  Outputs may be NULL. */
 int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* alpha_out, double* b_out);
 
+/* ---- KinshipHolder::decompose on the device (SURVEY §8f "next" #3) -------------------------------------------------------
+ * Replaces base/KinshipHolder.cpp:270-290 (Eigen::SelfAdjointEigenSolver<MatrixXf> of the N x N kinship): K is the float
+ * matrix as KinshipHolder::load fills it (column-major, symmetric), S_out (N) receives the eigenvalues in ASCENDING order
+ * and U_out (N x N, column-major) the eigenvectors, as matS / matU hold them (either may be NULL).  install != 0 also
+ * installs the decomposition for the family tests (as rvt_set_kinship would) without a round trip through host
+ * memory.  fp64 one-sided block Jacobi (rvtests_amd/csrc/jacobi_kernels.hip.h); device memory 16 N^2 bytes while it runs.
+ * Eigenvectors of repeated eigenvalues are an arbitrary orthonormal basis of their eigenspace — exactly as for any
+ * eigensolver; every statistic of the family tests depends on U only through U f(S) U'. */
+typedef struct rvt_decompose_info {
+  int sweeps;            /* block-Jacobi sweeps */
+  double max_cosine;     /* largest cosine between two columns of K U in the last sweep (convergence: < 1e-10) */
+  int64_t padded_order;  /* order of the padded problem (multiple of 64) */
+  double shift;          /* 0, or the diagonal shift of the second attempt (taken when a residual of the first was large:
+                            nearly opposite eigenvalues, which a positive semi-definite kinship does not have) */
+  double max_residual;   /* largest ||K u - lambda u|| */
+} rvt_decompose_info;
+int rvt_kinship_decompose(rvt_ctx* ctx, int64_t N, const float* K, float* U_out, float* S_out, int install,
+                          rvt_decompose_info* info);
+
 /* ---- raw / packed genotypes at the boundary (SURVEY §8f "next" #1) --------------------------------------------------
  * Like rvt_submit_gene, but the block is what the genotype extractor produced, BEFORE DataConsolidator::consolidate:
  * missing genotypes are negative (-9, libVcf/VCFConstant.h:4).  The device then does what consolidate() does to the

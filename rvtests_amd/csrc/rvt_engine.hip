@@ -34,6 +34,7 @@ void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N,
 #include "rot_gemm.hip.h"
 #include "perm_kernels.hip.h"
 #include "vcf_kernels.hip.h"
+#include "jacobi_kernels.hip.h"
 
 using namespace rvt;
 
@@ -1439,7 +1440,8 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     for (int64_t k0 = 0; k0 < N; k0 += cols_per) {
       const int64_t nc = std::min(cols_per, N - k0);
       const size_t n = (size_t)nc * N;
-      HIP_TRY(c, hipMemcpyAsync(d_tmp, U + (size_t)k0 * N, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+      // (hipMemcpyDefault: rvt_kinship_decompose hands over eigenvectors that are already on the device)
+      HIP_TRY(c, hipMemcpyAsync(d_tmp, U + (size_t)k0 * N, sizeof(float) * n, hipMemcpyDefault, c->stream));
       hipLaunchKernelGGL(rot_quantize_f32_kernel, dim3(2048), dim3(256), 0, c->stream, d_tmp, (long long)N, (long long)nc,
                          (long long)N, c->uq_sexp, kRotPlanesU, c->d_Uq, (long long)c->uq_ldk, (long long)c->uq_plane,
                          (long long)k0, d_flag);
@@ -1462,6 +1464,127 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   HIP_TRY(c, hipMemcpy(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost));
   c->kin_N = N;
   c->have_kin = true;
+  return RVT_OK;
+}
+
+// ---- KinshipHolder::decompose on the device (jacobi_kernels.hip.h) ---------------------------------------------------------
+int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, float* S_out, int install,
+                          rvt_decompose_info* info) {
+  if (!c || !K || N < 2) return fail(c, RVT_E_INVALID, "bad kinship matrix");
+  if (N > (int64_t)1 << 20) return fail(c, RVT_E_TOO_LARGE, "kinship of %lld samples", (long long)N);
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t np = (N + kJacP - 1) / kJacP * kJacP;  // an even number of 32-column blocks
+  const int nb = (int)(np / kJacB), pairs = nb / 2;
+  // |lambda| <= max row sum of |K| (Gershgorin); the pad entries sit well outside
+  double mu = 0.0;
+  {
+    std::vector<double> rows((size_t)N, 0.0);
+    for (int64_t j = 0; j < N; ++j) {
+      const float* col = K + (size_t)j * N;
+      for (int64_t i = 0; i < N; ++i) {
+        if (!std::isfinite(col[i])) return fail(c, RVT_E_INVALID, "kinship matrix holds a non-finite entry");
+        rows[i] += std::fabs((double)col[i]);
+      }
+    }
+    for (int64_t i = 0; i < N; ++i) mu = std::max(mu, rows[i]);
+    mu = 4.0 * std::max(mu, 1e-300);
+  }
+  struct Bufs {
+    float* dK = nullptr;
+    double *W = nullptr, *V = nullptr, *part = nullptr, *R = nullptr, *lam = nullptr;
+    unsigned long long* maxcos = nullptr;
+    float* dU = nullptr;
+    int* dsrc = nullptr;
+    ~Bufs() {
+      for (void* p : {(void*)dK, (void*)W, (void*)V, (void*)part, (void*)R, (void*)lam, (void*)maxcos, (void*)dU, (void*)dsrc})
+        if (p) hipFree(p);
+    }
+  } b;
+  const size_t nn = (size_t)np * (size_t)np;
+  HIP_TRY(c, hipMalloc((void**)&b.V, sizeof(double) * nn));
+  // row splits of the Gram pass / row slabs of the update: enough waves to fill the chip when there are few pairs
+  const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(np / 64, (1024 + pairs - 1) / pairs / 4));
+  const int nparts = splits * 4, slabs = splits;
+  HIP_TRY(c, hipMalloc((void**)&b.part, sizeof(double) * (size_t)pairs * nparts * kJacP * kJacP));
+  HIP_TRY(c, hipMalloc((void**)&b.R, sizeof(double) * (size_t)pairs * kJacP * kJacP));
+  HIP_TRY(c, hipMalloc((void**)&b.lam, sizeof(double) * 2 * (size_t)np));
+  HIP_TRY(c, hipMalloc((void**)&b.maxcos, sizeof(unsigned long long)));
+  const double tol = 1e-10;
+  const int max_sweeps = 40;
+  int sweeps = 0, total_sweeps = 0;
+  double last = 0.0, shift = 0.0, worst_resid = 0.0;
+  std::vector<double> lam((size_t)np), resid((size_t)np);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (!b.W) HIP_TRY(c, hipMalloc((void**)&b.W, sizeof(double) * nn));
+    HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
+    HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(jac_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)np, mu + shift, shift,
+                       b.W, b.V);
+    HIP_TRY(c, sync_stream(st));
+    hipFree(b.dK);
+    b.dK = nullptr;
+    for (sweeps = 0; sweeps < max_sweeps;) {
+      HIP_TRY(c, hipMemsetAsync(b.maxcos, 0, sizeof(unsigned long long), st));
+      for (int r = 0; r < nb - 1; ++r) {
+        hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)pairs, (unsigned)splits), dim3(256), 0, st, b.W, (long long)np, nb,
+                           r, splits, b.part);
+        hipLaunchKernelGGL(jac_small_eig_kernel, dim3((unsigned)pairs), dim3(256), 0, st, b.part, nparts, 1e-15, b.R,
+                           b.maxcos);
+        hipLaunchKernelGGL(jac_apply_kernel, dim3((unsigned)pairs, (unsigned)slabs, 2), dim3(256), 0, st, b.W, b.V,
+                           (long long)np, nb, r, b.R);
+      }
+      HIP_TRY(c, hipGetLastError());
+      unsigned long long bits = 0;
+      HIP_TRY(c, hipMemcpyAsync(&bits, b.maxcos, sizeof(bits), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, sync_stream(st));
+      std::memcpy(&last, &bits, sizeof(last));
+      ++sweeps;
+      if (last < tol) break;
+    }
+    total_sweeps += sweeps;
+    if (!(last < tol))
+      return fail(c, RVT_E_INVALID, "kinship decomposition did not converge (cosine %.3g after %d sweeps)", last, sweeps);
+    hipLaunchKernelGGL(jac_lambda_kernel, dim3((unsigned)np), dim3(256), 0, st, b.W, b.V, (long long)np, b.lam, b.lam + np);
+    HIP_TRY(c, hipMemcpyAsync(lam.data(), b.lam, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(resid.data(), b.lam + np, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+    worst_resid = 0.0;
+    for (int64_t j = 0; j < np; ++j) worst_resid = std::max(worst_resid, resid[j]);
+    if (worst_resid <= 1e-9 * mu || attempt == 1) break;
+    shift = 0.26 * mu;  // mu = 4 x (bound on the spectral radius): K + shift I is positive definite
+  }
+  for (int64_t j = 0; j < np; ++j) lam[j] -= shift;
+  hipFree(b.W);  // (80 GB at N = 100 000: not needed any more)
+  b.W = nullptr;
+  std::vector<int> src;
+  src.reserve((size_t)N);
+  for (int64_t j = 0; j < np; ++j)
+    if (lam[j] > -0.5 * mu - shift) src.push_back((int)j);
+  if ((int64_t)src.size() != N) return fail(c, RVT_E_INVALID, "kinship decomposition: %zu of %lld eigenpairs separated", src.size(), (long long)N);
+  std::stable_sort(src.begin(), src.end(), [&](int x, int y) { return lam[x] < lam[y]; });  // ascending, as Eigen returns them
+  std::vector<float> S((size_t)N);
+  for (int64_t j = 0; j < N; ++j) S[j] = (float)lam[src[j]];
+  HIP_TRY(c, hipMalloc((void**)&b.dsrc, sizeof(int) * (size_t)N));
+  HIP_TRY(c, hipMemcpyAsync(b.dsrc, src.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMalloc((void**)&b.dU, sizeof(float) * (size_t)N * (size_t)N));
+  hipLaunchKernelGGL(jac_gather_kernel, dim3((unsigned)N), dim3(256), 0, st, b.V, (long long)np, (long long)N, b.dsrc, b.dU);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sync_stream(st));
+  hipFree(b.V);
+  b.V = nullptr;
+  if (U_out) HIP_TRY(c, hipMemcpy(U_out, b.dU, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyDeviceToHost));
+  if (S_out) std::memcpy(S_out, S.data(), sizeof(float) * (size_t)N);
+  if (info) {
+    info->sweeps = total_sweeps;
+    info->max_cosine = last;
+    info->padded_order = np;
+    info->shift = shift;
+    info->max_residual = worst_resid;
+  }
+  if (install) return rvt_set_kinship(c, N, b.dU, S.data());
   return RVT_OK;
 }
 

@@ -237,6 +237,9 @@ def load_library():
     L.rvt_submit_gene_vcf.restype = C.c_int
     L.rvt_submit_gene_vcf.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p, c_int_p,
                                       C.c_uint32, C.POINTER(Params), c_double_p]
+    L.rvt_kinship_decompose.restype = C.c_int
+    L.rvt_kinship_decompose.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.c_int, C.POINTER(DecomposeInfo)]
     L.rvt_vcf_decode.restype = C.c_int
     L.rvt_vcf_decode.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p, c_int_p,
                                  C.POINTER(C.c_int8)]
@@ -273,6 +276,11 @@ def load_library():
 
 def _dp(a):
     return a.ctypes.data_as(c_double_p)
+
+
+class DecomposeInfo(C.Structure):
+    _fields_ = [("sweeps", C.c_int), ("max_cosine", C.c_double), ("padded_order", C.c_int64), ("shift", C.c_double),
+                ("max_residual", C.c_double)]
 
 
 def vcf_locate(L, line):
@@ -437,6 +445,20 @@ class Engine:
         self._check(self.L.rvt_submit_gene_bed(self.ctx, int(gene_id), int(M), bed.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
+
+    def kinship_decompose(self, K, install=False, want_vectors=True):
+        """Eigendecomposition of the symmetric float kinship K on the device (rvt_kinship_decompose).
+        Returns (U float32 N x N column-major or None, S float32 ascending, DecomposeInfo)."""
+        K = np.asfortranarray(K, dtype=np.float32)
+        N = K.shape[0]
+        U = np.zeros((N, N), dtype=np.float32, order="F") if want_vectors else None
+        S = np.zeros(N, dtype=np.float32)
+        info = DecomposeInfo()
+        fp = C.POINTER(C.c_float)
+        self._check(self.L.rvt_kinship_decompose(self.ctx, N, K.ctypes.data_as(fp),
+                                                 U.ctypes.data_as(fp) if want_vectors else None, S.ctypes.data_as(fp),
+                                                 1 if install else 0, C.byref(info)))
+        return U, S, info
 
     def vcf_set_samples(self, row_of_sample):
         rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)

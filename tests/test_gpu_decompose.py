@@ -1,0 +1,110 @@
+"""GPU: KinshipHolder::decompose on the device (rvt_kinship_decompose, one-sided block Jacobi).  The reference calls
+Eigen's SelfAdjointEigenSolver<MatrixXf> (base/KinshipHolder.cpp:270-290) and holds no test or fixture for it; the
+checks here are the defining properties (K U = U diag(S), U'U = I, ascending S equal to LAPACK's eigenvalues of the same
+float matrix) and the invariance the family tests rely on: statistics computed through the device's U, S equal those
+computed through LAPACK's U, S although the bases of repeated eigenvalues differ."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+from test_fam_cpu import make_family_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def eng():
+    import rvtests_amd
+    e = rvtests_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _check(K32, U, S, info):
+    K = K32.astype(np.float64)
+    N = K.shape[0]
+    ref = np.linalg.eigvalsh(K)
+    scale = np.abs(ref).max()
+    assert (np.diff(S) >= 0).all()
+    assert np.abs(S - ref).max() <= 3e-7 * scale                 # float storage of S
+    Ud = U.astype(np.float64)
+    assert np.abs(Ud.T @ Ud - np.eye(N)).max() <= 5e-6           # float storage of U
+    assert np.abs(K @ Ud - Ud * S.astype(np.float64)).max() <= 5e-6 * scale
+    assert info.max_cosine < 1e-10 and info.padded_order % 64 == 0 and info.padded_order >= N
+
+
+@pytest.mark.parametrize("n_fam", [16, 75, 333])
+def test_family_kinship(eng, n_fam):
+    """Nuclear-family kinship: eigenvalues 0.5 / 1 / 2 each repeated n_fam times or more."""
+    N, K, U0, S0, X, y = make_family_case(n_fam, 2, 7)
+    K32 = K.astype(np.float32)
+    U, S, info = eng.kinship_decompose(K32)
+    _check(K32, U, S, info)
+    assert info.shift == 0.0
+
+
+@pytest.mark.parametrize("N,kind", [(300, "psd"), (1000, "grm"), (257, "indefinite"), (130, "opposite")])
+def test_dense_matrices(eng, N, kind):
+    rng = np.random.default_rng(N)
+    if kind == "grm":                                            # genetic relationship matrix Z Z' / m: PSD, dense, full rank
+        Z = rng.standard_normal((N, 3 * N))
+        K = Z @ Z.T / (3 * N)
+    elif kind == "psd":                                          # rank-deficient
+        Z = rng.standard_normal((N, N // 2))
+        K = Z @ Z.T / N
+    elif kind == "indefinite":
+        A = rng.standard_normal((N, N))
+        K = (A + A.T) / 2
+    else:                                                        # exactly opposite eigenvalue pairs: needs the shift
+        Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        lam = np.concatenate([np.linspace(0.5, 3.0, N // 2), -np.linspace(0.5, 3.0, N // 2)])
+        K = (Q * lam) @ Q.T
+    K32 = ((K + K.T) / 2).astype(np.float32)
+    U, S, info = eng.kinship_decompose(K32)
+    _check(K32.astype(np.float32), U, S, info)
+    if kind in ("psd", "grm"):
+        assert info.shift == 0.0
+    if kind == "opposite":
+        assert info.shift > 0.0
+    if kind == "grm":                                            # simple spectrum: eigenvectors themselves, up to sign
+        w, V = np.linalg.eigh(K32.astype(np.float64))
+        gaps = np.minimum(np.diff(w, prepend=-np.inf), np.diff(w, append=np.inf))
+        ok = gaps > 1e-3 * np.abs(w).max()
+        dots = np.abs(np.sum(V * U.astype(np.float64), axis=0))
+        assert (dots[ok] > 1 - 1e-4).all() and ok.sum() > 50
+
+
+def test_famskat_through_the_device_decomposition(eng):
+    """install = 1: FamSKAT through the device's own U, S equals FamSKAT through LAPACK's (different bases of the repeated
+    eigenvalues, same U f(S) U')."""
+    N, K, U0, S0, X, y = make_family_case(60, 2, 21)
+    genes = [synth.make_gene(N, M, seed=500 + M, missing=0.02, common=True)[1] for M in (8, 25)]
+
+    def run(install_from_device):
+        if install_from_device:
+            eng.kinship_decompose(K.astype(np.float32), install=True, want_vectors=False)
+        else:
+            eng.set_kinship(U0, S0)
+        nul = eng.fit_fam_null(X, y)
+        ptrs = [eng.upload_block(G) for G in genes]
+        out = eng.run_fam_blocks(ptrs, [G.shape[1] for G in genes])
+        return nul, [(r.famskat_Q, r.famskat_p) for r in out]
+
+    nul_a, a = run(False)
+    nul_b, b = run(True)
+    assert abs(nul_a.delta - nul_b.delta) <= 2e-3 + 1e-3 * nul_a.delta      # Brent's own stopping accuracy
+    for (qa, pa), (qb, pb) in zip(a, b):
+        assert abs(qa - qb) <= 2e-2 * qa and abs(pa - pb) <= 5e-2 * pa + 1e-6
+    # with the SAME variance components the two bases must agree to float accuracy: pin delta through the oracle path
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul_a.delta, nul_a.sigma2_g
+    for k in range(2):
+        onul.beta[k] = nul_a.beta[k]
+    U1, S1, info = eng.kinship_decompose(K.astype(np.float32))
+    for G in genes:
+        rc0, o0 = orc.famskat(G, X, y, U0, S0, onul)
+        rc1, o1 = orc.famskat(G, X, y, U1.astype(np.float64), S1.astype(np.float64), onul)
+        assert rc0 == rc1 == 0
+        assert abs(o0.Q - o1.Q) <= 2e-5 * o0.Q and abs(o0.pvalue - o1.pvalue) <= 1e-4 * o0.pvalue
