@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const double* __restrict_
 // (32 disjoint rotations per step) and writes R (row-major 64 x 64, columns ordered by decreasing eigenvalue).
 __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double* __restrict__ part, int nparts, double tol,
                                                             double* __restrict__ Rout,
-                                                            unsigned long long* __restrict__ maxcos) {
+                                                            unsigned long long* __restrict__ maxcos, int sort_mode) {
   __shared__ double G[kJacP][kJacP + 1];
   __shared__ double R[kJacP][kJacP + 1];
   __shared__ double cs[kJacB][2];
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double* __rest
       const double e = G[j][j];
       if (e > d || (e == d && j < tid)) ++rank;
     }
+    if (sort_mode == 0) rank = tid;
     order[rank] = tid;
   }
   __syncthreads();

@@ -1514,6 +1514,7 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
   HIP_TRY(c, hipMalloc((void**)&b.maxcos, sizeof(unsigned long long)));
   const double tol = 1e-10;
   const int max_sweeps = 40;
+  const int sort_mode = getenv("RVT_JACOBI_NOSORT") ? 0 : 1;
   int sweeps = 0, total_sweeps = 0;
   double last = 0.0, shift = 0.0, worst_resid = 0.0;
   std::vector<double> lam((size_t)np), resid((size_t)np);
@@ -1532,7 +1533,7 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
         hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)pairs, (unsigned)splits), dim3(256), 0, st, b.W, (long long)np, nb,
                            r, splits, b.part);
         hipLaunchKernelGGL(jac_small_eig_kernel, dim3((unsigned)pairs), dim3(256), 0, st, b.part, nparts, 1e-15, b.R,
-                           b.maxcos);
+                           b.maxcos, sort_mode);
         hipLaunchKernelGGL(jac_apply_kernel, dim3((unsigned)pairs, (unsigned)slabs, 2), dim3(256), 0, st, b.W, b.V,
                            (long long)np, nb, r, b.R);
       }
@@ -1542,6 +1543,7 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
       HIP_TRY(c, sync_stream(st));
       std::memcpy(&last, &bits, sizeof(last));
       ++sweeps;
+      if (getenv("RVT_JACOBI_TRACE")) fprintf(stderr, "[rvt] jacobi sweep %d: max cosine %.3e\n", sweeps, last);
       if (last < tol) break;
     }
     total_sweeps += sweeps;

@@ -2,11 +2,14 @@
 usage: python tools/bench_decompose.py [--samples 8000] [--kind family|grm]"""
 import argparse
 import json
+import os
+import sys
 import time
 
 import numpy as np
 
-import rvtests_amd
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import rvtests_amd  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=8000)
