@@ -20,9 +20,23 @@
 
 #include "ModelFitterGpu.h"
 
+#include <execinfo.h>
+#include <memory>
+#include <signal.h>
+#include <unistd.h>
 using namespace rvt_host;
 
+static void on_fatal_signal(int sig) {  // test driver: say where it happened
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  fprintf(stderr, "host_driver: signal %d\n", sig);
+  backtrace_symbols_fd(frames, n, 2);
+  _exit(128 + sig);
+}
+
 int main(int argc, char** argv) {
+  signal(SIGSEGV, on_fatal_signal);
+  signal(SIGABRT, on_fatal_signal);
   if (argc < 4) {
     fprintf(stderr, "usage: host_driver input.bin <kernel list|-> <burden list|->\n");
     return 2;
@@ -38,7 +52,8 @@ int main(int argc, char** argv) {
   if (fread(y.data(), 8, N, f) != (size_t)N) return 2;
   if (ncov && fread(cov.data(), 8, (size_t)N * ncov, f) != (size_t)N * ncov) return 2;
 
-  ModelManager mm;
+  std::unique_ptr<ModelManager> mmp(new ModelManager());  // destroyed BEFORE the broker's contexts (models free device blocks)
+  ModelManager& mm = *mmp;
   if (std::string(argv[2]) != "-" && mm.create("kernel", argv[2])) {
     fprintf(stderr, "%s\n", mm.lastError.c_str());
     return 1;
@@ -163,6 +178,7 @@ int main(int argc, char** argv) {
   for (size_t m = 0; m < models.size(); ++m) models[m]->writeFootnote(&outs[m]);  // ModelManager::close, :304-314
   const auto names = mm.outputNames("out");
   for (size_t m = 0; m < models.size(); ++m) printf("== %s\n%s", names[m].c_str(), outs[m].text.c_str());
+  mmp.reset();
   GpuBroker::instance().shutdown();
   return 0;
 }

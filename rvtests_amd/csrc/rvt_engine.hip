@@ -137,6 +137,12 @@ struct rvt_ctx {
   int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
+  // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
+  struct ColKind {
+    int cols = 0;
+    int* d_flags = nullptr;
+  };
+  std::unordered_map<const double*, ColKind> col_kind;
   // VCF text front end (vcf_kernels.hip.h)
   char* d_vcf_text = nullptr;
   size_t vcf_text_cap = 0;
@@ -592,6 +598,8 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_af_ring) hipFree(c->d_af_ring);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
+  for (auto& kv : c->col_kind)
+    if (kv.second.d_flags) hipFree(kv.second.d_flags);
   if (c->d_vcf_text) hipFree(c->d_vcf_text);
   if (c->d_vcf_rec) hipFree(c->d_vcf_rec);
   if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
@@ -684,6 +692,12 @@ int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
   const size_t bytes = sizeof(double) * (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld) * M;
   HIP_TRY(c, hipMalloc((void**)out, bytes));
   HIP_TRY(c, hipMemset(*out, 0, bytes));
+  {  // (flags are allocated by the first column upload; a zeroed block holds hard calls only)
+    rvt_ctx::ColKind& ck = c->col_kind[*out];
+    if (ck.d_flags) hipFree(ck.d_flags);  // an earlier block at the same address that was freed behind our back
+    ck.d_flags = nullptr;
+    ck.cols = M;
+  }
   return RVT_OK;
 }
 
@@ -727,6 +741,13 @@ int rvt_block_free(rvt_ctx* c, double* dG) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
   c->block_kind.erase(dG);
+  {
+    auto it = c->col_kind.find(dG);
+    if (it != c->col_kind.end()) {
+      if (it->second.d_flags) hipFree(it->second.d_flags);
+      c->col_kind.erase(it);
+    }
+  }
   if (dG) HIP_TRY(c, hipFree(dG));
   return RVT_OK;
 }
@@ -735,6 +756,13 @@ static int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
   if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
+  {  // per-column flags of an earlier column-wise fill no longer describe the block
+    auto it = c->col_kind.find(dG);
+    if (it != c->col_kind.end() && it->second.d_flags) {
+      hipFree(it->second.d_flags);
+      it->second.d_flags = nullptr;
+    }
+  }
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t bld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   c->block_kind.erase(dG);
@@ -788,6 +816,7 @@ struct CovOut {  // rvt_cov_block: host destinations
   double *ustat = nullptr, *vstat = nullptr, *af = nullptr, *pval = nullptr;
   // MetaScoreTest (unrelated samples): ustat / vstat / effect / se / pval / ok, V entries each; no covariance rows
   bool score = false;
+  const unsigned char* slice_hc = nullptr;  // score mode: per slice, 1 = the slice holds hard calls only
   bool uncentred = false;  // family mode: FastLMM::disableCenterGenotype (MetaFamBinary)
   double *effect = nullptr, *se = nullptr;
   int* ok = nullptr;
@@ -928,7 +957,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   int maxM = 0, n_hc = 0;
   const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
                              c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
-  const bool hc_possible = c->hc_enabled && !nc.binary && !cov && !(dbg && dbg->cmc) && d <= kHcMaxD &&
+  const bool score_hc = cov && cov->score && cov->slice_hc;
+  const bool hc_possible = c->hc_enabled && !nc.binary && (!cov || score_hc) && !(dbg && dbg->cmc) && d <= kHcMaxD &&
                            !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
@@ -949,8 +979,12 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     // hard-call path: unweighted null model, block known to hold only 0.0 / 1.0 / 2.0, a single-pass tile class
     gd.hc = 0;
     if (hc_possible && gd.MT <= kHcMaxMT && (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31)) {
-      auto it = c->block_kind.find(dG[g]);
-      if (it != c->block_kind.end() && it->second == 1) gd.hc = 1;
+      if (score_hc) {
+        gd.hc = cov->slice_hc[g] ? 1 : 0;
+      } else {
+        auto it = c->block_kind.find(dG[g]);
+        if (it != c->block_kind.end() && it->second == 1) gd.hc = 1;
+      }
     }
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
     if (gd.hc) {
@@ -2752,15 +2786,36 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   int rc = rvt_sync(c);  // processed synchronously
   if (rc) return rc;
-  // columns per slice: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column tiles, i.e. tile
-  // class (2,2) (or (1,2) for 16 covariates) — 12 % fewer MFMA per genotype than 16-column slices and two row tiles
-  // of loads in flight per wave
-  int kSlice = 32 - (c->nc.d + 1);
+  // Which columns hold hard calls only: the whole block when it was classified (rvt_block_upload / rvt_block_classify),
+  // else the per-column flags that rvt_block_upload_columns recorded.
+  std::vector<int> colflag;
+  bool all_hc = false, any_hc = false;
+  {
+    auto bk = c->block_kind.find(dG);
+    if (bk != c->block_kind.end() && bk->second == 1) all_hc = any_hc = true;
+    auto it = c->col_kind.find(dG);
+    if (!all_hc && it != c->col_kind.end() && it->second.d_flags && V <= it->second.cols) {
+      colflag.resize((size_t)V);
+      HIP_TRY(c, hipMemcpyAsync(colflag.data(), it->second.d_flags, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, c->io_stream));
+      HIP_TRY(c, sync_stream(c->io_stream));
+      all_hc = true;
+      for (int j = 0; j < V; ++j) {
+        all_hc = all_hc && colflag[j] != 0;
+        any_hc = any_hc || colflag[j] != 0;
+      }
+    }
+    if (!c->hc_enabled || c->nc.binary) all_hc = any_hc = false;
+  }
+  // columns per slice.  General kernel: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column
+  // tiles, tile class (2,2).  Hard-call kernel: the null-model columns have a tile of their own, so a slice is two
+  // full genotype tiles (32 columns, class MT = 2) when the whole block qualifies.
+  int kSlice = all_hc ? 32 : 32 - (c->nc.d + 1);
   if (const char* e = getenv("RVT_SCORE_SLICE")) kSlice = std::max(1, std::min(64, atoi(e)));
   constexpr int kChunk = 256;  // slices per launch
   const int64_t ld = c->null_ld;
   std::vector<double> af((size_t)kSlice * kChunk, 0.01);
   std::vector<rvt_gene_result> rs(kChunk);
+  std::vector<unsigned char> shc(kChunk);
   for (int c0 = 0; c0 < V; c0 += kSlice * kChunk) {
     const int cols = std::min(V - c0, kSlice * kChunk), n = (cols + kSlice - 1) / kSlice;
     std::vector<const double*> ptr(n);
@@ -2770,9 +2825,16 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
       ptr[g] = dG + (size_t)(c0 + g * kSlice) * ld;
       Ms[g] = std::min(kSlice, cols - g * kSlice);
       ids[g] = (int64_t)g * kSlice;
+      bool hc = all_hc;
+      if (!all_hc && any_hc) {
+        hc = true;
+        for (int j = 0; j < Ms[g]; ++j) hc = hc && colflag[(size_t)c0 + (size_t)g * kSlice + j] != 0;
+      }
+      shc[g] = hc ? 1 : 0;
     }
     CovOut co;
     co.score = true;
+    co.slice_hc = any_hc ? shc.data() : nullptr;
     co.ok = ok + c0;
     co.ustat = ustat + c0;
     co.vstat = vstat + c0;
@@ -2994,6 +3056,22 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   c->block_kind.erase(dG);
   HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
                          hipMemcpyHostToDevice));
+  // content of the new columns (hard calls or not), recorded per column: rvt_score_block picks its kernel by it.  One
+  // read of data that has just crossed PCIe at a hundredth of the rate.
+  auto it = c->col_kind.find(dG);
+  if (it != c->col_kind.end() && c->hc_enabled && col0 + ncols <= it->second.cols) {
+    rvt_ctx::ColKind ck = it->second;
+    if (!ck.d_flags) {
+      HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
+      HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, c->io_stream));
+      it->second.d_flags = ck.d_flags;
+    }
+    for (int k = 0; k < ncols; ++k) {
+      int rc = enqueue_classify(c, dG + (size_t)(col0 + k) * ld, 1, (int64_t)N, (int64_t)ld, c->io_stream,
+                                ck.d_flags + col0 + k);
+      if (rc) return rc;
+    }
+  }
   return RVT_OK;
 }
 
@@ -3008,6 +3086,15 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
     HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
                               hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, sync_stream(c->stream));
+  auto it = c->col_kind.find(dG);
+  if (it != c->col_kind.end() && it->second.d_flags && src_col + ncols <= it->second.cols) {
+    std::vector<int> f((size_t)it->second.cols);
+    HIP_TRY(c, hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * f.size(), hipMemcpyDeviceToHost, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));
+    std::memmove(f.data() + dst_col, f.data() + src_col, sizeof(int) * (size_t)ncols);
+    HIP_TRY(c, hipMemcpyAsync(it->second.d_flags, f.data(), sizeof(int) * f.size(), hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));
+  }
   return RVT_OK;
 }
 

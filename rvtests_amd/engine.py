@@ -370,6 +370,13 @@ class Engine:
     def forget_block(self, ptr):
         self._check(self.L.rvt_block_forget(self.ctx, C.c_void_p(int(ptr))))
 
+    def alloc_block(self, M):
+        """Zeroed device block of M columns (rvt_block_alloc); fill it with upload_columns."""
+        p = C.c_void_p()
+        self._check(self.L.rvt_block_alloc(self.ctx, int(M), C.byref(p)))
+        self._blocks.append(p)
+        return p.value
+
     def free_block(self, ptr):
         self._check(self.L.rvt_block_free(self.ctx, C.c_void_p(ptr)))
         self._blocks = [b for b in self._blocks if b.value != ptr]
