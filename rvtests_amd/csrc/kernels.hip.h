@@ -574,6 +574,110 @@ __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts cc, co
   }
 }
 
+// MetaCov fast path for hard-call blocks: ONE pass over the window's columns produces everything the band needs
+// besides G'G — raw column sums and polymorphic flags (as raw_colstat_kernel), T = G'X (W x d, column-major) and the int8
+// copy of the columns that the exact integer product G'G reads (rot_gemm.hip.h).  Four columns per workgroup share the
+// loads of X; the rows are cut into gridDim.y slices whose partial results (part[slice][column][3 + DMAX]: sum, min,
+// max, T) are added in a fixed order by cov_hc_finish_kernel.  grid = (ceil(W / 4), slices), 256 threads; d <= DMAX.
+constexpr int kCovHcCols = 4;
+template <int DMAX>
+__global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restrict__ G, long long N, long long ld, int W,
+                                                          const double* __restrict__ X, long long ldx, int d,
+                                                          signed char* __restrict__ out8, long long ldk,
+                                                          double* __restrict__ part) {
+  const int c0 = blockIdx.x * kCovHcCols;
+  const int nc = min(kCovHcCols, W - c0);
+  const long long per = ((N + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+  const long long i0 = (long long)blockIdx.y * per, i1 = (i0 + per < N) ? i0 + per : N;
+  double s[kCovHcCols], mn[kCovHcCols], mx[kCovHcCols], t[kCovHcCols][DMAX];
+#pragma unroll
+  for (int c = 0; c < kCovHcCols; ++c) {
+    s[c] = 0.0;
+    mn[c] = INFINITY;
+    mx[c] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) t[c][k] = 0.0;
+  }
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    double x[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) x[k] = (k < d) ? X[(long long)k * ldx + i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < kCovHcCols; ++c) {
+      if (c < nc) {
+        const double g = G[(long long)(c0 + c) * ld + i];
+        out8[(long long)(c0 + c) * ldk + i] = (signed char)(int)g;
+        s[c] += g;
+        mn[c] = fmin(mn[c], g);
+        mx[c] = fmax(mx[c], g);
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) t[c][k] = fma(g, x[k], t[c][k]);
+      }
+    }
+  }
+  __shared__ double red[4][kCovHcCols][DMAX + 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < kCovHcCols; ++c) {
+    double v = s[c], a = mn[c], b = mx[c];
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_down(v, o);
+      a = fmin(a, __shfl_down(a, o));
+      b = fmax(b, __shfl_down(b, o));
+    }
+    if (lane == 0) {
+      red[wave][c][0] = v;
+      red[wave][c][1] = a;
+      red[wave][c][2] = b;
+    }
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+      double u = t[c][k];
+      for (int o = 32; o > 0; o >>= 1) u += __shfl_down(u, o);
+      if (lane == 0) red[wave][c][3 + k] = u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kCovHcCols * (DMAX + 3)) {
+    const int c = threadIdx.x / (DMAX + 3), f = threadIdx.x % (DMAX + 3);
+    if (c < nc) {
+      double r;
+      if (f == 1)
+        r = fmin(fmin(red[0][c][1], red[1][c][1]), fmin(red[2][c][1], red[3][c][1]));
+      else if (f == 2)
+        r = fmax(fmax(red[0][c][2], red[1][c][2]), fmax(red[2][c][2], red[3][c][2]));
+      else
+        r = red[0][c][f] + red[1][c][f] + red[2][c][f] + red[3][c][f];
+      part[((long long)blockIdx.y * W + c0 + c) * (DMAX + 3) + f] = r;
+    }
+  }
+}
+
+// one thread per (column, field): colsum, poly, T (W x d column-major)
+__global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices, int W, int d, int dmax,
+                                     double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = dmax + 3;
+  if (idx >= W * F) return;
+  const int j = idx / F, f = idx % F;
+  if (f == 2 || f - 3 >= d) return;  // (max is folded into f == 1)
+  if (f == 1) {
+    double a = INFINITY, b = -INFINITY;
+    for (int s = 0; s < slices; ++s) {
+      a = fmin(a, part[((long long)s * W + j) * F + 1]);
+      b = fmax(b, part[((long long)s * W + j) * F + 2]);
+    }
+    poly[j] = (a != b) ? 1 : 0;
+    return;
+  }
+  double r = 0.0;
+  for (int s = 0; s < slices; ++s) r += part[((long long)s * W + j) * F + f];
+  if (f == 0)
+    colsum[j] = r;
+  else
+    T[j + (long long)(f - 3) * W] = r;
+}
+
 // dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)
 __global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
                                   long long ld, double* __restrict__ dst) {

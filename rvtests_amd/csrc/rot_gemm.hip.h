@@ -51,18 +51,26 @@ __device__ __forceinline__ void rot_wait_vm_barrier() {
 
 // One plane pair.  A: [Mpad rows][ldk] int8 (row m = column m of U), B: [Npad cols][ldk] int8, kbytes = K rounded up to 128.
 // C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j] [* row_scale[m]],  m < M, j < N.
-// grid = sets * 256 workgroups, sets = ceil(n_row_panels / 32) * ceil(n_col_tiles / 8).
+// grid = (sets * 256, K slices) workgroups, sets = ceil(n_row_panels / 32) * ceil(n_col_tiles / 8); with one slice pass
+// kslice = kbytes and c_slice = 0.
 template <int WM, int WN, int TM, int TN, int NST, int MINB>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
-    const int8_t* __restrict__ A, const int8_t* __restrict__ B, long long ldk, long long kbytes, double* __restrict__ C,
+    const int8_t* __restrict__ A0, const int8_t* __restrict__ B0, long long ldk, long long kbytes0, double* __restrict__ C0,
     long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
-    const double* __restrict__ row_scale, double weight, int accumulate) {
+    const double* __restrict__ row_scale, double weight, int accumulate, long long kslice, long long c_slice) {
   constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+  // split K: slice blockIdx.y covers K bytes [y kslice, (y + 1) kslice) and writes its own result at C0 + y c_slice
+  const long long k_off = (long long)blockIdx.y * kslice;
+  const int8_t* __restrict__ A = A0 + k_off;
+  const int8_t* __restrict__ B = B0 + k_off;
+  double* __restrict__ C = C0 + (long long)blockIdx.y * c_slice;
+  const long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
   constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
   constexpr int kStage = (BM + BN) * kRotKC;
   static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
   __shared__ __attribute__((aligned(1024))) char lds[NST][kStage];
-  const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
+  // (K slices rotate the XCD that takes a given tile: a product with few tiles still spreads over the chip)
+  const int bid = blockIdx.x, xcd = (bid + blockIdx.y) & 7, w = bid >> 3;
   const int n_ctg = (n_col_tiles + 7) / 8;
   const int set = w >> 5, within = w & 31;
   const int ctg = set % n_ctg, rpg = set / n_ctg;
@@ -159,6 +167,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
 // the shipped configuration
 #define rot_gemm_i8_kernel (rot_gemm_i8_kernel_t<2, 4, 4, 2, 2, 1>)
 constexpr int kRotThreads = 512;
+
+// C[m + j ldc] = (accumulate ? C : 0) + sum over slices of part[s * stride + m + j ldc], m < M, j < N (fixed order:
+// reproducible; rows M .. ldc-1 of C are not touched)
+__global__ void rot_reduce_slices_kernel(const double* __restrict__ part, long long ldc, long long M, long long N,
+                                         long long stride, int slices, double* __restrict__ C, int accumulate) {
+  const long long total = M * N;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long i = (t / M) * ldc + t % M;
+    double s = accumulate ? C[i] : 0.0;
+    for (int k = 0; k < slices; ++k) s += part[(long long)k * stride + i];
+    C[i] = s;
+  }
+}
 
 // ---- digits ------------------------------------------------------------------------------------------------------------
 // q = sum_p d_p 128^p, d_p in [-64, 63]

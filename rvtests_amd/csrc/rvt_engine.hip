@@ -137,6 +137,8 @@ struct rvt_ctx {
   int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
+  double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
+  size_t rot_part_cap = 0;
   // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
   struct ColKind {
     int cols = 0;
@@ -608,6 +610,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
+  if (c->d_rot_part) hipFree(c->d_rot_part);
   if (c->d_rot_scale) hipFree(c->d_rot_scale);
   if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);
@@ -1646,15 +1649,17 @@ int ensure_rot_scratch(rvt_ctx* c) {
 // Quantise ncols <= kRotMaxCols columns of n_rows doubles (column-major, leading dimension ld_src) into planes laid out
 // [plane][column (padded to `pad`)][ldk].  One plane when every column holds integers in [-127, 127], else kRotPlanesG.
 int quantize_columns(rvt_ctx* c, const double* d_src, int64_t n_rows, int64_t ld_src, int ncols, int pad, int64_t ldk,
-                     signed char** buf, size_t* cap, hipStream_t st, QuantCols* out) {
+                     signed char** buf, size_t* cap, hipStream_t st, QuantCols* out, bool known_hard_calls = false) {
   int rc = ensure_rot_scratch(c);
   if (rc) return rc;
   double* d_max = c->d_rot_scale + kRotMaxCols;
-  hipLaunchKernelGGL(rot_colmax_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_src, (long long)n_rows,
-                     (long long)ld_src, d_max);
-  std::vector<double> cmax(ncols);
-  HIP_TRY(c, hipMemcpyAsync(cmax.data(), d_max, sizeof(double) * ncols, hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, sync_stream(st));
+  std::vector<double> cmax(ncols, 2.0);  // (hard calls: 0 / 1 / 2, no scan needed)
+  if (!known_hard_calls) {
+    hipLaunchKernelGGL(rot_colmax_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_src, (long long)n_rows,
+                       (long long)ld_src, d_max);
+    HIP_TRY(c, hipMemcpyAsync(cmax.data(), d_max, sizeof(double) * ncols, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+  }
   bool small = true;
   for (int j = 0; j < ncols; ++j) small = small && cmax[j] >= 0.0 && cmax[j] <= 127.0;
   const int PG = small ? 1 : kRotPlanesG;
@@ -1710,18 +1715,49 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
   long long kmax = std::max<long long>(kRotKC, ((1LL << 31) - 1) / bound / kRotKC * kRotKC);
   if (const char* e = getenv("RVT_ROT_KMAX"))  // tests: force the cut on small problems
     kmax = std::max<long long>(kRotKC, std::min<long long>(kmax, atoll(e) / kRotKC * kRotKC));
+  // Few output tiles (a short, wide product such as G'G of one MetaCov block: 16 tiles for 1024 x 1024) cannot fill
+  // 256 CUs: K is then also split across workgroups (grid.y), every slice writes its own partial result and a
+  // fixed-order reduction adds them.  Also used for the int32 range cut above.
+  const long long tiles = (long long)nrp * nct;
+  long long slices = 1;
+  if (tiles < 256) slices = std::min<long long>((512 + tiles - 1) / tiles, std::max<long long>(1, kbytes / (16 * kRotKC)));
+  slices = std::max(slices, (kbytes + kmax - 1) / kmax);
+  if (const char* e = getenv("RVT_ROT_SLICES")) slices = std::max<long long>(1, atoll(e));
+  long long kslice = ((kbytes + slices - 1) / slices + kRotKC - 1) / kRotKC * kRotKC;
+  kslice = std::min(kslice, kmax);
+  slices = (kbytes + kslice - 1) / kslice;
+  double* d_part = nullptr;
+  long long c_slice = 0;
+  if (slices > 1) {
+    c_slice = (long long)ldc * nB;
+    const size_t need = sizeof(double) * (size_t)c_slice * (size_t)slices;
+    if (c->rot_part_cap < need) {
+      if (c->d_rot_part) hipFree(c->d_rot_part);
+      c->d_rot_part = nullptr;
+      c->rot_part_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_rot_part, need));
+      c->rot_part_cap = need;
+    }
+    d_part = c->d_rot_part;
+  }
   int first = 1;
   for (int sdeg = 0; sdeg <= (PA - 1) + (PB - 1); ++sdeg)  // least significant digit pairs first
     for (int p = 0; p < PA; ++p) {
       const int q = sdeg - p;
       if (q < 0 || q >= PB) continue;
-      for (long long k0 = 0; k0 < kbytes; k0 += kmax) {
-        hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 256)), dim3(kRotThreads), 0, st,
-                           (const int8_t*)(A + (size_t)p * a_stride + k0), (const int8_t*)(B + (size_t)q * b_stride + k0),
-                           (long long)ldk, std::min(kmax, kbytes - k0), C, (long long)ldc, nA, nB, nrp, nct,
-                           c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1);
-        first = 0;
+      const dim3 grid((unsigned)(sets * 256), (unsigned)slices);
+      if (slices == 1) {
+        hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
+                           (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, C, (long long)ldc, nA, nB, nrp,
+                           nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1, kbytes, 0LL);
+      } else {
+        hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
+                           (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, d_part, (long long)ldc, nA, nB,
+                           nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), 0, kslice, c_slice);
+        hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_part, (long long)ldc, (long long)nA,
+                           (long long)nB, c_slice, (int)slices, C, first ? 0 : 1);
       }
+      first = 0;
     }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_stream(st));  // (the scale arrays are reused by the next call)
@@ -2778,6 +2814,34 @@ int rvt_rand_seed(rvt_ctx* c, unsigned seed) {
   return RVT_OK;
 }
 
+// Content of the first V columns of a block: 1 = hard calls only (the whole block was classified, or every column
+// that rvt_block_upload_columns brought in was), 0 = not / unknown.  colflag (optional) receives the per-column flags
+// when those are what is known (empty otherwise).
+static int block_hard_calls(rvt_ctx* c, const double* dG, int V, std::vector<int>* colflag, bool* any) {
+  if (colflag) colflag->clear();
+  if (any) *any = false;
+  if (!c->hc_enabled) return 0;
+  auto bk = c->block_kind.find(dG);
+  if (bk != c->block_kind.end() && bk->second == 1) {
+    if (any) *any = true;
+    return 1;
+  }
+  auto it = c->col_kind.find(dG);
+  if (it == c->col_kind.end() || !it->second.d_flags || V > it->second.cols) return 0;
+  std::vector<int> f((size_t)V);
+  if (hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, c->io_stream) != hipSuccess ||
+      sync_stream(c->io_stream) != hipSuccess)
+    return 0;
+  bool all = true, some = false;
+  for (int j = 0; j < V; ++j) {
+    all = all && f[j] != 0;
+    some = some || f[j] != 0;
+  }
+  if (any) *any = some;
+  if (colflag) *colflag = std::move(f);
+  return all ? 1 : 0;
+}
+
 // ---- MetaScore: single-variant score statistics of a block of variants (unrelated samples) -----------------
 int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat, double* vstat, double* effect,
                     double* effect_se, double* pvalue) {
@@ -2789,23 +2853,10 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   // Which columns hold hard calls only: the whole block when it was classified (rvt_block_upload / rvt_block_classify),
   // else the per-column flags that rvt_block_upload_columns recorded.
   std::vector<int> colflag;
-  bool all_hc = false, any_hc = false;
-  {
-    auto bk = c->block_kind.find(dG);
-    if (bk != c->block_kind.end() && bk->second == 1) all_hc = any_hc = true;
-    auto it = c->col_kind.find(dG);
-    if (!all_hc && it != c->col_kind.end() && it->second.d_flags && V <= it->second.cols) {
-      colflag.resize((size_t)V);
-      HIP_TRY(c, hipMemcpyAsync(colflag.data(), it->second.d_flags, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, c->io_stream));
-      HIP_TRY(c, sync_stream(c->io_stream));
-      all_hc = true;
-      for (int j = 0; j < V; ++j) {
-        all_hc = all_hc && colflag[j] != 0;
-        any_hc = any_hc || colflag[j] != 0;
-      }
-    }
-    if (!c->hc_enabled || c->nc.binary) all_hc = any_hc = false;
-  }
+  bool any_hc = false;
+  bool all_hc = block_hard_calls(c, dG, V, &colflag, &any_hc) != 0;
+  if (c->nc.binary) all_hc = any_hc = false;
+  if (!all_hc && colflag.empty()) any_hc = false;
   // columns per slice.  General kernel: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column
   // tiles, tile class (2,2).  Hard-call kernel: the null-model columns have a tile of their own, so a slice is two
   // full genotype tiles (32 columns, class MT = 2) when the whole block qualifies.
@@ -2870,6 +2921,10 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
   if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
   int rc = rvt_sync(c);  // the block is processed alone and synchronously
   if (rc) return rc;
+  // Hard calls and an unweighted model: G'G is an integer matrix — the band comes from the exact int8 product
+  // (rvt_cov_rect with heads = window) instead of the fp64 matrix cores, ~6x faster at V = 1024.
+  if (c->have_null && !c->nc.binary && V >= 64 && !getenv("RVT_METACOV_FP64") && block_hard_calls(c, dG, V, nullptr, nullptr))
+    return rvt_cov_rect(c, dG, 0, V, V, cov, xz, zz, polymorphic);
   std::vector<double> af(V, 0.01);
   rvt_gene_result r;
   CovOut co;
@@ -2923,8 +2978,6 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * d));
   HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
   HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
-  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
-                     d_poly);
   const double* Xop = c->d_X;   // N x d operand of T = G_W' D X
   const double* GHop = GW;      // N x H operand of S = G_H' D G_W
   if (nc.binary) {              // carry the weights on the small operands
@@ -2940,10 +2993,51 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   }
   // T = G_W' D X (W x d) and S = G_H' D G_W (H x W) as integer-plane products (rot_gemm.hip.h): exact for hard calls
   // and an unweighted model, ~2^-40 relative otherwise
-  rc = gemm_tn_planes(c, GW, ld, W, Xop, ld, d, N, d_T, W, st);
-  if (rc) return rc;
-  rc = gemm_tn_planes(c, GHop, ld, H, GW, ld, W, N, d_S, H, st);
-  if (rc) return rc;
+  const bool fast = !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
+  if (!fast)
+    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  if (fast) {
+    // heads = whole window of a hard-call block (rvt_cov_block's fast path): ONE pass over G gives the column
+    // statistics, T = G'X and the int8 copy (cov_hc_prep_kernel); S = G'G is then one exact integer product
+    const int64_t ldk = (N + 127) / 128 * 128;
+    const int64_t cols_pad = ((int64_t)W + kRotBM - 1) / kRotBM * kRotBM;
+    const size_t need = (size_t)cols_pad * (size_t)ldk;
+    if (c->rotB_cap < need) {
+      if (c->d_rotB) hipFree(c->d_rotB);
+      c->d_rotB = nullptr;
+      c->rotB_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
+      c->rotB_cap = need + need / 4;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+    {
+      const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+      const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
+      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>((2048 + wgs - 1) / wgs, N / 4096 + 1)));
+      HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)slices * W * (dmax + 3)));
+      const dim3 grid((unsigned)wgs, (unsigned)slices);
+      if (dmax == 4)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+      else if (dmax == 8)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+      else
+        hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W,
+                           c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
+                         W, d, dmax, d_cs, d_poly, d_T);
+    }
+    std::vector<int> zero_exp((size_t)W, 0);
+    rc = planes_gemm(c, c->d_rotB, need, 1, W, zero_exp.data(), 0, c->d_rotB, need, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
+    if (rc) return rc;
+  } else {
+    rc = gemm_tn_planes(c, GW, ld, W, Xop, ld, d, N, d_T, W, st);
+    if (rc) return rc;
+    rc = gemm_tn_planes(c, GHop, ld, H, GW, ld, W, N, d_S, H, st);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
   hipLaunchKernelGGL(cov_rect_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, H, W, d_cov);
   HIP_TRY(c, hipGetLastError());

@@ -103,3 +103,37 @@ def test_cov_rect_matches_block(engine_factory, binary):
             assert abs(rcov[h, j] - cov[col0 + h, col0 + j]) <= 1e-9 * scale
     assert np.allclose(rxz, xz[col0:col0 + W], rtol=1e-9, atol=1e-9 * max(np.abs(xz).max(), 1.0))
     assert np.allclose(rzz, zz, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("V,d,how", [(200, 3, "classify"), (517, 2, "columns"), (64, 1, "classify")])
+def test_cov_block_hard_call_fast_path(engine_factory, V, d, how, monkeypatch):
+    """Hard-call blocks with an unweighted model take the exact int8 product (split over K when the band has few
+    tiles): same numbers as the oracle and as the fp64 matrix-core path."""
+    N = 2300
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 4000 + V)
+    G = np.rint(G)
+    G[:, 7] = 2.0                                            # monomorphic non-zero
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    eng.set_profiling(True)
+    if how == "classify":
+        ptr = eng.upload_block(G)
+        assert eng.classify_block(ptr, V)
+    else:                                                     # the adapter's way: per-column flags
+        ptr = eng.alloc_block(V)
+        for j in range(0, V, 50):
+            eng.upload_columns(ptr, j, G[:, j:j + 50])
+    cov, xz, zz, poly = eng.cov_block(ptr, V)
+    monkeypatch.setenv("RVT_METACOV_FP64", "1")
+    cov0, xz0, zz0, poly0 = eng.cov_block(ptr, V)
+    monkeypatch.delenv("RVT_METACOV_FP64")
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, 0, 10 ** 7)
+    assert rc == 0 and (poly == kept).all() and (poly0 == kept).all()
+    m = ~np.isnan(ocov)
+    scale = np.abs(ocov[m]).max()
+    assert np.abs(cov[m] - ocov[m]).max() < REL * scale
+    assert np.abs(cov[m] - cov0[m]).max() < 1e-11 * scale
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    assert np.allclose(zz, ozz, rtol=1e-9, atol=1e-9 * max(np.abs(ozz).max(), 1.0))

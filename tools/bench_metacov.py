@@ -36,9 +36,18 @@ def main():
         cov, xz, zz, poly = eng.cov_block(blocks[0].data_ptr(), V)
     dt = (time.perf_counter() - t0) / a.reps
     pairs = V * (V + 1) / 2
-    print({"N": N, "V": V, "ms_per_block": 1e3 * dt, "pairs_per_s": pairs / dt,
-           "alg_GBps": 8.0 * N * V / dt / 1e9, "alg_TFLOPs_fp64": 2.0 * N * V * (V / 2 + 4) / dt / 1e12,
-           "polymorphic": int(poly.sum())})
+    print({"N": N, "V": V, "kernel": "fp64 matrix cores (content of the block unknown)", "ms_per_block": 1e3 * dt,
+           "pairs_per_s": pairs / dt, "alg_GBps": 8.0 * N * V / dt / 1e9,
+           "alg_TFLOPs_fp64": 2.0 * N * V * (V / 2 + 4) / dt / 1e12, "polymorphic": int(poly.sum())})
+    hard = torch.round(blocks[0]).contiguous()
+    assert eng.classify_block(hard.data_ptr(), V)
+    eng.cov_block(hard.data_ptr(), V)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        cov, xz, zz, poly = eng.cov_block(hard.data_ptr(), V)
+    dt = (time.perf_counter() - t0) / a.reps
+    print({"N": N, "V": V, "kernel": "hard calls: exact int8 product", "ms_per_block": 1e3 * dt, "pairs_per_s": pairs / dt,
+           "alg_GBps": 8.0 * N * V / dt / 1e9, "int8_TOPs": 2.0 * N * V * V / dt / 1e12, "polymorphic": int(poly.sum())})
 
 
 if __name__ == "__main__":
