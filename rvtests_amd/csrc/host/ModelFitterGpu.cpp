@@ -417,6 +417,27 @@ std::string ZegginiTest::formatRow(const rvt_gene_result* res) const {
   return (res && res->zeg_ok) ? floatToString(res->zeg_p) + "\n" : std::string("NA\n");
 }
 
+// ---- AnalyticVTTest ---------------------------------------------------------------------------------------------------------
+AnalyticVTTest::AnalyticVTTest() {
+  modelName = "AnalyticVT";
+  GpuBroker::instance().registerTests(RVT_TEST_ANALYTICVT, rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05});
+}
+int AnalyticVTTest::fit(GeneData* dc) { return deferredFit(dc); }
+void AnalyticVTTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.headerTab());
+  fp->write("MinMAF\tMaxMAF\tOptimMAF\tOptimNumVar\tU\tV\tStat\tPvalue\n");  // result.addHeader order, src/Model.h:2123-2130
+}
+void AnalyticVTTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
+void AnalyticVTTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+std::string AnalyticVTTest::formatRow(const rvt_gene_result* r) const {
+  // not fitted (binary trait, no polymorphic site, no usable threshold, integral not converged to 1e-3): the Result keeps
+  // its cleared values (src/Model.h:2233-2246 after ModelFitter::reset)
+  if (!r || !r->vt_ok || r->vt_p_error > 1e-3) return "NA\tNA\tNA\tNA\tNA\tNA\tNA\tNA\n";
+  return floatToString(r->vt_minmaf) + "\t" + floatToString(r->vt_maxmaf) + "\t" + floatToString(r->vt_optmaf) + "\t" +
+         std::to_string(r->vt_optnum) + "\t" + floatToString(r->vt_U) + "\t" + floatToString(r->vt_V) + "\t" +
+         floatToString(r->vt_stat) + "\t" + floatToString(r->vt_p) + "\n";
+}
+
 // ---- FamSkatTest ----------------------------------------------------------------------------------------------------------
 FamSkatTest::FamSkatTest(double, double) {
   modelName = "FamSkat";
@@ -945,6 +966,13 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);  // src/ModelManager.cpp:188-193
         model.push_back(new FamSkatTest(beta1, beta2));
       } else {
+        lastError = "Unknown model name: " + modelName + " .";
+        return -1;
+      }
+    } else if (modelType == "vt") {
+      if (modelName == "analytic")  // src/ModelManager.cpp:158-159
+        model.push_back(new AnalyticVTTest);
+      else {
         lastError = "Unknown model name: " + modelName + " .";
         return -1;
       }

@@ -270,6 +270,20 @@ class ZegginiTest : public ModelFitter {
  private:
 };
 
+// `--vt analytic` (src/ModelManager.cpp:158-159; AnalyticVT(UNRELATED), src/Model.h:2105-2259): quantitative traits only,
+// columns MinMAF MaxMAF OptimMAF OptimNumVar U V Stat Pvalue.  The reference's p-value comes from a randomised rule at
+// absolute accuracy 1e-3 and the row is NA when that rule's error estimate exceeds it (MvtNorm::compute_Band); here the
+// integral is evaluated deterministically and the row is NA when ITS error estimate exceeds 1e-3.
+class AnalyticVTTest : public ModelFitter {
+ public:
+  std::string formatRow(const rvt_gene_result* r) const override;
+  void writeFootnote(TextSink* fp) override;
+  AnalyticVTTest();
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+};
+
 // `--kernel famSkat[beta1:beta2]` (src/Model.h:3048-3145).  The reference ignores beta1 / beta2 for this model
 // (FamSkat.cpp:129-137 always uses Beta(1, 25)); so does this adapter.
 class FamSkatTest : public ModelFitter {

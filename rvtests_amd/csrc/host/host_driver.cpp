@@ -62,6 +62,12 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%s\n", mm.lastError.c_str());
     return 1;
   }
+  if (const char* vt = getenv("RVT_DRIVER_VT")) {  // `--vt analytic`
+    if (mm.create("vt", vt)) {
+      fprintf(stderr, "%s\n", mm.lastError.c_str());
+      return 1;
+    }
+  }
   const bool metaMode = argc >= 6 && std::string(argv[4]) != "-";
   std::vector<std::pair<std::string, std::string>> sitePos;
   if (metaMode) {

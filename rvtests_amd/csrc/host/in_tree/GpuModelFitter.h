@@ -120,6 +120,12 @@ typedef GpuModel<rvt_host::FamSkatTest> FamSkatTest;  // new FamSkatTest(beta1, 
 typedef GpuModel<rvt_host::FamBurdenTest> FamBurdenTest;
 typedef GpuModel<rvt_host::MetaCovTest> MetaCovTest;      // new MetaCovTest(windowSize)            :238-247
 typedef GpuModel<rvt_host::MetaScoreTest> MetaScoreTest;  // new MetaScoreTest()
+// new AnalyticVT(AnalyticVT::UNRELATED)   ModelManager.cpp:158-159 (the RELATED variant is not provided)
+class AnalyticVT : public GpuModel<rvt_host::AnalyticVTTest> {
+ public:
+  typedef enum { UNRELATED = 0, RELATED = 1 } Type;
+  explicit AnalyticVT(Type) {}
+};
 
 }  // namespace rvt_intree
 #endif  // RVT_GPU_MODEL_FITTER_H_

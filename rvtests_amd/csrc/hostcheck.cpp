@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 #include "rvt_pvalue.h"
+#include "rvt_mvn.h"
 
 using namespace rvt;
 
@@ -149,5 +150,12 @@ int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum,
   }
   return 0;
 }
+
+// AnalyticVT's band probability exactly as the device evaluates it (rvt_mvn.h): R = correlation (row-major n x n)
+double hc_mvn_band(const double* R, int n, double T, double* err) {
+  std::vector<double> A(R, R + (size_t)n * n), y(n), alpha(n);
+  return mvn_band_prob_serial(A.data(), n, T, y.data(), alpha.data(), err);
+}
+double hc_mvn_phiinv(double p) { return mvn_phiinv(p); }
 
 }  // extern "C"

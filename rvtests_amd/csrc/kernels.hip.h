@@ -8,7 +8,9 @@
 //  gene_pvalue_kernel           Davies / Liu / QAGS (one wave / gene, one lane / quadrature abscissa)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <float.h>
 #include "rvt_pvalue.h"
+#include "rvt_mvn.h"
 
 #include "suffstat_kernels.hip.h"
 #include "suffstat_hc.hip.h"
@@ -433,6 +435,302 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restric
     double quad = 0.0;
     for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
     cov[h + (long long)j * V] = xx - quad;
+  }
+}
+
+// ---- AnalyticVT (src/Model.h:2105-2259, UNRELATED, quantitative trait) from the assembled statistics ---------------------------
+// The reference residualises genotypes and phenotype on the covariates and forms u = x'y, v = x'x sigma2
+// (:2166-2188): with the intercept in X that is u = G'res and v = (G'G - G'X (X'X)^-1 X'G) sigma2 on the flipped,
+// polymorphic columns — exactly the u and Wm that gene_assemble leaves in the gene's scratch.  MultivariateVT::compute
+// (regression/MultivariateVT.cpp:22-144): maf = min(af, 1 - af) (af of filtered position a = counter of unfiltered
+// column a, as for the SKAT weights); a variant is skipped when maf < 1e-10 or v_aa < 1e-10; the distinct values of
+// ceil(maf 1e6) in ascending order are the cutoffs (as doubles: k / 1e6); phi(a, j) = maf_a <= cutoff_j; u_phi = u'phi,
+// v_phi = phi' v phi; Stat = max_j |u_phi_j / sqrt(v_phi_jj)| (first maximum); Pvalue = 1 - P(|Z_j| < Stat for all j),
+// Z ~ N(0, cor(v_phi)) — rvt_mvn.h.  One 256-thread workgroup per gene.
+// vt_mem (doubles): maf[Mp] | key[Mp] | ord[Mp] | cidx[Mp] | cut[K] | uphi[K] | start[K + 1] | alpha[K] | A[K x K] | y[256 x K]
+RVT_HD size_t gene_vt_doubles(int Mp) {
+  const size_t K = (size_t)(Mp < kMvnMaxDim ? Mp : kMvnMaxDim);
+  return 4 * (size_t)Mp + 4 * K + 8 + K * K + 256 * K;
+}
+
+__global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
+                                                      const NullConsts* __restrict__ ncp) {
+  const GeneDesc gd = genes[blockIdx.x];
+  rvt_gene_result* out = gd.result;
+  const int tid = threadIdx.x;
+  const GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  const int Mp = gd.Mp, M = gd.M, ldr = gd.Cp, d = ncp->d;
+  const int* kidx = ws.ivec;
+  const int m = kidx[Mp];
+  const double sigma2 = ncp->sigma2;
+  __shared__ int sK, sFail, sMaxIdx;
+  __shared__ double sRed[256];
+  __shared__ int sRedI[256];
+  if (tid == 0) {
+    out->vt_ok = 0;
+    out->vt_optnum = 0;
+    out->vt_ncutoff = 0;
+    out->vt_minmaf = out->vt_maxmaf = out->vt_optmaf = out->vt_U = out->vt_V = out->vt_stat = 0.0;
+    out->vt_p = out->vt_p_error = 0.0;
+    sK = 0;
+    sFail = 0;
+  }
+  __syncthreads();
+  if (m == 0 || ncp->binary || !gd.vt_mem) return;  // "Analytic VT test does not support binary outcomes" (:2143-2149)
+  const int Kmax = Mp < kMvnMaxDim ? Mp : kMvnMaxDim;
+  double* maf = gd.vt_mem;
+  double* keyd = maf + Mp;    // ceil(maf 1e6) as a double, -1: skipped
+  double* ordd = keyd + Mp;   // variants ordered by (first cutoff, index)
+  double* cidxd = ordd + Mp;  // first cutoff that includes the variant (K: none)
+  double* cut = cidxd + Mp;
+  double* uphi = cut + Kmax;
+  double* startd = uphi + Kmax;  // K + 1 range starts into ord
+  double* alpha = startd + Kmax + 8;
+  double* A = alpha + Kmax;
+  double* ymem = A + (size_t)Kmax * Kmax;
+  const double* Wm = ws.Wm;
+  // ---- 1. maf, skip rule, keys ----------------------------------------------------------------------------------------
+  double mn = INFINITY, mx = -INFINITY;
+  for (int a = tid; a < m; a += 256) {
+    const double f = gd.af[a];
+    const double mf = f < 0.5 ? f : 1.0 - f;
+    maf[a] = mf;
+    mn = fmin(mn, mf);
+    mx = fmax(mx, mf);
+    const double vaa = Wm[(size_t)a * m + a] * sigma2;
+    keyd[a] = (mf < 1e-10 || vaa < 1e-10) ? -1.0 : (double)(int)ceil(mf * 1000000);
+  }
+  sRed[tid] = mn;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) sRed[tid] = fmin(sRed[tid], sRed[tid + w]);
+    __syncthreads();
+  }
+  const double minmaf = sRed[0];
+  __syncthreads();
+  sRed[tid] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) sRed[tid] = fmax(sRed[tid], sRed[tid + w]);
+    __syncthreads();
+  }
+  const double maxmaf = sRed[0];
+  __syncthreads();
+  // ---- 2. distinct keys in ascending order = cutoffs (a key is a cutoff at its first occurrence) ---------------------------
+  for (int a = tid; a < m; a += 256) {
+    const double k = keyd[a];
+    if (k < 0.0) continue;
+    bool first = true;
+    int below = 0;  // distinct smaller keys = its position
+    for (int b = 0; b < m; ++b) {
+      const double kb = keyd[b];
+      if (kb < 0.0) continue;
+      if (b < a && kb == k) first = false;
+      if (kb < k) {
+        bool firstb = true;
+        for (int c2 = 0; c2 < b; ++c2)
+          if (keyd[c2] == kb) {
+            firstb = false;
+            break;
+          }
+        if (firstb) ++below;
+      }
+    }
+    if (first) {
+      if (below < Kmax) cut[below] = 1.0 * (int)k / 1000000;
+      atomicAdd(&sK, 1);
+    }
+  }
+  __syncthreads();
+  const int K = sK;
+  if (K == 0) return;  // numKeep == 0: compute() returns -1, the row is NA
+  if (K > Kmax) {
+    if (tid == 0) out->vt_ncutoff = K;
+    return;  // (more thresholds than the device integral handles: reported as not fitted)
+  }
+  // ---- 3. first cutoff of every variant, ordering by it --------------------------------------------------------------------
+  for (int a = tid; a < m; a += 256) {
+    int ci = K;
+    if (keyd[a] >= 0.0) {
+      for (int j = 0; j < K; ++j)
+        if (maf[a] <= cut[j]) {
+          ci = j;
+          break;
+        }
+    }
+    cidxd[a] = (double)ci;
+  }
+  __syncthreads();
+  for (int a = tid; a < m; a += 256) {  // rank sort by (cidx, index)
+    const double ca = cidxd[a];
+    int r = 0;
+    for (int b = 0; b < m; ++b) {
+      const double cb = cidxd[b];
+      if (cb < ca || (cb == ca && b < a)) ++r;
+    }
+    ordd[r] = (double)a;
+  }
+  for (int j = tid; j <= K; j += 256) {  // start[j] = number of variants with cidx < j
+    int cnt = 0;
+    for (int b = 0; b < m; ++b)
+      if (cidxd[b] < (double)j) ++cnt;
+    startd[j] = (double)cnt;
+  }
+  __syncthreads();
+  // ---- 4. block sums B[p][q] = sum of v over (first cutoff p) x (first cutoff q), then 2-D prefix sums = v_phi ----------------
+  for (int e = tid; e < K * K; e += 256) {
+    const int p = e / K, q = e % K;
+    double sacc = 0.0;
+    const int p0 = (int)startd[p], p1 = (int)startd[p + 1], q0 = (int)startd[q], q1 = (int)startd[q + 1];
+    for (int x = p0; x < p1; ++x) {
+      const int a = (int)ordd[x];
+      for (int z = q0; z < q1; ++z) sacc += Wm[(size_t)(int)ordd[z] * m + a];
+    }
+    A[(size_t)p * K + q] = sacc * sigma2;
+  }
+  for (int j = tid; j < K; j += 256) {  // u_phi before the prefix: block sums of u
+    double sacc = 0.0;
+    const int p0 = (int)startd[j], p1 = (int)startd[j + 1];
+    for (int x = p0; x < p1; ++x) sacc += ws.R[(size_t)kidx[(int)ordd[x]] * ldr + M + d];
+    uphi[j] = sacc;
+  }
+  __syncthreads();
+  for (int p = tid; p < K; p += 256)  // prefix along q
+    for (int q = 1; q < K; ++q) A[(size_t)p * K + q] += A[(size_t)p * K + q - 1];
+  __syncthreads();
+  for (int q = tid; q < K; q += 256)  // prefix along p
+    for (int p = 1; p < K; ++p) A[(size_t)p * K + q] += A[(size_t)(p - 1) * K + q];
+  if (tid == 0)
+    for (int j = 1; j < K; ++j) uphi[j] += uphi[j - 1];
+  __syncthreads();
+  // ---- 5. statistic -----------------------------------------------------------------------------------------------------
+  {
+    double best = -DBL_MAX;
+    int bi = -1;
+    for (int j = tid; j < K; j += 256) {
+      const double t = fabs(uphi[j] / sqrt(A[(size_t)j * K + j]));
+      if (t > best) {
+        best = t;
+        bi = j;
+      }
+    }
+    sRed[tid] = best;
+    sRedI[tid] = bi;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) {  // first maximum: larger value, or equal value with the smaller index
+        const double o = sRed[tid + w];
+        const int oi = sRedI[tid + w];
+        if (oi >= 0 && (sRedI[tid] < 0 || o > sRed[tid] || (o == sRed[tid] && oi < sRedI[tid]))) {
+          sRed[tid] = o;
+          sRedI[tid] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) sMaxIdx = sRedI[0];
+    __syncthreads();
+  }
+  const int maxIdx = sMaxIdx;
+  if (maxIdx < 0) return;  // every statistic is NaN (cannot happen with v_aa >= 1e-10): NA row
+  const double T = fabs(uphi[maxIdx] / sqrt(A[(size_t)maxIdx * K + maxIdx]));
+  if (tid == 0) {
+    out->vt_minmaf = minmaf;
+    out->vt_maxmaf = maxmaf;
+    out->vt_optmaf = cut[maxIdx];
+    out->vt_optnum = (int)startd[maxIdx + 1];
+    out->vt_U = uphi[maxIdx];
+    out->vt_V = A[(size_t)maxIdx * K + maxIdx];
+    out->vt_stat = T;
+    out->vt_ncutoff = K;
+  }
+  if (!(T == T) || !(T < INFINITY)) return;
+  if (K == 1) {  // getBandProbFromCor, n == 1 (regression/MultivariateNormalDistribution.cpp:18-21)
+    if (tid == 0) {
+      out->vt_p = 1.0 - (mvn_phi(T) - mvn_phi(-T));
+      out->vt_ok = 1;
+    }
+    return;
+  }
+  // ---- 6. correlation, Cholesky factor (columns one after the other, rows in parallel) ------------------------------------------
+  for (int j = tid; j < K; j += 256) uphi[j] = sqrt(A[(size_t)j * K + j]);  // uphi is free now: standard deviations
+  __syncthreads();
+  for (int e = tid; e < K * K; e += 256) {
+    const int p = e / K, q = e % K;
+    A[e] = (p == q) ? 1.0 : A[e] / (uphi[p] * uphi[q]);
+  }
+  __syncthreads();
+  for (int j = 0; j < K; ++j) {
+    if (tid == 0) {
+      double sacc = A[(size_t)j * K + j];
+      for (int k = 0; k < j; ++k) sacc -= A[(size_t)j * K + k] * A[(size_t)j * K + k];
+      A[(size_t)j * K + j] = sacc > 1e-10 ? sqrt(sacc) : 0.0;
+    }
+    __syncthreads();
+    const double l = A[(size_t)j * K + j];
+    for (int i = j + 1 + tid; i < K; i += 256) {
+      double t = 0.0;
+      if (l > 0.0) {
+        t = A[(size_t)i * K + j];
+        for (int k = 0; k < j; ++k) t -= A[(size_t)i * K + k] * A[(size_t)j * K + k];
+        t /= l;
+      }
+      A[(size_t)i * K + j] = t;
+    }
+    __syncthreads();
+  }
+  // ---- 7. lattice generators: frac(sqrt(prime_i)) -----------------------------------------------------------------------------
+  if (tid == 0) {
+    int found = 0;
+    for (int cand = 2; found < K; ++cand) {
+      bool prime = true;
+      for (int q = 2; q * q <= cand; ++q)
+        if (cand % q == 0) {
+          prime = false;
+          break;
+        }
+      if (prime) alpha[found++] = mvn_alpha(cand);
+    }
+  }
+  __syncthreads();
+  // ---- 8. the integral: kMvnShifts shifted lattices, points doubled until the spread of the shift means is small -------------------
+  double* y = ymem + tid;  // element q of this thread: y[q * 256]
+  double acc[kMvnShifts];
+#pragma unroll
+  for (int j = 0; j < kMvnShifts; ++j) acc[j] = 0.0;
+  long long done = 0;
+  double est = 0.0, err = 1.0;
+  for (long long P = 1024; P <= kMvnPoints; P *= 2) {
+    for (int j = 0; j < kMvnShifts; ++j) {
+      double sacc = 0.0;
+      for (long long k = done + tid; k < P; k += 256) sacc += mvn_band_point_strided(A, K, K, T, alpha, j, k + 1, y, 256);
+      acc[j] += sacc;
+    }
+    done = P;
+    // means per shift, then their mean and standard error
+    double mean = 0.0, sq = 0.0;
+    for (int j = 0; j < kMvnShifts; ++j) {
+      sRed[tid] = acc[j];
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) sRed[tid] += sRed[tid + w];
+        __syncthreads();
+      }
+      const double mj = sRed[0] / (double)P;
+      __syncthreads();
+      mean += mj;
+      sq += mj * mj;
+    }
+    mean /= kMvnShifts;
+    const double var = fmax(0.0, sq / kMvnShifts - mean * mean) / (kMvnShifts - 1);
+    est = mean;
+    err = 3.5 * sqrt(var);
+    if (err < 5e-5) break;
+  }
+  if (tid == 0) {
+    out->vt_p = 1.0 - est;
+    out->vt_p_error = err;
+    out->vt_ok = 1;
   }
 }
 

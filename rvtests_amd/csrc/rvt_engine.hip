@@ -884,11 +884,11 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
 
 // Arena layout of one gene of a batch (shared by run_batch and rvt_reserve).
 struct GeneOff {
-  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, dbg_flip, dbg_kept;
+  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, vt, dbg_flip, dbg_kept;
 };
 // hc: 1 = hard-call path (no mask planes, burden records per wave-part), 0 = general path, -1 = either (rvt_reserve)
 static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, int hc, size_t* total,
-                        GeneOff* o) {
+                        GeneOff* o, bool vt = false) {
   auto add = [&](size_t bytes) {
     *total = (*total + 255) / 256 * 256;
     const size_t at = *total;
@@ -906,6 +906,7 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   o->lambda = add(sizeof(double) * 2 * M);
   o->qags = add(qags_workspace_bytes(kSkatoLimit));
   o->stats = add(sizeof(GeneStats));
+  o->vt = vt ? add(sizeof(double) * gene_vt_doubles(Mp)) : 0;
   o->dbg_flip = o->dbg_kept = 0;
   if (dbg) {
     o->dbg_flip = add(sizeof(int) * M);
@@ -995,7 +996,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       for (int j = 0; j < M; ++j)  // predicted flips: column sum > N  <=>  allele frequency > 1/2 (verified on the device)
         if (af[af_total + j] > 0.5) gd.pflip[j >> 4] |= (unsigned short)(1u << (j & 15));
     }
-    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc, &total, &offs[g]);
+    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc, &total, &offs[g],
+                (tests & RVT_TEST_ANALYTICVT) != 0);
     af_total += M;
   }
   const size_t off_af = add(sizeof(double) * af_total);
@@ -1043,6 +1045,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.qags_mem = base + o.qags;
     gd.af = reinterpret_cast<const double*>(base + off_af) + afpos;
     gd.stats = reinterpret_cast<GeneStats*>(base + o.stats);
+    gd.vt_mem = (tests & RVT_TEST_ANALYTICVT) ? reinterpret_cast<double*>(base + o.vt) : nullptr;
     gd.result = reinterpret_cast<rvt_gene_result*>(base + off_res) + g;
     if (dbg) {
       gd.dbg_flip = reinterpret_cast<int*>(base + o.dbg_flip);
@@ -1224,6 +1227,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     else
       hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
                          n_bparts);
+  }
+  if ((tests & RVT_TEST_ANALYTICVT) && !(tests & RVT_TEST_FAMSKAT)) {
+    Scope sc(c, 2, st);
+    hipLaunchKernelGGL(gene_vt_kernel, dim3(n), dim3(256), 0, st, d_desc, c->d_nc);
   }
   const unsigned tests_eig = (tests & RVT_TEST_FAMSKAT) ? (unsigned)RVT_TEST_SKAT : tests_eff;
   if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO | RVT_TEST_FAMSKAT)) {

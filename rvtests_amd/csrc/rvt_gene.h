@@ -235,7 +235,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
       }
     }
   }
-  if (m == 0 || !(tests & (RVT_TEST_SKAT | RVT_TEST_SKATO))) {
+  if (m == 0 || !(tests & (RVT_TEST_SKAT | RVT_TEST_SKATO | RVT_TEST_ANALYTICVT))) {
     co.sync();
     return;
   }

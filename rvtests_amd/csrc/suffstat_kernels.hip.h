@@ -48,6 +48,7 @@ struct GeneDesc {
   unsigned short pflip[8];  // predicted flip bits (af > 0.5) per 16-variant block, first 6 blocks
   int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
   int hc;                   // 1: the block holds only 0.0 / 1.0 / 2.0 and went through gene_suffstat_hc
+  double* vt_mem;           // AnalyticVT workspace (gene_vt_doubles(Mp)), null unless the test is requested
 };
 
 struct NullDev {

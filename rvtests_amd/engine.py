@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBNAME = "librvtests_amd.so"
 
 TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL = 1, 2, 4, 8, 15
+TEST_ANALYTICVT = 128
 MAX_INFLIGHT = 8  # RVT_MAX_INFLIGHT (include/rvtests_amd.h)
 TRAIT_QUANTITATIVE, TRAIT_BINARY = 0, 1
 
@@ -50,6 +51,9 @@ class GeneResult(C.Structure):
         ("famcmc_p", C.c_double),
         ("famzeg_ok", C.c_int), ("famzeg_af", C.c_double), ("famzeg_U", C.c_double), ("famzeg_V", C.c_double),
         ("famzeg_p", C.c_double),
+        ("vt_ok", C.c_int), ("vt_optnum", C.c_int), ("vt_ncutoff", C.c_int),
+        ("vt_minmaf", C.c_double), ("vt_maxmaf", C.c_double), ("vt_optmaf", C.c_double), ("vt_U", C.c_double),
+        ("vt_V", C.c_double), ("vt_stat", C.c_double), ("vt_p", C.c_double), ("vt_p_error", C.c_double),
     ]
 
 

@@ -167,3 +167,21 @@ def gene(G, af, X, res, v, binary, sigma2, tests=15, params=None, bstats=None):
                   kept.ctypes.data_as(c_int_p), _dp(lam), _dp(dbg))
     out.dbg = dbg
     return out, flip, kept, lam
+
+
+def mvn_band(R, T):
+    """(probability, 3.5-sigma error estimate) of P(|Z_i| < T) by the device's deterministic lattice rule."""
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    err = C.c_double(0.0)
+    L = lib()
+    L.hc_mvn_band.restype = C.c_double
+    L.hc_mvn_band.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double)]
+    p = L.hc_mvn_band(_dp(R), R.shape[0], float(T), C.byref(err))
+    return p, err.value
+
+
+def mvn_phiinv(p):
+    L = lib()
+    L.hc_mvn_phiinv.restype = C.c_double
+    L.hc_mvn_phiinv.argtypes = [C.c_double]
+    return L.hc_mvn_phiinv(float(p))

@@ -497,3 +497,68 @@ def vcf_decode_record(text, row_of_sample, n_rows, gt_idx, gd_idx=-1, gq_idx=-1,
     n = L.orc_vcf_decode_record(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), gt_idx, gd_idx, gq_idx,
                                 flt.ctypes.data_as(c_int_p), out.ctypes.data_as(C.POINTER(C.c_int8)))
     return out, n
+
+
+# ---- AnalyticVT (oracle/orc_vt.cpp; reference fragment oracle/_ref/libref_mvt.so = the reference's mvt.f) -----------------
+class VtResult(C.Structure):
+    _fields_ = [("fit_ok", C.c_int), ("n_poly", C.c_int), ("opt_num", C.c_int), ("n_cutoff", C.c_int),
+                ("min_maf", C.c_double), ("max_maf", C.c_double), ("opt_maf", C.c_double), ("U", C.c_double),
+                ("V", C.c_double), ("stat", C.c_double), ("pvalue", C.c_double), ("p_err", C.c_double)]
+
+
+def analytic_vt(G, af, X, y, mvn_points=4096):
+    """(rc, VtResult, correlation matrix of the threshold statistics)."""
+    G = F(G)
+    X = F(X)
+    N, M = G.shape
+    d = X.shape[1]
+    af = np.ascontiguousarray(af, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = VtResult()
+    cor = np.zeros((M, M))
+    L = lib()
+    L.orc_analytic_vt.restype = C.c_int
+    rc = L.orc_analytic_vt(_dp(G), _dp(af), _dp(X), _dp(y), C.c_int64(N), M, d, C.c_longlong(mvn_points), C.byref(out),
+                           _dp(cor))
+    K = out.n_cutoff
+    return rc, out, cor.ravel()[:K * K].reshape(K, K).copy()
+
+
+def mvn_band(R, T, points=4096):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    err = C.c_double(0.0)
+    L = lib()
+    L.orc_mvn_band.restype = C.c_double
+    L.orc_mvn_band.argtypes = [c_double_p, C.c_int, C.c_double, C.c_longlong, c_double_p]
+    p = L.orc_mvn_band(_dp(R), R.shape[0], float(T), points, C.byref(err))
+    return p, err.value
+
+
+_ref_mvt = None
+
+
+def ref_mvt():
+    """The reference's own MVTDST (mvt.f built with flang), or None where it is not built."""
+    global _ref_mvt
+    if _ref_mvt is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_mvt.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_mvn_band.restype = C.c_int
+        R.ref_mvn_band.argtypes = [C.c_int, C.c_double, c_double_p, C.c_uint, c_double_p, c_double_p]
+        _ref_mvt = R
+    return _ref_mvt
+
+
+def ref_mvn_band(R, T, seed=1):
+    """(inform, probability, error estimate) from the reference's MVTDST with MvtNorm's settings."""
+    lib_ = ref_mvt()
+    R = np.asarray(R, dtype=np.float64)
+    n = R.shape[0]
+    packed = np.array([R[i, j] for i in range(1, n) for j in range(i)], dtype=np.float64)
+    if packed.size == 0:
+        packed = np.zeros(1)
+    prob, err = C.c_double(0.0), C.c_double(0.0)
+    inform = lib_.ref_mvn_band(n, float(T), _dp(packed), int(seed), C.byref(prob), C.byref(err))
+    return inform, prob.value, err.value

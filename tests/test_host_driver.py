@@ -489,3 +489,33 @@ def test_driver_metascore_with_kinship(tmp_path, binary):
         got = [float(row[2].split(":")[0])] + [float(t) for t in row[-5:]]
         assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
     assert tested > 10
+
+
+@pytest.mark.gpu
+def test_driver_analytic_vt_rows(tmp_path):
+    """--vt analytic through the C++ adapter: header, %g-style columns, NA rule, numbers against the oracle."""
+    _ensure_driver()
+    N, d = 800, 2
+    genes = [synth.make_gene(N, M, seed=310 + M, missing=0.01, common=(M > 10), mono=True)[1:] for M in (6, 21, 35)]
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=29)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, genes)
+    env = dict(os.environ)
+    env["RVT_DRIVER_VT"] = "analytic"
+    p = subprocess.run([DRIVER, path, "-", "-"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.AnalyticVT.assoc"
+    assert lines[1].split("\t")[-8:] == ["MinMAF", "MaxMAF", "OptimMAF", "OptimNumVar", "U", "V", "Stat", "Pvalue"]
+    rows = [ln.split("\t") for ln in lines[2:]]
+    assert len(rows) == len(genes)
+    for row, (G, af) in zip(rows, genes):
+        rc, o, cor = orc.analytic_vt(G, af, X, y, mvn_points=1024)
+        if rc != 0:
+            assert row[-8:] == ["NA"] * 8
+            continue
+        got = row[-8:]
+        assert int(got[3]) == o.opt_num
+        for k, want in zip((0, 1, 2, 4, 5, 6), (o.min_maf, o.max_maf, o.opt_maf, o.U, o.V, o.stat)):
+            assert abs(float(got[k]) - want) <= 6e-6 * abs(want) + 1e-12          # floatToString: 6 digits
+        assert abs(float(got[7]) - o.pvalue) <= 2e-3
