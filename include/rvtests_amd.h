@@ -373,6 +373,28 @@ typedef struct rvt_decompose_info {
 int rvt_kinship_decompose(rvt_ctx* ctx, int64_t N, const float* K, float* U_out, float* S_out, int install,
                           rvt_decompose_info* info);
 
+/* ---- KBAC (--kernel kbac[nPerm:alpha], KBACTest src/Model.h:2891-3045 over regression/kbac.cpp) --------------------------------
+ * Genotype-pattern test for BINARY traits WITHOUT covariates: every sample's multi-site genotype pattern over the
+ * flipped, polymorphic columns with 0 < frequency <= 1 (imputed non-integers count as wild type), the statistic
+ * sum over patterns of (case frequency - control frequency) x hypergeometric kernel weight, and nperm cumulative
+ * std::random_shuffle permutations of the phenotype on the process-wide rand() stream (the same emulated stream as the
+ * SKAT permutations, rvt_rand_seed; consumed in gene order) with the reference's adaptive stopping rule (every 5000
+ * permutations when alpha < 1).  pvalue is what KBACTest prints with "%f".  The device holds the blocks (as for
+ * rvt_run_blocks) and a null model must be set (it defines N); y = the 0 / 1 phenotype, af = the concatenated
+ * frequencies dc->getMarkerFrequency(j) of every gene's columns. */
+typedef struct rvt_kbac_result {
+  int fit_ok;      /* 0: no polymorphic column (NA row) */
+  int n_poly;      /* columns after flip-to-minor + monomorphic removal */
+  int n_pattern;   /* distinct non-wild-type genotype patterns */
+  int n_carrier;   /* samples with a non-wild-type pattern */
+  int actual_perm; /* permuted statistics evaluated */
+  int num_ge, num_le; /* permutations with statistic >= / <= observed */
+  double stat;     /* observed statistic */
+  double pvalue;
+} rvt_kbac_result;
+int rvt_kbac_blocks(rvt_ctx* ctx, int n, const double* const* dG, const int* M, const double* af, const double* y,
+                    int nperm, double alpha, rvt_kbac_result* out);
+
 /* ---- raw / packed genotypes at the boundary (SURVEY §8f "next" #1) --------------------------------------------------
  * Like rvt_submit_gene, but the block is what the genotype extractor produced, BEFORE DataConsolidator::consolidate:
  * missing genotypes are negative (-9, libVcf/VCFConstant.h:4).  The device then does what consolidate() does to the

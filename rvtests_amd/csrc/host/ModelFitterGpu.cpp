@@ -438,6 +438,52 @@ std::string AnalyticVTTest::formatRow(const rvt_gene_result* r) const {
          floatToString(r->vt_stat) + "\t" + floatToString(r->vt_p) + "\n";
 }
 
+// ---- KbacTest ---------------------------------------------------------------------------------------------------------------
+KbacTest::KbacTest(int nPerm_, double alpha_) : nPerm(nPerm_), alpha(alpha_) { modelName = "Kbac"; }
+int KbacTest::fit(GeneData* dc) {
+  fitOK = false;
+  if (!isBinaryOutcome()) {  // src/Model.h:2930-2936
+    lastError = "KBAC test does not support continuous outcomes. Results will be all NAs.";
+    return -1;
+  }
+  if (dc->ncov != 0) {  // src/Model.h:2937-2942
+    lastError = "KBAC test does not support covariates. Results will be all NAs.";
+    return -1;
+  }
+  rvt_ctx* ctx = GpuBroker::instance().contextWithNull(*dc, true, &lastError);  // (the null model defines N on the device)
+  if (!ctx) return -1;
+  double* block = nullptr;
+  if (rvt_block_alloc(ctx, dc->M, &block) || rvt_block_upload(ctx, block, dc->M, dc->genotype)) {
+    lastError = rvt_last_error(ctx);
+    if (block) rvt_block_free(ctx, block);
+    return -1;
+  }
+  const double* bp = block;
+  const int M = dc->M;
+  const int rc = rvt_kbac_blocks(ctx, 1, &bp, &M, dc->markerFrequency.data(), dc->phenotype, nPerm, alpha, &rec);
+  rvt_block_free(ctx, block);
+  if (rc) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  fitOK = rec.fit_ok != 0;
+  return fitOK ? 0 : -1;
+}
+void KbacTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.headerTab());
+  fp->write("Pvalue\n");
+}
+void KbacTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  fp->write(siteInfo.valueTab());
+  if (!fitOK) {
+    fp->write("NA\n");
+  } else {
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%f\n", rec.pvalue);  // fp->printf("%f\n", this->pValue), src/Model.h:3005
+    fp->write(buf);
+  }
+}
+
 // ---- FamSkatTest ----------------------------------------------------------------------------------------------------------
 FamSkatTest::FamSkatTest(double, double) {
   modelName = "FamSkat";
@@ -961,6 +1007,9 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         double beta1, beta2;
         parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);
         model.push_back(new SkatOTest(beta1, beta2));
+      } else if (modelName == "kbac") {
+        parser.assign("nPerm", &nPerm, 10000).assign("alpha", &alpha, 0.05);
+        model.push_back(new KbacTest(nPerm, alpha));
       } else if (modelName == "famskat") {
         double beta1, beta2;
         parser.assign("beta1", &beta1, 1.0).assign("beta2", &beta2, 25.0);  // src/ModelManager.cpp:188-193

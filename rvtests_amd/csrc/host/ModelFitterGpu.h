@@ -284,6 +284,23 @@ class AnalyticVTTest : public ModelFitter {
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
 };
 
+// `--kernel kbac[nPerm=10000:alpha=0.05]` (src/ModelManager.cpp kernel switch; KBACTest, src/Model.h:2891-3045): binary
+// traits without covariates, one column "Pvalue" printed with %f.  Synchronous: the permutations consume the process-wide
+// random stream gene by gene.
+class KbacTest : public ModelFitter {
+ public:
+  KbacTest(int nPerm, double alpha);
+  int fit(GeneData* dc) override;
+  void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
+  void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  int nPerm;
+  double alpha;
+  bool fitOK = false;
+  rvt_kbac_result rec{};
+};
+
 // `--kernel famSkat[beta1:beta2]` (src/Model.h:3048-3145).  The reference ignores beta1 / beta2 for this model
 // (FamSkat.cpp:129-137 always uses Beta(1, 25)); so does this adapter.
 class FamSkatTest : public ModelFitter {

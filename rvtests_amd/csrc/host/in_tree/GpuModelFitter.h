@@ -120,6 +120,7 @@ typedef GpuModel<rvt_host::FamSkatTest> FamSkatTest;  // new FamSkatTest(beta1, 
 typedef GpuModel<rvt_host::FamBurdenTest> FamBurdenTest;
 typedef GpuModel<rvt_host::MetaCovTest> MetaCovTest;      // new MetaCovTest(windowSize)            :238-247
 typedef GpuModel<rvt_host::MetaScoreTest> MetaScoreTest;  // new MetaScoreTest()
+typedef GpuModel<rvt_host::KbacTest> KBACTest;            // new KBACTest(nPerm, alpha)
 // new AnalyticVT(AnalyticVT::UNRELATED)   ModelManager.cpp:158-159 (the RELATED variant is not provided)
 class AnalyticVT : public GpuModel<rvt_host::AnalyticVTTest> {
  public:

@@ -30,6 +30,7 @@ int rvt_binding_check(DataConsolidator* dc, FileWriter* fp, const Result& siteIn
   model.push_back(new rvt_intree::MetaCovTest(windowSize));
   model.push_back(new rvt_intree::MetaScoreTest());
   model.push_back(new rvt_intree::AnalyticVT(rvt_intree::AnalyticVT::UNRELATED));  // src/ModelManager.cpp:158-159
+  model.push_back(new rvt_intree::KBACTest(nPerm, alpha));
   int rc = 0;
   for (size_t m = 0; m < model.size(); ++m) {  // src/ModelManager.cpp:273-282, src/Main.cpp:1207-1256
     model[m]->setParameter(parser);

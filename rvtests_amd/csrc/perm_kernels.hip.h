@@ -56,6 +56,79 @@ __global__ __launch_bounds__(64) void perm_fisher_yates_kernel(const uint32_t* _
   }
 }
 
+// std::random_shuffle as libstdc++ implements it (the KBAC permutations, regression/kbac.cpp:323): i = 1 .. N-1,
+// j = rand() % (i + 1), swap(i, j).  Same state layout and draw as perm_fisher_yates_kernel, forward order.
+__global__ __launch_bounds__(64) void perm_random_shuffle_kernel(const uint32_t* __restrict__ states,
+                                                                 uint32_t* __restrict__ idx, long long N, int B) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  uint32_t x[31];
+#pragma unroll
+  for (int t = 0; t < 31; ++t) x[t] = states[(long long)p * 31 + t];
+  long long i = 1;
+  while (i < N) {
+#pragma unroll
+    for (int t = 0; t < 31; ++t) {
+      if (i < N) {
+        const uint32_t v = x[t] + x[(t + 28) % 31];
+        x[t] = v;
+        const uint32_t r = v >> 1;                          // rand()
+        const uint32_t j = r % (uint32_t)(i + 1);           // 0 <= j <= i
+        if ((long long)j != i) {
+          uint32_t* pi = idx + i * (long long)B + p;
+          uint32_t* pj = idx + (long long)j * B + p;
+          const uint32_t a = *pi, b = *pj;
+          *pi = b;
+          *pj = a;
+        }
+        ++i;
+      }
+    }
+  }
+}
+
+// next[k] = cur[idx[k][p]] for a vector of bytes (the 0 / 1 phenotype of the KBAC permutations)
+__global__ void perm_apply_u8_kernel(const uint32_t* __restrict__ idx, const unsigned char* __restrict__ cur,
+                                     unsigned char* __restrict__ next, long long N, int B, int p) {
+  const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  next[k] = cur[idx[k * B + p]];
+}
+
+// out[c] = vec[carrier[c]]
+__global__ void perm_gather_u8_kernel(const unsigned char* __restrict__ vec, const int* __restrict__ carrier, int n,
+                                      unsigned char* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) out[c] = vec[carrier[c]];
+}
+
+// KBAC genotype-pattern id of every sample (regression/kbac.cpp:120-147), exactly as the reference's double arithmetic
+// runs: columns in order, invalid codings (anything but 0 / 1 / 2: imputed means) count as wild type, p3[k] = the host's
+// pow(3.0, k).  G: flipped / polymorphic block (column-major, ld), cols: the n_used columns that survive the frequency trim.
+__global__ void kbac_pattern_kernel(const double* __restrict__ G, long long N, long long ld, const int* __restrict__ cols,
+                                    int n_used, const double* __restrict__ p3, double* __restrict__ id) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double ixiix = 3486784401.0;  // pow(9.0, 10.0)
+  double L = 0.0, R = 0.0;
+  unsigned lastCnt = 0, tmpCnt = 0;
+  for (unsigned j = 0; j != (unsigned)n_used; ++j) {
+    double g = G[(long long)cols[j] * ld + i];
+    if (g != 0.0 && g != 1.0 && g != 2.0) g = 0.0;
+    if (g == 0.0) continue;
+    R = __dadd_rn(R, __dmul_rn(p3[j - lastCnt], g));  // (no contraction: two roundings, as on the host)
+    if (R >= ixiix) {
+      L = L + 1.0;
+      R = R - ixiix;
+      lastCnt = lastCnt + tmpCnt + 1;
+      tmpCnt = 0;
+    } else {
+      ++tmpCnt;
+    }
+  }
+  id[i] = __dadd_rn(L, __dmul_rn(R, 1e-10));
+}
+
 // cumulative application of shuffle p to the current residual vector: next[k] = cur[idx[k][p]];
 // also column p of the chunk matrix Rp (N x B column-major: Rp[k + p*N])
 __global__ void perm_apply_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ cur,

@@ -35,6 +35,7 @@ void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N,
 #include "perm_kernels.hip.h"
 #include "vcf_kernels.hip.h"
 #include "jacobi_kernels.hip.h"
+#include "rvt_hyper.h"
 
 using namespace rvt;
 
@@ -2793,6 +2794,206 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   return RVT_OK;
 }
 
+// KBAC (KBACTest::fit, src/Model.h:2925-2998 over regression/kbac.cpp) of one gene.  y: the 0 / 1 phenotype (host).
+int kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std::vector<unsigned char>& y, int nPerm,
+               double alpha, rvt_kbac_result* r) {
+  std::memset(r, 0, sizeof(*r));
+  r->pvalue = 9.0;
+  const int64_t N = c->nc.N, ld = c->nc.ld;
+  hipStream_t st = c->stream;
+  // ---- flipped, polymorphic block (dc->getFlippedToMinorPolymorphicGenotype()) ---------------------------------------
+  std::vector<const double*> cols(M);
+  for (int j = 0; j < M; ++j) cols[j] = dG + (size_t)j * ld;
+  const double** d_cols = nullptr;
+  int* d_flags = nullptr;
+  double* d_id = nullptr;
+  int* d_carrier = nullptr;
+  unsigned char *d_y = nullptr, *d_sub = nullptr;
+  struct Guard {
+    std::vector<void**> p;
+    ~Guard() {
+      for (void** q : p)
+        if (*q) hipFree(*q);
+    }
+  } guard{{(void**)&d_cols, (void**)&d_flags, (void**)&d_id, (void**)&d_carrier, (void**)&d_y, (void**)&d_sub}};
+  HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * (size_t)M * 2));
+  HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * (size_t)M * 3));
+  HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * M, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+  std::vector<int> flags(M);
+  HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  std::vector<const double*> kc;
+  std::vector<int> kf;
+  for (int j = 0; j < M; ++j)
+    if (flags[j] & 2) {
+      kc.push_back(cols[j]);
+      kf.push_back(flags[j] & 1);
+    }
+  const int m = (int)kc.size();
+  r->n_poly = m;
+  if (m == 0) {  // genotype.cols == 0: xdat is empty, KbacTest's constructor would reject it; rvtests prints what it got
+    r->fit_ok = 0;
+    return RVT_OK;
+  }
+  int rc = ensure_fam_cols(c, (size_t)m, ld);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(d_cols + M, kc.data(), sizeof(double*) * m, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(d_flags + M, kf.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)m), dim3(256), 0, st, d_cols + M, d_flags + M,
+                     (long long)N, (long long)ld, c->d_Gp);
+  // ---- m_trimXdat: columns with 0 < maf <= 1 (maf of filtered position j = counter of unfiltered column j) --------------
+  std::vector<int> use;
+  for (int j = 0; j < m; ++j)
+    if (!(af[j] <= 0.0 || af[j] > 1.0)) use.push_back(j);
+  const int n_used = (int)use.size();
+  std::vector<double> id((size_t)N, 0.0);
+  if (n_used > 0) {
+    std::vector<double> p3((size_t)n_used + 1);
+    for (int k = 0; k <= n_used; ++k) p3[k] = std::pow(3.0, 1.0 * k);  // the host's pow, as the reference evaluates it
+    double* d_p3 = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_id, sizeof(double) * ((size_t)N + p3.size())));
+    d_p3 = d_id + N;
+    HIP_TRY(c, hipMemcpyAsync(d_p3, p3.data(), sizeof(double) * p3.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_flags + 2 * M, use.data(), sizeof(int) * n_used, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kbac_pattern_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_Gp, (long long)N,
+                       (long long)ld, d_flags + 2 * M, n_used, d_p3, d_id);
+    HIP_TRY(c, hipMemcpyAsync(id.data(), d_id, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+  }
+  // ---- unique patterns (ascending), their counts, the carriers --------------------------------------------------------
+  std::vector<double> pat;
+  for (int64_t i = 0; i < N; ++i)
+    if (id[i] != 0.0) pat.push_back(id[i]);
+  if (pat.empty()) {  // "non-wildtype genotype data is empty ... Return p-value 1.0"
+    r->fit_ok = 1;
+    r->pvalue = 1.0;
+    return RVT_OK;
+  }
+  std::sort(pat.begin(), pat.end());
+  pat.erase(std::unique(pat.begin(), pat.end()), pat.end());
+  const int P = (int)pat.size();
+  std::vector<int> carrier, cpat;
+  std::vector<unsigned> cnt(P, 0);
+  for (int64_t i = 0; i < N; ++i)
+    if (id[i] != 0.0) {
+      const int u = (int)(std::lower_bound(pat.begin(), pat.end(), id[i]) - pat.begin());
+      carrier.push_back((int)i);
+      cpat.push_back(u);
+      ++cnt[u];
+    }
+  const int nc_ = (int)carrier.size();
+  r->n_pattern = P;
+  r->n_carrier = nc_;
+  unsigned nCases = 0;
+  for (int64_t i = 0; i < N; ++i) nCases += y[i] == 1;
+  const unsigned nCtrls = (unsigned)N - nCases;
+  // kernel weights for every possible case count of every pattern
+  static const Hypergeometric hyper;
+  std::vector<std::vector<double>> W(P);
+  for (int u = 0; u < P; ++u) {
+    W[u].resize(cnt[u] + 1);
+    for (unsigned k = 0; k <= cnt[u]; ++k) W[u][k] = hyper.cdf(k, cnt[u], (unsigned)N - cnt[u], nCases);
+  }
+  std::vector<unsigned> sub(P);
+  auto statistic = [&](const unsigned char* yc) {  // yc: phenotype of the carriers, in carrier order
+    std::fill(sub.begin(), sub.end(), 0u);
+    for (int q = 0; q < nc_; ++q) sub[cpat[q]] += yc[q] == 1;
+    double kbac = 0.0;
+    for (int u = 0; u < P; ++u)
+      kbac = kbac + ((1.0 * sub[u]) / (1.0 * nCases) - (1.0 * (cnt[u] - sub[u])) / (1.0 * nCtrls)) * W[u][sub[u]];
+    return kbac;
+  };
+  std::vector<unsigned char> yc(nc_);
+  for (int q = 0; q < nc_; ++q) yc[q] = y[carrier[q]];
+  const double observed = statistic(yc.data());
+  r->stat = observed;
+  // ---- permutations: cumulative std::random_shuffle of the phenotype, chunks of B shuffles -------------------------------
+  const unsigned adaptive = alpha >= 1.0 ? 0u : 5000u;
+  const int total = nPerm + 1;  // the loop shuffles once more after the last statistic (kbac.cpp:185,323-324)
+  const int B = std::max(1, std::min(total, (int)std::min<int64_t>(2048, ((int64_t)6 << 30) / (4 * N))));
+  if ((size_t)N * B > c->perm_cap_NB || B > c->perm_cap_B) {
+    for (void** p : {(void**)&c->d_perm_idx, (void**)&c->d_perm_states, (void**)&c->d_perm_R, (void**)&c->d_perm_C,
+                     (void**)&c->d_perm_Q, (void**)&c->d_perm_cur}) {
+      if (*p) hipFree(*p);
+      *p = nullptr;
+    }
+    c->perm_cap_NB = c->perm_cap_BM = 0;
+    c->perm_cap_B = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_idx, sizeof(uint32_t) * (size_t)N * B));
+    HIP_TRY(c, hipMalloc((void**)&c->d_perm_states, sizeof(uint32_t) * 31 * (size_t)B));
+    c->perm_cap_NB = (size_t)N * B;
+    c->perm_cap_B = B;
+  }
+  if (c->jump_N != N) {
+    c->jump.resize(31 * 31);
+    jump_matrix((uint64_t)(N - 1), c->jump.data());  // one shuffle draws N-1 numbers
+    c->jump_N = N;
+  }
+  HIP_TRY(c, hipMalloc((void**)&d_y, (size_t)N * 2));
+  HIP_TRY(c, hipMalloc((void**)&d_sub, (size_t)B * nc_));
+  HIP_TRY(c, hipMalloc((void**)&d_carrier, sizeof(int) * (size_t)nc_));
+  HIP_TRY(c, hipMemcpyAsync(d_carrier, carrier.data(), sizeof(int) * (size_t)nc_, hipMemcpyHostToDevice, st));
+  unsigned char *cur = d_y, *nxt = d_y + N;
+  HIP_TRY(c, hipMemcpyAsync(cur, y.data(), (size_t)N, hipMemcpyHostToDevice, st));
+  uint32_t s0[31];
+  std::memcpy(s0, c->rand_state, sizeof(s0));
+  std::vector<uint32_t> states((size_t)31 * (B + 1));
+  std::vector<unsigned char> ysub((size_t)B * nc_);
+  unsigned pc1 = 0, pc2 = 0;
+  int done = 0;  // shuffles performed = statistics evaluated after the observed one
+  bool stop = false;
+  while (!stop && done < nPerm) {
+    const int nb = std::min(B, nPerm - done);
+    std::memcpy(states.data(), s0, sizeof(s0));
+    for (int p = 0; p < nb; ++p) mat31_apply(c->jump.data(), &states[(size_t)31 * p], &states[(size_t)31 * (p + 1)]);
+    HIP_TRY(c, hipMemcpyAsync(c->d_perm_states, states.data(), sizeof(uint32_t) * 31 * (size_t)nb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(perm_init_kernel, dim3(2048), dim3(256), 0, st, c->d_perm_idx, (long long)N, B);
+    hipLaunchKernelGGL(perm_random_shuffle_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, c->d_perm_states,
+                       c->d_perm_idx, (long long)N, B);
+    for (int p = 0; p < nb; ++p) {  // the shuffles are cumulative: apply them in order, keep the carriers' phenotype
+      hipLaunchKernelGGL(perm_apply_u8_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, c->d_perm_idx, cur, nxt,
+                         (long long)N, B, p);
+      hipLaunchKernelGGL(perm_gather_u8_kernel, dim3((unsigned)((nc_ + 255) / 256)), dim3(256), 0, st, nxt, d_carrier, nc_,
+                         d_sub + (size_t)p * nc_);
+      std::swap(cur, nxt);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(ysub.data(), d_sub, (size_t)nb * nc_, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+    int used = 0;
+    for (; used < nb; ++used) {
+      const double s = statistic(&ysub[(size_t)used * nc_]);
+      ++done;
+      if (s >= observed) ++pc1;
+      if (s <= observed) ++pc2;
+      if (adaptive != 0 && (unsigned)done % adaptive == 0) {  // m_checkAdaptivePvalue, alternative = 0 (kbac.cpp:338-372)
+        const double ap = (1.0 * pc1 + 1.0) / (1.0 * done + 1.0);
+        const double sd = std::sqrt(ap * (1.0 - ap) / (1.0 * done));
+        if (ap - 6.0 * sd > alpha) {
+          r->pvalue = ap;
+          stop = true;
+          ++used;
+          break;
+        }
+      }
+    }
+    std::memcpy(s0, &states[(size_t)31 * used], sizeof(s0));
+  }
+  if (!stop) {  // every statistic evaluated: the reference's loop shuffles once more before it ends
+    uint32_t t[31];
+    mat31_apply(c->jump.data(), s0, t);
+    std::memcpy(s0, t, sizeof(s0));
+    r->pvalue = (1.0 * pc1 + 1.0) / (1.0 * nPerm + 1.0);
+  }
+  std::memcpy(c->rand_state, s0, sizeof(s0));
+  r->fit_ok = 1;
+  r->actual_perm = done;
+  r->num_ge = (int)pc1;
+  r->num_le = (int)pc2;
+  return RVT_OK;
+}
+
 // analytic tests + permutation test, one gene at a time (the random stream is consumed in gene order)
 int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
                          const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out) {
@@ -2847,6 +3048,30 @@ static int block_hard_calls(rvt_ctx* c, const double* dG, int V, std::vector<int
   if (any) *any = some;
   if (colflag) *colflag = std::move(f);
   return all ? 1 : 0;
+}
+
+// ---- KBAC (--kernel kbac): genotype-pattern permutation test, binary traits without covariates ---------------------------------
+int rvt_kbac_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af, const double* y,
+                    int nperm, double alpha, rvt_kbac_result* out) {
+  if (!c || n < 0 || (n > 0 && (!dG || !M || !af || !y || !out)) || nperm < 0) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set (it defines the sample count)");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  const int64_t N = c->nc.N;
+  std::vector<unsigned char> yb((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    if (y[i] != 0.0 && y[i] != 1.0) return fail(c, RVT_E_INVALID, "KBAC needs a 0 / 1 phenotype");
+    yb[i] = y[i] == 1.0;
+  }
+  size_t afo = 0;
+  for (int g = 0; g < n; ++g) {  // one gene at a time: the random stream is consumed in gene order
+    if (M[g] < 1 || M[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M[g]);
+    rc = kbac_stage(c, dG[g], M[g], af + afo, yb, nperm, alpha, out + g);
+    if (rc) return rc;
+    afo += (size_t)M[g];
+  }
+  return RVT_OK;
 }
 
 // ---- MetaScore: single-variant score statistics of a block of variants (unrelated samples) -----------------

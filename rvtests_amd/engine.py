@@ -282,6 +282,12 @@ def _dp(a):
     return a.ctypes.data_as(c_double_p)
 
 
+class KbacResult(C.Structure):
+    _fields_ = [("fit_ok", C.c_int), ("n_poly", C.c_int), ("n_pattern", C.c_int), ("n_carrier", C.c_int),
+                ("actual_perm", C.c_int), ("num_ge", C.c_int), ("num_le", C.c_int), ("stat", C.c_double),
+                ("pvalue", C.c_double)]
+
+
 class DecomposeInfo(C.Structure):
     _fields_ = [("sweeps", C.c_int), ("max_cosine", C.c_double), ("padded_order", C.c_int64), ("shift", C.c_double),
                 ("max_residual", C.c_double)]
@@ -456,6 +462,19 @@ class Engine:
         self._check(self.L.rvt_submit_gene_bed(self.ctx, int(gene_id), int(M), bed.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
+
+    def kbac_blocks(self, ptrs, Ms, afs, y, nperm, alpha):
+        """KBAC of device-resident blocks (rvt_kbac_blocks); afs: list of per-gene frequency arrays."""
+        n = len(ptrs)
+        arr_p = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+        arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
+        af = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64) for a in afs]))
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        out = (KbacResult * n)()
+        self.L.rvt_kbac_blocks.restype = C.c_int
+        self._check(self.L.rvt_kbac_blocks(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p), _dp(af), _dp(y), int(nperm),
+                                           C.c_double(alpha), out))
+        return list(out)
 
     def kinship_decompose(self, K, install=False, want_vectors=True):
         """Eigendecomposition of the symmetric float kinship K on the device (rvt_kinship_decompose).

@@ -35,6 +35,9 @@ class GeneResult(C.Structure):
         ("famcmc_p", C.c_double),
         ("famzeg_ok", C.c_int), ("famzeg_af", C.c_double), ("famzeg_U", C.c_double), ("famzeg_V", C.c_double),
         ("famzeg_p", C.c_double),
+        ("vt_ok", C.c_int), ("vt_optnum", C.c_int), ("vt_ncutoff", C.c_int),
+        ("vt_minmaf", C.c_double), ("vt_maxmaf", C.c_double), ("vt_optmaf", C.c_double), ("vt_U", C.c_double),
+        ("vt_V", C.c_double), ("vt_stat", C.c_double), ("vt_p", C.c_double), ("vt_p_error", C.c_double),
     ]
 
 

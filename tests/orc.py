@@ -562,3 +562,29 @@ def ref_mvn_band(R, T, seed=1):
     prob, err = C.c_double(0.0), C.c_double(0.0)
     inform = lib_.ref_mvn_band(n, float(T), _dp(packed), int(seed), C.byref(prob), C.byref(err))
     return inform, prob.value, err.value
+
+
+# ---- KBAC (oracle/orc_kbac.cpp) ---------------------------------------------------------------------------------------------
+def hypergeometric_P(k, n1, n2, t):
+    L = lib()
+    L.orc_hypergeometric_P.restype = C.c_double
+    L.orc_hypergeometric_P.argtypes = [C.c_uint] * 4
+    return L.orc_hypergeometric_P(int(k), int(n1), int(n2), int(t))
+
+
+def kbac(Gf, y, maf, nperm, alpha, seed=None):
+    """Gf: N x M flipped / polymorphic / imputed genotype.  Returns (pvalue, observed statistic, patterns, permutations
+    done, next rand()).  seed: srand(seed) first (None: continue the stream)."""
+    L = lib()
+    Gf = np.ascontiguousarray(Gf, dtype=np.float64)          # people-major
+    N, M = Gf.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    maf = np.ascontiguousarray(maf, dtype=np.float64)
+    if seed is not None:
+        L.orc_rand_seed(int(seed))
+    p, obs = C.c_double(0.0), C.c_double(0.0)
+    npat, done = C.c_int(0), C.c_int(0)
+    L.orc_kbac.restype = C.c_int
+    L.orc_kbac(_dp(Gf), _dp(y), _dp(maf), N, M, int(nperm), C.c_double(alpha), C.byref(p), C.byref(obs), C.byref(npat),
+               C.byref(done))
+    return p.value, obs.value, npat.value, done.value

@@ -519,3 +519,34 @@ def test_driver_analytic_vt_rows(tmp_path):
         for k, want in zip((0, 1, 2, 4, 5, 6), (o.min_maf, o.max_maf, o.opt_maf, o.U, o.V, o.stat)):
             assert abs(float(got[k]) - want) <= 6e-6 * abs(want) + 1e-12          # floatToString: 6 digits
         assert abs(float(got[7]) - o.pvalue) <= 2e-3
+
+
+@pytest.mark.gpu
+def test_driver_kbac_rows(tmp_path):
+    """--kernel kbac[nPerm:alpha] through the C++ adapter: binary trait, no covariates; %f p-values equal to the oracle's
+    (the oracle is pinned on the reference's own kbac.cpp), genes consuming one random stream in order."""
+    _ensure_driver()
+    N = 900
+    rng = np.random.default_rng(8)
+    genes = [synth.make_gene(N, M, seed=410 + M, missing=0.01, common=False, mono=True)[1:] for M in (7, 16, 3)]
+    y = (rng.random(N) < 0.45).astype(np.float64)
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, np.zeros((N, 0)), 1, genes)
+    p = subprocess.run([DRIVER, path, "kbac[nPerm=600:alpha=0.05]", "-"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.Kbac.assoc" and lines[1].split("\t")[-1] == "Pvalue"
+    rows = [ln.split("\t") for ln in lines[2:]]
+    assert len(rows) == len(genes)
+    orc.rand_seed(1)                                   # the stream of a fresh process
+    for row, (G, af) in zip(rows, genes):
+        Gf, fl, kp = orc.flip_poly(G)
+        if Gf.shape[1] == 0:
+            assert row[-1] == "NA"
+            continue
+        pv = orc.kbac(Gf, y, af[:Gf.shape[1]], 600, 0.05)[0]
+        assert row[-1] == "%f" % pv
+    # a quantitative trait is refused with NA rows, as the reference does
+    write_input(path, rng.standard_normal(N), np.zeros((N, 0)), 0, genes)
+    p = subprocess.run([DRIVER, path, "kbac", "-"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and all(ln.split("\t")[-1] == "NA" for ln in p.stdout.splitlines()[2:])
