@@ -16,8 +16,11 @@ stats() {  # stats <name> <program args...>: rocprofv3 kernel statistics of one 
 }
 stats famskat python3 tools/bench_famskat.py --samples 100000 --genes 128
 stats metascore python3 tools/bench_metascore.py
+stats metacov python3 tools/bench_metacov.py --reps 5
 stats perm python3 tools/bench_perm.py
 stats stream_bed python3 tools/bench_stream.py --bed --genes 512
+python3 tools/bench_decompose.py --samples 3000 --kind grm > "$OUT/decompose.txt" 2>&1
+python3 tools/bench_decompose.py --samples 12000 --kind family >> "$OUT/decompose.txt" 2>&1
 ./tools/k2hc_bench bench > "$OUT/k2hc_isolated.txt" 2>&1
 ./tools/rotgemm_bench bench > "$OUT/rotgemm.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1 > "$OUT/bench_config1.json" 2>/dev/null
