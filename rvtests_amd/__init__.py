@@ -1,4 +1,5 @@
-"""rvtests_amd — MI355X-native kernel/burden association engine (SKAT, SKAT-O, CMC, Zeggini).
+"""rvtests_amd — MI355X-native kernel/burden association engine (SKAT, SKAT-O, CMC, Zeggini, FamSKAT, MetaCov,
+MetaScore, AnalyticVT, KBAC, the VCF text front end and the kinship decomposition).
 
 Python is plumbing only: this module loads the C-ABI shared library built from ``csrc/`` (hand-written
 HIP for gfx950) with ctypes and offers thin wrappers of it: ``Engine`` (one context = one GPU) and ``Group``
@@ -7,9 +8,9 @@ ModelManager plugin surface is C++ (``csrc/host/ModelFitterGpu.{h,cpp}``), as th
 CPU fallback: if the HIP library is missing or there is no GPU, construction fails loudly.
 """
 from .engine import (Engine, Group, GeneResult, Params, Timing, RvtError, build_library, library_path, load_library,
-                     TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL, TRAIT_QUANTITATIVE, TRAIT_BINARY,
-                     MAX_INFLIGHT)
+                     TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL, TEST_ANALYTICVT, TRAIT_QUANTITATIVE,
+                     TRAIT_BINARY, MAX_INFLIGHT, KbacResult, DecomposeInfo)
 
 __all__ = ["Engine", "Group", "GeneResult", "Params", "Timing", "RvtError", "build_library", "library_path", "load_library",
-           "TEST_SKAT", "TEST_SKATO", "TEST_CMC", "TEST_ZEGGINI", "TEST_ALL", "TRAIT_QUANTITATIVE", "TRAIT_BINARY",
-           "MAX_INFLIGHT"]
+           "TEST_SKAT", "TEST_SKATO", "TEST_CMC", "TEST_ZEGGINI", "TEST_ALL", "TEST_ANALYTICVT", "TRAIT_QUANTITATIVE",
+           "TRAIT_BINARY", "MAX_INFLIGHT", "KbacResult", "DecomposeInfo"]
