@@ -206,10 +206,10 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
     out = {}
     for mode in ("fp64", "int8", "bed2bit", "vcf_text"):
         if mode == "vcf_text":
-            lut = np.array([b"0/0", b"0/1", b"1/1"])
+            lut = np.frombuffer(b"0/0\t0/1\t1/1\t", dtype=np.uint8).reshape(3, 4)
             head = b"1\t1000\t.\tA\tG\t50\tPASS\t.\tGT\t"
             eng.vcf_set_samples(np.arange(N, dtype=np.int32))
-            data = [eng.prepare_vcf([head + b"\t".join(lut[h[:, j].astype(np.int64)].tolist())
+            data = [eng.prepare_vcf([head + lut[h[:, j].astype(np.int64)].tobytes()[:-1]
                                      for j in range(h.shape[1])]) for h in hard]
             nbytes = [sum(len(ln) for ln in d[1]) for d in data]
         elif mode == "int8":

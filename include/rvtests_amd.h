@@ -377,6 +377,11 @@ typedef struct rvt_decompose_info {
 int rvt_kinship_decompose(rvt_ctx* ctx, int64_t N, const float* K, float* U_out, float* S_out, int install,
                           rvt_decompose_info* info);
 
+/* FamAnalyticVT (--vt famanalytic: AnalyticVT(RELATED), src/Model.h:2189-2214) after rvt_set_kinship + rvt_fit_fam_null:
+ * frequencies from FastLMM::FastGetAF, (u, v) from FastLMM::CalculateUandV on the flipped, polymorphic columns of every
+ * block, then the same threshold search and integral as RVT_TEST_ANALYTICVT (vt_* fields of the records).  Synchronous. */
+int rvt_fam_analytic_vt(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, rvt_gene_result* out);
+
 /* ---- KBAC (--kernel kbac[nPerm:alpha], KBACTest src/Model.h:2891-3045 over regression/kbac.cpp) --------------------------------
  * Genotype-pattern test for BINARY traits WITHOUT covariates: every sample's multi-site genotype pattern over the
  * flipped, polymorphic columns with 0 < frequency <= 1 (imputed non-integers count as wild type), the statistic

@@ -138,6 +138,9 @@ double orc_mvn_band(const double* R, int n, double T, long long points, double* 
   return m;
 }
 
+static int vt_compute(int m, const double* af, const Mat& U, const Mat& V, long long mvn_points, orc_vt_result* out,
+                      double* cor_out);
+
 // G: imputed, unflipped N x M (column-major); af: M counter frequencies (dc->getMarkerFrequency); X: N x d with the
 // intercept; y: N.  cor_out (optional, K x K row-major, K <= M) receives the correlation of the threshold statistics.
 int orc_analytic_vt(const double* Gp, const double* af, const double* Xp, const double* yp, int64_t N, int M, int d,
@@ -177,6 +180,13 @@ int orc_analytic_vt(const double* Gp, const double* af, const double* Xp, const 
   }
   Mat U = orc::AtB(x, y), V = orc::AtB(x, x);
   for (double& e : V.a) e *= sigma2;
+  return vt_compute(m, af, U, V, mvn_points, out, cor_out);
+}
+
+// MultivariateVT::compute (regression/MultivariateVT.cpp:22-144) + the p-value; af: numFreq frequencies, U: numFreq x 1,
+// V: numFreq x numFreq
+static int vt_compute(int m, const double* af, const Mat& U, const Mat& V, long long mvn_points, orc_vt_result* out,
+                      double* cor_out) {
   // ---- MultivariateVT::compute ----
   const int numFreq = m;
   std::vector<double> maf(numFreq);
@@ -239,6 +249,89 @@ int orc_analytic_vt(const double* Gp, const double* af, const double* Xp, const 
   out->p_err = err;
   out->fit_ok = 1;
   return 0;
+}
+
+// FamAnalyticVT (src/Model.h:2189-2214): af_i = FastLMM::FastGetAF (regression/FastLMM.cpp:402-443) of column i of the
+// flipped, polymorphic genotype; (u, v) = FastLMM::CalculateUandV (:259-291) with the LITERAL N x N scaledK (:124-138):
+//   u = (U'g_c)' (lambda + delta)^-1 uResid / sigma2,  v = (U'g_c)' scaledK (U'g_c) / sigma2,  lambda = |S|.
+// delta, sigma2, beta: the FastLMM null model (orc_fastlmm_null).
+int orc_fam_analytic_vt(const double* Gp, const double* Xp, const double* yp, int64_t N, int M, int d, const double* Up,
+                        const double* S, double delta, double sigma2, const double* beta, long long mvn_points,
+                        orc_vt_result* out, double* cor_out) {
+  std::memset(out, 0, sizeof(*out));
+  std::vector<double> gbuf((size_t)N * M);
+  const int m = orc_flip_poly(Gp, N, M, gbuf.data(), nullptr, nullptr);
+  out->n_poly = m;
+  if (m == 0) return -1;
+  Mat G = wrap(gbuf.data(), N, m), X = wrap(Xp, N, d), Um = wrap(Up, N, N);
+  std::vector<double> lam(N), sinv(N);
+  for (int64_t i = 0; i < N; ++i) {
+    lam[i] = std::fabs(S[i]);
+    sinv[i] = 1.0 / (lam[i] + delta);
+  }
+  Mat ux = orc::AtB(Um, X);                         // U'X
+  Mat uy = orc::AtB(Um, wrap(yp, N, 1));
+  std::vector<double> ur(N);
+  for (int64_t k = 0; k < N; ++k) {
+    double p = 0;
+    for (int a = 0; a < d; ++a) p += ux(k, a) * beta[a];
+    ur[k] = uy(k, 0) - p;
+  }
+  Mat A(d, d), I(d, d), Ai;                         // (ux' Sinv ux)^-1
+  for (int a = 0; a < d; ++a) {
+    I(a, a) = 1.0;
+    for (int b = 0; b < d; ++b) {
+      double sacc = 0;
+      for (int64_t i = 0; i < N; ++i) sacc += ux(i, a) * sinv[i] * ux(i, b);
+      A(a, b) = sacc;
+    }
+  }
+  if (!orc::sym_solve(A, I, &Ai)) return -1;
+  Mat K(N, N);                                      // scaledK = Sinv - Sinv ux (ux' Sinv ux)^-1 ux' Sinv
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) {
+      double q = 0;
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) q += sinv[i] * ux(i, a) * Ai(a, b) * ux(j, b) * sinv[j];
+      K(i, j) = (i == j ? sinv[i] : 0.0) - q;
+    }
+  Mat Gc = G;                                       // g.rowwise() - g.colwise().mean()
+  for (int j = 0; j < m; ++j) {
+    double sacc = 0;
+    for (int64_t i = 0; i < N; ++i) sacc += G(i, j);
+    sacc /= (double)N;
+    for (int64_t i = 0; i < N; ++i) Gc(i, j) -= sacc;
+  }
+  Mat ugc = orc::AtB(Um, Gc), ug = orc::AtB(Um, G); // U'g_c, U'g
+  Mat Uv(m, 1), V(m, m);
+  for (int j = 0; j < m; ++j) {
+    double sacc = 0;
+    for (int64_t i = 0; i < N; ++i) sacc += ugc(i, j) * sinv[i] * ur[i];
+    Uv(j, 0) = sacc / sigma2;
+  }
+  Mat Kg = orc::mul(K, ugc);
+  Mat Vm = orc::AtB(ugc, Kg);
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) V(a, b) = Vm(a, b) / sigma2;
+  // FastGetAF: 0.5 * (u1s . U'g_j) / (u1s . u1), u1 = U'1, u1s = u1 / lambda
+  std::vector<double> af(m);
+  {
+    std::vector<double> u1(N), u1s(N);
+    double denom = 0;
+    for (int64_t k = 0; k < N; ++k) {
+      double sacc = 0;
+      for (int64_t i = 0; i < N; ++i) sacc += Um(i, k);
+      u1[k] = sacc;
+      u1s[k] = sacc / lam[k];
+      denom += u1s[k] * u1[k];
+    }
+    for (int j = 0; j < m; ++j) {
+      double numer = 0;
+      for (int64_t k = 0; k < N; ++k) numer += u1s[k] * ug(k, j);
+      af[j] = denom == 0.0 ? 0.0 : 0.5 * (numer / denom);
+    }
+  }
+  return vt_compute(m, af.data(), Uv, V, mvn_points, out, cor_out);
 }
 
 }  // extern "C"

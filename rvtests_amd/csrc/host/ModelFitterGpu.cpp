@@ -418,17 +418,55 @@ std::string ZegginiTest::formatRow(const rvt_gene_result* res) const {
 }
 
 // ---- AnalyticVTTest ---------------------------------------------------------------------------------------------------------
-AnalyticVTTest::AnalyticVTTest() {
-  modelName = "AnalyticVT";
-  GpuBroker::instance().registerTests(RVT_TEST_ANALYTICVT, rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05});
+AnalyticVTTest::AnalyticVTTest(bool related_) : related(related_) {
+  modelName = related ? "FamAnalyticVT" : "AnalyticVT";
+  if (!related) GpuBroker::instance().registerTests(RVT_TEST_ANALYTICVT, rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05});
 }
-int AnalyticVTTest::fit(GeneData* dc) { return deferredFit(dc); }
+int AnalyticVTTest::fit(GeneData* dc) {
+  if (!related) return deferredFit(dc);
+  fitOK = false;
+  if (isBinaryOutcome()) {  // src/Model.h:2143-2149
+    lastError = "Analytic VT test does not support binary outcomes. Results will be all NAs.";
+    return -1;
+  }
+  if (!dc->kinshipU || !dc->kinshipS) {  // model and data do not match (src/Model.h:2156-2160)
+    lastError = "Analytic VT test has internal error!";
+    return -1;
+  }
+  rvt_ctx* ctx = GpuBroker::instance().contextWithFamNull(*dc, &lastError);
+  if (!ctx) return -1;
+  double* block = nullptr;
+  if (rvt_block_alloc(ctx, dc->M, &block) || rvt_block_upload(ctx, block, dc->M, dc->genotype)) {
+    lastError = rvt_last_error(ctx);
+    if (block) rvt_block_free(ctx, block);
+    return -1;
+  }
+  const double* bp = block;
+  const int M = dc->M;
+  const int rc = rvt_fam_analytic_vt(ctx, 1, &bp, &M, &rec);
+  rvt_block_free(ctx, block);
+  if (rc) {
+    lastError = rvt_last_error(ctx);
+    return -1;
+  }
+  fitOK = rec.vt_ok != 0;
+  return fitOK ? 0 : -1;
+}
 void AnalyticVTTest::writeHeader(TextSink* fp, const SiteInfo& siteInfo) {
   fp->write(siteInfo.headerTab());
   fp->write("MinMAF\tMaxMAF\tOptimMAF\tOptimNumVar\tU\tV\tStat\tPvalue\n");  // result.addHeader order, src/Model.h:2123-2130
 }
-void AnalyticVTTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) { deferredOutput(fp, siteInfo); }
-void AnalyticVTTest::writeFootnote(TextSink*) { GpuBroker::instance().flush(); }
+void AnalyticVTTest::writeOutput(TextSink* fp, const SiteInfo& siteInfo) {
+  if (!related) {
+    deferredOutput(fp, siteInfo);
+    return;
+  }
+  fp->write(siteInfo.valueTab());
+  fp->write(formatRow(fitOK ? &rec : nullptr));
+}
+void AnalyticVTTest::writeFootnote(TextSink*) {
+  if (!related) GpuBroker::instance().flush();
+}
 std::string AnalyticVTTest::formatRow(const rvt_gene_result* r) const {
   // not fitted (binary trait, no polymorphic site, no usable threshold, integral not converged to 1e-3): the Result keeps
   // its cleared values (src/Model.h:2233-2246 after ModelFitter::reset)
@@ -1019,8 +1057,10 @@ int ModelManager::create(const std::string& type, const std::string& modelList) 
         return -1;
       }
     } else if (modelType == "vt") {
-      if (modelName == "analytic")  // src/ModelManager.cpp:158-159
-        model.push_back(new AnalyticVTTest);
+      if (modelName == "analytic")  // src/ModelManager.cpp:158-161
+        model.push_back(new AnalyticVTTest(false));
+      else if (modelName == "famanalytic")
+        model.push_back(new AnalyticVTTest(true));
       else {
         lastError = "Unknown model name: " + modelName + " .";
         return -1;

@@ -274,14 +274,21 @@ class ZegginiTest : public ModelFitter {
 // columns MinMAF MaxMAF OptimMAF OptimNumVar U V Stat Pvalue.  The reference's p-value comes from a randomised rule at
 // absolute accuracy 1e-3 and the row is NA when that rule's error estimate exceeds it (MvtNorm::compute_Band); here the
 // integral is evaluated deterministically and the row is NA when ITS error estimate exceeds 1e-3.
+// `--vt famanalytic` (AnalyticVT(RELATED), :160-161): the same columns from FastLMM's frequencies, scores and variances
+// (rvt_fam_analytic_vt); synchronous, one gene per call.
 class AnalyticVTTest : public ModelFitter {
  public:
   std::string formatRow(const rvt_gene_result* r) const override;
   void writeFootnote(TextSink* fp) override;
-  AnalyticVTTest();
+  explicit AnalyticVTTest(bool related = false);
   int fit(GeneData* dc) override;
   void writeHeader(TextSink* fp, const SiteInfo& siteInfo) override;
   void writeOutput(TextSink* fp, const SiteInfo& siteInfo) override;
+
+ private:
+  bool related;
+  bool fitOK = false;
+  rvt_gene_result rec{};
 };
 
 // `--kernel kbac[nPerm=10000:alpha=0.05]` (src/ModelManager.cpp kernel switch; KBACTest, src/Model.h:2891-3045): binary

@@ -121,11 +121,13 @@ typedef GpuModel<rvt_host::FamBurdenTest> FamBurdenTest;
 typedef GpuModel<rvt_host::MetaCovTest> MetaCovTest;      // new MetaCovTest(windowSize)            :238-247
 typedef GpuModel<rvt_host::MetaScoreTest> MetaScoreTest;  // new MetaScoreTest()
 typedef GpuModel<rvt_host::KbacTest> KBACTest;            // new KBACTest(nPerm, alpha)
-// new AnalyticVT(AnalyticVT::UNRELATED)   ModelManager.cpp:158-159 (the RELATED variant is not provided)
+// new AnalyticVT(AnalyticVT::UNRELATED) / new AnalyticVT(AnalyticVT::RELATED)   ModelManager.cpp:158-161
 class AnalyticVT : public GpuModel<rvt_host::AnalyticVTTest> {
  public:
   typedef enum { UNRELATED = 0, RELATED = 1 } Type;
-  explicit AnalyticVT(Type) {}
+  explicit AnalyticVT(Type t) : GpuModel<rvt_host::AnalyticVTTest>(t == RELATED) {
+    if (t == RELATED) related();
+  }
 };
 
 }  // namespace rvt_intree

@@ -453,16 +453,12 @@ RVT_HD size_t gene_vt_doubles(int Mp) {
   return 4 * (size_t)Mp + 4 * K + 8 + K * K + 256 * K;
 }
 
-__global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
-                                                      const NullConsts* __restrict__ ncp) {
-  const GeneDesc gd = genes[blockIdx.x];
-  rvt_gene_result* out = gd.result;
+// m: columns (flipped, polymorphic); afv[a]: frequency of position a; uvec[a]: score; Wm: m x m (column-major); the
+// variance matrix is Wm * sigma2; vt_mem: gene_vt_doubles(Mp) doubles with Mp >= m a multiple of 16.  256 threads.
+__device__ void vt_core(int m, int Mp, const double* __restrict__ afv, const double* __restrict__ uvec,
+                        const double* __restrict__ Wm, double sigma2, bool binary, double* __restrict__ vt_mem,
+                        rvt_gene_result* out) {
   const int tid = threadIdx.x;
-  const GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  const int Mp = gd.Mp, M = gd.M, ldr = gd.Cp, d = ncp->d;
-  const int* kidx = ws.ivec;
-  const int m = kidx[Mp];
-  const double sigma2 = ncp->sigma2;
   __shared__ int sK, sFail, sMaxIdx;
   __shared__ double sRed[256];
   __shared__ int sRedI[256];
@@ -476,9 +472,9 @@ __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict
     sFail = 0;
   }
   __syncthreads();
-  if (m == 0 || ncp->binary || !gd.vt_mem) return;  // "Analytic VT test does not support binary outcomes" (:2143-2149)
+  if (m == 0 || binary || !vt_mem) return;  // "Analytic VT test does not support binary outcomes" (:2143-2149)
   const int Kmax = Mp < kMvnMaxDim ? Mp : kMvnMaxDim;
-  double* maf = gd.vt_mem;
+  double* maf = vt_mem;
   double* keyd = maf + Mp;    // ceil(maf 1e6) as a double, -1: skipped
   double* ordd = keyd + Mp;   // variants ordered by (first cutoff, index)
   double* cidxd = ordd + Mp;  // first cutoff that includes the variant (K: none)
@@ -488,11 +484,10 @@ __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict
   double* alpha = startd + Kmax + 8;
   double* A = alpha + Kmax;
   double* ymem = A + (size_t)Kmax * Kmax;
-  const double* Wm = ws.Wm;
   // ---- 1. maf, skip rule, keys ----------------------------------------------------------------------------------------
   double mn = INFINITY, mx = -INFINITY;
   for (int a = tid; a < m; a += 256) {
-    const double f = gd.af[a];
+    const double f = afv[a];
     const double mf = f < 0.5 ? f : 1.0 - f;
     maf[a] = mf;
     mn = fmin(mn, mf);
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict
   for (int j = tid; j < K; j += 256) {  // u_phi before the prefix: block sums of u
     double sacc = 0.0;
     const int p0 = (int)startd[j], p1 = (int)startd[j + 1];
-    for (int x = p0; x < p1; ++x) sacc += ws.R[(size_t)kidx[(int)ordd[x]] * ldr + M + d];
+    for (int x = p0; x < p1; ++x) sacc += uvec[(int)ordd[x]];
     uphi[j] = sacc;
   }
   __syncthreads();
@@ -732,6 +727,26 @@ __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict
     out->vt_p_error = err;
     out->vt_ok = 1;
   }
+}
+
+// the unrelated-sample test: u and Wm are where gene_assemble left them (one workgroup per gene)
+__global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
+                                                      const NullConsts* __restrict__ ncp) {
+  const GeneDesc gd = genes[blockIdx.x];
+  const GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  const int* kidx = ws.ivec;
+  const int m = kidx[gd.Mp], M = gd.M, d = ncp->d, ldr = gd.Cp;
+  double* uvec = gd.vt_mem ? gd.vt_mem + gene_vt_doubles(gd.Mp) : nullptr;  // Mp doubles behind the core's workspace
+  if (uvec)
+    for (int a = threadIdx.x; a < m; a += 256) uvec[a] = ws.R[(size_t)kidx[a] * ldr + M + d];
+  __syncthreads();
+  vt_core(m, gd.Mp, gd.af, uvec, ws.Wm, ncp->sigma2, ncp->binary != 0, gd.vt_mem, gd.result);
+}
+
+// the related-sample test (FamAnalyticVT): frequency, score and variance matrix prepared by the host from the family
+// covariance machinery; buf = af[m] | u[m] | V[m x m] | workspace
+__global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, double* __restrict__ buf, rvt_gene_result* out) {
+  vt_core(m, Mp, buf, buf + m, buf + 2 * (size_t)m, 1.0, false, buf + 2 * (size_t)m + (size_t)m * m, out);
 }
 
 // ---- MetaScoreTest, unrelated samples: single-variant score statistics of one block from the same partials ----

@@ -907,7 +907,7 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   o->lambda = add(sizeof(double) * 2 * M);
   o->qags = add(qags_workspace_bytes(kSkatoLimit));
   o->stats = add(sizeof(GeneStats));
-  o->vt = vt ? add(sizeof(double) * gene_vt_doubles(Mp)) : 0;
+  o->vt = vt ? add(sizeof(double) * (gene_vt_doubles(Mp) + Mp)) : 0;
   o->dbg_flip = o->dbg_kept = 0;
   if (dbg) {
     o->dbg_flip = add(sizeof(int) * M);
@@ -2220,6 +2220,92 @@ int rvt_cov_block_fam(rvt_ctx* c, const double* dG, int V, double* cov, double* 
       for (int i = 0; i < du * du; ++i) zz[i] *= b2;
   }
   return rc;
+}
+
+// FamAnalyticVT (AnalyticVT(RELATED), src/Model.h:2189-2214): af_i = FastLMM::FastGetAF of column i of the flipped,
+// polymorphic genotype, (u, v) = FastLMM::CalculateUandV (regression/FastLMM.cpp:259-291: u = (U'g_c)' (lambda + delta)^-1
+// uResid / sigma2, v = (U'g_c)' scaledK (U'g_c) / sigma2), then MultivariateVT::compute.  u, v and af of the RAW columns
+// come from the family-covariance machinery (ustat / band / GLS frequency of fam_block_run); flipping a column to its
+// minor allele (g -> 2 - g) changes the sign of its centred genotype and maps af to 1 - af, monomorphic columns drop out.
+int rvt_fam_analytic_vt(rvt_ctx* c, int n, const double* const* dG, const int* Ms, rvt_gene_result* out) {
+  if (!c || n < 0 || (n > 0 && (!dG || !Ms || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  hipSetDevice(c->device);
+  const int64_t N = c->fam_nc.N, ld = c->fam_nc.ld;
+  for (int g = 0; g < n; ++g) {
+    const int M = Ms[g];
+    rvt_gene_result& r = out[g];
+    std::memset(&r, 0, sizeof(r));
+    r.gene_id = g;
+    r.n_variants = M;
+    if (M < 1 || M > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
+    int rc = rvt_sync(c);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    // flip / polymorphic decisions on the raw columns (DataConsolidator.cpp:46-69,94-116)
+    std::vector<const double*> cols(M);
+    for (int j = 0; j < M; ++j) cols[j] = dG[g] + (size_t)j * ld;
+    const double** d_cols = nullptr;
+    int* d_flags = nullptr;
+    double* d_buf = nullptr;
+    rvt_gene_result* d_res = nullptr;
+    struct Guard {
+      std::vector<void**> p;
+      ~Guard() {
+        for (void** q : p)
+          if (*q) hipFree(*q);
+      }
+    } guard{{(void**)&d_cols, (void**)&d_flags, (void**)&d_buf, (void**)&d_res}};
+    HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * (size_t)M));
+    HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * (size_t)M));
+    HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * M, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+    std::vector<int> flags(M);
+    HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+    std::vector<double> cov((size_t)M * M), xz((size_t)M * RVT_MAX_COV), ustat(M), vstat(M), af(M), pval(M);
+    std::vector<int> poly(M);
+    CovOut co;
+    co.cov = cov.data();
+    co.xz = xz.data();
+    co.poly = poly.data();
+    co.ustat = ustat.data();
+    co.vstat = vstat.data();
+    co.af = af.data();
+    co.pval = pval.data();
+    rc = fam_block_run(c, dG[g], M, &co);
+    if (rc) return rc;
+    std::vector<int> kept;
+    for (int j = 0; j < M; ++j)
+      if (flags[j] & 2) kept.push_back(j);
+    const int m = (int)kept.size();
+    r.n_poly = m;
+    if (m == 0) continue;  // genotype.cols == 0 -> NA row
+    const int Mp = (m + 15) / 16 * 16;
+    const size_t nbuf = 2 * (size_t)m + (size_t)m * m + gene_vt_doubles(Mp);
+    std::vector<double> host(2 * (size_t)m + (size_t)m * m);
+    for (int a = 0; a < m; ++a) {
+      const int j = kept[a];
+      const double sa = (flags[j] & 1) ? -1.0 : 1.0;
+      host[a] = (flags[j] & 1) ? 1.0 - af[j] : af[j];
+      host[m + a] = sa * ustat[j];
+      for (int b = 0; b < m; ++b) {
+        const int k = kept[b];
+        const double sb = (flags[k] & 1) ? -1.0 : 1.0;
+        const double v = j <= k ? cov[(size_t)j + (size_t)k * M] : cov[(size_t)k + (size_t)j * M];
+        host[2 * (size_t)m + (size_t)b * m + a] = sa * sb * v;
+      }
+    }
+    HIP_TRY(c, hipMalloc((void**)&d_buf, sizeof(double) * nbuf));
+    HIP_TRY(c, hipMalloc((void**)&d_res, sizeof(rvt_gene_result)));
+    HIP_TRY(c, hipMemcpyAsync(d_buf, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_res, &r, sizeof(r), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(vt_direct_kernel, dim3(1), dim3(256), 0, st, m, Mp, d_buf, d_res);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, sync_stream(st));
+  }
+  return RVT_OK;
 }
 
 // MetaScore with kinship: FastLMM score test of every raw column, the block in pieces of RVT_MAX_VARIANTS.

@@ -463,6 +463,16 @@ class Engine:
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
 
+    def fam_analytic_vt(self, ptrs, Ms):
+        """FamAnalyticVT of device-resident raw blocks (rvt_fam_analytic_vt); vt_* fields of the records."""
+        n = len(ptrs)
+        arr_p = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+        arr_m = np.ascontiguousarray(Ms, dtype=np.int32)
+        out = (GeneResult * n)()
+        self.L.rvt_fam_analytic_vt.restype = C.c_int
+        self._check(self.L.rvt_fam_analytic_vt(self.ctx, n, arr_p, arr_m.ctypes.data_as(c_int_p), out))
+        return list(out)
+
     def kbac_blocks(self, ptrs, Ms, afs, y, nperm, alpha):
         """KBAC of device-resident blocks (rvt_kbac_blocks); afs: list of per-gene frequency arrays."""
         n = len(ptrs)

@@ -588,3 +588,23 @@ def kbac(Gf, y, maf, nperm, alpha, seed=None):
     L.orc_kbac(_dp(Gf), _dp(y), _dp(maf), N, M, int(nperm), C.c_double(alpha), C.byref(p), C.byref(obs), C.byref(npat),
                C.byref(done))
     return p.value, obs.value, npat.value, done.value
+
+
+def fam_analytic_vt(G, X, y, U, S, nul, mvn_points=2048):
+    """FamAnalyticVT restated literally (N x N scaledK).  nul: FamNull (delta, sigma2, beta)."""
+    G = F(G)
+    X = F(X)
+    U = F(U)
+    N, M = G.shape
+    d = X.shape[1]
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    beta = np.array([nul.beta[k] for k in range(d)], dtype=np.float64)
+    out = VtResult()
+    cor = np.zeros((M, M))
+    L = lib()
+    L.orc_fam_analytic_vt.restype = C.c_int
+    rc = L.orc_fam_analytic_vt(_dp(G), _dp(X), _dp(y), C.c_int64(N), M, d, _dp(U), _dp(S), C.c_double(nul.delta),
+                               C.c_double(nul.sigma2), _dp(beta), C.c_longlong(mvn_points), C.byref(out), _dp(cor))
+    K = out.n_cutoff
+    return rc, out, cor.ravel()[:K * K].reshape(K, K).copy()

@@ -57,3 +57,34 @@ def test_analytic_vt_binary_trait_is_not_fitted(eng):
     af0, G, af = synth.make_gene(N, 9, seed=3, missing=0.01, common=True)
     out = eng.run_blocks([eng.upload_block(G)], [9], [af], tests=TEST_VT)
     assert out[0].vt_ok == 0
+
+
+@pytest.mark.parametrize("n_fam,d,Ms", [(40, 2, (9, 24)), (75, 3, (35, 6))])
+def test_fam_analytic_vt_matches_oracle(eng, n_fam, d, Ms):
+    """FamAnalyticVT (rvt_fam_analytic_vt): frequencies, scores and variances from the family-covariance machinery of
+    the raw block with flips applied algebraically, against the oracle's literal N x N restatement."""
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(n_fam, d, 300 + d)
+    eng.set_kinship(U, S)
+    nul = eng.fit_fam_null(X, y)
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(d):
+        onul.beta[k] = nul.beta[k]
+    genes = [synth.make_gene(N, M, seed=800 + M, missing=0.02, common=True, mono=(M > 7))[1] for M in Ms]
+    genes[0][:, 1] = 2.0 - genes[0][:, 1] * (genes[0][:, 1] <= 2)          # a column that has to be flipped
+    ptrs = [eng.upload_block(G) for G in genes]
+    out = eng.fam_analytic_vt(ptrs, [G.shape[1] for G in genes])
+    for r, G in zip(out, genes):
+        rc, o, cor = orc.fam_analytic_vt(G, X, y, U, S, onul, mvn_points=1024)
+        if rc != 0:
+            assert r.vt_ok == 0
+            continue
+        assert r.vt_ok == 1 and r.n_poly == o.n_poly
+        assert r.vt_ncutoff == o.n_cutoff and r.vt_optnum == o.opt_num
+        assert abs(r.vt_optmaf - o.opt_maf) <= 1e-12 and abs(r.vt_minmaf - o.min_maf) <= 1e-9
+        assert abs(r.vt_U - o.U) <= 1e-7 * abs(o.U) + 1e-10
+        assert abs(r.vt_V - o.V) <= 1e-7 * o.V
+        assert abs(r.vt_stat - o.stat) <= 1e-7 * o.stat
+        assert abs(r.vt_p - o.pvalue) <= r.vt_p_error + o.p_err + 1e-5

@@ -550,3 +550,39 @@ def test_driver_kbac_rows(tmp_path):
     write_input(path, rng.standard_normal(N), np.zeros((N, 0)), 0, genes)
     p = subprocess.run([DRIVER, path, "kbac", "-"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and all(ln.split("\t")[-1] == "NA" for ln in p.stdout.splitlines()[2:])
+
+
+@pytest.mark.gpu
+def test_driver_fam_analytic_vt_rows(tmp_path):
+    """--vt famanalytic through the C++ adapter (kinship file as for famSkat): rows against the oracle's literal
+    restatement fed with the oracle's own FastLMM null (delta is pinned to Brent's stopping accuracy only)."""
+    _ensure_driver()
+    from test_fam_cpu import make_family_case
+    N, K, U, S, X, y = make_family_case(45, 2, 71)
+    genes = [synth.make_gene(N, M, seed=510 + M, missing=0.01, common=True, mono=(M > 5))[1:] for M in (8, 19)]
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, genes)
+    kin = str(tmp_path / "kin.bin")
+    with open(kin, "wb") as f:
+        f.write(struct.pack("<q", N))
+        f.write(np.asfortranarray(U, dtype="<f4").tobytes(order="F"))
+        f.write(np.ascontiguousarray(S, dtype="<f4").tobytes())
+    env = dict(os.environ)
+    env["RVT_DRIVER_VT"] = "famanalytic"
+    p = subprocess.run([DRIVER, path, "-", "-", "-", "-", kin], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "== out.FamAnalyticVT.assoc"
+    rows = [ln.split("\t") for ln in lines[2:]]
+    assert len(rows) == len(genes)
+    rc, onul = orc.fastlmm_null(X, y, U, S)
+    for row, (G, af) in zip(rows, genes):
+        rc, o, cor = orc.fam_analytic_vt(G, X, y, U, S, onul, mvn_points=1024)
+        got = row[-8:]
+        if rc != 0:
+            assert got == ["NA"] * 8
+            continue
+        assert int(got[3]) == o.opt_num
+        for k, want in zip((2, 4, 5, 6), (o.opt_maf, o.U, o.V, o.stat)):
+            assert abs(float(got[k]) - want) <= 2e-2 * abs(want) + 1e-9
+        assert abs(float(got[7]) - o.pvalue) <= 2e-2
