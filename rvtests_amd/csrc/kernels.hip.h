@@ -447,10 +447,15 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restric
 // ceil(maf 1e6) in ascending order are the cutoffs (as doubles: k / 1e6); phi(a, j) = maf_a <= cutoff_j; u_phi = u'phi,
 // v_phi = phi' v phi; Stat = max_j |u_phi_j / sqrt(v_phi_jj)| (first maximum); Pvalue = 1 - P(|Z_j| < Stat for all j),
 // Z ~ N(0, cor(v_phi)) — rvt_mvn.h.  One 256-thread workgroup per gene.
-// vt_mem (doubles): maf[Mp] | key[Mp] | ord[Mp] | cidx[Mp] | cut[K] | uphi[K] | start[K + 1] | alpha[K] | A[K x K] | y[256 x K]
+// vt_mem (doubles): hdr[16 + kMvnShifts] | maf[Mp] | key[Mp] | ord[Mp] | cidx[Mp] | cut[K] | uphi[K] | start[K + 1] | alpha[K] |
+//                   A[K x K] | y[kMvnShifts x 256 x K]
+// hdr: [0] state (0 nothing to integrate, 1 integrate), [1] K, [2] T, [3] 1 = second integration stage wanted,
+//      [16 + j] running sum of the integrand over the points of shift j
+constexpr int kVtHdr = 16 + kMvnShifts;
+constexpr int kVtStage0 = 4096;  // lattice points per shift of the first integration stage
 RVT_HD size_t gene_vt_doubles(int Mp) {
   const size_t K = (size_t)(Mp < kMvnMaxDim ? Mp : kMvnMaxDim);
-  return 4 * (size_t)Mp + 4 * K + 8 + K * K + 256 * K;
+  return kVtHdr + 4 * (size_t)Mp + 4 * K + 8 + K * K + (size_t)kMvnShifts * 256 * K;
 }
 
 // m: columns (flipped, polymorphic); afv[a]: frequency of position a; uvec[a]: score; Wm: m x m (column-major); the
@@ -470,11 +475,14 @@ __device__ void vt_core(int m, int Mp, const double* __restrict__ afv, const dou
     out->vt_p = out->vt_p_error = 0.0;
     sK = 0;
     sFail = 0;
+    if (vt_mem)
+      for (int j = 0; j < kVtHdr; ++j) vt_mem[j] = 0.0;
   }
   __syncthreads();
   if (m == 0 || binary || !vt_mem) return;  // "Analytic VT test does not support binary outcomes" (:2143-2149)
   const int Kmax = Mp < kMvnMaxDim ? Mp : kMvnMaxDim;
-  double* maf = vt_mem;
+  double* hdr = vt_mem;
+  double* maf = vt_mem + kVtHdr;
   double* keyd = maf + Mp;    // ceil(maf 1e6) as a double, -1: skipped
   double* ordd = keyd + Mp;   // variants ordered by (first cutoff, index)
   double* cidxd = ordd + Mp;  // first cutoff that includes the variant (K: none)
@@ -655,22 +663,77 @@ __device__ void vt_core(int m, int Mp, const double* __restrict__ afv, const dou
     A[e] = (p == q) ? 1.0 : A[e] / (uphi[p] * uphi[q]);
   }
   __syncthreads();
-  for (int j = 0; j < K; ++j) {
-    if (tid == 0) {
-      double sacc = A[(size_t)j * K + j];
-      for (int k = 0; k < j; ++k) sacc -= A[(size_t)j * K + k] * A[(size_t)j * K + k];
-      A[(size_t)j * K + j] = sacc > 1e-10 ? sqrt(sacc) : 0.0;
+  // Cholesky factor with Genz's variable reordering (mvn_cholesky in rvt_mvn.h, same choices): at step i every thread
+  // rates its candidates, the narrowest expected interval wins, rows / columns are swapped, column i is formed
+  double* yexp = uphi;  // (free again: conditional expectations of the variables already placed)
+  __syncthreads();
+  for (int i = 0; i < K; ++i) {
+    double bw = 2.0, bv = 0.0, bex = 0.0;
+    int bj = -1;
+    for (int j = i + tid; j < K; j += 256) {
+      double v = A[(size_t)j * K + j], sh = 0.0;
+      for (int k = 0; k < i; ++k) {
+        v -= A[(size_t)j * K + k] * A[(size_t)j * K + k];
+        sh += A[(size_t)j * K + k] * yexp[k];
+      }
+      double ex;
+      const double w = mvn_candidate_width(v, sh, T, 1e-10, &ex);
+      if (w < bw) {  // (ascending j inside a thread: the first minimum)
+        bw = w;
+        bj = j;
+        bv = v;
+        bex = ex;
+      }
+    }
+    sRed[tid] = bw;
+    sRedI[tid] = bj;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) {  // smaller width, or equal width with the smaller index
+        const double o = sRed[tid + w];
+        const int oi = sRedI[tid + w];
+        if (oi >= 0 && (sRedI[tid] < 0 || o < sRed[tid] || (o == sRed[tid] && oi < sRedI[tid]))) {
+          sRed[tid] = o;
+          sRedI[tid] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    const int best = sRedI[0];
+    __syncthreads();
+    if (bj == best) {  // the owner of the winner publishes its variance and expectation
+      sRed[0] = bv;
+      sRed[1] = bex;
     }
     __syncthreads();
-    const double l = A[(size_t)j * K + j];
-    for (int i = j + 1 + tid; i < K; i += 256) {
+    const double vbest = sRed[0], exbest = sRed[1];
+    if (best != i) {
+      for (int k = tid; k < K; k += 256) {  // rows
+        const double t = A[(size_t)i * K + k];
+        A[(size_t)i * K + k] = A[(size_t)best * K + k];
+        A[(size_t)best * K + k] = t;
+      }
+      __syncthreads();
+      for (int r = tid; r < K; r += 256) {  // columns
+        const double t = A[(size_t)r * K + i];
+        A[(size_t)r * K + i] = A[(size_t)r * K + best];
+        A[(size_t)r * K + best] = t;
+      }
+    }
+    __syncthreads();
+    const double l = vbest > 1e-10 ? sqrt(vbest) : 0.0;
+    if (tid == 0) {
+      yexp[i] = exbest;
+      A[(size_t)i * K + i] = l;
+    }
+    for (int r = i + 1 + tid; r < K; r += 256) {
       double t = 0.0;
       if (l > 0.0) {
-        t = A[(size_t)i * K + j];
-        for (int k = 0; k < j; ++k) t -= A[(size_t)i * K + k] * A[(size_t)j * K + k];
+        t = A[(size_t)r * K + i];
+        for (int k = 0; k < i; ++k) t -= A[(size_t)r * K + k] * A[(size_t)i * K + k];
         t /= l;
       }
-      A[(size_t)i * K + j] = t;
+      A[(size_t)r * K + i] = t;
     }
     __syncthreads();
   }
@@ -688,45 +751,84 @@ __device__ void vt_core(int m, int Mp, const double* __restrict__ afv, const dou
     }
   }
   __syncthreads();
-  // ---- 8. the integral: kMvnShifts shifted lattices, points doubled until the spread of the shift means is small -------------------
-  double* y = ymem + tid;  // element q of this thread: y[q * 256]
-  double acc[kMvnShifts];
-#pragma unroll
-  for (int j = 0; j < kMvnShifts; ++j) acc[j] = 0.0;
-  long long done = 0;
-  double est = 0.0, err = 1.0;
-  for (long long P = 1024; P <= kMvnPoints; P *= 2) {
-    for (int j = 0; j < kMvnShifts; ++j) {
-      double sacc = 0.0;
-      for (long long k = done + tid; k < P; k += 256) sacc += mvn_band_point_strided(A, K, K, T, alpha, j, k + 1, y, 256);
-      acc[j] += sacc;
-    }
-    done = P;
-    // means per shift, then their mean and standard error
-    double mean = 0.0, sq = 0.0;
-    for (int j = 0; j < kMvnShifts; ++j) {
-      sRed[tid] = acc[j];
-      __syncthreads();
-      for (int w = 128; w > 0; w >>= 1) {
-        if (tid < w) sRed[tid] += sRed[tid + w];
-        __syncthreads();
-      }
-      const double mj = sRed[0] / (double)P;
-      __syncthreads();
-      mean += mj;
-      sq += mj * mj;
-    }
-    mean /= kMvnShifts;
-    const double var = fmax(0.0, sq / kMvnShifts - mean * mean) / (kMvnShifts - 1);
-    est = mean;
-    err = 3.5 * sqrt(var);
-    if (err < 5e-5) break;
-  }
+  // ---- 8. hand over to the integration kernels (vt_integrate_kernel / vt_finish_kernel) -----------------------------------------------
   if (tid == 0) {
-    out->vt_p = 1.0 - est;
-    out->vt_p_error = err;
-    out->vt_ok = 1;
+    hdr[1] = (double)K;
+    hdr[2] = T;
+    __threadfence();
+    hdr[0] = 1.0;
   }
+}
+
+// vt_mem sections the integration kernels need
+__device__ __forceinline__ void vt_sections(double* vt_mem, int Mp, double** alpha, double** A, double** ymem) {
+  const int Kmax = Mp < kMvnMaxDim ? Mp : kMvnMaxDim;
+  double* cut = vt_mem + kVtHdr + 4 * (size_t)Mp;
+  *alpha = cut + 2 * (size_t)Kmax + Kmax + 8;
+  *A = *alpha + Kmax;
+  *ymem = *A + (size_t)Kmax * Kmax;
+}
+
+// The integral.  grid (genes, kMvnShifts), 256 threads: one workgroup sums the integrand over the lattice points of one
+// shift — stage 0: points [0, kVtStage0); stage 1 (genes whose first estimate was not accurate enough): the points up to
+// kMvnPoints.  One thread = one lattice point at a time; the factor sits in LDS when it fits, the per-thread vectors of
+// conditioned values in the workspace ([dimension][thread]: coalesced).
+__global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc* __restrict__ genes, int stage) {
+  const GeneDesc gd = genes[blockIdx.x];
+  double* vt_mem = gd.vt_mem;
+  if (!vt_mem || vt_mem[0] != 1.0) return;
+  if (stage == 1 && vt_mem[3] != 1.0) return;
+  const int tid = threadIdx.x, j = blockIdx.y;
+  const int K = (int)vt_mem[1];
+  const double T = vt_mem[2];
+  double *alpha, *A, *ymem;
+  vt_sections(vt_mem, gd.Mp, &alpha, &A, &ymem);
+  constexpr int kLdsDoubles = 4096;  // factors up to 64 x 64
+  __shared__ double sL[kLdsDoubles];
+  __shared__ double sRed[256];
+  const double* Lp = A;
+  if (K * K <= kLdsDoubles) {
+    for (int e = tid; e < K * K; e += 256) sL[e] = A[e];
+    Lp = sL;
+  }
+  __syncthreads();
+  double* y = ymem + (size_t)j * 256 * K + tid;
+  const long long k0 = stage == 0 ? 0 : kVtStage0, k1 = stage == 0 ? kVtStage0 : kMvnPoints;
+  double sacc = 0.0;
+  for (long long k = k0 + tid; k < k1; k += 256) sacc += mvn_band_point_strided(Lp, K, K, T, alpha, j, k + 1, y, 256);
+  sRed[tid] = sacc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) sRed[tid] += sRed[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) vt_mem[16 + j] += sRed[0];
+}
+
+// one thread per gene: estimate and error from the shift sums; after stage 0 genes that are not accurate enough ask for
+// stage 1
+__global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int n, int stage) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const GeneDesc gd = genes[g];
+  double* vt_mem = gd.vt_mem;
+  if (!vt_mem || vt_mem[0] != 1.0) return;
+  if (stage == 1 && vt_mem[3] != 1.0) return;
+  const double P = stage == 0 ? (double)kVtStage0 : (double)kMvnPoints;
+  double mean = 0.0, sq = 0.0;
+  for (int j = 0; j < kMvnShifts; ++j) {
+    const double mj = vt_mem[16 + j] / P;
+    mean += mj;
+    sq += mj * mj;
+  }
+  mean /= kMvnShifts;
+  const double var = fmax(0.0, sq / kMvnShifts - mean * mean) / (kMvnShifts - 1);
+  const double err = 3.5 * sqrt(var);
+  rvt_gene_result* out = gd.result;
+  out->vt_p = 1.0 - mean;
+  out->vt_p_error = err;
+  out->vt_ok = 1;
+  if (stage == 0) vt_mem[3] = err < 2.5e-4 ? 0.0 : 1.0;  // (the reference asks its rule for 1e-3)
 }
 
 // the unrelated-sample test: u and Wm are where gene_assemble left them (one workgroup per gene)

@@ -1232,6 +1232,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   if ((tests & RVT_TEST_ANALYTICVT) && !(tests & RVT_TEST_FAMSKAT)) {
     Scope sc(c, 2, st);
     hipLaunchKernelGGL(gene_vt_kernel, dim3(n), dim3(256), 0, st, d_desc, c->d_nc);
+    for (int stage = 0; stage < 2; ++stage) {  // the band probability: a short first stage, a long one where it is needed
+      hipLaunchKernelGGL(vt_integrate_kernel, dim3(n, kMvnShifts), dim3(256), 0, st, d_desc, stage);
+      hipLaunchKernelGGL(vt_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_desc, n, stage);
+    }
   }
   const unsigned tests_eig = (tests & RVT_TEST_FAMSKAT) ? (unsigned)RVT_TEST_SKAT : tests_eff;
   if (tests & (RVT_TEST_SKAT | RVT_TEST_SKATO | RVT_TEST_FAMSKAT)) {
@@ -2301,6 +2305,23 @@ int rvt_fam_analytic_vt(rvt_ctx* c, int n, const double* const* dG, const int* M
     HIP_TRY(c, hipMemcpyAsync(d_buf, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(d_res, &r, sizeof(r), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(vt_direct_kernel, dim3(1), dim3(256), 0, st, m, Mp, d_buf, d_res);
+    {
+      GeneDesc gdv;
+      std::memset(&gdv, 0, sizeof(gdv));
+      gdv.Mp = Mp;
+      gdv.vt_mem = d_buf + 2 * (size_t)m + (size_t)m * m;
+      gdv.result = d_res;
+      GeneDesc* d_gdv = nullptr;
+      HIP_TRY(c, hipMalloc((void**)&d_gdv, sizeof(GeneDesc)));
+      hipError_t e = hipMemcpyAsync(d_gdv, &gdv, sizeof(gdv), hipMemcpyHostToDevice, st);
+      for (int stage = 0; stage < 2 && e == hipSuccess; ++stage) {
+        hipLaunchKernelGGL(vt_integrate_kernel, dim3(1, kMvnShifts), dim3(256), 0, st, d_gdv, stage);
+        hipLaunchKernelGGL(vt_finish_kernel, dim3(1), dim3(256), 0, st, d_gdv, 1, stage);
+      }
+      if (e == hipSuccess) e = sync_stream(st);
+      hipFree(d_gdv);
+      HIP_TRY(c, e);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(&r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, sync_stream(st));

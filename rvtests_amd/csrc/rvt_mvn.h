@@ -7,7 +7,7 @@
 // digits beyond ~1e-3 are noise and differ from run to run of the process-wide random stream.  There is therefore no
 // 1e-6 parity to be had; what is computed here is the SAME integral by the same separation-of-variables transformation
 // (Genz 1992: Cholesky factor, conditional limits, one uniform per dimension), evaluated deterministically on a fixed
-// lattice with far more points, so that the result is accurate to ~1e-5 and reproducible:
+// lattice with far more points and with Genz's variable reordering, so that the result is accurate to ~1e-5 and reproducible:
 //   e_1 = Phi(T / l_11), d_1 = Phi(-T / l_11), f = e_1 - d_1
 //   for i = 2..n:  y_{i-1} = Phi^-1(d_{i-1} + w_{i-1} (e_{i-1} - d_{i-1})),  s = sum_{j<i} l_ij y_j,
 //                  d_i = Phi((-T - s) / l_ii), e_i = Phi((T - s) / l_ii),  f *= e_i - d_i
@@ -29,44 +29,107 @@ constexpr int kMvnPoints = 16384;   // lattice points per shift at most (doubled
 
 RVT_HDI double mvn_phi(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
 
-// inverse normal cdf: rational starting value (Abramowitz & Stegun 26.2.23), then Halley steps on Phi
+// inverse normal cdf: P. J. Acklam's rational approximation (relative error ~1e-9) refined by one Halley step on Phi
 RVT_HDI double mvn_phiinv(double p) {
   if (!(p > 0.0)) return -INFINITY;
   if (!(p < 1.0)) return INFINITY;
-  const bool upper = p > 0.5;
-  const double q = upper ? 1.0 - p : p;
-  const double t = sqrt(-2.0 * log(q));
-  double x = t - (2.515517 + t * (0.802853 + t * 0.010328)) / (1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
-  x = -x;  // lower-tail quantile of q
-  for (int it = 0; it < 3; ++it) {
-    const double err = mvn_phi(x) - q;
-    const double pdf = 0.39894228040143267794 * exp(-0.5 * x * x);
-    if (!(pdf > 0.0)) break;
+  const double plow = 0.02425;
+  double x;
+  if (p < plow || p > 1.0 - plow) {
+    const double pp = p < plow ? p : 1.0 - p;
+    const double q = sqrt(-2.0 * log(pp));
+    x = (((((-7.784894002430293e-03 * q - 3.223964580411365e-01) * q - 2.400758277161838e+00) * q - 2.549732539343734e+00) * q +
+          4.374664141464968e+00) * q + 2.938163982698783e+00) /
+        ((((7.784695709041462e-03 * q + 3.224671290700398e-01) * q + 2.445134137142996e+00) * q + 3.754408661907416e+00) * q + 1.0);
+    if (p > 1.0 - plow) x = -x;
+  } else {
+    const double q = p - 0.5, r = q * q;
+    x = (((((-3.969683028665376e+01 * r + 2.209460984245205e+02) * r - 2.759285104469687e+02) * r + 1.383577518672690e+02) * r -
+          3.066479806614716e+01) * r + 2.506628277459239e+00) * q /
+        (((((-5.447609879822406e+01 * r + 1.615858368580409e+02) * r - 1.556989798598866e+02) * r + 6.680131188771972e+01) * r -
+          1.328068155288572e+01) * r + 1.0);
+  }
+  // one Halley step on the tail that keeps relative accuracy: err = Phi(x) - p evaluated through the nearer tail
+  const bool upper = x > 0.0;
+  const double tail = upper ? mvn_phi(-x) : mvn_phi(x);        // Phi of the nearer tail
+  const double target = upper ? 1.0 - p : p;
+  const double pdf = 0.39894228040143267794 * exp(-0.5 * x * x);
+  if (pdf > 0.0) {
+    const double err = upper ? target - tail : tail - target;  // Phi(x) - p
     const double u = err / pdf;
     x -= u / (1.0 + 0.5 * x * u);
   }
-  return upper ? -x : x;
+  return x;
 }
 
-// In-place lower Cholesky factor of the symmetric n x n matrix A (row-major, leading dimension lda); pivots below
-// `tol` become exact zeros with a zero column below them.  Returns the number of zero pivots.
-RVT_HDI int mvn_cholesky(double* A, int n, int lda, double tol) {
+RVT_HDI double mvn_pdf(double x) { return 0.39894228040143267794 * exp(-0.5 * x * x); }
+
+// Expected width of the conditional integration interval of a candidate variable with conditional variance v and
+// conditional mean shift s (Genz's ordering criterion); *ex receives the conditional expectation of its standardised
+// value over that interval.
+RVT_HDI double mvn_candidate_width(double v, double s, double T, double tol, double* ex) {
+  if (v > tol) {
+    const double c = sqrt(v), a = (-T - s) / c, b = (T - s) / c;
+    const double w = mvn_phi(b) - mvn_phi(a);
+    *ex = w > 0.0 ? (mvn_pdf(a) - mvn_pdf(b)) / w : 0.0;
+    return w;
+  }
+  *ex = 0.0;
+  return (s > -T && s < T) ? 1.0 : 0.0;
+}
+
+// In-place lower Cholesky factor of the symmetric n x n correlation matrix A (row-major, leading dimension lda; the
+// FULL matrix must be stored) with Genz's variable reordering for the band (-T, T)^n: at step i the remaining variable
+// with the smallest expected conditional interval width comes next (rows and columns are swapped; all limits are equal,
+// so nothing else moves), which concentrates the variation of the integrand in the first dimensions.  Pivots below
+// `tol` become exact zeros with a zero column below them.  yexp: n doubles of scratch.  Returns the number of zero pivots.
+RVT_HDI int mvn_cholesky(double* A, int n, int lda, double tol, double T, double* yexp) {
   int zeros = 0;
-  for (int j = 0; j < n; ++j) {
-    double s = A[j * lda + j];
-    for (int k = 0; k < j; ++k) s -= A[j * lda + k] * A[j * lda + k];
-    if (s > tol) {
-      const double l = sqrt(s);
-      A[j * lda + j] = l;
-      for (int i = j + 1; i < n; ++i) {
-        double t = A[i * lda + j];
-        for (int k = 0; k < j; ++k) t -= A[i * lda + k] * A[j * lda + k];
-        A[i * lda + j] = t / l;
+  for (int i = 0; i < n; ++i) {
+    int best = i;
+    double bestw = 2.0, bestv = 0.0, bests = 0.0, bestex = 0.0;
+    for (int j = i; j < n; ++j) {
+      double v = A[j * lda + j], sh = 0.0;
+      for (int k = 0; k < i; ++k) {
+        v -= A[j * lda + k] * A[j * lda + k];
+        sh += A[j * lda + k] * yexp[k];
+      }
+      double ex;
+      const double w = mvn_candidate_width(v, sh, T, tol, &ex);
+      if (w < bestw) {
+        bestw = w;
+        best = j;
+        bestv = v;
+        bests = sh;
+        bestex = ex;
+      }
+    }
+    (void)bests;
+    if (best != i) {
+      for (int k = 0; k < n; ++k) {  // rows
+        const double t = A[i * lda + k];
+        A[i * lda + k] = A[best * lda + k];
+        A[best * lda + k] = t;
+      }
+      for (int r = 0; r < n; ++r) {  // columns
+        const double t = A[r * lda + i];
+        A[r * lda + i] = A[r * lda + best];
+        A[r * lda + best] = t;
+      }
+    }
+    yexp[i] = bestex;
+    if (bestv > tol) {
+      const double l = sqrt(bestv);
+      A[i * lda + i] = l;
+      for (int r = i + 1; r < n; ++r) {
+        double t = A[r * lda + i];
+        for (int k = 0; k < i; ++k) t -= A[r * lda + k] * A[i * lda + k];
+        A[r * lda + i] = t / l;
       }
     } else {
       ++zeros;
-      A[j * lda + j] = 0.0;
-      for (int i = j + 1; i < n; ++i) A[i * lda + j] = 0.0;
+      A[i * lda + i] = 0.0;
+      for (int r = i + 1; r < n; ++r) A[r * lda + i] = 0.0;
     }
   }
   return zeros;
@@ -128,7 +191,7 @@ RVT_HD double mvn_band_prob_serial(double* A, int n, double T, double* y, double
     if (err) *err = 0.0;
     return mvn_phi(T) - mvn_phi(-T);
   }
-  mvn_cholesky(A, n, n, 1e-10);
+  mvn_cholesky(A, n, n, 1e-10, T, y);
   int found = 0;
   for (int cand = 2; found < n; ++cand) {
     bool prime = true;
