@@ -100,6 +100,41 @@ int orc_vcf_decode_record(const char* text, int64_t len, int n_file_samples, con
   return s;
 }
 
+// dosage mode (useDosage: ret = indv.justGet(genoIdx).toDouble(), src/VCFGenotypeExtractor.cpp:403-414; toDouble = atof of
+// the NUL-terminated subfield, libVcf/VCFValue.h:38-41; the default value "." reads 0.0); then the GD / GQ filters
+int orc_vcf_decode_record_dosage(const char* text, int64_t len, int n_file_samples, const int32_t* row_of_sample,
+                                 int tag_idx, int gd_idx, int gq_idx, const int* flt, double* out) {
+  int s = 0;
+  int64_t b = 0;
+  for (;;) {
+    int64_t e = b;
+    while (e < len && text[e] != '\t') ++e;
+    if (s < n_file_samples && row_of_sample[s] >= 0) {
+      const std::vector<std::string> fd = split_column(text + b, e - b);
+      auto just_get = [&](int i) -> std::string {
+        if (i < 0 || i >= (int)fd.size()) return std::string(".");
+        return fd[i];
+      };
+      double g = tag_idx < 0 ? (double)kMissing : atof(just_get(tag_idx).c_str());
+      if (flt) {
+        if (flt[0] > 0 || flt[1] > 0) {
+          const int gd = atoi(just_get(gd_idx).c_str());
+          if ((flt[0] > 0 && gd < flt[0]) || (flt[1] > 0 && gd > flt[1])) g = kMissing;
+        }
+        if (flt[2] > 0 || flt[3] > 0) {
+          const int gq = atoi(just_get(gq_idx).c_str());
+          if ((flt[2] > 0 && gq < flt[2]) || (flt[3] > 0 && gq > flt[3])) g = kMissing;
+        }
+      }
+      out[row_of_sample[s]] = g;
+    }
+    ++s;
+    if (e >= len) break;
+    b = e + 1;
+  }
+  return s;
+}
+
 // VCFRecord::getFormatIndex: the FORMAT entry at the current position only has to START with the key
 int orc_vcf_format_index(const char* format, int64_t len, const char* key) {
   std::string f(format, format + len);

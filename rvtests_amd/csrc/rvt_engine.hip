@@ -156,6 +156,7 @@ struct rvt_ctx {
   int vcf_n_file = 0;
   int64_t vcf_n_rows = 0;      // rows the map addresses (must equal the null model's N)
   VcfFilters vcf_flt{0, 0, 0, 0};
+  bool vcf_dosage = false;     // rvt_vcf_set_dosage: the index handed over is a dosage tag's, values through atof
   int* h_vcf_err = nullptr;    // pinned, device-visible: record index + 1 of a record with a wrong column count
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
   uint32_t rand_state[31];
@@ -3656,7 +3657,8 @@ struct VcfGene {
   const int* gd_idx;        // may be NULL (-1)
   const int* gq_idx;        // may be NULL (-1)
 };
-int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t st) {
+int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t st, double* dosage_out = nullptr,
+                    int64_t dosage_ld = 0) {
   std::vector<VcfRecord> rec(M);
   size_t total = 0;
   int64_t max_len = 0;
@@ -3696,16 +3698,23 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
       HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j], hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M, hipMemcpyHostToDevice, st));
   HIP_TRY(c, sync_stream(st));  // `rec` is a local
-  signed char* out = (signed char*)c->d_consol_i8;
-  HIP_TRY(c, hipMemsetAsync(out, 0xF7, (size_t)N * M, st));  // -9: rows the sample map never addresses stay missing
   int* d_err = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_vcf_err, 0));
   const dim3 grid((unsigned)max_seg, (unsigned)M);
   hipLaunchKernelGGL(vcf_tab_count_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg);
   hipLaunchKernelGGL(vcf_tab_scan_kernel, dim3((unsigned)M), dim3(256), 0, st, c->d_vcf_rec, max_seg, c->vcf_n_file,
                      c->d_vcf_seg, d_err);
-  hipLaunchKernelGGL(vcf_decode_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg,
-                     c->d_vcf_rows, c->vcf_n_file, (long long)N, c->vcf_flt, out);
+  if (dosage_out) {  // --dosage TAG: doubles straight into the gene's block (rows the map never addresses stay missing)
+    hipLaunchKernelGGL(vcf_fill_kernel, dim3(1024), dim3(256), 0, st, dosage_out, (long long)N, (long long)dosage_ld, M,
+                       (double)kVcfMissing);
+    hipLaunchKernelGGL(vcf_decode_dosage_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg,
+                       c->d_vcf_seg, c->d_vcf_rows, c->vcf_n_file, (long long)dosage_ld, c->vcf_flt, dosage_out, d_err);
+  } else {
+    signed char* out = (signed char*)c->d_consol_i8;
+    HIP_TRY(c, hipMemsetAsync(out, 0xF7, (size_t)N * M, st));  // -9: rows the sample map never addresses stay missing
+    hipLaunchKernelGGL(vcf_decode_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg,
+                       c->d_vcf_rows, c->vcf_n_file, (long long)N, c->vcf_flt, out);
+  }
   HIP_TRY(c, hipGetLastError());
   return RVT_OK;
 }
@@ -3777,8 +3786,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     const dim3 cgrid((unsigned)nparts, (unsigned)M);
     if (e != hipSuccess) {
       // fall through to the error return below
-    } else if (mode == 1) {
-      int rc = upload_block_data(c, p.dG, M, (const double*)G);
+    } else if (mode == 1 || mode == 5) {
+      int rc = mode == 1 ? upload_block_data(c, p.dG, M, (const double*)G)
+                         : vcf_decode_gene(c, (const VcfGene*)G, M, N, st, p.dG, ld);  // VCF dosage text -> doubles
       if (rc) {
         give_back();
         return rc;
@@ -3932,6 +3942,12 @@ int rvt_vcf_set_samples(rvt_ctx* c, int n_file_samples, const int32_t* row_of_sa
   return RVT_OK;
 }
 
+int rvt_vcf_set_dosage(rvt_ctx* c, int use_dosage) {
+  if (!c) return RVT_E_INVALID;
+  c->vcf_dosage = use_dosage != 0;
+  return RVT_OK;
+}
+
 int rvt_vcf_set_filters(rvt_ctx* c, int gd_min, int gd_max, int gq_min, int gq_max) {
   if (!c) return RVT_E_INVALID;
   c->vcf_flt = VcfFilters{gd_min, gd_max, gq_min, gq_max};
@@ -3951,10 +3967,13 @@ int rvt_submit_gene_vcf(rvt_ctx* c, int64_t gene_id, int M, const char* const* s
   if (c->h_vcf_err && *c->h_vcf_err) {
     const int k = *c->h_vcf_err;
     *c->h_vcf_err = 0;
+    if (k < 0)
+      return fail(c, RVT_E_INVALID, "VCF record %d of an earlier gene holds a dosage the device cannot round exactly "
+                  "(more than 15 digits, |exponent| > 22, inf / nan / hex)", -k - 1);
     return fail(c, RVT_E_INVALID, "VCF record %d of an earlier gene does not hold %d sample columns", k - 1, c->vcf_n_file);
   }
   VcfGene vg{sample_text, text_len, gt_index, gd_index, gq_index};
-  return submit_common(c, gene_id, M, &vg, 4, nullptr, af_out, tests, prm);
+  return submit_common(c, gene_id, M, &vg, c->vcf_dosage ? 5 : 4, nullptr, af_out, tests, prm);
 }
 
 // Decode only: the N x M signed bytes (column-major) the device reads out of the text, copied back to the caller.
@@ -4023,6 +4042,72 @@ int rvt_vcf_locate(const char* line, int64_t len, int64_t* sample_off, int* gt_i
   if (gt_index) *gt_index = index_of("GT");
   if (gd_index) *gd_index = index_of("GD");
   if (gq_index) *gq_index = index_of("GQ");
+  return RVT_OK;
+}
+
+// FORMAT index of an arbitrary key (the dosage tag of --dosage), same prefix rule
+int rvt_vcf_format_index(const char* line, int64_t len, const char* key, int* index) {
+  if (!line || len < 0 || !key || !index) return RVT_E_INVALID;
+  int64_t p = 0, fmt_b = -1, fmt_e = -1;
+  int tabs = 0;
+  for (; p < len && tabs < 9; ++p)
+    if (line[p] == '\t') {
+      ++tabs;
+      if (tabs == 8) fmt_b = p + 1;
+      if (tabs == 9) fmt_e = p;
+    }
+  if (tabs < 9) return RVT_E_INVALID;
+  int64_t b = fmt_b;
+  int idx = 0;
+  *index = -1;
+  while (b < fmt_e) {
+    bool match = true;
+    for (int i = 0; key[i]; ++i)
+      if (b + i >= len || line[b + i] != key[i]) {
+        match = false;
+        break;
+      }
+    if (match) {
+      *index = idx;
+      return RVT_OK;
+    }
+    ++idx;
+    bool more = false;
+    while (b < fmt_e)
+      if (line[b++] == ':') {
+        more = true;
+        break;
+      }
+    if (!more) break;
+  }
+  return RVT_OK;
+}
+
+// Decode only, dosage mode: out = N x M doubles (column-major, leading dimension N), missing = -9
+int rvt_vcf_decode_dosage(rvt_ctx* c, int M, const char* const* sample_text, const int64_t* text_len, const int* tag_index,
+                          const int* gd_index, const int* gq_index, double* out) {
+  if (!c || !sample_text || !text_len || !tag_index || !out || M < 1 || M > RVT_MAX_VARIANTS)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->d_vcf_rows) return fail(c, RVT_E_STATE, "rvt_vcf_set_samples first");
+  hipSetDevice(c->device);
+  const int64_t N = c->vcf_n_rows;
+  hipStream_t st = c->io_stream;
+  HIP_TRY(c, sync_stream(st));
+  double* d_out = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)N * M));
+  VcfGene vg{sample_text, text_len, tag_index, gd_index, gq_index};
+  int rc = vcf_decode_gene(c, &vg, M, N, st, d_out, N);
+  hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)N * M, hipMemcpyDeviceToHost, st);
+  if (!rc && e == hipSuccess) e = sync_stream(st);
+  hipFree(d_out);
+  if (rc) return rc;
+  HIP_TRY(c, e);
+  if (*c->h_vcf_err) {
+    const int k = *c->h_vcf_err;
+    *c->h_vcf_err = 0;
+    if (k < 0) return fail(c, RVT_E_INVALID, "VCF record %d holds a dosage the device cannot round exactly", -k - 1);
+    return fail(c, RVT_E_INVALID, "VCF record %d does not hold %d sample columns", k - 1, c->vcf_n_file);
+  }
   return RVT_OK;
 }
 

@@ -176,6 +176,140 @@ __device__ __forceinline__ int vcf_decode_column(const char* __restrict__ t, lon
   return g;
 }
 
+// atof() of a subfield (VCFValue::toDouble, libVcf/VCFValue.h:38-41) for the dosage mode: optional sign, decimal digits
+// with an optional point, optional exponent.  With at most 15 significant digits and a decimal exponent within +-22 the
+// value is ONE correctly rounded operation on exact doubles (digits * 10^e or digits / 10^-e) — exactly what a
+// correctly rounding strtod returns.  Anything else (more digits, huge exponents, inf / nan / hex) raises *inexact;
+// an empty or non-numeric field is 0.0, as atof gives.
+__device__ __forceinline__ double vcf_atof(const char* __restrict__ t, long long b, long long e, int* inexact) {
+  while (b < e && (t[b] == ' ' || (t[b] >= '\t' && t[b] <= '\r'))) ++b;
+  bool neg = false;
+  if (b < e && (t[b] == '-' || t[b] == '+')) neg = t[b++] == '-';
+  unsigned long long mant = 0;
+  int digits = 0, exp10 = 0;
+  bool any = false, seen_nonzero = false;
+  while (b < e && t[b] >= '0' && t[b] <= '9') {
+    any = true;
+    if (t[b] != '0' || seen_nonzero) {
+      seen_nonzero = true;
+      if (digits < 19) {
+        mant = mant * 10 + (unsigned)(t[b] - '0');
+        ++digits;
+      } else {
+        ++exp10;
+        *inexact = 1;
+      }
+    }
+    ++b;
+  }
+  if (b < e && t[b] == '.') {
+    ++b;
+    while (b < e && t[b] >= '0' && t[b] <= '9') {
+      any = true;
+      if (t[b] != '0' || seen_nonzero) {
+        seen_nonzero = true;
+        if (digits < 19) {
+          mant = mant * 10 + (unsigned)(t[b] - '0');
+          ++digits;
+          --exp10;
+        } else {
+          *inexact = 1;
+        }
+      } else {
+        --exp10;  // leading zeros behind the point
+      }
+      ++b;
+    }
+  }
+  if (!any) {
+    if (b < e && (t[b] == 'i' || t[b] == 'I' || t[b] == 'n' || t[b] == 'N')) *inexact = 1;  // inf / nan
+    return 0.0;
+  }
+  if (b < e && (t[b] == 'x' || t[b] == 'X') && mant == 0) *inexact = 1;  // hex float
+  if (b < e && (t[b] == 'e' || t[b] == 'E')) {
+    long long q = b + 1;
+    bool eneg = false;
+    if (q < e && (t[q] == '-' || t[q] == '+')) eneg = t[q++] == '-';
+    if (q < e && t[q] >= '0' && t[q] <= '9') {
+      int ex = 0;
+      while (q < e && t[q] >= '0' && t[q] <= '9' && ex < 10000) ex = ex * 10 + (t[q++] - '0');
+      exp10 += eneg ? -ex : ex;
+    }
+  }
+  if (mant == 0) return neg ? -0.0 : 0.0;
+  if (digits > 15 || exp10 > 22 || exp10 < -22) *inexact = 1;
+  const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                          1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  double v = (double)mant;
+  const int ae = exp10 < 0 ? -exp10 : exp10;
+  const double scale = p10[ae > 22 ? 22 : ae];
+  v = exp10 < 0 ? __ddiv_rn(v, scale) : __dmul_rn(v, scale);
+  return neg ? -v : v;
+}
+
+// dosage mode of the decode pass (--dosage TAG): the subfield at the tag's FORMAT index through atof; a column without
+// that subfield reads the default value "." = 0.0; the GD / GQ filters turn a value into -9 as for hard calls.
+// out: [record][ld] doubles, the first n_rows of every column pre-filled with -9.
+__global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __restrict__ text,
+                                                                const VcfRecord* __restrict__ rec, int max_seg,
+                                                                const int* __restrict__ seg_count,
+                                                                const int* __restrict__ row_of_sample, int n_file_samples,
+                                                                long long ld, VcfFilters flt, double* __restrict__ out,
+                                                                int* __restrict__ err) {
+  const VcfRecord r = rec[blockIdx.y];
+  const long long seg0 = (long long)blockIdx.x * kVcfSegBytes;
+  if (seg0 >= r.len) return;
+  const char* t = text + r.text_off;
+  double* col = out + (long long)blockIdx.y * ld;
+  const long long pos = seg0 + 16 * threadIdx.x;
+  unsigned m[4];
+  const int n = vcf_tabs16(t, pos, r.len, m);
+  int x = n;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if ((threadIdx.x & 63) >= o) x += y;
+  }
+  __shared__ int ws[4];
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
+  __syncthreads();
+  int k = seg_count[(long long)blockIdx.y * max_seg + blockIdx.x] + x - n;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) k += ws[w];
+  int inexact = 0;
+  auto column = [&](long long start) {
+    long long b, e;
+    double g = vcf_subfield(t, start, r.len, r.gt_idx, &b, &e) ? vcf_atof(t, b, e, &inexact) : 0.0;
+    if (r.gt_idx < 0) g = (double)kVcfMissing;  // "Cannot find <tag> field!"
+    if (flt.gd_min > 0 || flt.gd_max > 0) {
+      const int gd = vcf_subfield(t, start, r.len, r.gd_idx, &b, &e) ? vcf_atoi(t, b, e) : 0;
+      if ((flt.gd_min > 0 && gd < flt.gd_min) || (flt.gd_max > 0 && gd > flt.gd_max)) g = (double)kVcfMissing;
+    }
+    if (flt.gq_min > 0 || flt.gq_max > 0) {
+      const int gq = vcf_subfield(t, start, r.len, r.gq_idx, &b, &e) ? vcf_atoi(t, b, e) : 0;
+      if ((flt.gq_min > 0 && gq < flt.gq_min) || (flt.gq_max > 0 && gq > flt.gq_max)) g = (double)kVcfMissing;
+    }
+    return g;
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_file_samples > 0) {
+    const int row = row_of_sample[0];
+    if (row >= 0) col[row] = column(0);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned mm = m[w];
+    while (mm) {
+      const int bit = __ffs(mm) - 1;
+      mm &= mm - 1;
+      const int s = k + 1;
+      ++k;
+      if (s < n_file_samples) {
+        const int row = row_of_sample[s];
+        if (row >= 0) col[row] = column(pos + 4 * w + (bit >> 3) + 1);
+      }
+    }
+  }
+  if (inexact) atomicCAS_system(err, 0, -((int)blockIdx.y + 1));  // negative: a number the device cannot round exactly
+}
+
 // pass 3: decode.  grid (max segments, records), 256 threads.  out: [record][n_rows] signed bytes, pre-filled with -9
 __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict__ text, const VcfRecord* __restrict__ rec,
                                                          int max_seg, const int* __restrict__ seg_count,
@@ -217,6 +351,13 @@ __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict_
       }
     }
   }
+}
+
+// dst[i + j * ld] = value for i < n_rows (the dosage matrix before the decode pass: every row missing)
+__global__ void vcf_fill_kernel(double* __restrict__ dst, long long n_rows, long long ld, int ncols, double value) {
+  const long long total = n_rows * ncols;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
+    dst[(t / n_rows) * ld + t % n_rows] = value;
 }
 
 }  // namespace rvt

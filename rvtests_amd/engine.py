@@ -244,6 +244,10 @@ def load_library():
     L.rvt_kinship_decompose.restype = C.c_int
     L.rvt_kinship_decompose.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.c_int, C.POINTER(DecomposeInfo)]
+    L.rvt_vcf_set_dosage.restype = C.c_int
+    L.rvt_vcf_set_dosage.argtypes = [vp, C.c_int]
+    L.rvt_vcf_format_index.restype = C.c_int
+    L.rvt_vcf_format_index.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, c_int_p]
     L.rvt_vcf_decode.restype = C.c_int
     L.rvt_vcf_decode.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_i64_p, c_int_p, c_int_p, c_int_p,
                                  C.POINTER(C.c_int8)]
@@ -528,12 +532,36 @@ class Engine:
 
     prepare_vcf = _vcf_args
 
+    def vcf_set_dosage(self, on=True):
+        self._check(self.L.rvt_vcf_set_dosage(self.ctx, 1 if on else 0))
+
+    def vcf_args_for_tag(self, lines, tag):
+        """As _vcf_args, with the FORMAT index of `tag` (bytes) in place of GT's."""
+        M, keep, text, tlen, gt, gd, gq = self._vcf_args(lines)
+        for j, ln in enumerate(lines):
+            idx = C.c_int(-1)
+            self.L.rvt_vcf_format_index(ln, len(ln), tag, C.byref(idx))
+            gt[j] = idx.value
+        return M, keep, text, tlen, gt, gd, gq
+
+    def vcf_decode_dosage(self, lines, tag, n_rows):
+        """Dosage matrix (n_rows x M float64, missing = -9) the device reads out of the records' text."""
+        M, keep, text, tlen, gt, gd, gq = self.vcf_args_for_tag(lines, tag)
+        out = np.zeros((n_rows, M), dtype=np.float64, order="F")
+        self.L.rvt_vcf_decode_dosage.restype = C.c_int
+        self._check(self.L.rvt_vcf_decode_dosage(self.ctx, M, text, tlen, gt, gd, gq, _dp(out)))
+        return out
+
     def vcf_decode(self, lines, n_rows):
         """Genotype bytes (n_rows x M int8, missing = -9) the device reads out of the records' text."""
         M, keep, text, tlen, gt, gd, gq = self._vcf_args(lines)
         out = np.zeros((n_rows, M), dtype=np.int8, order="F")
         self._check(self.L.rvt_vcf_decode(self.ctx, M, text, tlen, gt, gd, gq, out.ctypes.data_as(C.POINTER(C.c_int8))))
         return out
+
+    def submit_gene_vcf_dosage(self, gene_id, lines, tag, tests=TEST_ALL, params=None, want_af=True):
+        """As submit_gene_vcf in dosage mode (vcf_set_dosage(True) first): values of FORMAT tag `tag` through atof."""
+        return self.submit_gene_vcf(gene_id, self.vcf_args_for_tag(lines, tag), tests, params, want_af)
 
     def submit_gene_vcf(self, gene_id, lines, tests=TEST_ALL, params=None, want_af=True):
         """lines: the full text of the gene's VCF records (bytes, no newline).  rvt_vcf_locate finds the sample columns

@@ -608,3 +608,16 @@ def fam_analytic_vt(G, X, y, U, S, nul, mvn_points=2048):
                                C.c_double(nul.sigma2), _dp(beta), C.c_longlong(mvn_points), C.byref(out), _dp(cor))
     K = out.n_cutoff
     return rc, out, cor.ravel()[:K * K].reshape(K, K).copy()
+
+
+def vcf_decode_record_dosage(text, row_of_sample, n_rows, tag_idx, gd_idx=-1, gq_idx=-1, filters=(0, 0, 0, 0)):
+    L = lib()
+    L.orc_vcf_decode_record_dosage.restype = C.c_int
+    L.orc_vcf_decode_record_dosage.argtypes = [C.c_char_p, C.c_int64, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int,
+                                               c_int_p, c_double_p]
+    rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)
+    flt = np.ascontiguousarray(filters, dtype=np.int32)
+    out = np.full(n_rows, -9.0)
+    n = L.orc_vcf_decode_record_dosage(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), tag_idx, gd_idx, gq_idx,
+                                       flt.ctypes.data_as(c_int_p), _dp(out))
+    return out, n

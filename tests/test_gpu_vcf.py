@@ -110,3 +110,80 @@ def test_submit_gene_vcf_equals_int8_hand_off(eng, binary):
     G8[G8 < 0] = np.nan
     af = np.nansum(G8, axis=0) * 0.5 / N                            # GenotypeCounter: missing in the denominator
     assert np.allclose(af_vcf[0], af, rtol=0, atol=1e-15)
+
+
+def _dosage_record(rng, n_file, fmt=b"GT:DS", pos=1):
+    keys = fmt.split(b":")
+    pool = [b"0", b"1", b"2", b".", b"0.5", b"1.25", b"0.001", b"1e-2", b"2.000", b"1.999999", b"0.333333333333333",
+            b"-0", b"+1.5", b" 0.75", b"1.5e0", b".25", b"3.", b"0.1234567", b"12345.678e-4", b"abc", b""]
+    cols = []
+    for s_ in range(n_file):
+        parts = []
+        for k in keys:
+            if k == b"DS":
+                parts.append(pool[rng.integers(len(pool))] if rng.random() < 0.3 else (b"%.3f" % rng.uniform(0, 2)))
+            elif k == b"GT":
+                parts.append([b"0/0", b"0/1", b"1/1", b"./."][rng.integers(4)])
+            else:
+                parts.append(b"%d" % rng.integers(0, 60))
+        if rng.random() < 0.03:
+            parts = parts[:1]                               # truncated column: the tag's subfield is absent -> 0.0
+        if parts[-1] == b"":
+            parts[-1] = b"0"                                # (no empty trailing subfield: malformed for the reference too)
+        cols.append(b":".join(parts))
+    head = b"\t".join([b"1", b"%d" % pos, b".", b"A", b"G", b"50", b"PASS", b".", fmt])
+    return head + b"\t" + b"\t".join(cols)
+
+
+@pytest.mark.parametrize("fmt,filters", [(b"GT:DS", (0, 0, 0, 0)), (b"DS", (0, 0, 0, 0)), (b"GT:GD:DS:GQ", (10, 0, 20, 0))])
+def test_dosage_decode_matches_atof_bit_exactly(eng, fmt, filters):
+    """--dosage TAG: the device's decimal parser against atof (the oracle calls libc), value by value, bit for bit."""
+    import rvtests_amd.engine as e
+    rng = np.random.default_rng(len(fmt))
+    n_file, n_keep = 4000, 3500
+    rows = _sample_map(rng, n_file, n_keep)
+    lines = [_dosage_record(rng, n_file, fmt, pos=5 + j) for j in range(5)]
+    eng.vcf_set_samples(rows)
+    eng.vcf_set_filters(*filters)
+    got = eng.vcf_decode_dosage(lines, b"DS", n_keep)
+    for j, ln in enumerate(lines):
+        off, gt, gd, gq = e.vcf_locate(eng.L, ln)
+        tag = orc.vcf_format_index(fmt, b"DS")
+        want, n = orc.vcf_decode_record_dosage(ln[off:], rows, n_keep, tag, gd, gq, filters)
+        assert n == n_file
+        assert (got[:, j].view(np.int64) == want.view(np.int64)).all()      # bit patterns (also -0.0)
+
+
+def test_dosage_the_device_cannot_round_is_an_error(eng):
+    import rvtests_amd
+    eng.vcf_set_samples(np.arange(3, dtype=np.int32))
+    eng.vcf_set_filters(0, 0, 0, 0)
+    head = b"1\t5\t.\tA\tG\t50\tPASS\t.\tDS\t"
+    with pytest.raises(rvtests_amd.RvtError):
+        eng.vcf_decode_dosage([head + b"0.12345678901234567\t1\t2"], b"DS", 3)
+    assert eng.vcf_decode_dosage([head + b"0.5\t1\t2"], b"DS", 3)[:, 0].tolist() == [0.5, 1.0, 2.0]
+
+
+def test_submit_gene_vcf_dosage_equals_raw_hand_off(eng):
+    N, d, n_file = 3000, 2, 3200
+    rng = np.random.default_rng(77)
+    rows = _sample_map(rng, n_file, N)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=14)
+    eng.fit_null(0, X, y)
+    eng.vcf_set_samples(rows)
+    eng.vcf_set_filters(0, 0, 0, 0)
+    eng.vcf_set_dosage(True)
+    lines = [_dosage_record(rng, n_file, b"GT:DS", pos=j) for j in range(14)]
+    af_v = eng.submit_gene_vcf_dosage(0, lines, b"DS")
+    rec_v = eng.collect()[0]
+    eng.vcf_set_dosage(False)
+    import rvtests_amd.engine as e
+    Graw = np.zeros((N, len(lines)), order="F")
+    for j, ln in enumerate(lines):
+        off, gt, gd, gq = e.vcf_locate(eng.L, ln)
+        Graw[:, j] = orc.vcf_decode_record_dosage(ln[off:], rows, N, 1)[0]
+    af_r = eng.submit_gene_raw(0, Graw)
+    rec_r = eng.collect()[0]
+    assert (af_v == af_r).all()
+    for f in ("status", "n_poly", "skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p"):
+        assert getattr(rec_v, f) == getattr(rec_r, f), f
