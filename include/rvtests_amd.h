@@ -429,8 +429,7 @@ int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned cha
  * hard calls: the caller hands over the TEXT of the sample columns of each record of a gene; splitting at tabs and ':',
  * VCFValue::getGenotype (libVcf/VCFValue.h:74-117; '.', multi-allelic or malformed calls -> missing, haploid calls -> 0 / 1),
  * the GD / GQ filters (src/VCFGenotypeExtractor.cpp:304-317) and then everything rvt_submit_gene_i8 does (allele
- * frequencies, mean imputation) run on the device.  Not provided: multi-allelic mode, the hemizygous (non-PAR X)
- * recoding by sex.
+ * frequencies, mean imputation) run on the device.  Not provided: the hemizygous (non-PAR X) recoding by sex.
  *   rvt_vcf_locate      host-only helper: offset of the first sample column of a record line and the FORMAT indices
  *                       of GT / GD / GQ by VCFRecord::getFormatIndex's prefix rule (libVcf/VCFRecord.h:280-305); -1 = absent
  *   rvt_vcf_set_samples once per file: row_of_sample[s] = row of the analysis (0 .. N-1) that sample column s of the
@@ -449,6 +448,10 @@ int rvt_vcf_set_filters(rvt_ctx* ctx, int gd_min, int gd_max, int gq_min, int gq
  * the gene then follows the path of rvt_submit_gene_raw.  Numbers of up to 15 significant digits with a decimal exponent
  * within +-22 are rounded exactly as strtod rounds them; anything else is reported as an error, never approximated. */
 int rvt_vcf_set_dosage(rvt_ctx* ctx, int use_dosage);
+/* --multipleAllele (multiAllelicMode, src/VCFGenotypeExtractor.cpp:44-47,441-484): the caller submits a record once per
+ * alternative allele; alt[j] > 0 makes record j of the NEXT rvt_submit_gene_vcf / rvt_vcf_decode call count that allele
+ * (VCFValue::countAltAllele, libVcf/VCFValue.h:180-213), alt[j] = 0 keeps the bi-allelic coding.  Consumed by that call. */
+int rvt_vcf_set_alt_alleles(rvt_ctx* ctx, int M, const int* alt);
 int rvt_vcf_format_index(const char* line, int64_t len, const char* key, int* index);
 int rvt_vcf_decode_dosage(rvt_ctx* ctx, int M, const char* const* sample_text, const int64_t* text_len,
                           const int* tag_index, const int* gd_index, const int* gq_index, double* out);

@@ -56,14 +56,36 @@ int gt_code(const std::string& s) {  // VCFValue::getGenotype; s.c_str() supplie
   return g;
 }
 
-int column_code(const char* col, int64_t len, int gt_idx, int gd_idx, int gq_idx, const int* flt) {
+int alt_code(const std::string& s, int alt) {  // VCFValue::countAltAllele (libVcf/VCFValue.h:180-213)
+  const char* line = s.c_str();
+  const int end = (int)s.size();
+  int g = 0, p = 0;
+  if (line[p] == '.') return kMissing;
+  g += (line[p] - '0' == alt ? 1 : 0);
+  p++;
+  if (p == end) return g;
+  if (line[p] != '|' && line[p] != '/') return kMissing;
+  p++;
+  if (p == end) return kMissing;
+  if (line[p] == '.') return kMissing;
+  if (line[p] < '0' || line[p] > '9') {
+    // only reported
+  } else {
+    g += (line[p] - '0' == alt ? 1 : 0);
+  }
+  p++;
+  if (p != end) return kMissing;
+  return g;
+}
+
+int column_code(const char* col, int64_t len, int gt_idx, int gd_idx, int gq_idx, const int* flt, int alt = 0) {
   const std::vector<std::string> fd = split_column(col, len);
   auto just_get = [&](int i) -> std::string {  // index past the end (or negative: unsigned wrap) -> default "."
     if (i < 0 || i >= (int)fd.size()) return std::string(".");
     return fd[i];
   };
   if (gt_idx < 0) return kMissing;  // "Cannot find GT field!"
-  int ret = gt_code(just_get(gt_idx));
+  int ret = alt > 0 ? alt_code(just_get(gt_idx), alt) : gt_code(just_get(gt_idx));
   if (flt) {
     if (flt[0] > 0 || flt[1] > 0) {
       const int gd = atoi(just_get(gd_idx).c_str());
@@ -81,6 +103,9 @@ int column_code(const char* col, int64_t len, int gt_idx, int gd_idx, int gq_idx
 extern "C" {
 
 int orc_vcf_column_genotype(const char* col, int64_t len, int gt_idx) { return column_code(col, len, gt_idx, -1, -1, nullptr); }
+int orc_vcf_column_alt(const char* col, int64_t len, int gt_idx, int alt) {
+  return column_code(col, len, gt_idx, -1, -1, nullptr, alt);
+}
 
 // text = the sample columns of one record (tab separated, no newline).  out[row_of_sample[s]] = code of column s.
 // Returns the number of columns found.

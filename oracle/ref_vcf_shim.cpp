@@ -24,3 +24,12 @@ extern "C" int ref_vcf_column_int(const char* column, int len, int idx) {
   indv.parse(v);
   return indv.justGet(idx).toInt();
 }
+
+extern "C" int ref_vcf_column_alt(const char* column, int len, int gt_idx, int alt) {
+  std::string buf(column, len);
+  buf.append(32, '\0');
+  VCFValue v(&buf[0], 0, len);
+  VCFIndividual indv;
+  indv.parse(v);
+  return indv.justGet(gt_idx).countAltAllele(alt);
+}

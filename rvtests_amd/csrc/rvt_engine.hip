@@ -156,6 +156,7 @@ struct rvt_ctx {
   int vcf_n_file = 0;
   int64_t vcf_n_rows = 0;      // rows the map addresses (must equal the null model's N)
   VcfFilters vcf_flt{0, 0, 0, 0};
+  std::vector<int> vcf_alt;    // rvt_vcf_set_alt_alleles: alternative-allele index per record of the NEXT VCF call
   bool vcf_dosage = false;     // rvt_vcf_set_dosage: the index handed over is a dosage tag's, values through atof
   int* h_vcf_err = nullptr;    // pinned, device-visible: record index + 1 of a record with a wrong column count
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
@@ -3668,7 +3669,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     rec[j].gt_idx = vg->gt_idx[j];
     rec[j].gd_idx = vg->gd_idx ? vg->gd_idx[j] : -1;
     rec[j].gq_idx = vg->gq_idx ? vg->gq_idx[j] : -1;
-    rec[j].pad = 0;
+    rec[j].alt = ((int)c->vcf_alt.size() == M) ? c->vcf_alt[j] : 0;
     total += ((size_t)vg->len[j] + 31) / 16 * 16;  // 16-byte aligned starts, >= 16 readable bytes behind the end
     max_len = std::max<int64_t>(max_len, vg->len[j]);
   }
@@ -3693,6 +3694,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     HIP_TRY(c, hipHostMalloc((void**)&c->h_vcf_err, sizeof(int), hipHostMallocMapped));
     *c->h_vcf_err = 0;
   }
+  c->vcf_alt.clear();  // (one call only)
   for (int j = 0; j < M; ++j)  // (a copy from pageable memory returns once the source has been read)
     if (vg->len[j] > 0)
       HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j], hipMemcpyHostToDevice, st));
@@ -3939,6 +3941,14 @@ int rvt_vcf_set_samples(rvt_ctx* c, int n_file_samples, const int32_t* row_of_sa
   HIP_TRY(c, hipMemcpy(c->d_vcf_rows, row_of_sample, sizeof(int) * (size_t)n_file_samples, hipMemcpyHostToDevice));
   c->vcf_n_file = n_file_samples;
   c->vcf_n_rows = rows;
+  return RVT_OK;
+}
+
+int rvt_vcf_set_alt_alleles(rvt_ctx* c, int M, const int* alt) {
+  if (!c || M < 0 || (M > 0 && !alt)) return RVT_E_INVALID;
+  for (int j = 0; j < M; ++j)
+    if (alt[j] < 0 || alt[j] > 9) return fail(c, RVT_E_INVALID, "alternative allele index %d (single digits only)", alt[j]);
+  c->vcf_alt.assign(alt, alt + M);
   return RVT_OK;
 }
 

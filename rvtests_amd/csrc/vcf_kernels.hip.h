@@ -26,7 +26,7 @@ struct VcfRecord {          // one record (variant) of a gene
   long long text_off;       // offset of its sample columns inside the text buffer (multiple of 16)
   long long len;            // bytes
   int gt_idx, gd_idx, gq_idx;  // FORMAT indices (-1: not present)
-  int pad;
+  int alt;                     // 0: bi-allelic coding (getGenotype); a > 0: count of alternative allele a (multi-allelic mode)
 };
 struct VcfFilters {
   int gd_min, gd_max, gq_min, gq_max;  // <= 0: off (the reference's `GDmin > 0 &&` tests)
@@ -149,6 +149,24 @@ __device__ __forceinline__ int vcf_gt_code(const char* __restrict__ t, long long
   return g;
 }
 
+// VCFValue::countAltAllele(alt) (libVcf/VCFValue.h:180-213; multi-allelic mode, src/VCFGenotypeExtractor.cpp:441-484): single
+// digit allele indices; an allele that is not a digit is only reported and counts as "not alt"
+__device__ __forceinline__ int vcf_alt_code(const char* __restrict__ t, long long b, long long e, int alt) {
+  if (b >= e) return kVcfMissing;  // (empty subfield: malformed for the reference too)
+  const signed char c0 = (signed char)t[b];
+  if (c0 == '.') return kVcfMissing;
+  int g = (c0 - '0' == alt) ? 1 : 0;
+  if (b + 1 == e) return g;
+  const signed char c1 = (signed char)t[b + 1];
+  if (c1 != '|' && c1 != '/') return kVcfMissing;
+  if (b + 2 == e) return kVcfMissing;
+  const signed char c2 = (signed char)t[b + 2];
+  if (c2 == '.') return kVcfMissing;
+  if (!(c2 < '0' || c2 > '9')) g += (c2 - '0' == alt) ? 1 : 0;
+  if (b + 3 != e) return kVcfMissing;
+  return g;
+}
+
 // atoi() of the subfield (NUL-terminated at its end in the reference)
 __device__ __forceinline__ int vcf_atoi(const char* __restrict__ t, long long b, long long e) {
   while (b < e && (t[b] == ' ' || (t[b] >= '\t' && t[b] <= '\r'))) ++b;
@@ -164,7 +182,8 @@ __device__ __forceinline__ int vcf_decode_column(const char* __restrict__ t, lon
                                                  const VcfRecord& r, const VcfFilters& f) {
   long long b, e;
   int g = kVcfMissing;
-  if (vcf_subfield(t, start, len, r.gt_idx, &b, &e)) g = vcf_gt_code(t, b, e);  // else "." -> missing
+  if (vcf_subfield(t, start, len, r.gt_idx, &b, &e))  // else "." -> missing
+    g = r.alt > 0 ? vcf_alt_code(t, b, e, r.alt) : vcf_gt_code(t, b, e);
   if (f.gd_min > 0 || f.gd_max > 0) {                                            // checkGD (:304-310)
     const int gd = vcf_subfield(t, start, len, r.gd_idx, &b, &e) ? vcf_atoi(t, b, e) : 0;  // atoi(".") = 0
     if ((f.gd_min > 0 && gd < f.gd_min) || (f.gd_max > 0 && gd > f.gd_max)) g = kVcfMissing;

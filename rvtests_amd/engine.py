@@ -532,6 +532,12 @@ class Engine:
 
     prepare_vcf = _vcf_args
 
+    def vcf_set_alt_alleles(self, alt):
+        """Multi-allelic mode for the NEXT vcf_decode / submit_gene_vcf call: alt[j] > 0 counts that allele in record j."""
+        a = np.ascontiguousarray(alt, dtype=np.int32)
+        self.L.rvt_vcf_set_alt_alleles.restype = C.c_int
+        self._check(self.L.rvt_vcf_set_alt_alleles(self.ctx, len(a), a.ctypes.data_as(c_int_p)))
+
     def vcf_set_dosage(self, on=True):
         self._check(self.L.rvt_vcf_set_dosage(self.ctx, 1 if on else 0))
 

@@ -21,7 +21,14 @@ for idx in (0, 1, 2):
         c = R.ref_vcf_column_genotype(col, len(col), idx)
         s.append("m" if c < 0 else str(c))
     codes[str(idx)] = "".join(s)
-out = {"alphabet": ALPHABET.decode(), "max_len": 4, "n_columns": len(cols), "codes": codes,
+alt_codes = {}
+for alt in (1, 2):                       # VCFValue::countAltAllele(alt) of subfield 0 (multi-allelic mode)
+    s = []
+    for col in cols:
+        c = R.ref_vcf_column_alt(col, len(col), 0, alt)
+        s.append("m" if c < 0 else str(c))
+    alt_codes[str(alt)] = "".join(s)
+out = {"alphabet": ALPHABET.decode(), "max_len": 4, "n_columns": len(cols), "codes": codes, "alt_codes": alt_codes,
        "source": "libVcf/VCFIndividual.h:27-58,88-93 + libVcf/VCFValue.h:74-117 compiled from /root/reference"}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vcf_genotype.json")
 json.dump(out, open(path, "w"))

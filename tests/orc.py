@@ -465,6 +465,8 @@ def ref_vcf():
         R = C.CDLL(path)
         R.ref_vcf_column_genotype.restype = C.c_int
         R.ref_vcf_column_genotype.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        R.ref_vcf_column_alt.restype = C.c_int
+        R.ref_vcf_column_alt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
         R.ref_vcf_column_int.restype = C.c_int
         R.ref_vcf_column_int.argtypes = [C.c_char_p, C.c_int, C.c_int]
         _ref_vcf = R
@@ -621,3 +623,10 @@ def vcf_decode_record_dosage(text, row_of_sample, n_rows, tag_idx, gd_idx=-1, gq
     n = L.orc_vcf_decode_record_dosage(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), tag_idx, gd_idx, gq_idx,
                                        flt.ctypes.data_as(c_int_p), _dp(out))
     return out, n
+
+
+def vcf_column_alt(col, gt_idx, alt):
+    L = lib()
+    L.orc_vcf_column_alt.restype = C.c_int
+    L.orc_vcf_column_alt.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int]
+    return L.orc_vcf_column_alt(col, len(col), gt_idx, alt)

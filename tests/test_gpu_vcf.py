@@ -187,3 +187,28 @@ def test_submit_gene_vcf_dosage_equals_raw_hand_off(eng):
     assert (af_v == af_r).all()
     for f in ("status", "n_poly", "skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p"):
         assert getattr(rec_v, f) == getattr(rec_r, f), f
+
+
+def test_multi_allelic_mode_counts_the_requested_allele(eng):
+    """rvt_vcf_set_alt_alleles: record j counts alternative allele alt[j] (countAltAllele); consumed by one call."""
+    rng = np.random.default_rng(12)
+    n_file = 2000
+    pool = [b"0/0", b"0/1", b"1/2", b"2/2", b"0|2", b"3/1", b"./.", b".", b"2", b"1", b"2/.", b"1/2/3", b"x/2", b"2/x"]
+    recs, alts = [], [1, 2, 3, 0, 2]
+    head = b"\t".join([b"1", b"77", b".", b"A", b"C,G,T", b"50", b"PASS", b".", b"GT:DP"])
+    for j in range(len(alts)):
+        cols = [pool[rng.integers(len(pool))] + b":%d" % rng.integers(1, 40) for _ in range(n_file)]
+        recs.append(head + b"\t" + b"\t".join(cols))
+    rows = np.arange(n_file, dtype=np.int32)
+    eng.vcf_set_samples(rows)
+    eng.vcf_set_filters(0, 0, 0, 0)
+    eng.vcf_set_alt_alleles(alts)
+    got = eng.vcf_decode(recs, n_file)
+    import rvtests_amd.engine as e
+    for j, (ln, alt) in enumerate(zip(recs, alts)):
+        off = e.vcf_locate(eng.L, ln)[0]
+        cols = ln[off:].split(b"\t")
+        want = [orc.vcf_column_alt(c_, 0, alt) if alt > 0 else orc.vcf_column_genotype(c_, 0) for c_ in cols]
+        assert got[:, j].tolist() == want
+    again = eng.vcf_decode(recs[:1], n_file)                 # the setting was consumed: bi-allelic coding again
+    assert again[:, 0].tolist() == [orc.vcf_column_genotype(c_, 0) for c_ in recs[0][e.vcf_locate(eng.L, recs[0])[0]:].split(b"\t")]

@@ -39,6 +39,22 @@ def test_oracle_matches_golden_vector():
         assert got == want
 
 
+def test_alt_allele_rule_matches_golden_and_reference():
+    """Multi-allelic mode: VCFValue::countAltAllele for alt = 1, 2."""
+    g = json.load(open(GOLDEN))
+    cols = list(enumerate_columns(4))
+    R = orc.ref_vcf()
+    for alt in (1, 2):
+        got = "".join("m" if (c := orc.vcf_column_alt(col, 0, alt)) < 0 else str(c) for col in cols)
+        assert got == g["alt_codes"][str(alt)]
+        if R is not None:
+            for col in list(enumerate_columns(3)) + [b"1/2/3", b"12", b"9|9", b"3/3", b"2|.", b"x/2"]:
+                if col.endswith(b":"):
+                    continue
+                for a in (1, 2, 3, 9):
+                    assert orc.vcf_column_alt(col, 0, a) == R.ref_vcf_column_alt(col, len(col), 0, a), (col, a)
+
+
 def test_oracle_matches_compiled_reference_exhaustively():
     R = orc.ref_vcf()
     if R is None:
