@@ -14,6 +14,7 @@
 
 #include "suffstat_kernels.hip.h"
 #include "suffstat_hc.hip.h"
+#include "suffstat_hcw.hip.h"
 
 namespace rvt {
 
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
 constexpr int kFallbackSplit = 8;
 template <int DMAX>
 __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __restrict__ genes, NullDev nd,
-                                                              long long N, long long ld, int d) {
+                                                              long long N, long long ld, int d, int binary) {
   const GeneDesc gd = genes[blockIdx.y];
   if (!gd.bparts || gd.flags[2 * gd.MT] == 0) return;
   constexpr int NV = 2 * (3 + DMAX);
@@ -254,16 +255,16 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
       n += ((int)gf > 0) ? 1 : 0;
     }
     const double cv[2] = {n > 0 ? 1.0 : 0.0, (double)n};
-    const double r = nd.res[i];
+    const double r = nd.res[i], w = binary ? nd.v[i] : 1.0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const double c = cv[t];
       val[t * (3 + DMAX) + 0] += c * r;
-      val[t * (3 + DMAX) + 1] += c * c;
+      val[t * (3 + DMAX) + 1] += (c * w) * c;
       val[t * (3 + DMAX) + 2] += (c != 0.0) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < DMAX; ++k)
-        if (k < d) val[t * (3 + DMAX) + 3 + k] += c * nd.X[(long long)k * ld + i];
+        if (k < d) val[t * (3 + DMAX) + 3 + k] += (c * w) * nd.X[(long long)k * ld + i];
     }
   }
 #pragma unroll

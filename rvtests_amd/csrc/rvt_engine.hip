@@ -28,6 +28,8 @@ void k2_launch_panel_w1(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullD
                         int d);
 void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
                   int d);
+void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
+                   int d);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
@@ -176,6 +178,9 @@ struct rvt_ctx {
   NullConsts* d_nc = nullptr;
   double *d_X = nullptr, *d_res = nullptr, *d_rr = nullptr, *d_v = nullptr, *d_zeros = nullptr;
   double* d_nulltile = nullptr;  // ONE allocation [X_0 .. X_{d-1} | rr | zeros]: d_X, d_rr and d_zeros point into it
+  // binary trait: the weighted hard-call kernel's tile [vX_0 .. vX_{d-1} | res | v | zeros] and the digit planes of v
+  double* d_nulltile_w = nullptr;
+  unsigned char* d_vq = nullptr;
   int64_t null_ld = 0;
   // what is known about the CONTENT of device blocks: 1 = every entry is exactly 0.0, 1.0 or 2.0 ("hard calls": the
   // integer sufficient-statistics kernel applies), 0 = anything else.  Recorded when a block is uploaded through the
@@ -555,6 +560,10 @@ static void free_null(rvt_ctx* c) {
     *p = nullptr;
   }
   c->d_X = c->d_rr = c->d_zeros = nullptr;  // inside d_nulltile
+  if (c->d_nulltile_w) hipFree(c->d_nulltile_w);
+  if (c->d_vq) hipFree(c->d_vq);
+  c->d_nulltile_w = nullptr;
+  c->d_vq = nullptr;
   c->have_null = false;
 }
 
@@ -684,6 +693,37 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
     else
       for (int64_t i = 0; i < N; ++i) rr[i] = res[i];
     HIP_TRY(c, hipMemcpy(c->d_rr, rr.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  }
+  if (nc.binary && c->hc_enabled && d <= kHcwMaxD) {
+    // weighted hard-call kernel (suffstat_hcw.hip.h): v = p (1 - p) <= 1/4 rounded to 49 fractional bits and split into
+    // seven balanced base-128 digits (value = sum_p digit_p 128^-(p+1), digits in [-64, 63]: reaches 0.496), stored per
+    // four samples as [plane 0..7][4 bytes]; a model with a weight outside [0, 0.49] stays on the fp64 kernel
+    bool ok = true;
+    for (int64_t i = 0; i < N && ok; ++i) ok = v[i] >= 0.0 && v[i] <= 0.49;
+    if (ok) {
+      std::vector<unsigned char> vq((size_t)ld * 8, 0);
+      for (int64_t i = 0; i < N; ++i) {
+        long long q = llrint(std::ldexp(v[i], 7 * kHcwPlanes));
+        unsigned char* grp = vq.data() + (size_t)(i >> 2) * 32 + (size_t)(i & 3);
+        for (int p = kHcwPlanes - 1; p >= 0; --p) {
+          long long r = q & 127;
+          if (r >= 64) r -= 128;
+          q = (q - r) >> 7;
+          grp[p * 4] = (unsigned char)(signed char)r;
+        }
+      }
+      std::vector<double> tile((size_t)ld * (d + 3), 0.0);
+      for (int k = 0; k < d; ++k)
+        for (int64_t i = 0; i < N; ++i) tile[(size_t)k * ld + i] = v[i] * X[(size_t)k * N + i];
+      for (int64_t i = 0; i < N; ++i) {
+        tile[(size_t)d * ld + i] = res[i];
+        tile[(size_t)(d + 1) * ld + i] = v[i];
+      }
+      HIP_TRY(c, hipMalloc((void**)&c->d_nulltile_w, sizeof(double) * tile.size()));
+      HIP_TRY(c, hipMalloc((void**)&c->d_vq, vq.size()));
+      HIP_TRY(c, hipMemcpy(c->d_nulltile_w, tile.data(), sizeof(double) * tile.size(), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_vq, vq.data(), vq.size(), hipMemcpyHostToDevice));
+    }
   }
   HIP_TRY(c, hipMemcpy(c->d_nc, &nc, sizeof(nc), hipMemcpyHostToDevice));
   c->null_ld = ld;
@@ -965,8 +1005,11 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
                              c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
   const bool score_hc = cov && cov->score && cov->slice_hc;
-  const bool hc_possible = c->hc_enabled && !nc.binary && (!cov || score_hc) && !(dbg && dbg->cmc) && d <= kHcMaxD &&
-                           !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
+  // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests only)
+  const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && !cov;
+  const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) && !(dbg && dbg->cmc) &&
+                           d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
+  const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
@@ -985,7 +1028,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.gene_id = ids ? ids[g] : g;
     // hard-call path: unweighted null model, block known to hold only 0.0 / 1.0 / 2.0, a single-pass tile class
     gd.hc = 0;
-    if (hc_possible && gd.MT <= kHcMaxMT && (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31)) {
+    if (hc_possible && gd.MT <= hc_max_mt && (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31)) {
       if (score_hc) {
         gd.hc = cov->slice_hc[g] ? 1 : 0;
       } else {
@@ -1118,8 +1161,12 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
     hipStream_t hst = (c->k2_alternate && (hc_launches++ & 1)) ? c->k2b_stream : c->k2_stream;
     Scope sc(c, 4, hst);
-    k2_launch_hc(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
-                 (long long)ld, d);
+    if (hcw)
+      k2_launch_hcw(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTileW{c->d_nulltile_w, d + 3, c->d_vq},
+                    (long long)N, (long long)ld, d);
+    else
+      k2_launch_hc(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
+                   (long long)ld, d);
     k = e;
   }
   if (split) {
@@ -1216,10 +1263,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, bs, d_desc + n_gen, (long long)N);
       if (d <= 4)
         hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
-                           (long long)N, (long long)ld, d);
+                           (long long)N, (long long)ld, d, nc.binary);
       else
         hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs,
-                           d_desc + n_gen, nd, (long long)N, (long long)ld, d);
+                           d_desc + n_gen, nd, (long long)N, (long long)ld, d, nc.binary);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
@@ -1277,7 +1324,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     c->timing.genes += n;
     c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
-      if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
+      if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + (hcw ? 4 : 2));
       c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
     }
@@ -3869,7 +3916,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     }
     if (af_out) std::memcpy(af_out, p.af.data(), afb);
   }
-  if (c->hc_enabled && !c->nc.binary) {
+  if (c->hc_enabled && (!c->nc.binary || c->d_vq)) {
     // content of the finished block (hard calls or not), classified on the io stream behind the copy / consolidation;
     // the flag comes back through a pinned ring and is read when the gene's group is launched
     hipError_t e = hipSuccess;

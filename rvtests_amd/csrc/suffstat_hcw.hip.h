@@ -1,0 +1,338 @@
+// rvtests_amd — sufficient statistics of HARD-CALL genotype blocks against a WEIGHTED (binary-trait) null model.
+//
+// Same outputs as gene_suffstat_mfma<*, weighted> (suffstat_kernels.hip.h): R = G'V[G | X | rr] with V = diag(v),
+// v_i = p_i (1 - p_i) of the logistic null model, exact column statistics, the burden sums of the collapsed genotypes.
+// The fp64 kernel is bound by the fp64 matrix pipe there (16 instructions of 64 cycles per tile per 64 samples).  For
+// hard calls the weighted Gram matrix sum_i v_i g_i g_i' goes to the int8 pipe as well:
+//   * once per null model v_i (<= 1/4) is rounded to 49 fractional bits and split into SEVEN balanced base-128 digits
+//     d_ip in [-64, 63], v_i = sum_p d_ip 128^-(p+1) (rvt_set_null; absolute error <= 2^-50 per weight, the size of the
+//     rounding of the fp64 sum it replaces); stored per group of four samples as [plane 0..7][4 bytes], so a lane's
+//     digits for the four samples of a step are 32 contiguous bytes at the same offset its genotype doubles have inside
+//     a column;
+//   * per 64-sample operand and plane the A operand is the byte-wise product d_p (x) g (|.| <= 128, built from two masks
+//     and a shift: g is 0 / 1 / 2), the B operand the packed genotypes: ONE v_mfma_i32_16x16x64_i8 per plane and tile,
+//     7 per tile against 16 fp64 instructions of four times the latency;
+//   * every plane's int32 tile is exact and is folded at once into the fp64 accumulator with its weight 2^-(7 (p + 1))
+//     (one int32 tile set in flight, not seven);
+//   * G'V[X | rr] stays on the fp64 matrix cores against the null tile [vX_0 .. vX_{d-1} | res | v | 0] (res = v rr);
+//     its v column also gives the weighted burden sums c'Vc;
+//   * column sums and the counts behind min / max are byte sums of g and g^2.
+// Structure (load ring, raw buffer loads with range checks, wave-parts, burden collapse with predicted flips) as in
+// suffstat_hc.hip.h, whose helpers it uses.
+#pragma once
+#include "suffstat_hc.hip.h"
+
+namespace rvt {
+
+constexpr int kHcwPlanes = 7;
+constexpr int kHcwMaxMT = 5;   // widest weighted hard-call class (M <= 80)
+constexpr int kHcwMaxD = 13;   // X columns + res + v share ONE 16-column tile
+
+struct NullTileW {
+  const double* base;       // [vX_0 .. vX_{d-1} | res | v | zeros], ld doubles per column
+  int cols;                 // d + 3
+  const unsigned char* vq;  // digit planes of 2 v: 8 bytes per sample (32 per 4-sample group: [plane][4]), ld * 8 bytes
+};
+
+template <int MT>
+struct HcwStep {
+  u4_t glo[MT], ghi[MT];
+  u4_t xlo, xhi;
+  u4_t dq0, dq1;  // digits of planes 0-3 / 4-7 for the lane's four samples
+};
+
+template <int MT>
+__device__ __forceinline__ void hcw_issue(HcwStep<MT>& f, const __amdgpu_buffer_rsrc_t& rg, const unsigned (&voff)[MT],
+                                          const __amdgpu_buffer_rsrc_t& rx, unsigned xoff, const __amdgpu_buffer_rsrc_t& rq,
+                                          unsigned qoff, int imm) {
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    f.glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + imm, 0, 0));
+    f.ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + imm + 16, 0, 0));
+  }
+  f.xlo = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + imm, 0, 0));
+  f.xhi = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + imm + 16, 0, 0));
+  f.dq0 = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + imm, 0, 0));
+  f.dq1 = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + imm + 16, 0, 0));
+}
+
+struct HcwBurden {
+  double a_cmc, a_zeg, a_zz;  // sum c x, sum c_zeg x, sum c_zeg^2 x over this lane's null column
+  unsigned cnt;               // #(c != 0) over the samples of this lane's row
+};
+
+// one step: fp64 tile of G'V[X | rr | v], packing, byte sums of g and g^2, burden hits, digits of the step
+template <int MT, bool MASKED>
+__device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
+                                         unsigned (&dg)[4][8], unsigned (&cs)[MT], unsigned (&cs2)[MT],
+                                         const unsigned (&fx)[MT], HcwBurden& bu, bool valid, unsigned vmask) {
+  double xv[4] = {hc_dbl(f.xlo[0], f.xlo[1]), hc_dbl(f.xlo[2], f.xlo[3]), hc_dbl(f.xhi[0], f.xhi[1]),
+                  hc_dbl(f.xhi[2], f.xhi[3])};
+  if (MASKED) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) xv[l] = valid ? xv[l] : 0.0;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    dg[T][p] = (MASKED && !valid) ? 0u : f.dq0[p];
+    dg[T][4 + p] = (MASKED && !valid) ? 0u : f.dq1[p];
+  }
+  unsigned h = 0;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    hc_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], fx[c], h, valid);
+    const unsigned p = pk[c][T];
+    cs2[c] = __builtin_amdgcn_sad_u8((p & 0x01010101u) | ((p & 0x02020202u) << 1), 0u, cs2[c]);  // g^2: 0 / 1 / 4
+  }
+  h = row16_sum(h);
+  if (MASKED) h &= vmask;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const unsigned cz = (h >> (8 * l)) & 0xffu;
+    const unsigned cc = cz ? 1u : 0u;
+    bu.cnt += cc;
+    bu.a_zeg = fma((double)cz, xv[l], bu.a_zeg);
+    bu.a_zz = fma((double)(cz * cz), xv[l], bu.a_zz);
+    bu.a_cmc = fma((double)cc, xv[l], bu.a_cmc);
+  }
+}
+
+// the weighted Gram tiles of one 64-sample operand: per plane, A = digits (x) genotypes, B = genotypes
+template <int MT>
+__device__ __forceinline__ void hcw_gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8],
+                                         d4_t (&accW)[MT * (MT + 1) / 2]) {
+  i4_t op[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
+  // One int8 instruction per (row tile, plane, column tile).  The fold of a tile into its fp64 accumulator (4 x
+  // convert + fma) is issued right AFTER the next instruction has gone to the matrix pipe, so the vector work of tile
+  // k - 1 runs while tile k is in the pipe and only two int32 tiles are live at any time.
+  int t0 = 0, tprev = -1;
+  i4_t zprev = i4_t{0, 0, 0, 0};
+  double sprev = 0.0;
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+    unsigned m1[4], m2[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      m1[s] = (pk[r][s] & 0x01010101u) * 0xFFu;                         // bytes with g = 1
+      m2[s] = (((pk[r][s] >> 1) & 0x01010101u) * 0xFFu) & 0xFEFEFEFEu;  // bytes with g = 2, without the bit a shift carries in
+    }
+#pragma unroll
+    for (int p = 0; p < kHcwPlanes; ++p) {
+      const double scale = __builtin_bit_cast(double, (unsigned long long)(1023 - 7 * (p + 1)) << 52);  // 2^-(7 (p + 1))
+      unsigned w[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned d = dg[s][p];
+        w[s] = (d & m1[s]) | ((d << 1) & m2[s]);  // d g per byte (|d| <= 64: 2 d fits a signed byte)
+      }
+      const i4_t a = i4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+#pragma unroll
+      for (int c = r; c < MT; ++c) {
+        const i4_t z = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
+        if (tprev >= 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accW[tprev][i] = fma((double)zprev[i], sprev, accW[tprev][i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        zprev = z;
+        tprev = t0 + c - r;
+        sprev = scale;
+      }
+    }
+    t0 += MT - r;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accW[tprev][i] = fma((double)zprev[i], sprev, accW[tprev][i]);
+}
+
+template <int MT, int DEPTH>
+__device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const NullTileW& nt, long long N, long long ld,
+                                                  int d) {
+  const int lane = threadIdx.x & 63;
+  const int v = lane & 15, q = lane >> 4;
+  const int wpart = blockIdx.x;
+  if (wpart >= gd.n_wparts) return;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  if (s_begin >= s_end) return;
+  const int M = gd.M;
+  auto uniform = [](const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const unsigned gbytes = (unsigned)((unsigned long long)M * (unsigned long long)ld * 8ull);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(uniform(gd.G), 0, gbytes, 0x00020000);
+  const unsigned xbytes = (unsigned)((unsigned long long)nt.cols * (unsigned long long)ld * 8ull);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uniform(nt.base), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq =
+      __builtin_amdgcn_make_buffer_rsrc(uniform(nt.vq), 0, (unsigned)((unsigned long long)ld * 8ull), 0x00020000);
+  const unsigned lane_off = (unsigned)(q * 32);
+  const unsigned col_bytes = (unsigned)((unsigned long long)ld * 8ull);
+  unsigned vbase[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    const int col = c * 16 + v;
+    vbase[c] = (col < M) ? (unsigned)col * col_bytes + lane_off : 0x80000000u;
+  }
+  const int xcol = (v <= d + 1) ? v : d + 2;  // vX_k, res, v, or the zero column
+  const unsigned xbase = (unsigned)xcol * col_bytes + lane_off;
+  unsigned fx[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) fx[c] = ((gd.pflip[c] >> v) & 1) ? 0x02020202u : 0u;
+
+  d4_t accT[MT], accW[MT * (MT + 1) / 2];
+  unsigned cs[MT], cs2[MT], pk[MT][4], dg[4][8];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    accT[c] = d4_t{0.0, 0.0, 0.0, 0.0};
+    cs[c] = cs2[c] = 0;
+  }
+#pragma unroll
+  for (int t = 0; t < MT * (MT + 1) / 2; ++t) accW[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+  HcwBurden bu{0.0, 0.0, 0.0, 0u};
+
+  long long s = s_begin;
+  const long long full = N >> 4;
+  const long long s_fast_end = (s_end < full) ? s_end : full;
+  constexpr int U = (DEPTH == 3) ? 12 : 4;  // (the host cuts the sample axis in multiples of kHcStepUnit = 12 steps)
+  const long long n_fast = (s_fast_end > s_begin) ? (s_fast_end - s_begin) / U : 0;
+  if (n_fast > 0) {
+    unsigned voff[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(s_begin * 128);
+    unsigned xoff = xbase + (unsigned)(s_begin * 128);
+    unsigned qoff = lane_off + (unsigned)(s_begin * 128);
+    HcwStep<MT> f[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH - 1; ++u) hcw_issue<MT>(f[u], rg, voff, rx, xoff, rq, qoff, u * 128);
+    for (long long it = 0; it < n_fast; ++it) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        hcw_issue<MT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, rq, qoff, (u + DEPTH - 1) * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu);
+        if ((u & 3) == 3) hcw_gram<MT>(pk, dg, accW);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int c = 0; c < MT; ++c) voff[c] += U * 128;
+      xoff += U * 128;
+      qoff += U * 128;
+    }
+    s += n_fast * U;
+  }
+  while (s < s_end) {  // remainder: groups of 4 steps, each loaded from a clamped position and masked
+#pragma unroll
+    for (int c = 0; c < MT; ++c) pk[c][0] = pk[c][1] = pk[c][2] = pk[c][3] = 0u;
+    auto one = [&](const int T, long long su) {
+      const bool valid = su < s_end;
+      const long long sc = valid ? su : s_end - 1;
+      unsigned voff[MT];
+#pragma unroll
+      for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(sc * 128);
+      HcwStep<MT> f;
+      hcw_issue<MT>(f, rg, voff, rx, xbase + (unsigned)(sc * 128), rq, lane_off + (unsigned)(sc * 128), 0);
+      unsigned vmask = 0u;
+      const long long smp = sc * 16 + q * 4;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) vmask |= (valid && smp + l < N) ? (0xffu << (8 * l)) : 0u;
+      hcw_step<MT, true>(f, T, accT, pk, dg, cs, cs2, fx, bu, valid, vmask);
+    };
+    one(0, s);
+    one(1, s + 1);
+    one(2, s + 2);
+    one(3, s + 3);
+    hcw_gram<MT>(pk, dg, accW);
+    s += 4;
+  }
+
+  // ---- partial tiles: element (row, col) -> parts[row * Cp + col], the layout gene_assemble reduces ---------------
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+  const int Cp = gd.Cp;
+  {
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < MT; ++r)
+#pragma unroll
+      for (int c = r; c < MT; ++c, ++t) {
+        const int col = c * 16 + v;
+        if (col < M) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = accW[t][i];  // i32 map
+        }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r * 16 + q + 4 * i;  // f64 C/D map
+      if (M + v < Cp) out[(long long)row * Cp + M + v] = (v <= d) ? accT[r][i] : 0.0;  // (the v column is not part of R)
+      if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
+    }
+  }
+  // ---- column sum / min / max from the byte sums of g and g^2 ------------------------------------------------------
+  long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
+  if (cnt_w < 0) cnt_w = 0;
+  double* cst = gd.colstat + (long long)wpart * 3 * gd.Mp;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    unsigned sc = cs[c], sq = cs2[c];
+    sc += __shfl_xor(sc, 16, 64);
+    sq += __shfl_xor(sq, 16, 64);
+    sc += __shfl_xor(sc, 32, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    const long long sm = (long long)sc, n2 = ((long long)sq - sm) / 2, n1 = 2 * sm - (long long)sq, n0 = cnt_w - n1 - n2;
+    const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+    const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+    if (lane < 16) {
+      cst[c * 16 + lane] = (double)sm;
+      cst[gd.Mp + c * 16 + lane] = mn;
+      cst[2 * gd.Mp + c * 16 + lane] = mx;
+    }
+  }
+  // ---- burden partial sums: [test][U, c'Vc, count, c'VX_0 .. c'VX_{d-1}], test 0 = CMC, 1 = Zeggini ------------------
+  if (gd.bparts) {
+    double ac = bu.a_cmc, az = bu.a_zeg, azz = bu.a_zz;
+    ac += __shfl_xor(ac, 16, 64);
+    az += __shfl_xor(az, 16, 64);
+    azz += __shfl_xor(azz, 16, 64);
+    ac += __shfl_xor(ac, 32, 64);
+    az += __shfl_xor(az, 32, 64);
+    azz += __shfl_xor(azz, 32, 64);
+    unsigned cn = bu.cnt;
+    cn += __shfl_xor(cn, 16, 64);
+    cn += __shfl_xor(cn, 32, 64);
+    const int rl = 3 + d;
+    double* bp = gd.bparts + (long long)wpart * 2 * rl;
+    if (lane <= d) {  // lane k < d: column v X_k; lane d: res
+      const int k = (lane == d) ? 0 : 3 + lane;
+      bp[k] = ac;
+      bp[rl + k] = az;
+    }
+    if (lane == d + 1) {  // the v column: c'Vc (CMC: c^2 = c)
+      bp[1] = ac;
+      bp[rl + 1] = azz;
+    }
+    if (lane == 0) {
+      bp[2] = (double)cn;
+      bp[rl + 2] = (double)cn;
+    }
+  }
+}
+
+template <int MT, int DEPTH, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void gene_suffstat_hcw(const GeneDesc* __restrict__ genes, NullTileW nt,
+                                                               long long N, long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  if (gd.MT != MT) return;
+  suffstat_hcw_body<MT, DEPTH>(gd, nt, N, ld, d);
+}
+
+}  // namespace rvt

@@ -123,10 +123,92 @@ def test_classification(engine):
     assert abs(out[0].skat_Q - a.Q) <= 1e-10 * a.Q
 
 
-def test_binary_trait_never_takes_the_hardcall_path(engine):
+@pytest.mark.parametrize("N,d", [(3000, 2), (4099, 1), (10007, 4)])
+def test_binary_trait_weighted_hardcall_path(engine, N, d):
+    """Binary trait: hard-call blocks of up to 80 variants run on the weighted int8 kernel (suffstat_hcw.hip.h: digit
+    planes of v = p (1 - p)); wider ones stay on the fp64 kernel.  Both against the general path and the oracle."""
+    Ms = (1, 7, 16, 17, 30, 33, 48, 50, 64, 65, 80, 81, 96)
+    genes = [_hard_gene(N, M, seed=19 * M + d, flip_col=(2 if M % 3 == 0 else None),
+                        twos_col=(5 if M % 4 == 1 else None), zero_col=(1 if M % 5 == 2 else None)) for M in Ms]
+    eff = 0.5 * genes[4][0][:, :3].sum(1)
+    X, y, res, v, s2 = synth.make_null(N, d, 1, seed=12, G_effect=eff)
+    engine.set_null(1, X, res, v, s2)
+    hc, tm_hc = _run(engine, genes, True)
+    gen, tm_gen = _run(engine, genes, False)
+    assert tm_hc.genes == len(genes) and tm_hc.genes_hard_call == sum(1 for M in Ms if M <= 80)
+    assert tm_gen.genes_hard_call == 0
+    for a, b, (G, af) in zip(hc, gen, genes):
+        assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref and a.status == b.status
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            assert abs(x - y_) <= 1e-9 * abs(y_) + 1e-300, (G.shape[1], f, x, y_)
+        rc, o = orc.skat(G, af, X, res, v, 1)
+        assert a.n_poly == o.n_poly
+        if o.n_poly:
+            assert abs(a.skat_Q - o.Q) <= 1e-10 * o.Q and abs(a.skat_p - o.pvalue) <= 1e-6 * o.pvalue + 1e-14
+        rc2, so = orc.skato(G, af, X, res, v, 1)
+        if rc2 == 0 and o.n_poly:
+            assert abs(a.skato_p - so.pvalue) <= 1e-6 * so.pvalue + 5e-13
+        for which, ok, p in ((0, a.cmc_ok, a.cmc_p), (1, a.zeg_ok, a.zeg_p)):
+            rc3, c = orc.burden(G, X, y, 1, which)
+            if rc3 == 0:
+                assert ok and abs(p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
+
+
+def test_binary_trait_weights_at_the_digit_range_limits(engine):
+    """v = 1/4 exactly (intercept-only model, balanced cases) is the largest weight the digit planes must hold; weights
+    that are tiny or have all 49 fractional bits set exercise the balanced-digit carries."""
+    N = 4000
+    G, af = _hard_gene(N, 40, seed=31, flip_col=3)
+    X = np.ones((N, 1), order="F")
+    y = (np.arange(N) % 2).astype(np.float64)
+    p0 = np.full(N, 0.5)
+    res, v = y - p0, p0 * (1 - p0)
+    engine.set_null(1, X, res, v, 1.0)
+    (a,), tm = _run(engine, [(G, af)], True)
+    (b,), _ = _run(engine, [(G, af)], False)
+    assert tm.genes_hard_call == 1
+    for f in FIELDS:
+        assert abs(getattr(a, f) - getattr(b, f)) <= 1e-9 * abs(getattr(b, f)) + 1e-300, f
+    rng = np.random.default_rng(5)
+    pr = np.concatenate([10.0 ** rng.uniform(-9, -1, N // 2), 1.0 - 10.0 ** rng.uniform(-9, -1, N - N // 2)])
+    v2 = pr * (1 - pr)
+    v2[:8] = [0.25, 0.25 - 2.0 ** -49, 2.0 ** -49, 2.0 ** -50, 2.0 ** -40, 127.0 / 512, 63.0 / 128 / 2, 1e-300]
+    X2, y2, res2, _, s2 = synth.make_null(N, 2, 1, seed=9)
+    engine.set_null(1, X2, res2, v2, 1.0)
+    (a,), tm = _run(engine, [(G, af)], True)
+    (b,), _ = _run(engine, [(G, af)], False)
+    assert tm.genes_hard_call == 1
+    for f in FIELDS:
+        assert abs(getattr(a, f) - getattr(b, f)) <= 1e-8 * abs(getattr(b, f)) + 1e-300, f
+
+
+def test_binary_trait_burden_fallback(engine):
+    N, d = 5003, 2
+    g_ones = _hard_gene(N, 20, seed=1, ones_col=4)
+    g_flip = _hard_gene(N, 35, seed=2, flip_col=7)
+    wrong_af = g_flip[1].copy()
+    wrong_af[7] = 0.01
+    wrong_af[3] = 0.9
+    genes = [g_ones, (g_flip[0], wrong_af)]
+    X, y, res, v, s2 = synth.make_null(N, d, 1, seed=8, G_effect=0.4 * g_ones[0][:, :4].sum(1))
+    engine.set_null(1, X, res, v, s2)
+    out, tm = _run(engine, genes, True)
+    assert tm.genes_hard_call == 2
+    for r, (G, af) in zip(out, genes):
+        for which, ok, stat, p in ((0, r.cmc_ok, r.cmc_stat, r.cmc_p), (1, r.zeg_ok, r.zeg_stat, r.zeg_p)):
+            rc, b = orc.burden(G, X, y, 1, which)
+            assert ok == (rc == 0)
+            if ok:
+                assert abs(stat - b.stat) <= 1e-9 * b.stat + 1e-13 and abs(p - b.pvalue) <= 1e-6 * b.pvalue + 1e-14
+
+
+def test_binary_trait_with_a_weight_out_of_range_stays_on_fp64(engine):
     N = 3000
     G, af = _hard_gene(N, 30, seed=11)
     X, y, res, v, s2 = synth.make_null(N, 2, 1, seed=12)
+    v = v.copy()
+    v[5] = 0.6                                  # not a logistic weight: no digit planes, general kernel
     engine.set_null(1, X, res, v, s2)
     out, tm = _run(engine, [(G, af)], True)
     assert tm.genes_hard_call == 0
