@@ -433,6 +433,7 @@ void choose_split(int64_t ld, int n_genes, int* n_wparts, int* steps_per) {
   int64_t spw = (nsteps + target - 1) / target;
   if (spw < 64) spw = 64;
   spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;  // whole ring iterations of the hard-call kernel
+  if (spw > kHcwMaxSteps) spw = kHcwMaxSteps;                   // (int32 range of the weighted hard-call kernel's tiles)
   int64_t nw = (nsteps + spw - 1) / spw;
   if (nw < 1) nw = 1;
   *n_wparts = (int)nw;
@@ -695,8 +696,8 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
     HIP_TRY(c, hipMemcpy(c->d_rr, rr.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
   }
   if (nc.binary && c->hc_enabled && d <= kHcwMaxD) {
-    // weighted hard-call kernel (suffstat_hcw.hip.h): v = p (1 - p) <= 1/4 rounded to 49 fractional bits and split into
-    // seven balanced base-128 digits (value = sum_p digit_p 128^-(p+1), digits in [-64, 63]: reaches 0.496), stored per
+    // weighted hard-call kernel (suffstat_hcw.hip.h): v = p (1 - p) <= 1/4 rounded to 7 * kHcwPlanes fractional bits and split
+    // into that many balanced base-128 digits (value = sum_p digit_p 128^-(p+1), digits in [-64, 63]: reaches 0.496), stored per
     // four samples as [plane 0..7][4 bytes]; a model with a weight outside [0, 0.49] stays on the fp64 kernel
     bool ok = true;
     for (int64_t i = 0; i < N && ok; ++i) ok = v[i] >= 0.0 && v[i] <= 0.49;

@@ -4,16 +4,15 @@
 // v_i = p_i (1 - p_i) of the logistic null model, exact column statistics, the burden sums of the collapsed genotypes.
 // The fp64 kernel is bound by the fp64 matrix pipe there (16 instructions of 64 cycles per tile per 64 samples).  For
 // hard calls the weighted Gram matrix sum_i v_i g_i g_i' goes to the int8 pipe as well:
-//   * once per null model v_i (<= 1/4) is rounded to 49 fractional bits and split into SEVEN balanced base-128 digits
-//     d_ip in [-64, 63], v_i = sum_p d_ip 128^-(p+1) (rvt_set_null; absolute error <= 2^-50 per weight, the size of the
-//     rounding of the fp64 sum it replaces); stored per group of four samples as [plane 0..7][4 bytes], so a lane's
-//     digits for the four samples of a step are 32 contiguous bytes at the same offset its genotype doubles have inside
-//     a column;
-//   * per 64-sample operand and plane the A operand is the byte-wise product d_p (x) g (|.| <= 128, built from two masks
-//     and a shift: g is 0 / 1 / 2), the B operand the packed genotypes: ONE v_mfma_i32_16x16x64_i8 per plane and tile,
-//     7 per tile against 16 fp64 instructions of four times the latency;
-//   * every plane's int32 tile is exact and is folded at once into the fp64 accumulator with its weight 2^-(7 (p + 1))
-//     (one int32 tile set in flight, not seven);
+//   * once per null model v_i (<= 1/4) is rounded to 42 fractional bits and split into SIX balanced base-128 digits
+//     d_ip in [-64, 63], v_i = sum_p d_ip 128^-(p+1) (rvt_set_null; absolute error <= 2^-43 per weight, unbiased — the
+//     size of the rounding the fp64 sums of 10^5 terms carry); stored per group of four samples as [plane 0..7][4 bytes],
+//     so a lane's digits for the four samples of a step are 32 contiguous bytes at the same offset its genotype doubles
+//     have inside a column;
+//   * per 64-sample operand and plane the A operand is the byte-wise product d_p (x) g (|.| <= 128, built from two masks:
+//     g is 0 / 1 / 2), the B operand the packed genotypes: ONE v_mfma_i32_16x16x64_i8 (16 cycles) per plane and tile,
+//     6 per tile against 16 fp64 instructions of 64 cycles;
+//   * the six plane products of a tile are combined exactly in int32 (HcwAcc below);
 //   * G'V[X | rr] stays on the fp64 matrix cores against the null tile [vX_0 .. vX_{d-1} | res | v | 0] (res = v rr);
 //     its v column also gives the weighted burden sums c'Vc;
 //   * column sums and the counts behind min / max are byte sums of g and g^2.
@@ -24,7 +23,9 @@
 
 namespace rvt {
 
-constexpr int kHcwPlanes = 7;
+constexpr int kHcwPlanes = 6;
+constexpr int kHcwPairs = 3;
+constexpr int kHcwMaxSteps = 3072;  // 16-sample steps per wave-part: keeps the int32 pair tiles exact (see above)
 constexpr int kHcwMaxMT = 5;   // widest weighted hard-call class (M <= 80)
 constexpr int kHcwMaxD = 13;   // X columns + res + v share ONE 16-column tile
 
@@ -61,7 +62,31 @@ struct HcwBurden {
   unsigned cnt;               // #(c != 0) over the samples of this lane's row
 };
 
-// one step: fp64 tile of G'V[X | rr | v], packing, byte sums of g and g^2, burden hits, digits of the step
+// one tile row of one step: fp64 tile of G'V[X | rr | v], packing, byte sums of g and g^2, burden hits
+template <bool MASKED>
+__device__ __forceinline__ void hcw_row(const u4_t& glo, const u4_t& ghi, const double (&xv)[4], d4_t& accT, unsigned& pk,
+                                        unsigned& cs, unsigned& cs2, unsigned fx, unsigned& h, bool valid) {
+  hc_row<MASKED>(glo, ghi, xv, accT, pk, cs, fx, h, valid);
+  cs2 = __builtin_amdgcn_sad_u8((pk & 0x01010101u) | ((pk & 0x02020202u) << 1), 0u, cs2);  // g^2: 0 / 1 / 4
+}
+
+// end of a step: the per-sample variant counts of this lane's row and the burden sums
+template <bool MASKED>
+__device__ __forceinline__ void hcw_finish(unsigned h, const double (&xv)[4], HcwBurden& bu, unsigned vmask) {
+  h = row16_sum(h);
+  if (MASKED) h &= vmask;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const unsigned cz = (h >> (8 * l)) & 0xffu;
+    const unsigned cc = cz ? 1u : 0u;
+    bu.cnt += cc;
+    bu.a_zeg = fma((double)cz, xv[l], bu.a_zeg);
+    bu.a_zz = fma((double)(cz * cz), xv[l], bu.a_zz);
+    bu.a_cmc = fma((double)cc, xv[l], bu.a_cmc);
+  }
+}
+
+// One step from a step buffer.  T = position of the step in its group of 4.
 template <int MT, bool MASKED>
 __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
                                          unsigned (&dg)[4][8], unsigned (&cs)[MT], unsigned (&cs2)[MT],
@@ -79,73 +104,144 @@ __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t
   }
   unsigned h = 0;
 #pragma unroll
-  for (int c = 0; c < MT; ++c) {
-    hc_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], fx[c], h, valid);
-    const unsigned p = pk[c][T];
-    cs2[c] = __builtin_amdgcn_sad_u8((p & 0x01010101u) | ((p & 0x02020202u) << 1), 0u, cs2[c]);  // g^2: 0 / 1 / 4
-  }
-  h = row16_sum(h);
-  if (MASKED) h &= vmask;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const unsigned cz = (h >> (8 * l)) & 0xffu;
-    const unsigned cc = cz ? 1u : 0u;
-    bu.cnt += cc;
-    bu.a_zeg = fma((double)cz, xv[l], bu.a_zeg);
-    bu.a_zz = fma((double)(cz * cz), xv[l], bu.a_zz);
-    bu.a_cmc = fma((double)cc, xv[l], bu.a_cmc);
-  }
+  for (int c = 0; c < MT; ++c) hcw_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], cs2[c], fx[c], h, valid);
+  hcw_finish<MASKED>(h, xv, bu, vmask);
 }
 
-// the weighted Gram tiles of one 64-sample operand: per plane, A = digits (x) genotypes, B = genotypes
+__device__ __forceinline__ double hcw_pow2(int e) { return __builtin_bit_cast(double, (unsigned long long)(1023 + e) << 52); }
+
+// A operands of one row tile: byte-wise d g from the digits d, their doubles d2 and the two genotype masks of the row
 template <int MT>
-__device__ __forceinline__ void hcw_gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8],
-                                         d4_t (&accW)[MT * (MT + 1) / 2]) {
-  i4_t op[MT];
-#pragma unroll
-  for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
-  // One int8 instruction per (row tile, plane, column tile).  The fold of a tile into its fp64 accumulator (4 x
-  // convert + fma) is issued right AFTER the next instruction has gone to the matrix pipe, so the vector work of tile
-  // k - 1 runs while tile k is in the pipe and only two int32 tiles are live at any time.
-  int t0 = 0, tprev = -1;
-  i4_t zprev = i4_t{0, 0, 0, 0};
-  double sprev = 0.0;
-#pragma unroll
-  for (int r = 0; r < MT; ++r) {
-    unsigned m1[4], m2[4];
+struct HcwRow {
+  unsigned m1[4], m2[4];
+  __device__ __forceinline__ explicit HcwRow(const unsigned (&pkr)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      m1[s] = (pk[r][s] & 0x01010101u) * 0xFFu;                         // bytes with g = 1
-      m2[s] = (((pk[r][s] >> 1) & 0x01010101u) * 0xFFu) & 0xFEFEFEFEu;  // bytes with g = 2, without the bit a shift carries in
+      const unsigned b1 = pkr[s] & 0x01010101u, b2 = (pkr[s] >> 1) & 0x01010101u;
+      m1[s] = (b1 << 8) - b1;  // 0xFF in the bytes with g = 1
+      m2[s] = (b2 << 8) - b2;  // 0xFF in the bytes with g = 2
     }
-#pragma unroll
-    for (int p = 0; p < kHcwPlanes; ++p) {
-      const double scale = __builtin_bit_cast(double, (unsigned long long)(1023 - 7 * (p + 1)) << 52);  // 2^-(7 (p + 1))
-      unsigned w[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned d = dg[s][p];
-        w[s] = (d & m1[s]) | ((d << 1) & m2[s]);  // d g per byte (|d| <= 64: 2 d fits a signed byte)
-      }
-      const i4_t a = i4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-#pragma unroll
-      for (int c = r; c < MT; ++c) {
-        const i4_t z = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
-        if (tprev >= 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) accW[tprev][i] = fma((double)zprev[i], sprev, accW[tprev][i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        zprev = z;
-        tprev = t0 + c - r;
-        sprev = scale;
-      }
-    }
-    t0 += MT - r;
   }
+  __device__ __forceinline__ i4_t aop(const unsigned (&dg)[4][8], const unsigned (&d2)[4][kHcwPlanes], int p) const {
+    unsigned w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accW[tprev][i] = fma((double)zprev[i], sprev, accW[tprev][i]);
+    for (int s = 0; s < 4; ++s) w[s] = (dg[s][p] & m1[s]) | (d2[s][p] & m2[s]);
+    return i4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+  }
+};
+
+__device__ __forceinline__ void hcw_doubles(const unsigned (&dg)[4][8], unsigned (&d2)[4][kHcwPlanes]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int p = 0; p < kHcwPlanes; ++p) d2[s][p] = (dg[s][p] << 1) & 0xFEFEFEFEu;  // 2 d per byte (|d| <= 64)
 }
+
+// The weighted Gram tiles sum_i v_i g_ri g_ci.  Two ways to combine the six plane products of a tile:
+//   PAIRS   (MT <= 4)  planes are accumulated in pairs in exact int32 tiles that live across the whole wave-part: the
+//           even plane's fresh tile is shifted left by 7 bits and added to the pair's accumulator (one v_lshl_add_u32
+//           per element), which is the C operand of the odd plane's instruction.  |pair sum| <= 2^21 + 2^14 per operand,
+//           so a wave-part may hold up to 1016 operands (the host cuts at kHcwMaxSteps = 3072 steps); the three pair
+//           tiles are combined in fp64 once, at the end.  12 vector instructions per tile and operand.
+//   TRIPLES (MT = 5: 3 x 15 int32 tiles do not fit the register file beside the load ring) three planes are chained
+//           through the C operand (shift, instruction, shift, instruction: |.| < 2^29) and each triple is folded into
+//           ONE fp64 tile per Gram tile (convert + fma).
+template <int MT, bool TRIPLES>
+struct HcwAcc;
+
+template <int MT>
+struct HcwAcc<MT, false> {
+  static constexpr int T = MT * (MT + 1) / 2;
+  i4_t p[kHcwPairs][T];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < kHcwPairs; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t) p[j][t] = i4_t{0, 0, 0, 0};
+  }
+  __device__ __forceinline__ double value(int t, int i) const {  // pair j: weight 128^-(2j+2)
+    double x = 0.0;
+#pragma unroll
+    for (int j = kHcwPairs - 1; j >= 0; --j) x = fma((double)p[j][t][i], hcw_pow2(-14 * (j + 1)), x);
+    return x;
+  }
+  __device__ __forceinline__ void gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8]) {
+    i4_t op[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
+    unsigned d2[4][kHcwPlanes];
+    hcw_doubles(dg, d2);
+    int t0 = 0;
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+      const HcwRow<MT> row(pk[r]);
+#pragma unroll
+      for (int j = 0; j < kHcwPairs; ++j) {
+        const i4_t a0 = row.aop(dg, d2, 2 * j), a1 = row.aop(dg, d2, 2 * j + 1);
+        i4_t z[MT];
+#pragma unroll
+        for (int c = r; c < MT; ++c) z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int c = r; c < MT; ++c) {
+          i4_t acc = p[j][t0 + c - r];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = (int)(((unsigned)z[c][i] << 7) + (unsigned)acc[i]);
+          p[j][t0 + c - r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, op[c], acc, 0, 0, 0);
+        }
+      }
+      t0 += MT - r;
+      __builtin_amdgcn_sched_barrier(0);  // (row by row: keeps the live set to one row's operands)
+    }
+  }
+};
+
+template <int MT>
+struct HcwAcc<MT, true> {
+  static constexpr int T = MT * (MT + 1) / 2;
+  static_assert(kHcwPlanes % 3 == 0, "triples");
+  d4_t w[T];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < T; ++t) w[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  __device__ __forceinline__ double value(int t, int i) const { return w[t][i]; }
+  __device__ __forceinline__ void gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8]) {
+    i4_t op[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
+    unsigned d2[4][kHcwPlanes];
+    hcw_doubles(dg, d2);
+    int t0 = 0;
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+      const HcwRow<MT> row(pk[r]);
+#pragma unroll
+      for (int j = 0; j < kHcwPlanes / 3; ++j) {
+        const i4_t a0 = row.aop(dg, d2, 3 * j), a1 = row.aop(dg, d2, 3 * j + 1), a2 = row.aop(dg, d2, 3 * j + 2);
+        i4_t z[MT];
+#pragma unroll
+        for (int c = r; c < MT; ++c) z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int c = r; c < MT; ++c) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[c][i] = (int)((unsigned)z[c][i] << 7);
+          z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, op[c], z[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = r; c < MT; ++c) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[c][i] = (int)((unsigned)z[c][i] << 7);
+          z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, op[c], z[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = r; c < MT; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[t0 + c - r][i] = fma((double)z[c][i], hcw_pow2(-21 * (j + 1)), w[t0 + c - r][i]);
+      }
+      t0 += MT - r;
+    }
+  }
+};
 
 template <int MT, int DEPTH>
 __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const NullTileW& nt, long long N, long long ld,
@@ -186,15 +282,16 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
 #pragma unroll
   for (int c = 0; c < MT; ++c) fx[c] = ((gd.pflip[c] >> v) & 1) ? 0x02020202u : 0u;
 
-  d4_t accT[MT], accW[MT * (MT + 1) / 2];
+  d4_t accT[MT];
+  constexpr bool kTriples = MT >= 5;
+  HcwAcc<MT, kTriples> acc;
   unsigned cs[MT], cs2[MT], pk[MT][4], dg[4][8];
 #pragma unroll
   for (int c = 0; c < MT; ++c) {
     accT[c] = d4_t{0.0, 0.0, 0.0, 0.0};
     cs[c] = cs2[c] = 0;
   }
-#pragma unroll
-  for (int t = 0; t < MT * (MT + 1) / 2; ++t) accW[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+  acc.init();
   HcwBurden bu{0.0, 0.0, 0.0, 0u};
 
   long long s = s_begin;
@@ -202,7 +299,62 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
   const long long s_fast_end = (s_end < full) ? s_end : full;
   constexpr int U = (DEPTH == 3) ? 12 : 4;  // (the host cuts the sample axis in multiples of kHcStepUnit = 12 steps)
   const long long n_fast = (s_fast_end > s_begin) ? (s_fast_end - s_begin) / U : 0;
-  if (n_fast > 0) {
+  if constexpr (DEPTH == 1) {
+   if (n_fast > 0) {
+    // Rolling refill (as suffstat_hc_body, DEPTH = 1): ONE genotype step buffer; as soon as a tile row of step s has
+    // been consumed its registers are the destination of the same row of step s + 1.  The null-model tile and the
+    // digits are double-buffered.
+    unsigned voff[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(s_begin * 128);
+    unsigned xoff = xbase + (unsigned)(s_begin * 128);
+    unsigned qoff = lane_off + (unsigned)(s_begin * 128);
+    u4_t glo[MT], ghi[MT], xlo[2], xhi[2], dq0[2], dq1[2];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+      glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c], 0, 0));
+      ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + 16, 0, 0));
+    }
+    xlo[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, 0, 0));
+    xhi[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + 16, 0, 0));
+    dq0[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff, 0, 0));
+    dq1[0] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + 16, 0, 0));
+    for (long long it = 0; it < n_fast; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nb = (u + 1) & 1, cb = u & 1;
+        xlo[nb] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (u + 1) * 128, 0, 0));
+        xhi[nb] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (u + 1) * 128 + 16, 0, 0));
+        dq0[nb] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + (u + 1) * 128, 0, 0));
+        dq1[nb] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + (u + 1) * 128 + 16, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const double xv[4] = {hc_dbl(xlo[cb][0], xlo[cb][1]), hc_dbl(xlo[cb][2], xlo[cb][3]),
+                              hc_dbl(xhi[cb][0], xhi[cb][1]), hc_dbl(xhi[cb][2], xhi[cb][3])};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          dg[u][p] = dq0[cb][p];
+          dg[u][4 + p] = dq1[cb][p];
+        }
+        unsigned h = 0;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+          hcw_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], cs2[c], fx[c], h, true);
+          glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128, 0, 0));
+          ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128 + 16, 0, 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        hcw_finish<false>(h, xv, bu, 0xffffffffu);
+        if (u == 3) acc.gram(pk, dg);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int c = 0; c < MT; ++c) voff[c] += 4 * 128;
+      xoff += 4 * 128;
+      qoff += 4 * 128;
+    }
+    s += n_fast * U;
+   }
+  } else if (n_fast > 0) {
     unsigned voff[MT];
 #pragma unroll
     for (int c = 0; c < MT; ++c) voff[c] = vbase[c] + (unsigned)(s_begin * 128);
@@ -217,8 +369,9 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         hcw_issue<MT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, rq, qoff, (u + DEPTH - 1) * 128);
         __builtin_amdgcn_sched_barrier(0);
         hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu);
-        if ((u & 3) == 3) hcw_gram<MT>(pk, dg, accW);
-        __builtin_amdgcn_sched_barrier(0);
+        if ((u & 3) == 3) acc.gram(pk, dg);
+        if constexpr (!kTriples) __builtin_amdgcn_sched_barrier(0);  // (MT = 5 measured faster with the operand's
+                                                                     // instructions free to mix with the next step's)
       }
 #pragma unroll
       for (int c = 0; c < MT; ++c) voff[c] += U * 128;
@@ -248,7 +401,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
     one(1, s + 1);
     one(2, s + 2);
     one(3, s + 3);
-    hcw_gram<MT>(pk, dg, accW);
+    acc.gram(pk, dg);
     s += 4;
   }
 
@@ -264,7 +417,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         const int col = c * 16 + v;
         if (col < M) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = accW[t][i];  // i32 map
+          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = acc.value(t, i);  // i32 map
         }
       }
   }

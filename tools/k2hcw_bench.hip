@@ -1,0 +1,127 @@
+// tools/k2hcw_bench.hip — micro-benchmark of the weighted hard-call sufficient-statistics kernel
+// (rvtests_amd/csrc/suffstat_hcw.hip.h) outside the engine: N = 200 000, 64 genes per tile class, candidate
+// (ring depth, waves per SIMD) configurations; algorithmic TB/s (8 N M + 8 N (d + 4) bytes per gene).
+// Results are checked by the engine's tests (tests/test_gpu_hardcall.py), not here.
+// build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/k2hcw_bench.hip -o tools/k2hcw_bench
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../rvtests_amd/csrc/suffstat_hcw.hip.h"
+
+using namespace rvt;
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                      \
+    }                                                                               \
+  } while (0)
+
+__device__ __host__ inline unsigned long long mix(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void fill_G(double* G, long long total, unsigned long long seed) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long h = mix(seed ^ (unsigned long long)idx * 0xD1B54A32D192ED03ull);
+    const double a = (double)(h >> 40) * (1.0 / 16777216.0), b = (double)((h >> 16) & 0xffffff) * (1.0 / 16777216.0);
+    G[idx] = (a < 0.02 ? 1.0 : 0.0) + (b < 0.02 ? 1.0 : 0.0);
+  }
+}
+__global__ void fill_bytes(unsigned* p, long long n, unsigned long long seed) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
+    p[idx] = (unsigned)mix(seed + idx) & 0x3f3f3f3fu;
+}
+__global__ void fill_null(double* T, long long total, unsigned long long seed) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    T[idx] = (double)(mix(seed + idx) >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+
+typedef void (*hcw_kernel_t)(const GeneDesc*, NullTileW, long long, long long, int);
+struct Cfg {
+  int MT, depth, waves;
+  hcw_kernel_t k;
+};
+#define CFG(mt, dp, w) {mt, dp, w, gene_suffstat_hcw<mt, dp, w>}
+static const Cfg kCfgs[] = {
+#ifdef HCW_CFGS
+    HCW_CFGS
+#else
+    CFG(1, 2, 3), CFG(2, 2, 2), CFG(2, 3, 1), CFG(3, 2, 1), CFG(3, 3, 1), CFG(4, 2, 1), CFG(4, 1, 1), CFG(5, 2, 1), CFG(5, 1, 1),
+#endif
+};
+
+int main(int argc, char** argv) {
+  CK(hipSetDevice(0));
+  const long long N = 200000, ld = (N + 15) / 16 * 16;
+  const int d = 3;
+  const long long nsteps = ld >> 4;
+  long long spw = (nsteps + 63) / 64;
+  spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;
+  const int nw = (int)((nsteps + spw - 1) / spw);
+  double* dT;
+  unsigned char* dq;
+  CK(hipMalloc(&dT, sizeof(double) * ld * (d + 3)));
+  CK(hipMalloc(&dq, ld * 8));
+  hipLaunchKernelGGL(fill_null, dim3(1024), dim3(256), 0, 0, dT, ld * (d + 3), 99ull);
+  hipLaunchKernelGGL(fill_bytes, dim3(1024), dim3(256), 0, 0, (unsigned*)dq, ld * 2, 5ull);
+  NullTileW nt{dT, d + 3, dq};
+  const int Ms[] = {12, 28, 44, 60, 76};
+  const int ngenes = 128;
+  for (int M : Ms) {
+    const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CT;
+    double* dG;
+    const size_t gstride = (size_t)ld * M;
+    CK(hipMalloc(&dG, sizeof(double) * gstride * ngenes));
+    hipLaunchKernelGGL(fill_G, dim3(4096), dim3(256), 0, 0, dG, (long long)(gstride * ngenes), 7ull);
+    double *parts, *colstat, *bparts;
+    CK(hipMalloc(&parts, sizeof(double) * (size_t)ngenes * nw * Mp * Cp));
+    CK(hipMalloc(&colstat, sizeof(double) * (size_t)ngenes * nw * 3 * Mp));
+    CK(hipMalloc(&bparts, sizeof(double) * (size_t)ngenes * nw * 2 * (3 + d)));
+    std::vector<GeneDesc> gds(ngenes);
+    for (int g = 0; g < ngenes; ++g) {
+      GeneDesc& gd = gds[g];
+      memset(&gd, 0, sizeof(gd));
+      gd.G = dG + gstride * g;
+      gd.M = M; gd.MT = MT; gd.CT = CT; gd.Mp = Mp; gd.Cp = Cp;
+      gd.n_wparts = nw; gd.steps_per_wpart = (int)spw;
+      gd.parts = parts + (size_t)g * nw * Mp * Cp;
+      gd.colstat = colstat + (size_t)g * nw * 3 * Mp;
+      gd.bparts = bparts + (size_t)g * nw * 2 * (3 + d);
+      gd.n_bparts = nw; gd.hc = 1;
+    }
+    GeneDesc* dgd;
+    CK(hipMalloc(&dgd, sizeof(GeneDesc) * ngenes));
+    CK(hipMemcpy(dgd, gds.data(), sizeof(GeneDesc) * ngenes, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (const Cfg& cf : kCfgs) {
+      if (cf.MT != MT) continue;
+      auto launch = [&]() { hipLaunchKernelGGL(cf.k, dim3(nw, ngenes), dim3(64), 0, 0, dgd, nt, N, ld, d); };
+      launch();
+      CK(hipDeviceSynchronize());
+      const int reps = 5;
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) launch();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double bytes = (8.0 * N * M + 8.0 * N * (d + 4)) * ngenes * reps;
+      printf("bench M=%d MT=%d depth=%d waves=%d: %.3f ms per %d genes, %.2f TB/s algorithmic\n", M, MT, cf.depth, cf.waves,
+             ms / reps, ngenes, bytes / (ms * 1e-3) / 1e12);
+    }
+    CK(hipFree(dG)); CK(hipFree(parts)); CK(hipFree(colstat)); CK(hipFree(bparts)); CK(hipFree(dgd));
+  }
+  return 0;
+}
