@@ -392,7 +392,7 @@ def main():
         # the few blocks with imputed means take the general fp64 kernel gene_suffstat_mfma, which runs BESIDE it on
         # a second stream — its numbers are reported separately (an overlapped kernel's own duration is not chip time).
         if tm.n_suffstat_hc_launches > 0:
-            k2_name = "gene_suffstat_hc"
+            k2_name = "gene_suffstat_hcw" if binary else "gene_suffstat_hc"   # (weighted variant for a binary trait)
             n_l, ms_l, by_l = tm.n_suffstat_hc_launches, tm.ms_suffstat_hc, tm.alg_bytes_hc
         else:
             k2_name = "gene_suffstat_mfma"
@@ -412,7 +412,7 @@ def main():
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            k2 = pmc["kernels"].get("suffstat_hc" if k2_name == "gene_suffstat_hc" else "suffstat")
+            k2 = pmc["kernels"].get("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat")
             if pmc.get("workload") == key and k2:
                 traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
         line = {

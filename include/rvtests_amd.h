@@ -189,7 +189,9 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * model is unweighted (quantitative trait), G'G is an integer matrix and the engine computes it on the int8 matrix
  * cores instead of the fp64 ones, with the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h) —
  * the results are the same numbers (the integer part exactly, G'X and G'r by the same fp64 products), the kernel is
- * then bound by HBM alone.  What a block holds is recorded when it is written through this ABI (rvt_block_upload,
+ * then bound by HBM alone.  Under a binary trait (weights v = p (1 - p)) the weighted Gram matrix takes the int8 cores
+ * as well, with v split once per null model into six 7-bit digit planes (suffstat_hcw.hip.h; M <= 80, weights in
+ * [0, 0.49], agreement with the fp64 kernel ~1e-12 relative).  What a block holds is recorded when it is written through this ABI (rvt_block_upload,
  * rvt_submit_gene*: one extra streaming pass, ~0.03 ms per gene at N = 500 000) and forgotten when it is modified or
  * freed.  For a device allocation the engine did not fill (e.g. a torch tensor handed to rvt_run_blocks)
  * rvt_block_classify scans it once and records the answer (is_hard_call may be NULL); the CALLER must call it again,
