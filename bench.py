@@ -198,14 +198,31 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
     """Secondary figures: the same hot path fed from HOST memory through the ModelFitter-style streaming calls (what a
     drop-in rvtests run does): pageable fp64 blocks (rvt_submit_gene, 8 B per genotype over PCIe), int8 hard calls
     (rvt_submit_gene_i8, 1 B), PLINK 2-bit rows (rvt_submit_gene_bed, 1/4 B) and the TEXT of the VCF records
-    (rvt_submit_gene_vcf: "0/1<tab>" = 4 B per genotype, split and decoded on the device); records are taken with
+    (rvt_submit_gene_vcf: "0/1<tab>" = 4 B per genotype, split and decoded on the device) and BGEN v1.2 probability
+    blocks (rvt_submit_gene_bgen: unphased diploid, 16 bits = 4 B + 1 ploidy byte per genotype); records are taken with
     rvt_collect_ready while the stream runs (no drain) and rvt_collect at the end."""
     ks = [k for k in range(len(Ms)) if 40 <= Ms[k] <= 60][:4] or list(range(min(4, len(Ms))))
     host = [np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()) for k in ks]
     hard = [np.rint(h) for h in host]
     out = {}
-    for mode in ("fp64", "int8", "bed2bit", "vcf_text"):
-        if mode == "vcf_text":
+    for mode in ("fp64", "int8", "bed2bit", "vcf_text", "bgen16"):
+        if mode == "bgen16":
+            # probabilities 1 (= 65535) on the called genotype: the dosages are exactly the hard calls
+            head = np.array([N], dtype="<u4").tobytes() + np.array([2], dtype="<u2").tobytes() + bytes([2, 2])
+            pm = np.full(N, 2, dtype=np.uint8).tobytes() + bytes([0, 16])
+            data = []
+            for h in hard:
+                gi = h.astype(np.int64)
+                blks = []
+                for j in range(h.shape[1]):
+                    v = np.zeros((N, 2), dtype="<u2")
+                    v[gi[:, j] == 0, 0] = 65535
+                    v[gi[:, j] == 1, 1] = 65535
+                    blks.append(head + pm + v.tobytes())
+                data.append(blks)
+            eng.vcf_set_samples(np.arange(N, dtype=np.int32))
+            nbytes = [sum(len(b) for b in d) for d in data]
+        elif mode == "vcf_text":
             lut = np.frombuffer(b"0/0\t0/1\t1/1\t", dtype=np.uint8).reshape(3, 4)
             head = b"1\t1000\t.\tA\tG\t50\tPASS\t.\tGT\t"
             eng.vcf_set_samples(np.arange(N, dtype=np.int32))
@@ -228,13 +245,15 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
                 eng.submit_gene_raw(g, data[i], want_af=False)
             elif mode == "vcf_text":
                 eng.submit_gene_vcf(g, data[i], want_af=False)
+            elif mode == "bgen16":
+                eng.submit_gene_bgen(g, data[i], 2, want_af=False)
             else:
                 eng.submit_gene_bed(g, data[i], Ms[ks[i]], want_af=False)
             if (g + 1) % window == 0:
                 done += len(eng.collect_ready())
         done += len(eng.collect())
         dt = time.perf_counter() - t0
-        per_gene = (sum(nbytes) if mode == "vcf_text" else sum(d.nbytes for d in data)) / len(data)
+        per_gene = (sum(nbytes) if mode in ("vcf_text", "bgen16") else sum(d.nbytes for d in data)) / len(data)
         out[mode] = {"gene_sets_per_s": done / dt, "genes": done, "host_GBps": per_gene * done / dt / 1e9}
     return out
 

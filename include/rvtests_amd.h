@@ -465,6 +465,29 @@ int rvt_submit_gene_vcf(rvt_ctx* ctx, int64_t gene_id, int M, const char* const*
 int rvt_vcf_decode(rvt_ctx* ctx, int M, const char* const* sample_text, const int64_t* text_len, const int* gt_index,
                    const int* gd_index, const int* gq_index, int8_t* out);
 
+/* ---- BGEN genotype-probability blocks at the boundary (SURVEY §8f "next" #1: "also enables BGEN ... input") ------------------
+ * Replaces, for the UNCOMPRESSED probability block of each variant of a gene (what the reference holds after uncompress /
+ * ZSTD_decompress, libBgen/BGenFile.cpp:289-319 — the caller inflates; variant identifying data and the .bgi index stay
+ * with the caller):
+ *   BGenFile::parseLayout1 (libBgen/BGenFile.cpp:205-238; v1.1: 3 x uint16 / 32768, an all-zero triple = missing),
+ *   BGenFile::parseLayout2 + BitReader (libBgen/BGenFile.cpp:321-392, libBgen/BitReader.h: v1.2 / v1.3 — per-sample
+ *     ploidy / missing bytes, phased or unphased, any number of alleles, 1..32-bit values, float(v) * scale and the float
+ *     remainder 1 - sum),
+ *   BGenGenotypeExtractor::getGenotype (src/BGenGenotypeExtractor.cpp:413-478: always a dosage, prob[1] + 2 prob[2] of the
+ *     sample's stored probabilities — kept as written also for phased and haploid samples —, 2 for a single allele, the
+ *     normalised form for more than two alleles, MISSING_GENOTYPE for a missing sample or a ploidy other than 1 / 2)
+ * and then everything rvt_submit_gene_raw does (GenotypeCounter frequencies, mean imputation) — all on the device, with the
+ * reference's arithmetic type at every step: the doubles are the reference's bit for bit.  layout = 1 or 2 (the file
+ * header's flag, one per file).  The sample map of rvt_vcf_set_samples applies (file sample -> analysis row, -1 = not
+ * analysed); without one, file sample i is row i.  Not provided: the hemizygous-region / sex checks (they only log) and
+ * multiAllelicMode (getGenotypeForAltAllele).  A block shorter than its ploidy bytes demand is reported by a later
+ * submit (RVT_E_INVALID), like a malformed VCF record. */
+int rvt_submit_gene_bgen(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* const* block, const int64_t* block_len,
+                         int layout, uint32_t tests, const rvt_params* params, double* af_out);
+/* decode only (synchronous): out = n_rows x M doubles, column-major; the genotype before consolidate(), -9 = missing */
+int rvt_bgen_decode(rvt_ctx* ctx, int M, const unsigned char* const* block, const int64_t* block_len, int layout,
+                    int64_t n_rows, double* out);
+
 /* ---- device groups: several GPUs of one node behind one calling thread ---------------------------------------------------
  * Genes are independent units that share only the null model, so a group is one engine context per device
  * (rvtests_amd/csrc/rvt_group.cpp): the null model / kinship decomposition is installed on every member, the gene stream is
@@ -496,6 +519,9 @@ int rvt_group_vcf_set_filters(rvt_group* group, int gd_min, int gd_max, int gq_m
 int rvt_group_submit_gene_vcf(rvt_group* group, int64_t gene_id, int M, const char* const* sample_text,
                               const int64_t* text_len, const int* gt_index, const int* gd_index, const int* gq_index,
                               uint32_t tests, const rvt_params* params, double* af_out);
+int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const unsigned char* const* block,
+                               const int64_t* block_len, int layout, uint32_t tests, const rvt_params* params,
+                               double* af_out);
 int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
 int rvt_group_collect_ready(rvt_group* group, rvt_gene_result* out, int cap, int* n_out); /* cf. rvt_collect_ready */
 /* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host

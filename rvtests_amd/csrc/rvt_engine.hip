@@ -36,6 +36,7 @@ void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N,
 #include "rot_gemm.hip.h"
 #include "perm_kernels.hip.h"
 #include "vcf_kernels.hip.h"
+#include "bgen_kernels.hip.h"
 #include "jacobi_kernels.hip.h"
 #include "rvt_hyper.h"
 
@@ -160,6 +161,11 @@ struct rvt_ctx {
   VcfFilters vcf_flt{0, 0, 0, 0};
   std::vector<int> vcf_alt;    // rvt_vcf_set_alt_alleles: alternative-allele index per record of the NEXT VCF call
   bool vcf_dosage = false;     // rvt_vcf_set_dosage: the index handed over is a dosage tag's, values through atof
+  // BGEN probability blocks (bgen_kernels.hip.h); the blocks are staged in d_vcf_text
+  BgenRecord* d_bgen_rec = nullptr;
+  long long* d_bgen_seg = nullptr;
+  size_t bgen_seg_cap = 0;
+  int* h_bgen_err = nullptr;   // pinned, device-visible: variant index + 1 of a block shorter than its ploidy bytes demand
   int* h_vcf_err = nullptr;    // pinned, device-visible: record index + 1 of a record with a wrong column count
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
   uint32_t rand_state[31];
@@ -620,6 +626,9 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
   if (c->h_vcf_err) hipHostFree(c->h_vcf_err);
+  if (c->d_bgen_rec) hipFree(c->d_bgen_rec);
+  if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
+  if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
@@ -3769,6 +3778,106 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
   return RVT_OK;
 }
 
+// BGEN probability blocks of one gene -> raw genotype doubles (missing = -9) in out (N rows x M, leading dimension ld)
+struct BgenGene {
+  const unsigned char* const* block;  // per variant: the uncompressed probability block
+  const int64_t* len;
+  int layout;                         // 1 (v1.1) or 2 (v1.2 / v1.3)
+};
+int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream_t st, double* out, int64_t ld) {
+  const int64_t n_file = c->d_vcf_rows ? c->vcf_n_file : N;
+  std::vector<BgenRecord> rec(M);
+  size_t total = 0;
+  for (int j = 0; j < M; ++j) {
+    const unsigned char* b = bg->block[j];
+    const int64_t len = bg->len[j];
+    BgenRecord& r = rec[j];
+    r.layout = bg->layout;
+    r.len = len;
+    size_t pad = 0;
+    if (bg->layout == 1) {
+      if (len < 6 * n_file) return fail(c, RVT_E_INVALID, "BGEN variant %d: block of %lld bytes, %lld samples", j, (long long)len, (long long)n_file);
+      r.K = 2;
+      r.phased = 0;
+      r.bits = 16;
+      r.scale = 0.0f;
+      r.zmax = 2;
+    } else {
+      if (len < 10 + n_file) return fail(c, RVT_E_INVALID, "BGEN variant %d: block of %lld bytes, %lld samples", j, (long long)len, (long long)n_file);
+      uint32_t n_indv;
+      uint16_t K;
+      std::memcpy(&n_indv, b, 4);
+      std::memcpy(&K, b + 4, 2);
+      if ((int64_t)n_indv != n_file)
+        return fail(c, RVT_E_INVALID, "BGEN variant %d holds %u samples, the sample map %lld", j, n_indv, (long long)n_file);
+      const int B = b[8 + n_file + 1];
+      if (B < 1 || B > 32 || K < 1) return fail(c, RVT_E_INVALID, "BGEN variant %d: %d bits, %d alleles", j, B, (int)K);
+      r.K = K;
+      r.phased = b[8 + n_file] != 0;
+      r.bits = B;
+      float scale = 1.0f;  // BitReader's constructor, in float (libBgen/BitReader.h:17-27)
+      for (int i = 0; i < B; ++i) scale *= 2;
+      scale -= 1;
+      scale = (float)(1.0 / scale);
+      r.scale = scale;
+      const int zmax = b[7] & 0x3f;  // declared maximum ploidy; the device checks every sample against it
+      r.zmax = zmax;
+      if (!r.phased) {  // C(Z + K - 1, K - 1) must stay an ordinary int (the reference's choose() overflows silently beyond)
+        double cmb = 1.0;
+        for (int i = 0; i < K - 1 && cmb < 1e9; ++i) cmb = cmb * (zmax + K - 1 - i) / (i + 1);
+        if (cmb > 16777216.0)
+          return fail(c, RVT_E_TOO_LARGE, "BGEN variant %d: ploidy %d with %d alleles is not supported", j, zmax, (int)K);
+      }
+      pad = (size_t)((4 - (10 + n_file) % 4) % 4);  // the packed values start on a 4-byte boundary
+    }
+    total = (total + 15) / 16 * 16 + pad;
+    r.off = (long long)total;
+    total += (size_t)len + 16;
+  }
+  total += 16;
+  if (c->vcf_text_cap < total) {
+    if (c->d_vcf_text) hipFree(c->d_vcf_text);
+    c->d_vcf_text = nullptr;
+    c->vcf_text_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_vcf_text, total + total / 4));
+    c->vcf_text_cap = total + total / 4;
+  }
+  if (!c->d_bgen_rec) HIP_TRY(c, hipMalloc((void**)&c->d_bgen_rec, sizeof(BgenRecord) * RVT_MAX_VARIANTS));
+  const int max_seg = (int)((n_file + kBgenSeg - 1) / kBgenSeg);
+  if (c->bgen_seg_cap < (size_t)max_seg * M) {
+    if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
+    c->d_bgen_seg = nullptr;
+    c->bgen_seg_cap = 0;
+    const size_t want = (size_t)max_seg * std::max(M, 64);
+    HIP_TRY(c, hipMalloc((void**)&c->d_bgen_seg, sizeof(long long) * want));
+    c->bgen_seg_cap = want;
+  }
+  if (!c->h_bgen_err) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_bgen_err, sizeof(int), hipHostMallocMapped));
+    *c->h_bgen_err = 0;
+  }
+  for (int j = 0; j < M; ++j) {  // the bytes behind a block read as zero (BitReader stops at its end)
+    HIP_TRY(c, hipMemsetAsync(c->d_vcf_text + rec[j].off + bg->len[j], 0, 16, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].off, bg->block[j], (size_t)bg->len[j], hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_bgen_rec, rec.data(), sizeof(BgenRecord) * M, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, sync_stream(st));  // `rec` is a local
+  int* d_err = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_bgen_err, 0));
+  const unsigned char* data = reinterpret_cast<const unsigned char*>(c->d_vcf_text);
+  const dim3 grid((unsigned)max_seg, (unsigned)M);
+  if (bg->layout == 2) {
+    hipLaunchKernelGGL(bgen_count_kernel, grid, dim3(kBgenSeg), 0, st, data, c->d_bgen_rec, (long long)n_file, max_seg,
+                       c->d_bgen_seg, d_err);
+    hipLaunchKernelGGL(bgen_scan_kernel, dim3((unsigned)M), dim3(256), 0, st, c->d_bgen_rec, (long long)n_file, max_seg,
+                       c->d_bgen_seg, d_err);
+  }
+  hipLaunchKernelGGL(bgen_decode_kernel, grid, dim3(kBgenSeg), 0, st, data, c->d_bgen_rec, (long long)n_file, max_seg,
+                     c->d_bgen_seg, c->d_vcf_rows, (long long)ld, out);
+  HIP_TRY(c, hipGetLastError());
+  return RVT_OK;
+}
+
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
   if (!c || !G || M < 1 || (mode == 0 && !af)) return fail(c, RVT_E_INVALID, "bad gene");
@@ -3836,9 +3945,10 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     const dim3 cgrid((unsigned)nparts, (unsigned)M);
     if (e != hipSuccess) {
       // fall through to the error return below
-    } else if (mode == 1 || mode == 5) {
-      int rc = mode == 1 ? upload_block_data(c, p.dG, M, (const double*)G)
-                         : vcf_decode_gene(c, (const VcfGene*)G, M, N, st, p.dG, ld);  // VCF dosage text -> doubles
+    } else if (mode == 1 || mode == 5 || mode == 6) {
+      int rc = mode == 1   ? upload_block_data(c, p.dG, M, (const double*)G)
+               : mode == 5 ? vcf_decode_gene(c, (const VcfGene*)G, M, N, st, p.dG, ld)  // VCF dosage text -> doubles
+                           : bgen_decode_gene(c, (const BgenGene*)G, M, N, st, p.dG, ld);  // BGEN blocks -> doubles
       if (rc) {
         give_back();
         return rc;
@@ -4061,6 +4171,60 @@ int rvt_vcf_decode(rvt_ctx* c, int M, const char* const* sample_text, const int6
     const int k = *c->h_vcf_err;
     *c->h_vcf_err = 0;
     return fail(c, RVT_E_INVALID, "VCF record %d does not hold %d sample columns", k - 1, c->vcf_n_file);
+  }
+  return RVT_OK;
+}
+
+static int bgen_check(rvt_ctx* c, int M, const unsigned char* const* block, const int64_t* len, int layout) {
+  if (!c || !block || !len || M < 1 || M > RVT_MAX_VARIANTS || (layout != 1 && layout != 2))
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  for (int j = 0; j < M; ++j)
+    if (!block[j] || len[j] < 0) return fail(c, RVT_E_INVALID, "variant %d: no block", j);
+  if (c->h_bgen_err && *c->h_bgen_err) {
+    const int k = *c->h_bgen_err;
+    *c->h_bgen_err = 0;
+    return fail(c, RVT_E_INVALID, "BGEN variant %d of an earlier gene: the block is shorter than its ploidy bytes demand (or a ploidy exceeds the declared maximum)", k - 1);
+  }
+  return RVT_OK;
+}
+
+int rvt_submit_gene_bgen(rvt_ctx* c, int64_t gene_id, int M, const unsigned char* const* block, const int64_t* block_len,
+                         int layout, uint32_t tests, const rvt_params* prm, double* af_out) {
+  int rc = bgen_check(c, M, block, block_len, layout);
+  if (rc) return rc;
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (c->d_vcf_rows && c->vcf_n_rows != c->nc.N)
+    return fail(c, RVT_E_STATE, "the sample map addresses %lld rows, the null model has %lld samples",
+                (long long)c->vcf_n_rows, (long long)c->nc.N);
+  BgenGene bg{block, block_len, layout};
+  return submit_common(c, gene_id, M, &bg, 6, nullptr, af_out, tests, prm);
+}
+
+// Decode only: the N x M raw genotypes (column-major doubles, -9 = missing) the device reads out of the blocks
+int rvt_bgen_decode(rvt_ctx* c, int M, const unsigned char* const* block, const int64_t* block_len, int layout,
+                    int64_t n_rows, double* out) {
+  int rc = bgen_check(c, M, block, block_len, layout);
+  if (rc) return rc;
+  if (!out || n_rows < 1) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (c->d_vcf_rows && c->vcf_n_rows != n_rows)
+    return fail(c, RVT_E_STATE, "the sample map addresses %lld rows, not %lld", (long long)c->vcf_n_rows, (long long)n_rows);
+  hipSetDevice(c->device);
+  hipStream_t st = c->io_stream;
+  HIP_TRY(c, sync_stream(st));
+  double* d_out = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)n_rows * M));
+  BgenGene bg{block, block_len, layout};
+  rc = bgen_decode_gene(c, &bg, M, n_rows, st, d_out, n_rows);
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_rows * M, hipMemcpyDeviceToHost, st);
+  if (!rc && e == hipSuccess) e = sync_stream(st);
+  hipFree(d_out);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(c, RVT_E_HIP, "BGEN decode failed: %s", hipGetErrorString(e));
+  if (*c->h_bgen_err) {
+    const int k = *c->h_bgen_err;
+    *c->h_bgen_err = 0;
+    return fail(c, RVT_E_INVALID, "BGEN variant %d: the block is shorter than its ploidy bytes demand (or a ploidy exceeds the declared maximum)", k - 1);
   }
   return RVT_OK;
 }

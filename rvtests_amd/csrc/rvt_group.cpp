@@ -141,6 +141,12 @@ int rvt_group_submit_gene_vcf(rvt_group* g, int64_t gene_id, int M, const char* 
   RVT_GROUP_SUBMIT(rvt_submit_gene_vcf(m, gene_id, M, sample_text, text_len, gt_index, gd_index, gq_index, tests, params, af_out))
 }
 
+int rvt_group_submit_gene_bgen(rvt_group* g, int64_t gene_id, int M, const unsigned char* const* block,
+                               const int64_t* block_len, int layout, uint32_t tests, const rvt_params* params,
+                               double* af_out) {
+  RVT_GROUP_SUBMIT(rvt_submit_gene_bgen(m, gene_id, M, block, block_len, layout, tests, params, af_out))
+}
+
 // the ordered merge: each member's records arrive in ITS submission order; hand out the global prefix
 static int pop_in_order(rvt_group* g, rvt_gene_result* out, int cap) {
   int n = 0;

@@ -579,6 +579,37 @@ class Engine:
                                                C.byref(prm), _dp(af) if want_af else None))
         return af
 
+    # ---- BGEN genotype-probability blocks (rvt_submit_gene_bgen / rvt_bgen_decode) ------------------------------------
+    @staticmethod
+    def _bgen_args(blocks):
+        """blocks: the UNCOMPRESSED probability block of each variant (bytes-like).  ctypes pointer arrays over them."""
+        M = len(blocks)
+        keep = [np.frombuffer(b, dtype=np.uint8) for b in blocks]           # zero-copy views; kept alive by the caller
+        ptr = (C.c_void_p * M)(*[k.ctypes.data for k in keep])
+        blen = (C.c_int64 * M)(*[k.size for k in keep])
+        return M, keep, ptr, blen
+
+    def bgen_decode(self, blocks, layout, n_rows):
+        """Raw genotype matrix (n_rows x M float64, missing = -9) the device reads out of the blocks."""
+        M, keep, ptr, blen = self._bgen_args(blocks)
+        out = np.zeros((n_rows, M), dtype=np.float64, order="F")
+        self.L.rvt_bgen_decode.restype = C.c_int
+        self.L.rvt_bgen_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, c_double_p]
+        self._check(self.L.rvt_bgen_decode(self.ctx, M, ptr, blen, int(layout), int(n_rows), _dp(out)))
+        return out
+
+    def submit_gene_bgen(self, gene_id, blocks, layout, tests=TEST_ALL, params=None, want_af=True):
+        """One gene as BGEN probability blocks: dosages, allele frequencies and mean imputation on the device."""
+        prm = params or Params.default()
+        M, keep, ptr, blen = self._bgen_args(blocks)
+        af = np.zeros(M) if want_af else None
+        self.L.rvt_submit_gene_bgen.restype = C.c_int
+        self.L.rvt_submit_gene_bgen.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32,
+                                                C.c_void_p, c_double_p]
+        self._check(self.L.rvt_submit_gene_bgen(self.ctx, int(gene_id), M, ptr, blen, int(layout), int(tests),
+                                                C.byref(prm), _dp(af) if want_af else None))
+        return af
+
     def submit_gene_raw(self, gene_id, Graw, tests=TEST_ALL, params=None, want_af=True):
         """Raw extractor output (missing < 0): float64 -> rvt_submit_gene_raw, int8 -> rvt_submit_gene_i8.  The device
         imputes and counts allele frequencies; returns the frequencies the tests will use (None with want_af=False)."""

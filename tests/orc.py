@@ -630,3 +630,39 @@ def vcf_column_alt(col, gt_idx, alt):
     L.orc_vcf_column_alt.restype = C.c_int
     L.orc_vcf_column_alt.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int]
     return L.orc_vcf_column_alt(col, len(col), gt_idx, alt)
+
+
+# ---- BGEN genotype-probability blocks (oracle/orc_bgen.cpp) -------------------------------------------------------------
+def bgen_decode(block, layout, N):
+    """-> (info dict, missing[N], ploidy[N], index[N+1], prob float32[...]) as BGenFile::parseLayout1/2 leave them."""
+    L = lib()
+    L.orc_bgen_decode.restype = C.c_int64
+    L.orc_bgen_decode.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int64, c_int_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64]
+    missing = np.zeros(N, dtype=np.uint8)
+    ploidy = np.zeros(N, dtype=np.uint8)
+    index = np.zeros(N + 1, dtype=np.int64)
+    info = np.zeros(3, dtype=np.int32)
+    cap = 3 * N + 16
+    while True:
+        prob = np.zeros(cap, dtype=np.float32)
+        n = L.orc_bgen_decode(bytes(block), len(block), layout, N, info.ctypes.data_as(c_int_p), missing.ctypes.data,
+                              ploidy.ctypes.data, index.ctypes.data, prob.ctypes.data, cap)
+        if n != -2:
+            break
+        cap *= 4
+    if n < 0:
+        raise ValueError("orc_bgen_decode: %d" % n)
+    return {"phased": int(info[0]), "bits": int(info[1]), "K": int(info[2])}, missing, ploidy, index, prob[:n]
+
+
+def bgen_block_genotypes(block, layout, N):
+    """BGenGenotypeExtractor::getGenotype for every file sample of one uncompressed block (-9 = missing)."""
+    L = lib()
+    L.orc_bgen_block_genotypes.restype = C.c_int
+    L.orc_bgen_block_genotypes.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int64, c_double_p]
+    out = np.zeros(N, dtype=np.float64)
+    rc = L.orc_bgen_block_genotypes(bytes(block), len(block), layout, N, out.ctypes.data_as(c_double_p))
+    if rc:
+        raise ValueError("orc_bgen_block_genotypes: %d" % rc)
+    return out
