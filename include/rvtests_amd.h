@@ -19,6 +19,8 @@
  *   AnalyticVT (UNRELATED) over MultivariateVT::compute                  src/Model.h:2105-2259, regression/MultivariateVT.cpp:22-144
  *   KBACTest over KbacTest::calcKbacP                                     src/Model.h:2891-3045, regression/kbac.cpp:16-391
  *   VCFGenotypeExtractor::extractMultipleGenotype (GT text)               src/VCFGenotypeExtractor.cpp:29-140,397-439
+ *   BGenFile::parseLayout1 / parseLayout2 (probability blocks),           libBgen/BGenFile.cpp:205-238,321-392,
+ *   BGenGenotypeExtractor::getGenotype                                    src/BGenGenotypeExtractor.cpp:413-478
  *   KinshipHolder::decompose                                              base/KinshipHolder.cpp:270-290
  * Plain C, plain pointers and sizes; no C++ or torch types cross it.  All functions return 0 on
  * success and a negative RVT_E_* code on failure; rvt_last_error() gives the text.  One calling
