@@ -433,7 +433,7 @@ int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned cha
  * hard calls: the caller hands over the TEXT of the sample columns of each record of a gene; splitting at tabs and ':',
  * VCFValue::getGenotype (libVcf/VCFValue.h:74-117; '.', multi-allelic or malformed calls -> missing, haploid calls -> 0 / 1),
  * the GD / GQ filters (src/VCFGenotypeExtractor.cpp:304-317) and then everything rvt_submit_gene_i8 does (allele
- * frequencies, mean imputation) run on the device.  Not provided: the hemizygous (non-PAR X) recoding by sex.
+ * frequencies, mean imputation) run on the device.
  *   rvt_vcf_locate      host-only helper: offset of the first sample column of a record line and the FORMAT indices
  *                       of GT / GD / GQ by VCFRecord::getFormatIndex's prefix rule (libVcf/VCFRecord.h:280-305); -1 = absent
  *   rvt_vcf_set_samples once per file: row_of_sample[s] = row of the analysis (0 .. N-1) that sample column s of the
@@ -456,6 +456,14 @@ int rvt_vcf_set_dosage(rvt_ctx* ctx, int use_dosage);
  * alternative allele; alt[j] > 0 makes record j of the NEXT rvt_submit_gene_vcf / rvt_vcf_decode call count that allele
  * (VCFValue::countAltAllele, libVcf/VCFValue.h:180-213), alt[j] = 0 keeps the bi-allelic coding.  Consumed by that call. */
 int rvt_vcf_set_alt_alleles(rvt_ctx* ctx, int M, const int* alt);
+/* Hemizygous regions (--xHemi / ParRegion::isHemiRegion, src/VCFGenotypeExtractor.cpp:85-86,416-426): sex[s] = PLINK code
+ * of FILE sample s (1 male, 2 female, anything else unknown; once per file, after rvt_vcf_set_samples); hemi[j] != 0 marks
+ * record j of the NEXT rvt_submit_gene_vcf / rvt_vcf_decode call as lying in a hemizygous region (the caller evaluates
+ * ParRegion on chrom:pos).  There a male is coded by VCFValue::getMaleNonParGenotype02 (haploid "1" or homozygous "1/1"
+ * = 2, heterozygous = missing; libVcf/VCFValue.h:125-142) or countMaleNonParAltAllele2 in multi-allelic mode, a female
+ * as everywhere else, unknown sex is missing; in dosage mode a male's value is doubled.  Consumed by that call. */
+int rvt_vcf_set_sex(rvt_ctx* ctx, int n_file_samples, const int8_t* sex);
+int rvt_vcf_set_hemi(rvt_ctx* ctx, int M, const int* hemi);
 int rvt_vcf_format_index(const char* line, int64_t len, const char* key, int* index);
 int rvt_vcf_decode_dosage(rvt_ctx* ctx, int M, const char* const* sample_text, const int64_t* text_len,
                           const int* tag_index, const int* gd_index, const int* gq_index, double* out);
@@ -481,8 +489,9 @@ int rvt_vcf_decode(rvt_ctx* ctx, int M, const char* const* sample_text, const in
  * and then everything rvt_submit_gene_raw does (GenotypeCounter frequencies, mean imputation) — all on the device, with the
  * reference's arithmetic type at every step: the doubles are the reference's bit for bit.  layout = 1 or 2 (the file
  * header's flag, one per file).  The sample map of rvt_vcf_set_samples applies (file sample -> analysis row, -1 = not
- * analysed); without one, file sample i is row i.  Not provided: the hemizygous-region / sex checks (they only log) and
- * multiAllelicMode (getGenotypeForAltAllele).  A block shorter than its ploidy bytes demand is reported by a later
+ * analysed); without one, file sample i is row i.  multiAllelicMode: rvt_vcf_set_alt_alleles applies to the next call —
+ * the reference supports the first alternative allele only (getGenotypeForAltAllele, :470-482: alt > 1 -> every sample
+ * missing).  The hemizygous-region / sex checks of getGenotype only log and have no counterpart.  A block shorter than its ploidy bytes demand is reported by a later
  * submit (RVT_E_INVALID), like a malformed VCF record. */
 int rvt_submit_gene_bgen(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* const* block, const int64_t* block_len,
                          int layout, uint32_t tests, const rvt_params* params, double* af_out);

@@ -3,6 +3,8 @@
 //   * GT text -> 0 / 1 / 2 / MISSING_GENOTYPE    VCFValue::getGenotype            libVcf/VCFValue.h:74-117
 //   * depth / quality filters                    checkGD / checkGQ                src/VCFGenotypeExtractor.cpp:304-317
 //   * the per-sample loop and its -9 on failure  getGenotype                      src/VCFGenotypeExtractor.cpp:397-439
+//   * hemizygous regions: males through          getMaleNonParGenotype02 /        libVcf/VCFValue.h:125-142,214-236
+//     (unknown sex -> missing, dosage x 2)       countMaleNonParAltAllele2
 //   * FORMAT key -> subfield index (prefix match) VCFRecord::getFormatIndex       libVcf/VCFRecord.h:280-305
 // Pinned against the reference's own libVcf/VCFIndividual + VCFValue compiled where they lie (oracle/_ref/libref_vcf.so,
 // oracle/ref_vcf_shim.cpp) in tests/test_vcf_cpu.py.  Not covered (malformed input on which the reference itself
@@ -78,14 +80,61 @@ int alt_code(const std::string& s, int alt) {  // VCFValue::countAltAllele (libV
   return g;
 }
 
-int column_code(const char* col, int64_t len, int gt_idx, int gd_idx, int gq_idx, const int* flt, int alt = 0) {
+// VCFValue::getAllele1 / getAllele2 / isHaploid (libVcf/VCFValue.h:159-179,242)
+int allele1(const std::string& s) {
+  const char* line = s.c_str();
+  if (line[0] == '.') return kMissing;
+  if (line[0] < '0') return 0;  // only reported
+  return line[0] - '0';
+}
+int allele2(const std::string& s) {
+  const char* line = s.c_str();
+  if (2 >= (int)s.size()) return kMissing;
+  if (line[2] == '.') return kMissing;
+  if (line[2] < '0') return 0;  // only reported
+  return line[2] - '0';
+}
+// VCFValue::getMaleNonParGenotype02 (libVcf/VCFValue.h:125-142): a male in a hemizygous region
+int male02_code(const std::string& s) {
+  const int g = allele1(s);
+  if (g == kMissing) return kMissing;
+  if (s.size() == 1) return g == 0 ? 0 : (g == 1 ? 2 : kMissing);
+  const int g2 = allele2(s);
+  if (g2 == kMissing) return kMissing;
+  if (g == g2) {
+    if (g == 0) return 0;
+    if (g == 1) return 2;
+  }
+  return kMissing;
+}
+// VCFValue::countMaleNonParAltAllele2 (libVcf/VCFValue.h:214-236; release build: its range assert is compiled out)
+int male_alt_code(const std::string& s, int alt) {
+  const int g = allele1(s);
+  if (g == kMissing) return kMissing;
+  if (s.size() == 1) return g == alt ? 2 : 0;
+  const int g2 = allele2(s);
+  if (g2 == kMissing) return kMissing;
+  if (g == g2) return (g == alt ? 1 : 0) + (g2 == alt ? 1 : 0);
+  return kMissing;
+}
+
+// hemi: the record lies in a hemizygous region (ParRegion::isHemiRegion); sex: PLINK code of the sample (1 male,
+// 2 female, anything else unknown) — src/VCFGenotypeExtractor.cpp:397-439 (getGenotype), :441-484 (...ForAltAllele)
+int column_code(const char* col, int64_t len, int gt_idx, int gd_idx, int gq_idx, const int* flt, int alt = 0,
+                int hemi = 0, int sex = 0) {
   const std::vector<std::string> fd = split_column(col, len);
   auto just_get = [&](int i) -> std::string {  // index past the end (or negative: unsigned wrap) -> default "."
     if (i < 0 || i >= (int)fd.size()) return std::string(".");
     return fd[i];
   };
   if (gt_idx < 0) return kMissing;  // "Cannot find GT field!"
-  int ret = alt > 0 ? alt_code(just_get(gt_idx), alt) : gt_code(just_get(gt_idx));
+  int ret;
+  if (!hemi || sex == 2)
+    ret = alt > 0 ? alt_code(just_get(gt_idx), alt) : gt_code(just_get(gt_idx));
+  else if (sex == 1)
+    ret = alt > 0 ? male_alt_code(just_get(gt_idx), alt) : male02_code(just_get(gt_idx));
+  else
+    ret = kMissing;
   if (flt) {
     if (flt[0] > 0 || flt[1] > 0) {
       const int gd = atoi(just_get(gd_idx).c_str());
@@ -105,6 +154,33 @@ extern "C" {
 int orc_vcf_column_genotype(const char* col, int64_t len, int gt_idx) { return column_code(col, len, gt_idx, -1, -1, nullptr); }
 int orc_vcf_column_alt(const char* col, int64_t len, int gt_idx, int alt) {
   return column_code(col, len, gt_idx, -1, -1, nullptr, alt);
+}
+
+int orc_vcf_column_male02(const char* col, int64_t len, int gt_idx) {
+  return column_code(col, len, gt_idx, -1, -1, nullptr, 0, 1, 1);
+}
+int orc_vcf_column_male_alt(const char* col, int64_t len, int gt_idx, int alt) {
+  return column_code(col, len, gt_idx, -1, -1, nullptr, alt, 1, 1);
+}
+
+// as orc_vcf_decode_record with the alternative allele of multi-allelic mode (0 = bi-allelic coding), the hemizygous
+// flag of the record and the PLINK sex code of every FILE sample (may be NULL when hemi = 0)
+int orc_vcf_decode_record_sex(const char* text, int64_t len, int n_file_samples, const int32_t* row_of_sample, int gt_idx,
+                              int gd_idx, int gq_idx, const int* filters, int alt, int hemi, const int8_t* sex,
+                              int8_t* out) {
+  int s = 0;
+  int64_t b = 0;
+  for (;;) {
+    int64_t e = b;
+    while (e < len && text[e] != '\t') ++e;
+    if (s < n_file_samples && row_of_sample[s] >= 0)
+      out[row_of_sample[s]] = (int8_t)column_code(text + b, e - b, gt_idx, gd_idx, gq_idx, filters, alt, hemi,
+                                                  (hemi && sex) ? sex[s] : 0);
+    ++s;
+    if (e >= len) break;
+    b = e + 1;
+  }
+  return s;
 }
 
 // text = the sample columns of one record (tab separated, no newline).  out[row_of_sample[s]] = code of column s.
@@ -127,8 +203,18 @@ int orc_vcf_decode_record(const char* text, int64_t len, int n_file_samples, con
 
 // dosage mode (useDosage: ret = indv.justGet(genoIdx).toDouble(), src/VCFGenotypeExtractor.cpp:403-414; toDouble = atof of
 // the NUL-terminated subfield, libVcf/VCFValue.h:38-41; the default value "." reads 0.0); then the GD / GQ filters
+int orc_vcf_decode_record_dosage_sex(const char* text, int64_t len, int n_file_samples, const int32_t* row_of_sample,
+                                     int tag_idx, int gd_idx, int gq_idx, const int* flt, int hemi, const int8_t* sex,
+                                     double* out);
 int orc_vcf_decode_record_dosage(const char* text, int64_t len, int n_file_samples, const int32_t* row_of_sample,
                                  int tag_idx, int gd_idx, int gq_idx, const int* flt, double* out) {
+  return orc_vcf_decode_record_dosage_sex(text, len, n_file_samples, row_of_sample, tag_idx, gd_idx, gq_idx, flt, 0,
+                                          nullptr, out);
+}
+// ... in a hemizygous region a male's dosage is doubled (src/VCFGenotypeExtractor.cpp:407-414); sex is not looked at otherwise
+int orc_vcf_decode_record_dosage_sex(const char* text, int64_t len, int n_file_samples, const int32_t* row_of_sample,
+                                     int tag_idx, int gd_idx, int gq_idx, const int* flt, int hemi, const int8_t* sex,
+                                     double* out) {
   int s = 0;
   int64_t b = 0;
   for (;;) {
@@ -141,6 +227,7 @@ int orc_vcf_decode_record_dosage(const char* text, int64_t len, int n_file_sampl
         return fd[i];
       };
       double g = tag_idx < 0 ? (double)kMissing : atof(just_get(tag_idx).c_str());
+      if (tag_idx >= 0 && hemi && sex && sex[s] == 1) g = g * 2.0;
       if (flt) {
         if (flt[0] > 0 || flt[1] > 0) {
           const int gd = atoi(just_get(gd_idx).c_str());

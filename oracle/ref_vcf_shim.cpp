@@ -33,3 +33,21 @@ extern "C" int ref_vcf_column_alt(const char* column, int len, int gt_idx, int a
   indv.parse(v);
   return indv.justGet(gt_idx).countAltAllele(alt);
 }
+
+extern "C" int ref_vcf_column_male02(const char* column, int len, int gt_idx) {
+  std::string buf(column, len);
+  buf.append(32, '\0');
+  VCFValue v(&buf[0], 0, len);
+  VCFIndividual indv;
+  indv.parse(v);
+  return indv.justGet(gt_idx).getMaleNonParGenotype02();
+}
+
+extern "C" int ref_vcf_column_male_alt(const char* column, int len, int gt_idx, int alt) {
+  std::string buf(column, len);
+  buf.append(32, '\0');
+  VCFValue v(&buf[0], 0, len);
+  VCFIndividual indv;
+  indv.parse(v);
+  return indv.justGet(gt_idx).countMaleNonParAltAllele2(alt);
+}

@@ -35,6 +35,8 @@ struct BgenRecord {
   int bits;       // B
   float scale;    // BitReader's scale: float(1.0 / float(2^B - 1)), computed by the host in float
   int zmax;       // largest ploidy the block header declares (byte 7): a sample above it raises the error flag
+  int alt;        // multi-allelic mode: the alternative allele asked for; > 1 -> every sample missing
+                  // (BGenGenotypeExtractor::getGenotypeForAltAllele, src/BGenGenotypeExtractor.cpp:470-482)
 };
 
 // BGenFile::choose (libBgen/BGenFile.cpp:438-453), int arithmetic
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(kBgenSeg) void bgen_decode_kernel(const unsigned ch
       }
     }
   }
+  if (r.alt > 1) g = kBgenMissing;
   if (i < N) {
     const int row = row_of_sample ? row_of_sample[i] : (int)i;
     if (row >= 0) out[(long long)row + (long long)blockIdx.y * ld] = g;

@@ -162,6 +162,8 @@ struct rvt_ctx {
   std::vector<int> vcf_alt;    // rvt_vcf_set_alt_alleles: alternative-allele index per record of the NEXT VCF call
   bool vcf_dosage = false;     // rvt_vcf_set_dosage: the index handed over is a dosage tag's, values through atof
   // BGEN probability blocks (bgen_kernels.hip.h); the blocks are staged in d_vcf_text
+  signed char* d_vcf_sex = nullptr;  // PLINK sex code per file sample (rvt_vcf_set_sex); hemizygous records only
+  std::vector<int> vcf_hemi;         // per record of the NEXT decode call (rvt_vcf_set_hemi)
   BgenRecord* d_bgen_rec = nullptr;
   long long* d_bgen_seg = nullptr;
   size_t bgen_seg_cap = 0;
@@ -626,6 +628,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
   if (c->h_vcf_err) hipHostFree(c->h_vcf_err);
+  if (c->d_vcf_sex) hipFree(c->d_vcf_sex);
   if (c->d_bgen_rec) hipFree(c->d_bgen_rec);
   if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
   if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
@@ -3727,6 +3730,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     rec[j].gd_idx = vg->gd_idx ? vg->gd_idx[j] : -1;
     rec[j].gq_idx = vg->gq_idx ? vg->gq_idx[j] : -1;
     rec[j].alt = ((int)c->vcf_alt.size() == M) ? c->vcf_alt[j] : 0;
+    rec[j].hemi = ((int)c->vcf_hemi.size() == M && c->d_vcf_sex) ? c->vcf_hemi[j] : 0;
     total += ((size_t)vg->len[j] + 31) / 16 * 16;  // 16-byte aligned starts, >= 16 readable bytes behind the end
     max_len = std::max<int64_t>(max_len, vg->len[j]);
   }
@@ -3752,6 +3756,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     *c->h_vcf_err = 0;
   }
   c->vcf_alt.clear();  // (one call only)
+  c->vcf_hemi.clear();
   for (int j = 0; j < M; ++j)  // (a copy from pageable memory returns once the source has been read)
     if (vg->len[j] > 0)
       HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j], hipMemcpyHostToDevice, st));
@@ -3767,12 +3772,13 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     hipLaunchKernelGGL(vcf_fill_kernel, dim3(1024), dim3(256), 0, st, dosage_out, (long long)N, (long long)dosage_ld, M,
                        (double)kVcfMissing);
     hipLaunchKernelGGL(vcf_decode_dosage_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg,
-                       c->d_vcf_seg, c->d_vcf_rows, c->vcf_n_file, (long long)dosage_ld, c->vcf_flt, dosage_out, d_err);
+                       c->d_vcf_seg, c->d_vcf_rows, c->d_vcf_sex, c->vcf_n_file, (long long)dosage_ld, c->vcf_flt, dosage_out,
+                       d_err);
   } else {
     signed char* out = (signed char*)c->d_consol_i8;
     HIP_TRY(c, hipMemsetAsync(out, 0xF7, (size_t)N * M, st));  // -9: rows the sample map never addresses stay missing
     hipLaunchKernelGGL(vcf_decode_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg,
-                       c->d_vcf_rows, c->vcf_n_file, (long long)N, c->vcf_flt, out);
+                       c->d_vcf_rows, c->d_vcf_sex, c->vcf_n_file, (long long)N, c->vcf_flt, out);
   }
   HIP_TRY(c, hipGetLastError());
   return RVT_OK;
@@ -3794,6 +3800,7 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
     BgenRecord& r = rec[j];
     r.layout = bg->layout;
     r.len = len;
+    r.alt = ((int)c->vcf_alt.size() == M) ? c->vcf_alt[j] : 0;
     size_t pad = 0;
     if (bg->layout == 1) {
       if (len < 6 * n_file) return fail(c, RVT_E_INVALID, "BGEN variant %d: block of %lld bytes, %lld samples", j, (long long)len, (long long)n_file);
@@ -3842,6 +3849,7 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
     HIP_TRY(c, hipMalloc((void**)&c->d_vcf_text, total + total / 4));
     c->vcf_text_cap = total + total / 4;
   }
+  c->vcf_alt.clear();  // (one call only)
   if (!c->d_bgen_rec) HIP_TRY(c, hipMalloc((void**)&c->d_bgen_rec, sizeof(BgenRecord) * RVT_MAX_VARIANTS));
   const int max_seg = (int)((n_file + kBgenSeg - 1) / kBgenSeg);
   if (c->bgen_seg_cap < (size_t)max_seg * M) {
@@ -4095,6 +4103,8 @@ int rvt_vcf_set_samples(rvt_ctx* c, int n_file_samples, const int32_t* row_of_sa
   if (rc) return rc;
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
   c->d_vcf_rows = nullptr;
+  if (c->d_vcf_sex) hipFree(c->d_vcf_sex);  // (belongs to the previous file)
+  c->d_vcf_sex = nullptr;
   HIP_TRY(c, hipMalloc((void**)&c->d_vcf_rows, sizeof(int) * (size_t)n_file_samples));
   HIP_TRY(c, hipMemcpy(c->d_vcf_rows, row_of_sample, sizeof(int) * (size_t)n_file_samples, hipMemcpyHostToDevice));
   c->vcf_n_file = n_file_samples;
@@ -4107,6 +4117,27 @@ int rvt_vcf_set_alt_alleles(rvt_ctx* c, int M, const int* alt) {
   for (int j = 0; j < M; ++j)
     if (alt[j] < 0 || alt[j] > 9) return fail(c, RVT_E_INVALID, "alternative allele index %d (single digits only)", alt[j]);
   c->vcf_alt.assign(alt, alt + M);
+  return RVT_OK;
+}
+
+int rvt_vcf_set_sex(rvt_ctx* c, int n_file_samples, const int8_t* sex) {
+  if (!c || n_file_samples < 1 || !sex) return fail(c, RVT_E_INVALID, "bad sex codes");
+  if (!c->d_vcf_rows || c->vcf_n_file != n_file_samples)
+    return fail(c, RVT_E_STATE, "rvt_vcf_set_samples first (same number of file samples)");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  if (c->d_vcf_sex) hipFree(c->d_vcf_sex);
+  c->d_vcf_sex = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&c->d_vcf_sex, (size_t)n_file_samples));
+  HIP_TRY(c, hipMemcpy(c->d_vcf_sex, sex, (size_t)n_file_samples, hipMemcpyHostToDevice));
+  return RVT_OK;
+}
+
+int rvt_vcf_set_hemi(rvt_ctx* c, int M, const int* hemi) {
+  if (!c || M < 0 || (M > 0 && !hemi)) return RVT_E_INVALID;
+  if (M > 0 && !c->d_vcf_sex) return fail(c, RVT_E_STATE, "rvt_vcf_set_sex first");
+  c->vcf_hemi.assign(hemi, hemi + M);
   return RVT_OK;
 }
 

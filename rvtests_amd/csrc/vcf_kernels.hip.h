@@ -27,6 +27,7 @@ struct VcfRecord {          // one record (variant) of a gene
   long long len;            // bytes
   int gt_idx, gd_idx, gq_idx;  // FORMAT indices (-1: not present)
   int alt;                     // 0: bi-allelic coding (getGenotype); a > 0: count of alternative allele a (multi-allelic mode)
+  int hemi;                    // 1: the record lies in a hemizygous region (ParRegion::isHemiRegion): males are recoded
 };
 struct VcfFilters {
   int gd_min, gd_max, gq_min, gq_max;  // <= 0: off (the reference's `GDmin > 0 &&` tests)
@@ -167,6 +168,29 @@ __device__ __forceinline__ int vcf_alt_code(const char* __restrict__ t, long lon
   return g;
 }
 
+// VCFValue::getAllele1 / getAllele2 (libVcf/VCFValue.h:159-179); a byte below '0' is only reported and reads as allele 0
+__device__ __forceinline__ int vcf_allele(const char* __restrict__ t, long long p, long long e) {
+  if (p >= e) return 0;  // (allele 1 of an empty subfield: the terminator is below '0')
+  const signed char c = (signed char)t[p];
+  if (c == '.') return kVcfMissing;
+  return c < '0' ? 0 : c - '0';
+}
+// a MALE in a hemizygous region: VCFValue::getMaleNonParGenotype02 (libVcf/VCFValue.h:125-142; alt = 0) or
+// countMaleNonParAltAllele2 (:214-236; alt > 0) — haploid calls count double, diploid calls must be homozygous
+__device__ __forceinline__ int vcf_male_code(const char* __restrict__ t, long long b, long long e, int alt) {
+  const int g = vcf_allele(t, b, e);
+  if (g == kVcfMissing) return kVcfMissing;
+  if (e - b == 1) {
+    if (alt > 0) return g == alt ? 2 : 0;
+    return g == 0 ? 0 : (g == 1 ? 2 : kVcfMissing);
+  }
+  if (b + 2 >= e) return kVcfMissing;
+  const int g2 = vcf_allele(t, b + 2, e);
+  if (g2 == kVcfMissing || g != g2) return kVcfMissing;
+  if (alt > 0) return g == alt ? 2 : 0;
+  return g == 0 ? 0 : (g == 1 ? 2 : kVcfMissing);
+}
+
 // atoi() of the subfield (NUL-terminated at its end in the reference)
 __device__ __forceinline__ int vcf_atoi(const char* __restrict__ t, long long b, long long e) {
   while (b < e && (t[b] == ' ' || (t[b] >= '\t' && t[b] <= '\r'))) ++b;
@@ -178,11 +202,19 @@ __device__ __forceinline__ int vcf_atoi(const char* __restrict__ t, long long b,
   return neg ? -(int)v : (int)v;
 }
 
+// sex: PLINK code of the sample (1 male, 2 female, else unknown); only looked at in a hemizygous record
+// (src/VCFGenotypeExtractor.cpp:416-426: males through the non-PAR rule, females as usual, unknown sex -> missing)
 __device__ __forceinline__ int vcf_decode_column(const char* __restrict__ t, long long start, long long len,
-                                                 const VcfRecord& r, const VcfFilters& f) {
+                                                 const VcfRecord& r, const VcfFilters& f, int sex) {
   long long b, e;
   int g = kVcfMissing;
-  if (vcf_subfield(t, start, len, r.gt_idx, &b, &e))  // else "." -> missing
+  if (r.hemi && sex != 2) {
+    if (sex == 1 && r.gt_idx >= 0) {
+      if (vcf_subfield(t, start, len, r.gt_idx, &b, &e))
+        g = vcf_male_code(t, b, e, r.alt);
+      // (an absent subfield reads the default value ".": missing)
+    }
+  } else if (vcf_subfield(t, start, len, r.gt_idx, &b, &e))  // else "." -> missing
     g = r.alt > 0 ? vcf_alt_code(t, b, e, r.alt) : vcf_gt_code(t, b, e);
   if (f.gd_min > 0 || f.gd_max > 0) {                                            // checkGD (:304-310)
     const int gd = vcf_subfield(t, start, len, r.gd_idx, &b, &e) ? vcf_atoi(t, b, e) : 0;  // atoi(".") = 0
@@ -272,7 +304,8 @@ __device__ __forceinline__ double vcf_atof(const char* __restrict__ t, long long
 __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __restrict__ text,
                                                                 const VcfRecord* __restrict__ rec, int max_seg,
                                                                 const int* __restrict__ seg_count,
-                                                                const int* __restrict__ row_of_sample, int n_file_samples,
+                                                                const int* __restrict__ row_of_sample,
+                                                                const signed char* __restrict__ sex, int n_file_samples,
                                                                 long long ld, VcfFilters flt, double* __restrict__ out,
                                                                 int* __restrict__ err) {
   const VcfRecord r = rec[blockIdx.y];
@@ -294,9 +327,10 @@ __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __re
   int k = seg_count[(long long)blockIdx.y * max_seg + blockIdx.x] + x - n;
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) k += ws[w];
   int inexact = 0;
-  auto column = [&](long long start) {
+  auto column = [&](long long start, int s) {
     long long b, e;
     double g = vcf_subfield(t, start, r.len, r.gt_idx, &b, &e) ? vcf_atof(t, b, e, &inexact) : 0.0;
+    if (r.hemi && sex && sex[s] == 1) g = g * 2.0;  // a male's dosage in a hemizygous region (exact)
     if (r.gt_idx < 0) g = (double)kVcfMissing;  // "Cannot find <tag> field!"
     if (flt.gd_min > 0 || flt.gd_max > 0) {
       const int gd = vcf_subfield(t, start, r.len, r.gd_idx, &b, &e) ? vcf_atoi(t, b, e) : 0;
@@ -310,7 +344,7 @@ __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __re
   };
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_file_samples > 0) {
     const int row = row_of_sample[0];
-    if (row >= 0) col[row] = column(0);
+    if (row >= 0) col[row] = column(0, 0);
   }
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -322,7 +356,7 @@ __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __re
       ++k;
       if (s < n_file_samples) {
         const int row = row_of_sample[s];
-        if (row >= 0) col[row] = column(pos + 4 * w + (bit >> 3) + 1);
+        if (row >= 0) col[row] = column(pos + 4 * w + (bit >> 3) + 1, s);
       }
     }
   }
@@ -332,7 +366,8 @@ __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __re
 // pass 3: decode.  grid (max segments, records), 256 threads.  out: [record][n_rows] signed bytes, pre-filled with -9
 __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict__ text, const VcfRecord* __restrict__ rec,
                                                          int max_seg, const int* __restrict__ seg_count,
-                                                         const int* __restrict__ row_of_sample, int n_file_samples,
+                                                         const int* __restrict__ row_of_sample,
+                                                         const signed char* __restrict__ sex, int n_file_samples,
                                                          long long n_rows, VcfFilters flt, signed char* __restrict__ out) {
   const VcfRecord r = rec[blockIdx.y];
   const long long seg0 = (long long)blockIdx.x * kVcfSegBytes;
@@ -354,7 +389,7 @@ __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict_
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) k += ws[w];
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_file_samples > 0) {  // the first column has no tab in front of it
     const int row = row_of_sample[0];
-    if (row >= 0) col[row] = (signed char)vcf_decode_column(t, 0, r.len, r, flt);
+    if (row >= 0) col[row] = (signed char)vcf_decode_column(t, 0, r.len, r, flt, sex ? sex[0] : 0);
   }
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -366,7 +401,8 @@ __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict_
       ++k;
       if (s < n_file_samples) {
         const int row = row_of_sample[s];
-        if (row >= 0) col[row] = (signed char)vcf_decode_column(t, pos + 4 * w + (bit >> 3) + 1, r.len, r, flt);
+        if (row >= 0)
+          col[row] = (signed char)vcf_decode_column(t, pos + 4 * w + (bit >> 3) + 1, r.len, r, flt, sex ? sex[s] : 0);
       }
     }
   }

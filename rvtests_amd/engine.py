@@ -538,6 +538,20 @@ class Engine:
         self.L.rvt_vcf_set_alt_alleles.restype = C.c_int
         self._check(self.L.rvt_vcf_set_alt_alleles(self.ctx, len(a), a.ctypes.data_as(c_int_p)))
 
+    def vcf_set_sex(self, sex):
+        """PLINK sex code (1 male, 2 female, else unknown) of every FILE sample; used in hemizygous records only."""
+        a = np.ascontiguousarray(sex, dtype=np.int8)
+        self.L.rvt_vcf_set_sex.restype = C.c_int
+        self.L.rvt_vcf_set_sex.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._check(self.L.rvt_vcf_set_sex(self.ctx, len(a), a.ctypes.data))
+
+    def vcf_set_hemi(self, hemi):
+        """hemi[j] != 0: record j of the NEXT vcf_decode / submit_gene_vcf call lies in a hemizygous region."""
+        a = np.ascontiguousarray(hemi, dtype=np.int32)
+        self.L.rvt_vcf_set_hemi.restype = C.c_int
+        self.L.rvt_vcf_set_hemi.argtypes = [C.c_void_p, C.c_int, c_int_p]
+        self._check(self.L.rvt_vcf_set_hemi(self.ctx, len(a), a.ctypes.data_as(c_int_p)))
+
     def vcf_set_dosage(self, on=True):
         self._check(self.L.rvt_vcf_set_dosage(self.ctx, 1 if on else 0))
 

@@ -28,7 +28,15 @@ for alt in (1, 2):                       # VCFValue::countAltAllele(alt) of subf
         c = R.ref_vcf_column_alt(col, len(col), 0, alt)
         s.append("m" if c < 0 else str(c))
     alt_codes[str(alt)] = "".join(s)
+male_codes = {}                          # hemizygous regions, males: getMaleNonParGenotype02 ("0") and
+for alt in (0, 1, 2):                    # countMaleNonParAltAllele2(alt) ("1", "2"; release build: asserts compiled out)
+    s = []
+    for col in cols:
+        c = R.ref_vcf_column_male02(col, len(col), 0) if alt == 0 else R.ref_vcf_column_male_alt(col, len(col), 0, alt)
+        s.append("m" if c < 0 else str(c))
+    male_codes[str(alt)] = "".join(s)
 out = {"alphabet": ALPHABET.decode(), "max_len": 4, "n_columns": len(cols), "codes": codes, "alt_codes": alt_codes,
+       "male_codes": male_codes,
        "source": "libVcf/VCFIndividual.h:27-58,88-93 + libVcf/VCFValue.h:74-117 compiled from /root/reference"}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vcf_genotype.json")
 json.dump(out, open(path, "w"))

@@ -467,6 +467,10 @@ def ref_vcf():
         R.ref_vcf_column_genotype.argtypes = [C.c_char_p, C.c_int, C.c_int]
         R.ref_vcf_column_alt.restype = C.c_int
         R.ref_vcf_column_alt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        R.ref_vcf_column_male02.restype = C.c_int
+        R.ref_vcf_column_male02.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        R.ref_vcf_column_male_alt.restype = C.c_int
+        R.ref_vcf_column_male_alt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
         R.ref_vcf_column_int.restype = C.c_int
         R.ref_vcf_column_int.argtypes = [C.c_char_p, C.c_int, C.c_int]
         _ref_vcf = R
@@ -478,6 +482,53 @@ def vcf_column_genotype(col, gt_idx):
     L.orc_vcf_column_genotype.restype = C.c_int
     L.orc_vcf_column_genotype.argtypes = [C.c_char_p, C.c_int64, C.c_int]
     return L.orc_vcf_column_genotype(col, len(col), gt_idx)
+
+
+def vcf_column_male02(col, gt_idx):
+    L = lib()
+    L.orc_vcf_column_male02.restype = C.c_int
+    L.orc_vcf_column_male02.argtypes = [C.c_char_p, C.c_int64, C.c_int]
+    return L.orc_vcf_column_male02(col, len(col), gt_idx)
+
+
+def vcf_column_male_alt(col, gt_idx, alt):
+    L = lib()
+    L.orc_vcf_column_male_alt.restype = C.c_int
+    L.orc_vcf_column_male_alt.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int]
+    return L.orc_vcf_column_male_alt(col, len(col), gt_idx, alt)
+
+
+def vcf_decode_record_sex(text, row_of_sample, n_rows, gt_idx, gd_idx=-1, gq_idx=-1, filters=(0, 0, 0, 0), alt=0, hemi=0,
+                          sex=None):
+    """vcf_decode_record with the multi-allelic allele, the record's hemizygous flag and the file samples' PLINK sex."""
+    L = lib()
+    L.orc_vcf_decode_record_sex.restype = C.c_int
+    L.orc_vcf_decode_record_sex.argtypes = [C.c_char_p, C.c_int64, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, c_int_p,
+                                            C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int8)]
+    rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)
+    flt = np.ascontiguousarray(filters, dtype=np.int32)
+    sx = None if sex is None else np.ascontiguousarray(sex, dtype=np.int8)
+    out = np.full(n_rows, -9, dtype=np.int8)
+    n = L.orc_vcf_decode_record_sex(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), gt_idx, gd_idx, gq_idx,
+                                    flt.ctypes.data_as(c_int_p), alt, hemi, None if sx is None else sx.ctypes.data,
+                                    out.ctypes.data_as(C.POINTER(C.c_int8)))
+    return out, n
+
+
+def vcf_decode_record_dosage_sex(text, row_of_sample, n_rows, tag_idx, gd_idx=-1, gq_idx=-1, filters=(0, 0, 0, 0), hemi=0,
+                                 sex=None):
+    L = lib()
+    L.orc_vcf_decode_record_dosage_sex.restype = C.c_int
+    L.orc_vcf_decode_record_dosage_sex.argtypes = [C.c_char_p, C.c_int64, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int,
+                                                   c_int_p, C.c_int, C.c_void_p, c_double_p]
+    rows = np.ascontiguousarray(row_of_sample, dtype=np.int32)
+    flt = np.ascontiguousarray(filters, dtype=np.int32)
+    sx = None if sex is None else np.ascontiguousarray(sex, dtype=np.int8)
+    out = np.full(n_rows, -9.0, dtype=np.float64)
+    n = L.orc_vcf_decode_record_dosage_sex(text, len(text), len(rows), rows.ctypes.data_as(c_int_p), tag_idx, gd_idx,
+                                           gq_idx, flt.ctypes.data_as(c_int_p), hemi,
+                                           None if sx is None else sx.ctypes.data, out.ctypes.data_as(c_double_p))
+    return out, n
 
 
 def vcf_format_index(fmt, key):

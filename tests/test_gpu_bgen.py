@@ -130,3 +130,16 @@ def test_short_block_is_reported(eng):
     with pytest.raises(Exception):
         eng.bgen_decode([bytes(lied)], 2, N)
     assert np.array_equal(eng.bgen_decode([good], 2, N), _oracle_matrix([good], 2, N))
+
+
+def test_multi_allelic_mode_only_knows_the_first_alternative_allele(eng):
+    """getGenotypeForAltAllele (src/BGenGenotypeExtractor.cpp:470-482): alt > 1 -> every sample missing, alt = 1 -> getGenotype."""
+    rng = np.random.default_rng(9)
+    N = 1500
+    blocks = [bgengen.layout2_block(rng, N, 8, K=3, missing=0.01) for _ in range(3)]
+    eng.vcf_set_alt_alleles([1, 2, 0])
+    got = eng.bgen_decode(blocks, 2, N)
+    want = _oracle_matrix(blocks, 2, N)
+    want[:, 1] = -9.0
+    assert np.array_equal(got, want)
+    assert np.array_equal(eng.bgen_decode(blocks, 2, N), _oracle_matrix(blocks, 2, N))     # consumed

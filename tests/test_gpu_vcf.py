@@ -212,3 +212,47 @@ def test_multi_allelic_mode_counts_the_requested_allele(eng):
         assert got[:, j].tolist() == want
     again = eng.vcf_decode(recs[:1], n_file)                 # the setting was consumed: bi-allelic coding again
     assert again[:, 0].tolist() == [orc.vcf_column_genotype(c_, 0) for c_ in recs[0][e.vcf_locate(eng.L, recs[0])[0]:].split(b"\t")]
+
+
+def test_hemizygous_records_recode_males(eng):
+    """rvt_vcf_set_sex / rvt_vcf_set_hemi: in a hemizygous record males go through getMaleNonParGenotype02 (or
+    countMaleNonParAltAllele2 in multi-allelic mode), females through the ordinary rule, unknown sex is missing; the GD /
+    GQ filters apply afterwards; records not flagged are untouched; the flags are consumed by one call."""
+    rng = np.random.default_rng(31)
+    n_file, n_keep = 4000, 3100
+    rows = _sample_map(rng, n_file, n_keep)
+    sex = rng.choice(np.array([1, 2, 0, 9], dtype=np.int8), size=n_file, p=[0.45, 0.45, 0.05, 0.05])
+    fmts = [b"GT", b"GT:GD:GQ", b"DP:GT", b"GT"]
+    lines = [vcfgen.make_record(rng, n_file, fmt=fmts[j % 4], edge=0.3, chrom=b"X", pos=5000 + j) for j in range(6)]
+    hemi = [1, 1, 0, 1, 1, 0]
+    alts = [0, 0, 0, 1, 2, 1]
+    filters = (0, 0, 10, 0)
+    eng.vcf_set_samples(rows)
+    eng.vcf_set_sex(sex)
+    eng.vcf_set_filters(*filters)
+    eng.vcf_set_hemi(hemi)
+    eng.vcf_set_alt_alleles(alts)
+    got = eng.vcf_decode(lines, n_keep)
+    import rvtests_amd.engine as e
+    for j, ln in enumerate(lines):
+        off, gt, gd, gq = e.vcf_locate(eng.L, ln)
+        want, n = orc.vcf_decode_record_sex(ln[off:], rows, n_keep, gt, gd, gq, filters, alt=alts[j], hemi=hemi[j], sex=sex)
+        assert n == n_file and got[:, j].tolist() == want.tolist(), j
+    plain = eng.vcf_decode(lines[:2], n_keep)                 # consumed: the same records without flags
+    for j in range(2):
+        off, gt, gd, gq = e.vcf_locate(eng.L, lines[j])
+        want, _ = orc.vcf_decode_record(lines[j][off:], rows, n_keep, gt, gd, gq, filters)
+        assert plain[:, j].tolist() == want.tolist()
+    assert (got[:, 1] != plain[:, 1]).any() and (got[:, 1] >= 0).any()
+    # dosage mode: a male's value is doubled in a hemizygous record
+    vals = rng.choice([b"0", b"0.5", b"1", b"0.125", b"1e-1", b"."], size=n_file)
+    head = b"\t".join([b"X", b"9", b".", b"A", b"G", b"50", b"PASS", b".", b"DS"])
+    rec = head + b"\t" + b"\t".join(vals.tolist())
+    eng.vcf_set_filters(0, 0, 0, 0)
+    eng.vcf_set_dosage(True)
+    eng.vcf_set_hemi([1])
+    d = eng.vcf_decode_dosage([rec], b"DS", n_keep)
+    eng.vcf_set_dosage(False)
+    off = e.vcf_locate(eng.L, rec)[0]
+    want, _ = orc.vcf_decode_record_dosage_sex(rec[off:], rows, n_keep, 0, hemi=1, sex=sex)
+    assert np.array_equal(d[:, 0], want)

@@ -55,6 +55,35 @@ def test_alt_allele_rule_matches_golden_and_reference():
                     assert orc.vcf_column_alt(col, 0, a) == R.ref_vcf_column_alt(col, len(col), 0, a), (col, a)
 
 
+def test_male_hemizygous_rules_match_golden_and_reference():
+    """Hemizygous regions: VCFValue::getMaleNonParGenotype02 and countMaleNonParAltAllele2 for males; the sample loop sends
+    females through the ordinary rule, unknown sex to missing, and doubles a male's dosage."""
+    g = json.load(open(GOLDEN))
+    cols = list(enumerate_columns(4))
+    for alt in (0, 1, 2):
+        got = "".join("m" if (c := (orc.vcf_column_male02(col, 0) if alt == 0 else orc.vcf_column_male_alt(col, 0, alt))) < 0
+                      else str(c) for col in cols)
+        assert got == g["male_codes"][str(alt)]
+    R = orc.ref_vcf()
+    if R is not None:
+        for col in list(enumerate_columns(3)) + [b"1/1/1", b"1x1", b"12", b"9|9", b"3/3", b"2|.", b"x/2", b"1", b"2", b"A"]:
+            if col.endswith(b":"):
+                continue
+            assert orc.vcf_column_male02(col, 0) == R.ref_vcf_column_male02(col, len(col), 0), col
+            for a in (1, 2, 3, 9):
+                assert orc.vcf_column_male_alt(col, 0, a) == R.ref_vcf_column_male_alt(col, len(col), 0, a), (col, a)
+    text = b"0/1\t1/1\t1\t0|0\t1/1\t0/1\t1"
+    rows = np.arange(7, dtype=np.int32)
+    sex = np.array([1, 1, 1, 1, 2, 2, 0], dtype=np.int8)
+    out, n = orc.vcf_decode_record_sex(text, rows, 7, 0, hemi=1, sex=sex)
+    assert n == 7 and out.tolist() == [-9, 2, 2, 0, 2, 1, -9]      # male het -> missing, unknown sex -> missing
+    out, n = orc.vcf_decode_record_sex(text, rows, 7, 0, hemi=0, sex=sex)
+    assert out.tolist() == [1, 2, 1, 0, 2, 1, 1]
+    d, n = orc.vcf_decode_record_dosage_sex(b"0.25\t0.5\t1.5", np.arange(3, dtype=np.int32), 3, 0, hemi=1,
+                                            sex=np.array([1, 2, 0], dtype=np.int8))
+    assert d.tolist() == [0.5, 0.5, 1.5]
+
+
 def test_oracle_matches_compiled_reference_exhaustively():
     R = orc.ref_vcf()
     if R is None:
