@@ -336,6 +336,13 @@ int rvt_rand_seed(rvt_ctx* ctx, unsigned seed);
  *                   beta_pdf(FastGetAF; 1, 25) (FastLMM.cpp:402-443), Q, eigenvalues of wg P0 wg', Davies only.
  *                   Fills n_variants, n_poly, famskat_ok / famskat_Q / famskat_p of each record.  Synchronous. */
 int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
+/* Structure of the installed eigenvectors.  The kinship of unrelated families is block diagonal, and then so is U: every
+ * eigenvector is non-zero on one family's samples only.  rvt_set_kinship detects that (first / last non-zero row of each
+ * column), re-orders the eigenpairs by support — the statistics do not depend on their order — and the rotation U'G then
+ * visits only the K chunks that hold non-zeros: visited_fraction = the share of the N x N product that is computed
+ * (1 = dense U, e.g. a GRM's eigenvectors; ~4 / 782 for nuclear families at N = 100 000).  The skipped parts are exact
+ * zeros, so the results are those of the dense product.  RVT_KINSHIP_DENSE=1 in the environment disables the detection. */
+int rvt_kinship_structure(rvt_ctx* ctx, double* visited_fraction);
 int rvt_fit_fam_null(rvt_ctx* ctx, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
 int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
                        rvt_gene_result* out);

@@ -57,14 +57,13 @@ template <int WM, int WN, int TM, int TN, int NST, int MINB>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
     const int8_t* __restrict__ A0, const int8_t* __restrict__ B0, long long ldk, long long kbytes0, double* __restrict__ C0,
     long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
-    const double* __restrict__ row_scale, double weight, int accumulate, long long kslice, long long c_slice) {
+    const double* __restrict__ row_scale, double weight, int accumulate, long long kslice, long long c_slice,
+    const int2* __restrict__ a_krange) {
   constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
   // split K: slice blockIdx.y covers K bytes [y kslice, (y + 1) kslice) and writes its own result at C0 + y c_slice
-  const long long k_off = (long long)blockIdx.y * kslice;
-  const int8_t* __restrict__ A = A0 + k_off;
-  const int8_t* __restrict__ B = B0 + k_off;
+  long long k_off = (long long)blockIdx.y * kslice;
   double* __restrict__ C = C0 + (long long)blockIdx.y * c_slice;
-  const long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
+  long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
   constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
   constexpr int kStage = (BM + BN) * kRotKC;
   static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
@@ -76,6 +75,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
   const int ctg = set % n_ctg, rpg = set / n_ctg;
   const int rp = (rpg * 8 + xcd) * 4 + (within & 3), ct = ctg * 8 + (within >> 2);
   if (rp >= n_row_panels || ct >= n_col_tiles) return;
+  if (a_krange) {  // structured A (a block-diagonal kinship's eigenvectors): K chunks [x, y) hold every non-zero of this
+    const int2 kr = a_krange[rp];  // row panel — the rest contributes exact zeros and is skipped
+    const long long lo = (long long)kr.x * kRotKC, hi = (long long)kr.y * kRotKC;
+    const long long b = k_off > lo ? k_off : lo, e = (k_off + kbytes < hi) ? k_off + kbytes : hi;
+    k_off = b;
+    kbytes = e > b ? e - b : 0;
+  }
+  const int8_t* __restrict__ A = A0 + k_off;
+  const int8_t* __restrict__ B = B0 + k_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const long long m0 = (long long)rp * BM, n0 = (long long)ct * BN;
@@ -102,8 +110,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
   const long long nchunks = kbytes / kRotKC;
+  if (nchunks > 0) {
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
+    for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
+  }
   const int lrow = lane & 31, lk = lane >> 5;
   int cur = 0;
   for (long long kc = 0; kc < nchunks; ++kc) {
@@ -164,9 +174,125 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
   }
 }
 
+// Structured A (a_krange, see above): a row panel meets only a few K chunks, so one plane pair is a handful of matrix
+// instructions per tile and the fp64 read-modify-write of C (8 bytes per output per plane pair) would dominate.  This
+// variant walks ALL planes of A inside the kernel — int32 tile per plane, folded into fp64 registers with the plane's
+// weight, least significant plane first: the same sums in the same order as one launch per plane — and writes C once.
+// One LDS stage (the K loop is too short to pipeline), 8 waves as WM x WN, TM x TN tiles per wave.
+// C[m + j ldc] = (accumulate ? C : 0) + sum_p (double)acc_p 128^p * weight * col_scale[j]
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void rot_gemm_i8_short_kernel(
+    const int8_t* __restrict__ A0, long long a_plane_stride, int planes_a, const int8_t* __restrict__ B0, long long ldk,
+    long long kbytes0, double* __restrict__ C, long long ldc, int M, int N, int n_row_panels, int n_col_tiles,
+    const double* __restrict__ col_scale, double weight, int accumulate, const int2* __restrict__ a_krange) {
+  constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;
+  static_assert(kPieces % kWaves == 0 && BM == kRotBM, "row panels are kRotBM rows");
+  __shared__ __attribute__((aligned(1024))) char lds[(BM + BN) * kRotKC];
+  const int bid = blockIdx.x, xcd = bid & 7, w = bid >> 3;
+  const int n_ctg = (n_col_tiles + 7) / 8;
+  const int set = w >> 5, within = w & 31;
+  const int ctg = set % n_ctg, rpg = set / n_ctg;
+  const int rp = (rpg * 8 + xcd) * 4 + (within & 3), ct = ctg * 8 + (within >> 2);
+  if (rp >= n_row_panels || ct >= n_col_tiles) return;
+  const int2 kr = a_krange[rp];
+  long long k_lo = (long long)kr.x * kRotKC, k_hi = (long long)kr.y * kRotKC;
+  if (k_hi > kbytes0) k_hi = kbytes0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long m0 = (long long)rp * BM, n0 = (long long)ct * BN;
+  const int8_t* gsrc[PPW];
+  bool is_a[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int P = wave + kWaves * q;
+    const int r = 8 * P + (lane >> 3), slot = lane & 7, seg = slot ^ ((r >> 1) & 7);
+    is_a[q] = r < BM;
+    gsrc[q] = (r < BM ? A0 + (m0 + r) * ldk : B0 + (n0 + (r - BM)) * ldk) + seg * 16;
+  }
+  double accd[TM][TN][16];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accd[a][b][e] = 0.0;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const char* la = &lds[0];
+  const char* lb = &lds[BM * 128];
+  double pw = 1.0;  // 128^p
+  for (int p = 0; p < planes_a; ++p, pw *= 128.0) {
+    i16v_t acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+    for (long long kb = k_lo; kb < k_hi; kb += kRotKC) {
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        const int P = wave + kWaves * q;
+        const int8_t* src = gsrc[q] + kb + (is_a[q] ? (long long)p * a_plane_stride : 0ll);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(&lds[1024 * P]), 16, 0, 0);
+      }
+      rot_wait_vm_barrier<0>();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        i4v_t fa[TM], fb[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+          fa[a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          fb[b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read this chunk before the next lands
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accd[a][b][e] += (double)acc[a][b][e] * pw;  // (exact product, one rounding per sum)
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const long long j = n0 + wn * 32 * TN + b * 32 + (lane & 31);
+    if (j >= N) continue;
+    const double sc = weight * col_scale[j];
+    double* cj = C + j * ldc;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long long m = m0 + wm * 32 * TM + a * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (m + e < M) {
+            const double v = accd[a][b][4 * g + e] * sc;
+            cj[m + e] = accumulate ? cj[m + e] + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+constexpr int kRotShortBN = 128;  // column tile of the short-K kernel (<4, 2, 2, 2>: 256 x 128 per workgroup)
+#define rot_gemm_i8_short (rot_gemm_i8_short_kernel<4, 2, 2, 2>)
+
 // the shipped configuration
-#define rot_gemm_i8_kernel (rot_gemm_i8_kernel_t<2, 4, 4, 2, 2, 1>)
-constexpr int kRotThreads = 512;
+#ifndef RVT_ROT_CFG
+#define RVT_ROT_CFG 2, 4, 4, 2, 2, 1
+#define RVT_ROT_THREADS 512
+#endif
+#define rot_gemm_i8_kernel (rot_gemm_i8_kernel_t<RVT_ROT_CFG>)
+constexpr int kRotThreads = RVT_ROT_THREADS;
 
 // C[m + j ldc] = (accumulate ? C : 0) + sum over slices of part[s * stride + m + j ldc], m < M, j < N (fixed order:
 // reproducible; rows M .. ldc-1 of C are not touched)
@@ -209,6 +335,41 @@ __global__ void rot_quantize_f32_kernel(const float* __restrict__ src, long long
     rot_digits(llrint(v), planes, d);
     for (int p = 0; p < planes; ++p) dst[p * plane_stride + (col0 + j) * ldk + i] = d[p];
   }
+}
+
+// first / last row with a non-zero entry per column of a float matrix (lo = n, hi = -1 for an all-zero column)
+__global__ void rot_span_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ lo,
+                                int* __restrict__ hi) {
+  __shared__ int slo[256], shi[256];
+  const float* s = src + (long long)blockIdx.x * ld_src;
+  int l = (int)n, h = -1;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x)
+    if (s[i] != 0.0f) {
+      l = l < (int)i ? l : (int)i;
+      h = h > (int)i ? h : (int)i;
+    }
+  slo[threadIdx.x] = l;
+  shi[threadIdx.x] = h;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      slo[threadIdx.x] = min(slo[threadIdx.x], slo[threadIdx.x + w]);
+      shi[threadIdx.x] = max(shi[threadIdx.x], shi[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    lo[blockIdx.x] = slo[0];
+    hi[blockIdx.x] = shi[0];
+  }
+}
+
+// dst row r = src row order[r] of a [rows][ldk] byte matrix (ldk a multiple of 16); grid = rows
+__global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, const int* __restrict__ order, long long ldk,
+                                       signed char* __restrict__ dst) {
+  const uint4* s = reinterpret_cast<const uint4*>(src + (long long)order[blockIdx.x] * ldk);
+  uint4* d = reinterpret_cast<uint4*>(dst + (long long)blockIdx.x * ldk);
+  for (long long i = threadIdx.x; i < ldk / 16; i += blockDim.x) d[i] = s[i];
 }
 
 // per-column max |x| of a double matrix (column-major, ld)

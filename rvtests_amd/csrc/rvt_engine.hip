@@ -97,6 +97,8 @@ struct rvt_ctx {
   // eigenvectors of the kinship as kRotPlanesU signed base-128 digit planes (rot_gemm.hip.h): plane p at
   // d_Uq + p * uq_plane, row k (= column k of U) at k * uq_ldk; scaled by 2^uq_sexp
   signed char* d_Uq = nullptr;
+  int2* d_uq_range = nullptr;  // per 256-row panel of the planes: K chunks [x, y) that hold its non-zeros; null = dense U
+  double uq_visit = 1.0;       // fraction of the K chunks the rotation visits (1 = dense)
   size_t uq_plane = 0;
   int64_t uq_ldk = 0, uq_rows_pad = 0;
   int uq_sexp = 0;
@@ -633,6 +635,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
   if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
   if (c->d_Uq) hipFree(c->d_Uq);
+  if (c->d_uq_range) hipFree(c->d_uq_range);
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_part) hipFree(c->d_rot_part);
@@ -1529,6 +1532,9 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   }
   if (c->d_Uq) hipFree(c->d_Uq);
   c->d_Uq = nullptr;
+  if (c->d_uq_range) hipFree(c->d_uq_range);
+  c->d_uq_range = nullptr;
+  c->uq_visit = 1.0;
   c->have_kin = c->have_fam = false;
   HIP_TRY(c, hipMalloc((void**)&c->d_S, sizeof(double) * N));
   HIP_TRY(c, hipMalloc((void**)&c->d_u1, sizeof(double) * N));
@@ -1539,11 +1545,13 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   c->uq_sexp = 7 * kRotPlanesU - 3;
   HIP_TRY(c, hipMalloc((void**)&c->d_Uq, c->uq_plane * kRotPlanesU));
   HIP_TRY(c, hipMemsetAsync(c->d_Uq, 0, c->uq_plane * kRotPlanesU, c->stream));
+  int* d_span = nullptr;  // first / last non-zero row of every column of U
   {  // whole columns at a time through a bounded staging buffer (the caller's U can be tens of GB): digits + column sums
     const int64_t cols_per = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)256 << 20) / N));
     float* d_tmp = nullptr;
     double* d_tmp64 = nullptr;
     int* d_flag = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_span, sizeof(int) * 2 * (size_t)N));
     HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(float) * (size_t)cols_per * N));
     HIP_TRY(c, hipMalloc((void**)&d_tmp64, sizeof(double) * (size_t)cols_per * N));
     HIP_TRY(c, hipMalloc((void**)&d_flag, sizeof(int)));
@@ -1556,6 +1564,8 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
       hipLaunchKernelGGL(rot_quantize_f32_kernel, dim3(2048), dim3(256), 0, c->stream, d_tmp, (long long)N, (long long)nc,
                          (long long)N, c->uq_sexp, kRotPlanesU, c->d_Uq, (long long)c->uq_ldk, (long long)c->uq_plane,
                          (long long)k0, d_flag);
+      hipLaunchKernelGGL(rot_span_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp, (long long)N, (long long)N,
+                         d_span + k0, d_span + N + k0);
       hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, d_tmp64, n);
       hipLaunchKernelGGL(column_sums_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp64, (long long)N,
                          (long long)N, c->d_u1 + k0);
@@ -1566,15 +1576,85 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     hipFree(d_tmp);
     hipFree(d_tmp64);
     hipFree(d_flag);
-    if (bad) return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
+    if (bad) {
+      hipFree(d_span);
+      return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
+    }
   }
   c->h_S.resize(N);
   for (int64_t i = 0; i < N; ++i) c->h_S[i] = (double)S[i];
-  HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
   c->h_u1.resize(N);
   HIP_TRY(c, hipMemcpy(c->h_u1.data(), c->d_u1, sizeof(double) * N, hipMemcpyDeviceToHost));
+  {
+    // Structure of U.  A kinship matrix of unrelated families is block diagonal and so are its eigenvectors: column k
+    // of U is non-zero on the rows [lo_k, hi_k] of one family only.  The statistics do not depend on the ORDER of the
+    // eigenpairs, so they are re-ordered by lo_k (stable; a dense U keeps its order): a 256-row panel of the planes
+    // then holds eigenvectors of neighbouring families, its non-zeros fall into a few K chunks, and the rotation GEMM
+    // visits only those (rot_gemm.hip.h: a_krange).  Exact — the skipped chunks are exact zeros.
+    std::vector<int> span(2 * (size_t)N);
+    HIP_TRY(c, hipMemcpy(span.data(), d_span, sizeof(int) * 2 * (size_t)N, hipMemcpyDeviceToHost));
+    hipFree(d_span);
+    d_span = nullptr;
+    const int* lo = span.data();
+    const int* hi = span.data() + N;
+    std::vector<int> order((size_t)N);
+    for (int64_t k = 0; k < N; ++k) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lo[a] < lo[b]; });
+    const int64_t nrp = c->uq_rows_pad / kRotBM, nchunk = c->uq_ldk / kRotKC;
+    std::vector<int2> range((size_t)nrp);
+    double visited = 0.0;
+    for (int64_t rp = 0; rp < nrp; ++rp) {
+      int l = (int)N, h = -1;
+      for (int64_t r = rp * kRotBM; r < std::min<int64_t>(N, (rp + 1) * kRotBM); ++r) {
+        l = std::min(l, lo[order[r]]);
+        h = std::max(h, hi[order[r]]);
+      }
+      range[rp] = (h < l) ? int2{0, 0} : int2{l / kRotKC, h / kRotKC + 1};
+      visited += range[rp].y - range[rp].x;
+    }
+    const double frac = visited / ((double)nrp * (double)nchunk);
+    if (frac < 0.5 && !getenv("RVT_KINSHIP_DENSE")) {
+      bool identity = true;
+      for (int64_t k = 0; k < N && identity; ++k) identity = order[k] == (int)k;
+      if (!identity) {  // re-order the rows of every plane (one plane-sized scratch buffer) and S, U'1 with them
+        signed char* d_scratch = nullptr;
+        int* d_order = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d_scratch, c->uq_plane));
+        HIP_TRY(c, hipMalloc((void**)&d_order, sizeof(int) * (size_t)N));
+        HIP_TRY(c, hipMemcpy(d_order, order.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
+        for (int p = 0; p < kRotPlanesU; ++p) {
+          signed char* plane = c->d_Uq + (size_t)p * c->uq_plane;
+          HIP_TRY(c, hipMemcpyAsync(d_scratch, plane, (size_t)N * c->uq_ldk, hipMemcpyDeviceToDevice, c->stream));
+          hipLaunchKernelGGL(rot_gather_rows_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, d_scratch, d_order,
+                             (long long)c->uq_ldk, plane);
+        }
+        HIP_TRY(c, sync_stream(c->stream));
+        hipFree(d_scratch);
+        hipFree(d_order);
+        std::vector<double> s2((size_t)N), u2((size_t)N);
+        for (int64_t r = 0; r < N; ++r) {
+          s2[r] = c->h_S[order[r]];
+          u2[r] = c->h_u1[order[r]];
+        }
+        c->h_S.swap(s2);
+        c->h_u1.swap(u2);
+        HIP_TRY(c, hipMemcpy(c->d_u1, c->h_u1.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+      }
+      HIP_TRY(c, hipMalloc((void**)&c->d_uq_range, sizeof(int2) * (size_t)nrp));
+      HIP_TRY(c, hipMemcpy(c->d_uq_range, range.data(), sizeof(int2) * (size_t)nrp, hipMemcpyHostToDevice));
+      c->uq_visit = frac;
+    }
+  }
+  HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
   c->kin_N = N;
   c->have_kin = true;
+  return RVT_OK;
+}
+
+int rvt_kinship_structure(rvt_ctx* c, double* visited_fraction) {
+  if (!c || !visited_fraction) return RVT_E_INVALID;
+  if (!c->have_kin) return fail(c, RVT_E_STATE, "no kinship decomposition installed");
+  *visited_fraction = c->uq_visit;
   return RVT_OK;
 }
 
@@ -1767,7 +1847,7 @@ int quantize_columns(rvt_ctx* c, const double* d_src, int64_t n_rows, int64_t ld
 // row_exp (host, may be null: uniform a_exp) / col_exp: binary scale exponents of the two sides.
 int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int nA, const int* row_exp, int a_exp,
                 const signed char* B, size_t b_stride, int PB, int nB, const int* col_exp, int64_t n_rows, int64_t ldk,
-                double* C, int64_t ldc, hipStream_t st) {
+                double* C, int64_t ldc, hipStream_t st, const int2* a_krange = nullptr) {
   int rc = ensure_rot_scratch(c);
   if (rc) return rc;
   std::vector<double> cs(nB), rs;
@@ -1814,6 +1894,18 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
     }
     d_part = c->d_rot_part;
   }
+  if (a_krange && !row_exp) {
+    // structured A: every plane of A inside one launch per plane of B, C written once (rot_gemm_i8_short_kernel)
+    const int nct_s = (nB + kRotShortBN - 1) / kRotShortBN;
+    const long long sets_s = (long long)((nrp + 31) / 32) * ((nct_s + 7) / 8);
+    for (int q = 0; q < PB; ++q)
+      hipLaunchKernelGGL(rot_gemm_i8_short, dim3((unsigned)(sets_s * 256)), dim3(512), 0, st, (const int8_t*)A,
+                         (long long)a_stride, PA, (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, C,
+                         (long long)ldc, nA, nB, nrp, nct_s, c->d_rot_scale, std::ldexp(1.0, 7 * q), q > 0 ? 1 : 0, a_krange);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, sync_stream(st));
+    return RVT_OK;
+  }
   int first = 1;
   for (int sdeg = 0; sdeg <= (PA - 1) + (PB - 1); ++sdeg)  // least significant digit pairs first
     for (int p = 0; p < PA; ++p) {
@@ -1823,11 +1915,11 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
       if (slices == 1) {
         hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
                            (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, C, (long long)ldc, nA, nB, nrp,
-                           nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1, kbytes, 0LL);
+                           nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1, kbytes, 0LL, a_krange);
       } else {
         hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
                            (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, d_part, (long long)ldc, nA, nB,
-                           nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), 0, kslice, c_slice);
+                           nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), 0, kslice, c_slice, a_krange);
         hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_part, (long long)ldc, (long long)nA,
                            (long long)nB, c_slice, (int)slices, C, first ? 0 : 1);
       }
@@ -1852,7 +1944,7 @@ static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int n
                               &qb);
     if (rc) return rc;
     rc = planes_gemm(c, c->d_Uq, c->uq_plane, kRotPlanesU, (int)N, nullptr, c->uq_sexp, qb.d, qb.plane_stride, qb.planes,
-                     nc, qb.sexp.data(), N, c->uq_ldk, d_dst + (size_t)c0 * ld_dst, ld_dst, st);
+                     nc, qb.sexp.data(), N, c->uq_ldk, d_dst + (size_t)c0 * ld_dst, ld_dst, st, c->d_uq_range);
     if (rc) return rc;
   }
   return RVT_OK;

@@ -690,6 +690,14 @@ class Engine:
         self._check(self.L.rvt_set_kinship(self.ctx, N, U.ctypes.data_as(fp), S.ctypes.data_as(fp)))
         self.N = N
 
+    def kinship_structure(self):
+        """Share of the N x N rotation product that is computed (1 = dense eigenvectors; small for family structure)."""
+        f = C.c_double(0.0)
+        self.L.rvt_kinship_structure.restype = C.c_int
+        self.L.rvt_kinship_structure.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._check(self.L.rvt_kinship_structure(self.ctx, C.byref(f)))
+        return f.value
+
     def fit_fam_null(self, X, y):
         X = np.asfortranarray(X, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)

@@ -220,3 +220,53 @@ def test_rotation_k_range_cut_is_exact(monkeypatch):
             e.close()
     for (q0, p0), (q1, p1) in zip(*outs):
         assert abs(q0 - q1) <= 1e-12 * abs(q0) and abs(p0 - p1) <= 1e-9 * p0 + 1e-14
+
+
+def test_family_structure_is_detected_and_changes_nothing(monkeypatch):
+    """Block-diagonal kinship (families of mixed size, eigenpairs handed over sorted by eigenvalue, i.e. scattered over
+    the families): rvt_set_kinship clusters the eigenvectors by support and the rotation skips the zero blocks.  The
+    results must be those of the dense product (RVT_KINSHIP_DENSE=1) to rounding, and the oracle's."""
+    import rvtests_amd
+    rng = np.random.default_rng(5)
+    sizes = rng.choice([1, 2, 3, 4, 6], size=700)
+    N = int(sizes.sum())
+    U = np.zeros((N, N))
+    S = np.zeros(N)
+    o = 0
+    for sz in sizes:                                   # a random positive-definite "kinship" per family
+        A = rng.uniform(0.1, 0.5, (sz, sz))
+        Kf = (A + A.T) / 2 + np.eye(sz)
+        s, u = np.linalg.eigh(Kf)
+        U[o:o + sz, o:o + sz] = u
+        S[o:o + sz] = s
+        o += sz
+    order = np.argsort(S, kind="stable")               # what an eigen-solver hands over: ascending eigenvalues
+    U, S = np.asfortranarray(U[:, order].astype(np.float32)), S[order].astype(np.float32)
+    d = 3
+    X = np.column_stack([np.ones(N)] + [rng.standard_normal(N) for _ in range(d - 1)])
+    y = 0.3 * X[:, 1] + rng.standard_normal(N)
+    genes = [synth.make_gene(N, M, seed=800 + M, missing=0.01, common=True)[1] for M in (5, 24, 40)]
+    outs, nulls, fracs = [], [], []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("RVT_KINSHIP_DENSE", "1")
+        e = rvtests_amd.Engine(0)
+        try:
+            e.set_kinship(U, S)
+            fracs.append(e.kinship_structure())
+            nulls.append(e.fit_fam_null(X, y))
+            ptrs = [e.upload_block(G) for G in genes]
+            outs.append([(r.famskat_ok, r.n_poly, r.famskat_Q, r.famskat_p)
+                         for r in e.run_fam_blocks(ptrs, [G.shape[1] for G in genes])])
+        finally:
+            e.close()
+    assert fracs[0] < 0.25 and fracs[1] == 1.0
+    assert nulls[0].brent_evals == nulls[1].brent_evals and abs(nulls[0].delta - nulls[1].delta) <= 1e-9 * nulls[1].delta
+    for (ok0, n0, q0, p0), (ok1, n1, q1, p1) in zip(*outs):
+        assert ok0 == ok1 == 1 and n0 == n1
+        assert abs(q0 - q1) <= 1e-11 * abs(q1) and abs(p0 - p1) <= 1e-8 * p1 + 1e-14
+    rc, onul = orc.fastlmm_null(X, y, U.astype(np.float64), S.astype(np.float64))
+    assert rc == 0
+    for (ok0, n0, q0, p0), G in zip(outs[0], genes):
+        rc, s = orc.famskat(G, X, y, U.astype(np.float64), S.astype(np.float64), onul)
+        assert rc == 0 and abs(q0 - s.Q) <= 1e-6 * s.Q
