@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--genes", type=int, default=256)
     ap.add_argument("--variants", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--dense", action="store_true",
+                    help="treat U as a dense matrix (RVT_KINSHIP_DENSE=1): the rate of a GRM's eigenvectors")
     a = ap.parse_args()
     N = a.samples // 4 * 4
     rng = np.random.default_rng(4)
@@ -34,6 +36,8 @@ def main():
     X = np.column_stack([np.ones(N), rng.standard_normal(N), rng.standard_normal(N)])
     fam = np.repeat(rng.standard_normal(N // 4), 4)
     y = 0.3 * X[:, 1] - 0.2 * X[:, 2] + np.sqrt(0.4) * fam + np.sqrt(0.6) * rng.standard_normal(N)
+    if a.dense:
+        os.environ["RVT_KINSHIP_DENSE"] = "1"
     eng = rvtests_amd.Engine(0)
     t0 = time.perf_counter()
     eng.set_kinship(U, S)
@@ -62,7 +66,7 @@ def main():
         out = eng.run_fam_blocks(ptrs, Ms)
     dt = (time.perf_counter() - t0) / a.reps
     npoly = sum(r.n_poly for r in out)
-    print({"N": N, "genes": a.genes, "M": a.variants, "kinship_install_s": t_kin, "null_fit_s": t_null,
+    print({"N": N, "genes": a.genes, "M": a.variants, "rotation_visits": eng.kinship_structure(), "kinship_install_s": t_kin, "null_fit_s": t_null,
            "delta": nul.delta, "brent_evals": nul.brent_evals, "ms_per_batch": 1e3 * dt,
            "gene_sets_per_s": a.genes / dt, "rotation_TFLOPs_if_all_time": 2.0 * N * N * npoly / dt / 1e12,
            "ok": sum(r.famskat_ok for r in out)})
