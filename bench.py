@@ -38,7 +38,7 @@ import rvtests_amd  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (≈6.3 TB/s achievable)
 
 
-def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi):
+def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05):
     """Synthetic genotype blocks on the device (config 3 of SURVEY.md §8d): per-variant MAF ~ LogUniform(5e-4,
     5e-2), g ~ Binomial(2, maf); 0.1 % of genotypes missing in 5 % of the genes and imputed to the column mean
     exactly as DataConsolidator::imputeGenotypeToMean leaves them.  Returns blocks (M x ld tensors, i.e.
@@ -56,7 +56,7 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi):
             G[:, :N] += (u < maf[:, None]).to(torch.float64)
             del u
         nsample = float(N)
-        if rng.random() < 0.05:
+        if rng.random() < missing_frac:
             miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3
             Gv = G[:, :N]
             ac = torch.where(miss, torch.zeros_like(Gv), Gv).sum(1)                  # integer-valued
@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--genes", type=int, default=512, help="genes per step per GPU (512 x ~200 MB = 102 GB resident)")
     ap.add_argument("--m-lo", type=int, default=20)
     ap.add_argument("--m-hi", type=int, default=80)
+    ap.add_argument("--missing-frac", type=float, default=0.05,
+                    help="share of the genes with missing genotypes (imputed means: general fp64 kernel); SURVEY config 3: 0.05")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
@@ -332,7 +334,8 @@ def main():
     eng.fit_null(rvtests_amd.TRAIT_BINARY if binary else rvtests_amd.TRAIT_QUANTITATIVE, Xh, yh)
 
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
-    blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi)
+    blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi,
+                                 args.missing_frac)
     torch.cuda.synchronize()
     # the blocks are torch allocations: let the engine record once what each one holds (hard calls only, or also
     # imputed means) — what rvt_block_upload / rvt_submit_gene* do when they write a block themselves

@@ -57,13 +57,14 @@ template <int WM, int WN, int TM, int TN, int NST, int MINB>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
     const int8_t* __restrict__ A0, const int8_t* __restrict__ B0, long long ldk, long long kbytes0, double* __restrict__ C0,
     long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
-    const double* __restrict__ row_scale, double weight, int accumulate, long long kslice, long long c_slice,
-    const int2* __restrict__ a_krange) {
+    const double* __restrict__ row_scale, double weight, int accumulate, long long kslice, long long c_slice) {
   constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
   // split K: slice blockIdx.y covers K bytes [y kslice, (y + 1) kslice) and writes its own result at C0 + y c_slice
-  long long k_off = (long long)blockIdx.y * kslice;
+  const long long k_off = (long long)blockIdx.y * kslice;
+  const int8_t* __restrict__ A = A0 + k_off;
+  const int8_t* __restrict__ B = B0 + k_off;
   double* __restrict__ C = C0 + (long long)blockIdx.y * c_slice;
-  long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
+  const long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
   constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
   constexpr int kStage = (BM + BN) * kRotKC;
   static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
@@ -75,15 +76,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
   const int ctg = set % n_ctg, rpg = set / n_ctg;
   const int rp = (rpg * 8 + xcd) * 4 + (within & 3), ct = ctg * 8 + (within >> 2);
   if (rp >= n_row_panels || ct >= n_col_tiles) return;
-  if (a_krange) {  // structured A (a block-diagonal kinship's eigenvectors): K chunks [x, y) hold every non-zero of this
-    const int2 kr = a_krange[rp];  // row panel — the rest contributes exact zeros and is skipped
-    const long long lo = (long long)kr.x * kRotKC, hi = (long long)kr.y * kRotKC;
-    const long long b = k_off > lo ? k_off : lo, e = (k_off + kbytes < hi) ? k_off + kbytes : hi;
-    k_off = b;
-    kbytes = e > b ? e - b : 0;
-  }
-  const int8_t* __restrict__ A = A0 + k_off;
-  const int8_t* __restrict__ B = B0 + k_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const long long m0 = (long long)rp * BM, n0 = (long long)ct * BN;
@@ -110,10 +102,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
   const long long nchunks = kbytes / kRotKC;
-  if (nchunks > 0) {
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
-  }
+  for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
   const int lrow = lane & 31, lk = lane >> 5;
   int cur = 0;
   for (long long kc = 0; kc < nchunks; ++kc) {
@@ -174,7 +164,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
   }
 }
 
-// Structured A (a_krange, see above): a row panel meets only a few K chunks, so one plane pair is a handful of matrix
+// Structured A — the eigenvectors of a block-diagonal kinship after rvt_set_kinship has clustered them by support:
+// a_krange[row panel] = the K chunks [x, y) that hold every non-zero of those 256 rows; everything else contributes exact
+// zeros and is skipped.  A row panel meets only a few K chunks, so one plane pair is a handful of matrix
 // instructions per tile and the fp64 read-modify-write of C (8 bytes per output per plane pair) would dominate.  This
 // variant walks ALL planes of A inside the kernel — int32 tile per plane, folded into fp64 registers with the plane's
 // weight, least significant plane first: the same sums in the same order as one launch per plane — and writes C once.

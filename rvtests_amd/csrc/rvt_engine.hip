@@ -1915,11 +1915,11 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
       if (slices == 1) {
         hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
                            (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, C, (long long)ldc, nA, nB, nrp,
-                           nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1, kbytes, 0LL, a_krange);
+                           nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), first ? 0 : 1, kbytes, 0LL);
       } else {
         hipLaunchKernelGGL(rot_gemm_i8_kernel, grid, dim3(kRotThreads), 0, st, (const int8_t*)(A + (size_t)p * a_stride),
                            (const int8_t*)(B + (size_t)q * b_stride), (long long)ldk, kbytes, d_part, (long long)ldc, nA, nB,
-                           nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), 0, kslice, c_slice, a_krange);
+                           nrp, nct, c->d_rot_scale, d_rs, std::ldexp(1.0, 7 * (p + q)), 0, kslice, c_slice);
         hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_part, (long long)ldc, (long long)nA,
                            (long long)nB, c_slice, (int)slices, C, first ? 0 : 1);
       }

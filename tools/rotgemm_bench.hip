@@ -29,7 +29,7 @@ static void launch_gemm(const signed char* A, const signed char* B, long long ld
   const int nrpg = (nrp + 31) / 32, nctg = (nct + 7) / 8;
   const long long sets = (long long)nrpg * nctg;
   hipLaunchKernelGGL(rot_gemm_i8_kernel, dim3((unsigned)(sets * 32 * 8)), dim3(kRotThreads), 0, 0, (const int8_t*)A, (const int8_t*)B, ldk,
-                     kbytes, C, ldc, M, N, nrp, nct, cs, (const double*)nullptr, weight, accumulate, kbytes, 0LL, (const int2*)nullptr);
+                     kbytes, C, ldc, M, N, nrp, nct, cs, (const double*)nullptr, weight, accumulate, kbytes, 0LL);
 }
 
 int main(int argc, char** argv) {
