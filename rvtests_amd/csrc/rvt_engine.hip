@@ -164,6 +164,8 @@ struct rvt_ctx {
   std::vector<int> vcf_alt;    // rvt_vcf_set_alt_alleles: alternative-allele index per record of the NEXT VCF call
   bool vcf_dosage = false;     // rvt_vcf_set_dosage: the index handed over is a dosage tag's, values through atof
   // BGEN probability blocks (bgen_kernels.hip.h); the blocks are staged in d_vcf_text
+  char* d_fam_list = nullptr;  // rvt_run_fam_tests: column pointers + flags of a batch (grow-only)
+  size_t fam_list_cap = 0;
   signed char* d_vcf_sex = nullptr;  // PLINK sex code per file sample (rvt_vcf_set_sex); hemizygous records only
   std::vector<int> vcf_hemi;         // per record of the NEXT decode call (rvt_vcf_set_hemi)
   BgenRecord* d_bgen_rec = nullptr;
@@ -631,6 +633,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
   if (c->h_vcf_err) hipHostFree(c->h_vcf_err);
   if (c->d_vcf_sex) hipFree(c->d_vcf_sex);
+  if (c->d_fam_list) hipFree(c->d_fam_list);
   if (c->d_bgen_rec) hipFree(c->d_bgen_rec);
   if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
   if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
@@ -2591,17 +2594,19 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
     for (int g = 0; g < n; ++g)
       for (int j = 0; j < Ms[g]; ++j) cols[k++] = dG[g] + (size_t)j * ld;
   }
-  const double** d_cols = nullptr;
-  int* d_flags = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * tot * 2));
-  HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * tot * 2));
-  struct Guard {
-    void *a, *b;
-    ~Guard() {
-      hipFree(a);
-      hipFree(b);
+  // column pointer / flag lists of the batch: one grow-only allocation of the context (no hipMalloc / hipFree per batch)
+  {
+    const size_t need = (sizeof(double*) + sizeof(int)) * tot * 2 + 64;
+    if (c->fam_list_cap < need) {
+      if (c->d_fam_list) hipFree(c->d_fam_list);
+      c->d_fam_list = nullptr;
+      c->fam_list_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_fam_list, need + need / 2));
+      c->fam_list_cap = need + need / 2;
     }
-  } guard{(void*)d_cols, (void*)d_flags};
+  }
+  const double** d_cols = reinterpret_cast<const double**>(c->d_fam_list);
+  int* d_flags = reinterpret_cast<int*>(c->d_fam_list + sizeof(double*) * tot * 2);
   HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * tot, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)tot), dim3(256), 0, st, d_cols, (long long)N, d_flags);
   std::vector<int> flags(tot);
@@ -2645,7 +2650,8 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(d_cols + tot, kept_cols.data(), sizeof(double*) * T, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(d_flags + tot, kept_flip.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * (T + TB), st));  // pad rows must be zero
+  if (ld != N)  // pad rows must be zero (the rotation writes rows 0 .. N-1 of every column)
+    HIP_TRY(c, hipMemset2DAsync(c->d_Gt + N, sizeof(double) * (size_t)ld, 0, sizeof(double) * (size_t)(ld - N), T + TB, st));
   hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
                      (long long)N, (long long)ld, c->d_Gp);
   int* d_koff = nullptr;
