@@ -1549,6 +1549,12 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   HIP_TRY(c, hipMalloc((void**)&c->d_Uq, c->uq_plane * kRotPlanesU));
   HIP_TRY(c, hipMemsetAsync(c->d_Uq, 0, c->uq_plane * kRotPlanesU, c->stream));
   int* d_span = nullptr;  // first / last non-zero row of every column of U
+  struct SpanGuard {
+    int** p;
+    ~SpanGuard() {
+      if (*p) hipFree(*p);
+    }
+  } span_guard{&d_span};
   {  // whole columns at a time through a bounded staging buffer (the caller's U can be tens of GB): digits + column sums
     const int64_t cols_per = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)256 << 20) / N));
     float* d_tmp = nullptr;
@@ -1579,10 +1585,7 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     hipFree(d_tmp);
     hipFree(d_tmp64);
     hipFree(d_flag);
-    if (bad) {
-      hipFree(d_span);
-      return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
-    }
+    if (bad) return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
   }
   c->h_S.resize(N);
   for (int64_t i = 0; i < N; ++i) c->h_S[i] = (double)S[i];
