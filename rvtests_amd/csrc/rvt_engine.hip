@@ -756,7 +756,10 @@ int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
   hipSetDevice(c->device);
   const size_t bytes = sizeof(double) * (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld) * M;
   HIP_TRY(c, hipMalloc((void**)out, bytes));
-  HIP_TRY(c, hipMemset(*out, 0, bytes));
+  // cleared on the stream the streaming entry points write blocks on, and complete on return: a hipMemset on the null
+  // stream is not ordered against that (non-blocking) stream and could land after a decoder had filled the block
+  HIP_TRY(c, hipMemsetAsync(*out, 0, bytes, c->io_stream));
+  HIP_TRY(c, sync_stream(c->io_stream));
   {  // (flags are allocated by the first column upload; a zeroed block holds hard calls only)
     rvt_ctx::ColKind& ck = c->col_kind[*out];
     if (ck.d_flags) hipFree(ck.d_flags);  // an earlier block at the same address that was freed behind our back

@@ -862,6 +862,17 @@ class Group:
                                                     G8.ctypes.data_as(C.POINTER(C.c_int8)), int(tests), C.byref(prm),
                                                     None))
 
+    def submit_gene_bgen(self, gene_id, blocks, layout, tests=TEST_ALL, params=None):
+        """One gene as uncompressed BGEN probability blocks (rvt_group_submit_gene_bgen); file sample i = analysis row i
+        unless a sample map was installed on the members."""
+        prm = params or Params.default()
+        M, keep, ptr, blen = Engine._bgen_args(blocks)
+        self.L.rvt_group_submit_gene_bgen.restype = C.c_int
+        self.L.rvt_group_submit_gene_bgen.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                      C.c_uint32, C.c_void_p, c_double_p]
+        self._check(self.L.rvt_group_submit_gene_bgen(self.g, int(gene_id), M, ptr, blen, int(layout), int(tests),
+                                                      C.byref(prm), None))
+
     def collect(self, cap=4096):
         out = (GeneResult * cap)()
         n = C.c_int(0)

@@ -91,3 +91,30 @@ def test_bench_two_ranks_share_one_gpu():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["genes_ok"] == 48 and line["value"] > 0
     assert line["gathered_records_last_step"] == 96 and line["gathered_ids_in_order"] is True
+
+
+def test_group_bgen_stream_matches_single_context(engine):
+    """BGEN probability blocks through a two-member group: submission order kept, records equal the single context's."""
+    import bgengen
+    import rvtests_amd
+    N, d = 2500, 2
+    rng = np.random.default_rng(17)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=4)
+    genes = [[bgengen.layout2_block_fast(rng, N, bits=(8, 16, 32)[g % 3], missing=0.01)
+              for _ in range(int(rng.integers(2, 30)))] for g in range(40)]
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        grp.fit_null(0, X, y)
+        for g, blocks in enumerate(genes):
+            grp.submit_gene_bgen(50 + g, blocks, 2)
+        got = grp.collect()
+    finally:
+        grp.close()
+    engine.fit_null(0, X, y)
+    for g, blocks in enumerate(genes):
+        engine.submit_gene_bgen(50 + g, blocks, 2, want_af=False)
+    ref = engine.collect()
+    assert [r.gene_id for r in got] == [r.gene_id for r in ref] == [50 + g for g in range(40)]
+    for a, b in zip(got, ref):
+        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f
