@@ -5,8 +5,8 @@
 namespace rvt {
 
 // (ring depth, waves per SIMD) per tile class: the fastest of tools/k2hcw_bench.hip (N = 200 000, isolated:
-// 5.8 / 6.3 / 5.9 / 6.0 / 4.7 TB/s algorithmic); MT = 5 takes the rolling refill (depth 1): its fp64 fold
-// accumulators and the load ring of two whole steps do not fit the 256 vector registers a VALU instruction can address
+// 5.7 / 6.1 / 5.9 / 5.9 / 5.7 TB/s algorithmic); MT = 5 takes the rolling refill (depth 1): three int32 pair sets and the
+// load ring of two whole steps do not fit the register file
 void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
                    int d) {
   switch (MT) {

@@ -137,20 +137,15 @@ __device__ __forceinline__ void hcw_doubles(const unsigned (&dg)[4][8], unsigned
     for (int p = 0; p < kHcwPlanes; ++p) d2[s][p] = (dg[s][p] << 1) & 0xFEFEFEFEu;  // 2 d per byte (|d| <= 64)
 }
 
-// The weighted Gram tiles sum_i v_i g_ri g_ci.  Two ways to combine the six plane products of a tile:
-//   PAIRS   (MT <= 4)  planes are accumulated in pairs in exact int32 tiles that live across the whole wave-part: the
-//           even plane's fresh tile is shifted left by 7 bits and added to the pair's accumulator (one v_lshl_add_u32
-//           per element), which is the C operand of the odd plane's instruction.  |pair sum| <= 2^21 + 2^14 per operand,
-//           so a wave-part may hold up to 1016 operands (the host cuts at kHcwMaxSteps = 3072 steps); the three pair
-//           tiles are combined in fp64 once, at the end.  12 vector instructions per tile and operand.
-//   TRIPLES (MT = 5: 3 x 15 int32 tiles do not fit the register file beside the load ring) three planes are chained
-//           through the C operand (shift, instruction, shift, instruction: |.| < 2^29) and each triple is folded into
-//           ONE fp64 tile per Gram tile (convert + fma).
-template <int MT, bool TRIPLES>
-struct HcwAcc;
-
+// The weighted Gram tiles sum_i v_i g_ri g_ci.  Planes are accumulated in PAIRS in exact int32 tiles that live across the
+// whole wave-part: the even plane's fresh tile is shifted left by 7 bits and added to the pair's accumulator (one
+// v_lshl_add_u32 per element), which is the C operand of the odd plane's instruction.  |pair sum| <= 2^21 + 2^14 per
+// operand, so a wave-part may hold up to 1016 operands (the host cuts at kHcwMaxSteps = 3072 steps); the three pair tiles
+// are combined in fp64 once, at the end.  12 vector instructions per tile and operand.  (Folding every plane, or chained
+// triples of planes, into fp64 tiles per operand was measured slower in every class: the conversions cost more than
+// the shifts.)
 template <int MT>
-struct HcwAcc<MT, false> {
+struct HcwAcc {
   static constexpr int T = MT * (MT + 1) / 2;
   i4_t p[kHcwPairs][T];
   __device__ __forceinline__ void init() {
@@ -195,54 +190,6 @@ struct HcwAcc<MT, false> {
   }
 };
 
-template <int MT>
-struct HcwAcc<MT, true> {
-  static constexpr int T = MT * (MT + 1) / 2;
-  static_assert(kHcwPlanes % 3 == 0, "triples");
-  d4_t w[T];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int t = 0; t < T; ++t) w[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-  }
-  __device__ __forceinline__ double value(int t, int i) const { return w[t][i]; }
-  __device__ __forceinline__ void gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8]) {
-    i4_t op[MT];
-#pragma unroll
-    for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
-    unsigned d2[4][kHcwPlanes];
-    hcw_doubles(dg, d2);
-    int t0 = 0;
-#pragma unroll
-    for (int r = 0; r < MT; ++r) {
-      const HcwRow<MT> row(pk[r]);
-#pragma unroll
-      for (int j = 0; j < kHcwPlanes / 3; ++j) {
-        const i4_t a0 = row.aop(dg, d2, 3 * j), a1 = row.aop(dg, d2, 3 * j + 1), a2 = row.aop(dg, d2, 3 * j + 2);
-        i4_t z[MT];
-#pragma unroll
-        for (int c = r; c < MT; ++c) z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-        for (int c = r; c < MT; ++c) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) z[c][i] = (int)((unsigned)z[c][i] << 7);
-          z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, op[c], z[c], 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = r; c < MT; ++c) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) z[c][i] = (int)((unsigned)z[c][i] << 7);
-          z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, op[c], z[c], 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = r; c < MT; ++c)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) w[t0 + c - r][i] = fma((double)z[c][i], hcw_pow2(-21 * (j + 1)), w[t0 + c - r][i]);
-      }
-      t0 += MT - r;
-    }
-  }
-};
-
 template <int MT, int DEPTH>
 __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const NullTileW& nt, long long N, long long ld,
                                                   int d) {
@@ -283,8 +230,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
   for (int c = 0; c < MT; ++c) fx[c] = ((gd.pflip[c] >> v) & 1) ? 0x02020202u : 0u;
 
   d4_t accT[MT];
-  constexpr bool kTriples = MT >= 5;
-  HcwAcc<MT, kTriples> acc;
+  HcwAcc<MT> acc;
   unsigned cs[MT], cs2[MT], pk[MT][4], dg[4][8];
 #pragma unroll
   for (int c = 0; c < MT; ++c) {
@@ -370,8 +316,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         __builtin_amdgcn_sched_barrier(0);
         hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu);
         if ((u & 3) == 3) acc.gram(pk, dg);
-        if constexpr (!kTriples) __builtin_amdgcn_sched_barrier(0);  // (MT = 5 measured faster with the operand's
-                                                                     // instructions free to mix with the next step's)
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int c = 0; c < MT; ++c) voff[c] += U * 128;
