@@ -1027,8 +1027,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
                              c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
   const bool score_hc = cov && cov->score && cov->slice_hc;
-  // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests only)
-  const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && !cov;
+  // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests and MetaScore slices)
+  const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && (!cov || score_hc);
   const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) && !(dbg && dbg->cmc) &&
                            d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
   const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
@@ -3360,7 +3360,7 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   std::vector<int> colflag;
   bool any_hc = false;
   bool all_hc = block_hard_calls(c, dG, V, &colflag, &any_hc) != 0;
-  if (c->nc.binary) all_hc = any_hc = false;
+  if (c->nc.binary && !(c->d_nulltile_w && c->d_vq)) all_hc = any_hc = false;  // (no digit planes: fp64 kernel)
   if (!all_hc && colflag.empty()) any_hc = false;
   // columns per slice.  General kernel: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column
   // tiles, tile class (2,2).  Hard-call kernel: the null-model columns have a tile of their own, so a slice is two
