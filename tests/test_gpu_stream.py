@@ -73,3 +73,46 @@ def test_long_stream_equals_block_submission(eng, mode):
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
             assert x == y_ or abs(x - y_) <= 1e-12 * abs(y_), (mode, a.gene_id, f, x, y_)
+
+
+def test_mixed_entry_points_with_partial_collects(eng):
+    """One stream that mixes every entry point gene by gene, with rvt_collect_ready calls in between and blocks going
+    back to the pool and out again: order kept, records those of the finished-block submission."""
+    rng = np.random.default_rng(77)
+    N, d, n_genes = 2011, 3, 130                       # odd N: pad rows in every block
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=8)
+    eng.set_null(0, X, res, v, s2)
+    eng.vcf_set_samples(np.arange(N, dtype=np.int32))
+    mats, got = [], []
+    for g in range(n_genes):
+        M = int(rng.integers(1, 60))
+        mode = ("raw", "i8", "bed", "vcf", "bgen", "block")[int(rng.integers(0, 6))]
+        if mode == "bgen":
+            blocks = [bgengen.layout2_block_fast(rng, N, bits=16, missing=0.02) for _ in range(M)]
+            raw = np.asfortranarray(np.column_stack([orc.bgen_block_genotypes(b, 2, N) for b in blocks]))
+            eng.submit_gene_bgen(g, blocks, 2, want_af=False)
+        else:
+            maf = 10 ** rng.uniform(-2.5, -0.5, M)
+            raw = np.asfortranarray(rng.binomial(2, maf, size=(N, M)).astype(np.float64))
+            raw[rng.random((N, M)) < 0.01] = -9.0
+            if mode == "raw":
+                eng.submit_gene_raw(g, raw, want_af=bool(g % 2))
+            elif mode == "i8":
+                eng.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
+            elif mode == "bed":
+                eng.submit_gene_bed(g, eng.pack_bed(raw), M, want_af=False)
+            elif mode == "vcf":
+                eng.submit_gene_vcf(g, [vcfgen.fixed_width_record(raw[:, j].astype(np.int64), pos=9 + j) for j in range(M)],
+                                    want_af=False)
+            else:
+                eng.submit_gene(g, orc.impute_mean(raw), orc.counter_af(raw))
+        mats.append(raw)
+        if g % 23 == 22:
+            got += eng.collect_ready()
+    got += eng.collect()
+    ref = _reference(eng, mats)
+    assert [r.gene_id for r in got] == list(range(n_genes))
+    for a, b in zip(got, ref):
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            assert x == y_ or abs(x - y_) <= 1e-12 * abs(y_), (a.gene_id, f, x, y_)
