@@ -116,3 +116,32 @@ def test_mixed_entry_points_with_partial_collects(eng):
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
             assert x == y_ or abs(x - y_) <= 1e-12 * abs(y_), (a.gene_id, f, x, y_)
+
+
+def test_long_stream_binary_trait(eng):
+    """The same under a logistic null model: streamed hard-call blocks are classified on the transfer stream and take the
+    weighted int8 kernel; records equal those of the finished-block submission (which classifies at upload)."""
+    rng = np.random.default_rng(5)
+    N, d, n_genes = 2500, 2, 40
+    X, y, res, v, s2 = synth.make_null(N, d, 1, seed=10)
+    eng.set_null(1, X, res, v, s2)
+    mats = []
+    eng.set_profiling(True)
+    eng.timing(reset=True)
+    for g in range(n_genes):
+        M = int(rng.integers(1, 70))
+        maf = 10 ** rng.uniform(-2.5, -0.7, M)
+        raw = np.asfortranarray(rng.binomial(2, maf, size=(N, M)).astype(np.float64))
+        if g % 3 == 0:
+            raw[rng.random((N, M)) < 0.01] = -9.0          # imputed means: these genes stay on the fp64 kernel
+        mats.append(raw)
+        eng.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
+    got = eng.collect()
+    tm = eng.timing(reset=True)
+    eng.set_profiling(False)
+    assert 0 < tm.genes_hard_call < n_genes
+    ref = _reference(eng, mats)
+    for a, b in zip(got, ref):
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            assert x == y_ or abs(x - y_) <= 1e-9 * abs(y_), (a.gene_id, f, x, y_)
