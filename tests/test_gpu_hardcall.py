@@ -262,3 +262,30 @@ def test_collect_ready_returns_finished_prefix_without_draining(engine):
     for r, (G, af) in zip(got[::9], genes[::9]):
         rc, a = orc.skat(G, af, X, res, v, 0)
         assert abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14
+
+
+def test_weighted_hardcall_at_the_wave_part_cap(engine):
+    """The weighted kernel keeps int32 pair sums across a whole wave-part; the host cuts wave-parts at 3072 steps
+    (49 152 samples).  N = 6.4 million reaches that cap; weights whose digits are all near +63 and a column that is 2
+    almost everywhere come close to the int32 range.  Against the fp64 kernel."""
+    N = 6_400_000
+    rng = np.random.default_rng(2)
+    G = np.empty((N, 2), order="F")
+    G[:, 0] = 2.0
+    G[rng.integers(0, N, N // 100), 0] = 0.0
+    G[:, 1] = rng.binomial(2, 0.3, N)
+    af = G.sum(0) / (2.0 * N)
+    X = np.ones((N, 1), order="F")
+    vval = sum(d * 128.0 ** -(p + 1) for p, d in enumerate([62, 63, 63, 63, 63, 63]))
+    assert 0.48 < vval < 0.49
+    v = np.full(N, vval)
+    res = rng.standard_normal(N) * 0.5
+    res -= res.mean()
+    engine.set_null(1, X, res, v, 1.0)
+    (a,), tm = _run(engine, [(G, af)], True)
+    (b,), _ = _run(engine, [(G, af)], False)
+    assert tm.genes_hard_call == 1
+    assert a.n_poly == b.n_poly == 2
+    for f in FIELDS:
+        x, y_ = getattr(a, f), getattr(b, f)
+        assert abs(x - y_) <= 1e-9 * abs(y_) + 1e-300, (f, x, y_)
