@@ -341,7 +341,8 @@ int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
  * column), re-orders the eigenpairs by support — the statistics do not depend on their order — and the rotation U'G then
  * visits only the K chunks that hold non-zeros: visited_fraction = the share of the N x N product that is computed
  * (1 = dense U, e.g. a GRM's eigenvectors; ~4 / 782 for nuclear families at N = 100 000).  The skipped parts are exact
- * zeros, so the results are those of the dense product.  RVT_KINSHIP_DENSE=1 in the environment disables the detection. */
+ * zeros, so the rotated values are those of the dense product (the statistics sum the eigenpairs in the new order: equal to
+ * rounding).  RVT_KINSHIP_DENSE=1 in the environment disables the detection. */
 int rvt_kinship_structure(rvt_ctx* ctx, double* visited_fraction);
 int rvt_fit_fam_null(rvt_ctx* ctx, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out);
 int rvt_run_fam_blocks(rvt_ctx* ctx, int n_genes, const double* const* dG, const int* M, const int64_t* gene_ids,
