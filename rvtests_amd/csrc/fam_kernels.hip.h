@@ -393,12 +393,15 @@ __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* _
   __shared__ double rs[256], rmn[256], rmx[256];
   const double* col = cols[blockIdx.x];
   double s = 0.0, mn = INFINITY, mx = -INFINITY;
+  bool hard = true;
   for (long long i = threadIdx.x; i < N; i += 256) {
     const double g = col[i];
     s += g;
     mn = fmin(mn, g);
     mx = fmax(mx, g);
+    hard = hard && (g == 0.0 || g == 1.0 || g == 2.0);
   }
+  const int all_hard = __syncthreads_and(hard ? 1 : 0);
   rs[threadIdx.x] = s;
   rmn[threadIdx.x] = mn;
   rmx[threadIdx.x] = mx;
@@ -411,7 +414,29 @@ __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* _
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) flags[blockIdx.x] = (!(rs[0] <= (double)N) ? 1 : 0) | ((rmn[0] != rmx[0]) ? 2 : 0);
+  if (threadIdx.x == 0)  // bit 0: flip, bit 1: polymorphic, bit 2: every entry is a hard call (0 / 1 / 2)
+    flags[blockIdx.x] = (!(rs[0] <= (double)N) ? 1 : 0) | ((rmn[0] != rmx[0]) ? 2 : 0) | (all_hard ? 4 : 0);
+}
+
+// kept hard-call columns straight to the int8 plane of the rotation GEMM ([column][ldk] bytes), flipped to 2 - g where
+// flagged: what fam_flip_compact_kernel + the column quantiser produce, in one pass over the genotypes
+__global__ void fam_flip_quant_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
+                                      long long N, long long ldk, signed char* __restrict__ dst) {
+  const double* s = src_cols[blockIdx.y];
+  const bool fl = src_flip[blockIdx.y] != 0;
+  signed char* d = dst + (long long)blockIdx.y * ldk;
+  // eight samples per thread: 64 bytes of doubles in, one 8-byte store out (columns start on 128-byte lines, ldk too)
+  const long long n8 = (N + 7) / 8;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+    const long long i0 = t * 8;
+    unsigned long long w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int g = (i0 + k < N) ? (int)s[i0 + k] : 0;
+      w |= (unsigned long long)(unsigned char)(fl && i0 + k < N ? 2 - g : g) << (8 * k);
+    }
+    *reinterpret_cast<unsigned long long*>(d + i0) = w;
+  }
 }
 
 // dst column c (of the compact N x T matrix, leading dimension ld) = kept source column, flipped to 2 - g if flagged

@@ -2621,6 +2621,7 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
   // ---- 2. compact the kept columns (flipped where needed) and rotate them by U' --------------------------------
   std::vector<const double*> kept_cols;
   std::vector<int> kept_flip, Mk(n), off(n);
+  bool all_hard = true;  // every kept column holds hard calls only
   {
     size_t k = 0;
     for (int g = 0; g < n; ++g) {
@@ -2629,6 +2630,7 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
         if (flags[k] & 2) {
           kept_cols.push_back(cols[k]);
           kept_flip.push_back(flags[k] & 1);
+          all_hard = all_hard && (flags[k] & 4);
         }
       Mk[g] = (int)kept_cols.size() - off[g];
     }
@@ -2658,8 +2660,12 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
   HIP_TRY(c, hipMemcpyAsync(d_flags + tot, kept_flip.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
   if (ld != N)  // pad rows must be zero (the rotation writes rows 0 .. N-1 of every column)
     HIP_TRY(c, hipMemset2DAsync(c->d_Gt + N, sizeof(double) * (size_t)ld, 0, sizeof(double) * (size_t)(ld - N), T + TB, st));
-  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
-                     (long long)N, (long long)ld, c->d_Gp);
+  // FamSKAT alone on hard calls: the flipped columns go straight to the int8 plane of the rotation (no fp64 copy, no
+  // column scan, no separate quantiser pass)
+  const bool direct = !burden && all_hard && c->hc_enabled && !getenv("RVT_FAM_NO_DIRECT");
+  if (!direct)
+    hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
+                       (long long)N, (long long)ld, c->d_Gp);
   int* d_koff = nullptr;
   double* d_bcs = nullptr;
   int* d_bpoly = nullptr;
@@ -2684,7 +2690,28 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
     hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)TB), dim3(256), 0, st, c->d_Gp + (size_t)T * ld,
                        (long long)N, (long long)ld, d_bcs, d_bpoly);
   }
-  {  // the rotation of the whole batch: genotype columns + collapsed burden columns (exact int8 products, rot_gemm.hip.h)
+  if (direct) {
+    const int64_t ldk = c->uq_ldk;
+    for (size_t c0 = 0; c0 < T; c0 += kRotMaxCols) {  // long lists in pieces, as rotate_columns
+      const int ncp = (int)std::min<size_t>(kRotMaxCols, T - c0);
+      const int64_t cols_pad = ((int64_t)ncp + kRotBN - 1) / kRotBN * kRotBN;
+      const size_t need = (size_t)cols_pad * (size_t)ldk;
+      if (c->rotB_cap < need) {
+        if (c->d_rotB) hipFree(c->d_rotB);
+        c->d_rotB = nullptr;
+        c->rotB_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
+        c->rotB_cap = need + need / 4;
+      }
+      HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+      hipLaunchKernelGGL(fam_flip_quant_kernel, dim3(64, (unsigned)ncp), dim3(256), 0, st, d_cols + tot + c0,
+                         d_flags + tot + c0, (long long)N, (long long)ldk, c->d_rotB);
+      std::vector<int> zero_exp((size_t)ncp, 0);
+      int rcr = planes_gemm(c, c->d_Uq, c->uq_plane, kRotPlanesU, (int)N, nullptr, c->uq_sexp, c->d_rotB, need, 1, ncp,
+                            zero_exp.data(), N, ldk, c->d_Gt + c0 * (size_t)ld, ld, st, c->d_uq_range);
+      if (rcr) return rcr;
+    }
+  } else {  // the rotation of the whole batch: genotype columns + collapsed burden columns (exact int8 products, rot_gemm.hip.h)
     int rcr = rotate_columns(c, c->d_Gp, ld, (int)(T + TB), c->d_Gt, ld, st);
     if (rcr) return rcr;
   }
