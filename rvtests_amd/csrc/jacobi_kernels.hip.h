@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const double* __restrict_
 // (32 disjoint rotations per step) and writes R (row-major 64 x 64, columns ordered by decreasing eigenvalue).
 __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double* __restrict__ part, int nparts, double tol,
                                                             double* __restrict__ Rout,
-                                                            unsigned long long* __restrict__ maxcos, int sort_mode) {
+                                                            unsigned long long* __restrict__ maxcos, int sort_mode,
+                                                            double* __restrict__ lam_out = nullptr) {
   __shared__ double G[kJacP][kJacP + 1];
   __shared__ double R[kJacP][kJacP + 1];
   __shared__ double cs[kJacB][2];
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double* __rest
     }
     if (sort_mode == 0) rank = tid;
     order[rank] = tid;
+    if (lam_out) lam_out[(long long)blockIdx.x * kJacP + rank] = d;  // eigenvalue of output column `rank`
   }
   __syncthreads();
   double* out = Rout + (long long)blockIdx.x * (kJacP * kJacP);
@@ -334,6 +336,19 @@ __global__ __launch_bounds__(256) void jac_gather_kernel(const double* __restric
   const double inv = red[0] > 0.0 ? 1.0 / sqrt(red[0]) : 0.0;
   float* u = U + (long long)blockIdx.x * n;
   for (long long i = threadIdx.x; i < n; i += 256) u[i] = (float)(v[i] * inv);
+}
+
+// Family-wise decomposition (rvt_kinship_decompose on a block-diagonal kinship): column k of U (float, n x n, column-major,
+// pre-cleared) gets the `len[k]` entries of eigenvector column `col[k]` of tile `tile[k]` (R: [tile][64 x 64] row-major)
+// at rows start[k] ..; one thread per column.
+__global__ void jac_scatter_blocks_kernel(const double* __restrict__ R, const int* __restrict__ tile,
+                                          const int* __restrict__ col, const int* __restrict__ start,
+                                          const int* __restrict__ len, long long n, float* __restrict__ U) {
+  const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* r = R + (long long)tile[k] * (kJacP * kJacP) + col[k];
+  float* u = U + k * n + start[k];
+  for (int i = 0; i < len[k]; ++i) u[i] = (float)r[(long long)i * kJacP];
 }
 
 }  // namespace rvt

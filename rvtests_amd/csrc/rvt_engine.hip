@@ -1667,6 +1667,131 @@ int rvt_kinship_structure(rvt_ctx* c, double* visited_fraction) {
   return RVT_OK;
 }
 
+// Family-wise form of rvt_kinship_decompose.  When the sparsity pattern of K splits the samples into CONTIGUOUS index
+// ranges that do not interact (families listed one after the other, the usual pedigree kinship) and none is larger than
+// 64, the eigenproblem is that of its blocks: consecutive families are packed into 64 x 64 tiles (block diagonal inside a
+// tile, distinct negative pads on the rest of the diagonal: zero off-diagonals are never rotated, so nothing mixes),
+// every tile is diagonalised by the two-sided cyclic Jacobi kernel of the dense iteration (jac_small_eig_kernel) and the
+// eigenpairs are merged in ascending order.  *done = false: K is not of that form, take the dense iteration.
+static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K, const std::vector<int>& lo, const std::vector<int>& hi,
+                               double mu, int64_t np, float* U_out, float* S_out, int install, rvt_decompose_info* info,
+                               bool* done) {
+  *done = false;
+  std::vector<int> cstart, clen;
+  for (int64_t i = 0; i < N;) {
+    int64_t end = i;
+    for (int64_t k = i; k <= end; ++k) {
+      if (hi[k] >= 0 && lo[k] < i) return RVT_OK;  // reaches back into an earlier range: not interval-structured
+      if (hi[k] > end) end = hi[k];
+    }
+    if (end - i + 1 > kJacP) return RVT_OK;
+    cstart.push_back((int)i);
+    clen.push_back((int)(end - i + 1));
+    i = end + 1;
+  }
+  if ((int64_t)cstart.size() < 2) return RVT_OK;
+  // tiles of consecutive families
+  std::vector<int> tstart, tlen;
+  for (size_t f = 0; f < cstart.size(); ++f) {
+    if (!tstart.empty() && tlen.back() + clen[f] <= kJacP)
+      tlen.back() += clen[f];
+    else {
+      tstart.push_back(cstart[f]);
+      tlen.push_back(clen[f]);
+    }
+  }
+  const size_t nt = tstart.size();
+  std::vector<double> A(nt * (size_t)kJacP * kJacP, 0.0);
+  for (size_t t = 0; t < nt; ++t) {
+    double* a = A.data() + t * (size_t)kJacP * kJacP;
+    const int64_t s0 = tstart[t];
+    for (int q = 0; q < tlen[t]; ++q)
+      for (int r = 0; r < tlen[t]; ++r) a[(size_t)r * kJacP + q] = (double)K[(size_t)(s0 + r) + (size_t)(s0 + q) * N];
+    for (int r = tlen[t]; r < kJacP; ++r) a[(size_t)r * kJacP + r] = -mu * (1.0 + (double)r / kJacP);  // pads: last, apart
+  }
+  hipStream_t st = c->stream;
+  struct Bufs {
+    double *A = nullptr, *R = nullptr, *lam = nullptr;
+    unsigned long long* maxcos = nullptr;
+    float* dU = nullptr;
+    int* meta = nullptr;
+    ~Bufs() {
+      for (void* p : {(void*)A, (void*)R, (void*)lam, (void*)maxcos, (void*)dU, (void*)meta})
+        if (p) hipFree(p);
+    }
+  } b;
+  const size_t tile_bytes = sizeof(double) * (size_t)kJacP * kJacP;
+  HIP_TRY(c, hipMalloc((void**)&b.A, tile_bytes * nt));
+  HIP_TRY(c, hipMalloc((void**)&b.R, tile_bytes * nt));
+  HIP_TRY(c, hipMalloc((void**)&b.lam, sizeof(double) * kJacP * nt));
+  HIP_TRY(c, hipMalloc((void**)&b.maxcos, sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemsetAsync(b.maxcos, 0, sizeof(unsigned long long), st));
+  HIP_TRY(c, hipMemcpyAsync(b.A, A.data(), tile_bytes * nt, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(jac_small_eig_kernel, dim3((unsigned)nt), dim3(256), 0, st, b.A, 1, 1e-14, b.R, b.maxcos, 1, b.lam);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> R(nt * (size_t)kJacP * kJacP), lam(nt * (size_t)kJacP);
+  HIP_TRY(c, hipMemcpyAsync(R.data(), b.R, tile_bytes * nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(lam.data(), b.lam, sizeof(double) * kJacP * nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  // the first tlen[t] output columns of a tile are its own eigenpairs (decreasing; the pads are below all of them)
+  struct Pair {
+    double lam;
+    int tile, col;
+  };
+  std::vector<Pair> pairs;
+  pairs.reserve((size_t)N);
+  double worst = 0.0;
+  for (size_t t = 0; t < nt; ++t) {
+    const double* a = A.data() + t * (size_t)kJacP * kJacP;
+    const double* r = R.data() + t * (size_t)kJacP * kJacP;
+    for (int q = 0; q < tlen[t]; ++q) {
+      const double l = lam[t * kJacP + q];
+      pairs.push_back({l, (int)t, q});
+      double res2 = 0.0;  // || K u - lambda u || inside the tile (K is zero outside)
+      for (int i = 0; i < tlen[t]; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < tlen[t]; ++k) s += a[(size_t)i * kJacP + k] * r[(size_t)k * kJacP + q];
+        s -= l * r[(size_t)i * kJacP + q];
+        res2 += s * s;
+      }
+      worst = std::max(worst, std::sqrt(res2));
+    }
+  }
+  if ((int64_t)pairs.size() != N) return fail(c, RVT_E_STATE, "family-wise decomposition lost eigenpairs");
+  std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.lam < y.lam; });  // ascending
+  std::vector<float> S((size_t)N);
+  std::vector<int> meta(4 * (size_t)N);
+  for (int64_t k = 0; k < N; ++k) {
+    S[k] = (float)pairs[k].lam;
+    meta[k] = pairs[k].tile;
+    meta[(size_t)N + k] = pairs[k].col;
+    meta[2 * (size_t)N + k] = tstart[pairs[k].tile];
+    meta[3 * (size_t)N + k] = tlen[pairs[k].tile];
+  }
+  if (U_out || install) {
+    HIP_TRY(c, hipMalloc((void**)&b.dU, sizeof(float) * (size_t)N * (size_t)N));
+    HIP_TRY(c, hipMemsetAsync(b.dU, 0, sizeof(float) * (size_t)N * (size_t)N, st));
+    HIP_TRY(c, hipMalloc((void**)&b.meta, sizeof(int) * 4 * (size_t)N));
+    HIP_TRY(c, hipMemcpyAsync(b.meta, meta.data(), sizeof(int) * 4 * (size_t)N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(jac_scatter_blocks_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.R, b.meta,
+                       b.meta + N, b.meta + 2 * N, b.meta + 3 * N, (long long)N, b.dU);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, sync_stream(st));
+    if (U_out) HIP_TRY(c, hipMemcpy(U_out, b.dU, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyDeviceToHost));
+  }
+  if (S_out) std::memcpy(S_out, S.data(), sizeof(float) * (size_t)N);
+  if (info) {
+    info->sweeps = 0;  // no block sweeps: every family is an eigenproblem of its own
+    info->max_cosine = 0.0;
+    info->padded_order = np;
+    info->shift = 0.0;
+    info->max_residual = worst;
+  }
+  *done = true;
+  if (install) return rvt_set_kinship(c, N, b.dU, S.data());
+  return RVT_OK;
+}
+
 // ---- KinshipHolder::decompose on the device (jacobi_kernels.hip.h) ---------------------------------------------------------
 int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, float* S_out, int install,
                           rvt_decompose_info* info) {
@@ -1680,17 +1805,30 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
   const int nb = (int)(np / kJacB), pairs = nb / 2;
   // |lambda| <= max row sum of |K| (Gershgorin); the pad entries sit well outside
   double mu = 0.0;
+  std::vector<int> span_lo((size_t)N), span_hi((size_t)N);  // first / last non-zero row of every column
   {
     std::vector<double> rows((size_t)N, 0.0);
     for (int64_t j = 0; j < N; ++j) {
       const float* col = K + (size_t)j * N;
+      int l = (int)N, h = -1;
       for (int64_t i = 0; i < N; ++i) {
         if (!std::isfinite(col[i])) return fail(c, RVT_E_INVALID, "kinship matrix holds a non-finite entry");
         rows[i] += std::fabs((double)col[i]);
+        if (col[i] != 0.0f) {
+          if (l > (int)i) l = (int)i;
+          h = (int)i;
+        }
       }
+      span_lo[j] = l;
+      span_hi[j] = h;
     }
     for (int64_t i = 0; i < N; ++i) mu = std::max(mu, rows[i]);
     mu = 4.0 * std::max(mu, 1e-300);
+  }
+  if (!getenv("RVT_KINSHIP_DENSE")) {  // a block-diagonal (pedigree) kinship is decomposed family by family
+    bool done = false;
+    rc = decompose_by_family(c, N, K, span_lo, span_hi, mu, np, U_out, S_out, install, info, &done);
+    if (rc || done) return rc;
   }
   struct Bufs {
     float* dK = nullptr;

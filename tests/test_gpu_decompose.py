@@ -114,3 +114,36 @@ def test_famskat_through_the_device_decomposition(eng):
         rc1, o1 = orc.famskat(G, X, y, U1.astype(np.float64), S1.astype(np.float64), onul)
         assert rc0 == rc1 == 0
         assert abs(o0.Q - o1.Q) <= 2e-5 * o0.Q and abs(o0.pvalue - o1.pvalue) <= 1e-4 * o0.pvalue
+
+
+def _block_kinship(rng, sizes):
+    N = int(np.sum(sizes))
+    K = np.zeros((N, N))
+    o = 0
+    for sz in sizes:
+        A = rng.uniform(0.05, 0.5, (sz, sz))
+        K[o:o + sz, o:o + sz] = (A + A.T) / 2 + np.eye(sz)
+        o += sz
+    return K
+
+
+def test_block_diagonal_kinship_is_decomposed_family_by_family(eng):
+    """Families listed one after the other (sizes 1..9, an all-zero row / column among them): no block sweeps, the
+    eigenpairs of the blocks merged in ascending order.  The same matrix with its samples shuffled is not of that form
+    and goes through the dense iteration — same spectrum."""
+    rng = np.random.default_rng(12)
+    sizes = rng.choice([1, 2, 3, 4, 6, 9], size=260)
+    K = _block_kinship(rng, sizes)
+    K[7, :] = 0.0
+    K[:, 7] = 0.0                                        # an isolated sample without even a diagonal entry
+    K32 = K.astype(np.float32)
+    U, S, info = eng.kinship_decompose(K32)
+    _check(K32, U, S, info)
+    assert info.sweeps == 0 and info.shift == 0.0
+    assert (np.count_nonzero(U, axis=0) <= 9).all()
+    perm = rng.permutation(K.shape[0])
+    Kp = np.ascontiguousarray(K32[np.ix_(perm, perm)])
+    U2, S2, info2 = eng.kinship_decompose(Kp)
+    _check(Kp, U2, S2, info2)
+    assert info2.sweeps >= 1
+    assert np.abs(S2 - S).max() <= 2e-6 * np.abs(S).max()
