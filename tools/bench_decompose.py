@@ -14,6 +14,8 @@ import rvtests_amd  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=8000)
 ap.add_argument("--kind", default="family")
+ap.add_argument("--install", action="store_true",
+                help="install the decomposition for the family models instead of returning the eigenvectors (large N)")
 args = ap.parse_args()
 N = args.samples // 4 * 4
 rng = np.random.default_rng(1)
@@ -27,6 +29,14 @@ else:
     K = np.asfortranarray((Z @ Z.T) / np.float32(2 * N))
     K = (K + K.T) / 2
 eng = rvtests_amd.Engine(0)
+if args.install:
+    t0 = time.perf_counter()
+    eng.kinship_decompose(K, install=True, want_vectors=False)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"N": N, "kind": args.kind, "seconds_decompose_and_install": dt,
+                      "rotation_visits": eng.kinship_structure()}))
+    eng.close()
+    sys.exit(0)
 t0 = time.perf_counter()
 U, S, info = eng.kinship_decompose(K, want_vectors=True)
 dt = time.perf_counter() - t0

@@ -22,6 +22,7 @@ stats perm python3 tools/bench_perm.py
 stats stream_bed python3 tools/bench_stream.py --bed --genes 512
 python3 tools/bench_decompose.py --samples 3000 --kind grm > "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 12000 --kind family >> "$OUT/decompose.txt" 2>&1
+python3 tools/bench_decompose.py --samples 100000 --kind family --install >> "$OUT/decompose.txt" 2>&1
 for t in k2hc_bench k2hcw_bench rotgemm_bench; do  # micro-benchmarks: built here when the snapshot has no binary
   [ -x tools/$t ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/$t.hip -o tools/$t > "$OUT/build_$t.log" 2>&1
 done
