@@ -378,8 +378,8 @@ int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* a
  * memory.  fp64 one-sided block Jacobi (rvtests_amd/csrc/jacobi_kernels.hip.h); device memory 16 N^2 bytes while it runs.
  * Eigenvectors of repeated eigenvalues are an arbitrary orthonormal basis of their eigenspace — exactly as for any
  * eigensolver; every statistic of the family tests depends on U only through U f(S) U'. *
- * A block-diagonal kinship — families listed one after the other, none larger than 64 samples: the usual pedigree
- * kinship — is recognised from its sparsity pattern and decomposed family by family (the blocks are packed into
+ * A kinship of separate families (the connected components of its sparsity pattern, in any sample order), none larger
+ * than 64 samples — the usual pedigree kinship — is recognised and decomposed family by family (the blocks are packed into
  * 64 x 64 tiles for the same Jacobi kernel; sweeps = 0 in the info): 1.7 s including the installation at N = 100 000,
  * where the dense iteration would need 200 GB and minutes.  RVT_KINSHIP_DENSE=1 forces the dense iteration. */
 typedef struct rvt_decompose_info {

@@ -338,17 +338,18 @@ __global__ __launch_bounds__(256) void jac_gather_kernel(const double* __restric
   for (long long i = threadIdx.x; i < n; i += 256) u[i] = (float)(v[i] * inv);
 }
 
-// Family-wise decomposition (rvt_kinship_decompose on a block-diagonal kinship): column k of U (float, n x n, column-major,
-// pre-cleared) gets the `len[k]` entries of eigenvector column `col[k]` of tile `tile[k]` (R: [tile][64 x 64] row-major)
-// at rows start[k] ..; one thread per column.
+// Family-wise decomposition (rvt_kinship_decompose on a kinship of separate families): column k of U (float, n x n,
+// column-major, pre-cleared) gets the `len[k]` entries of eigenvector column `col[k]` of tile `tile[k]` (R: [tile][64 x 64]
+// row-major) at the sample rows of that tile (rows: [tile][64]); one thread per column.
 __global__ void jac_scatter_blocks_kernel(const double* __restrict__ R, const int* __restrict__ tile,
-                                          const int* __restrict__ col, const int* __restrict__ start,
-                                          const int* __restrict__ len, long long n, float* __restrict__ U) {
+                                          const int* __restrict__ col, const int* __restrict__ len,
+                                          const int* __restrict__ rows, long long n, float* __restrict__ U) {
   const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (k >= n) return;
   const double* r = R + (long long)tile[k] * (kJacP * kJacP) + col[k];
-  float* u = U + k * n + start[k];
-  for (int i = 0; i < len[k]; ++i) u[i] = (float)r[(long long)i * kJacP];
+  const int* rw = rows + (long long)tile[k] * kJacP;
+  float* u = U + k * n;
+  for (int i = 0; i < len[k]; ++i) u[rw[i]] = (float)r[(long long)i * kJacP];
 }
 
 }  // namespace rvt

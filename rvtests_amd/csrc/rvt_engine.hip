@@ -1668,46 +1668,64 @@ int rvt_kinship_structure(rvt_ctx* c, double* visited_fraction) {
   return RVT_OK;
 }
 
-// Family-wise form of rvt_kinship_decompose.  When the sparsity pattern of K splits the samples into CONTIGUOUS index
-// ranges that do not interact (families listed one after the other, the usual pedigree kinship) and none is larger than
-// 64, the eigenproblem is that of its blocks: consecutive families are packed into 64 x 64 tiles (block diagonal inside a
+// Family-wise form of rvt_kinship_decompose.  When the sparsity pattern of K splits the samples into groups that do not
+// interact (the connected components of its non-zeros: families, in whatever order the samples are listed) and none is
+// larger than 64, the eigenproblem is that of its blocks: families are packed into 64 x 64 tiles (block diagonal inside a
 // tile, distinct negative pads on the rest of the diagonal: zero off-diagonals are never rotated, so nothing mixes),
 // every tile is diagonalised by the two-sided cyclic Jacobi kernel of the dense iteration (jac_small_eig_kernel) and the
 // eigenpairs are merged in ascending order.  *done = false: K is not of that form, take the dense iteration.
-static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K, const std::vector<int>& lo, const std::vector<int>& hi,
-                               double mu, int64_t np, float* U_out, float* S_out, int install, rvt_decompose_info* info,
-                               bool* done) {
+static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K,
+                               const std::vector<std::vector<std::pair<int, int>>>& edges, double mu, int64_t np,
+                               float* U_out, float* S_out, int install, rvt_decompose_info* info, bool* done) {
   *done = false;
-  std::vector<int> cstart, clen;
-  for (int64_t i = 0; i < N;) {
-    int64_t end = i;
-    for (int64_t k = i; k <= end; ++k) {
-      if (hi[k] >= 0 && lo[k] < i) return RVT_OK;  // reaches back into an earlier range: not interval-structured
-      if (hi[k] > end) end = hi[k];
+  // families = connected components of the sparsity pattern (union-find over the off-diagonal non-zeros)
+  std::vector<int> parent((size_t)N), csize((size_t)N, 1);
+  for (int64_t i = 0; i < N; ++i) parent[i] = (int)i;
+  auto find = [&](int x) {
+    while (parent[x] != x) {
+      parent[x] = parent[parent[x]];
+      x = parent[x];
     }
-    if (end - i + 1 > kJacP) return RVT_OK;
-    cstart.push_back((int)i);
-    clen.push_back((int)(end - i + 1));
-    i = end + 1;
-  }
-  if ((int64_t)cstart.size() < 2) return RVT_OK;
-  // tiles of consecutive families
-  std::vector<int> tstart, tlen;
-  for (size_t f = 0; f < cstart.size(); ++f) {
-    if (!tstart.empty() && tlen.back() + clen[f] <= kJacP)
-      tlen.back() += clen[f];
-    else {
-      tstart.push_back(cstart[f]);
-      tlen.push_back(clen[f]);
+    return x;
+  };
+  for (const auto& ed : edges)
+    for (const auto& e : ed) {
+      int a = find(e.first), b = find(e.second);
+      if (a == b) continue;
+      if (csize[a] < csize[b]) std::swap(a, b);
+      parent[b] = a;
+      csize[a] += csize[b];
+      if (csize[a] > kJacP) return RVT_OK;  // a family larger than a tile: the dense iteration
     }
+  // members of every family in ascending order; families in the order of their first member
+  std::vector<int> first_of((size_t)N, -1);
+  std::vector<std::vector<int>> fam;
+  for (int64_t i = 0; i < N; ++i) {
+    const int r = find((int)i);
+    if (first_of[r] < 0) {
+      first_of[r] = (int)fam.size();
+      fam.emplace_back();
+    }
+    fam[first_of[r]].push_back((int)i);
   }
-  const size_t nt = tstart.size();
+  if (fam.size() < 2) return RVT_OK;
+  // tiles of consecutive families: trow[t] = the sample index behind every row of the tile
+  std::vector<std::vector<int>> trow;
+  for (const auto& f : fam) {
+    if (!trow.empty() && trow.back().size() + f.size() <= (size_t)kJacP)
+      trow.back().insert(trow.back().end(), f.begin(), f.end());
+    else
+      trow.push_back(f);
+  }
+  std::vector<int> tlen;
+  for (const auto& r : trow) tlen.push_back((int)r.size());
+  const size_t nt = trow.size();
   std::vector<double> A(nt * (size_t)kJacP * kJacP, 0.0);
   for (size_t t = 0; t < nt; ++t) {
     double* a = A.data() + t * (size_t)kJacP * kJacP;
-    const int64_t s0 = tstart[t];
+    const std::vector<int>& rows = trow[t];
     for (int q = 0; q < tlen[t]; ++q)
-      for (int r = 0; r < tlen[t]; ++r) a[(size_t)r * kJacP + q] = (double)K[(size_t)(s0 + r) + (size_t)(s0 + q) * N];
+      for (int r = 0; r < tlen[t]; ++r) a[(size_t)r * kJacP + q] = (double)K[(size_t)rows[r] + (size_t)rows[q] * N];
     for (int r = tlen[t]; r < kJacP; ++r) a[(size_t)r * kJacP + r] = -mu * (1.0 + (double)r / kJacP);  // pads: last, apart
   }
   hipStream_t st = c->stream;
@@ -1761,19 +1779,20 @@ static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K, const std:
   if ((int64_t)pairs.size() != N) return fail(c, RVT_E_STATE, "family-wise decomposition lost eigenpairs");
   std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.lam < y.lam; });  // ascending
   std::vector<float> S((size_t)N);
-  std::vector<int> meta(4 * (size_t)N);
+  std::vector<int> meta(3 * (size_t)N + nt * (size_t)kJacP, 0);  // tile | column | length per eigenpair, rows per tile
   for (int64_t k = 0; k < N; ++k) {
     S[k] = (float)pairs[k].lam;
     meta[k] = pairs[k].tile;
     meta[(size_t)N + k] = pairs[k].col;
-    meta[2 * (size_t)N + k] = tstart[pairs[k].tile];
-    meta[3 * (size_t)N + k] = tlen[pairs[k].tile];
+    meta[2 * (size_t)N + k] = tlen[pairs[k].tile];
   }
+  for (size_t t = 0; t < nt; ++t)
+    for (int r = 0; r < tlen[t]; ++r) meta[3 * (size_t)N + t * kJacP + r] = trow[t][r];
   if (U_out || install) {
     HIP_TRY(c, hipMalloc((void**)&b.dU, sizeof(float) * (size_t)N * (size_t)N));
     HIP_TRY(c, hipMemsetAsync(b.dU, 0, sizeof(float) * (size_t)N * (size_t)N, st));
-    HIP_TRY(c, hipMalloc((void**)&b.meta, sizeof(int) * 4 * (size_t)N));
-    HIP_TRY(c, hipMemcpyAsync(b.meta, meta.data(), sizeof(int) * 4 * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMalloc((void**)&b.meta, sizeof(int) * meta.size()));
+    HIP_TRY(c, hipMemcpyAsync(b.meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(jac_scatter_blocks_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.R, b.meta,
                        b.meta + N, b.meta + 2 * N, b.meta + 3 * N, (long long)N, b.dU);
     HIP_TRY(c, hipGetLastError());
@@ -1806,35 +1825,43 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
   const int nb = (int)(np / kJacB), pairs = nb / 2;
   // |lambda| <= max row sum of |K| (Gershgorin); the pad entries sit well outside
   double mu = 0.0;
-  std::vector<int> span_lo((size_t)N), span_hi((size_t)N);  // first / last non-zero row of every column
+  std::vector<std::vector<std::pair<int, int>>> edges;  // off-diagonal non-zeros (j, i), i > j, per scanning thread
+  bool sparse_pattern = true;                            // false: more non-zeros than families of <= 64 could have
   {
     // one pass over the N^2 floats on the host (40 GB at N = 100 000): column ranges dealt to a few threads
     const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)16, (int64_t)std::thread::hardware_concurrency(),
                                                                  N / 512}));
     std::vector<std::vector<double>> part((size_t)nthr, std::vector<double>((size_t)N, 0.0));
     std::vector<int> bad((size_t)nthr, 0);
+    edges.assign((size_t)nthr, {});
     std::vector<std::thread> pool;
     for (int t = 0; t < nthr; ++t)
       pool.emplace_back([&, t]() {
         std::vector<double>& rows = part[t];
-        for (int64_t j = N * t / nthr; j < N * (t + 1) / nthr; ++j) {
+        std::vector<std::pair<int, int>>& ed = edges[t];
+        const int64_t j0 = N * t / nthr, j1 = N * (t + 1) / nthr;
+        const size_t cap = (size_t)(j1 - j0) * kJacP;  // more non-zeros than families of 64 could have: a dense matrix
+        bool dense_here = false;
+        for (int64_t j = j0; j < j1; ++j) {
           const float* col = K + (size_t)j * N;
-          int l = (int)N, h = -1;
           for (int64_t i = 0; i < N; ++i) {
             if (!std::isfinite(col[i])) bad[t] = 1;
             rows[i] += std::fabs((double)col[i]);
-            if (col[i] != 0.0f) {
-              if (l > (int)i) l = (int)i;
-              h = (int)i;
+            if (col[i] != 0.0f && i > j && !dense_here) {  // (the lower triangle is enough: K is symmetric)
+              if (ed.size() >= cap)
+                dense_here = true;
+              else
+                ed.emplace_back((int)j, (int)i);
             }
           }
-          span_lo[j] = l;
-          span_hi[j] = h;
         }
+        if (dense_here) bad[t] |= 2;
       });
     for (auto& th : pool) th.join();
-    for (int t = 0; t < nthr; ++t)
-      if (bad[t]) return fail(c, RVT_E_INVALID, "kinship matrix holds a non-finite entry");
+    for (int t = 0; t < nthr; ++t) {
+      if (bad[t] & 1) return fail(c, RVT_E_INVALID, "kinship matrix holds a non-finite entry");
+      if (bad[t] & 2) sparse_pattern = false;
+    }
     for (int64_t i = 0; i < N; ++i) {
       double r = 0.0;
       for (int t = 0; t < nthr; ++t) r += part[t][i];
@@ -1844,7 +1871,7 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
   }
   if (!getenv("RVT_KINSHIP_DENSE")) {  // a block-diagonal (pedigree) kinship is decomposed family by family
     bool done = false;
-    rc = decompose_by_family(c, N, K, span_lo, span_hi, mu, np, U_out, S_out, install, info, &done);
+    if (sparse_pattern) rc = decompose_by_family(c, N, K, edges, mu, np, U_out, S_out, install, info, &done);
     if (rc || done) return rc;
   }
   struct Bufs {

@@ -502,6 +502,8 @@ class Engine:
         self._check(self.L.rvt_kinship_decompose(self.ctx, N, K.ctypes.data_as(fp),
                                                  U.ctypes.data_as(fp) if want_vectors else None, S.ctypes.data_as(fp),
                                                  1 if install else 0, C.byref(info)))
+        if install:
+            self.N = N
         return U, S, info
 
     def vcf_set_samples(self, row_of_sample):

@@ -128,9 +128,10 @@ def _block_kinship(rng, sizes):
 
 
 def test_block_diagonal_kinship_is_decomposed_family_by_family(eng):
-    """Families listed one after the other (sizes 1..9, an all-zero row / column among them): no block sweeps, the
-    eigenpairs of the blocks merged in ascending order.  The same matrix with its samples shuffled is not of that form
-    and goes through the dense iteration — same spectrum."""
+    """Separate families (sizes 1..9, an all-zero row / column among them): no block sweeps, the eigenpairs of the
+    blocks merged in ascending order — with the families listed one after the other and with the samples shuffled
+    (connected components of the sparsity pattern).  One family larger than a tile sends the matrix to the dense
+    iteration; the spectrum is the same every time."""
     rng = np.random.default_rng(12)
     sizes = rng.choice([1, 2, 3, 4, 6, 9], size=260)
     K = _block_kinship(rng, sizes)
@@ -145,5 +146,35 @@ def test_block_diagonal_kinship_is_decomposed_family_by_family(eng):
     Kp = np.ascontiguousarray(K32[np.ix_(perm, perm)])
     U2, S2, info2 = eng.kinship_decompose(Kp)
     _check(Kp, U2, S2, info2)
-    assert info2.sweeps >= 1
+    assert info2.sweeps == 0 and (np.count_nonzero(U2, axis=0) <= 9).all()
     assert np.abs(S2 - S).max() <= 2e-6 * np.abs(S).max()
+    big = _block_kinship(rng, [70, 3, 4, 2, 5] * 20).astype(np.float32)
+    U3, S3, info3 = eng.kinship_decompose(big)
+    _check(big, U3, S3, info3)
+    assert info3.sweeps >= 1
+
+
+def test_shuffled_families_through_famskat(eng):
+    """Families interleaved in the sample order: decomposition by connected components, installation, FamSKAT against the
+    oracle on the same (shuffled) data."""
+    N, K, U0, S0, X, y = make_family_case(90, 2, 33)
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(N)
+    Kp = np.ascontiguousarray(K[np.ix_(perm, perm)]).astype(np.float32)
+    Xp, yp = X[perm], y[perm]
+    genes = [synth.make_gene(N, M, seed=300 + M, missing=0.01, common=True)[1] for M in (6, 21)]
+    U1, S1, info = eng.kinship_decompose(Kp)
+    assert info.sweeps == 0
+    eng.kinship_decompose(Kp, install=True, want_vectors=False)
+    nul = eng.fit_fam_null(Xp, yp)
+    ptrs = [eng.upload_block(G) for G in genes]
+    out = eng.run_fam_blocks(ptrs, [G.shape[1] for G in genes])
+    onul = orc.FamNull()
+    onul.ok = 1
+    onul.delta, onul.sigma2 = nul.delta, nul.sigma2_g
+    for k in range(2):
+        onul.beta[k] = nul.beta[k]
+    for r, G in zip(out, genes):
+        rc, o = orc.famskat(G, Xp, yp, U1.astype(np.float64), S1.astype(np.float64), onul)
+        assert rc == 0 and r.famskat_ok == 1
+        assert abs(r.famskat_Q - o.Q) <= 1e-6 * o.Q and abs(r.famskat_p - o.pvalue) <= 1e-5 * o.pvalue + 1e-12
