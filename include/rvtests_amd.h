@@ -339,7 +339,8 @@ int rvt_set_kinship(rvt_ctx* ctx, int64_t N, const float* U, const float* S);
 /* Structure of the installed eigenvectors.  The kinship of unrelated families is block diagonal, and then so is U: every
  * eigenvector is non-zero on one family's samples only.  rvt_set_kinship detects that (first / last non-zero row of each
  * column), re-orders the eigenpairs by support — the statistics do not depend on their order — and the rotation U'G then
- * visits only the K chunks that hold non-zeros: visited_fraction = the share of the N x N product that is computed
+ * visits only the K chunks that hold non-zeros (families listed contiguously) or gathers the few non-zeros of every
+ * eigenvector (families interleaved in the sample order): visited_fraction = the share of the N x N product that is computed
  * (1 = dense U, e.g. a GRM's eigenvectors; ~4 / 782 for nuclear families at N = 100 000).  The skipped parts are exact
  * zeros, so the rotated values are those of the dense product (the statistics sum the eigenpairs in the new order: equal to
  * rounding).  RVT_KINSHIP_DENSE=1 in the environment disables the detection. */

@@ -364,6 +364,63 @@ __global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, cons
   for (long long i = threadIdx.x; i < ldk / 16; i += blockDim.x) d[i] = s[i];
 }
 
+// ---- sparse eigenvectors (families interleaved in the sample order) --------------------------------------------------------
+// non-zeros per column of a float matrix; grid = columns
+__global__ void rot_nnz_count_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ count) {
+  __shared__ int red[256];
+  const float* s = src + (long long)blockIdx.x * ld_src;
+  int c = 0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) c += (s[i] != 0.0f) ? 1 : 0;
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[blockIdx.x] = red[0];
+}
+// the non-zeros of column blockIdx.x, in ascending row order, to rows / vals at offset colptr[blockIdx.x]; 256 threads
+__global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* __restrict__ src, long long n, long long ld_src,
+                                                           const long long* __restrict__ colptr, int* __restrict__ rows,
+                                                           double* __restrict__ vals) {
+  __shared__ int wsum[4];
+  __shared__ long long base;
+  const float* s = src + (long long)blockIdx.x * ld_src;
+  if (threadIdx.x == 0) base = colptr[blockIdx.x];
+  __syncthreads();
+  for (long long i0 = 0; i0 < n; i0 += 256) {
+    const long long i = i0 + threadIdx.x;
+    const float v = i < n ? s[i] : 0.0f;
+    const bool nz = v != 0.0f;
+    const unsigned long long m = __ballot(nz);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (nz) {
+      rows[base + before] = (int)i;
+      vals[base + before] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+// out[k + t ld_dst] = sum over the non-zeros e of column k of U: vals[e] * G[rows[e] + t ld_src]   (U' G for sparse U);
+// grid (ceil(n / 256), columns of G)
+__global__ __launch_bounds__(256) void rot_sparse_kernel(const long long* __restrict__ colptr, const int* __restrict__ rows,
+                                                         const double* __restrict__ vals, long long n,
+                                                         const double* __restrict__ G, long long ld_src,
+                                                         double* __restrict__ out, long long ld_dst) {
+  const long long k = blockIdx.x * 256ll + threadIdx.x;
+  if (k >= n) return;
+  const double* g = G + (long long)blockIdx.y * ld_src;
+  double s = 0.0;
+  for (long long e = colptr[k]; e < colptr[k + 1]; ++e) s = fma(vals[e], g[rows[e]], s);
+  out[k + (long long)blockIdx.y * ld_dst] = s;
+}
+
 // per-column max |x| of a double matrix (column-major, ld)
 __global__ void rot_colmax_kernel(const double* __restrict__ src, long long n, long long ld, double* __restrict__ out) {
   __shared__ double red[256];

@@ -98,6 +98,11 @@ struct rvt_ctx {
   // eigenvectors of the kinship as kRotPlanesU signed base-128 digit planes (rot_gemm.hip.h): plane p at
   // d_Uq + p * uq_plane, row k (= column k of U) at k * uq_ldk; scaled by 2^uq_sexp
   signed char* d_Uq = nullptr;
+  // sparse form of U (<= 64 non-zeros per eigenvector on average: families in any sample order), column-compressed;
+  // used by the rotation when the K-chunk ranges (d_uq_range) do not apply; null otherwise
+  long long* d_csc_ptr = nullptr;
+  int* d_csc_rows = nullptr;
+  double* d_csc_vals = nullptr;
   int2* d_uq_range = nullptr;  // per 256-row panel of the planes: K chunks [x, y) that hold its non-zeros; null = dense U
   double uq_visit = 1.0;       // fraction of the K chunks the rotation visits (1 = dense)
   size_t uq_plane = 0;
@@ -640,6 +645,8 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_uq_range) hipFree(c->d_uq_range);
+  for (void* q : {(void*)c->d_csc_ptr, (void*)c->d_csc_rows, (void*)c->d_csc_vals})
+    if (q) hipFree(q);
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_part) hipFree(c->d_rot_part);
@@ -1541,6 +1548,10 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   c->d_Uq = nullptr;
   if (c->d_uq_range) hipFree(c->d_uq_range);
   c->d_uq_range = nullptr;
+  for (void** q : {(void**)&c->d_csc_ptr, (void**)&c->d_csc_rows, (void**)&c->d_csc_vals}) {
+    if (*q) hipFree(*q);
+    *q = nullptr;
+  }
   c->uq_visit = 1.0;
   c->have_kin = c->have_fam = false;
   HIP_TRY(c, hipMalloc((void**)&c->d_S, sizeof(double) * N));
@@ -1552,6 +1563,10 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
   c->uq_sexp = 7 * kRotPlanesU - 3;
   HIP_TRY(c, hipMalloc((void**)&c->d_Uq, c->uq_plane * kRotPlanesU));
   HIP_TRY(c, hipMemsetAsync(c->d_Uq, 0, c->uq_plane * kRotPlanesU, c->stream));
+  const long long csc_cap = 64ll * N;  // non-zeros the sparse form may hold
+  std::vector<long long> csc_ptr((size_t)N + 1, 0);
+  bool csc_ok = !getenv("RVT_KINSHIP_DENSE");
+  int* d_cnt = nullptr;
   int* d_span = nullptr;  // first / last non-zero row of every column of U
   struct SpanGuard {
     int** p;
@@ -1565,6 +1580,10 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     double* d_tmp64 = nullptr;
     int* d_flag = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d_span, sizeof(int) * 2 * (size_t)N));
+    HIP_TRY(c, hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)cols_per));
+    HIP_TRY(c, hipMalloc((void**)&c->d_csc_ptr, sizeof(long long) * (size_t)(N + 1)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_csc_rows, sizeof(int) * (size_t)csc_cap));
+    HIP_TRY(c, hipMalloc((void**)&c->d_csc_vals, sizeof(double) * (size_t)csc_cap));
     HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(float) * (size_t)cols_per * N));
     HIP_TRY(c, hipMalloc((void**)&d_tmp64, sizeof(double) * (size_t)cols_per * N));
     HIP_TRY(c, hipMalloc((void**)&d_flag, sizeof(int)));
@@ -1579,6 +1598,22 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
                          (long long)k0, d_flag);
       hipLaunchKernelGGL(rot_span_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp, (long long)N, (long long)N,
                          d_span + k0, d_span + N + k0);
+      if (csc_ok) {  // column-compressed copy of the chunk while it fits the budget of 64 non-zeros per column
+        hipLaunchKernelGGL(rot_nnz_count_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp, (long long)N,
+                           (long long)N, d_cnt);
+        std::vector<int> cnt((size_t)nc);
+        HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, sync_stream(c->stream));
+        for (int64_t j = 0; j < nc; ++j) csc_ptr[k0 + j + 1] = csc_ptr[k0 + j] + cnt[j];
+        if (csc_ptr[k0 + nc] > csc_cap) {
+          csc_ok = false;
+        } else {
+          HIP_TRY(c, hipMemcpyAsync(c->d_csc_ptr + k0, csc_ptr.data() + k0, sizeof(long long) * (size_t)(nc + 1),
+                                    hipMemcpyHostToDevice, c->stream));
+          hipLaunchKernelGGL(rot_nnz_fill_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp, (long long)N,
+                             (long long)N, c->d_csc_ptr + k0, c->d_csc_rows, c->d_csc_vals);
+        }
+      }
       hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(1024), dim3(256), 0, c->stream, d_tmp, d_tmp64, n);
       hipLaunchKernelGGL(column_sums_kernel, dim3((unsigned)nc), dim3(256), 0, c->stream, d_tmp64, (long long)N,
                          (long long)N, c->d_u1 + k0);
@@ -1589,6 +1624,12 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     hipFree(d_tmp);
     hipFree(d_tmp64);
     hipFree(d_flag);
+    hipFree(d_cnt);
+    if (!csc_ok)
+      for (void** q : {(void**)&c->d_csc_ptr, (void**)&c->d_csc_rows, (void**)&c->d_csc_vals}) {
+        if (*q) hipFree(*q);
+        *q = nullptr;
+      }
     if (bad) return fail(c, RVT_E_INVALID, "kinship eigenvectors have entries >= 2 in magnitude (not unit vectors)");
   }
   c->h_S.resize(N);
@@ -1653,6 +1694,14 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
       HIP_TRY(c, hipMalloc((void**)&c->d_uq_range, sizeof(int2) * (size_t)nrp));
       HIP_TRY(c, hipMemcpy(c->d_uq_range, range.data(), sizeof(int2) * (size_t)nrp, hipMemcpyHostToDevice));
       c->uq_visit = frac;
+      for (void** q : {(void**)&c->d_csc_ptr, (void**)&c->d_csc_rows, (void**)&c->d_csc_vals}) {  // not needed then
+        if (*q) hipFree(*q);
+        *q = nullptr;
+      }
+    } else if (c->d_csc_ptr) {
+      // sparse eigenvectors whose supports are scattered over the samples (families interleaved in the sample order):
+      // the rotation gathers (rot_sparse_kernel); eigenpairs stay in the caller's order
+      c->uq_visit = (double)csc_ptr[N] / ((double)N * (double)N);
     }
   }
   HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -2128,6 +2177,13 @@ int planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int n
 static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int ncols, double* d_dst, int64_t ld_dst,
                           hipStream_t st) {
   const int64_t N = c->kin_N;
+  if (c->d_csc_ptr && !c->d_uq_range) {  // sparse U, scattered supports: a gather per output (fp64 products and sums)
+    hipLaunchKernelGGL(rot_sparse_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ncols), dim3(256), 0, st,
+                       c->d_csc_ptr, c->d_csc_rows, c->d_csc_vals, (long long)N, d_src, (long long)ld_src, d_dst,
+                       (long long)ld_dst);
+    HIP_TRY(c, hipGetLastError());
+    return RVT_OK;
+  }
   for (int c0 = 0; c0 < ncols; c0 += kRotMaxCols) {  // long lists in pieces
     const int nc = std::min(kRotMaxCols, ncols - c0);
     QuantCols qb;
@@ -2844,7 +2900,8 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
     HIP_TRY(c, hipMemset2DAsync(c->d_Gt + N, sizeof(double) * (size_t)ld, 0, sizeof(double) * (size_t)(ld - N), T + TB, st));
   // FamSKAT alone on hard calls: the flipped columns go straight to the int8 plane of the rotation (no fp64 copy, no
   // column scan, no separate quantiser pass)
-  const bool direct = !burden && all_hard && c->hc_enabled && !getenv("RVT_FAM_NO_DIRECT");
+  const bool direct = !burden && all_hard && c->hc_enabled && !(c->d_csc_ptr && !c->d_uq_range) &&
+                      !getenv("RVT_FAM_NO_DIRECT");
   if (!direct)
     hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
                        (long long)N, (long long)ld, c->d_Gp);

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--genes", type=int, default=256)
     ap.add_argument("--variants", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--shuffle", action="store_true",
+                    help="families interleaved in the sample order (random membership): the sparse-gather rotation")
     ap.add_argument("--dense", action="store_true",
                     help="treat U as a dense matrix (RVT_KINSHIP_DENSE=1): the rate of a GRM's eigenvectors")
     a = ap.parse_args()
@@ -29,12 +31,14 @@ def main():
     blk = np.array([[1, 0, .5, .5], [0, 1, .5, .5], [.5, .5, 1, .5], [.5, .5, .5, 1]])
     s4, u4 = np.linalg.eigh(blk)
     U = np.zeros((N, N), dtype=np.float32, order="F")
+    member = rng.permutation(N) if a.shuffle else np.arange(N)
     for f in range(N // 4):
-        U[4 * f:4 * f + 4, 4 * f:4 * f + 4] = u4
+        U[member[4 * f:4 * f + 4], 4 * f:4 * f + 4] = u4
     S = np.tile(s4, N // 4).astype(np.float32)
     # a random orthogonal mixing inside the eigenspaces is not needed: any orthogonal U with these S is a valid input
     X = np.column_stack([np.ones(N), rng.standard_normal(N), rng.standard_normal(N)])
-    fam = np.repeat(rng.standard_normal(N // 4), 4)
+    fam = np.zeros(N)
+    fam[member] = np.repeat(rng.standard_normal(N // 4), 4)
     y = 0.3 * X[:, 1] - 0.2 * X[:, 2] + np.sqrt(0.4) * fam + np.sqrt(0.6) * rng.standard_normal(N)
     if a.dense:
         os.environ["RVT_KINSHIP_DENSE"] = "1"
