@@ -16,6 +16,7 @@ stats() {  # stats <name> <program args...>: rocprofv3 kernel statistics of one 
 }
 stats famskat python3 tools/bench_famskat.py --samples 100000 --genes 128
 stats famskat_dense python3 tools/bench_famskat.py --samples 100000 --genes 128 --dense
+stats famskat_shuffled python3 tools/bench_famskat.py --samples 100000 --genes 128 --shuffle
 stats metascore python3 tools/bench_metascore.py
 stats metacov python3 tools/bench_metacov.py --reps 5
 stats perm python3 tools/bench_perm.py
