@@ -160,6 +160,8 @@ typedef struct rvt_timing {
   double ms_suffstat_hc;   /* of ms_suffstat: the gene_suffstat_hc launches                              */
   int64_t n_suffstat_hc_launches;
   double alg_bytes_hc;     /* of alg_bytes: the hard-call genes                                           */
+  int64_t genes_handed_back; /* of genes_hard_call: those whose block held something else (dosages) and that were
+                                computed again by the fp64 kernel                                              */
 } rvt_timing;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -184,23 +186,30 @@ int rvt_set_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, con
  * fit() is called), N x M doubles, column-major with leading dimension rvt_padded_ld(N), pad = 0. */
 int rvt_block_alloc(rvt_ctx* ctx, int M, double** dG_out);
 int rvt_block_free(rvt_ctx* ctx, double* dG);
-/* copy a host N x M column-major matrix (leading dimension N) into a block; the copy is followed by one streaming pass
- * that records whether the block holds hard calls only (see rvt_block_classify) */
+/* copy a host N x M column-major matrix (leading dimension N) into a block */
 int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
-/* Hard-call blocks.  When every entry of a block is exactly 0.0, 1.0 or 2.0 (no dosages, no imputed means) and the null
- * model is unweighted (quantitative trait), G'G is an integer matrix and the engine computes it on the int8 matrix
- * cores instead of the fp64 ones, with the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h) —
- * the results are the same numbers (the integer part exactly, G'X and G'r by the same fp64 products), the kernel is
- * then bound by HBM alone.  Under a binary trait (weights v = p (1 - p)) the weighted Gram matrix takes the int8 cores
- * as well, with v split once per null model into six 7-bit digit planes (suffstat_hcw.hip.h; M <= 80, weights in
- * [0, 0.49], agreement with the fp64 kernel ~1e-12 relative).  What a block holds is recorded when it is written through this ABI (rvt_block_upload,
- * rvt_submit_gene*: one extra streaming pass, ~0.03 ms per gene at N = 500 000) and forgotten when it is modified or
- * freed.  For a device allocation the engine did not fill (e.g. a torch tensor handed to rvt_run_blocks)
- * rvt_block_classify scans it once and records the answer (is_hard_call may be NULL); the CALLER must call it again,
- * or rvt_block_forget, after changing the block's content or releasing the memory.  Blocks the engine knows nothing
- * about take the general fp64 kernel. */
+/* Hard calls.  Where the entries of a block are exactly 0.0, 1.0 or 2.0 and the null model is unweighted (quantitative
+ * trait), G'G is an integer matrix and the engine computes it on the int8 matrix cores instead of the fp64 ones, with
+ * the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h): same numbers (the integer part exactly,
+ * G'X and G'r by the same fp64 products), and the kernel is bound by HBM alone.  A column that imputeGenotypeToMean
+ * (src/DataConsolidator.cpp:217-245) has filled — hard calls plus ONE other value in the places of the missing calls —
+ * stays on that kernel: the other value is carried as a 0/1 mask, three integer matrices and one multiplication per
+ * entry of G'G.  Under a binary trait (weights v = p (1 - p)) the weighted Gram matrix takes the int8 cores as well, with
+ * v split once per null model into six 7-bit digit planes (suffstat_hcw.hip.h; M <= 80, weights in [0, 0.49], agreement
+ * with the fp64 kernel ~1e-12 relative; hard calls only).
+ * NOTHING is remembered about the content of a block.  The integer kernels test every value they load; a block that
+ * holds anything else (dosages) is handed back and computed by the fp64 kernel in the same call — the records are the
+ * same either way.  Which kernel a block starts on is a prediction: what the engine's own decoders wrote; for the
+ * caller's doubles (rvt_submit_gene, rvt_submit_gene_raw, rvt_run_blocks*): hard calls, unless the caller has said
+ * otherwise with rvt_set_content_hint(ctx, 0) — what an adapter does when the analysis reads dosages (`--dosage`,
+ * src/Main.cpp FLAG_dosageTag; BGEN input) and the test blocks would only be handed back.  A wrong hint costs time, never
+ * correctness.  hint: -1 unknown (default), 0 dosages, 1 hard calls / mean-imputed hard calls.
+ * rvt_block_classify is a query for tools and tests: one streaming pass, 1 when every entry is 0.0 / 1.0 / 2.0. */
 int rvt_block_classify(rvt_ctx* ctx, const double* dG, int M, int* is_hard_call);
-int rvt_block_forget(rvt_ctx* ctx, const double* dG);
+int rvt_set_content_hint(rvt_ctx* ctx, int hint);
+/* experiments / tests: on = 0 keeps every gene on the fp64 kernel (as the environment variable RVT_HARDCALL=0 does for
+ * the whole process), on = 1 restores the default */
+int rvt_set_hardcall(rvt_ctx* ctx, int on);
 
 /* Run the selected tests on n_genes blocks that are already in HBM.  dG[g] are DEVICE pointers
  * (rvt_block_alloc, or any 128-byte aligned device allocation with the layout above, e.g. a torch

@@ -188,30 +188,51 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 //   flags[0 .. MT)      flip bits per 16-variant block (column sum > N)
 //   flags[MT .. 2 MT)   polymorphic bits
 //   flags[2 MT]         1 = the burden sums of gene_suffstat_hc are NOT valid: a column's flip was predicted wrongly
-//                       (allele frequency vs exact column sum) or a monomorphic column was counted by the collapse
-//                       (all-1 column; all-0 and all-2 columns never count) -> burden_fallback_kernel redoes them
+//                       (allele frequency vs exact column sum), a monomorphic column was counted by the collapse
+//                       (all-1 column; all-0 and all-2 columns never count), or a column's imputed value counts
+//                       ((int)g' > 0) where the in-pass collapse skips masked entries -> burden_fallback_kernel
+//   flags[2 MT + 1]     1 = the block is not "hard calls + one imputed value per column" (dosages, -inf): the statistics
+//                       of gene_suffstat_hc are void; gene_assemble marks the gene kStatusRerun and the engine runs it
+//                       again on the general fp64 kernel
 // =====================================================================================================
 __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N) {
   const GeneDesc gd = genes[blockIdx.x];
   const int tid = threadIdx.x;
-  bool bad = false;
+  bool bad = false, rerun = false;
+  for (int p = tid; p < gd.n_wparts; p += 64) rerun |= gd.wflags && (gd.wflags[p] & 2u);  // an entry with code 3 (-inf)
   for (int base = 0; base < gd.Mp; base += 64) {
     const int j = base + tid;
-    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    double s = 0.0, mn = INFINITY, mx = -INFINITY, cm = 0.0;
+    unsigned long long orb = 0ull, andb = ~0ull;
     if (j < gd.M) {
       for (int p = 0; p < gd.n_wparts; ++p) {
-        const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+        const double* c = gd.colstat + (long long)p * kHcColstatRows * gd.Mp;
         s += c[j];
         mn = fmin(mn, c[gd.Mp + j]);
         mx = fmax(mx, c[2 * gd.Mp + j]);
+        cm += c[3 * gd.Mp + j];
+        orb |= reinterpret_cast<const unsigned long long*>(c)[4 * gd.Mp + j];
+        andb &= reinterpret_cast<const unsigned long long*>(c)[5 * gd.Mp + j];
       }
     }
     const bool in = j < gd.M;
+    // masked entries: one bit pattern per column (OR == AND), a finite value in [0, 2] — the mean imputeGenotypeToMean
+    // wrote (src/DataConsolidator.cpp:217-245).  Anything else (dosages) is the general kernel's.
+    const double mu = rvt_bits_to_double(orb);
+    const bool masked = in && cm > 0.0;
+    if (masked) {
+      if (orb != andb || !(mu >= 0.0 && mu <= 2.0)) rerun = true;
+      s += cm * mu;
+      mn = fmin(mn, mu);
+      mx = fmax(mx, mu);
+    }
     const bool flip = in && !(s <= (double)N);
     const bool poly = in && !(mn == mx);
     const bool pred = in && (j >> 4) < 8 && ((gd.pflip[(j >> 4) & 7] >> (j & 15)) & 1);
     const bool counted_mono = in && !poly && (pred ? mn != 2.0 : mn != 0.0);
-    bad |= (flip != pred) || counted_mono;
+    // the in-pass collapse never counts a masked entry: wrong when (int)g' > 0 for the imputed value
+    const bool masked_counts = masked && poly && (flip ? mu <= 1.0 : mu >= 1.0);
+    bad |= (flip != pred) || counted_mono || masked_counts;
     const unsigned long long bf = __ballot(flip), bp = __ballot(poly);
     if (tid < 4) {
       const int b = (base >> 4) + tid;
@@ -221,8 +242,11 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
       }
     }
   }
-  const bool any = __any(bad);
-  if (tid == 0) gd.flags[2 * gd.MT] = any ? 1 : 0;
+  const bool any = __any(bad), anyr = __any(rerun);
+  if (tid == 0) {
+    gd.flags[2 * gd.MT] = (any && !anyr) ? 1 : 0;
+    gd.flags[2 * gd.MT + 1] = anyr ? 1 : 0;
+  }
 }
 
 // Burden partial sums of a hard-call gene straight from its genotype block with the ACTUAL flags (rare: see above).
@@ -300,10 +324,13 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT)};
+  const bool masks = gd.hc == 1;  // (pq is null for the weighted hard-call kernel: 6-row statistics, no masked tiles)
+  const unsigned force = (gd.hc && gd.flags[2 * gd.MT + 1]) ? kStatusRerun : 0u;
   gene_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
                 (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, gd.n_bparts > 0 ? gd.n_bparts : n_bparts,
                 gd.af, prm, tests, ws,
-                gd.stats, gd.dbg_flip, gd.dbg_kept);
+                gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, force);
 }
 
 __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
@@ -870,11 +897,26 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
   const int V = gd.M, h = threadIdx.x;
   if (h >= V) return;
   const long long col = gd.gene_id + h;
-  double mn = INFINITY, mx = -INFINITY;
+  double mn = INFINITY, mx = -INFINITY, cm = 0.0;
+  unsigned long long orb = 0ull, andb = ~0ull;
+  bool redo = false;  // hard-call slice that holds something else: the host runs the slice again on the fp64 kernel
+  const int cs_rows = gd.hc ? kHcColstatRows : 3;
   for (int p = 0; p < gd.n_wparts; ++p) {
-    const double* c = gd.colstat + (long long)p * 3 * gd.Mp;
+    const double* c = gd.colstat + (long long)p * cs_rows * gd.Mp;
     mn = fmin(mn, c[gd.Mp + h]);
     mx = fmax(mx, c[2 * gd.Mp + h]);
+    if (gd.hc) {
+      cm += c[3 * gd.Mp + h];
+      orb |= reinterpret_cast<const unsigned long long*>(c)[4 * gd.Mp + h];
+      andb &= reinterpret_cast<const unsigned long long*>(c)[5 * gd.Mp + h];
+      redo |= gd.wflags && (gd.wflags[p] & 2u);
+    }
+  }
+  const double mu = rvt_bits_to_double(orb);
+  if (cm > 0.0) {  // mean-imputed column (suffstat_hc.hip.h): one value for every masked entry
+    redo |= orb != andb || !(mu >= 0.0 && mu <= 2.0);
+    mn = fmin(mn, mu);
+    mx = fmax(mx, mu);
   }
   const int polymorphic = (mn == mx) ? 0 : 1;
   const int d = ncp->d, binary = ncp->binary;
@@ -887,6 +929,8 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
     for (int k = 0; k < d; ++k) t[k] += row[V + k];
     u += row[V + d];
   }
+  // the diagonal of the hard-call Gram tile is sum (H + 4m)^2 = sum H^2 + 16 cm, and H = 0 where masked
+  if (cm > 0.0) shh = (shh - 16.0 * cm) + (mu * mu) * cm;
   double q = 0.0;
   for (int k = 0; k < d; ++k) {
     double s = 0.0;
@@ -894,9 +938,9 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
     q += t[k] * s;
   }
   const double SS = shh - q;
-  const int fit = polymorphic && SS > 0.0;
+  const int fit = redo ? -2 : (polymorphic && SS > 0.0);
   double us = 0.0, vs = 0.0, eff = 0.0, se = 0.0, pv = 1.0;
-  if (fit) {
+  if (fit > 0) {
     if (!binary) {
       us = u / sigma2;
       vs = SS / sigma2;
@@ -1000,8 +1044,9 @@ template <int DMAX>
 __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restrict__ G, long long N, long long ld, int W,
                                                           const double* __restrict__ X, long long ldx, int d,
                                                           signed char* __restrict__ out8, long long ldk,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, int* __restrict__ bad) {
   const int c0 = blockIdx.x * kCovHcCols;
+  bool not_hard = false;  // a value other than 0.0 / 1.0 / 2.0: the int8 copy is not the block (the host falls back)
   const int nc = min(kCovHcCols, W - c0);
   const long long per = ((N + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
   const long long i0 = (long long)blockIdx.y * per, i1 = (i0 + per < N) ? i0 + per : N;
@@ -1023,6 +1068,7 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
       if (c < nc) {
         const double g = G[(long long)(c0 + c) * ld + i];
         out8[(long long)(c0 + c) * ldk + i] = (signed char)(int)g;
+        not_hard |= !(g == 0.0 || g == 1.0 || g == 2.0);
         s[c] += g;
         mn[c] = fmin(mn[c], g);
         mx[c] = fmax(mx[c], g);
@@ -1033,6 +1079,7 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
   }
   __shared__ double red[4][kCovHcCols][DMAX + 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (__any(not_hard) && lane == 0) atomicOr(bad, 1);
 #pragma unroll
   for (int c = 0; c < kCovHcCols; ++c) {
     double v = s[c], a = mn[c], b = mx[c];

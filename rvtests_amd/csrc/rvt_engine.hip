@@ -79,12 +79,31 @@ struct Slot {
   rvt_gene_result* h_results = nullptr;
   int pending_n = 0;
   unsigned long long seq = 0;  // launch order
+  // what the batch was, for the genes the hard-call kernel hands back (kStatusRerun): they run again on the general
+  // kernel when the batch is finished (finish_slot)
+  struct Rerun {
+    std::vector<const double*> dG;
+    std::vector<int> M;
+    std::vector<double> af;      // concatenated
+    std::vector<size_t> af_off;  // per gene
+    std::vector<int64_t> ids;
+    std::vector<unsigned char> predicted;  // 1: the gene took the hard-call kernel on a prediction (unknown content)
+    uint32_t tests = 0;
+    rvt_params prm;
+    bool armed = false;
+    // a re-run that was launched ahead of finish_slot (poll_reruns): which slot computes it, which genes, their records
+    int launched_slot = -1;
+    std::vector<int> idx;
+    std::vector<rvt_gene_result> res;
+  } rerun;
 };
 constexpr int kSlots = RVT_MAX_INFLIGHT;
+constexpr int kRerunSlots = 2;               // slots that re-runs on the general kernel use (never part of the rotation)
+constexpr int kSlotsAll = kSlots + kRerunSlots;
 
 struct rvt_ctx {
   int device = 0;
-  Slot slots[kSlots];
+  Slot slots[kSlotsAll];
   unsigned long long launch_seq = 0;
   hipStream_t stream = nullptr;  // == slots[0].stream (set-up work, rvt_stream())
   hipStream_t io_stream = nullptr;  // host copies + consolidation of the streaming interface: never behind a batch
@@ -188,7 +207,7 @@ struct rvt_ctx {
   double *d_perm_R = nullptr, *d_perm_C = nullptr, *d_perm_Q = nullptr, *d_perm_cur = nullptr;
   size_t perm_cap_NB = 0, perm_cap_BM = 0;
   int perm_cap_B = 0;
-  hipEvent_t ev_in[kSlots] = {}, ev_k2[kSlots] = {}, ev_k2b[kSlots] = {};
+  hipEvent_t ev_in[kSlotsAll] = {}, ev_k2[kSlotsAll] = {}, ev_k2b[kSlotsAll] = {};
   std::string err;
   // null model
   bool have_null = false;
@@ -200,14 +219,14 @@ struct rvt_ctx {
   double* d_nulltile_w = nullptr;
   unsigned char* d_vq = nullptr;
   int64_t null_ld = 0;
-  // what is known about the CONTENT of device blocks: 1 = every entry is exactly 0.0, 1.0 or 2.0 ("hard calls": the
-  // integer sufficient-statistics kernel applies), 0 = anything else.  Recorded when a block is uploaded through the
-  // ABI (one streaming pass, ~0.03 ms per gene against ~5 ms of PCIe) or registered with rvt_block_classify; erased
-  // when the block is written to or freed.  Unknown pointers take the general fp64 kernel.
-  std::unordered_map<const void*, int> block_kind;
-  int* d_kind = nullptr;      // device flag of the synchronous classification
-  int* d_kind_ring = nullptr; // flags of streaming submissions (kAfSlots), copied back with the allele frequencies
-  int* h_kind_ring = nullptr; // pinned mirror
+  // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
+  // double it loads and hands back genes that hold anything but hard calls and one imputed value per column
+  // (kStatusRerun; finish_slot runs them again on the general fp64 kernel).  The engine's own decoders say what they
+  // wrote (hint per gene: 1 hard calls / imputed, 0 dosages); blocks of unknown content (fp64 from the caller) start on
+  // the hard-call kernel unless the caller has said they hold dosages (rvt_set_content_hint).  No history: the kernel
+  // a block runs on — and with it the last bits of its records — depends on the block and the hint alone.
+  int content_hint = -1;
+  int* d_kind = nullptr;      // device flag of rvt_block_classify (a stateless query)
   bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
   bool k2_alternate = false;  // RVT_K2_ALT=1: consecutive hard-call launches alternate between the two K2 streams
   double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
@@ -224,8 +243,7 @@ struct rvt_ctx {
     rvt_gene_result res;  // filled by the batch this gene was launched in (the queue is a deque: stable addresses)
     bool launched;
     int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
-    int kind = 0;         // 1: hard-call block (see block_kind)
-    int kind_slot = -1;   // >= 0: the classification flag is still on its way back (kind_ring slot)
+    int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages, -1 unknown
   };
   std::deque<Pending> queue;
   std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
@@ -292,6 +310,8 @@ int ensure_arena(rvt_ctx* c, Slot& sl, size_t bytes) {
   const size_t want = bytes + bytes / 4;
   HIP_TRY(c, hipMalloc((void**)&sl.arena.base, want));
   sl.arena.cap = want;
+  // tests: fill the workspace with a byte pattern — no result may depend on what a fresh allocation happens to hold
+  if (const char* e = getenv("RVT_POISON")) HIP_TRY(c, hipMemset(sl.arena.base, atoi(e) & 0xff, want));
   return RVT_OK;
 }
 
@@ -308,15 +328,39 @@ int ensure_stage(rvt_ctx* c, Slot& sl, size_t bytes) {
   return RVT_OK;
 }
 
-// wait for one slot's batch and hand its records to the caller
+int rerun_launch(rvt_ctx* c, Slot& sl, const rvt_gene_result* h, int n, bool wait_for_slot);
+int poll_reruns(rvt_ctx* c);
+
+// wait for one slot's batch and hand its records to the caller.  Genes the hard-call kernel handed back (kStatusRerun:
+// their block holds something other than hard calls and one imputed value per column) first run again on the general
+// kernel.
 int finish_slot(rvt_ctx* c, Slot& sl) {
   HIP_TRY(c, sync_stream(sl.stream));
   if (sl.pending_out) {
-    std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
-    if (sl.pending_done) *sl.pending_done = true;
+    rvt_gene_result* out = sl.pending_out;
+    rvt_gene_result* h = sl.h_results;
+    bool* done = sl.pending_done;
+    const int n = sl.pending_n;
     sl.pending_done = nullptr;
     sl.pending_out = nullptr;
     sl.pending_n = 0;
+    if (sl.rerun.armed) {
+      if (sl.rerun.launched_slot < 0) {  // not looked at yet (poll_reruns): now, and wait for it
+        int rc = rerun_launch(c, sl, h, n, true);
+        if (rc) return rc;
+      }
+      sl.rerun.armed = false;
+      if (sl.rerun.launched_slot >= 0) {
+        Slot::Rerun rr = std::move(sl.rerun);  // (finishing the re-run's slot must not find this slot half-finished)
+        sl.rerun = Slot::Rerun();
+        int rc = finish_slot(c, c->slots[rr.launched_slot]);
+        if (rc) return rc;
+        for (size_t i = 0; i < rr.idx.size(); ++i) h[rr.idx[i]] = rr.res[i];
+        if (c->profiling) c->timing.genes_handed_back += (int64_t)rr.idx.size();
+      }
+    }
+    std::memcpy(out, h, sizeof(rvt_gene_result) * n);
+    if (done) *done = true;
   }
   return RVT_OK;
 }
@@ -441,17 +485,16 @@ bool invert_spd(const double* M, int n, double* Minv) {
 // that a gene still spreads over >= 32..128 waves
 // n_genes: genes of the batch — a big batch fills the chip with fewer, longer waves per gene (half the partial tiles
 // to write and to reduce: measured +2.7 % at 512 genes)
-void choose_split(int64_t ld, int n_genes, int* n_wparts, int* steps_per) {
+void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* steps_per) {
   const int64_t nsteps = ld >> 4;
-  static const int forced = [] {
-    const char* e = getenv("RVT_WPARTS");
-    return e ? atoi(e) : 0;
-  }();
+  const char* fe = getenv("RVT_WPARTS");  // (experiments / tests)
+  const int forced = fe ? atoi(fe) : 0;
   const int target = forced > 0 ? forced : (n_genes >= 128 ? 64 : 128);
   int64_t spw = (nsteps + target - 1) / target;
   if (spw < 64) spw = 64;
   spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;  // whole ring iterations of the hard-call kernel
   if (spw > kHcwMaxSteps) spw = kHcwMaxSteps;                   // (int32 range of the weighted hard-call kernel's tiles)
+  if (!weighted && spw > kHcMaxSteps) spw = kHcMaxSteps;        // (16-bit range of the hard-call kernel's masked-tile counters)
   int64_t nw = (nsteps + spw - 1) / spw;
   if (nw < 1) nw = 1;
   *n_wparts = (int)nw;
@@ -515,7 +558,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
     } else {
       masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
     }
-    for (int i = 0; masked && i < kSlots; ++i)
+    for (int i = 0; masked && i < kSlotsAll; ++i)
       masked = hipExtStreamCreateWithCUMask(&c->slots[i].stream, words, m2.data()) == hipSuccess;
     if (!masked) {
       (void)hipGetLastError();
@@ -523,7 +566,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
       c->k2_stream = nullptr;
       if (c->k2b_stream) hipStreamDestroy(c->k2b_stream);
       c->k2b_stream = nullptr;
-      for (int i = 0; i < kSlots; ++i) {
+      for (int i = 0; i < kSlotsAll; ++i) {
         if (c->slots[i].stream) hipStreamDestroy(c->slots[i].stream);
         c->slots[i].stream = nullptr;
       }
@@ -531,7 +574,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
   }
   c->cu_partitioned = masked && stage2_cus > 0;
   if (!masked) {
-    for (int i = 0; i < kSlots; ++i)
+    for (int i = 0; i < kSlotsAll; ++i)
       if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return RVT_E_HIP;
@@ -550,7 +593,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
     delete c;
     return RVT_E_HIP;
   }
-  for (int i = 0; i < kSlots; ++i) {
+  for (int i = 0; i < kSlotsAll; ++i) {
     hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_k2b[i], hipEventDisableTiming);
@@ -602,7 +645,7 @@ void rvt_destroy(rvt_ctx* c) {
     sync_stream(c->io_stream);
     hipStreamDestroy(c->io_stream);
   }
-  for (int i = 0; i < kSlots; ++i) {
+  for (int i = 0; i < kSlotsAll; ++i) {
     if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
     if (c->ev_k2[i]) hipEventDestroy(c->ev_k2[i]);
     if (c->ev_k2b[i]) hipEventDestroy(c->ev_k2b[i]);
@@ -653,8 +696,6 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_rot_scale) hipFree(c->d_rot_scale);
   if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);
-  if (c->d_kind_ring) hipFree(c->d_kind_ring);
-  if (c->h_kind_ring) hipHostFree(c->h_kind_ring);
   if (c->d_fam_nc) hipFree(c->d_fam_nc);
   delete c;
 }
@@ -667,7 +708,6 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (!c->queue.empty()) return fail(c, RVT_E_STATE, "collect the submitted genes before changing the null model");
   for (auto& bp : c->block_pool) hipFree(bp.second);  // pooled blocks were laid out for the previous N
   c->block_pool.clear();
-  c->block_kind.clear();  // recorded for blocks of the previous N
   free_null(c);
   c->have_null_beta = false;
   const int64_t ld = rvt_padded_ld(N);
@@ -802,21 +842,27 @@ int rvt_block_classify(rvt_ctx* c, const double* dG, int M, int* is_hard_call) {
   int flag = 0;
   HIP_TRY(c, hipMemcpyAsync(&flag, c->d_kind, sizeof(int), hipMemcpyDeviceToHost, c->io_stream));
   HIP_TRY(c, sync_stream(c->io_stream));
-  c->block_kind[dG] = flag ? 1 : 0;
-  if (is_hard_call) *is_hard_call = flag ? 1 : 0;
+  if (is_hard_call) *is_hard_call = flag ? 1 : 0;  // a query: nothing is remembered about the block
   return RVT_OK;
 }
 
-int rvt_block_forget(rvt_ctx* c, const double* dG) {
+int rvt_set_hardcall(rvt_ctx* c, int on) {
   if (!c) return RVT_E_INVALID;
-  c->block_kind.erase(dG);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  c->hc_enabled = on != 0;
+  return RVT_OK;
+}
+
+int rvt_set_content_hint(rvt_ctx* c, int hint) {
+  if (!c || hint < -1 || hint > 1) return fail(c, RVT_E_INVALID, "hint must be -1, 0 or 1");
+  c->content_hint = hint;
   return RVT_OK;
 }
 
 int rvt_block_free(rvt_ctx* c, double* dG) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
-  c->block_kind.erase(dG);
   {
     auto it = c->col_kind.find(dG);
     if (it != c->col_kind.end()) {
@@ -841,17 +887,12 @@ static int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   }
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t bld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  c->block_kind.erase(dG);
   HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * bld, G, sizeof(double) * N, sizeof(double) * N, M,
                          hipMemcpyHostToDevice));
   return RVT_OK;
 }
 
-int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
-  int rc = upload_block_data(c, dG, M, G);
-  if (rc) return rc;
-  return rvt_block_classify(c, dG, M, nullptr);  // content known from now on (see rvt_ctx::block_kind)
-}
+int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) { return upload_block_data(c, dG, M, G); }
 
 int rvt_set_profiling(rvt_ctx* c, int on) {
   if (!c) return RVT_E_INVALID;
@@ -957,7 +998,7 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
 
 // Arena layout of one gene of a batch (shared by run_batch and rvt_reserve).
 struct GeneOff {
-  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, vt, dbg_flip, dbg_kept;
+  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, vt, dbg_flip, dbg_kept, pq, wflags;
 };
 // hc: 1 = hard-call path (no mask planes, burden records per wave-part), 0 = general path, -1 = either (rvt_reserve)
 static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, int hc, size_t* total,
@@ -970,8 +1011,13 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   };
   const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CT;
   o->parts = add(sizeof(double) * (size_t)n_wparts * Mp * Cp);
-  o->colstat = add(sizeof(double) * (size_t)n_wparts * 3 * Mp);
+  o->colstat = add(sizeof(double) * (size_t)n_wparts * (hc == 0 ? 3 : kHcColstatRows) * Mp);
   o->masks = (hc == 1) ? 0 : add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
+  o->pq = o->wflags = 0;
+  if (hc != 0 && MT <= kHcMaxMT) {  // packed counters of the masked tiles + flags, per wave-part (suffstat_hc.hip.h)
+    o->pq = add(sizeof(unsigned) * (size_t)n_wparts * hc_pq_words(MT));
+    o->wflags = add(sizeof(unsigned) * (size_t)n_wparts);
+  }
   o->flags = add(sizeof(unsigned short) * (2 * MT + 2));
   const int nb = (hc == 1) ? n_wparts : (hc == 0 ? n_bparts : std::max(n_bparts, n_wparts));
   o->bparts = add(sizeof(double) * (size_t)nb * 2 * (3 + d));
@@ -987,21 +1033,30 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   }
 }
 
+// kind (optional, per gene): what the engine's own decoder wrote into the block — 1 hard calls (+ imputed means),
+// 0 dosages, -1 unknown.  rerun_slot >= 0: the batch is the re-run of genes the hard-call kernel handed back: general
+// kernel only, on that (re-run) slot.
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
                      const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
-                     DebugOut* dbg, CovOut* cov = nullptr) {
+                     DebugOut* dbg, CovOut* cov = nullptr, const signed char* kind = nullptr, int rerun_slot = -1) {
+  const bool rerun_of = rerun_slot >= 0;
   if (!c || n < 0 || (n > 0 && (!dG || !Ms || !af || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
   hipSetDevice(c->device);
   // pick the slot that was launched longest ago; if its batch is still in flight, finish it first
   Slot* slp = &c->slots[0];
-  for (auto& cand : c->slots)
-    if (cand.seq < slp->seq) slp = &cand;
+  for (int i = 1; i < kSlots; ++i)
+    if (c->slots[i].seq < slp->seq) slp = &c->slots[i];
   if (dbg) {  // inspection calls run alone
     int rc = rvt_sync(c);
     if (rc) return rc;
     slp = &c->slots[0];
+  }
+  if (rerun_of) slp = &c->slots[rerun_slot];
+  if (!rerun_of && !dbg && !cov) {
+    int rc = poll_reruns(c);
+    if (rc) return rc;
   }
   Slot& sl = *slp;
   {
@@ -1020,7 +1075,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int64_t ld = nc.ld, N = nc.N, nsteps = ld >> 4;
   const int n_bparts = (int)((N + kBurdenSPB - 1) / kBurdenSPB);
   int n_wparts, steps_per;
-  choose_split(ld, n, &n_wparts, &steps_per);
+  choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per);
   // ---- sizes ---------------------------------------------------------------------------------------
   std::vector<GeneDesc> desc(n);
   size_t total = 0, af_total = 0;
@@ -1037,9 +1092,12 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const bool score_hc = cov && cov->score && cov->slice_hc;
   // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests and MetaScore slices)
   const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && (!cov || score_hc);
-  const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) && !(dbg && dbg->cmc) &&
-                           d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) && c->d_nulltile != nullptr && nd_is_default;
+  const bool hc_possible = c->hc_enabled && !rerun_of && (!nc.binary || hcw) && (!cov || score_hc) &&
+                           !(dbg && dbg->cmc) && d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) &&
+                           c->d_nulltile != nullptr && nd_is_default;
   const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
+  const bool predict_hc = c->content_hint != 0;  // blocks of unknown content (rvt_set_content_hint)
+  std::vector<unsigned char> predicted(n, 0);
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
@@ -1062,8 +1120,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       if (score_hc) {
         gd.hc = cov->slice_hc[g] ? 1 : 0;
       } else {
-        auto it = c->block_kind.find(dG[g]);
-        if (it != c->block_kind.end() && it->second == 1) gd.hc = 1;
+        const int k = kind ? kind[g] : -1;
+        gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;
+        predicted[g] = (gd.hc && k < 0) ? 1 : 0;
       }
     }
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
@@ -1114,6 +1173,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.parts = reinterpret_cast<double*>(base + o.parts);
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
     gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
+    gd.pq = (gd.hc && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
+    gd.wflags = (gd.hc && o.wflags) ? reinterpret_cast<unsigned*>(base + o.wflags) : nullptr;
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
     gd.scratch = reinterpret_cast<double*>(base + o.scratch);
@@ -1267,6 +1328,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     return RVT_OK;
   }
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
+  if (n_hc > 0 && !(burden || dbg)) {  // (flip / polymorphic flags are not needed, the hand-back flag is: gene_assemble)
+    Scope sc(c, 1, st);
+    hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, st, d_desc + n_gen, (long long)N);
+  }
   if (burden || dbg) {
     // on the batch's own stream: the collapse overlaps the next batch's sufficient-statistics launches, which
     // leave about half of the HBM bandwidth unused
@@ -1350,7 +1415,27 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   c->next_done_flag = nullptr;
   sl.h_results = h_res;
   sl.pending_n = n;
-  if (c->profiling) {
+  sl.rerun.armed = false;
+  if (n_hc > 0 && !dbg) {  // remember the batch: genes the hard-call kernel hands back run again (finish_slot)
+    Slot::Rerun& rr = sl.rerun;
+    rr.dG.assign(dG, dG + n);
+    rr.M.assign(Ms, Ms + n);
+    rr.af.assign(af, af + af_total);
+    rr.af_off.resize(n);
+    size_t o = 0;
+    for (int g = 0; g < n; ++g) {
+      rr.af_off[g] = o;
+      o += (size_t)Ms[g];
+    }
+    rr.ids.resize(n);
+    for (int g = 0; g < n; ++g) rr.ids[g] = ids ? ids[g] : g;
+    rr.predicted = predicted;
+    rr.tests = tests;
+    rr.prm = params;
+    rr.launched_slot = -1;
+    rr.armed = true;
+  }
+  if (c->profiling && !rerun_of) {
     c->timing.genes += n;
     c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
@@ -1361,6 +1446,17 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   if (dbg) {
     HIP_TRY(c, sync_stream(st));
+    if (n_hc > 0) {  // an inspection call whose block is not the hard-call kernel's: once more on the general kernel
+      bool again = false;
+      for (int g = 0; g < n; ++g) again = again || (h_res[g].status & kStatusRerun);
+      if (again) {
+        sl.pending_out = nullptr;
+        sl.pending_done = nullptr;
+        sl.pending_n = 0;
+        std::vector<signed char> k0((size_t)n, 0);
+        return run_batch(c, n, dG, Ms, af, ids, tests, prm, out, dbg, cov, k0.data(), -1);
+      }
+    }
     const GeneDesc& g0 = desc[0];
     if (dbg->flip) HIP_TRY(c, hipMemcpy(dbg->flip, g0.dbg_flip, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
     if (dbg->kept) HIP_TRY(c, hipMemcpy(dbg->kept, g0.dbg_kept, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
@@ -1370,6 +1466,68 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   return RVT_OK;
 }
+
+namespace {
+// The finished batch of slot `sl` (its records are in sl.h_results): genes the hard-call kernel handed back are launched
+// again on the general kernel, in a re-run slot, asynchronously; finish_slot(sl) waits for them and patches the records.
+// wait_for_slot: when every re-run slot is busy, finish the older one first (else: leave it for later, return).
+int rerun_launch(rvt_ctx* c, Slot& sl, const rvt_gene_result* h, int n, bool wait_for_slot) {
+  Slot::Rerun& rr = sl.rerun;
+  rr.idx.clear();
+  for (int g = 0; g < n; ++g)
+    if (h[g].status & kStatusRerun) rr.idx.push_back(g);
+  if (rr.idx.empty()) {
+    rr.armed = false;
+    return RVT_OK;
+  }
+  int slot = -1;
+  for (int i = kSlots; i < kSlotsAll; ++i)
+    if (!c->slots[i].pending_out) slot = i;
+  if (slot < 0) {
+    if (!wait_for_slot) return RVT_OK;
+    slot = kSlots;
+    for (int i = kSlots; i < kSlotsAll; ++i)
+      if (c->slots[i].seq < c->slots[slot].seq) slot = i;
+    // its owner (another rotating slot) picks the records up from its own rr.res later: finishing it here is enough
+    int rc = finish_slot(c, c->slots[slot]);
+    if (rc) return rc;
+  }
+  const int k = (int)rr.idx.size();
+  std::vector<const double*> ptr(k);
+  std::vector<int> Ms(k);
+  std::vector<int64_t> ids(k);
+  std::vector<double> af;
+  for (int i = 0; i < k; ++i) {
+    const int g = rr.idx[i];
+    ptr[i] = rr.dG[g];
+    Ms[i] = rr.M[g];
+    ids[i] = rr.ids[g];
+    af.insert(af.end(), rr.af.begin() + rr.af_off[g], rr.af.begin() + rr.af_off[g] + rr.M[g]);
+  }
+  rr.res.assign((size_t)k, rvt_gene_result());
+  int rc = run_batch(c, k, ptr.data(), Ms.data(), af.data(), ids.data(), rr.tests, &rr.prm, rr.res.data(), nullptr, nullptr,
+                     nullptr, slot);
+  if (rc) return rc;
+  rr.launched_slot = slot;
+  return RVT_OK;
+}
+
+// called when a new batch is about to be launched: batches that have finished in the meantime get their re-runs started
+// now, so that they overlap the pipeline instead of stalling the caller when their slot comes up for reuse
+int poll_reruns(rvt_ctx* c) {
+  for (int i = 0; i < kSlots; ++i) {
+    Slot& sl = c->slots[i];
+    if (!sl.pending_out || !sl.rerun.armed || sl.rerun.launched_slot >= 0) continue;
+    if (hipStreamQuery(sl.stream) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    int rc = rerun_launch(c, sl, sl.h_results, sl.pending_n, false);
+    if (rc) return rc;
+  }
+  return RVT_OK;
+}
+}  // namespace
 
 int rvt_sync(rvt_ctx* c) {
   if (!c) return RVT_E_INVALID;
@@ -1403,7 +1561,7 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   const int64_t nsteps = nc.ld >> 4;
   const int n_bparts = (int)((nc.N + kBurdenSPB - 1) / kBurdenSPB);
   int n_wparts, steps_per;
-  choose_split(nc.ld, n, &n_wparts, &steps_per);
+  choose_split(nc.ld, n, nc.binary != 0, &n_wparts, &steps_per);
   size_t total = 0, af_total = 0;
   GeneOff o;
   for (int g = 0; g < n; ++g) {
@@ -1413,7 +1571,8 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   }
   total += sizeof(double) * af_total + sizeof(GeneDesc) * n + sizeof(rvt_gene_result) * n + 4 * 256;
   const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
-  for (auto& sl : c->slots) {
+  for (int i = 0; i < kSlots; ++i) {  // (the re-run slot grows on demand)
+    Slot& sl = c->slots[i];
     int rc = ensure_arena(c, sl, total + 4096);
     if (rc) return rc;
     rc = ensure_stage(c, sl, stage_bytes);
@@ -1489,13 +1648,66 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
   if (rc) return rc;
   const int d = c->nc.d;
   const size_t psz = (size_t)g0.Mp * g0.Cp;
-  std::vector<double> parts((size_t)g0.n_wparts * psz), cs((size_t)g0.n_wparts * 3 * g0.Mp);
+  const int rows = g0.hc ? kHcColstatRows : 3;
+  std::vector<double> parts((size_t)g0.n_wparts * psz), cs((size_t)g0.n_wparts * rows * g0.Mp);
   HIP_TRY(c, hipMemcpy(parts.data(), g0.parts, sizeof(double) * parts.size(), hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(cs.data(), g0.colstat, sizeof(double) * cs.size(), hipMemcpyDeviceToHost));
+  // hard-call kernel (suffstat_hc.hip.h): masked-entry tiles and per-column imputed values, combined as gene_assemble does
+  const int Mp = g0.Mp, MT = g0.MT;
+  std::vector<double> Pp, Qq, mu((size_t)Mp, 0.0), cm((size_t)Mp, 0.0);
+  if (g0.hc && g0.pq && g0.wflags) {
+    const int pqw = hc_pq_words(MT);
+    std::vector<unsigned> pq((size_t)g0.n_wparts * pqw), wf((size_t)g0.n_wparts);
+    HIP_TRY(c, hipMemcpy(pq.data(), g0.pq, sizeof(unsigned) * pq.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(wf.data(), g0.wflags, sizeof(unsigned) * wf.size(), hipMemcpyDeviceToHost));
+    Pp.assign((size_t)Mp * Mp, 0.0);
+    Qq.assign((size_t)Mp * Mp, 0.0);
+    const int ntiles = hc_pq_tiles(MT);
+    for (int p2 = 0; p2 < g0.n_wparts; ++p2) {
+      if (!(wf[p2] & 1u)) continue;
+      for (int tile = 0; tile < ntiles; ++tile)
+        for (int ri = 0; ri < 16; ++ri)
+          for (int ci = 0; ci < 16; ++ci) {
+            const int lane = 16 * (ri >> 2) + ci, reg = ri & 3;
+            const unsigned w = pq[(size_t)p2 * pqw + (size_t)(tile * 2 + (reg >> 1)) * 64 + lane];
+            const double val = (double)((w >> (16 * (reg & 1))) & 0xffffu);
+            if (tile < MT * MT) {
+              Pp[(size_t)((tile / MT) * 16 + ri) * Mp + (tile % MT) * 16 + ci] += val;
+            } else {
+              int t = tile - MT * MT, r = 0;
+              while (t >= MT - r) {
+                t -= MT - r;
+                ++r;
+              }
+              const int cc = r + t;
+              Qq[(size_t)(r * 16 + ri) * Mp + cc * 16 + ci] += val;
+              if (cc != r) Qq[(size_t)(cc * 16 + ci) * Mp + r * 16 + ri] += val;
+            }
+          }
+    }
+  }
+  if (g0.hc)
+    for (int j = 0; j < M; ++j) {
+      unsigned long long orb = 0ull;
+      for (int p2 = 0; p2 < g0.n_wparts; ++p2) {
+        const double* cc = cs.data() + (size_t)p2 * rows * Mp;
+        cm[j] += cc[3 * Mp + j];
+        unsigned long long b;
+        std::memcpy(&b, &cc[4 * Mp + j], 8);
+        orb |= b;
+      }
+      if (cm[j] > 0) std::memcpy(&mu[j], &orb, 8);
+    }
   auto R = [&](int i, int j) {
     if (j < M && j < i) std::swap(i, j);  // the engine uses the upper triangle of G'DG
     double s = 0;
     for (int p2 = 0; p2 < g0.n_wparts; ++p2) s += parts[(size_t)p2 * psz + (size_t)i * g0.Cp + j];
+    if (j < M && !Pp.empty()) {
+      const double q = Qq[(size_t)i * Mp + j];
+      const double pij = Pp[(size_t)i * Mp + j] - 4.0 * q, pji = Pp[(size_t)j * Mp + i] - 4.0 * q;
+      const double hh = s - 4.0 * (pij + pji) - 16.0 * q;
+      s = hh + mu[j] * pij + mu[i] * pji + (mu[i] * mu[j]) * q;
+    }
     return s;
   };
   for (int i = 0; i < M; ++i) {
@@ -1506,10 +1718,15 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
     if (u) u[i] = R(i, M + d);
     double s = 0, mn = INFINITY, mx = -INFINITY;
     for (int p2 = 0; p2 < g0.n_wparts; ++p2) {
-      const double* cc = cs.data() + (size_t)p2 * 3 * g0.Mp;
+      const double* cc = cs.data() + (size_t)p2 * rows * g0.Mp;
       s += cc[i];
       mn = std::min(mn, cc[g0.Mp + i]);
       mx = std::max(mx, cc[2 * g0.Mp + i]);
+    }
+    if (g0.hc && cm[i] > 0) {
+      s += cm[i] * mu[i];
+      mn = std::min(mn, mu[i]);
+      mx = std::max(mx, mu[i]);
     }
     if (colsum) colsum[i] = s;
     if (cmin) cmin[i] = mn;
@@ -3561,20 +3778,19 @@ int rvt_rand_seed(rvt_ctx* c, unsigned seed) {
   return RVT_OK;
 }
 
-// Content of the first V columns of a block: 1 = hard calls only (the whole block was classified, or every column
-// that rvt_block_upload_columns brought in was), 0 = not / unknown.  colflag (optional) receives the per-column flags
-// when those are what is known (empty otherwise).
+// What the engine wrote into the first V columns of a block it filled column by column (rvt_block_upload_columns records a
+// flag per column behind the copy): 1 = hard calls only, 0 = something else, -1 = nothing known (a caller's own
+// allocation, or a block filled another way).  A HINT for choosing the kernel to start on: the integer paths test every
+// value they read and fall back.  colflag (optional) receives the per-column flags when they exist (empty otherwise).
 static int block_hard_calls(rvt_ctx* c, const double* dG, int V, std::vector<int>* colflag, bool* any) {
   if (colflag) colflag->clear();
   if (any) *any = false;
   if (!c->hc_enabled) return 0;
-  auto bk = c->block_kind.find(dG);
-  if (bk != c->block_kind.end() && bk->second == 1) {
-    if (any) *any = true;
-    return 1;
-  }
   auto it = c->col_kind.find(dG);
-  if (it == c->col_kind.end() || !it->second.d_flags || V > it->second.cols) return 0;
+  if (it == c->col_kind.end() || !it->second.d_flags || V > it->second.cols) {
+    if (any) *any = true;
+    return -1;
+  }
   std::vector<int> f((size_t)V);
   if (hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, c->io_stream) != hipSuccess ||
       sync_stream(c->io_stream) != hipSuccess)
@@ -3621,11 +3837,13 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   int rc = rvt_sync(c);  // processed synchronously
   if (rc) return rc;
-  // Which columns hold hard calls only: the whole block when it was classified (rvt_block_upload / rvt_block_classify),
-  // else the per-column flags that rvt_block_upload_columns recorded.
+  // Which slices START on the hard-call kernel: all of them unless the per-column flags of rvt_block_upload_columns say a
+  // slice holds something else.  The kernel tests what it reads; a slice it hands back (ok = -2) runs again on the fp64
+  // kernel below.
   std::vector<int> colflag;
   bool any_hc = false;
   bool all_hc = block_hard_calls(c, dG, V, &colflag, &any_hc) != 0;
+  if (!c->hc_enabled) all_hc = any_hc = false;
   if (c->nc.binary && !(c->d_nulltile_w && c->d_vq)) all_hc = any_hc = false;  // (no digit planes: fp64 kernel)
   if (!all_hc && colflag.empty()) any_hc = false;
   // columns per slice.  General kernel: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column
@@ -3664,13 +3882,22 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
     co.se = effect_se + c0;
     co.pval = pvalue + c0;
     rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
-    for (auto& sl : c->slots) {
-      if (sl.pending_out == rs.data()) {
-        sl.pending_out = nullptr;
-        sl.pending_n = 0;
+    if (rc) return rc;
+    if (any_hc) {  // slices the hard-call kernel handed back: the chunk once more, those slices on the fp64 kernel
+      bool redo = false;
+      for (int g = 0; g < n; ++g) {
+        bool back = false;
+        for (int j = 0; j < Ms[g]; ++j) back = back || ok[(size_t)c0 + (size_t)g * kSlice + j] == -2;
+        if (back) {
+          shc[g] = 0;
+          redo = true;
+        }
+      }
+      if (redo) {
+        rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
+        if (rc) return rc;
       }
     }
-    if (rc) return rc;
   }
   return RVT_OK;
 }
@@ -3695,7 +3922,7 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
   // Hard calls and an unweighted model: G'G is an integer matrix — the band comes from the exact int8 product
   // (rvt_cov_rect with heads = window) instead of the fp64 matrix cores, ~6x faster at V = 1024.
   if (c->have_null && !c->nc.binary && V >= 64 && !getenv("RVT_METACOV_FP64") && block_hard_calls(c, dG, V, nullptr, nullptr))
-    return rvt_cov_rect(c, dG, 0, V, V, cov, xz, zz, polymorphic);
+    return rvt_cov_rect(c, dG, 0, V, V, cov, xz, zz, polymorphic);  // (tests what it reads; falls back by itself)
   std::vector<double> af(V, 0.01);
   rvt_gene_result r;
   CovOut co;
@@ -3716,8 +3943,14 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
   return RVT_OK;
 }
 
+static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                         int* polymorphic, bool allow_fast);
 int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
                  int* polymorphic) {
+  return cov_rect_impl(c, dG, col0, H, W, cov, xz, zz, polymorphic, true);
+}
+static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                         int* polymorphic, bool allow_fast) {
   if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
     return fail(c, RVT_E_INVALID, "bad arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
@@ -3764,7 +3997,11 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   }
   // T = G_W' D X (W x d) and S = G_H' D G_W (H x W) as integer-plane products (rot_gemm.hip.h): exact for hard calls
   // and an unweighted model, ~2^-40 relative otherwise
-  const bool fast = !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
+  // (hard calls are a prediction — the engine's own per-column flags when it filled the block, optimism otherwise —
+  // that cov_hc_prep_kernel verifies on every value it converts; a block that fails is computed again the general way)
+  const bool fast = allow_fast && !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
+  int* d_bad = nullptr;
+  int h_bad = 0;
   if (!fast)
     hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
                      d_poly);
@@ -3782,6 +4019,9 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
       c->rotB_cap = need + need / 4;
     }
     HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+    if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
+    d_bad = c->d_kind;
+    HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
     {
       const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
       const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
@@ -3790,13 +4030,13 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
       const dim3 grid((unsigned)wgs, (unsigned)slices);
       if (dmax == 4)
         hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
-                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
       else if (dmax == 8)
         hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
-                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
       else
         hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W,
-                           c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp);
+                           c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
       hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
                          W, d, dmax, d_cs, d_poly, d_T);
     }
@@ -3815,7 +4055,9 @@ int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* c
   HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  if (d_bad) HIP_TRY(c, hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
+  if (h_bad) return cov_rect_impl(c, dG, col0, H, W, cov, xz, zz, polymorphic, false);  // not hard calls after all
   if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
   return RVT_OK;
 }
@@ -3906,7 +4148,6 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   if (ncols == 0) return RVT_OK;
   hipSetDevice(c->device);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  c->block_kind.erase(dst);
   HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
                        hipMemcpyDeviceToDevice));
   return RVT_OK;
@@ -3918,7 +4159,6 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   hipSetDevice(c->device);
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  c->block_kind.erase(dG);
   HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
                          hipMemcpyHostToDevice));
   // content of the new columns (hard calls or not), recorded per column: rvt_score_block picks its kernel by it.  One
@@ -3945,7 +4185,6 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   if (ncols == 0 || dst_col == src_col) return RVT_OK;
   hipSetDevice(c->device);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  c->block_kind.erase(dG);
   // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
   for (int k = 0; k < ncols; ++k)
     HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
@@ -3982,10 +4221,6 @@ int resolve_af(rvt_ctx* c) {
       p.af.assign(h, h + p.M);
       p.af_slot = -1;
     }
-    if (p.kind_slot >= 0) {
-      p.kind = c->h_kind_ring[p.kind_slot] ? 1 : 0;
-      p.kind_slot = -1;
-    }
   }
   c->af_unresolved = 0;
   return RVT_OK;
@@ -4001,13 +4236,14 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
   std::vector<int> Ms;
   std::vector<double> af;
   std::vector<int64_t> ids;
+  std::vector<signed char> kinds;
   for (int g = 0; g < n; ++g) {
     const rvt_ctx::Pending& p = c->queue[first + g];
     ptrs.push_back(p.dG);
     Ms.push_back(p.M);
     ids.push_back(p.id);
     af.insert(af.end(), p.af.begin(), p.af.end());
-    c->block_kind[p.dG] = p.kind;  // (erased again when the block goes back to the pool)
+    kinds.push_back((signed char)p.kind);
   }
   c->launched.emplace_back();
   rvt_ctx::Launched& L = c->launched.back();
@@ -4016,7 +4252,8 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
   L.res.resize(n);
   const rvt_ctx::Pending& p0 = c->queue[first];
   c->next_done_flag = &L.done;
-  int rc = run_batch(c, n, ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm, L.res.data(), nullptr);
+  int rc = run_batch(c, n, ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm, L.res.data(), nullptr, nullptr,
+                     kinds.data());
   c->next_done_flag = nullptr;
   if (rc) {
     c->launched.pop_back();
@@ -4057,7 +4294,6 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
         Ms.push_back(c->queue[g].M);
         ids.push_back(c->queue[g].id);
         af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
-        c->block_kind[c->queue[g].dG] = c->queue[g].kind;
       }
       std::vector<rvt_gene_result> res(e - i);
       rc = run_blocks_with_perm(c, (int)(e - i), ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm,
@@ -4286,7 +4522,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   }
   auto give_back = [&]() { c->block_pool.emplace_back(p.bytes, p.dG); };
   const int64_t N = c->nc.N, ld = c->null_ld;
-  c->block_kind.erase(p.dG);
+  // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
+  // (dosage text, BGEN), or whatever the caller's doubles are
+  p.kind = (mode == 2 || mode == 3 || mode == 4) ? 1 : ((mode == 5 || mode == 6) ? 0 : -1);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
     if (rc) {
@@ -4404,30 +4642,6 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       return fail(c, RVT_E_HIP, "genotype consolidation failed: %s", hipGetErrorString(e));
     }
     if (af_out) std::memcpy(af_out, p.af.data(), afb);
-  }
-  if (c->hc_enabled && (!c->nc.binary || c->d_vq)) {
-    // content of the finished block (hard calls or not), classified on the io stream behind the copy / consolidation;
-    // the flag comes back through a pinned ring and is read when the gene's group is launched
-    hipError_t e = hipSuccess;
-    if (!c->d_kind_ring) {
-      e = hipMalloc((void**)&c->d_kind_ring, sizeof(int) * rvt_ctx::kAfSlots);
-      if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_kind_ring, sizeof(int) * rvt_ctx::kAfSlots, hipHostMallocDefault);
-    }
-    if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
-    if (e == hipSuccess) {
-      const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
-      if (enqueue_classify(c, p.dG, M, N, ld, c->io_stream, c->d_kind_ring + slot) != RVT_OK) e = hipErrorUnknown;
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(c->h_kind_ring + slot, c->d_kind_ring + slot, sizeof(int), hipMemcpyDeviceToHost, c->io_stream);
-      if (e == hipSuccess) {
-        p.kind_slot = slot;
-        ++c->af_unresolved;
-      }
-    }
-    if (e != hipSuccess) {
-      give_back();
-      return fail(c, RVT_E_HIP, "block classification failed: %s", hipGetErrorString(e));
-    }
   }
   p.tests = tests;
   p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
@@ -4743,7 +4957,6 @@ static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
   }
   for (int g = 0; g < n; ++g) {
     out[g] = c->queue[g].res;
-    c->block_kind.erase(c->queue[g].dG);
     c->block_pool.emplace_back(c->queue[g].bytes, c->queue[g].dG);
   }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);

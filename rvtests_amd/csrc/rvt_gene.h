@@ -92,11 +92,32 @@ RVT_HD double skato_rho_value(int i) {
 //   parts:   P partial matrices of Mp x Cp doubles (row-major); only tiles with tile_col >= tile_row hold data
 //   colstat: P x 3 x Mp  (sum, min, max) partials
 //   bparts:  PB x 2 x burden_rec_len(d) partial burden sums (CMC, Zeggini) — may be null when no burden test
+// Hard-call path with masked entries (suffstat_hc.hip.h; mean-imputed columns G_j = H_j + mu_j m_j): `hcm` carries the
+// per-wave-part images of the 16-bit counters of P' = (H + 4m)'m and Q = m'm and the wave-part flags; colstat then has
+// kHcRows rows per part (sum of H, min / max over the hard calls, masked count, OR / AND of the masked bit patterns) and
+// the G'DG block of `parts` holds C = (H + 4m)'(H + 4m).  Recovered here, in exact integer arithmetic up to one rounding
+// per product:  P = P' - 4Q,  H'H = C - 4(P + P') - 16 Q,  G'G = H'H + P diag(mu) + diag(mu) P' + diag(mu) Q diag(mu).
+// force_status != 0: the gene is not evaluated (it will be run again on the general kernel): no polymorphic column.
 // ======================================================================================================
+constexpr unsigned kStatusRerun = 0x100u;  // internal: the hard-call kernel found content it does not handle (never returned)
+
+RVT_HD double rvt_bits_to_double(unsigned long long b) {
+  double x;
+  __builtin_memcpy(&x, &b, sizeof(x));
+  return x;
+}
+
+struct HcMasked {
+  const unsigned* pq;      // P x pq_words packed counters ([tile][half][lane], tiles: P' MT x MT, then Q upper triangle)
+  const unsigned* wflags;  // P flags: bit 0 = the part's image was written
+  int pq_words;
+};
+constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
+
 RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
                           const double* colstat, const double* bparts, int PB, const double* af,
                           const rvt_params& prm, unsigned tests, GeneScratch ws, GeneStats* out, int* flip_out,
-                          int* kept_out) {
+                          int* kept_out, const HcMasked* hcm = nullptr, unsigned force_status = 0u) {
   const int d = nc.d;
   const int ldr = Cp;
   double* R = ws.R;
@@ -137,13 +158,32 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
   double* bw_skato = ws.bw + Mp;    // beta_pdf
   double* rowsum = ws.rowsum;
   int* kidx = ws.ivec;              // kept column list
+  double* muv = ws.vecs + 6 * Mp;   // [Mp]  imputed value of a column with masked entries (hard-call path)
+  double* cmv = ws.vecs + 7 * Mp;   // [Mp]  number of masked entries
+  const int cs_rows = hcm ? kHcRows : 3;
   for (int j = co.tid; j < M; j += co.nt) {
-    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    double s = 0.0, mn = INFINITY, mx = -INFINITY, cm = 0.0;
+    unsigned long long orb = 0ull;
     for (int p = 0; p < P; ++p) {
-      const double* c = colstat + (size_t)p * 3 * Mp;
+      const double* c = colstat + (size_t)p * cs_rows * Mp;
       s += c[j];
       mn = fmin(mn, c[Mp + j]);
       mx = fmax(mx, c[2 * Mp + j]);
+      if (hcm) {
+        cm += c[3 * Mp + j];
+        orb |= reinterpret_cast<const unsigned long long*>(c)[4 * Mp + j];
+      }
+    }
+    if (hcm) {
+      double mu = 0.0;
+      if (cm > 0.0) {  // (gene_flags_hc_kernel has checked that every masked entry of the column holds these bits)
+        mu = rvt_bits_to_double(orb);
+        s += cm * mu;
+        mn = fmin(mn, mu);
+        mx = fmax(mx, mu);
+      }
+      muv[j] = mu;
+      cmv[j] = cm;
     }
     colsum[j] = s;
     cmin[j] = mn;
@@ -154,6 +194,48 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     if (flip_out) flip_out[j] = flip ? 1 : 0;
   }
   co.sync();
+  // hard-call path: masked-entry corrections of the G'G block (upper tiles; the completion below mirrors them)
+  if (hcm && hcm->pq) {
+    bool any = false;
+    for (int p = 0; p < P; ++p) any = any || (hcm->wflags[p] & 1u);
+    if (any) {
+      const int MT = Mp >> 4, ntiles = MT * MT + MT * (MT + 1) / 2;
+      double* Pp = ws.eig;                    // Mp x Mp: P'
+      double* Qq = ws.eig + (size_t)Mp * Mp;  // Mp x Mp: Q (both triangles)
+      for (int idx = co.tid; idx < ntiles * 256; idx += co.nt) {
+        const int tile = idx >> 8, e = idx & 255, ri = e >> 4, ci = e & 15;
+        const int lane = 16 * (ri >> 2) + ci, reg = ri & 3;
+        const size_t word = (size_t)(tile * 2 + (reg >> 1)) * 64 + lane;
+        const int sh = 16 * (reg & 1);
+        long long acc = 0;
+        for (int p = 0; p < P; ++p)
+          if (hcm->wflags[p] & 1u) acc += (long long)((hcm->pq[(size_t)p * hcm->pq_words + word] >> sh) & 0xffffu);
+        if (tile < MT * MT) {
+          const int r = tile / MT, c = tile % MT;
+          Pp[(size_t)(r * 16 + ri) * Mp + c * 16 + ci] = (double)acc;
+        } else {
+          int t = tile - MT * MT, r = 0;
+          while (t >= MT - r) {
+            t -= MT - r;
+            ++r;
+          }
+          const int c = r + t;
+          Qq[(size_t)(r * 16 + ri) * Mp + c * 16 + ci] = (double)acc;
+          if (c != r) Qq[(size_t)(c * 16 + ci) * Mp + r * 16 + ri] = (double)acc;
+        }
+      }
+      co.sync();
+      for (int idx = co.tid; idx < M * M; idx += co.nt) {
+        const int i = idx / M, j = idx % M;
+        if ((j >> 4) < (i >> 4)) continue;
+        const double q = Qq[(size_t)i * Mp + j];
+        const double pij = Pp[(size_t)i * Mp + j] - 4.0 * q, pji = Pp[(size_t)j * Mp + i] - 4.0 * q;
+        const double hh = R[(size_t)i * ldr + j] - 4.0 * (pij + pji) - 16.0 * q;  // exact: integers below 2^53
+        R[(size_t)i * ldr + j] = hh + muv[j] * pij + muv[i] * pji + (muv[i] * muv[j]) * q;
+      }
+      co.sync();
+    }
+  }
   // symmetric completion of the G'DG block
   for (int idx = co.tid; idx < M * M; idx += co.nt) {
     const int i = idx / M, j = idx % M;
@@ -169,11 +251,12 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
       if (!mono) kidx[m++] = j;
       if (shf[j] != 0.0) ++nf;
     }
+    if (force_status) m = 0;
     kidx[Mp] = m;  // stash
     out->n_variants = M;
     out->n_poly = m;
     out->flip_count = nf;
-    out->status = (m == 0) ? RVT_ST_NO_POLY : 0;
+    out->status = ((m == 0) ? RVT_ST_NO_POLY : 0) | force_status;
     out->skato_ok = 0;
     out->skato_single = 0;
     out->skat_nlambda = 0;

@@ -21,7 +21,22 @@
 //     non-zero column, gets its burden sums recomputed by burden_fallback_kernel.  The bit-mask planes and the
 //     burden_collapse_kernel launch of the fp64 path are not needed.
 //
-// Matrix pipe ~30 % busy, vector ALU ~10 %: the kernel is bound by HBM alone, which the fp64 kernel (matrix pipe
+//   * NOTHING is assumed about the block.  Every loaded double is tested (low dword zero, high dword one of the three
+//     patterns) in the registers it already sits in.  An entry that is not a hard call is a MASKED entry m = 1 with
+//     integer part H = 0: mean imputation (imputeGenotypeToMean, src/DataConsolidator.cpp:217-245) turns a column with
+//     missing calls into H_j + mu_j m_j — integer H, 0/1 mask m, ONE value mu_j per column.  The kernel keeps such
+//     columns on the integer pipe: the packed operand byte carries H + 4 m (0, 1, 2, 4), so the ordinary Gram tiles hold
+//     C = (H + 4m)'(H + 4m); when a 64-sample operand holds a masked entry (wave-uniform test) two more sets of tiles,
+//     P' = (H + 4m)'m and Q = m'm, are formed with the same instruction and added to 16-bit counters in LDS
+//     (ds_add_u32 on packed pairs).  gene_assemble recovers H'H = C - 4(P + P') - 16 Q, P = P' - 4 Q, and
+//     G'G = H'H + P diag(mu) + diag(mu) P' + diag(mu) Q diag(mu): exact integers, one rounding per product.
+//     G'[X | rr] needs no correction (the fp64 operands are the true values).  That all masked entries of a column are
+//     bit-identical is verified with LDS atomics (OR and AND of the masked bit patterns per column); a column where
+//     they are not — dosages — or a value that is not finite sends the gene to the general fp64 kernel (flags[2 MT + 1],
+//     gene_flags_hc_kernel; the engine re-runs it).  No separate classification pass, no trust in what a block held
+//     when it was last looked at.
+//
+// Matrix pipe ~30 % busy, vector ALU ~25 %: the kernel is bound by HBM alone, which the fp64 kernel (matrix pipe
 // co-limited at M ~ 50) is not.
 #pragma once
 #include <type_traits>
@@ -35,6 +50,18 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 constexpr int kHcMaxMT = 6;      // widest hard-call class (M <= 96), as the single-pass fp64 kernel
 constexpr int kHcMaxD = 13;      // the null-model columns + rr share ONE 16-column tile
 constexpr int kHcStepUnit = 12;  // a wave's step count is a multiple of this (ring of 3 buffers x groups of 4 steps)
+constexpr int kHcMaxSteps = 1020; // steps per wave-part: the 16-bit LDS counters of P' hold <= 4 x 16 x 1020 < 65536
+constexpr int kHcColstatRows = 6; // sum of H, min, max (hard calls only), masked count, OR / AND of the masked bit patterns
+
+// LDS of one wave (= one workgroup), 32-bit words:
+//   [0, PQ)            P' tiles (MT x MT, row tile = H + 4m side) then Q tiles (upper triangle): [tile][half][lane],
+//                      each word two 16-bit counters (accumulator elements 0|1 resp. 2|3 of the lane)
+//   [PQ, PQ + 64 MT)   per column c * 16 + v: OR lo, OR hi, AND lo, AND hi of the masked entries' bit patterns
+//   [PQ + 64 MT]       bit 0: the wave-part met a masked entry (the P'/Q image is written out), bit 1: an entry passed
+//                      the hard-call test with code 3 (-inf): the gene goes to the general kernel
+constexpr int hc_pq_tiles(int MT) { return MT * MT + MT * (MT + 1) / 2; }
+constexpr int hc_pq_words(int MT) { return hc_pq_tiles(MT) * 128; }
+constexpr int hc_lds_words(int MT) { return hc_pq_words(MT) + 64 * MT + 4; }
 
 // Null-model tile of the hard-call kernel: ONE allocation [X_0 .. X_{d-1} | rr | zeros], ld doubles per column.
 struct NullTile {
@@ -80,10 +107,14 @@ struct HcBurden {       // per-lane running sums of the collapsed-genotype score
   unsigned zz, cnt;     // sum c_zeg^2 and #(c != 0) over the samples of this lane's row
 };
 
-// one tile row of one step: fp64 MFMAs for G'[X | rr], packing, column sum, burden hits
+// one tile row of one step: fp64 MFMAs for G'[X | rr], hard-call test, packing, column sum, burden hits.
+// pk = the integer genotypes H (0 / 1 / 2; 0 where masked), mk = 0x01 in the byte of every entry that is NOT exactly
+// 0.0, 1.0 or 2.0.  A double is a hard call iff its low dword is zero and its high dword is 0, 0x3FF00000 or
+// 0x40000000: hi + 0x00100000 then has no bit outside {20, 30}.  (0xFFF00000 = -inf passes too, with code 3: caught by
+// the caller through hc_code3.)
 template <bool MASKED>
 __device__ __forceinline__ void hc_row(const u4_t& glo, const u4_t& ghi, const double (&xv)[4], d4_t& accT,
-                                       unsigned& pk, unsigned& cs, unsigned fx, unsigned& h, bool valid) {
+                                       unsigned& pk, unsigned& mk, unsigned& cs, unsigned fx, unsigned& h, bool valid) {
   const double g0 = hc_dbl(glo[0], glo[1]), g1 = hc_dbl(glo[2], glo[3]), g2 = hc_dbl(ghi[0], ghi[1]),
                g3 = hc_dbl(ghi[2], ghi[3]);
   accT = __builtin_amdgcn_mfma_f64_16x16x4f64(g0, xv[0], accT, 0, 0, 0);
@@ -95,11 +126,37 @@ __device__ __forceinline__ void hc_row(const u4_t& glo, const u4_t& ghi, const d
   const unsigned w01 = __builtin_amdgcn_perm(glo[3], glo[1], 0x0c0c0703u);
   const unsigned w23 = __builtin_amdgcn_perm(ghi[3], ghi[1], 0x07030c0cu);
   unsigned p = ((w01 | w23) >> 5) & 0x03030303u;
-  if (MASKED) p = valid ? p : 0u;
+  constexpr unsigned kAdd = 0x00100000u, kBits = 0xBFEFFFFFu;
+  const unsigned i0 = ((glo[1] + kAdd) & kBits) | glo[0], i1 = ((glo[3] + kAdd) & kBits) | glo[2],
+                 i2 = ((ghi[1] + kAdd) & kBits) | ghi[0], i3 = ((ghi[3] + kAdd) & kBits) | ghi[2];
+  auto one = [](unsigned x) { return x < 1u ? x : 1u; };  // v_min_u32
+  unsigned m = one(i0) | (one(i1) << 8) | (one(i2) << 16) | (one(i3) << 24);
+  if (MASKED) {
+    p = valid ? p : 0u;
+    m = valid ? m : 0u;
+  }
+  const unsigned m3 = m * 3u;
+  p &= ~m3;
   pk = p;
+  mk = m;
   cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
-  const unsigned t = p ^ fx;  // flipped column: (int)(2 - g) > 0  <=>  g != 2
-  h += (t | (t >> 1)) & 0x01010101u;
+  const unsigned t = (p ^ fx) & ~m3;  // flipped column: (int)(2 - g) > 0  <=>  g != 2; a masked entry never counts here
+  h += (t | (t >> 1)) & 0x01010101u;  // (gene_flags_hc_kernel sends the gene to the fallback when its mu says it should)
+}
+__device__ __forceinline__ unsigned hc_code3(unsigned p) { return p & (p >> 1) & 0x01010101u; }
+
+// masked entries of one tile row of one step (rare path): OR / AND of their bit patterns per column, in LDS
+__device__ __forceinline__ void hc_note_masked(const u4_t& glo, const u4_t& ghi, unsigned mk, unsigned* oa) {
+  auto note = [&](unsigned lo, unsigned hi) {
+    __hip_atomic_fetch_or(oa + 0, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(oa + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_and(oa + 2, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_and(oa + 3, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (mk & 0x000000ffu) note(glo[0], glo[1]);
+  if (mk & 0x0000ff00u) note(glo[2], glo[3]);
+  if (mk & 0x00ff0000u) note(ghi[0], ghi[1]);
+  if (mk & 0xff000000u) note(ghi[2], ghi[3]);
 }
 
 // end of a step: the per-sample variant counts of this lane's row and the burden sums
@@ -118,11 +175,17 @@ __device__ __forceinline__ void hc_finish(unsigned h, const double (&xv)[4], HcB
   }
 }
 
-// One step from a step buffer.  T = position of the step in its group of 4.
+// per-wave state of the masked-entry bookkeeping: where this lane's columns keep their OR / AND words, the flag word
+struct HcMaskCtx {
+  unsigned* oa;    // LDS: OR lo, OR hi, AND lo, AND hi of column 0 * 16 + v; row tile c at oa + 64 c
+  unsigned* flag;  // LDS flag word (see hc_lds_words)
+};
+
+// One step from a step buffer.  T = position of the step in its group of 4.  anym collects the mask bytes of the group.
 template <int MT, bool MASKED>
 __device__ __forceinline__ void hc_step(const HcStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
                                         unsigned (&cs)[MT], const unsigned (&fx)[MT], HcBurden& bu, bool valid,
-                                        unsigned vmask) {
+                                        unsigned vmask, unsigned& anym, const HcMaskCtx& mc) {
   double xv[4] = {hc_dbl(f.xlo[0], f.xlo[1]), hc_dbl(f.xlo[2], f.xlo[3]), hc_dbl(f.xhi[0], f.xhi[1]),
                   hc_dbl(f.xhi[2], f.xhi[3])};
   if (MASKED) {
@@ -131,7 +194,14 @@ __device__ __forceinline__ void hc_step(const HcStep<MT>& f, const int T, d4_t (
   }
   unsigned h = 0;
 #pragma unroll
-  for (int c = 0; c < MT; ++c) hc_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], fx[c], h, valid);
+  for (int c = 0; c < MT; ++c) {
+    unsigned p, m;
+    hc_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], p, m, cs[c], fx[c], h, valid);
+    if (m) hc_note_masked(f.glo[c], f.ghi[c], m, mc.oa + 64 * c);
+    if (hc_code3(p)) __hip_atomic_fetch_or(mc.flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pk[c][T] = p | (m << 2);  // operand byte H + 4 m
+    anym |= m;
+  }
   hc_finish<MASKED>(h, xv, bu, vmask);
 }
 
@@ -147,17 +217,68 @@ __device__ __forceinline__ void hc_gram(const unsigned (&pk)[MT][4], i4_t (&accS
     for (int c = r; c < MT; ++c, ++t) accS[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[r], op[c], accS[t], 0, 0, 0);
 }
 
+// The masked tiles of one 64-sample operand (only when it holds a masked entry): P' = (H + 4m)'m and Q = m'm, every
+// element <= 256, added to the 16-bit LDS counters as packed pairs.
+template <int MT>
+__device__ __forceinline__ void hc_gram_masked(const unsigned (&pk)[MT][4], unsigned* lds, int lane) {
+  // (the mask operands are rebuilt where they are used: 8 transient registers instead of 4 MT — this path runs beside a
+  // full load ring)
+  auto mask_op = [&](int c) {
+    return i4_t{(int)((pk[c][0] >> 2) & 0x01010101u), (int)((pk[c][1] >> 2) & 0x01010101u),
+                (int)((pk[c][2] >> 2) & 0x01010101u), (int)((pk[c][3] >> 2) & 0x01010101u)};
+  };
+  auto add = [&](int tile, const i4_t& z) {
+    const unsigned w0 = (unsigned)z[0] | ((unsigned)z[1] << 16), w1 = (unsigned)z[2] | ((unsigned)z[3] << 16);
+    __hip_atomic_fetch_add(lds + (tile * 2 + 0) * 64 + lane, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(lds + (tile * 2 + 1) * 64 + lane, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    const i4_t mc = mask_op(c);
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+      const i4_t a = i4_t{(int)pk[r][0], (int)pk[r][1], (int)pk[r][2], (int)pk[r][3]};
+      add(r * MT + c, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, mc, i4_t{0, 0, 0, 0}, 0, 0, 0));
+      if (r <= c) {  // Q tile (r, c): index MT^2 + r MT - r (r - 1) / 2 + (c - r)
+        const i4_t mr = (r == c) ? mc : mask_op(r);
+        add(MT * MT + r * MT - r * (r - 1) / 2 + (c - r), __builtin_amdgcn_mfma_i32_16x16x64_i8(mr, mc, i4_t{0, 0, 0, 0}, 0, 0, 0));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __hip_atomic_fetch_or(lds + hc_pq_words(MT) + 64 * MT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// end of a group of 4 steps: the Gram tiles, and the masked tiles when any lane met a masked entry
+template <int MT>
+__device__ __forceinline__ void hc_group_end(const unsigned (&pk)[MT][4], i4_t (&accS)[MT * (MT + 1) / 2], unsigned& anym,
+                                             unsigned* lds, int lane) {
+  hc_gram<MT>(pk, accS);
+  if (__builtin_amdgcn_ballot_w64(anym != 0u) != 0ull) hc_gram_masked<MT>(pk, lds, lane);
+  anym = 0u;
+}
+
 // The wave's sample range [s_begin, s_end) (16-sample steps) is processed in iterations of U steps (groups of 4 = one
 // int8 operand each) through a ring of DEPTH step buffers with DEPTH - 1 steps in flight (U = 12 for DEPTH = 3, else
 // 4).  Whole iterations inside [0, N) run branch-free with immediate offsets; the remainder (only the last wave of a
 // gene has one) is loaded step by step from clamped positions and masked.
 template <int MT, int DEPTH, bool NT>
 __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullTile& nt, long long N, long long ld,
-                                                 int d) {
+                                                 int d, unsigned* lds) {
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, q = lane >> 4;
   const int wpart = blockIdx.x;
   if (wpart >= gd.n_wparts) return;
+  // ---- LDS of this wave: masked-tile counters = 0, OR words = 0, AND words = ~0, flag = 0 (one wave per workgroup: LDS
+  // operations of a wave execute in order, no barrier needed) ---------------------------------------------------------
+  constexpr int kPQ = hc_pq_words(MT);
+#pragma unroll 4
+  for (int w = lane; w < kPQ; w += 64) lds[w] = 0u;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) lds[kPQ + 64 * c + lane] = (lane & 2) ? 0xffffffffu : 0u;
+  if (lane < 4) lds[kPQ + 64 * MT + lane] = 0u;
+  const HcMaskCtx mc{lds + kPQ + 4 * v, lds + kPQ + 64 * MT};
+  unsigned anym = 0u;
   const long long nsteps = ld >> 4;
   const long long s_begin = (long long)wpart * gd.steps_per_wpart;
   long long s_end = s_begin + gd.steps_per_wpart;
@@ -235,13 +356,18 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
         unsigned h = 0;
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-          hc_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], fx[c], h, true);
+          unsigned p, m;
+          hc_row<false>(glo[c], ghi[c], xv, accT[c], p, m, cs[c], fx[c], h, true);
+          if (m) hc_note_masked(glo[c], ghi[c], m, mc.oa + 64 * c);
+          if (hc_code3(p)) __hip_atomic_fetch_or(mc.flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          pk[c][u] = p | (m << 2);
+          anym |= m;
           glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128, 0, NT ? 2 : 0));
           ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128 + 16, 0, NT ? 2 : 0));
           __builtin_amdgcn_sched_barrier(0);
         }
         hc_finish<false>(h, xv, bu, 0xffffffffu);
-        if (u == 3) hc_gram<MT>(pk, accS);
+        if (u == 3) hc_group_end<MT>(pk, accS, anym, lds, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -266,8 +392,8 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
         // (the scheduler must not hoist later steps' loads above this step's work: that is what the ring is for)
         hc_issue<MT, NT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, (u + DEPTH - 1) * 128);
         __builtin_amdgcn_sched_barrier(0);
-        hc_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, cs, fx, bu, true, 0xffffffffu);
-        if ((u & 3) == 3) hc_gram<MT>(pk, accS);
+        hc_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, cs, fx, bu, true, 0xffffffffu, anym, mc);
+        if ((u & 3) == 3) hc_group_end<MT>(pk, accS, anym, lds, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -292,13 +418,13 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
       const long long smp = sc * 16 + q * 4;
 #pragma unroll
       for (int l = 0; l < 4; ++l) vmask |= (valid && smp + l < N) ? (0xffu << (8 * l)) : 0u;
-      hc_step<MT, true>(f, T, accT, pk, cs, fx, bu, valid, vmask);
+      hc_step<MT, true>(f, T, accT, pk, cs, fx, bu, valid, vmask, anym, mc);
     };
     one(0, s);
     one(1, s + 1);
     one(2, s + 2);
     one(3, s + 3);
-    hc_gram<MT>(pk, accS);
+    hc_group_end<MT>(pk, accS, anym, lds, lane);
     s += 4;
   }
 
@@ -327,10 +453,11 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
       if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
     }
   }
-  // ---- column sum / min / max ---------------------------------------------------------------------------------------
+  // ---- column statistics: sum of H, min / max over the hard calls, masked count, OR / AND of the masked patterns --------
   long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
   if (cnt_w < 0) cnt_w = 0;
-  double* cst = gd.colstat + (long long)wpart * 3 * gd.Mp;
+  double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
+  const unsigned wflag = lds[kPQ + 64 * MT];
   {
     int t = 0;
 #pragma unroll
@@ -338,21 +465,38 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
       unsigned sc = cs[c];
       sc += __shfl_xor(sc, 16, 64);
       sc += __shfl_xor(sc, 32, 64);
-      // S_vv sits in lane v + 16 (v >> 2), accumulator element v & 3 of the diagonal tile
+      // C_vv sits in lane v + 16 (v >> 2), accumulator element v & 3 of the diagonal tile; Q_vv likewise in the LDS
+      // image: word (tile, v & 2 ? 1 : 0, that lane), half v & 1
       const i4_t dg = accS[t];
       const int sel = (lane & 3) == 0 ? dg[0] : ((lane & 3) == 1 ? dg[1] : ((lane & 3) == 2 ? dg[2] : dg[3]));
       const int diag = __shfl(sel, v + 16 * (v >> 2), 64);
+      const int tq = MT * MT + t;
+      const unsigned qw = lds[(tq * 2 + ((v >> 1) & 1)) * 64 + v + 16 * (v >> 2)];
+      const long long nm = (long long)((qw >> (16 * (v & 1))) & 0xffffu);  // masked entries of column c * 16 + v
       t += MT - c;
-      const long long sm = (long long)sc, n2 = ((long long)diag - sm) / 2, n1 = 2 * sm - (long long)diag,
-                      n0 = cnt_w - n1 - n2;
+      // C_vv = sum (H + 4m)^2 = sum H^2 + 16 nm
+      const long long sm = (long long)sc, hh = (long long)diag - 16 * nm, n2 = (hh - sm) / 2, n1 = 2 * sm - hh,
+                      n0 = cnt_w - n1 - n2 - nm;
       const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
       const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
       if (lane < 16) {
-        cst[c * 16 + lane] = (double)sm;
-        cst[gd.Mp + c * 16 + lane] = mn;
-        cst[2 * gd.Mp + c * 16 + lane] = mx;
+        const int j = c * 16 + lane;
+        cst[j] = (double)sm;
+        cst[gd.Mp + j] = mn;
+        cst[2 * gd.Mp + j] = mx;
+        cst[3 * gd.Mp + j] = (double)nm;
+        const unsigned* w = lds + kPQ + 64 * c + 4 * lane;
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(cst);
+        bits[4 * gd.Mp + j] = ((unsigned long long)w[1] << 32) | w[0];
+        bits[5 * gd.Mp + j] = ((unsigned long long)w[3] << 32) | w[2];
       }
     }
+  }
+  if (gd.wflags && lane == 0) gd.wflags[wpart] = wflag;
+  if ((wflag & 1u) && gd.pq) {  // the masked tiles of this wave-part (read by gene_assemble only when the flag says so)
+    unsigned* dst = gd.pq + (long long)wpart * kPQ;
+#pragma unroll 4
+    for (int w = lane; w < kPQ; w += 64) dst[w] = lds[w];
   }
   // ---- burden partial sums: [test][U, c'c, count, c'X_0 .. c'X_{d-1}], test 0 = CMC, 1 = Zeggini ---------------------
   if (gd.bparts) {
@@ -386,9 +530,10 @@ __device__ __forceinline__ void suffstat_hc_body(const GeneDesc& gd, const NullT
 template <int MT, int DEPTH, int WAVES, bool NT>
 __global__ __launch_bounds__(64, WAVES) void gene_suffstat_hc(const GeneDesc* __restrict__ genes, NullTile nt,
                                                               long long N, long long ld, int d) {
+  __shared__ unsigned lds[hc_lds_words(MT)];
   const GeneDesc gd = genes[blockIdx.y];
   if (gd.MT != MT) return;
-  suffstat_hc_body<MT, DEPTH, NT>(gd, nt, N, ld, d);
+  suffstat_hc_body<MT, DEPTH, NT>(gd, nt, N, ld, d, lds);
 }
 
 // ---- block classification: is every entry of an N x M block exactly 0.0, 1.0 or 2.0? -------------------------------

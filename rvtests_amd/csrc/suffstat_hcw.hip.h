@@ -65,8 +65,12 @@ struct HcwBurden {
 // one tile row of one step: fp64 tile of G'V[X | rr | v], packing, byte sums of g and g^2, burden hits
 template <bool MASKED>
 __device__ __forceinline__ void hcw_row(const u4_t& glo, const u4_t& ghi, const double (&xv)[4], d4_t& accT, unsigned& pk,
-                                        unsigned& cs, unsigned& cs2, unsigned fx, unsigned& h, bool valid) {
-  hc_row<MASKED>(glo, ghi, xv, accT, pk, cs, fx, h, valid);
+                                        unsigned& cs, unsigned& cs2, unsigned fx, unsigned& h, bool valid, unsigned& notHard) {
+  // entries that are not hard calls (mk) void the gene here: the weighted kernel has no masked-entry tiles, the engine
+  // runs such a gene on the fp64 kernel (wflags bit 1).  -inf (code 3, see hc_row) likewise.
+  unsigned mk;
+  hc_row<MASKED>(glo, ghi, xv, accT, pk, mk, cs, fx, h, valid);
+  notHard |= mk | hc_code3(pk);
   cs2 = __builtin_amdgcn_sad_u8((pk & 0x01010101u) | ((pk & 0x02020202u) << 1), 0u, cs2);  // g^2: 0 / 1 / 4
 }
 
@@ -90,7 +94,8 @@ __device__ __forceinline__ void hcw_finish(unsigned h, const double (&xv)[4], Hc
 template <int MT, bool MASKED>
 __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
                                          unsigned (&dg)[4][8], unsigned (&cs)[MT], unsigned (&cs2)[MT],
-                                         const unsigned (&fx)[MT], HcwBurden& bu, bool valid, unsigned vmask) {
+                                         const unsigned (&fx)[MT], HcwBurden& bu, bool valid, unsigned vmask,
+                                         unsigned& notHard) {
   double xv[4] = {hc_dbl(f.xlo[0], f.xlo[1]), hc_dbl(f.xlo[2], f.xlo[3]), hc_dbl(f.xhi[0], f.xhi[1]),
                   hc_dbl(f.xhi[2], f.xhi[3])};
   if (MASKED) {
@@ -104,7 +109,8 @@ __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t
   }
   unsigned h = 0;
 #pragma unroll
-  for (int c = 0; c < MT; ++c) hcw_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], cs2[c], fx[c], h, valid);
+  for (int c = 0; c < MT; ++c)
+    hcw_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], cs2[c], fx[c], h, valid, notHard);
   hcw_finish<MASKED>(h, xv, bu, vmask);
 }
 
@@ -239,6 +245,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
   }
   acc.init();
   HcwBurden bu{0.0, 0.0, 0.0, 0u};
+  unsigned notHard = 0u;
 
   long long s = s_begin;
   const long long full = N >> 4;
@@ -284,7 +291,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         unsigned h = 0;
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-          hcw_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], cs2[c], fx[c], h, true);
+          hcw_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], cs2[c], fx[c], h, true, notHard);
           glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128, 0, 0));
           ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128 + 16, 0, 0));
           __builtin_amdgcn_sched_barrier(0);
@@ -314,7 +321,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
       for (int u = 0; u < U; ++u) {
         hcw_issue<MT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, rq, qoff, (u + DEPTH - 1) * 128);
         __builtin_amdgcn_sched_barrier(0);
-        hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu);
+        hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu, notHard);
         if ((u & 3) == 3) acc.gram(pk, dg);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -340,7 +347,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
       const long long smp = sc * 16 + q * 4;
 #pragma unroll
       for (int l = 0; l < 4; ++l) vmask |= (valid && smp + l < N) ? (0xffu << (8 * l)) : 0u;
-      hcw_step<MT, true>(f, T, accT, pk, dg, cs, cs2, fx, bu, valid, vmask);
+      hcw_step<MT, true>(f, T, accT, pk, dg, cs, cs2, fx, bu, valid, vmask, notHard);
     };
     one(0, s);
     one(1, s + 1);
@@ -378,7 +385,11 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
   // ---- column sum / min / max from the byte sums of g and g^2 ------------------------------------------------------
   long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
   if (cnt_w < 0) cnt_w = 0;
-  double* cst = gd.colstat + (long long)wpart * 3 * gd.Mp;
+  double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
+  if (gd.wflags) {
+    const bool nh = __builtin_amdgcn_ballot_w64(notHard != 0u) != 0ull;
+    if (lane == 0) gd.wflags[wpart] = nh ? 2u : 0u;
+  }
 #pragma unroll
   for (int c = 0; c < MT; ++c) {
     unsigned sc = cs[c], sq = cs2[c];
@@ -393,6 +404,9 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
       cst[c * 16 + lane] = (double)sm;
       cst[gd.Mp + c * 16 + lane] = mn;
       cst[2 * gd.Mp + c * 16 + lane] = mx;
+      cst[3 * gd.Mp + c * 16 + lane] = 0.0;  // no masked entries on this path (rows 3-5 as suffstat_hc.hip.h writes them)
+      reinterpret_cast<unsigned long long*>(cst)[4 * gd.Mp + c * 16 + lane] = 0ull;
+      reinterpret_cast<unsigned long long*>(cst)[5 * gd.Mp + c * 16 + lane] = ~0ull;
     }
   }
   // ---- burden partial sums: [test][U, c'Vc, count, c'VX_0 .. c'VX_{d-1}], test 0 = CMC, 1 = Zeggini ------------------

@@ -29,7 +29,7 @@ struct GeneDesc {
   int n_wparts;          // wave-parts the sample axis is cut into
   int steps_per_wpart;   // 16-sample steps per wave-part
   double* parts;         // n_wparts x Mp x Cp partial statistics (row-major)
-  double* colstat;       // n_wparts x 3 x Mp
+  double* colstat;       // n_wparts x 3 x Mp (hard-call path: n_wparts x kHcColstatRows x Mp, suffstat_hc.hip.h)
   unsigned long long* masks;  // [2][nsteps][MT][4] ballots: kind 0 "g >= 1", kind 1 "g <= 1"
   unsigned short* flags;      // [2][MT]: flip bits, polymorphic bits per 16-variant block
   double* bparts;        // n_bparts x 2 x (3+d)
@@ -49,6 +49,8 @@ struct GeneDesc {
   int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
   int hc;                   // 1: the block holds only 0.0 / 1.0 / 2.0 and went through gene_suffstat_hc
   double* vt_mem;           // AnalyticVT workspace (gene_vt_doubles(Mp)), null unless the test is requested
+  unsigned* pq;             // hard-call path: n_wparts x hc_pq_words(MT) packed 16-bit counters of the masked tiles
+  unsigned* wflags;         // hard-call path: per wave-part, bit 0 = masked entries met (pq written), bit 1 = bad entry
 };
 
 struct NullDev {

@@ -67,7 +67,8 @@ class Timing(C.Structure):
                 ("ms_pvalue", C.c_double), ("n_suffstat_launches", C.c_int64), ("n_burden_launches", C.c_int64),
                 ("n_stats_launches", C.c_int64), ("n_pvalue_launches", C.c_int64), ("genes", C.c_int64),
                 ("alg_bytes", C.c_double), ("alg_flops", C.c_double), ("genes_hard_call", C.c_int64),
-                ("ms_suffstat_hc", C.c_double), ("n_suffstat_hc_launches", C.c_int64), ("alg_bytes_hc", C.c_double)]
+                ("ms_suffstat_hc", C.c_double), ("n_suffstat_hc_launches", C.c_int64), ("alg_bytes_hc", C.c_double),
+                ("genes_handed_back", C.c_int64)]
 
 
 def library_path():
@@ -138,8 +139,10 @@ def load_library():
     L.rvt_block_upload.argtypes = [vp, vp, C.c_int, c_double_p]
     L.rvt_block_classify.restype = C.c_int
     L.rvt_block_classify.argtypes = [vp, vp, C.c_int, c_int_p]
-    L.rvt_block_forget.restype = C.c_int
-    L.rvt_block_forget.argtypes = [vp, vp]
+    L.rvt_set_hardcall.restype = C.c_int
+    L.rvt_set_hardcall.argtypes = [vp, C.c_int]
+    L.rvt_set_content_hint.restype = C.c_int
+    L.rvt_set_content_hint.argtypes = [vp, C.c_int]
     run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
                 C.POINTER(Params), C.POINTER(GeneResult)]
     L.rvt_run_blocks.restype = C.c_int
@@ -374,15 +377,20 @@ class Engine:
         self._blocks.append(p)
         return p.value
 
+    def set_hardcall(self, on):
+        """Tests / experiments: False keeps every gene on the fp64 kernel (rvt_set_hardcall)."""
+        self._check(self.L.rvt_set_hardcall(self.ctx, 1 if on else 0))
+
+    def set_content_hint(self, hint):
+        """What the caller's own fp64 blocks hold: -1 unknown (start on the hard-call kernel), 0 dosages (start on the fp64
+        kernel), 1 hard calls / mean-imputed hard calls (rvt_set_content_hint).  Never affects correctness."""
+        self._check(self.L.rvt_set_content_hint(self.ctx, int(hint)))
+
     def classify_block(self, ptr, M):
-        """Scan a device block the engine did not fill (e.g. a torch tensor) and record whether it holds hard calls only
-        (rvt_block_classify); returns True / False."""
+        """Query (nothing is remembered): does the device block hold hard calls only (rvt_block_classify)?"""
         flag = C.c_int(0)
         self._check(self.L.rvt_block_classify(self.ctx, C.c_void_p(int(ptr)), int(M), C.byref(flag)))
         return bool(flag.value)
-
-    def forget_block(self, ptr):
-        self._check(self.L.rvt_block_forget(self.ctx, C.c_void_p(int(ptr))))
 
     def alloc_block(self, M):
         """Zeroed device block of M columns (rvt_block_alloc); fill it with upload_columns."""

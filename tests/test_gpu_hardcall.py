@@ -29,16 +29,18 @@ def _hard_gene(N, M, seed, flip_col=None, ones_col=None, twos_col=None, zero_col
 
 
 def _run(engine, genes, hard):
-    """Run the genes with the blocks registered as hard-call (hard=True) or unknown (general path)."""
-    ptrs = [engine.upload_block(G) for G, af in genes]         # upload classifies
-    if not hard:
-        for p in ptrs:
-            engine.forget_block(p)
+    """Run the genes starting on the hard-call kernel (hard=True: the default for blocks of unknown content) or with the
+    engine confined to the general fp64 kernel (hard=False)."""
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    engine.set_hardcall(hard)
     engine.set_profiling(True)
     engine.timing(reset=True)
-    out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
-    tm = engine.timing(reset=True)
-    engine.set_profiling(False)
+    try:
+        out = engine.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+        tm = engine.timing(reset=True)
+    finally:
+        engine.set_profiling(False)
+        engine.set_hardcall(True)
     for p in ptrs:
         engine.free_block(p)
     return out, tm
@@ -101,7 +103,7 @@ def test_burden_fallback_cases(engine):
         assert r.n_poly == a.n_poly and abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
 
 
-def test_classification(engine):
+def test_classification_query(engine):
     N = 2000
     X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=4)
     engine.set_null(0, X, res, v, s2)
@@ -115,12 +117,228 @@ def test_classification(engine):
         p = engine.upload_block(H)
         assert engine.classify_block(p, 9) is False, bad
         engine.free_block(p)
-    # an imputed block (fractional means) must take the general path and still match the oracle
-    Graw, Gi, afi = synth.make_gene(N, 25, seed=3, missing=0.02)
-    out, tm = _run(engine, [(Gi, afi)], True)
-    assert tm.genes_hard_call == 0
-    rc, a = orc.skat(Gi, afi, X, res, v, 0)
-    assert abs(out[0].skat_Q - a.Q) <= 1e-10 * a.Q
+
+
+def _exact_gram(G):
+    """G'G with every product and sum exact (Fractions are overkill: the entries are doubles, use integer arithmetic on
+    their 2^-k grid through Python's arbitrary precision)."""
+    from fractions import Fraction
+    N, M = G.shape
+    S = np.empty((M, M))
+    cols = [[Fraction(x) for x in G[:, j]] for j in range(M)]
+    for a in range(M):
+        for b in range(a, M):
+            S[a, b] = S[b, a] = float(sum(x * y for x, y in zip(cols[a], cols[b])))
+    return S
+
+
+@pytest.mark.parametrize("N,d,miss", [(3000, 3, 0.02), (4099, 1, 0.3), (10007, 2, 0.001)])
+def test_mean_imputed_columns_stay_on_the_hardcall_kernel(engine, N, d, miss):
+    """imputeGenotypeToMean (src/DataConsolidator.cpp:217-245) leaves hard calls plus ONE other value per column.  Such
+    genes run on the integer kernel (masked-entry tiles), are not handed back, and give the numbers of the general
+    kernel and of the oracle; G'G equals the exactly rounded product."""
+    genes = []
+    for M in (1, 7, 16, 17, 30, 33, 48, 50, 64, 65, 80, 81, 96):
+        Graw, Gi, afi = synth.make_gene(N, M, seed=3 * M + d, missing=miss, common=(M % 2 == 0), mono=(M % 3 == 0))
+        genes.append((Gi, afi))
+    assert any(((G != 0) & (G != 1) & (G != 2)).any() for G, af in genes)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=5, G_effect=0.4 * genes[4][0][:, :3].sum(1))
+    engine.set_null(0, X, res, v, s2)
+    hc, tm_hc = _run(engine, genes, True)
+    gen, tm_gen = _run(engine, genes, False)
+    assert tm_hc.genes_hard_call == len(genes) and tm_hc.genes_handed_back == 0
+    assert tm_gen.genes_hard_call == 0
+    for a, b, (G, af) in zip(hc, gen, genes):
+        assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref and a.status == b.status
+        for f in FIELDS:
+            # (the statistics agree to rounding; Davies' term count is a floor() of its inputs, so a p-value may move by
+            # ~1e-7 relative under a last-bit change of G'G — DESIGN.md section 4)
+            x, y_ = getattr(a, f), getattr(b, f)
+            tol = 1e-6 if f.endswith("_p") else 1e-10
+            assert abs(x - y_) <= tol * abs(y_) + 1e-300, (G.shape[1], f, x, y_)
+        rc, o = orc.skat(G, af, X, res, v, 0)
+        assert a.n_poly == o.n_poly
+        if o.n_poly:
+            assert abs(a.skat_Q - o.Q) <= 1e-10 * o.Q and abs(a.skat_p - o.pvalue) <= 1e-6 * o.pvalue + 1e-14
+        rc2, so = orc.skato(G, af, X, res, v, 0)
+        if rc2 == 0 and o.n_poly:
+            assert abs(a.skato_p - so.pvalue) <= 1e-6 * so.pvalue + 5e-13
+        for which, ok, p, nonref in ((0, a.cmc_ok, a.cmc_p, a.cmc_nonref), (1, a.zeg_ok, a.zeg_p, None)):
+            rc3, c = orc.burden(G, X, y, 0, which)
+            if rc3 == 0:
+                assert ok and abs(p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
+                if nonref is not None:
+                    assert nonref == c.nonref_site
+    # the Gram matrix itself: integer pieces exact, one rounding per product of the imputed value
+    G, af = genes[3]
+    ptr = engine.upload_block(G)
+    S, T, u, colsum = engine.debug_suffstat(ptr, G.shape[1])[:4]
+    engine.free_block(ptr)
+    Sx = _exact_gram(G[:, :G.shape[1]])
+    assert np.max(np.abs(S - Sx) / np.maximum(np.abs(Sx), 1.0)) <= 4 * np.finfo(float).eps
+    assert np.allclose(T, G.T @ X, rtol=1e-12, atol=1e-9) and np.allclose(colsum, G.sum(0), rtol=1e-13)
+
+
+def test_imputed_value_that_counts_in_the_burden_collapse(engine):
+    """(int)g' > 0 for the imputed value itself: mu >= 1 in an unflipped column, mu <= 1 in a flipped one.  The in-pass
+    collapse skips masked entries; such a gene must come out as the oracle has it (burden fallback)."""
+    N, d = 5003, 2
+    rng = np.random.default_rng(7)
+    G, af = _hard_gene(N, 24, seed=5, maf_hi=-0.5)
+    G = G.copy()
+    col = rng.binomial(2, 0.52, N).astype(float)          # mean just above 1: unflipped when the sum stays <= N
+    col[rng.random(N) < 0.05] = np.nan
+    mu = np.nansum(col) / np.sum(~np.isnan(col))
+    col[np.isnan(col)] = mu
+    G[:, 3] = col
+    col2 = rng.binomial(2, 0.9, N).astype(float)          # flipped column whose imputed value stays above 1
+    col2[rng.random(N) < 0.03] = 1.8123
+    G[:, 9] = col2
+    G = np.asfortranarray(G)
+    af = G.sum(0) / (2.0 * N)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=8, G_effect=0.3 * G[:, :4].sum(1))
+    engine.set_null(0, X, res, v, s2)
+    (r,), tm = _run(engine, [(G, af)], True)
+    assert tm.genes_hard_call == 1 and tm.genes_handed_back == 0
+    for which, ok, stat, p in ((0, r.cmc_ok, r.cmc_stat, r.cmc_p), (1, r.zeg_ok, r.zeg_stat, r.zeg_p)):
+        rc, b = orc.burden(G, X, y, 0, which)
+        assert ok == (rc == 0)
+        if ok:
+            assert abs(stat - b.stat) <= 1e-9 * b.stat + 1e-13 and abs(p - b.pvalue) <= 1e-6 * b.pvalue + 1e-14
+    rc, c = orc.burden(G, X, y, 0, 0)
+    assert r.cmc_nonref == c.nonref_site
+    rc, a = orc.skat(G, af, X, res, v, 0)
+    assert r.n_poly == a.n_poly and abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
+
+
+def test_block_rewritten_in_place_with_dosages(engine):
+    """Nothing is remembered about a block: the same device allocation first holds hard calls, then — rewritten in
+    place, no call to the engine in between — dosages, then a column with two different non-integer values, then an
+    infinity.  Every run must give the oracle's numbers (the integer kernel hands the gene back to the fp64 kernel)."""
+    import ctypes as C
+    N, M, d = 6007, 37, 2
+    rng = np.random.default_rng(11)
+    Gh, af = _hard_gene(N, M, seed=9, flip_col=4)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=3, G_effect=0.3 * Gh[:, :3].sum(1))
+    engine.set_null(0, X, res, v, s2)
+    ptr = engine.upload_block(Gh)
+    ld = int(engine.L.rvt_padded_ld(N))
+
+    def rewrite(G):
+        buf = np.zeros((ld, M), order="F")
+        buf[:N] = G
+        rc = _hip_memcpy_h2d(ptr, buf)
+        assert rc == 0
+
+    def check(G, handed_back):
+        afx = G.sum(0) / (2.0 * N)
+        engine.set_profiling(True)
+        engine.timing(reset=True)
+        (r,) = engine.run_blocks([ptr], [M], [afx])
+        tm = engine.timing(reset=True)
+        engine.set_profiling(False)
+        assert tm.genes_hard_call == 1 and tm.genes_handed_back == handed_back
+        rc, a = orc.skat(G, afx, X, res, v, 0)
+        rc2, o = orc.skato(G, afx, X, res, v, 0)
+        rc3, c = orc.burden(G, X, y, 0, 0)
+        assert r.n_poly == a.n_poly and abs(r.skat_Q - a.Q) <= 1e-10 * a.Q
+        assert abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14 and abs(r.skato_p - o.pvalue) <= 1e-6 * o.pvalue + 5e-13
+        assert r.cmc_nonref == c.nonref_site and abs(r.cmc_p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
+
+    check(Gh, 0)
+    Gd = np.clip(Gh + rng.normal(0, 0.05, Gh.shape), 0, 2)                 # dosages everywhere
+    rewrite(Gd)
+    check(Gd, 1)
+    G2 = Gh.copy()                                                          # ONE column with two distinct fractions
+    G2[17, 5] = 0.25
+    G2[4000, 5] = 0.75
+    rewrite(G2)
+    check(G2, 1)
+    G3 = Gh.copy()                                                          # one imputed value: stays
+    G3[rng.random(N) < 0.01, 8] = 0.0371
+    rewrite(G3)
+    check(G3, 0)
+    rewrite(Gh)
+    check(Gh, 0)
+    engine.free_block(ptr)
+
+
+def _hip_memcpy_h2d(ptr, arr):
+    """Write a host array into device memory behind the engine's back (hipMemcpy through the HIP runtime)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    a = np.ascontiguousarray(arr.T)           # column-major bytes
+    return hip.hipMemcpy(C.c_void_p(int(ptr)), a.ctypes.data_as(C.c_void_p), a.nbytes, 1)
+
+
+def test_content_hint_only_chooses_the_starting_kernel(engine):
+    """Dosage blocks of the caller: without a hint they start on the integer kernel and are handed back gene by gene, with
+    rvt_set_content_hint(0) they start on the fp64 kernel; hard calls under the wrong hint simply run on the fp64
+    kernel.  The records are right every time, and equal between the two ways for dosages (same kernel computes them)."""
+    N, M, d = 3001, 20, 2
+    rng = np.random.default_rng(2)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=13)
+    engine.set_null(0, X, res, v, s2)
+    dos = []
+    for g in range(6):
+        G = np.asfortranarray(np.clip(rng.binomial(2, 0.05, (N, M)) + rng.normal(0, 0.02, (N, M)), 0, 2))
+        dos.append((G, G.sum(0) / (2.0 * N)))
+    hard = [_hard_gene(N, M, seed=70 + g) for g in range(6)]
+    pd = [engine.upload_block(G) for G, af in dos]
+    ph = [engine.upload_block(G) for G, af in hard]
+    engine.set_profiling(True)
+
+    def run(ptrs, genes):
+        engine.timing(reset=True)
+        out = engine.run_blocks(ptrs, [M] * 6, [af for G, af in genes])
+        tm = engine.timing(reset=True)
+        for r, (G, af) in zip(out, genes):
+            rc, a = orc.skat(G, af, X, res, v, 0)
+            assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q and abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14
+        return out, (tm.genes_hard_call, tm.genes_handed_back)
+
+    try:
+        a, seen = run(pd, dos)
+        assert seen == (6, 6)
+        a2, seen = run(pd, dos)                       # no history: the same again
+        assert seen == (6, 6)
+        engine.set_content_hint(0)
+        b, seen = run(pd, dos)
+        assert seen == (0, 0)
+        for x, y_ in zip(a, b):
+            assert all(getattr(x, f) == getattr(y_, f) for f in FIELDS)
+        h0, seen = run(ph, hard)                      # hard calls under the "dosages" hint: fp64 kernel, still right
+        assert seen == (0, 0)
+        engine.set_content_hint(-1)
+        h1, seen = run(ph, hard)
+        assert seen == (6, 0)
+    finally:
+        engine.set_content_hint(-1)
+        engine.set_profiling(False)
+    for p in pd + ph:
+        engine.free_block(p)
+
+
+def test_masked_tile_counters_at_the_wave_part_cap(engine, monkeypatch):
+    """The masked tiles are 16-bit counters per wave-part; the host cuts wave-parts at 1020 steps (16 320 samples) so that
+    P' = (H + 4m)'m <= 4 x 16 320 < 65 536.  A column that is imputed EVERYWHERE reaches that bound."""
+    N = 70_000
+    rng = np.random.default_rng(4)
+    G = rng.binomial(2, 0.2, (N, 3)).astype(float)
+    G[:, 1] = 0.4137                                  # every entry masked
+    G[rng.random(N) < 0.5, 2] = 0.7311                # half the entries masked
+    G = np.asfortranarray(G)
+    af = G.sum(0) / (2.0 * N)
+    X, y, res, v, s2 = synth.make_null(N, 1, 0, seed=6)
+    engine.set_null(0, X, res, v, s2)
+    monkeypatch.setenv("RVT_WPARTS", "1")             # as few wave-parts as the cap allows
+    ptr = engine.upload_block(G)
+    S = engine.debug_suffstat(ptr, 3)[0]
+    engine.free_block(ptr)
+    Sx = G.T.astype(np.longdouble) @ G.astype(np.longdouble)
+    assert np.max(np.abs(S - Sx) / np.abs(Sx)) < 1e-14
 
 
 @pytest.mark.parametrize("N,d", [(3000, 2), (4099, 1), (10007, 4)])
@@ -217,8 +435,7 @@ def test_binary_trait_with_a_weight_out_of_range_stays_on_fp64(engine):
 
 
 def test_streaming_submissions_take_the_hardcall_path(engine):
-    """rvt_submit_gene / _i8 / _bed classify the block they write; hard calls without missing values then run on the
-    int8 path and give the oracle's numbers."""
+    """Blocks written by rvt_submit_gene / _i8 / _bed start on the int8 path and give the oracle's numbers."""
     N, d = 4001, 3
     X, y, res, v, s2 = synth.make_null(N, d, 0, seed=21)
     engine.set_null(0, X, res, v, s2)
