@@ -25,6 +25,8 @@ namespace rvt {
 // =====================================================================================================
 __global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restrict__ genes, long long N) {
   const GeneDesc gd = genes[blockIdx.x];
+  // (a hard-call gene: only when it was handed back and gene_suffstat_mfma has computed it — three-row statistics)
+  if (gd.hc && gd.flags[2 * gd.MT + 1] == 0) return;
   const int tid = threadIdx.x;  // blockDim.x == 64: one wave
   for (int base = 0; base < gd.Mp; base += 64) {
     const int j = base + tid;
@@ -192,10 +194,15 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 //                       (all-1 column; all-0 and all-2 columns never count), or a column's imputed value counts
 //                       ((int)g' > 0) where the in-pass collapse skips masked entries -> burden_fallback_kernel
 //   flags[2 MT + 1]     1 = the block is not "hard calls + one imputed value per column" (dosages, -inf): the statistics
-//                       of gene_suffstat_hc are void; gene_assemble marks the gene kStatusRerun and the engine runs it
-//                       again on the general fp64 kernel
+//                       of gene_suffstat_hc are void.  The gene is HANDED BACK: the conditional launch of
+//                       gene_suffstat_mfma that follows on the same stream computes it (every other workgroup of that
+//                       launch leaves at once), gene_flags_kernel derives its flags from the three-row statistics, its
+//                       burden sums come from burden_fallback_kernel, and gene_assemble reads it as a general-path gene
 // =====================================================================================================
-__global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N) {
+// lists: [0] number of handed-back genes, [1] number of genes whose burden sums are redone, [4 ..) / [4 + n_genes ..) their
+// indices (the work lists of the conditional general-kernel launch and of burden_fallback_kernel; zeroed by the host).
+__global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N,
+                                                           int* __restrict__ lists, int n_genes) {
   const GeneDesc gd = genes[blockIdx.x];
   const int tid = threadIdx.x;
   bool bad = false, rerun = false;
@@ -244,25 +251,31 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
   }
   const bool any = __any(bad), anyr = __any(rerun);
   if (tid == 0) {
-    gd.flags[2 * gd.MT] = (any && !anyr) ? 1 : 0;
+    gd.flags[2 * gd.MT] = (any || anyr) ? 1 : 0;
     gd.flags[2 * gd.MT + 1] = anyr ? 1 : 0;
+    if (anyr) lists[4 + atomicAdd(&lists[0], 1)] = blockIdx.x;
+    if (any || anyr) lists[4 + n_genes + atomicAdd(&lists[1], 1)] = blockIdx.x;
   }
 }
 
 // Burden partial sums of a hard-call gene straight from its genotype block with the ACTUAL flags (rare: see above).
-// grid (kFallbackSplit, genes), 256 threads: almost every workgroup leaves at once (flag clear), so the grid is kept
-// small; a flagged gene's wave-parts are dealt to its kFallbackSplit workgroups.  Writes the same records
-// gene_suffstat_hc writes: bparts[part][test][..].
-constexpr int kFallbackSplit = 8;
+// The genes come from the device work list gene_flags_hc_kernel wrote (lists[1] entries at lists[4 + n_genes ..)); a
+// fixed grid of kFallbackGrid workgroups loops over the (gene, wave-part) items and leaves at once when the list is
+// empty.  Writes the same records gene_suffstat_hc writes: bparts[part][test][..].
+constexpr int kFallbackGrid = 1024;
 template <int DMAX>
-__global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __restrict__ genes, NullDev nd,
-                                                              long long N, long long ld, int d, int binary) {
-  const GeneDesc gd = genes[blockIdx.y];
-  if (!gd.bparts || gd.flags[2 * gd.MT] == 0) return;
+__global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __restrict__ genes,
+                                                              const int* __restrict__ lists, int n_genes, int n_wparts,
+                                                              NullDev nd, long long N, long long ld, int d, int binary) {
+  const long long n_items = (long long)lists[1] * n_wparts;
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const GeneDesc gd = genes[lists[4 + n_genes + (int)(item / n_wparts)]];
+  if (!gd.bparts) continue;  // (uniform over the workgroup)
   constexpr int NV = 2 * (3 + DMAX);
   __shared__ double red[4][NV];
   const int tid = threadIdx.x;
-  for (int part = blockIdx.x; part < gd.n_wparts; part += gridDim.x) {
+  {
+  const int part = (int)(item % n_wparts);
   const long long s0 = (long long)part * gd.steps_per_wpart * 16;
   long long s1 = s0 + (long long)gd.steps_per_wpart * 16;
   if (s1 > N) s1 = N;
@@ -305,6 +318,7 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
   }
   __syncthreads();
   }
+  }
 }
 
 // =====================================================================================================
@@ -325,12 +339,13 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT)};
-  const bool masks = gd.hc == 1;  // (pq is null for the weighted hard-call kernel: 6-row statistics, no masked tiles)
-  const unsigned force = (gd.hc && gd.flags[2 * gd.MT + 1]) ? kStatusRerun : 0u;
+  // a hard-call gene that was handed back holds the general kernel's statistics (three rows per wave-part, G'DG itself)
+  const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
+  const bool masks = gd.hc == 1 && !handed_back;  // (pq is null for the weighted hard-call kernel: no masked tiles)
   gene_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
                 (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, gd.n_bparts > 0 ? gd.n_bparts : n_bparts,
                 gd.af, prm, tests, ws,
-                gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, force);
+                gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, handed_back ? kStatusHandedBack : 0u);
 }
 
 __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
@@ -898,23 +913,21 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
   if (h >= V) return;
   const long long col = gd.gene_id + h;
   double mn = INFINITY, mx = -INFINITY, cm = 0.0;
-  unsigned long long orb = 0ull, andb = ~0ull;
-  bool redo = false;  // hard-call slice that holds something else: the host runs the slice again on the fp64 kernel
-  const int cs_rows = gd.hc ? kHcColstatRows : 3;
+  unsigned long long orb = 0ull;
+  // a hard-call slice that was handed back (gene_flags_hc_kernel) holds the general kernel's statistics
+  const bool hcs = gd.hc && gd.flags[2 * gd.MT + 1] == 0;
+  const int cs_rows = hcs ? kHcColstatRows : 3;
   for (int p = 0; p < gd.n_wparts; ++p) {
     const double* c = gd.colstat + (long long)p * cs_rows * gd.Mp;
     mn = fmin(mn, c[gd.Mp + h]);
     mx = fmax(mx, c[2 * gd.Mp + h]);
-    if (gd.hc) {
+    if (hcs) {
       cm += c[3 * gd.Mp + h];
       orb |= reinterpret_cast<const unsigned long long*>(c)[4 * gd.Mp + h];
-      andb &= reinterpret_cast<const unsigned long long*>(c)[5 * gd.Mp + h];
-      redo |= gd.wflags && (gd.wflags[p] & 2u);
     }
   }
   const double mu = rvt_bits_to_double(orb);
   if (cm > 0.0) {  // mean-imputed column (suffstat_hc.hip.h): one value for every masked entry
-    redo |= orb != andb || !(mu >= 0.0 && mu <= 2.0);
     mn = fmin(mn, mu);
     mx = fmax(mx, mu);
   }
@@ -938,9 +951,9 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
     q += t[k] * s;
   }
   const double SS = shh - q;
-  const int fit = redo ? -2 : (polymorphic && SS > 0.0);
+  const int fit = polymorphic && SS > 0.0;
   double us = 0.0, vs = 0.0, eff = 0.0, se = 0.0, pv = 1.0;
-  if (fit > 0) {
+  if (fit) {
     if (!binary) {
       us = u / sigma2;
       vs = SS / sigma2;

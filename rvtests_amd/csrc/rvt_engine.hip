@@ -19,10 +19,10 @@
 #include "kernels.hip.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
-void k2_launch_group_w0(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N,
-                        long long ld, int d);
-void k2_launch_group_w1(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N,
-                        long long ld, int d);
+void k2_launch_group_w0(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const int* list, int n_wparts,
+                        NullDev nd, long long N, long long ld, int d);
+void k2_launch_group_w1(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const int* list, int n_wparts,
+                        NullDev nd, long long N, long long ld, int d);
 void k2_launch_panel_w0(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N, long long ld,
                         int d);
 void k2_launch_panel_w1(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullDev nd, long long N, long long ld,
@@ -79,27 +79,9 @@ struct Slot {
   rvt_gene_result* h_results = nullptr;
   int pending_n = 0;
   unsigned long long seq = 0;  // launch order
-  // what the batch was, for the genes the hard-call kernel hands back (kStatusRerun): they run again on the general
-  // kernel when the batch is finished (finish_slot)
-  struct Rerun {
-    std::vector<const double*> dG;
-    std::vector<int> M;
-    std::vector<double> af;      // concatenated
-    std::vector<size_t> af_off;  // per gene
-    std::vector<int64_t> ids;
-    std::vector<unsigned char> predicted;  // 1: the gene took the hard-call kernel on a prediction (unknown content)
-    uint32_t tests = 0;
-    rvt_params prm;
-    bool armed = false;
-    // a re-run that was launched ahead of finish_slot (poll_reruns): which slot computes it, which genes, their records
-    int launched_slot = -1;
-    std::vector<int> idx;
-    std::vector<rvt_gene_result> res;
-  } rerun;
 };
 constexpr int kSlots = RVT_MAX_INFLIGHT;
-constexpr int kRerunSlots = 2;               // slots that re-runs on the general kernel use (never part of the rotation)
-constexpr int kSlotsAll = kSlots + kRerunSlots;
+constexpr int kSlotsAll = kSlots;
 
 struct rvt_ctx {
   int device = 0;
@@ -221,14 +203,14 @@ struct rvt_ctx {
   int64_t null_ld = 0;
   // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
   // double it loads and hands back genes that hold anything but hard calls and one imputed value per column
-  // (kStatusRerun; finish_slot runs them again on the general fp64 kernel).  The engine's own decoders say what they
-  // wrote (hint per gene: 1 hard calls / imputed, 0 dosages); blocks of unknown content (fp64 from the caller) start on
-  // the hard-call kernel unless the caller has said they hold dosages (rvt_set_content_hint).  No history: the kernel
-  // a block runs on — and with it the last bits of its records — depends on the block and the hint alone.
+  // (gene_flags_hc_kernel); those are computed by the general fp64 kernel in the same batch, through a conditional launch
+  // that follows the hard-call launches on the same stream.  The engine's own decoders say what they wrote (hint per
+  // gene: 1 hard calls / imputed, 0 dosages); blocks of unknown content (fp64 from the caller) start on the hard-call
+  // kernel unless the caller has said they hold dosages (rvt_set_content_hint).  No history: the kernel a block runs on
+  // — and with it the last bits of its records — depends on the block and the hint alone.
   int content_hint = -1;
   int* d_kind = nullptr;      // device flag of rvt_block_classify (a stateless query)
   bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
-  bool k2_alternate = false;  // RVT_K2_ALT=1: consecutive hard-call launches alternate between the two K2 streams
   double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
   bool have_null_beta = false;
   // streaming interface
@@ -328,39 +310,22 @@ int ensure_stage(rvt_ctx* c, Slot& sl, size_t bytes) {
   return RVT_OK;
 }
 
-int rerun_launch(rvt_ctx* c, Slot& sl, const rvt_gene_result* h, int n, bool wait_for_slot);
-int poll_reruns(rvt_ctx* c);
-
-// wait for one slot's batch and hand its records to the caller.  Genes the hard-call kernel handed back (kStatusRerun:
-// their block holds something other than hard calls and one imputed value per column) first run again on the general
-// kernel.
+// wait for one slot's batch and hand its records to the caller
 int finish_slot(rvt_ctx* c, Slot& sl) {
   HIP_TRY(c, sync_stream(sl.stream));
   if (sl.pending_out) {
-    rvt_gene_result* out = sl.pending_out;
-    rvt_gene_result* h = sl.h_results;
-    bool* done = sl.pending_done;
-    const int n = sl.pending_n;
+    // (kStatusHandedBack is bookkeeping: the gene started on the hard-call kernel and was computed by the fp64 kernel)
+    for (int g = 0; g < sl.pending_n; ++g) {
+      if (sl.h_results[g].status & kStatusHandedBack) {
+        sl.h_results[g].status &= ~kStatusHandedBack;
+        if (c->profiling) ++c->timing.genes_handed_back;
+      }
+    }
+    std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
+    if (sl.pending_done) *sl.pending_done = true;
     sl.pending_done = nullptr;
     sl.pending_out = nullptr;
     sl.pending_n = 0;
-    if (sl.rerun.armed) {
-      if (sl.rerun.launched_slot < 0) {  // not looked at yet (poll_reruns): now, and wait for it
-        int rc = rerun_launch(c, sl, h, n, true);
-        if (rc) return rc;
-      }
-      sl.rerun.armed = false;
-      if (sl.rerun.launched_slot >= 0) {
-        Slot::Rerun rr = std::move(sl.rerun);  // (finishing the re-run's slot must not find this slot half-finished)
-        sl.rerun = Slot::Rerun();
-        int rc = finish_slot(c, c->slots[rr.launched_slot]);
-        if (rc) return rc;
-        for (size_t i = 0; i < rr.idx.size(); ++i) h[rr.idx[i]] = rr.res[i];
-        if (c->profiling) c->timing.genes_handed_back += (int64_t)rr.idx.size();
-      }
-    }
-    std::memcpy(out, h, sizeof(rvt_gene_result) * n);
-    if (done) *done = true;
   }
   return RVT_OK;
 }
@@ -410,6 +375,7 @@ void drain_events(rvt_ctx* c) {
         break;
       case 1: c->timing.ms_burden += ms; c->timing.n_burden_launches++; break;
       case 2: c->timing.ms_stats += ms; c->timing.n_stats_launches++; break;
+      case 5: break;  // conditional launches of the general kernel over hard-call genes (mostly empty): not counted
       default: c->timing.ms_pvalue += ms; c->timing.n_pvalue_launches++; break;
     }
     c->event_pool.push_back(e.a);
@@ -419,19 +385,22 @@ void drain_events(rvt_ctx* c) {
 }
 
 // genes [0, n) of one register-budget group (kernels.hip.h: suffstat_group)
+// list != nullptr: the genes come from a device work list (handed-back hard-call genes, suffstat_kernels.hip.h); the
+// launch is then a fixed small grid whose workgroups loop over the list — empty almost always.
 void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_desc, int n, int max_wparts,
-                     const NullDev& nd) {
-  Scope sc(c, 0, st);
+                     const NullDev& nd, const int* list = nullptr) {
+  Scope sc(c, list ? 5 : 0, st);
   // Waves are independent (no LDS, no barriers), so a workgroup is ONE wave: the dispatcher can then place the
   // wide classes (one wave fills a SIMD's register file) on any free SIMD, instead of needing four free SIMDs on
   // one CU at once — which a single long-lived p-value wave per CU would block for its whole lifetime.
   dim3 grid(max_wparts, n);
+  if (list) grid = dim3(1024, 1);
   const long long N = c->nc.N, ld = c->nc.ld;
   const int d = c->nc.d;
   if (c->nc.binary)
-    k2_launch_group_w1(group, grid, st, d_desc, nd, N, ld, d);
+    k2_launch_group_w1(group, grid, st, d_desc, list, max_wparts, nd, N, ld, d);
   else
-    k2_launch_group_w0(group, grid, st, d_desc, nd, N, ld, d);
+    k2_launch_group_w0(group, grid, st, d_desc, list, max_wparts, nd, N, ld, d);
 }
 
 // glibc srandom_r / random_r for the default TYPE_3 generator: r[i] = 16807 r[i-1] mod (2^31 - 1) for the first 31
@@ -611,7 +580,6 @@ int rvt_init(rvt_ctx** out, int device_id) {
   }
   seed_rand_state(c->rand_state, 1u);
   if (const char* e = getenv("RVT_HARDCALL")) c->hc_enabled = atoi(e) != 0;
-  if (const char* e = getenv("RVT_K2_ALT")) c->k2_alternate = atoi(e) != 0;
   *out = c;
   return RVT_OK;
 }
@@ -1034,12 +1002,10 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
 }
 
 // kind (optional, per gene): what the engine's own decoder wrote into the block — 1 hard calls (+ imputed means),
-// 0 dosages, -1 unknown.  rerun_slot >= 0: the batch is the re-run of genes the hard-call kernel handed back: general
-// kernel only, on that (re-run) slot.
+// 0 dosages, -1 unknown.
 static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
                      const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
-                     DebugOut* dbg, CovOut* cov = nullptr, const signed char* kind = nullptr, int rerun_slot = -1) {
-  const bool rerun_of = rerun_slot >= 0;
+                     DebugOut* dbg, CovOut* cov = nullptr, const signed char* kind = nullptr) {
   if (!c || n < 0 || (n > 0 && (!dG || !Ms || !af || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
@@ -1052,11 +1018,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     int rc = rvt_sync(c);
     if (rc) return rc;
     slp = &c->slots[0];
-  }
-  if (rerun_of) slp = &c->slots[rerun_slot];
-  if (!rerun_of && !dbg && !cov) {
-    int rc = poll_reruns(c);
-    if (rc) return rc;
   }
   Slot& sl = *slp;
   {
@@ -1092,12 +1053,12 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const bool score_hc = cov && cov->score && cov->slice_hc;
   // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests and MetaScore slices)
   const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && (!cov || score_hc);
-  const bool hc_possible = c->hc_enabled && !rerun_of && (!nc.binary || hcw) && (!cov || score_hc) &&
+  const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) &&
                            !(dbg && dbg->cmc) && d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) &&
                            c->d_nulltile != nullptr && nd_is_default;
   const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
   const bool predict_hc = c->content_hint != 0;  // blocks of unknown content (rvt_set_content_hint)
-  std::vector<unsigned char> predicted(n, 0);
+
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
     if (M < 1) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M);
@@ -1122,7 +1083,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       } else {
         const int k = kind ? kind[g] : -1;
         gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;
-        predicted[g] = (gd.hc && k < 0) ? 1 : 0;
       }
     }
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
@@ -1138,6 +1098,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
+  // device work lists of the hard-call genes (gene_flags_hc_kernel): [0] handed back, [1] burden sums to redo, then
+  // the two index lists
+  const size_t off_lists = add(sizeof(int) * (4 + 2 * (size_t)std::max(n_hc, 1)));
   size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0, off_cov_bur = 0, off_cov_ok = 0;
   if (cov && cov->score) {  // one gene per 16-column slice of the block: per-variant records only
     size_t vt = 0;
@@ -1223,7 +1186,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
   // general-path genes of a mixed batch (a few genes with imputed values among hard-call ones) go to the second
   // sufficient-statistics stream and run beside the hard-call launches
-  const bool split = (n_gen > 0 && n_hc > 0) || (c->k2_alternate && n_hc > 0);
+  const bool split = n_gen > 0 && n_hc > 0;
   hipStream_t gst = split ? c->k2b_stream : c->k2_stream;
   if (split) HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_in[slot_idx], 0));
   int k0 = 0;
@@ -1246,11 +1209,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     launch_suffstat(c, gst, grp, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
-  int hc_launches = 0;
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
     while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
-    hipStream_t hst = (c->k2_alternate && (hc_launches++ & 1)) ? c->k2b_stream : c->k2_stream;
+    hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
     if (hcw)
       k2_launch_hcw(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTileW{c->d_nulltile_w, d + 3, c->d_vq},
@@ -1266,6 +1228,21 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   HIP_TRY(c, hipEventRecord(c->ev_k2[slot_idx], c->k2_stream));
   HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k2[slot_idx], 0));
+  if (n_hc > 0) {
+    // What the hard-call kernels assumed is verified now (flip predictions, counted monomorphic columns, and above all
+    // that every block held hard calls and at most one other value per column): gene_flags_hc_kernel.  Genes it hands
+    // back are computed by the general kernel right here, on the batch's own stream (the shared streaming stream goes
+    // straight on to the next batch) — one launch per register-budget group over the device work list the flags kernel
+    // writes; its workgroups leave at once when the list is empty.
+    int* d_lists = reinterpret_cast<int*>(base + off_lists);
+    HIP_TRY(c, hipMemsetAsync(d_lists, 0, 4 * sizeof(int), st));
+    hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, st, d_desc + n_gen, (long long)N, d_lists,
+                       n_hc);
+    bool grp_present[3] = {false, false, false};
+    for (int k = n_gen; k < n; ++k) grp_present[suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0)] = true;
+    for (int grp = 0; grp < 3; ++grp)
+      if (grp_present[grp]) launch_suffstat(c, st, grp, d_desc + n_gen, n_hc, n_wparts, nd, d_lists);
+  }
   if (cov && cov->score) {  // MetaScore: per-variant statistics of every slice, returned synchronously
     size_t vt = 0;
     for (int g = 0; g < n; ++g) vt += (size_t)Ms[g];
@@ -1328,10 +1305,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     return RVT_OK;
   }
   const bool burden = (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) != 0;
-  if (n_hc > 0 && !(burden || dbg)) {  // (flip / polymorphic flags are not needed, the hand-back flag is: gene_assemble)
-    Scope sc(c, 1, st);
-    hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, st, d_desc + n_gen, (long long)N);
-  }
   if (burden || dbg) {
     // on the batch's own stream: the collapse overlaps the next batch's sufficient-statistics launches, which
     // leave about half of the HBM bandwidth unused
@@ -1352,16 +1325,18 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                            n_gen, gpg, nd, (long long)N, (long long)ld, d, nc.binary, tests);
     }
     if (n_hc > 0) {
-      // hard-call genes carry their burden sums already; verify what the in-pass collapse assumed (flip prediction,
-      // no counted monomorphic column) and redo the sums of the rare gene where it does not hold
+      // hard-call genes carry their burden sums already; where gene_flags_hc_kernel found the in-pass collapse wrong
+      // (flip prediction, a counted monomorphic column, an imputed value that counts) or handed the gene back, the sums
+      // are redone from the block (a handed-back gene first gets its flags from the general kernel's statistics)
       Scope sc(c, 1, bs);
-      hipLaunchKernelGGL(gene_flags_hc_kernel, dim3(n_hc), dim3(64), 0, bs, d_desc + n_gen, (long long)N);
+      const int* d_lists = reinterpret_cast<const int*>(base + off_lists);
+      hipLaunchKernelGGL(gene_flags_kernel, dim3(n_hc), dim3(64), 0, bs, d_desc + n_gen, (long long)N);
       if (d <= 4)
-        hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs, d_desc + n_gen, nd,
-                           (long long)N, (long long)ld, d, nc.binary);
+        hipLaunchKernelGGL((burden_fallback_kernel<4>), dim3(kFallbackGrid), dim3(256), 0, bs, d_desc + n_gen, d_lists,
+                           n_hc, n_wparts, nd, (long long)N, (long long)ld, d, nc.binary);
       else
-        hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(kFallbackSplit, n_hc), dim3(256), 0, bs,
-                           d_desc + n_gen, nd, (long long)N, (long long)ld, d, nc.binary);
+        hipLaunchKernelGGL((burden_fallback_kernel<kHcMaxD>), dim3(kFallbackGrid), dim3(256), 0, bs, d_desc + n_gen,
+                           d_lists, n_hc, n_wparts, nd, (long long)N, (long long)ld, d, nc.binary);
     }
   }
   const unsigned tests_eff = burden ? tests : (tests & ~(RVT_TEST_CMC | RVT_TEST_ZEGGINI));
@@ -1415,27 +1390,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   c->next_done_flag = nullptr;
   sl.h_results = h_res;
   sl.pending_n = n;
-  sl.rerun.armed = false;
-  if (n_hc > 0 && !dbg) {  // remember the batch: genes the hard-call kernel hands back run again (finish_slot)
-    Slot::Rerun& rr = sl.rerun;
-    rr.dG.assign(dG, dG + n);
-    rr.M.assign(Ms, Ms + n);
-    rr.af.assign(af, af + af_total);
-    rr.af_off.resize(n);
-    size_t o = 0;
-    for (int g = 0; g < n; ++g) {
-      rr.af_off[g] = o;
-      o += (size_t)Ms[g];
-    }
-    rr.ids.resize(n);
-    for (int g = 0; g < n; ++g) rr.ids[g] = ids ? ids[g] : g;
-    rr.predicted = predicted;
-    rr.tests = tests;
-    rr.prm = params;
-    rr.launched_slot = -1;
-    rr.armed = true;
-  }
-  if (c->profiling && !rerun_of) {
+  if (c->profiling) {
     c->timing.genes += n;
     c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
@@ -1446,17 +1401,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   if (dbg) {
     HIP_TRY(c, sync_stream(st));
-    if (n_hc > 0) {  // an inspection call whose block is not the hard-call kernel's: once more on the general kernel
-      bool again = false;
-      for (int g = 0; g < n; ++g) again = again || (h_res[g].status & kStatusRerun);
-      if (again) {
-        sl.pending_out = nullptr;
-        sl.pending_done = nullptr;
-        sl.pending_n = 0;
-        std::vector<signed char> k0((size_t)n, 0);
-        return run_batch(c, n, dG, Ms, af, ids, tests, prm, out, dbg, cov, k0.data(), -1);
-      }
-    }
     const GeneDesc& g0 = desc[0];
     if (dbg->flip) HIP_TRY(c, hipMemcpy(dbg->flip, g0.dbg_flip, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
     if (dbg->kept) HIP_TRY(c, hipMemcpy(dbg->kept, g0.dbg_kept, sizeof(int) * g0.M, hipMemcpyDeviceToHost));
@@ -1466,68 +1410,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   return RVT_OK;
 }
-
-namespace {
-// The finished batch of slot `sl` (its records are in sl.h_results): genes the hard-call kernel handed back are launched
-// again on the general kernel, in a re-run slot, asynchronously; finish_slot(sl) waits for them and patches the records.
-// wait_for_slot: when every re-run slot is busy, finish the older one first (else: leave it for later, return).
-int rerun_launch(rvt_ctx* c, Slot& sl, const rvt_gene_result* h, int n, bool wait_for_slot) {
-  Slot::Rerun& rr = sl.rerun;
-  rr.idx.clear();
-  for (int g = 0; g < n; ++g)
-    if (h[g].status & kStatusRerun) rr.idx.push_back(g);
-  if (rr.idx.empty()) {
-    rr.armed = false;
-    return RVT_OK;
-  }
-  int slot = -1;
-  for (int i = kSlots; i < kSlotsAll; ++i)
-    if (!c->slots[i].pending_out) slot = i;
-  if (slot < 0) {
-    if (!wait_for_slot) return RVT_OK;
-    slot = kSlots;
-    for (int i = kSlots; i < kSlotsAll; ++i)
-      if (c->slots[i].seq < c->slots[slot].seq) slot = i;
-    // its owner (another rotating slot) picks the records up from its own rr.res later: finishing it here is enough
-    int rc = finish_slot(c, c->slots[slot]);
-    if (rc) return rc;
-  }
-  const int k = (int)rr.idx.size();
-  std::vector<const double*> ptr(k);
-  std::vector<int> Ms(k);
-  std::vector<int64_t> ids(k);
-  std::vector<double> af;
-  for (int i = 0; i < k; ++i) {
-    const int g = rr.idx[i];
-    ptr[i] = rr.dG[g];
-    Ms[i] = rr.M[g];
-    ids[i] = rr.ids[g];
-    af.insert(af.end(), rr.af.begin() + rr.af_off[g], rr.af.begin() + rr.af_off[g] + rr.M[g]);
-  }
-  rr.res.assign((size_t)k, rvt_gene_result());
-  int rc = run_batch(c, k, ptr.data(), Ms.data(), af.data(), ids.data(), rr.tests, &rr.prm, rr.res.data(), nullptr, nullptr,
-                     nullptr, slot);
-  if (rc) return rc;
-  rr.launched_slot = slot;
-  return RVT_OK;
-}
-
-// called when a new batch is about to be launched: batches that have finished in the meantime get their re-runs started
-// now, so that they overlap the pipeline instead of stalling the caller when their slot comes up for reuse
-int poll_reruns(rvt_ctx* c) {
-  for (int i = 0; i < kSlots; ++i) {
-    Slot& sl = c->slots[i];
-    if (!sl.pending_out || !sl.rerun.armed || sl.rerun.launched_slot >= 0) continue;
-    if (hipStreamQuery(sl.stream) != hipSuccess) {
-      (void)hipGetLastError();
-      continue;
-    }
-    int rc = rerun_launch(c, sl, sl.h_results, sl.pending_n, false);
-    if (rc) return rc;
-  }
-  return RVT_OK;
-}
-}  // namespace
 
 int rvt_sync(rvt_ctx* c) {
   if (!c) return RVT_E_INVALID;
@@ -1648,6 +1530,11 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
   if (rc) return rc;
   const int d = c->nc.d;
   const size_t psz = (size_t)g0.Mp * g0.Cp;
+  if (g0.hc) {  // handed back by the hard-call kernel: the general kernel's statistics are what the buffers hold
+    unsigned short fl = 0;
+    HIP_TRY(c, hipMemcpy(&fl, g0.flags + 2 * g0.MT + 1, sizeof(fl), hipMemcpyDeviceToHost));
+    if (fl) g0.hc = 0;
+  }
   const int rows = g0.hc ? kHcColstatRows : 3;
   std::vector<double> parts((size_t)g0.n_wparts * psz), cs((size_t)g0.n_wparts * rows * g0.Mp);
   HIP_TRY(c, hipMemcpy(parts.data(), g0.parts, sizeof(double) * parts.size(), hipMemcpyDeviceToHost));
@@ -3838,8 +3725,8 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   int rc = rvt_sync(c);  // processed synchronously
   if (rc) return rc;
   // Which slices START on the hard-call kernel: all of them unless the per-column flags of rvt_block_upload_columns say a
-  // slice holds something else.  The kernel tests what it reads; a slice it hands back (ok = -2) runs again on the fp64
-  // kernel below.
+  // slice holds something else.  The kernel tests what it reads; a slice it hands back is computed by the fp64 kernel in
+  // the same batch (run_batch).
   std::vector<int> colflag;
   bool any_hc = false;
   bool all_hc = block_hard_calls(c, dG, V, &colflag, &any_hc) != 0;
@@ -3883,21 +3770,6 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
     co.pval = pvalue + c0;
     rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
     if (rc) return rc;
-    if (any_hc) {  // slices the hard-call kernel handed back: the chunk once more, those slices on the fp64 kernel
-      bool redo = false;
-      for (int g = 0; g < n; ++g) {
-        bool back = false;
-        for (int j = 0; j < Ms[g]; ++j) back = back || ok[(size_t)c0 + (size_t)g * kSlice + j] == -2;
-        if (back) {
-          shc[g] = 0;
-          redo = true;
-        }
-      }
-      if (redo) {
-        rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
-        if (rc) return rc;
-      }
-    }
   }
   return RVT_OK;
 }

@@ -97,9 +97,10 @@ RVT_HD double skato_rho_value(int i) {
 // kHcRows rows per part (sum of H, min / max over the hard calls, masked count, OR / AND of the masked bit patterns) and
 // the G'DG block of `parts` holds C = (H + 4m)'(H + 4m).  Recovered here, in exact integer arithmetic up to one rounding
 // per product:  P = P' - 4Q,  H'H = C - 4(P + P') - 16 Q,  G'G = H'H + P diag(mu) + diag(mu) P' + diag(mu) Q diag(mu).
-// force_status != 0: the gene is not evaluated (it will be run again on the general kernel): no polymorphic column.
+// extra_status: OR-ed into the gene's status word.
 // ======================================================================================================
-constexpr unsigned kStatusRerun = 0x100u;  // internal: the hard-call kernel found content it does not handle (never returned)
+constexpr unsigned kStatusHandedBack = 0x100u;  // internal bookkeeping (cleared before a record is returned): the gene
+                                                // started on the hard-call kernel and was computed by the fp64 kernel
 
 RVT_HD double rvt_bits_to_double(unsigned long long b) {
   double x;
@@ -117,7 +118,7 @@ constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
                           const double* colstat, const double* bparts, int PB, const double* af,
                           const rvt_params& prm, unsigned tests, GeneScratch ws, GeneStats* out, int* flip_out,
-                          int* kept_out, const HcMasked* hcm = nullptr, unsigned force_status = 0u) {
+                          int* kept_out, const HcMasked* hcm = nullptr, unsigned extra_status = 0u) {
   const int d = nc.d;
   const int ldr = Cp;
   double* R = ws.R;
@@ -251,12 +252,11 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
       if (!mono) kidx[m++] = j;
       if (shf[j] != 0.0) ++nf;
     }
-    if (force_status) m = 0;
     kidx[Mp] = m;  // stash
     out->n_variants = M;
     out->n_poly = m;
     out->flip_count = nf;
-    out->status = ((m == 0) ? RVT_ST_NO_POLY : 0) | force_status;
+    out->status = ((m == 0) ? RVT_ST_NO_POLY : 0) | extra_status;
     out->skato_ok = 0;
     out->skato_single = 0;
     out->skat_nlambda = 0;

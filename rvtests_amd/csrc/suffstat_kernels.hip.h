@@ -91,7 +91,8 @@ template <int MT, int CT, bool WEIGHTED, bool GUARD>
 __device__ __forceinline__ void suffstat_step(const gcdp_t (&colp)[CT], gcdp_t vptr, long long off,
                                               long long nvalid, d4_t (&acc)[MT][CT], double (&cs)[MT],
                                               double (&cmn)[MT], double (&cmx)[MT], double (&f)[CT][4],
-                                              unsigned long long* mask_ge, unsigned long long* mask_le, int lane) {
+                                              unsigned long long* mask_ge, unsigned long long* mask_le, int lane,
+                                              unsigned mask_bytes) {
   // (loads for this step were issued by the caller into f)
   double a[MT][4];
   if (WEIGHTED) {
@@ -145,8 +146,10 @@ __device__ __forceinline__ void suffstat_step(const gcdp_t (&colp)[CT], gcdp_t v
       const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
       return (void*)(((unsigned long long)hi << 32) | lo);
     };
-    const __amdgpu_buffer_rsrc_t rge = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_ge), 0, MT * 32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rle = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_le), 0, MT * 32, 0x00020000);
+    // (mask_bytes = MT * 32, or 0 for a gene without mask planes — a hard-call gene handed back to this kernel, whose
+    // burden sums come from burden_fallback_kernel: every store is then out of range and dropped)
+    const __amdgpu_buffer_rsrc_t rge = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_ge), 0, mask_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rle = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mask_le), 0, mask_bytes, 0x00020000);
     u2_t dge, dle;
     dge[0] = (unsigned)wge;
     dge[1] = (unsigned)(wge >> 32);
@@ -193,9 +196,9 @@ __device__ __forceinline__ void suffstat_load(const gcdp_t (&colp)[CT], long lon
 }
 
 template <int MT, int CT, bool WEIGHTED, int DEPTH>
-__device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev& nd, long long N, long long ld, int d) {
+__device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev& nd, long long N, long long ld, int d,
+                                              int wpart) {
   const int lane = threadIdx.x & 63;
-  const int wpart = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wpart >= gd.n_wparts) return;
   const long long nsteps = ld >> 4;
   const long long s_begin = (long long)wpart * gd.steps_per_wpart;
@@ -234,6 +237,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
   const long long koff = (long long)(lane >> 4) * 4;
   unsigned long long* mge = gd.masks;
   unsigned long long* mle = gd.masks + nsteps * MT * 4;
+  const unsigned mask_bytes = gd.masks ? (unsigned)(MT * 32) : 0u;
   // steps whose 16 samples are all < N need no guard
   const long long full_steps = N >> 4;
   // Register ring of DEPTH step buffers: while step s is multiplied, the loads of the next DEPTH-1 steps are in
@@ -244,7 +248,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
   const long long s_lim = (s_end < full_steps) ? s_end : full_steps;
   auto step = [&](double (&f)[CT][4], long long s) {
     suffstat_step<MT, CT, WEIGHTED, false>(colp, vglob, s * 16 + koff, 4, acc, cs, cmn, cmx, f, mge + s * MT * 4,
-                                           mle + s * MT * 4, lane);
+                                           mle + s * MT * 4, lane, mask_bytes);
   };
   auto load = [&](double (&f)[CT][4], long long s) {
     const long long sc = (s < s_lim) ? s : s_lim - 1;  // clamp: a redundant reload near the end, never out of range
@@ -283,7 +287,7 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
     const long long sg = full_steps, off = sg * 16 + koff;
     suffstat_load<CT>(colp, off, fg);
     suffstat_step<MT, CT, WEIGHTED, true>(colp, vglob, off, N - off, acc, cs, cmn, cmx, fg, mge + sg * MT * 4,
-                                          mle + sg * MT * 4, lane);
+                                          mle + sg * MT * 4, lane, mask_bytes);
   }
   // ---- write this wave's partial tiles: element (row, col) -> parts[row*Cp + col] --------------------
   double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
@@ -330,47 +334,65 @@ __device__ __forceinline__ void suffstat_body(const GeneDesc& gd, const NullDev&
 // the kernel is the largest of its group.  Grid = (wave-parts, genes of the group), one wave per workgroup.
 template <int MT, int CT, bool WEIGHTED>
 __device__ __forceinline__ void suffstat_class(const GeneDesc& gd, const NullDev& nd, long long N, long long ld,
-                                               int d) {
+                                               int d, int wpart) {
   // ring depth: 3 wherever the registers allow it without dropping an occupancy step (see tools/kernel_regs.sh)
   constexpr int kDepth = (CT <= 3)         ? 3
                          : (MT * CT <= 16) ? (WEIGHTED ? 2 : 3)
                          : (MT * CT <= 20) ? 2   // (4,5): fits 256 registers, two waves per SIMD
                          : (CT <= 5)       ? 3
                                            : 2;
-  suffstat_body<MT, CT, WEIGHTED, kDepth>(gd, nd, N, ld, d);
+  suffstat_body<MT, CT, WEIGHTED, kDepth>(gd, nd, N, ld, d, wpart);
 }
 
 __host__ __device__ constexpr int suffstat_group(int MT, int CT, bool weighted) {
   return (MT * CT > 20) ? 2 : ((MT * CT <= 4 && !(weighted && MT == 2)) ? 0 : 1);
 }
 
+// Two ways to launch it:
+//   list == nullptr   grid (wave-parts, genes): workgroup (x, y) computes wave-part x of genes[y];
+//   list != nullptr   a WORK LIST written on the device (gene_flags_hc_kernel): list[0] = number of genes the hard-call
+//                     kernel handed back, list[4 ..] = their indices into `genes`; any grid — the workgroups loop over
+//                     the (gene, wave-part) items, and leave at once when the list is empty (the usual case).
 template <int GROUP, bool WEIGHTED>
 __global__ __launch_bounds__(64, GROUP == 0 ? 4 : (GROUP == 1 ? 2 : 1)) void gene_suffstat_mfma(
-    const GeneDesc* __restrict__ genes, NullDev nd, long long N, long long ld, int d) {
-  const GeneDesc gd = genes[blockIdx.y];
-  const int cls = gd.MT * 8 + gd.CT;
+    const GeneDesc* __restrict__ genes, const int* __restrict__ list, int n_wparts, NullDev nd, long long N,
+    long long ld, int d) {
+  long long item = (long long)blockIdx.x + (long long)blockIdx.y * gridDim.x;
+  const long long stride = (long long)gridDim.x * gridDim.y;
+  const long long n_items = list ? (long long)list[0] * n_wparts : 0;
+  do {
+    int gi = blockIdx.y, wpart = blockIdx.x;
+    if (list) {
+      if (item >= n_items) return;
+      gi = list[4 + (int)(item / n_wparts)];
+      wpart = (int)(item % n_wparts);
+    }
+    const GeneDesc gd = genes[gi];
+    const int cls = gd.MT * 8 + gd.CT;
 #define RVT_CLASS(mt, ct)                                                \
   case mt * 8 + ct:                                                      \
     if constexpr (suffstat_group(mt, ct, WEIGHTED) == GROUP)             \
-      suffstat_class<mt, ct, WEIGHTED>(gd, nd, N, ld, d);                \
+      suffstat_class<mt, ct, WEIGHTED>(gd, nd, N, ld, d, wpart);         \
     break
-  switch (cls) {
-    RVT_CLASS(1, 1);
-    RVT_CLASS(1, 2);
-    RVT_CLASS(2, 2);
-    RVT_CLASS(2, 3);
-    RVT_CLASS(3, 3);
-    RVT_CLASS(3, 4);
-    RVT_CLASS(4, 4);
-    RVT_CLASS(4, 5);
-    RVT_CLASS(5, 5);
-    RVT_CLASS(5, 6);
-    RVT_CLASS(6, 6);
-    RVT_CLASS(6, 7);
-    default:
-      break;
-  }
+    switch (cls) {
+      RVT_CLASS(1, 1);
+      RVT_CLASS(1, 2);
+      RVT_CLASS(2, 2);
+      RVT_CLASS(2, 3);
+      RVT_CLASS(3, 3);
+      RVT_CLASS(3, 4);
+      RVT_CLASS(4, 4);
+      RVT_CLASS(4, 5);
+      RVT_CLASS(5, 5);
+      RVT_CLASS(5, 6);
+      RVT_CLASS(6, 6);
+      RVT_CLASS(6, 7);
+      default:
+        break;
+    }
 #undef RVT_CLASS
+    item += stride;
+  } while (list);
 }
 
 // ---- genes wider than 6 row tiles (M > 96): the tile grid is cut into panels of up to 4 x 4 tiles -----------
@@ -431,6 +453,7 @@ __global__ __launch_bounds__(256) void gene_suffstat_panel(const GeneDesc* __res
   const long long koff = (long long)(lane >> 4) * 4;
   unsigned long long* mge = gd.masks;
   unsigned long long* mle = gd.masks + nsteps * MT * 4;
+  const unsigned mask_bytes = gd.masks ? (unsigned)(MT * 32) : 0u;
   const int nrow = (MT - r0 < 4) ? MT - r0 : 4;  // row tiles of this panel that exist
   for (long long s = s_begin; s < s_end; ++s) {
     const long long off = s * 16 + koff;

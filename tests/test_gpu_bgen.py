@@ -109,8 +109,10 @@ def test_submit_gene_bgen_equals_raw_handoff(eng):
     assert [r.gene_id for r in got] == list(range(6))
     for a, b in zip(got, want):
         assert a.n_poly == b.n_poly and a.status == b.status
-        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p"):
+        for f in ("skat_Q", "skat_p", "skato_p"):
             assert getattr(a, f) == getattr(b, f), f
+        for f in ("cmc_p", "zeg_p"):  # (handed-back raw doubles: burden sums in burden_fallback_kernel's order)
+            assert abs(getattr(a, f) - getattr(b, f)) <= 1e-12 * abs(getattr(b, f)) + 1e-7 * (getattr(b, f) > 0.999), f
     # the counter frequencies (GenotypeCounter on dosages) against the oracle's consolidation
     blocks, layout = genes[0]
     raw = _oracle_matrix(blocks, layout, N)

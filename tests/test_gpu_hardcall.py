@@ -307,8 +307,9 @@ def test_content_hint_only_chooses_the_starting_kernel(engine):
         engine.set_content_hint(0)
         b, seen = run(pd, dos)
         assert seen == (0, 0)
-        for x, y_ in zip(a, b):
-            assert all(getattr(x, f) == getattr(y_, f) for f in FIELDS)
+        for x, y_ in zip(a, b):      # same fp64 statistics; the burden sums take another summation order
+            assert all(getattr(x, f) == getattr(y_, f) for f in FIELDS if not f.startswith(("cmc", "zeg")))
+            assert all(abs(getattr(x, f) - getattr(y_, f)) <= 1e-12 * abs(getattr(y_, f)) for f in FIELDS)
         h0, seen = run(ph, hard)                      # hard calls under the "dosages" hint: fp64 kernel, still right
         assert seen == (0, 0)
         engine.set_content_hint(-1)

@@ -185,8 +185,12 @@ def test_submit_gene_vcf_dosage_equals_raw_hand_off(eng):
     af_r = eng.submit_gene_raw(0, Graw)
     rec_r = eng.collect()[0]
     assert (af_v == af_r).all()
-    for f in ("status", "n_poly", "skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p"):
+    # (the raw doubles start on the hard-call kernel and are handed back: same fp64 sufficient statistics, but the burden
+    # sums come from burden_fallback_kernel instead of the mask planes — another summation order)
+    for f in ("status", "n_poly", "skat_Q", "skat_p", "skato_Q", "skato_p"):
         assert getattr(rec_v, f) == getattr(rec_r, f), f
+    for f in ("cmc_p", "zeg_p"):
+        assert abs(getattr(rec_v, f) - getattr(rec_r, f)) <= 1e-12 * abs(getattr(rec_r, f)), f
 
 
 def test_multi_allelic_mode_counts_the_requested_allele(eng):
