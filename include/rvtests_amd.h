@@ -79,6 +79,9 @@ extern "C" {
 #define RVT_ST_SKATO_EIGEN 2u  /* SkatO::Fit returned -1 (no positive eigenvalue)  SkatO.cpp:170-175 */
 #define RVT_ST_CMC_FAIL 4u
 #define RVT_ST_ZEG_FAIL 8u
+#define RVT_ST_INPUT_ERROR 16u /* streaming VCF-text / BGEN submission: a record of THIS gene was malformed (wrong column
+                                  count, inexact dosage, truncated block); every test is NA, rvt_last_error names the
+                                  record.  With af_out != NULL the submit call itself returns RVT_E_INVALID instead. */
 
 typedef struct rvt_ctx rvt_ctx;
 
@@ -464,7 +467,9 @@ int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned cha
  *   rvt_submit_gene_vcf per record j: sample_text[j] = first byte of the first sample column, text_len[j] = bytes up to
  *                       (not including) the end of line, gt_index[j] (and gd_index / gq_index, may be NULL) from
  *                       rvt_vcf_locate.  The text is consumed before the call returns.  A record whose column count
- *                       differs from the file's sample count is reported by a later submit / collect (RVT_E_INVALID). */
+ *                       differs from the file's sample count voids THIS gene: with af_out the call returns
+ *                       RVT_E_INVALID, without it the gene's record comes back with RVT_ST_INPUT_ERROR (every test NA)
+ *                       and rvt_last_error names the record.  Other genes are unaffected. */
 int rvt_vcf_locate(const char* line, int64_t len, int64_t* sample_off, int* gt_index, int* gd_index, int* gq_index);
 int rvt_vcf_set_samples(rvt_ctx* ctx, int n_file_samples, const int32_t* row_of_sample);
 int rvt_vcf_set_filters(rvt_ctx* ctx, int gd_min, int gd_max, int gq_min, int gq_max);

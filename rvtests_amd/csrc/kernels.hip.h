@@ -979,7 +979,8 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
 }
 
 // ---- MetaCov for windows wider than one block: heads x window rectangle from two plain GEMMs ------------------
-// S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from rocBLAS; cs = raw column sums
+// S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from the integer-plane products of
+// rot_gemm.hip.h (gemm_tn_planes; exact for hard calls and an unweighted model); cs = raw column sums
 // of the W window columns (the H heads are its first H columns).  Unrelated samples only.
 __global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
                                    double* __restrict__ xz) {

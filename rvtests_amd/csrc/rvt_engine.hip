@@ -178,8 +178,11 @@ struct rvt_ctx {
   BgenRecord* d_bgen_rec = nullptr;
   long long* d_bgen_seg = nullptr;
   size_t bgen_seg_cap = 0;
-  int* h_bgen_err = nullptr;   // pinned, device-visible: variant index + 1 of a block shorter than its ploidy bytes demand
-  int* h_vcf_err = nullptr;    // pinned, device-visible: record index + 1 of a record with a wrong column count
+  // pinned, device-visible input-error words of the VCF / BGEN decoders: record index + 1 of a record with a wrong column
+  // count (negative: a dosage the device cannot round exactly) resp. variant index + 1 of a block shorter than its ploidy
+  // bytes demand.  One word per allele-frequency ring slot (the streaming submissions: read when the gene's frequencies
+  // are resolved, so the error lands on the gene that caused it) + word kAfSlots for the synchronous calls.
+  int* h_io_err = nullptr;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
   uint32_t rand_state[31];
   int64_t jump_N = -1;                 // J = A^(jump_N - 1) is cached for this sample count
@@ -225,6 +228,8 @@ struct rvt_ctx {
     rvt_gene_result res;  // filled by the batch this gene was launched in (the queue is a deque: stable addresses)
     bool launched;
     int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
+    int io_error = 0;     // != 0: the gene's VCF text / BGEN blocks were malformed (h_io_err): its record is void
+    int decoded = 0;      // 1: VCF text, 2: BGEN blocks (the submission has an input-error word in its ring slot)
     int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages, -1 unknown
   };
   std::deque<Pending> queue;
@@ -648,12 +653,11 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_vcf_rec) hipFree(c->d_vcf_rec);
   if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
-  if (c->h_vcf_err) hipHostFree(c->h_vcf_err);
+  if (c->h_io_err) hipHostFree(c->h_io_err);
   if (c->d_vcf_sex) hipFree(c->d_vcf_sex);
   if (c->d_fam_list) hipFree(c->d_fam_list);
   if (c->d_bgen_rec) hipFree(c->d_bgen_rec);
   if (c->d_bgen_seg) hipFree(c->d_bgen_seg);
-  if (c->h_bgen_err) hipHostFree(c->h_bgen_err);
   if (c->d_Uq) hipFree(c->d_Uq);
   if (c->d_uq_range) hipFree(c->d_uq_range);
   for (void* q : {(void*)c->d_csc_ptr, (void*)c->d_csc_rows, (void*)c->d_csc_vals})
@@ -1683,6 +1687,13 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     float* d_tmp = nullptr;
     double* d_tmp64 = nullptr;
     int* d_flag = nullptr;
+    struct TmpGuard {  // (every early return below leaves through HIP_TRY)
+      void** p[4];
+      ~TmpGuard() {
+        for (void** q : p)
+          if (*q) hipFree(*q);
+      }
+    } tmp_guard{{(void**)&d_tmp, (void**)&d_tmp64, (void**)&d_flag, (void**)&d_cnt}};
     HIP_TRY(c, hipMalloc((void**)&d_span, sizeof(int) * 2 * (size_t)N));
     HIP_TRY(c, hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)cols_per));
     HIP_TRY(c, hipMalloc((void**)&c->d_csc_ptr, sizeof(long long) * (size_t)(N + 1)));
@@ -1725,10 +1736,6 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
     }
     int bad = 0;
     HIP_TRY(c, hipMemcpy(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost));
-    hipFree(d_tmp);
-    hipFree(d_tmp64);
-    hipFree(d_flag);
-    hipFree(d_cnt);
     if (!csc_ok)
       for (void** q : {(void**)&c->d_csc_ptr, (void**)&c->d_csc_rows, (void**)&c->d_csc_vals}) {
         if (*q) hipFree(*q);
@@ -1804,8 +1811,11 @@ int rvt_set_kinship(rvt_ctx* c, int64_t N, const float* U, const float* S) {
       }
     } else if (c->d_csc_ptr) {
       // sparse eigenvectors whose supports are scattered over the samples (families interleaved in the sample order):
-      // the rotation gathers (rot_sparse_kernel); eigenpairs stay in the caller's order
+      // the rotation gathers (rot_sparse_kernel); eigenpairs stay in the caller's order.  The digit planes (6 N^2 bytes)
+      // are never read in this mode: give them back.
       c->uq_visit = (double)csc_ptr[N] / ((double)N * (double)N);
+      hipFree(c->d_Uq);
+      c->d_Uq = nullptr;
     }
   }
   HIP_TRY(c, hipMemcpy(c->d_S, c->h_S.data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -1930,6 +1940,9 @@ static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K,
     }
   }
   if ((int64_t)pairs.size() != N) return fail(c, RVT_E_STATE, "family-wise decomposition lost eigenpairs");
+  // the 30 cyclic sweeps of jac_small_eig_kernel converge for every family tile seen so far; should one not have, the
+  // dense iteration (which checks its own convergence and residuals) takes the matrix instead
+  if (worst > 1e-9 * mu) return RVT_OK;  // (*done stays false)
   std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.lam < y.lam; });  // ascending
   std::vector<float> S((size_t)N);
   std::vector<int> meta(3 * (size_t)N + nt * (size_t)kJacP, 0);  // tile | column | length per eigenpair, rows per tile
@@ -2000,11 +2013,16 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
           for (int64_t i = 0; i < N; ++i) {
             if (!std::isfinite(col[i])) bad[t] = 1;
             rows[i] += std::fabs((double)col[i]);
-            if (col[i] != 0.0f && i > j && !dense_here) {  // (the lower triangle is enough: K is symmetric)
-              if (ed.size() >= cap)
-                dense_here = true;
-              else
-                ed.emplace_back((int)j, (int)i);
+            if (col[i] != 0.0f && i != j && !dense_here) {
+              // edges come from the lower triangle; every off-diagonal non-zero of either triangle must have its mirror
+              // image (an asymmetric matrix would silently lose cross-family entries otherwise)
+              if (col[i] != K[(size_t)i * N + j]) bad[t] |= 4;
+              if (i > j) {
+                if (ed.size() >= cap)
+                  dense_here = true;
+                else
+                  ed.emplace_back((int)j, (int)i);
+              }
             }
           }
         }
@@ -2013,6 +2031,7 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
     for (auto& th : pool) th.join();
     for (int t = 0; t < nthr; ++t) {
       if (bad[t] & 1) return fail(c, RVT_E_INVALID, "kinship matrix holds a non-finite entry");
+      if (bad[t] & 4) return fail(c, RVT_E_INVALID, "kinship matrix is not symmetric");
       if (bad[t] & 2) sparse_pattern = false;
     }
     for (int64_t i = 0; i < N; ++i) {
@@ -2282,10 +2301,13 @@ static int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int n
                           hipStream_t st) {
   const int64_t N = c->kin_N;
   if (c->d_csc_ptr && !c->d_uq_range) {  // sparse U, scattered supports: a gather per output (fp64 products and sums)
-    hipLaunchKernelGGL(rot_sparse_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)ncols), dim3(256), 0, st,
-                       c->d_csc_ptr, c->d_csc_rows, c->d_csc_vals, (long long)N, d_src, (long long)ld_src, d_dst,
-                       (long long)ld_dst);
-    HIP_TRY(c, hipGetLastError());
+    for (int c0 = 0; c0 < ncols; c0 += 65535) {  // (gridDim.y holds at most 65535 columns)
+      const int nc = std::min(65535, ncols - c0);
+      hipLaunchKernelGGL(rot_sparse_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, st,
+                         c->d_csc_ptr, c->d_csc_rows, c->d_csc_vals, (long long)N, d_src + (size_t)c0 * ld_src,
+                         (long long)ld_src, d_dst + (size_t)c0 * ld_dst, (long long)ld_dst);
+      HIP_TRY(c, hipGetLastError());
+    }
     return RVT_OK;
   }
   for (int c0 = 0; c0 < ncols; c0 += kRotMaxCols) {  // long lists in pieces
@@ -3006,9 +3028,14 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
   // column scan, no separate quantiser pass)
   const bool direct = !burden && all_hard && c->hc_enabled && !(c->d_csc_ptr && !c->d_uq_range) &&
                       !getenv("RVT_FAM_NO_DIRECT");
-  if (!direct)
-    hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)T), dim3(256), 0, st, d_cols + tot, d_flags + tot,
-                       (long long)N, (long long)ld, c->d_Gp);
+  if (!direct) {
+    for (size_t t0 = 0; t0 < T; t0 += 65535) {  // (gridDim.y holds at most 65535 columns)
+      const unsigned nt = (unsigned)std::min<size_t>(65535, T - t0);
+      hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, nt), dim3(256), 0, st, d_cols + tot + t0, d_flags + tot + t0,
+                         (long long)N, (long long)ld, c->d_Gp + t0 * (size_t)ld);
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
   int* d_koff = nullptr;
   double* d_bcs = nullptr;
   int* d_bpoly = nullptr;
@@ -4091,6 +4118,10 @@ int resolve_af(rvt_ctx* c) {
     if (p.af_slot >= 0) {
       const double* h = c->h_af_ring + (size_t)p.af_slot * RVT_MAX_VARIANTS;
       p.af.assign(h, h + p.M);
+      if (p.decoded && c->h_io_err && c->h_io_err[p.af_slot]) {  // malformed VCF text / BGEN block of THIS gene
+        p.io_error = c->h_io_err[p.af_slot];
+        c->h_io_err[p.af_slot] = 0;
+      }
       p.af_slot = -1;
     }
   }
@@ -4186,6 +4217,23 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
 }  // namespace
 
 namespace {
+int io_err_ready(rvt_ctx* c) {
+  if (c->h_io_err) return RVT_OK;
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_io_err, sizeof(int) * (rvt_ctx::kAfSlots + 1), hipHostMallocMapped));
+  std::memset(c->h_io_err, 0, sizeof(int) * (rvt_ctx::kAfSlots + 1));
+  return RVT_OK;
+}
+void io_err_message(rvt_ctx* c, int k, bool bgen, const char* whose) {
+  if (bgen)
+    fail(c, RVT_E_INVALID, "BGEN variant %d%s: the block is shorter than its ploidy bytes demand (or a ploidy exceeds the "
+         "declared maximum)", k - 1, whose);
+  else if (k < 0)
+    fail(c, RVT_E_INVALID, "VCF record %d%s holds a dosage the device cannot round exactly (more than 15 digits, "
+         "|exponent| > 22, inf / nan / hex)", -k - 1, whose);
+  else
+    fail(c, RVT_E_INVALID, "VCF record %d%s does not hold %d sample columns", k - 1, whose, c->vcf_n_file);
+}
+
 // mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto);
 // 3: PLINK 2-bit codes (ditto)
 // VCF text of one gene -> N x M signed bytes in c->d_consol_i8 (vcf_kernels.hip.h), on stream st
@@ -4196,7 +4244,7 @@ struct VcfGene {
   const int* gd_idx;        // may be NULL (-1)
   const int* gq_idx;        // may be NULL (-1)
 };
-int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t st, double* dosage_out = nullptr,
+int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t st, int err_slot, double* dosage_out = nullptr,
                     int64_t dosage_ld = 0) {
   std::vector<VcfRecord> rec(M);
   size_t total = 0;
@@ -4229,9 +4277,9 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     HIP_TRY(c, hipMalloc((void**)&c->d_vcf_seg, sizeof(int) * want));
     c->vcf_seg_cap = want;
   }
-  if (!c->h_vcf_err) {
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_vcf_err, sizeof(int), hipHostMallocMapped));
-    *c->h_vcf_err = 0;
+  {
+    int rce = io_err_ready(c);
+    if (rce) return rce;
   }
   c->vcf_alt.clear();  // (one call only)
   c->vcf_hemi.clear();
@@ -4241,7 +4289,8 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
   HIP_TRY(c, hipMemcpyAsync(c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M, hipMemcpyHostToDevice, st));
   HIP_TRY(c, sync_stream(st));  // `rec` is a local
   int* d_err = nullptr;
-  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_vcf_err, 0));
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_io_err, 0));
+  d_err += err_slot;
   const dim3 grid((unsigned)max_seg, (unsigned)M);
   hipLaunchKernelGGL(vcf_tab_count_kernel, grid, dim3(256), 0, st, c->d_vcf_text, c->d_vcf_rec, max_seg, c->d_vcf_seg);
   hipLaunchKernelGGL(vcf_tab_scan_kernel, dim3((unsigned)M), dim3(256), 0, st, c->d_vcf_rec, max_seg, c->vcf_n_file,
@@ -4268,7 +4317,8 @@ struct BgenGene {
   const int64_t* len;
   int layout;                         // 1 (v1.1) or 2 (v1.2 / v1.3)
 };
-int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream_t st, double* out, int64_t ld) {
+int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream_t st, int err_slot, double* out,
+                     int64_t ld) {
   const int64_t n_file = c->d_vcf_rows ? c->vcf_n_file : N;
   std::vector<BgenRecord> rec(M);
   size_t total = 0;
@@ -4313,6 +4363,33 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
         if (cmb > 16777216.0)
           return fail(c, RVT_E_TOO_LARGE, "BGEN variant %d: ploidy %d with %d alleles is not supported", j, zmax, (int)K);
       }
+      // The packed values every sample's ploidy byte demands must lie inside the block: the decode kernels index them from
+      // those bytes alone (as the reference's BitReader would read on, libBgen/BitReader.h), so a truncated or corrupt
+      // block is refused HERE, before anything is enqueued (one pass over the N ploidy bytes of the variant).
+      {
+        auto choose = [](int n, int m) {  // BGenFile::choose (libBgen/BGenFile.cpp:438-453), int arithmetic
+          if (m == 1) return n;
+          if (n == 1) return 1;
+          int ret = 1;
+          for (int i = 0; i < m; ++i) ret *= (n - i);
+          for (int i = 0; i < m; ++i) ret /= (i + 1);
+          return ret;
+        };
+        int per_z[64];
+        for (int z = 0; z < 64; ++z) per_z[z] = r.phased ? z * ((int)K - 1) : (z == 0 ? 0 : choose(z + (int)K - 1, (int)K - 1) - 1);
+        unsigned long long values = 0;
+        int worst = 0;
+        const unsigned char* pm = b + 8;
+        for (int64_t i = 0; i < n_file; ++i) {
+          const int z = pm[i] & 0x3f;
+          values += (unsigned long long)per_z[z];
+          worst = z > worst ? z : worst;
+        }
+        const unsigned long long have_bits = (unsigned long long)(len - (10 + n_file)) * 8ull;
+        if (worst > zmax || values * (unsigned long long)B > have_bits)
+          return fail(c, RVT_E_INVALID, "BGEN variant %d: the block is shorter than its ploidy bytes demand (or a ploidy "
+                      "exceeds the declared maximum)", j);
+      }
       pad = (size_t)((4 - (10 + n_file) % 4) % 4);  // the packed values start on a 4-byte boundary
     }
     total = (total + 15) / 16 * 16 + pad;
@@ -4338,9 +4415,9 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
     HIP_TRY(c, hipMalloc((void**)&c->d_bgen_seg, sizeof(long long) * want));
     c->bgen_seg_cap = want;
   }
-  if (!c->h_bgen_err) {
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_bgen_err, sizeof(int), hipHostMallocMapped));
-    *c->h_bgen_err = 0;
+  {
+    int rce = io_err_ready(c);
+    if (rce) return rce;
   }
   for (int j = 0; j < M; ++j) {  // the bytes behind a block read as zero (BitReader stops at its end)
     HIP_TRY(c, hipMemsetAsync(c->d_vcf_text + rec[j].off + bg->len[j], 0, 16, st));
@@ -4349,7 +4426,8 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
   HIP_TRY(c, hipMemcpyAsync(c->d_bgen_rec, rec.data(), sizeof(BgenRecord) * M, hipMemcpyHostToDevice, st));
   HIP_TRY(c, sync_stream(st));  // `rec` is a local
   int* d_err = nullptr;
-  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_bgen_err, 0));
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_io_err, 0));
+  d_err += err_slot;
   const unsigned char* data = reinterpret_cast<const unsigned char*>(c->d_vcf_text);
   const dim3 grid((unsigned)max_seg, (unsigned)M);
   if (bg->layout == 2) {
@@ -4397,6 +4475,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
   // (dosage text, BGEN), or whatever the caller's doubles are
   p.kind = (mode == 2 || mode == 3 || mode == 4) ? 1 : ((mode == 5 || mode == 6) ? 0 : -1);
+  p.decoded = (mode == 4 || mode == 5) ? 1 : (mode == 6 ? 2 : 0);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
     if (rc) {
@@ -4431,12 +4510,33 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     }
     double* d_fill = c->d_consol_af + RVT_MAX_VARIANTS;
     const dim3 cgrid((unsigned)nparts, (unsigned)M);
+    // where this gene's allele frequencies (and, for VCF text / BGEN blocks, its input-error word) come back: through a
+    // ring slot when nobody waits for them, through the synchronous word otherwise
+    int ring_slot = -1;
+    if (!af_out && e == hipSuccess) {
+      if (!c->d_af_ring) {
+        e = hipMalloc((void**)&c->d_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS);
+        if (e == hipSuccess)
+          e = hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS,
+                            hipHostMallocDefault);
+      }
+      if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
+      if (e == hipSuccess) ring_slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+    }
+    const int err_slot = ring_slot >= 0 ? ring_slot : rvt_ctx::kAfSlots;
+    const bool decodes = mode == 4 || mode == 5 || mode == 6;
+    if (decodes && e == hipSuccess) {
+      if (io_err_ready(c) != RVT_OK)
+        e = hipErrorUnknown;
+      else
+        c->h_io_err[err_slot] = 0;  // (the slot's previous user has been resolved; nothing on the device refers to it)
+    }
     if (e != hipSuccess) {
       // fall through to the error return below
     } else if (mode == 1 || mode == 5 || mode == 6) {
       int rc = mode == 1   ? upload_block_data(c, p.dG, M, (const double*)G)
-               : mode == 5 ? vcf_decode_gene(c, (const VcfGene*)G, M, N, st, p.dG, ld)  // VCF dosage text -> doubles
-                           : bgen_decode_gene(c, (const BgenGene*)G, M, N, st, p.dG, ld);  // BGEN blocks -> doubles
+               : mode == 5 ? vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot, p.dG, ld)  // VCF dosage text -> doubles
+                           : bgen_decode_gene(c, (const BgenGene*)G, M, N, st, err_slot, p.dG, ld);  // BGEN blocks -> doubles
       if (rc) {
         give_back();
         return rc;
@@ -4460,7 +4560,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
       }
       if (e == hipSuccess && mode == 4) {
-        if (vcf_decode_gene(c, (const VcfGene*)G, M, N, st) != RVT_OK) e = hipErrorUnknown;
+        if (vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot) != RVT_OK) e = hipErrorUnknown;
       } else if (e == hipSuccess) {
         e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
       }
@@ -4487,18 +4587,17 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     if (af_out) {
       if (e == hipSuccess) e = hipMemcpyAsync(p.af.data(), c->d_consol_af, afb, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = sync_stream(st);
+      if (e == hipSuccess && decodes && c->h_io_err[err_slot]) {  // malformed text / block: this very gene is refused
+        io_err_message(c, c->h_io_err[err_slot], mode == 6, "");
+        c->h_io_err[err_slot] = 0;
+        give_back();
+        return RVT_E_INVALID;
+      }
     } else if (e == hipSuccess) {
       // nobody waits for the frequencies: the host copy of the block is already consumed (a copy from pageable memory
       // returns once the source has been read), so return now and pick the frequencies up at launch time
-      if (!c->d_af_ring) {
-        e = hipMalloc((void**)&c->d_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS);
-        if (e == hipSuccess)
-          e = hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS,
-                            hipHostMallocDefault);
-      }
-      if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
-      if (e == hipSuccess) {
-        const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+      {
+        const int slot = ring_slot;
         double* d_slot = c->d_af_ring + (size_t)slot * RVT_MAX_VARIANTS;
         e = hipMemcpyAsync(d_slot, c->d_consol_af, afb, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess)
@@ -4619,14 +4718,6 @@ int rvt_submit_gene_vcf(rvt_ctx* c, int64_t gene_id, int M, const char* const* s
                 (long long)c->vcf_n_rows, (long long)c->nc.N);
   for (int j = 0; j < M; ++j)
     if (!sample_text[j] || text_len[j] < 0) return fail(c, RVT_E_INVALID, "record %d: no text", j);
-  if (c->h_vcf_err && *c->h_vcf_err) {
-    const int k = *c->h_vcf_err;
-    *c->h_vcf_err = 0;
-    if (k < 0)
-      return fail(c, RVT_E_INVALID, "VCF record %d of an earlier gene holds a dosage the device cannot round exactly "
-                  "(more than 15 digits, |exponent| > 22, inf / nan / hex)", -k - 1);
-    return fail(c, RVT_E_INVALID, "VCF record %d of an earlier gene does not hold %d sample columns", k - 1, c->vcf_n_file);
-  }
   VcfGene vg{sample_text, text_len, gt_index, gd_index, gq_index};
   return submit_common(c, gene_id, M, &vg, c->vcf_dosage ? 5 : 4, nullptr, af_out, tests, prm);
 }
@@ -4650,14 +4741,17 @@ int rvt_vcf_decode(rvt_ctx* c, int M, const char* const* sample_text, const int6
     c->consol_i8_cap = bytes8 + bytes8 / 4;
   }
   VcfGene vg{sample_text, text_len, gt_index, gd_index, gq_index};
-  int rc = vcf_decode_gene(c, &vg, M, N, st);
+  int rc = io_err_ready(c);
+  if (rc) return rc;
+  c->h_io_err[rvt_ctx::kAfSlots] = 0;
+  rc = vcf_decode_gene(c, &vg, M, N, st, rvt_ctx::kAfSlots);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(out, c->d_consol_i8, bytes8, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
-  if (*c->h_vcf_err) {
-    const int k = *c->h_vcf_err;
-    *c->h_vcf_err = 0;
-    return fail(c, RVT_E_INVALID, "VCF record %d does not hold %d sample columns", k - 1, c->vcf_n_file);
+  if (const int k = c->h_io_err[rvt_ctx::kAfSlots]) {
+    c->h_io_err[rvt_ctx::kAfSlots] = 0;
+    io_err_message(c, k, false, "");
+    return RVT_E_INVALID;
   }
   return RVT_OK;
 }
@@ -4667,11 +4761,6 @@ static int bgen_check(rvt_ctx* c, int M, const unsigned char* const* block, cons
     return fail(c, RVT_E_INVALID, "bad arguments");
   for (int j = 0; j < M; ++j)
     if (!block[j] || len[j] < 0) return fail(c, RVT_E_INVALID, "variant %d: no block", j);
-  if (c->h_bgen_err && *c->h_bgen_err) {
-    const int k = *c->h_bgen_err;
-    *c->h_bgen_err = 0;
-    return fail(c, RVT_E_INVALID, "BGEN variant %d of an earlier gene: the block is shorter than its ploidy bytes demand (or a ploidy exceeds the declared maximum)", k - 1);
-  }
   return RVT_OK;
 }
 
@@ -4701,17 +4790,21 @@ int rvt_bgen_decode(rvt_ctx* c, int M, const unsigned char* const* block, const 
   double* d_out = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)n_rows * M));
   BgenGene bg{block, block_len, layout};
-  rc = bgen_decode_gene(c, &bg, M, n_rows, st, d_out, n_rows);
+  rc = io_err_ready(c);
+  if (!rc) {
+    c->h_io_err[rvt_ctx::kAfSlots] = 0;
+    rc = bgen_decode_gene(c, &bg, M, n_rows, st, rvt_ctx::kAfSlots, d_out, n_rows);
+  }
   hipError_t e = hipSuccess;
   if (!rc) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_rows * M, hipMemcpyDeviceToHost, st);
   if (!rc && e == hipSuccess) e = sync_stream(st);
   hipFree(d_out);
   if (rc) return rc;
   if (e != hipSuccess) return fail(c, RVT_E_HIP, "BGEN decode failed: %s", hipGetErrorString(e));
-  if (*c->h_bgen_err) {
-    const int k = *c->h_bgen_err;
-    *c->h_bgen_err = 0;
-    return fail(c, RVT_E_INVALID, "BGEN variant %d: the block is shorter than its ploidy bytes demand (or a ploidy exceeds the declared maximum)", k - 1);
+  if (const int k = c->h_io_err[rvt_ctx::kAfSlots]) {
+    c->h_io_err[rvt_ctx::kAfSlots] = 0;
+    io_err_message(c, k, true, "");
+    return RVT_E_INVALID;
   }
   return RVT_OK;
 }
@@ -4805,17 +4898,20 @@ int rvt_vcf_decode_dosage(rvt_ctx* c, int M, const char* const* sample_text, con
   double* d_out = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)N * M));
   VcfGene vg{sample_text, text_len, tag_index, gd_index, gq_index};
-  int rc = vcf_decode_gene(c, &vg, M, N, st, d_out, N);
+  int rc = io_err_ready(c);
+  if (!rc) {
+    c->h_io_err[rvt_ctx::kAfSlots] = 0;
+    rc = vcf_decode_gene(c, &vg, M, N, st, rvt_ctx::kAfSlots, d_out, N);
+  }
   hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)N * M, hipMemcpyDeviceToHost, st);
   if (!rc && e == hipSuccess) e = sync_stream(st);
   hipFree(d_out);
   if (rc) return rc;
   HIP_TRY(c, e);
-  if (*c->h_vcf_err) {
-    const int k = *c->h_vcf_err;
-    *c->h_vcf_err = 0;
-    if (k < 0) return fail(c, RVT_E_INVALID, "VCF record %d holds a dosage the device cannot round exactly", -k - 1);
-    return fail(c, RVT_E_INVALID, "VCF record %d does not hold %d sample columns", k - 1, c->vcf_n_file);
+  if (const int k = c->h_io_err[rvt_ctx::kAfSlots]) {
+    c->h_io_err[rvt_ctx::kAfSlots] = 0;
+    io_err_message(c, k, false, "");
+    return RVT_E_INVALID;
   }
   return RVT_OK;
 }
@@ -4829,13 +4925,30 @@ static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
   }
   for (int g = 0; g < n; ++g) {
     out[g] = c->queue[g].res;
+    if (c->queue[g].io_error) {
+      // the gene's VCF text / BGEN blocks were malformed: what was computed from the partly decoded block is void.  The
+      // record keeps its place in the order, says so (RVT_ST_INPUT_ERROR: every test NA) and the message names the record.
+      rvt_gene_result r;
+      std::memset(&r, 0, sizeof(r));
+      r.gene_id = c->queue[g].id;
+      r.n_variants = c->queue[g].M;
+      r.status = RVT_ST_INPUT_ERROR | RVT_ST_NO_POLY;
+      r.skat_p = r.skato_p = r.cmc_p = r.zeg_p = NAN;
+      out[g] = r;
+      char who[64];
+      snprintf(who, sizeof(who), " of gene %lld", (long long)c->queue[g].id);
+      io_err_message(c, c->queue[g].io_error, c->queue[g].decoded == 2, who);
+    }
     c->block_pool.emplace_back(c->queue[g].bytes, c->queue[g].dG);
   }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);
   for (auto& L : c->launched) L.first -= (size_t)n;
   {  // keep the free blocks for the next window, bounded by their BYTES (a count bound would free and re-allocate
      // half of a 256-gene window every time: hipMalloc + memset of a 200 MB block is ~3 ms)
-    constexpr size_t kPoolBytes = (size_t)96 << 30;
+    static const size_t kPoolBytes = [] {  // a third of the device memory (96 GB of the MI355X's 288)
+      size_t fr = 0, tot = 0;
+      return (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? tot / 3 : (size_t)16 << 30;
+    }();
     size_t total = 0;
     for (auto& bp : c->block_pool) total += bp.first;
     while (!c->block_pool.empty() && (total > kPoolBytes || c->block_pool.size() > 4096)) {

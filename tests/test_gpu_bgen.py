@@ -134,6 +134,28 @@ def test_short_block_is_reported(eng):
     assert np.array_equal(eng.bgen_decode([good], 2, N), _oracle_matrix([good], 2, N))
 
 
+def test_truncated_block_is_refused_before_anything_runs(eng):
+    """A layout-2 block whose ploidy bytes demand more packed values than it holds (truncated file): the submit call is
+    refused on the host — the decode kernels, which index the values from the ploidy bytes alone, never see it — and the
+    stream goes on."""
+    import rvtests_amd
+    rng = np.random.default_rng(13)
+    N = 3000
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=4)
+    eng.fit_null(0, X, y)
+    blocks = [bgengen.layout2_block(rng, N, 16, missing=0.01) for _ in range(4)]
+    eng.submit_gene_bgen(0, blocks, 2, want_af=False)
+    (clean,) = eng.collect()
+    cut = list(blocks)
+    cut[2] = blocks[2][:len(blocks[2]) // 2]
+    for want_af in (False, True):
+        with pytest.raises(rvtests_amd.RvtError):
+            eng.submit_gene_bgen(1, cut, 2, want_af=want_af)
+    eng.submit_gene_bgen(2, blocks, 2, want_af=False)
+    (again,) = eng.collect()
+    assert again.gene_id == 2 and again.skat_p == clean.skat_p and again.skato_p == clean.skato_p
+
+
 def test_multi_allelic_mode_only_knows_the_first_alternative_allele(eng):
     """getGenotypeForAltAllele (src/BGenGenotypeExtractor.cpp:470-482): alt > 1 -> every sample missing, alt = 1 -> getGenotype."""
     rng = np.random.default_rng(9)

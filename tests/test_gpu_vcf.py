@@ -79,6 +79,41 @@ def test_wrong_column_count_is_reported(eng):
     assert eng.vcf_decode([good], 50).shape == (50, 1)          # the flag does not stick
 
 
+def test_malformed_record_voids_its_own_gene_only(eng):
+    """A record with a wrong column count in a STREAMED gene (nobody waits for its allele frequencies): that gene's record
+    comes back with RVT_ST_INPUT_ERROR and every test NA — also when it is the last gene before collect — and the genes
+    around it are the ones the clean stream gives.  With want_af the submit call itself fails."""
+    import rvtests_amd
+    N, d, n_file = 3000, 2, 3000
+    rng = np.random.default_rng(77)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=4)
+    eng.fit_null(0, X, y)
+    eng.vcf_set_samples(np.arange(n_file, dtype=np.int32))
+    genes = [[vcfgen.make_record(rng, n_file, pos=100 * g + j) for j in range(6)] for g in range(5)]
+    for g, lines in enumerate(genes):
+        eng.submit_gene_vcf(g, lines, want_af=False)
+    clean = eng.collect()
+    bad = [list(l) for l in genes]
+    bad[1][3] = vcfgen.make_record(rng, n_file - 1, pos=777)       # one column short
+    bad[4][0] = vcfgen.make_record(rng, n_file + 2, pos=778)       # the LAST gene before collect
+    for g, lines in enumerate(bad):
+        eng.submit_gene_vcf(g, lines, want_af=False)
+    got = eng.collect()
+    ST_INPUT_ERROR = 16
+    assert [r.gene_id for r in got] == [0, 1, 2, 3, 4]
+    for g, (r, c) in enumerate(zip(got, clean)):
+        if g in (1, 4):
+            assert r.status & ST_INPUT_ERROR and not (r.skat_ok or r.skato_ok or r.cmc_ok or r.zeg_ok)
+        else:
+            assert r.status == c.status and r.skat_p == c.skat_p and r.skato_p == c.skato_p and r.cmc_p == c.cmc_p
+    assert b"gene 4" in eng.L.rvt_last_error(eng.ctx)
+    with pytest.raises(rvtests_amd.RvtError):                       # somebody waits: the call itself is refused
+        eng.submit_gene_vcf(9, bad[1], want_af=True)
+    eng.submit_gene_vcf(10, genes[2], want_af=True)                 # ... and nothing sticks
+    (r,) = eng.collect()
+    assert r.gene_id == 10 and r.skat_p == clean[2].skat_p
+
+
 @pytest.mark.parametrize("binary", [0, 1])
 def test_submit_gene_vcf_equals_int8_hand_off(eng, binary):
     N, d = 6000, 3
