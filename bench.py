@@ -73,18 +73,36 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05):
     return blocks, Ms, afs
 
 
-def make_phenotype(dev, N, seed, binary=False):
-    """Covariates and phenotype of SURVEY §8d: quantitative y = 0.3 c1 - 0.2 c2 + N(0,1) (configs 2/3) or binary
-    y ~ Bernoulli(logit^-1(-2 + 0.3 c1)) (config 4).  Returns X (with intercept) and y as device tensors."""
+N_CAUSAL = 12          # genes 0 .. 11 of rank 0's shard carry an effect ("10 causal genes")
+
+
+def causal_effect(blocks, N, binary):
+    """Genetic effect of the causal genes: beta_k x (rare alleles in the first 5 variants of gene k), the betas graded so
+    that the association p-values of the causal genes spread over the decades 1e-2 .. 1e-14 — the in-run parity check
+    then sees small p-values, not only null genes.  A device vector of N doubles."""
+    eff = torch.zeros(N, dtype=torch.float64, device=blocks[0].device)
+    for k in range(min(N_CAUSAL, len(blocks))):
+        burden = blocks[k][:5, :N].sum(0)
+        var = float(burden.var())
+        ncp = 8.0 + 7.0 * k                                   # non-centrality aimed at: 8 .. 85
+        beta = (ncp / max(var * N, 1e-30)) ** 0.5
+        eff += (4.0 if binary else 1.0) * beta * (burden - burden.mean())
+    return eff
+
+
+def make_phenotype(dev, N, seed, binary=False, effect=None):
+    """Covariates and phenotype of SURVEY §8d: quantitative y = 0.3 c1 - 0.2 c2 + genes + N(0,1) (configs 2/3) or binary
+    y ~ Bernoulli(logit^-1(-2 + 0.3 c1 + genes)) (config 4).  Returns X (with intercept) and y as device tensors."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     c = torch.randn((N, 2), generator=g, device=dev, dtype=torch.float64)
     X = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float64), c], 1)
+    e = effect if effect is not None else torch.zeros(N, dtype=torch.float64, device=dev)
     if binary:
-        pr = torch.sigmoid(-2.0 + 0.3 * c[:, 0])
+        pr = torch.sigmoid(-2.0 + 0.3 * c[:, 0] + e)
         y = (torch.rand(N, generator=g, device=dev, dtype=torch.float64) < pr).to(torch.float64)
     else:
-        y = 0.3 * c[:, 0] - 0.2 * c[:, 1] + torch.randn(N, generator=g, device=dev, dtype=torch.float64)
+        y = 0.3 * c[:, 0] - 0.2 * c[:, 1] + e + torch.randn(N, generator=g, device=dev, dtype=torch.float64)
     return X, y
 
 
@@ -135,7 +153,7 @@ def cpu_worker(path):
     print(json.dumps({"results": out, "seconds": time.perf_counter() - t_all}))
 
 
-def cpu_oracle_pool(genes, X, y, binary, workers):
+def cpu_oracle_pool(genes, X, y, binary, workers, library=None):
     """Run the oracle on `genes` ({index: (G_host, af)}) in `workers` independent single-thread processes at once, the
     genes dealt round-robin (genes are independent: this is how the CPU port would use a whole host).  The timed
     wall clock starts when the processes are started and includes their start-up and null fit.  Returns
@@ -157,8 +175,11 @@ def cpu_oracle_pool(genes, X, y, binary, workers):
                 arrs["af%d" % k] = genes[k][1]
             np.savez(path, **arrs)
             paths.append(path)
+        env = dict(os.environ)
+        if library:
+            env["ORC_LIBRARY"] = library
         t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for path in paths]
         recs = {}
         ok = True
@@ -191,6 +212,20 @@ def parity_summary(recs, gpu):
     worst["genes_compared"] = len(recs)
     worst["counts_bit_exact"] = bool(nonref_equal)
     worst["min_p_compared"] = min(min(r["skat_p"], r["skato_p"]) for r in recs.values()) if recs else None
+    # per decade of the oracle's p-value: largest relative difference, SKAT and SKAT-O apart (north_star: 1e-6 relative)
+    dec = {}
+    for k, r in recs.items():
+        g = gpu[k]
+        for name in ("skat_p", "skato_p"):
+            b = r[name]
+            if not (b > 0):
+                continue
+            key = "1e%d" % int(np.floor(np.log10(b)))
+            e = dec.setdefault(key, {"n": 0, "skat_max_rel": 0.0, "skato_max_rel": 0.0})
+            e["n"] += 1
+            f = name.replace("_p", "_max_rel")
+            e[f] = max(e[f], abs(getattr(g, name) - b) / b)
+    worst["by_decade"] = dict(sorted(dec.items(), key=lambda kv: -int(kv[0][2:])))
     return worst
 
 
@@ -328,9 +363,12 @@ def main():
     #      every rank by the engine itself (rvt_fit_null: OLS / IRLS on the device) -----------------------------
     d = 3
     binary = args.trait == "binary"
+    # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
+    blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi,
+                                 args.missing_frac)
     pack = torch.empty((N, d + 1), dtype=torch.float64, device=dev)
     if rank == 0:
-        X, y = make_phenotype(dev, N, 20260002, binary)
+        X, y = make_phenotype(dev, N, 20260002, binary, causal_effect(blocks, N, binary))
         pack[:, :d] = X
         pack[:, d] = y
     if world > 1:
@@ -339,9 +377,6 @@ def main():
     yh = pack[:, d].cpu().numpy().copy()
     eng.fit_null(rvtests_amd.TRAIT_BINARY if binary else rvtests_amd.TRAIT_QUANTITATIVE, Xh, yh)
 
-    # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
-    blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi,
-                                 args.missing_frac)
     torch.cuda.synchronize()
     # (the blocks are torch allocations the engine knows nothing about: no classification pass, nothing registered —
     # the hard-call kernel tests what it loads, in the timed region)
@@ -493,7 +528,9 @@ def main():
             # spread over the batch's widths: every (genes / n_sample)-th gene in order of M
             by_m = np.argsort(np.array(Ms), kind="stable")
             pick = [int(by_m[int(round(i * (len(by_m) - 1) / max(n_sample - 1, 1)))]) for i in range(n_sample)]
-            pick = sorted(set(pick))
+            # ... of which the first half are the causal genes (small p-values), the rest null genes of every width
+            n_c = min(N_CAUSAL, n_sample // 2, args.genes)
+            pick = sorted(set(list(range(n_c)) + pick[:max(n_sample - n_c, 1)]))
             k1 = int(np.argmin(np.abs(np.array(Ms) - 50)))           # the 1-thread gene: mean width
             host = {k: (np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()), afs[k]) for k in set(pick) | {k1}}
             one, wall1 = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, 1)
@@ -501,8 +538,16 @@ def main():
                 t1 = one[k1]["seconds"]
                 line["cpu_baseline"] = {"value": 1.0 / t1, "unit": "gene-sets/s", "cores": 1, "kind": "port",
                                         "sample": "1 gene of the batch (M=%d, N=%d) alone on the host: oracle folded SKAT "
-                                                  "+ literal SKAT-O + CMC + Zeggini, g++ -O2 -msse2, %.1f s (null fit "
-                                                  "excluded)" % (Ms[k1], N, t1)}
+                                                  "+ literal SKAT-O + CMC + Zeggini, g++ -O2 -msse2 (the reference's "
+                                                  "release flags), %.1f s (null fit excluded)" % (Ms[k1], N, t1)}
+                # the same sources built -O3 -march=native (what a tuned CPU build of the same loops gives)
+                nat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "liboracle_native.so")
+                if os.path.exists(nat):
+                    one_n, _ = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, 1, library=nat)
+                    if one_n:
+                        line["cpu_baseline"]["native_build"] = {
+                            "value": 1.0 / one_n[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
+                            "flags": "g++ -O3 -march=native", "seconds": one_n[k1]["seconds"]}
             recs, wall = cpu_oracle_pool({k: host[k] for k in pick}, Xh, yh, 1 if binary else 0, workers)
             if recs:
                 line["cpu_baseline_all_cores"] = {

@@ -54,7 +54,9 @@ _ref = None
 def lib(native=False):
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        # ORC_LIBRARY: another build of the same sources (oracle/liboracle_native.so: -O3 -march=native; bench.py times it
+        # beside the reference-flags build)
+        path = os.environ.get("ORC_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -507,3 +507,41 @@ def test_weighted_hardcall_at_the_wave_part_cap(engine):
     for f in FIELDS:
         x, y_ = getattr(a, f), getattr(b, f)
         assert abs(x - y_) <= 1e-9 * abs(y_) + 1e-300, (f, x, y_)
+
+
+def test_weighted_hardcall_digit_rounding_at_small_p(engine):
+    """The weighted kernel rounds every v = p (1 - p) to 42 fractional bits (six 7-bit digits).  Bound what that does to
+    SMALL p-values at the size of BASELINE configs[3] (N = 200 000): causal genes whose SKAT / SKAT-O p-values lie in the
+    decades 1e-7 .. 1e-13, the int8 kernel against the fp64 kernel on the same blocks (north_star: 1e-6 relative)."""
+    N, d = 200_000, 2
+    rng = np.random.default_rng(2026)
+    X = np.asfortranarray(np.column_stack([np.ones(N), rng.standard_normal(N)]))
+    genes = []
+    eff = np.zeros(N)
+    for k in range(10):
+        M = (24, 50, 72)[k % 3]
+        maf = 10 ** rng.uniform(-3.3, -1.3, M)
+        G = np.asfortranarray(rng.binomial(2, maf, size=(N, M)).astype(np.float64))
+        burden = G[:, :5].sum(1)
+        ncp = 25.0 + 8.0 * k
+        eff += 4.0 * np.sqrt(ncp / (burden.var() * N)) * (burden - burden.mean())
+        genes.append((G, G.sum(0) / (2.0 * N)))
+    pr = 1.0 / (1.0 + np.exp(-(-2.0 + 0.3 * X[:, 1] + eff)))
+    y = (rng.random(N) < pr).astype(np.float64)
+    engine.fit_null(1, X, y)
+    hc, tm = _run(engine, genes, True)
+    gen, _ = _run(engine, genes, False)
+    assert tm.genes_hard_call == len(genes) and tm.genes_handed_back == 0
+    small = 0
+    worst = 0.0
+    for a, b in zip(hc, gen):
+        for f in ("skat_p", "skato_p"):
+            x, y_ = getattr(a, f), getattr(b, f)
+            if 1e-13 <= y_ <= 1e-7:
+                small += 1
+            if y_ >= 1e-13:
+                worst = max(worst, abs(x - y_) / y_)
+                assert abs(x - y_) <= 1e-6 * y_, (f, x, y_)
+        assert abs(a.skato_Q - b.skato_Q) <= 1e-10 * abs(b.skato_Q)
+    assert small >= 4, "the planted effects no longer reach the small decades: %d" % small
+    print("weighted int8 vs fp64 kernel, p in [1e-13, 1]: max relative difference %.3g (%d values below 1e-7)" % (worst, small))
