@@ -529,7 +529,7 @@ int rvt_bgen_decode(rvt_ctx* ctx, int M, const unsigned char* const* block, cons
 /* ---- device groups: several GPUs of one node behind one calling thread ---------------------------------------------------
  * Genes are independent units that share only the null model, so a group is one engine context per device
  * (rvtests_amd/csrc/rvt_group.cpp): the null model / kinship decomposition is installed on every member, the gene stream is
- * dealt to the members in runs of 16 genes, and rvt_group_collect returns the records in SUBMISSION order whichever member
+ * dealt to the members in runs of 32 genes, and rvt_group_collect returns the records in SUBMISSION order whichever member
  * produced them (the reference's output files are gene-ordered, src/Main.cpp:1221-1254).  There is no device-to-device
  * traffic; the ordered merge of the fixed-size records on the host is the only "gather".  A gene that asks for
  * permutation p-values goes to member 0 (one process-wide random stream, src/Permutation.h:69-98).  The same device may

@@ -1,0 +1,183 @@
+// rvtests_amd — feeding the device from the caller's PAGEABLE memory at the rate of the PCIe link.
+//
+// The drop-in boundary hands over host buffers the caller reuses for the next gene (src/Main.cpp:1086,1225: one Matrix
+// for every gene), so a submission must have consumed its input when it returns.  A plain hipMemcpy from pageable memory
+// does that, but it returns only when the data has crossed the link (measured: 46-48 GB/s for 200 MB blocks, 12-40 GB/s for
+// the 6-25 MB of packed genotypes).  Here the copy into pinned memory is done by a small pool of worker threads, in chunks,
+// and every chunk is handed to the DMA engine as soon as it is complete — the copies of chunk k + 1 run while chunk k
+// crosses the link, and the call returns when the LAST host copy is done, not when the data has arrived (the stream
+// orders everything behind it), so the caller's next HIP calls overlap the transfer.
+//
+// Host-only code (threads, memcpy); the HIP calls are passed in as callbacks so that the test harness (hostcheck.cpp) can
+// measure the copy pool without a GPU.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace rvt {
+
+// Persistent worker threads that execute batches of memcpy tasks.  One pool per process (contexts share it: the caller
+// is a single thread, src/Main.cpp).  RVT_COPY_THREADS sets the size (default: min(3, hardware threads / 2), at least 1 —
+// measured on the MI355X host: one thread copies ~30 GB/s, three keep the link busy, eight only disturb each other).
+class CopyPool {
+ public:
+  struct Task {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  };
+  explicit CopyPool(int threads) {
+    n_ = std::max(1, threads);
+    for (int i = 0; i + 1 < n_; ++i) workers_.emplace_back([this] { loop(); });  // the caller's thread is worker n_ - 1
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  int threads() const { return n_; }
+  static int default_threads() {
+    if (const char* e = getenv("RVT_COPY_THREADS")) return std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(3u, hw / 2));
+  }
+  static CopyPool& instance() {
+    static CopyPool pool(default_threads());
+    return pool;
+  }
+  // copy [src, src + bytes) to dst with all threads (pieces of >= 256 KiB); returns when the copy is complete
+  void copy(void* dst, const void* src, size_t bytes) {
+    Task t{dst, src, bytes};
+    run(&t, 1);
+  }
+  // run a batch of copies, split into pieces so that every thread has work; returns when all are done
+  void run(const Task* tasks, size_t n) {
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += tasks[i].bytes;
+    if (total == 0) return;
+    if (n_ == 1 || total < (size_t)512 << 10) {
+      for (size_t i = 0; i < n; ++i) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes);
+      return;
+    }
+    const size_t piece = std::max<size_t>((size_t)256 << 10, (total / (size_t)(n_ * 2) + 4095) / 4096 * 4096);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      for (size_t i = 0; i < n; ++i)
+        for (size_t o = 0; o < tasks[i].bytes; o += piece) {
+          q_.push_back(Task{(char*)tasks[i].dst + o, (const char*)tasks[i].src + o, std::min(piece, tasks[i].bytes - o)});
+          ++pending_;
+        }
+    }
+    cv_.notify_all();
+    help();  // the calling thread works too
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+  }
+
+ private:
+  bool take(Task* t) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (q_.empty()) return false;
+    *t = q_.front();
+    q_.pop_front();
+    return true;
+  }
+  void finish_one() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (--pending_ == 0) done_.notify_all();
+  }
+  void help() {
+    Task t;
+    while (take(&t)) {
+      std::memcpy(t.dst, t.src, t.bytes);
+      finish_one();
+    }
+  }
+  void loop() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+      }
+      help();
+    }
+  }
+  int n_ = 1;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::deque<Task> q_;
+  size_t pending_ = 0;
+  bool stop_ = false;
+};
+
+// A ring of pinned staging chunks.  The owner supplies the pinned memory and three callbacks:
+//   wait(k)                       block until the DMA that last read chunk k has finished
+//   send(k, off, dst, bytes)      enqueue the DMA of chunk k's bytes [off, off + bytes) to device address dst
+//   send2d(k, dst, dpitch, width, rows)  enqueue a 2-D DMA of `rows` packed rows of `width` bytes from the start of chunk k
+//   sent(k)                       the DMAs of chunk k have been enqueued (record its event)
+struct StageRing {
+  std::vector<char*> chunk;  // pinned
+  size_t chunk_bytes = 0;
+  int next = 0;
+  std::function<int(int)> wait;
+  std::function<int(int, size_t, void*, size_t)> send;
+  std::function<int(int, void*, size_t, size_t, size_t)> send2d;
+  std::function<int(int)> sent;
+
+  // contiguous host range -> contiguous device range
+  int copy(void* dst, const void* src, size_t bytes, CopyPool& pool) {
+    for (size_t o = 0; o < bytes; o += chunk_bytes) {
+      const size_t n = std::min(chunk_bytes, bytes - o);
+      const int k = next;
+      next = (next + 1) % (int)chunk.size();
+      if (int rc = wait(k)) return rc;
+      pool.copy(chunk[k], (const char*)src + o, n);
+      if (int rc = send(k, 0, (char*)dst + o, n)) return rc;
+      if (int rc = sent(k)) return rc;
+    }
+    return 0;
+  }
+  // `rows` rows of `width` bytes, spitch apart on the host, dpitch apart on the device (hipMemcpy2D's meaning)
+  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, CopyPool& pool) {
+    if (width == 0 || rows == 0) return 0;
+    if (width > chunk_bytes) {  // a row is longer than a chunk: row by row, each in contiguous pieces
+      for (size_t r = 0; r < rows; ++r)
+        if (int rc = copy((char*)dst + r * dpitch, (const char*)src + r * spitch, width, pool)) return rc;
+      return 0;
+    }
+    const size_t per = std::max<size_t>(1, chunk_bytes / width);  // whole rows per chunk, packed
+    std::vector<CopyPool::Task> tasks;
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+      const size_t nr = std::min(per, rows - r0);
+      const int k = next;
+      next = (next + 1) % (int)chunk.size();
+      if (int rc = wait(k)) return rc;
+      if (spitch == width) {
+        pool.copy(chunk[k], (const char*)src + r0 * spitch, nr * width);
+      } else {
+        tasks.clear();
+        for (size_t r = 0; r < nr; ++r)
+          tasks.push_back(CopyPool::Task{chunk[k] + r * width, (const char*)src + (r0 + r) * spitch, width});
+        pool.run(tasks.data(), tasks.size());
+      }
+      if (int rc = send2d(k, (char*)dst + r0 * dpitch, dpitch, width, nr)) return rc;
+      if (int rc = sent(k)) return rc;
+    }
+    return 0;
+  }
+};
+
+}  // namespace rvt

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include "host_stage.h"
 #include "rvt_pvalue.h"
 #include "rvt_mvn.h"
 
@@ -157,5 +159,49 @@ double hc_mvn_band(const double* R, int n, double T, double* err) {
   return mvn_band_prob_serial(A.data(), n, T, y.data(), alpha.data(), err);
 }
 double hc_mvn_phiinv(double p) { return mvn_phiinv(p); }
+
+// ---- host_stage.h: the copy pool and the staging ring that feed the device from pageable memory -------------------------
+// GB/s of `reps` copies of `bytes` bytes with a pool of `threads` threads (plain memory to plain memory: what the host
+// side of a staged copy costs)
+double hc_copy_rate(size_t bytes, int threads, int reps) {
+  std::vector<char> src(bytes), dst(bytes);
+  for (size_t i = 0; i < bytes; i += 4096) src[i] = (char)i;  // touch every page
+  std::memset(dst.data(), 1, bytes);
+  rvt::CopyPool pool(threads);
+  pool.copy(dst.data(), src.data(), bytes);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; ++r) pool.copy(dst.data(), src.data(), bytes);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return (double)bytes * reps / dt / 1e9;
+}
+// The staging ring with a fake device (plain memory): a 2-D copy of `rows` rows of `width` bytes (host pitch spitch,
+// "device" pitch dpitch) through `chunks` chunks of `chunk_bytes`; returns 0 when every byte arrived where hipMemcpy2D
+// would have put it and nothing else was touched.
+int hc_stage_copy2d(size_t width, size_t rows, size_t spitch, size_t dpitch, size_t chunk_bytes, int chunks, int threads) {
+  std::vector<unsigned char> src(spitch * rows), dev(dpitch * rows, 0xEE);
+  for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)((i * 2654435761u) >> 13);
+  std::vector<std::vector<char>> mem((size_t)chunks, std::vector<char>(chunk_bytes));
+  rvt::StageRing ring;
+  for (auto& m : mem) ring.chunk.push_back(m.data());
+  ring.chunk_bytes = chunk_bytes;
+  ring.wait = [](int) { return 0; };
+  ring.send = [&](int k, size_t off, void* dst, size_t bytes) {
+    std::memcpy(dst, ring.chunk[k] + off, bytes);
+    return 0;
+  };
+  ring.send2d = [&](int k, void* dst, size_t dp, size_t w, size_t r) {
+    for (size_t i = 0; i < r; ++i) std::memcpy((char*)dst + i * dp, ring.chunk[k] + i * w, w);
+    return 0;
+  };
+  ring.sent = [](int) { return 0; };
+  rvt::CopyPool pool(threads);
+  if (ring.copy2d(dev.data(), dpitch, src.data(), spitch, width, rows, pool)) return 1;
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t b = 0; b < dpitch; ++b) {
+      const unsigned char want = b < width ? src[r * spitch + b] : 0xEE;
+      if (dev[r * dpitch + b] != want) return 2;
+    }
+  return 0;
+}
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <functional>
 #include "kernels.hip.h"
+#include "host_stage.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
 void k2_launch_group_w0(int group, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const int* list, int n_wparts,
@@ -144,8 +145,7 @@ struct rvt_ctx {
   // allele frequencies of raw / packed submissions whose caller did not ask for them: written into a ring slot and
   // copied back asynchronously; resolved (one stream wait) when the gene's group is launched
   static constexpr int kAfSlots = 128;
-  double* d_af_ring = nullptr;  // kAfSlots x RVT_MAX_VARIANTS
-  double* h_af_ring = nullptr;  // pinned mirror
+  double* h_af_ring = nullptr;  // kAfSlots x RVT_MAX_VARIANTS, pinned and device-mapped: the kernels write it directly
   unsigned long long af_seq = 0;
   int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
@@ -193,6 +193,24 @@ struct rvt_ctx {
   size_t perm_cap_NB = 0, perm_cap_BM = 0;
   int perm_cap_B = 0;
   hipEvent_t ev_in[kSlotsAll] = {}, ev_k2[kSlotsAll] = {}, ev_k2b[kSlotsAll] = {};
+  // host -> device copies of the streaming interface: pinned staging ring filled by the process-wide copy threads
+  // (host_stage.h), drained by DMA on io_stream.  RVT_STAGE=0 restores the runtime's own pageable copies.
+  static constexpr int kStageChunks = 4;
+  static constexpr size_t kStageBytes = (size_t)32 << 20;
+  StageRing stage;
+  hipEvent_t stage_ev[kStageChunks] = {};
+  bool stage_on = true;
+  static constexpr int kSmallSlots = 8;
+  static constexpr size_t kSmallBytes = (size_t)128 << 10;
+  char* h_small = nullptr;      // pinned: kSmallSlots x kSmallBytes (record tables of the VCF / BGEN decoders)
+  hipEvent_t small_ev[kSmallSlots] = {};
+  int small_next = 0;
+  // RVT_TRACE_SUBMIT=1: host seconds spent in the phases of the streaming submissions, printed by rvt_destroy
+  bool trace_submit = false;
+  double tr_block = 0, tr_copy = 0, tr_consol = 0, tr_af = 0, tr_launch = 0, tr_collect = 0;
+  long long tr_genes = 0;
+  hipEvent_t ev_io = nullptr;   // recorded on io_stream when a group of submitted genes is launched
+  bool io_wait_pending = false;  // the next batch waits for ev_io (its blocks may still be crossing the link)
   std::string err;
   // null model
   bool have_null = false;
@@ -585,6 +603,9 @@ int rvt_init(rvt_ctx** out, int device_id) {
   }
   seed_rand_state(c->rand_state, 1u);
   if (const char* e = getenv("RVT_HARDCALL")) c->hc_enabled = atoi(e) != 0;
+  if (const char* e = getenv("RVT_STAGE")) c->stage_on = atoi(e) != 0;
+  if (const char* e = getenv("RVT_TRACE_SUBMIT")) c->trace_submit = atoi(e) != 0;
+  hipEventCreateWithFlags(&c->ev_io, hipEventDisableTiming);
   *out = c;
   return RVT_OK;
 }
@@ -604,6 +625,11 @@ static void free_null(rvt_ctx* c) {
 
 void rvt_destroy(rvt_ctx* c) {
   if (!c) return;
+  if (c->trace_submit && c->tr_genes > 0)
+    fprintf(stderr, "[rvt submit trace] %lld genes: per gene us: total %.1f  copy %.1f  (unused %.1f %.1f)  launch %.1f "
+            "| collect total %.1f ms\n", c->tr_genes, 1e6 * c->tr_block / c->tr_genes, 1e6 * c->tr_copy / c->tr_genes,
+            1e6 * c->tr_consol / c->tr_genes, 1e6 * c->tr_af / c->tr_genes, 1e6 * c->tr_launch / c->tr_genes,
+            1e3 * c->tr_collect);
   hipSetDevice(c->device);
   for (auto& sl : c->slots) sync_stream(sl.stream);
   if (c->k2b_stream) {
@@ -618,6 +644,13 @@ void rvt_destroy(rvt_ctx* c) {
     sync_stream(c->io_stream);
     hipStreamDestroy(c->io_stream);
   }
+  for (char* p : c->stage.chunk) hipHostFree(p);
+  if (c->h_small) hipHostFree(c->h_small);
+  for (hipEvent_t e : c->small_ev)
+    if (e) hipEventDestroy(e);
+  for (hipEvent_t e : c->stage_ev)
+    if (e) hipEventDestroy(e);
+  if (c->ev_io) hipEventDestroy(c->ev_io);
   for (int i = 0; i < kSlotsAll; ++i) {
     if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
     if (c->ev_k2[i]) hipEventDestroy(c->ev_k2[i]);
@@ -644,7 +677,6 @@ void rvt_destroy(rvt_ctx* c) {
     if (p) hipFree(p);
   if (c->d_consol_af) hipFree(c->d_consol_af);
   if (c->d_consol_parts) hipFree(c->d_consol_parts);
-  if (c->d_af_ring) hipFree(c->d_af_ring);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
   for (auto& kv : c->col_kind)
@@ -846,6 +878,106 @@ int rvt_block_free(rvt_ctx* c, double* dG) {
   return RVT_OK;
 }
 
+// ---- host -> device through the pinned staging ring (host_stage.h), on io_stream --------------------------------------
+// The calls return when the caller's memory has been READ; the data arrives in stream order behind them.
+static int stage_ready(rvt_ctx* c) {
+  if (!c->stage.chunk.empty()) return RVT_OK;
+  for (int k = 0; k < rvt_ctx::kStageChunks; ++k) {
+    char* p = nullptr;
+    HIP_TRY(c, hipHostMalloc((void**)&p, rvt_ctx::kStageBytes, hipHostMallocDefault));
+    c->stage.chunk.push_back(p);
+    HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
+  }
+  c->stage.chunk_bytes = rvt_ctx::kStageBytes;
+  c->stage.wait = [c](int k) {
+    hipError_t e;
+    int spins = 0;
+    while ((e = hipEventQuery(c->stage_ev[k])) == hipErrorNotReady)
+      if (++spins > 64) {
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+      }
+    (void)hipGetLastError();
+    return e == hipSuccess ? 0 : 1;
+  };
+  c->stage.send = [c](int k, size_t off, void* dst, size_t bytes) {
+    return hipMemcpyAsync(dst, c->stage.chunk[k] + off, bytes, hipMemcpyHostToDevice, c->io_stream) == hipSuccess ? 0 : 1;
+  };
+  c->stage.send2d = [c](int k, void* dst, size_t dpitch, size_t width, size_t rows) {
+    return hipMemcpy2DAsync(dst, dpitch, c->stage.chunk[k], width, width, rows, hipMemcpyHostToDevice, c->io_stream) ==
+                   hipSuccess
+               ? 0
+               : 1;
+  };
+  c->stage.sent = [c](int k) { return hipEventRecord(c->stage_ev[k], c->io_stream) == hipSuccess ? 0 : 1; };
+  return RVT_OK;
+}
+// a small table (<= kSmallBytes) through a pinned ring: no host synchronisation, the source may be a local
+static int small_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes > rvt_ctx::kSmallBytes) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));
+    return RVT_OK;
+  }
+  if (!c->h_small) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_small, rvt_ctx::kSmallSlots * rvt_ctx::kSmallBytes, hipHostMallocDefault));
+    for (auto& e : c->small_ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int k = c->small_next;
+  c->small_next = (k + 1) % rvt_ctx::kSmallSlots;
+  while (hipEventQuery(c->small_ev[k]) == hipErrorNotReady) {
+    struct timespec ts = {0, 20000};
+    nanosleep(&ts, nullptr);
+  }
+  (void)hipGetLastError();
+  char* p = c->h_small + (size_t)k * rvt_ctx::kSmallBytes;
+  std::memcpy(p, src, bytes);
+  HIP_TRY(c, hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, c->io_stream));
+  HIP_TRY(c, hipEventRecord(c->small_ev[k], c->io_stream));
+  return RVT_OK;
+}
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+struct TraceScope {  // RVT_TRACE_SUBMIT: adds the scope's host time to *acc
+  double* acc;
+  double t0;
+  TraceScope(rvt_ctx* c, double* a) : acc(c->trace_submit ? a : nullptr), t0(acc ? now_s() : 0.0) {}
+  ~TraceScope() {
+    if (acc) *acc += now_s() - t0;
+  }
+};
+static int staged_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {
+  TraceScope ts(c, &c->tr_copy);
+  if (!c->stage_on || bytes < ((size_t)256 << 10)) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->io_stream));
+    return RVT_OK;
+  }
+  int rc = stage_ready(c);
+  if (rc) return rc;
+  if (c->stage.copy(dst, src, bytes, CopyPool::instance())) return fail(c, RVT_E_HIP, "staged host-to-device copy failed");
+  return RVT_OK;
+}
+static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+  TraceScope ts(c, &c->tr_copy);
+  // Big blocks (the 200 MB of an fp64 gene at N = 500 000) go through the runtime's own pageable path: measured 46-48
+  // GB/s of the link's 57 (tools/bench_group_stream.py), which the staged ring does not beat at this size; the call is
+  // then synchronous.  The ring is for the packed hand-offs, where returning before the data has crossed matters.
+  if (!c->stage_on || width * rows < ((size_t)256 << 10) || width * rows >= ((size_t)64 << 20)) {
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));  // (a small pageable copy: the runtime has not necessarily read it yet)
+    return RVT_OK;
+  }
+  int rc = stage_ready(c);
+  if (rc) return rc;
+  if (c->stage.copy2d(dst, dpitch, src, spitch, width, rows, CopyPool::instance()))
+    return fail(c, RVT_E_HIP, "staged host-to-device copy failed");
+  return RVT_OK;
+}
+
+// (enqueued on io_stream: the block is complete in stream order behind the call, see staged_h2d_2d)
 static int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
   if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
@@ -859,12 +991,15 @@ static int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   }
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t bld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  HIP_TRY(c, hipMemcpy2D(dG, sizeof(double) * bld, G, sizeof(double) * N, sizeof(double) * N, M,
-                         hipMemcpyHostToDevice));
-  return RVT_OK;
+  return staged_h2d_2d(c, dG, sizeof(double) * bld, G, sizeof(double) * N, sizeof(double) * N, (size_t)M);
 }
 
-int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) { return upload_block_data(c, dG, M, G); }
+int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
+  int rc = upload_block_data(c, dG, M, G);
+  if (rc) return rc;
+  HIP_TRY(c, sync_stream(c->io_stream));  // the block is complete on return
+  return RVT_OK;
+}
 
 int rvt_set_profiling(rvt_ctx* c, int on) {
   if (!c) return RVT_E_INVALID;
@@ -1030,6 +1165,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   sl.seq = ++c->launch_seq;
   hipStream_t st = sl.stream;
+  if (c->io_wait_pending) {
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_io, 0));
+    c->io_wait_pending = false;
+  }
   rvt_params params;
   if (prm)
     params = *prm;
@@ -4103,7 +4242,7 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
 
 // ---- streaming interface --------------------------------------------------------------------------------
 namespace {
-constexpr int kSubmitGroup = 16;  // genes per asynchronous sub-batch of the streaming interface
+constexpr int kSubmitGroup = 32;  // genes per asynchronous sub-batch of the streaming interface
 
 bool same_config(const rvt_ctx::Pending& a, const rvt_ctx::Pending& b) {
   return a.tests == b.tests && std::memcmp(&a.prm, &b.prm, sizeof(rvt_params)) == 0;
@@ -4154,6 +4293,9 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
   L.n = n;
   L.res.resize(n);
   const rvt_ctx::Pending& p0 = c->queue[first];
+  // the blocks of these genes may still be crossing the link (staged copies on io_stream): the batch waits for them
+  HIP_TRY(c, hipEventRecord(c->ev_io, c->io_stream));
+  c->io_wait_pending = true;
   c->next_done_flag = &L.done;
   int rc = run_batch(c, n, ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm, L.res.data(), nullptr, nullptr,
                      kinds.data());
@@ -4199,6 +4341,7 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
         af.insert(af.end(), c->queue[g].af.begin(), c->queue[g].af.end());
       }
       std::vector<rvt_gene_result> res(e - i);
+      HIP_TRY(c, sync_stream(c->io_stream));  // (the blocks are complete before the synchronous permutation path)
       rc = run_blocks_with_perm(c, (int)(e - i), ptrs.data(), Ms.data(), af.data(), ids.data(), p0.tests, &p0.prm,
                                 res.data());
       if (rc) return rc;
@@ -4285,9 +4428,8 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
   c->vcf_hemi.clear();
   for (int j = 0; j < M; ++j)  // (a copy from pageable memory returns once the source has been read)
     if (vg->len[j] > 0)
-      HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j], hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, sync_stream(st));  // `rec` is a local
+      if (int rcs = staged_h2d(c, c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j])) return rcs;
+  if (int rcs = small_h2d(c, c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M)) return rcs;  // (`rec` is a local)
   int* d_err = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_io_err, 0));
   d_err += err_slot;
@@ -4380,7 +4522,26 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
         unsigned long long values = 0;
         int worst = 0;
         const unsigned char* pm = b + 8;
-        for (int64_t i = 0; i < n_file; ++i) {
+        // (nearly every sample has the same ploidy byte: eight at a time while they equal the first one)
+        unsigned long long pat;
+        std::memset(&pat, pm[0], 8);
+        const int z0 = pm[0] & 0x3f;
+        int64_t i = 0;
+        for (; i + 8 <= n_file; i += 8) {
+          unsigned long long w;
+          std::memcpy(&w, pm + i, 8);
+          if (w == pat) {
+            values += 8ull * (unsigned long long)per_z[z0];
+          } else {
+            for (int t = 0; t < 8; ++t) {
+              const int z = pm[i + t] & 0x3f;
+              values += (unsigned long long)per_z[z];
+              worst = z > worst ? z : worst;
+            }
+          }
+        }
+        worst = z0 > worst ? z0 : worst;
+        for (; i < n_file; ++i) {
           const int z = pm[i] & 0x3f;
           values += (unsigned long long)per_z[z];
           worst = z > worst ? z : worst;
@@ -4421,10 +4582,9 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
   }
   for (int j = 0; j < M; ++j) {  // the bytes behind a block read as zero (BitReader stops at its end)
     HIP_TRY(c, hipMemsetAsync(c->d_vcf_text + rec[j].off + bg->len[j], 0, 16, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_vcf_text + rec[j].off, bg->block[j], (size_t)bg->len[j], hipMemcpyHostToDevice, st));
+    if (int rcs = staged_h2d(c, c->d_vcf_text + rec[j].off, bg->block[j], (size_t)bg->len[j])) return rcs;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_bgen_rec, rec.data(), sizeof(BgenRecord) * M, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, sync_stream(st));  // `rec` is a local
+  if (int rcs = small_h2d(c, c->d_bgen_rec, rec.data(), sizeof(BgenRecord) * M)) return rcs;  // (`rec` is a local)
   int* d_err = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_io_err, 0));
   d_err += err_slot;
@@ -4449,6 +4609,8 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   if (tests & RVT_TEST_FAMSKAT) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
   if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene of %d variants exceeds RVT_MAX_VARIANTS", M);
   hipSetDevice(c->device);
+  TraceScope ts_all(c, &c->tr_block);  // (the whole call; "block" in the trace line = total per gene)
+  if (c->trace_submit) ++c->tr_genes;
   rvt_ctx::Pending p;
   p.id = gene_id;
   p.M = M;
@@ -4514,14 +4676,17 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     // ring slot when nobody waits for them, through the synchronous word otherwise
     int ring_slot = -1;
     if (!af_out && e == hipSuccess) {
-      if (!c->d_af_ring) {
-        e = hipMalloc((void**)&c->d_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS);
-        if (e == hipSuccess)
-          e = hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS,
-                            hipHostMallocDefault);
-      }
+      if (!c->h_af_ring)
+        e = hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS, hipHostMallocMapped);
       if (e == hipSuccess && c->af_unresolved >= rvt_ctx::kAfSlots && resolve_af(c)) e = hipErrorUnknown;
       if (e == hipSuccess) ring_slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+    }
+    // the frequencies go straight into the (device-mapped) ring slot, or into the device buffer the caller waits for
+    double* d_af_dst = c->d_consol_af;
+    if (ring_slot >= 0 && e == hipSuccess) {
+      double* mapped = nullptr;
+      e = hipHostGetDevicePointer((void**)&mapped, c->h_af_ring, 0);
+      if (e == hipSuccess) d_af_dst = mapped + (size_t)ring_slot * RVT_MAX_VARIANTS;
     }
     const int err_slot = ring_slot >= 0 ? ring_slot : rvt_ctx::kAfSlots;
     const bool decodes = mode == 4 || mode == 5 || mode == 6;
@@ -4544,7 +4709,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       hipLaunchKernelGGL((consolidate_count_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
                          c->d_consol_parts);
       hipLaunchKernelGGL((consolidate_fill_kernel<double>), dim3((unsigned)M), dim3(64), 0, st, p.dG, (long long)ld,
-                         (long long)N, nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+                         (long long)N, nparts, c->d_consol_parts, d_af_dst, d_fill);
       hipLaunchKernelGGL((consolidate_write_kernel<double>), cgrid, dim3(256), 0, st, p.dG, (long long)ld, (long long)N,
                          (long long)ld, d_fill, p.dG);
     } else {
@@ -4562,7 +4727,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       if (e == hipSuccess && mode == 4) {
         if (vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot) != RVT_OK) e = hipErrorUnknown;
       } else if (e == hipSuccess) {
-        e = hipMemcpyAsync(c->d_consol_i8, G, bytes8, hipMemcpyHostToDevice, st);
+        if (staged_h2d(c, c->d_consol_i8, G, bytes8) != RVT_OK) e = hipErrorUnknown;
       }
       if (e == hipSuccess && mode == 3) {
         const bed2_t* sb = (const bed2_t*)c->d_consol_i8;
@@ -4570,7 +4735,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
                            c->d_consol_parts);
         hipLaunchKernelGGL((consolidate_fill_kernel<bed2_t>), dim3((unsigned)M), dim3(64), 0, st, sb, cb, (long long)N,
-                           nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+                           nparts, c->d_consol_parts, d_af_dst, d_fill);
         hipLaunchKernelGGL((consolidate_write_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
                            (long long)ld, d_fill, p.dG);
       } else if (e == hipSuccess) {
@@ -4578,7 +4743,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         hipLaunchKernelGGL((consolidate_count_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
                            (long long)N, c->d_consol_parts);
         hipLaunchKernelGGL((consolidate_fill_kernel<signed char>), dim3((unsigned)M), dim3(64), 0, st, s8, (long long)N,
-                           (long long)N, nparts, c->d_consol_parts, c->d_consol_af, d_fill);
+                           (long long)N, nparts, c->d_consol_parts, d_af_dst, d_fill);
         hipLaunchKernelGGL((consolidate_write_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
                            (long long)N, (long long)ld, d_fill, p.dG);
       }
@@ -4596,17 +4761,8 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     } else if (e == hipSuccess) {
       // nobody waits for the frequencies: the host copy of the block is already consumed (a copy from pageable memory
       // returns once the source has been read), so return now and pick the frequencies up at launch time
-      {
-        const int slot = ring_slot;
-        double* d_slot = c->d_af_ring + (size_t)slot * RVT_MAX_VARIANTS;
-        e = hipMemcpyAsync(d_slot, c->d_consol_af, afb, hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess)
-          e = hipMemcpyAsync(c->h_af_ring + (size_t)slot * RVT_MAX_VARIANTS, d_slot, afb, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) {
-          p.af_slot = slot;
-          ++c->af_unresolved;
-        }
-      }
+      p.af_slot = ring_slot;  // (written by consolidate_fill_kernel through the mapping; read after the stream is waited for)
+      ++c->af_unresolved;
     }
     if (e != hipSuccess) {
       give_back();
@@ -4618,6 +4774,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   c->queue.push_back(std::move(p));
   // complete groups start computing now and overlap the host-side copies of the following genes
+  TraceScope ts_l(c, &c->tr_launch);
   return launch_pending(c, c->queue.size(), true);
 }
 }  // namespace
@@ -4975,6 +5132,7 @@ int rvt_collect(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
 
 int rvt_collect_ready(rvt_ctx* c, rvt_gene_result* out, int cap, int* n_out) {
   if (!c || !out || !n_out) return RVT_E_INVALID;
+  TraceScope ts_c(c, &c->tr_collect);
   *n_out = 0;
   hipSetDevice(c->device);
   // batches whose stream has run dry are finished: take their records without waiting for anything else

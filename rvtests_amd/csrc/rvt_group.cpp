@@ -27,7 +27,7 @@ struct rvt_group {
 };
 
 namespace {
-constexpr int kRun = 16;  // genes dealt to one member before moving on (= the engine's asynchronous sub-batch)
+constexpr int kRun = 32;  // genes dealt to one member before moving on (= the engine's asynchronous sub-batch)
 
 int gfail(rvt_group* g, int code, const char* what, rvt_ctx* c) {
   if (g) g->err = std::string(what) + (c ? std::string(": ") + rvt_last_error(c) : std::string());

@@ -828,7 +828,7 @@ class Engine:
 
 
 class Group:
-    """Several GPUs behind one caller (rvt_group_*): the null model on every member, the gene stream dealt in runs of 16,
+    """Several GPUs behind one caller (rvt_group_*): the null model on every member, the gene stream dealt in runs of 32,
     records back in submission order.  `devices`: list of HIP device indices (a device may repeat)."""
 
     def __init__(self, devices):
@@ -871,6 +871,16 @@ class Group:
         self._check(self.L.rvt_group_submit_gene_i8(self.g, int(gene_id), G8.shape[1],
                                                     G8.ctypes.data_as(C.POINTER(C.c_int8)), int(tests), C.byref(prm),
                                                     None))
+
+    def submit_gene_bed(self, gene_id, bed, M, tests=TEST_ALL, params=None):
+        """PLINK 2-bit codes, SNP-major (rvt_group_submit_gene_bed)."""
+        bed = np.ascontiguousarray(bed, dtype=np.uint8)
+        prm = params or Params.default()
+        self.L.rvt_group_submit_gene_bed.restype = C.c_int
+        self.L.rvt_group_submit_gene_bed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                     c_double_p]
+        self._check(self.L.rvt_group_submit_gene_bed(self.g, int(gene_id), int(M), bed.ctypes.data_as(C.c_void_p),
+                                                     int(tests), C.byref(prm), None))
 
     def submit_gene_bgen(self, gene_id, blocks, layout, tests=TEST_ALL, params=None):
         """One gene as uncompressed BGEN probability blocks (rvt_group_submit_gene_bgen); file sample i = analysis row i

@@ -55,7 +55,7 @@ _lib = None
 def build():
     out = os.path.join(CSRC, "librvt_hostcheck.so")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", out,
-                           os.path.join(CSRC, "hostcheck.cpp"), "-lm"])
+                           os.path.join(CSRC, "hostcheck.cpp"), "-lm", "-lpthread"])
     return out
 
 

@@ -21,7 +21,7 @@ def test_group_orders_records_and_matches_single_context(engine):
     N, d = 3001, 3
     rng = np.random.default_rng(3)
     genes = []
-    for g in range(75):                       # several runs of 16 per member + a ragged tail
+    for g in range(75):                       # several runs per member + a ragged tail
         M = int(rng.integers(1, 70))
         Graw, G, af = synth.make_gene(N, M, seed=7000 + g, missing=0.01 if g % 4 == 0 else 0.0, common=(g % 5 == 1))
         genes.append((G, af))

@@ -474,7 +474,7 @@ def test_collect_ready_returns_finished_prefix_without_draining(engine):
         engine.submit_gene(500 + g, G, af)
         if g % 10 == 9:
             got += engine.collect_ready()
-    assert len(got) <= 64                     # the last, incomplete group of 16 cannot have been launched
+    assert len(got) <= 64                     # the last, incomplete group of 32 cannot have been launched
     got += engine.collect()
     assert [r.gene_id for r in got] == [500 + g for g in range(70)]
     for r, (G, af) in zip(got[::9], genes[::9]):

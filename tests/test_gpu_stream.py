@@ -145,3 +145,51 @@ def test_long_stream_binary_trait(eng):
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
             assert x == y_ or abs(x - y_) <= 1e-9 * abs(y_), (a.gene_id, f, x, y_)
+
+
+def test_copy_pool_scales_on_the_gpu_host():
+    """The staged copies (host_stage.h) are filled by a pool of threads: on the GPU box's host several threads must move
+    clearly more than one does (one core copies ~10 GB/s, the link takes ~55)."""
+    import ctypes as C
+    import hc
+    L = hc.lib()
+    L.hc_copy_rate.restype = C.c_double
+    L.hc_copy_rate.argtypes = [C.c_size_t, C.c_int, C.c_int]
+    r1 = L.hc_copy_rate(256 << 20, 1, 4)
+    r8 = L.hc_copy_rate(256 << 20, 8, 4)
+    print("copy pool on this host: 1 thread %.1f GB/s, 8 threads %.1f GB/s" % (r1, r8))
+    assert r8 > 2.0 * r1
+
+
+def test_staged_and_plain_copies_give_the_same_records(monkeypatch):
+    """RVT_STAGE=0 (the runtime's own pageable copies) against the staged copies: identical records, every entry point."""
+    import rvtests_amd
+    rng = np.random.default_rng(8)
+    N, d = 40_000, 2
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=3)
+    genes = []
+    for g in range(20):
+        M = int(rng.integers(3, 60))
+        raw = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.5, -0.7, M), size=(N, M)).astype(np.float64))
+        if g % 3 == 0:
+            raw[rng.random((N, M)) < 0.01] = -9.0
+        genes.append(raw)
+    outs = []
+    for stage in ("1", "0"):
+        monkeypatch.setenv("RVT_STAGE", stage)
+        e = rvtests_amd.Engine(0)
+        e.fit_null(0, X, y)
+        for g, raw in enumerate(genes):
+            if g % 4 == 0:
+                e.submit_gene(g, orc.impute_mean(raw), orc.counter_af(raw))
+            elif g % 4 == 1:
+                e.submit_gene_raw(g, raw, want_af=False)
+            elif g % 4 == 2:
+                e.submit_gene_raw(g, raw.astype(np.int8), want_af=(g % 8 == 2))
+            else:
+                e.submit_gene_bed(g, e.pack_bed(raw), raw.shape[1], want_af=False)
+        outs.append(e.collect())
+        e.close()
+    for a, b in zip(*outs):
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f), (a.gene_id, f)
