@@ -324,14 +324,24 @@ int rvt_fit_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, con
                  double* sigma2_out);
 
 /* ---- SKAT permutations -----------------------------------------------------------------------------------------
- * With rvt_params.skat_nperm > 0, rvt_run_blocks / rvt_collect also run the adaptive permutation test of
- * SkatTest::fit (src/Model.h:2706-2718; Permutation src/Permutation.h:69-98; permute src/LinearAlgebra.h:8-21;
- * Skat::GetQFromNewResidual regression/Skat.cpp:107-116) gene after gene, drawing from ONE emulated glibc rand()
- * stream exactly as the reference's process-wide rand() is consumed, so the permutations themselves are the
- * reference's (Q is evaluated in fp64 instead of fp32).  rvt_rand_seed restarts that stream (srand semantics; the
- * reference never calls srand, i.e. seed 1, which is also the state of a fresh context).
- * rvt_run_blocks_async rejects skat_nperm > 0. */
+ * With rvt_params.skat_nperm > 0 (the reference's default for `--kernel skat`: nPerm = 10000, src/ModelManager.cpp:171-175),
+ * rvt_run_blocks / rvt_collect also run the adaptive permutation test of SkatTest::fit (src/Model.h:2706-2718;
+ * Permutation src/Permutation.h:69-98; permute src/LinearAlgebra.h:8-21; Skat::GetQFromNewResidual
+ * regression/Skat.cpp:107-116), gene after gene.  Two modes (rvt_set_perm_exact, or RVT_PERM_EXACT=1 in the environment):
+ *   counter-based (default)  shuffle s of gene g is a keyed bijection of [0, N) — Philox keys from (seed, gene_id, s), a
+ *                            cycle-walked Feistel network (rvtests_amd/csrc/perm_counter.h).  No state is shared between
+ *                            genes, so any context of a device group may take any gene, in any order, and the records do
+ *                            not depend on how the genes were dealt; nothing is stored per shuffle.  STATISTICAL parity
+ *                            with the reference: the same estimator of the same tail probability with the same stopping
+ *                            rule, other random numbers.
+ *   exact                    ONE emulated glibc rand() stream consumed exactly as the reference's process-wide rand() is, so
+ *                            the permutations themselves — and ActualPerm / NumGreater / NumEqual — are the reference's
+ *                            (Q is evaluated in fp64 instead of fp32).  Sequential across genes: a device group sends every
+ *                            such gene to member 0.
+ * rvt_rand_seed restarts the rand() stream (srand semantics; the reference never calls srand, i.e. seed 1, which is also
+ * the state of a fresh context) and is the seed of the counter-based keys.  rvt_run_blocks_async rejects skat_nperm > 0. */
 int rvt_rand_seed(rvt_ctx* ctx, unsigned seed);
+int rvt_set_perm_exact(rvt_ctx* ctx, int on);
 
 /* ---- related samples: FastLMM null + FamSKAT (`--kernel famSkat`) --------------------------------------------
  * rvt_set_kinship   installs the eigendecomposition of the kinship the caller already holds
@@ -560,6 +570,10 @@ int rvt_group_submit_gene_vcf(rvt_group* group, int64_t gene_id, int M, const ch
 int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const unsigned char* const* block,
                                const int64_t* block_len, int layout, uint32_t tests, const rvt_params* params,
                                double* af_out);
+/* SKAT permutations in a group: counter-based by default (any member takes any gene); rvt_group_set_perm_exact(g, 1)
+ * sends every permutation gene to member 0, which replays the reference's rand() stream (see rvt_set_perm_exact) */
+int rvt_group_set_perm_exact(rvt_group* group, int on);
+int rvt_group_rand_seed(rvt_group* group, unsigned seed);
 int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
 int rvt_group_collect_ready(rvt_group* group, rvt_gene_result* out, int cap, int* n_out); /* cf. rvt_collect_ready */
 /* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host

@@ -10,6 +10,7 @@
 #include <vector>
 #include <chrono>
 #include "host_stage.h"
+#include "perm_counter.h"
 #include "rvt_pvalue.h"
 #include "rvt_mvn.h"
 
@@ -159,6 +160,13 @@ double hc_mvn_band(const double* R, int n, double T, double* err) {
   return mvn_band_prob_serial(A.data(), n, T, y.data(), alpha.data(), err);
 }
 double hc_mvn_phiinv(double p) { return mvn_phiinv(p); }
+
+// ---- perm_counter.h: the keyed bijection of [0, n) the counter-based SKAT permutations use --------------------------------
+void hc_perm_indices(uint64_t seed, uint64_t gene, uint32_t shuffle, uint32_t n, uint32_t* out) {
+  const rvt::PermKeys pk = rvt::perm_keys(seed, gene, shuffle);
+  const int bits = rvt::perm_bits(n);
+  for (uint32_t i = 0; i < n; ++i) out[i] = rvt::perm_index(i, n, bits, pk);
+}
 
 // ---- host_stage.h: the copy pool and the staging ring that feed the device from pageable memory -------------------------
 // GB/s of `reps` copies of `bytes` bytes with a pool of `threads` threads (plain memory to plain memory: what the host

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "perm_counter.h"
 
 namespace rvt {
 
@@ -167,6 +168,104 @@ __global__ void perm_q_kernel(const double* __restrict__ C, const double* __rest
     s += u * u;
   }
   Q[p] = s;
+}
+
+// =====================================================================================================================
+// Counter-based mode (perm_counter.h): C = R_pi' G for a chunk of shuffles without ever storing a permutation or a
+// permuted residual vector.
+//   grid (sample slices, ceil(n_shuffles / 64)), one wave per workgroup: the wave owns 64 shuffles (4 row tiles of the
+//   fp64 matrix instruction) and, per pass, up to 64 variants (4 column tiles); it walks its sample slice in steps of 16
+//   samples.  A operand (16 shuffles x 4 samples) = r[pi_s(i)], one permutation evaluation and one gather from the
+//   L2-resident residual vector per lane; B operand (4 samples x 16 variants) = the flipped, polymorphic genotype block,
+//   each lane reading 4 consecutive samples (32 B) of its column per group of four steps, as the sufficient-statistics
+//   kernels do.  Partial products go to part[slice][shuffle][variant]; perm_counter_q_kernel adds the slices in a fixed
+//   order and forms Q = sum_j (w_j^1/2 C_sj)^2 (Skat.cpp:107-116).
+// =====================================================================================================================
+typedef double pc_d4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64, 2) void perm_counter_partial_kernel(
+    const double* __restrict__ G, long long ld, long long N, int m, const double* __restrict__ res,
+    unsigned long long seed, unsigned long long gene, unsigned shuffle0, int n_shuffles, int groups_per_slice,
+    int Mp, double* __restrict__ part) {
+  const int lane = threadIdx.x & 63, v = lane & 15, k = lane >> 4;
+  const int slice = blockIdx.x, bt = blockIdx.y;
+  const long long ngroups = (N + 15) >> 4;  // groups of 16 samples
+  const long long g0 = (long long)slice * groups_per_slice;
+  long long g1 = g0 + groups_per_slice;
+  if (g1 > ngroups) g1 = ngroups;
+  const int bits = perm_bits((unsigned long long)N);
+  PermKeys pk[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) pk[rt] = perm_keys(seed, gene, shuffle0 + (unsigned)(bt * 64 + rt * 16 + v));
+  for (int c0 = 0; c0 < Mp; c0 += 64) {  // (genes wider than 64 variants: the permutations are evaluated once per pass)
+    pc_d4_t acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = pc_d4_t{0.0, 0.0, 0.0, 0.0};
+    const double* col[4];
+    bool colok[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int j = c0 + ct * 16 + v;
+      colok[ct] = j < m;
+      col[ct] = G + (long long)(colok[ct] ? j : 0) * ld;
+    }
+    for (long long g = g0; g < g1; ++g) {
+      const long long i0 = g * 16 + (long long)k * 4;  // this lane's four consecutive samples
+      double b[4][4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[ct][t] = (colok[ct] && i0 + t < N) ? col[ct][i0 + t] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long long i = i0 + t;
+        const bool in = i < N;
+        double a[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const uint32_t src = perm_index((uint32_t)(in ? i : 0), (uint32_t)N, bits, pk[rt]);
+          a[rt] = in ? res[src] : 0.0;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct][t], acc[rt][ct], 0, 0, 0);
+      }
+    }
+    // D: row (shuffle) = rt * 16 + k + 4 i, column (variant) = ct * 16 + v
+    double* out = part + ((long long)slice * n_shuffles) * Mp;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int srow = bt * 64 + rt * 16 + k + 4 * i;
+        if (srow < n_shuffles) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const int j = c0 + ct * 16 + v;
+            if (j < Mp) out[(long long)srow * Mp + j] = acc[rt][ct][i];
+          }
+        }
+      }
+  }
+}
+
+// Q[s] = sum_j bw_j^2 (sum_slices part[slice][s][j])^2, slices in order
+__global__ void perm_counter_q_kernel(const double* __restrict__ part, int n_slices, int n_shuffles, int Mp, int m,
+                                      const double* __restrict__ bw, double* __restrict__ Q) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_shuffles) return;
+  double q = 0.0;
+  for (int j = 0; j < m; ++j) {
+    double c = 0.0;
+    for (int sl = 0; sl < n_slices; ++sl) c += part[((long long)sl * n_shuffles + s) * Mp + j];
+    const double w = bw[j] * c;
+    q += w * w;
+  }
+  Q[s] = q;
 }
 
 }  // namespace rvt

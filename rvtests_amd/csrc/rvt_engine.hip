@@ -184,6 +184,15 @@ struct rvt_ctx {
   // are resolved, so the error lands on the gene that caused it) + word kAfSlots for the synchronous calls.
   int* h_io_err = nullptr;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
+  // Permutation mode: exact = the reference's own rand() stream replayed (one sequential stream in gene order: bit-identical
+  // counters, ~3 k shuffles/s at N = 500 000); default = counter-based permutations keyed by (seed, gene id, shuffle)
+  // (perm_counter.h: statistical parity, any context / device / gene order, ~10^5 shuffles/s).  RVT_PERM_EXACT=1 or
+  // rvt_set_perm_exact.
+  bool perm_exact = false;
+  uint64_t perm_seed = 1;
+  double* d_pc_part = nullptr;  // counter mode: partial products [slice][shuffle][variant]
+  size_t pc_part_cap = 0;
+  double* d_pc_Q = nullptr;
   uint32_t rand_state[31];
   int64_t jump_N = -1;                 // J = A^(jump_N - 1) is cached for this sample count
   std::vector<uint32_t> jump;          // 31 x 31, row-major
@@ -604,6 +613,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
   seed_rand_state(c->rand_state, 1u);
   if (const char* e = getenv("RVT_HARDCALL")) c->hc_enabled = atoi(e) != 0;
   if (const char* e = getenv("RVT_STAGE")) c->stage_on = atoi(e) != 0;
+  if (const char* e = getenv("RVT_PERM_EXACT")) c->perm_exact = atoi(e) != 0;
   if (const char* e = getenv("RVT_TRACE_SUBMIT")) c->trace_submit = atoi(e) != 0;
   hipEventCreateWithFlags(&c->ev_io, hipEventDisableTiming);
   *out = c;
@@ -673,7 +683,7 @@ void rvt_destroy(rvt_ctx* c) {
     if (p) hipFree(p);
   if (c->d_famcov_nc) hipFree(c->d_famcov_nc);
   for (void* p : {(void*)c->d_perm_idx, (void*)c->d_perm_states, (void*)c->d_perm_R, (void*)c->d_perm_C,
-                  (void*)c->d_perm_Q, (void*)c->d_perm_cur})
+                  (void*)c->d_perm_Q, (void*)c->d_perm_cur, (void*)c->d_pc_part, (void*)c->d_pc_Q})
     if (p) hipFree(p);
   if (c->d_consol_af) hipFree(c->d_consol_af);
   if (c->d_consol_parts) hipFree(c->d_consol_parts);
@@ -3511,6 +3521,61 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)m), dim3(256), 0, st, d_cols + M, d_flags + M,
                      (long long)N, (long long)ld, c->d_Gp);
   const double* d_bw = gene_scratch_carve(g0.scratch, g0.Mp, g0.Cp).bw;  // sqrt of the SKAT weights, filtered order
+  if (!c->perm_exact) {
+    // ---- counter-based permutations (perm_counter.h): no stream shared between genes, nothing stored per shuffle ----------
+    constexpr int kChunk = 2048;
+    const int Mp = (m + 15) / 16 * 16;
+    const long long ngroups = (N + 15) / 16;
+    if (!c->d_pc_Q) HIP_TRY(c, hipMalloc((void**)&c->d_pc_Q, sizeof(double) * kChunk));
+    const double obs = r->skat_Q;
+    const double threshold = 1.0 * nPerm * prm.skat_alpha * 2;  // Permutation::init
+    int actual = 0, numX = 0, numEq = 0;
+    std::vector<double> Q(kChunk);
+    bool more = true;
+    while (more) {
+      if (actual >= nPerm || numX + numEq >= threshold) break;  // Permutation::next() before every shuffle
+      // the first chunk is short: a gene far from significance stops after ~2 threshold shuffles
+      const int want = actual == 0 ? std::min<int>(kChunk, (int)std::max(64.0, 2.5 * threshold)) : kChunk;
+      const int nb = std::min(want, nPerm - actual);
+      const int n_bt = (nb + 63) / 64;
+      // ~4096 waves per launch; a slice holds at least 64 groups of 16 samples
+      int slices = (int)std::max<long long>(1, std::min<long long>(4096 / n_bt, (ngroups + 63) / 64));
+      const int gps = (int)((ngroups + slices - 1) / slices);
+      slices = (int)((ngroups + gps - 1) / gps);
+      const size_t need = (size_t)slices * nb * Mp;
+      if (c->pc_part_cap < need) {
+        if (c->d_pc_part) hipFree(c->d_pc_part);
+        c->d_pc_part = nullptr;
+        c->pc_part_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_pc_part, sizeof(double) * (need + need / 4)));
+        c->pc_part_cap = need + need / 4;
+      }
+      hipLaunchKernelGGL(perm_counter_partial_kernel, dim3((unsigned)slices, (unsigned)n_bt), dim3(64), 0, st, c->d_Gp,
+                         (long long)ld, (long long)N, m, c->d_res, (unsigned long long)c->perm_seed,
+                         (unsigned long long)r->gene_id, (unsigned)actual, nb, gps, Mp, c->d_pc_part);
+      hipLaunchKernelGGL(perm_counter_q_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, c->d_pc_part, slices,
+                         nb, Mp, m, d_bw, c->d_pc_Q);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipMemcpyAsync(Q.data(), c->d_pc_Q, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, sync_stream(st));
+      for (int u = 0; u < nb; ++u) {
+        if (actual >= nPerm || numX + numEq >= threshold) {
+          more = false;
+          break;
+        }
+        ++actual;  // Permutation::add
+        if (Q[u] > obs) ++numX;
+        if (Q[u] == obs) ++numEq;
+      }
+    }
+    r->perm_ok = 1;
+    r->perm_num_perm = nPerm;
+    r->perm_actual_perm = actual;
+    r->perm_num_greater = numX;
+    r->perm_num_equal = numEq;
+    r->perm_pvalue = actual == 0 ? 1.0 : 1.0 * (numX + 0.5 * numEq) / actual;
+    return RVT_OK;
+  }
   // chunk buffers
   const int B = std::max(1, std::min(nPerm, (int)std::min<int64_t>(2048, ((int64_t)6 << 30) / (8 * N))));
   if ((size_t)N * B > c->perm_cap_NB || B > c->perm_cap_B || (size_t)B * m > c->perm_cap_BM) {
@@ -3828,6 +3893,13 @@ int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* 
 int rvt_rand_seed(rvt_ctx* c, unsigned seed) {
   if (!c) return RVT_E_INVALID;
   seed_rand_state(c->rand_state, seed);
+  c->perm_seed = seed;
+  return RVT_OK;
+}
+
+int rvt_set_perm_exact(rvt_ctx* c, int on) {
+  if (!c) return RVT_E_INVALID;
+  c->perm_exact = on != 0;
   return RVT_OK;
 }
 

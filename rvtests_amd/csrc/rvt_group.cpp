@@ -11,6 +11,7 @@
 //
 // Plain host C++ over the single-device C ABI; nothing here touches HIP directly.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -23,6 +24,7 @@ struct rvt_group {
   std::deque<int> owner;       // member of every submitted, not yet collected gene, in submission order
   std::vector<std::deque<rvt_gene_result>> inbox;  // records already taken from a member, waiting for their turn
   long long submitted = 0;     // genes dealt so far (decides the member of the next one)
+  bool perm_exact = false;     // SKAT permutations replay ONE rand() stream (member 0 only) instead of counter-based keys
   std::string err;
 };
 
@@ -35,7 +37,8 @@ int gfail(rvt_group* g, int code, const char* what, rvt_ctx* c) {
 }
 
 int next_member(rvt_group* g, const rvt_params* prm, uint32_t tests) {
-  if (prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) return 0;
+  // (counter-based permutations are keyed by gene: any member; the exact mode consumes one stream in gene order)
+  if (g->perm_exact && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) return 0;
   return (int)((g->submitted / kRun) % (long long)g->member.size());
 }
 }  // namespace
@@ -57,7 +60,22 @@ int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
     g->member.push_back(c);
   }
   g->inbox.resize(g->member.size());
+  if (const char* e = getenv("RVT_PERM_EXACT")) g->perm_exact = atoi(e) != 0;
   *out = g;
+  return RVT_OK;
+}
+
+int rvt_group_set_perm_exact(rvt_group* g, int on) {
+  if (!g) return RVT_E_INVALID;
+  if (!g->owner.empty()) return gfail(g, RVT_E_STATE, "collect the submitted genes before changing the permutation mode", nullptr);
+  g->perm_exact = on != 0;
+  for (rvt_ctx* m : g->member) rvt_set_perm_exact(m, on);
+  return RVT_OK;
+}
+
+int rvt_group_rand_seed(rvt_group* g, unsigned seed) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member) rvt_rand_seed(m, seed);
   return RVT_OK;
 }
 

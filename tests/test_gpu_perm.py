@@ -1,5 +1,7 @@
-"""SKAT permutation p-values through the C ABI against the oracle: same emulated glibc rand() stream, so the
-permutations — and with them ActualPerm / NumGreater / NumEqual — are identical, gene after gene."""
+"""SKAT permutation p-values through the C ABI.  Exact mode (rvt_set_perm_exact): the same emulated glibc rand() stream as
+the oracle, so the permutations — and with them ActualPerm / NumGreater / NumEqual — are identical, gene after gene.
+Counter-based mode (the default): other random numbers, the same estimator — compared with the exact mode within binomial
+error."""
 import numpy as np
 import pytest
 
@@ -36,6 +38,7 @@ def test_permutation_counts_match_oracle(eng, N, n_perm, alpha):
     eng.set_null(0, X, res, v, s2)
     prm = rvtests_amd.Params(1.0, 25.0, 1.0, 25.0, n_perm, alpha)
     ptrs = [eng.upload_block(G) for G, af in genes]
+    eng.set_perm_exact(True)
     eng.rand_seed(1)
     out = eng.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes],
                          tests=rvtests_amd.TEST_SKAT, params=prm)
@@ -55,3 +58,45 @@ def test_permutation_counts_match_oracle(eng, N, n_perm, alpha):
         assert r.perm_pvalue == p.pvalue
         stopped_early += p.actual_perm < n_perm
     assert stopped_early >= 1          # the adaptive stop was exercised
+
+
+def test_counter_based_mode_agrees_with_the_exact_mode_within_binomial_error(eng):
+    """200 null genes, N = 2000: permutation p-values of the counter-based mode against the replay of the reference's
+    stream — two Monte-Carlo estimates of the same tail probability, so their difference scales with the binomial
+    standard errors; and against the analytic SKAT p-value (both modes estimate it)."""
+    import rvtests_amd
+    N, d, n_genes, n_perm, alpha = 2000, 2, 200, 2000, 0.05
+    rng = np.random.default_rng(99)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=21)
+    eng.set_null(0, X, res, v, s2)
+    genes = []
+    for g in range(n_genes):
+        M = int(rng.integers(3, 40))
+        G = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.3, -0.8, M), size=(N, M)).astype(np.float64))
+        genes.append((G, G.sum(0) / (2.0 * N)))
+    ptrs = [eng.upload_block(G) for G, af in genes]
+    prm = rvtests_amd.Params(1.0, 25.0, 1.0, 25.0, n_perm, alpha)
+    Ms, afs = [G.shape[1] for G, af in genes], [af for G, af in genes]
+    eng.set_perm_exact(True)
+    eng.rand_seed(1)
+    exact = eng.run_blocks(ptrs, Ms, afs, tests=rvtests_amd.TEST_SKAT, params=prm)
+    eng.set_perm_exact(False)
+    eng.rand_seed(1)
+    cb = eng.run_blocks(ptrs, Ms, afs, tests=rvtests_amd.TEST_SKAT, params=prm, ids=list(range(100, 100 + n_genes)))
+    cb2 = eng.run_blocks(ptrs[::-1], Ms[::-1], afs[::-1], tests=rvtests_amd.TEST_SKAT, params=prm,
+                         ids=list(range(100, 100 + n_genes))[::-1])[::-1]
+    z = []
+    for a, b, b2 in zip(exact, cb, cb2):
+        assert a.perm_ok and b.perm_ok
+        # keyed by gene id: the order of the genes does not matter
+        assert (b.perm_actual_perm, b.perm_num_greater, b.perm_pvalue) == (b2.perm_actual_perm, b2.perm_num_greater, b2.perm_pvalue)
+        pa, pb = a.perm_pvalue, b.perm_pvalue
+        se = np.sqrt(pa * (1 - pa) / a.perm_actual_perm + pb * (1 - pb) / b.perm_actual_perm) + 1e-9
+        z.append((pb - pa) / se)
+    z = np.array(z)
+    assert abs(z.mean()) < 0.25 and 0.7 < z.std() < 1.35 and (np.abs(z) > 4).sum() == 0, (z.mean(), z.std(), np.abs(z).max())
+    # both estimate the analytic p-value (Davies): no systematic offset of the counter-based estimates
+    dev = np.array([(b.perm_pvalue - b.skat_p) for b in cb])
+    assert abs(dev.mean()) < 0.02
+    for p in ptrs:
+        eng.free_block(p)
