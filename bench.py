@@ -471,7 +471,7 @@ def main():
         key = "N=%d,genes=%d,m=%d..%d,seed=20260002,tests=%d" % (N, args.genes, args.m_lo, args.m_hi, args.tests)
         if binary:
             key += ",binary"
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             k2 = pmc["kernels"].get("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat")

@@ -19,7 +19,7 @@ stats famskat_dense python3 tools/bench_famskat.py --samples 100000 --genes 128 
 stats famskat_shuffled python3 tools/bench_famskat.py --samples 100000 --genes 128 --shuffle
 stats metascore python3 tools/bench_metascore.py
 stats metacov python3 tools/bench_metacov.py --reps 5
-stats perm python3 tools/bench_perm.py
+stats perm python3 tools/bench_perm.py --genes 4
 stats stream_bed python3 tools/bench_stream.py --bed --genes 512
 python3 tools/bench_decompose.py --samples 3000 --kind grm > "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 12000 --kind family >> "$OUT/decompose.txt" 2>&1
@@ -30,6 +30,11 @@ done
 ./tools/k2hc_bench bench > "$OUT/k2hc_isolated.txt" 2>&1
 ./tools/k2hcw_bench > "$OUT/k2hcw_isolated.txt" 2>&1
 ./tools/rotgemm_bench bench > "$OUT/rotgemm.txt" 2>&1
+python3 tools/bench_perm.py --genes 8 > "$OUT/perm_result.txt" 2>&1
+python3 tools/bench_perm.py --genes 2 --alpha 1 --nperm 16384 >> "$OUT/perm_result.txt" 2>&1
+python3 tools/bench_perm.py --genes 1 --exact >> "$OUT/perm_result.txt" 2>&1
+python3 tools/bench_group_stream.py > "$OUT/group_stream.txt" 2>&1
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --missing-frac 1.0 > "$OUT/bench_missing_all.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1 > "$OUT/bench_config1.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --trait binary --samples 200000 > "$OUT/bench_config3_binary.json" 2>/dev/null
 ls -la "$OUT"
