@@ -287,6 +287,8 @@ int rvt_score_block(rvt_ctx* ctx, const double* dG, int V, int* ok, double* usta
  * covB = (X'X)^-1 sigma2, regression/LinearRegression.cpp:62-66; LogisticRegression covB = (X'WX)^-1,
  * regression/LogisticRegression.cpp:330-334) and sigma2 (quantitative; 1 for a binary trait).  beta / sigma2 may be
  * NULL. */
+/* dimensions of the installed null model: samples, columns of X (with the intercept) */
+int rvt_null_dims(rvt_ctx* ctx, int64_t* N, int* d);
 int rvt_null_summary(rvt_ctx* ctx, double* beta, double* covb_diag, double* sigma2);
 /* MetaScore with kinship (MetaFamQtl, src/Model.h:3398-3499; MetaFamBinary, :3556-3668): FastLMM::TestCovariate in its
  * SCORE branch (regression/FastLMM.cpp:215-247) and FastLMM::FastGetAF (:400-424) of every raw column of a device
@@ -574,6 +576,18 @@ int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const u
  * sends every permutation gene to member 0, which replays the reference's rand() stream (see rvt_set_perm_exact) */
 int rvt_group_set_perm_exact(rvt_group* group, int on);
 int rvt_group_rand_seed(rvt_group* group, unsigned seed);
+/* `--meta score` / `--meta cov` over a group (chunks with a one-window halo, no exchange).  G_host: N x V
+ * column-major (leading dimension N), the genotype vectors of V consecutive single-variant fit() calls; one host thread per
+ * member for the duration of the call.
+ *   rvt_group_score_block_host  outputs as rvt_score_block (V entries each); the columns are cut into one share per member
+ *   rvt_group_cov_band_host     band[h * (halo + 1) + t] = the value of head h and marker h + t as rvt_cov_rect gives it
+ *                               (t = 0 .. halo; NaN beyond the last variant); heads are dealt in chunks (chunk = 0: a
+ *                               default) to the members in turn, every chunk's device block holds its heads and the
+ *                               `halo` columns behind them.  xz: V x d, zz: d x d (may be NULL), polymorphic: V. */
+int rvt_group_score_block_host(rvt_group* group, int64_t N, int V, const double* G_host, int* ok, double* ustat,
+                               double* vstat, double* effect, double* effect_se, double* pvalue);
+int rvt_group_cov_band_host(rvt_group* group, int64_t N, int V, const double* G_host, int halo, int chunk, double* band,
+                            double* xz, double* zz, int* polymorphic);
 int rvt_group_collect(rvt_group* group, rvt_gene_result* out, int cap, int* n_out);
 int rvt_group_collect_ready(rvt_group* group, rvt_gene_result* out, int cap, int* n_out); /* cf. rvt_collect_ready */
 /* related samples: the kinship decomposition is replicated on every member (6 N^2 bytes each); rvt_group_run_fam_tests_host

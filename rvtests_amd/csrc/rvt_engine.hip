@@ -4012,6 +4012,14 @@ int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat,
   return RVT_OK;
 }
 
+int rvt_null_dims(rvt_ctx* c, int64_t* N, int* d) {
+  if (!c) return RVT_E_INVALID;
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (N) *N = c->nc.N;
+  if (d) *d = c->nc.d;
+  return RVT_OK;
+}
+
 int rvt_null_summary(rvt_ctx* c, double* beta, double* covb_diag, double* sigma2) {
   if (!c || !covb_diag) return fail(c, RVT_E_INVALID, "bad arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");

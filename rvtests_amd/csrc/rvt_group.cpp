@@ -11,6 +11,7 @@
 //
 // Plain host C++ over the single-device C ABI; nothing here touches HIP directly.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -278,6 +279,100 @@ int rvt_group_run_fam_tests_host(rvt_group* g, int n_genes, const double* const*
   for (std::thread& t : workers) t.join();
   for (int k = 0; k < nm; ++k)
     if (rcs[k]) return gfail(g, rcs[k], "rvt_run_fam_tests", g->member[k]);
+  return RVT_OK;
+}
+
+// ---- `--meta score` / `--meta cov` over a device group ("shard by chromosome / chunk with one-window halo
+// overlap": every chunk carries the columns its windows reach into, so the chunks are independent and nothing is
+// exchanged) ------------------------------------------------------------------------------------------------------------
+// G_host: N x V column-major (leading dimension N), the genotype vectors of V consecutive single-variant fit() calls.
+// One host thread per member for the duration of the call; each context is used by exactly one thread.
+
+// MetaScore: the V columns are cut into contiguous shares, one per member; outputs as rvt_score_block (V entries each).
+int rvt_group_score_block_host(rvt_group* g, int64_t N, int V, const double* G_host, int* ok, double* ustat, double* vstat,
+                               double* effect, double* effect_se, double* pvalue) {
+  if (!g || N < 1 || V < 1 || !G_host || !ok || !ustat || !vstat || !effect || !effect_se || !pvalue) return RVT_E_INVALID;
+  const int nm = (int)g->member.size();
+  std::vector<int> rcs(nm, RVT_OK);
+  std::vector<std::thread> workers;
+  for (int k = 0; k < nm; ++k) {
+    const int c0 = (int)((long long)V * k / nm), c1 = (int)((long long)V * (k + 1) / nm);
+    if (c1 <= c0) continue;
+    rvt_ctx* m = g->member[k];
+    workers.emplace_back([=, &rcs]() {
+      int rc = RVT_OK;
+      constexpr int kBlock = 4096;  // columns per device block
+      for (int b0 = c0; b0 < c1 && !rc; b0 += kBlock) {
+        const int nb = std::min(kBlock, c1 - b0);
+        double* blk = nullptr;
+        rc = rvt_block_alloc(m, nb, &blk);
+        if (!rc) rc = rvt_block_upload(m, blk, nb, G_host + (size_t)b0 * (size_t)N);
+        if (!rc) rc = rvt_score_block(m, blk, nb, ok + b0, ustat + b0, vstat + b0, effect + b0, effect_se + b0, pvalue + b0);
+        if (blk) rvt_block_free(m, blk);
+      }
+      rcs[k] = rc;
+    });
+  }
+  for (std::thread& t : workers) t.join();
+  for (int k = 0; k < nm; ++k)
+    if (rcs[k]) return gfail(g, rcs[k], "rvt_score_block", g->member[k]);
+  return RVT_OK;
+}
+
+// MetaCov: the band of the V variants with up to `halo` following markers per head (the caller's window rule never looks
+// further: halo = the largest number of sites one window holds).  band[h * (halo + 1) + t] = the value of head h and
+// marker h + t as rvt_cov_block / rvt_cov_rect give it (t = 0 .. halo, NaN beyond the last variant); xz: V x d as
+// rvt_cov_block; polymorphic: V.  Heads are dealt in chunks of `chunk` (0 = default) to the members in turn; a chunk's
+// device block holds its heads AND the halo behind them, so every chunk is computed on its own.
+int rvt_group_cov_band_host(rvt_group* g, int64_t N, int V, const double* G_host, int halo, int chunk, double* band,
+                            double* xz, double* zz, int* polymorphic) {
+  if (!g || N < 1 || V < 1 || !G_host || halo < 0 || !band || !xz || !polymorphic) return RVT_E_INVALID;
+  const int nm = (int)g->member.size();
+  if (chunk <= 0) chunk = std::max(256, std::min(1024, (V + nm - 1) / nm));
+  const int n_chunks = (V + chunk - 1) / chunk;
+  const size_t bw = (size_t)halo + 1;
+  std::vector<int> rcs(nm, RVT_OK);
+  std::vector<int> dcov(nm, 0);
+  std::vector<std::thread> workers;
+  for (int k = 0; k < nm; ++k) {
+    rvt_ctx* m = g->member[k];
+    workers.emplace_back([=, &rcs, &dcov]() {
+      int rc = RVT_OK;
+      std::vector<double> cov, xzc;
+      std::vector<int> poly;
+      for (int ch = k; ch < n_chunks && !rc; ch += nm) {
+        const int h0 = ch * chunk, H = std::min(chunk, V - h0), W = std::min(V - h0, H + halo);
+        double* blk = nullptr;
+        rc = rvt_block_alloc(m, W, &blk);
+        if (!rc) rc = rvt_block_upload(m, blk, W, G_host + (size_t)h0 * (size_t)N);
+        cov.assign((size_t)H * W, 0.0);
+        poly.assign((size_t)W, 0);
+        // (covariate count: the xz rows are d wide; rvt_cov_rect writes W x d, so size for the widest d)
+        xzc.assign((size_t)W * RVT_MAX_COV, 0.0);
+        std::vector<double> zzc((size_t)RVT_MAX_COV * RVT_MAX_COV, 0.0);
+        if (!rc) rc = rvt_cov_rect(m, blk, 0, H, W, cov.data(), xzc.data(), zzc.data(), poly.data());
+        if (blk) rvt_block_free(m, blk);
+        if (rc) break;
+        int64_t Nm = 0;
+        int d = 0;
+        rvt_null_dims(m, &Nm, &d);  // columns of the installed design matrix (xz rows are d wide)
+        dcov[k] = d;
+        for (int h = 0; h < H; ++h) {
+          for (size_t t = 0; t < bw; ++t) {
+            const int j = h + (int)t;
+            band[(size_t)(h0 + h) * bw + t] = (j < W) ? cov[(size_t)h + (size_t)j * H] : (0.0 / 0.0);
+          }
+          polymorphic[h0 + h] = poly[h];
+          for (int c = 0; c < d; ++c) xz[(size_t)(h0 + h) * d + c] = xzc[(size_t)h * d + c];
+        }
+        if (zz && ch == 0) std::memcpy(zz, zzc.data(), sizeof(double) * (size_t)d * d);
+      }
+      rcs[k] = rc;
+    });
+  }
+  for (std::thread& t : workers) t.join();
+  for (int k = 0; k < nm; ++k)
+    if (rcs[k]) return gfail(g, rcs[k], "rvt_cov_rect", g->member[k]);
   return RVT_OK;
 }
 

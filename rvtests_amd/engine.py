@@ -900,6 +900,33 @@ class Group:
         self._check(self.L.rvt_group_submit_gene_bgen(self.g, int(gene_id), M, ptr, blen, int(layout), int(tests),
                                                       C.byref(prm), None))
 
+    def score_block_host(self, G):
+        """--meta score over the group: G is the host N x V matrix of consecutive sites (rvt_group_score_block_host)."""
+        G = np.asfortranarray(G, dtype=np.float64)
+        N, V = G.shape
+        ok = np.zeros(V, dtype=np.int32)
+        outs = [np.zeros(V) for _ in range(5)]
+        self.L.rvt_group_score_block_host.restype = C.c_int
+        self.L.rvt_group_score_block_host.argtypes = [C.c_void_p, C.c_int64, C.c_int, c_double_p, c_int_p] + [c_double_p] * 5
+        self._check(self.L.rvt_group_score_block_host(self.g, N, V, _dp(G), ok.ctypes.data_as(c_int_p),
+                                                      *[_dp(o) for o in outs]))
+        return (ok,) + tuple(outs)
+
+    def cov_band_host(self, G, d, halo, chunk=0):
+        """--meta cov over the group: band[h, t] = value of head h and marker h + t (rvt_group_cov_band_host)."""
+        G = np.asfortranarray(G, dtype=np.float64)
+        N, V = G.shape
+        band = np.zeros((V, halo + 1))
+        xz = np.zeros((V, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(V, dtype=np.int32)
+        self.L.rvt_group_cov_band_host.restype = C.c_int
+        self.L.rvt_group_cov_band_host.argtypes = [C.c_void_p, C.c_int64, C.c_int, c_double_p, C.c_int, C.c_int, c_double_p,
+                                                   c_double_p, c_double_p, c_int_p]
+        self._check(self.L.rvt_group_cov_band_host(self.g, N, V, _dp(G), int(halo), int(chunk), _dp(band), _dp(xz), _dp(zz),
+                                                   poly.ctypes.data_as(c_int_p)))
+        return band, xz, zz, poly
+
     def collect(self, cap=4096):
         out = (GeneResult * cap)()
         n = C.c_int(0)

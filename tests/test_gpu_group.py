@@ -118,3 +118,41 @@ def test_group_bgen_stream_matches_single_context(engine):
     for a, b in zip(got, ref):
         for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "n_poly", "status"):
             assert getattr(a, f) == getattr(b, f), f
+
+
+def test_group_meta_score_and_cov_band_equal_the_single_context(engine):
+    """`--meta score` / `--meta cov` over a 2-member group (both on device 0): shares / chunks with a one-window halo,
+    no exchange — the numbers of the single-context calls on the whole block."""
+    import rvtests_amd
+    N, V, d, halo = 3001, 700, 3, 150
+    rng = np.random.default_rng(12)
+    G = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.5, -0.6, V), size=(N, V)).astype(np.float64))
+    G[:, 5] = 0.0                                           # a monomorphic site
+    G[rng.random(N) < 0.01, 9] = G[:, 9].mean()             # an imputed column
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=9)
+    engine.fit_null(0, X, y)
+    ptr = engine.upload_block(G)
+    sc = engine.score_block(ptr, V)
+    ok0, u0, v0, e0, se0, p0 = sc["ok"], sc["U"], sc["V"], sc["effect"], sc["se"], sc["p"]
+    cov0, xz0, zz0, poly0 = engine.cov_block(ptr, V)
+    engine.free_block(ptr)
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        grp.fit_null(0, X, y)
+        ok, u, vv, e, se, p = grp.score_block_host(G)
+        band, xz, zz, poly = grp.cov_band_host(G, d, halo, chunk=200)
+    finally:
+        grp.close()
+    assert (ok == ok0).all() and (poly == poly0).all()
+    good = ok0 == 1
+    for a, b in ((u, u0), (vv, v0), (e, e0), (se, se0), (p, p0)):
+        assert np.allclose(a[good], b[good], rtol=1e-11, atol=0)
+    scale = np.nanmax(np.abs(cov0[np.triu_indices(V)]))
+    for h in range(V):
+        for t in range(halo + 1):
+            j = h + t
+            if j >= V:
+                assert np.isnan(band[h, t])
+            else:
+                assert abs(band[h, t] - cov0[h, j]) <= 1e-9 * scale, (h, j)
+    assert np.allclose(xz, xz0, rtol=1e-9, atol=1e-9 * max(np.abs(xz0).max(), 1.0)) and np.allclose(zz, zz0, rtol=1e-12)
