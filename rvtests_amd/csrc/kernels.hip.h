@@ -273,9 +273,21 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
   if (!gd.bparts) continue;  // (uniform over the workgroup)
   constexpr int NV = 2 * (3 + DMAX);
   __shared__ double red[4][NV];
+  __shared__ int kcol[RVT_MAX_VARIANTS];  // kept (polymorphic) columns: index | flip << 30
+  __shared__ int nkept;
   const int tid = threadIdx.x;
   {
   const int part = (int)(item % n_wparts);
+  if (tid == 0) {  // (one pass over <= 96 flag bits; the sample loop below then touches no flag)
+    int m = 0;
+    for (int j = 0; j < gd.M; ++j) {
+      const int b = j >> 4, bit = j & 15;
+      if ((gd.flags[gd.MT + b] >> bit) & 1) kcol[m++] = j | (((gd.flags[b] >> bit) & 1) << 30);
+    }
+    nkept = m;
+  }
+  __syncthreads();
+  const int m_kept = nkept;
   const long long s0 = (long long)part * gd.steps_per_wpart * 16;
   long long s1 = s0 + (long long)gd.steps_per_wpart * 16;
   if (s1 > N) s1 = N;
@@ -284,12 +296,18 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
   for (int k = 0; k < NV; ++k) val[k] = 0.0;
   for (long long i = s0 + tid; i < s1; i += 256) {
     int n = 0;
-    for (int j = 0; j < gd.M; ++j) {
-      const int b = j >> 4, bit = j & 15;
-      if (!((gd.flags[gd.MT + b] >> bit) & 1)) continue;
-      const double g = gd.G[(long long)j * ld + i];
-      const double gf = ((gd.flags[b] >> bit) & 1) ? 2.0 - g : g;
-      n += ((int)gf > 0) ? 1 : 0;
+    int a = 0;
+    for (; a + 4 <= m_kept; a += 4) {  // four independent loads in flight
+      const int c0 = kcol[a], c1 = kcol[a + 1], c2 = kcol[a + 2], c3 = kcol[a + 3];
+      const double g0 = gd.G[(long long)(c0 & 0x3fffffff) * ld + i], g1 = gd.G[(long long)(c1 & 0x3fffffff) * ld + i],
+                   g2 = gd.G[(long long)(c2 & 0x3fffffff) * ld + i], g3 = gd.G[(long long)(c3 & 0x3fffffff) * ld + i];
+      n += ((int)((c0 >> 30) ? 2.0 - g0 : g0) > 0) + ((int)((c1 >> 30) ? 2.0 - g1 : g1) > 0) +
+           ((int)((c2 >> 30) ? 2.0 - g2 : g2) > 0) + ((int)((c3 >> 30) ? 2.0 - g3 : g3) > 0);
+    }
+    for (; a < m_kept; ++a) {
+      const int c0 = kcol[a];
+      const double g0 = gd.G[(long long)(c0 & 0x3fffffff) * ld + i];
+      n += ((int)((c0 >> 30) ? 2.0 - g0 : g0) > 0);
     }
     const double cv[2] = {n > 0 ? 1.0 : 0.0, (double)n};
     const double r = nd.res[i], w = binary ? nd.v[i] : 1.0;
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT)};
+  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), gd.dS};
   // a hard-call gene that was handed back holds the general kernel's statistics (three rows per wave-part, G'DG itself)
   const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
   const bool masks = gd.hc == 1 && !handed_back;  // (pq is null for the weighted hard-call kernel: no masked tiles)
