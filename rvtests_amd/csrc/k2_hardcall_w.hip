@@ -19,8 +19,4 @@ void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nu
   }
 }
 
-void k2_launch_hcw_correct(int n_genes, hipStream_t st, const GeneDesc* d_desc, const double* v, long long ld) {
-  hipLaunchKernelGGL(hcw_mask_correct_kernel<0>, dim3(kHcwCorrSplit, (unsigned)n_genes), dim3(256), 0, st, d_desc, v, ld);
-}
-
 }  // namespace rvt

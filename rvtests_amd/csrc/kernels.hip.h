@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), gd.dS};
+  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT)};
   // a hard-call gene that was handed back holds the general kernel's statistics (three rows per wave-part, G'DG itself)
   const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
   const bool masks = gd.hc == 1 && !handed_back;  // (pq is null for the weighted hard-call kernel: no masked tiles)

@@ -33,7 +33,6 @@ void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nul
 void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
                    int d);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
-void k2_launch_hcw_correct(int n_genes, hipStream_t st, const GeneDesc* d_desc, const double* v, long long ld);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
 #include "rot_gemm.hip.h"
@@ -1116,15 +1115,11 @@ int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp
 
 // Arena layout of one gene of a batch (shared by run_batch and rvt_reserve).
 struct GeneOff {
-  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, vt, dbg_flip, dbg_kept, pq, wflags, mlist,
-      mcount;
-  unsigned mlist_cap;
+  size_t parts, colstat, masks, flags, bparts, scratch, lambda, qags, stats, vt, dbg_flip, dbg_kept, pq, wflags;
 };
 // hc: 1 = hard-call path (no mask planes, burden records per wave-part), 0 = general path, -1 = either (rvt_reserve)
-// weighted: a binary trait's hard-call genes list their masked entries (suffstat_hcw.hip.h) instead of counting them in
-// LDS tiles: room for 1/32 of a wave-part's entries (>= 64 pairs); a wave-part with more hands the gene back
 static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts, bool dbg, int hc, size_t* total,
-                        GeneOff* o, bool vt = false, bool weighted = false, int steps_per = 0) {
+                        GeneOff* o, bool vt = false) {
   auto add = [&](size_t bytes) {
     *total = (*total + 255) / 256 * 256;
     const size_t at = *total;
@@ -1135,16 +1130,10 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
   o->parts = add(sizeof(double) * (size_t)n_wparts * Mp * Cp);
   o->colstat = add(sizeof(double) * (size_t)n_wparts * (hc == 0 ? 3 : kHcColstatRows) * Mp);
   o->masks = (hc == 1) ? 0 : add(sizeof(unsigned long long) * (size_t)2 * nsteps * MT * 4);
-  o->pq = o->wflags = o->mlist = o->mcount = 0;
-  o->mlist_cap = 0;
+  o->pq = o->wflags = 0;
   if (hc != 0 && MT <= kHcMaxMT) {  // packed counters of the masked tiles + flags, per wave-part (suffstat_hc.hip.h)
-    if (!weighted) o->pq = add(sizeof(unsigned) * (size_t)n_wparts * hc_pq_words(MT));
+    o->pq = add(sizeof(unsigned) * (size_t)n_wparts * hc_pq_words(MT));
     o->wflags = add(sizeof(unsigned) * (size_t)n_wparts);
-    if (weighted && MT <= kHcwMaxMT) {
-      o->mlist_cap = (unsigned)std::max<long long>(64, (long long)steps_per * 16 * M / 32);
-      o->mlist = add(sizeof(unsigned) * 2 * (size_t)n_wparts * o->mlist_cap);
-      o->mcount = add(sizeof(unsigned) * (size_t)n_wparts);
-    }
   }
   o->flags = add(sizeof(unsigned short) * (2 * MT + 2));
   const int nb = (hc == 1) ? n_wparts : (hc == 0 ? n_bparts : std::max(n_bparts, n_wparts));
@@ -1256,7 +1245,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
         if (af[af_total + j] > 0.5) gd.pflip[j >> 4] |= (unsigned short)(1u << (j & 15));
     }
     layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc, &total, &offs[g],
-                (tests & RVT_TEST_ANALYTICVT) != 0, hcw && !cov, steps_per);
+                (tests & RVT_TEST_ANALYTICVT) != 0);
     af_total += M;
   }
   const size_t off_af = add(sizeof(double) * af_total);
@@ -1265,17 +1254,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   // device work lists of the hard-call genes (gene_flags_hc_kernel): [0] handed back, [1] burden sums to redo, then
   // the two index lists
   const size_t off_lists = add(sizeof(int) * (4 + 2 * (size_t)std::max(n_hc, 1)));
-  // weighted hard-call genes: fixed-point corrections of G'VG for the masked entries, Mp x Mp each, zeroed per batch
-  std::vector<size_t> ds_off(n, 0);
-  size_t ds_bytes = 0;
-  if (hcw && !cov) {
-    for (int g = 0; g < n; ++g)
-      if (desc[g].hc) {
-        ds_off[g] = ds_bytes;
-        ds_bytes += sizeof(long long) * (size_t)desc[g].Mp * desc[g].Mp;
-      }
-  }
-  const size_t off_ds = ds_bytes ? add(ds_bytes) : 0;
   size_t off_cov = 0, off_cov_xz = 0, off_cov_cs = 0, off_cov_poly = 0, off_cov_bur = 0, off_cov_ok = 0;
   if (cov && cov->score) {  // one gene per 16-column slice of the block: per-variant records only
     size_t vt = 0;
@@ -1313,10 +1291,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
     gd.pq = (gd.hc && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
     gd.wflags = (gd.hc && o.wflags) ? reinterpret_cast<unsigned*>(base + o.wflags) : nullptr;
-    gd.mlist = (gd.hc && o.mlist) ? reinterpret_cast<unsigned*>(base + o.mlist) : nullptr;
-    gd.mcount = (gd.hc && o.mcount) ? reinterpret_cast<unsigned*>(base + o.mcount) : nullptr;
-    gd.mlist_cap = o.mlist_cap;
-    gd.dS = (gd.hc && gd.mlist && ds_bytes) ? reinterpret_cast<long long*>(base + off_ds + ds_off[g]) : nullptr;
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
     gd.scratch = reinterpret_cast<double*>(base + o.scratch);
@@ -1388,7 +1362,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     launch_suffstat(c, gst, grp, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
-  if (ds_bytes) HIP_TRY(c, hipMemsetAsync(base + off_ds, 0, ds_bytes, c->k2_stream));
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
     while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
@@ -1422,8 +1395,6 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     for (int k = n_gen; k < n; ++k) grp_present[suffstat_group(h_desc[k].MT, h_desc[k].CT, nc.binary != 0)] = true;
     for (int grp = 0; grp < 3; ++grp)
       if (grp_present[grp]) launch_suffstat(c, st, grp, d_desc + n_gen, n_hc, n_wparts, nd, d_lists);
-    // weighted kernel: the listed masked entries' share of G'VG (workgroups of genes without any leave at once)
-    if (ds_bytes) k2_launch_hcw_correct(n_hc, st, d_desc + n_gen, c->d_v, (long long)ld);
   }
   if (cov && cov->score) {  // MetaScore: per-variant statistics of every slice, returned synchronously
     size_t vt = 0;
@@ -1630,15 +1601,10 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   GeneOff o;
   for (int g = 0; g < n; ++g) {
     if (Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, Ms[g]);
-    layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, -1, &total, &o, false,
-                nc.binary != 0 && c->d_nulltile_w != nullptr && c->d_vq != nullptr, steps_per);
+    layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, -1, &total, &o);
     af_total += (size_t)Ms[g];
   }
   total += sizeof(double) * af_total + sizeof(GeneDesc) * n + sizeof(rvt_gene_result) * n + 4 * 256;
-  total += sizeof(int) * (4 + 2 * (size_t)n) + 256;  // the work lists of the hard-call genes
-  if (nc.binary && c->d_nulltile_w && c->d_vq)       // ... and the weighted kernel's fixed-point corrections
-    for (int g = 0; g < n; ++g) total += sizeof(long long) * (size_t)((Ms[g] + 15) / 16 * 16) * ((Ms[g] + 15) / 16 * 16);
-  total += 512;
   const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
   for (int i = 0; i < kSlots; ++i) {  // (the re-run slot grows on demand)
     Slot& sl = c->slots[i];

@@ -112,9 +112,6 @@ struct HcMasked {
   const unsigned* pq;      // P x pq_words packed counters ([tile][half][lane], tiles: P' MT x MT, then Q upper triangle)
   const unsigned* wflags;  // P flags: bit 0 = the part's image was written
   int pq_words;
-  // weighted hard-call kernel (suffstat_hcw.hip.h) instead of pq: the masked entries' share of G'VG, Mp x Mp row-major,
-  // 64-bit fixed point with 42 fractional bits (hcw_mask_correct_kernel)
-  const long long* dS = nullptr;
 };
 constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 
@@ -236,18 +233,6 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
         const double pij = Pp[(size_t)i * Mp + j] - 4.0 * q, pji = Pp[(size_t)j * Mp + i] - 4.0 * q;
         const double hh = R[(size_t)i * ldr + j] - 4.0 * (pij + pji) - 16.0 * q;  // exact: integers below 2^53
         R[(size_t)i * ldr + j] = hh + muv[j] * pij + muv[i] * pji + (muv[i] * muv[j]) * q;
-      }
-      co.sync();
-    }
-  }
-  if (hcm && !hcm->pq && hcm->dS) {
-    bool any = false;
-    for (int p = 0; p < P; ++p) any = any || (hcm->wflags[p] & 1u);
-    if (any) {
-      for (int idx = co.tid; idx < M * M; idx += co.nt) {
-        const int i = idx / M, j = idx % M;
-        if ((j >> 4) < (i >> 4)) continue;
-        R[(size_t)i * ldr + j] += (double)hcm->dS[(size_t)i * Mp + j] * (1.0 / 4398046511104.0);
       }
       co.sync();
     }

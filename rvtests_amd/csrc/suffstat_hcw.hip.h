@@ -16,14 +16,6 @@
 //   * G'V[X | rr] stays on the fp64 matrix cores against the null tile [vX_0 .. vX_{d-1} | res | v | 0] (res = v rr);
 //     its v column also gives the weighted burden sums c'Vc;
 //   * column sums and the counts behind min / max are byte sums of g and g^2.
-//   * entries that are not hard calls (the imputed means of columns with missing calls) are MASKED: integer part 0 in
-//     every integer product, listed per wave-part as (sample, column) pairs — position from an LDS counter, no global
-//     atomic — with the per-column count and the OR / AND of their bit patterns kept in LDS exactly as suffstat_hc.hip.h
-//     does.  hcw_mask_correct_kernel then adds, for every listed entry (i, j), v_i mu_j g_ik to (G'VG)_jk for all k (and
-//     to (k, j) when g_ik is a hard call), reading row i of the block: the masked entries are sparse, so this is a few
-//     thousand strided loads per gene.  The sums are accumulated as 64-bit fixed point (2^-42, the resolution the digits
-//     of v have) with integer atomics: exact addition, order-independent, so the result is deterministic.  G'V[X | rr]
-//     needs no correction (fp64 operands = the true values).
 // Structure (load ring, raw buffer loads with range checks, wave-parts, burden collapse with predicted flips) as in
 // suffstat_hc.hip.h, whose helpers it uses.
 #pragma once
@@ -70,53 +62,15 @@ struct HcwBurden {
   unsigned cnt;               // #(c != 0) over the samples of this lane's row
 };
 
-// LDS of one wave (32-bit words): [0, 64 MT) OR lo / OR hi / AND lo / AND hi per column (as suffstat_hc.hip.h),
-// [64 MT, 80 MT) masked entries per column, [80 MT] entries listed by this wave-part
-constexpr int hcw_lds_words(int MT) { return 80 * MT + 4; }
-
-struct HcwMaskCtx {
-  unsigned* lds;    // this wave's LDS block
-  unsigned* list;   // global: this wave-part's (sample, column) pairs, or null
-  unsigned cap;     // pairs the list holds
-  int v, q, MT;
-};
-
-// the masked entries of one tile row of one step (rare path; a real call, so that its temporaries do not count against the
-// register budget of the streaming loop)
-__device__ __attribute__((noinline)) void hcw_note_masked(const u4_t& glo, const u4_t& ghi, unsigned mk, int c,
-                                                          long long step, const HcwMaskCtx& mc, unsigned& notHard) {
-  hc_note_masked(glo, ghi, mk, mc.lds + 64 * c + 4 * mc.v);
-  if (!mc.list) {  // (no list: MetaScore slices — the gene is handed back)
-    notHard |= 1u;
-    return;
-  }
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    if ((mk >> (8 * l)) & 0xffu) {
-      __hip_atomic_fetch_add(mc.lds + 64 * mc.MT + c * 16 + mc.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned pos =
-          __hip_atomic_fetch_add(mc.lds + 80 * mc.MT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (pos < mc.cap) {
-        mc.list[2 * (size_t)pos] = (unsigned)(step * 16 + mc.q * 4 + l);
-        mc.list[2 * (size_t)pos + 1] = (unsigned)(c * 16 + mc.v);
-      } else {
-        notHard |= 1u;  // more masked entries than the list holds: the fp64 kernel takes the gene
-      }
-    }
-  }
-}
-
 // one tile row of one step: fp64 tile of G'V[X | rr | v], packing, byte sums of g and g^2, burden hits
 template <bool MASKED>
 __device__ __forceinline__ void hcw_row(const u4_t& glo, const u4_t& ghi, const double (&xv)[4], d4_t& accT, unsigned& pk,
-                                        unsigned& cs, unsigned& cs2, unsigned fx, unsigned& h, bool valid, unsigned& notHard,
-                                        int c, long long step, const HcwMaskCtx& mc) {
-  // entries that are not hard calls (mk) have integer part 0 here and are listed for hcw_mask_correct_kernel; -inf
-  // (code 3, see hc_row) voids the gene (wflags bit 1: the fp64 kernel takes it)
+                                        unsigned& cs, unsigned& cs2, unsigned fx, unsigned& h, bool valid, unsigned& notHard) {
+  // entries that are not hard calls (mk) void the gene here: the weighted kernel has no masked-entry tiles, the engine
+  // runs such a gene on the fp64 kernel (wflags bit 1).  -inf (code 3, see hc_row) likewise.
   unsigned mk;
   hc_row<MASKED>(glo, ghi, xv, accT, pk, mk, cs, fx, h, valid);
-  if (mk) hcw_note_masked(glo, ghi, mk, c, step, mc, notHard);
-  notHard |= hc_code3(pk);
+  notHard |= mk | hc_code3(pk);
   cs2 = __builtin_amdgcn_sad_u8((pk & 0x01010101u) | ((pk & 0x02020202u) << 1), 0u, cs2);  // g^2: 0 / 1 / 4
 }
 
@@ -141,7 +95,7 @@ template <int MT, bool MASKED>
 __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t (&accT)[MT], unsigned (&pk)[MT][4],
                                          unsigned (&dg)[4][8], unsigned (&cs)[MT], unsigned (&cs2)[MT],
                                          const unsigned (&fx)[MT], HcwBurden& bu, bool valid, unsigned vmask,
-                                         unsigned& notHard, long long step, const HcwMaskCtx& mc) {
+                                         unsigned& notHard) {
   double xv[4] = {hc_dbl(f.xlo[0], f.xlo[1]), hc_dbl(f.xlo[2], f.xlo[3]), hc_dbl(f.xhi[0], f.xhi[1]),
                   hc_dbl(f.xhi[2], f.xhi[3])};
   if (MASKED) {
@@ -156,7 +110,7 @@ __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t
   unsigned h = 0;
 #pragma unroll
   for (int c = 0; c < MT; ++c)
-    hcw_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], cs2[c], fx[c], h, valid, notHard, c, step, mc);
+    hcw_row<MASKED>(f.glo[c], f.ghi[c], xv, accT[c], pk[c][T], cs[c], cs2[c], fx[c], h, valid, notHard);
   hcw_finish<MASKED>(h, xv, bu, vmask);
 }
 
@@ -244,15 +198,11 @@ struct HcwAcc {
 
 template <int MT, int DEPTH>
 __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const NullTileW& nt, long long N, long long ld,
-                                                  int d, unsigned* lds) {
+                                                  int d) {
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, q = lane >> 4;
   const int wpart = blockIdx.x;
   if (wpart >= gd.n_wparts) return;
-#pragma unroll
-  for (int c = 0; c < MT; ++c) lds[64 * c + lane] = (lane & 2) ? 0xffffffffu : 0u;  // OR words 0, AND words ~0
-  for (int w = lane; w < 16 * MT + 4; w += 64) lds[64 * MT + w] = 0u;                // counts, list position
-  const HcwMaskCtx mc{lds, gd.mlist ? gd.mlist + 2 * (size_t)wpart * gd.mlist_cap : nullptr, gd.mlist_cap, v, q, MT};
   const long long nsteps = ld >> 4;
   const long long s_begin = (long long)wpart * gd.steps_per_wpart;
   long long s_end = s_begin + gd.steps_per_wpart;
@@ -341,8 +291,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         unsigned h = 0;
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-          hcw_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], cs2[c], fx[c], h, true, notHard, c,
-                         s_begin + it * 4 + u, mc);
+          hcw_row<false>(glo[c], ghi[c], xv, accT[c], pk[c][u], cs[c], cs2[c], fx[c], h, true, notHard);
           glo[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128, 0, 0));
           ghi[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, voff[c] + (u + 1) * 128 + 16, 0, 0));
           __builtin_amdgcn_sched_barrier(0);
@@ -372,8 +321,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
       for (int u = 0; u < U; ++u) {
         hcw_issue<MT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, rq, qoff, (u + DEPTH - 1) * 128);
         __builtin_amdgcn_sched_barrier(0);
-        hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu, notHard,
-                            s_begin + it * U + u, mc);
+        hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu, notHard);
         if ((u & 3) == 3) acc.gram(pk, dg);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -399,7 +347,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
       const long long smp = sc * 16 + q * 4;
 #pragma unroll
       for (int l = 0; l < 4; ++l) vmask |= (valid && smp + l < N) ? (0xffu << (8 * l)) : 0u;
-      hcw_step<MT, true>(f, T, accT, pk, dg, cs, cs2, fx, bu, valid, vmask, notHard, sc, mc);
+      hcw_step<MT, true>(f, T, accT, pk, dg, cs, cs2, fx, bu, valid, vmask, notHard);
     };
     one(0, s);
     one(1, s + 1);
@@ -438,12 +386,10 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
   long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
   if (cnt_w < 0) cnt_w = 0;
   double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
-  const unsigned listed = lds[80 * MT];
   if (gd.wflags) {
     const bool nh = __builtin_amdgcn_ballot_w64(notHard != 0u) != 0ull;
-    if (lane == 0) gd.wflags[wpart] = (nh ? 2u : 0u) | (listed ? 1u : 0u);
+    if (lane == 0) gd.wflags[wpart] = nh ? 2u : 0u;
   }
-  if (gd.mcount && lane == 0) gd.mcount[wpart] = listed < gd.mlist_cap ? listed : gd.mlist_cap;
 #pragma unroll
   for (int c = 0; c < MT; ++c) {
     unsigned sc = cs[c], sq = cs2[c];
@@ -451,19 +397,16 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
     sq += __shfl_xor(sq, 16, 64);
     sc += __shfl_xor(sc, 32, 64);
     sq += __shfl_xor(sq, 32, 64);
-    const long long nm = (long long)lds[64 * MT + c * 16 + v];  // masked entries of column c * 16 + v in this wave-part
-    const long long sm = (long long)sc, n2 = ((long long)sq - sm) / 2, n1 = 2 * sm - (long long)sq,
-                    n0 = cnt_w - n1 - n2 - nm;
+    const long long sm = (long long)sc, n2 = ((long long)sq - sm) / 2, n1 = 2 * sm - (long long)sq, n0 = cnt_w - n1 - n2;
     const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
     const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
     if (lane < 16) {
       cst[c * 16 + lane] = (double)sm;
       cst[gd.Mp + c * 16 + lane] = mn;
       cst[2 * gd.Mp + c * 16 + lane] = mx;
-      cst[3 * gd.Mp + c * 16 + lane] = (double)nm;  // rows 3-5 as suffstat_hc.hip.h writes them
-      const unsigned* w = lds + 64 * c + 4 * lane;
-      reinterpret_cast<unsigned long long*>(cst)[4 * gd.Mp + c * 16 + lane] = ((unsigned long long)w[1] << 32) | w[0];
-      reinterpret_cast<unsigned long long*>(cst)[5 * gd.Mp + c * 16 + lane] = ((unsigned long long)w[3] << 32) | w[2];
+      cst[3 * gd.Mp + c * 16 + lane] = 0.0;  // no masked entries on this path (rows 3-5 as suffstat_hc.hip.h writes them)
+      reinterpret_cast<unsigned long long*>(cst)[4 * gd.Mp + c * 16 + lane] = 0ull;
+      reinterpret_cast<unsigned long long*>(cst)[5 * gd.Mp + c * 16 + lane] = ~0ull;
     }
   }
   // ---- burden partial sums: [test][U, c'Vc, count, c'VX_0 .. c'VX_{d-1}], test 0 = CMC, 1 = Zeggini ------------------
@@ -499,60 +442,9 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
 template <int MT, int DEPTH, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void gene_suffstat_hcw(const GeneDesc* __restrict__ genes, NullTileW nt,
                                                                long long N, long long ld, int d) {
-  __shared__ unsigned lds[hcw_lds_words(MT)];
   const GeneDesc gd = genes[blockIdx.y];
   if (gd.MT != MT) return;
-  suffstat_hcw_body<MT, DEPTH>(gd, nt, N, ld, d, lds);
-}
-
-// ---- sparse correction of G'VG for the masked entries the weighted kernel listed -----------------------------------------
-// grid (kHcwCorrSplit, genes), 256 threads.  Every workgroup first rebuilds the imputed value of every column from the
-// OR words of the wave-parts (gene_flags_hc_kernel has verified OR == AND), then walks its share of the listed entries:
-// one wave per entry (i, j), lane k <-> column k:  dS[j][k] += v_i mu_j g_ik, and dS[k][j] likewise when g_ik is a hard
-// call (a masked g_ik contributes its own entry).  64-bit fixed point, integer atomics: exact and order-independent.
-constexpr int kHcwCorrSplit = 8;
-constexpr double kHcwCorrScale = 4398046511104.0;  // 2^42
-
-template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void hcw_mask_correct_kernel(const GeneDesc* __restrict__ genes,
-                                                               const double* __restrict__ vw, long long ld) {
-  const GeneDesc gd = genes[blockIdx.y];
-  if (!gd.mlist || !gd.dS || !gd.hc || gd.flags[2 * gd.MT + 1]) return;  // (a handed-back gene is the fp64 kernel's)
-  __shared__ double mu[RVT_MAX_VARIANTS / 8];  // M <= 80 on this path
-  __shared__ int any;
-  if (threadIdx.x == 0) any = 0;
-  __syncthreads();
-  for (int p = threadIdx.x; p < gd.n_wparts; p += 256)
-    if (gd.mcount[p]) any = 1;
-  __syncthreads();
-  if (!any) return;
-  for (int j = threadIdx.x; j < gd.M; j += 256) {
-    unsigned long long orb = 0ull;
-    for (int p = 0; p < gd.n_wparts; ++p)
-      orb |= reinterpret_cast<const unsigned long long*>(gd.colstat + (long long)p * kHcColstatRows * gd.Mp)[4 * gd.Mp + j];
-    mu[j] = __builtin_bit_cast(double, orb);
-  }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nwv = 4 * gridDim.x, me = blockIdx.x * 4 + wave;
-  long long seen = 0;
-  for (int p = 0; p < gd.n_wparts; ++p) {
-    const unsigned cnt = gd.mcount[p];
-    const unsigned* lst = gd.mlist + 2 * (size_t)p * gd.mlist_cap;
-    for (unsigned e = 0; e < cnt; ++e, ++seen) {
-      if ((int)(seen % nwv) != me) continue;
-      const long long i = lst[2 * (size_t)e];
-      const int j = (int)lst[2 * (size_t)e + 1];
-      const double f = vw[i] * mu[j];
-      for (int k = lane; k < gd.M; k += 64) {
-        const double g = gd.G[(long long)k * ld + i];
-        const long long q = (long long)__double2ll_rn(f * g * kHcwCorrScale);
-        atomicAdd(reinterpret_cast<unsigned long long*>(gd.dS) + (size_t)j * gd.Mp + k, (unsigned long long)q);
-        if (k != j && (g == 0.0 || g == 1.0 || g == 2.0))
-          atomicAdd(reinterpret_cast<unsigned long long*>(gd.dS) + (size_t)k * gd.Mp + j, (unsigned long long)q);
-      }
-    }
-  }
+  suffstat_hcw_body<MT, DEPTH>(gd, nt, N, ld, d);
 }
 
 }  // namespace rvt

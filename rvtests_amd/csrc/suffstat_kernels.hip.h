@@ -51,11 +51,6 @@ struct GeneDesc {
   double* vt_mem;           // AnalyticVT workspace (gene_vt_doubles(Mp)), null unless the test is requested
   unsigned* pq;             // hard-call path: n_wparts x hc_pq_words(MT) packed 16-bit counters of the masked tiles
   unsigned* wflags;         // hard-call path: per wave-part, bit 0 = masked entries met (pq written), bit 1 = bad entry
-  // weighted hard-call path (suffstat_hcw.hip.h): the masked entries themselves, for the sparse correction of G'VG
-  unsigned* mlist;          // n_wparts x mlist_cap pairs (sample, column); null: a masked entry hands the gene back
-  unsigned* mcount;         // n_wparts: entries each wave-part listed
-  long long* dS;            // Mp x Mp fixed-point (2^-42) corrections, accumulated by hcw_mask_correct_kernel
-  unsigned mlist_cap;       // pairs per wave-part
 };
 
 struct NullDev {

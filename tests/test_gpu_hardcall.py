@@ -374,58 +374,6 @@ def test_binary_trait_weighted_hardcall_path(engine, N, d):
                 assert ok and abs(p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
 
 
-@pytest.mark.parametrize("N,d,miss", [(3000, 2, 0.02), (10007, 3, 0.002), (4099, 1, 0.2)])
-def test_binary_trait_mean_imputed_columns_stay_on_the_weighted_kernel(engine, N, d, miss):
-    """Binary trait, columns with imputed means: the weighted int8 kernel lists the masked entries and
-    hcw_mask_correct_kernel adds their share of G'VG (64-bit fixed point, integer atomics).  Not handed back; the numbers of
-    the fp64 kernel and of the oracle; identical on repetition (the atomics are exact additions)."""
-    Ms = (1, 7, 16, 17, 30, 33, 48, 50, 64, 65, 80)
-    genes = []
-    for M in Ms:
-        Graw, Gi, afi = synth.make_gene(N, M, seed=5 * M + d, missing=miss, common=(M % 2 == 0), mono=(M % 3 == 0))
-        genes.append((Gi, afi))
-    X, y, res, v, s2 = synth.make_null(N, d, 1, seed=12, G_effect=0.5 * genes[4][0][:, :3].sum(1))
-    engine.set_null(1, X, res, v, s2)
-    hc, tm = _run(engine, genes, True)
-    hc2, _ = _run(engine, genes, True)
-    gen, tm_gen = _run(engine, genes, False)
-    assert tm.genes_hard_call == len(genes) and tm.genes_handed_back == 0 and tm_gen.genes_hard_call == 0
-    for a, a2, b, (G, af) in zip(hc, hc2, gen, genes):
-        assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref and a.status == b.status
-        for f in FIELDS:
-            x, x2, y_ = getattr(a, f), getattr(a2, f), getattr(b, f)
-            assert x == x2, (f, x, x2)                                   # deterministic
-            tol = 1e-6 if f.endswith("_p") else 1e-9
-            assert abs(x - y_) <= tol * abs(y_) + 1e-300, (G.shape[1], f, x, y_)
-        rc, o = orc.skat(G, af, X, res, v, 1)
-        assert a.n_poly == o.n_poly
-        if o.n_poly:
-            assert abs(a.skat_Q - o.Q) <= 1e-10 * o.Q and abs(a.skat_p - o.pvalue) <= 1e-6 * o.pvalue + 1e-14
-        rc2, so = orc.skato(G, af, X, res, v, 1)
-        if rc2 == 0 and o.n_poly:
-            assert abs(a.skato_p - so.pvalue) <= 1e-6 * so.pvalue + 5e-13
-
-
-def test_binary_trait_too_many_masked_entries_are_handed_back(engine):
-    """A column that is imputed almost everywhere overflows the wave-parts' lists (1/32 of the entries): the gene is the
-    fp64 kernel's, with the same record."""
-    N = 6000
-    G, af = _hard_gene(N, 20, seed=8)
-    G = G.copy()
-    G[:, 3] = 0.3125
-    G[::2, 7] = 0.0625
-    G = np.asfortranarray(G)
-    af = G.sum(0) / (2.0 * N)
-    X, y, res, v, s2 = synth.make_null(N, 2, 1, seed=3)
-    engine.set_null(1, X, res, v, s2)
-    (a,), tm = _run(engine, [(G, af)], True)
-    (b,), _ = _run(engine, [(G, af)], False)
-    assert tm.genes_hard_call == 1 and tm.genes_handed_back == 1
-    for f in FIELDS:
-        if not f.startswith(("cmc", "zeg")):
-            assert getattr(a, f) == getattr(b, f), f
-
-
 def test_binary_trait_weights_at_the_digit_range_limits(engine):
     """v = 1/4 exactly (intercept-only model, balanced cases) is the largest weight the digit planes must hold; weights
     that are tiny or have all 49 fractional bits set exercise the balanced-digit carries."""

@@ -119,9 +119,8 @@ def test_mixed_entry_points_with_partial_collects(eng):
 
 
 def test_long_stream_binary_trait(eng):
-    """The same under a logistic null model: streamed hard-call blocks run on the weighted int8 kernel, the genes with
-    imputed means included (listed masked entries, sparse correction); records equal those of the finished-block
-    submission."""
+    """The same under a logistic null model: streamed hard-call blocks start on the weighted int8 kernel, which hands the
+    genes with imputed means back to the fp64 kernel; records equal those of the finished-block submission."""
     rng = np.random.default_rng(5)
     N, d, n_genes = 2500, 2, 40
     X, y, res, v, s2 = synth.make_null(N, d, 1, seed=10)
@@ -134,13 +133,13 @@ def test_long_stream_binary_trait(eng):
         maf = 10 ** rng.uniform(-2.5, -0.7, M)
         raw = np.asfortranarray(rng.binomial(2, maf, size=(N, M)).astype(np.float64))
         if g % 3 == 0:
-            raw[rng.random((N, M)) < 0.01] = -9.0          # imputed means: masked entries of the weighted kernel
+            raw[rng.random((N, M)) < 0.01] = -9.0          # imputed means: handed back to the fp64 kernel
         mats.append(raw)
         eng.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
     got = eng.collect()
     tm = eng.timing(reset=True)
     eng.set_profiling(False)
-    assert tm.genes_hard_call == n_genes and tm.genes_handed_back == 0
+    assert tm.genes_hard_call == n_genes and 0 < tm.genes_handed_back < n_genes
     ref = _reference(eng, mats)
     for a, b in zip(got, ref):
         for f in FIELDS:
