@@ -38,7 +38,7 @@ import rvtests_amd  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (≈6.3 TB/s achievable)
 
 
-def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05):
+def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=False):
     """Synthetic genotype blocks on the device (config 3 of SURVEY.md §8d): per-variant MAF ~ LogUniform(5e-4,
     5e-2), g ~ Binomial(2, maf); 0.1 % of genotypes missing in 5 % of the genes and imputed to the column mean
     exactly as DataConsolidator::imputeGenotypeToMean leaves them.  Returns blocks (M x ld tensors, i.e.
@@ -56,6 +56,13 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05):
             G[:, :N] += (u < maf[:, None]).to(torch.float64)
             del u
         nsample = float(N)
+        if dosage:
+            # imputed dosages: every call blurred by its genotype probabilities, quantised to 1/256 as an 8-bit BGEN stores
+            # them (no block of the batch holds hard calls only)
+            e = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) * 0.12
+            Gv = G[:, :N]
+            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 256.0) / 256.0)
+            del e
         if rng.random() < missing_frac:
             miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3
             Gv = G[:, :N]
@@ -326,6 +333,9 @@ def main():
     ap.add_argument("--missing-frac", type=float, default=0.05,
                     help="share of the genes with missing genotypes (0.1 %% of their calls, imputed to the column mean); "
                          "SURVEY config 3: 0.05")
+    ap.add_argument("--dosage", action="store_true",
+                    help="every block holds dosages (imputed data): the general fp64 kernel; the engine is told so "
+                         "(rvt_set_content_hint) as an adapter reading --dosage / BGEN input would")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
@@ -365,7 +375,9 @@ def main():
     binary = args.trait == "binary"
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
     blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi,
-                                 args.missing_frac)
+                                 args.missing_frac, args.dosage)
+    if args.dosage:
+        eng.set_content_hint(0)
     pack = torch.empty((N, d + 1), dtype=torch.float64, device=dev)
     if rank == 0:
         X, y = make_phenotype(dev, N, 20260002, binary, causal_effect(blocks, N, binary))
@@ -484,8 +496,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: N=%d, genes/step/GPU=%d, M~U{%d..%d}, %s trait, "
                                    "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
-                                   "fp64 column-major blocks" % (3 if binary else 2, N, args.genes, args.m_lo,
-                                                                 args.m_hi, "binary" if binary else "quantitative"),
+                                   "fp64 column-major blocks%s" % (3 if binary else 2, N, args.genes, args.m_lo,
+                                                                   args.m_hi, "binary" if binary else "quantitative",
+                                                                   " of DOSAGES (no hard-call block)" if args.dosage else ""),
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
                        "parallelism": "gene-sharded x%d" % world, "genes_ok": ok,
                        "hard_call_genes_per_step": (tm.genes_hard_call - tm.genes_handed_back) / max(args.steps, 1),

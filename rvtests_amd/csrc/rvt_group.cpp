@@ -16,12 +16,118 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/rvtests_amd.h"
+#include "host_stage.h"
+
+// One submit worker per member.  The caller's thread only COPIES a gene's buffer (with the copy pool of host_stage.h: the
+// reference reuses its buffer for the next gene) and queues a job; the member's worker thread makes the engine calls —
+// the staged host-to-device copy and the ~10 HIP launches a packed submission costs (~300 us) — so the members' PCIe
+// links and launch queues are fed concurrently, not one after the other by a single thread.  A context is still used by
+// one thread at a time: the worker holds `ctx_mu` during each engine call, rvt_group_collect waits for the queues to
+// drain, rvt_group_collect_ready skips a member whose worker is inside a call.
+struct MemberWorker {
+  struct Job {
+    int kind = 0;  // 0 fp64 imputed + af, 1 raw doubles, 2 int8, 3 PLINK 2-bit
+    int64_t gene_id = 0;
+    int M = 0;
+    uint32_t tests = 0;
+    rvt_params prm;
+    bool has_prm = false;
+    int buf = -1;
+    std::vector<double> af;
+  };
+  static constexpr int kDepth = 3;  // copied genes a member may hold before the caller waits
+  rvt_ctx* ctx = nullptr;
+  std::thread th;
+  std::mutex mu;       // queue state
+  std::mutex ctx_mu;   // the engine context
+  std::condition_variable cv_job, cv_idle;
+  std::deque<Job> q;
+  std::vector<std::vector<char>> bufs;
+  std::vector<int> free_bufs;
+  bool stop = false;
+  bool busy = false;
+  int err = RVT_OK;
+  std::string errmsg;
+
+  void start(rvt_ctx* c) {
+    ctx = c;
+    bufs.resize(kDepth);
+    for (int i = 0; i < kDepth; ++i) free_bufs.push_back(i);
+    th = std::thread([this] { loop(); });
+  }
+  void loop() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [this] { return stop || !q.empty(); });
+        if (q.empty()) return;  // stop
+        j = std::move(q.front());
+        q.pop_front();
+        busy = true;
+      }
+      int rc = RVT_OK;
+      {
+        std::lock_guard<std::mutex> cl(ctx_mu);
+        const rvt_params* prm = j.has_prm ? &j.prm : nullptr;
+        const char* data = bufs[j.buf].data();
+        switch (j.kind) {
+          case 0: rc = rvt_submit_gene(ctx, j.gene_id, j.M, (const double*)data, j.af.data(), j.tests, prm); break;
+          case 1: rc = rvt_submit_gene_raw(ctx, j.gene_id, j.M, (const double*)data, j.tests, prm, nullptr); break;
+          case 2: rc = rvt_submit_gene_i8(ctx, j.gene_id, j.M, (const int8_t*)data, j.tests, prm, nullptr); break;
+          default: rc = rvt_submit_gene_bed(ctx, j.gene_id, j.M, (const unsigned char*)data, j.tests, prm, nullptr); break;
+        }
+        if (rc && err == RVT_OK) {
+          err = rc;
+          errmsg = rvt_last_error(ctx);
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        free_bufs.push_back(j.buf);
+        busy = false;
+      }
+      cv_idle.notify_all();
+    }
+  }
+  // caller: a buffer to copy the next gene into (waits while the member holds kDepth genes)
+  int take_buffer() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_idle.wait(lk, [this] { return !free_bufs.empty(); });
+    const int b = free_bufs.back();
+    free_bufs.pop_back();
+    return b;
+  }
+  void push(Job&& j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      q.push_back(std::move(j));
+    }
+    cv_job.notify_one();
+  }
+  void flush() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_idle.wait(lk, [this] { return q.empty() && !busy; });
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
 
 struct rvt_group {
   std::vector<rvt_ctx*> member;
+  std::vector<std::unique_ptr<MemberWorker>> worker;  // empty (the default): every call on the caller's thread
   std::deque<int> owner;       // member of every submitted, not yet collected gene, in submission order
   std::vector<std::deque<rvt_gene_result>> inbox;  // records already taken from a member, waiting for their turn
   long long submitted = 0;     // genes dealt so far (decides the member of the next one)
@@ -42,6 +148,48 @@ int next_member(rvt_group* g, const rvt_params* prm, uint32_t tests) {
   if (g->perm_exact && prm && prm->skat_nperm > 0 && (tests & RVT_TEST_SKAT)) return 0;
   return (int)((g->submitted / kRun) % (long long)g->member.size());
 }
+// every worker idle (their queues drained): the caller's thread may use the contexts
+int group_flush(rvt_group* g) {
+  for (size_t k = 0; k < g->worker.size(); ++k) {
+    MemberWorker& w = *g->worker[k];
+    w.flush();
+    if (w.err) {
+      const int rc = w.err;
+      g->err = "submit: " + w.errmsg;
+      w.err = RVT_OK;
+      return rc;
+    }
+  }
+  return RVT_OK;
+}
+
+// queue one gene for member k: copy `bytes` of `data` (and the frequencies) now, engine calls on the member's worker
+int group_submit_async(rvt_group* g, int k, int kind, int64_t gene_id, int M, const void* data, size_t bytes,
+                       const double* af, uint32_t tests, const rvt_params* prm) {
+  MemberWorker& w = *g->worker[k];
+  if (w.err) {  // an earlier job of this member failed
+    const int rc = w.err;
+    g->err = "submit: " + w.errmsg;
+    w.err = RVT_OK;
+    return rc;
+  }
+  MemberWorker::Job j;
+  j.kind = kind;
+  j.gene_id = gene_id;
+  j.M = M;
+  j.tests = tests;
+  j.has_prm = prm != nullptr;
+  if (prm) j.prm = *prm;
+  if (af) j.af.assign(af, af + M);
+  j.buf = w.take_buffer();
+  std::vector<char>& b = w.bufs[j.buf];
+  if (b.size() < bytes) b.resize(bytes);
+  rvt::CopyPool::instance().copy(b.data(), data, bytes);
+  w.push(std::move(j));
+  g->owner.push_back(k);
+  ++g->submitted;
+  return RVT_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -61,6 +209,18 @@ int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
     g->member.push_back(c);
   }
   g->inbox.resize(g->member.size());
+  {
+    // Opt-in (RVT_GROUP_ASYNC=1).  Measured with both members on ONE GPU (tools/bench_group_stream.py) the extra host
+    // copy costs more than the overlapped engine calls save (fp64 273 -> 140-157, int8 1 510 -> 266-1 084, 2-bit
+    // 1 870-3 220 -> 2 950-3 000 gene-sets/s): the members share one PCIe link there, and the blocks are copied twice.
+    // Whether separate links change the balance has not been measured (no multi-GPU box in this environment).
+    const char* e = getenv("RVT_GROUP_ASYNC");
+    if (e && atoi(e) != 0)
+      for (rvt_ctx* m : g->member) {
+        g->worker.emplace_back(new MemberWorker());
+        g->worker.back()->start(m);
+      }
+  }
   if (const char* e = getenv("RVT_PERM_EXACT")) g->perm_exact = atoi(e) != 0;
   *out = g;
   return RVT_OK;
@@ -76,12 +236,14 @@ int rvt_group_set_perm_exact(rvt_group* g, int on) {
 
 int rvt_group_rand_seed(rvt_group* g, unsigned seed) {
   if (!g) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   for (rvt_ctx* m : g->member) rvt_rand_seed(m, seed);
   return RVT_OK;
 }
 
 void rvt_group_destroy(rvt_group* g) {
   if (!g) return;
+  for (auto& w : g->worker) w->shutdown();
   for (rvt_ctx* m : g->member) rvt_destroy(m);
   delete g;
 }
@@ -118,31 +280,60 @@ int rvt_group_fit_null(rvt_group* g, int trait, int64_t N, int d, const double* 
   if (!g) return RVT_E_INVALID;                                 \
   const int k = next_member(g, params, tests);                  \
   rvt_ctx* m = g->member[k];                                    \
+  if (!g->worker.empty()) {                                     \
+    g->worker[k]->flush();                                      \
+    if (g->worker[k]->err) return group_flush(g);               \
+  }                                                             \
   const int rc = (call);                                        \
   if (rc) return gfail(g, rc, "submit", m);                     \
   g->owner.push_back(k);                                        \
   ++g->submitted;                                               \
   return RVT_OK;
 
+// bytes of one gene's buffer at the boundary (kind as MemberWorker::Job::kind), or 0 when the arguments are unusable
+static size_t gene_bytes(rvt_group* g, int kind, int M) {
+  int64_t N = 0;
+  int d = 0;
+  if (M < 1 || M > RVT_MAX_VARIANTS || rvt_null_dims(g->member[0], &N, &d) != RVT_OK) return 0;
+  return kind <= 1 ? sizeof(double) * (size_t)N * M : (kind == 2 ? (size_t)N * M : (size_t)((N + 3) / 4) * M);
+}
+
 int rvt_group_submit_gene(rvt_group* g, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                           const rvt_params* params) {
+  if (g && !g->worker.empty() && G && af) {
+    if (const size_t bytes = gene_bytes(g, 0, M))
+      return group_submit_async(g, next_member(g, params, tests), 0, gene_id, M, G, bytes, af, tests, params);
+  }
   RVT_GROUP_SUBMIT(rvt_submit_gene(m, gene_id, M, G, af, tests, params))
 }
 int rvt_group_submit_gene_raw(rvt_group* g, int64_t gene_id, int M, const double* Graw, uint32_t tests,
                               const rvt_params* params, double* af_out) {
+  if (g && !g->worker.empty() && Graw && !af_out) {  // (somebody waiting for the frequencies: the synchronous call)
+    if (const size_t bytes = gene_bytes(g, 1, M))
+      return group_submit_async(g, next_member(g, params, tests), 1, gene_id, M, Graw, bytes, nullptr, tests, params);
+  }
   RVT_GROUP_SUBMIT(rvt_submit_gene_raw(m, gene_id, M, Graw, tests, params, af_out))
 }
 int rvt_group_submit_gene_i8(rvt_group* g, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
                              const rvt_params* params, double* af_out) {
+  if (g && !g->worker.empty() && G8 && !af_out) {
+    if (const size_t bytes = gene_bytes(g, 2, M))
+      return group_submit_async(g, next_member(g, params, tests), 2, gene_id, M, G8, bytes, nullptr, tests, params);
+  }
   RVT_GROUP_SUBMIT(rvt_submit_gene_i8(m, gene_id, M, G8, tests, params, af_out))
 }
 int rvt_group_submit_gene_bed(rvt_group* g, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                               const rvt_params* params, double* af_out) {
+  if (g && !g->worker.empty() && bed && !af_out) {
+    if (const size_t bytes = gene_bytes(g, 3, M))
+      return group_submit_async(g, next_member(g, params, tests), 3, gene_id, M, bed, bytes, nullptr, tests, params);
+  }
   RVT_GROUP_SUBMIT(rvt_submit_gene_bed(m, gene_id, M, bed, tests, params, af_out))
 }
 
 int rvt_group_vcf_set_samples(rvt_group* g, int n_file_samples, const int32_t* row_of_sample) {
   if (!g) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   for (rvt_ctx* m : g->member) {
     const int rc = rvt_vcf_set_samples(m, n_file_samples, row_of_sample);
     if (rc) return gfail(g, rc, "rvt_vcf_set_samples", m);
@@ -151,6 +342,7 @@ int rvt_group_vcf_set_samples(rvt_group* g, int n_file_samples, const int32_t* r
 }
 int rvt_group_vcf_set_filters(rvt_group* g, int gd_min, int gd_max, int gq_min, int gq_max) {
   if (!g) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   for (rvt_ctx* m : g->member) rvt_vcf_set_filters(m, gd_min, gd_max, gq_min, gq_max);
   return RVT_OK;
 }
@@ -184,6 +376,10 @@ int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
   *n_out = 0;
   const int n = (int)std::min<size_t>(g->owner.size(), (size_t)std::max(cap, 0));
   if (n == 0) return RVT_OK;
+  {
+    const int rcf = group_flush(g);  // every queued gene has reached its member
+    if (rcf) return rcf;
+  }
   const int nm = (int)g->member.size();
   std::vector<int> want(nm, 0);
   for (int i = 0; i < n; ++i) ++want[g->owner[i]];
@@ -207,6 +403,12 @@ int rvt_group_collect_ready(rvt_group* g, rvt_gene_result* out, int cap, int* n_
   if (g->owner.empty() || cap <= 0) return RVT_OK;
   std::vector<rvt_gene_result> got(256);
   for (size_t k = 0; k < g->member.size(); ++k) {
+    // (a member whose worker is inside an engine call is left for the next time: the context has one user at a time)
+    std::unique_lock<std::mutex> cl;
+    if (!g->worker.empty()) {
+      cl = std::unique_lock<std::mutex>(g->worker[k]->ctx_mu, std::try_to_lock);
+      if (!cl.owns_lock()) continue;
+    }
     for (;;) {  // whatever the member has finished, without waiting
       int nk = 0;
       const int rc = rvt_collect_ready(g->member[k], got.data(), (int)got.size(), &nk);
@@ -222,6 +424,7 @@ int rvt_group_collect_ready(rvt_group* g, rvt_gene_result* out, int cap, int* n_
 // ---- related samples: the kinship decomposition is replicated on every member ------------------------------------------
 int rvt_group_set_kinship(rvt_group* g, int64_t N, const float* U, const float* S) {
   if (!g) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   for (rvt_ctx* m : g->member) {
     const int rc = rvt_set_kinship(m, N, U, S);
     if (rc) return gfail(g, rc, "rvt_set_kinship", m);
@@ -231,6 +434,7 @@ int rvt_group_set_kinship(rvt_group* g, int64_t N, const float* U, const float* 
 
 int rvt_group_fit_fam_null(rvt_group* g, int64_t N, int d, const double* X, const double* y, rvt_fam_null* out) {
   if (!g) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   for (size_t k = 0; k < g->member.size(); ++k) {
     rvt_fam_null tmp;
     const int rc = rvt_fit_fam_null(g->member[k], N, d, X, y, k == 0 && out ? out : &tmp);
@@ -244,6 +448,7 @@ int rvt_group_fit_fam_null(rvt_group* g, int64_t N, int d, const double* X, cons
 int rvt_group_run_fam_tests_host(rvt_group* g, int n_genes, const double* const* G_host, const int* M,
                                  const int64_t* gene_ids, uint32_t tests, rvt_gene_result* out) {
   if (!g || n_genes < 0 || (n_genes > 0 && (!G_host || !M || !out))) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   const int nm = (int)g->member.size();
   // contiguous shares balanced by column count (the rotation's cost is proportional to the columns)
   long long total = 0;
@@ -292,6 +497,7 @@ int rvt_group_run_fam_tests_host(rvt_group* g, int n_genes, const double* const*
 int rvt_group_score_block_host(rvt_group* g, int64_t N, int V, const double* G_host, int* ok, double* ustat, double* vstat,
                                double* effect, double* effect_se, double* pvalue) {
   if (!g || N < 1 || V < 1 || !G_host || !ok || !ustat || !vstat || !effect || !effect_se || !pvalue) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   const int nm = (int)g->member.size();
   std::vector<int> rcs(nm, RVT_OK);
   std::vector<std::thread> workers;
@@ -327,6 +533,7 @@ int rvt_group_score_block_host(rvt_group* g, int64_t N, int V, const double* G_h
 int rvt_group_cov_band_host(rvt_group* g, int64_t N, int V, const double* G_host, int halo, int chunk, double* band,
                             double* xz, double* zz, int* polymorphic) {
   if (!g || N < 1 || V < 1 || !G_host || halo < 0 || !band || !xz || !polymorphic) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
   const int nm = (int)g->member.size();
   if (chunk <= 0) chunk = std::max(256, std::min(1024, (V + nm - 1) / nm));
   const int n_chunks = (V + chunk - 1) / chunk;

@@ -120,6 +120,42 @@ def test_group_bgen_stream_matches_single_context(engine):
             assert getattr(a, f) == getattr(b, f), f
 
 
+def test_group_with_submit_workers_gives_the_same_records(engine, monkeypatch):
+    """RVT_GROUP_ASYNC=1: every member gets a submit worker thread (the caller only copies the buffer); records and their
+    order are those of the synchronous group."""
+    import rvtests_amd
+    N, d = 3001, 2
+    rng = np.random.default_rng(5)
+    genes = []
+    for g in range(70):
+        M = int(rng.integers(1, 60))
+        Graw, G, af = synth.make_gene(N, M, seed=9000 + g, missing=0.01 if g % 3 == 0 else 0.0, common=(g % 5 == 1))
+        genes.append((Graw, G, af))
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=19)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RVT_GROUP_ASYNC", mode)
+        grp = rvtests_amd.Group([0, 0])
+        try:
+            grp.fit_null(0, X, y)
+            got = []
+            for g, (Graw, G, af) in enumerate(genes):
+                if g % 2:
+                    grp.submit_gene(g, G, af)
+                else:
+                    grp.submit_gene_i8(g, np.where(np.isnan(Graw) | (Graw < 0), -9, Graw).astype(np.int8))
+                if g == 33:
+                    got += grp.collect_ready()
+            got += grp.collect()
+        finally:
+            grp.close()
+        assert [r.gene_id for r in got] == list(range(len(genes)))
+        outs.append(got)
+    for a, b in zip(*outs):
+        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f
+
+
 def test_group_meta_score_and_cov_band_equal_the_single_context(engine):
     """`--meta score` / `--meta cov` over a 2-member group (both on device 0): shares / chunks with a one-window halo,
     no exchange — the numbers of the single-context calls on the whole block."""
