@@ -150,23 +150,45 @@ __device__ __forceinline__ void hcw_doubles(const unsigned (&dg)[4][8], unsigned
 // are combined in fp64 once, at the end.  12 vector instructions per tile and operand.  (Folding every plane, or chained
 // triples of planes, into fp64 tiles per operand was measured slower in every class: the conversions cost more than
 // the shifts.)
+// Wide classes keep the tiles of their LAST pairs (the low planes) in LDS instead of registers: 4 T registers less per
+// lane and pair (60 at MT = 5, where the compiler otherwise spills 80 registers of the streaming loop to scratch memory:
+// 4.2 instead of 5.9 TB/s isolated).  The workgroup is one wave, its LDS operations execute in order, and a tile costs
+// one ds_read_b128 + one ds_write_b128 per 64-sample operand.
+#ifndef RVT_HCW_LDS_PAIRS_MT5
+#define RVT_HCW_LDS_PAIRS_MT5 1
+#endif
+template <int MT>
+constexpr int hcw_lds_pairs() {
+  return MT >= 5 ? RVT_HCW_LDS_PAIRS_MT5 : 0;
+}
+template <int MT>
+constexpr int hcw_lds_tiles() {
+  return hcw_lds_pairs<MT>() * (MT * (MT + 1) / 2);
+}
+
 template <int MT>
 struct HcwAcc {
   static constexpr int T = MT * (MT + 1) / 2;
-  i4_t p[kHcwPairs][T];
-  __device__ __forceinline__ void init() {
+  static constexpr int NL = hcw_lds_pairs<MT>();  // pairs kept in LDS: pair j >= R at lp[((j - R) T + t) 64 + lane]
+  static constexpr int R = kHcwPairs - NL;         // pairs kept in registers
+  i4_t p[R > 0 ? R : 1][T];
+  __device__ __forceinline__ void init(i4_t* lp, int lane) {
 #pragma unroll
-    for (int j = 0; j < kHcwPairs; ++j)
+    for (int j = 0; j < R; ++j)
 #pragma unroll
       for (int t = 0; t < T; ++t) p[j][t] = i4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NL * T; ++t) lp[t * 64 + lane] = i4_t{0, 0, 0, 0};
   }
-  __device__ __forceinline__ double value(int t, int i) const {  // pair j: weight 128^-(2j+2)
+  __device__ __forceinline__ double value(int t, int i, const i4_t* lp, int lane) const {  // pair j: weight 128^-(2j+2)
     double x = 0.0;
 #pragma unroll
-    for (int j = kHcwPairs - 1; j >= 0; --j) x = fma((double)p[j][t][i], hcw_pow2(-14 * (j + 1)), x);
+    for (int j = kHcwPairs - 1; j >= R; --j) x = fma((double)lp[((j - R) * T + t) * 64 + lane][i], hcw_pow2(-14 * (j + 1)), x);
+#pragma unroll
+    for (int j = R - 1; j >= 0; --j) x = fma((double)p[j][t][i], hcw_pow2(-14 * (j + 1)), x);
     return x;
   }
-  __device__ __forceinline__ void gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8]) {
+  __device__ __forceinline__ void gram(const unsigned (&pk)[MT][4], const unsigned (&dg)[4][8], i4_t* lp, int lane) {
     i4_t op[MT];
 #pragma unroll
     for (int c = 0; c < MT; ++c) op[c] = i4_t{(int)pk[c][0], (int)pk[c][1], (int)pk[c][2], (int)pk[c][3]};
@@ -184,10 +206,16 @@ struct HcwAcc {
         for (int c = r; c < MT; ++c) z[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, op[c], i4_t{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
         for (int c = r; c < MT; ++c) {
-          i4_t acc = p[j][t0 + c - r];
+          const bool in_lds = j >= R;
+          i4_t* const lt = lp + ((in_lds ? j - R : 0) * T + t0 + c - r) * 64 + lane;
+          i4_t acc = in_lds ? *lt : p[in_lds ? 0 : j][t0 + c - r];
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i] = (int)(((unsigned)z[c][i] << 7) + (unsigned)acc[i]);
-          p[j][t0 + c - r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, op[c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, op[c], acc, 0, 0, 0);
+          if (in_lds)
+            *lt = acc;
+          else
+            p[in_lds ? 0 : j][t0 + c - r] = acc;
         }
       }
       t0 += MT - r;
@@ -198,7 +226,7 @@ struct HcwAcc {
 
 template <int MT, int DEPTH>
 __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const NullTileW& nt, long long N, long long ld,
-                                                  int d) {
+                                                  int d, i4_t* lp) {
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, q = lane >> 4;
   const int wpart = blockIdx.x;
@@ -243,7 +271,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
     accT[c] = d4_t{0.0, 0.0, 0.0, 0.0};
     cs[c] = cs2[c] = 0;
   }
-  acc.init();
+  acc.init(lp, lane);
   HcwBurden bu{0.0, 0.0, 0.0, 0u};
   unsigned notHard = 0u;
 
@@ -297,7 +325,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
           __builtin_amdgcn_sched_barrier(0);
         }
         hcw_finish<false>(h, xv, bu, 0xffffffffu);
-        if (u == 3) acc.gram(pk, dg);
+        if (u == 3) acc.gram(pk, dg, lp, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -322,7 +350,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         hcw_issue<MT>(f[(u + DEPTH - 1) % DEPTH], rg, voff, rx, xoff, rq, qoff, (u + DEPTH - 1) * 128);
         __builtin_amdgcn_sched_barrier(0);
         hcw_step<MT, false>(f[u % DEPTH], u & 3, accT, pk, dg, cs, cs2, fx, bu, true, 0xffffffffu, notHard);
-        if ((u & 3) == 3) acc.gram(pk, dg);
+        if ((u & 3) == 3) acc.gram(pk, dg, lp, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -353,7 +381,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
     one(1, s + 1);
     one(2, s + 2);
     one(3, s + 3);
-    acc.gram(pk, dg);
+    acc.gram(pk, dg, lp, lane);
     s += 4;
   }
 
@@ -369,7 +397,7 @@ __device__ __forceinline__ void suffstat_hcw_body(const GeneDesc& gd, const Null
         const int col = c * 16 + v;
         if (col < M) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = acc.value(t, i);  // i32 map
+          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = acc.value(t, i, lp, lane);  // i32 map
         }
       }
   }
@@ -444,7 +472,8 @@ __global__ __launch_bounds__(64, WAVES) void gene_suffstat_hcw(const GeneDesc* _
                                                                long long N, long long ld, int d) {
   const GeneDesc gd = genes[blockIdx.y];
   if (gd.MT != MT) return;
-  suffstat_hcw_body<MT, DEPTH>(gd, nt, N, ld, d);
+  __shared__ i4_t lp[hcw_lds_tiles<MT>() > 0 ? hcw_lds_tiles<MT>() * 64 : 1];
+  suffstat_hcw_body<MT, DEPTH>(gd, nt, N, ld, d, lp);
 }
 
 }  // namespace rvt

@@ -56,7 +56,7 @@ static const Cfg kCfgs[] = {
 #ifdef HCW_CFGS
     HCW_CFGS
 #else
-    CFG(1, 2, 3), CFG(2, 2, 2), CFG(2, 3, 1), CFG(3, 2, 1), CFG(3, 3, 1), CFG(4, 2, 1), CFG(4, 1, 1), CFG(5, 2, 1), CFG(5, 1, 1),
+    CFG(1, 2, 3), CFG(2, 2, 2), CFG(3, 3, 1), CFG(3, 2, 1), CFG(4, 2, 1), CFG(4, 1, 1), CFG(5, 1, 1),
 #endif
 };
 
@@ -85,7 +85,9 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_G, dim3(4096), dim3(256), 0, 0, dG, (long long)(gstride * ngenes), 7ull);
     double *parts, *colstat, *bparts;
     CK(hipMalloc(&parts, sizeof(double) * (size_t)ngenes * nw * Mp * Cp));
-    CK(hipMalloc(&colstat, sizeof(double) * (size_t)ngenes * nw * 3 * Mp));
+    CK(hipMalloc(&colstat, sizeof(double) * (size_t)ngenes * nw * kHcColstatRows * Mp));
+    unsigned* wflags;
+    CK(hipMalloc(&wflags, sizeof(unsigned) * (size_t)ngenes * nw));
     CK(hipMalloc(&bparts, sizeof(double) * (size_t)ngenes * nw * 2 * (3 + d)));
     std::vector<GeneDesc> gds(ngenes);
     for (int g = 0; g < ngenes; ++g) {
@@ -95,7 +97,8 @@ int main(int argc, char** argv) {
       gd.M = M; gd.MT = MT; gd.CT = CT; gd.Mp = Mp; gd.Cp = Cp;
       gd.n_wparts = nw; gd.steps_per_wpart = (int)spw;
       gd.parts = parts + (size_t)g * nw * Mp * Cp;
-      gd.colstat = colstat + (size_t)g * nw * 3 * Mp;
+      gd.colstat = colstat + (size_t)g * nw * kHcColstatRows * Mp;
+      gd.wflags = wflags + (size_t)g * nw;
       gd.bparts = bparts + (size_t)g * nw * 2 * (3 + d);
       gd.n_bparts = nw; gd.hc = 1;
     }
@@ -121,7 +124,7 @@ int main(int argc, char** argv) {
       printf("bench M=%d MT=%d depth=%d waves=%d: %.3f ms per %d genes, %.2f TB/s algorithmic\n", M, MT, cf.depth, cf.waves,
              ms / reps, ngenes, bytes / (ms * 1e-3) / 1e12);
     }
-    CK(hipFree(dG)); CK(hipFree(parts)); CK(hipFree(colstat)); CK(hipFree(bparts)); CK(hipFree(dgd));
+    CK(hipFree(dG)); CK(hipFree(parts)); CK(hipFree(colstat)); CK(hipFree(bparts)); CK(hipFree(dgd)); CK(hipFree(wflags));
   }
   return 0;
 }
