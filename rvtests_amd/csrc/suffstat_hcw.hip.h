@@ -150,16 +150,25 @@ __device__ __forceinline__ void hcw_doubles(const unsigned (&dg)[4][8], unsigned
 // are combined in fp64 once, at the end.  12 vector instructions per tile and operand.  (Folding every plane, or chained
 // triples of planes, into fp64 tiles per operand was measured slower in every class: the conversions cost more than
 // the shifts.)
-// Wide classes keep the tiles of their LAST pairs (the low planes) in LDS instead of registers: 4 T registers less per
-// lane and pair (60 at MT = 5, where the compiler otherwise spills 80 registers of the streaming loop to scratch memory:
-// 4.2 instead of 5.9 TB/s isolated).  The workgroup is one wave, its LDS operations execute in order, and a tile costs
-// one ds_read_b128 + one ds_write_b128 per 64-sample operand.
+// Classes of three and five tiles keep the tiles of their LAST pairs (the low planes) in LDS instead of registers: 4 T
+// registers less per lane and pair.  The workgroup is one wave, its LDS operations execute in order, and a tile costs one
+// ds_read_b128 + one ds_write_b128 per 64-sample operand.  MT = 5: 120 registers less, no spilling (with all three pairs
+// in registers the compiler spills 80 registers of the streaming loop to scratch memory: 4.2 instead of 5.4 TB/s
+// isolated).  MT = 3: 48 registers less bring the kernel under 256, i.e. TWO waves per SIMD (5.2 -> 6.0 TB/s on the widths
+// M = 33..48 of a batch; with one wave per SIMD the loop is bound by its own instruction issue, not by memory).  MT = 4
+// does not get under 256 registers this way (20 KB of tiles per wave x 8 waves is also all of the CU's LDS).
 #ifndef RVT_HCW_LDS_PAIRS_MT5
-#define RVT_HCW_LDS_PAIRS_MT5 1
+#define RVT_HCW_LDS_PAIRS_MT5 2
+#endif
+#ifndef RVT_HCW_LDS_PAIRS_MT4
+#define RVT_HCW_LDS_PAIRS_MT4 0
+#endif
+#ifndef RVT_HCW_LDS_PAIRS_MT3
+#define RVT_HCW_LDS_PAIRS_MT3 2
 #endif
 template <int MT>
 constexpr int hcw_lds_pairs() {
-  return MT >= 5 ? RVT_HCW_LDS_PAIRS_MT5 : 0;
+  return MT >= 5 ? RVT_HCW_LDS_PAIRS_MT5 : (MT == 4 ? RVT_HCW_LDS_PAIRS_MT4 : (MT == 3 ? RVT_HCW_LDS_PAIRS_MT3 : 0));
 }
 template <int MT>
 constexpr int hcw_lds_tiles() {

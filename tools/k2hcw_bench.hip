@@ -56,7 +56,7 @@ static const Cfg kCfgs[] = {
 #ifdef HCW_CFGS
     HCW_CFGS
 #else
-    CFG(1, 2, 3), CFG(2, 2, 2), CFG(3, 3, 1), CFG(3, 2, 1), CFG(4, 2, 1), CFG(4, 1, 1), CFG(5, 1, 1),
+    CFG(1, 2, 3), CFG(2, 2, 2), CFG(3, 2, 2), CFG(3, 1, 2), CFG(4, 2, 1), CFG(4, 1, 1), CFG(5, 1, 1),
 #endif
 };
 
@@ -75,10 +75,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_null, dim3(1024), dim3(256), 0, 0, dT, ld * (d + 3), 99ull);
   hipLaunchKernelGGL(fill_bytes, dim3(1024), dim3(256), 0, 0, (unsigned*)dq, ld * 2, 5ull);
   NullTileW nt{dT, d + 3, dq};
+  // default: 128 genes of one width near the top of each class; "spread" as first argument: the widths of a class as a
+  // 512-gene batch with M ~ U{20..80} holds them (every width of the class in turn, 134 genes for the full classes)
+  const bool spread = argc > 1 && !strcmp(argv[1], "spread");
   const int Ms[] = {12, 28, 44, 60, 76};
-  const int ngenes = 128;
-  for (int M : Ms) {
-    const int MT = (M + 15) / 16, CT = (M + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CT;
+  for (int Mtop : Ms) {
+    const int MT = (Mtop + 15) / 16;
+    const int Mlo = spread ? (MT == 2 ? 20 : 16 * (MT - 1) + 1) : Mtop, Mhi = spread ? 16 * MT : Mtop;
+    if (spread && MT == 1) continue;
+    const int ngenes = spread ? (int)(512.0 * (Mhi - Mlo + 1) / 61.0 + 0.5) : 128;
+    const int M = Mhi;  // (allocation width)
+    const int CTmax = (Mhi + d + 1 + 15) / 16, Mp = 16 * MT, Cp = 16 * CTmax;
+    double sumM = 0;
     double* dG;
     const size_t gstride = (size_t)ld * M;
     CK(hipMalloc(&dG, sizeof(double) * gstride * ngenes));
@@ -94,7 +102,9 @@ int main(int argc, char** argv) {
       GeneDesc& gd = gds[g];
       memset(&gd, 0, sizeof(gd));
       gd.G = dG + gstride * g;
-      gd.M = M; gd.MT = MT; gd.CT = CT; gd.Mp = Mp; gd.Cp = Cp;
+      const int Mg = Mlo + (g * 7) % (Mhi - Mlo + 1);
+      sumM += Mg;
+      gd.M = Mg; gd.MT = MT; gd.CT = (Mg + d + 1 + 15) / 16; gd.Mp = Mp; gd.Cp = 16 * gd.CT;
       gd.n_wparts = nw; gd.steps_per_wpart = (int)spw;
       gd.parts = parts + (size_t)g * nw * Mp * Cp;
       gd.colstat = colstat + (size_t)g * nw * kHcColstatRows * Mp;
@@ -120,8 +130,8 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(e1));
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      const double bytes = (8.0 * N * M + 8.0 * N * (d + 4)) * ngenes * reps;
-      printf("bench M=%d MT=%d depth=%d waves=%d: %.3f ms per %d genes, %.2f TB/s algorithmic\n", M, MT, cf.depth, cf.waves,
+      const double bytes = (8.0 * N * (sumM / ngenes) + 8.0 * N * (d + 4)) * ngenes * reps;
+      printf("bench M=%d..%d MT=%d depth=%d waves=%d: %.3f ms per %d genes, %.2f TB/s algorithmic\n", Mlo, Mhi, MT, cf.depth, cf.waves,
              ms / reps, ngenes, bytes / (ms * 1e-3) / 1e12);
     }
     CK(hipFree(dG)); CK(hipFree(parts)); CK(hipFree(colstat)); CK(hipFree(bparts)); CK(hipFree(dgd)); CK(hipFree(wflags));

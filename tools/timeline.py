@@ -9,6 +9,9 @@ from collections import defaultdict
 
 
 def short(name):
+    if "gene_suffstat_hcw" in name:
+        i = name.find("<")
+        return "K2hcw" + name[i:name.find(",", i)].replace(" ", "") + ">"
     if "gene_suffstat_hc" in name:
         i = name.find("<")
         return "K2hc" + name[i:name.find(",", i)].replace(" ", "") + ">"
