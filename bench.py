@@ -57,13 +57,14 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=
             del u
         nsample = float(N)
         if dosage:
-            # imputed dosages: every call blurred by its genotype probabilities, quantised to 1/256 as an 8-bit BGEN stores
-            # them (no block of the batch holds hard calls only)
+            # imputed dosages: every call blurred by its genotype probabilities and printed with three decimals, as the
+            # DS field of an imputation server's VCF holds it (`rvtest --dosage DS`): the double nearest to K / 1000.  No
+            # block of the batch holds hard calls only; imputed data has no missing entries.
             e = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) * 0.12
             Gv = G[:, :N]
-            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 256.0) / 256.0)
+            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 1000.0) / 1000.0)
             del e
-        if rng.random() < missing_frac:
+        if not dosage and rng.random() < missing_frac:
             miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3
             Gv = G[:, :N]
             ac = torch.where(miss, torch.zeros_like(Gv), Gv).sum(1)                  # integer-valued
@@ -334,8 +335,11 @@ def main():
                     help="share of the genes with missing genotypes (0.1 %% of their calls, imputed to the column mean); "
                          "SURVEY config 3: 0.05")
     ap.add_argument("--dosage", action="store_true",
-                    help="every block holds dosages (imputed data): the general fp64 kernel; the engine is told so "
-                         "(rvt_set_content_hint) as an adapter reading --dosage / BGEN input would")
+                    help="every block holds dosages with three decimals (imputed data, VCF DS fields); the engine is told "
+                         "so (rvt_set_content_hint, rvt_set_dosage_lattice) as an adapter reading --dosage input would")
+    ap.add_argument("--dosage-lattice", type=int, default=1000,
+                    help="with --dosage: the lattice denominator stated to the engine (1000 = three decimals: the int8 "
+                         "lattice kernel); 0 = not stated: the general fp64 kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
@@ -378,6 +382,7 @@ def main():
                                  args.missing_frac, args.dosage)
     if args.dosage:
         eng.set_content_hint(0)
+        eng.set_dosage_lattice(args.dosage_lattice)
     pack = torch.empty((N, d + 1), dtype=torch.float64, device=dev)
     if rank == 0:
         X, y = make_phenotype(dev, N, 20260002, binary, causal_effect(blocks, N, binary))
@@ -467,6 +472,8 @@ def main():
         # a second stream — its numbers are reported separately (an overlapped kernel's own duration is not chip time).
         if tm.n_suffstat_hc_launches > 0:
             k2_name = "gene_suffstat_hcw" if binary else "gene_suffstat_hc"   # (weighted variant for a binary trait)
+            if args.dosage:
+                k2_name = "gene_suffstat_lat"                                 # (dosages on the stated decimal lattice)
             n_l, ms_l, by_l = tm.n_suffstat_hc_launches, tm.ms_suffstat_hc, tm.alg_bytes_hc
         else:
             k2_name = "gene_suffstat_mfma"
@@ -498,12 +505,13 @@ def main():
                                    "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
                                    "fp64 column-major blocks%s" % (3 if binary else 2, N, args.genes, args.m_lo,
                                                                    args.m_hi, "binary" if binary else "quantitative",
-                                                                   " of DOSAGES (no hard-call block)" if args.dosage else ""),
+                                                                   (" of DOSAGES with three decimals (no hard-call block; lattice stated: %d)"
+                                                                    % args.dosage_lattice) if args.dosage else ""),
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
                        "parallelism": "gene-sharded x%d" % world, "genes_ok": ok,
                        "hard_call_genes_per_step": (tm.genes_hard_call - tm.genes_handed_back) / max(args.steps, 1),
                        "genes_handed_back_per_step": tm.genes_handed_back / max(args.steps, 1),
-                       "genes_with_imputed_columns": args.missing_frac},
+                       "genes_with_imputed_columns": 0.0 if args.dosage else args.missing_frac},
             "roofline": {"kernel": k2_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -210,6 +210,17 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * rvt_block_classify is a query for tools and tests: one streaming pass, 1 when every entry is 0.0 / 1.0 / 2.0. */
 int rvt_block_classify(rvt_ctx* ctx, const double* dG, int M, int* is_hard_call);
 int rvt_set_content_hint(rvt_ctx* ctx, int hint);
+/* Dosages on a decimal lattice.  `rvtest --dosage DS` (src/Main.cpp FLAG_dosageTag; VCFGenotypeExtractor) hands fit() the
+ * doubles strtod made of a VCF field printed with a fixed number of decimals — imputation servers write three — i.e. the
+ * doubles nearest to K / denominator, K an integer, denominator = 10^decimals.  When the adapter states the denominator
+ * (1 .. 2048; 0 = not stated, the default) such blocks — the caller's doubles under rvt_set_content_hint(ctx, 0), and
+ * what rvt_submit_gene_vcf_dosage decodes — take gene_suffstat_lat (rvtests_amd/csrc/suffstat_lat.hip.h) under a
+ * quantitative trait: K = rint(g denominator) is split into two 7-bit digits and G'G = K'K / denominator^2 is formed on
+ * the int8 matrix cores, exactly, with the burden collapse in the same pass; the kernel is bound by HBM where the fp64
+ * kernel is bound by the fp64 matrix pipe.  Every value is tested (|g denominator - K| <= 2^-30, 0 <= g <= 2): a block that
+ * holds anything else (BGEN's float probabilities, mean-imputed entries, a different number of decimals) is handed back
+ * and computed by the fp64 kernel in the same call.  A wrong statement costs time, never correctness. */
+int rvt_set_dosage_lattice(rvt_ctx* ctx, int denominator);
 /* experiments / tests: on = 0 keeps every gene on the fp64 kernel (as the environment variable RVT_HARDCALL=0 does for
  * the whole process), on = 1 restores the default */
 int rvt_set_hardcall(rvt_ctx* ctx, int on);

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <functional>
 #include "kernels.hip.h"
+#include "suffstat_lat.hip.h"
 #include "host_stage.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
@@ -32,6 +33,8 @@ void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nul
                   int d);
 void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
                    int d);
+void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
+                   long long ld, int d);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
@@ -239,6 +242,7 @@ struct rvt_ctx {
   // kernel unless the caller has said they hold dosages (rvt_set_content_hint).  No history: the kernel a block runs on
   // — and with it the last bits of its records — depends on the block and the hint alone.
   int content_hint = -1;
+  int lattice_den = 0;        // rvt_set_dosage_lattice: dosage doubles are multiples of 1 / lattice_den (0: not stated)
   int* d_kind = nullptr;      // device flag of rvt_block_classify (a stateless query)
   bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
   double null_beta[RVT_MAX_COV] = {};  // estimates of the model rvt_fit_null fitted
@@ -257,7 +261,8 @@ struct rvt_ctx {
     int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
     int io_error = 0;     // != 0: the gene's VCF text / BGEN blocks were malformed (h_io_err): its record is void
     int decoded = 0;      // 1: VCF text, 2: BGEN blocks (the submission has an input-error word in its ring slot)
-    int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages, -1 unknown
+    int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages (BGEN), 2 decimal
+                          // dosages (VCF text), -1 unknown
   };
   std::deque<Pending> queue;
   std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
@@ -868,6 +873,14 @@ int rvt_set_hardcall(rvt_ctx* c, int on) {
   return RVT_OK;
 }
 
+int rvt_set_dosage_lattice(rvt_ctx* c, int denominator) {
+  if (!c) return RVT_E_INVALID;
+  if (denominator < 0 || denominator > kLatMaxDen)
+    return fail(c, RVT_E_INVALID, "rvt_set_dosage_lattice: denominator %d outside [0, %d]", denominator, kLatMaxDen);
+  c->lattice_den = denominator;
+  return RVT_OK;
+}
+
 int rvt_set_content_hint(rvt_ctx* c, int hint) {
   if (!c || hint < -1 || hint > 1) return fail(c, RVT_E_INVALID, "hint must be -1, 0 or 1");
   c->content_hint = hint;
@@ -1211,6 +1224,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
                            c->d_nulltile != nullptr && nd_is_default;
   const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
   const bool predict_hc = c->content_hint != 0;  // blocks of unknown content (rvt_set_content_hint)
+  // dosages on a decimal lattice (rvt_set_dosage_lattice): the caller's doubles when the hint says dosages, and what the
+  // VCF dosage decoder wrote — gene_suffstat_lat (hc = 2), which tests every value like the hard-call kernel does
+  const bool lat_possible = hc_possible && !nc.binary && !cov && c->lattice_den > 0;
 
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
@@ -1236,6 +1252,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       } else {
         const int k = kind ? kind[g] : -1;
         gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;
+        if (lat_possible && gd.MT <= kLatMaxMT && (k == 2 || (k < 0 && !predict_hc))) {
+          gd.hc = 2;
+          gd.lat_den = (double)c->lattice_den;
+        }
       }
     }
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
@@ -1244,7 +1264,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       for (int j = 0; j < M; ++j)  // predicted flips: column sum > N  <=>  allele frequency > 1/2 (verified on the device)
         if (af[af_total + j] > 0.5) gd.pflip[j >> 4] |= (unsigned short)(1u << (j & 15));
     }
-    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc, &total, &offs[g],
+    layout_gene(M, d, n_wparts, nsteps, n_bparts, dbg != nullptr, gd.hc ? 1 : 0, &total, &offs[g],
                 (tests & RVT_TEST_ANALYTICVT) != 0);
     af_total += M;
   }
@@ -1289,7 +1309,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.parts = reinterpret_cast<double*>(base + o.parts);
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
     gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
-    gd.pq = (gd.hc && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
+    gd.pq = (gd.hc == 1 && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
     gd.wflags = (gd.hc && o.wflags) ? reinterpret_cast<unsigned*>(base + o.wflags) : nullptr;
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
@@ -1364,10 +1384,13 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   }
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
-    while (e < n && h_desc[e].MT == h_desc[k].MT) ++e;
+    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].hc == h_desc[k].hc) ++e;
     hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
-    if (hcw)
+    if (h_desc[k].hc == 2)
+      k2_launch_lat(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2},
+                    (double)c->lattice_den, (long long)N, (long long)ld, d);
+    else if (hcw)
       k2_launch_hcw(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTileW{c->d_nulltile_w, d + 3, c->d_vq},
                     (long long)N, (long long)ld, d);
     else
@@ -1748,6 +1771,7 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
       const double hh = s - 4.0 * (pij + pji) - 16.0 * q;
       s = hh + mu[j] * pij + mu[i] * pji + (mu[i] * mu[j]) * q;
     }
+    if (j < M && g0.hc == 2) s /= g0.lat_den * g0.lat_den;  // lattice dosages: the integer K'K, divided once (gene_assemble)
     return s;
   };
   for (int i = 0; i < M; ++i) {
@@ -1768,6 +1792,7 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
       mn = std::min(mn, mu[i]);
       mx = std::max(mx, mu[i]);
     }
+    if (g0.hc == 2) s /= g0.lat_den;
     if (colsum) colsum[i] = s;
     if (cmin) cmin[i] = mn;
     if (cmax) cmax[i] = mx;
@@ -4716,7 +4741,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   const int64_t N = c->nc.N, ld = c->null_ld;
   // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
   // (dosage text, BGEN), or whatever the caller's doubles are
-  p.kind = (mode == 2 || mode == 3 || mode == 4) ? 1 : ((mode == 5 || mode == 6) ? 0 : -1);
+  p.kind = (mode == 2 || mode == 3 || mode == 4) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1));
   p.decoded = (mode == 4 || mode == 5) ? 1 : (mode == 6 ? 2 : 0);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return

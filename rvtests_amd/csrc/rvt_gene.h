@@ -112,6 +112,7 @@ struct HcMasked {
   const unsigned* pq;      // P x pq_words packed counters ([tile][half][lane], tiles: P' MT x MT, then Q upper triangle)
   const unsigned* wflags;  // P flags: bit 0 = the part's image was written
   int pq_words;
+  double lat_den;  // > 0: lattice dosages (suffstat_lat.hip.h) — the G'G block and the column sums are integers, scaled here
 };
 constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 
@@ -146,6 +147,8 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
         s += a7;
       }
       for (; p < P; ++p) s += src[(size_t)p * stride];
+      // lattice dosages: the sum of the integer tiles K'K is exact; G'G = K'K / den^2 with one rounding
+      if (hcm && hcm->lat_den > 0.0 && j < M) s /= hcm->lat_den * hcm->lat_den;
     }
     R[idx] = s;
   }
@@ -185,6 +188,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
       }
       muv[j] = mu;
       cmv[j] = cm;
+      if (hcm->lat_den > 0.0) s /= hcm->lat_den;  // (the exact integer sum of K)
     }
     colsum[j] = s;
     cmin[j] = mn;

@@ -47,10 +47,12 @@ struct GeneDesc {
   // hard-call path (suffstat_hc.hip.h)
   unsigned short pflip[8];  // predicted flip bits (af > 0.5) per 16-variant block, first 6 blocks
   int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
-  int hc;                   // 1: the block holds only 0.0 / 1.0 / 2.0 and went through gene_suffstat_hc
+  int hc;                   // 1: gene_suffstat_hc / _hcw (hard calls), 2: gene_suffstat_lat (lattice dosages), 0: general kernel
   double* vt_mem;           // AnalyticVT workspace (gene_vt_doubles(Mp)), null unless the test is requested
   unsigned* pq;             // hard-call path: n_wparts x hc_pq_words(MT) packed 16-bit counters of the masked tiles
   unsigned* wflags;         // hard-call path: per wave-part, bit 0 = masked entries met (pq written), bit 1 = bad entry
+  double lat_den;           // hc == 2: the lattice denominator — the G'G tiles and column sums of `parts` / `colstat` are
+                            // the INTEGERS K'K and sum K (exact through the reduction), divided once in gene_assemble
 };
 
 struct NullDev {

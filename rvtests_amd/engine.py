@@ -82,9 +82,10 @@ def build_library(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
-    # five objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
+    # six objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-    units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip"]
+    units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
+             "k2_lattice.hip"]
     objs, procs = [], []
     for u in units:
         obj = os.path.join(CSRC, u.replace(".hip", ".o"))
@@ -143,6 +144,8 @@ def load_library():
     L.rvt_set_hardcall.argtypes = [vp, C.c_int]
     L.rvt_set_content_hint.restype = C.c_int
     L.rvt_set_content_hint.argtypes = [vp, C.c_int]
+    L.rvt_set_dosage_lattice.restype = C.c_int
+    L.rvt_set_dosage_lattice.argtypes = [vp, C.c_int]
     run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
                 C.POINTER(Params), C.POINTER(GeneResult)]
     L.rvt_run_blocks.restype = C.c_int
@@ -385,6 +388,11 @@ class Engine:
         """What the caller's own fp64 blocks hold: -1 unknown (start on the hard-call kernel), 0 dosages (start on the fp64
         kernel), 1 hard calls / mean-imputed hard calls (rvt_set_content_hint).  Never affects correctness."""
         self._check(self.L.rvt_set_content_hint(self.ctx, int(hint)))
+
+    def set_dosage_lattice(self, denominator):
+        """The dosage doubles are multiples of 1 / denominator rounded to double (VCF DS fields with a fixed number of
+        decimals: 1000 for three); 0 = not stated (rvt_set_dosage_lattice).  Never affects correctness."""
+        self._check(self.L.rvt_set_dosage_lattice(self.ctx, int(denominator)))
 
     def classify_block(self, ptr, M):
         """Query (nothing is remembered): does the device block hold hard calls only (rvt_block_classify)?"""
