@@ -254,3 +254,50 @@ def test_streamed_dosage_genes_take_the_lattice_kernel(engine):
         assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref
         for f in FIELDS:
             assert abs(getattr(a, f) - getattr(b, f)) <= 1e-10 * abs(getattr(b, f)) + 1e-300, f
+
+
+def test_vcf_dosage_text_takes_the_lattice_kernel():
+    """`--dosage DS` through the engine's own VCF text decoder: complete three-decimal fields run on the lattice kernel when
+    the adapter has stated the lattice ("." is atof's 0.0 there, not a missing call); a gene with a five-decimal field is
+    handed back.  Records as without the statement."""
+    import rvtests_amd
+    eng = rvtests_amd.Engine(0)
+    try:
+        N, d, n_file = 3000, 2, 3100
+        rng = np.random.default_rng(5)
+        rows = np.full(n_file, -1, dtype=np.int32)
+        keep = rng.choice(n_file, N, replace=False)
+        rows[keep] = rng.permutation(N)
+        X, y, res, v, s2 = synth.make_null(N, d, 0, seed=14)
+        eng.fit_null(0, X, y)
+        eng.vcf_set_samples(rows)
+        eng.vcf_set_filters(0, 0, 0, 0)
+        eng.vcf_set_dosage(True)
+
+        def record(pos, odd):
+            vals = np.where(rng.random(n_file) < 0.03, rng.uniform(0.3, 2.0, n_file), rng.uniform(0, 0.08, n_file))
+            cols = [b"0/0:%.3f" % x for x in vals]
+            cols[int(keep[1])] = b"./.:."
+            if odd:
+                cols[int(keep[0])] = b"0/1:0.12345"
+            head = b"\t".join([b"1", b"%d" % pos, b".", b"A", b"G", b"50", b"PASS", b".", b"GT:DS"])
+            return head + b"\t" + b"\t".join(cols)
+
+        genes = [[record(10 * g + j, g == 2) for j in range(9 + 4 * g)] for g in range(4)]
+        runs = {}
+        for den in (0, 1000):
+            eng.set_dosage_lattice(den)
+            eng.set_profiling(True)
+            eng.timing(reset=True)
+            for g, lines in enumerate(genes):
+                eng.submit_gene_vcf_dosage(g, lines, b"DS")
+            runs[den] = (eng.collect(), eng.timing(reset=True))
+            eng.set_profiling(False)
+        assert runs[0][1].genes_hard_call == 0
+        assert runs[1000][1].genes_hard_call == 4 and runs[1000][1].genes_handed_back == 1
+        for a, b in zip(runs[1000][0], runs[0][0]):
+            assert a.gene_id == b.gene_id and a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref and a.status == b.status
+            for f in FIELDS:
+                assert abs(getattr(a, f) - getattr(b, f)) <= 1e-10 * abs(getattr(b, f)) + 1e-300, f
+    finally:
+        eng.close()
