@@ -9,8 +9,8 @@
 //     size of the rounding the fp64 sums of 10^5 terms carry); stored per group of four samples as [plane 0..7][4 bytes],
 //     so a lane's digits for the four samples of a step are 32 contiguous bytes at the same offset its genotype doubles
 //     have inside a column;
-//   * per 64-sample operand and plane the A operand is the byte-wise product d_p (x) g (|.| <= 128, built from two masks:
-//     g is 0 / 1 / 2), the B operand the packed genotypes: ONE v_mfma_i32_16x16x64_i8 (16 cycles) per plane and tile,
+//   * per 64-sample operand and plane the A operand is the byte-wise product d_p (x) g (|.| <= 128: a byte select among
+//     0, d, 2 d — one v_perm_b32, see HcwRow), the B operand the packed genotypes: ONE v_mfma_i32_16x16x64_i8 (16 cycles) per plane and tile,
 //     6 per tile against 16 fp64 instructions of 64 cycles;
 //   * the six plane products of a tile are combined exactly in int32 (HcwAcc below);
 //   * G'V[X | rr] stays on the fp64 matrix cores against the null tile [vX_0 .. vX_{d-1} | res | v | 0] (res = v rr);
@@ -116,22 +116,26 @@ __device__ __forceinline__ void hcw_step(const HcwStep<MT>& f, const int T, d4_t
 
 __device__ __forceinline__ double hcw_pow2(int e) { return __builtin_bit_cast(double, (unsigned long long)(1023 + e) << 52); }
 
-// A operands of one row tile: byte-wise d g from the digits d, their doubles d2 and the two genotype masks of the row
+// A operands of one row tile: byte-wise d g from the digits d and their doubles d2.  The product is a byte SELECT — 0, d or
+// 2 d for g = 0, 1, 2 — so one v_perm_b32 per (plane, step) forms it from {d2, d} with a selector built once per step of
+// the row: byte k of the selector is 0x0c (constant 0), k (byte k of d) or 4 + k (byte k of d2).  The selector itself
+// comes from two table look-ups with the packed genotypes AS selector (v_perm_b32 again) — 3 instructions per step and
+// row, 1 per plane and step, where the mask form ((d & m1) | (d2 & m2)) took 4 + 3.
 template <int MT>
 struct HcwRow {
-  unsigned m1[4], m2[4];
+  unsigned sel[4];
   __device__ __forceinline__ explicit HcwRow(const unsigned (&pkr)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const unsigned b1 = pkr[s] & 0x01010101u, b2 = (pkr[s] >> 1) & 0x01010101u;
-      m1[s] = (b1 << 8) - b1;  // 0xFF in the bytes with g = 1
-      m2[s] = (b2 << 8) - b2;  // 0xFF in the bytes with g = 2
+      const unsigned base = __builtin_amdgcn_perm(0u, 0x0004000cu, pkr[s]);  // g = 0 / 1 / 2 -> 0x0c / 0x00 / 0x04
+      const unsigned nz = __builtin_amdgcn_perm(0u, 0x00ffff00u, pkr[s]);    // g = 0 / 1 / 2 -> 0x00 / 0xff / 0xff
+      sel[s] = base | (nz & 0x03020100u);
     }
   }
   __device__ __forceinline__ i4_t aop(const unsigned (&dg)[4][8], const unsigned (&d2)[4][kHcwPlanes], int p) const {
     unsigned w[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w[s] = (dg[s][p] & m1[s]) | (d2[s][p] & m2[s]);
+    for (int s = 0; s < 4; ++s) w[s] = __builtin_amdgcn_perm(d2[s][p], dg[s][p], sel[s]);
     return i4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
   }
 };
