@@ -587,6 +587,8 @@ int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const u
  * sends every permutation gene to member 0, which replays the reference's rand() stream (see rvt_set_perm_exact) */
 int rvt_group_set_perm_exact(rvt_group* group, int on);
 int rvt_group_rand_seed(rvt_group* group, unsigned seed);
+/* rvt_set_content_hint + rvt_set_dosage_lattice on every member (what the caller's blocks hold: see those functions) */
+int rvt_group_set_content(rvt_group* group, int hint, int lattice_denominator);
 /* `--meta score` / `--meta cov` over a group (chunks with a one-window halo, no exchange).  G_host: N x V
  * column-major (leading dimension N), the genotype vectors of V consecutive single-variant fit() calls; one host thread per
  * member for the duration of the call.

@@ -85,6 +85,12 @@ GpuBroker& GpuBroker::instance() {
     init = true;
     if (const char* e = getenv("RVT_ADAPTER_BATCH")) b.setBatchWindow(atoi(e));
     if (const char* e = getenv("RVT_ADAPTER_BATCH_GB")) b.setBatchBytes((size_t)std::max(1, atoi(e)) << 30);
+    if (const char* e = getenv("RVT_DOSAGE")) {  // "1": dosages; "d3": dosages printed with three decimals
+      if (e[0] == 'd')
+        b.setDosage(atoi(e + 1));
+      else if (atoi(e) != 0)
+        b.setDosage(-1);
+    }
   }
   return b;
 }
@@ -105,6 +111,14 @@ int GpuBroker::ensureContext(int device) {
   const int rc = rvt_group_init(&grp, (int)ids.size(), ids.data());
   if (rc) return rc;
   ctx = rvt_group_member(grp, 0);
+  if (dosage) {
+    int den = 0;
+    if (dosageDecimals >= 0 && dosageDecimals <= 3) {
+      den = 1;
+      for (int k = 0; k < dosageDecimals; ++k) den *= 10;
+    }
+    return rvt_group_set_content(grp, 0, den);
+  }
   return 0;
 }
 

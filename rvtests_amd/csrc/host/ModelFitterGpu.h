@@ -137,6 +137,14 @@ class GpuBroker {
   // RVT_ADAPTER_BATCH_GB override; window = 1 keeps at most one gene in flight).
   void setBatchWindow(int k) { window = k < 1 ? 1 : k; }
   void setBatchBytes(size_t b) { windowBytes = b; }
+  // `--dosage TAG` (src/Main.cpp FLAG_dosageTag): the blocks fit() receives hold dosages, not hard calls; `decimals` = the
+  // number of decimals the tag is printed with (3 for an imputation server's DS; -1 = unknown / not decimal text, e.g.
+  // BGEN): states the lattice 10^decimals to the engine (rvt_group_set_content).  Call before the first fit(); RVT_DOSAGE
+  // (1 / the number of decimals as "d3") does the same from the environment.  Never affects the records.
+  void setDosage(int decimals) {
+    dosage = true;
+    dosageDecimals = decimals;
+  }
   int submit(const GeneData& gd, bool binary, std::string* err);
   void enqueue(ModelFitter* m, TextSink* fp, const std::string& siteTab, int64_t serial);
   int flush();       // wait for everything pending and write all rows
@@ -160,6 +168,8 @@ class GpuBroker {
  private:
   rvt_group* grp = nullptr;
   rvt_ctx* ctx = nullptr;  // member 0
+  bool dosage = false;
+  int dosageDecimals = -1;
   uint32_t tests = 0;
   rvt_params params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   bool haveNull = false;

@@ -234,6 +234,16 @@ int rvt_group_set_perm_exact(rvt_group* g, int on) {
   return RVT_OK;
 }
 
+int rvt_group_set_content(rvt_group* g, int hint, int lattice_denominator) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member) {
+    int rc = rvt_set_content_hint(m, hint);
+    if (!rc) rc = rvt_set_dosage_lattice(m, lattice_denominator);
+    if (rc) return gfail(g, rc, "rvt_group_set_content", m);
+  }
+  return RVT_OK;
+}
+
 int rvt_group_rand_seed(rvt_group* g, unsigned seed) {
   if (!g) return RVT_E_INVALID;
   if (int rcf = group_flush(g)) return rcf;

@@ -267,6 +267,8 @@ def load_library():
     L.rvt_group_submit_gene_bed.restype = C.c_int
     L.rvt_group_submit_gene_bed.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(Params),
                                             c_double_p]
+    L.rvt_group_set_content.restype = C.c_int
+    L.rvt_group_set_content.argtypes = [gp, C.c_int, C.c_int]
     L.rvt_group_collect.restype = C.c_int
     L.rvt_group_collect.argtypes = [gp, C.POINTER(GeneResult), C.c_int, c_int_p]
     L.rvt_group_collect_ready.restype = C.c_int
@@ -862,6 +864,11 @@ class Group:
         if self.g:
             self.L.rvt_group_destroy(self.g)
             self.g = C.c_void_p()
+
+    def set_content(self, hint, lattice_denominator=0):
+        """What the caller's fp64 blocks hold, on every member (rvt_group_set_content): hint as Engine.set_content_hint,
+        lattice_denominator as Engine.set_dosage_lattice."""
+        self._check(self.L.rvt_group_set_content(self.g, int(hint), int(lattice_denominator)))
 
     def fit_null(self, trait, X, y):
         X = np.asfortranarray(X, dtype=np.float64)

@@ -301,3 +301,39 @@ def test_vcf_dosage_text_takes_the_lattice_kernel():
                 assert abs(getattr(a, f) - getattr(b, f)) <= 1e-10 * abs(getattr(b, f)) + 1e-300, f
     finally:
         eng.close()
+
+
+def test_group_members_take_lattice_dosages(engine):
+    """rvt_group_set_content: the hint and the lattice on every member of a device group (two contexts on one GPU); the
+    records equal the single-context ones."""
+    import rvtests_amd
+    N, d, den = 2501, 2, 1000
+    rng = np.random.default_rng(8)
+    genes = [_gene(_dosage_K(N, int(rng.integers(1, 81)), seed=900 + g, den=den, common_col=1), den) for g in range(70)]
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=2, G_effect=0.4 * genes[3][0][:, :2].sum(1))
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        grp.fit_null(0, X, y)
+        grp.set_content(0, den)
+        with pytest.raises(rvtests_amd.RvtError):
+            grp.set_content(0, 5000)
+        grp.set_content(0, den)
+        for g, (G, af) in enumerate(genes):
+            grp.submit_gene(g, G, af)
+        got = grp.collect()
+    finally:
+        grp.close()
+    engine.fit_null(0, X, y)
+    engine.set_content_hint(0)
+    engine.set_dosage_lattice(den)
+    try:
+        for g, (G, af) in enumerate(genes):
+            engine.submit_gene(g, G, af)
+        ref = engine.collect()
+    finally:
+        engine.set_dosage_lattice(0)
+        engine.set_content_hint(-1)
+    assert [r.gene_id for r in got] == list(range(70))
+    for a, b in zip(got, ref):
+        for f in ("skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f

@@ -588,3 +588,49 @@ def test_driver_fam_analytic_vt_rows(tmp_path):
         for k, want in zip((2, 4, 5, 6), (o.opt_maf, o.U, o.V, o.stat)):
             assert abs(float(got[k]) - want) <= 2e-2 * abs(want) + 1e-9
         assert abs(float(got[7]) - o.pvalue) <= 2e-2
+
+
+@pytest.mark.gpu
+def test_dosage_input_with_the_lattice_stated_prints_the_same_rows(tmp_path):
+    """`--dosage DS` with three decimals: the adapter states the lattice (RVT_DOSAGE=d3 -> GpuBroker::setDosage(3) ->
+    rvt_group_set_content) and the genes run on the int8 lattice kernel; the printed rows are those of the run without
+    the statement (fp64 kernel after a hand-back) and carry the oracle's numbers."""
+    _ensure_driver()
+    N, d = 2000, 3
+    rng = np.random.default_rng(6)
+    genes = []
+    for M in (6, 21, 1, 40):
+        H = rng.binomial(2, 10 ** rng.uniform(-2.5, -1.0, M), size=(N, M))
+        blur = np.rint(np.abs(rng.normal(0, 40, size=(N, M)))).astype(np.int64) * (rng.random((N, M)) < 0.3)
+        K = np.clip(np.where(H == 0, blur, 1000 * H - blur), 0, 2000)
+        G = np.asfortranarray(K / 1000.0)
+        genes.append((G, G.sum(0) / (2.0 * N)))
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=4, G_effect=0.5 * genes[0][0][:, :2].sum(1))
+    path = str(tmp_path / "in.bin")
+    write_input(path, y, X[:, 1:], 0, genes)
+    out = {}
+    for tag in ("", "d3", "1"):
+        os.environ.pop("RVT_DOSAGE", None)
+        if tag:
+            os.environ["RVT_DOSAGE"] = tag
+        try:
+            rc, sec, err = run_driver(path, "skat[nPerm=0],skato", "cmc,zeggini")
+        finally:
+            os.environ.pop("RVT_DOSAGE", None)
+        assert rc == 0, err
+        out[tag] = sec
+    assert out["1"] == out[""]                              # the same kernel either way: hint only
+
+    def same(a, b):                                         # the lattice kernel's G'G is exact, the fp64 one's rounded: a last
+        try:                                                # printed digit may differ
+            return abs(float(a) - float(b)) <= 2e-6 * abs(float(b))
+        except ValueError:
+            return a == b
+    for name in out[""]:
+        assert len(out["d3"][name]) == len(out[""][name])
+        for ra, rb in zip(out["d3"][name], out[""][name]):
+            assert len(ra) == len(rb) and all(same(x, y_) for x, y_ in zip(ra, rb)), (name, ra, rb)
+    rows = out["d3"]["out.Skat.assoc"][1:]
+    for (G, af), row in zip(genes, rows):
+        rc, a = orc.skat(G, af, X, res, v, 0)
+        assert abs(float(row[-2]) - a.Q) <= 6e-6 * a.Q and abs(float(row[-1]) - a.pvalue) <= 6e-6 * a.pvalue + 1e-14
