@@ -494,7 +494,7 @@ def main():
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             k2 = pmc["kernels"].get("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat")
-            if pmc.get("workload") == key and k2:
+            if pmc.get("workload") == key and k2 and not args.dosage:   # (the PMC passes are of the hard-call workload)
                 traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
         line = {
             "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",
