@@ -191,6 +191,15 @@ int rvt_block_alloc(rvt_ctx* ctx, int M, double** dG_out);
 int rvt_block_free(rvt_ctx* ctx, double* dG);
 /* copy a host N x M column-major matrix (leading dimension N) into a block */
 int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
+/* Page-locking the caller's hand-off buffer.  The reference fills ONE genotype buffer per gene and reuses it for the next
+ * (src/Main.cpp:1086,1225), so every submission has to have read its input when it returns: by default the engine copies
+ * pageable memory into a pinned ring with a few CPU threads (host_stage.h; ~35 GB/s) or lets the runtime do it.  An
+ * adapter that owns the buffer can page-lock it ONCE — rvt_host_register(ctx, ptr, bytes) — and every later rvt_submit_* /
+ * rvt_block_upload whose source lies inside a registered range is a DMA straight out of it at the rate of the link, with
+ * no CPU copy; the call still returns only when the range has been read.  rvt_host_unregister before the buffer is freed
+ * (rvt_destroy unregisters what is left).  Registration changes no result. */
+int rvt_host_register(rvt_ctx* ctx, const void* ptr, size_t bytes);
+int rvt_host_unregister(rvt_ctx* ctx, const void* ptr);
 /* Hard calls.  Where the entries of a block are exactly 0.0, 1.0 or 2.0 and the null model is unweighted (quantitative
  * trait), G'G is an integer matrix and the engine computes it on the int8 matrix cores instead of the fp64 ones, with
  * the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h): same numbers (the integer part exactly,
@@ -587,6 +596,9 @@ int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const u
  * sends every permutation gene to member 0, which replays the reference's rand() stream (see rvt_set_perm_exact) */
 int rvt_group_set_perm_exact(rvt_group* group, int on);
 int rvt_group_rand_seed(rvt_group* group, unsigned seed);
+/* rvt_host_register / rvt_host_unregister for a group: the range is page-locked once, for every member's device */
+int rvt_group_host_register(rvt_group* group, const void* ptr, size_t bytes);
+int rvt_group_host_unregister(rvt_group* group, const void* ptr);
 /* rvt_set_content_hint + rvt_set_dosage_lattice on every member (what the caller's blocks hold: see those functions) */
 int rvt_group_set_content(rvt_group* group, int hint, int lattice_denominator);
 /* `--meta score` / `--meta cov` over a group (chunks with a one-window halo, no exchange).  G_host: N x V

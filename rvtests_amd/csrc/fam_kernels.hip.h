@@ -167,6 +167,45 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel(const SRC* __res
     parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] = ConsolPart{s_sum[0], s_ac[0], s_cnt[0], s_flag[0], 0};
 }
 
+// PLINK 2-bit rows: one thread per BYTE (four samples), the three counts by population counts of bit masks — a quarter of
+// the iterations of the generic kernel and no floating point (45 -> ~10 microseconds for a 500 000 x 50 gene: the count
+// sits between the host copy of a gene and its expansion).  Hard calls: the truncating accumulation is an integer sum.
+template <>
+__global__ __launch_bounds__(256) void consolidate_count_kernel<bed2_t>(const bed2_t* __restrict__ src, long long src_ld,
+                                                                        long long N, ConsolPart* __restrict__ parts) {
+  __shared__ unsigned s_n1[256], s_n2[256], s_nm[256];
+  const unsigned char* col = reinterpret_cast<const unsigned char*>(src) + (long long)blockIdx.y * src_ld;
+  const long long i0 = (long long)blockIdx.x * kConsolChunk;  // (a multiple of 4)
+  const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
+  unsigned n1 = 0, n2 = 0, nm = 0;
+  for (long long b = (i0 >> 2) + threadIdx.x; 4 * b < i1; b += 256) {
+    unsigned v = col[b];
+    const long long left = i1 - 4 * b;  // samples of this byte that exist (the last byte of a row may carry padding)
+    if (left < 4) v &= (1u << (2 * left)) - 1u;
+    const unsigned lo = v & 0x55u, hi = (v >> 1) & 0x55u;
+    n1 += __popc(hi & ~lo);  // 10 -> 1
+    n2 += __popc(hi & lo);   // 11 -> 2
+    nm += __popc(lo & ~hi);  // 01 -> missing
+  }
+  s_n1[threadIdx.x] = n1;
+  s_n2[threadIdx.x] = n2;
+  s_nm[threadIdx.x] = nm;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s_n1[threadIdx.x] += s_n1[threadIdx.x + off];
+      s_n2[threadIdx.x] += s_n2[threadIdx.x + off];
+      s_nm[threadIdx.x] += s_nm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double ac = (double)s_n1[0] + 2.0 * (double)s_n2[0];
+    parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] =
+        ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, 0};
+  }
+}
+
 // one wave per column: AF and the imputation value
 template <typename SRC>
 __global__ __launch_bounds__(64) void consolidate_fill_kernel(const SRC* __restrict__ src, long long src_ld,

@@ -153,6 +153,16 @@ struct rvt_ctx {
   int af_unresolved = 0;
   void* d_consol_i8 = nullptr;
   size_t consol_i8_cap = 0;
+  // packed hand-offs from the host (int8 / 2-bit): a ring of landing buffers and a copy stream of their own, so that the DMA of
+  // gene g + 1 runs while the consolidation kernels of gene g read another buffer (one stream serialised them: 3.3 k
+  // 2-bit genes/s where the link carries 8 k)
+  static constexpr int kPack = 8;  // landing buffers: a consolidation delayed by a batch launch does not stop the copies
+  void* d_pack[kPack] = {};
+  size_t pack_cap[kPack] = {};
+  hipEvent_t ev_pack_copied[kPack] = {}, ev_pack_free[kPack] = {};
+  int pack_next = 0;
+  hipStream_t copy_stream = nullptr;
+  hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
   size_t rot_part_cap = 0;
   // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
@@ -242,6 +252,12 @@ struct rvt_ctx {
   // kernel unless the caller has said they hold dosages (rvt_set_content_hint).  No history: the kernel a block runs on
   // — and with it the last bits of its records — depends on the block and the hint alone.
   int content_hint = -1;
+  // rvt_host_register: host ranges of the caller that are page-locked — copies out of them are DMA straight from the
+  // caller's memory (no staging copy by the CPU); `reg_pending`: such a copy has been enqueued and not yet waited for
+  std::vector<std::pair<const char*, size_t>> host_reg;
+  std::vector<char> host_reg_owned;  // (1: this context called hipHostRegister; 0: adopted from another member of a group)
+  hipEvent_t ev_reg = nullptr;
+  bool reg_pending = false;
   int lattice_den = 0;        // rvt_set_dosage_lattice: dosage doubles are multiples of 1 / lattice_den (0: not stated)
   int* d_kind = nullptr;      // device flag of rvt_block_classify (a stateless query)
   bool hc_enabled = true;     // RVT_HARDCALL=0 forces the general kernel (experiments)
@@ -595,9 +611,15 @@ int rvt_init(rvt_ctx** out, int device_id) {
     return RVT_E_HIP;
   }
   c->stream = c->slots[0].stream;
-  if (hipStreamCreateWithFlags(&c->io_stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->io_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return RVT_E_HIP;
+  }
+  c->h2d_stream = c->io_stream;
+  for (int k = 0; k < rvt_ctx::kPack; ++k) {
+    hipEventCreateWithFlags(&c->ev_pack_copied[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_pack_free[k], hipEventDisableTiming);
   }
   for (int i = 0; i < kSlotsAll; ++i) {
     hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
@@ -647,6 +669,11 @@ void rvt_destroy(rvt_ctx* c) {
             1e3 * c->tr_collect);
   hipSetDevice(c->device);
   for (auto& sl : c->slots) sync_stream(sl.stream);
+  if (c->io_stream) sync_stream(c->io_stream);
+  for (size_t i = 0; i < c->host_reg.size(); ++i)
+    if (c->host_reg_owned[i]) (void)hipHostUnregister(const_cast<char*>(c->host_reg[i].first));
+  c->host_reg.clear();
+  if (c->ev_reg) hipEventDestroy(c->ev_reg);
   if (c->k2b_stream) {
     sync_stream(c->k2b_stream);
     hipStreamDestroy(c->k2b_stream);
@@ -694,6 +721,15 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_consol_parts) hipFree(c->d_consol_parts);
   if (c->h_af_ring) hipHostFree(c->h_af_ring);
   if (c->d_consol_i8) hipFree(c->d_consol_i8);
+  for (int k = 0; k < rvt_ctx::kPack; ++k) {
+    if (c->d_pack[k]) hipFree(c->d_pack[k]);
+    if (c->ev_pack_copied[k]) hipEventDestroy(c->ev_pack_copied[k]);
+    if (c->ev_pack_free[k]) hipEventDestroy(c->ev_pack_free[k]);
+  }
+  if (c->copy_stream) {
+    sync_stream(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+  }
   for (auto& kv : c->col_kind)
     if (kv.second.d_flags) hipFree(kv.second.d_flags);
   if (c->d_vcf_text) hipFree(c->d_vcf_text);
@@ -924,18 +960,97 @@ static int stage_ready(rvt_ctx* c) {
     return e == hipSuccess ? 0 : 1;
   };
   c->stage.send = [c](int k, size_t off, void* dst, size_t bytes) {
-    return hipMemcpyAsync(dst, c->stage.chunk[k] + off, bytes, hipMemcpyHostToDevice, c->io_stream) == hipSuccess ? 0 : 1;
+    return hipMemcpyAsync(dst, c->stage.chunk[k] + off, bytes, hipMemcpyHostToDevice, c->h2d_stream) == hipSuccess ? 0 : 1;
   };
   c->stage.send2d = [c](int k, void* dst, size_t dpitch, size_t width, size_t rows) {
-    return hipMemcpy2DAsync(dst, dpitch, c->stage.chunk[k], width, width, rows, hipMemcpyHostToDevice, c->io_stream) ==
+    return hipMemcpy2DAsync(dst, dpitch, c->stage.chunk[k], width, width, rows, hipMemcpyHostToDevice, c->h2d_stream) ==
                    hipSuccess
                ? 0
                : 1;
   };
-  c->stage.sent = [c](int k) { return hipEventRecord(c->stage_ev[k], c->io_stream) == hipSuccess ? 0 : 1; };
+  c->stage.sent = [c](int k) { return hipEventRecord(c->stage_ev[k], c->h2d_stream) == hipSuccess ? 0 : 1; };
   return RVT_OK;
 }
 // a small table (<= kSmallBytes) through a pinned ring: no host synchronisation, the source may be a local
+static bool host_registered(const rvt_ctx* c, const void* src, size_t bytes) {
+  const char* p = (const char*)src;
+  for (const auto& r : c->host_reg)
+    if (p >= r.first && p + bytes <= r.first + r.second) return true;
+  return false;
+}
+// a copy out of registered caller memory has been enqueued on the io stream: remember to wait for it before the entry
+// point returns (the caller may overwrite its buffer then)
+static int reg_mark(rvt_ctx* c) {
+  if (!c->ev_reg) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_reg, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->ev_reg, c->h2d_stream));
+  c->reg_pending = true;
+  return RVT_OK;
+}
+static int reg_wait(rvt_ctx* c) {
+  if (!c->reg_pending) return RVT_OK;
+  c->reg_pending = false;
+  for (int spins = 0;; ++spins) {  // (copies of 0.1 - 4 ms: poll closely first)
+    const hipError_t e = hipEventQuery(c->ev_reg);
+    if (e == hipSuccess) return RVT_OK;
+    if (e != hipErrorNotReady) return fail(c, RVT_E_HIP, "copy from registered host memory failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    if (spins > 200) {
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+}
+struct RegWait {  // every entry point that copies out of the caller's memory ends with the wait
+  rvt_ctx* c;
+  explicit RegWait(rvt_ctx* c_) : c(c_) {}
+  ~RegWait() {
+    if (c) (void)reg_wait(c);
+  }
+};
+
+int rvt_host_register(rvt_ctx* c, const void* ptr, size_t bytes) {
+  if (!c || !ptr || bytes == 0) return fail(c, RVT_E_INVALID, "rvt_host_register: bad range");
+  hipSetDevice(c->device);
+  for (const auto& r : c->host_reg)
+    if ((const char*)ptr < r.first + r.second && r.first < (const char*)ptr + bytes)
+      return fail(c, RVT_E_STATE, "rvt_host_register: the range overlaps a registered one");
+  const hipError_t e = hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, RVT_E_HIP, "hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  }
+  c->host_reg.emplace_back((const char*)ptr, bytes);
+  c->host_reg_owned.push_back(1);
+  return RVT_OK;
+}
+
+// group members other than the one that registered: the range is page-locked for every device already (portable)
+int rvt_host_adopt(rvt_ctx* c, const void* ptr, size_t bytes) {
+  if (!c || !ptr || bytes == 0) return RVT_E_INVALID;
+  c->host_reg.emplace_back((const char*)ptr, bytes);
+  c->host_reg_owned.push_back(0);
+  return RVT_OK;
+}
+
+int rvt_host_unregister(rvt_ctx* c, const void* ptr) {
+  if (!c || !ptr) return RVT_E_INVALID;
+  hipSetDevice(c->device);
+  for (size_t i = 0; i < c->host_reg.size(); ++i)
+    if (c->host_reg[i].first == (const char*)ptr) {
+      int rc = reg_wait(c);
+      if (!rc) rc = sync_stream(c->io_stream) == hipSuccess ? RVT_OK : RVT_E_HIP;  // nothing in flight reads the range any more
+      const bool owned = c->host_reg_owned[i] != 0;
+      c->host_reg.erase(c->host_reg.begin() + (long)i);
+      c->host_reg_owned.erase(c->host_reg_owned.begin() + (long)i);
+      if (owned && hipHostUnregister(const_cast<void*>(ptr)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, RVT_E_HIP, "hipHostUnregister failed");
+      }
+      return rc;
+    }
+  return fail(c, RVT_E_INVALID, "rvt_host_unregister: not a registered range");
+}
+
 static int small_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes > rvt_ctx::kSmallBytes) {
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->io_stream));
@@ -974,8 +1089,12 @@ struct TraceScope {  // RVT_TRACE_SUBMIT: adds the scope's host time to *acc
 };
 static int staged_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {
   TraceScope ts(c, &c->tr_copy);
+  if (host_registered(c, src, bytes)) {  // DMA straight out of the caller's page-locked buffer
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->h2d_stream));
+    return reg_mark(c);
+  }
   if (!c->stage_on || bytes < ((size_t)256 << 10)) {
-    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->h2d_stream));
     return RVT_OK;
   }
   int rc = stage_ready(c);
@@ -988,6 +1107,10 @@ static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, 
   // Big blocks (the 200 MB of an fp64 gene at N = 500 000) go through the runtime's own pageable path: measured 46-48
   // GB/s of the link's 57 (tools/bench_group_stream.py), which the staged ring does not beat at this size; the call is
   // then synchronous.  The ring is for the packed hand-offs, where returning before the data has crossed matters.
+  if (host_registered(c, src, spitch * (rows - 1) + width)) {
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
+    return reg_mark(c);
+  }
   if (!c->stage_on || width * rows < ((size_t)256 << 10) || width * rows >= ((size_t)64 << 20)) {
     HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
     HIP_TRY(c, sync_stream(c->io_stream));  // (a small pageable copy: the runtime has not necessarily read it yet)
@@ -1021,6 +1144,7 @@ int rvt_block_upload(rvt_ctx* c, double* dG, int M, const double* G) {
   int rc = upload_block_data(c, dG, M, G);
   if (rc) return rc;
   HIP_TRY(c, sync_stream(c->io_stream));  // the block is complete on return
+  c->reg_pending = false;
   return RVT_OK;
 }
 
@@ -4709,6 +4833,7 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
 
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
+  RegWait reg_wait_on_return(c);
   if (!c || !G || M < 1 || (mode == 0 && !af)) return fail(c, RVT_E_INVALID, "bad gene");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (tests & RVT_TEST_FAMSKAT) return fail(c, RVT_E_INVALID, "FamSKAT runs through rvt_run_fam_blocks");
@@ -4822,20 +4947,43 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       // 2-bit codes, ceil(N/4) bytes per variant (mode 3)
       const size_t col_bytes = (mode == 3) ? (size_t)((N + 3) / 4) : (size_t)N;
       const size_t bytes8 = col_bytes * M;
-      if (c->consol_i8_cap < bytes8) {
-        if (c->d_consol_i8) hipFree(c->d_consol_i8);
-        c->d_consol_i8 = nullptr;
-        c->consol_i8_cap = 0;
-        e = hipMalloc((void**)&c->d_consol_i8, bytes8 + bytes8 / 4);
-        if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
-      }
-      if (e == hipSuccess && mode == 4) {
-        if (vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot) != RVT_OK) e = hipErrorUnknown;
-      } else if (e == hipSuccess) {
-        if (staged_h2d(c, c->d_consol_i8, G, bytes8) != RVT_OK) e = hipErrorUnknown;
+      const void* d_packed = nullptr;  // where the packed genotypes of this gene are on the device
+      int pk = -1;
+      if (mode == 4) {
+        if (c->consol_i8_cap < bytes8) {
+          if (c->d_consol_i8) hipFree(c->d_consol_i8);
+          c->d_consol_i8 = nullptr;
+          c->consol_i8_cap = 0;
+          e = hipMalloc((void**)&c->d_consol_i8, bytes8 + bytes8 / 4);
+          if (e == hipSuccess) c->consol_i8_cap = bytes8 + bytes8 / 4;
+        }
+        if (e == hipSuccess && vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot) != RVT_OK) e = hipErrorUnknown;
+        d_packed = c->d_consol_i8;
+      } else {
+        // host copy on the copy stream into the next landing buffer of the ring (free once the consolidation kernels of
+        // the gene that used it last have run); the kernels of THIS gene wait for the copy by event
+        pk = c->pack_next;
+        c->pack_next = (pk + 1) % rvt_ctx::kPack;
+        if (c->pack_cap[pk] < bytes8) {
+          if (c->d_pack[pk]) hipFree(c->d_pack[pk]);
+          c->d_pack[pk] = nullptr;
+          c->pack_cap[pk] = 0;
+          e = hipMalloc((void**)&c->d_pack[pk], bytes8 + bytes8 / 4);
+          if (e == hipSuccess) c->pack_cap[pk] = bytes8 + bytes8 / 4;
+        }
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_pack_free[pk], 0);
+        if (e == hipSuccess) {
+          c->h2d_stream = c->copy_stream;
+          const int rcs = staged_h2d(c, c->d_pack[pk], G, bytes8);
+          c->h2d_stream = c->io_stream;
+          if (rcs != RVT_OK) e = hipErrorUnknown;
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->ev_pack_copied[pk], c->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_pack_copied[pk], 0);
+        d_packed = c->d_pack[pk];
       }
       if (e == hipSuccess && mode == 3) {
-        const bed2_t* sb = (const bed2_t*)c->d_consol_i8;
+        const bed2_t* sb = (const bed2_t*)d_packed;
         const long long cb = (long long)col_bytes;
         hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
                            c->d_consol_parts);
@@ -4844,7 +4992,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         hipLaunchKernelGGL((consolidate_write_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
                            (long long)ld, d_fill, p.dG);
       } else if (e == hipSuccess) {
-        const signed char* s8 = (const signed char*)c->d_consol_i8;
+        const signed char* s8 = (const signed char*)d_packed;
         hipLaunchKernelGGL((consolidate_count_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
                            (long long)N, c->d_consol_parts);
         hipLaunchKernelGGL((consolidate_fill_kernel<signed char>), dim3((unsigned)M), dim3(64), 0, st, s8, (long long)N,
@@ -4852,6 +5000,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         hipLaunchKernelGGL((consolidate_write_kernel<signed char>), cgrid, dim3(256), 0, st, s8, (long long)N,
                            (long long)N, (long long)ld, d_fill, p.dG);
       }
+      if (pk >= 0 && e == hipSuccess) e = hipEventRecord(c->ev_pack_free[pk], st);  // the landing buffer may be refilled
     }
     p.af.resize(M);
     if (af_out) {

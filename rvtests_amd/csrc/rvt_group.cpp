@@ -234,6 +234,28 @@ int rvt_group_set_perm_exact(rvt_group* g, int on) {
   return RVT_OK;
 }
 
+extern "C" int rvt_host_adopt(rvt_ctx* c, const void* ptr, size_t bytes);  // (engine-internal: a range another member registered)
+
+int rvt_group_host_register(rvt_group* g, const void* ptr, size_t bytes) {
+  if (!g || g->member.empty()) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
+  int rc = rvt_host_register(g->member[0], ptr, bytes);
+  if (rc) return gfail(g, rc, "rvt_host_register", g->member[0]);
+  for (size_t k = 1; k < g->member.size(); ++k) rvt_host_adopt(g->member[k], ptr, bytes);
+  return RVT_OK;
+}
+
+int rvt_group_host_unregister(rvt_group* g, const void* ptr) {
+  if (!g || g->member.empty()) return RVT_E_INVALID;
+  if (int rcf = group_flush(g)) return rcf;
+  int rc = RVT_OK;
+  for (size_t k = g->member.size(); k-- > 0;) {  // member 0 (the owner of the registration) last
+    const int r = rvt_host_unregister(g->member[k], ptr);
+    if (r && !rc) rc = gfail(g, r, "rvt_host_unregister", g->member[k]);
+  }
+  return rc;
+}
+
 int rvt_group_set_content(rvt_group* g, int hint, int lattice_denominator) {
   if (!g) return RVT_E_INVALID;
   for (rvt_ctx* m : g->member) {

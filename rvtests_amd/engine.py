@@ -144,6 +144,10 @@ def load_library():
     L.rvt_set_hardcall.argtypes = [vp, C.c_int]
     L.rvt_set_content_hint.restype = C.c_int
     L.rvt_set_content_hint.argtypes = [vp, C.c_int]
+    L.rvt_host_register.restype = C.c_int
+    L.rvt_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.rvt_host_unregister.restype = C.c_int
+    L.rvt_host_unregister.argtypes = [vp, C.c_void_p]
     L.rvt_set_dosage_lattice.restype = C.c_int
     L.rvt_set_dosage_lattice.argtypes = [vp, C.c_int]
     run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
@@ -267,6 +271,10 @@ def load_library():
     L.rvt_group_submit_gene_bed.restype = C.c_int
     L.rvt_group_submit_gene_bed.argtypes = [gp, C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(Params),
                                             c_double_p]
+    L.rvt_group_host_register.restype = C.c_int
+    L.rvt_group_host_register.argtypes = [gp, C.c_void_p, C.c_size_t]
+    L.rvt_group_host_unregister.restype = C.c_int
+    L.rvt_group_host_unregister.argtypes = [gp, C.c_void_p]
     L.rvt_group_set_content.restype = C.c_int
     L.rvt_group_set_content.argtypes = [gp, C.c_int, C.c_int]
     L.rvt_group_collect.restype = C.c_int
@@ -390,6 +398,14 @@ class Engine:
         """What the caller's own fp64 blocks hold: -1 unknown (start on the hard-call kernel), 0 dosages (start on the fp64
         kernel), 1 hard calls / mean-imputed hard calls (rvt_set_content_hint).  Never affects correctness."""
         self._check(self.L.rvt_set_content_hint(self.ctx, int(hint)))
+
+    def host_register(self, arr):
+        """Page-lock a numpy array the caller reuses as its hand-off buffer (rvt_host_register): submissions whose source
+        lies inside it are DMA straight from it.  Keep the array alive until host_unregister."""
+        self._check(self.L.rvt_host_register(self.ctx, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def host_unregister(self, arr):
+        self._check(self.L.rvt_host_unregister(self.ctx, C.c_void_p(arr.ctypes.data)))
 
     def set_dosage_lattice(self, denominator):
         """The dosage doubles are multiples of 1 / denominator rounded to double (VCF DS fields with a fixed number of
@@ -864,6 +880,12 @@ class Group:
         if self.g:
             self.L.rvt_group_destroy(self.g)
             self.g = C.c_void_p()
+
+    def host_register(self, arr):
+        self._check(self.L.rvt_group_host_register(self.g, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def host_unregister(self, arr):
+        self._check(self.L.rvt_group_host_unregister(self.g, C.c_void_p(arr.ctypes.data)))
 
     def set_content(self, hint, lattice_denominator=0):
         """What the caller's fp64 blocks hold, on every member (rvt_group_set_content): hint as Engine.set_content_hint,

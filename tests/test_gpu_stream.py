@@ -193,3 +193,91 @@ def test_staged_and_plain_copies_give_the_same_records(monkeypatch):
     for a, b in zip(*outs):
         for f in FIELDS:
             assert getattr(a, f) == getattr(b, f), (a.gene_id, f)
+
+
+def test_registered_hand_off_buffer_is_read_before_the_call_returns():
+    """rvt_host_register: ONE page-locked buffer, refilled with the next gene as soon as the submission returns (the
+    reference's loop, src/Main.cpp:1086,1225) — fp64, raw, int8 and 2-bit hand-offs; identical records to the same stream
+    from ordinary pageable arrays; a group registers the range once for both members."""
+    import rvtests_amd
+    rng = np.random.default_rng(18)
+    N, d = 60_000, 2
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=3)
+    genes = []
+    for g in range(24):
+        M = int(rng.integers(3, 60))
+        raw = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.5, -0.7, M), size=(N, M)).astype(np.float64))
+        if g % 3 == 0:
+            raw[rng.random((N, M)) < 0.01] = -9.0
+        genes.append(raw)
+    buf = np.zeros(N * 60 * 8 + 4096, dtype=np.uint8)            # the caller's reused buffer (bytes)
+
+    def view(dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return buf[:n].view(dtype).reshape(shape, order="F")
+
+    def stream(e, registered):
+        for g, raw in enumerate(genes):
+            M = raw.shape[1]
+            if g % 4 == 0:
+                src = orc.impute_mean(raw)
+                dst = view(np.float64, (N, M)) if registered else src
+                dst[...] = src
+                e.submit_gene(g, dst, orc.counter_af(raw))
+            elif g % 4 == 1:
+                dst = view(np.float64, (N, M)) if registered else raw
+                dst[...] = raw
+                e.submit_gene_raw(g, dst, want_af=False)
+            elif g % 4 == 2:
+                r8 = raw.astype(np.int8)
+                dst = view(np.int8, (N, M)) if registered else r8
+                dst[...] = r8
+                e.submit_gene_raw(g, dst, want_af=(g % 8 == 2))
+            else:
+                bed = e.pack_bed(raw)
+                dst = buf[:bed.size].reshape(bed.shape) if registered else bed
+                dst[...] = bed
+                e.submit_gene_bed(g, dst, M, want_af=False)
+            if registered:
+                buf[:N * M * 8] = 0xA5                            # the caller moves on at once
+        return e.collect()
+
+    e = rvtests_amd.Engine(0)
+    e.fit_null(0, X, y)
+    want = stream(e, False)
+    e.host_register(buf)
+    with pytest.raises(rvtests_amd.RvtError):
+        e.host_register(buf[100:200])                             # overlaps a registered range
+    got = stream(e, True)
+    e.host_unregister(buf)
+    with pytest.raises(rvtests_amd.RvtError):
+        e.host_unregister(buf)
+    again = stream(e, False)
+    e.close()
+    for a, b, c_ in zip(got, want, again):
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f) == getattr(c_, f), (a.gene_id, f)
+    grp = rvtests_amd.Group([0, 0])
+    try:
+        grp.fit_null(0, X, y)
+        grp.host_register(buf)
+        for g, raw in enumerate(genes[:16]):
+            M = raw.shape[1]
+            r8 = raw.astype(np.int8)
+            dst = view(np.int8, (N, M))
+            dst[...] = r8
+            grp.submit_gene_i8(g, dst)
+            buf[:N * M] = 0x5A
+        out = grp.collect()
+        grp.host_unregister(buf)
+    finally:
+        grp.close()
+    e = rvtests_amd.Engine(0)
+    e.fit_null(0, X, y)
+    for g, raw in enumerate(genes[:16]):
+        e.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
+    ref = e.collect()
+    e.close()
+    for a, b in zip(out, ref):
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f), (a.gene_id, f)
