@@ -156,7 +156,7 @@ struct rvt_ctx {
   // packed hand-offs from the host (int8 / 2-bit): a ring of landing buffers and a copy stream of their own, so that the DMA of
   // gene g + 1 runs while the consolidation kernels of gene g read another buffer (one stream serialised them: 3.3 k
   // 2-bit genes/s where the link carries 8 k)
-  static constexpr int kPack = 8;  // landing buffers: a consolidation delayed by a batch launch does not stop the copies
+  static constexpr int kPack = 16;  // landing buffers: a consolidation delayed by a batch launch does not stop the copies
   void* d_pack[kPack] = {};
   size_t pack_cap[kPack] = {};
   hipEvent_t ev_pack_copied[kPack] = {}, ev_pack_free[kPack] = {};
