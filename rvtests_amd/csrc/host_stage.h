@@ -150,6 +150,58 @@ struct StageRing {
     }
     return 0;
   }
+  // Many separate host pieces (the text of a gene's VCF records, its BGEN blocks) into ONE device range: piece i goes to
+  // dst_base + dst_off[i] (offsets increasing, pieces not overlapping; the gaps between them and `tail_zero` bytes behind
+  // the last one arrive as zeros).  The image of the device range is assembled chunk by chunk in pinned memory — one pool
+  // batch and one DMA per chunk instead of one of each per piece (a 2 MB piece costs more in hand-offs than in bytes).
+  struct Piece {
+    size_t dst_off;
+    const void* src;
+    size_t bytes;
+  };
+  int copy_gather(void* dst_base, const Piece* t, size_t n, size_t tail_zero, CopyPool& pool) {
+    std::vector<CopyPool::Task> tasks;
+    size_t i = 0;
+    while (i < n) {
+      if (t[i].bytes + tail_zero > chunk_bytes) {  // a piece longer than a chunk: contiguous pieces of its own
+        if (int rc = copy((char*)dst_base + t[i].dst_off, t[i].src, t[i].bytes, pool)) return rc;
+        const size_t pend = t[i].dst_off + t[i].bytes;
+        const size_t zlen = std::min(tail_zero, (i + 1 < n) ? t[i + 1].dst_off - pend : tail_zero);
+        if (zlen > 0) {  // the zeros behind it
+          const int kz = next;
+          next = (next + 1) % (int)chunk.size();
+          if (int rc = wait(kz)) return rc;
+          std::memset(chunk[kz], 0, zlen);
+          if (int rc = send(kz, 0, (char*)dst_base + pend, zlen)) return rc;
+          if (int rc = sent(kz)) return rc;
+        }
+        ++i;
+        continue;
+      }
+      const int k = next;
+      next = (next + 1) % (int)chunk.size();
+      if (int rc = wait(k)) return rc;
+      const size_t base = t[i].dst_off;
+      size_t end = base;
+      tasks.clear();
+      while (i < n && t[i].bytes + tail_zero <= chunk_bytes && t[i].dst_off + t[i].bytes + tail_zero - base <= chunk_bytes) {
+        if (t[i].dst_off > end) std::memset(chunk[k] + (end - base), 0, t[i].dst_off - end);
+        tasks.push_back(CopyPool::Task{chunk[k] + (t[i].dst_off - base), t[i].src, t[i].bytes});
+        end = t[i].dst_off + t[i].bytes;
+        ++i;
+      }
+      // zeros behind the last piece of this chunk: up to the next piece's start, or tail_zero behind the very last one
+      const size_t zend = (i < n) ? std::min(t[i].dst_off, end + tail_zero) : end + tail_zero;
+      if (zend > end) {
+        std::memset(chunk[k] + (end - base), 0, zend - end);
+        end = zend;
+      }
+      pool.run(tasks.data(), tasks.size());
+      if (int rc = send(k, 0, (char*)dst_base + base, end - base)) return rc;
+      if (int rc = sent(k)) return rc;
+    }
+    return 0;
+  }
   // `rows` rows of `width` bytes, spitch apart on the host, dpitch apart on the device (hipMemcpy2D's meaning)
   int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, CopyPool& pool) {
     if (width == 0 || rows == 0) return 0;

@@ -182,6 +182,55 @@ double hc_copy_rate(size_t bytes, int threads, int reps) {
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return (double)bytes * reps / dt / 1e9;
 }
+// copy_gather with a fake device: n pieces of random lengths at increasing offsets with gaps; returns 0 when the "device"
+// range holds every piece at its offset, zeros in the gaps and behind the last piece, and nothing beyond was touched.
+int hc_stage_gather(int n, size_t max_piece, size_t chunk_bytes, int chunks, int threads, unsigned seed) {
+  std::vector<size_t> len(n), off(n);
+  size_t total = 0;
+  unsigned x = seed * 2654435761u + 12345u;
+  auto rnd = [&]() {
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+  };
+  const size_t tail = 16;
+  for (int i = 0; i < n; ++i) {
+    len[i] = 1 + rnd() % max_piece;
+    off[i] = total;
+    total += (len[i] + 31) / 16 * 16;
+  }
+  std::vector<std::vector<unsigned char>> src(n);
+  for (int i = 0; i < n; ++i) {
+    src[i].resize(len[i]);
+    for (auto& b : src[i]) b = (unsigned char)(1 + rnd() % 255);
+  }
+  std::vector<unsigned char> dev(total + 64, 0xEE);
+  std::vector<std::vector<char>> mem((size_t)chunks, std::vector<char>(chunk_bytes, (char)0x77));
+  rvt::StageRing ring;
+  for (auto& m : mem) ring.chunk.push_back(m.data());
+  ring.chunk_bytes = chunk_bytes;
+  ring.wait = [](int) { return 0; };
+  ring.send = [&](int k, size_t o, void* dst, size_t bytes) {
+    std::memcpy(dst, ring.chunk[k] + o, bytes);
+    return 0;
+  };
+  ring.send2d = [&](int, void*, size_t, size_t, size_t) { return 1; };
+  ring.sent = [](int) { return 0; };
+  std::vector<rvt::StageRing::Piece> pieces(n);
+  for (int i = 0; i < n; ++i) pieces[i] = rvt::StageRing::Piece{off[i], src[i].data(), len[i]};
+  rvt::CopyPool pool(threads);
+  if (ring.copy_gather(dev.data(), pieces.data(), pieces.size(), tail, pool)) return 1;
+  for (int i = 0; i < n; ++i) {
+    if (std::memcmp(dev.data() + off[i], src[i].data(), len[i])) return 2;
+    const size_t gap_end = (i + 1 < n) ? off[i + 1] : off[i] + len[i] + tail;
+    for (size_t b = off[i] + len[i]; b < gap_end && b < off[i] + len[i] + tail; ++b)
+      if (dev[b] != 0) return 3;  // (at least `tail` zero bytes behind every piece that has the room)
+  }
+  for (size_t b = off[n - 1] + len[n - 1] + tail; b < dev.size(); ++b)
+    if (dev[b] != 0xEE) return 4;
+  return 0;
+}
 // The staging ring with a fake device (plain memory): a 2-D copy of `rows` rows of `width` bytes (host pitch spitch,
 // "device" pitch dpitch) through `chunks` chunks of `chunk_bytes`; returns 0 when every byte arrived where hipMemcpy2D
 // would have put it and nothing else was touched.

@@ -172,7 +172,12 @@ struct rvt_ctx {
   };
   std::unordered_map<const double*, ColKind> col_kind;
   // VCF text front end (vcf_kernels.hip.h)
-  char* d_vcf_text = nullptr;
+  char* d_vcf_text = nullptr;   // the text / block buffer of the gene being submitted: text_buf[text_cur]
+  static constexpr int kTextBufs = 3;  // ring: the copies of gene g + 1 run while the decode kernels of gene g read theirs
+  char* text_buf[kTextBufs] = {};
+  size_t text_buf_cap[kTextBufs] = {};
+  hipEvent_t ev_text_copied[kTextBufs] = {}, ev_text_free[kTextBufs] = {};
+  int text_next = 0, text_cur = 0;
   size_t vcf_text_cap = 0;
   VcfRecord* d_vcf_rec = nullptr;
   int* d_vcf_seg = nullptr;
@@ -732,7 +737,11 @@ void rvt_destroy(rvt_ctx* c) {
   }
   for (auto& kv : c->col_kind)
     if (kv.second.d_flags) hipFree(kv.second.d_flags);
-  if (c->d_vcf_text) hipFree(c->d_vcf_text);
+  for (int k = 0; k < rvt_ctx::kTextBufs; ++k) {
+    if (c->text_buf[k]) hipFree(c->text_buf[k]);
+    if (c->ev_text_free[k]) hipEventDestroy(c->ev_text_free[k]);
+    if (c->ev_text_copied[k]) hipEventDestroy(c->ev_text_copied[k]);
+  }
   if (c->d_vcf_rec) hipFree(c->d_vcf_rec);
   if (c->d_vcf_seg) hipFree(c->d_vcf_seg);
   if (c->d_vcf_rows) hipFree(c->d_vcf_rows);
@@ -4606,6 +4615,64 @@ void io_err_message(rvt_ctx* c, int k, bool bgen, const char* whose) {
     fail(c, RVT_E_INVALID, "VCF record %d%s does not hold %d sample columns", k - 1, whose, c->vcf_n_file);
 }
 
+// ---- the text / block buffer of a gene (VCF text, BGEN blocks): a ring of device buffers fed through the copy stream -------
+// The copies of gene g + 1 cross the link while the decode kernels of gene g read their own buffer (one buffer on one
+// stream serialised them).  text_acquire: next buffer, grown to `total` bytes; the copy stream waits for the kernels that
+// read it last.  text_copied: the kernels on `st` wait for the copies.  text_release: the last reader has been enqueued.
+static int text_acquire(rvt_ctx* c, size_t total) {
+  const int k = c->text_next;
+  c->text_next = (k + 1) % rvt_ctx::kTextBufs;
+  if (!c->ev_text_free[k]) {
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_text_free[k], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_text_copied[k], hipEventDisableTiming));
+  }
+  if (c->text_buf_cap[k] < total) {
+    if (c->text_buf[k]) hipFree(c->text_buf[k]);
+    c->text_buf[k] = nullptr;
+    c->text_buf_cap[k] = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->text_buf[k], total + total / 4));
+    c->text_buf_cap[k] = total + total / 4;
+  }
+  HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_text_free[k], 0));
+  c->d_vcf_text = c->text_buf[k];
+  c->text_cur = k;
+  return RVT_OK;
+}
+static int text_copied(rvt_ctx* c, hipStream_t st) {
+  HIP_TRY(c, hipEventRecord(c->ev_text_copied[c->text_cur], c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(st, c->ev_text_copied[c->text_cur], 0));
+  return RVT_OK;
+}
+static int text_release(rvt_ctx* c, hipStream_t st) {
+  HIP_TRY(c, hipEventRecord(c->ev_text_free[c->text_cur], st));
+  return RVT_OK;
+}
+// the pieces of a gene (records / blocks) from the caller's memory into the acquired buffer, on the copy stream: gathered
+// through the pinned ring (one pool batch and one DMA per 32 MB, gaps and `tail_zero` bytes behind every piece zeroed), or
+// piece by piece when the staging ring is off or a piece lies in registered memory
+static int text_upload(rvt_ctx* c, const std::vector<StageRing::Piece>& pieces, size_t tail_zero) {
+  TraceScope ts(c, &c->tr_copy);
+  bool gather = c->stage_on;
+  for (const auto& pc : pieces)
+    if (host_registered(c, pc.src, pc.bytes)) gather = false;
+  c->h2d_stream = c->copy_stream;
+  int rc = RVT_OK;
+  if (gather) {
+    rc = stage_ready(c);
+    if (!rc && c->stage.copy_gather(c->d_vcf_text, pieces.data(), pieces.size(), tail_zero, CopyPool::instance()))
+      rc = fail(c, RVT_E_HIP, "staged host-to-device copy failed");
+  } else {
+    for (const auto& pc : pieces) {
+      if (tail_zero && hipMemsetAsync(c->d_vcf_text + pc.dst_off + pc.bytes, 0, tail_zero, c->copy_stream) != hipSuccess)
+        rc = fail(c, RVT_E_HIP, "hipMemsetAsync failed");
+      if (!rc) rc = staged_h2d(c, c->d_vcf_text + pc.dst_off, pc.src, pc.bytes);
+      if (rc) break;
+    }
+  }
+  c->h2d_stream = c->io_stream;
+  return rc;
+}
+
 // mode 0: imputed doubles + caller's af; 1: raw doubles (consolidated on the device); 2: packed int8 (ditto);
 // 3: PLINK 2-bit codes (ditto)
 // VCF text of one gene -> N x M signed bytes in c->d_consol_i8 (vcf_kernels.hip.h), on stream st
@@ -4632,13 +4699,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
     total += ((size_t)vg->len[j] + 31) / 16 * 16;  // 16-byte aligned starts, >= 16 readable bytes behind the end
     max_len = std::max<int64_t>(max_len, vg->len[j]);
   }
-  if (c->vcf_text_cap < total) {
-    if (c->d_vcf_text) hipFree(c->d_vcf_text);
-    c->d_vcf_text = nullptr;
-    c->vcf_text_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_vcf_text, total + total / 4));
-    c->vcf_text_cap = total + total / 4;
-  }
+  if (int rca = text_acquire(c, total)) return rca;
   if (!c->d_vcf_rec) HIP_TRY(c, hipMalloc((void**)&c->d_vcf_rec, sizeof(VcfRecord) * RVT_MAX_VARIANTS));
   const int max_seg = (int)std::max<int64_t>(1, (max_len + kVcfSegBytes - 1) / kVcfSegBytes);
   if (c->vcf_seg_cap < (size_t)max_seg * M) {
@@ -4655,9 +4716,13 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
   }
   c->vcf_alt.clear();  // (one call only)
   c->vcf_hemi.clear();
-  for (int j = 0; j < M; ++j)  // (a copy from pageable memory returns once the source has been read)
-    if (vg->len[j] > 0)
-      if (int rcs = staged_h2d(c, c->d_vcf_text + rec[j].text_off, vg->text[j], (size_t)vg->len[j])) return rcs;
+  {
+    std::vector<StageRing::Piece> pieces;
+    for (int j = 0; j < M; ++j)
+      if (vg->len[j] > 0) pieces.push_back(StageRing::Piece{(size_t)rec[j].text_off, vg->text[j], (size_t)vg->len[j]});
+    if (int rcs = text_upload(c, pieces, 0)) return rcs;
+    if (int rcs = text_copied(c, st)) return rcs;
+  }
   if (int rcs = small_h2d(c, c->d_vcf_rec, rec.data(), sizeof(VcfRecord) * M)) return rcs;  // (`rec` is a local)
   int* d_err = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void**)&d_err, c->h_io_err, 0));
@@ -4679,7 +4744,7 @@ int vcf_decode_gene(rvt_ctx* c, const VcfGene* vg, int M, int64_t N, hipStream_t
                        c->d_vcf_rows, c->d_vcf_sex, c->vcf_n_file, (long long)N, c->vcf_flt, out);
   }
   HIP_TRY(c, hipGetLastError());
-  return RVT_OK;
+  return text_release(c, st);
 }
 
 // BGEN probability blocks of one gene -> raw genotype doubles (missing = -9) in out (N rows x M, leading dimension ld)
@@ -4787,13 +4852,7 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
     total += (size_t)len + 16;
   }
   total += 16;
-  if (c->vcf_text_cap < total) {
-    if (c->d_vcf_text) hipFree(c->d_vcf_text);
-    c->d_vcf_text = nullptr;
-    c->vcf_text_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_vcf_text, total + total / 4));
-    c->vcf_text_cap = total + total / 4;
-  }
+  if (int rca = text_acquire(c, total)) return rca;
   c->vcf_alt.clear();  // (one call only)
   if (!c->d_bgen_rec) HIP_TRY(c, hipMalloc((void**)&c->d_bgen_rec, sizeof(BgenRecord) * RVT_MAX_VARIANTS));
   const int max_seg = (int)((n_file + kBgenSeg - 1) / kBgenSeg);
@@ -4809,9 +4868,11 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
     int rce = io_err_ready(c);
     if (rce) return rce;
   }
-  for (int j = 0; j < M; ++j) {  // the bytes behind a block read as zero (BitReader stops at its end)
-    HIP_TRY(c, hipMemsetAsync(c->d_vcf_text + rec[j].off + bg->len[j], 0, 16, st));
-    if (int rcs = staged_h2d(c, c->d_vcf_text + rec[j].off, bg->block[j], (size_t)bg->len[j])) return rcs;
+  {  // the bytes behind a block read as zero (BitReader stops at its end)
+    std::vector<StageRing::Piece> pieces;
+    for (int j = 0; j < M; ++j) pieces.push_back(StageRing::Piece{(size_t)rec[j].off, bg->block[j], (size_t)bg->len[j]});
+    if (int rcs = text_upload(c, pieces, 16)) return rcs;
+    if (int rcs = text_copied(c, st)) return rcs;
   }
   if (int rcs = small_h2d(c, c->d_bgen_rec, rec.data(), sizeof(BgenRecord) * M)) return rcs;  // (`rec` is a local)
   int* d_err = nullptr;
@@ -4828,7 +4889,7 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
   hipLaunchKernelGGL(bgen_decode_kernel, grid, dim3(kBgenSeg), 0, st, data, c->d_bgen_rec, (long long)n_file, max_seg,
                      c->d_bgen_seg, c->d_vcf_rows, (long long)ld, out);
   HIP_TRY(c, hipGetLastError());
-  return RVT_OK;
+  return text_release(c, st);
 }
 
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,

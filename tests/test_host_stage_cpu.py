@@ -36,3 +36,20 @@ def test_copy_pool_rates():
     r4 = L.hc_copy_rate(64 << 20, 4, 3)
     print("copy pool: 1 thread %.1f GB/s, 4 threads %.1f GB/s" % (r1, r4))
     assert r1 > 0.2 and r4 > 0.2 * r1          # (a loaded CI host: the test is about collapse, not speed)
+
+
+@pytest.mark.parametrize("n,max_piece,chunk,chunks,threads,seed", [
+    (50, 2 << 20, 32 << 20, 4, 3, 1),      # a gene's VCF records: 2 MB pieces, 32 MB chunks
+    (7, 100, 4096, 2, 1, 2),               # tiny pieces, one chunk
+    (200, 70000, 1 << 20, 3, 4, 3),        # many pieces per chunk, several chunks
+    (5, 3 << 20, 1 << 20, 4, 2, 4),        # pieces longer than a chunk
+    (1, 10, 64, 1, 1, 5),
+    (40, 5000, 4096, 2, 3, 6),             # pieces around the chunk size: both paths mixed
+    (30, 9000, 4096, 3, 2, 7),
+])
+def test_gathered_copy_assembles_the_device_range(n, max_piece, chunk, chunks, threads, seed):
+    """StageRing::copy_gather: every piece at its offset, zeros in the gaps and behind the last piece, nothing beyond."""
+    L = _lib()
+    L.hc_stage_gather.restype = C.c_int
+    L.hc_stage_gather.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_uint]
+    assert L.hc_stage_gather(n, max_piece, chunk, chunks, threads, seed) == 0
