@@ -1120,7 +1120,8 @@ static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, 
     HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
     return reg_mark(c);
   }
-  if (!c->stage_on || width * rows < ((size_t)256 << 10) || width * rows >= ((size_t)64 << 20)) {
+  static const bool stage_big = getenv("RVT_STAGE_BIG") && atoi(getenv("RVT_STAGE_BIG")) != 0;
+  if (!c->stage_on || width * rows < ((size_t)256 << 10) || (!stage_big && width * rows >= ((size_t)64 << 20))) {
     HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
     HIP_TRY(c, sync_stream(c->io_stream));  // (a small pageable copy: the runtime has not necessarily read it yet)
     return RVT_OK;
