@@ -337,3 +337,39 @@ def test_group_members_take_lattice_dosages(engine):
     for a, b in zip(got, ref):
         for f in ("skat_Q", "skat_p", "skato_Q", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
             assert getattr(a, f) == getattr(b, f), f
+
+
+def test_full_size_and_the_operand_bound():
+    """BASELINE's N = 500 000 (exact integers again), and N = 1.1 million with every entry at the largest value the widest
+    lattice allows (K = 4096 at den = 2048): the wave-parts then hold the 255 operands the 32-bit tiles are proved for."""
+    import rvtests_amd
+    eng = rvtests_amd.Engine(0)
+    try:
+        for N, M, den, worst in ((500_000, 50, 1000, False), (1_100_000, 16, 2048, True)):
+            X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=3)
+            eng.set_null(0, X, res, v, s2)
+            eng.set_content_hint(0)
+            eng.set_dosage_lattice(den)
+            if worst:
+                K = np.full((N, M), 2 * den, dtype=np.int64)
+                K[::7, ::3] = 2 * den - 1            # (not monomorphic; low digit 127 next to high digit 31)
+            else:
+                K = _dosage_K(N, M, seed=77, den=den, common_col=3)
+            G, af = _gene(K, den)
+            p = eng.upload_block(G)
+            S, T, u, cs, mn, mx = eng.debug_suffstat(p, M)
+            eng.set_profiling(True)
+            eng.timing(reset=True)
+            (r,) = eng.run_blocks([p], [M], [af])
+            tm = eng.timing(reset=True)
+            eng.set_profiling(False)
+            eng.free_block(p)
+            assert tm.genes_hard_call == 1 and tm.genes_handed_back == 0
+            exact = (K.T @ K).astype(np.float64) / float(den * den)
+            assert np.array_equal(np.triu(S), np.triu(exact))
+            assert np.array_equal(cs, K.sum(0).astype(np.float64) / float(den))
+            assert r.n_poly == (M if not worst else len(range(0, M, 3)))
+    finally:
+        eng.set_dosage_lattice(0)
+        eng.set_content_hint(-1)
+        eng.close()
