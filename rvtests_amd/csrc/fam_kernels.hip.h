@@ -121,6 +121,7 @@ struct ConsolPart {
   double sumAC, ac;
   long long nonneg;
   int flags, pad;  // bit 0: counter saw a missing value; bit 1: a value < 0 exists; bit 2: a fractional value >= 0
+                   // (pad: 2-bit rows only — the number of 2s of the part, for the header of the packed-row kernel)
 };
 
 template <typename SRC>
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel<bed2_t>(const be
   if (threadIdx.x == 0) {
     const double ac = (double)s_n1[0] + 2.0 * (double)s_n2[0];
     parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] =
-        ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, 0};
+        ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, (int)s_n2[0]};  // pad = #(g = 2)
   }
 }
 

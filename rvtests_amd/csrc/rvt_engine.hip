@@ -18,6 +18,7 @@
 #include <functional>
 #include "kernels.hip.h"
 #include "suffstat_lat.hip.h"
+#include "suffstat_hcp.hip.h"
 #include "host_stage.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
@@ -35,6 +36,8 @@ void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nu
                    int d);
 void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
                    long long ld, int d);
+void k2_launch_hcp(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
+                   int d);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
@@ -283,10 +286,12 @@ struct rvt_ctx {
     int io_error = 0;     // != 0: the gene's VCF text / BGEN blocks were malformed (h_io_err): its record is void
     int decoded = 0;      // 1: VCF text, 2: BGEN blocks (the submission has an input-error word in its ring slot)
     int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages (BGEN), 2 decimal
-                          // dosages (VCF text), -1 unknown
+                          // dosages (VCF text), 3 the block holds PLINK 2-bit rows (not doubles), -1 unknown
   };
   std::deque<Pending> queue;
   std::vector<std::pair<size_t, double*>> block_pool;  // free device blocks of the streaming interface (bytes, ptr)
+  std::vector<std::pair<size_t, double*>> pk_pool;     // free PACKED blocks (2-bit rows): never handed out as fp64 blocks,
+                                                       // whose pad rows must be zero
   // results of launched sub-batches land in contiguous arrays, then move into Pending::res at collect time
   struct Launched {
     size_t first;  // index into the queue at launch time (adjusted when the queue is popped)
@@ -709,6 +714,8 @@ void rvt_destroy(rvt_ctx* c) {
   for (auto& p : c->queue)
     if (p.dG) hipFree(p.dG);
   for (auto& bp : c->block_pool) hipFree(bp.second);
+  for (auto& bp : c->pk_pool) hipFree(bp.second);
+  c->pk_pool.clear();
   for (auto& sl : c->slots) {
     if (sl.arena.base) hipFree(sl.arena.base);
     if (sl.h_stage) hipHostFree(sl.h_stage);
@@ -772,6 +779,8 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   if (!c->queue.empty()) return fail(c, RVT_E_STATE, "collect the submitted genes before changing the null model");
   for (auto& bp : c->block_pool) hipFree(bp.second);  // pooled blocks were laid out for the previous N
   c->block_pool.clear();
+  for (auto& bp : c->pk_pool) hipFree(bp.second);
+  c->pk_pool.clear();
   free_null(c);
   c->have_null_beta = false;
   const int64_t ld = rvt_padded_ld(N);
@@ -1117,13 +1126,13 @@ static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, 
   // GB/s of the link's 57 (tools/bench_group_stream.py), which the staged ring does not beat at this size; the call is
   // then synchronous.  The ring is for the packed hand-offs, where returning before the data has crossed matters.
   if (host_registered(c, src, spitch * (rows - 1) + width)) {
-    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->h2d_stream));
     return reg_mark(c);
   }
   static const bool stage_big = getenv("RVT_STAGE_BIG") && atoi(getenv("RVT_STAGE_BIG")) != 0;
   if (!c->stage_on || width * rows < ((size_t)256 << 10) || (!stage_big && width * rows >= ((size_t)64 << 20))) {
-    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->io_stream));
-    HIP_TRY(c, sync_stream(c->io_stream));  // (a small pageable copy: the runtime has not necessarily read it yet)
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->h2d_stream));
+    HIP_TRY(c, sync_stream(c->h2d_stream));  // (a small pageable copy: the runtime has not necessarily read it yet)
     return RVT_OK;
   }
   int rc = stage_ready(c);
@@ -1380,18 +1389,24 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.gene_id = ids ? ids[g] : g;
     // hard-call path: unweighted null model, block known to hold only 0.0 / 1.0 / 2.0, a single-pass tile class
     gd.hc = 0;
-    if (hc_possible && gd.MT <= hc_max_mt && (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31)) {
+    if (hc_possible && gd.MT <= hc_max_mt && ((kind && kind[g] == 3) || (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31))) {
       if (score_hc) {
         gd.hc = cov->slice_hc[g] ? 1 : 0;
       } else {
         const int k = kind ? kind[g] : -1;
         gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;
+        if (k == 3) {  // the block holds PLINK 2-bit rows (rvt_submit_gene_bed): gene_suffstat_hcp
+          gd.hc = 3;
+          gd.pk_pitch = (int)(((size_t)((N + 3) / 4) + 15) / 16 * 16);
+        }
         if (lat_possible && gd.MT <= kLatMaxMT && (k == 2 || (k < 0 && !predict_hc))) {
           gd.hc = 2;
           gd.lat_den = (double)c->lattice_den;
         }
       }
     }
+    if (kind && kind[g] == 3 && gd.hc != 3)
+      return fail(c, RVT_E_STATE, "gene %d was submitted as packed rows but the batch cannot take the packed kernel", g);
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
     if (gd.hc) {
       n_hc++;
@@ -1443,7 +1458,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.parts = reinterpret_cast<double*>(base + o.parts);
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
     gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
-    gd.pq = (gd.hc == 1 && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
+    gd.pq = ((gd.hc == 1 || gd.hc == 3) && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
     gd.wflags = (gd.hc && o.wflags) ? reinterpret_cast<unsigned*>(base + o.wflags) : nullptr;
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
@@ -1521,7 +1536,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].hc == h_desc[k].hc) ++e;
     hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
-    if (h_desc[k].hc == 2)
+    if (h_desc[k].hc == 3)
+      k2_launch_hcp(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
+                    (long long)ld, d);
+    else if (h_desc[k].hc == 2)
       k2_launch_lat(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2},
                     (double)c->lattice_den, (long long)N, (long long)ld, d);
     else if (hcw)
@@ -1704,7 +1722,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     c->timing.genes += n;
     c->timing.genes_hard_call += n_hc;
     for (int g = 0; g < n; ++g) {
-      if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + (hcw ? 4 : 2));
+      if (desc[g].hc == 3)
+        c->timing.alg_bytes_hc += (double)desc[g].pk_pitch * Ms[g] + 8.0 * (double)N * (d + 2);
+      else if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + (hcw ? 4 : 2));
       c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
     }
@@ -4893,6 +4913,63 @@ int bgen_decode_gene(rvt_ctx* c, const BgenGene* bg, int M, int64_t N, hipStream
   return text_release(c, st);
 }
 
+// Header of a packed block (suffstat_hcp.hip.h) from the count pass over its 2-bit rows: per column the imputed value,
+// whether the column is flipped (sum of the imputed column > N, DataConsolidator.cpp:46-69), polymorphic (min != max,
+// DataConsolidator.cpp:94-116) and whether its imputed value counts in the burden collapse ((int)mu' > 0).  One thread per
+// column; parts: consolidate_count_kernel<bed2_t>'s records (pad = the number of 2s), fill: consolidate_fill_kernel's.
+__global__ __launch_bounds__(128) void hcp_header_kernel(const ConsolPart* __restrict__ parts, int nparts, int M, long long N,
+                                                         const double* __restrict__ fill, HcpHeader* __restrict__ hdr) {
+  const int j = threadIdx.x;
+  bool flip = false, poly = false, cm = false;
+  if (j < M) {
+    const ConsolPart* p = parts + (long long)j * nparts;
+    double ac = 0.0;
+    long long nonneg = 0, n2 = 0;
+    for (int k = 0; k < nparts; ++k) {
+      ac += p[k].ac;
+      nonneg += p[k].nonneg;
+      n2 += p[k].pad;
+    }
+    const long long nm = N - nonneg, n1 = (long long)ac - 2 * n2, n0 = nonneg - n1 - n2;
+    const double mu = nm > 0 ? fill[j] : 0.0;
+    hdr->mu[j] = mu;
+    const double s = ac + (double)nm * mu;
+    flip = !(s <= (double)N);
+    double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+    double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+    if (nm > 0) {
+      mn = fmin(mn, mu);
+      mx = fmax(mx, mu);
+    }
+    poly = !(mn == mx);
+    cm = nm > 0 && poly && (flip ? mu <= 1.0 : mu >= 1.0);
+  }
+  const unsigned long long bf = __ballot(flip), bp = __ballot(poly), bc = __ballot(cm);
+  if ((j & 15) == 0 && j < 96) {
+    const int b = j >> 4, sh = 16 * ((j >> 4) & 3);
+    hdr->flip[b] = (unsigned short)((bf >> sh) & 0xffffu);
+    hdr->poly[b] = (unsigned short)((bp >> sh) & 0xffffu);
+    hdr->cm[b] = (unsigned short)((bc >> sh) & 0xffffu);
+  }
+}
+
+// The genes rvt_submit_gene_bed may keep as 2-bit rows (gene_suffstat_hcp): the conditions under which run_batch takes the
+// hard-call family, and nothing that needs the fp64 block itself (permutations, AnalyticVT).  RVT_PACKED=0: always expand.
+static bool null_is_default(const rvt_ctx* c) {
+  const int d = c->nc.d;
+  const int64_t ld = c->nc.ld;
+  return c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
+         c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
+}
+static bool packed_eligible(const rvt_ctx* c, int M, uint32_t tests, const rvt_params* prm) {
+  static const bool on = !(getenv("RVT_PACKED") && atoi(getenv("RVT_PACKED")) == 0);
+  if (!on || !c->hc_enabled || c->nc.binary || c->nc.d > kHcMaxD || !null_is_default(c)) return false;
+  if ((M + 15) / 16 > kHcMaxMT) return false;
+  if (tests & (RVT_TEST_FAMSKAT | RVT_TEST_ANALYTICVT | RVT_TEST_FAMCMC | RVT_TEST_FAMZEGGINI)) return false;
+  if ((tests & RVT_TEST_SKAT) && prm && prm->skat_nperm > 0) return false;
+  return true;
+}
+
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
   RegWait reg_wait_on_return(c);
@@ -4911,24 +4988,37 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   std::memset(&p.res, 0, sizeof(p.res));
   // device block from the pool (smallest that fits) or a fresh zeroed allocation; pad rows stay zero because only
   // the N data rows of a column are ever written
-  const size_t need = sizeof(double) * (size_t)c->null_ld * M;
+  // PLINK 2-bit rows stay packed when the gene's tests allow it (gene_suffstat_hcp): a block of header + M padded rows
+  const bool packed = mode == 3 && packed_eligible(c, M, tests, prm);
+  const size_t pk_pitch = ((size_t)((c->nc.N + 3) / 4) + 15) / 16 * 16;
+  const size_t need = packed ? (size_t)kHcpHeaderBytes + pk_pitch * M + 16 : sizeof(double) * (size_t)c->null_ld * M;
+  bool fresh_packed = false;
   int best = -1;
-  for (int i = 0; i < (int)c->block_pool.size(); ++i)
-    if (c->block_pool[i].first >= need && (best < 0 || c->block_pool[i].first < c->block_pool[best].first)) best = i;
+  auto& pool = packed ? c->pk_pool : c->block_pool;
+  for (int i = 0; i < (int)pool.size(); ++i)
+    if (pool[i].first >= need && (!packed || pool[i].first <= 4 * need) && (best < 0 || pool[i].first < pool[best].first))
+      best = i;
   if (best >= 0) {
-    p.dG = c->block_pool[best].second;
-    p.bytes = c->block_pool[best].first;
-    c->block_pool.erase(c->block_pool.begin() + best);
+    p.dG = pool[best].second;
+    p.bytes = pool[best].first;
+    pool.erase(pool.begin() + best);
+  } else if (packed) {
+    if (hipMalloc((void**)&p.dG, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(c, RVT_E_HIP, "hipMalloc(%zu bytes) failed for a packed gene", need);
+    }
+    p.bytes = need;
+    fresh_packed = true;
   } else {
     int rc = rvt_block_alloc(c, M, &p.dG);
     if (rc) return rc;
     p.bytes = need;
   }
-  auto give_back = [&]() { c->block_pool.emplace_back(p.bytes, p.dG); };
+  auto give_back = [&]() { (packed ? c->pk_pool : c->block_pool).emplace_back(p.bytes, p.dG); };
   const int64_t N = c->nc.N, ld = c->null_ld;
   // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
   // (dosage text, BGEN), or whatever the caller's doubles are
-  p.kind = (mode == 2 || mode == 3 || mode == 4) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1));
+  p.kind = packed ? 3 : ((mode == 2 || mode == 3 || mode == 4) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1)));
   p.decoded = (mode == 4 || mode == 5) ? 1 : (mode == 6 ? 2 : 0);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
@@ -4990,6 +5080,32 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     }
     if (e != hipSuccess) {
       // fall through to the error return below
+    } else if (packed) {
+      // the rows go straight into the gene's own block (copy stream, 2-D: pitch padded to 16 bytes); the count pass and the
+      // header follow on the io stream.  Nothing is expanded.
+      unsigned char* rows = reinterpret_cast<unsigned char*>(p.dG) + kHcpHeaderBytes;
+      const size_t cb = (size_t)((N + 3) / 4);
+      const int ek = c->pack_next;
+      c->pack_next = (ek + 1) % rvt_ctx::kPack;
+      // (the pad bytes of a row read as zeros: cleared once, when the block is allocated — the copies never write them)
+      if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
+      if (e == hipSuccess) {
+        c->h2d_stream = c->copy_stream;
+        const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M);
+        c->h2d_stream = c->io_stream;
+        if (rcs != RVT_OK) e = hipErrorUnknown;
+      }
+      if (e == hipSuccess) e = hipEventRecord(c->ev_pack_copied[ek], c->copy_stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_pack_copied[ek], 0);
+      if (e == hipSuccess) {
+        const bed2_t* sb = reinterpret_cast<const bed2_t*>(rows);
+        hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, (long long)pk_pitch, (long long)N,
+                           c->d_consol_parts);
+        hipLaunchKernelGGL((consolidate_fill_kernel<bed2_t>), dim3((unsigned)M), dim3(64), 0, st, sb, (long long)pk_pitch,
+                           (long long)N, nparts, c->d_consol_parts, d_af_dst, d_fill);
+        hipLaunchKernelGGL(hcp_header_kernel, dim3(1), dim3(128), 0, st, c->d_consol_parts, nparts, M, (long long)N, d_fill,
+                           reinterpret_cast<HcpHeader*>(p.dG));
+      }
     } else if (mode == 1 || mode == 5 || mode == 6) {
       int rc = mode == 1   ? upload_block_data(c, p.dG, M, (const double*)G)
                : mode == 5 ? vcf_decode_gene(c, (const VcfGene*)G, M, N, st, err_slot, p.dG, ld)  // VCF dosage text -> doubles
@@ -5412,7 +5528,7 @@ static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
       snprintf(who, sizeof(who), " of gene %lld", (long long)c->queue[g].id);
       io_err_message(c, c->queue[g].io_error, c->queue[g].decoded == 2, who);
     }
-    c->block_pool.emplace_back(c->queue[g].bytes, c->queue[g].dG);
+    (c->queue[g].kind == 3 ? c->pk_pool : c->block_pool).emplace_back(c->queue[g].bytes, c->queue[g].dG);
   }
   c->queue.erase(c->queue.begin(), c->queue.begin() + n);
   for (auto& L : c->launched) L.first -= (size_t)n;
@@ -5428,6 +5544,10 @@ static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
       total -= c->block_pool.back().first;
       hipFree(c->block_pool.back().second);
       c->block_pool.pop_back();
+    }
+    while (c->pk_pool.size() > 4096) {
+      hipFree(c->pk_pool.back().second);
+      c->pk_pool.pop_back();
     }
   }
 }

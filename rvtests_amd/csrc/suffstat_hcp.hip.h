@@ -1,0 +1,285 @@
+// rvtests_amd — sufficient statistics of a gene straight from its PLINK 2-bit rows (rvt_submit_gene_bed), unweighted
+// (quantitative-trait) null model.
+//
+// The packed hand-off used to be EXPANDED on the device into the boundary's fp64 block (consolidate_write_kernel: 200 MB
+// written per gene at N = 500 000) which gene_suffstat_hc then read back — 400 MB of HBM traffic for 6 MB of information,
+// and what held the 2-bit feed at 4.5 k gene-sets/s where the link carries 8 k (DESIGN.md "Host feed").  Here the rows are
+// read as they arrived: one 16-byte load per column and 64 samples, i.e. 1/64 of the bytes, same arithmetic:
+//   * a 2-bit code (libVcf/PlinkInputFile.h:206-209: 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing) becomes the integer H and
+//     the mask m of suffstat_hc.hip.h's masked-entry scheme by byte-parallel logic; the operand byte is H + 4 m, the
+//     ordinary tiles hold C = (H + 4m)'(H + 4m), the tiles P' and Q are added to the 16-bit LDS counters when a 64-sample
+//     operand holds a missing call (hc_group_end), and gene_assemble recovers G'G exactly as for an fp64 block whose
+//     missing calls imputeGenotypeToMean has filled;
+//   * the value imputeGenotypeToMean would have written — mu_j per column, from the count pass over the packed rows
+//     (consolidate_count_kernel<bed2_t> / consolidate_fill_kernel: the reference's truncating allele count) — is known
+//     BEFORE this kernel runs (header of the packed block), so G'[X | rr] is formed with the true values on the fp64 matrix
+//     cores, and the burden collapse is exact in the same pass: the flip of a column (sum > N), whether it is
+//     polymorphic, and whether its imputed value counts ((int)mu' > 0) come from the header — no prediction, no fallback;
+//   * outputs as gene_suffstat_hc writes them (partial tiles, six-row column statistics with the bit pattern of mu as
+//     the OR / AND rows, packed P' / Q images, burden partial sums): everything behind this kernel is unchanged.
+// Bound by the vector and matrix pipes, not by memory (≈6 MB per gene).
+#pragma once
+#include "suffstat_hc.hip.h"
+
+namespace rvt {
+
+constexpr int kHcpHeaderBytes = 1024;  // in front of the packed rows
+struct HcpHeader {                     // written by hcp_header_kernel (fam_kernels.hip.h) after the count pass
+  double mu[96];                       // imputed value of column j (0 when the column has no missing call)
+  unsigned short flip[8], poly[8], cm[8];  // per 16-column block: sum > N; min != max; the imputed value counts
+};
+static_assert(sizeof(HcpHeader) <= kHcpHeaderBytes, "header does not fit");
+
+// codes of four samples (one byte of a PLINK row) -> H (0 / 1 / 2 per byte; 0 where missing) and m (1 where missing)
+__device__ __forceinline__ void hcp_decode(unsigned b, unsigned& p, unsigned& m) {
+  const unsigned w = (b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u;  // one 2-bit code per byte
+  const unsigned hi = (w >> 1) & 0x01010101u, lo = w & 0x01010101u;
+  m = lo & ~hi;         // 01
+  p = hi + (hi & lo);   // 10 -> 1, 11 -> 2
+}
+
+// the double a sample's (H, m) stands for: 0.0 / 1.0 / 2.0, or the column's imputed value
+__device__ __forceinline__ double hcp_value(unsigned p, unsigned m, int l, unsigned mu_lo, unsigned mu_hi) {
+  const unsigned H = (p >> (8 * l)) & 3u;
+  unsigned hi = H ? 0x3FE00000u + (H << 20) : 0u;  // 0x3FF00000, 0x40000000
+  unsigned lo = 0u;
+  if ((m >> (8 * l)) & 1u) {
+    hi = mu_hi;
+    lo = mu_lo;
+  }
+  return hc_dbl(lo, hi);
+}
+
+struct HcpCol {  // per lane and tile row
+  unsigned fx, pm, cmk, mu_lo, mu_hi;
+};
+
+// one tile row of one step.  b = the byte with the lane's four samples; vb = 0xff in the bytes of samples that exist
+__device__ __forceinline__ void hcp_row(unsigned b, const double (&xv)[4], d4_t& accT, unsigned& pk, unsigned& cs,
+                                        const HcpCol& cl, unsigned& h, unsigned& anym, unsigned vb) {
+  unsigned p, m;
+  hcp_decode(b, p, m);
+  p &= vb;
+  m &= vb;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    accT = __builtin_amdgcn_mfma_f64_16x16x4f64(hcp_value(p, m, l, cl.mu_lo, cl.mu_hi), xv[l], accT, 0, 0, 0);
+  cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
+  const unsigned t = p ^ cl.fx;  // flipped column: (int)(2 - g) > 0  <=>  g != 2
+  h += ((((t | (t >> 1)) & 0x01010101u) & ~m) | (m & cl.cmk)) & cl.pm;
+  pk = p | (m << 2);  // operand byte H + 4 m
+  anym |= m;
+}
+
+template <int MT>
+__device__ __forceinline__ void suffstat_hcp_body(const GeneDesc& gd, const NullTile& nt, long long N, long long ld,
+                                                  int d, unsigned* lds) {
+  const int lane = threadIdx.x & 63;
+  const int v = lane & 15, q = lane >> 4;
+  const int wpart = blockIdx.x;
+  if (wpart >= gd.n_wparts) return;
+  constexpr int kPQ = hc_pq_words(MT);
+#pragma unroll 4
+  for (int w = lane; w < kPQ; w += 64) lds[w] = 0u;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) lds[kPQ + 64 * c + lane] = (lane & 2) ? 0xffffffffu : 0u;
+  if (lane < 4) lds[kPQ + 64 * MT + lane] = 0u;
+  unsigned anym = 0u;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;  // (a multiple of 4 steps: kHcStepUnit)
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  if (s_begin >= s_end) return;
+  const int M = gd.M;
+  auto uniform = [](const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const unsigned char* blk = reinterpret_cast<const unsigned char*>(uniform(gd.G));
+  const HcpHeader* hdr = reinterpret_cast<const HcpHeader*>(blk);
+  const unsigned pitch = (unsigned)gd.pk_pitch;
+  const __amdgpu_buffer_rsrc_t rp =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(blk + kHcpHeaderBytes), 0, (unsigned)M * pitch, 0x00020000);
+  const unsigned xbytes = (unsigned)((unsigned long long)nt.cols * (unsigned long long)ld * 8ull);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uniform(nt.base), 0, xbytes, 0x00020000);
+  const unsigned col_bytes = (unsigned)((unsigned long long)ld * 8ull);
+  const int xcol = (v <= d) ? v : d + 1;  // X_k, rr, or the zero column
+  const unsigned xbase = (unsigned)xcol * col_bytes + (unsigned)(q * 32);
+  unsigned cbase[MT];
+  HcpCol cl[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    const int col = c * 16 + v;
+    const bool in = col < M;
+    cbase[c] = in ? (unsigned)col * pitch : 0x80000000u;  // a pad column reads zeros
+    const double mu = in ? hdr->mu[col] : 0.0;
+    const unsigned long long mb = __builtin_bit_cast(unsigned long long, mu);
+    cl[c].mu_lo = (unsigned)mb;
+    cl[c].mu_hi = (unsigned)(mb >> 32);
+    cl[c].fx = (in && ((hdr->flip[c] >> v) & 1)) ? 0x02020202u : 0u;
+    cl[c].pm = (in && ((hdr->poly[c] >> v) & 1)) ? 0x01010101u : 0u;
+    cl[c].cmk = (in && ((hdr->cm[c] >> v) & 1)) ? 0x01010101u : 0u;
+  }
+  d4_t accT[MT];
+  i4_t accS[MT * (MT + 1) / 2];
+  unsigned cs[MT], pk[MT][4];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    accT[c] = d4_t{0.0, 0.0, 0.0, 0.0};
+    cs[c] = 0;
+  }
+#pragma unroll
+  for (int t = 0; t < MT * (MT + 1) / 2; ++t) accS[t] = i4_t{0, 0, 0, 0};
+  HcBurden bu{0.0, 0.0, 0u, 0u};
+
+  // groups of 4 steps = 64 samples = 16 bytes of every row.  A group that reaches beyond N (or beyond the wave's range) is
+  // masked sample by sample; rows are padded to 16 bytes and loads beyond the block return zeros.
+  for (long long s = s_begin; s < s_end; s += 4) {
+    u4_t cw[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+      cw[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rp, cbase[c] + (unsigned)(s * 4), 0, 0));
+    u4_t xlo[4], xhi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long su = (s + u < s_end) ? s + u : s_end - 1;  // (clamped: its samples are masked below)
+      xlo[u] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xbase + (unsigned)(su * 128), 0, 0));
+      xhi[u] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xbase + (unsigned)(su * 128) + 16, 0, 0));
+    }
+    const bool whole = (s + 4 <= s_end) && ((s + 4) * 16 <= N);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      unsigned vmask = 0xffffffffu;
+      if (!whole) {
+        vmask = 0u;
+        const long long smp = (s + u) * 16 + q * 4;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) vmask |= (s + u < s_end && smp + l < N) ? (0xffu << (8 * l)) : 0u;
+      }
+      double xv[4] = {hc_dbl(xlo[u][0], xlo[u][1]), hc_dbl(xlo[u][2], xlo[u][3]), hc_dbl(xhi[u][0], xhi[u][1]),
+                      hc_dbl(xhi[u][2], xhi[u][3])};
+      if (!whole) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) xv[l] = ((vmask >> (8 * l)) & 1u) ? xv[l] : 0.0;
+      }
+      unsigned h = 0;
+#pragma unroll
+      for (int c = 0; c < MT; ++c) {
+        const unsigned b = (cw[c][u] >> (8 * q)) & 0xffu;
+        hcp_row(b, xv, accT[c], pk[c][u], cs[c], cl[c], h, anym, vmask);
+      }
+      if (whole)
+        hc_finish<false>(h, xv, bu, 0xffffffffu);
+      else
+        hc_finish<true>(h, xv, bu, vmask);
+    }
+    hc_group_end<MT>(pk, accS, anym, lds, lane);
+  }
+
+  // ---- partial tiles: element (row, col) -> parts[row * Cp + col], the layout gene_assemble reduces ---------------
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+  const int Cp = gd.Cp;
+  {
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < MT; ++r)
+#pragma unroll
+      for (int c = r; c < MT; ++c, ++t) {
+        const int col = c * 16 + v;
+        if (col < M) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[(long long)(r * 16 + q * 4 + i) * Cp + col] = (double)accS[t][i];  // i32 map
+        }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r * 16 + q + 4 * i;  // f64 C/D map
+      if (M + v < Cp) out[(long long)row * Cp + M + v] = accT[r][i];
+      if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
+    }
+  }
+  // ---- column statistics: sum of H, min / max over the hard calls, masked count, the bit pattern of mu ------------------
+  long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
+  if (cnt_w < 0) cnt_w = 0;
+  double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
+  const unsigned wflag = lds[kPQ + 64 * MT];
+  {
+    int t = 0;
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+      unsigned sc = cs[c];
+      sc += __shfl_xor(sc, 16, 64);
+      sc += __shfl_xor(sc, 32, 64);
+      const i4_t dg = accS[t];
+      const int sel = (lane & 3) == 0 ? dg[0] : ((lane & 3) == 1 ? dg[1] : ((lane & 3) == 2 ? dg[2] : dg[3]));
+      const int diag = __shfl(sel, v + 16 * (v >> 2), 64);
+      const int tq = MT * MT + t;
+      const unsigned qw = lds[(tq * 2 + ((v >> 1) & 1)) * 64 + v + 16 * (v >> 2)];
+      const long long nm = (long long)((qw >> (16 * (v & 1))) & 0xffffu);  // missing calls of column c * 16 + v
+      t += MT - c;
+      const long long sm = (long long)sc, hh = (long long)diag - 16 * nm, n2 = (hh - sm) / 2, n1 = 2 * sm - hh,
+                      n0 = cnt_w - n1 - n2 - nm;
+      const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+      const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+      if (lane < 16) {
+        const int j = c * 16 + lane;
+        cst[j] = (double)sm;
+        cst[gd.Mp + j] = mn;
+        cst[2 * gd.Mp + j] = mx;
+        cst[3 * gd.Mp + j] = (double)nm;
+        const unsigned long long mb = ((unsigned long long)cl[c].mu_hi << 32) | cl[c].mu_lo;
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(cst);
+        bits[4 * gd.Mp + j] = nm > 0 ? mb : 0ull;
+        bits[5 * gd.Mp + j] = nm > 0 ? mb : ~0ull;
+      }
+    }
+  }
+  if (gd.wflags && lane == 0) gd.wflags[wpart] = wflag & 1u;
+  if ((wflag & 1u) && gd.pq) {
+    unsigned* dst = gd.pq + (long long)wpart * kPQ;
+#pragma unroll 4
+    for (int w = lane; w < kPQ; w += 64) dst[w] = lds[w];
+  }
+  // ---- burden partial sums: [test][U, c'c, count, c'X_0 .. c'X_{d-1}], test 0 = CMC, 1 = Zeggini ---------------------
+  if (gd.bparts) {
+    double ac = bu.a_cmc, az = bu.a_zeg;
+    ac += __shfl_xor(ac, 16, 64);
+    az += __shfl_xor(az, 16, 64);
+    ac += __shfl_xor(ac, 32, 64);
+    az += __shfl_xor(az, 32, 64);
+    unsigned zz = bu.zz, cn = bu.cnt;
+    zz += __shfl_xor(zz, 16, 64);
+    cn += __shfl_xor(cn, 16, 64);
+    zz += __shfl_xor(zz, 32, 64);
+    cn += __shfl_xor(cn, 32, 64);
+    const int rl = 3 + d;
+    double* bp = gd.bparts + (long long)wpart * 2 * rl;
+    if (lane <= d) {
+      const int k = (lane == d) ? 0 : 3 + lane;
+      bp[k] = ac;
+      bp[rl + k] = az;
+    }
+    if (lane == 0) {
+      bp[1] = (double)cn;
+      bp[2] = (double)cn;
+      bp[rl + 1] = (double)zz;
+      bp[rl + 2] = (double)cn;
+    }
+  }
+}
+
+template <int MT, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void gene_suffstat_hcp(const GeneDesc* __restrict__ genes, NullTile nt, long long N,
+                                                               long long ld, int d) {
+  __shared__ unsigned lds[hc_lds_words(MT)];
+  const GeneDesc gd = genes[blockIdx.y];
+  if (gd.MT != MT) return;
+  suffstat_hcp_body<MT>(gd, nt, N, ld, d, lds);
+}
+
+}  // namespace rvt

@@ -47,10 +47,13 @@ struct GeneDesc {
   // hard-call path (suffstat_hc.hip.h)
   unsigned short pflip[8];  // predicted flip bits (af > 0.5) per 16-variant block, first 6 blocks
   int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
-  int hc;                   // 1: gene_suffstat_hc / _hcw (hard calls), 2: gene_suffstat_lat (lattice dosages), 0: general kernel
+  int hc;                   // 1: gene_suffstat_hc / _hcw (hard calls), 2: gene_suffstat_lat (lattice dosages), 3: gene_suffstat_hcp
+                            // (PLINK 2-bit rows), 0: general kernel
   double* vt_mem;           // AnalyticVT workspace (gene_vt_doubles(Mp)), null unless the test is requested
   unsigned* pq;             // hard-call path: n_wparts x hc_pq_words(MT) packed 16-bit counters of the masked tiles
   unsigned* wflags;         // hard-call path: per wave-part, bit 0 = masked entries met (pq written), bit 1 = bad entry
+  int pk_pitch;             // hc == 3 (gene_suffstat_hcp): G points to a packed block — header, then M rows of 2-bit codes,
+                            // pk_pitch bytes apart
   double lat_den;           // hc == 2: the lattice denominator — the G'G tiles and column sums of `parts` / `colstat` are
                             // the INTEGERS K'K and sum K (exact through the reduction), divided once in gene_assemble
 };

@@ -1,0 +1,104 @@
+"""GPU: genes kept as PLINK 2-bit rows on the device (rvtests_amd/csrc/suffstat_hcp.hip.h, rvt_submit_gene_bed) against the
+same genes expanded to fp64 blocks (RVT_PACKED=0 / the block entry points) and against the oracle: missing calls in every
+shape (none, sparse, a whole column, a column of one value plus missing), flipped and monomorphic columns, every tile class,
+sample counts that are not multiples of 4 / 16 / 64, and tests the packed kernel does not serve (permutations)."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("skat_Q", "skat_p", "skato_Q", "skato_p", "skato_rho", "cmc_U", "cmc_V", "cmc_stat", "cmc_p", "zeg_U",
+          "zeg_V", "zeg_stat", "zeg_p", "cmc_nonref", "n_poly", "status")
+
+
+def _raw_gene(N, M, seed, missing=0.01):
+    rng = np.random.default_rng(seed)
+    maf = 10 ** rng.uniform(-2.7, -0.5, M)
+    raw = rng.binomial(2, maf, size=(N, M)).astype(np.float64)
+    if missing > 0:
+        raw[rng.random((N, M)) < missing] = -9.0
+    if M > 3:
+        raw[:, 1] = np.where(raw[:, 1] < 0, -9.0, rng.binomial(2, 0.9, size=N))      # flipped column (sum > N)
+    if M > 6:
+        raw[:, 4] = np.where(rng.random(N) < 0.1, -9.0, 1.0)                        # one value + missing: monomorphic
+    if M > 8:
+        raw[:, 7] = 0.0                                                             # all zero
+    if M > 10:
+        raw[:, 9] = -9.0                                                            # nothing but missing calls
+    if M > 12:
+        raw[:, 11] = np.where(rng.random(N) < 0.3, -9.0, rng.binomial(2, 0.7, size=N))  # imputed value >= 1: it counts
+    return np.asfortranarray(raw)
+
+
+@pytest.mark.parametrize("N,d", [(3000, 2), (4099, 1), (10007, 3), (61, 1), (130, 2)])
+def test_packed_rows_equal_the_expanded_blocks_and_the_oracle(N, d, monkeypatch):
+    import rvtests_amd
+    genes = [_raw_gene(N, M, seed=31 * M + d, missing=(0.0 if M % 4 == 0 else 0.01))
+             for M in (1, 5, 16, 17, 30, 33, 48, 50, 64, 65, 80, 81, 96)]
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=5, G_effect=0.4 * orc.impute_mean(genes[4])[:, :3].sum(1))
+    outs = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("RVT_PACKED", packed)
+        # (the switch is read once per process: a fresh library handle would not re-read it — use the engine's own knob)
+        e = rvtests_amd.Engine(0)
+        e.set_null(0, X, res, v, s2)
+        if packed == "0":
+            e.set_hardcall(True)
+        e.set_profiling(True)
+        e.timing(reset=True)
+        afs = []
+        for g, raw in enumerate(genes):
+            if packed == "1":
+                afs.append(e.submit_gene_bed(g, e.pack_bed(raw), raw.shape[1]))
+            else:
+                afs.append(e.submit_gene_raw(g, raw.astype(np.int8)))
+        outs[packed] = (e.collect(), afs, e.timing(reset=True))
+        e.close()
+    got, af_p, tm = outs["1"]
+    ref, af_r, _ = outs["0"]
+    assert tm.genes_hard_call == len(genes) and tm.genes_handed_back == 0
+    for a, b, fa, fb, raw in zip(got, ref, af_p, af_r, genes):
+        assert np.array_equal(fa, fb)
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            if f.startswith("cmc") and f != "cmc_nonref" and abs(b.cmc_U) < 1e-8:
+                continue      # every sample counts: the CMC genotype is the constant 1 and U = the sum of the residuals = rounding
+            assert x == y_ or abs(x - y_) <= 1e-11 * abs(y_), (raw.shape[1], f, x, y_)
+        G = orc.impute_mean(raw)
+        rc, o = orc.skat(G, orc.counter_af(raw), X, res, v, 0)
+        assert a.n_poly == o.n_poly
+        if o.n_poly:
+            assert abs(a.skat_Q - o.Q) <= 1e-10 * o.Q and abs(a.skat_p - o.pvalue) <= 1e-6 * o.pvalue + 1e-14
+        rc3, c = orc.burden(G, X, y, 0, 0)
+        if rc3 == 0:
+            assert a.cmc_nonref == c.nonref_site
+            if abs(b.cmc_U) >= 1e-8:        # (not the constant genotype, whose variance is rounding noise on both sides)
+                assert a.cmc_ok and abs(a.cmc_p - c.pvalue) <= 1e-6 * c.pvalue + 1e-14
+        rc4, z = orc.burden(G, X, y, 0, 1)
+        if rc4 == 0:
+            assert a.zeg_ok and abs(a.zeg_stat - z.stat) <= 1e-9 * z.stat + 1e-13
+
+
+def test_tests_that_need_the_block_expand_it(engine):
+    """SKAT with permutations reads the fp64 block: such a gene is expanded as before; a binary trait likewise."""
+    import rvtests_amd
+    N = 2000
+    raw = _raw_gene(N, 20, seed=3)
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=4)
+    engine.set_null(0, X, res, v, s2)
+    prm = rvtests_amd.Params.default()
+    prm.skat_nperm = 200
+    engine.submit_gene_bed(0, engine.pack_bed(raw), 20, params=prm, want_af=False)
+    engine.submit_gene_bed(1, engine.pack_bed(raw), 20, want_af=False)
+    a, b = engine.collect()
+    assert a.skat_Q == b.skat_Q and a.n_poly == b.n_poly and a.skat_p == b.skat_p
+    Xb, yb, resb, vb, s2b = synth.make_null(N, 2, 1, seed=4)
+    engine.set_null(1, Xb, resb, vb, s2b)
+    engine.submit_gene_bed(0, engine.pack_bed(raw), 20, want_af=False)
+    engine.submit_gene_raw(1, raw.astype(np.int8), want_af=False)
+    a, b = engine.collect()
+    for f in FIELDS:
+        assert getattr(a, f) == getattr(b, f), f
