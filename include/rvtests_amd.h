@@ -476,7 +476,10 @@ int rvt_kbac_blocks(rvt_ctx* ctx, int n, const double* const* dG, const int* M, 
  *   rvt_submit_gene_bed : PLINK .bed storage as PlinkInputFile reads it in SNP-major mode
  *                         (libVcf/PlinkInputFile.cpp:24-47, codes libVcf/PlinkInputFile.h:206-209): M rows of
  *                         ceil(N/4) bytes, sample p in bits 2(p&3).. of byte p>>2; 00 -> 0, 10 -> 1, 11 -> 2,
- *                         01 -> missing: a quarter of a byte per genotype
+ *                         01 -> missing: a quarter of a byte per genotype.  Under a quantitative trait, for tests that
+ *                         do not need the fp64 block (no permutations, no AnalyticVT, M <= 96), the rows stay packed on
+ *                         the device and the sufficient statistics are formed from them (suffstat_hcp.hip.h): same
+ *                         records, 1/64 of the device memory and traffic
  * af_out (M, may be NULL) receives the allele frequencies the tests use (dc->getMarkerFrequency). */
 int rvt_submit_gene_raw(rvt_ctx* ctx, int64_t gene_id, int M, const double* Graw, uint32_t tests,
                         const rvt_params* params, double* af_out);
