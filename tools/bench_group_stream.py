@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """From-host rate of the device-group interface (rvt_group_*: several engine contexts behind ONE caller thread) next to a
-single context, and the link's own pinned host-to-device rate for reference.  On a 1-GPU box both members sit on device 0:
-the point is that two members are not slower than one (the caller thread, not the device, bounds the packed hand-offs).
+single context, and the link's own pinned host-to-device rate for reference.  On a 1-GPU box both members sit on device 0
+and share its link and its compute units: measured (round 3, 2 048 genes) two members reach 94 % of one member's rate for
+fp64 blocks and 67-78 % for the packed hand-offs — what two contexts cost on ONE device, not what a second device adds
+(no multi-GPU box was available to measure that).
 usage (GPU box): python tools/bench_group_stream.py [--samples 500000] [--variants 50] [--genes 256]"""
 import argparse
 import os
