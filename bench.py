@@ -297,7 +297,9 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
                 continue
         done = 0
         t0 = None
-        for g in range(-window, genes):          # one untimed window first: buffers, block pool and page mappings warm
+        # (the packed hand-offs stream thousands of genes per second: 192 genes would be 40 ms, a third of it the drain)
+        n_timed = genes * 8 if mode in ("int8", "bed2bit") else genes
+        for g in range(-window, n_timed):        # one untimed window first: buffers, block pool and page mappings warm
             if g == 0:
                 eng.collect()
                 t0 = time.perf_counter()
