@@ -512,11 +512,15 @@ def main():
         key = "N=%d,genes=%d,m=%d..%d,seed=20260002,tests=%d" % (N, args.genes, args.m_lo, args.m_hi, args.tests)
         if binary:
             key += ",binary"
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
+        if args.dosage:                                  # (the dosage workload has PMC passes of its own)
+            key += ",dosage,lattice=%d" % args.dosage_lattice
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                "r3_pmc_traffic_dosage.json" if args.dosage else "r3_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            k2 = pmc["kernels"].get("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat")
-            if pmc.get("workload") == key and k2 and not args.dosage:   # (the PMC passes are of the hard-call workload)
+            k2 = pmc["kernels"].get("suffstat_lat" if k2_name == "gene_suffstat_lat" else
+                                    ("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat"))
+            if pmc.get("workload") == key and k2:
                 traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
         line = {
             "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",

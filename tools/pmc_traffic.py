@@ -25,7 +25,9 @@ def main():
     f, w = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     fam = {}
     for k in f:
-        if "gene_suffstat_hc" in k:
+        if "gene_suffstat_lat" in k:
+            tag = "suffstat_lat"
+        elif "gene_suffstat_hc" in k:
             tag = "suffstat_hc"
         elif "gene_suffstat" in k:
             tag = "suffstat"
@@ -40,7 +42,7 @@ def main():
         e["launches_per_step"] = e["dispatches"] / batches
     json.dump({"workload": key, "batches": batches, "correction": "FETCH_SIZE x2 (gfx950), x1024 B; WRITE_SIZE x1024 B",
                "kernels": fam}, open(outp, "w"), indent=1)
-    print(json.dumps({k: fam[k] for k in ("suffstat_hc", "suffstat") if k in fam}))
+    print(json.dumps({k: fam[k] for k in ("suffstat_hc", "suffstat_lat", "suffstat") if k in fam}))
 
 
 if __name__ == "__main__":
