@@ -921,6 +921,8 @@ int rvt_block_classify(rvt_ctx* c, const double* dG, int M, int* is_hard_call) {
 
 int rvt_set_hardcall(rvt_ctx* c, int on) {
   if (!c) return RVT_E_INVALID;
+  // (genes kept as packed rows are waiting for the integer kernels they were submitted for)
+  if (!c->queue.empty()) return fail(c, RVT_E_STATE, "collect the submitted genes before switching the hard-call kernels");
   int rc = rvt_sync(c);
   if (rc) return rc;
   c->hc_enabled = on != 0;
