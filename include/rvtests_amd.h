@@ -226,7 +226,7 @@ int rvt_set_content_hint(rvt_ctx* ctx, int hint);
  * what rvt_submit_gene_vcf_dosage decodes — take gene_suffstat_lat (rvtests_amd/csrc/suffstat_lat.hip.h) under a
  * quantitative trait: K = rint(g denominator) is split into two 7-bit digits and G'G = K'K / denominator^2 is formed on
  * the int8 matrix cores, exactly, with the burden collapse in the same pass; the kernel is bound by HBM where the fp64
- * kernel is bound by the fp64 matrix pipe.  Every value is tested (|g denominator - K| <= 2^-30, 0 <= g <= 2): a block that
+ * kernel is bound by the fp64 matrix pipe.  Every value is tested (|g denominator - K| <= K 2^-53 — i.e. g is the double nearest to K / denominator —, 0 <= g <= 2): a block that
  * holds anything else (BGEN's float probabilities, mean-imputed entries, a different number of decimals) is handed back
  * and computed by the fp64 kernel in the same call.  A wrong statement costs time, never correctness. */
 int rvt_set_dosage_lattice(rvt_ctx* ctx, int denominator);
@@ -349,17 +349,16 @@ int rvt_fit_null(rvt_ctx* ctx, int trait, int64_t N, int d, const double* X, con
  * With rvt_params.skat_nperm > 0 (the reference's default for `--kernel skat`: nPerm = 10000, src/ModelManager.cpp:171-175),
  * rvt_run_blocks / rvt_collect also run the adaptive permutation test of SkatTest::fit (src/Model.h:2706-2718;
  * Permutation src/Permutation.h:69-98; permute src/LinearAlgebra.h:8-21; Skat::GetQFromNewResidual
- * regression/Skat.cpp:107-116), gene after gene.  Two modes (rvt_set_perm_exact, or RVT_PERM_EXACT=1 in the environment):
- *   counter-based (default)  shuffle s of gene g is a keyed bijection of [0, N) — Philox keys from (seed, gene_id, s), a
- *                            cycle-walked Feistel network (rvtests_amd/csrc/perm_counter.h).  No state is shared between
- *                            genes, so any context of a device group may take any gene, in any order, and the records do
- *                            not depend on how the genes were dealt; nothing is stored per shuffle.  STATISTICAL parity
- *                            with the reference: the same estimator of the same tail probability with the same stopping
- *                            rule, other random numbers.
- *   exact                    ONE emulated glibc rand() stream consumed exactly as the reference's process-wide rand() is, so
- *                            the permutations themselves — and ActualPerm / NumGreater / NumEqual — are the reference's
- *                            (Q is evaluated in fp64 instead of fp32).  Sequential across genes: a device group sends every
- *                            such gene to member 0.
+ * regression/Skat.cpp:107-116), gene after gene.  Two modes (rvt_set_perm_exact, or RVT_PERM_EXACT=0/1 in the environment):
+ *   exact (DEFAULT of a       ONE emulated glibc rand() stream consumed exactly as the reference's process-wide rand() is, so
+ *   context and of a          the permutations themselves — and ActualPerm / NumGreater / NumEqual / PermPvalue — are the
+ *   one-member group)         reference's (Q is evaluated in fp64 instead of fp32).  Sequential across genes.
+ *   counter-based (default    shuffle s of gene g is a keyed bijection of [0, N) — Philox keys from (seed, gene_id, s), a
+ *   of a group with more      cycle-walked Feistel network (rvtests_amd/csrc/perm_counter.h).  No state is shared between
+ *   than one member;          genes, so any context of a device group may take any gene, in any order, and the records do
+ *   rvt_set_perm_exact(c,0))  not depend on how the genes were dealt; nothing is stored per shuffle.  STATISTICAL parity
+ *                             with the reference: the same estimator of the same tail probability with the same stopping
+ *                             rule, other random numbers (granted to sharded runs).  ~40x faster.
  * rvt_rand_seed restarts the rand() stream (srand semantics; the reference never calls srand, i.e. seed 1, which is also
  * the state of a fresh context) and is the seed of the counter-based keys.  rvt_run_blocks_async rejects skat_nperm > 0. */
 int rvt_rand_seed(rvt_ctx* ctx, unsigned seed);
@@ -595,8 +594,10 @@ int rvt_group_submit_gene_vcf(rvt_group* group, int64_t gene_id, int M, const ch
 int rvt_group_submit_gene_bgen(rvt_group* group, int64_t gene_id, int M, const unsigned char* const* block,
                                const int64_t* block_len, int layout, uint32_t tests, const rvt_params* params,
                                double* af_out);
-/* SKAT permutations in a group: counter-based by default (any member takes any gene); rvt_group_set_perm_exact(g, 1)
- * sends every permutation gene to member 0, which replays the reference's rand() stream (see rvt_set_perm_exact) */
+/* SKAT permutations in a group: a ONE-member group replays the reference's rand() stream (exact, as a single context);
+ * a group that deals genes over several members takes the counter-based permutations (any member takes any gene).
+ * rvt_group_set_perm_exact(g, 1) sends every permutation gene to member 0, which replays the reference's rand() stream;
+ * rvt_group_set_perm_exact(g, 0) selects the counter-based mode for a one-member group too (see rvt_set_perm_exact) */
 int rvt_group_set_perm_exact(rvt_group* group, int on);
 int rvt_group_rand_seed(rvt_group* group, unsigned seed);
 /* rvt_host_register / rvt_host_unregister for a group: the range is page-locked once, for every member's device */

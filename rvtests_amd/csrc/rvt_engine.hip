@@ -205,11 +205,13 @@ struct rvt_ctx {
   // are resolved, so the error lands on the gene that caused it) + word kAfSlots for the synchronous calls.
   int* h_io_err = nullptr;
   // ---- SKAT permutations: the emulated glibc rand() stream (TYPE_3), oldest word first ----
-  // Permutation mode: exact = the reference's own rand() stream replayed (one sequential stream in gene order: bit-identical
-  // counters, ~3 k shuffles/s at N = 500 000); default = counter-based permutations keyed by (seed, gene id, shuffle)
-  // (perm_counter.h: statistical parity, any context / device / gene order, ~10^5 shuffles/s).  RVT_PERM_EXACT=1 or
-  // rvt_set_perm_exact.
-  bool perm_exact = false;
+  // Permutation mode: exact (the DEFAULT of a single context: `--kernel skat[nPerm=..]` reproduces the reference's
+  // ActualPerm / NumGreater / NumEqual / PermPvalue) = the reference's own rand() stream replayed (one sequential stream in
+  // gene order: bit-identical counters, ~3 k shuffles/s at N = 500 000); counter-based = permutations keyed by (seed, gene
+  // id, shuffle) (perm_counter.h: statistical parity — SURVEY 8e grants it to SHARDED runs only —, any context / device /
+  // gene order, ~10^5 shuffles/s): selected by rvt_set_perm_exact(ctx, 0) / RVT_PERM_EXACT=0, and by a device group that
+  // deals genes over more than one member (rvt_group_init).
+  bool perm_exact = true;
   uint64_t perm_seed = 1;
   double* d_pc_part = nullptr;  // counter mode: partial products [slice][shuffle][variant]
   size_t pc_part_cap = 0;

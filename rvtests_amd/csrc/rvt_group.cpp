@@ -131,7 +131,8 @@ struct rvt_group {
   std::deque<int> owner;       // member of every submitted, not yet collected gene, in submission order
   std::vector<std::deque<rvt_gene_result>> inbox;  // records already taken from a member, waiting for their turn
   long long submitted = 0;     // genes dealt so far (decides the member of the next one)
-  bool perm_exact = false;     // SKAT permutations replay ONE rand() stream (member 0 only) instead of counter-based keys
+  bool perm_exact = true;      // SKAT permutations replay ONE rand() stream (member 0 only) instead of counter-based keys;
+                               // the default of a ONE-member group (= the reference's numbers), off when genes are dealt
   std::string err;
 };
 
@@ -221,7 +222,12 @@ int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
         g->worker.back()->start(m);
       }
   }
+  // Permutation mode: one member = one gene stream = the reference's own rand() stream (bit-identical counters).  Genes
+  // dealt over several members cannot share one sequential stream without serialising on member 0, so such a group takes
+  // the counter-based permutations (statistical parity) unless the caller asks for the exact stream.
+  g->perm_exact = g->member.size() == 1;
   if (const char* e = getenv("RVT_PERM_EXACT")) g->perm_exact = atoi(e) != 0;
+  for (rvt_ctx* m : g->member) rvt_set_perm_exact(m, g->perm_exact ? 1 : 0);
   *out = g;
   return RVT_OK;
 }

@@ -1,0 +1,734 @@
+// rvtests_amd — sufficient statistics of HARD-CALL genotype blocks against a WEIGHTED (binary-trait) null model, computed by
+// a WORKGROUP of four waves in INTEGER arithmetic throughout (round 4).  Same inputs and outputs as gene_suffstat_hcw
+// (suffstat_hcw.hip.h; replaces SkatO.cpp:150-160 with V = diag(p(1-p)), LogisticRegressionScoreTest.cpp:260-263, the
+// collapsers Model.cpp:73-89,115-130 and DataConsolidator.cpp:46-69,94-116), with the work divided differently:
+//
+//   * the one-wave kernel keeps ALL T = MT (MT + 1) / 2 Gram tiles x 3 pair accumulators of a gene AND the fp64 tiles of
+//     G'V[X | rr] in one wave: 416-440 registers for M > 48 — one wave per SIMD, 40 KB of loads in flight per CU
+//     (latency-bound at 4.9-5.4 TB/s), and a wave that needs a SIMD of its own: every 256-register wave of the per-gene
+//     stages (p-values, assembly) that sits on a SIMD keeps such a wave out (0.46 of HBM live, 0.61-0.67 alone);
+//   * here a workgroup is EIGHT waves in two roles.  Each of the four LOADER waves streams a different 64-sample slice of
+//     ALL columns per iteration — the value tests, the packing to 2-bit integers, the byte sums and the per-sample burden
+//     counts are per sample and stay with the wave that loaded it — and writes the packed operands (1 byte per genotype)
+//     to LDS.  The four TILE waves multiply: each owns a share of the output tiles over the four slices — waves 4-6 the
+//     Gram tiles G'VG (assigned by A-operand row: the row's byte-select operands d_p (x) g are built once per slice and
+//     reused for the row's tiles), wave 7 the tiles G'V[X | res | v] and the burden sums: at most 6 tiles x 3 pairs = 72
+//     accumulator registers per wave instead of 180 + 40.  ONE barrier per iteration, two operand buffers: the loaders
+//     fill buffer i + 1 while the tile waves multiply buffer i, so a wave-part costs max(stream, multiply) instead of
+//     their sum, the loaders never stop issuing loads (a ring of 2-4 steps per wave in flight), and the two roles share
+//     every SIMD (waves w and w + 4 of a workgroup sit on SIMD w mod 4);
+//   * G'V[X | res] and the burden sums c'V[X | res | v] go to the int8 matrix cores as well: the null-model tile
+//     [vX_0 .. vX_{d-1} | res | v] is quantised ONCE per null model to six balanced base-128 digit planes per column with a
+//     power-of-two scale per column (42 bits below twice the column's largest entry; rvt_set_null checks that no column's
+//     largest entry exceeds 256 x its root mean square, else the model stays on gene_suffstat_hcw) and stored in operand
+//     order.  One v_mfma_i32_16x16x64_i8 per plane, row tile and 64 samples replaces SIXTEEN fp64 instructions of 64 cycles
+//     — the fp64 matrix pipe leaves the kernel — and every statistic is an exact integer of the quantised inputs:
+//     bit-reproducible whatever the order of the sums;
+//   * every class fits 256 registers: two waves per SIMD, 80-130 KB of loads in flight per CU, and any per-gene stage
+//     can share the SIMD;
+//   * MEAN-IMPUTED COLUMNS STAY ON THIS KERNEL (the one-wave kernel hands such a gene to the fp64 kernel: 0.33 of HBM).
+//     G_j = H_j + mu_j m_j (integer H, 0/1 mask m, one mu per column: imputeGenotypeToMean, DataConsolidator.cpp:217-245):
+//       G'VG = H'VH + P diag(mu) + diag(mu) P' + diag(mu) Q diag(mu),   P = H'Vm,  Q = m'Vm,
+//       G'V[X | res] = H'V[X | res] + diag(mu) R,   R = m'V[X | res].
+//     The dense tiles hold the H terms (a masked entry packs as H = 0).  P, Q and R are SPARSE — sums over the masked
+//     entries — and are accumulated exactly, as 64-bit integers, by the wave that loaded the slice: for every masked
+//     entry (sample i, column j) it walks sample i's row of packed integers and mask bits IN LDS (80 bytes, already there
+//     for the Gram tiles) and adds V_i H_ik to P_jk, V_i to Q_jk and the fixed-point row i of the null tile to R_j
+//     with integer atomics on the gene's own table in global memory (order-independent, hence bit-reproducible; measured
+//     23 G atomics/s device-wide, the path needs ~1.5 G/s at 0.1 % missing calls).  No extra pass over G, no extra HBM
+//     traffic.  That the masked entries of a column are bit-identical is verified with LDS atomics (OR / AND of the bit
+//     patterns) exactly as in suffstat_hc.hip.h; a column where they are not sends the gene to the fp64 kernel.
+//
+// Wave-parts: one workgroup owns steps_per_wpart 16-sample steps (a multiple of 16); an iteration is 16 steps (4 loader waves
+// x 4 steps = one int8 operand per wave and column tile).  The host cuts a gene into a quarter of the parts the one-wave
+// kernels use (the partial-statistics image written per part and read by gene_assemble shrinks accordingly).
+#pragma once
+#include "suffstat_hcw.hip.h"
+
+namespace rvt {
+
+constexpr int kHcxNW = 4;          // loader waves = slices per iteration = tile waves (a workgroup is 2 kHcxNW waves)
+constexpr int kHcxIterSteps = 16;  // steps per workgroup iteration (kHcxNW x 4)
+constexpr int kHcxMaxMT = 5;
+constexpr int kHcxNullCols = 16;   // the null tile is ONE 16-column operand: vX_0 .. vX_{d-1}, res, v, zeros
+
+// Null-model operands of the kernel (built by rvt_set_null):
+//   dq    digit planes of v in the order the tile waves read them: [group of 64 samples][q 4][pair 3][step 4] x 16 bytes =
+//         (d_2j, d_2j+1, 2 d_2j, 2 d_2j+1) of the four samples 64 g + 16 T + 4 q + 0..3 (one dword each, a byte per sample):
+//         768 bytes per slice, copied to LDS as they are
+//   xq    digit planes of the null tile in OPERAND order: [group of 64 samples][plane 0..5][lane 0..63][16 bytes], lane =
+//         column k + 16 q, byte 4 T + l = digit of sample 64 g + 16 T + 4 q + l — one 16-byte load per lane, plane and slice
+//   scale value of column k = integer x scale[k] (a power of two)
+struct NullTileX {
+  const unsigned char* dq;
+  const unsigned char* xq;
+  double scale[kHcxNullCols];
+  int ncols;  // d + 2 non-zero columns (vX_0 .. vX_{d-1}, res, v)
+};
+
+// ---- tile assignment of the tile waves (index w = wave - 4).  0-2: Gram tiles by A-operand row; 3: the tiles G'V[X | res | v]
+// of every row + the burden tile
+struct HcxAsg {
+  int nrows;
+  int arow[2];
+  int ncols[2];
+  int col[2][5];
+};
+constexpr HcxAsg hcx_asg(int MT, int w) {
+  switch (MT) {
+    case 1:
+      return w == 0 ? HcxAsg{1, {0, 0}, {1, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}} : HcxAsg{0, {0, 0}, {0, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+    case 2:
+      return w == 0   ? HcxAsg{1, {0, 0}, {2, 0}, {{0, 1, 0, 0, 0}, {0, 0, 0, 0, 0}}}
+             : w == 1 ? HcxAsg{1, {1, 0}, {1, 0}, {{1, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}}
+                      : HcxAsg{0, {0, 0}, {0, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+    case 3:
+      return w == 0   ? HcxAsg{1, {0, 0}, {3, 0}, {{0, 1, 2, 0, 0}, {0, 0, 0, 0, 0}}}
+             : w == 1 ? HcxAsg{1, {1, 0}, {2, 0}, {{1, 2, 0, 0, 0}, {0, 0, 0, 0, 0}}}
+             : w == 2 ? HcxAsg{1, {2, 0}, {1, 0}, {{2, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}}
+                      : HcxAsg{0, {0, 0}, {0, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+    case 4:
+      return w == 0   ? HcxAsg{1, {0, 0}, {4, 0}, {{0, 1, 2, 3, 0}, {0, 0, 0, 0, 0}}}
+             : w == 1 ? HcxAsg{1, {1, 0}, {3, 0}, {{1, 2, 3, 0, 0}, {0, 0, 0, 0, 0}}}
+             : w == 2 ? HcxAsg{2, {2, 3}, {2, 1}, {{2, 3, 0, 0, 0}, {3, 0, 0, 0, 0}}}
+                      : HcxAsg{0, {0, 0}, {0, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+    default:
+      return w == 0   ? HcxAsg{1, {0, 0}, {5, 0}, {{0, 1, 2, 3, 4}, {0, 0, 0, 0, 0}}}
+             : w == 1 ? HcxAsg{2, {1, 4}, {4, 1}, {{1, 2, 3, 4, 0}, {4, 0, 0, 0, 0}}}
+             : w == 2 ? HcxAsg{2, {2, 3}, {3, 2}, {{2, 3, 4, 0, 0}, {3, 4, 0, 0, 0}}}
+                      : HcxAsg{0, {0, 0}, {0, 0}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+  }
+}
+constexpr int hcx_ntiles(int MT, int w) {
+  if (w == 3) return MT + 1;
+  const HcxAsg a = hcx_asg(MT, w);
+  return (a.nrows > 0 ? a.ncols[0] : 0) + (a.nrows > 1 ? a.ncols[1] : 0);
+}
+constexpr int hcx_max_tiles(int MT) {
+  int m = 1;
+  for (int w = 0; w < kHcxNW; ++w) m = hcx_ntiles(MT, w) > m ? hcx_ntiles(MT, w) : m;
+  return m;
+}
+
+// ---- LDS of one workgroup (bytes) ------------------------------------------------------------------------------------
+//   2 buffers x 4 slices x (MT + 1) x 64 lanes x 16 B: the int8 operand of every column tile (4 steps x 4 samples per lane),
+//        then the burden operand (rows 0-3 = lanes v < 4: c_cmc, c_zeg, c_zeg^2 low 7 bits, c_zeg^2 >> 7 of the lane row's
+//        samples; the other lanes hold zero)
+//   per loader wave: mk: MT x 64 lanes x 4 B: bit 4 T + l = entry (step T, sample l) of the lane's column is masked (zero
+//        except between a masked entry and the end of its slice's treatment); the masked-entry list of hcx_masked_slice
+//   OR / AND words: MT x 64 x 4 B;  per column: masked-entry count, sum g, sum g^2: 3 x MT x 16 x 4 B;  4 words: flag (bit 0:
+//        a masked entry was met, bit 1: an entry with code 3 = -inf), number of samples with a non-zero collapsed genotype
+//   digit stage: 2 buffers x 4 slices x 768 B (NullTileX::dq as it is);  xq stage: 2 buffers x 4 slices x 6 planes x 64 lanes
+//        x 16 B — the weights' and the null tile's operands of an iteration, fetched by LDS-DMA (tile wave 3) one iteration
+//        ahead, right after the barrier behind which nobody reads the buffer any more
+constexpr int hcx_slice_bytes(int MT) { return (MT + 1) * 1024; }
+constexpr int hcx_buf_bytes(int MT) { return 2 * kHcxNW * hcx_slice_bytes(MT); }
+constexpr int hcx_mk_bytes(int MT) { return MT * 256; }
+constexpr int kHcxListCap = 48;  // entries per round: 12 bytes each (meta, V lo, V hi)
+constexpr int hcx_list_bytes() { return 16 + kHcxListCap * 12; }
+constexpr int hcx_wave_bytes(int MT) { return hcx_mk_bytes(MT) + hcx_list_bytes(); }
+constexpr int hcx_tail_bytes(int MT) { return MT * 256 + 3 * MT * 64 + 16; }
+constexpr int kHcxSliceDg = 768;
+constexpr int kHcxDgStage = 2 * kHcxNW * kHcxSliceDg;
+constexpr int kHcxPlaneStage = 1024;  // one plane of one slice
+constexpr int kHcxStageBuf = kHcxNW * kHcwPlanes * kHcxPlaneStage;  // the null tile's operands of one iteration
+constexpr int kHcxStageBytes = 2 * kHcxStageBuf;
+constexpr int hcx_off_wave(int MT) { return hcx_buf_bytes(MT); }
+constexpr int hcx_off_tail(int MT) { return hcx_off_wave(MT) + kHcxNW * hcx_wave_bytes(MT); }
+constexpr int hcx_off_dg(int MT) { return hcx_off_tail(MT) + hcx_tail_bytes(MT); }
+constexpr int hcx_off_stage(int MT) { return hcx_off_dg(MT) + kHcxDgStage; }
+constexpr int hcx_lds_bytes(int MT) { return hcx_off_stage(MT) + kHcxStageBytes; }
+
+// the masked-entry tables of a gene, 64-bit integers: P (Mp x Mp, row = the masked column; units 2^-42), Q (Mp x Mp, upper
+// triangle; units 2^-42), R (Mp x 16: sum of the null tile's fixed-point rows over the column's masked samples; column
+// k in units of NullTileX::scale[k])
+constexpr size_t hcx_pq_entries(int Mp) { return 2 * (size_t)Mp * Mp + (size_t)Mp * kHcxNullCols; }
+
+// one tile row of one step: hard-call test, packing (a masked entry packs as 0), byte sums of g and g^2, burden hits.
+// mk = 0x01 in the byte of every entry that is not exactly 0.0 / 1.0 / 2.0 (see hc_row, suffstat_hc.hip.h).
+template <bool MASKED>
+__device__ __forceinline__ void hcx_row(const u4_t& glo, const u4_t& ghi, unsigned& pk, unsigned& mk, unsigned& cs,
+                                        unsigned& cs2, unsigned fx, unsigned& h, bool valid) {
+  const unsigned w01 = __builtin_amdgcn_perm(glo[3], glo[1], 0x0c0c0703u);
+  const unsigned w23 = __builtin_amdgcn_perm(ghi[3], ghi[1], 0x07030c0cu);
+  unsigned p = ((w01 | w23) >> 5) & 0x03030303u;
+  constexpr unsigned kAdd = 0x00100000u, kBits = 0xBFEFFFFFu;
+  const unsigned i0 = ((glo[1] + kAdd) & kBits) | glo[0], i1 = ((glo[3] + kAdd) & kBits) | glo[2],
+                 i2 = ((ghi[1] + kAdd) & kBits) | ghi[0], i3 = ((ghi[3] + kAdd) & kBits) | ghi[2];
+  auto one = [](unsigned x) { return x < 1u ? x : 1u; };  // v_min_u32
+  unsigned m = one(i0) | (one(i1) << 8) | (one(i2) << 16) | (one(i3) << 24);
+  if (MASKED) {
+    p = valid ? p : 0u;
+    m = valid ? m : 0u;
+  }
+  const unsigned m3 = m * 3u;
+  p &= ~m3;
+  pk = p;
+  mk = m;
+  cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
+  cs2 = __builtin_amdgcn_sad_u8((p & 0x01010101u) | ((p & 0x02020202u) << 1), 0u, cs2);  // g^2: 0 / 1 / 4
+  const unsigned t = (p ^ fx) & ~m3;  // flipped column: (int)(2 - g) > 0  <=>  g != 2; a masked entry never counts here
+  h += (t | (t >> 1)) & 0x01010101u;  // (gene_flags_hc_kernel sends the gene to the fallback when its mu says it should)
+}
+
+// the rare path of one row-step — a lane that holds a masked entry: OR / AND of the bit patterns and the count of its column,
+// the entry's bit in the slice's mask word of this lane (all in LDS: nothing of it lives in registers)
+__device__ __forceinline__ void hcx_note(const u4_t& glo, const u4_t& ghi, unsigned m, int T, unsigned* mkw, unsigned* cmw,
+                                         unsigned* oa) {
+  hc_note_masked(glo, ghi, m, oa);
+  const unsigned nib = (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xfu;
+  __hip_atomic_fetch_or(mkw, nib << (4 * T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(cmw, (unsigned)__builtin_popcount(nib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The burden operand of one step from the per-sample variant counts (byte l of h = count of sample l of the lane row, the
+// same in its 16 lanes): lane v = 0: c_cmc = (n > 0), v = 1: c_zeg = n, v = 2 / 3: the low 7 bits / the rest of n^2 (n <= 80).
+__device__ __forceinline__ unsigned hcx_burden_bytes(unsigned h, int v, unsigned& cnt) {
+  const unsigned cc = ((h + 0x7f7f7f7fu) >> 7) & 0x01010101u;  // n > 0 (n < 128)
+  cnt += (unsigned)__builtin_popcount(cc);
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const unsigned n = (h >> (8 * l)) & 0xffu, n2 = n * n;
+    lo |= (n2 & 127u) << (8 * l);
+    hi |= (n2 >> 7) << (8 * l);
+  }
+  return v == 0 ? cc : (v == 1 ? h : (v == 2 ? lo : (v == 3 ? hi : 0u)));
+}
+
+// Masked entries of the slice this wave has just written to LDS: P_jk += V_i H_ik, Q_jk += V_i m_ik (k >= j), R_jk += X_ik for
+// every masked entry (sample i, column j).  The lanes that hold masked entries push them (column, lane row, step, sample,
+// the sample's weight V_i) onto a small list in the wave's own LDS scratch, then ALL lanes share the items (entry, null
+// column k | column k of the sample's row): the digits of the null tile's row from global memory resp. one LDS read of the
+// packed integer and of the mask word, and the integer atomics.  A list that is full is worked off and refilled (a slice
+// with many missing calls takes several rounds).  Clears the wave's mask words behind itself.
+// dgb: the digits of v of this slice (LDS digit stage); xq_slice: the null tile's digit planes of this slice (LDS stage).
+template <int MT>
+__device__ __noinline__ void hcx_masked_slice(const char* slice, const char* dgb, char* wscratch, int lane,
+                                              unsigned long long* pq, int Mp, const char* xq_slice, int ncols) {
+  const char* pkb = slice;
+  unsigned* mkb = reinterpret_cast<unsigned*>(wscratch);
+  unsigned* cntw = reinterpret_cast<unsigned*>(wscratch + hcx_mk_bytes(MT));
+  unsigned* list = cntw + 4;
+  const int v = lane & 15, q = lane >> 4;
+  unsigned word[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) word[c] = mkb[c * 64 + lane];
+  bool more = true;
+  while (more) {
+    if (lane == 0) cntw[0] = 0u;
+    asm volatile("" ::: "memory");
+    bool full = false;
+#pragma unroll
+    for (int c0 = 0; c0 < MT; ++c0) {
+      while (word[c0] && !full) {
+        const unsigned idx = __hip_atomic_fetch_add(cntw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (idx >= (unsigned)kHcxListCap) {
+          full = true;
+          break;
+        }
+        const int b = __builtin_ctz(word[c0]);
+        word[c0] &= word[c0] - 1;
+        const int T0 = b >> 2, l0 = b & 3;
+        // V = sum_p d_p 128^(5 - p): the sample's weight in units of 2^-42 (what the six digit planes encode)
+        long long V = 0;
+#pragma unroll
+        for (int jp = 0; jp < kHcwPairs; ++jp) {
+          const unsigned* w = reinterpret_cast<const unsigned*>(dgb + ((q * kHcwPairs + jp) * 4 + T0) * 16);
+          const int de = (int)(signed char)((w[0] >> (8 * l0)) & 0xffu), dod = (int)(signed char)((w[1] >> (8 * l0)) & 0xffu);
+          V = V * 16384 + (long long)(de * 128 + dod);
+        }
+        list[idx * 3 + 0] = (unsigned)(c0 * 16 + v) | ((unsigned)q << 8) | ((unsigned)b << 12);
+        list[idx * 3 + 1] = (unsigned)(unsigned long long)V;
+        list[idx * 3 + 2] = (unsigned)((unsigned long long)V >> 32);
+      }
+    }
+    asm volatile("" ::: "memory");
+    const unsigned pushed = cntw[0];
+    const int E = pushed < (unsigned)kHcxListCap ? (int)pushed : kHcxListCap;
+    // the null tile's rows of the entries' samples
+    for (int item = lane; item < E * ncols; item += 64) {
+      const int e = item / ncols, kk = item - e * ncols;
+      const unsigned meta = list[e * 3];
+      const int j = (int)(meta & 0xffu), q0 = (int)((meta >> 8) & 3u), b = (int)(meta >> 12);
+      const char* src = xq_slice + (kk + 16 * q0) * 16 + b;  // (byte 4 T0 + l0 = b)
+      int dgt[kHcwPlanes];
+#pragma unroll
+      for (int p = 0; p < kHcwPlanes; ++p) dgt[p] = (int)(signed char)src[p * 1024];
+      long long X = 0;
+#pragma unroll
+      for (int p = 0; p < kHcwPlanes; ++p) X = X * 128 + (long long)dgt[p];
+      __hip_atomic_fetch_add(pq + 2 * (size_t)Mp * Mp + (size_t)j * kHcxNullCols + kk, (unsigned long long)X, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    constexpr int NKC = MT * 16;
+    for (int item0 = lane; item0 < E * NKC; item0 += 128) {  // two items per lane and pass: their LDS reads overlap
+      int j[2], k[2], b[2];
+      unsigned hw[2], mw[2];
+      unsigned long long Vu[2];
+      bool on[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int item = item0 + 64 * x;
+        on[x] = item < E * NKC;
+        const int e = on[x] ? item / NKC : 0;
+        k[x] = item - e * NKC;
+        const unsigned meta = list[e * 3];
+        Vu[x] = ((unsigned long long)list[e * 3 + 2] << 32) | list[e * 3 + 1];
+        j[x] = (int)(meta & 0xffu);
+        b[x] = (int)(meta >> 12);
+        const int q0 = (int)((meta >> 8) & 3u);
+        const int slot = on[x] ? (k[x] >> 4) * 64 + (k[x] & 15) + 16 * q0 : 0;
+        hw[x] = *reinterpret_cast<const unsigned*>(pkb + slot * 16 + (b[x] >> 2) * 4);
+        mw[x] = mkb[slot];
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const unsigned hval = (hw[x] >> (8 * (b[x] & 3))) & 3u;
+        if (on[x] && hval)
+          __hip_atomic_fetch_add(pq + (size_t)j[x] * Mp + k[x], Vu[x] * hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (on[x] && ((mw[x] >> b[x]) & 1u) && k[x] >= j[x])
+          __hip_atomic_fetch_add(pq + (size_t)Mp * Mp + (size_t)j[x] * Mp + k[x], Vu[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    bool rest = false;
+#pragma unroll
+    for (int c = 0; c < MT; ++c) rest |= word[c] != 0u;
+    more = __builtin_amdgcn_ballot_w64(rest) != 0ull;
+  }
+#pragma unroll
+  for (int c = 0; c < MT; ++c) mkb[c * 64 + lane] = 0u;
+}
+
+// two digit planes of one tile and one 64-sample operand: acc = 128 (A0'B0) + A1'B1 + acc, exactly, in int32
+__device__ __forceinline__ void hcx_pair_step(i4_t& acc, const i4_t& a0, const i4_t& b0, const i4_t& a1, const i4_t& b1) {
+  const i4_t z = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, i4_t{0, 0, 0, 0}, 0, 0, 0);
+  i4_t a = acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = (int)(((unsigned)z[i] << 7) + (unsigned)a[i]);
+  acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, a, 0, 0, 0);
+}
+__device__ __forceinline__ i4_t hcx_op(const u4_t& x) { return i4_t{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}; }
+
+// Gram tiles of wave W (0-2) over the kHcxNW slices of one buffer
+template <int MT, int W, int NT>
+__device__ __forceinline__ void hcx_gram(i4_t (&acc)[kHcwPairs][NT], const char* buf, const char* dgbuf, int lane) {
+  constexpr HcxAsg A = hcx_asg(MT, W);
+  const int q = lane >> 4;
+#pragma unroll 1
+  for (int s = 0; s < kHcxNW; ++s) {
+    const char* slice = buf + s * hcx_slice_bytes(MT);
+    const u4_t* pk = reinterpret_cast<const u4_t*>(slice) + lane;
+    const u4_t* dg = reinterpret_cast<const u4_t*>(dgbuf + s * kHcxSliceDg) + q * (kHcwPairs * 4);
+    int t = 0;
+#pragma unroll
+    for (int ri = 0; ri < A.nrows; ++ri) {
+      const u4_t pr = pk[A.arow[ri] * 64];
+      const unsigned pkr[4] = {pr[0], pr[1], pr[2], pr[3]};
+      const HcwRow<MT> row(pkr);
+#pragma unroll
+      for (int j = 0; j < kHcwPairs; ++j) {
+        i4_t a0, a1;
+        {
+          const u4_t d0 = dg[j * 4 + 0], d1 = dg[j * 4 + 1], d2 = dg[j * 4 + 2], d3 = dg[j * 4 + 3];
+          a0 = i4_t{(int)__builtin_amdgcn_perm(d0[2], d0[0], row.sel[0]), (int)__builtin_amdgcn_perm(d1[2], d1[0], row.sel[1]),
+                    (int)__builtin_amdgcn_perm(d2[2], d2[0], row.sel[2]), (int)__builtin_amdgcn_perm(d3[2], d3[0], row.sel[3])};
+          a1 = i4_t{(int)__builtin_amdgcn_perm(d0[3], d0[1], row.sel[0]), (int)__builtin_amdgcn_perm(d1[3], d1[1], row.sel[1]),
+                    (int)__builtin_amdgcn_perm(d2[3], d2[1], row.sel[2]), (int)__builtin_amdgcn_perm(d3[3], d3[1], row.sel[3])};
+        }
+#pragma unroll
+        for (int ci = 0; ci < A.ncols[ri]; ++ci) {
+          const i4_t b = hcx_op(pk[A.col[ri][ci] * 64]);
+          hcx_pair_step(acc[j][t + ci], a0, b, a1, b);
+        }
+      }
+      t += A.ncols[ri];
+    }
+  }
+}
+
+// Tile wave 3: the tiles H_r'V[X | res | v] of every row tile r (A = the packed integers as they are, B = digit plane p of the
+// null tile, from the LDS stage) and the burden tile (A = the burden operand, tile index MT).
+template <int MT, int NT>
+__device__ __forceinline__ void hcx_null_tiles(i4_t (&acc)[kHcwPairs][NT], const char* buf, int lane, const char* stage) {
+#pragma unroll 1
+  for (int s = 0; s < kHcxNW; ++s) {
+    const char* slice = buf + s * hcx_slice_bytes(MT);
+    const u4_t* pk = reinterpret_cast<const u4_t*>(slice) + lane;
+    const u4_t* st = reinterpret_cast<const u4_t*>(stage + s * (kHcwPlanes * kHcxPlaneStage)) + lane;
+#pragma unroll
+    for (int j = 0; j < kHcwPairs; ++j) {
+      const i4_t b0 = hcx_op(st[(2 * j) * 64]), b1 = hcx_op(st[(2 * j + 1) * 64]);
+#pragma unroll
+      for (int r = 0; r <= MT; ++r) {
+        const i4_t a = hcx_op(pk[r * 64]);
+        hcx_pair_step(acc[j][r], a, b0, a, b1);
+      }
+    }
+  }
+}
+
+// Tile wave 3: fetch the digits of v of the iteration that starts at 64-sample group g0 into a digit stage buffer (768 bytes per
+// slice = 48 lanes x 16 bytes, as they lie in NullTileX::dq)
+__device__ __forceinline__ void hcx_stage_dq(char* dgbuf, const unsigned char* dq, long long g0, long long n_groups, int lane) {
+  if (lane < kHcxSliceDg / 16) {
+#pragma unroll
+    for (int s = 0; s < kHcxNW; ++s) {
+      long long g = g0 + s;
+      g = g < n_groups ? g : n_groups - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dq + g * kHcxSliceDg + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dgbuf + s * kHcxSliceDg), 16, 0, 0);
+    }
+  }
+}
+
+// Tile wave 3: fetch the null tile's operands of the iteration that starts at 64-sample group g0 into the LDS stage (LDS-DMA: no
+// registers, 16 bytes per lane, plane and slice, written lane-linear = operand order).  Groups beyond the image are
+// clamped (their genotype operands are zero).
+__device__ __forceinline__ void hcx_stage_xq(char* stage, const unsigned char* xq, long long g0, long long n_groups, int lane) {
+#pragma unroll
+  for (int s = 0; s < kHcxNW; ++s) {
+    long long g = g0 + s;
+    g = g < n_groups ? g : n_groups - 1;
+    const unsigned char* src = xq + g * (kHcwPlanes * 1024) + lane * 16;
+#pragma unroll
+    for (int p = 0; p < kHcwPlanes; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                       (__attribute__((address_space(3))) void*)(stage + (s * kHcwPlanes + p) * kHcxPlaneStage), 16, 0, 0);
+  }
+}
+
+// pair tiles -> the integer they encode, as a double (one rounding when it exceeds 2^53): p0 2^28 + p1 2^14 + p2
+__device__ __forceinline__ double hcx_pairs_value(int p0, int p1, int p2) {
+  const long long x = ((long long)p0 << 28) + ((long long)p1 << 14) + (long long)p2;
+  return (double)x;
+}
+
+// ring depth of a loader wave per tile class: steps in flight (1, 2 or 4)
+constexpr int hcx_ring(int MT) { return MT <= 3 ? 4 : 2; }
+
+template <int MT>
+__device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const NullTileX& nt, long long N, long long ld, int d,
+                                                  char* lds) {
+  constexpr int NT = hcx_max_tiles(MT);
+  constexpr int RING = hcx_ring(MT);
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;  // 0-3: loader waves (slice w of every iteration), 4-7: tile waves
+  const int v = lane & 15, q = lane >> 4;
+  const int wpart = blockIdx.x;
+  if (wpart >= gd.n_wparts) return;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  if (s_begin >= s_end) return;  // (uniform over the workgroup)
+  const int M = gd.M;
+  unsigned* const oa_all = reinterpret_cast<unsigned*>(lds + hcx_off_tail(MT));
+  unsigned* const cm_all = oa_all + MT * 64;     // masked count, then sum g, then sum g^2: [3][MT * 16]
+  unsigned* const flagw = cm_all + 3 * MT * 16;  // [0] flags, [1] samples with a non-zero collapsed genotype
+  char* const stage = lds + hcx_off_stage(MT);
+  char* const dgstage = lds + hcx_off_dg(MT);
+  // OR words = 0, AND words = ~0, counts = 0, flags = 0; the loaders' mask words and the burden operand of every slice = 0
+  for (int x = threadIdx.x; x < MT * 64; x += 2 * kHcxNW * 64) oa_all[x] = (x & 2) ? 0xffffffffu : 0u;
+  for (int x = threadIdx.x; x < 3 * MT * 16 + 4; x += 2 * kHcxNW * 64) cm_all[x] = 0u;
+  for (int x = threadIdx.x; x < kHcxNW * MT * 64; x += 2 * kHcxNW * 64)
+    reinterpret_cast<unsigned*>(lds + hcx_off_wave(MT) + (x / (MT * 64)) * hcx_wave_bytes(MT))[x % (MT * 64)] = 0u;
+  for (int x = threadIdx.x; x < 2 * kHcxNW * 256; x += 2 * kHcxNW * 64)
+    reinterpret_cast<unsigned*>(lds + (x / 256) * hcx_slice_bytes(MT) + MT * 1024)[x % 256] = 0u;
+  __syncthreads();
+
+  const long long full = N >> 4;  // steps whose 16 samples all exist
+  const long long s_fast_end = (s_end < full) ? s_end : full;
+  const long long n_fast = (s_fast_end > s_begin) ? (s_fast_end - s_begin) / kHcxIterSteps : 0;
+  const long long n_iter = (s_end - s_begin + kHcxIterSteps - 1) / kHcxIterSteps;
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+  const int Cp = gd.Cp;
+
+  if (w >= kHcxNW) {
+    // ================================================ tile waves ================================================
+    const int tw = w - kHcxNW;
+    i4_t acc[kHcwPairs][NT];
+#pragma unroll
+    for (int j = 0; j < kHcwPairs; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[j][t] = i4_t{0, 0, 0, 0};
+    const long long n_groups = (ld + 63) / 64;
+    if (tw == 3) {
+      hcx_stage_dq(dgstage, nt.dq, s_begin >> 2, n_groups, lane);
+      hcx_stage_xq(stage, nt.xq, s_begin >> 2, n_groups, lane);
+    }
+    for (long long it = 0; it < n_iter; ++it) {
+      const char* buf = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT));
+      const char* dgbuf = dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg);
+      if (tw == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages of this iteration have arrived
+      __syncthreads();                                                // ... and so have the loaders' operands
+      const long long g_next = (s_begin + (it + 1) * kHcxIterSteps) >> 2;
+      switch (tw) {
+        case 0: hcx_gram<MT, 0, NT>(acc, buf, dgbuf, lane); break;
+        case 1: hcx_gram<MT, 1, NT>(acc, buf, dgbuf, lane); break;
+        case 2: hcx_gram<MT, 2, NT>(acc, buf, dgbuf, lane); break;
+        default:
+          // (the other stage buffers were last read before this barrier: refill them now, for the next iteration)
+          hcx_stage_dq(dgstage + (int)((it + 1) & 1) * (kHcxNW * kHcxSliceDg), nt.dq, g_next, n_groups, lane);
+#ifndef HCX_XQ_EARLY
+          hcx_null_tiles<MT, NT>(acc, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
+          hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
+#else
+          hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
+          hcx_null_tiles<MT, NT>(acc, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
+#endif
+          break;
+      }
+    }
+    if (tw == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA may land after the workgroup has left)
+    // ---- partial tiles: element (row, col) -> parts[row * Cp + col], the layout gene_assemble reduces -------------
+    auto store_gram = [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
+      constexpr HcxAsg A = hcx_asg(MT, W);
+      int t = 0;
+#pragma unroll
+      for (int ri = 0; ri < A.nrows; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < A.ncols[ri]; ++ci, ++t) {
+          const int r = A.arow[ri], c = A.col[ri][ci];
+          const int col = c * 16 + v;
+          if (col < M) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              out[(long long)(r * 16 + q * 4 + i) * Cp + col] = hcx_pairs_value(acc[0][t][i], acc[1][t][i], acc[2][t][i]) * 0x1p-42;
+          }
+        }
+    };
+    if (tw == 0) store_gram(std::integral_constant<int, 0>{});
+    if (tw == 1) store_gram(std::integral_constant<int, 1>{});
+    if (tw == 2) store_gram(std::integral_constant<int, 2>{});
+    __syncthreads();  // (the loaders' counts are in LDS)
+    if (tw == 3) {
+      // G'V[X | res] columns of the partial matrix (i32 C/D map: lane (v, q), element i = row 4 q + i, column v)
+      const double sc = nt.scale[v];
+#pragma unroll
+      for (int r = 0; r < MT; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = r * 16 + q * 4 + i;
+          const double x = hcx_pairs_value(acc[0][r][i], acc[1][r][i], acc[2][r][i]) * sc;
+          if (M + v < Cp) out[(long long)row * Cp + M + v] = (v <= d) ? x : 0.0;  // (the v column is not part of R)
+          if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
+        }
+      }
+      // ---- burden partial sums: [test][U, c'Vc, count, c'VX_0 .. c'VX_{d-1}], test 0 = CMC, 1 = Zeggini.  The burden tile's
+      // rows 0-3 (lanes q = 0, elements 0-3): c_cmc, c_zeg, low / high part of c_zeg^2 against the null column v
+      if (gd.bparts && lane < 16) {
+        const double ac = hcx_pairs_value(acc[0][MT][0], acc[1][MT][0], acc[2][MT][0]) * sc;
+        const double az = hcx_pairs_value(acc[0][MT][1], acc[1][MT][1], acc[2][MT][1]) * sc;
+        const double azz = (hcx_pairs_value(acc[0][MT][2], acc[1][MT][2], acc[2][MT][2]) +
+                            128.0 * hcx_pairs_value(acc[0][MT][3], acc[1][MT][3], acc[2][MT][3])) * sc;
+        const double cn = (double)flagw[1];
+        const int rl = 3 + d;
+        double* bp = gd.bparts + (long long)wpart * 2 * rl;
+        if (lane <= d) {  // lane k < d: column v X_k; lane d: res
+          const int k = (lane == d) ? 0 : 3 + lane;
+          bp[k] = ac;
+          bp[rl + k] = az;
+        }
+        if (lane == d + 1) {  // the v column: c'Vc (CMC: c^2 = c)
+          bp[1] = ac;
+          bp[rl + 1] = azz;
+        }
+        if (lane == 0) {
+          bp[2] = cn;
+          bp[rl + 2] = cn;
+        }
+      }
+    }
+    if (tw == 0) {
+      // ---- column statistics (six rows as suffstat_hc.hip.h writes them) --------------------------------------------
+      long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
+      if (cnt_w < 0) cnt_w = 0;
+      double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
+      for (int j = lane; j < MT * 16; j += 64) {
+        const int c = j >> 4, l = j & 15;
+        const long long nm = cm_all[j], sm = cm_all[MT * 16 + j], sq = cm_all[2 * MT * 16 + j];
+        const long long n2 = (sq - sm) / 2, n1 = 2 * sm - sq, n0 = cnt_w - n1 - n2 - nm;
+        const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+        const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+        cst[j] = (double)sm;
+        cst[gd.Mp + j] = mn;
+        cst[2 * gd.Mp + j] = mx;
+        cst[3 * gd.Mp + j] = (double)nm;
+        const unsigned* ow = oa_all + 64 * c + 4 * l;
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(cst);
+        bits[4 * gd.Mp + j] = ((unsigned long long)ow[1] << 32) | ow[0];
+        bits[5 * gd.Mp + j] = ((unsigned long long)ow[3] << 32) | ow[2];
+      }
+      if (gd.wflags && lane == 0) gd.wflags[wpart] = flagw[0] & 3u;
+    }
+    return;
+  }
+
+  // ================================================== loader waves ==================================================
+  char* const wscratch = lds + hcx_off_wave(MT) + w * hcx_wave_bytes(MT);  // this wave's mask words, then its entry list
+  unsigned* const oa = oa_all + 4 * v;  // this lane's column of row tile c: oa + 64 c
+  unsigned* const cmw = cm_all + v;     //                                     cmw + 16 c
+  unsigned* const mkw = reinterpret_cast<unsigned*>(wscratch) + lane;
+
+  auto uniform = [](const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const unsigned gbytes = (unsigned)((unsigned long long)M * (unsigned long long)ld * 8ull);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(uniform(gd.G), 0, gbytes, 0x00020000);
+  const unsigned lane_off = (unsigned)(q * 32);
+  const unsigned col_bytes = (unsigned)((unsigned long long)ld * 8ull);
+  // Column tile c of the lane: byte offset (c 16 + v) col_bytes + lane_off.  The tiles 0 .. MT - 2 are full (every column
+  // exists), so ONE per-lane offset serves them, with the tile's 16 col_bytes as the instruction's scalar offset; the last
+  // tile has its own offset, beyond num_records for a pad column (reads zeros).
+  const unsigned vfull = (unsigned)v * col_bytes + lane_off;
+  const unsigned vlast = ((MT - 1) * 16 + v < M) ? (unsigned)((MT - 1) * 16 + v) * col_bytes + lane_off : 0x80000000u;
+  const unsigned tile_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(16u * col_bytes));
+  auto gload = [&](int c, unsigned off_full, unsigned off_last, int imm) {
+    return (c == MT - 1) ? __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, off_last + imm, 0, 0))
+                         : __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, off_full + imm, c * tile_bytes, 0));
+  };
+  int fxb = 0;  // bit c: the lane's column of tile c is predicted flipped
+#pragma unroll
+  for (int c = 0; c < MT; ++c) fxb |= (int)((gd.pflip[c] >> v) & 1) << c;
+  auto fxof = [&](int c) { return (unsigned)__builtin_amdgcn_sbfe(fxb, c, 1) & 0x02020202u; };
+
+  unsigned cs[MT], cs2[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) cs[c] = cs2[c] = 0u;
+  unsigned code3 = 0u, anym = 0u, cnt = 0u;
+
+  // The masked entries of a slice -> P / Q / R (rare), AFTER the iteration's barrier: the slice's operands stay valid until
+  // the loaders refill the buffer two iterations later, the digits of v of the iteration are in the digit stage from that
+  // barrier on (and so are the null tile's planes), and the tile waves multiply meanwhile.
+  auto masked_entries = [&](const char* slice, const char* dgslice, const char* xqslice) {
+    if (__builtin_amdgcn_ballot_w64(anym != 0u) != 0ull) {
+      asm volatile("" ::: "memory");
+      if (gd.pqw)
+        hcx_masked_slice<MT>(slice, dgslice, wscratch, lane, gd.pqw, gd.Mp, xqslice, nt.ncols);
+      else
+        for (int x = lane; x < MT * 64; x += 64) reinterpret_cast<unsigned*>(wscratch)[x] = 0u;
+      if (lane == 0) __hip_atomic_fetch_or(flagw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      anym = 0u;
+    }
+  };
+
+  long long it = 0;
+  if (n_fast > 0) {
+    // Rolling refill: a ring of RING genotype step buffers; as soon as a tile row of a step has been consumed its registers
+    // are the destination of the same row of the wave's step RING steps ahead (across the iteration boundary).
+    unsigned offF = vfull + (unsigned)((s_begin + 4 * w) * 128), offL = vlast + (unsigned)((s_begin + 4 * w) * 128);
+    u4_t glo[RING][MT], ghi[RING][MT];
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+#pragma unroll
+      for (int c = 0; c < MT; ++c) {
+        glo[r][c] = gload(c, offF, offL, r * 128);
+        ghi[r][c] = gload(c, offF, offL, r * 128 + 16);
+      }
+    for (; it < n_fast; ++it) {
+      char* slice = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT)) + w * hcx_slice_bytes(MT);
+      unsigned* pkw = reinterpret_cast<unsigned*>(slice) + lane * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rb = u % RING;  // this step's ring buffer
+        const int nxt = (u + RING < 4) ? (u + RING) * 128 : kHcxIterSteps * 128 + (u + RING - 4) * 128;  // RING steps ahead
+        unsigned h = 0;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+          unsigned m, p;
+          hcx_row<false>(glo[rb][c], ghi[rb][c], p, m, cs[c], cs2[c], fxof(c), h, true);
+          if (m) hcx_note(glo[rb][c], ghi[rb][c], m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c);
+          anym |= m;
+          code3 |= hc_code3(p);
+          pkw[c * 256 + u] = p;
+          glo[rb][c] = gload(c, offF, offL, nxt);
+          ghi[rb][c] = gload(c, offF, offL, nxt + 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        h = row16_sum(h);
+        const unsigned bb = hcx_burden_bytes(h, v, cnt);
+        if (v < 4) pkw[MT * 256 + u] = bb;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      masked_entries(slice, dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg) + w * kHcxSliceDg,
+                     stage + (int)(it & 1) * kHcxStageBuf + w * (kHcwPlanes * kHcxPlaneStage));
+      offF += kHcxIterSteps * 128;
+      offL += kHcxIterSteps * 128;
+    }
+  }
+  for (; it < n_iter; ++it) {  // ragged end: every step loaded from a clamped position and masked
+    const long long s0 = s_begin + it * kHcxIterSteps + 4 * w;
+    char* slice = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT)) + w * hcx_slice_bytes(MT);
+    unsigned* pkw = reinterpret_cast<unsigned*>(slice) + lane * 4;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+      const long long su = s0 + u;
+      const bool valid = su < s_end;
+      const long long sc = valid ? su : s_end - 1;
+      const unsigned so = (unsigned)(sc * 128);
+      unsigned vmask = 0u;
+      const long long smp = sc * 16 + q * 4;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) vmask |= (valid && smp + l < N) ? (0xffu << (8 * l)) : 0u;
+      unsigned h = 0;
+#pragma unroll
+      for (int c = 0; c < MT; ++c) {
+        const u4_t glo = gload(c, vfull + so, vlast + so, 0), ghi = gload(c, vfull + so, vlast + so, 16);
+        unsigned m, p;
+        hcx_row<true>(glo, ghi, p, m, cs[c], cs2[c], fxof(c), h, valid);
+        if (m) hcx_note(glo, ghi, m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c);
+        anym |= m;
+        code3 |= hc_code3(p);
+        pkw[c * 256 + u] = p;
+      }
+      h = row16_sum(h) & vmask;
+      const unsigned bb = hcx_burden_bytes(h, v, cnt);
+      if (v < 4) pkw[MT * 256 + u] = bb;
+    }
+    __syncthreads();
+    masked_entries(slice, dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg) + w * kHcxSliceDg,
+                   stage + (int)(it & 1) * kHcxStageBuf + w * (kHcwPlanes * kHcxPlaneStage));
+  }
+  // ---- byte sums, counts and flags of the loader waves meet in LDS (integers: any order) ---------------------------------
+#pragma unroll
+  for (int c = 0; c < MT; ++c) {
+    unsigned sc = cs[c], sq = cs2[c];
+    sc += __shfl_xor(sc, 16, 64);
+    sq += __shfl_xor(sq, 16, 64);
+    sc += __shfl_xor(sc, 32, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16) {
+      __hip_atomic_fetch_add(cm_all + (1 * MT + c) * 16 + lane, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(cm_all + (2 * MT + c) * 16 + lane, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  {
+    // (every lane of a 16-lane row counted the row's samples: lane 0 of each row speaks for it)
+    unsigned cn = (v == 0) ? cnt : 0u;
+    cn += __shfl_xor(cn, 16, 64);
+    cn += __shfl_xor(cn, 32, 64);
+    const bool c3 = __builtin_amdgcn_ballot_w64(code3 != 0u) != 0ull;
+    if (lane == 0) {
+      __hip_atomic_fetch_add(flagw + 1, cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (c3) __hip_atomic_fetch_or(flagw, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();  // (pairs with the tile waves' barrier before they read the counts)
+}
+
+template <int MT>
+__global__ __launch_bounds__(2 * kHcxNW * 64, 2) void gene_suffstat_hcx(const GeneDesc* __restrict__ genes, NullTileX nt,
+                                                                         long long N, long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  if (gd.MT != MT) return;
+  __shared__ __attribute__((aligned(16))) char lds[hcx_lds_bytes(MT)];
+  suffstat_hcx_body<MT>(gd, nt, N, ld, d, lds);
+}
+
+}  // namespace rvt

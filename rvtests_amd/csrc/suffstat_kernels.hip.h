@@ -56,6 +56,8 @@ struct GeneDesc {
                             // pk_pitch bytes apart
   double lat_den;           // hc == 2: the lattice denominator — the G'G tiles and column sums of `parts` / `colstat` are
                             // the INTEGERS K'K and sum K (exact through the reduction), divided once in gene_assemble
+  unsigned long long* pqw;  // weighted hard-call path (suffstat_hcx.hip.h): the gene's masked-entry tables P = H'Vm (Mp x Mp) and
+                            // Q = m'Vm (Mp x Mp, upper triangle) as 64-bit integers in units of 2^-42, zeroed by the host
 };
 
 struct NullDev {

@@ -8,7 +8,9 @@
 // fp64 kernel (suffstat_kernels.hip.h) is bound by the fp64 matrix pipe at 0.45 of the HBM rate for these blocks, and no
 // scheduling changes that (16 instructions of 64 cycles per tile and 64 samples):
 //   * every loaded double g is mapped to K = rint(g den) with the magic-number addition t = fma(g, den, 1.5 2^52) — the
-//     low dword of t IS K — and TESTED: |g den - K| <= 2^-30 (one more fma gives the exact residual) and 0 <= g < 2 + 2^-19
+//     low dword of t IS K — and TESTED: |g den - K| <= K 2^-53 (one more fma gives the exact residual; the double nearest
+//     to K / den is K / den (1 + delta) with |delta| <= 2^-53, so exactly the doubles strtod makes of the printed field
+//     pass — a value a few ulps beside a lattice point does not, and 0 only as 0.0) and 0 <= g < 2 + 2^-19
 //     (high dword <= 0x40000000; catches negative values, NaN and infinities).  A block that fails (arbitrary doubles:
 //     BGEN's float probabilities, mean-imputed entries) is handed back to the fp64 kernel by gene_flags_hc_kernel, like
 //     a dosage block that was sent to the hard-call kernel;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void lat_row(u4_t glo, u4_t ghi, const double (&xv)[4
     const double t = __builtin_fma(g, den, kMagic);
     const double r = t - kMagic;
     const double e = __builtin_fma(g, den, -r);
-    emax = __builtin_fmax(emax, __builtin_fabs(e));
+    emax = __builtin_fmax(emax, __builtin_fma(r, -0x1p-53, __builtin_fabs(e)));  // |g den - K| - K 2^-53: must stay <= 0
     K[l] = (unsigned)__builtin_bit_cast(unsigned long long, t);
     sh[l] = (unsigned)(((((unsigned long long)hi[l]) << 32 | lo[l]) + fl.C) >> 32);
   }
@@ -390,7 +392,7 @@ __device__ __forceinline__ void suffstat_lat_body(const GeneDesc& gd, const Null
   }
   // ---- the wave-part's flag: bit 1 = a value off the lattice (or outside [0, 2]): the gene goes to the fp64 kernel ----
   {
-    const bool bad = !(S.emax <= 0x1p-30) || S.hmax > 0x40000000u;
+    const bool bad = !(S.emax <= 0.0) || S.hmax > 0x40000000u;
     const bool any = __builtin_amdgcn_ballot_w64(bad) != 0ull;
     if (gd.wflags && lane == 0) gd.wflags[wpart] = any ? 2u : 0u;
   }

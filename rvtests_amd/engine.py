@@ -713,8 +713,8 @@ class Engine:
         return S, T, u, cs, mn, mx
 
     def set_perm_exact(self, on):
-        """True: SKAT permutations replay the reference's rand() stream (bit-identical counters, sequential); False (the
-        default): counter-based permutations keyed by (seed, gene id, shuffle) — rvt_set_perm_exact."""
+        """True (the default of a single context): SKAT permutations replay the reference's rand() stream (bit-identical
+        counters, sequential); False: counter-based permutations keyed by (seed, gene id, shuffle) — rvt_set_perm_exact."""
         self.L.rvt_set_perm_exact.restype = C.c_int
         self.L.rvt_set_perm_exact.argtypes = [C.c_void_p, C.c_int]
         self._check(self.L.rvt_set_perm_exact(self.ctx, 1 if on else 0))

@@ -117,11 +117,12 @@ def test_integer_part_is_exact(engine, N, den):
 
 def test_blocks_off_the_lattice_are_handed_back(engine):
     """Mean-imputed entries, another number of decimals, arbitrary doubles, values outside [0, 2], the neighbour doubles
-    of a lattice point: each such gene is computed by the fp64 kernel in the same call — the records of the confined
-    run — except the neighbours, which pass (2^-30 in units of 1 / den) with the same records up to rounding."""
+    of a lattice point (1 + 2^-52 and 1 - 2^-53 are not the doubles nearest to 1000 / 1000 — the test is |g den - K| <=
+    K 2^-53 — except that 1 - 2^-53 sits exactly AT the bound): each such gene is computed by the fp64 kernel in the same
+    call — the records of the confined run; gene 6, with lower neighbours only, stays on the lattice kernel."""
     N, d, den = 6000, 2, 1000
     rng = np.random.default_rng(11)
-    base = [_gene(_dosage_K(N, M, seed=100 + M, den=den, common_col=2), den) for M in (12, 30, 50, 70, 20, 44)]
+    base = [_gene(_dosage_K(N, M, seed=100 + M, den=den, common_col=2), den) for M in (12, 30, 50, 70, 20, 44, 44)]
     genes = [(G.copy(order="F"), af.copy()) for G, af in base]
     G = genes[0][0]
     miss = rng.random(N) < 0.02
@@ -133,26 +134,29 @@ def test_blocks_off_the_lattice_are_handed_back(engine):
     G5 = genes[5][0]
     G5[G5[:, 7] == 1.0, 7] = np.nextafter(1.0, 0.0)              # (int)g = 0 where the lattice point says 1
     G5[G5[:, 2] == 1.0, 2] = np.nextafter(1.0, 2.0)              # column 2 is flipped: (int)(2 - g) = 0
+    G6 = genes[6][0]
+    G6[G6[:, 7] == 1.0, 7] = np.nextafter(1.0, 0.0)              # at the bound: passes, counted as (int)g = 0
     genes = [(g, g.sum(0) / (2.0 * N)) for g, _ in genes]
     X, y, res, v, s2 = synth.make_null(N, d, 0, seed=9, G_effect=0.3 * base[4][0][:, :4].sum(1))
     engine.set_null(0, X, res, v, s2)
     lat, tm = _run(engine, genes, "lat", den)
     gen, _ = _run(engine, genes, "gen")
-    assert tm.genes_hard_call == 6 and tm.genes_handed_back == 4
+    assert tm.genes_hard_call == 7 and tm.genes_handed_back == 5
     for k, (a, b) in enumerate(zip(lat, gen)):
         assert a.status == b.status and a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
-            if k < 4 and not f.startswith(("cmc", "zeg")):
+            if k in (0, 1, 2, 3, 5) and not f.startswith(("cmc", "zeg")):
                 assert x == y_, (k, f)                           # the same kernel computed it
             elif k == 2 and f.startswith("cmc"):
                 continue       # every sample counts: the CMC genotype is the constant 1, U = sum of the residuals = rounding
             else:
                 assert abs(x - y_) <= 1e-10 * abs(y_) + 1e-300, (k, f, x, y_)
-    rc, c = orc.burden(genes[5][0], X, y, 0, 0)
-    assert lat[5].cmc_nonref == c.nonref_site
-    rc, z = orc.burden(genes[5][0], X, y, 0, 1)
-    assert abs(lat[5].zeg_stat - z.stat) <= 1e-9 * z.stat
+    for k in (5, 6):
+        rc, c = orc.burden(genes[k][0], X, y, 0, 0)
+        assert lat[k].cmc_nonref == c.nonref_site
+        rc, z = orc.burden(genes[k][0], X, y, 0, 1)
+        assert abs(lat[k].zeg_stat - z.stat) <= 1e-9 * z.stat
 
 
 def test_burden_collapse_on_dosages(engine):

@@ -28,9 +28,13 @@ def test_glibc_stream_matches_libc():
     assert [libc.rand() for _ in range(2000)] == [orc.lib().orc_rand() for _ in range(2000)]
 
 
-@pytest.mark.parametrize("N,n_perm,alpha", [(331, 300, 0.05), (1000, 120, 0.2)])
-def test_permutation_counts_match_oracle(eng, N, n_perm, alpha):
+@pytest.mark.parametrize("N,n_perm,alpha,explicit", [(331, 300, 0.05, True), (1000, 120, 0.2, True), (331, 300, 0.05, False)])
+def test_permutation_counts_match_oracle(eng, N, n_perm, alpha, explicit):
+    """explicit = False: NO mode is selected — a fresh single context must reproduce the reference's counters by DEFAULT
+    (the counter-based mode is for genes dealt over several devices, or on request)."""
     import rvtests_amd
+    if not explicit:
+        eng = rvtests_amd.Engine(0)     # a context nobody has configured
     d = 2
     genes = [synth.make_gene(N, M, seed=500 + M, missing=0.01, common=True, mono=True)[1:] for M in (8, 1, 21, 5)]
     genes.insert(2, (np.zeros((N, 3)), np.zeros(3)))       # no polymorphic column: no permutations, no draws
@@ -38,8 +42,9 @@ def test_permutation_counts_match_oracle(eng, N, n_perm, alpha):
     eng.set_null(0, X, res, v, s2)
     prm = rvtests_amd.Params(1.0, 25.0, 1.0, 25.0, n_perm, alpha)
     ptrs = [eng.upload_block(G) for G, af in genes]
-    eng.set_perm_exact(True)
-    eng.rand_seed(1)
+    if explicit:
+        eng.set_perm_exact(True)
+        eng.rand_seed(1)
     out = eng.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes],
                          tests=rvtests_amd.TEST_SKAT, params=prm)
     orc.rand_seed(1)

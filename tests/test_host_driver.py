@@ -35,10 +35,11 @@ def write_input(path, y, cov, binary, genes):
             f.write(np.asfortranarray(G, dtype="<f8").tobytes(order="F"))
 
 
-def run_driver(path, kernel, burden, batch=None, perm_exact=False):
+def run_driver(path, kernel, burden, batch=None, perm_exact=None):
     env = dict(os.environ)
-    if perm_exact:
-        env["RVT_PERM_EXACT"] = "1"                # replay the reference's rand() stream (bit-identical counters)
+    env.pop("RVT_PERM_EXACT", None)                # default of the drop-in: replay the reference's rand() stream
+    if perm_exact is not None:
+        env["RVT_PERM_EXACT"] = "1" if perm_exact else "0"
     if batch:
         env["RVT_ADAPTER_BATCH"] = str(batch)      # genes the adapters keep in flight before collecting
     p = subprocess.run([DRIVER, path, kernel, burden], capture_output=True, text=True, timeout=300, env=env)
@@ -282,7 +283,7 @@ def test_driver_skat_with_permutations(tmp_path):
     equal to the oracle's replay of the same rand() stream across consecutive genes."""
     _ensure_driver()
     path, genes, X, y, res, v = _case(tmp_path, binary=0, d=2, N=700)
-    rc, sec, err = run_driver(path, "skat[nPerm=150:alpha=0.1]", "-", perm_exact=True)
+    rc, sec, err = run_driver(path, "skat[nPerm=150:alpha=0.1]", "-")      # no mode selected: the DEFAULT is exact
     assert rc == 0, err
     rows = sec["out.Skat.assoc"]
     assert rows[0][-8:] == ["Q", "Pvalue", "NumPerm", "ActualPerm", "Stat", "NumGreater", "NumEqual", "PermPvalue"]

@@ -5,7 +5,11 @@ import numpy as np
 import pytest
 
 MAGIC = 6755399441055744.0          # 1.5 * 2^52
-TOL = 2.0 ** -30
+
+
+def _passes(e, K):
+    """the kernel's acceptance test: |g den - K| <= K 2^-53 (lat_row: emax = max(|e| - r 2^-53) must stay <= 0)"""
+    return np.abs(e) - np.asarray(K, dtype=np.float64) * 2.0 ** -53 <= 0.0
 
 
 def _fma_residual(g, den, r):
@@ -26,19 +30,36 @@ def test_magic_number_gives_K_and_the_residual_separates_lattice_from_noise(den)
     r = t - MAGIC
     assert np.array_equal(r, K.astype(np.float64))
     e = _fma_residual(g, den, r)
-    assert np.max(np.abs(e)) <= 2 * den * 2.0 ** -53 * 1.01   # |g den - K| <= K ulp / 2: far below the tolerance
-    assert np.max(np.abs(e)) < TOL
-    # neighbours of 1.0 pass too (by design: they differ from a lattice point by 1e-16) ...
-    for x in (np.nextafter(1.0, 0.0), np.nextafter(1.0, 2.0)):
-        tt = x * float(den) + MAGIC
-        ee = _fma_residual([x], den, [tt - MAGIC])[0]
-        assert abs(ee) < TOL
-    # ... and anything a mean imputation or another number of decimals produces does not
+    assert _passes(e, K).all()                                # the double nearest to K / den always passes
+    # EVERY lattice point of the denominator, not a sample
+    Kall = np.arange(0, 2 * den + 1)
+    gall = Kall.astype(np.float64) / float(den)
+    eall = _fma_residual(gall, den, (gall * float(den) + MAGIC) - MAGIC)
+    assert _passes(eall, Kall).all()
+    # a value a few ulps beside a lattice point is NOT a lattice double: it must be handed back (round 3 accepted anything
+    # within 2^-30 and silently snapped it to K / den in G'G) ...
+    for ulps in (2, 3, 5, 100, 1 << 20):
+        for sign in (-1, 1):
+            x = gall[1:].copy()
+            for _ in range(min(ulps, 5)):
+                x = np.nextafter(x, np.inf if sign > 0 else -np.inf)
+            if ulps > 5:
+                x = gall[1:] * (1.0 + sign * ulps * 2.0 ** -52)
+            tt = x * float(den) + MAGIC
+            ee = _fma_residual(x, den, tt - MAGIC)
+            assert not _passes(ee, tt - MAGIC).any(), (den, ulps, sign)
+    # ... the upper neighbour of 1.0 (1 + 2^-52) as well; its lower neighbour (1 - 2^-53) sits exactly at the bound
+    tt = np.nextafter(1.0, 2.0) * float(den) + MAGIC
+    assert not _passes(_fma_residual([np.nextafter(1.0, 2.0)], den, [tt - MAGIC]), [tt - MAGIC])[0]
+    # 0 passes only as 0.0
+    tiny = np.array([5e-324, 1e-300, 2.0 ** -60])
+    assert not _passes(_fma_residual(tiny, den, [0.0] * 3), [0.0] * 3).any()
+    # ... and anything a mean imputation or another number of decimals produces does not pass
     if den >= 8:
         off = (K[:200].astype(np.float64) + rng.uniform(0.02, 0.98, 200)) / float(den)
         tt = off * float(den) + MAGIC
         ee = _fma_residual(off, den, tt - MAGIC)
-        assert np.min(np.abs(ee)) > TOL
+        assert not _passes(ee, tt - MAGIC).any()
 
 
 def test_range_test_on_the_high_dword():
