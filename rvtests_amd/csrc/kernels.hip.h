@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
 // =====================================================================================================
 __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
-                                                            unsigned tests, int n_bparts) {
+                                                            unsigned tests, int n_bparts, const double* xscale) {
   __shared__ double red[64];
   __shared__ NullConsts nc;
   const GeneDesc gd = genes[blockIdx.x];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), gd.hc == 2 ? gd.lat_den : 0.0};
+  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), gd.hc == 2 ? gd.lat_den : 0.0, gd.pqw, xscale};
   // a hard-call gene that was handed back holds the general kernel's statistics (three rows per wave-part, G'DG itself)
   const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
   const bool masks = gd.hc != 0 && !handed_back;  // (pq is null for the weighted and the lattice kernel: no masked tiles)

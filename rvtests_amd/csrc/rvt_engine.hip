@@ -19,6 +19,7 @@
 #include "kernels.hip.h"
 #include "suffstat_lat.hip.h"
 #include "suffstat_hcp.hip.h"
+#include "suffstat_hcx.hip.h"
 #include "host_stage.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
@@ -33,6 +34,8 @@ void k2_launch_panel_w1(dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullD
 void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
                   int d);
 void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
+                   int d);
+void k2_launch_hcx(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const NullTileX& nt, long long N, long long ld,
                    int d);
 void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
                    long long ld, int d);
@@ -253,6 +256,12 @@ struct rvt_ctx {
   // binary trait: the weighted hard-call kernel's tile [vX_0 .. vX_{d-1} | res | v | zeros] and the digit planes of v
   double* d_nulltile_w = nullptr;
   unsigned char* d_vq = nullptr;
+  // ... and the integer operands of the workgroup-cooperative kernel (suffstat_hcx.hip.h): the digits of v and of the null
+  // tile in operand order, the power-of-two scale of every null column (host copy in hcx_tile, device copy for gene_assemble)
+  unsigned char *d_dq = nullptr, *d_xq = nullptr;
+  double* d_xscale = nullptr;
+  NullTileX hcx_tile;
+  bool hcx_ok = false;
   int64_t null_ld = 0;
   // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
   // double it loads and hands back genes that hold anything but hard calls and one imputed value per column
@@ -519,14 +528,18 @@ bool invert_spd(const double* M, int n, double* Minv) {
 // that a gene still spreads over >= 32..128 waves
 // n_genes: genes of the batch — a big batch fills the chip with fewer, longer waves per gene (half the partial tiles
 // to write and to reduce: measured +2.7 % at 512 genes)
-void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* steps_per) {
+// hcx: the batch's hard-call genes take the workgroup-cooperative kernel (suffstat_hcx.hip.h): a part is worked by four loader
+// waves, so a quarter of the parts gives as many waves per gene; its iteration is 16 steps
+void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* steps_per, bool hcx = false) {
   const int64_t nsteps = ld >> 4;
   const char* fe = getenv("RVT_WPARTS");  // (experiments / tests)
   const int forced = fe ? atoi(fe) : 0;
-  const int target = forced > 0 ? forced : (n_genes >= 128 ? 64 : 128);
+  const int target = forced > 0 ? forced : (hcx ? (n_genes >= 256 ? 16 : 32) : (n_genes >= 128 ? 64 : 128));
   int64_t spw = (nsteps + target - 1) / target;
   if (spw < 64) spw = 64;
-  spw = (spw + kHcStepUnit - 1) / kHcStepUnit * kHcStepUnit;  // whole ring iterations of the hard-call kernel
+  const int unit = hcx ? 3 * kHcxIterSteps : kHcStepUnit;     // (48: whole iterations of both kernels)
+  spw = (spw + unit - 1) / unit * unit;                       // whole ring iterations of the hard-call kernel
+  if (hcx && spw > kHcwMaxSteps) spw = kHcwMaxSteps / unit * unit;
   if (spw > kHcwMaxSteps) spw = kHcwMaxSteps;                   // (int32 range of the weighted hard-call kernel's tiles)
   if (!weighted && spw > kHcMaxSteps) spw = kHcMaxSteps;        // (16-bit range of the hard-call kernel's masked-tile counters)
   int64_t nw = (nsteps + spw - 1) / spw;
@@ -667,8 +680,14 @@ static void free_null(rvt_ctx* c) {
   c->d_X = c->d_rr = c->d_zeros = nullptr;  // inside d_nulltile
   if (c->d_nulltile_w) hipFree(c->d_nulltile_w);
   if (c->d_vq) hipFree(c->d_vq);
+  if (c->d_dq) hipFree(c->d_dq);
+  if (c->d_xq) hipFree(c->d_xq);
+  if (c->d_xscale) hipFree(c->d_xscale);
   c->d_nulltile_w = nullptr;
   c->d_vq = nullptr;
+  c->d_dq = c->d_xq = nullptr;
+  c->d_xscale = nullptr;
+  c->hcx_ok = false;
   c->have_null = false;
 }
 
@@ -865,6 +884,76 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       HIP_TRY(c, hipMalloc((void**)&c->d_vq, vq.size()));
       HIP_TRY(c, hipMemcpy(c->d_nulltile_w, tile.data(), sizeof(double) * tile.size(), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(c->d_vq, vq.data(), vq.size(), hipMemcpyHostToDevice));
+      // The workgroup-cooperative kernel (suffstat_hcx.hip.h) multiplies the null tile on the int8 matrix cores too: every
+      // column [vX_k | res | v] as six balanced base-128 digits of its fixed-point value, 42 bits below a power of two above
+      // twice the column's largest entry.  A column whose largest entry exceeds 256 x its root mean square would leave
+      // its typical entries fewer than 34 bits: such a model stays on the one-wave kernel (fp64 products of the tile).
+      const char* ex = getenv("RVT_HCX");
+      bool okx = !(ex && atoi(ex) == 0) && d + 2 <= kHcxNullCols;
+      double scale[kHcxNullCols];
+      int shift[kHcxNullCols];
+      for (int k = 0; k < kHcxNullCols; ++k) {
+        scale[k] = 1.0;
+        shift[k] = 0;
+      }
+      for (int k = 0; k < d + 2 && okx; ++k) {
+        double mx = 0.0, ss = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+          const double x = tile[(size_t)k * ld + i];
+          mx = std::max(mx, std::fabs(x));
+          ss += x * x;
+        }
+        if (!std::isfinite(mx)) okx = false;
+        if (mx > 0.0) {
+          if (mx > 256.0 * std::sqrt(ss / (double)N)) okx = false;
+          int e;
+          std::frexp(mx, &e);        // mx = f 2^e, 0.5 <= f < 1
+          shift[k] = 42 - (e + 1);   // |x| 2^shift < 2^41 ...
+          // ... but six balanced digits end at 63 (128^5 + .. + 1) = 0.496 2^42: keep the top digit at 62 or below
+          if (std::ldexp(mx, shift[k]) > 0.98 * 0x1p41) shift[k] -= 1;
+          scale[k] = std::ldexp(1.0, -shift[k]);
+        }
+      }
+      if (okx) {
+        const int64_t ngroups = (ld + 63) / 64;
+        std::vector<unsigned char> dq((size_t)ngroups * kHcxSliceDg, 0), xq((size_t)ngroups * kHcwPlanes * 1024, 0);
+        auto digits6 = [](long long q, signed char* dg) {
+          for (int p = kHcwPlanes - 1; p >= 0; --p) {
+            long long r = q & 127;
+            if (r >= 64) r -= 128;
+            q = (q - r) >> 7;
+            dg[p] = (signed char)r;
+          }
+        };
+        for (int64_t i = 0; i < N; ++i) {
+          const int64_t g = i >> 6, T = (i >> 4) & 3, q = (i >> 2) & 3, l = i & 3;
+          signed char dg[kHcwPlanes];
+          digits6(llrint(std::ldexp(v[i], 7 * kHcwPlanes)), dg);  // (the same integer the planes of vq encode)
+          for (int j = 0; j < kHcwPairs; ++j) {
+            unsigned char* e = dq.data() + (size_t)g * kHcxSliceDg + ((q * kHcwPairs + j) * 4 + T) * 16 + l;
+            e[0] = (unsigned char)dg[2 * j];
+            e[4] = (unsigned char)dg[2 * j + 1];
+            e[8] = (unsigned char)(signed char)(2 * dg[2 * j]);
+            e[12] = (unsigned char)(signed char)(2 * dg[2 * j + 1]);
+          }
+          for (int k = 0; k < d + 2; ++k) {
+            digits6(llrint(std::ldexp(tile[(size_t)k * ld + i], shift[k])), dg);
+            for (int p = 0; p < kHcwPlanes; ++p)
+              xq[((size_t)(g * kHcwPlanes + p) * 64 + k + 16 * q) * 16 + T * 4 + l] = (unsigned char)dg[p];
+          }
+        }
+        HIP_TRY(c, hipMalloc((void**)&c->d_dq, dq.size()));
+        HIP_TRY(c, hipMalloc((void**)&c->d_xq, xq.size()));
+        HIP_TRY(c, hipMalloc((void**)&c->d_xscale, sizeof(scale)));
+        HIP_TRY(c, hipMemcpy(c->d_dq, dq.data(), dq.size(), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_xq, xq.data(), xq.size(), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_xscale, scale, sizeof(scale), hipMemcpyHostToDevice));
+        c->hcx_tile.dq = c->d_dq;
+        c->hcx_tile.xq = c->d_xq;
+        for (int k = 0; k < kHcxNullCols; ++k) c->hcx_tile.scale[k] = scale[k];
+        c->hcx_tile.ncols = d + 2;
+        c->hcx_ok = true;
+      }
     }
   }
   HIP_TRY(c, hipMemcpy(c->d_nc, &nc, sizeof(nc), hipMemcpyHostToDevice));
@@ -1348,8 +1437,11 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int d = nc.d;
   const int64_t ld = nc.ld, N = nc.N, nsteps = ld >> 4;
   const int n_bparts = (int)((N + kBurdenSPB - 1) / kBurdenSPB);
+  // binary trait, gene tests: the hard-call genes of the batch take the workgroup-cooperative integer kernel when the null
+  // model's operands exist (rvt_set_null); MetaScore slices and debug runs keep the one-wave kernel
+  const bool hcx = nc.binary && c->hcx_ok && c->hc_enabled && !cov && !(dbg && dbg->cmc) && !(tests & RVT_TEST_FAMSKAT);
   int n_wparts, steps_per;
-  choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per);
+  choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx);
   // ---- sizes ---------------------------------------------------------------------------------------
   std::vector<GeneDesc> desc(n);
   size_t total = 0, af_total = 0;
@@ -1424,6 +1516,16 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
+  // masked-entry tables of the genes on the cooperative weighted kernel (64-bit integers, zeroed before the launch)
+  size_t pqw_bytes = 0;
+  std::vector<size_t> pqw_at(hcx ? n : 0);
+  if (hcx)
+    for (int g = 0; g < n; ++g)
+      if (desc[g].hc == 1) {
+        pqw_at[g] = pqw_bytes;
+        pqw_bytes += sizeof(unsigned long long) * hcx_pq_entries(desc[g].Mp);
+      }
+  const size_t off_pqw = pqw_bytes ? add(pqw_bytes) : 0;
   // device work lists of the hard-call genes (gene_flags_hc_kernel): [0] handed back, [1] burden sums to redo, then
   // the two index lists
   const size_t off_lists = add(sizeof(int) * (4 + 2 * (size_t)std::max(n_hc, 1)));
@@ -1463,6 +1565,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     gd.colstat = reinterpret_cast<double*>(base + o.colstat);
     gd.masks = gd.hc ? nullptr : reinterpret_cast<unsigned long long*>(base + o.masks);
     gd.pq = ((gd.hc == 1 || gd.hc == 3) && !hcw && o.pq) ? reinterpret_cast<unsigned*>(base + o.pq) : nullptr;
+    gd.pqw = (hcx && gd.hc == 1) ? reinterpret_cast<unsigned long long*>(base + off_pqw + pqw_at[g]) : nullptr;
     gd.wflags = (gd.hc && o.wflags) ? reinterpret_cast<unsigned*>(base + o.wflags) : nullptr;
     gd.flags = reinterpret_cast<unsigned short*>(base + o.flags);
     gd.bparts = reinterpret_cast<double*>(base + o.bparts);
@@ -1535,6 +1638,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     launch_suffstat(c, gst, grp, d_desc + k, e - k, n_wparts, nd);
     k = e;
   }
+  if (pqw_bytes) HIP_TRY(c, hipMemsetAsync(base + off_pqw, 0, pqw_bytes, c->k2_stream));
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
     while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].hc == h_desc[k].hc) ++e;
@@ -1546,6 +1650,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     else if (h_desc[k].hc == 2)
       k2_launch_lat(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2},
                     (double)c->lattice_den, (long long)N, (long long)ld, d);
+    else if (hcx)
+      k2_launch_hcx(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->hcx_tile, (long long)N, (long long)ld, d);
     else if (hcw)
       k2_launch_hcw(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTileW{c->d_nulltile_w, d + 3, c->d_vq},
                     (long long)N, (long long)ld, d);
@@ -1678,7 +1784,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       hipLaunchKernelGGL(fam_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc);
     else
       hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
-                         n_bparts);
+                         n_bparts, (const double*)c->d_xscale);
   }
   if ((tests & RVT_TEST_ANALYTICVT) && !(tests & RVT_TEST_FAMSKAT)) {
     Scope sc(c, 2, st);
@@ -1776,14 +1882,18 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   const int d = nc.d;
   const int64_t nsteps = nc.ld >> 4;
   const int n_bparts = (int)((nc.N + kBurdenSPB - 1) / kBurdenSPB);
-  int n_wparts, steps_per;
-  choose_split(nc.ld, n, nc.binary != 0, &n_wparts, &steps_per);
+  const bool hcx = nc.binary && c->hcx_ok && c->hc_enabled;
+  int n_wparts, steps_per, n_wparts1, steps_per1;
+  choose_split(nc.ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx);
+  choose_split(nc.ld, n, nc.binary != 0, &n_wparts1, &steps_per1, false);  // (a batch that cannot take the cooperative kernel)
+  n_wparts = std::max(n_wparts, n_wparts1);
   size_t total = 0, af_total = 0;
   GeneOff o;
   for (int g = 0; g < n; ++g) {
     if (Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, Ms[g]);
     layout_gene(Ms[g], d, n_wparts, nsteps, n_bparts, false, -1, &total, &o);
     af_total += (size_t)Ms[g];
+    if (hcx) total += 256 + sizeof(unsigned long long) * hcx_pq_entries(16 * ((Ms[g] + 15) / 16));
   }
   total += sizeof(double) * af_total + sizeof(GeneDesc) * n + sizeof(rvt_gene_result) * n + 4 * 256;
   const size_t stage_bytes = sizeof(GeneDesc) * n + sizeof(double) * af_total + sizeof(rvt_gene_result) * n + 64;
@@ -1919,10 +2029,25 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
       }
       if (cm[j] > 0) std::memcpy(&mu[j], &orb, 8);
     }
+  // weighted cooperative kernel (suffstat_hcx.hip.h): the gene's integer tables P = m'VH, Q = m'Vm, R = m'V[X | res]
+  std::vector<long long> pqx;
+  if (g0.hc && g0.pqw) {
+    pqx.resize(hcx_pq_entries(Mp));
+    HIP_TRY(c, hipMemcpy(pqx.data(), g0.pqw, sizeof(long long) * pqx.size(), hipMemcpyDeviceToHost));
+  }
   auto R = [&](int i, int j) {
     if (j < M && j < i) std::swap(i, j);  // the engine uses the upper triangle of G'DG
     double s = 0;
     for (int p2 = 0; p2 < g0.n_wparts; ++p2) s += parts[(size_t)p2 * psz + (size_t)i * g0.Cp + j];
+    if (!pqx.empty()) {  // (as gene_assemble combines them)
+      if (j < M) {
+        const double pij = (double)pqx[(size_t)i * Mp + j] * 0x1p-42, pji = (double)pqx[(size_t)j * Mp + i] * 0x1p-42;
+        const double q = (double)pqx[(size_t)Mp * Mp + (size_t)i * Mp + j] * 0x1p-42;  // (i <= j here)
+        s += mu[j] * pji + mu[i] * pij + (mu[i] * mu[j]) * q;
+      } else if (j - M <= d) {
+        s += mu[i] * ((double)pqx[2 * (size_t)Mp * Mp + (size_t)i * kHcxNullCols + (j - M)] * c->hcx_tile.scale[j - M]);
+      }
+    }
     if (j < M && !Pp.empty()) {
       const double q = Qq[(size_t)i * Mp + j];
       const double pij = Pp[(size_t)i * Mp + j] - 4.0 * q, pji = Pp[(size_t)j * Mp + i] - 4.0 * q;

@@ -113,6 +113,11 @@ struct HcMasked {
   const unsigned* wflags;  // P flags: bit 0 = the part's image was written
   int pq_words;
   double lat_den;  // > 0: lattice dosages (suffstat_lat.hip.h) — the G'G block and the column sums are integers, scaled here
+  // weighted hard-call path (suffstat_hcx.hip.h): the gene's masked-entry tables as 64-bit integers — P = m'VH (Mp x Mp, row =
+  // the masked column) and Q = m'Vm (Mp x Mp, upper triangle) in units of 2^-42, R = m'V[X | res] (Mp x 16) in units of
+  // xscale[k]; `parts` holds H'VH and H'V[X | res] (a masked entry counted as 0)
+  const unsigned long long* pqw = nullptr;
+  const double* xscale = nullptr;
 };
 constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 
@@ -237,6 +242,31 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
         const double pij = Pp[(size_t)i * Mp + j] - 4.0 * q, pji = Pp[(size_t)j * Mp + i] - 4.0 * q;
         const double hh = R[(size_t)i * ldr + j] - 4.0 * (pij + pji) - 16.0 * q;  // exact: integers below 2^53
         R[(size_t)i * ldr + j] = hh + muv[j] * pij + muv[i] * pji + (muv[i] * muv[j]) * q;
+      }
+      co.sync();
+    }
+  }
+  // weighted hard-call path: G'VG = H'VH + P diag(mu) + diag(mu) P' + diag(mu) Q diag(mu), G'V[X | res] = H'V[X | res] + diag(mu) R
+  // (exact integers, one rounding per product)
+  if (hcm && hcm->pqw) {
+    bool any = false;
+    for (int p = 0; p < P; ++p) any = any || (hcm->wflags[p] & 1u);
+    if (any) {
+      const long long* Pw = reinterpret_cast<const long long*>(hcm->pqw);
+      const long long* Qw = Pw + (size_t)Mp * Mp;
+      const long long* Rw = Qw + (size_t)Mp * Mp;
+      for (int idx = co.tid; idx < M * M; idx += co.nt) {
+        const int i = idx / M, j = idx % M;
+        if ((j >> 4) < (i >> 4)) continue;
+        if (muv[i] == 0.0 && muv[j] == 0.0) continue;
+        const double pij = (double)Pw[(size_t)i * Mp + j] * 0x1p-42;  // m_i'V H_j
+        const double pji = (double)Pw[(size_t)j * Mp + i] * 0x1p-42;  // m_j'V H_i
+        const double q = (double)Qw[(size_t)(i < j ? i : j) * Mp + (i < j ? j : i)] * 0x1p-42;
+        R[(size_t)i * ldr + j] += muv[j] * pji + muv[i] * pij + (muv[i] * muv[j]) * q;
+      }
+      for (int idx = co.tid; idx < M * (d + 1); idx += co.nt) {
+        const int i = idx / (d + 1), k = idx % (d + 1);
+        if (muv[i] != 0.0) R[(size_t)i * ldr + M + k] += muv[i] * ((double)Rw[(size_t)i * 16 + k] * hcm->xscale[k]);
       }
       co.sync();
     }

@@ -100,7 +100,7 @@ constexpr HcxAsg hcx_asg(int MT, int w) {
   }
 }
 constexpr int hcx_ntiles(int MT, int w) {
-  if (w == 3) return MT + 1;
+  if (w == 3) return MT;  // (+ the burden tile, six unpaired plane sums)
   const HcxAsg a = hcx_asg(MT, w);
   return (a.nrows > 0 ? a.ncols[0] : 0) + (a.nrows > 1 ? a.ncols[1] : 0);
 }
@@ -348,22 +348,28 @@ __device__ __forceinline__ void hcx_gram(i4_t (&acc)[kHcwPairs][NT], const char*
 }
 
 // Tile wave 3: the tiles H_r'V[X | res | v] of every row tile r (A = the packed integers as they are, B = digit plane p of the
-// null tile, from the LDS stage) and the burden tile (A = the burden operand, tile index MT).
+// null tile, from the LDS stage) and the burden tile (A = the burden operand).  The burden operand's bytes reach 127 (the
+// low part of a squared count), so its planes are NOT paired: 127 x 64 digits x 64 samples < 2^19 per operand and plane keeps
+// a plain int32 sum exact over the 768 operands of the longest wave-part; shifted by 7 bits it would not.
 template <int MT, int NT>
-__device__ __forceinline__ void hcx_null_tiles(i4_t (&acc)[kHcwPairs][NT], const char* buf, int lane, const char* stage) {
+__device__ __forceinline__ void hcx_null_tiles(i4_t (&acc)[kHcwPairs][NT], i4_t (&accb)[kHcwPlanes], const char* buf, int lane,
+                                               const char* stage) {
 #pragma unroll 1
   for (int s = 0; s < kHcxNW; ++s) {
     const char* slice = buf + s * hcx_slice_bytes(MT);
     const u4_t* pk = reinterpret_cast<const u4_t*>(slice) + lane;
     const u4_t* st = reinterpret_cast<const u4_t*>(stage + s * (kHcwPlanes * kHcxPlaneStage)) + lane;
+    const i4_t ab = hcx_op(pk[MT * 64]);
 #pragma unroll
     for (int j = 0; j < kHcwPairs; ++j) {
       const i4_t b0 = hcx_op(st[(2 * j) * 64]), b1 = hcx_op(st[(2 * j + 1) * 64]);
 #pragma unroll
-      for (int r = 0; r <= MT; ++r) {
+      for (int r = 0; r < MT; ++r) {
         const i4_t a = hcx_op(pk[r * 64]);
         hcx_pair_step(acc[j][r], a, b0, a, b1);
       }
+      accb[2 * j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b0, accb[2 * j], 0, 0, 0);
+      accb[2 * j + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b1, accb[2 * j + 1], 0, 0, 0);
     }
   }
 }
@@ -452,6 +458,9 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
     for (int j = 0; j < kHcwPairs; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[j][t] = i4_t{0, 0, 0, 0};
+    i4_t accb[kHcwPlanes];  // tile wave 3: the burden tile, one sum per digit plane
+#pragma unroll
+    for (int p = 0; p < kHcwPlanes; ++p) accb[p] = i4_t{0, 0, 0, 0};
     const long long n_groups = (ld + 63) / 64;
     if (tw == 3) {
       hcx_stage_dq(dgstage, nt.dq, s_begin >> 2, n_groups, lane);
@@ -471,11 +480,11 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
           // (the other stage buffers were last read before this barrier: refill them now, for the next iteration)
           hcx_stage_dq(dgstage + (int)((it + 1) & 1) * (kHcxNW * kHcxSliceDg), nt.dq, g_next, n_groups, lane);
 #ifndef HCX_XQ_EARLY
-          hcx_null_tiles<MT, NT>(acc, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
+          hcx_null_tiles<MT, NT>(acc, accb, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
           hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
 #else
           hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
-          hcx_null_tiles<MT, NT>(acc, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
+          hcx_null_tiles<MT, NT>(acc, accb, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
 #endif
           break;
       }
@@ -519,10 +528,15 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
       // ---- burden partial sums: [test][U, c'Vc, count, c'VX_0 .. c'VX_{d-1}], test 0 = CMC, 1 = Zeggini.  The burden tile's
       // rows 0-3 (lanes q = 0, elements 0-3): c_cmc, c_zeg, low / high part of c_zeg^2 against the null column v
       if (gd.bparts && lane < 16) {
-        const double ac = hcx_pairs_value(acc[0][MT][0], acc[1][MT][0], acc[2][MT][0]) * sc;
-        const double az = hcx_pairs_value(acc[0][MT][1], acc[1][MT][1], acc[2][MT][1]) * sc;
-        const double azz = (hcx_pairs_value(acc[0][MT][2], acc[1][MT][2], acc[2][MT][2]) +
-                            128.0 * hcx_pairs_value(acc[0][MT][3], acc[1][MT][3], acc[2][MT][3])) * sc;
+        auto planes = [&](int i) {  // sum_p plane_p 128^(5 - p): |.| < 2^19 768 2^35 (exact in 64 bits)
+          long long x = 0;
+#pragma unroll
+          for (int p = 0; p < kHcwPlanes; ++p) x = x * 128 + (long long)accb[p][i];
+          return x;
+        };
+        const double ac = (double)planes(0) * sc;
+        const double az = (double)planes(1) * sc;
+        const double azz = (double)(planes(2) + 128 * planes(3)) * sc;
         const double cn = (double)flagw[1];
         const int rl = 3 + d;
         double* bp = gd.bparts + (long long)wpart * 2 * rl;

@@ -82,10 +82,10 @@ def build_library(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
-    # seven objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
+    # eight objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
-             "k2_lattice.hip", "k2_packed.hip"]
+             "k2_hardcall_x.hip", "k2_lattice.hip", "k2_packed.hip"]
     objs, procs = [], []
     for u in units:
         obj = os.path.join(CSRC, u.replace(".hip", ".o"))

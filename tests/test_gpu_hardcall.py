@@ -28,6 +28,14 @@ def _hard_gene(N, M, seed, flip_col=None, ones_col=None, twos_col=None, zero_col
     return np.asfortranarray(G), G.sum(0) / (2.0 * N)
 
 
+def _same(f, x, y_, rel=1e-9):
+    """int8 path against the fp64 path: `rel` relative; the 1-df burden statistics get an absolute floor as well — U is
+    a sum that cancels to almost nothing for a null gene, and the weighted kernel's fixed-point null tile (42 bits per
+    column, suffstat_hcx.hip.h) moves it by ~1e-12 of its natural scale, i.e. the chi-square statistic by ~1e-12 absolute"""
+    floor = 1e-11 if f in ("cmc_stat", "zeg_stat", "cmc_U", "zeg_U") else 1e-300
+    return abs(x - y_) <= rel * abs(y_) + floor
+
+
 def _run(engine, genes, hard):
     """Run the genes starting on the hard-call kernel (hard=True: the default for blocks of unknown content) or with the
     engine confined to the general fp64 kernel (hard=False)."""
@@ -360,7 +368,7 @@ def test_binary_trait_weighted_hardcall_path(engine, N, d):
         assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref and a.status == b.status
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
-            assert abs(x - y_) <= 1e-9 * abs(y_) + 1e-300, (G.shape[1], f, x, y_)
+            assert _same(f, x, y_), (G.shape[1], f, x, y_)
         rc, o = orc.skat(G, af, X, res, v, 1)
         assert a.n_poly == o.n_poly
         if o.n_poly:
@@ -388,7 +396,7 @@ def test_binary_trait_weights_at_the_digit_range_limits(engine):
     (b,), _ = _run(engine, [(G, af)], False)
     assert tm.genes_hard_call == 1
     for f in FIELDS:
-        assert abs(getattr(a, f) - getattr(b, f)) <= 1e-9 * abs(getattr(b, f)) + 1e-300, f
+        assert _same(f, getattr(a, f), getattr(b, f)), f
     rng = np.random.default_rng(5)
     pr = np.concatenate([10.0 ** rng.uniform(-9, -1, N // 2), 1.0 - 10.0 ** rng.uniform(-9, -1, N - N // 2)])
     v2 = pr * (1 - pr)
@@ -399,7 +407,7 @@ def test_binary_trait_weights_at_the_digit_range_limits(engine):
     (b,), _ = _run(engine, [(G, af)], False)
     assert tm.genes_hard_call == 1
     for f in FIELDS:
-        assert abs(getattr(a, f) - getattr(b, f)) <= 1e-8 * abs(getattr(b, f)) + 1e-300, f
+        assert _same(f, getattr(a, f), getattr(b, f), rel=1e-8), f
 
 
 def test_binary_trait_burden_fallback(engine):
@@ -506,7 +514,7 @@ def test_weighted_hardcall_at_the_wave_part_cap(engine):
     assert a.n_poly == b.n_poly == 2
     for f in FIELDS:
         x, y_ = getattr(a, f), getattr(b, f)
-        assert abs(x - y_) <= 1e-9 * abs(y_) + 1e-300, (f, x, y_)
+        assert _same(f, x, y_), (f, x, y_)
 
 
 def test_weighted_hardcall_digit_rounding_at_small_p(engine):

@@ -87,7 +87,9 @@ def _check_gene(r, G, af, X, y, res, v, binary, d):
             rc3, b = orc.burden(G, X, y, binary, which)
             assert ok == (rc3 == 0)
             if ok:
-                assert close(stat, b.stat, 1e-9, 1e-13)      # (a statistic that is zero up to rounding)
+                # (a statistic that is zero up to rounding: U cancels to almost nothing for a null gene; under a binary trait
+                #  the null tile is 42-bit fixed point per column, which moves U by ~1e-12 of its natural scale)
+                assert close(stat, b.stat, 1e-9, 1e-11 if binary else 1e-13)
                 assert close(p, b.pvalue, REL, ABS_P)
                 if nonref is not None:
                     assert nonref == b.nonref_site  # bit-exact count

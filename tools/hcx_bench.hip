@@ -38,14 +38,14 @@ __device__ inline unsigned long long dmix(unsigned long long x) {
   return x ^ (x >> 31);
 }
 // hard calls with rare alleles; miss_per_million of the entries replaced by the column's "mean" mu_j = 0.01 (j % 7 + 1)
-__global__ void fill_G(double* G, long long ld, long long N, int M, unsigned long long seed, int miss_per_million) {
+__global__ void fill_G(double* G, long long ld, long long N, int M, unsigned long long seed, int miss_per_million, double rate) {
   const long long total = ld * M;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long i = idx % ld;
     const int j = (int)(idx / ld);
     const unsigned long long h = dmix(seed ^ (unsigned long long)idx * 0xD1B54A32D192ED03ull);
     const double a = (double)(h >> 40) * (1.0 / 16777216.0), b = (double)((h >> 16) & 0xffffff) * (1.0 / 16777216.0);
-    double g = (a < 0.02 ? 1.0 : 0.0) + (b < 0.02 ? 1.0 : 0.0);
+    double g = (a < rate ? 1.0 : 0.0) + (b < rate ? 1.0 : 0.0);
     if ((int)(dmix(h) % 1000000ull) < miss_per_million) g = 0.01 * (j % 7 + 1);
     G[idx] = (i < N) ? g : 0.0;
   }
@@ -122,7 +122,7 @@ struct DevGenes {
   }
 };
 static DevGenes make_genes(long long N, long long ld, int d, int MT, int Mlo, int Mhi, int ngenes, int nw, long long spw,
-                           int miss_ppm, bool with_pq) {
+                           int miss_ppm, bool with_pq, double rate = 0.02) {
   DevGenes D;
   D.ngenes = ngenes;
   D.nw = nw;
@@ -144,7 +144,7 @@ static DevGenes make_genes(long long N, long long ld, int d, int MT, int Mlo, in
     memset(&gd, 0, sizeof(gd));
     gd.G = D.dG + D.gstride * g;
     const int Mg = Mlo + (g * 7) % (Mhi - Mlo + 1);
-    hipLaunchKernelGGL(fill_G, dim3(1024), dim3(256), 0, 0, D.dG + D.gstride * g, ld, N, Mg, 7ull + g, miss_ppm);
+    hipLaunchKernelGGL(fill_G, dim3(1024), dim3(256), 0, 0, D.dG + D.gstride * g, ld, N, Mg, 7ull + g, miss_ppm, rate);
     gd.M = Mg; gd.MT = MT; gd.CT = (Mg + d + 1 + 15) / 16; gd.Mp = D.Mp; gd.Cp = 16 * gd.CT;
     gd.n_wparts = nw; gd.steps_per_wpart = (int)spw;
     gd.parts = D.parts + (size_t)g * nw * D.Mp * D.Cp;
@@ -186,8 +186,8 @@ static hcw_kernel_t hcw_kernel(int MT) {
 static int check() {
   int bad_total = 0;
   const int d = 3;
-  const struct { long long N; int M; int miss; int steps; } cases[] = {
-      {5000, 80, 3000, 32}, {5000, 65, 0, 48}, {3333, 50, 5000, 16}, {4097, 64, 2000, 32}, {2600, 37, 8000, 64},
+  const struct { long long N; int M; int miss; int steps; double rate; } cases[] = {
+      {49152, 80, 100, 3072, 0.7}, {5000, 80, 3000, 32}, {5000, 65, 0, 48}, {3333, 50, 5000, 16}, {4097, 64, 2000, 32}, {2600, 37, 8000, 64},
       {3000, 20, 3000, 16}, {1000, 9, 20000, 16}, {777, 1, 50000, 16}, {6000, 33, 0, 400}};
   for (const auto& cs : cases) {
     const long long N = cs.N;
@@ -196,7 +196,7 @@ static int check() {
     const int M = cs.M, MT = (M + 15) / 16;
     const long long spw = cs.steps;
     const int nw = (int)((nsteps + spw - 1) / spw);
-    DevGenes D = make_genes(N, ld, d, MT, M, M, 1, nw, spw, cs.miss, true);
+    DevGenes D = make_genes(N, ld, d, MT, M, M, 1, nw, spw, cs.miss, true, cs.rate > 0 ? cs.rate : 0.02);
     unsigned char *dvq, *dxq;
     CK(hipMalloc(&dvq, nl.dq.size()));
     CK(hipMalloc(&dxq, nl.xq.size()));
