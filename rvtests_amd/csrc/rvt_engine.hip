@@ -228,6 +228,12 @@ struct rvt_ctx {
   size_t perm_cap_NB = 0, perm_cap_BM = 0;
   int perm_cap_B = 0;
   hipEvent_t ev_in[kSlotsAll] = {}, ev_k2[kSlotsAll] = {}, ev_k2b[kSlotsAll] = {};
+  // The p-value kernel on CUs of its own (RVT_PV_CUS, see rvt_init): two streams restricted to the first pv_cus mask bits,
+  // used by alternate batches; the batch's stream hands over by event and takes the records back by event.
+  hipStream_t pv_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_pv_in[kSlotsAll] = {}, ev_pv_out[kSlotsAll] = {};
+  int pv_cus = 0;
+  unsigned pv_turn = 0;
   // host -> device copies of the streaming interface: pinned staging ring filled by the process-wide copy threads
   // (host_stage.h), drained by DMA on io_stream.  RVT_STAGE=0 restores the runtime's own pageable copies.
   static constexpr int kStageChunks = 4;
@@ -605,6 +611,15 @@ int rvt_init(rvt_ctx** out, int device_id) {
     } else {
       masked = hipExtStreamCreateWithCUMask(&c->k2_stream, words, m1.data()) == hipSuccess;
     }
+    // RVT_TAIL_CUS = k (experimental): the batch streams (flags, assembly, eigen stages, hand-backs) on the first k mask
+    // bits only, the streaming stage everywhere
+    if (const char* e = getenv("RVT_TAIL_CUS")) {
+      const int tk = atoi(e) / 32 * 32;
+      if (stage2_cus == 0 && tk >= 32 && tk < ncu) {
+        std::fill(m2.begin(), m2.end(), 0u);
+        for (int b = 0; b < tk; ++b) m2[b / 32] |= 1u << (b % 32);
+      }
+    }
     for (int i = 0; masked && i < kSlotsAll; ++i)
       masked = hipExtStreamCreateWithCUMask(&c->slots[i].stream, words, m2.data()) == hipSuccess;
     if (!masked) {
@@ -620,6 +635,35 @@ int rvt_init(rvt_ctx** out, int device_id) {
     }
   }
   c->cu_partitioned = masked && stage2_cus > 0;
+  // The SKAT-O p-values keep a 256-register wave per gene resident for milliseconds (QAGS over ~10^3 Davies evaluations:
+  // latency-bound).  Spread over the whole chip those waves sit on every CU, and the workgroup-cooperative streaming
+  // kernel (suffstat_hcx.hip.h: eight waves, all the registers of a CU's SIMDs) finds no free CU.  RVT_PV_CUS = k
+  // (a multiple of 32; default 64) confines the p-value kernel to k CUs — 8 per XCD for 64: two waves per SIMD hold all
+  // 512 genes of a batch — and leaves the others to the streaming stage; 0 = everywhere, as before round 4.
+  {
+    int pv = 64;
+    if (const char* e = getenv("RVT_PV_CUS")) pv = atoi(e);
+    pv = pv > 0 ? std::max(32, pv / 32 * 32) : 0;
+    if (masked && stage2_cus == 0 && pv > 0 && pv < ncu) {
+      const int words = (ncu + 31) / 32;
+      std::vector<uint32_t> mp(words, 0u);
+      for (int b = 0; b < pv; ++b) mp[b / 32] |= 1u << (b % 32);
+      if (hipExtStreamCreateWithCUMask(&c->pv_stream[0], words, mp.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&c->pv_stream[1], words, mp.data()) == hipSuccess) {
+        c->pv_cus = pv;
+        for (int i = 0; i < kSlotsAll; ++i) {
+          hipEventCreateWithFlags(&c->ev_pv_in[i], hipEventDisableTiming);
+          hipEventCreateWithFlags(&c->ev_pv_out[i], hipEventDisableTiming);
+        }
+      } else {
+        (void)hipGetLastError();
+        for (int k = 0; k < 2; ++k) {
+          if (c->pv_stream[k]) hipStreamDestroy(c->pv_stream[k]);
+          c->pv_stream[k] = nullptr;
+        }
+      }
+    }
+  }
   if (!masked) {
     for (int i = 0; i < kSlotsAll; ++i)
       if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
@@ -708,6 +752,15 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->k2b_stream) {
     sync_stream(c->k2b_stream);
     hipStreamDestroy(c->k2b_stream);
+  }
+  for (int k = 0; k < 2; ++k)
+    if (c->pv_stream[k]) {
+      sync_stream(c->pv_stream[k]);
+      hipStreamDestroy(c->pv_stream[k]);
+    }
+  for (int i = 0; i < kSlotsAll; ++i) {
+    if (c->ev_pv_in[i]) hipEventDestroy(c->ev_pv_in[i]);
+    if (c->ev_pv_out[i]) hipEventDestroy(c->ev_pv_out[i]);
   }
   if (c->k2_stream) {
     sync_stream(c->k2_stream);
@@ -889,7 +942,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       // twice the column's largest entry.  A column whose largest entry exceeds 256 x its root mean square would leave
       // its typical entries fewer than 34 bits: such a model stays on the one-wave kernel (fp64 products of the tile).
       const char* ex = getenv("RVT_HCX");
-      bool okx = !(ex && atoi(ex) == 0) && d + 2 <= kHcxNullCols;
+      bool okx = !(ex && atoi(ex) == 0) && d + 2 <= kHcxStageCols;  // (wider models: the LDS stage of the kernel holds 8 columns)
       double scale[kHcxNullCols];
       int shift[kHcxNullCols];
       for (int k = 0; k < kHcxNullCols; ++k) {
@@ -915,8 +968,9 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
         }
       }
       if (okx) {
-        const int64_t ngroups = (ld + 63) / 64;
-        std::vector<unsigned char> dq((size_t)ngroups * kHcxSliceDg, 0), xq((size_t)ngroups * kHcwPlanes * 1024, 0);
+        const int64_t ngroups = (ld + 63) / 64 + 4;  // (four groups of padding: the kernel fetches an iteration as one range)
+        const int ncx = d + 2;
+        std::vector<unsigned char> dq((size_t)ngroups * kHcxSliceDg, 0), xq((size_t)ngroups * kHcwPlanes * 4 * ncx * 16, 0);
         auto digits6 = [](long long q, signed char* dg) {
           for (int p = kHcwPlanes - 1; p >= 0; --p) {
             long long r = q & 127;
@@ -939,7 +993,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
           for (int k = 0; k < d + 2; ++k) {
             digits6(llrint(std::ldexp(tile[(size_t)k * ld + i], shift[k])), dg);
             for (int p = 0; p < kHcwPlanes; ++p)
-              xq[((size_t)(g * kHcwPlanes + p) * 64 + k + 16 * q) * 16 + T * 4 + l] = (unsigned char)dg[p];
+              xq[(((size_t)(g * kHcwPlanes + p) * 4 + q) * ncx + k) * 16 + T * 4 + l] = (unsigned char)dg[p];
           }
         }
         HIP_TRY(c, hipMalloc((void**)&c->d_dq, dq.size()));
@@ -1811,13 +1865,27 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
   }
   {
-    Scope sc(c, 3, st);
-    const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
-                        sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
-    if (tests & RVT_TEST_EXACT_DAVIES)  // Davies' coefficient sums term by term (verification) / in product form
-      hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, st, d_desc, tests);
-    else
-      hipLaunchKernelGGL((gene_pvalue_kernel<true>), dim3(n), dim3(64), smem, st, d_desc, tests);
+    // (on CUs of its own when RVT_PV_CUS is in force and the batch is big enough to matter: see rvt_init)
+    const bool pv_apart = c->pv_cus > 0 && n >= 64 && (tests & RVT_TEST_SKATO);
+    hipStream_t pst = st;
+    if (pv_apart) {
+      pst = c->pv_stream[c->pv_turn++ & 1];
+      HIP_TRY(c, hipEventRecord(c->ev_pv_in[slot_idx], st));
+      HIP_TRY(c, hipStreamWaitEvent(pst, c->ev_pv_in[slot_idx], 0));
+    }
+    {
+      Scope sc(c, 3, pst);
+      const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
+                          sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
+      if (tests & RVT_TEST_EXACT_DAVIES)  // Davies' coefficient sums term by term (verification) / in product form
+        hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, pst, d_desc, tests);
+      else
+        hipLaunchKernelGGL((gene_pvalue_kernel<true>), dim3(n), dim3(64), smem, pst, d_desc, tests);
+    }
+    if (pv_apart) {
+      HIP_TRY(c, hipEventRecord(c->ev_pv_out[slot_idx], pst));
+      HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pv_out[slot_idx], 0));
+    }
   }
   HIP_TRY(c, hipGetLastError());
   rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(sl.h_stage + sizeof(GeneDesc) * n +

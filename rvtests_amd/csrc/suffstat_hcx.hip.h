@@ -51,19 +51,21 @@ constexpr int kHcxNW = 4;          // loader waves = slices per iteration = tile
 constexpr int kHcxIterSteps = 16;  // steps per workgroup iteration (kHcxNW x 4)
 constexpr int kHcxMaxMT = 5;
 constexpr int kHcxNullCols = 16;   // the null tile is ONE 16-column operand: vX_0 .. vX_{d-1}, res, v, zeros
+constexpr int kHcxStageCols = 8;   // non-zero null columns the kernel stages in LDS (d <= 6; wider models: gene_suffstat_hcw)
 
 // Null-model operands of the kernel (built by rvt_set_null):
 //   dq    digit planes of v in the order the tile waves read them: [group of 64 samples][q 4][pair 3][step 4] x 16 bytes =
 //         (d_2j, d_2j+1, 2 d_2j, 2 d_2j+1) of the four samples 64 g + 16 T + 4 q + 0..3 (one dword each, a byte per sample):
 //         768 bytes per slice, copied to LDS as they are
-//   xq    digit planes of the null tile in OPERAND order: [group of 64 samples][plane 0..5][lane 0..63][16 bytes], lane =
-//         column k + 16 q, byte 4 T + l = digit of sample 64 g + 16 T + 4 q + l — one 16-byte load per lane, plane and slice
+//   xq    digit planes of the null tile's ncols non-zero columns: [group of 64 samples][plane 0..5][q 0..3][column k < ncols]
+//         x 16 bytes, byte 4 T + l = digit of sample 64 g + 16 T + 4 q + l — the operand of plane p is lane (k, q) <- entry
+//         (p, q, k), zero for k >= ncols.  Both images are padded by four groups (an iteration is fetched as one range)
 //   scale value of column k = integer x scale[k] (a power of two)
 struct NullTileX {
   const unsigned char* dq;
   const unsigned char* xq;
   double scale[kHcxNullCols];
-  int ncols;  // d + 2 non-zero columns (vX_0 .. vX_{d-1}, res, v)
+  int ncols;  // d + 2 non-zero columns (vX_0 .. vX_{d-1}, res, v); <= kHcxStageCols
 };
 
 // ---- tile assignment of the tile waves (index w = wave - 4).  0-2: Gram tiles by A-operand row; 3: the tiles G'V[X | res | v]
@@ -114,24 +116,27 @@ constexpr int hcx_max_tiles(int MT) {
 //   2 buffers x 4 slices x (MT + 1) x 64 lanes x 16 B: the int8 operand of every column tile (4 steps x 4 samples per lane),
 //        then the burden operand (rows 0-3 = lanes v < 4: c_cmc, c_zeg, c_zeg^2 low 7 bits, c_zeg^2 >> 7 of the lane row's
 //        samples; the other lanes hold zero)
-//   per loader wave: mk: MT x 64 lanes x 4 B: bit 4 T + l = entry (step T, sample l) of the lane's column is masked (zero
-//        except between a masked entry and the end of its slice's treatment); the masked-entry list of hcx_masked_slice
-//   OR / AND words: MT x 64 x 4 B;  per column: masked-entry count, sum g, sum g^2: 3 x MT x 16 x 4 B;  4 words: flag (bit 0:
+//   per slice: 2 buffers x mk: MT x 64 lanes x 4 B: bit 4 T + l = entry (step T, sample l) of the lane's column is masked
+//        (zero except between a masked entry and the end of its slice's treatment); the masked-entry list of
+//        hcx_masked_slice; in the tail: one word per slice and buffer "the slice holds masked entries"
+//   OR / AND words: MT x 64 x 4 B;  per column: masked-entry count, sum g, number of non-zero g: 3 x MT x 16 x 4 B;  4 words: flag (bit 0:
 //        a masked entry was met, bit 1: an entry with code 3 = -inf), number of samples with a non-zero collapsed genotype
-//   digit stage: 2 buffers x 4 slices x 768 B (NullTileX::dq as it is);  xq stage: 2 buffers x 4 slices x 6 planes x 64 lanes
-//        x 16 B — the weights' and the null tile's operands of an iteration, fetched by LDS-DMA (tile wave 3) one iteration
-//        ahead, right after the barrier behind which nobody reads the buffer any more
+//   digit stage: 2 buffers x 4 slices x 768 B;  xq stage: 2 buffers x 4 slices x 6 planes x 4 lane rows x ncols x 16 B — the
+//        weights' and the null tile's operands of an iteration (NullTileX::dq / xq as they lie in memory), fetched by LDS-DMA:
+//        every loader wave its own slice's, at the start of its load phase (a tile wave that issues them is stalled for
+//        thousands of cycles behind the loads the loaders keep the memory pipeline full with)
 constexpr int hcx_slice_bytes(int MT) { return (MT + 1) * 1024; }
 constexpr int hcx_buf_bytes(int MT) { return 2 * kHcxNW * hcx_slice_bytes(MT); }
-constexpr int hcx_mk_bytes(int MT) { return MT * 256; }
-constexpr int kHcxListCap = 48;  // entries per round: 12 bytes each (meta, V lo, V hi)
-constexpr int hcx_list_bytes() { return 16 + kHcxListCap * 12; }
-constexpr int hcx_wave_bytes(int MT) { return hcx_mk_bytes(MT) + hcx_list_bytes(); }
-constexpr int hcx_tail_bytes(int MT) { return MT * 256 + 3 * MT * 64 + 16; }
+constexpr int hcx_mk_bytes(int MT) { return MT * 256; }  // the mask words of one slice
+constexpr int kHcxListCap = 48;   // entries per round: 12 bytes each (meta, V lo, V hi)
+constexpr int kHcxUpdCap = 128;   // table updates collected per round: 12 bytes each (table index, value lo, value hi)
+constexpr int hcx_list_bytes() { return 16 + kHcxListCap * 12 + kHcxUpdCap * 12; }
+// per slice w: mask words of the two operand buffers, then the entry list of the tile wave that treats the slice
+constexpr int hcx_wave_bytes(int MT) { return 2 * hcx_mk_bytes(MT) + hcx_list_bytes(); }
+constexpr int hcx_tail_bytes(int MT) { return MT * 256 + 3 * MT * 64 + 16 + 2 * kHcxNW * 4; }
 constexpr int kHcxSliceDg = 768;
 constexpr int kHcxDgStage = 2 * kHcxNW * kHcxSliceDg;
-constexpr int kHcxPlaneStage = 1024;  // one plane of one slice
-constexpr int kHcxStageBuf = kHcxNW * kHcwPlanes * kHcxPlaneStage;  // the null tile's operands of one iteration
+constexpr int kHcxStageBuf = kHcxNW * kHcwPlanes * 4 * kHcxStageCols * 16;  // the null tile's operands of one iteration (at most)
 constexpr int kHcxStageBytes = 2 * kHcxStageBuf;
 constexpr int hcx_off_wave(int MT) { return hcx_buf_bytes(MT); }
 constexpr int hcx_off_tail(int MT) { return hcx_off_wave(MT) + kHcxNW * hcx_wave_bytes(MT); }
@@ -144,37 +149,50 @@ constexpr int hcx_lds_bytes(int MT) { return hcx_off_stage(MT) + kHcxStageBytes;
 // k in units of NullTileX::scale[k])
 constexpr size_t hcx_pq_entries(int Mp) { return 2 * (size_t)Mp * Mp + (size_t)Mp * kHcxNullCols; }
 
-// one tile row of one step: hard-call test, packing (a masked entry packs as 0), byte sums of g and g^2, burden hits.
-// mk = 0x01 in the byte of every entry that is not exactly 0.0 / 1.0 / 2.0 (see hc_row, suffstat_hc.hip.h).
-template <bool MASKED>
-__device__ __forceinline__ void hcx_row(const u4_t& glo, const u4_t& ghi, unsigned& pk, unsigned& mk, unsigned& cs,
-                                        unsigned& cs2, unsigned fx, unsigned& h, bool valid) {
+// one tile row of one step: hard-call test, packing, byte sums, burden hits.  A double is a hard call iff its low dword is
+// zero and its high dword is 0, 0x3FF00000 or 0x40000000: hi + 0x00100000 then has no bit outside {20, 30} (see hc_row,
+// suffstat_hc.hip.h).  The common path only asks whether ALL FOUR doubles of the lane are hard calls (`bad` = 0); which of
+// them are not, the mask bytes and the clean-up of their codes are the rare path's (hcx_row_masked).  top: OR of the top
+// bytes of every double the lane has met — bit 7 set in a byte says negative / -inf / NaN: the gene goes to the fp64 kernel.
+// cs: running sum of g, cb: running count of non-zero g (their codes 1 = 01b and 2 = 10b hold one bit each): n2 = cs - cb,
+// n1 = 2 cb - cs.
+__device__ __forceinline__ void hcx_row(const u4_t& glo, const u4_t& ghi, unsigned& p, unsigned& bad, unsigned& top) {
   const unsigned w01 = __builtin_amdgcn_perm(glo[3], glo[1], 0x0c0c0703u);
   const unsigned w23 = __builtin_amdgcn_perm(ghi[3], ghi[1], 0x07030c0cu);
-  unsigned p = ((w01 | w23) >> 5) & 0x03030303u;
+  const unsigned w = w01 | w23;
+  top |= w;
+  p = (w >> 5) & 0x03030303u;
+  constexpr unsigned kAdd = 0x00100000u, kBits = 0xBFEFFFFFu;
+  const unsigned i0 = ((glo[1] + kAdd) & kBits) | glo[0], i1 = ((glo[3] + kAdd) & kBits) | glo[2],
+                 i2 = ((ghi[1] + kAdd) & kBits) | ghi[0], i3 = ((ghi[3] + kAdd) & kBits) | ghi[2];
+  bad = (i0 | i1) | (i2 | i3);
+}
+// the lane holds an entry that is not a hard call: its mask bytes (0x01 per such entry); their codes are cleared
+__device__ __forceinline__ unsigned hcx_row_masked(const u4_t& glo, const u4_t& ghi, unsigned& p) {
   constexpr unsigned kAdd = 0x00100000u, kBits = 0xBFEFFFFFu;
   const unsigned i0 = ((glo[1] + kAdd) & kBits) | glo[0], i1 = ((glo[3] + kAdd) & kBits) | glo[2],
                  i2 = ((ghi[1] + kAdd) & kBits) | ghi[0], i3 = ((ghi[3] + kAdd) & kBits) | ghi[2];
   auto one = [](unsigned x) { return x < 1u ? x : 1u; };  // v_min_u32
-  unsigned m = one(i0) | (one(i1) << 8) | (one(i2) << 16) | (one(i3) << 24);
-  if (MASKED) {
-    p = valid ? p : 0u;
-    m = valid ? m : 0u;
-  }
-  const unsigned m3 = m * 3u;
-  p &= ~m3;
-  pk = p;
-  mk = m;
+  const unsigned m = one(i0) | (one(i1) << 8) | (one(i2) << 16) | (one(i3) << 24);
+  p &= ~(m * 3u);
+  return m;
+}
+// sums and burden hits of the (cleaned) codes.  fx: 0x02 in every byte when the column is predicted flipped — (int)(2 - g) > 0
+// <=> g != 2; a masked entry (code 0 after the clean-up) counts as 0 there, i.e. it would count for a flipped column: the
+// rare path takes its bits out of h again (hcx_note)
+__device__ __forceinline__ void hcx_sums(unsigned p, unsigned fx, unsigned& cs, unsigned& cb, unsigned& h) {
   cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
-  cs2 = __builtin_amdgcn_sad_u8((p & 0x01010101u) | ((p & 0x02020202u) << 1), 0u, cs2);  // g^2: 0 / 1 / 4
-  const unsigned t = (p ^ fx) & ~m3;  // flipped column: (int)(2 - g) > 0  <=>  g != 2; a masked entry never counts here
-  h += (t | (t >> 1)) & 0x01010101u;  // (gene_flags_hc_kernel sends the gene to the fallback when its mu says it should)
+  cb = (unsigned)__builtin_popcount(p) + cb;
+  const unsigned t = p ^ fx;
+  h += (t | (t >> 1)) & 0x01010101u;
 }
 
 // the rare path of one row-step — a lane that holds a masked entry: OR / AND of the bit patterns and the count of its column,
 // the entry's bit in the slice's mask word of this lane (all in LDS: nothing of it lives in registers)
 __device__ __forceinline__ void hcx_note(const u4_t& glo, const u4_t& ghi, unsigned m, int T, unsigned* mkw, unsigned* cmw,
-                                         unsigned* oa) {
+                                         unsigned* oa, unsigned& anym, unsigned& h, unsigned fx) {
+  anym = 1u;
+  h -= m & (fx >> 1);  // (hcx_sums counts a cleared code in a flipped column: a masked entry never counts in the in-pass collapse)
   hc_note_masked(glo, ghi, m, oa);
   const unsigned nib = (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xfu;
   __hip_atomic_fetch_or(mkw, nib << (4 * T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -186,13 +204,12 @@ __device__ __forceinline__ void hcx_note(const u4_t& glo, const u4_t& ghi, unsig
 __device__ __forceinline__ unsigned hcx_burden_bytes(unsigned h, int v, unsigned& cnt) {
   const unsigned cc = ((h + 0x7f7f7f7fu) >> 7) & 0x01010101u;  // n > 0 (n < 128)
   cnt += (unsigned)__builtin_popcount(cc);
-  unsigned lo = 0u, hi = 0u;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const unsigned n = (h >> (8 * l)) & 0xffu, n2 = n * n;
-    lo |= (n2 & 127u) << (8 * l);
-    hi |= (n2 >> 7) << (8 * l);
-  }
+  // n^2 of the four counts as packed 16-bit products (n <= 80: n^2 < 2^13)
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 a = __builtin_bit_cast(us2, h & 0x00ff00ffu), b = __builtin_bit_cast(us2, (h >> 8) & 0x00ff00ffu);
+  const unsigned s02 = __builtin_bit_cast(unsigned, a * a), s13 = __builtin_bit_cast(unsigned, b * b);
+  const unsigned lo = (s02 & 0x007f007fu) | ((s13 & 0x007f007fu) << 8);
+  const unsigned hi = ((s02 >> 7) & 0x00ff00ffu) | (((s13 >> 7) & 0x00ff00ffu) << 8);
   return v == 0 ? cc : (v == 1 ? h : (v == 2 ? lo : (v == 3 ? hi : 0u)));
 }
 
@@ -201,75 +218,108 @@ __device__ __forceinline__ unsigned hcx_burden_bytes(unsigned h, int v, unsigned
 // the sample's weight V_i) onto a small list in the wave's own LDS scratch, then ALL lanes share the items (entry, null
 // column k | column k of the sample's row): the digits of the null tile's row from global memory resp. one LDS read of the
 // packed integer and of the mask word, and the integer atomics.  A list that is full is worked off and refilled (a slice
-// with many missing calls takes several rounds).  Clears the wave's mask words behind itself.
+// with many missing calls takes several rounds).  Clears the slice's mask words behind itself.  Run by the TILE wave of
+// the slice's number after the iteration's barrier: the tile waves have time to spare, the loaders do not.
 // dgb: the digits of v of this slice (LDS digit stage); xq_slice: the null tile's digit planes of this slice (LDS stage).
+// (Inlined, and the pointers carry their address spaces.  As an out-of-line function taking generic pointers every LDS access
+//  became a FLAT instruction — which queues in the vector-memory pipeline the loaders keep full: 12 000 cycles for five
+//  entries — and its return waited for the table atomics to complete, a round trip to memory under full load.)
+typedef __attribute__((address_space(3))) char hcx_lchar;
+typedef __attribute__((address_space(3))) unsigned hcx_luint;
+typedef __attribute__((address_space(1))) unsigned long long hcx_gull;
 template <int MT>
-__device__ __noinline__ void hcx_masked_slice(const char* slice, const char* dgb, char* wscratch, int lane,
-                                              unsigned long long* pq, int Mp, const char* xq_slice, int ncols) {
-  const char* pkb = slice;
-  unsigned* mkb = reinterpret_cast<unsigned*>(wscratch);
-  unsigned* cntw = reinterpret_cast<unsigned*>(wscratch + hcx_mk_bytes(MT));
-  unsigned* list = cntw + 4;
+__device__ __forceinline__ void hcx_masked_slice(const hcx_lchar* pkb, const hcx_lchar* dgb, hcx_luint* mkb, hcx_luint* cntw, int lane,
+                                              hcx_gull* pq, int Mp, const hcx_lchar* xq_slice, int ncols) {
+  hcx_luint* list = cntw + 4;
+  hcx_luint* upd = list + kHcxListCap * 3;
   const int v = lane & 15, q = lane >> 4;
   unsigned word[MT];
 #pragma unroll
   for (int c = 0; c < MT; ++c) word[c] = mkb[c * 64 + lane];
-  bool more = true;
-  while (more) {
-    if (lane == 0) cntw[0] = 0u;
-    asm volatile("" ::: "memory");
-    bool full = false;
+  // rank of this lane among the lanes of `mask` (wave-uniform compaction without atomics: the whole wave runs this code)
+  auto rank_of = [&](unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  };
+  for (;;) {
+    // ---- a round of entries: every lane that still holds masked entries hands over one per turn, until the list is full
+    int E = 0;
+    for (;;) {
+      int c0 = -1;
 #pragma unroll
-    for (int c0 = 0; c0 < MT; ++c0) {
-      while (word[c0] && !full) {
-        const unsigned idx = __hip_atomic_fetch_add(cntw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (idx >= (unsigned)kHcxListCap) {
-          full = true;
-          break;
-        }
-        const int b = __builtin_ctz(word[c0]);
-        word[c0] &= word[c0] - 1;
+      for (int c = MT - 1; c >= 0; --c) c0 = word[c] ? c : c0;
+      const unsigned long long have = __builtin_amdgcn_ballot_w64(c0 >= 0);
+      if (have == 0ull || E + __builtin_popcountll(have) > kHcxListCap) break;
+      if (c0 >= 0) {
+        unsigned wsel = 0u;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) wsel = (c == c0) ? word[c] : wsel;
+        const int b = __builtin_ctz(wsel);
+#pragma unroll
+        for (int c = 0; c < MT; ++c) word[c] = (c == c0) ? (word[c] & (word[c] - 1)) : word[c];
         const int T0 = b >> 2, l0 = b & 3;
         // V = sum_p d_p 128^(5 - p): the sample's weight in units of 2^-42 (what the six digit planes encode)
         long long V = 0;
 #pragma unroll
         for (int jp = 0; jp < kHcwPairs; ++jp) {
-          const unsigned* w = reinterpret_cast<const unsigned*>(dgb + ((q * kHcwPairs + jp) * 4 + T0) * 16);
+          const hcx_luint* w = reinterpret_cast<const hcx_luint*>(dgb + ((q * kHcwPairs + jp) * 4 + T0) * 16);
           const int de = (int)(signed char)((w[0] >> (8 * l0)) & 0xffu), dod = (int)(signed char)((w[1] >> (8 * l0)) & 0xffu);
           V = V * 16384 + (long long)(de * 128 + dod);
         }
+        const int idx = E + rank_of(have);
         list[idx * 3 + 0] = (unsigned)(c0 * 16 + v) | ((unsigned)q << 8) | ((unsigned)b << 12);
         list[idx * 3 + 1] = (unsigned)(unsigned long long)V;
         list[idx * 3 + 2] = (unsigned)((unsigned long long)V >> 32);
       }
+      E += __builtin_popcountll(have);
     }
+    if (E == 0) break;  // (nothing left)
     asm volatile("" ::: "memory");
-    const unsigned pushed = cntw[0];
-    const int E = pushed < (unsigned)kHcxListCap ? (int)pushed : kHcxListCap;
+    // ---- The table updates (index, value) are COLLECTED in LDS and applied by all lanes at once: an atomic instruction with
+    // one or two active lanes per item costs as much as a full one, and every vector-memory instruction of this wave queues
+    // behind the loads the loaders keep the memory pipeline full with (~1000 cycles each).
+    int U = 0;
+    auto flush = [&]() {
+      asm volatile("" ::: "memory");
+      for (int u = lane; u < U; u += 64)
+        __hip_atomic_fetch_add(pq + upd[u * 3], ((unsigned long long)upd[u * 3 + 2] << 32) | upd[u * 3 + 1], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      U = 0;
+    };
+    auto add = [&](bool pred, size_t index, unsigned long long val) {  // (called by the whole wave)
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+      const int n = __builtin_popcountll(m);
+      if (U + n > kHcxUpdCap) flush();
+      if (pred) {
+        const int u = U + rank_of(m);
+        upd[u * 3 + 0] = (unsigned)index;
+        upd[u * 3 + 1] = (unsigned)val;
+        upd[u * 3 + 2] = (unsigned)(val >> 32);
+      }
+      U += n;
+    };
     // the null tile's rows of the entries' samples
-    for (int item = lane; item < E * ncols; item += 64) {
-      const int e = item / ncols, kk = item - e * ncols;
+    for (int item0 = 0; item0 < E * ncols; item0 += 64) {
+      const int item = item0 + lane;
+      const bool on = item < E * ncols;
+      const int e = on ? item / ncols : 0, kk = item - e * ncols;
       const unsigned meta = list[e * 3];
       const int j = (int)(meta & 0xffu), q0 = (int)((meta >> 8) & 3u), b = (int)(meta >> 12);
-      const char* src = xq_slice + (kk + 16 * q0) * 16 + b;  // (byte 4 T0 + l0 = b)
-      int dgt[kHcwPlanes];
-#pragma unroll
-      for (int p = 0; p < kHcwPlanes; ++p) dgt[p] = (int)(signed char)src[p * 1024];
+      const hcx_lchar* src = xq_slice + (q0 * ncols + (on ? kk : 0)) * 16 + b;  // (byte 4 T0 + l0 = b)
       long long X = 0;
 #pragma unroll
-      for (int p = 0; p < kHcwPlanes; ++p) X = X * 128 + (long long)dgt[p];
-      __hip_atomic_fetch_add(pq + 2 * (size_t)Mp * Mp + (size_t)j * kHcxNullCols + kk, (unsigned long long)X, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+      for (int p = 0; p < kHcwPlanes; ++p) X = X * 128 + (long long)(signed char)src[p * 4 * ncols * 16];
+      add(on, 2 * (size_t)Mp * Mp + (size_t)j * kHcxNullCols + kk, (unsigned long long)X);
     }
     constexpr int NKC = MT * 16;
-    for (int item0 = lane; item0 < E * NKC; item0 += 128) {  // two items per lane and pass: their LDS reads overlap
+    for (int item0 = 0; item0 < E * NKC; item0 += 128) {  // two items per lane and pass: their LDS reads overlap
       int j[2], k[2], b[2];
       unsigned hw[2], mw[2];
       unsigned long long Vu[2];
       bool on[2];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
-        const int item = item0 + 64 * x;
+        const int item = item0 + lane + 64 * x;
         on[x] = item < E * NKC;
         const int e = on[x] ? item / NKC : 0;
         k[x] = item - e * NKC;
@@ -279,22 +329,17 @@ __device__ __noinline__ void hcx_masked_slice(const char* slice, const char* dgb
         b[x] = (int)(meta >> 12);
         const int q0 = (int)((meta >> 8) & 3u);
         const int slot = on[x] ? (k[x] >> 4) * 64 + (k[x] & 15) + 16 * q0 : 0;
-        hw[x] = *reinterpret_cast<const unsigned*>(pkb + slot * 16 + (b[x] >> 2) * 4);
+        hw[x] = *reinterpret_cast<const hcx_luint*>(pkb + slot * 16 + (b[x] >> 2) * 4);
         mw[x] = mkb[slot];
       }
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const unsigned hval = (hw[x] >> (8 * (b[x] & 3))) & 3u;
-        if (on[x] && hval)
-          __hip_atomic_fetch_add(pq + (size_t)j[x] * Mp + k[x], Vu[x] * hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (on[x] && ((mw[x] >> b[x]) & 1u) && k[x] >= j[x])
-          __hip_atomic_fetch_add(pq + (size_t)Mp * Mp + (size_t)j[x] * Mp + k[x], Vu[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        add(on[x] && hval != 0u, (size_t)j[x] * Mp + k[x], Vu[x] * hval);
+        add(on[x] && ((mw[x] >> b[x]) & 1u) && k[x] >= j[x], (size_t)Mp * Mp + (size_t)j[x] * Mp + k[x], Vu[x]);
       }
     }
-    bool rest = false;
-#pragma unroll
-    for (int c = 0; c < MT; ++c) rest |= word[c] != 0u;
-    more = __builtin_amdgcn_ballot_w64(rest) != 0ull;
+    flush();
   }
 #pragma unroll
   for (int c = 0; c < MT; ++c) mkb[c * 64 + lane] = 0u;
@@ -353,16 +398,19 @@ __device__ __forceinline__ void hcx_gram(i4_t (&acc)[kHcwPairs][NT], const char*
 // a plain int32 sum exact over the 768 operands of the longest wave-part; shifted by 7 bits it would not.
 template <int MT, int NT>
 __device__ __forceinline__ void hcx_null_tiles(i4_t (&acc)[kHcwPairs][NT], i4_t (&accb)[kHcwPlanes], const char* buf, int lane,
-                                               const char* stage) {
+                                               const char* stage, int xslot, int plane_bytes) {
 #pragma unroll 1
   for (int s = 0; s < kHcxNW; ++s) {
     const char* slice = buf + s * hcx_slice_bytes(MT);
     const u4_t* pk = reinterpret_cast<const u4_t*>(slice) + lane;
-    const u4_t* st = reinterpret_cast<const u4_t*>(stage + s * (kHcwPlanes * kHcxPlaneStage)) + lane;
+    const char* st = stage + s * (kHcwPlanes * plane_bytes) + (xslot < 0 ? 0 : xslot);  // (slice s: planes of 4 ncols x 16 B)
     const i4_t ab = hcx_op(pk[MT * 64]);
 #pragma unroll
     for (int j = 0; j < kHcwPairs; ++j) {
-      const i4_t b0 = hcx_op(st[(2 * j) * 64]), b1 = hcx_op(st[(2 * j + 1) * 64]);
+      u4_t q0 = *reinterpret_cast<const u4_t*>(st + (2 * j) * plane_bytes);
+      u4_t q1 = *reinterpret_cast<const u4_t*>(st + (2 * j + 1) * plane_bytes);
+      if (xslot < 0) q0 = q1 = u4_t{0u, 0u, 0u, 0u};  // (a zero column of the null tile)
+      const i4_t b0 = hcx_op(q0), b1 = hcx_op(q1);
 #pragma unroll
       for (int r = 0; r < MT; ++r) {
         const i4_t a = hcx_op(pk[r * 64]);
@@ -374,34 +422,12 @@ __device__ __forceinline__ void hcx_null_tiles(i4_t (&acc)[kHcwPairs][NT], i4_t 
   }
 }
 
-// Tile wave 3: fetch the digits of v of the iteration that starts at 64-sample group g0 into a digit stage buffer (768 bytes per
-// slice = 48 lanes x 16 bytes, as they lie in NullTileX::dq)
-__device__ __forceinline__ void hcx_stage_dq(char* dgbuf, const unsigned char* dq, long long g0, long long n_groups, int lane) {
-  if (lane < kHcxSliceDg / 16) {
-#pragma unroll
-    for (int s = 0; s < kHcxNW; ++s) {
-      long long g = g0 + s;
-      g = g < n_groups ? g : n_groups - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dq + g * kHcxSliceDg + lane * 16),
-                                       (__attribute__((address_space(3))) void*)(dgbuf + s * kHcxSliceDg), 16, 0, 0);
-    }
-  }
-}
-
-// Tile wave 3: fetch the null tile's operands of the iteration that starts at 64-sample group g0 into the LDS stage (LDS-DMA: no
-// registers, 16 bytes per lane, plane and slice, written lane-linear = operand order).  Groups beyond the image are
-// clamped (their genotype operands are zero).
-__device__ __forceinline__ void hcx_stage_xq(char* stage, const unsigned char* xq, long long g0, long long n_groups, int lane) {
-#pragma unroll
-  for (int s = 0; s < kHcxNW; ++s) {
-    long long g = g0 + s;
-    g = g < n_groups ? g : n_groups - 1;
-    const unsigned char* src = xq + g * (kHcwPlanes * 1024) + lane * 16;
-#pragma unroll
-    for (int p = 0; p < kHcwPlanes; ++p)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
-                                       (__attribute__((address_space(3))) void*)(stage + (s * kHcwPlanes + p) * kHcxPlaneStage), 16, 0, 0);
-  }
+// LDS-DMA of `bytes` contiguous bytes (a multiple of 16) from global memory to LDS, 64 lanes x 16 bytes per instruction, lane-linear
+__device__ __forceinline__ void hcx_dma(char* dst, const unsigned char* src, int bytes, int lane) {
+  for (int off = 0; off < bytes; off += 1024)
+    if (off + lane * 16 < bytes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
 }
 
 // pair tiles -> the integer they encode, as a double (one rounding when it exceeds 2^53): p0 2^28 + p1 2^14 + p2
@@ -410,7 +436,7 @@ __device__ __forceinline__ double hcx_pairs_value(int p0, int p1, int p2) {
   return (double)x;
 }
 
-// ring depth of a loader wave per tile class: steps in flight (1, 2 or 4)
+// ring depth of a loader wave per tile class: steps in flight (1 .. 4; 3: the loop body is three iterations)
 constexpr int hcx_ring(int MT) { return MT <= 3 ? 4 : 2; }
 
 template <int MT>
@@ -419,7 +445,8 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
   constexpr int NT = hcx_max_tiles(MT);
   constexpr int RING = hcx_ring(MT);
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;  // 0-3: loader waves (slice w of every iteration), 4-7: tile waves
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0-3: loader waves (slice w of every iteration), 4-7:
+                                                                          // tile waves; wave-uniform, i.e. scalar branches
   const int v = lane & 15, q = lane >> 4;
   const int wpart = blockIdx.x;
   if (wpart >= gd.n_wparts) return;
@@ -430,19 +457,32 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
   if (s_begin >= s_end) return;  // (uniform over the workgroup)
   const int M = gd.M;
   unsigned* const oa_all = reinterpret_cast<unsigned*>(lds + hcx_off_tail(MT));
-  unsigned* const cm_all = oa_all + MT * 64;     // masked count, then sum g, then sum g^2: [3][MT * 16]
+  unsigned* const cm_all = oa_all + MT * 64;     // masked count, then sum g, then the number of non-zero g: [3][MT * 16]
   unsigned* const flagw = cm_all + 3 * MT * 16;  // [0] flags, [1] samples with a non-zero collapsed genotype
+  unsigned* const mflag = flagw + 4;             // [buffer][slice]: the slice holds masked entries
   char* const stage = lds + hcx_off_stage(MT);
   char* const dgstage = lds + hcx_off_dg(MT);
   // OR words = 0, AND words = ~0, counts = 0, flags = 0; the loaders' mask words and the burden operand of every slice = 0
   for (int x = threadIdx.x; x < MT * 64; x += 2 * kHcxNW * 64) oa_all[x] = (x & 2) ? 0xffffffffu : 0u;
-  for (int x = threadIdx.x; x < 3 * MT * 16 + 4; x += 2 * kHcxNW * 64) cm_all[x] = 0u;
-  for (int x = threadIdx.x; x < kHcxNW * MT * 64; x += 2 * kHcxNW * 64)
-    reinterpret_cast<unsigned*>(lds + hcx_off_wave(MT) + (x / (MT * 64)) * hcx_wave_bytes(MT))[x % (MT * 64)] = 0u;
+  for (int x = threadIdx.x; x < 3 * MT * 16 + 4 + 2 * kHcxNW; x += 2 * kHcxNW * 64) cm_all[x] = 0u;
+  for (int x = threadIdx.x; x < kHcxNW * 2 * MT * 64; x += 2 * kHcxNW * 64)
+    reinterpret_cast<unsigned*>(lds + hcx_off_wave(MT) + (x / (2 * MT * 64)) * hcx_wave_bytes(MT))[x % (2 * MT * 64)] = 0u;
   for (int x = threadIdx.x; x < 2 * kHcxNW * 256; x += 2 * kHcxNW * 64)
     reinterpret_cast<unsigned*>(lds + (x / 256) * hcx_slice_bytes(MT) + MT * 1024)[x % 256] = 0u;
   __syncthreads();
 
+#ifdef HCX_PROF
+  long long prof[4] = {0, 0, 0, 0};  // cycles: loaders: load phase, barrier wait, masked entries | tile waves: barrier wait, tiles
+#define HCX_NOW() ((long long)__builtin_readcyclecounter())
+#define HCX_TICK(k, t0) prof[k] += HCX_NOW() - (t0)
+#define HCX_DUMP()                                                                                                       \
+  if (gd.dbg_cmc && lane == 0)                                                                                           \
+    for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(gd.dbg_cmc) + w * 4 + k, (unsigned long long)prof[k])
+#else
+#define HCX_NOW() 0ll
+#define HCX_TICK(k, t0)
+#define HCX_DUMP()
+#endif
   const long long full = N >> 4;  // steps whose 16 samples all exist
   const long long s_fast_end = (s_end < full) ? s_end : full;
   const long long n_fast = (s_fast_end > s_begin) ? (s_fast_end - s_begin) / kHcxIterSteps : 0;
@@ -461,35 +501,44 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
     i4_t accb[kHcwPlanes];  // tile wave 3: the burden tile, one sum per digit plane
 #pragma unroll
     for (int p = 0; p < kHcwPlanes; ++p) accb[p] = i4_t{0, 0, 0, 0};
-    const long long n_groups = (ld + 63) / 64;
-    if (tw == 3) {
-      hcx_stage_dq(dgstage, nt.dq, s_begin >> 2, n_groups, lane);
-      hcx_stage_xq(stage, nt.xq, s_begin >> 2, n_groups, lane);
-    }
+    // tile wave 3's view of the null tile: operand lane (k, q) reads stage entry q ncols + k of a plane
+    const int ncols = nt.ncols;
+    const int plane_bytes = 4 * ncols * 16;
+    const int xslot = (v < ncols) ? (q * ncols + v) * 16 : -1;
     for (long long it = 0; it < n_iter; ++it) {
       const char* buf = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT));
       const char* dgbuf = dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg);
-      if (tw == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages of this iteration have arrived
-      __syncthreads();                                                // ... and so have the loaders' operands
-      const long long g_next = (s_begin + (it + 1) * kHcxIterSteps) >> 2;
+      const long long t_a = HCX_NOW();
+      __syncthreads();  // the loaders' operands and the stages of this iteration have arrived
+      HCX_TICK(0, t_a);
+      const long long t_b = HCX_NOW();
       switch (tw) {
         case 0: hcx_gram<MT, 0, NT>(acc, buf, dgbuf, lane); break;
         case 1: hcx_gram<MT, 1, NT>(acc, buf, dgbuf, lane); break;
         case 2: hcx_gram<MT, 2, NT>(acc, buf, dgbuf, lane); break;
-        default:
-          // (the other stage buffers were last read before this barrier: refill them now, for the next iteration)
-          hcx_stage_dq(dgstage + (int)((it + 1) & 1) * (kHcxNW * kHcxSliceDg), nt.dq, g_next, n_groups, lane);
-#ifndef HCX_XQ_EARLY
-          hcx_null_tiles<MT, NT>(acc, accb, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
-          hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
-#else
-          hcx_stage_xq(stage + (int)((it + 1) & 1) * kHcxStageBuf, nt.xq, g_next, n_groups, lane);
-          hcx_null_tiles<MT, NT>(acc, accb, buf, lane, stage + (int)(it & 1) * kHcxStageBuf);
-#endif
-          break;
+        default: hcx_null_tiles<MT, NT>(acc, accb, buf, lane, stage + (int)(it & 1) * kHcxStageBuf, xslot, plane_bytes); break;
+      }
+      HCX_TICK(1, t_b);
+      // The masked entries of slice tw -> P / Q / R (rare).  Everything it reads is in LDS and stays until the loaders refill
+      // the buffers two iterations later: the slice's operands and mask words, the digits of v, the null tile's planes.
+      if (mflag[(it & 1) * kHcxNW + tw]) {
+        const long long t_c = HCX_NOW();
+        char* ws = lds + hcx_off_wave(MT) + tw * hcx_wave_bytes(MT);
+        unsigned* mkb = reinterpret_cast<unsigned*>(ws + (int)(it & 1) * hcx_mk_bytes(MT));
+        if (gd.pqw)
+          hcx_masked_slice<MT>((const hcx_lchar*)(buf + tw * hcx_slice_bytes(MT)), (const hcx_lchar*)(dgbuf + tw * kHcxSliceDg),
+                               (hcx_luint*)mkb, (hcx_luint*)(ws + 2 * hcx_mk_bytes(MT)), lane, (hcx_gull*)gd.pqw, gd.Mp,
+                               (const hcx_lchar*)(stage + (int)(it & 1) * kHcxStageBuf + tw * (kHcwPlanes * plane_bytes)), ncols);
+        else
+          for (int x = lane; x < MT * 64; x += 64) mkb[x] = 0u;
+        if (lane == 0) {
+          mflag[(it & 1) * kHcxNW + tw] = 0u;
+          __hip_atomic_fetch_or(flagw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        HCX_TICK(2, t_c);
       }
     }
-    if (tw == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA may land after the workgroup has left)
+    HCX_DUMP();
     // ---- partial tiles: element (row, col) -> parts[row * Cp + col], the layout gene_assemble reduces -------------
     auto store_gram = [&](auto wtag) {
       constexpr int W = decltype(wtag)::value;
@@ -562,8 +611,8 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
       double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
       for (int j = lane; j < MT * 16; j += 64) {
         const int c = j >> 4, l = j & 15;
-        const long long nm = cm_all[j], sm = cm_all[MT * 16 + j], sq = cm_all[2 * MT * 16 + j];
-        const long long n2 = (sq - sm) / 2, n1 = 2 * sm - sq, n0 = cnt_w - n1 - n2 - nm;
+        const long long nm = cm_all[j], sm = cm_all[MT * 16 + j], nz = cm_all[2 * MT * 16 + j];  // masked, sum g, # g != 0
+        const long long n2 = sm - nz, n1 = 2 * nz - sm, n0 = cnt_w - n1 - n2 - nm;
         const double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
         const double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
         cst[j] = (double)sm;
@@ -581,10 +630,10 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
   }
 
   // ================================================== loader waves ==================================================
-  char* const wscratch = lds + hcx_off_wave(MT) + w * hcx_wave_bytes(MT);  // this wave's mask words, then its entry list
+  char* const wscratch = lds + hcx_off_wave(MT) + w * hcx_wave_bytes(MT);  // this slice's mask words (two buffers)
   unsigned* const oa = oa_all + 4 * v;  // this lane's column of row tile c: oa + 64 c
   unsigned* const cmw = cm_all + v;     //                                     cmw + 16 c
-  unsigned* const mkw = reinterpret_cast<unsigned*>(wscratch) + lane;
+  unsigned* const mkw0 = reinterpret_cast<unsigned*>(wscratch) + lane;
 
   auto uniform = [](const void* p) {
     const unsigned long long a = (unsigned long long)p;
@@ -611,75 +660,100 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
   for (int c = 0; c < MT; ++c) fxb |= (int)((gd.pflip[c] >> v) & 1) << c;
   auto fxof = [&](int c) { return (unsigned)__builtin_amdgcn_sbfe(fxb, c, 1) & 0x02020202u; };
 
-  unsigned cs[MT], cs2[MT];
+  unsigned cs[MT], cb[MT];
 #pragma unroll
-  for (int c = 0; c < MT; ++c) cs[c] = cs2[c] = 0u;
-  unsigned code3 = 0u, anym = 0u, cnt = 0u;
+  for (int c = 0; c < MT; ++c) cs[c] = cb[c] = 0u;
+  unsigned top = 0u, anym = 0u, cnt = 0u;
 
-  // The masked entries of a slice -> P / Q / R (rare), AFTER the iteration's barrier: the slice's operands stay valid until
-  // the loaders refill the buffer two iterations later, the digits of v of the iteration are in the digit stage from that
-  // barrier on (and so are the null tile's planes), and the tile waves multiply meanwhile.
-  auto masked_entries = [&](const char* slice, const char* dgslice, const char* xqslice) {
+  // The digits of v and the null tile's planes of this wave's slice of iteration i -> the stage buffers i & 1 (LDS-DMA: no
+  // registers, three instructions).  Issued at the start of the load phase, i.e. before the ring's refills: see the wait
+  // in front of the barrier.  The buffers were last read two iterations ago.
+  const int xq_group = kHcwPlanes * 4 * nt.ncols * 16;
+  auto fetch_operands = [&](long long i) {
+    const long long g = ((s_begin + i * kHcxIterSteps) >> 2) + w;
+    hcx_dma(dgstage + (int)(i & 1) * (kHcxNW * kHcxSliceDg) + w * kHcxSliceDg, nt.dq + g * kHcxSliceDg, kHcxSliceDg, lane);
+    hcx_dma(stage + (int)(i & 1) * kHcxStageBuf + w * xq_group, nt.xq + g * xq_group, xq_group, lane);
+  };
+  // a slice with masked entries: tell the tile wave that treats it (before the iteration's barrier)
+  auto flag_masked = [&](long long i) {
     if (__builtin_amdgcn_ballot_w64(anym != 0u) != 0ull) {
-      asm volatile("" ::: "memory");
-      if (gd.pqw)
-        hcx_masked_slice<MT>(slice, dgslice, wscratch, lane, gd.pqw, gd.Mp, xqslice, nt.ncols);
-      else
-        for (int x = lane; x < MT * 64; x += 64) reinterpret_cast<unsigned*>(wscratch)[x] = 0u;
-      if (lane == 0) __hip_atomic_fetch_or(flagw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) mflag[(i & 1) * kHcxNW + w] = 1u;
       anym = 0u;
     }
   };
-
   long long it = 0;
-  if (n_fast > 0) {
+  constexpr int UNR = (RING == 3) ? 3 : 1;  // iterations per unrolled body: the ring index of a step must be a constant
+  const long long n_body = n_fast / UNR;
+  if (n_body > 0) {
     // Rolling refill: a ring of RING genotype step buffers; as soon as a tile row of a step has been consumed its registers
-    // are the destination of the same row of the wave's step RING steps ahead (across the iteration boundary).
+    // are the destination of the same row of the wave's step RING steps ahead (across iteration boundaries: the wave's
+    // steps 4 i + u lie 16 steps apart from iteration to iteration).  Iterations left over by the unrolled body (RING = 3:
+    // up to two, at the end of a gene only — the host cuts wave-parts in multiples of 3 iterations) take the ragged loop.
     unsigned offF = vfull + (unsigned)((s_begin + 4 * w) * 128), offL = vlast + (unsigned)((s_begin + 4 * w) * 128);
     u4_t glo[RING][MT], ghi[RING][MT];
+    auto gload2 = [&](int c, int n_ahead, int half) {  // the wave's step n_ahead (counted from the body's first step)
+      const int imm = (n_ahead & 3) * 128 + half * 16;
+      const unsigned so = (unsigned)((n_ahead >> 2) * kHcxIterSteps * 128);  // whole iterations: a scalar offset
+      return (c == MT - 1) ? __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, offL + imm, so, 0))
+                           : __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, offF + imm, c * tile_bytes + so, 0));
+    };
 #pragma unroll
     for (int r = 0; r < RING; ++r)
 #pragma unroll
       for (int c = 0; c < MT; ++c) {
-        glo[r][c] = gload(c, offF, offL, r * 128);
-        ghi[r][c] = gload(c, offF, offL, r * 128 + 16);
+        glo[r][c] = gload2(c, r, 0);
+        ghi[r][c] = gload2(c, r, 1);
       }
-    for (; it < n_fast; ++it) {
-      char* slice = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT)) + w * hcx_slice_bytes(MT);
-      unsigned* pkw = reinterpret_cast<unsigned*>(slice) + lane * 4;
+    for (long long body = 0; body < n_body; ++body) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rb = u % RING;  // this step's ring buffer
-        const int nxt = (u + RING < 4) ? (u + RING) * 128 : kHcxIterSteps * 128 + (u + RING - 4) * 128;  // RING steps ahead
-        unsigned h = 0;
+      for (int k = 0; k < UNR; ++k, ++it) {
+        const long long t_a = HCX_NOW();
+        char* slice = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT)) + w * hcx_slice_bytes(MT);
+        unsigned* pkw = reinterpret_cast<unsigned*>(slice) + lane * 4;
+        unsigned* mkw = mkw0 + (int)(it & 1) * (MT * 64);
+        fetch_operands(it);
 #pragma unroll
-        for (int c = 0; c < MT; ++c) {
-          unsigned m, p;
-          hcx_row<false>(glo[rb][c], ghi[rb][c], p, m, cs[c], cs2[c], fxof(c), h, true);
-          if (m) hcx_note(glo[rb][c], ghi[rb][c], m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c);
-          anym |= m;
-          code3 |= hc_code3(p);
-          pkw[c * 256 + u] = p;
-          glo[rb][c] = gload(c, offF, offL, nxt);
-          ghi[rb][c] = gload(c, offF, offL, nxt + 16);
+        for (int u = 0; u < 4; ++u) {
+          const int n = 4 * k + u, rb = n % RING;  // this step's ring buffer
+          unsigned h = 0;
+#pragma unroll
+          for (int c = 0; c < MT; ++c) {
+            unsigned bad, p;
+            const unsigned fx = fxof(c);
+            hcx_row(glo[rb][c], ghi[rb][c], p, bad, top);
+            if (bad) {
+              const unsigned m = hcx_row_masked(glo[rb][c], ghi[rb][c], p);
+              hcx_note(glo[rb][c], ghi[rb][c], m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c, anym, h, fx);
+            }
+            hcx_sums(p, fx, cs[c], cb[c], h);
+            pkw[c * 256 + u] = p;
+            glo[rb][c] = gload2(c, n + RING, 0);
+            ghi[rb][c] = gload2(c, n + RING, 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          h = row16_sum(h);
+          const unsigned bb = hcx_burden_bytes(h, v, cnt);
+          if (v < 4) pkw[MT * 256 + u] = bb;
           __builtin_amdgcn_sched_barrier(0);
         }
-        h = row16_sum(h);
-        const unsigned bb = hcx_burden_bytes(h, v, cnt);
-        if (v < 4) pkw[MT * 256 + u] = bb;
-        __builtin_amdgcn_sched_barrier(0);
+        flag_masked(it);
+        HCX_TICK(0, t_a);
+        const long long t_b = HCX_NOW();
+        // (loads return in order: with only the ring's RING x MT x 2 loads outstanding, the DMA issued before them has landed)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING * MT * 2) : "memory");
+        __syncthreads();
+        HCX_TICK(1, t_b);
       }
-      __syncthreads();
-      masked_entries(slice, dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg) + w * kHcxSliceDg,
-                     stage + (int)(it & 1) * kHcxStageBuf + w * (kHcwPlanes * kHcxPlaneStage));
-      offF += kHcxIterSteps * 128;
-      offL += kHcxIterSteps * 128;
+      offF += UNR * kHcxIterSteps * 128;
+      offL += UNR * kHcxIterSteps * 128;
     }
   }
   for (; it < n_iter; ++it) {  // ragged end: every step loaded from a clamped position and masked
     const long long s0 = s_begin + it * kHcxIterSteps + 4 * w;
     char* slice = lds + (int)(it & 1) * (kHcxNW * hcx_slice_bytes(MT)) + w * hcx_slice_bytes(MT);
     unsigned* pkw = reinterpret_cast<unsigned*>(slice) + lane * 4;
+    unsigned* mkw = mkw0 + (int)(it & 1) * (MT * 64);
+    fetch_operands(it);
 #pragma unroll 1
     for (int u = 0; u < 4; ++u) {
       const long long su = s0 + u;
@@ -694,25 +768,31 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
 #pragma unroll
       for (int c = 0; c < MT; ++c) {
         const u4_t glo = gload(c, vfull + so, vlast + so, 0), ghi = gload(c, vfull + so, vlast + so, 16);
-        unsigned m, p;
-        hcx_row<true>(glo, ghi, p, m, cs[c], cs2[c], fxof(c), h, valid);
-        if (m) hcx_note(glo, ghi, m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c);
-        anym |= m;
-        code3 |= hc_code3(p);
+        unsigned bad, p;
+        const unsigned fx = fxof(c);
+        hcx_row(glo, ghi, p, bad, top);
+        p = valid ? p : 0u;
+        bad = valid ? bad : 0u;
+        if (bad) {
+          const unsigned m = hcx_row_masked(glo, ghi, p);
+          hcx_note(glo, ghi, m, u, mkw + 64 * c, cmw + 16 * c, oa + 64 * c, anym, h, fx);
+        }
+        hcx_sums(p, valid ? fx : 0u, cs[c], cb[c], h);
         pkw[c * 256 + u] = p;
       }
       h = row16_sum(h) & vmask;
       const unsigned bb = hcx_burden_bytes(h, v, cnt);
       if (v < 4) pkw[MT * 256 + u] = bb;
     }
+    flag_masked(it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    masked_entries(slice, dgstage + (int)(it & 1) * (kHcxNW * kHcxSliceDg) + w * kHcxSliceDg,
-                   stage + (int)(it & 1) * kHcxStageBuf + w * (kHcwPlanes * kHcxPlaneStage));
   }
+  HCX_DUMP();
   // ---- byte sums, counts and flags of the loader waves meet in LDS (integers: any order) ---------------------------------
 #pragma unroll
   for (int c = 0; c < MT; ++c) {
-    unsigned sc = cs[c], sq = cs2[c];
+    unsigned sc = cs[c], sq = cb[c];
     sc += __shfl_xor(sc, 16, 64);
     sq += __shfl_xor(sq, 16, 64);
     sc += __shfl_xor(sc, 32, 64);
@@ -727,7 +807,7 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
     unsigned cn = (v == 0) ? cnt : 0u;
     cn += __shfl_xor(cn, 16, 64);
     cn += __shfl_xor(cn, 32, 64);
-    const bool c3 = __builtin_amdgcn_ballot_w64(code3 != 0u) != 0ull;
+    const bool c3 = __builtin_amdgcn_ballot_w64((top & 0x80808080u) != 0u) != 0ull;  // a negative value, -inf or NaN was met
     if (lane == 0) {
       __hip_atomic_fetch_add(flagw + 1, cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (c3) __hip_atomic_fetch_or(flagw, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -78,8 +78,9 @@ static Null make_null(long long N, int d, unsigned long long seed) {
   nl.V.assign(ld, 0);
   nl.X.assign(16 * ld, 0);
   nl.vq.assign(ld * 8, 0);
-  const long long ngroups = (ld + 63) / 64;
-  nl.xq.assign(ngroups * 6 * 1024, 0);
+  const long long ngroups = (ld + 63) / 64 + 4;  // (four groups of padding: an iteration is fetched as one range)
+  const int ncols = d + 2;
+  nl.xq.assign(ngroups * 6 * 4 * ncols * 16, 0);
   nl.dq.assign(ngroups * 768, 0);
   for (long long i = 0; i < N; ++i) {
     nl.V[i] = (long long)(mix(seed + i) % (1ull << 40));  // v < 1/4
@@ -102,7 +103,7 @@ static Null make_null(long long N, int d, unsigned long long seed) {
       nl.X[(size_t)k * ld + i] = x;
       digits6(x, dg);
       const long long g = i >> 6, T = (i >> 4) & 3, q = (i >> 2) & 3, l = i & 3;
-      for (int p = 0; p < 6; ++p) nl.xq[((size_t)(g * 6 + p) * 64 + k + 16 * q) * 16 + T * 4 + l] = (unsigned char)dg[p];
+      for (int p = 0; p < 6; ++p) nl.xq[(((size_t)(g * 6 + p) * 4 + q) * ncols + k) * 16 + T * 4 + l] = (unsigned char)dg[p];
     }
   }
   for (int k = 0; k < 16; ++k) nl.scale[k] = std::ldexp(1.0, -42 + k % 3);
@@ -400,6 +401,14 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  hipStream_t bst = 0;
+  if (const char* e = getenv("HCX_CUS")) {  // restrict the launches to the LAST k mask bits (the p-value kernel takes the first)
+    const int k = atoi(e), ncu = 256, words = 8;
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = ncu - k; b < ncu; ++b) m[b / 32] |= 1u << (b % 32);
+    CK(hipExtStreamCreateWithCUMask(&bst, words, m));
+    printf("launches restricted to %d CUs\n", k);
+  }
   for (int Mtop : Ms) {
     const int MT = (Mtop + 15) / 16;
     const int Mlo = spread ? (MT == 2 ? 20 : 16 * (MT - 1) + 1) : Mtop, Mhi = spread ? 16 * MT : Mtop;
@@ -416,23 +425,23 @@ int main(int argc, char** argv) {
       for (const GeneDesc& g : D.gds) sumM += g.M;
 #ifdef HCX_PROF
       unsigned long long* dprof;
-      CK(hipMalloc(&dprof, 16 * 8));
-      CK(hipMemset(dprof, 0, 16 * 8));
+      CK(hipMalloc(&dprof, 32 * 8));
+      CK(hipMemset(dprof, 0, 32 * 8));
       for (GeneDesc& g : D.gds) g.dbg_cmc = reinterpret_cast<double*>(dprof);
       CK(hipMemcpy(D.dgd, D.gds.data(), sizeof(GeneDesc) * ngenes, hipMemcpyHostToDevice));
 #endif
       auto launch = [&]() {
         if (variant == 0)
-          hipLaunchKernelGGL(hcw_kernel(MT), dim3(nw, ngenes), dim3(64), 0, 0, D.dgd, ntw, N, ld, d);
+          hipLaunchKernelGGL(hcw_kernel(MT), dim3(nw, ngenes), dim3(64), 0, bst, D.dgd, ntw, N, ld, d);
         else
-          hipLaunchKernelGGL(hcx_kernel(MT), dim3(nw, ngenes), dim3(2 * kHcxNW * 64), 0, 0, D.dgd, ntx, N, ld, d);
+          hipLaunchKernelGGL(hcx_kernel(MT), dim3(nw, ngenes), dim3(2 * kHcxNW * 64), 0, bst, D.dgd, ntx, N, ld, d);
       };
       launch();
       CK(hipDeviceSynchronize());
       const int reps = 5;
-      CK(hipEventRecord(e0, 0));
+      CK(hipEventRecord(e0, bst));
       for (int r = 0; r < reps; ++r) launch();
-      CK(hipEventRecord(e1, 0));
+      CK(hipEventRecord(e1, bst));
       CK(hipEventSynchronize(e1));
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
@@ -442,12 +451,15 @@ int main(int argc, char** argv) {
              bytes / (ms * 1e-3) / 1e12);
 #ifdef HCX_PROF
       if (variant) {
-        unsigned long long hp[16];
+        unsigned long long hp[32];
         CK(hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
         const double nwg = (double)nw * ngenes * (reps + 1), niter = nwg * (double)(spw / kHcxIterSteps);
         for (int w = 0; w < 4; ++w)
-          printf("   wave %d cycles per iteration: load %.0f  masked %.0f  barrier %.0f  tiles %.0f\n", w, hp[w * 4] / niter,
-                 hp[w * 4 + 1] / niter, hp[w * 4 + 2] / niter, hp[w * 4 + 3] / niter);
+          printf("   loader %d cycles per iteration: load %.0f  barrier %.0f  masked %.0f\n", w, hp[w * 4] / niter,
+                 hp[w * 4 + 1] / niter, hp[w * 4 + 2] / niter);
+        for (int w = 4; w < 8; ++w)
+          printf("   tile wave %d cycles per iteration: barrier %.0f  tiles %.0f  masked %.0f\n", w - 4, hp[w * 4] / niter,
+                 hp[w * 4 + 1] / niter, hp[w * 4 + 2] / niter);
       }
 #endif
       D.free_all();

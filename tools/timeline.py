@@ -9,6 +9,9 @@ from collections import defaultdict
 
 
 def short(name):
+    if "gene_suffstat_hcx" in name:
+        i = name.find("<")
+        return "K2hcx" + name[i:name.find(">", i) + 1].replace(" ", "")
     if "gene_suffstat_hcw" in name:
         i = name.find("<")
         return "K2hcw" + name[i:name.find(",", i)].replace(" ", "") + ">"
