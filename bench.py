@@ -437,14 +437,17 @@ def main():
     counts = [args.genes] * world
     inflight = []
 
-    last_gather = {"n": None, "ordered": None}
+    last_gather = {"n": None, "ordered": None, "seconds": 0.0, "calls": 0}
 
     def retire(b):
         """step finished on this rank: C2 = gather its per-gene records on rank 0 (gene order)"""
         if world > 1:
             rec = shard.records_from_results(b["out"])
             rec[:, 0] += rank * args.genes          # gene ids are rank-local: make them global for the ordered merge
+            tg = time.perf_counter()
             allr = shard.gather_records(dist, rec, counts, device=dev if backend == "nccl" else None, dst=0)
+            last_gather["seconds"] += time.perf_counter() - tg
+            last_gather["calls"] += 1
             if rank == 0:
                 last_gather["n"] = int(allr.shape[0])
                 last_gather["ordered"] = bool(np.array_equal(allr[:, 0], np.arange(world * args.genes)))
@@ -477,11 +480,20 @@ def main():
     eng.timing(reset=True)
     t0 = time.perf_counter()
     run_steps(args.steps)
+    own_elapsed = time.perf_counter() - t0       # (this rank's own steps, before the barrier: per-rank rate below)
     barrier()
     elapsed = time.perf_counter() - t0
     tm = eng.timing(reset=True)
     eng.set_profiling(False)
     elapsed = max_over_ranks(elapsed)
+    # every rank's own rate and C2 time, for rank 0's line: the first real multi-GPU run is self-checking
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([args.genes * args.steps / own_elapsed, last_gather["seconds"] / max(last_gather["calls"], 1)],
+                            dtype=torch.float64, device=dev if backend == "nccl" else None)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        per_rank = [[float(t[0]), float(t[1])] for t in allm]
 
     if rank == 0:
         total_genes = world * args.genes * args.steps
@@ -493,7 +505,8 @@ def main():
         # the few blocks with imputed means take the general fp64 kernel gene_suffstat_mfma, which runs BESIDE it on
         # a second stream — its numbers are reported separately (an overlapped kernel's own duration is not chip time).
         if tm.n_suffstat_hc_launches > 0:
-            k2_name = "gene_suffstat_hcw" if binary else "gene_suffstat_hc"   # (weighted variant for a binary trait)
+            # (binary trait: the weighted kernels — gene_suffstat_hcx, or gene_suffstat_hcw with RVT_HCX=0 / a null model it does not take)
+            k2_name = eng.hardcall_kernel() or ("gene_suffstat_hcw" if binary else "gene_suffstat_hc")
             if args.dosage:
                 k2_name = "gene_suffstat_lat"                                 # (dosages on the stated decimal lattice)
             n_l, ms_l, by_l = tm.n_suffstat_hc_launches, tm.ms_suffstat_hc, tm.alg_bytes_hc
@@ -514,14 +527,21 @@ def main():
             key += ",binary"
         if args.dosage:                                  # (the dosage workload has PMC passes of its own)
             key += ",dosage,lattice=%d" % args.dosage_lattice
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r3_pmc_traffic_dosage.json" if args.dosage else "r3_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            k2 = pmc["kernels"].get("suffstat_lat" if k2_name == "gene_suffstat_lat" else
-                                    ("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat"))
-            if pmc.get("workload") == key and k2:
+        # (the newest committed PMC summary of exactly this workload: profiles/r*_pmc_traffic*.json, tools/pmc_traffic.py)
+        import glob
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        traffic_src = None
+        for pmc_path in sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic*.json")), reverse=True):
+            try:
+                pmc = json.load(open(pmc_path))
+            except Exception:
+                continue
+            k2 = pmc.get("kernels", {}).get("suffstat_lat" if k2_name == "gene_suffstat_lat" else
+                                            ("suffstat_hc" if k2_name.startswith("gene_suffstat_hc") else "suffstat"))
+            if pmc.get("workload") == key and k2 and pmc.get("kernel_name", k2_name) == k2_name:
                 traffic = k2["hbm_bytes_per_step"] / k2["launches_per_step"]
+                traffic_src = os.path.basename(pmc_path)
+                break
         line = {
             "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",
             "value": value, "unit": "gene-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -539,7 +559,7 @@ def main():
                        "genes_handed_back_per_step": tm.genes_handed_back / max(args.steps, 1),
                        "genes_with_imputed_columns": 0.0 if args.dosage else args.missing_frac},
             "roofline": {"kernel": k2_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": ms_k2, "launches": int(n_l),
                          "general_fp64_kernel": {"kernel": "gene_suffstat_mfma", "launches": int(n_g),
@@ -560,6 +580,10 @@ def main():
             except Exception as e:                        # (secondary figures must never cost the line)
                 line["from_host"] = {"error": repr(e)[:300]}
         if world > 1:
+            line["ranks_seen"] = int(dist.get_world_size())
+            line["devices_seen_by_rank0"] = int(torch.cuda.device_count())
+            line["per_rank_gene_sets_per_s"] = [r[0] for r in per_rank]
+            line["c2_gather_ms_per_step_by_rank"] = [1e3 * r[1] for r in per_rank]
             line["gathered_records_last_step"] = last_gather["n"]
             line["gathered_ids_in_order"] = last_gather["ordered"]
         if world == 1 and not args.no_cpu_baseline and args.cpu_genes > 0:
@@ -598,10 +622,21 @@ def main():
                         line["cpu_baseline"]["native_build"] = {
                             "value": 1.0 / one_n[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
                             "flags": "g++ -O3 -march=native", "seconds": one_n[k1]["seconds"]}
+                # ... and with the N-sized products (A'B, A'diag(w)B) register-blocked 4 x 4 with 4-wide vectors instead of
+                # one dot product per output (oracle/orc_linalg.cpp, -DORC_BLOCKED_GEMM): what a BLAS-class inner kernel gives
+                blk = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "liboracle_blocked.so")
+                if os.path.exists(blk):
+                    one_b, _ = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, 1, library=blk)
+                    if one_b:
+                        line["cpu_baseline"]["blocked_gemm_build"] = {
+                            "value": 1.0 / one_b[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
+                            "flags": "g++ -O3 -march=native -DORC_BLOCKED_GEMM", "seconds": one_b[k1]["seconds"]}
             recs, wall = cpu_oracle_pool({k: host[k] for k in pick}, Xh, yh, 1 if binary else 0, workers)
             if recs:
-                line["cpu_baseline_all_cores"] = {
-                    "value": len(pick) / wall, "unit": "gene-sets/s", "cores": workers, "kind": "port",
+                # (named for what it is: `workers` single-thread processes — one per sampled gene, bounded by memory —, NOT every
+                #  core of the host; the default sample keeps the whole bench inside a few minutes)
+                line["cpu_baseline_multiproc"] = {
+                    "value": len(pick) / wall, "unit": "gene-sets/s", "cores": workers, "host_cores": ncpu, "kind": "port",
                     "sample": "%d genes of the batch (M %d..%d) dealt to %d single-thread processes at once, %.1f s wall "
                               "(process start-up and one null fit per process included); host has %d cores"
                               % (len(pick), min(Ms[k] for k in pick), max(Ms[k] for k in pick), workers, wall, ncpu)}

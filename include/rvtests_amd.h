@@ -207,8 +207,13 @@ int rvt_host_unregister(rvt_ctx* ctx, const void* ptr);
  * (src/DataConsolidator.cpp:217-245) has filled — hard calls plus ONE other value in the places of the missing calls —
  * stays on that kernel: the other value is carried as a 0/1 mask, three integer matrices and one multiplication per
  * entry of G'G.  Under a binary trait (weights v = p (1 - p)) the weighted Gram matrix takes the int8 cores as well, with
- * v split once per null model into six 7-bit digit planes (suffstat_hcw.hip.h; M <= 80, weights in [0, 0.49], agreement
- * with the fp64 kernel ~1e-12 relative; hard calls only).
+ * v split once per null model into six 7-bit digit planes (M <= 80, weights in [0, 0.49], agreement with the fp64 kernel
+ * ~1e-12 relative).  Round 4 (suffstat_hcx.hip.h, gene tests with d <= 6 covariate columns): a workgroup of eight waves per
+ * wave-part — four stream and pack, four multiply —, the null-model tile [vX | res | v] on the int8 cores too (six digit
+ * planes per column, a power-of-two scale per column; a column whose largest entry exceeds 256 x its root mean square
+ * keeps the model on the one-wave kernel suffstat_hcw.hip.h), every statistic an exact integer of the quantised inputs,
+ * and mean-imputed columns stay on the kernel (sparse integer tables of the masked entries).  RVT_HCX=0 selects the
+ * one-wave kernel, which hands a gene with an imputed column to the fp64 kernel.
  * NOTHING is remembered about the content of a block.  The integer kernels test every value they load; a block that
  * holds anything else (dosages) is handed back and computed by the fp64 kernel in the same call — the records are the
  * same either way.  Which kernel a block starts on is a prediction: what the engine's own decoders wrote; for the
@@ -219,6 +224,10 @@ int rvt_host_unregister(rvt_ctx* ctx, const void* ptr);
  * rvt_block_classify is a query for tools and tests: one streaming pass, 1 when every entry is 0.0 / 1.0 / 2.0. */
 int rvt_block_classify(rvt_ctx* ctx, const double* dG, int M, int* is_hard_call);
 int rvt_set_content_hint(rvt_ctx* ctx, int hint);
+/* Which sufficient-statistics kernel the hard-call genes of the installed null model take (for tools: bench.py names the
+ * kernel its roofline line is about): 0 none (no null model / hard-call path off), 1 gene_suffstat_hc (quantitative trait),
+ * 2 gene_suffstat_hcw (binary trait, one wave per part), 3 gene_suffstat_hcx (binary trait, cooperative workgroups). */
+int rvt_hardcall_kernel(const rvt_ctx* ctx);
 /* Dosages on a decimal lattice.  `rvtest --dosage DS` (src/Main.cpp FLAG_dosageTag; VCFGenotypeExtractor) hands fit() the
  * doubles strtod made of a VCF field printed with a fixed number of decimals — imputation servers write three — i.e. the
  * doubles nearest to K / denominator, K an integer, denominator = 10^decimals.  When the adapter states the denominator

@@ -1082,6 +1082,13 @@ int rvt_set_dosage_lattice(rvt_ctx* c, int denominator) {
   return RVT_OK;
 }
 
+int rvt_hardcall_kernel(const rvt_ctx* c) {
+  if (!c || !c->have_null || !c->hc_enabled) return 0;
+  if (!c->nc.binary) return 1;
+  if (c->hcx_ok) return 3;
+  return (c->d_nulltile_w && c->d_vq) ? 2 : 0;
+}
+
 int rvt_set_content_hint(rvt_ctx* c, int hint) {
   if (!c || hint < -1 || hint > 1) return fail(c, RVT_E_INVALID, "hint must be -1, 0 or 1");
   c->content_hint = hint;

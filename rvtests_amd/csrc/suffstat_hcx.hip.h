@@ -227,9 +227,20 @@ __device__ __forceinline__ unsigned hcx_burden_bytes(unsigned h, int v, unsigned
 typedef __attribute__((address_space(3))) char hcx_lchar;
 typedef __attribute__((address_space(3))) unsigned hcx_luint;
 typedef __attribute__((address_space(1))) unsigned long long hcx_gull;
+// apply the collected table updates (see hcx_masked_slice)
+__device__ __forceinline__ void hcx_apply_updates(hcx_luint* cntw, hcx_gull* pq, int lane, int& U) {
+  hcx_luint* upd = cntw + 4 + kHcxListCap * 3;
+  asm volatile("" ::: "memory");
+  for (int u = lane; u < U; u += 64)
+    __hip_atomic_fetch_add(pq + upd[u * 3], ((unsigned long long)upd[u * 3 + 2] << 32) | upd[u * 3 + 1], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  U = 0;
+}
+
 template <int MT>
 __device__ __forceinline__ void hcx_masked_slice(const hcx_lchar* pkb, const hcx_lchar* dgb, hcx_luint* mkb, hcx_luint* cntw, int lane,
-                                              hcx_gull* pq, int Mp, const hcx_lchar* xq_slice, int ncols) {
+                                              hcx_gull* pq, int Mp, const hcx_lchar* xq_slice, int ncols, int& U) {
   hcx_luint* list = cntw + 4;
   hcx_luint* upd = list + kHcxListCap * 3;
   const int v = lane & 15, q = lane >> 4;
@@ -276,8 +287,8 @@ __device__ __forceinline__ void hcx_masked_slice(const hcx_lchar* pkb, const hcx
     asm volatile("" ::: "memory");
     // ---- The table updates (index, value) are COLLECTED in LDS and applied by all lanes at once: an atomic instruction with
     // one or two active lanes per item costs as much as a full one, and every vector-memory instruction of this wave queues
-    // behind the loads the loaders keep the memory pipeline full with (~1000 cycles each).
-    int U = 0;
+    // behind the loads the loaders keep the memory pipeline full with (~1000 cycles each).  The collection lives on from
+    // slice to slice (U: its fill, kept by the caller) and is applied when it is nearly full, and at the end of the wave-part.
     auto flush = [&]() {
       asm volatile("" ::: "memory");
       for (int u = lane; u < U; u += 64)
@@ -334,12 +345,14 @@ __device__ __forceinline__ void hcx_masked_slice(const hcx_lchar* pkb, const hcx
       }
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
+        // (column k of the sample is either a hard call — its code goes to P — or masked — Q —, never both)
         const unsigned hval = (hw[x] >> (8 * (b[x] & 3))) & 3u;
-        add(on[x] && hval != 0u, (size_t)j[x] * Mp + k[x], Vu[x] * hval);
-        add(on[x] && ((mw[x] >> b[x]) & 1u) && k[x] >= j[x], (size_t)Mp * Mp + (size_t)j[x] * Mp + k[x], Vu[x]);
+        const bool isq = ((mw[x] >> b[x]) & 1u) != 0u;
+        const size_t cell = (size_t)j[x] * Mp + k[x];
+        add(on[x] && (hval != 0u || (isq && k[x] >= j[x])), isq ? (size_t)Mp * Mp + cell : cell, isq ? Vu[x] : Vu[x] * hval);
       }
     }
-    flush();
+    if (U > kHcxUpdCap - 48) flush();
   }
 #pragma unroll
   for (int c = 0; c < MT; ++c) mkb[c * 64 + lane] = 0u;
@@ -498,6 +511,7 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
     for (int j = 0; j < kHcwPairs; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[j][t] = i4_t{0, 0, 0, 0};
+    int n_upd = 0;          // masked-entry table updates collected in LDS and not yet applied (hcx_masked_slice)
     i4_t accb[kHcwPlanes];  // tile wave 3: the burden tile, one sum per digit plane
 #pragma unroll
     for (int p = 0; p < kHcwPlanes; ++p) accb[p] = i4_t{0, 0, 0, 0};
@@ -528,7 +542,7 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
         if (gd.pqw)
           hcx_masked_slice<MT>((const hcx_lchar*)(buf + tw * hcx_slice_bytes(MT)), (const hcx_lchar*)(dgbuf + tw * kHcxSliceDg),
                                (hcx_luint*)mkb, (hcx_luint*)(ws + 2 * hcx_mk_bytes(MT)), lane, (hcx_gull*)gd.pqw, gd.Mp,
-                               (const hcx_lchar*)(stage + (int)(it & 1) * kHcxStageBuf + tw * (kHcwPlanes * plane_bytes)), ncols);
+                               (const hcx_lchar*)(stage + (int)(it & 1) * kHcxStageBuf + tw * (kHcwPlanes * plane_bytes)), ncols, n_upd);
         else
           for (int x = lane; x < MT * 64; x += 64) mkb[x] = 0u;
         if (lane == 0) {
@@ -538,6 +552,8 @@ __device__ __forceinline__ void suffstat_hcx_body(const GeneDesc& gd, const Null
         HCX_TICK(2, t_c);
       }
     }
+    if (n_upd > 0)
+      hcx_apply_updates((hcx_luint*)(lds + hcx_off_wave(MT) + tw * hcx_wave_bytes(MT) + 2 * hcx_mk_bytes(MT)), (hcx_gull*)gd.pqw, lane, n_upd);
     HCX_DUMP();
     // ---- partial tiles: element (row, col) -> parts[row * Cp + col], the layout gene_assemble reduces -------------
     auto store_gram = [&](auto wtag) {

@@ -394,6 +394,12 @@ class Engine:
         """Tests / experiments: False keeps every gene on the fp64 kernel (rvt_set_hardcall)."""
         self._check(self.L.rvt_set_hardcall(self.ctx, 1 if on else 0))
 
+    def hardcall_kernel(self):
+        """Name of the kernel the hard-call genes of the installed null model take (rvt_hardcall_kernel), or None."""
+        self.L.rvt_hardcall_kernel.restype = C.c_int
+        self.L.rvt_hardcall_kernel.argtypes = [C.c_void_p]
+        return {1: "gene_suffstat_hc", 2: "gene_suffstat_hcw", 3: "gene_suffstat_hcx"}.get(int(self.L.rvt_hardcall_kernel(self.ctx)))
+
     def set_content_hint(self, hint):
         """What the caller's own fp64 blocks hold: -1 unknown (start on the hard-call kernel), 0 dosages (start on the fp64
         kernel), 1 hard calls / mean-imputed hard calls (rvt_set_content_hint).  Never affects correctness."""
