@@ -493,6 +493,12 @@ int rvt_submit_gene_raw(rvt_ctx* ctx, int64_t gene_id, int M, const double* Graw
                         const rvt_params* params, double* af_out);
 int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
                        const rvt_params* params, double* af_out);
+/* Several genes per call: the hand-off of rvt_submit_gene_raw (kind 1: doubles, negative = missing), rvt_submit_gene_i8
+ * (kind 2) or rvt_submit_gene_bed (kind 3: PLINK 2-bit rows), gene after gene, without allele frequencies returned.  For
+ * callers whose per-call cost (ctypes, JNI, cgo) is not negligible against the ~120 us a packed gene of N = 500 000 needs on
+ * the link; the C++ adapters call the single-gene forms (src/Main.cpp:1221-1254 hands over one gene at a time). */
+int rvt_submit_genes(rvt_ctx* ctx, int kind, int n, const int64_t* gene_ids, const int* M, const void* const* data,
+                     uint32_t tests, const rvt_params* params);
 int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                         const rvt_params* params, double* af_out);
 

@@ -24,8 +24,8 @@
 
 namespace rvt {
 
-// Persistent worker threads that execute batches of memcpy tasks.  One pool per process (contexts share it: the caller
-// is a single thread, src/Main.cpp).  RVT_COPY_THREADS sets the size (default: min(3, hardware threads / 2), at least 1 —
+// Persistent worker threads that execute batches of memcpy tasks.  One pool per process, shared by every context: usually
+// one caller thread (src/Main.cpp), but a device group runs one caller per member at once — batches complete independently.  RVT_COPY_THREADS sets the size (default: min(3, hardware threads / 2), at least 1 —
 // measured on the MI355X host: one thread copies ~30 GB/s, three keep the link busy, eight only disturb each other).
 class CopyPool {
  public:
@@ -61,7 +61,9 @@ class CopyPool {
     Task t{dst, src, bytes};
     run(&t, 1);
   }
-  // run a batch of copies, split into pieces so that every thread has work; returns when all are done
+  // run a batch of copies, split into pieces so that every thread has work; returns when all of THIS batch are done.
+  // Several caller threads may be inside run() at once (one per member of a device group): completion is counted per batch
+  // (round 3 kept one process-wide counter: every caller then also waited for the other callers' pieces).
   void run(const Task* tasks, size_t n) {
     size_t total = 0;
     for (size_t i = 0; i < n; ++i) total += tasks[i].bytes;
@@ -71,37 +73,44 @@ class CopyPool {
       return;
     }
     const size_t piece = std::max<size_t>((size_t)256 << 10, (total / (size_t)(n_ * 2) + 4095) / 4096 * 4096);
+    size_t left = 0;  // pieces of this batch not yet copied (guarded by m_)
     {
       std::lock_guard<std::mutex> lk(m_);
       for (size_t i = 0; i < n; ++i)
         for (size_t o = 0; o < tasks[i].bytes; o += piece) {
-          q_.push_back(Task{(char*)tasks[i].dst + o, (const char*)tasks[i].src + o, std::min(piece, tasks[i].bytes - o)});
-          ++pending_;
+          q_.push_back(Piece{(char*)tasks[i].dst + o, (const char*)tasks[i].src + o, std::min(piece, tasks[i].bytes - o), &left});
+          ++left;
         }
     }
     cv_.notify_all();
     help();  // the calling thread works too
     std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
+    done_.wait(lk, [&left] { return left == 0; });
   }
 
  private:
-  bool take(Task* t) {
+  struct Piece {
+    void* dst;
+    const void* src;
+    size_t bytes;
+    size_t* left;  // the batch's counter
+  };
+  bool take(Piece* t) {
     std::lock_guard<std::mutex> lk(m_);
     if (q_.empty()) return false;
     *t = q_.front();
     q_.pop_front();
     return true;
   }
-  void finish_one() {
+  void finish_one(size_t* left) {
     std::lock_guard<std::mutex> lk(m_);
-    if (--pending_ == 0) done_.notify_all();
+    if (--*left == 0) done_.notify_all();
   }
   void help() {
-    Task t;
+    Piece t;
     while (take(&t)) {
       std::memcpy(t.dst, t.src, t.bytes);
-      finish_one();
+      finish_one(t.left);
     }
   }
   void loop() {
@@ -118,8 +127,7 @@ class CopyPool {
   std::vector<std::thread> workers_;
   std::mutex m_;
   std::condition_variable cv_, done_;
-  std::deque<Task> q_;
-  size_t pending_ = 0;
+  std::deque<Piece> q_;
   bool stop_ = false;
 };
 
@@ -203,11 +211,36 @@ struct StageRing {
     return 0;
   }
   // `rows` rows of `width` bytes, spitch apart on the host, dpitch apart on the device (hipMemcpy2D's meaning)
-  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, CopyPool& pool) {
+  // pad_zero: the destination's pad bytes between rows may be written (with zeros): rows narrower than the device pitch by a
+  // few bytes are then staged AT the device pitch and cross as ONE contiguous DMA
+  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, CopyPool& pool,
+             bool pad_zero = false) {
     if (width == 0 || rows == 0) return 0;
     if (width > chunk_bytes) {  // a row is longer than a chunk: row by row, each in contiguous pieces
       for (size_t r = 0; r < rows; ++r)
         if (int rc = copy((char*)dst + r * dpitch, (const char*)src + r * spitch, width, pool)) return rc;
+      return 0;
+    }
+    // Rows whose device pitch is only a few bytes wider than the rows (the 16-byte padding of packed genotype rows) are
+    // staged AT THE DEVICE PITCH, pad bytes zero, and cross as ONE contiguous DMA: a 2-D copy of fifty 125 KB rows is fifty
+    // DMA commands and ran at 31-35 GB/s of the link's 57 (tools/host_feed_bench: 2-bit genes 5.6 k/s -> see DESIGN 6).
+    if (pad_zero && dpitch > width && dpitch - width <= 64 && dpitch <= chunk_bytes) {
+      const size_t perp = std::max<size_t>(1, chunk_bytes / dpitch);
+      std::vector<CopyPool::Task> tasks;
+      for (size_t r0 = 0; r0 < rows; r0 += perp) {
+        const size_t nr = std::min(perp, rows - r0);
+        const int k = next;
+        next = (next + 1) % (int)chunk.size();
+        if (int rc = wait(k)) return rc;
+        tasks.clear();
+        for (size_t r = 0; r < nr; ++r) {
+          tasks.push_back(CopyPool::Task{chunk[k] + r * dpitch, (const char*)src + (r0 + r) * spitch, width});
+          if (r + 1 < nr) std::memset(chunk[k] + r * dpitch + width, 0, dpitch - width);
+        }
+        pool.run(tasks.data(), tasks.size());
+        if (int rc = send(k, 0, (char*)dst + r0 * dpitch, (nr - 1) * dpitch + width)) return rc;
+        if (int rc = sent(k)) return rc;
+      }
       return 0;
     }
     const size_t per = std::max<size_t>(1, chunk_bytes / width);  // whole rows per chunk, packed

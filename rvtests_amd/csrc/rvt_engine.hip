@@ -1274,7 +1274,8 @@ static int staged_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (c->stage.copy(dst, src, bytes, CopyPool::instance())) return fail(c, RVT_E_HIP, "staged host-to-device copy failed");
   return RVT_OK;
 }
-static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+                         bool pad_zero = false) {
   TraceScope ts(c, &c->tr_copy);
   // Big blocks (the 200 MB of an fp64 gene at N = 500 000) go through the runtime's own pageable path: measured 46-48
   // GB/s of the link's 57 (tools/bench_group_stream.py), which the staged ring does not beat at this size; the call is
@@ -1291,7 +1292,7 @@ static int staged_h2d_2d(rvt_ctx* c, void* dst, size_t dpitch, const void* src, 
   }
   int rc = stage_ready(c);
   if (rc) return rc;
-  if (c->stage.copy2d(dst, dpitch, src, spitch, width, rows, CopyPool::instance()))
+  if (c->stage.copy2d(dst, dpitch, src, spitch, width, rows, CopyPool::instance(), pad_zero))
     return fail(c, RVT_E_HIP, "staged host-to-device copy failed");
   return RVT_OK;
 }
@@ -1500,7 +1501,16 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   const int n_bparts = (int)((N + kBurdenSPB - 1) / kBurdenSPB);
   // binary trait, gene tests: the hard-call genes of the batch take the workgroup-cooperative integer kernel when the null
   // model's operands exist (rvt_set_null); MetaScore slices and debug runs keep the one-wave kernel
-  const bool hcx = nc.binary && c->hcx_ok && c->hc_enabled && !cov && !(dbg && dbg->cmc) && !(tests & RVT_TEST_FAMSKAT);
+  bool hcx = nc.binary && c->hcx_ok && c->hc_enabled && !cov && !(dbg && dbg->cmc) && !(tests & RVT_TEST_FAMSKAT);
+  if (hcx) {  // ... and only if a gene of the batch will start on it (the split of the sample axis follows the kernel: a batch
+              // of dosage blocks must be cut exactly as with the hard-call path off — the same records bit for bit)
+    bool any = false;
+    for (int g = 0; g < n && !any; ++g) {
+      const int k = kind ? kind[g] : -1;
+      any = (Ms[g] + 15) / 16 <= kHcxMaxMT && (k == 1 || (k < 0 && c->content_hint != 0));
+    }
+    hcx = any;
+  }
   int n_wparts, steps_per;
   choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx);
   // ---- sizes ---------------------------------------------------------------------------------------
@@ -5295,7 +5305,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
       if (e == hipSuccess) {
         c->h2d_stream = c->copy_stream;
-        const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M);
+        const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M, true);  // (pad bytes of a packed row are zero anyway)
         c->h2d_stream = c->io_stream;
         if (rcs != RVT_OK) e = hipErrorUnknown;
       }
@@ -5430,6 +5440,19 @@ int rvt_submit_gene_raw(rvt_ctx* c, int64_t gene_id, int M, const double* Graw, 
 int rvt_submit_gene_i8(rvt_ctx* c, int64_t gene_id, int M, const int8_t* G8, uint32_t tests, const rvt_params* prm,
                        double* af_out) {
   return submit_common(c, gene_id, M, G8, 2, nullptr, af_out, tests, prm);
+}
+
+// Several genes per call (the same hand-off as rvt_submit_gene_raw / _i8 / _bed, gene after gene): for callers whose
+// per-call cost is not negligible against the ~120 us a packed gene needs on the link (a ctypes / JNI / cgo caller)
+int rvt_submit_genes(rvt_ctx* c, int kind, int n, const int64_t* gene_ids, const int* M, const void* const* data,
+                     uint32_t tests, const rvt_params* prm) {
+  if (!c || n < 0 || (n > 0 && (!gene_ids || !M || !data))) return fail(c, RVT_E_INVALID, "bad gene list");
+  if (kind < 1 || kind > 3) return fail(c, RVT_E_INVALID, "kind %d: 1 = doubles with missing codes, 2 = int8, 3 = PLINK 2-bit rows", kind);
+  for (int g = 0; g < n; ++g) {
+    const int rc = submit_common(c, gene_ids[g], M[g], data[g], kind, nullptr, nullptr, tests, prm);
+    if (rc) return rc;  // (genes [0, g) are queued; the message names what failed)
+  }
+  return RVT_OK;
 }
 
 // ---- VCF text front end ----------------------------------------------------------------------------------------------
@@ -5726,7 +5749,9 @@ static void pop_collected(rvt_ctx* c, int n, rvt_gene_result* out) {
       r.gene_id = c->queue[g].id;
       r.n_variants = c->queue[g].M;
       r.status = RVT_ST_INPUT_ERROR | RVT_ST_NO_POLY;
-      r.skat_p = r.skato_p = r.cmc_p = r.zeg_p = NAN;
+      // (every p-value field NaN, not 0: a consumer that prints p-values without looking at the *_ok flags must not read
+      //  "most significant")
+      r.skat_p = r.skato_p = r.cmc_p = r.zeg_p = r.perm_pvalue = r.famskat_p = r.famcmc_p = r.famzeg_p = r.vt_p = NAN;
       out[g] = r;
       char who[64];
       snprintf(who, sizeof(who), " of gene %lld", (long long)c->queue[g].id);

@@ -134,6 +134,10 @@ struct rvt_group {
   bool perm_exact = true;      // SKAT permutations replay ONE rand() stream (member 0 only) instead of counter-based keys;
                                // the default of a ONE-member group (= the reference's numbers), off when genes are dealt
   std::string err;
+  // A submission that failed on a member's worker thread (RVT_GROUP_ASYNC): the gene was already counted in `owner`, so the
+  // member now holds fewer records than the group expects.  The group stays FAILED — every call returns this code — until
+  // rvt_group_collect has discarded what is pending and left the group empty again.
+  int failed = RVT_OK;
 };
 
 namespace {
@@ -151,28 +155,30 @@ int next_member(rvt_group* g, const rvt_params* prm, uint32_t tests) {
 }
 // every worker idle (their queues drained): the caller's thread may use the contexts
 int group_flush(rvt_group* g) {
-  for (size_t k = 0; k < g->worker.size(); ++k) {
+  for (size_t k = 0; k < g->worker.size(); ++k) {  // (every worker: none keeps an error behind the first one found)
     MemberWorker& w = *g->worker[k];
     w.flush();
     if (w.err) {
-      const int rc = w.err;
-      g->err = "submit: " + w.errmsg;
+      if (!g->failed) {
+        g->failed = w.err;
+        g->err = "submit (member " + std::to_string(k) + "): " + w.errmsg + " — collect to reset the group";
+      }
       w.err = RVT_OK;
-      return rc;
     }
   }
-  return RVT_OK;
+  return g->failed;
 }
 
 // queue one gene for member k: copy `bytes` of `data` (and the frequencies) now, engine calls on the member's worker
 int group_submit_async(rvt_group* g, int k, int kind, int64_t gene_id, int M, const void* data, size_t bytes,
                        const double* af, uint32_t tests, const rvt_params* prm) {
   MemberWorker& w = *g->worker[k];
-  if (w.err) {  // an earlier job of this member failed
-    const int rc = w.err;
-    g->err = "submit: " + w.errmsg;
+  if (g->failed) return g->failed;
+  if (w.err) {  // an earlier job of this member failed: its gene is counted in `owner` but the member does not hold it
+    g->failed = w.err;
+    g->err = "submit (member " + std::to_string(k) + "): " + w.errmsg + " — collect to reset the group";
     w.err = RVT_OK;
-    return rc;
+    return g->failed;
   }
   MemberWorker::Job j;
   j.kind = kind;
@@ -215,8 +221,16 @@ int rvt_group_init(rvt_group** out, int n_dev, const int* dev_ids) {
     // copy costs more than the overlapped engine calls save (fp64 273 -> 140-157, int8 1 510 -> 266-1 084, 2-bit
     // 1 870-3 220 -> 2 950-3 000 gene-sets/s): the members share one PCIe link there, and the blocks are copied twice.
     // Whether separate links change the balance has not been measured (no multi-GPU box in this environment).
+    // Members on DIFFERENT devices get their feeder threads by default (each has a PCIe link and a staging ring of its own:
+    // the caller's thread only copies the gene into the member's host buffer and moves on; the engine calls — staging copy,
+    // DMA enqueue, launches: ~170 us per packed gene, tools/host_feed_bench — run on the member's thread).  RVT_GROUP_ASYNC=0
+    // turns them off, =1 forces them on.
     const char* e = getenv("RVT_GROUP_ASYNC");
-    if (e && atoi(e) != 0)
+    bool distinct = n_dev > 1;
+    for (int a = 0; a < n_dev && distinct; ++a)
+      for (int b = a + 1; b < n_dev; ++b)
+        if ((dev_ids ? dev_ids[a] : a) == (dev_ids ? dev_ids[b] : b)) distinct = false;
+    if (e ? atoi(e) != 0 : distinct)
       for (rvt_ctx* m : g->member) {
         g->worker.emplace_back(new MemberWorker());
         g->worker.back()->start(m);
@@ -414,9 +428,18 @@ int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
   *n_out = 0;
   const int n = (int)std::min<size_t>(g->owner.size(), (size_t)std::max(cap, 0));
   if (n == 0) return RVT_OK;
-  {
-    const int rcf = group_flush(g);  // every queued gene has reached its member
-    if (rcf) return rcf;
+  if (const int rcf = group_flush(g)) {  // every queued gene has reached its member — or one of them failed on the way:
+    // the members' records no longer line up with the submission order.  Discard what is pending and start clean.
+    std::vector<rvt_gene_result> drop(256);
+    for (rvt_ctx* m : g->member)
+      for (;;) {
+        int nk = 0;
+        if (rvt_collect(m, drop.data(), (int)drop.size(), &nk) != RVT_OK || nk == 0) break;
+      }
+    g->owner.clear();
+    for (auto& q : g->inbox) q.clear();
+    g->failed = RVT_OK;
+    return rcf;
   }
   const int nm = (int)g->member.size();
   std::vector<int> want(nm, 0);

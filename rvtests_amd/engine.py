@@ -507,6 +507,21 @@ class Engine:
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
 
+    def submit_genes(self, kind, gene_ids, arrays, Ms, tests=TEST_ALL, params=None):
+        """Several genes in ONE call (rvt_submit_genes): kind 1 = doubles with missing codes (N x M, Fortran order), 2 = int8
+        (N x M, Fortran order), 3 = PLINK 2-bit rows (pack_bed layout).  The arrays must be contiguous and stay alive until
+        the call returns.  No allele frequencies are returned."""
+        n = len(arrays)
+        prm = params or Params.default()
+        ids = np.ascontiguousarray(gene_ids, dtype=np.int64)
+        ms = np.ascontiguousarray(Ms, dtype=np.int32)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(a.ctypes.data) for a in arrays])
+        self.L.rvt_submit_genes.restype = C.c_int
+        self.L.rvt_submit_genes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p]
+        self._check(self.L.rvt_submit_genes(self.ctx, int(kind), n, ids.ctypes.data_as(C.c_void_p),
+                                            ms.ctypes.data_as(C.c_void_p), ptrs, int(tests), C.byref(prm)))
+
     def fam_analytic_vt(self, ptrs, Ms):
         """FamAnalyticVT of device-resident raw blocks (rvt_fam_analytic_vt); vt_* fields of the records."""
         n = len(ptrs)

@@ -192,3 +192,43 @@ def test_group_meta_score_and_cov_band_equal_the_single_context(engine):
             else:
                 assert abs(band[h, t] - cov0[h, j]) <= 1e-9 * scale, (h, j)
     assert np.allclose(xz, xz0, rtol=1e-9, atol=1e-9 * max(np.abs(xz0).max(), 1.0)) and np.allclose(zz, zz0, rtol=1e-12)
+
+
+def test_group_on_two_devices_matches_single_context(engine):
+    """Members on DIFFERENT devices (the case the group exists for): feeder threads are on by default, the 2-bit and int8
+    hand-offs are dealt over both GPUs, records come back in submission order with the single-context values, and SKAT
+    permutations take the counter-based mode (genes dealt over members cannot share one rand() stream).  Skips on a box with
+    one GPU — every box this suite has run on so far; it runs the day a multi-GPU lease exists."""
+    import torch
+    import rvtests_amd
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    N, d = 4003, 2
+    rng = np.random.default_rng(12)
+    genes = []
+    for g in range(96):
+        M = int(rng.integers(1, 70))
+        raw = rng.binomial(2, 10 ** rng.uniform(-2.5, -0.7, M), size=(N, M)).astype(np.int8)
+        if g % 3 == 0:
+            raw[rng.random((N, M)) < 0.01] = -9
+        genes.append(np.asfortranarray(raw))
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=5)
+    grp = rvtests_amd.Group([0, 1])
+    try:
+        grp.fit_null(0, X, y)
+        for g, raw in enumerate(genes):
+            if g % 2:
+                grp.submit_gene_bed(g, rvtests_amd.Engine.pack_bed(raw.astype(np.float64)), raw.shape[1])
+            else:
+                grp.submit_gene_i8(g, raw)
+        got = grp.collect()
+    finally:
+        grp.close()
+    assert [r.gene_id for r in got] == list(range(len(genes)))
+    engine.fit_null(0, X, y)
+    for g, raw in enumerate(genes):
+        engine.submit_gene_raw(g, raw, want_af=False)
+    ref = engine.collect()
+    for a, b in zip(got, ref):
+        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f

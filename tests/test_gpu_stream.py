@@ -282,3 +282,36 @@ def test_registered_hand_off_buffer_is_read_before_the_call_returns():
     for a, b in zip(out, ref):
         for f in FIELDS:
             assert getattr(a, f) == getattr(b, f), (a.gene_id, f)
+
+
+def test_batched_submit_equals_gene_by_gene(eng):
+    """rvt_submit_genes (several genes per call: int8 matrices and PLINK 2-bit rows) gives the records of the single-gene
+    entry points."""
+    import rvtests_amd
+    rng = np.random.default_rng(17)
+    N, d = 3001, 2
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=4)
+    eng.set_null(0, X, res, v, s2)
+    raws = []
+    for g in range(21):
+        M = int(rng.integers(1, 80))
+        raw = rng.binomial(2, 10 ** rng.uniform(-2.5, -0.7, M), size=(N, M)).astype(np.int8)
+        if g % 2:
+            raw[rng.random((N, M)) < 0.01] = -9
+        raws.append(np.asfortranarray(raw))
+    for g, raw in enumerate(raws):
+        eng.submit_gene_raw(g, raw, want_af=False)
+    ref = eng.collect()
+    eng.submit_genes(2, range(len(raws)), raws, [r.shape[1] for r in raws])
+    got8 = eng.collect()
+    beds = [eng.pack_bed(r.astype(np.float64)) for r in raws]
+    eng.submit_genes(3, range(len(raws)), beds, [r.shape[1] for r in raws])
+    gotb = eng.collect()
+    for a, b, c in zip(ref, got8, gotb):
+        for f in ("gene_id", "skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(b, f), f
+        for f in ("gene_id", "cmc_nonref", "n_poly", "status"):
+            assert getattr(a, f) == getattr(c, f), f
+        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p"):
+            x, y_ = getattr(a, f), getattr(c, f)
+            assert abs(x - y_) <= 1e-9 * abs(x) + 1e-300, f      # (the packed-row kernel sums in another order)

@@ -1,0 +1,136 @@
+// tools/host_feed_bench.cpp — the streaming hand-off measured from a C++ caller (what the drop-in adapters are): one thread
+// submits genes from HOST memory through the C ABI exactly as ModelFitterGpu.cpp does (rvt_submit_gene_* per gene,
+// rvt_collect_ready while the stream runs), no Python in the loop.  Prints one JSON object per mode: gene-sets/s, the host
+// bytes per second that implies, and the caller thread's own microseconds per gene (the time inside rvt_submit_*: what one
+// feeding thread spends per gene, i.e. the bound of a single-thread feed of several devices).
+//   host_feed_bench [--samples N] [--m M] [--genes G] [--modes fp64,int8,bed] [--registered]
+// build: g++ -std=c++17 -O2 tools/host_feed_bench.cpp -Iinclude -Lrvtests_amd/csrc -lrvtests_amd -Wl,-rpath,$ORIGIN/../rvtests_amd/csrc
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rvtests_amd.h"
+
+static uint64_t mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+  long long N = 500000;
+  int M = 50, genes = 1536, window = 64, registered = 0;
+  std::string modes = "int8,bed,fp64";
+  for (int a = 1; a < argc; ++a) {
+    if (!strcmp(argv[a], "--samples") && a + 1 < argc) N = atoll(argv[++a]);
+    else if (!strcmp(argv[a], "--m") && a + 1 < argc) M = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--genes") && a + 1 < argc) genes = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--modes") && a + 1 < argc) modes = argv[++a];
+    else if (!strcmp(argv[a], "--registered")) registered = 1;
+  }
+  rvt_ctx* ctx = nullptr;
+  if (rvt_init(&ctx, 0)) { fprintf(stderr, "rvt_init failed\n"); return 2; }
+  const int d = 3;
+  std::vector<double> X((size_t)N * d), y(N);
+  for (long long i = 0; i < N; ++i) {
+    X[i] = 1.0;
+    for (int k = 1; k < d; ++k) X[(size_t)k * N + i] = (double)(mix(i * 7 + k) >> 11) / 9007199254740992.0 - 0.5;
+    y[i] = 0.3 * X[(size_t)N + i] + (double)(mix(i * 13 + 5) >> 11) / 9007199254740992.0;
+  }
+  if (rvt_fit_null(ctx, RVT_TRAIT_QUANTITATIVE, N, d, X.data(), y.data(), nullptr, nullptr)) {
+    fprintf(stderr, "rvt_fit_null: %s\n", rvt_last_error(ctx));
+    return 2;
+  }
+  const int K = 4;  // distinct host buffers, reused in turn (the reference refills ONE matrix per gene)
+  std::vector<std::vector<int8_t>> g8(K);
+  for (int k = 0; k < K; ++k) {
+    g8[k].resize((size_t)N * M);
+    for (size_t i = 0; i < g8[k].size(); ++i) {
+      const uint64_t h = mix(i * 31 + k);
+      g8[k][i] = (int8_t)(((h & 0xffff) < 1300) + (((h >> 16) & 0xffff) < 1300));
+      if (((h >> 40) & 0xfffff) < 1000) g8[k][i] = -9;  // ~0.1 % missing calls
+    }
+  }
+  rvt_params prm{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+  std::vector<rvt_gene_result> out(4096);
+  size_t pos = 0;
+  while (pos < modes.size()) {
+    size_t e = modes.find(',', pos);
+    if (e == std::string::npos) e = modes.size();
+    const std::string mode = modes.substr(pos, e - pos);
+    pos = e + 1;
+    std::vector<std::vector<unsigned char>> buf(K);
+    size_t bytes = 0;
+    for (int k = 0; k < K; ++k) {
+      if (mode == "int8") {
+        buf[k].assign((const unsigned char*)g8[k].data(), (const unsigned char*)g8[k].data() + g8[k].size());
+      } else if (mode == "bed") {  // PLINK 2-bit, SNP-major: 00 hom A1 (2), 01 missing, 10 het, 11 hom A2 (0)
+        const size_t cb = (size_t)((N + 3) / 4);
+        buf[k].assign(cb * M, 0);
+        for (int j = 0; j < M; ++j)
+          for (long long i = 0; i < N; ++i) {
+            const int g = g8[k][(size_t)j * N + i];
+            const unsigned code = g < 0 ? 1u : (g == 0 ? 3u : (g == 1 ? 2u : 0u));
+            buf[k][(size_t)j * cb + (i >> 2)] |= (unsigned char)(code << (2 * (i & 3)));
+          }
+      } else {  // fp64 with missing codes
+        buf[k].resize(sizeof(double) * (size_t)N * M);
+        double* dd = (double*)buf[k].data();
+        for (size_t i = 0; i < (size_t)N * M; ++i) dd[i] = (double)g8[k][i];
+      }
+      bytes = buf[k].size();
+      if (registered && rvt_host_register(ctx, buf[k].data(), buf[k].size())) {
+        fprintf(stderr, "rvt_host_register: %s\n", rvt_last_error(ctx));
+        return 2;
+      }
+    }
+    const int n_timed = (mode == "fp64") ? genes / 8 : genes;
+    double t0 = 0, in_submit = 0;
+    long long done = 0;
+    for (int g = -window; g < n_timed; ++g) {  // one untimed window first
+      if (g == 0) {
+        int n = 0;
+        rvt_collect(ctx, out.data(), (int)out.size(), &n);
+        t0 = now();
+        in_submit = 0;
+        done = 0;
+      }
+      const unsigned char* b = buf[(g + window) % K].data();
+      const double ts = now();
+      int rc;
+      if (mode == "int8") rc = rvt_submit_gene_i8(ctx, g, M, (const int8_t*)b, RVT_TEST_ALL, &prm, nullptr);
+      else if (mode == "bed") rc = rvt_submit_gene_bed(ctx, g, M, b, RVT_TEST_ALL, &prm, nullptr);
+      else rc = rvt_submit_gene_raw(ctx, g, M, (const double*)b, RVT_TEST_ALL, &prm, nullptr);
+      in_submit += now() - ts;
+      if (rc) { fprintf(stderr, "submit: %s\n", rvt_last_error(ctx)); return 2; }
+      if ((g + 1) % window == 0) {
+        int n = 0;
+        if (rvt_collect_ready(ctx, out.data(), (int)out.size(), &n)) return 2;
+        done += n;
+      }
+    }
+    for (;;) {
+      int n = 0;
+      if (rvt_collect(ctx, out.data(), (int)out.size(), &n)) return 2;
+      if (n == 0) break;
+      done += n;
+    }
+    const double dt = now() - t0;
+    printf("{\"mode\": \"%s%s\", \"N\": %lld, \"M\": %d, \"genes\": %lld, \"gene_sets_per_s\": %.1f, \"host_GBps\": %.2f, "
+           "\"caller_us_per_gene\": %.1f, \"caller\": \"C++, one thread, rvt_submit_gene_* per gene\"}\n",
+           mode.c_str(), registered ? "_registered" : "", N, M, done, done / dt, (double)bytes * done / dt / 1e9,
+           1e6 * in_submit / n_timed);
+    fflush(stdout);
+    if (registered)
+      for (int k = 0; k < K; ++k) rvt_host_unregister(ctx, buf[k].data());
+  }
+  rvt_destroy(ctx);
+  return 0;
+}
