@@ -55,6 +55,14 @@ void hc_sym_eigvals(const double* Ain, int n, double* out) {
   coop_sym_eigvals(co, A.data(), n, d.data(), e.data(), v.data(), w.data(), out);
 }
 
+// the bisection alone: d[n], e[n-1] -> all eigenvalues ascending (division-free Sturm count, rvt_coop.h)
+void hc_tridiag_eigvals(const double* din, const double* ein, int n, double* out) {
+  std::vector<double> d(din, din + n), e(n, 0.0), red(64);
+  for (int j = 0; j + 1 < n; ++j) e[j] = ein[j];
+  Coop co{0, 1, red.data()};
+  coop_tridiag_eigvals(co, d.data(), e.data(), n, out);
+}
+
 // QAGS state machine driven serially on one of the fixture integrands (ids as in the oracle)
 static double builtin_f(int id, double alpha, double x) {
   switch (id) {

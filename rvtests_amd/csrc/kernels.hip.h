@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ PvShared sh;
-  const GeneDesc& gd = genes[blockIdx.x];
+  const GeneDesc& gd = genes[genes[blockIdx.x].pv_gene];
   const int lane = threadIdx.x;
   {  // GeneStats -> LDS
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(gd.stats);

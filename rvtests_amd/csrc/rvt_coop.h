@@ -4,6 +4,7 @@
 // thread in the host test harness (tid = 0, nt = 1, sync() a no-op), so the CPU test-suite can walk
 // the very same flip-algebra / eigenvalue code the kernel runs.
 #pragma once
+#include <string.h>
 #include "rvt_special.h"
 
 namespace rvt {
@@ -96,58 +97,103 @@ RVT_HD void coop_tridiagonalize(const Coop& co, double* A, int n, double* d, dou
   co.sync();
 }
 
-// number of eigenvalues of the tridiagonal (d, e) that are < x
-// 1/q for the Sturm recurrence: on the device the hardware reciprocal refined by one Newton step (error ~1e-15,
-// a third of the latency of the IEEE division sequence; the count is a sign pattern and insensitive to it)
-RVT_HD double sturm_recip(double q) {
+// ---- Sturm count, division-free -------------------------------------------------------------------------------------
+// Number of eigenvalues of the tridiagonal (d, e) below x = number of sign changes in p_0 = 1, p_1 = d_0 - x,
+// p_j = (d_{j-1} - x) p_{j-1} - e_{j-2}^2 p_{j-2}.  The quotient form q_j = p_j / p_{j-1} (LAPACK's dlaebz) pays a division
+// per row — on this machine a quarter-rate reciprocal plus its Newton step, and the count loop is THE instruction stream
+// of the eigenvalue stage (13 problems x ~55 bisection steps x n rows per gene).  The product form costs a subtraction, a
+// multiplication and an FMA per row; its historical weakness, over- and underflow, is handled by rescaling the pair
+// (p_{j-1}, p_j) by a power of two every two rows (exponent instructions, no rounding: signs and ratios are unchanged).
+// The computed sequence is the exact one of a matrix whose entries are perturbed by a few ulp (Wilkinson), as for the
+// quotient form.  `e2` holds max(e_j^2, floor) of the matrix scaled to a span below 1 (coop_tridiag_eigvals): the positive
+// floor keeps an exactly split matrix from zeroing the whole tail of the sequence.
+RVT_HD int rvt_hi_word(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const double r = __builtin_amdgcn_rcp(q);
-  return r * (2.0 - q * r);
+  return __double2hiint(v);
 #else
-  return 1.0 / q;
+  long long b;
+  memcpy(&b, &v, 8);
+  return (int)(b >> 32);
 #endif
 }
-
-RVT_HD int sturm_count(const double* d, const double* e, int n, double x, double pivmin) {
-  int cnt = 0;
-  double q = d[0] - x;
-  if (fabs(q) < pivmin) q = -pivmin;
-  if (q < 0.0) ++cnt;
-  for (int j = 1; j < n; ++j) {
-    q = d[j] - x - (e[j - 1] * e[j - 1]) * sturm_recip(q);
-    if (fabs(q) < pivmin) q = -pivmin;
-    if (q < 0.0) ++cnt;
+RVT_HD void sturm_rescale(double& p0, double& p1) {  // the larger of the pair into [1/2, 1)
+  const double m = fmax(fabs(p0), fabs(p1));            // (> 0: the floor on e2 keeps the pair from vanishing together)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int k = __builtin_amdgcn_frexp_exp(m);
+  p0 = __builtin_amdgcn_ldexp(p0, -k);
+  p1 = __builtin_amdgcn_ldexp(p1, -k);
+#else
+  int k = 0;
+  if (m != 0.0) (void)frexp(m, &k);
+  p0 = ldexp(p0, -k);
+  p1 = ldexp(p1, -k);
+#endif
+}
+RVT_HD int sturm_count(const double* d, const double* e2, int n, double x) {
+  double p0 = 1.0, p1 = d[0] - x;
+  int cnt = (int)((unsigned)rvt_hi_word(p1) >> 31);
+  int j = 1;
+  for (; j + 1 < n; j += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double pn = fma(d[j + u] - x, p1, -(e2[j + u - 1] * p0));
+      cnt += (int)((unsigned)(rvt_hi_word(pn) ^ rvt_hi_word(p1)) >> 31);
+      p0 = p1;
+      p1 = pn;
+    }
+    sturm_rescale(p0, p1);
+  }
+  if (j < n) {
+    const double pn = fma(d[j] - x, p1, -(e2[j - 1] * p0));
+    cnt += (int)((unsigned)(rvt_hi_word(pn) ^ rvt_hi_word(p1)) >> 31);
   }
   return cnt;
 }
 
-// all eigenvalues, ascending, into out[n]
-RVT_HD void coop_tridiag_eigvals(const Coop& co, const double* d, const double* e, int n, double* out) {
-  // Gershgorin interval and pivot floor (every thread computes the same numbers)
-  double lo = d[0], hi = d[0], emax2 = 0.0;
+// All eigenvalues, ascending, into out[n].  d and e (n - 1 off-diagonal entries) are OVERWRITTEN: the matrix is scaled by
+// the power of two that brings its Gershgorin span into [1/2, 1) (exact; the eigenvalues are scaled back the same way), so
+// that a row multiplies the Sturm pair by at most 3, and e becomes max(e^2, 2^-200) — a floor of 2^-100 of the span on the
+// coupling, 15 orders below rounding, which bounds how fast the pair can shrink (two rows between rescalings stay some 500
+// binary orders clear of underflow).
+RVT_HD void coop_tridiag_eigvals(const Coop& co, double* d, double* e, int n, double* out) {
+  // Gershgorin interval (every thread computes the same numbers)
+  double lo = d[0], hi = d[0];
   for (int j = 0; j < n; ++j) {
     const double r = (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0);
     lo = fmin(lo, d[j] - r);
     hi = fmax(hi, d[j] + r);
-    if (j < n - 1) emax2 = fmax(emax2, e[j] * e[j]);
   }
-  const double span = fmax(fabs(lo), fabs(hi));
-  const double pivmin = fmax(DBL_MIN * fmax(1.0, emax2) * 4.0, DBL_MIN * 1024.0);
+  const double span0 = fmax(fabs(lo), fabs(hi));
+  int sh = 0;
+  if (span0 > 0.0 && span0 < INFINITY) (void)frexp(span0, &sh);
+  co.sync();  // (every thread has read d and e)
+  for (int j = co.tid; j < n; j += co.nt) {
+    d[j] = ldexp(d[j], -sh);
+    if (j < n - 1) {
+      const double es = ldexp(e[j], -sh);
+      e[j] = fmax(es * es, 0x1p-200);
+    }
+  }
+  lo = ldexp(lo, -sh);
+  hi = ldexp(hi, -sh);
+  const double span = fmax(fabs(lo), fabs(hi));  // in [1/2, 1), or 0 for the zero matrix
+  const double pivmin = DBL_MIN * 1024.0;
   lo -= 2.0 * kDblEps * span * n + 2.0 * pivmin;
   hi += 2.0 * kDblEps * span * n + 2.0 * pivmin;
+  co.sync();
   for (int idx = co.tid; idx < n; idx += co.nt) {
     // eigenvalue number idx (0 = smallest): largest x with count(x) <= idx
     double a = lo, b = hi;
     for (int it = 0; it < 200; ++it) {
       const double mid = 0.5 * (a + b);
       if (mid <= a || mid >= b) break;
-      if (sturm_count(d, e, n, mid, pivmin) <= idx)
+      if (sturm_count(d, e, n, mid) <= idx)
         a = mid;
       else
         b = mid;
       if (b - a <= 2.0 * kDblEps * fmax(fabs(a), fabs(b)) + 2.0 * pivmin) break;
     }
-    out[idx] = 0.5 * (a + b);
+    out[idx] = ldexp(0.5 * (a + b), sh);
   }
   co.sync();
 }

@@ -234,6 +234,7 @@ struct rvt_ctx {
   hipEvent_t ev_pv_in[kSlotsAll] = {}, ev_pv_out[kSlotsAll] = {};
   int pv_cus = 0;
   unsigned pv_turn = 0;
+  std::vector<int> pv_order;  // scratch of run_batch: the batch's genes by falling M (GeneDesc::pv_gene)
   // host -> device copies of the streaming interface: pinned staging ring filled by the process-wide copy threads
   // (host_stage.h), drained by DMA on io_stream.  RVT_STAGE=0 restores the runtime's own pageable copies.
   static constexpr int kStageChunks = 4;
@@ -268,6 +269,7 @@ struct rvt_ctx {
   double* d_xscale = nullptr;
   NullTileX hcx_tile;
   bool hcx_ok = false;
+  bool hcx_fused = true;  // one launch for every tile class of a batch (gene_suffstat_hcx_any); RVT_HCX_FUSED=0: one per class
   int64_t null_ld = 0;
   // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
   // double it loads and hands back genes that hold anything but hard calls and one imputed value per column
@@ -614,8 +616,8 @@ int rvt_init(rvt_ctx** out, int device_id) {
     // RVT_TAIL_CUS = k (experimental): the batch streams (flags, assembly, eigen stages, hand-backs) on the first k mask
     // bits only, the streaming stage everywhere
     if (const char* e = getenv("RVT_TAIL_CUS")) {
-      const int tk = atoi(e) / 32 * 32;
-      if (stage2_cus == 0 && tk >= 32 && tk < ncu) {
+      const int tk = atoi(e) / 8 * 8;
+      if (stage2_cus == 0 && tk >= 8 && tk < ncu) {
         std::fill(m2.begin(), m2.end(), 0u);
         for (int b = 0; b < tk; ++b) m2[b / 32] |= 1u << (b % 32);
       }
@@ -638,12 +640,13 @@ int rvt_init(rvt_ctx** out, int device_id) {
   // The SKAT-O p-values keep a 256-register wave per gene resident for milliseconds (QAGS over ~10^3 Davies evaluations:
   // latency-bound).  Spread over the whole chip those waves sit on every CU, and the workgroup-cooperative streaming
   // kernel (suffstat_hcx.hip.h: eight waves, all the registers of a CU's SIMDs) finds no free CU.  RVT_PV_CUS = k
-  // (a multiple of 32; default 64) confines the p-value kernel to k CUs — 8 per XCD for 64: two waves per SIMD hold all
+  // (a multiple of 8; default 64) confines the p-value kernel to k CUs — 8 per XCD for 64: two waves per SIMD hold all
   // 512 genes of a batch — and leaves the others to the streaming stage; 0 = everywhere, as before round 4.
   {
     int pv = 64;
     if (const char* e = getenv("RVT_PV_CUS")) pv = atoi(e);
-    pv = pv > 0 ? std::max(32, pv / 32 * 32) : 0;
+    pv = pv > 0 ? std::max(8, pv / 8 * 8) : 0;  // (whole CUs per XCD: the mask bits go round the 8 XCDs)
+    if (const char* e = getenv("RVT_HCX_FUSED")) c->hcx_fused = atoi(e) != 0;
     if (masked && stage2_cus == 0 && pv > 0 && pv < ncu) {
       const int words = (ncu + 31) / 32;
       std::vector<uint32_t> mp(words, 0u);
@@ -1657,6 +1660,13 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
     afpos += gd.M;
   }
+  {  // order of the p-value workgroups: falling M (stable)
+    std::vector<int>& ord = c->pv_order;
+    ord.resize(n);
+    for (int g = 0; g < n; ++g) ord[g] = g;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return Ms[a] > Ms[b]; });
+    for (int g = 0; g < n; ++g) desc[g].pv_gene = ord[g];
+  }
   std::memcpy(h_af, af, sizeof(double) * af_total);
   HIP_TRY(c, hipMemcpyAsync(base + off_af, h_af, sizeof(double) * af_total, hipMemcpyHostToDevice, st));
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
@@ -1712,7 +1722,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   if (pqw_bytes) HIP_TRY(c, hipMemsetAsync(base + off_pqw, 0, pqw_bytes, c->k2_stream));
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
-    while (e < n && h_desc[e].MT == h_desc[k].MT && h_desc[e].hc == h_desc[k].hc) ++e;
+    const bool one_launch = hcx && c->hcx_fused && h_desc[k].hc == 1;  // (gene_suffstat_hcx_any: every class at once)
+    while (e < n && (one_launch || h_desc[e].MT == h_desc[k].MT) && h_desc[e].hc == h_desc[k].hc) ++e;
     hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
     if (h_desc[k].hc == 3)
@@ -1722,7 +1733,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
       k2_launch_lat(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2},
                     (double)c->lattice_den, (long long)N, (long long)ld, d);
     else if (hcx)
-      k2_launch_hcx(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->hcx_tile, (long long)N, (long long)ld, d);
+      k2_launch_hcx(one_launch ? 0 : h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->hcx_tile, (long long)N,
+                    (long long)ld, d);
     else if (hcw)
       k2_launch_hcw(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTileW{c->d_nulltile_w, d + 3, c->d_vq},
                     (long long)N, (long long)ld, d);

@@ -841,4 +841,23 @@ __global__ __launch_bounds__(2 * kHcxNW * 64, 2) void gene_suffstat_hcx(const Ge
   suffstat_hcx_body<MT>(gd, nt, N, ld, d, lds);
 }
 
+// Every tile class in ONE launch (the engine's default): the workgroup takes the body of its gene's class (a scalar branch —
+// the descriptor comes through scalar loads).  A batch's genes are sorted widest class first, so the launch hands out its
+// longest workgroups first and ends on the shortest ones: one tail per batch instead of one per class, no launch gaps
+// between the classes.  Registers and LDS are those of the widest class (every class fills a CU with one workgroup anyway).
+template <int TOP>  // (the widest class compiled in; a template so that the header can sit in several translation units)
+__global__ __launch_bounds__(2 * kHcxNW * 64, 2) void gene_suffstat_hcx_any(const GeneDesc* __restrict__ genes, NullTileX nt,
+                                                                             long long N, long long ld, int d) {
+  const GeneDesc gd = genes[blockIdx.y];
+  __shared__ __attribute__((aligned(16))) char lds[hcx_lds_bytes(TOP)];
+  switch (gd.MT) {
+    case 1: suffstat_hcx_body<1>(gd, nt, N, ld, d, lds); break;
+    case 2: suffstat_hcx_body<2>(gd, nt, N, ld, d, lds); break;
+    case 3: suffstat_hcx_body<3>(gd, nt, N, ld, d, lds); break;
+    case 4: suffstat_hcx_body<4>(gd, nt, N, ld, d, lds); break;
+    case 5: suffstat_hcx_body<5>(gd, nt, N, ld, d, lds); break;
+    default: break;
+  }
+}
+
 }  // namespace rvt

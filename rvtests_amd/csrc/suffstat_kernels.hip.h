@@ -58,6 +58,8 @@ struct GeneDesc {
                             // the INTEGERS K'K and sum K (exact through the reduction), divided once in gene_assemble
   unsigned long long* pqw;  // weighted hard-call path (suffstat_hcx.hip.h): the gene's masked-entry tables P = H'Vm (Mp x Mp) and
                             // Q = m'Vm (Mp x Mp, upper triangle) as 64-bit integers in units of 2^-42, zeroed by the host
+  int pv_gene;              // gene_pvalue_kernel: workgroup b of the launch takes gene genes[b].pv_gene — the batch in order of
+                            // falling M (longest p-value work first, so the short ones fill the tail of the launch)
 };
 
 struct NullDev {

@@ -83,6 +83,8 @@ def lib():
         L.hc_liu_pvalue.argtypes = [c_double_p, C.c_int, d]
         L.hc_sym_eigvals.restype = None
         L.hc_sym_eigvals.argtypes = [c_double_p, C.c_int, c_double_p]
+        L.hc_tridiag_eigvals.restype = None
+        L.hc_tridiag_eigvals.argtypes = [c_double_p, c_double_p, C.c_int, c_double_p]
         L.hc_qags_builtin.restype = C.c_int
         L.hc_qags_builtin.argtypes = [C.c_int, d, d, d, d, d, C.c_int, c_double_p, c_double_p, c_int_p]
         L.hc_gene.restype = C.c_int
@@ -110,6 +112,14 @@ def davies(lam, Q, cached=False, fast=False):
 def liu(lam, Q):
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     return lib().hc_liu_pvalue(_dp(lam), len(lam), float(Q))
+
+
+def tridiag_eigvals(d, e):
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    e = np.ascontiguousarray(np.append(np.asarray(e, dtype=np.float64), 0.0))
+    w = np.zeros(len(d))
+    lib().hc_tridiag_eigvals(_dp(d), _dp(e), len(d), _dp(w))
+    return w
 
 
 def sym_eigvals(A):

@@ -88,3 +88,37 @@ def test_eigen_solvers_agree_with_lapack():
         scale = max(abs(w0).max(), 1e-300)
         assert np.max(np.abs(orc.sym_eigvals(A) - w0)) < 1e-12 * scale
         assert np.max(np.abs(hc.sym_eigvals(A) - w0)) < 1e-12 * scale
+
+
+def test_division_free_sturm_bisection_on_hard_tridiagonals():
+    """rvt_coop.h's product-form Sturm count (rescaled every four rows) against LAPACK on the matrices that break a naive
+    product recurrence: exactly split matrices, graded ones (under- / overflow of the unscaled sequence within a few
+    rows), huge and tiny scales, clustered and repeated eigenvalues, Wilkinson's W21+."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(11)
+    cases = []
+    n = 64
+    cases.append((rng.normal(size=n), rng.normal(size=n - 1)))
+    d, e = rng.normal(size=n), rng.normal(size=n - 1)
+    e[[7, 8, 30]] = 0.0                                            # exact splits, two of them adjacent
+    cases.append((d, e))
+    cases.append((np.zeros(n), np.zeros(n - 1)))                  # the zero matrix
+    cases.append((np.ones(n), np.zeros(n - 1)))                   # n-fold eigenvalue, fully split
+    cases.append((10.0 ** np.linspace(150, -150, n), 10.0 ** np.linspace(149, -149, n - 1)))   # graded over 300 decades
+    cases.append((rng.normal(size=n) * 1e150, rng.normal(size=n - 1) * 1e150))
+    cases.append((rng.normal(size=n) * 1e-150, rng.normal(size=n - 1) * 1e-150))
+    cases.append((np.abs(np.arange(-10, 11)).astype(float), np.ones(20)))                      # W21+
+    cases.append((np.full(n, 2.0), np.full(n - 1, -1.0)))         # second difference: the sequence grows like 3^j unscaled
+    cases.append((np.full(200, 1e5), np.full(199, 1e-3)))         # long, nearly diagonal (p shrinks by 1e-8 per row at x = d)
+    d, e = rng.normal(size=n), rng.normal(size=n - 1) * 1e-12     # clustered pairs
+    d[1::2] = d[0::2]
+    cases.append((d, e))
+    cases.append((np.array([3.0]), np.zeros(0)))
+    cases.append((np.array([1.0, 1.0]), np.array([1e-200])))
+    for d, e in cases:
+        w0 = sla.eigvalsh_tridiagonal(d, e) if len(d) > 1 else np.array(d)
+        w = hc.tridiag_eigvals(d, e)
+        scale = max(np.abs(w0).max(), 1e-300)
+        assert np.all(np.isfinite(w))
+        assert np.all(np.diff(w) >= 0)
+        assert np.max(np.abs(w - w0)) <= 4e-15 * scale * max(1, len(d) / 16) + 1e-290, (len(d), np.max(np.abs(w - w0)) / scale)

@@ -6,7 +6,8 @@ FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B; on gfx950 FETCH_SIZE co
 coalesced streaming reads (MI355X_MICROARCH.md, "HBM"), so it is doubled; WRITE_SIZE is taken as reported
 (uncalibrated per the same guide).
 
-usage: pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batches profiled> <workload key> <out.json>
+usage: pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batches profiled> <workload key> <out.json> [kernel name]
+(kernel name: the hard-call kernel the passes saw, e.g. gene_suffstat_hcx — bench.py only takes the figure for that kernel)
 """
 import csv
 import json
@@ -40,7 +41,10 @@ def main():
     for e in fam.values():
         e["hbm_bytes_per_step"] = (e["fetch_bytes"] + e["write_bytes"]) / batches
         e["launches_per_step"] = e["dispatches"] / batches
-    json.dump({"workload": key, "batches": batches, "correction": "FETCH_SIZE x2 (gfx950), x1024 B; WRITE_SIZE x1024 B",
+    head = {"workload": key, "batches": batches}
+    if len(sys.argv) > 6:
+        head["kernel_name"] = sys.argv[6]
+    json.dump({**head, "correction": "FETCH_SIZE x2 (gfx950), x1024 B; WRITE_SIZE x1024 B",
                "kernels": fam}, open(outp, "w"), indent=1)
     print(json.dumps({k: fam[k] for k in ("suffstat_hc", "suffstat_lat", "suffstat") if k in fam}))
 
