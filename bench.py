@@ -62,7 +62,11 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=
             # block of the batch holds hard calls only; imputed data has no missing entries.
             e = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) * 0.12
             Gv = G[:, :N]
-            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 1000.0) / 1000.0)
+            # (the division by a device TENSOR: torch turns `x / 1000.0` with a Python scalar into x * (1 / 1000.0) on the
+            #  GPU, which is up to 1.5 ulp away from the double strtod makes of "0.998" — the lattice kernel's test, exact
+            #  to the last bit since round 4, rightly refuses such values)
+            den = torch.full((), 1000.0, device=dev, dtype=torch.float64)
+            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 1000.0) / den)
             del e
         if not dosage and rng.random() < missing_frac:
             miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3

@@ -191,7 +191,9 @@ RVT_HD void coop_tridiag_eigvals(const Coop& co, double* d, double* e, int n, do
         a = mid;
       else
         b = mid;
-      if (b - a <= 2.0 * kDblEps * fmax(fabs(a), fabs(b)) + 2.0 * pivmin) break;
+      // (relative for eigenvalues of the matrix's own size; never finer than 2^-62 of the span — 2^-10 of the rounding
+      //  the tridiagonal form itself carries: an eigenvalue that is zero to rounding stops after ~62 halvings, not 200)
+      if (b - a <= 2.0 * kDblEps * fmax(fabs(a), fabs(b)) + (span * 0x1p-62 + 2.0 * pivmin)) break;
     }
     out[idx] = ldexp(0.5 * (a + b), sh);
   }

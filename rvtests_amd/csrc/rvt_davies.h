@@ -160,8 +160,15 @@ RVT_HDI void dv_tick(DaviesState& st) {
 }
 
 // bound on the tail probability from the mgf; cutoff returned in *cx      (qfc.c:137-155)
+#if defined(RVT_DV_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
+#define RVT_DV_HIT(k) (++rvt_dv_profile[k])   // host-side call counters of a profiling build (tools/davies_calls.cpp)
+extern long long rvt_dv_profile[8];
+#else
+#define RVT_DV_HIT(k) ((void)0)
+#endif
 template <bool FAST>
 RVT_HDI double dv_errbd(DaviesState& st, double u, double* cx) {
+  RVT_DV_HIT(0);
   dv_tick(st);
   if (st.over) {
     *cx = 0.0;
@@ -217,12 +224,14 @@ RVT_HDI double dv_ctff(DaviesState& st, double accx, double* upn) {
   c1 = st.mean;
   rb = 2.0 * ((u2 > 0.0) ? st.lmax : st.lmin);
   for (u = u2 / (1.0 + u2 * rb); dv_errbd<FAST>(st, u, &c2) > accx && !st.over; u = u2 / (1.0 + u2 * rb)) {
+    RVT_DV_HIT(2);  // a doubling
     u1 = u2;
     c1 = c2;
     u2 = 2.0 * u2;
   }
   for (u = (c1 - st.mean) / (c2 - st.mean); u < 0.9 && !st.over; u = (c1 - st.mean) / (c2 - st.mean)) {
     u = (u1 + u2) / 2.0;
+    RVT_DV_HIT(3);  // a bisection
     if (dv_errbd<FAST>(st, u / (1.0 + u * rb), &xconst) > accx) {
       u1 = u;
       c1 = xconst;
@@ -238,6 +247,7 @@ RVT_HDI double dv_ctff(DaviesState& st, double accx, double* upn) {
 // bound on the integration error due to truncation at u      (qfc.c:180-215)
 template <bool FAST>
 RVT_HDI double dv_truncation(DaviesState& st, double u, double tausq) {
+  RVT_DV_HIT(1);
   dv_tick(st);
   if (st.over) return 0.0;
   double sum1 = 0.0, prod2 = 0.0, prod3 = 0.0;
@@ -654,6 +664,7 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
           break;
         }
         acc1 = .67 * acc1;
+        RVT_DV_HIT(4);  // an auxiliary integration
         dv_integrate<FAST>(st, ntm, intv1, tausq, false);
         task->nterms += ntm + 1;
         xlim = xlim - xntm;

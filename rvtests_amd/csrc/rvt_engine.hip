@@ -269,6 +269,7 @@ struct rvt_ctx {
   double* d_xscale = nullptr;
   NullTileX hcx_tile;
   bool hcx_ok = false;
+  int as_threads = 1024;  // workgroup size of gene_assemble_kernel (RVT_AS_THREADS)
   bool hcx_fused = true;  // one launch for every tile class of a batch (gene_suffstat_hcx_any); RVT_HCX_FUSED=0: one per class
   int64_t null_ld = 0;
   // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
@@ -647,6 +648,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
     if (const char* e = getenv("RVT_PV_CUS")) pv = atoi(e);
     pv = pv > 0 ? std::max(8, pv / 8 * 8) : 0;  // (whole CUs per XCD: the mask bits go round the 8 XCDs)
     if (const char* e = getenv("RVT_HCX_FUSED")) c->hcx_fused = atoi(e) != 0;
+    if (const char* e = getenv("RVT_AS_THREADS")) c->as_threads = std::min(1024, std::max(64, atoi(e) / 64 * 64));
     if (masked && stage2_cus == 0 && pv > 0 && pv < ncu) {
       const int words = (ncu + 31) / 32;
       std::vector<uint32_t> mp(words, 0u);
@@ -1866,7 +1868,7 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     if (tests & RVT_TEST_FAMSKAT)
       hipLaunchKernelGGL(fam_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc);
     else
-      hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc, params, tests_eff,
+      hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(c->as_threads), 0, st, d_desc, c->d_nc, params, tests_eff,
                          n_bparts, (const double*)c->d_xscale);
   }
   if ((tests & RVT_TEST_ANALYTICVT) && !(tests & RVT_TEST_FAMSKAT)) {
