@@ -16,6 +16,17 @@
 
 using namespace rvt;
 
+#ifdef RVT_DV_PROFILE
+// profiling build (tools/davies_divergence.py): what every abscissa of a SKAT-O quadrature spent in qf()'s searches
+namespace rvt {
+long long rvt_dv_profile[8];
+std::vector<long long> g_dv_log;
+void rvt_dv_eval_mark() {
+  for (int k = 0; k < 5; ++k) g_dv_log.push_back(rvt_dv_profile[k]);
+}
+}  // namespace rvt
+#endif
+
 extern "C" {
 
 double hc_chisq_Q(double x, double nu) { return chisq_Q(x, nu); }
@@ -62,6 +73,15 @@ void hc_tridiag_eigvals(const double* din, const double* ein, int n, double* out
   Coop co{0, 1, red.data()};
   coop_tridiag_eigvals(co, d.data(), e.data(), n, out);
 }
+
+#ifdef RVT_DV_PROFILE
+int hc_dv_log(long long* out, int cap) {  // 5 cumulative counters per abscissa; returns the number of records and clears
+  const int n = (int)(rvt::g_dv_log.size() / 5);
+  for (int i = 0; i < n * 5 && i < cap; ++i) out[i] = rvt::g_dv_log[i];
+  rvt::g_dv_log.clear();
+  return n;
+}
+#endif
 
 // QAGS state machine driven serially on one of the fixture integrands (ids as in the oracle)
 static double builtin_f(int id, double alpha, double x) {

@@ -163,6 +163,7 @@ RVT_HDI void dv_tick(DaviesState& st) {
 #if defined(RVT_DV_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
 #define RVT_DV_HIT(k) (++rvt_dv_profile[k])   // host-side call counters of a profiling build (tools/davies_calls.cpp)
 extern long long rvt_dv_profile[8];
+void rvt_dv_eval_mark();
 #else
 #define RVT_DV_HIT(k) ((void)0)
 #endif

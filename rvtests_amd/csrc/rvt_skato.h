@@ -91,6 +91,9 @@ RVT_HD double skato_integrand_davies(const SkatoIntegrand& s, double x, double* 
     temp = davies_pvalue(s.lambda, s.th, s.r, Q, &fault, nterms, s.pre);
     if (temp <= 0.0 || temp == 1.0) temp = s.liu ? liu_pvalue_pre(*s.liu, Q) : liu_pvalue(s.lambda, s.r, Q);
   }
+#if defined(RVT_DV_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
+  rvt_dv_eval_mark();  // (profiling build of the host harness: one log record per abscissa)
+#endif
   return (1.0 - temp) * chisq_density_lg(x, 1.0, s.lg_half);
 }
 

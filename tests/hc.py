@@ -62,10 +62,12 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(CSRC, "librvt_hostcheck.so")
-        srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp"))]
-        if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
-            build()
+        path = os.environ.get("RVT_HOSTCHECK_LIB")     # (a caller-built variant, e.g. tools/davies_divergence.py's profiling build)
+        if not path:
+            path = os.path.join(CSRC, "librvt_hostcheck.so")
+            srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp"))]
+            if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+                build()
         L = C.CDLL(path)
         d = C.c_double
         for n in ("hc_chisq_Q", "hc_chisq_P", "hc_chisq_Qinv", "hc_chisq_pdf"):
