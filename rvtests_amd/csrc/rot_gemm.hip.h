@@ -28,6 +28,13 @@
 // Measured ladder at N = 100 000, T = 3840 (tools/rotgemm_bench, POP/s per plane pair): 256 x 128 tile, 2 x 2 tiles per
 // wave, register staging + ds_write, 64-byte chunks 1.23; the same with LDS-DMA 1.24 (the stores were not the limit);
 // 256 x 256 tile, 4 x 2 per wave 1.79; + 3 stages with counted vmcnt 2.01; + 128-byte chunks and fragment prefetch 2.11.
+// Round 4 (tools/rotgemm_bench with -DRVT_ROT_CFG / -DRVT_ROT_DIAG / -DRVT_ROT_SPREAD; the template takes the K bytes of a
+// stage, 64 or 128): a ring of five / four / three 32 KB stages of 64 K-bytes — 96-128 KB of loads in flight instead of 64 —
+// gives 2.01 / 2.01 / 1.98 POP/s against 2.23 for two 64 KB stages: the prefetch distance is NOT what bounds this kernel
+// (twice the barriers cost 10 %).  Timing-only builds: without any refill after the prologue 2.88 POP/s, without the fragment
+// reads of k-steps 1-3 2.35, with the refill's pieces spread between the matrix instructions instead of issued at the top of
+// the iteration 2.08.  So the matrix instructions with their barrier per 128 K-bytes run at 2.9 of the 3.9 POP/s ceiling by
+// themselves, and the LDS-DMA refill costs another 23 % that neither depth nor placement gives back.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,6 +51,14 @@ typedef int i4v_t __attribute__((ext_vector_type(4)));
 // position of the 16-byte segment `seg` (0..7) of row `row` inside a [rows][128 B] LDS tile
 __device__ __forceinline__ int rot_lds_off(int row, int seg) { return row * 128 + ((seg ^ ((row >> 1) & 7)) << 4); }
 
+// the same for rows of KC bytes (KC = 128: the function above; KC = 64: four segments per row, slot = seg ^ ((row >> 2) & 3) —
+// the 16 lanes of a ds_read_b128 group read rows r = 0..3 mod 4 four times each, with four different (row >> 2) & 3)
+template <int KC>
+__device__ __forceinline__ int rot_lds_off_t(int row, int seg) {
+  if (KC == 128) return rot_lds_off(row, seg);
+  return row * 64 + ((seg ^ ((row >> 2) & 3)) << 4);
+}
+
 template <int N>
 __device__ __forceinline__ void rot_wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -53,7 +68,7 @@ __device__ __forceinline__ void rot_wait_vm_barrier() {
 // C[m + j * ldc] = (accumulate ? C : 0) + (double)acc * weight * col_scale[j] [* row_scale[m]],  m < M, j < N.
 // grid = (sets * 256, K slices) workgroups, sets = ceil(n_row_panels / 32) * ceil(n_col_tiles / 8); with one slice pass
 // kslice = kbytes and c_slice = 0.
-template <int WM, int WN, int TM, int TN, int NST, int MINB>
+template <int WM, int WN, int TM, int TN, int NST, int MINB, int KC>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
     const int8_t* __restrict__ A0, const int8_t* __restrict__ B0, long long ldk, long long kbytes0, double* __restrict__ C0,
     long long ldc, int M, int N, int n_row_panels, int n_col_tiles, const double* __restrict__ col_scale,
@@ -65,9 +80,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
   const int8_t* __restrict__ B = B0 + k_off;
   double* __restrict__ C = C0 + (long long)blockIdx.y * c_slice;
   const long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
-  constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
-  constexpr int kStage = (BM + BN) * kRotKC;
+  static_assert(KC == 64 || KC == 128, "a stage holds 64 or 128 bytes of K per row");
+  constexpr int kRowsPerPiece = 1024 / KC, kSegs = KC / 16;                   // 1 KiB pieces: 8 rows x 128 B or 16 rows x 64 B
+  constexpr int kPieces = (BM + BN) / kRowsPerPiece, PPW = kPieces / kWaves;
+  constexpr int kStage = (BM + BN) * KC;
   static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
+  static_assert(PPW * (NST - 1) < 64, "the ring's loads must fit the vmcnt counter");
   __shared__ __attribute__((aligned(1024))) char lds[NST][kStage];
   // (K slices rotate the XCD that takes a given tile: a product with few tiles still spreads over the chip)
   const int bid = blockIdx.x, xcd = (bid + blockIdx.y) & 7, w = bid >> 3;
@@ -83,14 +101,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int P = wave + kWaves * q;
-    const int r = 8 * P + (lane >> 3), slot = lane & 7, seg = slot ^ ((r >> 1) & 7);
+    const int r = kRowsPerPiece * P + lane / kSegs, slot = lane % kSegs;
+    const int seg = (KC == 128) ? (slot ^ ((r >> 1) & 7)) : (slot ^ ((r >> 2) & 3));
     gsrc[q] = (r < BM ? A + (m0 + r) * ldk : B + (n0 + (r - BM)) * ldk) + seg * 16;
   }
   auto stage = [&](int buf, long long kc) {
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
       const int P = wave + kWaves * q;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * kRotKC),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * KC),
                                        (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
     }
   };
@@ -101,40 +120,67 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void rot_gemm_i8_kernel_t(
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
-  const long long nchunks = kbytes / kRotKC;
+  const long long nchunks = kbytes / KC;
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
   const int lrow = lane & 31, lk = lane >> 5;
   int cur = 0;
+  constexpr int KS = KC / 32;  // k-steps (32 bytes of K per matrix instruction) per stage
+  auto stage_piece = [&](int buf, long long kc, int q) {
+    const int P = wave + kWaves * q;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * KC),
+                                     (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
+  };
   for (long long kc = 0; kc < nchunks; ++kc) {
     rot_wait_vm_barrier<PPW*(NST - 2)>();
-    {
-      const long long nx = kc + NST - 1;
-      int buf = cur + NST - 1;
-      if (buf >= NST) buf -= NST;
-      stage(buf, nx < nchunks ? nx : nchunks - 1);
-    }
+    // the stage that is refilled during this iteration: the buffer every wave left at the barrier above
+    const long long nx = (kc + NST - 1 < nchunks) ? kc + NST - 1 : nchunks - 1;
+    int nbuf = cur + NST - 1;
+    if (nbuf >= NST) nbuf -= NST;
+#if !defined(RVT_ROT_SPREAD)
+#if !defined(RVT_ROT_DIAG) || RVT_ROT_DIAG != 1   // (diagnostic builds of tools/rotgemm_bench: 1 = no loads after the prologue,
+    stage(nbuf, nx);                                //  2 = no fragment reads after the first k-step — wrong results, timing only)
+#endif
+#endif
     const char* la = &lds[cur][0];
-    const char* lb = &lds[cur][BM * 128];
+    const char* lb = &lds[cur][BM * KC];
     i4v_t fa[2][TM], fb[2][TN];
     auto frags = [&](int ks, int slot) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        fa[slot][a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
+        fa[slot][a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off_t<KC>(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        fb[slot][b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+        fb[slot][b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off_t<KC>(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
     };
     frags(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+    for (int ks = 0; ks < KS; ++ks) {
+#if !defined(RVT_ROT_DIAG) || RVT_ROT_DIAG != 2
+      if (ks < KS - 1) frags(ks + 1, (ks + 1) & 1);
+#else
+      if (ks < KS - 1) { for (int a = 0; a < TM; ++a) fa[(ks + 1) & 1][a] = fa[ks & 1][a]; for (int b = 0; b < TN; ++b) fb[(ks + 1) & 1][b] = fb[ks & 1][b]; }
+#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads in front of this k-step's matrix instructions
+#if defined(RVT_ROT_SPREAD)
+      // the refill's pieces spread over the k-steps, each between matrix instructions (a burst of pieces at the top of the
+      // iteration stalls the wave's issue for ~150 cycles per piece)
+      constexpr int PPK = (PPW + KS - 1) / KS;
+      int qn = ks * PPK;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+          if (((a * TN + b) & 1) == 1 && qn < (ks + 1) * PPK && qn < PPW) stage_piece(nbuf, nx, qn++);
+        }
+#else
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("" ::: "memory");
@@ -280,7 +326,7 @@ constexpr int kRotShortBN = 128;  // column tile of the short-K kernel (<4, 2, 2
 
 // the shipped configuration
 #ifndef RVT_ROT_CFG
-#define RVT_ROT_CFG 2, 4, 4, 2, 2, 1
+#define RVT_ROT_CFG 2, 4, 4, 2, 2, 1, 128  // (2 x 4 waves, 4 x 2 tiles per wave, two 64 KB stages of 128 K-bytes)
 #define RVT_ROT_THREADS 512
 #endif
 #define rot_gemm_i8_kernel (rot_gemm_i8_kernel_t<RVT_ROT_CFG>)
