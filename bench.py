@@ -38,7 +38,7 @@ import rvtests_amd  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (≈6.3 TB/s achievable)
 
 
-def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=False):
+def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=False, dosage_float=False):
     """Synthetic genotype blocks on the device (config 3 of SURVEY.md §8d): per-variant MAF ~ LogUniform(5e-4,
     5e-2), g ~ Binomial(2, maf); 0.1 % of genotypes missing in 5 % of the genes and imputed to the column mean
     exactly as DataConsolidator::imputeGenotypeToMean leaves them.  Returns blocks (M x ld tensors, i.e.
@@ -66,7 +66,19 @@ def make_genes(dev, N, ld, n_genes, seed, m_lo, m_hi, missing_frac=0.05, dosage=
             #  GPU, which is up to 1.5 ulp away from the double strtod makes of "0.998" — the lattice kernel's test, exact
             #  to the last bit since round 4, rightly refuses such values)
             den = torch.full((), 1000.0, device=dev, dtype=torch.float64)
-            Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 1000.0) / den)
+            if dosage_float:
+                # float-precision dosages as an 8-bit BGEN file gives them: p1 = float(v1) * float(1 / 255), p2 likewise,
+                # dosage = p1 + 2 p2 in double (src/BGenGenotypeExtractor.cpp:413-478) — integer multiples of 2^-31
+                blur = (Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv))
+                v2 = torch.round(torch.clamp(blur - 1.0, min=0.0) * 255.0)
+                v1 = torch.round(torch.clamp(blur - 2.0 * v2 / 255.0, min=0.0, max=1.0) * 255.0)
+                sc = torch.full((), 1.0 / 255.0, device=dev, dtype=torch.float32)
+                p1 = (v1.to(torch.float32) * sc).to(torch.float64)
+                p2 = (v2.to(torch.float32) * sc).to(torch.float64)
+                Gv.copy_(p1 + 2.0 * p2)
+                del blur, v1, v2, p1, p2
+            else:
+                Gv.copy_(torch.round((Gv * (1.0 - e.to(torch.float64)) + 0.5 * e.to(torch.float64) * (2.0 - Gv)) * 1000.0) / den)
             del e
         if not dosage and rng.random() < missing_frac:
             miss = torch.rand((M, N), generator=g, device=dev, dtype=torch.float32) < 1e-3
@@ -366,6 +378,9 @@ def main():
     ap.add_argument("--dosage-lattice", type=int, default=1000,
                     help="with --dosage: the lattice denominator stated to the engine (1000 = three decimals: the int8 "
                          "lattice kernel); 0 = not stated: the general fp64 kernel")
+    ap.add_argument("--dosage-float", action="store_true",
+                    help="with --dosage: float-precision dosages as an 8-bit BGEN file gives them (multiples of 2^-31), no lattice "
+                         "stated; the engine is told so (rvt_set_dosage_float) and tries the float-digit int8 kernel for M <= 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
@@ -405,10 +420,14 @@ def main():
     binary = args.trait == "binary"
     # ---- this rank's shard of genes, resident in HBM -----------------------------------------------------------
     blocks, Ms, afs = make_genes(dev, N, ld, args.genes, 20260002 + 1000 * rank, args.m_lo, args.m_hi,
-                                 args.missing_frac, args.dosage)
+                                 args.missing_frac, args.dosage, args.dosage_float)
+    if args.dosage_float:
+        args.dosage_lattice = 0
     if args.dosage:
         eng.set_content_hint(0)
         eng.set_dosage_lattice(args.dosage_lattice)
+        if args.dosage_float:
+            eng.set_dosage_float(True)
     pack = torch.empty((N, d + 1), dtype=torch.float64, device=dev)
     if rank == 0:
         X, y = make_phenotype(dev, N, 20260002, binary, causal_effect(blocks, N, binary))
@@ -513,6 +532,8 @@ def main():
             k2_name = eng.hardcall_kernel() or ("gene_suffstat_hcw" if binary else "gene_suffstat_hc")
             if args.dosage:
                 k2_name = "gene_suffstat_lat"                                 # (dosages on the stated decimal lattice)
+            if args.dosage_float:
+                k2_name = "gene_suffstat_fdx"                                 # (float-precision dosages, M <= 64)
             n_l, ms_l, by_l = tm.n_suffstat_hc_launches, tm.ms_suffstat_hc, tm.alg_bytes_hc
         else:
             k2_name = "gene_suffstat_mfma"
@@ -531,6 +552,8 @@ def main():
             key += ",binary"
         if args.dosage:                                  # (the dosage workload has PMC passes of its own)
             key += ",dosage,lattice=%d" % args.dosage_lattice
+        if args.dosage_float:
+            key += ",float"
         # (the newest committed PMC summary of exactly this workload: profiles/r*_pmc_traffic*.json, tools/pmc_traffic.py)
         import glob
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -555,7 +578,8 @@ def main():
                                    "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
                                    "fp64 column-major blocks%s" % (3 if binary else 2, N, args.genes, args.m_lo,
                                                                    args.m_hi, "binary" if binary else "quantitative",
-                                                                   (" of DOSAGES with three decimals (no hard-call block; lattice stated: %d)"
+                                                                   (" of float-precision DOSAGES (8-bit BGEN values; stated to the engine)" if args.dosage_float else
+                                                                    " of DOSAGES with three decimals (no hard-call block; lattice stated: %d)"
                                                                     % args.dosage_lattice) if args.dosage else ""),
                        "N": N, "genes_per_step_per_gpu": args.genes, "mean_M": float(np.mean(Ms)),
                        "parallelism": "gene-sharded x%d" % world, "genes_ok": ok,

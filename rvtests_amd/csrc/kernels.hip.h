@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __res
       mx = fmax(mx, mu);
     }
     // (lattice dosages, hc == 2: s is the integer sum of K = den x the column sum — compared exactly)
-    const bool flip = in && !(s <= (gd.hc == 2 ? (double)N * gd.lat_den : (double)N));
+    const bool flip = in && !(s <= ((gd.hc == 2 || gd.hc == 4) ? (double)N * gd.lat_den : (double)N));
     const bool poly = in && !(mn == mx);
     const bool pred = in && (j >> 4) < 8 && ((gd.pflip[(j >> 4) & 7] >> (j & 15)) & 1);
     const bool counted_mono = in && !poly && (pred ? mn != 2.0 : mn != 0.0);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
   __syncthreads();
   Coop co{(int)threadIdx.x, (int)blockDim.x, red};
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
-  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), gd.hc == 2 ? gd.lat_den : 0.0, gd.pqw, xscale};
+  const HcMasked hcm{gd.pq, gd.wflags, hc_pq_words(gd.MT), (gd.hc == 2 || gd.hc == 4) ? gd.lat_den : 0.0, gd.pqw, xscale};
   // a hard-call gene that was handed back holds the general kernel's statistics (three rows per wave-part, G'DG itself)
   const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
   const bool masks = gd.hc != 0 && !handed_back;  // (pq is null for the weighted and the lattice kernel: no masked tiles)

@@ -20,6 +20,7 @@
 #include "suffstat_lat.hip.h"
 #include "suffstat_hcp.hip.h"
 #include "suffstat_hcx.hip.h"
+#include "suffstat_fdx.hip.h"
 #include "host_stage.h"
 
 namespace rvt {  // defined in k2_unweighted.hip / k2_weighted.hip
@@ -36,6 +37,8 @@ void k2_launch_hc(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, Nul
 void k2_launch_hcw(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTileW nt, long long N, long long ld,
                    int d);
 void k2_launch_hcx(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const NullTileX& nt, long long N, long long ld,
+                   int d);
+void k2_launch_fdx(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, const NullTileF& nt, long long N, long long ld,
                    int d);
 void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
                    long long ld, int d);
@@ -269,6 +272,11 @@ struct rvt_ctx {
   double* d_xscale = nullptr;
   NullTileX hcx_tile;
   bool hcx_ok = false;
+  // ... and of the float-digit dosage kernel (suffstat_fdx.hip.h; quantitative trait): five base-256 digit planes of [X | res | 1]
+  unsigned char* d_fxq = nullptr;
+  NullTileF fdx_tile;
+  bool fdx_ok = false;
+  bool dosage_float = false;  // rvt_set_dosage_float: blocks of unknown content hold float-precision dosages
   int as_threads = 1024;  // workgroup size of gene_assemble_kernel (RVT_AS_THREADS)
   bool hcx_fused = true;  // one launch for every tile class of a batch (gene_suffstat_hcx_any); RVT_HCX_FUSED=0: one per class
   int64_t null_ld = 0;
@@ -539,7 +547,7 @@ bool invert_spd(const double* M, int n, double* Minv) {
 // to write and to reduce: measured +2.7 % at 512 genes)
 // hcx: the batch's hard-call genes take the workgroup-cooperative kernel (suffstat_hcx.hip.h): a part is worked by four loader
 // waves, so a quarter of the parts gives as many waves per gene; its iteration is 16 steps
-void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* steps_per, bool hcx = false) {
+void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* steps_per, bool hcx = false, bool fdx = false) {
   const int64_t nsteps = ld >> 4;
   const char* fe = getenv("RVT_WPARTS");  // (experiments / tests)
   const int forced = fe ? atoi(fe) : 0;
@@ -551,6 +559,7 @@ void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* st
   if (hcx && spw > kHcwMaxSteps) spw = kHcwMaxSteps / unit * unit;
   if (spw > kHcwMaxSteps) spw = kHcwMaxSteps;                   // (int32 range of the weighted hard-call kernel's tiles)
   if (!weighted && spw > kHcMaxSteps) spw = kHcMaxSteps;        // (16-bit range of the hard-call kernel's masked-tile counters)
+  if (fdx && spw > kFdxMaxSteps / 24 * 24) spw = kFdxMaxSteps / 24 * 24;  // (int32 range of the float-digit kernel's order sums)
   int64_t nw = (nsteps + spw - 1) / spw;
   if (nw < 1) nw = 1;
   *n_wparts = (int)nw;
@@ -732,6 +741,9 @@ static void free_null(rvt_ctx* c) {
   if (c->d_dq) hipFree(c->d_dq);
   if (c->d_xq) hipFree(c->d_xq);
   if (c->d_xscale) hipFree(c->d_xscale);
+  if (c->d_fxq) hipFree(c->d_fxq);
+  c->d_fxq = nullptr;
+  c->fdx_ok = false;
   c->d_nulltile_w = nullptr;
   c->d_vq = nullptr;
   c->d_dq = c->d_xq = nullptr;
@@ -1015,6 +1027,52 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       }
     }
   }
+  if (!nc.binary && c->hc_enabled && d + 2 <= kFdxStageCols) {
+    // float-digit dosage kernel (suffstat_fdx.hip.h): the columns [X_0 .. X_{d-1} | res | 1] as five balanced base-256 digits of
+    // their fixed-point values — 38 bits below a power of two above the column's largest entry (|error| <= 2^-39 of it per
+    // entry, unbiased); the column of ones is the integer 1 (its tile column is the exact column sum of K).  Digits: the
+    // bytes of q + 0x8080808080 with the top bits flipped.
+    const char* ef = getenv("RVT_FDX");
+    bool okf = !(ef && atoi(ef) == 0);
+    const int ncf = d + 2;
+    double scale[16];
+    int shift[16];
+    for (int k = 0; k < 16; ++k) {
+      scale[k] = 1.0;
+      shift[k] = 0;
+    }
+    for (int k = 0; k <= d && okf; ++k) {
+      const double* col = (k < d) ? X + (size_t)k * N : res;
+      double mx = 0.0;
+      for (int64_t i = 0; i < N; ++i) mx = std::max(mx, std::fabs(col[i]));
+      if (!std::isfinite(mx)) okf = false;
+      if (mx > 0.0) {
+        int e;
+        std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
+        shift[k] = 38 - e;        // |x| 2^shift < 2^38: the top digit stays below 64
+        scale[k] = std::ldexp(1.0, -shift[k]);
+      }
+    }
+    if (okf) {
+      const int64_t ngroups = (ld + 31) / 32 + 8;  // (padding: the kernel fetches the groups of an iteration, also past the end)
+      std::vector<unsigned char> fx((size_t)ngroups * kFdxPlanes * 4 * ncf * 8, 0);
+      for (int64_t i = 0; i < N; ++i) {
+        const int64_t g = i >> 5, T = (i >> 4) & 1, q = (i >> 2) & 3, l = i & 3;
+        for (int k = 0; k < ncf; ++k) {
+          const long long qv = (k == d + 1) ? 1ll : llrint(std::ldexp((k < d) ? X[(size_t)k * N + i] : res[i], shift[k]));
+          const unsigned long long kb = (unsigned long long)(qv + 0x8080808080ll);
+          for (int p = 0; p < kFdxPlanes; ++p)
+            fx[(((size_t)(g * kFdxPlanes + p) * 4 + q) * ncf + k) * 8 + T * 4 + l] = (unsigned char)(((kb >> (8 * p)) & 0xffu) ^ 0x80u);
+        }
+      }
+      HIP_TRY(c, hipMalloc((void**)&c->d_fxq, fx.size()));
+      HIP_TRY(c, hipMemcpy(c->d_fxq, fx.data(), fx.size(), hipMemcpyHostToDevice));
+      c->fdx_tile.xq = c->d_fxq;
+      for (int k = 0; k < 16; ++k) c->fdx_tile.scale[k] = scale[k];
+      c->fdx_tile.ncols = ncf;
+      c->fdx_ok = true;
+    }
+  }
   HIP_TRY(c, hipMemcpy(c->d_nc, &nc, sizeof(nc), hipMemcpyHostToDevice));
   c->null_ld = ld;
   c->have_null = true;
@@ -1084,6 +1142,12 @@ int rvt_set_dosage_lattice(rvt_ctx* c, int denominator) {
   if (denominator < 0 || denominator > kLatMaxDen)
     return fail(c, RVT_E_INVALID, "rvt_set_dosage_lattice: denominator %d outside [0, %d]", denominator, kLatMaxDen);
   c->lattice_den = denominator;
+  return RVT_OK;
+}
+
+int rvt_set_dosage_float(rvt_ctx* c, int on) {
+  if (!c) return RVT_E_INVALID;
+  c->dosage_float = on != 0;
   return RVT_OK;
 }
 
@@ -1516,8 +1580,15 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
     }
     hcx = any;
   }
+  // quantitative trait: does a gene of the batch start on the float-digit dosage kernel?  (its wave-parts are shorter)
+  bool fdx_batch = false;
+  if (!nc.binary && c->fdx_ok && c->hc_enabled && !cov && c->lattice_den == 0 && !(dbg && dbg->cmc) && !(tests & RVT_TEST_FAMSKAT))
+    for (int g = 0; g < n && !fdx_batch; ++g) {
+      const int k = kind ? kind[g] : -1;
+      fdx_batch = (Ms[g] + 15) / 16 <= kFdxEngineMT && (k == 0 || (k < 0 && c->content_hint == 0 && c->dosage_float));
+    }
   int n_wparts, steps_per;
-  choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx);
+  choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx, fdx_batch);
   // ---- sizes ---------------------------------------------------------------------------------------
   std::vector<GeneDesc> desc(n);
   size_t total = 0, af_total = 0;
@@ -1542,6 +1613,9 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   // dosages on a decimal lattice (rvt_set_dosage_lattice): the caller's doubles when the hint says dosages, and what the
   // VCF dosage decoder wrote — gene_suffstat_lat (hc = 2), which tests every value like the hard-call kernel does
   const bool lat_possible = hc_possible && !nc.binary && !cov && c->lattice_den > 0;
+  // float-precision dosages (what the BGEN decoder wrote: kind 0; blocks of unknown content when rvt_set_dosage_float says
+  // so): gene_suffstat_fdx (hc = 4), which tests every value as well.  M <= 64; the batch's wave-parts are cut for it.
+  const bool fdx_possible = hc_possible && !nc.binary && !cov && c->fdx_ok && c->lattice_den == 0 && steps_per <= kFdxMaxSteps;
 
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
@@ -1574,6 +1648,10 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
         if (lat_possible && gd.MT <= kLatMaxMT && (k == 2 || (k < 0 && !predict_hc))) {
           gd.hc = 2;
           gd.lat_den = (double)c->lattice_den;
+        }
+        if (fdx_possible && gd.MT <= kFdxEngineMT && (k == 0 || (k < 0 && !predict_hc && c->dosage_float))) {
+          gd.hc = 4;
+          gd.lat_den = 0x1p37;
         }
       }
     }
@@ -1698,7 +1776,8 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
   // general-path genes of a mixed batch (a few genes with imputed values among hard-call ones) go to the second
   // sufficient-statistics stream and run beside the hard-call launches
-  const bool split = n_gen > 0 && n_hc > 0;
+  // (not beside the float-digit kernel: its whole-CU workgroups find no free CU while one-wave workgroups flood the chip)
+  const bool split = n_gen > 0 && n_hc > 0 && !fdx_batch;
   hipStream_t gst = split ? c->k2b_stream : c->k2_stream;
   if (split) HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_in[slot_idx], 0));
   int k0 = 0;
@@ -1724,13 +1803,16 @@ static int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, 
   if (pqw_bytes) HIP_TRY(c, hipMemsetAsync(base + off_pqw, 0, pqw_bytes, c->k2_stream));
   for (int k = n_gen; k < n;) {  // hard-call genes: one launch per tile class (contiguous runs, widest class first)
     int e = k;
-    const bool one_launch = hcx && c->hcx_fused && h_desc[k].hc == 1;  // (gene_suffstat_hcx_any: every class at once)
+    // (gene_suffstat_hcx_any / gene_suffstat_fdx_any: every class at once)
+    const bool one_launch = (hcx && c->hcx_fused && h_desc[k].hc == 1) || (h_desc[k].hc == 4 && c->hcx_fused);
     while (e < n && (one_launch || h_desc[e].MT == h_desc[k].MT) && h_desc[e].hc == h_desc[k].hc) ++e;
     hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
     if (h_desc[k].hc == 3)
       k2_launch_hcp(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
                     (long long)ld, d);
+    else if (h_desc[k].hc == 4)
+      k2_launch_fdx(one_launch ? 0 : h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->fdx_tile, (long long)N, (long long)ld, d);
     else if (h_desc[k].hc == 2)
       k2_launch_lat(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2},
                     (double)c->lattice_den, (long long)N, (long long)ld, d);
@@ -1986,6 +2068,10 @@ int rvt_reserve(rvt_ctx* c, int n, const int* Ms) {
   choose_split(nc.ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx);
   choose_split(nc.ld, n, nc.binary != 0, &n_wparts1, &steps_per1, false);  // (a batch that cannot take the cooperative kernel)
   n_wparts = std::max(n_wparts, n_wparts1);
+  if (!nc.binary && c->fdx_ok) {  // (a batch with float-precision dosages is cut into shorter wave-parts)
+    choose_split(nc.ld, n, false, &n_wparts1, &steps_per1, false, true);
+    n_wparts = std::max(n_wparts, n_wparts1);
+  }
   size_t total = 0, af_total = 0;
   GeneOff o;
   for (int g = 0; g < n; ++g) {
@@ -2153,7 +2239,7 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
       const double hh = s - 4.0 * (pij + pji) - 16.0 * q;
       s = hh + mu[j] * pij + mu[i] * pji + (mu[i] * mu[j]) * q;
     }
-    if (j < M && g0.hc == 2) s /= g0.lat_den * g0.lat_den;  // lattice dosages: the integer K'K, divided once (gene_assemble)
+    if (j < M && (g0.hc == 2 || g0.hc == 4)) s /= g0.lat_den * g0.lat_den;  // lattice dosages: the integer K'K, divided once (gene_assemble)
     return s;
   };
   for (int i = 0; i < M; ++i) {
@@ -2174,7 +2260,7 @@ int rvt_debug_suffstat(rvt_ctx* c, const double* dG, int M, double* S, double* T
       mn = std::min(mn, mu[i]);
       mx = std::max(mx, mu[i]);
     }
-    if (g0.hc == 2) s /= g0.lat_den;
+    if (g0.hc == 2 || g0.hc == 4) s /= g0.lat_den;
     if (colsum) colsum[i] = s;
     if (cmin) cmin[i] = mn;
     if (cmax) cmax[i] = mx;

@@ -44,6 +44,7 @@ constexpr int kFdxTW = 4;                // tile waves: a workgroup is 8 waves, 
 constexpr int kFdxWaveSteps = 2;         // 16-sample steps per loader wave and iteration (32 samples: one int8 operand)
 constexpr int kFdxIterSteps = kFdxNW * kFdxWaveSteps;
 constexpr int kFdxMaxMT = 5;
+constexpr int kFdxEngineMT = 4;          // widest class the ENGINE sends here: M in 65..80 (five pairs of nine tiles per wave) spills — fp64 kernel
 constexpr int kFdxStageCols = 8;         // null columns the kernel stages (d + 2 <= 8)
 constexpr int kFdxMaxSteps = 512;        // steps per wave-part: 8 192 samples keep the order sums below 2^31
 constexpr int kFdxOrders = 2 * kFdxPlanes - 1;
@@ -527,7 +528,9 @@ __global__ __launch_bounds__((kFdxNW + kFdxTW) * 64, 2) void gene_suffstat_fdx_a
     case 2: suffstat_fdx_body<2>(gd, nt, N, ld, d, lds); break;
     case 3: suffstat_fdx_body<3>(gd, nt, N, ld, d, lds); break;
     case 4: suffstat_fdx_body<4>(gd, nt, N, ld, d, lds); break;
-    case 5: suffstat_fdx_body<5>(gd, nt, N, ld, d, lds); break;
+    case 5:
+      if constexpr (TOP >= 5) suffstat_fdx_body<5>(gd, nt, N, ld, d, lds);
+      break;
     default: break;
   }
 }

@@ -85,7 +85,7 @@ def build_library(force=False, verbose=False):
     # eight objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     units = ["rvt_engine.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
-             "k2_hardcall_x.hip", "k2_lattice.hip", "k2_packed.hip"]
+             "k2_hardcall_x.hip", "k2_lattice.hip", "k2_packed.hip", "k2_floatdigit.hip"]
     objs, procs = [], []
     for u in units:
         obj = os.path.join(CSRC, u.replace(".hip", ".o"))
@@ -150,6 +150,8 @@ def load_library():
     L.rvt_host_unregister.argtypes = [vp, C.c_void_p]
     L.rvt_set_dosage_lattice.restype = C.c_int
     L.rvt_set_dosage_lattice.argtypes = [vp, C.c_int]
+    L.rvt_set_dosage_float.restype = C.c_int
+    L.rvt_set_dosage_float.argtypes = [vp, C.c_int]
     run_args = [vp, C.c_int, C.POINTER(vp), c_int_p, c_double_p, C.POINTER(C.c_int64), C.c_uint32,
                 C.POINTER(Params), C.POINTER(GeneResult)]
     L.rvt_run_blocks.restype = C.c_int
@@ -417,6 +419,11 @@ class Engine:
         """The dosage doubles are multiples of 1 / denominator rounded to double (VCF DS fields with a fixed number of
         decimals: 1000 for three); 0 = not stated (rvt_set_dosage_lattice).  Never affects correctness."""
         self._check(self.L.rvt_set_dosage_lattice(self.ctx, int(denominator)))
+
+    def set_dosage_float(self, on=True):
+        """Blocks of unknown content hold float-precision dosages (BGEN-style values: multiples of 2^-37): the float-digit
+        int8 kernel is tried first for M <= 64 (rvt_set_dosage_float).  Never affects correctness."""
+        self._check(self.L.rvt_set_dosage_float(self.ctx, 1 if on else 0))
 
     def classify_block(self, ptr, M):
         """Query (nothing is remembered): does the device block hold hard calls only (rvt_block_classify)?"""
