@@ -1030,14 +1030,15 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       }
     }
   }
-  if (!nc.binary && c->hc_enabled && d + 2 <= kFdxStageCols) {
-    // float-digit dosage kernel (suffstat_fdx.hip.h): the columns [X_0 .. X_{d-1} | res | 1] as five balanced base-256 digits of
-    // their fixed-point values — 38 bits below a power of two above the column's largest entry (|error| <= 2^-39 of it per
-    // entry, unbiased); the column of ones is the integer 1 (its tile column is the exact column sum of K).  Digits: the
-    // bytes of q + 0x8080808080 with the top bits flipped.
+  if (!nc.binary && c->hc_enabled && 2 * d + 3 <= kFdxStageCols) {
+    // float-digit dosage kernel (suffstat_fdx.hip.h): the columns [X_0 .. X_{d-1} | res | 1 | lo ..] as balanced base-256 digits
+    // of their fixed-point values Q = 256 hi + lo, 46 bits below a power of two above the column's largest entry (|error| <=
+    // 2^-47 of it per entry, unbiased): hi in the five digit planes of column k, lo (one digit) in plane 0 of column d + 2 + k;
+    // the column of ones is the integer 1 (its tile column is the exact column sum of K).  Digits of an integer q: the bytes of
+    // q + 0x8080808080 with the top bits flipped.
     const char* ef = getenv("RVT_FDX");
     bool okf = !(ef && atoi(ef) == 0);
-    const int ncf = d + 2;
+    const int ncf = 2 * d + 3;
     double scale[16];
     int shift[16];
     for (int k = 0; k < 16; ++k) {
@@ -1052,21 +1053,29 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       if (mx > 0.0) {
         int e;
         std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
-        shift[k] = 38 - e;        // |x| 2^shift < 2^38: the top digit stays below 64
+        shift[k] = 38 - e;        // |x| 2^shift < 2^38: the top digit of hi stays below 64
         scale[k] = std::ldexp(1.0, -shift[k]);
+        scale[d + 2 + k] = std::ldexp(1.0, -shift[k] - 8);
       }
     }
     if (okf) {
       const int64_t ngroups = (ld + 31) / 32 + 8;  // (padding: the kernel fetches the groups of an iteration, also past the end)
       std::vector<unsigned char> fx((size_t)ngroups * kFdxPlanes * 4 * ncf * 8, 0);
-      for (int64_t i = 0; i < N; ++i) {
+      auto put = [&](int64_t i, int k, long long qv) {
         const int64_t g = i >> 5, T = (i >> 4) & 1, q = (i >> 2) & 3, l = i & 3;
-        for (int k = 0; k < ncf; ++k) {
-          const long long qv = (k == d + 1) ? 1ll : llrint(std::ldexp((k < d) ? X[(size_t)k * N + i] : res[i], shift[k]));
-          const unsigned long long kb = (unsigned long long)(qv + 0x8080808080ll);
-          for (int p = 0; p < kFdxPlanes; ++p)
-            fx[(((size_t)(g * kFdxPlanes + p) * 4 + q) * ncf + k) * 8 + T * 4 + l] = (unsigned char)(((kb >> (8 * p)) & 0xffu) ^ 0x80u);
+        const unsigned long long kb = (unsigned long long)(qv + 0x8080808080ll);
+        for (int p = 0; p < kFdxPlanes; ++p)
+          fx[(((size_t)(g * kFdxPlanes + p) * 4 + q) * ncf + k) * 8 + T * 4 + l] = (unsigned char)(((kb >> (8 * p)) & 0xffu) ^ 0x80u);
+      };
+      for (int64_t i = 0; i < N; ++i) {
+        for (int k = 0; k <= d; ++k) {
+          const long long Q = llrint(std::ldexp((k < d) ? X[(size_t)k * N + i] : res[i], shift[k] + 8));
+          long long lo = Q & 255;
+          if (lo >= 128) lo -= 256;
+          put(i, k, (Q - lo) >> 8);
+          put(i, d + 2 + k, lo);
         }
+        put(i, d + 1, 1ll);
       }
       HIP_TRY(c, hipMalloc((void**)&c->d_fxq, fx.size()));
       HIP_TRY(c, hipMemcpy(c->d_fxq, fx.data(), fx.size(), hipMemcpyHostToDevice));

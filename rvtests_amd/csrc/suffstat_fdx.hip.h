@@ -45,18 +45,23 @@ constexpr int kFdxWaveSteps = 2;         // 16-sample steps per loader wave and 
 constexpr int kFdxIterSteps = kFdxNW * kFdxWaveSteps;
 constexpr int kFdxMaxMT = 5;
 constexpr int kFdxEngineMT = 4;          // widest class the ENGINE sends here: M in 65..80 (five pairs of nine tiles per wave) spills — fp64 kernel
-constexpr int kFdxStageCols = 8;         // null columns the kernel stages (d + 2 <= 8)
+constexpr int kFdxStageCols = 16;        // null columns the kernel stages (2 d + 3 <= 16)
 constexpr int kFdxMaxSteps = 512;        // steps per wave-part: 8 192 samples keep the order sums below 2^31
 constexpr int kFdxOrders = 2 * kFdxPlanes - 1;
 
-// Null-model operands (rvt_set_null): five balanced base-256 digit planes of the columns [X_0 .. X_{d-1} | res | 1] (the last
-// one is the integer 1 with scale 1: its tile column is the exact column sum of K), in the order
-// the tile waves read them: [group of 32 samples][plane 0..4][q 0..3][column k < ncols] x 8 bytes, byte 4 T + l = digit of
-// sample 32 g + 16 T + 4 q + l; padded by four groups.  value of column k = integer x scale[k] (a power of two).
+// Null-model operands (rvt_set_null): five balanced base-256 digit planes of the columns
+//     [X_0 .. X_{d-1} | res | 1 | lo(X_0) .. lo(X_{d-1}) | lo(res)]
+// Every null column x is the 46-bit fixed-point value 256 hi + lo (hi in five digits, lo ONE digit in [-128, 127] that sits in
+// plane 0 of a column of its own): 2^-47 of the column's largest entry per entry, the precision the other integer kernels
+// give their null tiles (five digits alone leave scores that differ from the fp64 path's in the twelfth digit).  The kernel
+// adds the two tile columns of a null column when it stores them (lane v and lane v + d + 2 of a 16-lane row).  The column
+// of ones is the integer 1 with scale 1: its tile column is the exact column sum of K.  Layout, in the order the tile waves
+// read it: [group of 32 samples][plane 0..4][q 0..3][column k < ncols] x 8 bytes, byte 4 T + l = digit of sample
+// 32 g + 16 T + 4 q + l; padded by eight groups.  value of column k = integer x scale[k] (a power of two).
 struct NullTileF {
   const unsigned char* xq;
   double scale[16];
-  int ncols;  // d + 2 <= kFdxStageCols
+  int ncols;  // 2 d + 3 <= kFdxStageCols
 };
 
 // ---- tile pairs: (r, c) with r <= c <= MT in row-major order; c == MT: the null tile --------------------------------
@@ -319,7 +324,7 @@ __device__ __forceinline__ void suffstat_fdx_body(const GeneDesc& gd, const Null
         for (int e = 0; e < 4; ++e) {
           const int row = pr_r[i] * 16 + q * 4 + e;
           const double xi = value(acc[i], e, kFdxOrders - 1);
-          const double x = xi * sc;
+          const double x = xi * sc + __shfl_down(xi * sc, d + 2, 16);  // (+ the column's low digit: lane v + d + 2 of the row)
           if (M + v < Cp) out[(long long)row * Cp + M + v] = (v <= d) ? x : 0.0;
           if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
           if (v == d + 1) cst0[row] = xi;  // the ones column: the integer sum of K of the row's variant
@@ -337,7 +342,9 @@ __device__ __forceinline__ void suffstat_fdx_body(const GeneDesc& gd, const Null
         return x;
       };
       const double sc = nt.scale[v];
-      const double ac = planes(0) * sc, az = planes(1) * sc;
+      double ac = planes(0) * sc, az = planes(1) * sc;
+      ac += __shfl_down(ac, d + 2, 16);  // (+ the columns' low digits)
+      az += __shfl_down(az, d + 2, 16);
       const int rl = 3 + d;
       double* bp = gd.bparts + (long long)wpart * 2 * rl;
       if (lane <= d) {

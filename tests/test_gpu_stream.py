@@ -1,6 +1,8 @@
 """GPU: long streams through every streaming entry point.  More genes than one launch group (16) are in flight, so blocks are
 decoded / consolidated on the transfer stream WHILE earlier groups compute — the records must be those of the same genes
 submitted as finished fp64 blocks, whatever the entry point."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -31,7 +33,7 @@ def _reference(eng, mats):
 
 @pytest.mark.parametrize("mode", ["raw", "i8", "bed", "vcf", "bgen"])
 def test_long_stream_equals_block_submission(eng, mode):
-    rng = np.random.default_rng(hash(mode) % 1000)
+    rng = np.random.default_rng(zlib.crc32(mode.encode()) % 1000)   # (str hashes change from process to process)
     N, d, n_genes = 3000, 2, 45
     X, y, res, v, s2 = synth.make_null(N, d, 0, seed=6)
     eng.set_null(0, X, res, v, s2)

@@ -71,21 +71,22 @@ static Null make_null(long long N, int d, unsigned long long seed) {
   nl.N = N;
   nl.ld = (N + 15) / 16 * 16;
   nl.d = d;
-  nl.ncols = d + 2;
+  nl.ncols = 2 * d + 3;  // [X_0 .. | res | 1 | low digits of X_0 .. res] as rvt_set_null lays them out
   const long long ld = nl.ld;
   nl.X.assign((size_t)nl.ncols * ld, 0);
   const long long ngroups = (ld + 31) / 32 + 8;
   nl.xq.assign((size_t)ngroups * kFdxPlanes * 4 * nl.ncols * 8, 0);
   for (long long i = 0; i < N; ++i)
     for (int k = 0; k < nl.ncols; ++k) {
-      long long x = (k == d + 1) ? 1 : (long long)(mix(seed * 77 + i * 16 + k) % (1ull << 39)) - (1ll << 38);
+      long long x = (k == d + 1) ? 1 : (k > d + 1) ? (long long)(mix(seed * 91 + i * 16 + k) % 256ull) - 128
+                                   : (long long)(mix(seed * 77 + i * 16 + k) % (1ull << 39)) - (1ll << 38);
       nl.X[(size_t)k * ld + i] = x;
       const unsigned long long kb = (unsigned long long)(x + 0x8080808080ll);   // balanced base-256 digits: the biased bytes ^ 0x80
       const long long g = i >> 5, T = (i >> 4) & 1, q = (i >> 2) & 3, l = i & 3;
       for (int p = 0; p < kFdxPlanes; ++p)
         nl.xq[(((size_t)(g * kFdxPlanes + p) * 4 + q) * nl.ncols + k) * 8 + T * 4 + l] = (unsigned char)(((kb >> (8 * p)) & 0xff) ^ 0x80);
     }
-  for (int k = 0; k < 16; ++k) nl.scale[k] = (k == d + 1) ? 1.0 : std::ldexp(1.0, -40 + k % 3);
+  for (int k = 0; k < 16; ++k) nl.scale[k] = (k == d + 1) ? 1.0 : (k > d + 1) ? std::ldexp(1.0, -48 + (k - d - 2) % 3) : std::ldexp(1.0, -40 + k % 3);
   return nl;
 }
 
@@ -223,11 +224,14 @@ static int check() {
           expect(near(got, d128(s)), "K'K", j, k, got, d128(s));
         }
         for (int k = 0; k < 16 && M + k < Cp; ++k) {
-          i128 s = 0;
+          i128 s = 0, sl = 0;
           if (k <= d)
-            for (long long i = i0; i < i1; ++i) s += (i128)K[(size_t)i * M + j] * nl.X[(size_t)k * ld + i];
+            for (long long i = i0; i < i1; ++i) {
+              s += (i128)K[(size_t)i * M + j] * nl.X[(size_t)k * ld + i];
+              sl += (i128)K[(size_t)i * M + j] * nl.X[(size_t)(k + d + 2) * ld + i];
+            }
           const double got = parts[((size_t)p * Mp + j) * Cp + M + k];
-          const double want = d128(s) * (nl.scale[k] * 0x1p-37);
+          const double want = (k <= d) ? d128(s) * (nl.scale[k] * 0x1p-37) + d128(sl) * (nl.scale[k + d + 2] * 0x1p-37) : 0.0;
           expect(near(got, want), "K'[X|res]", j, k, got, want);
         }
         long long s = 0;
@@ -257,17 +261,21 @@ static int check() {
         cnt += n > 0;
         for (int t = 0; t < 2; ++t) {
           cc2[t] += c[t] * c[t];
-          for (int k = 0; k <= d; ++k) cx[t][k] += (i128)c[t] * nl.X[(size_t)k * ld + i];
+          for (int k = 0; k <= d; ++k) {
+            cx[t][k] += (i128)c[t] * nl.X[(size_t)k * ld + i];
+            cx[t][8 + k] += (i128)c[t] * nl.X[(size_t)(k + d + 2) * ld + i];
+          }
         }
       }
       (void)U;
       const int rl = 3 + d;
       for (int t = 0; t < 2; ++t) {
         const double* b = bparts.data() + ((size_t)p * 2 + t) * rl;
-        expect(near(b[0], d128(cx[t][d]) * nl.scale[d]), "burden U", t, p, b[0], d128(cx[t][d]) * nl.scale[d]);
+        auto both = [&](int k) { return d128(cx[t][k]) * nl.scale[k] + d128(cx[t][8 + k]) * nl.scale[k + d + 2]; };
+        expect(near(b[0], both(d)), "burden U", t, p, b[0], both(d));
         expect(b[1] == (double)cc2[t], "burden c'c", t, p, b[1], (double)cc2[t]);
         expect(b[2] == (double)cnt, "burden count", t, p, b[2], (double)cnt);
-        for (int k = 0; k < d; ++k) expect(near(b[3 + k], d128(cx[t][k]) * nl.scale[k]), "burden c'X", t, k, b[3 + k], d128(cx[t][k]) * nl.scale[k]);
+        for (int k = 0; k < d; ++k) expect(near(b[3 + k], both(k)), "burden c'X", t, k, b[3 + k], both(k));
       }
     }
     expect(fl == 0u, "wflags", 0, 0, fl, 0);
