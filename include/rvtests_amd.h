@@ -630,6 +630,8 @@ int rvt_group_host_register(rvt_group* group, const void* ptr, size_t bytes);
 int rvt_group_host_unregister(rvt_group* group, const void* ptr);
 /* rvt_set_content_hint + rvt_set_dosage_lattice on every member (what the caller's blocks hold: see those functions) */
 int rvt_group_set_content(rvt_group* group, int hint, int lattice_denominator);
+/* rvt_set_dosage_float on every member */
+int rvt_group_set_dosage_float(rvt_group* group, int on);
 /* `--meta score` / `--meta cov` over a group (chunks with a one-window halo, no exchange).  G_host: N x V
  * column-major (leading dimension N), the genotype vectors of V consecutive single-variant fit() calls; one host thread per
  * member for the duration of the call.

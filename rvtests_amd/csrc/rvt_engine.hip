@@ -554,7 +554,7 @@ void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* st
   // (cooperative kernel: one workgroup per CU — about eight rounds of workgroups over the chip balance a launch; fewer, longer
   //  wave-parts measured better down to that: 47.8 k gene-sets/s with 16 parts, 49.6 k with 8, 50.4-50.9 k with 5-6 at N = 200 000)
   const int coop = std::min(32, std::max(4, (2048 + n_genes - 1) / std::max(n_genes, 1)));
-  const int target = forced > 0 ? forced : (hcx ? coop : (n_genes >= 128 ? 64 : 128));
+  const int target = forced > 0 ? forced : (hcx ? coop : (n_genes >= 1024 ? 32 : (n_genes >= 128 ? 64 : 128)));
   int64_t spw = (nsteps + target - 1) / target;
   if (spw < 64) spw = 64;
   const int unit = hcx ? 3 * kHcxIterSteps : kHcStepUnit;     // (48: whole iterations of both kernels)

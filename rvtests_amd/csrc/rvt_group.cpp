@@ -286,6 +286,13 @@ int rvt_group_set_content(rvt_group* g, int hint, int lattice_denominator) {
   return RVT_OK;
 }
 
+int rvt_group_set_dosage_float(rvt_group* g, int on) {
+  if (!g) return RVT_E_INVALID;
+  for (rvt_ctx* m : g->member)
+    if (int rc = rvt_set_dosage_float(m, on)) return gfail(g, rc, "rvt_group_set_dosage_float", m);
+  return RVT_OK;
+}
+
 int rvt_group_rand_seed(rvt_group* g, unsigned seed) {
   if (!g) return RVT_E_INVALID;
   if (int rcf = group_flush(g)) return rcf;

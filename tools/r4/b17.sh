@@ -1,0 +1,17 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4b17
+run() { tag=$1; shift; env "$@" > gpurun_out/r4b17/$tag.json 2> gpurun_out/r4b17/$tag.err; python - gpurun_out/r4b17/$tag.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1], round(d['value']), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['avg_launch_ms'],3), round(d['kernel_time_share']['device_ms_per_step'],1))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e); print(open(sys.argv[1].replace('.json','.err')).read()[-800:])
+PY
+}
+C1="python bench.py --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1"
+run c1_default $C1
+run c1_w32 RVT_WPARTS=32 $C1
+run c1_w16 RVT_WPARTS=16 $C1
+run c1_w8 RVT_WPARTS=8 $C1
+run c1_default2 $C1
