@@ -111,7 +111,7 @@ __device__ __forceinline__ float bgen_stored_prob(const unsigned char* __restric
 }
 
 // pass 1.  seg_count[variant * max_seg + segment] = packed values of the segment's samples
-__global__ __launch_bounds__(kBgenSeg) void bgen_count_kernel(const unsigned char* __restrict__ data,
+static __global__ __launch_bounds__(kBgenSeg) void bgen_count_kernel(const unsigned char* __restrict__ data,
                                                               const BgenRecord* __restrict__ rec, long long N,
                                                               int max_seg, long long* __restrict__ seg_count,
                                                               int* __restrict__ err) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBgenSeg) void bgen_count_kernel(const unsigned cha
 
 // pass 2: exclusive scan over the segments of one variant (in place); a block whose packed area is shorter than its
 // ploidy bytes demand raises *err (host-visible) to variant index + 1
-__global__ __launch_bounds__(256) void bgen_scan_kernel(const BgenRecord* __restrict__ rec, long long N, int max_seg,
+static __global__ __launch_bounds__(256) void bgen_scan_kernel(const BgenRecord* __restrict__ rec, long long N, int max_seg,
                                                         long long* __restrict__ seg_count, int* __restrict__ err) {
   const BgenRecord r = rec[blockIdx.x];
   if (r.layout != 2) return;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void bgen_scan_kernel(const BgenRecord* __rest
 
 // pass 3.  out[row_of_sample[i] + variant * ld] = the genotype of file sample i (rows the map never addresses are
 // filled beforehand)
-__global__ __launch_bounds__(kBgenSeg) void bgen_decode_kernel(const unsigned char* __restrict__ data,
+static __global__ __launch_bounds__(kBgenSeg) void bgen_decode_kernel(const unsigned char* __restrict__ data,
                                                                const BgenRecord* __restrict__ rec, long long N,
                                                                int max_seg, const long long* __restrict__ seg_count,
                                                                const int* __restrict__ row_of_sample, long long ld,

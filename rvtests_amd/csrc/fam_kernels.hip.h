@@ -16,13 +16,13 @@
 
 namespace rvt {
 
-__global__ void cvt_f32_f64_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+static __global__ void cvt_f32_f64_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = (double)in[i];
 }
 
 // out[k] = sum_i A[i + k*lda], one workgroup per column, fixed reduction order
-__global__ __launch_bounds__(256) void column_sums_kernel(const double* __restrict__ A, long long n, long long lda,
+static __global__ __launch_bounds__(256) void column_sums_kernel(const double* __restrict__ A, long long n, long long lda,
                                                           double* __restrict__ out) {
   __shared__ double red[256];
   const double* col = A + (long long)blockIdx.x * lda;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void column_sums_kernel(const double* __restri
 constexpr int kLmmBlocks = 256;
 __host__ __device__ constexpr int lmm_rec_len(int d) { return d * d + d + 2; }
 
-__global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict__ uxy, const double* __restrict__ lam,
+static __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict__ uxy, const double* __restrict__ lam,
                                                        long long N, int d, double delta, int take_abs,
                                                        double* __restrict__ partial) {
   extern __shared__ double sm[];  // 256 doubles
@@ -171,6 +171,8 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel(const SRC* __res
 // PLINK 2-bit rows: one thread per BYTE (four samples), the three counts by population counts of bit masks — a quarter of
 // the iterations of the generic kernel and no floating point (45 -> ~10 microseconds for a 500 000 x 50 gene: the count
 // sits between the host copy of a gene and its expansion).  Hard calls: the truncating accumulation is an integer sum.
+// (a full specialisation is an ordinary function: it lives in the ONE translation unit that launches it, rvt_stream.hip)
+#ifdef RVT_STREAM_UNIT
 template <>
 __global__ __launch_bounds__(256) void consolidate_count_kernel<bed2_t>(const bed2_t* __restrict__ src, long long src_ld,
                                                                         long long N, ConsolPart* __restrict__ parts) {
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel<bed2_t>(const be
         ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, (int)s_n2[0]};  // pad = #(g = 2)
   }
 }
+#endif
 
 // one wave per column: AF and the imputation value
 template <typename SRC>
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void consolidate_write_kernel(const SRC* __res
 // ---- unrelated null models on the device (LinearRegression.cpp:20-69, LogisticRegression.cpp:279-336) ----------------
 // One IRLS round: p = 1/(1+exp(-X beta)), V = p(1-p) stored; per-workgroup partial record
 //   D = X'VX (d x d), r = X'(y - p) (d), dev = sum y log p + (1-y) log(1-p)      -> lmm_rec_len(d) doubles (last slot unused... dev in slot d*d+d)
-__global__ __launch_bounds__(256) void logistic_round_kernel(const double* __restrict__ X, const double* __restrict__ y,
+static __global__ __launch_bounds__(256) void logistic_round_kernel(const double* __restrict__ X, const double* __restrict__ y,
                                                              const double* __restrict__ beta, long long N,
                                                              long long ldx, int d, double* __restrict__ p_out,
                                                              double* __restrict__ v_out, double* __restrict__ partial) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void logistic_round_kernel(const double* __res
 }
 
 // res = y - X beta (linear) and per-workgroup partial sum of res^2
-__global__ __launch_bounds__(256) void linear_residual_kernel(const double* __restrict__ X, const double* __restrict__ y,
+static __global__ __launch_bounds__(256) void linear_residual_kernel(const double* __restrict__ X, const double* __restrict__ y,
                                                               const double* __restrict__ beta, long long N,
                                                               long long ldx, int d, double* __restrict__ res,
                                                               double* __restrict__ partial) {
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void linear_residual_kernel(const double* __re
 }
 
 // The "null set" the sufficient-statistics kernels read in FamSKAT mode (see the header comment).
-__global__ void fam_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
+static __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                       const double* __restrict__ u1, long long N, long long ld, int d, double sigma2,
                                       double delta, const double* __restrict__ beta, double* __restrict__ Xin,
                                       double* __restrict__ rr, double* __restrict__ v) {
@@ -353,7 +356,7 @@ __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const doub
 }
 
 // null set of the family MetaCov (MetaCovFamQtl): weights D = 1/((|S| + delta) sigma2), columns [U'X | u1]
-__global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
+static __global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                          const double* __restrict__ u1, long long N, long long ld, int d,
                                          double sigma2, double delta, const double* __restrict__ beta,
                                          double* __restrict__ Xin, double* __restrict__ rr, double* __restrict__ v) {
@@ -374,7 +377,7 @@ __global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const d
 
 // cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130) of flipped, filtered blocks: gene k owns columns
 // [off[k], off[k] + m[k]) of Gp and writes its two collapsed columns to out + (2k) * ld and out + (2k+1) * ld
-__global__ void fam_collapse_kernel(const double* __restrict__ Gp, const int* __restrict__ off,
+static __global__ void fam_collapse_kernel(const double* __restrict__ Gp, const int* __restrict__ off,
                                     const int* __restrict__ m, long long N, long long ld, double* __restrict__ out) {
   const int k = blockIdx.y;
   const double* g0 = Gp + (long long)off[k] * ld;
@@ -388,7 +391,7 @@ __global__ void fam_collapse_kernel(const double* __restrict__ Gp, const int* __
 }
 
 // FastLMM::TestCovariate, SCORE branch (FastLMM.cpp:236-247): stat = U^2 / V, p = chisq_Q(stat, 1) when V > 0
-__global__ void fam_burden_finish_kernel(const double* __restrict__ cov, int V, const double* __restrict__ ustat,
+static __global__ void fam_burden_finish_kernel(const double* __restrict__ cov, int V, const double* __restrict__ ustat,
                                          double* __restrict__ vstat, double* __restrict__ pval) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= V) return;
@@ -398,7 +401,7 @@ __global__ void fam_burden_finish_kernel(const double* __restrict__ cov, int V, 
 }
 
 // raw column sum + monomorphic flag of the columns of one block (MetaCov family mode)
-__global__ __launch_bounds__(256) void raw_colstat_kernel(const double* __restrict__ G, long long N, long long ld,
+static __global__ __launch_bounds__(256) void raw_colstat_kernel(const double* __restrict__ G, long long N, long long ld,
                                                           double* __restrict__ colsum, int* __restrict__ poly) {
   __shared__ double rs[256], rmn[256], rmx[256];
   const double* col = G + (long long)blockIdx.x * ld;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void raw_colstat_kernel(const double* __restri
 }
 
 // flip / polymorphic decision per genotype column (DataConsolidator.cpp:46-69,94-116): bit 0 = flip, bit 1 = keep
-__global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* __restrict__ cols, long long N,
+static __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* __restrict__ cols, long long N,
                                                           int* __restrict__ flags) {
   __shared__ double rs[256], rmn[256], rmx[256];
   const double* col = cols[blockIdx.x];
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* _
 
 // kept hard-call columns straight to the int8 plane of the rotation GEMM ([column][ldk] bytes), flipped to 2 - g where
 // flagged: what fam_flip_compact_kernel + the column quantiser produce, in one pass over the genotypes
-__global__ void fam_flip_quant_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
+static __global__ void fam_flip_quant_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
                                       long long N, long long ldk, signed char* __restrict__ dst) {
   const double* s = src_cols[blockIdx.y];
   const bool fl = src_flip[blockIdx.y] != 0;
@@ -480,7 +483,7 @@ __global__ void fam_flip_quant_kernel(const double* const* __restrict__ src_cols
 }
 
 // dst column c (of the compact N x T matrix, leading dimension ld) = kept source column, flipped to 2 - g if flagged
-__global__ void fam_flip_compact_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
+static __global__ void fam_flip_compact_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
                                         long long N, long long ld, double* __restrict__ dst) {
   const double* s = src_cols[blockIdx.y];
   const bool fl = src_flip[blockIdx.y] != 0;
@@ -548,7 +551,7 @@ RVT_HD void fam_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, in
   co.sync();
 }
 
-__global__ __launch_bounds__(1024) void fam_assemble_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(1024) void fam_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                            const NullConsts* __restrict__ ncp) {
   __shared__ double red[64];
   __shared__ NullConsts nc;

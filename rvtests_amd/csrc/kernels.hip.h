@@ -23,7 +23,7 @@ namespace rvt {
 //   flip:  column sum > N       convertToMinorAlleleCount   src/DataConsolidator.cpp:46-69
 //   poly:  min != max           isMonomorphicMarker          src/DataConsolidator.cpp:94-116
 // =====================================================================================================
-__global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restrict__ genes, long long N) {
+static __global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restrict__ genes, long long N) {
   const GeneDesc gd = genes[blockIdx.x];
   // (a hard-call gene: only when it was handed back and gene_suffstat_mfma has computed it — three-row statistics)
   if (gd.hc && gd.flags[2 * gd.MT + 1] == 0) return;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 // =====================================================================================================
 // lists: [0] number of handed-back genes, [1] number of genes whose burden sums are redone, [4 ..) / [4 + n_genes ..) their
 // indices (the work lists of the conditional general-kernel launch and of burden_fallback_kernel; zeroed by the host).
-__global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N,
+static __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N,
                                                            int* __restrict__ lists, int n_genes) {
   const GeneDesc gd = genes[blockIdx.x];
   const int tid = threadIdx.x;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
 //      (one shared reduction serves the 12 SKAT-O eigenproblems, see rvt_gene.h stage B).
 // K3c: one workgroup per (eigenproblem, gene): Sturm bisection of its tridiagonal, eigenvalue filter, moments.
 // =====================================================================================================
-__global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
                                                             unsigned tests, int n_bparts, const double* xscale) {
   __shared__ double red[64];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __r
                 gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, handed_back ? kStatusHandedBack : 0u);
 }
 
-__global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
                                                            const NullConsts* __restrict__ ncp, unsigned tests,
                                                            int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double esm[];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __res
   gene_tridiag(co, *ncp, which, gd.M, gd.Mp, tests, ws, Bm, vec, gd.stats);
 }
 
-__global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, unsigned tests) {
   extern __shared__ __attribute__((aligned(16))) double esm[];  // 4 * Mp doubles
   __shared__ double red[64];
@@ -419,7 +419,7 @@ struct CovConsts {
 };
 
 // one workgroup: column sums, polymorphic flags, T = G'DX, covXZ   (xz: V x d row-major; colsum: V)
-__global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
+static __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
                                                           double* __restrict__ xz, double* __restrict__ colsum,
                                                           int* __restrict__ poly, double* __restrict__ ustat,
                                                           double* __restrict__ afout) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __rest
 }
 
 // grid = V workgroups (one per head h): value(h, j) for j >= h into cov[h + j*V]
-__global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
+static __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
                                                        const double* __restrict__ xz,
                                                        const double* __restrict__ colsum, double* __restrict__ cov) {
   const GeneDesc gd = genes[0];
@@ -836,7 +836,7 @@ __device__ __forceinline__ void vt_sections(double* vt_mem, int Mp, double** alp
 // shift — stage 0: points [0, kVtStage0); stage 1 (genes whose first estimate was not accurate enough): the points up to
 // kMvnPoints.  One thread = one lattice point at a time; the factor sits in LDS when it fits, the per-thread vectors of
 // conditioned values in the workspace ([dimension][thread]: coalesced).
-__global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc* __restrict__ genes, int stage) {
+static __global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc* __restrict__ genes, int stage) {
   const GeneDesc gd = genes[blockIdx.x];
   double* vt_mem = gd.vt_mem;
   if (!vt_mem || vt_mem[0] != 1.0) return;
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc* __res
 
 // one thread per gene: estimate and error from the shift sums; after stage 0 genes that are not accurate enough ask for
 // stage 1
-__global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int n, int stage) {
+static __global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int n, int stage) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const GeneDesc gd = genes[g];
@@ -895,7 +895,7 @@ __global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int n, int 
 }
 
 // the unrelated-sample test: u and Wm are where gene_assemble left them (one workgroup per gene)
-__global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
                                                       const NullConsts* __restrict__ ncp) {
   const GeneDesc gd = genes[blockIdx.x];
   const GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict
 
 // the related-sample test (FamAnalyticVT): frequency, score and variance matrix prepared by the host from the family
 // covariance machinery; buf = af[m] | u[m] | V[m x m] | workspace
-__global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, double* __restrict__ buf, rvt_gene_result* out) {
+static __global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, double* __restrict__ buf, rvt_gene_result* out) {
   vt_core(m, Mp, buf, buf + m, buf + 2 * (size_t)m, 1.0, false, buf + 2 * (size_t)m + (size_t)m * m, out);
 }
 
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, double* _
 // The block is submitted as one "gene" per slice of <= 16 columns (only the diagonal tile and the [X | rr] tile are
 // needed, so each slice streams once at the narrow-class rate); gene_id carries the slice's first column.
 // out: ustat | vstat | effect | se | pval (vt entries each); ok[h] = 1 when the site is polymorphic and SS > 0.
-__global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __restrict__ genes,
+static __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __restrict__ genes,
                                                           const NullConsts* __restrict__ ncp, int vt,
                                                           double* __restrict__ out, int* __restrict__ ok) {
   const GeneDesc gd = genes[blockIdx.x];
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __rest
 // S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from the integer-plane products of
 // rot_gemm.hip.h (gemm_tn_planes; exact for hard calls and an unweighted model); cs = raw column sums
 // of the W window columns (the H heads are its first H columns).  Unrelated samples only.
-__global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
+static __global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
                                    double* __restrict__ xz) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= W) return;
@@ -1013,7 +1013,7 @@ __global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, c
 }
 
 // grid = H workgroups: cov[h + j*H] for j >= h
-__global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const double* __restrict__ S,
+static __global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const double* __restrict__ S,
                                                             const double* __restrict__ cs,
                                                             const double* __restrict__ xz, int H, int W,
                                                             double* __restrict__ cov) {
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const 
 
 // family mode of the two rectangle kernels (MetaCovFamQtl on rotated data, regression/FastLMM.cpp:510-595): T holds
 // G~_W' D [U'X | u1] (W x (d + 1), column-major), cs the RAW column sums; see CovConsts for the centring algebra
-__global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
+static __global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
                                        double* __restrict__ xz, double* __restrict__ t1) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= W) return;
@@ -1045,7 +1045,7 @@ __global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __restrict__ 
   for (int k = 0; k < cc.d; ++k) xz[(long long)j * cc.d + k] = T[j + (long long)k * W] - m * cc.zsum[k];
   t1[j] = T[j + (long long)cc.d * W];
 }
-__global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts cc, const double* __restrict__ S,
+static __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts cc, const double* __restrict__ S,
                                                                 const double* __restrict__ cs,
                                                                 const double* __restrict__ xz,
                                                                 const double* __restrict__ t1, int H, int W,
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 }
 
 // one thread per (column, field): colsum, poly, T (W x d column-major)
-__global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices, int W, int d, int dmax,
+static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices, int W, int d, int dmax,
                                      double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int F = dmax + 3;
@@ -1176,7 +1176,7 @@ __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices
 }
 
 // dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)
-__global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
+static __global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
                                   long long ld, double* __restrict__ dst) {
   const double* s = src + (long long)blockIdx.y * ld;
   double* d = dst + (long long)blockIdx.y * ld;

@@ -334,7 +334,7 @@ constexpr int kRotThreads = RVT_ROT_THREADS;
 
 // C[m + j ldc] = (accumulate ? C : 0) + sum over slices of part[s * stride + m + j ldc], m < M, j < N (fixed order:
 // reproducible; rows M .. ldc-1 of C are not touched)
-__global__ void rot_reduce_slices_kernel(const double* __restrict__ part, long long ldc, long long M, long long N,
+static __global__ void rot_reduce_slices_kernel(const double* __restrict__ part, long long ldc, long long M, long long N,
                                          long long stride, int slices, double* __restrict__ C, int accumulate) {
   const long long total = M * N;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void rot_digits(long long q, int planes, signed char*
 
 // float matrix (column-major, n x ncols, leading dimension lds_src) -> digit planes [plane][col][ldk]; entries scaled
 // by 2^sexp.  flag[0] is set when an entry does not fit (|u| * 2^sexp >= 2^(7 planes - 2)).
-__global__ void rot_quantize_f32_kernel(const float* __restrict__ src, long long n, long long ncols, long long ld_src,
+static __global__ void rot_quantize_f32_kernel(const float* __restrict__ src, long long n, long long ncols, long long ld_src,
                                         int sexp, int planes, signed char* __restrict__ dst, long long ldk,
                                         long long plane_stride, long long col0, int* __restrict__ flag) {
   const double scale = ldexp(1.0, sexp), lim = ldexp(1.0, 7 * planes - 2);
@@ -376,7 +376,7 @@ __global__ void rot_quantize_f32_kernel(const float* __restrict__ src, long long
 }
 
 // first / last row with a non-zero entry per column of a float matrix (lo = n, hi = -1 for an all-zero column)
-__global__ void rot_span_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ lo,
+static __global__ void rot_span_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ lo,
                                 int* __restrict__ hi) {
   __shared__ int slo[256], shi[256];
   const float* s = src + (long long)blockIdx.x * ld_src;
@@ -403,7 +403,7 @@ __global__ void rot_span_kernel(const float* __restrict__ src, long long n, long
 }
 
 // dst row r = src row order[r] of a [rows][ldk] byte matrix (ldk a multiple of 16); grid = rows
-__global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, const int* __restrict__ order, long long ldk,
+static __global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, const int* __restrict__ order, long long ldk,
                                        signed char* __restrict__ dst) {
   const uint4* s = reinterpret_cast<const uint4*>(src + (long long)order[blockIdx.x] * ldk);
   uint4* d = reinterpret_cast<uint4*>(dst + (long long)blockIdx.x * ldk);
@@ -412,7 +412,7 @@ __global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, cons
 
 // ---- sparse eigenvectors (families interleaved in the sample order) --------------------------------------------------------
 // non-zeros per column of a float matrix; grid = columns
-__global__ void rot_nnz_count_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ count) {
+static __global__ void rot_nnz_count_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ count) {
   __shared__ int red[256];
   const float* s = src + (long long)blockIdx.x * ld_src;
   int c = 0;
@@ -426,7 +426,7 @@ __global__ void rot_nnz_count_kernel(const float* __restrict__ src, long long n,
   if (threadIdx.x == 0) count[blockIdx.x] = red[0];
 }
 // the non-zeros of column blockIdx.x, in ascending row order, to rows / vals at offset colptr[blockIdx.x]; 256 threads
-__global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* __restrict__ src, long long n, long long ld_src,
+static __global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* __restrict__ src, long long n, long long ld_src,
                                                            const long long* __restrict__ colptr, int* __restrict__ rows,
                                                            double* __restrict__ vals) {
   __shared__ int wsum[4];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* __restri
 }
 // out[k + t ld_dst] = sum over the non-zeros e of column k of U: vals[e] * G[rows[e] + t ld_src]   (U' G for sparse U);
 // grid (ceil(n / 256), columns of G)
-__global__ __launch_bounds__(256) void rot_sparse_kernel(const long long* __restrict__ colptr, const int* __restrict__ rows,
+static __global__ __launch_bounds__(256) void rot_sparse_kernel(const long long* __restrict__ colptr, const int* __restrict__ rows,
                                                          const double* __restrict__ vals, long long n,
                                                          const double* __restrict__ G, long long ld_src,
                                                          double* __restrict__ out, long long ld_dst) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void rot_sparse_kernel(const long long* __rest
 }
 
 // per-column max |x| of a double matrix (column-major, ld)
-__global__ void rot_colmax_kernel(const double* __restrict__ src, long long n, long long ld, double* __restrict__ out) {
+static __global__ void rot_colmax_kernel(const double* __restrict__ src, long long n, long long ld, double* __restrict__ out) {
   __shared__ double red[256];
   const double* s = src + (long long)blockIdx.x * ld;
   double m = 0.0;
@@ -494,7 +494,7 @@ __global__ void rot_colmax_kernel(const double* __restrict__ src, long long n, l
 
 // double columns -> digit planes.  planes == 1: the entries are integers in [-128, 127], stored as they are (sexp[j]
 // must be 0); else entries scaled by 2^sexp[j].
-__global__ void rot_quantize_f64_kernel(const double* __restrict__ src, long long n, long long ncols, long long ld_src,
+static __global__ void rot_quantize_f64_kernel(const double* __restrict__ src, long long n, long long ncols, long long ld_src,
                                         const int* __restrict__ sexp, int planes, signed char* __restrict__ dst,
                                         long long ldk, long long plane_stride) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n * ncols;

@@ -61,7 +61,7 @@ __device__ __forceinline__ int vcf_tabs16(const char* __restrict__ text, long lo
 }
 
 // pass 1: tabs per segment.  grid (max segments, records), 256 threads
-__global__ __launch_bounds__(256) void vcf_tab_count_kernel(const char* __restrict__ text,
+static __global__ __launch_bounds__(256) void vcf_tab_count_kernel(const char* __restrict__ text,
                                                             const VcfRecord* __restrict__ rec, int max_seg,
                                                             int* __restrict__ seg_count) {
   const VcfRecord r = rec[blockIdx.y];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void vcf_tab_count_kernel(const char* __restri
 
 // pass 2: exclusive scan over the segments of one record (in place); a record whose column count differs from the
 // file's sample count raises *err (host-visible) to record index + 1.  grid (records), 256 threads
-__global__ __launch_bounds__(256) void vcf_tab_scan_kernel(const VcfRecord* __restrict__ rec, int max_seg,
+static __global__ __launch_bounds__(256) void vcf_tab_scan_kernel(const VcfRecord* __restrict__ rec, int max_seg,
                                                            int n_file_samples, int* __restrict__ seg_count,
                                                            int* __restrict__ err) {
   const VcfRecord r = rec[blockIdx.x];
@@ -301,7 +301,7 @@ __device__ __forceinline__ double vcf_atof(const char* __restrict__ t, long long
 // dosage mode of the decode pass (--dosage TAG): the subfield at the tag's FORMAT index through atof; a column without
 // that subfield reads the default value "." = 0.0; the GD / GQ filters turn a value into -9 as for hard calls.
 // out: [record][ld] doubles, the first n_rows of every column pre-filled with -9.
-__global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __restrict__ text,
+static __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __restrict__ text,
                                                                 const VcfRecord* __restrict__ rec, int max_seg,
                                                                 const int* __restrict__ seg_count,
                                                                 const int* __restrict__ row_of_sample,
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __re
 }
 
 // pass 3: decode.  grid (max segments, records), 256 threads.  out: [record][n_rows] signed bytes, pre-filled with -9
-__global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict__ text, const VcfRecord* __restrict__ rec,
+static __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict__ text, const VcfRecord* __restrict__ rec,
                                                          int max_seg, const int* __restrict__ seg_count,
                                                          const int* __restrict__ row_of_sample,
                                                          const signed char* __restrict__ sex, int n_file_samples,
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict_
 }
 
 // dst[i + j * ld] = value for i < n_rows (the dosage matrix before the decode pass: every row missing)
-__global__ void vcf_fill_kernel(double* __restrict__ dst, long long n_rows, long long ld, int ncols, double value) {
+static __global__ void vcf_fill_kernel(double* __restrict__ dst, long long n_rows, long long ld, int ncols, double value) {
   const long long total = n_rows * ncols;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
     dst[(t / n_rows) * ld + t % n_rows] = value;

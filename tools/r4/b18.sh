@@ -1,0 +1,18 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4b18
+run() { tag=$1; shift; env "$@" > gpurun_out/r4b18/$tag.json 2> gpurun_out/r4b18/$tag.err; python - gpurun_out/r4b18/$tag.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1], round(d['value']), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['avg_launch_ms'],3), round(d['kernel_time_share']['device_ms_per_step'],1))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e); print(open(sys.argv[1].replace('.json','.err')).read()[-800:])
+PY
+}
+C3="python bench.py --trait binary --samples 200000 --no-cpu-baseline --no-from-host"
+run c3_pv64 $C3
+run c3_pv72 RVT_PV_CUS=72 $C3
+run c3_pv80 RVT_PV_CUS=80 $C3
+run c3_pv56 RVT_PV_CUS=56 $C3
+run c3_pv64b $C3
+run c1 python bench.py --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1
