@@ -591,6 +591,16 @@ struct CovOut;
 RVT_INTERNAL int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af, const int64_t* ids,
                            uint32_t tests, const rvt_params* prm, rvt_gene_result* out, DebugOut* dbg, CovOut* cov = nullptr,
                            const signed char* kind = nullptr);
+// ---- defined in rvt_fam.hip
+RVT_INTERNAL int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld);
+RVT_INTERNAL int rotate_columns(rvt_ctx* c, const double* d_src, int64_t ld_src, int ncols, double* d_dst, int64_t ld_dst,
+                                hipStream_t st);
+RVT_INTERNAL int gemm_tn_planes(rvt_ctx* c, const double* dA, int64_t ldA, int nA, const double* dB, int64_t ldB, int nB,
+                                int64_t n_rows, double* C, int64_t ldc, hipStream_t st);
+RVT_INTERNAL int rvt_planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int nA, const int* row_exp, int a_exp,
+                                 const signed char* B, size_t b_stride, int PB, int nB, const int* col_exp, int64_t n_rows,
+                                 int64_t ldk, double* C, int64_t ldc, hipStream_t st, const int2* a_krange = nullptr);
+// ---- defined in rvt_engine.hip (continued)
 RVT_INTERNAL int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
                                       const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out);
 }
