@@ -600,7 +600,12 @@ RVT_INTERNAL int gemm_tn_planes(rvt_ctx* c, const double* dA, int64_t ldA, int n
 RVT_INTERNAL int rvt_planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stride, int PA, int nA, const int* row_exp, int a_exp,
                                  const signed char* B, size_t b_stride, int PB, int nB, const int* col_exp, int64_t n_rows,
                                  int64_t ldk, double* C, int64_t ldc, hipStream_t st, const int2* a_krange = nullptr);
+// ---- defined in rvt_perm.hip
+RVT_INTERNAL int rvt_kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std::vector<unsigned char>& y,
+                                int nPerm, double alpha, rvt_kbac_result* r);
 // ---- defined in rvt_engine.hip (continued)
+RVT_INTERNAL int enqueue_classify(rvt_ctx* c, const double* dG, int M, int64_t N, int64_t ld, hipStream_t st, int* d_flag);
+RVT_INTERNAL int cov_constants(rvt_ctx* c, bool fam, CovConsts* ccp, std::vector<double>* zzp);
 RVT_INTERNAL int run_blocks_with_perm(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af,
                                       const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out);
 }

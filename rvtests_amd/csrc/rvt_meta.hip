@@ -1,0 +1,424 @@
+// rvtests_amd — the tests that are not gene tests of the main pipeline: KBAC, MetaScore, MetaCov (bands and rectangles, the
+// exact int8 band for hard calls) and the column operations of the adapters' device ring.  Part of librvtests_amd.so.
+#include "rvt_engine_int.h"
+
+extern "C" {
+
+// What the engine wrote into the first V columns of a block it filled column by column (rvt_block_upload_columns records a
+// flag per column behind the copy): 1 = hard calls only, 0 = something else, -1 = nothing known (a caller's own
+// allocation, or a block filled another way).  A HINT for choosing the kernel to start on: the integer paths test every
+// value they read and fall back.  colflag (optional) receives the per-column flags when they exist (empty otherwise).
+static int block_hard_calls(rvt_ctx* c, const double* dG, int V, std::vector<int>* colflag, bool* any) {
+  if (colflag) colflag->clear();
+  if (any) *any = false;
+  if (!c->hc_enabled) return 0;
+  auto it = c->col_kind.find(dG);
+  if (it == c->col_kind.end() || !it->second.d_flags || V > it->second.cols) {
+    if (any) *any = true;
+    return -1;
+  }
+  std::vector<int> f((size_t)V);
+  if (hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * (size_t)V, hipMemcpyDeviceToHost, c->io_stream) != hipSuccess ||
+      sync_stream(c->io_stream) != hipSuccess)
+    return 0;
+  bool all = true, some = false;
+  for (int j = 0; j < V; ++j) {
+    all = all && f[j] != 0;
+    some = some || f[j] != 0;
+  }
+  if (any) *any = some;
+  if (colflag) *colflag = std::move(f);
+  return all ? 1 : 0;
+}
+
+// ---- KBAC (--kernel kbac): genotype-pattern permutation test, binary traits without covariates ---------------------------------
+int rvt_kbac_blocks(rvt_ctx* c, int n, const double* const* dG, const int* M, const double* af, const double* y,
+                    int nperm, double alpha, rvt_kbac_result* out) {
+  if (!c || n < 0 || (n > 0 && (!dG || !M || !af || !y || !out)) || nperm < 0) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set (it defines the sample count)");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  const int64_t N = c->nc.N;
+  std::vector<unsigned char> yb((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    if (y[i] != 0.0 && y[i] != 1.0) return fail(c, RVT_E_INVALID, "KBAC needs a 0 / 1 phenotype");
+    yb[i] = y[i] == 1.0;
+  }
+  size_t afo = 0;
+  for (int g = 0; g < n; ++g) {  // one gene at a time: the random stream is consumed in gene order
+    if (M[g] < 1 || M[g] > RVT_MAX_VARIANTS) return fail(c, RVT_E_INVALID, "gene %d has M=%d", g, M[g]);
+    rc = rvt_kbac_stage(c, dG[g], M[g], af + afo, yb, nperm, alpha, out + g);
+    if (rc) return rc;
+    afo += (size_t)M[g];
+  }
+  return RVT_OK;
+}
+
+// ---- MetaScore: single-variant score statistics of a block of variants (unrelated samples) -----------------
+int rvt_score_block(rvt_ctx* c, const double* dG, int V, int* ok, double* ustat, double* vstat, double* effect,
+                    double* effect_se, double* pvalue) {
+  if (!c || !dG || V < 1 || !ok || !ustat || !vstat || !effect || !effect_se || !pvalue)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  int rc = rvt_sync(c);  // processed synchronously
+  if (rc) return rc;
+  // Which slices START on the hard-call kernel: all of them unless the per-column flags of rvt_block_upload_columns say a
+  // slice holds something else.  The kernel tests what it reads; a slice it hands back is computed by the fp64 kernel in
+  // the same batch (run_batch).
+  std::vector<int> colflag;
+  bool any_hc = false;
+  bool all_hc = block_hard_calls(c, dG, V, &colflag, &any_hc) != 0;
+  if (!c->hc_enabled) all_hc = any_hc = false;
+  if (c->nc.binary && !(c->d_nulltile_w && c->d_vq)) all_hc = any_hc = false;  // (no digit planes: fp64 kernel)
+  if (!all_hc && colflag.empty()) any_hc = false;
+  // columns per slice.  General kernel: with M = 32 - (d + 1) the slice and its [X | rr] columns fill exactly two column
+  // tiles, tile class (2,2).  Hard-call kernel: the null-model columns have a tile of their own, so a slice is two
+  // full genotype tiles (32 columns, class MT = 2) when the whole block qualifies.
+  int kSlice = all_hc ? 32 : 32 - (c->nc.d + 1);
+  if (const char* e = getenv("RVT_SCORE_SLICE")) kSlice = std::max(1, std::min(64, atoi(e)));
+  constexpr int kChunk = 256;  // slices per launch
+  const int64_t ld = c->null_ld;
+  std::vector<double> af((size_t)kSlice * kChunk, 0.01);
+  std::vector<rvt_gene_result> rs(kChunk);
+  std::vector<unsigned char> shc(kChunk);
+  for (int c0 = 0; c0 < V; c0 += kSlice * kChunk) {
+    const int cols = std::min(V - c0, kSlice * kChunk), n = (cols + kSlice - 1) / kSlice;
+    std::vector<const double*> ptr(n);
+    std::vector<int> Ms(n);
+    std::vector<int64_t> ids(n);
+    for (int g = 0; g < n; ++g) {
+      ptr[g] = dG + (size_t)(c0 + g * kSlice) * ld;
+      Ms[g] = std::min(kSlice, cols - g * kSlice);
+      ids[g] = (int64_t)g * kSlice;
+      bool hc = all_hc;
+      if (!all_hc && any_hc) {
+        hc = true;
+        for (int j = 0; j < Ms[g]; ++j) hc = hc && colflag[(size_t)c0 + (size_t)g * kSlice + j] != 0;
+      }
+      shc[g] = hc ? 1 : 0;
+    }
+    CovOut co;
+    co.score = true;
+    co.slice_hc = any_hc ? shc.data() : nullptr;
+    co.ok = ok + c0;
+    co.ustat = ustat + c0;
+    co.vstat = vstat + c0;
+    co.effect = effect + c0;
+    co.se = effect_se + c0;
+    co.pval = pvalue + c0;
+    rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co);
+    if (rc) return rc;
+  }
+  return RVT_OK;
+}
+
+int rvt_null_dims(rvt_ctx* c, int64_t* N, int* d) {
+  if (!c) return RVT_E_INVALID;
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (N) *N = c->nc.N;
+  if (d) *d = c->nc.d;
+  return RVT_OK;
+}
+
+int rvt_null_summary(rvt_ctx* c, double* beta, double* covb_diag, double* sigma2) {
+  if (!c || !covb_diag) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  const NullConsts& nc = c->nc;
+  if (beta)
+    for (int k = 0; k < nc.d; ++k) beta[k] = c->have_null_beta ? c->null_beta[k] : NAN;
+  for (int k = 0; k < nc.d; ++k) covb_diag[k] = nc.Cinv[k * nc.d + k] * (nc.binary ? 1.0 : nc.sigma2);
+  if (sigma2) *sigma2 = nc.sigma2;
+  return RVT_OK;
+}
+
+// ---- MetaCov: covariance band of one block of consecutive variants ---------------------------------------
+int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
+  int rc = rvt_sync(c);  // the block is processed alone and synchronously
+  if (rc) return rc;
+  // Hard calls and an unweighted model: G'G is an integer matrix — the band comes from the exact int8 product
+  // (rvt_cov_rect with heads = window) instead of the fp64 matrix cores, ~6x faster at V = 1024.
+  if (c->have_null && !c->nc.binary && V >= 64 && !getenv("RVT_METACOV_FP64") && block_hard_calls(c, dG, V, nullptr, nullptr))
+    return rvt_cov_rect(c, dG, 0, V, V, cov, xz, zz, polymorphic);  // (tests what it reads; falls back by itself)
+  std::vector<double> af(V, 0.01);
+  rvt_gene_result r;
+  CovOut co;
+  co.cov = cov;
+  co.xz = xz;
+  co.zz = zz;
+  co.poly = polymorphic;
+  const double* p = dG;
+  rc = run_batch(c, 1, &p, &V, af.data(), nullptr, 0u, nullptr, &r, nullptr, &co);
+  if (rc) return rc;
+  // run_batch marked the slot busy without enqueuing a record copy: clear it
+  for (auto& sl : c->slots) {
+    if (sl.pending_out == &r) {
+      sl.pending_out = nullptr;
+      sl.pending_n = 0;
+    }
+  }
+  return RVT_OK;
+}
+
+static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                         int* polymorphic, bool allow_fast);
+int rvt_cov_rect(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                 int* polymorphic) {
+  return cov_rect_impl(c, dG, col0, H, W, cov, xz, zz, polymorphic, true);
+}
+static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                         int* polymorphic, bool allow_fast) {
+  if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const NullConsts& nc = c->nc;
+  const int64_t N = nc.N, ld = nc.ld;
+  const int d = nc.d;
+  CovConsts cc;
+  std::vector<double> zzv;
+  rc = cov_constants(c, false, &cc, &zzv);
+  if (rc) return rc;
+  const double* GW = dG + (size_t)col0 * ld;
+  double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_tmp = nullptr;
+  int* d_poly = nullptr;
+  struct Guard {
+    std::vector<void**> p;
+    ~Guard() {
+      for (void** q : p)
+        if (*q) hipFree(*q);
+    }
+  } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_tmp,
+           (void**)&d_poly}};
+  HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * d));
+  HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * d));
+  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
+  const double* Xop = c->d_X;   // N x d operand of T = G_W' D X
+  const double* GHop = GW;      // N x H operand of S = G_H' D G_W
+  if (nc.binary) {              // carry the weights on the small operands
+    const int cols = std::max(d, H);
+    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)ld * (d + H)));
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)d), dim3(256), 0, st, c->d_X, c->d_v, (long long)N,
+                       (long long)ld, d_tmp);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)H), dim3(256), 0, st, GW, c->d_v, (long long)N,
+                       (long long)ld, d_tmp + (size_t)ld * d);
+    (void)cols;
+    Xop = d_tmp;
+    GHop = d_tmp + (size_t)ld * d;
+  }
+  // T = G_W' D X (W x d) and S = G_H' D G_W (H x W) as integer-plane products (rot_gemm.hip.h): exact for hard calls
+  // and an unweighted model, ~2^-40 relative otherwise
+  // (hard calls are a prediction — the engine's own per-column flags when it filled the block, optimism otherwise —
+  // that cov_hc_prep_kernel verifies on every value it converts; a block that fails is computed again the general way)
+  const bool fast = allow_fast && !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
+  int* d_bad = nullptr;
+  int h_bad = 0;
+  if (!fast)
+    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  if (fast) {
+    // heads = whole window of a hard-call block (rvt_cov_block's fast path): ONE pass over G gives the column
+    // statistics, T = G'X and the int8 copy (cov_hc_prep_kernel); S = G'G is then one exact integer product
+    const int64_t ldk = (N + 127) / 128 * 128;
+    const int64_t cols_pad = ((int64_t)W + kRotBM - 1) / kRotBM * kRotBM;
+    const size_t need = (size_t)cols_pad * (size_t)ldk;
+    if (c->rotB_cap < need) {
+      if (c->d_rotB) hipFree(c->d_rotB);
+      c->d_rotB = nullptr;
+      c->rotB_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
+      c->rotB_cap = need + need / 4;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+    if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
+    d_bad = c->d_kind;
+    HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    {
+      const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+      const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
+      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>((2048 + wgs - 1) / wgs, N / 4096 + 1)));
+      HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)slices * W * (dmax + 3)));
+      const dim3 grid((unsigned)wgs, (unsigned)slices);
+      if (dmax == 4)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
+      else if (dmax == 8)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
+      else
+        hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W,
+                           c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
+      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
+                         W, d, dmax, d_cs, d_poly, d_T);
+    }
+    std::vector<int> zero_exp((size_t)W, 0);
+    rc = rvt_planes_gemm(c, c->d_rotB, need, 1, W, zero_exp.data(), 0, c->d_rotB, need, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
+    if (rc) return rc;
+  } else {
+    rc = gemm_tn_planes(c, GW, ld, W, Xop, ld, d, N, d_T, W, st);
+    if (rc) return rc;
+    rc = gemm_tn_planes(c, GHop, ld, H, GW, ld, W, N, d_S, H, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
+  hipLaunchKernelGGL(cov_rect_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, H, W, d_cov);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  if (d_bad) HIP_TRY(c, hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  if (h_bad) return cov_rect_impl(c, dG, col0, H, W, cov, xz, zz, polymorphic, false);  // not hard calls after all
+  if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
+  return RVT_OK;
+}
+
+// MetaCov with kinship for windows wider than one block (MetaCovFamQtl / MetaCovFamBinary, src/Model.cpp:437-504,595-692):
+// heads [col0, col0 + H) against markers [col0, col0 + W) of the RAW block dG.  The W columns are rotated by U'
+// (integer planes), then S = (D G~_H)' G~_W and T = G~_W' D [U'X | u1] are two more integer-plane products and the
+// centring algebra of the block kernel finishes the rows.  Same outputs as rvt_cov_rect.
+int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                     int* polymorphic) {
+  if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int64_t N = c->fam_nc.N, ld = c->fam_nc.ld;
+  const int du = c->famcov_nc.d - 2;  // columns of U'X
+  CovConsts cc;
+  std::vector<double> zzv;
+  {
+    const NullConsts keep = c->nc;
+    c->nc = c->famcov_nc;
+    rc = cov_constants(c, true, &cc, &zzv);
+    c->nc = keep;
+    if (rc) return rc;
+  }
+  rc = ensure_fam_cols(c, (size_t)W, ld);
+  if (rc) return rc;
+  const double* GW = dG + (size_t)col0 * ld;
+  double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_w = nullptr, *d_t1 = nullptr;
+  int* d_poly = nullptr;
+  struct Guard {
+    std::vector<void**> p;
+    ~Guard() {
+      for (void** q : p)
+        if (*q) hipFree(*q);
+    }
+  } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_w, (void**)&d_t1,
+           (void**)&d_poly}};
+  HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * (du + 1)));
+  HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * du));
+  HIP_TRY(c, hipMalloc((void**)&d_t1, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
+  HIP_TRY(c, hipMalloc((void**)&d_w, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H)));
+  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
+                     d_poly);
+  HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * W, st));
+  rc = rotate_columns(c, GW, ld, W, c->d_Gt, ld, st);
+  if (rc) return rc;
+  // the weights D = 1 / ((|lambda| + delta) sigma2) ride on the small operands: D [U'X | u1] and D G~_H
+  HIP_TRY(c, hipMemsetAsync(d_w, 0, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H), st));
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)(du + 1)), dim3(256), 0, st, c->d_cX, c->d_cv, (long long)N,
+                     (long long)ld, d_w);
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)H), dim3(256), 0, st, c->d_Gt, c->d_cv, (long long)N,
+                     (long long)ld, d_w + (size_t)ld * (du + 1));
+  rc = gemm_tn_planes(c, c->d_Gt, ld, W, d_w, ld, du + 1, N, d_T, W, st);
+  if (rc) return rc;
+  rc = gemm_tn_planes(c, d_w + (size_t)ld * (du + 1), ld, H, c->d_Gt, ld, W, N, d_S, H, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cov_rect_fam_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz,
+                     d_t1);
+  hipLaunchKernelGGL(cov_rect_fam_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, d_t1, H, W,
+                     d_cov);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * du, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)du * du);
+  if (c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
+    const double b2 = c->famcov_b2;
+    for (int h = 0; h < H; ++h)
+      for (int j = h; j < W; ++j) cov[(size_t)h + (size_t)j * H] *= b2;
+    for (size_t i = 0; i < (size_t)W * du; ++i) xz[i] *= b2;
+    if (zz)
+      for (int i = 0; i < du * du; ++i) zz[i] *= b2;
+  }
+  return RVT_OK;
+}
+
+int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* src, int src_col, int ncols) {
+  if (!c || !dst || !src || dst_col < 0 || src_col < 0 || ncols < 0) return fail(c, RVT_E_INVALID, "bad copy");
+  if (ncols == 0) return RVT_OK;
+  hipSetDevice(c->device);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
+                       hipMemcpyDeviceToDevice));
+  return RVT_OK;
+}
+
+int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const double* G) {
+  if (!c || !dG || !G || col0 < 0 || ncols < 1) return fail(c, RVT_E_INVALID, "bad upload");
+  if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
+  hipSetDevice(c->device);
+  const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
+                         hipMemcpyHostToDevice));
+  // content of the new columns (hard calls or not), recorded per column: rvt_score_block picks its kernel by it.  One
+  // read of data that has just crossed PCIe at a hundredth of the rate.
+  auto it = c->col_kind.find(dG);
+  if (it != c->col_kind.end() && c->hc_enabled && col0 + ncols <= it->second.cols) {
+    rvt_ctx::ColKind ck = it->second;
+    if (!ck.d_flags) {
+      HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
+      HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, c->io_stream));
+      it->second.d_flags = ck.d_flags;
+    }
+    for (int k = 0; k < ncols; ++k) {
+      int rc = enqueue_classify(c, dG + (size_t)(col0 + k) * ld, 1, (int64_t)N, (int64_t)ld, c->io_stream,
+                                ck.d_flags + col0 + k);
+      if (rc) return rc;
+    }
+  }
+  return RVT_OK;
+}
+
+int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int ncols) {
+  if (!c || !dG || dst_col < 0 || src_col < dst_col || ncols < 0) return fail(c, RVT_E_INVALID, "bad move");
+  if (ncols == 0 || dst_col == src_col) return RVT_OK;
+  hipSetDevice(c->device);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
+  for (int k = 0; k < ncols; ++k)
+    HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
+                              hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, sync_stream(c->stream));
+  auto it = c->col_kind.find(dG);
+  if (it != c->col_kind.end() && it->second.d_flags && src_col + ncols <= it->second.cols) {
+    std::vector<int> f((size_t)it->second.cols);
+    HIP_TRY(c, hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * f.size(), hipMemcpyDeviceToHost, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));
+    std::memmove(f.data() + dst_col, f.data() + src_col, sizeof(int) * (size_t)ncols);
+    HIP_TRY(c, hipMemcpyAsync(it->second.d_flags, f.data(), sizeof(int) * f.size(), hipMemcpyHostToDevice, c->io_stream));
+    HIP_TRY(c, sync_stream(c->io_stream));
+  }
+  return RVT_OK;
+}
+
+}  // extern "C"

@@ -84,7 +84,7 @@ def build_library(force=False, verbose=False):
         return out
     # eight objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function"]
-    units = ["rvt_engine.hip", "rvt_stream.hip", "rvt_fam.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
+    units = ["rvt_engine.hip", "rvt_stream.hip", "rvt_fam.hip", "rvt_perm.hip", "rvt_meta.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
              "k2_hardcall_x.hip", "k2_lattice.hip", "k2_packed.hip", "k2_floatdigit.hip"]
     objs, procs = [], []
     for u in units:
