@@ -160,3 +160,34 @@ def test_bgen_genes_take_it_without_being_told():
     for a, b in zip(out["default"], out["fp64"]):
         assert a.n_poly == b.n_poly and a.status == b.status
         _same(a, b)
+
+
+@pytest.mark.parametrize("N,d,M", [(777, 1, 9), (1000, 6, 33), (64, 2, 3), (33, 1, 1), (4097, 4, 64)])
+def test_shapes_covariate_counts_flipped_and_constant_columns(N, d, M):
+    """Ragged ends (N not a multiple of 16 / 32 / 128), one to six covariates (3 to 15 null columns), a column whose allele
+    frequency is above 1/2 (flipped), a constant column, a column of zeros."""
+    rng = np.random.default_rng(100 + N + d)
+    X = np.asfortranarray(np.column_stack([np.ones(N)] + [rng.normal(size=N) for _ in range(d - 1)]))
+    G = _bgen_dosages(rng, N, M, rate=0.08)
+    if M > 2:
+        G[:, 1] = 2.0 - G[:, 1]                      # major-allele dosages: the column is flipped
+        G[:, 2] = np.float32(11.0 / 255.0)           # monomorphic (a constant on the grid)
+    if M > 4:
+        G[:, 4] = 0.0
+    y = X @ rng.normal(size=d) + rng.normal(size=N) + 0.3 * G[:, 0]
+    af = np.clip(G.mean(0) / 2, 0.0, 1.0)
+    out = {}
+    for mode in ("fdx", "fp64"):
+        eng = rvtests_amd.Engine(0)
+        eng.fit_null(0, X, y.copy())
+        eng.set_content_hint(0)
+        if mode == "fdx":
+            eng.set_dosage_float(True)
+        recs, tm = _records(eng, [G], [af], rvtests_amd.TEST_ALL)
+        if mode == "fdx":
+            assert tm.genes_hard_call == 1 and tm.genes_handed_back == 0
+        out[mode] = recs[0]
+        eng.close()
+    a, b = out["fdx"], out["fp64"]
+    assert a.n_poly == b.n_poly and a.status == b.status and a.cmc_nonref == b.cmc_nonref
+    _same(a, b)
