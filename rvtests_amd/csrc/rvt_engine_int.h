@@ -275,6 +275,7 @@ struct rvt_ctx {
   NullTileX hcx_tile;
   bool hcx_ok = false;
   // ... and of the float-digit dosage kernel (suffstat_fdx.hip.h; quantitative trait): five base-256 digit planes of [X | res | 1]
+  bool reg_defer = false;  // inside rvt_submit_genes: the wait for the DMAs out of registered caller memory comes once, at the end
   unsigned char* d_fxq = nullptr;
   NullTileF fdx_tile;
   bool fdx_ok = false;
@@ -614,7 +615,7 @@ struct RegWait {  // every entry point that copies out of the caller's memory en
   rvt_ctx* c;
   explicit RegWait(rvt_ctx* c_) : c(c_) {}
   ~RegWait() {
-    if (c) (void)reg_wait(c);
+    if (c && !c->reg_defer) (void)reg_wait(c);  // (rvt_submit_genes waits ONCE, behind its last gene)
   }
 };
 

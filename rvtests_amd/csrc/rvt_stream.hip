@@ -741,11 +741,16 @@ int rvt_submit_genes(rvt_ctx* c, int kind, int n, const int64_t* gene_ids, const
                      uint32_t tests, const rvt_params* prm) {
   if (!c || n < 0 || (n > 0 && (!gene_ids || !M || !data))) return fail(c, RVT_E_INVALID, "bad gene list");
   if (kind < 1 || kind > 3) return fail(c, RVT_E_INVALID, "kind %d: 1 = doubles with missing codes, 2 = int8, 3 = PLINK 2-bit rows", kind);
-  for (int g = 0; g < n; ++g) {
-    const int rc = submit_common(c, gene_ids[g], M[g], data[g], kind, nullptr, nullptr, tests, prm);
-    if (rc) return rc;  // (genes [0, g) are queued; the message names what failed)
-  }
-  return RVT_OK;
+  // The genes' transfers out of page-locked caller memory (rvt_host_register) are queued back to back and waited for ONCE:
+  // the call returns when the last of them has been read (a gene-by-gene submission waits per gene — the buffer may be
+  // rewritten on return — which leaves the link idle between two genes).
+  c->reg_defer = true;
+  int rc = RVT_OK;
+  for (int g = 0; g < n && !rc; ++g)
+    rc = submit_common(c, gene_ids[g], M[g], data[g], kind, nullptr, nullptr, tests, prm);  // (genes [0, g) are queued on failure)
+  c->reg_defer = false;
+  const int rcw = reg_wait(c);
+  return rc ? rc : rcw;
 }
 
 // ---- VCF text front end ----------------------------------------------------------------------------------------------

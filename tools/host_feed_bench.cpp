@@ -3,7 +3,7 @@
 // rvt_collect_ready while the stream runs), no Python in the loop.  Prints one JSON object per mode: gene-sets/s, the host
 // bytes per second that implies, and the caller thread's own microseconds per gene (the time inside rvt_submit_*: what one
 // feeding thread spends per gene, i.e. the bound of a single-thread feed of several devices).
-//   host_feed_bench [--samples N] [--m M] [--genes G] [--modes fp64,int8,bed] [--registered]
+//   host_feed_bench [--samples N] [--m M] [--genes G] [--modes fp64,int8,bed] [--registered] [--batch B]
 // build: g++ -std=c++17 -O2 tools/host_feed_bench.cpp -Iinclude -Lrvtests_amd/csrc -lrvtests_amd -Wl,-rpath,$ORIGIN/../rvtests_amd/csrc
 #include <chrono>
 #include <cmath>
@@ -26,7 +26,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char** argv) {
   long long N = 500000;
-  int M = 50, genes = 1536, window = 64, registered = 0;
+  int M = 50, genes = 1536, window = 64, registered = 0, batch = 1;
   std::string modes = "int8,bed,fp64";
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--samples") && a + 1 < argc) N = atoll(argv[++a]);
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[a], "--genes") && a + 1 < argc) genes = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--modes") && a + 1 < argc) modes = argv[++a];
     else if (!strcmp(argv[a], "--registered")) registered = 1;
+    else if (!strcmp(argv[a], "--batch") && a + 1 < argc) batch = atoi(argv[++a]);  // genes per rvt_submit_genes call (1: per-gene calls)
   }
   rvt_ctx* ctx = nullptr;
   if (rvt_init(&ctx, 0)) { fprintf(stderr, "rvt_init failed\n"); return 2; }
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "rvt_fit_null: %s\n", rvt_last_error(ctx));
     return 2;
   }
-  const int K = 4;  // distinct host buffers, reused in turn (the reference refills ONE matrix per gene)
+  const int K = batch > 4 ? batch : 4;  // distinct host buffers, reused in turn (the reference refills ONE matrix per gene)
   std::vector<std::vector<int8_t>> g8(K);
   for (int k = 0; k < K; ++k) {
     g8[k].resize((size_t)N * M);
@@ -105,7 +106,18 @@ int main(int argc, char** argv) {
       const unsigned char* b = buf[(g + window) % K].data();
       const double ts = now();
       int rc;
-      if (mode == "int8") rc = rvt_submit_gene_i8(ctx, g, M, (const int8_t*)b, RVT_TEST_ALL, &prm, nullptr);
+      if (batch > 1) {  // rvt_submit_genes: `batch` genes per call, each out of its own buffer
+        if ((g + window) % batch != batch - 1 && g + 1 < n_timed) continue;
+        const int nb = ((g + window) % batch) + 1;
+        std::vector<int64_t> ids(nb);
+        std::vector<int> Ms(nb, M);
+        std::vector<const void*> ptrs(nb);
+        for (int k = 0; k < nb; ++k) {
+          ids[k] = g - (nb - 1) + k;
+          ptrs[k] = buf[(g - (nb - 1) + k + window) % K].data();
+        }
+        rc = rvt_submit_genes(ctx, mode == "int8" ? 2 : (mode == "bed" ? 3 : 1), nb, ids.data(), Ms.data(), ptrs.data(), RVT_TEST_ALL, &prm);
+      } else if (mode == "int8") rc = rvt_submit_gene_i8(ctx, g, M, (const int8_t*)b, RVT_TEST_ALL, &prm, nullptr);
       else if (mode == "bed") rc = rvt_submit_gene_bed(ctx, g, M, b, RVT_TEST_ALL, &prm, nullptr);
       else rc = rvt_submit_gene_raw(ctx, g, M, (const double*)b, RVT_TEST_ALL, &prm, nullptr);
       in_submit += now() - ts;
@@ -124,9 +136,9 @@ int main(int argc, char** argv) {
     }
     const double dt = now() - t0;
     printf("{\"mode\": \"%s%s\", \"N\": %lld, \"M\": %d, \"genes\": %lld, \"gene_sets_per_s\": %.1f, \"host_GBps\": %.2f, "
-           "\"caller_us_per_gene\": %.1f, \"caller\": \"C++, one thread, rvt_submit_gene_* per gene\"}\n",
+           "\"caller_us_per_gene\": %.1f, \"caller\": \"C++, one thread, %s\"}\n",
            mode.c_str(), registered ? "_registered" : "", N, M, done, done / dt, (double)bytes * done / dt / 1e9,
-           1e6 * in_submit / n_timed);
+           1e6 * in_submit / n_timed, batch > 1 ? "rvt_submit_genes (batched)" : "rvt_submit_gene_* per gene");
     fflush(stdout);
     if (registered)
       for (int k = 0; k < K; ++k) rvt_host_unregister(ctx, buf[k].data());
