@@ -553,3 +553,42 @@ def test_weighted_hardcall_digit_rounding_at_small_p(engine):
         assert abs(a.skato_Q - b.skato_Q) <= 1e-10 * abs(b.skato_Q)
     assert small >= 4, "the planted effects no longer reach the small decades: %d" % small
     print("weighted int8 vs fp64 kernel, p in [1e-13, 1]: max relative difference %.3g (%d values below 1e-7)" % (worst, small))
+
+
+def test_cooperative_kernel_is_bit_reproducible_across_launch_shapes(monkeypatch):
+    """The weighted cooperative kernel works in integers throughout: one launch for every class or one per class, the
+    p-values on their own CUs or anywhere, 4 or 29 wave-parts per gene — the records are the same bit for bit (the per-gene
+    stages reduce the wave-parts' integer partial sums in a fixed order)."""
+    import rvtests_amd
+    N, d = 20011, 3
+    Ms = (3, 20, 33, 50, 64, 80)
+    genes = [_hard_gene(N, M, seed=7 * M, flip_col=(2 if M > 40 else None)) for M in Ms]
+    # two genes with mean-imputed entries (the sparse tables)
+    for G, af in genes[2:4]:
+        rng = np.random.default_rng(G.shape[1])
+        for j in range(0, G.shape[1], 5):
+            rows = rng.choice(N, 9, replace=False)
+            keep = np.ones(N, dtype=bool)
+            keep[rows] = False
+            G[rows, j] = G[keep, j].mean()
+    X, y, res, v, s2 = synth.make_null(N, d, 1, seed=3, G_effect=0.4 * genes[3][0][:, :3].sum(1))
+    recs = {}
+    for tag, env in (("default", {}), ("per_class", {"RVT_HCX_FUSED": "0"}), ("pv_anywhere", {"RVT_PV_CUS": "0"}),
+                     ("parts29", {"RVT_WPARTS": "29"})):
+        for k in ("RVT_HCX_FUSED", "RVT_PV_CUS", "RVT_WPARTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        eng = rvtests_amd.Engine(0)
+        eng.set_null(1, X, res, v, s2)
+        out, tm = _run(eng, genes, True)
+        assert tm.genes_hard_call == len(genes) and tm.genes_handed_back == 0
+        recs[tag] = out
+        eng.close()
+    for tag in ("per_class", "pv_anywhere"):
+        for a, b in zip(recs["default"], recs[tag]):
+            for f in FIELDS:
+                assert getattr(a, f) == getattr(b, f), (tag, f)
+    for a, b in zip(recs["default"], recs["parts29"]):       # (another split: the fp64 per-gene reductions see other partials)
+        for f in FIELDS:
+            assert _same(f, getattr(a, f), getattr(b, f), rel=1e-11), ("parts29", f)
