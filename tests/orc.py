@@ -145,6 +145,41 @@ def ref():
     return _ref
 
 
+_ref_counter = None
+
+
+def ref_counter():
+    """The reference's GenotypeCounter (+ SNPHWE) and RingMemoryPool compiled where they lie (oracle/_ref/libref_counter.so),
+    or None when it has not been built / is absent."""
+    global _ref_counter
+    if _ref_counter is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_counter.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference/src"):
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+            else:
+                return None
+        R = C.CDLL(path)
+        R.ref_counter.restype = None
+        R.ref_counter.argtypes = [c_double_p, C.c_longlong, c_double_p]
+        R.ref_ring_new.restype = C.c_void_p
+        R.ref_ring_new.argtypes = [C.c_int, C.c_int]
+        R.ref_ring_delete.restype = None
+        R.ref_ring_delete.argtypes = [C.c_void_p]
+        R.ref_ring_allocate.restype = C.c_int
+        R.ref_ring_allocate.argtypes = [C.c_void_p]
+        R.ref_ring_deallocate.restype = None
+        R.ref_ring_deallocate.argtypes = [C.c_void_p, C.c_int]
+        R.ref_ring_chunk.restype = C.POINTER(C.c_float)
+        R.ref_ring_chunk.argtypes = [C.c_void_p, C.c_int]
+        R.ref_ring_size.restype = C.c_longlong
+        R.ref_ring_size.argtypes = [C.c_void_p]
+        R.ref_ring_capacity.restype = C.c_longlong
+        R.ref_ring_capacity.argtypes = [C.c_void_p]
+        _ref_counter = R
+    return _ref_counter
+
+
 # ------------------------------------------------------------------ convenience wrappers
 def F(a):
     return np.asfortranarray(np.asarray(a, dtype=np.float64))

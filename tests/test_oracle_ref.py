@@ -111,3 +111,129 @@ def test_product_form_davies_matches_term_by_term():
                     worst_rel = max(worst_rel, abs(pe - pf) / pe)
     assert n_terms_differ == 0
     assert worst_abs <= 5e-15 and worst_rel <= 1e-8, (worst_abs, worst_rel)   # observed: 1.6e-15 / 1e-9
+
+
+# ---- the reference's GenotypeCounter / SNPHWE / RingMemoryPool compiled where they lie (oracle/_ref/libref_counter.so) ----
+def _counter_columns(rng, N, M):
+    """Columns that hit every branch of GenotypeCounter::add: hard calls, missing (< 0), dosages around the 2/3 and 4/3
+    thresholds, exactly 2.0, above 2.0 (counted missing but still in nSample)."""
+    G = rng.choice([0.0, 1.0, 2.0], size=(N, M), p=[0.8, 0.15, 0.05])
+    G[rng.random((N, M)) < 0.03] = -9.0
+    dos = rng.random((N, M)) < 0.1
+    G[dos] = np.round(rng.uniform(0, 2.2, size=dos.sum()), 3)
+    G[0, :4] = [2.0 / 3, 4.0 / 3, 2.0, 2.0000001]
+    G[1, :4] = [np.nextafter(2.0 / 3, 0), np.nextafter(4.0 / 3, 0), np.nextafter(2.0, 3), -0.0]
+    G[:, M - 1] = -9.0                       # an all-missing column: AF = 0 with nSample = N
+    return np.asfortranarray(G)
+
+
+def test_counter_af_against_the_compiled_reference_counter():
+    """orc_counter_af (the weights of every kernel test, quirk #4) vs src/GenotypeCounter.h as compiled."""
+    R = orc.ref_counter()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_counter.so not built (no /root/reference here)")
+    rng = np.random.default_rng(11)
+    for N, M in ((1, 3), (7, 5), (500, 12), (4001, 9)):
+        G = _counter_columns(rng, max(N, 2), max(M, 5))[:N, :M].copy(order="F") if N >= 2 else np.asfortranarray(
+            rng.choice([0.0, 1.0, 2.0, -9.0], size=(N, M)))
+        af = orc.counter_af(G)
+        for j in range(M):
+            out = np.zeros(8)
+            col = np.ascontiguousarray(G[:, j])
+            R.ref_counter(orc._dp(col), N, orc._dp(out))
+            assert af[j] == out[0], (N, j, af[j], out[0])       # same additions in the same order: bit-identical
+            ok = (col >= 0) & (col <= 2.0)
+            assert out[7] == N - ok.sum() and out[4] + out[5] + out[6] == ok.sum()
+            assert 0.0 <= out[3] <= 1.0
+
+
+def test_hwe_exact_test_known_values():
+    """SNPHWE through GenotypeCounter::getHWE: the all-missing convention and a textbook table."""
+    R = orc.ref_counter()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_counter.so not built")
+    out = np.zeros(8)
+    col = np.full(10, -9.0)
+    R.ref_counter(orc._dp(col), 10, orc._dp(out))
+    assert out[3] == 0.0 and out[0] == 0.0 and out[2] == 0.0
+    # 57 het / 14 hom-alt / 50 hom-ref ... in HWE proportions the p-value is large; a het deficit gives a small one
+    col = np.array([1.0] * 42 + [0.0] * 49 + [2.0] * 9)
+    R.ref_counter(orc._dp(col), len(col), orc._dp(out))
+    assert out[3] > 0.9
+    col = np.array([1.0] * 2 + [0.0] * 69 + [2.0] * 29)
+    R.ref_counter(orc._dp(col), len(col), orc._dp(out))
+    assert out[3] < 1e-15
+
+
+def test_metacov_window_walk_on_the_reference_ring_pool():
+    """MetaCovTest keeps its window in RingMemoryPool chunks that are allocated per kept variant and released in queue
+    order (src/Model.h:3956-3990, quirk #20).  Drive the same walk over the REAL pool — chunk payload = the variant's
+    index, so a stale or moved chunk shows — and require the (head, marker) pairs it visits to be exactly the finite
+    entries of orc_metacov's band, through several doublings of the pool."""
+    R = orc.ref_counter()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_counter.so not built")
+    rng = np.random.default_rng(3)
+    N, V, d = 60, 300, 2
+    G = rng.choice([0.0, 1.0, 2.0], size=(N, V), p=[0.7, 0.25, 0.05])
+    mono = rng.random(V) < 0.1
+    G[:, mono] = 0.0
+    chrom = np.repeat([1, 2], V // 2).astype(np.int32)
+    pos = np.sort(rng.integers(0, 4000, size=V)).astype(np.int32)
+    pos[V // 2:] -= pos[V // 2]
+    X = np.column_stack([np.ones(N), rng.normal(size=N)])
+    y = rng.normal(size=N)
+    window = 700                                   # > 64 kept variants in a window: the pool has to grow (64 -> 128 -> ...)
+    rc, kept, cov, row_end, xz, zz = orc.metacov(G, chrom, pos, X, y, 0, window)
+    assert rc == 0
+    pool = R.ref_ring_new(4, 2)                    # small start: growth while head > tail is exercised (case 2 / 4)
+    queue, pairs, grew = [], set(), 0
+    try:
+        def evict_head():
+            h, idx = queue.pop(0)
+            for (j, jdx) in [(h, idx)] + queue:
+                assert R.ref_ring_chunk(pool, jdx)[0] == float(j)     # the chunk of index jdx still holds variant j
+                pairs.add((h, j))
+            R.ref_ring_deallocate(pool, idx)
+        for j in range(V):
+            while queue and (chrom[queue[0][0]] != chrom[j] or abs(int(pos[j]) - int(pos[queue[0][0]])) > window):
+                evict_head()
+            if not kept[j]:
+                continue
+            cap = R.ref_ring_capacity(pool)
+            idx = R.ref_ring_allocate(pool)
+            grew += R.ref_ring_capacity(pool) > cap
+            R.ref_ring_chunk(pool, idx)[0] = float(j)
+            queue.append((j, idx))
+        while queue:
+            evict_head()
+        assert R.ref_ring_size(pool) == 0
+    finally:
+        R.ref_ring_delete(pool)
+    assert grew >= 4
+    want = {(h, j) for h in range(V) for j in range(h, V) if np.isfinite(cov[h, j])}
+    assert pairs == want and len(want) > 5000
+    assert all((row_end[h] == max(j for (hh, j) in want if hh == h)) for h in range(V) if kept[h])
+
+
+def test_search_memo_changes_nothing_and_stays_small():
+    """rvt_davies.h DaviesMemo: the coefficient sums of errbd / truncation depend on the evaluation point alone and the
+    searches of qf() visit a small lattice of points whatever the quantile; a hit must return the doubles a miss computes
+    (bit-identical p-values with and without the memo) and hundreds of quantiles — over a far wider range than one
+    SKAT-O quadrature asks for — must typically need a dozen slots of the 32- / 64-slot tables (a full table only stops
+    memoising: coefficient sets of two or three terms that repeat the auxiliary integration can fill it)."""
+    rng = np.random.default_rng(21)
+    used = []
+    for trial in range(40):
+        r = int(rng.integers(2, 96))
+        lam = np.sort(rng.gamma(rng.choice([0.3, 1, 5]), 1.0, size=r) * 10 ** rng.uniform(-6, 6))[::-1].copy()
+        mu, sd = lam.sum(), np.sqrt(2 * (lam ** 2).sum())
+        Qs = np.concatenate([mu + sd * rng.uniform(-1.5, 12, size=300), mu * 10 ** rng.uniform(-3, 1.5, size=100), [0.0]])
+        p_memo, slots = hc.davies_memo_sweep(lam, Qs)
+        for Q, pm in zip(Qs[::7], p_memo[::7]):
+            p0, _, _ = hc.davies(lam, Q, cached=True, fast=True)
+            assert p0 == pm or (np.isnan(p0) and np.isnan(pm)), (trial, Q, p0, pm)
+        used.append(slots)
+    used = np.array(used)
+    assert np.median(used[:, 0]) <= 16 and np.median(used[:, 1]) <= 16, used.T   # (observed: 10-15 and 6-16)
+    assert used[:, 0].max() <= 32 and used[:, 1].max() <= 64

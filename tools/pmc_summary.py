@@ -5,13 +5,17 @@ import csv
 import sys
 
 
-def main(path, out=None, only="rvt"):
+def main(path, out=None, only="rvt", kernels=None):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     seen = set()
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"]
-        if only and only not in k:
+        if kernels:
+            if not any(t in k for t in kernels):
+                continue
+            k = k.split("(")[0][-48:]
+        elif only and only not in k:
             continue
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         key = (k, row.get("Dispatch_Id"))
@@ -29,4 +33,9 @@ def main(path, out=None, only="rvt"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    av = sys.argv[1:]
+    kern = None
+    if av and av[0] == "--kernels":  # comma-separated substrings of the kernel names to keep
+        kern = av[1].split(",")
+        av = av[2:]
+    main(av[0], av[1] if len(av) > 1 else None, kernels=kern)
