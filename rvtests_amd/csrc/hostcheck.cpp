@@ -7,6 +7,7 @@
 // engine and the shipped library has no path into it.
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <vector>
 #include <chrono>
 #include "host_stage.h"
@@ -23,6 +24,14 @@ long long rvt_dv_profile[8];
 std::vector<long long> g_dv_log;
 void rvt_dv_eval_mark() {
   for (int k = 0; k < 5; ++k) g_dv_log.push_back(rvt_dv_profile[k]);
+}
+std::set<unsigned long long> g_dv_keys[2];
+long long g_dv_key_calls[2];
+void rvt_dv_key(int kind, double u) {
+  unsigned long long b;
+  std::memcpy(&b, &u, 8);
+  g_dv_keys[kind].insert(b);
+  ++g_dv_key_calls[kind];
 }
 }  // namespace rvt
 #endif
@@ -58,6 +67,24 @@ double hc_davies_pvalue_fast(const double* lam, int n, double Q, int cached, int
   davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre, true);
   return davies_pvalue(lam, th.data(), n, Q, fault, nterms, &pre, true);
 }
+// the same against ONE memo of the searches' coefficient sums shared by all the points (what a SKAT-O quadrature does);
+// slots[2] = occupied memo slots (errbd, truncation) afterwards
+void hc_davies_memo_sweep(const double* lam, int n, const double* Q, int nq, double* p, int* slots) {
+  std::vector<int> th(n > 0 ? n : 1);
+  davies_order(lam, n, th.data());
+  DaviesPrelude pre;
+  DaviesMemo memo;
+  dv_memo_clear((dv_memo_p)&memo);
+  davies_prelude(lam, th.data(), n, 10000, 0.000001, &pre, true, &memo);
+  for (int i = 0; i < nq; ++i) {
+    int fault;
+    double nt;
+    p[i] = davies_pvalue(lam, th.data(), n, Q[i], &fault, &nt, &pre, true);
+  }
+  slots[0] = slots[1] = 0;
+  for (int i = 0; i < kMemoSlotsE; ++i) slots[0] += memo.ekey[i] != kMemoEmpty;
+  for (int i = 0; i < kMemoSlotsT; ++i) slots[1] += memo.tkey[i] != kMemoEmpty;
+}
 double hc_liu_pvalue(const double* lam, int n, double Q) { return liu_pvalue(lam, n, Q); }
 
 void hc_sym_eigvals(const double* Ain, int n, double* out) {
@@ -75,6 +102,15 @@ void hc_tridiag_eigvals(const double* din, const double* ein, int n, double* out
 }
 
 #ifdef RVT_DV_PROFILE
+// distinct evaluation points u of errbd (kind 0) / truncation (kind 1) since the last call, and the number of evaluations
+void hc_dv_keys(long long* out) {
+  for (int k = 0; k < 2; ++k) {
+    out[2 * k] = (long long)rvt::g_dv_keys[k].size();
+    out[2 * k + 1] = rvt::g_dv_key_calls[k];
+    rvt::g_dv_keys[k].clear();
+    rvt::g_dv_key_calls[k] = 0;
+  }
+}
 int hc_dv_log(long long* out, int cap) {  // 5 cumulative counters per abscissa; returns the number of records and clears
   const int n = (int)(rvt::g_dv_log.size() / 5);
   for (int i = 0; i < n * 5 && i < cap; ++i) out[i] = rvt::g_dv_log[i];

@@ -1196,30 +1196,30 @@ static __global__ void scale_rows_kernel(const double* __restrict__ src, const d
 // (davies_term), and each point's lane then adds its terms in the reference's order (k = nt .. 0), so the
 // sums are bit-identical to the sequential loop of qfc.c:241-270.
 // =====================================================================================================
-constexpr int kTermCap = 512;  // (point, term) pairs staged in LDS per pass
+constexpr int kTermCap = 256;  // (point, term) pairs staged in LDS per pass
 
-struct WaveDaviesLds {
-  double* c;      // [64]
-  double* sig;    // [64]
-  double* intv;   // [64]
-  int* nt1;       // [64]  nt+1, 0 = no main integration
-  int* which;     // [64]  coefficient set of the lane's task
-  int* off;       // [65]  exclusive prefix of nt1
-  double* v1;     // [kTermCap]
-  double* v2;     // [kTermCap]
+struct WaveDaviesLds {  // (LDS pointers by type: see RVT_LDSQ in rvt_davies.h)
+  RVT_LDSQ double* c;      // [64]
+  RVT_LDSQ double* sig;    // [64]
+  RVT_LDSQ double* intv;   // [64]
+  RVT_LDSQ int* nt1;       // [64]  nt+1, 0 = no main integration
+  RVT_LDSQ int* which;     // [64]  coefficient set of the lane's task (bit 0), bit 1: none of its coefficients is negative
+  RVT_LDSQ int* off;       // [65]  exclusive prefix of nt1
+  RVT_LDSQ double* v1;     // [kTermCap]
+  RVT_LDSQ double* v2;     // [kTermCap]
 };
 __device__ __forceinline__ size_t wave_davies_lds_bytes() {
   return sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66);
 }
 __device__ __forceinline__ WaveDaviesLds wave_davies_lds_carve(char* mem) {
   WaveDaviesLds w;
-  double* d = reinterpret_cast<double*>(mem);
+  RVT_LDSQ double* d = (RVT_LDSQ double*)reinterpret_cast<double*>(mem);
   w.c = d;
   w.sig = d + 64;
   w.intv = d + 128;
   w.v1 = d + 192;
   w.v2 = w.v1 + kTermCap;
-  int* ip = reinterpret_cast<int*>(w.v2 + kTermCap);
+  RVT_LDSQ int* ip = (RVT_LDSQ int*)(w.v2 + kTermCap);
   w.nt1 = ip;
   w.which = ip + 64;
   w.off = ip + 128;
@@ -1235,10 +1235,10 @@ __device__ __forceinline__ WaveDaviesLds wave_davies_lds_carve(char* mem) {
 #define RVT_K4_TICK(slot, t0) do { } while (0)
 #endif
 template <bool FAST>
-__device__ __forceinline__ double wave_davies_pvalue(bool active, int which, const double* const* lbs,
-                                                     const int* const* ths, const int* rs, double c,
-                                                     const DaviesPrelude* pre, int lane, const WaveDaviesLds& L,
-                                                     double* nterms, double* prof4 = nullptr) {
+__device__ __forceinline__ double wave_davies_pvalue(bool active, int which, const dv_coefs* lbs,
+                                                     const dv_coefs* lss, const int* rs, double c,
+                                                     dv_pre_cp pre, dv_memo_p memo, int lane,
+                                                     const WaveDaviesLds& L, double* nterms, double* prof4 = nullptr) {
 #ifdef RVT_PROF_K4
   const long long tq0 = clock64();
 #endif
@@ -1251,18 +1251,20 @@ __device__ __forceinline__ double wave_davies_pvalue(bool active, int which, con
   task.acc = 0.000001;
   task.c = task.sigsq = task.intv = 0.0;
   task.nt = 0;
+  task.allpos = false;
   bool direct = true;   // result already known (Liu for a single coefficient, 1.0 for c < 0, or inactive)
   double pdirect = 0.0;
   if (active) {
-    const double* lb = lbs[which];
+    const dv_coefs lb = which ? lbs[1] : lbs[0];
     const int r = rs[which];
     if (r == 1) {
-      pdirect = liu_pvalue(lb, r, c);
+      const double l1 = lb[0];
+      pdirect = liu_pvalue(&l1, r, c);
     } else if (c < 0.0) {
       pdirect = 1.0;  // see davies_pvalue(): qf() = 0 or a fault, both replaced by Liu at every call site
     } else {
       direct = false;
-      davies_qf_front_t<FAST>(lb, ths[which], r, c, 10000, 0.000001, pre, &task);
+      davies_qf_front_t<FAST>(lb, nullptr, r, c, 10000, 0.000001, pre, &task, memo, which ? lss[1] : lss[0]);
     }
   }
 
@@ -1272,7 +1274,7 @@ __device__ __forceinline__ double wave_davies_pvalue(bool active, int which, con
 #endif
   const bool need = active && !direct && task.need_main;
   L.nt1[lane] = need ? task.nt + 1 : 0;
-  L.which[lane] = which;
+  L.which[lane] = which | (task.allpos ? 2 : 0);
   L.c[lane] = task.c;
   L.sig[lane] = task.sigsq;
   L.intv[lane] = task.intv;
@@ -1292,14 +1294,14 @@ __device__ __forceinline__ double wave_davies_pvalue(bool active, int which, con
   for (int cs = 0; cs < total; cs += kTermCap) {
     const int ce = (cs + kTermCap < total) ? cs + kTermCap : total;
     for (int idx = cs + lane; idx < ce; idx += 64) {
-      int p = 0;
-      for (int q = 1; q < 64; ++q) p += (idx >= L.off[q]) ? 1 : 0;  // owner of this flat index
-      // (owners with nt1 == 0 share their offset with the next one; the count above lands on the last of
-      //  them, which is the one that really owns idx because off is non-decreasing)
+      int p = 0;  // owner of this flat index: the LAST q with off[q] <= idx (owners with nt1 == 0 share their offset
+                  // with the next one; the last of them is the one that really owns idx) — off is non-decreasing
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) p += (L.off[p + step] <= idx) ? step : 0;
       const int k = (L.nt1[p] - 1) - (idx - L.off[p]);
-      const int w = L.which[p];
+      const int wf = L.which[p], w = wf & 1;
       double t1, t2;
-      davies_term_t<FAST>(lbs[w], rs[w], L.c[p], L.sig[p], L.intv[p], k, &t1, &t2);
+      davies_term_t<FAST>(w ? lbs[1] : lbs[0], w ? rs[1] : rs[0], L.c[p], L.sig[p], L.intv[p], k, &t1, &t2, (wf & 2) != 0);
       L.v1[idx - cs] = t1;
       L.v2[idx - cs] = t2;
     }
@@ -1328,11 +1330,13 @@ __device__ __forceinline__ double wave_davies_pvalue(bool active, int which, con
 // Per-gene state of the p-value kernel that every lane reads (or lane 0 updates): in LDS, so that nothing of it is
 // replicated per lane in registers / scratch memory (the kernel used to carry 2.5 KB of scratch per lane, i.e. global
 // memory round trips inside the sequential QAGS bookkeeping and the per-abscissa integrand set-up).
-constexpr int kQagsLds = 96;  // QAGS intervals kept in LDS; a store that outgrows it moves to the global workspace
+constexpr int kQagsLds = 64;  // QAGS intervals kept in LDS; a store that outgrows it moves to the global workspace
 struct PvShared {
   GeneStats gs;
   SkatoIntegrand si;
-  DaviesPrelude pre;
+  DaviesPrelude pre;       // SKAT-O's coefficients (eigenvalues of Z(I-M)Z')
+  DaviesPrelude pre_skat;  // SKAT's own
+  DaviesMemo memo, memo_skat;
   LiuPre liu;
   QagsMachine qm;
   double pvals[kNRho];
@@ -1341,8 +1345,9 @@ struct PvShared {
   int order[kQagsLds], level[kQagsLds];
 };
 
-// indices of lb by decreasing |lb| (stable) — davies_order() as a rank computation, one element per lane
-__device__ __forceinline__ void wave_davies_order(const double* lb, int r, int* th, int lane) {
+// the coefficients by decreasing |lb| (stable): ls[rank(j)] = lb[j] — davies_order() as a rank computation, one element per
+// lane (dv_cfe, the only user of the order, reads the coefficients themselves in that order)
+__device__ __forceinline__ void wave_davies_sorted(const double* lb, int r, double* ls, int lane) {
   for (int j = lane; j < r; j += 64) {
     const double lj = fabs(lb[j]);
     int rank = 0;
@@ -1350,7 +1355,7 @@ __device__ __forceinline__ void wave_davies_order(const double* lb, int r, int* 
       const double lk = fabs(lb[k]);
       rank += (lk > lj || (lk == lj && k < j)) ? 1 : 0;
     }
-    th[rank] = j;
+    ls[rank] = lb[j];
   }
 }
 
@@ -1377,11 +1382,12 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   __syncthreads();
   const GeneStats& gs = sh.gs;
   const int M = gd.M;
+  const int Me = (M + 1) & ~1;  // (every array starts on a 16-byte boundary)
   double* lam_skat = reinterpret_cast<double*>(smem);
-  double* lam_zimz = lam_skat + M;
-  int* th_skat = reinterpret_cast<int*>(lam_zimz + M);
-  int* th_zimz = th_skat + M;
-  double* fv = reinterpret_cast<double*>(th_zimz + M);  // 42 doubles after the 2*M ints (8-byte aligned)
+  double* lam_zimz = lam_skat + Me;
+  double* ls_skat = lam_zimz + Me;   // the same coefficients by decreasing magnitude (dv_cfe)
+  double* ls_zimz = ls_skat + Me;
+  double* fv = ls_zimz + Me;         // 42 integrand values
   const WaveDaviesLds L = wave_davies_lds_carve(reinterpret_cast<char*>(fv + 42));
   rvt_gene_result* const out = gd.result;
   const int n_skat = gs.skat_nlambda, n_zimz = gs.zimz_nlambda;
@@ -1390,11 +1396,14 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   __syncthreads();
   if (lane == 0) pvalue_init_result(gs, gd.gene_id, out);
   if (gs.n_poly == 0) return;
-  wave_davies_order(lam_skat, n_skat, th_skat, lane);
-  wave_davies_order(lam_zimz, n_zimz, th_zimz, lane);
+  wave_davies_sorted(lam_skat, n_skat, ls_skat, lane);
+  wave_davies_sorted(lam_zimz, n_zimz, ls_zimz, lane);
+  dv_memo_clear((dv_memo_p)&sh.memo, lane, 64);
+  dv_memo_clear((dv_memo_p)&sh.memo_skat, lane, 64);
   __syncthreads();
-  const double* lbs[2] = {lam_zimz, lam_skat};
-  const int* ths[2] = {th_zimz, th_skat};
+  // (address-space-3 pointers: every read of the coefficients in the loops of rvt_davies.h is a ds_read)
+  const dv_coefs lbs[2] = {(dv_coefs)lam_zimz, (dv_coefs)lam_skat};
+  const dv_coefs lss[2] = {(dv_coefs)ls_zimz, (dv_coefs)ls_skat};
   const int rs[2] = {n_zimz, n_skat};
   double terms = 0.0;
   const bool fam = (tests & RVT_TEST_FAMSKAT) != 0;  // FamSkat.cpp:118: Davies only, result in the famskat fields
@@ -1435,18 +1444,28 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
       sh.si.varZeta = gs.varZeta;
       sh.si.df = gs.df;
       sh.si.lambda = lam_zimz;
-      sh.si.th = th_zimz;
+      sh.si.th = nullptr;
       sh.si.r = n_zimz;
       sh.si.lambda_sum = gs.zimz_lambda_sum;
       sh.si.pre = &sh.pre;
       sh.si.liu = &sh.liu;
       sh.si.lg_half = lgamma(0.5);
     }
-    if (lane == 12) davies_prelude_t<FAST>(lam_zimz, th_zimz, n_zimz, 10000, 0.000001, &sh.pre);
     if (lane == 13) sh.liu = liu_prepare(lam_zimz, n_zimz);
-  } else if (lane == 12) {
-    sh.pre.valid = false;
-    sh.pre.fast = FAST;
+  }
+  // The searches of qf() that do not depend on the quantile, once per coefficient set: SKAT-O's on lane 12, SKAT's own on
+  // lane 14 — the same code on two lanes, so they run side by side; both fill the memo of their set on the way.
+  if (lane == 12 || lane == 14) {
+    const int w = (lane == 14) ? 1 : 0;
+    const dv_pre_p P = w ? (dv_pre_p)&sh.pre_skat : (dv_pre_p)&sh.pre;
+    const dv_memo_p mm = w ? (dv_memo_p)&sh.memo_skat : (dv_memo_p)&sh.memo;
+    if (w ? (do_skat && rs[1] > 1) : skato_quad) {
+      davies_prelude_t<FAST>(w ? lbs[1] : lbs[0], nullptr, w ? rs[1] : rs[0], 10000, 0.000001, P, mm, w ? lss[1] : lss[0]);
+    } else {
+      P->valid = false;
+      P->fast = FAST;
+      P->memo = nullptr;
+    }
   }
   __syncthreads();
   const SkatoIntegrand& si = sh.si;
@@ -1464,7 +1483,8 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
     int which = 0;
     double c = 0.0, x = 0.0;
     bool skip_zero = false;  // kappa beyond the cut: integrand uses temp = 0
-    const DaviesPrelude* pp = nullptr;
+    dv_pre_cp pp = nullptr;
+    dv_memo_p mm = nullptr;
     if (lane < npts && skato_quad) {
       x = first ? gk21_abscissa(a1, b2, lane)
                 : ((lane < 21) ? gk21_abscissa(a1, b1, lane) : gk21_abscissa(b1, b2, lane - 21));
@@ -1475,13 +1495,16 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
         } else {
           c = (kappa - si.muQ) * sqrt(si.varQ - si.varZeta) / sqrt(si.varQ) + si.muQ;
           active = true;
-          pp = &sh.pre;
+          pp = (dv_pre_cp)&sh.pre;
+          mm = (dv_memo_p)&sh.memo;
         }
       }
     } else if (first && lane == 62 && do_skat) {
       active = true;
       which = 1;
       c = gs.skat_Q;
+      pp = (dv_pre_cp)&sh.pre_skat;
+      mm = (dv_memo_p)&sh.memo_skat;
     } else if (first && lane == 63 && do_skato && gs.skato_single) {
       active = true;
       which = 0;
@@ -1492,7 +1515,7 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
 #ifdef RVT_PROF_K4
     const long long tk0 = clock64();
 #endif
-    if (pass == 0 || first) p = wave_davies_pvalue<FAST>(active, which, lbs, ths, rs, c, pp, lane, L, &nt, prof4);
+    if (pass == 0 || first) p = wave_davies_pvalue<FAST>(active, which, lbs, lss, rs, c, pp, mm, lane, L, &nt, prof4);
     terms += nt;
 #ifdef RVT_PROF_K4
     const long long tk1 = clock64();

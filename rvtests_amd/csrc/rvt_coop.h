@@ -129,6 +129,11 @@ RVT_HD void sturm_rescale(double& p0, double& p1) {  // the larger of the pair i
   p1 = ldexp(p1, -k);
 #endif
 }
+// An exactly zero member p_j (x hit an eigenvalue of a leading block) needs no special case: the fma returns +0, the next
+// member is -e2 p_{j-1} != 0 (e2 is floored above zero), so the two comparisons around the zero count ONE sign change
+// between p_{j-1} and p_{j+1}, whichever side the zero is booked on — the same total as dlaebz's "zero pivot counts as
+// negative".  Only a zero LAST member differs (x is an eigenvalue of the whole matrix: whether it counts as "below x" is the
+// open / closed end of the bisection interval, which converges to it either way).
 RVT_HD int sturm_count(const double* d, const double* e2, int n, double x) {
   double p0 = 1.0, p1 = d[0] - x;
   int cnt = (int)((unsigned)rvt_hi_word(p1) >> 31);

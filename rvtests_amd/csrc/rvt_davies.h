@@ -27,11 +27,101 @@
 #define RVT_HDI inline __attribute__((always_inline))
 #endif
 
+// On the GPU every array the searches and the integrand terms read in their inner loops — the coefficients, their order,
+// the memo, the prelude — lives in LDS, and the pointer types SAY so (address space 3): through generic pointers the
+// compiler emitted flat loads, one fully exposed round trip per coefficient (measured: the loops ran at the flat-load latency,
+// ~150 cycles per coefficient).  On the host the qualifier is empty.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RVT_LDSQ __attribute__((address_space(3)))
+#else
+#define RVT_LDSQ
+#endif
+
 namespace rvt {
 
+typedef const RVT_LDSQ double* dv_coefs;  // coefficient array
+typedef const RVT_LDSQ int* dv_index;     // its order (davies_order)
+
+// ---- memo of the coefficient sums of errbd() / truncation() ---------------------------------------------------------
+// Both routines are  f(u, sigsq, tausq) = g(u * u * (sigsq + tausq), S(u))  where S(u) — the O(r) part: sums and products over
+// the coefficients — depends on the evaluation point u ALONE.  And the points the searches of qf() ask for come from a tiny
+// lattice that does not depend on the quantile c either: ctff() doubles and bisects from up = 4.5 / sd (qfc.c:157-178), findu()
+// walks utx * 4^k and then divides by 2, 1.4, 1.2, 1.1 (qfc.c:217-238); c and the convergence factor only decide which of
+// those points are visited.  The ~15 000 search evaluations of one SKAT-O quadrature (1 000 abscissae x 12) therefore ask for
+// about 35 distinct points (measured: tools/davies_divergence.py), and every abscissa performs the same floating-point
+// operations on the way to a point, so the keys agree bit for bit.  The memo is a small open-addressing table keyed by the
+// bits of u; a hit returns exactly the doubles a miss computes, so results do not depend on what the table holds.
+// On the GPU the table sits in LDS and is shared by the lanes of a wave (one lane per abscissa): a slot is claimed with a
+// compare-and-swap, filled, and published by storing its key last.
+constexpr int kMemoSlotsE = 32, kMemoSlotsT = 32;    // errbd / truncation points; a full table just stops memoising
+constexpr unsigned long long kMemoEmpty = ~0ull;     // (NaN bit patterns: never the bits of a finite u)
+constexpr unsigned long long kMemoBusy = ~0ull - 1;
+struct DaviesMemo {
+  unsigned long long ekey[kMemoSlotsE];  // errbd: bits of 2u
+  unsigned long long tkey[kMemoSlotsT];  // truncation: bits of 2u
+  double eval[kMemoSlotsE][2];           // sum_j [x^2/y + log y + x],  sum_j lb_j / y        (y = 1 - x, x = 2 u lb_j)
+  double tval[kMemoSlotsT][4];           // log prod_{x<=1}(1+x), log prod_{x>1} x, log prod_{x>1}(1+x), #{x>1}   (x = (2 u lb_j)^2)
+};
+typedef RVT_LDSQ DaviesMemo* dv_memo_p;
+RVT_HDI void dv_memo_clear(dv_memo_p m, int lane = 0, int nlanes = 1) {
+  for (int i = lane; i < kMemoSlotsE; i += nlanes) m->ekey[i] = kMemoEmpty;
+  for (int i = lane; i < kMemoSlotsT; i += nlanes) m->tkey[i] = kMemoEmpty;
+}
+// 1 = found (slot), 0 = absent (slot = where it may be inserted, or -1 when the table is full)
+template <int SLOTS>
+RVT_HDI int dv_memo_find(const RVT_LDSQ unsigned long long* keys, unsigned long long k, int* slot) {
+  const volatile RVT_LDSQ unsigned long long* vk = keys;
+  // the points differ in their exponent and leading mantissa bits (dyadic steps and a few fixed divisors)
+  int s = (int)(((((unsigned)(k >> 32)) ^ (unsigned)(k >> 13)) * 2654435761u) >> 16) & (SLOTS - 1);
+  int free_slot = -1;
+  for (int probe = 0; probe < SLOTS; ++probe) {
+    const unsigned long long cur = vk[s];
+    if (cur == k) {
+      *slot = s;
+      return 1;
+    }
+    if (cur == kMemoEmpty) {
+      free_slot = s;
+      break;
+    }
+    s = (s + 1) & (SLOTS - 1);
+  }
+  *slot = free_slot;
+  return 0;
+}
+// claim the slot (it may have been taken since it was seen empty: then the values are simply not stored)
+RVT_HDI bool dv_memo_claim(RVT_LDSQ unsigned long long* keys, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicCAS((unsigned long long*)&keys[slot], kMemoEmpty, kMemoBusy) == kMemoEmpty;  // (a known LDS address: ds_cmpst)
+#else
+  if (keys[slot] != kMemoEmpty) return false;
+  keys[slot] = kMemoBusy;
+  return true;
+#endif
+}
+RVT_HDI void dv_memo_publish(RVT_LDSQ unsigned long long* keys, int slot, unsigned long long k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __threadfence_block();
+  *(volatile RVT_LDSQ unsigned long long*)&keys[slot] = k;
+#else
+  keys[slot] = k;
+#endif
+}
+RVT_HDI unsigned long long dv_bits(double u) {
+  unsigned long long b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b = (unsigned long long)__double_as_longlong(u);
+#else
+  __builtin_memcpy(&b, &u, 8);
+#endif
+  return b;
+}
+
 struct DaviesState {
-  const double* lb;  // coefficients (all > 0 on the hot path), length r
-  const int* th;     // indices of lb ordered by decreasing |lb|
+  dv_memo_p memo;    // optional (product form only)
+  dv_coefs lb;       // coefficients (all > 0 on the hot path), length r
+  dv_index th;       // indices of lb ordered by decreasing |lb|
+  dv_coefs ls;       // optional: the coefficients IN that order, ls[j] = lb[th[j]] (then th is not read)
   int r;
   int lim;
   int count;
@@ -81,10 +171,59 @@ RVT_HD double sp_log(ScaledProd p) {  // log(m 2^e), m > 0
 // the second only falls (every factor turns by less than pi / 2), so the crossings of the negative real axis can be
 // counted and the principal value of atan2 unwrapped.  (The sign of a coefficient is the same for every lane of a
 // wave, so the branch does not diverge.)
-RVT_HDI void dv_arg_logmod(const double* lb, int r, double u2, double* sum_atan, double* sum_abs_atan,
-                           double* sum_log1p_sq) {
+// allpos: the caller knows that every coefficient is > 0 (the hot path: davies_all_positive) — the second product then
+// stays 1 and its renormalisations, its atan2 and its log are skipped (they contribute exact zeros).
+RVT_HDI void dv_arg_logmod(dv_coefs lb, int r, double u2, double* sum_atan, double* sum_abs_atan,
+                           double* sum_log1p_sq, bool allpos = false) {
   double ap = 1.0, bp = 0.0, an = 1.0, bn = 0.0;  // prod (1 + i x_j) / 2^E over x >= 0 / over x < 0
   int Ep = 0, En = 0, wp = 0, wn = 0;
+  if (allpos) {
+    // One complex multiplication per coefficient, j = r-1 .. 0, renormalised after every j that is a multiple of 4 — written
+    // as groups of four whose coefficients are fetched one group AHEAD of the multiplications (the chain of dependent FMAs
+    // is the critical path; the LDS reads must not sit on it).
+    auto step = [&](double lj) {
+      const double x = lj * u2;
+      const double na = fma(-bp, x, ap), nb = fma(ap, x, bp);
+      wp += (bp >= 0.0 && nb < 0.0) ? 1 : 0;
+      ap = na;
+      bp = nb;
+    };
+    auto renorm = [&]() {
+      int k;
+      (void)frexp(fmax(fabs(ap), fabs(bp)), &k);
+      ap = ldexp(ap, -k);
+      bp = ldexp(bp, -k);
+      Ep += k;
+    };
+    int j = r - 1;
+    for (; j >= 0 && (j & 3) != 3; --j) {  // the incomplete top group
+      step(lb[j]);
+      if ((j & 3) == 0) renorm();
+    }
+    if (j >= 3) {
+      double n3 = lb[j], n2 = lb[j - 1], n1 = lb[j - 2], n0 = lb[j - 3];
+      for (; j >= 3; j -= 4) {
+        const double c3 = n3, c2 = n2, c1 = n1, c0 = n0;
+        if (j >= 7) {
+          n3 = lb[j - 4];
+          n2 = lb[j - 5];
+          n1 = lb[j - 6];
+          n0 = lb[j - 7];
+        }
+        step(c3);
+        step(c2);
+        step(c1);
+        step(c0);
+        renorm();
+      }
+    }
+    const double fp = (double)wp;
+    const double tp = (atan2(bp, ap) + fp * kTwoPiHi) + fp * kTwoPiLo;   // >= 0
+    *sum_atan = tp;
+    *sum_abs_atan = tp;
+    *sum_log1p_sq = log(fma(ap, ap, bp * bp)) + (double)(2 * Ep) * kLn2;
+    return;
+  }
   for (int j = r - 1; j >= 0; --j) {
     const double x = lb[j] * u2;
     if (x >= 0.0) {
@@ -164,8 +303,11 @@ RVT_HDI void dv_tick(DaviesState& st) {
 #define RVT_DV_HIT(k) (++rvt_dv_profile[k])   // host-side call counters of a profiling build (tools/davies_calls.cpp)
 extern long long rvt_dv_profile[8];
 void rvt_dv_eval_mark();
+void rvt_dv_key(int kind, double u);          // every (kind, u) an errbd / truncation evaluation is asked for
+#define RVT_DV_KEY(kind, u) rvt_dv_key(kind, u)
 #else
 #define RVT_DV_HIT(k) ((void)0)
+#define RVT_DV_KEY(kind, u) ((void)0)
 #endif
 // 1 / y for y in (0, 1] (errbd's denominators 1 - 2 u lb_j): on the device the hardware reciprocal with two Newton steps
 // (relative error ~1e-16; 5 instructions where the IEEE division sequence takes 12 — errbd is three quarters of the
@@ -191,19 +333,39 @@ RVT_HDI double dv_errbd(DaviesState& st, double u, double* cx) {
   double xconst = u * st.sigsq, sum1 = u * xconst;
   u = 2.0 * u;
   if (FAST) {
-    // sum_j [x^2 / y + log(y) + x] with y = 1 - x in (0, 1]: one reciprocal per coefficient, log of the product
-    ScaledProd py{1.0, 0};
-    double sx = 0.0, sq = 0.0;
-    for (int j = st.r - 1; j >= 0; --j) {
-      const double lj = st.lb[j], x = u * lj, y = 1.0 - x, ry = dv_recip(y);
-      xconst = fma(lj, ry, xconst);
-      sq = fma(x * x, ry, sq);
-      sx += x;
-      py.m *= y;
-      if ((j & 7) == 0) sp_renorm(py);
+    // sum_j [x^2 / y + log(y) + x] with y = 1 - x in (0, 1]: one reciprocal per coefficient, log of the product.
+    // Both sums start from zero (not from the sigsq terms), so that they are functions of u alone: see DaviesMemo.
+    double B, X;
+    const unsigned long long key = dv_bits(u);
+    int slot = -1;
+    const bool use_memo = st.memo != nullptr && key < kMemoBusy;
+    if (use_memo && dv_memo_find<kMemoSlotsE>(st.memo->ekey, key, &slot)) {
+      const volatile RVT_LDSQ double* v = st.memo->eval[slot];
+      B = v[0];
+      X = v[1];
+    } else {
+      RVT_DV_KEY(0, u);
+      ScaledProd py{1.0, 0};
+      double sx = 0.0, sq = 0.0;
+      X = 0.0;
+#pragma unroll 4
+      for (int j = st.r - 1; j >= 0; --j) {
+        const double lj = st.lb[j], x = u * lj, y = 1.0 - x, ry = dv_recip(y);
+        X = fma(lj, ry, X);
+        sq = fma(x * x, ry, sq);
+        sx += x;
+        py.m *= y;
+        if ((j & 7) == 0) sp_renorm(py);
+      }
+      B = sq + (sp_log(py) + sx);
+      if (use_memo && slot >= 0 && dv_memo_claim(st.memo->ekey, slot)) {
+        st.memo->eval[slot][0] = B;
+        st.memo->eval[slot][1] = X;
+        dv_memo_publish(st.memo->ekey, slot, key);
+      }
     }
-    sum1 = sum1 + (sq + (sp_log(py) + sx));
-    *cx = xconst;
+    sum1 = sum1 + B;
+    *cx = xconst + X;
     return dv_exp1(-0.5 * sum1);
   }
   for (int j0 = st.r - 1; j0 >= 0; j0 -= 4) {  // elements evaluated 4 at a time, accumulated in the reference's order
@@ -270,24 +432,48 @@ RVT_HDI double dv_truncation(DaviesState& st, double u, double tausq) {
   double prod1 = 2.0 * sum2;
   u = 2.0 * u;
   if (FAST) {
-    // prod1 += sum_{x <= 1} log(1 + x), prod2 = sum_{x > 1} log(x), prod3 = sum_{x > 1} log(1 + x): three products
-    ScaledProd pa{1.0, 0}, pb{1.0, 0}, pc{1.0, 0};
-    for (int j = 0; j < st.r; ++j) {
-      const double t = u * st.lb[j], x = t * t;
-      const bool big = x > 1.0;
-      pa.m *= big ? 1.0 : 1.0 + x;
-      pb.m *= big ? x : 1.0;
-      pc.m *= big ? 1.0 + x : 1.0;
-      s += big ? 1 : 0;
-      if ((j & 3) == 3) {
-        sp_renorm(pa);
-        sp_renorm(pb);
-        sp_renorm(pc);
+    // prod1 += sum_{x <= 1} log(1 + x), prod2 = sum_{x > 1} log(x), prod3 = sum_{x > 1} log(1 + x): three products —
+    // functions of u alone (DaviesMemo)
+    double la;
+    const unsigned long long key = dv_bits(u);
+    int slot = -1;
+    const bool use_memo = st.memo != nullptr && key < kMemoBusy;
+    if (use_memo && dv_memo_find<kMemoSlotsT>(st.memo->tkey, key, &slot)) {
+      const volatile RVT_LDSQ double* v = st.memo->tval[slot];
+      la = v[0];
+      prod2 = v[1];
+      prod3 = v[2];
+      s = (int)v[3];
+    } else {
+      RVT_DV_KEY(1, u);
+      ScaledProd pa{1.0, 0}, pb{1.0, 0}, pc{1.0, 0};
+#pragma unroll 4
+      for (int j = 0; j < st.r; ++j) {
+        const double t = u * st.lb[j], x = t * t;
+        const bool big = x > 1.0;
+        pa.m *= big ? 1.0 : 1.0 + x;
+        pb.m *= big ? x : 1.0;
+        pc.m *= big ? 1.0 + x : 1.0;
+        s += big ? 1 : 0;
+        if ((j & 3) == 3) {
+          sp_renorm(pa);
+          sp_renorm(pb);
+          sp_renorm(pc);
+        }
+      }
+      la = sp_log(pa);
+      prod2 = sp_log(pb);
+      prod3 = sp_log(pc);
+      if (use_memo && slot >= 0 && dv_memo_claim(st.memo->tkey, slot)) {
+        RVT_LDSQ double* v = st.memo->tval[slot];
+        v[0] = la;
+        v[1] = prod2;
+        v[2] = prod3;
+        v[3] = (double)s;
+        dv_memo_publish(st.memo->tkey, slot, key);
       }
     }
-    prod1 = prod1 + sp_log(pa);
-    prod2 = sp_log(pb);
-    prod3 = sp_log(pc);
+    prod1 = prod1 + la;
   } else
   for (int j0 = 0; j0 < st.r; j0 += 4) {
     const int cnt = (st.r - j0 >= 4) ? 4 : st.r - j0;
@@ -353,7 +539,7 @@ RVT_HDI void dv_integrate(DaviesState& st, int nterm, double interv, double taus
     double sum3 = -0.5 * st.sigsq * (u * u);
     if (FAST) {
       double sa, sb, sl;
-      dv_arg_logmod(st.lb, st.r, 2.0 * u, &sa, &sb, &sl);
+      dv_arg_logmod(st.lb, st.r, 2.0 * u, &sa, &sb, &sl, st.lmin == 0.0);  // (lmin stays 0 when no coefficient is negative)
       sum1 = sum1 + sa;
       sum2 = sum2 + sb;
       sum3 = sum3 - 0.25 * sl;
@@ -376,23 +562,30 @@ RVT_HDI void dv_integrate(DaviesState& st, int nterm, double interv, double taus
 }
 
 // coefficient of tausq in the error when the convergence factor is used      (qfc.c:272-304)
+template <bool FAST>
 RVT_HDI double dv_cfe(DaviesState& st, double x) {
   dv_tick(st);
   if (st.over) return 1.0;
   double axl = fabs(x);
   const double sxl = (x > 0.0) ? 1.0 : -1.0;
   double sum1 = 0.0;
+  // (product form: lj / log28 as a multiplication by the rounded reciprocal — one ulp beside the quotient, on a quantity that
+  //  only sets the size of the convergence factor — and the `+ 1.0` loop of qfc.c:291 as one addition of the exact count)
+  constexpr double kInvLog28 = 1.0 / kDaviesLog28;
   for (int j = st.r - 1; j >= 0; j--) {
-    const int t = st.th[j];
-    if (st.lb[t] * sxl > 0.0) {
-      const double lj = fabs(st.lb[t]);
-      const double axl1 = axl - lj, axl2 = lj / kDaviesLog28;
+    const double lt = st.ls ? st.ls[j] : st.lb[st.th[j]];
+    if (lt * sxl > 0.0) {
+      const double lj = fabs(lt);
+      const double axl1 = axl - lj, axl2 = FAST ? lj * kInvLog28 : lj / kDaviesLog28;
       if (axl1 > axl2)
         axl = axl1;
       else {
         if (axl > axl2) axl = axl2;
         sum1 = (axl - axl1) / lj;
-        for (int k = j - 1; k >= 0; k--) sum1 = sum1 + 1.0;
+        if (FAST)
+          sum1 = sum1 + (double)j;
+        else
+          for (int k = j - 1; k >= 0; k--) sum1 = sum1 + 1.0;
         break;
       }
     }
@@ -401,7 +594,7 @@ RVT_HDI double dv_cfe(DaviesState& st, double x) {
     st.fail = true;
     return 1.0;
   }
-  return pow(2.0, (sum1 / 4.0)) / (kDaviesPi * (axl * axl));
+  return (FAST ? exp2(sum1 * 0.25) : pow(2.0, (sum1 / 4.0))) / (kDaviesPi * (axl * axl));
 }
 
 // ---- the part of qf() that does not depend on the evaluation point c ------------------------------------
@@ -414,6 +607,7 @@ RVT_HDI double dv_cfe(DaviesState& st, double x) {
 struct DaviesPrelude {
   bool valid;        // false: not usable (degenerate coefficients or the search overran lim) -> full path
   bool fast;         // the searches used (and davies_qf_front will use) the product form
+  dv_memo_p memo;    // memo of the coefficient sums shared by every evaluation against these coefficients (may be null)
   double sd, mean, lmax, lmin;
   double utx;        // after findu(&utx, .5*acc)
   int cnt_findu;     // errbd/truncation/cfe calls spent so far (qf's `count`)
@@ -430,12 +624,18 @@ RVT_HD bool davies_all_positive(const double* lb, int r) {
   return ok;
 }
 
+typedef RVT_LDSQ DaviesPrelude* dv_pre_p;
+typedef const RVT_LDSQ DaviesPrelude* dv_pre_cp;
 template <bool FAST>
-RVT_HDI void davies_prelude_t(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P) {
+RVT_HDI void davies_prelude_t(dv_coefs lb, dv_index th, int r, int lim, double acc, dv_pre_p P,
+                              dv_memo_p memo = nullptr, dv_coefs ls = nullptr) {
   DaviesState st;
   P->fast = FAST;
+  P->memo = FAST ? memo : nullptr;
+  st.memo = P->memo;
   st.lb = lb;
   st.th = th;
+  st.ls = ls;
   st.r = r;
   st.lim = lim;
   st.c = 0.0;
@@ -477,25 +677,26 @@ RVT_HDI void davies_prelude_t(const double* lb, const int* th, int r, int lim, d
   P->valid = !st.over;
 }
 // fast: product form of the coefficient sums (else term by term)
+// (the wrappers without template arguments take ordinary pointers: the host test harness and the serial form call them)
 RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P,
-                           bool fast = true) {
+                           bool fast = true, DaviesMemo* memo = nullptr) {
   if (fast)
-    davies_prelude_t<true>(lb, th, r, lim, acc, P);
+    davies_prelude_t<true>((dv_coefs)lb, (dv_index)th, r, lim, acc, (dv_pre_p)P, (dv_memo_p)memo);
   else
-    davies_prelude_t<false>(lb, th, r, lim, acc, P);
+    davies_prelude_t<false>((dv_coefs)lb, (dv_index)th, r, lim, acc, (dv_pre_p)P);
 }
 
 // One term of the inversion integral (the body of qfc.c:250-268 for term k, main integration).
 template <bool FAST>
-RVT_HDI void davies_term_t(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
-                           double* t2) {
+RVT_HDI void davies_term_t(dv_coefs lb, int r, double c, double sigsq, double interv, int k, double* t1,
+                           double* t2, bool allpos = false) {
   const double inpi = interv / kDaviesPi;
   const double u = (k + 0.5) * interv;
   double sum1 = -2.0 * u * c, sum2 = fabs(sum1);
   double sum3 = -0.5 * sigsq * (u * u);
   if (FAST) {
     double sa, sb, sl;
-    dv_arg_logmod(lb, r, 2.0 * u, &sa, &sb, &sl);
+    dv_arg_logmod(lb, r, 2.0 * u, &sa, &sb, &sl, allpos);
     sum1 = sum1 + sa;
     sum2 = sum2 + sb;
     sum3 = sum3 - 0.25 * sl;
@@ -525,11 +726,11 @@ RVT_HDI void davies_term_t(const double* lb, int r, double c, double sigsq, doub
   *t2 = 0.5 * sum2 * x;
 }
 RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
-                        double* t2, bool fast = false) {
+                        double* t2, bool fast = false, bool allpos = false) {
   if (fast)
-    davies_term_t<true>(lb, r, c, sigsq, interv, k, t1, t2);
+    davies_term_t<true>((dv_coefs)lb, r, c, sigsq, interv, k, t1, t2, allpos);
   else
-    davies_term_t<false>(lb, r, c, sigsq, interv, k, t1, t2);
+    davies_term_t<false>((dv_coefs)lb, r, c, sigsq, interv, k, t1, t2);
 }
 
 // qf() split at its main integration so that the GPU can spread the nt+1 independent terms of MANY
@@ -544,19 +745,23 @@ struct DaviesTask {
   int fault;
   bool over;
   bool fast;          // evaluate the main integration's terms in the product form
+  bool allpos;        // no coefficient is negative (dv_arg_logmod's short form applies)
   double nterms;      // terms already evaluated (auxiliary integrations)
 };
 
 // `pre` (optional) = davies_prelude() of the same coefficients: the c-independent searches are replayed.
 // the caller guarantees that `pre` (if any) was computed in the same form
 template <bool FAST>
-RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c, int lim, double acc,
-                               const DaviesPrelude* pre, DaviesTask* task) {
+RVT_HDI void davies_qf_front_t(dv_coefs lb, dv_index th, int r, double c, int lim, double acc,
+                               dv_pre_cp pre, DaviesTask* task, dv_memo_p memo = nullptr, dv_coefs ls = nullptr) {
   DaviesState st;
   task->fast = FAST;
+  // (the GPU kernel passes the memo directly, so that the compiler sees an LDS address; the host takes the prelude's)
+  st.memo = !FAST ? nullptr : (memo ? memo : (pre ? pre->memo : nullptr));
   if (pre && !pre->valid) pre = nullptr;
   st.lb = lb;
   st.th = th;
+  st.ls = ls;
   st.r = r;
   st.lim = lim;
   st.c = c;
@@ -578,6 +783,12 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
   st.lmax = 0.0;
   st.lmin = 0.0;
   st.mean = 0.0;
+  if (pre) {  // (a valid prelude holds the moments: the same loop over the same coefficients)
+    sd = pre->sd;  // (non-zero, which is all that is tested below; the root itself is taken from the prelude there)
+    st.mean = pre->mean;
+    st.lmax = pre->lmax;
+    st.lmin = pre->lmin;
+  } else
   for (int j = 0; j < r; j++) {
     const double lj = lb[j];
     sd = sd + (lj * lj) * 2.0;
@@ -587,6 +798,7 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
     else if (st.lmin > lj)
       st.lmin = lj;
   }
+  task->allpos = (st.lmin == 0.0);  // (lmin starts at 0 and only a negative coefficient lowers it)
   bool done = false;
   double utx = 0, up = 0, un = 0, intv = 0, xnt = 0;
   if (sd == 0.0) {
@@ -597,7 +809,7 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
     done = true;
   }
   if (!done) {
-    sd = sqrt(sd);
+    sd = pre ? pre->sd : sqrt(sd);
     const double almx = (st.lmax < -st.lmin) ? -st.lmin : st.lmax;
     utx = 16.0 / sd;
     up = 4.5 / sd;
@@ -610,7 +822,7 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
     }
     bool sig_changed = false;  // has a convergence factor been added to sigsq?
     if (c != 0.0 && (almx > 0.07 * sd)) {
-      const double tausq = .25 * acc1 / dv_cfe(st, c);
+      const double tausq = .25 * acc1 / dv_cfe<FAST>(st, c);
       if (st.fail)
         st.fail = false;
       else if (dv_truncation<FAST>(st, utx, tausq) < .2 * acc1) {
@@ -670,7 +882,7 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
           to_main = true;
           break;
         }
-        const double cf = dv_cfe(st, c - x) + dv_cfe(st, c + x);
+        const double cf = dv_cfe<FAST>(st, c - x) + dv_cfe<FAST>(st, c + x);
         if (st.over) break;
         const double tausq = .33 * acc1 / (1.1 * cf);
         if (st.fail) {
@@ -712,9 +924,9 @@ RVT_HDI void davies_qf_front_t(const double* lb, const int* th, int r, double c,
 RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
                             const DaviesPrelude* pre, DaviesTask* task, bool fast = true) {
   if (fast)
-    davies_qf_front_t<true>(lb, th, r, c, lim, acc, pre, task);
+    davies_qf_front_t<true>((dv_coefs)lb, (dv_index)th, r, c, lim, acc, (dv_pre_cp)pre, task);
   else
-    davies_qf_front_t<false>(lb, th, r, c, lim, acc, pre, task);
+    davies_qf_front_t<false>((dv_coefs)lb, (dv_index)th, r, c, lim, acc, (dv_pre_cp)pre, task);
 }
 
 // after the main integration: qfval and the round-off test (qfc.c:424-431)
@@ -739,7 +951,7 @@ RVT_HD double davies_qf(const double* lb, const int* th, int r, double c, int li
   if (task.need_main) {
     for (int k = task.nt; k >= 0; k--) {
       double t1, t2;
-      davies_term(lb, r, task.c, task.sigsq, task.intv, k, &t1, &t2, task.fast);
+      davies_term(lb, r, task.c, task.sigsq, task.intv, k, &t1, &t2, task.fast, task.allpos);
       intl = intl + t1;
       ersm = ersm + t2;
     }

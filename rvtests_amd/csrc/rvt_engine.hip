@@ -979,13 +979,25 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     }
     hcx = any;
   }
-  // quantitative trait: does a gene of the batch start on the float-digit dosage kernel?  (its wave-parts are shorter)
+  const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
+                             c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
+  const bool score_hc = cov && cov->score && cov->slice_hc;
+  // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests and MetaScore slices)
+  const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && (!cov || score_hc);
+  const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) &&
+                           !(dbg && dbg->cmc) && d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) &&
+                           c->d_nulltile != nullptr && nd_is_default;
+  // the per-gene condition of the float-digit dosage kernel (quantitative trait; wave-part length aside) — ONE predicate for
+  // the batch-level prediction below and the per-gene decision further down (they had drifted apart)
+  const bool fdx_model = hc_possible && !nc.binary && !cov && c->fdx_ok && c->lattice_den == 0;
+  auto fdx_gene = [&](int g) {
+    const int k = kind ? kind[g] : -1;
+    return fdx_model && (Ms[g] + 15) / 16 <= kFdxEngineMT && (uint64_t)Ms[g] * (uint64_t)ld * 8ull < (1ull << 31) &&
+           (k == 0 || (k < 0 && c->content_hint == 0 && c->dosage_float));
+  };
+  // does a gene of the batch start on it?  (its wave-parts are shorter, and the batch is not split over two streams)
   bool fdx_batch = false;
-  if (!nc.binary && c->fdx_ok && c->hc_enabled && !cov && c->lattice_den == 0 && !(dbg && dbg->cmc) && !(tests & RVT_TEST_FAMSKAT))
-    for (int g = 0; g < n && !fdx_batch; ++g) {
-      const int k = kind ? kind[g] : -1;
-      fdx_batch = (Ms[g] + 15) / 16 <= kFdxEngineMT && (k == 0 || (k < 0 && c->content_hint == 0 && c->dosage_float));
-    }
+  for (int g = 0; g < n && !fdx_batch; ++g) fdx_batch = fdx_gene(g);
   int n_wparts, steps_per;
   choose_split(ld, n, nc.binary != 0, &n_wparts, &steps_per, hcx, fdx_batch);
   // ---- sizes ---------------------------------------------------------------------------------------
@@ -999,14 +1011,6 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   };
   std::vector<GeneOff> offs(n);
   int maxM = 0, n_hc = 0;
-  const bool nd_is_default = c->d_nulltile && c->d_X == c->d_nulltile && c->d_rr == c->d_nulltile + (size_t)ld * d &&
-                             c->d_zeros == c->d_nulltile + (size_t)ld * (d + 1);
-  const bool score_hc = cov && cov->score && cov->slice_hc;
-  // (a binary trait takes the weighted hard-call kernel when its digit planes exist: gene tests and MetaScore slices)
-  const bool hcw = nc.binary && c->d_nulltile_w != nullptr && c->d_vq != nullptr && (!cov || score_hc);
-  const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) &&
-                           !(dbg && dbg->cmc) && d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) &&
-                           c->d_nulltile != nullptr && nd_is_default;
   const int hc_max_mt = hcw ? kHcwMaxMT : kHcMaxMT;
   const bool predict_hc = c->content_hint != 0;  // blocks of unknown content (rvt_set_content_hint)
   // dosages on a decimal lattice (rvt_set_dosage_lattice): the caller's doubles when the hint says dosages, and what the
@@ -1014,7 +1018,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   const bool lat_possible = hc_possible && !nc.binary && !cov && c->lattice_den > 0;
   // float-precision dosages (what the BGEN decoder wrote: kind 0; blocks of unknown content when rvt_set_dosage_float says
   // so): gene_suffstat_fdx (hc = 4), which tests every value as well.  M <= 64; the batch's wave-parts are cut for it.
-  const bool fdx_possible = hc_possible && !nc.binary && !cov && c->fdx_ok && c->lattice_den == 0 && steps_per <= kFdxMaxSteps;
+  const bool fdx_possible = fdx_model && steps_per <= kFdxMaxSteps;
 
   for (int g = 0; g < n; ++g) {
     const int M = Ms[g];
@@ -1048,7 +1052,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
           gd.hc = 2;
           gd.lat_den = (double)c->lattice_den;
         }
-        if (fdx_possible && gd.MT <= kFdxEngineMT && (k == 0 || (k < 0 && !predict_hc && c->dosage_float))) {
+        if (fdx_possible && fdx_gene(g)) {
           gd.hc = 4;
           gd.lat_den = 0x1p37;
         }
@@ -1139,13 +1143,6 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     }
     afpos += gd.M;
   }
-  {  // order of the p-value workgroups: falling M (stable)
-    std::vector<int>& ord = c->pv_order;
-    ord.resize(n);
-    for (int g = 0; g < n; ++g) ord[g] = g;
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return Ms[a] > Ms[b]; });
-    for (int g = 0; g < n; ++g) desc[g].pv_gene = ord[g];
-  }
   std::memcpy(h_af, af, sizeof(double) * af_total);
   HIP_TRY(c, hipMemcpyAsync(base + off_af, h_af, sizeof(double) * af_total, hipMemcpyHostToDevice, st));
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
@@ -1163,6 +1160,14 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   });
   const int n_gen = n - n_hc;  // descriptors [0, n_gen) take the general kernels, [n_gen, n) the hard-call kernels
   for (int k = 0; k < n; ++k) h_desc[k] = desc[order[k]];
+  {  // order of the p-value workgroups: workgroup b takes h_desc[h_desc[b].pv_gene] — indices into the SORTED array, by
+     // falling M (stable): the longest work first
+    std::vector<int>& ord = c->pv_order;
+    ord.resize(n);
+    for (int k = 0; k < n; ++k) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return h_desc[a].M > h_desc[b].M; });
+    for (int b = 0; b < n; ++b) h_desc[b].pv_gene = ord[b];
+  }
   GeneDesc* d_desc = reinterpret_cast<GeneDesc*>(base + off_desc);
   HIP_TRY(c, hipMemcpyAsync(d_desc, h_desc, sizeof(GeneDesc) * n, hipMemcpyHostToDevice, st));
   NullDev nd{c->d_X, c->d_res, c->d_rr, c->d_v, c->d_zeros};
@@ -1387,7 +1392,8 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     }
     {
       Scope sc(c, 3, pst);
-      const size_t smem = sizeof(double) * 2 * maxM + sizeof(int) * 2 * maxM + sizeof(double) * 42 +
+      // (four coefficient arrays of an even length, the 42 integrand values, the staging of wave_davies_pvalue)
+      const size_t smem = sizeof(double) * 4 * ((maxM + 1) & ~1) + sizeof(double) * 42 +
                           sizeof(double) * (3 * 64 + 2 * kTermCap) + sizeof(int) * (64 + 64 + 66) + 32;
       if (tests & RVT_TEST_EXACT_DAVIES)  // Davies' coefficient sums term by term (verification) / in product form
         hipLaunchKernelGGL((gene_pvalue_kernel<false>), dim3(n), dim3(64), smem, pst, d_desc, tests);

@@ -337,6 +337,7 @@ int rvt_group_fit_null(rvt_group* g, int trait, int64_t N, int d, const double* 
 
 #define RVT_GROUP_SUBMIT(call)                                  \
   if (!g) return RVT_E_INVALID;                                 \
+  if (g->failed) return g->failed; /* sticky until collected */ \
   const int k = next_member(g, params, tests);                  \
   rvt_ctx* m = g->member[k];                                    \
   if (!g->worker.empty()) {                                     \
@@ -434,7 +435,8 @@ int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
   if (!g || !out || !n_out) return RVT_E_INVALID;
   *n_out = 0;
   const int n = (int)std::min<size_t>(g->owner.size(), (size_t)std::max(cap, 0));
-  if (n == 0) return RVT_OK;
+  // (the flush and the failed-state reset come BEFORE the "nothing to hand back" exit: a failed group is reset by any
+  //  collect, also one with cap = 0 or nothing pending — ADVICE r4)
   if (const int rcf = group_flush(g)) {  // every queued gene has reached its member — or one of them failed on the way:
     // the members' records no longer line up with the submission order.  Discard what is pending and start clean.
     std::vector<rvt_gene_result> drop(256);
@@ -448,6 +450,7 @@ int rvt_group_collect(rvt_group* g, rvt_gene_result* out, int cap, int* n_out) {
     g->failed = RVT_OK;
     return rcf;
   }
+  if (n == 0) return RVT_OK;
   const int nm = (int)g->member.size();
   std::vector<int> want(nm, 0);
   for (int i = 0; i < n; ++i) ++want[g->owner[i]];

@@ -131,7 +131,9 @@ RVT_HD void gene_pvalue_serial(const GeneStats& gs, const double* lambda_buf, un
       SkatoIntegrand si;
       skato_fill_integrand(gs, qminp, lam, th_zimz, &si);
       DaviesPrelude pre;
-      davies_prelude(lam, th_zimz, n, 10000, 0.000001, &pre);
+      DaviesMemo memo;  // the coefficient sums of the searches, shared by every abscissa of the quadrature (rvt_davies.h)
+      dv_memo_clear((dv_memo_p)&memo);
+      davies_prelude(lam, th_zimz, n, 10000, 0.000001, &pre, true, &memo);
       si.pre = &pre;
       const LiuPre liu = liu_prepare(lam, n);
       si.liu = &liu;

@@ -111,6 +111,20 @@ def davies(lam, Q, cached=False, fast=False):
     return p, fault.value, nt.value
 
 
+def davies_memo_sweep(lam, Qs):
+    """Product-form Davies p-values of many points against ONE shared memo of the searches' coefficient sums (what the
+    p-value kernel does across the abscissae of a SKAT-O quadrature); returns p[], (errbd slots, truncation slots) used."""
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    Qs = np.ascontiguousarray(Qs, dtype=np.float64)
+    p = np.zeros(len(Qs))
+    slots = (C.c_int * 2)()
+    L = lib()
+    L.hc_davies_memo_sweep.restype = None
+    L.hc_davies_memo_sweep.argtypes = [c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, C.POINTER(C.c_int)]
+    L.hc_davies_memo_sweep(_dp(lam), len(lam), _dp(Qs), len(Qs), _dp(p), slots)
+    return p, (slots[0], slots[1])
+
+
 def liu(lam, Q):
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     return lib().hc_liu_pvalue(_dp(lam), len(lam), float(Q))

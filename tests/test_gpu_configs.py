@@ -352,3 +352,81 @@ def test_config2_n500k_against_the_oracle(engine):
         ps.append((a.pvalue, o.pvalue))
     assert min(p for p, _ in ps[:2]) < 1e-3, ps                  # the causal genes are significant
     _record("config2_oracle_parity_n500000.json", {"N": N, "genes": len(genes), "skat_skato_p": ps})
+
+
+# ------------------------------------------------------------------------------------------------ configs[3] vs the oracle
+def _config3_data():
+    """BASELINE configs[3] at full size: N = 200 000, binary trait with a logistic null (intercept + one covariate), four
+    genes: two causal (p around 1e-4 and 1e-9), one with mean-imputed columns (missing calls: the sparse integer tables of
+    the cooperative weighted kernel), one of 80 variants (its widest tile class)."""
+    N = 200000
+    rng = np.random.default_rng(20260003)
+    X = np.asfortranarray(np.column_stack([np.ones(N), rng.normal(size=N)]))
+    genes, eff = [], np.zeros(N)
+    for k, M in enumerate((50, 36, 64, 80)):
+        maf = 10 ** rng.uniform(np.log10(5e-4), np.log10(5e-2), M)
+        G = np.asfortranarray((rng.random((N, M)) < maf).astype(np.float64) + (rng.random((N, M)) < maf))
+        if k < 2:
+            burden = G[:, :5].sum(1)
+            eff += 4.0 * np.sqrt((19.0, 64.0)[k] / (burden.var() * N)) * (burden - burden.mean())
+        if k == 2:                                           # missing calls, imputed as consolidate() does
+            miss = rng.random((N, M)) < 1e-3
+            ac = np.where(miss, 0.0, G).sum(0)
+            G[miss] = np.broadcast_to(2.0 * np.floor(ac) / (2.0 * (~miss).sum(0)), G.shape)[miss]
+            af = 0.5 * ac / N
+        else:
+            af = G.sum(0) / (2.0 * N)
+        genes.append((G, af))
+    pr = 1.0 / (1.0 + np.exp(-(-2.0 + 0.3 * X[:, 1] + eff)))
+    y = (rng.random(N) < pr).astype(np.float64)
+    return N, X, y, genes
+
+
+def test_config3_n200k_against_the_oracle(engine):
+    """BASELINE configs[3] at FULL size against the ORACLE (until round 5 this size was only compared with the device
+    algorithms run on the host, and with the oracle inside bench.py): the logistic null fitted on the device against
+    orc.fit_logistic, SKAT + SKAT-O of every gene against orc.skat / orc.skato with the weights v = p(1 - p), and the
+    burden tests against orc.burden under an intercept-only null (with covariates the reference's binary burden test is
+    undefined behaviour, SURVEY quirk #15)."""
+    N, X, y, genes = _config3_data()
+    rc, beta, p, v = orc.fit_logistic(X, y)
+    assert rc == 0
+    res = y - p
+    gb, _ = engine.fit_null(1, X, y)                         # LogisticRegression::FitLogisticModel on the device
+    assert np.allclose(gb, beta, rtol=1e-9, atol=1e-12)
+    engine.set_profiling(True)
+    engine.timing(reset=True)
+    ptrs = [engine.upload_block(G) for G, af in genes]
+    Ms = [G.shape[1] for G, af in genes]
+    out = engine.run_blocks(ptrs, Ms, [af for G, af in genes])
+    tm = engine.timing(reset=True)
+    engine.set_profiling(False)
+    assert tm.genes_hard_call == len(genes) and tm.genes_handed_back == 0      # imputed columns stay on the int8 kernel
+    ps = []
+    for r, (G, af) in zip(out, genes):
+        rc1, a = orc.skat(G, af, X, res, v, 1)
+        rc2, o = orc.skato(G, af, X, res, v, 1)
+        assert rc1 == 0 and rc2 == 0 and r.n_poly == a.n_poly and r.skat_ok and r.skato_ok
+        assert abs(r.skat_Q - a.Q) <= 1e-10 * a.Q and abs(r.skat_p - a.pvalue) <= 1e-6 * a.pvalue + 1e-14
+        assert r.skato_rho == o.rho and abs(r.skato_Q - o.Q) <= 1e-10 * abs(o.Q)
+        assert abs(r.skato_p - o.pvalue) <= 1e-6 * o.pvalue + 5e-13
+        ps.append((a.pvalue, o.pvalue))
+    assert ps[0][0] < 1e-2 and ps[1][0] < 1e-6, ps           # the causal genes are significant
+    # burden tests: intercept-only null (d = 1)
+    X1 = np.ones((N, 1), order="F")
+    rc, b1, p1, v1 = orc.fit_logistic(X1, y)
+    assert rc == 0
+    gb1, _ = engine.fit_null(1, X1, y)
+    assert np.allclose(gb1, b1, rtol=1e-9, atol=1e-12)
+    out1 = engine.run_blocks(ptrs, Ms, [af for G, af in genes])
+    for q in ptrs:
+        engine.free_block(q)
+    for r, (G, af) in zip(out1, genes):
+        for which, ok, pv, nonref in ((0, r.cmc_ok, r.cmc_p, r.cmc_nonref), (1, r.zeg_ok, r.zeg_p, None)):
+            rc3, b = orc.burden(G, X1, y, 1, which)
+            assert ok == (rc3 == 0)
+            if ok:
+                assert abs(pv - b.pvalue) <= 1e-6 * b.pvalue + 1e-14
+                if nonref is not None:
+                    assert nonref == b.nonref_site               # bit-exact count
+    _record("config3_oracle_parity_n200000.json", {"N": N, "genes": len(genes), "skat_skato_p": ps})

@@ -115,6 +115,19 @@ def test_division_free_sturm_bisection_on_hard_tridiagonals():
     cases.append((d, e))
     cases.append((np.array([3.0]), np.zeros(0)))
     cases.append((np.array([1.0, 1.0]), np.array([1e-200])))
+    # a positive semi-definite spectrum spanning 1e-15 .. 1 (what SKAT's eigenvalue cut at 1e-30 and the Davies inputs see),
+    # once coupled, once with exact splits, once with diagonal entries that ARE eigenvalues (d_j - x = 0 exactly at a
+    # bisection point: a zero member of the Sturm sequence, whose sign bit the count reads — ADVICE r4)
+    lam = 10.0 ** np.linspace(-15, 0, 48)
+    Q, _ = np.linalg.qr(rng.normal(size=(48, 48)))
+    T = sla.hessenberg((Q * lam) @ Q.T)
+    d, e = np.diag(T).copy(), np.diag(T, 1).copy()
+    cases.append((d, e))
+    e2 = e.copy()
+    e2[[5, 6, 20, 40]] = 0.0
+    cases.append((d, e2))
+    cases.append((np.array([0.0, 0.5, 0.5, 0.25, 1.0, 0.0]), np.array([0.0, 0.0, 0.25, 0.0, 0.0])))
+    cases.append((np.array([0.5, 0.5, 0.5]), np.array([0.25, 0.25])))      # x = 0.5 = d_0 at the first bisection step
     for d, e in cases:
         w0 = sla.eigvalsh_tridiagonal(d, e) if len(d) > 1 else np.array(d)
         w = hc.tridiag_eigvals(d, e)

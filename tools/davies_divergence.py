@@ -47,6 +47,9 @@ def main():
         sigma2 = float(res @ res / (N - X.shape[1]))
         af = G.mean(0) / 2
         hc.gene(G, af, X, res, np.ones(N), 0, sigma2)
+        keys = (C.c_longlong * 4)()
+        lib.hc_dv_keys(keys)
+        print("   evaluation points: errbd %d distinct of %d, truncation %d distinct of %d" % (keys[0], keys[1], keys[2], keys[3]))
         buf = (C.c_longlong * (5 * 20000))()
         n = lib.hc_dv_log(buf, len(buf))
         cum = np.array(buf[:5 * n], dtype=np.int64).reshape(n, 5)
