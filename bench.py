@@ -177,7 +177,28 @@ def cpu_worker(path):
     print(json.dumps({"results": out, "seconds": time.perf_counter() - t_all}))
 
 
-def cpu_oracle_pool(genes, X, y, binary, workers, library=None):
+def literal_skat_baseline(N_full, M=50):
+    """orc.skat_literal(use_float=1) — the LITERAL Skat::Fit with its N x N float P0 — on one synthetic gene at three N."""
+    import orc
+    import synth
+    pts = []
+    for N in (4000, 8000, 16000):
+        rng = np.random.default_rng(N)
+        G = np.asfortranarray(rng.binomial(2, 0.02, size=(N, M)).astype(np.float64))
+        X, y, res, v, s2 = synth.make_null(N, 3, 0, seed=3)
+        t0 = time.perf_counter()
+        rc, lit = orc.skat_literal(G, G.sum(0) / (2.0 * N), X, res, v, 0, use_float=1)
+        pts.append((N, time.perf_counter() - t0))
+    ex = float(np.polyfit(np.log([p[0] for p in pts]), np.log([p[1] for p in pts]), 1)[0])
+    at_full = pts[-1][1] * (N_full / pts[-1][0]) ** ex
+    return {"value": 1.0 / pts[-1][1], "unit": "gene-sets/s at N=%d (SKAT only)" % pts[-1][0], "cores": 1, "kind": "port",
+            "sample": "orc.skat_literal (N x N P0 in float, Skat.cpp:57-76), M=%d, one gene at N = %s: %s s; cost ~ N^%.2f; "
+                      "extrapolated to N=%d: %.0f s per gene (and 4 N^2 bytes = %.1f TB)"
+                      % (M, [p[0] for p in pts], ["%.2f" % p[1] for p in pts], ex, N_full, at_full, 4.0 * N_full ** 2 / 1e12),
+            "exponent": ex, "extrapolated_seconds_per_gene": at_full}
+
+
+def cpu_oracle_pool(genes, X, y, binary, workers, library=None, replicate=False):
     """Run the oracle on `genes` ({index: (G_host, af)}) in `workers` independent single-thread processes at once, the
     genes dealt round-robin (genes are independent: this is how the CPU port would use a whole host).  The timed
     wall clock starts when the processes are started and includes their start-up and null fit.  Returns
@@ -190,6 +211,11 @@ def cpu_oracle_pool(genes, X, y, binary, workers, library=None):
         paths = []
         for w in range(workers):
             mine = idx[w::workers]
+            if replicate:                       # every process computes the same genes, out of ONE file
+                if w > 0:
+                    paths.append(paths[0])
+                    continue
+                mine = idx
             if not mine:
                 continue
             path = os.path.join(td, "w%d.npz" % w)
@@ -314,7 +340,7 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
         done = 0
         t0 = None
         # (the packed hand-offs stream thousands of genes per second: 192 genes would be 40 ms, a third of it the drain)
-        n_timed = genes * 8 if mode in ("int8", "bed2bit") else genes
+        n_timed = genes * 8 if mode in ("int8", "bed2bit") else (genes * 4 if mode == "fp64" and not registered else genes)
         for g in range(-window, n_timed):        # one untimed window first: buffers, block pool and page mappings warm
             if g == 0:
                 eng.collect()
@@ -382,6 +408,7 @@ def main():
                     help="with --dosage: float-precision dosages as an 8-bit BGEN file gives them (multiples of 2^-31), no lattice "
                          "stated; the engine is told so (rvt_set_dosage_float) and tries the float-digit int8 kernel for M <= 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal-baseline", action="store_true", help="skip the literal N x N SKAT timing (~20 s of CPU)")
     ap.add_argument("--no-from-host", action="store_true", help="skip the from-host (PCIe-inclusive) secondary rates")
     ap.add_argument("--cpu-genes", type=int, default=24,
                     help="genes of the batch run through the CPU oracle after the timed region (baseline + parity)")
@@ -662,15 +689,23 @@ def main():
                         line["cpu_baseline"]["native_build"] = {
                             "value": 1.0 / one_n[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
                             "flags": "g++ -O3 -march=native", "seconds": one_n[k1]["seconds"]}
-                # ... and with the N-sized products (A'B, A'diag(w)B) register-blocked 4 x 4 with 4-wide vectors instead of
-                # one dot product per output (oracle/orc_linalg.cpp, -DORC_BLOCKED_GEMM): what a BLAS-class inner kernel gives
-                blk = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "liboracle_blocked.so")
-                if os.path.exists(blk):
-                    one_b, _ = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, 1, library=blk)
-                    if one_b:
-                        line["cpu_baseline"]["blocked_gemm_build"] = {
-                            "value": 1.0 / one_b[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
-                            "flags": "g++ -O3 -march=native -DORC_BLOCKED_GEMM", "seconds": one_b[k1]["seconds"]}
+                # every core the affinity mask gives (bounded by memory and by 64): that many single-thread processes, each
+                # computing THE SAME mean-width gene at once — what the CPU port delivers per host when genes are dealt to cores
+                reps = max(1, min(ncpu, by_mem, 64))
+                if reps > 1:
+                    _, wall_all = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, reps, replicate=True)
+                    line["cpu_baseline_allcores"] = {
+                        "value": reps / wall_all, "unit": "gene-sets/s", "cores": reps, "host_cores": ncpu, "kind": "port",
+                        "sample": "%d single-thread processes at once, each the gene of M=%d (start-up and one null fit per "
+                                  "process included), %.1f s wall" % (reps, Ms[k1], wall_all)}
+                # B-lit-SKAT: the reference's own formulation — Skat.cpp:57-76 forms the N x N P0 in float —
+                # cannot run at this N (4 N^2 bytes = 1 TB); timed at N = 4 000 / 8 000 / 16 000 on one thread, its fitted
+                # power law gives what a gene would cost here
+                if not args.no_literal_baseline:
+                    try:
+                        line["cpu_baseline_literal_skat"] = literal_skat_baseline(N)
+                    except Exception as e:
+                        line["cpu_baseline_literal_skat"] = {"error": repr(e)[:200]}
             recs, wall = cpu_oracle_pool({k: host[k] for k in pick}, Xh, yh, 1 if binary else 0, workers)
             if recs:
                 # (named for what it is: `workers` single-thread processes — one per sampled gene, bounded by memory —, NOT every

@@ -15,70 +15,6 @@
 
 namespace orc {
 
-#ifdef ORC_BLOCKED_GEMM
-// A'B / A'diag(w)B with a 4 x 4 register block of outputs and 4-wide vectors along the samples (the timing build
-// liboracle_blocked.so: the baseline a BLAS-class inner kernel gives; its sums associate differently, so the parity tests use
-// the plain build below)
-typedef double v4d __attribute__((vector_size(32), aligned(8)));
-static inline v4d ld4(const double* p) {
-  v4d x;
-  __builtin_memcpy(&x, p, 32);
-  return x;
-}
-Mat AtB(const Mat& A, const Mat& B, const double* w) {
-  Mat C(A.c, B.c);
-  const int64_t n = A.r, CH = 2048;
-  std::vector<double> wa;  // a chunk of diag(w) A, formed once per chunk and column block
-  for (int64_t i0 = 0; i0 < n; i0 += CH) {
-    const int64_t i1 = std::min(n, i0 + CH), len = i1 - i0, len4 = len / 4 * 4;
-    for (int64_t p0 = 0; p0 < A.c; p0 += 4) {
-      const int64_t np = std::min<int64_t>(4, A.c - p0);
-      const double* ap[4];
-      if (w) {
-        wa.resize((size_t)4 * len);
-        for (int64_t p = 0; p < np; ++p) {
-          const double* a = A.col(p0 + p) + i0;
-          for (int64_t i = 0; i < len; ++i) wa[(size_t)p * len + i] = a[i] * w[i0 + i];
-        }
-      }
-      for (int64_t p = 0; p < 4; ++p) ap[p] = p < np ? (w ? wa.data() + (size_t)p * len : A.col(p0 + p) + i0) : nullptr;
-      for (int64_t q0 = 0; q0 < B.c; q0 += 4) {
-        const int64_t nq = std::min<int64_t>(4, B.c - q0);
-        if (np == 4 && nq == 4) {
-          const double* b0 = B.col(q0) + i0, *b1 = B.col(q0 + 1) + i0, *b2 = B.col(q0 + 2) + i0, *b3 = B.col(q0 + 3) + i0;
-          v4d acc[4][4] = {};
-          for (int64_t i = 0; i < len4; i += 4) {
-            const v4d vb0 = ld4(b0 + i), vb1 = ld4(b1 + i), vb2 = ld4(b2 + i), vb3 = ld4(b3 + i);
-            for (int p = 0; p < 4; ++p) {
-              const v4d va = ld4(ap[p] + i);
-              acc[p][0] += va * vb0;
-              acc[p][1] += va * vb1;
-              acc[p][2] += va * vb2;
-              acc[p][3] += va * vb3;
-            }
-          }
-          for (int p = 0; p < 4; ++p)
-            for (int q = 0; q < 4; ++q) {
-              double s = (acc[p][q][0] + acc[p][q][1]) + (acc[p][q][2] + acc[p][q][3]);
-              const double* b = B.col(q0 + q) + i0;
-              for (int64_t i = len4; i < len; ++i) s += ap[p][i] * b[i];
-              C(p0 + p, q0 + q) += s;
-            }
-        } else {
-          for (int64_t p = 0; p < np; ++p)
-            for (int64_t q = 0; q < nq; ++q) {
-              const double* b = B.col(q0 + q) + i0;
-              double s = 0.0;
-              for (int64_t i = 0; i < len; ++i) s += ap[p][i] * b[i];
-              C(p0 + p, q0 + q) += s;
-            }
-        }
-      }
-    }
-  }
-  return C;
-}
-#else
 Mat AtB(const Mat& A, const Mat& B, const double* w) {
   Mat C(A.c, B.c);
   const int64_t n = A.r;
@@ -101,7 +37,6 @@ Mat AtB(const Mat& A, const Mat& B, const double* w) {
   }
   return C;
 }
-#endif
 
 Mat mul(const Mat& A, const Mat& B) {
   Mat C(A.r, B.c);

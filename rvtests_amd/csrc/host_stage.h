@@ -21,6 +21,9 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 namespace rvt {
 
@@ -61,6 +64,34 @@ class CopyPool {
     Task t{dst, src, bytes};
     run(&t, 1);
   }
+  // n independent work items fn(0) .. fn(n - 1) on all threads (the packing of the fp64 boundary: one item per column);
+  // returns when all of THIS batch are done
+  void run_items(size_t n, const std::function<void(size_t)>& fn) {
+    if (n == 0) return;
+    if (n_ == 1 || n == 1) {
+      for (size_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    size_t left = n;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      for (size_t i = 0; i < n; ++i) q_.push_back(Piece{nullptr, nullptr, i, &left, &fn});
+    }
+    cv_.notify_all();
+    help();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&left] { return left == 0; });
+  }
+  // the pool of the packing passes: reading 200 MB per gene is bound by memory bandwidth per core, so it takes more threads
+  // than the copies into pinned memory do (RVT_PACK_THREADS; default min(16, hardware threads / 2))
+  static CopyPool& pack_instance() {
+    static CopyPool pool([] {
+      if (const char* e = getenv("RVT_PACK_THREADS")) return std::max(1, atoi(e));
+      const unsigned hw = std::thread::hardware_concurrency();
+      return (int)std::max(1u, std::min(16u, hw / 2));
+    }());
+    return pool;
+  }
   // run a batch of copies, split into pieces so that every thread has work; returns when all of THIS batch are done.
   // Several caller threads may be inside run() at once (one per member of a device group): completion is counted per batch
   // (round 3 kept one process-wide counter: every caller then also waited for the other callers' pieces).
@@ -78,7 +109,7 @@ class CopyPool {
       std::lock_guard<std::mutex> lk(m_);
       for (size_t i = 0; i < n; ++i)
         for (size_t o = 0; o < tasks[i].bytes; o += piece) {
-          q_.push_back(Piece{(char*)tasks[i].dst + o, (const char*)tasks[i].src + o, std::min(piece, tasks[i].bytes - o), &left});
+          q_.push_back(Piece{(char*)tasks[i].dst + o, (const char*)tasks[i].src + o, std::min(piece, tasks[i].bytes - o), &left, nullptr});
           ++left;
         }
     }
@@ -92,8 +123,9 @@ class CopyPool {
   struct Piece {
     void* dst;
     const void* src;
-    size_t bytes;
-    size_t* left;  // the batch's counter
+    size_t bytes;   // (run_items: the item's index)
+    size_t* left;   // the batch's counter
+    const std::function<void(size_t)>* fn;  // run_items: the work; null = memcpy
   };
   bool take(Piece* t) {
     std::lock_guard<std::mutex> lk(m_);
@@ -109,7 +141,10 @@ class CopyPool {
   void help() {
     Piece t;
     while (take(&t)) {
-      std::memcpy(t.dst, t.src, t.bytes);
+      if (t.fn)
+        (*t.fn)(t.bytes);
+      else
+        std::memcpy(t.dst, t.src, t.bytes);
       finish_one(t.left);
     }
   }
@@ -130,6 +165,116 @@ class CopyPool {
   std::deque<Piece> q_;
   bool stop_ = false;
 };
+
+// ---- the fp64 boundary, packed on the way (round 5) ------------------------------------------------------------------------
+// rvt_submit_gene is what the unchanged gene loop of the reference calls (src/Main.cpp:1221-1254): the imputed N x M block of
+// doubles, 200 MB per gene at N = 500 000, and the PCIe link carried every byte of it (192-294 gene-sets/s).  But what
+// consolidate() leaves in such a block is almost always hard calls plus ONE other value per column — the mean it imputed
+// (DataConsolidator.cpp:217-245) — and the threads that stage the block touch every double anyway.  pack_column_f64 turns
+// a column into PLINK 2-bit codes (00 -> 0, 10 -> 1, 11 -> 2, 01 -> "the column's other value": exactly the rows
+// rvt_submit_gene_bed hands over, with the other value where the imputed mean would be computed) — 32x fewer bytes — or
+// reports that the column holds a second other value (dosages): the gene then crosses as doubles, as before.
+// Values are compared as BIT PATTERNS (-0.0 is not 0.0 here, and is simply "the other value" of its column).
+struct PackedColumn {
+  bool ok = false;       // false: not representable (two different other values, or an other value outside [0, 2])
+  bool has_mu = false;   // the column holds an other value
+  double mu = 0.0;
+  long long n_other = 0;
+};
+
+inline unsigned char pack4_scalar(const double* g, size_t n, unsigned long long* mu_bits, bool* has_mu, bool* ok, long long* n_other) {
+  unsigned b = 0;
+  for (size_t e = 0; e < n; ++e) {
+    unsigned long long u;
+    std::memcpy(&u, &g[e], 8);
+    unsigned code;
+    if (u == 0ull)
+      code = 0u;
+    else if (u == 0x3FF0000000000000ull)
+      code = 2u;
+    else if (u == 0x4000000000000000ull)
+      code = 3u;
+    else {
+      if (!*has_mu) {
+        *has_mu = true;
+        *mu_bits = u;
+      }
+      if (u != *mu_bits) *ok = false;
+      code = 1u;
+      ++*n_other;
+    }
+    b |= code << (2 * e);
+  }
+  return (unsigned char)b;
+}
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// 16 doubles -> 4 bytes of codes with AVX2; returns false when a value is neither a hard call nor *mu_bits (the caller
+// then looks at the group with the scalar code, which also discovers the column's other value)
+__attribute__((target("avx2"))) inline bool pack16_avx2(const double* g, unsigned long long mu_bits, unsigned char* out, int* n_other) {
+  const __m256i one = _mm256_set1_epi64x(0x3FF0000000000000ll), two = _mm256_set1_epi64x(0x4000000000000000ll),
+                zero = _mm256_setzero_si256(), mu = _mm256_set1_epi64x((long long)mu_bits);
+  int others = 0;
+  for (int q = 0; q < 4; ++q) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(g + 4 * q));
+    const __m256i is0 = _mm256_cmpeq_epi64(v, zero), is1 = _mm256_cmpeq_epi64(v, one), is2 = _mm256_cmpeq_epi64(v, two),
+                  ism = _mm256_cmpeq_epi64(v, mu);
+    const int m_ok = _mm256_movemask_pd(_mm256_castsi256_pd(_mm256_or_si256(_mm256_or_si256(is0, is1), _mm256_or_si256(is2, ism))));
+    if (m_ok != 15) return false;
+    // code bit 0: 2 (11) and other (01); code bit 1: 1 (10) and 2 (11)  [a value equal to a hard call AND to mu is the hard call]
+    const __m256i hard = _mm256_or_si256(_mm256_or_si256(is0, is1), is2);
+    const int oth = _mm256_movemask_pd(_mm256_castsi256_pd(_mm256_andnot_si256(hard, ism)));
+    const int lo = _mm256_movemask_pd(_mm256_castsi256_pd(is2)) | oth;
+    const int hi = _mm256_movemask_pd(_mm256_castsi256_pd(_mm256_or_si256(is1, is2)));
+    others += __builtin_popcount((unsigned)oth);
+    // interleave the two 4-bit masks: bit 2e = lo_e, bit 2e + 1 = hi_e
+    unsigned x = (unsigned)lo | ((unsigned)hi << 8);             // .... hhhh .... llll
+    x = (x | (x << 2)) & 0x3333u;                                // ..hh..hh ..ll..ll
+    x = (x | (x << 1)) & 0x5555u;                                // .h.h.h.h .l.l.l.l
+    out[q] = (unsigned char)((x & 0xffu) | ((x >> 8) << 1));
+  }
+  *n_other += others;
+  return true;
+}
+#endif
+
+// g[0 .. n) -> out[0 .. ceil(n / 4)), then zeros up to `pitch` bytes
+inline PackedColumn pack_column_f64(const double* g, size_t n, unsigned char* out, size_t pitch, const std::atomic<int>* stop) {
+  PackedColumn r;
+  unsigned long long mu_bits = 0x7FF8DEADBEEF0001ull;  // (no double of a genotype block: a NaN payload)
+  bool has_mu = false, ok = true;
+  long long n_other = 0;
+  size_t i = 0, o = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) {
+    while (i + 16 <= n && ok) {
+      if ((o & 0xffff) == 0 && stop && stop->load(std::memory_order_relaxed)) return r;  // another column already failed
+      int no = 0;
+      if (pack16_avx2(g + i, mu_bits, out + o, &no)) {
+        n_other += no;
+      } else {  // a first other value, or a second one
+        for (int q = 0; q < 4; ++q) out[o + q] = pack4_scalar(g + i + 4 * q, 4, &mu_bits, &has_mu, &ok, &n_other);
+      }
+      i += 16;
+      o += 4;
+    }
+  }
+#endif
+  for (; i < n && ok; i += 4, ++o) out[o] = pack4_scalar(g + i, std::min<size_t>(4, n - i), &mu_bits, &has_mu, &ok, &n_other);
+  if (!ok) return r;
+  if (o < pitch) std::memset(out + o, 0, pitch - o);
+  double mu = 0.0;
+  if (has_mu) {
+    std::memcpy(&mu, &mu_bits, 8);
+    if (!(mu >= 0.0 && mu <= 2.0)) return r;  // (NaN, negative, > 2: the device's packed kernel does not take it)
+  }
+  r.ok = true;
+  r.has_mu = has_mu;
+  r.mu = mu;
+  r.n_other = n_other;
+  return r;
+}
 
 // A ring of pinned staging chunks.  The owner supplies the pinned memory and three callbacks:
 //   wait(k)                       block until the DMA that last read chunk k has finished
@@ -206,6 +351,32 @@ struct StageRing {
       }
       pool.run(tasks.data(), tasks.size());
       if (int rc = send(k, 0, (char*)dst_base + base, end - base)) return rc;
+      if (int rc = sent(k)) return rc;
+    }
+    return 0;
+  }
+  // The columns of an fp64 block packed on the way: column j = src + j * spitch_doubles, n doubles -> device row j of
+  // `dpitch` bytes (2-bit codes, zero padded).  out[j] describes every column.  Returns 0 = sent, 1 = a HIP call failed,
+  // 2 = not representable (nothing useful was sent; the caller sends the doubles).
+  int pack_f64(void* dst, size_t dpitch, const double* src, size_t spitch_doubles, size_t n, size_t cols, CopyPool& pool,
+               PackedColumn* out) {
+    if (dpitch > chunk_bytes || cols == 0) return 2;
+    const size_t per = std::max<size_t>(1, chunk_bytes / dpitch);
+    std::atomic<int> stop{0};
+    for (size_t c0 = 0; c0 < cols; c0 += per) {
+      const size_t nc = std::min(per, cols - c0);
+      const int k = next;
+      next = (next + 1) % (int)chunk.size();
+      if (int rc = wait(k)) return rc;
+      char* base = chunk[k];
+      const std::function<void(size_t)> fn = [&](size_t j) {
+        if (stop.load(std::memory_order_relaxed)) return;
+        out[c0 + j] = pack_column_f64(src + (c0 + j) * spitch_doubles, n, reinterpret_cast<unsigned char*>(base + j * dpitch), dpitch, &stop);
+        if (!out[c0 + j].ok) stop.store(1, std::memory_order_relaxed);
+      };
+      pool.run_items(nc, fn);
+      if (stop.load()) return 2;
+      if (int rc = send(k, 0, (char*)dst + c0 * dpitch, nc * dpitch)) return rc;
       if (int rc = sent(k)) return rc;
     }
     return 0;

@@ -1073,16 +1073,22 @@ static __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts
 // copy of the columns that the exact integer product G'G reads (rot_gemm.hip.h).  Four columns per workgroup share the
 // loads of X; the rows are cut into gridDim.y slices whose partial results (part[slice][column][3 + DMAX]: sum, min,
 // max, T) are added in a fixed order by cov_hc_finish_kernel.  grid = (ceil(W / 4), slices), 256 threads; d <= DMAX.
+// PACK = false (round 5): the same pass for blocks that are NOT hard calls (the fp64 band, gemm_f64.hip.h) — no int8 copy,
+// no content test, and optional weights wts (a binary trait's p(1 - p)): T = G' diag(wts) X.
 constexpr int kCovHcCols = 4;
-template <int DMAX>
+template <int DMAX, bool PACK = true>
 __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restrict__ G, long long N, long long ld, int W,
                                                           const double* __restrict__ X, long long ldx, int d,
                                                           signed char* __restrict__ out8, long long ldk,
-                                                          double* __restrict__ part, int* __restrict__ bad) {
+                                                          double* __restrict__ part, int* __restrict__ bad,
+                                                          const double* __restrict__ wts = nullptr) {
   const int c0 = blockIdx.x * kCovHcCols;
   bool not_hard = false;  // a value other than 0.0 / 1.0 / 2.0: the int8 copy is not the block (the host falls back)
   const int nc = min(kCovHcCols, W - c0);
-  const long long per = ((N + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+  // Round 5: a lane takes FOUR consecutive samples per column and step — two 16-byte loads, one 4-byte store of the packed
+  // int8 copy (the first version loaded 8 bytes and stored single bytes per lane: 2.6 TB/s on a pass that only streams).
+  // The block's pad rows (N .. ld, ld a multiple of 16) are zero and readable: only min / max have to skip them.
+  const long long per = ((N + gridDim.y - 1) / gridDim.y + 1023) / 1024 * 1024;
   const long long i0 = (long long)blockIdx.y * per, i1 = (i0 + per < N) ? i0 + per : N;
   double s[kCovHcCols], mn[kCovHcCols], mx[kCovHcCols], t[kCovHcCols][DMAX];
 #pragma unroll
@@ -1093,27 +1099,62 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) t[c][k] = 0.0;
   }
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    double x[DMAX];
+  for (long long i = i0 + 4 * (long long)threadIdx.x; i < i1; i += 1024) {
+    double x[DMAX][4];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) x[k] = (k < d) ? X[(long long)k * ldx + i] : 0.0;
+    for (int k = 0; k < DMAX; ++k) {
+      if (k < d) {
+        const double2 a = *reinterpret_cast<const double2*>(X + (long long)k * ldx + i);
+        const double2 b = *reinterpret_cast<const double2*>(X + (long long)k * ldx + i + 2);
+        x[k][0] = a.x;
+        x[k][1] = a.y;
+        x[k][2] = b.x;
+        x[k][3] = b.y;
+      } else {
+        x[k][0] = x[k][1] = x[k][2] = x[k][3] = 0.0;
+      }
+    }
+    if (!PACK && wts) {
+      const double2 a = *reinterpret_cast<const double2*>(wts + i);
+      const double2 b = *reinterpret_cast<const double2*>(wts + i + 2);
+#pragma unroll
+      for (int k = 0; k < DMAX; ++k) {
+        x[k][0] *= a.x;
+        x[k][1] *= a.y;
+        x[k][2] *= b.x;
+        x[k][3] *= b.y;
+      }
+    }
+    const int live = (int)((i1 - i < 4) ? i1 - i : 4);  // samples of this group inside the slice (the rest: pad rows, zero)
 #pragma unroll
     for (int c = 0; c < kCovHcCols; ++c) {
       if (c < nc) {
-        const double g = G[(long long)(c0 + c) * ld + i];
-        out8[(long long)(c0 + c) * ldk + i] = (signed char)(int)g;
-        not_hard |= !(g == 0.0 || g == 1.0 || g == 2.0);
-        s[c] += g;
-        mn[c] = fmin(mn[c], g);
-        mx[c] = fmax(mx[c], g);
+        const double* gp = G + (long long)(c0 + c) * ld + i;
+        const double2 a = *reinterpret_cast<const double2*>(gp);
+        const double2 b = *reinterpret_cast<const double2*>(gp + 2);
+        const double g[4] = {a.x, a.y, b.x, b.y};
+        unsigned packed = 0;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) t[c][k] = fma(g, x[k], t[c][k]);
+        for (int e = 0; e < 4; ++e) {
+          if (PACK) {
+            packed |= ((unsigned)(int)g[e] & 0xffu) << (8 * e);
+            not_hard |= !(g[e] == 0.0 || g[e] == 1.0 || g[e] == 2.0);
+          }
+          s[c] += g[e];
+          if (e < live) {
+            mn[c] = fmin(mn[c], g[e]);
+            mx[c] = fmax(mx[c], g[e]);
+          }
+#pragma unroll
+          for (int k = 0; k < DMAX; ++k) t[c][k] = fma(g[e], x[k][e], t[c][k]);
+        }
+        if (PACK) *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
       }
     }
   }
   __shared__ double red[4][kCovHcCols][DMAX + 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (__any(not_hard) && lane == 0) atomicOr(bad, 1);
+  if (PACK && __any(not_hard) && lane == 0) atomicOr(bad, 1);
 #pragma unroll
   for (int c = 0; c < kCovHcCols; ++c) {
     double v = s[c], a = mn[c], b = mx[c];

@@ -290,6 +290,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_rotB) hipFree(c->d_rotB);
   if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_part) hipFree(c->d_rot_part);
+  if (c->d_cov_work) hipFree(c->d_cov_work);
   if (c->d_rot_scale) hipFree(c->d_rot_scale);
   if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);

@@ -175,6 +175,8 @@ struct rvt_ctx {
   hipStream_t copy_stream = nullptr;
   hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
+  char* d_cov_work = nullptr;    // work space of the MetaCov rectangles (S, T, the band, column statistics): grow-only
+  size_t cov_work_cap = 0;
   size_t rot_part_cap = 0;
   // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
   struct ColKind {

@@ -1,6 +1,51 @@
 // rvtests_amd — the tests that are not gene tests of the main pipeline: KBAC, MetaScore, MetaCov (bands and rectangles, the
 // exact int8 band for hard calls) and the column operations of the adapters' device ring.  Part of librvtests_amd.so.
 #include "rvt_engine_int.h"
+#include "gemm_f64.hip.h"
+
+namespace {
+// C (M x (Nb + Nb2), column-major, leading dimension ldc) = A' D [B | B2] in fp64 on the matrix cores (gemm_f64.hip.h).
+// A: M columns (lda apart), B: Nb columns, B2: Nb2 further columns (the null-model columns), all N samples long and
+// zero-padded to a multiple of 16; w: optional weights along the samples (D = diag(w)), else D = I.
+// symmetric: A and B are the same columns, only the tiles that meet the upper triangle are computed (the rest of C is
+// left unspecified).  K is split over the chip; the partial results are added in a fixed order.
+int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B, int64_t ldb, int Nb, const double* B2,
+                int64_t ldb2, int Nb2, const double* w, int64_t N, double* C, int64_t ldc, bool symmetric, hipStream_t st) {
+  const int Ntot = Nb + Nb2;
+  if (M < 1 || Ntot < 1) return RVT_OK;
+  int nct = 0;
+  const int n_tiles = gemm_f64_tiles(M, Ntot, symmetric, &nct);
+  const int64_t chunks = (N + kGemmKC - 1) / kGemmKC;
+  int64_t slices = gemm_f64_slices(n_tiles, chunks);
+  if (const char* e = getenv("RVT_GEMM64_SLICES")) slices = std::max<int64_t>(1, atoll(e));
+  const int64_t kslice = ((chunks + slices - 1) / slices) * kGemmKC;
+  slices = (N + kslice - 1) / kslice;
+  double* d_out = C;
+  int64_t c_slice = 0;
+  if (slices > 1) {
+    c_slice = ldc * Ntot;
+    const size_t need = sizeof(double) * (size_t)c_slice * (size_t)slices;
+    if (c->rot_part_cap < need) {
+      if (c->d_rot_part) hipFree(c->d_rot_part);
+      c->d_rot_part = nullptr;
+      c->rot_part_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_rot_part, need));
+      c->rot_part_cap = need;
+    }
+    d_out = c->d_rot_part;
+  }
+  const int64_t groups = (slices + 7) / 8;
+  const dim3 grid((unsigned)(8 * (int64_t)n_tiles * groups));
+  hipLaunchKernelGGL((gemm_tn_f64_kernel<3>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
+                     B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, (int)slices, d_out,
+                     (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0);
+  if (slices > 1)
+    hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_out, (long long)ldc, (long long)M,
+                       (long long)Ntot, (long long)c_slice, (int)slices, C, 0);
+  HIP_TRY(c, hipGetLastError());
+  return RVT_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -133,6 +178,8 @@ int rvt_null_summary(rvt_ctx* c, double* beta, double* covb_diag, double* sigma2
 }
 
 // ---- MetaCov: covariance band of one block of consecutive variants ---------------------------------------
+static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                         int* polymorphic, bool allow_fast);
 int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, double* zz, int* polymorphic) {
   if (!c || !dG || V < 1 || !cov || !xz || !polymorphic) return fail(c, RVT_E_INVALID, "bad arguments");
   if (V > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "block of %d variants exceeds RVT_MAX_VARIANTS", V);
@@ -142,6 +189,9 @@ int rvt_cov_block(rvt_ctx* c, const double* dG, int V, double* cov, double* xz, 
   // (rvt_cov_rect with heads = window) instead of the fp64 matrix cores, ~6x faster at V = 1024.
   if (c->have_null && !c->nc.binary && V >= 64 && !getenv("RVT_METACOV_FP64") && block_hard_calls(c, dG, V, nullptr, nullptr))
     return rvt_cov_rect(c, dG, 0, V, V, cov, xz, zz, polymorphic);  // (tests what it reads; falls back by itself)
+  // Anything else — dosages, or a binary trait's weights: the LDS-tiled fp64 product (gemm_f64.hip.h) from V = 64 on;
+  // RVT_METACOV_PANEL=1 keeps round 4's path through the one-wave sufficient-statistics kernel (22 TFLOP/s at V = 1024)
+  if (c->have_null && V >= 64 && !getenv("RVT_METACOV_PANEL")) return cov_rect_impl(c, dG, 0, V, V, cov, xz, zz, polymorphic, false);
   std::vector<double> af(V, 0.01);
   rvt_gene_result r;
   CovOut co;
@@ -185,45 +235,67 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
   rc = cov_constants(c, false, &cc, &zzv);
   if (rc) return rc;
   const double* GW = dG + (size_t)col0 * ld;
+  // work space: one grow-only allocation of the context (a window walk calls this per eviction: six hipMalloc / hipFree
+  // pairs per call cost more than the kernels of a small window)
   double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_tmp = nullptr;
   int* d_poly = nullptr;
-  struct Guard {
-    std::vector<void**> p;
-    ~Guard() {
-      for (void** q : p)
-        if (*q) hipFree(*q);
+  {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t bS = up(sizeof(double) * (size_t)H * (W + d)), bC = up(sizeof(double) * (size_t)H * W),
+                 bT = up(sizeof(double) * (size_t)W * d), bV = up(sizeof(double) * (size_t)W), bP = up(sizeof(int) * (size_t)W);
+    const size_t bM = up(sizeof(double) * (size_t)64 * W * (RVT_MAX_COV + 3));   // slice partials of the column pass (<= 64 slices)
+    const size_t need = bS + bC + 2 * bT + bV + bP + bM;
+    if (c->cov_work_cap < need) {
+      if (c->d_cov_work) hipFree(c->d_cov_work);
+      c->d_cov_work = nullptr;
+      c->cov_work_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_cov_work, need + need / 4));
+      c->cov_work_cap = need + need / 4;
     }
-  } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_tmp,
-           (void**)&d_poly}};
-  HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
-  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
-  HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * d));
-  HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * d));
-  HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
-  HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
-  const double* Xop = c->d_X;   // N x d operand of T = G_W' D X
-  const double* GHop = GW;      // N x H operand of S = G_H' D G_W
-  if (nc.binary) {              // carry the weights on the small operands
-    const int cols = std::max(d, H);
-    HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)ld * (d + H)));
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)d), dim3(256), 0, st, c->d_X, c->d_v, (long long)N,
-                       (long long)ld, d_tmp);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)H), dim3(256), 0, st, GW, c->d_v, (long long)N,
-                       (long long)ld, d_tmp + (size_t)ld * d);
-    (void)cols;
-    Xop = d_tmp;
-    GHop = d_tmp + (size_t)ld * d;
+    char* q = c->d_cov_work;
+    d_S = reinterpret_cast<double*>(q);      // H x (W + d): T sits behind S when heads = window
+    q += bS;
+    d_cov = reinterpret_cast<double*>(q);
+    q += bC;
+    d_T = reinterpret_cast<double*>(q);
+    q += bT;
+    d_xz = reinterpret_cast<double*>(q);
+    q += bT;
+    d_cs = reinterpret_cast<double*>(q);
+    q += bV;
+    d_poly = reinterpret_cast<int*>(q);
+    q += bP;
+    d_tmp = reinterpret_cast<double*>(q);
   }
-  // T = G_W' D X (W x d) and S = G_H' D G_W (H x W) as integer-plane products (rot_gemm.hip.h): exact for hard calls
-  // and an unweighted model, ~2^-40 relative otherwise
+  const double* T_used = d_T;
+  // T = G_W' D X (W x d) and S = G_H' D G_W (H x W): for a hard-call block under an unweighted model the exact integer
+  // product of rot_gemm.hip.h, else the fp64 matrix cores (round 4 quantised such operands to six digit planes, 36
+  // int8 products, ~2^-40 relative)
   // (hard calls are a prediction — the engine's own per-column flags when it filled the block, optimism otherwise —
   // that cov_hc_prep_kernel verifies on every value it converts; a block that fails is computed again the general way)
   const bool fast = allow_fast && !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
   int* d_bad = nullptr;
   int h_bad = 0;
-  if (!fast)
-    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
-                     d_poly);
+  // one pass over the window's columns for the column statistics and T = G_W' D X (and, on the hard-call path, the int8
+  // copy): rows sliced across workgroups, partial results added in a fixed order
+  const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+  const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
+  const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>((2048 + wgs - 1) / wgs, N / 4096 + 1)));
+  if (!fast) {
+    const dim3 grid((unsigned)wgs, (unsigned)slices);
+    const double* wts = nc.binary ? c->d_v : nullptr;
+    if (dmax == 4)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<4, false>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts);
+    else if (dmax == 8)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<8, false>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts);
+    else
+      hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV, false>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W,
+                         c->d_X, (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts);
+    hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
+                       W, d, dmax, d_cs, d_poly, d_T);
+  }
   if (fast) {
     // heads = whole window of a hard-call block (rvt_cov_block's fast path): ONE pass over G gives the column
     // statistics, T = G'X and the int8 copy (cov_hc_prep_kernel); S = G'G is then one exact integer product
@@ -242,10 +314,6 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     d_bad = c->d_kind;
     HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
     {
-      const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
-      const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
-      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>((2048 + wgs - 1) / wgs, N / 4096 + 1)));
-      HIP_TRY(c, hipMalloc((void**)&d_tmp, sizeof(double) * (size_t)slices * W * (dmax + 3)));
       const dim3 grid((unsigned)wgs, (unsigned)slices);
       if (dmax == 4)
         hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
@@ -263,12 +331,14 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     rc = rvt_planes_gemm(c, c->d_rotB, need, 1, W, zero_exp.data(), 0, c->d_rotB, need, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
     if (rc) return rc;
   } else {
-    rc = gemm_tn_planes(c, GW, ld, W, Xop, ld, d, N, d_T, W, st);
-    if (rc) return rc;
-    rc = gemm_tn_planes(c, GHop, ld, H, GW, ld, W, N, d_S, H, st);
+    // anything else — dosages, a binary trait's weights — on the fp64 matrix cores (gemm_f64.hip.h): the upper triangle of
+    // S = G_H' D G_W
+    // (T came out of the pass above: a 128-column tile for d columns of X would cost as much as a whole tile of S)
+    const double* wts = nc.binary ? c->d_v : nullptr;
+    rc = gemm_tn_f64(c, GW, ld, H, GW, ld, W, nullptr, 0, 0, wts, N, d_S, H, true, st);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
+  hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, T_used, d_cs, W, d_xz);
   hipLaunchKernelGGL(cov_rect_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, H, W, d_cov);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));

@@ -477,6 +477,124 @@ static bool packed_eligible(const rvt_ctx* c, int M, uint32_t tests, const rvt_p
   return true;
 }
 
+// rvt_submit_gene's block of doubles packed on the way (host_stage.h, round 5): when the gene may take the packed kernel
+// (packed_eligible) and the content hint does not say dosages, the staging threads turn every column into 2-bit codes
+// + its one other value while they read it, 6 MB cross the link instead of 200, and the gene continues exactly as a
+// rvt_submit_gene_bed gene whose imputed values are GIVEN (the doubles the caller's consolidate() wrote) instead of
+// computed.  Returns 1 = submitted (rc_out holds the result), 0 = not applicable / not representable: the caller goes on with
+// the plain copy.  RVT_PACK_FP64=0 switches it off.
+int try_submit_packed_f64(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
+                          const rvt_params* prm, int* rc_out) {
+  const char* sw = getenv("RVT_PACK_FP64");  // (read per call: tests switch it inside one process)
+  const bool on = !(sw && atoi(sw) == 0);
+  if (!on || !c->stage_on || c->content_hint == 0 || !packed_eligible(c, M, tests, prm)) return 0;
+  if (host_registered(c, G, sizeof(double) * (size_t)c->nc.N * M)) return 0;  // (a page-locked caller buffer is read by DMA, not by threads)
+  const int64_t N = c->nc.N;
+  if (N < 4096) return 0;  // small blocks: nothing to gain
+  const size_t pk_pitch = ((size_t)((N + 3) / 4) + 15) / 16 * 16;
+  if (stage_ready(c) != RVT_OK || pk_pitch > c->stage.chunk_bytes) return 0;
+  const size_t need = (size_t)kHcpHeaderBytes + pk_pitch * M + 16;
+  rvt_ctx::Pending p;
+  p.id = gene_id;
+  p.M = M;
+  p.dG = nullptr;
+  p.launched = false;
+  std::memset(&p.res, 0, sizeof(p.res));
+  bool fresh = false;
+  int best = -1;
+  auto& pool = c->pk_pool;
+  for (int i = 0; i < (int)pool.size(); ++i)
+    if (pool[i].first >= need && pool[i].first <= 4 * need && (best < 0 || pool[i].first < pool[best].first)) best = i;
+  if (best >= 0) {
+    p.dG = pool[best].second;
+    p.bytes = pool[best].first;
+    pool.erase(pool.begin() + best);
+  } else {
+    if (hipMalloc((void**)&p.dG, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    p.bytes = need;
+    fresh = true;
+  }
+  auto give_back = [&]() { c->pk_pool.emplace_back(p.bytes, p.dG); };
+  hipStream_t st = c->io_stream;
+  hipError_t e = hipSuccess;
+  if (c->consol_af_cap < (size_t)M) {
+    if (c->d_consol_af) hipFree(c->d_consol_af);
+    c->d_consol_af = nullptr;
+    c->consol_af_cap = 0;
+    e = hipMalloc((void**)&c->d_consol_af, sizeof(double) * 2 * RVT_MAX_VARIANTS);
+    if (e == hipSuccess) c->consol_af_cap = RVT_MAX_VARIANTS;
+  }
+  const int nparts = (int)((N + kConsolChunk - 1) / kConsolChunk);
+  if (e == hipSuccess && c->consol_parts_cap < (size_t)M * nparts) {
+    if (c->d_consol_parts) hipFree(c->d_consol_parts);
+    c->d_consol_parts = nullptr;
+    c->consol_parts_cap = 0;
+    const size_t want = (size_t)std::max(M, 128) * nparts;
+    e = hipMalloc((void**)&c->d_consol_parts, sizeof(ConsolPart) * want);
+    if (e == hipSuccess) c->consol_parts_cap = want;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    give_back();
+    return 0;
+  }
+  unsigned char* rows = reinterpret_cast<unsigned char*>(p.dG) + kHcpHeaderBytes;
+  const int ek = c->pack_next;
+  c->pack_next = (ek + 1) % rvt_ctx::kPack;
+  if (fresh) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
+  std::vector<PackedColumn> cols((size_t)M);
+  int prc = 1;
+  if (e == hipSuccess) {
+    TraceScope ts(c, &c->tr_copy);
+    c->h2d_stream = c->copy_stream;
+    prc = c->stage.pack_f64(rows, pk_pitch, G, (size_t)N, (size_t)N, (size_t)M, CopyPool::pack_instance(), cols.data());
+    c->h2d_stream = c->io_stream;
+  }
+  if (prc == 2) {  // dosages, or a column with two other values: the block crosses as doubles
+    give_back();
+    return 0;
+  }
+  if (prc != 0 || e != hipSuccess) {
+    give_back();
+    *rc_out = fail(c, RVT_E_HIP, "packing the fp64 block failed");
+    return 1;
+  }
+  // the other value of every column (0 where it has none) where the header kernel reads the imputed values
+  double mu[RVT_MAX_VARIANTS > 96 ? 96 : RVT_MAX_VARIANTS];
+  for (int j = 0; j < M; ++j) mu[j] = cols[j].has_mu ? cols[j].mu : 0.0;
+  double* d_fill = c->d_consol_af + RVT_MAX_VARIANTS;
+  e = hipEventRecord(c->ev_pack_copied[ek], c->copy_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_pack_copied[ek], 0);
+  if (e == hipSuccess && small_h2d(c, d_fill, mu, sizeof(double) * (size_t)M) != RVT_OK) e = hipErrorUnknown;
+  if (e == hipSuccess) {
+    const bed2_t* sb = reinterpret_cast<const bed2_t*>(rows);
+    const dim3 cgrid((unsigned)nparts, (unsigned)M);
+    hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, (long long)pk_pitch, (long long)N,
+                       c->d_consol_parts);
+    hipLaunchKernelGGL(hcp_header_kernel, dim3(1), dim3(128), 0, st, c->d_consol_parts, nparts, M, (long long)N, d_fill,
+                       reinterpret_cast<HcpHeader*>(p.dG));
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    give_back();
+    *rc_out = fail(c, RVT_E_HIP, "packed fp64 gene: %s", hipGetErrorString(e));
+    return 1;
+  }
+  p.kind = 3;
+  p.decoded = 0;
+  p.af.assign(af, af + M);
+  p.tests = tests;
+  p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+  c->queue.push_back(std::move(p));
+  if (c->trace_submit) ++c->tr_genes;
+  TraceScope ts_l(c, &c->tr_launch);
+  *rc_out = launch_pending(c, c->queue.size(), true);
+  return 1;
+}
+
 int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, const double* af, double* af_out,
                   uint32_t tests, const rvt_params* prm) {
   RegWait reg_wait_on_return(c);
@@ -486,6 +604,10 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   if (M > RVT_MAX_VARIANTS) return fail(c, RVT_E_TOO_LARGE, "gene of %d variants exceeds RVT_MAX_VARIANTS", M);
   hipSetDevice(c->device);
   TraceScope ts_all(c, &c->tr_block);  // (the whole call; "block" in the trace line = total per gene)
+  if (mode == 0) {  // the fp64 boundary: packed on the way when the block allows it
+    int rcp = RVT_OK;
+    if (try_submit_packed_f64(c, gene_id, M, (const double*)G, af, tests, prm, &rcp)) return rcp;
+  }
   if (c->trace_submit) ++c->tr_genes;
   rvt_ctx::Pending p;
   p.id = gene_id;

@@ -137,3 +137,43 @@ def test_cov_block_hard_call_fast_path(engine_factory, V, d, how, monkeypatch):
     kk = kept.astype(bool)
     assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
     assert np.allclose(zz, ozz, rtol=1e-9, atol=1e-9 * max(np.abs(ozz).max(), 1.0))
+
+
+@pytest.mark.parametrize("binary", [0, 1])
+def test_cov_block_fp64_gemm_against_the_one_wave_kernel(engine_factory, binary, monkeypatch):
+    """Blocks that are not hard calls (dosages; any block under a binary trait) take the LDS-tiled fp64 product of round 5
+    (gemm_f64.hip.h: 256 x 128 tiles, K split over the chip, N not a multiple of the 16-sample chunk, three row panels so
+    that tiles below the diagonal are skipped and tiles across it are not).  Same band as round 4's path through the
+    sufficient-statistics kernel (RVT_METACOV_PANEL=1) to rounding, and as the oracle."""
+    N, V, d = 5003, 600, 3
+    G, chrom, pos, X, y = make_case(N, V, d, binary, 9100 + binary)
+    rng = np.random.default_rng(5)
+    G = np.asfortranarray(np.clip(G + rng.uniform(-0.2, 0.2, size=G.shape) * (G > 0), 0.0, 2.0))   # dosages
+    G[:, 11] = 0.5                                           # monomorphic
+    if binary:
+        rc, beta, p, v = orc.fit_logistic(X, y)
+        res, s2 = y - p, 1.0
+    else:
+        rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+        v = np.full(N, s2)
+    assert rc == 0
+    eng = engine_factory()
+    eng.set_null(binary, X, res, v, s2)
+    ptr = eng.upload_block(G)
+    cov, xz, zz, poly = eng.cov_block(ptr, V)
+    monkeypatch.setenv("RVT_METACOV_PANEL", "1")
+    cov0, xz0, zz0, poly0 = eng.cov_block(ptr, V)
+    monkeypatch.delenv("RVT_METACOV_PANEL")
+    monkeypatch.setenv("RVT_GEMM64_SLICES", "3")             # another split of the samples: same sums to rounding
+    cov3 = eng.cov_block(ptr, V)[0]
+    monkeypatch.delenv("RVT_GEMM64_SLICES")
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, binary, 10 ** 7)
+    assert rc == 0 and (poly == kept).all() and (poly0 == kept).all() and not poly[11]
+    m = ~np.isnan(ocov)
+    scale = np.abs(ocov[m]).max()
+    assert np.abs(cov[m] - ocov[m]).max() < REL * scale
+    assert np.abs(cov[m] - cov0[m]).max() < 1e-11 * scale
+    assert np.abs(cov[m] - cov3[m]).max() < 1e-11 * scale
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    assert np.allclose(xz[kk], xz0[kk], rtol=1e-11, atol=1e-11 * max(np.abs(xz0[kk]).max(), 1.0))

@@ -317,3 +317,45 @@ def test_batched_submit_equals_gene_by_gene(eng):
         for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p"):
             x, y_ = getattr(a, f), getattr(c, f)
             assert abs(x - y_) <= 1e-9 * abs(x) + 1e-300, f      # (the packed-row kernel sums in another order)
+
+
+def test_fp64_boundary_packed_on_the_way_gives_the_same_records(monkeypatch):
+    """rvt_submit_gene (the block of doubles the reference's gene loop hands over) packed to 2-bit rows by the staging threads
+    (host_stage.h pack_column_f64; RVT_PACK_FP64=0 switches it off): hard-call genes, genes with mean-imputed columns (one
+    other value per column), a column that is entirely the other value, N not a multiple of 4 / 16 — identical records; a
+    dosage gene and a gene with two other values in one column cross as doubles and give identical records as well."""
+    import rvtests_amd
+    rng = np.random.default_rng(18)
+    N, d = 40_003, 2
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=5)
+    genes = []
+    for g in range(14):
+        M = int(rng.integers(3, 90))
+        raw = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.5, -0.7, M), size=(N, M)).astype(np.float64))
+        if g % 2 == 0:
+            raw[rng.random((N, M)) < 0.01] = -9.0
+        if g == 4:
+            raw[:, 1] = -9.0                                 # every call missing: the column is one other value (0.0 here)
+        G = orc.impute_mean(raw)
+        af = orc.counter_af(raw)
+        if g == 6:
+            G[5, 2] = 0.25                                   # a second other value in an imputed column: not representable
+        if g == 9:
+            G = np.asfortranarray(np.round(G + rng.uniform(0, 0.3, size=G.shape) * (G > 0), 3))   # dosages
+        genes.append((G, af))
+    outs, packed = [], []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("RVT_PACK_FP64", sw)
+        e = rvtests_amd.Engine(0)
+        e.fit_null(0, X, y)
+        e.set_profiling(True)
+        for g, (G, af) in enumerate(genes):
+            e.submit_gene(g, G, af)
+        outs.append(e.collect())
+        packed.append(e.timing(reset=True).genes_hard_call)
+        e.close()
+    assert [r.gene_id for r in outs[0]] == list(range(len(genes)))
+    for a, b in zip(*outs):
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            assert x == y_ or (x != x and y_ != y_), (a.gene_id, f, x, y_)

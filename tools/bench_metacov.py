@@ -1,8 +1,22 @@
 #!/usr/bin/env python3
-"""Throughput of the MetaCov covariance band (rvt_cov_block) at full size: one block of V variants, N samples.
-Reports ms per block, algorithmic bytes/flops (8 N V read once; 2 N V (V/2 + d) flop for the upper triangle) and
-covariance pairs per second.  usage (GPU box): python tools/bench_metacov.py [--samples 500000] [--variants 1024]"""
+"""Throughput of the MetaCov score-covariance band (`--meta cov`; MetaCovTest, src/Model.cpp:844-1004) through the C ABI,
+measured like the headline: one JSON line per workload with `roofline` and `cpu_baseline` objects.
+
+  block   one block of V variants, N samples, all pairs of the upper triangle (rvt_cov_block):
+            fp64   dosages / anything that is not a hard call: the LDS-tiled fp64 product (gemm_f64.hip.h)  — matrix-core bound
+            hc     hard calls under an unweighted model: the exact int8 product (rot_gemm.hip.h)            — HBM bound
+  window  the reference's 1 Mb sliding window as the adapter drives it (ModelFitterGpu.cpp MetaCovTest::flush): a stream of
+          variants whose window holds `--window` markers; the device ring of 1024 columns is filled from HBM-resident
+          columns, flushed when full (one block call), the finished heads are dropped and the rest moved to the front.
+
+Algorithmic work: per pair of the band 2 N flop; per block 8 N V bytes read once.
+CPU baseline: the oracle's MetaCov (orc.metacov, float32 storage as the reference) on a bounded sample (N, V scaled down),
+single thread, rate in pairs/s scaled by N (its cost is N per pair).
+
+usage (GPU box): python tools/bench_metacov.py [--samples 500000] [--variants 1024] [--window 200,1000] [--no-cpu]"""
 import argparse
+import ctypes as C
+import json
 import os
 import sys
 import time
@@ -10,9 +24,33 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rvtests_amd  # noqa: E402
 import bench  # noqa: E402
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # vendor figure for fp64 matrix (= 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide lists no fp64 row
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(N_full, use_float=1):
+    """orc.metacov on N = 20 000, V = 160 (one window): seconds per pair, scaled to N_full (the cost is linear in N)."""
+    import orc
+    rng = np.random.default_rng(3)
+    N, V, d = 20000, 160, 3
+    G = np.asfortranarray(rng.binomial(2, 0.2, size=(N, V)).astype(np.float64))
+    X = np.column_stack([np.ones(N), rng.normal(size=(N, 2))])
+    y = rng.normal(size=N)
+    chrom = np.ones(V, dtype=np.int32)
+    pos = np.arange(V, dtype=np.int32)
+    t0 = time.perf_counter()
+    rc, kept, cov, row_end, xz, zz = orc.metacov(G, chrom, pos, X, y, 0, 10 ** 6, use_float=bool(use_float))
+    dt = time.perf_counter() - t0
+    pairs = int(np.isfinite(cov).sum())
+    per_pair_full = dt / pairs * (N_full / N)
+    return {"value": 1.0 / per_pair_full, "unit": "covariance pairs/s at N=%d" % N_full, "cores": 1, "kind": "port",
+            "sample": "orc.metacov (float32 storage as the reference), N=%d, V=%d, %d pairs in %.2f s, scaled by N" % (N, V, pairs, dt)}
 
 
 def main():
@@ -20,6 +58,9 @@ def main():
     ap.add_argument("--samples", type=int, default=500000)
     ap.add_argument("--variants", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--window", default="200,1000", help="comma-separated window widths (markers) of the stream runs; empty = none")
+    ap.add_argument("--stream", type=int, default=8192, help="variants of a stream run")
+    ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, V = a.samples, a.variants
@@ -30,29 +71,86 @@ def main():
                  np.full(N, float(sigma2)), float(sigma2))
     blocks, Ms, afs = bench.make_genes(dev, N, ld, 1, 5, V, V)
     torch.cuda.synchronize()
-    # line 1: the fp64 band.  The synthetic block holds hard calls, which the engine would send to the exact int8 product
-    # (round 3's line 1 did exactly that under an "fp64" label: 90 "fp64 TFLOP/s", above the 78.6 peak) — so the hard-call
-    # path is switched OFF for this measurement (rvt_set_hardcall(0)): gene_suffstat_mfma / gene_suffstat_panel + cov kernels
-    eng.set_hardcall(False)
-    eng.cov_block(blocks[0].data_ptr(), V)
-    t0 = time.perf_counter()
-    for _ in range(a.reps):
-        cov, xz, zz, poly = eng.cov_block(blocks[0].data_ptr(), V)
-    dt = (time.perf_counter() - t0) / a.reps
-    eng.set_hardcall(True)
+    cpu = None if a.no_cpu else cpu_baseline(N)
     pairs = V * (V + 1) / 2
-    print({"N": N, "V": V, "kernel": "fp64 matrix cores (hard-call path off: what a block of dosages takes)", "ms_per_block": 1e3 * dt,
-           "pairs_per_s": pairs / dt, "alg_GBps": 8.0 * N * V / dt / 1e9,
-           "alg_TFLOPs_fp64": 2.0 * N * V * (V / 2 + 4) / dt / 1e12, "polymorphic": int(poly.sum())})
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            out = fn()
+        return (time.perf_counter() - t0) / a.reps, out
+
+    # ---- block, fp64: dosages (the synthetic block + a fractional part in the non-zero entries)
+    dos = blocks[0].clone()
+    dos += (dos > 0) * 0.125 * torch.rand_like(dos)
+    torch.cuda.synchronize()
+    dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(dos.data_ptr(), V))
+    tf = 2.0 * N * pairs / dt / 1e12
+    print(json.dumps({"workload": "MetaCov block, dosages (fp64 matrix cores)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+                      "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
+                      "roofline": {"kernel": "gemm_tn_f64_kernel", "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                                   "note": "2 N flop per pair of the upper triangle over the wall time of the synchronous C call "
+                                           "(column pass, product, reduction, band, copy-back included)"},
+                      "cpu_baseline": cpu}))
+    # ---- block, hard calls
     hard = torch.round(blocks[0]).contiguous()
+    torch.cuda.synchronize()                                  # (torch's stream is not the engine's)
     assert eng.classify_block(hard.data_ptr(), V)
-    eng.cov_block(hard.data_ptr(), V)
-    t0 = time.perf_counter()
-    for _ in range(a.reps):
-        cov, xz, zz, poly = eng.cov_block(hard.data_ptr(), V)
-    dt = (time.perf_counter() - t0) / a.reps
-    print({"N": N, "V": V, "kernel": "hard calls: exact int8 product", "ms_per_block": 1e3 * dt, "pairs_per_s": pairs / dt,
-           "alg_GBps": 8.0 * N * V / dt / 1e9, "int8_TOPs": 2.0 * N * V * V / dt / 1e12, "polymorphic": int(poly.sum())})
+    dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(hard.data_ptr(), V))
+    gbs = 8.0 * N * V / dt / 1e9
+    print(json.dumps({"workload": "MetaCov block, hard calls (exact int8 product)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+                      "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
+                      "int8_TOPs": 2.0 * N * V * V / dt / 1e12,
+                      "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                   "note": "8 N V bytes of the block over the wall time of the synchronous C call"},
+                      "cpu_baseline": cpu}))
+    # ---- the sliding window, as the adapter drives it
+    widths = [int(w) for w in a.window.split(",") if w]
+    if widths:
+        cap = 1024
+        ring = eng.alloc_block(cap)
+        src = hard                                            # V resident columns, re-used cyclically as the stream
+        for w in widths:
+            if w >= cap:
+                continue
+            done = 0
+            fill = 0
+            t_cov = 0.0
+            flushes = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nxt = 0
+            while done < a.stream:
+                # fill the ring from resident columns (the adapter uploads each site's column; here: device copies)
+                while fill < cap:
+                    n = min(cap - fill, V - nxt)
+                    eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src.data_ptr()), nxt, n))
+                    fill += n
+                    nxt = (nxt + n) % V
+                t1 = time.perf_counter()
+                eng.cov_block(ring, cap)
+                t_cov += time.perf_counter() - t1
+                flushes += 1
+                heads = cap - w                               # heads whose window is complete
+                eng.move_columns(ring, 0, heads, cap - heads)
+                fill = cap - heads
+                done += heads
+            dt = time.perf_counter() - t0
+            npairs = done * (w + 1)
+            gbs = 8.0 * N * done / dt / 1e9
+            print(json.dumps({"workload": "MetaCov sliding window, hard calls, ring of %d columns" % cap, "N": N, "window_markers": w,
+                              "variants": done, "flushes": flushes, "ms_per_flush": 1e3 * dt / flushes,
+                              "ms_per_flush_in_cov_block": 1e3 * t_cov / flushes, "value": npairs / dt,
+                              "unit": "printed covariance pairs/s", "variants_per_s": done / dt,
+                              "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                           "note": "8 N bytes per evicted variant (each column of the stream read once) over the wall "
+                                                   "time; a flush recomputes the columns it keeps, so the ring reads 1024 / (1024 - w) times that"},
+                              "cpu_baseline": cpu}))
+        eng.free_block(ring)
 
 
 if __name__ == "__main__":
