@@ -689,15 +689,6 @@ def main():
                         line["cpu_baseline"]["native_build"] = {
                             "value": 1.0 / one_n[k1]["seconds"], "unit": "gene-sets/s", "cores": 1,
                             "flags": "g++ -O3 -march=native", "seconds": one_n[k1]["seconds"]}
-                # every core the affinity mask gives (bounded by memory and by 64): that many single-thread processes, each
-                # computing THE SAME mean-width gene at once — what the CPU port delivers per host when genes are dealt to cores
-                reps = max(1, min(ncpu, by_mem, 64))
-                if reps > 1:
-                    _, wall_all = cpu_oracle_pool({k1: host[k1]}, Xh, yh, 1 if binary else 0, reps, replicate=True)
-                    line["cpu_baseline_allcores"] = {
-                        "value": reps / wall_all, "unit": "gene-sets/s", "cores": reps, "host_cores": ncpu, "kind": "port",
-                        "sample": "%d single-thread processes at once, each the gene of M=%d (start-up and one null fit per "
-                                  "process included), %.1f s wall" % (reps, Ms[k1], wall_all)}
                 # B-lit-SKAT: the reference's own formulation — Skat.cpp:57-76 forms the N x N P0 in float —
                 # cannot run at this N (4 N^2 bytes = 1 TB); timed at N = 4 000 / 8 000 / 16 000 on one thread, its fitted
                 # power law gives what a gene would cost here
@@ -706,15 +697,23 @@ def main():
                         line["cpu_baseline_literal_skat"] = literal_skat_baseline(N)
                     except Exception as e:
                         line["cpu_baseline_literal_skat"] = {"error": repr(e)[:200]}
-            recs, wall = cpu_oracle_pool({k: host[k] for k in pick}, Xh, yh, 1 if binary else 0, workers)
+            # every core the affinity mask gives, bounded by memory and by 48: the sampled genes (parity) plus replicas of the
+            # mean-width gene until there is one gene per process — what the CPU port delivers per host with genes dealt to cores
+            W = max(len(pick), min(ncpu, by_mem, 48))
+            pool_genes = {k: host[k] for k in pick}
+            for i in range(W - len(pick)):
+                pool_genes[-(i + 1)] = host[k1]
+            recs, wall = cpu_oracle_pool(pool_genes, Xh, yh, 1 if binary else 0, W)
             if recs:
-                # (named for what it is: `workers` single-thread processes — one per sampled gene, bounded by memory —, NOT every
-                #  core of the host; the default sample keeps the whole bench inside a few minutes)
+                n_all = len(recs)
+                recs = {k: r for k, r in recs.items() if k >= 0}
                 line["cpu_baseline_multiproc"] = {
-                    "value": len(pick) / wall, "unit": "gene-sets/s", "cores": workers, "host_cores": ncpu, "kind": "port",
-                    "sample": "%d genes of the batch (M %d..%d) dealt to %d single-thread processes at once, %.1f s wall "
-                              "(process start-up and one null fit per process included); host has %d cores"
-                              % (len(pick), min(Ms[k] for k in pick), max(Ms[k] for k in pick), workers, wall, ncpu)}
+                    "value": n_all / wall, "unit": "gene-sets/s", "cores": W, "host_cores": ncpu, "kind": "port",
+                    "sample": "%d genes (the %d sampled genes of the batch, M %d..%d, + %d replicas of the M=%d gene) on %d "
+                              "single-thread processes at once, one gene each, %.1f s wall (process start-up and one null fit "
+                              "per process included); the affinity mask has %d cores, memory allows %d processes"
+                              % (n_all, len(pick), min(Ms[k] for k in pick), max(Ms[k] for k in pick), W - len(pick), Ms[k1],
+                                 W, wall, ncpu, by_mem)}
                 if one:
                     recs.setdefault(k1, one[k1])
                 line["parity"] = parity_summary(recs, out0)

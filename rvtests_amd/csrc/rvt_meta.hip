@@ -59,6 +59,7 @@ static int block_hard_calls(rvt_ctx* c, const double* dG, int V, std::vector<int
   if (!c->hc_enabled) return 0;
   auto it = c->col_kind.find(dG);
   if (it == c->col_kind.end() || !it->second.d_flags || V > it->second.cols) {
+    if (c->content_hint == 0) return 0;  // the caller said dosages (rvt_set_content_hint): do not try the integer path first
     if (any) *any = true;
     return -1;
   }
