@@ -242,8 +242,9 @@ int rvt_set_dosage_lattice(rvt_ctx* ctx, int denominator);
 /* Float-precision dosages.  BGEN input reaches fit() as dosages formed from FLOAT probabilities
  * (src/BGenGenotypeExtractor.cpp:413-478: prob[] is std::vector<float>, dosage = p1 + 2 p2): integer multiples of 2^-31 for
  * 8-bit files, and any float-precision dosage that is 0 or >= 2^-14 is a multiple of 2^-37.  Under a quantitative trait
- * such blocks — what rvt_submit_gene_bgen decodes, and the caller's doubles under rvt_set_content_hint(ctx, 0) when
- * rvt_set_dosage_float(ctx, 1) says so (no lattice denominator stated) — take gene_suffstat_fdx
+ * such blocks — what rvt_submit_gene_bgen decodes, and the caller's doubles under rvt_set_content_hint(ctx, 0) — take
+ * gene_suffstat_fdx WHEN rvt_set_dosage_float(ctx, 1) ASKS FOR IT (no lattice denominator stated; round 5: opt-in — the
+ * kernel gives G'G as an exact integer but runs no faster than the fp64 kernel, so nothing starts on it unasked)
  * (rvtests_amd/csrc/suffstat_fdx.hip.h) for M <= 64: K = g 2^37 is read off the double, split into five balanced base-256
  * digits and K'K is formed exactly on the int8 matrix cores.  Every value is tested (g 2^37 an integer, 0 <= g <= 2): a
  * block that holds anything else is handed back and computed by the fp64 kernel in the same call.  A wrong statement costs

@@ -93,6 +93,44 @@ void hc_sym_eigvals(const double* Ain, int n, double* out) {
   coop_sym_eigvals(co, A.data(), n, d.data(), e.data(), v.data(), w.data(), out);
 }
 
+// evaluations of the Sturm recurrence per eigenvalue (mean and maximum) of the same solver: what the hybrid of bisection and
+// interpolation costs (pure bisection: ~53-62)
+void hc_tridiag_evals(const double* din, const double* ein, int n, double* mean_out, int* max_out) {
+  std::vector<double> d(din, din + n), e(n, 0.0);
+  for (int j = 0; j + 1 < n; ++j) e[j] = ein[j];
+  double lo = d[0], hi = d[0];
+  for (int j = 0; j < n; ++j) {
+    const double r = (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0);
+    lo = fmin(lo, d[j] - r);
+    hi = fmax(hi, d[j] + r);
+  }
+  const double span0 = fmax(fabs(lo), fabs(hi));
+  int sh = 0;
+  if (span0 > 0.0 && span0 < INFINITY) (void)frexp(span0, &sh);
+  for (int j = 0; j < n; ++j) {
+    d[j] = ldexp(d[j], -sh);
+    if (j < n - 1) {
+      const double es = ldexp(e[j], -sh);
+      e[j] = fmax(es * es, 0x1p-200);
+    }
+  }
+  lo = ldexp(lo, -sh);
+  hi = ldexp(hi, -sh);
+  const double span = fmax(fabs(lo), fabs(hi)), pivmin = DBL_MIN * 1024.0;
+  lo -= 2.0 * kDblEps * span * n + 2.0 * pivmin;
+  hi += 2.0 * kDblEps * span * n + 2.0 * pivmin;
+  long long tot = 0;
+  int mx = 0;
+  for (int idx = 0; idx < n; ++idx) {
+    int ev = 0;
+    (void)sturm_eigenvalue(d.data(), e.data(), n, idx, lo, hi, span, pivmin, &ev);
+    tot += ev;
+    mx = std::max(mx, ev);
+  }
+  *mean_out = (double)tot / n;
+  *max_out = mx;
+}
+
 // the bisection alone: d[n], e[n-1] -> all eigenvalues ascending (division-free Sturm count, rvt_coop.h)
 void hc_tridiag_eigvals(const double* din, const double* ein, int n, double* out) {
   std::vector<double> d(din, din + n), e(n, 0.0), red(64);

@@ -988,13 +988,17 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   const bool hc_possible = c->hc_enabled && (!nc.binary || hcw) && (!cov || score_hc) &&
                            !(dbg && dbg->cmc) && d <= kHcMaxD && !(tests & RVT_TEST_FAMSKAT) &&
                            c->d_nulltile != nullptr && nd_is_default;
-  // the per-gene condition of the float-digit dosage kernel (quantitative trait; wave-part length aside) — ONE predicate for
+  // the per-gene condition of the float-digit dosage kernel (quantitative trait; wave-part length aside).  Round 5: OPT-IN —
+  // only when the caller asked for it with rvt_set_dosage_float(1).  It computes G'G of float-precision dosages as an exact
+  // integer (bit-reproducible whatever the split of the samples), but it does not pay in speed (0.44 of HBM live against the
+  // fp64 kernel's 0.42: +3 %), and BGEN genes with a missing call paid a failed pass on it — so BGEN genes no
+  // longer start on it by themselves.  ONE predicate for
   // the batch-level prediction below and the per-gene decision further down (they had drifted apart)
   const bool fdx_model = hc_possible && !nc.binary && !cov && c->fdx_ok && c->lattice_den == 0;
   auto fdx_gene = [&](int g) {
     const int k = kind ? kind[g] : -1;
     return fdx_model && (Ms[g] + 15) / 16 <= kFdxEngineMT && (uint64_t)Ms[g] * (uint64_t)ld * 8ull < (1ull << 31) &&
-           (k == 0 || (k < 0 && c->content_hint == 0 && c->dosage_float));
+           c->dosage_float && (k == 0 || (k < 0 && c->content_hint == 0));
   };
   // does a gene of the batch start on it?  (its wave-parts are shorter, and the batch is not split over two streams)
   bool fdx_batch = false;

@@ -130,9 +130,11 @@ def test_against_the_oracle():
         pass
 
 
-def test_bgen_genes_take_it_without_being_told():
-    """rvt_submit_gene_bgen marks its blocks as dosages (kind 0): complete 8-bit blocks go to gene_suffstat_fdx by themselves —
-    every value is a multiple of 2^-31 — and give the records of the fp64 path."""
+def test_bgen_genes_take_it_when_asked():
+    """rvt_submit_gene_bgen marks its blocks as dosages (kind 0).  Round 5: the float-digit kernel is OPT-IN
+    (rvt_set_dosage_float(1)) — it gives G'G as an exact integer but does not pay in speed, so BGEN genes start on the fp64
+    kernel unless the caller asks.  Asked: complete 8-bit blocks (every value a multiple of 2^-31) go to gene_suffstat_fdx and give
+    the records of the fp64 path; not asked: none of them does."""
     import bgengen
     import synth
     rng = np.random.default_rng(5)
@@ -140,11 +142,13 @@ def test_bgen_genes_take_it_without_being_told():
     X, y, res, v, s2 = synth.make_null(N, d, 0, seed=9)
     genes = [[bgengen.layout2_block_fast(rng, N, bits=8, missing=0.0) for _ in range(M)] for M in (7, 30, 48)]
     out = {}
-    for mode in ("default", "fp64"):
+    for mode in ("default", "fp64", "not_asked"):
         eng = rvtests_amd.Engine(0)
         eng.set_null(0, X, res, v, s2)
         if mode == "fp64":
             eng.set_hardcall(False)
+        if mode == "default":
+            eng.set_dosage_float(True)
         eng.set_profiling(True)
         eng.timing(reset=True)
         for g, blocks in enumerate(genes):
