@@ -2,6 +2,7 @@
 // and the C ABI.  Built by hipcc for gfx950 into librvtests_amd.so.  There is no CPU fallback: without a
 // HIP device rvt_init() fails with RVT_E_NO_DEVICE.
 #include "rvt_engine_int.h"
+#include <chrono>
 
 extern "C" {
 
@@ -932,9 +933,29 @@ static void layout_gene(int M, int d, int n_wparts, int64_t nsteps, int n_bparts
 
 // kind (optional, per gene): what the engine's own decoder wrote into the block — 1 hard calls (+ imputed means),
 // 0 dosages, -1 unknown.
+// RVT_TRACE_BATCH=1: host time of run_batch's phases to stderr (diagnosis of a host-bound launch path)
+struct BatchTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  BatchTrace() : on(getenv("RVT_TRACE_BATCH") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(int k) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    ph[k] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+  }
+  void print(int n) const {
+    if (on)
+      fprintf(stderr, "run_batch n=%d us: slot %.0f layout %.0f arena+desc %.0f sort+copy %.0f suffstat %.0f tail %.0f\n", n, ph[0],
+              ph[1], ph[2], ph[3], ph[4], ph[5]);
+  }
+};
+
 int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
               const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
               DebugOut* dbg, CovOut* cov, const signed char* kind) {
+  BatchTrace bt;
   if (!c || n < 0 || (n > 0 && (!dG || !Ms || !af || !out))) return fail(c, RVT_E_INVALID, "bad batch arguments");
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
@@ -953,6 +974,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     int rc = finish_slot(c, sl);
     if (rc) return rc;
   }
+  bt.mark(0);
   sl.seq = ++c->launch_seq;
   hipStream_t st = sl.stream;
   if (c->io_wait_pending) {
@@ -1075,6 +1097,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
                 (tests & RVT_TEST_ANALYTICVT) != 0);
     af_total += M;
   }
+  bt.mark(1);
   const size_t off_af = add(sizeof(double) * af_total);
   const size_t off_desc = add(sizeof(GeneDesc) * n);
   const size_t off_res = add(sizeof(rvt_gene_result) * n);
@@ -1148,6 +1171,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     }
     afpos += gd.M;
   }
+  bt.mark(2);
   std::memcpy(h_af, af, sizeof(double) * af_total);
   HIP_TRY(c, hipMemcpyAsync(base + off_af, h_af, sizeof(double) * af_total, hipMemcpyHostToDevice, st));
   // widest genes first: their workgroups run longest, so they should not be the tail of the launch
@@ -1180,6 +1204,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   // Stage 1 (bandwidth / MFMA bound) runs on the shared K2 stream so that two batches never split the chip
   // between two sufficient-statistics launches; stage 2 (latency bound, few waves) continues on the slot's
   // stream and overlaps the NEXT batch's stage 1.
+  bt.mark(3);
   const int slot_idx = (int)(slp - &c->slots[0]);
   HIP_TRY(c, hipEventRecord(c->ev_in[slot_idx], st));
   HIP_TRY(c, hipStreamWaitEvent(c->k2_stream, c->ev_in[slot_idx], 0));
@@ -1257,6 +1282,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     for (int grp = 0; grp < 3; ++grp)
       if (grp_present[grp]) launch_suffstat(c, st, grp, d_desc + n_gen, n_hc, n_wparts, nd, d_lists);
   }
+  bt.mark(4);
   if (cov && cov->score) {  // MetaScore: per-variant statistics of every slice, returned synchronously
     size_t vt = 0;
     for (int g = 0; g < n; ++g) vt += (size_t)Ms[g];
@@ -1414,6 +1440,8 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   rvt_gene_result* h_res = reinterpret_cast<rvt_gene_result*>(sl.h_stage + sizeof(GeneDesc) * n +
                                                                (sizeof(double) * af_total + 63) / 64 * 64);
   HIP_TRY(c, hipMemcpyAsync(h_res, base + off_res, sizeof(rvt_gene_result) * n, hipMemcpyDeviceToHost, st));
+  bt.mark(5);
+  bt.print(n);
   sl.pending_out = out;
   sl.pending_done = c->next_done_flag;
   c->next_done_flag = nullptr;

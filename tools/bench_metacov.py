@@ -121,7 +121,7 @@ def main():
             done = 0
             fill = 0
             t_cov = t_move = t_fill = 0.0
-            flushes = 0
+            flushes = -1
             nxt = 0
             while done < a.stream:
                 # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies,
@@ -139,11 +139,14 @@ def main():
                 heads = cap - w                               # heads whose window is complete
                 eng.move_columns(ring, 0, heads, cap - heads)
                 t4 = time.perf_counter()
+                fill = cap - heads
+                if flushes < 0:                               # the first flush of a width is a warm-up (first touch of the ring)
+                    flushes = 0
+                    continue
                 t_fill += t2 - t1
                 t_cov += t3 - t2
                 t_move += t4 - t3
                 flushes += 1
-                fill = cap - heads
                 done += heads
             dt = t_cov + t_move
             npairs = done * (w + 1)
