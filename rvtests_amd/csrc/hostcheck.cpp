@@ -233,7 +233,13 @@ int hc_gene(int trait, int64_t N, int d, double sigma2, double rss, double rsum,
   std::vector<double> vec((size_t)8 * Mp + 8);
   for (int w = 0; w < kNTridiag; ++w)
     gene_tridiag(co, nc, w, M, Mp, tests, ws, ws.eig + (size_t)w * Mp * Mp, vec.data(), &gs);
-  for (int k = 0; k < kNEigen; ++k) gene_spectrum(co, nc, k, M, Mp, tests, ws, vec.data(), &gs, lam.data());
+  if (getenv("RVT_SPECTRUM_PER_PROBLEM")) {  // the per-problem form (one workgroup per eigenproblem on the device until round 5)
+    for (int k = 0; k < kNEigen; ++k) gene_spectrum(co, nc, k, M, Mp, tests, ws, vec.data(), &gs, lam.data());
+  } else {
+    std::vector<double> vec2((size_t)39 * Mp + 64);
+    SpectrumMeta meta[kNEigen];
+    gene_spectrum_all(co, nc, M, Mp, tests, ws, vec2.data(), meta, &gs, lam.data());
+  }
   std::vector<int> th1(M + 1), th2(M + 1);
   std::vector<char> qmem(qags_workspace_bytes(kSkatoLimit));
   gene_pvalue_serial(gs, lam.data(), tests, 0, th1.data(), th2.data(), qmem.data(), out);

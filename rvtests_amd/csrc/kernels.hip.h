@@ -392,6 +392,18 @@ static __global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDes
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   gene_spectrum(co, *ncp, blockIdx.x, gd.M, gd.Mp, tests, ws, esm, gd.stats, gd.lambda);
 }
+// round 5: ONE workgroup per gene walks the (problem, eigenvalue) tasks of all 13 problems (rvt_gene.h gene_spectrum_all);
+// dynamic LDS: 39 * Mp + 64 doubles
+static __global__ __launch_bounds__(128) void gene_spectrum_all_kernel(const GeneDesc* __restrict__ genes,
+                                                                const NullConsts* __restrict__ ncp, unsigned tests) {
+  extern __shared__ __attribute__((aligned(16))) double esm[];
+  __shared__ double red[64];
+  __shared__ SpectrumMeta meta[kNEigen];
+  const GeneDesc gd = genes[blockIdx.x];
+  Coop co{(int)threadIdx.x, (int)blockDim.x, red};
+  GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
+  gene_spectrum_all(co, *ncp, gd.M, gd.Mp, tests, ws, esm, meta, gd.stats, gd.lambda);
+}
 
 // =====================================================================================================
 // MetaCov (src/Model.cpp:844-1004): the score covariances of a block of V consecutive variants are a by-product
@@ -1446,6 +1458,9 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   const dv_coefs lbs[2] = {(dv_coefs)lam_zimz, (dv_coefs)lam_skat};
   const dv_coefs lss[2] = {(dv_coefs)ls_zimz, (dv_coefs)ls_skat};
   const int rs[2] = {n_zimz, n_skat};
+#ifdef RVT_PROF_K4
+  const long long tk_a = clock64();  // loads, sorted copies, memo clear
+#endif
   double terms = 0.0;
   const bool fam = (tests & RVT_TEST_FAMSKAT) != 0;  // FamSkat.cpp:118: Davies only, result in the famskat fields
   const bool do_skat = (tests & (RVT_TEST_SKAT | RVT_TEST_FAMSKAT)) != 0;
@@ -1468,6 +1483,9 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   }
   const double cmc_p = __shfl(pv_rho, 61, 64), zeg_p = __shfl(pv_rho, 60, 64);
   __syncthreads();
+#ifdef RVT_PROF_K4
+  const long long tk_b = clock64();  // per-rho tails, burden tails
+#endif
   // ---- SKAT-O preparation -------------------------------------------------------------------------------
   double minP = 1.0;
   int minIndex = 0;
@@ -1494,6 +1512,9 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
     }
     if (lane == 13) sh.liu = liu_prepare(lam_zimz, n_zimz);
   }
+#ifdef RVT_PROF_K4
+  const long long tk_c = clock64();  // quantiles, Liu moments
+#endif
   // The searches of qf() that do not depend on the quantile, once per coefficient set: SKAT-O's on lane 12, SKAT's own on
   // lane 14 — the same code on two lanes, so they run side by side; both fill the memo of their set on the way.
   if (lane == 12 || lane == 14) {
@@ -1711,6 +1732,10 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   out->famcmc_V = prof4[1];                          // flattened main integration
   out->famzeg_U = prof4[2];                          // lane-0 QAGS bookkeeping
   out->famzeg_V = (double)(tk_start - tk_entry);     // before the QAGS loop (loads, order, prelude, moments)
+  out->famskat_Q = (double)(tk_a - tk_entry);        //   loads, sorted copies, memo clear
+  out->famskat_p = (double)(tk_b - tk_a);            //   per-rho tails
+  out->famcmc_af = (double)(tk_c - tk_b);            //   min-p, quantiles, Liu moments
+  out->famzeg_af = (double)(tk_start - tk_c);        //   the two preludes
 #endif
 }
 

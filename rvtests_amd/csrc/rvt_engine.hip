@@ -1408,8 +1408,15 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     }
     {
       Scope sc(c, 2, st);
-      hipLaunchKernelGGL(gene_spectrum_kernel, dim3(kNEigen, n), dim3(128), sizeof(double) * (size_t)4 * maxMp, st,
-                         d_desc, c->d_nc, tests_eig);
+      // (one workgroup per gene over all 13 problems; RVT_SPECTRUM_PER_PROBLEM=1 or a gene too wide for the LDS: a workgroup
+      //  per problem, as until round 4)
+      static const bool per_problem = getenv("RVT_SPECTRUM_PER_PROBLEM") != nullptr;
+      const size_t lds_all = sizeof(double) * ((size_t)39 * maxMp + 64);
+      if (per_problem || lds_all > ((size_t)60 << 10))
+        hipLaunchKernelGGL(gene_spectrum_kernel, dim3(kNEigen, n), dim3(128), sizeof(double) * (size_t)4 * maxMp, st,
+                           d_desc, c->d_nc, tests_eig);
+      else
+        hipLaunchKernelGGL(gene_spectrum_all_kernel, dim3(n), dim3(128), lds_all, st, d_desc, c->d_nc, tests_eig);
     }
   }
   {

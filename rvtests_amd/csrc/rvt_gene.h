@@ -697,6 +697,180 @@ RVT_HD void gene_spectrum(const Coop& co, const NullConsts& nc, int k, int M, in
   co.sync();
 }
 
+// Stage B2, all 13 eigenproblems of a gene in ONE workgroup (round 5).  The per-problem form above gives every problem a
+// workgroup of its own and every eigenvalue a lane: 13 waves per gene, each as slow as its slowest eigenvalue (~55 evaluations
+// of the recurrence where the average eigenvalue needs ~25, rvt_coop.h).  Here the 13 scaled tridiagonals sit side by side in
+// `vec` (3 m doubles per problem: d, e^2, eigenvalues) and the lanes walk the list of (problem, eigenvalue) tasks with a
+// stride — a lane solves several eigenvalues of different problems one after the other, so what it pays is the AVERAGE cost.
+// Every number is the per-problem form's: the same raw arrays, the same Gershgorin bounds and power-of-two scaling (computed
+// by one thread per problem), the same sturm_eigenvalue, the same filters and moments.  `vec` >= 39 * m + 64 doubles.
+struct SpectrumMeta {
+  double lo, hi, span;
+  int sh, n, active;
+};
+RVT_HD void gene_spectrum_all(const Coop& co, const NullConsts& nc, int M, int Mp, unsigned tests, GeneScratch ws,
+                              double* vec, SpectrumMeta* meta, GeneStats* out, double* lambda_out) {
+  const int m = out->n_poly;
+  if (m == 0) return;
+  if (m == 1) {  // the single-variant shortcuts: no recurrence to run
+    gene_spectrum(co, nc, 11, M, Mp, tests, ws, vec, out, lambda_out);
+    gene_spectrum(co, nc, 12, M, Mp, tests, ws, vec, out, lambda_out);
+    return;
+  }
+  const double* d0 = ws.tri;
+  const double* e0 = ws.tri + Mp;
+  const bool shares = skat_shares_weights(ws, Mp, m);
+  const bool zimz_bad = !(d0[0] > 0.0);  // 1'A1 <= 0: the reference's M is 0/0 and every eigenvalue NaN
+  auto active = [&](int k) {
+    if (k == 12) return (tests & RVT_TEST_SKAT) != 0;
+    if (!(tests & RVT_TEST_SKATO)) return false;
+    return !(k == 11 && zimz_bad);
+  };
+  auto size_of = [&](int k) { return k == 11 ? m - 1 : m; };
+  // ---- A: the raw tridiagonals, one entry per item
+  for (int item = co.tid; item < kNEigen * m; item += co.nt) {
+    const int k = item / m, i = item % m;
+    if (!active(k) || i >= size_of(k)) continue;
+    double* td = vec + (size_t)k * 3 * m;
+    double* te = td + m;
+    if (k == 12) {
+      if (shares) {
+        const double sc = 2.0 * (nc.binary ? 1.0 : nc.sigma2);
+        td[i] = sc * d0[i];
+        te[i] = sc * e0[i];
+      } else {
+        td[i] = ws.tri[2 * Mp + i];
+        te[i] = ws.tri[3 * Mp + i];
+      }
+    } else if (k == 11) {
+      td[i] = (i == 0) ? d0[1] - e0[0] * e0[0] / d0[0] : d0[i + 1];
+      te[i] = e0[i + 1];
+    } else {
+      const double rh = skato_rho_value(k);
+      const double s1 = 1.0 - rh, sm = 1.0 - rh + (double)m * rh;
+      const double s1m = sqrt(s1 * sm);
+      td[i] = (i == 0) ? sm * d0[0] : s1 * d0[i];
+      te[i] = (i == 0) ? s1m * e0[0] : s1 * e0[i];
+    }
+  }
+  co.sync();
+  // ---- B: per problem, one thread: Gershgorin interval, the power of two that brings its span into [1/2, 1)
+  const double pivmin = DBL_MIN * 1024.0;
+  for (int k = co.tid; k < kNEigen; k += co.nt) {
+    SpectrumMeta mt;
+    mt.active = active(k) ? 1 : 0;
+    mt.n = size_of(k);
+    mt.lo = mt.hi = mt.span = 0.0;
+    mt.sh = 0;
+    if (mt.active) {
+      const double* d = vec + (size_t)k * 3 * m;
+      const double* e = d + m;
+      const int n = mt.n;
+      double lo = d[0], hi = d[0];
+      for (int j = 0; j < n; ++j) {
+        const double r = (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0);
+        lo = fmin(lo, d[j] - r);
+        hi = fmax(hi, d[j] + r);
+      }
+      const double span0 = fmax(fabs(lo), fabs(hi));
+      int sh = 0;
+      if (span0 > 0.0 && span0 < INFINITY) (void)frexp(span0, &sh);
+      lo = ldexp(lo, -sh);
+      hi = ldexp(hi, -sh);
+      const double span = fmax(fabs(lo), fabs(hi));
+      mt.lo = lo - (2.0 * kDblEps * span * n + 2.0 * pivmin);
+      mt.hi = hi + (2.0 * kDblEps * span * n + 2.0 * pivmin);
+      mt.span = span;
+      mt.sh = sh;
+    }
+    meta[k] = mt;
+  }
+  co.sync();
+  // ---- C: scale (exact) and square the couplings, floored as coop_tridiag_eigvals floors them
+  for (int item = co.tid; item < kNEigen * m; item += co.nt) {
+    const int k = item / m, i = item % m;
+    if (!meta[k].active || i >= meta[k].n) continue;
+    double* td = vec + (size_t)k * 3 * m;
+    double* te = td + m;
+    td[i] = ldexp(td[i], -meta[k].sh);
+    if (i < meta[k].n - 1) {
+      const double es = ldexp(te[i], -meta[k].sh);
+      te[i] = fmax(es * es, 0x1p-200);
+    }
+  }
+  co.sync();
+  // ---- D: the (problem, eigenvalue) tasks, strided over the lanes
+  int off[kNEigen + 1];
+  off[0] = 0;
+  for (int k = 0; k < kNEigen; ++k) off[k + 1] = off[k] + (meta[k].active ? meta[k].n : 0);
+  for (int t = co.tid; t < off[kNEigen]; t += co.nt) {
+    int k = 0;
+    while (t >= off[k + 1]) ++k;
+    const int idx = t - off[k];
+    const double* d = vec + (size_t)k * 3 * m;
+    double* ev = vec + (size_t)k * 3 * m + 2 * m;
+    ev[idx] = ldexp(sturm_eigenvalue(d, d + m, meta[k].n, idx, meta[k].lo, meta[k].hi, meta[k].span, pivmin), meta[k].sh);
+  }
+  co.sync();
+  // ---- E: per problem, one thread: the reference's filters and moments (the kept values overwrite the problem's d)
+  for (int k = co.tid; k < kNEigen; k += co.nt) {
+    if (k == 12 ? !(tests & RVT_TEST_SKAT) : !(tests & RVT_TEST_SKATO)) continue;
+    if (!meta[k].active) {
+      out->eig_ok[k] = 0;  // (k == 11 with 1'A1 <= 0)
+      continue;
+    }
+    const int n = meta[k].n;
+    const double* ev = vec + (size_t)k * 3 * m + 2 * m;
+    double* tmpv = vec + (size_t)k * 3 * m;
+    if (k == 12) {
+      double* lam_skat = lambda_out;
+      const int r_ub = (nc.N < (int64_t)m) ? (int)nc.N : m;
+      int r = 0;
+      for (int i = n - 1; i >= 0; --i) {
+        if (ev[i] > 1e-30 && r < r_ub) {
+          lam_skat[r++] = ev[i];
+        } else
+          break;
+      }
+      out->skat_nlambda = r;
+      out->eig_ok[12] = 1;
+    } else if (k == 11) {
+      double* lam_zimz = lambda_out + M;
+      const int nk = skato_filter_eigen(ev, n, lam_zimz);
+      if (nk < 0) {
+        out->eig_ok[11] = 0;
+      } else {
+        out->zimz_nlambda = nk;
+        double ls = 0, l2 = 0, l4 = 0;
+        for (int i = 0; i < nk; ++i) {
+          const double l = lam_zimz[i];
+          ls += l;
+          l2 += l * l;
+          l4 += l * l * l * l;
+        }
+        out->zimz_lambda_sum = ls;
+        out->muQ = ls;
+        out->varQ = 2.0 * l2 + out->varZeta;
+        const double KerQ = l4 / l2 / l2 * 12;
+        out->df = 12 / KerQ;
+        out->eig_ok[11] = 1;
+      }
+    } else {
+      const int nk = skato_filter_eigen(ev, n, tmpv);
+      if (nk < 0) {
+        out->eig_ok[k] = 0;
+      } else {
+        const SkatoMoment mo = skato_moment(tmpv, nk);
+        out->mom_mu[k] = mo.muQ;
+        out->mom_var[k] = mo.varQ;
+        out->mom_df[k] = mo.df;
+        out->eig_ok[k] = 1;
+      }
+    }
+  }
+  co.sync();
+}
+
 // did SkatO::Fit succeed?  (every getEigen found a positive eigenvalue)
 RVT_HD bool skato_fit_ok(const GeneStats& gs) {
   if (!gs.skato_ok || gs.n_poly == 0) return false;

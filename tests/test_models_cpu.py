@@ -119,3 +119,31 @@ def test_data_consolidator_semantics():
     cz = orc.collapse(Gf, 1)
     # (int) truncation: 0.9 -> 0 does not count, 1.7 -> 1 counts
     assert cz[0] == 0 + 0 + 0 and cz[2] == 0 + 0 + 1
+
+
+def test_spectrum_all_in_one_workgroup_equals_the_per_problem_form(monkeypatch):
+    """rvt_gene.h gene_spectrum_all (round 5: the 13 eigenproblems of a gene as one list of (problem, eigenvalue) tasks) against
+    gene_spectrum (one problem at a time): the same eigenvalues bit for bit, hence the same records — unweighted and binary,
+    SKAT sharing SKAT-O's weights or not, a monomorphic column, M = 1 and M = 2."""
+    import hc
+    import synth
+    rng = np.random.default_rng(77)
+    for case, (N, M, binary, b2) in enumerate(((600, 1, 0, 25.0), (600, 2, 0, 25.0), (900, 17, 0, 25.0), (900, 40, 1, 25.0),
+                                              (700, 33, 0, 10.0), (500, 64, 0, 25.0))):
+        Graw, G, af = synth.make_gene(N, M, seed=300 + case, missing=0.01 if case % 2 else 0.0, mono=(M > 4))
+        X, y, res, v, s2 = synth.make_null(N, 3, binary, seed=40 + case)
+        prm = hc.default_params()
+        prm.skat_beta2 = b2                                  # != SKAT-O's 25: SKAT gets a tridiagonal of its own
+        recs = []
+        for form in ("all", "per_problem"):
+            if form == "per_problem":
+                monkeypatch.setenv("RVT_SPECTRUM_PER_PROBLEM", "1")
+            else:
+                monkeypatch.delenv("RVT_SPECTRUM_PER_PROBLEM", raising=False)
+            r, flip, kept, lam = hc.gene(G, af, X, res, v, binary, s2, params=prm)
+            recs.append((r.skat_p, r.skato_p, r.skat_Q, r.skato_Q, r.skato_rho, r.skat_nlambda, tuple(lam)))
+        monkeypatch.delenv("RVT_SPECTRUM_PER_PROBLEM", raising=False)
+        a, b = recs
+        for x, y_ in zip(a[:6], b[:6]):
+            assert x == y_ or (x != x and y_ != y_), (case, a[:6], b[:6])
+        assert a[6] == b[6], case

@@ -18,13 +18,13 @@ stats famskat python3 tools/bench_famskat.py --samples 100000 --genes 128
 stats famskat_dense python3 tools/bench_famskat.py --samples 100000 --genes 128 --dense
 stats famskat_shuffled python3 tools/bench_famskat.py --samples 100000 --genes 128 --shuffle
 stats metascore python3 tools/bench_metascore.py
-stats metacov python3 tools/bench_metacov.py --reps 5
+tools/collect_profiles_metacov.sh "$TAG" > "$OUT/collect_metacov.log" 2>&1
 stats perm python3 tools/bench_perm.py --genes 4
 stats stream_bed python3 tools/bench_stream.py --bed --genes 512
 python3 tools/bench_decompose.py --samples 3000 --kind grm > "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 12000 --kind family >> "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 100000 --kind family --install >> "$OUT/decompose.txt" 2>&1
-for t in k2hc_bench k2hcw_bench k2lat_bench rotgemm_bench; do  # micro-benchmarks: built here when the snapshot has no binary
+for t in k2hc_bench k2hcw_bench k2lat_bench rotgemm_bench gemm64_bench; do  # micro-benchmarks: built here when the snapshot has no binary
   [ -x tools/$t ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/$t.hip -o tools/$t > "$OUT/build_$t.log" 2>&1
 done
 ./tools/k2hc_bench bench > "$OUT/k2hc_isolated.txt" 2>&1
@@ -33,6 +33,13 @@ done
 ./tools/k2lat_bench > "$OUT/k2lat_isolated.txt" 2>&1
 ./tools/k2lat_bench spread >> "$OUT/k2lat_isolated.txt" 2>&1
 ./tools/rotgemm_bench bench > "$OUT/rotgemm.txt" 2>&1
+./tools/gemm64_bench check > "$OUT/gemm64.txt" 2>&1
+./tools/gemm64_bench bench 500000 1024 >> "$OUT/gemm64.txt" 2>&1
+./tools/gemm64_bench bench 500000 512 >> "$OUT/gemm64.txt" 2>&1
+./tools/gemm64_bench bench 200000 2048 >> "$OUT/gemm64.txt" 2>&1
+# the per-gene stages on one isolated batch: cycle counters of the profiling build and SQ counters (tools/probe.sh)
+tools/probe.sh pvprof 200000 512 > "$OUT/pvprof.txt" 2>&1
+tools/probe.sh pvpmc 200000 512 > "$OUT/pmc_sq_pvalue.csv" 2>&1
 python3 tools/bench_perm.py --genes 8 > "$OUT/perm_result.txt" 2>&1
 python3 tools/bench_perm.py --genes 2 --alpha 1 --nperm 16384 >> "$OUT/perm_result.txt" 2>&1
 python3 tools/bench_perm.py --genes 1 --exact >> "$OUT/perm_result.txt" 2>&1

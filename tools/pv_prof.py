@@ -46,9 +46,12 @@ def main():
     f = lambda name: np.array([getattr(r, name) for r in out])
     tot, dav, post, neval = f("zeg_U"), f("cmc_U"), f("cmc_V"), f("zeg_V")
     front, main, book, pre = f("famcmc_U"), f("famcmc_V"), f("famzeg_U"), f("famzeg_V")
+    pre_a, pre_b, pre_c, pre_d = f("famskat_Q"), f("famskat_p"), f("famcmc_af"), f("famzeg_af")
     print("batch of %d genes: wall %.2f ms; pvalue kernel %.2f ms" % (a.genes, wall * 1e3, tm.ms_pvalue))
     for name, v in (("total QAGS loop", tot), ("  davies rounds", dav), ("    front", front), ("    main", main),
-                    ("  post (Liu, density)", post), ("  lane-0 bookkeeping", book), ("before the loop", pre)):
+                    ("  post (Liu, density)", post), ("  lane-0 bookkeeping", book), ("before the loop", pre),
+                    ("  loads, sorted copies", pre_a), ("  per-rho tails", pre_b), ("  quantiles, Liu moments", pre_c),
+                    ("  the two preludes", pre_d)):
         print("%-24s mean %10.0f  max %10.0f  cycles   (%.2f / %.2f ms at 2.1 GHz)" % (name, v.mean(), v.max(),
                                                                                      v.mean() / 2.1e6, v.max() / 2.1e6))
     print("neval mean %.0f max %.0f; davies terms mean %.0f" % (neval.mean(), neval.max(), f("davies_terms").mean()))
