@@ -439,7 +439,11 @@ int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* a
  * matrix as KinshipHolder::load fills it (column-major, symmetric), S_out (N) receives the eigenvalues in ASCENDING order
  * and U_out (N x N, column-major) the eigenvectors, as matS / matU hold them (either may be NULL).  install != 0 also
  * installs the decomposition for the family tests (as rvt_set_kinship would) without a round trip through host
- * memory.  fp64 one-sided block Jacobi (rvtests_amd/csrc/jacobi_kernels.hip.h); device memory 16 N^2 bytes while it runs.
+ * memory.  A dense matrix of 128 <= N <= 48 000 whose eigenvalues are simple (no two closer than 1e-7 of the spectrum's
+ * width: a genetic relationship matrix) takes Householder tridiagonalisation + Sturm bisection + inverse iteration + the
+ * matrix-core back-transformation (rvtests_amd/csrc/tridiag_kernels.hip.h; 40 N^2 bytes of device memory; sweeps = 0 in the
+ * info), closed by a check of max |K u - lambda u| and |U'U - I| on the device; anything else — repeated eigenvalues, a failed
+ * check, RVT_KINSHIP_JACOBI=1 — the fp64 one-sided block Jacobi iteration (rvtests_amd/csrc/jacobi_kernels.hip.h; 16 N^2 bytes).
  * Eigenvectors of repeated eigenvalues are an arbitrary orthonormal basis of their eigenspace — exactly as for any
  * eigensolver; every statistic of the family tests depends on U only through U f(S) U'. *
  * A kinship of separate families (the connected components of its sparsity pattern, in any sample order), none larger
@@ -447,7 +451,7 @@ int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* a
  * 64 x 64 tiles for the same Jacobi kernel; sweeps = 0 in the info): 1.7 s including the installation at N = 100 000,
  * where the dense iteration would need 200 GB and minutes.  RVT_KINSHIP_DENSE=1 forces the dense iteration. */
 typedef struct rvt_decompose_info {
-  int sweeps;            /* block-Jacobi sweeps */
+  int sweeps;            /* block-Jacobi sweeps (0: decomposed family by family, or through the tridiagonal form) */
   double max_cosine;     /* largest cosine between two columns of K U in the last sweep (convergence: < 1e-10) */
   int64_t padded_order;  /* order of the padded problem (multiple of 64) */
   double shift;          /* 0, or the diagonal shift of the second attempt (taken when a residual of the first was large:

@@ -2,6 +2,7 @@
 // exact integer rotation G~ = U'G (rot_gemm.hip.h), the FastLMM null model, FamSKAT / the family burden tests / the family
 // forms of MetaCov and MetaScore.  Part of librvtests_amd.so; the per-gene pipeline behind it is rvt_engine.hip's.
 #include "rvt_engine_int.h"
+#include "tridiag_kernels.hip.h"
 
 extern "C" {
 
@@ -355,6 +356,196 @@ static int decompose_by_family(rvt_ctx* c, int64_t N, const float* K,
   return RVT_OK;
 }
 
+// ---- dense kinship: tridiagonalisation + bisection + inverse iteration (tridiag_kernels.hip.h) ------------------------------
+// *done = true when U and S were produced AND passed the closing check (residual, orthogonality); false (and RVT_OK) when the
+// matrix has eigenvalues closer than the inverse iteration separates, or the check failed: the caller then runs the Jacobi
+// iteration.  mu: 4 x the largest absolute row sum (a bound on 4 x the spectral radius).
+static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double mu, float* U_out, float* S_out, int install,
+                                   rvt_decompose_info* info, bool* done) {
+  *done = false;
+  hipStream_t st = c->stream;
+  const bool trace = getenv("RVT_TRIDIAG_TRACE") != nullptr;
+  const double t_start = now_s();
+  const int n = (int)N;
+  const int64_t ld = (N + 63) / 64 * 64;
+  struct Bufs {
+    float* dK = nullptr;
+    float* dU = nullptr;
+    double *A = nullptr, *B1 = nullptr, *B2 = nullptr, *B3 = nullptr, *B4 = nullptr, *W = nullptr, *vec = nullptr, *cz = nullptr,
+           *yy = nullptr;
+    unsigned long long* worst = nullptr;
+    ~Bufs() {
+      for (void* p : {(void*)dK, (void*)dU, (void*)A, (void*)B1, (void*)B2, (void*)B3, (void*)B4, (void*)W, (void*)vec, (void*)cz,
+                      (void*)yy, (void*)worst})
+        if (p) hipFree(p);
+    }
+  } b;
+  const size_t mat = sizeof(double) * (size_t)ld * (size_t)N;
+  HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
+  HIP_TRY(c, hipMalloc((void**)&b.A, mat));
+  HIP_TRY(c, hipMalloc((void**)&b.W, sizeof(double) * (size_t)ld * kTdNb));
+  // vec: d | e | tau | y | t12 (2 kTdNb) | partial dots (1024) | scaled d | scaled e^2 | lambda
+  const int64_t vs = std::max<int64_t>(ld, 1024);  // (y doubles as the panel's Gram matrix later)
+  const size_t nv = 7 * (size_t)vs + 2 * kTdNb + 1024;
+  HIP_TRY(c, hipMalloc((void**)&b.vec, sizeof(double) * nv));
+  HIP_TRY(c, hipMemsetAsync(b.vec, 0, sizeof(double) * nv, st));
+  HIP_TRY(c, hipMemsetAsync(b.W, 0, sizeof(double) * (size_t)ld * kTdNb, st));
+  double *d_d = b.vec, *d_e = d_d + vs, *d_tau = d_e + vs, *d_y = d_tau + vs, *d_t12 = d_y + vs, *d_part = d_t12 + 2 * kTdNb,
+         *d_ds = d_part + 1024, *d_e2s = d_ds + vs, *d_lam = d_e2s + vs;
+  HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.A);
+  // 1. K = Q T Q'
+  const int comb_blocks = (int)std::min<int64_t>(1024, (N + 255) / 256);
+  for (int j0 = 0; j0 < n; j0 += kTdNb) {
+    const int j1 = std::min(n, j0 + kTdNb);
+    for (int j = j0; j < j1; ++j) {
+      hipLaunchKernelGGL(td_col_house_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W, d_d, d_e,
+                         d_tau);
+      if (j + 1 >= n) continue;
+      const int i = j - j0;
+      hipLaunchKernelGGL(td_dots_kernel, dim3((unsigned)(n - j - 1 + 2 * i)), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j,
+                         j0, b.W, d_y, d_t12);
+      hipLaunchKernelGGL(td_w_comb_kernel, dim3((unsigned)comb_blocks), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0,
+                         b.W, d_y, d_t12, d_tau, d_part);
+      hipLaunchKernelGGL(td_w_final_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W, d_tau, d_part,
+                         comb_blocks);
+    }
+    if (j1 < n) {
+      const unsigned tiles = (unsigned)((n - j1 + 63) / 64);
+      hipLaunchKernelGGL(td_rank2k_kernel, dim3(tiles, tiles), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j0, j1, b.W);
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> hd((size_t)N), he((size_t)N, 0.0);
+  HIP_TRY(c, hipMemcpyAsync(hd.data(), d_d, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(he.data(), d_e, sizeof(double) * (size_t)(N - 1), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  hipFree(b.dK);
+  b.dK = nullptr;
+  const double t_tri = now_s();
+  // 2. eigenvalues of T (scaled as coop_tridiag_eigvals scales: Gershgorin span into [1/2, 1), squares floored)
+  double lo = hd[0], hi = hd[0];
+  for (int64_t j = 0; j < N; ++j) {
+    if (!std::isfinite(hd[j]) || !std::isfinite(he[j])) return RVT_OK;  // (the Jacobi iteration reports what is wrong)
+    const double r = (j > 0 ? std::fabs(he[j - 1]) : 0.0) + (j < N - 1 ? std::fabs(he[j]) : 0.0);
+    lo = std::min(lo, hd[j] - r);
+    hi = std::max(hi, hd[j] + r);
+  }
+  const double span0 = std::max(std::fabs(lo), std::fabs(hi));
+  if (!(span0 > 0.0)) return RVT_OK;
+  int sh = 0;
+  (void)std::frexp(span0, &sh);
+  {
+    std::vector<double> ds((size_t)N), e2s((size_t)N, 0.0);
+    for (int64_t j = 0; j < N; ++j) {
+      ds[j] = std::ldexp(hd[j], -sh);
+      if (j < N - 1) {
+        const double es = std::ldexp(he[j], -sh);
+        e2s[j] = std::max(es * es, 0x1p-200);
+      }
+    }
+    HIP_TRY(c, hipMemcpyAsync(d_ds, ds.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_e2s, e2s.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, sync_stream(st));
+  }
+  const double slo = std::ldexp(lo, -sh), shi = std::ldexp(hi, -sh), span = std::max(std::fabs(slo), std::fabs(shi));
+  const double pivmin = DBL_MIN * 1024.0, slack = 2.0 * kDblEps * span * (double)N + 2.0 * pivmin;
+  hipLaunchKernelGGL(td_eigvals_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, d_ds, d_e2s, n, slo - slack, shi + slack,
+                     span, sh, d_lam);
+  std::vector<double> lam((size_t)N);
+  HIP_TRY(c, hipMemcpyAsync(lam.data(), d_lam, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  const double t_eig = now_s();
+  // gaps: the inverse iteration is not reorthogonalised
+  double min_gap = span0;
+  for (int64_t j = 1; j < N; ++j) min_gap = std::min(min_gap, lam[j] - lam[j - 1]);
+  if (trace) fprintf(stderr, "[rvt] tridiag: N %lld, reduction %.3f s, eigenvalues %.3f s, smallest gap %.3g of %.3g\n", (long long)N,
+                     t_tri - t_start, t_eig - t_tri, min_gap, span0);
+  if (!(min_gap > 1e-7 * span0)) return RVT_OK;
+  // 3. eigenvectors of T
+  HIP_TRY(c, hipMalloc((void**)&b.B1, mat));
+  HIP_TRY(c, hipMalloc((void**)&b.B2, mat));
+  HIP_TRY(c, hipMalloc((void**)&b.B3, mat));
+  HIP_TRY(c, hipMalloc((void**)&b.B4, mat));
+  hipLaunchKernelGGL(td_invit_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, d_d, d_e, n, d_lam, (long long)ld,
+                     kDblEps * span0, b.B2, b.B3, b.B4, b.B1);
+  HIP_TRY(c, hipMemsetAsync(b.B2, 0, mat, st));  // (behind the kernel in the stream)
+  {
+    const unsigned t32 = (unsigned)((N + 31) / 32);
+    hipLaunchKernelGGL(td_transpose_kernel, dim3(t32, t32), dim3(256), 0, st, b.B1, (long long)ld, n, (long long)ld, b.B2);
+  }
+  double* Z = b.B2;
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sync_stream(st));
+  const double t_vec = now_s();
+  // 4. U = Q Z, the panels in reverse order
+  HIP_TRY(c, hipMalloc((void**)&b.cz, sizeof(double) * (size_t)ld * kTdNb));
+  HIP_TRY(c, hipMalloc((void**)&b.yy, sizeof(double) * (size_t)ld * kTdNb));
+  double *d_tp = d_part, *d_gram = d_y;  // kTdNb^2 = 1024 doubles each
+  for (int j0 = ((n - 1) / kTdNb) * kTdNb; j0 >= 0; j0 -= kTdNb) {
+    const int nbp = std::min(n, j0 + kTdNb) - j0;
+    hipLaunchKernelGGL(td_gram_kernel, dim3((unsigned)nbp, (unsigned)nbp), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j0,
+                       d_gram);
+    hipLaunchKernelGGL(td_larft_kernel, dim3(1), dim3(64), 0, st, d_gram, j0, nbp, d_tau, d_tp);
+    int rc = gemm_tn_f64(c, Z, ld, n, b.A + (size_t)j0 * ld, ld, nbp, nullptr, 0, 0, nullptr, ld, b.cz, ld, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(td_apply_t_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.cz, (long long)ld, n, nbp, d_tp,
+                       b.yy);
+    const unsigned tiles = (unsigned)((N + 63) / 64);
+    hipLaunchKernelGGL(td_update_z_kernel, dim3(tiles, tiles), dim3(256), 0, st, Z, (long long)N, (long long)ld, b.A, j0, nbp, b.yy,
+                       (long long)ld);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sync_stream(st));
+  const double t_back = now_s();
+  // 5. the closing check: max |K u - lambda u|, max |U'U - I|, in column batches (the product's K slices need room)
+  HIP_TRY(c, hipMalloc((void**)&b.worst, 2 * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemsetAsync(b.worst, 0, 2 * sizeof(unsigned long long), st));
+  HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
+  HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.B1);
+  constexpr int kBatch = 1024;
+  for (int k0 = 0; k0 < n; k0 += kBatch) {
+    const int nk = std::min(kBatch, n - k0);
+    int rc = gemm_tn_f64(c, b.B1, ld, n, Z + (size_t)k0 * ld, ld, nk, nullptr, 0, 0, nullptr, ld, b.B3, ld, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(td_residual_kernel, dim3((unsigned)nk), dim3(256), 0, st, b.B3, (long long)ld, Z + (size_t)k0 * ld,
+                       (long long)ld, n, d_lam + k0, b.worst);
+    rc = gemm_tn_f64(c, Z, ld, n, Z + (size_t)k0 * ld, ld, nk, nullptr, 0, 0, nullptr, ld, b.B3, ld, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(td_orth_kernel, dim3((unsigned)nk), dim3(256), 0, st, b.B3, (long long)ld, n, k0, b.worst);
+  }
+  unsigned long long bits[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(bits, b.worst, sizeof(bits), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  double resid, orth;
+  std::memcpy(&resid, &bits[0], 8);
+  std::memcpy(&orth, &bits[1], 8);
+  const double t_chk = now_s();
+  if (trace)
+    fprintf(stderr, "[rvt] tridiag: vectors %.3f s, back-transformation %.3f s, check %.3f s: residual %.3g (scale %.3g), |U'U - I| %.3g\n",
+            t_vec - t_eig, t_back - t_vec, t_chk - t_back, resid, span0, orth);
+  if (!(resid <= 1e-9 * mu) || !(orth <= 1e-7)) return RVT_OK;  // (mu = 4 x a bound on the spectral radius; Jacobi's own bar)
+  std::vector<float> S((size_t)N);
+  for (int64_t j = 0; j < N; ++j) S[j] = (float)lam[j];
+  HIP_TRY(c, hipMalloc((void**)&b.dU, sizeof(float) * (size_t)N * (size_t)N));
+  hipLaunchKernelGGL(td_to_float_kernel, dim3(4096), dim3(256), 0, st, Z, (long long)ld, (long long)N, b.dU);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sync_stream(st));
+  if (U_out) HIP_TRY(c, hipMemcpy(U_out, b.dU, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyDeviceToHost));
+  if (S_out) std::memcpy(S_out, S.data(), sizeof(float) * (size_t)N);
+  if (info) {
+    info->sweeps = 0;  // no Jacobi sweeps
+    info->max_cosine = 0.0;
+    info->padded_order = ld;
+    info->shift = 0.0;
+    info->max_residual = resid;
+  }
+  *done = true;
+  if (install) return rvt_set_kinship(c, N, b.dU, S.data());
+  return RVT_OK;
+}
+
 // ---- KinshipHolder::decompose on the device (jacobi_kernels.hip.h) ---------------------------------------------------------
 int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, float* S_out, int install,
                           rvt_decompose_info* info) {
@@ -421,6 +612,13 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
   if (!getenv("RVT_KINSHIP_DENSE")) {  // a block-diagonal (pedigree) kinship is decomposed family by family
     bool done = false;
     if (sparse_pattern) rc = decompose_by_family(c, N, K, edges, mu, np, U_out, S_out, install, info, &done);
+    if (rc || done) return rc;
+  }
+  // a dense matrix of a size whose five N x N fp64 work areas fit: tridiagonalisation + bisection + inverse iteration;
+  // repeated eigenvalues (and anything that fails its closing check) fall through to the Jacobi iteration
+  if (!getenv("RVT_KINSHIP_JACOBI") && N >= 128 && N <= 48000) {
+    bool done = false;
+    rc = decompose_dense_tridiag(c, N, K, mu, U_out, S_out, install, info, &done);
     if (rc || done) return rc;
   }
   struct Bufs {

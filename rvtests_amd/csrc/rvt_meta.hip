@@ -3,7 +3,7 @@
 #include "rvt_engine_int.h"
 #include "gemm_f64.hip.h"
 
-namespace {
+extern "C" {
 // C (M x (Nb + Nb2), column-major, leading dimension ldc) = A' D [B | B2] in fp64 on the matrix cores (gemm_f64.hip.h).
 // A: M columns (lda apart), B: Nb columns, B2: Nb2 further columns (the null-model columns), all N samples long and
 // zero-padded to a multiple of 16; w: optional weights along the samples (D = diag(w)), else D = I.
@@ -45,7 +45,7 @@ int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B
   HIP_TRY(c, hipGetLastError());
   return RVT_OK;
 }
-}  // namespace
+}
 
 extern "C" {
 

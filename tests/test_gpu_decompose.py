@@ -50,8 +50,14 @@ def test_family_kinship(eng, n_fam):
         assert eng.kinship_structure() < 0.35
 
 
+@pytest.mark.parametrize("solver", ["default", "jacobi"])
 @pytest.mark.parametrize("N,kind", [(300, "psd"), (1000, "grm"), (257, "indefinite"), (130, "opposite")])
-def test_dense_matrices(eng, N, kind):
+def test_dense_matrices(eng, N, kind, solver, monkeypatch):
+    """Dense matrices take the tridiagonalisation + bisection + inverse iteration (sweeps = 0) unless eigenvalues repeat
+    (the rank-deficient matrix: its null space goes to the Jacobi iteration); RVT_KINSHIP_JACOBI=1 keeps them all on the
+    Jacobi iteration."""
+    if solver == "jacobi":
+        monkeypatch.setenv("RVT_KINSHIP_JACOBI", "1")
     rng = np.random.default_rng(N)
     if kind == "grm":                                            # genetic relationship matrix Z Z' / m: PSD, dense, full rank
         Z = rng.standard_normal((N, 3 * N))
@@ -71,8 +77,12 @@ def test_dense_matrices(eng, N, kind):
     _check(K32.astype(np.float32), U, S, info)
     if kind in ("psd", "grm"):
         assert info.shift == 0.0
-    if kind == "opposite":
-        assert info.shift > 0.0
+    if solver == "jacobi" or kind == "psd":
+        assert info.sweeps > 0
+        if kind == "opposite":
+            assert info.shift > 0.0
+    else:
+        assert info.sweeps == 0 and info.shift == 0.0 and info.max_residual <= 1e-12 * np.abs(S).max() * N
     if kind == "grm":                                            # simple spectrum: eigenvectors themselves, up to sign
         w, V = np.linalg.eigh(K32.astype(np.float64))
         gaps = np.minimum(np.diff(w, prepend=-np.inf), np.diff(w, append=np.inf))
