@@ -669,7 +669,14 @@ bool host_registered(const rvt_ctx* c, const void* src, size_t bytes) {
 // point returns (the caller may overwrite its buffer then)
 static int reg_mark(rvt_ctx* c) {
   if (!c->ev_reg) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_reg, hipEventDisableTiming));
+  // one event stands for every copy marked so far only while they all went to ONE stream (a deferred wait, rvt_submit_genes,
+  // marks once per gene): a copy on another stream first waits out what is pending
+  if (c->reg_pending && c->reg_stream != c->h2d_stream) {
+    const int rc = reg_wait(c);
+    if (rc) return rc;
+  }
   HIP_TRY(c, hipEventRecord(c->ev_reg, c->h2d_stream));
+  c->reg_stream = c->h2d_stream;
   c->reg_pending = true;
   return RVT_OK;
 }

@@ -298,6 +298,7 @@ struct rvt_ctx {
   std::vector<std::pair<const char*, size_t>> host_reg;
   std::vector<char> host_reg_owned;  // (1: this context called hipHostRegister; 0: adopted from another member of a group)
   hipEvent_t ev_reg = nullptr;
+  hipStream_t reg_stream = nullptr;  // the stream ev_reg was last recorded on
   bool reg_pending = false;
   int lattice_den = 0;        // rvt_set_dosage_lattice: dosage doubles are multiples of 1 / lattice_den (0: not stated)
   int* d_kind = nullptr;      // device flag of rvt_block_classify (a stateless query)

@@ -316,7 +316,11 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
     {
       const dim3 grid((unsigned)wgs, (unsigned)slices);
-      if (dmax == 4)
+      static const bool split_loads = getenv("RVT_COV_PREP_SPLIT") != nullptr;  // (A/B probe of the load pattern)
+      if (dmax == 4 && split_loads)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<4, true, true>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
+                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, nullptr);
+      else if (dmax == 4)
         hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
                            (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
       else if (dmax == 8)

@@ -716,7 +716,10 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       const size_t cb = (size_t)((N + 3) / 4);
       const int ek = c->pack_next;
       c->pack_next = (ek + 1) % rvt_ctx::kPack;
-      // (the pad bytes of a row read as zeros: cleared once, when the block is allocated — the copies never write them)
+      // The pad bytes of a row read as zeros.  Invariant: a block is cleared once, when it is allocated, and the pool hands a
+      // block out again only for the same (N, M) — the same pk_pitch — so a later gene's rows land on the same offsets; the
+      // staged copy (pad_zero) writes zeros into the pads BETWEEN rows of a chunk and nothing into the pad behind a chunk's last
+      // row, which therefore still holds the allocation's zeros.
       if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
       if (e == hipSuccess) {
         c->h2d_stream = c->copy_stream;

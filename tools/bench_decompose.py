@@ -47,10 +47,23 @@ res = np.abs(K.astype(np.float64) @ Ud - Ud * S[idx].astype(np.float64)).max()
 # Jacobi: 12 n^3 per sweep; through the tridiagonal form: 4/3 n^3 (reduction) + 2 n^3 (back-transformation) + 4 n^3 (check)
 flops = 12.0 * info.padded_order ** 3 * info.sweeps if info.sweeps else (4.0 / 3 + 2 + 4) * float(N) ** 3
 w = np.linalg.eigvalsh(K.astype(np.float64)) if N <= 16000 else None
+# CPU baseline: what KinshipHolder::decompose does on the host — a dense symmetric eigensolver on the FLOAT matrix (Eigen's
+# SelfAdjointEigenSolver<MatrixXf> there, LAPACK's ssyevd through numpy here), bounded to n = 4000 and scaled by N^3
+nb = min(N, 4000)
+t1 = time.perf_counter()
+np.linalg.eigh(np.ascontiguousarray(K[:nb, :nb]))
+tb = time.perf_counter() - t1
+try:
+    from threadpoolctl import threadpool_info
+    thr = max([p_.get("num_threads", 1) for p_ in threadpool_info()] or [1])
+except Exception:
+    thr = None
+cpu = {"value": tb * (N / nb) ** 3, "unit": "s per decomposition at N=%d" % N, "cores": thr, "kind": "port",
+       "sample": "numpy.linalg.eigh (ssyevd) of the leading %d x %d float block: %.2f s, scaled by (N / %d)^3" % (nb, nb, tb, nb)}
 print(json.dumps({"N": N, "kind": args.kind, "seconds": dt, "sweeps": info.sweeps,
                   "solver": "jacobi" if info.sweeps else "tridiagonal form",
                   "eigenvalues_vs_lapack_max_abs": None if w is None else float(np.abs(w - S).max()),
                   "orthogonality_sample_max_abs": float(np.abs(Ud.T @ Ud - np.eye(16)).max()), "max_cosine": info.max_cosine,
                   "shift": info.shift, "residual_max_abs": res, "lambda_min": float(S[0]), "lambda_max": float(S[-1]),
-                  "fp64_TFLOPs_nominal": flops / dt / 1e12}))
+                  "fp64_TFLOPs_nominal": flops / dt / 1e12, "cpu_baseline": cpu}))
 eng.close()
