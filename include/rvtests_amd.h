@@ -52,7 +52,9 @@ extern "C" {
 #define RVT_E_TOO_LARGE (-5) /* gene wider than RVT_MAX_VARIANTS */
 
 #define RVT_MAX_VARIANTS 1024
+#ifndef RVT_MAX_INFLIGHT
 #define RVT_MAX_INFLIGHT 8 /* batches that rvt_run_blocks_async keeps in flight */
+#endif
 
 /* test selection bitmask (which ModelFitter::fit bodies to run) */
 #define RVT_TEST_SKAT 1u    /* --kernel skat   : SkatTest    src/Model.h:2612-2772 */

@@ -858,14 +858,36 @@ int MetaCovTest::fit(GeneData* dc) {
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;
+    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB): 24 000 columns at N = 500 000
+    {
+      double gb = 96.0;
+      if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
+      const double cols = gb * 1e9 / (8.0 * (double)std::max<int64_t>(dc->N, 1));
+      if (cols < (double)maxColumns) maxColumns = std::max(capacity, (int)cols);
+    }
+    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB): 24 000 columns at N = 500 000
+    {
+      double gb = 96.0;
+      if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
+      const double cols = gb * 1e9 / (8.0 * (double)std::max<int64_t>(dc->N, 1));
+      if (cols < (double)maxColumns) maxColumns = std::max(capacity, (int)cols);
+    }
     if (rvt_block_alloc(ctx, capacity, &block)) {
       lastError = rvt_last_error(ctx);
       return -1;
     }
   }
   if ((int)sites.size() == capacity) {
+    const int before = (int)sites.size();
     if (flush(false)) return -1;
-    if ((int)sites.size() == capacity && grow()) return -1;  // one window holds more sites than the ring: enlarge it
+    // One window holds more sites than the ring: enlarge it.  Round 5: ALSO when the flush could emit less than half of the
+    // ring — a window of 1 000 markers in a ring of 1 024 recomputed 1 000 columns to write 24 rows (4 400 variants/s at
+    // N = 500 000, tools/bench_metacov.py); with a ring of at least twice the window every flush emits half of what it reads.
+    const bool full = (int)sites.size() == capacity;
+    if (full || 2 * (before - (int)sites.size()) < before) {
+      if (grow() && full) return -1;
+      if (!full) lastError.clear();  // (a ring that cannot grow any further just stays as efficient as it was)
+    }
   }
   // the caller overwrites the genotype buffer for the next site: copy the column into the device ring now
   if (rvt_block_upload_columns(ctx, block, (int)sites.size(), 1, dc->genotype)) {
@@ -972,7 +994,9 @@ int MetaCovTest::flush(bool final) {
     }
   } else {
     // wide windows: chunks of heads against everything up to the end of the last head's window
-    const int Hc = std::min(256, rectAbove);
+    // (every call runs the column pass over its W = heads + window columns: 1 024 heads per call read a window of 1 000
+    //  markers twice, 256 heads read it five times)
+    const int Hc = std::min(1024, rectAbove);
     for (int h0 = 0; h0 < H; h0 += Hc) {
       const int h1 = std::min(H, h0 + Hc);
       int jmax = h1 - 1;

@@ -1088,7 +1088,7 @@ static __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts
 // PACK = false (round 5): the same pass for blocks that are NOT hard calls (the fp64 band, gemm_f64.hip.h) — no int8 copy,
 // no content test, and optional weights wts (a binary trait's p(1 - p)): T = G' diag(wts) X.
 constexpr int kCovHcCols = 4;
-template <int DMAX, bool PACK = true, bool SPLIT = false>
+template <int DMAX, bool PACK = true>
 __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restrict__ G, long long N, long long ld, int W,
                                                           const double* __restrict__ X, long long ldx, int d,
                                                           signed char* __restrict__ out8, long long ldk,
@@ -1111,21 +1111,13 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) t[c][k] = 0.0;
   }
-  // SPLIT: the two 16-byte loads of a lane are 128 samples apart, so that each wave instruction reads 1 KB in one piece
-  // (a lane's samples: ia, ia + 1, ia + 128, ia + 129; a wave covers 256 consecutive samples either way)
-  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-  const long long first = SPLIT ? i0 + 256 * (long long)wave_ + 2 * lane_ : i0 + 4 * (long long)threadIdx.x;
-  constexpr int kGap = SPLIT ? 128 : 2;
-  for (long long i = first; SPLIT ? (i - 2 * lane_ < i1) : (i < i1); i += 1024) {
+  for (long long i = i0 + 4 * (long long)threadIdx.x; i < i1; i += 1024) {
     double x[DMAX][4];
-    // (SPLIT: a lane's pairs may start behind the slice — and behind the column's pad rows: not read, zero)
-    const bool va = !SPLIT || i < i1, vb = !SPLIT || i + kGap < i1;
-    const double2 zero2 = {0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) {
       if (k < d) {
-        const double2 a = va ? *reinterpret_cast<const double2*>(X + (long long)k * ldx + i) : zero2;
-        const double2 b = vb ? *reinterpret_cast<const double2*>(X + (long long)k * ldx + i + kGap) : zero2;
+        const double2 a = *reinterpret_cast<const double2*>(X + (long long)k * ldx + i);
+        const double2 b = *reinterpret_cast<const double2*>(X + (long long)k * ldx + i + 2);
         x[k][0] = a.x;
         x[k][1] = a.y;
         x[k][2] = b.x;
@@ -1135,8 +1127,8 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
       }
     }
     if (!PACK && wts) {
-      const double2 a = va ? *reinterpret_cast<const double2*>(wts + i) : zero2;
-      const double2 b = vb ? *reinterpret_cast<const double2*>(wts + i + kGap) : zero2;
+      const double2 a = *reinterpret_cast<const double2*>(wts + i);
+      const double2 b = *reinterpret_cast<const double2*>(wts + i + 2);
 #pragma unroll
       for (int k = 0; k < DMAX; ++k) {
         x[k][0] *= a.x;
@@ -1145,14 +1137,13 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
         x[k][3] *= b.y;
       }
     }
-    // samples of this group inside the slice (the rest: pad rows, zero)
-    const bool in[4] = {i < i1, i + 1 < i1, i + kGap < i1, i + kGap + 1 < i1};
+    const int live = (int)((i1 - i < 4) ? i1 - i : 4);  // samples of this group inside the slice (the rest: pad rows, zero)
 #pragma unroll
     for (int c = 0; c < kCovHcCols; ++c) {
       if (c < nc) {
         const double* gp = G + (long long)(c0 + c) * ld + i;
-        const double2 a = va ? *reinterpret_cast<const double2*>(gp) : zero2;
-        const double2 b = vb ? *reinterpret_cast<const double2*>(gp + kGap) : zero2;
+        const double2 a = *reinterpret_cast<const double2*>(gp);
+        const double2 b = *reinterpret_cast<const double2*>(gp + 2);
         const double g[4] = {a.x, a.y, b.x, b.y};
         unsigned packed = 0;
 #pragma unroll
@@ -1162,22 +1153,14 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
             not_hard |= !(g[e] == 0.0 || g[e] == 1.0 || g[e] == 2.0);
           }
           s[c] += g[e];
-          if (in[e]) {
+          if (e < live) {
             mn[c] = fmin(mn[c], g[e]);
             mx[c] = fmax(mx[c], g[e]);
           }
 #pragma unroll
           for (int k = 0; k < DMAX; ++k) t[c][k] = fma(g[e], x[k][e], t[c][k]);
         }
-        if (PACK) {
-          if (SPLIT) {
-            if (va) *reinterpret_cast<unsigned short*>(out8 + (long long)(c0 + c) * ldk + i) = (unsigned short)(packed & 0xffffu);
-            if (vb)
-              *reinterpret_cast<unsigned short*>(out8 + (long long)(c0 + c) * ldk + i + kGap) = (unsigned short)(packed >> 16);
-          } else {
-            *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
-          }
-        }
+        if (PACK) *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
       }
     }
   }

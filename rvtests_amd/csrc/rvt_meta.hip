@@ -274,7 +274,8 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
   // int8 products, ~2^-40 relative)
   // (hard calls are a prediction — the engine's own per-column flags when it filled the block, optimism otherwise —
   // that cov_hc_prep_kernel verifies on every value it converts; a block that fails is computed again the general way)
-  const bool fast = allow_fast && !nc.binary && H == W && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
+  // (round 5: rectangles too — heads against a wider window, as the adapter's ring hands them over from 1 025 columns on)
+  const bool fast = allow_fast && !nc.binary && W >= 64 && block_hard_calls(c, dG, col0 + W, nullptr, nullptr) != 0;
   int* d_bad = nullptr;
   int h_bad = 0;
   // one pass over the window's columns for the column statistics and T = G_W' D X (and, on the hard-call path, the int8
@@ -298,7 +299,7 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
                        W, d, dmax, d_cs, d_poly, d_T);
   }
   if (fast) {
-    // heads = whole window of a hard-call block (rvt_cov_block's fast path): ONE pass over G gives the column
+    // a hard-call block (rvt_cov_block's fast path; heads = the first H of the W columns): ONE pass over G gives the column
     // statistics, T = G'X and the int8 copy (cov_hc_prep_kernel); S = G'G is then one exact integer product
     const int64_t ldk = (N + 127) / 128 * 128;
     const int64_t cols_pad = ((int64_t)W + kRotBM - 1) / kRotBM * kRotBM;
@@ -316,11 +317,7 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
     {
       const dim3 grid((unsigned)wgs, (unsigned)slices);
-      static const bool split_loads = getenv("RVT_COV_PREP_SPLIT") != nullptr;  // (A/B probe of the load pattern)
-      if (dmax == 4 && split_loads)
-        hipLaunchKernelGGL((cov_hc_prep_kernel<4, true, true>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
-                           (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, nullptr);
-      else if (dmax == 4)
+      if (dmax == 4)
         hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, GW, (long long)N, (long long)ld, W, c->d_X,
                            (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad);
       else if (dmax == 8)
@@ -333,7 +330,7 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
                          W, d, dmax, d_cs, d_poly, d_T);
     }
     std::vector<int> zero_exp((size_t)W, 0);
-    rc = rvt_planes_gemm(c, c->d_rotB, need, 1, W, zero_exp.data(), 0, c->d_rotB, need, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
+    rc = rvt_planes_gemm(c, c->d_rotB, need, 1, H, zero_exp.data(), 0, c->d_rotB, need, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
     if (rc) return rc;
   } else {
     // anything else — dosages, a binary trait's weights — on the fp64 matrix cores (gemm_f64.hip.h): the upper triangle of

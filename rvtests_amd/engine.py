@@ -14,7 +14,7 @@ LIBNAME = "librvtests_amd.so"
 
 TEST_SKAT, TEST_SKATO, TEST_CMC, TEST_ZEGGINI, TEST_ALL = 1, 2, 4, 8, 15
 TEST_ANALYTICVT = 128
-MAX_INFLIGHT = 8  # RVT_MAX_INFLIGHT (include/rvtests_amd.h)
+MAX_INFLIGHT = int(os.environ.get("RVT_PY_MAX_INFLIGHT", 8))  # RVT_MAX_INFLIGHT (include/rvtests_amd.h; the env only for tools/build_variant.sh builds)
 TRAIT_QUANTITATIVE, TRAIT_BINARY = 0, 1
 
 c_double_p = C.POINTER(C.c_double)

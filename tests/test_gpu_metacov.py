@@ -105,6 +105,41 @@ def test_cov_rect_matches_block(engine_factory, binary):
     assert np.allclose(rzz, zz, rtol=1e-12, atol=0)
 
 
+def test_cov_rect_hard_call_fast_path(engine_factory, monkeypatch):
+    """Heads against a wider window of a hard-call block (what the adapter's ring hands over once it holds more than 1 024
+    columns) take the exact int8 product too (round 5): the rows equal the symmetric block's BIT FOR BIT (the products are
+    integers either way), with a monomorphic column and a non-zero column offset; a dosage inside the window falls back."""
+    N, V, d = 2100, 260, 2
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 909)
+    G = np.rint(G)
+    G[:, 31] = 1.0
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ptr = eng.upload_block(G)
+    assert eng.classify_block(ptr, V)
+    cov, xz, zz, poly = eng.cov_block(ptr, V)
+    for col0, H, W in ((0, 100, 260), (9, 64, 200), (20, 1, 64)):
+        eng.set_profiling(True)
+        eng.timing(reset=True)
+        rcov, rxz, rzz, rpoly = eng.cov_rect(ptr, col0, H, W)
+        assert (rpoly == poly[col0:col0 + W]).all()
+        for h in range(H):
+            assert np.array_equal(rcov[h, h:], cov[col0 + h, col0 + h:col0 + W], equal_nan=True)
+        assert np.array_equal(rxz, xz[col0:col0 + W])
+    # a dosage in the window: the int8 pass reports it and the call is computed again the general way
+    G2 = G.copy()
+    G2[5, 100] = 0.37
+    ptr2 = eng.upload_block(G2)
+    rcov, rxz, rzz, rpoly = eng.cov_rect(ptr2, 9, 64, 200)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G2, chrom, pos, X, y, 0, 10 ** 7)
+    scale = np.nanmax(np.abs(ocov))
+    for h in range(64):
+        for j in range(h, 200):
+            if kept[9 + h] and kept[9 + j] and not np.isnan(ocov[9 + h, 9 + j]):
+                assert abs(rcov[h, j] - ocov[9 + h, 9 + j]) <= REL * scale
+
+
 @pytest.mark.parametrize("V,d,how", [(200, 3, "classify"), (517, 2, "columns"), (64, 1, "classify")])
 def test_cov_block_hard_call_fast_path(engine_factory, V, d, how, monkeypatch):
     """Hard-call blocks with an unweighted model take the exact int8 product (split over K when the band has few

@@ -5,9 +5,10 @@ measured like the headline: one JSON line per workload with `roofline` and `cpu_
   block   one block of V variants, N samples, all pairs of the upper triangle (rvt_cov_block):
             fp64   dosages / anything that is not a hard call: the LDS-tiled fp64 product (gemm_f64.hip.h)  — matrix-core bound
             hc     hard calls under an unweighted model: the exact int8 product (rot_gemm.hip.h)            — HBM bound
-  window  the reference's 1 Mb sliding window as the adapter drives it (ModelFitterGpu.cpp MetaCovTest::flush): a stream of
-          variants whose window holds `--window` markers; the device ring of 1024 columns is filled from HBM-resident
-          columns, flushed when full (one block call), the finished heads are dropped and the rest moved to the front.
+  window  the reference's 1 Mb sliding window as the adapter drives it (ModelFitterGpu.cpp MetaCovTest::fit / flush): a stream
+          of variants whose window holds `--window` markers; the device ring (1 024 columns, doubled until it holds two
+          windows) is filled from HBM-resident columns, flushed when full (one block call, or rectangles of up to 1 024 heads),
+          the finished heads are dropped and the rest moved to the front.
 
 Algorithmic work: per pair of the band 2 N flop; per block 8 N V bytes read once.
 CPU baseline: the oracle's MetaCov (orc.metacov, float32 storage as the reference) on a bounded sample (N, V scaled down),
@@ -109,59 +110,67 @@ def main():
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                    "note": "8 N V bytes of the block over the wall time of the synchronous C call"},
                       "cpu_baseline": cpu}))
-    # ---- the sliding window, as the adapter drives it
+    # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): the ring starts at
+    # 1 024 columns and doubles while a flush emits less than half of it; a ring of up to 1 024 columns is one symmetric
+    # block call, a wider one goes through heads x window rectangles of up to 1 024 heads
     widths = [int(w) for w in a.window.split(",") if w]
-    if widths:
+    src = hard                                                # V resident columns, re-used cyclically as the stream
+    for w in widths:
         cap = 1024
+        while cap < 2 * w:
+            cap *= 2
         ring = eng.alloc_block(cap)
-        src = hard                                            # V resident columns, re-used cyclically as the stream
-        for w in widths:
-            if w >= cap:
-                continue
-            done = 0
-            fill = 0
-            t_cov = t_move = t_fill = 0.0
-            flushes = -1
-            nxt = 0
-            while done < a.stream:
-                # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies,
-                # timed apart — input delivery is not part of the measured path)
-                t1 = time.perf_counter()
-                while fill < cap:
-                    n = min(cap - fill, V - nxt)
-                    eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src.data_ptr()), nxt, n))
-                    fill += n
-                    nxt = (nxt + n) % V
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
+        done = fill = nxt = 0
+        t_cov = t_move = t_fill = 0.0
+        flushes = -1
+        calls = 0
+        while done < a.stream:
+            # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies,
+            # timed apart — input delivery is not part of the measured path)
+            t1 = time.perf_counter()
+            while fill < cap:
+                n = min(cap - fill, V - nxt)
+                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src.data_ptr()), nxt, n))
+                fill += n
+                nxt = (nxt + n) % V
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            heads = cap - w                                   # heads whose window is complete
+            if cap <= 1024:
                 eng.cov_block(ring, cap)
-                t3 = time.perf_counter()
-                heads = cap - w                               # heads whose window is complete
-                eng.move_columns(ring, 0, heads, cap - heads)
-                t4 = time.perf_counter()
-                fill = cap - heads
-                if flushes < 0:                               # the first flush of a width is a warm-up (first touch of the ring)
-                    flushes = 0
-                    continue
-                t_fill += t2 - t1
-                t_cov += t3 - t2
-                t_move += t4 - t3
-                flushes += 1
-                done += heads
-            dt = t_cov + t_move
-            npairs = done * (w + 1)
-            gbs = 8.0 * N * done / dt / 1e9
-            print(json.dumps({"workload": "MetaCov sliding window, hard calls, ring of %d columns" % cap, "N": N, "window_markers": w,
-                              "variants": done, "flushes": flushes, "ms_per_flush": 1e3 * dt / flushes,
-                              "ms_per_flush_in_cov_block": 1e3 * t_cov / flushes, "ms_per_flush_moving_the_ring": 1e3 * t_move / flushes,
-                              "ms_per_flush_filling_the_ring_untimed": 1e3 * t_fill / flushes, "value": npairs / dt,
-                              "unit": "printed covariance pairs/s", "variants_per_s": done / dt,
-                              "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                           "note": "8 N bytes per evicted variant (each column of the stream read once) over the time "
-                                                   "of the block calls and ring moves; a flush recomputes the columns it keeps, so the "
-                                                   "ring reads 1024 / (1024 - w) times that"},
-                              "cpu_baseline": cpu}))
+                calls += 1
+            else:
+                for h0 in range(0, heads, 1024):
+                    nh = min(1024, heads - h0)
+                    eng.cov_rect(ring, h0, nh, nh + w)
+                    calls += 1
+            t3 = time.perf_counter()
+            eng.move_columns(ring, 0, heads, cap - heads)
+            t4 = time.perf_counter()
+            fill = cap - heads
+            if flushes < 0:                                   # the first flush of a width is a warm-up (first touch of the ring)
+                flushes = calls = 0
+                continue
+            t_fill += t2 - t1
+            t_cov += t3 - t2
+            t_move += t4 - t3
+            flushes += 1
+            done += heads
+        dt = t_cov + t_move
+        npairs = done * (w + 1)
+        gbs = 8.0 * N * done / dt / 1e9
+        print(json.dumps({"workload": "MetaCov sliding window, hard calls, adapter's ring policy", "N": N, "window_markers": w,
+                          "ring_columns": cap, "variants": done, "flushes": flushes, "device_calls": calls,
+                          "ms_per_flush": 1e3 * dt / flushes,
+                          "ms_per_flush_in_cov_calls": 1e3 * t_cov / flushes, "ms_per_flush_moving_the_ring": 1e3 * t_move / flushes,
+                          "ms_per_flush_filling_the_ring_untimed": 1e3 * t_fill / flushes, "value": npairs / dt,
+                          "unit": "printed covariance pairs/s", "variants_per_s": done / dt,
+                          "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                       "note": "8 N bytes per evicted variant (each column of the stream read once) over the time "
+                                               "of the device calls and ring moves; a call re-reads the window's columns behind "
+                                               "its heads, so the ring reads (heads + w) / heads times that"},
+                          "cpu_baseline": cpu}))
         eng.free_block(ring)
 
 
