@@ -634,18 +634,6 @@ def main():
                 line["from_host"] = from_host_rates(eng, blocks, Ms, afs, N)
             except Exception as e:                        # (secondary figures must never cost the line)
                 line["from_host"] = {"error": repr(e)[:300]}
-        if world == 1 and not args.no_from_host and not binary:
-            # the same hand-off from a C++ caller (tools/host_feed_bench: one thread, rvt_submit_gene_* per gene — what the
-            # drop-in adapters do), as a child process while this one is idle
-            tool = os.path.join(ROOT, "tools", "host_feed_bench")
-            if os.path.exists(tool):
-                import subprocess
-                try:
-                    pr = subprocess.run([tool, "--samples", str(N), "--m", "50", "--genes", "1536", "--modes", "int8,bed"],
-                                        capture_output=True, text=True, timeout=240)
-                    line["from_host_cpp"] = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
-                except Exception as e:
-                    line["from_host_cpp"] = {"error": repr(e)[:300]}
         if world > 1:
             line["ranks_seen"] = int(dist.get_world_size())
             line["devices_seen_by_rank0"] = int(torch.cuda.device_count())
@@ -719,6 +707,23 @@ def main():
                 line["parity"] = parity_summary(recs, out0)
                 line["pvalue_max_abs_diff"] = line["parity"]["pvalue_max_abs_diff"]
                 line["q_max_rel_diff"] = line["parity"]["q_max_rel_diff"]
+        if world == 1 and not args.no_from_host and not binary:
+            # the same hand-off from a C++ caller (tools/host_feed_bench: one thread, rvt_submit_gene_* per gene — what the
+            # drop-in adapters do), as a child process AFTER this process has closed its engine: two contexts on one device
+            # oversubscribe its hardware queues (every context creates its streams with queues of their own) — the
+            # figures of rounds 3-4, taken beside the parent's idle context, were 30-40 % low for that reason
+            tool = os.path.join(ROOT, "tools", "host_feed_bench")
+            if os.path.exists(tool):
+                import subprocess
+                try:
+                    eng.close()
+                    del blocks
+                    torch.cuda.empty_cache()
+                    pr = subprocess.run([tool, "--samples", str(N), "--m", "50", "--genes", "1536", "--modes", "int8,bed"],
+                                        capture_output=True, text=True, timeout=240)
+                    line["from_host_cpp"] = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                except Exception as e:
+                    line["from_host_cpp"] = {"error": repr(e)[:300]}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

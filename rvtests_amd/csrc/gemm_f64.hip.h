@@ -66,7 +66,7 @@ inline long long gemm_f64_slices(int n_tiles, long long chunks) {
   return best;
 }
 
-template <int NST>
+template <int NST, bool SUB = false>
 __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
     const double* __restrict__ A, long long lda, int M, const double* __restrict__ B, long long ldb, int Nb,
     const double* __restrict__ B2, long long ldb2, int Nb2, const double* __restrict__ w, long long K, long long kslice,
@@ -85,10 +85,11 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
   // enumerated (n_tiles of them): workgroups that return at once are not harmless — the workgroups of an XCD are dealt to
   // its four shader engines in turn, and with the skipped tiles of a symmetric product in the list two of the four engines
   // received 18 of 60 working groups for their 8 CUs (three rounds instead of two; measured).
+  // ONE slice (a short K: the rank-k update of the kinship back-transformation): the grid is the tile list itself.
   const int id = blockIdx.x, xcd = id & 7, wq = id >> 3;
-  const int slice = xcd + 8 * (wq / n_tiles);
-  if (slice >= n_slices) return;
-  int t = wq % n_tiles, rp = 0, ct = 0;
+  const int slice = SUB ? 0 : xcd + 8 * (wq / n_tiles);
+  if (slice >= n_slices || (SUB && id >= n_tiles)) return;
+  int t = SUB ? id : wq % n_tiles, rp = 0, ct = 0;
   if (symmetric) {  // row panel rp holds the column tiles ct >= first(rp) = (rp * BM) / BN
     for (;; ++rp) {
       const int first = (rp * BM) / BN, cnt = n_col_tiles - first;
@@ -217,12 +218,19 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
     if (j >= Ntot) continue;
     double* cj = C + j * ldc;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a) {
+      if (SUB) asm volatile("" ::: "memory");  // (keep the loads of C next to their stores: 128 of them at once spill)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long m = m0 + wm * 16 * TM + a * 16 + 4 * r + lg;
-        if (m < M) cj[m] = acc[a][b][r];
+        if (m < M) {
+          if (SUB)
+            cj[m] -= acc[a][b][r];  // (C -= A'DB: one K slice, the grid is the tile list)
+          else
+            cj[m] = acc[a][b][r];
+        }
       }
+    }
   }
 }
 

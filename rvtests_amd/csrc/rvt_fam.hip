@@ -372,11 +372,11 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
     float* dK = nullptr;
     float* dU = nullptr;
     double *A = nullptr, *B1 = nullptr, *B2 = nullptr, *B3 = nullptr, *B4 = nullptr, *W = nullptr, *vec = nullptr, *cz = nullptr,
-           *yy = nullptr;
+           *yy = nullptr, *P = nullptr;
     unsigned long long* worst = nullptr;
     ~Bufs() {
       for (void* p : {(void*)dK, (void*)dU, (void*)A, (void*)B1, (void*)B2, (void*)B3, (void*)B4, (void*)W, (void*)vec, (void*)cz,
-                      (void*)yy, (void*)worst})
+                      (void*)yy, (void*)P, (void*)worst})
         if (p) hipFree(p);
     }
   } b;
@@ -390,23 +390,29 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   HIP_TRY(c, hipMalloc((void**)&b.vec, sizeof(double) * nv));
   HIP_TRY(c, hipMemsetAsync(b.vec, 0, sizeof(double) * nv, st));
   HIP_TRY(c, hipMemsetAsync(b.W, 0, sizeof(double) * (size_t)ld * kTdNb, st));
-  double *d_d = b.vec, *d_e = d_d + vs, *d_tau = d_e + vs, *d_y = d_tau + vs, *d_t12 = d_y + vs, *d_part = d_t12 + 2 * kTdNb,
+  double *d_d = b.vec, *d_e = d_d + vs, *d_tau = d_e + vs, *d_y = d_tau + vs, *d_t12 = d_y + vs, *d_part = d_t12 + 2 * kTdNb, *d_ss = d_y,
          *d_ds = d_part + 1024, *d_e2s = d_ds + vs, *d_lam = d_e2s + vs;
   HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.A);
   // 1. K = Q T Q'
-  const int comb_blocks = (int)std::min<int64_t>(1024, (N + 255) / 256);
+  const int comb_blocks = (int)((N + 63) / 64);  // (<= 750 partial dots at N = 48 000: d_part holds 1024)
+  const int nblk = (int)((N + kSyT - 1) / kSyT);  // 64-row blocks of the matrix; P: the (nblk + 1) x ld partial products of a column step
+  HIP_TRY(c, hipMalloc((void**)&b.P, sizeof(double) * (size_t)(nblk + 1) * (size_t)ld));
   for (int j0 = 0; j0 < n; j0 += kTdNb) {
     const int j1 = std::min(n, j0 + kTdNb);
     for (int j = j0; j < j1; ++j) {
-      hipLaunchKernelGGL(td_col_house_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W, d_d, d_e,
+      const int n_ss = (n - j + 255) / 256;
+      hipLaunchKernelGGL(td_col_update_kernel, dim3((unsigned)n_ss), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W,
+                         d_ss);
+      hipLaunchKernelGGL(td_col_house_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, d_ss, n_ss, d_d, d_e,
                          d_tau);
       if (j + 1 >= n) continue;
       const int i = j - j0;
-      hipLaunchKernelGGL(td_dots_kernel, dim3((unsigned)(n - j - 1 + 2 * i)), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j,
-                         j0, b.W, d_y, d_t12);
+      const int nbt = nblk - (j + 1) / kSyT, n_tiles = nbt * (nbt + 1) / 2;
+      hipLaunchKernelGGL(td_symv_kernel, dim3((unsigned)(n_tiles + 2 * i)), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0,
+                         n_tiles, nbt, b.W, b.P, d_t12);
       hipLaunchKernelGGL(td_w_comb_kernel, dim3((unsigned)comb_blocks), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0,
-                         b.W, d_y, d_t12, d_tau, d_part);
+                         b.W, b.P, nblk, d_t12, d_tau, d_part);
       hipLaunchKernelGGL(td_w_final_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W, d_tau, d_part,
                          comb_blocks);
     }
@@ -478,22 +484,25 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_stream(st));
   const double t_vec = now_s();
-  // 4. U = Q Z, the panels in reverse order
-  HIP_TRY(c, hipMalloc((void**)&b.cz, sizeof(double) * (size_t)ld * kTdNb));
-  HIP_TRY(c, hipMalloc((void**)&b.yy, sizeof(double) * (size_t)ld * kTdNb));
-  double *d_tp = d_part, *d_gram = d_y;  // kTdNb^2 = 1024 doubles each
-  for (int j0 = ((n - 1) / kTdNb) * kTdNb; j0 >= 0; j0 -= kTdNb) {
-    const int nbp = std::min(n, j0 + kTdNb) - j0;
-    hipLaunchKernelGGL(td_gram_kernel, dim3((unsigned)nbp, (unsigned)nbp), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j0,
-                       d_gram);
-    hipLaunchKernelGGL(td_larft_kernel, dim3(1), dim3(64), 0, st, d_gram, j0, nbp, d_tau, d_tp);
-    int rc = gemm_tn_f64(c, Z, ld, n, b.A + (size_t)j0 * ld, ld, nbp, nullptr, 0, 0, nullptr, ld, b.cz, ld, false, st);
+  // 4. U = Q Z, the reflectors kTdNbb at a time in reverse order: G = V'V and V'Z (K = N), the back substitution with
+  //    T^-1 = triu(G, 1) + diag(1 / tau), and Z -= V Y' (K = kTdNbb) — all three products on the matrix cores
+  HIP_TRY(c, hipMalloc((void**)&b.cz, sizeof(double) * (size_t)ld * kTdNbb));
+  HIP_TRY(c, hipMalloc((void**)&b.yy, sizeof(double) * (size_t)ld * kTdNbb * 2 + sizeof(double) * kTdNbb * kTdNbb));
+  double *d_yt = b.yy, *d_vt = b.yy + (size_t)ld * kTdNbb, *d_gram = d_vt + (size_t)ld * kTdNbb;
+  HIP_TRY(c, hipMemsetAsync(d_gram, 0, sizeof(double) * kTdNbb * kTdNbb, st));
+  for (int j0 = ((n - 1) / kTdNbb) * kTdNbb; j0 >= 0; j0 -= kTdNbb) {
+    const int nbp = std::min(n, j0 + kTdNbb) - j0;
+    const double* Vp = b.A + (size_t)j0 * ld;
+    int rc = gemm_tn_f64(c, Vp, ld, nbp, Vp, ld, nbp, nullptr, 0, 0, nullptr, ld, d_gram, kTdNbb, true, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(td_apply_t_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.cz, (long long)ld, n, nbp, d_tp,
-                       b.yy);
-    const unsigned tiles = (unsigned)((N + 63) / 64);
-    hipLaunchKernelGGL(td_update_z_kernel, dim3(tiles, tiles), dim3(256), 0, st, Z, (long long)N, (long long)ld, b.A, j0, nbp, b.yy,
-                       (long long)ld);
+    rc = gemm_tn_f64(c, Z, ld, n, Vp, ld, nbp, nullptr, 0, 0, nullptr, ld, b.cz, ld, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(td_rsolve_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, b.cz, (long long)ld, n, nbp, d_gram,
+                       d_tau + j0, d_yt);
+    hipLaunchKernelGGL(td_panel_transpose_kernel, dim3((unsigned)((N + 31) / 32), kTdNbb / 32), dim3(256), 0, st, b.A, (long long)N,
+                       (long long)ld, j0, nbp, d_vt);
+    rc = gemm_tn_f64(c, d_vt, kTdNbb, n, d_yt, kTdNbb, n, nullptr, 0, 0, nullptr, kTdNbb, Z, ld, false, st, true);
+    if (rc) return rc;
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_stream(st));

@@ -9,8 +9,11 @@ extern "C" {
 // zero-padded to a multiple of 16; w: optional weights along the samples (D = diag(w)), else D = I.
 // symmetric: A and B are the same columns, only the tiles that meet the upper triangle are computed (the rest of C is
 // left unspecified).  K is split over the chip; the partial results are added in a fixed order.
+// subtract: C -= A' D B instead (every entry is read and written by one thread); the product then runs as ONE K slice, the
+// grid being the tile list — meant for short K (a rank-k update of a large C).
 int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B, int64_t ldb, int Nb, const double* B2,
-                int64_t ldb2, int Nb2, const double* w, int64_t N, double* C, int64_t ldc, bool symmetric, hipStream_t st) {
+                int64_t ldb2, int Nb2, const double* w, int64_t N, double* C, int64_t ldc, bool symmetric, hipStream_t st,
+                bool subtract) {
   const int Ntot = Nb + Nb2;
   if (M < 1 || Ntot < 1) return RVT_OK;
   int nct = 0;
@@ -18,6 +21,7 @@ int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B
   const int64_t chunks = (N + kGemmKC - 1) / kGemmKC;
   int64_t slices = gemm_f64_slices(n_tiles, chunks);
   if (const char* e = getenv("RVT_GEMM64_SLICES")) slices = std::max<int64_t>(1, atoll(e));
+  if (subtract) slices = 1;
   const int64_t kslice = ((chunks + slices - 1) / slices) * kGemmKC;
   slices = (N + kslice - 1) / kslice;
   double* d_out = C;
@@ -35,10 +39,15 @@ int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B
     d_out = c->d_rot_part;
   }
   const int64_t groups = (slices + 7) / 8;
-  const dim3 grid((unsigned)(8 * (int64_t)n_tiles * groups));
-  hipLaunchKernelGGL((gemm_tn_f64_kernel<3>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
-                     B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, (int)slices, d_out,
-                     (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0);
+  const dim3 grid(subtract ? (unsigned)n_tiles : (unsigned)(8 * (int64_t)n_tiles * groups));
+  if (subtract)
+    hipLaunchKernelGGL((gemm_tn_f64_kernel<3, true>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
+                       B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, 1, d_out, (long long)ldc,
+                       0LL, n_tiles, nct, symmetric ? 1 : 0);
+  else
+    hipLaunchKernelGGL((gemm_tn_f64_kernel<3, false>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
+                       B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, (int)slices, d_out,
+                       (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0);
   if (slices > 1)
     hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_out, (long long)ldc, (long long)M,
                        (long long)Ntot, (long long)c_slice, (int)slices, C, 0);

@@ -5,17 +5,18 @@
 // N x N kinship; eigenvalues ascending in matS, eigenvectors in the columns of matU).  The one-sided block Jacobi iteration of
 // jacobi_kernels.hip.h needs 16-30 sweeps on a gap-free spectrum, every sweep N^3 bytes of HBM traffic: 44 s at N = 12 000.
 // Here:
-//   1. K = Q T Q'.  Blocked Householder tridiagonalisation (LAPACK's dsytrd / dlatrd scheme, panels of kTdNb columns, the full
-//      symmetric matrix kept so that the O(N^2) product of every column is a plain column-dot-product pass: 8 N^3 / 3 bytes of
-//      traffic in all, the rank-2nb updates 16 N^3 / nb).  The reflector v_j overwrites column j of the matrix.
+//   1. K = Q T Q'.  Blocked Householder tridiagonalisation (LAPACK's dsytrd / dlatrd scheme, panels of kTdNb columns).  The
+//      O(N^2) product of every column reads the LOWER triangle of the trailing matrix once, tile by tile (td_symv_kernel:
+//      4 N^3 / 3 bytes of traffic in all — the HBM-bound part), the rank-2nb updates touch the lower triangle only.  The
+//      reflector v_j overwrites column j of the matrix.
 //   2. The eigenvalues of T by the Sturm bisection + interpolation of rvt_coop.h, one thread per eigenvalue.
 //   3. The eigenvectors of T by inverse iteration, one thread per eigenvector (tridiagonal LU with partial pivoting, three
 //      solves), WITHOUT reorthogonalisation: the vectors of eigenvalues a gap g apart are orthogonal to ~eps / g, and the
 //      boundary stores U as FLOAT (EigenMatrix = Eigen::MatrixXf) — a gap of 1e-7 of the spectrum's width is enough.  A matrix
 //      with a tighter cluster (repeated eigenvalues: pedigree kinships, rank-deficient matrices) is left to the Jacobi
 //      iteration, which does not care; so is a result that fails the residual / orthogonality check that closes the procedure.
-//   4. U = Q Z: the reflectors applied panel by panel in compact WY form, Z <- Z - V (T_p (V'Z)); V'Z is the fp64 matrix-core
-//      product of gemm_f64.hip.h (both operands run along the rows).
+//   4. U = Q Z: the reflectors applied 256 at a time in compact WY form, Z <- Z - V (T (V'Z)); V'Z, V'V and the rank-256 update
+//      are the fp64 matrix-core product of gemm_f64.hip.h, T is applied as a back substitution with T^-1 = triu(V'V, 1) + diag(1 / tau).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,13 +48,10 @@ __device__ __forceinline__ double td_block_sum(double v, double* red) {  // sum 
 
 // Column j of the matrix, i = j - j0 columns of the panel before it (V = columns j0 .. j0 + i - 1 of A, W = the panel's W):
 //   a[r] -= sum_p V[r, p] W[j, p] + W[r, p] V[j, p]   for r >= j          (dlatrd's update of the column)
-//   d[j] = a[j];  reflector of x = a[j + 1 .. n): beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = [1; x[1:] / (x0 - beta)]
-//   e[j] = beta;  column j of A becomes v (zeros in rows 0 .. j)
-// ONE workgroup of 1024 threads.
-static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __restrict__ A, long long n, long long ld, int j, int j0,
-                                                            const double* __restrict__ W, double* __restrict__ dvec,
-                                                            double* __restrict__ evec, double* __restrict__ tau) {
-  __shared__ double red[16];
+// td_col_update_kernel: 256 rows per workgroup; ss[blockIdx.x] = the workgroup's share of sum_{r > j + 1} a[r]^2.
+static __global__ __launch_bounds__(256) void td_col_update_kernel(double* __restrict__ A, long long n, long long ld, int j, int j0,
+                                                             const double* __restrict__ W, double* __restrict__ ss) {
+  __shared__ double red[4];
   __shared__ double wj[kTdNb], vj[kTdNb];
   const int i = j - j0, tid = threadIdx.x;
   double* a = A + (long long)j * ld;
@@ -62,15 +60,27 @@ static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __res
     vj[tid] = A[(long long)(j0 + tid) * ld + j];
   }
   __syncthreads();
-  double ss = 0.0;  // sum of squares of x[1:]
-  for (long long r = j + tid; r < n; r += 1024) {
+  const long long r = j + (long long)blockIdx.x * 256 + tid;
+  double sq = 0.0;
+  if (r < n) {
     double v = a[r];
     for (int p = 0; p < i; ++p) v -= A[(long long)(j0 + p) * ld + r] * wj[p] + W[(long long)p * ld + r] * vj[p];
     a[r] = v;
-    if (r > j + 1) ss += v * v;
+    if (r > j + 1) sq = v * v;
   }
-  const double xss = td_block_sum(ss, red);
-  __syncthreads();
+  const double tot = td_block_sum(sq, red);
+  if (tid == 0) ss[blockIdx.x] = tot;
+}
+// td_col_house_kernel (ONE workgroup of 1024 threads, behind td_col_update_kernel's n_ss workgroups):
+//   d[j] = a[j];  reflector of x = a[j + 1 .. n): beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = [1; x[1:] / (x0 - beta)]
+//   e[j] = beta;  column j of A becomes v (zeros in rows 0 .. j)
+static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __restrict__ A, long long n, long long ld, int j,
+                                                            const double* __restrict__ ss, int n_ss, double* __restrict__ dvec,
+                                                            double* __restrict__ evec, double* __restrict__ tau) {
+  const int tid = threadIdx.x;
+  double* a = A + (long long)j * ld;
+  double xss = 0.0;
+  for (int k = 0; k < n_ss; ++k) xss += ss[k];  // fixed order, every thread the same
   const double ajj = a[j], x0 = (j + 1 < n) ? a[j + 1] : 0.0;
   double beta = x0, t = 0.0, scale = 0.0;
   if (xss > 0.0) {
@@ -79,7 +89,7 @@ static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __res
     t = (beta - x0) / beta;
     scale = 1.0 / (x0 - beta);
   }
-  __syncthreads();
+  __syncthreads();  // (every thread has read a[j], a[j + 1])
   for (long long r = tid; r < n; r += 1024) {
     double v = 0.0;
     if (r == j + 1)
@@ -95,64 +105,110 @@ static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __res
   }
 }
 
-// Column dot products against v = column j of A (rows j + 1 .. n):
-//   group 0: y[c] = A[:, c]' v                 for c in (j, n)         (the trailing matrix: A22 v, A symmetric)
-//   group 1: t1[p] = W[:, p]' v,  group 2: t2[p] = V[:, p]' v          for p < i
-// grid = (n - j - 1) + 2 i workgroups of 256 threads, one per column.
-static __global__ __launch_bounds__(256) void td_dots_kernel(const double* __restrict__ A, long long n, long long ld, int j, int j0,
-                                                       const double* __restrict__ W, double* __restrict__ y,
-                                                       double* __restrict__ t12) {
+// y = A22 v (v = column j of A, zero in rows 0 .. j) from the LOWER triangle of the trailing matrix only — the O(N^2) half of
+// the reduction is a pass over HBM, and reading one triangle halves it.  The matrix is cut into 64 x 64 tiles on absolute
+// multiples of 64; a workgroup takes ONE tile (R, C), R >= C >= B0 = (j + 1) / 64, through LDS and produces
+//   the tile's share of the rows    sum_c A[r, c] v[c]   (c <= r inside a diagonal tile)   -> P[C][r]
+//   the tile's share of the columns sum_r A[r, c] v[r]   (r >  c inside a diagonal tile)   -> P[R + 1][c]
+// (rows / columns <= j contribute nothing: v is zero there).  For an index i of block B the slots B0 .. B come from the row
+// shares and B + 1 .. nblk from the column shares: every slot B0 .. nblk of P[.][i] is written in every step, and
+// td_w_comb_kernel adds them in slot order.  P: (nblk + 1) x ld.
+// The same launch computes the panel's dot products  t1[p] = W[:, p]' v,  t2[p] = V[:, p]' v  (p < i): workgroups behind the tiles.
+constexpr int kSyT = 64;
+static __global__ __launch_bounds__(256) void td_symv_kernel(const double* __restrict__ A, long long n, long long ld, int j, int j0,
+                                                       int n_tiles, int nbt, const double* __restrict__ W,
+                                                       double* __restrict__ P, double* __restrict__ t12) {
+  __shared__ double tile[kSyT][kSyT + 1];
+  __shared__ double vr[kSyT], vc[kSyT];
   __shared__ double red[4];
-  const int i = j - j0, b = blockIdx.x;
-  const long long ntrail = n - j - 1;
-  const double* col;
-  double* out;
-  if (b < ntrail) {
-    col = A + (long long)(j + 1 + b) * ld;
-    out = y + (j + 1 + b);
-  } else if (b < ntrail + i) {
-    col = W + (long long)(b - ntrail) * ld;
-    out = t12 + (b - ntrail);
-  } else {
-    col = A + (long long)(j0 + (b - ntrail - i)) * ld;
-    out = t12 + kTdNb + (b - ntrail - i);
-  }
   const double* v = A + (long long)j * ld;
-  double s = 0.0;
-  for (long long r = j + 1 + threadIdx.x; r < n; r += 256) s = fma(col[r], v[r], s);
-  const double tot = td_block_sum(s, red);
-  if (threadIdx.x == 0) *out = tot;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= n_tiles) {  // a column of the panel
+    const int i = j - j0, q = blockIdx.x - n_tiles;
+    const double* col = q < i ? W + (long long)q * ld : A + (long long)(j0 + q - i) * ld;
+    double sacc = 0.0;
+    for (long long r = j + 1 + tid; r < n; r += 256) sacc = fma(col[r], v[r], sacc);
+    const double tot = td_block_sum(sacc, red);
+    if (tid == 0) t12[q < i ? q : kTdNb + (q - i)] = tot;
+    return;
+  }
+  // tile number -> (R, C), 0 <= C <= R < nbt, walking DOWN the column strips (id = C nbt - C (C - 1) / 2 + R - C): the
+  // workgroups resident at one time then read vertically adjacent tiles — runs of many KB of the same columns, not 512-byte
+  // pieces of a thousand different ones
+  const int id = blockIdx.x;
+  int C = (int)(((double)(2 * nbt + 1) - sqrt((double)(2 * nbt + 1) * (double)(2 * nbt + 1) - 8.0 * (double)id)) * 0.5);
+  if (C < 0) C = 0;
+  if (C > nbt - 1) C = nbt - 1;
+  while (C > 0 && C * nbt - C * (C - 1) / 2 > id) --C;
+  while (C + 1 < nbt && (C + 1) * nbt - (C + 1) * C / 2 <= id) ++C;
+  const int R = C + (id - (C * nbt - C * (C - 1) / 2));
+  const int B0 = (j + 1) / kSyT, Rb = B0 + R, Cb = B0 + C;
+  const long long r0 = (long long)Rb * kSyT, c0 = (long long)Cb * kSyT;
+  if (tid < kSyT) {
+    vr[tid] = (r0 + tid < n) ? v[r0 + tid] : 0.0;
+    vc[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
+  }
+  {  // 32 row pairs x 8 columns per pass (ld is a multiple of 64: the pair behind the last row reads zero pad rows)
+    const int rp = 2 * (tid & 31), cq = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cq + 8 * k;
+      double2 a = {0.0, 0.0};
+      if (c0 + c < n) a = *reinterpret_cast<const double2*>(A + (c0 + c) * ld + r0 + rp);
+      tile[rp][c] = a.x;
+      tile[rp + 1][c] = a.y;
+    }
+  }
+  __syncthreads();
+  const bool diag = R == C;
+  if (tid < kSyT) {
+    const int r = tid, cend = diag ? r + 1 : kSyT;
+    double sacc = 0.0;
+    for (int c = 0; c < cend; ++c) sacc = fma(tile[r][c], vc[c], sacc);
+    if (r0 + r < n) P[(long long)Cb * ld + r0 + r] = sacc;
+  } else if (tid < 2 * kSyT) {
+    const int c = tid - kSyT, rbeg = diag ? c + 1 : 0;
+    double sacc = 0.0;
+    for (int r = rbeg; r < kSyT; ++r) sacc = fma(tile[r][c], vr[r], sacc);
+    if (c0 + c < n) P[(long long)(Rb + 1) * ld + c0 + c] = sacc;
+  }
 }
 
-// w'[r] = tau (y[r] - sum_p V[r, p] t1[p] + W[r, p] t2[p]),  r > j; per-workgroup partial of w' . v into part[blockIdx.x]
+// w'[r] = tau (y[r] - sum_p V[r, p] t1[p] + W[r, p] t2[p]),  r > j; per-workgroup partial of w' . v into part[blockIdx.x].
+// y[r] = the sum of the slots B0 .. nblk of P[.][r] (td_symv_kernel).  64 rows per workgroup: wave q adds the slots B0 + q,
+// B0 + q + 4, ... of its 64 rows, wave 0 adds the four sums in wave order and finishes the row.
 static __global__ __launch_bounds__(256) void td_w_comb_kernel(const double* __restrict__ A, long long n, long long ld, int j, int j0,
-                                                         double* __restrict__ W, const double* __restrict__ y,
+                                                         double* __restrict__ W, const double* __restrict__ P, int nblk,
                                                          const double* __restrict__ t12, const double* __restrict__ tau,
                                                          double* __restrict__ part) {
-  __shared__ double red[4];
+  __shared__ double quarter[4][64];
   __shared__ double t1[kTdNb], t2[kTdNb];
-  const int i = j - j0;
+  const int i = j - j0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)threadIdx.x < i) {
     t1[threadIdx.x] = t12[threadIdx.x];
     t2[threadIdx.x] = t12[kTdNb + threadIdx.x];
   }
+  const long long r = (long long)blockIdx.x * 64 + lane;
+  double sacc = 0.0;
+  if (r > j && r < n)
+    for (int bq = (j + 1) / kSyT + wave; bq <= nblk; bq += 4) sacc += P[(long long)bq * ld + r];
+  quarter[wave][lane] = sacc;
   __syncthreads();
+  if (wave != 0) return;
   const double tj = tau[j];
   const double* v = A + (long long)j * ld;
-  double* w = W + (long long)i * ld;
-  double dot = 0.0;
-  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) {
-    double val = 0.0;
+  double val = 0.0, dot = 0.0;
+  if (r < n) {
     if (r > j) {
-      val = y[r];
+      val = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
       for (int p = 0; p < i; ++p) val -= A[(long long)(j0 + p) * ld + r] * t1[p] + W[(long long)p * ld + r] * t2[p];
       val *= tj;
-      dot = fma(val, v[r], dot);
+      dot = val * v[r];
     }
-    w[r] = val;
+    W[(long long)i * ld + r] = val;
   }
-  const double tot = td_block_sum(dot, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+  if (lane == 0) part[blockIdx.x] = dot;
 }
 // w = w' - (tau / 2) (w' . v) v        (one workgroup; nparts partial dots)
 static __global__ __launch_bounds__(1024) void td_w_final_kernel(const double* __restrict__ A, long long n, long long ld, int j, int j0,
@@ -166,11 +222,13 @@ static __global__ __launch_bounds__(1024) void td_w_final_kernel(const double* _
   for (long long r = j + 1 + threadIdx.x; r < n; r += 1024) w[r] = fma(alpha, v[r], w[r]);
 }
 
-// A[r, c] -= sum_p V[r, p] W[c, p] + W[r, p] V[c, p]   for r, c >= j1 (the columns behind the panel j0 .. j1 - 1)
+// A[r, c] -= sum_p V[r, p] W[c, p] + W[r, p] V[c, p]   for r >= c >= j1 (the columns behind the panel j0 .. j1 - 1; tiles that
+// meet the lower triangle)
 // grid (tiles, tiles) of 64 x 64 outputs, 256 threads (4 x 4 outputs each); the panel rows of both tiles in LDS
 static __global__ __launch_bounds__(256) void td_rank2k_kernel(double* __restrict__ A, long long n, long long ld, int j0, int j1,
                                                          const double* __restrict__ W) {
   __shared__ double vr[kTdNb][64 + 1], wr[kTdNb][64 + 1], vc[kTdNb][64 + 1], wc[kTdNb][64 + 1];
+  if (blockIdx.x < blockIdx.y) return;  // (only the lower triangle of the trailing matrix is read afterwards: td_symv_kernel)
   const long long r0 = j1 + (long long)blockIdx.x * 64, c0 = j1 + (long long)blockIdx.y * 64;
   const int nb = j1 - j0;
   for (int idx = threadIdx.x; idx < nb * 64; idx += 256) {
@@ -316,94 +374,64 @@ static __global__ __launch_bounds__(256) void td_transpose_kernel(const double* 
   }
 }
 
-// ---- back-transformation U = Q Z, panel by panel ----------------------------------------------------------------------------
-// The triangular factor of the panel's block reflector H_j0 ... H_{j1-1} = I - V T V' (dlarft, forward, columnwise):
-//   T[i][i] = tau_i,  T[0:i, i] = -tau_i T[0:i, 0:i] (V[:, 0:i]' v_i).
-// td_gram_kernel: G[a][b] = v_a' v_b for a < b, one workgroup per pair (grid nb x nb);  td_larft_kernel: T from G and tau, one
-// thread (nb^3 / 6 multiply-adds).  g, tp: kTdNb x kTdNb, row-major.
-static __global__ __launch_bounds__(256) void td_gram_kernel(const double* __restrict__ A, long long n, long long ld, int j0,
-                                                       double* __restrict__ g) {
-  __shared__ double red[4];
-  const int a = blockIdx.x, b = blockIdx.y;
-  if (a >= b) return;
-  const double* va = A + (long long)(j0 + a) * ld;
-  const double* vb = A + (long long)(j0 + b) * ld;
-  double s = 0.0;
-  for (long long r = j0 + b + 1 + threadIdx.x; r < n; r += 256) s = fma(va[r], vb[r], s);
-  const double tot = td_block_sum(s, red);
-  if (threadIdx.x == 0) g[a * kTdNb + b] = tot;
-}
-static __global__ __launch_bounds__(64) void td_larft_kernel(const double* __restrict__ g, int j0, int nb,
-                                                       const double* __restrict__ tau, double* __restrict__ tp) {
-  __shared__ double T[kTdNb][kTdNb];
-  if (threadIdx.x != 0) return;
-  for (int i = 0; i < nb; ++i) {
-    for (int a = 0; a < kTdNb; ++a) T[a][i] = 0.0;
-    const double ti = tau[j0 + i];
-    T[i][i] = ti;
-    for (int a = 0; a < i; ++a) {
-      double s = 0.0;
-      for (int b = a; b < i; ++b) s += T[a][b] * g[b * kTdNb + i];
-      T[a][i] = -ti * s;
-    }
-  }
-  for (int a = 0; a < kTdNb; ++a)
-    for (int b = 0; b < kTdNb; ++b) tp[a * kTdNb + b] = (a < nb && b < nb) ? T[a][b] : 0.0;
-}
-// y[k, p] = sum_q cz[k, q] T[p, q]   (cz = Z'V, n x nb column-major with leading dimension ldc;  y likewise)
-static __global__ __launch_bounds__(256) void td_apply_t_kernel(const double* __restrict__ cz, long long ldc, int n, int nb,
-                                                          const double* __restrict__ tp, double* __restrict__ y) {
-  __shared__ double T[kTdNb][kTdNb];
-  for (int t = threadIdx.x; t < kTdNb * kTdNb; t += 256) T[t / kTdNb][t % kTdNb] = tp[t];
-  __syncthreads();
-  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+// ---- back-transformation U = Q Z: kTdNbb reflectors at a time, every O(N^2 nb) product on the matrix cores -----------------
+// The block reflector of a panel is I - V T V' with T^-1 = triu(V'V, 1) + diag(1 / tau) (from T^-1 + T^-T = V'V: the product is
+// orthogonal), so T is never formed:  Z <- Z - V Y',  Y' = T (V'Z)  <=>  T^-1 Y' = V'Z, a back substitution per column of Z.
+constexpr int kTdNbb = 256;
+
+// One thread per column k of Z:  y_p = tau_p (c_p - sum_{p' > p} G[p, p'] y_p'),  c = cz[k, :] (cz: n x nb, leading dimension
+// ldc; overwritten), G = V'V (column-major, leading dimension kTdNbb, entries above the diagonal), in blocks of 32 from the
+// last: a block is solved in registers, stored, and subtracted from the c's in front of it.  yt[p + k kTdNbb] (p >= nb: 0).
+static __global__ __launch_bounds__(64) void td_rsolve_kernel(double* __restrict__ cz, long long ldc, int n, int nb,
+                                                        const double* __restrict__ G, const double* __restrict__ tau,
+                                                        double* __restrict__ yt) {
+  const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
   if (k >= n) return;
-  double c[kTdNb];
-  for (int q = 0; q < nb; ++q) c[q] = cz[(long long)q * ldc + k];
-  for (int p = 0; p < nb; ++p) {
-    double s = 0.0;
-    for (int q = p; q < nb; ++q) s = fma(c[q], T[p][q], s);  // T upper triangular
-    y[(long long)p * ldc + k] = s;
+  double* yk = yt + k * kTdNbb;
+  for (int p = nb; p < kTdNbb; ++p) yk[p] = 0.0;
+  for (int p0 = ((nb - 1) / 32) * 32; p0 >= 0; p0 -= 32) {
+    double y[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) y[q] = (p0 + q < nb) ? cz[k + (long long)(p0 + q) * ldc] : 0.0;
+#pragma unroll
+    for (int q = 31; q >= 0; --q) {
+      const int p = p0 + q;
+      if (p < nb) {  // (uniform)
+        double sacc = y[q];
+#pragma unroll
+        for (int q2 = q + 1; q2 < 32; ++q2) sacc = fma(-G[p + (long long)(p0 + q2) * kTdNbb], y[q2], sacc);  // (y = 0 beyond nb)
+        y[q] = sacc * tau[p];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+      if (p0 + q < nb) yk[p0 + q] = y[q];
+    for (int i = 0; i < p0; ++i) {
+      double sacc = cz[k + (long long)i * ldc];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) sacc = fma(-G[i + (long long)(p0 + q) * kTdNbb], y[q], sacc);
+      cz[k + (long long)i * ldc] = sacc;
+    }
   }
 }
-// Z[r, k] -= sum_p V[r, p] y[k, p]    grid (row tiles, column tiles) of 64 x 64, 256 threads
-static __global__ __launch_bounds__(256) void td_update_z_kernel(double* __restrict__ Z, long long n, long long ld,
-                                                           const double* __restrict__ A, int j0, int nb,
-                                                           const double* __restrict__ y, long long ldc) {
-  __shared__ double vr[kTdNb][64 + 1], yk[kTdNb][64 + 1];
-  const long long r0 = (long long)blockIdx.x * 64, k0 = (long long)blockIdx.y * 64;
-  for (int idx = threadIdx.x; idx < nb * 64; idx += 256) {
-    const int p = idx / 64, q = idx % 64;
-    const long long r = r0 + q, k = k0 + q;
-    vr[p][q] = r < n ? A[(long long)(j0 + p) * ld + r] : 0.0;
-    yk[p][q] = k < n ? y[(long long)p * ldc + k] : 0.0;
+// vt[p + r kTdNbb] = V[r, p] = A[r + (j0 + p) ld]  (p >= nb: 0);  32 x 32 tiles through LDS.  grid (rows / 32, kTdNbb / 32)
+static __global__ __launch_bounds__(256) void td_panel_transpose_kernel(const double* __restrict__ A, long long n, long long ld,
+                                                                  int j0, int nb, double* __restrict__ vt) {
+  __shared__ double tile[32][33];
+  const long long r0 = (long long)blockIdx.x * 32;
+  const int p0 = blockIdx.y * 32;
+  for (int t = threadIdx.x; t < 1024; t += 256) {
+    const int pp = t / 32, rr = t % 32;  // rows fastest: contiguous in A
+    const long long r = r0 + rr;
+    const int p = p0 + pp;
+    tile[pp][rr] = (r < n && p < nb) ? A[(long long)(j0 + p) * ld + r] : 0.0;
   }
   __syncthreads();
-  const int tr = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  for (int p = 0; p < nb; ++p) {
-    double av[4], bv[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      av[a] = vr[p][tr + a];
-      bv[a] = yk[p][tc + a];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+  for (int t = threadIdx.x; t < 1024; t += 256) {
+    const int rr = t / 32, pp = t % 32;  // p fastest: contiguous in vt
+    const long long r = r0 + rr;
+    if (r < n) vt[r * kTdNbb + p0 + pp] = tile[pp][rr];
   }
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const long long r = r0 + tr + a, k = k0 + tc + b;
-      if (r < n && k < n) Z[k * ld + r] -= acc[a][b];
-    }
 }
 
 // ---- the closing check and the hand-over --------------------------------------------------------------------------------

@@ -37,9 +37,9 @@ static int launch(const double* A, long long lda, int M, const double* B, long l
   slices = (N + kslice - 1) / kslice;
   const long long c_slice = ldc * Ntot;
   const long long groups = (slices + 7) / 8;
-  hipLaunchKernelGGL((gemm_tn_f64_kernel<3>), dim3((unsigned)(8 * (long long)n_tiles * groups)), dim3(kGemmThreads), 0, 0, A, lda, M,
-                     B, ldb, Nb, B2 ? B2 : B, B2 ? ldb2 : ldb, Nb2, w, N, kslice, (int)slices, slices > 1 ? part : C, ldc,
-                     slices > 1 ? c_slice : 0LL, n_tiles, nct, symmetric);
+  hipLaunchKernelGGL((gemm_tn_f64_kernel<3>), dim3((unsigned)(8 * (long long)n_tiles * groups)),
+                     dim3(kGemmThreads), 0, 0, A, lda, M, B, ldb, Nb, B2 ? B2 : B, B2 ? ldb2 : ldb, Nb2, w, N, kslice, (int)slices,
+                     slices > 1 ? part : C, ldc, slices > 1 ? c_slice : 0LL, n_tiles, nct, symmetric);
   if (slices > 1)
     hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, 0, part, ldc, (long long)M, (long long)Ntot, c_slice,
                        (int)slices, C, 0);
