@@ -381,6 +381,18 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
     }
   } b;
   const size_t mat = sizeof(double) * (size_t)ld * (size_t)N;
+  {
+    // five N x N fp64 areas, the float matrix, the panels and the product's K slices: when the device cannot hold them (other
+    // contexts, a large block pool) the Jacobi iteration (16 N^2 bytes) gets the matrix instead of an allocation failure
+    size_t free_b = 0, total_b = 0;
+    const size_t need = 5 * mat + sizeof(float) * (size_t)N * (size_t)N + sizeof(double) * (size_t)ld * (4 * kTdNbb + kTdNb + 8 * 1024) +
+                        ((size_t)1 << 30);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
+      (void)hipGetLastError();
+      if (trace) fprintf(stderr, "[rvt] tridiag: %zu MB needed, %zu MB free: left to the Jacobi iteration\n", need >> 20, free_b >> 20);
+      return RVT_OK;
+    }
+  }
   HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
   HIP_TRY(c, hipMalloc((void**)&b.A, mat));
   HIP_TRY(c, hipMalloc((void**)&b.W, sizeof(double) * (size_t)ld * kTdNb));
@@ -408,9 +420,9 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
                          d_tau);
       if (j + 1 >= n) continue;
       const int i = j - j0;
-      const int nbt = nblk - (j + 1) / kSyT, n_tiles = nbt * (nbt + 1) / 2;
-      hipLaunchKernelGGL(td_symv_kernel, dim3((unsigned)(n_tiles + 2 * i)), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0,
-                         n_tiles, nbt, b.W, b.P, d_t12);
+      const int nbt = nblk - (j + 1) / kSyT, groups = (nbt + kSyRun - 1) / kSyRun;
+      hipLaunchKernelGGL(td_symv_kernel, dim3((unsigned)groups, (unsigned)(nbt + (2 * i + groups - 1) / groups)), dim3(256), 0, st, b.A,
+                         (long long)N, (long long)ld, j, j0, nbt, b.W, b.P, d_t12);
       hipLaunchKernelGGL(td_w_comb_kernel, dim3((unsigned)comb_blocks), dim3(256), 0, st, b.A, (long long)N, (long long)ld, j, j0,
                          b.W, b.P, nblk, d_t12, d_tau, d_part);
       hipLaunchKernelGGL(td_w_final_kernel, dim3(1), dim3(1024), 0, st, b.A, (long long)N, (long long)ld, j, j0, b.W, d_tau, d_part,

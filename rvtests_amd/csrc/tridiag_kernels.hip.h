@@ -114,17 +114,18 @@ static __global__ __launch_bounds__(1024) void td_col_house_kernel(double* __res
 // shares and B + 1 .. nblk from the column shares: every slot B0 .. nblk of P[.][i] is written in every step, and
 // td_w_comb_kernel adds them in slot order.  P: (nblk + 1) x ld.
 // The same launch computes the panel's dot products  t1[p] = W[:, p]' v,  t2[p] = V[:, p]' v  (p < i): workgroups behind the tiles.
-constexpr int kSyT = 64;
+constexpr int kSyT = 64, kSyRun = 4;
 static __global__ __launch_bounds__(256) void td_symv_kernel(const double* __restrict__ A, long long n, long long ld, int j, int j0,
-                                                       int n_tiles, int nbt, const double* __restrict__ W,
+                                                       int nbt, const double* __restrict__ W,
                                                        double* __restrict__ P, double* __restrict__ t12) {
   __shared__ double tile[kSyT][kSyT + 1];
   __shared__ double vr[kSyT], vc[kSyT];
   __shared__ double red[4];
   const double* v = A + (long long)j * ld;
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= n_tiles) {  // a column of the panel
-    const int i = j - j0, q = blockIdx.x - n_tiles;
+  if ((int)blockIdx.y >= nbt) {  // a column of the panel
+    const int i = j - j0, q = ((int)blockIdx.y - nbt) * (int)gridDim.x + (int)blockIdx.x;
+    if (q >= 2 * i) return;
     const double* col = q < i ? W + (long long)q * ld : A + (long long)(j0 + q - i) * ld;
     double sacc = 0.0;
     for (long long r = j + 1 + tid; r < n; r += 256) sacc = fma(col[r], v[r], sacc);
@@ -132,45 +133,50 @@ static __global__ __launch_bounds__(256) void td_symv_kernel(const double* __res
     if (tid == 0) t12[q < i ? q : kTdNb + (q - i)] = tot;
     return;
   }
-  // tile number -> (R, C), 0 <= C <= R < nbt, walking DOWN the column strips (id = C nbt - C (C - 1) / 2 + R - C): the
-  // workgroups resident at one time then read vertically adjacent tiles — runs of many KB of the same columns, not 512-byte
-  // pieces of a thousand different ones
-  const int id = blockIdx.x;
-  int C = (int)(((double)(2 * nbt + 1) - sqrt((double)(2 * nbt + 1) * (double)(2 * nbt + 1) - 8.0 * (double)id)) * 0.5);
-  if (C < 0) C = 0;
-  if (C > nbt - 1) C = nbt - 1;
-  while (C > 0 && C * nbt - C * (C - 1) / 2 > id) --C;
-  while (C + 1 < nbt && (C + 1) * nbt - (C + 1) * C / 2 <= id) ++C;
-  const int R = C + (id - (C * nbt - C * (C - 1) / 2));
-  const int B0 = (j + 1) / kSyT, Rb = B0 + R, Cb = B0 + C;
-  const long long r0 = (long long)Rb * kSyT, c0 = (long long)Cb * kSyT;
-  if (tid < kSyT) {
-    vr[tid] = (r0 + tid < n) ? v[r0 + tid] : 0.0;
-    vc[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
-  }
-  {  // 32 row pairs x 8 columns per pass (ld is a multiple of 64: the pair behind the last row reads zero pad rows)
-    const int rp = 2 * (tid & 31), cq = tid >> 5;
+  // A workgroup walks kSyRun tiles DOWN one column strip (C fixed, R = C + kSyRun g ...): the loads of the next tile are in
+  // flight while the shares of this one are computed.  grid (groups, strips): strip C holds nbt - C tiles.
+  const int C = blockIdx.y, L = nbt - C, first = kSyRun * (int)blockIdx.x;
+  if (first >= L) return;
+  const int last = (first + kSyRun < L ? first + kSyRun : L) - 1;
+  const int B0 = (j + 1) / kSyT, Cb = B0 + C;
+  const long long c0 = (long long)Cb * kSyT;
+  const int rp = 2 * (tid & 31), cq = tid >> 5;  // 32 row pairs x 8 columns per pass
+  double2 buf[8];
+  auto load = [&](int R) {  // (ld is a multiple of 64: the pair behind the last row reads zero pad rows)
+    const long long r0 = (long long)(B0 + R) * kSyT;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int c = cq + 8 * k;
-      double2 a = {0.0, 0.0};
-      if (c0 + c < n) a = *reinterpret_cast<const double2*>(A + (c0 + c) * ld + r0 + rp);
-      tile[rp][c] = a.x;
-      tile[rp + 1][c] = a.y;
+      buf[k] = double2{0.0, 0.0};
+      if (c0 + c < n) buf[k] = *reinterpret_cast<const double2*>(A + (c0 + c) * ld + r0 + rp);
     }
-  }
-  __syncthreads();
-  const bool diag = R == C;
-  if (tid < kSyT) {
-    const int r = tid, cend = diag ? r + 1 : kSyT;
-    double sacc = 0.0;
-    for (int c = 0; c < cend; ++c) sacc = fma(tile[r][c], vc[c], sacc);
-    if (r0 + r < n) P[(long long)Cb * ld + r0 + r] = sacc;
-  } else if (tid < 2 * kSyT) {
-    const int c = tid - kSyT, rbeg = diag ? c + 1 : 0;
-    double sacc = 0.0;
-    for (int r = rbeg; r < kSyT; ++r) sacc = fma(tile[r][c], vr[r], sacc);
-    if (c0 + c < n) P[(long long)(Rb + 1) * ld + c0 + c] = sacc;
+  };
+  load(C + first);
+  if (tid < kSyT) vc[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
+  for (int t = first; t <= last; ++t) {
+    const int R = C + t, Rb = B0 + R;
+    const long long r0 = (long long)Rb * kSyT;
+    if (tid < kSyT) vr[tid] = (r0 + tid < n) ? v[r0 + tid] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tile[rp][cq + 8 * k] = buf[k].x;
+      tile[rp + 1][cq + 8 * k] = buf[k].y;
+    }
+    __syncthreads();
+    if (t < last) load(R + 1);
+    const bool diag = R == C;
+    if (tid < kSyT) {
+      const int r = tid, cend = diag ? r + 1 : kSyT;
+      double sacc = 0.0;
+      for (int c = 0; c < cend; ++c) sacc = fma(tile[r][c], vc[c], sacc);
+      if (r0 + r < n) P[(long long)Cb * ld + r0 + r] = sacc;
+    } else if (tid < 2 * kSyT) {
+      const int c = tid - kSyT, rbeg = diag ? c + 1 : 0;
+      double sacc = 0.0;
+      for (int r = rbeg; r < kSyT; ++r) sacc = fma(tile[r][c], vr[r], sacc);
+      if (c0 + c < n) P[(long long)(Rb + 1) * ld + c0 + c] = sacc;
+    }
+    __syncthreads();
   }
 }
 
