@@ -441,10 +441,10 @@ int rvt_fam_binary_scale(rvt_ctx* ctx, int64_t n_case, int64_t n_ctrl, double* a
  * matrix as KinshipHolder::load fills it (column-major, symmetric), S_out (N) receives the eigenvalues in ASCENDING order
  * and U_out (N x N, column-major) the eigenvectors, as matS / matU hold them (either may be NULL).  install != 0 also
  * installs the decomposition for the family tests (as rvt_set_kinship would) without a round trip through host
- * memory.  A dense matrix of 128 <= N <= 48 000 whose eigenvalues are simple (no two closer than 1e-7 of the spectrum's
+ * memory.  A dense matrix of N >= 128 whose eigenvalues are simple (no two closer than 4e-9 of the spectrum's
  * width: a genetic relationship matrix) takes Householder tridiagonalisation + Sturm bisection + inverse iteration + the
- * matrix-core back-transformation (rvtests_amd/csrc/tridiag_kernels.hip.h; 40 N^2 bytes of device memory; sweeps = 0 in the
- * info), closed by a check of max |K u - lambda u| and |U'U - I| on the device; anything else — repeated eigenvalues, a failed
+ * matrix-core back-transformation (rvtests_amd/csrc/tridiag_kernels.hip.h; 20 N^2 bytes of device memory at the peak — it must be free, else the
+ * matrix goes to Jacobi; sweeps = 0 in the info), closed by a check of max |K u - lambda u| and |U'U - I| on the device; anything else — repeated eigenvalues, a failed
  * check, RVT_KINSHIP_JACOBI=1 — the fp64 one-sided block Jacobi iteration (rvtests_amd/csrc/jacobi_kernels.hip.h; 16 N^2 bytes).
  * Eigenvectors of repeated eigenvalues are an arbitrary orthonormal basis of their eigenspace — exactly as for any
  * eigensolver; every statistic of the family tests depends on U only through U f(S) U'. *

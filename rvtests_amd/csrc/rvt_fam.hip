@@ -382,11 +382,13 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   } b;
   const size_t mat = sizeof(double) * (size_t)ld * (size_t)N;
   {
-    // five N x N fp64 areas, the float matrix, the panels and the product's K slices: when the device cannot hold them (other
-    // contexts, a large block pool) the Jacobi iteration (16 N^2 bytes) gets the matrix instead of an allocation failure
+    // Peak: the matrix with its reflectors (A), the eigenvectors (Z) and the float matrix for the closing check — 20 N^2 bytes
+    // (the inverse iteration's factors are kept for a batch of eigenvectors at a time and the check's fp64 copy of K re-uses A).
+    // When the device cannot hold that (other contexts, a large block pool) the Jacobi iteration (16 N^2 bytes) gets the matrix
+    // instead of an allocation failure.
     size_t free_b = 0, total_b = 0;
-    const size_t need = 5 * mat + sizeof(float) * (size_t)N * (size_t)N + sizeof(double) * (size_t)ld * (4 * kTdNbb + kTdNb + 8 * 1024) +
-                        ((size_t)1 << 30);
+    const size_t need = 2 * mat + sizeof(float) * (size_t)N * (size_t)N + sizeof(double) * (size_t)ld * (4 * kTdNbb + kTdNb + 16 * 1024) +
+                        ((size_t)2 << 30);
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
       (void)hipGetLastError();
       if (trace) fprintf(stderr, "[rvt] tridiag: %zu MB needed, %zu MB free: left to the Jacobi iteration\n", need >> 20, free_b >> 20);
@@ -396,18 +398,19 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
   HIP_TRY(c, hipMalloc((void**)&b.A, mat));
   HIP_TRY(c, hipMalloc((void**)&b.W, sizeof(double) * (size_t)ld * kTdNb));
-  // vec: d | e | tau | y | t12 (2 kTdNb) | partial dots (1024) | scaled d | scaled e^2 | lambda
+  // vec: d | e | tau | y | t12 (2 kTdNb) | partial dots | scaled d | scaled e^2 | lambda
   const int64_t vs = std::max<int64_t>(ld, 1024);  // (y doubles as the panel's Gram matrix later)
-  const size_t nv = 7 * (size_t)vs + 2 * kTdNb + 1024;
+  const int comb_blocks = (int)((N + 63) / 64);                   // workgroups of td_w_comb_kernel = partial dots per column
+  const int64_t n_part = std::max<int64_t>(1024, comb_blocks);
+  const size_t nv = 7 * (size_t)vs + 2 * kTdNb + (size_t)n_part;
   HIP_TRY(c, hipMalloc((void**)&b.vec, sizeof(double) * nv));
   HIP_TRY(c, hipMemsetAsync(b.vec, 0, sizeof(double) * nv, st));
   HIP_TRY(c, hipMemsetAsync(b.W, 0, sizeof(double) * (size_t)ld * kTdNb, st));
   double *d_d = b.vec, *d_e = d_d + vs, *d_tau = d_e + vs, *d_y = d_tau + vs, *d_t12 = d_y + vs, *d_part = d_t12 + 2 * kTdNb, *d_ss = d_y,
-         *d_ds = d_part + 1024, *d_e2s = d_ds + vs, *d_lam = d_e2s + vs;
+         *d_ds = d_part + n_part, *d_e2s = d_ds + vs, *d_lam = d_e2s + vs;
   HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.A);
   // 1. K = Q T Q'
-  const int comb_blocks = (int)((N + 63) / 64);  // (<= 750 partial dots at N = 48 000: d_part holds 1024)
   const int nblk = (int)((N + kSyT - 1) / kSyT);  // 64-row blocks of the matrix; P: the (nblk + 1) x ld partial products of a column step
   HIP_TRY(c, hipMalloc((void**)&b.P, sizeof(double) * (size_t)(nblk + 1) * (size_t)ld));
   for (int j0 = 0; j0 < n; j0 += kTdNb) {
@@ -479,18 +482,31 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   for (int64_t j = 1; j < N; ++j) min_gap = std::min(min_gap, lam[j] - lam[j - 1]);
   if (trace) fprintf(stderr, "[rvt] tridiag: N %lld, reduction %.3f s, eigenvalues %.3f s, smallest gap %.3g of %.3g\n", (long long)N,
                      t_tri - t_start, t_eig - t_tri, min_gap, span0);
-  if (!(min_gap > 1e-7 * span0)) return RVT_OK;
-  // 3. eigenvectors of T
-  HIP_TRY(c, hipMalloc((void**)&b.B1, mat));
+  // neighbours a gap g apart come out orthogonal to ~ eps |T| / g: 4e-9 of the norm promises 6e-8, float rounding of the U the
+  // boundary stores (the closing check below holds the result to 1e-7 whatever this predicts)
+  if (!(min_gap > 4e-9 * span0)) return RVT_OK;
+  // 3. eigenvectors of T, a batch of columns at a time (the factors of a batch: three [row][eigenvector] arrays + the vectors)
   HIP_TRY(c, hipMalloc((void**)&b.B2, mat));
-  HIP_TRY(c, hipMalloc((void**)&b.B3, mat));
-  HIP_TRY(c, hipMalloc((void**)&b.B4, mat));
-  hipLaunchKernelGGL(td_invit_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, d_d, d_e, n, d_lam, (long long)ld,
-                     kDblEps * span0, b.B2, b.B3, b.B4, b.B1);
-  HIP_TRY(c, hipMemsetAsync(b.B2, 0, mat, st));  // (behind the kernel in the stream)
+  HIP_TRY(c, hipMemsetAsync(b.B2, 0, mat, st));
   {
-    const unsigned t32 = (unsigned)((N + 31) / 32);
-    hipLaunchKernelGGL(td_transpose_kernel, dim3(t32, t32), dim3(256), 0, st, b.B1, (long long)ld, n, (long long)ld, b.B2);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    int64_t nkb = (int64_t)((free_b / 2) / (4 * sizeof(double) * (size_t)ld)) / 64 * 64;  // half of what is free
+    nkb = std::max<int64_t>(64, std::min<int64_t>(nkb, ld));
+    const size_t arr = sizeof(double) * (size_t)ld * (size_t)nkb;
+    HIP_TRY(c, hipMalloc((void**)&b.B1, 4 * arr));
+    double *zt = b.B1, *ud = zt + (size_t)ld * nkb, *uu = ud + (size_t)ld * nkb, *uw = uu + (size_t)ld * nkb;
+    for (int64_t k0 = 0; k0 < N; k0 += nkb) {
+      const int nk = (int)std::min<int64_t>(nkb, N - k0);
+      hipLaunchKernelGGL(td_invit_kernel, dim3((unsigned)((nk + 63) / 64)), dim3(64), 0, st, d_d, d_e, n, d_lam + k0, nk, (long long)k0, (long long)nkb,
+                         kDblEps * span0, ud, uu, uw, zt);
+      hipLaunchKernelGGL(td_transpose_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((nk + 31) / 32)), dim3(256), 0, st, zt,
+                         (long long)nkb, n, nk, (long long)ld, b.B2 + (size_t)k0 * ld);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, sync_stream(st));
+    hipFree(b.B1);
+    b.B1 = nullptr;
   }
   double* Z = b.B2;
   HIP_TRY(c, hipGetLastError());
@@ -522,13 +538,22 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   // 5. the closing check: max |K u - lambda u|, max |U'U - I|, in column batches (the product's K slices need room)
   HIP_TRY(c, hipMalloc((void**)&b.worst, 2 * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(b.worst, 0, 2 * sizeof(unsigned long long), st));
+  // (the reflectors are not needed any more: A takes the fp64 copy of K; the float upload is freed behind the conversion)
+  for (double** q : {&b.cz, &b.yy, &b.W, &b.P}) {
+    if (*q) hipFree(*q);
+    *q = nullptr;
+  }
   HIP_TRY(c, hipMalloc((void**)&b.dK, sizeof(float) * (size_t)N * (size_t)N));
   HIP_TRY(c, hipMemcpyAsync(b.dK, K, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.B1);
+  hipLaunchKernelGGL(td_init_kernel, dim3(4096), dim3(256), 0, st, b.dK, (long long)N, (long long)ld, b.A);
+  HIP_TRY(c, sync_stream(st));
+  hipFree(b.dK);
+  b.dK = nullptr;
   constexpr int kBatch = 1024;
+  HIP_TRY(c, hipMalloc((void**)&b.B3, sizeof(double) * (size_t)ld * kBatch));
   for (int k0 = 0; k0 < n; k0 += kBatch) {
     const int nk = std::min(kBatch, n - k0);
-    int rc = gemm_tn_f64(c, b.B1, ld, n, Z + (size_t)k0 * ld, ld, nk, nullptr, 0, 0, nullptr, ld, b.B3, ld, false, st);
+    int rc = gemm_tn_f64(c, b.A, ld, n, Z + (size_t)k0 * ld, ld, nk, nullptr, 0, 0, nullptr, ld, b.B3, ld, false, st);
     if (rc) return rc;
     hipLaunchKernelGGL(td_residual_kernel, dim3((unsigned)nk), dim3(256), 0, st, b.B3, (long long)ld, Z + (size_t)k0 * ld,
                        (long long)ld, n, d_lam + k0, b.worst);
@@ -549,10 +574,19 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   if (!(resid <= 1e-9 * mu) || !(orth <= 1e-7)) return RVT_OK;  // (mu = 4 x a bound on the spectral radius; Jacobi's own bar)
   std::vector<float> S((size_t)N);
   for (int64_t j = 0; j < N; ++j) S[j] = (float)lam[j];
+  hipFree(b.A);
+  b.A = nullptr;
   HIP_TRY(c, hipMalloc((void**)&b.dU, sizeof(float) * (size_t)N * (size_t)N));
   hipLaunchKernelGGL(td_to_float_kernel, dim3(4096), dim3(256), 0, st, Z, (long long)ld, (long long)N, b.dU);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_stream(st));
+  hipFree(b.B2);  // (Z: the installation below needs room for the digit planes of U)
+  b.B2 = nullptr;
+  if (c->d_rot_part) {  // (the K slices of the check's products: GBs at this size)
+    hipFree(c->d_rot_part);
+    c->d_rot_part = nullptr;
+    c->rot_part_cap = 0;
+  }
   if (U_out) HIP_TRY(c, hipMemcpy(U_out, b.dU, sizeof(float) * (size_t)N * (size_t)N, hipMemcpyDeviceToHost));
   if (S_out) std::memcpy(S_out, S.data(), sizeof(float) * (size_t)N);
   if (info) {
@@ -635,9 +669,9 @@ int rvt_kinship_decompose(rvt_ctx* c, int64_t N, const float* K, float* U_out, f
     if (sparse_pattern) rc = decompose_by_family(c, N, K, edges, mu, np, U_out, S_out, install, info, &done);
     if (rc || done) return rc;
   }
-  // a dense matrix of a size whose five N x N fp64 work areas fit: tridiagonalisation + bisection + inverse iteration;
+  // a dense matrix whose work areas fit (20 N^2 bytes at the peak): tridiagonalisation + bisection + inverse iteration;
   // repeated eigenvalues (and anything that fails its closing check) fall through to the Jacobi iteration
-  if (!getenv("RVT_KINSHIP_JACOBI") && N >= 128 && N <= 48000) {
+  if (!getenv("RVT_KINSHIP_JACOBI") && N >= 128) {
     bool done = false;
     rc = decompose_dense_tridiag(c, N, K, mu, U_out, S_out, install, info, &done);
     if (rc || done) return rc;

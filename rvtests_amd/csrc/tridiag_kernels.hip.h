@@ -12,7 +12,7 @@
 //   2. The eigenvalues of T by the Sturm bisection + interpolation of rvt_coop.h, one thread per eigenvalue.
 //   3. The eigenvectors of T by inverse iteration, one thread per eigenvector (tridiagonal LU with partial pivoting, three
 //      solves), WITHOUT reorthogonalisation: the vectors of eigenvalues a gap g apart are orthogonal to ~eps / g, and the
-//      boundary stores U as FLOAT (EigenMatrix = Eigen::MatrixXf) — a gap of 1e-7 of the spectrum's width is enough.  A matrix
+//      boundary stores U as FLOAT (EigenMatrix = Eigen::MatrixXf) — a gap of 4e-9 of the spectrum's width is enough.  A matrix
 //      with a tighter cluster (repeated eigenvalues: pedigree kinships, rank-deficient matrices) is left to the Jacobi
 //      iteration, which does not care; so is a result that fails the residual / orthogonality check that closes the procedure.
 //   4. U = Q Z: the reflectors applied 256 at a time in compact WY form, Z <- Z - V (T (V'Z)); V'Z, V'V and the rank-256 update
@@ -288,16 +288,17 @@ static __global__ __launch_bounds__(64) void td_eigvals_kernel(const double* __r
 // Inverse iteration, one thread per eigenvector k: (T - lam_k I) z = b by LU with partial pivoting, three times; the rows of
 // the factor and the vector live in [row][k] arrays (nk = padded count: consecutive threads touch consecutive doubles).
 // zt[i * nk + k] = component i of eigenvector k, 2-norm 1.
+// (lam: the nv eigenvalues of this launch, a batch of the spectrum)
 static __global__ __launch_bounds__(64) void td_invit_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
-                                                      const double* __restrict__ lam, long long nk, double pert,
+                                                      const double* __restrict__ lam, int nv, long long k_first, long long nk, double pert,
                                                       double* __restrict__ ud, double* __restrict__ uu, double* __restrict__ uw,
                                                       double* __restrict__ zt) {
   const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (k >= n) return;
+  if (k >= nv) return;
   const double l = lam[k];
   // start vector: deterministic, no zero component, not aligned with anything in particular
   for (int i = 0; i < n; ++i) {
-    unsigned h = (unsigned)i * 2654435761u ^ ((unsigned)k * 40503u + 0x9E3779B9u);
+    unsigned h = (unsigned)i * 2654435761u ^ ((unsigned)(k_first + k) * 40503u + 0x9E3779B9u);  // (the eigenvector's number in the spectrum: batch sizes do not change the result)
     h ^= h >> 15;
     h *= 2246822519u;
     h ^= h >> 13;
@@ -362,21 +363,21 @@ static __global__ __launch_bounds__(64) void td_invit_kernel(const double* __res
   }
 }
 
-// zc[i + k * ld] = zt[i * nk + k]   (32 x 32 tiles through LDS)
-static __global__ __launch_bounds__(256) void td_transpose_kernel(const double* __restrict__ zt, long long nk, int n, long long ld,
-                                                            double* __restrict__ zc) {
+// zc[i + k * ld] = zt[i * nk + k]   for i < n, k < nv   (32 x 32 tiles through LDS; grid (n / 32, nv / 32))
+static __global__ __launch_bounds__(256) void td_transpose_kernel(const double* __restrict__ zt, long long nk, int n, int nv,
+                                                            long long ld, double* __restrict__ zc) {
   __shared__ double tile[32][33];
   const long long i0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
   for (int t = threadIdx.x; t < 1024; t += 256) {
     const int a = t / 32, b = t % 32;  // a: row i, b: column k (k fastest in zt)
     const long long i = i0 + a, k = k0 + b;
-    tile[a][b] = (i < n && k < n) ? zt[i * nk + k] : 0.0;
+    tile[a][b] = (i < n && k < nv) ? zt[i * nk + k] : 0.0;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < 1024; t += 256) {
     const int b = t / 32, a = t % 32;  // a fastest: row i contiguous in zc
     const long long i = i0 + a, k = k0 + b;
-    if (i < n && k < n) zc[k * ld + i] = tile[a][b];
+    if (i < n && k < nv) zc[k * ld + i] = tile[a][b];
   }
 }
 

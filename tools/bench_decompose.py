@@ -24,6 +24,19 @@ if args.kind == "family":
     K = np.zeros((N, N), dtype=np.float32, order="F")
     for f in range(N // 4):
         K[4 * f:4 * f + 4, 4 * f:4 * f + 4] = blk
+elif args.kind == "lowrank":
+    # a dense matrix that is cheap to make at N = 100 000 (the GRM below needs an N x 2N factor): an equally spaced diagonal
+    # plus a dense rank-64 term of the same size — eigenvalues interlace the diagonal's, no clusters; filled a block of columns at a time
+    Z = rng.standard_normal((N, 64)).astype(np.float32)
+    K = np.zeros((N, N), dtype=np.float32, order="F")
+    for c0 in range(0, N, 4096):
+        c1 = min(N, c0 + 4096)
+        K[:, c0:c1] = (Z @ Z[c0:c1].T) / np.float32(N)
+    K[np.arange(N), np.arange(N)] += np.linspace(0.5, 1.5, N, dtype=np.float32)
+    for c0 in range(0, N, 4096):                     # exact symmetry (the product is symmetric only to rounding)
+        c1 = min(N, c0 + 4096)
+        blk = K[c0:c1, :c1].copy()
+        K[:c1, c0:c1] = blk.T
 else:
     Z = rng.standard_normal((N, 2 * N)).astype(np.float32)
     K = np.asfortranarray((Z @ Z.T) / np.float32(2 * N))
@@ -34,7 +47,7 @@ if args.install:
     eng.kinship_decompose(K, install=True, want_vectors=False)
     dt = time.perf_counter() - t0
     print(json.dumps({"N": N, "kind": args.kind, "seconds_decompose_and_install": dt,
-                      "rotation_visits": eng.kinship_structure()}))
+                      "rotation_visits": eng.kinship_structure()}), flush=True)
     eng.close()
     sys.exit(0)
 t0 = time.perf_counter()

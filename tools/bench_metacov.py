@@ -59,8 +59,8 @@ def main():
     ap.add_argument("--samples", type=int, default=500000)
     ap.add_argument("--variants", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--window", default="200,1000", help="comma-separated window widths (markers) of the stream runs; empty = none")
-    ap.add_argument("--stream", type=int, default=8192, help="variants of a stream run")
+    ap.add_argument("--window", default="200,1000,3000", help="comma-separated window widths (markers) of the stream runs; empty = none")
+    ap.add_argument("--stream", type=int, default=16384, help="variants of a stream run")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")

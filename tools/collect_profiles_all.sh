@@ -24,6 +24,9 @@ stats stream_bed python3 tools/bench_stream.py --bed --genes 512
 python3 tools/bench_decompose.py --samples 3000 --kind grm > "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 12000 --kind family >> "$OUT/decompose.txt" 2>&1
 python3 tools/bench_decompose.py --samples 100000 --kind family --install >> "$OUT/decompose.txt" 2>&1
+# a dense GRM through the tridiagonal form (phase times on stderr), with the numpy CPU baseline
+RVT_TRIDIAG_TRACE=1 python3 tools/bench_decompose.py --samples 12000 --kind grm 2>&1 | grep "^{\|^\[rvt\]" > "$OUT/decompose_dense.txt"
+RVT_TRIDIAG_TRACE=1 python3 tools/bench_decompose.py --samples 24000 --kind grm 2>&1 | grep "^{\|^\[rvt\]" >> "$OUT/decompose_dense.txt"
 for t in k2hc_bench k2hcw_bench k2lat_bench rotgemm_bench gemm64_bench; do  # micro-benchmarks: built here when the snapshot has no binary
   [ -x tools/$t ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/$t.hip -o tools/$t > "$OUT/build_$t.log" 2>&1
 done
@@ -46,6 +49,7 @@ python3 tools/bench_perm.py --genes 1 --exact >> "$OUT/perm_result.txt" 2>&1
 python3 tools/bench_group_stream.py > "$OUT/group_stream.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --missing-frac 1.0 > "$OUT/bench_missing_all.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1 > "$OUT/bench_config1.json" 2>/dev/null
+python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-from-host --samples 50000 --m-lo 30 --m-hi 30 --genes 1024 --tests 1 > "$OUT/bench_config1_100steps.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --trait binary --samples 200000 > "$OUT/bench_config3_binary.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-from-host --dosage > "$OUT/bench_dosage.json" 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --dosage --dosage-lattice 0 > "$OUT/bench_dosage_fp64.json" 2>/dev/null
