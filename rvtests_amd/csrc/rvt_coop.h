@@ -254,7 +254,12 @@ RVT_HD double sturm_eigenvalue(const double* d, const double* e2, int n, int idx
 // that a row multiplies the Sturm pair by at most 3, and e becomes max(e^2, 2^-200) — a floor of 2^-100 of the span on the
 // coupling, 15 orders below rounding, which bounds how fast the pair can shrink (two rows between rescalings stay some 500
 // binary orders clear of underflow).
-RVT_HD void coop_tridiag_eigvals(const Coop& co, double* d, double* e, int n, double* out) {
+// (the two halves separately: rvt_gene.h looks at the scaled form before it decides whether the eigenvalues are needed)
+struct TridiagScale {
+  double lo, hi, span;
+  int sh;
+};
+RVT_HD TridiagScale coop_tridiag_scale(const Coop& co, double* d, double* e, int n) {
   // Gershgorin interval (every thread computes the same numbers)
   double lo = d[0], hi = d[0];
   for (int j = 0; j < n; ++j) {
@@ -277,17 +282,29 @@ RVT_HD void coop_tridiag_eigvals(const Coop& co, double* d, double* e, int n, do
   hi = ldexp(hi, -sh);
   const double span = fmax(fabs(lo), fabs(hi));  // in [1/2, 1), or 0 for the zero matrix
   const double pivmin = DBL_MIN * 1024.0;
-  lo -= 2.0 * kDblEps * span * n + 2.0 * pivmin;
-  hi += 2.0 * kDblEps * span * n + 2.0 * pivmin;
+  TridiagScale ts;
+  ts.lo = lo - (2.0 * kDblEps * span * n + 2.0 * pivmin);
+  ts.hi = hi + (2.0 * kDblEps * span * n + 2.0 * pivmin);
+  ts.span = span;
+  ts.sh = sh;
   co.sync();
+  return ts;
+}
+RVT_HD void coop_tridiag_eigvals_scaled(const Coop& co, const double* d, const double* e2, int n, const TridiagScale& ts,
+                                        double* out) {
+  const double pivmin = DBL_MIN * 1024.0;
   for (int idx = co.tid; idx < n; idx += co.nt) {
     // eigenvalue number idx (0 = smallest): largest x with count(x) <= idx
     // (relative for eigenvalues of the matrix's own size; never finer than 2^-62 of the span — 2^-10 of the rounding
     //  the tridiagonal form itself carries: an eigenvalue that is zero to rounding stops after ~62 halvings, not 200)
-    const double ev = sturm_eigenvalue(d, e, n, idx, lo, hi, span, pivmin);
-    out[idx] = ldexp(ev, sh);
+    const double ev = sturm_eigenvalue(d, e2, n, idx, ts.lo, ts.hi, ts.span, pivmin);
+    out[idx] = ldexp(ev, ts.sh);
   }
   co.sync();
+}
+RVT_HD void coop_tridiag_eigvals(const Coop& co, double* d, double* e, int n, double* out) {
+  const TridiagScale ts = coop_tridiag_scale(co, d, e, n);
+  coop_tridiag_eigvals_scaled(co, d, e, n, ts, out);
 }
 
 // eigenvalues (ascending) of the symmetric n x n matrix in A (column-major; destroyed)

@@ -571,6 +571,38 @@ RVT_HD void gene_tridiag(const Coop& co, const NullConsts& nc, int which, int M,
   co.sync();
 }
 
+// Moments of a rho problem WITHOUT its eigenvalues (round 5).  The reference uses the eigenvalues of L'AL only through their
+// power sums (getMoment, SkatO.cpp:383-418) after dropping those below t = mean(positive) / 1e5 (getEigen, :350-382) — and the
+// power sums of ALL eigenvalues are traces of powers of the tridiagonal form, O(m) sums of its entries.  They are the
+// reference's sums whenever what the filter drops is rounding, which three Sturm counts certify: no eigenvalue in
+// [x_lo, x_hi), x_lo = 1e-13 tr, x_hi = tr / 1e5 (t lies in (x_lo, x_hi] whatever sign the zero-level eigenvalues take: at
+// least one of the m eigenvalues counts as positive, at most all), none below -x_lo.  Then the dropped ones change a sum by
+// less than m 1e-13 of it.  Otherwise (false) the caller computes the eigenvalues and filters them as the reference does.
+// d, e2: the SCALED tridiagonal (by 2^-sh; couplings squared and floored) of coop_tridiag_scale / gene_spectrum_all's stage C.
+RVT_HD bool skato_moment_by_trace(const double* d, const double* e2, int n, int sh, SkatoMoment* mo) {
+  double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double di = d[i], d2 = di * di;
+    p1 += di;
+    p2 += d2;
+    p3 += d2 * di;
+    p4 += d2 * d2;
+    if (i < n - 1) {
+      const double q = e2[i], dn = d[i + 1];
+      p2 += 2.0 * q;
+      p3 += 3.0 * q * (di + dn);
+      p4 += 4.0 * q * (d2 + di * dn + dn * dn) + 2.0 * q * q;
+      if (i < n - 2) p4 += 4.0 * q * e2[i + 1];
+    }
+  }
+  if (!(p1 > 0.0) || !(p2 > 0.0)) return false;
+  const double x_hi = p1 * 1e-5, x_lo = p1 * 1e-13;
+  const int c_hi = sturm_count(d, e2, n, x_hi), c_lo = sturm_count(d, e2, n, x_lo), c_neg = sturm_count(d, e2, n, -x_lo);
+  if (c_hi != c_lo || c_neg != 0 || c_hi >= n) return false;
+  *mo = skato_moment_from_sums(ldexp(p1, sh), ldexp(p2, 2 * sh), ldexp(p3, 3 * sh), ldexp(p4, 4 * sh));
+  return true;
+}
+
 // Stage B2 (one workgroup per gene AND eigenproblem k): the k-th tridiagonal from stage B1's, bisection for all
 // eigenvalues, the reference's eigenvalue filter and moments.  `vec` >= 4*m doubles.
 RVT_HD void gene_spectrum(const Coop& co, const NullConsts& nc, int k, int M, int Mp, unsigned tests, GeneScratch ws,
@@ -645,7 +677,21 @@ RVT_HD void gene_spectrum(const Coop& co, const NullConsts& nc, int k, int M, in
       }
     }
     co.sync();
-    coop_tridiag_eigvals(co, td, te, n, ev);
+    const TridiagScale ts = coop_tridiag_scale(co, td, te, n);
+    if (!is_skat && k != 11) {  // a rho problem: its moments from the traces when the filter provably drops rounding only
+      SkatoMoment mo;
+      if (skato_moment_by_trace(td, te, n, ts.sh, &mo)) {  // (every thread computes the same answer)
+        if (co.tid == 0) {
+          out->mom_mu[k] = mo.muQ;
+          out->mom_var[k] = mo.varQ;
+          out->mom_df[k] = mo.df;
+          out->eig_ok[k] = 1;
+        }
+        co.sync();
+        return;
+      }
+    }
+    coop_tridiag_eigvals_scaled(co, td, te, n, ts, ev);
   }
   if (co.tid == 0) {
     if (is_skat) {
@@ -799,10 +845,25 @@ RVT_HD void gene_spectrum_all(const Coop& co, const NullConsts& nc, int M, int M
     }
   }
   co.sync();
+  // ---- C2: the rho problems, one thread each: moments from the traces of the tridiagonal's powers when the reference's
+  //      filter provably drops rounding only (skato_moment_by_trace) — such a problem (active = 2) needs no eigenvalues
+  for (int k = co.tid; k < 11; k += co.nt) {
+    if (meta[k].active != 1) continue;
+    const double* d = vec + (size_t)k * 3 * m;
+    SkatoMoment mo;
+    if (skato_moment_by_trace(d, d + m, meta[k].n, meta[k].sh, &mo)) {
+      out->mom_mu[k] = mo.muQ;
+      out->mom_var[k] = mo.varQ;
+      out->mom_df[k] = mo.df;
+      out->eig_ok[k] = 1;
+      meta[k].active = 2;
+    }
+  }
+  co.sync();
   // ---- D: the (problem, eigenvalue) tasks, strided over the lanes
   int off[kNEigen + 1];
   off[0] = 0;
-  for (int k = 0; k < kNEigen; ++k) off[k + 1] = off[k] + (meta[k].active ? meta[k].n : 0);
+  for (int k = 0; k < kNEigen; ++k) off[k + 1] = off[k] + (meta[k].active == 1 ? meta[k].n : 0);
   for (int t = co.tid; t < off[kNEigen]; t += co.nt) {
     int k = 0;
     while (t >= off[k + 1]) ++k;
@@ -819,6 +880,7 @@ RVT_HD void gene_spectrum_all(const Coop& co, const NullConsts& nc, int M, int M
       out->eig_ok[k] = 0;  // (k == 11 with 1'A1 <= 0)
       continue;
     }
+    if (meta[k].active == 2) continue;  // (stage C2 wrote the moments)
     const int n = meta[k].n;
     const double* ev = vec + (size_t)k * 3 * m + 2 * m;
     double* tmpv = vec + (size_t)k * 3 * m;

@@ -16,15 +16,8 @@ struct SkatoMoment {
 };
 
 // SkatOImpl::getMoment       (regression/SkatO.cpp:383-418)
-RVT_HD SkatoMoment skato_moment(const double* la, int n) {
-  double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  for (int i = 0; i < n; ++i) {
-    const double l = la[i], l2 = l * l;
-    c0 += l;
-    c1 += l2;
-    c2 += l2 * l;
-    c3 += l2 * l2;
-  }
+// (from the power sums c0..c3 = sum lambda^1..4)
+RVT_HD SkatoMoment skato_moment_from_sums(double c0, double c1, double c2, double c3) {
   SkatoMoment m;
   m.muQ = c0;
   const double sigmaQ = sqrt(2 * c1);
@@ -41,6 +34,17 @@ RVT_HD SkatoMoment skato_moment(const double* la, int n) {
   m.varQ = sigmaQ * sigmaQ;
   m.df = l;
   return m;
+}
+RVT_HD SkatoMoment skato_moment(const double* la, int n) {
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (int i = 0; i < n; ++i) {
+    const double l = la[i], l2 = l * l;
+    c0 += l;
+    c1 += l2;
+    c2 += l2 * l;
+    c3 += l2 * l2;
+  }
+  return skato_moment_from_sums(c0, c1, c2, c3);
 }
 
 // getPvalByMoment / getQvalByMoment       (regression/SkatO.cpp:420-435)
