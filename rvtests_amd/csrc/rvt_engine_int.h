@@ -282,7 +282,9 @@ struct rvt_ctx {
   NullTileF fdx_tile;
   bool fdx_ok = false;
   bool dosage_float = false;  // rvt_set_dosage_float: blocks of unknown content hold float-precision dosages
-  int as_threads = 1024;  // workgroup size of gene_assemble_kernel (RVT_AS_THREADS)
+  int as_threads = 256;   // workgroup size of gene_assemble_kernel (RVT_AS_THREADS).  Round 5: 256 instead of 1024 — many of its phases
+                          // keep M threads busy while the rest wait at the barriers, and with the eigenvalue stage cut down its
+                          // resident waves were 56 % of the per-gene tail (configs[1]: 347 k -> 369 k; the other shapes unchanged)
   bool hcx_fused = true;  // one launch for every tile class of a batch (gene_suffstat_hcx_any); RVT_HCX_FUSED=0: one per class
   int64_t null_ld = 0;
   // Which sufficient-statistics kernel a gene STARTS on is a prediction, never a trust: the hard-call kernel tests every
