@@ -129,33 +129,37 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
   const int ldr = Cp;
   double* R = ws.R;
   // ---- 1. reduce the partial statistics (fixed order => deterministic) ----------------------------
-  for (int idx = co.tid; idx < Mp * Cp; idx += co.nt) {
-    const int i = idx / Cp, j = idx % Cp;
-    double s = 0.0;
-    if ((j >> 4) >= (i >> 4)) {
-      // fixed order p = 0..P-1 (bit-reproducible); loads are independent, so keep many in flight
-      const double* src = parts + idx;
-      const size_t stride = (size_t)Mp * Cp;
-      int p = 0;
-      for (; p + 8 <= P; p += 8) {
-        const double a0 = src[(size_t)(p + 0) * stride], a1 = src[(size_t)(p + 1) * stride],
-                     a2 = src[(size_t)(p + 2) * stride], a3 = src[(size_t)(p + 3) * stride],
-                     a4 = src[(size_t)(p + 4) * stride], a5 = src[(size_t)(p + 5) * stride],
-                     a6 = src[(size_t)(p + 6) * stride], a7 = src[(size_t)(p + 7) * stride];
-        s += a0;
-        s += a1;
-        s += a2;
-        s += a3;
-        s += a4;
-        s += a5;
-        s += a6;
-        s += a7;
+  // (eight entries per thread and pass: their 8 P loads are independent and in flight together — with one entry per pass a
+  //  thread waited out P round trips to HBM per entry; the order of the sum over p is unchanged: bit-reproducible)
+  {
+    const int total = Mp * Cp;
+    const size_t stride = (size_t)Mp * Cp;
+    const double lat2 = (hcm && hcm->lat_den > 0.0) ? hcm->lat_den * hcm->lat_den : 0.0;
+    for (int idx0 = co.tid; idx0 < total; idx0 += 8 * co.nt) {
+      double s8[8];
+      bool use[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + u * co.nt;
+        s8[u] = 0.0;
+        use[u] = idx < total && ((idx % Cp) >> 4) >= ((idx / Cp) >> 4);
       }
-      for (; p < P; ++p) s += src[(size_t)p * stride];
-      // lattice dosages: the sum of the integer tiles K'K is exact; G'G = K'K / den^2 with one rounding
-      if (hcm && hcm->lat_den > 0.0 && j < M) s /= hcm->lat_den * hcm->lat_den;
+      for (int p = 0; p < P; ++p) {
+        const double* src = parts + (size_t)p * stride;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (use[u]) s8[u] += src[idx0 + u * co.nt];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + u * co.nt;
+        if (idx >= total) continue;
+        double sv = s8[u];
+        // lattice dosages: the sum of the integer tiles K'K is exact; G'G = K'K / den^2 with one rounding
+        if (use[u] && lat2 > 0.0 && (idx % Cp) < M) sv /= lat2;
+        R[idx] = sv;
+      }
     }
-    R[idx] = s;
   }
   double* colsum = ws.vecs;         // [Mp]
   double* cmin = ws.vecs + Mp;      // [Mp]
