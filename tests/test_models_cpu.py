@@ -102,6 +102,29 @@ def test_device_algorithms_on_host_match_oracle(seed):
                 assert abs(p - b.pvalue) <= 1e-6 * b.pvalue
 
 
+@pytest.mark.parametrize("eps", [0.0, 1e-9, 3e-5, 2e-3, 0.3])
+def test_skato_rho_moments_with_nearly_collinear_columns(eps):
+    """The moments of the rho problems come from the traces of the tridiagonal form's powers when the reference's eigenvalue
+    filter (getEigen: below mean / 1e5) provably drops rounding only, certified by Sturm counts (skato_moment_by_trace); an
+    eigenvalue between rounding and the threshold sends the problem to the eigenvalues and the filter itself.  A column that
+    duplicates another one up to eps * noise puts the smallest eigenvalue at ~eps^2 of the others: exactly zero (certified:
+    rounding), 1e-18 (certified), 1e-9 (inside the band: falls back), 4e-6 (just below the threshold: falls back), 0.1 (kept)."""
+    rng = np.random.default_rng(77)
+    N, M, d = 400, 7, 2
+    Graw, G, af = synth.make_gene(N, M, 5, missing=0.0, common=True, mono=False, maf_hi=-0.8)
+    G = G.copy()
+    G[:, M - 1] = G[:, 0] + eps * rng.normal(size=N) * (G[:, 0] > 0)
+    af = af.copy()
+    af[M - 1] = af[0]
+    X, y, res, v, s2 = synth.make_null(N, d, 0, 5, G_effect=0.4 * G[:, :3].sum(1))
+    out, flip, kept, lam = hc.gene(G, af, X, res, v, 0, s2)
+    rc2, o = orc.skato(G, af, X, res, v, 0)
+    assert rc2 == 0 and out.skato_ok == 1
+    assert abs(out.skato_Q - o.Q) <= 1e-10 * abs(o.Q) and out.skato_rho == o.rho
+    assert abs(out.skato_p - o.pvalue) <= 1e-9 * o.pvalue + 5e-13
+    assert out.skato_qags_neval == o.qags_neval
+
+
 def test_data_consolidator_semantics():
     """impute-to-mean with the integer-truncated allele count, AF with missing in the denominator, flip rule
     s <= N keeps, monomorphic rule, (int)g > 0 collapsing (SURVEY Appendix B #4-6, #14)."""
