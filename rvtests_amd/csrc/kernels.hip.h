@@ -1736,6 +1736,19 @@ __global__ __launch_bounds__(64, FAST ? RVT_PV_WAVES : 2) void gene_pvalue_kerne
   out->famskat_p = (double)(tk_b - tk_a);            //   per-rho tails
   out->famcmc_af = (double)(tk_c - tk_b);            //   min-p, quantiles, Liu moments
   out->famzeg_af = (double)(tk_start - tk_c);        //   the two preludes
+  {  // gene_assemble's phases (its own clock readings, left in the gene's statistics)
+    const double* at = gd.stats->as_ticks;
+    out->vt_minmaf = at[1] - at[0];
+    out->vt_maxmaf = at[2] - at[1];
+    out->vt_optmaf = at[3] - at[2];
+    out->vt_U = at[4] - at[3];
+    out->vt_V = at[5] - at[4];
+    out->vt_stat = at[6] - at[5];
+    out->vt_p = at[7] - at[6];
+    out->vt_p_error = at[7] - at[0];
+    out->perm_pvalue = at[8] - at[0];  // (thread 0's own share of the partial-statistics loop)
+    out->cmc_stat = at[9];             // (wave-parts summed)
+  }
 #endif
 }
 

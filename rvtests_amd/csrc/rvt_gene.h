@@ -121,6 +121,11 @@ struct HcMasked {
 };
 constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 
+#if defined(RVT_PROF_K4) && defined(__HIP_DEVICE_COMPILE__)
+#define RVT_AS_TICK(k) do { if (co.tid == 0) out->as_ticks[k] = (double)clock64(); } while (0)
+#else
+#define RVT_AS_TICK(k) do { } while (0)
+#endif
 RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
                           const double* colstat, const double* bparts, int PB, const double* af,
                           const rvt_params& prm, unsigned tests, GeneScratch ws, GeneStats* out, int* flip_out,
@@ -128,6 +133,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
   const int d = nc.d;
   const int ldr = Cp;
   double* R = ws.R;
+  RVT_AS_TICK(0);
   // ---- 1. reduce the partial statistics (fixed order => deterministic) ----------------------------
   // (eight entries per thread and pass: their 8 P loads are independent and in flight together — with one entry per pass a
   //  thread waited out P round trips to HBM per entry; the order of the sum over p is unchanged: bit-reproducible)
@@ -144,11 +150,19 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
         s8[u] = 0.0;
         use[u] = idx < total && ((idx % Cp) >> 4) >= ((idx / Cp) >> 4);
       }
-      for (int p = 0; p < P; ++p) {
-        const double* src = parts + (size_t)p * stride;
+      for (int p0 = 0; p0 < P; p0 += 4) {  // four wave-parts x eight entries: 32 loads issued before the first sum
+        double t[4][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (use[u]) s8[u] += src[idx0 + u * co.nt];
+        for (int q = 0; q < 4; ++q) {
+          const double* src = parts + (size_t)(p0 + q) * stride;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[q][u] = (use[u] && p0 + q < P) ? src[idx0 + u * co.nt] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (p0 + q < P) s8[u] += t[q][u];  // (p ascending, as always)
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -161,6 +175,10 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
       }
     }
   }
+  RVT_AS_TICK(8);
+#if defined(RVT_PROF_K4) && defined(__HIP_DEVICE_COMPILE__)
+  if (co.tid == 0) out->as_ticks[9] = (double)P;
+#endif
   double* colsum = ws.vecs;         // [Mp]
   double* cmin = ws.vecs + Mp;      // [Mp]
   double* cmax = ws.vecs + 2 * Mp;  // [Mp]
@@ -208,6 +226,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     if (flip_out) flip_out[j] = flip ? 1 : 0;
   }
   co.sync();
+  RVT_AS_TICK(1);
   // hard-call path: masked-entry corrections of the G'G block (upper tiles; the completion below mirrors them)
   if (hcm && hcm->pq) {
     bool any = false;
@@ -281,6 +300,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     if (j < i) R[(size_t)i * ldr + j] = R[(size_t)j * ldr + i];  // lower triangle := upper (exact symmetry)
   }
   co.sync();
+  RVT_AS_TICK(2);
   // ---- 2. polymorphic columns ----------------------------------------------------------------------
   if (co.tid == 0) {
     int m = 0, nf = 0;
@@ -360,6 +380,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     co.sync();
     return;
   }
+  RVT_AS_TICK(3);
   // ---- 3. flip algebra:  g' = sgn*g + shf*1 ----------------------------------------------------------
   //   S'_ij = s_i s_j S_ij + s_i t_j g1_i + t_i s_j g1_j + t_i t_j c00,  g1 = G'D1 = T[:,0]
   //   T'_ik = s_i T_ik + t_i C[0][k],   u'_i = s_i u_i + t_i * sum(res)
@@ -380,6 +401,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     }
   }
   co.sync();
+  RVT_AS_TICK(4);
   // ---- 4. projected matrix  Wm = S' − T' Cinv T'ᵀ  on the kept columns (column-major m x m) ----------
   double* Wm = ws.Wm;
   for (int idx = co.tid; idx < m * m; idx += co.nt) {
@@ -407,6 +429,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     bw_skato[a] = w2;
   }
   co.sync();
+  RVT_AS_TICK(5);
   // ---- 6. SKAT Q = || W½ G'ᵀ r ||²      (Skat.cpp:52) ----------------------------------------------------
   if ((tests & RVT_TEST_SKAT) && co.tid == 0) {
     double Q = 0.0;
@@ -428,6 +451,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     rowsum[a] = s;
   }
   co.sync();
+  RVT_AS_TICK(6);
   if (co.tid == 0) {
     double s2;
     if (nc.binary)
@@ -470,6 +494,7 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     }
   }
   co.sync();
+  RVT_AS_TICK(7);
 }
 
 // ======================================================================================================

@@ -47,6 +47,9 @@ struct GeneStats {
   int cmc_ok, zeg_ok;
   double cmc_U, cmc_V, cmc_stat;
   double zeg_U, zeg_V, zeg_stat;
+#ifdef RVT_PROF_K4
+  double as_ticks[10];  // profiling build: clock at the phase boundaries of gene_assemble (tools/pv_prof.py)
+#endif
 };
 
 }  // namespace rvt

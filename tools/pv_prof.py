@@ -54,6 +54,14 @@ def main():
                     ("  the two preludes", pre_d)):
         print("%-24s mean %10.0f  max %10.0f  cycles   (%.2f / %.2f ms at 2.1 GHz)" % (name, v.mean(), v.max(),
                                                                                      v.mean() / 2.1e6, v.max() / 2.1e6))
+    asm = [f(n) for n in ("vt_minmaf", "vt_maxmaf", "vt_optmaf", "vt_U", "vt_V", "vt_stat", "vt_p", "vt_p_error")]
+    print("gene_assemble (thread 0's clock at the phase boundaries):")
+    for name, v in zip(("  1 partial statistics + column statistics", "  masked-entry corrections + symmetric completion",
+                        "  2 polymorphic columns + burden statistics", "  3 flip algebra", "  4 projected matrix + 5 weights",
+                        "  6 SKAT Q + 7 SKAT-O row sums", "  7 SKAT-O scalars", "  whole stage"), asm):
+        print("%-50s mean %10.0f  max %10.0f  cycles   (%.3f / %.3f ms at 2.1 GHz)" % (name, v.mean(), v.max(), v.mean() / 2.1e6, v.max() / 2.1e6))
+    v = f("perm_pvalue")
+    print("    of phase 1, thread 0 in the partial-statistics loop: mean %.0f max %.0f cycles; wave-parts %.0f" % (v.mean(), v.max(), f("cmc_stat").mean()))
     print("neval mean %.0f max %.0f; davies terms mean %.0f" % (neval.mean(), neval.max(), f("davies_terms").mean()))
     k = int(np.argmax(tot))
     print("slowest gene: M=%d neval=%d total %.0f front %.0f main %.0f book %.0f" % (Ms[k], neval[k], tot[k], front[k], main[k], book[k]))
