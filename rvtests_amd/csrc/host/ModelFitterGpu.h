@@ -351,9 +351,11 @@ class FamBurdenTest : public ModelFitter {
 // src/Model.cpp:844-858) and only copies the column into a device-resident ring; covariance rows are produced block
 // by block on the GPU (rvt_cov_block) and written in the reference's order and format when their window is complete
 // — the reference itself defers each row until its head is evicted (src/Model.h:3956-3968), so deferring changes
-// when a row reaches the file, not what the file holds.  A window that holds more sites than the ring makes the ring
-// grow (up to RVT_METACOV_MAX_COLUMNS); rings wider than one block of the symmetric kernel are processed as
-// heads-by-window rectangles (rvt_cov_rect).  Rows still pending are flushed by writeFootnote() / the
+// when a row reaches the file, not what the file holds.  A window that holds more sites than the ring — and, since round 5,
+// a flush that could emit less than half of the ring — makes the ring grow (up to RVT_METACOV_MAX_COLUMNS and 96 GB of columns,
+// RVT_METACOV_RING_GB): with at least two windows in the ring every flush emits half of what it reads.  Rings wider than one
+// block of the symmetric kernel are processed as heads-by-window rectangles of up to 1 024 heads (rvt_cov_rect; the exact int8
+// product for hard calls like the symmetric block).  Rows still pending are flushed by writeFootnote() / the
 // destructor, as the reference's destructor does (src/Model.cpp:828-834).
 class MetaCovTest : public ModelFitter {
  public:
