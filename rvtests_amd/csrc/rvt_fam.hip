@@ -492,6 +492,7 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     int64_t nkb = (int64_t)((free_b / 2) / (4 * sizeof(double) * (size_t)ld)) / 64 * 64;  // half of what is free
+    if (const char* e = getenv("RVT_TRIDIAG_BATCH")) nkb = std::max(64, atoi(e) / 64 * 64);  // (tests: several batches on a small matrix)
     nkb = std::max<int64_t>(64, std::min<int64_t>(nkb, ld));
     const size_t arr = sizeof(double) * (size_t)ld * (size_t)nkb;
     HIP_TRY(c, hipMalloc((void**)&b.B1, 4 * arr));

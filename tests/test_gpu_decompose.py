@@ -91,6 +91,24 @@ def test_dense_matrices(eng, N, kind, solver, monkeypatch):
         assert (dots[ok] > 1 - 1e-4).all() and ok.sum() > 50
 
 
+def test_inverse_iteration_in_batches_gives_the_same_vectors(eng, monkeypatch):
+    """The eigenvectors of the tridiagonal form are computed a batch of columns at a time (as many as the free device memory
+    holds factors for: several batches only at N ~ 100 000).  A start vector depends on the eigenvector's number in the spectrum,
+    not on its place in a batch, so U must not depend on the batch size: bit-identical with batches of 192 and of 64 columns."""
+    rng = np.random.default_rng(5)
+    N = 700
+    Z = rng.standard_normal((N, 2 * N))
+    K32 = ((Z @ Z.T) / (2 * N)).astype(np.float32)
+    K32 = (K32 + K32.T) / 2
+    U0, S0, info0 = eng.kinship_decompose(K32)
+    assert info0.sweeps == 0
+    _check(K32, U0, S0, info0)
+    for batch in (192, 64):
+        monkeypatch.setenv("RVT_TRIDIAG_BATCH", str(batch))
+        U1, S1, info1 = eng.kinship_decompose(K32)
+        assert info1.sweeps == 0 and np.array_equal(S1, S0) and np.array_equal(U1, U0)
+
+
 def test_famskat_through_the_device_decomposition(eng):
     """install = 1: FamSKAT through the device's own U, S equals FamSKAT through LAPACK's (different bases of the repeated
     eigenvalues, same U f(S) U')."""
