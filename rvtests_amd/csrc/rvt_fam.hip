@@ -572,7 +572,14 @@ static int decompose_dense_tridiag(rvt_ctx* c, int64_t N, const float* K, double
   if (trace)
     fprintf(stderr, "[rvt] tridiag: vectors %.3f s, back-transformation %.3f s, check %.3f s: residual %.3g (scale %.3g), |U'U - I| %.3g\n",
             t_vec - t_eig, t_back - t_vec, t_chk - t_back, resid, span0, orth);
-  if (!(resid <= 1e-9 * mu) || !(orth <= 1e-7)) return RVT_OK;  // (mu = 4 x a bound on the spectral radius; Jacobi's own bar)
+  if (!(resid <= 1e-9 * mu) || !(orth <= 1e-7)) {  // (mu = 4 x a bound on the spectral radius; Jacobi's own bar)
+    if (c->d_rot_part) {  // (the products' K slices: the Jacobi iteration that takes over needs the room)
+      hipFree(c->d_rot_part);
+      c->d_rot_part = nullptr;
+      c->rot_part_cap = 0;
+    }
+    return RVT_OK;
+  }
   std::vector<float> S((size_t)N);
   for (int64_t j = 0; j < N; ++j) S[j] = (float)lam[j];
   hipFree(b.A);
