@@ -320,7 +320,14 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
       HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
       c->rotB_cap = need + need / 4;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_rotB, 0, need, st));
+    // the product reads cols_pad columns of ldk bytes: the column pass writes the W columns' rows up to N rounded to 4 — only
+    // the pad rows behind them and the pad columns have to be zeroed (the whole 0.5 GB copy cost 0.1 ms of a 2.3 ms block)
+    {
+      const int64_t n4 = (N + 3) / 4 * 4;
+      if (ldk > n4)
+        HIP_TRY(c, hipMemset2DAsync(c->d_rotB + n4, (size_t)ldk, 0, (size_t)(ldk - n4), (size_t)W, st));
+      if (cols_pad > W) HIP_TRY(c, hipMemsetAsync(c->d_rotB + (size_t)W * ldk, 0, (size_t)(cols_pad - W) * (size_t)ldk, st));
+    }
     if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
     d_bad = c->d_kind;
     HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
