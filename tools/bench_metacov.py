@@ -72,7 +72,8 @@ def main():
                  np.full(N, float(sigma2)), float(sigma2))
     blocks, Ms, afs = bench.make_genes(dev, N, ld, 1, 5, V, V)
     torch.cuda.synchronize()
-    cpu = None if a.no_cpu else cpu_baseline(N)
+    lines = []   # (printed at the end: the CPU baseline is timed AFTER the device measurements, so that nothing of it —
+                 #  threads, heap state — sits under them)
     pairs = V * (V + 1) / 2
 
     def timed(fn):
@@ -90,26 +91,26 @@ def main():
     dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(dos.data_ptr(), V))
     eng.set_content_hint(-1)
     tf = 2.0 * N * pairs / dt / 1e12
-    print(json.dumps({"workload": "MetaCov block, dosages (fp64 matrix cores)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+    lines.append(({"workload": "MetaCov block, dosages (fp64 matrix cores)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
                       "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
                       "roofline": {"kernel": "gemm_tn_f64_kernel", "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
                                    "note": "2 N flop per pair of the upper triangle over the wall time of the synchronous C call "
                                            "(column pass, product, reduction, band, copy-back included)"},
-                      "cpu_baseline": cpu}))
+                      "cpu_baseline": None}))
     # ---- block, hard calls
     hard = torch.round(blocks[0]).contiguous()
     torch.cuda.synchronize()                                  # (torch's stream is not the engine's)
     assert eng.classify_block(hard.data_ptr(), V)
     dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(hard.data_ptr(), V))
     gbs = 8.0 * N * V / dt / 1e9
-    print(json.dumps({"workload": "MetaCov block, hard calls (exact int8 product)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+    lines.append(({"workload": "MetaCov block, hard calls (exact int8 product)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
                       "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
                       "int8_TOPs": 2.0 * N * V * V / dt / 1e12,
                       "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                    "note": "8 N V bytes of the block over the wall time of the synchronous C call"},
-                      "cpu_baseline": cpu}))
+                      "cpu_baseline": None}))
     # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): the ring starts at
     # 1 024 columns and doubles while a flush emits less than half of it; a ring of up to 1 024 columns is one symmetric
     # block call, a wider one goes through heads x window rectangles of up to 1 024 heads
@@ -159,7 +160,7 @@ def main():
         dt = t_cov + t_move
         npairs = done * (w + 1)
         gbs = 8.0 * N * done / dt / 1e9
-        print(json.dumps({"workload": "MetaCov sliding window, hard calls, adapter's ring policy", "N": N, "window_markers": w,
+        lines.append(({"workload": "MetaCov sliding window, hard calls, adapter's ring policy", "N": N, "window_markers": w,
                           "ring_columns": cap, "variants": done, "flushes": flushes, "device_calls": calls,
                           "ms_per_flush": 1e3 * dt / flushes,
                           "ms_per_flush_in_cov_calls": 1e3 * t_cov / flushes, "ms_per_flush_moving_the_ring": 1e3 * t_move / flushes,
@@ -170,8 +171,12 @@ def main():
                                        "note": "8 N bytes per evicted variant (each column of the stream read once) over the time "
                                                "of the device calls and ring moves; a call re-reads the window's columns behind "
                                                "its heads, so the ring reads (heads + w) / heads times that"},
-                          "cpu_baseline": cpu}))
+                          "cpu_baseline": None}))
         eng.free_block(ring)
+    cpu = None if a.no_cpu else cpu_baseline(N)
+    for ln in lines:
+        ln["cpu_baseline"] = cpu
+        print(json.dumps(ln))
 
 
 if __name__ == "__main__":
