@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
                                                           const double* __restrict__ X, long long ldx, int d,
                                                           signed char* __restrict__ out8, long long ldk,
                                                           double* __restrict__ part, int* __restrict__ bad,
-                                                          const double* __restrict__ wts = nullptr) {
+                                                          const double* __restrict__ wts = nullptr,
+                                                          int* __restrict__ hard_flag = nullptr) {
   const int c0 = blockIdx.x * kCovHcCols;
   bool not_hard = false;  // a value other than 0.0 / 1.0 / 2.0: the int8 copy is not the block (the host falls back)
   const int nc = min(kCovHcCols, W - c0);
@@ -1166,7 +1167,10 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
   }
   __shared__ double red[4][kCovHcCols][DMAX + 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (PACK && __any(not_hard) && lane == 0) atomicOr(bad, 1);
+  if (PACK && __any(not_hard) && lane == 0) {
+    if (bad) atomicOr(bad, 1);
+    if (hard_flag) atomicAnd(hard_flag, 0);  // (the per-column flag of rvt_block_upload_columns: nonzero = hard calls only)
+  }
 #pragma unroll
   for (int c = 0; c < kCovHcCols; ++c) {
     double v = s[c], a = mn[c], b = mx[c];
@@ -1226,6 +1230,17 @@ static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int
     colsum[j] = r;
   else
     T[j + (long long)(f - 3) * W] = r;
+}
+
+// the column statistics a block keeps per column (rvt_ctx::ColKind) -> the work arrays of a covariance call: W columns from col0
+static __global__ void cov_cache_gather_kernel(const double* __restrict__ cs_c, const int* __restrict__ poly_c,
+                                        const double* __restrict__ T_c, int W, int d, int t_stride, double* __restrict__ colsum,
+                                        int* __restrict__ poly, double* __restrict__ T) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W) return;
+  colsum[j] = cs_c[j];
+  poly[j] = poly_c[j];
+  for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[(long long)j * t_stride + k];
 }
 
 // dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)

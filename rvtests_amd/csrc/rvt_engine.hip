@@ -269,8 +269,8 @@ void rvt_destroy(rvt_ctx* c) {
     sync_stream(c->copy_stream);
     hipStreamDestroy(c->copy_stream);
   }
-  for (auto& kv : c->col_kind)
-    if (kv.second.d_flags) hipFree(kv.second.d_flags);
+  for (auto& kv : c->col_kind) kv.second.release();
+  if (c->d_cc_part) hipFree(c->d_cc_part);
   for (int k = 0; k < rvt_ctx::kTextBufs; ++k) {
     if (c->text_buf[k]) hipFree(c->text_buf[k]);
     if (c->ev_text_free[k]) hipEventDestroy(c->ev_text_free[k]);
@@ -522,6 +522,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   HIP_TRY(c, hipMemcpy(c->d_nc, &nc, sizeof(nc), hipMemcpyHostToDevice));
   c->null_ld = ld;
   c->have_null = true;
+  ++c->null_gen;
   return RVT_OK;
 }
 
@@ -537,8 +538,7 @@ int rvt_block_alloc(rvt_ctx* c, int M, double** out) {
   HIP_TRY(c, sync_stream(c->io_stream));
   {  // (flags are allocated by the first column upload; a zeroed block holds hard calls only)
     rvt_ctx::ColKind& ck = c->col_kind[*out];
-    if (ck.d_flags) hipFree(ck.d_flags);  // an earlier block at the same address that was freed behind our back
-    ck.d_flags = nullptr;
+    ck.release();  // (an earlier block at the same address that was freed behind our back)
     ck.cols = M;
   }
   return RVT_OK;
@@ -616,7 +616,7 @@ int rvt_block_free(rvt_ctx* c, double* dG) {
   {
     auto it = c->col_kind.find(dG);
     if (it != c->col_kind.end()) {
-      if (it->second.d_flags) hipFree(it->second.d_flags);
+      it->second.release();
       c->col_kind.erase(it);
     }
   }
@@ -806,9 +806,10 @@ int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   hipSetDevice(c->device);
   {  // per-column flags of an earlier column-wise fill no longer describe the block
     auto it = c->col_kind.find(dG);
-    if (it != c->col_kind.end() && it->second.d_flags) {
-      hipFree(it->second.d_flags);
-      it->second.d_flags = nullptr;
+    if (it != c->col_kind.end()) {
+      const int cols = it->second.cols;
+      it->second.release();
+      it->second.cols = cols;
     }
   }
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);

@@ -179,10 +179,33 @@ struct rvt_ctx {
   size_t cov_work_cap = 0;
   size_t rot_part_cap = 0;
   // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
+  // Round 5: ... and, for a ring that MetaCov will read (unweighted model), what the column pass of the hard-call band would
+  // compute for the column anyway — the int8 copy, the column sum, the polymorphic flag and its row of T = G'X — made by the
+  // pass that classifies the column behind its PCIe copy and kept with the block (moved and copied with its columns), so that a
+  // flush starts at the integer product.  `valid[j]`: column j's entries were made under null model number `gen`.
   struct ColKind {
     int cols = 0;
     int* d_flags = nullptr;
+    signed char* d_i8 = nullptr;  // [cols rounded up + a tile of slack][ldk]
+    double* d_cs = nullptr;       // [cols] column sums
+    int* d_poly = nullptr;        // [cols]
+    double* d_T = nullptr;        // [cols][RVT_MAX_COV]
+    int64_t ldk = 0;
+    uint64_t gen = 0;
+    std::vector<unsigned char> valid;
+    void release() {
+      for (void* q : {(void*)d_flags, (void*)d_i8, (void*)d_cs, (void*)d_poly, (void*)d_T})
+        if (q) hipFree(q);
+      d_flags = nullptr;
+      d_i8 = nullptr;
+      d_cs = nullptr;
+      d_poly = nullptr;
+      d_T = nullptr;
+      valid.clear();
+    }
   };
+  uint64_t null_gen = 0;          // counts rvt_set_null / rvt_fit_null: a column cache made under another model is not used
+  double* d_cc_part = nullptr;    // slice partials of the one-column pass (64 slices x (RVT_MAX_COV + 3))
   std::unordered_map<const double*, ColKind> col_kind;
   // VCF text front end (vcf_kernels.hip.h)
   char* d_vcf_text = nullptr;   // the text / block buffer of the gene being submitted: text_buf[text_cur]

@@ -3,6 +3,10 @@
 #include "rvt_engine_int.h"
 #include "gemm_f64.hip.h"
 
+// row slices of MetaCov's column pass (cov_hc_prep_kernel): a function of N alone, so that a column's sums are the same numbers
+// whether it is treated inside a block or alone behind its upload (rvt_block_upload_columns)
+static constexpr int kCovSlices = 16;
+
 extern "C" {
 // C (M x (Nb + Nb2), column-major, leading dimension ldc) = A' D [B | B2] in fp64 on the matrix cores (gemm_f64.hip.h).
 // A: M columns (lda apart), B: Nb columns, B2: Nb2 further columns (the null-model columns), all N samples long and
@@ -291,7 +295,9 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
   // copy): rows sliced across workgroups, partial results added in a fixed order
   const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
   const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
-  const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(64, std::min<int64_t>((2048 + wgs - 1) / wgs, N / 4096 + 1)));
+  // (the slice count depends on N alone: a column's sums then come out the same whether the column is treated with 1 023
+  //  others here or alone behind its upload, rvt_block_upload_columns)
+  const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, N / 4096 + 1));
   if (!fast) {
     const dim3 grid((unsigned)wgs, (unsigned)slices);
     const double* wts = nc.binary ? c->d_v : nullptr;
@@ -307,7 +313,27 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
                        W, d, dmax, d_cs, d_poly, d_T);
   }
+  // the block's own column cache (rvt_block_upload_columns made it behind the PCIe copies): every column of the window has its
+  // int8 copy, sum, flag and row of T under THIS null model -> the call starts at the integer product
+  const rvt_ctx::ColKind* ckc = nullptr;
   if (fast) {
+    auto itc = c->col_kind.find(dG);
+    if (itc != c->col_kind.end() && itc->second.d_i8 && itc->second.gen == c->null_gen &&
+        itc->second.ldk == (N + 127) / 128 * 128 && col0 + W <= itc->second.cols && !getenv("RVT_METACOV_NO_CACHE")) {
+      bool all = true;
+      for (int j = col0; j < col0 + W && all; ++j) all = itc->second.valid[(size_t)j] != 0;
+      if (all) ckc = &itc->second;
+    }
+  }
+  if (fast && ckc) {
+    const int64_t ldk = ckc->ldk;
+    hipLaunchKernelGGL(cov_cache_gather_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, ckc->d_cs + col0,
+                       ckc->d_poly + col0, ckc->d_T + (size_t)col0 * RVT_MAX_COV, W, d, RVT_MAX_COV, d_cs, d_poly, d_T);
+    const signed char* A8 = ckc->d_i8 + (size_t)col0 * (size_t)ldk;
+    std::vector<int> zero_exp((size_t)W, 0);
+    rc = rvt_planes_gemm(c, A8, 0, 1, H, zero_exp.data(), 0, A8, 0, 1, W, zero_exp.data(), N, ldk, d_S, H, st);
+    if (rc) return rc;
+  } else if (fast) {
     // a hard-call block (rvt_cov_block's fast path; heads = the first H of the W columns): ONE pass over G gives the column
     // statistics, T = G'X and the int8 copy (cov_hc_prep_kernel); S = G'G is then one exact integer product
     const int64_t ldk = (N + 127) / 128 * 128;
@@ -450,6 +476,42 @@ int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, doubl
   return RVT_OK;
 }
 
+// the column cache of ncols columns from (block s, column sc) to (block t, column tc), t == s allowed (a forward move: tc < sc);
+// columns whose source has no valid entry become invalid in the target
+static int move_col_cache(rvt_ctx* c, rvt_ctx::ColKind* t, int tc, const rvt_ctx::ColKind* s, int sc, int ncols, hipStream_t st) {
+  if (!t || tc + ncols > t->cols) return RVT_OK;
+  const bool src_ok = s && s->d_i8 && sc + ncols <= s->cols;
+  if (!src_ok || (t->d_i8 && (t->ldk != s->ldk || t->gen != s->gen))) {
+    if (!t->valid.empty())
+      for (int k = 0; k < ncols; ++k) t->valid[(size_t)(tc + k)] = 0;
+    return RVT_OK;
+  }
+  if (!t->d_i8) {  // the target block has no cache yet: same shape as the source's
+    const size_t cap = ((size_t)t->cols + 255) / 256 * 256 + 256;
+    HIP_TRY(c, hipMalloc((void**)&t->d_i8, cap * (size_t)s->ldk));
+    HIP_TRY(c, hipMemsetAsync(t->d_i8, 0, cap * (size_t)s->ldk, st));
+    HIP_TRY(c, hipMalloc((void**)&t->d_cs, sizeof(double) * (size_t)t->cols));
+    HIP_TRY(c, hipMalloc((void**)&t->d_poly, sizeof(int) * (size_t)t->cols));
+    HIP_TRY(c, hipMalloc((void**)&t->d_T, sizeof(double) * (size_t)t->cols * RVT_MAX_COV));
+    t->ldk = s->ldk;
+    t->gen = s->gen;
+    t->valid.assign((size_t)t->cols, 0);
+  }
+  // (forward, in pieces no longer than the shift: a piece never overwrites what it has not read)
+  const int shift = (t == s) ? sc - tc : ncols;
+  for (int k0 = 0; k0 < ncols; k0 += std::max(shift, 1)) {
+    const int nk = std::min(std::max(shift, 1), ncols - k0);
+    HIP_TRY(c, hipMemcpyAsync(t->d_i8 + (size_t)(tc + k0) * (size_t)s->ldk, s->d_i8 + (size_t)(sc + k0) * (size_t)s->ldk,
+                              (size_t)nk * (size_t)s->ldk, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(t->d_cs + tc + k0, s->d_cs + sc + k0, sizeof(double) * (size_t)nk, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(t->d_poly + tc + k0, s->d_poly + sc + k0, sizeof(int) * (size_t)nk, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(t->d_T + (size_t)(tc + k0) * RVT_MAX_COV, s->d_T + (size_t)(sc + k0) * RVT_MAX_COV,
+                              sizeof(double) * (size_t)nk * RVT_MAX_COV, hipMemcpyDeviceToDevice, st));
+  }
+  for (int k = 0; k < ncols; ++k) t->valid[(size_t)(tc + k)] = s->valid[(size_t)(sc + k)];
+  return RVT_OK;
+}
+
 int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* src, int src_col, int ncols) {
   if (!c || !dst || !src || dst_col < 0 || src_col < 0 || ncols < 0) return fail(c, RVT_E_INVALID, "bad copy");
   if (ncols == 0) return RVT_OK;
@@ -457,6 +519,28 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
                        hipMemcpyDeviceToDevice));
+  // what the engine knows about the columns travels with them: content flags and the column cache
+  auto itd = c->col_kind.find(dst);
+  auto its = c->col_kind.find(src);
+  if (itd != c->col_kind.end() && dst != src) {
+    rvt_ctx::ColKind& t = itd->second;
+    const rvt_ctx::ColKind* s = its != c->col_kind.end() ? &its->second : nullptr;
+    if (dst_col + ncols <= t.cols) {
+      if (s && s->d_flags && src_col + ncols <= s->cols) {
+        if (!t.d_flags) {
+          HIP_TRY(c, hipMalloc((void**)&t.d_flags, sizeof(int) * (size_t)t.cols));
+          HIP_TRY(c, hipMemsetAsync(t.d_flags, 0x01, sizeof(int) * (size_t)t.cols, c->io_stream));
+        }
+        HIP_TRY(c, hipMemcpyAsync(t.d_flags + dst_col, s->d_flags + src_col, sizeof(int) * (size_t)ncols, hipMemcpyDeviceToDevice,
+                                  c->io_stream));
+      } else if (t.d_flags) {
+        HIP_TRY(c, hipMemsetAsync(t.d_flags + dst_col, 0, sizeof(int) * (size_t)ncols, c->io_stream));  // (unknown: not hard calls)
+      }
+      int rc = move_col_cache(c, &t, dst_col, s, src_col, ncols, c->io_stream);
+      if (rc) return rc;
+      HIP_TRY(c, sync_stream(c->io_stream));
+    }
+  }
   return RVT_OK;
 }
 
@@ -469,19 +553,69 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
                          hipMemcpyHostToDevice));
   // content of the new columns (hard calls or not), recorded per column: rvt_score_block picks its kernel by it.  One
-  // read of data that has just crossed PCIe at a hundredth of the rate.
+  // read of data that has just crossed PCIe at a hundredth of the rate.  Under an unweighted null model that read is the
+  // column pass of MetaCov's hard-call band itself (cov_hc_prep_kernel on the one column): int8 copy, sum, min / max and the
+  // row of T = G'X stay with the block (ColKind), the flag falls out of its value test.
   auto it = c->col_kind.find(dG);
   if (it != c->col_kind.end() && c->hc_enabled && col0 + ncols <= it->second.cols) {
-    rvt_ctx::ColKind ck = it->second;
+    rvt_ctx::ColKind& ck = it->second;
     if (!ck.d_flags) {
       HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
       HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, c->io_stream));
-      it->second.d_flags = ck.d_flags;
+    }
+    const bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
+    const int d = c->nc.d, dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+    const int64_t ldk = ((int64_t)N + 127) / 128 * 128;
+    if (cache) {
+      if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen)) {  // another model: nothing of the old cache is used
+        for (void* q : {(void*)ck.d_i8, (void*)ck.d_cs, (void*)ck.d_poly, (void*)ck.d_T}) hipFree(q);
+        ck.d_i8 = nullptr;
+        ck.d_cs = nullptr;
+        ck.d_poly = nullptr;
+        ck.d_T = nullptr;
+      }
+      if (!ck.d_i8) {
+        const size_t cap = ((size_t)ck.cols + 255) / 256 * 256 + 256;  // (the product reads whole tiles of columns)
+        HIP_TRY(c, hipMalloc((void**)&ck.d_i8, cap * (size_t)ldk));
+        HIP_TRY(c, hipMemsetAsync(ck.d_i8, 0, cap * (size_t)ldk, c->io_stream));
+        HIP_TRY(c, hipMalloc((void**)&ck.d_cs, sizeof(double) * (size_t)ck.cols));
+        HIP_TRY(c, hipMalloc((void**)&ck.d_poly, sizeof(int) * (size_t)ck.cols));
+        HIP_TRY(c, hipMalloc((void**)&ck.d_T, sizeof(double) * (size_t)ck.cols * RVT_MAX_COV));
+        ck.ldk = ldk;
+        ck.gen = c->null_gen;
+        ck.valid.assign((size_t)ck.cols, 0);
+      }
+      if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * kCovSlices * (RVT_MAX_COV + 3)));
     }
     for (int k = 0; k < ncols; ++k) {
-      int rc = enqueue_classify(c, dG + (size_t)(col0 + k) * ld, 1, (int64_t)N, (int64_t)ld, c->io_stream,
-                                ck.d_flags + col0 + k);
-      if (rc) return rc;
+      const int col = col0 + k;
+      if (!cache) {
+        int rc = enqueue_classify(c, dG + (size_t)col * ld, 1, (int64_t)N, (int64_t)ld, c->io_stream, ck.d_flags + col);
+        if (rc) return rc;
+        continue;
+      }
+      static const int one = 1;
+      HIP_TRY(c, hipMemcpyAsync(ck.d_flags + col, &one, sizeof(int), hipMemcpyHostToDevice, c->io_stream));
+      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
+      const dim3 grid(1, (unsigned)slices);
+      const double* GW = dG + (size_t)col * ld;
+      signed char* o8 = ck.d_i8 + (size_t)col * (size_t)ldk;
+      if (dmax == 4)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1, c->d_X,
+                           (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
+                           ck.d_flags + col);
+      else if (dmax == 8)
+        hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1, c->d_X,
+                           (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
+                           ck.d_flags + col);
+      else
+        hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1,
+                           c->d_X, (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
+                           ck.d_flags + col);
+      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3(1), dim3(256), 0, c->io_stream, c->d_cc_part, slices, 1, d, dmax,
+                         ck.d_cs + col, ck.d_poly + col, ck.d_T + (size_t)col * RVT_MAX_COV);
+      HIP_TRY(c, hipGetLastError());
+      ck.valid[(size_t)col] = 1;
     }
   }
   return RVT_OK;
@@ -492,10 +626,24 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   if (ncols == 0 || dst_col == src_col) return RVT_OK;
   hipSetDevice(c->device);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  // forward move of a possibly overlapping range: column by column in increasing order never overwrites unread data
-  for (int k = 0; k < ncols; ++k)
-    HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k) * ld, dG + (size_t)(src_col + k) * ld, sizeof(double) * ld,
-                              hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, sync_stream(c->io_stream));  // (the passes behind the last uploads write the cache this call moves)
+  // forward move of a possibly overlapping range: in pieces no longer than the shift, in increasing order — a piece never
+  // overwrites data that has not been read (a ring that drops more than it keeps moves in ONE copy)
+  {
+    const int shift = src_col - dst_col;
+    for (int k0 = 0; k0 < ncols; k0 += shift) {
+      const int nk = std::min(shift, ncols - k0);
+      HIP_TRY(c, hipMemcpyAsync(dG + (size_t)(dst_col + k0) * ld, dG + (size_t)(src_col + k0) * ld, sizeof(double) * ld * (size_t)nk,
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  {
+    auto itc = c->col_kind.find(dG);
+    if (itc != c->col_kind.end()) {
+      int rc = move_col_cache(c, &itc->second, dst_col, &itc->second, src_col, ncols, c->stream);
+      if (rc) return rc;
+    }
+  }
   HIP_TRY(c, sync_stream(c->stream));
   auto it = c->col_kind.find(dG);
   if (it != c->col_kind.end() && it->second.d_flags && src_col + ncols <= it->second.cols) {

@@ -1,4 +1,6 @@
 """GPU parity of the MetaCov covariance band (rvt_cov_block, through the C ABI) against the CPU oracle."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -76,6 +78,60 @@ def test_cov_block_ring_moves(engine_factory):
     got = eng.cov_block(ring, V)[0]
     iu = np.triu_indices(V)
     assert np.array_equal(got[iu], ref[iu])
+
+
+def test_column_cache_of_uploaded_columns(engine_factory, monkeypatch):
+    """rvt_block_upload_columns leaves with every hard-call column what MetaCov's column pass would compute for it (int8 copy,
+    sum, polymorphic flag, row of T = G'X), so that a covariance call on such a block starts at the integer product.  The
+    numbers must be those of the same block uploaded at once — bit for bit —; the cache travels with moved and copied columns,
+    is not used after the null model changed, and a dosage column switches the block to the general path."""
+    N, V, d = 9000, 150, 3                                   # (N > 2 x 4096: several row slices)
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 31337)
+    G = np.rint(G)
+    G[:, 11] = 0.0                                            # monomorphic
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    whole = eng.upload_block(G)
+    assert eng.classify_block(whole, V)
+    ref = eng.cov_block(whole, V)
+    ring = eng.alloc_block(V + 20)
+    for j0 in range(0, V, 37):
+        eng.upload_columns(ring, 20 + j0, G[:, j0:j0 + 37])
+    eng.move_columns(ring, 0, 20, V)                          # overlapping forward move: the cache moves with the columns
+    got = eng.cov_block(ring, V)
+    iu = np.triu_indices(V)
+    assert np.array_equal(got[0][iu], ref[0][iu]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[3], ref[3])
+    monkeypatch.setenv("RVT_METACOV_NO_CACHE", "1")           # the same call without the cache
+    got2 = eng.cov_block(ring, V)
+    monkeypatch.delenv("RVT_METACOV_NO_CACHE")
+    assert np.array_equal(got2[0][iu], ref[0][iu]) and np.array_equal(got2[1], ref[1])
+    r1 = eng.cov_rect(ring, 7, 64, 120)                       # a rectangle inside the cached block
+    r0 = eng.cov_rect(whole, 7, 64, 120)
+    for h in range(64):
+        assert np.array_equal(r1[0][h, h:], r0[0][h, h:], equal_nan=True)
+    other = eng.alloc_block(V)                                # device copies hand the cache on
+    eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(other), 0, C.c_void_p(ring), 0, V))
+    got3 = eng.cov_block(other, V)
+    assert np.array_equal(got3[0][iu], ref[0][iu]) and np.array_equal(got3[1], ref[1])
+    # another null model: the cached rows of T belong to the old one and must not be used
+    X2 = X.copy()
+    X2[:, 1] = X[:, 1] ** 2
+    rc, beta2, pred2, res2, s22 = orc.fit_linear(X2, y)
+    eng.set_null(0, X2, res2, np.full(N, s22), s22)
+    got4 = eng.cov_block(ring, V)
+    ref4 = eng.cov_block(whole, V)
+    assert np.array_equal(got4[0][iu], ref4[0][iu]) and np.array_equal(got4[1], ref4[1])
+    assert not np.array_equal(ref4[1], ref[1])
+    # a dosage in one column: its flag says so and the block takes the general path (same numbers as the block uploaded at once)
+    G2 = G.copy()
+    G2[3, 40] = 0.25
+    eng.upload_columns(ring, 40, G2[:, 40])
+    whole2 = eng.upload_block(G2)
+    got5 = eng.cov_block(ring, V)
+    ref5 = eng.cov_block(whole2, V)
+    scale = np.nanmax(np.abs(ref5[0][iu]))
+    assert np.abs(got5[0][iu] - ref5[0][iu]).max() <= 1e-12 * scale and np.array_equal(got5[3], ref5[3])
 
 
 @pytest.mark.parametrize("binary", [0, 1])

@@ -111,11 +111,30 @@ def main():
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                    "note": "8 N V bytes of the block over the wall time of the synchronous C call"},
                       "cpu_baseline": None}))
+    # ---- block, hard calls, filled column by column as the adapter fills its ring: the engine made the int8 copy and the
+    #      column statistics behind every upload, the call starts at the integer product
+    # V resident columns, re-used cyclically as the stream.  They are put on the device the way the adapter puts a site's
+    # column there (rvt_block_upload_columns), so that they carry what the engine keeps per uploaded column — content flag,
+    # int8 copy, column statistics — and the device copies below hand that on to the ring (untimed, like the fill)
+    src_blk = eng.alloc_block(V)
+    hard_host = hard[:, :N].cpu().numpy()                     # (V, N): row j = column j of the block
+    for j0 in range(0, V, 64):
+        eng.upload_columns(src_blk, j0, np.asfortranarray(hard_host[j0:j0 + 64].T))
+    del hard_host
+    dt, (cov2, xz2, zz2, poly2) = timed(lambda: eng.cov_block(src_blk, V))
+    assert np.array_equal(np.triu(cov2), np.triu(cov)) and np.array_equal(xz2, xz)       # (same numbers as the block above)
+    gbs = 8.0 * N * V / dt / 1e9
+    lines.append(({"workload": "MetaCov block, hard calls, block filled by rvt_block_upload_columns (column cache)", "N": N, "V": V,
+                   "ms_per_block": 1e3 * dt, "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly2.sum()),
+                   "roofline": {"kernel": "rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                "note": "8 N V bytes of the block over the wall time of the synchronous C call; the call itself reads "
+                                        "the N V bytes of the int8 copy made at upload time"},
+                   "cpu_baseline": None}))
     # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): the ring starts at
     # 1 024 columns and doubles while a flush emits less than half of it; a ring of up to 1 024 columns is one symmetric
     # block call, a wider one goes through heads x window rectangles of up to 1 024 heads
     widths = [int(w) for w in a.window.split(",") if w]
-    src = hard                                                # V resident columns, re-used cyclically as the stream
     for w in widths:
         cap = 1024
         while cap < 2 * w:
@@ -131,7 +150,7 @@ def main():
             t1 = time.perf_counter()
             while fill < cap:
                 n = min(cap - fill, V - nxt)
-                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src.data_ptr()), nxt, n))
+                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src_blk), nxt, n))
                 fill += n
                 nxt = (nxt + n) % V
             torch.cuda.synchronize()
