@@ -346,11 +346,18 @@ int rvt_score_block_fam(rvt_ctx* ctx, const double* dG, int V, int binary, int* 
 /* Diagonal of FastLMM::GetNullCovB (regression/FastLMM.cpp:473-483) for MetaFamQtl::PrintNullModel; beta, SigmaG2 =
  * sigma2_g and SigmaE2 = sigma2_g * delta come from rvt_fit_fam_null's rvt_fam_null. */
 int rvt_fam_null_summary(rvt_ctx* ctx, double* covb_diag);
-/* Copy columns between two device blocks (growing the adapter's ring). */
+/* Copy columns between two device blocks (growing the adapter's ring).  What the engine keeps per uploaded column (below)
+ * travels with them when both blocks came from rvt_block_alloc. */
 int rvt_block_copy_columns(rvt_ctx* ctx, double* dst, int dst_col, const double* src, int src_col, int ncols);
-/* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous). */
+/* Fill columns [col0, col0+ncols) of a device block from host memory (N doubles per column, contiguous).  Behind the copy the
+ * engine reads the column once on the device: it records whether the column holds hard calls only (rvt_score_block / the
+ * MetaCov calls start on the integer kernels then) and, under an unweighted null model, keeps with the block what MetaCov's
+ * column pass would compute for the column — its int8 copy, sum, polymorphic flag and row of T = G'X — so that rvt_cov_block /
+ * rvt_cov_rect on such a block start at the integer product (same numbers, bit for bit, as for a block uploaded at once;
+ * not used after the null model changed).  N more bytes of device memory per column. */
 int rvt_block_upload_columns(rvt_ctx* ctx, double* dG, int col0, int ncols, const double* G);
-/* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction). */
+/* Move columns [src_col, src_col+ncols) of a device block down to dst_col <= src_col (ring compaction; the per-column records
+ * move with them). */
 int rvt_block_move_columns(rvt_ctx* ctx, double* dG, int dst_col, int src_col, int ncols);
 
 /* ---- null models of unrelated samples on the device ---------------------------------------------------------------
