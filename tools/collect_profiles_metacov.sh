@@ -20,7 +20,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$OUT/pmc_mc_$C"
 done
 # (REPS timed + 1 warm-up call per workload: REPS + 1 launches of every kernel of a block call)
-python3 tools/pmc_traffic.py "$OUT/metacov_pmc_FETCH_SIZE.csv" "$OUT/metacov_pmc_WRITE_SIZE.csv" $((REPS + 1)) "metacov block N=500000,V=1024 (one fp64 + one hard-call block call per batch)" "$OUT/pmc_traffic_metacov.json"
+python3 tools/pmc_traffic.py "$OUT/metacov_pmc_FETCH_SIZE.csv" "$OUT/metacov_pmc_WRITE_SIZE.csv" $((REPS + 1)) "metacov block N=500000,V=1024 (per batch: one fp64 call, one hard-call call on a block uploaded at once, one on a block filled column by column; cov_hc_prep_kernel<4,true> also counts the 1024 one-column passes behind the uploads)" "$OUT/pmc_traffic_metacov.json"
 python3 - "$OUT/pmc_traffic_metacov.json" <<'PY'
 import json, sys
 j = json.load(open(sys.argv[1]))
