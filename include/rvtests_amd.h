@@ -311,6 +311,24 @@ int rvt_cov_block(rvt_ctx* ctx, const double* dG, int V, double* cov, double* xz
  * (rvtests_amd/csrc/rot_gemm.hip.h) replace the symmetric block kernel.  cov[(h-col0) + (j-col0)*H] for j >= h; xz: W x d; polymorphic: W. */
 int rvt_cov_rect(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
                  int* polymorphic);
+/* The sliding window itself: a device block used as a RING — what RingMemoryPool (base/RingMemoryPool.cpp:31-63: allocate /
+ * deallocate by index, nothing ever moves) is to MetaCovTest's queue of genotype vectors (src/Model.cpp:936-942, the eviction
+ * loop :879-905, printCovariance :942-1004).  ring_cols > 0: logical column j of the call is PHYSICAL column
+ * (col0 + j) mod ring_cols of `dG` (ring_cols <= the block's columns; the caller uploads a new site into the physical column
+ * behind the tail with rvt_block_upload_columns and drops heads by advancing col0 — no column is ever moved);
+ * ring_cols = 0: a linear range, columns [col0, col0 + W) as in rvt_cov_rect.
+ * Heads = logical columns [0, H), markers = logical columns [0, W), H <= W (W is clipped to H + halo); halo = the most
+ * markers behind a head that the caller will print (the window, in markers).  Only the BAND is computed and returned:
+ *   band[h * (halo + 1) + t], t = 0 .. halo : (float)value(h, h + t) * scale — value as rvt_cov_rect's cov, the float cast
+ *                          and the float multiplication by scale = (float)(1 / N) being what printCovariance applies before
+ *                          "%g" (src/Model.cpp:975-984; scale = 1 gives the cast value) — NaN where h + t >= W
+ *   xz[j*d + k], polymorphic[j] : the W markers;  zz as above.
+ * H is not limited by RVT_MAX_VARIANTS.  Hard-call columns under an unweighted model: only the int8 copies that
+ * rvt_block_upload_columns keeps are read (1 byte per genotype), the tiles of the band go to the int8 matrix cores
+ * (rvtests_amd/csrc/band_gemm.hip.h); dosages / a binary trait: the same band tiles on the fp64 matrix cores.  `band` is
+ * written by DMA when it lies inside a range registered with rvt_host_register.  Synchronous. */
+int rvt_cov_band(rvt_ctx* ctx, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
+                 double* xz, double* zz, int* polymorphic);
 /* ---- MetaScore: single-variant score statistics (unrelated samples) ----------------------------------------------
  * Replaces the per-variant body of MetaScoreTest::fit for MetaUnrelatedQtl / MetaUnrelatedBinary
  * (src/Model.h:3246-3258 -> 3516-3549 / 3706-3769), i.e. LinearRegressionScoreTest::TestCovariate
@@ -437,6 +455,10 @@ int rvt_cov_block_fam(rvt_ctx* ctx, const double* dG, int V, double* cov, double
  * d = columns of X). */
 int rvt_cov_rect_fam(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
                      int* polymorphic);
+/* The family counterpart of rvt_cov_band (same arguments and outputs; xz: W x d of U'X): the ring holds RAW columns, every
+ * pass of up to 1 024 heads rotates its heads and the window behind them by U'. */
+int rvt_cov_band_fam(rvt_ctx* ctx, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
+                     double* xz, double* zz, int* polymorphic);
 /* MetaCovFamBinary (src/Model.cpp:595-692): after rvt_fit_fam_null on the 0/1 phenotype, scale everything
  * rvt_cov_block_fam returns by b^2, b = obtainB(alpha) = integral of logistic'(alpha + x) phi(x) dx
  * (src/Model.cpp:339-369; the reference uses gsl_integration_qagi with epsrel 1e-7), alpha = log(n_case / n_ctrl) kept

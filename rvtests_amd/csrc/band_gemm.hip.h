@@ -1,0 +1,280 @@
+// rvtests_amd — the score-covariance BAND of MetaCovTest's sliding window on a circular device ring.
+//
+// The reference keeps the genotype vectors of the variants inside the window in RingMemoryPool (base/RingMemoryPool.cpp:31-63:
+// allocate / deallocate by index, nothing ever moves) and, when a head leaves the window, prints its covariance with every
+// marker still in it (MetaCovTest::printCovariance, src/Model.cpp:942-1004; the window rule src/Model.h:3954-3990).  Here the
+// window is a ring of columns in HBM addressed modulo its capacity: logical column j of a call is physical column
+// (col0 + j) mod ring.  For hard calls under an unweighted model only the int8 copy of a column (1 byte per genotype, made
+// behind its upload) is read: S = G_H' G_W is an exact integer product on the int8 matrix cores.
+//
+// Only the tiles of the band are enumerated: row panel rp (heads 256 rp .. 256 rp + 255) needs the markers
+// 256 rp .. 256 rp + 255 + halo, i.e. ceil((256 + halo) / 256) column tiles that start ON the panel's own diagonal tile
+// (a heads x window rectangle computes about twice the band that is printed).  K (the sample index) is split into slices
+// that are dealt to the XCDs — XCD x takes the slices x, x + 8, ... and walks the tile list of one slice before the next, so
+// the 32 workgroups resident on an XCD read the same sample range of neighbouring columns at the same time and share it
+// through that XCD's L2.  Every (slice, tile) writes its own 256 x 256 int32 partial tile, row-major so that the 32 lanes of a
+// half-wave store one 128-byte line; band_finish_i32_kernel adds the slices (integers: exact in any order), applies the
+// centring / covariate algebra of computeScaledXX (src/Model.h:3997-4005) and writes the band in the layout the adapter
+// prints from: band[h * (halo + 1) + t] = value(head h, marker h + t).
+//
+// The inner loop is the one of rot_gemm.hip.h (global_load_lds_dwordx4 into XOR-swizzled 128-byte rows, two 64 KB stages,
+// one barrier per 128 K-bytes, v_mfma_i32_32x32x32_i8, 4 x 2 tiles per wave).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rot_gemm.hip.h"
+
+namespace rvt {
+
+constexpr int kBandBT = 256;  // tile edge: heads x markers
+
+// column tiles of row panel rp: the markers [256 rp, min(W, 256 rp + 256 + halo))
+__host__ __device__ inline int band_panel_tiles(int rp, int W, int halo) {
+  const long long lo = (long long)rp * kBandBT;
+  long long hi = lo + kBandBT + halo;
+  if (hi > W) hi = W;
+  return hi > lo ? (int)((hi - lo + kBandBT - 1) / kBandBT) : 0;
+}
+inline int band_tiles(int H, int W, int halo) {
+  int n = 0;
+  for (int rp = 0; rp < (H + kBandBT - 1) / kBandBT; ++rp) n += band_panel_tiles(rp, W, halo);
+  return n;
+}
+// K slices (a multiple of 8): the count that minimises rounds x chunks per workgroup, a round being the 32 workgroups an
+// XCD holds at once (one workgroup of 128 KB LDS per CU); slices of at least 16 chunks of 128 samples; the partial tiles of
+// all slices must fit `max_part_bytes`
+inline long long band_slices(int n_tiles, long long chunks, size_t max_part_bytes) {
+  long long best = 8, best_cost = -1;
+  for (long long k = 1; k <= 16; ++k) {
+    if (k > 1 && chunks / (8 * k) < 16) break;
+    if (k > 1 && (size_t)n_tiles * (size_t)(8 * k) * (size_t)kBandBT * kBandBT * sizeof(int) > max_part_bytes) break;
+    const long long rounds = ((long long)n_tiles * k + 31) / 32, cost = rounds * ((chunks + 8 * k - 1) / (8 * k));
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = 8 * k;
+    }
+  }
+  return best;
+}
+
+// R: the int8 columns, [physical column][ldk] (ldk a multiple of 128, pad rows zero).  part: [slice][tile][256][256] int32.
+// grid = 8 * n_tiles * ceil(n_slices / 8) workgroups of 512 threads.
+template <int WM, int WN, int TM, int TN, int NST, int KC>
+__global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int8_t* __restrict__ R, long long ldk, int ring,
+                                                                        int col0, int H, int W, int halo, long long kbytes0,
+                                                                        long long kslice, int n_slices, int n_tiles,
+                                                                        int* __restrict__ part) {
+  constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static_assert(BM == kBandBT && BN == kBandBT, "band tiles are 256 x 256");
+  static_assert(KC == 128, "a stage holds 128 bytes of K per row");
+  constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
+  constexpr int kStage = (BM + BN) * KC;
+  static_assert(kPieces % kWaves == 0, "pieces must divide evenly among the waves");
+  static_assert(PPW * (NST - 1) < 64, "the ring's loads must fit the vmcnt counter");
+  __shared__ __attribute__((aligned(1024))) char lds[NST][kStage];
+  const int id = blockIdx.x, xcd = id & 7, wq = id >> 3;
+  const int slice = xcd + 8 * (wq / n_tiles);
+  if (slice >= n_slices) return;
+  const int tile = wq % n_tiles;
+  int rp = 0, ct = 0;
+  {
+    int t = tile;
+    for (;; ++rp) {
+      const int cnt = band_panel_tiles(rp, W, halo);
+      if (t < cnt) {
+        ct = rp + t;
+        break;
+      }
+      t -= cnt;
+    }
+  }
+  const long long k_off = (long long)slice * kslice;
+  const long long kbytes = (kbytes0 - k_off < kslice) ? kbytes0 - k_off : kslice;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = rp * BM, n0 = ct * BN;
+  const int8_t* gsrc[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int P = wave + kWaves * q;
+    const int r = 8 * P + (lane >> 3), slot = lane & 7;
+    const int seg = slot ^ ((r >> 1) & 7);
+    int L = (r < BM) ? m0 + r : n0 + (r - BM);  // logical column of the window
+    if (L >= W) L = W - 1;                      // (rows beyond the window read a valid column; their outputs are never used)
+    long long phys = (long long)col0 + L;
+    if (ring > 0 && phys >= ring) phys -= ring;
+    gsrc[q] = R + phys * ldk + k_off + seg * 16;
+  }
+  auto stage = [&](int buf, long long kc) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int P = wave + kWaves * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[q] + kc * KC),
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
+    }
+  };
+  i16v_t acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+  const long long nchunks = kbytes / KC;
+  if (nchunks <= 0) return;
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) stage(t, t < nchunks ? t : nchunks - 1);
+  const int lrow = lane & 31, lk = lane >> 5;
+  int cur = 0;
+  constexpr int KS = KC / 32;  // k-steps (32 bytes of K per matrix instruction) per stage
+  for (long long kc = 0; kc < nchunks; ++kc) {
+    rot_wait_vm_barrier<PPW*(NST - 2)>();
+    // the stage that is refilled during this iteration: the buffer every wave left at the barrier above
+    const long long nx = (kc + NST - 1 < nchunks) ? kc + NST - 1 : nchunks - 1;
+    int nbuf = cur + NST - 1;
+    if (nbuf >= NST) nbuf -= NST;
+    stage(nbuf, nx);
+    const char* la = &lds[cur][0];
+    const char* lb = &lds[cur][BM * KC];
+    i4v_t fa[2][TM], fb[2][TN];
+    auto frags = [&](int ks, int slot) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        fa[slot][a] = *reinterpret_cast<const i4v_t*>(la + rot_lds_off(wm * 32 * TM + a * 32 + lrow, ks * 2 + lk));
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        fb[slot][b] = *reinterpret_cast<const i4v_t*>(lb + rot_lds_off(wn * 32 * TN + b * 32 + lrow, ks * 2 + lk));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks < KS - 1) frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads in front of this k-step's matrix instructions
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::: "memory");
+    if (++cur == NST) cur = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // element 4 g + e of a lane's 32 x 32 tile: row 8 g + 4 (lane >> 5) + e of the head side, column lane & 31 of the marker side
+  int* __restrict__ out = part + (((long long)slice * n_tiles + tile) << 16);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ml = wm * 32 * TM + a * 32 + 8 * g + 4 * (lane >> 5) + e;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) out[ml * kBandBT + wn * 32 * TN + b * 32 + (lane & 31)] = acc[a][b][4 * g + e];
+      }
+}
+#define band_gemm_i8 (band_gemm_i8_kernel<2, 4, 4, 2, 2, 128>)
+constexpr int kBandThreads = 512;
+
+// One workgroup per head h of the pass: S(h, h + t), t = 0 .. halo, from the partial tiles; then the algebra of
+// cov_rect_rows_kernel (the same expressions in the same order: the rows are bit-identical to rvt_cov_rect's).
+// cs / xz: column sums and covXZ rows of the pass's columns (index 0 = the pass's first head).
+// band_f32 (optional): (float)value * scale, the number the adapter prints with %g (src/Model.cpp:975-984 casts to float and
+// divides by N in float); band_f64 (optional): the value itself.  Entries beyond the window (h + t >= W) are NaN.
+__global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, const int* __restrict__ part, int n_slices,
+                                                              int n_tiles, const double* __restrict__ cs,
+                                                              const double* __restrict__ xz, int H, int W, int halo,
+                                                              float scale, float* __restrict__ band_f32,
+                                                              double* __restrict__ band_f64) {
+  const int h = blockIdx.x, d = cc.d;
+  __shared__ double a[RVT_MAX_COV];
+  __shared__ int tile0;
+  if (threadIdx.x < d) {
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
+    a[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 64) {
+    int t0 = 0;
+    for (int rp = 0; rp < (h >> 8); ++rp) t0 += band_panel_tiles(rp, W, halo);
+    tile0 = t0;
+  }
+  __syncthreads();
+  const double sh = cs[h];
+  const long long row = (long long)h * (halo + 1);
+  for (int t = threadIdx.x; t <= halo; t += blockDim.x) {
+    const int j = h + t;
+    double v = NAN;
+    if (j < W) {
+      const int tile = tile0 + (j >> 8) - (h >> 8);
+      const int* p = part + ((long long)tile << 16) + (h & 255) * kBandBT + (j & 255);
+      long long s = 0;
+      for (int sl = 0; sl < n_slices; ++sl) s += p[((long long)sl * n_tiles) << 16];
+      const double sxx = (double)s;
+      const double xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
+      double quad = 0.0;
+      for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
+      v = xx - quad;
+    }
+    if (band_f32) band_f32[row + t] = (float)v * scale;
+    if (band_f64) band_f64[row + t] = v;
+  }
+}
+
+// The same band from a rectangle of doubles S (H x Wd, column-major, leading dimension lds: the fp64 matrix cores' product
+// for dosages / a binary trait, or the rotated product of the family model).  fam: the centring algebra of
+// cov_rect_fam_rows_kernel (t1 = G~' D u1).  b2: MetaCovFamBinary's factor on covXX (1 otherwise).
+__global__ __launch_bounds__(256) void band_rows_f64_kernel(CovConsts cc, const double* __restrict__ S, long long lds,
+                                                            const double* __restrict__ cs, const double* __restrict__ xz,
+                                                            const double* __restrict__ t1, int H, int W, int halo, double b2,
+                                                            float scale, float* __restrict__ band_f32,
+                                                            double* __restrict__ band_f64) {
+  const int h = blockIdx.x, d = cc.d;
+  __shared__ double a[RVT_MAX_COV];
+  if (threadIdx.x < d) {
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
+    a[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double sh = cs[h];
+  const double mh = sh * cc.inv_n, t1h = t1 ? t1[h] : 0.0;
+  const long long row = (long long)h * (halo + 1);
+  for (int t = threadIdx.x; t <= halo; t += blockDim.x) {
+    const int j = h + t;
+    double v = NAN;
+    if (j < W) {
+      const double sxx = S[h + (long long)j * lds];
+      double xx;
+      if (t1) {
+        const double mj = cs[j] * cc.inv_n;
+        xx = sxx - mh * t1[j] - mj * t1h + mh * mj * cc.c11;
+      } else {
+        xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
+      }
+      double quad = 0.0;
+      for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
+      v = xx - quad;
+      if (b2 != 1.0) v *= b2;
+    }
+    if (band_f32) band_f32[row + t] = (float)v * scale;
+    if (band_f64) band_f64[row + t] = v;
+  }
+}
+
+// the column statistics a ring keeps per PHYSICAL column -> the work arrays of a band call: logical column j = physical
+// (col0 + j) mod ring
+__global__ void band_cache_gather_kernel(const double* __restrict__ cs_c, const int* __restrict__ poly_c,
+                                         const double* __restrict__ T_c, int ring, int col0, int W, int d, int t_stride,
+                                         double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W) return;
+  long long p = (long long)col0 + j;
+  if (ring > 0 && p >= ring) p -= ring;
+  colsum[j] = cs_c[p];
+  poly[j] = poly_c[p];
+  for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[p * t_stride + k];
+}
+
+}  // namespace rvt

@@ -43,12 +43,19 @@ constexpr int kGemmThreads = 64 * kGemmWM * kGemmWN;
 // symmetric: A and B are the same columns — tiles entirely below the diagonal are skipped (their C entries are not written).
 // n_tiles = the tiles that are computed (gemm_f64_tiles); grid = 8 * n_tiles * ceil(n_slices / 8), see the index map.
 // tiles of an M x Ntot product that are computed
-inline int gemm_f64_tiles(int M, int Ntot, bool symmetric, int* n_col_tiles) {
+// (halo >= 0, symmetric only: a BAND — row m needs the columns m .. m + halo; row panel rp then ends at the column tile that
+//  holds column rp BM + BM - 1 + halo)
+__host__ __device__ inline int gemm_f64_panel_last(int rp, int n_col_tiles, int halo) {
+  if (halo < 0) return n_col_tiles;
+  const long long l = ((long long)rp * kGemmBM + kGemmBM + halo + kGemmBN - 1) / kGemmBN;
+  return l < n_col_tiles ? (int)l : n_col_tiles;
+}
+inline int gemm_f64_tiles(int M, int Ntot, bool symmetric, int* n_col_tiles, int halo = -1) {
   const int nrp = (M + kGemmBM - 1) / kGemmBM, nct = (Ntot + kGemmBN - 1) / kGemmBN;
   *n_col_tiles = nct;
   if (!symmetric) return nrp * nct;
   int n = 0;
-  for (int rp = 0; rp < nrp; ++rp) n += std::max(0, nct - (rp * kGemmBM) / kGemmBN);
+  for (int rp = 0; rp < nrp; ++rp) n += std::max(0, gemm_f64_panel_last(rp, nct, halo) - (rp * kGemmBM) / kGemmBN);
   return n;
 }
 // K slices (a multiple of 8: XCD x takes every 8th slice): the count that minimises rounds x chunks per workgroup, a round
@@ -71,7 +78,9 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
     const double* __restrict__ A, long long lda, int M, const double* __restrict__ B, long long ldb, int Nb,
     const double* __restrict__ B2, long long ldb2, int Nb2, const double* __restrict__ w, long long K, long long kslice,
     int n_slices, double* __restrict__ C0, long long ldc, long long c_slice, int n_tiles, int n_col_tiles,
-    int symmetric) {
+    int symmetric, int halo = -1, int ring = 0, int col0 = 0) {
+  // ring > 0: A and B are the base of a block used as a ring of `ring` columns; column m of either side is the physical
+  // column (col0 + m) mod ring (MetaCov's circular window, band_gemm.hip.h)
   constexpr int WM = kGemmWM, WN = kGemmWN, TM = kGemmTM, TN = kGemmTN, BM = kGemmBM, BN = kGemmBN, KC = kGemmKC;
   constexpr int kWaves = WM * WN;
   constexpr int kPieces = (BM + BN) / 8, PPW = kPieces / kWaves;  // 1 KiB pieces: 8 rows x 128 B
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
   int t = SUB ? id : wq % n_tiles, rp = 0, ct = 0;
   if (symmetric) {  // row panel rp holds the column tiles ct >= first(rp) = (rp * BM) / BN
     for (;; ++rp) {
-      const int first = (rp * BM) / BN, cnt = n_col_tiles - first;
+      const int first = (rp * BM) / BN, cnt = gemm_f64_panel_last(rp, n_col_tiles, halo) - first;
       if (t < cnt) {
         ct = first + t;
         break;
@@ -121,11 +130,23 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
     if (r < BM) {
       long long m = m0 + r;
       if (m >= M) m = M - 1;  // (rows beyond the matrix read a valid column; their outputs are never stored)
+      if (ring > 0) {
+        m += col0;
+        if (m >= ring) m -= ring;
+      }
       base = A + m * lda;
     } else {
       long long j = n0 + (r - BM);
       if (j >= Ntot) j = Ntot - 1;
-      base = (j < Nb) ? B + j * ldb : B2 + (j - Nb) * ldb2;
+      if (j < Nb) {
+        if (ring > 0) {
+          j += col0;
+          if (j >= ring) j -= ring;
+        }
+        base = B + j * ldb;
+      } else {
+        base = B2 + (j - Nb) * ldb2;
+      }
     }
     gsrc[q] = base + k_lo + seg * 2;  // (16-byte segment = 2 samples)
   }

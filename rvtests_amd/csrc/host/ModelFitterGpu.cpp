@@ -814,14 +814,13 @@ int MetaScoreTest::flush() {
 // ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
 MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
   modelName = "MetaCov";
-  // block size of the device ring; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush with it)
+  // columns of the device ring at the start; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush and the wrap with it)
   if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(RVT_MAX_VARIANTS, atoi(e)));
-  // blocks up to this many columns use the symmetric block kernel, wider ones the heads-by-window rectangle
-  if (const char* e = getenv("RVT_METACOV_RECT_ABOVE")) rectAbove = std::max(1, std::min(RVT_MAX_VARIANTS, atoi(e)));
   if (const char* e = getenv("RVT_METACOV_MAX_COLUMNS")) maxColumns = std::max(capacity, atoi(e));
 }
 MetaCovTest::~MetaCovTest() {
   if (fout) flush(true);
+  if (ctx && bandReg) rvt_host_unregister(ctx, bandReg);
   if (ctx && block) rvt_block_free(ctx, block);
 }
 int MetaCovTest::setParameter(const ModelParser& parser) {
@@ -858,18 +857,12 @@ int MetaCovTest::fit(GeneData* dc) {
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;
-    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB): 24 000 columns at N = 500 000
+    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB; the int8 copy the engine keeps per column counted in:
+    // 9 bytes per genotype): 21 000 columns at N = 500 000
     {
       double gb = 96.0;
       if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
-      const double cols = gb * 1e9 / (8.0 * (double)std::max<int64_t>(dc->N, 1));
-      if (cols < (double)maxColumns) maxColumns = std::max(capacity, (int)cols);
-    }
-    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB): 24 000 columns at N = 500 000
-    {
-      double gb = 96.0;
-      if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
-      const double cols = gb * 1e9 / (8.0 * (double)std::max<int64_t>(dc->N, 1));
+      const double cols = gb * 1e9 / (9.0 * (double)std::max<int64_t>(dc->N, 1));
       if (cols < (double)maxColumns) maxColumns = std::max(capacity, (int)cols);
     }
     if (rvt_block_alloc(ctx, capacity, &block)) {
@@ -880,17 +873,21 @@ int MetaCovTest::fit(GeneData* dc) {
   if ((int)sites.size() == capacity) {
     const int before = (int)sites.size();
     if (flush(false)) return -1;
-    // One window holds more sites than the ring: enlarge it.  Round 5: ALSO when the flush could emit less than half of the
-    // ring — a window of 1 000 markers in a ring of 1 024 recomputed 1 000 columns to write 24 rows (4 400 variants/s at
-    // N = 500 000, tools/bench_metacov.py); with a ring of at least twice the window every flush emits half of what it reads.
+    // One window holds more sites than the ring: enlarge it.  ALSO when the flush could emit less than half of the ring — a
+    // window of 1 000 markers in a ring of 1 024 would read 1 000 columns to write 24 rows; with a ring of at least twice the
+    // window every flush emits half of what it reads.
     const bool full = (int)sites.size() == capacity;
-    if (full || 2 * (before - (int)sites.size()) < before) {
-      if (grow() && full) return -1;
-      if (!full) lastError.clear();  // (a ring that cannot grow any further just stays as efficient as it was)
+    if (full || (canGrow && 2 * (before - (int)sites.size()) < before)) {
+      if (grow()) {
+        if (full) return -1;
+        canGrow = false;     // (a ring that cannot grow any further just stays as efficient as it was: do not retry every fill)
+        lastError.clear();
+      }
     }
   }
-  // the caller overwrites the genotype buffer for the next site: copy the column into the device ring now
-  if (rvt_block_upload_columns(ctx, block, (int)sites.size(), 1, dc->genotype)) {
+  // the caller overwrites the genotype buffer for the next site: copy the column into the device ring now — into the physical
+  // column behind the tail; nothing in the ring ever moves (RingMemoryPool::allocate, base/RingMemoryPool.cpp:31-47)
+  if (rvt_block_upload_columns(ctx, block, (head + (int)sites.size()) % capacity, 1, dc->genotype)) {
     lastError = rvt_last_error(ctx);
     return -1;
   }
@@ -907,7 +904,8 @@ void MetaCovTest::writeFootnote(TextSink* fp) {
   flush(true);
 }
 
-// Double the device ring (a window can hold more sites than the current block).
+// Double the device ring (a window can hold more sites than the current block): the one occasion on which columns are copied —
+// the old ring's two runs, head first, to the front of the new one.
 int MetaCovTest::grow() {
   const int want = std::min(maxColumns, capacity * 2);
   if (want <= capacity) {
@@ -915,8 +913,9 @@ int MetaCovTest::grow() {
     return -1;
   }
   double* bigger = nullptr;
-  if (rvt_block_alloc(ctx, want, &bigger) ||
-      rvt_block_copy_columns(ctx, bigger, 0, block, 0, (int)sites.size())) {
+  const int V = (int)sites.size(), first = std::min(V, capacity - head);
+  if (rvt_block_alloc(ctx, want, &bigger) || rvt_block_copy_columns(ctx, bigger, 0, block, head, first) ||
+      (V > first && rvt_block_copy_columns(ctx, bigger, first, block, 0, V - first))) {
     lastError = rvt_last_error(ctx);
     if (bigger) rvt_block_free(ctx, bigger);
     return -1;
@@ -924,10 +923,12 @@ int MetaCovTest::grow() {
   rvt_block_free(ctx, block);
   block = bigger;
   capacity = want;
+  head = 0;
   return 0;
 }
 
-// Emit the rows of every head whose window is complete (all of them when `final`), then compact the ring.
+// Emit the rows of every head whose window is complete (all of them when `final`) and drop those heads: the ring's head index
+// advances, no column moves (RingMemoryPool::deallocate, base/RingMemoryPool.cpp:49-63).
 int MetaCovTest::flush(bool final) {
   const int V = (int)sites.size();
   if (V == 0 || !fout) return 0;
@@ -942,88 +943,83 @@ int MetaCovTest::flush(bool final) {
     if (!complete) break;
   }
   if (H == 0) return 0;  // nothing can be written yet: the caller enlarges the ring
+  // whole row panels of the band kernel (256 heads): a panel of 24 heads costs the tiles of a full one; the rest waits in the
+  // ring — nothing moves, so keeping them costs nothing
+  if (!final && H > 256) H -= H % 256;
   const float scale = (float)(1.0 / (double)nSample);
   std::vector<double> zz((size_t)d * d);
-  // one output row; covAt(j) / xzHead / polyAt(j) read whichever layout the device call produced
-  auto emitRow = [&](int h, const std::function<double(int)>& covAt, const double* xzHead,
-                     const std::function<bool(int)>& polyAt) {
-    std::string positions, values;
-    int last = h, num = 0;
-    for (int j = h; j < V; ++j) {
-      if (outOfWindow(h, j)) break;
-      if (!polyAt(j)) continue;
-      if (num) {
-        positions += ',';
-        values += ',';
-      }
-      positions += std::to_string(sites[j].pos);
-      values += formatG((double)((float)covAt(j) * scale));
-      last = j;
-      ++num;
+  // last[h] = the last site printed in head h's row (the scan of printCovariance stops at the first site out of the window)
+  std::vector<int> last((size_t)H);
+  for (int h = 0; h < H; ++h) {
+    int j = h;
+    while (j + 1 < V && !outOfWindow(h, j + 1)) ++j;
+    last[(size_t)h] = j;
+  }
+  // chunks of heads: one device call each — the band of the chunk's heads against everything up to the end of their windows,
+  // read from the ring where it lies (the call addresses the columns modulo the capacity)
+  const int Hc = 4096;
+  std::vector<double> xz;
+  std::vector<int> poly;
+  for (int h0 = 0; h0 < H; h0 += Hc) {
+    const int h1 = std::min(H, h0 + Hc), nh = h1 - h0;
+    int halo = 0, jmax = h1 - 1;
+    for (int h = h0; h < h1; ++h) {
+      halo = std::max(halo, last[(size_t)h] - h);
+      jmax = std::max(jmax, last[(size_t)h]);
     }
-    if (outputGwama || isBinaryOutcome()) {  // src/Model.cpp:992-1000
-      values += ':';
-      for (int k = 0; k < d; ++k) {
-        if (k) values += ',';
-        values += formatG((double)((float)xzHead[k] * scale));
-      }
-      values += ':';
-      for (int a = 0; a < d; ++a)
-        for (int b = 0; b <= a; ++b) {
-          if (a || b) values += ',';
-          values += floatToString(zz[(size_t)a * d + b] * (double)scale);
-        }
+    const int W = jmax - h0 + 1;
+    const size_t need = (size_t)nh * ((size_t)halo + 1);
+    if (bandBuf.size() < need) {
+      // the band lands by DMA in a page-locked buffer (a pageable target went through the runtime's staging copies: a third of
+      // the device-side time of a flush)
+      if (bandReg) rvt_host_unregister(ctx, bandReg);
+      bandReg = nullptr;
+      bandBuf.assign(need + need / 4, 0.0f);
+      if (rvt_host_register(ctx, bandBuf.data(), sizeof(float) * bandBuf.size()) == 0) bandReg = bandBuf.data();
     }
-    fout->write(sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[last].pos) + "\t" +
-                std::to_string(num) + "\t" + positions + "\t" + values + "\n");
-  };
-  if (V <= rectAbove) {
-    // the whole ring is one block of the symmetric kernel
-    std::vector<double> cov((size_t)V * V), xz((size_t)V * d);
-    std::vector<int> poly(V);
-    if (useFamilyModel ? rvt_cov_block_fam(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())
-                       : rvt_cov_block(ctx, block, V, cov.data(), xz.data(), zz.data(), poly.data())) {
+    xz.assign((size_t)W * d, 0.0);
+    poly.assign((size_t)W, 0);
+    const int col0 = (head + h0) % capacity;
+    if (useFamilyModel ? rvt_cov_band_fam(ctx, block, capacity, col0, nh, W, halo, scale, bandBuf.data(), xz.data(), zz.data(), poly.data())
+                       : rvt_cov_band(ctx, block, capacity, col0, nh, W, halo, scale, bandBuf.data(), xz.data(), zz.data(), poly.data())) {
       lastError = rvt_last_error(ctx);
       return -1;
     }
-    for (int h = 0; h < H; ++h) {
-      if (!poly[h]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
-      emitRow(
-          h, [&](int j) { return cov[(size_t)h + (size_t)j * V]; }, xz.data() + (size_t)h * d,
-          [&](int j) { return poly[j] != 0; });
-    }
-  } else {
-    // wide windows: chunks of heads against everything up to the end of the last head's window
-    // (every call runs the column pass over its W = heads + window columns: 1 024 heads per call read a window of 1 000
-    //  markers twice, 256 heads read it five times)
-    const int Hc = std::min(1024, rectAbove);
-    for (int h0 = 0; h0 < H; h0 += Hc) {
-      const int h1 = std::min(H, h0 + Hc);
-      int jmax = h1 - 1;
-      for (int j = h1; j < V && !outOfWindow(h1 - 1, j); ++j) jmax = j;
-      // (positions are sorted within a chromosome, so the last head's window contains the others' windows)
-      for (int h = h0; h < h1; ++h)
-        for (int j = jmax + 1; j < V && !outOfWindow(h, j); ++j) jmax = j;
-      const int nh = h1 - h0, W = jmax - h0 + 1;
-      std::vector<double> cov((size_t)nh * W), xz((size_t)W * d);
-      std::vector<int> poly(W);
-      if (useFamilyModel ? rvt_cov_rect_fam(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())
-                         : rvt_cov_rect(ctx, block, h0, nh, W, cov.data(), xz.data(), zz.data(), poly.data())) {
-        lastError = rvt_last_error(ctx);
-        return -1;
+    for (int h = h0; h < h1; ++h) {
+      if (!poly[(size_t)(h - h0)]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
+      const float* row = bandBuf.data() + (size_t)(h - h0) * ((size_t)halo + 1);
+      std::string positions, values;
+      int lastPrinted = h, num = 0;
+      for (int j = h; j <= last[(size_t)h]; ++j) {
+        if (!poly[(size_t)(j - h0)]) continue;
+        if (num) {
+          positions += ',';
+          values += ',';
+        }
+        positions += std::to_string(sites[j].pos);
+        values += formatG((double)row[j - h]);   // (the device applied the float cast and the float 1/N, src/Model.cpp:975-984)
+        lastPrinted = j;
+        ++num;
       }
-      for (int h = h0; h < h1; ++h) {
-        if (!poly[h - h0]) continue;
-        emitRow(
-            h, [&](int j) { return cov[(size_t)(h - h0) + (size_t)(j - h0) * nh]; },
-            xz.data() + (size_t)(h - h0) * d, [&](int j) { return j - h0 < W && poly[j - h0] != 0; });
+      if (outputGwama || isBinaryOutcome()) {  // src/Model.cpp:992-1000
+        const double* xzHead = xz.data() + (size_t)(h - h0) * d;
+        values += ':';
+        for (int k = 0; k < d; ++k) {
+          if (k) values += ',';
+          values += formatG((double)((float)xzHead[k] * scale));
+        }
+        values += ':';
+        for (int a = 0; a < d; ++a)
+          for (int b = 0; b <= a; ++b) {
+            if (a || b) values += ',';
+            values += floatToString(zz[(size_t)a * d + b] * (double)scale);
+          }
       }
+      fout->write(sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[lastPrinted].pos) + "\t" +
+                  std::to_string(num) + "\t" + positions + "\t" + values + "\n");
     }
   }
-  if (H < V && rvt_block_move_columns(ctx, block, 0, H, V - H)) {
-    lastError = rvt_last_error(ctx);
-    return -1;
-  }
+  head = (head + H) % capacity;
   sites.erase(sites.begin(), sites.begin() + H);
   return 0;
 }

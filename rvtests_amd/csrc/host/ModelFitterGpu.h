@@ -376,16 +376,19 @@ class MetaCovTest : public ModelFitter {
   int grow();
   int windowSize;
   int capacity = RVT_MAX_VARIANTS;     // columns of the device ring (grows when one window needs more)
-  int rectAbove = RVT_MAX_VARIANTS;    // widest ring handled by the symmetric block kernel
+  int head = 0;                        // physical column of sites[0]: site k lives in column (head + k) mod capacity
   int maxColumns = 65536;              // RVT_METACOV_MAX_COLUMNS
+  bool canGrow = true;                 // false once a non-mandatory grow() failed (not retried on every fill)
+  std::vector<float> bandBuf;          // where the band of a flush lands (page-locked: rvt_host_register)
+  float* bandReg = nullptr;
   bool outputGwama = false;
   bool fitOK = false;
   bool useFamilyModel = false;
   int64_t nSample = -1;
   int nCovariate = 0;
   rvt_ctx* ctx = nullptr;
-  double* block = nullptr;   // device block of RVT_MAX_VARIANTS columns
-  std::vector<Site> sites;   // variants currently in the block, file order
+  double* block = nullptr;   // the device ring: `capacity` columns, never compacted
+  std::vector<Site> sites;   // variants currently in the ring, file order
   TextSink* fout = nullptr;
 };
 

@@ -1094,7 +1094,10 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
                                                           signed char* __restrict__ out8, long long ldk,
                                                           double* __restrict__ part, int* __restrict__ bad,
                                                           const double* __restrict__ wts = nullptr,
-                                                          int* __restrict__ hard_flag = nullptr) {
+                                                          int* __restrict__ hard_flag = nullptr, int ring = 0,
+                                                          int ring_col0 = 0) {
+  // ring > 0: G is the base of a block used as a ring of `ring` columns, column j of the call is the physical column
+  // (ring_col0 + j) mod ring (MetaCov's circular window); the outputs (out8, part) are indexed by j
   const int c0 = blockIdx.x * kCovHcCols;
   bool not_hard = false;  // a value other than 0.0 / 1.0 / 2.0: the int8 copy is not the block (the host falls back)
   const int nc = min(kCovHcCols, W - c0);
@@ -1142,7 +1145,12 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 #pragma unroll
     for (int c = 0; c < kCovHcCols; ++c) {
       if (c < nc) {
-        const double* gp = G + (long long)(c0 + c) * ld + i;
+        long long pc = c0 + c;
+        if (ring > 0) {
+          pc += ring_col0;
+          if (pc >= ring) pc -= ring;
+        }
+        const double* gp = G + pc * ld + i;
         const double2 a = *reinterpret_cast<const double2*>(gp);
         const double2 b = *reinterpret_cast<const double2*>(gp + 2);
         const double g[4] = {a.x, a.y, b.x, b.y};

@@ -632,7 +632,7 @@ RVT_INTERNAL int rvt_planes_gemm(rvt_ctx* c, const signed char* A, size_t a_stri
 // ---- defined in rvt_meta.hip: C = A' D [B | B2] in fp64 on the matrix cores (gemm_f64.hip.h)
 RVT_INTERNAL int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B, int64_t ldb, int Nb, const double* B2,
                              int64_t ldb2, int Nb2, const double* w, int64_t N, double* C, int64_t ldc, bool symmetric,
-                             hipStream_t st, bool subtract = false);
+                             hipStream_t st, bool subtract = false, int halo = -1, int ring = 0, int col0 = 0);
 // ---- defined in rvt_perm.hip
 RVT_INTERNAL int rvt_kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std::vector<unsigned char>& y,
                                 int nPerm, double alpha, rvt_kbac_result* r);

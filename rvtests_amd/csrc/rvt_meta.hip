@@ -2,6 +2,7 @@
 // exact int8 band for hard calls) and the column operations of the adapters' device ring.  Part of librvtests_amd.so.
 #include "rvt_engine_int.h"
 #include "gemm_f64.hip.h"
+#include "band_gemm.hip.h"
 
 // row slices of MetaCov's column pass (cov_hc_prep_kernel): a function of N alone, so that a column's sums are the same numbers
 // whether it is treated inside a block or alone behind its upload (rvt_block_upload_columns)
@@ -15,13 +16,16 @@ extern "C" {
 // left unspecified).  K is split over the chip; the partial results are added in a fixed order.
 // subtract: C -= A' D B instead (every entry is read and written by one thread); the product then runs as ONE K slice, the
 // grid being the tile list — meant for short K (a rank-k update of a large C).
+// halo >= 0 (symmetric only): a band — row m needs the columns m .. m + halo, only those tiles are computed.
+// ring > 0: A = B = the base of a block used as a ring of `ring` columns, column m is physical column (col0 + m) mod ring.
 int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B, int64_t ldb, int Nb, const double* B2,
                 int64_t ldb2, int Nb2, const double* w, int64_t N, double* C, int64_t ldc, bool symmetric, hipStream_t st,
-                bool subtract) {
+                bool subtract, int halo, int ring, int col0) {
   const int Ntot = Nb + Nb2;
   if (M < 1 || Ntot < 1) return RVT_OK;
+  if (!symmetric) halo = -1;
   int nct = 0;
-  const int n_tiles = gemm_f64_tiles(M, Ntot, symmetric, &nct);
+  const int n_tiles = gemm_f64_tiles(M, Ntot, symmetric, &nct, halo);
   const int64_t chunks = (N + kGemmKC - 1) / kGemmKC;
   int64_t slices = gemm_f64_slices(n_tiles, chunks);
   if (const char* e = getenv("RVT_GEMM64_SLICES")) slices = std::max<int64_t>(1, atoll(e));
@@ -47,11 +51,11 @@ int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B
   if (subtract)
     hipLaunchKernelGGL((gemm_tn_f64_kernel<3, true>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
                        B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, 1, d_out, (long long)ldc,
-                       0LL, n_tiles, nct, symmetric ? 1 : 0);
+                       0LL, n_tiles, nct, symmetric ? 1 : 0, halo, ring, col0);
   else
     hipLaunchKernelGGL((gemm_tn_f64_kernel<3, false>), grid, dim3(kGemmThreads), 0, st, A, (long long)lda, M, B, (long long)ldb, Nb,
                        B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, (int)slices, d_out,
-                       (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0);
+                       (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0, halo, ring, col0);
   if (slices > 1)
     hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_out, (long long)ldc, (long long)M,
                        (long long)Ntot, (long long)c_slice, (int)slices, C, 0);
@@ -395,15 +399,234 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
   return RVT_OK;
 }
 
+
+// ---- MetaCov on a circular ring: the band of a sliding window ----------------------------------------------------------------
+// flags of the W logical columns of a ring (physical (col0 + j) mod ring): 1 = every column holds hard calls only, 0 = some
+// column holds something else, -1 = nothing known about the block
+static int ring_hard_calls(rvt_ctx* c, const double* dG, int ring, int col0, int W) {
+  if (!c->hc_enabled) return 0;
+  auto it = c->col_kind.find(dG);
+  const int span = ring > 0 ? ring : col0 + W;
+  if (it == c->col_kind.end() || !it->second.d_flags || span > it->second.cols) return c->content_hint == 0 ? 0 : -1;
+  std::vector<int> f((size_t)span);
+  if (hipMemcpyAsync(f.data(), it->second.d_flags, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->io_stream) != hipSuccess ||
+      sync_stream(c->io_stream) != hipSuccess)
+    return 0;
+  for (int j = 0; j < W; ++j) {
+    int p = col0 + j;
+    if (ring > 0 && p >= ring) p -= ring;
+    if (!f[(size_t)p]) return 0;
+  }
+  return 1;
+}
+
+static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H, int W, int halo, float scale, float* band,
+                         double* xz, double* zz, int* polymorphic, bool allow_fast) {
+  if (!c || !dG || ring < 0 || col0 < 0 || H < 1 || W < H || halo < 0 || !band || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (ring > 0 && (col0 >= ring || W > ring)) return fail(c, RVT_E_INVALID, "window of %d columns from %d in a ring of %d", W, col0, ring);
+  if ((long long)W > (long long)H + halo) W = H + halo;  // (markers behind the last head's window are never read)
+  {
+    auto it = c->col_kind.find(dG);
+    if (it != c->col_kind.end() && (ring > 0 ? ring : col0 + W) > it->second.cols)
+      return fail(c, RVT_E_INVALID, "the window leaves the block (%d columns)", it->second.cols);
+  }
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const NullConsts& nc = c->nc;
+  const int64_t N = nc.N, ld = nc.ld;
+  const int d = nc.d;
+  CovConsts cc;
+  std::vector<double> zzv;
+  rc = cov_constants(c, false, &cc, &zzv);
+  if (rc) return rc;
+  const int ringk = (ring > 0 && col0 + W > ring) ? ring : 0;   // (a window that does not wrap is a linear range)
+  const bool fast = allow_fast && !nc.binary && ring_hard_calls(c, dG, ring, col0, W) != 0 && !getenv("RVT_METACOV_FP64");
+  // heads per pass: the partial tiles (int8) or the rectangle of doubles (fp64) of a pass stay within a few hundred MB
+  const int Hc = fast ? 4096 : 1024;
+  const int Hp = std::min(H, Hc), Wp = (int)std::min<long long>(W, (long long)Hp + halo);
+  double *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_tmp = nullptr, *d_S = nullptr;
+  float* d_band = nullptr;
+  int* d_poly = nullptr;
+  {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t bT = up(sizeof(double) * (size_t)W * d), bV = up(sizeof(double) * (size_t)W), bP = up(sizeof(int) * (size_t)W);
+    const size_t bM = up(sizeof(double) * (size_t)kCovSlices * W * (RVT_MAX_COV + 3));
+    const size_t bB = up(sizeof(float) * (size_t)Hp * ((size_t)halo + 1));
+    const size_t bS = fast ? 0 : up(sizeof(double) * (size_t)Hp * Wp);
+    const size_t need = 2 * bT + bV + bP + bM + bB + bS;
+    if (c->cov_work_cap < need) {
+      if (c->d_cov_work) hipFree(c->d_cov_work);
+      c->d_cov_work = nullptr;
+      c->cov_work_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_cov_work, need + need / 4));
+      c->cov_work_cap = need + need / 4;
+    }
+    char* q = c->d_cov_work;
+    d_T = reinterpret_cast<double*>(q);
+    q += bT;
+    d_xz = reinterpret_cast<double*>(q);
+    q += bT;
+    d_cs = reinterpret_cast<double*>(q);
+    q += bV;
+    d_poly = reinterpret_cast<int*>(q);
+    q += bP;
+    d_tmp = reinterpret_cast<double*>(q);
+    q += bM;
+    d_band = reinterpret_cast<float*>(q);
+    q += bB;
+    d_S = reinterpret_cast<double*>(q);
+  }
+  const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+  const int wgs = (W + kCovHcCols - 1) / kCovHcCols;
+  const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, N / 4096 + 1));
+  const double* Gbase = ringk ? dG : dG + (size_t)col0 * ld;   // what the column pass indexes from
+  const int pcol0 = ringk ? col0 : 0;
+  int* d_bad = nullptr;
+  int h_bad = 0;
+  // the ring's own column cache (rvt_block_upload_columns made it behind the PCIe copies)
+  const rvt_ctx::ColKind* ckc = nullptr;
+  if (fast) {
+    auto itc = c->col_kind.find(dG);
+    if (itc != c->col_kind.end() && itc->second.d_i8 && itc->second.gen == c->null_gen &&
+        itc->second.ldk == (N + 127) / 128 * 128 && !getenv("RVT_METACOV_NO_CACHE")) {
+      bool all = true;
+      for (int j = 0; j < W && all; ++j) {
+        int p = col0 + j;
+        if (ring > 0 && p >= ring) p -= ring;
+        all = itc->second.valid[(size_t)p] != 0;
+      }
+      if (all) ckc = &itc->second;
+    }
+  }
+  const int8_t* R8 = nullptr;   // the int8 columns the product reads, their ring and first column
+  int r8_ring = 0, r8_col0 = 0;
+  int64_t ldk = (N + 127) / 128 * 128;
+  if (fast && ckc) {
+    hipLaunchKernelGGL(band_cache_gather_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, ckc->d_cs, ckc->d_poly,
+                       ckc->d_T, ringk, col0, W, d, RVT_MAX_COV, d_cs, d_poly, d_T);
+    R8 = reinterpret_cast<const int8_t*>(ckc->d_i8);
+    r8_ring = ringk;
+    r8_col0 = col0;
+  } else if (fast) {
+    // no cache: ONE pass over the window's columns gives the statistics, T = G'X and a linear int8 copy of the window
+    const size_t need = ((size_t)W + kBandBT) * (size_t)ldk;
+    if (c->rotB_cap < need) {
+      if (c->d_rotB) hipFree(c->d_rotB);
+      c->d_rotB = nullptr;
+      c->rotB_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
+      c->rotB_cap = need + need / 4;
+    }
+    const int64_t n4 = (N + 3) / 4 * 4;
+    if (ldk > n4) HIP_TRY(c, hipMemset2DAsync(c->d_rotB + n4, (size_t)ldk, 0, (size_t)(ldk - n4), (size_t)W, st));
+    if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
+    d_bad = c->d_kind;
+    HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    const dim3 grid((unsigned)wgs, (unsigned)slices);
+    if (dmax == 4)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr, ringk, pcol0);
+    else if (dmax == 8)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr, ringk, pcol0);
+    else
+      hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W,
+                         c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr,
+                         ringk, pcol0);
+    hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
+                       W, d, dmax, d_cs, d_poly, d_T);
+    R8 = reinterpret_cast<const int8_t*>(c->d_rotB);
+  } else {
+    const dim3 grid((unsigned)wgs, (unsigned)slices);
+    const double* wts = nc.binary ? c->d_v : nullptr;
+    if (dmax == 4)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<4, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk, pcol0);
+    else if (dmax == 8)
+      hipLaunchKernelGGL((cov_hc_prep_kernel<8, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
+                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk, pcol0);
+    else
+      hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W,
+                         c->d_X, (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk,
+                         pcol0);
+    hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
+                       W, d, dmax, d_cs, d_poly, d_T);
+  }
+  hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
+  HIP_TRY(c, hipGetLastError());
+  // the heads in passes of up to Hc: pass (h0, nh) covers the logical columns [h0, h0 + wsub)
+  for (int h0 = 0; h0 < H; h0 += Hc) {
+    const int nh = std::min(Hc, H - h0);
+    const int wsub = (int)std::min<long long>((long long)W - h0, (long long)nh + halo);
+    if (fast) {
+      const int n_tiles = band_tiles(nh, wsub, halo);
+      const int64_t kbytes = ldk, chunks = kbytes / kRotKC;
+      int64_t nsl = band_slices(n_tiles, chunks, (size_t)3 << 30);
+      if (const char* e = getenv("RVT_BAND_SLICES")) nsl = std::max<int64_t>(1, atoll(e));
+      const int64_t kslice = ((chunks + nsl - 1) / nsl) * kRotKC;
+      nsl = (kbytes + kslice - 1) / kslice;
+      const size_t need = sizeof(int) * (size_t)n_tiles * (size_t)nsl * kBandBT * kBandBT;
+      if (c->rot_part_cap < need) {
+        if (c->d_rot_part) hipFree(c->d_rot_part);
+        c->d_rot_part = nullptr;
+        c->rot_part_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_rot_part, need));
+        c->rot_part_cap = need;
+      }
+      int* d_part = reinterpret_cast<int*>(c->d_rot_part);
+      int pc = r8_col0 + h0;
+      if (r8_ring > 0 && pc >= r8_ring) pc -= r8_ring;
+      const int pr = (r8_ring > 0 && pc + wsub > r8_ring) ? r8_ring : 0;
+      const unsigned grid = (unsigned)(8 * (int64_t)n_tiles * ((nsl + 7) / 8));
+      hipLaunchKernelGGL(band_gemm_i8, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
+                         (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
+      hipLaunchKernelGGL(band_finish_i32_kernel, dim3((unsigned)nh), dim3(256), 0, st, cc, d_part, (int)nsl, n_tiles, d_cs + h0,
+                         d_xz + (size_t)h0 * d, nh, wsub, halo, scale, d_band, (double*)nullptr);
+    } else {
+      // dosages, a binary trait's weights: the band tiles of S = G_H' D G_W on the fp64 matrix cores (gemm_f64.hip.h)
+      const double* wts = nc.binary ? c->d_v : nullptr;
+      int pc = col0 + h0;
+      if (ring > 0 && pc >= ring) pc -= ring;
+      const int pr = (ring > 0 && pc + wsub > ring) ? ring : 0;
+      const double* base = pr ? dG : dG + (size_t)pc * ld;
+      rc = gemm_tn_f64(c, base, ld, nh, base, ld, wsub, nullptr, 0, 0, wts, N, d_S, nh, true, st, false, halo, pr, pr ? pc : 0);
+      if (rc) return rc;
+      hipLaunchKernelGGL(band_rows_f64_kernel, dim3((unsigned)nh), dim3(256), 0, st, cc, d_S, (long long)nh, d_cs + h0,
+                         d_xz + (size_t)h0 * d, (const double*)nullptr, nh, wsub, halo, 1.0, scale, d_band, (double*)nullptr);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(band + (size_t)h0 * ((size_t)halo + 1), d_band, sizeof(float) * (size_t)nh * ((size_t)halo + 1),
+                              hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
+  if (d_bad) HIP_TRY(c, hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, sync_stream(st));
+  if (h_bad) return cov_band_impl(c, dG, ring, col0, H, W, halo, scale, band, xz, zz, polymorphic, false);  // not hard calls after all
+  if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
+  return RVT_OK;
+}
+int rvt_cov_band(rvt_ctx* c, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
+                 double* xz, double* zz, int* polymorphic) {
+  return cov_band_impl(c, dG, ring_cols, col0, H, W, halo, scale, band, xz, zz, polymorphic, true);
+}
+
 // MetaCov with kinship for windows wider than one block (MetaCovFamQtl / MetaCovFamBinary, src/Model.cpp:437-504,595-692):
 // heads [col0, col0 + H) against markers [col0, col0 + W) of the RAW block dG.  The W columns are rotated by U'
 // (integer planes), then S = (D G~_H)' G~_W and T = G~_W' D [U'X | u1] are two more integer-plane products and the
 // centring algebra of the block kernel finishes the rows.  Same outputs as rvt_cov_rect.
-int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
-                     int* polymorphic) {
-  if (!c || !dG || col0 < 0 || H < 1 || W < H || !cov || !xz || !polymorphic)
+// (ring > 0: dG is a block used as a ring of `ring` columns, logical column j = physical (col0 + j) mod ring.
+//  halo < 0: the rectangle cov[h + j H]; halo >= 0: the band, band[h (halo + 1) + t] = (float)value(h, h + t) * scale.)
+static int cov_rect_fam_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H, int W, int halo, float scale, double* cov,
+                             float* band, double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || col0 < 0 || H < 1 || W < H || (!cov && !band) || !xz || !polymorphic)
     return fail(c, RVT_E_INVALID, "bad arguments");
   if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  if (ring > 0 && (col0 >= ring || W > ring)) return fail(c, RVT_E_INVALID, "window of %d columns from %d in a ring of %d", W, col0, ring);
   hipSetDevice(c->device);
   int rc = rvt_sync(c);
   if (rc) return rc;
@@ -421,8 +644,20 @@ int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, doubl
   }
   rc = ensure_fam_cols(c, (size_t)W, ld);
   if (rc) return rc;
-  const double* GW = dG + (size_t)col0 * ld;
+  // the window's columns as at most two contiguous runs of the ring
+  struct Seg {
+    int phys, n, at;
+  };
+  Seg segs[2];
+  int nseg = 1;
+  segs[0] = Seg{col0, W, 0};
+  if (ring > 0 && col0 + W > ring) {
+    segs[0].n = ring - col0;
+    segs[1] = Seg{0, W - segs[0].n, segs[0].n};
+    nseg = 2;
+  }
   double *d_S = nullptr, *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_cov = nullptr, *d_w = nullptr, *d_t1 = nullptr;
+  float* d_band = nullptr;
   int* d_poly = nullptr;
   struct Guard {
     std::vector<void**> p;
@@ -431,20 +666,24 @@ int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, doubl
         if (*q) hipFree(*q);
     }
   } guard{{(void**)&d_S, (void**)&d_T, (void**)&d_cs, (void**)&d_xz, (void**)&d_cov, (void**)&d_w, (void**)&d_t1,
-           (void**)&d_poly}};
+           (void**)&d_poly, (void**)&d_band}};
   HIP_TRY(c, hipMalloc((void**)&d_S, sizeof(double) * (size_t)H * W));
-  HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  if (halo < 0) HIP_TRY(c, hipMalloc((void**)&d_cov, sizeof(double) * (size_t)H * W));
+  else HIP_TRY(c, hipMalloc((void**)&d_band, sizeof(float) * (size_t)H * ((size_t)halo + 1)));
   HIP_TRY(c, hipMalloc((void**)&d_T, sizeof(double) * (size_t)W * (du + 1)));
   HIP_TRY(c, hipMalloc((void**)&d_xz, sizeof(double) * (size_t)W * du));
   HIP_TRY(c, hipMalloc((void**)&d_t1, sizeof(double) * (size_t)W));
   HIP_TRY(c, hipMalloc((void**)&d_cs, sizeof(double) * (size_t)W));
   HIP_TRY(c, hipMalloc((void**)&d_poly, sizeof(int) * (size_t)W));
   HIP_TRY(c, hipMalloc((void**)&d_w, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H)));
-  hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)W), dim3(256), 0, st, GW, (long long)N, (long long)ld, d_cs,
-                     d_poly);
   HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * W, st));
-  rc = rotate_columns(c, GW, ld, W, c->d_Gt, ld, st);
-  if (rc) return rc;
+  for (int k = 0; k < nseg; ++k) {
+    const double* GW = dG + (size_t)segs[k].phys * ld;
+    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)segs[k].n), dim3(256), 0, st, GW, (long long)N, (long long)ld,
+                       d_cs + segs[k].at, d_poly + segs[k].at);
+    rc = rotate_columns(c, GW, ld, segs[k].n, c->d_Gt + (size_t)segs[k].at * ld, ld, st);
+    if (rc) return rc;
+  }
   // the weights D = 1 / ((|lambda| + delta) sigma2) ride on the small operands: D [U'X | u1] and D G~_H
   HIP_TRY(c, hipMemsetAsync(d_w, 0, sizeof(double) * (size_t)ld * (size_t)(du + 1 + H), st));
   hipLaunchKernelGGL(scale_rows_kernel, dim3(64, (unsigned)(du + 1)), dim3(256), 0, st, c->d_cX, c->d_cv, (long long)N,
@@ -457,21 +696,60 @@ int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, doubl
   if (rc) return rc;
   hipLaunchKernelGGL(cov_rect_fam_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz,
                      d_t1);
-  hipLaunchKernelGGL(cov_rect_fam_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, d_t1, H, W,
-                     d_cov);
-  HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  const double b2 = c->famcov_b2;  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
+  if (halo < 0) {
+    hipLaunchKernelGGL(cov_rect_fam_rows_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, d_cs, d_xz, d_t1, H, W,
+                       d_cov);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, st));
+  } else {
+    hipLaunchKernelGGL(band_rows_f64_kernel, dim3((unsigned)H), dim3(256), 0, st, cc, d_S, (long long)H, d_cs, d_xz,
+                       (const double*)d_t1, H, W, halo, b2, scale, d_band, (double*)nullptr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(band, d_band, sizeof(float) * (size_t)H * ((size_t)halo + 1), hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * du, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
   if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)du * du);
-  if (c->famcov_b2 != 1.0) {  // MetaCovFamBinary: covXX, covXZ, covZZ each carry b^2 (Model.cpp:651-668)
-    const double b2 = c->famcov_b2;
-    for (int h = 0; h < H; ++h)
-      for (int j = h; j < W; ++j) cov[(size_t)h + (size_t)j * H] *= b2;
+  if (b2 != 1.0) {
+    if (halo < 0)
+      for (int h = 0; h < H; ++h)
+        for (int j = h; j < W; ++j) cov[(size_t)h + (size_t)j * H] *= b2;
     for (size_t i = 0; i < (size_t)W * du; ++i) xz[i] *= b2;
     if (zz)
       for (int i = 0; i < du * du; ++i) zz[i] *= b2;
+  }
+  return RVT_OK;
+}
+int rvt_cov_rect_fam(rvt_ctx* c, const double* dG, int col0, int H, int W, double* cov, double* xz, double* zz,
+                     int* polymorphic) {
+  if (!cov) return fail(c, RVT_E_INVALID, "bad arguments");
+  return cov_rect_fam_impl(c, dG, 0, col0, H, W, -1, 1.0f, cov, nullptr, xz, zz, polymorphic);
+}
+// The family counterpart of rvt_cov_band: the heads in passes of up to 1 024 (every pass rotates the columns of its heads and
+// of the window behind them).  xz / polymorphic: the W logical columns.
+int rvt_cov_band_fam(rvt_ctx* c, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
+                     double* xz, double* zz, int* polymorphic) {
+  if (!c || !dG || ring_cols < 0 || col0 < 0 || H < 1 || W < H || halo < 0 || !band || !xz || !polymorphic)
+    return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_fam) return fail(c, RVT_E_STATE, "rvt_set_kinship + rvt_fit_fam_null first");
+  if ((long long)W > (long long)H + halo) W = H + halo;
+  const int du = c->famcov_nc.d - 2, Hc = 1024;
+  std::vector<double> xzp;
+  std::vector<int> pp;
+  for (int h0 = 0; h0 < H; h0 += Hc) {
+    const int nh = std::min(Hc, H - h0);
+    const int wsub = (int)std::min<long long>((long long)W - h0, (long long)nh + halo);
+    int pc = col0 + h0;
+    if (ring_cols > 0 && pc >= ring_cols) pc -= ring_cols;
+    xzp.assign((size_t)wsub * du, 0.0);
+    pp.assign((size_t)wsub, 0);
+    int rc = cov_rect_fam_impl(c, dG, ring_cols, pc, nh, wsub, halo, scale, nullptr, band + (size_t)h0 * ((size_t)halo + 1),
+                               xzp.data(), zz, pp.data());
+    if (rc) return rc;
+    std::memcpy(xz + (size_t)h0 * du, xzp.data(), sizeof(double) * xzp.size());
+    std::memcpy(polymorphic + h0, pp.data(), sizeof(int) * pp.size());
   }
   return RVT_OK;
 }
@@ -522,6 +800,17 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   // what the engine knows about the columns travels with them: content flags and the column cache
   auto itd = c->col_kind.find(dst);
   auto its = c->col_kind.find(src);
+  if (itd != c->col_kind.end() && dst == src) {
+    // a copy inside one block (not the forward move of rvt_block_move_columns): the target columns' flags and cache entries
+    // describe what was there before — unknown from here on
+    rvt_ctx::ColKind& t = itd->second;
+    for (int k = 0; k < ncols && !t.valid.empty(); ++k)
+      if ((size_t)(dst_col + k) < t.valid.size()) t.valid[(size_t)(dst_col + k)] = 0;
+    if (t.d_flags && dst_col < t.cols) {
+      HIP_TRY(c, hipMemsetAsync(t.d_flags + dst_col, 0, sizeof(int) * (size_t)std::min(ncols, t.cols - dst_col), c->io_stream));
+      HIP_TRY(c, sync_stream(c->io_stream));
+    }
+  }
   if (itd != c->col_kind.end() && dst != src) {
     rvt_ctx::ColKind& t = itd->second;
     const rvt_ctx::ColKind* s = its != c->col_kind.end() ? &its->second : nullptr;
@@ -557,6 +846,16 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   // column pass of MetaCov's hard-call band itself (cov_hc_prep_kernel on the one column): int8 copy, sum, min / max and the
   // row of T = G'X stay with the block (ColKind), the flag falls out of its value test.
   auto it = c->col_kind.find(dG);
+  if (it != c->col_kind.end()) {
+    // whatever the engine knew about the overwritten columns is void from here on — also when the passes below do not run
+    // (hard calls switched off, RVT_METACOV_NO_CACHE): a stale cache entry would hand the OLD column to the integer product,
+    // which no longer tests what it reads once the entry is marked valid
+    rvt_ctx::ColKind& ck = it->second;
+    for (int k = 0; k < ncols && !ck.valid.empty(); ++k)
+      if ((size_t)(col0 + k) < ck.valid.size()) ck.valid[(size_t)(col0 + k)] = 0;
+    if (ck.d_flags && !c->hc_enabled && col0 < ck.cols)  // (flags are not recomputed below: unknown = not hard calls)
+      HIP_TRY(c, hipMemsetAsync(ck.d_flags + col0, 0, sizeof(int) * (size_t)std::min(ncols, ck.cols - col0), c->io_stream));
+  }
   if (it != c->col_kind.end() && c->hc_enabled && col0 + ncols <= it->second.cols) {
     rvt_ctx::ColKind& ck = it->second;
     if (!ck.d_flags) {

@@ -203,6 +203,10 @@ def load_library():
     L.rvt_cov_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
     L.rvt_cov_rect_fam.restype = C.c_int
     L.rvt_cov_rect_fam.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]
+    for f in (L.rvt_cov_band, L.rvt_cov_band_fam):
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), c_double_p,
+                      c_double_p, c_int_p]
     L.rvt_block_copy_columns.restype = C.c_int
     L.rvt_block_copy_columns.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
     L.rvt_cov_block_fam.restype = C.c_int
@@ -849,6 +853,24 @@ class Engine:
         self._check(self.L.rvt_cov_rect(self.ctx, C.c_void_p(int(ptr)), int(col0), int(H), int(W), _dp(cov), _dp(xz),
                                         _dp(zz), poly.ctypes.data_as(c_int_p)))
         return cov, xz, zz, poly
+
+    def cov_band(self, ptr, ring, col0, H, W, halo, scale=1.0, band=None, fam_d=None):
+        """The band of a sliding window on a block used as a ring (rvt_cov_band; fam_d = columns of X: rvt_cov_band_fam):
+        logical column j = physical (col0 + j) mod ring (ring = 0: a linear range).  Returns (band H x (halo + 1) float32 with
+        band[h, t] = float(value(h, h + t)) * scale, NaN beyond the window; xz W x d; zz; polymorphic flags of the W markers).
+        `band`: an optional float32 array to write into (e.g. one registered with host_register)."""
+        d = self.d if fam_d is None else fam_d
+        W = min(W, H + halo)
+        if band is None:
+            band = np.empty((H, halo + 1), dtype=np.float32)
+        assert band.dtype == np.float32 and band.flags.c_contiguous and band.size >= H * (halo + 1)
+        xz = np.zeros((W, d))
+        zz = np.zeros((d, d))
+        poly = np.zeros(W, dtype=np.int32)
+        fn = self.L.rvt_cov_band if fam_d is None else self.L.rvt_cov_band_fam
+        self._check(fn(self.ctx, C.c_void_p(int(ptr)), int(ring), int(col0), int(H), int(W), int(halo), float(scale),
+                       band.ctypes.data_as(C.POINTER(C.c_float)), _dp(xz), _dp(zz), poly.ctypes.data_as(c_int_p)))
+        return band.reshape(-1)[:H * (halo + 1)].reshape(H, halo + 1), xz, zz, poly
 
     def cov_rect_fam(self, ptr, col0, H, W, d):
         """Family-mode heads x window rectangle (after set_kinship + fit_fam_null); d = columns of X."""

@@ -268,3 +268,199 @@ def test_cov_block_fp64_gemm_against_the_one_wave_kernel(engine_factory, binary,
     kk = kept.astype(bool)
     assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
     assert np.allclose(xz[kk], xz0[kk], rtol=1e-11, atol=1e-11 * max(np.abs(xz0[kk]).max(), 1.0))
+
+
+def _ring_fill(eng, ring, cap, col0, G, step=97):
+    """Put the columns of G into a block used as a ring of `cap` columns, logical column j at physical (col0 + j) mod cap, the
+    way the adapter does (rvt_block_upload_columns, a few columns at a time, split at the wrap)."""
+    V = G.shape[1]
+    j = 0
+    while j < V:
+        p = (col0 + j) % cap
+        n = min(step, V - j, cap - p)
+        eng.upload_columns(ring, p, G[:, j:j + n])
+        j += n
+
+
+def test_cov_band_wrapped_ring_against_the_oracle(engine_factory, monkeypatch):
+    """The sliding window on a CIRCULAR ring (rvt_cov_band; RingMemoryPool, base/RingMemoryPool.cpp:31-63): 1 100 hard-call
+    columns uploaded column-wise into a ring of 1 300 from physical column 900 on (the window wraps), N = 9 100 (several row
+    slices of the column pass, K split over the chip), heads = every column, halo = 300 markers.  Against the ORACLE's rows
+    (window = 300 positions apart), bit-identical to the rectangle call on the same columns laid out linearly, the same with
+    the column cache off (the in-call int8 copy reads the wrapped columns), and with the float / (1/N) formatting applied on
+    the device."""
+    N, V, d, halo, cap, col0 = 9100, 1100, 3, 300, 1300, 900
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 4242)
+    G = np.asfortranarray(np.rint(G))
+    G[:, 17] = 0.0                                            # monomorphic
+    G[:, 1050] = 2.0
+    chrom = np.ones(V, dtype=np.int32)
+    pos = np.arange(V, dtype=np.int32)
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ring = eng.alloc_block(cap)
+    _ring_fill(eng, ring, cap, col0, G)
+    band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, 0, halo)
+    assert rc == 0 and (poly == kept).all() and not poly[17] and not poly[1050]
+    scale = np.nanmax(np.abs(ocov))
+    checked = 0
+    for h in range(V):
+        if not kept[h]:
+            continue
+        js = np.arange(h, min(V, h + halo + 1))
+        js = js[kept[js].astype(bool)]
+        assert not np.isnan(ocov[h, js]).any() and row_end[h] == js[-1]
+        assert np.abs(band[h, js - h].astype(np.float64) - ocov[h, js]).max() <= 2e-7 * scale   # (float32 band)
+        checked += len(js)
+        if h + halo + 1 > V:
+            assert np.isnan(band[h, V - h:]).all()            # beyond the window: NaN
+    assert checked > 250000
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    assert np.allclose(zz, ozz, rtol=1e-9, atol=1e-9 * max(np.abs(ozz).max(), 1.0))
+    # the same columns in a linear block through the rectangle call: the int8 products are exact either way -> bit-identical
+    whole = eng.upload_block(G)
+    rcov, rxz, rzz, rpoly = eng.cov_rect(whole, 0, V, V)
+    for h in range(0, V, 13):
+        w = min(halo + 1, V - h)
+        assert np.array_equal(band[h, :w], rcov[h, h:h + w].astype(np.float32))
+    assert np.array_equal(xz, rxz) and np.array_equal(poly, rpoly)
+    # heads in the middle of the ring, a window that does not wrap, a window of one column
+    for c0, H, W in ((col0 + 40, 500, 800), (5, 300, 400), (1299, 1, 1)):
+        lo = (c0 - col0) % cap
+        if lo + W > V:
+            continue
+        b2 = eng.cov_band(ring, cap, c0, H, W, halo)[0]
+        for h in range(0, H, 7):
+            w = min(halo + 1, W - h)
+            assert np.array_equal(b2[h, :w], band[lo + h, :w])
+    # the column cache off: the call makes its own int8 copy from the wrapped fp64 columns
+    monkeypatch.setenv("RVT_METACOV_NO_CACHE", "1")
+    band_nc = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    monkeypatch.delenv("RVT_METACOV_NO_CACHE")
+    assert np.array_equal(band_nc, band, equal_nan=True)
+    # K split differently: integers, the same sums
+    monkeypatch.setenv("RVT_BAND_SLICES", "3")
+    band_s3 = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    monkeypatch.delenv("RVT_BAND_SLICES")
+    assert np.array_equal(band_s3, band, equal_nan=True)
+    # what the adapter prints: (float)value * (float)(1 / N), applied on the device
+    sc = np.float32(1.0 / N)
+    band_sc = eng.cov_band(ring, cap, col0, V, V, halo, scale=sc)[0]
+    assert np.array_equal(band_sc, band * sc, equal_nan=True)
+
+
+@pytest.mark.parametrize("binary", [0, 1])
+def test_cov_band_wrapped_ring_fp64(engine_factory, binary):
+    """Dosages (quantitative trait) and a binary trait's weights on the same circular ring: the band tiles on the fp64 matrix
+    cores with the columns addressed modulo the capacity; 1 100 heads = two passes of 1 024.  Against the oracle."""
+    N, V, d, halo, cap, col0 = 5003, 1100, 2, 150, 1200, 1000
+    G, chrom, pos, X, y = make_case(N, V, d, binary, 777 + binary)
+    if not binary:
+        rng = np.random.default_rng(5)
+        G = np.asfortranarray(np.clip(G + rng.uniform(-0.2, 0.2, size=G.shape) * (G > 0), 0.0, 2.0))   # dosages
+    else:
+        G = np.asfortranarray(np.rint(G))
+    G[:, 30] = 1.0
+    chrom = np.ones(V, dtype=np.int32)
+    pos = np.arange(V, dtype=np.int32)
+    if binary:
+        rc, beta, p, v = orc.fit_logistic(X, y)
+        res, s2 = y - p, 1.0
+    else:
+        rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+        v = np.full(N, s2)
+    assert rc == 0
+    eng = engine_factory()
+    eng.set_null(binary, X, res, v, s2)
+    ring = eng.alloc_block(cap)
+    _ring_fill(eng, ring, cap, col0, G)
+    band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, binary, halo)
+    assert rc == 0 and (poly == kept).all() and not poly[30]
+    scale = np.nanmax(np.abs(ocov))
+    for h in range(V):
+        if not kept[h]:
+            continue
+        js = np.arange(h, min(V, h + halo + 1))
+        js = js[kept[js].astype(bool)]
+        assert np.abs(band[h, js - h].astype(np.float64) - ocov[h, js]).max() <= 2e-7 * scale
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    # against the rectangle call on a linear copy (another split of the samples: equal to rounding)
+    whole = eng.upload_block(G)
+    rcov = eng.cov_rect(whole, 0, 1024, V)[0]
+    for h in range(0, 1024, 11):
+        w = min(halo + 1, V - h)
+        assert np.abs(band[h, :w] - rcov[h, h:h + w]).max() <= 2e-7 * scale
+
+
+def test_cov_band_many_heads_two_passes(engine_factory):
+    """More heads than one pass of the integer band takes (4 096): 4 500 hard-call columns, halo 40, a ring of 4 600 that
+    wraps; rows against the oracle."""
+    N, V, d, halo, cap, col0 = 4100, 4500, 1, 40, 4600, 4000
+    rng = np.random.default_rng(99)
+    G = np.asfortranarray(rng.binomial(2, rng.uniform(0.02, 0.4, V), size=(N, V)).astype(np.float64))
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=5)
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    chrom = np.ones(V, dtype=np.int32)
+    pos = np.arange(V, dtype=np.int32)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ring = eng.alloc_block(cap)
+    _ring_fill(eng, ring, cap, col0, G, step=512)
+    H = V - 10
+    band, xz, zz, poly = eng.cov_band(ring, cap, col0, H, V, halo)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, 0, halo)
+    assert rc == 0 and (poly == kept).all()
+    scale = np.nanmax(np.abs(ocov))
+    for h in range(H):
+        js = np.arange(h, min(V, h + halo + 1))
+        js = js[kept[js].astype(bool)]
+        if kept[h]:
+            assert np.abs(band[h, js - h].astype(np.float64) - ocov[h, js]).max() <= 2e-7 * scale
+
+
+def test_stale_column_cache_is_not_used(engine_factory):
+    """A column overwritten while hard calls are switched off (no column pass runs behind the upload) must not leave its OLD
+    int8 copy / sums marked valid: after rvt_set_hardcall(1) a covariance call gives the numbers of the NEW data."""
+    N, V, d = 3000, 130, 2
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 2024)
+    G = np.asfortranarray(np.rint(G))
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ring = eng.alloc_block(V)
+    eng.upload_columns(ring, 0, G)
+    first = eng.cov_block(ring, V)
+    G2 = G.copy()
+    G2[:, 40:60] = G[:, 60:80]                                # other hard calls in 20 columns
+    eng.set_hardcall(False)
+    eng.upload_columns(ring, 40, G2[:, 40:60])
+    eng.set_hardcall(True)
+    got = eng.cov_block(ring, V)
+    ref = eng.cov_block(eng.upload_block(G2), V)
+    iu = np.triu_indices(V)
+    assert not np.array_equal(first[0][iu], ref[0][iu])
+    scale = np.nanmax(np.abs(ref[0][iu]))
+    assert np.abs(got[0][iu] - ref[0][iu]).max() <= 1e-11 * scale and np.array_equal(got[3], ref[3])
+    # a copy inside one block invalidates what was known about its target columns as well
+    eng.upload_columns(ring, 0, G)
+    eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), 40, C.c_void_p(ring), 60, 20))
+    got = eng.cov_block(ring, V)
+    assert np.abs(got[0][iu] - ref[0][iu]).max() <= 1e-11 * scale
+
+
+def test_fp64_band_product_exact_integer_check():
+    """tools/gemm64_bench check: C = A' D B of small-integer operands (dyadic weights: every sum exact whatever the order) on
+    the fp64 matrix cores against a host product — symmetric / rectangular, weights, K not a multiple of the chunk, several K
+    slices, the band enumeration (halo) and the ring addressing of the circular window."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm64_bench")
+    assert os.path.exists(exe), "tools/gemm64_bench is built by __graft_entry__.build()"
+    p = subprocess.run([exe, "check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
+    assert p.stdout.count(": 0 /") == 9

@@ -6,9 +6,9 @@ measured like the headline: one JSON line per workload with `roofline` and `cpu_
             fp64   dosages / anything that is not a hard call: the LDS-tiled fp64 product (gemm_f64.hip.h)  — matrix-core bound
             hc     hard calls under an unweighted model: the exact int8 product (rot_gemm.hip.h)            — HBM bound
   window  the reference's 1 Mb sliding window as the adapter drives it (ModelFitterGpu.cpp MetaCovTest::fit / flush): a stream
-          of variants whose window holds `--window` markers; the device ring (1 024 columns, doubled until it holds two
-          windows) is filled from HBM-resident columns, flushed when full (one block call, or rectangles of up to 1 024 heads),
-          the finished heads are dropped and the rest moved to the front.
+          of variants whose window holds `--window` markers; the circular device ring (1 024 columns, doubled until it holds
+          two windows) is filled from HBM-resident columns and flushed when full: ONE rvt_cov_band call computes the band of the
+          finished heads where the columns lie (modulo the capacity), the head index advances, nothing is moved.
 
 Algorithmic work: per pair of the band 2 N flop; per block 8 N V bytes read once.
 CPU baseline: the oracle's MetaCov (orc.metacov, float32 storage as the reference) on a bounded sample (N, V scaled down),
@@ -61,7 +61,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--window", default="200,1000,3000", help="comma-separated window widths (markers) of the stream runs; empty = none")
     ap.add_argument("--stream", type=int, default=16384, help="variants of a stream run")
+    ap.add_argument("--ring", type=int, default=0, help="columns of the device ring of the stream runs (default: the adapter's policy)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--skip-blocks", action="store_true", help="only the stream runs (profiles of the window)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, V = a.samples, a.variants
@@ -88,10 +90,13 @@ def main():
     dos += (dos > 0) * 0.125 * torch.rand_like(dos)
     torch.cuda.synchronize()
     eng.set_content_hint(0)                                   # as an adapter reading --dosage input says
-    dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(dos.data_ptr(), V))
+    if not a.skip_blocks:
+        dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(dos.data_ptr(), V))
     eng.set_content_hint(-1)
-    tf = 2.0 * N * pairs / dt / 1e12
-    lines.append(({"workload": "MetaCov block, dosages (fp64 matrix cores)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+    del dos
+    if not a.skip_blocks:
+      tf = 2.0 * N * pairs / dt / 1e12
+      lines.append(({"workload": "MetaCov block, dosages (fp64 matrix cores)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
                       "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
                       "roofline": {"kernel": "gemm_tn_f64_kernel", "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
@@ -102,9 +107,10 @@ def main():
     hard = torch.round(blocks[0]).contiguous()
     torch.cuda.synchronize()                                  # (torch's stream is not the engine's)
     assert eng.classify_block(hard.data_ptr(), V)
-    dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(hard.data_ptr(), V))
-    gbs = 8.0 * N * V / dt / 1e9
-    lines.append(({"workload": "MetaCov block, hard calls (exact int8 product)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
+    if not a.skip_blocks:
+      dt, (cov, xz, zz, poly) = timed(lambda: eng.cov_block(hard.data_ptr(), V))
+      gbs = 8.0 * N * V / dt / 1e9
+      lines.append(({"workload": "MetaCov block, hard calls (exact int8 product)", "N": N, "V": V, "ms_per_block": 1e3 * dt,
                       "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly.sum()),
                       "int8_TOPs": 2.0 * N * V * V / dt / 1e12,
                       "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
@@ -121,76 +127,81 @@ def main():
     for j0 in range(0, V, 64):
         eng.upload_columns(src_blk, j0, np.asfortranarray(hard_host[j0:j0 + 64].T))
     del hard_host
-    dt, (cov2, xz2, zz2, poly2) = timed(lambda: eng.cov_block(src_blk, V))
-    assert np.array_equal(np.triu(cov2), np.triu(cov)) and np.array_equal(xz2, xz)       # (same numbers as the block above)
-    gbs = 8.0 * N * V / dt / 1e9
-    lines.append(({"workload": "MetaCov block, hard calls, block filled by rvt_block_upload_columns (column cache)", "N": N, "V": V,
+    if not a.skip_blocks:
+      dt, (cov2, xz2, zz2, poly2) = timed(lambda: eng.cov_block(src_blk, V))
+      assert np.array_equal(np.triu(cov2), np.triu(cov)) and np.array_equal(xz2, xz)       # (same numbers as the block above)
+      gbs = 8.0 * N * V / dt / 1e9
+      lines.append(({"workload": "MetaCov block, hard calls, block filled by rvt_block_upload_columns (column cache)", "N": N, "V": V,
                    "ms_per_block": 1e3 * dt, "value": pairs / dt, "unit": "covariance pairs/s", "polymorphic": int(poly2.sum()),
                    "roofline": {"kernel": "rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                 "note": "8 N V bytes of the block over the wall time of the synchronous C call; the call itself reads "
                                         "the N V bytes of the int8 copy made at upload time"},
                    "cpu_baseline": None}))
-    # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): the ring starts at
-    # 1 024 columns and doubles while a flush emits less than half of it; a ring of up to 1 024 columns is one symmetric
-    # block call, a wider one goes through heads x window rectangles of up to 1 024 heads
+    # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): a CIRCULAR ring — a new
+    # site goes into the physical column behind the tail, a flush computes the band of the finished heads where the columns lie
+    # (rvt_cov_band addresses them modulo the capacity) and advances the head index; nothing is ever moved.  The ring starts at
+    # 1 024 columns and doubles while a flush emits less than half of it (--ring overrides the capacity).
     widths = [int(w) for w in a.window.split(",") if w]
     for w in widths:
         cap = 1024
         while cap < 2 * w:
             cap *= 2
+        if a.ring:
+            cap = max(a.ring, w + 1)
         ring = eng.alloc_block(cap)
-        done = fill = nxt = 0
-        t_cov = t_move = t_fill = 0.0
+        heads = cap - w                                       # heads whose window is complete when the ring is full
+        if heads > 256:
+            heads -= heads % 256                              # (whole row panels of the band kernel; the rest waits, as in flush())
+        band = np.zeros((heads, w + 1), dtype=np.float32)
+        eng.host_register(band)                               # the band lands by DMA (the adapter registers its buffer too)
+        scale = np.float32(1.0 / N)
+        done = fill = nxt = head = 0
+        t_cov = t_fill = 0.0
         flushes = -1
         calls = 0
         while done < a.stream:
-            # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies,
-            # timed apart — input delivery is not part of the measured path)
+            # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies of the
+            # columns AND of what the engine keeps per uploaded column, timed apart — input delivery is not part of the path)
             t1 = time.perf_counter()
             while fill < cap:
-                n = min(cap - fill, V - nxt)
-                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), fill, C.c_void_p(src_blk), nxt, n))
+                tail = (head + fill) % cap
+                n = min(cap - fill, V - nxt, cap - tail)
+                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), tail, C.c_void_p(src_blk), nxt, n))
                 fill += n
                 nxt = (nxt + n) % V
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            heads = cap - w                                   # heads whose window is complete
-            if cap <= 1024:
-                eng.cov_block(ring, cap)
-                calls += 1
-            else:
-                for h0 in range(0, heads, 1024):
-                    nh = min(1024, heads - h0)
-                    eng.cov_rect(ring, h0, nh, nh + w)
-                    calls += 1
+            eng.cov_band(ring, cap, head, heads, cap, w, scale=scale, band=band)
+            calls += 1
             t3 = time.perf_counter()
-            eng.move_columns(ring, 0, heads, cap - heads)
-            t4 = time.perf_counter()
+            head = (head + heads) % cap                       # the finished heads are dropped: the head index advances
             fill = cap - heads
             if flushes < 0:                                   # the first flush of a width is a warm-up (first touch of the ring)
                 flushes = calls = 0
                 continue
             t_fill += t2 - t1
             t_cov += t3 - t2
-            t_move += t4 - t3
             flushes += 1
             done += heads
-        dt = t_cov + t_move
+        dt = t_cov
         npairs = done * (w + 1)
         gbs = 8.0 * N * done / dt / 1e9
-        lines.append(({"workload": "MetaCov sliding window, hard calls, adapter's ring policy", "N": N, "window_markers": w,
+        lines.append(({"workload": "MetaCov sliding window, hard calls, circular device ring (rvt_cov_band)", "N": N, "window_markers": w,
                           "ring_columns": cap, "variants": done, "flushes": flushes, "device_calls": calls,
                           "ms_per_flush": 1e3 * dt / flushes,
-                          "ms_per_flush_in_cov_calls": 1e3 * t_cov / flushes, "ms_per_flush_moving_the_ring": 1e3 * t_move / flushes,
+                          "ms_per_flush_in_cov_calls": 1e3 * t_cov / flushes, "ms_per_flush_moving_the_ring": 0.0,
                           "ms_per_flush_filling_the_ring_untimed": 1e3 * t_fill / flushes, "value": npairs / dt,
                           "unit": "printed covariance pairs/s", "variants_per_s": done / dt,
-                          "roofline": {"kernel": "cov_hc_prep_kernel + rot_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
+                          "int8_band_TOPs": 2.0 * N * npairs / dt / 1e12,
+                          "roofline": {"kernel": "band_gemm_i8_kernel", "bound": "hbm", "achieved": gbs,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                       "note": "8 N bytes per evicted variant (each column of the stream read once) over the time "
-                                               "of the device calls and ring moves; a call re-reads the window's columns behind "
-                                               "its heads, so the ring reads (heads + w) / heads times that"},
+                                       "note": "8 N bytes per evicted variant (SURVEY 8d: each column of the stream read once) over "
+                                               "the time of the device calls; the calls themselves read the int8 copies (N bytes "
+                                               "per column and pass) — int8_band_TOPs = 2 N per printed pair against the 3.94 POP/s "
+                                               "int8 ceiling is the figure that bounds this kernel"},
                           "cpu_baseline": None}))
+        eng.host_unregister(band)
         eng.free_block(ring)
     cpu = None if a.no_cpu else cpu_baseline(N)
     for ln in lines:

@@ -27,10 +27,11 @@ __global__ void fill_f64(double* p, long long n, long long ld, long long rows, u
 
 // slices = 0: the engine's heuristic
 static int launch(const double* A, long long lda, int M, const double* B, long long ldb, int Nb, const double* B2, long long ldb2,
-                  int Nb2, const double* w, long long N, double* C, long long ldc, double* part, int symmetric, int slices_in) {
+                  int Nb2, const double* w, long long N, double* C, long long ldc, double* part, int symmetric, int slices_in,
+                  int halo = -1, int ring = 0, int col0 = 0) {
   const int Ntot = Nb + Nb2;
   int nct = 0;
-  const int n_tiles = gemm_f64_tiles(M, Ntot, symmetric != 0, &nct);
+  const int n_tiles = gemm_f64_tiles(M, Ntot, symmetric != 0, &nct, halo);
   const long long chunks = (N + kGemmKC - 1) / kGemmKC;
   long long slices = slices_in > 0 ? std::min(slices_in, 64) : gemm_f64_slices(n_tiles, chunks);
   const long long kslice = ((chunks + slices - 1) / slices) * kGemmKC;
@@ -39,7 +40,7 @@ static int launch(const double* A, long long lda, int M, const double* B, long l
   const long long groups = (slices + 7) / 8;
   hipLaunchKernelGGL((gemm_tn_f64_kernel<3>), dim3((unsigned)(8 * (long long)n_tiles * groups)),
                      dim3(kGemmThreads), 0, 0, A, lda, M, B, ldb, Nb, B2 ? B2 : B, B2 ? ldb2 : ldb, Nb2, w, N, kslice, (int)slices,
-                     slices > 1 ? part : C, ldc, slices > 1 ? c_slice : 0LL, n_tiles, nct, symmetric);
+                     slices > 1 ? part : C, ldc, slices > 1 ? c_slice : 0LL, n_tiles, nct, symmetric, halo, ring, col0);
   if (slices > 1)
     hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, 0, part, ldc, (long long)M, (long long)Ntot, c_slice,
                        (int)slices, C, 0);
@@ -50,16 +51,29 @@ int main(int argc, char** argv) {
   const char* mode = argc > 1 ? argv[1] : "check";
   CK(hipSetDevice(0));
   if (!strcmp(mode, "check")) {
-    struct Case { long long N; int M, Nb, Nb2, sym, weighted, slices; };
-    const Case cases[] = {{1000, 300, 300, 0, 1, 0, 0}, {5003, 600, 600, 0, 1, 1, 3}, {777, 40, 130, 3, 0, 0, 1},
-                          {4096, 257, 129, 2, 0, 1, 5}, {33, 16, 16, 0, 1, 0, 1}, {20000, 1024, 1024, 0, 1, 0, 0}};
+    // halo >= 0: only the band j - m <= halo of a symmetric product is computed (and checked); ring > 0: the columns live in a
+    // ring of `ring` physical columns, logical column l at physical (col0 + l) mod ring (MetaCov's circular window)
+    struct Case { long long N; int M, Nb, Nb2, sym, weighted, slices, halo, ring, col0; };
+    const Case cases[] = {{1000, 300, 300, 0, 1, 0, 0, -1, 0, 0}, {5003, 600, 600, 0, 1, 1, 3, -1, 0, 0}, {777, 40, 130, 3, 0, 0, 1, -1, 0, 0},
+                          {4096, 257, 129, 2, 0, 1, 5, -1, 0, 0}, {33, 16, 16, 0, 1, 0, 1, -1, 0, 0}, {20000, 1024, 1024, 0, 1, 0, 0, -1, 0, 0},
+                          {3001, 900, 900, 0, 1, 0, 0, 100, 0, 0}, {2000, 700, 700, 0, 1, 1, 2, 300, 1000, 650},
+                          {1500, 520, 520, 0, 1, 0, 0, 0, 520, 519}};
     int fails = 0;
     for (const Case& cs : cases) {
       const long long N = cs.N, ld = (N + 15) / 16 * 16;
       const int M = cs.M, Nb = cs.sym ? cs.M : cs.Nb, Nb2 = cs.Nb2, Ntot = Nb + Nb2;
-      std::vector<double> hA((size_t)ld * M, 0.0), hB((size_t)ld * Nb, 0.0), hB2((size_t)ld * std::max(Nb2, 1), 0.0), hw(ld, 0.0);
+      const int physM = cs.ring > 0 ? cs.ring : M;
+      auto phys = [&](int l) { return cs.ring > 0 ? (cs.col0 + l) % cs.ring : l; };
+      std::vector<double> hA((size_t)ld * physM, 0.0), hB((size_t)ld * Nb, 0.0), hB2((size_t)ld * std::max(Nb2, 1), 0.0), hw(ld, 0.0);
       for (int j = 0; j < M; ++j)
-        for (long long i = 0; i < N; ++i) hA[(size_t)j * ld + i] = (double)(mix(j * 1000003ull + i) % 3);
+        for (long long i = 0; i < N; ++i) hA[(size_t)phys(j) * ld + i] = (double)(mix(j * 1000003ull + i) % 3);
+      if (cs.ring > 0)   // (the physical columns outside the window hold something else)
+        for (int p = 0; p < physM; ++p) {
+          bool used = false;
+          for (int j = 0; j < M && !used; ++j) used = phys(j) == p;
+          if (!used)
+            for (long long i = 0; i < N; ++i) hA[(size_t)p * ld + i] = 7.0;
+        }
       if (cs.sym) hB = hA;
       else
         for (int j = 0; j < Nb; ++j)
@@ -73,7 +87,8 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 8, hipMemcpyHostToDevice));
       CK(hipMemcpy(dB2, hB2.data(), hB2.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), hw.size() * 8, hipMemcpyHostToDevice));
       CK(hipMemset(dC, 0xff, (size_t)M * Ntot * 8));
-      const int sl = launch(dA, ld, M, cs.sym ? dA : dB, ld, Nb, Nb2 ? dB2 : nullptr, ld, Nb2, cs.weighted ? dw : nullptr, N, dC, M, dP, cs.sym, cs.slices);
+      const int sl = launch(dA, ld, M, cs.sym ? dA : dB, ld, Nb, Nb2 ? dB2 : nullptr, ld, Nb2, cs.weighted ? dw : nullptr, N, dC, M, dP, cs.sym, cs.slices,
+                            cs.halo, cs.ring, cs.col0);
       CK(hipDeviceSynchronize());
       std::vector<double> hC((size_t)M * Ntot);
       CK(hipMemcpy(hC.data(), dC, hC.size() * 8, hipMemcpyDeviceToHost));
@@ -82,8 +97,9 @@ int main(int argc, char** argv) {
       for (int m = 0; m < M; m += step)
         for (int j = 0; j < Ntot; j += 1) {
           if (cs.sym && j < m) continue;  // below the diagonal: unspecified
-          const double* b = j < Nb ? &hB[(size_t)j * ld] : &hB2[(size_t)(j - Nb) * ld];
-          const double* a = &hA[(size_t)m * ld];
+          if (cs.halo >= 0 && j - m > cs.halo) continue;  // outside the band: unspecified
+          const double* b = j < Nb ? &hB[(size_t)(cs.sym ? phys(j) : j) * ld] : &hB2[(size_t)(j - Nb) * ld];
+          const double* a = &hA[(size_t)phys(m) * ld];
           double s = 0.0;
           for (long long i = 0; i < N; ++i) s += a[i] * (cs.weighted ? hw[i] : 1.0) * b[i];
           ++checked;
@@ -92,7 +108,8 @@ int main(int argc, char** argv) {
             ++bad;
           }
         }
-      printf("check N=%lld M=%d Nb=%d+%d sym=%d weighted=%d slices=%d: %lld / %lld wrong\n", N, M, Nb, Nb2, cs.sym, cs.weighted, sl, bad, checked);
+      printf("check N=%lld M=%d Nb=%d+%d sym=%d weighted=%d slices=%d halo=%d ring=%d col0=%d: %lld / %lld wrong\n", N, M, Nb, Nb2, cs.sym,
+             cs.weighted, sl, cs.halo, cs.ring, cs.col0, bad, checked);
       fails += bad != 0;
       hipFree(dA); hipFree(dB); hipFree(dB2); hipFree(dw); hipFree(dC); hipFree(dP);
     }
