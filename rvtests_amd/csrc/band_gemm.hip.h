@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rot_gemm.hip.h"
 
 namespace rvt {
@@ -40,15 +41,17 @@ inline int band_tiles(int H, int W, int halo) {
   for (int rp = 0; rp < (H + kBandBT - 1) / kBandBT; ++rp) n += band_panel_tiles(rp, W, halo);
   return n;
 }
-// K slices (a multiple of 8): the count that minimises rounds x chunks per workgroup, a round being the 32 workgroups an
-// XCD holds at once (one workgroup of 128 KB LDS per CU); slices of at least 16 chunks of 128 samples; the partial tiles of
-// all slices must fit `max_part_bytes`
+// K slices (a multiple of 8): the count that minimises rounds x (chunks per slice + 10), a round being the 32 workgroups an
+// XCD holds at once (one workgroup of 128 KB LDS per CU) and 10 chunks what a workgroup spends besides its K loop (pipeline
+// fill, the 256 KB partial tile it writes and band_finish reads again) — fitted on N = 500 000: 6 / 20 / 52 tiles run fastest
+// with 32-40 / 24 / 24 slices, 64 slices cost 10-20 % more; slices of at least 16 chunks; the partial tiles of all slices must
+// fit `max_part_bytes`
 inline long long band_slices(int n_tiles, long long chunks, size_t max_part_bytes) {
   long long best = 8, best_cost = -1;
   for (long long k = 1; k <= 16; ++k) {
     if (k > 1 && chunks / (8 * k) < 16) break;
     if (k > 1 && (size_t)n_tiles * (size_t)(8 * k) * (size_t)kBandBT * kBandBT * sizeof(int) > max_part_bytes) break;
-    const long long rounds = ((long long)n_tiles * k + 31) / 32, cost = rounds * ((chunks + 8 * k - 1) / (8 * k));
+    const long long rounds = ((long long)n_tiles * k + 31) / 32, cost = rounds * ((chunks + 8 * k - 1) / (8 * k) + 10);
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best = 8 * k;
@@ -59,7 +62,17 @@ inline long long band_slices(int n_tiles, long long chunks, size_t max_part_byte
 
 // R: the int8 columns, [physical column][ldk] (ldk a multiple of 128, pad rows zero).  part: [slice][tile][256][256] int32.
 // grid = 8 * n_tiles * ceil(n_slices / 8) workgroups of 512 threads.
-template <int WM, int WN, int TM, int TN, int NST, int KC>
+//
+// FP4 = true: the columns are stored as 4-bit E2M1 codes, two genotypes per byte (0 -> 0x0, 1 -> 0x2 = 1.0, 2 -> 0x4 = 2.0:
+// hard calls are exactly representable in MXFP4), and the tile products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit
+// block scales (E8M0 127): the same 16-byte fragment per lane now carries 32 samples instead of 16, the matrix instruction
+// contracts 64 samples at the rate the int8 one contracts 32, and every byte moved (HBM, L2, LDS) carries two genotypes.  The
+// accumulation is fp32 and EXACT: all products are in {0, 1, 2, 4}, a slice's partial sum is an integer below 2^24 (the host
+// keeps 4 x slice length under it), and fp32 adds integers below 2^24 without rounding in any order.  The partial tiles are
+// stored as int32 like the int8 kernel's — everything behind the product is shared.  A stage row of 128 bytes = 256 samples.
+typedef float f16v_t __attribute__((ext_vector_type(16)));
+typedef int i8v_t __attribute__((ext_vector_type(8)));
+template <int WM, int WN, int TM, int TN, int NST, int KC, bool FP4 = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int8_t* __restrict__ R, long long ldk, int ring,
                                                                         int col0, int H, int W, int halo, long long kbytes0,
                                                                         long long kslice, int n_slices, int n_tiles,
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int
                                        (__attribute__((address_space(3))) void*)(&lds[buf][1024 * P]), 16, 0, 0);
     }
   };
-  i16v_t acc[TM][TN];
+  typename std::conditional<FP4, f16v_t, i16v_t>::type acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -153,8 +166,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b) {
+          if constexpr (FP4) {
+            const i4v_t x = fa[ks & 1][a], y = fb[ks & 1][b];
+            const i8v_t xa = {x[0], x[1], x[2], x[3], 0, 0, 0, 0}, yb = {y[0], y[1], y[2], y[3], 0, 0, 0, 0};
+            // (cbsz = blgp = 4: both operands E2M1; scales 0x7f = 2^0 in every byte)
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, yb, acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          } else {
+            acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("" ::: "memory");
@@ -171,110 +192,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int
       for (int e = 0; e < 4; ++e) {
         const int ml = wm * 32 * TM + a * 32 + 8 * g + 4 * (lane >> 5) + e;
 #pragma unroll
-        for (int b = 0; b < TN; ++b) out[ml * kBandBT + wn * 32 * TN + b * 32 + (lane & 31)] = acc[a][b][4 * g + e];
+        for (int b = 0; b < TN; ++b) out[ml * kBandBT + wn * 32 * TN + b * 32 + (lane & 31)] = (int)acc[a][b][4 * g + e];
       }
 }
 #define band_gemm_i8 (band_gemm_i8_kernel<2, 4, 4, 2, 2, 128>)
+#define band_gemm_fp4 (band_gemm_i8_kernel<2, 4, 4, 2, 2, 128, true>)
 constexpr int kBandThreads = 512;
-
-// One workgroup per head h of the pass: S(h, h + t), t = 0 .. halo, from the partial tiles; then the algebra of
-// cov_rect_rows_kernel (the same expressions in the same order: the rows are bit-identical to rvt_cov_rect's).
-// cs / xz: column sums and covXZ rows of the pass's columns (index 0 = the pass's first head).
-// band_f32 (optional): (float)value * scale, the number the adapter prints with %g (src/Model.cpp:975-984 casts to float and
-// divides by N in float); band_f64 (optional): the value itself.  Entries beyond the window (h + t >= W) are NaN.
-__global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, const int* __restrict__ part, int n_slices,
-                                                              int n_tiles, const double* __restrict__ cs,
-                                                              const double* __restrict__ xz, int H, int W, int halo,
-                                                              float scale, float* __restrict__ band_f32,
-                                                              double* __restrict__ band_f64) {
-  const int h = blockIdx.x, d = cc.d;
-  __shared__ double a[RVT_MAX_COV];
-  __shared__ int tile0;
-  if (threadIdx.x < d) {
-    double t = 0.0;
-    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
-    a[threadIdx.x] = t;
-  }
-  if (threadIdx.x == 64) {
-    int t0 = 0;
-    for (int rp = 0; rp < (h >> 8); ++rp) t0 += band_panel_tiles(rp, W, halo);
-    tile0 = t0;
-  }
-  __syncthreads();
-  const double sh = cs[h];
-  const long long row = (long long)h * (halo + 1);
-  for (int t = threadIdx.x; t <= halo; t += blockDim.x) {
-    const int j = h + t;
-    double v = NAN;
-    if (j < W) {
-      const int tile = tile0 + (j >> 8) - (h >> 8);
-      const int* p = part + ((long long)tile << 16) + (h & 255) * kBandBT + (j & 255);
-      long long s = 0;
-      for (int sl = 0; sl < n_slices; ++sl) s += p[((long long)sl * n_tiles) << 16];
-      const double sxx = (double)s;
-      const double xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
-      double quad = 0.0;
-      for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
-      v = xx - quad;
-    }
-    if (band_f32) band_f32[row + t] = (float)v * scale;
-    if (band_f64) band_f64[row + t] = v;
-  }
-}
-
-// The same band from a rectangle of doubles S (H x Wd, column-major, leading dimension lds: the fp64 matrix cores' product
-// for dosages / a binary trait, or the rotated product of the family model).  fam: the centring algebra of
-// cov_rect_fam_rows_kernel (t1 = G~' D u1).  b2: MetaCovFamBinary's factor on covXX (1 otherwise).
-__global__ __launch_bounds__(256) void band_rows_f64_kernel(CovConsts cc, const double* __restrict__ S, long long lds,
-                                                            const double* __restrict__ cs, const double* __restrict__ xz,
-                                                            const double* __restrict__ t1, int H, int W, int halo, double b2,
-                                                            float scale, float* __restrict__ band_f32,
-                                                            double* __restrict__ band_f64) {
-  const int h = blockIdx.x, d = cc.d;
-  __shared__ double a[RVT_MAX_COV];
-  if (threadIdx.x < d) {
-    double t = 0.0;
-    for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
-    a[threadIdx.x] = t;
-  }
-  __syncthreads();
-  const double sh = cs[h];
-  const double mh = sh * cc.inv_n, t1h = t1 ? t1[h] : 0.0;
-  const long long row = (long long)h * (halo + 1);
-  for (int t = threadIdx.x; t <= halo; t += blockDim.x) {
-    const int j = h + t;
-    double v = NAN;
-    if (j < W) {
-      const double sxx = S[h + (long long)j * lds];
-      double xx;
-      if (t1) {
-        const double mj = cs[j] * cc.inv_n;
-        xx = sxx - mh * t1[j] - mj * t1h + mh * mj * cc.c11;
-      } else {
-        xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
-      }
-      double quad = 0.0;
-      for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
-      v = xx - quad;
-      if (b2 != 1.0) v *= b2;
-    }
-    if (band_f32) band_f32[row + t] = (float)v * scale;
-    if (band_f64) band_f64[row + t] = v;
-  }
-}
-
-// the column statistics a ring keeps per PHYSICAL column -> the work arrays of a band call: logical column j = physical
-// (col0 + j) mod ring
-__global__ void band_cache_gather_kernel(const double* __restrict__ cs_c, const int* __restrict__ poly_c,
-                                         const double* __restrict__ T_c, int ring, int col0, int W, int d, int t_stride,
-                                         double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= W) return;
-  long long p = (long long)col0 + j;
-  if (ring > 0 && p >= ring) p -= ring;
-  colsum[j] = cs_c[p];
-  poly[j] = poly_c[p];
-  for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[p * t_stride + k];
-}
 
 }  // namespace rvt

@@ -814,8 +814,9 @@ int MetaScoreTest::flush() {
 // ---- MetaCovTest ---------------------------------------------------------------------------------------------------------
 MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
   modelName = "MetaCov";
+  capacity = 4096;  // (columns; shrunk to the memory budget at the first fit(), when N is known)
   // columns of the device ring at the start; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush and the wrap with it)
-  if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(RVT_MAX_VARIANTS, atoi(e)));
+  if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(65536, atoi(e)));
   if (const char* e = getenv("RVT_METACOV_MAX_COLUMNS")) maxColumns = std::max(capacity, atoi(e));
 }
 MetaCovTest::~MetaCovTest() {
@@ -857,13 +858,14 @@ int MetaCovTest::fit(GeneData* dc) {
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;
-    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB; the int8 copy the engine keeps per column counted in:
-    // 9 bytes per genotype): 21 000 columns at N = 500 000
+    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB; the int8 and 4-bit copies the engine keeps per column
+    // counted in: 9.5 bytes per genotype): 20 000 columns at N = 500 000
     {
       double gb = 96.0;
       if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
-      const double cols = gb * 1e9 / (9.0 * (double)std::max<int64_t>(dc->N, 1));
-      if (cols < (double)maxColumns) maxColumns = std::max(capacity, (int)cols);
+      const double cols = gb * 1e9 / (9.5 * (double)std::max<int64_t>(dc->N, 1));
+      if (cols < (double)maxColumns) maxColumns = std::max(std::min(capacity, 1024), (int)cols);
+      if (capacity > maxColumns) capacity = maxColumns;
     }
     if (rvt_block_alloc(ctx, capacity, &block)) {
       lastError = rvt_last_error(ctx);
@@ -873,11 +875,13 @@ int MetaCovTest::fit(GeneData* dc) {
   if ((int)sites.size() == capacity) {
     const int before = (int)sites.size();
     if (flush(false)) return -1;
-    // One window holds more sites than the ring: enlarge it.  ALSO when the flush could emit less than half of the ring — a
-    // window of 1 000 markers in a ring of 1 024 would read 1 000 columns to write 24 rows; with a ring of at least twice the
-    // window every flush emits half of what it reads.
+    // One window holds more sites than the ring: enlarge it.  ALSO when the flush could emit less than three quarters of the
+    // ring — a window of 1 000 markers in a ring of 1 024 would read 1 000 columns to write 24 rows; with a ring of at least
+    // four windows every flush emits three quarters of what it reads and is long enough to hide its fixed cost (measured at
+    // N = 500 000, windows of 200 / 1 000 / 3 000 markers: rings of 4 096 / 4 096 / 16 384 columns run 2.0 / 1.3 / 1.1 times
+    // as fast as rings of two windows).
     const bool full = (int)sites.size() == capacity;
-    if (full || (canGrow && 2 * (before - (int)sites.size()) < before)) {
+    if (full || (canGrow && 4 * (before - (int)sites.size()) < 3 * before)) {
       if (grow()) {
         if (full) return -1;
         canGrow = false;     // (a ring that cannot grow any further just stays as efficient as it was: do not retry every fill)

@@ -375,7 +375,7 @@ class MetaCovTest : public ModelFitter {
   int flush(bool final);
   int grow();
   int windowSize;
-  int capacity = RVT_MAX_VARIANTS;     // columns of the device ring (grows when one window needs more)
+  int capacity = 4096;                 // columns of the device ring (grows until it holds four windows)
   int head = 0;                        // physical column of sites[0]: site k lives in column (head + k) mod capacity
   int maxColumns = 65536;              // RVT_METACOV_MAX_COLUMNS
   bool canGrow = true;                 // false once a non-mandatory grow() failed (not retried on every fill)

@@ -1095,7 +1095,10 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
                                                           double* __restrict__ part, int* __restrict__ bad,
                                                           const double* __restrict__ wts = nullptr,
                                                           int* __restrict__ hard_flag = nullptr, int ring = 0,
-                                                          int ring_col0 = 0) {
+                                                          int ring_col0 = 0, unsigned char* __restrict__ out4 = nullptr,
+                                                          long long ldk4 = 0) {
+  // out4 (PACK only, optional): the same hard calls as 4-bit E2M1 codes (0 -> 0x0, 1 -> 0x2, 2 -> 0x4), sample 2 i in the low
+  // nibble of byte i — what the MXFP4 band product reads (band_gemm.hip.h); out8 may then be null
   // ring > 0: G is the base of a block used as a ring of `ring` columns, column j of the call is the physical column
   // (ring_col0 + j) mod ring (MetaCov's circular window); the outputs (out8, part) are indexed by j
   const int c0 = blockIdx.x * kCovHcCols;
@@ -1169,7 +1172,13 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 #pragma unroll
           for (int k = 0; k < DMAX; ++k) t[c][k] = fma(g[e], x[k][e], t[c][k]);
         }
-        if (PACK) *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
+        if (PACK && out8) *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
+        if (PACK && out4) {
+          // bytes 0..3 of `packed` hold g in {0, 1, 2}: code = g << 1, two codes per byte
+          const unsigned q = (packed << 1) & 0x0e0e0e0eu;
+          *reinterpret_cast<unsigned short*>(out4 + (long long)(c0 + c) * ldk4 + (i >> 1)) =
+              (unsigned short)((q & 0xfu) | ((q >> 4) & 0xf0u) | ((q >> 8) & 0xf00u) | ((q >> 12) & 0xf000u));
+        }
       }
     }
   }

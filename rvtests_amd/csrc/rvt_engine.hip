@@ -292,6 +292,10 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_part) hipFree(c->d_rot_part);
   if (c->d_cov_work) hipFree(c->d_cov_work);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_band_fin[i]) hipEventDestroy(c->ev_band_fin[i]);
+    if (c->ev_band_copied[i]) hipEventDestroy(c->ev_band_copied[i]);
+  }
   if (c->d_rot_scale) hipFree(c->d_rot_scale);
   if (c->d_rot_sexp) hipFree(c->d_rot_sexp);
   if (c->d_kind) hipFree(c->d_kind);

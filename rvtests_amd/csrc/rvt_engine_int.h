@@ -176,6 +176,7 @@ struct rvt_ctx {
   hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
   char* d_cov_work = nullptr;    // work space of the MetaCov rectangles (S, T, the band, column statistics): grow-only
+  hipEvent_t ev_band_fin[2] = {}, ev_band_copied[2] = {};  // rvt_cov_band: a pass's rows are copied out while the next pass multiplies
   size_t cov_work_cap = 0;
   size_t rot_part_cap = 0;
   // per-column content flags of blocks filled column by column (rvt_block_upload_columns): nonzero = hard calls only
@@ -187,6 +188,9 @@ struct rvt_ctx {
     int cols = 0;
     int* d_flags = nullptr;
     signed char* d_i8 = nullptr;  // [cols rounded up + a tile of slack][ldk]
+    unsigned char* d_i4 = nullptr;  // [cols][ldk4]: the same hard calls as E2M1 codes, two per byte (band_gemm.hip.h, FP4)
+    int64_t ldk4 = 0;
+    bool cache_failed = false;  // the cache could not be allocated once: not retried for this block
     double* d_cs = nullptr;       // [cols] column sums
     int* d_poly = nullptr;        // [cols]
     double* d_T = nullptr;        // [cols][RVT_MAX_COV]
@@ -194,10 +198,11 @@ struct rvt_ctx {
     uint64_t gen = 0;
     std::vector<unsigned char> valid;
     void release() {
-      for (void* q : {(void*)d_flags, (void*)d_i8, (void*)d_cs, (void*)d_poly, (void*)d_T})
+      for (void* q : {(void*)d_flags, (void*)d_i8, (void*)d_i4, (void*)d_cs, (void*)d_poly, (void*)d_T})
         if (q) hipFree(q);
       d_flags = nullptr;
       d_i8 = nullptr;
+      d_i4 = nullptr;
       d_cs = nullptr;
       d_poly = nullptr;
       d_T = nullptr;

@@ -2,7 +2,7 @@
 // exact int8 band for hard calls) and the column operations of the adapters' device ring.  Part of librvtests_amd.so.
 #include "rvt_engine_int.h"
 #include "gemm_f64.hip.h"
-#include "band_gemm.hip.h"
+#include "band_rows.hip.h"
 
 // row slices of MetaCov's column pass (cov_hc_prep_kernel): a function of N alone, so that a column's sums are the same numbers
 // whether it is treated inside a block or alone behind its upload (rvt_block_upload_columns)
@@ -400,6 +400,28 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
 }
 
 
+
+// one launch of MetaCov's column pass (cov_hc_prep_kernel) for d covariates; pack: the hard-call variant (value test, int8 / E2M1
+// copies), else the general one (optional weights)
+static void launch_cov_prep(hipStream_t st, int d, bool pack, dim3 grid, const double* G, int64_t N, int64_t ld, int W, const double* X,
+                            signed char* out8, int64_t ldk, double* part, int* bad, const double* wts, int* hard_flag, int ring,
+                            int col0, unsigned char* out4, int64_t ldk4) {
+  const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+#define RVT_PREP(DM, PK)                                                                                                          \
+  hipLaunchKernelGGL((cov_hc_prep_kernel<DM, PK>), grid, dim3(256), 0, st, G, (long long)N, (long long)ld, W, X, (long long)ld, d, \
+                     out8, (long long)ldk, part, bad, wts, hard_flag, ring, col0, out4, (long long)ldk4)
+  if (pack) {
+    if (dmax == 4) RVT_PREP(4, true);
+    else if (dmax == 8) RVT_PREP(8, true);
+    else RVT_PREP(RVT_MAX_COV, true);
+  } else {
+    if (dmax == 4) RVT_PREP(4, false);
+    else if (dmax == 8) RVT_PREP(8, false);
+    else RVT_PREP(RVT_MAX_COV, false);
+  }
+#undef RVT_PREP
+}
+
 // ---- MetaCov on a circular ring: the band of a sliding window ----------------------------------------------------------------
 // flags of the W logical columns of a ring (physical (col0 + j) mod ring): 1 = every column holds hard calls only, 0 = some
 // column holds something else, -1 = nothing known about the block
@@ -445,8 +467,10 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
   if (rc) return rc;
   const int ringk = (ring > 0 && col0 + W > ring) ? ring : 0;   // (a window that does not wrap is a linear range)
   const bool fast = allow_fast && !nc.binary && ring_hard_calls(c, dG, ring, col0, W) != 0 && !getenv("RVT_METACOV_FP64");
-  // heads per pass: the partial tiles (int8) or the rectangle of doubles (fp64) of a pass stay within a few hundred MB
-  const int Hc = fast ? 4096 : 1024;
+  // heads per pass: the rectangle of doubles (fp64) of a pass stays within a few hundred MB; the integer band in passes of 1 024
+  // so that the rows of one pass cross PCIe while the next pass multiplies (two band buffers, the copies on copy_stream)
+  int Hc = 1024;
+  if (const char* e = getenv("RVT_BAND_PASS")) Hc = std::max(256, atoi(e) / 256 * 256);
   const int Hp = std::min(H, Hc), Wp = (int)std::min<long long>(W, (long long)Hp + halo);
   double *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_tmp = nullptr, *d_S = nullptr;
   float* d_band = nullptr;
@@ -455,7 +479,7 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t bT = up(sizeof(double) * (size_t)W * d), bV = up(sizeof(double) * (size_t)W), bP = up(sizeof(int) * (size_t)W);
     const size_t bM = up(sizeof(double) * (size_t)kCovSlices * W * (RVT_MAX_COV + 3));
-    const size_t bB = up(sizeof(float) * (size_t)Hp * ((size_t)halo + 1));
+    const size_t bB = 2 * up(sizeof(float) * (size_t)Hp * ((size_t)halo + 1));
     const size_t bS = fast ? 0 : up(sizeof(double) * (size_t)Hp * Wp);
     const size_t need = 2 * bT + bV + bP + bM + bB + bS;
     if (c->cov_work_cap < need) {
@@ -502,17 +526,22 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
       if (all) ckc = &itc->second;
     }
   }
-  const int8_t* R8 = nullptr;   // the int8 columns the product reads, their ring and first column
+  // what the product reads: the columns' hard calls as E2M1 codes, two per byte, on the MXFP4 matrix instruction (exact, see
+  // band_gemm.hip.h; RVT_BAND_INT8=1: one byte per genotype on the int8 one), their ring and first column
+  const bool fp4 = !getenv("RVT_BAND_INT8");
+  const int8_t* R8 = nullptr;
   int r8_ring = 0, r8_col0 = 0;
-  int64_t ldk = (N + 127) / 128 * 128;
+  const int64_t ldk8 = (N + 127) / 128 * 128, ldk4 = ((N + 1) / 2 + 127) / 128 * 128;
+  int64_t ldk = fp4 ? ldk4 : ldk8;
+  if (fast && ckc && fp4 && !ckc->d_i4) ckc = nullptr;  // (a cache made without the 4-bit copy)
   if (fast && ckc) {
     hipLaunchKernelGGL(band_cache_gather_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, ckc->d_cs, ckc->d_poly,
                        ckc->d_T, ringk, col0, W, d, RVT_MAX_COV, d_cs, d_poly, d_T);
-    R8 = reinterpret_cast<const int8_t*>(ckc->d_i8);
+    R8 = fp4 ? reinterpret_cast<const int8_t*>(ckc->d_i4) : reinterpret_cast<const int8_t*>(ckc->d_i8);
     r8_ring = ringk;
     r8_col0 = col0;
   } else if (fast) {
-    // no cache: ONE pass over the window's columns gives the statistics, T = G'X and a linear int8 copy of the window
+    // no cache: ONE pass over the window's columns gives the statistics, T = G'X and a linear copy of the window's hard calls
     const size_t need = ((size_t)W + kBandBT) * (size_t)ldk;
     if (c->rotB_cap < need) {
       if (c->d_rotB) hipFree(c->d_rotB);
@@ -521,53 +550,46 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
       HIP_TRY(c, hipMalloc((void**)&c->d_rotB, need + need / 4));
       c->rotB_cap = need + need / 4;
     }
-    const int64_t n4 = (N + 3) / 4 * 4;
-    if (ldk > n4) HIP_TRY(c, hipMemset2DAsync(c->d_rotB + n4, (size_t)ldk, 0, (size_t)(ldk - n4), (size_t)W, st));
+    const int64_t n4 = (N + 3) / 4 * 4, nw = fp4 ? n4 / 2 : n4;   // bytes of a column the pass writes; the pad behind them: zero
+    if (ldk > nw) HIP_TRY(c, hipMemset2DAsync(c->d_rotB + nw, (size_t)ldk, 0, (size_t)(ldk - nw), (size_t)W, st));
     if (!c->d_kind) HIP_TRY(c, hipMalloc((void**)&c->d_kind, sizeof(int)));
     d_bad = c->d_kind;
     HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), st));
-    const dim3 grid((unsigned)wgs, (unsigned)slices);
-    if (dmax == 4)
-      hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
-                         (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr, ringk, pcol0);
-    else if (dmax == 8)
-      hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
-                         (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr, ringk, pcol0);
-    else
-      hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W,
-                         c->d_X, (long long)ld, d, c->d_rotB, (long long)ldk, d_tmp, d_bad, (const double*)nullptr, (int*)nullptr,
-                         ringk, pcol0);
+    launch_cov_prep(st, d, true, dim3((unsigned)wgs, (unsigned)slices), Gbase, N, ld, W, c->d_X, fp4 ? nullptr : c->d_rotB, ldk8, d_tmp,
+                    d_bad, nullptr, nullptr, ringk, pcol0, fp4 ? reinterpret_cast<unsigned char*>(c->d_rotB) : nullptr, ldk4);
     hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
                        W, d, dmax, d_cs, d_poly, d_T);
     R8 = reinterpret_cast<const int8_t*>(c->d_rotB);
   } else {
-    const dim3 grid((unsigned)wgs, (unsigned)slices);
-    const double* wts = nc.binary ? c->d_v : nullptr;
-    if (dmax == 4)
-      hipLaunchKernelGGL((cov_hc_prep_kernel<4, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
-                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk, pcol0);
-    else if (dmax == 8)
-      hipLaunchKernelGGL((cov_hc_prep_kernel<8, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W, c->d_X,
-                         (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk, pcol0);
-    else
-      hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV, false>), grid, dim3(256), 0, st, Gbase, (long long)N, (long long)ld, W,
-                         c->d_X, (long long)ld, d, (signed char*)nullptr, 0LL, d_tmp, (int*)nullptr, wts, (int*)nullptr, ringk,
-                         pcol0);
+    launch_cov_prep(st, d, false, dim3((unsigned)wgs, (unsigned)slices), Gbase, N, ld, W, c->d_X, nullptr, 0, d_tmp, nullptr,
+                    nc.binary ? c->d_v : nullptr, nullptr, ringk, pcol0, nullptr, 0);
     hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((W * (dmax + 3) + 255) / 256)), dim3(256), 0, st, d_tmp, slices,
                        W, d, dmax, d_cs, d_poly, d_T);
   }
   hipLaunchKernelGGL(cov_rect_xz_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, cc, d_T, d_cs, W, d_xz);
   HIP_TRY(c, hipGetLastError());
   // the heads in passes of up to Hc: pass (h0, nh) covers the logical columns [h0, h0 + wsub)
-  for (int h0 = 0; h0 < H; h0 += Hc) {
+  for (int i = 0; i < 2; ++i) {
+    if (!c->ev_band_fin[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_band_fin[i], hipEventDisableTiming));
+    if (!c->ev_band_copied[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_band_copied[i], hipEventDisableTiming));
+  }
+  float* const d_band2[2] = {d_band, d_band + (size_t)Hp * ((size_t)halo + 1)};
+  int pass = 0;
+  for (int h0 = 0; h0 < H; h0 += Hc, ++pass) {
+    float* const d_band = d_band2[pass & 1];
+    if (pass >= 2) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_band_copied[pass & 1], 0));  // (the buffer's previous rows have left)
     const int nh = std::min(Hc, H - h0);
     const int wsub = (int)std::min<long long>((long long)W - h0, (long long)nh + halo);
     if (fast) {
       const int n_tiles = band_tiles(nh, wsub, halo);
       const int64_t kbytes = ldk, chunks = kbytes / kRotKC;
       int64_t nsl = band_slices(n_tiles, chunks, (size_t)3 << 30);
-      if (const char* e = getenv("RVT_BAND_SLICES")) nsl = std::max<int64_t>(1, atoll(e));
-      const int64_t kslice = ((chunks + nsl - 1) / nsl) * kRotKC;
+      if (const char* e = getenv("RVT_BAND_SLICES"))
+        if (atoll(e) > 0) nsl = atoll(e);
+      int64_t kslice = ((chunks + nsl - 1) / nsl) * kRotKC;
+      // a slice's sums are exact in the accumulator: int32 holds 4 N for any N the engine takes; fp32 holds integers below 2^24,
+      // i.e. at most 2^22 samples = 2^21 bytes of E2M1 codes per slice
+      if (fp4) kslice = std::min<int64_t>(kslice, (int64_t)1 << 21);
       nsl = (kbytes + kslice - 1) / kslice;
       const size_t need = sizeof(int) * (size_t)n_tiles * (size_t)nsl * kBandBT * kBandBT;
       if (c->rot_part_cap < need) {
@@ -582,8 +604,12 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
       if (r8_ring > 0 && pc >= r8_ring) pc -= r8_ring;
       const int pr = (r8_ring > 0 && pc + wsub > r8_ring) ? r8_ring : 0;
       const unsigned grid = (unsigned)(8 * (int64_t)n_tiles * ((nsl + 7) / 8));
-      hipLaunchKernelGGL(band_gemm_i8, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
-                         (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
+      if (fp4)
+        hipLaunchKernelGGL(band_gemm_fp4, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
+                           (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
+      else
+        hipLaunchKernelGGL(band_gemm_i8, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
+                           (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
       hipLaunchKernelGGL(band_finish_i32_kernel, dim3((unsigned)nh), dim3(256), 0, st, cc, d_part, (int)nsl, n_tiles, d_cs + h0,
                          d_xz + (size_t)h0 * d, nh, wsub, halo, scale, d_band, (double*)nullptr);
     } else {
@@ -599,13 +625,17 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
                          d_xz + (size_t)h0 * d, (const double*)nullptr, nh, wsub, halo, 1.0, scale, d_band, (double*)nullptr);
     }
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_band_fin[pass & 1], st));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_band_fin[pass & 1], 0));
     HIP_TRY(c, hipMemcpyAsync(band + (size_t)h0 * ((size_t)halo + 1), d_band, sizeof(float) * (size_t)nh * ((size_t)halo + 1),
-                              hipMemcpyDeviceToHost, st));
+                              hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_band_copied[pass & 1], c->copy_stream));
   }
   HIP_TRY(c, hipMemcpyAsync(xz, d_xz, sizeof(double) * (size_t)W * d, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipMemcpyAsync(polymorphic, d_poly, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, st));
   if (d_bad) HIP_TRY(c, hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
+  HIP_TRY(c, sync_stream(c->copy_stream));
   if (h_bad) return cov_band_impl(c, dG, ring, col0, H, W, halo, scale, band, xz, zz, polymorphic, false);  // not hard calls after all
   if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
   return RVT_OK;
@@ -754,6 +784,40 @@ int rvt_cov_band_fam(rvt_ctx* c, const double* dG, int ring_cols, int col0, int 
   return RVT_OK;
 }
 
+// the column cache of a block (int8 copy, E2M1 copy, sums, flags, rows of T): an optimisation — a failed allocation leaves the
+// block without one (every column invalid; the covariance calls then run their own column pass), it does not fail the call
+static void free_col_cache(rvt_ctx::ColKind& ck) {
+  for (void* q : {(void*)ck.d_i8, (void*)ck.d_i4, (void*)ck.d_cs, (void*)ck.d_poly, (void*)ck.d_T})
+    if (q) hipFree(q);
+  ck.d_i8 = nullptr;
+  ck.d_i4 = nullptr;
+  ck.d_cs = nullptr;
+  ck.d_poly = nullptr;
+  ck.d_T = nullptr;
+  std::fill(ck.valid.begin(), ck.valid.end(), 0);
+}
+static bool alloc_col_cache(rvt_ctx* c, rvt_ctx::ColKind& ck, int64_t ldk, int64_t ldk4, uint64_t gen, hipStream_t st) {
+  const size_t cap = ((size_t)ck.cols + 255) / 256 * 256 + 256;  // (the products read whole tiles of columns)
+  bool ok = hipMalloc((void**)&ck.d_i8, cap * (size_t)ldk) == hipSuccess &&
+            hipMalloc((void**)&ck.d_i4, cap * (size_t)ldk4) == hipSuccess &&
+            hipMalloc((void**)&ck.d_cs, sizeof(double) * (size_t)ck.cols) == hipSuccess &&
+            hipMalloc((void**)&ck.d_poly, sizeof(int) * (size_t)ck.cols) == hipSuccess &&
+            hipMalloc((void**)&ck.d_T, sizeof(double) * (size_t)ck.cols * RVT_MAX_COV) == hipSuccess;
+  ok = ok && hipMemsetAsync(ck.d_i8, 0, cap * (size_t)ldk, st) == hipSuccess &&
+       hipMemsetAsync(ck.d_i4, 0, cap * (size_t)ldk4, st) == hipSuccess;
+  ck.valid.assign((size_t)ck.cols, 0);
+  if (!ok) {
+    (void)hipGetLastError();
+    free_col_cache(ck);
+    return false;
+  }
+  ck.ldk = ldk;
+  ck.ldk4 = ldk4;
+  ck.gen = gen;
+  (void)c;
+  return true;
+}
+
 // the column cache of ncols columns from (block s, column sc) to (block t, column tc), t == s allowed (a forward move: tc < sc);
 // columns whose source has no valid entry become invalid in the target
 static int move_col_cache(rvt_ctx* c, rvt_ctx::ColKind* t, int tc, const rvt_ctx::ColKind* s, int sc, int ncols, hipStream_t st) {
@@ -765,15 +829,11 @@ static int move_col_cache(rvt_ctx* c, rvt_ctx::ColKind* t, int tc, const rvt_ctx
     return RVT_OK;
   }
   if (!t->d_i8) {  // the target block has no cache yet: same shape as the source's
-    const size_t cap = ((size_t)t->cols + 255) / 256 * 256 + 256;
-    HIP_TRY(c, hipMalloc((void**)&t->d_i8, cap * (size_t)s->ldk));
-    HIP_TRY(c, hipMemsetAsync(t->d_i8, 0, cap * (size_t)s->ldk, st));
-    HIP_TRY(c, hipMalloc((void**)&t->d_cs, sizeof(double) * (size_t)t->cols));
-    HIP_TRY(c, hipMalloc((void**)&t->d_poly, sizeof(int) * (size_t)t->cols));
-    HIP_TRY(c, hipMalloc((void**)&t->d_T, sizeof(double) * (size_t)t->cols * RVT_MAX_COV));
-    t->ldk = s->ldk;
-    t->gen = s->gen;
-    t->valid.assign((size_t)t->cols, 0);
+    if (!s->d_i4 || !alloc_col_cache(c, *t, s->ldk, s->ldk4, s->gen, st)) {
+      if (!t->valid.empty())
+        for (int k = 0; k < ncols; ++k) t->valid[(size_t)(tc + k)] = 0;
+      return RVT_OK;
+    }
   }
   // (forward, in pieces no longer than the shift: a piece never overwrites what it has not read)
   const int shift = (t == s) ? sc - tc : ncols;
@@ -781,6 +841,9 @@ static int move_col_cache(rvt_ctx* c, rvt_ctx::ColKind* t, int tc, const rvt_ctx
     const int nk = std::min(std::max(shift, 1), ncols - k0);
     HIP_TRY(c, hipMemcpyAsync(t->d_i8 + (size_t)(tc + k0) * (size_t)s->ldk, s->d_i8 + (size_t)(sc + k0) * (size_t)s->ldk,
                               (size_t)nk * (size_t)s->ldk, hipMemcpyDeviceToDevice, st));
+    if (t->d_i4 && s->d_i4)
+      HIP_TRY(c, hipMemcpyAsync(t->d_i4 + (size_t)(tc + k0) * (size_t)s->ldk4, s->d_i4 + (size_t)(sc + k0) * (size_t)s->ldk4,
+                                (size_t)nk * (size_t)s->ldk4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(t->d_cs + tc + k0, s->d_cs + sc + k0, sizeof(double) * (size_t)nk, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(t->d_poly + tc + k0, s->d_poly + sc + k0, sizeof(int) * (size_t)nk, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(t->d_T + (size_t)(tc + k0) * RVT_MAX_COV, s->d_T + (size_t)(sc + k0) * RVT_MAX_COV,
@@ -862,29 +925,14 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
       HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
       HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, c->io_stream));
     }
-    const bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
+    bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
     const int d = c->nc.d, dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
-    const int64_t ldk = ((int64_t)N + 127) / 128 * 128;
+    const int64_t ldk = ((int64_t)N + 127) / 128 * 128, ldk4 = (((int64_t)N + 1) / 2 + 127) / 128 * 128;
     if (cache) {
-      if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen)) {  // another model: nothing of the old cache is used
-        for (void* q : {(void*)ck.d_i8, (void*)ck.d_cs, (void*)ck.d_poly, (void*)ck.d_T}) hipFree(q);
-        ck.d_i8 = nullptr;
-        ck.d_cs = nullptr;
-        ck.d_poly = nullptr;
-        ck.d_T = nullptr;
-      }
-      if (!ck.d_i8) {
-        const size_t cap = ((size_t)ck.cols + 255) / 256 * 256 + 256;  // (the product reads whole tiles of columns)
-        HIP_TRY(c, hipMalloc((void**)&ck.d_i8, cap * (size_t)ldk));
-        HIP_TRY(c, hipMemsetAsync(ck.d_i8, 0, cap * (size_t)ldk, c->io_stream));
-        HIP_TRY(c, hipMalloc((void**)&ck.d_cs, sizeof(double) * (size_t)ck.cols));
-        HIP_TRY(c, hipMalloc((void**)&ck.d_poly, sizeof(int) * (size_t)ck.cols));
-        HIP_TRY(c, hipMalloc((void**)&ck.d_T, sizeof(double) * (size_t)ck.cols * RVT_MAX_COV));
-        ck.ldk = ldk;
-        ck.gen = c->null_gen;
-        ck.valid.assign((size_t)ck.cols, 0);
-      }
-      if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * kCovSlices * (RVT_MAX_COV + 3)));
+      if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen || !ck.d_i4)) free_col_cache(ck);  // another model: nothing of the old cache is used
+      if (!ck.d_i8 && !ck.cache_failed && !alloc_col_cache(c, ck, ldk, ldk4, c->null_gen, c->io_stream)) ck.cache_failed = true;
+      cache = ck.d_i8 != nullptr;
+      if (cache && !c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * kCovSlices * (RVT_MAX_COV + 3)));
     }
     for (int k = 0; k < ncols; ++k) {
       const int col = col0 + k;
@@ -896,21 +944,9 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
       static const int one = 1;
       HIP_TRY(c, hipMemcpyAsync(ck.d_flags + col, &one, sizeof(int), hipMemcpyHostToDevice, c->io_stream));
       const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
-      const dim3 grid(1, (unsigned)slices);
-      const double* GW = dG + (size_t)col * ld;
-      signed char* o8 = ck.d_i8 + (size_t)col * (size_t)ldk;
-      if (dmax == 4)
-        hipLaunchKernelGGL((cov_hc_prep_kernel<4>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1, c->d_X,
-                           (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
-                           ck.d_flags + col);
-      else if (dmax == 8)
-        hipLaunchKernelGGL((cov_hc_prep_kernel<8>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1, c->d_X,
-                           (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
-                           ck.d_flags + col);
-      else
-        hipLaunchKernelGGL((cov_hc_prep_kernel<RVT_MAX_COV>), grid, dim3(256), 0, c->io_stream, GW, (long long)N, (long long)ld, 1,
-                           c->d_X, (long long)ld, d, o8, (long long)ldk, c->d_cc_part, (int*)nullptr, (const double*)nullptr,
-                           ck.d_flags + col);
+      launch_cov_prep(c->io_stream, d, true, dim3(1, (unsigned)slices), dG + (size_t)col * ld, (int64_t)N, (int64_t)ld, 1, c->d_X,
+                      ck.d_i8 + (size_t)col * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr, ck.d_flags + col, 0, 0,
+                      ck.d_i4 + (size_t)col * (size_t)ldk4, ldk4);
       hipLaunchKernelGGL(cov_hc_finish_kernel, dim3(1), dim3(256), 0, c->io_stream, c->d_cc_part, slices, 1, d, dmax,
                          ck.d_cs + col, ck.d_poly + col, ck.d_T + (size_t)col * RVT_MAX_COV);
       HIP_TRY(c, hipGetLastError());

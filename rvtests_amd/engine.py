@@ -82,15 +82,31 @@ def build_library(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "rvtests_amd.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
-    # eight objects compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one link
+    # one object per translation unit, compiled in parallel (the fully unrolled K2 bodies dominate the compile time), then one
+    # link.  Every unit leaves a dependency file (-MMD): a unit whose sources are older than its object is not compiled again.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function"]
     units = ["rvt_engine.hip", "rvt_stream.hip", "rvt_fam.hip", "rvt_perm.hip", "rvt_meta.hip", "k2_unweighted.hip", "k2_weighted.hip", "k2_hardcall.hip", "k2_hardcall_w.hip",
              "k2_hardcall_x.hip", "k2_lattice.hip", "k2_packed.hip", "k2_floatdigit.hip"]
+
+    def fresh(obj, dep):
+        if force or not os.path.exists(obj) or not os.path.exists(dep):
+            return False
+        t = os.path.getmtime(obj)
+        try:
+            words = open(dep).read().replace("\\\n", " ").split()
+        except OSError:
+            return False
+        deps = [w for w in words if not w.endswith(":")]
+        return bool(deps) and all(os.path.exists(d) and os.path.getmtime(d) <= t for d in deps)
+
     objs, procs = [], []
     for u in units:
         obj = os.path.join(CSRC, u.replace(".hip", ".o"))
+        dep = obj[:-2] + ".d"
         objs.append(obj)
-        cmd = ["hipcc"] + flags + ["-c", os.path.join(CSRC, u), "-o", obj]
+        if fresh(obj, dep):
+            continue
+        cmd = ["hipcc"] + flags + ["-MMD", "-MF", dep, "-c", os.path.join(CSRC, u), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))

@@ -341,6 +341,14 @@ def test_cov_band_wrapped_ring_against_the_oracle(engine_factory, monkeypatch):
     band_nc = eng.cov_band(ring, cap, col0, V, V, halo)[0]
     monkeypatch.delenv("RVT_METACOV_NO_CACHE")
     assert np.array_equal(band_nc, band, equal_nan=True)
+    # one byte per genotype on the int8 matrix instruction instead of E2M1 codes on the MXFP4 one: the same integers
+    monkeypatch.setenv("RVT_BAND_INT8", "1")
+    band_i8 = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    monkeypatch.setenv("RVT_METACOV_NO_CACHE", "1")
+    band_i8_nc = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    monkeypatch.delenv("RVT_METACOV_NO_CACHE")
+    monkeypatch.delenv("RVT_BAND_INT8")
+    assert np.array_equal(band_i8, band, equal_nan=True) and np.array_equal(band_i8_nc, band, equal_nan=True)
     # K split differently: integers, the same sums
     monkeypatch.setenv("RVT_BAND_SLICES", "3")
     band_s3 = eng.cov_band(ring, cap, col0, V, V, halo)[0]
@@ -464,3 +472,16 @@ def test_fp64_band_product_exact_integer_check():
     p = subprocess.run([exe, "check"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
     assert p.stdout.count(": 0 /") == 9
+
+
+def test_mxfp4_band_product_exact_integer_check():
+    """tools/band_bench check: the band tiles of hard calls on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 codes, unit block scales,
+    fp32 accumulation of integers below 2^24) against the int8 kernel — every entry of the band — and both against plain dot
+    products of the columns; rings that wrap, K not a multiple of the chunk, one / several K slices."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "band_bench")
+    assert os.path.exists(exe), "tools/band_bench is built by __graft_entry__.build()"
+    p = subprocess.run([exe, "check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
+    assert p.stdout.count("fp4 != int8 in 0 /") == 5 and p.stdout.count("int8 0, fp4 0 of 512 wrong") == 5

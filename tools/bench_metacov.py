@@ -6,8 +6,8 @@ measured like the headline: one JSON line per workload with `roofline` and `cpu_
             fp64   dosages / anything that is not a hard call: the LDS-tiled fp64 product (gemm_f64.hip.h)  — matrix-core bound
             hc     hard calls under an unweighted model: the exact int8 product (rot_gemm.hip.h)            — HBM bound
   window  the reference's 1 Mb sliding window as the adapter drives it (ModelFitterGpu.cpp MetaCovTest::fit / flush): a stream
-          of variants whose window holds `--window` markers; the circular device ring (1 024 columns, doubled until it holds
-          two windows) is filled from HBM-resident columns and flushed when full: ONE rvt_cov_band call computes the band of the
+          of variants whose window holds `--window` markers; the circular device ring (4 096 columns, doubled until it holds
+          four windows) is filled from HBM-resident columns and flushed when full: ONE rvt_cov_band call computes the band of the
           finished heads where the columns lie (modulo the capacity), the head index advances, nothing is moved.
 
 Algorithmic work: per pair of the band 2 N flop; per block 8 N V bytes read once.
@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--variants", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--window", default="200,1000,3000", help="comma-separated window widths (markers) of the stream runs; empty = none")
-    ap.add_argument("--stream", type=int, default=16384, help="variants of a stream run")
+    ap.add_argument("--stream", type=int, default=40000, help="variants of a stream run")
     ap.add_argument("--ring", type=int, default=0, help="columns of the device ring of the stream runs (default: the adapter's policy)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-blocks", action="store_true", help="only the stream runs (profiles of the window)")
@@ -141,11 +141,11 @@ def main():
     # ---- the sliding window, as the adapter drives it (MetaCovTest::fit / flush of ModelFitterGpu.cpp): a CIRCULAR ring — a new
     # site goes into the physical column behind the tail, a flush computes the band of the finished heads where the columns lie
     # (rvt_cov_band addresses them modulo the capacity) and advances the head index; nothing is ever moved.  The ring starts at
-    # 1 024 columns and doubles while a flush emits less than half of it (--ring overrides the capacity).
+    # 4 096 columns and doubles while a flush emits less than three quarters of it (--ring overrides the capacity).
     widths = [int(w) for w in a.window.split(",") if w]
     for w in widths:
-        cap = 1024
-        while cap < 2 * w:
+        cap = 4096
+        while cap < 4 * w:
             cap *= 2
         if a.ring:
             cap = max(a.ring, w + 1)
