@@ -721,9 +721,34 @@ def main():
                     torch.cuda.empty_cache()
                     pr = subprocess.run([tool, "--samples", str(N), "--m", "50", "--genes", "1536", "--modes", "int8,bed"],
                                         capture_output=True, text=True, timeout=240)
-                    line["from_host_cpp"] = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    recs = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    line["from_host_cpp"] = [r for r in recs if "diag" not in r]
+                    # what this box gives the hand-off to work with (rvt_host_diagnose: threads, NUMA nodes, memcpy / staging /
+                    # DMA rates measured in place): a from-host figure far below another box's is explained by these or by
+                    # nothing the engine controls
+                    line["from_host_cpp_diag"] = next((r["diag"] for r in recs if "diag" in r), None)
                 except Exception as e:
                     line["from_host_cpp"] = {"error": repr(e)[:300]}
+            # the DROP-IN itself at the size of the headline: the C++ adapters end to end (ModelManager::create, fit() /
+            # writeOutput() per gene and model as src/Main.cpp:1221-1254 drives them, GpuBroker's deferred gene-ordered rows,
+            # writeFootnote()) over 1 536 synthetic genes of N samples, M ~ U{20..80}, SKAT + SKAT-O + CMC + Zeggini, handed
+            # over as dc->getGenotype() holds them (fp64, 8 bytes per genotype: the only layout a stock rvtest has) and as
+            # PLINK 2-bit rows before consolidation; the two runs print the same .assoc text (rows_sha256)
+            drv = os.path.join(ROOT, "rvtests_amd", "csrc", "host", "host_driver")
+            if os.path.exists(drv):
+                import subprocess
+                di = {}
+                for mode in ("fp64", "bed"):
+                    try:
+                        pr = subprocess.run([drv, "--synthetic", str(N), "1536", "20", "80", mode, "skat[nPerm=0],skato", "cmc,zeggini",
+                                             "--pool", "16"], capture_output=True, text=True, timeout=300)
+                        rec = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                        di[mode] = rec[0] if rec else {"error": (pr.stderr or "no output")[-300:]}
+                    except Exception as e:
+                        di[mode] = {"error": repr(e)[:300]}
+                di["rows_identical"] = bool(di.get("fp64", {}).get("rows_sha256")) and \
+                    di["fp64"].get("rows_sha256") == di.get("bed", {}).get("rows_sha256")
+                line["drop_in"] = di
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -202,6 +202,25 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * (rvt_destroy unregisters what is left).  Registration changes no result. */
 int rvt_host_register(rvt_ctx* ctx, const void* ptr, size_t bytes);
 int rvt_host_unregister(rvt_ctx* ctx, const void* ptr);
+/* What the host side of the hand-off has to work with on THIS machine, measured in place (about a third of a second): a
+ * figure from host memory that is far below another box's is explained by these numbers or by nothing the engine controls.
+ * Rates in GB/s on a 64 MB buffer, best of three. */
+typedef struct rvt_host_diag {
+  int hardware_threads;        /* std::thread::hardware_concurrency()                                            */
+  int affinity_cpus;           /* CPUs in this process's affinity mask (sched_getaffinity)                       */
+  int copy_threads;            /* threads that copy pageable memory into the pinned ring (RVT_COPY_THREADS)      */
+  int pack_threads;            /* threads of the fp64 -> 2-bit packing pass (RVT_PACK_THREADS)                   */
+  int thp;                     /* transparent huge pages: 0 never, 1 madvise, 2 always, -1 unknown               */
+  int gpu_numa_node;           /* NUMA node of the device (sysfs), -1 unknown                                    */
+  int buffer_numa_node;        /* NUMA node the test buffer's pages landed on (first touch by the caller), -1    */
+  int pinned_numa_node;        /* NUMA node of the pinned staging memory (hipHostMalloc), -1                     */
+  double memcpy_one_thread;    /* pageable -> pageable memcpy, the calling thread                                */
+  double stage_pool;           /* pageable -> pinned with the copy pool (what a staged hand-off does per gene)   */
+  double h2d_pinned;           /* pinned -> device DMA                                                           */
+  double d2h_pinned;           /* device -> pinned DMA                                                           */
+  double loadavg1;             /* 1-minute load average of the machine                                           */
+} rvt_host_diag;
+int rvt_host_diagnose(rvt_ctx* ctx, rvt_host_diag* out);
 /* Hard calls.  Where the entries of a block are exactly 0.0, 1.0 or 2.0 and the null model is unweighted (quantitative
  * trait), G'G is an integer matrix and the engine computes it on the int8 matrix cores instead of the fp64 ones, with
  * the burden collapse in the same pass (rvtests_amd/csrc/suffstat_hc.hip.h): same numbers (the integer part exactly,

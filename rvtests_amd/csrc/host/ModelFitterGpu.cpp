@@ -271,13 +271,20 @@ int GpuBroker::submit(const GeneData& gd, bool binary, std::string* err) {
     flush();  // pending genes belong to the previous null model
     if (installNull(gd, binary, err)) return failed();
   }
-  if ((int)gd.markerFrequency.size() < gd.M) {
-    *err = "marker frequencies missing";
-    return failed();
-  }
-  if (rvt_group_submit_gene(grp, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params)) {
-    *err = rvt_group_last_error(grp);
-    return failed();
+  if (gd.bed) {  // 2-bit rows before consolidation: frequencies and imputation happen on the device
+    if (rvt_group_submit_gene_bed(grp, gd.serial, gd.M, gd.bed, tests, &params, nullptr)) {
+      *err = rvt_group_last_error(grp);
+      return failed();
+    }
+  } else {
+    if ((int)gd.markerFrequency.size() < gd.M) {
+      *err = "marker frequencies missing";
+      return failed();
+    }
+    if (rvt_group_submit_gene(grp, gd.serial, gd.M, gd.genotype, gd.markerFrequency.data(), tests, &params)) {
+      *err = rvt_group_last_error(grp);
+      return failed();
+    }
   }
   pendingSerial.push_back(gd.serial);
   pendingBytes += geneBytes;

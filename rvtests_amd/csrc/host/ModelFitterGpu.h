@@ -46,6 +46,11 @@ struct GeneData {
   int64_t N = 0;
   int M = 0;
   const double* genotype = nullptr;   // dc->getGenotype(): imputed, unflipped, N x M column-major
+  // Optional, INSTEAD of `genotype` for the gene tests (SKAT / SKAT-O / CMC / Zeggini): the gene as the extractor of a PLINK
+  // file holds it BEFORE consolidation — M rows of ceil(N / 4) bytes, SNP-major 2-bit codes (libVcf/PlinkInputFile.cpp:24-47;
+  // 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing).  The device then does what DataConsolidator::consolidate does (allele
+  // frequencies, mean imputation: rvt_submit_gene_bed); markerFrequency is not needed.  1/32 of the bytes of `genotype`.
+  const unsigned char* bed = nullptr;
   const double* phenotype = nullptr;  // dc->getPhenotype(): N
   const double* covariate = nullptr;  // dc->getCovariate(): N x ncov column-major, NO intercept
   int ncov = 0;

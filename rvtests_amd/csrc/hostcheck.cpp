@@ -369,4 +369,22 @@ int hc_stage_copy2d(size_t width, size_t rows, size_t spitch, size_t dpitch, siz
   return 0;
 }
 
+// pack_column_f64 with a chosen instruction set (0 scalar, 1 AVX2, 2 AVX-512; an ISA the CPU lacks falls back to scalar):
+// returns ok; mu / has_mu / n_other as PackedColumn.  reps > 1: repeated (for a rate), the last result counts.
+int hc_pack_column(const double* g, size_t n, unsigned char* out, size_t pitch, int isa, int reps, double* mu, int* has_mu,
+                   long long* n_other) {
+  rvt::PackedColumn r;
+  for (int k = 0; k < (reps < 1 ? 1 : reps); ++k) r = rvt::pack_column_f64(g, n, out, pitch, nullptr, isa);
+  *mu = r.mu;
+  *has_mu = r.has_mu ? 1 : 0;
+  *n_other = r.n_other;
+  return r.ok ? 1 : 0;
+}
+int hc_cpu_has(int isa) {
+#if defined(__x86_64__)
+  if (isa == 1) return __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (isa == 2) return (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("bmi2")) ? 1 : 0;
+#endif
+  return isa == 0;
+}
 }  // extern "C"

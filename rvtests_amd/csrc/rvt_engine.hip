@@ -3,6 +3,12 @@
 // HIP device rvt_init() fails with RVT_E_NO_DEVICE.
 #include "rvt_engine_int.h"
 #include <chrono>
+#include <functional>
+#include <thread>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <cctype>
 
 extern "C" {
 
@@ -740,6 +746,94 @@ int rvt_host_unregister(rvt_ctx* c, const void* ptr) {
       return rc;
     }
   return fail(c, RVT_E_INVALID, "rvt_host_unregister: not a registered range");
+}
+
+// NUMA node of the page at p (move_pages with no target nodes only reports), -1 when the kernel does not say
+static int numa_node_of(void* p) {
+  void* page = (void*)((uintptr_t)p & ~(uintptr_t)4095);
+  int status = -1;
+  if (syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0) != 0) return -1;
+  return status < 0 ? -1 : status;
+}
+
+int rvt_host_diagnose(rvt_ctx* c, rvt_host_diag* o) {
+  if (!c || !o) return fail(c, RVT_E_INVALID, "bad arguments");
+  std::memset(o, 0, sizeof(*o));
+  hipSetDevice(c->device);
+  o->hardware_threads = (int)std::thread::hardware_concurrency();
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    o->affinity_cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : -1;
+  }
+  o->copy_threads = CopyPool::instance().threads();
+  o->pack_threads = CopyPool::pack_instance().threads();
+  o->thp = -1;
+  if (FILE* f = fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r")) {
+    char buf[128] = {0};
+    if (fgets(buf, sizeof(buf), f)) {
+      if (strstr(buf, "[never]")) o->thp = 0;
+      else if (strstr(buf, "[madvise]")) o->thp = 1;
+      else if (strstr(buf, "[always]")) o->thp = 2;
+    }
+    fclose(f);
+  }
+  o->gpu_numa_node = -1;
+  {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), c->device) == hipSuccess) {
+      for (char* q = bus; *q; ++q) *q = (char)tolower(*q);
+      const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+      if (FILE* f = fopen(path.c_str(), "r")) {
+        if (fscanf(f, "%d", &o->gpu_numa_node) != 1) o->gpu_numa_node = -1;
+        fclose(f);
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  {
+    double la[1] = {0};
+    o->loadavg1 = getloadavg(la, 1) == 1 ? la[0] : -1.0;
+  }
+  const size_t B = (size_t)64 << 20;
+  std::vector<char> src(B), dst(B);
+  for (size_t i = 0; i < B; i += 4096) {  // first touch by the caller, as an adapter's genotype buffer
+    src[i] = (char)i;
+    dst[i] = 1;
+  }
+  o->buffer_numa_node = numa_node_of(src.data());
+  char* pin = nullptr;
+  void* dev = nullptr;
+  auto best = [&](const std::function<void()>& fn) {
+    double t = 1e30;
+    for (int r = 0; r < 3; ++r) {
+      const auto a = std::chrono::steady_clock::now();
+      fn();
+      t = std::min(t, std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count());
+    }
+    return (double)B / t / 1e9;
+  };
+  o->memcpy_one_thread = best([&] { std::memcpy(dst.data(), src.data(), B); });
+  if (hipHostMalloc((void**)&pin, B, hipHostMallocDefault) == hipSuccess && hipMalloc(&dev, B) == hipSuccess) {
+    std::memset(pin, 0, B);
+    o->pinned_numa_node = numa_node_of(pin);
+    o->stage_pool = best([&] { CopyPool::instance().copy(pin, src.data(), B); });
+    o->h2d_pinned = best([&] {
+      (void)hipMemcpyAsync(dev, pin, B, hipMemcpyHostToDevice, c->io_stream);
+      (void)sync_stream(c->io_stream);
+    });
+    o->d2h_pinned = best([&] {
+      (void)hipMemcpyAsync(pin, dev, B, hipMemcpyDeviceToHost, c->io_stream);
+      (void)sync_stream(c->io_stream);
+    });
+  } else {
+    (void)hipGetLastError();
+    o->pinned_numa_node = -1;
+  }
+  if (pin) hipHostFree(pin);
+  if (dev) hipFree(dev);
+  return RVT_OK;
 }
 
 int small_h2d(rvt_ctx* c, void* dst, const void* src, size_t bytes) {

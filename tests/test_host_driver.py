@@ -635,3 +635,113 @@ def test_dosage_input_with_the_lattice_stated_prints_the_same_rows(tmp_path):
     for (G, af), row in zip(genes, rows):
         rc, a = orc.skat(G, af, X, res, v, 0)
         assert abs(float(row[-2]) - a.Q) <= 6e-6 * a.Q and abs(float(row[-1]) - a.pvalue) <= 6e-6 * a.pvalue + 1e-14
+
+
+# ---- the synthetic drop-in run (host_driver --synthetic: what bench.py times at configs[2] size as `drop_in`) ---------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64's finaliser on uint64 arrays (wrap-around arithmetic), as host_driver.cpp's mix64."""
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def synthetic_inputs(N, Mlo, Mhi, pool, seed=1):
+    """The generator of host_driver --synthetic restated: covariates, phenotype and the pool's genotype blocks."""
+    with np.errstate(over="ignore"):
+        i = np.arange(N, dtype=np.uint64)
+        cov = np.empty((N, 2))
+        for k in range(2):
+            cov[:, k] = (_mix64(np.uint64((seed * 1000003 + k + 1) & _M64) + i * np.uint64(7)) >> np.uint64(11)) / 9007199254740992.0 - 0.5
+        y = 0.3 * cov[:, 0] + (_mix64(np.uint64((seed * 999983 + 5) & _M64) + i * np.uint64(13)) >> np.uint64(11)) / 9007199254740992.0
+        blocks = []
+        for k in range(pool):
+            M = Mlo + int(_mix64(np.uint64((seed * 7919 + k) & _M64))) % (Mhi - Mlo + 1)
+            G = np.empty((N, M), order="F")
+            for j in range(M):
+                thr = np.uint64(200 + int(_mix64(np.uint64((seed * 131 + k * 4099 + j) & _M64))) % 3000)
+                base = np.uint64((((k * 1000003 + j) * 0x100000001B3) + seed) & _M64)
+                h = _mix64(base + i)
+                G[:, j] = ((h & np.uint64(0xffff)) < thr).astype(np.float64) + (((h >> np.uint64(16)) & np.uint64(0xffff)) < thr)
+            blocks.append(G)
+    return cov, y, blocks
+
+
+def run_synthetic(mode, N, genes, Mlo, Mhi, pool, rows_path, kernel="skat[nPerm=0],skato", burden="cmc,zeggini"):
+    import json
+    p = subprocess.run([DRIVER, "--synthetic", str(N), str(genes), str(Mlo), str(Mhi), mode, kernel, burden, "--pool", str(pool),
+                        "--rows", rows_path], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    sections, cur = {}, None
+    for ln in open(rows_path).read().splitlines(keepends=True):
+        if ln.startswith("== "):
+            cur = ln[3:].strip()
+            sections[cur] = ""
+        else:
+            sections[cur] += ln
+    return line, sections
+
+
+@pytest.mark.gpu
+def test_synthetic_drop_in_rows_match_oracle(tmp_path):
+    """host_driver --synthetic (the C++ adapters end to end: ModelManager, fit / writeOutput per gene, GpuBroker's deferred ordered
+    rows) from the fp64 boundary and from PLINK 2-bit rows: the same .assoc text either way (same SHA-256, which is the SHA-256
+    of the text the driver wrote), one row per gene and model in gene order, and the numbers of sampled genes equal to the
+    oracle's on the regenerated inputs, formatted as the reference prints them."""
+    import hashlib
+    _ensure_driver()
+    N, genes, Mlo, Mhi, pool = 3000, 40, 5, 30, 8
+    line64, sec64 = run_synthetic("fp64", N, genes, Mlo, Mhi, pool, str(tmp_path / "rows64.txt"))
+    lineb, secb = run_synthetic("bed", N, genes, Mlo, Mhi, pool, str(tmp_path / "rowsb.txt"))
+    assert line64["rows_sha256"] == lineb["rows_sha256"] and sec64 == secb
+    names = ["out.Skat.assoc", "out.SkatO.assoc", "out.CMC.assoc", "out.Zeggini.assoc"]
+    assert list(sec64) == names
+    sha = hashlib.sha256("".join(hashlib.sha256(sec64[n].encode()).hexdigest() for n in names).encode()).hexdigest()
+    assert sha == line64["rows_sha256"]
+    assert line64["assoc_lines"] == 4 * (genes + 1) and line64["gene_sets_per_s"] > 0 and line64["caller_us_per_gene"] > 0
+    cov, y, blocks = synthetic_inputs(N, Mlo, Mhi, pool)
+    X = np.column_stack([np.ones(N), cov])
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    assert rc == 0
+    v = np.full(N, s2)
+    rows = {n: [r.split("\t") for r in sec64[n].splitlines()] for n in names}
+    for g in (0, 3, 7, 8, 21, 39):
+        G = blocks[g % pool]
+        af = G.sum(0) / (2.0 * N)
+        for n in names:
+            assert rows[n][1 + g][0] == "gene%d" % g and rows[n][1 + g][2] == str(G.shape[1])
+        rc1, a = orc.skat(G, af, X, res, v, 0)
+        row = rows["out.Skat.assoc"][1 + g]
+        if a.n_poly == 0:
+            assert row[-2:] == ["NA", "NA"]
+            continue
+        assert abs(float(row[-2]) - a.Q) <= 6e-6 * a.Q and abs(float(row[-1]) - a.pvalue) <= 6e-6 * a.pvalue + 1e-14
+        rc2, o = orc.skato(G, af, X, res, v, 0)
+        row = rows["out.SkatO.assoc"][1 + g]
+        if rc2 == 0:
+            assert abs(float(row[-3]) - o.Q) <= 6e-6 * o.Q and float(row[-2]) == o.rho
+            assert abs(float(row[-1]) - o.pvalue) <= 6e-6 * o.pvalue + 1e-12
+        rc3, c = orc.burden(G, X, y, 0, 0)
+        row = rows["out.CMC.assoc"][1 + g]
+        if rc3 == 0:
+            assert int(row[-2]) == c.nonref_site and abs(float(row[-1]) - c.pvalue) <= 6e-6 * c.pvalue
+        rc4, z = orc.burden(G, X, y, 0, 1)
+        row = rows["out.Zeggini.assoc"][1 + g]
+        if rc4 == 0:
+            assert abs(float(row[-1]) - z.pvalue) <= 6e-6 * z.pvalue
+    # genes that share a pool block print the same numbers
+    assert rows["out.Skat.assoc"][1 + 3][3:] == rows["out.Skat.assoc"][1 + 3 + pool][3:]
+
+
+def test_synthetic_generator_restatement_cpu():
+    """The numpy restatement of the driver's generator: allele frequencies in the stated range, hard calls only (CPU)."""
+    cov, y, blocks = synthetic_inputs(2000, 5, 12, 3)
+    assert cov.shape == (2000, 2) and np.abs(cov).max() <= 0.5 and len(blocks) == 3
+    for G in blocks:
+        assert 5 <= G.shape[1] <= 12 and set(np.unique(G)) <= {0.0, 1.0, 2.0}
+        af = G.mean(0) / 2
+        assert af.max() < 0.07

@@ -53,3 +53,70 @@ def test_gathered_copy_assembles_the_device_range(n, max_piece, chunk, chunks, t
     L.hc_stage_gather.restype = C.c_int
     L.hc_stage_gather.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_uint]
     assert L.hc_stage_gather(n, max_piece, chunk, chunks, threads, seed) == 0
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099, 500000])
+def test_fp64_packing_agrees_across_instruction_sets(n):
+    """pack_column_f64 (the fp64 boundary packed to PLINK 2-bit rows by the staging threads): the AVX2 and AVX-512 forms give the
+    bytes, the other value and its count of the scalar form — hard calls, a column with one other value (the imputed mean),
+    -0.0 as an other value, and the refusals: a second other value, an other value outside [0, 2]."""
+    import time
+
+    import numpy as np
+    L = hc.lib()
+    L.hc_pack_column.restype = C.c_int
+    L.hc_pack_column.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, C.c_int, C.c_int,
+                                 C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    L.hc_cpu_has.restype = C.c_int
+    rng = np.random.default_rng(n)
+    pitch = (n + 3) // 4 + 5
+
+    def run(g, isa, reps=1):
+        out = np.full(pitch, 0xAB, dtype=np.uint8)
+        mu, has, cnt = C.c_double(), C.c_int(), C.c_longlong()
+        t0 = time.perf_counter()
+        ok = L.hc_pack_column(g.ctypes.data_as(C.POINTER(C.c_double)), n, out.ctypes.data_as(C.POINTER(C.c_ubyte)), pitch, isa, reps,
+                              C.byref(mu), C.byref(has), C.byref(cnt))
+        return ok, out, mu.value, has.value, cnt.value, (time.perf_counter() - t0) / reps
+
+    cases = []
+    g = rng.integers(0, 3, n).astype(np.float64)
+    cases.append(("hard calls", g, True))
+    g2 = g.copy()
+    g2[rng.random(n) < 0.03] = 0.137
+    cases.append(("one other value", g2, True))
+    g3 = g.copy()
+    g3[n // 2] = -0.0
+    cases.append(("-0.0 is an other value (outside nothing: accepted as 0 <= -0.0)", g3, True))
+    if n > 20:
+        g4 = g2.copy()
+        g4[3] = 0.137
+        g4[n - 2] = 0.25
+        cases.append(("two other values", g4, False))
+        g5 = g.copy()
+        g5[n // 3] = 2.5
+        cases.append(("other value above 2", g5, False))
+    for name, col, want_ok in cases:
+        ref = run(col, 0)
+        assert bool(ref[0]) == want_ok, name
+        if want_ok:                                                # the codes, by hand
+            codes = np.where(col == 0, 0, np.where(col == 1, 2, np.where(col == 2, 3, 1)))
+            if name.startswith("-0.0"):
+                codes[n // 2] = 1
+            packed = np.zeros(pitch, dtype=np.uint8)
+            for e in range(4):
+                part = codes[e::4].astype(np.uint8)
+                packed[:len(part)] |= part << (2 * e)
+            assert np.array_equal(ref[1], packed), name
+        for isa in (1, 2):
+            if not L.hc_cpu_has(isa):
+                continue
+            got = run(col, isa)
+            assert got[0] == ref[0], (name, isa)
+            if want_ok:
+                assert np.array_equal(got[1], ref[1]) and got[2:5] == ref[2:5], (name, isa)
+    if n == 500000:                                                # rates (informative: printed with -s)
+        for isa in (0, 1, 2):
+            if L.hc_cpu_has(isa):
+                dt = run(cases[1][1], isa, reps=20)[5]
+                print("pack_column_f64 isa %d: %.1f GB/s" % (isa, 8.0 * n / dt / 1e9))

@@ -59,6 +59,16 @@ int main(int argc, char** argv) {
       if (((h >> 40) & 0xfffff) < 1000) g8[k][i] = -9;  // ~0.1 % missing calls
     }
   }
+  {  // what this machine gives the hand-off to work with: the figures below are bounded by stage_pool / h2d_pinned
+    rvt_host_diag dg;
+    if (rvt_host_diagnose(ctx, &dg) == 0)
+      printf("{\"diag\": {\"hardware_threads\": %d, \"affinity_cpus\": %d, \"copy_threads\": %d, \"pack_threads\": %d, \"thp\": %d, "
+             "\"gpu_numa_node\": %d, \"buffer_numa_node\": %d, \"pinned_numa_node\": %d, \"memcpy_one_thread_GBps\": %.1f, "
+             "\"stage_pool_GBps\": %.1f, \"h2d_pinned_GBps\": %.1f, \"d2h_pinned_GBps\": %.1f, \"loadavg1\": %.1f}}\n",
+             dg.hardware_threads, dg.affinity_cpus, dg.copy_threads, dg.pack_threads, dg.thp, dg.gpu_numa_node, dg.buffer_numa_node,
+             dg.pinned_numa_node, dg.memcpy_one_thread, dg.stage_pool, dg.h2d_pinned, dg.d2h_pinned, dg.loadavg1);
+    fflush(stdout);
+  }
   rvt_params prm{1.0, 25.0, 1.0, 25.0, 0, 0.05};
   std::vector<rvt_gene_result> out(4096);
   size_t pos = 0;
