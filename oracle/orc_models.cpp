@@ -887,6 +887,49 @@ int orc_metascore(const double* Gp, int64_t N, int V, const double* Xp, int d, c
 // SKAT adaptive permutation (src/Model.h:2707-2717, src/Permutation.h:69-98, src/LinearAlgebra.h:8-21,
 // regression/Skat.cpp:107-116).  The residual vector is permuted cumulatively.
 // ---------------------------------------------------------------------------------------------
+// The adaptive stop rule of Permutation (src/Permutation.h:69-98): init / next / add / getPvalue.  Used by orc_skat_permute
+// below and exported alone (orc_perm_stop_run) so that tests can feed the SAME sequence of statistics to it and to the
+// reference's compiled class (oracle/_ref/libref_host.so).
+namespace {
+struct PermStop {
+  int numPerm = 0, actualPerm = 0, numX = 0, numEqual = 0;
+  int threshold = 0;  // (an int in the reference, src/Permutation.h:153: the product below is truncated)
+  double alpha = 0, obs = 0;
+  void init(int nPerm, double a, double observation) {
+    numPerm = nPerm;
+    alpha = a;
+    obs = observation;
+    actualPerm = 0;
+    threshold = (int)(1.0 * nPerm * a * 2);
+    numX = 0;
+    numEqual = 0;
+  }
+  bool next() const {
+    if (actualPerm >= numPerm) return false;
+    if (numX + numEqual >= threshold) return false;
+    return true;
+  }
+  void add(double s) {
+    actualPerm++;
+    if (s > obs) numX++;
+    if (s == obs) numEqual++;
+  }
+  double pvalue() const { return actualPerm == 0 ? 1.0 : 1.0 * (numX + 0.5 * numEqual) / actualPerm; }
+};
+}  // namespace
+
+// feed stats[0 .. n) until the rule stops (or the list ends); out3 = actualPerm, numX, numEqual; returns the p-value
+extern "C" double orc_perm_stop_run(int nPerm, double alpha, double obs, const double* stats, int n, int* out3) {
+  PermStop p;
+  p.init(nPerm, alpha, obs);
+  int used = 0;
+  while (p.next() && used < n) p.add(stats[used++]);
+  out3[0] = p.actualPerm;
+  out3[1] = p.numX;
+  out3[2] = p.numEqual;
+  return p.pvalue();
+}
+
 int orc_skat_permute(const double* Gp, const double* af, int64_t N, int M, const double* res, double beta1,
                      double beta2, double obs, int nPerm, double alpha, int use_float, orc_perm_result* out) {
   Mat G0 = wrap(Gp, N, M);
@@ -902,11 +945,9 @@ int orc_skat_permute(const double* Gp, const double* af, int64_t N, int M, const
     for (int64_t i = 0; i < N; ++i) Ks(j, i) = F(ws * F(G(i, j)));
   }
   std::vector<double> pr(res, res + N);
-  int actualPerm = 0, numX = 0, numEqual = 0;
-  const double threshold = 1.0 * nPerm * alpha * 2;
-  for (;;) {
-    if (actualPerm >= nPerm) break;
-    if (numX + numEqual >= threshold) break;
+  PermStop stop;
+  stop.init(nPerm, alpha, obs);
+  while (stop.next()) {
     for (int64_t i = N - 1; i >= 1; --i) {
       const int64_t j = orc_rand() % (i + 1);
       if (i != j) std::swap(pr[i], pr[j]);
@@ -917,16 +958,14 @@ int orc_skat_permute(const double* Gp, const double* af, int64_t N, int M, const
       for (int64_t i = 0; i < N; ++i) s = F(s + F(Ks(j, i) * F(pr[i])));
       Q = F(Q + F(s * s));
     }
-    actualPerm++;
-    if (Q > obs) numX++;
-    if (Q == obs) numEqual++;
+    stop.add(Q);
   }
   out->num_perm = nPerm;
-  out->actual_perm = actualPerm;
-  out->num_x = numX;
-  out->num_equal = numEqual;
-  out->threshold = threshold;
-  out->pvalue = actualPerm == 0 ? 1.0 : 1.0 * (numX + 0.5 * numEqual) / actualPerm;
+  out->actual_perm = stop.actualPerm;
+  out->num_x = stop.numX;
+  out->num_equal = stop.numEqual;
+  out->threshold = stop.threshold;
+  out->pvalue = stop.pvalue();
   return 0;
 }
 

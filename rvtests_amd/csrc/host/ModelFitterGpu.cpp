@@ -47,7 +47,7 @@ int ModelParser::parse(const std::string& s) {
     size_t e = all.find_first_of(":,", pos);
     if (e == std::string::npos) e = all.size();
     std::string tok = all.substr(pos, e - pos);
-    if (!tok.empty()) {
+    {  // (empty pieces are kept, as stringTokenize keeps them, base/Utils.h:194-218: "cmc[]" has ONE parameter, the tag "")
       size_t q = tok.find('=');
       if (q == std::string::npos)
         param[tok] = "";
@@ -69,7 +69,8 @@ const ModelParser& ModelParser::assign(const std::string& tag, double* v, double
   return *this;
 }
 const ModelParser& ModelParser::assign(const std::string& tag, int* v, int def) const {
-  *v = hasTag(tag) ? atoi(value(tag)) : def;
+  // (through a double, as src/ModelParser.cpp:130-146: "nPerm=1e4" is 10 000)
+  *v = hasTag(tag) ? (int)atof(value(tag)) : def;
   return *this;
 }
 const ModelParser& ModelParser::assign(const std::string& tag, bool* v, bool def) const {

@@ -348,9 +348,59 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
 //      (one shared reduction serves the 12 SKAT-O eigenproblems, see rvt_gene.h stage B).
 // K3c: one workgroup per (eigenproblem, gene): Sturm bisection of its tridiagonal, eigenvalue filter, moments.
 // =====================================================================================================
+// Round 6: step 1 of the assembly — R = the sum of the gene's wave-part images, 2 MB read per gene of M = 50 — on a grid of its
+// own, (pieces of 1 024 entries, genes): the one workgroup per gene of gene_assemble_kernel issued at most 32 loads per
+// thread and waited out the round trips (0.42 of its 0.72 ms per gene; 1.39 G of the kernel's 1.54 G wave cycles waiting,
+// profiles/r5_pvprof.txt), eight times as many workgroups keep eight times as many loads in flight.  Every entry is still
+// the sum over p = 0 .. P - 1 in that order: bit-identical to the loop it replaces (rvt_gene.h gene_assemble step 1).
+constexpr int kReducePiece = 1024;
+static __global__ __launch_bounds__(256) void gene_reduce_parts_kernel(const GeneDesc* __restrict__ genes) {
+  const GeneDesc gd = genes[blockIdx.y];
+  const int Mp = gd.Mp, Cp = gd.Cp, total = Mp * Cp;
+  const int idx = blockIdx.x * kReducePiece + (int)threadIdx.x;
+  if (blockIdx.x * kReducePiece >= total) return;
+  GeneScratch ws = gene_scratch_carve(gd.scratch, Mp, Cp);
+  const bool handed_back = gd.hc && gd.flags[2 * gd.MT + 1];
+  const double lat_den = ((gd.hc == 2 || gd.hc == 4) && !handed_back) ? gd.lat_den : 0.0;
+  const double lat2 = lat_den > 0.0 ? lat_den * lat_den : 0.0;
+  const size_t stride = (size_t)Mp * Cp;
+  const int P = gd.n_wparts;
+  double s4[4];
+  bool use[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = idx + u * 256;
+    s4[u] = 0.0;
+    use[u] = i < total && ((i % Cp) >> 4) >= ((i / Cp) >> 4);
+  }
+  for (int p0 = 0; p0 < P; p0 += 8) {  // eight wave-parts x four entries: 32 loads issued before the first sum
+    double t[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double* src = gd.parts + (size_t)(p0 + q) * stride;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[q][u] = (use[u] && p0 + q < P) ? src[idx + u * 256] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + q < P) s4[u] += t[q][u];  // (p ascending, as always)
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = idx + u * 256;
+    if (i >= total) continue;
+    double sv = s4[u];
+    if (use[u] && lat2 > 0.0 && (i % Cp) < gd.M) sv /= lat2;  // lattice dosages: G'G = K'K / den^2 with one rounding
+    ws.R[i] = sv;
+  }
+}
+
 static __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
-                                                            unsigned tests, int n_bparts, const double* xscale) {
+                                                            unsigned tests, int n_bparts, const double* xscale,
+                                                            int parts_reduced = 0) {
   __shared__ double red[64];
   __shared__ NullConsts nc;
   const GeneDesc gd = genes[blockIdx.x];
@@ -365,7 +415,7 @@ static __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDe
   gene_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, gd.colstat,
                 (tests & (RVT_TEST_CMC | RVT_TEST_ZEGGINI)) ? gd.bparts : nullptr, gd.n_bparts > 0 ? gd.n_bparts : n_bparts,
                 gd.af, prm, tests, ws,
-                gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, handed_back ? kStatusHandedBack : 0u);
+                gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, handed_back ? kStatusHandedBack : 0u, parts_reduced != 0);
 }
 
 static __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,

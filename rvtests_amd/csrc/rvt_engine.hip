@@ -1490,9 +1490,17 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     Scope sc(c, 2, st);
     if (tests & RVT_TEST_FAMSKAT)
       hipLaunchKernelGGL(fam_assemble_kernel, dim3(n), dim3(1024), 0, st, d_desc, c->d_nc);
-    else
+    else {
+      // the sum of the wave-part images on a grid of its own (RVT_AS_REDUCE=0: inside the assembly kernel, as until round 5)
+      static const bool reduce_apart = !(getenv("RVT_AS_REDUCE") && atoi(getenv("RVT_AS_REDUCE")) == 0);
+      if (reduce_apart) {
+        const int maxMpA = (maxM + 15) / 16 * 16, maxCpA = (maxM + d + 1 + 15) / 16 * 16;
+        hipLaunchKernelGGL(gene_reduce_parts_kernel, dim3((unsigned)((maxMpA * maxCpA + kReducePiece - 1) / kReducePiece), (unsigned)n),
+                           dim3(256), 0, st, d_desc);
+      }
       hipLaunchKernelGGL(gene_assemble_kernel, dim3(n), dim3(c->as_threads), 0, st, d_desc, c->d_nc, params, tests_eff,
-                         n_bparts, (const double*)c->d_xscale);
+                         n_bparts, (const double*)c->d_xscale, reduce_apart ? 1 : 0);
+    }
   }
   if ((tests & RVT_TEST_ANALYTICVT) && !(tests & RVT_TEST_FAMSKAT)) {
     Scope sc(c, 2, st);
@@ -1566,7 +1574,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     for (int g = 0; g < n; ++g) {
       if (desc[g].hc == 3)
         c->timing.alg_bytes_hc += (double)desc[g].pk_pitch * Ms[g] + 8.0 * (double)N * (d + 2);
-      else if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + (hcw ? 4 : 2));
+      else if (desc[g].hc) c->timing.alg_bytes_hc += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);  // (SURVEY 8d's d + 2, also for the weighted kernels)
       c->timing.alg_bytes += 8.0 * (double)N * Ms[g] + 8.0 * (double)N * (d + 2);
       c->timing.alg_flops += 2.0 * (double)N * Ms[g] * (Ms[g] + d + 1);
     }

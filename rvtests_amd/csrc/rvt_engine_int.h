@@ -209,6 +209,7 @@ struct rvt_ctx {
       valid.clear();
     }
   };
+  int handed_back_recently = 0;   // > 0: a hard-call gene was handed back within the last 16 batches (launch_suffstat's list grid)
   uint64_t null_gen = 0;          // counts rvt_set_null / rvt_fit_null: a column cache made under another model is not used
   double* d_cc_part = nullptr;    // slice partials of the one-column pass (64 slices x (RVT_MAX_COV + 3))
   std::unordered_map<const double*, ColKind> col_kind;
@@ -442,12 +443,18 @@ int finish_slot(rvt_ctx* c, Slot& sl) {
   HIP_TRY(c, sync_stream(sl.stream));
   if (sl.pending_out) {
     // (kStatusHandedBack is bookkeeping: the gene started on the hard-call kernel and was computed by the fp64 kernel)
+    bool any_back = false;
     for (int g = 0; g < sl.pending_n; ++g) {
       if (sl.h_results[g].status & kStatusHandedBack) {
         sl.h_results[g].status &= ~kStatusHandedBack;
+        any_back = true;
         if (c->profiling) ++c->timing.genes_handed_back;
       }
     }
+    // how wide the NEXT batches launch the general kernel over their hand-back lists (launch_suffstat): a stream that has
+    // handed nothing back for a while gets a grid of 32 waves instead of 1 024
+    if (any_back) c->handed_back_recently = 16;
+    else if (c->handed_back_recently > 0) --c->handed_back_recently;
     std::memcpy(sl.pending_out, sl.h_results, sizeof(rvt_gene_result) * sl.pending_n);
     if (sl.pending_done) *sl.pending_done = true;
     sl.pending_done = nullptr;
@@ -521,7 +528,11 @@ void launch_suffstat(rvt_ctx* c, hipStream_t st, int group, const GeneDesc* d_de
   // wide classes (one wave fills a SIMD's register file) on any free SIMD, instead of needing four free SIMDs on
   // one CU at once — which a single long-lived p-value wave per CU would block for its whole lifetime.
   dim3 grid(max_wparts, n);
-  if (list) grid = dim3(1024, 1);
+  // (the list is empty almost always, but every wave of these kernels needs a SIMD's whole register file before it can start
+  //  and leave: 1 024 of them took 2 ms to trickle through a chip that is busy with the next batch's streaming kernel, and the
+  //  batch's tail waited behind them.  While no batch has handed a gene back for 16 batches the grid is 32 waves; a stream that
+  //  does hand genes back — dosages the caller did not announce — keeps the wide grid.)
+  if (list) grid = dim3(c->handed_back_recently > 0 ? 1024 : 32, 1);
   const long long N = c->nc.N, ld = c->nc.ld;
   const int d = c->nc.d;
   if (c->nc.binary)

@@ -129,11 +129,14 @@ constexpr int kHcRows = 6;  // == kHcColstatRows (suffstat_hc.hip.h)
 RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, int Cp, const double* parts, int P,
                           const double* colstat, const double* bparts, int PB, const double* af,
                           const rvt_params& prm, unsigned tests, GeneScratch ws, GeneStats* out, int* flip_out,
-                          int* kept_out, const HcMasked* hcm = nullptr, unsigned extra_status = 0u) {
+                          int* kept_out, const HcMasked* hcm = nullptr, unsigned extra_status = 0u, bool parts_reduced = false) {
   const int d = nc.d;
   const int ldr = Cp;
   double* R = ws.R;
   RVT_AS_TICK(0);
+  // (parts_reduced: gene_reduce_parts_kernel has already put the sums of step 1 into R — the same additions in the same order,
+  //  spread over several workgroups per gene)
+  if (!parts_reduced)
   // ---- 1. reduce the partial statistics (fixed order => deterministic) ----------------------------
   // (eight entries per thread and pass: their 8 P loads are independent and in flight together — with one entry per pass a
   //  thread waited out P round trips to HBM per entry; the order of the sum over p is unchanged: bit-reproducible)

@@ -88,7 +88,10 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
     const long long ngroups = (N + 15) / 16;
     if (!c->d_pc_Q) HIP_TRY(c, hipMalloc((void**)&c->d_pc_Q, sizeof(double) * kChunk));
     const double obs = r->skat_Q;
-    const double threshold = 1.0 * nPerm * prm.skat_alpha * 2;  // Permutation::init
+    // Permutation::init — `threshold` is an INT member of the reference's class (src/Permutation.h:153): the product is truncated
+    // (nPerm = 100, alpha = 0.001 -> 0: the test stops before its first shuffle and reports p = 1; found by running the
+    // reference's compiled class beside this rule, tests/test_oracle_ref.py)
+    const double threshold = (double)(int)(1.0 * nPerm * prm.skat_alpha * 2);
     int actual = 0, numX = 0, numEq = 0;
     std::vector<double> Q(kChunk);
     bool more = true;
@@ -167,7 +170,10 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   double* nxt = c->d_perm_cur + N;
   HIP_TRY(c, hipMemcpyAsync(cur, c->d_res, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
   const double obs = r->skat_Q;
-  const double threshold = 1.0 * nPerm * prm.skat_alpha * 2;  // Permutation::init
+  // Permutation::init — `threshold` is an INT member of the reference's class (src/Permutation.h:153): the product is truncated
+    // (nPerm = 100, alpha = 0.001 -> 0: the test stops before its first shuffle and reports p = 1; found by running the
+    // reference's compiled class beside this rule, tests/test_oracle_ref.py)
+    const double threshold = (double)(int)(1.0 * nPerm * prm.skat_alpha * 2);
   int actual = 0, numX = 0, numEq = 0;
   uint32_t s0[31];
   std::memcpy(s0, c->rand_state, sizeof(s0));

@@ -28,7 +28,11 @@ def test_glibc_stream_matches_libc():
     assert [libc.rand() for _ in range(2000)] == [orc.lib().orc_rand() for _ in range(2000)]
 
 
-@pytest.mark.parametrize("N,n_perm,alpha,explicit", [(331, 300, 0.05, True), (1000, 120, 0.2, True), (331, 300, 0.05, False)])
+# (300 x 0.0333 x 2 = 19.98: the reference's threshold is an INT member, src/Permutation.h:153 -> 19, not 19.98 -> a stop one
+#  hit earlier; 100 x 0.001 x 2 = 0.2 -> 0: no permutation at all, p = 1 — both pinned on the reference's compiled class in
+#  tests/test_oracle_ref.py)
+@pytest.mark.parametrize("N,n_perm,alpha,explicit", [(331, 300, 0.05, True), (1000, 120, 0.2, True), (331, 300, 0.05, False),
+                                                     (331, 300, 0.0333, True), (331, 100, 0.001, True)])
 def test_permutation_counts_match_oracle(eng, N, n_perm, alpha, explicit):
     """explicit = False: NO mode is selected — a fresh single context must reproduce the reference's counters by DEFAULT
     (the counter-based mode is for genes dealt over several devices, or on request)."""
@@ -63,6 +67,8 @@ def test_permutation_counts_match_oracle(eng, N, n_perm, alpha, explicit):
         assert r.perm_pvalue == p.pvalue
         stopped_early += p.actual_perm < n_perm
     assert stopped_early >= 1          # the adaptive stop was exercised
+    if n_perm == 100:                  # threshold truncated to 0: Permutation::next() is false before the first shuffle
+        assert all(r.perm_actual_perm == 0 and r.perm_pvalue == 1.0 for r in out if r.perm_ok)
 
 
 def test_counter_based_mode_agrees_with_the_exact_mode_within_binomial_error(eng):

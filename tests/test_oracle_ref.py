@@ -237,3 +237,129 @@ def test_search_memo_changes_nothing_and_stays_small():
     used = np.array(used)
     assert np.median(used[:, 0]) <= 16 and np.median(used[:, 1]) <= 16, used.T   # (observed: 10-15 and 6-16)
     assert used[:, 0].max() <= 32 and used[:, 1].max() <= 64
+
+
+# ---- the reference's Permutation stop rule, ModelParser and floatToString compiled where they lie (oracle/_ref/libref_host.so) ----
+def _ref_host():
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_host.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_host.so not built (needs the reference tree: make -C oracle ref)")
+    L = C.CDLL(path)
+    L.ref_permutation_run.restype = C.c_double
+    L.ref_permutation_run.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    L.ref_parser_parse.restype = C.c_int
+    L.ref_parser_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ref_parser_has.argtypes = [C.c_char_p]
+    L.ref_parser_value.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.ref_parser_double.restype = C.c_double
+    L.ref_parser_double.argtypes = [C.c_char_p, C.c_double]
+    L.ref_parser_int.argtypes = [C.c_char_p, C.c_int]
+    L.ref_parser_bool.argtypes = [C.c_char_p, C.c_int]
+    L.ref_float_to_string.argtypes = [C.c_double, C.c_char_p, C.c_int]
+    L.ref_float_to_string_f32.argtypes = [C.c_float, C.c_char_p, C.c_int]
+    return L
+
+
+def test_permutation_stop_rule_matches_the_compiled_reference():
+    """The oracle's adaptive stop rule (orc_perm_stop_run = the PermStop that orc_skat_permute runs, which the engine's counters
+    are compared with in tests/test_gpu_perm.py) against the reference's own Permutation class (src/Permutation.h:48-158) on
+    the same sequences of statistics: permutations used, counters and p-value identical — early stops, ties with the observed
+    value, nPerm exhausted, alpha = 0 and an empty list included."""
+    import ctypes as C
+    R = _ref_host()
+    O = orc.lib()
+    O.orc_perm_stop_run.restype = C.c_double
+    O.orc_perm_stop_run.argtypes = R.ref_permutation_run.argtypes
+    rng = np.random.default_rng(20)
+    n_early = 0
+    for trial in range(400):
+        nperm = int(rng.choice([0, 1, 10, 100, 1000, 10000]))
+        alpha = float(rng.choice([0.0, 0.001, 0.05, 0.5, 1.0]))
+        obs = float(rng.normal())
+        n = int(rng.integers(0, nperm + 5))
+        stats = rng.normal(size=max(n, 1)) + rng.choice([-1.0, 0.0, 1.5])
+        stats[rng.random(max(n, 1)) < 0.05] = obs                 # ties
+        sp = stats.ctypes.data_as(C.POINTER(C.c_double))
+        a, b = (C.c_int * 3)(), (C.c_int * 3)()
+        pr = R.ref_permutation_run(nperm, alpha, obs, sp, n, a)
+        po = O.orc_perm_stop_run(nperm, alpha, obs, sp, n, b)
+        assert list(a) == list(b) and pr == po, (trial, nperm, alpha, list(a), list(b))
+        n_early += a[0] < min(n, nperm)
+    assert n_early > 50                                            # the rule did stop early in many trials
+
+
+def _driver(args, stdin=None):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rvtests_amd", "csrc", "host", "host_driver")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    p = subprocess.run([exe] + args, input=stdin, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    return p.stdout.splitlines()
+
+
+def test_model_parser_matches_the_compiled_reference():
+    """The adapters' ModelParser (csrc/host/ModelFitterGpu.cpp) against the reference's compiled src/ModelParser.cpp: return code,
+    model name, number of parameters, hasTag / value and the assign() conversions (int through a double: "1e4" is 10 000;
+    case folding; ':' and ',' separators; flags without a value; empty pieces; a missing ']')."""
+    import ctypes as C
+    R = _ref_host()
+    specs = ["skat", "Skat[nPerm=1e4:alpha=0.05,beta1=1:beta2=25]", "SKATO", "cmc[]", "kbac[nPerm=10000,alpha=0.001]",
+             "famSkat[Beta1=0.5]", "cov[windowSize=1000000:gwama]", "score[]", "skat[nperm=5", "vt[a=1::b=2]", "x[=3]", "x[a==3,b=]",
+             "analytic[k=1.9,K=2.7]", "Skat[nPerm=-3.7]", "skat[nperm=abc]", "m[,]", "m[a]", "M[A=Hello:b=WORLD]", "[a=1]", "x]"]
+    tags = ["nperm", "nPerm", "alpha", "beta1", "BETA2", "windowsize", "gwama", "a", "b", "k", "", "nosuch"]
+    for spec in specs:
+        name = C.create_string_buffer(256)
+        npar = C.c_int()
+        rc = R.ref_parser_parse(spec.encode(), name, 256, C.byref(npar))
+        got = _driver(["--parse", spec] + tags)
+        assert int(got[0]) == rc, spec
+        if rc != 0:
+            continue                                              # (a rejected spec: the models are not created)
+        assert got[1] == name.value.decode() and int(got[2]) == npar.value, (spec, got[:3], name.value, npar.value)
+        for tag, line in zip(tags, got[3:]):
+            has, val, dv, iv, bv = line.split("\t")
+            assert int(has) == R.ref_parser_has(tag.encode()), (spec, tag)
+            buf = C.create_string_buffer(256)
+            if R.ref_parser_value(tag.encode(), buf, 256):
+                assert val == buf.value.decode(), (spec, tag)
+            else:
+                assert val == "<null>"
+            assert float(dv) == R.ref_parser_double(tag.encode(), -7.5), (spec, tag)
+            assert int(iv) == R.ref_parser_int(tag.encode(), -7), (spec, tag)
+            assert int(bv) == R.ref_parser_bool(tag.encode(), 0), (spec, tag)
+
+
+def test_float_to_string_matches_the_compiled_reference():
+    """floatToString (base/TypeConversion.h:97-105: a stringstream at precision 6, what Result prints the CMC / Zeggini / covZZ
+    numbers with) compiled from the reference against the adapters' floatToString and against C's "%g" (formatG, what the SKAT /
+    MetaCov rows use): the three agree on every finite value tried, as doubles and through float."""
+    import ctypes as C
+    R = _ref_host()
+    rng = np.random.default_rng(3)
+    xs = [0.0, -0.0, 1.0, -1.0, 0.5, 1e-5, 9.99999e-5, 1e-4, 0.000123456789, 123456.0, 1234567.0, 999999.5, 1e6, 1e15, 1e16, 1e-300,
+          5e-324, 1.7976931348623157e308, 0.1, 2.5e-7, 100.0, 1e5, 99999.95, 0.05, 3.14159265358979, 2.0 / 3.0]
+    xs += list(10.0 ** rng.uniform(-320, 308, 3000) * rng.choice([-1.0, 1.0], 3000))
+    xs += list(rng.normal(size=2000)) + list(np.round(rng.normal(size=500) * 1000, 2))
+    for f32 in (False, True):
+        if f32:
+            vals = [float(np.float32(x)) for x in xs if abs(x) < 3e38]
+            lines = _driver(["--format"], "".join("f:%r\n" % v for v in vals))
+        else:
+            vals = [float(x) for x in xs]
+            lines = _driver(["--format"], "".join("%r\n" % v for v in vals))
+        assert len(lines) == len(vals)
+        buf = C.create_string_buffer(128)
+        for v, line in zip(vals, lines):
+            fts, g = line.split("\t")
+            if f32:
+                R.ref_float_to_string_f32(C.c_float(v), buf, 128)
+            else:
+                R.ref_float_to_string(v, buf, 128)
+            ref = buf.value.decode()
+            assert fts == ref, (v, fts, ref)
+            assert g == "%g" % v == ref, (v, g, ref)               # (the stream at precision 6 prints what %g prints)
