@@ -111,6 +111,7 @@ __device__ __forceinline__ float bgen_stored_prob(const unsigned char* __restric
 }
 
 // pass 1.  seg_count[variant * max_seg + segment] = packed values of the segment's samples
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(kBgenSeg) void bgen_count_kernel(const unsigned char* __restrict__ data,
                                                               const BgenRecord* __restrict__ rec, long long N,
                                                               int max_seg, long long* __restrict__ seg_count,
@@ -135,9 +136,11 @@ static __global__ __launch_bounds__(kBgenSeg) void bgen_count_kernel(const unsig
     seg_count[(long long)blockIdx.y * max_seg + blockIdx.x] = s;
   }
 }
+#endif  // RVT_K_STREAM
 
 // pass 2: exclusive scan over the segments of one variant (in place); a block whose packed area is shorter than its
 // ploidy bytes demand raises *err (host-visible) to variant index + 1
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(256) void bgen_scan_kernel(const BgenRecord* __restrict__ rec, long long N, int max_seg,
                                                         long long* __restrict__ seg_count, int* __restrict__ err) {
   const BgenRecord r = rec[blockIdx.x];
@@ -170,9 +173,11 @@ static __global__ __launch_bounds__(256) void bgen_scan_kernel(const BgenRecord*
     if (carry * r.bits > have) atomicCAS_system(err, 0, (int)blockIdx.x + 1);
   }
 }
+#endif  // RVT_K_STREAM
 
 // pass 3.  out[row_of_sample[i] + variant * ld] = the genotype of file sample i (rows the map never addresses are
 // filled beforehand)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(kBgenSeg) void bgen_decode_kernel(const unsigned char* __restrict__ data,
                                                                const BgenRecord* __restrict__ rec, long long N,
                                                                int max_seg, const long long* __restrict__ seg_count,
@@ -229,5 +234,6 @@ static __global__ __launch_bounds__(kBgenSeg) void bgen_decode_kernel(const unsi
     if (row >= 0) out[(long long)row + (long long)blockIdx.y * ld] = g;
   }
 }
+#endif  // RVT_K_STREAM
 
 }  // namespace rvt

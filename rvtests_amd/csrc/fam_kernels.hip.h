@@ -16,12 +16,15 @@
 
 namespace rvt {
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void cvt_f32_f64_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = (double)in[i];
 }
+#endif  // RVT_K_FAM
 
 // out[k] = sum_i A[i + k*lda], one workgroup per column, fixed reduction order
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void column_sums_kernel(const double* __restrict__ A, long long n, long long lda,
                                                           double* __restrict__ out) {
   __shared__ double red[256];
@@ -36,6 +39,7 @@ static __global__ __launch_bounds__(256) void column_sums_kernel(const double* _
   }
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
+#endif  // RVT_K_FAM
 
 // FastLMM getBetaSigma2 / getLogLikelihood (regression/FastLMM.cpp:297-346) need, for one delta,
 //   A = ux' D ux, b = ux' D uy, yy = uy' D uy (D = 1/|lambda + delta|) and sum log|lambda + delta|.
@@ -44,6 +48,7 @@ static __global__ __launch_bounds__(256) void column_sums_kernel(const double* _
 constexpr int kLmmBlocks = 256;
 __host__ __device__ constexpr int lmm_rec_len(int d) { return d * d + d + 2; }
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __restrict__ uxy, const double* __restrict__ lam,
                                                        long long N, int d, double delta, int take_abs,
                                                        double* __restrict__ partial) {
@@ -87,6 +92,7 @@ static __global__ __launch_bounds__(256) void lmm_sums_kernel(const double* __re
     __syncthreads();
   }
 }
+#endif  // RVT_K_FAM
 
 // ---- genotype consolidation on the device (the "next" row of the boundary: raw / packed genotypes) -------------------
 // Reproduces, for every column of raw genotypes (missing = negative):
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(256) void consolidate_write_kernel(const SRC* __res
 // ---- unrelated null models on the device (LinearRegression.cpp:20-69, LogisticRegression.cpp:279-336) ----------------
 // One IRLS round: p = 1/(1+exp(-X beta)), V = p(1-p) stored; per-workgroup partial record
 //   D = X'VX (d x d), r = X'(y - p) (d), dev = sum y log p + (1-y) log(1-p)      -> lmm_rec_len(d) doubles (last slot unused... dev in slot d*d+d)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void logistic_round_kernel(const double* __restrict__ X, const double* __restrict__ y,
                                                              const double* __restrict__ beta, long long N,
                                                              long long ldx, int d, double* __restrict__ p_out,
@@ -314,8 +321,10 @@ static __global__ __launch_bounds__(256) void logistic_round_kernel(const double
     __syncthreads();
   }
 }
+#endif  // RVT_K_ENGINE
 
 // res = y - X beta (linear) and per-workgroup partial sum of res^2
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void linear_residual_kernel(const double* __restrict__ X, const double* __restrict__ y,
                                                               const double* __restrict__ beta, long long N,
                                                               long long ldx, int d, double* __restrict__ res,
@@ -337,8 +346,10 @@ static __global__ __launch_bounds__(256) void linear_residual_kernel(const doubl
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
+#endif  // RVT_K_ENGINE
 
 // The "null set" the sufficient-statistics kernels read in FamSKAT mode (see the header comment).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void fam_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                       const double* __restrict__ u1, long long N, long long ld, int d, double sigma2,
                                       double delta, const double* __restrict__ beta, double* __restrict__ Xin,
@@ -354,8 +365,10 @@ static __global__ void fam_build_null_kernel(const double* __restrict__ uxy, con
   rr[i] = r / (V * V);
   v[i] = V;
 }
+#endif  // RVT_K_FAM
 
 // null set of the family MetaCov (MetaCovFamQtl): weights D = 1/((|S| + delta) sigma2), columns [U'X | u1]
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void famcov_build_null_kernel(const double* __restrict__ uxy, const double* __restrict__ S,
                                          const double* __restrict__ u1, long long N, long long ld, int d,
                                          double sigma2, double delta, const double* __restrict__ beta,
@@ -374,9 +387,11 @@ static __global__ void famcov_build_null_kernel(const double* __restrict__ uxy, 
   rr[i] = uxy[i + (long long)d * N] - p;                 // uResid = U'y - U'X beta (score statistic)
   v[i] = D;
 }
+#endif  // RVT_K_FAM
 
 // cmcCollapse / zegginiCollapse (src/Model.cpp:73-89,115-130) of flipped, filtered blocks: gene k owns columns
 // [off[k], off[k] + m[k]) of Gp and writes its two collapsed columns to out + (2k) * ld and out + (2k+1) * ld
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void fam_collapse_kernel(const double* __restrict__ Gp, const int* __restrict__ off,
                                     const int* __restrict__ m, long long N, long long ld, double* __restrict__ out) {
   const int k = blockIdx.y;
@@ -389,8 +404,10 @@ static __global__ void fam_collapse_kernel(const double* __restrict__ Gp, const 
     out[i + (long long)(2 * k + 1) * ld] = (double)n;
   }
 }
+#endif  // RVT_K_FAM
 
 // FastLMM::TestCovariate, SCORE branch (FastLMM.cpp:236-247): stat = U^2 / V, p = chisq_Q(stat, 1) when V > 0
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ void fam_burden_finish_kernel(const double* __restrict__ cov, int V, const double* __restrict__ ustat,
                                          double* __restrict__ vstat, double* __restrict__ pval) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,8 +416,10 @@ static __global__ void fam_burden_finish_kernel(const double* __restrict__ cov, 
   vstat[h] = v;
   pval[h] = (v > 0.0) ? chisq_Q(u * u / v, 1.0) : 1.0;
 }
+#endif  // RVT_K_ENGINE
 
 // raw column sum + monomorphic flag of the columns of one block (MetaCov family mode)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void raw_colstat_kernel(const double* __restrict__ G, long long N, long long ld,
                                                           double* __restrict__ colsum, int* __restrict__ poly) {
   __shared__ double rs[256], rmn[256], rmx[256];
@@ -429,8 +448,10 @@ static __global__ __launch_bounds__(256) void raw_colstat_kernel(const double* _
     poly[blockIdx.x] = (rmn[0] != rmx[0]) ? 1 : 0;
   }
 }
+#endif  // RVT_K_FAM
 
 // flip / polymorphic decision per genotype column (DataConsolidator.cpp:46-69,94-116): bit 0 = flip, bit 1 = keep
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* const* __restrict__ cols, long long N,
                                                           int* __restrict__ flags) {
   __shared__ double rs[256], rmn[256], rmx[256];
@@ -460,9 +481,11 @@ static __global__ __launch_bounds__(256) void fam_colstat_kernel(const double* c
   if (threadIdx.x == 0)  // bit 0: flip, bit 1: polymorphic, bit 2: every entry is a hard call (0 / 1 / 2)
     flags[blockIdx.x] = (!(rs[0] <= (double)N) ? 1 : 0) | ((rmn[0] != rmx[0]) ? 2 : 0) | (all_hard ? 4 : 0);
 }
+#endif  // RVT_K_FAM
 
 // kept hard-call columns straight to the int8 plane of the rotation GEMM ([column][ldk] bytes), flipped to 2 - g where
 // flagged: what fam_flip_compact_kernel + the column quantiser produce, in one pass over the genotypes
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void fam_flip_quant_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
                                       long long N, long long ldk, signed char* __restrict__ dst) {
   const double* s = src_cols[blockIdx.y];
@@ -481,8 +504,10 @@ static __global__ void fam_flip_quant_kernel(const double* const* __restrict__ s
     *reinterpret_cast<unsigned long long*>(d + i0) = w;
   }
 }
+#endif  // RVT_K_FAM
 
 // dst column c (of the compact N x T matrix, leading dimension ld) = kept source column, flipped to 2 - g if flagged
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void fam_flip_compact_kernel(const double* const* __restrict__ src_cols, const int* __restrict__ src_flip,
                                         long long N, long long ld, double* __restrict__ dst) {
   const double* s = src_cols[blockIdx.y];
@@ -491,6 +516,7 @@ static __global__ void fam_flip_compact_kernel(const double* const* __restrict__
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
     d[i] = fl ? 2.0 - s[i] : s[i];
 }
+#endif  // RVT_K_FAM
 
 // Stage A of FamSkat::TestCovariate on the rotated statistics (one workgroup per gene).
 //   R = G~' V [G~ | V^-1 U'X | V^-1 u1/|S| | V^-2 r~]  ->  weights, Q, Wm = S - T Cinv T'  (m = M: the block was
@@ -551,6 +577,7 @@ RVT_HD void fam_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, in
   co.sync();
 }
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(1024) void fam_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                            const NullConsts* __restrict__ ncp) {
   __shared__ double red[64];
@@ -562,5 +589,6 @@ static __global__ __launch_bounds__(1024) void fam_assemble_kernel(const GeneDes
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   fam_assemble(co, nc, gd.M, gd.Mp, gd.Cp, gd.parts, gd.n_wparts, ws, gd.stats);
 }
+#endif  // RVT_K_ENGINE
 
 }  // namespace rvt

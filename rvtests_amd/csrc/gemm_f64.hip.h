@@ -188,6 +188,10 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
 #pragma unroll
       for (int a = 0; a < TM; ++a) fa[slot][a] = fa[slot][a] * wv;
     }
+    if (SUB) {  // accumulate -(A'DB): the epilogue then ADDS the accumulators to C, straight out of their registers
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[slot][a] = -fa[slot][a];
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -240,15 +244,22 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_tn_f64_kernel(
     double* cj = C + j * ldc;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      if (SUB) asm volatile("" ::: "memory");  // (keep the loads of C next to their stores: 128 of them at once spill)
+      if (SUB) {
+        // C -= A'DB (one K slice, the grid is the tile list: every entry belongs to ONE thread).  The accumulators hold the
+        // NEGATED product (the A fragments were negated on their way in: rounding is symmetric in sign, the sums are the
+        // same numbers with the other sign), so the update is a fire-and-forget fp64 atomic add whose data operand is the
+        // accumulator register itself.  The load-subtract-store form had to copy all 256 accumulator registers of a lane into
+        // VGPRs for the subtraction and spilled (316 B of scratch at 512 registers).
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long m = m0 + wm * 16 * TM + a * 16 + 4 * r + lg;
-        if (m < M) {
-          if (SUB)
-            cj[m] -= acc[a][b][r];  // (C -= A'DB: one K slice, the grid is the tile list)
-          else
-            cj[m] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r) {
+          const long long m = m0 + wm * 16 * TM + a * 16 + 4 * r + lg;
+          if (m < M) unsafeAtomicAdd(&cj[m], acc[a][b][r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long m = m0 + wm * 16 * TM + a * 16 + 4 * r + lg;
+          if (m < M) cj[m] = acc[a][b][r];
         }
       }
     }

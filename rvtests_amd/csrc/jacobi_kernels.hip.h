@@ -45,6 +45,7 @@ __host__ __device__ inline void jac_rr_pair(int n, int r, int k, int* a, int* b)
 
 // float (column-major, n x n, leading dimension n) -> padded fp64 W (np x np, leading dimension np) with -mu on the
 // pad diagonal; V = identity
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void jac_init_kernel(const float* __restrict__ K, long long n, long long np, double mu, double shift,
                                 double* __restrict__ W, double* __restrict__ V) {
   const long long total = np * np;
@@ -60,11 +61,13 @@ static __global__ void jac_init_kernel(const float* __restrict__ K, long long n,
     V[idx] = (i == j) ? 1.0 : 0.0;
   }
 }
+#endif  // RVT_K_FAM
 
 // ---- Gram matrices of one round ---------------------------------------------------------------------------------------
 // grid (pairs, splits), 256 threads: every wave accumulates the upper 16 x 16 tiles of G over its rows with
 // v_mfma_f64_16x16x4_f64 (the register holding 16 columns x 4 rows is the A operand of a tile row and the B operand of a
 // tile column) and writes its partial to part[pair][split * 4 + wave][64 x 64] (row-major, upper tiles only).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void jac_gram_kernel(const double* __restrict__ W, long long np, int nb, int round,
                                                        int splits, double* __restrict__ part) {
   int bi, bj;
@@ -115,11 +118,13 @@ static __global__ __launch_bounds__(256) void jac_gram_kernel(const double* __re
       ++q;
     }
 }
+#endif  // RVT_K_FAM
 
 // ---- the 64 x 64 eigenproblem of every pair --------------------------------------------------------------------------
 // grid (pairs), 256 threads.  Sums the partial Gram matrices, records the largest cross-block cosine (before rotating)
 // into *maxcos (bits of a non-negative double, atomicMax), diagonalises G by cyclic Jacobi with the round-robin ordering
 // (32 disjoint rotations per step) and writes R (row-major 64 x 64, columns ordered by decreasing eigenvalue).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double* __restrict__ part, int nparts, double tol,
                                                             double* __restrict__ Rout,
                                                             unsigned long long* __restrict__ maxcos, int sort_mode,
@@ -241,11 +246,13 @@ static __global__ __launch_bounds__(256) void jac_small_eig_kernel(const double*
     out[e] = R[i][order[j]];
   }
 }
+#endif  // RVT_K_FAM
 
 // ---- [X_I X_J] <- [X_I X_J] R for X = W and X = V ----------------------------------------------------------------------
 // grid (pairs, slabs, 2), 256 threads; blockIdx.z selects W or V.  Transposed formulation C' = R' X': the A operand is R'
 // (held in registers for the lifetime of the wave), the B operand a 16-row slab of X (16 consecutive rows of one
 // column per 16 lanes: whole 128-byte lines), and the result tile stores 16 consecutive rows per column.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void jac_apply_kernel(double* __restrict__ W, double* __restrict__ V, long long np,
                                                         int nb, int round, const double* __restrict__ Rall) {
   int bi, bj;
@@ -285,8 +292,10 @@ static __global__ __launch_bounds__(256) void jac_apply_kernel(double* __restric
     }
   }
 }
+#endif  // RVT_K_FAM
 
 // lambda_j = v_j' w_j and the residual ||w_j - lambda_j v_j||; one workgroup per column
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void jac_lambda_kernel(const double* __restrict__ W, const double* __restrict__ V,
                                                          long long np, double* __restrict__ lambda,
                                                          double* __restrict__ resid) {
@@ -319,8 +328,10 @@ static __global__ __launch_bounds__(256) void jac_lambda_kernel(const double* __
     resid[blockIdx.x] = sqrt(red[0]);
   }
 }
+#endif  // RVT_K_FAM
 
 // U (float, n x n, column-major, leading dimension n): column j = column src[j] of V (first n rows), normalised
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void jac_gather_kernel(const double* __restrict__ V, long long np, long long n,
                                                          const int* __restrict__ src, float* __restrict__ U) {
   __shared__ double red[256];
@@ -337,10 +348,12 @@ static __global__ __launch_bounds__(256) void jac_gather_kernel(const double* __
   float* u = U + (long long)blockIdx.x * n;
   for (long long i = threadIdx.x; i < n; i += 256) u[i] = (float)(v[i] * inv);
 }
+#endif  // RVT_K_FAM
 
 // Family-wise decomposition (rvt_kinship_decompose on a kinship of separate families): column k of U (float, n x n,
 // column-major, pre-cleared) gets the `len[k]` entries of eigenvector column `col[k]` of tile `tile[k]` (R: [tile][64 x 64]
 // row-major) at the sample rows of that tile (rows: [tile][64]); one thread per column.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void jac_scatter_blocks_kernel(const double* __restrict__ R, const int* __restrict__ tile,
                                           const int* __restrict__ col, const int* __restrict__ len,
                                           const int* __restrict__ rows, long long n, float* __restrict__ U) {
@@ -351,5 +364,6 @@ static __global__ void jac_scatter_blocks_kernel(const double* __restrict__ R, c
   float* u = U + k * n;
   for (int i = 0; i < len[k]; ++i) u[rw[i]] = (float)r[(long long)i * kJacP];
 }
+#endif  // RVT_K_FAM
 
 }  // namespace rvt

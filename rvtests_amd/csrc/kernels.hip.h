@@ -23,6 +23,7 @@ namespace rvt {
 //   flip:  column sum > N       convertToMinorAlleleCount   src/DataConsolidator.cpp:46-69
 //   poly:  min != max           isMonomorphicMarker          src/DataConsolidator.cpp:94-116
 // =====================================================================================================
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* __restrict__ genes, long long N) {
   const GeneDesc gd = genes[blockIdx.x];
   // (a hard-call gene: only when it was handed back and gene_suffstat_mfma has computed it — three-row statistics)
@@ -51,6 +52,7 @@ static __global__ __launch_bounds__(64) void gene_flags_kernel(const GeneDesc* _
     }
   }
 }
+#endif  // RVT_K_ENGINE
 
 // =====================================================================================================
 // K1b: collapsed burden genotypes and their score-test partial sums.
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) void burden_collapse_kernel(const GeneDesc* __
 // =====================================================================================================
 // lists: [0] number of handed-back genes, [1] number of genes whose burden sums are redone, [4 ..) / [4 + n_genes ..) their
 // indices (the work lists of the conditional general-kernel launch and of burden_fallback_kernel; zeroed by the host).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc* __restrict__ genes, long long N,
                                                            int* __restrict__ lists, int n_genes) {
   const GeneDesc gd = genes[blockIdx.x];
@@ -259,6 +262,7 @@ static __global__ __launch_bounds__(64) void gene_flags_hc_kernel(const GeneDesc
     if (any || anyr) lists[4 + n_genes + atomicAdd(&lists[1], 1)] = blockIdx.x;
   }
 }
+#endif  // RVT_K_ENGINE
 
 // Burden partial sums of a hard-call gene straight from its genotype block with the ACTUAL flags (rare: see above).
 // The genes come from the device work list gene_flags_hc_kernel wrote (lists[1] entries at lists[4 + n_genes ..)); a
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(256) void burden_fallback_kernel(const GeneDesc* __
 // profiles/r5_pvprof.txt), eight times as many workgroups keep eight times as many loads in flight.  Every entry is still
 // the sum over p = 0 .. P - 1 in that order: bit-identical to the loop it replaces (rvt_gene.h gene_assemble step 1).
 constexpr int kReducePiece = 1024;
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void gene_reduce_parts_kernel(const GeneDesc* __restrict__ genes) {
   const GeneDesc gd = genes[blockIdx.y];
   const int Mp = gd.Mp, Cp = gd.Cp, total = Mp * Cp;
@@ -396,7 +401,9 @@ static __global__ __launch_bounds__(256) void gene_reduce_parts_kernel(const Gen
     ws.R[i] = sv;
   }
 }
+#endif  // RVT_K_ENGINE
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, rvt_params prm,
                                                             unsigned tests, int n_bparts, const double* xscale,
@@ -417,7 +424,9 @@ static __global__ __launch_bounds__(1024) void gene_assemble_kernel(const GeneDe
                 gd.af, prm, tests, ws,
                 gd.stats, gd.dbg_flip, gd.dbg_kept, masks ? &hcm : nullptr, handed_back ? kStatusHandedBack : 0u, parts_reduced != 0);
 }
+#endif  // RVT_K_ENGINE
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc* __restrict__ genes,
                                                            const NullConsts* __restrict__ ncp, unsigned tests,
                                                            int lds_doubles) {
@@ -432,7 +441,9 @@ static __global__ __launch_bounds__(256) void gene_tridiag_kernel(const GeneDesc
   double* Bm = (4 * gd.Mp + m * m <= lds_doubles) ? esm + 4 * gd.Mp : ws.eig + (size_t)which * gd.Mp * gd.Mp;
   gene_tridiag(co, *ncp, which, gd.M, gd.Mp, tests, ws, Bm, vec, gd.stats);
 }
+#endif  // RVT_K_ENGINE
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDesc* __restrict__ genes,
                                                             const NullConsts* __restrict__ ncp, unsigned tests) {
   extern __shared__ __attribute__((aligned(16))) double esm[];  // 4 * Mp doubles
@@ -442,8 +453,10 @@ static __global__ __launch_bounds__(128) void gene_spectrum_kernel(const GeneDes
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   gene_spectrum(co, *ncp, blockIdx.x, gd.M, gd.Mp, tests, ws, esm, gd.stats, gd.lambda);
 }
+#endif  // RVT_K_ENGINE
 // round 5: ONE workgroup per gene walks the (problem, eigenvalue) tasks of all 13 problems (rvt_gene.h gene_spectrum_all);
 // dynamic LDS: 39 * Mp + 64 doubles
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(128) void gene_spectrum_all_kernel(const GeneDesc* __restrict__ genes,
                                                                 const NullConsts* __restrict__ ncp, unsigned tests) {
   extern __shared__ __attribute__((aligned(16))) double esm[];
@@ -454,6 +467,7 @@ static __global__ __launch_bounds__(128) void gene_spectrum_all_kernel(const Gen
   GeneScratch ws = gene_scratch_carve(gd.scratch, gd.Mp, gd.Cp);
   gene_spectrum_all(co, *ncp, gd.M, gd.Mp, tests, ws, esm, meta, gd.stats, gd.lambda);
 }
+#endif  // RVT_K_ENGINE
 
 // =====================================================================================================
 // MetaCov (src/Model.cpp:844-1004): the score covariances of a block of V consecutive variants are a by-product
@@ -481,6 +495,7 @@ struct CovConsts {
 };
 
 // one workgroup: column sums, polymorphic flags, T = G'DX, covXZ   (xz: V x d row-major; colsum: V)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
                                                           double* __restrict__ xz, double* __restrict__ colsum,
                                                           int* __restrict__ poly, double* __restrict__ ustat,
@@ -522,8 +537,10 @@ static __global__ __launch_bounds__(256) void cov_prepare_kernel(const GeneDesc*
     }
   }
 }
+#endif  // RVT_K_ENGINE
 
 // grid = V workgroups (one per head h): value(h, j) for j >= h into cov[h + j*V]
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __restrict__ genes, CovConsts cc,
                                                        const double* __restrict__ xz,
                                                        const double* __restrict__ colsum, double* __restrict__ cov) {
@@ -562,6 +579,7 @@ static __global__ __launch_bounds__(256) void cov_rows_kernel(const GeneDesc* __
     cov[h + (long long)j * V] = xx - quad;
   }
 }
+#endif  // RVT_K_ENGINE
 
 // ---- AnalyticVT (src/Model.h:2105-2259, UNRELATED, quantitative trait) from the assembled statistics ---------------------------
 // The reference residualises genotypes and phenotype on the covariates and forms u = x'y, v = x'x sigma2
@@ -898,6 +916,7 @@ __device__ __forceinline__ void vt_sections(double* vt_mem, int Mp, double** alp
 // shift — stage 0: points [0, kVtStage0); stage 1 (genes whose first estimate was not accurate enough): the points up to
 // kMvnPoints.  One thread = one lattice point at a time; the factor sits in LDS when it fits, the per-thread vectors of
 // conditioned values in the workspace ([dimension][thread]: coalesced).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc* __restrict__ genes, int stage) {
   const GeneDesc gd = genes[blockIdx.x];
   double* vt_mem = gd.vt_mem;
@@ -929,9 +948,11 @@ static __global__ __launch_bounds__(256) void vt_integrate_kernel(const GeneDesc
   }
   if (tid == 0) vt_mem[16 + j] += sRed[0];
 }
+#endif  // RVT_K_ENGINE
 
 // one thread per gene: estimate and error from the shift sums; after stage 0 genes that are not accurate enough ask for
 // stage 1
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int n, int stage) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -955,8 +976,10 @@ static __global__ void vt_finish_kernel(const GeneDesc* __restrict__ genes, int 
   out->vt_ok = 1;
   if (stage == 0) vt_mem[3] = err < 2.5e-4 ? 0.0 : 1.0;  // (the reference asks its rule for 1e-3)
 }
+#endif  // RVT_K_ENGINE
 
 // the unrelated-sample test: u and Wm are where gene_assemble left them (one workgroup per gene)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __restrict__ genes,
                                                       const NullConsts* __restrict__ ncp) {
   const GeneDesc gd = genes[blockIdx.x];
@@ -969,12 +992,15 @@ static __global__ __launch_bounds__(256) void gene_vt_kernel(const GeneDesc* __r
   __syncthreads();
   vt_core(m, gd.Mp, gd.af, uvec, ws.Wm, ncp->sigma2, ncp->binary != 0, gd.vt_mem, gd.result);
 }
+#endif  // RVT_K_ENGINE
 
 // the related-sample test (FamAnalyticVT): frequency, score and variance matrix prepared by the host from the family
 // covariance machinery; buf = af[m] | u[m] | V[m x m] | workspace
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, double* __restrict__ buf, rvt_gene_result* out) {
   vt_core(m, Mp, buf, buf + m, buf + 2 * (size_t)m, 1.0, false, buf + 2 * (size_t)m + (size_t)m * m, out);
 }
+#endif  // RVT_K_FAM
 
 // ---- MetaScoreTest, unrelated samples: single-variant score statistics of one block from the same partials ----
 //   quantitative (MetaUnrelatedQtl, src/Model.h:3516-3549 over LinearRegressionScoreTest.cpp:173-263):
@@ -987,6 +1013,7 @@ static __global__ __launch_bounds__(256) void vt_direct_kernel(int m, int Mp, do
 // The block is submitted as one "gene" per slice of <= 16 columns (only the diagonal tile and the [X | rr] tile are
 // needed, so each slice streams once at the narrow-class rate); gene_id carries the slice's first column.
 // out: ustat | vstat | effect | se | pval (vt entries each); ok[h] = 1 when the site is polymorphic and SS > 0.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_ENGINE)
 static __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc* __restrict__ genes,
                                                           const NullConsts* __restrict__ ncp, int vt,
                                                           double* __restrict__ out, int* __restrict__ ok) {
@@ -1059,11 +1086,13 @@ static __global__ __launch_bounds__(64) void score_finish_kernel(const GeneDesc*
   out[4LL * vt + col] = pv;
   ok[col] = fit;
 }
+#endif  // RVT_K_ENGINE
 
 // ---- MetaCov for windows wider than one block: heads x window rectangle from two plain GEMMs ------------------
 // S = G_H' D G_W (H x W, column-major) and T = G_W' D X (W x d, column-major) come from the integer-plane products of
 // rot_gemm.hip.h (gemm_tn_planes; exact for hard calls and an unweighted model); cs = raw column sums
 // of the W window columns (the H heads are its first H columns).  Unrelated samples only.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
                                    double* __restrict__ xz) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1073,8 +1102,10 @@ static __global__ void cov_rect_xz_kernel(CovConsts cc, const double* __restrict
     xz[(long long)j * cc.d + k] = cc.binary ? t : (t - cs[j] * cc.inv_n * cc.zsum[k]) * cc.inv_sigma2;
   }
 }
+#endif  // RVT_K_META
 
 // grid = H workgroups: cov[h + j*H] for j >= h
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc, const double* __restrict__ S,
                                                             const double* __restrict__ cs,
                                                             const double* __restrict__ xz, int H, int W,
@@ -1096,9 +1127,11 @@ static __global__ __launch_bounds__(256) void cov_rect_rows_kernel(CovConsts cc,
     cov[h + (long long)j * H] = xx - quad;
   }
 }
+#endif  // RVT_K_META
 
 // family mode of the two rectangle kernels (MetaCovFamQtl on rotated data, regression/FastLMM.cpp:510-595): T holds
 // G~_W' D [U'X | u1] (W x (d + 1), column-major), cs the RAW column sums; see CovConsts for the centring algebra
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __restrict__ T, const double* __restrict__ cs, int W,
                                        double* __restrict__ xz, double* __restrict__ t1) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1107,6 +1140,8 @@ static __global__ void cov_rect_fam_xz_kernel(CovConsts cc, const double* __rest
   for (int k = 0; k < cc.d; ++k) xz[(long long)j * cc.d + k] = T[j + (long long)k * W] - m * cc.zsum[k];
   t1[j] = T[j + (long long)cc.d * W];
 }
+#endif  // RVT_K_META
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts cc, const double* __restrict__ S,
                                                                 const double* __restrict__ cs,
                                                                 const double* __restrict__ xz,
@@ -1129,6 +1164,7 @@ static __global__ __launch_bounds__(256) void cov_rect_fam_rows_kernel(CovConsts
     cov[h + (long long)j * H] = xx - quad;
   }
 }
+#endif  // RVT_K_META
 
 // MetaCov fast path for hard-call blocks: ONE pass over the window's columns produces everything the band needs
 // besides G'G — raw column sums and polymorphic flags (as raw_colstat_kernel), T = G'X (W x d, column-major) and the int8
@@ -1275,6 +1311,7 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 }
 
 // one thread per (column, field): colsum, poly, T (W x d column-major)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices, int W, int d, int dmax,
                                      double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1298,8 +1335,10 @@ static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int
   else
     T[j + (long long)(f - 3) * W] = r;
 }
+#endif  // RVT_K_META
 
 // the column statistics a block keeps per column (rvt_ctx::ColKind) -> the work arrays of a covariance call: W columns from col0
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ void cov_cache_gather_kernel(const double* __restrict__ cs_c, const int* __restrict__ poly_c,
                                         const double* __restrict__ T_c, int W, int d, int t_stride, double* __restrict__ colsum,
                                         int* __restrict__ poly, double* __restrict__ T) {
@@ -1309,8 +1348,10 @@ static __global__ void cov_cache_gather_kernel(const double* __restrict__ cs_c, 
   poly[j] = poly_c[j];
   for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[(long long)j * t_stride + k];
 }
+#endif  // RVT_K_META
 
 // dst[i + k*ld] = src[i + k*ld] * v[i]  (binary trait: one GEMM operand carries the weights)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
 static __global__ void scale_rows_kernel(const double* __restrict__ src, const double* __restrict__ v, long long N,
                                   long long ld, double* __restrict__ dst) {
   const double* s = src + (long long)blockIdx.y * ld;
@@ -1318,6 +1359,7 @@ static __global__ void scale_rows_kernel(const double* __restrict__ src, const d
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
     d[i] = s[i] * v[i];
 }
+#endif  // RVT_K_META
 
 // =====================================================================================================
 // K4: p-values, one wave per gene.

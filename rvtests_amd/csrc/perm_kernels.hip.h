@@ -20,14 +20,17 @@
 namespace rvt {
 
 // idx[k * B + p] = k : permutation-minor layout, so that the sequential side of the swaps is coalesced
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_init_kernel(uint32_t* __restrict__ idx, long long N, int B) {
   const long long n = N * (long long)B;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     idx[i] = (uint32_t)(i / B);
 }
+#endif  // RVT_K_PERM
 
 // One thread = one permutation.  states: B x 31 words, the generator state at the start of each shuffle, ordered
 // oldest word first (x[t] = o[k-31+t]); a draw is x[t] += x[(t+28) % 31] with t cycling 0..30.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ __launch_bounds__(64) void perm_fisher_yates_kernel(const uint32_t* __restrict__ states,
                                                                uint32_t* __restrict__ idx, long long N, int B) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,9 +59,11 @@ static __global__ __launch_bounds__(64) void perm_fisher_yates_kernel(const uint
     }
   }
 }
+#endif  // RVT_K_PERM
 
 // std::random_shuffle as libstdc++ implements it (the KBAC permutations, regression/kbac.cpp:323): i = 1 .. N-1,
 // j = rand() % (i + 1), swap(i, j).  Same state layout and draw as perm_fisher_yates_kernel, forward order.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ __launch_bounds__(64) void perm_random_shuffle_kernel(const uint32_t* __restrict__ states,
                                                                  uint32_t* __restrict__ idx, long long N, int B) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,25 +92,31 @@ static __global__ __launch_bounds__(64) void perm_random_shuffle_kernel(const ui
     }
   }
 }
+#endif  // RVT_K_PERM
 
 // next[k] = cur[idx[k][p]] for a vector of bytes (the 0 / 1 phenotype of the KBAC permutations)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_apply_u8_kernel(const uint32_t* __restrict__ idx, const unsigned char* __restrict__ cur,
                                      unsigned char* __restrict__ next, long long N, int B, int p) {
   const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (k >= N) return;
   next[k] = cur[idx[k * B + p]];
 }
+#endif  // RVT_K_PERM
 
 // out[c] = vec[carrier[c]]
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_gather_u8_kernel(const unsigned char* __restrict__ vec, const int* __restrict__ carrier, int n,
                                       unsigned char* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < n) out[c] = vec[carrier[c]];
 }
+#endif  // RVT_K_PERM
 
 // KBAC genotype-pattern id of every sample (regression/kbac.cpp:120-147), exactly as the reference's double arithmetic
 // runs: columns in order, invalid codings (anything but 0 / 1 / 2: imputed means) count as wild type, p3[k] = the host's
 // pow(3.0, k).  G: flipped / polymorphic block (column-major, ld), cols: the n_used columns that survive the frequency trim.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void kbac_pattern_kernel(const double* __restrict__ G, long long N, long long ld, const int* __restrict__ cols,
                                     int n_used, const double* __restrict__ p3, double* __restrict__ id) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -129,9 +140,11 @@ static __global__ void kbac_pattern_kernel(const double* __restrict__ G, long lo
   }
   id[i] = __dadd_rn(L, __dmul_rn(R, 1e-10));
 }
+#endif  // RVT_K_PERM
 
 // cumulative application of shuffle p to the current residual vector: next[k] = cur[idx[k][p]];
 // also column p of the chunk matrix Rp (N x B column-major: Rp[k + p*N])
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_apply_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ cur,
                                   double* __restrict__ next, double* __restrict__ Rp, long long N, int B, int p) {
   const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -140,11 +153,13 @@ static __global__ void perm_apply_kernel(const uint32_t* __restrict__ idx, const
   next[k] = v;
   Rp[k + (long long)p * N] = v;
 }
+#endif  // RVT_K_PERM
 
 // Small sample counts: C[p + j*B] = sum_i G[i + j*ld] Rp[i + p*N] summed in sample order i = 0 .. N-1, exactly as the
 // reference's (and the oracle's) dot product runs.  With a handful of samples — the reference's own example has 9 —
 // many shuffles reproduce the observed Q mathematically, and whether such a tie counts as "greater" is decided by the
 // last bit; only the same summation order resolves it the same way.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_dot_sequential_kernel(const double* __restrict__ Rp, const double* __restrict__ G, long long N,
                                            long long ld, int nb, int m, int B, double* __restrict__ C) {
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -156,8 +171,10 @@ static __global__ void perm_dot_sequential_kernel(const double* __restrict__ Rp,
   for (long long i = 0; i < N; ++i) s += g[i] * r[i];
   C[p + (long long)j * B] = s;
 }
+#endif  // RVT_K_PERM
 
 // Q_p = sum_j w_j (g_j . r_p)^2 from C = Rp * G' (B x m, column-major, ldc = B); bw[j] = sqrt(w_j)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_q_kernel(const double* __restrict__ C, const double* __restrict__ bw, int B, int m,
                               double* __restrict__ Q) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,6 +186,7 @@ static __global__ void perm_q_kernel(const double* __restrict__ C, const double*
   }
   Q[p] = s;
 }
+#endif  // RVT_K_PERM
 
 // =====================================================================================================================
 // Counter-based mode (perm_counter.h): C = R_pi' G for a chunk of shuffles without ever storing a permutation or a
@@ -183,6 +201,7 @@ static __global__ void perm_q_kernel(const double* __restrict__ C, const double*
 // =====================================================================================================================
 typedef double pc_d4_t __attribute__((ext_vector_type(4)));
 
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ __launch_bounds__(64, 2) void perm_counter_partial_kernel(
     const double* __restrict__ G, long long ld, long long N, int m, const double* __restrict__ res,
     unsigned long long seed, unsigned long long gene, unsigned shuffle0, int n_shuffles, int groups_per_slice,
@@ -252,8 +271,10 @@ static __global__ __launch_bounds__(64, 2) void perm_counter_partial_kernel(
       }
   }
 }
+#endif  // RVT_K_PERM
 
 // Q[s] = sum_j bw_j^2 (sum_slices part[slice][s][j])^2, slices in order
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_PERM)
 static __global__ void perm_counter_q_kernel(const double* __restrict__ part, int n_slices, int n_shuffles, int Mp, int m,
                                       const double* __restrict__ bw, double* __restrict__ Q) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,5 +288,6 @@ static __global__ void perm_counter_q_kernel(const double* __restrict__ part, in
   }
   Q[s] = q;
 }
+#endif  // RVT_K_PERM
 
 }  // namespace rvt

@@ -334,6 +334,7 @@ constexpr int kRotThreads = RVT_ROT_THREADS;
 
 // C[m + j ldc] = (accumulate ? C : 0) + sum over slices of part[s * stride + m + j ldc], m < M, j < N (fixed order:
 // reproducible; rows M .. ldc-1 of C are not touched)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_reduce_slices_kernel(const double* __restrict__ part, long long ldc, long long M, long long N,
                                          long long stride, int slices, double* __restrict__ C, int accumulate) {
   const long long total = M * N;
@@ -344,6 +345,7 @@ static __global__ void rot_reduce_slices_kernel(const double* __restrict__ part,
     C[i] = s;
   }
 }
+#endif  // RVT_K_FAM
 
 // ---- digits ------------------------------------------------------------------------------------------------------------
 // q = sum_p d_p 128^p, d_p in [-64, 63]
@@ -357,6 +359,7 @@ __device__ __forceinline__ void rot_digits(long long q, int planes, signed char*
 
 // float matrix (column-major, n x ncols, leading dimension lds_src) -> digit planes [plane][col][ldk]; entries scaled
 // by 2^sexp.  flag[0] is set when an entry does not fit (|u| * 2^sexp >= 2^(7 planes - 2)).
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_quantize_f32_kernel(const float* __restrict__ src, long long n, long long ncols, long long ld_src,
                                         int sexp, int planes, signed char* __restrict__ dst, long long ldk,
                                         long long plane_stride, long long col0, int* __restrict__ flag) {
@@ -374,8 +377,10 @@ static __global__ void rot_quantize_f32_kernel(const float* __restrict__ src, lo
     for (int p = 0; p < planes; ++p) dst[p * plane_stride + (col0 + j) * ldk + i] = d[p];
   }
 }
+#endif  // RVT_K_FAM
 
 // first / last row with a non-zero entry per column of a float matrix (lo = n, hi = -1 for an all-zero column)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_span_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ lo,
                                 int* __restrict__ hi) {
   __shared__ int slo[256], shi[256];
@@ -401,17 +406,21 @@ static __global__ void rot_span_kernel(const float* __restrict__ src, long long 
     hi[blockIdx.x] = shi[0];
   }
 }
+#endif  // RVT_K_FAM
 
 // dst row r = src row order[r] of a [rows][ldk] byte matrix (ldk a multiple of 16); grid = rows
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_gather_rows_kernel(const signed char* __restrict__ src, const int* __restrict__ order, long long ldk,
                                        signed char* __restrict__ dst) {
   const uint4* s = reinterpret_cast<const uint4*>(src + (long long)order[blockIdx.x] * ldk);
   uint4* d = reinterpret_cast<uint4*>(dst + (long long)blockIdx.x * ldk);
   for (long long i = threadIdx.x; i < ldk / 16; i += blockDim.x) d[i] = s[i];
 }
+#endif  // RVT_K_FAM
 
 // ---- sparse eigenvectors (families interleaved in the sample order) --------------------------------------------------------
 // non-zeros per column of a float matrix; grid = columns
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_nnz_count_kernel(const float* __restrict__ src, long long n, long long ld_src, int* __restrict__ count) {
   __shared__ int red[256];
   const float* s = src + (long long)blockIdx.x * ld_src;
@@ -425,7 +434,9 @@ static __global__ void rot_nnz_count_kernel(const float* __restrict__ src, long 
   }
   if (threadIdx.x == 0) count[blockIdx.x] = red[0];
 }
+#endif  // RVT_K_FAM
 // the non-zeros of column blockIdx.x, in ascending row order, to rows / vals at offset colptr[blockIdx.x]; 256 threads
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* __restrict__ src, long long n, long long ld_src,
                                                            const long long* __restrict__ colptr, int* __restrict__ rows,
                                                            double* __restrict__ vals) {
@@ -453,8 +464,10 @@ static __global__ __launch_bounds__(256) void rot_nnz_fill_kernel(const float* _
     __syncthreads();
   }
 }
+#endif  // RVT_K_FAM
 // out[k + t ld_dst] = sum over the non-zeros e of column k of U: vals[e] * G[rows[e] + t ld_src]   (U' G for sparse U);
 // grid (ceil(n / 256), columns of G)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ __launch_bounds__(256) void rot_sparse_kernel(const long long* __restrict__ colptr, const int* __restrict__ rows,
                                                          const double* __restrict__ vals, long long n,
                                                          const double* __restrict__ G, long long ld_src,
@@ -466,8 +479,10 @@ static __global__ __launch_bounds__(256) void rot_sparse_kernel(const long long*
   for (long long e = colptr[k]; e < colptr[k + 1]; ++e) s = fma(vals[e], g[rows[e]], s);
   out[k + (long long)blockIdx.y * ld_dst] = s;
 }
+#endif  // RVT_K_FAM
 
 // per-column max |x| of a double matrix (column-major, ld)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_colmax_kernel(const double* __restrict__ src, long long n, long long ld, double* __restrict__ out) {
   __shared__ double red[256];
   const double* s = src + (long long)blockIdx.x * ld;
@@ -491,9 +506,11 @@ static __global__ void rot_colmax_kernel(const double* __restrict__ src, long lo
   }
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];  // >= 0: integer column with this max; < 0: -(max) - 1, not integer
 }
+#endif  // RVT_K_FAM
 
 // double columns -> digit planes.  planes == 1: the entries are integers in [-128, 127], stored as they are (sexp[j]
 // must be 0); else entries scaled by 2^sexp[j].
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_FAM)
 static __global__ void rot_quantize_f64_kernel(const double* __restrict__ src, long long n, long long ncols, long long ld_src,
                                         const int* __restrict__ sexp, int planes, signed char* __restrict__ dst,
                                         long long ldk, long long plane_stride) {
@@ -510,5 +527,6 @@ static __global__ void rot_quantize_f64_kernel(const double* __restrict__ src, l
     }
   }
 }
+#endif  // RVT_K_FAM
 
 }  // namespace rvt

@@ -1,6 +1,9 @@
 // rvtests_amd — the engine behind include/rvtests_amd.h: device memory, the per-batch kernel pipeline
 // and the C ABI.  Built by hipcc for gfx950 into librvtests_amd.so.  There is no CPU fallback: without a
 // HIP device rvt_init() fails with RVT_E_NO_DEVICE.
+// this unit compiles (and ships) the ENGINE kernel family only: see "kernel families" in rvt_engine_int.h
+#define RVT_K_SPLIT
+#define RVT_K_ENGINE
 #include "rvt_engine_int.h"
 #include <chrono>
 #include <functional>
@@ -1862,8 +1865,7 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
   double sigma2 = 1.0;
   if (!binary) {
     // X'X, X'y with the weighted-sums kernel at unit weights (lambda = 0, delta = 1)
-    hipLaunchKernelGGL(lmm_sums_kernel, dim3(kLmmBlocks), dim3(256), sizeof(double) * 256, st, d_xy, d_zero,
-                       (long long)N, d, 1.0, 0, d_part);
+    k_lmm_sums(dim3(kLmmBlocks), st, d_xy, d_zero, (long long)N, d, 1.0, 0, d_part);
     HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, sync_stream(st));
     reduce(rec);
@@ -1929,3 +1931,11 @@ int rvt_fit_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
 }
 
 }  // extern "C"
+
+// ---- launchers of this unit's kernels for the other units (rvt_engine_int.h, "kernel families") -----------------------------
+void k_vt_integrate(dim3 grid, hipStream_t st, const GeneDesc* genes, int stage) {
+  hipLaunchKernelGGL(vt_integrate_kernel, grid, dim3(256), 0, st, genes, stage);
+}
+void k_vt_finish(dim3 grid, hipStream_t st, const GeneDesc* genes, int n, int stage) {
+  hipLaunchKernelGGL(vt_finish_kernel, grid, dim3(256), 0, st, genes, n, stage);
+}

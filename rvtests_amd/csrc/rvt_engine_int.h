@@ -620,6 +620,23 @@ void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* st
 
 // ---- defined in rvt_engine.hip, called from the other translation units (hidden: not part of the ABI) ------------------------
 #define RVT_INTERNAL __attribute__((visibility("hidden")))
+// ---- kernel families -----------------------------------------------------------------------------------------------------
+// Every non-template kernel of the engine is `static` in a header that all five rvt_*.hip units see through this file; until
+// round 6 each unit therefore compiled and shipped its own copy of all of them (76 kernels x 5 code objects).  Now a unit
+// defines RVT_K_SPLIT and ONE of RVT_K_ENGINE / RVT_K_STREAM / RVT_K_FAM / RVT_K_PERM / RVT_K_META before including this
+// header and gets the bodies of that family alone (tools and the host harness define nothing and get everything).  The few
+// kernels that two units launch live in one of them; the other goes through these host launchers (tools/kernel_units.sh
+// lists which object carries which kernel).
+RVT_INTERNAL void k_lmm_sums(dim3 grid, hipStream_t st, const double* uxy, const double* lam, long long N, int d, double delta,
+                             int take_abs, double* partial);                                                   // rvt_fam.hip
+RVT_INTERNAL void k_fam_colstat(dim3 grid, hipStream_t st, const double* const* cols, long long N, int* flags);  // rvt_fam.hip
+RVT_INTERNAL void k_fam_flip_compact(dim3 grid, hipStream_t st, const double* const* src_cols, const int* src_flip, long long N,
+                                     long long ld, double* dst);                                               // rvt_fam.hip
+RVT_INTERNAL void k_raw_colstat(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, double* colsum, int* poly);  // rvt_fam.hip
+RVT_INTERNAL void k_rot_reduce_slices(hipStream_t st, const double* part, long long ldc, long long M, long long N, long long stride,
+                                      int slices, double* C, int accumulate);                                  // rvt_fam.hip
+RVT_INTERNAL void k_vt_integrate(dim3 grid, hipStream_t st, const GeneDesc* genes, int stage);                  // rvt_engine.hip
+RVT_INTERNAL void k_vt_finish(dim3 grid, hipStream_t st, const GeneDesc* genes, int n, int stage);              // rvt_engine.hip
 extern "C" {
 RVT_INTERNAL int stage_ready(rvt_ctx* c);
 RVT_INTERNAL bool host_registered(const rvt_ctx* c, const void* src, size_t bytes);

@@ -1,6 +1,9 @@
 // rvtests_amd — related samples: the kinship (installation, family structure, KinshipHolder::decompose on the device), the
 // exact integer rotation G~ = U'G (rot_gemm.hip.h), the FastLMM null model, FamSKAT / the family burden tests / the family
 // forms of MetaCov and MetaScore.  Part of librvtests_amd.so; the per-gene pipeline behind it is rvt_engine.hip's.
+// this unit compiles (and ships) the FAM kernel family only: see "kernel families" in rvt_engine_int.h
+#define RVT_K_SPLIT
+#define RVT_K_FAM
 #include "rvt_engine_int.h"
 #include "tridiag_kernels.hip.h"
 
@@ -1486,8 +1489,8 @@ int rvt_fam_analytic_vt(rvt_ctx* c, int n, const double* const* dG, const int* M
       HIP_TRY(c, hipMalloc((void**)&d_gdv, sizeof(GeneDesc)));
       hipError_t e = hipMemcpyAsync(d_gdv, &gdv, sizeof(gdv), hipMemcpyHostToDevice, st);
       for (int stage = 0; stage < 2 && e == hipSuccess; ++stage) {
-        hipLaunchKernelGGL(vt_integrate_kernel, dim3(1, kMvnShifts), dim3(256), 0, st, d_gdv, stage);
-        hipLaunchKernelGGL(vt_finish_kernel, dim3(1), dim3(256), 0, st, d_gdv, 1, stage);
+        k_vt_integrate(dim3(1, kMvnShifts), st, d_gdv, stage);
+        k_vt_finish(dim3(1), st, d_gdv, 1, stage);
       }
       if (e == hipSuccess) e = sync_stream(st);
       hipFree(d_gdv);
@@ -1835,3 +1838,23 @@ int rvt_run_fam_tests(rvt_ctx* c, int n, const double* const* dG, const int* Ms,
 }
 
 }  // extern "C"
+
+// ---- launchers of this unit's kernels for the other units (rvt_engine_int.h, "kernel families") -----------------------------
+void k_lmm_sums(dim3 grid, hipStream_t st, const double* uxy, const double* lam, long long N, int d, double delta, int take_abs,
+                double* partial) {
+  hipLaunchKernelGGL(lmm_sums_kernel, grid, dim3(256), sizeof(double) * 256, st, uxy, lam, N, d, delta, take_abs, partial);
+}
+void k_fam_colstat(dim3 grid, hipStream_t st, const double* const* cols, long long N, int* flags) {
+  hipLaunchKernelGGL(fam_colstat_kernel, grid, dim3(256), 0, st, cols, N, flags);
+}
+void k_fam_flip_compact(dim3 grid, hipStream_t st, const double* const* src_cols, const int* src_flip, long long N, long long ld,
+                        double* dst) {
+  hipLaunchKernelGGL(fam_flip_compact_kernel, grid, dim3(256), 0, st, src_cols, src_flip, N, ld, dst);
+}
+void k_raw_colstat(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, double* colsum, int* poly) {
+  hipLaunchKernelGGL(raw_colstat_kernel, grid, dim3(256), 0, st, G, N, ld, colsum, poly);
+}
+void k_rot_reduce_slices(hipStream_t st, const double* part, long long ldc, long long M, long long N, long long stride, int slices,
+                         double* C, int accumulate) {
+  hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, part, ldc, M, N, stride, slices, C, accumulate);
+}

@@ -1,5 +1,8 @@
 // rvtests_amd — the tests that are not gene tests of the main pipeline: KBAC, MetaScore, MetaCov (bands and rectangles, the
 // exact int8 band for hard calls) and the column operations of the adapters' device ring.  Part of librvtests_amd.so.
+// this unit compiles (and ships) the META kernel family only: see "kernel families" in rvt_engine_int.h
+#define RVT_K_SPLIT
+#define RVT_K_META
 #include "rvt_engine_int.h"
 #include "gemm_f64.hip.h"
 #include "band_rows.hip.h"
@@ -57,8 +60,7 @@ int gemm_tn_f64(rvt_ctx* c, const double* A, int64_t lda, int M, const double* B
                        B2 ? B2 : B, (long long)(B2 ? ldb2 : ldb), Nb2, w, (long long)N, (long long)kslice, (int)slices, d_out,
                        (long long)ldc, (long long)c_slice, n_tiles, nct, symmetric ? 1 : 0, halo, ring, col0);
   if (slices > 1)
-    hipLaunchKernelGGL(rot_reduce_slices_kernel, dim3(1024), dim3(256), 0, st, d_out, (long long)ldc, (long long)M,
-                       (long long)Ntot, (long long)c_slice, (int)slices, C, 0);
+    k_rot_reduce_slices(st, d_out, (long long)ldc, (long long)M, (long long)Ntot, (long long)c_slice, (int)slices, C, 0);
   HIP_TRY(c, hipGetLastError());
   return RVT_OK;
 }
@@ -709,8 +711,7 @@ static int cov_rect_fam_impl(rvt_ctx* c, const double* dG, int ring, int col0, i
   HIP_TRY(c, hipMemsetAsync(c->d_Gt, 0, sizeof(double) * (size_t)ld * W, st));
   for (int k = 0; k < nseg; ++k) {
     const double* GW = dG + (size_t)segs[k].phys * ld;
-    hipLaunchKernelGGL(raw_colstat_kernel, dim3((unsigned)segs[k].n), dim3(256), 0, st, GW, (long long)N, (long long)ld,
-                       d_cs + segs[k].at, d_poly + segs[k].at);
+    k_raw_colstat(dim3((unsigned)segs[k].n), st, GW, (long long)N, (long long)ld, d_cs + segs[k].at, d_poly + segs[k].at);
     rc = rotate_columns(c, GW, ld, segs[k].n, c->d_Gt + (size_t)segs[k].at * ld, ld, st);
     if (rc) return rc;
   }

@@ -1,5 +1,8 @@
 // rvtests_amd — the SKAT permutation test (--kernel skat[nPerm=..]): the exact replay of the reference's rand() stream and the
 // counter-based shuffles (perm_kernels.hip.h, perm_counter.h).  Part of librvtests_amd.so.
+// this unit compiles (and ships) the PERM kernel family only: see "kernel families" in rvt_engine_int.h
+#define RVT_K_SPLIT
+#define RVT_K_PERM
 #include "rvt_engine_int.h"
 
 extern "C" {
@@ -61,7 +64,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
     }
   } guard{(void*)d_cols, (void*)d_flags};
   HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * M, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+  k_fam_colstat(dim3((unsigned)M), st, d_cols, (long long)N, d_flags);
   std::vector<int> flags(M);
   HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
@@ -78,8 +81,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(d_cols + M, kc.data(), sizeof(double*) * m, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(d_flags + M, kf.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)m), dim3(256), 0, st, d_cols + M, d_flags + M,
-                     (long long)N, (long long)ld, c->d_Gp);
+  k_fam_flip_compact(dim3(64, (unsigned)m), st, d_cols + M, d_flags + M, (long long)N, (long long)ld, c->d_Gp);
   const double* d_bw = gene_scratch_carve(g0.scratch, g0.Mp, g0.Cp).bw;  // sqrt of the SKAT weights, filtered order
   if (!c->perm_exact) {
     // ---- counter-based permutations (perm_counter.h): no stream shared between genes, nothing stored per shuffle ----------
@@ -259,7 +261,7 @@ int kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std:
   HIP_TRY(c, hipMalloc((void**)&d_cols, sizeof(double*) * (size_t)M * 2));
   HIP_TRY(c, hipMalloc((void**)&d_flags, sizeof(int) * (size_t)M * 3));
   HIP_TRY(c, hipMemcpyAsync(d_cols, cols.data(), sizeof(double*) * M, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(fam_colstat_kernel, dim3((unsigned)M), dim3(256), 0, st, d_cols, (long long)N, d_flags);
+  k_fam_colstat(dim3((unsigned)M), st, d_cols, (long long)N, d_flags);
   std::vector<int> flags(M);
   HIP_TRY(c, hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * M, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, sync_stream(st));
@@ -280,8 +282,7 @@ int kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std:
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(d_cols + M, kc.data(), sizeof(double*) * m, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(d_flags + M, kf.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(fam_flip_compact_kernel, dim3(64, (unsigned)m), dim3(256), 0, st, d_cols + M, d_flags + M,
-                     (long long)N, (long long)ld, c->d_Gp);
+  k_fam_flip_compact(dim3(64, (unsigned)m), st, d_cols + M, d_flags + M, (long long)N, (long long)ld, c->d_Gp);
   // ---- m_trimXdat: columns with 0 < maf <= 1 (maf of filtered position j = counter of unfiltered column j) --------------
   std::vector<int> use;
   for (int j = 0; j < m; ++j)

@@ -2,6 +2,9 @@
 // hand-offs (raw / int8 / PLINK 2-bit), VCF record text, BGEN probability blocks — all decoded on the device.  Part of
 // librvtests_amd.so; the batch pipeline it feeds is rvt_engine.hip's run_batch.
 #define RVT_STREAM_UNIT 1
+// this unit compiles (and ships) the STREAM kernel family only: see "kernel families" in rvt_engine_int.h
+#define RVT_K_SPLIT
+#define RVT_K_STREAM
 #include "rvt_engine_int.h"
 
 extern "C" {

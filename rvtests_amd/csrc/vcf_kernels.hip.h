@@ -61,6 +61,7 @@ __device__ __forceinline__ int vcf_tabs16(const char* __restrict__ text, long lo
 }
 
 // pass 1: tabs per segment.  grid (max segments, records), 256 threads
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(256) void vcf_tab_count_kernel(const char* __restrict__ text,
                                                             const VcfRecord* __restrict__ rec, int max_seg,
                                                             int* __restrict__ seg_count) {
@@ -75,9 +76,11 @@ static __global__ __launch_bounds__(256) void vcf_tab_count_kernel(const char* _
   __syncthreads();
   if (threadIdx.x == 0) seg_count[(long long)blockIdx.y * max_seg + blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
+#endif  // RVT_K_STREAM
 
 // pass 2: exclusive scan over the segments of one record (in place); a record whose column count differs from the
 // file's sample count raises *err (host-visible) to record index + 1.  grid (records), 256 threads
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(256) void vcf_tab_scan_kernel(const VcfRecord* __restrict__ rec, int max_seg,
                                                            int n_file_samples, int* __restrict__ seg_count,
                                                            int* __restrict__ err) {
@@ -107,6 +110,7 @@ static __global__ __launch_bounds__(256) void vcf_tab_scan_kernel(const VcfRecor
   }
   if (threadIdx.x == 0 && carry != n_file_samples - 1) atomicCAS_system(err, 0, (int)blockIdx.x + 1);
 }
+#endif  // RVT_K_STREAM
 
 // ---- one sample column -------------------------------------------------------------------------------------------------
 // [b, e) of subfield idx of the column that starts at `start`; false when the column has fewer subfields (the
@@ -301,6 +305,7 @@ __device__ __forceinline__ double vcf_atof(const char* __restrict__ t, long long
 // dosage mode of the decode pass (--dosage TAG): the subfield at the tag's FORMAT index through atof; a column without
 // that subfield reads the default value "." = 0.0; the GD / GQ filters turn a value into -9 as for hard calls.
 // out: [record][ld] doubles, the first n_rows of every column pre-filled with -9.
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const char* __restrict__ text,
                                                                 const VcfRecord* __restrict__ rec, int max_seg,
                                                                 const int* __restrict__ seg_count,
@@ -362,8 +367,10 @@ static __global__ __launch_bounds__(256) void vcf_decode_dosage_kernel(const cha
   }
   if (inexact) atomicCAS_system(err, 0, -((int)blockIdx.y + 1));  // negative: a number the device cannot round exactly
 }
+#endif  // RVT_K_STREAM
 
 // pass 3: decode.  grid (max segments, records), 256 threads.  out: [record][n_rows] signed bytes, pre-filled with -9
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __restrict__ text, const VcfRecord* __restrict__ rec,
                                                          int max_seg, const int* __restrict__ seg_count,
                                                          const int* __restrict__ row_of_sample,
@@ -407,12 +414,15 @@ static __global__ __launch_bounds__(256) void vcf_decode_kernel(const char* __re
     }
   }
 }
+#endif  // RVT_K_STREAM
 
 // dst[i + j * ld] = value for i < n_rows (the dosage matrix before the decode pass: every row missing)
+#if !defined(RVT_K_SPLIT) || defined(RVT_K_STREAM)
 static __global__ void vcf_fill_kernel(double* __restrict__ dst, long long n_rows, long long ld, int ncols, double value) {
   const long long total = n_rows * ncols;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
     dst[(t / n_rows) * ld + t % n_rows] = value;
 }
+#endif  // RVT_K_STREAM
 
 }  // namespace rvt

@@ -232,3 +232,67 @@ def test_group_on_two_devices_matches_single_context(engine):
     for a, b in zip(got, ref):
         for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "cmc_nonref", "n_poly", "status"):
             assert getattr(a, f) == getattr(b, f), f
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """bench.py --gpus 8 as the driver launches it on an 8-GPU node, with all eight ranks on GPU 0 over gloo (the one device a
+    1-GPU lease has): eight ranks seen, every rank's gene shard computed (genes_ok counts rank 0's), the per-step C2 gather of
+    real engine records complete (8 x genes) and in gene order, a rate and a gather time per rank.  What is left for the first
+    real 8-GPU run to show is RCCL over xGMI itself, not the plumbing."""
+    env = dict(os.environ, RVT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--samples",
+           "12000", "--genes", "24", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["config"]["genes_ok"] == 24 and line["value"] > 0
+    assert line["gathered_records_last_step"] == 8 * 24 and line["gathered_ids_in_order"] is True
+    assert len(line["per_rank_gene_sets_per_s"]) == 8 and min(line["per_rank_gene_sets_per_s"]) > 0
+    assert len(line["c2_gather_ms_per_step_by_rank"]) == 8
+    assert line["scaling"] == "weak" and abs(line["value"] - 8 * 24 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+
+
+def test_group_of_eight_members_equals_the_single_context(engine):
+    """rvt_group with EIGHT members (the one-thread C++ caller's form of the 8-GPU node; all on device 0 here): the gene stream
+    dealt in runs over eight contexts comes back in submission order with the single context's records, and `--meta score` /
+    `--meta cov` over eight shares with a one-window halo give the single context's numbers."""
+    import rvtests_amd
+    N, d = 2501, 2
+    rng = np.random.default_rng(8)
+    X, y, res, v, s2 = synth.make_null(N, d, 0, seed=6)
+    genes = [synth.make_gene(N, int(rng.integers(1, 40)), seed=900 + g, missing=0.01, common=True, mono=True)[1:] for g in range(300)]
+    grp = rvtests_amd.Group([0] * 8)
+    try:
+        grp.fit_null(0, X, y)
+        for g, (G, af) in enumerate(genes):
+            grp.submit_gene(1000 + g, G, af)
+        got = grp.collect()
+        V, halo = 640, 90
+        Gm = np.asfortranarray(rng.binomial(2, 10 ** rng.uniform(-2.5, -0.6, V), size=(N, V)).astype(np.float64))
+        Gm[:, 3] = 2.0
+        sc = grp.score_block_host(Gm)
+        band, xz, zz, poly = grp.cov_band_host(Gm, d, halo, chunk=70)
+    finally:
+        grp.close()
+    engine.fit_null(0, X, y)
+    for g, (G, af) in enumerate(genes):
+        engine.submit_gene(1000 + g, G, af)
+    ref = engine.collect()
+    assert [r.gene_id for r in got] == [r.gene_id for r in ref] == [1000 + g for g in range(300)]
+    for a, b in zip(got, ref):
+        for f in ("skat_Q", "skat_p", "skato_p", "cmc_p", "zeg_p", "n_poly", "status", "cmc_nonref"):
+            assert getattr(a, f) == getattr(b, f), (a.gene_id, f)
+    ptr = engine.upload_block(Gm)
+    s0 = engine.score_block(ptr, V)
+    cov0, xz0, zz0, poly0 = engine.cov_block(ptr, V)
+    ok, u, vv, e, se, p_ = sc
+    assert (ok == s0["ok"]).all() and (poly == poly0).all() and not poly[3]
+    good = s0["ok"] == 1
+    for a, b in ((u, s0["U"]), (vv, s0["V"]), (e, s0["effect"]), (se, s0["se"]), (p_, s0["p"])):
+        assert np.allclose(a[good], b[good], rtol=1e-11, atol=0)
+    scale = np.nanmax(np.abs(cov0[np.triu_indices(V)]))
+    for h in range(0, V, 3):
+        w = min(halo + 1, V - h)
+        assert np.abs(band[h, :w] - cov0[h, h:h + w]).max() <= 1e-9 * scale
+        assert np.isnan(band[h, w:]).all()
