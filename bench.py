@@ -748,6 +748,14 @@ def main():
                         di[mode] = {"error": repr(e)[:300]}
                 di["rows_identical"] = bool(di.get("fp64", {}).get("rows_sha256")) and \
                     di["fp64"].get("rows_sha256") == di.get("bed", {}).get("rows_sha256")
+                # `--meta cov` the same way: MetaCovTest::fit() per variant with its fp64 column (the reference's single-variant
+                # loop, src/Main.cpp:1010-1078), windows of 200 markers, rows formatted and hashed on the host
+                try:
+                    pr = subprocess.run([drv, "--synthetic-meta", str(N), "8000", "200"], capture_output=True, text=True, timeout=300)
+                    rec = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    di["meta_cov"] = rec[0] if rec else {"error": (pr.stderr or "no output")[-300:]}
+                except Exception as e:
+                    di["meta_cov"] = {"error": repr(e)[:300]}
                 line["drop_in"] = di
         print(json.dumps(line))
     if world > 1:

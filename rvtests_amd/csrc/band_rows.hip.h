@@ -122,4 +122,30 @@ __global__ void band_cache_gather_kernel(const double* __restrict__ cs_c, const 
   for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[p * t_stride + k];
 }
 
+// Columns that crossed PCIe as PLINK 2-bit codes (host_stage.h pack_column_f64: 00 -> 0, 10 -> 1, 11 -> 2, 01 -> the column's one
+// other value mu[j], e.g. an imputed mean) back to the doubles of the block: rows [column j][pitch bytes], sample i in bits
+// 2 (i & 3) of byte i >> 2.  grid (ceil(N / 1024), columns), 256 threads, four samples per thread.
+__global__ __launch_bounds__(256) void bed_expand_columns_kernel(const unsigned char* __restrict__ rows, long long pitch,
+                                                                 const double* __restrict__ mu, long long N, long long ld,
+                                                                 double* __restrict__ G) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x, i = 4 * b;
+  if (i >= N) return;
+  const int j = blockIdx.y;
+  const unsigned code = rows[(long long)j * pitch + b];
+  const double m = mu[j];
+  double* g = G + (long long)j * ld + i;
+  double v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned q = (code >> (2 * e)) & 3u;
+    v[e] = q == 0u ? 0.0 : (q == 2u ? 1.0 : (q == 3u ? 2.0 : m));
+  }
+  if (i + 4 <= N) {
+    *reinterpret_cast<double2*>(g) = double2{v[0], v[1]};
+    *reinterpret_cast<double2*>(g + 2) = double2{v[2], v[3]};
+  } else {
+    for (int e = 0; e < 4 && i + e < N; ++e) g[e] = v[e];
+  }
+}
+
 }  // namespace rvt

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <iterator>
+#include <thread>
 
 namespace rvt_host {
 
@@ -826,6 +827,8 @@ MetaCovTest::MetaCovTest(int windowSize_) : windowSize(windowSize_) {
   // columns of the device ring at the start; RVT_METACOV_BLOCK lowers it (tests exercise the mid-stream flush and the wrap with it)
   if (const char* e = getenv("RVT_METACOV_BLOCK")) capacity = std::max(2, std::min(65536, atoi(e)));
   if (const char* e = getenv("RVT_METACOV_MAX_COLUMNS")) maxColumns = std::max(capacity, atoi(e));
+  formatThreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+  if (const char* e = getenv("RVT_METACOV_FORMAT_THREADS")) formatThreads = std::max(1, atoi(e));
 }
 MetaCovTest::~MetaCovTest() {
   if (fout) flush(true);
@@ -997,8 +1000,12 @@ int MetaCovTest::flush(bool final) {
       lastError = rvt_last_error(ctx);
       return -1;
     }
-    for (int h = h0; h < h1; ++h) {
-      if (!poly[(size_t)(h - h0)]) continue;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
+    // the rows of the chunk as text: a row of a 1 000-marker window is 1 000 "%g" conversions (~0.2 ms on one core, more than
+    // the device spends on it by two orders of magnitude), and rows are independent — formatted by a few threads, written in
+    // order by this one
+    std::vector<std::string> rowText((size_t)nh);
+    auto formatRow = [&](int h) {
+      if (!poly[(size_t)(h - h0)]) return;  // monomorphic sites never entered the reference's queue (src/Model.cpp:879-884)
       const float* row = bandBuf.data() + (size_t)(h - h0) * ((size_t)halo + 1);
       std::string positions, values;
       int lastPrinted = h, num = 0;
@@ -1027,9 +1034,25 @@ int MetaCovTest::flush(bool final) {
             values += floatToString(zz[(size_t)a * d + b] * (double)scale);
           }
       }
-      fout->write(sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[lastPrinted].pos) + "\t" +
-                  std::to_string(num) + "\t" + positions + "\t" + values + "\n");
+      rowText[(size_t)(h - h0)] = sites[h].chrom + "\t" + std::to_string(sites[h].pos) + "\t" + std::to_string(sites[lastPrinted].pos) +
+                                  "\t" + std::to_string(num) + "\t" + positions + "\t" + values + "\n";
+    };
+    {
+      const size_t work = (size_t)nh * ((size_t)halo + 1);
+      int T = (int)std::min<size_t>(formatThreads, work / 20000 + 1);  // (a thread is worth its start from ~20 000 values on)
+      if (T <= 1) {
+        for (int h = h0; h < h1; ++h) formatRow(h);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t)
+          pool.emplace_back([&, t] {
+            for (int h = h0 + t; h < h1; h += T) formatRow(h);  // (interleaved: rows near the end of the ring are shorter)
+          });
+        for (auto& th : pool) th.join();
+      }
     }
+    for (int h = h0; h < h1; ++h)
+      if (!rowText[(size_t)(h - h0)].empty()) fout->write(rowText[(size_t)(h - h0)]);
   }
   head = (head + H) % capacity;
   sites.erase(sites.begin(), sites.begin() + H);

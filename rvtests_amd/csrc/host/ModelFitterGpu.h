@@ -384,6 +384,7 @@ class MetaCovTest : public ModelFitter {
   int head = 0;                        // physical column of sites[0]: site k lives in column (head + k) mod capacity
   int maxColumns = 65536;              // RVT_METACOV_MAX_COLUMNS
   bool canGrow = true;                 // false once a non-mandatory grow() failed (not retried on every fill)
+  int formatThreads = 1;               // threads that turn the band of a flush into text (RVT_METACOV_FORMAT_THREADS; default up to 8)
   std::vector<float> bandBuf;          // where the band of a flush lands (page-locked: rvt_host_register)
   float* bandReg = nullptr;
   bool outputGwama = false;

@@ -301,6 +301,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_rotA) hipFree(c->d_rotA);
   if (c->d_rot_part) hipFree(c->d_rot_part);
   if (c->d_cov_work) hipFree(c->d_cov_work);
+  if (c->d_colpack) hipFree(c->d_colpack);
   for (int i = 0; i < 2; ++i) {
     if (c->ev_band_fin[i]) hipEventDestroy(c->ev_band_fin[i]);
     if (c->ev_band_copied[i]) hipEventDestroy(c->ev_band_copied[i]);

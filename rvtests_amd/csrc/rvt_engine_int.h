@@ -175,6 +175,8 @@ struct rvt_ctx {
   hipStream_t copy_stream = nullptr;
   hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
+  char* d_colpack = nullptr;     // rvt_block_upload_columns: the columns as 2-bit rows + their other values, before they are expanded
+  size_t colpack_cap = 0;
   char* d_cov_work = nullptr;    // work space of the MetaCov rectangles (S, T, the band, column statistics): grow-only
   hipEvent_t ev_band_fin[2] = {}, ev_band_copied[2] = {};  // rvt_cov_band: a pass's rows are copied out while the next pass multiplies
   size_t cov_work_cap = 0;

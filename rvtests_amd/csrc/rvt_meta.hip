@@ -903,8 +903,45 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   hipSetDevice(c->device);
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
-  HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
-                         hipMemcpyHostToDevice));
+  // The columns cross PCIe as 2-bit codes when they are what consolidate() almost always leaves — hard calls plus at most one
+  // other value per column (the imputed mean): the staging threads pack them (host_stage.h pack_column_f64, as for the genes
+  // of rvt_submit_gene), 1/32 of the bytes go over the link, a small kernel writes the doubles of the block back.  Until round 6
+  // every site's column crossed as 4 MB of doubles out of pageable memory (~120 us per site at N = 500 000: the adapter's
+  // `--meta cov` ran at 8 k sites/s whatever the window).  Dosages (a second other value) cross as doubles, as before.
+  bool packed = false;
+  if (c->hc_enabled && !getenv("RVT_UPLOAD_FP64") && N >= 4096) {
+    int rc = stage_ready(c);
+    if (rc) return rc;
+    const size_t pitch = ((N + 3) / 4 + 15) / 16 * 16;
+    const size_t need = pitch * (size_t)ncols + sizeof(double) * (size_t)ncols;
+    if (c->colpack_cap < need) {
+      if (c->d_colpack) hipFree(c->d_colpack);
+      c->d_colpack = nullptr;
+      c->colpack_cap = 0;
+      HIP_TRY(c, hipMalloc((void**)&c->d_colpack, need + need / 2));
+      c->colpack_cap = need + need / 2;
+    }
+    if (pitch <= c->stage.chunk_bytes) {
+      std::vector<PackedColumn> pc((size_t)ncols);
+      const int prc = c->stage.pack_f64(c->d_colpack, pitch, G, N, N, (size_t)ncols, CopyPool::pack_instance(), pc.data());
+      if (prc == 1) return fail(c, RVT_E_HIP, "packing the uploaded columns failed");
+      if (prc == 0) {
+        double* d_mu = reinterpret_cast<double*>(c->d_colpack + pitch * (size_t)ncols);
+        std::vector<double> mu((size_t)ncols);
+        for (int j = 0; j < ncols; ++j) mu[(size_t)j] = pc[(size_t)j].has_mu ? pc[(size_t)j].mu : 0.0;
+        rc = small_h2d(c, d_mu, mu.data(), sizeof(double) * (size_t)ncols);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bed_expand_columns_kernel, dim3((unsigned)((N + 1023) / 1024), (unsigned)ncols), dim3(256), 0, c->io_stream,
+                           reinterpret_cast<const unsigned char*>(c->d_colpack), (long long)pitch, d_mu, (long long)N, (long long)ld,
+                           dG + (size_t)col0 * ld);
+        HIP_TRY(c, hipGetLastError());
+        packed = true;
+      }
+    }
+  }
+  if (!packed)
+    HIP_TRY(c, hipMemcpy2D(dG + (size_t)col0 * ld, sizeof(double) * ld, G, sizeof(double) * N, sizeof(double) * N, ncols,
+                           hipMemcpyHostToDevice));
   // content of the new columns (hard calls or not), recorded per column: rvt_score_block picks its kernel by it.  One
   // read of data that has just crossed PCIe at a hundredth of the rate.  Under an unweighted null model that read is the
   // column pass of MetaCov's hard-call band itself (cov_hc_prep_kernel on the one column): int8 copy, sum, min / max and the
