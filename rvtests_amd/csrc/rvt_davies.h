@@ -627,6 +627,14 @@ RVT_HD bool davies_all_positive(const double* lb, int r) {
 typedef RVT_LDSQ DaviesPrelude* dv_pre_p;
 typedef const RVT_LDSQ DaviesPrelude* dv_pre_cp;
 template <bool FAST>
+// The wrappers below take ORDINARY pointers and hand them to the templated bodies as address-space-3 types — a no-op on the
+// host (the harness, the oracle's checks), a truncation to an LDS offset in device code: they are host-only, so that a device
+// caller cannot be compiled against them by accident (the kernels call the _t forms with real LDS pointers).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RVT_HOST_ONLY __host__ inline
+#else
+#define RVT_HOST_ONLY RVT_HD
+#endif
 RVT_HDI void davies_prelude_t(dv_coefs lb, dv_index th, int r, int lim, double acc, dv_pre_p P,
                               dv_memo_p memo = nullptr, dv_coefs ls = nullptr) {
   DaviesState st;
@@ -678,7 +686,7 @@ RVT_HDI void davies_prelude_t(dv_coefs lb, dv_index th, int r, int lim, double a
 }
 // fast: product form of the coefficient sums (else term by term)
 // (the wrappers without template arguments take ordinary pointers: the host test harness and the serial form call them)
-RVT_HD void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P,
+RVT_HOST_ONLY void davies_prelude(const double* lb, const int* th, int r, int lim, double acc, DaviesPrelude* P,
                            bool fast = true, DaviesMemo* memo = nullptr) {
   if (fast)
     davies_prelude_t<true>((dv_coefs)lb, (dv_index)th, r, lim, acc, (dv_pre_p)P, (dv_memo_p)memo);
@@ -725,7 +733,7 @@ RVT_HDI void davies_term_t(dv_coefs lb, int r, double c, double sigsq, double in
   *t1 = sin(0.5 * sum1) * x;
   *t2 = 0.5 * sum2 * x;
 }
-RVT_HD void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
+RVT_HOST_ONLY void davies_term(const double* lb, int r, double c, double sigsq, double interv, int k, double* t1,
                         double* t2, bool fast = false, bool allpos = false) {
   if (fast)
     davies_term_t<true>((dv_coefs)lb, r, c, sigsq, interv, k, t1, t2, allpos);
@@ -921,7 +929,7 @@ RVT_HDI void davies_qf_front_t(dv_coefs lb, dv_index th, int r, double c, int li
     task->need_main = false;
   }
 }
-RVT_HD void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
+RVT_HOST_ONLY void davies_qf_front(const double* lb, const int* th, int r, double c, int lim, double acc,
                             const DaviesPrelude* pre, DaviesTask* task, bool fast = true) {
   if (fast)
     davies_qf_front_t<true>((dv_coefs)lb, (dv_index)th, r, c, lim, acc, (dv_pre_cp)pre, task);
