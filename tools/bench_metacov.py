@@ -58,7 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=500000)
     ap.add_argument("--variants", type=int, default=1024)
-    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--window", default="200,1000,3000", help="comma-separated window widths (markers) of the stream runs; empty = none")
     ap.add_argument("--stream", type=int, default=40000, help="variants of a stream run")
     ap.add_argument("--ring", type=int, default=0, help="columns of the device ring of the stream runs (default: the adapter's policy)")
@@ -79,11 +79,16 @@ def main():
     pairs = V * (V + 1) / 2
 
     def timed(fn):
+        """median of `reps` calls after one warm-up (the GPU boxes are shared hosts: a mean of three carried the occasional
+        10 ms stall of a HIP call into a 2 ms figure)"""
         fn()
-        t0 = time.perf_counter()
-        for _ in range(a.reps):
+        ts = []
+        for _ in range(max(a.reps, 1)):
+            t0 = time.perf_counter()
             out = fn()
-        return (time.perf_counter() - t0) / a.reps, out
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], out
 
     # ---- block, fp64: dosages (the synthetic block + a fractional part in the non-zero entries)
     dos = blocks[0].clone()
