@@ -77,10 +77,20 @@ class CopyPool {
       std::lock_guard<std::mutex> lk(m_);
       for (size_t i = 0; i < n; ++i) q_.push_back(Piece{nullptr, nullptr, i, &left, &fn});
     }
+    pending_.fetch_add((int)n, std::memory_order_release);
     cv_.notify_all();
     help();
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&left] { return left == 0; });
+    wait_batch(&left);
+  }
+  // a third pool for ONE column at a time (rvt_block_upload_columns: a site of MetaCovTest / MetaScoreTest::fit, 4 MB): eight
+  // threads — with sixteen the wake-ups cost more than the second eight save (12.9 k against 20.5 k sites/s, round 6)
+  static CopyPool& column_instance() {
+    static CopyPool pool([] {
+      if (const char* e = getenv("RVT_COLUMN_THREADS")) return std::max(1, atoi(e));
+      const unsigned hw = std::thread::hardware_concurrency();
+      return (int)std::max(1u, std::min(8u, hw / 2));
+    }());
+    return pool;
   }
   // the pool of the packing passes: reading 200 MB per gene is bound by memory bandwidth per core, so it takes more threads
   // than the copies into pinned memory do (RVT_PACK_THREADS; default min(16, hardware threads / 2))
@@ -113,10 +123,10 @@ class CopyPool {
           ++left;
         }
     }
+    pending_.fetch_add((int)left, std::memory_order_release);
     cv_.notify_all();
     help();  // the calling thread works too
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&left] { return left == 0; });
+    wait_batch(&left);
   }
 
  private:
@@ -132,7 +142,32 @@ class CopyPool {
     if (q_.empty()) return false;
     *t = q_.front();
     q_.pop_front();
+    pending_.fetch_sub(1, std::memory_order_relaxed);
     return true;
+  }
+  // the caller waits for ITS batch: a short spin first — a batch of a few hundred microseconds (one 4 MB column on eight
+  // threads takes ~20 us) should not pay a futex sleep and wake-up on top (round 6) — then the condition variable
+  static bool spin_enabled() {
+    static const bool on = !(getenv("RVT_POOL_SPIN") && atoi(getenv("RVT_POOL_SPIN")) == 0);
+    return on;
+  }
+  void wait_batch(size_t* left) {
+    for (int i = 0; spin_enabled() && i < 4000; ++i) {
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (*left == 0) return;
+      }
+      for (int k = 0; k < 16; ++k) cpu_relax();
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [left] { return *left == 0; });
+  }
+  static void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
   }
   void finish_one(size_t* left) {
     std::lock_guard<std::mutex> lk(m_);
@@ -150,7 +185,15 @@ class CopyPool {
   }
   void loop() {
     for (;;) {
-      {
+      // a worker that has just finished looks for the next batch for ~50 us before it sleeps: a caller that hands over one
+      // column per call (every ~50 us) then finds its workers awake
+      bool found = false;
+      for (int i = 0; spin_enabled() && i < 3000 && !found; ++i) {
+        if (pending_.load(std::memory_order_acquire) > 0) found = true;
+        else
+          for (int k = 0; k < 16; ++k) cpu_relax();
+      }
+      if (!found) {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
         if (stop_ && q_.empty()) return;
@@ -163,6 +206,7 @@ class CopyPool {
   std::mutex m_;
   std::condition_variable cv_, done_;
   std::deque<Piece> q_;
+  std::atomic<int> pending_{0};  // pieces queued and not yet taken (the spinning workers' wake-up word)
   bool stop_ = false;
 };
 
@@ -398,6 +442,42 @@ struct StageRing {
     }
     return 0;
   }
+  // `nc` columns packed into rows of `dpitch` bytes at `base` (host memory) by the pool's threads; out[j] describes column j.
+  // Returns false when a column is not representable (a second other value, an other value outside [0, 2]).
+  static bool pack_columns_to(char* base, size_t dpitch, const double* src, size_t spitch_doubles, size_t n, size_t nc,
+                              CopyPool& pool, PackedColumn* out) {
+    std::atomic<int> stop{0};
+    // a column is cut into `segs` runs of rows (multiples of 1 024 samples = 256 bytes of codes) so that the pool's threads
+    // stay busy to the end — 50 columns on 16 threads were four rounds, the last one with two columns (round 6) —; a
+    // column's runs must agree on its other value
+    const size_t segs = std::max<size_t>(1, std::min<size_t>(8, (8 * (size_t)pool.threads() + nc - 1) / nc));
+    const size_t seg = std::max<size_t>(1024, ((n + segs - 1) / segs + 1023) / 1024 * 1024), nseg = (n + seg - 1) / seg;
+    std::vector<PackedColumn> part(nc * nseg);
+    const std::function<void(size_t)> fn = [&](size_t item) {
+      if (stop.load(std::memory_order_relaxed)) return;
+      const size_t j = item / nseg, q = item % nseg, r0 = q * seg, len = std::min(seg, n - r0);
+      unsigned char* o = reinterpret_cast<unsigned char*>(base + j * dpitch) + r0 / 4;
+      part[item] = pack_column_f64(src + j * spitch_doubles + r0, len, o, q + 1 == nseg ? dpitch - r0 / 4 : len / 4, &stop);
+      if (!part[item].ok) stop.store(1, std::memory_order_relaxed);
+    };
+    pool.run_items(nc * nseg, fn);
+    if (stop.load()) return false;
+    for (size_t j = 0; j < nc; ++j) {
+      PackedColumn r;
+      r.ok = true;
+      for (size_t q = 0; q < nseg; ++q) {
+        const PackedColumn& t = part[j * nseg + q];
+        if (t.has_mu) {
+          if (r.has_mu && std::memcmp(&r.mu, &t.mu, sizeof(double)) != 0) return false;  // two other values in one column
+          r.has_mu = true;
+          r.mu = t.mu;
+        }
+        r.n_other += t.n_other;
+      }
+      out[j] = r;
+    }
+    return true;
+  }
   // The columns of an fp64 block packed on the way: column j = src + j * spitch_doubles, n doubles -> device row j of
   // `dpitch` bytes (2-bit codes, zero padded).  out[j] describes every column.  Returns 0 = sent, 1 = a HIP call failed,
   // 2 = not representable (nothing useful was sent; the caller sends the doubles).
@@ -405,42 +485,12 @@ struct StageRing {
                PackedColumn* out) {
     if (dpitch > chunk_bytes || cols == 0) return 2;
     const size_t per = std::max<size_t>(1, chunk_bytes / dpitch);
-    std::atomic<int> stop{0};
     for (size_t c0 = 0; c0 < cols; c0 += per) {
       const size_t nc = std::min(per, cols - c0);
       const int k = next;
       next = (next + 1) % (int)chunk.size();
       if (int rc = wait(k)) return rc;
-      char* base = chunk[k];
-      // a column is cut into `segs` runs of rows (multiples of 1 024 samples = 256 bytes of codes) so that the pool's threads
-      // stay busy to the end — 50 columns on 16 threads were four rounds, the last one with two columns (round 6) —; a
-      // column's runs must agree on its other value
-      const size_t segs = std::max<size_t>(1, std::min<size_t>(8, (8 * (size_t)pool.threads() + nc - 1) / nc));
-      const size_t seg = std::max<size_t>(1024, ((n + segs - 1) / segs + 1023) / 1024 * 1024), nseg = (n + seg - 1) / seg;
-      std::vector<PackedColumn> part(nc * nseg);
-      const std::function<void(size_t)> fn = [&](size_t item) {
-        if (stop.load(std::memory_order_relaxed)) return;
-        const size_t j = item / nseg, q = item % nseg, r0 = q * seg, len = std::min(seg, n - r0);
-        unsigned char* o = reinterpret_cast<unsigned char*>(base + j * dpitch) + r0 / 4;
-        part[item] = pack_column_f64(src + (c0 + j) * spitch_doubles + r0, len, o, q + 1 == nseg ? dpitch - r0 / 4 : len / 4, &stop);
-        if (!part[item].ok) stop.store(1, std::memory_order_relaxed);
-      };
-      pool.run_items(nc * nseg, fn);
-      if (stop.load()) return 2;
-      for (size_t j = 0; j < nc; ++j) {
-        PackedColumn r;
-        r.ok = true;
-        for (size_t q = 0; q < nseg; ++q) {
-          const PackedColumn& t = part[j * nseg + q];
-          if (t.has_mu) {
-            if (r.has_mu && std::memcmp(&r.mu, &t.mu, sizeof(double)) != 0) return 2;  // two other values in one column
-            r.has_mu = true;
-            r.mu = t.mu;
-          }
-          r.n_other += t.n_other;
-        }
-        out[c0 + j] = r;
-      }
+      if (!pack_columns_to(chunk[k], dpitch, src + c0 * spitch_doubles, spitch_doubles, n, nc, pool, out + c0)) return 2;
       if (int rc = send(k, 0, (char*)dst + c0 * dpitch, nc * dpitch)) return rc;
       if (int rc = sent(k)) return rc;
     }

@@ -1312,8 +1312,10 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
 
 // one thread per (column, field): colsum, poly, T (W x d column-major)
 #if !defined(RVT_K_SPLIT) || defined(RVT_K_META)
+// (t_row_stride > 0: T row-major, T[j * t_row_stride + k] — the layout of a block's column cache — instead of T[j + k W])
 static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int slices, int W, int d, int dmax,
-                                     double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
+                                     double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T,
+                                     int t_row_stride = 0) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int F = dmax + 3;
   if (idx >= W * F) return;
@@ -1332,6 +1334,8 @@ static __global__ void cov_hc_finish_kernel(const double* __restrict__ part, int
   for (int s = 0; s < slices; ++s) r += part[((long long)s * W + j) * F + f];
   if (f == 0)
     colsum[j] = r;
+  else if (t_row_stride > 0)
+    T[(long long)j * t_row_stride + (f - 3)] = r;
   else
     T[j + (long long)(f - 3) * W] = r;
 }

@@ -303,6 +303,10 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_cov_work) hipFree(c->d_cov_work);
   if (c->d_colpack) hipFree(c->d_colpack);
   for (int i = 0; i < 2; ++i) {
+    if (c->colq.h[i]) hipHostFree(c->colq.h[i]);
+    if (c->colq.ev[i]) hipEventDestroy(c->colq.ev[i]);
+  }
+  for (int i = 0; i < 2; ++i) {
     if (c->ev_band_fin[i]) hipEventDestroy(c->ev_band_fin[i]);
     if (c->ev_band_copied[i]) hipEventDestroy(c->ev_band_copied[i]);
   }
@@ -627,6 +631,11 @@ int rvt_set_content_hint(rvt_ctx* c, int hint) {
 int rvt_block_free(rvt_ctx* c, double* dG) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {
+    if (c->colq.dG == dG) c->colq.n = 0;  // (queued columns of the block that goes away)
+    else if (int rc = flush_col_queue(c)) return rc;
+  }
+  (void)sync_stream(c->io_stream);
   {
     auto it = c->col_kind.find(dG);
     if (it != c->col_kind.end()) {
@@ -906,6 +915,10 @@ int upload_block_data(rvt_ctx* c, double* dG, int M, const double* G) {
   if (!c || !dG || !G || M < 1) return fail(c, RVT_E_INVALID, "bad upload");
   if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {
+    int rcq = flush_col_queue(c);
+    if (rcq) return rcq;
+  }
   {  // per-column flags of an earlier column-wise fill no longer describe the block
     auto it = c->col_kind.find(dG);
     if (it != c->col_kind.end()) {
@@ -1070,6 +1083,11 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
   if (n == 0) return RVT_OK;
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {  // (columns queued by rvt_block_upload_columns may belong to a block of this batch)
+    int rcq = flush_col_queue(c);
+    if (rcq) return rcq;
+    HIP_TRY(c, sync_stream(c->io_stream));
+  }
   // pick the slot that was launched longest ago; if its batch is still in flight, finish it first
   Slot* slp = &c->slots[0];
   for (int i = 1; i < kSlots; ++i)
@@ -1598,6 +1616,11 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
 int rvt_sync(rvt_ctx* c) {
   if (!c) return RVT_E_INVALID;
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {  // columns queued by rvt_block_upload_columns reach their block before anything reads it
+    int rc = flush_col_queue(c);
+    if (rc) return rc;
+  }
+  if (c->colq.used[0] || c->colq.used[1]) HIP_TRY(c, sync_stream(c->io_stream));  // (the uploads' device work is on io_stream)
   // oldest batch first, so records reach the caller in launch order
   Slot* order[kSlots];
   for (int i = 0; i < kSlots; ++i) order[i] = &c->slots[i];

@@ -177,6 +177,21 @@ struct rvt_ctx {
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
   char* d_colpack = nullptr;     // rvt_block_upload_columns: the columns as 2-bit rows + their other values, before they are expanded
   size_t colpack_cap = 0;
+  // single columns uploaded one call at a time (MetaCovTest / MetaScoreTest: one site per fit()) are packed into pinned memory
+  // and QUEUED: the DMA, the expansion and the column pass run once per kColQueue consecutive columns (flush_col_queue) — the
+  // per-call device work (eight HIP calls, ~70 us) was what held the adapter at 9 k sites/s.  Everything that reads a block
+  // flushes first (rvt_sync, the column operations).
+  static constexpr int kColQueue = 32;
+  struct ColQueue {
+    unsigned char* h[2] = {nullptr, nullptr};  // pinned, kColQueue rows of `pitch` bytes each
+    hipEvent_t ev[2] = {nullptr, nullptr};     // recorded behind the DMA that read h[k]
+    bool used[2] = {false, false};
+    size_t pitch = 0;
+    int cur = 0, n = 0, col0 = 0;
+    double* dG = nullptr;
+    double mu[kColQueue];
+    int hard[kColQueue];
+  } colq;
   char* d_cov_work = nullptr;    // work space of the MetaCov rectangles (S, T, the band, column statistics): grow-only
   hipEvent_t ev_band_fin[2] = {}, ev_band_copied[2] = {};  // rvt_cov_band: a pass's rows are copied out while the next pass multiplies
   size_t cov_work_cap = 0;
@@ -629,6 +644,7 @@ void choose_split(int64_t ld, int n_genes, bool weighted, int* n_wparts, int* st
 // header and gets the bodies of that family alone (tools and the host harness define nothing and get everything).  The few
 // kernels that two units launch live in one of them; the other goes through these host launchers (tools/kernel_units.sh
 // lists which object carries which kernel).
+extern "C" RVT_INTERNAL int flush_col_queue(rvt_ctx* c);                                                      // rvt_meta.hip
 RVT_INTERNAL void k_lmm_sums(dim3 grid, hipStream_t st, const double* uxy, const double* lam, long long N, int d, double delta,
                              int take_abs, double* partial);                                                   // rvt_fam.hip
 RVT_INTERNAL void k_fam_colstat(dim3 grid, hipStream_t st, const double* const* cols, long long N, int* flags);  // rvt_fam.hip

@@ -858,6 +858,11 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   if (!c || !dst || !src || dst_col < 0 || src_col < 0 || ncols < 0) return fail(c, RVT_E_INVALID, "bad copy");
   if (ncols == 0) return RVT_OK;
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {
+    int rc = flush_col_queue(c);
+    if (rc) return rc;
+  }
+  HIP_TRY(c, sync_stream(c->io_stream));  // (queued uploads and the passes behind them write what is copied here)
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   HIP_TRY(c, hipMemcpy(dst + (size_t)dst_col * ld, src + (size_t)src_col * ld, sizeof(double) * ld * ncols,
                        hipMemcpyDeviceToDevice));
@@ -897,12 +902,132 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   return RVT_OK;
 }
 
+static void free_col_cache(rvt_ctx::ColKind& ck);
+static bool alloc_col_cache(rvt_ctx* c, rvt_ctx::ColKind& ck, int64_t ldk, int64_t ldk4, uint64_t gen, hipStream_t st);
+// What rvt_block_upload_columns queued (rvt_ctx::ColQueue: up to 32 consecutive columns of one block, packed to 2-bit rows in
+// pinned memory, their other values and hard-call flags known on the host) goes to the device: ONE DMA of the rows, the other
+// values, the flags; the expansion to doubles; and — when the block keeps a column cache — the column pass over all of them.
+int flush_col_queue(rvt_ctx* c) {
+  rvt_ctx::ColQueue& q = c->colq;
+  const int n = q.n;
+  if (n == 0) return RVT_OK;
+  q.n = 0;
+  hipSetDevice(c->device);
+  const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  const size_t pitch = q.pitch;
+  const size_t need = pitch * (size_t)rvt_ctx::kColQueue + sizeof(double) * (size_t)rvt_ctx::kColQueue;
+  if (c->colpack_cap < need) {
+    HIP_TRY(c, sync_stream(c->io_stream));
+    if (c->d_colpack) hipFree(c->d_colpack);
+    c->d_colpack = nullptr;
+    c->colpack_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_colpack, need + need / 2));
+    c->colpack_cap = need + need / 2;
+  }
+  hipStream_t st = c->io_stream;
+  double* dG = q.dG;
+  const int col0 = q.col0;
+  double* d_mu = reinterpret_cast<double*>(c->d_colpack + pitch * (size_t)rvt_ctx::kColQueue);
+  HIP_TRY(c, hipMemcpyAsync(c->d_colpack, q.h[q.cur], pitch * (size_t)n, hipMemcpyHostToDevice, st));
+  if (!q.ev[q.cur]) HIP_TRY(c, hipEventCreateWithFlags(&q.ev[q.cur], hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(q.ev[q.cur], st));
+  q.used[q.cur] = true;
+  q.cur ^= 1;
+  int rc = small_h2d(c, d_mu, q.mu, sizeof(double) * (size_t)n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bed_expand_columns_kernel, dim3((unsigned)((N + 1023) / 1024), (unsigned)n), dim3(256), 0, st,
+                     reinterpret_cast<const unsigned char*>(c->d_colpack), (long long)pitch, d_mu, (long long)N, (long long)ld,
+                     dG + (size_t)col0 * ld);
+  HIP_TRY(c, hipGetLastError());
+  auto it = c->col_kind.find(dG);
+  if (it == c->col_kind.end() || !c->hc_enabled || col0 + n > it->second.cols) return RVT_OK;
+  rvt_ctx::ColKind& ck = it->second;
+  if (!ck.d_flags) {
+    HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
+    HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, st));
+  }
+  // the content of a packed column is KNOWN: hard calls only unless it has an other value
+  rc = small_h2d(c, ck.d_flags + col0, q.hard, sizeof(int) * (size_t)n);
+  if (rc) return rc;
+  bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
+  if (cache) {
+    const int d = c->nc.d, dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+    const int64_t ldk = ((int64_t)N + 127) / 128 * 128, ldk4 = (((int64_t)N + 1) / 2 + 127) / 128 * 128;
+    if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen || !ck.d_i4)) free_col_cache(ck);
+    if (!ck.d_i8 && !ck.cache_failed && !alloc_col_cache(c, ck, ldk, ldk4, c->null_gen, st)) ck.cache_failed = true;
+    cache = ck.d_i8 != nullptr;
+    if (cache) {
+      const size_t part_doubles = (size_t)kCovSlices * rvt_ctx::kColQueue * (RVT_MAX_COV + 3);
+      if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * part_doubles));
+      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
+      launch_cov_prep(st, d, true, dim3((unsigned)((n + kCovHcCols - 1) / kCovHcCols), (unsigned)slices), dG + (size_t)col0 * ld,
+                      (int64_t)N, (int64_t)ld, n, c->d_X, ck.d_i8 + (size_t)col0 * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr,
+                      nullptr, 0, 0, ck.d_i4 + (size_t)col0 * (size_t)ldk4, ldk4);
+      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((n * (dmax + 3) + 255) / 256)), dim3(256), 0, st, c->d_cc_part, slices,
+                         n, d, dmax, ck.d_cs + col0, ck.d_poly + col0, ck.d_T + (size_t)col0 * RVT_MAX_COV, RVT_MAX_COV);
+      HIP_TRY(c, hipGetLastError());
+      for (int k = 0; k < n; ++k) ck.valid[(size_t)(col0 + k)] = (unsigned char)(q.hard[k] != 0);
+    }
+  }
+  return RVT_OK;
+}
+
 int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const double* G) {
   if (!c || !dG || !G || col0 < 0 || ncols < 1) return fail(c, RVT_E_INVALID, "bad upload");
   if (!c->have_null && !c->have_fam) return fail(c, RVT_E_STATE, "set the null model first");
   hipSetDevice(c->device);
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  // ONE column (a site of MetaCovTest / MetaScoreTest::fit): packed by the staging threads into pinned memory and queued; the
+  // device work runs once per 32 consecutive columns (flush_col_queue)
+  if (ncols == 1 && c->hc_enabled && !getenv("RVT_UPLOAD_FP64") && !getenv("RVT_UPLOAD_NO_QUEUE") && N >= 4096) {
+    rvt_ctx::ColQueue& q = c->colq;
+    const size_t pitch = ((N + 3) / 4 + 15) / 16 * 16;
+    if (q.n > 0 && (q.dG != dG || col0 != q.col0 + q.n || q.n == rvt_ctx::kColQueue || q.pitch != pitch)) {
+      int rc = flush_col_queue(c);
+      if (rc) return rc;
+    }
+    if (q.pitch != pitch) {  // (another N: new pinned rows)
+      HIP_TRY(c, sync_stream(c->io_stream));
+      for (int i = 0; i < 2; ++i) {
+        if (q.h[i]) hipHostFree(q.h[i]);
+        q.h[i] = nullptr;
+        q.used[i] = false;
+      }
+      q.pitch = pitch;
+    }
+    for (int i = 0; i < 2; ++i)
+      if (!q.h[i]) HIP_TRY(c, hipHostMalloc((void**)&q.h[i], pitch * (size_t)rvt_ctx::kColQueue, hipHostMallocDefault));
+    if (q.n == 0) {
+      if (q.used[q.cur]) {  // the DMA that last read these rows has finished?
+        while (hipEventQuery(q.ev[q.cur]) == hipErrorNotReady) {
+          struct timespec ts = {0, 20000};
+          nanosleep(&ts, nullptr);
+        }
+        (void)hipGetLastError();
+      }
+      q.dG = dG;
+      q.col0 = col0;
+    }
+    PackedColumn pc;
+    if (StageRing::pack_columns_to(reinterpret_cast<char*>(q.h[q.cur]) + pitch * (size_t)q.n, pitch, G, N, N, 1,
+                                   CopyPool::column_instance(), &pc)) {
+      // whatever the engine knew about the overwritten column is void from here on
+      auto itq = c->col_kind.find(dG);
+      if (itq != c->col_kind.end() && (size_t)col0 < itq->second.valid.size()) itq->second.valid[(size_t)col0] = 0;
+      q.mu[q.n] = pc.has_mu ? pc.mu : 0.0;
+      q.hard[q.n] = pc.has_mu ? 0 : 1;
+      ++q.n;
+      return RVT_OK;
+    }
+    // not representable (dosages): this column crosses as doubles — behind whatever was queued before it
+    int rc = flush_col_queue(c);
+    if (rc) return rc;
+  } else if (c->colq.n > 0) {
+    int rc = flush_col_queue(c);
+    if (rc) return rc;
+  }
   // The columns cross PCIe as 2-bit codes when they are what consolidate() almost always leaves — hard calls plus at most one
   // other value per column (the imputed mean): the staging threads pack them (host_stage.h pack_column_f64, as for the genes
   // of rvt_submit_gene), 1/32 of the bytes go over the link, a small kernel writes the doubles of the block back.  Until round 6
@@ -970,7 +1095,8 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
       if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen || !ck.d_i4)) free_col_cache(ck);  // another model: nothing of the old cache is used
       if (!ck.d_i8 && !ck.cache_failed && !alloc_col_cache(c, ck, ldk, ldk4, c->null_gen, c->io_stream)) ck.cache_failed = true;
       cache = ck.d_i8 != nullptr;
-      if (cache && !c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * kCovSlices * (RVT_MAX_COV + 3)));
+      if (cache && !c->d_cc_part)
+        HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * (size_t)kCovSlices * rvt_ctx::kColQueue * (RVT_MAX_COV + 3)));
     }
     for (int k = 0; k < ncols; ++k) {
       const int col = col0 + k;
@@ -998,6 +1124,10 @@ int rvt_block_move_columns(rvt_ctx* c, double* dG, int dst_col, int src_col, int
   if (!c || !dG || dst_col < 0 || src_col < dst_col || ncols < 0) return fail(c, RVT_E_INVALID, "bad move");
   if (ncols == 0 || dst_col == src_col) return RVT_OK;
   hipSetDevice(c->device);
+  if (c->colq.n > 0) {
+    int rc = flush_col_queue(c);
+    if (rc) return rc;
+  }
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   HIP_TRY(c, sync_stream(c->io_stream));  // (the passes behind the last uploads write the cache this call moves)
   // forward move of a possibly overlapping range: in pieces no longer than the shift, in increasing order — a piece never
