@@ -720,9 +720,13 @@ def main():
                     del blocks
                     torch.cuda.empty_cache()
                     pr = subprocess.run([tool, "--samples", str(N), "--m", "50", "--genes", "1536", "--modes", "int8,bed"],
-                                        capture_output=True, text=True, timeout=240)
+                                        capture_output=True, text=True, timeout=240, env=dict(os.environ, RVT_TRACE_SUBMIT="1"))
                     recs = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
-                    line["from_host_cpp"] = [r for r in recs if "diag" not in r]
+                    line["from_host_cpp"] = [r for r in recs if "diag" not in r and "link_settle" not in r]
+                    line["from_host_cpp_link_settle"] = next((r["link_settle"] for r in recs if "link_settle" in r), None)
+                    # the engine's own account of the caller's time per gene (RVT_TRACE_SUBMIT: staging copy incl. the wait for a
+                    # free pinned chunk, consolidation launches, batch launches), both modes together
+                    line["from_host_cpp_submit_trace"] = [ln.strip() for ln in pr.stderr.splitlines() if "submit trace" in ln][:4]
                     # what this box gives the hand-off to work with (rvt_host_diagnose: threads, NUMA nodes, memcpy / staging /
                     # DMA rates measured in place): a from-host figure far below another box's is explained by these or by
                     # nothing the engine controls

@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/resource.h>
+
 #include "rvtests_amd.h"
 
 static uint64_t mix(uint64_t x) {
@@ -21,6 +23,43 @@ static uint64_t mix(uint64_t x) {
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
+}
+// what the kernel did to this process's memory meanwhile (/proc/vmstat is machine-wide, getrusage is ours): automatic NUMA
+// balancing unmaps pages to sample accesses (numa_hint_faults) and migrates them (numa_pages_migrated) — a staging copy whose
+// source pages are being migrated under it runs at a fraction of its rate
+struct VmSnap {
+  long long hint_faults = -1, pages_migrated = -1, pgmigrate = -1, thp_collapse = -1;
+  long minflt = 0, majflt = 0, nvcsw = 0, nivcsw = 0;
+};
+static VmSnap vm_snap() {
+  VmSnap v;
+  if (FILE* f = fopen("/proc/vmstat", "r")) {
+    char key[128];
+    long long val;
+    while (fscanf(f, "%127s %lld", key, &val) == 2) {
+      if (!strcmp(key, "numa_hint_faults")) v.hint_faults = val;
+      else if (!strcmp(key, "numa_pages_migrated")) v.pages_migrated = val;
+      else if (!strcmp(key, "pgmigrate_success")) v.pgmigrate = val;
+      else if (!strcmp(key, "thp_collapse_alloc")) v.thp_collapse = val;
+    }
+    fclose(f);
+  }
+  struct rusage ru;
+  if (getrusage(RUSAGE_SELF, &ru) == 0) {
+    v.minflt = ru.ru_minflt;
+    v.majflt = ru.ru_majflt;
+    v.nvcsw = ru.ru_nvcsw;
+    v.nivcsw = ru.ru_nivcsw;
+  }
+  return v;
+}
+static int numa_balancing_setting() {
+  int v = -1;
+  if (FILE* f = fopen("/proc/sys/kernel/numa_balancing", "r")) {
+    if (fscanf(f, "%d", &v) != 1) v = -1;
+    fclose(f);
+  }
+  return v;
 }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -64,9 +103,28 @@ int main(int argc, char** argv) {
     if (rvt_host_diagnose(ctx, &dg) == 0)
       printf("{\"diag\": {\"hardware_threads\": %d, \"affinity_cpus\": %d, \"copy_threads\": %d, \"pack_threads\": %d, \"thp\": %d, "
              "\"gpu_numa_node\": %d, \"buffer_numa_node\": %d, \"pinned_numa_node\": %d, \"memcpy_one_thread_GBps\": %.1f, "
-             "\"stage_pool_GBps\": %.1f, \"h2d_pinned_GBps\": %.1f, \"d2h_pinned_GBps\": %.1f, \"loadavg1\": %.1f}}\n",
+             "\"stage_pool_GBps\": %.1f, \"h2d_pinned_GBps\": %.1f, \"d2h_pinned_GBps\": %.1f, \"loadavg1\": %.1f, "
+             "\"numa_balancing\": %d}}\n",
              dg.hardware_threads, dg.affinity_cpus, dg.copy_threads, dg.pack_threads, dg.thp, dg.gpu_numa_node, dg.buffer_numa_node,
-             dg.pinned_numa_node, dg.memcpy_one_thread, dg.stage_pool, dg.h2d_pinned, dg.d2h_pinned, dg.loadavg1);
+             dg.pinned_numa_node, dg.memcpy_one_thread, dg.stage_pool, dg.h2d_pinned, dg.d2h_pinned, dg.loadavg1,
+             numa_balancing_setting());
+    fflush(stdout);
+  }
+  {  // Is the link ours yet?  As bench.py's child this tool starts right after the parent released ~100 GB of device memory; on
+     // one run in six the first mode then ran at 8.7 GB/s of DMA (351 gene-sets/s in round 5's driver run, 349 in one of this
+     // round's) while the second mode, seconds later, ran at the link's rate — the copies share the SDMA engines with whatever
+     // the driver does to freed VRAM.  So: measure the pinned -> device rate until two measurements in a row reach 45 GB/s (at
+     // most 12 tries of ~0.3 s), and print the series — a slow start is then visible instead of folded into the first mode.
+    printf("{\"link_settle\": {\"h2d_pinned_GBps_series\": [");
+    int good = 0;
+    const double t_s = now();
+    for (int k = 0; k < 12 && good < 2; ++k) {
+      rvt_host_diag dg;
+      if (rvt_host_diagnose(ctx, &dg) != 0) break;
+      printf("%s%.1f", k ? ", " : "", dg.h2d_pinned);
+      good = dg.h2d_pinned >= 45.0 ? good + 1 : 0;
+    }
+    printf("], \"seconds\": %.2f}}\n", now() - t_s);
     fflush(stdout);
   }
   rvt_params prm{1.0, 25.0, 1.0, 25.0, 0, 0.05};
@@ -105,6 +163,7 @@ int main(int argc, char** argv) {
     const int n_timed = (mode == "fp64") ? genes / 8 : genes;
     double t0 = 0, in_submit = 0;
     long long done = 0;
+    VmSnap vm0;
     for (int g = -window; g < n_timed; ++g) {  // one untimed window first
       if (g == 0) {
         int n = 0;
@@ -112,6 +171,7 @@ int main(int argc, char** argv) {
         t0 = now();
         in_submit = 0;
         done = 0;
+        vm0 = vm_snap();
       }
       const unsigned char* b = buf[(g + window) % K].data();
       const double ts = now();
@@ -145,10 +205,16 @@ int main(int argc, char** argv) {
       done += n;
     }
     const double dt = now() - t0;
+    const VmSnap vm1 = vm_snap();
     printf("{\"mode\": \"%s%s\", \"N\": %lld, \"M\": %d, \"genes\": %lld, \"gene_sets_per_s\": %.1f, \"host_GBps\": %.2f, "
-           "\"caller_us_per_gene\": %.1f, \"caller\": \"C++, one thread, %s\"}\n",
+           "\"caller_us_per_gene\": %.1f, \"caller\": \"C++, one thread, %s\", \"during\": {\"numa_hint_faults\": %lld, "
+           "\"numa_pages_migrated\": %lld, \"pgmigrate_success\": %lld, \"thp_collapse_alloc\": %lld, \"minor_faults\": %ld, "
+           "\"major_faults\": %ld, \"voluntary_ctx_switches\": %ld, \"involuntary_ctx_switches\": %ld}}\n",
            mode.c_str(), registered ? "_registered" : "", N, M, done, done / dt, (double)bytes * done / dt / 1e9,
-           1e6 * in_submit / n_timed, batch > 1 ? "rvt_submit_genes (batched)" : "rvt_submit_gene_* per gene");
+           1e6 * in_submit / n_timed, batch > 1 ? "rvt_submit_genes (batched)" : "rvt_submit_gene_* per gene",
+           vm1.hint_faults - vm0.hint_faults, vm1.pages_migrated - vm0.pages_migrated, vm1.pgmigrate - vm0.pgmigrate,
+           vm1.thp_collapse - vm0.thp_collapse, vm1.minflt - vm0.minflt, vm1.majflt - vm0.majflt, vm1.nvcsw - vm0.nvcsw,
+           vm1.nivcsw - vm0.nivcsw);
     fflush(stdout);
     if (registered)
       for (int k = 0; k < K; ++k) rvt_host_unregister(ctx, buf[k].data());
