@@ -23,42 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "band_tiles.h"
 #include "rot_gemm.hip.h"
 
 namespace rvt {
-
-constexpr int kBandBT = 256;  // tile edge: heads x markers
-
-// column tiles of row panel rp: the markers [256 rp, min(W, 256 rp + 256 + halo))
-__host__ __device__ inline int band_panel_tiles(int rp, int W, int halo) {
-  const long long lo = (long long)rp * kBandBT;
-  long long hi = lo + kBandBT + halo;
-  if (hi > W) hi = W;
-  return hi > lo ? (int)((hi - lo + kBandBT - 1) / kBandBT) : 0;
-}
-inline int band_tiles(int H, int W, int halo) {
-  int n = 0;
-  for (int rp = 0; rp < (H + kBandBT - 1) / kBandBT; ++rp) n += band_panel_tiles(rp, W, halo);
-  return n;
-}
-// K slices (a multiple of 8): the count that minimises rounds x (chunks per slice + 10), a round being the 32 workgroups an
-// XCD holds at once (one workgroup of 128 KB LDS per CU) and 10 chunks what a workgroup spends besides its K loop (pipeline
-// fill, the 256 KB partial tile it writes and band_finish reads again) — fitted on N = 500 000: 6 / 20 / 52 tiles run fastest
-// with 32-40 / 24 / 24 slices, 64 slices cost 10-20 % more; slices of at least 16 chunks; the partial tiles of all slices must
-// fit `max_part_bytes`
-inline long long band_slices(int n_tiles, long long chunks, size_t max_part_bytes) {
-  long long best = 8, best_cost = -1;
-  for (long long k = 1; k <= 16; ++k) {
-    if (k > 1 && chunks / (8 * k) < 16) break;
-    if (k > 1 && (size_t)n_tiles * (size_t)(8 * k) * (size_t)kBandBT * kBandBT * sizeof(int) > max_part_bytes) break;
-    const long long rounds = ((long long)n_tiles * k + 31) / 32, cost = rounds * ((chunks + 8 * k - 1) / (8 * k) + 10);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      best = 8 * k;
-    }
-  }
-  return best;
-}
 
 // R: the int8 columns, [physical column][ldk] (ldk a multiple of 128, pad rows zero).  part: [slice][tile][256][256] int32.
 // grid = 8 * n_tiles * ceil(n_slices / 8) workgroups of 512 threads.

@@ -24,11 +24,7 @@ __global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, cons
     for (int k = 0; k < d; ++k) t += xz[(long long)h * d + k] * cc.zzinv[k * d + threadIdx.x];
     a[threadIdx.x] = t;
   }
-  if (threadIdx.x == 64) {
-    int t0 = 0;
-    for (int rp = 0; rp < (h >> 8); ++rp) t0 += band_panel_tiles(rp, W, halo);
-    tile0 = t0;
-  }
+  if (threadIdx.x == 64) tile0 = band_tile_of(h, h, W, halo);  // (the panel's diagonal tile; marker j adds (j >> 8) - (h >> 8))
   __syncthreads();
   const double sh = cs[h];
   const long long row = (long long)h * (halo + 1);

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include "band_tiles.h"    // gemm_f64_tiles, gemm_f64_panel_last
 #include "rot_gemm.hip.h"  // rot_lds_off, rot_wait_vm_barrier
 
 namespace rvt {
@@ -33,6 +34,7 @@ typedef double gd2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kGemmWM = 2, kGemmWN = 2, kGemmTM = 8, kGemmTN = 4;         // 4 waves, 128 x 64 outputs each
 constexpr int kGemmBM = 16 * kGemmWM * kGemmTM, kGemmBN = 16 * kGemmWN * kGemmTN;   // 256 x 128
+static_assert(kGemmBM == kGemmTileM && kGemmBN == kGemmTileN, "band_tiles.h enumerates 256 x 128 tiles");
 constexpr int kGemmKC = 16;                                               // samples per chunk (128 bytes per row)
 constexpr int kGemmThreads = 64 * kGemmWM * kGemmWN;
 
@@ -42,22 +44,7 @@ constexpr int kGemmThreads = 64 * kGemmWM * kGemmWN;
 // 16, pad rows zero).  Slice s covers samples [s kslice, (s + 1) kslice) and writes C + s c_slice; C[m + j ldc].
 // symmetric: A and B are the same columns — tiles entirely below the diagonal are skipped (their C entries are not written).
 // n_tiles = the tiles that are computed (gemm_f64_tiles); grid = 8 * n_tiles * ceil(n_slices / 8), see the index map.
-// tiles of an M x Ntot product that are computed
-// (halo >= 0, symmetric only: a BAND — row m needs the columns m .. m + halo; row panel rp then ends at the column tile that
-//  holds column rp BM + BM - 1 + halo)
-__host__ __device__ inline int gemm_f64_panel_last(int rp, int n_col_tiles, int halo) {
-  if (halo < 0) return n_col_tiles;
-  const long long l = ((long long)rp * kGemmBM + kGemmBM + halo + kGemmBN - 1) / kGemmBN;
-  return l < n_col_tiles ? (int)l : n_col_tiles;
-}
-inline int gemm_f64_tiles(int M, int Ntot, bool symmetric, int* n_col_tiles, int halo = -1) {
-  const int nrp = (M + kGemmBM - 1) / kGemmBM, nct = (Ntot + kGemmBN - 1) / kGemmBN;
-  *n_col_tiles = nct;
-  if (!symmetric) return nrp * nct;
-  int n = 0;
-  for (int rp = 0; rp < nrp; ++rp) n += std::max(0, gemm_f64_panel_last(rp, nct, halo) - (rp * kGemmBM) / kGemmBN);
-  return n;
-}
+// (the tiles of an M x Ntot product that are computed: gemm_f64_tiles, band_tiles.h)
 // K slices (a multiple of 8: XCD x takes every 8th slice): the count that minimises rounds x chunks per workgroup, a round
 // being the 32 workgroups an XCD holds at once; slices of at least 64 chunks
 inline long long gemm_f64_slices(int n_tiles, long long chunks) {

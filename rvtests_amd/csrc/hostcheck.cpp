@@ -11,6 +11,7 @@
 #include <vector>
 #include <chrono>
 #include "host_stage.h"
+#include "band_tiles.h"
 #include "perm_counter.h"
 #include "rvt_pvalue.h"
 #include "rvt_mvn.h"
@@ -367,6 +368,45 @@ int hc_stage_copy2d(size_t width, size_t rows, size_t spitch, size_t dpitch, siz
       if (dev[r * dpitch + b] != want) return 2;
     }
   return 0;
+}
+
+// ---- band_tiles.h: the tile lists of MetaCov's band products ---------------------------------------------------------------------
+// the integer band (256 x 256 tiles): number of tiles; with out != null, out[3 t .. 3 t + 2] = row panel, column tile (in tiles of
+// the window), index within the panel, in the order the kernels enumerate them
+int hc_band_tiles(int H, int W, int halo, int* out) {
+  const int n = rvt::band_tiles(H, W, halo);
+  if (out) {
+    int t = 0;
+    for (int rp = 0; rp < (H + rvt::kBandBT - 1) / rvt::kBandBT; ++rp)
+      for (int k = 0; k < rvt::band_panel_tiles(rp, W, halo); ++k, ++t) {
+        out[3 * t] = rp;
+        out[3 * t + 1] = rp + k;
+        out[3 * t + 2] = k;
+      }
+  }
+  return n;
+}
+int hc_band_tile_of(int h, int j, int W, int halo) { return rvt::band_tile_of(h, j, W, halo); }
+long long hc_band_slices(int n_tiles, long long chunks, long long max_part_bytes) {
+  return rvt::band_slices(n_tiles, chunks, (size_t)max_part_bytes);
+}
+// the fp64 product (256 x 128 tiles): number of tiles computed; out[2 t], out[2 t + 1] = row panel, column tile
+int hc_gemm_f64_tiles(int M, int Ntot, int symmetric, int halo, int* out) {
+  int nct = 0;
+  const int n = rvt::gemm_f64_tiles(M, Ntot, symmetric != 0, &nct, halo);
+  if (out) {
+    int t = 0;
+    const int nrp = (M + rvt::kGemmTileM - 1) / rvt::kGemmTileM;
+    for (int rp = 0; rp < nrp; ++rp) {
+      const int first = symmetric ? (rp * rvt::kGemmTileM) / rvt::kGemmTileN : 0;
+      const int last = symmetric ? rvt::gemm_f64_panel_last(rp, nct, halo) : nct;
+      for (int ct = first; ct < last; ++ct, ++t) {
+        out[2 * t] = rp;
+        out[2 * t + 1] = ct;
+      }
+    }
+  }
+  return n;
 }
 
 // pack_column_f64 with a chosen instruction set (0 scalar, 1 AVX2, 2 AVX-512; an ISA the CPU lacks falls back to scalar):
