@@ -348,6 +348,12 @@ int rvt_cov_rect(rvt_ctx* ctx, const double* dG, int col0, int H, int W, double*
  * written by DMA when it lies inside a range registered with rvt_host_register.  Synchronous. */
 int rvt_cov_band(rvt_ctx* ctx, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
                  double* xz, double* zz, int* polymorphic);
+/* Which product the last rvt_cov_band call of this context took (tests, tools): 0 the fp64 matrix cores (dosages, a binary
+ * trait, columns the engine knows nothing about that turned out not to be hard calls); 1 the MXFP4 band on the column cache
+ * (hard calls only); 4 the MXFP4 band of MEAN-IMPUTED hard calls — every column 0 / 1 / 2 plus at most one other value known
+ * from its packed upload: four exact integer products combined with the other values in fp64; 2 the MXFP4 band on a copy
+ * made inside the call (no cache); 11 / 12 the same on the int8 instruction (RVT_BAND_INT8=1); -1 no call yet. */
+int rvt_cov_band_last_path(rvt_ctx* ctx);
 /* ---- MetaScore: single-variant score statistics (unrelated samples) ----------------------------------------------
  * Replaces the per-variant body of MetaScoreTest::fit for MetaUnrelatedQtl / MetaUnrelatedBinary
  * (src/Model.h:3246-3258 -> 3516-3549 / 3706-3769), i.e. LinearRegressionScoreTest::TestCovariate

@@ -28,7 +28,7 @@
 
 namespace rvt {
 
-// R: the int8 columns, [physical column][ldk] (ldk a multiple of 128, pad rows zero).  part: [slice][tile][256][256] int32.
+// RA, RB: the int8 columns, [physical column][ldk] (ldk a multiple of 128, pad rows zero).  part: [slice][tile][256][256] int32.
 // grid = 8 * n_tiles * ceil(n_slices / 8) workgroups of 512 threads.
 //
 // FP4 = true: the columns are stored as 4-bit E2M1 codes, two genotypes per byte (0 -> 0x0, 1 -> 0x2 = 1.0, 2 -> 0x4 = 2.0:
@@ -41,10 +41,13 @@ namespace rvt {
 typedef float f16v_t __attribute__((ext_vector_type(16)));
 typedef int i8v_t __attribute__((ext_vector_type(8)));
 template <int WM, int WN, int TM, int TN, int NST, int KC, bool FP4 = false>
-__global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int8_t* __restrict__ R, long long ldk, int ring,
+__global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int8_t* __restrict__ RA,
+                                                                        const int8_t* __restrict__ RB, long long ldk, int ring,
                                                                         int col0, int H, int W, int halo, long long kbytes0,
                                                                         long long kslice, int n_slices, int n_tiles,
                                                                         int* __restrict__ part) {
+  // RA / RB: the column stores the HEAD side and the MARKER side of a tile are read from — the same store for the plain band;
+  // the hard-call parts and the other-value masks of mean-imputed columns in any of the four combinations (band_rows.hip.h)
   constexpr int kWaves = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(BM == kBandBT && BN == kBandBT, "band tiles are 256 x 256");
   static_assert(KC == 128, "a stage holds 128 bytes of K per row");
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void band_gemm_i8_kernel(const int
     if (L >= W) L = W - 1;                      // (rows beyond the window read a valid column; their outputs are never used)
     long long phys = (long long)col0 + L;
     if (ring > 0 && phys >= ring) phys -= ring;
-    gsrc[q] = R + phys * ldk + k_off + seg * 16;
+    gsrc[q] = (r < BM ? RA : RB) + phys * ldk + k_off + seg * 16;
   }
   auto stage = [&](int buf, long long kc) {
 #pragma unroll

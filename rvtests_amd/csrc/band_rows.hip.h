@@ -11,11 +11,17 @@ namespace rvt {
 // cs / xz: column sums and covXZ rows of the pass's columns (index 0 = the pass's first head).
 // band_f32 (optional): (float)value * scale, the number the adapter prints with %g (src/Model.cpp:975-984 casts to float and
 // divides by N in float); band_f64 (optional): the value itself.  Entries beyond the window (h + t >= W) are NaN.
+// mu != null (round 6): some columns are hard calls plus ONE other value (g = h + mu m, mu[j] = 0 for a column without one);
+// `part` then holds FOUR sets of partial tiles, set_stride ints apart — h'h, h'm, m'h, m'm (head side first) — and
+//   S(h, j) = h_h'h_j + mu_j h_h'm_j + mu_h m_h'h_j + mu_h mu_j m_h'm_j,
+// four exact integers combined in fp64 (three roundings; the fp64 product of the doubles themselves rounds N times).
 __global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, const int* __restrict__ part, int n_slices,
                                                               int n_tiles, const double* __restrict__ cs,
                                                               const double* __restrict__ xz, int H, int W, int halo,
                                                               float scale, float* __restrict__ band_f32,
-                                                              double* __restrict__ band_f64) {
+                                                              double* __restrict__ band_f64,
+                                                              const double* __restrict__ mu = nullptr,
+                                                              long long set_stride = 0) {
   const int h = blockIdx.x, d = cc.d;
   __shared__ double a[RVT_MAX_COV];
   __shared__ int tile0;
@@ -34,6 +40,7 @@ __global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, cons
   for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const int j0 = jbeg + 4 * g;
     long long s[4] = {0, 0, 0, 0};
+    double sm[4] = {0.0, 0.0, 0.0, 0.0};  // (masked columns: the three mixed products, already weighted by the mu's)
     if (j0 < W) {
       const int tile = tile0 + (j0 >> 8) - (h >> 8);
       const i4v_t* p = reinterpret_cast<const i4v_t*>(part + ((long long)tile << 16) + (h & 255) * kBandBT + (j0 & 255));
@@ -44,6 +51,28 @@ __global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, cons
         s[2] += v[2];
         s[3] += v[3];
       }
+      if (mu) {
+        long long hm[4] = {0, 0, 0, 0}, mh[4] = {0, 0, 0, 0}, mm[4] = {0, 0, 0, 0};
+        const i4v_t* p1 = reinterpret_cast<const i4v_t*>(reinterpret_cast<const int*>(p) + set_stride);
+        const i4v_t* p2 = reinterpret_cast<const i4v_t*>(reinterpret_cast<const int*>(p) + 2 * set_stride);
+        const i4v_t* p3 = reinterpret_cast<const i4v_t*>(reinterpret_cast<const int*>(p) + 3 * set_stride);
+        for (int sl = 0; sl < n_slices; ++sl) {
+          const long long o = ((long long)sl * n_tiles) << 14;
+          const i4v_t a1 = p1[o], a2 = p2[o], a3 = p3[o];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hm[e] += a1[e];
+            mh[e] += a2[e];
+            mm[e] += a3[e];
+          }
+        }
+        const double muh = mu[h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double muj = (j0 + e < W) ? mu[j0 + e] : 0.0;
+          sm[e] = muj * (double)hm[e] + muh * (double)mh[e] + (muh * muj) * (double)mm[e];
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -51,7 +80,7 @@ __global__ __launch_bounds__(256) void band_finish_i32_kernel(CovConsts cc, cons
       if (t < 0 || t > halo) continue;
       double v = NAN;
       if (j < W) {
-        const double sxx = (double)s[e];
+        const double sxx = mu ? (double)s[e] + sm[e] : (double)s[e];
         const double xx = cc.binary ? sxx : (sxx - sh * cs[j] * cc.inv_n) * cc.inv_sigma2;
         double quad = 0.0;
         for (int k = 0; k < d; ++k) quad += a[k] * xz[(long long)j * d + k];
@@ -108,13 +137,15 @@ __global__ __launch_bounds__(256) void band_rows_f64_kernel(CovConsts cc, const 
 // (col0 + j) mod ring
 __global__ void band_cache_gather_kernel(const double* __restrict__ cs_c, const int* __restrict__ poly_c,
                                          const double* __restrict__ T_c, int ring, int col0, int W, int d, int t_stride,
-                                         double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T) {
+                                         double* __restrict__ colsum, int* __restrict__ poly, double* __restrict__ T,
+                                         const double* __restrict__ mu_c = nullptr, double* __restrict__ mu = nullptr) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= W) return;
   long long p = (long long)col0 + j;
   if (ring > 0 && p >= ring) p -= ring;
   colsum[j] = cs_c[p];
   poly[j] = poly_c[p];
+  if (mu) mu[j] = mu_c[p];
   for (int k = 0; k < d; ++k) T[j + (long long)k * W] = T_c[p * t_stride + k];
 }
 

@@ -1182,9 +1182,14 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
                                                           const double* __restrict__ wts = nullptr,
                                                           int* __restrict__ hard_flag = nullptr, int ring = 0,
                                                           int ring_col0 = 0, unsigned char* __restrict__ out4 = nullptr,
-                                                          long long ldk4 = 0) {
+                                                          long long ldk4 = 0, const double* __restrict__ mu_known = nullptr,
+                                                          unsigned char* __restrict__ out4m = nullptr) {
   // out4 (PACK only, optional): the same hard calls as 4-bit E2M1 codes (0 -> 0x0, 1 -> 0x2, 2 -> 0x4), sample 2 i in the low
   // nibble of byte i — what the MXFP4 band product reads (band_gemm.hip.h); out8 may then be null
+  // mu_known / out4m (PACK only, optional; round 6): column j is hard calls plus ONE other value mu_known[j] (the mean that
+  // consolidate() imputed; NaN = none) — known because the column crossed PCIe as 2-bit codes.  Then out4 holds the hard-call
+  // part h (0 where the entry is mu) and out4m the mask m (code of 1 where the entry is mu): g = h + mu m, and the band of such
+  // columns is four exact integer products (h'h, h'm, m'h, m'm) combined with the mu's in fp64 (band_finish_i32_kernel)
   // ring > 0: G is the base of a block used as a ring of `ring` columns, column j of the call is the physical column
   // (ring_col0 + j) mod ring (MetaCov's circular window); the outputs (out8, part) are indexed by j
   const int c0 = blockIdx.x * kCovHcCols;
@@ -1243,12 +1248,17 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
         const double2 a = *reinterpret_cast<const double2*>(gp);
         const double2 b = *reinterpret_cast<const double2*>(gp + 2);
         const double g[4] = {a.x, a.y, b.x, b.y};
-        unsigned packed = 0;
+        unsigned packed = 0, hpacked = 0, mpacked = 0;
+        const double muc = (PACK && mu_known) ? mu_known[c0 + c] : NAN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (PACK) {
+            const bool hard = g[e] == 0.0 || g[e] == 1.0 || g[e] == 2.0;
+            const bool is_mu = !hard && g[e] == muc;  // (NaN compares false: a column without an other value)
             packed |= ((unsigned)(int)g[e] & 0xffu) << (8 * e);
-            not_hard |= !(g[e] == 0.0 || g[e] == 1.0 || g[e] == 2.0);
+            hpacked |= (hard ? ((unsigned)(int)g[e] & 0xffu) : 0u) << (8 * e);
+            mpacked |= (is_mu ? 1u : 0u) << (8 * e);
+            not_hard |= !(hard || is_mu);
           }
           s[c] += g[e];
           if (e < live) {
@@ -1260,9 +1270,14 @@ __global__ __launch_bounds__(256) void cov_hc_prep_kernel(const double* __restri
         }
         if (PACK && out8) *reinterpret_cast<unsigned*>(out8 + (long long)(c0 + c) * ldk + i) = packed;
         if (PACK && out4) {
-          // bytes 0..3 of `packed` hold g in {0, 1, 2}: code = g << 1, two codes per byte
-          const unsigned q = (packed << 1) & 0x0e0e0e0eu;
+          // bytes 0..3 of `hpacked` hold the hard-call part in {0, 1, 2}: code = value << 1, two codes per byte
+          const unsigned q = (hpacked << 1) & 0x0e0e0e0eu;
           *reinterpret_cast<unsigned short*>(out4 + (long long)(c0 + c) * ldk4 + (i >> 1)) =
+              (unsigned short)((q & 0xfu) | ((q >> 4) & 0xf0u) | ((q >> 8) & 0xf00u) | ((q >> 12) & 0xf000u));
+        }
+        if (PACK && out4m) {
+          const unsigned q = (mpacked << 1) & 0x0e0e0e0eu;
+          *reinterpret_cast<unsigned short*>(out4m + (long long)(c0 + c) * ldk4 + (i >> 1)) =
               (unsigned short)((q & 0xfu) | ((q >> 4) & 0xf0u) | ((q >> 8) & 0xf00u) | ((q >> 12) & 0xf000u));
         }
       }

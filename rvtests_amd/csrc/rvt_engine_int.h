@@ -175,6 +175,7 @@ struct rvt_ctx {
   hipStream_t copy_stream = nullptr;
   hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
+  int band_last_path = -1;       // which product the last rvt_cov_band took (rvt_cov_band_last_path)
   char* d_colpack = nullptr;     // rvt_block_upload_columns: the columns as 2-bit rows + their other values, before they are expanded
   size_t colpack_cap = 0;
   // single columns uploaded one call at a time (MetaCovTest / MetaScoreTest: one site per fit()) are packed into pinned memory
@@ -206,6 +207,8 @@ struct rvt_ctx {
     int* d_flags = nullptr;
     signed char* d_i8 = nullptr;  // [cols rounded up + a tile of slack][ldk]
     unsigned char* d_i4 = nullptr;  // [cols][ldk4]: the same hard calls as E2M1 codes, two per byte (band_gemm.hip.h, FP4)
+    unsigned char* d_m4 = nullptr;  // [cols][ldk4]: round 6 — the mask of a column's ONE other value (the imputed mean), same codes
+    double* d_mu = nullptr;         // [cols]: that other value (0 for a column without one)
     int64_t ldk4 = 0;
     bool cache_failed = false;  // the cache could not be allocated once: not retried for this block
     double* d_cs = nullptr;       // [cols] column sums
@@ -213,13 +216,15 @@ struct rvt_ctx {
     double* d_T = nullptr;        // [cols][RVT_MAX_COV]
     int64_t ldk = 0;
     uint64_t gen = 0;
-    std::vector<unsigned char> valid;
+    std::vector<unsigned char> valid;  // per column: 0 nothing known / not usable, 1 hard calls only, 2 hard calls + one other value
     void release() {
-      for (void* q : {(void*)d_flags, (void*)d_i8, (void*)d_i4, (void*)d_cs, (void*)d_poly, (void*)d_T})
+      for (void* q : {(void*)d_flags, (void*)d_i8, (void*)d_i4, (void*)d_m4, (void*)d_mu, (void*)d_cs, (void*)d_poly, (void*)d_T})
         if (q) hipFree(q);
       d_flags = nullptr;
       d_i8 = nullptr;
       d_i4 = nullptr;
+      d_m4 = nullptr;
+      d_mu = nullptr;
       d_cs = nullptr;
       d_poly = nullptr;
       d_T = nullptr;

@@ -327,7 +327,7 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
     if (itc != c->col_kind.end() && itc->second.d_i8 && itc->second.gen == c->null_gen &&
         itc->second.ldk == (N + 127) / 128 * 128 && col0 + W <= itc->second.cols && !getenv("RVT_METACOV_NO_CACHE")) {
       bool all = true;
-      for (int j = col0; j < col0 + W && all; ++j) all = itc->second.valid[(size_t)j] != 0;
+      for (int j = col0; j < col0 + W && all; ++j) all = itc->second.valid[(size_t)j] == 1;  // (2 = hard calls + an other value: MXFP4 band only)
       if (all) ckc = &itc->second;
     }
   }
@@ -407,11 +407,12 @@ static int cov_rect_impl(rvt_ctx* c, const double* dG, int col0, int H, int W, d
 // copies), else the general one (optional weights)
 static void launch_cov_prep(hipStream_t st, int d, bool pack, dim3 grid, const double* G, int64_t N, int64_t ld, int W, const double* X,
                             signed char* out8, int64_t ldk, double* part, int* bad, const double* wts, int* hard_flag, int ring,
-                            int col0, unsigned char* out4, int64_t ldk4) {
+                            int col0, unsigned char* out4, int64_t ldk4, const double* mu_known = nullptr,
+                            unsigned char* out4m = nullptr) {
   const int dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
 #define RVT_PREP(DM, PK)                                                                                                          \
   hipLaunchKernelGGL((cov_hc_prep_kernel<DM, PK>), grid, dim3(256), 0, st, G, (long long)N, (long long)ld, W, X, (long long)ld, d, \
-                     out8, (long long)ldk, part, bad, wts, hard_flag, ring, col0, out4, (long long)ldk4)
+                     out8, (long long)ldk, part, bad, wts, hard_flag, ring, col0, out4, (long long)ldk4, mu_known, out4m)
   if (pack) {
     if (dmax == 4) RVT_PREP(4, true);
     else if (dmax == 8) RVT_PREP(8, true);
@@ -427,7 +428,9 @@ static void launch_cov_prep(hipStream_t st, int d, bool pack, dim3 grid, const d
 // ---- MetaCov on a circular ring: the band of a sliding window ----------------------------------------------------------------
 // flags of the W logical columns of a ring (physical (col0 + j) mod ring): 1 = every column holds hard calls only, 0 = some
 // column holds something else, -1 = nothing known about the block
-static int ring_hard_calls(rvt_ctx* c, const double* dG, int ring, int col0, int W) {
+// (masked_ok: the block's per-column cache states — a column in state 2, hard calls plus ONE other value known from its packed
+//  upload, counts as usable although its content flag says "not hard calls only")
+static int ring_hard_calls(rvt_ctx* c, const double* dG, int ring, int col0, int W, const unsigned char* masked_ok = nullptr) {
   if (!c->hc_enabled) return 0;
   auto it = c->col_kind.find(dG);
   const int span = ring > 0 ? ring : col0 + W;
@@ -439,7 +442,7 @@ static int ring_hard_calls(rvt_ctx* c, const double* dG, int ring, int col0, int
   for (int j = 0; j < W; ++j) {
     int p = col0 + j;
     if (ring > 0 && p >= ring) p -= ring;
-    if (!f[(size_t)p]) return 0;
+    if (!f[(size_t)p] && !(masked_ok && masked_ok[(size_t)p] == 2)) return 0;
   }
   return 1;
 }
@@ -468,13 +471,42 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
   rc = cov_constants(c, false, &cc, &zzv);
   if (rc) return rc;
   const int ringk = (ring > 0 && col0 + W > ring) ? ring : 0;   // (a window that does not wrap is a linear range)
-  const bool fast = allow_fast && !nc.binary && ring_hard_calls(c, dG, ring, col0, W) != 0 && !getenv("RVT_METACOV_FP64");
+  // what the product reads: the columns' hard calls as E2M1 codes, two per byte, on the MXFP4 matrix instruction (exact, see
+  // band_gemm.hip.h; RVT_BAND_INT8=1: one byte per genotype on the int8 one)
+  const bool fp4 = !getenv("RVT_BAND_INT8");
+  // the ring's own column cache (rvt_block_upload_columns made it behind the uploads): usable when every column of the window
+  // has an entry made under THIS null model — state 1 hard calls only, state 2 hard calls plus one other value (MXFP4 only)
+  const rvt_ctx::ColKind* ckc = nullptr;
+  bool masked = false;
+  {
+    auto itc = c->col_kind.find(dG);
+    if (itc != c->col_kind.end() && itc->second.d_i8 && itc->second.gen == c->null_gen &&
+        itc->second.ldk == (N + 127) / 128 * 128 && !getenv("RVT_METACOV_NO_CACHE") && (!fp4 || itc->second.d_i4)) {
+      bool all = true;
+      for (int j = 0; j < W && all; ++j) {
+        int p = col0 + j;
+        if (ring > 0 && p >= ring) p -= ring;
+        const unsigned char v = itc->second.valid[(size_t)p];
+        all = v != 0 && (v == 1 || (fp4 && itc->second.d_m4));
+        masked = masked || v == 2;
+      }
+      if (all) ckc = &itc->second;
+      else masked = false;
+    }
+  }
+  const bool fast = allow_fast && !nc.binary && !getenv("RVT_METACOV_FP64") &&
+                    ring_hard_calls(c, dG, ring, col0, W, (ckc && masked) ? ckc->valid.data() : nullptr) != 0;
+  if (!fast) {
+    ckc = nullptr;
+    masked = false;
+  }
+  c->band_last_path = !fast ? 0 : (masked ? 4 : (ckc ? (fp4 ? 1 : 11) : (fp4 ? 2 : 12)));
   // heads per pass: the rectangle of doubles (fp64) of a pass stays within a few hundred MB; the integer band in passes of 1 024
   // so that the rows of one pass cross PCIe while the next pass multiplies (two band buffers, the copies on copy_stream)
   int Hc = 1024;
   if (const char* e = getenv("RVT_BAND_PASS")) Hc = std::max(256, atoi(e) / 256 * 256);
   const int Hp = std::min(H, Hc), Wp = (int)std::min<long long>(W, (long long)Hp + halo);
-  double *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_tmp = nullptr, *d_S = nullptr;
+  double *d_T = nullptr, *d_cs = nullptr, *d_xz = nullptr, *d_tmp = nullptr, *d_S = nullptr, *d_mu_l = nullptr;
   float* d_band = nullptr;
   int* d_poly = nullptr;
   {
@@ -483,7 +515,7 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
     const size_t bM = up(sizeof(double) * (size_t)kCovSlices * W * (RVT_MAX_COV + 3));
     const size_t bB = 2 * up(sizeof(float) * (size_t)Hp * ((size_t)halo + 1));
     const size_t bS = fast ? 0 : up(sizeof(double) * (size_t)Hp * Wp);
-    const size_t need = 2 * bT + bV + bP + bM + bB + bS;
+    const size_t need = 2 * bT + 2 * bV + bP + bM + bB + bS;
     if (c->cov_work_cap < need) {
       if (c->d_cov_work) hipFree(c->d_cov_work);
       c->d_cov_work = nullptr;
@@ -497,6 +529,8 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
     d_xz = reinterpret_cast<double*>(q);
     q += bT;
     d_cs = reinterpret_cast<double*>(q);
+    q += bV;
+    d_mu_l = reinterpret_cast<double*>(q);
     q += bV;
     d_poly = reinterpret_cast<int*>(q);
     q += bP;
@@ -513,32 +547,15 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
   const int pcol0 = ringk ? col0 : 0;
   int* d_bad = nullptr;
   int h_bad = 0;
-  // the ring's own column cache (rvt_block_upload_columns made it behind the PCIe copies)
-  const rvt_ctx::ColKind* ckc = nullptr;
-  if (fast) {
-    auto itc = c->col_kind.find(dG);
-    if (itc != c->col_kind.end() && itc->second.d_i8 && itc->second.gen == c->null_gen &&
-        itc->second.ldk == (N + 127) / 128 * 128 && !getenv("RVT_METACOV_NO_CACHE")) {
-      bool all = true;
-      for (int j = 0; j < W && all; ++j) {
-        int p = col0 + j;
-        if (ring > 0 && p >= ring) p -= ring;
-        all = itc->second.valid[(size_t)p] != 0;
-      }
-      if (all) ckc = &itc->second;
-    }
-  }
-  // what the product reads: the columns' hard calls as E2M1 codes, two per byte, on the MXFP4 matrix instruction (exact, see
-  // band_gemm.hip.h; RVT_BAND_INT8=1: one byte per genotype on the int8 one), their ring and first column
-  const bool fp4 = !getenv("RVT_BAND_INT8");
+  // (the store the product reads, its ring and first column)
   const int8_t* R8 = nullptr;
   int r8_ring = 0, r8_col0 = 0;
   const int64_t ldk8 = (N + 127) / 128 * 128, ldk4 = ((N + 1) / 2 + 127) / 128 * 128;
   int64_t ldk = fp4 ? ldk4 : ldk8;
-  if (fast && ckc && fp4 && !ckc->d_i4) ckc = nullptr;  // (a cache made without the 4-bit copy)
   if (fast && ckc) {
     hipLaunchKernelGGL(band_cache_gather_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, ckc->d_cs, ckc->d_poly,
-                       ckc->d_T, ringk, col0, W, d, RVT_MAX_COV, d_cs, d_poly, d_T);
+                       ckc->d_T, ringk, col0, W, d, RVT_MAX_COV, d_cs, d_poly, d_T, masked ? ckc->d_mu : (const double*)nullptr,
+                       masked ? d_mu_l : (double*)nullptr);
     R8 = fp4 ? reinterpret_cast<const int8_t*>(ckc->d_i4) : reinterpret_cast<const int8_t*>(ckc->d_i8);
     r8_ring = ringk;
     r8_col0 = col0;
@@ -585,7 +602,8 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
     if (fast) {
       const int n_tiles = band_tiles(nh, wsub, halo);
       const int64_t kbytes = ldk, chunks = kbytes / kRotKC;
-      int64_t nsl = band_slices(n_tiles, chunks, (size_t)3 << 30);
+      const int n_sets = masked ? 4 : 1;  // (mean-imputed columns: h'h, h'm, m'h, m'm)
+      int64_t nsl = band_slices(n_tiles, chunks, ((size_t)3 << 30) / (size_t)n_sets);
       if (const char* e = getenv("RVT_BAND_SLICES"))
         if (atoll(e) > 0) nsl = atoll(e);
       int64_t kslice = ((chunks + nsl - 1) / nsl) * kRotKC;
@@ -593,7 +611,8 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
       // i.e. at most 2^22 samples = 2^21 bytes of E2M1 codes per slice
       if (fp4) kslice = std::min<int64_t>(kslice, (int64_t)1 << 21);
       nsl = (kbytes + kslice - 1) / kslice;
-      const size_t need = sizeof(int) * (size_t)n_tiles * (size_t)nsl * kBandBT * kBandBT;
+      const long long set_stride = (long long)n_tiles * (long long)nsl * kBandBT * kBandBT;
+      const size_t need = sizeof(int) * (size_t)set_stride * (size_t)n_sets;
       if (c->rot_part_cap < need) {
         if (c->d_rot_part) hipFree(c->d_rot_part);
         c->d_rot_part = nullptr;
@@ -606,14 +625,24 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
       if (r8_ring > 0 && pc >= r8_ring) pc -= r8_ring;
       const int pr = (r8_ring > 0 && pc + wsub > r8_ring) ? r8_ring : 0;
       const unsigned grid = (unsigned)(8 * (int64_t)n_tiles * ((nsl + 7) / 8));
-      if (fp4)
-        hipLaunchKernelGGL(band_gemm_fp4, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
+      if (masked) {
+        const int8_t* Hs = reinterpret_cast<const int8_t*>(ckc->d_i4);
+        const int8_t* Ms = reinterpret_cast<const int8_t*>(ckc->d_m4);
+        const int8_t* sideA[4] = {Hs, Hs, Ms, Ms};
+        const int8_t* sideB[4] = {Hs, Ms, Hs, Ms};
+        for (int k = 0; k < 4; ++k)
+          hipLaunchKernelGGL(band_gemm_fp4, dim3(grid), dim3(kBandThreads), 0, st, sideA[k], sideB[k], (long long)ldk, pr, pc, nh, wsub,
+                             halo, (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part + (size_t)k * (size_t)set_stride);
+      } else if (fp4) {
+        hipLaunchKernelGGL(band_gemm_fp4, dim3(grid), dim3(kBandThreads), 0, st, R8, R8, (long long)ldk, pr, pc, nh, wsub, halo,
                            (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
-      else
-        hipLaunchKernelGGL(band_gemm_i8, dim3(grid), dim3(kBandThreads), 0, st, R8, (long long)ldk, pr, pc, nh, wsub, halo,
+      } else {
+        hipLaunchKernelGGL(band_gemm_i8, dim3(grid), dim3(kBandThreads), 0, st, R8, R8, (long long)ldk, pr, pc, nh, wsub, halo,
                            (long long)kbytes, (long long)kslice, (int)nsl, n_tiles, d_part);
+      }
       hipLaunchKernelGGL(band_finish_i32_kernel, dim3((unsigned)nh), dim3(256), 0, st, cc, d_part, (int)nsl, n_tiles, d_cs + h0,
-                         d_xz + (size_t)h0 * d, nh, wsub, halo, scale, d_band, (double*)nullptr);
+                         d_xz + (size_t)h0 * d, nh, wsub, halo, scale, d_band, (double*)nullptr,
+                         masked ? d_mu_l + h0 : (const double*)nullptr, set_stride);
     } else {
       // dosages, a binary trait's weights: the band tiles of S = G_H' D G_W on the fp64 matrix cores (gemm_f64.hip.h)
       const double* wts = nc.binary ? c->d_v : nullptr;
@@ -642,6 +671,7 @@ static int cov_band_impl(rvt_ctx* c, const double* dG, int ring, int col0, int H
   if (zz) std::memcpy(zz, zzv.data(), sizeof(double) * (size_t)d * d);
   return RVT_OK;
 }
+int rvt_cov_band_last_path(rvt_ctx* c) { return c ? c->band_last_path : -1; }
 int rvt_cov_band(rvt_ctx* c, const double* dG, int ring_cols, int col0, int H, int W, int halo, float scale, float* band,
                  double* xz, double* zz, int* polymorphic) {
   return cov_band_impl(c, dG, ring_cols, col0, H, W, halo, scale, band, xz, zz, polymorphic, true);
@@ -788,10 +818,12 @@ int rvt_cov_band_fam(rvt_ctx* c, const double* dG, int ring_cols, int col0, int 
 // the column cache of a block (int8 copy, E2M1 copy, sums, flags, rows of T): an optimisation — a failed allocation leaves the
 // block without one (every column invalid; the covariance calls then run their own column pass), it does not fail the call
 static void free_col_cache(rvt_ctx::ColKind& ck) {
-  for (void* q : {(void*)ck.d_i8, (void*)ck.d_i4, (void*)ck.d_cs, (void*)ck.d_poly, (void*)ck.d_T})
+  for (void* q : {(void*)ck.d_i8, (void*)ck.d_i4, (void*)ck.d_m4, (void*)ck.d_mu, (void*)ck.d_cs, (void*)ck.d_poly, (void*)ck.d_T})
     if (q) hipFree(q);
   ck.d_i8 = nullptr;
   ck.d_i4 = nullptr;
+  ck.d_m4 = nullptr;
+  ck.d_mu = nullptr;
   ck.d_cs = nullptr;
   ck.d_poly = nullptr;
   ck.d_T = nullptr;
@@ -801,11 +833,15 @@ static bool alloc_col_cache(rvt_ctx* c, rvt_ctx::ColKind& ck, int64_t ldk, int64
   const size_t cap = ((size_t)ck.cols + 255) / 256 * 256 + 256;  // (the products read whole tiles of columns)
   bool ok = hipMalloc((void**)&ck.d_i8, cap * (size_t)ldk) == hipSuccess &&
             hipMalloc((void**)&ck.d_i4, cap * (size_t)ldk4) == hipSuccess &&
+            hipMalloc((void**)&ck.d_m4, cap * (size_t)ldk4) == hipSuccess &&
+            hipMalloc((void**)&ck.d_mu, sizeof(double) * (size_t)ck.cols) == hipSuccess &&
             hipMalloc((void**)&ck.d_cs, sizeof(double) * (size_t)ck.cols) == hipSuccess &&
             hipMalloc((void**)&ck.d_poly, sizeof(int) * (size_t)ck.cols) == hipSuccess &&
             hipMalloc((void**)&ck.d_T, sizeof(double) * (size_t)ck.cols * RVT_MAX_COV) == hipSuccess;
   ok = ok && hipMemsetAsync(ck.d_i8, 0, cap * (size_t)ldk, st) == hipSuccess &&
-       hipMemsetAsync(ck.d_i4, 0, cap * (size_t)ldk4, st) == hipSuccess;
+       hipMemsetAsync(ck.d_i4, 0, cap * (size_t)ldk4, st) == hipSuccess &&
+       hipMemsetAsync(ck.d_m4, 0, cap * (size_t)ldk4, st) == hipSuccess &&
+       hipMemsetAsync(ck.d_mu, 0, sizeof(double) * (size_t)ck.cols, st) == hipSuccess;
   ck.valid.assign((size_t)ck.cols, 0);
   if (!ok) {
     (void)hipGetLastError();
@@ -845,6 +881,11 @@ static int move_col_cache(rvt_ctx* c, rvt_ctx::ColKind* t, int tc, const rvt_ctx
     if (t->d_i4 && s->d_i4)
       HIP_TRY(c, hipMemcpyAsync(t->d_i4 + (size_t)(tc + k0) * (size_t)s->ldk4, s->d_i4 + (size_t)(sc + k0) * (size_t)s->ldk4,
                                 (size_t)nk * (size_t)s->ldk4, hipMemcpyDeviceToDevice, st));
+    if (t->d_m4 && s->d_m4) {
+      HIP_TRY(c, hipMemcpyAsync(t->d_m4 + (size_t)(tc + k0) * (size_t)s->ldk4, s->d_m4 + (size_t)(sc + k0) * (size_t)s->ldk4,
+                                (size_t)nk * (size_t)s->ldk4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(t->d_mu + tc + k0, s->d_mu + sc + k0, sizeof(double) * (size_t)nk, hipMemcpyDeviceToDevice, st));
+    }
     HIP_TRY(c, hipMemcpyAsync(t->d_cs + tc + k0, s->d_cs + sc + k0, sizeof(double) * (size_t)nk, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(t->d_poly + tc + k0, s->d_poly + sc + k0, sizeof(int) * (size_t)nk, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(t->d_T + (size_t)(tc + k0) * RVT_MAX_COV, s->d_T + (size_t)(sc + k0) * RVT_MAX_COV,
@@ -916,7 +957,7 @@ int flush_col_queue(rvt_ctx* c) {
   const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
   const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
   const size_t pitch = q.pitch;
-  const size_t need = pitch * (size_t)rvt_ctx::kColQueue + sizeof(double) * (size_t)rvt_ctx::kColQueue;
+  const size_t need = pitch * (size_t)rvt_ctx::kColQueue + 2 * sizeof(double) * (size_t)rvt_ctx::kColQueue;
   if (c->colpack_cap < need) {
     HIP_TRY(c, sync_stream(c->io_stream));
     if (c->d_colpack) hipFree(c->d_colpack);
@@ -961,13 +1002,21 @@ int flush_col_queue(rvt_ctx* c) {
       const size_t part_doubles = (size_t)kCovSlices * rvt_ctx::kColQueue * (RVT_MAX_COV + 3);
       if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * part_doubles));
       const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
+      // (the columns' other values, NaN where a column has none: the pass splits g = h + mu m by them)
+      double mu_nan[rvt_ctx::kColQueue];
+      for (int k = 0; k < n; ++k) mu_nan[k] = q.hard[k] ? (double)NAN : q.mu[k];
+      double* d_mu_nan = d_mu + rvt_ctx::kColQueue;
+      rc = small_h2d(c, d_mu_nan, mu_nan, sizeof(double) * (size_t)n);
+      if (rc) return rc;
+      rc = small_h2d(c, ck.d_mu + col0, q.mu, sizeof(double) * (size_t)n);
+      if (rc) return rc;
       launch_cov_prep(st, d, true, dim3((unsigned)((n + kCovHcCols - 1) / kCovHcCols), (unsigned)slices), dG + (size_t)col0 * ld,
                       (int64_t)N, (int64_t)ld, n, c->d_X, ck.d_i8 + (size_t)col0 * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr,
-                      nullptr, 0, 0, ck.d_i4 + (size_t)col0 * (size_t)ldk4, ldk4);
+                      nullptr, 0, 0, ck.d_i4 + (size_t)col0 * (size_t)ldk4, ldk4, d_mu_nan, ck.d_m4 + (size_t)col0 * (size_t)ldk4);
       hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((n * (dmax + 3) + 255) / 256)), dim3(256), 0, st, c->d_cc_part, slices,
                          n, d, dmax, ck.d_cs + col0, ck.d_poly + col0, ck.d_T + (size_t)col0 * RVT_MAX_COV, RVT_MAX_COV);
       HIP_TRY(c, hipGetLastError());
-      for (int k = 0; k < n; ++k) ck.valid[(size_t)(col0 + k)] = (unsigned char)(q.hard[k] != 0);
+      for (int k = 0; k < n; ++k) ck.valid[(size_t)(col0 + k)] = (unsigned char)(q.hard[k] ? 1 : 2);
     }
   }
   return RVT_OK;

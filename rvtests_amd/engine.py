@@ -888,6 +888,13 @@ class Engine:
                        band.ctypes.data_as(C.POINTER(C.c_float)), _dp(xz), _dp(zz), poly.ctypes.data_as(c_int_p)))
         return band.reshape(-1)[:H * (halo + 1)].reshape(H, halo + 1), xz, zz, poly
 
+    def cov_band_last_path(self):
+        """0 fp64 product, 1 MXFP4 band on the column cache, 4 the same for mean-imputed columns (four products), 2 MXFP4 band on a
+        copy made in the call, 11 / 12 the int8 instruction (rvt_cov_band_last_path)."""
+        self.L.rvt_cov_band_last_path.restype = C.c_int
+        self.L.rvt_cov_band_last_path.argtypes = [C.c_void_p]
+        return int(self.L.rvt_cov_band_last_path(self.ctx))
+
     def cov_rect_fam(self, ptr, col0, H, W, d):
         """Family-mode heads x window rectangle (after set_kinship + fit_fam_null); d = columns of X."""
         cov = np.full((H, W), np.nan, order="F")

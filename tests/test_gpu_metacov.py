@@ -302,6 +302,7 @@ def test_cov_band_wrapped_ring_against_the_oracle(engine_factory, monkeypatch):
     ring = eng.alloc_block(cap)
     _ring_fill(eng, ring, cap, col0, G)
     band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo)
+    assert eng.cov_band_last_path() == 1                      # MXFP4 band on the column cache
     rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, 0, halo)
     assert rc == 0 and (poly == kept).all() and not poly[17] and not poly[1050]
     scale = np.nanmax(np.abs(ocov))
@@ -344,8 +345,10 @@ def test_cov_band_wrapped_ring_against_the_oracle(engine_factory, monkeypatch):
     # one byte per genotype on the int8 matrix instruction instead of E2M1 codes on the MXFP4 one: the same integers
     monkeypatch.setenv("RVT_BAND_INT8", "1")
     band_i8 = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    assert eng.cov_band_last_path() == 11
     monkeypatch.setenv("RVT_METACOV_NO_CACHE", "1")
     band_i8_nc = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    assert eng.cov_band_last_path() == 12
     monkeypatch.delenv("RVT_METACOV_NO_CACHE")
     monkeypatch.delenv("RVT_BAND_INT8")
     assert np.array_equal(band_i8, band, equal_nan=True) and np.array_equal(band_i8_nc, band, equal_nan=True)
@@ -485,3 +488,76 @@ def test_mxfp4_band_product_exact_integer_check():
     p = subprocess.run([exe, "check"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "all checks passed" in p.stdout, p.stdout + p.stderr
     assert p.stdout.count("fp4 != int8 in 0 /") == 5 and p.stdout.count("int8 0, fp4 0 of 512 wrong") == 5
+
+
+def test_cov_band_mean_imputed_columns_stay_on_the_integer_band(engine_factory, monkeypatch):
+    """What consolidate() leaves for real hard-call data: 0 / 1 / 2 plus ONE other value per column, the mean it imputed for
+    the missing calls.  Uploaded a site at a time (as MetaCovTest::fit does) such a column crosses PCIe as 2-bit codes, the
+    engine knows its other value, and the band is FOUR exact integer products on the MXFP4 instruction (h'h, h'm, m'h, m'm)
+    combined with the mu's in fp64 — against the oracle's rows, against the fp64 band of the same ring
+    (RVT_METACOV_FP64=1) to rounding, mixed with columns that have no missing call, on a ring that wraps, in two passes."""
+    N, V, d, halo, cap, col0 = 6100, 1100, 2, 180, 1200, 1150
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 8080)
+    G = np.asfortranarray(np.rint(G))
+    rng = np.random.default_rng(17)
+    n_imputed = 0
+    for j in range(V):
+        if j % 3 == 0:
+            continue                                          # a third of the columns: no missing call
+        miss = rng.random(N) < rng.choice([0.002, 0.02, 0.2])
+        if miss.any() and not miss.all():
+            G[miss, j] = G[~miss, j].mean()                   # imputeGenotypeToMean (DataConsolidator.cpp:217-245)
+            n_imputed += 1
+    G[:, 40] = 1.0                                            # monomorphic
+    miss = rng.random(N) < 0.5
+    G[miss, 41] = 0.0
+    G[~miss, 41] = G[miss, 41].mean() + 0.25                  # a column that is one hard call and one other value only
+    assert n_imputed > 600
+    chrom = np.ones(V, dtype=np.int32)
+    pos = np.arange(V, dtype=np.int32)
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ring = eng.alloc_block(cap)
+    for j in range(V):                                        # one site per call: the queued, packed upload
+        eng.upload_columns(ring, (col0 + j) % cap, G[:, j])
+    eng.set_profiling(True)
+    band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo)
+    assert eng.cov_band_last_path() == 4                      # the four-product integer band, not the fp64 one
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, 0, halo)
+    assert rc == 0 and (poly == kept).all() and not poly[40]
+    scale = np.nanmax(np.abs(ocov))
+    worst = 0.0
+    for h in range(V):
+        if not kept[h]:
+            continue
+        js = np.arange(h, min(V, h + halo + 1))
+        js = js[kept[js].astype(bool)]
+        worst = max(worst, np.abs(band[h, js - h].astype(np.float64) - ocov[h, js]).max())
+    assert worst <= 2e-7 * scale                              # (float32 band)
+    kk = kept.astype(bool)
+    assert np.allclose(xz[kk], oxz[kk], rtol=1e-9, atol=1e-9 * max(np.abs(oxz[kk]).max(), 1.0))
+    # the same ring through the fp64 band: the integer decomposition agrees to rounding — and was actually taken above
+    monkeypatch.setenv("RVT_METACOV_FP64", "1")
+    band64 = eng.cov_band(ring, cap, col0, V, V, halo)[0]
+    assert eng.cov_band_last_path() == 0
+    monkeypatch.delenv("RVT_METACOV_FP64")
+    m = ~np.isnan(band64)
+    assert np.array_equal(np.isnan(band), np.isnan(band64)) and np.abs(band[m] - band64[m]).max() <= 2e-7 * scale
+    # a window of columns without any other value inside the same ring takes the single product (bit-identical to a ring of
+    # those columns alone) — and one dosage column sends its window to the fp64 band
+    G2 = G.copy()
+    G2[5, 300] = 0.3
+    G2[6, 300] = 0.7                                          # two other values: not representable, crosses as doubles
+    eng.upload_columns(ring, (col0 + 300) % cap, G2[:, 300])
+    pure_cols = [(col0 + j) % cap for j in range(V) if j % 3 == 0]
+    b3 = eng.cov_band(ring, cap, (col0 + 200) % cap, 150, 300, halo)[0]
+    assert eng.cov_band_last_path() == 0                      # a window with a dosage column: the fp64 band
+    eng.cov_band(ring, cap, (col0 + 400) % cap, 100, 250, halo)
+    assert eng.cov_band_last_path() == 4                      # a window behind it: the integer band again
+    rc, kept2, ocov2, _, _, _ = orc.metacov(G2, chrom, pos, X, y, 0, halo)
+    for h in range(150):
+        if kept2[200 + h]:
+            js = np.arange(h, min(300, h + halo + 1))
+            js = js[kept2[200 + js].astype(bool)]
+            assert np.abs(b3[h, js - h].astype(np.float64) - ocov2[200 + h, 200 + js]).max() <= 2e-7 * scale

@@ -111,12 +111,12 @@ int main(int argc, char** argv) {
     const size_t nS = (size_t)H * (halo + 1);
     CK(hipMalloc(&S8, nS * 8)); CK(hipMalloc(&S4, nS * 8)); CK(hipMalloc(&d_bad, 8)); CK(hipMemset(d_bad, 0, 8));
     auto run8 = [&]() {
-      hipLaunchKernelGGL(band_gemm_i8, dim3((unsigned)(8 * (long long)p8.n_tiles * ((p8.nsl + 7) / 8))), dim3(kBandThreads), 0, 0, R8, ldk,
+      hipLaunchKernelGGL(band_gemm_i8, dim3((unsigned)(8 * (long long)p8.n_tiles * ((p8.nsl + 7) / 8))), dim3(kBandThreads), 0, 0, R8, R8, ldk,
                          ring, col0, H, W, halo, p8.kbytes, p8.kslice, (int)p8.nsl, p8.n_tiles, part);
     };
     auto run4 = [&]() {
       hipLaunchKernelGGL(band_gemm_fp4, dim3((unsigned)(8 * (long long)p4.n_tiles * ((p4.nsl + 7) / 8))), dim3(kBandThreads), 0, 0,
-                         (const int8_t*)R4, ldk4, ring, col0, H, W, halo, p4.kbytes, p4.kslice, (int)p4.nsl, p4.n_tiles, part);
+                         (const int8_t*)R4, (const int8_t*)R4, ldk4, ring, col0, H, W, halo, p4.kbytes, p4.kslice, (int)p4.nsl, p4.n_tiles, part);
     };
     run8();
     hipLaunchKernelGGL(band_sum, dim3((unsigned)H), dim3(256), 0, 0, part, (int)p8.nsl, p8.n_tiles, H, W, halo, S8);

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="columns of the device ring of the stream runs (default: the adapter's policy)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-blocks", action="store_true", help="only the stream runs (profiles of the window)")
+    ap.add_argument("--window-dosage", default="1000", help="window widths of the DOSAGE stream runs (the fp64 band: what columns "
+                    "with imputed means or dosages take); empty = none")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, V = a.samples, a.variants
@@ -208,6 +210,60 @@ def main():
                           "cpu_baseline": None}))
         eng.host_unregister(band)
         eng.free_block(ring)
+    # ---- the same window on columns that are NOT hard calls (dosages; also what every column with a mean-imputed entry is): the
+    # band tiles on the fp64 matrix cores (gemm_tn_f64_kernel with the ring's addressing), passes of 1 024 heads
+    if a.window_dosage:
+        dsrc = eng.alloc_block(V)
+        dh = (torch.round(blocks[0]) + (torch.round(blocks[0]) > 0) * 0.125 * torch.rand_like(blocks[0]))[:, :N].cpu().numpy()
+        for j0 in range(0, V, 64):
+            eng.upload_columns(dsrc, j0, np.asfortranarray(dh[j0:j0 + 64].T))
+        del dh
+        eng.set_content_hint(0)
+        for w in [int(x) for x in a.window_dosage.split(",") if x]:
+            cap = 4096
+            while cap < 4 * w:
+                cap *= 2
+            ring = eng.alloc_block(cap)
+            heads = cap - w
+            heads -= heads % 256
+            band = np.zeros((heads, w + 1), dtype=np.float32)
+            eng.host_register(band)
+            done = fill = nxt = head = 0
+            t_cov = 0.0
+            flushes = -1
+            while done < min(a.stream, 3 * heads):
+                while fill < cap:
+                    tail = (head + fill) % cap
+                    n = min(cap - fill, V - nxt, cap - tail)
+                    eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), tail, C.c_void_p(dsrc), nxt, n))
+                    fill += n
+                    nxt = (nxt + n) % V
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                eng.cov_band(ring, cap, head, heads, cap, w, scale=np.float32(1.0 / N), band=band)
+                t3 = time.perf_counter()
+                head = (head + heads) % cap
+                fill = cap - heads
+                if flushes < 0:
+                    flushes = 0
+                    continue
+                t_cov += t3 - t2
+                flushes += 1
+                done += heads
+            tf = 2.0 * N * done * (w + 1) / t_cov / 1e12
+            lines.append({"workload": "MetaCov sliding window, DOSAGES (fp64 band), circular device ring (rvt_cov_band)", "N": N,
+                          "window_markers": w, "ring_columns": cap, "variants": done, "flushes": flushes,
+                          "ms_per_flush": 1e3 * t_cov / flushes, "value": done * (w + 1) / t_cov, "unit": "printed covariance pairs/s",
+                          "variants_per_s": done / t_cov,
+                          "roofline": {"kernel": "gemm_tn_f64_kernel", "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                                       "note": "2 N flop per printed pair over the time of the device calls (column pass, band tiles "
+                                               "of the fp64 product, reduction of the K slices, rows, copy-back)"},
+                          "cpu_baseline": None})
+            eng.host_unregister(band)
+            eng.free_block(ring)
+        eng.set_content_hint(-1)
+        eng.free_block(dsrc)
     cpu = None if a.no_cpu else cpu_baseline(N)
     for ln in lines:
         ln["cpu_baseline"] = cpu

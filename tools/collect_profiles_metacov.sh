@@ -9,12 +9,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 tools/bench_metacov.py > "$OUT/metacov_result.txt" 2> "$OUT/metacov.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_mc" -o k -- python3 tools/bench_metacov.py --window "" --no-cpu > "$OUT/metacov_kt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_mc" -o k -- python3 tools/bench_metacov.py --window "" --window-dosage "" --no-cpu > "$OUT/metacov_kt.log" 2>&1
 find "$OUT/kt_mc" -name '*kernel_stats.csv' -exec cp {} "$OUT/metacov_kernel_stats.csv" \;
 rm -rf "$OUT/kt_mc"
 REPS=3
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mc_$C" -o p -- python3 tools/bench_metacov.py --window "" --no-cpu --reps $REPS > "$OUT/metacov_pmc_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mc_$C" -o p -- python3 tools/bench_metacov.py --window "" --window-dosage "" --no-cpu --reps $REPS > "$OUT/metacov_pmc_$C.log" 2>&1
   F=$(find "$OUT/pmc_mc_$C" -name '*counter_collection.csv' | head -1)
   python3 tools/pmc_summary.py "$F" "$OUT/metacov_pmc_$C.csv" > /dev/null
   rm -rf "$OUT/pmc_mc_$C"
