@@ -869,12 +869,12 @@ int MetaCovTest::fit(GeneData* dc) {
   if (nSample < 0) {
     nSample = dc->N;
     nCovariate = dc->ncov + 1;
-    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB; the int8 and 4-bit copies the engine keeps per column
-    // counted in: 9.5 bytes per genotype): 20 000 columns at N = 500 000
+    // the ring may grow to 96 GB of columns (RVT_METACOV_RING_GB; the int8 copy and the two 4-bit stores the engine keeps per
+    // column counted in: 10 bytes per genotype): 19 000 columns at N = 500 000
     {
       double gb = 96.0;
       if (const char* e = getenv("RVT_METACOV_RING_GB")) gb = std::max(1.0, atof(e));
-      const double cols = gb * 1e9 / (9.5 * (double)std::max<int64_t>(dc->N, 1));
+      const double cols = gb * 1e9 / (10.0 * (double)std::max<int64_t>(dc->N, 1));
       if (cols < (double)maxColumns) maxColumns = std::max(std::min(capacity, 1024), (int)cols);
       if (capacity > maxColumns) capacity = maxColumns;
     }

@@ -33,6 +33,7 @@ import bench  # noqa: E402
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # vendor figure for fp64 matrix (= 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide lists no fp64 row
 HBM_PEAK_GBS = 8000.0
+FP4_PEAK_TOPS = 10000.0          # MI355X_MICROARCH.md: FP4 MFMA ~10 PF dense (block-scaled mfma_scale_*_f8f6f4)
 
 
 def cpu_baseline(N_full, use_float=1):
@@ -54,6 +55,56 @@ def cpu_baseline(N_full, use_float=1):
             "sample": "orc.metacov (float32 storage as the reference), N=%d, V=%d, %d pairs in %.2f s, scaled by N" % (N, V, pairs, dt)}
 
 
+def stream_window(eng, src_blk, V, N, w, cap, stream):
+    """Drive the circular ring as the adapter does: fill from the resident columns of src_blk (device copies that hand on what
+    the engine keeps per uploaded column; untimed), one rvt_cov_band call per flush.  The first flush is a warm-up.
+    -> dict(done, flushes, calls, t_cov, t_fill, path)"""
+    ring = eng.alloc_block(cap)
+    heads = cap - w                                           # heads whose window is complete when the ring is full
+    if heads > 256:
+        heads -= heads % 256                                  # (whole row panels of the band kernel; the rest waits, as in flush())
+    band = np.zeros((heads, w + 1), dtype=np.float32)
+    eng.host_register(band)                                   # the band lands by DMA (the adapter registers its buffer too)
+    scale = np.float32(1.0 / N)
+    done = fill = nxt = head = 0
+    t_cov = t_fill = 0.0
+    flushes = -1
+    calls = 0
+    while done < stream:
+        t1 = time.perf_counter()
+        while fill < cap:
+            tail = (head + fill) % cap
+            n = min(cap - fill, V - nxt, cap - tail)
+            eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), tail, C.c_void_p(src_blk), nxt, n))
+            fill += n
+            nxt = (nxt + n) % V
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        eng.cov_band(ring, cap, head, heads, cap, w, scale=scale, band=band)
+        calls += 1
+        t3 = time.perf_counter()
+        head = (head + heads) % cap                           # the finished heads are dropped: the head index advances
+        fill = cap - heads
+        if flushes < 0:                                       # the first flush of a width is a warm-up (first touch of the ring)
+            flushes = calls = 0
+            continue
+        t_fill += t2 - t1
+        t_cov += t3 - t2
+        flushes += 1
+        done += heads
+    path = eng.cov_band_last_path()
+    eng.host_unregister(band)
+    eng.free_block(ring)
+    return dict(done=done, flushes=flushes, calls=calls, t_cov=t_cov, t_fill=t_fill, path=path)
+
+
+def ring_policy(w, forced=0):
+    cap = 4096
+    while cap < 4 * w:
+        cap *= 2
+    return max(forced, w + 1) if forced else cap
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=500000)
@@ -64,8 +115,10 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="columns of the device ring of the stream runs (default: the adapter's policy)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-blocks", action="store_true", help="only the stream runs (profiles of the window)")
-    ap.add_argument("--window-dosage", default="1000", help="window widths of the DOSAGE stream runs (the fp64 band: what columns "
-                    "with imputed means or dosages take); empty = none")
+    ap.add_argument("--window-imputed", default="200,1000,3000", help="window widths of the stream runs on MEAN-IMPUTED hard calls")
+    ap.add_argument("--missing-rate", type=float, default=0.01)
+    ap.add_argument("--window-dosage", default="1000", help="window widths of the DOSAGE stream runs (the fp64 band: what dosages and columns "
+                    "with more than one value besides 0 / 1 / 2 take); empty = none")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, V = a.samples, a.variants
@@ -151,46 +204,10 @@ def main():
     # 4 096 columns and doubles while a flush emits less than three quarters of it (--ring overrides the capacity).
     widths = [int(w) for w in a.window.split(",") if w]
     for w in widths:
-        cap = 4096
-        while cap < 4 * w:
-            cap *= 2
-        if a.ring:
-            cap = max(a.ring, w + 1)
-        ring = eng.alloc_block(cap)
-        heads = cap - w                                       # heads whose window is complete when the ring is full
-        if heads > 256:
-            heads -= heads % 256                              # (whole row panels of the band kernel; the rest waits, as in flush())
-        band = np.zeros((heads, w + 1), dtype=np.float32)
-        eng.host_register(band)                               # the band lands by DMA (the adapter registers its buffer too)
-        scale = np.float32(1.0 / N)
-        done = fill = nxt = head = 0
-        t_cov = t_fill = 0.0
-        flushes = -1
-        calls = 0
-        while done < a.stream:
-            # fill the ring from resident columns (the adapter uploads each site's column over PCIe; here: device copies of the
-            # columns AND of what the engine keeps per uploaded column, timed apart — input delivery is not part of the path)
-            t1 = time.perf_counter()
-            while fill < cap:
-                tail = (head + fill) % cap
-                n = min(cap - fill, V - nxt, cap - tail)
-                eng._check(eng.L.rvt_block_copy_columns(eng.ctx, C.c_void_p(ring), tail, C.c_void_p(src_blk), nxt, n))
-                fill += n
-                nxt = (nxt + n) % V
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            eng.cov_band(ring, cap, head, heads, cap, w, scale=scale, band=band)
-            calls += 1
-            t3 = time.perf_counter()
-            head = (head + heads) % cap                       # the finished heads are dropped: the head index advances
-            fill = cap - heads
-            if flushes < 0:                                   # the first flush of a width is a warm-up (first touch of the ring)
-                flushes = calls = 0
-                continue
-            t_fill += t2 - t1
-            t_cov += t3 - t2
-            flushes += 1
-            done += heads
+        cap = ring_policy(w, a.ring)
+        r = stream_window(eng, src_blk, V, N, w, cap, a.stream)
+        assert r["path"] in (1, 11), r["path"]                # the integer band on the column cache
+        done, flushes, calls, t_cov, t_fill = r["done"], r["flushes"], r["calls"], r["t_cov"], r["t_fill"]
         dt = t_cov
         npairs = done * (w + 1)
         gbs = 8.0 * N * done / dt / 1e9
@@ -208,9 +225,37 @@ def main():
                                                "per column and pass) — int8_band_TOPs = 2 N per printed pair against the 3.94 POP/s "
                                                "int8 ceiling is the figure that bounds this kernel"},
                           "cpu_baseline": None}))
-        eng.host_unregister(band)
-        eng.free_block(ring)
-    # ---- the same window on columns that are NOT hard calls (dosages; also what every column with a mean-imputed entry is): the
+    # ---- the same window on MEAN-IMPUTED hard calls — what the reference's matrices hold when a genotype is missing (the
+    # column mean in place of it: src/DataConsolidator.h imputeGenotypeToMean): columns uploaded one at a time as the adapter
+    # uploads them, so the engine knows each column's one other value; the band is four exact MXFP4 products
+    if a.window_imputed:
+        isrc = eng.alloc_block(V)
+        ih = hard[:, :N].cpu().numpy().copy()
+        rs = np.random.RandomState(11)
+        for j in range(V):
+            miss = rs.rand(N) < a.missing_rate
+            if miss.any() and not miss.all():
+                ih[j, miss] = ih[j, ~miss].mean()
+        for j in range(V):
+            eng.upload_columns(isrc, j, np.asfortranarray(ih[j:j + 1].T))
+        del ih
+        for w in [int(x) for x in a.window_imputed.split(",") if x]:
+            cap = ring_policy(w, a.ring)
+            r = stream_window(eng, isrc, V, N, w, cap, a.stream)
+            assert r["path"] == 4, r["path"]
+            tp = 4 * 2.0 * N * r["done"] * (w + 1) / r["t_cov"] / 1e12
+            lines.append({"workload": "MetaCov sliding window, MEAN-IMPUTED hard calls (four MXFP4 products), circular device ring "
+                                      "(rvt_cov_band)", "N": N, "missing_rate": a.missing_rate,
+                          "window_markers": w, "ring_columns": cap, "variants": r["done"], "flushes": r["flushes"],
+                          "ms_per_flush": 1e3 * r["t_cov"] / r["flushes"], "value": r["done"] * (w + 1) / r["t_cov"],
+                          "unit": "printed covariance pairs/s", "variants_per_s": r["done"] / r["t_cov"], "fp4_band_TOPs": tp,
+                          "roofline": {"kernel": "band_gemm_i8_kernel<FP4>", "bound": "mfma", "achieved": tp, "peak": FP4_PEAK_TOPS,
+                                       "unit": "TOP/s", "frac": tp / FP4_PEAK_TOPS, "traffic": None,
+                                       "note": "4 x 2 N operations per printed pair (h'h, h'm, m'h, m'm) over the time of the device "
+                                               "calls"},
+                          "cpu_baseline": None})
+        eng.free_block(isrc)
+    # ---- the same window on columns that are NOT hard calls (dosages): the
     # band tiles on the fp64 matrix cores (gemm_tn_f64_kernel with the ring's addressing), passes of 1 024 heads
     if a.window_dosage:
         dsrc = eng.alloc_block(V)
