@@ -274,7 +274,7 @@ def test_block_rewritten_in_place_with_dosages(engine):
 def _hip_memcpy_h2d(ptr, arr):
     """Write a host array into device memory behind the engine's back (hipMemcpy through the HIP runtime)."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL("libamdhip64.so.7")
     hip.hipMemcpy.restype = C.c_int
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     a = np.ascontiguousarray(arr.T)           # column-major bytes

@@ -390,7 +390,7 @@ def test_cov_band_wrapped_ring_fp64(engine_factory, binary):
     _ring_fill(eng, ring, cap, col0, G)
     band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo)
     rc, kept, ocov, row_end, oxz, ozz = orc.metacov(G, chrom, pos, X, y, binary, halo)
-    assert rc == 0 and (poly == kept).all() and not poly[30]
+    assert rc == 0 and (poly == kept).all() and not poly[30], (np.nonzero(poly != kept)[0], poly[poly != kept])
     scale = np.nanmax(np.abs(ocov))
     for h in range(V):
         if not kept[h]:
@@ -561,3 +561,43 @@ def test_cov_band_mean_imputed_columns_stay_on_the_integer_band(engine_factory, 
             js = np.arange(h, min(300, h + halo + 1))
             js = js[kept2[200 + js].astype(bool)]
             assert np.abs(b3[h, js - h].astype(np.float64) - ocov2[200 + h, 200 + js]).max() <= 2e-7 * scale
+
+
+def _device_read(ptr, nbytes):
+    """Read device memory behind the engine's back (hipMemcpy through the HIP runtime)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(nbytes, dtype=np.uint8)
+    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(int(ptr)), nbytes, 2) == 0
+    return out
+
+
+@pytest.mark.parametrize("ncols", [64, 5, 1])
+def test_uploaded_columns_are_what_the_block_holds(engine_factory, ncols):
+    """rvt_block_upload_columns packs the caller's columns to 2-bit codes, sends them on one stream and expands them to doubles
+    on another: uploads issued back to back — alternating between two matrices, into neighbouring column ranges, several columns
+    at once (the immediate path) or one at a time (the queue) — must each land whole.  The block is read back with hipMemcpy."""
+    N, d = 300_000, 2
+    rng = np.random.default_rng(91)
+    X = np.column_stack([np.ones(N), rng.normal(size=(N, d - 1))])
+    y = rng.normal(size=N)
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ld = eng.padded_ld(N)
+    mats = []
+    for k in range(2):
+        A = (rng.random((N, ncols)) < 0.2).astype(np.float64) + (rng.random((N, ncols)) < 0.2)
+        A[rng.random((N, ncols)) < 0.01] = 0.37 + k            # one other value per column (what an imputed mean is)
+        mats.append(np.asfortranarray(A))
+    reps = 10 if ncols > 1 else 70
+    blk = eng.alloc_block(ncols * reps)
+    for r in range(reps):
+        eng.upload_columns(blk, ncols * r, mats[r % 2])
+    eng.sync()
+    got = _device_read(blk, 8 * ld * ncols * reps).view(np.float64).reshape(ncols * reps, ld)
+    for r in range(reps):
+        assert np.array_equal(got[ncols * r:ncols * (r + 1), :N], mats[r % 2].T), r
+        assert not got[ncols * r:ncols * (r + 1), N:].any()
