@@ -549,7 +549,15 @@ def main():
         total_genes = world * args.genes * args.steps
         value = total_genes / elapsed
         out0 = batches[(args.steps - 1) % NSLOT]["out"] if args.steps else batch["out"]
-        ok = sum(1 for r in out0 if r.skat_ok and r.skato_ok)
+        T = args.tests
+        # (genes whose requested kernel tests all came back with a p-value; the flags of the line below name what was asked)
+        ok = sum(1 for r in out0 if (r.skat_ok or not T & rvtests_amd.TEST_SKAT) and (r.skato_ok or not T & rvtests_amd.TEST_SKATO))
+        kern = ",".join(n for n, b in (("skat[nPerm=0]", rvtests_amd.TEST_SKAT), ("skato", rvtests_amd.TEST_SKATO)) if T & b)
+        burd = ",".join(n for n, b in (("cmc", rvtests_amd.TEST_CMC), ("zeggini", rvtests_amd.TEST_ZEGGINI)) if T & b)
+        flags = " ".join(x for x in ("--kernel " + kern if kern else "", "--burden " + burd if burd else "") if x)
+        names = "+".join(n for n, b in (("SKAT", rvtests_amd.TEST_SKAT), ("SKAT-O", rvtests_amd.TEST_SKATO),
+                                        ("CMC", rvtests_amd.TEST_CMC), ("Zeggini", rvtests_amd.TEST_ZEGGINI)) if T & b)
+        cfg_index = 3 if binary else (1 if (N == 50000 and T == rvtests_amd.TEST_SKAT) else 2)
         # roofline of the sufficient-statistics kernel (the contraction over N): algorithmic bytes / measured time.
         # The dominant kernel is gene_suffstat_hc (hard-call blocks: ~95 % of the genes and bytes of this workload);
         # the few blocks with imputed means take the general fp64 kernel gene_suffstat_mfma, which runs BESIDE it on
@@ -597,14 +605,14 @@ def main():
                 traffic_src = os.path.basename(pmc_path)
                 break
         line = {
-            "metric": "gene-sets/sec (SKAT+SKAT-O+CMC+Zeggini, analytic p-values)",
+            "metric": "gene-sets/sec (%s, analytic p-values)" % names,
             "value": value, "unit": "gene-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: N=%d, genes/step/GPU=%d, M~U{%d..%d}, %s trait, "
-                                   "d=3, --kernel skat[nPerm=0],skato --burden cmc,zeggini; genes resident in HBM as "
-                                   "fp64 column-major blocks%s" % (3 if binary else 2, N, args.genes, args.m_lo,
-                                                                   args.m_hi, "binary" if binary else "quantitative",
+                                   "d=3, %s; genes resident in HBM as "
+                                   "fp64 column-major blocks%s" % (cfg_index, N, args.genes, args.m_lo,
+                                                                   args.m_hi, "binary" if binary else "quantitative", flags,
                                                                    (" of float-precision DOSAGES (8-bit BGEN values; stated to the engine)" if args.dosage_float else
                                                                     " of DOSAGES with three decimals (no hard-call block; lattice stated: %d)"
                                                                     % args.dosage_lattice) if args.dosage else ""),

@@ -601,3 +601,56 @@ def test_uploaded_columns_are_what_the_block_holds(engine_factory, ncols):
     for r in range(reps):
         assert np.array_equal(got[ncols * r:ncols * (r + 1), :N], mats[r % 2].T), r
         assert not got[ncols * r:ncols * (r + 1), N:].any()
+
+
+@pytest.mark.parametrize("imputed", [False, True])
+def test_cov_band_at_the_bench_size_n500k(engine_factory, monkeypatch, imputed):
+    """The window's integer band at BASELINE's sample count (N = 500 000: a K split over the whole chip, ~5 000 samples short of
+    the 2^22-sample bound of an exact fp32 slice times none — every slice sum far above what a float mantissa holds in an
+    inexact product): 300 hard-call columns (imputed: two thirds of them with 1 % of the calls replaced by the column mean)
+    uploaded a site at a time into a ring that wraps.  Three checks that do not need the oracle on all of it: the integer
+    band against the fp64 band of the same ring; 24 neighbouring columns against the ORACLE's rows on those columns alone (an
+    entry depends on its two columns and the null model only); and the heads' order / flags."""
+    N, V, d, halo, cap, col0 = 500_000, 300, 3, 120, 320, 250
+    rng = np.random.default_rng(2026)
+    X = np.column_stack([np.ones(N)] + [rng.normal(size=N) for _ in range(d - 1)])
+    maf = rng.uniform(0.002, 0.3, V)
+    G = np.empty((N, V), order="F")
+    for j in range(V):
+        G[:, j] = (rng.random(N) < maf[j]).astype(np.float64) + (rng.random(N) < maf[j])
+    y = X @ rng.normal(size=d) + 0.05 * G[:, 7] + rng.normal(size=N)
+    if imputed:
+        for j in range(V):
+            if j % 3:
+                miss = rng.random(N) < 0.01
+                G[miss, j] = G[~miss, j].mean()
+    G[:, 11] = 2.0                                            # monomorphic
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    assert rc == 0
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    ring = eng.alloc_block(cap)
+    for j in range(V):
+        eng.upload_columns(ring, (col0 + j) % cap, G[:, j])
+    scale_f = np.float32(1.0 / N)
+    band, xz, zz, poly = eng.cov_band(ring, cap, col0, V, V, halo, scale=scale_f)
+    assert eng.cov_band_last_path() == (4 if imputed else 1)
+    assert not poly[11] and poly.sum() == V - 1
+    monkeypatch.setenv("RVT_METACOV_FP64", "1")
+    band64 = eng.cov_band(ring, cap, col0, V, V, halo, scale=scale_f)[0]
+    assert eng.cov_band_last_path() == 0
+    monkeypatch.delenv("RVT_METACOV_FP64")
+    m = ~np.isnan(band64)
+    assert np.array_equal(np.isnan(band), np.isnan(band64))
+    top = np.abs(band64[m]).max()
+    assert np.abs(band[m] - band64[m]).max() <= 2e-7 * top    # (float32 rows of two fp64 computations)
+    sub = np.arange(90, 114)
+    chrom = np.ones(len(sub), dtype=np.int32)
+    pos = np.arange(len(sub), dtype=np.int32)
+    rc, kept, ocov, row_end, oxz, ozz = orc.metacov(np.asfortranarray(G[:, sub]), chrom, pos, X, y, 0, len(sub))
+    assert rc == 0 and kept.all()
+    for a, h in enumerate(sub):
+        want = ocov[a, a:] * float(scale_f)
+        got = band[h, :len(sub) - a].astype(np.float64)
+        assert np.abs(got - want).max() <= 3e-7 * np.nanmax(np.abs(ocov)) * float(scale_f)
+    assert np.allclose(xz[sub], oxz, rtol=1e-9, atol=1e-9 * max(np.abs(oxz).max(), 1.0))
