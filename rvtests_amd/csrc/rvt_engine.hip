@@ -302,6 +302,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_rot_part) hipFree(c->d_rot_part);
   if (c->d_cov_work) hipFree(c->d_cov_work);
   if (c->d_colpack) hipFree(c->d_colpack);
+  if (c->d_mu_nan) hipFree(c->d_mu_nan);
   for (int i = 0; i < 2; ++i) {
     if (c->colq.h[i]) hipHostFree(c->colq.h[i]);
     if (c->colq.ev[i]) hipEventDestroy(c->colq.ev[i]);

@@ -176,6 +176,7 @@ struct rvt_ctx {
   hipStream_t h2d_stream = nullptr;  // where staged_h2d enqueues: io_stream, or copy_stream for the packed hand-offs
   double* d_rot_part = nullptr;  // split-K partial results of the integer GEMM
   int band_last_path = -1;       // which product the last rvt_cov_band took (rvt_cov_band_last_path)
+  double* d_mu_nan = nullptr;    // packed_columns_pass: the other values of up to kColQueue columns (NaN = none)
   char* d_colpack = nullptr;     // rvt_block_upload_columns: the columns as 2-bit rows + their other values, before they are expanded
   size_t colpack_cap = 0;
   // single columns uploaded one call at a time (MetaCovTest / MetaScoreTest: one site per fit()) are packed into pinned memory

@@ -943,6 +943,57 @@ int rvt_block_copy_columns(rvt_ctx* c, double* dst, int dst_col, const double* s
   return RVT_OK;
 }
 
+// What the engine keeps per column of a block filled by rvt_block_upload_columns, for n <= kColQueue columns that crossed PCIe
+// PACKED (their content is known from the packing: hard[k] = hard calls only, otherwise hard calls plus the one other value
+// mu[k]) and have been expanded into dG on io_stream: the content flags, and under an unweighted null model the column pass
+// of MetaCov's band on these columns (int8 copy, E2M1 codes of the hard calls and of the other value's mask, sum, flag, row of
+// T) — cache state 1 / 2.
+static int packed_columns_pass(rvt_ctx* c, double* dG, int col0, int n, const double* mu, const int* hard) {
+  hipStream_t st = c->io_stream;
+  const size_t N = (size_t)(c->have_null ? c->nc.N : c->fam_nc.N);
+  const size_t ld = (size_t)(c->have_null ? c->null_ld : c->fam_nc.ld);
+  auto it = c->col_kind.find(dG);
+  if (it == c->col_kind.end() || !c->hc_enabled || col0 + n > it->second.cols) return RVT_OK;
+  rvt_ctx::ColKind& ck = it->second;
+  if (!ck.d_flags) {
+    HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
+    HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, st));
+  }
+  // the content of a packed column is KNOWN: hard calls only unless it has an other value
+  int rc = small_h2d(c, ck.d_flags + col0, hard, sizeof(int) * (size_t)n);
+  if (rc) return rc;
+  bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
+  if (cache) {
+    const int d = c->nc.d, dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
+    const int64_t ldk = ((int64_t)N + 127) / 128 * 128, ldk4 = (((int64_t)N + 1) / 2 + 127) / 128 * 128;
+    if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen || !ck.d_i4)) free_col_cache(ck);
+    if (!ck.d_i8 && !ck.cache_failed && !alloc_col_cache(c, ck, ldk, ldk4, c->null_gen, st)) ck.cache_failed = true;
+    cache = ck.d_i8 != nullptr;
+    if (cache) {
+      const size_t part_doubles = (size_t)kCovSlices * rvt_ctx::kColQueue * (RVT_MAX_COV + 3);
+      if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * part_doubles));
+      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
+      // (the columns' other values, NaN where a column has none: the pass splits g = h + mu m by them)
+      double mu_nan[rvt_ctx::kColQueue];
+      for (int k = 0; k < n; ++k) mu_nan[k] = hard[k] ? (double)NAN : mu[k];
+      if (!c->d_mu_nan) HIP_TRY(c, hipMalloc((void**)&c->d_mu_nan, sizeof(double) * (size_t)rvt_ctx::kColQueue));
+      double* d_mu_nan = c->d_mu_nan;
+      rc = small_h2d(c, d_mu_nan, mu_nan, sizeof(double) * (size_t)n);
+      if (rc) return rc;
+      rc = small_h2d(c, ck.d_mu + col0, mu, sizeof(double) * (size_t)n);
+      if (rc) return rc;
+      launch_cov_prep(st, d, true, dim3((unsigned)((n + kCovHcCols - 1) / kCovHcCols), (unsigned)slices), dG + (size_t)col0 * ld,
+                      (int64_t)N, (int64_t)ld, n, c->d_X, ck.d_i8 + (size_t)col0 * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr,
+                      nullptr, 0, 0, ck.d_i4 + (size_t)col0 * (size_t)ldk4, ldk4, d_mu_nan, ck.d_m4 + (size_t)col0 * (size_t)ldk4);
+      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((n * (dmax + 3) + 255) / 256)), dim3(256), 0, st, c->d_cc_part, slices,
+                         n, d, dmax, ck.d_cs + col0, ck.d_poly + col0, ck.d_T + (size_t)col0 * RVT_MAX_COV, RVT_MAX_COV);
+      HIP_TRY(c, hipGetLastError());
+      for (int k = 0; k < n; ++k) ck.valid[(size_t)(col0 + k)] = (unsigned char)(hard[k] ? 1 : 2);
+    }
+  }
+  return RVT_OK;
+}
+
 static void free_col_cache(rvt_ctx::ColKind& ck);
 static bool alloc_col_cache(rvt_ctx* c, rvt_ctx::ColKind& ck, int64_t ldk, int64_t ldk4, uint64_t gen, hipStream_t st);
 // What rvt_block_upload_columns queued (rvt_ctx::ColQueue: up to 32 consecutive columns of one block, packed to 2-bit rows in
@@ -981,45 +1032,7 @@ int flush_col_queue(rvt_ctx* c) {
                      reinterpret_cast<const unsigned char*>(c->d_colpack), (long long)pitch, d_mu, (long long)N, (long long)ld,
                      dG + (size_t)col0 * ld);
   HIP_TRY(c, hipGetLastError());
-  auto it = c->col_kind.find(dG);
-  if (it == c->col_kind.end() || !c->hc_enabled || col0 + n > it->second.cols) return RVT_OK;
-  rvt_ctx::ColKind& ck = it->second;
-  if (!ck.d_flags) {
-    HIP_TRY(c, hipMalloc((void**)&ck.d_flags, sizeof(int) * (size_t)ck.cols));
-    HIP_TRY(c, hipMemsetAsync(ck.d_flags, 0x01, sizeof(int) * (size_t)ck.cols, st));
-  }
-  // the content of a packed column is KNOWN: hard calls only unless it has an other value
-  rc = small_h2d(c, ck.d_flags + col0, q.hard, sizeof(int) * (size_t)n);
-  if (rc) return rc;
-  bool cache = c->have_null && !c->nc.binary && !getenv("RVT_METACOV_NO_CACHE");
-  if (cache) {
-    const int d = c->nc.d, dmax = d <= 4 ? 4 : (d <= 8 ? 8 : RVT_MAX_COV);
-    const int64_t ldk = ((int64_t)N + 127) / 128 * 128, ldk4 = (((int64_t)N + 1) / 2 + 127) / 128 * 128;
-    if (ck.d_i8 && (ck.ldk != ldk || ck.gen != c->null_gen || !ck.d_i4)) free_col_cache(ck);
-    if (!ck.d_i8 && !ck.cache_failed && !alloc_col_cache(c, ck, ldk, ldk4, c->null_gen, st)) ck.cache_failed = true;
-    cache = ck.d_i8 != nullptr;
-    if (cache) {
-      const size_t part_doubles = (size_t)kCovSlices * rvt_ctx::kColQueue * (RVT_MAX_COV + 3);
-      if (!c->d_cc_part) HIP_TRY(c, hipMalloc((void**)&c->d_cc_part, sizeof(double) * part_doubles));
-      const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
-      // (the columns' other values, NaN where a column has none: the pass splits g = h + mu m by them)
-      double mu_nan[rvt_ctx::kColQueue];
-      for (int k = 0; k < n; ++k) mu_nan[k] = q.hard[k] ? (double)NAN : q.mu[k];
-      double* d_mu_nan = d_mu + rvt_ctx::kColQueue;
-      rc = small_h2d(c, d_mu_nan, mu_nan, sizeof(double) * (size_t)n);
-      if (rc) return rc;
-      rc = small_h2d(c, ck.d_mu + col0, q.mu, sizeof(double) * (size_t)n);
-      if (rc) return rc;
-      launch_cov_prep(st, d, true, dim3((unsigned)((n + kCovHcCols - 1) / kCovHcCols), (unsigned)slices), dG + (size_t)col0 * ld,
-                      (int64_t)N, (int64_t)ld, n, c->d_X, ck.d_i8 + (size_t)col0 * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr,
-                      nullptr, 0, 0, ck.d_i4 + (size_t)col0 * (size_t)ldk4, ldk4, d_mu_nan, ck.d_m4 + (size_t)col0 * (size_t)ldk4);
-      hipLaunchKernelGGL(cov_hc_finish_kernel, dim3((unsigned)((n * (dmax + 3) + 255) / 256)), dim3(256), 0, st, c->d_cc_part, slices,
-                         n, d, dmax, ck.d_cs + col0, ck.d_poly + col0, ck.d_T + (size_t)col0 * RVT_MAX_COV, RVT_MAX_COV);
-      HIP_TRY(c, hipGetLastError());
-      for (int k = 0; k < n; ++k) ck.valid[(size_t)(col0 + k)] = (unsigned char)(q.hard[k] ? 1 : 2);
-    }
-  }
-  return RVT_OK;
+  return packed_columns_pass(c, dG, col0, n, q.mu, q.hard);
 }
 
 int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const double* G) {
@@ -1083,6 +1096,8 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
   // every site's column crossed as 4 MB of doubles out of pageable memory (~120 us per site at N = 500 000: the adapter's
   // `--meta cov` ran at 8 k sites/s whatever the window).  Dosages (a second other value) cross as doubles, as before.
   bool packed = false;
+  std::vector<double> pmu;   // (packed: the columns' other values and whether they have none)
+  std::vector<int> phard;
   if (c->hc_enabled && !getenv("RVT_UPLOAD_FP64") && N >= 4096) {
     int rc = stage_ready(c);
     if (rc) return rc;
@@ -1110,6 +1125,9 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
                            dG + (size_t)col0 * ld);
         HIP_TRY(c, hipGetLastError());
         packed = true;
+        pmu = mu;
+        phard.resize((size_t)ncols);
+        for (int j = 0; j < ncols; ++j) phard[(size_t)j] = pc[(size_t)j].has_mu ? 0 : 1;
       }
     }
   }
@@ -1130,6 +1148,14 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
       if ((size_t)(col0 + k) < ck.valid.size()) ck.valid[(size_t)(col0 + k)] = 0;
     if (ck.d_flags && !c->hc_enabled && col0 < ck.cols)  // (flags are not recomputed below: unknown = not hard calls)
       HIP_TRY(c, hipMemsetAsync(ck.d_flags + col0, 0, sizeof(int) * (size_t)std::min(ncols, ck.cols - col0), c->io_stream));
+  }
+  if (packed) {  // content known from the packing: the same pass as behind the queued single columns, 32 columns at a time
+    for (int k0 = 0; k0 < ncols; k0 += rvt_ctx::kColQueue) {
+      const int nk = std::min(rvt_ctx::kColQueue, ncols - k0);
+      int rc = packed_columns_pass(c, dG, col0 + k0, nk, pmu.data() + k0, phard.data() + k0);
+      if (rc) return rc;
+    }
+    return RVT_OK;
   }
   if (it != c->col_kind.end() && c->hc_enabled && col0 + ncols <= it->second.cols) {
     rvt_ctx::ColKind& ck = it->second;

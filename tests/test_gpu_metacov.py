@@ -654,3 +654,27 @@ def test_cov_band_at_the_bench_size_n500k(engine_factory, monkeypatch, imputed):
         got = band[h, :len(sub) - a].astype(np.float64)
         assert np.abs(got - want).max() <= 3e-7 * np.nanmax(np.abs(ocov)) * float(scale_f)
     assert np.allclose(xz[sub], oxz, rtol=1e-9, atol=1e-9 * max(np.abs(oxz).max(), 1.0))
+
+
+def test_cov_band_does_not_depend_on_how_the_columns_were_uploaded(engine_factory):
+    """Mean-imputed columns uploaded 97 at a time (packed, expanded and passed over in chunks of 32) leave the same cache as the
+    same columns uploaded a site at a time: both rings take the four-product integer band and give the same bits."""
+    N, V, d, halo, cap, col0 = 7001, 500, 2, 90, 640, 600
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 515)
+    G = np.asfortranarray(np.rint(G))
+    rng = np.random.default_rng(3)
+    for j in range(0, V, 2):
+        miss = rng.random(N) < 0.03
+        G[miss, j] = G[~miss, j].mean()
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    r1, r2 = eng.alloc_block(cap), eng.alloc_block(cap)
+    for j in range(V):
+        eng.upload_columns(r1, (col0 + j) % cap, G[:, j])
+    _ring_fill(eng, r2, cap, col0, G)
+    b1, xz1, zz1, p1 = eng.cov_band(r1, cap, col0, V, V, halo)
+    assert eng.cov_band_last_path() == 4
+    b2, xz2, zz2, p2 = eng.cov_band(r2, cap, col0, V, V, halo)
+    assert eng.cov_band_last_path() == 4
+    assert np.array_equal(b1, b2, equal_nan=True) and np.array_equal(xz1, xz2) and np.array_equal(p1, p2)
