@@ -762,12 +762,16 @@ def main():
                     di["fp64"].get("rows_sha256") == di.get("bed", {}).get("rows_sha256")
                 # `--meta cov` the same way: MetaCovTest::fit() per variant with its fp64 column (the reference's single-variant
                 # loop, src/Main.cpp:1010-1078), windows of 200 markers, rows formatted and hashed on the host
-                try:
-                    pr = subprocess.run([drv, "--synthetic-meta", str(N), "8000", "200"], capture_output=True, text=True, timeout=300)
-                    rec = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
-                    di["meta_cov"] = rec[0] if rec else {"error": (pr.stderr or "no output")[-300:]}
-                except Exception as e:
-                    di["meta_cov"] = {"error": repr(e)[:300]}
+                # (meta_cov_imputed: 1 % of every column's calls missing and imputed to the column mean, as real matrices are —
+                #  the window's band then is four MXFP4 products instead of one)
+                for key, extra in (("meta_cov", []), ("meta_cov_imputed", ["--missing", "0.01"])):
+                    try:
+                        pr = subprocess.run([drv, "--synthetic-meta", str(N), "8000", "200"] + extra, capture_output=True, text=True,
+                                            timeout=300)
+                        rec = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                        di[key] = rec[0] if rec else {"error": (pr.stderr or "no output")[-300:]}
+                    except Exception as e:
+                        di[key] = {"error": repr(e)[:300]}
                 line["drop_in"] = di
         print(json.dumps(line))
     if world > 1:
