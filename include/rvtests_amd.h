@@ -565,13 +565,30 @@ int rvt_submit_gene_raw(rvt_ctx* ctx, int64_t gene_id, int M, const double* Graw
 int rvt_submit_gene_i8(rvt_ctx* ctx, int64_t gene_id, int M, const int8_t* G8, uint32_t tests,
                        const rvt_params* params, double* af_out);
 /* Several genes per call: the hand-off of rvt_submit_gene_raw (kind 1: doubles, negative = missing), rvt_submit_gene_i8
- * (kind 2) or rvt_submit_gene_bed (kind 3: PLINK 2-bit rows), gene after gene, without allele frequencies returned.  For
+ * (kind 2) or rvt_submit_gene_bed (kind 3: PLINK 2-bit rows; kind 7: such rows resident on the device, rvt_submit_gene_bed_dev), gene after gene, without allele frequencies returned.  For
  * callers whose per-call cost (ctypes, JNI, cgo) is not negligible against the ~120 us a packed gene of N = 500 000 needs on
  * the link; the C++ adapters call the single-gene forms (src/Main.cpp:1221-1254 hands over one gene at a time). */
 int rvt_submit_genes(rvt_ctx* ctx, int kind, int n, const int64_t* gene_ids, const int* M, const void* const* data,
                      uint32_t tests, const rvt_params* params);
 int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* bed, uint32_t tests,
                         const rvt_params* params, double* af_out);
+/* A .bed matrix RESIDENT in device memory (replaces, for a whole analysis, PlinkInputFile::readIntoMatrix per gene,
+ * libVcf/PlinkInputFile.cpp:24-47, and the PCIe crossing of rvt_submit_gene_bed): 500 000 samples x 2 000 000 variants of 2-bit
+ * codes are 250 GB — an exome-scale cohort fits the 288 GB of one MI355X, and a gene is then named by the device address of its
+ * first row.
+ *   rvt_bed_alloc            n_variants rows of ceil(N/4) bytes, the FILE's layout (no padding between rows; the three magic
+ *                            bytes of the file are not part of it); N is the null model's sample count
+ *   rvt_bed_upload           rows [first_variant, first_variant + n_variants) from host memory (returns when they are there)
+ *   rvt_submit_gene_bed_dev  like rvt_submit_gene_bed with d_rows = d_bed + first_row * ceil(N/4): M consecutive rows.  The
+ *                            rows are read when the gene is computed: they must stay unchanged until its record has been
+ *                            collected.  Same records as rvt_submit_gene_bed of the same rows, bit for bit.
+ *   rvt_submit_genes         kind 7 = the same, several genes per call (data[g] = device address of gene g's first row)
+ *   rvt_bed_free             waits for queued genes, then frees */
+int rvt_bed_alloc(rvt_ctx* ctx, int64_t n_variants, unsigned char** d_bed);
+int rvt_bed_upload(rvt_ctx* ctx, unsigned char* d_bed, int64_t first_variant, int64_t n_variants, const unsigned char* rows);
+int rvt_bed_free(rvt_ctx* ctx, unsigned char* d_bed);
+int rvt_submit_gene_bed_dev(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* d_rows, uint32_t tests,
+                            const rvt_params* params, double* af_out);
 
 /* ---- VCF text at the boundary (SURVEY §8f "next" #1: the genotype front end) -------------------------------------------
  * Replaces the per-sample loop of VCFGenotypeExtractor::extractMultipleGenotype (src/VCFGenotypeExtractor.cpp:29-140) for

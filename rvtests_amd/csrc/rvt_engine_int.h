@@ -151,6 +151,7 @@ struct rvt_ctx {
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
   double* d_Gt = nullptr;  // ... rotated by U'
   size_t fam_cols_cap = 0;
+  int64_t fam_cols_ld = 0;  // (the leading dimension d_Gp / d_Gt were sized for)
   // raw / packed genotype submission
   double* d_consol_af = nullptr;  // af (RVT_MAX_VARIANTS) | fill values (RVT_MAX_VARIANTS)
   size_t consol_af_cap = 0;
@@ -284,7 +285,7 @@ struct rvt_ctx {
   uint32_t* d_perm_idx = nullptr;      // N x B
   uint32_t* d_perm_states = nullptr;   // B x 31
   double *d_perm_R = nullptr, *d_perm_C = nullptr, *d_perm_Q = nullptr, *d_perm_cur = nullptr;
-  size_t perm_cap_NB = 0, perm_cap_BM = 0;
+  size_t perm_cap_NB = 0, perm_cap_BM = 0, perm_cap_N = 0;
   int perm_cap_B = 0;
   hipEvent_t ev_in[kSlotsAll] = {}, ev_k2[kSlotsAll] = {}, ev_k2b[kSlotsAll] = {};
   // The p-value kernel on CUs of its own (RVT_PV_CUS, see rvt_init): two streams restricted to the first pv_cus mask bits,

@@ -10,15 +10,19 @@
 extern "C" {
 
 int ensure_fam_cols(rvt_ctx* c, size_t T, int64_t ld) {
-  if (T <= c->fam_cols_cap) return RVT_OK;
+  // (the capacity is columns OF THIS LEADING DIMENSION: a context whose null model was replaced by one with more samples
+  //  otherwise kept buffers of the old column length — a memory fault in the permutation stage, found in round 6)
+  if (T <= c->fam_cols_cap && ld <= c->fam_cols_ld) return RVT_OK;
   if (c->d_Gp) hipFree(c->d_Gp);
   if (c->d_Gt) hipFree(c->d_Gt);
   c->d_Gp = c->d_Gt = nullptr;
+  const size_t want = std::max(T + T / 4, c->fam_cols_cap);
   c->fam_cols_cap = 0;
-  const size_t want = T + T / 4;
+  c->fam_cols_ld = 0;
   HIP_TRY(c, hipMalloc((void**)&c->d_Gp, sizeof(double) * (size_t)ld * want));
   HIP_TRY(c, hipMalloc((void**)&c->d_Gt, sizeof(double) * (size_t)ld * want));
   c->fam_cols_cap = want;
+  c->fam_cols_ld = ld;
   return RVT_OK;
 }
 

@@ -143,7 +143,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
   }
   // chunk buffers
   const int B = std::max(1, std::min(nPerm, (int)std::min<int64_t>(2048, ((int64_t)6 << 30) / (8 * N))));
-  if ((size_t)N * B > c->perm_cap_NB || B > c->perm_cap_B || (size_t)B * m > c->perm_cap_BM) {
+  if ((size_t)N * B > c->perm_cap_NB || B > c->perm_cap_B || (size_t)B * m > c->perm_cap_BM || (size_t)N > c->perm_cap_N) {
     for (void** p : {(void**)&c->d_perm_idx, (void**)&c->d_perm_states, (void**)&c->d_perm_R, (void**)&c->d_perm_C,
                      (void**)&c->d_perm_Q, (void**)&c->d_perm_cur}) {
       if (*p) hipFree(*p);
@@ -151,6 +151,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
     }
     c->perm_cap_NB = c->perm_cap_BM = 0;
     c->perm_cap_B = 0;
+    c->perm_cap_N = 0;
     const size_t bm = (size_t)B * std::max(m, RVT_MAX_VARIANTS / 4);
     HIP_TRY(c, hipMalloc((void**)&c->d_perm_idx, sizeof(uint32_t) * (size_t)N * B));
     HIP_TRY(c, hipMalloc((void**)&c->d_perm_states, sizeof(uint32_t) * 31 * (size_t)B));
@@ -161,6 +162,7 @@ int perm_stage(rvt_ctx* c, const double* dG, int M, const GeneDesc& g0, const rv
     c->perm_cap_NB = (size_t)N * B;
     c->perm_cap_B = B;
     c->perm_cap_BM = bm;
+    c->perm_cap_N = (size_t)N;  // (d_perm_cur holds 2 N doubles whatever B is: fewer shuffles of more samples must not keep it)
   }
   if (c->jump_N != N) {
     c->jump.resize(31 * 31);
@@ -361,6 +363,7 @@ int kbac_stage(rvt_ctx* c, const double* dG, int M, const double* af, const std:
     }
     c->perm_cap_NB = c->perm_cap_BM = 0;
     c->perm_cap_B = 0;
+    c->perm_cap_N = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_perm_idx, sizeof(uint32_t) * (size_t)N * B));
     HIP_TRY(c, hipMalloc((void**)&c->d_perm_states, sizeof(uint32_t) * 31 * (size_t)B));
     c->perm_cap_NB = (size_t)N * B;

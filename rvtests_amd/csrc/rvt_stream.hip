@@ -621,7 +621,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   // device block from the pool (smallest that fits) or a fresh zeroed allocation; pad rows stay zero because only
   // the N data rows of a column are ever written
   // PLINK 2-bit rows stay packed when the gene's tests allow it (gene_suffstat_hcp): a block of header + M padded rows
-  const bool packed = mode == 3 && packed_eligible(c, M, tests, prm);
+  const bool packed = (mode == 3 || mode == 7) && packed_eligible(c, M, tests, prm);  // (7: the rows are on the device already)
   const size_t pk_pitch = ((size_t)((c->nc.N + 3) / 4) + 15) / 16 * 16;
   const size_t need = packed ? (size_t)kHcpHeaderBytes + pk_pitch * M + 16 : sizeof(double) * (size_t)c->null_ld * M;
   bool fresh_packed = false;
@@ -650,7 +650,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   const int64_t N = c->nc.N, ld = c->null_ld;
   // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
   // (dosage text, BGEN), or whatever the caller's doubles are
-  p.kind = packed ? 3 : ((mode == 2 || mode == 3 || mode == 4) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1)));
+  p.kind = packed ? 3 : ((mode == 2 || mode == 3 || mode == 4 || mode == 7) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1)));
   p.decoded = (mode == 4 || mode == 5) ? 1 : (mode == 6 ? 2 : 0);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
@@ -724,7 +724,10 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       // staged copy (pad_zero) writes zeros into the pads BETWEEN rows of a chunk and nothing into the pad behind a chunk's last
       // row, which therefore still holds the allocation's zeros.
       if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
-      if (e == hipSuccess) {
+      if (e == hipSuccess && mode == 7) {
+        // rows of a .bed matrix RESIDENT on the device (rvt_submit_gene_bed_dev): 6 MB of HBM traffic instead of the link
+        e = hipMemcpy2DAsync(rows, pk_pitch, G, cb, cb, (size_t)M, hipMemcpyDeviceToDevice, c->copy_stream);
+      } else if (e == hipSuccess) {
         c->h2d_stream = c->copy_stream;
         const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M, true);  // (pad bytes of a packed row are zero anyway)
         c->h2d_stream = c->io_stream;
@@ -758,7 +761,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
     } else {
       // packed hard calls: one byte per genotype (mode 2; mode 4 decodes VCF text into that form first) or PLINK's
       // 2-bit codes, ceil(N/4) bytes per variant (mode 3)
-      const size_t col_bytes = (mode == 3) ? (size_t)((N + 3) / 4) : (size_t)N;
+      const size_t col_bytes = (mode == 3 || mode == 7) ? (size_t)((N + 3) / 4) : (size_t)N;
       const size_t bytes8 = col_bytes * M;
       const void* d_packed = nullptr;  // where the packed genotypes of this gene are on the device
       int pk = -1;
@@ -785,7 +788,9 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
           if (e == hipSuccess) c->pack_cap[pk] = bytes8 + bytes8 / 4;
         }
         if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_pack_free[pk], 0);
-        if (e == hipSuccess) {
+        if (e == hipSuccess && mode == 7) {  // (device-resident rows: into the same landing buffer, whatever their alignment)
+          e = hipMemcpyAsync(c->d_pack[pk], G, bytes8, hipMemcpyDeviceToDevice, c->copy_stream);
+        } else if (e == hipSuccess) {
           c->h2d_stream = c->copy_stream;
           const int rcs = staged_h2d(c, c->d_pack[pk], G, bytes8);
           c->h2d_stream = c->io_stream;
@@ -795,7 +800,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_pack_copied[pk], 0);
         d_packed = c->d_pack[pk];
       }
-      if (e == hipSuccess && mode == 3) {
+      if (e == hipSuccess && (mode == 3 || mode == 7)) {
         const bed2_t* sb = (const bed2_t*)d_packed;
         const long long cb = (long long)col_bytes;
         hipLaunchKernelGGL((consolidate_count_kernel<bed2_t>), cgrid, dim3(256), 0, st, sb, cb, (long long)N,
@@ -854,6 +859,45 @@ int rvt_submit_gene_bed(rvt_ctx* c, int64_t gene_id, int M, const unsigned char*
                         const rvt_params* prm, double* af_out) {
   return submit_common(c, gene_id, M, bed, 3, nullptr, af_out, tests, prm);
 }
+// ---- a .bed matrix resident in HBM ---------------------------------------------------------------------------------------
+// 500 000 samples x 2 000 000 variants of PLINK 2-bit rows are 250 GB: a whole exome-scale cohort fits the 288 GB of one
+// MI355X.  rvt_bed_alloc / rvt_bed_upload put rows there once (file layout: ceil(N/4) bytes per variant, no padding);
+// rvt_submit_gene_bed_dev then names a gene by the device address of its first row.
+int rvt_bed_alloc(rvt_ctx* c, int64_t n_variants, unsigned char** d_bed) {
+  if (!c || !d_bed || n_variants < 1) return fail(c, RVT_E_INVALID, "bad .bed allocation");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  hipSetDevice(c->device);
+  const size_t cb = (size_t)((c->nc.N + 3) / 4);
+  *d_bed = nullptr;
+  if (hipMalloc((void**)d_bed, cb * (size_t)n_variants + 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, RVT_E_HIP, "hipMalloc(%zu bytes) failed for a resident .bed matrix", cb * (size_t)n_variants);
+  }
+  return RVT_OK;
+}
+int rvt_bed_upload(rvt_ctx* c, unsigned char* d_bed, int64_t first_variant, int64_t n_variants, const unsigned char* rows) {
+  if (!c || !d_bed || !rows || first_variant < 0 || n_variants < 0) return fail(c, RVT_E_INVALID, "bad .bed upload");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  if (n_variants == 0) return RVT_OK;
+  hipSetDevice(c->device);
+  const size_t cb = (size_t)((c->nc.N + 3) / 4);
+  int rc = staged_h2d(c, d_bed + cb * (size_t)first_variant, rows, cb * (size_t)n_variants);
+  if (rc) return rc;
+  HIP_TRY(c, sync_stream(c->h2d_stream));  // (the caller may reuse `rows`; genes submitted next read the device copy)
+  return RVT_OK;
+}
+int rvt_bed_free(rvt_ctx* c, unsigned char* d_bed) {
+  if (!c) return RVT_E_INVALID;
+  if (!d_bed) return RVT_OK;
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);  // (queued genes may still read it)
+  hipFree(d_bed);
+  return rc;
+}
+int rvt_submit_gene_bed_dev(rvt_ctx* c, int64_t gene_id, int M, const unsigned char* d_rows, uint32_t tests,
+                            const rvt_params* prm, double* af_out) {
+  return submit_common(c, gene_id, M, d_rows, 7, nullptr, af_out, tests, prm);
+}
 int rvt_submit_gene_raw(rvt_ctx* c, int64_t gene_id, int M, const double* Graw, uint32_t tests,
                         const rvt_params* prm, double* af_out) {
   return submit_common(c, gene_id, M, Graw, 1, nullptr, af_out, tests, prm);
@@ -868,7 +912,8 @@ int rvt_submit_gene_i8(rvt_ctx* c, int64_t gene_id, int M, const int8_t* G8, uin
 int rvt_submit_genes(rvt_ctx* c, int kind, int n, const int64_t* gene_ids, const int* M, const void* const* data,
                      uint32_t tests, const rvt_params* prm) {
   if (!c || n < 0 || (n > 0 && (!gene_ids || !M || !data))) return fail(c, RVT_E_INVALID, "bad gene list");
-  if (kind < 1 || kind > 3) return fail(c, RVT_E_INVALID, "kind %d: 1 = doubles with missing codes, 2 = int8, 3 = PLINK 2-bit rows", kind);
+  if ((kind < 1 || kind > 3) && kind != 7)
+    return fail(c, RVT_E_INVALID, "kind %d: 1 = doubles with missing codes, 2 = int8, 3 = PLINK 2-bit rows, 7 = PLINK 2-bit rows on the device", kind);
   // The genes' transfers out of page-locked caller memory (rvt_host_register) are queued back to back and waited for ONCE:
   // the call returns when the last of them has been read (a gene-by-gene submission waits per gene — the buffer may be
   // rewritten on return — which leaves the link idle between two genes).

@@ -534,6 +534,51 @@ class Engine:
                                                int(tests), C.byref(prm), _dp(af) if want_af else None))
         return af
 
+    # ---- a .bed matrix resident in device memory (rvt_bed_alloc / rvt_bed_upload / rvt_submit_gene_bed_dev) ------------
+    def bed_alloc(self, n_variants):
+        p = C.c_void_p()
+        self.L.rvt_bed_alloc.restype = C.c_int
+        self.L.rvt_bed_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        self._check(self.L.rvt_bed_alloc(self.ctx, int(n_variants), C.byref(p)))
+        return p.value
+
+    def bed_upload(self, d_bed, first_variant, rows):
+        """rows: (n, ceil(N/4)) uint8, pack_bed layout."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        self.L.rvt_bed_upload.restype = C.c_int
+        self.L.rvt_bed_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        self._check(self.L.rvt_bed_upload(self.ctx, C.c_void_p(int(d_bed)), int(first_variant), rows.shape[0],
+                                          rows.ctypes.data_as(C.c_void_p)))
+
+    def bed_free(self, d_bed):
+        self.L.rvt_bed_free.restype = C.c_int
+        self.L.rvt_bed_free.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.rvt_bed_free(self.ctx, C.c_void_p(int(d_bed))))
+
+    def submit_gene_bed_dev(self, gene_id, d_rows, M, tests=TEST_ALL, params=None, want_af=True):
+        """M consecutive rows of a resident .bed matrix, d_rows = device address of the first (rvt_submit_gene_bed_dev)."""
+        prm = params or Params.default()
+        af = np.zeros(M) if want_af else None
+        self.L.rvt_submit_gene_bed_dev.restype = C.c_int
+        self.L.rvt_submit_gene_bed_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, c_double_p]
+        self._check(self.L.rvt_submit_gene_bed_dev(self.ctx, int(gene_id), int(M), C.c_void_p(int(d_rows)), int(tests),
+                                                   C.byref(prm), _dp(af) if want_af else None))
+        return af
+
+    def submit_genes_bed_dev(self, gene_ids, d_rows, Ms, tests=TEST_ALL, params=None):
+        """Several genes of a resident .bed matrix in one call (rvt_submit_genes, kind 7): d_rows[g] = device address of the
+        first row of gene g."""
+        n = len(d_rows)
+        prm = params or Params.default()
+        ids = np.ascontiguousarray(gene_ids, dtype=np.int64)
+        ms = np.ascontiguousarray(Ms, dtype=np.int32)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(a)) for a in d_rows])
+        self.L.rvt_submit_genes.restype = C.c_int
+        self.L.rvt_submit_genes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p]
+        self._check(self.L.rvt_submit_genes(self.ctx, 7, n, ids.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), ptrs,
+                                            int(tests), C.byref(prm)))
+
     def submit_genes(self, kind, gene_ids, arrays, Ms, tests=TEST_ALL, params=None):
         """Several genes in ONE call (rvt_submit_genes): kind 1 = doubles with missing codes (N x M, Fortran order), 2 = int8
         (N x M, Fortran order), 3 = PLINK 2-bit rows (pack_bed layout).  The arrays must be contiguous and stay alive until

@@ -102,3 +102,46 @@ def test_tests_that_need_the_block_expand_it(engine):
     a, b = engine.collect()
     for f in FIELDS:
         assert getattr(a, f) == getattr(b, f), f
+
+
+@pytest.mark.parametrize("N,binary", [(4099, 0), (10007, 0), (3001, 1)])
+def test_genes_of_a_resident_bed_matrix_give_the_records_of_the_host_rows(engine, N, binary):
+    """rvt_bed_alloc / rvt_bed_upload / rvt_submit_gene_bed_dev: a .bed matrix kept in device memory in the file's own layout
+    (rows of ceil(N/4) bytes, no padding: rows start at odd addresses for these N), genes named by the device address of their
+    first row — one at a time with allele frequencies, several per call, with permutations (the gene is expanded) and under a
+    binary trait (expanded too).  Every record and frequency equals the one rvt_submit_gene_bed gives for the same rows."""
+    import rvtests_amd
+    Ms = (1, 5, 17, 30, 48, 64, 81, 96)
+    genes = [_raw_gene(N, M, seed=77 * M + 1, missing=(0.0 if M % 2 else 0.02)) for M in Ms]
+    X, y, res, v, s2 = synth.make_null(N, 2, binary, seed=12)
+    engine.set_null(binary, X, res, v, s2)
+    rows = [engine.pack_bed(g) for g in genes]
+    cb = (N + 3) // 4
+    first = np.concatenate([[0], np.cumsum(Ms)[:-1]]) + 3     # (three rows of something else in front)
+    total = int(first[-1] + Ms[-1] + 2)
+    d_bed = engine.bed_alloc(total)
+    engine.bed_upload(d_bed, 0, np.full((3, cb), 0x55, dtype=np.uint8))
+    for f, r in zip(first, rows):
+        engine.bed_upload(d_bed, int(f), r)
+    prm = rvtests_amd.Params.default()
+    prm.skat_nperm = 100
+    want_af, want = [], []
+    for g, (r, M) in enumerate(zip(rows, Ms)):
+        want_af.append(engine.submit_gene_bed(g, r, M))
+    engine.submit_gene_bed(100, rows[3], Ms[3], params=prm, want_af=False)
+    want = engine.collect()
+    got_af = [engine.submit_gene_bed_dev(g, d_bed + int(first[g]) * cb, M) for g, M in enumerate(Ms)]
+    engine.submit_gene_bed_dev(100, d_bed + int(first[3]) * cb, Ms[3], params=prm, want_af=False)
+    got = engine.collect()
+    engine.submit_genes_bed_dev(list(range(len(Ms))), [d_bed + int(f) * cb for f in first], Ms)
+    got_many = engine.collect()
+    engine.bed_free(d_bed)
+    assert len(got) == len(want) == len(Ms) + 1 and len(got_many) == len(Ms)
+    for a, b in zip(got_af, want_af):
+        assert np.array_equal(a, b)
+    for a, b in list(zip(got, want)) + list(zip(got_many, want[:len(Ms)])):
+        for f in FIELDS:
+            x, y_ = getattr(a, f), getattr(b, f)
+            assert x == y_ or (x != x and y_ != y_), (f, x, y_)
+    if not binary:
+        assert want[3].skat_p > 0

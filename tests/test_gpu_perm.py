@@ -111,3 +111,31 @@ def test_counter_based_mode_agrees_with_the_exact_mode_within_binomial_error(eng
     assert abs(dev.mean()) < 0.02
     for p in ptrs:
         eng.free_block(p)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_a_context_whose_null_model_grows_keeps_no_buffer_of_the_old_size(eng, exact):
+    """One context, two analyses: N = 700 with 400 permutations, then N = 9 001 with 30 (fewer shuffles of more samples: the
+    chunk of shuffles N x B shrinks while every per-sample buffer grows).  The second analysis gives what a fresh context gives
+    (round 6: the flipped-genotype buffer of the permutation stage was kept by its column count alone and overran)."""
+    import rvtests_amd
+    outs = []
+    for fresh in (False, True):
+        e = rvtests_amd.Engine(0) if fresh else eng
+        for N, n_perm in ((700, 400), (9001, 30)) if not fresh else ((9001, 30),):
+            genes = [synth.make_gene(N, M, seed=900 + M, missing=0.01, common=True, mono=True)[1:] for M in (24, 7, 40)]
+            X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=18, G_effect=0.5 * genes[0][0][:, :2].sum(1))
+            e.set_null(0, X, res, v, s2)
+            prm = rvtests_amd.Params(1.0, 25.0, 1.0, 25.0, n_perm, 0.4)
+            e.set_perm_exact(exact)
+            if exact:
+                e.rand_seed(1)
+            ptrs = [e.upload_block(G) for G, af in genes]
+            out = e.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes], tests=rvtests_amd.TEST_SKAT,
+                               params=prm, ids=[0, 1, 2])   # (the counter-based shuffles are a function of the gene id)
+            for p in ptrs:
+                e.free_block(p)
+        outs.append([(r.skat_Q, r.skat_p, r.perm_actual_perm, r.perm_num_greater, r.perm_num_equal, r.perm_pvalue) for r in out])
+        if fresh:
+            e.close()
+    assert outs[0] == outs[1] and all(t[2] > 0 for t in outs[0])
