@@ -370,6 +370,50 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
     return out
 
 
+def resident_bed_rate(eng, blocks, Ms, N, rows_resident=8192, genes=6144, per_call=64, m_lo=20, m_hi=80):
+    """Secondary figure: the same four tests on genes of a PLINK .bed matrix RESIDENT in HBM (rvt_bed_alloc / rvt_bed_upload /
+    rvt_submit_genes kind 7): a gene is M consecutive rows named by their device address, nothing crosses PCIe, the sufficient
+    statistics are formed from the 2-bit rows (gene_suffstat_hcp).  500 000 x 2 000 000 such genotypes are 250 GB: a whole
+    exome-scale cohort fits one MI355X.  The matrix here: `rows_resident` rows (the hard calls of four of the batch's genes,
+    repeated), genes of M ~ U{m_lo..m_hi} consecutive rows at random offsets; one untimed pass first."""
+    ks = [k for k in range(len(Ms)) if 40 <= Ms[k] <= 60][:4] or list(range(min(4, len(Ms))))
+    packed = [eng.pack_bed(np.rint(np.asfortranarray(blocks[k][:, :N].T.cpu().numpy()))) for k in ks]
+    cb = (N + 3) // 4
+    d_bed = eng.bed_alloc(rows_resident)
+    r = 0
+    while r < rows_resident:
+        for pk in packed:
+            n = min(pk.shape[0], rows_resident - r)
+            if n <= 0:
+                break
+            eng.bed_upload(d_bed, r, pk[:n])
+            r += n
+    rng = np.random.default_rng(11)
+    gm = rng.integers(m_lo, m_hi + 1, genes)
+    first = rng.integers(0, rows_resident - m_hi, genes)
+    ptrs = [d_bed + int(f) * cb for f in first]
+    out = {}
+    try:
+        for timed in (False, True):
+            n = genes if timed else min(genes, 1024)
+            eng.collect()
+            t0 = time.perf_counter()
+            done = 0
+            for g0 in range(0, n, per_call):
+                g1 = min(n, g0 + per_call)
+                eng.submit_genes_bed_dev(list(range(g0, g1)), ptrs[g0:g1], gm[g0:g1])
+                done += len(eng.collect_ready())
+            done += len(eng.collect())
+            dt = time.perf_counter() - t0
+        out = {"gene_sets_per_s": done / dt, "genes": done, "rows_resident": rows_resident,
+               "resident_GB": rows_resident * cb / 1e9, "mean_M": float(gm.mean()),
+               "workload": "N=%d, genes = M~U{%d..%d} consecutive rows of a device-resident .bed matrix, all four tests; "
+                           "caller: Python, %d genes per rvt_submit_genes call" % (N, m_lo, m_hi, per_call)}
+    finally:
+        eng.bed_free(d_bed)
+    return out
+
+
 def spawn_ranks(n):
     """`--gpus n` without a launcher: start n ranks as a child torch.distributed.run BEFORE this process touches the
     GPU, pass its output through and return its exit code."""
@@ -642,6 +686,11 @@ def main():
                 line["from_host"] = from_host_rates(eng, blocks, Ms, afs, N)
             except Exception as e:                        # (secondary figures must never cost the line)
                 line["from_host"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.no_from_host and not binary and not args.dosage and args.tests == rvtests_amd.TEST_ALL:
+            try:
+                line["resident_bed"] = resident_bed_rate(eng, blocks, Ms, N)
+            except Exception as e:
+                line["resident_bed"] = {"error": repr(e)[:300]}
         if world > 1:
             line["ranks_seen"] = int(dist.get_world_size())
             line["devices_seen_by_rank0"] = int(torch.cuda.device_count())

@@ -214,6 +214,46 @@ __global__ __launch_bounds__(256) void consolidate_count_kernel<bed2_t>(const be
         ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, (int)s_n2[0]};  // pad = #(g = 2)
   }
 }
+// The same count for rows that lie elsewhere on the device in the FILE's layout (rvt_submit_gene_bed_dev: a resident .bed
+// matrix, rows ceil(N/4) bytes apart, any alignment): every byte read is also written into the gene's own block, whose rows
+// are padded to 16 bytes for the packed-row kernel — the copy costs no pass and no call of its own.
+__global__ __launch_bounds__(256) void bed_count_copy_kernel(const unsigned char* __restrict__ src, long long src_ld, long long N,
+                                                             ConsolPart* __restrict__ parts, unsigned char* __restrict__ dst,
+                                                             long long dst_ld) {
+  __shared__ unsigned s_n1[256], s_n2[256], s_nm[256];
+  const unsigned char* col = src + (long long)blockIdx.y * src_ld;
+  unsigned char* out = dst + (long long)blockIdx.y * dst_ld;
+  const long long i0 = (long long)blockIdx.x * kConsolChunk;
+  const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
+  unsigned n1 = 0, n2 = 0, nm = 0;
+  for (long long b = (i0 >> 2) + threadIdx.x; 4 * b < i1; b += 256) {
+    unsigned v = col[b];
+    const long long left = i1 - 4 * b;
+    if (left < 4) v &= (1u << (2 * left)) - 1u;  // (padding bits of a row's last byte: stored as zeros, as the staged copy's pads are)
+    out[b] = (unsigned char)v;
+    const unsigned lo = v & 0x55u, hi = (v >> 1) & 0x55u;
+    n1 += __popc(hi & ~lo);
+    n2 += __popc(hi & lo);
+    nm += __popc(lo & ~hi);
+  }
+  s_n1[threadIdx.x] = n1;
+  s_n2[threadIdx.x] = n2;
+  s_nm[threadIdx.x] = nm;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s_n1[threadIdx.x] += s_n1[threadIdx.x + off];
+      s_n2[threadIdx.x] += s_n2[threadIdx.x + off];
+      s_nm[threadIdx.x] += s_nm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double ac = (double)s_n1[0] + 2.0 * (double)s_n2[0];
+    parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] =
+        ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, (int)s_n2[0]};
+  }
+}
 #endif
 
 // one wave per column: AF and the imputation value

@@ -102,6 +102,7 @@ int rvt_init(rvt_ctx** out, int device_id) {
     if (const char* e = getenv("RVT_PV_CUS")) pv = atoi(e);
     pv = pv > 0 ? std::max(8, pv / 8 * 8) : 0;  // (whole CUs per XCD: the mask bits go round the 8 XCDs)
     if (const char* e = getenv("RVT_HCX_FUSED")) c->hcx_fused = atoi(e) != 0;
+    if (const char* e = getenv("RVT_SUBMIT_GROUP")) c->submit_group = std::min(256, std::max(1, atoi(e)));
     if (const char* e = getenv("RVT_AS_THREADS")) c->as_threads = std::min(1024, std::max(64, atoi(e) / 64 * 64));
     if (masked && stage2_cus == 0 && pv > 0 && pv < ncu) {
       const int words = (ncu + 31) / 32;
@@ -303,6 +304,7 @@ void rvt_destroy(rvt_ctx* c) {
   if (c->d_cov_work) hipFree(c->d_cov_work);
   if (c->d_colpack) hipFree(c->d_colpack);
   if (c->d_mu_nan) hipFree(c->d_mu_nan);
+  if (c->d_bedbatch) hipFree(c->d_bedbatch);
   for (int i = 0; i < 2; ++i) {
     if (c->colq.h[i]) hipHostFree(c->colq.h[i]);
     if (c->colq.ev[i]) hipEventDestroy(c->colq.ev[i]);

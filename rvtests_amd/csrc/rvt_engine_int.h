@@ -150,6 +150,9 @@ struct rvt_ctx {
          famcov_zzinv[RVT_MAX_COV * RVT_MAX_COV];
   double* d_Gp = nullptr;  // flipped / filtered genotypes of a FamSKAT batch (ld x T)
   double* d_Gt = nullptr;  // ... rotated by U'
+  char* d_bedbatch = nullptr;   // rvt_submit_genes kind 7: row / gene references and partial counts of one call
+  size_t bedbatch_cap = 0;
+  int submit_group = 32;   // genes per asynchronous sub-batch of the streaming interface (RVT_SUBMIT_GROUP, rvt_set_submit_group)
   size_t fam_cols_cap = 0;
   int64_t fam_cols_ld = 0;  // (the leading dimension d_Gp / d_Gt were sized for)
   // raw / packed genotype submission

@@ -88,11 +88,11 @@ int launch_pending(rvt_ctx* c, size_t upto, bool only_full) {
     }
     size_t e = i + 1;
     while (e < upto && !c->queue[e].launched && same_config(c->queue[e], c->queue[i]) &&
-           (int)(e - i) < (only_full ? kSubmitGroup : 256))
+           (int)(e - i) < (only_full ? c->submit_group : 256))
       ++e;
     const rvt_ctx::Pending& p0 = c->queue[i];
     const bool perm = p0.prm.skat_nperm > 0 && (p0.tests & RVT_TEST_SKAT);
-    if (only_full && ((int)(e - i) < kSubmitGroup || perm)) return RVT_OK;  // wait for more genes / for collect
+    if (only_full && ((int)(e - i) < c->submit_group || perm)) return RVT_OK;  // wait for more genes / for collect
     if (perm) {
       // permutation p-values consume one random stream in gene order: synchronous, gene by gene
       int rc = rvt_sync(c);
@@ -723,11 +723,22 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
       // block out again only for the same (N, M) — the same pk_pitch — so a later gene's rows land on the same offsets; the
       // staged copy (pad_zero) writes zeros into the pads BETWEEN rows of a chunk and nothing into the pad behind a chunk's last
       // row, which therefore still holds the allocation's zeros.
+      if (mode == 7) {
+        // rows of a .bed matrix RESIDENT on the device (rvt_submit_gene_bed_dev): the count pass copies them into the gene's
+        // block as it reads them — 6 MB of HBM traffic instead of the link, three launches per gene on one stream
+        if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, st);
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL(bed_count_copy_kernel, cgrid, dim3(256), 0, st, (const unsigned char*)G, (long long)cb, (long long)N,
+                             c->d_consol_parts, rows, (long long)pk_pitch);
+          const bed2_t* sb = reinterpret_cast<const bed2_t*>(rows);
+          hipLaunchKernelGGL((consolidate_fill_kernel<bed2_t>), dim3((unsigned)M), dim3(64), 0, st, sb, (long long)pk_pitch,
+                             (long long)N, nparts, c->d_consol_parts, d_af_dst, d_fill);
+          hipLaunchKernelGGL(hcp_header_kernel, dim3(1), dim3(128), 0, st, c->d_consol_parts, nparts, M, (long long)N, d_fill,
+                             reinterpret_cast<HcpHeader*>(p.dG));
+        }
+      } else {
       if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
-      if (e == hipSuccess && mode == 7) {
-        // rows of a .bed matrix RESIDENT on the device (rvt_submit_gene_bed_dev): 6 MB of HBM traffic instead of the link
-        e = hipMemcpy2DAsync(rows, pk_pitch, G, cb, cb, (size_t)M, hipMemcpyDeviceToDevice, c->copy_stream);
-      } else if (e == hipSuccess) {
+      if (e == hipSuccess) {
         c->h2d_stream = c->copy_stream;
         const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M, true);  // (pad bytes of a packed row are zero anyway)
         c->h2d_stream = c->io_stream;
@@ -743,6 +754,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
                            (long long)N, nparts, c->d_consol_parts, d_af_dst, d_fill);
         hipLaunchKernelGGL(hcp_header_kernel, dim3(1), dim3(128), 0, st, c->d_consol_parts, nparts, M, (long long)N, d_fill,
                            reinterpret_cast<HcpHeader*>(p.dG));
+      }
       }
     } else if (mode == 1 || mode == 5 || mode == 6) {
       int rc = mode == 1   ? upload_block_data(c, p.dG, M, (const double*)G)
@@ -851,6 +863,213 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
 }
 }  // namespace
 
+// ---- several genes of a device-resident .bed matrix per call (rvt_submit_genes, kind 7) -----------------------------------------
+// One gene at a time the hand-off is three small dependent kernels on one stream (~45 us per gene whatever the host does).  A
+// call that names n genes runs them as TWO launches: every row of every gene counted and copied into its gene's block (grid
+// (sample pieces, rows)), then one workgroup per gene for the allele frequencies, the imputation values and the header of the
+// packed-row kernel — the same expressions in the same order as consolidate_count_kernel<bed2_t>, consolidate_fill_kernel and
+// hcp_header_kernel: the records are bit-identical.
+namespace {
+struct BedRowRef {
+  const unsigned char* src;
+  unsigned char* dst;
+};
+struct BedGeneRef {
+  int row0, M;
+  HcpHeader* hdr;
+  double* af_dst;
+};
+__global__ __launch_bounds__(256) void bed_count_copy_rows_kernel(const BedRowRef* __restrict__ rows, long long N,
+                                                                  ConsolPart* __restrict__ parts) {
+  __shared__ unsigned s_n1[256], s_n2[256], s_nm[256];
+  const BedRowRef rr = rows[blockIdx.y];
+  const long long i0 = (long long)blockIdx.x * kConsolChunk;
+  const long long i1 = (i0 + kConsolChunk < N) ? i0 + kConsolChunk : N;
+  unsigned n1 = 0, n2 = 0, nm = 0;
+  for (long long b = (i0 >> 2) + threadIdx.x; 4 * b < i1; b += 256) {
+    unsigned v = rr.src[b];
+    const long long left = i1 - 4 * b;
+    if (left < 4) v &= (1u << (2 * left)) - 1u;
+    rr.dst[b] = (unsigned char)v;
+    const unsigned lo = v & 0x55u, hi = (v >> 1) & 0x55u;
+    n1 += __popc(hi & ~lo);
+    n2 += __popc(hi & lo);
+    nm += __popc(lo & ~hi);
+  }
+  s_n1[threadIdx.x] = n1;
+  s_n2[threadIdx.x] = n2;
+  s_nm[threadIdx.x] = nm;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s_n1[threadIdx.x] += s_n1[threadIdx.x + off];
+      s_n2[threadIdx.x] += s_n2[threadIdx.x + off];
+      s_nm[threadIdx.x] += s_nm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double ac = (double)s_n1[0] + 2.0 * (double)s_n2[0];
+    parts[(long long)blockIdx.y * gridDim.x + blockIdx.x] =
+        ConsolPart{ac, ac, (long long)(i1 - i0) - (long long)s_nm[0], s_nm[0] ? 3 : 0, (int)s_n2[0]};
+  }
+}
+__global__ __launch_bounds__(128) void bed_fill_header_kernel(const BedGeneRef* __restrict__ genes,
+                                                              const ConsolPart* __restrict__ parts, int nparts, long long N) {
+  const BedGeneRef g = genes[blockIdx.x];
+  const int j = threadIdx.x, M = g.M;
+  bool flip = false, poly = false, cm = false;
+  if (j < M) {
+    const ConsolPart* p = parts + (long long)(g.row0 + j) * nparts;
+    double sumAC = 0.0, ac = 0.0;
+    long long nonneg = 0, n2 = 0;
+    int flags = 0;
+    for (int k = 0; k < nparts; ++k) {
+      sumAC += p[k].sumAC;
+      ac += p[k].ac;
+      nonneg += p[k].nonneg;
+      flags |= p[k].flags;
+      n2 += p[k].pad;
+    }
+    g.af_dst[j] = N ? 0.5 * sumAC / (double)N : -1.0;  // (consolidate_fill_kernel)
+    double fill = 0.0;
+    if ((flags & 1) && (flags & 2)) {
+      const long long an = 2 * nonneg;
+      const int aci = (int)ac;
+      fill = (an == 0) ? 0.0 : 2.0 * (1.0 * aci / (double)an);
+    }
+    const long long nm = N - nonneg, n1 = (long long)ac - 2 * n2, n0 = nonneg - n1 - n2;  // (hcp_header_kernel)
+    const double mu = nm > 0 ? fill : 0.0;
+    g.hdr->mu[j] = mu;
+    const double s = ac + (double)nm * mu;
+    flip = !(s <= (double)N);
+    double mn = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+    double mx = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+    if (nm > 0) {
+      mn = fmin(mn, mu);
+      mx = fmax(mx, mu);
+    }
+    poly = !(mn == mx);
+    cm = nm > 0 && poly && (flip ? mu <= 1.0 : mu >= 1.0);
+  }
+  const unsigned long long bf = __ballot(flip), bp = __ballot(poly), bc = __ballot(cm);
+  if ((j & 15) == 0 && j < 96) {
+    const int b = j >> 4, sh = 16 * ((j >> 4) & 3);
+    g.hdr->flip[b] = (unsigned short)((bf >> sh) & 0xffffu);
+    g.hdr->poly[b] = (unsigned short)((bp >> sh) & 0xffffu);
+    g.hdr->cm[b] = (unsigned short)((bc >> sh) & 0xffffu);
+  }
+}
+
+// returns -1 when the call does not apply (a gene that has to be expanded): the caller submits gene by gene
+int submit_bed_dev_batch(rvt_ctx* c, int n, const int64_t* ids, const int* Ms, const void* const* data, uint32_t tests,
+                         const rvt_params* prm) {
+  if (n < 1 || n > rvt_ctx::kAfSlots / 2) return -1;
+  if (!c->have_null || (tests & RVT_TEST_FAMSKAT)) return -1;
+  int R = 0;
+  for (int g = 0; g < n; ++g) {
+    if (!data[g] || Ms[g] < 1 || Ms[g] > RVT_MAX_VARIANTS || !packed_eligible(c, Ms[g], tests, prm)) return -1;
+    R += Ms[g];
+  }
+  hipSetDevice(c->device);
+  TraceScope ts_all(c, &c->tr_block);
+  hipStream_t st = c->io_stream;
+  const int64_t N = c->nc.N;
+  const size_t cb = (size_t)((N + 3) / 4), pk_pitch = (cb + 15) / 16 * 16;
+  const int nparts = (int)((N + kConsolChunk - 1) / kConsolChunk);
+  if (!c->h_af_ring)
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_af_ring, sizeof(double) * rvt_ctx::kAfSlots * RVT_MAX_VARIANTS, hipHostMallocMapped));
+  if (c->af_unresolved + n > rvt_ctx::kAfSlots) {
+    int rc = resolve_af(c);
+    if (rc) return rc;
+  }
+  double* mapped = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&mapped, c->h_af_ring, 0));
+  // device work space of the call: row and gene references, the rows' partial counts
+  const size_t b_rows = (sizeof(BedRowRef) * (size_t)R + 255) / 256 * 256, b_genes = (sizeof(BedGeneRef) * (size_t)n + 255) / 256 * 256;
+  const size_t need = b_rows + b_genes + sizeof(ConsolPart) * (size_t)R * nparts;
+  if (c->bedbatch_cap < need) {
+    HIP_TRY(c, sync_stream(st));
+    if (c->d_bedbatch) hipFree(c->d_bedbatch);
+    c->d_bedbatch = nullptr;
+    c->bedbatch_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_bedbatch, need + need / 2));
+    c->bedbatch_cap = need + need / 2;
+  }
+  std::vector<BedRowRef> rows((size_t)R);
+  std::vector<BedGeneRef> genes((size_t)n);
+  std::vector<rvt_ctx::Pending> pend((size_t)n);
+  auto give_back = [&](int upto) {
+    for (int g = 0; g < upto; ++g) c->pk_pool.emplace_back(pend[(size_t)g].bytes, pend[(size_t)g].dG);
+  };
+  int r0 = 0;
+  for (int g = 0; g < n; ++g) {
+    rvt_ctx::Pending& p = pend[(size_t)g];
+    const int M = Ms[g];
+    p.id = ids[g];
+    p.M = M;
+    p.launched = false;
+    std::memset(&p.res, 0, sizeof(p.res));
+    const size_t gene_bytes = (size_t)kHcpHeaderBytes + pk_pitch * M + 16;
+    int best = -1;
+    for (int i = 0; i < (int)c->pk_pool.size(); ++i)
+      if (c->pk_pool[i].first >= gene_bytes && c->pk_pool[i].first <= 4 * gene_bytes &&
+          (best < 0 || c->pk_pool[i].first < c->pk_pool[best].first))
+        best = i;
+    if (best >= 0) {
+      p.dG = c->pk_pool[best].second;
+      p.bytes = c->pk_pool[best].first;
+      c->pk_pool.erase(c->pk_pool.begin() + best);
+    } else {
+      if (hipMalloc((void**)&p.dG, gene_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        give_back(g);
+        return fail(c, RVT_E_HIP, "hipMalloc(%zu bytes) failed for a packed gene", gene_bytes);
+      }
+      p.bytes = gene_bytes;
+      if (hipMemsetAsync(p.dG, 0, gene_bytes, st) != hipSuccess) {
+        give_back(g + 1);
+        return fail(c, RVT_E_HIP, "clearing a packed gene's block failed");
+      }
+    }
+    unsigned char* dst = reinterpret_cast<unsigned char*>(p.dG) + kHcpHeaderBytes;
+    const unsigned char* src = static_cast<const unsigned char*>(data[g]);
+    for (int j = 0; j < M; ++j) rows[(size_t)(r0 + j)] = BedRowRef{src + cb * (size_t)j, dst + pk_pitch * (size_t)j};
+    const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
+    genes[(size_t)g] = BedGeneRef{r0, M, reinterpret_cast<HcpHeader*>(p.dG), mapped + (size_t)slot * RVT_MAX_VARIANTS};
+    p.af_slot = slot;
+    p.af.resize((size_t)M);
+    p.kind = 3;
+    p.decoded = 0;
+    p.tests = tests;
+    p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};
+    r0 += M;
+  }
+  char* w = c->d_bedbatch;
+  BedRowRef* d_rows = reinterpret_cast<BedRowRef*>(w);
+  BedGeneRef* d_genes = reinterpret_cast<BedGeneRef*>(w + b_rows);
+  ConsolPart* d_parts = reinterpret_cast<ConsolPart*>(w + b_rows + b_genes);
+  hipError_t e = hipMemcpyAsync(d_rows, rows.data(), sizeof(BedRowRef) * (size_t)R, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_genes, genes.data(), sizeof(BedGeneRef) * (size_t)n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bed_count_copy_rows_kernel, dim3((unsigned)nparts, (unsigned)R), dim3(256), 0, st, d_rows, (long long)N, d_parts);
+    hipLaunchKernelGGL(bed_fill_header_kernel, dim3((unsigned)n), dim3(128), 0, st, d_genes, d_parts, nparts, (long long)N);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    give_back(n);
+    return fail(c, RVT_E_HIP, "resident .bed genes: %s", hipGetErrorString(e));
+  }
+  for (int g = 0; g < n; ++g) {
+    c->queue.push_back(std::move(pend[(size_t)g]));
+    ++c->af_unresolved;
+    if (c->trace_submit) ++c->tr_genes;
+  }
+  TraceScope ts_l(c, &c->tr_launch);
+  return launch_pending(c, c->queue.size(), true);
+}
+}  // namespace
+
 int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                     const rvt_params* prm) {
   return submit_common(c, gene_id, M, G, 0, af, nullptr, tests, prm);
@@ -917,6 +1136,24 @@ int rvt_submit_genes(rvt_ctx* c, int kind, int n, const int64_t* gene_ids, const
   // The genes' transfers out of page-locked caller memory (rvt_host_register) are queued back to back and waited for ONCE:
   // the call returns when the last of them has been read (a gene-by-gene submission waits per gene — the buffer may be
   // rewritten on return — which leaves the link idle between two genes).
+  if (kind == 7) {
+    // resident rows: whole calls at once where every gene may stay packed, groups of up to 256 genes per batch of the pipeline
+    // (nothing waits for a link here: the larger the batch, the fuller the chip)
+    const int group0 = c->submit_group;
+    c->submit_group = std::max(group0, 256);
+    int rc = RVT_OK;
+    for (int g0 = 0; g0 < n && !rc; g0 += rvt_ctx::kAfSlots / 2) {
+      const int ng = std::min(n - g0, rvt_ctx::kAfSlots / 2);
+      rc = submit_bed_dev_batch(c, ng, gene_ids + g0, M + g0, data + g0, tests, prm);
+      if (rc == -1) {
+        rc = RVT_OK;
+        for (int g = g0; g < g0 + ng && !rc; ++g)
+          rc = submit_common(c, gene_ids[g], M[g], data[g], 7, nullptr, nullptr, tests, prm);
+      }
+    }
+    c->submit_group = group0;
+    return rc;
+  }
   c->reg_defer = true;
   int rc = RVT_OK;
   for (int g = 0; g < n && !rc; ++g)
