@@ -198,7 +198,9 @@ int rvt_block_upload(rvt_ctx* ctx, double* dG, int M, const double* G_host);
  * pageable memory into a pinned ring with a few CPU threads (host_stage.h; ~35 GB/s) or lets the runtime do it.  An
  * adapter that owns the buffer can page-lock it ONCE — rvt_host_register(ctx, ptr, bytes) — and every later rvt_submit_* /
  * rvt_block_upload whose source lies inside a registered range is a DMA straight out of it at the rate of the link, with
- * no CPU copy; the call still returns only when the range has been read.  rvt_host_unregister before the buffer is freed
+ * no CPU copy (fp64 blocks that hold hard calls and imputed means are still packed to 2-bit rows by the staging threads first:
+ * reading 200 MB at memory speed and sending 6 MB beats sending 200 MB at link speed); the call still returns only when the
+ * range has been read.  rvt_host_unregister before the buffer is freed
  * (rvt_destroy unregisters what is left).  Registration changes no result. */
 int rvt_host_register(rvt_ctx* ctx, const void* ptr, size_t bytes);
 int rvt_host_unregister(rvt_ctx* ctx, const void* ptr);
