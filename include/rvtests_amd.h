@@ -552,8 +552,11 @@ int rvt_kbac_blocks(rvt_ctx* ctx, int n, const double* const* dG, const int* M, 
  * genotype matrix: GenotypeCounter allele frequencies (src/GenotypeCounter.h:14-51; missing counted in the
  * denominator) and imputeGenotypeToMean with its integer-truncated allele count (src/DataConsolidator.cpp:217-245).
  *   rvt_submit_gene_raw : N x M doubles, column-major (hard calls or dosages)
- *   rvt_submit_gene_i8  : N x M int8, column-major (hard calls 0/1/2, negative = missing): 1 byte per genotype over
- *                         PCIe instead of 8
+ *   rvt_submit_gene_i8  : N x M int8, column-major (hard calls 0/1/2, negative = missing): 1 byte per genotype in the
+ *                         caller's memory; when the gene may stay packed (see rvt_submit_gene_bed) the staging threads turn
+ *                         the bytes into .bed rows on the way — a quarter of a byte per genotype over PCIe — and the gene
+ *                         continues as a rvt_submit_gene_bed gene (a value above 2 is not a hard call: that gene crosses as
+ *                         bytes and is expanded to doubles on the device)
  *   rvt_submit_gene_bed : PLINK .bed storage as PlinkInputFile reads it in SNP-major mode
  *                         (libVcf/PlinkInputFile.cpp:24-47, codes libVcf/PlinkInputFile.h:206-209): M rows of
  *                         ceil(N/4) bytes, sample p in bits 2(p&3).. of byte p>>2; 00 -> 0, 10 -> 1, 11 -> 2,

@@ -363,6 +363,55 @@ inline PackedColumn pack_column_f64(const double* g, size_t n, unsigned char* ou
   return r;
 }
 
+// ---- the int8 boundary, packed on the way (round 6) -------------------------------------------------------------------------
+// rvt_submit_gene_i8 hands over hard calls 0 / 1 / 2 with negative = missing, one byte per genotype: exactly what PLINK's 2-bit
+// codes say (00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing).  The staging threads that would copy the 25 MB of a gene into the pinned
+// ring write the 6 MB of its .bed rows there instead, and the gene continues as a rvt_submit_gene_bed gene: a quarter of the
+// bytes on the link (the int8 feed ran at the link's rate, 1.4-2.0 k gene-sets/s at N = 500 000).  A value above 2 is not a
+// hard call: the gene then crosses as bytes, as before.
+inline bool pack_i8_scalar(const signed char* g, size_t n, unsigned char* out) {
+  for (size_t i = 0; i < n; i += 4) {
+    unsigned b = 0;
+    for (size_t e = 0; e < 4 && i + e < n; ++e) {
+      const int v = g[i + e];
+      if (v > 2) return false;
+      const unsigned code = v < 0 ? 1u : (v == 0 ? 0u : (v == 1 ? 2u : 3u));
+      b |= code << (2 * e);
+    }
+    out[i >> 2] = (unsigned char)b;
+  }
+  return true;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// 32 bytes -> 8 bytes of codes: the two code bits are two byte masks, deposited into the even and the odd bit positions
+__attribute__((target("avx2,bmi2"))) inline bool pack32_i8_avx2(const signed char* g, unsigned char* out) {
+  const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(g));
+  const __m256i two = _mm256_set1_epi8(2), one = _mm256_set1_epi8(1);
+  if (_mm256_movemask_epi8(_mm256_cmpgt_epi8(v, two))) return false;
+  const __m256i is2 = _mm256_cmpeq_epi8(v, two), is1 = _mm256_cmpeq_epi8(v, one);
+  const unsigned neg = (unsigned)_mm256_movemask_epi8(v);  // sign bits: missing
+  const unsigned m2 = (unsigned)_mm256_movemask_epi8(is2), m1 = (unsigned)_mm256_movemask_epi8(is1);
+  const unsigned long long x = _pdep_u64((unsigned long long)(m2 | neg), 0x5555555555555555ull) |
+                               _pdep_u64((unsigned long long)(m1 | m2), 0xAAAAAAAAAAAAAAAAull);
+  std::memcpy(out, &x, 8);
+  return true;
+}
+#endif
+// g[0 .. n) -> out[0 .. ceil(n / 4)), zeros up to `pitch` bytes; false = a value above 2.  isa: -1 widest, 0 scalar, 1 AVX2
+inline bool pack_column_i8(const signed char* g, size_t n, unsigned char* out, size_t pitch, int isa = -1) {
+  size_t i = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+  if ((isa < 0 || isa == 1) && avx2)
+    for (; i + 32 <= n; i += 32)
+      if (!pack32_i8_avx2(g + i, out + i / 4)) return false;
+#endif
+  if (i < n && !pack_i8_scalar(g + i, n - i, out + i / 4)) return false;
+  const size_t o = (n + 3) / 4;
+  if (o < pitch) std::memset(out + o, 0, pitch - o);
+  return true;
+}
+
 // A ring of pinned staging chunks.  The owner supplies the pinned memory and three callbacks:
 //   wait(k)                       block until the DMA that last read chunk k has finished
 //   send(k, off, dst, bytes)      enqueue the DMA of chunk k's bytes [off, off + bytes) to device address dst
@@ -491,6 +540,35 @@ struct StageRing {
       next = (next + 1) % (int)chunk.size();
       if (int rc = wait(k)) return rc;
       if (!pack_columns_to(chunk[k], dpitch, src + c0 * spitch_doubles, spitch_doubles, n, nc, pool, out + c0)) return 2;
+      if (int rc = send(k, 0, (char*)dst + c0 * dpitch, nc * dpitch)) return rc;
+      if (int rc = sent(k)) return rc;
+    }
+    return 0;
+  }
+  // The columns of an int8 block packed on the way (pack_column_i8): column j = src + j * spitch bytes, n samples -> device row j
+  // of `dpitch` bytes.  Returns 0 = sent, 1 = a HIP call failed, 2 = a value above 2 (the caller sends the bytes).
+  int pack_i8(void* dst, size_t dpitch, const signed char* src, size_t spitch, size_t n, size_t cols, CopyPool& pool) {
+    if (dpitch > chunk_bytes || cols == 0) return 2;
+    const size_t per = std::max<size_t>(1, chunk_bytes / dpitch);
+    for (size_t c0 = 0; c0 < cols; c0 += per) {
+      const size_t nc = std::min(per, cols - c0);
+      const int k = next;
+      next = (next + 1) % (int)chunk.size();
+      if (int rc = wait(k)) return rc;
+      // columns cut into runs of rows (multiples of 1 024 samples) so that all threads stay busy, as for the doubles
+      const size_t segs = std::max<size_t>(1, std::min<size_t>(8, (4 * (size_t)pool.threads() + nc - 1) / nc));
+      const size_t seg = std::max<size_t>(4096, ((n + segs - 1) / segs + 1023) / 1024 * 1024), nseg = (n + seg - 1) / seg;
+      std::atomic<int> bad{0};
+      char* base = chunk[k];
+      const std::function<void(size_t)> fn = [&](size_t item) {
+        if (bad.load(std::memory_order_relaxed)) return;
+        const size_t j = item / nseg, q = item % nseg, r0 = q * seg, len = std::min(seg, n - r0);
+        unsigned char* o = reinterpret_cast<unsigned char*>(base + j * dpitch) + r0 / 4;
+        if (!pack_column_i8(src + (c0 + j) * spitch + r0, len, o, q + 1 == nseg ? dpitch - r0 / 4 : len / 4))
+          bad.store(1, std::memory_order_relaxed);
+      };
+      pool.run_items(nc * nseg, fn);
+      if (bad.load()) return 2;
       if (int rc = send(k, 0, (char*)dst + c0 * dpitch, nc * dpitch)) return rc;
       if (int rc = sent(k)) return rc;
     }

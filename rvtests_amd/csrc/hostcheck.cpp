@@ -420,6 +420,12 @@ int hc_pack_column(const double* g, size_t n, unsigned char* out, size_t pitch, 
   *n_other = r.n_other;
   return r.ok ? 1 : 0;
 }
+// pack_column_i8 (int8 hard calls, negative = missing -> PLINK 2-bit codes) with a chosen instruction set (0 scalar, 1 AVX2)
+int hc_pack_column_i8(const signed char* g, size_t n, unsigned char* out, size_t pitch, int isa, int reps) {
+  bool ok = false;
+  for (int k = 0; k < (reps < 1 ? 1 : reps); ++k) ok = rvt::pack_column_i8(g, n, out, pitch, isa);
+  return ok ? 1 : 0;
+}
 int hc_cpu_has(int isa) {
 #if defined(__x86_64__)
   if (isa == 1) return __builtin_cpu_supports("avx2") ? 1 : 0;

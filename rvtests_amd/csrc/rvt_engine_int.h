@@ -152,6 +152,7 @@ struct rvt_ctx {
   double* d_Gt = nullptr;  // ... rotated by U'
   char* d_bedbatch = nullptr;   // rvt_submit_genes kind 7: row / gene references and partial counts of one call
   size_t bedbatch_cap = 0;
+  bool no_i8_pack = false;      // submit_common: this int8 gene holds a value above 2 — send its bytes
   int submit_group = 32;   // genes per asynchronous sub-batch of the streaming interface (RVT_SUBMIT_GROUP, rvt_set_submit_group)
   size_t fam_cols_cap = 0;
   int64_t fam_cols_ld = 0;  // (the leading dimension d_Gp / d_Gt were sized for)

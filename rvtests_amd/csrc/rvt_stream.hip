@@ -623,7 +623,11 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   // device block from the pool (smallest that fits) or a fresh zeroed allocation; pad rows stay zero because only
   // the N data rows of a column are ever written
   // PLINK 2-bit rows stay packed when the gene's tests allow it (gene_suffstat_hcp): a block of header + M padded rows
-  const bool packed = (mode == 3 || mode == 7) && packed_eligible(c, M, tests, prm);  // (7: the rows are on the device already)
+  // (7: the rows are on the device already; 2: int8 hard calls, turned into 2-bit rows by the staging threads on the way —
+  //  RVT_PACK_I8=0 sends the bytes)
+  const bool i8_packs = mode == 2 && !c->no_i8_pack && c->stage_on && c->nc.N >= 4096 &&
+                        !(getenv("RVT_PACK_I8") && atoi(getenv("RVT_PACK_I8")) == 0);
+  const bool packed = (mode == 3 || mode == 7 || i8_packs) && packed_eligible(c, M, tests, prm);
   const size_t pk_pitch = ((size_t)((c->nc.N + 3) / 4) + 15) / 16 * 16;
   const size_t need = packed ? (size_t)kHcpHeaderBytes + pk_pitch * M + 16 : sizeof(double) * (size_t)c->null_ld * M;
   bool fresh_packed = false;
@@ -740,7 +744,24 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
         }
       } else {
       if (fresh_packed) e = hipMemsetAsync(p.dG, 0, need, c->copy_stream);
-      if (e == hipSuccess) {
+      if (e == hipSuccess && mode == 2) {
+        // int8 hard calls: the staging threads write the gene's .bed rows into the pinned ring while they read its bytes
+        int prc = stage_ready(c) == RVT_OK ? 0 : 1;
+        if (prc == 0) {
+          c->h2d_stream = c->copy_stream;
+          prc = c->stage.pack_i8(rows, pk_pitch, (const signed char*)G, (size_t)N, (size_t)N, (size_t)M, CopyPool::pack_instance());
+          c->h2d_stream = c->io_stream;
+        }
+        if (prc == 2) {  // a value above 2 (not a hard call), or rows longer than a staging chunk: this gene crosses as bytes
+          (void)hipStreamSynchronize(c->copy_stream);  // (rows already on their way land before the block is handed out again)
+          give_back();
+          c->no_i8_pack = true;
+          const int rc2 = submit_common(c, gene_id, M, G, mode, af, af_out, tests, prm);
+          c->no_i8_pack = false;
+          return rc2;
+        }
+        if (prc != 0) e = hipErrorUnknown;
+      } else if (e == hipSuccess) {
         c->h2d_stream = c->copy_stream;
         const int rcs = staged_h2d_2d(c, rows, pk_pitch, G, cb, cb, (size_t)M, true);  // (pad bytes of a packed row are zero anyway)
         c->h2d_stream = c->io_stream;

@@ -145,3 +145,43 @@ def test_genes_of_a_resident_bed_matrix_give_the_records_of_the_host_rows(engine
             assert x == y_ or (x != x and y_ != y_), (f, x, y_)
     if not binary:
         assert want[3].skat_p > 0
+
+
+def test_int8_genes_are_packed_on_the_way(engine, monkeypatch):
+    """rvt_submit_gene_i8 at a size where the staging threads pack (N >= 4096): the gene crosses PCIe as .bed rows and gives the
+    records and allele frequencies of rvt_submit_gene_bed on the same calls bit for bit, and those of the unpacked int8
+    hand-off (RVT_PACK_I8=0) to rounding; a gene with a value above 2 is not a hard-call gene and crosses as bytes."""
+    N = 9001
+    Ms = (5, 30, 64, 81)
+    genes = [_raw_gene(N, M, seed=5 * M + 2, missing=0.02) for M in Ms]
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=21)
+    engine.set_null(0, X, res, v, s2)
+    engine.set_profiling(True)
+    af_bed = [engine.submit_gene_bed(g, engine.pack_bed(raw), raw.shape[1]) for g, raw in enumerate(genes)]
+    want = engine.collect()
+    engine.timing(reset=True)
+    af_i8 = [engine.submit_gene_raw(g, raw.astype(np.int8)) for g, raw in enumerate(genes)]
+    got = engine.collect()
+    tm = engine.timing(reset=True)
+    assert tm.genes_hard_call == len(genes)
+    monkeypatch.setenv("RVT_PACK_I8", "0")
+    af_un = [engine.submit_gene_raw(g, raw.astype(np.int8)) for g, raw in enumerate(genes)]
+    plain = engine.collect()
+    monkeypatch.delenv("RVT_PACK_I8")
+    for a, b, c_, fa, fb, fc in zip(got, want, plain, af_i8, af_bed, af_un):
+        assert np.array_equal(fa, fb) and np.array_equal(fa, fc)
+        for f in FIELDS:
+            x, y_, z = getattr(a, f), getattr(b, f), getattr(c_, f)
+            assert x == y_ or (x != x and y_ != y_), (f, x, y_)
+            if f.startswith("cmc") and f != "cmc_nonref" and abs(c_.cmc_U) < 1e-8:
+                continue
+            assert x == z or abs(x - z) <= 1e-11 * abs(z), (f, x, z)
+    odd = genes[1].astype(np.int8)
+    odd[17, 3] = 3                                            # not a hard call: PLINK's codes cannot say it
+    engine.submit_gene_raw(0, odd, want_af=False)
+    monkeypatch.setenv("RVT_PACK_I8", "0")
+    engine.submit_gene_raw(1, odd, want_af=False)
+    monkeypatch.delenv("RVT_PACK_I8")
+    a, b = engine.collect()
+    for f in FIELDS:
+        assert getattr(a, f) == getattr(b, f), f

@@ -120,3 +120,34 @@ def test_fp64_packing_agrees_across_instruction_sets(n):
             if L.hc_cpu_has(isa):
                 dt = run(cases[1][1], isa, reps=20)[5]
                 print("pack_column_f64 isa %d: %.1f GB/s" % (isa, 8.0 * n / dt / 1e9))
+
+
+@pytest.mark.parametrize("n", [1, 3, 31, 32, 33, 100, 4099, 65536 + 7])
+def test_int8_packing_gives_plink_codes(n):
+    """pack_column_i8 (the int8 boundary packed to PLINK 2-bit rows by the staging threads): 0 -> 00, 1 -> 10, 2 -> 11, negative ->
+    01 (missing), sample p in bits 2 (p & 3) of byte p >> 2 — the scalar and the AVX2 form against a numpy statement of the codes
+    (libVcf/PlinkInputFile.h:206-209); zeros behind the row up to its pitch; a value above 2 is refused by both."""
+    import numpy as np
+    L = hc.lib()
+    L.hc_pack_column_i8.restype = C.c_int
+    L.hc_pack_column_i8.argtypes = [C.POINTER(C.c_byte), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, C.c_int, C.c_int]
+    rng = np.random.default_rng(n)
+    g = rng.integers(0, 3, n).astype(np.int8)
+    g[rng.random(n) < 0.1] = -9
+    if n > 2:
+        g[1] = -128
+    pitch = (n + 3) // 4 + 7
+    code = np.where(g < 0, 1, np.where(g == 0, 0, np.where(g == 1, 2, 3))).astype(np.uint8)
+    code = np.concatenate([code, np.zeros((-n) % 4, dtype=np.uint8)]).reshape(-1, 4)
+    want = np.concatenate([code[:, 0] | (code[:, 1] << 2) | (code[:, 2] << 4) | (code[:, 3] << 6), np.zeros(7, dtype=np.uint8)])
+    for isa in (0, 1):
+        out = np.full(pitch, 0xAB, dtype=np.uint8)
+        ok = L.hc_pack_column_i8(g.ctypes.data_as(C.POINTER(C.c_byte)), n, out.ctypes.data_as(C.POINTER(C.c_ubyte)), pitch, isa, 1)
+        assert ok == 1 and np.array_equal(out, want), isa
+    for pos in {0, n // 2, n - 1}:
+        bad = g.copy()
+        bad[pos] = 3
+        for isa in (0, 1):
+            out = np.zeros(pitch, dtype=np.uint8)
+            assert L.hc_pack_column_i8(bad.ctypes.data_as(C.POINTER(C.c_byte)), n, out.ctypes.data_as(C.POINTER(C.c_ubyte)), pitch, isa,
+                                       1) == 0
