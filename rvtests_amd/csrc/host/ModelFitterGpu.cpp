@@ -20,10 +20,94 @@ std::string floatToString(double v) {
   return ss.str();
 }
 
+// printf("%g") without printf: a row of MetaCov's window is a thousand of these, and glibc's conversion (arbitrary precision,
+// locale, stream state) costs ~200 ns each — the formatting threads of the adapter spent more on a flush than the device.
+// The six significant digits are round-to-nearest of v x 10^(5 - k) computed in double: v x 10^p is ONE rounding of an exact
+// product for |p| <= 22 (10^p is a double), i.e. off by at most 1.2e-10 at 10^6, so the digits are those of the exact decimal
+// expansion unless the fraction lies within 1e-7 of one half — those (and everything outside the range, infinities, NaN) go
+// to snprintf.  Same characters as "%g" in the C locale: fixed notation for exponents -4 .. 5, otherwise d.ddddde+XX, trailing
+// zeros and a trailing point removed, "-0" for a negative zero.  tests/test_host_format_cpu.py: 3 million values against printf.
+size_t formatG(double v, char* out) {
+  static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  char* o = out;
+  double a = v;
+  if (std::signbit(v)) {
+    a = -v;
+    *o++ = '-';
+  }
+  if (a == 0.0) {
+    *o++ = '0';
+    return (size_t)(o - out);
+  }
+  if (!(a >= 1e-17 && a < 1e22)) return (size_t)snprintf(out, 32, "%g", v);  // (also NaN, infinities)
+  int ex;
+  (void)std::frexp(a, &ex);                       // a in [2^(ex-1), 2^ex)
+  int k = (int)std::floor((ex - 1) * 0.30102999566398120);  // floor(log10 a) or one less
+  long long digits = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const int p = 5 - k;
+    if (p > 22 || p < -22) return (size_t)snprintf(out, 32, "%g", v);
+    const double x = p >= 0 ? a * p10[p] : a / p10[-p];
+    if (x < 1e5) {
+      --k;
+      continue;
+    }
+    if (x >= 1e6) {
+      ++k;
+      continue;
+    }
+    const double r = std::floor(x), f = x - r;
+    if (std::fabs(f - 0.5) < 1e-7) return (size_t)snprintf(out, 32, "%g", v);  // a tie, or too close to call in double
+    digits = (long long)r + (f > 0.5 ? 1 : 0);
+    if (digits == 1000000) {
+      digits = 100000;
+      ++k;
+    }
+    break;
+  }
+  if (digits == 0) return (size_t)snprintf(out, 32, "%g", v);
+  char d[6];
+  for (int i = 5; i >= 0; --i) {
+    d[i] = (char)('0' + digits % 10);
+    digits /= 10;
+  }
+  int nd = 6;
+  while (nd > 1 && d[nd - 1] == '0') --nd;  // trailing zeros go
+  if (k < -4 || k >= 6) {
+    *o++ = d[0];
+    if (nd > 1) {
+      *o++ = '.';
+      for (int i = 1; i < nd; ++i) *o++ = d[i];
+    }
+    *o++ = 'e';
+    int e = k;
+    if (e < 0) {
+      *o++ = '-';
+      e = -e;
+    } else {
+      *o++ = '+';
+    }
+    if (e >= 100) *o++ = (char)('0' + e / 100);
+    *o++ = (char)('0' + (e / 10) % 10);
+    *o++ = (char)('0' + e % 10);
+  } else if (k >= 0) {
+    for (int i = 0; i <= k; ++i) *o++ = i < nd ? d[i] : '0';
+    if (nd > k + 1) {
+      *o++ = '.';
+      for (int i = k + 1; i < nd; ++i) *o++ = d[i];
+    }
+  } else {
+    *o++ = '0';
+    *o++ = '.';
+    for (int i = 0; i < -k - 1; ++i) *o++ = '0';
+    for (int i = 0; i < nd; ++i) *o++ = d[i];
+  }
+  return (size_t)(o - out);
+}
 std::string formatG(double v) {
-  char buf[64];
-  snprintf(buf, sizeof(buf), "%g", v);
-  return buf;
+  char buf[40];
+  return std::string(buf, formatG(v, buf));
 }
 
 static std::string lower(std::string s) {
@@ -1016,7 +1100,9 @@ int MetaCovTest::flush(bool final) {
           values += ',';
         }
         positions += std::to_string(sites[j].pos);
-        values += formatG((double)row[j - h]);   // (the device applied the float cast and the float 1/N, src/Model.cpp:975-984)
+        char num_buf[40];
+        values.append(num_buf, formatG((double)row[j - h], num_buf));  // (the device applied the float cast and the float 1/N,
+                                                                      //  src/Model.cpp:975-984)
         lastPrinted = j;
         ++num;
       }

@@ -101,6 +101,7 @@ struct SiteInfo {
 
 std::string floatToString(double v);  // base/TypeConversion.h:100-105 (6 significant digits)
 std::string formatG(double v);        // printf("%g")
+size_t formatG(double v, char* out);  // the same characters into out (at least 32 bytes, not terminated); returns their number
 
 // ---- ModelParser --------------------------------------------------------------------------------------------
 class ModelParser {
