@@ -111,7 +111,7 @@ def test_genes_of_a_resident_bed_matrix_give_the_records_of_the_host_rows(engine
     first row — one at a time with allele frequencies, several per call, with permutations (the gene is expanded) and under a
     binary trait (expanded too).  Every record and frequency equals the one rvt_submit_gene_bed gives for the same rows."""
     import rvtests_amd
-    Ms = (1, 5, 17, 30, 48, 64, 81, 96)
+    Ms = (1, 5, 17, 30, 48, 64, 81, 96, 120)                 # (120: wider than the packed-row kernel takes — expanded)
     genes = [_raw_gene(N, M, seed=77 * M + 1, missing=(0.0 if M % 2 else 0.02)) for M in Ms]
     X, y, res, v, s2 = synth.make_null(N, 2, binary, seed=12)
     engine.set_null(binary, X, res, v, s2)

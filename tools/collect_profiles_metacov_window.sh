@@ -11,11 +11,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 tools/bench_metacov.py --skip-blocks --window "$WIN" > "$OUT/metacov_window_result.txt" 2> "$OUT/metacov_window.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_mw" -o k -- python3 tools/bench_metacov.py --skip-blocks --no-cpu --window-dosage "" --window "$WIN" > "$OUT/metacov_window_kt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_mw" -o k -- python3 tools/bench_metacov.py --skip-blocks --no-cpu --window-dosage "" --window-imputed "" --window "$WIN" > "$OUT/metacov_window_kt.log" 2>&1
 find "$OUT/kt_mw" -name '*kernel_stats.csv' -exec cp {} "$OUT/metacov_window_kernel_stats.csv" \;
 rm -rf "$OUT/kt_mw"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mw_$C" -o p -- python3 tools/bench_metacov.py --skip-blocks --no-cpu --window-dosage "" --window "$WIN" > "$OUT/metacov_window_pmc_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mw_$C" -o p -- python3 tools/bench_metacov.py --skip-blocks --no-cpu --window-dosage "" --window-imputed "" --window "$WIN" > "$OUT/metacov_window_pmc_$C.log" 2>&1
   F=$(find "$OUT/pmc_mw_$C" -name '*counter_collection.csv' | head -1)
   python3 tools/pmc_summary.py "$F" "$OUT/metacov_window_pmc_$C.csv" > /dev/null
   rm -rf "$OUT/pmc_mw_$C"
@@ -23,7 +23,9 @@ done
 python3 - "$OUT" <<'PY'
 import csv, json, sys
 out = sys.argv[1]
+# (the counter passes run the hard-call windows only: the figure is §8(d)'s bytes per evicted variant of the path the bench names)
 lines = [json.loads(l) for l in open(out + "/metacov_window_result.txt") if l.startswith("{") and "window_markers" in l]
+lines = [l for l in lines if "hard calls, circular" in l["workload"]]
 N = lines[0]["N"]
 evicted = sum(l["variants"] * (l["flushes"] + 1) / l["flushes"] for l in lines)      # (the warm-up flush of every width counts)
 def load(path, col):
