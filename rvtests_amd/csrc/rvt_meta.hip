@@ -1182,6 +1182,9 @@ int rvt_block_upload_columns(rvt_ctx* c, double* dG, int col0, int ncols, const 
       }
       static const int one = 1;
       HIP_TRY(c, hipMemcpyAsync(ck.d_flags + col, &one, sizeof(int), hipMemcpyHostToDevice, c->io_stream));
+      // (this pass knows no other value: the slot's mask of an earlier occupant must not survive it — a window that mixes
+      //  this column with mean-imputed ones reads the masks of all its columns)
+      if (ck.d_m4) HIP_TRY(c, hipMemsetAsync(ck.d_m4 + (size_t)col * (size_t)ldk4, 0, (size_t)ldk4, c->io_stream));
       const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(kCovSlices, (int64_t)N / 4096 + 1));
       launch_cov_prep(c->io_stream, d, true, dim3(1, (unsigned)slices), dG + (size_t)col * ld, (int64_t)N, (int64_t)ld, 1, c->d_X,
                       ck.d_i8 + (size_t)col * (size_t)ldk, ldk, c->d_cc_part, nullptr, nullptr, ck.d_flags + col, 0, 0,

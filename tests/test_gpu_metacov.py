@@ -678,3 +678,37 @@ def test_cov_band_does_not_depend_on_how_the_columns_were_uploaded(engine_factor
     b2, xz2, zz2, p2 = eng.cov_band(r2, cap, col0, V, V, halo)
     assert eng.cov_band_last_path() == 4
     assert np.array_equal(b1, b2, equal_nan=True) and np.array_equal(xz1, xz2) and np.array_equal(p1, p2)
+
+
+def test_a_slot_rewritten_without_packing_leaves_no_mask_behind(engine_factory, monkeypatch):
+    """A ring slot that held a mean-imputed column (cache state 2: hard calls + a mask of the other value) is overwritten by a
+    column of pure hard calls that crosses as doubles (RVT_UPLOAD_FP64=1: the column pass of that path knows no other value).
+    The window still mixes it with imputed columns, so the four-product band reads the slot's mask: it must be empty."""
+    N, V, d, halo = 5200, 300, 2, 80
+    G, chrom, pos, X, y = make_case(N, V, d, 0, 909)
+    G = np.asfortranarray(np.rint(G))
+    rng = np.random.default_rng(4)
+    for j in range(V):
+        miss = rng.random(N) < 0.05
+        G[miss, j] = G[~miss, j].mean()
+    rc, beta, pred, res, s2 = orc.fit_linear(X, y)
+    eng = engine_factory()
+    eng.set_null(0, X, res, np.full(N, s2), s2)
+    blk = eng.alloc_block(V)
+    for j in range(V):
+        eng.upload_columns(blk, j, G[:, j])
+    G2 = G.copy()
+    for j in (10, 11, 150):
+        G2[:, j] = np.rint(rng.random(N) * 2.2).clip(0, 2)     # pure hard calls, no other value
+    monkeypatch.setenv("RVT_UPLOAD_FP64", "1")
+    for j in (10, 11, 150):
+        eng.upload_columns(blk, j, G2[:, j])
+    monkeypatch.delenv("RVT_UPLOAD_FP64")
+    band = eng.cov_band(blk, 0, 0, V, V, halo)[0]
+    assert eng.cov_band_last_path() == 4
+    monkeypatch.setenv("RVT_METACOV_FP64", "1")
+    band64 = eng.cov_band(blk, 0, 0, V, V, halo)[0]
+    monkeypatch.delenv("RVT_METACOV_FP64")
+    m = ~np.isnan(band64)
+    assert np.array_equal(np.isnan(band), np.isnan(band64))
+    assert np.abs(band[m] - band64[m]).max() <= 2e-7 * np.abs(band64[m]).max()
