@@ -185,3 +185,31 @@ def test_int8_genes_are_packed_on_the_way(engine, monkeypatch):
     a, b = engine.collect()
     for f in FIELDS:
         assert getattr(a, f) == getattr(b, f), f
+
+
+def test_resident_bed_genes_at_the_bench_size(engine):
+    """N = 500 000 (rows of 125 000 bytes; the batch path of rvt_submit_genes kind 7): two genes of a resident matrix against the
+    same rows handed over from host memory and against the int8 hand-off packed on the way — identical records."""
+    N = 500_000
+    Ms = (50, 77)
+    genes = [_raw_gene(N, M, seed=3 * M, missing=0.01) for M in Ms]
+    X, y, res, v, s2 = synth.make_null(N, 3, 0, seed=33)
+    engine.set_null(0, X, res, v, s2)
+    rows = [engine.pack_bed(g) for g in genes]
+    cb = (N + 3) // 4
+    d_bed = engine.bed_alloc(sum(Ms))
+    engine.bed_upload(d_bed, 0, rows[0])
+    engine.bed_upload(d_bed, Ms[0], rows[1])
+    for g, (r, M) in enumerate(zip(rows, Ms)):
+        engine.submit_gene_bed(g, r, M, want_af=False)
+    want = engine.collect()
+    engine.submit_genes_bed_dev([0, 1], [d_bed, d_bed + Ms[0] * cb], Ms)
+    got = engine.collect()
+    for g, raw in enumerate(genes):
+        engine.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
+    got8 = engine.collect()
+    engine.bed_free(d_bed)
+    for a, b, c_ in zip(got, want, got8):
+        assert a.skat_p > 0 and a.n_poly > 0
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f) and getattr(c_, f) == getattr(b, f), f
