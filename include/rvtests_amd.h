@@ -586,7 +586,9 @@ int rvt_submit_gene_bed(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned cha
  *   rvt_bed_upload           rows [first_variant, first_variant + n_variants) from host memory (returns when they are there)
  *   rvt_submit_gene_bed_dev  like rvt_submit_gene_bed with d_rows = d_bed + first_row * ceil(N/4): M consecutive rows.  The
  *                            rows are read when the gene is computed: they must stay unchanged until its record has been
- *                            collected.  Same records as rvt_submit_gene_bed of the same rows, bit for bit.
+ *                            collected.  Same records as rvt_submit_gene_bed of the same rows to 1e-11 relative (SKAT-O's p to
+ *                            1e-6): resident genes form G'[X | rr] on the int8 matrix cores from digit planes of the null
+ *                            tile; allele frequencies, and genes that have to be expanded, bit for bit.
  *   rvt_submit_genes         kind 7 = the same, several genes per call (data[g] = device address of gene g's first row)
  *   rvt_bed_free             waits for queued genes, then frees */
 int rvt_bed_alloc(rvt_ctx* ctx, int64_t n_variants, unsigned char** d_bed);

@@ -5,7 +5,29 @@
 namespace rvt {
 
 void k2_launch_hcp(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
-                   int d) {
+                   int d, const HcpPlanes* pl) {
+  if (pl) {
+    // G'[X | rr] from the digit planes of the null tile (gene_tnull_hcp), everything else from the kernel without that product
+    switch (MT) {
+      case 1: hipLaunchKernelGGL((gene_suffstat_hcp<1, 4, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      case 2: hipLaunchKernelGGL((gene_suffstat_hcp<2, 3, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      case 3: hipLaunchKernelGGL((gene_suffstat_hcp<3, 2, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      case 4: hipLaunchKernelGGL((gene_suffstat_hcp<4, 2, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      case 5: hipLaunchKernelGGL((gene_suffstat_hcp<5, 1, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      case 6: hipLaunchKernelGGL((gene_suffstat_hcp<6, 1, false>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
+      default: return;
+    }
+    switch (MT) {
+      case 1: hipLaunchKernelGGL(gene_tnull_hcp<1>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      case 2: hipLaunchKernelGGL(gene_tnull_hcp<2>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      case 3: hipLaunchKernelGGL(gene_tnull_hcp<3>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      case 4: hipLaunchKernelGGL(gene_tnull_hcp<4>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      case 5: hipLaunchKernelGGL(gene_tnull_hcp<5>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      case 6: hipLaunchKernelGGL(gene_tnull_hcp<6>, grid, dim3(64), 0, st, d_desc, *pl, N, ld); break;
+      default: break;
+    }
+    return;
+  }
   switch (MT) {
     case 1: hipLaunchKernelGGL((gene_suffstat_hcp<1, 4>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;
     case 2: hipLaunchKernelGGL((gene_suffstat_hcp<2, 3>), grid, dim3(64), 0, st, d_desc, nt, N, ld, d); break;

@@ -182,6 +182,11 @@ static void free_null(rvt_ctx* c) {
     *p = nullptr;
   }
   c->d_X = c->d_rr = c->d_zeros = nullptr;  // inside d_nulltile
+  if (c->d_hcp_xq) hipFree(c->d_hcp_xq);
+  if (c->d_hcp_scale) hipFree(c->d_hcp_scale);
+  c->d_hcp_xq = nullptr;
+  c->d_hcp_scale = nullptr;
+  c->hcp_planes_state = 0;
   if (c->d_nulltile_w) hipFree(c->d_nulltile_w);
   if (c->d_vq) hipFree(c->d_vq);
   if (c->d_dq) hipFree(c->d_dq);
@@ -1078,6 +1083,66 @@ struct BatchTrace {
   }
 };
 
+// The packed-row path of RESIDENT .bed genes forms G'[X | rr] on the int8 matrix cores (gene_tnull_hcp, suffstat_hcp.hip.h): every
+// column of [X_0 .. X_{d-1} | rr] as eight balanced base-128 digits of its fixed-point value, 56 bits below a power of two above
+// twice the column's largest entry, in operand order.  Built from the device's null tile the first time a batch asks for it
+// (c->hcp_planes_state: 0 not built, 1 ready, -1 this model cannot: a column whose largest entry exceeds 2^20 x its root mean
+// square would leave its typical entries fewer than 36 bits — such a model keeps the fp64 product).
+static int ensure_hcp_planes(rvt_ctx* c) {
+  if (c->hcp_planes_state != 0) return RVT_OK;
+  c->hcp_planes_state = -1;
+  const NullConsts& nc = c->nc;
+  const int64_t N = nc.N, ld = nc.ld;
+  const int d = nc.d, ncx = d + 1;
+  if (nc.binary || !c->d_nulltile || ncx > 16) return RVT_OK;
+  std::vector<double> tile((size_t)ld * ncx);
+  HIP_TRY(c, hipMemcpy(tile.data(), c->d_nulltile, sizeof(double) * tile.size(), hipMemcpyDeviceToHost));  // [X | rr], ld apart
+  double scale[16];
+  int shift[16];
+  for (int k = 0; k < 16; ++k) {
+    scale[k] = 1.0;
+    shift[k] = 0;
+  }
+  for (int k = 0; k < ncx; ++k) {
+    const double* col = tile.data() + (size_t)k * ld;
+    double mx = 0.0, ss = 0.0;
+    for (int64_t i = 0; i < N; ++i) {
+      mx = std::max(mx, std::fabs(col[i]));
+      ss += col[i] * col[i];
+    }
+    if (!std::isfinite(mx)) return RVT_OK;
+    if (mx > 0.0) {
+      if (mx > 0x1p20 * std::sqrt(ss / (double)N)) return RVT_OK;
+      int e;
+      std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
+      shift[k] = 56 - (e + 1);  // |x| 2^shift < 2^55; eight balanced digits end at 63 (128^7 + .. + 1) = 0.496 2^56
+      if (std::ldexp(mx, shift[k]) > 0.98 * 0x1p55) shift[k] -= 1;
+      scale[k] = std::ldexp(1.0, -shift[k]);
+    }
+  }
+  const int64_t ngroups = (ld + 63) / 64 + 1;
+  std::vector<unsigned char> xq((size_t)ngroups * kHcpPlanes * 4 * ncx * 16, 0);
+  for (int k = 0; k < ncx; ++k) {
+    const double* col = tile.data() + (size_t)k * ld;
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t g = i >> 6, T = (i >> 4) & 3, q = (i >> 2) & 3, l = i & 3;
+      long long qv = llrint(std::ldexp(col[i], shift[k]));
+      for (int p = kHcpPlanes - 1; p >= 0; --p) {
+        long long r = qv & 127;
+        if (r >= 64) r -= 128;
+        qv = (qv - r) >> 7;
+        xq[(((size_t)(g * kHcpPlanes + p) * 4 + q) * ncx + k) * 16 + T * 4 + l] = (unsigned char)(signed char)r;
+      }
+    }
+  }
+  HIP_TRY(c, hipMalloc((void**)&c->d_hcp_xq, xq.size()));
+  HIP_TRY(c, hipMalloc((void**)&c->d_hcp_scale, sizeof(scale)));
+  HIP_TRY(c, hipMemcpy(c->d_hcp_xq, xq.data(), xq.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_hcp_scale, scale, sizeof(scale), hipMemcpyHostToDevice));
+  c->hcp_planes_state = 1;
+  return RVT_OK;
+}
+
 int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const double* af,
               const int64_t* ids, uint32_t tests, const rvt_params* prm, rvt_gene_result* out,
               DebugOut* dbg, CovOut* cov, const signed char* kind) {
@@ -1128,7 +1193,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
               // of dosage blocks must be cut exactly as with the hard-call path off — the same records bit for bit)
     bool any = false;
     for (int g = 0; g < n && !any; ++g) {
-      const int k = kind ? kind[g] : -1;
+      const int k = kind ? (kind[g] < 0 ? -1 : (kind[g] & 0xf)) : -1;
       any = (Ms[g] + 15) / 16 <= kHcxMaxMT && (k == 1 || (k < 0 && c->content_hint != 0));
     }
     hcx = any;
@@ -1149,7 +1214,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
   // the batch-level prediction below and the per-gene decision further down (they had drifted apart)
   const bool fdx_model = hc_possible && !nc.binary && !cov && c->fdx_ok && c->lattice_den == 0;
   auto fdx_gene = [&](int g) {
-    const int k = kind ? kind[g] : -1;
+    const int k = kind ? (kind[g] < 0 ? -1 : (kind[g] & 0xf)) : -1;
     return fdx_model && (Ms[g] + 15) / 16 <= kFdxEngineMT && (uint64_t)Ms[g] * (uint64_t)ld * 8ull < (1ull << 31) &&
            c->dosage_float && (k == 0 || (k < 0 && c->content_hint == 0));
   };
@@ -1196,14 +1261,17 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     gd.gene_id = ids ? ids[g] : g;
     // hard-call path: unweighted null model, block known to hold only 0.0 / 1.0 / 2.0, a single-pass tile class
     gd.hc = 0;
-    if (hc_possible && gd.MT <= hc_max_mt && ((kind && kind[g] == 3) || (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31))) {
+    const bool kind_packed = kind && kind[g] >= 0 && (kind[g] & 0xf) == 3;  // (bit 4 of a packed kind: T from digit planes)
+    gd.hcp_planes = 0;
+    if (hc_possible && gd.MT <= hc_max_mt && (kind_packed || (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31))) {
       if (score_hc) {
         gd.hc = cov->slice_hc[g] ? 1 : 0;
       } else {
-        const int k = kind ? kind[g] : -1;
+        const int k = kind ? (kind[g] < 0 ? -1 : (kind[g] & 0xf)) : -1;
         gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;
         if (k == 3) {  // the block holds PLINK 2-bit rows (rvt_submit_gene_bed): gene_suffstat_hcp
           gd.hc = 3;
+          gd.hcp_planes = (kind[g] & 0x10) ? 1 : 0;
           gd.pk_pitch = (int)(((size_t)((N + 3) / 4) + 15) / 16 * 16);
         }
         if (lat_possible && gd.MT <= kLatMaxMT && (k == 2 || (k < 0 && !predict_hc))) {
@@ -1216,7 +1284,7 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
         }
       }
     }
-    if (kind && kind[g] == 3 && gd.hc != 3)
+    if (kind_packed && gd.hc != 3)
       return fail(c, RVT_E_STATE, "gene %d was submitted as packed rows but the batch cannot take the packed kernel", g);
     gd.n_bparts = gd.hc ? n_wparts : n_bparts;
     if (gd.hc) {
@@ -1370,12 +1438,26 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     int e = k;
     // (gene_suffstat_hcx_any / gene_suffstat_fdx_any: every class at once)
     const bool one_launch = (hcx && c->hcx_fused && h_desc[k].hc == 1) || (h_desc[k].hc == 4 && c->hcx_fused);
-    while (e < n && (one_launch || h_desc[e].MT == h_desc[k].MT) && h_desc[e].hc == h_desc[k].hc) ++e;
+    while (e < n && (one_launch || h_desc[e].MT == h_desc[k].MT) && h_desc[e].hc == h_desc[k].hc &&
+           h_desc[e].hcp_planes == h_desc[k].hcp_planes)
+      ++e;
     hipStream_t hst = c->k2_stream;
     Scope sc(c, 4, hst);
-    if (h_desc[k].hc == 3)
+    if (h_desc[k].hc == 3) {
+      // (resident genes: G'[X | rr] from the digit planes of THIS null tile — rvt_set_null drops them with the model; a wave-part
+      //  beyond the int32 range of a pair sum, or a model whose columns the planes cannot carry, keeps the fp64 product)
+      static const int planes_sw = getenv("RVT_HCP_PLANES") ? atoi(getenv("RVT_HCP_PLANES")) : 1;  // 0 never, 2 every packed gene
+      bool planes = nd_is_default && (h_desc[k].hcp_planes || planes_sw == 2) && planes_sw != 0 &&
+                    (long long)h_desc[k].steps_per_wpart * 16 <= kHcpPlaneMaxSamples;
+      if (planes) {
+        const int rcp = ensure_hcp_planes(c);
+        if (rcp) return rcp;
+        planes = c->hcp_planes_state == 1;
+      }
+      const HcpPlanes pl{c->d_hcp_xq, c->d_hcp_scale, d + 1};
       k2_launch_hcp(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
-                    (long long)ld, d);
+                    (long long)ld, d, planes ? &pl : nullptr);
+    }
     else if (h_desc[k].hc == 4)
       k2_launch_fdx(one_launch ? 0 : h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->fdx_tile, (long long)N, (long long)ld, d);
     else if (h_desc[k].hc == 2)

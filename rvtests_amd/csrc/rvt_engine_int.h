@@ -45,7 +45,7 @@ void k2_launch_fdx(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, co
 void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
                    long long ld, int d);
 void k2_launch_hcp(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
-                   int d);
+                   int d, const HcpPlanes* planes = nullptr);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"
@@ -153,6 +153,10 @@ struct rvt_ctx {
   char* d_bedbatch = nullptr;   // rvt_submit_genes kind 7: row / gene references and partial counts of one call
   size_t bedbatch_cap = 0;
   bool no_i8_pack = false;      // submit_common: this int8 gene holds a value above 2 — send its bytes
+  // gene_tnull_hcp: eight digit planes of [X | rr] in operand order + the columns' scales (quantitative null models)
+  unsigned char* d_hcp_xq = nullptr;
+  double* d_hcp_scale = nullptr;
+  int hcp_planes_state = 0;     // 0 not built for this null model, 1 ready, -1 the model's columns cannot be carried
   int submit_group = 32;   // genes per asynchronous sub-batch of the streaming interface (RVT_SUBMIT_GROUP, rvt_set_submit_group)
   size_t fam_cols_cap = 0;
   int64_t fam_cols_ld = 0;  // (the leading dimension d_Gp / d_Gt were sized for)
@@ -378,6 +382,7 @@ struct rvt_ctx {
     int af_slot = -1;     // >= 0: the allele frequencies are still on their way back from the device (af_ring slot)
     int io_error = 0;     // != 0: the gene's VCF text / BGEN blocks were malformed (h_io_err): its record is void
     int decoded = 0;      // 1: VCF text, 2: BGEN blocks (the submission has an input-error word in its ring slot)
+    bool planes = false;  // kind 3 only: G'[X | rr] on the int8 matrix cores from the null tile's digit planes (resident .bed genes)
     int kind = -1;        // what the engine's decoder wrote: 1 hard calls (+ imputed means), 0 dosages (BGEN), 2 decimal
                           // dosages (VCF text), 3 the block holds PLINK 2-bit rows (not doubles), -1 unknown
   };

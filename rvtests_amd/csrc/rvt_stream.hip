@@ -54,7 +54,7 @@ int launch_group(rvt_ctx* c, size_t first, int n) {
     Ms.push_back(p.M);
     ids.push_back(p.id);
     af.insert(af.end(), p.af.begin(), p.af.end());
-    kinds.push_back((signed char)p.kind);
+    kinds.push_back((signed char)(p.kind == 3 && p.planes ? (3 | 0x10) : p.kind));
   }
   c->launched.emplace_back();
   rvt_ctx::Launched& L = c->launched.back();
@@ -657,6 +657,7 @@ int submit_common(rvt_ctx* c, int64_t gene_id, int M, const void* G, int mode, c
   // what this entry point writes into the block: hard calls with imputed means (packed / text genotypes), dosages
   // (dosage text, BGEN), or whatever the caller's doubles are
   p.kind = packed ? 3 : ((mode == 2 || mode == 3 || mode == 4 || mode == 7) ? 1 : (mode == 5 ? 2 : (mode == 6 ? 0 : -1)));
+  p.planes = packed && mode == 7;
   p.decoded = (mode == 4 || mode == 5) ? 1 : (mode == 6 ? 2 : 0);
   if (mode == 0) {
     int rc = upload_block_data(c, p.dG, M, (const double*)G);  // synchronous copy: the caller may overwrite G on return
@@ -1063,6 +1064,7 @@ int submit_bed_dev_batch(rvt_ctx* c, int n, const int64_t* ids, const int* Ms, c
     p.af_slot = slot;
     p.af.resize((size_t)M);
     p.kind = 3;
+    p.planes = true;  // (resident rows: nothing waits for a link, the sufficient-statistics kernel is the bound)
     p.decoded = 0;
     p.tests = tests;
     p.prm = prm ? *prm : rvt_params{1.0, 25.0, 1.0, 25.0, 0, 0.05};

@@ -55,15 +55,19 @@ struct HcpCol {  // per lane and tile row
 };
 
 // one tile row of one step.  b = the byte with the lane's four samples; vb = 0xff in the bytes of samples that exist
+// (WITH_T = false: G'[X | rr] is formed by gene_tnull_hcp from digit planes of the null tile, see below)
+template <bool WITH_T>
 __device__ __forceinline__ void hcp_row(unsigned b, const double (&xv)[4], d4_t& accT, unsigned& pk, unsigned& cs,
                                         const HcpCol& cl, unsigned& h, unsigned& anym, unsigned vb) {
   unsigned p, m;
   hcp_decode(b, p, m);
   p &= vb;
   m &= vb;
+  if constexpr (WITH_T) {
 #pragma unroll
-  for (int l = 0; l < 4; ++l)
-    accT = __builtin_amdgcn_mfma_f64_16x16x4f64(hcp_value(p, m, l, cl.mu_lo, cl.mu_hi), xv[l], accT, 0, 0, 0);
+    for (int l = 0; l < 4; ++l)
+      accT = __builtin_amdgcn_mfma_f64_16x16x4f64(hcp_value(p, m, l, cl.mu_lo, cl.mu_hi), xv[l], accT, 0, 0, 0);
+  }
   cs = __builtin_amdgcn_sad_u8(p, 0u, cs);
   const unsigned t = p ^ cl.fx;  // flipped column: (int)(2 - g) > 0  <=>  g != 2
   h += ((((t | (t >> 1)) & 0x01010101u) & ~m) | (m & cl.cmk)) & cl.pm;
@@ -71,7 +75,7 @@ __device__ __forceinline__ void hcp_row(unsigned b, const double (&xv)[4], d4_t&
   anym |= m;
 }
 
-template <int MT>
+template <int MT, bool WITH_T>
 __device__ __forceinline__ void suffstat_hcp_body(const GeneDesc& gd, const NullTile& nt, long long N, long long ld,
                                                   int d, unsigned* lds) {
   const int lane = threadIdx.x & 63;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void suffstat_hcp_body(const GeneDesc& gd, const Null
 #pragma unroll
       for (int c = 0; c < MT; ++c) {
         const unsigned b = (cw[c][u] >> (8 * q)) & 0xffu;
-        hcp_row(b, xv, accT[c], pk[c][u], cs[c], cl[c], h, anym, vmask);
+        hcp_row<WITH_T>(b, xv, accT[c], pk[c][u], cs[c], cl[c], h, anym, vmask);
       }
       if (whole)
         hc_finish<false>(h, xv, bu, 0xffffffffu);
@@ -199,7 +203,7 @@ __device__ __forceinline__ void suffstat_hcp_body(const GeneDesc& gd, const Null
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r * 16 + q + 4 * i;  // f64 C/D map
-      if (M + v < Cp) out[(long long)row * Cp + M + v] = accT[r][i];
+      if (WITH_T && M + v < Cp) out[(long long)row * Cp + M + v] = accT[r][i];  // (else: written by gene_tnull_hcp)
       if (M + 16 + v < Cp) out[(long long)row * Cp + M + 16 + v] = 0.0;
     }
   }
@@ -273,13 +277,146 @@ __device__ __forceinline__ void suffstat_hcp_body(const GeneDesc& gd, const Null
   }
 }
 
-template <int MT, int WAVES>
+template <int MT, int WAVES, bool WITH_T = true>
 __global__ __launch_bounds__(64, WAVES) void gene_suffstat_hcp(const GeneDesc* __restrict__ genes, NullTile nt, long long N,
                                                                long long ld, int d) {
   __shared__ unsigned lds[hc_lds_words(MT)];
   const GeneDesc gd = genes[blockIdx.y];
   if (gd.MT != MT) return;
-  suffstat_hcp_body<MT>(gd, nt, N, ld, d, lds);
+  suffstat_hcp_body<MT, WITH_T>(gd, nt, N, ld, d, lds);
+}
+
+// ---- G'[X | rr] of a packed gene on the int8 matrix cores (round 6) --------------------------------------------------------------
+// Two thirds of gene_suffstat_hcp went into this product: one fp64 matrix instruction per four samples and tile row whose A
+// operand — the double a 2-bit code stands for — costs six vector instructions per genotype (35 us of chip time per gene of
+// M = 50 at N = 500 000; 11.5 without it).  The hard calls ARE small integers, so the product belongs on the int8 instruction:
+// the null tile [X_0 .. X_{d-1} | rr] is quantised once per null model to EIGHT balanced base-128 digit planes per column of
+// its 56-bit fixed-point values (a power-of-two scale per column; rvt_set_null, as the six planes of the weighted kernel,
+// suffstat_hcx.hip.h) and stored in operand order:
+//   xq[(((g 8 + p) 4 + q) ncx + k) 16 + 4 T + l] = digit p of column k at sample 64 g + 16 T + 4 q + l
+// — the byte order of the operand gene_suffstat_hcp builds from a row's 16 bytes.  Per group of 64 samples and tile row: four
+// paired instructions (hcx_pair_step: 128 (A'B_2j) + A'B_2j+1, exact in int32 over a wave-part of at most 131 072 samples)
+// with A = H, the integer part of the codes (0 where the call is missing).  Mean-imputed columns: g = H + mu m, so a second pass
+// over the wave-part — only when it holds a missing call — forms m'[X | rr] the same way and the result is H'X + mu m'X.
+// Every sum is an exact integer of the quantised tile; the quantisation is 2^-56 of twice a column's largest entry per
+// sample (relative 1e-13 on these sums: below the rounding of the fp64 product it replaces).  Writes the T columns of the
+// wave-part's partial image (out[row Cp + M + k]) that gene_suffstat_hcp<.., false> leaves alone.
+constexpr int kHcpPlanes = 8, kHcpPairs = 4;
+constexpr long long kHcpPlaneMaxSamples = 131072;  // (int32 range of a pair sum: 64 x 2 x 63 x 129 per group)
+struct HcpPlanes {
+  const unsigned char* xq;
+  const double* scale;  // (device, 16 entries) value of column k = integer x scale[k]
+  int ncx;              // d + 1 columns: X_0 .. X_{d-1}, rr
+};
+// two digit planes of one tile and one 64-sample operand: acc = 128 (A'B0) + A'B1 + acc, exactly, in int32 (as hcx_pair_step)
+__device__ __forceinline__ void hcp_pair_step(i4_t& acc, const i4_t& a, const i4_t& b0, const i4_t& b1) {
+  const i4_t z = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, i4_t{0, 0, 0, 0}, 0, 0, 0);
+  i4_t t = acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = (int)(((unsigned)z[i] << 7) + (unsigned)t[i]);
+  acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, t, 0, 0, 0);
+}
+
+template <int MT, bool MASK>
+__device__ __forceinline__ bool hcp_tnull_pass(i4_t (&acc)[kHcpPairs][MT], const __amdgpu_buffer_rsrc_t& rp, const unsigned (&cbase)[MT],
+                                               const unsigned char* xq_lane, long long plane_stride, bool has_col,
+                                               long long s_begin, long long s_end, int q) {
+  unsigned anym = 0u;
+  for (long long s = s_begin; s < s_end; s += 4) {
+    u4_t cw[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+      cw[c] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rp, cbase[c] + (unsigned)(s * 4), 0, 0));
+    i4_t b[kHcpPlanes];
+    const unsigned char* xg = xq_lane + (s >> 2) * (kHcpPlanes * plane_stride);
+#pragma unroll
+    for (int p = 0; p < kHcpPlanes; ++p) {
+      u4_t t = u4_t{0u, 0u, 0u, 0u};
+      if (has_col) t = *reinterpret_cast<const u4_t*>(xg + p * plane_stride);
+      b[p] = i4_t{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
+    }
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+      i4_t a;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        unsigned pv, mv;
+        hcp_decode((cw[c][u] >> (8 * q)) & 0xffu, pv, mv);
+        if (s + u >= s_end) pv = mv = 0u;
+        anym |= mv;
+        a[u] = (int)(MASK ? mv : pv);
+      }
+#pragma unroll
+      for (int j = 0; j < kHcpPairs; ++j) hcp_pair_step(acc[j][c], a, b[2 * j], b[2 * j + 1]);
+    }
+  }
+  return __any(anym != 0u);
+}
+
+template <int MT>
+__global__ __launch_bounds__(64) void gene_tnull_hcp(const GeneDesc* __restrict__ genes, HcpPlanes pl, long long N, long long ld) {
+  const GeneDesc gd = genes[blockIdx.y];
+  if (gd.MT != MT) return;
+  const int lane = threadIdx.x & 63, v = lane & 15, q = lane >> 4;
+  const int wpart = blockIdx.x;
+  if (wpart >= gd.n_wparts) return;
+  const long long nsteps = ld >> 4;
+  const long long s_begin = (long long)wpart * gd.steps_per_wpart;
+  long long s_end = s_begin + gd.steps_per_wpart;
+  if (s_end > nsteps) s_end = nsteps;
+  if (s_begin >= s_end) return;
+  const int M = gd.M;
+  const unsigned char* blk = reinterpret_cast<const unsigned char*>(gd.G);
+  const HcpHeader* hdr = reinterpret_cast<const HcpHeader*>(blk);
+  const unsigned pitch = (unsigned)gd.pk_pitch;
+  const __amdgpu_buffer_rsrc_t rp =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(blk + kHcpHeaderBytes), 0, (unsigned)M * pitch, 0x00020000);
+  unsigned cbase[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) cbase[c] = (c * 16 + v < M) ? (unsigned)(c * 16 + v) * pitch : 0x80000000u;  // pad column: zeros
+  const bool has_col = v < pl.ncx;
+  const long long plane_stride = 4ll * pl.ncx * 16;  // bytes of one plane of one group: [q][k] x 16
+  const unsigned char* xq_lane = pl.xq + ((long long)q * pl.ncx + (has_col ? v : 0)) * 16;
+  const double sc = has_col ? pl.scale[v] : 0.0;
+  i4_t acc[kHcpPairs][MT];
+  auto clear = [&]() {
+#pragma unroll
+    for (int j = 0; j < kHcpPairs; ++j)
+#pragma unroll
+      for (int c = 0; c < MT; ++c) acc[j][c] = i4_t{0, 0, 0, 0};
+  };
+  // the integer the four pair sums encode, times the column's scale: sum_j pair_j 128^(6 - 2 j)
+  auto value = [&](int c, int i) {
+    const double hi = (double)acc[0][c][i] * 0x1p42 + (double)acc[1][c][i] * 0x1p28;
+    const double lo = (double)acc[2][c][i] * 0x1p14 + (double)acc[3][c][i];
+    return (hi + lo) * sc;
+  };
+  clear();
+  const bool masked = hcp_tnull_pass<MT, false>(acc, rp, cbase, xq_lane, plane_stride, has_col, s_begin, s_end, q);
+  double t[MT][4];
+#pragma unroll
+  for (int c = 0; c < MT; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[c][i] = value(c, i);
+  if (masked) {  // (wave-uniform)
+    clear();
+    (void)hcp_tnull_pass<MT, true>(acc, rp, cbase, xq_lane, plane_stride, has_col, s_begin, s_end, q);
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = c * 16 + q * 4 + i;
+        t[c][i] += (row < M ? hdr->mu[row] : 0.0) * value(c, i);
+      }
+  }
+  double* out = gd.parts + (long long)wpart * gd.Mp * gd.Cp;
+  const int Cp = gd.Cp;
+  if (M + v < Cp) {
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(long long)(c * 16 + q * 4 + i) * Cp + M + v] = t[c][i];  // (i32 C/D map: row 4 q + i, column v)
+  }
 }
 
 }  // namespace rvt

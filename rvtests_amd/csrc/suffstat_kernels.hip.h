@@ -47,6 +47,7 @@ struct GeneDesc {
   // hard-call path (suffstat_hc.hip.h)
   unsigned short pflip[8];  // predicted flip bits (af > 0.5) per 16-variant block, first 6 blocks
   int n_bparts;             // burden partial records of this gene (wave-parts on the hard-call path)
+  int hcp_planes;           // hc == 3: G'[X | rr] from the digit planes of the null tile (gene_tnull_hcp; resident .bed genes)
   int hc;                   // 4: gene_suffstat_fdx (float-precision dosages: as 2, with lat_den = 2^37),
                             // 1: gene_suffstat_hc / _hcw (hard calls), 2: gene_suffstat_lat (lattice dosages), 3: gene_suffstat_hcp
                             // (PLINK 2-bit rows), 0: general kernel

@@ -139,10 +139,20 @@ def test_genes_of_a_resident_bed_matrix_give_the_records_of_the_host_rows(engine
     assert len(got) == len(want) == len(Ms) + 1 and len(got_many) == len(Ms)
     for a, b in zip(got_af, want_af):
         assert np.array_equal(a, b)
-    for a, b in list(zip(got, want)) + list(zip(got_many, want[:len(Ms)])):
+    # (resident genes that stay packed form G'[X | rr] on the int8 matrix cores from digit planes of the null tile: 1e-13 from the
+    #  fp64 product of the host hand-off — and SKAT-O's p, Davies' method inside a quadrature, moves at the 1e-7 level with the
+    #  last bits of its inputs; expanded genes (permutations, a binary trait, M > 96) are bit-identical)
+    widths = list(Ms) + [None] + list(Ms)                      # (None: the gene with permutations)
+    for k, (a, b) in enumerate(list(zip(got, want)) + list(zip(got_many, want[:len(Ms)]))):
+        exact = binary or widths[k] is None or widths[k] > 96
         for f in FIELDS:
             x, y_ = getattr(a, f), getattr(b, f)
-            assert x == y_ or (x != x and y_ != y_), (f, x, y_)
+            if exact or f in ("cmc_nonref", "n_poly", "status"):
+                assert x == y_ or (x != x and y_ != y_), (k, f, x, y_)
+            elif f.startswith("cmc") and abs(b.cmc_U) < 1e-8:
+                continue
+            else:
+                assert x == y_ or (x != x and y_ != y_) or abs(x - y_) <= (1e-6 if f == "skato_p" else 1e-11) * abs(y_), (k, f, x, y_)
     if not binary:
         assert want[3].skat_p > 0
 
@@ -212,4 +222,6 @@ def test_resident_bed_genes_at_the_bench_size(engine):
     for a, b, c_ in zip(got, want, got8):
         assert a.skat_p > 0 and a.n_poly > 0
         for f in FIELDS:
-            assert getattr(a, f) == getattr(b, f) and getattr(c_, f) == getattr(b, f), f
+            assert getattr(c_, f) == getattr(b, f), f              # (the two host hand-offs: the same kernels, the same bits)
+            x, y_ = getattr(a, f), getattr(b, f)                   # (resident: G'[X | rr] from digit planes, see above)
+            assert x == y_ or abs(x - y_) <= (1e-6 if f == "skato_p" else 1e-11) * abs(y_), (f, x, y_)
