@@ -341,7 +341,10 @@ def from_host_rates(eng, blocks, Ms, afs, N, genes=192, window=64):
         t0 = None
         # (the packed hand-offs stream thousands of genes per second: 192 genes would be 40 ms, a third of it the drain)
         n_timed = genes * 8 if mode in ("int8", "bed2bit") else (genes * 4 if mode == "fp64" and not registered else genes)
-        for g in range(-window, n_timed):        # one untimed window first: buffers, block pool and page mappings warm
+        # (the text / BGEN modes are the only ones left that fill fp64 blocks on the device — since round 6 the fp64 and int8
+        #  hand-offs stay packed — and nobody before them has grown the block pool to its steady state: three windows for them)
+        warm = window * (3 if mode in ("vcf_text", "bgen16") else 1)
+        for g in range(-warm, n_timed):          # untimed windows first: buffers, block pool and page mappings warm
             if g == 0:
                 eng.collect()
                 t0 = time.perf_counter()
