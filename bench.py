@@ -18,6 +18,7 @@ per core — and `parity` compares the oracle's numbers for those genes with the
 process, before this process touches the GPU).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -485,6 +486,17 @@ def main():
             dist.init_process_group(backend)
 
     N = args.samples
+    # this rank on the NUMA node its device hangs on (rvt_pin_to_device_node: what a main() built on the library calls first; the
+    # staging threads inherit the mask).  The timed region does not depend on it; the from-host figures do.  RVT_NO_PIN=1: off
+    pinned_node = -1
+    if not os.environ.get("RVT_NO_PIN"):
+        try:
+            L0 = rvtests_amd.load_library()
+            L0.rvt_pin_to_device_node.restype = ctypes.c_int
+            L0.rvt_pin_to_device_node.argtypes = [ctypes.c_int]
+            pinned_node = int(L0.rvt_pin_to_device_node(int(gpu_index)))
+        except Exception:
+            pinned_node = -1
     eng = rvtests_amd.Engine(gpu_index)
     ld = eng.padded_ld(N)
 
@@ -681,6 +693,7 @@ def main():
             "kernel_time_share": {"suffstat_mfma": tm.ms_suffstat / tot_ms, "burden": tm.ms_burden / tot_ms,
                                   "gene_stats": tm.ms_stats / tot_ms, "gene_pvalue": tm.ms_pvalue / tot_ms,
                                   "device_ms_per_step": tot_ms / args.steps},
+            "pinned_numa_node": pinned_node,
             "davies_terms_per_gene": float(np.mean([r.davies_terms for r in out0])),
             "warmup_ms_per_step": warm_ms,
         }

@@ -64,6 +64,7 @@ static int numa_balancing_setting() {
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
+  if (!getenv("RVT_NO_PIN")) (void)rvt_pin_to_device_node(0);  // (as a main() built on the library does first)
   long long N = 500000;
   int M = 50, genes = 1536, window = 64, registered = 0, batch = 1;
   std::string modes = "int8,bed,fp64";
