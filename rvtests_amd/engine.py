@@ -126,6 +126,15 @@ def build_library(force=False, verbose=False):
 _lib = None
 
 
+def pin_to_device_node(device=0):
+    """Bind this thread (and the threads created after it) to the CPUs of the NUMA node the device hangs on
+    (rvt_pin_to_device_node); returns the node or -1."""
+    L = load_library()
+    L.rvt_pin_to_device_node.restype = C.c_int
+    L.rvt_pin_to_device_node.argtypes = [C.c_int]
+    return int(L.rvt_pin_to_device_node(int(device)))
+
+
 def load_library():
     """Load librvtests_amd.so; raises RvtError when it has not been built (no silent fallback)."""
     global _lib
