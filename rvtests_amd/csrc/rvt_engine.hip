@@ -1133,8 +1133,8 @@ struct BatchTrace {
 // The packed-row path of RESIDENT .bed genes forms G'[X | rr] on the int8 matrix cores (gene_tnull_hcp, suffstat_hcp.hip.h): every
 // column of [X_0 .. X_{d-1} | rr] as eight balanced base-128 digits of its fixed-point value, 56 bits below a power of two above
 // twice the column's largest entry, in operand order.  Built from the device's null tile the first time a batch asks for it
-// (c->hcp_planes_state: 0 not built, 1 ready, -1 this model cannot: a column whose largest entry exceeds 2^20 x its root mean
-// square would leave its typical entries fewer than 36 bits — such a model keeps the fp64 product).
+// (c->hcp_planes_state: 0 not built, 1 ready, -1 this model cannot: a column whose largest entry exceeds 2^16 x the median of
+// its non-zero magnitudes would leave its typical entries fewer than 39 bits — such a model keeps the fp64 product).
 static int ensure_hcp_planes(rvt_ctx* c) {
   if (c->hcp_planes_state != 0) return RVT_OK;
   c->hcp_planes_state = -1;
@@ -1152,14 +1152,18 @@ static int ensure_hcp_planes(rvt_ctx* c) {
   }
   for (int k = 0; k < ncx; ++k) {
     const double* col = tile.data() + (size_t)k * ld;
-    double mx = 0.0, ss = 0.0;
-    for (int64_t i = 0; i < N; ++i) {
-      mx = std::max(mx, std::fabs(col[i]));
-      ss += col[i] * col[i];
-    }
+    double mx = 0.0;
+    for (int64_t i = 0; i < N; ++i) mx = std::max(mx, std::fabs(col[i]));
     if (!std::isfinite(mx)) return RVT_OK;
     if (mx > 0.0) {
-      if (mx > 0x1p20 * std::sqrt(ss / (double)N)) return RVT_OK;
+      // the fixed point is 56 bits below twice the LARGEST entry: the column's typical entry — the median of its non-zero
+      // magnitudes (a root mean square follows a single outlier) — must keep 39 of them
+      std::vector<double> mag;
+      mag.reserve((size_t)N);
+      for (int64_t i = 0; i < N; ++i)
+        if (col[i] != 0.0) mag.push_back(std::fabs(col[i]));
+      std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
+      if (mx > 0x1p16 * mag[mag.size() / 2]) return RVT_OK;
       int e;
       std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
       shift[k] = 56 - (e + 1);  // |x| 2^shift < 2^55; eight balanced digits end at 63 (128^7 + .. + 1) = 0.496 2^56

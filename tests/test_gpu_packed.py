@@ -225,3 +225,40 @@ def test_resident_bed_genes_at_the_bench_size(engine):
             assert getattr(c_, f) == getattr(b, f), f              # (the two host hand-offs: the same kernels, the same bits)
             x, y_ = getattr(a, f), getattr(b, f)                   # (resident: G'[X | rr] from digit planes, see above)
             assert x == y_ or abs(x - y_) <= (1e-6 if f == "skato_p" else 1e-11) * abs(y_), (f, x, y_)
+
+
+def test_resident_genes_with_a_badly_scaled_covariate(engine):
+    """The digit planes of the null tile carry 56 bits below twice a column's LARGEST entry: a covariate with one entry five
+    orders of magnitude above the rest leaves its typical entries ~40 bits — the resident records still agree with the host
+    hand-off's (fp64 product) far inside the parity tolerance; a column whose largest entry exceeds 2^16 x the median of its
+    non-zero magnitudes is refused and the fp64 product is used (bit-identical records then)."""
+    N = 9001
+    Ms = (30, 64)
+    genes = [_raw_gene(N, M, seed=11 * M, missing=0.01) for M in Ms]
+    rows = [engine.pack_bed(g) for g in genes]
+    cb = (N + 3) // 4
+    rng = np.random.default_rng(5)
+    for outlier, exact in ((3e4, False), (1e9, True)):
+        X = np.column_stack([np.ones(N), rng.normal(size=N), rng.normal(size=N)])
+        X[17, 2] = outlier
+        y = X[:, 1] * 0.3 + rng.normal(size=N)
+        rc, beta, pred, res, s2 = orc.fit_linear(np.asfortranarray(X), y)
+        assert rc == 0
+        engine.set_null(0, np.asfortranarray(X), res, np.full(N, s2), s2)
+        d_bed = engine.bed_alloc(sum(Ms))
+        engine.bed_upload(d_bed, 0, rows[0])
+        engine.bed_upload(d_bed, Ms[0], rows[1])
+        for g, (r, M) in enumerate(zip(rows, Ms)):
+            engine.submit_gene_bed(g, r, M, want_af=False)
+        want = engine.collect()
+        engine.submit_genes_bed_dev([0, 1], [d_bed, d_bed + Ms[0] * cb], Ms)
+        got = engine.collect()
+        engine.bed_free(d_bed)
+        for a, b in zip(got, want):
+            assert b.skat_p > 0
+            for f in FIELDS:
+                x, y_ = getattr(a, f), getattr(b, f)
+                if exact:
+                    assert x == y_, (outlier, f, x, y_)
+                else:
+                    assert x == y_ or abs(x - y_) <= (1e-6 if f == "skato_p" else 1e-9) * abs(y_), (outlier, f, x, y_)
