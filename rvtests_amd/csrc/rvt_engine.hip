@@ -325,6 +325,18 @@ void rvt_destroy(rvt_ctx* c) {
   delete c;
 }
 
+// A fixed-point image of a null-model column sits a fixed number of bits below the column's LARGEST entry: are its typical
+// entries — the median of the non-zero magnitudes; a root mean square follows a single outlier — within `ratio` of it?
+static bool column_scale_ok(const double* col, int64_t N, double mx, double ratio) {
+  std::vector<double> mag;
+  mag.reserve((size_t)N);
+  for (int64_t i = 0; i < N; ++i)
+    if (col[i] != 0.0) mag.push_back(std::fabs(col[i]));
+  if (mag.empty()) return true;
+  std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
+  return mx <= ratio * mag[mag.size() / 2];
+}
+
 int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const double* res, const double* v,
                  double sigma2) {
   if (!c || !X || !res || !v || N < 1 || d < 1 || d > RVT_MAX_COV) return fail(c, RVT_E_INVALID, "bad null model");
@@ -438,7 +450,10 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
         }
         if (!std::isfinite(mx)) okx = false;
         if (mx > 0.0) {
-          if (mx > 256.0 * std::sqrt(ss / (double)N)) okx = false;
+          // (until round 6 the test was 256 x the root mean square, which one outlier drags along with itself; against the
+          //  median a rare disease's residual column — cases near 1, controls at minus the prevalence — must still pass: 4 096,
+          //  i.e. typical entries keep 30 of the 42 bits)
+          if (!column_scale_ok(tile.data() + (size_t)k * ld, N, mx, 4096.0)) okx = false;
           int e;
           std::frexp(mx, &e);        // mx = f 2^e, 0.5 <= f < 1
           shift[k] = 42 - (e + 1);   // |x| 2^shift < 2^41 ...
@@ -510,6 +525,7 @@ int rvt_set_null(rvt_ctx* c, int trait, int64_t N, int d, const double* X, const
       double mx = 0.0;
       for (int64_t i = 0; i < N; ++i) mx = std::max(mx, std::fabs(col[i]));
       if (!std::isfinite(mx)) okf = false;
+      if (mx > 0.0 && !column_scale_ok(col, N, mx, 4096.0)) okf = false;  // (typical entries keep 34 of the 46 bits)
       if (mx > 0.0) {
         int e;
         std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
@@ -1158,12 +1174,7 @@ static int ensure_hcp_planes(rvt_ctx* c) {
     if (mx > 0.0) {
       // the fixed point is 56 bits below twice the LARGEST entry: the column's typical entry — the median of its non-zero
       // magnitudes (a root mean square follows a single outlier) — must keep 39 of them
-      std::vector<double> mag;
-      mag.reserve((size_t)N);
-      for (int64_t i = 0; i < N; ++i)
-        if (col[i] != 0.0) mag.push_back(std::fabs(col[i]));
-      std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
-      if (mx > 0x1p16 * mag[mag.size() / 2]) return RVT_OK;
+      if (!column_scale_ok(col, N, mx, 0x1p16)) return RVT_OK;
       int e;
       std::frexp(mx, &e);       // mx = f 2^e, 0.5 <= f < 1
       shift[k] = 56 - (e + 1);  // |x| 2^shift < 2^55; eight balanced digits end at 63 (128^7 + .. + 1) = 0.496 2^56
