@@ -592,3 +592,35 @@ def test_cooperative_kernel_is_bit_reproducible_across_launch_shapes(monkeypatch
     for a, b in zip(recs["default"], recs["parts29"]):       # (another split: the fp64 per-gene reductions see other partials)
         for f in FIELDS:
             assert _same(f, getattr(a, f), getattr(b, f), rel=1e-11), ("parts29", f)
+
+
+def test_binary_trait_with_an_outlier_covariate_keeps_the_exact_null_tile(monkeypatch):
+    """The workgroup-cooperative binary-trait kernel multiplies the null tile as 42-bit fixed point below each column's LARGEST
+    entry.  A covariate with one entry seven orders of magnitude above the rest would leave its typical entries a few bits: such
+    a model must stay on the one-wave kernel (fp64 products of the tile) — the records then equal those with RVT_HCX=0 bit for
+    bit (round 6: the test against the root mean square let this model through, the outlier drags the rms along)."""
+    import rvtests_amd
+    N, d = 20000, 3
+    rng = np.random.default_rng(44)
+    X = np.column_stack([np.ones(N), rng.normal(size=N), rng.normal(size=N)])
+    X[123, 2] = 1e7
+    eta = -1.0 + 0.4 * X[:, 1]
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    rc, beta, p, v = orc.fit_logistic(np.asfortranarray(X), y)
+    assert rc == 0
+    genes = [_hard_gene(N, M, seed=60 + M) for M in (20, 48, 70)]
+    outs = []
+    for hcx in (None, "0"):
+        if hcx is None:
+            monkeypatch.delenv("RVT_HCX", raising=False)
+        else:
+            monkeypatch.setenv("RVT_HCX", hcx)
+        e = rvtests_amd.Engine(0)
+        e.set_null(1, np.asfortranarray(X), y - p, v, 1.0)
+        ptrs = [e.upload_block(G) for G, af in genes]
+        out = e.run_blocks(ptrs, [G.shape[1] for G, af in genes], [af for G, af in genes])
+        outs.append([(r.skat_Q, r.skat_p, r.skato_p, r.cmc_U, r.cmc_p, r.zeg_stat) for r in out])
+        e.close()
+    assert outs[0] == outs[1]
+    rc, a = orc.skat(genes[1][0], genes[1][1], np.asfortranarray(X), y - p, v, 1)
+    assert abs(outs[0][1][0] - a.Q) <= 1e-9 * a.Q
