@@ -262,3 +262,31 @@ def test_resident_genes_with_a_badly_scaled_covariate(engine):
                     assert x == y_, (outlier, f, x, y_)
                 else:
                     assert x == y_ or abs(x - y_) <= (1e-6 if f == "skato_p" else 1e-9) * abs(y_), (outlier, f, x, y_)
+
+
+def test_resident_bed_entry_points_refuse_what_they_cannot_take():
+    """Error behaviour of the resident .bed calls: no null model yet (it defines the row length), bad arguments, an empty list."""
+    import rvtests_amd
+    e = rvtests_amd.Engine(0)
+    with pytest.raises(rvtests_amd.RvtError):
+        e.bed_alloc(10)                                       # no null model: N unknown
+    N = 5000
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=1)
+    e.set_null(0, X, res, v, s2)
+    with pytest.raises(rvtests_amd.RvtError):
+        e.bed_alloc(0)
+    d_bed = e.bed_alloc(40)
+    raw = _raw_gene(N, 40, seed=9)
+    e.bed_upload(d_bed, 0, e.pack_bed(raw))
+    with pytest.raises(rvtests_amd.RvtError):
+        e.submit_gene_bed_dev(0, d_bed, 0)                    # M = 0
+    with pytest.raises(rvtests_amd.RvtError):
+        e.submit_gene_bed_dev(0, 0, 5)                        # null address
+    e.submit_genes_bed_dev([], [], [])                        # nothing: fine
+    assert e.collect() == []
+    af = e.submit_gene_bed_dev(7, d_bed, 40)
+    (r,) = e.collect()
+    assert r.gene_id == 7 and np.array_equal(af, orc.counter_af(raw))
+    e.bed_free(d_bed)
+    e.bed_free(0)                                             # a null pointer: nothing to free
+    e.close()
