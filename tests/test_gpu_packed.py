@@ -219,6 +219,14 @@ def test_resident_bed_genes_at_the_bench_size(engine):
         engine.submit_gene_raw(g, raw.astype(np.int8), want_af=False)
     got8 = engine.collect()
     engine.bed_free(d_bed)
+    # the resident records against the ORACLE at this size (gene 0: SKAT's Q and p, both burden tests)
+    G0 = orc.impute_mean(genes[0])
+    rc, o = orc.skat(G0, orc.counter_af(genes[0]), X, res, v, 0)
+    assert rc == 0 and got[0].n_poly == o.n_poly
+    assert abs(got[0].skat_Q - o.Q) <= 1e-10 * o.Q and abs(got[0].skat_p - o.pvalue) <= 1e-6 * o.pvalue + 1e-14
+    for which, stat, pv in ((0, got[0].cmc_stat, got[0].cmc_p), (1, got[0].zeg_stat, got[0].zeg_p)):
+        rcb, b_ = orc.burden(G0, X, y, 0, which)
+        assert rcb == 0 and abs(stat - b_.stat) <= 1e-9 * b_.stat + 1e-13 and abs(pv - b_.pvalue) <= 1e-6 * b_.pvalue + 1e-14
     for a, b, c_ in zip(got, want, got8):
         assert a.skat_p > 0 and a.n_poly > 0
         for f in FIELDS:
