@@ -603,6 +603,14 @@ int rvt_bed_upload(rvt_ctx* ctx, unsigned char* d_bed, int64_t first_variant, in
 int rvt_bed_free(rvt_ctx* ctx, unsigned char* d_bed);
 int rvt_submit_gene_bed_dev(rvt_ctx* ctx, int64_t gene_id, int M, const unsigned char* d_rows, uint32_t tests,
                             const rvt_params* params, double* af_out);
+/* Single-variant score tests of V consecutive rows of a resident .bed matrix: rvt_score_block's outputs (the per-variant body of
+ * MetaScoreTest::fit, i.e. LinearRegressionScoreTest::TestCovariate on one column, regression/LinearRegressionScoreTest.cpp:
+ * 173-263) computed from the 2-bit rows where they lie — N/4 bytes of device traffic per site instead of 8 N — with missing calls
+ * imputed to the column mean as DataConsolidator does (src/DataConsolidator.cpp:217-245).  counts (optional, 4 V entries):
+ * per variant the numbers of 0 / 1 / 2 / missing calls, what the adapter's AF / call-rate / HWE columns are made of
+ * (src/Model.h:3211-3230).  Quantitative traits (the packed-row kernel's domain; RVT_E_STATE otherwise).  Synchronous. */
+int rvt_score_bed_dev(rvt_ctx* ctx, const unsigned char* d_rows, int64_t V, int* ok, double* ustat, double* vstat, double* effect,
+                      double* effect_se, double* pvalue, long long* counts);
 
 /* ---- VCF text at the boundary (SURVEY §8f "next" #1: the genotype front end) -------------------------------------------
  * Replaces the per-sample loop of VCFGenotypeExtractor::extractMultipleGenotype (src/VCFGenotypeExtractor.cpp:29-140) for

@@ -1328,6 +1328,11 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
     if (hc_possible && gd.MT <= hc_max_mt && (kind_packed || (uint64_t)M * (uint64_t)ld * 8ull < (1ull << 31))) {
       if (score_hc) {
         gd.hc = cov->slice_hc[g] ? 1 : 0;
+        if (kind_packed) {  // a slice of a resident .bed matrix (rvt_score_bed_dev): packed rows, gene_suffstat_hcp
+          gd.hc = 3;
+          gd.pk_pitch = (int)(((size_t)((N + 3) / 4) + 15) / 16 * 16);
+          gd.hcp_planes = (kind[g] & 0x10) ? 1 : 0;
+        }
       } else {
         const int k = kind ? (kind[g] < 0 ? -1 : (kind[g] & 0xf)) : -1;
         gd.hc = (k == 1 || (k < 0 && predict_hc)) ? 1 : 0;

@@ -902,6 +902,7 @@ struct BedGeneRef {
   int row0, M;
   HcpHeader* hdr;
   double* af_dst;
+  long long* cnt_dst;  // optional: per row the numbers of 0 / 1 / 2 / missing calls (rvt_score_bed_dev)
 };
 __global__ __launch_bounds__(256) void bed_count_copy_rows_kernel(const BedRowRef* __restrict__ rows, long long N,
                                                                   ConsolPart* __restrict__ parts) {
@@ -963,6 +964,12 @@ __global__ __launch_bounds__(128) void bed_fill_header_kernel(const BedGeneRef* 
       fill = (an == 0) ? 0.0 : 2.0 * (1.0 * aci / (double)an);
     }
     const long long nm = N - nonneg, n1 = (long long)ac - 2 * n2, n0 = nonneg - n1 - n2;  // (hcp_header_kernel)
+    if (g.cnt_dst) {
+      g.cnt_dst[4 * j + 0] = n0;
+      g.cnt_dst[4 * j + 1] = n1;
+      g.cnt_dst[4 * j + 2] = n2;
+      g.cnt_dst[4 * j + 3] = nm;
+    }
     const double mu = nm > 0 ? fill : 0.0;
     g.hdr->mu[j] = mu;
     const double s = ac + (double)nm * mu;
@@ -1060,7 +1067,7 @@ int submit_bed_dev_batch(rvt_ctx* c, int n, const int64_t* ids, const int* Ms, c
     const unsigned char* src = static_cast<const unsigned char*>(data[g]);
     for (int j = 0; j < M; ++j) rows[(size_t)(r0 + j)] = BedRowRef{src + cb * (size_t)j, dst + pk_pitch * (size_t)j};
     const int slot = (int)(c->af_seq++ % rvt_ctx::kAfSlots);
-    genes[(size_t)g] = BedGeneRef{r0, M, reinterpret_cast<HcpHeader*>(p.dG), mapped + (size_t)slot * RVT_MAX_VARIANTS};
+    genes[(size_t)g] = BedGeneRef{r0, M, reinterpret_cast<HcpHeader*>(p.dG), mapped + (size_t)slot * RVT_MAX_VARIANTS, nullptr};
     p.af_slot = slot;
     p.af.resize((size_t)M);
     p.kind = 3;
@@ -1094,6 +1101,138 @@ int submit_bed_dev_batch(rvt_ctx* c, int n, const int64_t* ids, const int* Ms, c
   return launch_pending(c, c->queue.size(), true);
 }
 }  // namespace
+
+// ---- single-variant score tests of a resident .bed matrix ------------------------------------------------------------------------
+// LinearRegressionScoreTest::TestCovariate on ONE column per variant (regression/LinearRegressionScoreTest.cpp:173-263; what
+// MetaScoreTest::fit prints per site, src/Model.h:3246-3258) for V consecutive rows of a .bed matrix in device memory: slices
+// of 32 rows go through the packed-row machinery as "genes" of 32 variants — counts and imputation values per row, the rows
+// copied into pitched blocks (two launches per 256 slices), gene_suffstat_hcp + gene_tnull_hcp, then the score finisher that
+// rvt_score_block uses — so a site costs N/4 bytes of HBM traffic instead of 8 N.  Quantitative traits (the packed kernel's
+// domain); same outputs as rvt_score_block plus, optionally, the genotype counts (n0, n1, n2, missing per variant) the
+// adapter's AF / call rate / HWE columns are made of.  Synchronous.
+int rvt_score_bed_dev(rvt_ctx* c, const unsigned char* d_rows, int64_t V, int* ok, double* ustat, double* vstat, double* effect,
+                      double* effect_se, double* pvalue, long long* counts) {
+  if (!c || !d_rows || V < 1 || !ok || !ustat || !vstat || !effect || !effect_se || !pvalue) return fail(c, RVT_E_INVALID, "bad arguments");
+  if (!c->have_null) return fail(c, RVT_E_STATE, "no null model set");
+  constexpr int kSlice = 32;
+  static const int kChunk = getenv("RVT_SCORE_BED_CHUNK") ? std::max(16, std::min(2048, atoi(getenv("RVT_SCORE_BED_CHUNK")))) : 256;
+  if (!packed_eligible(c, kSlice, 0u, nullptr)) return fail(c, RVT_E_STATE, "the packed-row kernel does not take this null model (binary trait, too many covariates, hard calls switched off)");
+  hipSetDevice(c->device);
+  int rc = rvt_sync(c);
+  if (rc) return rc;
+  hipStream_t st = c->io_stream;
+  const int64_t N = c->nc.N;
+  const size_t cb = (size_t)((N + 3) / 4), pk_pitch = (cb + 15) / 16 * 16;
+  const int nparts = (int)((N + kConsolChunk - 1) / kConsolChunk);
+  const size_t gene_bytes = (size_t)kHcpHeaderBytes + pk_pitch * kSlice + 16;
+  // work space: row / gene references, partial counts (as submit_bed_dev_batch), a frequency sink, the counts
+  const int Rmax = kSlice * kChunk;
+  const size_t b_rows = (sizeof(BedRowRef) * (size_t)Rmax + 255) / 256 * 256, b_genes = (sizeof(BedGeneRef) * (size_t)kChunk + 255) / 256 * 256;
+  const size_t b_parts = (sizeof(ConsolPart) * (size_t)Rmax * nparts + 255) / 256 * 256, b_af = sizeof(double) * (size_t)Rmax;
+  const size_t need = b_rows + b_genes + b_parts + b_af + sizeof(long long) * 4 * (size_t)Rmax;
+  if (c->bedbatch_cap < need) {
+    HIP_TRY(c, sync_stream(st));
+    if (c->d_bedbatch) hipFree(c->d_bedbatch);
+    c->d_bedbatch = nullptr;
+    c->bedbatch_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_bedbatch, need + need / 2));
+    c->bedbatch_cap = need + need / 2;
+  }
+  char* w = c->d_bedbatch;
+  BedRowRef* d_rref = reinterpret_cast<BedRowRef*>(w);
+  BedGeneRef* d_gref = reinterpret_cast<BedGeneRef*>(w + b_rows);
+  ConsolPart* d_parts = reinterpret_cast<ConsolPart*>(w + b_rows + b_genes);
+  double* d_afsink = reinterpret_cast<double*>(w + b_rows + b_genes + b_parts);
+  long long* d_cnt = reinterpret_cast<long long*>(w + b_rows + b_genes + b_parts + b_af);
+  // the slices' blocks: kChunk of them, reused chunk after chunk (the batch is synchronous)
+  std::vector<double*> blk;
+  auto release = [&]() {
+    for (double* b : blk) c->pk_pool.emplace_back(gene_bytes, b);
+    blk.clear();
+  };
+  const int64_t n_slices_all = (V + kSlice - 1) / kSlice;
+  const int n_blk = (int)std::min<int64_t>(kChunk, n_slices_all);
+  for (int g = 0; g < n_blk; ++g) {
+    double* b = nullptr;
+    int best = -1;
+    for (int i = 0; i < (int)c->pk_pool.size(); ++i)
+      if (c->pk_pool[i].first >= gene_bytes && c->pk_pool[i].first <= 4 * gene_bytes && (best < 0 || c->pk_pool[i].first < c->pk_pool[best].first)) best = i;
+    if (best >= 0) {
+      b = c->pk_pool[best].second;
+      c->pk_pool.erase(c->pk_pool.begin() + best);
+    } else {
+      if (hipMalloc((void**)&b, gene_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        return fail(c, RVT_E_HIP, "hipMalloc(%zu bytes) failed for a packed slice", gene_bytes);
+      }
+      if (hipMemsetAsync(b, 0, gene_bytes, st) != hipSuccess) {
+        blk.push_back(b);
+        release();
+        return fail(c, RVT_E_HIP, "clearing a packed slice failed");
+      }
+    }
+    blk.push_back(b);
+  }
+  std::vector<BedRowRef> rows;
+  std::vector<BedGeneRef> genes;
+  std::vector<const double*> ptr;
+  std::vector<int> Ms;
+  std::vector<int64_t> ids;
+  std::vector<signed char> kinds;
+  std::vector<unsigned char> shc;
+  std::vector<double> af((size_t)kSlice * kChunk, 0.01);
+  std::vector<rvt_gene_result> rs(kChunk);
+  for (int64_t v0 = 0; v0 < V && !rc; v0 += (int64_t)kSlice * kChunk) {
+    const int cols = (int)std::min<int64_t>(V - v0, (int64_t)kSlice * kChunk), n = (cols + kSlice - 1) / kSlice;
+    rows.clear();
+    genes.clear();
+    ptr.clear();
+    Ms.clear();
+    ids.clear();
+    kinds.assign((size_t)n, (signed char)(3 | 0x10));
+    shc.assign((size_t)n, 1);
+    for (int g = 0; g < n; ++g) {
+      const int M = std::min(kSlice, cols - g * kSlice);
+      unsigned char* dst = reinterpret_cast<unsigned char*>(blk[(size_t)g]) + kHcpHeaderBytes;
+      const unsigned char* src = d_rows + cb * (size_t)(v0 + (int64_t)g * kSlice);
+      const int r0 = (int)rows.size();
+      for (int j = 0; j < M; ++j) rows.push_back(BedRowRef{src + cb * (size_t)j, dst + pk_pitch * (size_t)j});
+      // (a shorter last slice: the rows behind it in the block keep an earlier slice's codes — beyond M, never read)
+      genes.push_back(BedGeneRef{r0, M, reinterpret_cast<HcpHeader*>(blk[(size_t)g]), d_afsink + r0, d_cnt + 4 * (size_t)r0});
+      ptr.push_back(blk[(size_t)g]);
+      Ms.push_back(M);
+      ids.push_back((int64_t)g * kSlice);
+    }
+    const int R = (int)rows.size();
+    hipError_t e = hipMemcpyAsync(d_rref, rows.data(), sizeof(BedRowRef) * (size_t)R, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gref, genes.data(), sizeof(BedGeneRef) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(bed_count_copy_rows_kernel, dim3((unsigned)nparts, (unsigned)R), dim3(256), 0, st, d_rref, (long long)N, d_parts);
+      hipLaunchKernelGGL(bed_fill_header_kernel, dim3((unsigned)n), dim3(128), 0, st, d_gref, d_parts, nparts, (long long)N);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && counts)
+      e = hipMemcpyAsync(counts + 4 * v0, d_cnt, sizeof(long long) * 4 * (size_t)R, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (run_batch launches on its own streams)
+    if (e != hipSuccess) {
+      release();
+      return fail(c, RVT_E_HIP, "resident .bed score: %s", hipGetErrorString(e));
+    }
+    CovOut co;
+    co.score = true;
+    co.slice_hc = shc.data();
+    co.ok = ok + v0;
+    co.ustat = ustat + v0;
+    co.vstat = vstat + v0;
+    co.effect = effect + v0;
+    co.se = effect_se + v0;
+    co.pval = pvalue + v0;
+    rc = run_batch(c, n, ptr.data(), Ms.data(), af.data(), ids.data(), 0u, nullptr, rs.data(), nullptr, &co, kinds.data());
+  }
+  release();
+  return rc;
+}
 
 int rvt_submit_gene(rvt_ctx* c, int64_t gene_id, int M, const double* G, const double* af, uint32_t tests,
                     const rvt_params* prm) {

@@ -574,6 +574,18 @@ class Engine:
                                                    C.byref(prm), _dp(af) if want_af else None))
         return af
 
+    def score_bed_dev(self, d_rows, V, want_counts=True):
+        """Single-variant score tests of V consecutive rows of a resident .bed matrix (rvt_score_bed_dev):
+        (ok, ustat, vstat, effect, se, pvalue[, counts (V, 4): n0 n1 n2 missing])."""
+        ok = np.zeros(V, dtype=np.int32)
+        outs = [np.zeros(V) for _ in range(5)]
+        cnt = np.zeros((V, 4), dtype=np.int64) if want_counts else None
+        self.L.rvt_score_bed_dev.restype = C.c_int
+        self.L.rvt_score_bed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [c_double_p] * 5 + [C.c_void_p]
+        self._check(self.L.rvt_score_bed_dev(self.ctx, C.c_void_p(int(d_rows)), int(V), ok.ctypes.data_as(C.c_void_p),
+                                             *[_dp(o) for o in outs], cnt.ctypes.data_as(C.c_void_p) if want_counts else None))
+        return (ok,) + tuple(outs) + ((cnt,) if want_counts else ())
+
     def submit_genes_bed_dev(self, gene_ids, d_rows, Ms, tests=TEST_ALL, params=None):
         """Several genes of a resident .bed matrix in one call (rvt_submit_genes, kind 7): d_rows[g] = device address of the
         first row of gene g."""

@@ -177,3 +177,42 @@ def test_score_block_hard_call_slices(engine_factory, mixed, binary, monkeypatch
     for f in ("U", "V", "p"):
         k = o["ok"].astype(bool)
         assert np.allclose(r1[f][k], r0[f][k], rtol=1e-8 if binary else 1e-11, atol=0)   # (binary: digit planes of v)
+
+
+@pytest.mark.parametrize("N,V,d", [(4099, 70, 2), (10007, 1000, 3), (3001, 8300, 1)])
+def test_score_of_resident_bed_rows_matches_the_oracle(engine_factory, N, V, d):
+    """rvt_score_bed_dev: the single-variant score test straight from the 2-bit rows of a resident .bed matrix (missing calls
+    imputed to the column mean, as DataConsolidator does) — against the oracle's MetaScore on the imputed matrix, against
+    rvt_score_block on the same matrix as doubles, and the genotype counts against numpy.  V = 8 300: more than one chunk of
+    256 slices; V not a multiple of 32: a short last slice."""
+    rng = np.random.default_rng(N + V)
+    maf = 10 ** rng.uniform(-2.5, -0.4, V)
+    raw = rng.binomial(2, maf, size=(N, V)).astype(np.float64)
+    raw[rng.random((N, V)) < 0.01] = -9.0
+    raw[:, 3] = np.where(raw[:, 3] < 0, -9.0, 2.0)            # monomorphic apart from its missing calls
+    raw[:, 5] = 0.0
+    if V > 40:
+        raw[:, 40] = -9.0                                     # nothing but missing calls
+    X = np.column_stack([np.ones(N)] + [rng.normal(size=N) for _ in range(d - 1)])
+    y = X @ rng.normal(size=d) + 0.2 * np.maximum(raw[:, 7], 0) + rng.normal(size=N)
+    eng = engine_factory()
+    eng.fit_null(0, np.asfortranarray(X), y)
+    d_bed = eng.bed_alloc(V + 2)
+    cb = (N + 3) // 4
+    eng.bed_upload(d_bed, 0, np.zeros((2, cb), dtype=np.uint8))
+    eng.bed_upload(d_bed, 2, eng.pack_bed(raw))
+    ok, U, Vs, eff, se, p, cnt = eng.score_bed_dev(d_bed + 2 * cb, V)
+    G = orc.impute_mean(np.asfortranarray(raw))
+    rc, o = orc.metascore(G, np.asfortranarray(X), y, 0)
+    assert rc == 0
+    check(o, dict(ok=ok, U=U, V=Vs, effect=eff, se=se, p=p))
+    want_cnt = np.stack([(raw == 0).sum(0), (raw == 1).sum(0), (raw == 2).sum(0), (raw < 0).sum(0)], axis=1)
+    assert np.array_equal(cnt, want_cnt)
+    ptr = eng.upload_block(G)
+    r = eng.score_block(ptr, V)
+    k = ok.astype(bool)
+    assert (r["ok"] == ok).all()
+    for a, b in ((U, r["U"]), (Vs, r["V"]), (eff, r["effect"]), (se, r["se"]), (p, r["p"])):
+        assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12 * max(np.abs(b[k]).max(), 1e-300))
+    eng.free_block(ptr)
+    eng.bed_free(d_bed)

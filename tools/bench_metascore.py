@@ -48,6 +48,21 @@ def main():
     dt = (time.perf_counter() - t0) / a.reps
     print({"N": N, "V": V, "kernel": "hard-call int8", "ms_per_block": 1e3 * dt, "variants_per_s": V / dt,
            "alg_GBps": 8.0 * N * V / dt / 1e9, "tested": int(r["ok"].sum())})
+    # the same hard calls as a RESIDENT .bed matrix (rvt_score_bed_dev): N/4 bytes per site instead of 8 N
+    packed = eng.pack_bed(np.asfortranarray(hard[:256, :N].T.cpu().numpy()))
+    rows = 32768
+    d_bed = eng.bed_alloc(rows)
+    for r0 in range(0, rows, packed.shape[0]):
+        eng.bed_upload(d_bed, r0, packed[:min(packed.shape[0], rows - r0)])
+    eng.score_bed_dev(d_bed, rows, want_counts=False)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        out = eng.score_bed_dev(d_bed, rows)
+    dt = (time.perf_counter() - t0) / a.reps
+    print({"N": N, "V": rows, "kernel": "resident .bed rows (gene_suffstat_hcp + gene_tnull_hcp)", "ms_per_call": 1e3 * dt,
+           "variants_per_s": rows / dt, "device_GBps_of_codes": (N / 4.0) * rows / dt / 1e9,
+           "alg_GBps_at_8N_per_site": 8.0 * N * rows / dt / 1e9, "tested": int(out[0].sum())})
+    eng.bed_free(d_bed)
 
 
 if __name__ == "__main__":
