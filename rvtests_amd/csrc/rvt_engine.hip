@@ -1523,7 +1523,8 @@ int run_batch(rvt_ctx* c, int n, const double* const* dG, const int* Ms, const d
       }
       const HcpPlanes pl{c->d_hcp_xq, c->d_hcp_scale, d + 1};
       k2_launch_hcp(h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, NullTile{c->d_nulltile, d + 2}, (long long)N,
-                    (long long)ld, d, planes ? &pl : nullptr);
+                    (long long)ld, d, planes ? &pl : nullptr,
+                    planes && cov && cov->score && h_desc[k].MT <= 2 && !getenv("RVT_SCORE_BED_FULL"));
     }
     else if (h_desc[k].hc == 4)
       k2_launch_fdx(one_launch ? 0 : h_desc[k].MT, dim3(n_wparts, e - k), hst, d_desc + k, c->fdx_tile, (long long)N, (long long)ld, d);

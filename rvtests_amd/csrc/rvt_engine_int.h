@@ -45,7 +45,7 @@ void k2_launch_fdx(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, co
 void k2_launch_lat(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, double den, long long N,
                    long long ld, int d);
 void k2_launch_hcp(int MT, dim3 grid, hipStream_t st, const GeneDesc* d_desc, NullTile nt, long long N, long long ld,
-                   int d, const HcpPlanes* planes = nullptr);
+                   int d, const HcpPlanes* planes = nullptr, bool score_only = false);
 void k2_launch_classify(dim3 grid, hipStream_t st, const double* G, long long N, long long ld, int M, int* flag);
 }  // namespace rvt
 #include "fam_kernels.hip.h"

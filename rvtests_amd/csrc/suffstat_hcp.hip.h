@@ -317,10 +317,12 @@ __device__ __forceinline__ void hcp_pair_step(i4_t& acc, const i4_t& a, const i4
   acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, t, 0, 0, 0);
 }
 
-template <int MT, bool MASK>
+// (STATS: also the column statistics gene_suffstat_hcp keeps — sum of H, sum of H^2, number of missing calls per column and
+//  lane — for callers that need nothing else of that kernel, see gene_tnull_hcp<MT, true>)
+template <int MT, bool MASK, bool STATS = false>
 __device__ __forceinline__ bool hcp_tnull_pass(i4_t (&acc)[kHcpPairs][MT], const __amdgpu_buffer_rsrc_t& rp, const unsigned (&cbase)[MT],
                                                const unsigned char* xq_lane, long long plane_stride, bool has_col,
-                                               long long s_begin, long long s_end, int q) {
+                                               long long s_begin, long long s_end, int q, unsigned (*st)[3] = nullptr) {
   unsigned anym = 0u;
   for (long long s = s_begin; s < s_end; s += 4) {
     u4_t cw[MT];
@@ -345,6 +347,11 @@ __device__ __forceinline__ bool hcp_tnull_pass(i4_t (&acc)[kHcpPairs][MT], const
         if (s + u >= s_end) pv = mv = 0u;
         anym |= mv;
         a[u] = (int)(MASK ? mv : pv);
+        if constexpr (STATS) {
+          st[c][0] = __builtin_amdgcn_sad_u8(pv, 0u, st[c][0]);                                        // sum H
+          st[c][1] = __builtin_amdgcn_sad_u8(pv + (((pv >> 1) & 0x01010101u) << 1), 0u, st[c][1]);    // sum H^2 (2 -> 4)
+          st[c][2] = __builtin_amdgcn_sad_u8(mv, 0u, st[c][2]);                                        // missing calls
+        }
       }
 #pragma unroll
       for (int j = 0; j < kHcpPairs; ++j) hcp_pair_step(acc[j][c], a, b[2 * j], b[2 * j + 1]);
@@ -353,7 +360,10 @@ __device__ __forceinline__ bool hcp_tnull_pass(i4_t (&acc)[kHcpPairs][MT], const
   return __any(anym != 0u);
 }
 
-template <int MT>
+// SCORE = true: the single-variant score test needs of a slice only its columns' T rows, the diagonal of its Gram tile and the
+// column statistics (score_finish_kernel) — all of which this kernel has in hand: sum H^2 + 16 nm is the diagonal entry of the
+// operand's Gram tile, the statistics rows are those gene_suffstat_hcp writes.  gene_suffstat_hcp is then not launched at all.
+template <int MT, bool SCORE = false>
 __global__ __launch_bounds__(64) void gene_tnull_hcp(const GeneDesc* __restrict__ genes, HcpPlanes pl, long long N, long long ld) {
   const GeneDesc gd = genes[blockIdx.y];
   if (gd.MT != MT) return;
@@ -392,7 +402,10 @@ __global__ __launch_bounds__(64) void gene_tnull_hcp(const GeneDesc* __restrict_
     return (hi + lo) * sc;
   };
   clear();
-  const bool masked = hcp_tnull_pass<MT, false>(acc, rp, cbase, xq_lane, plane_stride, has_col, s_begin, s_end, q);
+  unsigned st[MT][3];
+#pragma unroll
+  for (int c = 0; c < MT; ++c) st[c][0] = st[c][1] = st[c][2] = 0u;
+  const bool masked = hcp_tnull_pass<MT, false, SCORE>(acc, rp, cbase, xq_lane, plane_stride, has_col, s_begin, s_end, q, st);
   double t[MT][4];
 #pragma unroll
   for (int c = 0; c < MT; ++c)
@@ -416,6 +429,35 @@ __global__ __launch_bounds__(64) void gene_tnull_hcp(const GeneDesc* __restrict_
     for (int c = 0; c < MT; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) out[(long long)(c * 16 + q * 4 + i) * Cp + M + v] = t[c][i];  // (i32 C/D map: row 4 q + i, column v)
+  }
+  if constexpr (SCORE) {
+    long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
+    if (cnt_w < 0) cnt_w = 0;
+    double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+      unsigned sm = st[c][0], hh = st[c][1], nmu = st[c][2];
+      sm += __shfl_xor(sm, 16, 64);
+      hh += __shfl_xor(hh, 16, 64);
+      nmu += __shfl_xor(nmu, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      hh += __shfl_xor(hh, 32, 64);
+      nmu += __shfl_xor(nmu, 32, 64);
+      if (lane < 16) {
+        const int j = c * 16 + lane;
+        const long long nm = (long long)nmu, n2 = ((long long)hh - (long long)sm) / 2, n1 = 2 * (long long)sm - (long long)hh,
+                        n0 = cnt_w - n1 - n2 - nm;
+        cst[j] = (double)sm;
+        cst[gd.Mp + j] = n0 > 0 ? 0.0 : (n1 > 0 ? 1.0 : (n2 > 0 ? 2.0 : INFINITY));
+        cst[2 * gd.Mp + j] = n2 > 0 ? 2.0 : (n1 > 0 ? 1.0 : (n0 > 0 ? 0.0 : -INFINITY));
+        cst[3 * gd.Mp + j] = (double)nm;
+        const unsigned long long mb = j < M ? __builtin_bit_cast(unsigned long long, hdr->mu[j]) : 0ull;
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(cst);
+        bits[4 * gd.Mp + j] = nm > 0 ? mb : 0ull;
+        bits[5 * gd.Mp + j] = nm > 0 ? mb : ~0ull;
+        if (j < M) out[(long long)j * Cp + j] = (double)((long long)hh + 16 * nm);  // the diagonal of (H + 4 m)'(H + 4 m)
+      }
+    }
   }
 }
 
