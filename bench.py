@@ -409,7 +409,16 @@ def resident_bed_rate(eng, blocks, Ms, N, rows_resident=8192, genes=6144, per_ca
                 done += len(eng.collect_ready())
             done += len(eng.collect())
             dt = time.perf_counter() - t0
+        # the single-variant score test over the same rows (rvt_score_bed_dev; median of five calls)
+        eng.score_bed_dev(d_bed, rows_resident, want_counts=False)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            eng.score_bed_dev(d_bed, rows_resident)
+            ts.append(time.perf_counter() - t1)
+        score_rate = rows_resident / float(np.median(ts))
         out = {"gene_sets_per_s": done / dt, "genes": done, "rows_resident": rows_resident,
+               "score_test_variants_per_s": score_rate,
                "resident_GB": rows_resident * cb / 1e9, "mean_M": float(gm.mean()),
                "workload": "N=%d, genes = M~U{%d..%d} consecutive rows of a device-resident .bed matrix, all four tests; "
                            "caller: Python, %d genes per rvt_submit_genes call" % (N, m_lo, m_hi, per_call)}
