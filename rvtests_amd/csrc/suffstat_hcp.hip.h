@@ -431,6 +431,10 @@ __global__ __launch_bounds__(64) void gene_tnull_hcp(const GeneDesc* __restrict_
       for (int i = 0; i < 4; ++i) out[(long long)(c * 16 + q * 4 + i) * Cp + M + v] = t[c][i];  // (i32 C/D map: row 4 q + i, column v)
   }
   if constexpr (SCORE) {
+    // (what gene_suffstat_hcp leaves for gene_flags_hc_kernel: "no entry of this wave-part is outside the codes" — the word lives in
+    //  a work space the batch before may have used, and a stale bit there hands the slice to the fp64 kernel, which would read
+    //  the packed rows as doubles)
+    if (gd.wflags && lane == 0) gd.wflags[wpart] = 0u;
     long long cnt_w = ((s_end * 16 < N) ? s_end * 16 : N) - s_begin * 16;
     if (cnt_w < 0) cnt_w = 0;
     double* cst = gd.colstat + (long long)wpart * kHcColstatRows * gd.Mp;

@@ -180,7 +180,7 @@ def test_score_block_hard_call_slices(engine_factory, mixed, binary, monkeypatch
 
 
 @pytest.mark.parametrize("N,V,d", [(4099, 70, 2), (10007, 1000, 3), (3001, 8300, 1)])
-def test_score_of_resident_bed_rows_matches_the_oracle(engine_factory, N, V, d):
+def test_score_of_resident_bed_rows_matches_the_oracle(engine_factory, monkeypatch, N, V, d):
     """rvt_score_bed_dev: the single-variant score test straight from the 2-bit rows of a resident .bed matrix (missing calls
     imputed to the column mean, as DataConsolidator does) — against the oracle's MetaScore on the imputed matrix, against
     rvt_score_block on the same matrix as doubles, and the genotype counts against numpy.  V = 8 300: more than one chunk of
@@ -195,6 +195,7 @@ def test_score_of_resident_bed_rows_matches_the_oracle(engine_factory, N, V, d):
         raw[:, 40] = -9.0                                     # nothing but missing calls
     X = np.column_stack([np.ones(N)] + [rng.normal(size=N) for _ in range(d - 1)])
     y = X @ rng.normal(size=d) + 0.2 * np.maximum(raw[:, 7], 0) + rng.normal(size=N)
+    monkeypatch.setenv("RVT_POISON", "255")                   # fresh work spaces hold 0xff bytes: nothing may be read unwritten
     eng = engine_factory()
     eng.fit_null(0, np.asfortranarray(X), y)
     d_bed = eng.bed_alloc(V + 2)
@@ -216,3 +217,35 @@ def test_score_of_resident_bed_rows_matches_the_oracle(engine_factory, N, V, d):
         assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12 * max(np.abs(b[k]).max(), 1e-300))
     eng.free_block(ptr)
     eng.bed_free(d_bed)
+
+
+def test_score_of_resident_rows_after_gene_batches_used_the_work_space(engine_factory):
+    """The score path of resident rows runs ONE streaming kernel and must leave everything the flag kernel reads — also the
+    per-wave-part "an entry outside the codes" word, which lives in a work space that gene batches before it have written: a
+    stale bit there hands a slice of packed rows to the fp64 kernel (round 6: a memory fault in the bench run, found by it).
+    2 048 genes first, then the score test of the same matrix — equal to the score test of a fresh context."""
+    N, V = 20011, 4096
+    rng = np.random.default_rng(77)
+    raw = rng.binomial(2, 10 ** rng.uniform(-2.3, -0.5, V), size=(N, V)).astype(np.float64)
+    raw[rng.random((N, V)) < 0.02] = -9.0
+    X = np.column_stack([np.ones(N), rng.normal(size=N)])
+    y = rng.normal(size=N) + 0.3 * X[:, 1]
+    outs = []
+    for dirty in (True, False):
+        eng = engine_factory()
+        eng.fit_null(0, np.asfortranarray(X), y)
+        cb = (N + 3) // 4
+        d_bed = eng.bed_alloc(V)
+        eng.bed_upload(d_bed, 0, eng.pack_bed(raw))
+        if dirty:
+            Ms = rng.integers(20, 81, 2048)
+            first = rng.integers(0, V - 80, 2048)
+            for g0 in range(0, 2048, 64):
+                eng.submit_genes_bed_dev(list(range(g0, g0 + 64)), [d_bed + int(f) * cb for f in first[g0:g0 + 64]], Ms[g0:g0 + 64])
+                eng.collect_ready()
+            assert len(eng.collect()) > 0
+        outs.append(eng.score_bed_dev(d_bed, V))
+        eng.bed_free(d_bed)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert outs[0][0].sum() > V // 2
