@@ -326,6 +326,11 @@ RVT_HD void gene_assemble(const Coop& co, const NullConsts& nc, int M, int Mp, i
     out->zimz_lambda_off = M;
     out->cmc_ok = out->zeg_ok = 0;
     out->cmc_nonref = 0;
+    // (the numbers of a test that is not run — no polymorphic variant, a test not asked for — are zeros in the record, not what
+    //  the work space held: records are reproducible bit for bit whatever ran before)
+    out->skat_Q = 0.0;
+    out->cmc_U = out->cmc_V = out->cmc_stat = 0.0;
+    out->zeg_U = out->zeg_V = out->zeg_stat = 0.0;
     for (int k = 0; k < kNEigen; ++k) out->eig_ok[k] = 0;
   }
   co.sync();
