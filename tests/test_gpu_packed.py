@@ -298,3 +298,42 @@ def test_resident_bed_entry_points_refuse_what_they_cannot_take():
     e.bed_free(d_bed)
     e.bed_free(0)                                             # a null pointer: nothing to free
     e.close()
+
+
+@pytest.mark.parametrize("N", [8000, 8001, 16016])
+def test_resident_rows_of_whole_dwords_take_the_same_records(engine, N):
+    """ceil(N/4) a multiple of 4 (N = 8 000, 16 016): the batched count-and-copy pass moves 16 samples per thread; N = 8 001: bytes.
+    Records and counts of resident genes equal the host hand-off's either way (expanded genes: bit for bit)."""
+    import rvtests_amd
+    Ms = (7, 33, 64)
+    genes = [_raw_gene(N, M, seed=3 * M + N % 7, missing=0.02) for M in Ms]
+    X, y, res, v, s2 = synth.make_null(N, 2, 0, seed=2)
+    engine.set_null(0, X, res, v, s2)
+    rows = [engine.pack_bed(g) for g in genes]
+    cb = (N + 3) // 4
+    first = np.concatenate([[0], np.cumsum(Ms)[:-1]])
+    d_bed = engine.bed_alloc(int(sum(Ms)))
+    for f, r in zip(first, rows):
+        engine.bed_upload(d_bed, int(f), r)
+    prm = rvtests_amd.Params.default()
+    prm.skat_nperm = 50                                       # expanded genes: the same kernels on the same doubles
+    for g, (r, M) in enumerate(zip(rows, Ms)):
+        engine.submit_gene_bed(g, r, M, params=prm, want_af=False)
+    want = engine.collect()
+    engine.submit_genes_bed_dev(list(range(len(Ms))), [d_bed + int(f) * cb for f in first], Ms, params=prm)
+    got = engine.collect()
+    for a, b in zip(got, want):
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f), f
+    engine.submit_genes_bed_dev(list(range(len(Ms))), [d_bed + int(f) * cb for f in first], Ms)
+    got2 = engine.collect()
+    for g, raw in enumerate(genes):
+        engine.submit_gene_bed(g, rows[g], Ms[g], want_af=False)
+    want2 = engine.collect()
+    for a, b in zip(got2, want2):
+        assert a.n_poly == b.n_poly and a.cmc_nonref == b.cmc_nonref
+        assert abs(a.skat_Q - b.skat_Q) <= 1e-11 * abs(b.skat_Q) and abs(a.skat_p - b.skat_p) <= 1e-9 * b.skat_p
+    ok, U, Vs, eff, se, p, cnt = engine.score_bed_dev(d_bed, int(sum(Ms)))
+    raw_all = np.concatenate(genes, axis=1)
+    assert np.array_equal(cnt, np.stack([(raw_all == 0).sum(0), (raw_all == 1).sum(0), (raw_all == 2).sum(0), (raw_all < 0).sum(0)], axis=1))
+    engine.bed_free(d_bed)
